@@ -1,0 +1,496 @@
+"""ORACLE (test infrastructure only -- never imported by the product path).
+
+Builtins used by the reference's in-tree templates (SURVEY.md Appendix B lists the call counts), restated from the
+OPA v1.17.1 builtin reference (third-party; go.mod:19).  A builtin that raises BuiltinError makes the calling
+expression undefined (OPA's default non-strict mode).
+"""
+from __future__ import annotations
+
+import json
+import math
+import re
+
+from .values import (RObj, RSet, compare, equal, from_json, go_float_v, num_to_string, quote, sorted_values,
+                     to_json, to_string, type_name)
+
+
+class BuiltinError(Exception):
+    pass
+
+
+def _need(v, *types):
+    for t in types:
+        if t == "number":
+            if isinstance(v, (int, float)) and not isinstance(v, bool):
+                return v
+        elif t == "string":
+            if isinstance(v, str):
+                return v
+        elif t == "array":
+            if isinstance(v, tuple):
+                return v
+        elif t == "object":
+            if isinstance(v, RObj):
+                return v
+        elif t == "set":
+            if isinstance(v, RSet):
+                return v
+        elif t == "boolean":
+            if isinstance(v, bool):
+                return v
+    raise BuiltinError("operand must be %s, got %s" % ("/".join(types), type_name(v)))
+
+
+def _isnum(v):
+    return isinstance(v, (int, float)) and not isinstance(v, bool)
+
+
+def _norm(n):
+    if isinstance(n, float) and n.is_integer() and abs(n) < 2 ** 63:
+        return int(n)
+    return n
+
+
+# ---------------------------------------------------------------- Go regexp (RE2) -> python re
+_POSIX = {"alpha": "a-zA-Z", "digit": "0-9", "alnum": "a-zA-Z0-9", "upper": "A-Z", "lower": "a-z",
+          "space": r" \t\n\r\f\v", "punct": r"!-/:-@\[-`{-~", "xdigit": "0-9A-Fa-f", "word": r"\w"}
+_re_cache = {}
+
+
+def go_regex(pat):
+    r = _re_cache.get(pat)
+    if r is None:
+        p = re.sub(r"\[:(\w+):\]", lambda m: _POSIX.get(m.group(1), m.group(0)), pat)
+        p = p.replace(r"\z", r"\Z")
+        try:
+            r = re.compile(p)
+        except re.error as e:
+            raise BuiltinError("bad regex %r: %s" % (pat, e))
+        _re_cache[pat] = r
+    return r
+
+
+# ---------------------------------------------------------------- sprintf (Go fmt)
+_VERB_RE = re.compile(r"%([-+# 0]*)(\d+|\*)?(?:\.(\d+|\*))?([a-zA-Z%])")
+
+
+def _go_arg(v):
+    """OPA topdown builtinSprintf argument conversion."""
+    if _isnum(v):
+        if isinstance(v, int):
+            return ("int", v)
+        if v.is_integer() and abs(v) < 2 ** 63:
+            return ("int", int(v))
+        return ("float64", v)
+    if isinstance(v, str):
+        return ("string", v)
+    return ("string", to_string(v))
+
+
+def _bad(verb, kind, val):
+    if kind == "string":
+        return "%%!%s(string=%s)" % (verb, val)
+    if kind == "int":
+        return "%%!%s(int=%d)" % (verb, val)
+    return "%%!%s(float64=%s)" % (verb, go_float_v(val))
+
+
+def _pad(s, flags, width):
+    if width is None or len(s) >= width:
+        return s
+    if "-" in flags:
+        return s + " " * (width - len(s))
+    if "0" in flags and s and (s[0].isdigit() or s[0] in "+-"):
+        sign = ""
+        if s[0] in "+-":
+            sign, s = s[0], s[1:]
+        return sign + "0" * (width - len(s) - len(sign)) + s
+    return " " * (width - len(s)) + s
+
+
+def go_sprintf(fmt, args):
+    args = [_go_arg(a) for a in args]
+    out = []
+    pos = 0
+    ai = 0
+    for m in _VERB_RE.finditer(fmt):
+        out.append(fmt[pos:m.start()])
+        pos = m.end()
+        flags, width, prec, verb = m.group(1), m.group(2), m.group(3), m.group(4)
+        if verb == "%":
+            out.append("%")
+            continue
+        if ai >= len(args):
+            out.append("%%!%s(MISSING)" % verb)
+            continue
+        kind, val = args[ai]
+        ai += 1
+        width = int(width) if width and width != "*" else None
+        prec = int(prec) if prec and prec != "*" else None
+        if verb == "v":
+            if kind == "string":
+                s = val
+            elif kind == "int":
+                s = ("+" if "+" in flags and val >= 0 else "") + str(val)
+            else:
+                s = go_float_v(val)
+        elif verb == "s":
+            s = (val if prec is None else val[:prec]) if kind == "string" else _bad(verb, kind, val)
+        elif verb == "q":
+            s = quote(val) if kind == "string" else _bad(verb, kind, val)
+        elif verb == "d":
+            s = (("+" if "+" in flags and val >= 0 else "") + str(val)) if kind == "int" else _bad(verb, kind, val)
+        elif verb in "xXob":
+            if kind == "int":
+                s = {"x": "%x", "X": "%X", "o": "%o"}.get(verb, "%s") % val if verb != "b" else bin(val)[2:]
+            elif kind == "string" and verb in "xX":
+                s = val.encode().hex()
+                s = s.upper() if verb == "X" else s
+            else:
+                s = _bad(verb, kind, val)
+        elif verb in "feEgG":
+            if kind == "float64" or kind == "int":
+                if kind == "int":
+                    s = _bad(verb, kind, val)
+                else:
+                    p = 6 if prec is None else prec
+                    s = ("%." + str(p) + verb) % val
+                    if verb in "eE":
+                        s = re.sub(r"e([+-])(\d)$", r"e\g<1>0\2", s)
+            else:
+                s = _bad(verb, kind, val)
+        elif verb == "t":
+            s = _bad(verb, kind, val)
+        elif verb == "c":
+            s = chr(val) if kind == "int" else _bad(verb, kind, val)
+        else:
+            s = "%%!%s(%s=%s)" % (verb, kind, val if kind != "float64" else go_float_v(val))
+        out.append(_pad(s, flags, width))
+    out.append(fmt[pos:])
+    if ai < len(args):
+        extra = ", ".join("%s=%s" % (k, v if k != "float64" else go_float_v(v)) for k, v in args[ai:])
+        out.append("%!(EXTRA " + extra + ")")
+    return "".join(out)
+
+
+# ---------------------------------------------------------------- builtins
+def b_count(x):
+    if isinstance(x, str):
+        return len(x)
+    if isinstance(x, (tuple, RObj, RSet)):
+        return len(x)
+    raise BuiltinError("count: bad operand")
+
+
+def _numbers(c, name):
+    if isinstance(c, tuple):
+        it = c
+    elif isinstance(c, RSet):
+        it = list(c.elems())
+    else:
+        raise BuiltinError(name + ": operand must be array or set")
+    for v in it:
+        _need(v, "number")
+    return it
+
+
+def b_sum(c):
+    return _norm(sum(_numbers(c, "sum")))
+
+
+def b_product(c):
+    r = 1
+    for v in _numbers(c, "product"):
+        r *= v
+    return _norm(r)
+
+
+def _coll(c, name):
+    if isinstance(c, tuple):
+        return list(c)
+    if isinstance(c, RSet):
+        return list(c.elems())
+    raise BuiltinError(name + ": operand must be array or set")
+
+
+def b_max(c):
+    it = _coll(c, "max")
+    if not it:
+        raise BuiltinError("max of empty")
+    return sorted_values(it)[-1]
+
+
+def b_min(c):
+    it = _coll(c, "min")
+    if not it:
+        raise BuiltinError("min of empty")
+    return sorted_values(it)[0]
+
+
+def b_sort(c):
+    return tuple(sorted_values(_coll(c, "sort")))
+
+
+def b_any(c):
+    return any(v is True for v in _coll(c, "any"))
+
+
+def b_all(c):
+    return all(v is True for v in _coll(c, "all"))
+
+
+def b_concat(delim, c):
+    _need(delim, "string")
+    it = _coll(c, "concat")
+    if isinstance(c, RSet):
+        it = sorted_values(it)
+    for v in it:
+        _need(v, "string")
+    return delim.join(it)
+
+
+def b_substring(s, off, ln):
+    _need(s, "string")
+    _need(off, "number")
+    _need(ln, "number")
+    off, ln = int(off), int(ln)
+    if off < 0:
+        raise BuiltinError("negative offset")
+    if off >= len(s):
+        return ""
+    if ln < 0:
+        return s[off:]
+    return s[off:off + ln]
+
+
+def b_split(s, d):
+    _need(s, "string")
+    _need(d, "string")
+    if d == "":
+        return tuple(s)
+    return tuple(s.split(d))
+
+
+def b_trim(s, cut):
+    return _need(s, "string").strip(_need(cut, "string")) if cut else s
+
+
+def b_replace(s, old, new):
+    return _need(s, "string").replace(_need(old, "string"), _need(new, "string"))
+
+
+def b_to_number(x):
+    if x is None:
+        return 0
+    if isinstance(x, bool):
+        return 1 if x else 0
+    if _isnum(x):
+        return x
+    if isinstance(x, str):
+        if not re.fullmatch(r"[+-]?(\d+\.?\d*([eE][+-]?\d+)?|\.\d+([eE][+-]?\d+)?|0[xX][0-9a-fA-F]+|[iI]nf|NaN)", x):
+            raise BuiltinError("to_number: invalid syntax")
+        try:
+            return int(x)
+        except ValueError:
+            try:
+                return _norm(float(x))
+            except ValueError:
+                raise BuiltinError("to_number: invalid syntax")
+    raise BuiltinError("to_number: bad operand")
+
+
+def b_object_get(obj, key, default):
+    _need(obj, "object")
+    if isinstance(key, tuple):
+        cur = obj
+        for k in key:
+            if isinstance(cur, RObj) and cur.has(k):
+                cur = cur.get(k)
+            elif isinstance(cur, tuple) and _isnum(k) and 0 <= int(k) < len(cur) and float(k).is_integer():
+                cur = cur[int(k)]
+            else:
+                return default
+        return cur
+    return obj.get(key) if obj.has(key) else default
+
+
+def _strs(x, name):
+    if isinstance(x, str):
+        return [x]
+    it = _coll(x, name)
+    for v in it:
+        _need(v, "string")
+    return it
+
+
+def b_any_prefix_match(search, base):
+    ss, bs = _strs(search, "strings.any_prefix_match"), _strs(base, "strings.any_prefix_match")
+    return any(s.startswith(b) for s in ss for b in bs)
+
+
+def b_any_suffix_match(search, base):
+    ss, bs = _strs(search, "strings.any_suffix_match"), _strs(base, "strings.any_suffix_match")
+    return any(s.endswith(b) for s in ss for b in bs)
+
+
+def b_re_match(pat, val):
+    _need(pat, "string")
+    _need(val, "string")
+    return go_regex(pat).search(val) is not None
+
+
+def b_format_int(n, base):
+    _need(n, "number")
+    _need(base, "number")
+    n = int(math.floor(n)) if n >= 0 else -int(math.floor(-n))
+    digs = "0123456789abcdef"
+    if base not in (2, 8, 10, 16):
+        raise BuiltinError("format_int: bad base")
+    if n == 0:
+        return "0"
+    s, m = "", abs(n)
+    while m:
+        s = digs[m % base] + s
+        m //= base
+    return ("-" if n < 0 else "") + s
+
+
+def b_indexof(s, sub):
+    return _need(s, "string").find(_need(sub, "string"))
+
+
+def b_array_slice(a, lo, hi):
+    _need(a, "array")
+    lo = max(0, int(_need(lo, "number")))
+    hi = min(len(a), int(_need(hi, "number")))
+    return a[lo:hi] if lo < hi else ()
+
+
+def b_union(s):
+    r = RSet()
+    for x in _need(s, "set").elems():
+        r = r.union(_need(x, "set"))
+    return r
+
+
+def b_intersection(s):
+    it = list(_need(s, "set").elems())
+    if not it:
+        return RSet()
+    r = _need(it[0], "set")
+    for x in it[1:]:
+        r = r.intersect(_need(x, "set"))
+    return r
+
+
+def b_object_keys(o):
+    return RSet(_need(o, "object").keys())
+
+
+def b_object_remove(o, ks):
+    _need(o, "object")
+    kk = RSet(_coll(ks, "object.remove") if not isinstance(ks, RObj) else ks.keys())
+    return RObj((k, v) for k, v in o.items() if not kk.has(k))
+
+
+def b_object_union(a, b):
+    _need(a, "object")
+    _need(b, "object")
+    d = {}
+    for k, v in a.items():
+        d[id(k)] = (k, v)
+    out = RObj(list(a.items()))
+    for k, v in b.items():
+        if out.has(k) and isinstance(out.get(k), RObj) and isinstance(v, RObj):
+            v = b_object_union(out.get(k), v)
+        out = RObj([(kk, vv) for kk, vv in out.items() if not equal(kk, k)] + [(k, v)])
+    return out
+
+
+BUILTINS = {
+    "count": b_count, "sum": b_sum, "product": b_product, "max": b_max, "min": b_min, "sort": b_sort,
+    "any": b_any, "all": b_all,
+    "abs": lambda x: abs(_need(x, "number")),
+    "round": lambda x: int(math.floor(_need(x, "number") + 0.5)) if x >= 0 else -int(math.floor(-x + 0.5)),
+    "ceil": lambda x: int(math.ceil(_need(x, "number"))),
+    "floor": lambda x: int(math.floor(_need(x, "number"))),
+    "sprintf": lambda f, a: go_sprintf(_need(f, "string"), _need(a, "array")),
+    "concat": b_concat,
+    "contains": lambda s, sub: _need(sub, "string") in _need(s, "string"),
+    "startswith": lambda s, p: _need(s, "string").startswith(_need(p, "string")),
+    "endswith": lambda s, p: _need(s, "string").endswith(_need(p, "string")),
+    "lower": lambda s: _need(s, "string").lower(),
+    "upper": lambda s: _need(s, "string").upper(),
+    "trim": b_trim,
+    "trim_left": lambda s, c: _need(s, "string").lstrip(_need(c, "string")) if c else s,
+    "trim_right": lambda s, c: _need(s, "string").rstrip(_need(c, "string")) if c else s,
+    "trim_prefix": lambda s, p: s[len(p):] if _need(s, "string").startswith(_need(p, "string")) else s,
+    "trim_suffix": lambda s, p: s[:len(s) - len(p)] if p and _need(s, "string").endswith(_need(p, "string")) else s,
+    "trim_space": lambda s: _need(s, "string").strip(" \t\n\r\v\f\x85\xa0"),
+    "split": b_split, "replace": b_replace, "substring": b_substring, "indexof": b_indexof,
+    "format_int": b_format_int,
+    "strings.reverse": lambda s: _need(s, "string")[::-1],
+    "strings.any_prefix_match": b_any_prefix_match, "strings.any_suffix_match": b_any_suffix_match,
+    "re_match": b_re_match, "regex.match": b_re_match,
+    "regex.is_valid": lambda p: _regex_valid(p),
+    "is_string": lambda x: isinstance(x, str), "is_number": _isnum,
+    "is_boolean": lambda x: isinstance(x, bool), "is_array": lambda x: isinstance(x, tuple),
+    "is_object": lambda x: isinstance(x, RObj), "is_set": lambda x: isinstance(x, RSet),
+    "is_null": lambda x: x is None, "type_name": type_name,
+    "to_number": b_to_number,
+    "object.get": b_object_get, "object.keys": b_object_keys, "object.remove": b_object_remove,
+    "object.union": b_object_union,
+    "array.concat": lambda a, b: _need(a, "array") + _need(b, "array"),
+    "array.slice": b_array_slice, "array.reverse": lambda a: _need(a, "array")[::-1],
+    "union": b_union, "intersection": b_intersection,
+    "json.marshal": lambda x: json.dumps(to_json(x), separators=(",", ":"), sort_keys=True, ensure_ascii=False),
+    "json.unmarshal": lambda s: _json_unmarshal(s),
+    "print": lambda *a: True, "trace": lambda s: True,
+}
+
+
+def _regex_valid(p):
+    if not isinstance(p, str):
+        return False
+    try:
+        go_regex(p)
+        return True
+    except BuiltinError:
+        return False
+
+
+def _json_unmarshal(s):
+    try:
+        return from_json(json.loads(_need(s, "string")))
+    except ValueError as e:
+        raise BuiltinError(str(e))
+
+
+def arith(op, a, b):
+    if op == "-" and isinstance(a, RSet) and isinstance(b, RSet):
+        return a.diff(b)
+    if op == "&":
+        return _need(a, "set").intersect(_need(b, "set"))
+    if op == "|":
+        return _need(a, "set").union(_need(b, "set"))
+    _need(a, "number")
+    _need(b, "number")
+    if op == "+":
+        return _norm(a + b)
+    if op == "-":
+        return _norm(a - b)
+    if op == "*":
+        return _norm(a * b)
+    if op == "/":
+        if b == 0:
+            raise BuiltinError("divide by zero")
+        if isinstance(a, int) and isinstance(b, int) and a % b == 0:
+            return a // b
+        return _norm(a / b)
+    if op == "%":
+        if not (isinstance(a, int) and isinstance(b, int)):
+            raise BuiltinError("modulo on floating-point number")
+        if b == 0:
+            raise BuiltinError("modulo by zero")
+        return int(math.fmod(a, b))
+    raise BuiltinError("bad operator " + op)

@@ -1,0 +1,297 @@
+"""ORACLE (test infrastructure only -- never imported by the product path).
+
+Rego value model for the CPU restatement of the reference's Rego driver.
+
+The reference evaluates ConstraintTemplate Rego with OPA v1.17.1 (go.mod:19), whose source is NOT in
+/root/reference.  This file restates OPA's published value semantics:
+
+  * types and their total order  null < boolean < number < string < array < object < set
+    (OPA docs "policy-reference: comparison"; used by `sort`, set printing and `<`),
+  * value equality (true != 1, 1 == 1.0),
+  * `String()` rendering of composite terms used by sprintf("%v") -- pinned by the reference at
+    website/docs/constrainttemplates.md:118 (`you must provide labels: {"gatekeeper"}`) and
+    test/gator/test/test.bats:241.
+
+Python representation
+  null -> None, boolean -> bool, number -> int | float, string -> str,
+  array -> tuple, object -> RObj, set -> RSet.
+"""
+from __future__ import annotations
+
+import math
+
+
+class RObj:
+    """Immutable Rego object. Keys may be any Rego value."""
+
+    __slots__ = ("d", "_h")
+
+    def __init__(self, pairs=()):
+        d = {}
+        for k, v in pairs:
+            d[hk(k)] = (k, v)
+        self.d = d
+        self._h = None
+
+    @staticmethod
+    def from_str_dict(m):
+        o = RObj.__new__(RObj)
+        o.d = {k: (k, v) for k, v in m.items()}
+        o._h = None
+        return o
+
+    def get(self, k, default=None):
+        e = self.d.get(hk(k))
+        return default if e is None else e[1]
+
+    def has(self, k):
+        return hk(k) in self.d
+
+    def items(self):
+        return self.d.values()
+
+    def keys(self):
+        return [k for k, _ in self.d.values()]
+
+    def __len__(self):
+        return len(self.d)
+
+    def __repr__(self):
+        return "RObj(%s)" % to_string(self)
+
+
+class RSet:
+    """Immutable Rego set."""
+
+    __slots__ = ("d", "_h")
+
+    def __init__(self, elems=()):
+        d = {}
+        for v in elems:
+            d[hk(v)] = v
+        self.d = d
+        self._h = None
+
+    def has(self, v):
+        return hk(v) in self.d
+
+    def elems(self):
+        return self.d.values()
+
+    def __len__(self):
+        return len(self.d)
+
+    def union(self, o):
+        r = RSet()
+        r.d = dict(self.d)
+        r.d.update(o.d)
+        return r
+
+    def intersect(self, o):
+        r = RSet()
+        r.d = {k: v for k, v in self.d.items() if k in o.d}
+        return r
+
+    def diff(self, o):
+        r = RSet()
+        r.d = {k: v for k, v in self.d.items() if k not in o.d}
+        return r
+
+    def __repr__(self):
+        return "RSet(%s)" % to_string(self)
+
+
+def hk(v):
+    """Hashable canonical key: equal Rego values <=> equal keys."""
+    if isinstance(v, str):
+        return v
+    if v is None:
+        return (0,)
+    if isinstance(v, bool):
+        return (1, v)
+    if isinstance(v, (int, float)):
+        if isinstance(v, float) and v.is_integer():
+            v = int(v)
+        return (2, v)
+    if isinstance(v, tuple):
+        return (4, tuple(hk(x) for x in v))
+    if isinstance(v, RObj):
+        if v._h is None:
+            v._h = (5, frozenset((k, hk(e[1])) for k, e in v.d.items()))
+        return v._h
+    if isinstance(v, RSet):
+        if v._h is None:
+            v._h = (6, frozenset(v.d.keys()))
+        return v._h
+    raise TypeError("not a rego value: %r" % (v,))
+
+
+def type_rank(v):
+    if v is None:
+        return 0
+    if isinstance(v, bool):
+        return 1
+    if isinstance(v, (int, float)):
+        return 2
+    if isinstance(v, str):
+        return 3
+    if isinstance(v, tuple):
+        return 4
+    if isinstance(v, RObj):
+        return 5
+    if isinstance(v, RSet):
+        return 6
+    raise TypeError("not a rego value: %r" % (v,))
+
+
+def type_name(v):
+    return ("null", "boolean", "number", "string", "array", "object", "set")[type_rank(v)]
+
+
+def _cmp_seq(a, b):
+    for x, y in zip(a, b):
+        c = compare(x, y)
+        if c:
+            return c
+    return (len(a) > len(b)) - (len(a) < len(b))
+
+
+def sorted_values(vals):
+    import functools
+    return sorted(vals, key=functools.cmp_to_key(compare))
+
+
+def compare(a, b):
+    """Total order over Rego values (OPA ast.Compare)."""
+    ra, rb = type_rank(a), type_rank(b)
+    if ra != rb:
+        return (ra > rb) - (ra < rb)
+    if ra == 0:
+        return 0
+    if ra in (1, 2, 3):
+        return (a > b) - (a < b)
+    if ra == 4:
+        return _cmp_seq(a, b)
+    if ra == 5:
+        # objects compare by sorted keys, then values (OPA: key-by-key over sorted keys)
+        ka = sorted_values(a.keys())
+        kb = sorted_values(b.keys())
+        for x, y in zip(ka, kb):
+            c = compare(x, y)
+            if c:
+                return c
+            c = compare(a.get(x), b.get(y))
+            if c:
+                return c
+        return (len(ka) > len(kb)) - (len(ka) < len(kb))
+    return _cmp_seq(sorted_values(a.elems()), sorted_values(b.elems()))
+
+
+def equal(a, b):
+    return hk(a) == hk(b)
+
+
+def from_json(j):
+    """Python JSON (dict/list/...) -> Rego value."""
+    if isinstance(j, dict):
+        return RObj.from_str_dict({k: from_json(v) for k, v in j.items()})
+    if isinstance(j, (list, tuple)):
+        return tuple(from_json(x) for x in j)
+    return j
+
+
+def to_json(v):
+    """Rego value -> Python JSON. Sets become sorted arrays (OPA ast.JSON)."""
+    if isinstance(v, RObj):
+        out = {}
+        for k, e in v.items():
+            out[k if isinstance(k, str) else to_string(k)] = to_json(e)
+        return out
+    if isinstance(v, tuple):
+        return [to_json(x) for x in v]
+    if isinstance(v, RSet):
+        return [to_json(x) for x in sorted_values(v.elems())]
+    return v
+
+
+_ESC = {'"': '\\"', "\\": "\\\\", "\n": "\\n", "\t": "\\t", "\r": "\\r", "\a": "\\a", "\b": "\\b", "\f": "\\f",
+        "\v": "\\v"}
+
+
+def quote(s):
+    """Go strconv.Quote (what ast.String.String() uses)."""
+    out = ['"']
+    for ch in s:
+        if ch in _ESC:
+            out.append(_ESC[ch])
+        elif ord(ch) < 0x20 or ord(ch) == 0x7F:
+            out.append("\\x%02x" % ord(ch))
+        else:
+            out.append(ch)
+    out.append('"')
+    return "".join(out)
+
+
+def num_to_string(n):
+    if isinstance(n, int):
+        return str(n)
+    if math.isfinite(n) and n.is_integer() and abs(n) < 1e21:
+        return str(int(n))
+    return go_float_v(n)
+
+
+def go_float_v(f):
+    """Go fmt %v for float64: strconv.FormatFloat(f, 'g', -1, 64) with exponent threshold 21."""
+    if f != f:
+        return "NaN"
+    if f in (float("inf"), float("-inf")):
+        return "+Inf" if f > 0 else "-Inf"
+    if f == 0:
+        return "0"
+    r = repr(f)  # shortest round-trip digits
+    mant, _, exp = r.partition("e")
+    sign = ""
+    if mant.startswith("-"):
+        sign, mant = "-", mant[1:]
+    ip, _, fp = mant.partition(".")
+    if fp == "0":
+        fp = ""
+    digits = (ip + fp).lstrip("0") or "0"
+    e10 = int(exp) if exp else 0
+    # decimal exponent of the first significant digit
+    if ip.strip("0"):
+        x = len(ip.lstrip("0")) - 1 + e10
+    else:
+        lead = len(fp) - len(fp.lstrip("0"))
+        x = -(lead + 1) + e10
+    digits = digits.rstrip("0") or "0"
+    if x < -4 or x >= 21:
+        m = digits[0] + ("." + digits[1:] if len(digits) > 1 else "")
+        return "%s%se%s%02d" % (sign, m, "+" if x >= 0 else "-", abs(x))
+    if x >= 0:
+        if len(digits) <= x + 1:
+            return sign + digits + "0" * (x + 1 - len(digits))
+        return sign + digits[: x + 1] + "." + digits[x + 1:]
+    return sign + "0." + "0" * (-x - 1) + digits
+
+
+def to_string(v):
+    """OPA ast term String()."""
+    if v is None:
+        return "null"
+    if isinstance(v, bool):
+        return "true" if v else "false"
+    if isinstance(v, (int, float)):
+        return num_to_string(v)
+    if isinstance(v, str):
+        return quote(v)
+    if isinstance(v, tuple):
+        return "[" + ", ".join(to_string(x) for x in v) + "]"
+    if isinstance(v, RObj):
+        ks = sorted_values(v.keys())
+        return "{" + ", ".join("%s: %s" % (to_string(k), to_string(v.get(k))) for k in ks) + "}"
+    if isinstance(v, RSet):
+        if len(v) == 0:
+            return "set()"
+        return "{" + ", ".join(to_string(x) for x in sorted_values(v.elems())) + "}"
+    raise TypeError(v)

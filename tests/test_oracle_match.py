@@ -1,0 +1,118 @@
+"""Pins the oracle's Match layer against the reference's own table tests."""
+import pytest
+
+import reference_tables as T
+from oracle import audit, match
+from oracle import target as tg
+from oracle.client import AUDIT_EP, Client
+
+
+@pytest.mark.parametrize("w,cand,want", T.WILDCARD_MATCHES)
+def test_wildcard_matches(w, cand, want):
+    assert match.wildcard_matches(w, cand) is want
+
+
+@pytest.mark.parametrize("w,cand,want", T.WILDCARD_GENERATE_NAME)
+def test_wildcard_generate_name(w, cand, want):
+    assert match.wildcard_matches_generate_name(w, cand) is want
+
+
+@pytest.mark.parametrize("case", T.MATCH_CASES, ids=[c[0] for c in T.MATCH_CASES])
+def test_match_table(case):
+    _, obj, mt, ns, source, want, want_err = case
+    if want_err:
+        with pytest.raises(match.MatchError) as ei:
+            match.matches(mt, obj, ns, source)
+        assert str(ei.value).startswith(match.ERR_MATCH)
+    else:
+        assert match.matches(mt, obj, ns, source) is want
+
+
+@pytest.mark.parametrize("case", T.NAMES_MATCH_CASES, ids=[c[0] for c in T.NAMES_MATCH_CASES])
+def test_names_match(case):
+    _, name, obj, want = case
+    assert match.names_match({"name": name}, obj, None, "") is want
+
+
+DENYALL = None
+
+
+def _denyall(fixtures):
+    return fixtures["go_consts"]["pkg/target/target_integration_test.go"]["testTemplate"]["docs"][0]
+
+
+@pytest.mark.parametrize("case", T.ENFORCEMENT_CASES, ids=[c[0] for c in T.ENFORCEMENT_CASES])
+def test_constraint_enforcement(case, fixtures):
+    """pkg/target/target_integration_test.go:163-527: allowed <=> zero results, in all three review shapes."""
+    _, obj, ns, mt, allowed = case
+    c = Client(enforcement_points=(AUDIT_EP,))
+    c.add_template(_denyall(fixtures))
+    cons = {"apiVersion": "constraints.gatekeeper.sh/v1beta1", "kind": "DenyAll", "metadata": {"name": "my-constraint"}}
+    if mt is not None:
+        cons["spec"] = {"match": mt}
+    c.add_constraint(cons)
+    g, v, k = match.obj_gvk(obj)
+    kind = {"group": g, "version": v, "kind": k}
+    req = tg.AdmissionRequest({"kind": kind, "object": obj})
+    req2 = tg.AdmissionRequest({"kind": kind, "oldObject": obj})
+    if ns is not None:
+        req["namespace"] = ns["metadata"]["name"]
+        req2["namespace"] = ns["metadata"]["name"]
+    for review in (tg.AugmentedReview(req, ns), tg.AugmentedReview(req2, ns), tg.AugmentedUnstructured(tg.Unstructured(obj), ns)):
+        res = c.review(review, AUDIT_EP)
+        assert (len(res) == 0) is allowed
+        if not allowed:
+            assert res[0].msg == "denyall constraint installed"
+
+
+def test_delete_handling():
+    """pkg/target/target.go:269-287 / target_test.go:1154-1216"""
+    obj = {"apiVersion": "v1", "kind": "Pod", "metadata": {"name": "p"}}
+    with pytest.raises(tg.ReviewError) as ei:
+        tg.handle_review(tg.AdmissionRequest({"operation": "DELETE", "object": obj}))
+    assert str(ei.value) == tg.ERR_OLD_OBJECT_IS_NIL
+    handled, r = tg.handle_review(tg.AdmissionRequest({"operation": "DELETE", "oldObject": obj}))
+    assert handled and r.request["object"] == obj
+    handled, r = tg.handle_review(tg.AugmentedUnstructured(tg.Unstructured(obj), operation="DELETE"))
+    assert handled and r.request["object"] == obj and r.request["oldObject"] == obj
+    assert tg.handle_review("not a review") == (False, None)
+
+
+def test_process_data():
+    """pkg/target/target.go:40-66 / target_test.go:401"""
+    pod = tg.Unstructured({"apiVersion": "v1", "kind": "Pod", "metadata": {"name": "p", "namespace": "ns"}})
+    assert tg.process_data(pod)[1] == ["namespace", "ns", "v1", "Pod", "p"]
+    dep = tg.Unstructured({"apiVersion": "apps/v1", "kind": "Deployment", "metadata": {"name": "d"}})
+    assert tg.process_data(dep)[1] == ["cluster", "apps/v1", "Deployment", "d"]
+    with pytest.raises(tg.ReviewError):
+        tg.process_data(tg.Unstructured({"kind": "Pod", "metadata": {"name": "x"}}))
+
+
+def test_ns_cache_lookup():
+    """matcher.go:37-39: namespaceSelector falls back to the Namespace cached through AddData."""
+    c = Client()
+    c.add_data({"apiVersion": "v1", "kind": "Namespace", "metadata": {"name": "foo", "labels": {"bar": "qux"}}})
+    mt = tg.Matcher({"namespaceSelector": {"matchLabels": {"bar": "qux"}}}, c.cache)
+    obj = {"apiVersion": "v1", "kind": "Pod", "metadata": {"name": "p", "namespace": "foo"}}
+    rv = tg.GkReview(tg.AdmissionRequest({"object": obj, "namespace": "foo"}))
+    assert mt.match_review(rv) is True
+    rv2 = tg.GkReview(tg.AdmissionRequest({"object": obj, "namespace": "other"}))
+    with pytest.raises(tg.ReviewError) as ei:
+        mt.match_review(rv2)
+    assert str(ei.value) == ("error matching the requested object: p :failed to run Match criteria: "
+                             "namespace selector for namespace-scoped object but missing Namespace")
+
+
+@pytest.mark.parametrize("s,size,want", T.TRUNCATE_CASES)
+def test_truncate(s, size, want):
+    assert audit.truncate_string(s, size) == want
+
+
+def test_limit_queue():
+    items = [dict(name="", message="", enforcementAction="", **i) for i in T.SVQ_ITEMS]
+    desc = sorted(range(3), key=lambda i: audit.sv_key(items[i]), reverse=True)
+    assert desc == T.SVQ_POP_ORDER
+    q = audit.LimitQueue(2)
+    for it in items:
+        q.push(it)
+    assert sorted(items.index(x) for x in q.items) == T.LIMITQ2_REMAINING
