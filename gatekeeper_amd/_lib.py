@@ -1,0 +1,106 @@
+"""ctypes binding of the C ABI declared in include/gkgpu.h.
+
+The product library is gatekeeper_amd/libgkgpu.so (host engine + HIP kernels for gfx950), built in-tree by
+`__graft_entry__.build()` / `make -C gatekeeper_amd/csrc`.  There is NO CPU fallback: if the library is missing, or
+no MI355X is visible, loading / gk_engine_create fail loudly.
+
+tests/ may set GK_TEST_HOSTEMU=1 to load tests/native/libgkgpu_hostemu.so instead -- a test-only build in which the
+kernels' per-row / per-review code (vm_core.hpp) is executed lane by lane on the CPU, so that the AOT compiler and
+the flattener can be checked against the oracle in the GPU-less build container.  Nothing outside tests/ sets it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+
+GK_OK = 0
+GK_ERR_INVALID, GK_ERR_REGO, GK_ERR_UNSUPPORTED, GK_ERR_NOT_FOUND, GK_ERR_DEVICE, GK_ERR_REVIEW, GK_ERR_INTERNAL = (
+    -1, -2, -3, -4, -5, -6, -7)
+GK_REVIEW_ADMISSION_REQUEST, GK_REVIEW_OBJECT = 0, 1
+GK_SRC_EMPTY, GK_SRC_ORIGINAL, GK_SRC_GENERATED, GK_SRC_ALL, GK_SRC_INVALID = 0, 1, 2, 3, 4
+GK_TABLE_KEEP_DOCS = 1
+GK_EVAL_WANT_MATCH, GK_EVAL_NO_DOWNLOAD, GK_EVAL_WANT_LIST, GK_EVAL_ASYNC = 1, 2, 4, 8
+
+EXPORTS = [
+    "gk_engine_create", "gk_engine_destroy", "gk_last_error", "gk_version", "gk_template_add", "gk_template_remove",
+    "gk_constraint_add", "gk_constraint_remove", "gk_data_put", "gk_data_remove", "gk_table_create", "gk_table_free",
+    "gk_table_eval", "gk_eval_free", "gk_render", "gk_render_error", "gk_free", "gk_dump",
+]
+
+
+class gk_opts(C.Structure):
+    _fields_ = [("device", C.c_int32), ("elem_cap", C.c_uint16 * 3), ("reserved", C.c_uint16)]
+
+
+class gk_review_in(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("source", C.c_int32),
+                ("json", C.c_char_p), ("json_len", C.c_size_t),
+                ("namespace_json", C.c_char_p), ("namespace_len", C.c_size_t),
+                ("ns_object_json", C.c_char_p), ("ns_object_len", C.c_size_t),
+                ("operation", C.c_char_p)]
+
+
+class gk_eval_out(C.Structure):
+    _fields_ = [("n_reviews", C.c_uint32), ("n_constraints", C.c_uint32), ("n_tiles", C.c_uint32),
+                ("constraint_ids", C.POINTER(C.c_uint32)),
+                ("viol", C.POINTER(C.c_uint64)), ("err", C.POINTER(C.c_uint64)), ("match", C.POINTER(C.c_uint64)),
+                ("too_big", C.POINTER(C.c_uint64)), ("counts", C.POINTER(C.c_uint32)), ("list", C.POINTER(C.c_uint32)),
+                ("list_len", C.c_uint32), ("list_total", C.c_uint32), ("n_overflow", C.c_uint32),
+                ("kernel_ms", C.c_float), ("fast_kernel_ms", C.c_float),
+                ("algo_bytes", C.c_uint64), ("n_rows", C.c_uint64), ("n_launches", C.c_uint32), ("reserved", C.c_uint32),
+                ("d_viol", C.c_void_p), ("d_err", C.c_void_p), ("d_counts", C.c_void_p)]
+
+
+class EngineLoadError(RuntimeError):
+    pass
+
+
+def library_path(hostemu: bool = False) -> str:
+    if hostemu:
+        return os.path.join(_ROOT, "tests", "native", "libgkgpu_hostemu.so")
+    return os.path.join(_HERE, "libgkgpu.so")
+
+
+_cache = {}
+
+
+def load(hostemu: bool | None = None):
+    """Load the C-ABI library. hostemu=None consults GK_TEST_HOSTEMU (tests only)."""
+    if hostemu is None:
+        hostemu = os.environ.get("GK_TEST_HOSTEMU", "") == "1"
+    if hostemu in _cache:
+        return _cache[hostemu]
+    path = library_path(hostemu)
+    if not os.path.exists(path):
+        raise EngineLoadError(
+            "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(there is no CPU fallback for the constraint-evaluation path)" % path)
+    lib = C.CDLL(path)
+    vp, cp, sz, u32 = C.c_void_p, C.c_char_p, C.c_size_t, C.c_uint32
+    lib.gk_engine_create.argtypes = [C.POINTER(gk_opts), C.POINTER(vp)]
+    lib.gk_engine_destroy.argtypes = [vp]
+    lib.gk_engine_destroy.restype = None
+    lib.gk_last_error.restype = cp
+    lib.gk_version.restype = cp
+    lib.gk_template_add.argtypes = [vp, cp, cp, C.POINTER(cp), sz]
+    lib.gk_template_remove.argtypes = [vp, cp]
+    lib.gk_constraint_add.argtypes = [vp, cp, sz, C.POINTER(u32)]
+    lib.gk_constraint_remove.argtypes = [vp, cp, cp]
+    lib.gk_data_put.argtypes = [vp, C.POINTER(cp), sz, cp, sz]
+    lib.gk_data_remove.argtypes = [vp, C.POINTER(cp), sz]
+    lib.gk_table_create.argtypes = [vp, C.POINTER(gk_review_in), sz, u32, C.POINTER(C.c_int32), C.POINTER(vp)]
+    lib.gk_table_free.argtypes = [vp]
+    lib.gk_table_free.restype = None
+    lib.gk_table_eval.argtypes = [vp, vp, u32, C.POINTER(C.POINTER(gk_eval_out))]
+    lib.gk_eval_free.argtypes = [C.POINTER(gk_eval_out)]
+    lib.gk_eval_free.restype = None
+    lib.gk_render.argtypes = [vp, vp, u32, u32, C.POINTER(vp)]
+    lib.gk_render_error.argtypes = [vp, vp, u32, u32, C.POINTER(vp)]
+    lib.gk_free.argtypes = [vp]
+    lib.gk_free.restype = None
+    lib.gk_dump.argtypes = [vp, C.POINTER(vp)]
+    _cache[hostemu] = lib
+    return lib

@@ -1,0 +1,444 @@
+// Rego builtins over concrete Values (constant folding in the AOT compiler; message rendering on the host).
+// Restates the OPA v1.17.1 builtins the reference's in-tree templates call.  A builtin
+// returning Undefined makes the calling expression undefined (OPA's default non-strict error mode).
+#include "builtins.hpp"
+
+#include <cmath>
+#include <map>
+#include <mutex>
+#include <unordered_map>
+
+#include "regex.hpp"
+
+namespace gk {
+namespace {
+
+const Value U;   // undefined
+
+bool is_num(const Value& v) { return v.is_number(); }
+
+// ---------------------------------------------------------------------------------------------- sprintf
+struct GoArg { int kind; i128 i; double f; std::string s; };   // 0 int, 1 float64, 2 string
+
+GoArg go_arg(const Value& v) {
+  GoArg a{2, 0, 0, ""};
+  if (v.is_number()) {
+    if (v.is_int) { a.kind = 0; a.i = v.i; }
+    else { a.kind = 1; a.f = v.d; }
+  } else if (v.is_string()) a.s = v.str();
+  else a.s = to_term_string(v);
+  return a;
+}
+
+std::string bad_verb(char verb, const GoArg& a) {
+  std::string o = "%!";
+  o.push_back(verb);
+  if (a.kind == 2) return o + "(string=" + a.s + ")";
+  if (a.kind == 0) return o + "(int=" + i128_to_string(a.i) + ")";
+  return o + "(float64=" + go_float_v(a.f) + ")";
+}
+
+std::string pad(std::string s, const std::string& flags, int width) {
+  if (width < 0 || (int)s.size() >= width) return s;
+  if (flags.find('-') != std::string::npos) return s + std::string(width - s.size(), ' ');
+  if (flags.find('0') != std::string::npos && !s.empty() && (isdigit((unsigned char)s[0]) || s[0] == '+' || s[0] == '-')) {
+    std::string sign;
+    if (s[0] == '+' || s[0] == '-') { sign = s.substr(0, 1); s = s.substr(1); }
+    return sign + std::string(width - s.size() - sign.size(), '0') + s;
+  }
+  return std::string(width - s.size(), ' ') + s;
+}
+
+std::string to_base(i128 v, int base, bool upper) {
+  if (v == 0) return "0";
+  bool neg = v < 0;
+  unsigned __int128 u = neg ? (unsigned __int128)(-v) : (unsigned __int128)v;
+  const char* digs = upper ? "0123456789ABCDEF" : "0123456789abcdef";
+  std::string s;
+  while (u) { s.push_back(digs[(int)(u % base)]); u /= base; }
+  if (neg) s.push_back('-');
+  std::reverse(s.begin(), s.end());
+  return s;
+}
+
+}  // namespace
+
+std::string go_sprintf(const std::string& fmt, const ValueVec& argv) {
+  std::vector<GoArg> args;
+  for (const Value& v : argv) args.push_back(go_arg(v));
+  std::string out;
+  size_t ai = 0, n = fmt.size();
+  for (size_t i = 0; i < n;) {
+    if (fmt[i] != '%') { out.push_back(fmt[i++]); continue; }
+    size_t j = i + 1;
+    std::string flags;
+    while (j < n && strchr("-+# 0", fmt[j])) flags.push_back(fmt[j++]);
+    int width = -1, prec = -1;
+    if (j < n && isdigit((unsigned char)fmt[j])) { width = 0; while (j < n && isdigit((unsigned char)fmt[j])) width = width * 10 + (fmt[j++] - '0'); }
+    if (j < n && fmt[j] == '.') { j++; prec = 0; while (j < n && isdigit((unsigned char)fmt[j])) prec = prec * 10 + (fmt[j++] - '0'); }
+    if (j >= n) { out += "%!(NOVERB)"; break; }
+    char verb = fmt[j++];
+    i = j;
+    if (verb == '%') { out.push_back('%'); continue; }
+    if (ai >= args.size()) { out += "%!"; out.push_back(verb); out += "(MISSING)"; continue; }
+    const GoArg& a = args[ai++];
+    std::string s;
+    bool plus = flags.find('+') != std::string::npos;
+    switch (verb) {
+      case 'v':
+        if (a.kind == 2) s = a.s;
+        else if (a.kind == 0) s = ((plus && a.i >= 0) ? "+" : "") + i128_to_string(a.i);
+        else s = go_float_v(a.f);
+        break;
+      case 's': s = a.kind == 2 ? (prec >= 0 ? a.s.substr(0, prec) : a.s) : bad_verb(verb, a); break;
+      case 'q': s = a.kind == 2 ? go_quote(a.s) : bad_verb(verb, a); break;
+      case 'd': s = a.kind == 0 ? ((plus && a.i >= 0) ? "+" : "") + i128_to_string(a.i) : bad_verb(verb, a); break;
+      case 'x': case 'X':
+        if (a.kind == 0) s = to_base(a.i, 16, verb == 'X');
+        else if (a.kind == 2) { const char* d = verb == 'X' ? "0123456789ABCDEF" : "0123456789abcdef"; for (unsigned char c : a.s) { s.push_back(d[c >> 4]); s.push_back(d[c & 15]); } }
+        else s = bad_verb(verb, a);
+        break;
+      case 'o': s = a.kind == 0 ? to_base(a.i, 8, false) : bad_verb(verb, a); break;
+      case 'b': s = a.kind == 0 ? to_base(a.i, 2, false) : bad_verb(verb, a); break;
+      case 'c': if (a.kind == 0) { s.push_back((char)a.i); } else s = bad_verb(verb, a); break;
+      case 'f': case 'e': case 'E': case 'g': case 'G':
+        if (a.kind == 1) {
+          char buf[128], f[16];
+          snprintf(f, sizeof f, "%%.%d%c", prec < 0 ? 6 : prec, verb);
+          snprintf(buf, sizeof buf, f, a.f);
+          s = buf;
+          if (verb == 'e' || verb == 'E') {   // Go prints at least two exponent digits, C too; nothing to fix
+          }
+        } else s = bad_verb(verb, a);
+        break;
+      default: s = bad_verb(verb, a);
+    }
+    out += pad(s, flags, width);
+  }
+  if (ai < args.size()) {
+    out += "%!(EXTRA ";
+    for (size_t k = ai; k < args.size(); k++) {
+      if (k > ai) out += ", ";
+      const GoArg& a = args[k];
+      if (a.kind == 0) out += "int=" + i128_to_string(a.i);
+      else if (a.kind == 1) out += "float64=" + go_float_v(a.f);
+      else out += "string=" + a.s;
+    }
+    out += ")";
+  }
+  return out;
+}
+
+namespace {
+
+std::mutex g_re_mu;
+std::unordered_map<std::string, std::shared_ptr<Regex>> g_re_cache;
+
+std::shared_ptr<Regex> get_regex(const std::string& pat) {
+  std::lock_guard<std::mutex> l(g_re_mu);
+  auto it = g_re_cache.find(pat);
+  if (it != g_re_cache.end()) return it->second;
+  std::shared_ptr<Regex> r;
+  try { r = std::make_shared<Regex>(pat); } catch (const RegexError&) { r = nullptr; }
+  g_re_cache[pat] = r;
+  return r;
+}
+
+// utf-8 helpers: strings are byte strings; Rego's count/substring work on code points
+size_t rune_count(const std::string& s) {
+  size_t n = 0;
+  for (unsigned char c : s) if ((c & 0xC0) != 0x80) n++;
+  return n;
+}
+size_t rune_offset(const std::string& s, size_t runes) {
+  size_t i = 0, n = 0;
+  while (i < s.size() && n < runes) { i++; while (i < s.size() && ((unsigned char)s[i] & 0xC0) == 0x80) i++; n++; }
+  return i;
+}
+
+Value norm_num(double d) { return Value::real(d); }
+
+bool coll_items(const Value& c, ValueVec* out) {
+  if (c.is_array() || c.is_set()) { *out = c.items(); return true; }
+  return false;
+}
+
+std::string trim_set(const std::string& s, const std::string& cut, bool left, bool right) {
+  size_t lo = 0, hi = s.size();
+  if (left) while (lo < hi && cut.find(s[lo]) != std::string::npos) lo++;
+  if (right) while (hi > lo && cut.find(s[hi - 1]) != std::string::npos) hi--;
+  return s.substr(lo, hi - lo);
+}
+
+bool to_strs(const Value& v, std::vector<std::string>* out) {
+  if (v.is_string()) { out->push_back(v.str()); return true; }
+  ValueVec it;
+  if (!coll_items(v, &it)) return false;
+  for (const Value& x : it) { if (!x.is_string()) return false; out->push_back(x.str()); }
+  return true;
+}
+
+Value parse_number_str(const std::string& x) {
+  if (x.empty()) return U;
+  size_t i = 0;
+  if (x[i] == '+' || x[i] == '-') i++;
+  size_t digits = 0, dot = 0, exp = 0;
+  for (; i < x.size(); i++) {
+    char c = x[i];
+    if (isdigit((unsigned char)c)) digits++;
+    else if (c == '.' && !dot && !exp) dot = 1;
+    else if ((c == 'e' || c == 'E') && digits && !exp) { exp = 1; if (i + 1 < x.size() && (x[i + 1] == '+' || x[i + 1] == '-')) i++; }
+    else return U;
+  }
+  if (!digits) return U;
+  if (!dot && !exp && x.size() <= 37) {
+    i128 v = 0; size_t k = 0; bool neg = false;
+    if (x[0] == '-') { neg = true; k = 1; } else if (x[0] == '+') k = 1;
+    for (; k < x.size(); k++) v = v * 10 + (x[k] - '0');
+    return Value::integer(neg ? -v : v);
+  }
+  return norm_num(strtod(x.c_str(), nullptr));
+}
+
+typedef Value (*Fn)(const ValueVec&);
+#define ARGS const ValueVec& a
+#define NEED(n) if (a.size() != (n)) return U
+#define STR(k) if (!a[k].is_string()) return U
+#define NUM(k) if (!a[k].is_number()) return U
+
+Value b_count(ARGS) {
+  NEED(1);
+  if (a[0].is_string()) return Value::integer((i128)rune_count(a[0].str()));
+  if (a[0].is_array() || a[0].is_set() || a[0].is_object()) return Value::integer((i128)a[0].size());
+  return U;
+}
+Value b_sum(ARGS) {
+  NEED(1); ValueVec it; if (!coll_items(a[0], &it)) return U;
+  bool all_int = true; i128 si = 0; double sd = 0;
+  for (auto& v : it) { if (!v.is_number()) return U; if (v.is_int) si += v.i; else all_int = false; sd += v.as_double(); }
+  return all_int ? Value::integer(si) : norm_num(sd);
+}
+Value b_product(ARGS) {
+  NEED(1); ValueVec it; if (!coll_items(a[0], &it)) return U;
+  bool all_int = true; i128 pi = 1; double pd = 1;
+  for (auto& v : it) { if (!v.is_number()) return U; if (v.is_int) pi *= v.i; else all_int = false; pd *= v.as_double(); }
+  return all_int ? Value::integer(pi) : norm_num(pd);
+}
+Value b_max(ARGS) { NEED(1); ValueVec it; if (!coll_items(a[0], &it) || it.empty()) return U; return *std::max_element(it.begin(), it.end()); }
+Value b_min(ARGS) { NEED(1); ValueVec it; if (!coll_items(a[0], &it) || it.empty()) return U; return *std::min_element(it.begin(), it.end()); }
+Value b_sort(ARGS) { NEED(1); ValueVec it; if (!coll_items(a[0], &it)) return U; std::sort(it.begin(), it.end()); return Value::array(it); }
+Value b_any(ARGS) { NEED(1); ValueVec it; if (!coll_items(a[0], &it)) return U; for (auto& v : it) if (v.is_bool() && v.b) return Value::boolean(true); return Value::boolean(false); }
+Value b_all(ARGS) { NEED(1); ValueVec it; if (!coll_items(a[0], &it)) return U; for (auto& v : it) if (!(v.is_bool() && v.b)) return Value::boolean(false); return Value::boolean(true); }
+Value b_abs(ARGS) { NEED(1); NUM(0); return a[0].is_int ? Value::integer(a[0].i < 0 ? -a[0].i : a[0].i) : norm_num(std::fabs(a[0].d)); }
+Value b_round(ARGS) { NEED(1); NUM(0); return a[0].is_int ? a[0] : norm_num(std::round(a[0].d)); }
+Value b_ceil(ARGS) { NEED(1); NUM(0); return a[0].is_int ? a[0] : norm_num(std::ceil(a[0].d)); }
+Value b_floor(ARGS) { NEED(1); NUM(0); return a[0].is_int ? a[0] : norm_num(std::floor(a[0].d)); }
+Value b_sprintf(ARGS) { NEED(2); STR(0); if (!a[1].is_array()) return U; return Value::string(go_sprintf(a[0].str(), a[1].items())); }
+Value b_concat(ARGS) {
+  NEED(2); STR(0); ValueVec it; if (!coll_items(a[1], &it)) return U;
+  std::string o;
+  for (size_t k = 0; k < it.size(); k++) { if (!it[k].is_string()) return U; if (k) o += a[0].str(); o += it[k].str(); }
+  return Value::string(o);
+}
+Value b_contains(ARGS) { NEED(2); STR(0); STR(1); return Value::boolean(a[0].str().find(a[1].str()) != std::string::npos); }
+Value b_startswith(ARGS) { NEED(2); STR(0); STR(1); const std::string &s = a[0].str(), &p = a[1].str(); return Value::boolean(s.size() >= p.size() && s.compare(0, p.size(), p) == 0); }
+Value b_endswith(ARGS) { NEED(2); STR(0); STR(1); const std::string &s = a[0].str(), &p = a[1].str(); return Value::boolean(s.size() >= p.size() && s.compare(s.size() - p.size(), p.size(), p) == 0); }
+Value b_lower(ARGS) { NEED(1); STR(0); std::string s = a[0].str(); for (auto& c : s) if (c >= 'A' && c <= 'Z') c += 32; return Value::string(s); }
+Value b_upper(ARGS) { NEED(1); STR(0); std::string s = a[0].str(); for (auto& c : s) if (c >= 'a' && c <= 'z') c -= 32; return Value::string(s); }
+Value b_trim(ARGS) { NEED(2); STR(0); STR(1); return Value::string(trim_set(a[0].str(), a[1].str(), true, true)); }
+Value b_trim_left(ARGS) { NEED(2); STR(0); STR(1); return Value::string(trim_set(a[0].str(), a[1].str(), true, false)); }
+Value b_trim_right(ARGS) { NEED(2); STR(0); STR(1); return Value::string(trim_set(a[0].str(), a[1].str(), false, true)); }
+Value b_trim_prefix(ARGS) { NEED(2); STR(0); STR(1); const std::string &s = a[0].str(), &p = a[1].str(); return Value::string(s.compare(0, p.size(), p) == 0 && s.size() >= p.size() ? s.substr(p.size()) : s); }
+Value b_trim_suffix(ARGS) { NEED(2); STR(0); STR(1); const std::string &s = a[0].str(), &p = a[1].str(); return Value::string(s.size() >= p.size() && s.compare(s.size() - p.size(), p.size(), p) == 0 ? s.substr(0, s.size() - p.size()) : s); }
+Value b_trim_space(ARGS) { NEED(1); STR(0); return Value::string(trim_set(a[0].str(), " \t\n\r\v\f", true, true)); }
+Value b_split(ARGS) {
+  NEED(2); STR(0); STR(1);
+  const std::string &s = a[0].str(), &d = a[1].str();
+  ValueVec out;
+  if (d.empty()) { size_t i = 0; while (i < s.size()) { size_t j = rune_offset(s.substr(i), 1); out.push_back(Value::string(s.substr(i, j))); i += j; } return Value::array(out); }
+  size_t pos = 0;
+  for (;;) {
+    size_t k = s.find(d, pos);
+    if (k == std::string::npos) { out.push_back(Value::string(s.substr(pos))); break; }
+    out.push_back(Value::string(s.substr(pos, k - pos)));
+    pos = k + d.size();
+  }
+  return Value::array(out);
+}
+Value b_replace(ARGS) {
+  NEED(3); STR(0); STR(1); STR(2);
+  const std::string &s = a[0].str(), &o = a[1].str(), &n = a[2].str();
+  std::string r;
+  if (o.empty()) { r = n; size_t i = 0; while (i < s.size()) { size_t j = rune_offset(s.substr(i), 1); r += s.substr(i, j); r += n; i += j; } return Value::string(r); }
+  size_t pos = 0;
+  for (;;) {
+    size_t k = s.find(o, pos);
+    if (k == std::string::npos) { r += s.substr(pos); break; }
+    r += s.substr(pos, k - pos);
+    r += n;
+    pos = k + o.size();
+  }
+  return Value::string(r);
+}
+Value b_substring(ARGS) {
+  NEED(3); STR(0); NUM(1); NUM(2);
+  const std::string& s = a[0].str();
+  long long off = (long long)a[1].as_double(), len = (long long)a[2].as_double();
+  if (off < 0) return U;
+  size_t rc = rune_count(s);
+  if ((size_t)off >= rc) return Value::string("");
+  size_t b = rune_offset(s, off);
+  if (len < 0) return Value::string(s.substr(b));
+  size_t e = b + rune_offset(s.substr(b), len);
+  return Value::string(s.substr(b, e - b));
+}
+Value b_indexof(ARGS) { NEED(2); STR(0); STR(1); size_t k = a[0].str().find(a[1].str()); return Value::integer(k == std::string::npos ? -1 : (i128)rune_count(a[0].str().substr(0, k))); }
+Value b_format_int(ARGS) {
+  NEED(2); NUM(0); NUM(1);
+  int base = (int)a[1].as_double();
+  if (base != 2 && base != 8 && base != 10 && base != 16) return U;
+  i128 v = a[0].is_int ? a[0].i : (i128)std::floor(a[0].d);
+  return Value::string(to_base(v, base, false));
+}
+Value b_reverse(ARGS) { NEED(1); STR(0); std::string s = a[0].str(); std::reverse(s.begin(), s.end()); return Value::string(s); }
+Value b_any_prefix(ARGS) {
+  NEED(2); std::vector<std::string> ss, bs; if (!to_strs(a[0], &ss) || !to_strs(a[1], &bs)) return U;
+  for (auto& s : ss) for (auto& b : bs) if (s.size() >= b.size() && s.compare(0, b.size(), b) == 0) return Value::boolean(true);
+  return Value::boolean(false);
+}
+Value b_any_suffix(ARGS) {
+  NEED(2); std::vector<std::string> ss, bs; if (!to_strs(a[0], &ss) || !to_strs(a[1], &bs)) return U;
+  for (auto& s : ss) for (auto& b : bs) if (s.size() >= b.size() && s.compare(s.size() - b.size(), b.size(), b) == 0) return Value::boolean(true);
+  return Value::boolean(false);
+}
+Value b_re_match(ARGS) { NEED(2); STR(0); STR(1); auto r = get_regex(a[0].str()); if (!r) return U; return Value::boolean(r->search(a[1].str())); }
+Value b_regex_valid(ARGS) { NEED(1); if (!a[0].is_string()) return Value::boolean(false); return Value::boolean(get_regex(a[0].str()) != nullptr); }
+Value b_is_string(ARGS) { NEED(1); return Value::boolean(a[0].is_string()); }
+Value b_is_number(ARGS) { NEED(1); return Value::boolean(a[0].is_number()); }
+Value b_is_boolean(ARGS) { NEED(1); return Value::boolean(a[0].is_bool()); }
+Value b_is_array(ARGS) { NEED(1); return Value::boolean(a[0].is_array()); }
+Value b_is_object(ARGS) { NEED(1); return Value::boolean(a[0].is_object()); }
+Value b_is_set(ARGS) { NEED(1); return Value::boolean(a[0].is_set()); }
+Value b_is_null(ARGS) { NEED(1); return Value::boolean(a[0].is_null()); }
+Value b_type_name(ARGS) {
+  NEED(1);
+  static const char* names[] = {"null", "boolean", "number", "string", "array", "object", "set"};
+  if (!a[0].defined()) return U;
+  return Value::string(names[a[0].kind]);
+}
+Value b_to_number(ARGS) {
+  NEED(1);
+  if (a[0].is_null()) return Value::integer(0);
+  if (a[0].is_bool()) return Value::integer(a[0].b ? 1 : 0);
+  if (a[0].is_number()) return a[0];
+  if (a[0].is_string()) return parse_number_str(a[0].str());
+  return U;
+}
+Value b_object_get(ARGS) {
+  NEED(3);
+  if (!a[0].is_object()) return U;
+  if (a[1].is_array()) {
+    Value cur = a[0];
+    for (const Value& k : a[1].items()) {
+      if (cur.is_object()) { const Value* v = cur.get(k); if (!v) return a[2]; cur = *v; }
+      else if (cur.is_array() && k.is_number() && k.is_int && k.i >= 0 && (size_t)k.i < cur.size()) cur = cur.items()[(size_t)k.i];
+      else return a[2];
+    }
+    return cur;
+  }
+  const Value* v = a[0].get(a[1]);
+  return v ? *v : a[2];
+}
+Value b_object_keys(ARGS) { NEED(1); if (!a[0].is_object()) return U; ValueVec ks; for (auto& kv : a[0].pairs()) ks.push_back(kv.first); return Value::set(ks); }
+Value b_object_remove(ARGS) {
+  NEED(2); if (!a[0].is_object()) return U;
+  ValueVec ks;
+  if (a[1].is_object()) for (auto& kv : a[1].pairs()) ks.push_back(kv.first); else if (!coll_items(a[1], &ks)) return U;
+  Value kset = Value::set(ks);
+  ValuePairs out;
+  for (auto& kv : a[0].pairs()) if (!kset.set_has(kv.first)) out.push_back(kv);
+  return Value::object(out);
+}
+Value obj_union(const Value& x, const Value& y) {
+  ValuePairs out = x.pairs();
+  for (auto& kv : y.pairs()) {
+    const Value* cur = x.get(kv.first);
+    if (cur && cur->is_object() && kv.second.is_object()) out.emplace_back(kv.first, obj_union(*cur, kv.second));
+    else out.push_back(kv);
+  }
+  return Value::object(out);
+}
+Value b_object_union(ARGS) { NEED(2); if (!a[0].is_object() || !a[1].is_object()) return U; return obj_union(a[0], a[1]); }
+Value b_array_concat(ARGS) { NEED(2); if (!a[0].is_array() || !a[1].is_array()) return U; ValueVec o = a[0].items(); o.insert(o.end(), a[1].items().begin(), a[1].items().end()); return Value::array(o); }
+Value b_array_slice(ARGS) {
+  NEED(3); if (!a[0].is_array()) return U; NUM(1); NUM(2);
+  long long lo = std::max(0LL, (long long)a[1].as_double()), hi = std::min((long long)a[0].size(), (long long)a[2].as_double());
+  ValueVec o;
+  for (long long k = lo; k < hi; k++) o.push_back(a[0].items()[k]);
+  return Value::array(o);
+}
+Value b_array_reverse(ARGS) { NEED(1); if (!a[0].is_array()) return U; ValueVec o = a[0].items(); std::reverse(o.begin(), o.end()); return Value::array(o); }
+Value b_union(ARGS) { NEED(1); if (!a[0].is_set()) return U; ValueVec o; for (auto& s : a[0].items()) { if (!s.is_set()) return U; o.insert(o.end(), s.items().begin(), s.items().end()); } return Value::set(o); }
+Value b_intersection(ARGS) {
+  NEED(1); if (!a[0].is_set()) return U;
+  if (a[0].size() == 0) return Value::set({});
+  ValueVec cur = a[0].items()[0].items();
+  for (size_t k = 1; k < a[0].size(); k++) { const Value& s = a[0].items()[k]; if (!s.is_set()) return U; ValueVec nx; for (auto& v : cur) if (s.set_has(v)) nx.push_back(v); cur = nx; }
+  return Value::set(cur);
+}
+Value b_json_marshal(ARGS) { NEED(1); return Value::string(to_json(a[0])); }
+Value b_json_unmarshal(ARGS) { NEED(1); STR(0); try { return parse_json(a[0].str()); } catch (const JsonError&) { return U; } }
+Value b_true(ARGS) { (void)a; return Value::boolean(true); }
+
+const std::map<std::string, Fn>& table() {
+  static const std::map<std::string, Fn> t = {
+      {"count", b_count}, {"sum", b_sum}, {"product", b_product}, {"max", b_max}, {"min", b_min}, {"sort", b_sort},
+      {"any", b_any}, {"all", b_all}, {"abs", b_abs}, {"round", b_round}, {"ceil", b_ceil}, {"floor", b_floor},
+      {"sprintf", b_sprintf}, {"concat", b_concat}, {"contains", b_contains}, {"startswith", b_startswith},
+      {"endswith", b_endswith}, {"lower", b_lower}, {"upper", b_upper}, {"trim", b_trim}, {"trim_left", b_trim_left},
+      {"trim_right", b_trim_right}, {"trim_prefix", b_trim_prefix}, {"trim_suffix", b_trim_suffix},
+      {"trim_space", b_trim_space}, {"split", b_split}, {"replace", b_replace}, {"substring", b_substring},
+      {"indexof", b_indexof}, {"format_int", b_format_int}, {"strings.reverse", b_reverse},
+      {"strings.any_prefix_match", b_any_prefix}, {"strings.any_suffix_match", b_any_suffix},
+      {"re_match", b_re_match}, {"regex.match", b_re_match}, {"regex.is_valid", b_regex_valid},
+      {"is_string", b_is_string}, {"is_number", b_is_number}, {"is_boolean", b_is_boolean}, {"is_array", b_is_array},
+      {"is_object", b_is_object}, {"is_set", b_is_set}, {"is_null", b_is_null}, {"type_name", b_type_name},
+      {"to_number", b_to_number}, {"object.get", b_object_get}, {"object.keys", b_object_keys},
+      {"object.remove", b_object_remove}, {"object.union", b_object_union}, {"array.concat", b_array_concat},
+      {"array.slice", b_array_slice}, {"array.reverse", b_array_reverse}, {"union", b_union},
+      {"intersection", b_intersection}, {"json.marshal", b_json_marshal}, {"json.unmarshal", b_json_unmarshal},
+      {"print", b_true}, {"trace", b_true},
+  };
+  return t;
+}
+
+}  // namespace
+
+bool has_builtin(const std::string& name) { return table().count(name) != 0; }
+
+Value call_builtin(const std::string& name, const ValueVec& args) {
+  auto it = table().find(name);
+  if (it == table().end()) return Value();
+  for (const Value& v : args) if (!v.defined()) return Value();
+  return it->second(args);
+}
+
+Value rego_arith(const std::string& op, const Value& a, const Value& b) {
+  if (op == "-" && a.is_set() && b.is_set()) { ValueVec o; for (auto& v : a.items()) if (!b.set_has(v)) o.push_back(v); return Value::set(o); }
+  if (op == "&") { if (!a.is_set() || !b.is_set()) return U; ValueVec o; for (auto& v : a.items()) if (b.set_has(v)) o.push_back(v); return Value::set(o); }
+  if (op == "|") { if (!a.is_set() || !b.is_set()) return U; ValueVec o = a.items(); o.insert(o.end(), b.items().begin(), b.items().end()); return Value::set(o); }
+  if (!a.is_number() || !b.is_number()) return U;
+  bool ii = a.is_int && b.is_int;
+  if (op == "+") return ii ? Value::integer(a.i + b.i) : norm_num(a.as_double() + b.as_double());
+  if (op == "-") return ii ? Value::integer(a.i - b.i) : norm_num(a.as_double() - b.as_double());
+  if (op == "*") return ii ? Value::integer(a.i * b.i) : norm_num(a.as_double() * b.as_double());
+  if (op == "/") {
+    if (b.as_double() == 0) return U;
+    if (ii && a.i % b.i == 0) return Value::integer(a.i / b.i);
+    return norm_num(a.as_double() / b.as_double());
+  }
+  if (op == "%") { if (!ii || b.i == 0) return U; return Value::integer(a.i % b.i); }
+  return U;
+}
+
+}  // namespace gk

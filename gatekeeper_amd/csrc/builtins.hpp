@@ -1,0 +1,12 @@
+// Concrete Rego builtins (see builtins.cpp).
+#pragma once
+#include <string>
+
+#include "value.hpp"
+
+namespace gk {
+bool has_builtin(const std::string& name);
+Value call_builtin(const std::string& name, const ValueVec& args);        // Undefined on error / unknown
+Value rego_arith(const std::string& op, const Value& a, const Value& b);  // + - * / % & | (numbers and sets)
+std::string go_sprintf(const std::string& fmt, const ValueVec& args);
+}  // namespace gk

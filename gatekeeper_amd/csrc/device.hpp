@@ -1,0 +1,50 @@
+// Device backend interface between the host engine (engine.cpp) and the HIP kernels (kernels.hip).
+// The product library links kernels.hip.  tests/native/hostemu.cpp implements the same interface on the CPU for
+// the build container's GPU-less unit tests ONLY (libgkgpu_hostemu.so; never loaded by the product path).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "flatten.hpp"
+#include "lower.hpp"
+
+namespace gk {
+
+struct DevTable;
+struct DevPlan;
+
+struct EvalOptions {
+  bool download = true;      // copy bitmaps / list back to the host
+  bool want_match = false;   // also produce the match-only bitmap
+  uint32_t list_capacity = 0;   // max violation-list entries (0 = no list)
+};
+
+struct EvalOut {
+  uint32_t n_reviews = 0, n_constraints = 0, n_tiles = 0;
+  std::vector<uint64_t> viol;     // [n_constraints][n_tiles]  bit r%64 of word r/64: constraint matched AND violated
+  std::vector<uint64_t> err;      // [n_constraints][n_tiles]  Matcher.Match returned an error (autoreject)
+  std::vector<uint64_t> match;    // [n_constraints][n_tiles]  (only if want_match)
+  std::vector<uint64_t> too_big;  // [n_tiles] reviews that exceed engine limits even in the large variant
+  std::vector<uint32_t> counts;   // [n_constraints] violating reviews per constraint
+  std::vector<uint32_t> list;     // pairs (constraint, review) -- compacted violation list
+  uint32_t list_total = 0;        // entries the kernel wanted to emit (may exceed capacity)
+  uint32_t n_overflow = 0;        // reviews re-run in the large-capacity variant
+  float kernel_ms = 0;            // device time of the evaluation kernels (HIP events on the launch stream)
+  float fast_kernel_ms = 0;       // average duration of the dominant (LDS) kernel per launch since the last finish
+  uint32_t n_launches = 0;        // launches averaged in fast_kernel_ms
+  const void *d_viol = nullptr, *d_err = nullptr, *d_counts = nullptr;   // device-resident results (valid until the table's next launch)
+};
+
+std::string dev_init(int device);                       // "" on success, else error text
+int dev_count();
+DevTable* dev_table_upload(const HostTable& t);
+void dev_table_free(DevTable* t);
+uint64_t dev_table_bytes(const DevTable* t);
+DevPlan* dev_plan_upload(const HostPlan& fast, const HostPlan& big);
+void dev_plan_free(DevPlan* p);
+void dev_eval(const DevPlan* p, const DevTable* t, const EvalOptions& opt, EvalOut* out);   // launch + finish; throws std::runtime_error
+void dev_eval_launch(const DevPlan* p, const DevTable* t, const EvalOptions& opt);          // asynchronous on the default stream
+void dev_eval_finish(const DevPlan* p, const DevTable* t, const EvalOptions& opt, EvalOut* out);   // sync, overflow re-run, download
+
+}  // namespace gk

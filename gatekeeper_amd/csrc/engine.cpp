@@ -1,0 +1,501 @@
+// Host engine + C ABI (include/gkgpu.h).  Holds templates, constraints, the path dictionary, the Namespace cache
+// and data.inventory; builds the device plan lazily; flattens reviews into HBM-resident tables; launches the HIP
+// kernels through device.hpp; renders messages for the sparse violating pairs.
+//
+// Mirrors the state a reference drivers.Driver keeps (pkg/drivers/k8scel/driver.go:60-160) plus the target handler
+// pieces that sit on the hot path (pkg/target/target.go:81-179, matcher.go:21-93, ns_cache.go:15-87).
+#include <atomic>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <shared_mutex>
+#include <sstream>
+
+#include "../../include/gkgpu.h"
+#include "device.hpp"
+#include "flatten.hpp"
+#include "lower.hpp"
+#include "pe.hpp"
+
+using namespace gk;
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+std::string lower_str(std::string s) { for (auto& c : s) if (c >= 'A' && c <= 'Z') c += 32; return s; }
+
+struct ConstraintRec {
+  uint32_t id;
+  std::string kind, name;
+  Value object, params, match;
+  FP viol;
+  MatchFormulas mf;
+  bool alive = true;
+};
+
+// ---- host-side matcher: only used to produce the exact autoreject message for pairs the device flagged -----------
+// pkg/mutation/match/match.go:32-258, pkg/target/matcher.go:44-71
+bool wildcard_matches(const std::string& w, const std::string& c) {
+  bool pre = !w.empty() && w.front() == '*', suf = !w.empty() && w.back() == '*';
+  if (pre && suf) { std::string in = w.substr(1); if (!in.empty() && in.back() == '*') in.pop_back(); return c.find(in) != std::string::npos; }
+  if (pre) { std::string s = w.substr(1); return c.size() >= s.size() && c.compare(c.size() - s.size(), s.size(), s) == 0; }
+  if (suf) { std::string p = w.substr(0, w.size() - 1); return c.compare(0, p.size(), p) == 0; }
+  return w == c;
+}
+
+std::string selector_error(const Value& sel) {
+  const Value* me = sel.get("matchExpressions");
+  if (me && me->is_array())
+    for (auto& e : me->items()) {
+      std::string op = obj_string(e, "operator");
+      if (op != "In" && op != "NotIn" && op != "Exists" && op != "DoesNotExist") return "\"" + op + "\" is not a valid label selector operator";
+    }
+  return "";
+}
+
+// error text of match.Matches for one candidate object, "" if none (subset: the error sources of match.go)
+std::string candidate_error(const Value& m, const Value& obj, const Value& ns, int source, bool* matched) {
+  *matched = false;
+  std::string g, v, k;
+  obj_gvk(obj, &g, &v, &k);
+  bool is_ns = k == "Namespace" && g.empty();
+  std::string name = obj_string(obj, "metadata", "name"), nsfield = obj_string(obj, "metadata", "namespace");
+  auto strs = [](const Value* l) { std::vector<std::string> o; if (l && l->is_array()) for (auto& x : l->items()) if (x.is_string()) o.push_back(x.str()); return o; };
+  // kinds
+  const Value* kinds = m.get("kinds");
+  if (kinds && kinds->is_array() && kinds->size()) {
+    bool any = false;
+    for (auto& kk : kinds->items()) {
+      auto ks = strs(kk.get("kinds")), gs = strs(kk.get("apiGroups"));
+      auto has = [](const std::vector<std::string>& l, const std::string& x) { return l.empty() || std::find(l.begin(), l.end(), "*") != l.end() || std::find(l.begin(), l.end(), x) != l.end(); };
+      if (has(ks, k) && has(gs, g)) any = true;
+    }
+    if (!any) return "";
+  }
+  std::string scope = obj_string(m, "scope");
+  bool has_ns = !nsfield.empty() || ns.defined();
+  if (scope == "Cluster" && !(is_ns || !has_ns)) return "";
+  if (scope == "Namespaced" && !(!is_ns && has_ns)) return "";
+  bool has_nsname = true;
+  std::string nsname;
+  if (is_ns) nsname = name; else if (ns.defined()) nsname = obj_string(ns, "metadata", "name"); else if (!nsfield.empty()) nsname = nsfield; else has_nsname = false;
+  auto nss = strs(m.get("namespaces"));
+  if (!nss.empty() && has_nsname) { bool any = false; for (auto& w : nss) if (wildcard_matches(w, nsname)) any = true; if (!any) return ""; }
+  auto ex = strs(m.get("excludedNamespaces"));
+  if (!ex.empty() && has_nsname) for (auto& w : ex) if (wildcard_matches(w, nsname)) return "";
+  const Value* ls = m.get("labelSelector");
+  if (ls && ls->is_object()) { std::string e = selector_error(*ls); if (!e.empty()) return e; }
+  // (label selector truth is decided on the device; for error text we only need to know whether evaluation continues,
+  //  which the device already established by flagging this pair)
+  const Value* nsel = m.get("namespaceSelector");
+  if (nsel && nsel->is_object() && !(!is_ns && !ns.defined() && nsfield.empty())) {
+    std::string e = selector_error(*nsel);
+    if (!e.empty()) return e;
+    if (!is_ns && !ns.defined()) return "namespace selector for namespace-scoped object but missing Namespace";
+  }
+  std::string src = obj_string(m, "source");
+  if (src.empty()) src = "All";
+  if (src != "All" && src != "Original" && src != "Generated") return "invalid source field \"" + src + "\"";
+  if (source == SRC_EMPTY && src != "All") return "source field not specified for resource " + name;
+  if (src != "All" && source == SRC_INVALID) return "invalid source field";
+  *matched = true;
+  return "";
+}
+
+std::string autoreject_message(const Value& match, const ReviewDoc& doc) {
+  const Value* obj = doc.request.get("object");
+  const Value* old = doc.request.get("oldObject");
+  bool any = false;
+  for (const Value* c : {obj, old}) {
+    if (!c || !c->is_object()) continue;
+    any = true;
+    bool matched;
+    std::string e = candidate_error(match, *c, doc.match_ns, doc.source, &matched);
+    if (!e.empty())
+      return "unable to match constraints: error matching the requested object: " + obj_string(*c, "metadata", "name") +
+             " :failed to run Match criteria: " + e;
+    if (matched) break;
+  }
+  if (!any) return "unable to match constraints: invalid request object: neither object nor old object are defined";
+  return "unable to match constraints: error matching the requested object";
+}
+
+}  // namespace
+
+struct gk_engine {
+  gk_opts opts{};
+  PathDict dict;
+  NsCache ns_cache;
+  std::shared_mutex mu;   // templates / constraints / inventory
+  std::map<std::string, std::shared_ptr<Template>> templates;   // lower(kind)
+  std::vector<ConstraintRec> constraints;
+  Value inventory = Value::object({});
+  int next_quant = 0;
+  // plan cache
+  std::mutex plan_mu;
+  bool plan_dirty = true;
+  HostPlan fast, big;
+  DevPlan* dev_plan = nullptr;
+  std::vector<uint32_t> plan_ids;   // bitmap row -> constraint id
+  std::string last_dump;
+};
+
+struct gk_table {
+  gk_engine* eng;
+  DevTable* dev = nullptr;
+  HostTable host;               // rows/heap released after upload unless needed
+  std::vector<ReviewDoc> docs;  // GK_TABLE_KEEP_DOCS
+  std::vector<std::string> review_errors;
+  uint64_t algo_bytes = 0, n_rows = 0;
+  uint32_t n_reviews = 0;
+};
+
+namespace {
+
+Value set_in(const Value& root, const std::vector<std::string>& path, size_t i, const Value* leaf) {
+  // returns a copy of root with path[i..] set to *leaf (or removed when leaf == nullptr)
+  ValuePairs p = root.is_object() ? root.pairs() : ValuePairs{};
+  Value key = Value::string(path[i]);
+  ValuePairs out;
+  bool done = false;
+  for (auto& kv : p) {
+    if (kv.first == key) {
+      done = true;
+      if (i + 1 == path.size()) { if (leaf) out.emplace_back(key, *leaf); }
+      else out.emplace_back(key, set_in(kv.second, path, i + 1, leaf));
+    } else out.push_back(kv);
+  }
+  if (!done && leaf) {
+    if (i + 1 == path.size()) out.emplace_back(key, *leaf);
+    else out.emplace_back(key, set_in(Value::object({}), path, i + 1, leaf));
+  }
+  return Value::object(out);
+}
+
+void ensure_plan(gk_engine* e) {
+  std::lock_guard<std::mutex> l(e->plan_mu);
+  std::shared_lock<std::shared_mutex> rl(e->mu);
+  if (!e->plan_dirty && e->dev_plan && e->fast.dict_size == e->dict.size()) return;
+  if (e->plan_dirty || !e->dev_plan) {
+    PlanBuilder pb(&e->dict);
+    e->plan_ids.clear();
+    for (auto& c : e->constraints) if (c.alive) { pb.add_constraint(c.viol, c.mf); e->plan_ids.push_back(c.id); }
+    PlanCaps caps;
+    for (int i = 0; i < 3; i++) if (e->opts.elem_cap[i]) caps.level_cap[i] = e->opts.elem_cap[i];
+    PlanCaps bigcaps;
+    bigcaps.level_cap[0] = bigcaps.level_cap[1] = bigcaps.level_cap[2] = 256;
+    e->fast = pb.build(caps);
+    e->big = pb.build(bigcaps);
+  } else {
+    e->fast.resolve_paths(e->dict);
+    e->big.resolve_paths(e->dict);
+  }
+  if (e->dev_plan) { dev_plan_free(e->dev_plan); e->dev_plan = nullptr; }
+  e->dev_plan = dev_plan_upload(e->fast, e->big);
+  e->plan_dirty = false;
+}
+
+Value parse_opt(const char* p, size_t n) { return (p && n) ? parse_json(p, n) : Value(); }
+
+}  // namespace
+
+extern "C" {
+
+const char* gk_last_error(void) { return g_err.c_str(); }
+const char* gk_version(void) { return "gkgpu 0.1 (gfx950)"; }
+
+int gk_engine_create(const gk_opts* opts, gk_engine** out) {
+  if (!out) return fail(GK_ERR_INVALID, "out is NULL");
+  int dev = opts ? opts->device : 0;
+  std::string err = dev_init(dev);
+  if (!err.empty()) return fail(GK_ERR_DEVICE, err);
+  gk_engine* e = new gk_engine();
+  if (opts) e->opts = *opts;
+  *out = e;
+  return GK_OK;
+}
+
+void gk_engine_destroy(gk_engine* e) {
+  if (!e) return;
+  if (e->dev_plan) dev_plan_free(e->dev_plan);
+  delete e;
+}
+
+int gk_template_add(gk_engine* e, const char* kind, const char* rego, const char* const* libs, size_t nlibs) {
+  if (!e || !kind || !rego) return fail(GK_ERR_INVALID, "NULL argument");
+  try {
+    std::vector<std::string> ls;
+    for (size_t i = 0; i < nlibs; i++) ls.emplace_back(libs[i]);
+    auto t = std::make_shared<Template>(rego, ls);
+    std::unique_lock<std::shared_mutex> l(e->mu);
+    e->templates[lower_str(kind)] = t;
+    // constraints of this kind must be recompiled against the new template
+    for (auto& c : e->constraints)
+      if (c.alive && lower_str(c.kind) == lower_str(kind)) {
+        try { c.viol = t->compile(c.params, &e->next_quant); } catch (const std::exception&) { c.alive = false; }
+      }
+    e->plan_dirty = true;
+    return GK_OK;
+  } catch (const RegoError& ex) { return fail(GK_ERR_REGO, ex.what());
+  } catch (const Unsupported& ex) { return fail(GK_ERR_UNSUPPORTED, ex.what());
+  } catch (const std::exception& ex) { return fail(GK_ERR_INTERNAL, ex.what()); }
+}
+
+int gk_template_remove(gk_engine* e, const char* kind) {
+  if (!e || !kind) return fail(GK_ERR_INVALID, "NULL argument");
+  std::unique_lock<std::shared_mutex> l(e->mu);
+  std::string k = lower_str(kind);
+  if (!e->templates.erase(k)) return fail(GK_ERR_NOT_FOUND, "unknown template " + k);
+  for (auto& c : e->constraints) if (lower_str(c.kind) == k) c.alive = false;
+  e->plan_dirty = true;
+  return GK_OK;
+}
+
+int gk_constraint_add(gk_engine* e, const char* json, size_t len, uint32_t* id_out) {
+  if (!e || !json) return fail(GK_ERR_INVALID, "NULL argument");
+  try {
+    Value c = parse_json(json, len);
+    if (!c.is_object()) return fail(GK_ERR_INVALID, "constraint must be a JSON object");
+    ConstraintRec rec;
+    rec.kind = obj_string(c, "kind");
+    rec.name = obj_string(c, "metadata", "name");
+    rec.object = c;
+    const Value* spec = c.get("spec");
+    const Value* params = spec ? spec->get("parameters") : nullptr;
+    rec.params = (params && !params->is_null()) ? *params : Value::object({});
+    const Value* match = spec ? spec->get("match") : nullptr;
+    rec.match = (match && match->is_object()) ? *match : Value();
+    std::unique_lock<std::shared_mutex> l(e->mu);
+    auto it = e->templates.find(lower_str(rec.kind));
+    if (it == e->templates.end()) return fail(GK_ERR_NOT_FOUND, "unknown constraint template validator: " + rec.kind);
+    if (it->second->references_inventory())
+      return fail(GK_ERR_UNSUPPORTED, "unsupported on the device plan: template " + rec.kind + " is referential (reads data.inventory)");
+    rec.viol = it->second->compile(rec.params, &e->next_quant);
+    rec.mf = compile_match(rec.match);
+    // validate that it lowers (element scopes, register pressure) before accepting it
+    {
+      PlanBuilder pb(&e->dict);
+      pb.add_constraint(rec.viol, rec.mf);
+      PlanCaps caps;
+      pb.build(caps);
+    }
+    for (auto& o : e->constraints) if (o.alive && o.kind == rec.kind && o.name == rec.name) o.alive = false;   // replace
+    rec.id = (uint32_t)e->constraints.size();
+    e->constraints.push_back(rec);
+    e->plan_dirty = true;
+    if (id_out) *id_out = rec.id;
+    return GK_OK;
+  } catch (const JsonError& ex) { return fail(GK_ERR_INVALID, ex.what());
+  } catch (const RegoError& ex) { return fail(GK_ERR_REGO, ex.what());
+  } catch (const Unsupported& ex) { return fail(GK_ERR_UNSUPPORTED, ex.what());
+  } catch (const std::exception& ex) { return fail(GK_ERR_INTERNAL, ex.what()); }
+}
+
+int gk_constraint_remove(gk_engine* e, const char* kind, const char* name) {
+  if (!e || !kind || !name) return fail(GK_ERR_INVALID, "NULL argument");
+  std::unique_lock<std::shared_mutex> l(e->mu);
+  bool found = false;
+  for (auto& c : e->constraints) if (c.alive && c.kind == kind && c.name == name) { c.alive = false; found = true; }
+  if (!found) return fail(GK_ERR_NOT_FOUND, std::string("unknown constraint ") + kind + "/" + name);
+  e->plan_dirty = true;
+  return GK_OK;
+}
+
+int gk_data_put(gk_engine* e, const char* const* path, size_t npath, const char* json, size_t len) {
+  if (!e || !path || !npath || !json) return fail(GK_ERR_INVALID, "NULL argument");
+  try {
+    Value v = parse_json(json, len);
+    std::vector<std::string> p;
+    for (size_t i = 0; i < npath; i++) p.emplace_back(path[i]);
+    std::unique_lock<std::shared_mutex> l(e->mu);
+    e->inventory = set_in(e->inventory, p, 0, &v);
+    // nsCache.Add: cluster-scoped core/v1 Namespace objects (ns_cache.go:22-43)
+    if (v.is_object() && obj_is_namespace(v) && p.size() == 4 && p[0] == "cluster") e->ns_cache.put(p[3], v);
+    return GK_OK;
+  } catch (const JsonError& ex) { return fail(GK_ERR_INVALID, ex.what()); }
+}
+
+int gk_data_remove(gk_engine* e, const char* const* path, size_t npath) {
+  if (!e || !path || !npath) return fail(GK_ERR_INVALID, "NULL argument");
+  std::vector<std::string> p;
+  for (size_t i = 0; i < npath; i++) p.emplace_back(path[i]);
+  std::unique_lock<std::shared_mutex> l(e->mu);
+  e->inventory = set_in(e->inventory, p, 0, nullptr);
+  if (p.size() == 4 && p[0] == "cluster" && p[1] == "v1" && p[2] == "Namespace") e->ns_cache.remove(p[3]);
+  return GK_OK;
+}
+
+int gk_table_create(gk_engine* e, const gk_review_in* reviews, size_t n, uint32_t flags, int32_t* statuses, gk_table** out) {
+  if (!e || !out || (n && !reviews)) return fail(GK_ERR_INVALID, "NULL argument");
+  try {
+    std::unique_ptr<gk_table> t(new gk_table());
+    t->eng = e;
+    Flattener fl(&e->dict);
+    bool keep = flags & GK_TABLE_KEEP_DOCS;
+    t->review_errors.resize(n);
+    for (size_t i = 0; i < n; i++) {
+      const gk_review_in& r = reviews[i];
+      ReviewDoc doc;
+      int st = GK_OK;
+      try {
+        Value body = parse_json(r.json, r.json_len);
+        Value mns = parse_opt(r.namespace_json, r.namespace_len);
+        Value nso = parse_opt(r.ns_object_json, r.ns_object_len);
+        if (r.kind == GK_REVIEW_OBJECT) doc = normalize_object(body, mns, nso, r.source, r.operation ? r.operation : "", e->ns_cache);
+        else doc = normalize_admission_request(body, mns, nso, r.source, e->ns_cache);
+      } catch (const std::exception& ex) {
+        st = GK_ERR_REVIEW;
+        t->review_errors[i] = ex.what();
+        doc = ReviewDoc();
+        doc.request = Value::object({});
+      }
+      if (statuses) statuses[i] = st;
+      fl.add(doc, &t->host);
+      if (keep) t->docs.push_back(doc);
+    }
+    fl.finish(&t->host);
+    if (t->host.rows.size() >= 0xFFFFFFF0ull || t->host.heap.size() >= 0xFFFFFFF0ull)
+      return fail(GK_ERR_INVALID, "table too large for 32-bit row/heap offsets: split the batch");
+    t->n_reviews = (uint32_t)n;
+    t->n_rows = t->host.rows.size();
+    t->algo_bytes = t->host.algo_bytes();
+    t->dev = dev_table_upload(t->host);
+    t->host.rows.clear(); t->host.rows.shrink_to_fit();
+    t->host.heap.clear(); t->host.heap.shrink_to_fit();
+    *out = t.release();
+    return GK_OK;
+  } catch (const std::exception& ex) { return fail(GK_ERR_DEVICE, ex.what()); }
+}
+
+void gk_table_free(gk_table* t) {
+  if (!t) return;
+  dev_table_free(t->dev);
+  delete t;
+}
+
+struct EvalHolder {
+  gk_eval_out pub;
+  EvalOut out;
+  std::vector<uint32_t> ids;
+};
+
+int gk_table_eval(gk_engine* e, gk_table* t, uint32_t flags, gk_eval_out** out) {
+  if (!e || !t || !out) return fail(GK_ERR_INVALID, "NULL argument");
+  try {
+    ensure_plan(e);
+    std::unique_ptr<EvalHolder> h(new EvalHolder());
+    EvalOptions opt;
+    opt.download = !(flags & GK_EVAL_NO_DOWNLOAD);
+    opt.want_match = flags & GK_EVAL_WANT_MATCH;
+    {
+      std::lock_guard<std::mutex> l(e->plan_mu);
+      h->ids = e->plan_ids;
+      if (flags & GK_EVAL_WANT_LIST) opt.list_capacity = std::max<uint32_t>(1024, t->n_reviews * 4u);
+      if (flags & GK_EVAL_ASYNC) {   // enqueue only; a later call without GK_EVAL_ASYNC collects
+        dev_eval_launch(e->dev_plan, t->dev, opt);
+        *out = nullptr;
+        return GK_OK;
+      }
+      dev_eval(e->dev_plan, t->dev, opt, &h->out);
+    }
+    gk_eval_out& p = h->pub;
+    memset(&p, 0, sizeof p);
+    p.n_reviews = h->out.n_reviews; p.n_constraints = h->out.n_constraints; p.n_tiles = h->out.n_tiles;
+    p.constraint_ids = h->ids.data();
+    p.viol = h->out.viol.data(); p.err = h->out.err.data();
+    p.match = h->out.match.empty() ? nullptr : h->out.match.data();
+    p.too_big = h->out.too_big.data();
+    p.counts = h->out.counts.data();
+    p.list = h->out.list.data(); p.list_len = (uint32_t)(h->out.list.size() / 2); p.list_total = h->out.list_total;
+    p.n_overflow = h->out.n_overflow;
+    p.kernel_ms = h->out.kernel_ms; p.fast_kernel_ms = h->out.fast_kernel_ms; p.n_launches = h->out.n_launches;
+    p.d_viol = h->out.d_viol; p.d_err = h->out.d_err; p.d_counts = h->out.d_counts;
+    p.n_rows = t->n_rows;
+    // algorithmic bytes: rows + headers read once, plan tables read once, bitmaps written once,
+    // 8 B per emitted violation-list entry
+    uint64_t plan_bytes = (uint64_t)e->fast.ptab.size() * 4 + e->fast.pred_list.size() * 4 + e->fast.preds.size() * sizeof(Pred) +
+                          e->fast.code.size() * 4 + e->fast.cheap.size();
+    p.algo_bytes = t->algo_bytes + plan_bytes + (uint64_t)p.n_constraints * p.n_tiles * 16 + (uint64_t)p.list_total * 8;
+    *out = &h.release()->pub;
+    return GK_OK;
+  } catch (const Unsupported& ex) { return fail(GK_ERR_UNSUPPORTED, ex.what());
+  } catch (const std::exception& ex) { return fail(GK_ERR_DEVICE, ex.what()); }
+}
+
+void gk_eval_free(gk_eval_out* o) {
+  if (!o) return;
+  delete reinterpret_cast<EvalHolder*>(o);   // pub is the first member
+}
+
+int gk_render(gk_engine* e, gk_table* t, uint32_t constraint_id, uint32_t review, char** json_out) {
+  if (!e || !t || !json_out) return fail(GK_ERR_INVALID, "NULL argument");
+  if (t->docs.empty()) return fail(GK_ERR_INVALID, "table was created without GK_TABLE_KEEP_DOCS");
+  if (review >= t->docs.size()) return fail(GK_ERR_INVALID, "review index out of range");
+  try {
+    std::shared_lock<std::shared_mutex> l(e->mu);
+    if (constraint_id >= e->constraints.size()) return fail(GK_ERR_NOT_FOUND, "unknown constraint id");
+    const ConstraintRec& c = e->constraints[constraint_id];
+    auto it = e->templates.find(lower_str(c.kind));
+    if (it == e->templates.end()) return fail(GK_ERR_NOT_FOUND, "unknown constraint template validator: " + c.kind);
+    const ReviewDoc& doc = t->docs[review];
+    ValueVec arr;
+    auto vs = it->second->render(doc.request, c.params, e->inventory);
+    for (auto& v : vs) {
+      ValuePairs o{{Value::string("msg"), Value::string(v.msg)}};
+      o.emplace_back(Value::string("details"), v.details.defined() ? v.details : Value::object({}));
+      arr.push_back(Value::object(o));
+    }
+    std::string s = to_json(Value::array(arr));
+    char* buf = (char*)malloc(s.size() + 1);
+    memcpy(buf, s.c_str(), s.size() + 1);
+    *json_out = buf;
+    return GK_OK;
+  } catch (const std::exception& ex) { return fail(GK_ERR_REGO, ex.what()); }
+}
+
+int gk_render_error(gk_engine* e, gk_table* t, uint32_t constraint_id, uint32_t review, char** json_out) {
+  if (!e || !t || !json_out) return fail(GK_ERR_INVALID, "NULL argument");
+  if (review >= t->docs.size()) return fail(GK_ERR_INVALID, "review index out of range (needs GK_TABLE_KEEP_DOCS)");
+  std::shared_lock<std::shared_mutex> l(e->mu);
+  if (constraint_id >= e->constraints.size()) return fail(GK_ERR_NOT_FOUND, "unknown constraint id");
+  std::string msg = autoreject_message(e->constraints[constraint_id].match, t->docs[review]);
+  ValuePairs o{{Value::string("msg"), Value::string(msg)}, {Value::string("autoreject"), Value::boolean(true)}, {Value::string("details"), Value::object({})}};
+  std::string s = to_json(Value::array({Value::object(o)}));
+  char* buf = (char*)malloc(s.size() + 1);
+  memcpy(buf, s.c_str(), s.size() + 1);
+  *json_out = buf;
+  return GK_OK;
+}
+
+void gk_free(void* p) { free(p); }
+
+int gk_dump(gk_engine* e, char** text_out) {
+  if (!e || !text_out) return fail(GK_ERR_INVALID, "NULL argument");
+  try {
+    ensure_plan(e);
+    std::ostringstream os;
+    std::lock_guard<std::mutex> l(e->plan_mu);
+    const HostPlan& p = e->fast;
+    os << "constraints=" << p.dims.n_constraints << " viol_formulas=" << p.n_viol << " match_formulas=" << p.n_match
+       << " preds=" << p.dims.n_preds << " scopes=" << p.dims.n_scopes << " code_words=" << p.dims.n_code
+       << " gwords=" << p.dims.n_gwords << " acc_words=" << p.dims.acc_words << " lds_bytes_per_tile=" << p.dims.acc_words * 256
+       << " paths=" << p.dims.n_paths << "\n";
+    for (size_t i = 0; i < p.preds.size(); i++)
+      os << "pred " << i << " op=" << (int)p.preds[i].op << " dst=" << (int)p.preds[i].dst << " scope=" << (int)p.preds[i].scope
+         << " bit=" << p.preds[i].bit << " " << pattern_to_string(p.pred_patterns[i]) << "\n";
+    {
+      std::shared_lock<std::shared_mutex> rl(e->mu);
+      for (auto& c : e->constraints) if (c.alive) os << "constraint " << c.id << " " << c.kind << "/" << c.name << " viol: " << f_to_string(c.viol) << "\n";
+    }
+    std::string s = os.str();
+    char* buf = (char*)malloc(s.size() + 1);
+    memcpy(buf, s.c_str(), s.size() + 1);
+    *text_out = buf;
+    return GK_OK;
+  } catch (const std::exception& ex) { return fail(GK_ERR_INTERNAL, ex.what()); }
+}
+
+}  // extern "C"

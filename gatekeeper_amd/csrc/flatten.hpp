@@ -1,0 +1,112 @@
+// Review normalisation + flattening (host).
+//
+//  * normalize_*: what K8sValidationTarget.HandleReview does before matching/evaluation
+//      pkg/target/target.go:81-138 (8 input shapes -> gkReview), :140-179 (unstructuredToAdmissionRequest),
+//      :269-287 (setObjectOnDelete, ErrOldObjectIsNil), pkg/target/matcher.go:37-39 (nsCache fallback).
+//  * Flattener: key-path -> value SoA rows (plan.hpp Row) + string heap + per-review header with the match-layer
+//    facts (RF_*) that pkg/mutation/match/match.go:73-258 derives from object/namespace/source.
+#pragma once
+#include <shared_mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "plan.hpp"
+#include "value.hpp"
+
+namespace gk {
+
+// ------------------------------------------------------------------------------------------------ path dictionary
+// Interns wildcarded key paths ("object.spec.containers[].image") to dense ids; exact, append-only, thread-safe.
+class PathDict {
+ public:
+  struct Info {
+    uint32_t parent;
+    std::string key;     // member name; empty for array elements
+    bool is_elem;        // "[]" step
+    uint8_t adepth;      // number of "[]" steps on the path (including this one)
+  };
+  static constexpr uint32_t kNone = 0xFFFFFFFFu;
+
+  PathDict();
+  uint32_t root() const { return 0; }
+  uint32_t child(uint32_t parent, const std::string& key);   // interns
+  uint32_t elem(uint32_t parent);                            // interns the "[]" child
+  uint32_t find_child(uint32_t parent, const std::string& key) const;   // kNone if unknown
+  Info info(uint32_t id) const;
+  uint32_t size() const;
+  std::string to_string(uint32_t id) const;
+
+ private:
+  struct KeyHash { size_t operator()(const std::pair<uint32_t, std::string>& k) const; };
+  mutable std::shared_mutex mu_;
+  std::unordered_map<std::pair<uint32_t, std::string>, uint32_t, KeyHash> map_;
+  std::vector<Info> infos_;
+  uint32_t intern(uint32_t parent, const std::string& key, bool is_elem);
+};
+
+uint32_t hash32(const uint8_t* p, size_t n);
+inline uint32_t hash32(const std::string& s) { return hash32((const uint8_t*)s.data(), s.size()); }
+
+// ------------------------------------------------------------------------------------------------ reviews
+enum SourceType : int { SRC_EMPTY = 0, SRC_ORIGINAL = 1, SRC_GENERATED = 2, SRC_ALL = 3, SRC_INVALID = 4 };
+
+struct ReviewDoc {
+  Value request;        // canonical input.review object (AdmissionRequest JSON incl. namespaceObject when provided)
+  Value match_ns;       // Matchable.Namespace (Undefined = nil)
+  int source = SRC_EMPTY;
+};
+
+struct ReviewError : std::runtime_error { using std::runtime_error::runtime_error; };
+
+class NsCache {   // pkg/target/ns_cache.go:15-87
+ public:
+  void put(const std::string& name, const Value& ns);
+  void remove(const std::string& name);
+  Value get(const std::string& name) const;   // Undefined if absent
+ private:
+  mutable std::shared_mutex mu_;
+  std::unordered_map<std::string, Value> m_;
+};
+
+// AdmissionRequest JSON (+ gkReview.namespace, + reviews.Namespace option) -> ReviewDoc. Throws ReviewError.
+ReviewDoc normalize_admission_request(const Value& request, const Value& match_ns, const Value& ns_object, int source,
+                                      const NsCache& cache);
+// Unstructured / AugmentedUnstructured -> ReviewDoc (target.go:140-179).
+ReviewDoc normalize_object(const Value& object, const Value& match_ns, const Value& ns_object, int source,
+                           const std::string& operation, const NsCache& cache);
+
+// unstructured accessors shared with the host matcher / renderer
+std::string obj_string(const Value& obj, const char* a, const char* b = nullptr);
+void obj_gvk(const Value& obj, std::string* group, std::string* version, std::string* kind);
+bool obj_is_namespace(const Value& obj);
+
+struct HostTable {
+  std::vector<Row> rows;
+  std::vector<ReviewHdr> hdrs;   // n + 1 entries
+  std::vector<uint8_t> heap;
+  uint32_t n_reviews = 0;
+  uint64_t algo_bytes() const { return rows.size() * sizeof(Row) + hdrs.size() * sizeof(ReviewHdr); }
+};
+
+class Flattener {
+ public:
+  explicit Flattener(PathDict* dict);
+  void add(const ReviewDoc& doc, HostTable* out);
+  void finish(HostTable* out);   // appends the sentinel header
+
+ private:
+  PathDict* dict_;
+  uint32_t id_object_, id_old_, id_m_, id_ns_;
+  struct Ctr { uint32_t path, n; };
+  std::vector<Ctr> ctrs_;
+  HostTable* t_ = nullptr;
+  uint32_t review_flags_ = 0;
+  void walk(const Value& v, uint32_t path, uint32_t meta_ords, int adepth, uint32_t extra);
+  void emit(uint32_t path, uint32_t meta, uint32_t lo, uint32_t hi);
+  uint32_t put_string(const std::string& s, uint32_t* hash);
+  void emit_str(uint32_t parent, const char* key, const std::string& s);
+  void match_facts(const Value& obj, const Value& ns, bool is_old, uint32_t m_parent);
+};
+
+}  // namespace gk

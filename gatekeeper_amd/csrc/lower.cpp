@@ -1,0 +1,746 @@
+// See lower.hpp.
+#include "lower.hpp"
+
+#include <functional>
+#include <regex>
+#include <set>
+
+namespace gk {
+
+// ================================================================================================ match blocks
+namespace {
+
+Step key_step(const std::string& k) { Step s; s.key = k; return s; }
+SPath mk_path(std::initializer_list<const char*> keys) { SPath p; for (auto k : keys) p.push_back(key_step(k)); return p; }
+
+int ctz32(uint32_t x) { int n = 0; while (!(x & 1)) { x >>= 1; n++; } return n; }
+FP flag_f(uint32_t mask) { Atom a; a.kind = Atom::FLAG; a.flag = (uint32_t)ctz32(mask); return f_atom(a); }
+
+FP atom_k(Atom::Kind kind, const SPath& p, const Value& k, int cmp = C_EQ) {
+  Atom a; a.kind = kind; a.path = p; a.k = k; a.cmp = cmp;
+  return f_atom(a);
+}
+
+// pkg/wildcard/wildcard.go:17-41
+FP glob_f(const SPath& p, const std::string& w, bool generate_name) {
+  bool pre = !w.empty() && w.front() == '*', suf = !w.empty() && w.back() == '*';
+  if (pre && suf) {
+    std::string inner = w.substr(1);
+    if (!inner.empty() && inner.back() == '*') inner.pop_back();
+    return atom_k(Atom::STR_CONTAINS, p, Value::string(inner));
+  }
+  if (pre) return generate_name ? f_false() : atom_k(Atom::STR_SUFFIX, p, Value::string(w.substr(1)));
+  if (suf) return atom_k(Atom::STR_PREFIX, p, Value::string(w.substr(0, w.size() - 1)));
+  return generate_name ? f_false() : atom_k(Atom::CMP, p, Value::string(w), C_EQ);
+}
+
+// apimachinery validation.IsQualifiedName / IsValidLabelValue (k8s.io/apimachinery v0.36.3, third-party)
+bool valid_label_key(const std::string& k) {
+  static const std::regex name_re("^([A-Za-z0-9][-A-Za-z0-9_.]*)?[A-Za-z0-9]$");
+  static const std::regex sub_re("^[a-z0-9]([-a-z0-9]*[a-z0-9])?(\\.[a-z0-9]([-a-z0-9]*[a-z0-9])?)*$");
+  size_t n = std::count(k.begin(), k.end(), '/');
+  std::string name = k;
+  if (n == 1) {
+    std::string prefix = k.substr(0, k.find('/'));
+    name = k.substr(k.find('/') + 1);
+    if (prefix.empty() || prefix.size() > 253 || !std::regex_match(prefix, sub_re)) return false;
+  } else if (n > 1) return false;
+  return !name.empty() && name.size() <= 63 && std::regex_match(name, name_re);
+}
+bool valid_label_value(const std::string& v) {
+  static const std::regex re("^(([A-Za-z0-9][-A-Za-z0-9_.]*)?[A-Za-z0-9])?$");
+  return v.size() <= 63 && std::regex_match(v, re);
+}
+
+struct Req { std::string key; int op; std::vector<std::string> vals; };   // op: 0 In/Equals, 1 NotIn, 2 Exists, 3 DoesNotExist
+
+// metav1.LabelSelectorAsSelector: false => conversion error; *everything => empty selector
+bool selector_reqs(const Value& sel, std::vector<Req>* reqs, bool* everything) {
+  *everything = false;
+  const Value* ml = sel.get("matchLabels");
+  const Value* me = sel.get("matchExpressions");
+  size_t n = (ml && ml->is_object() ? ml->size() : 0) + (me && me->is_array() ? me->size() : 0);
+  if (n == 0) { *everything = true; return true; }
+  if (ml && ml->is_object())
+    for (auto& kv : ml->pairs()) {
+      if (!kv.first.is_string() || !kv.second.is_string()) return false;
+      if (!valid_label_key(kv.first.str()) || !valid_label_value(kv.second.str())) return false;
+      reqs->push_back({kv.first.str(), 0, {kv.second.str()}});
+    }
+  if (me && me->is_array())
+    for (auto& e : me->items()) {
+      std::string op = obj_string(e, "operator"), key = obj_string(e, "key");
+      int o = op == "In" ? 0 : op == "NotIn" ? 1 : op == "Exists" ? 2 : op == "DoesNotExist" ? 3 : -1;
+      if (o < 0 || !valid_label_key(key)) return false;
+      std::vector<std::string> vals;
+      const Value* vs = e.get("values");
+      if (vs && vs->is_array()) for (auto& v : vs->items()) { if (!v.is_string() || !valid_label_value(v.str())) return false; vals.push_back(v.str()); }
+      if (o <= 1 && vals.empty()) return false;
+      if (o >= 2 && !vals.empty()) return false;
+      reqs->push_back({key, o, vals});
+    }
+  return true;
+}
+
+FP selector_f(const std::vector<Req>& reqs, const SPath& labels, uint32_t bad_flag) {
+  FP nb = f_not(flag_f(bad_flag));
+  FP r = f_true();
+  for (const Req& q : reqs) {
+    SPath p = labels;
+    p.push_back(key_step(q.key));
+    ValueVec vals;
+    for (auto& v : q.vals) vals.push_back(Value::string(v));
+    FP in = f_and(atom_k(Atom::STR_IN_SET, p, Value::set(vals)), nb);
+    Atom d; d.kind = Atom::DEFINED; d.path = p;
+    FP has = f_and(f_atom(d), nb);
+    switch (q.op) {
+      case 0: r = f_and(r, in); break;
+      case 1: r = f_and(r, f_not(in)); break;
+      case 2: r = f_and(r, has); break;
+      default: r = f_and(r, f_not(has)); break;
+    }
+  }
+  return r;
+}
+
+std::vector<std::string> str_list(const Value* v) {
+  std::vector<std::string> out;
+  if (v && v->is_array()) for (auto& x : v->items()) if (x.is_string()) out.push_back(x.str());
+  return out;
+}
+
+struct CandFlags { uint32_t has, is_ns, has_nsfield, has_nsname, labels_bad; const char* m; const char* obj; };
+
+void match_candidate(const Value& m, const CandFlags& c, FP* out_match, FP* out_err) {
+  FP p = f_true(), err = f_false();
+  FP is_ns = flag_f(c.is_ns), ns_present = flag_f(RF_NS_PRESENT), has_nsfield = flag_f(c.has_nsfield);
+  // 1. kinds (match.go:181-201)
+  const Value* kinds = m.get("kinds");
+  if (kinds && kinds->is_array() && kinds->size() > 0) {
+    FP any = f_false();
+    for (auto& kk : kinds->items()) {
+      std::vector<std::string> ks = str_list(kk.get("kinds")), gs = str_list(kk.get("apiGroups"));
+      auto member = [&](const std::vector<std::string>& l, const char* field) -> FP {
+        if (l.empty()) return f_true();
+        for (auto& x : l) if (x == "*") return f_true();
+        ValueVec vals;
+        for (auto& x : l) vals.push_back(Value::string(x));
+        return atom_k(Atom::STR_IN_SET, mk_path({"$m", c.m, field}), Value::set(vals));
+      };
+      any = f_or(any, f_and(member(ks, "kind"), member(gs, "group")));
+    }
+    p = f_and(p, any);
+  }
+  // 2. scope (match.go:214-227)
+  std::string scope = obj_string(m, "scope");
+  FP has_ns = f_or(has_nsfield, ns_present);
+  if (scope == "Cluster") p = f_and(p, f_or(is_ns, f_not(has_ns)));
+  else if (scope == "Namespaced") p = f_and(p, f_and(f_not(is_ns), has_ns));
+  // 3/4. namespaces, excludedNamespaces (match.go:118-179)
+  SPath nsname = mk_path({"$m", c.m, "nsname"});
+  FP no_nsname = f_not(flag_f(c.has_nsname));
+  std::vector<std::string> nss = str_list(m.get("namespaces"));
+  if (!nss.empty()) {
+    FP any = f_false();
+    for (auto& w : nss) any = f_or(any, glob_f(nsname, w, false));
+    p = f_and(p, f_or(no_nsname, any));
+  }
+  std::vector<std::string> ex = str_list(m.get("excludedNamespaces"));
+  if (!ex.empty()) {
+    FP any = f_false();
+    for (auto& w : ex) any = f_or(any, glob_f(nsname, w, false));
+    p = f_and(p, f_or(no_nsname, f_not(any)));
+  }
+  // 5. labelSelector (match.go:103-116)
+  const Value* ls = m.get("labelSelector");
+  if (ls && ls->is_object()) {
+    std::vector<Req> reqs;
+    bool everything;
+    if (!selector_reqs(*ls, &reqs, &everything)) { err = f_or(err, p); p = f_false(); }
+    else if (!everything) p = f_and(p, selector_f(reqs, mk_path({c.obj, "metadata", "labels"}), c.labels_bad));
+  }
+  // 6. namespaceSelector (match.go:73-101)
+  const Value* nsel = m.get("namespaceSelector");
+  if (nsel && nsel->is_object()) {
+    FP cluster_scoped = f_and(f_not(is_ns), f_and(f_not(ns_present), f_not(has_nsfield)));
+    std::vector<Req> reqs;
+    bool everything;
+    if (!selector_reqs(*nsel, &reqs, &everything)) {
+      err = f_or(err, f_and(p, f_not(cluster_scoped)));
+      p = f_and(p, cluster_scoped);
+    } else {
+      FP missing = f_and(f_not(is_ns), f_and(f_not(ns_present), has_nsfield));   // ns-scoped but no Namespace
+      err = f_or(err, f_and(p, missing));
+      FP own = everything ? f_true() : selector_f(reqs, mk_path({c.obj, "metadata", "labels"}), c.labels_bad);
+      FP nsl = everything ? f_true() : selector_f(reqs, mk_path({"$ns", "metadata", "labels"}), RF_NS_LABELS_BAD);
+      FP ok = f_or(cluster_scoped, f_or(f_and(is_ns, own), f_and(f_and(f_not(is_ns), ns_present), nsl)));
+      p = f_and(p, ok);
+    }
+  }
+  // 7. name (match.go:203-212)
+  std::string name = obj_string(m, "name");
+  if (!name.empty())
+    p = f_and(p, f_or(glob_f(mk_path({"$m", c.m, "name"}), name, false), glob_f(mk_path({"$m", c.m, "gname"}), name, true)));
+  // 8. source (match.go:229-253)
+  std::string src = obj_string(m, "source");
+  if (src.empty()) src = "All";
+  if (src != "All" && src != "Original" && src != "Generated") { err = f_or(err, p); p = f_false(); }
+  else if (src != "All") {
+    FP empty = f_and(f_and(f_not(flag_f(RF_SRC_ORIGINAL)), f_not(flag_f(RF_SRC_GENERATED))), f_and(f_not(flag_f(RF_SRC_ALL)), f_not(flag_f(RF_SRC_INVALID))));
+    err = f_or(err, f_and(p, f_or(empty, flag_f(RF_SRC_INVALID))));
+    p = f_and(p, flag_f(src == "Original" ? RF_SRC_ORIGINAL : RF_SRC_GENERATED));
+  }
+  FP has = flag_f(c.has);
+  *out_match = f_and(has, p);
+  *out_err = f_and(has, err);
+}
+
+}  // namespace
+
+MatchFormulas compile_match(const Value& m) {
+  if (!m.defined() || !m.is_object()) return {f_true(), f_false()};
+  CandFlags o{RF_HAS_OBJ, RF_OBJ_IS_NS, RF_OBJ_HAS_NSFIELD, RF_OBJ_HAS_NSNAME, RF_OBJ_LABELS_BAD, "o", "object"};
+  CandFlags old{RF_HAS_OLD, RF_OLD_IS_NS, RF_OLD_HAS_NSFIELD, RF_OLD_HAS_NSNAME, RF_OLD_LABELS_BAD, "old", "oldObject"};
+  FP mo, eo, mold, eold;
+  match_candidate(m, o, &mo, &eo);
+  match_candidate(m, old, &mold, &eold);
+  FP none = f_and(f_not(flag_f(RF_HAS_OBJ)), f_not(flag_f(RF_HAS_OLD)));
+  MatchFormulas r;
+  r.match = f_or(mo, f_and(f_not(eo), mold));
+  r.error = f_or(f_or(eo, f_and(f_and(f_not(mo), f_not(eo)), eold)), none);
+  return r;
+}
+
+// ================================================================================================ lowering
+std::string pattern_to_string(const Pattern& p) {
+  std::string o = "review";
+  for (const PatStep& s : p) {
+    if (!s.any) { o += "." + s.key; continue; }
+    o += s.elems_only ? "[]" : "[*";
+    for (auto& k : s.only) o += "=" + k;
+    for (auto& k : s.except) o += "!" + k;
+    if (!s.elems_only) o += "]";
+  }
+  return o;
+}
+
+namespace {
+
+void conjuncts(const FP& f, std::vector<FP>& out) {
+  if (f->kind == FNode::AND) { for (auto& k : f->kids) conjuncts(k, out); }
+  else if (f->kind != FNode::T) out.push_back(f);
+}
+
+bool is_prefix(const SPath& a, const SPath& b) {   // a is a (non-strict) prefix of b
+  if (a.size() > b.size()) return false;
+  for (size_t i = 0; i < a.size(); i++) {
+    if (a[i].iter != b[i].iter) return false;
+    if (a[i].iter ? a[i].q != b[i].q : a[i].key != b[i].key) return false;
+  }
+  return true;
+}
+
+bool path_mentions(const SPath& p, int q) { for (auto& s : p) if (s.iter && s.q == q) return true; return false; }
+bool mentions_q(const FP& f, int q) {
+  switch (f->kind) {
+    case FNode::T: case FNode::F: return false;
+    case FNode::ATOM: return f->atom.q == q || path_mentions(f->atom.path, q) || path_mentions(f->atom.path2, q);
+    case FNode::EXISTS: if (path_mentions(f->base, q)) return true;   // fallthrough to kids
+    default: for (auto& k : f->kids) if (mentions_q(k, q)) return true; return false;
+  }
+}
+
+FP simplify(const FP& f) {
+  switch (f->kind) {
+    case FNode::AND: {
+      std::vector<FP> flat;
+      for (auto& k : f->kids) conjuncts(simplify(k), flat);
+      // dedupe
+      std::vector<FP> uniq;
+      std::set<std::string> seen;
+      for (auto& k : flat) { if (k->kind == FNode::F) return f_false(); if (seen.insert(f_to_string(k)).second) uniq.push_back(k); }
+      // drop DEFINED(p) implied by another positive conjunct on p or below p
+      std::vector<FP> keep;
+      for (size_t i = 0; i < uniq.size(); i++) {
+        const FP& k = uniq[i];
+        bool implied = false;
+        if (k->kind == FNode::ATOM && k->atom.kind == Atom::DEFINED) {
+          for (size_t j = 0; j < uniq.size() && !implied; j++) {
+            if (j == i) continue;
+            const FP& o = uniq[j];
+            if (o->kind == FNode::ATOM && o->atom.kind != Atom::KEYCMP && o->atom.kind != Atom::FLAG) {
+              if (o->atom.kind == Atom::DEFINED && o->atom.path.size() == k->atom.path.size() && j > i) continue;
+              if (is_prefix(k->atom.path, o->atom.path)) implied = true;
+              if (o->atom.kind == Atom::VEQ && is_prefix(k->atom.path, o->atom.path2)) implied = true;
+            } else if (o->kind == FNode::EXISTS && is_prefix(k->atom.path, o->base)) implied = true;
+          }
+        }
+        if (!implied) keep.push_back(k);
+      }
+      return f_all(keep);
+    }
+    case FNode::OR: {
+      std::vector<FP> uniq;
+      std::set<std::string> seen;
+      for (auto& k : f->kids) { FP s = simplify(k); if (s->kind == FNode::T) return f_true(); if (s->kind != FNode::F && seen.insert(f_to_string(s)).second) uniq.push_back(s); }
+      return f_any(uniq);
+    }
+    case FNode::NOT: return f_not(simplify(f->kids[0]));
+    case FNode::EXISTS: {
+      // hoist conjuncts that do not depend on q:   E q. (A(q) & G)  ==  (E q. A(q)) & G
+      FP body = simplify(f->kids[0]);
+      std::vector<FP> conj, dep, indep;
+      conjuncts(body, conj);
+      for (auto& c : conj) (mentions_q(c, f->q) ? dep : indep).push_back(c);
+      if (indep.empty()) return f_exists(f->q, f->base, body);
+      FP inner = f_exists(f->q, f->base, f_all(dep));
+      return simplify(f_and(inner, f_all(indep)));
+    }
+    default: return f;
+  }
+}
+
+struct Lowerer {
+  PathDict* dict;
+  HostPlan plan;
+  PlanCaps caps;
+  std::map<std::string, uint32_t> global_bits;            // canonical pred key -> global bit
+  std::map<std::string, uint32_t> scope_ids;              // element pattern -> scope
+  std::vector<Pattern> scope_patterns;
+  std::vector<int> scope_level;
+  std::vector<std::map<std::string, uint32_t>> elem_bits;  // per scope
+  std::vector<std::map<std::string, uint32_t>> val_slots;  // per scope
+  std::vector<uint32_t> scope_nbits;
+  uint32_t n_gbits = 1;                                    // bit 0 = overflow
+  uint64_t regs_used = 0;
+  std::map<int, uint32_t> looped;                          // quantifier -> scope
+  std::set<int> pass;                                      // pass-through quantifiers
+  std::map<int, PatStep> wild;                             // wildcard quantifiers (global existentials)
+  std::map<std::string, uint32_t> cheap_strings;
+
+  [[noreturn]] void unsupported(const std::string& what) { throw Unsupported("unsupported on the device plan: " + what); }
+
+  int alloc() {
+    for (int i = 0; i < 64; i++) if (!(regs_used >> i & 1)) { regs_used |= 1ull << i; return i; }
+    unsupported("formula needs more than 64 boolean registers");
+  }
+  void release(int r) { regs_used &= ~(1ull << r); }
+  void emit(uint32_t w) { plan.code.push_back(w); }
+
+  uint32_t put_bytes(const std::string& s) {
+    auto it = cheap_strings.find(s);
+    if (it != cheap_strings.end()) return it->second;
+    uint32_t off = (uint32_t)plan.cheap.size();
+    plan.cheap.insert(plan.cheap.end(), s.begin(), s.end());
+    while (plan.cheap.size() & 3) plan.cheap.push_back(0);
+    cheap_strings[s] = off;
+    return off;
+  }
+  void put_u32(uint32_t v) { for (int i = 0; i < 4; i++) plan.cheap.push_back((uint8_t)(v >> (8 * i))); }
+
+  Pattern pattern_of(const SPath& p) {
+    Pattern out;
+    for (const Step& s : p) {
+      PatStep ps;
+      if (!s.iter) { ps.key = s.key; out.push_back(ps); continue; }
+      ps.any = true;
+      if (looped.count(s.q) || pass.count(s.q)) ps.elems_only = true;
+      else {
+        auto it = wild.find(s.q);
+        if (it == wild.end()) unsupported("free quantifier in a predicate path");
+        ps.only = it->second.only;
+        ps.except = it->second.except;
+      }
+      out.push_back(ps);
+    }
+    return out;
+  }
+
+  std::string atom_key(const Atom& a, const Pattern& pat) {
+    return std::to_string((int)a.kind) + "|" + pattern_to_string(pat) + "|" + std::to_string(a.cmp) + "|" + to_term_string(a.k) + "|" +
+           std::to_string(a.mask) + "|" + std::to_string((int)a.cut) + "|" + std::to_string((int)a.sep) + "|" + std::to_string(a.idx);
+  }
+
+  Pred make_pred(const Atom& a) {
+    Pred p{};
+    p.cmp = (uint8_t)a.cmp;
+    auto put_const_string = [&](const Value& v) { p.a = put_bytes(v.str()); p.b = (uint32_t)v.str().size(); p.k = hash32(v.str()); };
+    switch (a.kind) {
+      case Atom::DEFINED: p.op = P_DEFINED; break;
+      case Atom::TRUTHY: p.op = P_TRUTHY; break;
+      case Atom::TYPE: p.op = P_TYPE; p.ctype = (uint8_t)a.mask; break;
+      case Atom::CMP:
+        p.op = P_CMP;
+        switch (a.k.kind) {
+          case Value::Null: p.ctype = T_NULL; break;
+          case Value::Bool: p.ctype = T_BOOL; p.k = a.k.b ? 1 : 0; break;
+          case Value::Number:
+            if (a.k.is_int && a.k.i >= (i128)INT64_MIN && a.k.i <= (i128)INT64_MAX) { p.ctype = T_INT; p.k = (uint64_t)(int64_t)a.k.i; }
+            else { p.ctype = T_FLOAT; double d = a.k.as_double(); memcpy(&p.k, &d, 8); }
+            break;
+          case Value::String: p.ctype = T_STRING; put_const_string(a.k); break;
+          default: unsupported("comparison with a composite constant");
+        }
+        break;
+      case Atom::STR_PREFIX: p.op = P_STR_PREFIX; put_const_string(a.k); break;
+      case Atom::STR_SUFFIX: p.op = P_STR_SUFFIX; put_const_string(a.k); break;
+      case Atom::STR_CONTAINS: p.op = P_STR_CONTAINS; put_const_string(a.k); break;
+      case Atom::STR_IN_SET: {
+        p.op = P_STR_IN_SET;
+        std::vector<std::pair<uint32_t, uint32_t>> ents;
+        for (auto& v : a.k.items()) ents.emplace_back(put_bytes(v.str()), (uint32_t)v.str().size());
+        while (plan.cheap.size() & 3) plan.cheap.push_back(0);
+        p.a = (uint32_t)plan.cheap.size();
+        p.b = (uint32_t)ents.size();
+        size_t i = 0;
+        for (auto& v : a.k.items()) { put_u32(hash32(v.str())); put_u32(ents[i].first); put_u32(ents[i].second); i++; }
+        break;
+      }
+      case Atom::SPLIT_CMP:
+        p.op = P_SPLIT_CMP; put_const_string(a.k); p.idx = a.idx; p.pad = ((uint32_t)(uint8_t)a.cut << 8) | (uint8_t)a.sep;
+        break;
+      case Atom::SPLIT_COUNT:
+        p.op = P_SPLIT_COUNT; p.k = (uint64_t)(int64_t)a.k.i; p.pad = ((uint32_t)(uint8_t)a.cut << 8) | (uint8_t)a.sep;
+        break;
+      case Atom::COUNT_CMP: p.op = P_COUNT_CMP; p.k = (uint64_t)(int64_t)a.k.i; break;
+      default: unsupported("predicate kind");
+    }
+    return p;
+  }
+
+  uint32_t scope_for(const SPath& elem_path) {
+    Pattern pat = pattern_of(elem_path);
+    for (auto& s : pat) if (s.any && !s.elems_only) unsupported("correlated iteration below an object-key iteration");
+    std::string key = pattern_to_string(pat);
+    auto it = scope_ids.find(key);
+    if (it != scope_ids.end()) return it->second;
+    int level = -1;
+    for (auto& s : pat) if (s.any) level++;
+    if (level > 2) unsupported("correlated iteration nested deeper than 3 arrays");
+    if (scope_patterns.size() >= GK_MAX_SCOPES) unsupported("too many element scopes");
+    uint32_t id = (uint32_t)scope_patterns.size();
+    scope_ids[key] = id;
+    scope_patterns.push_back(pat);
+    scope_level.push_back(level);
+    elem_bits.emplace_back();
+    val_slots.emplace_back();
+    scope_nbits.push_back(1);
+    Pred p{};
+    p.op = P_PRESENT; p.dst = D_ELEM; p.scope = (uint8_t)id; p.level = (uint8_t)level;
+    plan.preds.push_back(p);
+    plan.pred_patterns.push_back(pat);
+    return id;
+  }
+
+  // innermost looped quantifier of a path: index of its ITER step, or -1
+  int last_looped(const SPath& p) {
+    for (int i = (int)p.size() - 1; i >= 0; i--) if (p[i].iter && looped.count(p[i].q)) return i;
+    return -1;
+  }
+
+  int lower_atom(const Atom& a) {
+    int r = alloc();
+    if (a.kind == Atom::FLAG) { emit(finst(F_LDF, r, a.flag)); return r; }
+    if (a.kind == Atom::KEYCMP) unsupported("key comparison outside a simple existential");
+    if (a.kind == Atom::VEQ) {
+      uint32_t sc[2], slot[2];
+      const SPath* ps[2] = {&a.path, &a.path2};
+      for (int k = 0; k < 2; k++) {
+        int li = last_looped(*ps[k]);
+        if (li < 0) unsupported("equality between two review values outside an iteration");
+        for (size_t j = li + 1; j < ps[k]->size(); j++) if ((*ps[k])[j].iter) unsupported("join on a nested iteration");
+        sc[k] = looped[(*ps[k])[li].q];
+        Pattern pat = pattern_of(*ps[k]);
+        std::string key = pattern_to_string(pat);
+        auto it = val_slots[sc[k]].find(key);
+        if (it == val_slots[sc[k]].end()) {
+          slot[k] = (uint32_t)val_slots[sc[k]].size();
+          val_slots[sc[k]][key] = slot[k];
+          Pred p{};
+          p.op = P_STORE; p.dst = D_ELEM; p.scope = (uint8_t)sc[k]; p.level = (uint8_t)scope_level[sc[k]]; p.bit = (uint16_t)slot[k];
+          plan.preds.push_back(p);
+          plan.pred_patterns.push_back(pat);
+        } else slot[k] = it->second;
+      }
+      emit(finst(F_VEQ, r));
+      emit(sc[0] | (slot[0] << 8) | (sc[1] << 16) | (slot[1] << 24));
+      return r;
+    }
+    Pattern pat = pattern_of(a.path);
+    std::string key = atom_key(a, pat);
+    int li = last_looped(a.path);
+    if (li < 0) {
+      auto it = global_bits.find(key);
+      uint32_t bit;
+      if (it == global_bits.end()) {
+        bit = n_gbits++;
+        global_bits[key] = bit;
+        Pred p = make_pred(a);
+        p.dst = D_GLOBAL; p.bit = (uint16_t)bit;
+        plan.preds.push_back(p);
+        plan.pred_patterns.push_back(pat);
+      } else bit = it->second;
+      if (bit > 0xFFFF) unsupported("too many global predicates");
+      emit(finst(F_LDG, r, bit & 0xFF, bit >> 8));
+      return r;
+    }
+    uint32_t sc = looped[a.path[li].q];
+    auto it = elem_bits[sc].find(key);
+    uint32_t bit;
+    if (it == elem_bits[sc].end()) {
+      bit = scope_nbits[sc]++;
+      if (bit >= 24 + 3 * 32) unsupported("too many predicates on one element scope");
+      elem_bits[sc][key] = bit;
+      Pred p = make_pred(a);
+      p.dst = D_ELEM; p.scope = (uint8_t)sc; p.level = (uint8_t)scope_level[sc]; p.bit = (uint16_t)bit;
+      plan.preds.push_back(p);
+      plan.pred_patterns.push_back(pat);
+    } else bit = it->second;
+    emit(finst(F_LDE, r, sc, bit));
+    return r;
+  }
+
+  static bool path_has_q(const SPath& p, int q) { for (auto& s : p) if (s.iter && s.q == q) return true; return false; }
+
+  // key constraints of quantifier q expressed by conjunct f; returns false if f is not such a constraint
+  bool key_constraint(const FP& f, int q, PatStep* ps) {
+    if (f->kind == FNode::ATOM && f->atom.kind == Atom::KEYCMP && f->atom.q == q && f->atom.k.is_string()) {
+      if (f->atom.cmp == C_EQ) ps->only.push_back(f->atom.k.str()); else ps->except.push_back(f->atom.k.str());
+      return true;
+    }
+    if (f->kind == FNode::NOT) {
+      const FP& in = f->kids[0];
+      std::vector<FP> alts;
+      if (in->kind == FNode::OR) alts = in->kids; else alts.push_back(in);
+      for (auto& x : alts) if (!(x->kind == FNode::ATOM && x->atom.kind == Atom::KEYCMP && x->atom.q == q && x->atom.cmp == C_EQ && x->atom.k.is_string())) return false;
+      for (auto& x : alts) ps->except.push_back(x->atom.k.str());
+      return true;
+    }
+    if (f->kind == FNode::OR) {   // key == a | key == b
+      for (auto& x : f->kids) if (!(x->kind == FNode::ATOM && x->atom.kind == Atom::KEYCMP && x->atom.q == q && x->atom.cmp == C_EQ && x->atom.k.is_string())) return false;
+      if (!ps->only.empty()) return false;
+      for (auto& x : f->kids) ps->only.push_back(x->atom.k.str());
+      return true;
+    }
+    return false;
+  }
+
+  // EXISTS chain that reduces to one wildcard predicate
+  bool try_flat(const FP& f, std::vector<std::pair<int, PatStep>>& wilds, Atom* out) {
+    int q = f->q;
+    std::vector<FP> conj;
+    conjuncts(f->kids[0], conj);
+    PatStep ps;
+    ps.any = true;
+    std::vector<FP> rest;
+    for (auto& c : conj) if (!key_constraint(c, q, &ps)) rest.push_back(c);
+    if (rest.size() > 1) return false;
+    wilds.emplace_back(q, ps);
+    if (rest.empty()) {
+      out->kind = Atom::DEFINED;
+      out->path = f->base;
+      Step st; st.iter = true; st.q = q;
+      out->path.push_back(st);
+      return true;
+    }
+    const FP& r0 = rest[0];
+    if (r0->kind == FNode::ATOM) {
+      const Atom& a = r0->atom;
+      if (a.kind == Atom::KEYCMP || a.kind == Atom::FLAG || a.kind == Atom::VEQ) return false;
+      if (!path_has_q(a.path, q)) return false;
+      *out = a;
+      return true;
+    }
+    if (r0->kind == FNode::EXISTS) {
+      if (!try_flat(r0, wilds, out)) return false;
+      return path_has_q(out->path, q);
+    }
+    return false;
+  }
+
+  bool uses_elem_directly(const FP& f, int q) {
+    switch (f->kind) {
+      case FNode::ATOM: {
+        auto last_iter = [](const SPath& p) { for (int i = (int)p.size() - 1; i >= 0; i--) if (p[i].iter) return p[i].q; return -1; };
+        if (f->atom.kind == Atom::KEYCMP) return f->atom.q == q;
+        if (last_iter(f->atom.path) == q) return true;
+        if (f->atom.kind == Atom::VEQ && last_iter(f->atom.path2) == q) return true;
+        return false;
+      }
+      case FNode::T: case FNode::F: return false;
+      default:
+        for (auto& k : f->kids) if (uses_elem_directly(k, q)) return true;
+        return false;
+    }
+  }
+
+  int lower_exists(const FP& f) {
+    int q = f->q;
+    {
+      std::vector<std::pair<int, PatStep>> wilds;
+      Atom flat;
+      if (try_flat(f, wilds, &flat)) {
+        bool ok = true;
+        for (auto& s : flat.path) if (s.iter && !looped.count(s.q) && !pass.count(s.q)) { bool w = false; for (auto& x : wilds) if (x.first == s.q) w = true; if (!w) ok = false; }
+        if (ok) {
+          for (auto& w : wilds) wild[w.first] = w.second;
+          int r = lower_atom(flat);
+          for (auto& w : wilds) wild.erase(w.first);
+          return r;
+        }
+      }
+    }
+    std::vector<FP> conj;
+    conjuncts(f->kids[0], conj);
+    for (auto& c : conj) { PatStep tmp; if (key_constraint(c, q, &tmp)) unsupported("correlated iteration over object keys"); }
+    // pass-through: exists q. exists q2 in (.. q ..). body   with nothing else tied to q's element
+    if (conj.size() == 1 && conj[0]->kind == FNode::EXISTS && path_has_q(conj[0]->base, q) && !uses_elem_directly(conj[0]->kids[0], q)) {
+      pass.insert(q);
+      int r = lower_exists(conj[0]);
+      pass.erase(q);
+      return r;
+    }
+    SPath elem = f->base;
+    Step st; st.iter = true; st.q = q;
+    elem.push_back(st);
+    // loop registration must precede pattern_of(elem)
+    looped[q] = 0;
+    uint32_t sc;
+    try { sc = scope_for(elem); } catch (...) { looped.erase(q); throw; }
+    looped[q] = sc;
+    uint32_t parent = 0;
+    for (int i = (int)f->base.size() - 1; i >= 0; i--)
+      if (f->base[i].iter) { if (looped.count(f->base[i].q)) parent = looped[f->base[i].q] + 1; break; }
+    int acc = alloc();
+    emit(finst(F_LOOP, sc, parent, acc));
+    int r = lower(f->kids[0]);
+    emit(finst(F_ENDLOOP, acc, r));
+    release(r);
+    looped.erase(q);
+    return acc;
+  }
+
+  int lower(const FP& f) {
+    switch (f->kind) {
+      case FNode::T: { int r = alloc(); emit(finst(F_CONST, r, 1)); return r; }
+      case FNode::F: { int r = alloc(); emit(finst(F_CONST, r, 0)); return r; }
+      case FNode::NOT: { int r = lower(f->kids[0]); emit(finst(F_NOT, r, r)); return r; }
+      case FNode::AND: case FNode::OR: {
+        int r = lower(f->kids[0]);
+        for (size_t i = 1; i < f->kids.size(); i++) {
+          int r2 = lower(f->kids[i]);
+          emit(finst(f->kind == FNode::AND ? F_AND : F_OR, r, r, r2));
+          release(r2);
+        }
+        return r;
+      }
+      case FNode::ATOM: return lower_atom(f->atom);
+      case FNode::EXISTS: return lower_exists(f);
+    }
+    return -1;
+  }
+};
+
+}  // namespace
+
+uint32_t PlanBuilder::add_constraint(const FP& violation, const MatchFormulas& m) {
+  cons_.push_back({violation, m});
+  return (uint32_t)cons_.size() - 1;
+}
+
+HostPlan PlanBuilder::build(const PlanCaps& caps) {
+  Lowerer L;
+  L.dict = dict_;
+  L.caps = caps;
+  std::map<std::string, uint32_t> viol_ids, match_ids;
+  std::vector<FP> viols, matches, errs;
+  for (auto& c : cons_) {
+    FP v = simplify(c.viol), m = simplify(c.m.match), e = simplify(c.m.error);
+    std::string vk = f_to_string(v), mk = f_to_string(m) + "##" + f_to_string(e);
+    ConstraintSlot slot;
+    auto it = viol_ids.find(vk);
+    if (it == viol_ids.end()) { slot.viol = (uint16_t)viols.size(); viol_ids[vk] = slot.viol; viols.push_back(v); } else slot.viol = (uint16_t)it->second;
+    auto jt = match_ids.find(mk);
+    if (jt == match_ids.end()) { slot.match = (uint16_t)matches.size(); match_ids[mk] = slot.match; matches.push_back(m); errs.push_back(e); } else slot.match = (uint16_t)jt->second;
+    L.plan.slots.push_back(slot);
+  }
+  if (viols.size() > GK_MAX_RES || matches.size() > GK_MAX_RES)
+    throw Unsupported("more than 64 distinct violation or match formulas in one plan (split the constraint set)");
+  for (size_t i = 0; i < viols.size(); i++) { int r = L.lower(viols[i]); L.emit(finst(F_RES, r, 0, (uint32_t)i)); L.release(r); }
+  for (size_t i = 0; i < matches.size(); i++) {
+    int r = L.lower(matches[i]); L.emit(finst(F_RES, r, 1, (uint32_t)i)); L.release(r);
+    r = L.lower(errs[i]); L.emit(finst(F_RES, r, 2, (uint32_t)i)); L.release(r);
+  }
+  L.emit(finst(F_END));
+  HostPlan& p = L.plan;
+  p.n_viol = (uint32_t)viols.size();
+  p.n_match = (uint32_t)matches.size();
+  // accumulator layout
+  uint32_t gwords = (L.n_gbits + 31) / 32;
+  uint32_t off = gwords;
+  for (size_t s = 0; s < L.scope_patterns.size(); s++) {
+    Scope sc{};
+    uint32_t nb = L.scope_nbits[s];
+    sc.wpe = (uint8_t)(nb <= 24 ? 1 : 1 + (nb - 24 + 31) / 32);
+    sc.cap = caps.level_cap[L.scope_level[s]];
+    sc.nvals = (uint8_t)L.val_slots[s].size();
+    sc.count_off = off++;
+    sc.word_off = off;
+    off += (uint32_t)sc.cap * sc.wpe;
+    sc.val_off = off;
+    off += (uint32_t)sc.cap * sc.nvals * 3;
+    p.scopes.push_back(sc);
+  }
+  p.dims.n_preds = (uint32_t)p.preds.size();
+  p.dims.n_scopes = (uint32_t)p.scopes.size();
+  p.dims.n_code = (uint32_t)p.code.size();
+  p.dims.n_constraints = (uint32_t)p.slots.size();
+  p.dims.n_gwords = gwords;
+  p.dims.acc_words = off;
+  while (p.cheap.size() & 3) p.cheap.push_back(0);
+  if (p.cheap.empty()) p.cheap.resize(4, 0);
+  p.dims.const_bytes = (uint32_t)p.cheap.size();
+  p.resolve_paths(*dict_);
+  return p;
+}
+
+void HostPlan::resolve_paths(const PathDict& dict) {
+  uint32_t n = dict.size();
+  std::vector<PathDict::Info> infos(n);
+  std::vector<std::vector<uint32_t>> children(n);
+  for (uint32_t i = 0; i < n; i++) { infos[i] = dict.info(i); if (i) children[infos[i].parent].push_back(i); }
+  std::vector<std::vector<uint32_t>> per_path(n);
+  for (uint32_t pi = 0; pi < preds.size(); pi++) {
+    const Pattern& pat = pred_patterns[pi];
+    std::vector<uint32_t> cur{0};
+    for (const PatStep& st : pat) {
+      std::vector<uint32_t> nxt;
+      for (uint32_t id : cur)
+        for (uint32_t ch : children[id]) {
+          const PathDict::Info& in = infos[ch];
+          if (!st.any) { if (!in.is_elem && in.key == st.key) nxt.push_back(ch); continue; }
+          if (in.is_elem) { if (st.only.empty() && st.except.empty()) nxt.push_back(ch); continue; }
+          if (st.elems_only) continue;
+          if (!st.only.empty() && std::find(st.only.begin(), st.only.end(), in.key) == st.only.end()) continue;
+          if (std::find(st.except.begin(), st.except.end(), in.key) != st.except.end()) continue;
+          nxt.push_back(ch);
+        }
+      cur.swap(nxt);
+      if (cur.empty()) break;
+    }
+    for (uint32_t id : cur) per_path[id].push_back(pi);
+  }
+  ptab.assign(n, 0);
+  pred_list.clear();
+  pred_list.push_back(0);   // keep entry 0 unused so that ptab == 0 means "none"
+  for (uint32_t i = 0; i < n; i++) {
+    if (per_path[i].empty()) continue;
+    if (per_path[i].size() > 255) throw Unsupported("more than 255 predicates on one path");
+    ptab[i] = ((uint32_t)pred_list.size() << 8) | (uint32_t)per_path[i].size();
+    pred_list.insert(pred_list.end(), per_path[i].begin(), per_path[i].end());
+  }
+  dict_size = n;
+  dims.n_paths = n;
+}
+
+}  // namespace gk

@@ -1,0 +1,68 @@
+// Lowering: quantified boolean formulas (pe.hpp) -> device plan (plan.hpp): predicate table, element scopes,
+// formula bytecode, constant heap; plus the Match-block compiler.
+//
+// Match blocks restate pkg/mutation/match/match.go:32-258 + pkg/target/matcher.go:44-71 as formulas over the
+// flattener's `$m` / `$ns` rows and RF_* review flags, so that the match layer runs in the same kernels as the
+// template predicates (K1 "match_filter" of SURVEY.md section 7.3 is fused into the predicate pass).
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+
+#include "flatten.hpp"
+#include "pe.hpp"
+#include "plan.hpp"
+
+namespace gk {
+
+struct MatchFormulas {
+  FP match;   // constraint applies to the review (object OR oldObject, matcher.go:44-71)
+  FP error;   // Matcher.Match returns an error (autoreject result)
+};
+// spec.match of a constraint (Undefined / null => match everything, target.go:246-261)
+MatchFormulas compile_match(const Value& match_spec);
+
+struct PlanCaps {
+  uint16_t level_cap[3] = {16, 32, 32};   // element capacity per array-nesting level
+};
+
+struct PatStep {
+  bool any = false;                 // true: any single step
+  bool elems_only = false;          // any: only "[]" children (array-element scopes)
+  std::string key;                  // !any: exact member name
+  std::vector<std::string> only;    // any: member name must be one of (key iteration with ==)
+  std::vector<std::string> except;  // any: member name must not be one of
+};
+typedef std::vector<PatStep> Pattern;
+
+struct HostPlan {
+  std::vector<Pred> preds;
+  std::vector<Pattern> pred_patterns;     // parallel to preds
+  std::vector<Scope> scopes;
+  std::vector<uint32_t> code;
+  std::vector<uint8_t> cheap;
+  std::vector<ConstraintSlot> slots;      // per constraint
+  uint32_t n_viol = 0, n_match = 0;       // unique formulas
+  PlanDims dims{};
+  // path table (depends on the dictionary contents at build time)
+  std::vector<uint32_t> ptab, pred_list;
+  uint32_t dict_size = 0;
+  void resolve_paths(const PathDict& dict);   // (re)builds ptab / pred_list for the current dictionary
+};
+
+class PlanBuilder {
+ public:
+  explicit PlanBuilder(PathDict* dict) : dict_(dict) {}
+  // returns the constraint index; formulas are deduplicated structurally
+  uint32_t add_constraint(const FP& violation, const MatchFormulas& m);
+  HostPlan build(const PlanCaps& caps);   // throws Unsupported
+
+ private:
+  PathDict* dict_;
+  struct C { FP viol; MatchFormulas m; };
+  std::vector<C> cons_;
+};
+
+std::string pattern_to_string(const Pattern& p);
+
+}  // namespace gk

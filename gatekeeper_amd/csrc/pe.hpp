@@ -1,0 +1,117 @@
+// Partial evaluator for the Rego subset: evaluates a template's `violation` rule with
+//   input.parameters = constant (the constraint's spec.parameters)   and
+//   input.review     = SYMBOLIC (AOT compile: result is a quantified boolean formula over review rows)
+//                   or CONCRETE (host-side rendering of msg/details for the sparse violating pairs).
+// One evaluator, two modes, so the compiled predicate plan and the rendered messages cannot drift apart.
+//
+// Semantics restated from the OPA language reference (the reference evaluates with OPA v1.17.1 topdown through the
+// frameworks Rego driver; both third-party, go.mod:18-19): bodies are conjunctions, undefined propagates,
+// `not` is negation as failure, partial-set rules are unions, functions may have several bodies.
+#pragma once
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "rego_ast.hpp"
+#include "value.hpp"
+
+namespace gk {
+
+struct Unsupported : std::runtime_error { using std::runtime_error::runtime_error; };   // construct not compilable
+
+// ------------------------------------------------------------------------------------------------ formulas
+struct Step {
+  bool iter = false;     // true: iterate children (array elements / object members), bound to quantifier q
+  std::string key;
+  int q = -1;
+};
+typedef std::vector<Step> SPath;   // rooted at input.review
+
+struct Atom {
+  enum Kind { DEFINED, TRUTHY, CMP, TYPE, STR_PREFIX, STR_SUFFIX, STR_CONTAINS, STR_IN_SET, SPLIT_CMP, SPLIT_COUNT,
+              COUNT_CMP, FLAG, VEQ, KEYCMP } kind = DEFINED;
+  SPath path;
+  int cmp = 0;          // CmpOp
+  Value k;              // constant operand (CMP / STR_* / SPLIT_* / COUNT_CMP / KEYCMP; STR_IN_SET: set/array of strings)
+  uint32_t mask = 0;    // TYPE: bit per RowType
+  char cut = 0, sep = 0;
+  int idx = 0;          // SPLIT_CMP component (negative: from end)
+  uint32_t flag = 0;    // FLAG: review flag bit index
+  SPath path2;          // VEQ
+  int q = -1;           // KEYCMP
+};
+
+struct FNode;
+typedef std::shared_ptr<const FNode> FP;
+struct FNode {
+  enum Kind { T, F, AND, OR, NOT, EXISTS, ATOM } kind = T;
+  std::vector<FP> kids;
+  int q = -1;           // EXISTS: quantifier id; quantifies over children of `base`
+  SPath base;           // EXISTS
+  Atom atom;
+};
+
+FP f_true();
+FP f_false();
+FP f_and(FP a, FP b);
+FP f_or(FP a, FP b);
+FP f_not(FP a);
+FP f_atom(const Atom& a);
+FP f_exists(int q, const SPath& base, FP body);
+FP f_all(const std::vector<FP>& v);
+FP f_any(const std::vector<FP>& v);
+std::string f_to_string(const FP& f);
+std::string spath_to_string(const SPath& p);
+
+// ------------------------------------------------------------------------------------------------ symbolic values
+struct SV;
+typedef std::shared_ptr<const SV> SVP;
+struct CondElem { SVP v; FP cond; };
+struct Gen { SVP elem; std::vector<int> quants; std::vector<SPath> bases; FP cond; };
+
+struct SV {
+  enum Kind { CONST, PATH, KEYOF, OBJ, ARR, SET, OPAQUE, BOOLF, STRX, COUNTOF, CARD } kind = CONST;
+  Value c;                                        // CONST
+  SPath path;                                     // PATH / STRX / COUNTOF
+  int q = -1;                                     // KEYOF
+  std::vector<std::pair<Value, SVP>> fields;      // OBJ (constant keys)
+  std::vector<CondElem> elems;                    // ARR / SET / CARD
+  std::vector<Gen> gens;                          // ARR / SET / CARD
+  FP f;                                           // OPAQUE: definedness; BOOLF: truth value
+  FP d;                                           // BOOLF: definedness
+  char cut = 0, sep = 0;                          // STRX
+  enum XK { XTRIM, XARR, XCOMP, XCOUNT } xkind = XTRIM;
+  int idx = 0;                                    // XCOMP index / XCOUNT offset
+};
+
+struct Violation {   // render mode output
+  std::string msg;
+  Value details;     // Undefined when the template gave none (driver reports {})
+};
+
+// One compiled template: main module + libs.
+class Template {
+ public:
+  Template(const std::string& rego, const std::vector<std::string>& libs);   // throws RegoError
+  const std::string& package_name() const { return pkg_name_; }
+
+  // AOT: formula that is true iff the template yields >= 1 violation for a review, given constant parameters.
+  // Throws Unsupported if the template uses constructs the device plan cannot express.
+  FP compile(const Value& parameters, int* next_quant) const;
+
+  // Host rendering: the violation set for a concrete review document (input.review) and parameters.
+  // `inventory` is data.inventory (may be Undefined).  Throws RegoError on evaluation errors.
+  std::vector<Violation> render(const Value& review, const Value& parameters, const Value& inventory) const;
+
+  bool references_inventory() const { return uses_data_; }
+
+ private:
+  friend class PE;
+  std::vector<Module> modules_;
+  std::map<std::pair<std::string, std::string>, std::vector<const Rule*>> rules_;   // (pkg, name)
+  std::string pkg_name_;
+  bool uses_data_ = false;
+};
+
+}  // namespace gk

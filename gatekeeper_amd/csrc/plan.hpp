@@ -1,0 +1,150 @@
+// Flattened-review table layout and the compiled predicate plan, shared by host (compiler, flattener) and device
+// (kernels.hip).  Everything here is POD with fixed-width fields.
+//
+// This is the MI355X engine's replacement for what the reference holds as Go structs + OPA ASTs on the hot path:
+//   pkg/target/matcher.go:73-93 re-unmarshals object/oldObject per (constraint, review); here a review is flattened
+//   ONCE into 16-byte rows that every constraint program reads, and match blocks (pkg/mutation/match/match.go:32-65)
+//   plus template Rego are compiled into the same predicate/formula plan.
+#pragma once
+#include <cstdint>
+
+namespace gk {
+
+// ------------------------------------------------------------------------------------------------ rows
+// One row per JSON node (scalars AND containers) of the review document, in document order.
+struct Row {
+  uint32_t path;   // interned wildcarded key-path id (array indices erased); collision-free (PathDict)
+  uint32_t meta;   // see ROW_* below
+  uint32_t lo;     // value payload
+  uint32_t hi;
+};
+static_assert(sizeof(Row) == 16, "Row must be 16 bytes");
+
+enum RowType : uint32_t { T_NULL = 0, T_BOOL = 1, T_INT = 2, T_FLOAT = 3, T_STRING = 4, T_OBJECT = 5, T_ARRAY = 6 };
+
+constexpr uint32_t ROW_TYPE_MASK = 0x7;
+constexpr uint32_t ROW_FIRST = 1u << 3;        // first row of a review
+constexpr uint32_t ROW_E_SHIFT0 = 4;           // ordinal of the enclosing element at array-nesting level 0
+constexpr uint32_t ROW_E_SHIFT1 = 12;          // ... level 1
+constexpr uint32_t ROW_E_SHIFT2 = 20;          // ... level 2
+constexpr uint32_t ROW_E_MASK = 0xFF;
+constexpr uint32_t ROW_ORD_OVERFLOW = 1u << 28;  // an enclosing ordinal did not fit in 8 bits (saturated at 255)
+constexpr uint32_t ROW_DEEP = 1u << 29;          // more than 3 enclosing arrays
+constexpr uint32_t ROW_INEXACT = 1u << 30;       // number not exactly representable (bigint / lossy float)
+// value payload:  bool: lo=0/1 | int: hi:lo = int64 | float: hi:lo = f64 bits
+//                 string: lo = byte offset in the table heap (u32 length stored at off-4), hi = hash32(bytes)
+//                 object/array: lo = member count
+
+struct ReviewHdr {
+  uint32_t row_start;   // first row; rows of review r are [hdr[r].row_start, hdr[r+1].row_start)
+  uint32_t flags;       // RF_* (match-layer facts computed once by the flattener)
+};
+
+enum ReviewFlag : uint32_t {
+  RF_HAS_OBJ = 1u << 0,          // request.object present (after setObjectOnDelete, pkg/target/target.go:269-287)
+  RF_HAS_OLD = 1u << 1,          // request.oldObject present
+  RF_NS_PRESENT = 1u << 2,       // Matchable.Namespace != nil (review namespace or nsCache hit, matcher.go:37-39)
+  RF_OBJ_IS_NS = 1u << 3,        // match.IsNamespace(object)  (match.go:255-258)
+  RF_OLD_IS_NS = 1u << 4,
+  RF_OBJ_HAS_NSFIELD = 1u << 5,  // object.metadata.namespace != ""
+  RF_OLD_HAS_NSFIELD = 1u << 6,
+  RF_SRC_ORIGINAL = 1u << 7,     // Matchable.Source (mutator.go:14-26); neither bit set => ""
+  RF_SRC_GENERATED = 1u << 8,
+  RF_SRC_INVALID = 1u << 9,      // non-empty source outside {All,Original,Generated}
+  RF_OBJ_HAS_NSNAME = 1u << 10,  // an effective namespace name exists for object (match.go:150-179 switch)
+  RF_OLD_HAS_NSNAME = 1u << 11,
+  RF_TOO_BIG = 1u << 12,         // review exceeds engine limits (ordinal overflow); reported, never guessed
+  RF_SRC_ALL = 1u << 13,
+  RF_OBJ_LABELS_BAD = 1u << 14,  // metadata.labels is not a string map: unstructured GetLabels() yields none
+  RF_OLD_LABELS_BAD = 1u << 15,
+  RF_NS_LABELS_BAD = 1u << 16,
+};
+
+// ------------------------------------------------------------------------------------------------ predicates
+// Phase 1: every row whose path has predicates evaluates them and ORs result bits into per-review accumulators.
+enum PredOp : uint32_t {
+  P_DEFINED = 1,     // row exists
+  P_TRUTHY = 2,      // row exists and is not `false`
+  P_CMP = 3,         // compare(row, const) <op> 0 under Rego's total order
+  P_TYPE = 4,        // (1<<type) & mask
+  P_STR_PREFIX = 5,  // string row startswith const
+  P_STR_SUFFIX = 6,
+  P_STR_CONTAINS = 7,
+  P_STR_IN_SET = 8,  // string row is a member of a const string set
+  P_SPLIT_CMP = 9,   // component idx of split(trim(row, cut), sep)  <op> const string
+  P_SPLIT_COUNT = 10,  // count(split(trim(row, cut), sep)) <op> const int
+  P_STORE = 11,      // store row value into an element value slot (joins)
+  P_COUNT_CMP = 12,  // member count of container / byte length of string <op> const int
+  P_PRESENT = 13,    // element marker: sets bit 0 and parent ordinal of the element word
+};
+enum CmpOp : uint32_t { C_EQ = 0, C_NE = 1, C_LT = 2, C_LE = 3, C_GT = 4, C_GE = 5 };
+enum PredDst : uint32_t { D_GLOBAL = 0, D_ELEM = 1 };
+
+struct Pred {
+  uint8_t op;       // PredOp
+  uint8_t dst;      // PredDst
+  uint8_t scope;    // D_ELEM: scope index
+  uint8_t level;    // D_ELEM: which ordinal of the row addresses the element (0..2)
+  uint16_t bit;     // D_GLOBAL: bit index in the global bitset; D_ELEM: bit in the element word (P_STORE: value slot)
+  uint8_t cmp;      // CmpOp for P_CMP / P_SPLIT_* / P_COUNT_CMP
+  uint8_t ctype;    // RowType of the constant (P_CMP); type mask (P_TYPE)
+  uint32_t a;       // const-heap byte offset (string / set)
+  uint32_t b;       // const length / set size
+  uint64_t k;       // immediate: int64 / f64 bits / hash32
+  int32_t idx;      // P_SPLIT_CMP component index (negative = from the end)
+  uint32_t pad;     // P_SPLIT_*: (cut << 8) | sep
+};
+static_assert(sizeof(Pred) == 32, "Pred must be 32 bytes");
+
+struct Scope {
+  uint32_t word_off;   // first accumulator word (per review) of this scope's element words
+  uint32_t val_off;    // first accumulator word of value slots
+  uint32_t count_off;  // accumulator word holding max ordinal + 1
+  uint16_t cap;        // element capacity in this variant
+  uint8_t nvals;       // value slots per element (3 words each: lo, hi, type|valid)
+  uint8_t wpe;         // accumulator words per element
+};
+
+// ------------------------------------------------------------------------------------------------ formulas
+// Phase 2: one lane per review runs this wave-uniform bytecode over the accumulators. 64 boolean registers.
+enum FOp : uint32_t {
+  F_LDG = 1,    // a = global bit (b | c<<8)
+  F_LDF = 2,    // a = review flag bit b
+  F_LDE = 3,    // a = bit c of the current element of scope b
+  F_AND = 4,    // a = b & c
+  F_OR = 5,     // a = b | c
+  F_NOT = 6,    // a = !b
+  F_ANDN = 7,   // a = b & !c
+  F_CONST = 8,  // a = b
+  F_MOV = 9,    // a = b
+  F_LOOP = 10,  // begin loop over elements of scope a; b = parent scope + 1 (restrict to children of its current elem)
+  F_ENDLOOP = 11,  // a = accumulator reg, b = body result reg:  a |= b & valid(elem); next element
+  F_VEQ = 12,   // a = (value slot == value slot); followed by one extra word scopeA | slotA<<8 | scopeB<<16 | slotB<<24
+  F_RES = 13,   // result[b (0 viol, 1 match, 2 error)][c] = reg a
+  F_END = 14,
+};
+inline constexpr uint32_t finst(uint32_t op, uint32_t a = 0, uint32_t b = 0, uint32_t c = 0) {
+  return op | (a << 8) | (b << 16) | (c << 24);
+}
+
+struct ConstraintSlot {
+  uint16_t viol;    // index into the violation-result bits
+  uint16_t match;   // index into the match-result bits (and match-error bits)
+};
+
+constexpr int GK_TILE = 64;            // reviews per wave tile (one lane per review in phase 2)
+constexpr int GK_MAX_RES = 64;         // unique formulas per result class per pass
+constexpr int GK_MAX_SCOPES = 32;
+
+struct PlanDims {
+  uint32_t n_paths;       // entries in ptab
+  uint32_t n_preds;
+  uint32_t n_scopes;
+  uint32_t n_code;        // formula words
+  uint32_t n_constraints;
+  uint32_t n_gwords;      // global bitset words
+  uint32_t acc_words;     // accumulator words per review (globals + scopes)
+  uint32_t const_bytes;
+};
+
+}  // namespace gk

@@ -1,0 +1,428 @@
+// Value model shared by the JSON reader, the Rego front end (parser / AOT compiler) and the host-side message
+// renderer.  Immutable, cheaply copyable (shared_ptr payloads).
+//
+// Replaces, for the MI355X engine, what the reference gets from OPA's ast.Value (github.com/open-policy-agent/opa
+// v1.17.1, go.mod:19): null < boolean < number < string < array < object < set total order, value equality,
+// and ast term String() rendering used by sprintf("%v") (pinned by website/docs/constrainttemplates.md:118).
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+namespace gk {
+
+typedef __int128 i128;
+
+struct Value;
+typedef std::vector<Value> ValueVec;
+typedef std::vector<std::pair<Value, Value>> ValuePairs;
+
+struct Value {
+  enum Kind : uint8_t { Null = 0, Bool = 1, Number = 2, String = 3, Array = 4, Object = 5, Set = 6, Undefined = 7 };
+  Kind kind = Undefined;
+  bool b = false;
+  bool is_int = true;   // Number: exact integer in `i`, otherwise double in `d`
+  i128 i = 0;
+  double d = 0;
+  std::shared_ptr<const std::string> s;
+  std::shared_ptr<const ValueVec> arr;     // Array: in order; Set: sorted unique
+  std::shared_ptr<const ValuePairs> obj;   // Object: sorted by key
+
+  Value() {}
+  static Value null() { Value v; v.kind = Null; return v; }
+  static Value boolean(bool x) { Value v; v.kind = Bool; v.b = x; return v; }
+  static Value integer(i128 x) { Value v; v.kind = Number; v.is_int = true; v.i = x; v.d = (double)x; return v; }
+  static Value real(double x) {
+    Value v; v.kind = Number;
+    if (std::isfinite(x) && std::floor(x) == x && std::fabs(x) < 1e30) { v.is_int = true; v.i = (i128)x; v.d = x; }
+    else { v.is_int = false; v.d = x; }
+    return v;
+  }
+  static Value string(std::string x) { Value v; v.kind = String; v.s = std::make_shared<const std::string>(std::move(x)); return v; }
+  static Value array(ValueVec x) { Value v; v.kind = Array; v.arr = std::make_shared<const ValueVec>(std::move(x)); return v; }
+  static Value set(ValueVec x);
+  static Value object(ValuePairs x);
+
+  bool defined() const { return kind != Undefined; }
+  bool is_null() const { return kind == Null; }
+  bool is_bool() const { return kind == Bool; }
+  bool is_number() const { return kind == Number; }
+  bool is_string() const { return kind == String; }
+  bool is_array() const { return kind == Array; }
+  bool is_object() const { return kind == Object; }
+  bool is_set() const { return kind == Set; }
+  const std::string& str() const { return *s; }
+  const ValueVec& items() const { return *arr; }
+  const ValuePairs& pairs() const { return *obj; }
+  double as_double() const { return is_int ? (double)i : d; }
+  size_t size() const {
+    if (kind == Array || kind == Set) return arr->size();
+    if (kind == Object) return obj->size();
+    if (kind == String) return s->size();
+    return 0;
+  }
+  const Value* get(const Value& key) const;       // object lookup
+  const Value* get(const char* key) const { return get(Value::string(key)); }
+  bool set_has(const Value& v) const;
+};
+
+inline int compare(const Value& a, const Value& b);
+
+inline int cmp_num(const Value& a, const Value& b) {
+  if (a.is_int && b.is_int) return a.i < b.i ? -1 : (a.i > b.i ? 1 : 0);
+  double x = a.as_double(), y = b.as_double();
+  return x < y ? -1 : (x > y ? 1 : 0);
+}
+
+inline int compare(const Value& a, const Value& b) {
+  if (a.kind != b.kind) return a.kind < b.kind ? -1 : 1;
+  switch (a.kind) {
+    case Value::Null: case Value::Undefined: return 0;
+    case Value::Bool: return (int)a.b - (int)b.b;
+    case Value::Number: return cmp_num(a, b);
+    case Value::String: { int c = a.s->compare(*b.s); return c < 0 ? -1 : (c > 0 ? 1 : 0); }
+    case Value::Array: case Value::Set: {
+      size_t n = std::min(a.arr->size(), b.arr->size());
+      for (size_t k = 0; k < n; k++) { int c = compare((*a.arr)[k], (*b.arr)[k]); if (c) return c; }
+      return a.arr->size() < b.arr->size() ? -1 : (a.arr->size() > b.arr->size() ? 1 : 0);
+    }
+    case Value::Object: {
+      size_t n = std::min(a.obj->size(), b.obj->size());
+      for (size_t k = 0; k < n; k++) {
+        int c = compare((*a.obj)[k].first, (*b.obj)[k].first); if (c) return c;
+        c = compare((*a.obj)[k].second, (*b.obj)[k].second); if (c) return c;
+      }
+      return a.obj->size() < b.obj->size() ? -1 : (a.obj->size() > b.obj->size() ? 1 : 0);
+    }
+  }
+  return 0;
+}
+inline bool operator==(const Value& a, const Value& b) { return compare(a, b) == 0; }
+inline bool operator!=(const Value& a, const Value& b) { return compare(a, b) != 0; }
+inline bool operator<(const Value& a, const Value& b) { return compare(a, b) < 0; }
+
+inline Value Value::set(ValueVec x) {
+  std::sort(x.begin(), x.end());
+  x.erase(std::unique(x.begin(), x.end()), x.end());
+  Value v; v.kind = Set; v.arr = std::make_shared<const ValueVec>(std::move(x)); return v;
+}
+inline Value Value::object(ValuePairs x) {
+  std::stable_sort(x.begin(), x.end(), [](const std::pair<Value, Value>& p, const std::pair<Value, Value>& q) { return p.first < q.first; });
+  // last write wins for duplicate keys
+  ValuePairs out;
+  for (auto& p : x) { if (!out.empty() && out.back().first == p.first) out.back().second = p.second; else out.push_back(p); }
+  Value v; v.kind = Object; v.obj = std::make_shared<const ValuePairs>(std::move(out)); return v;
+}
+inline const Value* Value::get(const Value& key) const {
+  if (kind != Object) return nullptr;
+  auto it = std::lower_bound(obj->begin(), obj->end(), key, [](const std::pair<Value, Value>& p, const Value& k) { return p.first < k; });
+  if (it != obj->end() && it->first == key) return &it->second;
+  return nullptr;
+}
+inline bool Value::set_has(const Value& v) const {
+  if (kind != Set) return false;
+  return std::binary_search(arr->begin(), arr->end(), v);
+}
+
+// ---------------------------------------------------------------------------------------------- rendering
+inline std::string i128_to_string(i128 x) {
+  if (x == 0) return "0";
+  bool neg = x < 0;
+  unsigned __int128 u = neg ? (unsigned __int128)(-(x + 1)) + 1 : (unsigned __int128)x;
+  std::string s;
+  while (u) { s.push_back('0' + (int)(u % 10)); u /= 10; }
+  if (neg) s.push_back('-');
+  std::reverse(s.begin(), s.end());
+  return s;
+}
+
+// Go fmt %v of a float64: strconv 'g' with shortest repr and exponent threshold 21.
+inline std::string go_float_v(double f) {
+  if (f != f) return "NaN";
+  if (std::isinf(f)) return f > 0 ? "+Inf" : "-Inf";
+  if (f == 0) return "0";
+  char buf[64];
+  int prec = 1;
+  for (; prec <= 17; prec++) { snprintf(buf, sizeof buf, "%.*e", prec - 1, f); if (strtod(buf, nullptr) == f) break; }
+  std::string r(buf);
+  size_t epos = r.find('e');
+  std::string mant = r.substr(0, epos);
+  int x = atoi(r.c_str() + epos + 1);
+  std::string sign;
+  if (mant[0] == '-') { sign = "-"; mant = mant.substr(1); }
+  std::string digits;
+  for (char c : mant) if (c != '.') digits.push_back(c);
+  while (digits.size() > 1 && digits.back() == '0') digits.pop_back();
+  if (x < -4 || x >= 21) {
+    std::string m = digits.substr(0, 1);
+    if (digits.size() > 1) m += "." + digits.substr(1);
+    char e[16]; snprintf(e, sizeof e, "e%c%02d", x >= 0 ? '+' : '-', std::abs(x));
+    return sign + m + e;
+  }
+  if (x >= 0) {
+    if ((int)digits.size() <= x + 1) return sign + digits + std::string(x + 1 - digits.size(), '0');
+    return sign + digits.substr(0, x + 1) + "." + digits.substr(x + 1);
+  }
+  return sign + "0." + std::string(-x - 1, '0') + digits;
+}
+
+inline std::string num_to_string(const Value& v) { return v.is_int ? i128_to_string(v.i) : go_float_v(v.d); }
+
+// Go strconv.Quote (ast.String.String()).
+inline std::string go_quote(const std::string& s) {
+  std::string o = "\"";
+  for (unsigned char c : s) {
+    switch (c) {
+      case '"': o += "\\\""; break;
+      case '\\': o += "\\\\"; break;
+      case '\n': o += "\\n"; break;
+      case '\t': o += "\\t"; break;
+      case '\r': o += "\\r"; break;
+      case '\a': o += "\\a"; break;
+      case '\b': o += "\\b"; break;
+      case '\f': o += "\\f"; break;
+      case '\v': o += "\\v"; break;
+      default:
+        if (c < 0x20 || c == 0x7f) { char b[8]; snprintf(b, sizeof b, "\\x%02x", c); o += b; }
+        else o.push_back((char)c);
+    }
+  }
+  o.push_back('"');
+  return o;
+}
+
+// OPA ast term String()
+inline std::string to_term_string(const Value& v) {
+  switch (v.kind) {
+    case Value::Null: return "null";
+    case Value::Undefined: return "undefined";
+    case Value::Bool: return v.b ? "true" : "false";
+    case Value::Number: return num_to_string(v);
+    case Value::String: return go_quote(*v.s);
+    case Value::Array: {
+      std::string o = "[";
+      for (size_t k = 0; k < v.arr->size(); k++) { if (k) o += ", "; o += to_term_string((*v.arr)[k]); }
+      return o + "]";
+    }
+    case Value::Set: {
+      if (v.arr->empty()) return "set()";
+      std::string o = "{";
+      for (size_t k = 0; k < v.arr->size(); k++) { if (k) o += ", "; o += to_term_string((*v.arr)[k]); }
+      return o + "}";
+    }
+    case Value::Object: {
+      std::string o = "{";
+      for (size_t k = 0; k < v.obj->size(); k++) {
+        if (k) o += ", ";
+        o += to_term_string((*v.obj)[k].first) + ": " + to_term_string((*v.obj)[k].second);
+      }
+      return o + "}";
+    }
+  }
+  return "";
+}
+
+// ---------------------------------------------------------------------------------------------- JSON
+struct JsonError : std::runtime_error { using std::runtime_error::runtime_error; };
+
+inline void json_escape(const std::string& s, std::string& o) {
+  o.push_back('"');
+  for (unsigned char c : s) {
+    switch (c) {
+      case '"': o += "\\\""; break;
+      case '\\': o += "\\\\"; break;
+      case '\n': o += "\\n"; break;
+      case '\t': o += "\\t"; break;
+      case '\r': o += "\\r"; break;
+      case '\b': o += "\\b"; break;
+      case '\f': o += "\\f"; break;
+      default:
+        if (c < 0x20) { char b[8]; snprintf(b, sizeof b, "\\u%04x", c); o += b; }
+        else o.push_back((char)c);
+    }
+  }
+  o.push_back('"');
+}
+
+// JSON text of a value; sets become sorted arrays (OPA ast.JSON), non-string object keys use their term string.
+inline void to_json(const Value& v, std::string& o) {
+  switch (v.kind) {
+    case Value::Null: case Value::Undefined: o += "null"; break;
+    case Value::Bool: o += v.b ? "true" : "false"; break;
+    case Value::Number: o += num_to_string(v); break;
+    case Value::String: json_escape(*v.s, o); break;
+    case Value::Array: case Value::Set:
+      o.push_back('[');
+      for (size_t k = 0; k < v.arr->size(); k++) { if (k) o.push_back(','); to_json((*v.arr)[k], o); }
+      o.push_back(']');
+      break;
+    case Value::Object:
+      o.push_back('{');
+      for (size_t k = 0; k < v.obj->size(); k++) {
+        if (k) o.push_back(',');
+        const Value& key = (*v.obj)[k].first;
+        json_escape(key.is_string() ? *key.s : to_term_string(key), o);
+        o.push_back(':');
+        to_json((*v.obj)[k].second, o);
+      }
+      o.push_back('}');
+      break;
+  }
+}
+inline std::string to_json(const Value& v) { std::string o; to_json(v, o); return o; }
+
+class JsonParser {
+ public:
+  JsonParser(const char* p, size_t n) : p_(p), e_(p + n) {}
+  Value parse() {
+    ws();
+    Value v = value(0);
+    ws();
+    if (p_ != e_) fail("trailing characters");
+    return v;
+  }
+
+ private:
+  const char *p_, *e_;
+  [[noreturn]] void fail(const char* m) { throw JsonError(std::string("invalid JSON: ") + m); }
+  void ws() { while (p_ < e_ && (*p_ == ' ' || *p_ == '\n' || *p_ == '\t' || *p_ == '\r')) p_++; }
+  Value value(int depth) {
+    if (depth > 512) fail("nesting too deep");
+    if (p_ >= e_) fail("unexpected end");
+    char c = *p_;
+    if (c == '{') {
+      p_++; ws();
+      ValuePairs pairs;
+      if (p_ < e_ && *p_ == '}') { p_++; return Value::object(std::move(pairs)); }
+      for (;;) {
+        ws();
+        if (p_ >= e_ || *p_ != '"') fail("expected object key");
+        std::string k = str();
+        ws();
+        if (p_ >= e_ || *p_ != ':') fail("expected ':'");
+        p_++; ws();
+        Value v = value(depth + 1);
+        pairs.emplace_back(Value::string(std::move(k)), std::move(v));
+        ws();
+        if (p_ < e_ && *p_ == ',') { p_++; continue; }
+        if (p_ < e_ && *p_ == '}') { p_++; break; }
+        fail("expected ',' or '}'");
+      }
+      return Value::object(std::move(pairs));
+    }
+    if (c == '[') {
+      p_++; ws();
+      ValueVec items;
+      if (p_ < e_ && *p_ == ']') { p_++; return Value::array(std::move(items)); }
+      for (;;) {
+        ws();
+        items.push_back(value(depth + 1));
+        ws();
+        if (p_ < e_ && *p_ == ',') { p_++; continue; }
+        if (p_ < e_ && *p_ == ']') { p_++; break; }
+        fail("expected ',' or ']'");
+      }
+      return Value::array(std::move(items));
+    }
+    if (c == '"') return Value::string(str());
+    if (c == 't') { lit("true"); return Value::boolean(true); }
+    if (c == 'f') { lit("false"); return Value::boolean(false); }
+    if (c == 'n') { lit("null"); return Value::null(); }
+    return number();
+  }
+  void lit(const char* w) {
+    size_t n = strlen(w);
+    if ((size_t)(e_ - p_) < n || memcmp(p_, w, n) != 0) fail("bad literal");
+    p_ += n;
+  }
+  Value number() {
+    const char* s = p_;
+    bool is_int = true;
+    if (p_ < e_ && *p_ == '-') p_++;
+    if (p_ >= e_ || !(*p_ >= '0' && *p_ <= '9')) fail("bad number");
+    while (p_ < e_ && *p_ >= '0' && *p_ <= '9') p_++;
+    if (p_ < e_ && *p_ == '.') { is_int = false; p_++; while (p_ < e_ && *p_ >= '0' && *p_ <= '9') p_++; }
+    if (p_ < e_ && (*p_ == 'e' || *p_ == 'E')) {
+      is_int = false; p_++;
+      if (p_ < e_ && (*p_ == '+' || *p_ == '-')) p_++;
+      while (p_ < e_ && *p_ >= '0' && *p_ <= '9') p_++;
+    }
+    std::string t(s, p_ - s);
+    if (is_int && t.size() <= 37) {
+      i128 x = 0; size_t k = 0; bool neg = false;
+      if (t[0] == '-') { neg = true; k = 1; }
+      for (; k < t.size(); k++) x = x * 10 + (t[k] - '0');
+      return Value::integer(neg ? -x : x);
+    }
+    return Value::real(strtod(t.c_str(), nullptr));
+  }
+  static void utf8(std::string& o, uint32_t cp) {
+    if (cp < 0x80) o.push_back((char)cp);
+    else if (cp < 0x800) { o.push_back((char)(0xC0 | (cp >> 6))); o.push_back((char)(0x80 | (cp & 0x3F))); }
+    else if (cp < 0x10000) { o.push_back((char)(0xE0 | (cp >> 12))); o.push_back((char)(0x80 | ((cp >> 6) & 0x3F))); o.push_back((char)(0x80 | (cp & 0x3F))); }
+    else { o.push_back((char)(0xF0 | (cp >> 18))); o.push_back((char)(0x80 | ((cp >> 12) & 0x3F))); o.push_back((char)(0x80 | ((cp >> 6) & 0x3F))); o.push_back((char)(0x80 | (cp & 0x3F))); }
+  }
+  uint32_t hex4() {
+    if (e_ - p_ < 4) fail("bad \\u escape");
+    uint32_t v = 0;
+    for (int k = 0; k < 4; k++) {
+      char c = *p_++;
+      v <<= 4;
+      if (c >= '0' && c <= '9') v |= c - '0';
+      else if (c >= 'a' && c <= 'f') v |= c - 'a' + 10;
+      else if (c >= 'A' && c <= 'F') v |= c - 'A' + 10;
+      else fail("bad \\u escape");
+    }
+    return v;
+  }
+  std::string str() {
+    p_++;  // opening quote
+    std::string o;
+    for (;;) {
+      if (p_ >= e_) fail("unterminated string");
+      const char* q = p_;
+      while (q < e_ && *q != '"' && *q != '\\') q++;
+      o.append(p_, q - p_);
+      p_ = q;
+      if (p_ >= e_) fail("unterminated string");
+      if (*p_ == '"') { p_++; return o; }
+      p_++;
+      if (p_ >= e_) fail("bad escape");
+      char c = *p_++;
+      switch (c) {
+        case '"': o.push_back('"'); break;
+        case '\\': o.push_back('\\'); break;
+        case '/': o.push_back('/'); break;
+        case 'b': o.push_back('\b'); break;
+        case 'f': o.push_back('\f'); break;
+        case 'n': o.push_back('\n'); break;
+        case 'r': o.push_back('\r'); break;
+        case 't': o.push_back('\t'); break;
+        case 'u': {
+          uint32_t cp = hex4();
+          if (cp >= 0xD800 && cp < 0xDC00 && e_ - p_ >= 6 && p_[0] == '\\' && p_[1] == 'u') {
+            p_ += 2;
+            uint32_t lo = hex4();
+            if (lo >= 0xDC00 && lo < 0xE000) cp = 0x10000 + ((cp - 0xD800) << 10) + (lo - 0xDC00);
+            else { utf8(o, 0xFFFD); cp = lo; }
+          }
+          utf8(o, cp);
+          break;
+        }
+        default: fail("bad escape");
+      }
+    }
+  }
+};
+
+inline Value parse_json(const char* p, size_t n) { return JsonParser(p, n).parse(); }
+inline Value parse_json(const std::string& s) { return parse_json(s.data(), s.size()); }
+
+}  // namespace gk

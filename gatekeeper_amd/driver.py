@@ -1,0 +1,594 @@
+"""Host-side mirror of the reference's plugin interface for the hot path, on top of the C ABI (include/gkgpu.h).
+
+The reference's Go toolchain is absent from this image, so the layer a Go maintainer would write with cgo
+ is mirrored here in Python with the same names, argument meaning and error behaviour:
+
+  Driver   -- drivers.Driver (frameworks constraint/pkg/client/drivers; compile-checked exemplar
+              pkg/drivers/k8scel/driver.go:56-264): Name/AddTemplate/RemoveTemplate/AddConstraint/RemoveConstraint/
+              AddData/RemoveData/Query/Dump/GetDescriptionForStat.  Name() == "Rego" so templates route here.
+  Client   -- the slice of constraintclient.Client the callers use (pkg/gator/test/test.go:33-176,
+              pkg/webhook/policy.go:826, pkg/audit/manager.go:621,719): AddTemplate/AddConstraint/AddData/Review,
+              including enforcement-point scoping (pkg/util/enforcement_action.go:132-174), CRD parameter
+              defaulting and the autoreject result for match errors.
+  AdmissionRequest / Unstructured / AugmentedReview / AugmentedUnstructured -- pkg/target/review.go:9-29,
+              pkg/target/data.go:26-31 input shapes of K8sValidationTarget.HandleReview (pkg/target/target.go:81-138).
+
+All evaluation (Match + violation predicates) runs in the HIP kernels; this module only marshals JSON, and renders
+messages for the sparse violating pairs through gk_render.  No CPU fallback exists.
+"""
+from __future__ import annotations
+
+import copy
+import ctypes as C
+import json
+
+import numpy as np
+
+from . import _lib as L
+
+TARGET_NAME = "admission.k8s.gatekeeper.sh"
+WEBHOOK_EP = "validation.gatekeeper.sh"
+AUDIT_EP = "audit.gatekeeper.sh"
+GATOR_EP = "gator.gatekeeper.sh"
+ALL_EP = "*"
+
+_SOURCES = {"": L.GK_SRC_EMPTY, "Original": L.GK_SRC_ORIGINAL, "Generated": L.GK_SRC_GENERATED, "All": L.GK_SRC_ALL}
+
+
+class EngineError(Exception):
+    def __init__(self, code, msg):
+        super().__init__(msg)
+        self.code = code
+
+
+class UnsupportedError(EngineError):
+    """GK_ERR_UNSUPPORTED: the template/constraint cannot run on the device plan (keep it on the CPU Rego driver)."""
+
+
+# ---------------------------------------------------------------------------------------------- review shapes
+class AdmissionRequest(dict):
+    """admissionv1.AdmissionRequest as its JSON dict."""
+
+
+class Unstructured(dict):
+    """unstructured.Unstructured"""
+
+
+class AugmentedReview:
+    def __init__(self, admission_request, namespace=None, source="", is_admission=False):
+        self.admission_request = admission_request
+        self.namespace = namespace
+        self.source = source
+        self.is_admission = is_admission
+
+
+class AugmentedUnstructured:
+    def __init__(self, obj, namespace=None, source="", operation=""):
+        self.object = obj
+        self.namespace = namespace
+        self.source = source
+        self.operation = operation
+
+
+class ReviewIn:
+    """One gk_review_in."""
+
+    __slots__ = ("kind", "json", "namespace", "ns_object", "source", "operation")
+
+    def __init__(self, kind, body, namespace=None, ns_object=None, source="", operation=""):
+        self.kind = kind
+        self.json = body if isinstance(body, (bytes, bytearray)) else json.dumps(body).encode()
+        self.namespace = None if namespace is None else json.dumps(namespace).encode()
+        self.ns_object = None if ns_object is None else json.dumps(ns_object).encode()
+        self.source = _SOURCES.get(source, L.GK_SRC_INVALID)
+        self.operation = operation.encode() if operation else None
+
+
+def to_review_in(obj, ns_object=None):
+    """HandleReview input shapes -> gk_review_in; returns None for unhandled types (handled=false)."""
+    if isinstance(obj, AugmentedReview):
+        return ReviewIn(L.GK_REVIEW_ADMISSION_REQUEST, dict(obj.admission_request), obj.namespace, ns_object, obj.source)
+    if isinstance(obj, AugmentedUnstructured):
+        return ReviewIn(L.GK_REVIEW_OBJECT, dict(obj.object), obj.namespace, ns_object, obj.source, obj.operation)
+    if isinstance(obj, AdmissionRequest):
+        return ReviewIn(L.GK_REVIEW_ADMISSION_REQUEST, dict(obj), None, ns_object)
+    if isinstance(obj, Unstructured):
+        return ReviewIn(L.GK_REVIEW_OBJECT, dict(obj), None, ns_object)
+    if isinstance(obj, ReviewIn):
+        return obj
+    return None
+
+
+# ---------------------------------------------------------------------------------------------- engine wrapper
+class EvalResult:
+    def __init__(self, lib, ptr):
+        o = ptr.contents
+        self.n_reviews, self.n_constraints, self.n_tiles = o.n_reviews, o.n_constraints, o.n_tiles
+        nc, nt = self.n_constraints, self.n_tiles
+        self.constraint_ids = np.ctypeslib.as_array(o.constraint_ids, (nc,)).copy() if nc else np.zeros(0, np.uint32)
+
+        def bm(p):
+            if not p or nc * nt == 0:
+                return np.zeros((nc, nt), np.uint64)
+            return np.ctypeslib.as_array(p, (nc * nt,)).reshape(nc, nt).copy()
+
+        has = bool(o.viol)
+        self.viol = bm(o.viol) if has else None
+        self.err = bm(o.err) if has else None
+        self.match = bm(o.match) if o.match else None
+        self.too_big = np.ctypeslib.as_array(o.too_big, (nt,)).copy() if (o.too_big and nt) else np.zeros(nt, np.uint64)
+        self.counts = np.ctypeslib.as_array(o.counts, (nc,)).copy() if (o.counts and nc) else np.zeros(nc, np.uint32)
+        self.list = (np.ctypeslib.as_array(o.list, (o.list_len * 2,)).reshape(-1, 2).copy()
+                     if (o.list and o.list_len) else np.zeros((0, 2), np.uint32))
+        self.list_total = o.list_total
+        self.n_overflow = o.n_overflow
+        self.kernel_ms, self.fast_kernel_ms = o.kernel_ms, o.fast_kernel_ms
+        self.algo_bytes, self.n_rows, self.n_launches = o.algo_bytes, o.n_rows, o.n_launches
+        self.d_viol, self.d_err, self.d_counts = o.d_viol, o.d_err, o.d_counts
+        lib.gk_eval_free(ptr)
+
+    @staticmethod
+    def bits(bitmap_row, n):
+        """indices of set bits in one bitmap row"""
+        b = np.unpackbits(bitmap_row.view(np.uint8), bitorder="little")[:n]
+        return np.nonzero(b)[0]
+
+    def pairs(self, which="viol"):
+        """sorted list of (constraint_id, review) for the chosen bitmap"""
+        bm = getattr(self, which)
+        out = []
+        for row in range(self.n_constraints):
+            cid = int(self.constraint_ids[row])
+            for r in self.bits(bm[row], self.n_reviews):
+                out.append((cid, int(r)))
+        return sorted(out)
+
+
+class Table:
+    def __init__(self, engine, handle, statuses, n):
+        self.engine, self.handle, self.statuses, self.n = engine, handle, statuses, n
+
+    def eval(self, want_match=False, download=True, want_list=False):
+        lib = self.engine.lib
+        flags = (L.GK_EVAL_WANT_MATCH if want_match else 0) | (0 if download else L.GK_EVAL_NO_DOWNLOAD) | (
+            L.GK_EVAL_WANT_LIST if want_list else 0)
+        out = C.POINTER(L.gk_eval_out)()
+        self.engine._check(lib.gk_table_eval(self.engine.handle, self.handle, flags, C.byref(out)))
+        return EvalResult(lib, out)
+
+    def launch(self, want_match=False):
+        """Enqueue one evaluation launch without waiting (GK_EVAL_ASYNC); a later eval() collects."""
+        out = C.POINTER(L.gk_eval_out)()
+        flags = L.GK_EVAL_ASYNC | (L.GK_EVAL_WANT_MATCH if want_match else 0)
+        self.engine._check(self.engine.lib.gk_table_eval(self.engine.handle, self.handle, flags, C.byref(out)))
+
+    def _render(self, fn, cid, review):
+        p = C.c_void_p()
+        self.engine._check(fn(self.engine.handle, self.handle, cid, review, C.byref(p)))
+        s = C.string_at(p).decode()
+        self.engine.lib.gk_free(p)
+        return json.loads(s)
+
+    def render(self, cid, review):
+        return self._render(self.engine.lib.gk_render, cid, review)
+
+    def render_error(self, cid, review):
+        return self._render(self.engine.lib.gk_render_error, cid, review)
+
+    def free(self):
+        if self.handle:
+            self.engine.lib.gk_table_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Engine:
+    """OO view of gk_engine."""
+
+    def __init__(self, device=0, elem_cap=None, hostemu=None):
+        self.lib = L.load(hostemu)
+        opts = L.gk_opts()
+        opts.device = device
+        if elem_cap:
+            for i, v in enumerate(elem_cap):
+                opts.elem_cap[i] = v
+        h = C.c_void_p()
+        self._check(self.lib.gk_engine_create(C.byref(opts), C.byref(h)))
+        self.handle = h
+
+    def _check(self, rc):
+        if rc != L.GK_OK:
+            msg = self.lib.gk_last_error().decode()
+            if rc == L.GK_ERR_UNSUPPORTED:
+                raise UnsupportedError(rc, msg)
+            raise EngineError(rc, msg)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.gk_engine_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def add_template(self, kind, rego, libs=()):
+        arr = (C.c_char_p * max(1, len(libs)))(*[l.encode() for l in libs])
+        self._check(self.lib.gk_template_add(self.handle, kind.encode(), rego.encode(), arr, len(libs)))
+
+    def remove_template(self, kind):
+        self._check(self.lib.gk_template_remove(self.handle, kind.encode()))
+
+    def add_constraint(self, constraint):
+        body = json.dumps(constraint).encode()
+        cid = C.c_uint32()
+        self._check(self.lib.gk_constraint_add(self.handle, body, len(body), C.byref(cid)))
+        return cid.value
+
+    def remove_constraint(self, kind, name):
+        self._check(self.lib.gk_constraint_remove(self.handle, kind.encode(), name.encode()))
+
+    def put_data(self, path, obj):
+        arr = (C.c_char_p * len(path))(*[p.encode() for p in path])
+        body = json.dumps(obj).encode()
+        self._check(self.lib.gk_data_put(self.handle, arr, len(path), body, len(body)))
+
+    def remove_data(self, path):
+        arr = (C.c_char_p * len(path))(*[p.encode() for p in path])
+        self._check(self.lib.gk_data_remove(self.handle, arr, len(path)))
+
+    def create_table(self, reviews, keep_docs=True):
+        n = len(reviews)
+        arr = (L.gk_review_in * max(1, n))()
+        keep = []
+        for i, r in enumerate(reviews):
+            a = arr[i]
+            a.kind, a.source = r.kind, r.source
+            a.json, a.json_len = r.json, len(r.json)
+            keep.append(r)
+            if r.namespace is not None:
+                a.namespace_json, a.namespace_len = r.namespace, len(r.namespace)
+            if r.ns_object is not None:
+                a.ns_object_json, a.ns_object_len = r.ns_object, len(r.ns_object)
+            a.operation = r.operation
+        st = (C.c_int32 * max(1, n))()
+        h = C.c_void_p()
+        self._check(self.lib.gk_table_create(self.handle, arr, n, L.GK_TABLE_KEEP_DOCS if keep_docs else 0, st, C.byref(h)))
+        return Table(self, h, list(st)[:n], n)
+
+    def dump(self):
+        p = C.c_void_p()
+        self._check(self.lib.gk_dump(self.handle, C.byref(p)))
+        s = C.string_at(p).decode()
+        self.lib.gk_free(p)
+        return s
+
+
+# ---------------------------------------------------------------------------------------------- types.Result etc.
+class Result:
+    """frameworks types.Result"""
+
+    def __init__(self, msg, constraint, details=None, enforcement_action="deny", scoped_actions=None, target=TARGET_NAME):
+        self.target = target
+        self.msg = msg
+        self.constraint = constraint
+        self.metadata = {"details": details if details is not None else {}}
+        self.enforcement_action = enforcement_action
+        self.scoped_enforcement_actions = scoped_actions
+
+    def key(self):
+        c = self.constraint
+        return (c.get("kind"), (c.get("metadata") or {}).get("name"), self.msg, json.dumps(self.metadata, sort_keys=True),
+                self.enforcement_action, tuple(self.scoped_enforcement_actions or ()))
+
+    def __repr__(self):
+        return "Result(%r, %s/%s, %s)" % (self.msg, self.constraint.get("kind"),
+                                          (self.constraint.get("metadata") or {}).get("name"), self.enforcement_action)
+
+
+class QueryResponse:
+    def __init__(self, results, stats_entries=None):
+        self.results = results
+        self.stats_entries = stats_entries or []
+
+
+class ClientError(Exception):
+    pass
+
+
+def template_source(ct):
+    """(kind, target, rego, libs): `code[engine=Rego]` wins over the legacy `rego` field
+    (website/docs/constrainttemplates.md:216-232)."""
+    spec = ct.get("spec")
+    if not isinstance(spec, dict):
+        raise ClientError("invalid ConstraintTemplate: spec must be an object")
+    try:
+        kind = spec["crd"]["spec"]["names"]["kind"]
+    except (KeyError, TypeError):
+        raise ClientError("invalid ConstraintTemplate: missing spec.crd.spec.names.kind")
+    targets = spec.get("targets") or []
+    if len(targets) != 1:
+        raise ClientError("invalid ConstraintTemplate: expected exactly 1 target, got %d" % len(targets))
+    tg = targets[0]
+    rego, libs = None, []
+    for code in tg.get("code") or []:
+        if code.get("engine") == "Rego":
+            src = code.get("source") or {}
+            rego, libs = src.get("rego"), list(src.get("libs") or [])
+    if rego is None:
+        rego, libs = tg.get("rego"), list(tg.get("libs") or [])
+    return kind, tg.get("target"), rego, libs
+
+
+class Driver:
+    """drivers.Driver backed by the MI355X engine."""
+
+    RUN_TIME_NS = "templateRunTimeNS"
+
+    def __init__(self, device=0, gather_stats=False, hostemu=None, elem_cap=None):
+        self.engine = Engine(device, elem_cap=elem_cap, hostemu=hostemu)
+        self.gather_stats = gather_stats
+        self._ids = {}   # (kind, name) -> engine constraint id
+
+    def Name(self):
+        return "Rego"
+
+    def AddTemplate(self, ct):
+        kind, _, rego, libs = template_source(ct)
+        if not rego:
+            raise ClientError("template %s has no Rego source" % kind)
+        self.engine.add_template(kind, rego, libs)
+
+    def RemoveTemplate(self, ct):
+        kind, _, _, _ = template_source(ct)
+        try:
+            self.engine.remove_template(kind)
+        except EngineError as e:
+            if e.code != L.GK_ERR_NOT_FOUND:
+                raise
+        for k in [k for k in self._ids if k[0].lower() == kind.lower()]:
+            del self._ids[k]
+
+    def AddConstraint(self, constraint):
+        cid = self.engine.add_constraint(constraint)
+        self._ids[(constraint.get("kind", ""), (constraint.get("metadata") or {}).get("name", ""))] = cid
+        return cid
+
+    def RemoveConstraint(self, constraint):
+        key = (constraint.get("kind", ""), (constraint.get("metadata") or {}).get("name", ""))
+        if key in self._ids:
+            self.engine.remove_constraint(*key)
+            del self._ids[key]
+
+    def AddData(self, target, path, data):
+        self.engine.put_data(list(path), data)
+
+    def RemoveData(self, target, path):
+        self.engine.remove_data(list(path))
+
+    def constraint_id(self, constraint):
+        key = (constraint.get("kind", ""), (constraint.get("metadata") or {}).get("name", ""))
+        if key not in self._ids:
+            raise EngineError(L.GK_ERR_NOT_FOUND, "unknown constraint template validator: %s" % constraint.get("kind"))
+        return self._ids[key]
+
+    def Query(self, target, constraints, review, namespace=None, stats_enabled=False):
+        """One review against the (already matched) constraints -> QueryResponse.  The device evaluates match AND
+        violation for every loaded constraint; rows for constraints not asked about are ignored."""
+        rin = to_review_in(review, namespace)
+        if rin is None:
+            raise EngineError(L.GK_ERR_INVALID, "cannot convert review to ARGetter")
+        table = self.engine.create_table([rin])
+        try:
+            if table.statuses[0] != L.GK_OK:
+                raise EngineError(L.GK_ERR_REVIEW, "review rejected by HandleReview")
+            ev = table.eval()
+            wanted = {self.constraint_id(c): c for c in constraints}
+            results = []
+            for cid, _ in ev.pairs("viol"):
+                if cid in wanted:
+                    for v in table.render(cid, 0):
+                        results.append(Result(v["msg"], wanted[cid], v.get("details", {})))
+            stats = []
+            if self.gather_stats or stats_enabled:
+                stats.append({"scope": "template", "statsFor": "batch", "stats": [
+                    {"name": self.RUN_TIME_NS, "value": int(ev.kernel_ms * 1e6),
+                     "source": {"type": "engine", "value": self.Name()}}], "labels": [{"name": "target", "value": target}]})
+            return QueryResponse(results, stats)
+        finally:
+            table.free()
+
+    def Dump(self):
+        return self.engine.dump()
+
+    def GetDescriptionForStat(self, stat_name):
+        if stat_name == self.RUN_TIME_NS:
+            return "the number of nanoseconds the device kernels took to evaluate all constraints for a batch of reviews"
+        raise ClientError("unknown stat name for Rego: %s" % stat_name)
+
+
+# ---------------------------------------------------------------------------------------------- Client mirror
+def get_enforcement_action(c):
+    """pkg/util/enforcement_action.go:132-151"""
+    spec = c.get("spec") if isinstance(c.get("spec"), dict) else {}
+    ea = spec.get("enforcementAction", "")
+    if ea == "":
+        return "deny"
+    return ea if ea in ("deny", "dryrun", "warn", "scoped") else "unrecognized"
+
+
+def scoped_actions_for_ep(ep, c):
+    """pkg/util/enforcement_action.go:153-174"""
+    spec = c.get("spec") if isinstance(c.get("spec"), dict) else {}
+    out = []
+    for sea in spec.get("scopedEnforcementActions") or []:
+        for p in sea.get("enforcementPoints") or []:
+            if p.get("name") in (ep, ALL_EP):
+                out.append(sea.get("action"))
+                break
+    return out
+
+
+def _default(schema, value):
+    if not isinstance(schema, dict):
+        return value
+    if isinstance(value, dict):
+        props = schema.get("properties") or {}
+        for k, sub in props.items():
+            if k not in value and isinstance(sub, dict) and "default" in sub:
+                value[k] = copy.deepcopy(sub["default"])
+            if k in value:
+                value[k] = _default(sub, value[k])
+        addl = schema.get("additionalProperties")
+        if isinstance(addl, dict):
+            for k in value:
+                if k not in props:
+                    value[k] = _default(addl, value[k])
+    elif isinstance(value, list):
+        items = schema.get("items")
+        if isinstance(items, dict):
+            value = [_default(items, v) for v in value]
+    return value
+
+
+def apply_schema_defaults(ct, c):
+    """Client.AddConstraint applies the template CRD's OpenAPI-v3 defaults before the driver sees the constraint
+    (pinned by test/gator/test/test.bats:277-291)."""
+    try:
+        schema = ct["spec"]["crd"]["spec"]["validation"]["openAPIV3Schema"]
+    except (KeyError, TypeError):
+        return c
+    if not isinstance(schema, dict):
+        return c
+    c = copy.deepcopy(c)
+    spec = c.get("spec")
+    if not isinstance(spec, dict):
+        if "default" not in json.dumps(schema):
+            return c
+        spec = c["spec"] = {}
+    if "parameters" not in spec:
+        if "default" in schema:
+            spec["parameters"] = copy.deepcopy(schema["default"])
+        else:
+            return c
+    spec["parameters"] = _default(schema, spec["parameters"])
+    return c
+
+
+def process_data(obj):
+    """K8sValidationTarget.ProcessData (pkg/target/target.go:40-79) -> inventory path"""
+    api = obj.get("apiVersion", "") if isinstance(obj.get("apiVersion"), str) else ""
+    kind = obj.get("kind", "") if isinstance(obj.get("kind"), str) else ""
+    md = obj.get("metadata") if isinstance(obj.get("metadata"), dict) else {}
+    name = md.get("name", "") if isinstance(md.get("name"), str) else ""
+    ns = md.get("namespace", "") if isinstance(md.get("namespace"), str) else ""
+    version = api.split("/")[-1] if api.count("/") <= 1 else ""
+    if version == "":
+        raise ClientError("invalid request object: resource %s has no version" % name)
+    if kind == "":
+        raise ClientError("invalid request object: resource %s has no kind" % name)
+    gv = api if "/" in api and not api.startswith("/") else version
+    if ns == "":
+        return ["cluster", gv, kind, name]
+    return ["namespace", ns, gv, kind, name]
+
+
+class Client:
+    """constraintclient.Client for the single K8sValidationTarget, evaluating on the device."""
+
+    def __init__(self, driver=None, enforcement_points=(WEBHOOK_EP, AUDIT_EP, GATOR_EP), hostemu=None):
+        self.driver = driver or Driver(hostemu=hostemu)
+        self.templates = {}
+        self.constraints = {}   # (kind, name) -> constraint (defaulted)
+        self.enforcement_points = tuple(enforcement_points)
+
+    def AddTemplate(self, ct):
+        kind, target, _, _ = template_source(ct)
+        name = (ct.get("metadata") or {}).get("name", "")
+        if name != kind.lower():
+            raise ClientError("the ConstraintTemplate's name must be the lowercase of kind: got %r for kind %r" % (name, kind))
+        if target != TARGET_NAME:
+            raise ClientError("unknown target %r" % target)
+        try:
+            self.driver.AddTemplate(ct)
+        except EngineError as e:
+            if isinstance(e, UnsupportedError):
+                raise
+            raise ClientError(str(e))
+        self.templates[kind.lower()] = ct
+
+    def RemoveTemplate(self, ct):
+        kind, _, _, _ = template_source(ct)
+        self.driver.RemoveTemplate(ct)
+        self.templates.pop(kind.lower(), None)
+        for k in [k for k in self.constraints if k[0].lower() == kind.lower()]:
+            del self.constraints[k]
+
+    def AddConstraint(self, c):
+        kind = c.get("kind", "")
+        if kind.lower() not in self.templates:
+            raise ClientError("missing ConstraintTemplate: %s" % kind)   # ErrMissingConstraintTemplate
+        c = apply_schema_defaults(self.templates[kind.lower()], c)
+        self.driver.AddConstraint(c)
+        self.constraints[(kind, (c.get("metadata") or {}).get("name", ""))] = c
+
+    def RemoveConstraint(self, c):
+        self.driver.RemoveConstraint(c)
+        self.constraints.pop((c.get("kind", ""), (c.get("metadata") or {}).get("name", "")), None)
+
+    def AddData(self, obj):
+        self.driver.AddData(TARGET_NAME, process_data(obj), dict(obj))
+
+    def RemoveData(self, obj):
+        self.driver.RemoveData(TARGET_NAME, process_data(obj))
+
+    def ReviewBatch(self, objs, enforcement_point=AUDIT_EP, namespaces=None):
+        """Review many objects in ONE device launch (the shape the audit sweep takes). -> list[list[Result]]"""
+        rins, idx = [], []
+        for i, o in enumerate(objs):
+            r = to_review_in(o, namespaces[i] if namespaces else None)
+            if r is not None:
+                rins.append(r)
+                idx.append(i)
+        out = [[] for _ in objs]
+        if not rins:
+            return out
+        table = self.driver.engine.create_table(rins)
+        try:
+            for k, st in enumerate(table.statuses):
+                if st != L.GK_OK:
+                    raise ClientError("review %d rejected by HandleReview" % idx[k])   # ErrReview
+            ev = table.eval()
+            by_id = {self.driver.constraint_id(c): c for c in self.constraints.values()}
+            info = {}
+            for cid, c in by_id.items():
+                ea = get_enforcement_action(c)
+                scoped = None
+                if ea == "scoped":
+                    scoped = scoped_actions_for_ep(enforcement_point, c)
+                    if not scoped:
+                        continue
+                info[cid] = (c, ea, scoped)
+            for cid, r in ev.pairs("err"):
+                if cid in info:
+                    c, ea, scoped = info[cid]
+                    for v in table.render_error(cid, r):
+                        out[idx[r]].append(Result(v["msg"], c, {}, ea, scoped))
+            for cid, r in ev.pairs("viol"):
+                if cid in info:
+                    c, ea, scoped = info[cid]
+                    for v in table.render(cid, r):
+                        out[idx[r]].append(Result(v["msg"], c, v.get("details", {}), ea, scoped))
+            return out
+        finally:
+            table.free()
+
+    def Review(self, obj, enforcement_point=AUDIT_EP, namespace=None):
+        return self.ReviewBatch([obj], enforcement_point, [namespace])[0]

@@ -1,0 +1,304 @@
+"""Synthetic workloads for BASELINE.json's configs: deterministic SplitMix64 generator.
+
+  config[1]  30 PSP constraints (5 in-tree PSP templates x 6 parameterisations) x N synthetic Pod reviews
+  config[2]  50 constraints (the 30 + 20 with heavier match blocks) x N mixed cluster objects (audit sweep)
+
+The PSP templates themselves are the reference's own policy fixtures
+(pkg/webhook/testdata/psp-all-violations/psp-templates/*.yaml), shipped as data in tests/golden/reference_fixtures.json
+because /root/reference does not exist on the GPU box.  Constraint parameterisations and objects are generated here.
+Shared by bench.py, __graft_entry__.smoke() and tests/ so that every leg sees identical inputs.
+"""
+from __future__ import annotations
+
+import json
+import os
+
+SEED = 0x6B8E9C4A
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PSP_DIR = "pkg/webhook/testdata/psp-all-violations/"
+
+
+class SplitMix64:
+    def __init__(self, seed=SEED):
+        self.s = seed & 0xFFFFFFFFFFFFFFFF
+
+    def next(self):
+        self.s = (self.s + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+        z = self.s
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+        return z ^ (z >> 31)
+
+    def uniform(self):
+        return (self.next() >> 11) / float(1 << 53)
+
+    def below(self, n):
+        return self.next() % n
+
+    def chance(self, p):
+        return self.uniform() < p
+
+    def pick(self, seq):
+        return seq[self.below(len(seq))]
+
+    def weighted(self, pairs):
+        u = self.uniform()
+        acc = 0.0
+        for v, p in pairs:
+            acc += p
+            if u < acc:
+                return v
+        return pairs[-1][0]
+
+
+def load_fixtures():
+    with open(os.path.join(_ROOT, "tests", "golden", "reference_fixtures.json"), encoding="utf-8") as fh:
+        return json.load(fh)
+
+
+# ------------------------------------------------------------------------------------------------ namespaces
+NAMESPACES = (["kube-%s" % s for s in ("system", "public", "node-lease", "proxy", "dns")] +
+              ["prod-%02d" % i for i in range(30)] + ["dev-%02d" % i for i in range(30)] +
+              ["team-%02d" % i for i in range(35)])
+LABEL_KEYS = ["app", "tier", "env", "team", "owner", "release", "track", "zone", "region", "cost-center", "app.kubernetes.io/name",
+              "app.kubernetes.io/part-of", "app.kubernetes.io/managed-by", "chart", "heritage", "component", "role", "version",
+              "stage", "project", "squad", "domain", "criticality", "pci", "gdpr", "tenant", "cluster", "shard", "canary",
+              "backup", "monitored", "sidecar"]
+LABEL_VALUES = ["a", "b", "prod", "dev", "web", "db", "cache", "true", "false", "blue", "green", "v1", "v2", "core", "edge", "x"]
+HOST_PATHS = ["/tmp", "/foo", "/foo/bar", "/var/log", "/etc"]
+IMAGES = ["nginx", "nginx:1.25", "openpolicyagent/opa:0.9.2", "gcr.io/proj/app:latest", "quay.io/org/tool:v3", "busybox"]
+
+
+def gen_namespaces():
+    """100 Namespace objects with deterministic labels (env / team / pci)."""
+    rng = SplitMix64(SEED ^ 0x5A5A)
+    out = {}
+    for name in NAMESPACES:
+        labels = {"kubernetes.io/metadata.name": name}
+        labels["env"] = "prod" if name.startswith("prod") else "dev" if name.startswith("dev") else "shared"
+        if rng.chance(0.5):
+            labels["team"] = "team-%d" % rng.below(8)
+        if rng.chance(0.2):
+            labels["pci"] = "true"
+        out[name] = {"apiVersion": "v1", "kind": "Namespace", "metadata": {"name": name, "labels": labels}}
+    return out
+
+
+def _labels(rng):
+    n = 2 + rng.below(5)
+    out = {}
+    for _ in range(n):
+        out[rng.pick(LABEL_KEYS)] = rng.pick(LABEL_VALUES)
+    return out
+
+
+def _container(rng, idx, vol_names, init=False):
+    c = {"name": ("init-%d" if init else "c%d") % idx, "image": rng.pick(IMAGES)}
+    if rng.chance(0.6):
+        sc = {}
+        if rng.chance(0.05 / 0.6):
+            sc["privileged"] = True
+        elif rng.chance(0.3):
+            sc["privileged"] = False
+        if rng.chance(0.3):
+            sc["runAsNonRoot"] = True
+        if rng.chance(0.2):
+            sc["allowPrivilegeEscalation"] = False
+        c["securityContext"] = sc
+    nports = rng.weighted([(0, 0.4), (1, 0.4), (2, 0.2)])
+    if nports:
+        ports = []
+        for _ in range(nports):
+            p = {"containerPort": 1 + rng.below(65535)}
+            if rng.chance(0.05):
+                p["hostPort"] = 1 + rng.below(65535)
+            if rng.chance(0.3):
+                p["protocol"] = "TCP"
+            ports.append(p)
+        c["ports"] = ports
+    if vol_names:
+        mounts = []
+        for vn in vol_names:
+            if rng.chance(0.6):
+                m = {"name": vn, "mountPath": "/mnt/" + vn}
+                if rng.chance(0.5):
+                    m["readOnly"] = rng.chance(0.8)
+                mounts.append(m)
+        if mounts:
+            c["volumeMounts"] = mounts
+    if rng.chance(0.5):
+        c["resources"] = {"limits": {"cpu": rng.pick(["100m", "200m", "1", "2"]), "memory": rng.pick(["128Mi", "1Gi", "2Gi"])}}
+    if rng.chance(0.3):
+        c["env"] = [{"name": "E%d" % k, "value": rng.pick(LABEL_VALUES)} for k in range(1 + rng.below(3))]
+    return c
+
+
+def _pod_spec(rng):
+    nvol = rng.weighted([(0, 0.4), (1, 0.3), (2, 0.2), (3, 0.1)])
+    vols = []
+    for v in range(nvol):
+        vt = rng.weighted([("configMap", 0.3), ("secret", 0.25), ("emptyDir", 0.25), ("hostPath", 0.1), ("persistentVolumeClaim", 0.1)])
+        vol = {"name": "vol-%d" % v}
+        if vt == "configMap":
+            vol[vt] = {"name": "cm-%d" % rng.below(20)}
+        elif vt == "secret":
+            vol[vt] = {"secretName": "s-%d" % rng.below(20)}
+        elif vt == "emptyDir":
+            vol[vt] = {}
+        elif vt == "hostPath":
+            vol[vt] = {"path": rng.pick(HOST_PATHS)}
+        else:
+            vol[vt] = {"claimName": "pvc-%d" % rng.below(20)}
+        vols.append(vol)
+    names = [v["name"] for v in vols]
+    nc = rng.weighted([(1, 0.5), (2, 0.3), (3, 0.15), (4, 0.05)])
+    spec = {"containers": [_container(rng, i, names) for i in range(nc)]}
+    if rng.chance(0.2):
+        spec["initContainers"] = [_container(rng, 0, names, init=True)]
+    if vols:
+        spec["volumes"] = vols
+    if rng.chance(0.03):
+        spec["hostNetwork"] = True
+    if rng.chance(0.02):
+        spec["hostPID"] = True
+    if rng.chance(0.02):
+        spec["hostIPC"] = True
+    if rng.chance(0.3):
+        spec["serviceAccountName"] = "sa-%d" % rng.below(10)
+    if rng.chance(0.3):
+        spec["restartPolicy"] = "Always"
+    return spec
+
+
+def gen_pod(rng, i):
+    ns = rng.pick(NAMESPACES)
+    md = {"name": "pod-%07d" % i, "namespace": ns, "labels": _labels(rng)}
+    if rng.chance(0.2):
+        md["annotations"] = {"note": "generated"}
+    return {"apiVersion": "v1", "kind": "Pod", "metadata": md, "spec": _pod_spec(rng)}
+
+
+def gen_objects(n, seed=SEED, mixed=False):
+    """n synthetic objects. mixed=False: all Pods (config[1]). mixed=True: 80% Pod, 10% Deployment, 5% Namespace,
+    5% Service/ConfigMap (config[2], the audit sweep)."""
+    rng = SplitMix64(seed)
+    out = []
+    for i in range(n):
+        kind = "Pod"
+        if mixed:
+            kind = rng.weighted([("Pod", 0.8), ("Deployment", 0.1), ("Namespace", 0.05), ("Service", 0.025), ("ConfigMap", 0.025)])
+        if kind == "Pod":
+            out.append(gen_pod(rng, i))
+        elif kind == "Deployment":
+            pod = gen_pod(rng, i)
+            out.append({"apiVersion": "apps/v1", "kind": "Deployment",
+                        "metadata": {"name": "dep-%07d" % i, "namespace": pod["metadata"]["namespace"], "labels": pod["metadata"]["labels"]},
+                        "spec": {"replicas": 1 + rng.below(5), "template": {"metadata": {"labels": pod["metadata"]["labels"]}, "spec": pod["spec"]}}})
+        elif kind == "Namespace":
+            out.append({"apiVersion": "v1", "kind": "Namespace", "metadata": {"name": "gen-ns-%07d" % i, "labels": _labels(rng)}})
+        elif kind == "Service":
+            out.append({"apiVersion": "v1", "kind": "Service", "metadata": {"name": "svc-%07d" % i, "namespace": rng.pick(NAMESPACES)},
+                        "spec": {"ports": [{"port": 80 + rng.below(1000)}], "selector": {"app": rng.pick(LABEL_VALUES)}}})
+        else:
+            out.append({"apiVersion": "v1", "kind": "ConfigMap", "metadata": {"name": "cm-%07d" % i, "namespace": rng.pick(NAMESPACES)},
+                        "data": {"k%d" % k: rng.pick(LABEL_VALUES) for k in range(1 + rng.below(4))}})
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ policies
+_POD_KINDS = [{"apiGroups": [""], "kinds": ["Pod"]}]
+
+_MATCH_VARIANTS = [
+    {"kinds": _POD_KINDS},
+    {"kinds": _POD_KINDS, "excludedNamespaces": ["kube-*"]},
+    {"kinds": _POD_KINDS, "namespaces": ["prod-*", "team-0*"]},
+    {"kinds": _POD_KINDS, "labelSelector": {"matchExpressions": [{"key": "canary", "operator": "DoesNotExist"}]}},
+    {"kinds": _POD_KINDS, "namespaceSelector": {"matchLabels": {"env": "prod"}}},
+    {"kinds": [{"apiGroups": ["*"], "kinds": ["*"]}], "scope": "Namespaced", "excludedNamespaces": ["*-system", "dev-1*"]},
+]
+
+_PARAMS = {
+    "K8sPSPHostFilesystem": [
+        {"allowedHostPaths": [{"readOnly": True, "pathPrefix": "/foo"}]},
+        {"allowedHostPaths": [{"pathPrefix": "/var/log"}]},
+        {"allowedHostPaths": []},
+        {"allowedHostPaths": [{"pathPrefix": "/tmp"}, {"readOnly": True, "pathPrefix": "/etc"}]},
+        {"allowedHostPaths": [{"readOnly": True, "pathPrefix": "/"}]},
+        {"allowedHostPaths": [{"readOnly": False, "pathPrefix": "/foo/bar"}, {"pathPrefix": "/var"}]},
+    ],
+    "K8sPSPHostNamespace": [None] * 6,
+    "K8sPSPHostNetworkingPorts": [
+        {"hostNetwork": True, "min": 80, "max": 9000},
+        {"hostNetwork": False, "min": 80, "max": 9000},
+        {"hostNetwork": False, "min": 1, "max": 65535},
+        {"hostNetwork": True, "min": 1024, "max": 32767},
+        {"hostNetwork": False},
+        {"hostNetwork": True, "min": 30000, "max": 30100},
+    ],
+    "K8sPSPPrivilegedContainer": [None] * 6,
+    "K8sPSPVolumeTypes": [
+        {"volumes": ["configMap", "emptyDir", "projected", "secret", "downwardAPI", "persistentVolumeClaim", "flexVolume"]},
+        {"volumes": ["*"]},
+        {"volumes": ["configMap", "secret"]},
+        {"volumes": ["emptyDir", "hostPath", "persistentVolumeClaim"]},
+        {"volumes": []},
+        {"volumes": ["configMap", "emptyDir", "secret", "hostPath"]},
+    ],
+}
+
+
+def psp_templates(fixtures=None):
+    fx = fixtures or load_fixtures()
+    return [fx["yaml"][p]["docs"][0] for p in sorted(fx["yaml"]) if p.startswith(PSP_DIR + "psp-templates/")]
+
+
+def psp_constraints():
+    """config[1]: 5 PSP template kinds x 6 parameterisations = 30 constraints."""
+    out = []
+    for kind in sorted(_PARAMS):
+        for k, params in enumerate(_PARAMS[kind]):
+            spec = {"match": _MATCH_VARIANTS[k]}
+            if params is not None:
+                spec["parameters"] = params
+            out.append({"apiVersion": "constraints.gatekeeper.sh/v1beta1", "kind": kind,
+                        "metadata": {"name": "%s-%d" % (kind.lower(), k)}, "spec": spec})
+    return out
+
+
+def audit_constraints():
+    """config[2]: the 30 above + 20 with heavier match blocks (globs, selectors, multi-kind, enforcement actions)."""
+    out = psp_constraints()
+    kinds = sorted(_PARAMS)
+    extra_match = [
+        {"kinds": [{"apiGroups": [""], "kinds": ["Pod"]}, {"apiGroups": ["apps"], "kinds": ["Deployment"]}], "namespaces": ["*-0*"]},
+        {"kinds": _POD_KINDS, "labelSelector": {"matchLabels": {"env": "prod"}}},
+        {"kinds": _POD_KINDS, "labelSelector": {"matchExpressions": [{"key": "tier", "operator": "In", "values": ["web", "db"]}]}},
+        {"kinds": _POD_KINDS, "labelSelector": {"matchExpressions": [{"key": "team", "operator": "NotIn", "values": ["a", "b"]},
+                                                                     {"key": "app", "operator": "Exists"}]}},
+        {"kinds": _POD_KINDS, "namespaceSelector": {"matchExpressions": [{"key": "pci", "operator": "Exists"}]}},
+        {"kinds": _POD_KINDS, "namespaceSelector": {"matchLabels": {"env": "dev"}}, "excludedNamespaces": ["dev-2*"]},
+        {"kinds": _POD_KINDS, "name": "pod-00*"},
+        {"kinds": _POD_KINDS, "name": "*7"},
+        {"kinds": _POD_KINDS, "scope": "Cluster"},
+        {"kinds": _POD_KINDS, "namespaces": ["team-*"], "excludedNamespaces": ["team-1*", "team-2*"], "source": "Original"},
+    ]
+    for k in range(20):
+        kind = kinds[k % 5]
+        params = _PARAMS[kind][(k // 5) % 6]
+        spec = {"match": extra_match[k % len(extra_match)]}
+        if params is not None:
+            spec["parameters"] = params
+        if k % 4 == 1:
+            spec["enforcementAction"] = "dryrun"
+        elif k % 4 == 2:
+            spec["enforcementAction"] = "warn"
+        out.append({"apiVersion": "constraints.gatekeeper.sh/v1beta1", "kind": kind,
+                    "metadata": {"name": "%s-x%d" % (kind.lower(), k)}, "spec": spec})
+    return out
+
+
+def namespace_for(obj, namespaces):
+    """The *corev1.Namespace the audit loop attaches (pkg/audit/manager.go:694-705): looked up by the object's
+    namespace; None for cluster-scoped objects or unknown namespaces."""
+    ns = (obj.get("metadata") or {}).get("namespace")
+    return namespaces.get(ns) if ns else None

@@ -1,0 +1,134 @@
+/* gkgpu.h -- C ABI of the MI355X-native constraint-evaluation engine (libgkgpu.so).
+ *
+ * This is the drop-in boundary a Go `drivers.Driver` (Name()=="Rego") binds through cgo; INTEGRATION.md shows the
+ * shim.  Each entry point cites the reference interface it replaces.  Plain pointers and sizes only; the callee
+ * copies whatever it retains; outputs are callee-allocated and released with the matching *_free.  All entry points
+ * are re-entrant; errors are negative gk_status codes plus gk_last_error() text (thread-local), never exceptions.
+ */
+#ifndef GKGPU_H
+#define GKGPU_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gk_engine gk_engine;   /* opaque, thread-safe */
+typedef struct gk_table gk_table;     /* opaque: a flattened, HBM-resident set of reviews */
+
+typedef enum {
+  GK_OK = 0,
+  GK_ERR_INVALID = -1,      /* bad argument / malformed JSON */
+  GK_ERR_REGO = -2,         /* template does not parse / compile (AddTemplate error, driver.go:74-137) */
+  GK_ERR_UNSUPPORTED = -3,  /* template/constraint uses constructs the device plan cannot express: the caller keeps
+                               it on the reference CPU driver -- this engine never approximates and never falls back */
+  GK_ERR_NOT_FOUND = -4,    /* unknown template kind / constraint (driver.go:198-200) */
+  GK_ERR_DEVICE = -5,       /* no MI355X / HIP failure */
+  GK_ERR_REVIEW = -6,       /* review rejected by HandleReview (target.go:81-138, e.g. ErrOldObjectIsNil) */
+  GK_ERR_INTERNAL = -7
+} gk_status;
+
+typedef struct {
+  int32_t device;          /* HIP device ordinal (one engine per GPU; one process per GPU under torch.distributed) */
+  uint16_t elem_cap[3];    /* LDS element capacity per array-nesting level; 0 = default (16, 32, 32) */
+  uint16_t reserved;
+} gk_opts;
+
+/* ---- lifecycle ------------------------------------------------------------------------------------------- */
+/* replaces rego.New(args...) at main.go:486, pkg/gator/opa.go:32, pkg/gator/test/test.go:48 */
+int gk_engine_create(const gk_opts* opts, gk_engine** out);
+void gk_engine_destroy(gk_engine* e);
+const char* gk_last_error(void);
+const char* gk_version(void);
+
+/* ---- policy state (drivers.Driver Add/Remove*, boundary exemplar pkg/drivers/k8scel/driver.go:74-160) ----- */
+/* Driver.AddTemplate: kind as in spec.crd.spec.names.kind; rego + libs from Source.Value{"rego","libs"}
+ * (pkg/fakes/fixtures.go:35-41).  Parses and statically checks the Rego. */
+int gk_template_add(gk_engine* e, const char* kind, const char* rego, const char* const* libs, size_t nlibs);
+/* Driver.RemoveTemplate */
+int gk_template_remove(gk_engine* e, const char* kind);
+/* Driver.AddConstraint: constraint object JSON AFTER the client applied CRD defaults.
+ * Compiles spec.match (pkg/target/target.go:246-261, pkg/mutation/match/match.go:32-258) and the template's
+ * violation rule specialised to spec.parameters.  Returns GK_ERR_UNSUPPORTED if it cannot run on the device. */
+int gk_constraint_add(gk_engine* e, const char* constraint_json, size_t len, uint32_t* id_out);
+/* Driver.RemoveConstraint */
+int gk_constraint_remove(gk_engine* e, const char* kind, const char* name);
+/* Driver.AddData / RemoveData with the path of K8sValidationTarget.ProcessData (pkg/target/target.go:40-66):
+ * ["cluster",gv,kind,name] or ["namespace",ns,gv,kind,name].  Namespace objects feed the nsCache
+ * (pkg/target/ns_cache.go:22-43); everything is kept as data.inventory for host-side rendering. */
+int gk_data_put(gk_engine* e, const char* const* path, size_t npath, const char* json, size_t len);
+int gk_data_remove(gk_engine* e, const char* const* path, size_t npath);
+
+/* ---- reviews --------------------------------------------------------------------------------------------- */
+typedef enum { GK_SRC_EMPTY = 0, GK_SRC_ORIGINAL = 1, GK_SRC_GENERATED = 2, GK_SRC_ALL = 3, GK_SRC_INVALID = 4 } gk_source;
+typedef enum {
+  GK_REVIEW_ADMISSION_REQUEST = 0,  /* json = admissionv1.AdmissionRequest (gkReview / AugmentedReview shapes) */
+  GK_REVIEW_OBJECT = 1              /* json = bare object (Unstructured / AugmentedUnstructured shapes, target.go:140-179) */
+} gk_review_kind;
+
+/* one input of K8sValidationTarget.HandleReview (pkg/target/target.go:81-138, pkg/target/review.go:9-29) */
+typedef struct {
+  int32_t kind;                 /* gk_review_kind */
+  int32_t source;               /* gk_source: gkReview.source / AugmentedUnstructured.Source */
+  const char* json;             size_t json_len;
+  const char* namespace_json;   size_t namespace_len;    /* gkReview.namespace (*corev1.Namespace) or NULL */
+  const char* ns_object_json;   size_t ns_object_len;    /* reviews.Namespace(nsMap) option -> input.review.namespaceObject, or NULL */
+  const char* operation;        /* AugmentedUnstructured.Operation ("" / NULL = none) */
+} gk_review_in;
+
+/* Flatten n reviews into key-path -> value SoA rows and upload them to HBM (they stay resident until freed).
+ * A review that HandleReview rejects gets status GK_ERR_REVIEW in statuses[i] (may be NULL) and evaluates to nothing. */
+int gk_table_create(gk_engine* e, const gk_review_in* reviews, size_t n, uint32_t flags, int32_t* statuses, gk_table** out);
+void gk_table_free(gk_table* t);
+#define GK_TABLE_KEEP_DOCS 1u   /* keep parsed reviews on the host so violations can be rendered to messages */
+
+typedef struct {
+  uint32_t n_reviews, n_constraints, n_tiles;   /* n_tiles = ceil(n_reviews / 64) */
+  const uint32_t* constraint_ids;   /* [n_constraints] ids as returned by gk_constraint_add, in bitmap-row order */
+  const uint64_t* viol;      /* [n_constraints][n_tiles]: bit (r%64) of word (r/64): constraint applies AND is violated */
+  const uint64_t* err;       /* same layout: Matcher.Match error (autoreject, "unable to match constraints: ...") */
+  const uint64_t* match;     /* same layout, only with GK_EVAL_WANT_MATCH */
+  const uint64_t* too_big;   /* [n_tiles]: reviews beyond engine limits (reported, never guessed) */
+  const uint32_t* counts;    /* [n_constraints] violating reviews per constraint */
+  const uint32_t* list;      /* list_len pairs (bitmap row, review): ballot/prefix-sum compacted violation list */
+  uint32_t list_len, list_total;
+  uint32_t n_overflow;       /* reviews evaluated by the large-capacity kernel variant */
+  float kernel_ms;           /* device time of the evaluation kernels (HIP events on the launch stream) */
+  float fast_kernel_ms;      /* ... of the dominant LDS kernel alone */
+  uint64_t algo_bytes;       /* algorithmic bytes of this launch (DESIGN.md "Roofline accounting") */
+  uint64_t n_rows;
+  uint32_t n_launches;       /* launches averaged in fast_kernel_ms (GK_EVAL_ASYNC enqueues without collecting) */
+  uint32_t reserved;
+  const void* d_viol;        /* device pointers to the same bitmaps / counts, valid until the table's next launch: */
+  const void* d_err;         /* lets the caller hand them to RCCL (all-gather of per-shard violation bitmaps)      */
+  const void* d_counts;
+} gk_eval_out;
+
+#define GK_EVAL_WANT_MATCH 1u
+#define GK_EVAL_NO_DOWNLOAD 2u   /* leave results on the device (timing runs) */
+#define GK_EVAL_WANT_LIST 4u
+#define GK_EVAL_ASYNC 8u         /* enqueue one launch on the default stream and return (out = NULL); the next call
+                                    without this flag synchronises, and reports the average kernel time per launch */
+
+/* The hot path: every loaded constraint x every review of the table -- Match (a3-a7) + violation predicate (a8/a9).
+ * Replaces the per-object Client.Review loops at pkg/audit/manager.go:591-642,706-719 and pkg/webhook/policy.go:826. */
+int gk_table_eval(gk_engine* e, gk_table* t, uint32_t flags, gk_eval_out** out);
+void gk_eval_free(gk_eval_out* o);
+
+/* Driver.Query result rendering for one (constraint, review) pair flagged in `viol`: evaluates the template on the
+ * host for that pair only and returns a JSON array [{"msg": "...", "details": ...}] (types.Result.Msg / Metadata).
+ * Needs GK_TABLE_KEEP_DOCS. */
+int gk_render(gk_engine* e, gk_table* t, uint32_t constraint_id, uint32_t review, char** json_out);
+/* The autoreject result for a pair flagged in `err` (frameworks Client.Review turns a Matcher.Match error into a
+ * result; message pinned by test/gator/test/test.bats:301): [{"msg": "unable to match constraints: ...", ...}] */
+int gk_render_error(gk_engine* e, gk_table* t, uint32_t constraint_id, uint32_t review, char** json_out);
+void gk_free(void* p);
+
+/* Debug: the compiled plan as text (Driver.Dump, pkg/drivers/k8scel/driver.go:253). */
+int gk_dump(gk_engine* e, char** text_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GKGPU_H */

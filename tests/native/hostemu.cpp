@@ -1,0 +1,86 @@
+// TEST-ONLY CPU implementation of device.hpp (see vm_core.hpp).  Built into libgkgpu_hostemu.so, which exists so the
+// AOT compiler, the flattener and the formula VM can be checked against the oracle in the GPU-less build container.
+// It executes exactly the same per-row / per-review code as kernels.hip, lane by lane.  The product library
+// (libgkgpu.so) never contains this file; gatekeeper_amd/_lib.py refuses to load it outside tests.
+#include <chrono>
+#include <cstring>
+#include <stdexcept>
+
+#include "device.hpp"
+#include "vm_core.hpp"
+
+namespace gk {
+
+struct DevTable { HostTable t; int pending = 0; };
+struct DevPlan { HostPlan fast, big; };
+
+struct VecAcc {
+  std::vector<uint32_t>* w;
+  void or_word(uint32_t i, uint32_t m) { (*w)[i] |= m; }
+  void max_word(uint32_t i, uint32_t v) { if ((*w)[i] < v) (*w)[i] = v; }
+  void store_word(uint32_t i, uint32_t v) { (*w)[i] = v; }
+  uint32_t load(uint32_t i) const { return (*w)[i]; }
+};
+
+std::string dev_init(int) { return ""; }
+int dev_count() { return 0; }
+DevTable* dev_table_upload(const HostTable& t) { DevTable* d = new DevTable(); d->t = t; d->t.heap.resize(d->t.heap.size() + 16, 0); return d; }
+void dev_table_free(DevTable* t) { delete t; }
+uint64_t dev_table_bytes(const DevTable* t) { return t->t.rows.size() * 16 + t->t.heap.size(); }
+DevPlan* dev_plan_upload(const HostPlan& fast, const HostPlan& big) { DevPlan* p = new DevPlan(); p->fast = fast; p->big = big; return p; }
+void dev_plan_free(DevPlan* p) { delete p; }
+
+static PlanView view_of(const HostPlan& h) {
+  return PlanView{h.ptab.data(), h.pred_list.data(), h.preds.data(), h.scopes.data(), h.code.data(), h.cheap.data(), h.dims};
+}
+
+static bool eval_review(const HostPlan& hp, const HostTable& t, uint32_t r, Results* res) {
+  PlanView pv = view_of(hp);
+  std::vector<uint32_t> words(hp.dims.acc_words, 0);
+  VecAcc acc{&words};
+  for (uint32_t i = t.hdrs[r].row_start; i < t.hdrs[r + 1].row_start; i++) eval_row(t.rows[i], pv, t.heap.data(), acc);
+  if (words[0] & 1u) return false;   // overflow
+  uint32_t bounds[GK_MAX_SCOPES] = {0};
+  for (uint32_t s = 0; s < hp.dims.n_scopes; s++) bounds[s] = words[hp.scopes[s].count_off];
+  *res = eval_formulas(pv, acc, t.hdrs[r].flags, t.heap.data(), bounds);
+  return true;
+}
+
+void dev_eval_launch(const DevPlan*, const DevTable* dt, const EvalOptions&) { const_cast<DevTable*>(dt)->pending++; }
+void dev_eval(const DevPlan* p, const DevTable* dt, const EvalOptions& opt, EvalOut* o) { dev_eval_launch(p, dt, opt); dev_eval_finish(p, dt, opt, o); }
+void dev_eval_finish(const DevPlan* p, const DevTable* dt, const EvalOptions& opt, EvalOut* o) {
+  o->n_launches = (uint32_t)dt->pending; const_cast<DevTable*>(dt)->pending = 0;
+  const HostTable& t = dt->t;
+  uint32_t n = t.n_reviews, nc = (uint32_t)p->fast.slots.size();
+  uint32_t nt = (n + GK_TILE - 1) / GK_TILE;
+  o->n_reviews = n; o->n_constraints = nc; o->n_tiles = nt;
+  o->viol.assign((size_t)nc * nt, 0); o->err.assign((size_t)nc * nt, 0);
+  o->match.clear();
+  if (opt.want_match) o->match.assign((size_t)nc * nt, 0);
+  o->too_big.assign(nt, 0); o->counts.assign(nc, 0); o->list.clear(); o->list_total = 0; o->n_overflow = 0;
+  auto t0 = std::chrono::steady_clock::now();
+  for (uint32_t r = 0; r < n; r++) {
+    uint32_t tile = r / GK_TILE; uint64_t bit = 1ull << (r % GK_TILE);
+    if (t.hdrs[r].flags & RF_TOO_BIG) { o->too_big[tile] |= bit; continue; }
+    Results res{0, 0, 0};
+    if (!eval_review(p->fast, t, r, &res)) {
+      o->n_overflow++;
+      if (!eval_review(p->big, t, r, &res)) { o->too_big[tile] |= bit; continue; }
+    }
+    for (uint32_t c = 0; c < nc; c++) {
+      ConstraintSlot sl = p->fast.slots[c];
+      bool m = (res.match >> sl.match) & 1, e = (res.err >> sl.match) & 1, v = m && ((res.viol >> sl.viol) & 1);
+      if (opt.want_match && m) o->match[(size_t)c * nt + tile] |= bit;
+      if (e) o->err[(size_t)c * nt + tile] |= bit;
+      if (v) {
+        o->viol[(size_t)c * nt + tile] |= bit;
+        o->counts[c]++;
+        o->list_total++;
+        if (opt.list_capacity && o->list.size() / 2 < opt.list_capacity) { o->list.push_back(c); o->list.push_back(r); }
+      }
+    }
+  }
+  o->kernel_ms = o->fast_kernel_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+}  // namespace gk

@@ -1,0 +1,258 @@
+"""Parity of the product path (AOT compiler -> flattener -> kernels -> host renderer, through the C ABI) with the
+oracle, on the reference's own fixtures and on seeded synthetic workloads.  Bit-exact: violation multisets
+(constraint, msg, details, enforcementAction) must be identical.
+
+Every test runs twice: `hostemu` (CPU container; the kernels' vm_core.hpp code executed lane by lane by a test-only
+library) and `gpu` (-m gpu: the HIP kernels on a real MI355X)."""
+import numpy as np
+import pytest
+
+import reference_tables as T
+from conftest import gconst, ydocs
+from gatekeeper_amd import _lib as L
+from gatekeeper_amd import driver as D
+from gatekeeper_amd import synth
+from parity_util import BACKENDS, assert_parity, key, load_both, make_client
+
+PSP = "pkg/webhook/testdata/psp-all-violations/"
+
+
+def _dir(fixtures, prefix):
+    return [ydocs(fixtures, p)[0] for p in sorted(fixtures["yaml"]) if p.startswith(prefix)]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_psp_all_violations(backend, fixtures):
+    """pkg/webhook/policy_benchmark_test.go:264-271 fixtures: 5 templates x 5 constraints x 5 pods."""
+    c, oc = load_both(backend, _dir(fixtures, PSP + "psp-templates/"), _dir(fixtures, PSP + "psp-constraints/"))
+    pods = _dir(fixtures, PSP + "psp-pods/")
+    n = assert_parity(c, oc, [D.AugmentedUnstructured(D.Unstructured(p), None, "Original") for p in pods])
+    assert n >= 5
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_config1_demo_basic(backend, fixtures):
+    d = "demo/basic/"
+    c, oc = load_both(backend, ydocs(fixtures, d + "templates/k8srequiredlabels_template.yaml"),
+                      ydocs(fixtures, d + "constraints/all_ns_must_have_gatekeeper.yaml"))
+    objs = ydocs(fixtures, d + "bad/bad_ns.yaml") + ydocs(fixtures, d + "good/good_ns.yaml")
+    got = c.ReviewBatch([D.AugmentedUnstructured(D.Unstructured(o), None, "Original") for o in objs], D.GATOR_EP)
+    assert [[r.msg for r in g] for g in got] == [[T.MSG_REQUIRED_LABELS_GATEKEEPER], []]
+    assert got[0][0].metadata == {"details": {"missing_labels": ["gatekeeper"]}}
+    # BASELINE.json configs[0]: 1 constraint x 10 Pods (5 labelled / 5 not) -> exactly 5 violations
+    cons = {"apiVersion": "constraints.gatekeeper.sh/v1beta1", "kind": "K8sRequiredLabels", "metadata": {"name": "pods-gk"},
+            "spec": {"match": {"kinds": [{"apiGroups": [""], "kinds": ["Pod"]}]}, "parameters": {"labels": ["gatekeeper"]}}}
+    c2, oc2 = load_both(backend, ydocs(fixtures, d + "templates/k8srequiredlabels_template.yaml"), [cons])
+    pods = [{"apiVersion": "v1", "kind": "Pod", "metadata": {"name": "p%d" % i, "namespace": "default",
+                                                             "labels": ({"gatekeeper": "x"} if i % 2 else {"other": "y"})}} for i in range(10)]
+    rv = [D.AugmentedUnstructured(D.Unstructured(p), None, "Original") for p in pods]
+    assert assert_parity(c2, oc2, rv, D.GATOR_EP) == 5
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("mixed,n", [(False, 600), (True, 600)])
+def test_synthetic_parity(backend, mixed, n, fixtures):
+    """configs[1]/[2] at oracle-sized N: 30 PSP constraints x Pods, 50 constraints x mixed objects."""
+    cons = synth.audit_constraints() if mixed else synth.psp_constraints()
+    c, oc = load_both(backend, synth.psp_templates(fixtures), cons)
+    nss = synth.gen_namespaces()
+    objs = synth.gen_objects(n, mixed=mixed)
+    rv = [D.AugmentedUnstructured(D.Unstructured(o), synth.namespace_for(o, nss), "Original") for o in objs]
+    total = assert_parity(c, oc, rv)
+    assert total > n // 10
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_match_table(backend, fixtures):
+    """pkg/mutation/match/match_test.go:17-684 through the device match program (deny-all template)."""
+    tmpl = fixtures["go_consts"]["pkg/target/target_integration_test.go"]["testTemplate"]["docs"][0]
+    for name, obj, mt, ns, source, want, want_err in T.MATCH_CASES:
+        if obj is None:
+            continue   # nil-object row: unreachable through HandleReview
+        cons = {"apiVersion": "constraints.gatekeeper.sh/v1beta1", "kind": "DenyAll", "metadata": {"name": "c"}, "spec": {"match": mt}}
+        c = make_client(backend)
+        c.AddTemplate(tmpl)
+        c.AddConstraint(cons)
+        res = c.Review(D.AugmentedUnstructured(D.Unstructured(obj), ns, source), D.AUDIT_EP)
+        if want_err:
+            assert len(res) == 1 and res[0].msg.startswith("unable to match constraints: "), name
+        else:
+            assert (len(res) == 1) is want, name
+            if want:
+                assert res[0].msg == "denyall constraint installed"
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_constraint_enforcement(backend, fixtures):
+    """pkg/target/target_integration_test.go:163-527: 26 scenarios x 3 review shapes, batched into one launch each."""
+    tmpl = fixtures["go_consts"]["pkg/target/target_integration_test.go"]["testTemplate"]["docs"][0]
+    for name, obj, ns, mt, allowed in T.ENFORCEMENT_CASES:
+        cons = {"apiVersion": "constraints.gatekeeper.sh/v1beta1", "kind": "DenyAll", "metadata": {"name": "my-constraint"}}
+        if mt is not None:
+            cons["spec"] = {"match": mt}
+        c, oc = load_both(backend, [tmpl], [cons])
+        g, v = obj["apiVersion"].split("/")[0], ""
+        kind = {"group": g, "version": v, "kind": obj["kind"]}
+        req = {"kind": kind, "object": obj}
+        req2 = {"kind": kind, "oldObject": obj}
+        if ns is not None:
+            req["namespace"] = req2["namespace"] = ns["metadata"]["name"]
+        shapes = [D.AugmentedReview(D.AdmissionRequest(req), ns), D.AugmentedReview(D.AdmissionRequest(req2), ns),
+                  D.AugmentedUnstructured(D.Unstructured(obj), ns)]
+        got = c.ReviewBatch(shapes, D.AUDIT_EP)
+        for g_ in got:
+            assert (len(g_) == 0) is allowed, name
+        assert_parity(c, oc, shapes)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_gator_fixtures(backend, fixtures):
+    """pkg/gator/test/test_test.go:86-330 message and enforcement-point pins, via Client.Review."""
+    def docs(*names):
+        out = []
+        for n in names:
+            out.extend(gconst(fixtures, n))
+        return out
+
+    objs = docs("TemplateNeverValidate", "ConstraintNeverValidate", "Object")
+    c, oc = load_both(backend, [objs[0]], [objs[1]])
+    rv = [D.AugmentedUnstructured(D.Unstructured(o), None, "Original") for o in objs]
+    got = c.ReviewBatch(rv, D.GATOR_EP)
+    assert [r.msg for g in got for r in g] == [T.MSG_NEVER_VALIDATE] * 3
+    assert_parity(c, oc, rv, D.GATOR_EP)
+    # scoped enforcement actions
+    objs = docs("TemplateNeverValidate", "ConstraintGatorValidate", "ConstraintAuditValidate", "Object")
+    c, oc = load_both(backend, [objs[0]], [objs[1], objs[2]])
+    rv = [D.AugmentedUnstructured(D.Unstructured(objs[3]), None, "Original")]
+    res = c.Review(rv[0], D.GATOR_EP)
+    assert [(r.enforcement_action, r.scoped_enforcement_actions) for r in res] == [("scoped", ["deny"])]
+    assert_parity(c, oc, rv, D.GATOR_EP)
+    assert_parity(c, oc, rv, D.AUDIT_EP)
+    assert_parity(c, oc, rv, D.WEBHOOK_EP)
+    # two bodies -> two messages; userInfo; restricted custom field
+    for tn, cn, on in [("TemplateNeverValidateTwice", "ConstraintNeverValidateTwice", "Object"),
+                       ("TemplateAlwaysValidate", "ConstraintAlwaysValidate", "Object"),
+                       ("TemplateRestrictCustomField", "ConstraintRestrictCustomField", "ObjectFooTemplate")]:
+        t_, k_, o_ = docs(tn, cn, on)
+        c, oc = load_both(backend, [t_], [k_])
+        assert_parity(c, oc, [D.AugmentedUnstructured(D.Unstructured(o_), None, "Original")], D.GATOR_EP)
+    t_, k_ = docs("TemplateValidateUserInfo", "ConstraintAlwaysValidateUserInfo")
+    c, oc = load_both(backend, [t_], [k_])
+    for ar in ("SystemAdmissionReview", "NonSystemAdmissionReview", "AdmissionReviewWithOldObject"):
+        req = gconst(fixtures, ar)[0]["request"]
+        assert_parity(c, oc, [D.AugmentedReview(D.AdmissionRequest(req), None, "Original")], D.GATOR_EP)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_namespace_cache_and_autoreject(backend, fixtures):
+    """matcher.go:37-39 nsCache fallback + the autoreject message pinned at test/gator/test/test.bats:301."""
+    t_ = gconst(fixtures, "TemplateNeverValidate")[0]
+    k_ = gconst(fixtures, "ConstraintNamespaceSelector")[0]
+    obj = gconst(fixtures, "ObjectNamespaceScope")[0]
+    for inv, want in ((["NamespaceSelected"], 1), (["NamespaceNotSelected"], 0), ([], 1)):
+        c, oc = load_both(backend, [t_], [k_], [gconst(fixtures, i)[0] for i in inv])
+        rv = [D.AugmentedUnstructured(D.Unstructured(obj), None, "Original")]
+        res = c.Review(rv[0], D.GATOR_EP)
+        assert len(res) == want
+        if not inv:
+            assert res[0].msg == ("unable to match constraints: error matching the requested object: object :failed to run "
+                                  "Match criteria: namespace selector for namespace-scoped object but missing Namespace")
+        assert_parity(c, oc, rv, D.GATOR_EP)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_template_families(backend, fixtures):
+    """In-tree template families beyond PSP that the device plan supports."""
+    d = "demo/agilebank/"
+    tmpls = {p: ydocs(fixtures, p)[0] for p in fixtures["yaml"] if p.startswith(d + "templates/")}
+    cons = {p: ydocs(fixtures, p)[0] for p in fixtures["yaml"] if p.startswith(d + "constraints/")}
+    objs = []
+    for p in sorted(fixtures["yaml"]):
+        if p.startswith(d + "good_resources/") or p.startswith(d + "bad_resources/"):
+            objs.extend(ydocs(fixtures, p))
+    pods = synth.gen_objects(200, seed=7)
+    ns = {"apiVersion": "v1", "kind": "Namespace", "metadata": {"name": "production"}}
+    supported = 0
+    for tp, t_ in sorted(tmpls.items()):
+        kind = t_["spec"]["crd"]["spec"]["names"]["kind"]
+        ks = [k for k in cons.values() if k["kind"] == kind]
+        try:
+            c, oc = load_both(backend, [t_], ks, [ns])
+        except D.UnsupportedError:
+            continue
+        supported += 1
+        rv = [D.AugmentedUnstructured(D.Unstructured(o), None, "Original") for o in objs + pods]
+        assert_parity(c, oc, rv)
+    assert supported >= 2   # allowedrepos, requiredprobes (regex / quantity parsing: see DESIGN.md "unsupported")
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_unsupported_is_an_error_not_a_fallback(backend, fixtures):
+    t_ = gconst(fixtures, "TemplateReferential")[0]
+    k_ = gconst(fixtures, "ConstraintReferential")[0]
+    c = make_client(backend)
+    c.AddTemplate(t_)
+    with pytest.raises(D.UnsupportedError):
+        c.AddConstraint(k_)
+    with pytest.raises(D.ClientError):
+        make_client(backend).AddTemplate(gconst(fixtures, "TemplateCompileError")[0])
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_edge_cases(backend, fixtures):
+    """empty and ragged batches, DELETE handling, element-capacity overflow (large-variant kernel), engine limits."""
+    c, oc = load_both(backend, synth.psp_templates(fixtures), synth.psp_constraints(), elem_cap=(4, 4, 4))
+    assert c.ReviewBatch([]) == []
+    # ragged: 1, 63, 64, 65 reviews
+    objs = synth.gen_objects(65, seed=11)
+    for n in (1, 63, 64, 65):
+        assert_parity(c, oc, [D.AugmentedUnstructured(D.Unstructured(o), None, "Original") for o in objs[:n]])
+    # overflow: a pod with 40 privileged containers / 40 hostPath volumes exceeds the LDS capacity of 4
+    big = {"apiVersion": "v1", "kind": "Pod", "metadata": {"name": "big", "namespace": "prod-01"}, "spec": {
+        "containers": [{"name": "c%d" % i, "image": "x", "securityContext": {"privileged": i == 37},
+                        "volumeMounts": [{"name": "v%d" % i, "mountPath": "/m", "readOnly": i % 2 == 0}]} for i in range(40)],
+        "volumes": [{"name": "v%d" % i, "hostPath": {"path": "/foo/x%d" % i}} for i in range(40)]}}
+    rv = [D.AugmentedUnstructured(D.Unstructured(o), None, "Original") for o in [objs[0], big, objs[1]]]
+    table = c.driver.engine.create_table([D.to_review_in(r) for r in rv])
+    ev = table.eval()
+    assert ev.n_overflow == 1
+    table.free()
+    assert_parity(c, oc, rv)
+    # DELETE: object := oldObject (target.go:269-287); missing oldObject is a review error
+    req = {"kind": {"group": "", "version": "v1", "kind": "Pod"}, "operation": "DELETE", "oldObject": objs[2]}
+    assert_parity(c, oc, [D.AugmentedReview(D.AdmissionRequest(req), None, "Original")])
+    with pytest.raises(D.ClientError):
+        c.Review(D.AugmentedReview(D.AdmissionRequest({"operation": "DELETE", "object": objs[2]}), None, "Original"))
+    # beyond engine limits (>255 elements of one array): reported in too_big, never guessed
+    huge = {"apiVersion": "v1", "kind": "Pod", "metadata": {"name": "huge"}, "spec": {
+        "containers": [{"name": "c%d" % i, "image": "x"} for i in range(300)]}}
+    table = c.driver.engine.create_table([D.to_review_in(D.AugmentedUnstructured(D.Unstructured(huge), None, "Original"))])
+    ev = table.eval()
+    assert int(ev.too_big[0]) == 1 and ev.viol.sum() == 0
+    table.free()
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_bitmap_list_counts_consistency(backend, fixtures):
+    """Size-independent invariants of one launch: counts == popcount(bitmap rows), list == bitmap, viol subset of match."""
+    c, _ = load_both(backend, synth.psp_templates(fixtures), synth.audit_constraints())
+    nss = synth.gen_namespaces()
+    objs = synth.gen_objects(1000, seed=5, mixed=True)
+    rins = [D.to_review_in(D.AugmentedUnstructured(D.Unstructured(o), synth.namespace_for(o, nss), "Original")) for o in objs]
+    table = c.driver.engine.create_table(rins, keep_docs=False)
+    ev = table.eval(want_match=True, want_list=True)
+    pop = np.array([sum(bin(int(w)).count("1") for w in row) for row in ev.viol])
+    assert (pop == ev.counts).all()
+    assert ev.list_total == pop.sum() == len(ev.list)
+    rows = {int(cid): i for i, cid in enumerate(ev.constraint_ids)}
+    assert sorted((int(ev.constraint_ids[a]), int(b)) for a, b in ev.list) == ev.pairs("viol")
+    assert ((ev.viol & ~ev.match) == 0).all() and ((ev.err & ev.match) == 0).all()
+    # shard invariance: evaluating two halves separately gives the same bits (audit shards objects across GPUs)
+    half = len(rins) // 2 // 64 * 64
+    t1, t2 = c.driver.engine.create_table(rins[:half], keep_docs=False), c.driver.engine.create_table(rins[half:], keep_docs=False)
+    e1, e2 = t1.eval(), t2.eval()
+    assert (np.concatenate([e1.viol, e2.viol], axis=1) == ev.viol).all()
+    assert (e1.counts + e2.counts == ev.counts).all()
+    for t in (table, t1, t2):
+        t.free()
+    assert rows
