@@ -93,16 +93,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        sweep.step()
-    sweep.collect()
+    if args.warmup:
+        sweep.sweep(args.warmup)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        sweep.step()
-    res = sweep.collect()
+    res = sweep.sweep(args.steps)          # exactly `steps` launches (+ exchanges when sharded) in the timed region
     barrier()
     dt = time.perf_counter() - t0
+    counts = sweep.sweep(1, download=True).counts
     if dist is not None:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -123,7 +121,7 @@ def main():
                        ("configs[2]: audit sweep, 50 constraints x %d mixed synthetic cluster objects per GPU" % args.reviews),
                        "constraints": nc, "reviews_per_gpu": args.reviews, "rows_per_gpu": int(res.n_rows),
                        "parallelism": "objects sharded across %d GPU(s); RCCL all-gather of violation bitmaps + all-reduce of counts" % world,
-                       "violating_pairs_rank0": int(res.counts.sum())},
+                       "violating_pairs_rank0": int(counts.sum())},
             "roofline": {"bound": "hbm", "kernel": "gk_eval_tiles", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algo_bytes_per_launch": int(res.algo_bytes),
                          "avg_kernel_ms": res.fast_kernel_ms, "launches_timed": int(res.n_launches),

@@ -22,7 +22,7 @@ GK_ERR_INVALID, GK_ERR_REGO, GK_ERR_UNSUPPORTED, GK_ERR_NOT_FOUND, GK_ERR_DEVICE
 GK_REVIEW_ADMISSION_REQUEST, GK_REVIEW_OBJECT = 0, 1
 GK_SRC_EMPTY, GK_SRC_ORIGINAL, GK_SRC_GENERATED, GK_SRC_ALL, GK_SRC_INVALID = 0, 1, 2, 3, 4
 GK_TABLE_KEEP_DOCS = 1
-GK_EVAL_WANT_MATCH, GK_EVAL_NO_DOWNLOAD, GK_EVAL_WANT_LIST, GK_EVAL_ASYNC = 1, 2, 4, 8
+GK_EVAL_WANT_MATCH, GK_EVAL_NO_DOWNLOAD, GK_EVAL_WANT_LIST, GK_EVAL_ASYNC, GK_EVAL_COLLECT = 1, 2, 4, 8, 16
 
 EXPORTS = [
     "gk_engine_create", "gk_engine_destroy", "gk_last_error", "gk_version", "gk_template_add", "gk_template_remove",

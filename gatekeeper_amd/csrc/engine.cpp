@@ -399,7 +399,8 @@ int gk_table_eval(gk_engine* e, gk_table* t, uint32_t flags, gk_eval_out** out) 
         *out = nullptr;
         return GK_OK;
       }
-      dev_eval(e->dev_plan, t->dev, opt, &h->out);
+      if (flags & GK_EVAL_COLLECT) dev_eval_finish(e->dev_plan, t->dev, opt, &h->out);   // no new launch
+      else dev_eval(e->dev_plan, t->dev, opt, &h->out);
     }
     gk_eval_out& p = h->pub;
     memset(&p, 0, sizeof p);

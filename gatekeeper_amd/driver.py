@@ -148,10 +148,11 @@ class Table:
     def __init__(self, engine, handle, statuses, n):
         self.engine, self.handle, self.statuses, self.n = engine, handle, statuses, n
 
-    def eval(self, want_match=False, download=True, want_list=False):
+    def eval(self, want_match=False, download=True, want_list=False, collect_only=False):
+        """Launch + collect (or, with collect_only, just collect the pending launch()es)."""
         lib = self.engine.lib
         flags = (L.GK_EVAL_WANT_MATCH if want_match else 0) | (0 if download else L.GK_EVAL_NO_DOWNLOAD) | (
-            L.GK_EVAL_WANT_LIST if want_list else 0)
+            L.GK_EVAL_WANT_LIST if want_list else 0) | (L.GK_EVAL_COLLECT if collect_only else 0)
         out = C.POINTER(L.gk_eval_out)()
         self.engine._check(lib.gk_table_eval(self.engine.handle, self.handle, flags, C.byref(out)))
         return EvalResult(lib, out)

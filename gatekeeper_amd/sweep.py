@@ -9,25 +9,36 @@ from __future__ import annotations
 
 import ctypes
 
-import numpy as np
-
 from . import driver as D
 from . import synth
 
+_hip = None
+
+
+def _d2d(dst_ptr, src_ptr, nbytes):
+    """device-to-device copy between a raw HIP pointer handed out by the C ABI and a torch tensor (plumbing only)."""
+    global _hip
+    if _hip is None:
+        _hip = ctypes.CDLL("libamdhip64.so")
+        _hip.hipMemcpyAsync.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
+    rc = _hip.hipMemcpyAsync(dst_ptr, src_ptr, nbytes, 3, None)   # hipMemcpyDeviceToDevice on the default stream
+    if rc != 0:
+        raise RuntimeError("hipMemcpyAsync failed: %d" % rc)
+
 
 class ShardedSweep:
+    """One rank's shard of the audited objects, resident in HBM, plus the exchange buffers."""
+
     def __init__(self, client, objs, namespaces, dist=None, device=None):
         self.client = client
         self.dist = dist
-        self.device = device
-        rins = [D.to_review_in(D.AugmentedUnstructured(D.Unstructured(o), synth.namespace_for(o, namespaces), "Original")) for o in objs]
+        rins = [D.to_review_in(D.AugmentedUnstructured(D.Unstructured(o), synth.namespace_for(o, namespaces), "Original"))
+                for o in objs]
         self.table = client.driver.engine.create_table(rins, keep_docs=False)
         self.n = len(objs)
         self.nc = len(client.constraints)
         self.n_tiles = (self.n + 63) // 64
-        self._pending = 0
-        self.gathered = None
-        self.total_counts = None
+        self.gathered = self.total_counts = None
         if dist is not None:
             import torch
             w = dist.get_world_size()
@@ -35,44 +46,25 @@ class ShardedSweep:
             self.gathered = torch.empty(w * self.nc * self.n_tiles, dtype=torch.int64, device=device)
             self.total_counts = torch.empty(self.nc, dtype=torch.int32, device=device)
 
-    def step(self):
-        """one pass of the hot path over the resident shard (+ the exchange step when sharded across GPUs)"""
+    def sweep(self, steps=1, download=False):
+        """`steps` passes of the hot path over the resident shard.  Single GPU: the launches are enqueued back to back
+        and collected once.  Sharded: every pass is followed by its exchange step (all-gather of bitmaps, all-reduce of
+        counts).  Returns the EvalResult of the last pass (kernel time = average over the passes)."""
         if self.dist is None:
-            self.table.launch()
-            self._pending += 1
-            return
+            for _ in range(steps):
+                self.table.launch()
+            return self.table.eval(download=download, collect_only=True)
         import torch
-        # the exchange needs the device-resident results of THIS launch: collect, then hand the raw device pointers
-        # to RCCL through zero-copy torch views
-        ev = self.table.eval(download=False)
-        self._last = ev
-        nbytes = self.nc * self.n_tiles * 8
-        hip = torch.cuda.current_stream().cuda_stream  # noqa: F841  (default stream: same one the engine launches on)
-        src = (ctypes.c_char * nbytes).from_address(0)  # placeholder type for clarity
-        del src
-        torch.cuda.synchronize()
-        _copy_from_device_ptr(self.local_bm, ev.d_viol, nbytes)
-        _copy_from_device_ptr(self.total_counts, ev.d_counts, self.nc * 4)
-        self.dist.all_gather_into_tensor(self.gathered, self.local_bm)
-        self.dist.all_reduce(self.total_counts)
-
-    def collect(self):
-        if self.dist is None:
-            ev = self.table.eval(download=True) if self._pending == 0 else self._collect_pending()
-            self._pending = 0
-            return ev
-        return self.table.eval(download=True)
-
-    def _collect_pending(self):
-        # eval() = one more launch + finish: callers that want exactly K timed launches issue K-1 step() calls
-        return self.table.eval(download=True)
-
-
-def _copy_from_device_ptr(dst_tensor, src_ptr, nbytes):
-    """device-to-device copy from a raw HIP pointer handed out by the C ABI into a torch tensor (plumbing only)."""
-    import torch
-    lib = ctypes.CDLL("libamdhip64.so")
-    lib.hipMemcpyAsync.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
-    rc = lib.hipMemcpyAsync(dst_tensor.data_ptr(), src_ptr, nbytes, 3, None)
-    assert rc == 0, "hipMemcpyAsync failed: %d" % rc
-    torch.cuda.synchronize()
+        ev = None
+        for _ in range(steps):
+            self.table.launch()
+            ev = self.table.eval(download=False, collect_only=True)   # sync: bitmaps of THIS pass are complete
+            _d2d(self.local_bm.data_ptr(), ev.d_viol, self.nc * self.n_tiles * 8)
+            _d2d(self.total_counts.data_ptr(), ev.d_counts, self.nc * 4)
+            torch.cuda.current_stream().synchronize()
+            self.dist.all_gather_into_tensor(self.gathered, self.local_bm)
+            self.dist.all_reduce(self.total_counts)
+        if download:
+            self.table.launch()
+            ev = self.table.eval(download=True, collect_only=True)
+        return ev

@@ -110,6 +110,7 @@ typedef struct {
 #define GK_EVAL_WANT_LIST 4u
 #define GK_EVAL_ASYNC 8u         /* enqueue one launch on the default stream and return (out = NULL); the next call
                                     without this flag synchronises, and reports the average kernel time per launch */
+#define GK_EVAL_COLLECT 16u      /* do not launch: synchronise and collect the results of the pending GK_EVAL_ASYNC launches */
 
 /* The hot path: every loaded constraint x every review of the table -- Match (a3-a7) + violation predicate (a8/a9).
  * Replaces the per-object Client.Review loops at pkg/audit/manager.go:591-642,706-719 and pkg/webhook/policy.go:826. */
