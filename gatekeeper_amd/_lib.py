@@ -78,6 +78,13 @@ def load(hostemu: bool | None = None):
         raise EngineLoadError(
             "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(there is no CPU fallback for the constraint-evaluation path)" % path)
+    if not hostemu:
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64; if it is going to be used in this
+        # process (device memory / RCCL plumbing) it must be loaded BEFORE libgkgpu.so resolves the same soname.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     lib = C.CDLL(path)
     vp, cp, sz, u32 = C.c_void_p, C.c_char_p, C.c_size_t, C.c_uint32
     lib.gk_engine_create.argtypes = [C.POINTER(gk_opts), C.POINTER(vp)]
