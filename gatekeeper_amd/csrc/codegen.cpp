@@ -1,0 +1,174 @@
+// Plan -> HIP source: the predicate dispatch (phase 1) and the formulas (phase 2) of ONE compiled plan as straight-line
+// code over the same primitives the interpreter uses (vm_core.hpp: eval_pred with a constexpr Pred folds to the single
+// operation; boolean registers become locals; loops become real loops with constant LDS offsets).  kernels.hip
+// compiles the result for gfx950 with hiprtc when the plan is uploaded; tests/native/hostemu.cpp can compile the same
+// text with g++ to validate the generator in the GPU-less container.
+#include "codegen.hpp"
+
+#include <map>
+#include <sstream>
+
+namespace gk {
+
+namespace {
+
+std::string u(uint64_t v) { return std::to_string(v) + "u"; }
+
+std::string pred_literal(const Pred& p) {
+  std::ostringstream o;
+  o << "Pred{" << (int)p.op << "," << (int)p.dst << "," << (int)p.scope << "," << (int)p.level << "," << p.bit << "," << (int)p.cmp << ","
+    << (int)p.ctype << "," << p.a << "u," << p.b << "u," << p.k << "ull," << p.idx << "," << p.pad << "u}";
+  return o.str();
+}
+
+}  // namespace
+
+std::vector<uint32_t> jit_path_classes(const HostPlan& plan, std::vector<std::vector<Pred>>* classes) {
+  // distinct predicate lists -> class ids (1-based); ptab_class[path] = class id, 0 = no predicates
+  std::vector<uint32_t> out(plan.ptab.size(), 0);
+  std::map<std::string, uint32_t> ids;
+  classes->clear();
+  classes->push_back({});
+  for (size_t i = 0; i < plan.ptab.size(); i++) {
+    uint32_t ent = plan.ptab[i];
+    if (!ent) continue;
+    uint32_t first = ent >> 8, cnt = ent & 0xFF;
+    std::string key((const char*)&plan.path_preds[first], cnt * sizeof(Pred));
+    auto it = ids.find(key);
+    if (it == ids.end()) {
+      uint32_t id = (uint32_t)classes->size();
+      ids[key] = id;
+      classes->emplace_back(plan.path_preds.begin() + first, plan.path_preds.begin() + first + cnt);
+      out[i] = id;
+    } else out[i] = it->second;
+  }
+  return out;
+}
+
+std::string generate_plan_source(const HostPlan& plan) {
+  std::ostringstream o;
+  std::vector<std::vector<Pred>> classes;
+  jit_path_classes(plan, &classes);
+  o << "namespace gk {\n";
+  // ---------------------------------------------------------------------------------------------- phase 1
+  o << "template <class Acc>\nGK_HD void jit_row(const Row& r, uint32_t row_index, uint32_t cls, const PlanView& pv, const uint8_t* heap, Acc& acc) {\n"
+    << "  const uint8_t* cheap = pv.cheap;\n  (void)cheap; (void)row_index;\n  switch (cls) {\n";
+  for (size_t c = 1; c < classes.size(); c++) {
+    o << "    case " << c << ": {\n";
+    for (const Pred& p : classes[c]) {
+      o << "      { constexpr Pred P = " << pred_literal(p) << ";\n";
+      bool always = p.op == P_DEFINED || p.op == P_PRESENT || p.op == P_STORE;
+      o << "        if (" << (always ? "true" : "eval_pred(r, P, heap, cheap)") << ") {\n";
+      if (p.dst == D_GLOBAL) {
+        o << "          acc.or_word(" << (p.bit >> 5) << "u, " << u(1u << (p.bit & 31)) << ");\n";
+      } else {
+        const Scope& sc = plan.scopes[p.scope];
+        o << "          const uint32_t ord = row_ordinal(r, " << (int)p.level << "u);\n"
+          << "          if (ord >= " << sc.cap << "u || (r.meta & ROW_ORD_OVERFLOW)) acc.or_word(0u, 1u);\n          else {\n";
+        if (p.op == P_STORE) o << "            acc.store_word(" << sc.val_off << "u + ord * " << (int)sc.nvals << "u + " << p.bit << "u, row_index + 1u);\n";
+        else if (p.op == P_PRESENT) {
+          if (p.level > 0) o << "            const uint32_t parent = row_ordinal(r, " << (int)(p.level - 1) << "u);\n";
+          else o << "            const uint32_t parent = 0u;\n";
+          o << "            acc.or_word(" << sc.word_off << "u + ord * " << (int)sc.wpe << "u, 1u | (parent << 24));\n"
+            << "            acc.max_word(" << sc.count_off << "u, ord + 1u);\n";
+        } else {
+          o << "            acc.or_word(" << sc.word_off << "u + ord * " << (int)sc.wpe << "u + " << elem_word_of_bit(p.bit) << "u, " << u(elem_mask_of_bit(p.bit)) << ");\n";
+        }
+        o << "          }\n";
+      }
+      o << "        }\n      }\n";
+    }
+    o << "    } break;\n";
+  }
+  o << "    default: break;\n  }\n}\n\n";
+  // ---------------------------------------------------------------------------------------------- phase 2
+  o << "template <class Acc>\nGK_HD Results jit_formulas(const PlanView& pv, Acc& acc, uint32_t flags, const Row* rows, const uint8_t* heap, const uint32_t* bounds) {\n"
+    << "  (void)pv; (void)rows; (void)heap; (void)flags;\n  Results res = {0, 0, 0};\n  bool";
+  for (int i = 0; i < 64; i++) o << (i ? ", " : " ") << "b" << i << " = false";
+  o << ";\n";
+  struct Loop { uint32_t scope; int depth; };
+  std::vector<Loop> stack;
+  auto var_of = [&](uint32_t scope) -> int {
+    for (size_t i = stack.size(); i-- > 0;) if (stack[i].scope == scope) return stack[i].depth;
+    return -1;
+  };
+  std::string ind = "  ";
+  const std::vector<uint32_t>& code = plan.code;
+  for (size_t pc = 0; pc < code.size();) {
+    uint32_t ins = code[pc++];
+    uint32_t op = ins & 0xFF, a = (ins >> 8) & 0xFF, b = (ins >> 16) & 0xFF, c = ins >> 24;
+    switch (op) {
+      case F_LDG: { uint32_t bit = b | (c << 8); o << ind << "b" << a << " = (acc.load(" << (bit >> 5) << "u) >> " << (bit & 31) << ") & 1u;\n"; break; }
+      case F_LDF: o << ind << "b" << a << " = (flags >> " << b << ") & 1u;\n"; break;
+      case F_LDE: {
+        const Scope& sc = plan.scopes[b];
+        int d = var_of(b);
+        if (d < 0) throw Unsupported("codegen: element load outside its loop");
+        if (elem_word_of_bit(c) == 0) o << ind << "b" << a << " = (w" << d << " & " << u(elem_mask_of_bit(c)) << ") != 0u;\n";
+        else o << ind << "b" << a << " = (acc.load(" << sc.word_off << "u + e" << d << " * " << (int)sc.wpe << "u + " << elem_word_of_bit(c) << "u) & " << u(elem_mask_of_bit(c)) << ") != 0u;\n";
+        break;
+      }
+      case F_AND: o << ind << "b" << a << " = b" << b << " & b" << c << ";\n"; break;
+      case F_OR: o << ind << "b" << a << " = b" << b << " | b" << c << ";\n"; break;
+      case F_NOT: o << ind << "b" << a << " = !b" << b << ";\n"; break;
+      case F_ANDN: o << ind << "b" << a << " = b" << b << " & !b" << c << ";\n"; break;
+      case F_CONST: o << ind << "b" << a << " = " << ((b & 1) ? "true" : "false") << ";\n"; break;
+      case F_MOV: o << ind << "b" << a << " = b" << b << ";\n"; break;
+      case F_LOOP: {
+        const Scope& sc = plan.scopes[a];
+        int d = (int)stack.size();
+        o << ind << "b" << c << " = false;\n";
+        o << ind << "{ const uint32_t n" << d << " = GK_UNI(bounds[" << a << "]);\n";
+        o << ind << "  for (uint32_t e" << d << " = 0; e" << d << " < n" << d << "; e" << d << "++) {\n";
+        o << ind << "    const uint32_t w" << d << " = acc.load(" << sc.word_off << "u + e" << d << " * " << (int)sc.wpe << "u);\n";
+        o << ind << "    bool v" << d << " = (w" << d << " & 1u) != 0u;\n";
+        if (b) {
+          int pd = var_of(b - 1);
+          if (pd < 0) throw Unsupported("codegen: parent loop not open");
+          o << ind << "    v" << d << " = v" << d << " && ((w" << d << " >> 24) == e" << pd << ");\n";
+        }
+        stack.push_back({a, d});
+        ind += "    ";
+        break;
+      }
+      case F_ENDLOOP: {
+        int d = stack.back().depth;
+        o << ind << "b" << a << " = b" << a << " | (b" << b << " & v" << d << ");\n";
+        stack.pop_back();
+        ind = ind.substr(0, ind.size() - 4);
+        o << ind << "  }\n" << ind << "}\n";
+        break;
+      }
+      case F_VEQ: {
+        uint32_t x = code[pc++];
+        uint32_t sa = x & 0xFF, la = (x >> 8) & 0xFF, sb = (x >> 16) & 0xFF, lb = x >> 24;
+        const Scope& A = plan.scopes[sa];
+        const Scope& B = plan.scopes[sb];
+        int da = var_of(sa), db = var_of(sb);
+        if (da < 0 || db < 0) throw Unsupported("codegen: join outside its loops");
+        o << ind << "b" << a << " = val_eq(acc.load(" << A.val_off << "u + e" << da << " * " << (int)A.nvals << "u + " << la << "u), acc.load(" << B.val_off
+          << "u + e" << db << " * " << (int)B.nvals << "u + " << lb << "u), rows, heap);\n";
+        break;
+      }
+      case F_STE: {
+        const Scope& sc = plan.scopes[b];
+        int d = var_of(b);
+        if (d < 0) throw Unsupported("codegen: element store outside its loop");
+        o << ind << "if (b" << a << ") acc.or_word(" << sc.word_off << "u + e" << d << " * " << (int)sc.wpe << "u + " << elem_word_of_bit(c) << "u, " << u(elem_mask_of_bit(c)) << ");\n";
+        break;
+      }
+      case F_STG: { uint32_t bit = b | (c << 8); o << ind << "if (b" << a << ") acc.or_word(" << (bit >> 5) << "u, " << u(1u << (bit & 31)) << ");\n"; break; }
+      case F_RES: {
+        const char* f = b == 0 ? "viol" : b == 1 ? "match" : "err";
+        o << ind << "res." << f << " |= (uint64_t)b" << a << " << " << c << ";\n";
+        break;
+      }
+      case F_END: pc = code.size(); break;
+      default: throw Unsupported("codegen: unknown formula op");
+    }
+  }
+  o << "  return res;\n}\n}  // namespace gk\n";
+  return o.str();
+}
+
+}  // namespace gk

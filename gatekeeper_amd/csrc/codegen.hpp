@@ -1,0 +1,14 @@
+// Plan-specialised source generation (see codegen.cpp).
+#pragma once
+#include <string>
+#include <vector>
+
+#include "lower.hpp"
+#include "vm_core.hpp"
+
+namespace gk {
+// HIP/C++ text defining gk::jit_row and gk::jit_formulas for this plan (to be compiled after plan.hpp + vm_core.hpp).
+std::string generate_plan_source(const HostPlan& plan);
+// path table for the generated dispatch: ptab_class[path] = predicate-list class id (0 = none)
+std::vector<uint32_t> jit_path_classes(const HostPlan& plan, std::vector<std::vector<Pred>>* classes);
+}  // namespace gk

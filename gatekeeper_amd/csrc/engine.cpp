@@ -417,7 +417,7 @@ int gk_table_eval(gk_engine* e, gk_table* t, uint32_t flags, gk_eval_out** out) 
     p.n_rows = t->n_rows;
     // algorithmic bytes: rows + headers read once, plan tables read once, bitmaps written once,
     // 8 B per emitted violation-list entry
-    uint64_t plan_bytes = (uint64_t)e->fast.ptab.size() * 4 + e->fast.pred_list.size() * 4 + e->fast.preds.size() * sizeof(Pred) +
+    uint64_t plan_bytes = (uint64_t)e->fast.ptab.size() * 4 + e->fast.path_preds.size() * sizeof(Pred) +
                           e->fast.code.size() * 4 + e->fast.cheap.size();
     p.algo_bytes = t->algo_bytes + plan_bytes + (uint64_t)p.n_constraints * p.n_tiles * 16 + (uint64_t)p.list_total * 8;
     *out = &h.release()->pub;

@@ -250,11 +250,67 @@ bool mentions_q(const FP& f, int q) {
   }
 }
 
+// count(split(p)) >= n  &  for every i < n:  !(count(split(p)) > i & split(p)[i] != a_i)      (the PSP path_matches idiom)
+//   ==>  one SPLIT_PREFIX predicate: the first n components of split(trim(p)) equal a_0..a_{n-1}
+void fuse_split_prefix(std::vector<FP>& conj) {
+  for (size_t ci = 0; ci < conj.size(); ci++) {
+    const FP& c = conj[ci];
+    if (!(c->kind == FNode::ATOM && c->atom.kind == Atom::SPLIT_COUNT && c->atom.cmp == C_GE && c->atom.k.is_int && c->atom.k.i >= 1 && c->atom.k.i <= 32)) continue;
+    const Atom& cnt = c->atom;
+    int n = (int)cnt.k.i;
+    std::string pkey = spath_to_string(cnt.path);
+    std::vector<Value> comps(n);
+    std::vector<int> where(n, -1);
+    for (size_t j = 0; j < conj.size(); j++) {
+      const FP& t = conj[j];
+      if (t->kind != FNode::NOT) continue;
+      std::vector<FP> inner;
+      conjuncts(t->kids[0], inner);
+      const Atom* cmp = nullptr;
+      bool ok = true;
+      for (auto& x : inner) {
+        if (x->kind != FNode::ATOM) { ok = false; break; }
+        const Atom& a = x->atom;
+        if (spath_to_string(a.path) != pkey) { ok = false; break; }
+        if (a.kind == Atom::TYPE && a.mask == (1u << T_STRING)) continue;
+        if (a.kind == Atom::SPLIT_COUNT && a.cut == cnt.cut && a.sep == cnt.sep && a.cmp == C_GT) continue;   // implied by count >= n when its bound < n (checked below)
+        if (a.kind == Atom::SPLIT_CMP && a.cut == cnt.cut && a.sep == cnt.sep && a.cmp == C_NE && a.k.is_string() && !cmp) { cmp = &a; continue; }
+        ok = false;
+        break;
+      }
+      if (!ok || !cmp || cmp->idx < 0 || cmp->idx >= n || where[cmp->idx] >= 0) continue;
+      for (auto& x : inner) if (x->atom.kind == Atom::SPLIT_COUNT && !(x->atom.k.is_int && x->atom.k.i == cmp->idx)) ok = false;
+      if (!ok) continue;
+      comps[cmp->idx] = cmp->k;
+      where[cmp->idx] = (int)j;
+    }
+    bool all = true;
+    for (int w : where) if (w < 0) all = false;
+    if (!all) continue;
+    Atom f;
+    f.kind = Atom::SPLIT_PREFIX;
+    f.path = cnt.path; f.cut = cnt.cut; f.sep = cnt.sep;
+    f.k = Value::array(ValueVec(comps.begin(), comps.end()));
+    std::vector<FP> out;
+    for (size_t j = 0; j < conj.size(); j++) {
+      if (j == ci) { out.push_back(f_atom(f)); continue; }
+      if (std::find(where.begin(), where.end(), (int)j) != where.end()) continue;
+      out.push_back(conj[j]);
+    }
+    conj.swap(out);
+    ci = (size_t)-1;   // restart: indices moved
+  }
+}
+
 FP simplify(const FP& f) {
   switch (f->kind) {
     case FNode::AND: {
-      std::vector<FP> flat;
-      for (auto& k : f->kids) conjuncts(simplify(k), flat);
+      std::vector<FP> flat0, flat;
+      for (auto& k : f->kids) conjuncts(simplify(k), flat0);
+      for (auto& k : flat0) {   // De Morgan inside conjunctions: !(a | b)  ->  !a & !b
+        if (k->kind == FNode::NOT && k->kids[0]->kind == FNode::OR) for (auto& x : k->kids[0]->kids) conjuncts(simplify(f_not(x)), flat);
+        else flat.push_back(k);
+      }
       // dedupe
       std::vector<FP> uniq;
       std::set<std::string> seen;
@@ -277,6 +333,7 @@ FP simplify(const FP& f) {
         }
         if (!implied) keep.push_back(k);
       }
+      fuse_split_prefix(keep);
       return f_all(keep);
     }
     case FNode::OR: {
@@ -300,6 +357,50 @@ FP simplify(const FP& f) {
   }
 }
 
+// ---- alpha-normalised canonical text: quantifier ids renumbered in order of first appearance, so structurally
+// identical (sub)formulas compiled for different constraints share predicates, derived bits and result slots.
+void collect_q(const FP& f, std::vector<int>& order) {
+  auto see = [&](int q) { if (q >= 0 && std::find(order.begin(), order.end(), q) == order.end()) order.push_back(q); };
+  auto see_path = [&](const SPath& p) { for (auto& s : p) if (s.iter) see(s.q); };
+  switch (f->kind) {
+    case FNode::T: case FNode::F: return;
+    case FNode::ATOM: see_path(f->atom.path); see_path(f->atom.path2); see(f->atom.q); return;
+    case FNode::EXISTS: see(f->q); see_path(f->base);   // fallthrough
+    default: for (auto& k : f->kids) collect_q(k, order);
+  }
+}
+SPath rename_path(const SPath& p, const std::map<int, int>& m) {
+  SPath o = p;
+  for (auto& s : o) if (s.iter) { auto it = m.find(s.q); if (it != m.end()) s.q = it->second; }
+  return o;
+}
+FP rename_f(const FP& f, const std::map<int, int>& m) {
+  switch (f->kind) {
+    case FNode::T: case FNode::F: return f;
+    case FNode::ATOM: {
+      Atom a = f->atom;
+      a.path = rename_path(a.path, m); a.path2 = rename_path(a.path2, m);
+      if (a.q >= 0) { auto it = m.find(a.q); if (it != m.end()) a.q = it->second; }
+      return f_atom(a);
+    }
+    default: {
+      FNode n = *f;
+      for (auto& k : n.kids) k = rename_f(k, m);
+      n.base = rename_path(n.base, m);
+      if (n.q >= 0) { auto it = m.find(n.q); if (it != m.end()) n.q = it->second; }
+      return std::make_shared<const FNode>(n);
+    }
+  }
+}
+// `first`: quantifiers that must get the lowest numbers (free loop variables), in order
+std::string canon(const FP& f, const std::vector<int>& first = {}) {
+  std::vector<int> order = first;
+  collect_q(f, order);
+  std::map<int, int> m;
+  for (size_t i = 0; i < order.size(); i++) m[order[i]] = 1000000 + (int)i;
+  return f_to_string(rename_f(f, m));
+}
+
 struct Lowerer {
   PathDict* dict;
   HostPlan plan;
@@ -317,6 +418,10 @@ struct Lowerer {
   std::set<int> pass;                                      // pass-through quantifiers
   std::map<int, PatStep> wild;                             // wildcard quantifiers (global existentials)
   std::map<std::string, uint32_t> cheap_strings;
+  std::map<std::string, uint32_t> derived_global;          // canonical closed EXISTS -> global bit
+  std::vector<std::map<std::string, uint32_t>> derived_elem;   // per scope: canonical EXISTS over (elem) -> elem bit
+  std::vector<uint32_t>* cur_code = nullptr;               // where emit() appends
+  std::vector<std::vector<uint32_t>> prologue;             // derived-bit blocks, run before the formulas
 
   [[noreturn]] void unsupported(const std::string& what) { throw Unsupported("unsupported on the device plan: " + what); }
 
@@ -325,7 +430,7 @@ struct Lowerer {
     unsupported("formula needs more than 64 boolean registers");
   }
   void release(int r) { regs_used &= ~(1ull << r); }
-  void emit(uint32_t w) { plan.code.push_back(w); }
+  void emit(uint32_t w) { (cur_code ? cur_code : &plan.code)->push_back(w); }
 
   uint32_t put_bytes(const std::string& s) {
     auto it = cheap_strings.find(s);
@@ -403,6 +508,12 @@ struct Lowerer {
         p.op = P_SPLIT_COUNT; p.k = (uint64_t)(int64_t)a.k.i; p.pad = ((uint32_t)(uint8_t)a.cut << 8) | (uint8_t)a.sep;
         break;
       case Atom::COUNT_CMP: p.op = P_COUNT_CMP; p.k = (uint64_t)(int64_t)a.k.i; break;
+      case Atom::SPLIT_PREFIX: {
+        std::string joined;
+        for (size_t i = 0; i < a.k.items().size(); i++) { if (i) joined.push_back(a.sep); joined += a.k.items()[i].str(); }
+        p.op = P_SPLIT_PREFIX; p.a = put_bytes(joined); p.b = (uint32_t)joined.size(); p.pad = ((uint32_t)(uint8_t)a.cut << 8) | (uint8_t)a.sep;
+        break;
+      }
       default: unsupported("predicate kind");
     }
     return p;
@@ -424,6 +535,7 @@ struct Lowerer {
     scope_level.push_back(level);
     elem_bits.emplace_back();
     val_slots.emplace_back();
+    derived_elem.emplace_back();
     scope_nbits.push_back(1);
     Pred p{};
     p.op = P_PRESENT; p.dst = D_ELEM; p.scope = (uint8_t)id; p.level = (uint8_t)level;
@@ -600,6 +712,73 @@ struct Lowerer {
       pass.erase(q);
       return r;
     }
+    // ---- common-subformula cache: an EXISTS that depends on no enclosing loop variable is computed once per review
+    // (derived global bit); one that depends on exactly one enclosing loop variable is computed once per element of
+    // that scope (derived element bit).  Both run in a prologue, before the per-constraint formulas.
+    std::vector<int> free;
+    {
+      std::vector<int> seen;
+      collect_q(f, seen);
+      for (int x : seen) if (looped.count(x)) free.push_back(x);
+    }
+    if (free.empty()) {
+      std::string key = canon(f);
+      auto it = derived_global.find(key);
+      uint32_t bit;
+      if (it == derived_global.end()) {
+        bit = n_gbits++;
+        if (bit > 0xFFFF) unsupported("too many global predicates");
+        derived_global[key] = bit;
+        std::vector<uint32_t> block;
+        std::vector<uint32_t>* saved = cur_code;
+        cur_code = &block;
+        int r = lower_exists_loop(f);
+        emit(finst(F_STG, r, bit & 0xFF, bit >> 8));
+        release(r);
+        cur_code = saved;
+        prologue.push_back(block);
+      } else bit = it->second;
+      int r = alloc();
+      emit(finst(F_LDG, r, bit & 0xFF, bit >> 8));
+      return r;
+    }
+    if (free.size() == 1) {
+      int q1 = free[0];
+      uint32_t s1 = looped[q1];
+      std::string key = canon(f, {q1});
+      auto it = derived_elem[s1].find(key);
+      uint32_t bit;
+      if (it == derived_elem[s1].end()) {
+        bit = scope_nbits[s1]++;
+        if (bit >= 24 + 3 * 32) unsupported("too many predicates on one element scope");
+        derived_elem[s1][key] = bit;
+        std::vector<uint32_t> block;
+        std::vector<uint32_t>* saved = cur_code;
+        std::map<int, uint32_t> saved_looped = looped;
+        cur_code = &block;
+        looped.clear();
+        looped[q1] = s1;
+        int acc = alloc();
+        emit(finst(F_LOOP, s1, 0, acc));
+        int r = lower_exists_loop(f);
+        emit(finst(F_STE, r, s1, bit));
+        emit(finst(F_ENDLOOP, acc, r));
+        release(r);
+        release(acc);
+        looped = saved_looped;
+        cur_code = saved;
+        prologue.push_back(block);
+      } else bit = it->second;
+      int r = alloc();
+      emit(finst(F_LDE, r, s1, bit));
+      return r;
+    }
+    return lower_exists_loop(f);
+  }
+
+  // EXISTS as an explicit loop over the elements of its scope
+  int lower_exists_loop(const FP& f) {
+    int q = f->q;
     SPath elem = f->base;
     Step st; st.iter = true; st.q = q;
     elem.push_back(st);
@@ -656,7 +835,7 @@ HostPlan PlanBuilder::build(const PlanCaps& caps) {
   std::vector<FP> viols, matches, errs;
   for (auto& c : cons_) {
     FP v = simplify(c.viol), m = simplify(c.m.match), e = simplify(c.m.error);
-    std::string vk = f_to_string(v), mk = f_to_string(m) + "##" + f_to_string(e);
+    std::string vk = canon(v), mk = canon(m) + "##" + canon(e);
     ConstraintSlot slot;
     auto it = viol_ids.find(vk);
     if (it == viol_ids.end()) { slot.viol = (uint16_t)viols.size(); viol_ids[vk] = slot.viol; viols.push_back(v); } else slot.viol = (uint16_t)it->second;
@@ -673,6 +852,12 @@ HostPlan PlanBuilder::build(const PlanCaps& caps) {
   }
   L.emit(finst(F_END));
   HostPlan& p = L.plan;
+  {   // derived-bit prologue blocks first (inner blocks were completed, hence appended, before outer ones)
+    std::vector<uint32_t> code;
+    for (auto& b : L.prologue) code.insert(code.end(), b.begin(), b.end());
+    code.insert(code.end(), p.code.begin(), p.code.end());
+    p.code.swap(code);
+  }
   p.n_viol = (uint32_t)viols.size();
   p.n_match = (uint32_t)matches.size();
   // accumulator layout
@@ -688,7 +873,7 @@ HostPlan PlanBuilder::build(const PlanCaps& caps) {
     sc.word_off = off;
     off += (uint32_t)sc.cap * sc.wpe;
     sc.val_off = off;
-    off += (uint32_t)sc.cap * sc.nvals * 3;
+    off += (uint32_t)sc.cap * sc.nvals;
     p.scopes.push_back(sc);
   }
   p.dims.n_preds = (uint32_t)p.preds.size();
@@ -731,13 +916,13 @@ void HostPlan::resolve_paths(const PathDict& dict) {
     for (uint32_t id : cur) per_path[id].push_back(pi);
   }
   ptab.assign(n, 0);
-  pred_list.clear();
-  pred_list.push_back(0);   // keep entry 0 unused so that ptab == 0 means "none"
+  path_preds.clear();
+  path_preds.push_back(Pred{});   // keep entry 0 unused so that ptab == 0 means "none"
   for (uint32_t i = 0; i < n; i++) {
     if (per_path[i].empty()) continue;
     if (per_path[i].size() > 255) throw Unsupported("more than 255 predicates on one path");
-    ptab[i] = ((uint32_t)pred_list.size() << 8) | (uint32_t)per_path[i].size();
-    pred_list.insert(pred_list.end(), per_path[i].begin(), per_path[i].end());
+    ptab[i] = ((uint32_t)path_preds.size() << 8) | (uint32_t)per_path[i].size();
+    for (uint32_t pi : per_path[i]) path_preds.push_back(preds[pi]);
   }
   dict_size = n;
   dims.n_paths = n;

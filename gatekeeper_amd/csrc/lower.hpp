@@ -23,7 +23,7 @@ struct MatchFormulas {
 MatchFormulas compile_match(const Value& match_spec);
 
 struct PlanCaps {
-  uint16_t level_cap[3] = {16, 32, 32};   // element capacity per array-nesting level
+  uint16_t level_cap[3] = {8, 16, 16};   // element capacity per array-nesting level
 };
 
 struct PatStep {
@@ -45,7 +45,8 @@ struct HostPlan {
   uint32_t n_viol = 0, n_match = 0;       // unique formulas
   PlanDims dims{};
   // path table (depends on the dictionary contents at build time)
-  std::vector<uint32_t> ptab, pred_list;
+  std::vector<uint32_t> ptab;
+  std::vector<Pred> path_preds;           // predicates grouped by path id (what the device reads)
   uint32_t dict_size = 0;
   void resolve_paths(const PathDict& dict);   // (re)builds ptab / pred_list for the current dictionary
 };

@@ -84,6 +84,7 @@ std::string f_to_string(const FP& f) {
         case Atom::COUNT_CMP: return "count(" + p + ") " + cmpn[a.cmp] + " " + to_term_string(a.k);
         case Atom::FLAG: return "flag" + std::to_string(a.flag);
         case Atom::VEQ: return p + " === " + spath_to_string(a.path2);
+        case Atom::SPLIT_PREFIX: return "splitprefix(" + p + "," + to_term_string(a.k) + ")";
         case Atom::KEYCMP: return "key(q" + std::to_string(a.q) + ") " + cmpn[a.cmp] + " " + to_term_string(a.k);
       }
     }

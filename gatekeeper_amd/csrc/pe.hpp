@@ -30,7 +30,7 @@ typedef std::vector<Step> SPath;   // rooted at input.review
 
 struct Atom {
   enum Kind { DEFINED, TRUTHY, CMP, TYPE, STR_PREFIX, STR_SUFFIX, STR_CONTAINS, STR_IN_SET, SPLIT_CMP, SPLIT_COUNT,
-              COUNT_CMP, FLAG, VEQ, KEYCMP } kind = DEFINED;
+              COUNT_CMP, FLAG, VEQ, KEYCMP, SPLIT_PREFIX } kind = DEFINED;
   SPath path;
   int cmp = 0;          // CmpOp
   Value k;              // constant operand (CMP / STR_* / SPLIT_* / COUNT_CMP / KEYCMP; STR_IN_SET: set/array of strings)

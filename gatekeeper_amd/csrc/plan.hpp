@@ -76,6 +76,7 @@ enum PredOp : uint32_t {
   P_STORE = 11,      // store row value into an element value slot (joins)
   P_COUNT_CMP = 12,  // member count of container / byte length of string <op> const int
   P_PRESENT = 13,    // element marker: sets bit 0 and parent ordinal of the element word
+  P_SPLIT_PREFIX = 14,  // split(trim(row, cut), sep) starts with the constant component list (fused path-prefix test)
 };
 enum CmpOp : uint32_t { C_EQ = 0, C_NE = 1, C_LT = 2, C_LE = 3, C_GT = 4, C_GE = 5 };
 enum PredDst : uint32_t { D_GLOBAL = 0, D_ELEM = 1 };
@@ -101,7 +102,7 @@ struct Scope {
   uint32_t val_off;    // first accumulator word of value slots
   uint32_t count_off;  // accumulator word holding max ordinal + 1
   uint16_t cap;        // element capacity in this variant
-  uint8_t nvals;       // value slots per element (3 words each: lo, hi, type|valid)
+  uint8_t nvals;       // value slots per element (1 word each: row index + 1 of the stored value)
   uint8_t wpe;         // accumulator words per element
 };
 
@@ -122,6 +123,8 @@ enum FOp : uint32_t {
   F_VEQ = 12,   // a = (value slot == value slot); followed by one extra word scopeA | slotA<<8 | scopeB<<16 | slotB<<24
   F_RES = 13,   // result[b (0 viol, 1 match, 2 error)][c] = reg a
   F_END = 14,
+  F_STE = 15,   // derived element bit: bit c of the current element of scope b |= reg a  (common-subformula cache)
+  F_STG = 16,   // derived global bit (b | c<<8) |= reg a
 };
 inline constexpr uint32_t finst(uint32_t op, uint32_t a = 0, uint32_t b = 0, uint32_t c = 0) {
   return op | (a << 8) | (b << 16) | (c << 24);

@@ -3,16 +3,33 @@
 // It executes exactly the same per-row / per-review code as kernels.hip, lane by lane.  The product library
 // (libgkgpu.so) never contains this file; gatekeeper_amd/_lib.py refuses to load it outside tests.
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 
+#include <dlfcn.h>
+#include <unistd.h>
+
+#include <fstream>
+
+#include "codegen.hpp"
 #include "device.hpp"
 #include "vm_core.hpp"
 
 namespace gk {
 
 struct DevTable { HostTable t; int pending = 0; };
-struct DevPlan { HostPlan fast, big; };
+typedef void (*HeRowFn)(const Row*, uint32_t, uint32_t, const PlanView*, const uint8_t*, std::vector<uint32_t>*);
+typedef void (*HeFormFn)(const PlanView*, std::vector<uint32_t>*, uint32_t, const Row*, const uint8_t*, const uint32_t*, Results*);
+struct DevPlan {
+  HostPlan fast, big;
+  // GK_HOSTEMU_JIT=1: the plan-specialised source (codegen.cpp, the text hiprtc compiles on the GPU) built with g++
+  void* dl = nullptr;
+  HeRowFn row = nullptr;
+  HeFormFn form = nullptr;
+  std::vector<uint32_t> cls;
+};
 
 struct VecAcc {
   std::vector<uint32_t>* w;
@@ -27,22 +44,51 @@ int dev_count() { return 0; }
 DevTable* dev_table_upload(const HostTable& t) { DevTable* d = new DevTable(); d->t = t; d->t.heap.resize(d->t.heap.size() + 16, 0); return d; }
 void dev_table_free(DevTable* t) { delete t; }
 uint64_t dev_table_bytes(const DevTable* t) { return t->t.rows.size() * 16 + t->t.heap.size(); }
-DevPlan* dev_plan_upload(const HostPlan& fast, const HostPlan& big) { DevPlan* p = new DevPlan(); p->fast = fast; p->big = big; return p; }
-void dev_plan_free(DevPlan* p) { delete p; }
+DevPlan* dev_plan_upload(const HostPlan& fast, const HostPlan& big) {
+  DevPlan* p = new DevPlan();
+  p->fast = fast; p->big = big;
+  if (getenv("GK_HOSTEMU_JIT")) {
+    static int counter = 0;
+    std::string base = "/tmp/gkjit_hostemu_" + std::to_string(getpid()) + "_" + std::to_string(counter++);
+    {
+      std::ofstream f(base + ".cpp");
+      f << "#include <vector>\n#include \"" << GK_CSRC_DIR << "/vm_core.hpp\"\n" << generate_plan_source(fast)
+        << "struct VecAcc { std::vector<uint32_t>* w; void or_word(uint32_t i, uint32_t m) { (*w)[i] |= m; } void max_word(uint32_t i, uint32_t v) { if ((*w)[i] < v) (*w)[i] = v; }\n"
+           "  void store_word(uint32_t i, uint32_t v) { (*w)[i] = v; } uint32_t load(uint32_t i) const { return (*w)[i]; } };\n"
+           "extern \"C\" void gk_he_row(const gk::Row* r, uint32_t i, uint32_t cls, const gk::PlanView* pv, const uint8_t* heap, std::vector<uint32_t>* w) { VecAcc acc{w}; gk::jit_row(*r, i, cls, *pv, heap, acc); }\n"
+           "extern \"C\" void gk_he_form(const gk::PlanView* pv, std::vector<uint32_t>* w, uint32_t flags, const gk::Row* rows, const uint8_t* heap, const uint32_t* bounds, gk::Results* out) { VecAcc acc{w}; *out = gk::jit_formulas(*pv, acc, flags, rows, heap, bounds); }\n";
+    }
+    std::string cmd = "g++ -std=c++17 -O1 -shared -fPIC -o " + base + ".so " + base + ".cpp 2> " + base + ".log";
+    if (system(cmd.c_str()) != 0) throw std::runtime_error("hostemu: generated plan source does not compile, see " + base + ".log");
+    p->dl = dlopen((base + ".so").c_str(), RTLD_NOW);
+    if (!p->dl) throw std::runtime_error(std::string("hostemu: dlopen failed: ") + dlerror());
+    p->row = (HeRowFn)dlsym(p->dl, "gk_he_row");
+    p->form = (HeFormFn)dlsym(p->dl, "gk_he_form");
+    std::vector<std::vector<Pred>> classes;
+    p->cls = jit_path_classes(fast, &classes);
+    unlink((base + ".cpp").c_str()); unlink((base + ".so").c_str()); unlink((base + ".log").c_str());
+  }
+  return p;
+}
+void dev_plan_free(DevPlan* p) { if (p && p->dl) dlclose(p->dl); delete p; }
 
 static PlanView view_of(const HostPlan& h) {
-  return PlanView{h.ptab.data(), h.pred_list.data(), h.preds.data(), h.scopes.data(), h.code.data(), h.cheap.data(), h.dims};
+  return PlanView{h.ptab.data(), h.path_preds.data(), h.scopes.data(), h.code.data(), h.cheap.data(), h.dims};
 }
 
-static bool eval_review(const HostPlan& hp, const HostTable& t, uint32_t r, Results* res) {
+static bool eval_review(const HostPlan& hp, const HostTable& t, uint32_t r, Results* res, const DevPlan* jit = nullptr) {
   PlanView pv = view_of(hp);
   std::vector<uint32_t> words(hp.dims.acc_words, 0);
   VecAcc acc{&words};
-  for (uint32_t i = t.hdrs[r].row_start; i < t.hdrs[r + 1].row_start; i++) eval_row(t.rows[i], pv, t.heap.data(), acc);
+  for (uint32_t i = t.hdrs[r].row_start; i < t.hdrs[r + 1].row_start; i++) {
+    if (jit) { uint32_t c = t.rows[i].path < jit->cls.size() ? jit->cls[t.rows[i].path] : 0; if (c) jit->row(&t.rows[i], i, c, &pv, t.heap.data(), &words); }
+    else eval_row(t.rows[i], i, pv, t.heap.data(), acc);
+  }
   if (words[0] & 1u) return false;   // overflow
   uint32_t bounds[GK_MAX_SCOPES] = {0};
   for (uint32_t s = 0; s < hp.dims.n_scopes; s++) bounds[s] = words[hp.scopes[s].count_off];
-  *res = eval_formulas(pv, acc, t.hdrs[r].flags, t.heap.data(), bounds);
+  if (jit) jit->form(&pv, &words, t.hdrs[r].flags, t.rows.data(), t.heap.data(), bounds, res);
+  else *res = eval_formulas(pv, acc, t.hdrs[r].flags, t.rows.data(), t.heap.data(), bounds);
   return true;
 }
 
@@ -63,7 +109,7 @@ void dev_eval_finish(const DevPlan* p, const DevTable* dt, const EvalOptions& op
     uint32_t tile = r / GK_TILE; uint64_t bit = 1ull << (r % GK_TILE);
     if (t.hdrs[r].flags & RF_TOO_BIG) { o->too_big[tile] |= bit; continue; }
     Results res{0, 0, 0};
-    if (!eval_review(p->fast, t, r, &res)) {
+    if (!eval_review(p->fast, t, r, &res, p->row ? p : nullptr)) {
       o->n_overflow++;
       if (!eval_review(p->big, t, r, &res)) { o->too_big[tile] |= bit; continue; }
     }
@@ -80,6 +126,10 @@ void dev_eval_finish(const DevPlan* p, const DevTable* dt, const EvalOptions& op
       }
     }
   }
+#ifdef GK_COUNT_OPS
+  if (getenv("GK_PRINT_OPS")) fprintf(stderr, "[hostemu] formula ops per review: %.1f\n", (double)gk_op_counter / (n ? n : 1));
+  gk_op_counter = 0;
+#endif
   o->kernel_ms = o->fast_kernel_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 

@@ -9,13 +9,24 @@ from gatekeeper_amd import synth
 from oracle import client as OC
 from oracle import target as OT
 
-BACKENDS = [pytest.param("hostemu", id="hostemu"), pytest.param("gpu", marks=pytest.mark.gpu, id="gpu")]
+BACKENDS = [pytest.param("hostemu", id="hostemu"), pytest.param("hostemu-gen", id="hostemu-gen"),
+            pytest.param("gpu", marks=pytest.mark.gpu, id="gpu"), pytest.param("gpu-interp", marks=pytest.mark.gpu, id="gpu-interp")]
 
 
 def make_client(backend, **kw):
-    """backend 'gpu': the product library (HIP kernels on cuda:0).  backend 'hostemu': the TEST-ONLY build in which
-    the same vm_core.hpp code runs lane by lane on the CPU (GPU-less container)."""
-    drv = D.Driver(hostemu=(backend == "hostemu"), **kw)
+    """backend 'gpu': the product library on cuda:0 with the plan-specialised (hiprtc) kernel; 'gpu-interp': the same
+    library forced onto its generic bytecode kernel (GK_NO_JIT=1).  'hostemu' / 'hostemu-gen': the TEST-ONLY build in
+    which the interpreter / the generated plan source (compiled with g++) runs lane by lane on the CPU."""
+    os.environ.pop("GK_NO_JIT", None)
+    os.environ.pop("GK_HOSTEMU_JIT", None)
+    os.environ.pop("GK_JIT_STRICT", None)
+    if backend == "gpu-interp":
+        os.environ["GK_NO_JIT"] = "1"
+    if backend == "gpu":
+        os.environ["GK_JIT_STRICT"] = "1"   # a hiprtc failure must fail the test, not silently use the interpreter
+    if backend == "hostemu-gen":
+        os.environ["GK_HOSTEMU_JIT"] = "1"
+    drv = D.Driver(hostemu=backend.startswith("hostemu"), **kw)
     return D.Client(drv)
 
 
