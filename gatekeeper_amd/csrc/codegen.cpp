@@ -51,14 +51,14 @@ std::string generate_plan_source(const HostPlan& plan) {
   jit_path_classes(plan, &classes);
   o << "namespace gk {\n";
   // ---------------------------------------------------------------------------------------------- phase 1
-  o << "template <class Acc>\nGK_HD void jit_row(const Row& r, uint32_t row_index, uint32_t cls, const PlanView& pv, const uint8_t* heap, Acc& acc) {\n"
-    << "  const uint8_t* cheap = pv.cheap;\n  (void)cheap; (void)row_index;\n  switch (cls) {\n";
+  o << "template <class Acc>\nGK_HD void jit_row(const Row& r, uint32_t row_index, uint32_t cls, const StrHdr& h, const PlanView& pv, const uint8_t* heap, Acc& acc) {\n"
+    << "  const uint8_t* cheap = pv.cheap;\n  (void)cheap; (void)row_index; (void)h;\n  switch (cls) {\n";
   for (size_t c = 1; c < classes.size(); c++) {
     o << "    case " << c << ": {\n";
     for (const Pred& p : classes[c]) {
       o << "      { constexpr Pred P = " << pred_literal(p) << ";\n";
       bool always = p.op == P_DEFINED || p.op == P_PRESENT || p.op == P_STORE;
-      o << "        if (" << (always ? "true" : "eval_pred(r, P, heap, cheap)") << ") {\n";
+      o << "        if (" << (always ? "true" : "eval_pred(r, P, h, heap, cheap)") << ") {\n";
       if (p.dst == D_GLOBAL) {
         o << "          acc.or_word(" << (p.bit >> 5) << "u, " << u(1u << (p.bit & 31)) << ");\n";
       } else {

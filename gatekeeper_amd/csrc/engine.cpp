@@ -13,6 +13,7 @@
 #include <sstream>
 
 #include "../../include/gkgpu.h"
+#include "codegen.hpp"
 #include "device.hpp"
 #include "flatten.hpp"
 #include "lower.hpp"
@@ -192,6 +193,10 @@ void ensure_plan(gk_engine* e) {
   } else {
     e->fast.resolve_paths(e->dict);
     e->big.resolve_paths(e->dict);
+  }
+  if (const char* dump = getenv("GK_PLAN_SOURCE_DUMP")) {   // debugging aid: the plan-specialised source text
+    FILE* f = fopen(dump, "w");
+    if (f) { std::string src = generate_plan_source(e->fast); fwrite(src.data(), 1, src.size(), f); fclose(f); }
   }
   if (e->dev_plan) { dev_plan_free(e->dev_plan); e->dev_plan = nullptr; }
   e->dev_plan = dev_plan_upload(e->fast, e->big);

@@ -193,20 +193,29 @@ void Flattener::emit(uint32_t path, uint32_t meta, uint32_t lo, uint32_t hi) {
 }
 
 uint32_t Flattener::put_string(const std::string& s, uint32_t* hash) {
+  // 16-byte aligned, zero-padded entry [u32 len][bytes][pad]: one aligned 16 B load fetches len + the first 12 bytes
   std::vector<uint8_t>& h = t_->heap;
   uint32_t n = (uint32_t)s.size();
-  size_t at = h.size();
-  h.resize(at + 4 + ((n + 3) & ~3u));
+  size_t at = (h.size() + 15) & ~(size_t)15;
+  h.resize(at + ((4 + (size_t)n + 15) & ~(size_t)15));
   memcpy(&h[at], &n, 4);
   memcpy(&h[at + 4], s.data(), n);
   *hash = hash32((const uint8_t*)s.data(), n);
   return (uint32_t)(at + 4);
 }
 
-void Flattener::emit_str(uint32_t parent, const char* key, const std::string& s) {
+void Flattener::emit_string_row(uint32_t path, uint32_t meta, const std::string& s) {
+  if (s.size() <= 7) {   // inline: no heap entry, no memory access on the device
+    uint64_t bits = 0;
+    memcpy(&bits, s.data(), s.size());
+    emit(path, meta | T_STRING | ROW_STR_INLINE, (uint32_t)bits, (uint32_t)(bits >> 32) | ((uint32_t)s.size() << 24));
+    return;
+  }
   uint32_t hsh, off = put_string(s, &hsh);
-  emit(dict_->child(parent, key), T_STRING, off, hsh);
+  emit(path, meta | T_STRING, off, hsh);
 }
+
+void Flattener::emit_str(uint32_t parent, const char* key, const std::string& s) { emit_string_row(dict_->child(parent, key), 0, s); }
 
 void Flattener::walk(const Value& v, uint32_t path, uint32_t ords, int adepth, uint32_t extra) {
   uint32_t meta = ords | extra;
@@ -224,11 +233,7 @@ void Flattener::walk(const Value& v, uint32_t path, uint32_t ords, int adepth, u
         emit(path, meta | T_FLOAT | (v.is_int ? ROW_INEXACT : 0), (uint32_t)u, (uint32_t)(u >> 32));
       }
       break;
-    case Value::String: {
-      uint32_t hsh, off = put_string(v.str(), &hsh);
-      emit(path, meta | T_STRING, off, hsh);
-      break;
-    }
+    case Value::String: emit_string_row(path, meta, v.str()); break;
     case Value::Object: {
       emit(path, meta | T_OBJECT, (uint32_t)v.size(), 0);
       for (const auto& kv : v.pairs()) walk(kv.second, dict_->child(path, kv.first.str()), ords, adepth, extra);

@@ -106,6 +106,7 @@ class Flattener {
   void emit(uint32_t path, uint32_t meta, uint32_t lo, uint32_t hi);
   uint32_t put_string(const std::string& s, uint32_t* hash);
   void emit_str(uint32_t parent, const char* key, const std::string& s);
+  void emit_string_row(uint32_t path, uint32_t meta, const std::string& s);
   void match_facts(const Value& obj, const Value& ns, bool is_old, uint32_t m_parent);
 };
 

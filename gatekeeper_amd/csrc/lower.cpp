@@ -401,6 +401,12 @@ std::string canon(const FP& f, const std::vector<int>& first = {}) {
   return f_to_string(rename_f(f, m));
 }
 
+// key of a constant string as the device compares it: packed bytes (len <= 7) or hash32
+uint64_t string_key(const std::string& s) {
+  if (s.size() <= 7) { uint64_t k = 0; memcpy(&k, s.data(), s.size()); return k; }
+  return hash32(s);
+}
+
 struct Lowerer {
   PathDict* dict;
   HostPlan plan;
@@ -435,9 +441,11 @@ struct Lowerer {
   uint32_t put_bytes(const std::string& s) {
     auto it = cheap_strings.find(s);
     if (it != cheap_strings.end()) return it->second;
+    while (plan.cheap.size() & 15) plan.cheap.push_back(0);
     uint32_t off = (uint32_t)plan.cheap.size();
     plan.cheap.insert(plan.cheap.end(), s.begin(), s.end());
-    while (plan.cheap.size() & 3) plan.cheap.push_back(0);
+    plan.cheap.push_back(0);                       // device loops may read one zero word past short constants
+    while (plan.cheap.size() & 15) plan.cheap.push_back(0);
     cheap_strings[s] = off;
     return off;
   }
@@ -469,7 +477,7 @@ struct Lowerer {
   Pred make_pred(const Atom& a) {
     Pred p{};
     p.cmp = (uint8_t)a.cmp;
-    auto put_const_string = [&](const Value& v) { p.a = put_bytes(v.str()); p.b = (uint32_t)v.str().size(); p.k = hash32(v.str()); };
+    auto put_const_string = [&](const Value& v) { p.a = put_bytes(v.str()); p.b = (uint32_t)v.str().size(); p.k = string_key(v.str()); };
     switch (a.kind) {
       case Atom::DEFINED: p.op = P_DEFINED; break;
       case Atom::TRUTHY: p.op = P_TRUTHY; break;
@@ -498,7 +506,13 @@ struct Lowerer {
         p.a = (uint32_t)plan.cheap.size();
         p.b = (uint32_t)ents.size();
         size_t i = 0;
-        for (auto& v : a.k.items()) { put_u32(hash32(v.str())); put_u32(ents[i].first); put_u32(ents[i].second); i++; }
+        for (auto& v : a.k.items()) {
+          const std::string& str = v.str();
+          if (str.size() <= 7) { uint64_t k = string_key(str); put_u32((uint32_t)k); put_u32((uint32_t)(k >> 32)); }
+          else { put_u32(hash32(str)); put_u32(ents[i].first); }
+          put_u32(ents[i].second);
+          i++;
+        }
         break;
       }
       case Atom::SPLIT_CMP:

@@ -31,8 +31,11 @@ constexpr uint32_t ROW_E_MASK = 0xFF;
 constexpr uint32_t ROW_ORD_OVERFLOW = 1u << 28;  // an enclosing ordinal did not fit in 8 bits (saturated at 255)
 constexpr uint32_t ROW_DEEP = 1u << 29;          // more than 3 enclosing arrays
 constexpr uint32_t ROW_INEXACT = 1u << 30;       // number not exactly representable (bigint / lossy float)
+constexpr uint32_t ROW_STR_INLINE = 1u << 31;    // string of <= 7 bytes packed into lo/hi (no heap entry)
 // value payload:  bool: lo=0/1 | int: hi:lo = int64 | float: hi:lo = f64 bits
-//                 string: lo = byte offset in the table heap (u32 length stored at off-4), hi = hash32(bytes)
+//                 string (<= 7 bytes, ROW_STR_INLINE): lo = bytes 0..3, hi = bytes 4..6 | len << 24
+//                 string (longer): lo = byte offset in the table heap of a 16-byte aligned entry [u32 len][bytes][pad]
+//                                  (so off-4 is 16-byte aligned), hi = hash32(bytes)
 //                 object/array: lo = member count
 
 struct ReviewHdr {
@@ -91,7 +94,7 @@ struct Pred {
   uint8_t ctype;    // RowType of the constant (P_CMP); type mask (P_TYPE)
   uint32_t a;       // const-heap byte offset (string / set)
   uint32_t b;       // const length / set size
-  uint64_t k;       // immediate: int64 / f64 bits / hash32
+  uint64_t k;       // immediate: int64 / f64 bits / string constant key (packed bytes if len <= 7, else hash32)
   int32_t idx;      // P_SPLIT_CMP component index (negative = from the end)
   uint32_t pad;     // P_SPLIT_*: (cut << 8) | sep
 };

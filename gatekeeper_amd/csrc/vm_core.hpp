@@ -36,10 +36,7 @@ struct PlanView {
 
 GK_HD uint32_t row_type(const Row& r) { return r.meta & ROW_TYPE_MASK; }
 GK_HD uint32_t row_ordinal(const Row& r, uint32_t level) { return (r.meta >> (ROW_E_SHIFT0 + 8 * level)) & ROW_E_MASK; }
-// Strings live in 4-byte aligned, zero-padded heap entries [u32 len][bytes][pad]: everything below uses aligned
-// 32-bit loads and accumulates differences without data-dependent early exits, so the loads of one predicate pipeline.
 GK_HD uint32_t ld32(const uint8_t* p) { return *reinterpret_cast<const uint32_t*>(p); }
-GK_HD uint32_t heap_len(const uint8_t* heap, uint32_t off) { return ld32(heap + off - 4); }
 GK_HD int64_t row_i64(const Row& r) { return (int64_t)(((uint64_t)r.hi << 32) | r.lo); }
 GK_HD double bits_f64(uint64_t b) {
   union { uint64_t u; double d; } x;
@@ -48,32 +45,84 @@ GK_HD double bits_f64(uint64_t b) {
 }
 GK_HD double row_f64(const Row& r) { return bits_f64(((uint64_t)r.hi << 32) | r.lo); }
 
-GK_HD int bytes_cmp(const uint8_t* a, uint32_t na, const uint8_t* b, uint32_t nb) {   // ordering compares only (rare)
-  uint32_t n = na < nb ? na : nb;
-  for (uint32_t i = 0; i < n; i++) {
-    if (a[i] != b[i]) return a[i] < b[i] ? -1 : 1;
+// ------------------------------------------------------------------------------------------------ strings
+// A string row is either INLINE (ROW_STR_INLINE: length <= 7, bytes packed in lo/hi, no memory access at all -- kinds,
+// short names, label values ...) or a HEAP string: lo = byte offset of a 16-byte aligned, zero-padded entry
+// [u32 len][bytes][pad], hi = hash32.  The 16-byte entry header (length + first 12 bytes) is fetched with ONE aligned
+// load, convergently for all lanes of a wave BEFORE the divergent predicate dispatch (kernel_body.inc), so most
+// predicates are decided without a dependent memory access inside a divergent branch.
+struct StrHdr { uint32_t w[4]; };
+
+GK_HD bool row_needs_hdr(const Row& r) { return (r.meta & ROW_TYPE_MASK) == T_STRING && !(r.meta & ROW_STR_INLINE); }
+GK_HD StrHdr load_hdr(const Row& r, const uint8_t* heap) {
+  StrHdr h;
+  const uint8_t* p = heap + r.lo - 4;
+  h.w[0] = ld32(p); h.w[1] = ld32(p + 4); h.w[2] = ld32(p + 8); h.w[3] = ld32(p + 12);
+  return h;
+}
+
+struct StrRef {
+  uint32_t n;          // length in bytes
+  uint64_t bits;       // first 8 bytes, zero padded (all of an inline string)
+  uint32_t w2;         // bytes 8..11 (heap strings)
+  uint32_t hash;       // heap strings only
+  const uint8_t* p;    // heap bytes (nullptr for inline strings)
+};
+GK_HD StrRef make_str(const Row& r, const StrHdr& h, const uint8_t* heap) {
+  StrRef s;
+  if (r.meta & ROW_STR_INLINE) {
+    s.n = r.hi >> 24; s.bits = ((uint64_t)(r.hi & 0x00FFFFFFu) << 32) | r.lo; s.w2 = 0; s.hash = 0; s.p = nullptr;
+  } else {
+    s.n = h.w[0]; s.bits = ((uint64_t)h.w[2] << 32) | h.w[1]; s.w2 = h.w[3]; s.hash = r.hi; s.p = heap + r.lo;
   }
-  return na < nb ? -1 : (na > nb ? 1 : 0);
+  return s;
 }
-// n bytes at two 4-aligned, zero-padded addresses are equal (whole strings of equal length)
-GK_HD bool words_eq(const uint8_t* a, const uint8_t* b, uint32_t n) {
-  uint32_t d = 0;
-  for (uint32_t j = 0; j < n; j += 4) d |= ld32(a + j) ^ ld32(b + j);
+GK_HD uint32_t sbyte(const StrRef& s, uint32_t i) {
+  if (i < 8) return (uint32_t)(s.bits >> (8 * i)) & 0xFFu;
+  if (i < 12) return (s.w2 >> (8 * (i - 8))) & 0xFFu;
+  return s.p[i];
+}
+GK_HD uint64_t mask_bytes(uint32_t m) { return m >= 8 ? ~0ull : ((1ull << (8 * m)) - 1ull); }
+
+// constant strings: bytes at cheap + off (16-byte aligned, zero padded), length len, key = packed bytes (len <= 7) or hash32
+GK_HD bool str_eq_c(const StrRef& s, const uint8_t* c, uint32_t len, uint64_t key) {
+  if (s.n != len) return false;
+  if (len <= 7) return s.bits == key;
+  if (s.hash != (uint32_t)key) return false;
+  uint32_t d = ((uint32_t)s.bits ^ ld32(c)) | ((uint32_t)(s.bits >> 32) ^ ld32(c + 4)) | (s.w2 ^ ld32(c + 8));
+  for (uint32_t j = 12; j < len; j += 4) d |= ld32(s.p + j) ^ ld32(c + j);
   return d == 0;
 }
-// first m bytes at 4-aligned s equal the 4-aligned constant c
-GK_HD bool prefix_eq(const uint8_t* s, const uint8_t* c, uint32_t m) {
-  uint32_t d = 0, full = m & ~3u;
-  for (uint32_t j = 0; j < full; j += 4) d |= ld32(s + j) ^ ld32(c + j);
+GK_HD bool str_prefix_c(const StrRef& s, const uint8_t* c, uint32_t m, uint64_t key) {
+  if (m == 0) return true;
+  if (s.n < m) return false;
+  if (m <= 7) return ((s.bits ^ key) & mask_bytes(m)) == 0;
+  uint32_t d = ((uint32_t)s.bits ^ ld32(c)) | ((uint32_t)(s.bits >> 32) ^ ld32(c + 4));
+  if (m <= 12) {
+    uint32_t r = m - 8;
+    uint32_t mk = r == 4 ? ~0u : ((1u << (8 * r)) - 1u);
+    return (d | ((s.w2 ^ ld32(c + 8)) & mk)) == 0;
+  }
+  d |= s.w2 ^ ld32(c + 8);
+  uint32_t full = m & ~3u;
+  for (uint32_t j = 12; j < full; j += 4) d |= ld32(s.p + j) ^ ld32(c + j);
   uint32_t r = m & 3u;
-  if (r) d |= (ld32(s + full) ^ ld32(c + full)) & ((1u << (8 * r)) - 1u);
+  if (r) d |= (ld32(s.p + full) ^ ld32(c + full)) & ((1u << (8 * r)) - 1u);
   return d == 0;
 }
-// m bytes at an arbitrary (unaligned) s equal the 4-aligned constant c
-GK_HD bool bytes_eq(const uint8_t* s, const uint8_t* c, uint32_t m) {
+// m bytes of s starting at byte `at` equal the constant bytes c[0..m)
+GK_HD bool str_at_c(const StrRef& s, uint32_t at, const uint8_t* c, uint32_t m) {
   uint32_t d = 0;
-  for (uint32_t i = 0; i < m; i++) d |= (uint32_t)(s[i] ^ c[i]);
+  for (uint32_t i = 0; i < m; i++) d |= sbyte(s, at + i) ^ (uint32_t)c[i];
   return d == 0;
+}
+GK_HD int str_cmp_c(const StrRef& s, uint32_t at, uint32_t n, const uint8_t* c, uint32_t nc) {   // ordering (rare)
+  uint32_t k = n < nc ? n : nc;
+  for (uint32_t i = 0; i < k; i++) {
+    uint32_t x = sbyte(s, at + i), y = c[i];
+    if (x != y) return x < y ? -1 : 1;
+  }
+  return n < nc ? -1 : (n > nc ? 1 : 0);
 }
 
 // Rego type rank: null < boolean < number < string < array < object < set
@@ -101,7 +150,7 @@ GK_HD bool cmp_test(int c, uint32_t op) {
 
 // three-way compare(row, scalar constant of predicate p). Composite rows only compare by rank (the compiler never
 // emits equality between a row and a composite constant).
-GK_HD int cmp_row_const(const Row& r, const Pred& p, const uint8_t* heap, const uint8_t* cheap) {
+GK_HD int cmp_row_const(const Row& r, const Pred& p, const StrHdr& h, const uint8_t* heap, const uint8_t* cheap) {
   uint32_t t = row_type(r);
   int ra = type_rank(t), rb = type_rank(p.ctype);
   if (ra != rb) return ra < rb ? -1 : 1;
@@ -116,34 +165,30 @@ GK_HD int cmp_row_const(const Row& r, const Pred& p, const uint8_t* heap, const 
       return a < b ? -1 : (a > b ? 1 : 0);
     }
     case T_STRING: {
-      if (p.cmp == C_EQ || p.cmp == C_NE) {   // equality never needs the ordering: hash is a fast reject, bytes decide
-        if (r.hi != (uint32_t)p.k) return 1;
-        uint32_t n = heap_len(heap, r.lo);
-        return (n == p.b && words_eq(heap + r.lo, cheap + p.a, n)) ? 0 : 1;
-      }
-      return bytes_cmp(heap + r.lo, heap_len(heap, r.lo), cheap + p.a, p.b);
+      StrRef sr = make_str(r, h, heap);
+      if (p.cmp == C_EQ || p.cmp == C_NE) return str_eq_c(sr, cheap + p.a, p.b, p.k) ? 0 : 1;   // equality never needs the ordering
+      return str_cmp_c(sr, 0, sr.n, cheap + p.a, p.b);
     }
     default: return 0;
   }
 }
 
 // component `idx` of split(trim(s, cut), sep): returns false when it does not exist.
-GK_HD bool split_component(const uint8_t* s, uint32_t n, uint8_t cut, uint8_t sep, int32_t idx, uint32_t* off, uint32_t* len,
-                           uint32_t* count) {
-  uint32_t lo = 0, hi = n;
+GK_HD bool split_component(const StrRef& s, uint8_t cut, uint8_t sep, int32_t idx, uint32_t* off, uint32_t* len, uint32_t* count) {
+  uint32_t lo = 0, hi = s.n;
   if (cut) {
-    while (lo < hi && s[lo] == cut) lo++;
-    while (hi > lo && s[hi - 1] == cut) hi--;
+    while (lo < hi && sbyte(s, lo) == cut) lo++;
+    while (hi > lo && sbyte(s, hi - 1) == cut) hi--;
   }
   uint32_t cnt = 1;
-  for (uint32_t i = lo; i < hi; i++) cnt += (s[i] == sep);
+  for (uint32_t i = lo; i < hi; i++) cnt += (sbyte(s, i) == sep);
   *count = cnt;
   int32_t want = idx >= 0 ? idx : (int32_t)cnt + idx;
   if (want < 0 || want >= (int32_t)cnt) return false;
   uint32_t start = lo;
   int32_t k = 0;
   for (uint32_t i = lo; i <= hi; i++) {
-    if (i == hi || s[i] == sep) {
+    if (i == hi || sbyte(s, i) == sep) {
       if (k == want) { *off = start; *len = i - start; return true; }
       k++;
       start = i + 1;
@@ -152,64 +197,67 @@ GK_HD bool split_component(const uint8_t* s, uint32_t n, uint8_t cut, uint8_t se
   return false;
 }
 
-GK_HD bool eval_pred(const Row& r, const Pred& p, const uint8_t* heap, const uint8_t* cheap) {
+GK_HD bool eval_pred(const Row& r, const Pred& p, const StrHdr& h, const uint8_t* heap, const uint8_t* cheap) {
   uint32_t t = row_type(r);
   switch (p.op) {
     case P_DEFINED: case P_PRESENT: case P_STORE: return true;
     case P_TRUTHY: return !(t == T_BOOL && r.lo == 0);
-    case P_CMP: return cmp_test(cmp_row_const(r, p, heap, cheap), p.cmp);
+    case P_CMP: return cmp_test(cmp_row_const(r, p, h, heap, cheap), p.cmp);
     case P_TYPE: return ((1u << t) & p.ctype) != 0;
     case P_STR_PREFIX: case P_STR_SUFFIX: case P_STR_CONTAINS: {
       if (t != T_STRING) return false;
       uint32_t m = p.b;
       if (m == 0) return true;
-      uint32_t n = heap_len(heap, r.lo);
-      if (m > n) return false;
-      const uint8_t* s = heap + r.lo;
+      StrRef s = make_str(r, h, heap);
+      if (m > s.n) return false;
       const uint8_t* c = cheap + p.a;
-      if (p.op == P_STR_PREFIX) return prefix_eq(s, c, m);
-      if (p.op == P_STR_SUFFIX) return bytes_eq(s + (n - m), c, m);
+      if (p.op == P_STR_PREFIX) return str_prefix_c(s, c, m, p.k);
+      if (p.op == P_STR_SUFFIX) return str_at_c(s, s.n - m, c, m);
       bool any = false;
-      for (uint32_t i = 0; i + m <= n; i++) any = any || bytes_eq(s + i, c, m);
+      for (uint32_t i = 0; i + m <= s.n; i++) any = any || str_at_c(s, i, c, m);
       return any;
     }
     case P_STR_IN_SET: {
       if (t != T_STRING) return false;
-      // set record in the const heap at p.a (4-aligned): p.b entries of {u32 hash, u32 off, u32 len}
+      // set record in the const heap at p.a (4-aligned): p.b entries {u32 a, u32 b, u32 len}:
+      //   len <= 7: (a, b) = packed bytes;  else a = hash32, b = const-heap offset of the bytes
+      StrRef s = make_str(r, h, heap);
       const uint8_t* e = cheap + p.a;
       bool hit = false;
       for (uint32_t i = 0; i < p.b; i++, e += 12) {
-        if (ld32(e) != r.hi) continue;
-        uint32_t n = heap_len(heap, r.lo);
-        if (ld32(e + 8) == n && words_eq(heap + r.lo, cheap + ld32(e + 4), n)) hit = true;
+        uint32_t len = ld32(e + 8);
+        if (len != s.n) continue;
+        uint32_t ea = ld32(e), eb = ld32(e + 4);
+        if (len <= 7) hit = hit || (s.bits == (((uint64_t)eb << 32) | ea));
+        else if (ea == s.hash) hit = hit || str_eq_c(s, cheap + eb, len, ea);
       }
       return hit;
     }
     case P_SPLIT_PREFIX: {
       // trim(s, cut) == P  or  trim(s, cut) starts with P + sep      (P = components joined by sep)
       if (t != T_STRING) return false;
-      uint32_t n = heap_len(heap, r.lo);
-      const uint8_t* s = heap + r.lo;
+      StrRef s = make_str(r, h, heap);
       uint8_t cut = (uint8_t)(p.pad >> 8), sep = (uint8_t)(p.pad & 0xFF);
-      uint32_t lo = 0, hi = n;
+      uint32_t lo = 0, hi = s.n;
       if (cut) {
-        while (lo < hi && s[lo] == cut) lo++;
-        while (hi > lo && s[hi - 1] == cut) hi--;
+        while (lo < hi && sbyte(s, lo) == cut) lo++;
+        while (hi > lo && sbyte(s, hi - 1) == cut) hi--;
       }
       uint32_t len = hi - lo, m = p.b;
       if (len < m) return false;
-      bool pre = (lo & 3u) == 0 ? prefix_eq(s + lo, cheap + p.a, m) : bytes_eq(s + lo, cheap + p.a, m);
-      if (!pre) return false;
-      return len == m || s[lo + m] == sep;
+      if (!str_at_c(s, lo, cheap + p.a, m)) return false;
+      return len == m || sbyte(s, lo + m) == sep;
     }
     case P_SPLIT_CMP: case P_SPLIT_COUNT: {
       if (t != T_STRING) return false;
-      uint32_t n = heap_len(heap, r.lo), off = 0, len = 0, cnt = 0;
+      StrRef s = make_str(r, h, heap);
+      uint32_t off = 0, len = 0, cnt = 0;
       uint8_t cut = (uint8_t)(p.pad >> 8), sep = (uint8_t)(p.pad & 0xFF);
-      bool have = split_component(heap + r.lo, n, cut, sep, p.idx, &off, &len, &cnt);
+      bool have = split_component(s, cut, sep, p.idx, &off, &len, &cnt);
       if (p.op == P_SPLIT_COUNT) { int64_t a = cnt, b = (int64_t)p.k; return cmp_test(a < b ? -1 : (a > b ? 1 : 0), p.cmp); }
       if (!have) return false;
-      return cmp_test(bytes_cmp(heap + r.lo + off, len, cheap + p.a, p.b), p.cmp);
+      if (p.cmp == C_EQ || p.cmp == C_NE) { bool eq = len == p.b && str_at_c(s, off, cheap + p.a, len); return (p.cmp == C_EQ) == eq; }
+      return cmp_test(str_cmp_c(s, off, len, cheap + p.a, p.b), p.cmp);
     }
     case P_COUNT_CMP: {
       int64_t a;
@@ -231,21 +279,23 @@ GK_HD uint32_t elem_mask_of_bit(uint32_t bit) { return bit < 24 ? (1u << bit) : 
 
 // Phase 1 for one row. `Acc` provides or_word(w, mask), max_word(w, v), store_word(w, v) for THIS row's review.
 template <class Acc>
-GK_HD void eval_row_ent(const Row& r, uint32_t row_index, uint32_t ent, const PlanView& pv, const uint8_t* heap, Acc& acc);
+GK_HD void eval_row_ent(const Row& r, uint32_t row_index, uint32_t ent, const StrHdr& h, const PlanView& pv, const uint8_t* heap, Acc& acc);
 template <class Acc>
 GK_HD void eval_row(const Row& r, uint32_t row_index, const PlanView& pv, const uint8_t* heap, Acc& acc) {
   if (r.path >= pv.dims.n_paths) return;
   uint32_t ent = pv.ptab[r.path];
   if (ent == 0) return;
-  eval_row_ent(r, row_index, ent, pv, heap, acc);
+  StrHdr h = {{0, 0, 0, 0}};
+  if (row_needs_hdr(r)) h = load_hdr(r, heap);
+  eval_row_ent(r, row_index, ent, h, pv, heap, acc);
 }
 // `ent` = the row's path-table entry (first << 8 | count), already fetched
 template <class Acc>
-GK_HD void eval_row_ent(const Row& r, uint32_t row_index, uint32_t ent, const PlanView& pv, const uint8_t* heap, Acc& acc) {
+GK_HD void eval_row_ent(const Row& r, uint32_t row_index, uint32_t ent, const StrHdr& h, const PlanView& pv, const uint8_t* heap, Acc& acc) {
   uint32_t first = ent >> 8, cnt = ent & 0xFF;
   for (uint32_t i = 0; i < cnt; i++) {
     const Pred& p = pv.preds[first + i];
-    if (!eval_pred(r, p, heap, pv.cheap)) continue;
+    if (!eval_pred(r, p, h, heap, pv.cheap)) continue;
     if (p.dst == D_GLOBAL) {
       acc.or_word(p.bit >> 5, 1u << (p.bit & 31));
       continue;
@@ -286,9 +336,16 @@ GK_HD bool val_eq(uint32_t sa, uint32_t sb, const Row* rows, const uint8_t* heap
       return x == y;
     }
     case T_STRING: {
-      if (a.hi != b.hi) return false;
-      uint32_t na = heap_len(heap, a.lo), nb = heap_len(heap, b.lo);
-      return na == nb && (a.lo == b.lo || words_eq(heap + a.lo, heap + b.lo, na));
+      bool ia = (a.meta & ROW_STR_INLINE) != 0, ib = (b.meta & ROW_STR_INLINE) != 0;
+      if (ia != ib) return false;                       // inline strings are <= 7 bytes, heap strings longer
+      if (ia) return a.lo == b.lo && a.hi == b.hi;      // packed bytes + length
+      if (a.hi != b.hi) return false;                   // hash32 fast reject
+      if (a.lo == b.lo) return true;
+      uint32_t na = ld32(heap + a.lo - 4), nb = ld32(heap + b.lo - 4);
+      if (na != nb) return false;
+      uint32_t d = 0;
+      for (uint32_t j = 0; j < na; j += 4) d |= ld32(heap + a.lo + j) ^ ld32(heap + b.lo + j);
+      return d == 0;
     }
     default: return false;   // composite joins are rejected by the compiler
   }

@@ -20,7 +20,7 @@
 namespace gk {
 
 struct DevTable { HostTable t; int pending = 0; };
-typedef void (*HeRowFn)(const Row*, uint32_t, uint32_t, const PlanView*, const uint8_t*, std::vector<uint32_t>*);
+typedef void (*HeRowFn)(const Row*, uint32_t, uint32_t, const StrHdr*, const PlanView*, const uint8_t*, std::vector<uint32_t>*);
 typedef void (*HeFormFn)(const PlanView*, std::vector<uint32_t>*, uint32_t, const Row*, const uint8_t*, const uint32_t*, Results*);
 struct DevPlan {
   HostPlan fast, big;
@@ -55,7 +55,7 @@ DevPlan* dev_plan_upload(const HostPlan& fast, const HostPlan& big) {
       f << "#include <vector>\n#include \"" << GK_CSRC_DIR << "/vm_core.hpp\"\n" << generate_plan_source(fast)
         << "struct VecAcc { std::vector<uint32_t>* w; void or_word(uint32_t i, uint32_t m) { (*w)[i] |= m; } void max_word(uint32_t i, uint32_t v) { if ((*w)[i] < v) (*w)[i] = v; }\n"
            "  void store_word(uint32_t i, uint32_t v) { (*w)[i] = v; } uint32_t load(uint32_t i) const { return (*w)[i]; } };\n"
-           "extern \"C\" void gk_he_row(const gk::Row* r, uint32_t i, uint32_t cls, const gk::PlanView* pv, const uint8_t* heap, std::vector<uint32_t>* w) { VecAcc acc{w}; gk::jit_row(*r, i, cls, *pv, heap, acc); }\n"
+           "extern \"C\" void gk_he_row(const gk::Row* r, uint32_t i, uint32_t cls, const gk::StrHdr* h, const gk::PlanView* pv, const uint8_t* heap, std::vector<uint32_t>* w) { VecAcc acc{w}; gk::jit_row(*r, i, cls, *h, *pv, heap, acc); }\n"
            "extern \"C\" void gk_he_form(const gk::PlanView* pv, std::vector<uint32_t>* w, uint32_t flags, const gk::Row* rows, const uint8_t* heap, const uint32_t* bounds, gk::Results* out) { VecAcc acc{w}; *out = gk::jit_formulas(*pv, acc, flags, rows, heap, bounds); }\n";
     }
     std::string cmd = "g++ -std=c++17 -O1 -shared -fPIC -o " + base + ".so " + base + ".cpp 2> " + base + ".log";
@@ -81,7 +81,7 @@ static bool eval_review(const HostPlan& hp, const HostTable& t, uint32_t r, Resu
   std::vector<uint32_t> words(hp.dims.acc_words, 0);
   VecAcc acc{&words};
   for (uint32_t i = t.hdrs[r].row_start; i < t.hdrs[r + 1].row_start; i++) {
-    if (jit) { uint32_t c = t.rows[i].path < jit->cls.size() ? jit->cls[t.rows[i].path] : 0; if (c) jit->row(&t.rows[i], i, c, &pv, t.heap.data(), &words); }
+    if (jit) { uint32_t c = t.rows[i].path < jit->cls.size() ? jit->cls[t.rows[i].path] : 0; if (c) { StrHdr h = {{0, 0, 0, 0}}; if (row_needs_hdr(t.rows[i])) h = load_hdr(t.rows[i], t.heap.data()); jit->row(&t.rows[i], i, c, &h, &pv, t.heap.data(), &words); } }
     else eval_row(t.rows[i], i, pv, t.heap.data(), acc);
   }
   if (words[0] & 1u) return false;   // overflow

@@ -13,7 +13,7 @@ d = json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('GK_DBG_PHASE=$ph avg_kernel_ms', d['roofline']['avg_kernel_ms'])" >> gpurun_out/${tag}_phases.log 2>&1
 done
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_prof -o ${tag} -- python bench.py --steps 30 --warmup 3 --no-cpu-baseline > gpurun_out/${tag}_prof_bench.json 2> gpurun_out/${tag}_prof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_prof -o ${tag} -- python bench.py --steps 30 --warmup 3 --no-cpu-baseline > gpurun_out/${tag}_prof_bench.json 2> gpurun_out/${tag}_prof.err
 find gpurun_out/${tag}_prof -name '*kernel_stats*' | head -3
 cat gpurun_out/${tag}_pytest_gpu.log | tail -3
 cat gpurun_out/${tag}_smoke.log | tail -2
