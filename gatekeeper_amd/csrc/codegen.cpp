@@ -65,7 +65,12 @@ std::string generate_plan_source(const HostPlan& plan) {
         const Scope& sc = plan.scopes[p.scope];
         o << "          const uint32_t ord = row_ordinal(r, " << (int)p.level << "u);\n"
           << "          if (ord >= " << sc.cap << "u || (r.meta & ROW_ORD_OVERFLOW)) acc.or_word(0u, 1u);\n          else {\n";
-        if (p.op == P_STORE) o << "            acc.store_word(" << sc.val_off << "u + ord * " << (int)sc.nvals << "u + " << p.bit << "u, row_index + 1u);\n";
+        if (p.op == P_STORE) {
+          uint32_t stride = sc.nvals * 2u + 1u;
+          o << "            const uint32_t vb = " << sc.val_off << "u + ord * " << stride << "u;\n"
+            << "            acc.store_word(vb + " << p.bit * 2u << "u, r.lo); acc.store_word(vb + " << p.bit * 2u + 1u << "u, r.hi);\n"
+            << "            acc.or_word(vb + " << sc.nvals * 2u << "u, val_nibble(r) << " << 4u * p.bit << "u);\n";
+        }
         else if (p.op == P_PRESENT) {
           if (p.level > 0) o << "            const uint32_t parent = row_ordinal(r, " << (int)(p.level - 1) << "u);\n";
           else o << "            const uint32_t parent = 0u;\n";
@@ -146,8 +151,10 @@ std::string generate_plan_source(const HostPlan& plan) {
         const Scope& B = plan.scopes[sb];
         int da = var_of(sa), db = var_of(sb);
         if (da < 0 || db < 0) throw Unsupported("codegen: join outside its loops");
-        o << ind << "b" << a << " = val_eq(acc.load(" << A.val_off << "u + e" << da << " * " << (int)A.nvals << "u + " << la << "u), acc.load(" << B.val_off
-          << "u + e" << db << " * " << (int)B.nvals << "u + " << lb << "u), rows, heap);\n";
+        uint32_t sa_ = A.nvals * 2u + 1u, sb_ = B.nvals * 2u + 1u;
+        o << ind << "{ const uint32_t wa = " << A.val_off << "u + e" << da << " * " << sa_ << "u, wb = " << B.val_off << "u + e" << db << " * " << sb_ << "u;\n"
+          << ind << "  b" << a << " = val_eq(acc.load(wa + " << la * 2u << "u), acc.load(wa + " << la * 2u + 1u << "u), (acc.load(wa + " << A.nvals * 2u << "u) >> " << 4u * la
+          << "u) & 15u, acc.load(wb + " << lb * 2u << "u), acc.load(wb + " << lb * 2u + 1u << "u), (acc.load(wb + " << B.nvals * 2u << "u) >> " << 4u * lb << "u) & 15u, heap); }\n";
         break;
       }
       case F_STE: {

@@ -581,6 +581,7 @@ struct Lowerer {
         auto it = val_slots[sc[k]].find(key);
         if (it == val_slots[sc[k]].end()) {
           slot[k] = (uint32_t)val_slots[sc[k]].size();
+          if (slot[k] >= 8) unsupported("more than 8 joined values on one element scope");
           val_slots[sc[k]][key] = slot[k];
           Pred p{};
           p.op = P_STORE; p.dst = D_ELEM; p.scope = (uint8_t)sc[k]; p.level = (uint8_t)scope_level[sc[k]]; p.bit = (uint16_t)slot[k];
@@ -887,7 +888,7 @@ HostPlan PlanBuilder::build(const PlanCaps& caps) {
     sc.word_off = off;
     off += (uint32_t)sc.cap * sc.wpe;
     sc.val_off = off;
-    off += (uint32_t)sc.cap * sc.nvals;
+    off += (uint32_t)sc.cap * (sc.nvals ? sc.nvals * 2u + 1u : 0u);
     p.scopes.push_back(sc);
   }
   p.dims.n_preds = (uint32_t)p.preds.size();

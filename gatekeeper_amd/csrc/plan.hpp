@@ -105,7 +105,7 @@ struct Scope {
   uint32_t val_off;    // first accumulator word of value slots
   uint32_t count_off;  // accumulator word holding max ordinal + 1
   uint16_t cap;        // element capacity in this variant
-  uint8_t nvals;       // value slots per element (1 word each: row index + 1 of the stored value)
+  uint8_t nvals;       // value slots per element: the element's value block is [lo, hi] x nvals + one type word
   uint8_t wpe;         // accumulator words per element
 };
 
@@ -138,7 +138,8 @@ struct ConstraintSlot {
   uint16_t match;   // index into the match-result bits (and match-error bits)
 };
 
-constexpr int GK_TILE = 64;            // reviews per wave tile (one lane per review in phase 2)
+constexpr int GK_TILE = 64;            // reviews per tile (one lane per review in phase 2)
+constexpr int GK_BLOCK = 256;          // threads per tile in the dominant kernel: 4 waves stream the tile's rows
 constexpr int GK_MAX_RES = 64;         // unique formulas per result class per pass
 constexpr int GK_MAX_SCOPES = 32;
 

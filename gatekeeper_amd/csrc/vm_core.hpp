@@ -270,6 +270,9 @@ GK_HD bool eval_pred(const Row& r, const Pred& p, const StrHdr& h, const uint8_t
   }
 }
 
+// type nibble of a stored join value: (type + 1) | inline-string flag << 3   (0 = slot empty)
+GK_HD uint32_t val_nibble(const Row& r) { return ((r.meta & ROW_TYPE_MASK) + 1u) | ((r.meta & ROW_STR_INLINE) ? 8u : 0u); }
+
 // Accumulator word index helpers ----------------------------------------------------------------------------
 // global bit g lives in word g>>5. Global bit 0 is reserved: ELEMENT OVERFLOW (an ordinal >= scope capacity).
 constexpr uint32_t GBIT_OVERFLOW = 0;
@@ -308,7 +311,11 @@ GK_HD void eval_row_ent(const Row& r, uint32_t row_index, uint32_t ent, const St
     }
     uint32_t wpe = sc.wpe;
     if (p.op == P_STORE) {
-      acc.store_word(sc.val_off + ord * sc.nvals + p.bit, row_index + 1u);   // value slot = row index + 1 (0 = empty)
+      // value slot: the row's 64-bit payload; the element's type word gets a nibble (type + 1 | inline << 3)
+      uint32_t vb = sc.val_off + ord * (sc.nvals * 2u + 1u);
+      acc.store_word(vb + p.bit * 2u, r.lo);
+      acc.store_word(vb + p.bit * 2u + 1u, r.hi);
+      acc.or_word(vb + sc.nvals * 2u, val_nibble(r) << (4u * p.bit));
     } else if (p.op == P_PRESENT) {
       uint32_t parent = p.level > 0 ? row_ordinal(r, p.level - 1) : 0;
       acc.or_word(sc.word_off + ord * wpe, 1u | (parent << 24));
@@ -319,32 +326,32 @@ GK_HD void eval_row_ent(const Row& r, uint32_t row_index, uint32_t ent, const St
   }
 }
 
-// value-slot equality (joins): slots hold row index + 1. Both rows must hold values of the same Rego type with
-// equal content (strings: hash fast-reject, then bytes).
-GK_HD bool val_eq(uint32_t sa, uint32_t sb, const Row* rows, const uint8_t* heap) {
-  if (sa == 0 || sb == 0) return false;
-  const Row a = rows[sa - 1], b = rows[sb - 1];
-  uint32_t ta = row_type(a), tb = row_type(b);
+// value-slot equality (joins).  A slot holds the stored row's 64-bit payload plus a type nibble; two values are equal
+// iff they have the same Rego type and content.  Memory is touched only to confirm two DIFFERENT heap strings whose
+// hashes agree.
+GK_HD bool val_eq(uint32_t alo, uint32_t ahi, uint32_t an, uint32_t blo, uint32_t bhi, uint32_t bn, const uint8_t* heap) {
+  if ((an & 7u) == 0u || (bn & 7u) == 0u) return false;
+  uint32_t ta = (an & 7u) - 1u, tb = (bn & 7u) - 1u;
   if (type_rank(ta) != type_rank(tb)) return false;
   switch (ta) {
     case T_NULL: return true;
-    case T_BOOL: return a.lo == b.lo;
+    case T_BOOL: return alo == blo;
     case T_INT: case T_FLOAT: {
-      if (ta == T_INT && tb == T_INT) return a.lo == b.lo && a.hi == b.hi;
-      double x = ta == T_INT ? (double)row_i64(a) : row_f64(a);
-      double y = tb == T_INT ? (double)row_i64(b) : row_f64(b);
+      if (ta == T_INT && tb == T_INT) return alo == blo && ahi == bhi;
+      uint64_t ua = ((uint64_t)ahi << 32) | alo, ub = ((uint64_t)bhi << 32) | blo;
+      double x = ta == T_INT ? (double)(int64_t)ua : bits_f64(ua);
+      double y = tb == T_INT ? (double)(int64_t)ub : bits_f64(ub);
       return x == y;
     }
     case T_STRING: {
-      bool ia = (a.meta & ROW_STR_INLINE) != 0, ib = (b.meta & ROW_STR_INLINE) != 0;
-      if (ia != ib) return false;                       // inline strings are <= 7 bytes, heap strings longer
-      if (ia) return a.lo == b.lo && a.hi == b.hi;      // packed bytes + length
-      if (a.hi != b.hi) return false;                   // hash32 fast reject
-      if (a.lo == b.lo) return true;
-      uint32_t na = ld32(heap + a.lo - 4), nb = ld32(heap + b.lo - 4);
+      if ((an & 8u) != (bn & 8u)) return false;       // inline strings are <= 7 bytes, heap strings longer
+      if (an & 8u) return alo == blo && ahi == bhi;   // packed bytes + length
+      if (ahi != bhi) return false;                   // hash32 fast reject
+      if (alo == blo) return true;
+      uint32_t na = ld32(heap + alo - 4), nb = ld32(heap + blo - 4);
       if (na != nb) return false;
       uint32_t d = 0;
-      for (uint32_t j = 0; j < na; j += 4) d |= ld32(heap + a.lo + j) ^ ld32(heap + b.lo + j);
+      for (uint32_t j = 0; j < na; j += 4) d |= ld32(heap + alo + j) ^ ld32(heap + blo + j);
       return d == 0;
     }
     default: return false;   // composite joins are rejected by the compiler
@@ -439,9 +446,9 @@ GK_HD Results eval_formulas(const PlanView& pv, Acc& acc, uint32_t flags, const 
         uint32_t sa = x & 0xFF, la = (x >> 8) & 0xFF, sb = (x >> 16) & 0xFF, lb = x >> 24;
         const Scope& A = pv.scopes[sa];
         const Scope& Bs = pv.scopes[sb];
-        uint32_t wa = A.val_off + cur[sa] * A.nvals + la;
-        uint32_t wb = Bs.val_off + cur[sb] * Bs.nvals + lb;
-        uint64_t v = val_eq(acc.load(wa), acc.load(wb), rows, heap) ? 1 : 0;
+        uint32_t wa = A.val_off + cur[sa] * (A.nvals * 2u + 1u), wb = Bs.val_off + cur[sb] * (Bs.nvals * 2u + 1u);
+        uint32_t na = (acc.load(wa + A.nvals * 2u) >> (4u * la)) & 15u, nb = (acc.load(wb + Bs.nvals * 2u) >> (4u * lb)) & 15u;
+        uint64_t v = val_eq(acc.load(wa + la * 2u), acc.load(wa + la * 2u + 1u), na, acc.load(wb + lb * 2u), acc.load(wb + lb * 2u + 1u), nb, heap) ? 1 : 0;
         B = (B & ~(1ull << a)) | (v << a);
         break;
       }
