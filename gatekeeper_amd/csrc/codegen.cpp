@@ -66,10 +66,11 @@ std::string generate_plan_source(const HostPlan& plan) {
         o << "          const uint32_t ord = row_ordinal(r, " << (int)p.level << "u);\n"
           << "          if (ord >= " << sc.cap << "u || (r.meta & ROW_ORD_OVERFLOW)) acc.or_word(0u, 1u);\n          else {\n";
         if (p.op == P_STORE) {
-          uint32_t stride = sc.nvals * 2u + 1u;
+          uint32_t stride = val_stride(sc.nvals);
           o << "            const uint32_t vb = " << sc.val_off << "u + ord * " << stride << "u;\n"
-            << "            acc.store_word(vb + " << p.bit * 2u << "u, r.lo); acc.store_word(vb + " << p.bit * 2u + 1u << "u, r.hi);\n"
-            << "            acc.or_word(vb + " << sc.nvals * 2u << "u, val_nibble(r) << " << 4u * p.bit << "u);\n";
+            << "            acc.store_word(vb + " << p.bit * 2u << "u, r.lo); acc.store_word(vb + " << p.bit * 2u + 1u << "u, r.hi);\n";
+          if (sc.nvals == 1) o << "            acc.or_word(" << sc.word_off << "u + ord * " << (int)sc.wpe << "u, val_nibble(r) << " << ELEM_NIBBLE_SHIFT << "u);\n";
+          else o << "            acc.or_word(vb + " << sc.nvals * 2u << "u, val_nibble(r) << " << 4u * p.bit << "u);\n";
         }
         else if (p.op == P_PRESENT) {
           if (p.level > 0) o << "            const uint32_t parent = row_ordinal(r, " << (int)(p.level - 1) << "u);\n";
@@ -91,6 +92,8 @@ std::string generate_plan_source(const HostPlan& plan) {
     << "  (void)pv; (void)rows; (void)heap; (void)flags;\n  Results res = {0, 0, 0};\n  bool";
   for (int i = 0; i < 64; i++) o << (i ? ", " : " ") << "b" << i << " = false";
   o << ";\n";
+  // the global predicate words are read once; derived global bits (F_STG) update the register copy as well
+  for (uint32_t w = 0; w < plan.dims.n_gwords; w++) o << "  uint32_t g" << w << " = acc.load(" << w << "u);\n";
   struct Loop { uint32_t scope; int depth; };
   std::vector<Loop> stack;
   auto var_of = [&](uint32_t scope) -> int {
@@ -103,7 +106,7 @@ std::string generate_plan_source(const HostPlan& plan) {
     uint32_t ins = code[pc++];
     uint32_t op = ins & 0xFF, a = (ins >> 8) & 0xFF, b = (ins >> 16) & 0xFF, c = ins >> 24;
     switch (op) {
-      case F_LDG: { uint32_t bit = b | (c << 8); o << ind << "b" << a << " = (acc.load(" << (bit >> 5) << "u) >> " << (bit & 31) << ") & 1u;\n"; break; }
+      case F_LDG: { uint32_t bit = b | (c << 8); o << ind << "b" << a << " = (g" << (bit >> 5) << " >> " << (bit & 31) << ") & 1u;\n"; break; }
       case F_LDF: o << ind << "b" << a << " = (flags >> " << b << ") & 1u;\n"; break;
       case F_LDE: {
         const Scope& sc = plan.scopes[b];
@@ -151,10 +154,16 @@ std::string generate_plan_source(const HostPlan& plan) {
         const Scope& B = plan.scopes[sb];
         int da = var_of(sa), db = var_of(sb);
         if (da < 0 || db < 0) throw Unsupported("codegen: join outside its loops");
-        uint32_t sa_ = A.nvals * 2u + 1u, sb_ = B.nvals * 2u + 1u;
+        uint32_t sa_ = val_stride(A.nvals), sb_ = val_stride(B.nvals);
+        auto nib = [&](const Scope& S, int d, const char* w, uint32_t slot) {
+          std::ostringstream x;
+          if (S.nvals == 1) x << "(w" << d << " >> " << ELEM_NIBBLE_SHIFT << "u) & 15u";   // word0 of the loop's current element is in a register
+          else x << "(acc.load(" << w << " + " << S.nvals * 2u << "u) >> " << 4u * slot << "u) & 15u";
+          return x.str();
+        };
         o << ind << "{ const uint32_t wa = " << A.val_off << "u + e" << da << " * " << sa_ << "u, wb = " << B.val_off << "u + e" << db << " * " << sb_ << "u;\n"
-          << ind << "  b" << a << " = val_eq(acc.load(wa + " << la * 2u << "u), acc.load(wa + " << la * 2u + 1u << "u), (acc.load(wa + " << A.nvals * 2u << "u) >> " << 4u * la
-          << "u) & 15u, acc.load(wb + " << lb * 2u << "u), acc.load(wb + " << lb * 2u + 1u << "u), (acc.load(wb + " << B.nvals * 2u << "u) >> " << 4u * lb << "u) & 15u, heap); }\n";
+          << ind << "  b" << a << " = val_eq(acc.load(wa + " << la * 2u << "u), acc.load(wa + " << la * 2u + 1u << "u), " << nib(A, da, "wa", la)
+          << ", acc.load(wb + " << lb * 2u << "u), acc.load(wb + " << lb * 2u + 1u << "u), " << nib(B, db, "wb", lb) << ", heap); }\n";
         break;
       }
       case F_STE: {
@@ -164,7 +173,7 @@ std::string generate_plan_source(const HostPlan& plan) {
         o << ind << "if (b" << a << ") acc.or_word(" << sc.word_off << "u + e" << d << " * " << (int)sc.wpe << "u + " << elem_word_of_bit(c) << "u, " << u(elem_mask_of_bit(c)) << ");\n";
         break;
       }
-      case F_STG: { uint32_t bit = b | (c << 8); o << ind << "if (b" << a << ") acc.or_word(" << (bit >> 5) << "u, " << u(1u << (bit & 31)) << ");\n"; break; }
+      case F_STG: { uint32_t bit = b | (c << 8); o << ind << "if (b" << a << ") g" << (bit >> 5) << " |= " << u(1u << (bit & 31)) << ";\n"; break; }
       case F_RES: {
         const char* f = b == 0 ? "viol" : b == 1 ? "match" : "err";
         o << ind << "res." << f << " |= (uint64_t)b" << a << " << " << c << ";\n";

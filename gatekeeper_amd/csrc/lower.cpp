@@ -1,6 +1,8 @@
 // See lower.hpp.
 #include "lower.hpp"
 
+#include "vm_core.hpp"
+
 #include <functional>
 #include <regex>
 #include <set>
@@ -616,7 +618,7 @@ struct Lowerer {
     uint32_t bit;
     if (it == elem_bits[sc].end()) {
       bit = scope_nbits[sc]++;
-      if (bit >= 24 + 3 * 32) unsupported("too many predicates on one element scope");
+      if (bit >= ELEM_W0_BITS + 3 * 32) unsupported("too many predicates on one element scope");
       elem_bits[sc][key] = bit;
       Pred p = make_pred(a);
       p.dst = D_ELEM; p.scope = (uint8_t)sc; p.level = (uint8_t)scope_level[sc]; p.bit = (uint16_t)bit;
@@ -765,7 +767,7 @@ struct Lowerer {
       uint32_t bit;
       if (it == derived_elem[s1].end()) {
         bit = scope_nbits[s1]++;
-        if (bit >= 24 + 3 * 32) unsupported("too many predicates on one element scope");
+        if (bit >= ELEM_W0_BITS + 3 * 32) unsupported("too many predicates on one element scope");
         derived_elem[s1][key] = bit;
         std::vector<uint32_t> block;
         std::vector<uint32_t>* saved = cur_code;
@@ -881,14 +883,14 @@ HostPlan PlanBuilder::build(const PlanCaps& caps) {
   for (size_t s = 0; s < L.scope_patterns.size(); s++) {
     Scope sc{};
     uint32_t nb = L.scope_nbits[s];
-    sc.wpe = (uint8_t)(nb <= 24 ? 1 : 1 + (nb - 24 + 31) / 32);
+    sc.wpe = (uint8_t)(nb <= ELEM_W0_BITS ? 1 : 1 + (nb - ELEM_W0_BITS + 31) / 32);
     sc.cap = caps.level_cap[L.scope_level[s]];
     sc.nvals = (uint8_t)L.val_slots[s].size();
     sc.count_off = off++;
     sc.word_off = off;
     off += (uint32_t)sc.cap * sc.wpe;
     sc.val_off = off;
-    off += (uint32_t)sc.cap * (sc.nvals ? sc.nvals * 2u + 1u : 0u);
+    off += (uint32_t)sc.cap * val_stride(sc.nvals);
     p.scopes.push_back(sc);
   }
   p.dims.n_preds = (uint32_t)p.preds.size();

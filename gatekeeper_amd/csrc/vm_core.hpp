@@ -276,9 +276,14 @@ GK_HD uint32_t val_nibble(const Row& r) { return ((r.meta & ROW_TYPE_MASK) + 1u)
 // Accumulator word index helpers ----------------------------------------------------------------------------
 // global bit g lives in word g>>5. Global bit 0 is reserved: ELEMENT OVERFLOW (an ordinal >= scope capacity).
 constexpr uint32_t GBIT_OVERFLOW = 0;
-// element word layout: word0 = [0] present | [1..23] leaf bits | [31:24] parent ordinal; bits >= 24 spill to word 1+
-GK_HD uint32_t elem_word_of_bit(uint32_t bit) { return bit < 24 ? 0 : 1 + ((bit - 24) >> 5); }
-GK_HD uint32_t elem_mask_of_bit(uint32_t bit) { return bit < 24 ? (1u << bit) : (1u << ((bit - 24) & 31)); }
+// element word layout: word0 = [0] present | [1..19] leaf bits | [23:20] type nibble of the scope's join value (when it
+// has exactly one) | [31:24] parent ordinal; leaf bits >= 20 spill to word 1+
+constexpr uint32_t ELEM_W0_BITS = 20;
+constexpr uint32_t ELEM_NIBBLE_SHIFT = 20;
+GK_HD uint32_t elem_word_of_bit(uint32_t bit) { return bit < ELEM_W0_BITS ? 0 : 1 + ((bit - ELEM_W0_BITS) >> 5); }
+GK_HD uint32_t elem_mask_of_bit(uint32_t bit) { return bit < ELEM_W0_BITS ? (1u << bit) : (1u << ((bit - ELEM_W0_BITS) & 31)); }
+// value block of an element: [lo, hi] per slot; the type nibbles live in word0 (one slot) or in one extra word
+GK_HD uint32_t val_stride(uint32_t nvals) { return nvals <= 1 ? nvals * 2u : nvals * 2u + 1u; }
 
 // Phase 1 for one row. `Acc` provides or_word(w, mask), max_word(w, v), store_word(w, v) for THIS row's review.
 template <class Acc>
@@ -312,10 +317,11 @@ GK_HD void eval_row_ent(const Row& r, uint32_t row_index, uint32_t ent, const St
     uint32_t wpe = sc.wpe;
     if (p.op == P_STORE) {
       // value slot: the row's 64-bit payload; the element's type word gets a nibble (type + 1 | inline << 3)
-      uint32_t vb = sc.val_off + ord * (sc.nvals * 2u + 1u);
+      uint32_t vb = sc.val_off + ord * val_stride(sc.nvals);
       acc.store_word(vb + p.bit * 2u, r.lo);
       acc.store_word(vb + p.bit * 2u + 1u, r.hi);
-      acc.or_word(vb + sc.nvals * 2u, val_nibble(r) << (4u * p.bit));
+      if (sc.nvals == 1) acc.or_word(sc.word_off + ord * wpe, val_nibble(r) << ELEM_NIBBLE_SHIFT);
+      else acc.or_word(vb + sc.nvals * 2u, val_nibble(r) << (4u * p.bit));
     } else if (p.op == P_PRESENT) {
       uint32_t parent = p.level > 0 ? row_ordinal(r, p.level - 1) : 0;
       acc.or_word(sc.word_off + ord * wpe, 1u | (parent << 24));
@@ -446,8 +452,9 @@ GK_HD Results eval_formulas(const PlanView& pv, Acc& acc, uint32_t flags, const 
         uint32_t sa = x & 0xFF, la = (x >> 8) & 0xFF, sb = (x >> 16) & 0xFF, lb = x >> 24;
         const Scope& A = pv.scopes[sa];
         const Scope& Bs = pv.scopes[sb];
-        uint32_t wa = A.val_off + cur[sa] * (A.nvals * 2u + 1u), wb = Bs.val_off + cur[sb] * (Bs.nvals * 2u + 1u);
-        uint32_t na = (acc.load(wa + A.nvals * 2u) >> (4u * la)) & 15u, nb = (acc.load(wb + Bs.nvals * 2u) >> (4u * lb)) & 15u;
+        uint32_t wa = A.val_off + cur[sa] * val_stride(A.nvals), wb = Bs.val_off + cur[sb] * val_stride(Bs.nvals);
+        uint32_t na = A.nvals == 1 ? (acc.load(A.word_off + cur[sa] * A.wpe) >> ELEM_NIBBLE_SHIFT) & 15u : (acc.load(wa + A.nvals * 2u) >> (4u * la)) & 15u;
+        uint32_t nb = Bs.nvals == 1 ? (acc.load(Bs.word_off + cur[sb] * Bs.wpe) >> ELEM_NIBBLE_SHIFT) & 15u : (acc.load(wb + Bs.nvals * 2u) >> (4u * lb)) & 15u;
         uint64_t v = val_eq(acc.load(wa + la * 2u), acc.load(wa + la * 2u + 1u), na, acc.load(wb + lb * 2u), acc.load(wb + lb * 2u + 1u), nb, heap) ? 1 : 0;
         B = (B & ~(1ull << a)) | (v << a);
         break;
