@@ -50,9 +50,14 @@ std::string generate_plan_source(const HostPlan& plan) {
   std::vector<std::vector<Pred>> classes;
   jit_path_classes(plan, &classes);
   o << "namespace gk {\n";
+  // the plan's constant heap as a constant-initialised array: with constexpr predicates every constant-string load has
+  // a compile-time address, so the optimiser folds the bytes into immediates (no memory traffic for constants)
+  o << "GK_CONST_ARRAY unsigned char gk_plan_consts[" << plan.cheap.size() << "] = {";
+  for (size_t i = 0; i < plan.cheap.size(); i++) o << (i ? "," : "") << (int)plan.cheap[i];
+  o << "};\n";
   // ---------------------------------------------------------------------------------------------- phase 1
   o << "template <class Acc>\nGK_HD void jit_row(const Row& r, uint32_t row_index, uint32_t cls, const StrHdr& h, const PlanView& pv, const uint8_t* heap, Acc& acc) {\n"
-    << "  const uint8_t* cheap = pv.cheap;\n  (void)cheap; (void)row_index; (void)h;\n  switch (cls) {\n";
+    << "  const uint8_t* cheap = gk_plan_consts;\n  (void)cheap; (void)row_index; (void)h; (void)pv;\n  switch (cls) {\n";
   for (size_t c = 1; c < classes.size(); c++) {
     o << "    case " << c << ": {\n";
     for (const Pred& p : classes[c]) {

@@ -13,6 +13,11 @@
 // The formula interpreter's control flow is wave-uniform by construction (same bytecode, same loop bounds for all 64
 // lanes).  GK_UNI makes that visible to the compiler so the program counter, the decoded instruction and the loop
 // counters live in SGPRs and the dispatch is scalar branching instead of exec-mask divergence.
+#if defined(__HIPCC__)
+#define GK_CONST_ARRAY __device__ const
+#else
+#define GK_CONST_ARRAY static const
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
 #define GK_UNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
 #else
