@@ -127,6 +127,15 @@ def main():
                          "avg_kernel_ms": res.fast_kernel_ms, "launches_timed": int(res.n_launches),
                          "kernel_only_evals_per_s": nc * args.reviews / kernel_s if kernel_s > 0 else None},
         }
+        # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes of this same command (bench.py
+        # cannot run a profiler around itself); only reported when the profiled workload is the one just timed
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
+            if pmc.get("config") == args.config and pmc.get("reviews") == args.reviews and world == 1:
+                out["roofline"]["traffic"] = pmc["hbm_bytes_per_launch"]
+                out["roofline"]["traffic_source"] = pmc["source"]
+        except (OSError, ValueError):
+            pass
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(templates, constraints, objs[:20000], nss)
         print(json.dumps(out))

@@ -23,7 +23,7 @@ struct MatchFormulas {
 MatchFormulas compile_match(const Value& match_spec);
 
 struct PlanCaps {
-  uint16_t level_cap[3] = {8, 16, 16};   // element capacity per array-nesting level
+  uint16_t level_cap[3] = {8, 12, 12};   // element capacity per array-nesting level
 };
 
 struct PatStep {

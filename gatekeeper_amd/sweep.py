@@ -39,6 +39,7 @@ class ShardedSweep:
         self.nc = len(client.constraints)
         self.n_tiles = (self.n + 63) // 64
         self.gathered = self.total_counts = None
+        self.on_device = device is not None and str(device).startswith("cuda")
         if dist is not None:
             import torch
             w = dist.get_world_size()
@@ -56,6 +57,17 @@ class ShardedSweep:
             return self.table.eval(download=download, collect_only=True)
         import torch
         ev = None
+        if not self.on_device:
+            # CPU path of the exchange (gloo; used by tests/test_sweep_dist.py with the test-only emulated kernels):
+            # same collectives on host tensors built from the downloaded bitmaps
+            import numpy as np
+            for _ in range(steps):
+                ev = self.table.eval(download=True)
+                self.local_bm.copy_(torch.from_numpy(ev.viol.reshape(-1).view(np.int64).copy()))
+                self.total_counts.copy_(torch.from_numpy(ev.counts.astype(np.int32)))
+                self.dist.all_gather_into_tensor(self.gathered, self.local_bm)
+                self.dist.all_reduce(self.total_counts)
+            return ev
         for _ in range(steps):
             self.table.launch()
             ev = self.table.eval(download=False, collect_only=True)   # sync: bitmaps of THIS pass are complete

@@ -31,7 +31,7 @@ typedef enum {
 
 typedef struct {
   int32_t device;          /* HIP device ordinal (one engine per GPU; one process per GPU under torch.distributed) */
-  uint16_t elem_cap[3];    /* LDS element capacity per array-nesting level; 0 = default (8, 16, 16); larger reviews take the HBM-accumulator kernel variant */
+  uint16_t elem_cap[3];    /* LDS element capacity per array-nesting level; 0 = default (8, 12, 12); larger reviews take the HBM-accumulator kernel variant */
   uint16_t reserved;
 } gk_opts;
 
