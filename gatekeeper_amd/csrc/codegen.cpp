@@ -23,44 +23,24 @@ std::string pred_literal(const Pred& p) {
 
 }  // namespace
 
-std::vector<uint32_t> jit_path_classes(const HostPlan& plan, std::vector<std::vector<Pred>>* classes, std::vector<uint32_t>* descs) {
-  // path -> entry.  Paths whose predicates are all "simple" (vm_core.hpp eval_simple) get (first << 8 | count) into the
-  // descriptor table; the others get GK_ENT_COMPLEX | class id, one class per distinct predicate list.
+std::vector<uint32_t> jit_path_classes(const HostPlan& plan, std::vector<std::vector<Pred>>* classes) {
+  // distinct predicate lists -> class ids (1-based); ptab_class[path] = class id, 0 = no predicates
   std::vector<uint32_t> out(plan.ptab.size(), 0);
-  std::map<std::string, uint32_t> ids, simple_ids;
+  std::map<std::string, uint32_t> ids;
   classes->clear();
   classes->push_back({});
-  descs->clear();
-  for (uint32_t k = 0; k < GK_DESC_WORDS; k++) descs->push_back(0);   // descriptor 0 unused
   for (size_t i = 0; i < plan.ptab.size(); i++) {
     uint32_t ent = plan.ptab[i];
     if (!ent) continue;
     uint32_t first = ent >> 8, cnt = ent & 0xFF;
     std::string key((const char*)&plan.path_preds[first], cnt * sizeof(Pred));
-    bool simple = true;
-    for (uint32_t j = 0; j < cnt; j++) if (!pred_is_simple(plan.path_preds[first + j])) simple = false;
-    if (simple) {
-      auto it = simple_ids.find(key);
-      if (it == simple_ids.end()) {
-        uint32_t f = (uint32_t)(descs->size() / GK_DESC_WORDS);
-        for (uint32_t j = 0; j < cnt; j++) {
-          uint32_t d[4];
-          make_simple_desc(plan.path_preds[first + j], plan.scopes.data(), d);
-          descs->insert(descs->end(), d, d + 4);
-        }
-        uint32_t e = (f << 8) | cnt;
-        simple_ids[key] = e;
-        out[i] = e;
-      } else out[i] = it->second;
-      continue;
-    }
     auto it = ids.find(key);
     if (it == ids.end()) {
       uint32_t id = (uint32_t)classes->size();
       ids[key] = id;
       classes->emplace_back(plan.path_preds.begin() + first, plan.path_preds.begin() + first + cnt);
-      out[i] = GK_ENT_COMPLEX | id;
-    } else out[i] = GK_ENT_COMPLEX | it->second;
+      out[i] = id;
+    } else out[i] = it->second;
   }
   return out;
 }
@@ -68,13 +48,8 @@ std::vector<uint32_t> jit_path_classes(const HostPlan& plan, std::vector<std::ve
 std::string generate_plan_source(const HostPlan& plan) {
   std::ostringstream o;
   std::vector<std::vector<Pred>> classes;
-  std::vector<uint32_t> descs;
-  jit_path_classes(plan, &classes, &descs);
-  o << "#define GK_HAS_SIMPLE 1\nnamespace gk {\n";
-  o << "constexpr uint32_t GK_N_DESC_WORDS = " << descs.size() << "u;\n";
-  o << "GK_CONST_ARRAY uint32_t gk_plan_descs[" << descs.size() << "] = {";
-  for (size_t i = 0; i < descs.size(); i++) o << (i ? "," : "") << descs[i] << "u";
-  o << "};\n";
+  jit_path_classes(plan, &classes);
+  o << "namespace gk {\n";
   // the plan's constant heap as a constant-initialised array: with constexpr predicates every constant-string load has
   // a compile-time address, so the optimiser folds the bytes into immediates (no memory traffic for constants)
   o << "GK_CONST_ARRAY unsigned char gk_plan_consts[" << plan.cheap.size() << "] = {";

@@ -337,111 +337,6 @@ GK_HD void eval_row_ent(const Row& r, uint32_t row_index, uint32_t ent, const St
   }
 }
 
-// ------------------------------------------------------------------------------------------------ uniform predicates
-// Most predicates are "simple": defined / truthy / type / compare with a number, bool, null or a <= 7 byte string /
-// short prefix / container count / element marker / join-value store.  They are described by a 16-byte descriptor and
-// evaluated by ONE branch-free routine that all 64 lanes execute together, whatever predicate each lane's row
-// carries -- the per-class switch (one serialized body per distinct class in the wave) is kept only for the complex
-// string predicates.  Descriptor words:
-//   d0: op[3:0] cmp[6:4] ctype[9:7] is_elem[10] level[12:11] len[15:13] cap[23:16] stride[28:24]
-//   d1: word[15:0] bit[20:16]          d2,d3: 64-bit constant (or op-specific fields, see make_simple_desc)
-enum SimpleOp : uint32_t { S_DEFINED = 0, S_TRUTHY = 1, S_TYPE = 2, S_CMP = 3, S_PREFIX = 4, S_COUNT = 5, S_PRESENT = 6, S_STORE = 7 };
-constexpr uint32_t GK_DESC_WORDS = 4;
-constexpr uint32_t GK_ENT_COMPLEX = 0x80000000u;   // path-table entry: complex class id instead of (first << 8 | count)
-
-GK_HD bool cmp_test_tbl(int c, uint32_t op) {
-  // bit (op*3 + {2: c<0, 1: c==0, 0: c>0}) of the truth table  EQ=010 NE=101 LT=100 LE=110 GT=001 GE=011
-  const uint32_t tbl = 0b011001110100101010u;
-  uint32_t k = c < 0 ? 2u : (c == 0 ? 1u : 0u);
-  return ((tbl >> (op * 3u + k)) & 1u) != 0u;
-}
-
-template <class Acc>
-GK_HD void eval_simple(uint32_t d0, uint32_t d1, uint32_t d2, uint32_t d3, const Row& r, const StrHdr& h, Acc& acc) {
-  const uint32_t op = d0 & 15u, cmp = (d0 >> 4) & 7u, ctype = (d0 >> 7) & 7u, is_elem = (d0 >> 10) & 1u, level = (d0 >> 11) & 3u,
-                 len = (d0 >> 13) & 7u, cap = (d0 >> 16) & 0xFFu, stride = (d0 >> 24) & 31u;
-  const uint32_t type = r.meta & ROW_TYPE_MASK;
-  const bool is_str = type == T_STRING, inl = (r.meta & ROW_STR_INLINE) != 0u;
-  const uint32_t n = inl ? (r.hi >> 24) : h.w[0];
-  const uint64_t bits = inl ? (((uint64_t)(r.hi & 0x00FFFFFFu) << 32) | r.lo) : (((uint64_t)h.w[2] << 32) | h.w[1]);
-  const uint64_t k = ((uint64_t)d3 << 32) | d2;
-  // three-way compare(row, constant) under Rego's total order (string constants: equality only)
-  const int ra = type_rank(type), rb = type_rank(ctype);
-  const int64_t ri = row_i64(r), ki = (int64_t)k;
-  const double rd = type == T_INT ? (double)ri : row_f64(r), kd = ctype == T_INT ? (double)ki : bits_f64(k);
-  const int c_num = (type == T_INT && ctype == T_INT) ? (ri < ki ? -1 : (ri > ki ? 1 : 0)) : (rd < kd ? -1 : (rd > kd ? 1 : 0));
-  const int c_bool = (int)r.lo - (int)(uint32_t)k;
-  const int c_str = (n == len && bits == k) ? 0 : 1;
-  const int c_same = type == T_BOOL ? c_bool : (ra == 2 ? c_num : (is_str ? c_str : 0));
-  const int c3 = ra != rb ? (ra < rb ? -1 : 1) : c_same;
-  const bool r_cmp = cmp_test_tbl(c3, cmp);
-  const bool r_truthy = !(type == T_BOOL && r.lo == 0u);
-  const bool r_type = ((d2 >> type) & 1u) != 0u;
-  const bool r_prefix = is_str && n >= len && ((bits ^ k) & mask_bytes(len)) == 0ull;
-  const bool is_cont = type == T_OBJECT || type == T_ARRAY;
-  const int64_t cn = (int64_t)r.lo;
-  const bool r_count = is_cont && cmp_test_tbl(cn < ki ? -1 : (cn > ki ? 1 : 0), cmp);
-  const bool t = op == S_TRUTHY ? r_truthy : op == S_TYPE ? r_type : op == S_CMP ? r_cmp : op == S_PREFIX ? r_prefix : op == S_COUNT ? r_count : true;
-  if (!t) return;
-  uint32_t word = d1 & 0xFFFFu, mask = 1u << ((d1 >> 16) & 31u);
-  if (is_elem) {
-    const uint32_t ord = row_ordinal(r, level);
-    if (ord >= cap || (r.meta & ROW_ORD_OVERFLOW)) { acc.or_word(0u, 1u); return; }
-    word += ord * stride;
-    if (op == S_PRESENT) {
-      const uint32_t parent = level ? row_ordinal(r, level - 1u) : 0u;
-      mask = 1u | (parent << 24);
-      acc.max_word(d2, ord + 1u);
-    } else if (op == S_STORE) {
-      const uint32_t vb = (d2 & 0xFFFFu) + ord * (d2 >> 16);
-      acc.store_word(vb, r.lo);
-      acc.store_word(vb + 1u, r.hi);
-      mask = val_nibble(r) << d3;
-    }
-  }
-  acc.or_word(word, mask);
-}
-
-// host side: can predicate p be expressed as a simple descriptor?  (plan scopes needed for element targets)
-GK_HD bool pred_is_simple(const Pred& p) {
-  switch (p.op) {
-    case P_DEFINED: case P_TRUTHY: case P_TYPE: case P_PRESENT: case P_STORE: case P_COUNT_CMP: return true;
-    case P_CMP: return p.ctype != T_STRING || (p.b <= 7u && (p.cmp == C_EQ || p.cmp == C_NE));
-    case P_STR_PREFIX: return p.b <= 7u;
-    default: return false;
-  }
-}
-GK_HD void make_simple_desc(const Pred& p, const Scope* scopes, uint32_t out[4]) {
-  uint32_t op = S_DEFINED, len = 0, cap = 0, stride = 0, word = 0, bit = 0, d2 = (uint32_t)p.k, d3 = (uint32_t)(p.k >> 32);
-  switch (p.op) {
-    case P_DEFINED: op = S_DEFINED; break;
-    case P_TRUTHY: op = S_TRUTHY; break;
-    case P_TYPE: op = S_TYPE; d2 = p.ctype; d3 = 0; break;
-    case P_CMP: op = S_CMP; len = p.ctype == T_STRING ? p.b : 0u; break;
-    case P_STR_PREFIX: op = S_PREFIX; len = p.b; break;
-    case P_COUNT_CMP: op = S_COUNT; break;
-    case P_PRESENT: op = S_PRESENT; break;
-    default: op = S_STORE; break;
-  }
-  if (p.dst == D_GLOBAL) { word = p.bit >> 5; bit = p.bit & 31u; }
-  else {
-    const Scope& sc = scopes[p.scope];
-    cap = sc.cap; stride = sc.wpe;
-    if (p.op == P_PRESENT) { word = sc.word_off; d2 = sc.count_off; d3 = 0; }
-    else if (p.op == P_STORE) {
-      const uint32_t vs = val_stride(sc.nvals);
-      d2 = (sc.val_off + p.bit * 2u) | (vs << 16);
-      if (sc.nvals == 1) { word = sc.word_off; d3 = ELEM_NIBBLE_SHIFT; }
-      else { word = sc.val_off + sc.nvals * 2u; stride = vs; d3 = 4u * p.bit; }
-    } else { word = sc.word_off + elem_word_of_bit(p.bit); bit = p.bit < ELEM_W0_BITS ? p.bit : ((p.bit - ELEM_W0_BITS) & 31u); }
-  }
-  out[0] = op | ((uint32_t)p.cmp << 4) | ((uint32_t)(p.op == P_CMP ? p.ctype : 0u) << 7) | ((p.dst == D_ELEM ? 1u : 0u) << 10) | ((uint32_t)p.level << 11) |
-           (len << 13) | (cap << 16) | (stride << 24);
-  out[1] = word | (bit << 16);
-  out[2] = d2;
-  out[3] = d3;
-}
-
 // value-slot equality (joins).  A slot holds the stored row's 64-bit payload plus a type nibble; two values are equal
 // iff they have the same Rego type and content.  Memory is touched only to confirm two DIFFERENT heap strings whose
 // hashes agree.

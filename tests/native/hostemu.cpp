@@ -28,7 +28,7 @@ struct DevPlan {
   void* dl = nullptr;
   HeRowFn row = nullptr;
   HeFormFn form = nullptr;
-  std::vector<uint32_t> cls, descs;
+  std::vector<uint32_t> cls;
 };
 
 struct VecAcc {
@@ -65,7 +65,7 @@ DevPlan* dev_plan_upload(const HostPlan& fast, const HostPlan& big) {
     p->row = (HeRowFn)dlsym(p->dl, "gk_he_row");
     p->form = (HeFormFn)dlsym(p->dl, "gk_he_form");
     std::vector<std::vector<Pred>> classes;
-    p->cls = jit_path_classes(fast, &classes, &p->descs);
+    p->cls = jit_path_classes(fast, &classes);
     unlink((base + ".cpp").c_str()); unlink((base + ".so").c_str()); unlink((base + ".log").c_str());
   }
   return p;
@@ -81,15 +81,7 @@ static bool eval_review(const HostPlan& hp, const HostTable& t, uint32_t r, Resu
   std::vector<uint32_t> words(hp.dims.acc_words, 0);
   VecAcc acc{&words};
   for (uint32_t i = t.hdrs[r].row_start; i < t.hdrs[r + 1].row_start; i++) {
-    if (jit) {
-      uint32_t c = t.rows[i].path < jit->cls.size() ? jit->cls[t.rows[i].path] : 0;
-      if (c) {
-        StrHdr h = {{0, 0, 0, 0}};
-        if (row_needs_hdr(t.rows[i])) h = load_hdr(t.rows[i], t.heap.data());
-        if (c & GK_ENT_COMPLEX) jit->row(&t.rows[i], i, c & ~GK_ENT_COMPLEX, &h, &pv, t.heap.data(), &words);
-        else for (uint32_t j = 0; j < (c & 0xFF); j++) { const uint32_t* d = &jit->descs[((c >> 8) + j) * GK_DESC_WORDS]; eval_simple(d[0], d[1], d[2], d[3], t.rows[i], h, acc); }
-      }
-    }
+    if (jit) { uint32_t c = t.rows[i].path < jit->cls.size() ? jit->cls[t.rows[i].path] : 0; if (c) { StrHdr h = {{0, 0, 0, 0}}; if (row_needs_hdr(t.rows[i])) h = load_hdr(t.rows[i], t.heap.data()); jit->row(&t.rows[i], i, c, &h, &pv, t.heap.data(), &words); } }
     else eval_row(t.rows[i], i, pv, t.heap.data(), acc);
   }
   if (words[0] & 1u) return false;   // overflow
