@@ -119,7 +119,7 @@ def main():
             "config": {"workload": ("configs[1]: 30 gatekeeper PSP constraints (5 in-tree PSP templates x 6 parameterisations) x "
                                     "%d synthetic Pod AdmissionReviews per GPU" % args.reviews) if args.config == 1 else
                        ("configs[2]: audit sweep, 50 constraints x %d mixed synthetic cluster objects per GPU" % args.reviews),
-                       "constraints": nc, "reviews_per_gpu": args.reviews, "rows_per_gpu": int(res.n_rows),
+                       "constraints": nc, "reviews_per_gpu": args.reviews, "rows_per_gpu": int(res.n_rows), "rows_read_per_gpu": int(res.n_rows_read),
                        "parallelism": "objects sharded across %d GPU(s); RCCL all-gather of violation bitmaps + all-reduce of counts" % world,
                        "violating_pairs_rank0": int(counts.sum())},
             "roofline": {"bound": "hbm", "kernel": "gk_eval_tiles", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

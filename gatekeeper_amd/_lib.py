@@ -51,7 +51,7 @@ class gk_eval_out(C.Structure):
                 ("list_len", C.c_uint32), ("list_total", C.c_uint32), ("n_overflow", C.c_uint32),
                 ("kernel_ms", C.c_float), ("fast_kernel_ms", C.c_float),
                 ("algo_bytes", C.c_uint64), ("n_rows", C.c_uint64), ("n_launches", C.c_uint32), ("reserved", C.c_uint32),
-                ("d_viol", C.c_void_p), ("d_err", C.c_void_p), ("d_counts", C.c_void_p)]
+                ("d_viol", C.c_void_p), ("d_err", C.c_void_p), ("d_counts", C.c_void_p), ("n_rows_read", C.c_uint64)]
 
 
 class EngineLoadError(RuntimeError):

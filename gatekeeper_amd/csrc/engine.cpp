@@ -150,7 +150,8 @@ struct gk_table {
   HostTable host;               // rows/heap released after upload unless needed
   std::vector<ReviewDoc> docs;  // GK_TABLE_KEEP_DOCS
   std::vector<std::string> review_errors;
-  uint64_t algo_bytes = 0, n_rows = 0;
+  uint64_t dir_bytes = 0, n_rows = 0;      // directory + review-flag bytes (read by every launch); rows in the table
+  std::vector<uint32_t> path_rows;          // rows per path: which rows a plan reads
   uint32_t n_reviews = 0;
 };
 
@@ -366,7 +367,8 @@ int gk_table_create(gk_engine* e, const gk_review_in* reviews, size_t n, uint32_
       return fail(GK_ERR_INVALID, "table too large for 32-bit row/heap offsets: split the batch");
     t->n_reviews = (uint32_t)n;
     t->n_rows = t->host.rows.size();
-    t->algo_bytes = t->host.algo_bytes();
+    t->dir_bytes = t->host.segs.size() * sizeof(Seg) + t->host.tile_seg.size() * 4 + t->host.rflags.size() * 4;
+    t->path_rows = t->host.path_rows;
     t->dev = dev_table_upload(t->host);
     t->host.rows.clear(); t->host.rows.shrink_to_fit();
     t->host.heap.clear(); t->host.heap.shrink_to_fit();
@@ -420,11 +422,16 @@ int gk_table_eval(gk_engine* e, gk_table* t, uint32_t flags, gk_eval_out** out) 
     p.kernel_ms = h->out.kernel_ms; p.fast_kernel_ms = h->out.fast_kernel_ms; p.n_launches = h->out.n_launches;
     p.d_viol = h->out.d_viol; p.d_err = h->out.d_err; p.d_counts = h->out.d_counts;
     p.n_rows = t->n_rows;
-    // algorithmic bytes: rows + headers read once, plan tables read once, bitmaps written once,
-    // 8 B per emitted violation-list entry
+    // algorithmic bytes: the rows of the segments whose path carries predicates + the segment
+    // directory + review flags, all read once; plan tables read once; bitmaps written once; 8 B per list entry
+    uint64_t rows_read = 0;
+    for (size_t pth = 0; pth < t->path_rows.size() && pth < e->fast.ptab.size(); pth++)
+      if (e->fast.ptab[pth]) rows_read += t->path_rows[pth];
+    p.n_rows_read = rows_read;
     uint64_t plan_bytes = (uint64_t)e->fast.ptab.size() * 4 + e->fast.path_preds.size() * sizeof(Pred) +
                           e->fast.code.size() * 4 + e->fast.cheap.size();
-    p.algo_bytes = t->algo_bytes + plan_bytes + (uint64_t)p.n_constraints * p.n_tiles * 16 + (uint64_t)p.list_total * 8;
+    p.algo_bytes = rows_read * sizeof(Row) + t->dir_bytes + plan_bytes + (uint64_t)p.n_constraints * p.n_tiles * 16 +
+                   (uint64_t)p.list_total * 8;
     *out = &h.release()->pub;
     return GK_OK;
   } catch (const Unsupported& ex) { return fail(GK_ERR_UNSUPPORTED, ex.what());

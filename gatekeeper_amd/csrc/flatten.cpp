@@ -1,6 +1,8 @@
 // See flatten.hpp.
 #include "flatten.hpp"
 
+#include <algorithm>
+
 #include <mutex>
 
 namespace gk {
@@ -188,8 +190,7 @@ Flattener::Flattener(PathDict* dict) : dict_(dict) {
 }
 
 void Flattener::emit(uint32_t path, uint32_t meta, uint32_t lo, uint32_t hi) {
-  if (t_->rows.size() == t_->hdrs.back().row_start) meta |= ROW_FIRST;
-  t_->rows.push_back({path, meta, lo, hi});
+  stage_.push_back({path, Row{t_->n_reviews % GK_TILE, meta, lo, hi}});
 }
 
 uint32_t Flattener::put_string(const std::string& s, uint32_t* hash) {
@@ -300,7 +301,6 @@ void Flattener::add(const ReviewDoc& doc, HostTable* out) {
   t_ = out;
   ctrs_.clear();
   review_flags_ = 0;
-  out->hdrs.push_back({(uint32_t)out->rows.size(), 0});
   const Value& req = doc.request;
   // root + request members (input.review.*)
   emit(0, T_OBJECT, (uint32_t)req.size(), 0);
@@ -335,10 +335,33 @@ void Flattener::add(const ReviewDoc& doc, HostTable* out) {
     case SRC_INVALID: review_flags_ |= RF_SRC_INVALID; break;
     default: break;
   }
-  out->hdrs.back().flags = review_flags_;
+  out->rflags.push_back(review_flags_);
   out->n_reviews++;
+  if (out->n_reviews % GK_TILE == 0) flush_tile(out);
 }
 
-void Flattener::finish(HostTable* out) { out->hdrs.push_back({(uint32_t)out->rows.size(), 0}); }
+// Close the current tile: stable sort of its rows by path (keeps review order, then document order, inside a
+// segment) and one directory entry per distinct path.
+void Flattener::flush_tile(HostTable* out) {
+  out->tile_seg.push_back((uint32_t)out->segs.size());
+  order_.resize(stage_.size());
+  for (uint32_t i = 0; i < order_.size(); i++) order_[i] = i;
+  std::stable_sort(order_.begin(), order_.end(), [&](uint32_t a, uint32_t b) { return stage_[a].path < stage_[b].path; });
+  uint32_t prev = PathDict::kNone;
+  for (uint32_t i : order_) {
+    const Staged& s = stage_[i];
+    if (s.path != prev) { out->segs.push_back({s.path, (uint32_t)out->rows.size()}); prev = s.path; }
+    if (s.path >= out->path_rows.size()) out->path_rows.resize(s.path + 1, 0);
+    out->path_rows[s.path]++;
+    out->rows.push_back(s.row);
+  }
+  stage_.clear();
+}
+
+void Flattener::finish(HostTable* out) {
+  if (!stage_.empty() || out->n_reviews % GK_TILE != 0) flush_tile(out);
+  out->tile_seg.push_back((uint32_t)out->segs.size());
+  out->segs.push_back({PathDict::kNone, (uint32_t)out->rows.size()});
+}
 
 }  // namespace gk

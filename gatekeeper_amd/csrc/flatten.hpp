@@ -82,18 +82,20 @@ void obj_gvk(const Value& obj, std::string* group, std::string* version, std::st
 bool obj_is_namespace(const Value& obj);
 
 struct HostTable {
-  std::vector<Row> rows;
-  std::vector<ReviewHdr> hdrs;   // n + 1 entries
+  std::vector<Row> rows;            // row groups: per tile, sorted by path (plan.hpp)
+  std::vector<Seg> segs;            // directory entries of all tiles + closing sentinel
+  std::vector<uint32_t> tile_seg;   // n_tiles + 1
+  std::vector<uint32_t> rflags;     // n_reviews
   std::vector<uint8_t> heap;
+  std::vector<uint32_t> path_rows;  // rows per path over the whole table (algorithmic-byte accounting per plan)
   uint32_t n_reviews = 0;
-  uint64_t algo_bytes() const { return rows.size() * sizeof(Row) + hdrs.size() * sizeof(ReviewHdr); }
 };
 
 class Flattener {
  public:
   explicit Flattener(PathDict* dict);
   void add(const ReviewDoc& doc, HostTable* out);
-  void finish(HostTable* out);   // appends the sentinel header
+  void finish(HostTable* out);   // flushes the last tile and closes the directory
 
  private:
   PathDict* dict_;
@@ -102,6 +104,10 @@ class Flattener {
   std::vector<Ctr> ctrs_;
   HostTable* t_ = nullptr;
   uint32_t review_flags_ = 0;
+  struct Staged { uint32_t path; Row row; };
+  std::vector<Staged> stage_;       // rows of the tile being built, review order / document order
+  std::vector<uint32_t> order_;
+  void flush_tile(HostTable* out);
   void walk(const Value& v, uint32_t path, uint32_t meta_ords, int adepth, uint32_t extra);
   void emit(uint32_t path, uint32_t meta, uint32_t lo, uint32_t hi);
   uint32_t put_string(const std::string& s, uint32_t* hash);

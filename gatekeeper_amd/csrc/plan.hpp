@@ -11,19 +11,29 @@
 namespace gk {
 
 // ------------------------------------------------------------------------------------------------ rows
-// One row per JSON node (scalars AND containers) of the review document, in document order.
+// One row per JSON node (scalars AND containers) of the review documents.  The table is stored as ROW GROUPS: reviews
+// are grouped in tiles of GK_TILE consecutive reviews, and within a tile the rows are sorted by key path (stable:
+// review order, then document order).  The rows of one (tile, path) pair form a SEGMENT, listed in the tile's segment
+// directory.  A plan touches only the segments of the paths it has predicates on -- typically a fifth of a Pod's rows
+// -- and every row of a segment takes the same predicates, so a wave evaluates them without divergence.
 struct Row {
-  uint32_t path;   // interned wildcarded key-path id (array indices erased); collision-free (PathDict)
+  uint32_t rev;    // review index within its tile (0 .. GK_TILE-1)
   uint32_t meta;   // see ROW_* below
   uint32_t lo;     // value payload
   uint32_t hi;
 };
 static_assert(sizeof(Row) == 16, "Row must be 16 bytes");
 
+struct Seg {
+  uint32_t path;    // interned wildcarded key-path id (array indices erased); collision-free (PathDict)
+  uint32_t start;   // first row; the segment ends where the next directory entry starts (a sentinel closes the table)
+};
+static_assert(sizeof(Seg) == 8, "Seg must be 8 bytes");
+
 enum RowType : uint32_t { T_NULL = 0, T_BOOL = 1, T_INT = 2, T_FLOAT = 3, T_STRING = 4, T_OBJECT = 5, T_ARRAY = 6 };
 
 constexpr uint32_t ROW_TYPE_MASK = 0x7;
-constexpr uint32_t ROW_FIRST = 1u << 3;        // first row of a review
+constexpr uint32_t ROW_RESERVED3 = 1u << 3;    // unused
 constexpr uint32_t ROW_E_SHIFT0 = 4;           // ordinal of the enclosing element at array-nesting level 0
 constexpr uint32_t ROW_E_SHIFT1 = 12;          // ... level 1
 constexpr uint32_t ROW_E_SHIFT2 = 20;          // ... level 2
@@ -38,10 +48,9 @@ constexpr uint32_t ROW_STR_INLINE = 1u << 31;    // string of <= 7 bytes packed 
 //                                  (so off-4 is 16-byte aligned), hi = hash32(bytes)
 //                 object/array: lo = member count
 
-struct ReviewHdr {
-  uint32_t row_start;   // first row; rows of review r are [hdr[r].row_start, hdr[r+1].row_start)
-  uint32_t flags;       // RF_* (match-layer facts computed once by the flattener)
-};
+// Table arrays: rows[n_rows], segs[n_segs + 1] (directory entries of all tiles + sentinel), tile_seg[n_tiles + 1]
+// (first directory entry of each tile), rflags[n_reviews] (RF_*: match-layer facts computed once by the flattener),
+// string heap.
 
 enum ReviewFlag : uint32_t {
   RF_HAS_OBJ = 1u << 0,          // request.object present (after setObjectOnDelete, pkg/target/target.go:269-287)
@@ -142,6 +151,7 @@ constexpr int GK_TILE = 64;            // reviews per tile (one lane per review 
 constexpr int GK_BLOCK = 256;          // threads per tile in the dominant kernel: 4 waves stream the tile's rows
 constexpr int GK_MAX_RES = 64;         // unique formulas per result class per pass
 constexpr int GK_MAX_SCOPES = 32;
+constexpr int GK_MAX_CHUNKS = 512;      // 64-row chunks of predicate-bearing segments per tile held in LDS; beyond: the tile's reviews take the big path
 
 struct PlanDims {
   uint32_t n_paths;       // entries in ptab

@@ -294,9 +294,9 @@ GK_HD uint32_t val_stride(uint32_t nvals) { return nvals <= 1 ? nvals * 2u : nva
 template <class Acc>
 GK_HD void eval_row_ent(const Row& r, uint32_t row_index, uint32_t ent, const StrHdr& h, const PlanView& pv, const uint8_t* heap, Acc& acc);
 template <class Acc>
-GK_HD void eval_row(const Row& r, uint32_t row_index, const PlanView& pv, const uint8_t* heap, Acc& acc) {
-  if (r.path >= pv.dims.n_paths) return;
-  uint32_t ent = pv.ptab[r.path];
+GK_HD void eval_row(const Row& r, uint32_t path, uint32_t row_index, const PlanView& pv, const uint8_t* heap, Acc& acc) {
+  if (path >= pv.dims.n_paths) return;
+  uint32_t ent = pv.ptab[path];
   if (ent == 0) return;
   StrHdr h = {{0, 0, 0, 0}};
   if (row_needs_hdr(r)) h = load_hdr(r, heap);

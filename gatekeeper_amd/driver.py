@@ -124,6 +124,7 @@ class EvalResult:
         self.n_overflow = o.n_overflow
         self.kernel_ms, self.fast_kernel_ms = o.kernel_ms, o.fast_kernel_ms
         self.algo_bytes, self.n_rows, self.n_launches = o.algo_bytes, o.n_rows, o.n_launches
+        self.n_rows_read = o.n_rows_read
         self.d_viol, self.d_err, self.d_counts = o.d_viol, o.d_err, o.d_counts
         lib.gk_eval_free(ptr)
 

@@ -97,12 +97,13 @@ typedef struct {
   float kernel_ms;           /* device time of the evaluation kernels (HIP events on the launch stream) */
   float fast_kernel_ms;      /* ... of the dominant LDS kernel alone */
   uint64_t algo_bytes;       /* algorithmic bytes of this launch (DESIGN.md "Roofline accounting") */
-  uint64_t n_rows;
+  uint64_t n_rows;           /* rows in the table */
   uint32_t n_launches;       /* launches averaged in fast_kernel_ms (GK_EVAL_ASYNC enqueues without collecting) */
   uint32_t reserved;
   const void* d_viol;        /* device pointers to the same bitmaps / counts, valid until the table's next launch: */
   const void* d_err;         /* lets the caller hand them to RCCL (all-gather of per-shard violation bitmaps)      */
   const void* d_counts;
+  uint64_t n_rows_read;      /* rows in the segments whose key path carries predicates of the current plan */
 } gk_eval_out;
 
 #define GK_EVAL_WANT_MATCH 1u

@@ -80,15 +80,23 @@ static bool eval_review(const HostPlan& hp, const HostTable& t, uint32_t r, Resu
   PlanView pv = view_of(hp);
   std::vector<uint32_t> words(hp.dims.acc_words, 0);
   VecAcc acc{&words};
-  for (uint32_t i = t.hdrs[r].row_start; i < t.hdrs[r + 1].row_start; i++) {
-    if (jit) { uint32_t c = t.rows[i].path < jit->cls.size() ? jit->cls[t.rows[i].path] : 0; if (c) { StrHdr h = {{0, 0, 0, 0}}; if (row_needs_hdr(t.rows[i])) h = load_hdr(t.rows[i], t.heap.data()); jit->row(&t.rows[i], i, c, &h, &pv, t.heap.data(), &words); } }
-    else eval_row(t.rows[i], i, pv, t.heap.data(), acc);
+  const uint32_t tile = r / GK_TILE, rl = r % GK_TILE;
+  for (uint32_t s = t.tile_seg[tile]; s < t.tile_seg[tile + 1]; s++) {
+    const uint32_t path = t.segs[s].path;
+    if (path >= pv.dims.n_paths || pv.ptab[path] == 0) continue;
+    for (uint32_t i = t.segs[s].start; i < t.segs[s + 1].start; i++) {
+      if (t.rows[i].rev != rl) continue;
+      if (jit) {
+        uint32_t c = path < jit->cls.size() ? jit->cls[path] : 0;
+        if (c) { StrHdr h = {{0, 0, 0, 0}}; if (row_needs_hdr(t.rows[i])) h = load_hdr(t.rows[i], t.heap.data()); jit->row(&t.rows[i], i, c, &h, &pv, t.heap.data(), &words); }
+      } else eval_row(t.rows[i], path, i, pv, t.heap.data(), acc);
+    }
   }
   if (words[0] & 1u) return false;   // overflow
   uint32_t bounds[GK_MAX_SCOPES] = {0};
   for (uint32_t s = 0; s < hp.dims.n_scopes; s++) bounds[s] = words[hp.scopes[s].count_off];
-  if (jit) jit->form(&pv, &words, t.hdrs[r].flags, t.rows.data(), t.heap.data(), bounds, res);
-  else *res = eval_formulas(pv, acc, t.hdrs[r].flags, t.rows.data(), t.heap.data(), bounds);
+  if (jit) jit->form(&pv, &words, t.rflags[r], t.rows.data(), t.heap.data(), bounds, res);
+  else *res = eval_formulas(pv, acc, t.rflags[r], t.rows.data(), t.heap.data(), bounds);
   return true;
 }
 
@@ -107,7 +115,7 @@ void dev_eval_finish(const DevPlan* p, const DevTable* dt, const EvalOptions& op
   auto t0 = std::chrono::steady_clock::now();
   for (uint32_t r = 0; r < n; r++) {
     uint32_t tile = r / GK_TILE; uint64_t bit = 1ull << (r % GK_TILE);
-    if (t.hdrs[r].flags & RF_TOO_BIG) { o->too_big[tile] |= bit; continue; }
+    if (t.rflags[r] & RF_TOO_BIG) { o->too_big[tile] |= bit; continue; }
     Results res{0, 0, 0};
     if (!eval_review(p->fast, t, r, &res, p->row ? p : nullptr)) {
       o->n_overflow++;
