@@ -5,6 +5,7 @@
 // text with g++ to validate the generator in the GPU-less container.
 #include "codegen.hpp"
 
+#include <algorithm>
 #include <map>
 #include <sstream>
 
@@ -105,9 +106,9 @@ std::string generate_plan_source(const HostPlan& plan) {
     for (size_t i = stack.size(); i-- > 0;) if (stack[i].scope == scope) return stack[i].depth;
     return -1;
   };
-  std::string ind = "  ";
   const std::vector<uint32_t>& code = plan.code;
-  for (size_t pc = 0; pc < code.size();) {
+  auto gen = [&](size_t pc0, size_t pc1, bool staged, std::string ind) {
+  for (size_t pc = pc0; pc < pc1;) {
     uint32_t ins = code[pc++];
     uint32_t op = ins & 0xFF, a = (ins >> 8) & 0xFF, b = (ins >> 16) & 0xFF, c = ins >> 24;
     switch (op) {
@@ -178,17 +179,85 @@ std::string generate_plan_source(const HostPlan& plan) {
         o << ind << "if (b" << a << ") acc.or_word(" << sc.word_off << "u + e" << d << " * " << (int)sc.wpe << "u + " << elem_word_of_bit(c) << "u, " << u(elem_mask_of_bit(c)) << ");\n";
         break;
       }
-      case F_STG: { uint32_t bit = b | (c << 8); o << ind << "if (b" << a << ") g" << (bit >> 5) << " |= " << u(1u << (bit & 31)) << ";\n"; break; }
+      case F_STG: {
+        uint32_t bit = b | (c << 8);
+        if (staged) o << ind << "if (b" << a << ") { g" << (bit >> 5) << " |= " << u(1u << (bit & 31)) << "; acc.or_word(" << (bit >> 5) << "u, " << u(1u << (bit & 31)) << "); }\n";
+        else o << ind << "if (b" << a << ") g" << (bit >> 5) << " |= " << u(1u << (bit & 31)) << ";\n";
+        break;
+      }
       case F_RES: {
         const char* f = b == 0 ? "viol" : b == 1 ? "match" : "err";
         o << ind << "res." << f << " |= (uint64_t)b" << a << " << " << c << ";\n";
         break;
       }
-      case F_END: pc = code.size(); break;
+      case F_END: pc = pc1; break;
       default: throw Unsupported("codegen: unknown formula op");
     }
   }
-  o << "  return res;\n}\n}  // namespace gk\n";
+  };
+  gen(0, code.size(), false, "  ");
+  o << "  return res;\n}\n\n";
+  // ---- the same formulas cut into self-contained blocks and spread over the tile's waves: blocks of one STAGE are
+  // independent (they only read bits written by earlier stages); part = stage * NW + wave
+  {
+    constexpr uint32_t NW = GK_BLOCK / GK_TILE;
+    struct Blk { size_t pc0, pc1; uint32_t stage; uint64_t cost; std::vector<uint64_t> writes, reads; };
+    std::vector<Blk> blks;
+    size_t prev = 0;
+    for (uint32_t e : plan.seg_ends) { blks.push_back({prev, e, 0, 0, {}, {}}); prev = e; }
+    std::map<uint64_t, size_t> writer;   // derived bit -> block
+    for (size_t bi = 0; bi < blks.size(); bi++) {
+      Blk& B = blks[bi];
+      uint64_t weight = 1;
+      for (size_t pc = B.pc0; pc < B.pc1;) {
+        uint32_t ins = code[pc++];
+        uint32_t op = ins & 0xFF, b = (ins >> 16) & 0xFF, c = ins >> 24;
+        if (op == F_VEQ) { pc++; B.cost += 12 * weight; }
+        else if (op == F_LOOP) { B.cost += 4 * weight; weight *= 3; }
+        else if (op == F_ENDLOOP) { weight /= 3; B.cost += weight; }
+        else B.cost += weight;
+        if (op == F_STG) B.writes.push_back(1ull << 40 | b | (c << 8));
+        if (op == F_STE) B.writes.push_back(2ull << 40 | (uint64_t)b << 16 | c);
+        if (op == F_LDG) B.reads.push_back(1ull << 40 | b | (c << 8));
+        if (op == F_LDE) B.reads.push_back(2ull << 40 | (uint64_t)b << 16 | c);
+      }
+      for (uint64_t r : B.reads) { auto it = writer.find(r); if (it != writer.end() && it->second != bi) B.stage = std::max(B.stage, blks[it->second].stage + 1); }
+      for (uint64_t w : B.writes) writer[w] = bi;
+    }
+    uint32_t n_stages = 0;
+    for (auto& B : blks) n_stages = std::max(n_stages, B.stage + 1);
+    std::vector<std::vector<size_t>> parts((size_t)n_stages * NW);
+    for (uint32_t st = 0; st < n_stages; st++) {   // greedy balance: heaviest block to the lightest wave
+      std::vector<size_t> ids;
+      for (size_t bi = 0; bi < blks.size(); bi++) if (blks[bi].stage == st) ids.push_back(bi);
+      std::stable_sort(ids.begin(), ids.end(), [&](size_t x, size_t y) { return blks[x].cost > blks[y].cost; });
+      uint64_t load[NW] = {0};
+      for (size_t bi : ids) {
+        uint32_t w = 0;
+        for (uint32_t k = 1; k < NW; k++) if (load[k] < load[w]) w = k;
+        load[w] += blks[bi].cost;
+        parts[(size_t)st * NW + w].push_back(bi);
+      }
+    }
+    o << "#define GK_HAS_STAGES 1\nconstexpr uint32_t GK_N_STAGES = " << n_stages << "u;\n"
+      << "template <class Acc>\nGK_HD void jit_formula_part(uint32_t part, Acc& acc, uint32_t flags, const uint8_t* heap, const uint32_t* bounds, Results& res) {\n"
+      << "  (void)heap; (void)flags; (void)bounds;\n  bool";
+    for (int i = 0; i < 64; i++) o << (i ? ", " : " ") << "b" << i << " = false";
+    o << ";\n";
+    for (uint32_t w = 0; w < plan.dims.n_gwords; w++) o << "  uint32_t g" << w << " = acc.load(" << w << "u);\n";
+    o << "  switch (part) {\n";
+    for (size_t p = 0; p < parts.size(); p++) {
+      o << "    case " << p << ": {\n";
+      std::vector<size_t> order = parts[p];
+      std::sort(order.begin(), order.end());
+      for (size_t bi : order) { stack.clear(); gen(blks[bi].pc0, blks[bi].pc1, true, "      "); }
+      o << "    } break;\n";
+    }
+    o << "    default: break;\n  }\n";
+    for (uint32_t w = 0; w < plan.dims.n_gwords; w++) o << "  (void)g" << w << ";\n";
+    o << "}\n";
+  }
+  o << "}  // namespace gk\n";
   return o.str();
 }
 

@@ -862,16 +862,20 @@ HostPlan PlanBuilder::build(const PlanCaps& caps) {
   }
   if (viols.size() > GK_MAX_RES || matches.size() > GK_MAX_RES)
     throw Unsupported("more than 64 distinct violation or match formulas in one plan (split the constraint set)");
-  for (size_t i = 0; i < viols.size(); i++) { int r = L.lower(viols[i]); L.emit(finst(F_RES, r, 0, (uint32_t)i)); L.release(r); }
+  std::vector<uint32_t> main_ends;
+  for (size_t i = 0; i < viols.size(); i++) { int r = L.lower(viols[i]); L.emit(finst(F_RES, r, 0, (uint32_t)i)); L.release(r); main_ends.push_back((uint32_t)L.plan.code.size()); }
   for (size_t i = 0; i < matches.size(); i++) {
     int r = L.lower(matches[i]); L.emit(finst(F_RES, r, 1, (uint32_t)i)); L.release(r);
+    main_ends.push_back((uint32_t)L.plan.code.size());
     r = L.lower(errs[i]); L.emit(finst(F_RES, r, 2, (uint32_t)i)); L.release(r);
+    main_ends.push_back((uint32_t)L.plan.code.size());
   }
   L.emit(finst(F_END));
   HostPlan& p = L.plan;
   {   // derived-bit prologue blocks first (inner blocks were completed, hence appended, before outer ones)
     std::vector<uint32_t> code;
-    for (auto& b : L.prologue) code.insert(code.end(), b.begin(), b.end());
+    for (auto& b : L.prologue) { code.insert(code.end(), b.begin(), b.end()); p.seg_ends.push_back((uint32_t)code.size()); }
+    for (uint32_t e : main_ends) p.seg_ends.push_back((uint32_t)code.size() + e);
     code.insert(code.end(), p.code.begin(), p.code.end());
     p.code.swap(code);
   }

@@ -40,6 +40,7 @@ struct HostPlan {
   std::vector<Pattern> pred_patterns;     // parallel to preds
   std::vector<Scope> scopes;
   std::vector<uint32_t> code;
+  std::vector<uint32_t> seg_ends;         // code offsets closing each self-contained block (derived-bit blocks, then one per result)
   std::vector<uint8_t> cheap;
   std::vector<ConstraintSlot> slots;      // per constraint
   uint32_t n_viol = 0, n_match = 0;       // unique formulas

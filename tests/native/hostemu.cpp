@@ -56,7 +56,13 @@ DevPlan* dev_plan_upload(const HostPlan& fast, const HostPlan& big) {
         << "struct VecAcc { std::vector<uint32_t>* w; void or_word(uint32_t i, uint32_t m) { (*w)[i] |= m; } void max_word(uint32_t i, uint32_t v) { if ((*w)[i] < v) (*w)[i] = v; }\n"
            "  void store_word(uint32_t i, uint32_t v) { (*w)[i] = v; } uint32_t load(uint32_t i) const { return (*w)[i]; } };\n"
            "extern \"C\" void gk_he_row(const gk::Row* r, uint32_t i, uint32_t cls, const gk::StrHdr* h, const gk::PlanView* pv, const uint8_t* heap, std::vector<uint32_t>* w) { VecAcc acc{w}; gk::jit_row(*r, i, cls, *h, *pv, heap, acc); }\n"
-           "extern \"C\" void gk_he_form(const gk::PlanView* pv, std::vector<uint32_t>* w, uint32_t flags, const gk::Row* rows, const uint8_t* heap, const uint32_t* bounds, gk::Results* out) { VecAcc acc{w}; *out = gk::jit_formulas(*pv, acc, flags, rows, heap, bounds); }\n";
+           "extern \"C\" void gk_he_form(const gk::PlanView* pv, std::vector<uint32_t>* w, uint32_t flags, const gk::Row* rows, const uint8_t* heap, const uint32_t* bounds, gk::Results* out) {\n"
+           "  VecAcc acc{w}; std::vector<uint32_t> w2 = *w; VecAcc acc2{&w2};\n"
+           "  gk::Results mono = gk::jit_formulas(*pv, acc2, flags, rows, heap, bounds);\n"
+           "  gk::Results r = {0, 0, 0};\n"
+           "  for (uint32_t st = 0; st < gk::GK_N_STAGES; st++) for (uint32_t wv = 0; wv < 4; wv++) gk::jit_formula_part(st * 4 + (3 - wv), acc, flags, heap, bounds, r);\n"
+           "  if (r.viol != mono.viol || r.match != mono.match || r.err != mono.err) { r.viol = ~0ull; r.match = ~0ull; r.err = ~0ull; }   // staged and monolithic code must agree\n"
+           "  *out = r; }\n";
     }
     std::string cmd = "g++ -std=c++17 -O1 -shared -fPIC -o " + base + ".so " + base + ".cpp 2> " + base + ".log";
     if (system(cmd.c_str()) != 0) throw std::runtime_error("hostemu: generated plan source does not compile, see " + base + ".log");
