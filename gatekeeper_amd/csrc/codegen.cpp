@@ -57,8 +57,8 @@ std::string generate_plan_source(const HostPlan& plan) {
   for (size_t i = 0; i < plan.cheap.size(); i++) o << (i ? "," : "") << (int)plan.cheap[i];
   o << "};\n";
   // ---------------------------------------------------------------------------------------------- phase 1
-  o << "template <class Acc>\nGK_HD void jit_row(const Row& r, uint32_t row_index, uint32_t cls, const StrHdr& h, const PlanView& pv, const uint8_t* heap, Acc& acc) {\n"
-    << "  const uint8_t* cheap = gk_plan_consts;\n  (void)cheap; (void)row_index; (void)h; (void)pv;\n  switch (cls) {\n";
+  o << "template <class Acc>\nGK_HD __attribute__((noinline)) void jit_row(Row r, uint32_t cls, StrHdr h, const uint8_t* heap, Acc acc) {\n"
+    << "  const uint8_t* cheap = gk_plan_consts;\n  (void)cheap; (void)h;\n  cls = GK_UNI(cls);   // one class per call: the dispatch is a scalar branch\n  switch (cls) {\n";
   for (size_t c = 1; c < classes.size(); c++) {
     o << "    case " << c << ": {\n";
     for (const Pred& p : classes[c]) {

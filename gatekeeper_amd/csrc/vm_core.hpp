@@ -43,11 +43,7 @@ GK_HD uint32_t row_type(const Row& r) { return r.meta & ROW_TYPE_MASK; }
 GK_HD uint32_t row_ordinal(const Row& r, uint32_t level) { return (r.meta >> (ROW_E_SHIFT0 + 8 * level)) & ROW_E_MASK; }
 GK_HD uint32_t ld32(const uint8_t* p) { return *reinterpret_cast<const uint32_t*>(p); }
 GK_HD int64_t row_i64(const Row& r) { return (int64_t)(((uint64_t)r.hi << 32) | r.lo); }
-GK_HD double bits_f64(uint64_t b) {
-  union { uint64_t u; double d; } x;
-  x.u = b;
-  return x.d;
-}
+GK_HD double bits_f64(uint64_t b) { return __builtin_bit_cast(double, b); }
 GK_HD double row_f64(const Row& r) { return bits_f64(((uint64_t)r.hi << 32) | r.lo); }
 
 // ------------------------------------------------------------------------------------------------ strings

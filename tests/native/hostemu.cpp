@@ -55,7 +55,7 @@ DevPlan* dev_plan_upload(const HostPlan& fast, const HostPlan& big) {
       f << "#include <vector>\n#include \"" << GK_CSRC_DIR << "/vm_core.hpp\"\n" << generate_plan_source(fast)
         << "struct VecAcc { std::vector<uint32_t>* w; void or_word(uint32_t i, uint32_t m) { (*w)[i] |= m; } void max_word(uint32_t i, uint32_t v) { if ((*w)[i] < v) (*w)[i] = v; }\n"
            "  void store_word(uint32_t i, uint32_t v) { (*w)[i] = v; } uint32_t load(uint32_t i) const { return (*w)[i]; } };\n"
-           "extern \"C\" void gk_he_row(const gk::Row* r, uint32_t i, uint32_t cls, const gk::StrHdr* h, const gk::PlanView* pv, const uint8_t* heap, std::vector<uint32_t>* w) { VecAcc acc{w}; gk::jit_row(*r, i, cls, *h, *pv, heap, acc); }\n"
+           "extern \"C\" void gk_he_row(const gk::Row* r, uint32_t i, uint32_t cls, const gk::StrHdr* h, const gk::PlanView* pv, const uint8_t* heap, std::vector<uint32_t>* w) { VecAcc acc{w}; (void)i; (void)pv; gk::jit_row(*r, cls, *h, heap, acc); }\n"
            "extern \"C\" void gk_he_form(const gk::PlanView* pv, std::vector<uint32_t>* w, uint32_t flags, const gk::Row* rows, const uint8_t* heap, const uint32_t* bounds, gk::Results* out) {\n"
            "  VecAcc acc{w}; std::vector<uint32_t> w2 = *w; VecAcc acc2{&w2};\n"
            "  gk::Results mono = gk::jit_formulas(*pv, acc2, flags, rows, heap, bounds);\n"

@@ -1,0 +1,22 @@
+#!/bin/bash
+# Offline view of the plan-specialised kernel: assembles the same source text kernels.hip hands to hiprtc (generated
+# part from GK_PLAN_SOURCE_DUMP) and compiles it with hipcc for gfx950, printing register / LDS / occupancy figures.
+# usage: tools/jit_offline.sh /tmp/plan_src.hip [outdir]
+set -e
+gen=${1:-/tmp/plan_src.hip}; out=${2:-/tmp/jit_offline}; mkdir -p $out
+here=$(cd $(dirname $0)/.. && pwd)
+python3 - "$gen" "$out/gk_plan.hip" "$here/gatekeeper_amd/csrc" <<'PY'
+import sys
+gen, dst, src = sys.argv[1:4]
+def text(name):
+    return "".join(l for l in open(src + "/" + name) if not l.startswith("#include") and not l.startswith("#pragma once"))
+s = ("#include <hip/hip_runtime.h>\n" + text("plan.hpp") + text("vm_core.hpp") + open(gen).read() +
+     "namespace gk {\n#define GK_KERNEL_TILES gk_jit_tiles\n#define GK_KERNEL_BIG gk_jit_big\n#define GK_KERNEL_LINKAGE extern \"C\"\n"
+     "#define GK_ROW_FN(r, i, ent, h, pv, heap, acc) jit_row(r, ent, h, heap, acc)\n"
+     "#define GK_FORMULA_FN(pv, acc, flags, rows, heap, bounds) jit_formulas(pv, acc, flags, rows, heap, bounds)\n" +
+     text("kernel_body.inc") + "}\n")
+open(dst, "w").write(s)
+PY
+cd $out
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -c gk_plan.hip -o gk_plan.o -Rpass-analysis=kernel-resource-usage --save-temps 2>&1 | grep -E "Function Name|VGPRs:|SGPRs:|ScratchSize|Occupancy|LDS Size|error" | sed 's/.*remark: //'
+ls -la $out/*.s 2>/dev/null | head -3
