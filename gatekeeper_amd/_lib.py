@@ -22,6 +22,7 @@ GK_ERR_INVALID, GK_ERR_REGO, GK_ERR_UNSUPPORTED, GK_ERR_NOT_FOUND, GK_ERR_DEVICE
 GK_REVIEW_ADMISSION_REQUEST, GK_REVIEW_OBJECT = 0, 1
 GK_SRC_EMPTY, GK_SRC_ORIGINAL, GK_SRC_GENERATED, GK_SRC_ALL, GK_SRC_INVALID = 0, 1, 2, 3, 4
 GK_TABLE_KEEP_DOCS = 1
+GK_TABLE_RESIDENT = 2
 GK_EVAL_WANT_MATCH, GK_EVAL_NO_DOWNLOAD, GK_EVAL_WANT_LIST, GK_EVAL_ASYNC, GK_EVAL_COLLECT = 1, 2, 4, 8, 16
 
 EXPORTS = [
@@ -50,7 +51,7 @@ class gk_eval_out(C.Structure):
                 ("too_big", C.POINTER(C.c_uint64)), ("counts", C.POINTER(C.c_uint32)), ("list", C.POINTER(C.c_uint32)),
                 ("list_len", C.c_uint32), ("list_total", C.c_uint32), ("n_overflow", C.c_uint32),
                 ("kernel_ms", C.c_float), ("fast_kernel_ms", C.c_float),
-                ("algo_bytes", C.c_uint64), ("n_rows", C.c_uint64), ("n_launches", C.c_uint32), ("reserved", C.c_uint32),
+                ("algo_bytes", C.c_uint64), ("n_rows", C.c_uint64), ("n_launches", C.c_uint32), ("lds_bytes", C.c_uint32),
                 ("d_viol", C.c_void_p), ("d_err", C.c_void_p), ("d_counts", C.c_void_p), ("n_rows_read", C.c_uint64)]
 
 

@@ -56,6 +56,32 @@ std::string generate_plan_source(const HostPlan& plan) {
   o << "GK_CONST_ARRAY unsigned char gk_plan_consts[" << plan.cheap.size() << "] = {";
   for (size_t i = 0; i < plan.cheap.size(); i++) o << (i ? "," : "") << (int)plan.cheap[i];
   o << "};\n";
+  {   // accumulator words that must start at zero: everything but value-slot payloads
+    std::vector<std::pair<uint32_t, uint32_t>> zr;
+    uint32_t lo = 0;
+    for (const Scope& sc : plan.scopes) {
+      if (sc.nvals == 0 || sc.cap == 0) continue;
+      uint32_t stride = val_stride(sc.nvals);
+      if (sc.nvals == 1) {   // payload only (the type nibble lives in the element word)
+        if (sc.val_off > lo) zr.emplace_back(lo, sc.val_off);
+        lo = sc.val_off + sc.cap * stride;
+      } else {
+        for (uint32_t e = 0; e < sc.cap; e++) {   // [payload x nvals][type word]
+          uint32_t tw = sc.val_off + e * stride + sc.nvals * 2u;
+          if (e == 0 && sc.val_off > lo) zr.emplace_back(lo, sc.val_off);
+          zr.emplace_back(tw, tw + 1);
+        }
+        lo = sc.val_off + sc.cap * stride;
+      }
+    }
+    if (plan.dims.acc_words > lo) zr.emplace_back(lo, plan.dims.acc_words);
+    o << "#define GK_HAS_ZERO_RANGES 1\nconstexpr uint32_t GK_N_ZERO_RANGES = " << zr.size() << "u;\n"
+      << "GK_CONST_ARRAY uint32_t gk_zero_lo[" << zr.size() << "] = {";
+    for (size_t i = 0; i < zr.size(); i++) o << (i ? "," : "") << zr[i].first << "u";
+    o << "};\nGK_CONST_ARRAY uint32_t gk_zero_hi[" << zr.size() << "] = {";
+    for (size_t i = 0; i < zr.size(); i++) o << (i ? "," : "") << zr[i].second << "u";
+    o << "};\n";
+  }
   // ---------------------------------------------------------------------------------------------- phase 1
   o << "template <class Acc>\nGK_HD __attribute__((noinline)) void jit_row(Row r, uint32_t cls, StrHdr h, const uint8_t* heap, Acc acc) {\n"
     << "  const uint8_t* cheap = gk_plan_consts;\n  (void)cheap; (void)h;\n  cls = GK_UNI(cls);   // one class per call: the dispatch is a scalar branch\n  switch (cls) {\n";

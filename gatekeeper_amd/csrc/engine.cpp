@@ -141,6 +141,10 @@ struct gk_engine {
   HostPlan fast, big;
   DevPlan* dev_plan = nullptr;
   std::vector<uint32_t> plan_ids;   // bitmap row -> constraint id
+  // table-specialised variants of the fast plan (GK_TABLE_RESIDENT): same formulas, element capacities = what the
+  // table's largest arrays need, so the per-review LDS footprint (hence occupancy) fits the data
+  struct Variant { HostPlan fast; DevPlan* dev = nullptr; };
+  std::map<std::vector<uint16_t>, std::unique_ptr<Variant>> variants;
   std::string last_dump;
 };
 
@@ -152,6 +156,8 @@ struct gk_table {
   std::vector<std::string> review_errors;
   uint64_t dir_bytes = 0, n_rows = 0;      // directory + review-flag bytes (read by every launch); rows in the table
   std::vector<uint32_t> path_rows;          // rows per path: which rows a plan reads
+  std::vector<uint32_t> path_max;           // per element path: largest array of one review
+  bool resident = false;
   uint32_t n_reviews = 0;
 };
 
@@ -177,19 +183,66 @@ Value set_in(const Value& root, const std::vector<std::string>& path, size_t i, 
   return Value::object(out);
 }
 
+PlanCaps default_caps(const gk_engine* e) {
+  PlanCaps caps;
+  for (int i = 0; i < 3; i++) if (e->opts.elem_cap[i]) caps.level_cap[i] = e->opts.elem_cap[i];
+  return caps;
+}
+
+// Plan for one table.  Resident tables (audit sets evaluated again and again) get a variant whose element capacities
+// are what the table's largest arrays need: fewer accumulator words per review -> more tiles resident per CU, and
+// reviews that would overflow the default capacities stay on the LDS kernel.  Caller holds plan_mu; ensure_plan ran.
+DevPlan* plan_for_table(gk_engine* e, const gk_table* t, const HostPlan** host) {
+  *host = &e->fast;
+  if (!t->resident || e->fast.scopes.empty()) return e->dev_plan;
+  std::vector<uint16_t> caps(e->fast.scopes.size(), 1);
+  for (size_t p = 0; p < e->fast.ptab.size(); p++) {
+    uint32_t ent = e->fast.ptab[p];
+    for (uint32_t j = 0; j < (ent & 0xFF); j++) {
+      const Pred& pr = e->fast.path_preds[(ent >> 8) + j];
+      if (pr.op != P_PRESENT || pr.dst != D_ELEM) continue;
+      uint32_t need = p < t->path_max.size() ? t->path_max[p] : 0;
+      if (need > caps[pr.scope]) caps[pr.scope] = (uint16_t)std::min<uint32_t>(need, 255);
+    }
+  }
+  static const uint16_t steps[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192, 255};
+  for (auto& c : caps) for (uint16_t s : steps) if (s >= c) { c = s; break; }
+  auto it = e->variants.find(caps);
+  if (it == e->variants.end()) {
+    std::unique_ptr<gk_engine::Variant> v(new gk_engine::Variant());
+    try {
+      PlanBuilder pb(&e->dict);
+      for (auto& c : e->constraints) if (c.alive) pb.add_constraint(c.viol, c.mf);
+      PlanCaps pc = default_caps(e);
+      pc.scope_cap = caps;
+      v->fast = pb.build(pc);
+      if (v->fast.scopes.size() != e->fast.scopes.size()) throw std::runtime_error("scope layout changed");
+      if (const char* dump = getenv("GK_PLAN_SOURCE_DUMP")) {
+        FILE* f = fopen((std::string(dump) + ".variant").c_str(), "w");
+        if (f) { std::string src = generate_plan_source(v->fast); fwrite(src.data(), 1, src.size(), f); fclose(f); }
+      }
+      v->dev = dev_plan_upload(v->fast, e->big);
+    } catch (const std::exception&) { v->dev = nullptr; }   // e.g. LDS limit: the default plan serves the table
+    it = e->variants.emplace(caps, std::move(v)).first;
+  }
+  if (!it->second->dev) return e->dev_plan;
+  *host = &it->second->fast;
+  return it->second->dev;
+}
+
 void ensure_plan(gk_engine* e) {
   std::lock_guard<std::mutex> l(e->plan_mu);
   std::shared_lock<std::shared_mutex> rl(e->mu);
   if (!e->plan_dirty && e->dev_plan && e->fast.dict_size == e->dict.size()) return;
+  for (auto& v : e->variants) dev_plan_free(v.second->dev);
+  e->variants.clear();
   if (e->plan_dirty || !e->dev_plan) {
     PlanBuilder pb(&e->dict);
     e->plan_ids.clear();
     for (auto& c : e->constraints) if (c.alive) { pb.add_constraint(c.viol, c.mf); e->plan_ids.push_back(c.id); }
-    PlanCaps caps;
-    for (int i = 0; i < 3; i++) if (e->opts.elem_cap[i]) caps.level_cap[i] = e->opts.elem_cap[i];
     PlanCaps bigcaps;
     bigcaps.level_cap[0] = bigcaps.level_cap[1] = bigcaps.level_cap[2] = 256;
-    e->fast = pb.build(caps);
+    e->fast = pb.build(default_caps(e));
     e->big = pb.build(bigcaps);
   } else {
     e->fast.resolve_paths(e->dict);
@@ -227,6 +280,7 @@ int gk_engine_create(const gk_opts* opts, gk_engine** out) {
 void gk_engine_destroy(gk_engine* e) {
   if (!e) return;
   if (e->dev_plan) dev_plan_free(e->dev_plan);
+  for (auto& v : e->variants) dev_plan_free(v.second->dev);
   delete e;
 }
 
@@ -369,6 +423,8 @@ int gk_table_create(gk_engine* e, const gk_review_in* reviews, size_t n, uint32_
     t->n_rows = t->host.rows.size();
     t->dir_bytes = t->host.segs.size() * sizeof(Seg) + t->host.tile_seg.size() * 4 + t->host.rflags.size() * 4;
     t->path_rows = t->host.path_rows;
+    t->path_max = t->host.path_max;
+    t->resident = (flags & GK_TABLE_RESIDENT) || getenv("GK_SPECIALIZE_ALL");
     t->dev = dev_table_upload(t->host);
     t->host.rows.clear(); t->host.rows.shrink_to_fit();
     t->host.heap.clear(); t->host.heap.shrink_to_fit();
@@ -384,7 +440,8 @@ void gk_table_free(gk_table* t) {
 }
 
 struct EvalHolder {
-  gk_eval_out pub;
+  gk_eval_out pub;   // first member: gk_eval_free recovers the holder from the public pointer
+  uint32_t lds_bytes = 0;
   EvalOut out;
   std::vector<uint32_t> ids;
 };
@@ -401,13 +458,16 @@ int gk_table_eval(gk_engine* e, gk_table* t, uint32_t flags, gk_eval_out** out) 
       std::lock_guard<std::mutex> l(e->plan_mu);
       h->ids = e->plan_ids;
       if (flags & GK_EVAL_WANT_LIST) opt.list_capacity = std::max<uint32_t>(1024, t->n_reviews * 4u);
+      const HostPlan* hp = nullptr;
+      DevPlan* dp = plan_for_table(e, t, &hp);
       if (flags & GK_EVAL_ASYNC) {   // enqueue only; a later call without GK_EVAL_ASYNC collects
-        dev_eval_launch(e->dev_plan, t->dev, opt);
+        dev_eval_launch(dp, t->dev, opt);
         *out = nullptr;
         return GK_OK;
       }
-      if (flags & GK_EVAL_COLLECT) dev_eval_finish(e->dev_plan, t->dev, opt, &h->out);   // no new launch
-      else dev_eval(e->dev_plan, t->dev, opt, &h->out);
+      if (flags & GK_EVAL_COLLECT) dev_eval_finish(dp, t->dev, opt, &h->out);   // no new launch
+      else dev_eval(dp, t->dev, opt, &h->out);
+      h->lds_bytes = hp->dims.acc_words * GK_TILE * 4;
     }
     gk_eval_out& p = h->pub;
     memset(&p, 0, sizeof p);
@@ -422,6 +482,7 @@ int gk_table_eval(gk_engine* e, gk_table* t, uint32_t flags, gk_eval_out** out) 
     p.kernel_ms = h->out.kernel_ms; p.fast_kernel_ms = h->out.fast_kernel_ms; p.n_launches = h->out.n_launches;
     p.d_viol = h->out.d_viol; p.d_err = h->out.d_err; p.d_counts = h->out.d_counts;
     p.n_rows = t->n_rows;
+    p.lds_bytes = h->lds_bytes;
     // algorithmic bytes: the rows of the segments whose path carries predicates + the segment
     // directory + review flags, all read once; plan tables read once; bitmaps written once; 8 B per list entry
     uint64_t rows_read = 0;

@@ -336,6 +336,10 @@ void Flattener::add(const ReviewDoc& doc, HostTable* out) {
     default: break;
   }
   out->rflags.push_back(review_flags_);
+  for (const Ctr& c : ctrs_) {
+    if (c.path >= out->path_max.size()) out->path_max.resize(c.path + 1, 0);
+    out->path_max[c.path] = std::max(out->path_max[c.path], c.n);
+  }
   out->n_reviews++;
   if (out->n_reviews % GK_TILE == 0) flush_tile(out);
 }

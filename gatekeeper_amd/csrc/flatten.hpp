@@ -88,6 +88,7 @@ struct HostTable {
   std::vector<uint32_t> rflags;     // n_reviews
   std::vector<uint8_t> heap;
   std::vector<uint32_t> path_rows;  // rows per path over the whole table (algorithmic-byte accounting per plan)
+  std::vector<uint32_t> path_max;   // per array-element path: largest element count of one review (plan specialisation)
   uint32_t n_reviews = 0;
 };
 

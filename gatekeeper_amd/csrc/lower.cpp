@@ -888,7 +888,7 @@ HostPlan PlanBuilder::build(const PlanCaps& caps) {
     Scope sc{};
     uint32_t nb = L.scope_nbits[s];
     sc.wpe = (uint8_t)(nb <= ELEM_W0_BITS ? 1 : 1 + (nb - ELEM_W0_BITS + 31) / 32);
-    sc.cap = caps.level_cap[L.scope_level[s]];
+    sc.cap = s < caps.scope_cap.size() && caps.scope_cap[s] ? caps.scope_cap[s] : caps.level_cap[L.scope_level[s]];
     sc.nvals = (uint8_t)L.val_slots[s].size();
     sc.count_off = off++;
     sc.word_off = off;

@@ -24,6 +24,7 @@ MatchFormulas compile_match(const Value& match_spec);
 
 struct PlanCaps {
   uint16_t level_cap[3] = {8, 12, 12};   // element capacity per array-nesting level
+  std::vector<uint16_t> scope_cap;       // optional: capacity per element scope (table-specialised variants), overrides level_cap
 };
 
 struct PatStep {

@@ -151,7 +151,7 @@ constexpr int GK_TILE = 64;            // reviews per tile (one lane per review 
 constexpr int GK_BLOCK = 256;          // threads per tile in the dominant kernel: 4 waves stream the tile's rows
 constexpr int GK_MAX_RES = 64;         // unique formulas per result class per pass
 constexpr int GK_MAX_SCOPES = 32;
-constexpr int GK_MAX_CHUNKS = 512;      // 64-row chunks of predicate-bearing segments per tile held in LDS; beyond: the tile's reviews take the big path
+constexpr int GK_MAX_CHUNKS = 256;      // 64-row chunks of predicate-bearing segments per tile held in LDS; beyond: the tile's reviews take the big path
 
 struct PlanDims {
   uint32_t n_paths;       // entries in ptab

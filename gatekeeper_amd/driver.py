@@ -125,6 +125,7 @@ class EvalResult:
         self.kernel_ms, self.fast_kernel_ms = o.kernel_ms, o.fast_kernel_ms
         self.algo_bytes, self.n_rows, self.n_launches = o.algo_bytes, o.n_rows, o.n_launches
         self.n_rows_read = o.n_rows_read
+        self.lds_bytes = o.lds_bytes
         self.d_viol, self.d_err, self.d_counts = o.d_viol, o.d_err, o.d_counts
         lib.gk_eval_free(ptr)
 
@@ -246,7 +247,7 @@ class Engine:
         arr = (C.c_char_p * len(path))(*[p.encode() for p in path])
         self._check(self.lib.gk_data_remove(self.handle, arr, len(path)))
 
-    def create_table(self, reviews, keep_docs=True):
+    def create_table(self, reviews, keep_docs=True, resident=False):
         n = len(reviews)
         arr = (L.gk_review_in * max(1, n))()
         keep = []
@@ -262,7 +263,8 @@ class Engine:
             a.operation = r.operation
         st = (C.c_int32 * max(1, n))()
         h = C.c_void_p()
-        self._check(self.lib.gk_table_create(self.handle, arr, n, L.GK_TABLE_KEEP_DOCS if keep_docs else 0, st, C.byref(h)))
+        flags = (L.GK_TABLE_KEEP_DOCS if keep_docs else 0) | (L.GK_TABLE_RESIDENT if resident else 0)
+        self._check(self.lib.gk_table_create(self.handle, arr, n, flags, st, C.byref(h)))
         return Table(self, h, list(st)[:n], n)
 
     def dump(self):

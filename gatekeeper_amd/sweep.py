@@ -34,7 +34,7 @@ class ShardedSweep:
         self.dist = dist
         rins = [D.to_review_in(D.AugmentedUnstructured(D.Unstructured(o), synth.namespace_for(o, namespaces), "Original"))
                 for o in objs]
-        self.table = client.driver.engine.create_table(rins, keep_docs=False)
+        self.table = client.driver.engine.create_table(rins, keep_docs=False, resident=True)   # the audit set stays on the GPU
         self.n = len(objs)
         self.nc = len(client.constraints)
         self.n_tiles = (self.n + 63) // 64

@@ -82,6 +82,8 @@ typedef struct {
 int gk_table_create(gk_engine* e, const gk_review_in* reviews, size_t n, uint32_t flags, int32_t* statuses, gk_table** out);
 void gk_table_free(gk_table* t);
 #define GK_TABLE_KEEP_DOCS 1u   /* keep parsed reviews on the host so violations can be rendered to messages */
+#define GK_TABLE_RESIDENT 2u    /* the table is evaluated again and again (audit set): the engine may compile a plan variant
+                                   whose LDS layout fits this table's array sizes (first evaluation pays the compile) */
 
 typedef struct {
   uint32_t n_reviews, n_constraints, n_tiles;   /* n_tiles = ceil(n_reviews / 64) */
@@ -99,7 +101,7 @@ typedef struct {
   uint64_t algo_bytes;       /* algorithmic bytes of this launch (DESIGN.md "Roofline accounting") */
   uint64_t n_rows;           /* rows in the table */
   uint32_t n_launches;       /* launches averaged in fast_kernel_ms (GK_EVAL_ASYNC enqueues without collecting) */
-  uint32_t reserved;
+  uint32_t lds_bytes;        /* accumulator LDS bytes per tile of the plan variant that ran */
   const void* d_viol;        /* device pointers to the same bitmaps / counts, valid until the table's next launch: */
   const void* d_err;         /* lets the caller hand them to RCCL (all-gather of per-shard violation bitmaps)      */
   const void* d_counts;
