@@ -6,6 +6,7 @@
 #include "codegen.hpp"
 
 #include <algorithm>
+#include <cstring>
 #include <map>
 #include <sstream>
 
@@ -85,35 +86,122 @@ std::string generate_plan_source(const HostPlan& plan) {
   // ---------------------------------------------------------------------------------------------- phase 1
   o << "template <class Acc>\nGK_HD __attribute__((noinline)) void jit_row(Row r, uint32_t cls, StrHdr h, const uint8_t* heap, Acc acc) {\n"
     << "  const uint8_t* cheap = gk_plan_consts;\n  (void)cheap; (void)h;\n  cls = GK_UNI(cls);   // one class per call: the dispatch is a scalar branch\n  switch (cls) {\n";
+  // One class = the predicates of one key path.  Results are gathered in one mask per destination word (a single LDS
+  // atomic per word, not per predicate); integer comparisons share one type test; short string equalities compare
+  // the packed payload; everything else goes through eval_pred with a constexpr predicate.
+  static const char* kCmpOps[] = {"==", "!=", "<", "<=", ">", ">="};
   for (size_t c = 1; c < classes.size(); c++) {
-    o << "    case " << c << ": {\n";
-    for (const Pred& p : classes[c]) {
-      o << "      { constexpr Pred P = " << pred_literal(p) << ";\n";
-      bool always = p.op == P_DEFINED || p.op == P_PRESENT || p.op == P_STORE;
-      o << "        if (" << (always ? "true" : "eval_pred(r, P, h, heap, cheap)") << ") {\n";
+    o << "    case " << c << ": {\n      const uint32_t t = r.meta & 7u; (void)t;\n";
+    const std::vector<Pred>& ps = classes[c];
+    struct Group { int scope, level; bool always = false; std::vector<std::string> masks; std::vector<size_t> stores; bool present = false; };
+    std::vector<Group> groups;          // element destinations by (scope, level)
+    std::vector<std::string> gmasks;    // global destination words
+    auto declare = [&](const std::string& name, std::vector<std::string>& list) {
+      if (std::find(list.begin(), list.end(), name) == list.end()) { list.push_back(name); o << "      uint32_t " << name << " = 0u;\n"; }
+    };
+    auto group_of = [&](const Pred& p) -> Group& {
+      for (auto& g : groups) if (g.scope == p.scope && g.level == p.level) return g;
+      groups.push_back(Group{p.scope, p.level});
+      return groups.back();
+    };
+    std::vector<std::string> target(ps.size());   // "mask |= bit" statement per predicate
+    for (size_t i = 0; i < ps.size(); i++) {
+      const Pred& p = ps[i];
       if (p.dst == D_GLOBAL) {
-        o << "          acc.or_word(" << (p.bit >> 5) << "u, " << u(1u << (p.bit & 31)) << ");\n";
+        std::string m = "mg" + std::to_string(p.bit >> 5);
+        declare(m, gmasks);
+        target[i] = m + " |= " + u(1u << (p.bit & 31)) + ";";
       } else {
-        const Scope& sc = plan.scopes[p.scope];
-        o << "          const uint32_t ord = row_ordinal(r, " << (int)p.level << "u);\n"
-          << "          if (ord >= " << sc.cap << "u || (r.meta & ROW_ORD_OVERFLOW)) acc.or_word(0u, 1u);\n          else {\n";
-        if (p.op == P_STORE) {
-          uint32_t stride = val_stride(sc.nvals);
-          o << "            const uint32_t vb = " << sc.val_off << "u + ord * " << stride << "u;\n"
-            << "            acc.store_word(vb + " << p.bit * 2u << "u, r.lo); acc.store_word(vb + " << p.bit * 2u + 1u << "u, r.hi);\n";
-          if (sc.nvals == 1) o << "            acc.or_word(" << sc.word_off << "u + ord * " << (int)sc.wpe << "u, val_nibble(r) << " << ELEM_NIBBLE_SHIFT << "u);\n";
-          else o << "            acc.or_word(vb + " << sc.nvals * 2u << "u, val_nibble(r) << " << 4u * p.bit << "u);\n";
+        Group& g = group_of(p);
+        if (p.op == P_STORE) { g.stores.push_back(i); g.always = true; continue; }
+        if (p.op == P_PRESENT) { g.present = true; g.always = true; continue; }
+        std::string m = "me" + std::to_string(p.scope) + "_" + std::to_string(p.level) + "_" + std::to_string(elem_word_of_bit(p.bit));
+        declare(m, g.masks);
+        target[i] = m + " |= " + u(elem_mask_of_bit(p.bit)) + ";";
+        if (p.op == P_DEFINED) g.always = true;
+      }
+    }
+    // integer comparisons: one type test for all of them
+    std::vector<size_t> icmp;
+    for (size_t i = 0; i < ps.size(); i++) if (ps[i].op == P_CMP && ps[i].ctype == T_INT && !target[i].empty()) icmp.push_back(i);
+    if (!icmp.empty()) {
+      o << "      if (t == T_INT) {\n        const int64_t a = row_i64(r);\n";
+      for (size_t i : icmp) o << "        if (a " << kCmpOps[ps[i].cmp] << " " << (long long)(int64_t)ps[i].k << "ll) " << target[i] << "\n";
+      o << "      } else {\n";
+      for (size_t i : icmp) o << "        { constexpr Pred P = " << pred_literal(ps[i]) << "; if (eval_pred(r, P, h, heap, cheap)) " << target[i] << " }\n";
+      o << "      }\n";
+    }
+    for (size_t i = 0; i < ps.size(); i++) {
+      const Pred& p = ps[i];
+      if (target[i].empty() || (p.op == P_CMP && p.ctype == T_INT)) continue;
+      std::string cond;
+      switch (p.op) {
+        case P_DEFINED: cond = "true"; break;
+        case P_TRUTHY: cond = "!(t == T_BOOL && r.lo == 0u)"; break;
+        case P_TYPE: cond = "((" + u(p.ctype) + " >> t) & 1u) != 0u"; break;
+        case P_COUNT_CMP: cond = std::string("(t == T_OBJECT || t == T_ARRAY) && ((int64_t)r.lo ") + kCmpOps[p.cmp] + " " + std::to_string((long long)(int64_t)p.k) + "ll)"; break;
+        case P_CMP:
+          if (p.ctype == T_STRING && (p.cmp == C_EQ || p.cmp == C_NE) && p.b <= 7) {
+            uint64_t bits = 0;
+            for (uint32_t k = 0; k < p.b; k++) bits |= (uint64_t)plan.cheap[p.a + k] << (8 * k);
+            uint32_t lo = (uint32_t)bits, hi = (uint32_t)(bits >> 32) | (p.b << 24);
+            cond = std::string(p.cmp == C_NE ? "!" : "") + "((r.meta & (7u | ROW_STR_INLINE)) == (4u | ROW_STR_INLINE) && r.lo == " + u(lo) + " && r.hi == " + u(hi) + ")";
+          }
+          break;
+        case P_STR_IN_SET: {   // all members short: compare the packed payload of an inline string row
+          bool all_short = p.b > 0 && p.b <= 8;
+          for (uint32_t k = 0; k < p.b && all_short; k++) {
+            uint32_t len; memcpy(&len, &plan.cheap[p.a + 12 * k + 8], 4);
+            if (len > 7) all_short = false;
+          }
+          if (!all_short) break;
+          cond = "(r.meta & (7u | ROW_STR_INLINE)) == (4u | ROW_STR_INLINE) && (";
+          for (uint32_t k = 0; k < p.b; k++) {
+            uint32_t ea, eb, len;
+            memcpy(&ea, &plan.cheap[p.a + 12 * k], 4); memcpy(&eb, &plan.cheap[p.a + 12 * k + 4], 4); memcpy(&len, &plan.cheap[p.a + 12 * k + 8], 4);
+            cond += std::string(k ? " || " : "") + "(r.lo == " + u(ea) + " && r.hi == " + u(eb | (len << 24)) + ")";
+          }
+          cond += ")";
+          break;
         }
-        else if (p.op == P_PRESENT) {
-          if (p.level > 0) o << "            const uint32_t parent = row_ordinal(r, " << (int)(p.level - 1) << "u);\n";
-          else o << "            const uint32_t parent = 0u;\n";
-          o << "            acc.or_word(" << sc.word_off << "u + ord * " << (int)sc.wpe << "u, 1u | (parent << 24));\n"
-            << "            acc.max_word(" << sc.count_off << "u, ord + 1u);\n";
-        } else {
-          o << "            acc.or_word(" << sc.word_off << "u + ord * " << (int)sc.wpe << "u + " << elem_word_of_bit(p.bit) << "u, " << u(elem_mask_of_bit(p.bit)) << ");\n";
-        }
+        default: break;
+      }
+      if (cond.empty()) o << "      { constexpr Pred P = " << pred_literal(p) << "; if (eval_pred(r, P, h, heap, cheap)) " << target[i] << " }\n";
+      else if (cond == "true") o << "      " << target[i] << "\n";
+      else o << "      if (" << cond << ") " << target[i] << "\n";
+    }
+    for (const std::string& m : gmasks) o << "      if (" << m << ") acc.or_word(" << m.substr(2) << "u, " << m << ");\n";
+    for (const Group& g : groups) {
+      const Scope& sc = plan.scopes[g.scope];
+      std::string hit = g.always ? "true" : "";
+      if (!g.always) for (size_t k = 0; k < g.masks.size(); k++) hit += (k ? " | " : "") + g.masks[k];
+      if (!g.always) hit = "(" + hit + ") != 0u";
+      o << "      if (" << hit << ") {\n        const uint32_t ord = row_ordinal(r, " << g.level << "u);\n"
+        << "        if (ord >= " << sc.cap << "u || (r.meta & ROW_ORD_OVERFLOW)) acc.or_word(0u, 1u);\n        else {\n";
+      std::string w0 = "0u";
+      for (const std::string& m : g.masks) if (m.back() == '0' && m[m.size() - 2] == '_') w0 = m;
+      std::string extra;
+      for (size_t i : g.stores) {
+        const Pred& p = ps[i];
+        uint32_t stride = val_stride(sc.nvals);
+        o << "          { const uint32_t vb = " << sc.val_off << "u + ord * " << stride << "u;\n"
+          << "            acc.store_word(vb + " << p.bit * 2u << "u, r.lo); acc.store_word(vb + " << p.bit * 2u + 1u << "u, r.hi);\n";
+        if (sc.nvals == 1) extra += " | (val_nibble(r) << " + std::to_string(ELEM_NIBBLE_SHIFT) + "u)";
+        else o << "            acc.or_word(vb + " << sc.nvals * 2u << "u, val_nibble(r) << " << 4u * p.bit << "u);\n";
         o << "          }\n";
       }
+      if (g.present) {
+        if (g.level > 0) extra += " | 1u | (row_ordinal(r, " + std::to_string(g.level - 1) + "u) << 24)";
+        else extra += " | 1u";
+        o << "          acc.max_word(" << sc.count_off << "u, ord + 1u);\n";
+      }
+      bool w0_done = false;
+      for (const std::string& m : g.masks) {
+        uint32_t wi = (uint32_t)atoi(m.substr(m.rfind('_') + 1).c_str());
+        if (wi == 0) { o << "          acc.or_word(" << sc.word_off << "u + ord * " << (int)sc.wpe << "u, " << m << extra << ");\n"; w0_done = true; }
+        else o << "          if (" << m << ") acc.or_word(" << sc.word_off << "u + ord * " << (int)sc.wpe << "u + " << wi << "u, " << m << ");\n";
+      }
+      if (!w0_done && !extra.empty()) o << "          acc.or_word(" << sc.word_off << "u + ord * " << (int)sc.wpe << "u, 0u" << extra << ");\n";
       o << "        }\n      }\n";
     }
     o << "    } break;\n";
