@@ -246,8 +246,17 @@ std::string generate_plan_source(const HostPlan& plan) {
         const Scope& sc = plan.scopes[a];
         int d = (int)stack.size();
         o << ind << "b" << c << " = false;\n";
-        o << ind << "{ const uint32_t n" << d << " = GK_UNI(bounds[" << a << "]);\n";
-        o << ind << "  for (uint32_t e" << d << " = 0; e" << d << " < n" << d << "; e" << d << "++) {\n";
+        // small capacities: constant trip count, fully unrolled -- the element words of absent elements are zero, so
+        // they contribute nothing, and the compiler can issue all LDS reads of the nest at once
+        uint64_t nest = sc.cap;
+        for (const Loop& l : stack) nest *= plan.scopes[l.scope].cap;
+        if (sc.cap <= 16 && nest <= 64) {
+          o << ind << "{ _Pragma(\"unroll\")\n";
+          o << ind << "  for (uint32_t e" << d << " = 0; e" << d << " < " << sc.cap << "u; e" << d << "++) {\n";
+        } else {
+          o << ind << "{ const uint32_t n" << d << " = GK_UNI(bounds[" << a << "]);\n";
+          o << ind << "  for (uint32_t e" << d << " = 0; e" << d << " < n" << d << "; e" << d << "++) {\n";
+        }
         o << ind << "    const uint32_t w" << d << " = acc.load(" << sc.word_off << "u + e" << d << " * " << (int)sc.wpe << "u);\n";
         o << ind << "    bool v" << d << " = (w" << d << " & 1u) != 0u;\n";
         if (b) {
@@ -282,7 +291,7 @@ std::string generate_plan_source(const HostPlan& plan) {
           return x.str();
         };
         o << ind << "{ const uint32_t wa = " << A.val_off << "u + e" << da << " * " << sa_ << "u, wb = " << B.val_off << "u + e" << db << " * " << sb_ << "u;\n"
-          << ind << "  b" << a << " = val_eq(acc.load(wa + " << la * 2u << "u), acc.load(wa + " << la * 2u + 1u << "u), " << nib(A, da, "wa", la)
+          << ind << "  b" << a << " = val_eq_quick(acc.load(wa + " << la * 2u << "u), acc.load(wa + " << la * 2u + 1u << "u), " << nib(A, da, "wa", la)
           << ", acc.load(wb + " << lb * 2u << "u), acc.load(wb + " << lb * 2u + 1u << "u), " << nib(B, db, "wb", lb) << ", heap); }\n";
         break;
       }

@@ -7,8 +7,10 @@
 
 #if defined(__HIPCC__)
 #define GK_HD __host__ __device__ inline
+#define GK_HD_COLD __host__ __device__ inline __attribute__((noinline))   // rare slow paths: keep them out of line
 #else
 #define GK_HD inline
+#define GK_HD_COLD inline
 #endif
 // The formula interpreter's control flow is wave-uniform by construction (same bytecode, same loop bounds for all 64
 // lanes).  GK_UNI makes that visible to the compiler so the program counter, the decoded instruction and the loop
@@ -336,7 +338,7 @@ GK_HD void eval_row_ent(const Row& r, uint32_t row_index, uint32_t ent, const St
 // value-slot equality (joins).  A slot holds the stored row's 64-bit payload plus a type nibble; two values are equal
 // iff they have the same Rego type and content.  Memory is touched only to confirm two DIFFERENT heap strings whose
 // hashes agree.
-GK_HD bool val_eq(uint32_t alo, uint32_t ahi, uint32_t an, uint32_t blo, uint32_t bhi, uint32_t bn, const uint8_t* heap) {
+GK_HD_COLD bool val_eq(uint32_t alo, uint32_t ahi, uint32_t an, uint32_t blo, uint32_t bhi, uint32_t bn, const uint8_t* heap) {
   if ((an & 7u) == 0u || (bn & 7u) == 0u) return false;
   uint32_t ta = (an & 7u) - 1u, tb = (bn & 7u) - 1u;
   if (type_rank(ta) != type_rank(tb)) return false;
@@ -363,6 +365,17 @@ GK_HD bool val_eq(uint32_t alo, uint32_t ahi, uint32_t an, uint32_t blo, uint32_
     }
     default: return false;   // composite joins are rejected by the compiler
   }
+}
+
+// The common cases of val_eq without control flow: identical type nibble and payload decide null / bool / int /
+// inline strings / the same heap entry.  Only float operands and distinct heap strings with equal hashes call val_eq.
+GK_HD bool val_eq_quick(uint32_t alo, uint32_t ahi, uint32_t an, uint32_t blo, uint32_t bhi, uint32_t bn, const uint8_t* heap) {
+  const uint32_t ta = an & 7u, tb = bn & 7u;   // type + 1
+  const bool same = (an == bn) & (alo == blo) & (ahi == bhi) & (ta != 0u);
+  const bool fl = ((ta == T_FLOAT + 1u) & ((tb == T_FLOAT + 1u) | (tb == T_INT + 1u))) | ((tb == T_FLOAT + 1u) & (ta == T_INT + 1u));
+  const bool hs = (an == T_STRING + 1u) & (bn == T_STRING + 1u) & (ahi == bhi) & (alo != blo);
+  if (fl | hs) return val_eq(alo, ahi, an, blo, bhi, bn, heap);
+  return same;
 }
 
 struct Results {
