@@ -26,7 +26,7 @@ std::string pred_literal(const Pred& p) {
 }  // namespace
 
 std::vector<uint32_t> jit_path_classes(const HostPlan& plan, std::vector<std::vector<Pred>>* classes) {
-  // distinct predicate lists -> class ids (1-based); ptab_class[path] = class id, 0 = no predicates
+  // distinct predicate lists -> class ids (1-based); entry[path] = class id | GK_ENT_NEEDS_STR, 0 = no predicates
   std::vector<uint32_t> out(plan.ptab.size(), 0);
   std::map<std::string, uint32_t> ids;
   classes->clear();
@@ -36,13 +36,16 @@ std::vector<uint32_t> jit_path_classes(const HostPlan& plan, std::vector<std::ve
     if (!ent) continue;
     uint32_t first = ent >> 8, cnt = ent & 0xFF;
     std::string key((const char*)&plan.path_preds[first], cnt * sizeof(Pred));
+    bool str = false;
+    for (uint32_t j = 0; j < cnt; j++) str = str || pred_needs_str(plan.path_preds[first + j]);
     auto it = ids.find(key);
+    uint32_t id;
     if (it == ids.end()) {
-      uint32_t id = (uint32_t)classes->size();
+      id = (uint32_t)classes->size();
       ids[key] = id;
       classes->emplace_back(plan.path_preds.begin() + first, plan.path_preds.begin() + first + cnt);
-      out[i] = id;
-    } else out[i] = it->second;
+    } else id = it->second;
+    out[i] = id | (str ? GK_ENT_NEEDS_STR : 0u);
   }
   return out;
 }
@@ -85,7 +88,7 @@ std::string generate_plan_source(const HostPlan& plan) {
   }
   // ---------------------------------------------------------------------------------------------- phase 1
   o << "template <class Acc>\nGK_HD __attribute__((noinline)) void jit_row(Row r, uint32_t cls, StrHdr h, const uint8_t* heap, Acc acc) {\n"
-    << "  const uint8_t* cheap = gk_plan_consts;\n  (void)cheap; (void)h;\n  cls = GK_UNI(cls);   // one class per call: the dispatch is a scalar branch\n  switch (cls) {\n";
+    << "  const uint8_t* cheap = gk_plan_consts;\n  (void)cheap; (void)h;\n  cls = GK_UNI(cls) & ~GK_ENT_NEEDS_STR;   // one class per call: the dispatch is a scalar branch\n  switch (cls) {\n";
   // One class = the predicates of one key path.  Results are gathered in one mask per destination word (a single LDS
   // atomic per word, not per predicate); integer comparisons share one type test; short string equalities compare
   // the packed payload; everything else goes through eval_pred with a constexpr predicate.

@@ -158,6 +158,7 @@ struct gk_table {
   std::vector<uint32_t> path_rows;          // rows per path: which rows a plan reads
   std::vector<uint32_t> path_max;           // per element path: largest array of one review
   bool resident = false;
+  std::vector<uint32_t> slot_path;          // path of each slot of the table's row-group index
   uint32_t n_reviews = 0;
 };
 
@@ -421,13 +422,16 @@ int gk_table_create(gk_engine* e, const gk_review_in* reviews, size_t n, uint32_
       return fail(GK_ERR_INVALID, "table too large for 32-bit row/heap offsets: split the batch");
     t->n_reviews = (uint32_t)n;
     t->n_rows = t->host.rows.size();
-    t->dir_bytes = t->host.segs.size() * sizeof(Seg) + t->host.tile_seg.size() * 4 + t->host.rflags.size() * 4;
+    t->dir_bytes = t->host.rflags.size() * 4;
+    t->slot_path = t->host.slot_path;
     t->path_rows = t->host.path_rows;
     t->path_max = t->host.path_max;
     t->resident = (flags & GK_TABLE_RESIDENT) || getenv("GK_SPECIALIZE_ALL");
     t->dev = dev_table_upload(t->host);
     t->host.rows.clear(); t->host.rows.shrink_to_fit();
     t->host.heap.clear(); t->host.heap.shrink_to_fit();
+    t->host.shdr.clear(); t->host.shdr.shrink_to_fit();
+    t->host.tile_idx.clear(); t->host.tile_idx.shrink_to_fit();
     *out = t.release();
     return GK_OK;
   } catch (const std::exception& ex) { return fail(GK_ERR_DEVICE, ex.what()); }
@@ -483,16 +487,24 @@ int gk_table_eval(gk_engine* e, gk_table* t, uint32_t flags, gk_eval_out** out) 
     p.d_viol = h->out.d_viol; p.d_err = h->out.d_err; p.d_counts = h->out.d_counts;
     p.n_rows = t->n_rows;
     p.lds_bytes = h->lds_bytes;
-    // algorithmic bytes: the rows of the segments whose path carries predicates + the segment
-    // directory + review flags, all read once; plan tables read once; bitmaps written once; 8 B per list entry
-    uint64_t rows_read = 0;
-    for (size_t pth = 0; pth < t->path_rows.size() && pth < e->fast.ptab.size(); pth++)
-      if (e->fast.ptab[pth]) rows_read += t->path_rows[pth];
+    // algorithmic bytes: rows of the segments whose path carries predicates (+ their string headers
+    // where a predicate reads string bytes) + two index words per bound path and tile + review flags, all read once;
+    // plan tables read once; bitmaps written once; 8 B per list entry
+    uint64_t rows_read = 0, hdrs_read = 0, bound = 0;
+    for (uint32_t pth : t->slot_path) {
+      if (pth >= e->fast.ptab.size() || !e->fast.ptab[pth]) continue;
+      bound++;
+      uint64_t n = pth < t->path_rows.size() ? t->path_rows[pth] : 0;
+      rows_read += n;
+      uint32_t ent = e->fast.ptab[pth];
+      bool str = false;
+      for (uint32_t j = 0; j < (ent & 0xFF); j++) str = str || pred_needs_str(e->fast.path_preds[(ent >> 8) + j]);
+      if (str) hdrs_read += n;
+    }
     p.n_rows_read = rows_read;
-    uint64_t plan_bytes = (uint64_t)e->fast.ptab.size() * 4 + e->fast.path_preds.size() * sizeof(Pred) +
-                          e->fast.code.size() * 4 + e->fast.cheap.size();
-    p.algo_bytes = rows_read * sizeof(Row) + t->dir_bytes + plan_bytes + (uint64_t)p.n_constraints * p.n_tiles * 16 +
-                   (uint64_t)p.list_total * 8;
+    uint64_t plan_bytes = (uint64_t)e->fast.path_preds.size() * sizeof(Pred) + e->fast.code.size() * 4 + e->fast.cheap.size() + bound * sizeof(Bind);
+    p.algo_bytes = rows_read * sizeof(Row) + hdrs_read * sizeof(StrHdr) + bound * 8 * p.n_tiles + t->dir_bytes + plan_bytes +
+                   (uint64_t)p.n_constraints * p.n_tiles * 16 + (uint64_t)p.list_total * 8;
     *out = &h.release()->pub;
     return GK_OK;
   } catch (const Unsupported& ex) { return fail(GK_ERR_UNSUPPORTED, ex.what());

@@ -190,7 +190,7 @@ Flattener::Flattener(PathDict* dict) : dict_(dict) {
 }
 
 void Flattener::emit(uint32_t path, uint32_t meta, uint32_t lo, uint32_t hi) {
-  stage_.push_back({path, Row{t_->n_reviews % GK_TILE, meta, lo, hi}});
+  stage_.push_back({path, Row{t_->n_reviews % GK_TILE, meta, lo, hi}, StrHdr{{0, 0, 0, 0}}});
 }
 
 uint32_t Flattener::put_string(const std::string& s, uint32_t* hash) {
@@ -214,6 +214,7 @@ void Flattener::emit_string_row(uint32_t path, uint32_t meta, const std::string&
   }
   uint32_t hsh, off = put_string(s, &hsh);
   emit(path, meta | T_STRING, off, hsh);
+  memcpy(&stage_.back().hdr, &t_->heap[off - 4], 16);   // entry header: length + first 12 bytes
 }
 
 void Flattener::emit_str(uint32_t parent, const char* key, const std::string& s) { emit_string_row(dict_->child(parent, key), 0, s); }
@@ -358,6 +359,7 @@ void Flattener::flush_tile(HostTable* out) {
     if (s.path >= out->path_rows.size()) out->path_rows.resize(s.path + 1, 0);
     out->path_rows[s.path]++;
     out->rows.push_back(s.row);
+    out->shdr.push_back(s.hdr);
   }
   stage_.clear();
 }
@@ -365,7 +367,28 @@ void Flattener::flush_tile(HostTable* out) {
 void Flattener::finish(HostTable* out) {
   if (!stage_.empty() || out->n_reviews % GK_TILE != 0) flush_tile(out);
   out->tile_seg.push_back((uint32_t)out->segs.size());
-  out->segs.push_back({PathDict::kNone, (uint32_t)out->rows.size()});
+  // slots = distinct paths of the table in path-id order; dense index [tile][slot] of first rows
+  std::vector<uint32_t> paths;
+  for (const auto& s : out->segs) paths.push_back(s.path);
+  std::sort(paths.begin(), paths.end());
+  paths.erase(std::unique(paths.begin(), paths.end()), paths.end());
+  out->slot_path = paths;
+  const uint32_t S = (uint32_t)paths.size(), T = out->n_tiles();
+  out->tile_idx.assign((size_t)T * (S + 1), 0);
+  for (uint32_t t = 0; t < T; t++) {
+    uint32_t* ix = &out->tile_idx[(size_t)t * (S + 1)];
+    const uint32_t s0 = out->tile_seg[t], s1 = out->tile_seg[t + 1];
+    const uint32_t tile_end = s1 < out->segs.size() ? out->segs[s1].start : (uint32_t)out->rows.size();
+    uint32_t k = s1;            // walk the tile's segments from the right; absent slots start where the next present one does
+    uint32_t next = tile_end;
+    for (uint32_t s = S; s-- > 0;) {
+      if (k > s0 && out->segs[k - 1].path == paths[s]) { k--; next = out->segs[k].start; }
+      ix[s] = next;
+    }
+    ix[S] = tile_end;
+  }
+  out->segs.clear(); out->segs.shrink_to_fit();
+  out->tile_seg.clear();
 }
 
 }  // namespace gk

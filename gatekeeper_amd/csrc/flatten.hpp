@@ -83,13 +83,20 @@ bool obj_is_namespace(const Value& obj);
 
 struct HostTable {
   std::vector<Row> rows;            // row groups: per tile, sorted by path (plan.hpp)
-  std::vector<Seg> segs;            // directory entries of all tiles + closing sentinel
-  std::vector<uint32_t> tile_seg;   // n_tiles + 1
+  std::vector<StrHdr> shdr;         // parallel to rows
+  std::vector<uint32_t> tile_idx;   // [n_tiles][n_slots + 1]
+  std::vector<uint32_t> slot_path;  // [n_slots] path id of each slot, increasing
   std::vector<uint32_t> rflags;     // n_reviews
   std::vector<uint8_t> heap;
   std::vector<uint32_t> path_rows;  // rows per path over the whole table (algorithmic-byte accounting per plan)
   std::vector<uint32_t> path_max;   // per array-element path: largest element count of one review (plan specialisation)
   uint32_t n_reviews = 0;
+  uint32_t n_tiles() const { return (n_reviews + GK_TILE - 1) / GK_TILE; }
+  uint32_t n_slots() const { return (uint32_t)slot_path.size(); }
+  // build-time only: per-tile segment lists, turned into tile_idx by Flattener::finish
+  struct SegRec { uint32_t path, start; };
+  std::vector<SegRec> segs;
+  std::vector<uint32_t> tile_seg;
 };
 
 class Flattener {
@@ -105,7 +112,7 @@ class Flattener {
   std::vector<Ctr> ctrs_;
   HostTable* t_ = nullptr;
   uint32_t review_flags_ = 0;
-  struct Staged { uint32_t path; Row row; };
+  struct Staged { uint32_t path; Row row; StrHdr hdr; };
   std::vector<Staged> stage_;       // rows of the tile being built, review order / document order
   std::vector<uint32_t> order_;
   void flush_tile(HostTable* out);

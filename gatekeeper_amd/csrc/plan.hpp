@@ -13,9 +13,19 @@ namespace gk {
 // ------------------------------------------------------------------------------------------------ rows
 // One row per JSON node (scalars AND containers) of the review documents.  The table is stored as ROW GROUPS: reviews
 // are grouped in tiles of GK_TILE consecutive reviews, and within a tile the rows are sorted by key path (stable:
-// review order, then document order).  The rows of one (tile, path) pair form a SEGMENT, listed in the tile's segment
-// directory.  A plan touches only the segments of the paths it has predicates on -- typically a fifth of a Pod's rows
-// -- and every row of a segment takes the same predicates, so a wave evaluates them without divergence.
+// review order, then document order).  The rows of one (tile, path) pair form a SEGMENT.  A plan touches only the
+// segments of the paths it has predicates on -- typically a fifth of a Pod's rows -- and every row of a segment takes
+// the same predicates, so a wave evaluates them without divergence.
+//
+// Table arrays (HostTable / DevTable):
+//   rows[n_rows]                 16 B each, see Row
+//   shdr[n_rows]                 16 B each, parallel to rows: for heap strings the entry header [u32 len][first 12
+//                                bytes], so string predicates get their operand with the same index as the row (no
+//                                dependent heap access unless the string is longer than 12 bytes); zero otherwise
+//   tile_idx[n_tiles][S + 1]     first row of slot s in tile t; slots = the table's distinct key paths in path-id order
+//                                (= row order inside a tile), so slot s of tile t is [idx[t][s], idx[t][s+1])
+//   rflags[n_reviews]            RF_*: match-layer facts computed once by the flattener
+//   heap                         string bytes, 16-byte aligned zero-padded entries [u32 len][bytes]
 struct Row {
   uint32_t rev;    // review index within its tile (0 .. GK_TILE-1)
   uint32_t meta;   // see ROW_* below
@@ -24,11 +34,14 @@ struct Row {
 };
 static_assert(sizeof(Row) == 16, "Row must be 16 bytes");
 
-struct Seg {
-  uint32_t path;    // interned wildcarded key-path id (array indices erased); collision-free (PathDict)
-  uint32_t start;   // first row; the segment ends where the next directory entry starts (a sentinel closes the table)
+struct StrHdr { uint32_t w[4]; };   // [len][bytes 0..11] of a heap string
+static_assert(sizeof(StrHdr) == 16, "StrHdr must be 16 bytes");
+
+// One plan path bound to a table: which slot holds its rows and which predicate list (path-table entry) they take.
+struct Bind {
+  uint32_t slot;
+  uint32_t ent;
 };
-static_assert(sizeof(Seg) == 8, "Seg must be 8 bytes");
 
 enum RowType : uint32_t { T_NULL = 0, T_BOOL = 1, T_INT = 2, T_FLOAT = 3, T_STRING = 4, T_OBJECT = 5, T_ARRAY = 6 };
 
@@ -47,10 +60,6 @@ constexpr uint32_t ROW_STR_INLINE = 1u << 31;    // string of <= 7 bytes packed 
 //                 string (longer): lo = byte offset in the table heap of a 16-byte aligned entry [u32 len][bytes][pad]
 //                                  (so off-4 is 16-byte aligned), hi = hash32(bytes)
 //                 object/array: lo = member count
-
-// Table arrays: rows[n_rows], segs[n_segs + 1] (directory entries of all tiles + sentinel), tile_seg[n_tiles + 1]
-// (first directory entry of each tile), rflags[n_reviews] (RF_*: match-layer facts computed once by the flattener),
-// string heap.
 
 enum ReviewFlag : uint32_t {
   RF_HAS_OBJ = 1u << 0,          // request.object present (after setObjectOnDelete, pkg/target/target.go:269-287)
@@ -151,7 +160,8 @@ constexpr int GK_TILE = 64;            // reviews per tile (one lane per review 
 constexpr int GK_BLOCK = 256;          // threads per tile in the dominant kernel: 4 waves stream the tile's rows
 constexpr int GK_MAX_RES = 64;         // unique formulas per result class per pass
 constexpr int GK_MAX_SCOPES = 32;
-constexpr int GK_MAX_CHUNKS = 256;      // 64-row chunks of predicate-bearing segments per tile held in LDS; beyond: the tile's reviews take the big path
+constexpr int GK_WAVE_CHUNKS = 64;      // 64-row chunks one wave queues per tile (LDS); beyond: the tile's reviews take the big path
+constexpr uint32_t GK_ENT_NEEDS_STR = 0x80000000u;   // class entry flag (plan-specialised build): some predicate reads string bytes
 
 struct PlanDims {
   uint32_t n_paths;       // entries in ptab

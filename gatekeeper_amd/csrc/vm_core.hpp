@@ -54,7 +54,6 @@ GK_HD double row_f64(const Row& r) { return bits_f64(((uint64_t)r.hi << 32) | r.
 // [u32 len][bytes][pad], hi = hash32.  The 16-byte entry header (length + first 12 bytes) is fetched with ONE aligned
 // load, convergently for all lanes of a wave BEFORE the divergent predicate dispatch (kernel_body.inc), so most
 // predicates are decided without a dependent memory access inside a divergent branch.
-struct StrHdr { uint32_t w[4]; };
 
 GK_HD bool row_needs_hdr(const Row& r) { return (r.meta & ROW_TYPE_MASK) == T_STRING && !(r.meta & ROW_STR_INLINE); }
 GK_HD StrHdr load_hdr(const Row& r, const uint8_t* heap) {
@@ -269,6 +268,16 @@ GK_HD bool eval_pred(const Row& r, const Pred& p, const StrHdr& h, const uint8_t
       int64_t b = (int64_t)p.k;
       return cmp_test(a < b ? -1 : (a > b ? 1 : 0), p.cmp);
     }
+    default: return false;
+  }
+}
+
+// does the predicate read the bytes of a string row (so heap strings need their header)?
+GK_HD bool pred_needs_str(const Pred& p) {
+  switch (p.op) {
+    case P_CMP: return p.ctype == T_STRING;
+    case P_STR_PREFIX: case P_STR_SUFFIX: case P_STR_CONTAINS: case P_STR_IN_SET:
+    case P_SPLIT_CMP: case P_SPLIT_COUNT: case P_SPLIT_PREFIX: return true;
     default: return false;
   }
 }

@@ -43,7 +43,7 @@ std::string dev_init(int) { return ""; }
 int dev_count() { return 0; }
 DevTable* dev_table_upload(const HostTable& t) { DevTable* d = new DevTable(); d->t = t; d->t.heap.resize(d->t.heap.size() + 16, 0); return d; }
 void dev_table_free(DevTable* t) { delete t; }
-uint64_t dev_table_bytes(const DevTable* t) { return t->t.rows.size() * 16 + t->t.heap.size(); }
+uint64_t dev_table_bytes(const DevTable* t) { return t->t.rows.size() * 32 + t->t.tile_idx.size() * 4 + t->t.heap.size(); }
 DevPlan* dev_plan_upload(const HostPlan& fast, const HostPlan& big) {
   DevPlan* p = new DevPlan();
   p->fast = fast; p->big = big;
@@ -87,15 +87,19 @@ static bool eval_review(const HostPlan& hp, const HostTable& t, uint32_t r, Resu
   std::vector<uint32_t> words(hp.dims.acc_words, 0);
   VecAcc acc{&words};
   const uint32_t tile = r / GK_TILE, rl = r % GK_TILE;
-  for (uint32_t s = t.tile_seg[tile]; s < t.tile_seg[tile + 1]; s++) {
-    const uint32_t path = t.segs[s].path;
+  const uint32_t S = t.n_slots();
+  const uint32_t* ix = &t.tile_idx[(size_t)tile * (S + 1)];
+  for (uint32_t s = 0; s < S; s++) {
+    const uint32_t path = t.slot_path[s];
     if (path >= pv.dims.n_paths || pv.ptab[path] == 0) continue;
-    for (uint32_t i = t.segs[s].start; i < t.segs[s + 1].start; i++) {
+    for (uint32_t i = ix[s]; i < ix[s + 1]; i++) {
       if (t.rows[i].rev != rl) continue;
       if (jit) {
         uint32_t c = path < jit->cls.size() ? jit->cls[path] : 0;
-        if (c) { StrHdr h = {{0, 0, 0, 0}}; if (row_needs_hdr(t.rows[i])) h = load_hdr(t.rows[i], t.heap.data()); jit->row(&t.rows[i], i, c, &h, &pv, t.heap.data(), &words); }
-      } else eval_row(t.rows[i], path, i, pv, t.heap.data(), acc);
+        // like the device: the string header is only fetched for classes flagged as reading string bytes
+        StrHdr h = (c & GK_ENT_NEEDS_STR) ? t.shdr[i] : StrHdr{{0, 0, 0, 0}};
+        if (c) jit->row(&t.rows[i], i, c, &h, &pv, t.heap.data(), &words);
+      } else eval_row_ent(t.rows[i], i, pv.ptab[path], t.shdr[i], pv, t.heap.data(), acc);
     }
   }
   if (words[0] & 1u) return false;   // overflow
