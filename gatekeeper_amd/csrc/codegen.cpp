@@ -6,6 +6,7 @@
 #include "codegen.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <sstream>
@@ -253,7 +254,8 @@ std::string generate_plan_source(const HostPlan& plan) {
         // they contribute nothing, and the compiler can issue all LDS reads of the nest at once
         uint64_t nest = sc.cap;
         for (const Loop& l : stack) nest *= plan.scopes[l.scope].cap;
-        if (sc.cap <= 16 && nest <= 64) {
+        static const uint64_t unroll_max = getenv("GK_UNROLL_MAX") ? (uint64_t)atoi(getenv("GK_UNROLL_MAX")) : 4;   // tuning aid
+        if (sc.cap <= 16 && nest <= unroll_max) {
           o << ind << "{ _Pragma(\"unroll\")\n";
           o << ind << "  for (uint32_t e" << d << " = 0; e" << d << " < " << sc.cap << "u; e" << d << "++) {\n";
         } else {
