@@ -130,9 +130,9 @@ std::string go_sprintf(const std::string& fmt, const ValueVec& argv) {
 }
 
 namespace {
-
 std::mutex g_re_mu;
 std::unordered_map<std::string, std::shared_ptr<Regex>> g_re_cache;
+}  // namespace
 
 std::shared_ptr<Regex> get_regex(const std::string& pat) {
   std::lock_guard<std::mutex> l(g_re_mu);
@@ -143,6 +143,8 @@ std::shared_ptr<Regex> get_regex(const std::string& pat) {
   g_re_cache[pat] = r;
   return r;
 }
+
+namespace {
 
 // utf-8 helpers: strings are byte strings; Rego's count/substring work on code points
 size_t rune_count(const std::string& s) {

@@ -1,5 +1,6 @@
 // Concrete Rego builtins (see builtins.cpp).
 #pragma once
+#include <memory>
 #include <string>
 
 #include "value.hpp"
@@ -9,4 +10,6 @@ bool has_builtin(const std::string& name);
 Value call_builtin(const std::string& name, const ValueVec& args);        // Undefined on error / unknown
 Value rego_arith(const std::string& op, const Value& a, const Value& b);  // + - * / % & | (numbers and sets)
 std::string go_sprintf(const std::string& fmt, const ValueVec& args);
+class Regex;
+std::shared_ptr<Regex> get_regex(const std::string& pat);   // compiled-pattern cache; nullptr for an invalid pattern
 }  // namespace gk

@@ -1,6 +1,8 @@
 // See lower.hpp.
 #include "lower.hpp"
 
+#include "builtins.hpp"
+#include "regex.hpp"
 #include "vm_core.hpp"
 
 #include <functional>
@@ -517,6 +519,15 @@ struct Lowerer {
         }
         break;
       }
+      case Atom::STR_REGEX: {
+        auto re = get_regex(a.k.str());
+        std::vector<uint8_t> table;
+        if (!re || !re->to_dfa(&table)) unsupported("regular expression needs more than 255 DFA states: " + a.k.str());
+        p.op = P_REGEX;
+        p.a = put_bytes(std::string(table.begin(), table.end()));
+        p.b = (uint32_t)table.size();
+        break;
+      }
       case Atom::SPLIT_CMP:
         p.op = P_SPLIT_CMP; put_const_string(a.k); p.idx = a.idx; p.pad = ((uint32_t)(uint8_t)a.cut << 8) | (uint8_t)a.sep;
         break;
@@ -654,6 +665,31 @@ struct Lowerer {
     return false;
   }
 
+  // f with quantifier q replaced by the constant member name `key`
+  static FP pin_key(const FP& f, int q, const std::string& key) {
+    auto pin_path = [&](SPath p) { for (auto& s : p) if (s.iter && s.q == q) { s.iter = false; s.q = -1; s.key = key; } return p; };
+    switch (f->kind) {
+      case FNode::T: case FNode::F: return f;
+      case FNode::ATOM: {
+        Atom a = f->atom;
+        if (a.kind == Atom::KEYCMP && a.q == q) {
+          if (!a.k.is_string()) return a.cmp == C_NE ? f_true() : f_false();
+          int c = key.compare(a.k.str());
+          bool r = a.cmp == C_EQ ? c == 0 : a.cmp == C_NE ? c != 0 : a.cmp == C_LT ? c < 0 : a.cmp == C_LE ? c <= 0 : a.cmp == C_GT ? c > 0 : c >= 0;
+          return r ? f_true() : f_false();
+        }
+        a.path = pin_path(a.path);
+        a.path2 = pin_path(a.path2);
+        return f_atom(a);
+      }
+      case FNode::NOT: return f_not(pin_key(f->kids[0], q, key));
+      case FNode::AND: { FP r = f_true(); for (auto& k : f->kids) r = f_and(r, pin_key(k, q, key)); return r; }
+      case FNode::OR: { FP r = f_false(); for (auto& k : f->kids) r = f_or(r, pin_key(k, q, key)); return r; }
+      case FNode::EXISTS: return f_exists(f->q, pin_path(f->base), pin_key(f->kids[0], q, key));
+    }
+    return f;
+  }
+
   // EXISTS chain that reduces to one wildcard predicate
   bool try_flat(const FP& f, std::vector<std::pair<int, PatStep>>& wilds, Atom* out) {
     int q = f->q;
@@ -721,6 +757,25 @@ struct Lowerer {
     }
     std::vector<FP> conj;
     conjuncts(f->kids[0], conj);
+    {
+      // key pinned to constants:  exists k. (k == "a" | k == "b") & body(base[k])   ==   OR_c  defined(base.c) & body(base.c)
+      PatStep ps;
+      std::vector<FP> rest;
+      for (auto& c : conj) if (!key_constraint(c, q, &ps)) rest.push_back(c);
+      if (!ps.only.empty() && ps.except.empty()) {
+        FP any = f_false();
+        for (const std::string& key : ps.only) {
+          SPath member = f->base;
+          Step st; st.key = key;
+          member.push_back(st);
+          Atom d; d.kind = Atom::DEFINED; d.path = member;
+          FP body = f_atom(d);
+          for (auto& c : rest) body = f_and(body, pin_key(c, q, key));
+          any = f_or(any, body);
+        }
+        return lower(simplify(any));
+      }
+    }
     for (auto& c : conj) { PatStep tmp; if (key_constraint(c, q, &tmp)) unsupported("correlated iteration over object keys"); }
     // pass-through: exists q. exists q2 in (.. q ..). body   with nothing else tied to q's element
     if (conj.size() == 1 && conj[0]->kind == FNode::EXISTS && path_has_q(conj[0]->base, q) && !uses_elem_directly(conj[0]->kids[0], q)) {

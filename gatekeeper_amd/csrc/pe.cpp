@@ -6,6 +6,7 @@
 #include <sstream>
 
 #include "builtins.hpp"
+#include "regex.hpp"
 #include "plan.hpp"
 
 namespace gk {
@@ -79,6 +80,7 @@ std::string f_to_string(const FP& f) {
         case Atom::STR_SUFFIX: return "suffix(" + p + "," + to_term_string(a.k) + ")";
         case Atom::STR_CONTAINS: return "contains(" + p + "," + to_term_string(a.k) + ")";
         case Atom::STR_IN_SET: return p + " in " + to_term_string(a.k);
+        case Atom::STR_REGEX: return "re_match(" + to_term_string(a.k) + "," + p + ")";
         case Atom::SPLIT_CMP: return "split(" + p + ")[" + std::to_string(a.idx) + "] " + cmpn[a.cmp] + " " + to_term_string(a.k);
         case Atom::SPLIT_COUNT: return "count(split(" + p + ")) " + cmpn[a.cmp] + " " + to_term_string(a.k);
         case Atom::COUNT_CMP: return "count(" + p + ") " + cmpn[a.cmp] + " " + to_term_string(a.k);
@@ -1227,6 +1229,19 @@ class PE {
         Atom at = atom_path(name == "startswith" ? Atom::STR_PREFIX : name == "endswith" ? Atom::STR_SUFFIX : Atom::STR_CONTAINS, a[0]->path);
         at.k = a[1]->c;
         push_bool(f_atom(at), f_type(a[0]->path, M_STRING));
+        return;
+      }
+      unsupported(name + " with these symbolic operands", line);
+    }
+    if (name == "re_match" || name == "regex.match") {
+      need(2);
+      // constant pattern, review string: a DFA predicate on the device.  An invalid pattern or a non-string operand is a
+      // builtin error, i.e. the expression is undefined (b_re_match in builtins.cpp mirrors this for concrete values).
+      if (a[0]->kind == SV::CONST && a[1]->kind == SV::PATH) {
+        if (!a[0]->c.is_string() || !get_regex(a[0]->c.str())) return;
+        Atom at = atom_path(Atom::STR_REGEX, a[1]->path);
+        at.k = a[0]->c;
+        push_bool(f_atom(at), f_type(a[1]->path, M_STRING));
         return;
       }
       unsupported(name + " with these symbolic operands", line);

@@ -29,7 +29,7 @@ struct Step {
 typedef std::vector<Step> SPath;   // rooted at input.review
 
 struct Atom {
-  enum Kind { DEFINED, TRUTHY, CMP, TYPE, STR_PREFIX, STR_SUFFIX, STR_CONTAINS, STR_IN_SET, SPLIT_CMP, SPLIT_COUNT,
+  enum Kind { DEFINED, TRUTHY, CMP, TYPE, STR_PREFIX, STR_SUFFIX, STR_CONTAINS, STR_IN_SET, STR_REGEX, SPLIT_CMP, SPLIT_COUNT,
               COUNT_CMP, FLAG, VEQ, KEYCMP, SPLIT_PREFIX } kind = DEFINED;
   SPath path;
   int cmp = 0;          // CmpOp

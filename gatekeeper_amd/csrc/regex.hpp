@@ -3,7 +3,10 @@
 // in-tree templates use: literals, '.', classes (ranges, negation, \d \w \s, [[:alpha:]]), ^ $ anchors, groups,
 // alternation, * + ? {m,n} (greedy/lazy are equivalent for matching).  Byte-oriented.
 #pragma once
+#include <algorithm>
 #include <bitset>
+#include <cstdint>
+#include <map>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -48,6 +51,89 @@ class Regex {
       if (pos >= n) return false;
       carried.swap(nxt);
     }
+  }
+
+  // The same search as a byte-class DFA for the device (P_REGEX, vm_core.hpp):
+  //   table = [u32 n_states][u32 n_classes][u8 class_of_byte[256]][u8 accept_at_end[n_states]][u8 next[n_states][n_classes]]
+  // state 0 = start of input; an early match moves to an absorbing accepting state.  A state is the set of threads
+  // carried over from the previous byte plus "still at position 0" (for ^); `accept_at_end` applies $ at the end.
+  // Returns false when the automaton needs more than `max_states` states (the caller reports "unsupported").
+  bool to_dfa(std::vector<uint8_t>* table, size_t max_states = 255) const {
+    // byte equivalence classes
+    std::vector<int> cls(256, 0);
+    int ncls = 1;
+    auto refine = [&](const std::bitset<256>& bs) {
+      std::map<std::pair<int, bool>, int> remap;
+      for (int b = 0; b < 256; b++) {
+        auto key = std::make_pair(cls[b], (bool)bs[b]);
+        auto it = remap.find(key);
+        if (it == remap.end()) it = remap.emplace(key, (int)remap.size()).first;
+        cls[b] = it->second;
+      }
+      ncls = (int)remap.size();
+    };
+    for (const Inst& in : prog_) {
+      std::bitset<256> bs;
+      if (in.op == CHAR) bs.set(in.c);
+      else if (in.op == ANY) { bs.set(); bs.reset('\n'); }
+      else if (in.op == CLASS) bs = classes_[in.x];
+      else continue;
+      refine(bs);
+    }
+    if (ncls > 255) return false;
+    std::vector<int> rep(ncls, -1);
+    for (int b = 0; b < 256; b++) if (rep[cls[b]] < 0) rep[cls[b]] = b;
+    typedef std::pair<std::vector<int>, bool> Key;   // carried threads (sorted), at position 0
+    std::map<Key, int> ids;
+    std::vector<Key> states;
+    auto intern = [&](const Key& k) { auto it = ids.find(k); if (it != ids.end()) return it->second; ids[k] = (int)states.size(); states.push_back(k); return (int)states.size() - 1; };
+    auto closure = [&](const Key& k, bool at_end, std::vector<int>* cur) {
+      std::vector<uint32_t> mark(prog_.size(), 0);
+      cur->clear();
+      size_t pos = k.second ? 0 : 1, n = at_end ? pos : pos + 1;
+      for (int pc : k.first) add(*cur, pc, pos, n, mark, 1);
+      add(*cur, start_, pos, n, mark, 1);
+    };
+    auto has_match = [&](const std::vector<int>& cur) { for (int pc : cur) if (prog_[pc].op == MATCH) return true; return false; };
+    intern(Key{{}, true});
+    const int ACCEPT = -2;
+    std::vector<std::vector<int>> next;
+    std::vector<uint8_t> accept;
+    std::vector<int> cur;
+    for (size_t s = 0; s < states.size(); s++) {
+      if (states.size() > max_states) return false;
+      Key k = states[s];
+      closure(k, true, &cur);
+      accept.push_back(has_match(cur) ? 1 : 0);
+      closure(k, false, &cur);
+      std::vector<int> row(ncls, 0);
+      if (has_match(cur)) { std::fill(row.begin(), row.end(), ACCEPT); next.push_back(row); continue; }
+      for (int c = 0; c < ncls; c++) {
+        unsigned char b = (unsigned char)rep[c];
+        std::vector<int> nxt;
+        for (int pc : cur) {
+          const Inst& in = prog_[pc];
+          bool ok = (in.op == CHAR && b == in.c) || (in.op == ANY && b != '\n') || (in.op == CLASS && classes_[in.x][b]);
+          if (ok) nxt.push_back(pc + 1);
+        }
+        std::sort(nxt.begin(), nxt.end());
+        nxt.erase(std::unique(nxt.begin(), nxt.end()), nxt.end());
+        row[c] = intern(Key{nxt, false});
+      }
+      next.push_back(row);
+    }
+    if (states.size() + 1 > max_states) return false;
+    const int acc_id = (int)states.size();   // absorbing accepting state
+    const uint32_t ns = (uint32_t)states.size() + 1, nc = (uint32_t)ncls;
+    table->clear();
+    auto put32 = [&](uint32_t v) { for (int k = 0; k < 4; k++) table->push_back((uint8_t)(v >> (8 * k))); };
+    put32(ns); put32(nc);
+    for (int b = 0; b < 256; b++) table->push_back((uint8_t)cls[b]);
+    for (uint8_t a : accept) table->push_back(a);
+    table->push_back(1);
+    for (auto& row : next) for (int t : row) table->push_back((uint8_t)(t == ACCEPT ? acc_id : t));
+    for (uint32_t c = 0; c < nc; c++) table->push_back((uint8_t)acc_id);
+    return true;
   }
 
  private:

@@ -261,6 +261,19 @@ GK_HD bool eval_pred(const Row& r, const Pred& p, const StrHdr& h, const uint8_t
       if (p.cmp == C_EQ || p.cmp == C_NE) { bool eq = len == p.b && str_at_c(s, off, cheap + p.a, len); return (p.cmp == C_EQ) == eq; }
       return cmp_test(str_cmp_c(s, off, len, cheap + p.a, p.b), p.cmp);
     }
+    case P_REGEX: {
+      // DFA table at cheap + p.a: [u32 n_states][u32 n_classes][u8 class_of_byte[256]][u8 accept[n_states]][u8 next[][]]
+      if (t != T_STRING) return false;
+      StrRef s = make_str(r, h, heap);
+      const uint8_t* d = cheap + p.a;
+      const uint32_t ns = ld32(d), nc = ld32(d + 4);
+      const uint8_t* cls = d + 8;
+      const uint8_t* acc = cls + 256;
+      const uint8_t* nxt = acc + ns;
+      uint32_t st = 0;
+      for (uint32_t i = 0; i < s.n; i++) st = nxt[st * nc + cls[sbyte(s, i)]];
+      return acc[st] != 0;
+    }
     case P_COUNT_CMP: {
       int64_t a;
       if (t == T_OBJECT || t == T_ARRAY) a = r.lo;
@@ -277,7 +290,7 @@ GK_HD bool pred_needs_str(const Pred& p) {
   switch (p.op) {
     case P_CMP: return p.ctype == T_STRING;
     case P_STR_PREFIX: case P_STR_SUFFIX: case P_STR_CONTAINS: case P_STR_IN_SET:
-    case P_SPLIT_CMP: case P_SPLIT_COUNT: case P_SPLIT_PREFIX: return true;
+    case P_SPLIT_CMP: case P_SPLIT_COUNT: case P_SPLIT_PREFIX: case P_REGEX: return true;
     default: return false;
   }
 }

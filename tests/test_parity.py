@@ -185,7 +185,50 @@ def test_template_families(backend, fixtures):
         supported += 1
         rv = [D.AugmentedUnstructured(D.Unstructured(o), None, "Original") for o in objs + pods]
         assert_parity(c, oc, rv)
-    assert supported >= 2   # allowedrepos, requiredprobes (regex / quantity parsing: see DESIGN.md "unsupported")
+    assert supported >= 3   # requiredlabels (allowedRegex), allowedrepos, requiredprobes; containerlimits needs quantity arithmetic
+
+
+REGEX_TEMPLATE = {
+    "apiVersion": "templates.gatekeeper.sh/v1", "kind": "ConstraintTemplate", "metadata": {"name": "k8slabelregex"},
+    "spec": {"crd": {"spec": {"names": {"kind": "K8sLabelRegex"}}},
+             "targets": [{"target": "admission.k8s.gatekeeper.sh", "rego": """
+package k8slabelregex
+violation[{"msg": msg}] {
+  value := input.review.object.metadata.labels[key]
+  expected := input.parameters.labels[_]
+  expected.key == key
+  expected.allowedRegex != ""
+  not re_match(expected.allowedRegex, value)
+  msg := sprintf("Label <%v: %v> does not satisfy allowed regex: %v", [key, value, expected.allowedRegex])
+}
+violation[{"msg": msg}] {
+  re_match(input.parameters.nameRegex, input.review.object.metadata.name)
+  msg := sprintf("name %v matches %v", [input.review.object.metadata.name, input.parameters.nameRegex])
+}
+"""}]}}
+
+REGEXES = ["^[a-zA-Z]+.agilebank.demo$", "^team-[0-9]+$", "prod|dev", "^(a|b)*c$", "[[:digit:]]{2,3}", "^$", "a.c", "^x?y+z*$",
+           "\\d+\\.\\d+", "(foo|bar)baz$", "^[^0-9]*$", ".", "^web-[a-f0-9]{4,}-(blue|green)$", "(", "kube-system-extended-name-[0-9]+"]
+REGEX_VALUES = ["", "a", "abc", "axc", "team-7", "team-", "xteam-12x", "prod", "devops", "aabbc", "abab", "42", "1234", "1.5", "v1.25.3",
+                "foobaz", "barbazz", "xyz", "yyzz", "y", "user.agilebank.demo", "user1.agilebank.demo", "web-0a1f-blue", "web-0a1-green",
+                "web-deadbeef-green-canary", "kube-system-extended-name-0042", "a\nc", "long-label-value-that-goes-well-beyond-twelve-bytes-77"]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_regex_predicates(backend):
+    """re_match(constant pattern, review string) compiles to a DFA predicate: differential test against the oracle over
+    anchors, classes, alternation, repetition, an invalid pattern (undefined), inline and heap strings."""
+    cons = [{"apiVersion": "constraints.gatekeeper.sh/v1beta1", "kind": "K8sLabelRegex", "metadata": {"name": "re-%d" % i},
+             "spec": {"parameters": {"labels": [{"key": "owner", "allowedRegex": rx}, {"key": "tier", "allowedRegex": REGEXES[(i + 3) % len(REGEXES)]}],
+                                     "nameRegex": REGEXES[(i + 7) % len(REGEXES)]}}}
+            for i, rx in enumerate(REGEXES)]
+    c, oc = load_both(backend, [REGEX_TEMPLATE], cons)
+    objs = [{"apiVersion": "v1", "kind": "Pod", "metadata": {"name": REGEX_VALUES[(i * 5 + 2) % len(REGEX_VALUES)] or "x", "namespace": "default",
+                                                           "labels": {"owner": v, "tier": REGEX_VALUES[(i * 3 + 1) % len(REGEX_VALUES)]}}}
+            for i, v in enumerate(REGEX_VALUES)]
+    objs.append({"apiVersion": "v1", "kind": "Pod", "metadata": {"name": "nolabels", "namespace": "default"}})
+    objs.append({"apiVersion": "v1", "kind": "Pod", "metadata": {"name": "numlabel", "namespace": "default", "labels": {"owner": 5}}})
+    assert_parity(c, oc, [D.AugmentedUnstructured(D.Unstructured(o), None, "Original") for o in objs])
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
