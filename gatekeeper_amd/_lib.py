@@ -28,7 +28,7 @@ GK_EVAL_WANT_MATCH, GK_EVAL_NO_DOWNLOAD, GK_EVAL_WANT_LIST, GK_EVAL_ASYNC, GK_EV
 EXPORTS = [
     "gk_engine_create", "gk_engine_destroy", "gk_last_error", "gk_version", "gk_template_add", "gk_template_remove",
     "gk_constraint_add", "gk_constraint_remove", "gk_data_put", "gk_data_remove", "gk_table_create", "gk_table_free",
-    "gk_table_eval", "gk_eval_free", "gk_render", "gk_render_error", "gk_free", "gk_dump",
+    "gk_table_eval", "gk_eval_free", "gk_render", "gk_render_error", "gk_free", "gk_dump", "gk_table_topk", "gk_topk_free",
 ]
 
 
@@ -53,6 +53,11 @@ class gk_eval_out(C.Structure):
                 ("kernel_ms", C.c_float), ("fast_kernel_ms", C.c_float),
                 ("algo_bytes", C.c_uint64), ("n_rows", C.c_uint64), ("n_launches", C.c_uint32), ("lds_bytes", C.c_uint32),
                 ("d_viol", C.c_void_p), ("d_err", C.c_void_p), ("d_counts", C.c_void_p), ("n_rows_read", C.c_uint64)]
+
+
+class gk_topk_out(C.Structure):
+    _fields_ = [("n_constraints", C.c_uint32), ("stride", C.c_uint32), ("constraint_ids", C.POINTER(C.c_uint32)),
+                ("counts", C.POINTER(C.c_uint32)), ("reviews", C.POINTER(C.c_uint32)), ("overflow", C.POINTER(C.c_uint32))]
 
 
 class EngineLoadError(RuntimeError):
@@ -110,5 +115,8 @@ def load(hostemu: bool | None = None):
     lib.gk_free.argtypes = [vp]
     lib.gk_free.restype = None
     lib.gk_dump.argtypes = [vp, C.POINTER(vp)]
+    lib.gk_table_topk.argtypes = [vp, vp, u32, C.POINTER(C.POINTER(gk_topk_out))]
+    lib.gk_topk_free.argtypes = [C.POINTER(gk_topk_out)]
+    lib.gk_topk_free.restype = None
     _cache[hostemu] = lib
     return lib

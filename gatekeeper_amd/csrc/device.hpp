@@ -44,6 +44,10 @@ uint64_t dev_table_bytes(const DevTable* t);
 DevPlan* dev_plan_upload(const HostPlan& fast, const HostPlan& big);
 void dev_plan_free(DevPlan* p);
 void dev_eval(const DevPlan* p, const DevTable* t, const EvalOptions& opt, EvalOut* out);   // launch + finish; throws std::runtime_error
+// first-k violating reviews per bitmap row in `order` (reviews sorted by object key; grp = dense key rank, ties equal);
+// uses the bitmaps of the table's most recent evaluation.  idx: [nc][cap], n: [nc], ovf: [nc]
+void dev_topk(const DevTable* t, uint32_t nc, const std::vector<uint32_t>& order, const std::vector<uint32_t>& grp, uint32_t k, uint32_t cap,
+              std::vector<uint32_t>* idx, std::vector<uint32_t>* n, std::vector<uint32_t>* ovf);
 void dev_eval_launch(const DevPlan* p, const DevTable* t, const EvalOptions& opt);          // asynchronous on the default stream
 void dev_eval_finish(const DevPlan* p, const DevTable* t, const EvalOptions& opt, EvalOut* out);   // sync, overflow re-run, download
 

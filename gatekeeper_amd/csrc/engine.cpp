@@ -6,6 +6,7 @@
 // pieces that sit on the hot path (pkg/target/target.go:81-179, matcher.go:21-93, ns_cache.go:15-87).
 #include <atomic>
 #include <cstring>
+#include <algorithm>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -159,6 +160,10 @@ struct gk_table {
   std::vector<uint32_t> path_max;           // per element path: largest array of one review
   bool resident = false;
   std::vector<uint32_t> slot_path;          // path of each slot of the table's row-group index
+  std::vector<std::string> obj_keys;        // per review: group \0 version \0 kind \0 namespace \0 name (audit order, manager.go:118-138)
+  std::vector<uint32_t> order, grp;         // reviews sorted by obj_keys / dense rank with ties equal (built by the first gk_table_topk)
+  uint32_t last_nc = 0;
+  std::vector<uint32_t> last_ids;
   uint32_t n_reviews = 0;
 };
 
@@ -414,6 +419,17 @@ int gk_table_create(gk_engine* e, const gk_review_in* reviews, size_t n, uint32_
         doc.request = Value::object({});
       }
       if (statuses) statuses[i] = st;
+      {   // object identity in the order pkg/audit sorts violations by
+        const Value* o = doc.request.get("object");
+        if (!o || !o->is_object()) o = doc.request.get("oldObject");
+        std::string g_, v_, k_, key;
+        if (o && o->is_object()) {
+          obj_gvk(*o, &g_, &v_, &k_);
+          key = g_; key.push_back('\0'); key += v_; key.push_back('\0'); key += k_; key.push_back('\0');
+          key += obj_string(*o, "metadata", "namespace"); key.push_back('\0'); key += obj_string(*o, "metadata", "name");
+        }
+        t->obj_keys.push_back(std::move(key));
+      }
       fl.add(doc, &t->host);
       if (keep) t->docs.push_back(doc);
     }
@@ -486,6 +502,7 @@ int gk_table_eval(gk_engine* e, gk_table* t, uint32_t flags, gk_eval_out** out) 
     p.kernel_ms = h->out.kernel_ms; p.fast_kernel_ms = h->out.fast_kernel_ms; p.n_launches = h->out.n_launches;
     p.d_viol = h->out.d_viol; p.d_err = h->out.d_err; p.d_counts = h->out.d_counts;
     p.n_rows = t->n_rows;
+    t->last_nc = p.n_constraints; t->last_ids = h->ids;
     p.lds_bytes = h->lds_bytes;
     // algorithmic bytes: rows of the segments whose path carries predicates (+ their string headers
     // where a predicate reads string bytes) + two index words per bound path and tile + review flags, all read once;
@@ -509,6 +526,44 @@ int gk_table_eval(gk_engine* e, gk_table* t, uint32_t flags, gk_eval_out** out) 
     return GK_OK;
   } catch (const Unsupported& ex) { return fail(GK_ERR_UNSUPPORTED, ex.what());
   } catch (const std::exception& ex) { return fail(GK_ERR_DEVICE, ex.what()); }
+}
+
+struct TopkHolder {
+  gk_topk_out pub;   // first member
+  std::vector<uint32_t> ids, counts, reviews, overflow;
+};
+
+int gk_table_topk(gk_engine* e, gk_table* t, uint32_t k, gk_topk_out** out) {
+  if (!e || !t || !out) return fail(GK_ERR_INVALID, "NULL argument");
+  try {
+    if (t->order.size() != t->n_reviews) {   // object-key order of the table, once
+      t->order.resize(t->n_reviews);
+      for (uint32_t i = 0; i < t->n_reviews; i++) t->order[i] = i;
+      // field-wise order == order of the \0-joined keys (\0 sorts below every byte a name can contain)
+      std::stable_sort(t->order.begin(), t->order.end(), [&](uint32_t a, uint32_t b) { return t->obj_keys[a] < t->obj_keys[b]; });
+      t->grp.resize(t->n_reviews);
+      uint32_t gid = 0;
+      for (uint32_t p = 0; p < t->n_reviews; p++) {
+        if (p && t->obj_keys[t->order[p]] != t->obj_keys[t->order[p - 1]]) gid++;
+        t->grp[p] = gid;
+      }
+    }
+    std::unique_ptr<TopkHolder> h(new TopkHolder());
+    const uint32_t cap = k + 64;
+    h->ids = t->last_ids;
+    {
+      std::lock_guard<std::mutex> l(e->plan_mu);
+      dev_topk(t->dev, t->last_nc, t->order, t->grp, k, cap, &h->reviews, &h->counts, &h->overflow);
+    }
+    h->pub.n_constraints = t->last_nc; h->pub.stride = cap;
+    h->pub.constraint_ids = h->ids.data(); h->pub.counts = h->counts.data(); h->pub.reviews = h->reviews.data(); h->pub.overflow = h->overflow.data();
+    *out = &h.release()->pub;
+    return GK_OK;
+  } catch (const std::exception& ex) { return fail(GK_ERR_DEVICE, ex.what()); }
+}
+
+void gk_topk_free(gk_topk_out* o) {
+  if (o) delete reinterpret_cast<TopkHolder*>(o);
 }
 
 void gk_eval_free(gk_eval_out* o) {

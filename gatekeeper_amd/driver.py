@@ -146,6 +146,29 @@ class EvalResult:
         return sorted(out)
 
 
+def truncate_string(s, size):
+    """pkg/audit/manager.go:1039-1048: Go slices bytes."""
+    b = s.encode("utf-8")
+    if len(b) > size:
+        if size > 3:
+            size -= 3
+        return b[:size].decode("utf-8", errors="surrogateescape") + "..."
+    return s
+
+
+def obj_gvk(obj):
+    api = obj.get("apiVersion", "") if isinstance(obj.get("apiVersion"), str) else ""
+    g, _, v = api.rpartition("/")
+    return g, v, obj.get("kind", "") if isinstance(obj.get("kind"), str) else ""
+
+
+def review_object(review):
+    """the audited object of a review shape (Unstructured / AugmentedUnstructured)"""
+    inner = getattr(review, "object", review)
+    inner = getattr(inner, "object", inner)
+    return inner if isinstance(inner, dict) else {}
+
+
 class Table:
     def __init__(self, engine, handle, statuses, n):
         self.engine, self.handle, self.statuses, self.n = engine, handle, statuses, n
@@ -177,6 +200,19 @@ class Table:
 
     def render_error(self, cid, review):
         return self._render(self.engine.lib.gk_render_error, cid, review)
+
+    def topk(self, k):
+        """Per bitmap row of the most recent eval(): the k violating reviews with the smallest object key
+        (group, version, kind, namespace, name), ties on the k-th key included -> {constraint id: (reviews, overflow)}."""
+        out = C.POINTER(L.gk_topk_out)()
+        self.engine._check(self.engine.lib.gk_table_topk(self.engine.handle, self.handle, k, C.byref(out)))
+        o = out.contents
+        res = {}
+        for i in range(o.n_constraints):
+            n = o.counts[i]
+            res[int(o.constraint_ids[i])] = ([int(o.reviews[i * o.stride + j]) for j in range(n)], bool(o.overflow[i]))
+        self.engine.lib.gk_topk_free(out)
+        return res
 
     def free(self):
         if self.handle:
@@ -596,3 +632,42 @@ class Client:
 
     def Review(self, obj, enforcement_point=AUDIT_EP, namespace=None):
         return self.ReviewBatch([obj], enforcement_point, [namespace])[0]
+
+    def AuditAggregate(self, objs, namespaces=None, limit=20, msg_size=256):
+        """pkg/audit/manager.go:885-941 (addAuditResponsesToUpdateLists) for one resident set: ONE device sweep, totals
+        per constraint from the bitmap rows, and the `limit` smallest violations per constraint (LimitQueue order:
+        group, version, kind, namespace, name, message, action; messages truncated to msg_size bytes, :1039-1048).
+        Only the top-k candidates selected on the device are rendered to messages; the totals count violating
+        (constraint, object) pairs -- the reference counts results, which differs only for templates that emit more
+        than one violation per object.  -> {(kind, apiVersion, name): {"total_pairs", "violations": [...]}}"""
+        rins = [to_review_in(o, namespaces[i] if namespaces else None) for i, o in enumerate(objs)]
+        table = self.driver.engine.create_table(rins, resident=True)
+        try:
+            ev = table.eval()
+            top = table.topk(limit)
+            row = {int(cid): i for i, cid in enumerate(ev.constraint_ids)}
+            out = {}
+            for c in self.constraints.values():
+                cid = self.driver.constraint_id(c)
+                ea = get_enforcement_action(c)
+                scoped = scoped_actions_for_ep(AUDIT_EP, c) if ea == "scoped" else None
+                if (ea == "scoped" and not scoped) or cid not in row:
+                    continue
+                reviews, overflow = top.get(cid, ([], False))
+                if overflow:   # more key ties than the device list holds: walk the bitmap row (exact, rare)
+                    reviews = [int(r) for r in EvalResult.bits(ev.viol[row[cid]], ev.n_reviews)]
+                cand = []
+                for r in reviews:
+                    obj = review_object(objs[r])
+                    g, ver, k = obj_gvk(obj)
+                    for v in table.render(cid, r):
+                        cand.append({"group": g, "version": ver, "kind": k, "namespace": (obj.get("metadata") or {}).get("namespace", "") or "",
+                                     "name": (obj.get("metadata") or {}).get("name", "") or "", "message": truncate_string(v["msg"], msg_size),
+                                     "enforcementAction": ea, "enforcementActions": scoped})
+                cand.sort(key=lambda x: tuple(s_.encode("utf-8") for s_ in (x["group"], x["version"], x["kind"], x["namespace"], x["name"],
+                                                                           x["message"], x["enforcementAction"])))
+                key = (c.get("kind", ""), c.get("apiVersion", ""), (c.get("metadata") or {}).get("name", ""))
+                out[key] = {"total_pairs": int(ev.counts[row[cid]]), "violations": cand[:limit]}
+            return out
+        finally:
+            table.free()

@@ -129,6 +129,23 @@ int gk_render(gk_engine* e, gk_table* t, uint32_t constraint_id, uint32_t review
 int gk_render_error(gk_engine* e, gk_table* t, uint32_t constraint_id, uint32_t review, char** json_out);
 void gk_free(void* p);
 
+/* ---- audit aggregation (row a11) ---------------------------------------------------------------------------------
+ * pkg/audit/manager.go:885-941 keeps, per constraint, the `--constraint-violations-limit` (default 20) SMALLEST
+ * violations by (group, version, kind, namespace, name, message, action) (LimitQueue, manager.go:112-203).  After a
+ * gk_table_eval, gk_table_topk selects on the device, for every bitmap row, the `k` violating reviews with the smallest
+ * object key (ties on the k-th key included, so the host-side message tie-break stays exact): the caller renders only
+ * those k x C pairs instead of every violating pair.  `reviews` is [n_constraints][stride], counts[c] entries valid,
+ * ascending by object key.  overflow[c] != 0: more ties than `stride` holds -- walk that bitmap row on the host. */
+typedef struct {
+  uint32_t n_constraints, stride;
+  const uint32_t* constraint_ids;
+  const uint32_t* counts;
+  const uint32_t* reviews;
+  const uint32_t* overflow;
+} gk_topk_out;
+int gk_table_topk(gk_engine* e, gk_table* t, uint32_t k, gk_topk_out** out);
+void gk_topk_free(gk_topk_out* o);
+
 /* Debug: the compiled plan as text (Driver.Dump, pkg/drivers/k8scel/driver.go:253). */
 int gk_dump(gk_engine* e, char** text_out);
 

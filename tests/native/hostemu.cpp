@@ -19,7 +19,7 @@
 
 namespace gk {
 
-struct DevTable { HostTable t; int pending = 0; };
+struct DevTable { HostTable t; int pending = 0; std::vector<uint64_t> last_viol; };
 typedef void (*HeRowFn)(const Row*, uint32_t, uint32_t, const StrHdr*, const PlanView*, const uint8_t*, std::vector<uint32_t>*);
 typedef void (*HeFormFn)(const PlanView*, std::vector<uint32_t>*, uint32_t, const Row*, const uint8_t*, const uint32_t*, Results*);
 struct DevPlan {
@@ -110,6 +110,24 @@ static bool eval_review(const HostPlan& hp, const HostTable& t, uint32_t r, Resu
   return true;
 }
 
+void dev_topk(const DevTable* t, uint32_t nc, const std::vector<uint32_t>& order, const std::vector<uint32_t>& grp, uint32_t k, uint32_t cap,
+              std::vector<uint32_t>* idx, std::vector<uint32_t>* n, std::vector<uint32_t>* ovf) {
+  idx->assign((size_t)nc * cap, 0xFFFFFFFFu); n->assign(nc, 0); ovf->assign(nc, 0);
+  const uint32_t nt = (t->t.n_reviews + GK_TILE - 1) / GK_TILE;
+  if (t->last_viol.size() != (size_t)nc * nt) throw std::runtime_error("dev_topk: evaluate the table first");
+  for (uint32_t c = 0; c < nc && k; c++) {
+    uint32_t count = 0, gk_ = 0;
+    for (uint32_t p = 0; p < order.size(); p++) {
+      uint32_t rev = order[p];
+      if (!((t->last_viol[(size_t)c * nt + rev / GK_TILE] >> (rev % GK_TILE)) & 1)) continue;
+      if (count >= k && grp[p] != gk_) break;
+      if (count == k - 1) gk_ = grp[p];
+      if (count < cap) (*idx)[(size_t)c * cap + count] = rev; else (*ovf)[c] = 1;
+      count++;
+    }
+    (*n)[c] = count < cap ? count : cap;
+  }
+}
 void dev_eval_launch(const DevPlan*, const DevTable* dt, const EvalOptions&) { const_cast<DevTable*>(dt)->pending++; }
 void dev_eval(const DevPlan* p, const DevTable* dt, const EvalOptions& opt, EvalOut* o) { dev_eval_launch(p, dt, opt); dev_eval_finish(p, dt, opt, o); }
 void dev_eval_finish(const DevPlan* p, const DevTable* dt, const EvalOptions& opt, EvalOut* o) {
@@ -148,6 +166,7 @@ void dev_eval_finish(const DevPlan* p, const DevTable* dt, const EvalOptions& op
   if (getenv("GK_PRINT_OPS")) fprintf(stderr, "[hostemu] formula ops per review: %.1f\n", (double)gk_op_counter / (n ? n : 1));
   gk_op_counter = 0;
 #endif
+  const_cast<DevTable*>(dt)->last_viol = o->viol;
   o->kernel_ms = o->fast_kernel_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 

@@ -5,6 +5,7 @@ oracle, on the reference's own fixtures and on seeded synthetic workloads.  Bit-
 Every test runs twice: `hostemu` (CPU container; the kernels' vm_core.hpp code executed lane by lane by a test-only
 library) and `gpu` (-m gpu: the HIP kernels on a real MI355X)."""
 import numpy as np
+import json
 import os
 
 import pytest
@@ -186,6 +187,34 @@ def test_template_families(backend, fixtures):
         rv = [D.AugmentedUnstructured(D.Unstructured(o), None, "Original") for o in objs + pods]
         assert_parity(c, oc, rv)
     assert supported >= 3   # requiredlabels (allowedRegex), allowedrepos, requiredprobes; containerlimits needs quantity arithmetic
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_audit_aggregation(backend, fixtures):
+    """Row a11: totals + the 20 smallest violations per constraint (pkg/audit/manager.go:885-941, LimitQueue order), with
+    the top-k candidates selected on the device, against the oracle's restatement fed with EVERY result.  Includes objects
+    that share one (gvk, namespace, name) key so the k-th key has ties."""
+    from oracle import audit as OA
+    from parity_util import to_oracle_review
+    c, oc = load_both(backend, synth.psp_templates(fixtures), synth.audit_constraints())
+    nss = synth.gen_namespaces()
+    objs = synth.gen_objects(700, seed=23, mixed=True)
+    dup = json.loads(json.dumps(objs[5]))
+    dup["spec"]["hostNetwork"] = True
+    objs += [dup, json.loads(json.dumps(dup)), json.loads(json.dumps(objs[5]))]      # same object key, different violations
+    reviews = [D.AugmentedUnstructured(D.Unstructured(o), synth.namespace_for(o, nss), "Original") for o in objs]
+    for limit in (20, 3):
+        got = c.AuditAggregate(reviews, limit=limit)
+        lists, totals, per_action, pairs = {}, {}, {}, {}
+        for o, rv in zip(objs, reviews):
+            res = oc.review(to_oracle_review(rv), D.AUDIT_EP, None)
+            OA.add_audit_responses(lists, totals, per_action, [(r, o) for r in res], limit=limit)
+            for k in {(r.constraint.get("kind", ""), r.constraint.get("apiVersion", ""), r.constraint["metadata"]["name"]) for r in res}:
+                pairs[k] = pairs.get(k, 0) + 1
+        assert {k: v["total_pairs"] for k, v in got.items() if v["total_pairs"]} == pairs
+        for k, q in lists.items():
+            assert got[k]["violations"] == q.sorted(), k
+        assert sum(len(v["violations"]) for v in got.values()) == sum(len(q.items) for q in lists.values()) > 0
 
 
 REGEX_TEMPLATE = {
