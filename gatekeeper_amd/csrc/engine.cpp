@@ -7,6 +7,7 @@
 #include <atomic>
 #include <cstring>
 #include <algorithm>
+#include <thread>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -399,41 +400,69 @@ int gk_table_create(gk_engine* e, const gk_review_in* reviews, size_t n, uint32_
   try {
     std::unique_ptr<gk_table> t(new gk_table());
     t->eng = e;
-    Flattener fl(&e->dict);
     bool keep = flags & GK_TABLE_KEEP_DOCS;
     t->review_errors.resize(n);
-    for (size_t i = 0; i < n; i++) {
-      const gk_review_in& r = reviews[i];
-      ReviewDoc doc;
-      int st = GK_OK;
+    t->obj_keys.resize(n);
+    if (keep) t->docs.resize(n);
+    // Reviews are parsed, normalised (HandleReview) and flattened by host threads, each on a contiguous range of whole
+    // tiles; the parts are appended in order (the path dictionary is shared and thread-safe).
+    const size_t n_tiles = (n + GK_TILE - 1) / GK_TILE;
+    size_t n_threads = std::max<size_t>(1, std::min<size_t>(std::thread::hardware_concurrency(), n_tiles / 8));
+    if (const char* ht = getenv("GK_HOST_THREADS")) n_threads = std::max(1, atoi(ht));
+    n_threads = std::min(n_threads, std::max<size_t>(n_tiles, 1));
+    const size_t tiles_per = (n_tiles + n_threads - 1) / std::max<size_t>(n_threads, 1);
+    std::vector<HostTable> parts(n_threads);
+    std::vector<std::string> part_err(n_threads);
+    auto work = [&](size_t w) {
       try {
-        Value body = parse_json(r.json, r.json_len);
-        Value mns = parse_opt(r.namespace_json, r.namespace_len);
-        Value nso = parse_opt(r.ns_object_json, r.ns_object_len);
-        if (r.kind == GK_REVIEW_OBJECT) doc = normalize_object(body, mns, nso, r.source, r.operation ? r.operation : "", e->ns_cache);
-        else doc = normalize_admission_request(body, mns, nso, r.source, e->ns_cache);
-      } catch (const std::exception& ex) {
-        st = GK_ERR_REVIEW;
-        t->review_errors[i] = ex.what();
-        doc = ReviewDoc();
-        doc.request = Value::object({});
-      }
-      if (statuses) statuses[i] = st;
-      {   // object identity in the order pkg/audit sorts violations by
-        const Value* o = doc.request.get("object");
-        if (!o || !o->is_object()) o = doc.request.get("oldObject");
-        std::string g_, v_, k_, key;
-        if (o && o->is_object()) {
-          obj_gvk(*o, &g_, &v_, &k_);
-          key = g_; key.push_back('\0'); key += v_; key.push_back('\0'); key += k_; key.push_back('\0');
-          key += obj_string(*o, "metadata", "namespace"); key.push_back('\0'); key += obj_string(*o, "metadata", "name");
+        Flattener fl(&e->dict);
+        const size_t lo = std::min(n, w * tiles_per * GK_TILE), hi = std::min(n, (w + 1) * tiles_per * GK_TILE);
+        for (size_t i = lo; i < hi; i++) {
+          const gk_review_in& r = reviews[i];
+          ReviewDoc doc;
+          int st = GK_OK;
+          try {
+            Value body = parse_json(r.json, r.json_len);
+            Value mns = parse_opt(r.namespace_json, r.namespace_len);
+            Value nso = parse_opt(r.ns_object_json, r.ns_object_len);
+            if (r.kind == GK_REVIEW_OBJECT) doc = normalize_object(body, mns, nso, r.source, r.operation ? r.operation : "", e->ns_cache);
+            else doc = normalize_admission_request(body, mns, nso, r.source, e->ns_cache);
+          } catch (const std::exception& ex) {
+            st = GK_ERR_REVIEW;
+            t->review_errors[i] = ex.what();
+            doc = ReviewDoc();
+            doc.request = Value::object({});
+          }
+          if (statuses) statuses[i] = st;
+          {   // object identity in the order pkg/audit sorts violations by
+            const Value* o = doc.request.get("object");
+            if (!o || !o->is_object()) o = doc.request.get("oldObject");
+            std::string g_, v_, k_, key;
+            if (o && o->is_object()) {
+              obj_gvk(*o, &g_, &v_, &k_);
+              key = g_; key.push_back('\0'); key += v_; key.push_back('\0'); key += k_; key.push_back('\0');
+              key += obj_string(*o, "metadata", "namespace"); key.push_back('\0'); key += obj_string(*o, "metadata", "name");
+            }
+            t->obj_keys[i] = std::move(key);
+          }
+          fl.add(doc, &parts[w]);
+          if (keep) t->docs[i] = doc;
         }
-        t->obj_keys.push_back(std::move(key));
-      }
-      fl.add(doc, &t->host);
-      if (keep) t->docs.push_back(doc);
+        fl.flush(&parts[w]);
+      } catch (const std::exception& ex) { part_err[w] = ex.what(); }
+    };
+    if (n_threads <= 1) work(0);
+    else {
+      std::vector<std::thread> th;
+      for (size_t w = 0; w < n_threads; w++) th.emplace_back(work, w);
+      for (auto& x : th) x.join();
     }
-    fl.finish(&t->host);
+    for (auto& pe_ : part_err) if (!pe_.empty()) return fail(GK_ERR_INTERNAL, pe_);
+    for (size_t w = 0; w < n_threads; w++) {
+      if (w == 0) t->host = std::move(parts[0]); else t->host.append(parts[w]);
+      parts[w] = HostTable();
+    }
+    Flattener::build_index(&t->host);
     if (t->host.rows.size() >= 0xFFFFFFF0ull || t->host.heap.size() >= 0xFFFFFFF0ull)
       return fail(GK_ERR_INVALID, "table too large for 32-bit row/heap offsets: split the batch");
     t->n_reviews = (uint32_t)n;

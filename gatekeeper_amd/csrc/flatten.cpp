@@ -217,7 +217,24 @@ void Flattener::emit_string_row(uint32_t path, uint32_t meta, const std::string&
   memcpy(&stage_.back().hdr, &t_->heap[off - 4], 16);   // entry header: length + first 12 bytes
 }
 
-void Flattener::emit_str(uint32_t parent, const char* key, const std::string& s) { emit_string_row(dict_->child(parent, key), 0, s); }
+void Flattener::emit_str(uint32_t parent, const char* key, const std::string& s) { emit_string_row(child(parent, key), 0, s); }
+
+// Flattener-local memo of the shared dictionary: the hot lookups take no lock (one Flattener per host thread).
+uint32_t Flattener::child(uint32_t parent, const std::string& key) {
+  auto& m = memo_[parent];
+  auto it = m.find(key);
+  if (it != m.end()) return it->second;
+  uint32_t id = dict_->child(parent, key);
+  m.emplace(key, id);
+  return id;
+}
+uint32_t Flattener::elem(uint32_t parent) {
+  auto it = memo_elem_.find(parent);
+  if (it != memo_elem_.end()) return it->second;
+  uint32_t id = dict_->elem(parent);
+  memo_elem_.emplace(parent, id);
+  return id;
+}
 
 void Flattener::walk(const Value& v, uint32_t path, uint32_t ords, int adepth, uint32_t extra) {
   uint32_t meta = ords | extra;
@@ -238,12 +255,12 @@ void Flattener::walk(const Value& v, uint32_t path, uint32_t ords, int adepth, u
     case Value::String: emit_string_row(path, meta, v.str()); break;
     case Value::Object: {
       emit(path, meta | T_OBJECT, (uint32_t)v.size(), 0);
-      for (const auto& kv : v.pairs()) walk(kv.second, dict_->child(path, kv.first.str()), ords, adepth, extra);
+      for (const auto& kv : v.pairs()) walk(kv.second, child(path, kv.first.str()), ords, adepth, extra);
       break;
     }
     case Value::Array: case Value::Set: {
       emit(path, meta | T_ARRAY, (uint32_t)v.size(), 0);
-      uint32_t ep = dict_->elem(path);
+      uint32_t ep = elem(path);
       Ctr* c = nullptr;
       for (auto& x : ctrs_) if (x.path == ep) { c = &x; break; }
       if (!c) { ctrs_.push_back({ep, 0}); c = &ctrs_.back(); }
@@ -305,7 +322,7 @@ void Flattener::add(const ReviewDoc& doc, HostTable* out) {
   const Value& req = doc.request;
   // root + request members (input.review.*)
   emit(0, T_OBJECT, (uint32_t)req.size(), 0);
-  for (const auto& kv : req.pairs()) walk(kv.second, dict_->child(0, kv.first.str()), 0, 0, 0);
+  for (const auto& kv : req.pairs()) walk(kv.second, child(0, kv.first.str()), 0, 0, 0);
   // $ns: only what the match layer reads from Matchable.Namespace (name + labels)
   const Value& ns = doc.match_ns;
   if (ns.defined()) {
@@ -364,8 +381,35 @@ void Flattener::flush_tile(HostTable* out) {
   stage_.clear();
 }
 
-void Flattener::finish(HostTable* out) {
+void Flattener::flush(HostTable* out) {
   if (!stage_.empty() || out->n_reviews % GK_TILE != 0) flush_tile(out);
+}
+
+// Appends `part` (whole tiles flattened by another Flattener over the same dictionary; the receiving table must end
+// on a tile boundary) -- row starts and heap offsets are relocated.
+void HostTable::append(const HostTable& part) {
+  const uint32_t row_base = (uint32_t)rows.size(), heap_base = (uint32_t)heap.size(), seg_base = (uint32_t)segs.size();
+  rows.insert(rows.end(), part.rows.begin(), part.rows.end());
+  for (size_t i = row_base; i < rows.size(); i++)
+    if ((rows[i].meta & ROW_TYPE_MASK) == T_STRING && !(rows[i].meta & ROW_STR_INLINE)) rows[i].lo += heap_base;
+  shdr.insert(shdr.end(), part.shdr.begin(), part.shdr.end());
+  heap.insert(heap.end(), part.heap.begin(), part.heap.end());
+  for (const SegRec& s : part.segs) segs.push_back({s.path, s.start + row_base});
+  for (uint32_t ts : part.tile_seg) tile_seg.push_back(ts + seg_base);
+  rflags.insert(rflags.end(), part.rflags.begin(), part.rflags.end());
+  if (part.path_rows.size() > path_rows.size()) path_rows.resize(part.path_rows.size(), 0);
+  for (size_t i = 0; i < part.path_rows.size(); i++) path_rows[i] += part.path_rows[i];
+  if (part.path_max.size() > path_max.size()) path_max.resize(part.path_max.size(), 0);
+  for (size_t i = 0; i < part.path_max.size(); i++) path_max[i] = std::max(path_max[i], part.path_max[i]);
+  n_reviews += part.n_reviews;
+}
+
+void Flattener::finish(HostTable* out) {
+  flush(out);
+  build_index(out);
+}
+
+void Flattener::build_index(HostTable* out) {
   out->tile_seg.push_back((uint32_t)out->segs.size());
   // slots = distinct paths of the table in path-id order; dense index [tile][slot] of first rows
   std::vector<uint32_t> paths;

@@ -97,13 +97,16 @@ struct HostTable {
   struct SegRec { uint32_t path, start; };
   std::vector<SegRec> segs;
   std::vector<uint32_t> tile_seg;
+  void append(const HostTable& part);
 };
 
 class Flattener {
  public:
   explicit Flattener(PathDict* dict);
   void add(const ReviewDoc& doc, HostTable* out);
-  void finish(HostTable* out);   // flushes the last tile and closes the directory
+  void finish(HostTable* out);   // flush + build_index
+  void flush(HostTable* out);    // closes the tile being built (parallel table builds flush per part, then append)
+  static void build_index(HostTable* out);   // slots + dense [tile][slot] index from the per-tile segment lists
 
  private:
   PathDict* dict_;
@@ -116,6 +119,10 @@ class Flattener {
   std::vector<Staged> stage_;       // rows of the tile being built, review order / document order
   std::vector<uint32_t> order_;
   void flush_tile(HostTable* out);
+  std::unordered_map<uint32_t, std::unordered_map<std::string, uint32_t>> memo_;
+  std::unordered_map<uint32_t, uint32_t> memo_elem_;
+  uint32_t child(uint32_t parent, const std::string& key);
+  uint32_t elem(uint32_t parent);
   void walk(const Value& v, uint32_t path, uint32_t meta_ords, int adepth, uint32_t extra);
   void emit(uint32_t path, uint32_t meta, uint32_t lo, uint32_t hi);
   uint32_t put_string(const std::string& s, uint32_t* hash);

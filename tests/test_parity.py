@@ -297,6 +297,17 @@ def test_edge_cases(backend, fixtures):
     assert ev2.n_overflow == 0 and (ev2.viol == ev.viol).all() and (ev2.err == ev.err).all() and (ev2.counts == ev.counts).all()
     table.free()
     assert_parity(c, oc, rv)
+    # a whole tile of very wide pods: more 64-row chunks than a wave queues in LDS -> every review of the tile takes the
+    # big path (on the GPU backends; the CPU emulation has no chunk lists), results unchanged
+    wide = [{"apiVersion": "v1", "kind": "Pod", "metadata": {"name": "wide-%d" % j, "namespace": "prod-01"}, "spec": {
+        "containers": [{"name": "c%d" % i, "image": "x", "securityContext": {"privileged": (i + j) % 29 == 0},
+                        "ports": [{"containerPort": 80, "hostPort": 8000 + i}]} for i in range(90)]}} for j in range(64)]
+    wrv = [D.AugmentedUnstructured(D.Unstructured(o), None, "Original") for o in wide + objs[:3]]
+    table = c.driver.engine.create_table([D.to_review_in(r) for r in wrv])
+    ev = table.eval()
+    assert ev.n_overflow >= 64 and int(ev.too_big.sum()) == 0
+    table.free()
+    assert_parity(c, oc, wrv)
     # DELETE: object := oldObject (target.go:269-287); missing oldObject is a review error
     req = {"kind": {"group": "", "version": "v1", "kind": "Pod"}, "operation": "DELETE", "oldObject": objs[2]}
     assert_parity(c, oc, [D.AugmentedReview(D.AdmissionRequest(req), None, "Original")])
@@ -332,6 +343,16 @@ def test_bitmap_list_counts_consistency(backend, fixtures):
     e1, e2 = t1.eval(), t2.eval()
     assert (np.concatenate([e1.viol, e2.viol], axis=1) == ev.viol).all()
     assert (e1.counts + e2.counts == ev.counts).all()
+    # host-side build: one thread == several threads (tile ranges flattened in parallel, parts appended in order)
+    os.environ["GK_HOST_THREADS"] = "1"
+    ts = c.driver.engine.create_table(rins, keep_docs=False)
+    os.environ["GK_HOST_THREADS"] = "3"
+    tp = c.driver.engine.create_table(rins, keep_docs=False)
+    del os.environ["GK_HOST_THREADS"]
+    es, ep = ts.eval(want_match=True), tp.eval(want_match=True)
+    for x in (es, ep):
+        assert (x.viol == ev.viol).all() and (x.err == ev.err).all() and (x.match == ev.match).all() and x.n_rows == ev.n_rows
+    ts.free(); tp.free()
     # resident (table-specialised plan variant, smaller LDS footprint) == default plan
     tr = c.driver.engine.create_table(rins, keep_docs=False, resident=True)
     er = tr.eval(want_match=True, want_list=True)
