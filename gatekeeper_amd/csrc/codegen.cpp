@@ -213,8 +213,8 @@ std::string generate_plan_source(const HostPlan& plan) {
   o << "    default: break;\n  }\n}\n\n";
   // ---------------------------------------------------------------------------------------------- phase 2
   o << "template <class Acc>\nGK_HD Results jit_formulas(const PlanView& pv, Acc& acc, uint32_t flags, const Row* rows, const uint8_t* heap, const uint32_t* bounds) {\n"
-    << "  (void)pv; (void)rows; (void)heap; (void)flags;\n  Results res = {0, 0, 0};\n  bool";
-  for (int i = 0; i < 64; i++) o << (i ? ", " : " ") << "b" << i << " = false";
+    << "  (void)pv; (void)rows; (void)heap; (void)flags;\n  Results res = {0, 0, 0};\n  uint32_t";
+  for (int i = 0; i < 64; i++) o << (i ? ", " : " ") << "b" << i << " = 0u";
   o << ";\n";
   // the global predicate words are read once; derived global bits (F_STG) update the register copy as well
   for (uint32_t w = 0; w < plan.dims.n_gwords; w++) o << "  uint32_t g" << w << " = acc.load(" << w << "u);\n";
@@ -236,20 +236,22 @@ std::string generate_plan_source(const HostPlan& plan) {
         const Scope& sc = plan.scopes[b];
         int d = var_of(b);
         if (d < 0) throw Unsupported("codegen: element load outside its loop");
-        if (elem_word_of_bit(c) == 0) o << ind << "b" << a << " = (w" << d << " & " << u(elem_mask_of_bit(c)) << ") != 0u;\n";
-        else o << ind << "b" << a << " = (acc.load(" << sc.word_off << "u + e" << d << " * " << (int)sc.wpe << "u + " << elem_word_of_bit(c) << "u) & " << u(elem_mask_of_bit(c)) << ") != 0u;\n";
+        // booleans are 0/1 integers in vector registers (bitwise VALU ops), not wave masks in scalar registers
+        const uint32_t sh = (uint32_t)__builtin_ctz(elem_mask_of_bit(c));
+        if (elem_word_of_bit(c) == 0) o << ind << "b" << a << " = (w" << d << " >> " << sh << "u) & 1u;\n";
+        else o << ind << "b" << a << " = (acc.load(" << sc.word_off << "u + e" << d << " * " << (int)sc.wpe << "u + " << elem_word_of_bit(c) << "u) >> " << sh << "u) & 1u;\n";
         break;
       }
       case F_AND: o << ind << "b" << a << " = b" << b << " & b" << c << ";\n"; break;
       case F_OR: o << ind << "b" << a << " = b" << b << " | b" << c << ";\n"; break;
-      case F_NOT: o << ind << "b" << a << " = !b" << b << ";\n"; break;
-      case F_ANDN: o << ind << "b" << a << " = b" << b << " & !b" << c << ";\n"; break;
-      case F_CONST: o << ind << "b" << a << " = " << ((b & 1) ? "true" : "false") << ";\n"; break;
+      case F_NOT: o << ind << "b" << a << " = b" << b << " ^ 1u;\n"; break;
+      case F_ANDN: o << ind << "b" << a << " = b" << b << " & (b" << c << " ^ 1u);\n"; break;
+      case F_CONST: o << ind << "b" << a << " = " << ((b & 1) ? "1u" : "0u") << ";\n"; break;
       case F_MOV: o << ind << "b" << a << " = b" << b << ";\n"; break;
       case F_LOOP: {
         const Scope& sc = plan.scopes[a];
         int d = (int)stack.size();
-        o << ind << "b" << c << " = false;\n";
+        o << ind << "b" << c << " = 0u;\n";
         // small capacities: constant trip count, fully unrolled -- the element words of absent elements are zero, so
         // they contribute nothing, and the compiler can issue all LDS reads of the nest at once
         uint64_t nest = sc.cap;
@@ -263,11 +265,11 @@ std::string generate_plan_source(const HostPlan& plan) {
           o << ind << "  for (uint32_t e" << d << " = 0; e" << d << " < n" << d << "; e" << d << "++) {\n";
         }
         o << ind << "    const uint32_t w" << d << " = acc.load(" << sc.word_off << "u + e" << d << " * " << (int)sc.wpe << "u);\n";
-        o << ind << "    bool v" << d << " = (w" << d << " & 1u) != 0u;\n";
+        o << ind << "    uint32_t v" << d << " = w" << d << " & 1u;\n";
         if (b) {
           int pd = var_of(b - 1);
           if (pd < 0) throw Unsupported("codegen: parent loop not open");
-          o << ind << "    v" << d << " = v" << d << " && ((w" << d << " >> 24) == e" << pd << ");\n";
+          o << ind << "    v" << d << " = v" << d << " & (uint32_t)((w" << d << " >> 24) == e" << pd << ");\n";
         }
         stack.push_back({a, d});
         ind += "    ";
@@ -296,7 +298,7 @@ std::string generate_plan_source(const HostPlan& plan) {
           return x.str();
         };
         o << ind << "{ const uint32_t wa = " << A.val_off << "u + e" << da << " * " << sa_ << "u, wb = " << B.val_off << "u + e" << db << " * " << sb_ << "u;\n"
-          << ind << "  b" << a << " = val_eq_quick(acc.load(wa + " << la * 2u << "u), acc.load(wa + " << la * 2u + 1u << "u), " << nib(A, da, "wa", la)
+          << ind << "  b" << a << " = (uint32_t)val_eq_quick(acc.load(wa + " << la * 2u << "u), acc.load(wa + " << la * 2u + 1u << "u), " << nib(A, da, "wa", la)
           << ", acc.load(wb + " << lb * 2u << "u), acc.load(wb + " << lb * 2u + 1u << "u), " << nib(B, db, "wb", lb) << ", heap); }\n";
         break;
       }
@@ -369,8 +371,8 @@ std::string generate_plan_source(const HostPlan& plan) {
     }
     o << "#define GK_HAS_STAGES 1\nconstexpr uint32_t GK_N_STAGES = " << n_stages << "u;\n"
       << "template <class Acc>\nGK_HD void jit_formula_part(uint32_t part, Acc& acc, uint32_t flags, const uint8_t* heap, const uint32_t* bounds, Results& res) {\n"
-      << "  (void)heap; (void)flags; (void)bounds;\n  bool";
-    for (int i = 0; i < 64; i++) o << (i ? ", " : " ") << "b" << i << " = false";
+      << "  (void)heap; (void)flags; (void)bounds;\n  uint32_t";
+    for (int i = 0; i < 64; i++) o << (i ? ", " : " ") << "b" << i << " = 0u";
     o << ";\n";
     for (uint32_t w = 0; w < plan.dims.n_gwords; w++) o << "  uint32_t g" << w << " = acc.load(" << w << "u);\n";
     o << "  switch (part) {\n";
