@@ -328,9 +328,9 @@ std::string generate_plan_source(const HostPlan& plan) {
   gen(0, code.size(), false, "  ");
   o << "  return res;\n}\n\n";
   // ---- the same formulas cut into self-contained blocks and spread over the tile's waves: blocks of one STAGE are
-  // independent (they only read bits written by earlier stages); part = stage * NW + wave
+  // independent (they only read bits written by earlier stages); part = stage * GK_PARTS + wave-within-half
   {
-    constexpr uint32_t NW = GK_BLOCK / GK_TILE;
+    constexpr uint32_t NW = GK_PARTS;   // waves that share the formulas of one 64-review half
     struct Blk { size_t pc0, pc1; uint32_t stage; uint64_t cost; std::vector<uint64_t> writes, reads; };
     std::vector<Blk> blks;
     size_t prev = 0;

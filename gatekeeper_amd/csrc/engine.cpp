@@ -406,7 +406,7 @@ int gk_table_create(gk_engine* e, const gk_review_in* reviews, size_t n, uint32_
     if (keep) t->docs.resize(n);
     // Reviews are parsed, normalised (HandleReview) and flattened by host threads, each on a contiguous range of whole
     // tiles; the parts are appended in order (the path dictionary is shared and thread-safe).
-    const size_t n_tiles = (n + GK_TILE - 1) / GK_TILE;
+    const size_t n_tiles = (n + GK_RPT - 1) / GK_RPT;
     size_t n_threads = std::max<size_t>(1, std::min<size_t>(std::thread::hardware_concurrency(), n_tiles / 8));
     if (const char* ht = getenv("GK_HOST_THREADS")) n_threads = std::max(1, atoi(ht));
     n_threads = std::min(n_threads, std::max<size_t>(n_tiles, 1));
@@ -416,7 +416,7 @@ int gk_table_create(gk_engine* e, const gk_review_in* reviews, size_t n, uint32_
     auto work = [&](size_t w) {
       try {
         Flattener fl(&e->dict);
-        const size_t lo = std::min(n, w * tiles_per * GK_TILE), hi = std::min(n, (w + 1) * tiles_per * GK_TILE);
+        const size_t lo = std::min(n, w * tiles_per * GK_RPT), hi = std::min(n, (w + 1) * tiles_per * GK_RPT);
         for (size_t i = lo; i < hi; i++) {
           const gk_review_in& r = reviews[i];
           ReviewDoc doc;
@@ -516,7 +516,7 @@ int gk_table_eval(gk_engine* e, gk_table* t, uint32_t flags, gk_eval_out** out) 
       }
       if (flags & GK_EVAL_COLLECT) dev_eval_finish(dp, t->dev, opt, &h->out);   // no new launch
       else dev_eval(dp, t->dev, opt, &h->out);
-      h->lds_bytes = hp->dims.acc_words * GK_TILE * 4;
+      h->lds_bytes = hp->dims.acc_words * GK_RPT * 4;
     }
     gk_eval_out& p = h->pub;
     memset(&p, 0, sizeof p);
@@ -549,7 +549,7 @@ int gk_table_eval(gk_engine* e, gk_table* t, uint32_t flags, gk_eval_out** out) 
     }
     p.n_rows_read = rows_read;
     uint64_t plan_bytes = (uint64_t)e->fast.path_preds.size() * sizeof(Pred) + e->fast.code.size() * 4 + e->fast.cheap.size() + bound * sizeof(Bind);
-    p.algo_bytes = rows_read * sizeof(Row) + hdrs_read * sizeof(StrHdr) + bound * 8 * p.n_tiles + t->dir_bytes + plan_bytes +
+    p.algo_bytes = rows_read * sizeof(Row) + hdrs_read * sizeof(StrHdr) + bound * 8 * ((p.n_reviews + GK_RPT - 1) / GK_RPT) + t->dir_bytes + plan_bytes +
                    (uint64_t)p.n_constraints * p.n_tiles * 16 + (uint64_t)p.list_total * 8;
     *out = &h.release()->pub;
     return GK_OK;

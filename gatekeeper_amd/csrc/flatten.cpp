@@ -190,7 +190,7 @@ Flattener::Flattener(PathDict* dict) : dict_(dict) {
 }
 
 void Flattener::emit(uint32_t path, uint32_t meta, uint32_t lo, uint32_t hi) {
-  stage_.push_back({path, Row{t_->n_reviews % GK_TILE, meta, lo, hi}, StrHdr{{0, 0, 0, 0}}});
+  stage_.push_back({path, Row{t_->n_reviews % GK_RPT, meta, lo, hi}, StrHdr{{0, 0, 0, 0}}});
 }
 
 uint32_t Flattener::put_string(const std::string& s, uint32_t* hash) {
@@ -359,7 +359,7 @@ void Flattener::add(const ReviewDoc& doc, HostTable* out) {
     out->path_max[c.path] = std::max(out->path_max[c.path], c.n);
   }
   out->n_reviews++;
-  if (out->n_reviews % GK_TILE == 0) flush_tile(out);
+  if (out->n_reviews % GK_RPT == 0) flush_tile(out);
 }
 
 // Close the current tile: stable sort of its rows by path (keeps review order, then document order, inside a
@@ -382,7 +382,7 @@ void Flattener::flush_tile(HostTable* out) {
 }
 
 void Flattener::flush(HostTable* out) {
-  if (!stage_.empty() || out->n_reviews % GK_TILE != 0) flush_tile(out);
+  if (!stage_.empty() || out->n_reviews % GK_RPT != 0) flush_tile(out);
 }
 
 // Appends `part` (whole tiles flattened by another Flattener over the same dictionary; the receiving table must end

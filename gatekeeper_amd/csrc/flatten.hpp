@@ -91,7 +91,7 @@ struct HostTable {
   std::vector<uint32_t> path_rows;  // rows per path over the whole table (algorithmic-byte accounting per plan)
   std::vector<uint32_t> path_max;   // per array-element path: largest element count of one review (plan specialisation)
   uint32_t n_reviews = 0;
-  uint32_t n_tiles() const { return (n_reviews + GK_TILE - 1) / GK_TILE; }
+  uint32_t n_tiles() const { return (n_reviews + GK_RPT - 1) / GK_RPT; }   // row groups
   uint32_t n_slots() const { return (uint32_t)slot_path.size(); }
   // build-time only: per-tile segment lists, turned into tile_idx by Flattener::finish
   struct SegRec { uint32_t path, start; };

@@ -12,7 +12,7 @@ namespace gk {
 
 // ------------------------------------------------------------------------------------------------ rows
 // One row per JSON node (scalars AND containers) of the review documents.  The table is stored as ROW GROUPS: reviews
-// are grouped in tiles of GK_TILE consecutive reviews, and within a tile the rows are sorted by key path (stable:
+// are grouped in tiles of GK_RPT consecutive reviews, and within a tile the rows are sorted by key path (stable:
 // review order, then document order).  The rows of one (tile, path) pair form a SEGMENT.  A plan touches only the
 // segments of the paths it has predicates on -- typically a fifth of a Pod's rows -- and every row of a segment takes
 // the same predicates, so a wave evaluates them without divergence.
@@ -27,7 +27,7 @@ namespace gk {
 //   rflags[n_reviews]            RF_*: match-layer facts computed once by the flattener
 //   heap                         string bytes, 16-byte aligned zero-padded entries [u32 len][bytes]
 struct Row {
-  uint32_t rev;    // review index within its tile (0 .. GK_TILE-1)
+  uint32_t rev;    // review index within its tile (0 .. GK_RPT-1)
   uint32_t meta;   // see ROW_* below
   uint32_t lo;     // value payload
   uint32_t hi;
@@ -157,8 +157,11 @@ struct ConstraintSlot {
   uint16_t match;   // index into the match-result bits (and match-error bits)
 };
 
-constexpr int GK_TILE = 64;            // reviews per tile (one lane per review in phase 2)
+constexpr int GK_TILE = 64;            // reviews per bitmap word = lanes of a wave (one lane per review in phase 2)
+constexpr int GK_RPT = 128;            // reviews per row group ("tile"): one workgroup of the dominant kernel; multiple of GK_TILE
+constexpr int GK_HALVES = GK_RPT / GK_TILE;   // 64-review halves of a row group
 constexpr int GK_BLOCK = 256;          // threads per tile in the dominant kernel: 4 waves stream the tile's rows
+constexpr int GK_PARTS = GK_BLOCK / GK_TILE / GK_HALVES;   // waves per 64-review half: phase 2 splits the formulas this many ways
 constexpr int GK_MAX_RES = 64;         // unique formulas per result class per pass
 constexpr int GK_MAX_SCOPES = 32;
 constexpr int GK_WAVE_CHUNKS = 64;      // 64-row chunks one wave queues per tile (LDS); beyond: the tile's reviews take the big path

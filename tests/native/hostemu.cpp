@@ -60,7 +60,7 @@ DevPlan* dev_plan_upload(const HostPlan& fast, const HostPlan& big) {
            "  VecAcc acc{w}; std::vector<uint32_t> w2 = *w; VecAcc acc2{&w2};\n"
            "  gk::Results mono = gk::jit_formulas(*pv, acc2, flags, rows, heap, bounds);\n"
            "  gk::Results r = {0, 0, 0};\n"
-           "  for (uint32_t st = 0; st < gk::GK_N_STAGES; st++) for (uint32_t wv = 0; wv < 4; wv++) gk::jit_formula_part(st * 4 + (3 - wv), acc, flags, heap, bounds, r);\n"
+           "  for (uint32_t st = 0; st < gk::GK_N_STAGES; st++) for (uint32_t wv = 0; wv < gk::GK_PARTS; wv++) gk::jit_formula_part(st * gk::GK_PARTS + (gk::GK_PARTS - 1 - wv), acc, flags, heap, bounds, r);\n"
            "  if (r.viol != mono.viol || r.match != mono.match || r.err != mono.err) { r.viol = ~0ull; r.match = ~0ull; r.err = ~0ull; }   // staged and monolithic code must agree\n"
            "  *out = r; }\n";
     }
@@ -86,7 +86,7 @@ static bool eval_review(const HostPlan& hp, const HostTable& t, uint32_t r, Resu
   PlanView pv = view_of(hp);
   std::vector<uint32_t> words(hp.dims.acc_words, 0);
   VecAcc acc{&words};
-  const uint32_t tile = r / GK_TILE, rl = r % GK_TILE;
+  const uint32_t tile = r / GK_RPT, rl = r % GK_RPT;
   const uint32_t S = t.n_slots();
   const uint32_t* ix = &t.tile_idx[(size_t)tile * (S + 1)];
   for (uint32_t s = 0; s < S; s++) {
