@@ -158,7 +158,9 @@ struct ConstraintSlot {
 };
 
 constexpr int GK_TILE = 64;            // reviews per bitmap word = lanes of a wave (one lane per review in phase 2)
-constexpr int GK_RPT = 128;            // reviews per row group ("tile"): one workgroup of the dominant kernel; multiple of GK_TILE
+constexpr int GK_RPT = 64;             // reviews per row group ("tile"): one workgroup of the dominant kernel; multiple of GK_TILE.
+                                       // 128 was measured (r01 v30): 33.1 vs 34.0 us on configs[1], but it doubles the LDS per tile
+                                       // (2 resident tiles per CU for the default plan), so 64 stays
 constexpr int GK_HALVES = GK_RPT / GK_TILE;   // 64-review halves of a row group
 constexpr int GK_BLOCK = 256;          // threads per tile in the dominant kernel: 4 waves stream the tile's rows
 constexpr int GK_PARTS = GK_BLOCK / GK_TILE / GK_HALVES;   // waves per 64-review half: phase 2 splits the formulas this many ways

@@ -12,7 +12,7 @@ def text(name):
     return "".join(l for l in open(src + "/" + name) if not l.startswith("#include") and not l.startswith("#pragma once"))
 import os
 waves = os.environ.get("WAVES")
-s = ("#include <hip/hip_runtime.h>\n" + ("#define GK_TILES_BOUNDS __launch_bounds__(256, %s)\n" % waves if waves else "") + text("plan.hpp") + text("vm_core.hpp") + open(gen).read() +
+s = ("#include <hip/hip_runtime.h>\n" + ("#define GK_TILES_BOUNDS __launch_bounds__(GK_BLOCK, %s)\n" % waves if waves else "") + text("plan.hpp") + text("vm_core.hpp") + open(gen).read() +
      "namespace gk {\n#define GK_KERNEL_TILES gk_jit_tiles\n#define GK_KERNEL_BIG gk_jit_big\n#define GK_KERNEL_LINKAGE extern \"C\"\n"
      "#define GK_ROW_FN(r, i, ent, h, pv, heap, acc) jit_row(r, ent, h, heap, acc)\n#define GK_BIND_ALWAYS_STR 0\n"
      "#define GK_FORMULA_FN(pv, acc, flags, rows, heap, bounds) jit_formulas(pv, acc, flags, rows, heap, bounds)\n" +
