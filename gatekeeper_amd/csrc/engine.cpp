@@ -156,7 +156,7 @@ struct gk_table {
   HostTable host;               // rows/heap released after upload unless needed
   std::vector<ReviewDoc> docs;  // GK_TABLE_KEEP_DOCS
   std::vector<std::string> review_errors;
-  uint64_t dir_bytes = 0, n_rows = 0;      // directory + review-flag bytes (read by every launch); rows in the table
+  uint64_t dir_bytes = 0, n_rows = 0;      // review-flag bytes (read by every launch); rows in the table
   std::vector<uint32_t> path_rows;          // rows per path: which rows a plan reads
   std::vector<uint32_t> path_max;           // per element path: largest array of one review
   bool resident = false;

@@ -363,7 +363,7 @@ void Flattener::add(const ReviewDoc& doc, HostTable* out) {
 }
 
 // Close the current tile: stable sort of its rows by path (keeps review order, then document order, inside a
-// segment) and one directory entry per distinct path.
+// segment) and one segment record per distinct path (turned into the slot index by build_index).
 void Flattener::flush_tile(HostTable* out) {
   out->tile_seg.push_back((uint32_t)out->segs.size());
   order_.resize(stage_.size());
