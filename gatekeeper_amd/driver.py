@@ -146,6 +146,31 @@ class EvalResult:
         return sorted(out)
 
 
+def process_validation_results(results):
+    """Row a12 -- pkg/webhook/policy.go:265-399: the deny / warn message lists the validating webhook builds from the hot
+    path's results ("[<constraint name>] <msg>", :390,394).  Results without a constraint, with an unknown enforcement
+    action, or scoped results without a valid scoped action are skipped (validatedEnforcementActions, :478-502)."""
+    deny, warn = [], []
+    for r in results:
+        if r is None or r.constraint is None:
+            continue
+        if r.enforcement_action == "scoped":
+            actions = [a for a in (r.scoped_enforcement_actions or []) if a in ("deny", "dryrun", "warn")]
+            if not actions:
+                continue
+        elif r.enforcement_action in ("deny", "dryrun", "warn"):
+            actions = [r.enforcement_action]
+        else:
+            continue
+        name = (r.constraint.get("metadata") or {}).get("name", "")
+        for a in actions:
+            if a == "deny":
+                deny.append("[%s] %s" % (name, r.msg))
+            elif a == "warn":
+                warn.append("[%s] %s" % (name, r.msg))
+    return deny, warn
+
+
 def truncate_string(s, size):
     """pkg/audit/manager.go:1039-1048: Go slices bytes."""
     b = s.encode("utf-8")

@@ -242,3 +242,21 @@ SVQ_ITEMS = [
 ]
 SVQ_POP_ORDER = [2, 0, 1]          # sv3, sv1, sv2
 LIMITQ2_REMAINING = [0, 1]         # limit 2 keeps sv1, sv2 (pops sv1 then sv2)
+
+
+# pkg/webhook/policy_test.go:1303-1339 (mixed results -> 2 deny, 2 warn) and :1395-1536 (count table), hand-transcribed:
+# (name, [(msg, constraint name or None, enforcementAction, scopedEnforcementActions)], deny count, warn count)
+PROCESS_RESULTS_CASES = [
+    ("Only One Dry Run", [("test", "c", "dryrun", None)], 0, 0),
+    ("Only One Deny", [("test", "c", "deny", None)], 1, 0),
+    ("Only One Warn", [("test", "c", "warn", None)], 0, 1),
+    ("One Dry Run and One Deny", [("test", "c", "dryrun", None), ("test", "c", "deny", None)], 1, 0),
+    ("One Dry Run, One Deny, One Warn", [("test", "c", "dryrun", None), ("test", "c", "deny", None), ("test", "c", "warn", None)], 1, 1),
+    ("Two Deny", [("test", "c", "deny", None), ("test", "c", "deny", None)], 2, 0),
+    ("Two Warn", [("test", "c", "warn", None), ("test", "c", "warn", None)], 0, 2),
+    ("Two Dry Run", [("test", "c", "dryrun", None), ("test", "c", "dryrun", None)], 0, 0),
+    ("Random EnforcementAction", [("test", "c", "random", None)], 0, 0),
+    ("export test mix (:1303-1339)", [None, ("missing constraint", None, "deny", None), ("deny", "deny", "deny", None),
+                                      ("warn", "warn", "warn", None), ("dryrun", "dryrun", "dryrun", None),
+                                      ("scoped", "scoped", "scoped", ["deny", "warn"]), ("invalid", "invalid", "invalid", None)], 2, 2),
+]

@@ -116,3 +116,27 @@ def test_limit_queue():
     for it in items:
         q.push(it)
     assert sorted(items.index(x) for x in q.items) == T.LIMITQ2_REMAINING
+
+
+def test_process_validation_results_a12():
+    """Row a12: deny / warn message lists (pkg/webhook/policy.go:265-399), oracle and product host mirror against the
+    reference's own table (policy_test.go:1303-1339, :1395-1536) and the "[<name>] <msg>" format (:390,394)."""
+    from golden.reference_tables import PROCESS_RESULTS_CASES
+    from oracle import client as OC
+    from oracle import webhook as OW
+    from gatekeeper_amd import driver as D
+    for name, rows, n_deny, n_warn in PROCESS_RESULTS_CASES:
+        for mod, proc in ((OC, OW.process_validation_results), (D, D.process_validation_results)):
+            res = []
+            for r in rows:
+                if r is None:
+                    res.append(None)
+                    continue
+                msg, cname, ea, scoped = r
+                c = {"kind": "Foo", "metadata": {"name": cname}, "spec": {"enforcementAction": ea}} if cname else None
+                res.append(mod.Result(msg, c, {}, ea, scoped))
+            deny, warn = proc(res)
+            assert (len(deny), len(warn)) == (n_deny, n_warn), (name, mod.__name__)
+    deny, warn = D.process_validation_results([D.Result("m1", {"metadata": {"name": "c1"}}, {}, "deny", None),
+                                               D.Result("m2", {"metadata": {"name": "c2"}}, {}, "scoped", ["warn", "bogus"])])
+    assert deny == ["[c1] m1"] and warn == ["[c2] m2"]
