@@ -45,6 +45,30 @@ def cpu_baseline(templates, constraints, objs, nss, budget_s=15.0):
                       "interpreter; the Go/OPA reference is not runnable here), %.1f s" % (n, len(constraints), dt)}
 
 
+def cxx_host_rate(client, objs, nss, budget_s=5.0):
+    """Orientation only (not the cpu_baseline): the engine's own host-side C++ evaluator -- the tree-walking Rego
+    evaluation that renders messages for violating pairs -- run over EVERY (constraint, review) pair of a sample on one
+    core, i.e. a compiled CPU execution of the same templates, without the match step."""
+    from gatekeeper_amd import driver as D
+    from gatekeeper_amd import synth
+    sample = objs[:512]
+    rins = [D.to_review_in(D.AugmentedUnstructured(D.Unstructured(o), synth.namespace_for(o, nss), "Original")) for o in sample]
+    table = client.driver.engine.create_table(rins, keep_docs=True)
+    cids = [client.driver.constraint_id(c) for c in client.constraints.values()]
+    t0 = time.perf_counter()
+    n = 0
+    for r in range(len(sample)):
+        for cid in cids:
+            table.render(cid, r)
+        n += len(cids)
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    table.free()
+    return {"value": n / dt, "unit": "evals/s", "cores": 1,
+            "what": "gk_render (host C++ tree-walking evaluation of the template for one pair, incl. the ctypes call) over %d pairs" % n}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -147,6 +171,7 @@ def main():
             pass
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(templates, constraints, objs[:20000], nss)
+            out["cpu_host_evaluator_cxx"] = cxx_host_rate(client, objs, nss)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
