@@ -84,7 +84,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("GK_FORCE_DIST"):   # GK_FORCE_DIST=1: exercise the sharded path on one GPU (world size 1)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
@@ -150,7 +150,7 @@ def main():
                                     "%d synthetic Pod AdmissionReviews per GPU" % args.reviews) if args.config == 1 else
                        ("configs[2]: audit sweep, 50 constraints x %d mixed synthetic cluster objects per GPU" % args.reviews),
                        "constraints": nc, "reviews_per_gpu": args.reviews, "rows_per_gpu": int(res.n_rows), "rows_read_per_gpu": int(res.n_rows_read),
-                       "parallelism": "objects sharded across %d GPU(s); RCCL all-gather of violation bitmaps + all-reduce of counts" % world,
+                       "parallelism": "objects sharded across %d GPU(s); one RCCL all-gather of [violation bitmaps | counts] per sweep" % world,
                        "violating_pairs_rank0": int(counts.sum())},
             "roofline": {"bound": "hbm", "kernel": "gk_eval_tiles", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algo_bytes_per_launch": int(res.algo_bytes),

@@ -27,7 +27,13 @@ def _d2d(dst_ptr, src_ptr, nbytes):
 
 
 class ShardedSweep:
-    """One rank's shard of the audited objects, resident in HBM, plus the exchange buffers."""
+    """One rank's shard of the audited objects, resident in HBM, plus the exchange buffers.
+
+    Exchange step of a pass: ONE all-gather of `[violation bitmap | per-constraint counts]` (bytes) per rank, so every
+    rank ends with all shards' bitmaps and counts; the global totals are the sum of the gathered counts (`total_counts`).
+    On the device path nothing waits on the host between passes: kernel, the two device-to-device copies into the
+    staging buffer and the collective are ordered by the stream; the host synchronises once, when the passes are
+    collected."""
 
     def __init__(self, client, objs, namespaces, dist=None, device=None):
         self.client = client
@@ -38,19 +44,38 @@ class ShardedSweep:
         self.n = len(objs)
         self.nc = len(client.constraints)
         self.n_tiles = (self.n + 63) // 64
-        self.gathered = self.total_counts = None
+        self.bm_bytes = self.nc * self.n_tiles * 8
+        self.stage = self.gathered_raw = None
         self.on_device = device is not None and str(device).startswith("cuda")
+        self._ptrs = None            # (d_viol, d_counts) of the table's result buffers, known after the first collect
         if dist is not None:
             import torch
-            w = dist.get_world_size()
-            self.local_bm = torch.empty(self.nc * self.n_tiles, dtype=torch.int64, device=device)
-            self.gathered = torch.empty(w * self.nc * self.n_tiles, dtype=torch.int64, device=device)
-            self.total_counts = torch.empty(self.nc, dtype=torch.int32, device=device)
+            self.world = dist.get_world_size()
+            self.stage = torch.zeros(self.bm_bytes + self.nc * 4, dtype=torch.uint8, device=device)
+            self.gathered_raw = torch.zeros(self.world * self.stage.numel(), dtype=torch.uint8, device=device)
+
+    # -- views of the gathered bytes ---------------------------------------------------------------------------------
+    @property
+    def gathered(self):
+        """[world * n_constraints * n_tiles] int64: every rank's violation bitmap, rank-major."""
+        import torch
+        g = self.gathered_raw.view(self.world, -1)[:, :self.bm_bytes].contiguous()
+        return g.view(torch.int64).reshape(-1)
+
+    @property
+    def total_counts(self):
+        """[n_constraints] int32: violating objects per constraint over all shards."""
+        import torch
+        c = self.gathered_raw.view(self.world, -1)[:, self.bm_bytes:].contiguous().view(torch.int32)
+        return c.reshape(self.world, self.nc).sum(0, dtype=torch.int32)
+
+    def _exchange(self):
+        self.dist.all_gather_into_tensor(self.gathered_raw, self.stage)
 
     def sweep(self, steps=1, download=False):
         """`steps` passes of the hot path over the resident shard.  Single GPU: the launches are enqueued back to back
-        and collected once.  Sharded: every pass is followed by its exchange step (all-gather of bitmaps, all-reduce of
-        counts).  Returns the EvalResult of the last pass (kernel time = average over the passes)."""
+        and collected once.  Sharded: every pass is followed by its exchange step.  Returns the EvalResult of the last
+        pass (kernel time = average over the passes)."""
         if self.dist is None:
             for _ in range(steps):
                 self.table.launch()
@@ -59,24 +84,37 @@ class ShardedSweep:
         ev = None
         if not self.on_device:
             # CPU path of the exchange (gloo; used by tests/test_sweep_dist.py with the test-only emulated kernels):
-            # same collectives on host tensors built from the downloaded bitmaps
+            # the same staging layout and collective on host tensors built from the downloaded results
             import numpy as np
             for _ in range(steps):
                 ev = self.table.eval(download=True)
-                self.local_bm.copy_(torch.from_numpy(ev.viol.reshape(-1).view(np.int64).copy()))
-                self.total_counts.copy_(torch.from_numpy(ev.counts.astype(np.int32)))
-                self.dist.all_gather_into_tensor(self.gathered, self.local_bm)
-                self.dist.all_reduce(self.total_counts)
+                raw = np.concatenate([ev.viol.reshape(-1).view(np.uint8), ev.counts.astype(np.int32).view(np.uint8)])
+                self.stage.copy_(torch.from_numpy(raw.copy()))
+                self._exchange()
             return ev
-        for _ in range(steps):
+        done = 0
+        if self._ptrs is None and steps > 0:
+            # first pass ever: one collect to learn where the table's result buffers live (stable afterwards)
             self.table.launch()
-            ev = self.table.eval(download=False, collect_only=True)   # sync: bitmaps of THIS pass are complete
-            _d2d(self.local_bm.data_ptr(), ev.d_viol, self.nc * self.n_tiles * 8)
-            _d2d(self.total_counts.data_ptr(), ev.d_counts, self.nc * 4)
-            torch.cuda.current_stream().synchronize()
-            self.dist.all_gather_into_tensor(self.gathered, self.local_bm)
-            self.dist.all_reduce(self.total_counts)
+            ev = self.table.eval(download=False, collect_only=True)
+            self._ptrs = (ev.d_viol, ev.d_counts)
+            self._stage_and_exchange()
+            done = 1
+        for _ in range(done, steps):
+            self.table.launch()
+            self._stage_and_exchange()
+        if steps > done:
+            ev = self.table.eval(download=False, collect_only=True)   # the one host synchronisation of the sweep
+            self._ptrs = (ev.d_viol, ev.d_counts)
+        torch.cuda.current_stream().synchronize()
         if download:
             self.table.launch()
             ev = self.table.eval(download=True, collect_only=True)
         return ev
+
+    def _stage_and_exchange(self):
+        d_viol, d_counts = self._ptrs
+        base = self.stage.data_ptr()
+        _d2d(base, d_viol, self.bm_bytes)
+        _d2d(base + self.bm_bytes, d_counts, self.nc * 4)
+        self._exchange()

@@ -1,5 +1,5 @@
 """Multi-GPU path on CPU: world_size 2, gloo.  Objects are block-sharded across ranks, each rank sweeps its shard and
-the per-shard violation bitmaps are all-gathered / the per-constraint counts all-reduced (gatekeeper_amd/sweep.py).
+the per-shard violation bitmaps are all-gathered together with the per-constraint counts (gatekeeper_amd/sweep.py).
 The gathered result must equal the single-process sweep over all objects, bit for bit."""
 import os
 import socket
