@@ -31,11 +31,9 @@ class ShardedSweep:
 
     Exchange step of a pass: ONE all-gather of `[violation bitmap | per-constraint counts]` (bytes) per rank, so every
     rank ends with all shards' bitmaps and counts; the global totals are the sum of the gathered counts (`total_counts`).
-    On the device path nothing waits on the host between passes, and the exchange of pass k overlaps the kernel of pass
-    k+1: the kernel and the two device-to-device copies into a staging buffer run on the compute stream, the collective
-    is issued asynchronously (RCCL's own stream, ordered after the copies), and the two staging buffers alternate -- a
-    buffer is only rewritten after the collective that read it has completed (stream-level wait).  The host
-    synchronises once, when the passes are collected."""
+    On the device path nothing waits on the host between passes: kernel, the two device-to-device copies into the
+    staging buffer and the collective are ordered by the stream; the host synchronises once, when the passes are
+    collected."""
 
     def __init__(self, client, objs, namespaces, dist=None, device=None):
         self.client = client
@@ -53,11 +51,8 @@ class ShardedSweep:
         if dist is not None:
             import torch
             self.world = dist.get_world_size()
-            self.stages = [torch.zeros(self.bm_bytes + self.nc * 4, dtype=torch.uint8, device=device) for _ in range(2)]
-            self.stage = self.stages[0]
+            self.stage = torch.zeros(self.bm_bytes + self.nc * 4, dtype=torch.uint8, device=device)
             self.gathered_raw = torch.zeros(self.world * self.stage.numel(), dtype=torch.uint8, device=device)
-            self._works = [None, None]   # outstanding collective per staging buffer
-            self._pass = 0
 
     # -- views of the gathered bytes ---------------------------------------------------------------------------------
     @property
@@ -108,10 +103,6 @@ class ShardedSweep:
         for _ in range(done, steps):
             self.table.launch()
             self._stage_and_exchange()
-        for i, w in enumerate(self._works):   # the compute stream (and then the host) waits for the last exchanges
-            if w is not None:
-                w.wait()
-                self._works[i] = None
         if steps > done:
             ev = self.table.eval(download=False, collect_only=True)   # the one host synchronisation of the sweep
             self._ptrs = (ev.d_viol, ev.d_counts)
@@ -123,11 +114,7 @@ class ShardedSweep:
 
     def _stage_and_exchange(self):
         d_viol, d_counts = self._ptrs
-        k = self._pass % 2
-        self._pass += 1
-        if self._works[k] is not None:       # the collective that last read this staging buffer must be done
-            self._works[k].wait()
-        base = self.stages[k].data_ptr()
+        base = self.stage.data_ptr()
         _d2d(base, d_viol, self.bm_bytes)
         _d2d(base + self.bm_bytes, d_counts, self.nc * 4)
-        self._works[k] = self.dist.all_gather_into_tensor(self.gathered_raw, self.stages[k], async_op=True)
+        self._exchange()
