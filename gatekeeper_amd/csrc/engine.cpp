@@ -140,6 +140,7 @@ struct gk_engine {
   // plan cache
   std::mutex plan_mu;
   bool plan_dirty = true;
+  uint64_t plan_gen = 0;   // bumped whenever the device plan (and with it every variant) is rebuilt
   HostPlan fast, big;
   DevPlan* dev_plan = nullptr;
   std::vector<uint32_t> plan_ids;   // bitmap row -> constraint id
@@ -160,6 +161,9 @@ struct gk_table {
   std::vector<uint32_t> path_rows;          // rows per path: which rows a plan reads
   std::vector<uint32_t> path_max;           // per element path: largest array of one review
   bool resident = false;
+  uint64_t cached_gen = 0;                  // plan generation the cached variant choice belongs to
+  DevPlan* cached_plan = nullptr;
+  const HostPlan* cached_host = nullptr;
   std::vector<uint32_t> slot_path;          // path of each slot of the table's row-group index
   std::vector<std::string> obj_keys;        // per review: group \0 version \0 kind \0 namespace \0 name (audit order, manager.go:118-138)
   std::vector<uint32_t> order, grp;         // reviews sorted by obj_keys / dense rank with ties equal (built by the first gk_table_topk)
@@ -199,9 +203,10 @@ PlanCaps default_caps(const gk_engine* e) {
 // Plan for one table.  Resident tables (audit sets evaluated again and again) get a variant whose element capacities
 // are what the table's largest arrays need: fewer accumulator words per review -> more tiles resident per CU, and
 // reviews that would overflow the default capacities stay on the LDS kernel.  Caller holds plan_mu; ensure_plan ran.
-DevPlan* plan_for_table(gk_engine* e, const gk_table* t, const HostPlan** host) {
+DevPlan* plan_for_table(gk_engine* e, gk_table* t, const HostPlan** host) {
   *host = &e->fast;
   if (!t->resident || e->fast.scopes.empty()) return e->dev_plan;
+  if (t->cached_gen == e->plan_gen && t->cached_plan) { *host = t->cached_host; return t->cached_plan; }   // per launch: no rescan
   std::vector<uint16_t> caps(e->fast.scopes.size(), 1);
   for (size_t p = 0; p < e->fast.ptab.size(); p++) {
     uint32_t ent = e->fast.ptab[p];
@@ -232,8 +237,10 @@ DevPlan* plan_for_table(gk_engine* e, const gk_table* t, const HostPlan** host) 
     } catch (const std::exception&) { v->dev = nullptr; }   // e.g. LDS limit: the default plan serves the table
     it = e->variants.emplace(caps, std::move(v)).first;
   }
-  if (!it->second->dev) return e->dev_plan;
+  t->cached_gen = e->plan_gen;
+  if (!it->second->dev) { t->cached_plan = e->dev_plan; t->cached_host = &e->fast; return e->dev_plan; }
   *host = &it->second->fast;
+  t->cached_plan = it->second->dev; t->cached_host = &it->second->fast;
   return it->second->dev;
 }
 
@@ -261,6 +268,7 @@ void ensure_plan(gk_engine* e) {
   }
   if (e->dev_plan) { dev_plan_free(e->dev_plan); e->dev_plan = nullptr; }
   e->dev_plan = dev_plan_upload(e->fast, e->big);
+  e->plan_gen++;
   e->plan_dirty = false;
 }
 

@@ -26,14 +26,22 @@ def _d2d(dst_ptr, src_ptr, nbytes):
         raise RuntimeError("hipMemcpyAsync failed: %d" % rc)
 
 
+class _DeviceBytes:
+    """A byte range in device memory owned by the engine, exposed through the CUDA array interface so that torch can
+    alias it without a copy."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
 class ShardedSweep:
     """One rank's shard of the audited objects, resident in HBM, plus the exchange buffers.
 
     Exchange step of a pass: ONE all-gather of `[violation bitmap | per-constraint counts]` (bytes) per rank, so every
     rank ends with all shards' bitmaps and counts; the global totals are the sum of the gathered counts (`total_counts`).
-    On the device path nothing waits on the host between passes: kernel, the two device-to-device copies into the
-    staging buffer and the collective are ordered by the stream; the host synchronises once, when the passes are
-    collected."""
+    On the device path nothing waits on the host between passes: the collective reads the engine's result buffer in
+    place (bitmap and counts are one contiguous allocation, aliased as a torch tensor) and is ordered after the kernels
+    by the stream; the host synchronises once, when the passes are collected."""
 
     def __init__(self, client, objs, namespaces, dist=None, device=None):
         self.client = client
@@ -48,6 +56,8 @@ class ShardedSweep:
         self.stage = self.gathered_raw = None
         self.on_device = device is not None and str(device).startswith("cuda")
         self._ptrs = None            # (d_viol, d_counts) of the table's result buffers, known after the first collect
+        self._alias = None           # torch view of the engine's [bitmap | counts] buffer (device path)
+        self._alias_ptr = None
         if dist is not None:
             import torch
             self.world = dist.get_world_size()
@@ -114,6 +124,18 @@ class ShardedSweep:
 
     def _stage_and_exchange(self):
         d_viol, d_counts = self._ptrs
+        if d_counts == d_viol + self.bm_bytes:
+            # the engine keeps [bitmap | counts] contiguous: gather straight from its buffer, no staging copies
+            if self._alias is None or self._alias_ptr != d_viol:
+                import torch
+                try:
+                    self._alias = torch.as_tensor(_DeviceBytes(d_viol, self.stage.numel()), device=self.stage.device)
+                except Exception:
+                    self._alias = False
+                self._alias_ptr = d_viol
+            if self._alias is not False:
+                self.dist.all_gather_into_tensor(self.gathered_raw, self._alias)
+                return
         base = self.stage.data_ptr()
         _d2d(base, d_viol, self.bm_bytes)
         _d2d(base + self.bm_bytes, d_counts, self.nc * 4)

@@ -102,7 +102,8 @@ typedef struct {
   uint64_t n_rows;           /* rows in the table */
   uint32_t n_launches;       /* launches averaged in fast_kernel_ms (GK_EVAL_ASYNC enqueues without collecting) */
   uint32_t lds_bytes;        /* accumulator LDS bytes per tile of the plan variant that ran */
-  const void* d_viol;        /* device pointers to the same bitmaps / counts, valid until the table's next launch: */
+  const void* d_viol;        /* device pointers to the same bitmaps / counts, valid until the table's next launch;     */
+                             /* d_counts == d_viol + n_constraints*n_tiles*8: one contiguous [bitmap | counts] range:  */
   const void* d_err;         /* lets the caller hand them to RCCL (all-gather of per-shard violation bitmaps)      */
   const void* d_counts;
   uint64_t n_rows_read;      /* rows in the segments whose key path carries predicates of the current plan */
