@@ -7,6 +7,7 @@
 #include <atomic>
 #include <cstring>
 #include <algorithm>
+#include <chrono>
 #include <thread>
 #include <map>
 #include <memory>
@@ -49,15 +50,7 @@ bool wildcard_matches(const std::string& w, const std::string& c) {
   return w == c;
 }
 
-std::string selector_error(const Value& sel) {
-  const Value* me = sel.get("matchExpressions");
-  if (me && me->is_array())
-    for (auto& e : me->items()) {
-      std::string op = obj_string(e, "operator");
-      if (op != "In" && op != "NotIn" && op != "Exists" && op != "DoesNotExist") return "\"" + op + "\" is not a valid label selector operator";
-    }
-  return "";
-}
+std::string selector_error(const Value& sel) { return selector_error_text(sel); }
 
 // error text of match.Matches for one candidate object, "" if none (subset: the error sources of match.go)
 std::string candidate_error(const Value& m, const Value& obj, const Value& ns, int source, bool* matched) {
@@ -425,16 +418,22 @@ int gk_table_create(gk_engine* e, const gk_review_in* reviews, size_t n, uint32_
       try {
         Flattener fl(&e->dict);
         const size_t lo = std::min(n, w * tiles_per * GK_RPT), hi = std::min(n, (w + 1) * tiles_per * GK_RPT);
+        const bool prof = getenv("GK_PROFILE_HOST") != nullptr;   // coarse host-side timing of the three steps
+        double t_parse = 0, t_norm = 0, t_flat = 0;
+        auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         for (size_t i = lo; i < hi; i++) {
           const gk_review_in& r = reviews[i];
           ReviewDoc doc;
           int st = GK_OK;
+          double t0 = prof ? now() : 0, t1 = 0;
           try {
             Value body = parse_json(r.json, r.json_len);
             Value mns = parse_opt(r.namespace_json, r.namespace_len);
             Value nso = parse_opt(r.ns_object_json, r.ns_object_len);
+            if (prof) { t1 = now(); t_parse += t1 - t0; }
             if (r.kind == GK_REVIEW_OBJECT) doc = normalize_object(body, mns, nso, r.source, r.operation ? r.operation : "", e->ns_cache);
             else doc = normalize_admission_request(body, mns, nso, r.source, e->ns_cache);
+            if (prof) t_norm += now() - t1;
           } catch (const std::exception& ex) {
             st = GK_ERR_REVIEW;
             t->review_errors[i] = ex.what();
@@ -453,10 +452,13 @@ int gk_table_create(gk_engine* e, const gk_review_in* reviews, size_t n, uint32_
             }
             t->obj_keys[i] = std::move(key);
           }
+          double t2 = prof ? now() : 0;
           fl.add(doc, &parts[w]);
+          if (prof) t_flat += now() - t2;
           if (keep) t->docs[i] = doc;
         }
         fl.flush(&parts[w]);
+        if (prof) fprintf(stderr, "[gkgpu host] part %zu: %zu reviews, parse %.3f s, normalise %.3f s, flatten %.3f s\n", w, hi - lo, t_parse, t_norm, t_flat);
       } catch (const std::exception& ex) { part_err[w] = ex.what(); }
     };
     if (n_threads <= 1) work(0);

@@ -59,32 +59,49 @@ bool valid_label_value(const std::string& v) {
 struct Req { std::string key; int op; std::vector<std::string> vals; };   // op: 0 In/Equals, 1 NotIn, 2 Exists, 3 DoesNotExist
 
 // metav1.LabelSelectorAsSelector: false => conversion error; *everything => empty selector
-bool selector_reqs(const Value& sel, std::vector<Req>* reqs, bool* everything) {
+// The conversion with its error text (labels.NewRequirement / LabelSelectorAsSelector validation, in evaluation order:
+// matchLabels by sorted key, then matchExpressions as listed).  "" = valid.  The same function decides the device's
+// error formula (compile_match) and words the host's autoreject message (engine.cpp), so the two cannot disagree.
+static std::string selector_convert(const Value& sel, std::vector<Req>* reqs, bool* everything) {
   *everything = false;
   const Value* ml = sel.get("matchLabels");
   const Value* me = sel.get("matchExpressions");
   size_t n = (ml && ml->is_object() ? ml->size() : 0) + (me && me->is_array() ? me->size() : 0);
-  if (n == 0) { *everything = true; return true; }
-  if (ml && ml->is_object())
-    for (auto& kv : ml->pairs()) {
-      if (!kv.first.is_string() || !kv.second.is_string()) return false;
-      if (!valid_label_key(kv.first.str()) || !valid_label_value(kv.second.str())) return false;
-      reqs->push_back({kv.first.str(), 0, {kv.second.str()}});
+  if (n == 0) { *everything = true; return ""; }
+  auto bad_key = [](const std::string& k) { return "key: Invalid value: \"" + k + "\": name part must be non-empty"; };
+  auto bad_val = [](const std::string& k, const std::string& v) { return "values[0][" + k + "]: Invalid value: \"" + v + "\""; };
+  if (ml && ml->is_object()) {
+    std::vector<std::pair<std::string, const Value*>> kv;
+    for (auto& p : ml->pairs()) kv.emplace_back(p.first.is_string() ? p.first.str() : std::string(), &p.second);
+    std::sort(kv.begin(), kv.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+    for (auto& p : kv) {
+      if (!valid_label_key(p.first)) return bad_key(p.first);
+      if (!p.second->is_string() || !valid_label_value(p.second->str())) return bad_val(p.first, p.second->is_string() ? p.second->str() : to_json(*p.second));
+      reqs->push_back({p.first, 0, {p.second->str()}});
     }
+  }
   if (me && me->is_array())
     for (auto& e : me->items()) {
       std::string op = obj_string(e, "operator"), key = obj_string(e, "key");
       int o = op == "In" ? 0 : op == "NotIn" ? 1 : op == "Exists" ? 2 : op == "DoesNotExist" ? 3 : -1;
-      if (o < 0 || !valid_label_key(key)) return false;
+      if (o < 0) return "\"" + op + "\" is not a valid label selector operator";
+      if (!valid_label_key(key)) return bad_key(key);
       std::vector<std::string> vals;
       const Value* vs = e.get("values");
-      if (vs && vs->is_array()) for (auto& v : vs->items()) { if (!v.is_string() || !valid_label_value(v.str())) return false; vals.push_back(v.str()); }
-      if (o <= 1 && vals.empty()) return false;
-      if (o >= 2 && !vals.empty()) return false;
+      size_t nvals = vs && vs->is_array() ? vs->size() : 0;
+      if (o <= 1 && nvals == 0) return "values: Invalid value: []: for 'in', 'notin' operators, values set can't be empty";
+      if (o >= 2 && nvals != 0) return "values: Invalid value: values set must be empty for exists and does not exist";
+      if (vs && vs->is_array())
+        for (auto& v : vs->items()) {
+          if (!v.is_string() || !valid_label_value(v.str())) return bad_val(key, v.is_string() ? v.str() : to_json(v));
+          vals.push_back(v.str());
+        }
       reqs->push_back({key, o, vals});
     }
-  return true;
+  return "";
 }
+
+bool selector_reqs(const Value& sel, std::vector<Req>* reqs, bool* everything) { return selector_convert(sel, reqs, everything).empty(); }
 
 FP selector_f(const std::vector<Req>& reqs, const SPath& labels, uint32_t bad_flag) {
   FP nb = f_not(flag_f(bad_flag));
@@ -200,6 +217,13 @@ void match_candidate(const Value& m, const CandFlags& c, FP* out_match, FP* out_
 }
 
 }  // namespace
+
+std::string selector_error_text(const Value& sel) {
+  std::vector<Req> reqs;
+  bool everything;
+  return selector_convert(sel, &reqs, &everything);
+}
+
 
 MatchFormulas compile_match(const Value& m) {
   if (!m.defined() || !m.is_object()) return {f_true(), f_false()};

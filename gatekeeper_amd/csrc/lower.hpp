@@ -21,6 +21,8 @@ struct MatchFormulas {
 };
 // spec.match of a constraint (Undefined / null => match everything, target.go:246-261)
 MatchFormulas compile_match(const Value& match_spec);
+// error text of metav1.LabelSelectorAsSelector for a selector ("" = valid); same validation compile_match applies
+std::string selector_error_text(const Value& selector);
 
 struct PlanCaps {
   uint16_t level_cap[3] = {8, 12, 12};   // element capacity per array-nesting level

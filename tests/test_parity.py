@@ -85,6 +85,86 @@ def test_match_table(backend, fixtures):
                 assert res[0].msg == "denyall constraint installed"
 
 
+def _random_match_world(seed, n_cons, n_objs):
+    """Seeded random spec.match blocks (all 8 matchers, globs, selectors incl. invalid ones) and objects / namespaces."""
+    rng = synth.SplitMix64(seed)
+    pick = lambda xs: xs[rng.below(len(xs))]
+    ns_names = ["default", "prod-1", "prod-2", "dev-1", "kube-system", "team-a", "team-b"]
+    globs = ["prod-*", "*-system", "*-1", "dev-1", "team-?", "*", "*eam*", "default", "prod-2", "x*"]
+    kinds = [("", "Pod"), ("", "Namespace"), ("apps", "Deployment"), ("", "Service"), ("batch", "Job")]
+    label_keys, label_vals = ["env", "tier", "app", "x"], ["prod", "dev", "web", "db", ""]
+    def selector():
+        sel = {}
+        if rng.chance(0.5):
+            sel["matchLabels"] = {pick(label_keys): pick(label_vals) for _ in range(1 + rng.below(2))}
+        if rng.chance(0.6):
+            exprs = []
+            for _ in range(1 + rng.below(2)):
+                op = pick(["In", "NotIn", "Exists", "DoesNotExist", "In", "Bogus"])
+                e = {"key": pick(label_keys), "operator": op}
+                if op in ("In", "NotIn") or (op in ("Exists", "Bogus") and rng.chance(0.15)):
+                    e["values"] = [pick(label_vals) for _ in range(rng.below(3))]   # may be empty (invalid for In/NotIn)
+                exprs.append(e)
+            sel["matchExpressions"] = exprs
+        return sel
+    cons = []
+    for i in range(n_cons):
+        m = {}
+        if rng.chance(0.5):
+            m["kinds"] = [{"apiGroups": [pick(["", "apps", "*", "batch"])] if rng.chance(0.8) else [],
+                           "kinds": [pick(["Pod", "Deployment", "*", "Namespace", "Service"]) for _ in range(1 + rng.below(2))] if rng.chance(0.85) else []}
+                          for _ in range(1 + rng.below(2))]
+        if rng.chance(0.3):
+            m["scope"] = pick(["*", "Cluster", "Namespaced", "Typo"])
+        if rng.chance(0.35):
+            m["namespaces"] = [pick(globs) for _ in range(1 + rng.below(2))]
+        if rng.chance(0.3):
+            m["excludedNamespaces"] = [pick(globs) for _ in range(1 + rng.below(2))]
+        if rng.chance(0.35):
+            m["labelSelector"] = selector()
+        if rng.chance(0.3):
+            m["namespaceSelector"] = selector()
+        if rng.chance(0.25):
+            m["name"] = pick(["web-*", "*-0", "db", "*e*", "*"])
+        if rng.chance(0.2):
+            m["source"] = pick(["All", "Original", "Generated", "Nope"])
+        c = {"apiVersion": "constraints.gatekeeper.sh/v1beta1", "kind": "DenyAll", "metadata": {"name": "c%d" % i}}
+        if m or rng.chance(0.5):
+            c["spec"] = {"match": m}
+        cons.append(c)
+    nss = {n: {"apiVersion": "v1", "kind": "Namespace", "metadata": {"name": n, "labels": {pick(label_keys): pick(label_vals) for _ in range(rng.below(3))}}}
+           for n in ns_names}
+    reviews = []
+    for j in range(n_objs):
+        g, k = pick(kinds)
+        meta = {"name": pick(["web-0", "web-1", "db", "cache-0", "e"])}
+        if rng.chance(0.15):
+            meta = {"generateName": pick(["web-", "db-", "e"])}
+        if rng.chance(0.7):
+            meta["labels"] = {pick(label_keys): pick(label_vals) for _ in range(rng.below(3))}
+        if k == "Namespace":
+            meta["name"] = pick(ns_names)
+        elif rng.chance(0.8):
+            meta["namespace"] = pick(ns_names)
+        obj = {"apiVersion": (g + "/v1") if g else "v1", "kind": k, "metadata": meta}
+        ns = nss.get(meta.get("namespace")) if rng.chance(0.75) else None      # sometimes the Namespace object is missing
+        src = pick(["Original", "Generated", "", "Original"])
+        reviews.append((D.AugmentedUnstructured(D.Unstructured(obj), ns, src), ns))
+    return cons, reviews
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_match_randomised(backend, fixtures):
+    """Differential test of the compiled Match layer (pkg/mutation/match/match.go:32-258 incl. its error paths and the
+    autoreject messages) against the oracle on seeded random match blocks x objects."""
+    tmpl = fixtures["go_consts"]["pkg/target/target_integration_test.go"]["testTemplate"]["docs"][0]
+    for seed in (101, 202):
+        cons, reviews = _random_match_world(seed, 60, 150)
+        c, oc = load_both(backend, [tmpl], cons)
+        total = assert_parity(c, oc, [r for r, _ in reviews])
+        assert total > 100
+
+
 @pytest.mark.parametrize("backend", BACKENDS)
 def test_constraint_enforcement(backend, fixtures):
     """pkg/target/target_integration_test.go:163-527: 26 scenarios x 3 review shapes, batched into one launch each."""
