@@ -1004,7 +1004,9 @@ void HostPlan::resolve_paths(const PathDict& dict) {
         for (uint32_t ch : children[id]) {
           const PathDict::Info& in = infos[ch];
           if (!st.any) { if (!in.is_elem && in.key == st.key) nxt.push_back(ch); continue; }
-          if (in.is_elem) { if (st.only.empty() && st.except.empty()) nxt.push_back(ch); continue; }
+          // array elements under a key iteration: the key is a numeric index, which differs from every string in an
+          // `except` list and equals none in an `only` list
+          if (in.is_elem) { if (st.only.empty()) nxt.push_back(ch); continue; }
           if (st.elems_only) continue;
           if (!st.only.empty() && std::find(st.only.begin(), st.only.end(), in.key) == st.only.end()) continue;
           if (std::find(st.except.begin(), st.except.end(), in.key) != st.except.end()) continue;

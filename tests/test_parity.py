@@ -297,6 +297,65 @@ def test_audit_aggregation(backend, fixtures):
         assert sum(len(v["violations"]) for v in got.values()) == sum(len(q.items) for q in lists.values()) > 0
 
 
+def _mutate(rng, v):
+    """random structural mutation of a JSON value: dropped / added members, duplicated elements, subtrees replaced by
+    scalars of the wrong type, numeric edge cases, long and non-ASCII strings"""
+    pick = lambda xs: xs[rng.below(len(xs))]
+    scalars = [None, True, False, 0, 1, -1, 80, 65535, 65536, 9000.5, 1e3, 2 ** 53, 2 ** 63, -2 ** 63, "", "x", "true", "privileged", "/foo/bar",
+               "hostPath", "a-very-long-string-value-exceeding-twelve-bytes", "\u00fcn\u00efc\u00f6d\u00e9", "0", "80", [], {}, [1, "a"], {"a": 1}]
+    if rng.chance(0.08):
+        return pick(scalars)
+    if isinstance(v, dict):
+        out = {k: _mutate(rng, x) for k, x in v.items() if not rng.chance(0.04)}
+        if rng.chance(0.05):
+            out[pick(["extra", "name", "hostPath", "privileged", "readOnly", "x-y"])] = pick(scalars)
+        return out
+    if isinstance(v, list):
+        out = [_mutate(rng, x) for x in v if not rng.chance(0.05)]
+        if out and rng.chance(0.1):
+            out.append(json.loads(json.dumps(out[0])))
+        if rng.chance(0.03):
+            out.append(pick(scalars))
+        return out
+    return v
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_structural_fuzz(backend, fixtures):
+    """Seeded structural fuzzing of the reviewed objects (wrong types, missing members, arrays where objects are expected
+    -- e.g. key iteration over an array yields numeric keys) through flattener, compiled predicates and renderer, against
+    the oracle; object and AdmissionRequest (CREATE / UPDATE / DELETE with oldObject) shapes."""
+    nss = synth.gen_namespaces()
+    c, oc = load_both(backend, synth.psp_templates(fixtures), synth.audit_constraints())
+    for seed in (1, 22):
+        rng = synth.SplitMix64(seed)
+        revs = []
+        for o in synth.gen_objects(220, seed=seed, mixed=True):
+            m = _mutate(rng, _mutate(rng, o))
+            if not isinstance(m, dict):
+                m = {"apiVersion": "v1", "kind": "Pod", "metadata": {"name": "m"}}
+            md = m.get("metadata")
+            ns = synth.namespace_for(m, nss) if isinstance(md, dict) and isinstance(md.get("namespace"), str) else None
+            shape = rng.below(4)
+            if shape == 0:
+                revs.append(D.AugmentedUnstructured(D.Unstructured(m), ns, "Original"))
+                continue
+            api = m.get("apiVersion") if isinstance(m.get("apiVersion"), str) else "v1"
+            g, _, ver = api.rpartition("/")
+            req = {"kind": {"group": g, "version": ver, "kind": m.get("kind") if isinstance(m.get("kind"), str) else ""},
+                   "operation": ["CREATE", "UPDATE", "DELETE"][shape - 1]}
+            if isinstance(md, dict) and isinstance(md.get("namespace"), str):
+                req["namespace"] = md["namespace"]
+            if shape == 1:
+                req["object"] = m
+            elif shape == 2:
+                req["object"], req["oldObject"] = m, _mutate(rng, m)
+            else:
+                req["oldObject"] = m
+            revs.append(D.AugmentedReview(D.AdmissionRequest(req), ns, "Original"))
+        assert assert_parity(c, oc, revs) > 50
+
+
 REGEX_TEMPLATE = {
     "apiVersion": "templates.gatekeeper.sh/v1", "kind": "ConstraintTemplate", "metadata": {"name": "k8slabelregex"},
     "spec": {"crd": {"spec": {"names": {"kind": "K8sLabelRegex"}}},
