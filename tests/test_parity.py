@@ -326,8 +326,8 @@ def test_structural_fuzz(backend, fixtures):
     -- e.g. key iteration over an array yields numeric keys) through flattener, compiled predicates and renderer, against
     the oracle; object and AdmissionRequest (CREATE / UPDATE / DELETE with oldObject) shapes."""
     nss = synth.gen_namespaces()
-    c, oc = load_both(backend, synth.psp_templates(fixtures), synth.audit_constraints())
-    for seed in (1, 22):
+    for seed, caps in ((1, None), (22, (2, 3, 2))):   # tiny element capacities: most reviews take the large-variant kernel
+        c, oc = load_both(backend, synth.psp_templates(fixtures), synth.audit_constraints(), **({"elem_cap": caps} if caps else {}))
         rng = synth.SplitMix64(seed)
         revs = []
         for o in synth.gen_objects(220, seed=seed, mixed=True):
@@ -397,6 +397,50 @@ def test_regex_predicates(backend):
     objs.append({"apiVersion": "v1", "kind": "Pod", "metadata": {"name": "nolabels", "namespace": "default"}})
     objs.append({"apiVersion": "v1", "kind": "Pod", "metadata": {"name": "numlabel", "namespace": "default", "labels": {"owner": 5}}})
     assert_parity(c, oc, [D.AugmentedUnstructured(D.Unstructured(o), None, "Original") for o in objs])
+
+
+def _random_regex(rng, depth=0):
+    pick = lambda xs: xs[rng.below(len(xs))]
+    atoms = ["a", "b", "c", "0", "1", "-", ".", "[ab]", "[^a]", "[0-9]", "\\d", "\\w", "[a-c0-1]", "x"]
+
+    def piece():
+        a = "(" + _random_regex(rng, depth + 1) + ")" if depth < 2 and rng.chance(0.25) else pick(atoms)
+        return a + pick(["", "", "", "*", "+", "?", "{2}", "{1,2}", "{0,1}", "*?"])
+
+    def seq():
+        return "".join(piece() for _ in range(1 + rng.below(4)))
+    r = seq()
+    while rng.chance(0.25):
+        r += "|" + seq()
+    if depth == 0:
+        r = ("^" if rng.chance(0.4) else "") + r + ("$" if rng.chance(0.4) else "")
+    return r
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_regex_randomised(backend):
+    """Seeded random patterns (groups, alternation, classes, bounded and lazy repetition, anchors) x random strings: the
+    DFA predicate on the device path against the oracle."""
+    rng = synth.SplitMix64(5)
+    pats = []
+    while len(pats) < 30:
+        rx = _random_regex(rng)
+        probe = make_client(backend)
+        probe.AddTemplate(REGEX_TEMPLATE)
+        try:
+            probe.AddConstraint({"apiVersion": "constraints.gatekeeper.sh/v1beta1", "kind": "K8sLabelRegex", "metadata": {"name": "t"},
+                                 "spec": {"parameters": {"labels": [{"key": "owner", "allowedRegex": rx}], "nameRegex": rx}}})
+            pats.append(rx)
+        except D.UnsupportedError:
+            pass   # automaton above the device limit of 255 states: reported, not approximated
+    cons = [{"apiVersion": "constraints.gatekeeper.sh/v1beta1", "kind": "K8sLabelRegex", "metadata": {"name": "re-%d" % i},
+             "spec": {"parameters": {"labels": [{"key": "owner", "allowedRegex": rx}], "nameRegex": pats[(i + 7) % len(pats)]}}}
+            for i, rx in enumerate(pats)]
+    c, oc = load_both(backend, [REGEX_TEMPLATE], cons)
+    al = "abc01-x."
+    rs = lambda: "".join(al[rng.below(len(al))] for _ in range(rng.below(16)))
+    objs = [{"apiVersion": "v1", "kind": "Pod", "metadata": {"name": rs() or "n", "namespace": "default", "labels": {"owner": rs()}}} for _ in range(100)]
+    assert assert_parity(c, oc, [D.AugmentedUnstructured(D.Unstructured(o), None, "Original") for o in objs]) > 100
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
