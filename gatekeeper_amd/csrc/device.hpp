@@ -40,6 +40,9 @@ std::string dev_init(int device);                       // "" on success, else e
 int dev_count();
 DevTable* dev_table_upload(const HostTable& t);
 void dev_table_free(DevTable* t);
+// A second handle on the same resident table with its own result buffers and path binding (plan groups beyond the
+// first evaluate through views); freeing a view leaves the table's arrays alone.  Free views before the table.
+DevTable* dev_table_view(DevTable* base);
 uint64_t dev_table_bytes(const DevTable* t);
 DevPlan* dev_plan_upload(const HostPlan& fast, const HostPlan& big);
 void dev_plan_free(DevPlan* p);

@@ -8,6 +8,7 @@
 #include <cstring>
 #include <algorithm>
 #include <chrono>
+#include <functional>
 #include <thread>
 #include <map>
 #include <memory>
@@ -139,6 +140,12 @@ struct gk_engine {
   std::vector<uint32_t> plan_ids;   // bitmap row -> constraint id
   // table-specialised variants of the fast plan (GK_TABLE_RESIDENT): same formulas, element capacities = what the
   // table's largest arrays need, so the per-review LDS footprint (hence occupancy) fits the data
+  // A plan holds at most 64 distinct violation / match formulas (one result bit each) and 32 element scopes.  Larger
+  // constraint sets are split: the first group is the primary plan above, the others are evaluated one after the
+  // other over the same resident table (each on its own view: result buffers + path binding) and their bitmap rows
+  // are appended, so callers see one [n_constraints][n_tiles] answer.
+  struct Group { HostPlan fast, big; DevPlan* dev = nullptr; std::vector<uint32_t> ids; };
+  std::vector<std::unique_ptr<Group>> extra;
   struct Variant { HostPlan fast; DevPlan* dev = nullptr; };
   std::map<std::vector<uint16_t>, std::unique_ptr<Variant>> variants;
   std::string last_dump;
@@ -153,6 +160,7 @@ struct gk_table {
   uint64_t dir_bytes = 0, n_rows = 0;      // review-flag bytes (read by every launch); rows in the table
   std::vector<uint32_t> path_rows;          // rows per path: which rows a plan reads
   std::vector<uint32_t> path_max;           // per element path: largest array of one review
+  std::vector<DevTable*> views;             // one per extra plan group (shares the device arrays of `dev`)
   bool resident = false;
   uint64_t cached_gen = 0;                  // plan generation the cached variant choice belongs to
   DevPlan* cached_plan = nullptr;
@@ -243,17 +251,57 @@ void ensure_plan(gk_engine* e) {
   if (!e->plan_dirty && e->dev_plan && e->fast.dict_size == e->dict.size()) return;
   for (auto& v : e->variants) dev_plan_free(v.second->dev);
   e->variants.clear();
+  PlanCaps bigcaps;
+  bigcaps.level_cap[0] = bigcaps.level_cap[1] = bigcaps.level_cap[2] = 256;
   if (e->plan_dirty || !e->dev_plan) {
-    PlanBuilder pb(&e->dict);
+    for (auto& g : e->extra) dev_plan_free(g->dev);
+    e->extra.clear();
+    std::vector<const ConstraintRec*> alive;
+    for (auto& c : e->constraints) if (c.alive) alive.push_back(&c);
+    // groups of constraints that fit one plan: everything if possible, else chunks of <= 64 constraints (a constraint
+    // contributes one violation and one match formula), halved further while a chunk still does not lower
+    std::vector<std::vector<const ConstraintRec*>> groups;
+    auto builds = [&](const std::vector<const ConstraintRec*>& g, HostPlan* fast, HostPlan* big) {
+      PlanBuilder pb(&e->dict);
+      for (auto* c : g) pb.add_constraint(c->viol, c->mf);
+      *fast = pb.build(default_caps(e));
+      *big = pb.build(bigcaps);
+    };
+    std::vector<std::pair<HostPlan, HostPlan>> plans;
+    std::function<void(const std::vector<const ConstraintRec*>&)> place = [&](const std::vector<const ConstraintRec*>& g) {
+      HostPlan f, b;
+      try { builds(g, &f, &b); }
+      catch (const Unsupported&) {
+        if (g.size() <= 1) throw;
+        size_t half = g.size() > 64 ? 64 : g.size() / 2;
+        for (size_t i = 0; i < g.size(); i += half)
+          place(std::vector<const ConstraintRec*>(g.begin() + i, g.begin() + std::min(g.size(), i + half)));
+        return;
+      }
+      groups.push_back(g);
+      plans.emplace_back(std::move(f), std::move(b));
+    };
+    place(alive);
     e->plan_ids.clear();
-    for (auto& c : e->constraints) if (c.alive) { pb.add_constraint(c.viol, c.mf); e->plan_ids.push_back(c.id); }
-    PlanCaps bigcaps;
-    bigcaps.level_cap[0] = bigcaps.level_cap[1] = bigcaps.level_cap[2] = 256;
-    e->fast = pb.build(default_caps(e));
-    e->big = pb.build(bigcaps);
+    if (groups.empty()) { groups.emplace_back(); HostPlan f, b; builds(groups[0], &f, &b); plans.emplace_back(std::move(f), std::move(b)); }
+    for (auto* c : groups[0]) e->plan_ids.push_back(c->id);
+    e->fast = std::move(plans[0].first);
+    e->big = std::move(plans[0].second);
+    for (size_t gi = 1; gi < groups.size(); gi++) {
+      std::unique_ptr<gk_engine::Group> g(new gk_engine::Group());
+      g->fast = std::move(plans[gi].first);
+      g->big = std::move(plans[gi].second);
+      for (auto* c : groups[gi]) g->ids.push_back(c->id);
+      e->extra.push_back(std::move(g));
+    }
   } else {
     e->fast.resolve_paths(e->dict);
     e->big.resolve_paths(e->dict);
+    for (auto& g : e->extra) { g->fast.resolve_paths(e->dict); g->big.resolve_paths(e->dict); }
+  }
+  for (auto& g : e->extra) {
+    if (g->dev) { dev_plan_free(g->dev); g->dev = nullptr; }
+    g->dev = dev_plan_upload(g->fast, g->big);
   }
   if (const char* dump = getenv("GK_PLAN_SOURCE_DUMP")) {   // debugging aid: the plan-specialised source text
     FILE* f = fopen(dump, "w");
@@ -289,6 +337,7 @@ void gk_engine_destroy(gk_engine* e) {
   if (!e) return;
   if (e->dev_plan) dev_plan_free(e->dev_plan);
   for (auto& v : e->variants) dev_plan_free(v.second->dev);
+  for (auto& g : e->extra) dev_plan_free(g->dev);
   delete e;
 }
 
@@ -494,6 +543,7 @@ int gk_table_create(gk_engine* e, const gk_review_in* reviews, size_t n, uint32_
 
 void gk_table_free(gk_table* t) {
   if (!t) return;
+  for (DevTable* v : t->views) dev_table_free(v);
   dev_table_free(t->dev);
   delete t;
 }
@@ -519,14 +569,36 @@ int gk_table_eval(gk_engine* e, gk_table* t, uint32_t flags, gk_eval_out** out) 
       if (flags & GK_EVAL_WANT_LIST) opt.list_capacity = std::max<uint32_t>(1024, t->n_reviews * 4u);
       const HostPlan* hp = nullptr;
       DevPlan* dp = plan_for_table(e, t, &hp);
+      while (t->views.size() < e->extra.size()) t->views.push_back(dev_table_view(t->dev));
       if (flags & GK_EVAL_ASYNC) {   // enqueue only; a later call without GK_EVAL_ASYNC collects
         dev_eval_launch(dp, t->dev, opt);
+        for (size_t gi = 0; gi < e->extra.size(); gi++) dev_eval_launch(e->extra[gi]->dev, t->views[gi], opt);
         *out = nullptr;
         return GK_OK;
       }
       if (flags & GK_EVAL_COLLECT) dev_eval_finish(dp, t->dev, opt, &h->out);   // no new launch
       else dev_eval(dp, t->dev, opt, &h->out);
       h->lds_bytes = hp->dims.acc_words * GK_RPT * 4;
+      // further plan groups: same table, their rows are appended below the primary group's
+      for (size_t gi = 0; gi < e->extra.size(); gi++) {
+        EvalOut og;
+        if (flags & GK_EVAL_COLLECT) dev_eval_finish(e->extra[gi]->dev, t->views[gi], opt, &og);
+        else dev_eval(e->extra[gi]->dev, t->views[gi], opt, &og);
+        const uint32_t row_base = h->out.n_constraints;
+        EvalOut& o = h->out;
+        o.viol.insert(o.viol.end(), og.viol.begin(), og.viol.end());
+        o.err.insert(o.err.end(), og.err.begin(), og.err.end());
+        o.match.insert(o.match.end(), og.match.begin(), og.match.end());
+        o.counts.insert(o.counts.end(), og.counts.begin(), og.counts.end());
+        for (size_t k = 0; k + 1 < og.list.size(); k += 2) { o.list.push_back(og.list[k] + row_base); o.list.push_back(og.list[k + 1]); }
+        for (size_t k = 0; k < og.too_big.size() && k < o.too_big.size(); k++) o.too_big[k] |= og.too_big[k];
+        o.list_total += og.list_total;
+        o.n_overflow += og.n_overflow;
+        o.kernel_ms += og.kernel_ms; o.fast_kernel_ms += og.fast_kernel_ms;
+        o.n_constraints += og.n_constraints;
+        o.d_viol = o.d_err = o.d_counts = nullptr;   // not one contiguous device buffer any more
+        h->ids.insert(h->ids.end(), e->extra[gi]->ids.begin(), e->extra[gi]->ids.end());
+      }
     }
     gk_eval_out& p = h->pub;
     memset(&p, 0, sizeof p);
@@ -546,21 +618,26 @@ int gk_table_eval(gk_engine* e, gk_table* t, uint32_t flags, gk_eval_out** out) 
     // algorithmic bytes: rows of the segments whose path carries predicates (+ their string headers
     // where a predicate reads string bytes) + two index words per bound path and tile + review flags, all read once;
     // plan tables read once; bitmaps written once; 8 B per list entry
-    uint64_t rows_read = 0, hdrs_read = 0, bound = 0;
-    for (uint32_t pth : t->slot_path) {
-      if (pth >= e->fast.ptab.size() || !e->fast.ptab[pth]) continue;
-      bound++;
-      uint64_t n = pth < t->path_rows.size() ? t->path_rows[pth] : 0;
-      rows_read += n;
-      uint32_t ent = e->fast.ptab[pth];
-      bool str = false;
-      for (uint32_t j = 0; j < (ent & 0xFF); j++) str = str || pred_needs_str(e->fast.path_preds[(ent >> 8) + j]);
-      if (str) hdrs_read += n;
-    }
+    uint64_t rows_read = 0, hdrs_read = 0, bound = 0, plan_bytes = 0;
+    auto account = [&](const HostPlan& hp) {   // every plan group streams its own bound segments
+      for (uint32_t pth : t->slot_path) {
+        if (pth >= hp.ptab.size() || !hp.ptab[pth]) continue;
+        bound++;
+        uint64_t n = pth < t->path_rows.size() ? t->path_rows[pth] : 0;
+        rows_read += n;
+        uint32_t ent = hp.ptab[pth];
+        bool str = false;
+        for (uint32_t j = 0; j < (ent & 0xFF); j++) str = str || pred_needs_str(hp.path_preds[(ent >> 8) + j]);
+        if (str) hdrs_read += n;
+      }
+      plan_bytes += (uint64_t)hp.path_preds.size() * sizeof(Pred) + hp.code.size() * 4 + hp.cheap.size();
+    };
+    account(e->fast);
+    for (auto& g : e->extra) account(g->fast);
     p.n_rows_read = rows_read;
-    uint64_t plan_bytes = (uint64_t)e->fast.path_preds.size() * sizeof(Pred) + e->fast.code.size() * 4 + e->fast.cheap.size() + bound * sizeof(Bind);
-    p.algo_bytes = rows_read * sizeof(Row) + hdrs_read * sizeof(StrHdr) + bound * 8 * ((p.n_reviews + GK_RPT - 1) / GK_RPT) + t->dir_bytes + plan_bytes +
-                   (uint64_t)p.n_constraints * p.n_tiles * 16 + (uint64_t)p.list_total * 8;
+    plan_bytes += bound * sizeof(Bind);
+    p.algo_bytes = rows_read * sizeof(Row) + hdrs_read * sizeof(StrHdr) + bound * 8 * ((p.n_reviews + GK_RPT - 1) / GK_RPT) +
+                   t->dir_bytes * (1 + e->extra.size()) + plan_bytes + (uint64_t)p.n_constraints * p.n_tiles * 16 + (uint64_t)p.list_total * 8;
     *out = &h.release()->pub;
     return GK_OK;
   } catch (const Unsupported& ex) { return fail(GK_ERR_UNSUPPORTED, ex.what());
@@ -592,7 +669,15 @@ int gk_table_topk(gk_engine* e, gk_table* t, uint32_t k, gk_topk_out** out) {
     h->ids = t->last_ids;
     {
       std::lock_guard<std::mutex> l(e->plan_mu);
-      dev_topk(t->dev, t->last_nc, t->order, t->grp, k, cap, &h->reviews, &h->counts, &h->overflow);
+      const uint32_t nc0 = (uint32_t)e->plan_ids.size();
+      dev_topk(t->dev, nc0, t->order, t->grp, k, cap, &h->reviews, &h->counts, &h->overflow);
+      for (size_t gi = 0; gi < e->extra.size() && gi < t->views.size(); gi++) {   // further plan groups: rows appended
+        std::vector<uint32_t> r, c, o;
+        dev_topk(t->views[gi], (uint32_t)e->extra[gi]->ids.size(), t->order, t->grp, k, cap, &r, &c, &o);
+        h->reviews.insert(h->reviews.end(), r.begin(), r.end());
+        h->counts.insert(h->counts.end(), c.begin(), c.end());
+        h->overflow.insert(h->overflow.end(), o.begin(), o.end());
+      }
     }
     h->pub.n_constraints = t->last_nc; h->pub.stride = cap;
     h->pub.constraint_ids = h->ids.data(); h->pub.counts = h->counts.data(); h->pub.reviews = h->reviews.data(); h->pub.overflow = h->overflow.data();

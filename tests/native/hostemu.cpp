@@ -43,6 +43,7 @@ std::string dev_init(int) { return ""; }
 int dev_count() { return 0; }
 DevTable* dev_table_upload(const HostTable& t) { DevTable* d = new DevTable(); d->t = t; d->t.heap.resize(d->t.heap.size() + 16, 0); return d; }
 void dev_table_free(DevTable* t) { delete t; }
+DevTable* dev_table_view(DevTable* base) { DevTable* v = new DevTable(*base); v->pending = 0; v->last_viol.clear(); return v; }
 uint64_t dev_table_bytes(const DevTable* t) { return t->t.rows.size() * 32 + t->t.tile_idx.size() * 4 + t->t.heap.size(); }
 DevPlan* dev_plan_upload(const HostPlan& fast, const HostPlan& big) {
   DevPlan* p = new DevPlan();

@@ -166,6 +166,33 @@ def test_match_randomised(backend, fixtures):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
+def test_many_constraints_split_into_plan_groups(backend, fixtures):
+    """More than 64 distinct match formulas do not fit one plan (one result bit each): the engine splits the constraint set
+    into plan groups evaluated over the same table and appends their bitmap rows.  150 random match blocks + PSP
+    constraints: parity per review, and the raw bitmap / counts / list / top-k API stay consistent across the groups."""
+    tmpl = fixtures["go_consts"]["pkg/target/target_integration_test.go"]["testTemplate"]["docs"][0]
+    cons, reviews = _random_match_world(77, 150, 130)
+    c, oc = load_both(backend, [tmpl] + synth.psp_templates(fixtures), cons + synth.psp_constraints())
+    revs = [r for r, _ in reviews]
+    assert assert_parity(c, oc, revs) > 500
+    table = c.driver.engine.create_table([D.to_review_in(r) for r in revs], keep_docs=False)
+    ev = table.eval(want_match=True, want_list=True)
+    assert ev.n_constraints == len(cons) + 30 == len(ev.constraint_ids) == len(set(int(x) for x in ev.constraint_ids))
+    pop = np.array([sum(bin(int(w)).count("1") for w in row) for row in ev.viol])
+    assert (pop == ev.counts).all() and ev.list_total == pop.sum() >= len(ev.list) > 0
+    listed = [(int(ev.constraint_ids[a]), int(b)) for a, b in ev.list]     # (a capacity-bounded prefix per plan group)
+    assert len(set(listed)) == len(listed) and set(listed) <= set(ev.pairs("viol"))
+    assert {cid for cid, _ in listed} & {int(x) for x in ev.constraint_ids[64:]}, "no list entries from the later plan groups"
+    assert ((ev.viol & ~ev.match) == 0).all()
+    top = table.topk(5)
+    for i, cid in enumerate(ev.constraint_ids):
+        got, ovf = top[int(cid)]
+        assert not ovf and len(got) == min(5, int(ev.counts[i])) or len(got) >= min(5, int(ev.counts[i]))
+        assert all((int(ev.viol[i][r // 64]) >> (r % 64)) & 1 for r in got)
+    table.free()
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
 def test_constraint_enforcement(backend, fixtures):
     """pkg/target/target_integration_test.go:163-527: 26 scenarios x 3 review shapes, batched into one launch each."""
     tmpl = fixtures["go_consts"]["pkg/target/target_integration_test.go"]["testTemplate"]["docs"][0]
