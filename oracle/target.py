@@ -176,6 +176,14 @@ class Matcher:
             raise ReviewError("unexpected review format")
         obj = _raw(review.request, "object")
         old = _raw(review.request, "oldObject")
+        # gkReviewToObject (matcher.go:73-93): Unstructured.UnmarshalJSON rejects a document without a `kind`
+        # (apimachinery UnstructuredJSONScheme, third-party) => ErrRequestObject.  The echoed raw bytes are the caller's
+        # encoding of the object; restated here as compact, key-sorted JSON ("parity unpinned" for that substring).
+        for which, o in (("object", obj), ("oldObject", old)):
+            if o is not None and not (isinstance(o, dict) and isinstance(o.get("kind"), str) and o.get("kind")):
+                import json as _json
+                raise ReviewError("%s: failed to unmarshal gkReview %s %s" % (
+                    ERR_REQUEST_OBJECT, which, _json.dumps(o, separators=(",", ":"), sort_keys=True, ensure_ascii=False)))
         ns = review.namespace
         req_ns = review.request.get("namespace", "") or ""
         if ns is None and req_ns != "":

@@ -260,3 +260,44 @@ PROCESS_RESULTS_CASES = [
                                       ("warn", "warn", "warn", None), ("dryrun", "dryrun", "dryrun", None),
                                       ("scoped", "scoped", "scoped", ["deny", "warn"]), ("invalid", "invalid", "invalid", None)], 2, 2),
 ]
+
+
+# pkg/target/target_test.go:657-981 TestMatcher_Match, hand-transcribed (the "nil" row is an unhandled input type).
+# (name, shape, request/object, review namespace, cached namespace, match, want matched, want error kind)
+def _thing(name, namespace=None, labels=None, group="some", kind="Thing"):
+    md = {"name": name}
+    if namespace is not None:
+        md["namespace"] = namespace
+    if labels:
+        md["labels"] = labels
+    return {"apiVersion": group + "/" if group else "v1", "kind": kind, "metadata": md}
+
+
+_FOO_MATCH = {"source": "All", "kinds": [{"kinds": ["Thing"], "apiGroups": ["some"]}], "scope": "Namespaced", "namespaces": ["my-ns"],
+              "labelSelector": {"matchLabels": {"obj": "label"}}, "namespaceSelector": {"matchLabels": {"ns": "label"}}}
+_NSSEL_MATCH = {"namespaceSelector": {"matchLabels": {"ns": "label"}}}
+_MATCHED = _thing("bar", "foo", {"obj": "label"})
+_UNMATCHED = _thing("bar", "foo", None, group="another", kind="thing")
+_NAMESPACED_FOO = _thing("foo", "foo", {"obj": "label"})
+_MY_NS = {"apiVersion": "v1", "kind": "Namespace", "metadata": {"name": "my-ns", "labels": {"ns": "label"}}}
+
+MATCHER_MATCH_CASES = [
+    ("AdmissionRequest supported", "request", {"object": _MATCHED}, None, None, _FOO_MATCH, False, None),
+    ("unstructured.Unstructured supported", "object", _thing("foo"), None, None, _FOO_MATCH, False, None),
+    ("Raw object doesn't unmarshal", "object", {"key": "Some invalid json"}, {"apiVersion": "v1", "kind": "Namespace", "metadata": {"name": "my-ns"}}, None, _FOO_MATCH, False, "request"),
+    ("Match error", "request", {"object": _NAMESPACED_FOO}, None, None, _NSSEL_MATCH, False, "matching"),
+    ("Success if Namespace not cached", "request", {"object": {"apiVersion": "v1", "kind": "Namespace", "metadata": {"name": "foo"}}}, None, None, _FOO_MATCH, False, None),
+    ("AugmentedReview is supported", "request", {"object": _MATCHED}, _MY_NS, None, _FOO_MATCH, True, None),
+    ("AugmentedUnstructured is supported", "object", _thing("foo", None, {"obj": "label"}), _MY_NS, None, _FOO_MATCH, True, None),
+    ("Both object and old object are matched", "request", {"object": _MATCHED, "oldObject": _MATCHED}, _MY_NS, None, _FOO_MATCH, True, None),
+    ("object is matched, old object is not matched", "request", {"object": _MATCHED, "oldObject": _UNMATCHED}, _MY_NS, None, _FOO_MATCH, True, None),
+    ("object is not matched, old object is matched", "request", {"object": _UNMATCHED, "oldObject": _MATCHED}, _MY_NS, None, _FOO_MATCH, True, None),
+    ("neither object is matched", "request", {"object": _UNMATCHED, "oldObject": _UNMATCHED}, _MY_NS, None, _FOO_MATCH, False, None),
+    ("new object is not matched, old object is not specified", "request", {"object": _UNMATCHED}, _MY_NS, None, _FOO_MATCH, False, None),
+    ("missing cached Namespace", "request", {"namespace": "foo", "object": _NAMESPACED_FOO}, None, None, _NSSEL_MATCH, False, "matching"),
+    ("use cached Namespace no match", "request", {"namespace": "foo", "object": _NAMESPACED_FOO}, None,
+     {"apiVersion": "v1", "kind": "Namespace", "metadata": {"name": "foo"}}, _NSSEL_MATCH, False, None),
+    ("use cached Namespace match", "request", {"namespace": "foo", "object": _NAMESPACED_FOO}, None,
+     {"apiVersion": "v1", "kind": "Namespace", "metadata": {"name": "foo", "labels": {"ns": "label"}}}, _NSSEL_MATCH, True, None),
+    ("neither new or old object is specified", "request", {}, _MY_NS, None, _FOO_MATCH, False, "request"),
+]
