@@ -21,6 +21,7 @@ from __future__ import annotations
 import copy
 import ctypes as C
 import json
+import re
 
 import numpy as np
 
@@ -144,6 +145,69 @@ class EvalResult:
             for r in self.bits(bm[row], self.n_reviews):
                 out.append((cid, int(r)))
         return sorted(out)
+
+
+_QNAME_RE = re.compile(r"^([A-Za-z0-9][-A-Za-z0-9_.]*)?[A-Za-z0-9]$")
+_DNS1123_SUB_RE = re.compile(r"^[a-z0-9]([-a-z0-9]*[a-z0-9])?(\.[a-z0-9]([-a-z0-9]*[a-z0-9])?)*$")
+_LVAL_RE = re.compile(r"^(([A-Za-z0-9][-A-Za-z0-9_.]*)?[A-Za-z0-9])?$")
+
+
+def _valid_label_key(k):
+    parts = k.split("/")
+    if len(parts) == 1:
+        name = parts[0]
+    elif len(parts) == 2:
+        prefix, name = parts
+        if prefix == "" or len(prefix) > 253 or not _DNS1123_SUB_RE.match(prefix):
+            return False
+    else:
+        return False
+    return name != "" and len(name) <= 63 and bool(_QNAME_RE.match(name))
+
+
+def validate_constraint(constraint):
+    """K8sValidationTarget.ValidateConstraint (pkg/target/target.go:185-219), run by Client.AddConstraint as the
+    frameworks client does: spec.match.labelSelector / namespaceSelector must be maps that decode into a
+    metav1.LabelSelector and pass apimachinery's ValidateLabelSelector.  Raises ClientError."""
+    spec = constraint.get("spec")
+    mt = spec.get("match") if isinstance(spec, dict) else None
+    if mt is None:
+        return
+    if not isinstance(mt, dict):
+        raise ClientError("spec.match must be an object")
+    for field in ("labelSelector", "namespaceSelector"):
+        sel = mt.get(field)
+        if sel is None:
+            continue
+        if not isinstance(sel, dict):
+            raise ClientError("spec.match.%s must be an object" % field)
+        ml = sel.get("matchLabels")
+        if ml is not None and not (isinstance(ml, dict) and all(isinstance(k, str) and isinstance(v, str) for k, v in ml.items())):
+            raise ClientError("Could not convert JSON to LabelSelector: matchLabels must be a map of strings")
+        for k, v in (ml or {}).items():
+            if not _valid_label_key(k) or len(v) > 63 or not _LVAL_RE.match(v):
+                raise ClientError("spec.labelSelector.matchLabels: Invalid value: %r" % ({k: v},))
+        me = sel.get("matchExpressions")
+        if me is None:
+            continue
+        if not isinstance(me, list) or not all(isinstance(e, dict) for e in me):
+            raise ClientError("Could not convert JSON to LabelSelector: matchExpressions must be a list of requirements")
+        for e in me:
+            key, op, vals = e.get("key", ""), e.get("operator", ""), e.get("values")
+            if not isinstance(key, str) or not isinstance(op, str) or not (vals is None or (isinstance(vals, list) and all(isinstance(v, str) for v in vals))):
+                raise ClientError("Could not convert JSON to LabelSelector: malformed requirement")
+            vals = vals or []
+            if op not in ("In", "NotIn", "Exists", "DoesNotExist"):
+                raise ClientError("spec.labelSelector.matchExpressions.operator: Invalid value: %r: not a valid selector operator" % op)
+            if op in ("In", "NotIn") and not vals:
+                raise ClientError("spec.labelSelector.matchExpressions.values: Required value: must be specified when `operator` is 'In' or 'NotIn'")
+            if op in ("Exists", "DoesNotExist") and vals:
+                raise ClientError("spec.labelSelector.matchExpressions.values: Forbidden: may not be specified when `operator` is 'Exists' or 'DoesNotExist'")
+            if not _valid_label_key(key):
+                raise ClientError("spec.labelSelector.matchExpressions.key: Invalid value: %r" % key)
+            for v in vals:
+                if len(v) > 63 or not _LVAL_RE.match(v):
+                    raise ClientError("spec.labelSelector.matchExpressions.values: Invalid value: %r" % v)
 
 
 def process_validation_results(results):
@@ -596,10 +660,12 @@ class Client:
         for k in [k for k in self.constraints if k[0].lower() == kind.lower()]:
             del self.constraints[k]
 
-    def AddConstraint(self, c):
+    def AddConstraint(self, c, validate=True):
         kind = c.get("kind", "")
         if kind.lower() not in self.templates:
             raise ClientError("missing ConstraintTemplate: %s" % kind)   # ErrMissingConstraintTemplate
+        if validate:
+            validate_constraint(c)   # the target handler's check (target.go:185-219); validate=False: Match-layer error-path tests
         c = apply_schema_defaults(self.templates[kind.lower()], c)
         self.driver.AddConstraint(c)
         self.constraints[(kind, (c.get("metadata") or {}).get("name", ""))] = c

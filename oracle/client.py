@@ -241,10 +241,18 @@ class Client:
         for k in [k for k in self.constraints if k[0].lower() == kind.lower()]:
             del self.constraints[k]
 
-    def add_constraint(self, c):
+    def add_constraint(self, c, validate=True):
+        """validate: the target handler's ValidateConstraint (target.go:185-219), as frameworks' client does on
+        AddConstraint; tests of the Match layer's own error paths (match_test.go) install invalid selectors with
+        validate=False."""
         kind = c.get("kind", "")
         if kind.lower() not in self.templates:
             raise ClientError("missing ConstraintTemplate: %s" % kind)   # ErrMissingConstraintTemplate
+        if validate:
+            try:
+                t.validate_constraint(c)
+            except t.ReviewError as e:
+                raise ClientError(str(e))
         name = (c.get("metadata") or {}).get("name", "")
         c = apply_schema_defaults(self.templates[kind.lower()], c)
         self.constraints[(kind, name)] = (c, t.to_matcher(c, self.cache))

@@ -206,6 +206,42 @@ class Matcher:
         return False
 
 
+def validate_constraint(constraint: dict):
+    """K8sValidationTarget.ValidateConstraint (target.go:185-219): spec.match.labelSelector / namespaceSelector must be
+    maps (unstructured.NestedMap), decode into metav1.LabelSelector (matchLabels: map[string]string, matchExpressions:
+    [{key, operator, values: []string}]) and pass apimachinery's ValidateLabelSelector (third-party; same rules as
+    labels.NewRequirement, restated in match.selector_requirements).  Raises ReviewError.
+    Pinned by target_test.go:42-399 (11 cases)."""
+    spec = constraint.get("spec")
+    mt = spec.get("match") if isinstance(spec, dict) else None
+    if mt is None:
+        return
+    if not isinstance(mt, dict):
+        raise ReviewError("spec.match accessor error: %r is of the type %s, expected map[string]interface{}" % (mt, type(mt).__name__))
+    for field in ("labelSelector", "namespaceSelector"):
+        if field not in mt or mt[field] is None:
+            continue
+        sel = mt[field]
+        if not isinstance(sel, dict):
+            raise ReviewError(".spec.match.%s accessor error: %r is of the type %s, expected map[string]interface{}" % (field, sel, type(sel).__name__))
+        ml = sel.get("matchLabels")
+        if ml is not None and not (isinstance(ml, dict) and all(isinstance(k, str) and isinstance(v, str) for k, v in ml.items())):
+            raise ReviewError("Could not convert JSON to LabelSelector: matchLabels must be a map of strings")
+        me = sel.get("matchExpressions")
+        if me is not None:
+            if not isinstance(me, list) or not all(isinstance(e, dict) for e in me):
+                raise ReviewError("Could not convert JSON to LabelSelector: matchExpressions must be a list of requirements")
+            for e in me:
+                vals = e.get("values")
+                if not isinstance(e.get("key", ""), str) or not isinstance(e.get("operator", ""), str) or not (
+                        vals is None or (isinstance(vals, list) and all(isinstance(v, str) for v in vals))):
+                    raise ReviewError("Could not convert JSON to LabelSelector: malformed requirement")
+        try:
+            m.selector_requirements(sel)
+        except m.MatchError as e:
+            raise ReviewError("spec.labelSelector: %s" % e)
+
+
 def to_matcher(constraint: dict, cache: NsCache) -> Matcher:
     """target.go:246-261: spec.match absent/null => match-everything Matcher."""
     spec = constraint.get("spec")

@@ -71,6 +71,16 @@ def go_consts(path):
     return out
 
 
+def validate_constraint_cases(path):
+    """pkg/target/target_test.go:42-399 TestValidateConstraint: (Name, Constraint JSON, ErrorExpected) rows."""
+    text = open(path, encoding="utf-8").read()
+    body = text[text.index("func TestValidateConstraint"):text.index("func TestProcessData")]
+    rows = []
+    for m in re.finditer(r'Name:\s*"([^"]*)",\s*Constraint:\s*`([^`]*)`,\s*ErrorExpected:\s*(true|false)', body):
+        rows.append({"name": m.group(1), "constraint": json.loads(m.group(2)), "error_expected": m.group(3) == "true"})
+    return rows
+
+
 def main():
     bundle = {"yaml": {}, "go_consts": {}}
     for g in YAML_GLOBS:
@@ -78,9 +88,11 @@ def main():
             bundle["yaml"][os.path.relpath(p, REF)] = load_docs(p)
     for f in GO_CONST_FILES:
         bundle["go_consts"][f] = go_consts(os.path.join(REF, f))
+    bundle["validate_constraint_cases"] = validate_constraint_cases(os.path.join(REF, "pkg/target/target_test.go"))
     with open(OUT, "w", encoding="utf-8") as fh:
         json.dump(bundle, fh, indent=1, sort_keys=True)
-    print("wrote %s: %d yaml files, %d go const files" % (OUT, len(bundle["yaml"]), len(bundle["go_consts"])))
+    print("wrote %s: %d yaml files, %d go const files, %d ValidateConstraint rows" % (
+        OUT, len(bundle["yaml"]), len(bundle["go_consts"]), len(bundle["validate_constraint_cases"])))
 
 
 if __name__ == "__main__":

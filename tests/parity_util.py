@@ -48,15 +48,16 @@ def to_oracle_review(obj):
     return obj
 
 
-def load_both(backend, templates, constraints, data=(), **kw):
+def load_both(backend, templates, constraints, data=(), validate=True, **kw):
+    """validate=False installs constraints without the target handler's ValidateConstraint (Match-layer error-path tests)"""
     c = make_client(backend, **kw)
     oc = OC.Client()
     for t in templates:
         c.AddTemplate(t)
         oc.add_template(t)
     for k in constraints:
-        c.AddConstraint(k)
-        oc.add_constraint(k)
+        c.AddConstraint(k, validate=validate)
+        oc.add_constraint(k, validate=validate)
     for d in data:
         c.AddData(d)
         oc.add_data(d)

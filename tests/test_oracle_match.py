@@ -140,3 +140,19 @@ def test_process_validation_results_a12():
     deny, warn = D.process_validation_results([D.Result("m1", {"metadata": {"name": "c1"}}, {}, "deny", None),
                                                D.Result("m2", {"metadata": {"name": "c2"}}, {}, "scoped", ["warn", "bogus"])])
     assert deny == ["[c1] m1"] and warn == ["[c2] m2"]
+
+
+def test_validate_constraint_table(fixtures):
+    """pkg/target/target_test.go:42-399 (TestValidateConstraint, rows extracted by make_golden.py): the target handler's
+    check run at AddConstraint, in the oracle and in the host mirror."""
+    from oracle import target as OT
+    from gatekeeper_amd import driver as D
+    rows = fixtures["validate_constraint_cases"]
+    assert len(rows) == 11 and sum(r["error_expected"] for r in rows) == 6
+    for r in rows:
+        for fn, exc in ((OT.validate_constraint, OT.ReviewError), (D.validate_constraint, D.ClientError)):
+            if r["error_expected"]:
+                with pytest.raises(exc):
+                    fn(r["constraint"])
+            else:
+                fn(r["constraint"])
