@@ -675,7 +675,18 @@ class Client:
         self.constraints.pop((c.get("kind", ""), (c.get("metadata") or {}).get("name", "")), None)
 
     def AddData(self, obj):
-        self.driver.AddData(TARGET_NAME, process_data(obj), dict(obj))
+        path = process_data(obj)
+        # nsCache.Add (pkg/target/ns_cache.go:23-44): a core/v1 Namespace must convert into the typed object
+        if path[:3] == ["cluster", "v1", "Namespace"]:
+            for f in ("metadata", "spec", "status"):
+                if obj.get(f) is not None and not isinstance(obj[f], dict):
+                    raise ClientError("cannot cache type: cannot cache Namespace: %s must be an object" % f)
+            md = obj.get("metadata") or {}
+            for f in ("labels", "annotations"):
+                v = md.get(f)
+                if v is not None and not (isinstance(v, dict) and all(isinstance(x, str) for x in v.values())):
+                    raise ClientError("cannot cache type: cannot cache Namespace: metadata.%s must be a map of strings" % f)
+        self.driver.AddData(TARGET_NAME, path, dict(obj))
 
     def RemoveData(self, obj):
         self.driver.RemoveData(TARGET_NAME, process_data(obj))

@@ -153,6 +153,16 @@ class NsCache:
         g, _, k = m.obj_gvk(obj)
         if not (g == "" and k == "Namespace"):
             return
+        # toNamespace (ns_cache.go:79-87): conversion into the typed corev1.Namespace fails on fields of the wrong JSON
+        # type (third-party converter; restated for the typed top-level fields and string maps of ObjectMeta)
+        for f in ("metadata", "spec", "status"):
+            if f in obj and obj[f] is not None and not isinstance(obj[f], dict):
+                raise ReviewError("cannot cache type: cannot cache Namespace: %s must be an object" % f)
+        md = obj.get("metadata") or {}
+        for f in ("labels", "annotations"):
+            v = md.get(f)
+            if v is not None and not (isinstance(v, dict) and all(isinstance(x, str) for x in v.values())):
+                raise ReviewError("cannot cache type: cannot cache Namespace: metadata.%s must be a map of strings" % f)
         self.cache["/".join(key)] = obj
 
     def remove(self, key):

@@ -156,3 +156,38 @@ def test_validate_constraint_table(fixtures):
                     fn(r["constraint"])
             else:
                 fn(r["constraint"])
+
+
+def test_namespace_cache_table():
+    """pkg/target/target_test.go:983-1152 (TestNamespaceCache): add / remove / lookup, non-Namespace objects are ignored,
+    a Namespace that does not convert into the typed object is refused (ErrCachingType)."""
+    def ns(name, labels):
+        return {"apiVersion": "v1", "kind": "Namespace", "metadata": {"name": name, "labels": labels}}
+    foo_constraint = {"apiVersion": "constraints.gatekeeper.sh/v1beta1", "kind": "Foo", "metadata": {"name": "c"}, "spec": {"match": {}}}
+    cases = [
+        ([], [], [("my-ns1", False)], False),
+        ([ns("my-ns1", {"ns1": "label"})], [], [("my-ns1", True), ("my-ns2", False)], False),
+        ([ns("my-ns1", {"ns1": "label"}), ns("my-ns2", {"ns2": "label"})], [], [("my-ns1", True), ("my-ns2", True)], False),
+        ([{"apiVersion": "v1", "kind": "Namespace", "spec": 3.0}], [], [], True),
+        ([foo_constraint, ns("my-ns2", {"ns2": "label"})], [], [("my-ns2", True)], False),
+        ([ns("my-ns1", {"ns1": "label"}), ns("my-ns2", {"ns2": "label"})], ["my-ns1"], [("my-ns1", False), ("my-ns2", True)], False),
+    ]
+    for adds, removes, checks, want_err in cases:
+        cache = tg.NsCache()
+        errs = 0
+        for o in adds:
+            _, key, _ = tg.process_data(tg.Unstructured(o))
+            try:
+                cache.add(key, o)
+            except tg.ReviewError:
+                errs += 1
+        assert (errs > 0) is want_err
+        for name in removes:
+            _, key, _ = tg.process_data(tg.Unstructured({"apiVersion": "v1", "kind": "Namespace", "metadata": {"name": name}}))
+            cache.remove(key)
+        assert len(cache.cache) == sum(1 for _, e in checks if e)
+        for name, exists in checks:
+            got = cache.get_namespace(name)
+            assert (got is not None) is exists
+            if exists:
+                assert got["metadata"]["name"] == name and got["metadata"]["labels"]

@@ -295,6 +295,20 @@ def test_namespace_cache_and_autoreject(backend, fixtures):
             assert res[0].msg == ("unable to match constraints: error matching the requested object: object :failed to run "
                                   "Match criteria: namespace selector for namespace-scoped object but missing Namespace")
         assert_parity(c, oc, rv, D.GATOR_EP)
+    # target_test.go:983-1152 (TestNamespaceCache) through Client.AddData / RemoveData: removal, non-Namespace data is
+    # ignored by the cache, a Namespace that does not convert into the typed object is refused
+    c, oc = load_both(backend, [t_], [k_], [gconst(fixtures, "NamespaceSelected")[0]])
+    rv = [D.AugmentedUnstructured(D.Unstructured(obj), None, "Original")]
+    before = [r.msg for r in c.Review(rv[0], D.GATOR_EP)]
+    c.RemoveData(gconst(fixtures, "NamespaceSelected")[0])
+    oc.remove_data(gconst(fixtures, "NamespaceSelected")[0])
+    after = [r.msg for r in c.Review(rv[0], D.GATOR_EP)]
+    assert before != after and after[0].startswith("unable to match constraints: ")
+    assert_parity(c, oc, rv, D.GATOR_EP)
+    with pytest.raises(D.ClientError):
+        c.AddData({"apiVersion": "v1", "kind": "Namespace", "spec": 3.0})
+    c.AddData({"apiVersion": "v1", "kind": "ConfigMap", "metadata": {"name": "cm", "namespace": "default"}})
+    assert [r.msg for r in c.Review(rv[0], D.GATOR_EP)] == after
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
