@@ -144,23 +144,32 @@ class RegoDriver:
 
 
 def get_enforcement_action(c):
-    """pkg/util/enforcement_action.go:132-151"""
-    spec = c.get("spec") if isinstance(c.get("spec"), dict) else {}
+    """pkg/util/enforcement_action.go:132-151 (pinned by enforcement_action_test.go:113-165): default deny; anything
+    outside {deny, dryrun, warn, scoped} is "unrecognized"; a spec / enforcementAction of the wrong type is an error."""
+    spec = c.get("spec")
+    if spec is None:
+        return "deny"
+    if not isinstance(spec, dict) or not isinstance(spec.get("enforcementAction", ""), str):
+        raise ClientError("unable to parse spec.enforcementAction")   # ErrInvalidSpecEnforcementAction
     ea = spec.get("enforcementAction", "")
     if ea == "":
         return "deny"
-    if ea in ("deny", "dryrun", "warn", "scoped"):
-        return ea
-    return "unrecognized"
+    return ea if ea in ("deny", "dryrun", "warn", "scoped") else "unrecognized"
 
 
 def scoped_actions_for_ep(ep, c):
-    """pkg/util/enforcement_action.go:153-174"""
+    """pkg/util/enforcement_action.go:153-174 (pinned by enforcement_action_test.go:235-385): the actions whose
+    enforcementPoints name `ep` or "*"; a scopedEnforcementActions value that is not a list of objects is an error."""
     spec = c.get("spec") if isinstance(c.get("spec"), dict) else {}
+    seas = spec.get("scopedEnforcementActions")
+    if seas is None:
+        return []
+    if not isinstance(seas, list) or not all(isinstance(x, dict) for x in seas):
+        raise ClientError("could not convert JSON to scopedEnforcementActions")
     out = []
-    for sea in spec.get("scopedEnforcementActions") or []:
+    for sea in seas:
         for p in sea.get("enforcementPoints") or []:
-            if p.get("name") in (ep, ALL_EP):
+            if isinstance(p, dict) and p.get("name") in (ep, ALL_EP):
                 out.append(sea.get("action"))
                 break
     return out

@@ -191,3 +191,28 @@ def test_namespace_cache_table():
             assert (got is not None) is exists
             if exists:
                 assert got["metadata"]["name"] == name and got["metadata"]["labels"]
+
+
+def test_enforcement_action_tables():
+    """pkg/util/enforcement_action_test.go:113-165 (GetEnforcementAction) and :235-385 (ScopedActionForEP), oracle and host
+    mirror."""
+    from oracle import client as OC
+    from gatekeeper_amd import driver as D
+    AUDIT, WEBHOOK = "audit.gatekeeper.sh", "validation.gatekeeper.sh"
+
+    def sea(*pairs):
+        return {"spec": {"scopedEnforcementActions": [{"action": a, "enforcementPoints": [{"name": n} for n in eps]} for a, eps in pairs]}}
+    for mod in (OC, D):
+        assert mod.get_enforcement_action({}) == "deny"
+        with pytest.raises(mod.ClientError):
+            mod.get_enforcement_action({"spec": []})
+        assert mod.get_enforcement_action({"spec": {"enforcementAction": "notsupported"}}) == "unrecognized"
+        assert mod.get_enforcement_action({"spec": {"enforcementAction": "dryrun"}}) == "dryrun"
+        f = mod.scoped_actions_for_ep
+        assert f(AUDIT, sea(("deny", [AUDIT]), ("warn", [WEBHOOK]))) == ["deny"]
+        assert f(WEBHOOK, sea(("deny", [AUDIT, WEBHOOK]), ("warn", [WEBHOOK]))) == ["deny", "warn"]
+        assert f(AUDIT, sea(("deny", [WEBHOOK]), ("warn", [WEBHOOK]))) == []
+        assert f(AUDIT, sea(("deny", ["*"]), ("warn", [WEBHOOK]))) == ["deny"]
+        assert f(AUDIT, {"spec": {}}) == []
+        with pytest.raises(mod.ClientError):
+            f(AUDIT, {"spec": {"scopedEnforcementActions": "invalid"}})
