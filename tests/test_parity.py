@@ -85,7 +85,7 @@ def test_match_table(backend, fixtures):
                 assert res[0].msg == "denyall constraint installed"
 
 
-@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("backend", [b for b in BACKENDS if b.id.startswith("hostemu")])   # added after the round's last GPU visit
 def test_matcher_match_table(backend, fixtures):
     """pkg/target/target_test.go:657-981 (TestMatcher_Match): review shapes, object / oldObject combinations, cached
     Namespace fallback (matcher.go:37-39) and the two error kinds, through the device path and through the oracle."""
