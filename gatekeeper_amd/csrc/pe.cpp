@@ -1184,6 +1184,15 @@ class PE {
       // fold composite args that are in fact constant
       std::vector<SVP> fa;
       for (auto& a : args) fa.push_back(fold(a));
+      bool folded_const = true;
+      for (auto& a : fa) if (a->kind != SV::CONST) folded_const = false;
+      if (folded_const) {   // e.g. an object / array literal argument of constants
+        ValueVec av;
+        for (auto& a : fa) av.push_back(a->c);
+        Value v = call_builtin(name, av);
+        if (v.defined()) out.push_back({sv_const(v), s2});
+        return;
+      }
       symbolic_builtin(name, fa, s2, t->line, out);
     });
   }
@@ -1317,6 +1326,11 @@ class PE {
         out.push_back({sv_path(p), s1});
         State s2 = s; s2.conds.push_back(f_and(isobj, f_not(d)));
         out.push_back({a[2], s2});
+        return;
+      }
+      if (a[0]->kind == SV::OBJ && a[1]->kind == SV::CONST) {   // e.g. object.get(input, "parameters", {}): constant keys
+        for (auto& f : a[0]->fields) if (f.first == a[1]->c) { out.push_back({f.second, s}); return; }
+        out.push_back({a[2], s});
         return;
       }
       unsupported("object.get with these operands on review data", line);

@@ -516,6 +516,24 @@ def test_regex_randomised(backend):
     assert assert_parity(c, oc, [D.AugmentedUnstructured(D.Unstructured(o), None, "Original") for o in objs]) > 100
 
 
+@pytest.mark.parametrize("backend", [b for b in BACKENDS if b.id.startswith("hostemu")])   # added after the round's last GPU visit
+def test_gator_verify_suite_template(backend, fixtures):
+    """test/gator/verify/{template,constraint*,allow_foo,deny_foo}.yaml (the reference's own `gator verify` suite): the
+    template reads its input through object.get(input, "parameters", {}) / object.get(input.review.object, "foo", "")."""
+    d = "test/gator/verify/"
+    tmpl = ydocs(fixtures, d + "template.yaml")[0]
+    objs = [ydocs(fixtures, d + "allow_foo.yaml")[0], ydocs(fixtures, d + "deny_foo.yaml")[0],
+            {"apiVersion": "v1", "kind": "Object", "metadata": {"name": "nofoo"}}, {"apiVersion": "v1", "kind": "Object", "metadata": {"name": "n"}, "foo": 5}]
+    for cfile, ep in (("constraint.yaml", D.GATOR_EP), ("constraint_with_scopedEA.yaml", D.GATOR_EP),
+                      ("constraint_with_scopedEA_without_gator_ep.yaml", D.GATOR_EP), ("constraint.yaml", D.AUDIT_EP)):
+        c, oc = load_both(backend, [tmpl], [ydocs(fixtures, d + cfile)[0]])
+        rv = [D.AugmentedUnstructured(D.Unstructured(o), None, "Original") for o in objs]
+        got = c.ReviewBatch(rv, ep)
+        if cfile == "constraint.yaml":
+            assert len(got[0]) == 0 and len(got[1]) == 1 and "but want" in got[1][0].msg
+        assert_parity(c, oc, rv, ep)
+
+
 @pytest.mark.parametrize("backend", BACKENDS)
 def test_unsupported_is_an_error_not_a_fallback(backend, fixtures):
     t_ = gconst(fixtures, "TemplateReferential")[0]
