@@ -156,6 +156,12 @@ def test_validate_constraint_table(fixtures):
                     fn(r["constraint"])
             else:
                 fn(r["constraint"])
+    # demo/basic/bad/bad_constraint_labelselector.yaml: the demo's deliberately invalid constraint (operator In, no values)
+    bad = fixtures["yaml"]["demo/basic/bad/bad_constraint_labelselector.yaml"]["docs"][0]
+    with pytest.raises(OT.ReviewError):
+        OT.validate_constraint(bad)
+    with pytest.raises(D.ClientError):
+        D.validate_constraint(bad)
 
 
 def test_namespace_cache_table():
