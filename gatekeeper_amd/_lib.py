@@ -4,9 +4,9 @@ The product library is gatekeeper_amd/libgkgpu.so (host engine + HIP kernels for
 `__graft_entry__.build()` / `make -C gatekeeper_amd/csrc`.  There is NO CPU fallback: if the library is missing, or
 no MI355X is visible, loading / gk_engine_create fail loudly.
 
-tests/ may set GK_TEST_HOSTEMU=1 to load tests/native/libgkgpu_hostemu.so instead -- a test-only build in which the
+tests/ pass hostemu=True explicitly to load tests/native/libgkgpu_hostemu.so instead -- a test-only build in which the
 kernels' per-row / per-review code (vm_core.hpp) is executed lane by lane on the CPU, so that the AOT compiler and
-the flattener can be checked against the oracle in the GPU-less build container.  Nothing outside tests/ sets it.
+the flattener can be checked against the oracle in the GPU-less build container.  No environment variable selects it.
 """
 from __future__ import annotations
 
@@ -17,8 +17,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 
 GK_OK = 0
-GK_ERR_INVALID, GK_ERR_REGO, GK_ERR_UNSUPPORTED, GK_ERR_NOT_FOUND, GK_ERR_DEVICE, GK_ERR_REVIEW, GK_ERR_INTERNAL = (
-    -1, -2, -3, -4, -5, -6, -7)
+GK_ERR_INVALID, GK_ERR_REGO, GK_ERR_UNSUPPORTED, GK_ERR_NOT_FOUND, GK_ERR_DEVICE, GK_ERR_REVIEW, GK_ERR_INTERNAL, GK_ERR_LIMIT = (
+    -1, -2, -3, -4, -5, -6, -7, -8)
 GK_REVIEW_ADMISSION_REQUEST, GK_REVIEW_OBJECT = 0, 1
 GK_SRC_EMPTY, GK_SRC_ORIGINAL, GK_SRC_GENERATED, GK_SRC_ALL, GK_SRC_INVALID = 0, 1, 2, 3, 4
 GK_TABLE_KEEP_DOCS = 1
@@ -29,6 +29,7 @@ EXPORTS = [
     "gk_engine_create", "gk_engine_destroy", "gk_last_error", "gk_version", "gk_template_add", "gk_template_remove",
     "gk_constraint_add", "gk_constraint_remove", "gk_data_put", "gk_data_remove", "gk_table_create", "gk_table_free",
     "gk_table_eval", "gk_eval_free", "gk_render", "gk_render_error", "gk_free", "gk_dump", "gk_table_topk", "gk_topk_free",
+    "gk_table_totals", "gk_totals_free",
 ]
 
 
@@ -60,6 +61,11 @@ class gk_topk_out(C.Structure):
                 ("counts", C.POINTER(C.c_uint32)), ("reviews", C.POINTER(C.c_uint32)), ("overflow", C.POINTER(C.c_uint32))]
 
 
+class gk_totals_out(C.Structure):
+    _fields_ = [("n_constraints", C.c_uint32), ("constraint_ids", C.POINTER(C.c_uint32)), ("results", C.POINTER(C.c_uint64)),
+                ("pairs", C.POINTER(C.c_uint64))]
+
+
 class EngineLoadError(RuntimeError):
     pass
 
@@ -74,9 +80,8 @@ _cache = {}
 
 
 def load(hostemu: bool | None = None):
-    """Load the C-ABI library. hostemu=None consults GK_TEST_HOSTEMU (tests only)."""
-    if hostemu is None:
-        hostemu = os.environ.get("GK_TEST_HOSTEMU", "") == "1"
+    """Load the C-ABI library (hostemu=True: the test-only emulation build, only ever passed by tests/)."""
+    hostemu = bool(hostemu)
     if hostemu in _cache:
         return _cache[hostemu]
     path = library_path(hostemu)
@@ -118,5 +123,8 @@ def load(hostemu: bool | None = None):
     lib.gk_table_topk.argtypes = [vp, vp, u32, C.POINTER(C.POINTER(gk_topk_out))]
     lib.gk_topk_free.argtypes = [C.POINTER(gk_topk_out)]
     lib.gk_topk_free.restype = None
+    lib.gk_table_totals.argtypes = [vp, vp, C.POINTER(C.POINTER(gk_totals_out))]
+    lib.gk_totals_free.argtypes = [C.POINTER(gk_totals_out)]
+    lib.gk_totals_free.restype = None
     _cache[hostemu] = lib
     return lib

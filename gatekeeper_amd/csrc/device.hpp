@@ -51,6 +51,8 @@ void dev_eval(const DevPlan* p, const DevTable* t, const EvalOptions& opt, EvalO
 // uses the bitmaps of the table's most recent evaluation.  idx: [nc][cap], n: [nc], ovf: [nc]
 void dev_topk(const DevTable* t, uint32_t nc, const std::vector<uint32_t>& order, const std::vector<uint32_t>& grp, uint32_t k, uint32_t cap,
               std::vector<uint32_t>* idx, std::vector<uint32_t>* n, std::vector<uint32_t>* ovf);
+// the violation bitmap [nc][n_tiles] of the table's most recent evaluation (device -> host copy)
+void dev_last_viol(const DevTable* t, uint32_t nc, std::vector<uint64_t>* viol);
 void dev_eval_launch(const DevPlan* p, const DevTable* t, const EvalOptions& opt);          // asynchronous on the default stream
 void dev_eval_finish(const DevPlan* p, const DevTable* t, const EvalOptions& opt, EvalOut* out);   // sync, overflow re-run, download
 

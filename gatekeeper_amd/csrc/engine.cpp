@@ -105,6 +105,12 @@ std::string candidate_error(const Value& m, const Value& obj, const Value& ns, i
 std::string autoreject_message(const Value& match, const ReviewDoc& doc) {
   const Value* obj = doc.request.get("object");
   const Value* old = doc.request.get("oldObject");
+  // gkReviewToObject (matcher.go:73-93): object first, then oldObject; the raw bytes are echoed (here: compact,
+  // key-sorted JSON of the parsed document)
+  if (obj && obj->is_object() && obj_string(*obj, "kind").empty())
+    return "unable to match constraints: invalid request object: failed to unmarshal gkReview object " + to_json(*obj);
+  if (old && old->is_object() && obj_string(*old, "kind").empty())
+    return "unable to match constraints: invalid request object: failed to unmarshal gkReview oldObject " + to_json(*old);
   bool any = false;
   for (const Value* c : {obj, old}) {
     if (!c || !c->is_object()) continue;
@@ -684,6 +690,83 @@ int gk_table_topk(gk_engine* e, gk_table* t, uint32_t k, gk_topk_out** out) {
     *out = &h.release()->pub;
     return GK_OK;
   } catch (const std::exception& ex) { return fail(GK_ERR_DEVICE, ex.what()); }
+}
+
+struct TotalsHolder {
+  gk_totals_out pub;   // first member
+  std::vector<uint32_t> ids;
+  std::vector<uint64_t> results, pairs;
+};
+
+// Result-level totals.  The device answers "does (constraint, review) violate" (one bit); the reference counts RESULTS
+// (pkg/audit/manager.go:902: totalViolationsPerConstraint[key]++ per types.Result), and a violating pair yields as many
+// results as the template's violation set has distinct {msg, details} members for that review.  The violating pairs of
+// the table's most recent evaluation are rendered on host threads (the reference renders -- and logs -- every message
+// as well, manager.go:926-928); only the counts are kept.
+int gk_table_totals(gk_engine* e, gk_table* t, gk_totals_out** out) {
+  if (!e || !t || !out) return fail(GK_ERR_INVALID, "NULL argument");
+  if (t->docs.size() != t->n_reviews) return fail(GK_ERR_INVALID, "table was created without GK_TABLE_KEEP_DOCS");
+  try {
+    std::unique_ptr<TotalsHolder> h(new TotalsHolder());
+    h->ids = t->last_ids;
+    const uint32_t nc = t->last_nc, nt = (t->n_reviews + GK_TILE - 1) / GK_TILE;
+    std::vector<uint64_t> viol;
+    {
+      std::lock_guard<std::mutex> l(e->plan_mu);
+      dev_last_viol(t->dev, (uint32_t)e->plan_ids.size(), &viol);
+      for (size_t gi = 0; gi < e->extra.size() && gi < t->views.size(); gi++) {
+        std::vector<uint64_t> v;
+        dev_last_viol(t->views[gi], (uint32_t)e->extra[gi]->ids.size(), &v);
+        viol.insert(viol.end(), v.begin(), v.end());
+      }
+    }
+    if (viol.size() != (size_t)nc * nt) return fail(GK_ERR_INVALID, "gk_table_totals: evaluate the table first");
+    h->results.assign(nc, 0); h->pairs.assign(nc, 0);
+    std::shared_lock<std::shared_mutex> rl(e->mu);
+    struct CRef { const ConstraintRec* c; const Template* tm; };
+    std::vector<CRef> cref(nc);
+    for (uint32_t row = 0; row < nc; row++) {
+      const ConstraintRec& c = e->constraints[h->ids[row]];
+      auto it = e->templates.find(lower_str(c.kind));
+      if (it == e->templates.end()) return fail(GK_ERR_NOT_FOUND, "unknown constraint template validator: " + c.kind);
+      cref[row] = {&c, it->second.get()};
+    }
+    size_t n_threads = std::max<size_t>(1, std::min<size_t>(std::thread::hardware_concurrency(), nt / 4 + 1));
+    if (const char* ht = getenv("GK_HOST_THREADS")) n_threads = std::max(1, atoi(ht));
+    std::vector<std::vector<uint64_t>> part_r(n_threads, std::vector<uint64_t>(nc, 0)), part_p(n_threads, std::vector<uint64_t>(nc, 0));
+    std::vector<std::string> errs(n_threads);
+    std::atomic<uint32_t> next_tile{0};
+    auto work = [&](size_t w) {
+      try {
+        for (;;) {
+          const uint32_t tl = next_tile.fetch_add(1);
+          if (tl >= nt) break;
+          for (uint32_t row = 0; row < nc; row++) {
+            for (uint64_t m = viol[(size_t)row * nt + tl]; m; m &= m - 1) {
+              const uint32_t r = tl * GK_TILE + (uint32_t)__builtin_ctzll(m);
+              part_p[w][row]++;
+              part_r[w][row] += cref[row].tm->render(t->docs[r].request, cref[row].c->params, e->inventory).size();
+            }
+          }
+        }
+      } catch (const std::exception& ex) { errs[w] = ex.what(); }
+    };
+    if (n_threads <= 1) work(0);
+    else {
+      std::vector<std::thread> th;
+      for (size_t w = 0; w < n_threads; w++) th.emplace_back(work, w);
+      for (auto& x : th) x.join();
+    }
+    for (auto& er : errs) if (!er.empty()) return fail(GK_ERR_REGO, er);
+    for (size_t w = 0; w < n_threads; w++) for (uint32_t row = 0; row < nc; row++) { h->results[row] += part_r[w][row]; h->pairs[row] += part_p[w][row]; }
+    h->pub.n_constraints = nc; h->pub.constraint_ids = h->ids.data(); h->pub.results = h->results.data(); h->pub.pairs = h->pairs.data();
+    *out = &h.release()->pub;
+    return GK_OK;
+  } catch (const std::exception& ex) { return fail(GK_ERR_DEVICE, ex.what()); }
+}
+
+void gk_totals_free(gk_totals_out* o) {
+  if (o) delete reinterpret_cast<TotalsHolder*>(o);
 }
 
 void gk_topk_free(gk_topk_out* o) {

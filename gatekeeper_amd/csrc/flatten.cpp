@@ -346,6 +346,9 @@ void Flattener::add(const ReviewDoc& doc, HostTable* out) {
   const Value* old = req.get("oldObject");
   if (obj && obj->is_object()) match_facts(*obj, ns, false, id_m_);
   if (old && old->is_object()) match_facts(*old, ns, true, id_m_);
+  // gkReviewToObject (matcher.go:73-93): Unstructured.UnmarshalJSON rejects a document without a non-empty string `kind`
+  if (obj && obj->is_object() && obj_string(*obj, "kind").empty()) review_flags_ |= RF_OBJ_BAD;
+  if (old && old->is_object() && obj_string(*old, "kind").empty()) review_flags_ |= RF_OLD_BAD;
   switch (doc.source) {
     case SRC_ORIGINAL: review_flags_ |= RF_SRC_ORIGINAL; break;
     case SRC_GENERATED: review_flags_ |= RF_SRC_GENERATED; break;

@@ -233,9 +233,12 @@ MatchFormulas compile_match(const Value& m) {
   match_candidate(m, o, &mo, &eo);
   match_candidate(m, old, &mold, &eold);
   FP none = f_and(f_not(flag_f(RF_HAS_OBJ)), f_not(flag_f(RF_HAS_OLD)));
+  // gkReviewToObject runs before any matcher (matcher.go:32-35): an object / oldObject that does not decode into an
+  // Unstructured makes every constraint WITH a match block fail with ErrRequestObject (target_test.go:690-703)
+  FP bad = f_or(flag_f(RF_OBJ_BAD), flag_f(RF_OLD_BAD));
   MatchFormulas r;
-  r.match = f_or(mo, f_and(f_not(eo), mold));
-  r.error = f_or(f_or(eo, f_and(f_and(f_not(mo), f_not(eo)), eold)), none);
+  r.match = f_and(f_not(bad), f_or(mo, f_and(f_not(eo), mold)));
+  r.error = f_or(bad, f_or(f_or(eo, f_and(f_and(f_not(mo), f_not(eo)), eold)), none));
   return r;
 }
 

@@ -74,11 +74,14 @@ enum ReviewFlag : uint32_t {
   RF_SRC_INVALID = 1u << 9,      // non-empty source outside {All,Original,Generated}
   RF_OBJ_HAS_NSNAME = 1u << 10,  // an effective namespace name exists for object (match.go:150-179 switch)
   RF_OLD_HAS_NSNAME = 1u << 11,
-  RF_TOO_BIG = 1u << 12,         // review exceeds engine limits (ordinal overflow); reported, never guessed
+  RF_TOO_BIG = 1u << 12,         // some array of the review has > 255 elements (informational: the kernels decide per ROW --
+                                 // ROW_ORD_OVERFLOW on a row an element predicate reads -- whether a review is beyond the engine's limits)
   RF_SRC_ALL = 1u << 13,
   RF_OBJ_LABELS_BAD = 1u << 14,  // metadata.labels is not a string map: unstructured GetLabels() yields none
   RF_OLD_LABELS_BAD = 1u << 15,
   RF_NS_LABELS_BAD = 1u << 16,
+  RF_OBJ_BAD = 1u << 17,         // request.object is a JSON object that Unstructured.UnmarshalJSON rejects (no `kind`):
+  RF_OLD_BAD = 1u << 18,         //   gkReviewToObject fails with ErrRequestObject (pkg/target/matcher.go:73-93)
 };
 
 // ------------------------------------------------------------------------------------------------ predicates

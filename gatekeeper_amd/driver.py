@@ -46,6 +46,16 @@ class UnsupportedError(EngineError):
     """GK_ERR_UNSUPPORTED: the template/constraint cannot run on the device plan (keep it on the CPU Rego driver)."""
 
 
+class LimitError(EngineError):
+    """GK_ERR_LIMIT: the review is beyond the engine's limits (an array that element predicates iterate has more than
+    255 elements).  The engine reports such reviews in `too_big` and NEVER answers "no violations" for them: every caller
+    below fails closed (raises / returns this error for that review) so the object can go to the reference CPU driver."""
+
+    def __init__(self, what="review"):
+        super().__init__(L.GK_ERR_LIMIT, "%s is beyond the engine's limits (more than 255 elements in an array that "
+                                         "constraint predicates iterate): not evaluated on the device" % what)
+
+
 # ---------------------------------------------------------------------------------------------- review shapes
 class AdmissionRequest(dict):
     """admissionv1.AdmissionRequest as its JSON dict."""
@@ -135,6 +145,10 @@ class EvalResult:
         """indices of set bits in one bitmap row"""
         b = np.unpackbits(bitmap_row.view(np.uint8), bitorder="little")[:n]
         return np.nonzero(b)[0]
+
+    def too_big_reviews(self):
+        """indices of the reviews the engine refused to evaluate (beyond its limits)"""
+        return [int(r) for r in self.bits(self.too_big, self.n_reviews)]
 
     def pairs(self, which="viol"):
         """sorted list of (constraint_id, review) for the chosen bitmap"""
@@ -303,6 +317,15 @@ class Table:
         self.engine.lib.gk_topk_free(out)
         return res
 
+    def totals(self):
+        """Result-level totals of the most recent eval(): {constraint id: (results, violating pairs)} (gk_table_totals)."""
+        out = C.POINTER(L.gk_totals_out)()
+        self.engine._check(self.engine.lib.gk_table_totals(self.engine.handle, self.handle, C.byref(out)))
+        o = out.contents
+        res = {int(o.constraint_ids[i]): (int(o.results[i]), int(o.pairs[i])) for i in range(o.n_constraints)}
+        self.engine.lib.gk_totals_free(out)
+        return res
+
     def free(self):
         if self.handle:
             self.engine.lib.gk_table_free(self.handle)
@@ -433,27 +456,24 @@ class ClientError(Exception):
 
 
 def template_source(ct):
-    """(kind, target, rego, libs): `code[engine=Rego]` wins over the legacy `rego` field
+    """-> (kind, target name, rego, libs) of a ConstraintTemplate with exactly one target.  The Rego of a target comes
+    from its `code` entry with engine "Rego" when there is one, else from the legacy `rego` / `libs` fields
     (website/docs/constrainttemplates.md:216-232)."""
     spec = ct.get("spec")
     if not isinstance(spec, dict):
         raise ClientError("invalid ConstraintTemplate: spec must be an object")
-    try:
-        kind = spec["crd"]["spec"]["names"]["kind"]
-    except (KeyError, TypeError):
+    names = spec
+    for step in ("crd", "spec", "names"):
+        names = names.get(step) if isinstance(names, dict) else None
+    if not isinstance(names, dict) or "kind" not in names:
         raise ClientError("invalid ConstraintTemplate: missing spec.crd.spec.names.kind")
     targets = spec.get("targets") or []
     if len(targets) != 1:
         raise ClientError("invalid ConstraintTemplate: expected exactly 1 target, got %d" % len(targets))
-    tg = targets[0]
-    rego, libs = None, []
-    for code in tg.get("code") or []:
-        if code.get("engine") == "Rego":
-            src = code.get("source") or {}
-            rego, libs = src.get("rego"), list(src.get("libs") or [])
-    if rego is None:
-        rego, libs = tg.get("rego"), list(tg.get("libs") or [])
-    return kind, tg.get("target"), rego, libs
+    target = targets[0]
+    rego_entries = [e.get("source") or {} for e in (target.get("code") or []) if e.get("engine") == "Rego"]
+    source = rego_entries[-1] if rego_entries and rego_entries[-1].get("rego") is not None else target
+    return names["kind"], target.get("target"), source.get("rego"), list(source.get("libs") or [])
 
 
 class Driver:
@@ -519,6 +539,8 @@ class Driver:
             if table.statuses[0] != L.GK_OK:
                 raise EngineError(L.GK_ERR_REVIEW, "review rejected by HandleReview")
             ev = table.eval()
+            if ev.too_big_reviews():
+                raise LimitError()
             wanted = {self.constraint_id(c): c for c in constraints}
             results = []
             for cid, _ in ev.pairs("viol"):
@@ -544,82 +566,81 @@ class Driver:
 
 
 # ---------------------------------------------------------------------------------------------- Client mirror
+_KNOWN_ACTIONS = frozenset(("deny", "dryrun", "warn", "scoped"))
+
+
 def get_enforcement_action(c):
-    """pkg/util/enforcement_action.go:132-151 (pinned by enforcement_action_test.go:113-165): default deny; anything
-    outside {deny, dryrun, warn, scoped} is "unrecognized"; a spec / enforcementAction of the wrong type is an error."""
-    spec = c.get("spec")
-    if spec is None:
+    """util.GetEnforcementAction (pkg/util/enforcement_action.go:132-151; table: enforcement_action_test.go:113-165).
+    No spec or an empty action -> deny; a known action -> itself; any other string -> "unrecognized"; a spec or an
+    action of the wrong JSON type -> error."""
+    if "spec" not in c or c["spec"] is None:
         return "deny"
-    if not isinstance(spec, dict) or not isinstance(spec.get("enforcementAction", ""), str):
-        raise ClientError("unable to parse spec.enforcementAction")   # ErrInvalidSpecEnforcementAction
-    ea = spec.get("enforcementAction", "")
-    if ea == "":
+    spec = c["spec"]
+    action = spec.get("enforcementAction", "") if isinstance(spec, dict) else None
+    if not isinstance(action, str):
+        raise ClientError("unable to parse spec.enforcementAction")
+    if not action:
         return "deny"
-    return ea if ea in ("deny", "dryrun", "warn", "scoped") else "unrecognized"
+    return action if action in _KNOWN_ACTIONS else "unrecognized"
 
 
 def scoped_actions_for_ep(ep, c):
-    """pkg/util/enforcement_action.go:153-174 (pinned by enforcement_action_test.go:235-385): the actions whose
-    enforcementPoints name `ep` or "*"; a scopedEnforcementActions value that is not a list of objects is an error."""
-    spec = c.get("spec") if isinstance(c.get("spec"), dict) else {}
-    seas = spec.get("scopedEnforcementActions")
-    if seas is None:
+    """util.ScopedActionForEP (pkg/util/enforcement_action.go:153-174; table: enforcement_action_test.go:235-385): one
+    entry per scopedEnforcementActions element that lists `ep` or "*" among its enforcementPoints."""
+    spec = c.get("spec")
+    entries = spec.get("scopedEnforcementActions") if isinstance(spec, dict) else None
+    if entries is None:
         return []
-    if not isinstance(seas, list) or not all(isinstance(x, dict) for x in seas):
+    if not isinstance(entries, list) or any(not isinstance(e, dict) for e in entries):
         raise ClientError("could not convert JSON to scopedEnforcementActions")
-    out = []
-    for sea in seas:
-        for p in sea.get("enforcementPoints") or []:
-            if isinstance(p, dict) and p.get("name") in (ep, ALL_EP):
-                out.append(sea.get("action"))
-                break
-    return out
+    wanted = (ep, ALL_EP)
+    return [e.get("action") for e in entries
+            if any(isinstance(pt, dict) and pt.get("name") in wanted for pt in (e.get("enforcementPoints") or []))]
 
 
-def _default(schema, value):
+def _fill_defaults(schema, node):
+    """structural-schema defaulting of one node (k8s apiextensions `default`): object properties, additionalProperties
+    and array items, depth first"""
     if not isinstance(schema, dict):
-        return value
-    if isinstance(value, dict):
-        props = schema.get("properties") or {}
-        for k, sub in props.items():
-            if k not in value and isinstance(sub, dict) and "default" in sub:
-                value[k] = copy.deepcopy(sub["default"])
-            if k in value:
-                value[k] = _default(sub, value[k])
-        addl = schema.get("additionalProperties")
-        if isinstance(addl, dict):
-            for k in value:
-                if k not in props:
-                    value[k] = _default(addl, value[k])
-    elif isinstance(value, list):
-        items = schema.get("items")
-        if isinstance(items, dict):
-            value = [_default(items, v) for v in value]
-    return value
+        return node
+    if isinstance(node, list):
+        item_schema = schema.get("items")
+        return [_fill_defaults(item_schema, x) for x in node] if isinstance(item_schema, dict) else node
+    if not isinstance(node, dict):
+        return node
+    declared = schema.get("properties") or {}
+    for name, sub in declared.items():
+        if name not in node and isinstance(sub, dict) and "default" in sub:
+            node[name] = copy.deepcopy(sub["default"])
+    extra = schema.get("additionalProperties")
+    for name in list(node):
+        if name in declared:
+            node[name] = _fill_defaults(declared[name], node[name])
+        elif isinstance(extra, dict):
+            node[name] = _fill_defaults(extra, node[name])
+    return node
 
 
 def apply_schema_defaults(ct, c):
     """Client.AddConstraint applies the template CRD's OpenAPI-v3 defaults before the driver sees the constraint
-    (pinned by test/gator/test/test.bats:277-291)."""
-    try:
-        schema = ct["spec"]["crd"]["spec"]["validation"]["openAPIV3Schema"]
-    except (KeyError, TypeError):
-        return c
+    (pinned by test/gator/test/test.bats:277-291 through tests/test_oracle_rego.py)."""
+    schema = ct
+    for step in ("spec", "crd", "spec", "validation", "openAPIV3Schema"):
+        schema = schema.get(step) if isinstance(schema, dict) else None
     if not isinstance(schema, dict):
         return c
-    c = copy.deepcopy(c)
-    spec = c.get("spec")
-    if not isinstance(spec, dict):
+    out = copy.deepcopy(c)
+    if not isinstance(out.get("spec"), dict):
         if "default" not in json.dumps(schema):
-            return c
-        spec = c["spec"] = {}
+            return out
+        out["spec"] = {}
+    spec = out["spec"]
     if "parameters" not in spec:
-        if "default" in schema:
-            spec["parameters"] = copy.deepcopy(schema["default"])
-        else:
-            return c
-    spec["parameters"] = _default(schema, spec["parameters"])
-    return c
+        if "default" not in schema:
+            return out
+        spec["parameters"] = copy.deepcopy(schema["default"])
+    spec["parameters"] = _fill_defaults(schema, spec["parameters"])
+    return out
 
 
 def process_data(obj):
@@ -638,6 +659,27 @@ def process_data(obj):
     if ns == "":
         return ["cluster", gv, kind, name]
     return ["namespace", ns, gv, kind, name]
+
+
+class ReviewFailure(ClientError):
+    """One review of a batch that could not be evaluated: HandleReview rejected it (ErrReview) or it is beyond the
+    engine's limits (`.cause` is then a LimitError).  ReviewBatch returns it IN PLACE of that review's result list, the
+    way the reference's audit loop logs a Review error and moves on to the next object (pkg/audit/manager.go:717-726)."""
+
+    def __init__(self, index, msg, cause=None):
+        super().__init__(msg)
+        self.index = index
+        self.cause = cause
+
+
+class AuditReport(dict):
+    """AuditAggregate's answer: {(kind, apiVersion, name): {"total", "total_pairs", "violations"}} plus
+    .totals_per_action ({enforcement action: results}, manager.go:904) and .errors ([ReviewFailure])."""
+
+    def __init__(self):
+        super().__init__()
+        self.totals_per_action = {}
+        self.errors = []
 
 
 class Client:
@@ -702,8 +744,24 @@ class Client:
     def RemoveData(self, obj):
         self.driver.RemoveData(TARGET_NAME, process_data(obj))
 
+    def _active(self, enforcement_point):
+        """{engine constraint id: (constraint, enforcement action, scoped actions)} of the constraints enforced at this
+        enforcement point (a `scoped` constraint without an action for the point is skipped, enforcement_action.go:153-174)"""
+        info = {}
+        for c in self.constraints.values():
+            ea = get_enforcement_action(c)
+            scoped = None
+            if ea == "scoped":
+                scoped = scoped_actions_for_ep(enforcement_point, c)
+                if not scoped:
+                    continue
+            info[self.driver.constraint_id(c)] = (c, ea, scoped)
+        return info
+
     def ReviewBatch(self, objs, enforcement_point=AUDIT_EP, namespaces=None):
-        """Review many objects in ONE device launch (the shape the audit sweep takes). -> list[list[Result]]"""
+        """Review many objects in ONE device launch (the shape the audit sweep takes).  -> one entry per object:
+        list[Result], or a ReviewFailure for an object that HandleReview rejects or that is beyond the engine's limits
+        (never an empty list for those: the engine fails closed)."""
         rins, idx = [], []
         for i, o in enumerate(objs):
             r = to_review_in(o, namespaces[i] if namespaces else None)
@@ -715,56 +773,61 @@ class Client:
             return out
         table = self.driver.engine.create_table(rins)
         try:
+            ev = table.eval()
+            failed = set()
             for k, st in enumerate(table.statuses):
                 if st != L.GK_OK:
-                    raise ClientError("review %d rejected by HandleReview" % idx[k])   # ErrReview
-            ev = table.eval()
-            by_id = {self.driver.constraint_id(c): c for c in self.constraints.values()}
-            info = {}
-            for cid, c in by_id.items():
-                ea = get_enforcement_action(c)
-                scoped = None
-                if ea == "scoped":
-                    scoped = scoped_actions_for_ep(enforcement_point, c)
-                    if not scoped:
-                        continue
-                info[cid] = (c, ea, scoped)
+                    failed.add(k)
+                    out[idx[k]] = ReviewFailure(idx[k], "review %d rejected by HandleReview" % idx[k])   # ErrReview
+            for k in ev.too_big_reviews():
+                failed.add(k)
+                out[idx[k]] = ReviewFailure(idx[k], str(LimitError("review %d" % idx[k])), LimitError("review %d" % idx[k]))
+            info = self._active(enforcement_point)
             for cid, r in ev.pairs("err"):
-                if cid in info:
+                if cid in info and r not in failed:
                     c, ea, scoped = info[cid]
                     for v in table.render_error(cid, r):
                         out[idx[r]].append(Result(v["msg"], c, {}, ea, scoped))
             for cid, r in ev.pairs("viol"):
-                if cid in info:
+                if cid in info and r not in failed:
                     c, ea, scoped = info[cid]
-                    for v in table.render(cid, r):
+                    rendered = table.render(cid, r)
+                    if not rendered:
+                        raise EngineError(L.GK_ERR_INTERNAL, "device flagged (constraint %d, review %d) but the template renders "
+                                                             "no violation: device / renderer disagree" % (cid, r))
+                    for v in rendered:
                         out[idx[r]].append(Result(v["msg"], c, v.get("details", {}), ea, scoped))
             return out
         finally:
             table.free()
 
     def Review(self, obj, enforcement_point=AUDIT_EP, namespace=None):
-        return self.ReviewBatch([obj], enforcement_point, [namespace])[0]
+        res = self.ReviewBatch([obj], enforcement_point, [namespace])[0]
+        if isinstance(res, ReviewFailure):
+            raise res
+        return res
 
     def AuditAggregate(self, objs, namespaces=None, limit=20, msg_size=256):
-        """pkg/audit/manager.go:885-941 (addAuditResponsesToUpdateLists) for one resident set: ONE device sweep, totals
-        per constraint from the bitmap rows, and the `limit` smallest violations per constraint (LimitQueue order:
-        group, version, kind, namespace, name, message, action; messages truncated to msg_size bytes, :1039-1048).
-        Only the top-k candidates selected on the device are rendered to messages; the totals count violating
-        (constraint, object) pairs -- the reference counts results, which differs only for templates that emit more
-        than one violation per object.  -> {(kind, apiVersion, name): {"total_pairs", "violations": [...]}}"""
+        """pkg/audit/manager.go:885-941 (addAuditResponsesToUpdateLists) for one resident set: ONE device sweep; per
+        constraint the RESULT total (totalViolationsPerConstraint, :902: one per types.Result -- gk_table_totals), the
+        totals per enforcement action (:904) and the `limit` smallest violations (LimitQueue order: group, version, kind,
+        namespace, name, message, action; messages truncated to msg_size bytes, :1039-1048).  Only the top-k candidates
+        selected on the device are rendered to messages for the lists.  -> AuditReport"""
         rins = [to_review_in(o, namespaces[i] if namespaces else None) for i, o in enumerate(objs)]
         table = self.driver.engine.create_table(rins, resident=True)
+        report = AuditReport()
         try:
             ev = table.eval()
+            for k, st in enumerate(table.statuses):
+                if st != L.GK_OK:
+                    report.errors.append(ReviewFailure(k, "review %d rejected by HandleReview" % k))
+            for k in ev.too_big_reviews():
+                report.errors.append(ReviewFailure(k, str(LimitError("review %d" % k)), LimitError("review %d" % k)))
             top = table.topk(limit)
+            totals = table.totals()
             row = {int(cid): i for i, cid in enumerate(ev.constraint_ids)}
-            out = {}
-            for c in self.constraints.values():
-                cid = self.driver.constraint_id(c)
-                ea = get_enforcement_action(c)
-                scoped = scoped_actions_for_ep(AUDIT_EP, c) if ea == "scoped" else None
-                if (ea == "scoped" and not scoped) or cid not in row:
+            for cid, (c, ea, scoped) in self._active(AUDIT_EP).items():
+                if cid not in row:
                     continue
                 reviews, overflow = top.get(cid, ([], False))
                 if overflow:   # more key ties than the device list holds: walk the bitmap row (exact, rare)
@@ -780,7 +843,10 @@ class Client:
                 cand.sort(key=lambda x: tuple(s_.encode("utf-8") for s_ in (x["group"], x["version"], x["kind"], x["namespace"], x["name"],
                                                                            x["message"], x["enforcementAction"])))
                 key = (c.get("kind", ""), c.get("apiVersion", ""), (c.get("metadata") or {}).get("name", ""))
-                out[key] = {"total_pairs": int(ev.counts[row[cid]]), "violations": cand[:limit]}
-            return out
+                n_results, n_pairs = totals.get(cid, (0, 0))
+                report[key] = {"total": n_results, "total_pairs": n_pairs, "violations": cand[:limit]}
+                if n_results:
+                    report.totals_per_action[ea] = report.totals_per_action.get(ea, 0) + n_results
+            return report
         finally:
             table.free()

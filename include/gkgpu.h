@@ -26,7 +26,10 @@ typedef enum {
   GK_ERR_NOT_FOUND = -4,    /* unknown template kind / constraint (driver.go:198-200) */
   GK_ERR_DEVICE = -5,       /* no MI355X / HIP failure */
   GK_ERR_REVIEW = -6,       /* review rejected by HandleReview (target.go:81-138, e.g. ErrOldObjectIsNil) */
-  GK_ERR_INTERNAL = -7
+  GK_ERR_INTERNAL = -7,
+  GK_ERR_LIMIT = -8         /* a review is beyond the engine's limits (an array that element predicates iterate has more
+                               than 255 elements): reported per review in gk_eval_out.too_big, NEVER evaluated to "no
+                               violations" -- the caller must fail closed or take that review to the reference CPU driver */
 } gk_status;
 
 typedef struct {
@@ -146,6 +149,19 @@ typedef struct {
 } gk_topk_out;
 int gk_table_topk(gk_engine* e, gk_table* t, uint32_t k, gk_topk_out** out);
 void gk_topk_free(gk_topk_out* o);
+
+/* Result-level totals of the table's most recent evaluation (row a11): pkg/audit/manager.go:902 increments
+ * totalViolationsPerConstraint once per types.Result, and one violating (constraint, object) pair yields as many
+ * results as the template's violation set has distinct {msg, details} members.  `pairs` = popcount of the bitmap row,
+ * `results` = what the reference's counters hold.  Needs GK_TABLE_KEEP_DOCS. */
+typedef struct {
+  uint32_t n_constraints;
+  const uint32_t* constraint_ids;
+  const uint64_t* results;
+  const uint64_t* pairs;
+} gk_totals_out;
+int gk_table_totals(gk_engine* e, gk_table* t, gk_totals_out** out);
+void gk_totals_free(gk_totals_out* o);
 
 /* Debug: the compiled plan as text (Driver.Dump, pkg/drivers/k8scel/driver.go:253). */
 int gk_dump(gk_engine* e, char** text_out);

@@ -129,6 +129,7 @@ void dev_topk(const DevTable* t, uint32_t nc, const std::vector<uint32_t>& order
     (*n)[c] = count < cap ? count : cap;
   }
 }
+void dev_last_viol(const DevTable* t, uint32_t nc, std::vector<uint64_t>* viol) { (void)nc; *viol = t->last_viol; }
 void dev_eval_launch(const DevPlan*, const DevTable* dt, const EvalOptions&) { const_cast<DevTable*>(dt)->pending++; }
 void dev_eval(const DevPlan* p, const DevTable* dt, const EvalOptions& opt, EvalOut* o) { dev_eval_launch(p, dt, opt); dev_eval_finish(p, dt, opt, o); }
 void dev_eval_finish(const DevPlan* p, const DevTable* dt, const EvalOptions& opt, EvalOut* o) {
@@ -144,7 +145,6 @@ void dev_eval_finish(const DevPlan* p, const DevTable* dt, const EvalOptions& op
   auto t0 = std::chrono::steady_clock::now();
   for (uint32_t r = 0; r < n; r++) {
     uint32_t tile = r / GK_TILE; uint64_t bit = 1ull << (r % GK_TILE);
-    if (t.rflags[r] & RF_TOO_BIG) { o->too_big[tile] |= bit; continue; }
     Results res{0, 0, 0};
     if (!eval_review(p->fast, t, r, &res, p->row ? p : nullptr)) {
       o->n_overflow++;

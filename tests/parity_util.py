@@ -65,11 +65,33 @@ def load_both(backend, templates, constraints, data=(), validate=True, **kw):
 
 
 def assert_parity(c, oc, reviews, ep=D.AUDIT_EP, namespaces=None):
+    """Product == oracle for every review: (1) the rendered result multisets (constraint, msg, details, actions), and
+    (2) the RAW device bitmaps -- the violation bits and the match-error bits, before any host rendering -- against the
+    pair sets the oracle's results imply, so that a spurious device bit cannot hide behind a renderer that returns []."""
     got = c.ReviewBatch(reviews, ep, namespaces)
     total = 0
+    want_viol, want_err = set(), set()
     for i, (rv, g) in enumerate(zip(reviews, got)):
         exp = oc.review(to_oracle_review(rv), ep, namespaces[i] if namespaces else None)
+        assert not isinstance(g, Exception), "review %d: %r" % (i, g)
         a, b = sorted(key(r) for r in g), sorted(key(r) for r in exp)
         assert a == b, "review %d: device %r != oracle %r" % (i, a, b)
         total += len(b)
+        for r in exp:
+            k = (r.constraint.get("kind"), (r.constraint.get("metadata") or {}).get("name"))
+            (want_err if r.msg.startswith("unable to match constraints: ") and not r.metadata.get("details") else want_viol).add((k, i))
+    rins = [D.to_review_in(rv, namespaces[i] if namespaces else None) for i, rv in enumerate(reviews)]
+    table = c.driver.engine.create_table(rins, keep_docs=False)
+    try:
+        ev = table.eval()
+        active = {cid: (cons.get("kind"), (cons.get("metadata") or {}).get("name")) for cid, (cons, _, _) in c._active(ep).items()}
+        assert not ev.too_big_reviews()
+        dev_viol = {(active[cid], r) for cid, r in ev.pairs("viol") if cid in active}
+        dev_err = {(active[cid], r) for cid, r in ev.pairs("err") if cid in active}
+        assert dev_viol == want_viol, "raw violation bitmap != oracle pairs: only device %r, only oracle %r" % (
+            sorted(dev_viol - want_viol)[:5], sorted(want_viol - dev_viol)[:5])
+        assert dev_err == want_err, "raw match-error bitmap != oracle pairs: only device %r, only oracle %r" % (
+            sorted(dev_err - want_err)[:5], sorted(want_err - dev_err)[:5])
+    finally:
+        table.free()
     return total

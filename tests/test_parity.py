@@ -85,10 +85,11 @@ def test_match_table(backend, fixtures):
                 assert res[0].msg == "denyall constraint installed"
 
 
-@pytest.mark.parametrize("backend", [b for b in BACKENDS if b.id.startswith("hostemu")])   # added after the round's last GPU visit
+@pytest.mark.parametrize("backend", BACKENDS)
 def test_matcher_match_table(backend, fixtures):
     """pkg/target/target_test.go:657-981 (TestMatcher_Match): review shapes, object / oldObject combinations, cached
-    Namespace fallback (matcher.go:37-39) and the two error kinds, through the device path and through the oracle."""
+    Namespace fallback (matcher.go:37-39) and the two error kinds (ErrMatching, ErrRequestObject -- incl. the object that
+    Unstructured.UnmarshalJSON rejects, matcher.go:73-93), through the device path and through the oracle."""
     tmpl = fixtures["go_consts"]["pkg/target/target_integration_test.go"]["testTemplate"]["docs"][0]
     for name, shape, body, ns, cached, mt, want, want_err in T.MATCHER_MATCH_CASES:
         cons = {"apiVersion": "constraints.gatekeeper.sh/v1beta1", "kind": "DenyAll", "metadata": {"name": "c"}, "spec": {"match": mt}}
@@ -97,19 +98,13 @@ def test_matcher_match_table(backend, fixtures):
             rv = D.AugmentedUnstructured(D.Unstructured(body), ns, "")
         else:
             rv = D.AugmentedReview(D.AdmissionRequest(dict(body)), ns, "")
-        # KNOWN GAP: a request object that Unstructured.UnmarshalJSON rejects (no `kind`) must yield
-        # the ErrRequestObject autoreject (matcher.go:73-93); the oracle restates it, the device plan does not yet
-        product_gap = name == "Raw object doesn't unmarshal"
         for client, review in ((c, rv), (oc, to_oracle_review(rv))):
-            if client is c and product_gap:
-                continue
             res = client.Review(review, D.AUDIT_EP) if client is c else client.review(review, D.AUDIT_EP, None)
             if want_err:
                 assert len(res) == 1 and res[0].msg.startswith("unable to match constraints: "), (name, [r.msg for r in res])
             else:
                 assert [r.msg for r in res] == (["denyall constraint installed"] if want else []), (name, [r.msg for r in res])
-        if not product_gap:
-            assert_parity(c, oc, [rv])
+        assert_parity(c, oc, [rv])
 
 
 def _random_match_world(seed, n_cons, n_objs):
@@ -360,6 +355,10 @@ def test_audit_aggregation(backend, fixtures):
             for k in {(r.constraint.get("kind", ""), r.constraint.get("apiVersion", ""), r.constraint["metadata"]["name"]) for r in res}:
                 pairs[k] = pairs.get(k, 0) + 1
         assert {k: v["total_pairs"] for k, v in got.items() if v["total_pairs"]} == pairs
+        # totalViolationsPerConstraint / PerEnforcementAction count RESULTS (manager.go:902-904), not violating pairs
+        assert {k: v["total"] for k, v in got.items() if v["total"]} == totals
+        assert got.totals_per_action == per_action and not got.errors
+        assert sum(totals.values()) > sum(pairs.values())   # the workload has multi-result pairs, so the two differ
         for k, q in lists.items():
             assert got[k]["violations"] == q.sorted(), k
         assert sum(len(v["violations"]) for v in got.values()) == sum(len(q.items) for q in lists.values()) > 0
@@ -516,7 +515,7 @@ def test_regex_randomised(backend):
     assert assert_parity(c, oc, [D.AugmentedUnstructured(D.Unstructured(o), None, "Original") for o in objs]) > 100
 
 
-@pytest.mark.parametrize("backend", [b for b in BACKENDS if b.id.startswith("hostemu")])   # added after the round's last GPU visit
+@pytest.mark.parametrize("backend", BACKENDS)
 def test_gator_verify_suite_template(backend, fixtures):
     """test/gator/verify/{template,constraint*,allow_foo,deny_foo}.yaml (the reference's own `gator verify` suite): the
     template reads its input through object.get(input, "parameters", {}) / object.get(input.review.object, "foo", "")."""
@@ -595,6 +594,27 @@ def test_edge_cases(backend, fixtures):
     ev = table.eval()
     assert int(ev.too_big[0]) == 1 and ev.viol.sum() == 0
     table.free()
+    # ... and every caller fails CLOSED on it (a padded array must not evade the constraints): Review raises,
+    # ReviewBatch returns the failure in place and still answers the other reviews, the audit report lists it
+    huge_priv = json.loads(json.dumps(huge))
+    huge_priv["spec"]["containers"][7]["securityContext"] = {"privileged": True}
+    hr = D.AugmentedUnstructured(D.Unstructured(huge_priv), None, "Original")
+    with pytest.raises(D.ReviewFailure) as ei:
+        c.Review(hr)
+    assert isinstance(ei.value.cause, D.LimitError)
+    with pytest.raises(D.LimitError):
+        c.driver.Query(D.TARGET_NAME, list(c.constraints.values()), hr)
+    batch = c.ReviewBatch([rv[0], hr, rv[1]])
+    assert isinstance(batch[1], D.ReviewFailure) and batch[1].index == 1
+    assert sorted(key(r) for r in batch[0]) == sorted(key(r) for r in oc.review(to_oracle_review(rv[0]), D.AUDIT_EP, None))
+    assert sorted(key(r) for r in batch[2]) == sorted(key(r) for r in oc.review(to_oracle_review(rv[1]), D.AUDIT_EP, None))
+    rep = c.AuditAggregate([rv[0], hr, rv[1]])
+    assert [e.index for e in rep.errors] == [1]
+    # an array of > 255 elements that NO element predicate iterates does not put the review beyond the limits:
+    # one privileged container + 300 finalizers evaluates exactly (the oracle finds the same violations)
+    padded = {"apiVersion": "v1", "kind": "Pod", "metadata": {"name": "padded", "namespace": "prod-01", "finalizers": ["f%d" % i for i in range(300)]},
+              "spec": {"containers": [{"name": "c0", "image": "x", "securityContext": {"privileged": True}}]}}
+    assert assert_parity(c, oc, [D.AugmentedUnstructured(D.Unstructured(padded), None, "Original")]) > 0
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
