@@ -2,12 +2,18 @@
 """Benchmark of the hot path: AdmissionReview x constraint evaluations per second (BASELINE.json `metric`).
 
 A "step" = one pass of the hot path (Match + violation predicates for every loaded constraint) over one batch of
-synthetic reviews that is already resident in HBM.  Default workload = BASELINE.json configs[1]:
-30 PSP constraints x 100k synthetic Pod reviews on one MI355X.  With --gpus N (launched by torch.distributed.run,
-one process per GPU) every rank sweeps its own shard of N x 100k objects (weak scaling) and the per-shard violation
-bitmaps / counts are exchanged with RCCL all-gather / all-reduce inside every step.
+synthetic reviews that is already resident in HBM.  Default workload at N=1 = BASELINE.json configs[2], the largest
+single-GPU configuration: the pkg/audit sweep, 50 constraints x 1 000 000 cached cluster objects on one MI355X
+(--config 1 --reviews 100000 gives configs[1]: 30 PSP constraints x 100k Pod reviews).  With --gpus N (launched by
+torch.distributed.run, one process per GPU) the objects are sharded: --scaling weak (default) gives every rank
+`--reviews` objects, --scaling strong splits `--reviews` objects over the ranks (configs[3]: --reviews 10000000); the
+per-shard violation bitmaps / counts are exchanged with one RCCL all-gather inside every step.
 
-Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` and `cpu_baseline` objects.
+Prints ONE JSON line on rank 0 (contract in the task description) with
+  roofline      dominant kernel: algorithmic bytes per launch / average launch duration (HIP events) vs 8 TB/s HBM
+  end_to_end    the PCIe-inclusive leg: host parse + HandleReview + flatten + H2D of the same objects (never `value`)
+  cpu_baseline  the compiled restated-reference CPU loop (oracle/cpu_ref.cpp) on 1 thread and on all host cores
+  parity_sample the device bitmap of the timed table compared with that CPU loop on a sample of the same objects
 """
 import argparse
 import json
@@ -21,63 +27,57 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def cpu_baseline(templates, constraints, objs, nss, budget_s=15.0):
-    """The oracle (Python restatement of the reference's serial audit loop, pkg/audit/manager.go:591-642: per object
-    Client.Review = per-constraint match + Rego evaluation) timed on ONE host core over a bounded sample."""
-    from oracle import client as OC
-    from oracle import target as OT
-    from gatekeeper_amd import synth
-    oc = OC.Client()
-    for t in templates:
-        oc.add_template(t)
-    for k in constraints:
-        oc.add_constraint(k)
-    t0 = time.perf_counter()
-    n = 0
-    for o in objs:
-        oc.review(OT.AugmentedUnstructured(OT.Unstructured(o), synth.namespace_for(o, nss), "Original"), OC.AUDIT_EP)
-        n += 1
-        if time.perf_counter() - t0 > budget_s:
-            break
-    dt = time.perf_counter() - t0
-    return {"value": n * len(constraints) / dt, "unit": "evals/s", "cores": 1, "kind": "port",
-            "sample": "%d of the same synthetic Pods x %d constraints, pure-Python oracle (tree-walking Rego "
-                      "interpreter; the Go/OPA reference is not runnable here), %.1f s" % (n, len(constraints), dt)}
+def cpu_leg(templates, constraints, batch, ev, budget_s=10.0):
+    """cpu_baseline + parity_sample.  The compiled restatement of the reference's serial audit loop (oracle/cpu_ref.cpp:
+    per object marshal, per constraint re-decode + match.Matches + template evaluation; pkg/audit/manager.go:591-642) is
+    timed on ONE thread (the reference's shape) and on all host cores, each on a bounded sample of the SAME objects the
+    device table holds; its violation / autoreject bitmaps are compared with the device's over the larger sample."""
+    import numpy as np
+    from oracle import cpu_ref as CR
+    ref = CR.CpuRef(templates, constraints)
+    nc = len(constraints)
+    cores = os.cpu_count() or 1
+    probe_n = min(batch.n, 1024)
+    probe = ref.review(batch.reviews, probe_n, 1)
+    rate1 = probe_n / max(probe["seconds"], 1e-9)               # reviews/s on one thread
+    n1 = int(max(64, min(batch.n, rate1 * budget_s)) // 64 * 64) or batch.n
+    one = ref.review(batch.reviews, n1, 1)
+    nall = int(max(n1, min(batch.n, rate1 * cores * budget_s * 0.6)) // 64 * 64) or batch.n
+    allc = ref.review(batch.reviews, nall, cores)
+    # parity: device bitmap rows (by constraint key) vs the CPU loop, over the all-core sample
+    row_of = {int(cid): i for i, cid in enumerate(ev.constraint_ids)}
+    words = nall // 64
+    equal, dev_pairs, cpu_pairs = True, 0, 0
+    for row, cid in enumerate(batch_constraint_ids):
+        d_v, d_e = ev.viol[row_of[cid]][:words], ev.err[row_of[cid]][:words]
+        equal = equal and bool((d_v == allc["viol"][row][:words]).all()) and bool((d_e == allc["err"][row][:words]).all())
+        dev_pairs += int(np.unpackbits(d_v.view(np.uint8)).sum())
+        cpu_pairs += int(np.unpackbits(allc["viol"][row][:words].view(np.uint8)).sum())
+    base = {"value": n1 * nc / one["seconds"], "unit": "evals/s", "cores": 1, "kind": "port",
+            "sample": "first %d of the same synthetic objects x %d constraints, compiled restated-reference CPU loop (oracle/cpu_ref.cpp: "
+                      "per-object marshal, per-constraint re-decode + match.Matches + tree-walking Rego evaluation; the Go/OPA "
+                      "reference itself cannot be built here), %.1f s on 1 thread" % (n1, nc, one["seconds"]),
+            "all_cores": {"value": nall * nc / allc["seconds"], "cores": cores, "sample_reviews": nall, "seconds": allc["seconds"]}}
+    parity = {"n": nall, "constraints": nc, "pairs_equal": equal, "device_violating_pairs": dev_pairs, "cpu_violating_pairs": cpu_pairs,
+              "checker": "oracle/cpu_ref.cpp (violation + autoreject bitmaps, bit for bit)"}
+    return base, parity
 
 
-def cxx_host_rate(client, objs, nss, budget_s=5.0):
-    """Orientation only (not the cpu_baseline): the engine's own host-side C++ evaluator -- the tree-walking Rego
-    evaluation that renders messages for violating pairs -- run over EVERY (constraint, review) pair of a sample on one
-    core, i.e. a compiled CPU execution of the same templates, without the match step."""
-    from gatekeeper_amd import driver as D
-    from gatekeeper_amd import synth
-    sample = objs[:512]
-    rins = [D.to_review_in(D.AugmentedUnstructured(D.Unstructured(o), synth.namespace_for(o, nss), "Original")) for o in sample]
-    table = client.driver.engine.create_table(rins, keep_docs=True)
-    cids = [client.driver.constraint_id(c) for c in client.constraints.values()]
-    t0 = time.perf_counter()
-    n = 0
-    for r in range(len(sample)):
-        for cid in cids:
-            table.render(cid, r)
-        n += len(cids)
-        if time.perf_counter() - t0 > budget_s:
-            break
-    dt = time.perf_counter() - t0
-    table.free()
-    return {"value": n / dt, "unit": "evals/s", "cores": 1,
-            "what": "gk_render (host C++ tree-walking evaluation of the template for one pair, incl. the ctypes call) over %d pairs" % n}
+batch_constraint_ids = []
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--reviews", type=int, default=100000, help="reviews per GPU")
-    ap.add_argument("--config", type=int, default=1, choices=[1, 2], help="1: 30 PSP x Pods; 2: 50 constraints x mixed objects")
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", type=int, default=2, choices=[1, 2], help="1: 30 PSP x Pods (configs[1]); 2: 50 constraints x mixed objects (configs[2])")
+    ap.add_argument("--reviews", type=int, default=None, help="objects per GPU (weak) / in total (strong); default 1000000 (config 2), 100000 (config 1)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.reviews is None:
+        args.reviews = 1000000 if args.config == 2 else 100000
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -101,8 +101,13 @@ def main():
     templates = synth.psp_templates(fx)
     constraints = synth.psp_constraints() if args.config == 1 else synth.audit_constraints()
     nss = synth.gen_namespaces()
-    # weak scaling: every rank owns `reviews` objects of the global, seeded object stream
-    objs = synth.gen_objects(args.reviews, seed=synth.SEED + rank, mixed=(args.config == 2))
+    if args.scaling == "strong":
+        per_rank = (args.reviews + world - 1) // world
+        start, n_local = rank * per_rank, max(0, min(per_rank, args.reviews - rank * per_rank))
+        total_reviews = args.reviews
+    else:
+        start, n_local = rank * args.reviews, args.reviews
+        total_reviews = args.reviews * world
 
     drv = D.Driver(device=local_rank, hostemu=False)
     client = D.Client(drv)
@@ -110,7 +115,17 @@ def main():
         client.AddTemplate(t)
     for k in constraints:
         client.AddConstraint(k)
-    sweep = ShardedSweep(client, objs, nss, dist=dist, device=dev)
+    defaulted = [client.constraints[(k["kind"], k["metadata"]["name"])] for k in constraints]
+    batch_constraint_ids[:] = [drv.constraint_id(c) for c in defaulted]
+
+    # objects [start, start + n_local) of the global synthetic stream, as JSON text (native generator == synth.py)
+    t_gen = time.perf_counter()
+    batch = synth.NativeBatch(drv.engine.lib, n_local, seed=synth.SEED, mixed=(args.config == 2), start=start, namespaces=nss)
+    t_gen = time.perf_counter() - t_gen
+    # end-to-end leg: JSON -> parse -> HandleReview -> flatten -> HBM (this is what a non-resident review costs)
+    table = drv.engine.create_table_native(batch.reviews, n_local, keep_docs=False, resident=True)
+    st = table.stats()
+    sweep = ShardedSweep(client, table=table, n=n_local, dist=dist, device=dev)
 
     def barrier():
         if dist is not None:
@@ -124,7 +139,8 @@ def main():
     res = sweep.sweep(args.steps)          # exactly `steps` launches (+ exchanges when sharded) in the timed region
     barrier()
     dt = time.perf_counter() - t0
-    counts = sweep.sweep(1, download=True).counts
+    final = sweep.sweep(1, download=True)
+    counts = final.counts
     # isolated kernel duration: a second, untimed pass with one HIP event pair per launch (the timed region above
     # brackets all launches with one pair, i.e. its average includes the gaps between consecutive launches)
     os.environ["GK_EVENT_PER_LAUNCH"] = "1"
@@ -137,41 +153,51 @@ def main():
 
     if rank == 0:
         nc = len(constraints)
-        evals = float(nc) * args.reviews * world * args.steps
+        evals = float(nc) * total_reviews * args.steps
         kernel_s = iso.fast_kernel_ms / 1e3          # average duration of the dominant kernel alone (per-launch events)
         achieved = res.algo_bytes / kernel_s / 1e9 if kernel_s > 0 else 0.0
-        full_table_bytes = int(res.n_rows) * 16 + args.reviews * 4   # what a kernel streaming every row would read
+        full_table_bytes = int(res.n_rows) * 16 + n_local * 4   # what a kernel streaming every row would read
+        cfg_name = ("configs[1]: 30 gatekeeper PSP constraints (5 in-tree PSP templates x 6 parameterisations) x %d synthetic Pod "
+                    "AdmissionReviews" if args.config == 1 else
+                    "configs[2]: pkg/audit sweep, 50 constraints x %d mixed synthetic cluster objects (80%% Pod, 10%% Deployment, 5%% Namespace, "
+                    "5%% Service/ConfigMap)") % total_reviews
+        e2e_s = st["flatten_s"] + st["upload_s"]
         out = {
             "metric": "AdmissionReview x constraint evals/sec",
             "value": evals / dt, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
-            "config": {"workload": ("configs[1]: 30 gatekeeper PSP constraints (5 in-tree PSP templates x 6 parameterisations) x "
-                                    "%d synthetic Pod AdmissionReviews per GPU" % args.reviews) if args.config == 1 else
-                       ("configs[2]: audit sweep, 50 constraints x %d mixed synthetic cluster objects per GPU" % args.reviews),
-                       "constraints": nc, "reviews_per_gpu": args.reviews, "rows_per_gpu": int(res.n_rows), "rows_read_per_gpu": int(res.n_rows_read),
+            "config": {"workload": cfg_name, "constraints": nc, "reviews_total": total_reviews, "reviews_rank0": n_local,
+                       "rows_rank0": int(res.n_rows), "rows_read_rank0": int(res.n_rows_read), "table_bytes_rank0": int(st["device_bytes"]),
+                       "timed_region_s": dt,
                        "parallelism": "objects sharded across %d GPU(s); one RCCL all-gather of [violation bitmaps | counts] per sweep" % world,
-                       "violating_pairs_rank0": int(counts.sum())},
+                       "violating_pairs_rank0": int(counts.sum()), "reviews_beyond_limits_rank0": len(final.too_big_reviews())},
             "roofline": {"bound": "hbm", "kernel": "gk_eval_tiles", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algo_bytes_per_launch": int(res.algo_bytes),
                          "avg_kernel_ms": iso.fast_kernel_ms, "launches_timed": int(iso.n_launches),
                          "avg_launch_ms_back_to_back": res.fast_kernel_ms, "lds_bytes_per_tile": int(res.lds_bytes),
                          "full_table_bytes": full_table_bytes,
                          "full_table_GBps": full_table_bytes / kernel_s / 1e9 if kernel_s > 0 else None,
-                         "kernel_only_evals_per_s": nc * args.reviews / kernel_s if kernel_s > 0 else None},
+                         "kernel_only_evals_per_s": nc * n_local / kernel_s if kernel_s > 0 else None},
+            "end_to_end": {"what": "rank 0: JSON text -> parse -> HandleReview -> flatten -> row groups -> HBM for the %d objects of its shard "
+                                   "(gk_table_create), then one sweep" % n_local,
+                           "flatten_s": st["flatten_s"], "h2d_s": st["upload_s"], "sweep_s": dt / args.steps, "host_threads": st["host_threads"],
+                           "json_bytes": st["json_bytes"], "reviews_per_s": n_local / e2e_s if e2e_s > 0 else None,
+                           "evals_per_s": nc * n_local / (e2e_s + dt / args.steps) if e2e_s > 0 else None,
+                           "json_MBps": st["json_bytes"] / st["flatten_s"] / 1e6 if st["flatten_s"] > 0 else None,
+                           "generate_s": t_gen},
         }
         # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes of this same command (bench.py
         # cannot run a profiler around itself); only reported when the profiled workload is the one just timed
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
-            if pmc.get("config") == args.config and pmc.get("reviews") == args.reviews and world == 1:
+            if pmc.get("config") == args.config and pmc.get("reviews") == n_local and world == 1:
                 out["roofline"]["traffic"] = pmc["hbm_bytes_per_launch"]
                 out["roofline"]["traffic_source"] = pmc["source"]
         except (OSError, ValueError):
             pass
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(templates, constraints, objs[:20000], nss)
-            out["cpu_host_evaluator_cxx"] = cxx_host_rate(client, objs, nss)
+            out["cpu_baseline"], out["parity_sample"] = cpu_leg(templates, defaulted, batch, final)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

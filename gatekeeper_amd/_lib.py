@@ -29,7 +29,9 @@ EXPORTS = [
     "gk_engine_create", "gk_engine_destroy", "gk_last_error", "gk_version", "gk_template_add", "gk_template_remove",
     "gk_constraint_add", "gk_constraint_remove", "gk_data_put", "gk_data_remove", "gk_table_create", "gk_table_free",
     "gk_table_eval", "gk_eval_free", "gk_render", "gk_render_error", "gk_free", "gk_dump", "gk_table_topk", "gk_topk_free",
-    "gk_table_totals", "gk_totals_free",
+    "gk_table_totals", "gk_totals_free", "gk_table_get_stats",
+    # include/gksynth.h (bench / test plumbing)
+    "gk_synth_batch_create", "gk_synth_batch_reviews", "gk_synth_batch_size", "gk_synth_batch_json_bytes", "gk_synth_batch_free",
 ]
 
 
@@ -64,6 +66,12 @@ class gk_topk_out(C.Structure):
 class gk_totals_out(C.Structure):
     _fields_ = [("n_constraints", C.c_uint32), ("constraint_ids", C.POINTER(C.c_uint32)), ("results", C.POINTER(C.c_uint64)),
                 ("pairs", C.POINTER(C.c_uint64))]
+
+
+class gk_table_stats(C.Structure):
+    _fields_ = [("n_reviews", C.c_uint64), ("n_rows", C.c_uint64), ("json_bytes", C.c_uint64), ("heap_bytes", C.c_uint64),
+                ("device_bytes", C.c_uint64), ("flatten_s", C.c_double), ("upload_s", C.c_double), ("host_threads", C.c_uint32),
+                ("reserved", C.c_uint32)]
 
 
 class EngineLoadError(RuntimeError):
@@ -123,8 +131,18 @@ def load(hostemu: bool | None = None):
     lib.gk_table_topk.argtypes = [vp, vp, u32, C.POINTER(C.POINTER(gk_topk_out))]
     lib.gk_topk_free.argtypes = [C.POINTER(gk_topk_out)]
     lib.gk_topk_free.restype = None
+    lib.gk_table_get_stats.argtypes = [vp, C.POINTER(gk_table_stats)]
     lib.gk_table_totals.argtypes = [vp, vp, C.POINTER(C.POINTER(gk_totals_out))]
     lib.gk_totals_free.argtypes = [C.POINTER(gk_totals_out)]
     lib.gk_totals_free.restype = None
+    lib.gk_synth_batch_create.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(cp), sz, C.POINTER(vp)]
+    lib.gk_synth_batch_reviews.argtypes = [vp]
+    lib.gk_synth_batch_reviews.restype = C.POINTER(gk_review_in)
+    lib.gk_synth_batch_size.argtypes = [vp]
+    lib.gk_synth_batch_size.restype = sz
+    lib.gk_synth_batch_json_bytes.argtypes = [vp]
+    lib.gk_synth_batch_json_bytes.restype = C.c_uint64
+    lib.gk_synth_batch_free.argtypes = [vp]
+    lib.gk_synth_batch_free.restype = None
     _cache[hostemu] = lib
     return lib

@@ -177,6 +177,7 @@ struct gk_table {
   uint32_t last_nc = 0;
   std::vector<uint32_t> last_ids;
   uint32_t n_reviews = 0;
+  gk_table_stats stats{};
 };
 
 namespace {
@@ -462,6 +463,7 @@ int gk_table_create(gk_engine* e, const gk_review_in* reviews, size_t n, uint32_
     if (keep) t->docs.resize(n);
     // Reviews are parsed, normalised (HandleReview) and flattened by host threads, each on a contiguous range of whole
     // tiles; the parts are appended in order (the path dictionary is shared and thread-safe).
+    const auto t_begin = std::chrono::steady_clock::now();
     const size_t n_tiles = (n + GK_RPT - 1) / GK_RPT;
     size_t n_threads = std::max<size_t>(1, std::min<size_t>(std::thread::hardware_concurrency(), n_tiles / 8));
     if (const char* ht = getenv("GK_HOST_THREADS")) n_threads = std::max(1, atoi(ht));
@@ -537,7 +539,15 @@ int gk_table_create(gk_engine* e, const gk_review_in* reviews, size_t n, uint32_
     t->path_rows = t->host.path_rows;
     t->path_max = t->host.path_max;
     t->resident = (flags & GK_TABLE_RESIDENT) || getenv("GK_SPECIALIZE_ALL");
+    const auto t_flat = std::chrono::steady_clock::now();
     t->dev = dev_table_upload(t->host);
+    const auto t_up = std::chrono::steady_clock::now();
+    t->stats.n_reviews = n; t->stats.n_rows = t->n_rows; t->stats.host_threads = (uint32_t)n_threads;
+    t->stats.heap_bytes = t->host.heap.size();
+    t->stats.device_bytes = dev_table_bytes(t->dev);
+    t->stats.flatten_s = std::chrono::duration<double>(t_flat - t_begin).count();
+    t->stats.upload_s = std::chrono::duration<double>(t_up - t_flat).count();
+    for (size_t i = 0; i < n; i++) t->stats.json_bytes += reviews[i].json_len;
     t->host.rows.clear(); t->host.rows.shrink_to_fit();
     t->host.heap.clear(); t->host.heap.shrink_to_fit();
     t->host.shdr.clear(); t->host.shdr.shrink_to_fit();
@@ -545,6 +555,12 @@ int gk_table_create(gk_engine* e, const gk_review_in* reviews, size_t n, uint32_
     *out = t.release();
     return GK_OK;
   } catch (const std::exception& ex) { return fail(GK_ERR_DEVICE, ex.what()); }
+}
+
+int gk_table_get_stats(const gk_table* t, gk_table_stats* out) {
+  if (!t || !out) return fail(GK_ERR_INVALID, "NULL argument");
+  *out = t->stats;
+  return GK_OK;
 }
 
 void gk_table_free(gk_table* t) {

@@ -317,6 +317,12 @@ class Table:
         self.engine.lib.gk_topk_free(out)
         return res
 
+    def stats(self):
+        """host-side cost of building the table (gk_table_get_stats) as a dict"""
+        st = L.gk_table_stats()
+        self.engine._check(self.engine.lib.gk_table_get_stats(self.handle, C.byref(st)))
+        return {f: getattr(st, f) for f, _ in st._fields_ if f != "reserved"}
+
     def totals(self):
         """Result-level totals of the most recent eval(): {constraint id: (results, violating pairs)} (gk_table_totals)."""
         out = C.POINTER(L.gk_totals_out)()
@@ -414,6 +420,14 @@ class Engine:
         flags = (L.GK_TABLE_KEEP_DOCS if keep_docs else 0) | (L.GK_TABLE_RESIDENT if resident else 0)
         self._check(self.lib.gk_table_create(self.handle, arr, n, flags, st, C.byref(h)))
         return Table(self, h, list(st)[:n], n)
+
+    def create_table_native(self, reviews_ptr, n, keep_docs=False, resident=False):
+        """gk_table_create on an existing gk_review_in array (e.g. synth.NativeBatch.reviews)"""
+        st = (C.c_int32 * max(1, n))()
+        h = C.c_void_p()
+        flags = (L.GK_TABLE_KEEP_DOCS if keep_docs else 0) | (L.GK_TABLE_RESIDENT if resident else 0)
+        self._check(self.lib.gk_table_create(self.handle, reviews_ptr, n, flags, st, C.byref(h)))
+        return Table(self, h, st, n)
 
     def dump(self):
         p = C.c_void_p()

@@ -43,13 +43,17 @@ class ShardedSweep:
     place (bitmap and counts are one contiguous allocation, aliased as a torch tensor) and is ordered after the kernels
     by the stream; the host synchronises once, when the passes are collected."""
 
-    def __init__(self, client, objs, namespaces, dist=None, device=None):
+    def __init__(self, client, objs=None, namespaces=None, dist=None, device=None, table=None, n=None):
+        """Either `objs` (+ their Namespace map) to flatten here, or an existing resident `table` of `n` reviews."""
         self.client = client
         self.dist = dist
-        rins = [D.to_review_in(D.AugmentedUnstructured(D.Unstructured(o), synth.namespace_for(o, namespaces), "Original"))
-                for o in objs]
-        self.table = client.driver.engine.create_table(rins, keep_docs=False, resident=True)   # the audit set stays on the GPU
-        self.n = len(objs)
+        if table is None:
+            rins = [D.to_review_in(D.AugmentedUnstructured(D.Unstructured(o), synth.namespace_for(o, namespaces), "Original"))
+                    for o in objs]
+            table = client.driver.engine.create_table(rins, keep_docs=False, resident=True)   # the audit set stays on the GPU
+            n = len(objs)
+        self.table = table
+        self.n = n
         self.nc = len(client.constraints)
         self.n_tiles = (self.n + 63) // 64
         self.bm_bytes = self.nc * self.n_tiles * 8
@@ -116,6 +120,12 @@ class ShardedSweep:
         if steps > done:
             ev = self.table.eval(download=False, collect_only=True)   # the one host synchronisation of the sweep
             self._ptrs = (ev.d_viol, ev.d_counts)
+        if ev is not None and ev.n_overflow:
+            # reviews that overflow the LDS element capacities are re-run by the big variant only when a pass is
+            # collected, i.e. AFTER its exchange step: their bits would be missing from what the other ranks gathered
+            raise RuntimeError("%d review(s) of this shard need the large-capacity kernel variant; the stream-ordered exchange "
+                               "would gather their bits too early (create the table with resident=True so the plan variant fits "
+                               "the shard's arrays)" % ev.n_overflow)
         torch.cuda.current_stream().synchronize()
         if download:
             self.table.launch()

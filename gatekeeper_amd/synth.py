@@ -88,7 +88,8 @@ def _labels(rng):
     n = 2 + rng.below(5)
     out = {}
     for _ in range(n):
-        out[rng.pick(LABEL_KEYS)] = rng.pick(LABEL_VALUES)
+        value = rng.pick(LABEL_VALUES)
+        out[rng.pick(LABEL_KEYS)] = value
     return out
 
 
@@ -178,31 +179,38 @@ def gen_pod(rng, i):
     return {"apiVersion": "v1", "kind": "Pod", "metadata": md, "spec": _pod_spec(rng)}
 
 
-def gen_objects(n, seed=SEED, mixed=False):
-    """n synthetic objects. mixed=False: all Pods (config[1]). mixed=True: 80% Pod, 10% Deployment, 5% Namespace,
-    5% Service/ConfigMap (config[2], the audit sweep)."""
-    rng = SplitMix64(seed)
-    out = []
-    for i in range(n):
-        kind = "Pod"
-        if mixed:
-            kind = rng.weighted([("Pod", 0.8), ("Deployment", 0.1), ("Namespace", 0.05), ("Service", 0.025), ("ConfigMap", 0.025)])
-        if kind == "Pod":
-            out.append(gen_pod(rng, i))
-        elif kind == "Deployment":
-            pod = gen_pod(rng, i)
-            out.append({"apiVersion": "apps/v1", "kind": "Deployment",
-                        "metadata": {"name": "dep-%07d" % i, "namespace": pod["metadata"]["namespace"], "labels": pod["metadata"]["labels"]},
-                        "spec": {"replicas": 1 + rng.below(5), "template": {"metadata": {"labels": pod["metadata"]["labels"]}, "spec": pod["spec"]}}})
-        elif kind == "Namespace":
-            out.append({"apiVersion": "v1", "kind": "Namespace", "metadata": {"name": "gen-ns-%07d" % i, "labels": _labels(rng)}})
-        elif kind == "Service":
-            out.append({"apiVersion": "v1", "kind": "Service", "metadata": {"name": "svc-%07d" % i, "namespace": rng.pick(NAMESPACES)},
-                        "spec": {"ports": [{"port": 80 + rng.below(1000)}], "selector": {"app": rng.pick(LABEL_VALUES)}}})
-        else:
-            out.append({"apiVersion": "v1", "kind": "ConfigMap", "metadata": {"name": "cm-%07d" % i, "namespace": rng.pick(NAMESPACES)},
-                        "data": {"k%d" % k: rng.pick(LABEL_VALUES) for k in range(1 + rng.below(4))}})
-    return out
+def object_rng(seed, i):
+    """Every object has its own generator, seeded from (seed, index): any slice of the object stream can be produced
+    independently (shards, samples, the native generator's threads) and is identical wherever it is produced."""
+    return SplitMix64(SplitMix64((seed ^ (i * 0xD1342543DE82EF95)) & 0xFFFFFFFFFFFFFFFF).next())
+
+
+def gen_object(seed, i, mixed=False):
+    rng = object_rng(seed, i)
+    kind = "Pod"
+    if mixed:
+        kind = rng.weighted([("Pod", 0.8), ("Deployment", 0.1), ("Namespace", 0.05), ("Service", 0.025), ("ConfigMap", 0.025)])
+    if kind == "Pod":
+        return gen_pod(rng, i)
+    if kind == "Deployment":
+        pod = gen_pod(rng, i)
+        return {"apiVersion": "apps/v1", "kind": "Deployment",
+                "metadata": {"name": "dep-%07d" % i, "namespace": pod["metadata"]["namespace"], "labels": pod["metadata"]["labels"]},
+                "spec": {"replicas": 1 + rng.below(5), "template": {"metadata": {"labels": pod["metadata"]["labels"]}, "spec": pod["spec"]}}}
+    if kind == "Namespace":
+        return {"apiVersion": "v1", "kind": "Namespace", "metadata": {"name": "gen-ns-%07d" % i, "labels": _labels(rng)}}
+    if kind == "Service":
+        return {"apiVersion": "v1", "kind": "Service", "metadata": {"name": "svc-%07d" % i, "namespace": rng.pick(NAMESPACES)},
+                "spec": {"ports": [{"port": 80 + rng.below(1000)}], "selector": {"app": rng.pick(LABEL_VALUES)}}}
+    return {"apiVersion": "v1", "kind": "ConfigMap", "metadata": {"name": "cm-%07d" % i, "namespace": rng.pick(NAMESPACES)},
+            "data": {"k%d" % k: rng.pick(LABEL_VALUES) for k in range(1 + rng.below(4))}}
+
+
+def gen_objects(n, seed=SEED, mixed=False, start=0):
+    """objects [start, start + n) of the synthetic stream `seed`.  mixed=False: all Pods (config[1]).  mixed=True: 80% Pod,
+    10% Deployment, 5% Namespace, 5% Service/ConfigMap (config[2], the audit sweep).  The native generator
+    (csrc/synth.cpp, gk_synth_batch_create) produces the same objects as JSON text; tests/test_synth.py pins the two."""
+    return [gen_object(seed, i, mixed) for i in range(start, start + n)]
 
 
 # ------------------------------------------------------------------------------------------------ policies
@@ -302,3 +310,51 @@ def namespace_for(obj, namespaces):
     namespace; None for cluster-scoped objects or unknown namespaces."""
     ns = (obj.get("metadata") or {}).get("namespace")
     return namespaces.get(ns) if ns else None
+
+
+class NativeBatch:
+    """objects [start, start + n) of stream `seed` generated by the native generator (csrc/synth.cpp): JSON text plus the
+    gk_review_in array, handed to Engine.create_table_native without touching Python objects."""
+
+    def __init__(self, lib, n, seed=SEED, mixed=False, start=0, namespaces=None):
+        import ctypes as C
+        self.lib = lib
+        arr, k = None, 0
+        if namespaces is not None:
+            self._ns = [json.dumps(namespaces[name]).encode() for name in NAMESPACES]
+            arr, k = (C.c_char_p * len(self._ns))(*self._ns), len(self._ns)
+        h = C.c_void_p()
+        rc = lib.gk_synth_batch_create(seed & 0xFFFFFFFFFFFFFFFF, start, n, 1 if mixed else 0, arr, k, C.byref(h))
+        if rc != 0:
+            raise RuntimeError("gk_synth_batch_create failed: %d" % rc)
+        self.handle = h
+        self.n = n
+
+    @property
+    def reviews(self):
+        return self.lib.gk_synth_batch_reviews(self.handle)
+
+    @property
+    def json_bytes(self):
+        return int(self.lib.gk_synth_batch_json_bytes(self.handle))
+
+    def json_text(self, i):
+        r = self.reviews[i]
+        import ctypes as C
+        return C.string_at(r.json, r.json_len)
+
+    def namespace_text(self, i):
+        r = self.reviews[i]
+        import ctypes as C
+        return C.string_at(r.namespace_json, r.namespace_len) if r.namespace_json else None
+
+    def free(self):
+        if self.handle:
+            self.lib.gk_synth_batch_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

@@ -84,6 +84,14 @@ typedef struct {
  * A review that HandleReview rejects gets status GK_ERR_REVIEW in statuses[i] (may be NULL) and evaluates to nothing. */
 int gk_table_create(gk_engine* e, const gk_review_in* reviews, size_t n, uint32_t flags, int32_t* statuses, gk_table** out);
 void gk_table_free(gk_table* t);
+/* what building the table cost on the host (the PCIe-inclusive, end-to-end leg of SURVEY.md section 8(d)) */
+typedef struct {
+  uint64_t n_reviews, n_rows, json_bytes, heap_bytes, device_bytes;
+  double flatten_s;        /* parse + HandleReview normalisation + flatten + row-group index, wall clock over host_threads */
+  double upload_s;         /* host -> HBM */
+  uint32_t host_threads, reserved;
+} gk_table_stats;
+int gk_table_get_stats(const gk_table* t, gk_table_stats* out);
 #define GK_TABLE_KEEP_DOCS 1u   /* keep parsed reviews on the host so violations can be rendered to messages */
 #define GK_TABLE_RESIDENT 2u    /* the table is evaluated again and again (audit set): the engine may compile a plan variant
                                    whose LDS layout fits this table's array sizes (first evaluation pays the compile) */

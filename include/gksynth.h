@@ -1,0 +1,32 @@
+/* gksynth.h -- native synthetic-workload generator exported by libgkgpu.so (bench / test plumbing, NOT part of the
+ * drivers.Driver boundary of gkgpu.h).  Generates SURVEY.md section 8(d)'s synthetic cluster objects -- the same objects
+ * as gatekeeper_amd/synth.py, pinned object by object in tests/test_synth.py -- as JSON text, already laid out as the
+ * gk_review_in array gk_table_create takes (AugmentedUnstructured{Object, Namespace, Source: Original}, the shape
+ * pkg/audit builds at pkg/audit/manager.go:694-713). */
+#ifndef GKSYNTH_H
+#define GKSYNTH_H
+#include <stddef.h>
+#include <stdint.h>
+
+#include "gkgpu.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gk_synth_batch gk_synth_batch;
+
+/* objects [start, start + n) of stream `seed`; mixed = 0: Pods only (configs[1]); 1: Pod / Deployment / Namespace /
+ * Service / ConfigMap mix (configs[2]).  namespace_jsons: the 100 Namespace objects in synth.py NAMESPACES order (the
+ * review's Namespace is looked up by the object's metadata.namespace) or NULL for none. */
+int gk_synth_batch_create(uint64_t seed, uint64_t start, uint64_t n, int mixed, const char* const* namespace_jsons, size_t n_namespaces,
+                          gk_synth_batch** out);
+const gk_review_in* gk_synth_batch_reviews(const gk_synth_batch* b);
+size_t gk_synth_batch_size(const gk_synth_batch* b);
+uint64_t gk_synth_batch_json_bytes(const gk_synth_batch* b);
+void gk_synth_batch_free(gk_synth_batch* b);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GKSYNTH_H */

@@ -1,4 +1,4 @@
-"""The C-ABI library loads and exports every symbol include/gkgpu.h declares (no compute without a GPU)."""
+"""The C-ABI library loads and exports every symbol include/*.h declares (no compute without a GPU)."""
 import ctypes
 import os
 import re
@@ -11,9 +11,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def header_functions():
-    src = open(os.path.join(ROOT, "include", "gkgpu.h")).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(gk_[a-z_]+)\s*\(", src)))
+    """every function any include/*.h declares"""
+    names = set()
+    for h in sorted(os.listdir(os.path.join(ROOT, "include"))):
+        if not h.endswith(".h"):
+            continue
+        src = open(os.path.join(ROOT, "include", h)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        names |= set(re.findall(r"\b(gk_[a-z0-9_]+)\s*\(", src))
+    return sorted(names)
 
 
 def test_header_matches_binding():

@@ -28,7 +28,7 @@ def _client():
 
 
 def _worker(rank, world, port, out_dir):
-    os.environ["GK_TEST_HOSTEMU"] = "1"
+
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     objs = synth.gen_objects(N_PER_RANK * world, seed=21, mixed=True)
     shard = objs[rank * N_PER_RANK:(rank + 1) * N_PER_RANK]
@@ -46,7 +46,7 @@ def test_sharded_sweep_matches_single_process(tmp_path):
     port = s.getsockname()[1]
     s.close()
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
-    os.environ["GK_TEST_HOSTEMU"] = "1"
+
     objs = synth.gen_objects(N_PER_RANK * world, seed=21, mixed=True)
     nss = synth.gen_namespaces()
     c = _client()

@@ -1,7 +1,7 @@
 #!/bin/bash
 # PMC counters for the dominant kernel, one counter group per pass (rocprofv3 --pmc with --kernel-trace only).
 tag=${1:-pmc}; mkdir -p gpurun_out; export TMPDIR=/tmp
-run() { name=$1; shift; rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d gpurun_out/${tag}_$name -o $name -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline > /dev/null 2> gpurun_out/${tag}_$name.err; }
+run() { name=$1; shift; rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d gpurun_out/${tag}_$name -o $name -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline $GK_BENCH_ARGS > /dev/null 2> gpurun_out/${tag}_$name.err; }
 run sq SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
 run sq2 SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE
 run fetch FETCH_SIZE
