@@ -42,7 +42,10 @@ def cpu_leg(templates, constraints, batch, ev, budget_s=10.0):
     rate1 = probe_n / max(probe["seconds"], 1e-9)               # reviews/s on one thread
     n1 = int(max(64, min(batch.n, rate1 * budget_s)) // 64 * 64) or batch.n
     one = ref.review(batch.reviews, n1, 1)
-    nall = int(max(n1, min(batch.n, rate1 * cores * budget_s * 0.6)) // 64 * 64) or batch.n
+    probe_all_n = int(min(batch.n, max(1024, cores * 128)) // 64 * 64) or batch.n
+    probe_all = ref.review(batch.reviews, probe_all_n, cores)                 # measured, not assumed, all-core rate
+    rate_all = probe_all_n / max(probe_all["seconds"], 1e-9)
+    nall = int(max(n1, min(batch.n, rate_all * budget_s)) // 64 * 64) or batch.n
     allc = ref.review(batch.reviews, nall, cores)
     # parity: device bitmap rows (by constraint key) vs the CPU loop, over the all-core sample
     row_of = {int(cid): i for i, cid in enumerate(ev.constraint_ids)}

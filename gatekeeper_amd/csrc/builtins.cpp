@@ -139,7 +139,8 @@ std::shared_ptr<Regex> get_regex(const std::string& pat) {
   auto it = g_re_cache.find(pat);
   if (it != g_re_cache.end()) return it->second;
   std::shared_ptr<Regex> r;
-  try { r = std::make_shared<Regex>(pat); } catch (const RegexError&) { r = nullptr; }
+  try { r = std::make_shared<Regex>(pat); } catch (const RegexError&) { r = nullptr; }   // invalid in Go: builtin error -> undefined
+  // RegexUnsupported (valid Go, outside this engine) propagates: GK_ERR_UNSUPPORTED at AddConstraint, an error when rendering
   g_re_cache[pat] = r;
   return r;
 }

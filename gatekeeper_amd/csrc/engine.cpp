@@ -22,6 +22,7 @@
 #include "flatten.hpp"
 #include "lower.hpp"
 #include "pe.hpp"
+#include "regex.hpp"
 
 using namespace gk;
 
@@ -365,6 +366,7 @@ int gk_template_add(gk_engine* e, const char* kind, const char* rego, const char
     return GK_OK;
   } catch (const RegoError& ex) { return fail(GK_ERR_REGO, ex.what());
   } catch (const Unsupported& ex) { return fail(GK_ERR_UNSUPPORTED, ex.what());
+  } catch (const RegexUnsupported& ex) { return fail(GK_ERR_UNSUPPORTED, std::string("unsupported on the device plan: ") + ex.what());
   } catch (const std::exception& ex) { return fail(GK_ERR_INTERNAL, ex.what()); }
 }
 
@@ -415,6 +417,7 @@ int gk_constraint_add(gk_engine* e, const char* json, size_t len, uint32_t* id_o
   } catch (const JsonError& ex) { return fail(GK_ERR_INVALID, ex.what());
   } catch (const RegoError& ex) { return fail(GK_ERR_REGO, ex.what());
   } catch (const Unsupported& ex) { return fail(GK_ERR_UNSUPPORTED, ex.what());
+  } catch (const RegexUnsupported& ex) { return fail(GK_ERR_UNSUPPORTED, std::string("unsupported on the device plan: ") + ex.what());
   } catch (const std::exception& ex) { return fail(GK_ERR_INTERNAL, ex.what()); }
 }
 

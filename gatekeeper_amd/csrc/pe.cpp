@@ -15,8 +15,10 @@ namespace gk {
 namespace {
 FP mkf(FNode n) { return std::make_shared<const FNode>(std::move(n)); }
 }
-FP f_true() { static FP t = [] { FNode n; n.kind = FNode::T; return mkf(n); }(); return t; }
-FP f_false() { static FP f = [] { FNode n; n.kind = FNode::F; return mkf(n); }(); return f; }
+// per-thread singletons: the reference count of a process-wide one would be the hottest cache line of every host thread
+// that renders messages (gk_table_totals, the CPU baseline loop)
+FP f_true() { static thread_local FP t = [] { FNode n; n.kind = FNode::T; return mkf(n); }(); return t; }
+FP f_false() { static thread_local FP f = [] { FNode n; n.kind = FNode::F; return mkf(n); }(); return f; }
 FP f_and(FP a, FP b) {
   if (a->kind == FNode::F || b->kind == FNode::F) return f_false();
   if (a->kind == FNode::T) return b;

@@ -239,9 +239,14 @@ struct Constraint {
 
 }  // namespace
 
+struct TemplateSrc { std::string kind, rego; std::vector<std::string> libs; };
 struct cpuref {
   std::map<std::string, std::shared_ptr<Template>> templates;   // lower-cased kind
   std::vector<Constraint> constraints;
+  // sources, so that every worker thread can build PRIVATE templates / parameters: the evaluator's values are
+  // reference counted, and 256 threads sharing one AST would spend their time on the same cache lines
+  std::vector<TemplateSrc> template_src;
+  std::vector<std::string> constraint_src;
   NsCache ns_cache;
 };
 
@@ -260,6 +265,7 @@ int cpuref_add_template(cpuref* r, const char* kind, const char* rego, const cha
     std::vector<std::string> ls;
     for (size_t i = 0; i < nlibs; i++) ls.emplace_back(libs[i]);
     r->templates[lower(kind)] = std::make_shared<Template>(rego, ls);
+    r->template_src.push_back({kind, rego, ls});
     return 0;
   } catch (const std::exception& e) { g_err = e.what(); return -1; }
 }
@@ -279,6 +285,7 @@ int cpuref_add_constraint(cpuref* r, const char* json, size_t len) {
     k.params = (p && !p->is_null()) ? *p : Value::object({});
     k.match = compile_match_spec(spec ? spec->get("match") : nullptr);
     r->constraints.push_back(k);
+    r->constraint_src.emplace_back(json, len);
     return 0;
   } catch (const std::exception& e) { g_err = e.what(); return -1; }
 }
@@ -304,6 +311,19 @@ int cpuref_review(cpuref* r, const gk_review_in* reviews, size_t n, int threads,
     try {
       const size_t lo = std::min(n, (size_t)w * words_per * 64), hi = std::min(n, ((size_t)w + 1) * words_per * 64);
       const Value inventory;
+      // thread-private policy state (see cpuref): same sources, own objects
+      std::unique_ptr<cpuref> mine;
+      const cpuref* pol = r;
+      if (threads > 1) {
+        mine.reset(cpuref_create());
+        for (auto& t : r->template_src) {
+          std::vector<const char*> ls;
+          for (auto& l : t.libs) ls.push_back(l.c_str());
+          if (cpuref_add_template(mine.get(), t.kind.c_str(), t.rego.c_str(), ls.data(), ls.size())) throw std::runtime_error(g_err);
+        }
+        for (auto& c : r->constraint_src) if (cpuref_add_constraint(mine.get(), c.data(), c.size())) throw std::runtime_error(g_err);
+        pol = mine.get();
+      }
       for (size_t i = lo; i < hi; i++) {
         const gk_review_in& in = reviews[i];
         ReviewDoc doc;
@@ -321,7 +341,7 @@ int cpuref_review(cpuref* r, const gk_review_in* reviews, size_t n, int threads,
         const std::string raw_old = (old && old->is_object()) ? to_json(*old) : std::string();
         const Value* ns = doc.match_ns.defined() ? &doc.match_ns : nullptr;
         for (size_t c = 0; c < nc; c++) {
-          const Constraint& k = r->constraints[c];
+          const Constraint& k = pol->constraints[c];
           Tri m = YES;
           if (k.match.present) {
             // ... and matcher.go:73-93 decodes it again for every constraint

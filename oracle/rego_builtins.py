@@ -52,18 +52,284 @@ def _norm(n):
 
 
 # ---------------------------------------------------------------- Go regexp (RE2) -> python re
-_POSIX = {"alpha": "a-zA-Z", "digit": "0-9", "alnum": "a-zA-Z0-9", "upper": "A-Z", "lower": "a-z",
-          "space": r" \t\n\r\f\v", "punct": r"!-/:-@\[-`{-~", "xdigit": "0-9A-Fa-f", "word": r"\w"}
+# OPA's re_match / regex.match call Go's regexp (regexp/syntax with Perl flags; third-party, absent from /root/reference).
+# The oracle evaluates them with Python's `re` after a TRANSLATION that restates Go's syntax rules -- "parity unpinned"
+# beyond the patterns the reference's fixtures hold (agilebank allowedRegex, tests/test_oracle_rego.py):
+#   * what regexp.Compile rejects raises BuiltinError (re_match is then undefined): unknown alphanumeric escapes, \C,
+#     backreferences, lookarounds, stacked repetition (a**), repeat counts > 1000 or {n,m} with n > m, bad classes
+#   * Go's ASCII definitions are spelled out: \d [0-9], \w [0-9A-Za-z_], \s [\t\n\f\r ] (no \v), \b ASCII word boundary;
+#     `$` without (?m) is end of TEXT (Python's `$` also matches before a final newline); a `{` that does not open a valid
+#     repetition is a literal; (?flags) apply to the rest of the enclosing group; (?U) only swaps greediness
+#   * matching itself is by code point with Unicode simple case folding under (?i), as in Go
+#   * OracleRegexUnsupported: valid Go this translator does not cover (\pL, [[:^alpha:]] / \D \W \S inside a class)
+_POSIX = {"alpha": "a-zA-Z", "digit": "0-9", "alnum": "a-zA-Z0-9", "upper": "A-Z", "lower": "a-z", "space": " \t\n\r\f\v",
+          "blank": " \t", "cntrl": "\x00-\x1f\x7f", "graph": "!-~", "print": " -~", "ascii": "\x00-\x7f",
+          "punct": "!-/:-@\\[-`{-~", "xdigit": "0-9A-Fa-f", "word": "0-9A-Za-z_"}
+_PERL = {"d": "0-9", "w": "0-9A-Za-z_", "s": "\t\n\f\r "}
+_WORD = "[0-9A-Za-z_]"
 _re_cache = {}
+
+
+class OracleRegexUnsupported(Exception):
+    """valid Go syntax outside the oracle's translator (tests skip such patterns)"""
+
+
+def _go_to_python(pat):
+    def bad(why):
+        return BuiltinError("error parsing regexp: %s: `%s`" % (why, pat))
+
+    n = len(pat)
+    out = []
+    i = 0
+    # group stack: (multiline flag on entry, specs of the (?flags) scopes opened inside the group: closed at its end and
+    # around every `|` of the group, because in Go the flags stay in force across the alternatives that follow)
+    stack = [[False, []]]
+    multiline = False
+    can_repeat = False      # the previous item is an operand
+    repeated = False        # ... and already carries a repetition operator
+
+    def esc_rune(k):
+        """rune denoted by the escape whose letter is pat[k]; -> (code point, next index)"""
+        e = pat[k]
+        simple = {"a": 7, "f": 12, "n": 10, "r": 13, "t": 9, "v": 11}
+        if e in simple:
+            return simple[e], k + 1
+        if e == "x":
+            if k + 1 >= n:
+                raise bad("invalid escape sequence")
+            if pat[k + 1] == "{":
+                end = pat.find("}", k + 2)
+                digits = pat[k + 2:end] if end > 0 else ""
+                if not digits or any(c not in "0123456789abcdefABCDEF" for c in digits) or int(digits, 16) > 0x10FFFF:
+                    raise bad("invalid escape sequence")
+                return int(digits, 16), end + 1
+            digits = pat[k + 1:k + 3]
+            if len(digits) != 2 or any(c not in "0123456789abcdefABCDEF" for c in digits):
+                raise bad("invalid escape sequence")
+            return int(digits, 16), k + 3
+        if e in "01234567":
+            if e != "0" and not (k + 1 < n and pat[k + 1] in "01234567"):
+                raise bad("invalid escape sequence")      # a lone digit would be a backreference
+            m = k + 1
+            while m < n and m < k + 3 and pat[m] in "01234567":
+                m += 1
+            return int(pat[k:m], 8), m
+        if ord(e) < 0x80 and not e.isalnum():
+            return ord(e), k + 1
+        raise bad("invalid escape sequence")
+
+    def lit(cp):
+        return re.escape(chr(cp))
+
+    def parse_class(k):
+        """pat[k] is the char after '['; -> (python class text, next index)"""
+        body = []
+        neg = False
+        if k < n and pat[k] == "^":
+            neg = True
+            k += 1
+        first = True
+        while True:
+            if k >= n:
+                raise bad("missing closing ]")
+            c = pat[k]
+            if c == "]" and not first:
+                k += 1
+                break
+            first = False
+            if c == "[" and k + 1 < n and pat[k + 1] == ":":
+                end = pat.find(":]", k + 2)
+                if end < 0:
+                    raise bad("invalid character class range")
+                name = pat[k + 2:end]
+                if name.startswith("^"):
+                    if name[1:] in _POSIX:
+                        raise OracleRegexUnsupported(pat)
+                    raise bad("invalid character class range")
+                if name not in _POSIX:
+                    raise bad("invalid character class range")
+                body.append(_POSIX[name])
+                k = end + 2
+                continue
+            if c == "\\":
+                if k + 1 >= n:
+                    raise bad("trailing backslash")
+                e = pat[k + 1]
+                if e in "dws":
+                    body.append(_PERL[e])
+                    k += 2
+                    continue
+                if e in "DWSpP":
+                    raise OracleRegexUnsupported(pat)
+                lo, k = esc_rune(k + 1)
+            else:
+                lo, k = ord(c), k + 1
+            if k + 1 < n and pat[k] == "-" and pat[k + 1] != "]":
+                h = pat[k + 1]
+                if h == "\\":
+                    if k + 2 >= n:
+                        raise bad("trailing backslash")
+                    if pat[k + 2] in "dwsDWSpP":
+                        raise bad("invalid character class range")
+                    hi, k = esc_rune(k + 2)
+                else:
+                    hi, k = ord(h), k + 2
+                if hi < lo:
+                    raise bad("invalid character class range")
+                body.append(lit(lo) + "-" + lit(hi))
+            else:
+                body.append(lit(lo))
+        return "[" + ("^" if neg else "") + "".join(body) + "]", k
+
+    while i < n:
+        c = pat[i]
+        if c in "*+?":
+            if not can_repeat:
+                raise bad("missing argument to repetition operator")
+            if repeated:
+                raise bad("invalid nested repetition operator")
+            out.append(c)
+            i += 1
+            if i < n and pat[i] == "?":
+                out.append("?")
+                i += 1
+            repeated = True
+            continue
+        if c == "{":
+            m = re.match(r"\{(\d+)(,(\d*))?\}", pat[i:])
+            if m and can_repeat:
+                lo = int(m.group(1))
+                hi = lo if m.group(2) is None else (int(m.group(3)) if m.group(3) else -1)
+                if lo > 1000 or hi > 1000 or (hi >= 0 and hi < lo):
+                    raise bad("invalid repeat count")
+                if repeated:
+                    raise bad("invalid nested repetition operator")
+                out.append(m.group(0))
+                i += len(m.group(0))
+                if i < n and pat[i] == "?":
+                    out.append("?")
+                    i += 1
+                repeated = True
+                continue
+            if m and not can_repeat:
+                raise bad("missing argument to repetition operator")
+            out.append("\\{")
+            i += 1
+            can_repeat, repeated = True, False
+            continue
+        repeated = False
+        if c == "(":
+            if pat.startswith("(?", i):
+                if pat.startswith("(?P<", i) or pat.startswith("(?<", i):
+                    start = i + (4 if pat.startswith("(?P<", i) else 3)
+                    end = pat.find(">", start)
+                    name = pat[start:end] if end > 0 else ""
+                    if not name or not re.fullmatch(r"[A-Za-z0-9_]+", name) or pat.startswith("(?<=", i) or pat.startswith("(?<!", i):
+                        raise bad("invalid named capture")
+                    out.append("(?P<%s>" % name)
+                    stack.append([multiline, []])
+                    i = end + 1
+                    can_repeat = False
+                    continue
+                m = re.match(r"\(\?([imsU]*)(-[imsU]+)?([:)])", pat[i:])
+                if not m or (not m.group(1) and not m.group(2) and m.group(3) == ")"):
+                    raise bad("invalid or unsupported Perl syntax")
+                on = m.group(1).replace("U", "")
+                off = (m.group(2) or "")[1:].replace("U", "")
+                new_ml = (multiline or "m" in on) and "m" not in off
+                spec = on + ("-" + off if off else "")
+                if m.group(3) == ":":
+                    stack.append([multiline, []])
+                    out.append("(?%s:" % spec if spec else "(?:")
+                else:                      # (?flags): in force until the enclosing group ends
+                    if spec:
+                        out.append("(?%s:" % spec)
+                        stack[-1][1].append(spec)
+                multiline = new_ml
+                i += len(m.group(0))
+                can_repeat = False
+                continue
+            out.append("(")
+            stack.append([multiline, []])
+            i += 1
+            can_repeat = False
+            continue
+        if c == ")":
+            if len(stack) == 1:
+                raise bad("unexpected )")
+            saved_ml, owed = stack.pop()
+            out.append(")" * len(owed) + ")")
+            multiline = saved_ml
+            i += 1
+            can_repeat = True
+            continue
+        if c == "|":
+            out.append(")" * len(stack[-1][1]) + "|" + "".join("(?%s:" % sp for sp in stack[-1][1]))
+            i += 1
+            can_repeat = False
+            continue
+        can_repeat = True
+        if c == "[":
+            text, i = parse_class(i + 1)
+            out.append(text)
+        elif c == "^":
+            out.append("^")
+            i += 1
+        elif c == "$":
+            out.append("$" if multiline else "\\Z")
+            i += 1
+        elif c == ".":
+            out.append(".")
+            i += 1
+        elif c == "\\":
+            if i + 1 >= n:
+                raise bad("trailing backslash")
+            e = pat[i + 1]
+            if e in "dws":
+                out.append("[" + _PERL[e] + "]")
+                i += 2
+            elif e in "DWS":
+                out.append("[^" + _PERL[e.lower()] + "]")
+                i += 2
+            elif e == "A":
+                out.append("\\A")
+                i += 2
+            elif e == "z":
+                out.append("\\Z")
+                i += 2
+            elif e == "b":
+                out.append("(?:(?<=%s)(?!%s)|(?<!%s)(?=%s))" % (_WORD, _WORD, _WORD, _WORD))
+                i += 2
+            elif e == "B":
+                out.append("(?:(?<=%s)(?=%s)|(?<!%s)(?!%s))" % (_WORD, _WORD, _WORD, _WORD))
+                i += 2
+            elif e in "pP":
+                raise OracleRegexUnsupported(pat)
+            elif e == "Q":
+                end = pat.find("\\E", i + 2)
+                text = pat[i + 2:] if end < 0 else pat[i + 2:end]
+                i = n if end < 0 else end + 2
+                if text:
+                    out.append(re.escape(text[:-1]) + "(?:" + re.escape(text[-1]) + ")")
+                else:
+                    can_repeat = False
+            else:
+                cp, i = esc_rune(i + 1)
+                out.append(lit(cp))
+        else:
+            out.append(re.escape(c))
+            i += 1
+    if len(stack) != 1:
+        raise bad("missing closing )")
+    out.append(")" * len(stack[0][1]))
+    return "".join(out)
 
 
 def go_regex(pat):
     r = _re_cache.get(pat)
     if r is None:
-        p = re.sub(r"\[:(\w+):\]", lambda m: _POSIX.get(m.group(1), m.group(0)), pat)
-        p = p.replace(r"\z", r"\Z")
         try:
-            r = re.compile(p)
+            r = re.compile(_go_to_python(pat))
         except re.error as e:
             raise BuiltinError("bad regex %r: %s" % (pat, e))
         _re_cache[pat] = r

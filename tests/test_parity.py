@@ -471,9 +471,56 @@ def test_regex_predicates(backend):
     assert_parity(c, oc, [D.AugmentedUnstructured(D.Unstructured(o), None, "Original") for o in objs])
 
 
+GO_REGEXES = ["(?i)^PROD", "\\bprod\\b", "^.{3}$", "^[^a]+$", "\\x41\\x{e9}", "\\Qa.b\\E+", "(?s)a.c", "a.c", "^\\s+$", "\\S\\s\\S", "(?i)k+", "(?i)[j-l]s$",
+              "a**", "x{2,1}", "\\8", "(?P<n>ab)+", "(?i:A)b", "a(?i)b|c", "(?m)^c$", "^c$", "\\Bb", "\\W", "[[:upper:]][[:^digit:]]", "\\pL+", "[\u00e9x]y",
+              "(?i)\u00e9", "[^\\x00-\\x7f]", "\\D\\d", "a{,2}", "\\z|^q", "\\101", "(?U)a+?b"]
+GO_VALUES = ["prod", "PROD-1", "bprodb", "a prod b", "h\u00e9\u00e9", "abc", "A\u00e9", "a.b.b", "a.bb", "a\nc", "axc", " \t\n", "\x0b", "x y", "KK", "k\u212a",
+             "LS", "l\u017f", "ab", "abab", "Ab", "aB", "C", "a\nc\nd", "c", "ab b", "b", "-", "Q7", "QZ", "\u00e9y", "\u00c9", "\u00e9", "5", "a5", "a{,2}", "q", "A",
+             "aab", "\u65e5\u672c", "x\U0001f600y"]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_regex_go_syntax(backend):
+    """Go regexp/syntax constructs beyond the reference's fixtures: inline flags, word boundaries, hex / octal /
+    \\Q..\\E escapes, rune-wise '.' and negated classes on non-ASCII text, case folding onto U+212A / U+017F, patterns
+    regexp.Compile rejects (re_match undefined), and valid patterns outside the engine (\\pL: GK_ERR_UNSUPPORTED at
+    AddConstraint, never a silent mis-evaluation).  Oracle: the restated Go->Python translation (oracle/rego_builtins.py)."""
+    from oracle import rego_builtins as OB
+    usable, rejected = [], []
+    for rx in GO_REGEXES:
+        try:
+            OB.go_regex(rx)
+        except OB.OracleRegexUnsupported:
+            oracle_ok = False
+        except OB.BuiltinError:
+            oracle_ok = True    # invalid in Go: both sides must treat re_match as undefined
+        else:
+            oracle_ok = True
+        probe = make_client(backend)
+        probe.AddTemplate(REGEX_TEMPLATE)
+        try:
+            probe.AddConstraint({"apiVersion": "constraints.gatekeeper.sh/v1beta1", "kind": "K8sLabelRegex", "metadata": {"name": "t"},
+                                 "spec": {"parameters": {"labels": [{"key": "owner", "allowedRegex": rx}], "nameRegex": rx}}})
+        except D.UnsupportedError:
+            rejected.append(rx)
+            continue
+        if oracle_ok:
+            usable.append(rx)
+    assert "\\pL+" in rejected and "(?i)\u00e9" in rejected          # valid Go, outside the engine: reported, not approximated
+    assert len(usable) >= len(GO_REGEXES) - 6, rejected
+    cons = [{"apiVersion": "constraints.gatekeeper.sh/v1beta1", "kind": "K8sLabelRegex", "metadata": {"name": "go-%d" % i},
+             "spec": {"parameters": {"labels": [{"key": "owner", "allowedRegex": rx}], "nameRegex": usable[(i + 5) % len(usable)]}}}
+            for i, rx in enumerate(usable)]
+    c, oc = load_both(backend, [REGEX_TEMPLATE], cons)
+    objs = [{"apiVersion": "v1", "kind": "Pod", "metadata": {"name": GO_VALUES[(i * 7 + 3) % len(GO_VALUES)], "namespace": "default", "labels": {"owner": v}}}
+            for i, v in enumerate(GO_VALUES)]
+    assert assert_parity(c, oc, [D.AugmentedUnstructured(D.Unstructured(o), None, "Original") for o in objs]) > len(GO_VALUES)
+
+
 def _random_regex(rng, depth=0):
     pick = lambda xs: xs[rng.below(len(xs))]
-    atoms = ["a", "b", "c", "0", "1", "-", ".", "[ab]", "[^a]", "[0-9]", "\\d", "\\w", "[a-c0-1]", "x"]
+    atoms = ["a", "b", "c", "0", "1", "-", ".", "[ab]", "[^a]", "[0-9]", "\\d", "\\w", "[a-c0-1]", "x", "\\b", "\\s", "\u00e9", "(?i)", "k", "\\W", "\\x41",
+             "(?i:b)", "(?s).", "[^\\d-]"]
 
     def piece():
         a = "(" + _random_regex(rng, depth + 1) + ")" if depth < 2 and rng.chance(0.25) else pick(atoms)
@@ -509,7 +556,7 @@ def test_regex_randomised(backend):
              "spec": {"parameters": {"labels": [{"key": "owner", "allowedRegex": rx}], "nameRegex": pats[(i + 7) % len(pats)]}}}
             for i, rx in enumerate(pats)]
     c, oc = load_both(backend, [REGEX_TEMPLATE], cons)
-    al = "abc01-x."
+    al = "abc01-x.AK \n\u00e9\u212a"
     rs = lambda: "".join(al[rng.below(len(al))] for _ in range(rng.below(16)))
     objs = [{"apiVersion": "v1", "kind": "Pod", "metadata": {"name": rs() or "n", "namespace": "default", "labels": {"owner": rs()}}} for _ in range(100)]
     assert assert_parity(c, oc, [D.AugmentedUnstructured(D.Unstructured(o), None, "Original") for o in objs]) > 100
