@@ -327,7 +327,12 @@ class Regex {
     Flags atom_flags = fl_;
     bool is_group_flags = false;
     Frag f = parse_atom(&is_group_flags);
-    if (is_group_flags) return f;   // (?i) and friends: not an operand
+    if (is_group_flags) {   // (?i) and friends: not an operand
+      // Go leaves whatever precedes the flag group on its parse stack, so a repetition here would bind to THAT (or fail
+      // when there is nothing): an edge this engine does not reproduce
+      if (at_repeat_op()) throw RegexUnsupported("regex: repetition operator after a flag group");
+      return f;
+    }
     if (!more()) return f;
     char c = peek();
     bool repeated = false;
@@ -352,13 +357,24 @@ class Regex {
         repeated = true;
       }
     }
-    if (repeated && more()) {   // Perl mode: a** / a+? * / a{2}* are syntax errors
-      char d = peek();
-      bool op = d == '*' || d == '+' || d == '?';
-      if (d == '{') { size_t save = i_; int x; i_++; bool ok = parse_int(&x); if (ok && more() && peek() == ',') { i_++; parse_int(&x); } op = ok && more() && peek() == '}'; i_ = save; }
-      if (op) throw RegexError("regex: invalid nested repetition operator");
-    }
+    if (repeated && at_repeat_op()) throw RegexError("regex: invalid nested repetition operator");   // Perl mode: a** / a+* / a{2}* are errors
     return f;
+  }
+
+  // is the next token a repetition operator (* + ? or a well-formed {n} / {n,} / {n,m})?
+  bool at_repeat_op() {
+    if (!more()) return false;
+    char d = peek();
+    if (d == '*' || d == '+' || d == '?') return true;
+    if (d != '{') return false;
+    size_t save = i_;
+    int x;
+    i_++;
+    bool ok = parse_int(&x);
+    if (ok && more() && peek() == ',') { i_++; parse_int(&x); }
+    bool op = ok && more() && peek() == '}';
+    i_ = save;
+    return op;
   }
 
   bool parse_int(int* v) {

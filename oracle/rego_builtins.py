@@ -248,6 +248,9 @@ def _go_to_python(pat):
                 multiline = new_ml
                 i += len(m.group(0))
                 can_repeat = False
+                if m.group(3) == ")" and (pat[i:i + 1] in ("*", "+", "?") or re.match(r"\\{\\d+(,\\d*)?\\}", pat[i:])):
+                    # Go binds a repetition after a flag group to whatever precedes the group on its parse stack
+                    raise OracleRegexUnsupported(pat)
                 continue
             out.append("(")
             stack.append([multiline, []])

@@ -606,7 +606,14 @@ def test_edge_cases(backend, fixtures):
         "containers": [{"name": "c%d" % i, "image": "x", "securityContext": {"privileged": i == 37},
                         "volumeMounts": [{"name": "v%d" % i, "mountPath": "/m", "readOnly": i % 2 == 0}]} for i in range(40)],
         "volumes": [{"name": "v%d" % i, "hostPath": {"path": "/foo/x%d" % i}} for i in range(40)]}}
-    rv = [D.AugmentedUnstructured(D.Unstructured(o), None, "Original") for o in [objs[0], big, objs[1]]]
+    def alone(o):   # does this object fit the LDS capacity of 4 by itself?
+        t_ = c.driver.engine.create_table([D.to_review_in(D.AugmentedUnstructured(D.Unstructured(o), None, "Original"))])
+        n_ = t_.eval().n_overflow
+        t_.free()
+        return n_ == 0
+    small = [o for o in objs if alone(o)][:2]
+    assert len(small) == 2 and not alone(big)
+    rv = [D.AugmentedUnstructured(D.Unstructured(o), None, "Original") for o in [small[0], big, small[1]]]
     table = c.driver.engine.create_table([D.to_review_in(r) for r in rv])
     ev = table.eval()
     assert ev.n_overflow == (0 if os.environ.get("GK_SPECIALIZE_ALL") else 1)
