@@ -71,7 +71,7 @@ class gk_totals_out(C.Structure):
 class gk_table_stats(C.Structure):
     _fields_ = [("n_reviews", C.c_uint64), ("n_rows", C.c_uint64), ("json_bytes", C.c_uint64), ("heap_bytes", C.c_uint64),
                 ("device_bytes", C.c_uint64), ("flatten_s", C.c_double), ("upload_s", C.c_double), ("host_threads", C.c_uint32),
-                ("reserved", C.c_uint32)]
+                ("reserved", C.c_uint32), ("fast_reviews", C.c_uint64), ("digest", C.c_uint64)]
 
 
 class EngineLoadError(RuntimeError):

@@ -38,7 +38,14 @@ struct EvalOut {
 
 std::string dev_init(int device);                       // "" on success, else error text
 int dev_count();
-DevTable* dev_table_upload(const HostTable& t);
+// A table goes to the device in PARTS: every host thread uploads the part it flattened as soon as it is done
+// (dev_part_upload: thread-safe, overlaps the other threads' flattening and their transfers); dev_table_assemble then
+// places the parts one after the other in the table's arrays ON THE DEVICE, relocating the rows' heap offsets there -- the
+// host never merges the gigabytes.  `meta` carries what is global: tile_idx, slot_path, rflags, n_reviews.
+struct DevPart;
+DevPart* dev_part_upload(int device, HostTable& part);   // releases the part's host arrays (rows / shdr / heap)
+void dev_part_free(DevPart* p);
+DevTable* dev_table_assemble(int device, std::vector<DevPart*>& parts, const HostTable& meta);   // consumes the parts
 void dev_table_free(DevTable* t);
 // A second handle on the same resident table with its own result buffers and path binding (plan groups beyond the
 // first evaluate through views); freeing a view leaves the table's arrays alone.  Free views before the table.

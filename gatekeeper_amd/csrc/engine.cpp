@@ -464,36 +464,41 @@ int gk_table_create(gk_engine* e, const gk_review_in* reviews, size_t n, uint32_
     t->review_errors.resize(n);
     t->obj_keys.resize(n);
     if (keep) t->docs.resize(n);
-    // Reviews are parsed, normalised (HandleReview) and flattened by host threads, each on a contiguous range of whole
-    // tiles; the parts are appended in order (the path dictionary is shared and thread-safe).
     const auto t_begin = std::chrono::steady_clock::now();
+    // Reviews are flattened by host threads, each on a contiguous range of whole tiles (the path dictionary is shared and
+    // thread-safe).  Fast path: JSON text -> rows in one pass (Flattener::add_json); reviews it declines -- and every
+    // review when the parsed documents must be kept for rendering -- go through parse_json + HandleReview normalisation +
+    // Flattener::add, which produces the same rows.  The parts are then copied, in parallel, into the table's arrays.
     const size_t n_tiles = (n + GK_RPT - 1) / GK_RPT;
     size_t n_threads = std::max<size_t>(1, std::min<size_t>(std::thread::hardware_concurrency(), n_tiles / 8));
     if (const char* ht = getenv("GK_HOST_THREADS")) n_threads = std::max(1, atoi(ht));
     n_threads = std::min(n_threads, std::max<size_t>(n_tiles, 1));
     const size_t tiles_per = (n_tiles + n_threads - 1) / std::max<size_t>(n_threads, 1);
+    const bool slow_only = keep || getenv("GK_SLOW_INGEST") != nullptr;
     std::vector<HostTable> parts(n_threads);
     std::vector<std::string> part_err(n_threads);
+    std::vector<uint64_t> part_fast(n_threads, 0);
     auto work = [&](size_t w) {
       try {
         Flattener fl(&e->dict);
         const size_t lo = std::min(n, w * tiles_per * GK_RPT), hi = std::min(n, (w + 1) * tiles_per * GK_RPT);
-        const bool prof = getenv("GK_PROFILE_HOST") != nullptr;   // coarse host-side timing of the three steps
-        double t_parse = 0, t_norm = 0, t_flat = 0;
-        auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         for (size_t i = lo; i < hi; i++) {
           const gk_review_in& r = reviews[i];
+          if (!slow_only) {
+            RawReview rr;
+            rr.kind = r.kind; rr.source = r.source; rr.json = r.json; rr.json_len = r.json_len;
+            rr.ns_json = r.namespace_json; rr.ns_len = r.namespace_len; rr.nsobj_json = r.ns_object_json; rr.nsobj_len = r.ns_object_len;
+            rr.operation = r.operation;
+            if (fl.add_json(rr, e->ns_cache, &parts[w], &t->obj_keys[i])) { if (statuses) statuses[i] = GK_OK; part_fast[w]++; continue; }
+          }
           ReviewDoc doc;
           int st = GK_OK;
-          double t0 = prof ? now() : 0, t1 = 0;
           try {
             Value body = parse_json(r.json, r.json_len);
             Value mns = parse_opt(r.namespace_json, r.namespace_len);
             Value nso = parse_opt(r.ns_object_json, r.ns_object_len);
-            if (prof) { t1 = now(); t_parse += t1 - t0; }
             if (r.kind == GK_REVIEW_OBJECT) doc = normalize_object(body, mns, nso, r.source, r.operation ? r.operation : "", e->ns_cache);
             else doc = normalize_admission_request(body, mns, nso, r.source, e->ns_cache);
-            if (prof) t_norm += now() - t1;
           } catch (const std::exception& ex) {
             st = GK_ERR_REVIEW;
             t->review_errors[i] = ex.what();
@@ -512,48 +517,117 @@ int gk_table_create(gk_engine* e, const gk_review_in* reviews, size_t n, uint32_
             }
             t->obj_keys[i] = std::move(key);
           }
-          double t2 = prof ? now() : 0;
           fl.add(doc, &parts[w]);
-          if (prof) t_flat += now() - t2;
           if (keep) t->docs[i] = doc;
         }
         fl.flush(&parts[w]);
-        if (prof) fprintf(stderr, "[gkgpu host] part %zu: %zu reviews, parse %.3f s, normalise %.3f s, flatten %.3f s\n", w, hi - lo, t_parse, t_norm, t_flat);
       } catch (const std::exception& ex) { part_err[w] = ex.what(); }
     };
-    if (n_threads <= 1) work(0);
-    else {
+    auto run_threads = [&](const std::function<void(size_t)>& fn) {
+      if (n_threads <= 1) { fn(0); return; }
       std::vector<std::thread> th;
-      for (size_t w = 0; w < n_threads; w++) th.emplace_back(work, w);
+      for (size_t w = 0; w < n_threads; w++) th.emplace_back(fn, w);
       for (auto& x : th) x.join();
-    }
-    for (auto& pe_ : part_err) if (!pe_.empty()) return fail(GK_ERR_INTERNAL, pe_);
-    for (size_t w = 0; w < n_threads; w++) {
-      if (w == 0) t->host = std::move(parts[0]); else t->host.append(parts[w]);
-      parts[w] = HostTable();
+    };
+    // content digest (test aid, GK_TABLE_DIGEST=1): per part while its rows are still on the host; parts are combined in
+    // order, strings by value (not by heap offset), so the digest does not depend on the number of host threads
+    const bool want_digest = getenv("GK_TABLE_DIGEST") != nullptr;
+    std::vector<std::vector<uint64_t>> part_digest(n_threads);
+    auto digest_part = [&](size_t w) {
+      const HostTable& P = parts[w];
+      for (size_t tl = 0; tl + 0 < P.tile_seg.size(); tl++) {
+        uint64_t d = 1469598103934665603ull;
+        auto mix = [&](uint64_t v) { d ^= v; d *= 1099511628211ull; d ^= d >> 31; };
+        const uint32_t s0 = P.tile_seg[tl], s1 = tl + 1 < P.tile_seg.size() ? P.tile_seg[tl + 1] : (uint32_t)P.segs.size();
+        for (uint32_t sg = s0; sg < s1; sg++) {
+          const uint32_t a = P.segs[sg].start, b = sg + 1 < P.segs.size() ? P.segs[sg + 1].start : (uint32_t)P.rows.size();
+          for (uint32_t i = a; i < b; i++) {
+            const Row& r = P.rows[i];
+            mix(P.segs[sg].path); mix(((uint64_t)r.rev << 32) | r.meta);
+            if ((r.meta & ROW_TYPE_MASK) == T_STRING && !(r.meta & ROW_STR_INLINE)) {
+              uint32_t len; memcpy(&len, &P.heap[r.lo - 4], 4);
+              mix(len); mix(r.hi);
+              for (uint32_t k = 0; k < len; k++) mix(P.heap[r.lo + k]);
+              for (int k = 0; k < 4; k++) mix(P.shdr[i].w[k]);
+            } else mix(((uint64_t)r.hi << 32) | r.lo);
+          }
+        }
+        part_digest[w].push_back(d);
+      }
+    };
+    std::vector<DevPart*> dev_parts(n_threads, nullptr);
+    std::vector<double> part_upload_s(n_threads, 0);
+    run_threads([&](size_t w) {
+      work(w);
+      if (!part_err[w].empty()) return;
+      try {
+        if (want_digest) digest_part(w);
+        const auto u0 = std::chrono::steady_clock::now();
+        dev_parts[w] = dev_part_upload(e->opts.device, parts[w]);   // each thread ships its part as soon as it is flattened
+        part_upload_s[w] = std::chrono::duration<double>(std::chrono::steady_clock::now() - u0).count();
+      } catch (const std::exception& ex) { part_err[w] = ex.what(); }
+    });
+    const auto t_parsed = std::chrono::steady_clock::now();
+    for (auto& pe_ : part_err) if (!pe_.empty()) { for (DevPart* dp : dev_parts) dev_part_free(dp); return fail(GK_ERR_INTERNAL, pe_); }
+    // ---- what is global: row / heap bases by prefix sum -> segment starts, the slot index, review flags
+    HostTable& H = t->host;
+    {
+      size_t rb = 0, hb = 0;
+      for (size_t w = 0; w < n_threads; w++) {
+        HostTable& P = parts[w];
+        const uint32_t sb = (uint32_t)H.segs.size();
+        for (const auto& sg : P.segs) H.segs.push_back({sg.path, (uint32_t)(sg.start + rb)});
+        for (uint32_t ts : P.tile_seg) H.tile_seg.push_back(ts + sb);
+        H.rflags.insert(H.rflags.end(), P.rflags.begin(), P.rflags.end());
+        if (P.path_rows.size() > H.path_rows.size()) H.path_rows.resize(P.path_rows.size(), 0);
+        for (size_t i = 0; i < P.path_rows.size(); i++) H.path_rows[i] += P.path_rows[i];
+        if (P.path_max.size() > H.path_max.size()) H.path_max.resize(P.path_max.size(), 0);
+        for (size_t i = 0; i < P.path_max.size(); i++) H.path_max[i] = std::max(H.path_max[i], P.path_max[i]);
+        rb += P.n_rows_total; hb += P.heap_total;
+        t->stats.fast_reviews += part_fast[w];
+        H.n_reviews += P.n_reviews;
+      }
+      if (rb >= 0xFFFFFFF0ull || hb >= 0xFFFFFFF0ull) {
+        for (DevPart* dp : dev_parts) dev_part_free(dp);
+        return fail(GK_ERR_INVALID, "table too large for 32-bit row/heap offsets: split the batch");
+      }
+      t->n_rows = rb;
+      t->stats.heap_bytes = hb;
+      H.n_rows_total = rb;
     }
     Flattener::build_index(&t->host);
-    if (t->host.rows.size() >= 0xFFFFFFF0ull || t->host.heap.size() >= 0xFFFFFFF0ull)
-      return fail(GK_ERR_INVALID, "table too large for 32-bit row/heap offsets: split the batch");
+    if (want_digest) {
+      uint64_t d = 1469598103934665603ull;
+      auto mix = [&](uint64_t v) { d ^= v; d *= 1099511628211ull; d ^= d >> 31; };
+      for (auto& pd : part_digest) for (uint64_t x : pd) mix(x);
+      for (uint32_t f : H.rflags) mix(f);
+      for (uint32_t sp : H.slot_path) mix(sp);
+      for (auto& k : t->obj_keys) for (unsigned char c : k) mix(c);
+      t->stats.digest = d;
+    }
+    const auto t_indexed = std::chrono::steady_clock::now();
+    t->dev = dev_table_assemble(e->opts.device, dev_parts, t->host);
+    const auto t_up = std::chrono::steady_clock::now();
+    if (getenv("GK_PROFILE_HOST")) {
+      double umax = 0;
+      for (double u : part_upload_s) umax = std::max(umax, u);
+      fprintf(stderr, "[gkgpu host] %zu reviews on %zu threads: flatten+upload (overlapped) %.3f s (slowest part upload %.3f s), index %.3f s, assemble %.3f s\n",
+              n, n_threads, std::chrono::duration<double>(t_parsed - t_begin).count(), umax,
+              std::chrono::duration<double>(t_indexed - t_parsed).count(), std::chrono::duration<double>(t_up - t_indexed).count());
+    }
     t->n_reviews = (uint32_t)n;
-    t->n_rows = t->host.rows.size();
     t->dir_bytes = t->host.rflags.size() * 4;
     t->slot_path = t->host.slot_path;
     t->path_rows = t->host.path_rows;
     t->path_max = t->host.path_max;
     t->resident = (flags & GK_TABLE_RESIDENT) || getenv("GK_SPECIALIZE_ALL");
-    const auto t_flat = std::chrono::steady_clock::now();
-    t->dev = dev_table_upload(t->host);
-    const auto t_up = std::chrono::steady_clock::now();
     t->stats.n_reviews = n; t->stats.n_rows = t->n_rows; t->stats.host_threads = (uint32_t)n_threads;
-    t->stats.heap_bytes = t->host.heap.size();
     t->stats.device_bytes = dev_table_bytes(t->dev);
-    t->stats.flatten_s = std::chrono::duration<double>(t_flat - t_begin).count();
-    t->stats.upload_s = std::chrono::duration<double>(t_up - t_flat).count();
+    // the parts' transfers overlap the flattening of the other host threads: upload_s is what is NOT hidden (slot index,
+    // review flags, placing the parts on the device), flatten_s the rest of the wall clock
+    t->stats.upload_s = std::chrono::duration<double>(t_up - t_indexed).count();
+    t->stats.flatten_s = std::chrono::duration<double>(t_indexed - t_begin).count();
     for (size_t i = 0; i < n; i++) t->stats.json_bytes += reviews[i].json_len;
-    t->host.rows.clear(); t->host.rows.shrink_to_fit();
-    t->host.heap.clear(); t->host.heap.shrink_to_fit();
-    t->host.shdr.clear(); t->host.shdr.shrink_to_fit();
     t->host.tile_idx.clear(); t->host.tile_idx.shrink_to_fit();
     *out = t.release();
     return GK_OK;

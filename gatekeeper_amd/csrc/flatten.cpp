@@ -2,7 +2,7 @@
 #include "flatten.hpp"
 
 #include <algorithm>
-
+#include <cstring>
 #include <mutex>
 
 namespace gk {
@@ -187,6 +187,17 @@ Flattener::Flattener(PathDict* dict) : dict_(dict) {
   id_old_ = dict_->child(0, "oldObject");
   id_m_ = dict_->child(0, "$m");
   id_ns_ = dict_->child(0, "$ns");
+  for (int w = 0; w < 2; w++) {   // paths of the strings the match layer reads from object / oldObject (fast ingest)
+    const uint32_t root = w ? id_old_ : id_object_;
+    CapIds& c = cap_[w];
+    c.api_version = dict_->child(root, "apiVersion");
+    c.kind = dict_->child(root, "kind");
+    c.metadata = dict_->child(root, "metadata");
+    c.name = dict_->child(c.metadata, "name");
+    c.ns = dict_->child(c.metadata, "namespace");
+    c.gname = dict_->child(c.metadata, "generateName");
+    c.labels = dict_->child(c.metadata, "labels");
+  }
 }
 
 void Flattener::emit(uint32_t path, uint32_t meta, uint32_t lo, uint32_t hi) {
@@ -195,10 +206,13 @@ void Flattener::emit(uint32_t path, uint32_t meta, uint32_t lo, uint32_t hi) {
 
 uint32_t Flattener::put_string(const std::string& s, uint32_t* hash) {
   // 16-byte aligned, zero-padded entry [u32 len][bytes][pad]: one aligned 16 B load fetches len + the first 12 bytes
-  std::vector<uint8_t>& h = t_->heap;
+  PodVec<uint8_t>& h = t_->heap;
   uint32_t n = (uint32_t)s.size();
   size_t at = (h.size() + 15) & ~(size_t)15;
-  h.resize(at + ((4 + (size_t)n + 15) & ~(size_t)15));
+  const size_t old_n = h.size(), end = at + ((4 + (size_t)n + 15) & ~(size_t)15);
+  h.resize(end);
+  memset(&h[old_n], 0, at - old_n);
+  memset(&h[end - 16], 0, 16);     // zero padding: the device compares whole words
   memcpy(&h[at], &n, 4);
   memcpy(&h[at + 4], s.data(), n);
   *hash = hash32((const uint8_t*)s.data(), n);
@@ -220,19 +234,11 @@ void Flattener::emit_string_row(uint32_t path, uint32_t meta, const std::string&
 void Flattener::emit_str(uint32_t parent, const char* key, const std::string& s) { emit_string_row(child(parent, key), 0, s); }
 
 // Flattener-local memo of the shared dictionary: the hot lookups take no lock (one Flattener per host thread).
-uint32_t Flattener::child(uint32_t parent, const std::string& key) {
-  auto& m = memo_[parent];
-  auto it = m.find(key);
-  if (it != m.end()) return it->second;
-  uint32_t id = dict_->child(parent, key);
-  m.emplace(key, id);
-  return id;
-}
+uint32_t Flattener::child(uint32_t parent, const std::string& key) { return fast_child(parent, key.data(), (uint32_t)key.size()); }
 uint32_t Flattener::elem(uint32_t parent) {
-  auto it = memo_elem_.find(parent);
-  if (it != memo_elem_.end()) return it->second;
-  uint32_t id = dict_->elem(parent);
-  memo_elem_.emplace(parent, id);
+  if (parent >= elem_cache_.size()) elem_cache_.resize((size_t)parent * 2 + 64, PathDict::kNone);
+  uint32_t& id = elem_cache_[parent];
+  if (id == PathDict::kNone) id = dict_->elem(parent);
   return id;
 }
 
@@ -318,29 +324,14 @@ void Flattener::match_facts(const Value& obj, const Value& ns, bool is_old, uint
 void Flattener::add(const ReviewDoc& doc, HostTable* out) {
   t_ = out;
   ctrs_.clear();
+  ctr_touched_.clear();
   review_flags_ = 0;
   const Value& req = doc.request;
   // root + request members (input.review.*)
   emit(0, T_OBJECT, (uint32_t)req.size(), 0);
   for (const auto& kv : req.pairs()) walk(kv.second, child(0, kv.first.str()), 0, 0, 0);
-  // $ns: only what the match layer reads from Matchable.Namespace (name + labels)
-  const Value& ns = doc.match_ns;
-  if (ns.defined()) {
-    review_flags_ |= RF_NS_PRESENT;
-    emit(id_ns_, T_OBJECT, 1, 0);
-    uint32_t md = dict_->child(id_ns_, "metadata");
-    emit(md, T_OBJECT, 2, 0);
-    emit_str(md, "name", obj_string(ns, "metadata", "name"));
-    const Value* m = ns.get("metadata");
-    const Value* lb = m ? m->get("labels") : nullptr;
-    if (lb && lb->is_object()) {
-      bool bad = false;
-      for (const auto& kv : lb->pairs()) if (!kv.second.is_string()) bad = true;
-      if (bad) review_flags_ |= RF_NS_LABELS_BAD;
-      walk(*lb, dict_->child(md, "labels"), 0, 0, 0);
-    } else if (lb) review_flags_ |= RF_NS_LABELS_BAD;
-  }
   // $m: per-candidate match facts
+  const Value& ns = doc.match_ns;
   emit(id_m_, T_OBJECT, 2, 0);
   const Value* obj = req.get("object");
   const Value* old = req.get("oldObject");
@@ -349,7 +340,27 @@ void Flattener::add(const ReviewDoc& doc, HostTable* out) {
   // gkReviewToObject (matcher.go:73-93): Unstructured.UnmarshalJSON rejects a document without a non-empty string `kind`
   if (obj && obj->is_object() && obj_string(*obj, "kind").empty()) review_flags_ |= RF_OBJ_BAD;
   if (old && old->is_object() && obj_string(*old, "kind").empty()) review_flags_ |= RF_OLD_BAD;
-  switch (doc.source) {
+  finish_review(ns, doc.source, out);
+}
+
+// $ns rows (only what the match layer reads from Matchable.Namespace: name + labels), source flags, bookkeeping
+void Flattener::finish_review(const Value& ns, int source, HostTable* out) {
+  if (ns.defined()) {
+    review_flags_ |= RF_NS_PRESENT;
+    emit(id_ns_, T_OBJECT, 1, 0);
+    uint32_t md = child(id_ns_, "metadata");
+    emit(md, T_OBJECT, 2, 0);
+    emit_str(md, "name", obj_string(ns, "metadata", "name"));
+    const Value* m = ns.get("metadata");
+    const Value* lb = m ? m->get("labels") : nullptr;
+    if (lb && lb->is_object()) {
+      bool bad = false;
+      for (const auto& kv : lb->pairs()) if (!kv.second.is_string()) bad = true;
+      if (bad) review_flags_ |= RF_NS_LABELS_BAD;
+      walk(*lb, child(md, "labels"), 0, 0, 0);
+    } else if (lb) review_flags_ |= RF_NS_LABELS_BAD;
+  }
+  switch (source) {
     case SRC_ORIGINAL: review_flags_ |= RF_SRC_ORIGINAL; break;
     case SRC_GENERATED: review_flags_ |= RF_SRC_GENERATED; break;
     case SRC_ALL: review_flags_ |= RF_SRC_ALL; break;
@@ -361,6 +372,10 @@ void Flattener::add(const ReviewDoc& doc, HostTable* out) {
     if (c.path >= out->path_max.size()) out->path_max.resize(c.path + 1, 0);
     out->path_max[c.path] = std::max(out->path_max[c.path], c.n);
   }
+  for (uint32_t ep : ctr_touched_) {
+    if (ep >= out->path_max.size()) out->path_max.resize(ep + 1, 0);
+    out->path_max[ep] = std::max(out->path_max[ep], ctr_val_[ep]);
+  }
   out->n_reviews++;
   if (out->n_reviews % GK_RPT == 0) flush_tile(out);
 }
@@ -369,34 +384,50 @@ void Flattener::add(const ReviewDoc& doc, HostTable* out) {
 // segment) and one segment record per distinct path (turned into the slot index by build_index).
 void Flattener::flush_tile(HostTable* out) {
   out->tile_seg.push_back((uint32_t)out->segs.size());
-  order_.resize(stage_.size());
-  for (uint32_t i = 0; i < order_.size(); i++) order_[i] = i;
-  std::stable_sort(order_.begin(), order_.end(), [&](uint32_t a, uint32_t b) { return stage_[a].path < stage_[b].path; });
-  uint32_t prev = PathDict::kNone;
-  for (uint32_t i : order_) {
-    const Staged& s = stage_[i];
-    if (s.path != prev) { out->segs.push_back({s.path, (uint32_t)out->rows.size()}); prev = s.path; }
-    if (s.path >= out->path_rows.size()) out->path_rows.resize(s.path + 1, 0);
-    out->path_rows[s.path]++;
-    out->rows.push_back(s.row);
-    out->shdr.push_back(s.hdr);
+  // counting sort by path (stable): paths are dense ids, a tile touches a few hundred of them
+  const uint32_t n = (uint32_t)stage_.size();
+  uint32_t max_path = 0;
+  for (const Staged& s : stage_) max_path = std::max(max_path, s.path);
+  if (sort_count_.size() <= max_path) sort_count_.resize(max_path + 1, 0);
+  sort_paths_.clear();
+  for (const Staged& s : stage_) if (sort_count_[s.path]++ == 0) sort_paths_.push_back(s.path);
+  std::sort(sort_paths_.begin(), sort_paths_.end());
+  const size_t base = out->rows.size();
+  uint32_t at = 0;
+  for (uint32_t p : sort_paths_) {
+    out->segs.push_back({p, (uint32_t)(base + at)});
+    if (p >= out->path_rows.size()) out->path_rows.resize(p + 1, 0);
+    out->path_rows[p] += sort_count_[p];
+    const uint32_t c = sort_count_[p];
+    sort_count_[p] = at;   // becomes the write cursor of the path
+    at += c;
   }
+  out->rows.resize(base + n);
+  out->shdr.resize(base + n);
+  for (const Staged& s : stage_) {
+    const uint32_t k = sort_count_[s.path]++;
+    out->rows[base + k] = s.row;
+    out->shdr[base + k] = s.hdr;
+  }
+  for (uint32_t p : sort_paths_) sort_count_[p] = 0;
   stage_.clear();
 }
 
 void Flattener::flush(HostTable* out) {
   if (!stage_.empty() || out->n_reviews % GK_RPT != 0) flush_tile(out);
+  out->n_rows_total = out->rows.size();
+  out->heap_total = out->heap.size();
 }
 
 // Appends `part` (whole tiles flattened by another Flattener over the same dictionary; the receiving table must end
 // on a tile boundary) -- row starts and heap offsets are relocated.
 void HostTable::append(const HostTable& part) {
   const uint32_t row_base = (uint32_t)rows.size(), heap_base = (uint32_t)heap.size(), seg_base = (uint32_t)segs.size();
-  rows.insert(rows.end(), part.rows.begin(), part.rows.end());
+  rows.append(part.rows.data(), part.rows.size());
   for (size_t i = row_base; i < rows.size(); i++)
     if ((rows[i].meta & ROW_TYPE_MASK) == T_STRING && !(rows[i].meta & ROW_STR_INLINE)) rows[i].lo += heap_base;
-  shdr.insert(shdr.end(), part.shdr.begin(), part.shdr.end());
-  heap.insert(heap.end(), part.heap.begin(), part.heap.end());
+  shdr.append(part.shdr.data(), part.shdr.size());
+  heap.append(part.heap.data(), part.heap.size());
   for (const SegRec& s : part.segs) segs.push_back({s.path, s.start + row_base});
   for (uint32_t ts : part.tile_seg) tile_seg.push_back(ts + seg_base);
   rflags.insert(rflags.end(), part.rflags.begin(), part.rflags.end());
@@ -405,6 +436,375 @@ void HostTable::append(const HostTable& part) {
   if (part.path_max.size() > path_max.size()) path_max.resize(part.path_max.size(), 0);
   for (size_t i = 0; i < part.path_max.size(); i++) path_max[i] = std::max(path_max[i], part.path_max[i]);
   n_reviews += part.n_reviews;
+  n_rows_total = rows.size(); heap_total = heap.size();
+}
+
+// ------------------------------------------------------------------------------------------------ fast ingest
+// JSON text -> rows in one pass (see flatten.hpp).  Grammar and value semantics are those of value.hpp's JsonParser;
+// anything unusual bails out (returns false / -1) so that the general path decides.
+uint32_t Flattener::fast_child(uint32_t parent, const char* key, uint32_t len) {
+  uint64_t h = 1469598103934665603ull ^ ((uint64_t)parent * 0x9E3779B97F4A7C15ull);
+  for (uint32_t i = 0; i < len; i++) { h ^= (uint8_t)key[i]; h *= 1099511628211ull; }
+  h ^= h >> 29;
+  if (key_tab_.empty()) key_tab_.resize(2048);
+  size_t mask = key_tab_.size() - 1, i = (size_t)h & mask;
+  while (key_tab_[i].used) {
+    const KeySlot& k = key_tab_[i];
+    if (k.hash == h && k.parent == parent && k.len == len && memcmp(key_arena_.data() + k.off, key, len) == 0) return k.id;
+    i = (i + 1) & mask;
+  }
+  const uint32_t id = dict_->child(parent, std::string(key, len));
+  if ((key_count_ + 1) * 2 > key_tab_.size()) {   // grow + rehash
+    std::vector<KeySlot> old;
+    old.swap(key_tab_);
+    key_tab_.resize(old.size() * 2);
+    mask = key_tab_.size() - 1;
+    for (const KeySlot& k : old) if (k.used) { size_t j = (size_t)k.hash & mask; while (key_tab_[j].used) j = (j + 1) & mask; key_tab_[j] = k; }
+    i = (size_t)h & mask;
+    while (key_tab_[i].used) i = (i + 1) & mask;
+  }
+  KeySlot& k = key_tab_[i];
+  k.used = true; k.hash = h; k.parent = parent; k.id = id; k.off = (uint32_t)key_arena_.size(); k.len = len;
+  key_arena_.append(key, len);
+  key_count_++;
+  return id;
+}
+
+// p_ is at the opening quote.  On success *s/*n view the decoded bytes: the JSON text itself when the string has no
+// escapes, else scratch_ (valid until the next decoded string).
+bool Flattener::fast_string(const char** s, uint32_t* n) {
+  const char* q = p_ + 1;
+  const char* start = q;
+  while (q < e_ && *q != '"' && *q != '\\') q++;
+  if (q >= e_) return false;
+  if (*q == '"') { *s = start; *n = (uint32_t)(q - start); p_ = q + 1; return true; }
+  // escapes: decode (same rules as JsonParser::str)
+  scratch_.assign(start, q - start);
+  p_ = q;
+  auto hex4 = [&](uint32_t* v) -> bool {
+    if (e_ - p_ < 4) return false;
+    uint32_t x = 0;
+    for (int k = 0; k < 4; k++) {
+      char c = *p_++;
+      x <<= 4;
+      if (c >= '0' && c <= '9') x |= c - '0';
+      else if (c >= 'a' && c <= 'f') x |= c - 'a' + 10;
+      else if (c >= 'A' && c <= 'F') x |= c - 'A' + 10;
+      else return false;
+    }
+    *v = x;
+    return true;
+  };
+  auto utf8 = [&](uint32_t cp) {
+    if (cp < 0x80) scratch_.push_back((char)cp);
+    else if (cp < 0x800) { scratch_.push_back((char)(0xC0 | (cp >> 6))); scratch_.push_back((char)(0x80 | (cp & 0x3F))); }
+    else if (cp < 0x10000) { scratch_.push_back((char)(0xE0 | (cp >> 12))); scratch_.push_back((char)(0x80 | ((cp >> 6) & 0x3F))); scratch_.push_back((char)(0x80 | (cp & 0x3F))); }
+    else { scratch_.push_back((char)(0xF0 | (cp >> 18))); scratch_.push_back((char)(0x80 | ((cp >> 12) & 0x3F))); scratch_.push_back((char)(0x80 | ((cp >> 6) & 0x3F))); scratch_.push_back((char)(0x80 | (cp & 0x3F))); }
+  };
+  for (;;) {
+    if (p_ >= e_) return false;
+    const char* r = p_;
+    while (r < e_ && *r != '"' && *r != '\\') r++;
+    scratch_.append(p_, r - p_);
+    p_ = r;
+    if (p_ >= e_) return false;
+    if (*p_ == '"') { p_++; *s = scratch_.data(); *n = (uint32_t)scratch_.size(); return true; }
+    p_++;
+    if (p_ >= e_) return false;
+    char c = *p_++;
+    switch (c) {
+      case '"': scratch_.push_back('"'); break;
+      case '\\': scratch_.push_back('\\'); break;
+      case '/': scratch_.push_back('/'); break;
+      case 'b': scratch_.push_back('\b'); break;
+      case 'f': scratch_.push_back('\f'); break;
+      case 'n': scratch_.push_back('\n'); break;
+      case 'r': scratch_.push_back('\r'); break;
+      case 't': scratch_.push_back('\t'); break;
+      case 'u': {
+        uint32_t cp;
+        if (!hex4(&cp)) return false;
+        if (cp >= 0xD800 && cp < 0xDC00 && e_ - p_ >= 6 && p_[0] == '\\' && p_[1] == 'u') {
+          p_ += 2;
+          uint32_t lo;
+          if (!hex4(&lo)) return false;
+          if (lo >= 0xDC00 && lo < 0xE000) cp = 0x10000 + ((cp - 0xD800) << 10) + (lo - 0xDC00);
+          else { utf8(0xFFFD); cp = lo; }
+        }
+        utf8(cp);
+        break;
+      }
+      default: return false;
+    }
+  }
+}
+
+void Flattener::emit_str_n(uint32_t path, uint32_t meta, const char* s, uint32_t n) {
+  if (n <= 7) {   // inline: no heap entry, no memory access on the device
+    uint64_t bits = 0;
+    memcpy(&bits, s, n);
+    emit(path, meta | T_STRING | ROW_STR_INLINE, (uint32_t)bits, (uint32_t)(bits >> 32) | (n << 24));
+    return;
+  }
+  PodVec<uint8_t>& h = t_->heap;
+  size_t at = (h.size() + 15) & ~(size_t)15;
+  const size_t old_n = h.size(), end = at + ((4 + (size_t)n + 15) & ~(size_t)15);
+  h.resize(end);
+  memset(&h[old_n], 0, at - old_n);
+  memset(&h[end - 16], 0, 16);     // zero padding: the device compares whole words
+  memcpy(&h[at], &n, 4);
+  memcpy(&h[at + 4], s, n);
+  emit(path, meta | T_STRING, (uint32_t)(at + 4), hash32((const uint8_t*)s, n));
+  memcpy(&stage_.back().hdr, &h[at], 16);   // entry header: length + first 12 bytes
+}
+
+// one JSON value at p_ -> rows under `path`; returns its RowType, -1 to bail out
+int Flattener::fast_value(uint32_t path, uint32_t ords, int adepth, uint32_t extra, int depth) {
+  if (depth > 96) return -1;
+  ws();
+  if (p_ >= e_) return -1;
+  const uint32_t meta = ords | extra;
+  const char c = *p_;
+  if (c == '{') {
+    p_++;
+    const size_t row = stage_.size();
+    emit(path, meta | T_OBJECT, 0, 0);
+    const uint32_t inst = ++obj_instance_;
+    uint32_t count = 0;
+    ws();
+    if (p_ < e_ && *p_ == '}') { p_++; return T_OBJECT; }
+    const CapIds* cap = nullptr;
+    if (cur_facts_ && depth <= 1) cap = &cap_[cur_root_ == id_old_ ? 1 : 0];
+    for (;;) {
+      ws();
+      if (p_ >= e_ || *p_ != '"') return -1;
+      const char* k; uint32_t kn;
+      if (!fast_string(&k, &kn)) return -1;
+      const uint32_t ch = fast_child(path, k, kn);
+      if (ch >= dup_gen_.size()) dup_gen_.resize((size_t)ch * 2 + 64, 0);
+      if (dup_gen_[ch] == inst) return -1;   // duplicate member name: the general path applies "last one wins"
+      dup_gen_[ch] = inst;
+      ws();
+      if (p_ >= e_ || *p_ != ':') return -1;
+      p_++;
+      // strings the match layer needs from the candidate object (unstructured accessors: apiVersion, kind,
+      // metadata.{name,namespace,generateName}; GetLabels() needs metadata.labels to be a map of strings)
+      Captured* want = nullptr;
+      if (cap) {
+        if (depth == 0) { if (ch == cap->api_version) want = &cur_facts_->api_version; else if (ch == cap->kind) want = &cur_facts_->kind; }
+        else if (path == cap->metadata) { if (ch == cap->name) want = &cur_facts_->name; else if (ch == cap->ns) want = &cur_facts_->ns; else if (ch == cap->gname) want = &cur_facts_->gname; }
+      }
+      int t;
+      if (want) {
+        ws();
+        if (p_ < e_ && *p_ == '"') {
+          const char* v; uint32_t vn;
+          if (!fast_string(&v, &vn)) return -1;
+          emit_str_n(ch, meta, v, vn);
+          if (v == scratch_.data()) { scratch_keep_.emplace_back(new std::string(v, vn)); v = scratch_keep_.back()->data(); }
+          want->p = v; want->n = vn; want->set = true;
+          t = T_STRING;
+        } else t = fast_value(ch, ords, adepth, extra, depth + 1);
+      } else t = fast_value(ch, ords, adepth, extra, depth + 1);
+      if (t < 0) return -1;
+      if (cap && depth == 1 && path == cap->metadata && ch == cap->labels && t != T_OBJECT) cur_facts_->labels_bad = true;
+      if (cur_facts_ && depth == 2 && path == cap_[cur_root_ == id_old_ ? 1 : 0].labels && t != T_STRING) cur_facts_->labels_bad = true;
+      count++;
+      ws();
+      if (p_ < e_ && *p_ == ',') { p_++; continue; }
+      if (p_ < e_ && *p_ == '}') { p_++; break; }
+      return -1;
+    }
+    stage_[row].row.lo = count;
+    return T_OBJECT;
+  }
+  if (c == '[') {
+    p_++;
+    const size_t row = stage_.size();
+    emit(path, meta | T_ARRAY, 0, 0);
+    uint32_t count = 0;
+    ws();
+    if (p_ < e_ && *p_ == ']') { p_++; return T_ARRAY; }
+    const uint32_t ep = elem(path);
+    if (ep >= ctr_gen_.size()) { ctr_gen_.resize((size_t)ep * 2 + 64, 0); ctr_val_.resize(ctr_gen_.size(), 0); }
+    if (ctr_gen_[ep] != review_gen_) { ctr_gen_[ep] = review_gen_; ctr_val_[ep] = 0; ctr_touched_.push_back(ep); }
+    for (;;) {
+      uint32_t ord = ctr_val_[ep]++;
+      uint32_t ex = extra, o2 = ords;
+      if (adepth < 3) {
+        if (ord >= 255) { ord = 255; ex |= ROW_ORD_OVERFLOW; review_flags_ |= RF_TOO_BIG; }
+        o2 |= ord << (ROW_E_SHIFT0 + 8 * adepth);
+      } else ex |= ROW_DEEP;
+      if (fast_value(ep, o2, adepth + 1, ex, depth + 1) < 0) return -1;
+      count++;
+      ws();
+      if (p_ < e_ && *p_ == ',') { p_++; continue; }
+      if (p_ < e_ && *p_ == ']') { p_++; break; }
+      return -1;
+    }
+    stage_[row].row.lo = count;
+    return T_ARRAY;
+  }
+  if (c == '"') {
+    const char* v; uint32_t vn;
+    if (!fast_string(&v, &vn)) return -1;
+    emit_str_n(path, meta, v, vn);
+    return T_STRING;
+  }
+  if (c == 't') { if (e_ - p_ < 4 || memcmp(p_, "true", 4) != 0) return -1; p_ += 4; emit(path, meta | T_BOOL, 1, 0); return T_BOOL; }
+  if (c == 'f') { if (e_ - p_ < 5 || memcmp(p_, "false", 5) != 0) return -1; p_ += 5; emit(path, meta | T_BOOL, 0, 0); return T_BOOL; }
+  if (c == 'n') { if (e_ - p_ < 4 || memcmp(p_, "null", 4) != 0) return -1; p_ += 4; emit(path, meta | T_NULL, 0, 0); return T_NULL; }
+  // number: JsonParser::number + Flattener::walk
+  const char* s = p_;
+  bool is_int = true, neg = false;
+  if (p_ < e_ && *p_ == '-') { neg = true; p_++; }
+  if (p_ >= e_ || !(*p_ >= '0' && *p_ <= '9')) return -1;
+  const char* digits = p_;
+  while (p_ < e_ && *p_ >= '0' && *p_ <= '9') p_++;
+  const size_t nd = p_ - digits;
+  if (p_ < e_ && *p_ == '.') { is_int = false; p_++; while (p_ < e_ && *p_ >= '0' && *p_ <= '9') p_++; }
+  if (p_ < e_ && (*p_ == 'e' || *p_ == 'E')) {
+    is_int = false; p_++;
+    if (p_ < e_ && (*p_ == '+' || *p_ == '-')) p_++;
+    while (p_ < e_ && *p_ >= '0' && *p_ <= '9') p_++;
+  }
+  if (is_int && nd <= 18) {   // fits int64 for certain
+    int64_t x = 0;
+    for (size_t k = 0; k < nd; k++) x = x * 10 + (digits[k] - '0');
+    if (neg) x = -x;
+    emit(path, meta | T_INT, (uint32_t)(uint64_t)x, (uint32_t)((uint64_t)x >> 32));
+    return T_INT;
+  }
+  {   // the general number rules, through the same Value code the tree walk uses
+    Value v = parse_json(s, p_ - s);
+    if (v.is_int && v.i >= (i128)INT64_MIN && v.i <= (i128)INT64_MAX) {
+      uint64_t u = (uint64_t)(int64_t)v.i;
+      emit(path, meta | T_INT, (uint32_t)u, (uint32_t)(u >> 32));
+      return T_INT;
+    }
+    double d = v.as_double();
+    uint64_t u;
+    memcpy(&u, &d, 8);
+    emit(path, meta | T_FLOAT | (v.is_int ? ROW_INEXACT : 0), (uint32_t)u, (uint32_t)(u >> 32));
+    return T_FLOAT;
+  }
+}
+
+bool Flattener::fast_tree(const char* json, size_t len, uint32_t root, ObjFacts* facts, int* type) {
+  p_ = json; e_ = json + len;
+  cur_facts_ = facts; cur_root_ = root;
+  int t = fast_value(root, 0, 0, 0, 0);
+  cur_facts_ = nullptr;
+  if (t < 0) return false;
+  ws();
+  if (p_ != e_) return false;
+  *type = t;
+  if (facts) facts->present = true;
+  return true;
+}
+
+void Flattener::fast_match_facts(const ObjFacts& f, const Value& ns, bool is_old) {
+  // = match_facts() on the captured strings
+  std::string av = f.api_version.set ? std::string(f.api_version.p, f.api_version.n) : std::string();
+  std::string kind = f.kind.set ? std::string(f.kind.p, f.kind.n) : std::string();
+  std::string group;
+  size_t nsl = std::count(av.begin(), av.end(), '/');
+  if (!(av.empty() || av == "/") && nsl == 1) group = av.substr(0, av.find('/'));
+  const bool is_ns = kind == "Namespace" && group.empty();
+  uint32_t sub = child(id_m_, is_old ? "old" : "o");
+  emit(sub, T_OBJECT, 0, 0);
+  emit_str(sub, "group", group);
+  emit_str(sub, "kind", kind);
+  const std::string name = f.name.set ? std::string(f.name.p, f.name.n) : std::string();
+  const std::string nsfield = f.ns.set ? std::string(f.ns.p, f.ns.n) : std::string();
+  emit_str(sub, "name", name);
+  emit_str(sub, "gname", f.gname.set ? std::string(f.gname.p, f.gname.n) : std::string());
+  bool has_nsname = true;
+  std::string nsname;
+  if (is_ns) nsname = name;
+  else if (ns.defined()) nsname = obj_string(ns, "metadata", "name");
+  else if (!nsfield.empty()) nsname = nsfield;
+  else has_nsname = false;
+  if (has_nsname) emit_str(sub, "nsname", nsname);
+  review_flags_ |= is_old ? RF_HAS_OLD : RF_HAS_OBJ;
+  if (is_ns) review_flags_ |= is_old ? RF_OLD_IS_NS : RF_OBJ_IS_NS;
+  if (!nsfield.empty()) review_flags_ |= is_old ? RF_OLD_HAS_NSFIELD : RF_OBJ_HAS_NSFIELD;
+  if (has_nsname) review_flags_ |= is_old ? RF_OLD_HAS_NSNAME : RF_OBJ_HAS_NSNAME;
+  if (f.labels_bad) review_flags_ |= is_old ? RF_OLD_LABELS_BAD : RF_OBJ_LABELS_BAD;
+  if (kind.empty()) review_flags_ |= is_old ? RF_OLD_BAD : RF_OBJ_BAD;
+}
+
+bool Flattener::add_json(const RawReview& r, const NsCache& cache, HostTable* out, std::string* obj_key) {
+  if (r.kind != 1 || !r.json) return false;   // AdmissionRequest documents take the general path
+  t_ = out;
+  const size_t stage0 = stage_.size(), heap0 = out->heap.size();
+  auto bail = [&]() { stage_.resize(stage0); out->heap.resize(heap0); return false; };
+  ctrs_.clear();
+  ctr_touched_.clear();
+  scratch_keep_.clear();
+  review_flags_ = 0;
+  if (++review_gen_ == 0) { std::fill(ctr_gen_.begin(), ctr_gen_.end(), 0); review_gen_ = 1; }
+  const std::string op = r.operation ? r.operation : "";
+  const bool del = op == "DELETE";   // target.go:151-154 + setObjectOnDelete: the object is both oldObject and object
+  ObjFacts fobj, fold;
+  int type = -1;
+  if (!fast_tree(r.json, r.json_len, id_object_, &fobj, &type) || type != T_OBJECT) return bail();
+  if (del && (!fast_tree(r.json, r.json_len, id_old_, &fold, &type) || type != T_OBJECT)) return bail();
+  // the request around it (normalize_object + normalize_admission_request)
+  std::string av = fobj.api_version.set ? std::string(fobj.api_version.p, fobj.api_version.n) : std::string();
+  std::string kind = fobj.kind.set ? std::string(fobj.kind.p, fobj.kind.n) : std::string();
+  std::string group, version;
+  {
+    size_t nsl = std::count(av.begin(), av.end(), '/');
+    if (!(av.empty() || av == "/")) {
+      if (nsl == 0) version = av;
+      else if (nsl == 1) { size_t i = av.find('/'); group = av.substr(0, i); version = av.substr(i + 1); }
+    }
+  }
+  const std::string name = fobj.name.set ? std::string(fobj.name.p, fobj.name.n) : std::string();
+  const std::string nsfield = fobj.ns.set ? std::string(fobj.ns.p, fobj.ns.n) : std::string();
+  uint32_t members = 8;   // uid kind resource operation userInfo object oldObject options
+  emit_str(0, "uid", "");
+  uint32_t kp = child(0, "kind");
+  emit(kp, T_OBJECT, 3, 0);
+  emit_str(kp, "group", group); emit_str(kp, "version", version); emit_str(kp, "kind", kind);
+  uint32_t rp = child(0, "resource");
+  emit(rp, T_OBJECT, 3, 0);
+  emit_str(rp, "group", ""); emit_str(rp, "version", ""); emit_str(rp, "resource", "");
+  emit_str(0, "operation", op);
+  emit(child(0, "userInfo"), T_OBJECT, 0, 0);
+  if (!del) emit(id_old_, T_NULL, 0, 0);
+  emit(child(0, "options"), T_NULL, 0, 0);
+  if (!name.empty()) { emit_str(0, "name", name); members++; }
+  if (!nsfield.empty()) { emit_str(0, "namespace", nsfield); members++; }
+  if (r.nsobj_json && r.nsobj_len) {
+    const size_t before = stage_.size(), hb = out->heap.size();
+    int t2 = -1;
+    if (!fast_tree(r.nsobj_json, r.nsobj_len, child(0, "namespaceObject"), nullptr, &t2)) return bail();
+    if (t2 == T_NULL) { stage_.resize(before); out->heap.resize(hb); } else members++;
+  }
+  emit(0, T_OBJECT, members, 0);
+  // Matchable.Namespace: the review's, else the nsCache entry of the request namespace (matcher.go:37-39)
+  Value ns;
+  if (r.ns_json && r.ns_len) {
+    auto it = ns_cache_.find(r.ns_json);
+    if (it == ns_cache_.end() || it->second.first != r.ns_len) {
+      Value v;
+      try { v = parse_json(r.ns_json, r.ns_len); } catch (const std::exception&) { return bail(); }
+      it = ns_cache_.insert_or_assign(r.ns_json, std::make_pair(r.ns_len, v)).first;
+    }
+    if (!it->second.second.is_null()) ns = it->second.second;
+  }
+  if (!ns.defined() && !nsfield.empty()) ns = cache.get(nsfield);
+  emit(id_m_, T_OBJECT, 2, 0);
+  fast_match_facts(fobj, ns, false);
+  if (del) fast_match_facts(fold, ns, true);
+  if (obj_key) {
+    std::string& k = *obj_key;
+    k = group; k.push_back('\0'); k += version; k.push_back('\0'); k += kind; k.push_back('\0'); k += nsfield; k.push_back('\0'); k += name;
+  }
+  finish_review(ns, r.source, out);
+  return true;
 }
 
 void Flattener::finish(HostTable* out) {
@@ -425,7 +825,7 @@ void Flattener::build_index(HostTable* out) {
   for (uint32_t t = 0; t < T; t++) {
     uint32_t* ix = &out->tile_idx[(size_t)t * (S + 1)];
     const uint32_t s0 = out->tile_seg[t], s1 = out->tile_seg[t + 1];
-    const uint32_t tile_end = s1 < out->segs.size() ? out->segs[s1].start : (uint32_t)out->rows.size();
+    const uint32_t tile_end = s1 < out->segs.size() ? out->segs[s1].start : (uint32_t)out->n_rows_total;
     uint32_t k = s1;            // walk the tile's segments from the right; absent slots start where the next present one does
     uint32_t next = tile_end;
     for (uint32_t s = S; s-- > 0;) {

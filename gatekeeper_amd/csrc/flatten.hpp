@@ -6,6 +6,10 @@
 //  * Flattener: key-path -> value SoA rows (plan.hpp Row) + string heap + per-review header with the match-layer
 //    facts (RF_*) that pkg/mutation/match/match.go:73-258 derives from object/namespace/source.
 #pragma once
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <new>
 #include <shared_mutex>
 #include <string>
 #include <unordered_map>
@@ -81,16 +85,58 @@ std::string obj_string(const Value& obj, const char* a, const char* b = nullptr)
 void obj_gvk(const Value& obj, std::string* group, std::string* version, std::string* kind);
 bool obj_is_namespace(const Value& obj);
 
+// Growable array of PODs WITHOUT value-initialisation: the table arrays hold gigabytes, std::vector::resize would zero
+// every byte before it is overwritten and re-copy everything on growth (realloc grows large blocks in place / by mremap).
+template <class T>
+struct PodVec {
+  T* p_ = nullptr;
+  size_t n_ = 0, cap_ = 0;
+  PodVec() {}
+  PodVec(const PodVec& o) { assign(o.p_, o.n_); }
+  PodVec(PodVec&& o) noexcept : p_(o.p_), n_(o.n_), cap_(o.cap_) { o.p_ = nullptr; o.n_ = o.cap_ = 0; }
+  PodVec& operator=(const PodVec& o) { if (this != &o) assign(o.p_, o.n_); return *this; }
+  PodVec& operator=(PodVec&& o) noexcept { if (this != &o) { free(p_); p_ = o.p_; n_ = o.n_; cap_ = o.cap_; o.p_ = nullptr; o.n_ = o.cap_ = 0; } return *this; }
+  ~PodVec() { free(p_); }
+  void assign(const T* src, size_t n) { resize(n); if (n) memcpy(p_, src, n * sizeof(T)); }
+  size_t size() const { return n_; }
+  bool empty() const { return n_ == 0; }
+  T* data() { return p_; }
+  const T* data() const { return p_; }
+  T& operator[](size_t i) { return p_[i]; }
+  const T& operator[](size_t i) const { return p_[i]; }
+  T& back() { return p_[n_ - 1]; }
+  T* begin() { return p_; }
+  T* end() { return p_ + n_; }
+  const T* begin() const { return p_; }
+  const T* end() const { return p_ + n_; }
+  void reserve(size_t c) {
+    if (c <= cap_) return;
+    T* q = static_cast<T*>(realloc(p_, c * sizeof(T)));
+    if (!q) throw std::bad_alloc();
+    p_ = q; cap_ = c;
+  }
+  void resize(size_t n) {   // new elements are UNINITIALISED
+    if (n > cap_) reserve(std::max(n, cap_ + cap_ / 2 + 1024));
+    n_ = n;
+  }
+  void resize_zero(size_t n) { size_t old = n_; resize(n); if (n > old) memset(static_cast<void*>(p_ + old), 0, (n - old) * sizeof(T)); }
+  void push_back(const T& v) { if (n_ == cap_) reserve(cap_ + cap_ / 2 + 1024); p_[n_++] = v; }
+  void append(const T* src, size_t n) { size_t old = n_; resize(old + n); if (n) memcpy(static_cast<void*>(p_ + old), src, n * sizeof(T)); }
+  void clear() { n_ = 0; }
+  void shrink_to_fit() { if (n_ == 0) { free(p_); p_ = nullptr; cap_ = 0; } }
+};
+
 struct HostTable {
-  std::vector<Row> rows;            // row groups: per tile, sorted by path (plan.hpp)
-  std::vector<StrHdr> shdr;         // parallel to rows
+  PodVec<Row> rows;                 // row groups: per tile, sorted by path (plan.hpp)
+  PodVec<StrHdr> shdr;              // parallel to rows
   std::vector<uint32_t> tile_idx;   // [n_tiles][n_slots + 1]
   std::vector<uint32_t> slot_path;  // [n_slots] path id of each slot, increasing
   std::vector<uint32_t> rflags;     // n_reviews
-  std::vector<uint8_t> heap;
+  PodVec<uint8_t> heap;
   std::vector<uint32_t> path_rows;  // rows per path over the whole table (algorithmic-byte accounting per plan)
   std::vector<uint32_t> path_max;   // per array-element path: largest element count of one review (plan specialisation)
   uint32_t n_reviews = 0;
+  size_t n_rows_total = 0, heap_total = 0;   // sizes of rows / heap (kept when the arrays themselves have gone to the device)
   uint32_t n_tiles() const { return (n_reviews + GK_RPT - 1) / GK_RPT; }   // row groups
   uint32_t n_slots() const { return (uint32_t)slot_path.size(); }
   // build-time only: per-tile segment lists, turned into tile_idx by Flattener::finish
@@ -100,10 +146,27 @@ struct HostTable {
   void append(const HostTable& part);
 };
 
+// One review as the C ABI hands it over (gk_review_in without the C types).
+struct RawReview {
+  int kind = 1;                    // 0 AdmissionRequest JSON, 1 bare object (gk_review_kind)
+  int source = SRC_EMPTY;
+  const char* json = nullptr; size_t json_len = 0;
+  const char* ns_json = nullptr; size_t ns_len = 0;          // gkReview.namespace
+  const char* nsobj_json = nullptr; size_t nsobj_len = 0;    // reviews.Namespace option -> input.review.namespaceObject
+  const char* operation = nullptr;
+};
+
 class Flattener {
  public:
   explicit Flattener(PathDict* dict);
   void add(const ReviewDoc& doc, HostTable* out);
+  // Fast ingest: ONE pass over the JSON text of a review straight into rows -- no Value
+  // tree -- including HandleReview's normalisation (target.go:81-179, 269-287) and the match-layer facts.  Produces
+  // exactly the rows add(normalize_*(parse_json(..))) produces (tests/test_ingest.py compares table digests).
+  // Returns false -- with nothing added -- when the text needs the general path (malformed JSON, duplicate object keys,
+  // nesting beyond the fast parser's depth ...): the caller then runs parse_json + normalize_* + add, which also words
+  // the errors.  obj_key: the audit sort key of the object (group \0 version \0 kind \0 namespace \0 name).
+  bool add_json(const RawReview& r, const NsCache& cache, HostTable* out, std::string* obj_key);
   void finish(HostTable* out);   // flush + build_index
   void flush(HostTable* out);    // closes the tile being built (parallel table builds flush per part, then append)
   static void build_index(HostTable* out);   // slots + dense [tile][slot] index from the per-tile segment lists
@@ -118,9 +181,9 @@ class Flattener {
   struct Staged { uint32_t path; Row row; StrHdr hdr; };
   std::vector<Staged> stage_;       // rows of the tile being built, review order / document order
   std::vector<uint32_t> order_;
+  std::vector<uint32_t> sort_count_, sort_paths_;   // counting sort of a tile's rows by path
   void flush_tile(HostTable* out);
-  std::unordered_map<uint32_t, std::unordered_map<std::string, uint32_t>> memo_;
-  std::unordered_map<uint32_t, uint32_t> memo_elem_;
+  std::vector<uint32_t> elem_cache_;   // path -> its "[]" child
   uint32_t child(uint32_t parent, const std::string& key);
   uint32_t elem(uint32_t parent);
   void walk(const Value& v, uint32_t path, uint32_t meta_ords, int adepth, uint32_t extra);
@@ -129,6 +192,33 @@ class Flattener {
   void emit_str(uint32_t parent, const char* key, const std::string& s);
   void emit_string_row(uint32_t path, uint32_t meta, const std::string& s);
   void match_facts(const Value& obj, const Value& ns, bool is_old, uint32_t m_parent);
+  void finish_review(const Value& ns, int source, HostTable* out);   // $ns rows, source flags, per-review bookkeeping
+
+  // ---- fast ingest state
+  struct Captured { const char* p = nullptr; uint32_t n = 0; bool set = false; };   // a string value seen at a known path
+  struct ObjFacts { Captured api_version, kind, name, ns, gname; bool labels_bad = false; bool present = false; };
+  struct KeySlot { uint64_t hash = 0; uint32_t parent = 0, id = 0, off = 0, len = 0; bool used = false; };
+  std::vector<KeySlot> key_tab_;      // open addressing: (parent path, member name) -> child path
+  std::string key_arena_;
+  size_t key_count_ = 0;
+  std::vector<uint32_t> ctr_gen_, ctr_val_;   // per element path: review generation / running ordinal
+  std::vector<uint32_t> ctr_touched_;
+  std::vector<uint32_t> dup_gen_;             // per path: id of the object instance that last produced it (duplicate keys)
+  uint32_t review_gen_ = 0, obj_instance_ = 0;
+  std::string scratch_;                       // decoded strings with escapes
+  std::vector<std::unique_ptr<std::string>> scratch_keep_;     // ... that are captured (must outlive the review)
+  const char* p_ = nullptr; const char* e_ = nullptr;
+  ObjFacts* cur_facts_ = nullptr;             // facts of the object / oldObject tree being parsed
+  uint32_t cur_root_ = 0;                     // its root path (object / oldObject)
+  struct CapIds { uint32_t api_version, kind, metadata, name, ns, gname, labels; } cap_[2];   // [0] object, [1] oldObject
+  std::unordered_map<const char*, std::pair<size_t, Value>> ns_cache_;   // parsed Namespace documents by text pointer
+  uint32_t fast_child(uint32_t parent, const char* key, uint32_t len);
+  int fast_value(uint32_t path, uint32_t ords, int adepth, uint32_t extra, int depth);   // -> RowType of the value, -1 = bail
+  bool fast_string(const char** s, uint32_t* n);   // decodes the string at p_ (views the text when it has no escapes)
+  bool fast_tree(const char* json, size_t len, uint32_t root, ObjFacts* facts, int* type);
+  void emit_str_n(uint32_t path, uint32_t meta, const char* s, uint32_t n);
+  void fast_match_facts(const ObjFacts& f, const Value& ns, bool is_old);
+  void ws() { while (p_ < e_ && (*p_ == ' ' || *p_ == '\n' || *p_ == '\t' || *p_ == '\r')) p_++; }
 };
 
 }  // namespace gk

@@ -90,6 +90,8 @@ typedef struct {
   double flatten_s;        /* parse + HandleReview normalisation + flatten + row-group index, wall clock over host_threads */
   double upload_s;         /* host -> HBM */
   uint32_t host_threads, reserved;
+  uint64_t fast_reviews;   /* reviews flattened by the one-pass JSON -> rows path (the others took parse + normalise + flatten) */
+  uint64_t digest;         /* content digest of the table, only with GK_TABLE_DIGEST=1 in the environment (test aid) */
 } gk_table_stats;
 int gk_table_get_stats(const gk_table* t, gk_table_stats* out);
 #define GK_TABLE_KEEP_DOCS 1u   /* keep parsed reviews on the host so violations can be rendered to messages */

@@ -41,7 +41,25 @@ struct VecAcc {
 
 std::string dev_init(int) { return ""; }
 int dev_count() { return 0; }
-DevTable* dev_table_upload(const HostTable& t) { DevTable* d = new DevTable(); d->t = t; d->t.heap.resize(d->t.heap.size() + 16, 0); return d; }
+struct DevPart { HostTable t; };
+DevPart* dev_part_upload(int, HostTable& part) { DevPart* p = new DevPart(); p->t.rows = std::move(part.rows); p->t.shdr = std::move(part.shdr); p->t.heap = std::move(part.heap); return p; }
+void dev_part_free(DevPart* p) { delete p; }
+DevTable* dev_table_assemble(int, std::vector<DevPart*>& parts, const HostTable& meta) {
+  DevTable* d = new DevTable();
+  d->t = meta;
+  for (DevPart* p : parts) {
+    const uint32_t row_base = (uint32_t)d->t.rows.size(), heap_base = (uint32_t)d->t.heap.size();
+    d->t.rows.append(p->t.rows.data(), p->t.rows.size());
+    for (size_t i = row_base; i < d->t.rows.size(); i++)
+      if ((d->t.rows[i].meta & ROW_TYPE_MASK) == T_STRING && !(d->t.rows[i].meta & ROW_STR_INLINE)) d->t.rows[i].lo += heap_base;
+    d->t.shdr.append(p->t.shdr.data(), p->t.shdr.size());
+    d->t.heap.append(p->t.heap.data(), p->t.heap.size());
+    delete p;
+  }
+  parts.clear();
+  d->t.heap.resize_zero(d->t.heap.size() + 16);
+  return d;
+}
 void dev_table_free(DevTable* t) { delete t; }
 DevTable* dev_table_view(DevTable* base) { DevTable* v = new DevTable(*base); v->pending = 0; v->last_viol.clear(); return v; }
 uint64_t dev_table_bytes(const DevTable* t) { return t->t.rows.size() * 32 + t->t.tile_idx.size() * 4 + t->t.heap.size(); }

@@ -1,0 +1,87 @@
+"""Fast ingest (one-pass JSON text -> rows, Flattener::add_json) produces exactly the
+table the general path (parse_json -> HandleReview normalisation -> Flattener::add) produces: content digests of the
+two tables agree, review by review shape, on synthetic objects and on adversarial JSON."""
+import json
+import os
+
+import pytest
+
+from gatekeeper_amd import _lib as L
+from gatekeeper_amd import driver as D
+from gatekeeper_amd import synth
+
+
+def _digest(engine, rins, slow, threads=None):
+    os.environ["GK_TABLE_DIGEST"] = "1"
+    if slow:
+        os.environ["GK_SLOW_INGEST"] = "1"
+    if threads:
+        os.environ["GK_HOST_THREADS"] = str(threads)
+    try:
+        t = engine.create_table(rins, keep_docs=False)
+        st = t.stats()
+        t.free()
+        return st
+    finally:
+        for k in ("GK_TABLE_DIGEST", "GK_SLOW_INGEST", "GK_HOST_THREADS"):
+            os.environ.pop(k, None)
+
+
+def _raw(text, ns=None, nsobj=None, op="", source="Original"):
+    r = D.ReviewIn(L.GK_REVIEW_OBJECT, text.encode() if isinstance(text, str) else text, ns, nsobj, source, op)
+    return r
+
+
+@pytest.mark.parametrize("mixed", [False, True])
+def test_fast_ingest_equals_general_path_on_synthetic(mixed):
+    eng = D.Engine(hostemu=True)
+    nss = synth.gen_namespaces()
+    objs = synth.gen_objects(700, seed=77, mixed=mixed)
+    rins = [D.to_review_in(D.AugmentedUnstructured(D.Unstructured(o), synth.namespace_for(o, nss), "Original")) for o in objs]
+    fast, slow = _digest(eng, rins, False), _digest(eng, rins, True)
+    assert fast["fast_reviews"] == len(rins) and slow["fast_reviews"] == 0
+    assert fast["digest"] == slow["digest"] != 0 and fast["n_rows"] == slow["n_rows"] and fast["heap_bytes"] == slow["heap_bytes"]
+    assert _digest(eng, rins, False, threads=3)["digest"] == fast["digest"] == _digest(eng, rins, False, threads=1)["digest"]
+
+
+def test_fast_ingest_adversarial_documents():
+    """escapes, surrogate pairs, numbers at the int64 / float boundaries, empty containers, deep nesting, arrays of arrays,
+    > 255 elements, DELETE, namespaceObject (incl. null), wrong-typed metadata, missing kind, whitespace, nsCache fallback"""
+    eng = D.Engine(hostemu=True)
+    eng.put_data(["cluster", "v1", "Namespace", "cached"], {"apiVersion": "v1", "kind": "Namespace", "metadata": {"name": "cached", "labels": {"env": "x"}}})
+    ns = {"apiVersion": "v1", "kind": "Namespace", "metadata": {"name": "prod", "labels": {"env": "prod", "n": 5}}}
+    docs = [
+        '{"apiVersion":"v1","kind":"Pod","metadata":{"name":"a\\u00e9\\n\\"q\\"","namespace":"cached","labels":{"k":"v\\/x","long-key-with-many-bytes":"\\ud83d\\ude00 long value over twelve"}}}',
+        '{ "apiVersion" : "apps/v1" ,\n "kind":"Deployment", "metadata": {"name":"d","generateName":"gen-","labels":{"a":1}} , "spec":{"replicas":3,"x":[[1,2],[3,[4,5]],[]],"e":{},"f":[]}}',
+        '{"apiVersion":"v1","kind":"Pod","metadata":{"name":"n","labels":"notamap"},"nums":[0,-0,1.0,1.5,1e3,1E-2,-7,9223372036854775807,9223372036854775808,-9223372036854775808,-9223372036854775809,123456789012345678901234567890,0.1,2e400,true,false,null]}',
+        '{"apiVersion":"a/b/c","kind":"","metadata":[1,2]}',
+        '{"apiVersion":"/","metadata":{"name":5,"namespace":null}}',
+        json.dumps({"apiVersion": "v1", "kind": "Pod", "metadata": {"name": "many"}, "spec": {"containers": [{"name": "c%d" % i, "ports": [{"p": i}]} for i in range(300)]}}),
+        json.dumps({"apiVersion": "v1", "kind": "Namespace", "metadata": {"name": "self", "labels": {"a": "b"}}}),
+        json.dumps({"apiVersion": "v1", "kind": "Pod", "metadata": {"name": "deep"}, "d": {"a": {"b": {"c": {"d": {"e": [[[["x"]]]]}}}}}}),
+        '{"apiVersion":"v1","kind":"Pod","metadata":{"name":"k\\u0000z","namespace":"ns\\u0001"},"s":"' + "y" * 5000 + '"}',
+    ]
+    rins = []
+    for i, d in enumerate(docs):
+        rins.append(_raw(d, ns if i % 2 == 0 else None, None, "", ["Original", "Generated", "", "All", "bogus"][i % 5]))
+        rins.append(_raw(d, None, {"metadata": {"name": "nsobj", "labels": {"z": "1"}}} if i % 3 else None, "DELETE" if i % 2 else "UPDATE"))
+    rins.append(_raw(docs[0], None, None))
+    rins[-1].ns_object = b"null"
+    fast, slow = _digest(eng, rins, False), _digest(eng, rins, True)
+    assert fast["digest"] == slow["digest"] != 0 and fast["n_rows"] == slow["n_rows"]
+    assert fast["fast_reviews"] == len(rins)
+    # documents the fast path must DECLINE (and the general path then handles identically): duplicate keys, malformed
+    # JSON, non-object documents, nesting beyond its depth -- statuses and tables agree
+    odd = ['{"apiVersion":"v1","kind":"Pod","kind":"Service","metadata":{"name":"dup","name":"dup2"}}', '{"apiVersion":"v1",', '[1,2,3]', '"str"',
+           '{"a":' * 120 + '1' + '}' * 120, '{"apiVersion":"v1","kind":"Pod"} trailing', '{"apiVersion":"v1","kind":"P\\x"}', '']
+    rins2 = [_raw(d) for d in odd] + [_raw(docs[1])]
+    os.environ["GK_TABLE_DIGEST"] = "1"
+    try:
+        tf = eng.create_table(rins2, keep_docs=False)
+        os.environ["GK_SLOW_INGEST"] = "1"
+        ts = eng.create_table(rins2, keep_docs=False)
+    finally:
+        os.environ.pop("GK_TABLE_DIGEST", None); os.environ.pop("GK_SLOW_INGEST", None)
+    assert list(tf.statuses) == list(ts.statuses) and tf.statuses[0] == L.GK_OK and tf.statuses[1] == L.GK_ERR_REVIEW
+    sf, ss = tf.stats(), ts.stats()
+    assert sf["digest"] == ss["digest"] and sf["fast_reviews"] == 1
