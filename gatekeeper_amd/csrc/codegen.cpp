@@ -51,7 +51,7 @@ std::vector<uint32_t> jit_path_classes(const HostPlan& plan, std::vector<std::ve
   return out;
 }
 
-std::string generate_plan_source(const HostPlan& plan) {
+std::string generate_plan_source(const HostPlan& plan, uint32_t parts) {
   std::ostringstream o;
   std::vector<std::vector<Pred>> classes;
   jit_path_classes(plan, &classes);
@@ -328,9 +328,9 @@ std::string generate_plan_source(const HostPlan& plan) {
   gen(0, code.size(), false, "  ");
   o << "  return res;\n}\n\n";
   // ---- the same formulas cut into self-contained blocks and spread over the tile's waves: blocks of one STAGE are
-  // independent (they only read bits written by earlier stages); part = stage * GK_PARTS + wave-within-half
+  // independent (they only read bits written by earlier stages); part = stage * parts + wave-within-half
   {
-    constexpr uint32_t NW = GK_PARTS;   // waves that share the formulas of one 64-review half
+    const uint32_t NW = parts;   // waves that share the formulas of one 64-review half
     struct Blk { size_t pc0, pc1; uint32_t stage; uint64_t cost; std::vector<uint64_t> writes, reads; };
     std::vector<Blk> blks;
     size_t prev = 0;
@@ -361,7 +361,7 @@ std::string generate_plan_source(const HostPlan& plan) {
       std::vector<size_t> ids;
       for (size_t bi = 0; bi < blks.size(); bi++) if (blks[bi].stage == st) ids.push_back(bi);
       std::stable_sort(ids.begin(), ids.end(), [&](size_t x, size_t y) { return blks[x].cost > blks[y].cost; });
-      uint64_t load[NW] = {0};
+      std::vector<uint64_t> load(NW, 0);
       for (size_t bi : ids) {
         uint32_t w = 0;
         for (uint32_t k = 1; k < NW; k++) if (load[k] < load[w]) w = k;
@@ -369,7 +369,7 @@ std::string generate_plan_source(const HostPlan& plan) {
         parts[(size_t)st * NW + w].push_back(bi);
       }
     }
-    o << "#define GK_HAS_STAGES 1\nconstexpr uint32_t GK_N_STAGES = " << n_stages << "u;\n"
+    o << "#define GK_HAS_STAGES 1\nconstexpr uint32_t GK_N_STAGES = " << n_stages << "u;\nconstexpr uint32_t GK_GEN_PARTS = " << NW << "u;\n"
       << "template <class Acc>\nGK_HD void jit_formula_part(uint32_t part, Acc& acc, uint32_t flags, const uint8_t* heap, const uint32_t* bounds, Results& res) {\n"
       << "  (void)heap; (void)flags; (void)bounds;\n  uint32_t";
     for (int i = 0; i < 64; i++) o << (i ? ", " : " ") << "b" << i << " = 0u";

@@ -33,6 +33,7 @@ struct EvalOut {
   float kernel_ms = 0;            // device time of the evaluation kernels (HIP events on the launch stream)
   float fast_kernel_ms = 0;       // average duration of the dominant (LDS) kernel per launch since the last finish
   uint32_t n_launches = 0;        // launches averaged in fast_kernel_ms
+  uint32_t lds_bytes = 0;         // accumulator LDS per workgroup of the dominant kernel's most recent launch
   const void *d_viol = nullptr, *d_err = nullptr, *d_counts = nullptr;   // device-resident results (valid until the table's next launch)
 };
 
@@ -51,7 +52,7 @@ void dev_table_free(DevTable* t);
 // first evaluate through views); freeing a view leaves the table's arrays alone.  Free views before the table.
 DevTable* dev_table_view(DevTable* base);
 uint64_t dev_table_bytes(const DevTable* t);
-DevPlan* dev_plan_upload(const HostPlan& fast, const HostPlan& big);
+DevPlan* dev_plan_upload(int device, const HostPlan& fast, const HostPlan& big);
 void dev_plan_free(DevPlan* p);
 void dev_eval(const DevPlan* p, const DevTable* t, const EvalOptions& opt, EvalOut* out);   // launch + finish; throws std::runtime_error
 // first-k violating reviews per bitmap row in `order` (reviews sorted by object key; grp = dense key rank, ties equal);

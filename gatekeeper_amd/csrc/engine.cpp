@@ -178,6 +178,7 @@ struct gk_table {
   uint32_t last_nc = 0;
   std::vector<uint32_t> last_ids;
   uint32_t n_reviews = 0;
+  uint32_t rpt = GK_RPT_MIN;                // reviews per row group of this table
   gk_table_stats stats{};
 };
 
@@ -240,9 +241,9 @@ DevPlan* plan_for_table(gk_engine* e, gk_table* t, const HostPlan** host) {
       if (v->fast.scopes.size() != e->fast.scopes.size()) throw std::runtime_error("scope layout changed");
       if (const char* dump = getenv("GK_PLAN_SOURCE_DUMP")) {
         FILE* f = fopen((std::string(dump) + ".variant").c_str(), "w");
-        if (f) { std::string src = generate_plan_source(v->fast); fwrite(src.data(), 1, src.size(), f); fclose(f); }
+        if (f) { std::string src = generate_plan_source(v->fast, getenv("GK_PLAN_SOURCE_PARTS") ? (uint32_t)atoi(getenv("GK_PLAN_SOURCE_PARTS")) : (uint32_t)GK_PARTS_MIN_RPT); fwrite(src.data(), 1, src.size(), f); fclose(f); }
       }
-      v->dev = dev_plan_upload(v->fast, e->big);
+      v->dev = dev_plan_upload(e->opts.device, v->fast, e->big);
     } catch (const std::exception&) { v->dev = nullptr; }   // e.g. LDS limit: the default plan serves the table
     it = e->variants.emplace(caps, std::move(v)).first;
   }
@@ -309,14 +310,14 @@ void ensure_plan(gk_engine* e) {
   }
   for (auto& g : e->extra) {
     if (g->dev) { dev_plan_free(g->dev); g->dev = nullptr; }
-    g->dev = dev_plan_upload(g->fast, g->big);
+    g->dev = dev_plan_upload(e->opts.device, g->fast, g->big);
   }
   if (const char* dump = getenv("GK_PLAN_SOURCE_DUMP")) {   // debugging aid: the plan-specialised source text
     FILE* f = fopen(dump, "w");
-    if (f) { std::string src = generate_plan_source(e->fast); fwrite(src.data(), 1, src.size(), f); fclose(f); }
+    if (f) { std::string src = generate_plan_source(e->fast, getenv("GK_PLAN_SOURCE_PARTS") ? (uint32_t)atoi(getenv("GK_PLAN_SOURCE_PARTS")) : (uint32_t)GK_PARTS_MIN_RPT); fwrite(src.data(), 1, src.size(), f); fclose(f); }
   }
   if (e->dev_plan) { dev_plan_free(e->dev_plan); e->dev_plan = nullptr; }
-  e->dev_plan = dev_plan_upload(e->fast, e->big);
+  e->dev_plan = dev_plan_upload(e->opts.device, e->fast, e->big);
   e->plan_gen++;
   e->plan_dirty = false;
 }
@@ -469,8 +470,13 @@ int gk_table_create(gk_engine* e, const gk_review_in* reviews, size_t n, uint32_
     // thread-safe).  Fast path: JSON text -> rows in one pass (Flattener::add_json); reviews it declines -- and every
     // review when the parsed documents must be kept for rendering -- go through parse_json + HandleReview normalisation +
     // Flattener::add, which produces the same rows.  The parts are then copied, in parallel, into the table's arrays.
-    const size_t n_tiles = (n + GK_RPT - 1) / GK_RPT;
-    size_t n_threads = std::max<size_t>(1, std::min<size_t>(std::thread::hardware_concurrency(), n_tiles / 8));
+    // reviews per row group: small batches (admission) keep 64-review groups; resident sets get large groups, whose
+    // segments fill the lanes of the waves that stream them (plan.hpp / kernel_body.inc).  GK_RPT overrides (64|256|512).
+    uint32_t rpt = n >= 8192 ? 512 : GK_RPT_MIN;
+    if (const char* rp = getenv("GK_RPT")) { int v = atoi(rp); if (v == 64 || v == 256 || v == 512) rpt = (uint32_t)v; }
+    t->rpt = rpt;
+    const size_t n_tiles = (n + rpt - 1) / rpt;
+    size_t n_threads = std::max<size_t>(1, std::min<size_t>(std::thread::hardware_concurrency(), (n + 511) / 512));
     if (const char* ht = getenv("GK_HOST_THREADS")) n_threads = std::max(1, atoi(ht));
     n_threads = std::min(n_threads, std::max<size_t>(n_tiles, 1));
     const size_t tiles_per = (n_tiles + n_threads - 1) / std::max<size_t>(n_threads, 1);
@@ -481,7 +487,8 @@ int gk_table_create(gk_engine* e, const gk_review_in* reviews, size_t n, uint32_
     auto work = [&](size_t w) {
       try {
         Flattener fl(&e->dict);
-        const size_t lo = std::min(n, w * tiles_per * GK_RPT), hi = std::min(n, (w + 1) * tiles_per * GK_RPT);
+        parts[w].rpt = rpt;
+        const size_t lo = std::min(n, w * tiles_per * rpt), hi = std::min(n, (w + 1) * tiles_per * rpt);
         for (size_t i = lo; i < hi; i++) {
           const gk_review_in& r = reviews[i];
           if (!slow_only) {
@@ -571,6 +578,7 @@ int gk_table_create(gk_engine* e, const gk_review_in* reviews, size_t n, uint32_
     for (auto& pe_ : part_err) if (!pe_.empty()) { for (DevPart* dp : dev_parts) dev_part_free(dp); return fail(GK_ERR_INTERNAL, pe_); }
     // ---- what is global: row / heap bases by prefix sum -> segment starts, the slot index, review flags
     HostTable& H = t->host;
+    H.rpt = rpt;
     {
       size_t rb = 0, hb = 0;
       for (size_t w = 0; w < n_threads; w++) {
@@ -677,7 +685,7 @@ int gk_table_eval(gk_engine* e, gk_table* t, uint32_t flags, gk_eval_out** out) 
       }
       if (flags & GK_EVAL_COLLECT) dev_eval_finish(dp, t->dev, opt, &h->out);   // no new launch
       else dev_eval(dp, t->dev, opt, &h->out);
-      h->lds_bytes = hp->dims.acc_words * GK_RPT * 4;
+      h->lds_bytes = h->out.lds_bytes;
       // further plan groups: same table, their rows are appended below the primary group's
       for (size_t gi = 0; gi < e->extra.size(); gi++) {
         EvalOut og;
@@ -735,7 +743,7 @@ int gk_table_eval(gk_engine* e, gk_table* t, uint32_t flags, gk_eval_out** out) 
     for (auto& g : e->extra) account(g->fast);
     p.n_rows_read = rows_read;
     plan_bytes += bound * sizeof(Bind);
-    p.algo_bytes = rows_read * sizeof(Row) + hdrs_read * sizeof(StrHdr) + bound * 8 * ((p.n_reviews + GK_RPT - 1) / GK_RPT) +
+    p.algo_bytes = rows_read * sizeof(Row) + hdrs_read * sizeof(StrHdr) + bound * 8 * ((p.n_reviews + t->rpt - 1) / t->rpt) +
                    t->dir_bytes * (1 + e->extra.size()) + plan_bytes + (uint64_t)p.n_constraints * p.n_tiles * 16 + (uint64_t)p.list_total * 8;
     *out = &h.release()->pub;
     return GK_OK;
@@ -922,7 +930,7 @@ int gk_dump(gk_engine* e, char** text_out) {
     const HostPlan& p = e->fast;
     os << "constraints=" << p.dims.n_constraints << " viol_formulas=" << p.n_viol << " match_formulas=" << p.n_match
        << " preds=" << p.dims.n_preds << " scopes=" << p.dims.n_scopes << " code_words=" << p.dims.n_code
-       << " gwords=" << p.dims.n_gwords << " acc_words=" << p.dims.acc_words << " lds_bytes_per_tile=" << p.dims.acc_words * 256
+       << " gwords=" << p.dims.n_gwords << " acc_words=" << p.dims.acc_words << " lds_bytes_per_64_reviews=" << p.dims.acc_words * 256
        << " paths=" << p.dims.n_paths << "\n";
     for (size_t i = 0; i < p.preds.size(); i++)
       os << "pred " << i << " op=" << (int)p.preds[i].op << " dst=" << (int)p.preds[i].dst << " scope=" << (int)p.preds[i].scope

@@ -201,7 +201,7 @@ Flattener::Flattener(PathDict* dict) : dict_(dict) {
 }
 
 void Flattener::emit(uint32_t path, uint32_t meta, uint32_t lo, uint32_t hi) {
-  stage_.push_back({path, Row{t_->n_reviews % GK_RPT, meta, lo, hi}, StrHdr{{0, 0, 0, 0}}});
+  stage_.push_back({path, Row{t_->n_reviews % t_->rpt, meta, lo, hi}, StrHdr{{0, 0, 0, 0}}});
 }
 
 uint32_t Flattener::put_string(const std::string& s, uint32_t* hash) {
@@ -377,7 +377,7 @@ void Flattener::finish_review(const Value& ns, int source, HostTable* out) {
     out->path_max[ep] = std::max(out->path_max[ep], ctr_val_[ep]);
   }
   out->n_reviews++;
-  if (out->n_reviews % GK_RPT == 0) flush_tile(out);
+  if (out->n_reviews % out->rpt == 0) flush_tile(out);
 }
 
 // Close the current tile: stable sort of its rows by path (keeps review order, then document order, inside a
@@ -414,7 +414,7 @@ void Flattener::flush_tile(HostTable* out) {
 }
 
 void Flattener::flush(HostTable* out) {
-  if (!stage_.empty() || out->n_reviews % GK_RPT != 0) flush_tile(out);
+  if (!stage_.empty() || out->n_reviews % out->rpt != 0) flush_tile(out);
   out->n_rows_total = out->rows.size();
   out->heap_total = out->heap.size();
 }

@@ -136,8 +136,9 @@ struct HostTable {
   std::vector<uint32_t> path_rows;  // rows per path over the whole table (algorithmic-byte accounting per plan)
   std::vector<uint32_t> path_max;   // per array-element path: largest element count of one review (plan specialisation)
   uint32_t n_reviews = 0;
+  uint32_t rpt = GK_RPT_MIN;        // reviews per row group
   size_t n_rows_total = 0, heap_total = 0;   // sizes of rows / heap (kept when the arrays themselves have gone to the device)
-  uint32_t n_tiles() const { return (n_reviews + GK_RPT - 1) / GK_RPT; }   // row groups
+  uint32_t n_tiles() const { return (n_reviews + rpt - 1) / rpt; }   // row groups
   uint32_t n_slots() const { return (uint32_t)slot_path.size(); }
   // build-time only: per-tile segment lists, turned into tile_idx by Flattener::finish
   struct SegRec { uint32_t path, start; };

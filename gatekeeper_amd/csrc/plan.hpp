@@ -12,7 +12,7 @@ namespace gk {
 
 // ------------------------------------------------------------------------------------------------ rows
 // One row per JSON node (scalars AND containers) of the review documents.  The table is stored as ROW GROUPS: reviews
-// are grouped in tiles of GK_RPT consecutive reviews, and within a tile the rows are sorted by key path (stable:
+// are grouped in tiles of `rpt` consecutive reviews (64 .. 512, per table), and within a tile the rows are sorted by key path (stable:
 // review order, then document order).  The rows of one (tile, path) pair form a SEGMENT.  A plan touches only the
 // segments of the paths it has predicates on -- typically a fifth of a Pod's rows -- and every row of a segment takes
 // the same predicates, so a wave evaluates them without divergence.
@@ -27,7 +27,7 @@ namespace gk {
 //   rflags[n_reviews]            RF_*: match-layer facts computed once by the flattener
 //   heap                         string bytes, 16-byte aligned zero-padded entries [u32 len][bytes]
 struct Row {
-  uint32_t rev;    // review index within its tile (0 .. GK_RPT-1)
+  uint32_t rev;    // review index within its row group (0 .. rpt-1)
   uint32_t meta;   // see ROW_* below
   uint32_t lo;     // value payload
   uint32_t hi;
@@ -161,12 +161,13 @@ struct ConstraintSlot {
 };
 
 constexpr int GK_TILE = 64;            // reviews per bitmap word = lanes of a wave (one lane per review in phase 2)
-constexpr int GK_RPT = 64;             // reviews per row group ("tile"): one workgroup of the dominant kernel; multiple of GK_TILE.
-                                       // 128 was measured (r01 v30): 33.1 vs 34.0 us on configs[1], but it doubles the LDS per tile
-                                       // (2 resident tiles per CU for the default plan), so 64 stays
-constexpr int GK_HALVES = GK_RPT / GK_TILE;   // 64-review halves of a row group
-constexpr int GK_BLOCK = 256;          // threads per tile in the dominant kernel: 4 waves stream the tile's rows
-constexpr int GK_PARTS = GK_BLOCK / GK_TILE / GK_HALVES;   // waves per 64-review half: phase 2 splits the formulas this many ways
+// Reviews per ROW GROUP ("tile") are a property of each table, fixed when it is flattened (HostTable::rpt): 64 for small
+// batches (admission), 256 / 512 for resident sets -- one workgroup of the dominant kernel per group, see kernel_body.inc.
+constexpr int GK_RPT_MIN = 64;
+constexpr int GK_RPT_MAX = 512;
+constexpr int GK_PARTS_MIN_RPT = 4;    // formula shares per 64-review half in the 64-review geometry (256 threads)
+inline constexpr int gk_block_of(int rpt) { return rpt <= 128 ? 256 : rpt * 2; }          // threads per row group
+inline constexpr int gk_parts_of(int rpt) { return gk_block_of(rpt) / GK_TILE / (rpt / GK_TILE); }   // formula shares per half
 constexpr int GK_MAX_RES = 64;         // unique formulas per result class per pass
 constexpr int GK_MAX_SCOPES = 32;
 constexpr int GK_WAVE_CHUNKS = 64;      // 64-row chunks one wave queues per tile (LDS); beyond: the tile's reviews take the big path

@@ -63,7 +63,7 @@ DevTable* dev_table_assemble(int, std::vector<DevPart*>& parts, const HostTable&
 void dev_table_free(DevTable* t) { delete t; }
 DevTable* dev_table_view(DevTable* base) { DevTable* v = new DevTable(*base); v->pending = 0; v->last_viol.clear(); return v; }
 uint64_t dev_table_bytes(const DevTable* t) { return t->t.rows.size() * 32 + t->t.tile_idx.size() * 4 + t->t.heap.size(); }
-DevPlan* dev_plan_upload(const HostPlan& fast, const HostPlan& big) {
+DevPlan* dev_plan_upload(int, const HostPlan& fast, const HostPlan& big) {
   DevPlan* p = new DevPlan();
   p->fast = fast; p->big = big;
   if (getenv("GK_HOSTEMU_JIT")) {
@@ -79,7 +79,7 @@ DevPlan* dev_plan_upload(const HostPlan& fast, const HostPlan& big) {
            "  VecAcc acc{w}; std::vector<uint32_t> w2 = *w; VecAcc acc2{&w2};\n"
            "  gk::Results mono = gk::jit_formulas(*pv, acc2, flags, rows, heap, bounds);\n"
            "  gk::Results r = {0, 0, 0};\n"
-           "  for (uint32_t st = 0; st < gk::GK_N_STAGES; st++) for (uint32_t wv = 0; wv < gk::GK_PARTS; wv++) gk::jit_formula_part(st * gk::GK_PARTS + (gk::GK_PARTS - 1 - wv), acc, flags, heap, bounds, r);\n"
+           "  for (uint32_t st = 0; st < gk::GK_N_STAGES; st++) for (uint32_t wv = 0; wv < gk::GK_GEN_PARTS; wv++) gk::jit_formula_part(st * gk::GK_GEN_PARTS + (gk::GK_GEN_PARTS - 1 - wv), acc, flags, heap, bounds, r);\n"
            "  if (r.viol != mono.viol || r.match != mono.match || r.err != mono.err) { r.viol = ~0ull; r.match = ~0ull; r.err = ~0ull; }   // staged and monolithic code must agree\n"
            "  *out = r; }\n";
     }
@@ -105,7 +105,7 @@ static bool eval_review(const HostPlan& hp, const HostTable& t, uint32_t r, Resu
   PlanView pv = view_of(hp);
   std::vector<uint32_t> words(hp.dims.acc_words, 0);
   VecAcc acc{&words};
-  const uint32_t tile = r / GK_RPT, rl = r % GK_RPT;
+  const uint32_t tile = r / t.rpt, rl = r % t.rpt;
   const uint32_t S = t.n_slots();
   const uint32_t* ix = &t.tile_idx[(size_t)tile * (S + 1)];
   for (uint32_t s = 0; s < S; s++) {
@@ -152,6 +152,7 @@ void dev_eval_launch(const DevPlan*, const DevTable* dt, const EvalOptions&) { c
 void dev_eval(const DevPlan* p, const DevTable* dt, const EvalOptions& opt, EvalOut* o) { dev_eval_launch(p, dt, opt); dev_eval_finish(p, dt, opt, o); }
 void dev_eval_finish(const DevPlan* p, const DevTable* dt, const EvalOptions& opt, EvalOut* o) {
   o->n_launches = (uint32_t)dt->pending; const_cast<DevTable*>(dt)->pending = 0;
+  o->lds_bytes = p->fast.dims.acc_words * dt->t.rpt * 4;
   const HostTable& t = dt->t;
   uint32_t n = t.n_reviews, nc = (uint32_t)p->fast.slots.size();
   uint32_t nt = (n + GK_TILE - 1) / GK_TILE;

@@ -711,3 +711,42 @@ def test_bitmap_list_counts_consistency(backend, fixtures):
     for t in (table, t1, t2, tr):
         t.free()
     assert rows
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("rpt,rpp", [(256, None), (512, None), (512, 128), (256, 64)])
+def test_row_group_geometries(backend, rpt, rpp, fixtures):
+    """A table's row-group size (64 / 256 / 512 reviews, fixed when it is flattened) selects the dominant kernel's geometry
+    (256 / 512 / 1024 threads per group; kernel_body.inc), and a group whose accumulators do not fit in LDS is processed in
+    several passes (forced here with GK_FORCE_RPP): every geometry gives the bits of the 64-review layout, which
+    test_synthetic_parity pins against the oracle -- incl. a ragged last group and reviews on the large-capacity variant."""
+    c, oc = load_both(backend, synth.psp_templates(fixtures), synth.audit_constraints())
+    nss = synth.gen_namespaces()
+    objs = synth.gen_objects(1100, seed=9, mixed=True)
+    objs[700]["spec"] = {"containers": [{"name": "c%d" % i, "image": "x", "securityContext": {"privileged": i % 7 == 0},
+                                         "ports": [{"containerPort": 80, "hostPort": 8000 + i}]} for i in range(30)]}   # overflows the default capacities
+    rins = [D.to_review_in(D.AugmentedUnstructured(D.Unstructured(o), synth.namespace_for(o, nss), "Original")) for o in objs]
+    base = c.driver.engine.create_table(rins, keep_docs=False)
+    ev0 = base.eval(want_match=True, want_list=True)
+    os.environ["GK_RPT"] = str(rpt)
+    if rpp:
+        os.environ["GK_FORCE_RPP"] = str(rpp)
+    try:
+        for resident in (False, True):
+            t = c.driver.engine.create_table(rins, keep_docs=False, resident=resident)
+            ev = t.eval(want_match=True, want_list=True)
+            assert (ev.viol == ev0.viol).all() and (ev.err == ev0.err).all() and (ev.match == ev0.match).all()
+            assert (ev.counts == ev0.counts).all() and (ev.too_big == ev0.too_big).all()
+            assert sorted(map(tuple, ev.list.tolist())) == sorted(map(tuple, ev0.list.tolist()))
+            assert (ev.n_overflow <= ev0.n_overflow) if resident else (ev.n_overflow == ev0.n_overflow >= 1)
+            t.free()
+    finally:
+        os.environ.pop("GK_RPT", None)
+        os.environ.pop("GK_FORCE_RPP", None)
+    base.free()
+    # and the oracle on a sample through the large geometry
+    os.environ["GK_RPT"] = str(rpt)
+    try:
+        assert_parity(c, oc, [D.AugmentedUnstructured(D.Unstructured(o), synth.namespace_for(o, nss), "Original") for o in objs[650:760]])
+    finally:
+        os.environ.pop("GK_RPT", None)

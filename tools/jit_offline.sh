@@ -1,7 +1,7 @@
 #!/bin/bash
 # Offline view of the plan-specialised kernel: assembles the same source text kernels.hip hands to hiprtc (generated
 # part from GK_PLAN_SOURCE_DUMP) and compiles it with hipcc for gfx950, printing register / LDS / occupancy figures.
-# usage: tools/jit_offline.sh /tmp/plan_src.hip [outdir]
+# usage: [RPT=512 RPP=512 WAVES=4] tools/jit_offline.sh /tmp/plan_src.hip [outdir]   (dump the source with GK_PLAN_SOURCE_DUMP=... GK_PLAN_SOURCE_PARTS=2 for RPT >= 128)
 set -e
 gen=${1:-/tmp/plan_src.hip}; out=${2:-/tmp/jit_offline}; mkdir -p $out
 here=$(cd $(dirname $0)/.. && pwd)
@@ -12,7 +12,8 @@ def text(name):
     return "".join(l for l in open(src + "/" + name) if not l.startswith("#include") and not l.startswith("#pragma once"))
 import os
 waves = os.environ.get("WAVES")
-s = ("#include <hip/hip_runtime.h>\n" + ("#define GK_TILES_BOUNDS __launch_bounds__(GK_BLOCK, %s)\n" % waves if waves else "") + text("plan.hpp") + text("vm_core.hpp") + open(gen).read() +
+rpt = int(os.environ.get("RPT", "64")); rpp = int(os.environ.get("RPP", str(rpt))); block = 256 if rpt <= 128 else rpt * 2
+s = ("#include <hip/hip_runtime.h>\n" + ("#define GK_TILES_BOUNDS __launch_bounds__(%d, %s)\n" % (block, waves) if waves else "") + "#define GK_RPT_K %d\n#define GK_RPP_K %d\n#define GK_SKIP_BIG\n" % (rpt, rpp) + text("plan.hpp") + text("vm_core.hpp") + open(gen).read() +
      "namespace gk {\n#define GK_KERNEL_TILES gk_jit_tiles\n#define GK_KERNEL_BIG gk_jit_big\n#define GK_KERNEL_LINKAGE extern \"C\"\n"
      "#define GK_ROW_FN(r, i, ent, h, pv, heap, acc) jit_row(r, ent, h, heap, acc)\n#define GK_BIND_ALWAYS_STR 0\n"
      "#define GK_FORMULA_FN(pv, acc, flags, rows, heap, bounds) jit_formulas(pv, acc, flags, rows, heap, bounds)\n" +
