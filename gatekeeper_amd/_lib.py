@@ -29,7 +29,7 @@ EXPORTS = [
     "gk_engine_create", "gk_engine_destroy", "gk_last_error", "gk_version", "gk_template_add", "gk_template_remove",
     "gk_constraint_add", "gk_constraint_remove", "gk_data_put", "gk_data_remove", "gk_table_create", "gk_table_free",
     "gk_table_eval", "gk_eval_free", "gk_render", "gk_render_error", "gk_free", "gk_dump", "gk_table_topk", "gk_topk_free",
-    "gk_table_totals", "gk_totals_free", "gk_table_get_stats",
+    "gk_table_totals", "gk_totals_free", "gk_table_get_stats", "gk_batcher_start", "gk_batcher_stop", "gk_query",
     # include/gksynth.h (bench / test plumbing)
     "gk_synth_batch_create", "gk_synth_batch_reviews", "gk_synth_batch_size", "gk_synth_batch_json_bytes", "gk_synth_batch_free",
 ]
@@ -72,6 +72,15 @@ class gk_table_stats(C.Structure):
     _fields_ = [("n_reviews", C.c_uint64), ("n_rows", C.c_uint64), ("json_bytes", C.c_uint64), ("heap_bytes", C.c_uint64),
                 ("device_bytes", C.c_uint64), ("flatten_s", C.c_double), ("upload_s", C.c_double), ("host_threads", C.c_uint32),
                 ("reserved", C.c_uint32), ("fast_reviews", C.c_uint64), ("digest", C.c_uint64)]
+
+
+class gk_batch_opts(C.Structure):
+    _fields_ = [("max_batch", C.c_uint32), ("window_us", C.c_uint32)]
+
+
+class gk_query_stats(C.Structure):
+    _fields_ = [("batch_size", C.c_uint32), ("reserved", C.c_uint32), ("queue_us", C.c_double), ("device_us", C.c_double),
+                ("total_us", C.c_double)]
 
 
 class EngineLoadError(RuntimeError):
@@ -131,6 +140,10 @@ def load(hostemu: bool | None = None):
     lib.gk_table_topk.argtypes = [vp, vp, u32, C.POINTER(C.POINTER(gk_topk_out))]
     lib.gk_topk_free.argtypes = [C.POINTER(gk_topk_out)]
     lib.gk_topk_free.restype = None
+    lib.gk_batcher_start.argtypes = [vp, C.POINTER(gk_batch_opts)]
+    lib.gk_batcher_stop.argtypes = [vp]
+    lib.gk_batcher_stop.restype = None
+    lib.gk_query.argtypes = [vp, C.POINTER(gk_review_in), C.POINTER(vp), C.POINTER(gk_query_stats)]
     lib.gk_table_get_stats.argtypes = [vp, C.POINTER(gk_table_stats)]
     lib.gk_table_totals.argtypes = [vp, vp, C.POINTER(C.POINTER(gk_totals_out))]
     lib.gk_totals_free.argtypes = [C.POINTER(gk_totals_out)]

@@ -8,6 +8,8 @@
 #include <cstring>
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
 #include <functional>
 #include <thread>
 #include <map>
@@ -156,6 +158,26 @@ struct gk_engine {
   struct Variant { HostPlan fast; DevPlan* dev = nullptr; };
   std::map<std::vector<uint16_t>, std::unique_ptr<Variant>> variants;
   std::string last_dump;
+  // ---- admission micro-batcher (gk_query): concurrent single-review calls coalesced into one table + one launch
+  struct Request {
+    const gk_review_in* in = nullptr;
+    std::chrono::steady_clock::time_point arrived;
+    int status = GK_OK;
+    std::string results, error;
+    uint32_t batch_size = 0;
+    double queue_us = 0, device_us = 0;
+    bool done = false;
+    std::condition_variable cv;
+  };
+  struct Batcher {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<Request*> queue;
+    std::thread worker;
+    bool running = false, stop = false;
+    gk_batch_opts opts{64, 200};
+    uint64_t batches = 0, reviews = 0;
+  } batcher;
 };
 
 struct gk_table {
@@ -344,6 +366,7 @@ int gk_engine_create(const gk_opts* opts, gk_engine** out) {
 
 void gk_engine_destroy(gk_engine* e) {
   if (!e) return;
+  gk_batcher_stop(e);
   if (e->dev_plan) dev_plan_free(e->dev_plan);
   for (auto& v : e->variants) dev_plan_free(v.second->dev);
   for (auto& g : e->extra) dev_plan_free(g->dev);
@@ -920,6 +943,155 @@ int gk_render_error(gk_engine* e, gk_table* t, uint32_t constraint_id, uint32_t 
 }
 
 void gk_free(void* p) { free(p); }
+
+// ------------------------------------------------------------------------------------------------ micro-batcher (row f1)
+namespace {
+
+// results of ONE review of an evaluated table as the JSON gk_query returns; renders from `doc` (parsed lazily: most
+// admission reviews violate nothing and never become a Value tree)
+std::string query_results_json(gk_engine* e, gk_table* t, const gk_eval_out& ev, uint32_t r, const gk_review_in& in, bool* too_big) {
+  const uint32_t nt = ev.n_tiles, w = r / GK_TILE;
+  const uint64_t bit = 1ull << (r % GK_TILE);
+  *too_big = (ev.too_big[w] & bit) != 0;
+  std::string out = "[";
+  bool have_doc = false;
+  ReviewDoc doc;
+  auto need_doc = [&]() {
+    if (have_doc) return;
+    Value body = parse_json(in.json, in.json_len);
+    Value mns = parse_opt(in.namespace_json, in.namespace_len);
+    Value nso = parse_opt(in.ns_object_json, in.ns_object_len);
+    if (in.kind == GK_REVIEW_OBJECT) doc = normalize_object(body, mns, nso, in.source, in.operation ? in.operation : "", e->ns_cache);
+    else doc = normalize_admission_request(body, mns, nso, in.source, e->ns_cache);
+    have_doc = true;
+  };
+  std::shared_lock<std::shared_mutex> l(e->mu);
+  for (uint32_t row = 0; row < ev.n_constraints; row++) {
+    const bool is_err = (ev.err[(size_t)row * nt + w] & bit) != 0, is_viol = (ev.viol[(size_t)row * nt + w] & bit) != 0;
+    if (!is_err && !is_viol) continue;
+    const uint32_t cid = ev.constraint_ids[row];
+    const ConstraintRec& c = e->constraints[cid];
+    need_doc();
+    if (is_err) {
+      ValuePairs o{{Value::string("constraint"), Value::integer(cid)}, {Value::string("msg"), Value::string(autoreject_message(c.match, doc))},
+                   {Value::string("autoreject"), Value::boolean(true)}, {Value::string("details"), Value::object({})}};
+      if (out.size() > 1) out += ",";
+      out += to_json(Value::object(o));
+      continue;
+    }
+    auto it = e->templates.find(lower_str(c.kind));
+    if (it == e->templates.end()) continue;
+    for (auto& v : it->second->render(doc.request, c.params, e->inventory)) {
+      ValuePairs o{{Value::string("constraint"), Value::integer(cid)}, {Value::string("msg"), Value::string(v.msg)},
+                   {Value::string("details"), v.details.defined() ? v.details : Value::object({})}};
+      if (out.size() > 1) out += ",";
+      out += to_json(Value::object(o));
+    }
+  }
+  return out + "]";
+}
+
+void batcher_loop(gk_engine* e) {
+  gk_engine::Batcher& B = e->batcher;
+  for (;;) {
+    std::vector<gk_engine::Request*> batch;
+    {
+      std::unique_lock<std::mutex> l(B.mu);
+      B.cv.wait(l, [&] { return B.stop || !B.queue.empty(); });
+      if (B.stop && B.queue.empty()) return;
+      // the first request of a batch waits up to window_us for company (or until max_batch requests are queued)
+      const auto deadline = B.queue.front()->arrived + std::chrono::microseconds(B.opts.window_us);
+      B.cv.wait_until(l, deadline, [&] { return B.stop || B.queue.size() >= B.opts.max_batch; });
+      while (!B.queue.empty() && batch.size() < B.opts.max_batch) { batch.push_back(B.queue.front()); B.queue.pop_front(); }
+    }
+    const auto t_start = std::chrono::steady_clock::now();
+    std::vector<gk_review_in> ins;
+    for (auto* r : batch) ins.push_back(*r->in);
+    std::vector<int32_t> st(batch.size(), GK_OK);
+    gk_table* table = nullptr;
+    gk_eval_out* ev = nullptr;
+    int rc = gk_table_create(e, ins.data(), ins.size(), 0, st.data(), &table);
+    std::string err = rc == GK_OK ? "" : gk_last_error();
+    if (rc == GK_OK) { rc = gk_table_eval(e, table, 0, &ev); if (rc != GK_OK) err = gk_last_error(); }
+    const double dev_us = ev ? ev->kernel_ms * 1e3 : 0;
+    for (size_t i = 0; i < batch.size(); i++) {
+      gk_engine::Request* r = batch[i];
+      r->batch_size = (uint32_t)batch.size();
+      r->queue_us = std::chrono::duration<double, std::micro>(t_start - r->arrived).count();
+      r->device_us = dev_us;
+      if (rc != GK_OK) { r->status = rc; r->error = err; }
+      else if (st[i] != GK_OK) { r->status = GK_ERR_REVIEW; r->error = table->review_errors[i]; }
+      else {
+        try {
+          bool too_big = false;
+          r->results = query_results_json(e, table, *ev, (uint32_t)i, ins[i], &too_big);
+          if (too_big) { r->status = GK_ERR_LIMIT; r->error = "review is beyond the engine's limits (more than 255 elements in an array that constraint predicates iterate)"; }
+        } catch (const std::exception& ex) { r->status = GK_ERR_REGO; r->error = ex.what(); }
+      }
+    }
+    if (ev) gk_eval_free(ev);
+    if (table) gk_table_free(table);
+    {
+      std::lock_guard<std::mutex> l(B.mu);
+      B.batches++; B.reviews += batch.size();
+      for (auto* r : batch) { r->done = true; r->cv.notify_one(); }
+    }
+  }
+}
+
+}  // namespace
+
+int gk_batcher_start(gk_engine* e, const gk_batch_opts* opts) {
+  if (!e) return fail(GK_ERR_INVALID, "NULL argument");
+  gk_engine::Batcher& B = e->batcher;
+  std::lock_guard<std::mutex> l(B.mu);
+  if (opts) { B.opts = *opts; if (!B.opts.max_batch) B.opts.max_batch = 64; }
+  if (B.running) return GK_OK;
+  B.stop = false;
+  B.running = true;
+  B.worker = std::thread(batcher_loop, e);
+  return GK_OK;
+}
+
+void gk_batcher_stop(gk_engine* e) {
+  if (!e) return;
+  gk_engine::Batcher& B = e->batcher;
+  {
+    std::lock_guard<std::mutex> l(B.mu);
+    if (!B.running) return;
+    B.stop = true;
+  }
+  B.cv.notify_all();
+  B.worker.join();
+  std::lock_guard<std::mutex> l(B.mu);
+  B.running = false;
+}
+
+int gk_query(gk_engine* e, const gk_review_in* review, char** results_json, gk_query_stats* stats) {
+  if (!e || !review || !results_json) return fail(GK_ERR_INVALID, "NULL argument");
+  if (!e->batcher.running) { int rc = gk_batcher_start(e, nullptr); if (rc != GK_OK) return rc; }
+  gk_engine::Request req;
+  req.in = review;
+  req.arrived = std::chrono::steady_clock::now();
+  gk_engine::Batcher& B = e->batcher;
+  {
+    std::unique_lock<std::mutex> l(B.mu);
+    B.queue.push_back(&req);
+    B.cv.notify_all();
+    req.cv.wait(l, [&] { return req.done; });
+  }
+  if (stats) {
+    stats->batch_size = req.batch_size;
+    stats->queue_us = req.queue_us;
+    stats->device_us = req.device_us;
+    stats->total_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - req.arrived).count();
+  }
+  if (req.status != GK_OK) return fail(req.status, req.error);
+  char* buf = (char*)malloc(req.results.size() + 1);
+  memcpy(buf, req.results.c_str(), req.results.size() + 1);
+  *results_json = buf;
+  return GK_OK;
+}
 
 int gk_dump(gk_engine* e, char** text_out) {
   if (!e || !text_out) return fail(GK_ERR_INVALID, "NULL argument");

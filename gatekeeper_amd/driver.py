@@ -543,32 +543,43 @@ class Driver:
         return self._ids[key]
 
     def Query(self, target, constraints, review, namespace=None, stats_enabled=False):
-        """One review against the (already matched) constraints -> QueryResponse.  The device evaluates match AND
-        violation for every loaded constraint; rows for constraints not asked about are ignored."""
+        """One review against the (already matched) constraints -> QueryResponse, through the engine's micro-batcher
+        (gk_query): safe to call from many threads at once -- the webhook's concurrency, pkg/webhook/policy.go:142-146 --
+        and concurrent calls share one flattened table and one launch.  The device evaluates match AND violation for
+        every loaded constraint; results of constraints not asked about are dropped here."""
         rin = to_review_in(review, namespace)
         if rin is None:
             raise EngineError(L.GK_ERR_INVALID, "cannot convert review to ARGetter")
-        table = self.engine.create_table([rin])
-        try:
-            if table.statuses[0] != L.GK_OK:
-                raise EngineError(L.GK_ERR_REVIEW, "review rejected by HandleReview")
-            ev = table.eval()
-            if ev.too_big_reviews():
-                raise LimitError()
-            wanted = {self.constraint_id(c): c for c in constraints}
-            results = []
-            for cid, _ in ev.pairs("viol"):
-                if cid in wanted:
-                    for v in table.render(cid, 0):
-                        results.append(Result(v["msg"], wanted[cid], v.get("details", {})))
-            stats = []
-            if self.gather_stats or stats_enabled:
-                stats.append({"scope": "template", "statsFor": "batch", "stats": [
-                    {"name": self.RUN_TIME_NS, "value": int(ev.kernel_ms * 1e6),
-                     "source": {"type": "engine", "value": self.Name()}}], "labels": [{"name": "target", "value": target}]})
-            return QueryResponse(results, stats)
-        finally:
-            table.free()
+        arr = (L.gk_review_in * 1)()
+        a = arr[0]
+        a.kind, a.source, a.json, a.json_len, a.operation = rin.kind, rin.source, rin.json, len(rin.json), rin.operation
+        if rin.namespace is not None:
+            a.namespace_json, a.namespace_len = rin.namespace, len(rin.namespace)
+        if rin.ns_object is not None:
+            a.ns_object_json, a.ns_object_len = rin.ns_object, len(rin.ns_object)
+        out, st = C.c_void_p(), L.gk_query_stats()
+        rc = self.engine.lib.gk_query(self.engine.handle, arr, C.byref(out), C.byref(st))
+        if rc == L.GK_ERR_LIMIT:
+            raise LimitError()
+        if rc == L.GK_ERR_REVIEW:
+            raise EngineError(rc, "review rejected by HandleReview: " + self.engine.lib.gk_last_error().decode())
+        self.engine._check(rc)
+        rows = json.loads(C.string_at(out).decode())
+        self.engine.lib.gk_free(out)
+        wanted = {self.constraint_id(c): c for c in constraints}
+        results = [Result(v["msg"], wanted[v["constraint"]], v.get("details", {})) for v in rows if v["constraint"] in wanted]
+        self.last_query_stats = {"batch_size": st.batch_size, "queue_us": st.queue_us, "device_us": st.device_us, "total_us": st.total_us}
+        stats = []
+        if self.gather_stats or stats_enabled:
+            stats.append({"scope": "template", "statsFor": "batch", "stats": [
+                {"name": self.RUN_TIME_NS, "value": int(st.device_us * 1e3),
+                 "source": {"type": "engine", "value": self.Name()}}], "labels": [{"name": "target", "value": target}]})
+        return QueryResponse(results, stats)
+
+    def StartBatcher(self, max_batch=64, window_us=200):
+        """gk_batcher_start: how many concurrent Query calls share a launch, and how long the first one waits for company"""
+        opts = L.gk_batch_opts(max_batch, window_us)
+        self.engine._check(self.engine.lib.gk_batcher_start(self.engine.handle, C.byref(opts)))
 
     def Dump(self):
         return self.engine.dump()

@@ -173,6 +173,30 @@ typedef struct {
 int gk_table_totals(gk_engine* e, gk_table* t, gk_totals_out** out);
 void gk_totals_free(gk_totals_out* o);
 
+/* ---- admission path: micro-batched Driver.Query (row f1) ----------------------------------------------------------
+ * Driver.Query evaluates ONE review (pkg/drivers/k8scel/driver.go:162-251) and the validating webhook calls it from up
+ * to GOMAXPROCS request goroutines at once (pkg/webhook/policy.go:142-146, 748-757).  gk_query may be called from any
+ * number of threads: the engine's batcher thread coalesces the calls that arrive within `window_us` (or `max_batch` of
+ * them) into ONE flattened table and ONE launch, then answers each caller with its own results:
+ *   [{"constraint": <id from gk_constraint_add>, "msg": "...", "details": {...}[, "autoreject": true]}, ...]
+ * for every loaded constraint that matches the review and is violated (or whose Matcher.Match failed: autoreject).  The
+ * caller keeps the results of the constraints it asked about (Driver.Query's `constraints` argument).
+ * GK_ERR_REVIEW: HandleReview rejected the review; GK_ERR_LIMIT: beyond the engine's limits (fail closed). */
+typedef struct {
+  uint32_t max_batch;    /* reviews per launch (0 = 64) */
+  uint32_t window_us;    /* how long the first call of a batch waits for company */
+} gk_batch_opts;
+typedef struct {
+  uint32_t batch_size;   /* reviews that shared the launch */
+  uint32_t reserved;
+  double queue_us;       /* arrival -> batch start */
+  double device_us;      /* device time of the batch's kernels */
+  double total_us;       /* arrival -> results ready */
+} gk_query_stats;
+int gk_batcher_start(gk_engine* e, const gk_batch_opts* opts);   /* optional: gk_query starts it with the defaults (64, 200 us) */
+void gk_batcher_stop(gk_engine* e);
+int gk_query(gk_engine* e, const gk_review_in* review, char** results_json, gk_query_stats* stats);
+
 /* Debug: the compiled plan as text (Driver.Dump, pkg/drivers/k8scel/driver.go:253). */
 int gk_dump(gk_engine* e, char** text_out);
 

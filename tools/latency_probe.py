@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Admission latency through the micro-batcher (row f1): T threads call Driver.Query concurrently on synthetic Pod reviews
+against the 30 PSP constraints; per-call latency (arrival -> results, gk_query_stats.total_us) p50 / p99, batch sizes and
+sustained reviews/s, for several concurrency levels and batching windows.  Prints one JSON object."""
+import json
+import os
+import sys
+import threading
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gatekeeper_amd import driver as D   # noqa: E402
+from gatekeeper_amd import synth         # noqa: E402
+
+
+def run(drv, cons, reviews, threads, per_thread):
+    lat, sizes = [], []
+    lock = threading.Lock()
+
+    def worker(w):
+        mine, ms = [], []
+        for k in range(per_thread):
+            rv = reviews[(w * per_thread + k) % len(reviews)]
+            t0 = time.perf_counter()
+            drv.Query(D.TARGET_NAME, cons, rv)
+            mine.append((time.perf_counter() - t0) * 1e6)
+            ms.append(drv.last_query_stats["batch_size"])
+        with lock:
+            lat.extend(mine)
+            sizes.extend(ms)
+
+    ts = [threading.Thread(target=worker, args=(w,)) for w in range(threads)]
+    t0 = time.perf_counter()
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    dt = time.perf_counter() - t0
+    lat.sort()
+    return {"threads": threads, "calls": len(lat), "p50_us": lat[len(lat) // 2], "p99_us": lat[int(len(lat) * 0.99)], "max_us": lat[-1],
+            "mean_batch": sum(sizes) / len(sizes), "reviews_per_s": len(lat) / dt}
+
+
+def main():
+    hostemu = len(sys.argv) > 1 and sys.argv[1] == "hostemu"
+    fx = synth.load_fixtures()
+    drv = D.Driver(hostemu=hostemu)
+    client = D.Client(drv)
+    for t in synth.psp_templates(fx):
+        client.AddTemplate(t)
+    for k in synth.psp_constraints():
+        client.AddConstraint(k)
+    cons = list(client.constraints.values())
+    nss = synth.gen_namespaces()
+    objs = synth.gen_objects(2048, seed=77)
+    reviews = [D.AugmentedUnstructured(D.Unstructured(o), synth.namespace_for(o, nss), "Original") for o in objs]
+    drv.Query(D.TARGET_NAME, cons, reviews[0])     # plan + kernel specialisation happen on the first call
+    out = {"what": "Driver.Query through gk_query (30 PSP constraints, synthetic Pod reviews); latency includes the Python/ctypes call, "
+                   "JSON encoding of the review, flatten, H2D, launch, D2H and rendering", "runs": []}
+    for window in (0, 200, 1000):
+        drv.StartBatcher(max_batch=64, window_us=window)
+        for threads in (1, 16, 64):
+            r = run(drv, cons, reviews, threads, 64 if threads > 1 else 256)
+            r["window_us"] = window
+            out["runs"].append(r)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
