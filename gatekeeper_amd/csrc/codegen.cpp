@@ -88,7 +88,10 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts) {
     o << "};\n";
   }
   // ---------------------------------------------------------------------------------------------- phase 1
-  o << "template <class Acc>\nGK_HD __attribute__((noinline)) void jit_row(Row r, uint32_t cls, StrHdr h, const uint8_t* heap, Acc acc) {\n"
+  // inlined into its single call site (the chunk loop): as a separate function every LDS atomic would first look the
+  // dynamic-LDS base up in a table (s_getpc + s_load + full wait; seen in the gfx950 ISA) and the call frame costs scratch
+  const bool inline_row = !(getenv("GK_JIT_INLINE_ROW") && atoi(getenv("GK_JIT_INLINE_ROW")) == 0);   // tuning aid
+  o << "template <class Acc>\nGK_HD __attribute__((" << (inline_row ? "always_inline" : "noinline") << ")) void jit_row(Row r, uint32_t cls, StrHdr h, const uint8_t* heap, Acc acc) {\n"
     << "  const uint8_t* cheap = gk_plan_consts;\n  (void)cheap; (void)h;\n  cls = GK_UNI(cls) & ~GK_ENT_NEEDS_STR;   // one class per call: the dispatch is a scalar branch\n  switch (cls) {\n";
   // One class = the predicates of one key path.  Results are gathered in one mask per destination word (a single LDS
   // atomic per word, not per predicate); integer comparisons share one type test; short string equalities compare
