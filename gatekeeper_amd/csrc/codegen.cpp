@@ -320,7 +320,10 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts) {
       }
       case F_RES: {
         const char* f = b == 0 ? "viol" : b == 1 ? "match" : "err";
-        o << ind << "res." << f << " |= (uint64_t)b" << a << " << " << c << ";\n";
+        // staged parts hand the result of slot c to GK_RES: on the device one ballot turns the 64 lanes' answers into the
+        // slot's bitmap word (kernel_body.inc), elsewhere it accumulates into `res` like the monolithic function
+        if (staged) o << ind << "GK_RES(" << b << ", " << c << ", b" << a << ");\n";
+        else o << ind << "res." << f << " |= (uint64_t)b" << a << " << " << c << ";\n";
         break;
       }
       case F_END: pc = pc1; break;
@@ -373,8 +376,10 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts) {
       }
     }
     o << "#define GK_HAS_STAGES 1\nconstexpr uint32_t GK_N_STAGES = " << n_stages << "u;\nconstexpr uint32_t GK_GEN_PARTS = " << NW << "u;\n"
-      << "template <class Acc>\nGK_HD void jit_formula_part(uint32_t part, Acc& acc, uint32_t flags, const uint8_t* heap, const uint32_t* bounds, Results& res) {\n"
-      << "  (void)heap; (void)flags; (void)bounds;\n  uint32_t";
+      << "#ifndef GK_RES\n#define GK_RES(kind, slot, b) do { if ((kind) == 0) res.viol |= (uint64_t)(b) << (slot); else if ((kind) == 1) res.match |= (uint64_t)(b) << (slot); "
+         "else res.err |= (uint64_t)(b) << (slot); } while (0)\n#define GK_RES_PROLOGUE\n#endif\n"
+      << "template <class Acc>\nGK_HD void jit_formula_part(uint32_t part, Acc& acc, uint32_t flags, const uint8_t* heap, const uint32_t* bounds, Results& res, unsigned long long* masks) {\n"
+      << "  (void)heap; (void)flags; (void)bounds; (void)res; (void)masks;\n  GK_RES_PROLOGUE\n  uint32_t";
     for (int i = 0; i < 64; i++) o << (i ? ", " : " ") << "b" << i << " = 0u";
     o << ";\n";
     for (uint32_t w = 0; w < plan.dims.n_gwords; w++) o << "  uint32_t g" << w << " = acc.load(" << w << "u);\n";

@@ -79,7 +79,7 @@ DevPlan* dev_plan_upload(int, const HostPlan& fast, const HostPlan& big) {
            "  VecAcc acc{w}; std::vector<uint32_t> w2 = *w; VecAcc acc2{&w2};\n"
            "  gk::Results mono = gk::jit_formulas(*pv, acc2, flags, rows, heap, bounds);\n"
            "  gk::Results r = {0, 0, 0};\n"
-           "  for (uint32_t st = 0; st < gk::GK_N_STAGES; st++) for (uint32_t wv = 0; wv < gk::GK_GEN_PARTS; wv++) gk::jit_formula_part(st * gk::GK_GEN_PARTS + (gk::GK_GEN_PARTS - 1 - wv), acc, flags, heap, bounds, r);\n"
+           "  for (uint32_t st = 0; st < gk::GK_N_STAGES; st++) for (uint32_t wv = 0; wv < gk::GK_GEN_PARTS; wv++) gk::jit_formula_part(st * gk::GK_GEN_PARTS + (gk::GK_GEN_PARTS - 1 - wv), acc, flags, heap, bounds, r, nullptr);\n"
            "  if (r.viol != mono.viol || r.match != mono.match || r.err != mono.err) { r.viol = ~0ull; r.match = ~0ull; r.err = ~0ull; }   // staged and monolithic code must agree\n"
            "  *out = r; }\n";
     }
