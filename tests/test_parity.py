@@ -714,7 +714,7 @@ def test_bitmap_list_counts_consistency(backend, fixtures):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
-@pytest.mark.parametrize("rpt,rpp", [(256, None), (512, None), (512, 128), (256, 64)])
+@pytest.mark.parametrize("rpt,rpp", [(128, None), (256, None), (512, None), (512, 128), (256, 64)])
 def test_row_group_geometries(backend, rpt, rpp, fixtures):
     """A table's row-group size (64 / 256 / 512 reviews, fixed when it is flattened) selects the dominant kernel's geometry
     (256 / 512 / 1024 threads per group; kernel_body.inc), and a group whose accumulators do not fit in LDS is processed in
