@@ -495,7 +495,7 @@ int gk_table_create(gk_engine* e, const gk_review_in* reviews, size_t n, uint32_
     // Flattener::add, which produces the same rows.  The parts are then copied, in parallel, into the table's arrays.
     // reviews per row group: small batches (admission) keep 64-review groups; resident sets get large groups, whose
     // segments fill the lanes of the waves that stream them (plan.hpp / kernel_body.inc).  GK_RPT overrides (64|128|256|512).
-    uint32_t rpt = n >= 8192 ? 512 : GK_RPT_MIN;
+    uint32_t rpt = n >= 8192 ? 256 : GK_RPT_MIN;
     if (const char* rp = getenv("GK_RPT")) { int v = atoi(rp); if (v == 64 || v == 128 || v == 256 || v == 512) rpt = (uint32_t)v; }
     t->rpt = rpt;
     const size_t n_tiles = (n + rpt - 1) / rpt;
