@@ -133,11 +133,7 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts) {
     for (size_t i = 0; i < ps.size(); i++) if (ps[i].op == P_CMP && ps[i].ctype == T_INT && !target[i].empty()) icmp.push_back(i);
     if (!icmp.empty()) {
       o << "      if (t == T_INT) {\n        const int64_t a = row_i64(r);\n";
-      for (size_t i : icmp) {
-        const std::string& tg = target[i];
-        const size_t eq = tg.find(" |= ");
-        o << "        " << tg.substr(0, eq) << " |= (a " << kCmpOps[ps[i].cmp] << " " << (long long)(int64_t)ps[i].k << "ll) ? " << tg.substr(eq + 4, tg.size() - eq - 5) << " : 0u;\n";
-      }
+      for (size_t i : icmp) o << "        if (a " << kCmpOps[ps[i].cmp] << " " << (long long)(int64_t)ps[i].k << "ll) " << target[i] << "\n";
       o << "      } else {\n";
       for (size_t i : icmp) o << "        { constexpr Pred P = " << pred_literal(ps[i]) << "; if (eval_pred(r, P, h, heap, cheap)) " << target[i] << " }\n";
       o << "      }\n";
@@ -179,13 +175,7 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts) {
       }
       if (cond.empty()) o << "      { constexpr Pred P = " << pred_literal(p) << "; if (eval_pred(r, P, h, heap, cheap)) " << target[i] << " }\n";
       else if (cond == "true") o << "      " << target[i] << "\n";
-      else {
-        // cheap conditions (register compares) are applied by SELECT, not by a branch: a divergent `if` costs a compare, an
-        // exec-mask save / restore and a branch -- scalar issue slots this kernel is bound by (r02 SQ counters)
-        const std::string& tg = target[i];
-        const size_t eq = tg.find(" |= ");
-        o << "      " << tg.substr(0, eq) << " |= (" << cond << ") ? " << tg.substr(eq + 4, tg.size() - eq - 5) << " : 0u;\n";
-      }
+      else o << "      if (" << cond << ") " << target[i] << "\n";
     }
     for (const std::string& m : gmasks) o << "      if (" << m << ") acc.or_word(" << m.substr(2) << "u, " << m << ");\n";
     for (const Group& g : groups) {
