@@ -24,12 +24,14 @@ GK_SRC_EMPTY, GK_SRC_ORIGINAL, GK_SRC_GENERATED, GK_SRC_ALL, GK_SRC_INVALID = 0,
 GK_TABLE_KEEP_DOCS = 1
 GK_TABLE_RESIDENT = 2
 GK_EVAL_WANT_MATCH, GK_EVAL_NO_DOWNLOAD, GK_EVAL_WANT_LIST, GK_EVAL_ASYNC, GK_EVAL_COLLECT = 1, 2, 4, 8, 16
+GK_SWEEP_RESULT_TOTALS = 1
 
 EXPORTS = [
     "gk_engine_create", "gk_engine_destroy", "gk_last_error", "gk_version", "gk_template_add", "gk_template_remove",
     "gk_constraint_add", "gk_constraint_remove", "gk_data_put", "gk_data_remove", "gk_table_create", "gk_table_free",
     "gk_table_eval", "gk_eval_free", "gk_render", "gk_render_error", "gk_free", "gk_dump", "gk_table_topk", "gk_topk_free",
     "gk_table_totals", "gk_totals_free", "gk_table_get_stats", "gk_batcher_start", "gk_batcher_stop", "gk_query",
+    "gk_resident_sweep", "gk_sweep_free", "gk_resident_review",
     # include/gksynth.h (bench / test plumbing)
     "gk_synth_batch_create", "gk_synth_batch_reviews", "gk_synth_batch_size", "gk_synth_batch_json_bytes", "gk_synth_batch_free",
 ]
@@ -72,6 +74,12 @@ class gk_table_stats(C.Structure):
     _fields_ = [("n_reviews", C.c_uint64), ("n_rows", C.c_uint64), ("json_bytes", C.c_uint64), ("heap_bytes", C.c_uint64),
                 ("device_bytes", C.c_uint64), ("flatten_s", C.c_double), ("upload_s", C.c_double), ("host_threads", C.c_uint32),
                 ("reserved", C.c_uint32), ("fast_reviews", C.c_uint64), ("digest", C.c_uint64)]
+
+
+class gk_sweep_out(C.Structure):
+    _fields_ = [("n_objects", C.c_uint64), ("n_constraints", C.c_uint32), ("n_chunks", C.c_uint32), ("constraint_ids", C.POINTER(C.c_uint32)),
+                ("pairs", C.POINTER(C.c_uint64)), ("results", C.POINTER(C.c_uint64)), ("flattened", C.c_uint64), ("beyond_limits", C.c_uint64),
+                ("sync_s", C.c_double), ("eval_s", C.c_double)]
 
 
 class gk_batch_opts(C.Structure):
@@ -140,6 +148,10 @@ def load(hostemu: bool | None = None):
     lib.gk_table_topk.argtypes = [vp, vp, u32, C.POINTER(C.POINTER(gk_topk_out))]
     lib.gk_topk_free.argtypes = [C.POINTER(gk_topk_out)]
     lib.gk_topk_free.restype = None
+    lib.gk_resident_sweep.argtypes = [vp, u32, C.POINTER(C.POINTER(gk_sweep_out))]
+    lib.gk_sweep_free.argtypes = [C.POINTER(gk_sweep_out)]
+    lib.gk_sweep_free.restype = None
+    lib.gk_resident_review.argtypes = [vp, C.POINTER(cp), sz, C.POINTER(vp)]
     lib.gk_batcher_start.argtypes = [vp, C.POINTER(gk_batch_opts)]
     lib.gk_batcher_stop.argtypes = [vp]
     lib.gk_batcher_stop.restype = None

@@ -13,6 +13,7 @@
 #include <functional>
 #include <thread>
 #include <map>
+#include <unordered_map>
 #include <memory>
 #include <mutex>
 #include <shared_mutex>
@@ -138,7 +139,7 @@ struct gk_engine {
   std::shared_mutex mu;   // templates / constraints / inventory
   std::map<std::string, std::shared_ptr<Template>> templates;   // lower(kind)
   std::vector<ConstraintRec> constraints;
-  Value inventory = Value::object({});
+  Value inventory = Value::object({});   // data.inventory for host rendering: only referential templates read it, and those are refused (GK_ERR_UNSUPPORTED)
   int next_quant = 0;
   // plan cache
   std::mutex plan_mu;
@@ -158,6 +159,32 @@ struct gk_engine {
   struct Variant { HostPlan fast; DevPlan* dev = nullptr; };
   std::map<std::vector<uint16_t>, std::unique_ptr<Variant>> variants;
   std::string last_dump;
+  // ---- resident set (row f2): every object synced through gk_data_put, flattened in HBM in chunks
+  struct ResObj {
+    std::vector<std::string> path;
+    std::string key, json, ns;        // ns: the namespace the object lives in ("" = cluster scoped)
+    bool is_namespace = false, alive = true;
+    uint32_t chunk = UINT32_MAX, slot = 0;
+  };
+  struct ResChunk {
+    gk_table* table = nullptr;
+    std::vector<uint32_t> obj_of_slot;
+    std::vector<uint64_t> live;       // bit per slot: still the current version of a live object
+    gk_eval_out* ev = nullptr;        // bitmaps of the chunk's most recent evaluation
+    uint64_t plan_gen = 0;            // ... and the plan generation they belong to
+    uint64_t n_live = 0;
+  };
+  struct Resident {
+    std::mutex mu;
+    std::vector<ResObj> objs;
+    std::unordered_map<std::string, uint32_t> by_key;
+    std::unordered_map<std::string, std::vector<uint32_t>> by_ns;   // namespace -> objects living in it
+    std::unordered_map<uint64_t, uint32_t> by_text;                 // hash of the JSON text -> object (gk_query's shortcut)
+    std::vector<uint32_t> pending;                                   // objects to (re)flatten at the next sweep
+    std::vector<ResChunk> chunks;
+    bool swept = false;               // bitmaps are current (no put / remove / policy change since the last sweep)
+    uint64_t n_live = 0, n_dead_slots = 0, flattened_total = 0;
+  } resident;
   // ---- admission micro-batcher (gk_query): concurrent single-review calls coalesced into one table + one launch
   struct Request {
     const gk_review_in* in = nullptr;
@@ -367,6 +394,7 @@ int gk_engine_create(const gk_opts* opts, gk_engine** out) {
 void gk_engine_destroy(gk_engine* e) {
   if (!e) return;
   gk_batcher_stop(e);
+  for (auto& c : e->resident.chunks) { if (c.ev) gk_eval_free(c.ev); if (c.table) gk_table_free(c.table); }
   if (e->dev_plan) dev_plan_free(e->dev_plan);
   for (auto& v : e->variants) dev_plan_free(v.second->dev);
   for (auto& g : e->extra) dev_plan_free(g->dev);
@@ -455,16 +483,76 @@ int gk_constraint_remove(gk_engine* e, const char* kind, const char* name) {
   return GK_OK;
 }
 
+namespace {
+
+uint64_t text_hash(const char* p, size_t n) {
+  uint64_t h = 1469598103934665603ull;
+  for (size_t i = 0; i < n; i++) { h ^= (uint8_t)p[i]; h *= 1099511628211ull; }
+  return h ^ (h >> 29);
+}
+
+// an object leaves its slot (replaced, removed, or its Namespace changed): the slot is masked out of every answer
+void resident_tombstone(gk_engine::Resident& R, gk_engine::ResObj& o) {
+  if (o.chunk == UINT32_MAX) return;
+  gk_engine::ResChunk& c = R.chunks[o.chunk];
+  const uint64_t bit = 1ull << (o.slot % 64);
+  if (c.live[o.slot / 64] & bit) { c.live[o.slot / 64] &= ~bit; c.n_live--; R.n_dead_slots++; }
+  o.chunk = UINT32_MAX;
+}
+
+void resident_requeue(gk_engine::Resident& R, uint32_t id) {
+  gk_engine::ResObj& o = R.objs[id];
+  if (!o.alive) return;
+  const bool queued = o.chunk == UINT32_MAX && std::find(R.pending.begin(), R.pending.end(), id) != R.pending.end();
+  resident_tombstone(R, o);
+  if (!queued) R.pending.push_back(id);
+}
+
+}  // namespace
+
 int gk_data_put(gk_engine* e, const char* const* path, size_t npath, const char* json, size_t len) {
   if (!e || !path || !npath || !json) return fail(GK_ERR_INVALID, "NULL argument");
   try {
     Value v = parse_json(json, len);
     std::vector<std::string> p;
     for (size_t i = 0; i < npath; i++) p.emplace_back(path[i]);
-    std::unique_lock<std::shared_mutex> l(e->mu);
-    e->inventory = set_in(e->inventory, p, 0, &v);
-    // nsCache.Add: cluster-scoped core/v1 Namespace objects (ns_cache.go:22-43)
-    if (v.is_object() && obj_is_namespace(v) && p.size() == 4 && p[0] == "cluster") e->ns_cache.put(p[3], v);
+    const bool is_ns = v.is_object() && obj_is_namespace(v) && p.size() == 4 && p[0] == "cluster";
+    {
+      std::unique_lock<std::shared_mutex> l(e->mu);
+      // nsCache.Add: cluster-scoped core/v1 Namespace objects (ns_cache.go:22-43)
+      if (is_ns) e->ns_cache.put(p[3], v);
+    }
+    // the resident set: this version of the object is flattened by the next gk_resident_sweep
+    gk_engine::Resident& R = e->resident;
+    std::lock_guard<std::mutex> rl(R.mu);
+    std::string key;
+    for (auto& x : p) { key += x; key.push_back('/'); }
+    auto it = R.by_key.find(key);
+    uint32_t id;
+    if (it == R.by_key.end()) {
+      id = (uint32_t)R.objs.size();
+      R.objs.emplace_back();
+      gk_engine::ResObj& o = R.objs.back();
+      o.path = p; o.key = key;
+      o.ns = (p.size() == 5 && p[0] == "namespace") ? p[1] : std::string();
+      o.is_namespace = is_ns;
+      R.by_key.emplace(key, id);
+      if (!o.ns.empty()) R.by_ns[o.ns].push_back(id);
+      R.n_live++;
+    } else {
+      id = it->second;
+      gk_engine::ResObj& o = R.objs[id];
+      if (o.alive && o.json.size() == len && memcmp(o.json.data(), json, len) == 0) return GK_OK;   // unchanged
+      if (!o.alive) { o.alive = true; R.n_live++; }
+      R.by_text.erase(text_hash(o.json.data(), o.json.size()));
+    }
+    gk_engine::ResObj& o = R.objs[id];
+    o.json.assign(json, len);
+    R.by_text[text_hash(json, len)] = id;
+    resident_requeue(R, id);
+    // a Namespace object is part of the review of every object living in it (Matchable.Namespace, namespaceObject)
+    if (is_ns) { auto bn = R.by_ns.find(p[3]); if (bn != R.by_ns.end()) for (uint32_t d : bn->second) resident_requeue(R, d); }
+    R.swept = false;
     return GK_OK;
   } catch (const JsonError& ex) { return fail(GK_ERR_INVALID, ex.what()); }
 }
@@ -473,9 +561,26 @@ int gk_data_remove(gk_engine* e, const char* const* path, size_t npath) {
   if (!e || !path || !npath) return fail(GK_ERR_INVALID, "NULL argument");
   std::vector<std::string> p;
   for (size_t i = 0; i < npath; i++) p.emplace_back(path[i]);
-  std::unique_lock<std::shared_mutex> l(e->mu);
-  e->inventory = set_in(e->inventory, p, 0, nullptr);
-  if (p.size() == 4 && p[0] == "cluster" && p[1] == "v1" && p[2] == "Namespace") e->ns_cache.remove(p[3]);
+  const bool is_ns = p.size() == 4 && p[0] == "cluster" && p[1] == "v1" && p[2] == "Namespace";
+  {
+    std::unique_lock<std::shared_mutex> l(e->mu);
+    if (is_ns) e->ns_cache.remove(p[3]);
+  }
+  gk_engine::Resident& R = e->resident;
+  std::lock_guard<std::mutex> rl(R.mu);
+  std::string key;
+  for (auto& x : p) { key += x; key.push_back('/'); }
+  auto it = R.by_key.find(key);
+  if (it != R.by_key.end() && R.objs[it->second].alive) {
+    gk_engine::ResObj& o = R.objs[it->second];
+    resident_tombstone(R, o);
+    R.pending.erase(std::remove(R.pending.begin(), R.pending.end(), it->second), R.pending.end());
+    R.by_text.erase(text_hash(o.json.data(), o.json.size()));
+    o.alive = false; o.json.clear();
+    R.n_live--;
+    if (is_ns) { auto bn = R.by_ns.find(p[3]); if (bn != R.by_ns.end()) for (uint32_t d : bn->second) resident_requeue(R, d); }
+    R.swept = false;
+  }
   return GK_OK;
 }
 
@@ -1041,6 +1146,191 @@ void batcher_loop(gk_engine* e) {
 
 }  // namespace
 
+// ------------------------------------------------------------------------------------------------ resident set (row f2)
+namespace {
+
+struct SweepHolder {
+  gk_sweep_out pub;   // first member
+  std::vector<uint32_t> ids;
+  std::vector<uint64_t> results, pairs;
+};
+
+const gk_engine::ResObj* resident_namespace_of(const gk_engine::Resident& R, const gk_engine::ResObj& o) {
+  if (o.ns.empty()) return nullptr;
+  auto it = R.by_key.find("cluster/v1/Namespace/" + o.ns + "/");
+  if (it == R.by_key.end() || !R.objs[it->second].alive) return nullptr;
+  return &R.objs[it->second];
+}
+
+// the review pkg/audit builds for a cached object (auditFromCache, pkg/audit/manager.go:591-642): AugmentedUnstructured
+// {Object, Namespace: the cached Namespace it lives in}, no Source, and the same Namespace as the namespaceObject option
+gk_review_in resident_review_in(const gk_engine::Resident& R, const gk_engine::ResObj& o) {
+  gk_review_in in;
+  memset(&in, 0, sizeof in);
+  in.kind = GK_REVIEW_OBJECT;
+  in.source = GK_SRC_EMPTY;
+  in.json = o.json.data(); in.json_len = o.json.size();
+  if (const gk_engine::ResObj* ns = resident_namespace_of(R, o)) {
+    in.namespace_json = ns->json.data(); in.namespace_len = ns->json.size();
+    in.ns_object_json = ns->json.data(); in.ns_object_len = ns->json.size();
+  }
+  return in;
+}
+
+void resident_drop_chunk(gk_engine::ResChunk& c) {
+  if (c.ev) gk_eval_free(c.ev);
+  if (c.table) gk_table_free(c.table);
+  c.ev = nullptr; c.table = nullptr;
+}
+
+}  // namespace
+
+int gk_resident_sweep(gk_engine* e, uint32_t flags, gk_sweep_out** out) {
+  if (!e || !out) return fail(GK_ERR_INVALID, "NULL argument");
+  try {
+    gk_engine::Resident& R = e->resident;
+    std::lock_guard<std::mutex> rl(R.mu);
+    const auto t0 = std::chrono::steady_clock::now();
+    ensure_plan(e);
+    uint64_t flattened = 0;
+    // compaction: when masked-out slots outnumber the live ones (or the chunks have piled up) everything is flattened
+    // again into one chunk
+    if (R.n_dead_slots > R.n_live + 1024 || R.chunks.size() > 16) {
+      for (auto& c : R.chunks) resident_drop_chunk(c);
+      R.chunks.clear();
+      R.pending.clear();
+      R.n_dead_slots = 0;
+      for (uint32_t id = 0; id < R.objs.size(); id++) if (R.objs[id].alive) { R.objs[id].chunk = UINT32_MAX; R.pending.push_back(id); }
+    }
+    if (!R.pending.empty()) {
+      std::vector<gk_review_in> ins;
+      gk_engine::ResChunk c;
+      for (uint32_t id : R.pending) {
+        if (!R.objs[id].alive) continue;
+        ins.push_back(resident_review_in(R, R.objs[id]));
+        c.obj_of_slot.push_back(id);
+      }
+      R.pending.clear();
+      if (!ins.empty()) {
+        std::vector<int32_t> st(ins.size(), GK_OK);
+        int rc = gk_table_create(e, ins.data(), ins.size(), GK_TABLE_RESIDENT, st.data(), &c.table);
+        if (rc != GK_OK) return rc;
+        c.live.assign((ins.size() + 63) / 64, 0);
+        for (size_t k = 0; k < ins.size(); k++) {
+          gk_engine::ResObj& o = R.objs[c.obj_of_slot[k]];
+          o.chunk = (uint32_t)R.chunks.size(); o.slot = (uint32_t)k;
+          if (st[k] == GK_OK) { c.live[k / 64] |= 1ull << (k % 64); c.n_live++; }
+        }
+        flattened = ins.size();
+        R.flattened_total += flattened;
+        R.chunks.push_back(std::move(c));
+      }
+    }
+    const auto t1 = std::chrono::steady_clock::now();
+    ensure_plan(e);   // flattening may have interned new key paths: the plan is re-bound to the dictionary first
+    uint64_t gen;
+    { std::lock_guard<std::mutex> l(e->plan_mu); gen = e->plan_gen; }
+    std::unique_ptr<SweepHolder> h(new SweepHolder());
+    for (auto& c : R.chunks) {
+      if (c.ev && c.plan_gen == gen) continue;   // bitmaps still valid: same rows, same policies
+      if (c.ev) { gk_eval_free(c.ev); c.ev = nullptr; }
+      int rc = gk_table_eval(e, c.table, 0, &c.ev);
+      if (rc != GK_OK) return rc;
+      c.plan_gen = gen;
+    }
+    // per-constraint totals over the live slots of all chunks
+    if (!R.chunks.empty()) {
+      const gk_eval_out* ev0 = R.chunks[0].ev;
+      h->ids.assign(ev0->constraint_ids, ev0->constraint_ids + ev0->n_constraints);
+    } else {
+      std::lock_guard<std::mutex> l(e->plan_mu);
+      h->ids = e->plan_ids;
+      for (auto& g : e->extra) h->ids.insert(h->ids.end(), g->ids.begin(), g->ids.end());
+    }
+    const uint32_t nc = (uint32_t)h->ids.size();
+    h->pairs.assign(nc, 0); h->results.assign(nc, 0);
+    uint64_t beyond = 0;
+    for (auto& c : R.chunks) {
+      const gk_eval_out* ev = c.ev;
+      for (uint32_t row = 0; row < ev->n_constraints && row < nc; row++)
+        for (uint32_t w = 0; w < ev->n_tiles; w++) h->pairs[row] += (uint64_t)__builtin_popcountll(ev->viol[(size_t)row * ev->n_tiles + w] & c.live[w]);
+      for (uint32_t w = 0; w < ev->n_tiles; w++) beyond += (uint64_t)__builtin_popcountll(ev->too_big[w] & c.live[w]);
+    }
+    if (flags & GK_SWEEP_RESULT_TOTALS) {   // results, not pairs (pkg/audit/manager.go:902): render the violating live pairs
+      std::shared_lock<std::shared_mutex> l(e->mu);
+      for (auto& c : R.chunks) {
+        const gk_eval_out* ev = c.ev;
+        for (uint32_t slot = 0; slot < c.obj_of_slot.size(); slot++) {
+          const uint64_t bit = 1ull << (slot % 64);
+          if (!(c.live[slot / 64] & bit)) continue;
+          bool any = false;
+          for (uint32_t row = 0; row < ev->n_constraints && !any; row++) any = (ev->viol[(size_t)row * ev->n_tiles + slot / 64] & bit) != 0;
+          if (!any) continue;
+          const gk_review_in in = resident_review_in(R, R.objs[c.obj_of_slot[slot]]);
+          ReviewDoc doc = normalize_object(parse_json(in.json, in.json_len), parse_opt(in.namespace_json, in.namespace_len),
+                                           parse_opt(in.ns_object_json, in.ns_object_len), in.source, "", e->ns_cache);
+          for (uint32_t row = 0; row < ev->n_constraints && row < nc; row++) {
+            if (!(ev->viol[(size_t)row * ev->n_tiles + slot / 64] & bit)) continue;
+            const ConstraintRec& k = e->constraints[h->ids[row]];
+            auto it = e->templates.find(lower_str(k.kind));
+            if (it != e->templates.end()) h->results[row] += it->second->render(doc.request, k.params, e->inventory).size();
+          }
+        }
+      }
+    }
+    R.swept = true;
+    gk_sweep_out& p = h->pub;
+    memset(&p, 0, sizeof p);
+    p.n_objects = R.n_live; p.n_constraints = nc; p.constraint_ids = h->ids.data();
+    p.pairs = h->pairs.data(); p.results = (flags & GK_SWEEP_RESULT_TOTALS) ? h->results.data() : nullptr;
+    p.n_chunks = (uint32_t)R.chunks.size(); p.flattened = flattened; p.beyond_limits = beyond;
+    p.sync_s = std::chrono::duration<double>(t1 - t0).count();
+    p.eval_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+    *out = &h.release()->pub;
+    return GK_OK;
+  } catch (const std::exception& ex) { return fail(GK_ERR_DEVICE, ex.what()); }
+}
+
+void gk_sweep_free(gk_sweep_out* o) { if (o) delete reinterpret_cast<SweepHolder*>(o); }
+
+namespace {
+// the cached answer for one resident object, as gk_query's JSON; false: not resident / not swept / its slot is stale
+bool resident_answer(gk_engine* e, uint32_t id, std::string* json, int* status, std::string* err) {
+  gk_engine::Resident& R = e->resident;
+  const gk_engine::ResObj& o = R.objs[id];
+  if (!R.swept || !o.alive || o.chunk == UINT32_MAX) return false;
+  const gk_engine::ResChunk& c = R.chunks[o.chunk];
+  if (!c.ev || !(c.live[o.slot / 64] & (1ull << (o.slot % 64)))) return false;
+  { std::lock_guard<std::mutex> l(e->plan_mu); if (e->plan_dirty || c.plan_gen != e->plan_gen) return false; }
+  const gk_review_in in = resident_review_in(R, o);
+  bool too_big = false;
+  *json = query_results_json(e, c.table, *c.ev, o.slot, in, &too_big);
+  *status = GK_OK;
+  if (too_big) { *status = GK_ERR_LIMIT; *err = "review is beyond the engine's limits (more than 255 elements in an array that constraint predicates iterate)"; }
+  return true;
+}
+}  // namespace
+
+int gk_resident_review(gk_engine* e, const char* const* path, size_t npath, char** results_json) {
+  if (!e || !path || !npath || !results_json) return fail(GK_ERR_INVALID, "NULL argument");
+  try {
+    gk_engine::Resident& R = e->resident;
+    std::lock_guard<std::mutex> rl(R.mu);
+    std::string key;
+    for (size_t i = 0; i < npath; i++) { key += path[i]; key.push_back('/'); }
+    auto it = R.by_key.find(key);
+    std::string js, err;
+    int st = GK_OK;
+    if (it == R.by_key.end() || !resident_answer(e, it->second, &js, &st, &err))
+      return fail(GK_ERR_NOT_FOUND, "object is not in the swept resident set (unknown, changed since the last gk_resident_sweep, or policies changed)");
+    if (st != GK_OK) return fail(st, err);
+    char* buf = (char*)malloc(js.size() + 1);
+    memcpy(buf, js.c_str(), js.size() + 1);
+    *results_json = buf;
+    return GK_OK;
+  } catch (const std::exception& ex) { return fail(GK_ERR_REGO, ex.what()); }
+}
+
 int gk_batcher_start(gk_engine* e, const gk_batch_opts* opts) {
   if (!e) return fail(GK_ERR_INVALID, "NULL argument");
   gk_engine::Batcher& B = e->batcher;
@@ -1069,6 +1359,36 @@ void gk_batcher_stop(gk_engine* e) {
 
 int gk_query(gk_engine* e, const gk_review_in* review, char** results_json, gk_query_stats* stats) {
   if (!e || !review || !results_json) return fail(GK_ERR_INVALID, "NULL argument");
+  // a review that is byte for byte a swept resident object (same object text, the Namespace the sweep used, no Source --
+  // what pkg/audit's auditFromCache sends, manager.go:611-614) is answered from the sweep's bitmap column: no flatten, no launch
+  if (review->kind == GK_REVIEW_OBJECT && review->source == GK_SRC_EMPTY && review->json && !(review->operation && *review->operation)) {
+    gk_engine::Resident& R = e->resident;
+    std::unique_lock<std::mutex> rl(R.mu, std::try_to_lock);
+    if (rl.owns_lock() && R.swept) {
+      auto it = R.by_text.find(text_hash(review->json, review->json_len));
+      if (it != R.by_text.end()) {
+        const gk_engine::ResObj& o = R.objs[it->second];
+        const gk_review_in want = resident_review_in(R, o);
+        auto same = [](const char* a, size_t an, const char* b, size_t bn) { return (an == 0 && bn == 0) || (a && b && an == bn && memcmp(a, b, an) == 0); };
+        if (o.alive && same(o.json.data(), o.json.size(), review->json, review->json_len) &&
+            same(want.namespace_json, want.namespace_len, review->namespace_json, review->namespace_len) &&
+            same(want.ns_object_json, want.ns_object_len, review->ns_object_json, review->ns_object_len)) {
+          std::string js, err;
+          int st = GK_OK;
+          try {
+            if (resident_answer(e, it->second, &js, &st, &err)) {
+              if (stats) { stats->batch_size = 0; stats->queue_us = 0; stats->device_us = 0; stats->total_us = 0; }
+              if (st != GK_OK) return fail(st, err);
+              char* buf = (char*)malloc(js.size() + 1);
+              memcpy(buf, js.c_str(), js.size() + 1);
+              *results_json = buf;
+              return GK_OK;
+            }
+          } catch (const std::exception&) { /* fall through to the regular path */ }
+        }
+      }
+    }
+  }
   if (!e->batcher.running) { int rc = gk_batcher_start(e, nullptr); if (rc != GK_OK) return rc; }
   gk_engine::Request req;
   req.in = review;

@@ -576,6 +576,34 @@ class Driver:
                  "source": {"type": "engine", "value": self.Name()}}], "labels": [{"name": "target", "value": target}]})
         return QueryResponse(results, stats)
 
+    def ResidentSweep(self, result_totals=False):
+        """gk_resident_sweep: bring the HBM-resident set (everything AddData'd) up to date and evaluate all constraints over
+        it.  -> dict(n_objects, n_chunks, flattened, beyond_limits, sync_s, eval_s, pairs {constraint id: n}, results {...})"""
+        out = C.POINTER(L.gk_sweep_out)()
+        self.engine._check(self.engine.lib.gk_resident_sweep(self.engine.handle, L.GK_SWEEP_RESULT_TOTALS if result_totals else 0, C.byref(out)))
+        o = out.contents
+        res = {"n_objects": int(o.n_objects), "n_chunks": int(o.n_chunks), "flattened": int(o.flattened), "beyond_limits": int(o.beyond_limits),
+               "sync_s": o.sync_s, "eval_s": o.eval_s,
+               "pairs": {int(o.constraint_ids[i]): int(o.pairs[i]) for i in range(o.n_constraints)},
+               "results": ({int(o.constraint_ids[i]): int(o.results[i]) for i in range(o.n_constraints)} if o.results else None)}
+        self.engine.lib.gk_sweep_free(out)
+        return res
+
+    def ResidentReview(self, path):
+        """gk_resident_review: the swept answer of one resident object (rows of gk_query's JSON), or None when the object is
+        not in the swept set (unknown / changed since the sweep / policies changed)."""
+        arr = (C.c_char_p * len(path))(*[p.encode() for p in path])
+        out = C.c_void_p()
+        rc = self.engine.lib.gk_resident_review(self.engine.handle, arr, len(path), C.byref(out))
+        if rc == L.GK_ERR_NOT_FOUND:
+            return None
+        if rc == L.GK_ERR_LIMIT:
+            raise LimitError("/".join(path))
+        self.engine._check(rc)
+        rows = json.loads(C.string_at(out).decode())
+        self.engine.lib.gk_free(out)
+        return rows
+
     def StartBatcher(self, max_batch=64, window_us=200):
         """gk_batcher_start: how many concurrent Query calls share a launch, and how long the first one waits for company"""
         opts = L.gk_batch_opts(max_batch, window_us)
@@ -714,6 +742,7 @@ class Client:
         self.driver = driver or Driver(hostemu=hostemu)
         self.templates = {}
         self.constraints = {}   # (kind, name) -> constraint (defaulted)
+        self.cached = {}        # inventory path -> object (everything AddData'd: the resident set)
         self.enforcement_points = tuple(enforcement_points)
 
     def AddTemplate(self, ct):
@@ -765,9 +794,35 @@ class Client:
                 if v is not None and not (isinstance(v, dict) and all(isinstance(x, str) for x in v.values())):
                     raise ClientError("cannot cache type: cannot cache Namespace: metadata.%s must be a map of strings" % f)
         self.driver.AddData(TARGET_NAME, path, dict(obj))
+        self.cached[tuple(path)] = obj
 
     def RemoveData(self, obj):
-        self.driver.RemoveData(TARGET_NAME, process_data(obj))
+        path = process_data(obj)
+        self.driver.RemoveData(TARGET_NAME, path)
+        self.cached.pop(tuple(path), None)
+
+    def AuditFromCache(self):
+        """pkg/audit's auditFromCache (manager.go:591-642) against the resident set: ONE sweep over everything that was
+        AddData'd, then every cached object's results are read from the sweep's bitmap column (rendered only where a bit
+        is set) -- the reference issues one serial Review per object.  -> ({path tuple: [Result]}, sweep dict)"""
+        sweep = self.driver.ResidentSweep()
+        info = self._active(AUDIT_EP)
+        out = {}
+        for path in self.cached:
+            try:
+                rows = self.driver.ResidentReview(list(path))
+            except LimitError as e:
+                out[path] = ReviewFailure(-1, str(e), e)
+                continue
+            if rows is None:
+                raise EngineError(L.GK_ERR_INTERNAL, "cached object %r missing from the swept resident set" % (path,))
+            res = []
+            for v in rows:
+                if v["constraint"] in info:
+                    c, ea, scoped = info[v["constraint"]]
+                    res.append(Result(v["msg"], c, {} if v.get("autoreject") else v.get("details", {}), ea, scoped))
+            out[path] = res
+        return out, sweep
 
     def _active(self, enforcement_point):
         """{engine constraint id: (constraint, enforcement action, scoped actions)} of the constraints enforced at this

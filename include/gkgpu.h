@@ -173,6 +173,33 @@ typedef struct {
 int gk_table_totals(gk_engine* e, gk_table* t, gk_totals_out** out);
 void gk_totals_free(gk_totals_out* o);
 
+/* ---- resident-set audit (row f2) -----------------------------------------------------------------------------------
+ * pkg/audit's auditFromCache reviews, one by one, exactly the objects that were synced into the driver through
+ * Driver.AddData (pkg/audit/manager.go:591-642; pkg/cachemanager/cachemanager.go:310-343).  gk_data_put / gk_data_remove
+ * therefore also maintain a RESIDENT SET: every synced object, flattened in HBM.  gk_resident_sweep brings the device
+ * tables up to date -- only objects added or changed since the last sweep are flattened (into a new chunk); replaced
+ * and removed objects are masked out; a changed Namespace re-flattens the objects living in it; chunks are compacted when
+ * the masked-out slots outnumber the live ones -- and evaluates every constraint over the set in one launch per chunk.
+ * The review of a resident object is the one auditFromCache builds: AugmentedUnstructured{Object, Namespace: the synced
+ * Namespace it lives in (or none)}, no Source, the same Namespace as the namespaceObject option.
+ * Afterwards the per-object answers are a column of the bitmaps: gk_resident_review (by path) and gk_query (for a review
+ * that is byte for byte such an object + Namespace) return them without flattening or launching anything. */
+typedef struct {
+  uint64_t n_objects;              /* live objects in the set */
+  uint32_t n_constraints, n_chunks;
+  const uint32_t* constraint_ids;  /* [n_constraints] */
+  const uint64_t* pairs;           /* [n_constraints] violating (constraint, object) pairs */
+  const uint64_t* results;         /* [n_constraints] results (manager.go:902 counts these), only with GK_SWEEP_RESULT_TOTALS */
+  uint64_t flattened;              /* objects (re)flattened by THIS sweep */
+  uint64_t beyond_limits;          /* live objects the engine refuses to evaluate (fail closed: review them on the CPU driver) */
+  double sync_s, eval_s;           /* host flatten + upload of the new chunk / device evaluation + download of the bitmaps */
+} gk_sweep_out;
+#define GK_SWEEP_RESULT_TOTALS 1u
+int gk_resident_sweep(gk_engine* e, uint32_t flags, gk_sweep_out** out);
+void gk_sweep_free(gk_sweep_out* o);
+/* results of one swept object, in gk_query's JSON; GK_ERR_NOT_FOUND when the object is unknown or its answer is stale */
+int gk_resident_review(gk_engine* e, const char* const* path, size_t npath, char** results_json);
+
 /* ---- admission path: micro-batched Driver.Query (row f1) ----------------------------------------------------------
  * Driver.Query evaluates ONE review (pkg/drivers/k8scel/driver.go:162-251) and the validating webhook calls it from up
  * to GOMAXPROCS request goroutines at once (pkg/webhook/policy.go:142-146, 748-757).  gk_query may be called from any

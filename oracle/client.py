@@ -82,6 +82,7 @@ class RegoDriver:
     def __init__(self):
         self.templates = {}      # lower(kind) -> Interp
         self.inventory = {}      # nested dict under data.inventory
+        self._data = None        # its converted form (cache)
 
     def add_template(self, ct):
         kind, _, rego, libs = template_source(ct)
@@ -107,6 +108,7 @@ class RegoDriver:
         for p in path[:-1]:
             cur = cur.setdefault(p, {})
         cur[path[-1]] = copy.deepcopy(data)
+        self._data = None
 
     def remove_data(self, target, path):
         cur = self.inventory
@@ -115,11 +117,14 @@ class RegoDriver:
             if cur is None:
                 return
         cur.pop(path[-1], None)
+        self._data = None
 
     def query(self, target, constraints, review, namespace=None):
         """-> list[Result] (EnforcementAction left for the client to fill)."""
         review_json = t.review_input_json(review, namespace)
-        data = from_json({"inventory": self.inventory})
+        if self._data is None:      # converted once per inventory state, not once per query
+            self._data = from_json({"inventory": self.inventory})
+        data = self._data
         out = []
         for c in constraints:
             ip = self.templates.get(c.get("kind", "").lower())
