@@ -135,19 +135,28 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def local(steps, download=False):
+        """plain launches of the hot path over this rank's shard, no exchange"""
+        for _ in range(steps):
+            table.launch()
+        return table.eval(download=download, collect_only=True)
+
+    step = sweep.sweep if dist is not None else local     # sharded: local evaluation + the engine's RCCL exchange per step
     if args.warmup:
-        sweep.sweep(args.warmup)
+        step(args.warmup)
     barrier()
     t0 = time.perf_counter()
-    res = sweep.sweep(args.steps)          # exactly `steps` launches (+ exchanges when sharded) in the timed region
+    step(args.steps)                       # exactly `steps` passes (+ exchanges when sharded) in the timed region
     barrier()
     dt = time.perf_counter() - t0
-    final = sweep.sweep(1, download=True)
+    sharded = sweep.sweep(1, download=False) if dist is not None else None
+    res = local(min(args.steps, 20))       # launch-to-launch average of the kernel alone (and the per-launch byte accounting)
+    final = local(1, download=True)
     counts = final.counts
     # isolated kernel duration: a second, untimed pass with one HIP event pair per launch (the timed region above
     # brackets all launches with one pair, i.e. its average includes the gaps between consecutive launches)
     os.environ["GK_EVENT_PER_LAUNCH"] = "1"
-    iso = sweep.sweep(min(args.steps, 20))
+    iso = local(min(args.steps, 20))
     del os.environ["GK_EVENT_PER_LAUNCH"]
     if dist is not None:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -173,7 +182,9 @@ def main():
             "config": {"workload": cfg_name, "constraints": nc, "reviews_total": total_reviews, "reviews_rank0": n_local,
                        "rows_rank0": int(res.n_rows), "rows_read_rank0": int(res.n_rows_read), "table_bytes_rank0": int(st["device_bytes"]),
                        "timed_region_s": dt,
-                       "parallelism": "objects sharded across %d GPU(s); one RCCL all-gather of [violation bitmaps | counts] per sweep" % world,
+                       "parallelism": ("objects block-sharded across %d GPUs; per sweep one in-place ncclAllGather of [violation bitmaps | counts] + "
+                                       "one ncclAllReduce of int64 totals, issued by the engine on the kernel's stream" % world) if dist is not None else "1 GPU",
+                       "global_violating_pairs": int(sharded.totals.sum()) if sharded is not None else int(counts.sum()),
                        "violating_pairs_rank0": int(counts.sum()), "reviews_beyond_limits_rank0": len(final.too_big_reviews())},
             "roofline": {"bound": "hbm", "kernel": "gk_eval_tiles", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algo_bytes_per_launch": int(res.algo_bytes),

@@ -32,6 +32,7 @@ EXPORTS = [
     "gk_table_eval", "gk_eval_free", "gk_render", "gk_render_error", "gk_free", "gk_dump", "gk_table_topk", "gk_topk_free",
     "gk_table_totals", "gk_totals_free", "gk_table_get_stats", "gk_batcher_start", "gk_batcher_stop", "gk_query",
     "gk_resident_sweep", "gk_sweep_free", "gk_resident_review",
+    "gk_comm_unique_id", "gk_comm_init", "gk_comm_destroy", "gk_table_sweep_sharded", "gk_shard_free",
     # include/gksynth.h (bench / test plumbing)
     "gk_synth_batch_create", "gk_synth_batch_reviews", "gk_synth_batch_size", "gk_synth_batch_json_bytes", "gk_synth_batch_free",
 ]
@@ -80,6 +81,19 @@ class gk_sweep_out(C.Structure):
     _fields_ = [("n_objects", C.c_uint64), ("n_constraints", C.c_uint32), ("n_chunks", C.c_uint32), ("constraint_ids", C.POINTER(C.c_uint32)),
                 ("pairs", C.POINTER(C.c_uint64)), ("results", C.POINTER(C.c_uint64)), ("flattened", C.c_uint64), ("beyond_limits", C.c_uint64),
                 ("sync_s", C.c_double), ("eval_s", C.c_double)]
+
+
+class gk_shard_out(C.Structure):
+    _fields_ = [("world", C.c_uint32), ("rank", C.c_uint32), ("n_constraints", C.c_uint32), ("stride_tiles", C.c_uint32), ("slot_bytes", C.c_uint64),
+                ("constraint_ids", C.POINTER(C.c_uint32)), ("shard_reviews", C.POINTER(C.c_uint32)), ("totals", C.POINTER(C.c_int64)),
+                ("gathered", C.POINTER(C.c_uint64)), ("d_gathered", C.c_void_p), ("kernel_ms", C.c_float), ("fast_kernel_ms", C.c_float),
+                ("n_overflow", C.c_uint32)]
+
+
+GK_SHARD_DOWNLOAD = 1
+GK_COMM_ID_BYTES = 128
+HE_ALLGATHER = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_uint64)     # test-only (libgkgpu_hostemu.so gk_comm_init_host)
+HE_ALLREDUCE = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_longlong), C.c_uint64)
 
 
 class gk_batch_opts(C.Structure):
@@ -148,6 +162,15 @@ def load(hostemu: bool | None = None):
     lib.gk_table_topk.argtypes = [vp, vp, u32, C.POINTER(C.POINTER(gk_topk_out))]
     lib.gk_topk_free.argtypes = [C.POINTER(gk_topk_out)]
     lib.gk_topk_free.restype = None
+    lib.gk_comm_unique_id.argtypes = [C.c_char_p]
+    lib.gk_comm_init.argtypes = [vp, C.c_char_p, C.c_int, C.c_int]
+    lib.gk_comm_destroy.argtypes = [vp]
+    lib.gk_comm_destroy.restype = None
+    lib.gk_table_sweep_sharded.argtypes = [vp, vp, u32, C.POINTER(C.POINTER(gk_shard_out))]
+    lib.gk_shard_free.argtypes = [C.POINTER(gk_shard_out)]
+    lib.gk_shard_free.restype = None
+    if hostemu:
+        lib.gk_comm_init_host.argtypes = [vp, C.c_int, C.c_int, HE_ALLGATHER, HE_ALLREDUCE, vp]
     lib.gk_resident_sweep.argtypes = [vp, u32, C.POINTER(C.POINTER(gk_sweep_out))]
     lib.gk_sweep_free.argtypes = [C.POINTER(gk_sweep_out)]
     lib.gk_sweep_free.restype = None

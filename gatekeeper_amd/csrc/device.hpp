@@ -18,6 +18,7 @@ struct EvalOptions {
   bool download = true;      // copy bitmaps / list back to the host
   bool want_match = false;   // also produce the match-only bitmap
   uint32_t list_capacity = 0;   // max violation-list entries (0 = no list)
+  bool shard = false;           // results go to the shard slot prepared by dev_shard_setup (bitmap stride = the largest shard's)
 };
 
 struct EvalOut {
@@ -61,6 +62,25 @@ void dev_topk(const DevTable* t, uint32_t nc, const std::vector<uint32_t>& order
               std::vector<uint32_t>* idx, std::vector<uint32_t>* n, std::vector<uint32_t>* ovf);
 // the violation bitmap [nc][n_tiles] of the table's most recent evaluation (device -> host copy)
 void dev_last_viol(const DevTable* t, uint32_t nc, std::vector<uint64_t>* viol);
+// ---- multi-GPU exchange step of a sharded sweep: one communicator per engine (= per GPU / rank)
+struct DevComm;
+bool dev_comm_unique_id(char id[128], std::string* err);                                  // rank 0: ncclGetUniqueId
+DevComm* dev_comm_init(int device, const char id[128], int rank, int world, std::string* err);   // ncclCommInitRank (RCCL over xGMI)
+void dev_comm_free(DevComm* c);
+int dev_comm_rank(const DevComm* c);
+int dev_comm_world(const DevComm* c);
+// A table evaluated as one SHARD: its violation bitmap and counts live in this rank's slot of an all-gather buffer
+// ([world] x ([nc][stride_tiles] u64 | [nc] u32 | pad)), stride_tiles = the largest shard's words per row.
+struct ShardInfo {
+  uint32_t stride_tiles = 0;            // bitmap words per row in every slot
+  uint64_t slot_bytes = 0;
+  std::vector<uint32_t> shard_reviews;  // [world]
+};
+void dev_shard_setup(DevTable* t, DevComm* c, uint32_t nc, ShardInfo* info);   // collective: exchanges the shard sizes
+// after a finished local evaluation of the shard (dev_eval): int64 totals <- counts, in-place all-gather of the slots,
+// all-reduce (sum) of the totals, on the evaluation stream; then synchronises and copies what was asked for to the host
+void dev_shard_exchange(DevTable* t, DevComm* c, uint32_t nc, std::vector<int64_t>* totals, std::vector<uint64_t>* gathered /* may be null */,
+                        const void** d_gathered);
 void dev_eval_launch(const DevPlan* p, const DevTable* t, const EvalOptions& opt);          // asynchronous on the default stream
 void dev_eval_finish(const DevPlan* p, const DevTable* t, const EvalOptions& opt, EvalOut* out);   // sync, overflow re-run, download
 

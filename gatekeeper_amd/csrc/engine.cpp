@@ -159,6 +159,7 @@ struct gk_engine {
   struct Variant { HostPlan fast; DevPlan* dev = nullptr; };
   std::map<std::vector<uint16_t>, std::unique_ptr<Variant>> variants;
   std::string last_dump;
+  DevComm* comm = nullptr;   // multi-GPU exchange (gk_comm_init)
   // ---- resident set (row f2): every object synced through gk_data_put, flattened in HBM in chunks
   struct ResObj {
     std::vector<std::string> path;
@@ -228,6 +229,8 @@ struct gk_table {
   std::vector<uint32_t> last_ids;
   uint32_t n_reviews = 0;
   uint32_t rpt = GK_RPT_MIN;                // reviews per row group of this table
+  ShardInfo shard;                          // sharded sweeps: slot layout agreed with the other ranks
+  uint64_t shard_gen = 0;
   gk_table_stats stats{};
 };
 
@@ -394,6 +397,7 @@ int gk_engine_create(const gk_opts* opts, gk_engine** out) {
 void gk_engine_destroy(gk_engine* e) {
   if (!e) return;
   gk_batcher_stop(e);
+  if (e->comm) dev_comm_free(e->comm);
   for (auto& c : e->resident.chunks) { if (c.ev) gk_eval_free(c.ev); if (c.table) gk_table_free(c.table); }
   if (e->dev_plan) dev_plan_free(e->dev_plan);
   for (auto& v : e->variants) dev_plan_free(v.second->dev);
@@ -1145,6 +1149,78 @@ void batcher_loop(gk_engine* e) {
 }
 
 }  // namespace
+
+// ------------------------------------------------------------------------------------------------ multi-GPU (row e)
+int gk_comm_unique_id(char id[GK_COMM_ID_BYTES]) {
+  std::string err;
+  if (!id) return fail(GK_ERR_INVALID, "NULL argument");
+  if (!dev_comm_unique_id(id, &err)) return fail(GK_ERR_DEVICE, err);
+  return GK_OK;
+}
+
+int gk_comm_init(gk_engine* e, const char id[GK_COMM_ID_BYTES], int rank, int world) {
+  if (!e || !id || rank < 0 || world < 1 || rank >= world) return fail(GK_ERR_INVALID, "bad argument");
+  std::string err;
+  DevComm* c = dev_comm_init(e->opts.device, id, rank, world, &err);
+  if (!c) return fail(GK_ERR_DEVICE, err);
+  if (e->comm) dev_comm_free(e->comm);
+  e->comm = c;
+  return GK_OK;
+}
+
+// used by the test-only CPU emulation (tests/native/hostemu.cpp): adopt a communicator built elsewhere
+int gk_comm_init_host_impl(gk_engine* e, DevComm* c) { if (!e || !c) return GK_ERR_INVALID; if (e->comm) dev_comm_free(e->comm); e->comm = c; return GK_OK; }
+
+void gk_comm_destroy(gk_engine* e) { if (e && e->comm) { dev_comm_free(e->comm); e->comm = nullptr; } }
+
+struct ShardHolder {
+  gk_shard_out pub;   // first member
+  std::vector<uint32_t> ids, shard_reviews;
+  std::vector<int64_t> totals;
+  std::vector<uint64_t> gathered;
+};
+
+int gk_table_sweep_sharded(gk_engine* e, gk_table* t, uint32_t flags, gk_shard_out** out) {
+  if (!e || !t || !out) return fail(GK_ERR_INVALID, "NULL argument");
+  if (!e->comm) return fail(GK_ERR_INVALID, "gk_comm_init first");
+  try {
+    ensure_plan(e);
+    std::unique_ptr<ShardHolder> h(new ShardHolder());
+    std::lock_guard<std::mutex> l(e->plan_mu);
+    if (!e->extra.empty()) return fail(GK_ERR_UNSUPPORTED, "sharded sweeps need the constraint set in one plan group (more than 64 distinct formulas loaded)");
+    const HostPlan* hp = nullptr;
+    DevPlan* dp = plan_for_table(e, t, &hp);
+    const uint32_t nc = (uint32_t)e->plan_ids.size();
+    if (t->shard_gen != e->plan_gen || t->shard.shard_reviews.empty()) {   // (collective) once per table and plan
+      dev_shard_setup(t->dev, e->comm, nc, &t->shard);
+      t->shard_gen = e->plan_gen;
+    }
+    EvalOptions opt;
+    opt.download = false;
+    opt.shard = true;
+    EvalOut eo;
+    // local evaluation, finished (incl. the large-capacity pass for overflowing reviews) BEFORE the exchange, so that the
+    // gathered bitmaps are complete; then the exchange step on the same stream
+    dev_eval(dp, t->dev, opt, &eo);
+    const void* d_all = nullptr;
+    dev_shard_exchange(t->dev, e->comm, nc, &h->totals, (flags & GK_SHARD_DOWNLOAD) ? &h->gathered : nullptr, &d_all);
+    h->ids = e->plan_ids;
+    h->shard_reviews = t->shard.shard_reviews;
+    gk_shard_out& p = h->pub;
+    memset(&p, 0, sizeof p);
+    p.world = (uint32_t)dev_comm_world(e->comm); p.rank = (uint32_t)dev_comm_rank(e->comm);
+    p.n_constraints = nc; p.stride_tiles = t->shard.stride_tiles; p.slot_bytes = t->shard.slot_bytes;
+    p.constraint_ids = h->ids.data(); p.shard_reviews = h->shard_reviews.data(); p.totals = h->totals.data();
+    p.gathered = h->gathered.empty() ? nullptr : h->gathered.data();
+    p.d_gathered = d_all;
+    p.kernel_ms = eo.kernel_ms; p.fast_kernel_ms = eo.fast_kernel_ms; p.n_overflow = eo.n_overflow;
+    *out = &h.release()->pub;
+    return GK_OK;
+  } catch (const Unsupported& ex) { return fail(GK_ERR_UNSUPPORTED, ex.what());
+  } catch (const std::exception& ex) { return fail(GK_ERR_DEVICE, ex.what()); }
+}
+
+void gk_shard_free(gk_shard_out* o) { if (o) delete reinterpret_cast<ShardHolder*>(o); }
 
 // ------------------------------------------------------------------------------------------------ resident set (row f2)
 namespace {

@@ -349,6 +349,7 @@ class Engine:
 
     def __init__(self, device=0, elem_cap=None, hostemu=None):
         self.lib = L.load(hostemu)
+        self.hostemu = bool(hostemu)
         opts = L.gk_opts()
         opts.device = device
         if elem_cap:

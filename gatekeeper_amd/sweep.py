@@ -1,152 +1,164 @@
 """Audit sweep over a resident, object-sharded set.
 
-The reference's audit loop is serial (pkg/audit/manager.go:591-642: for obj { Client.Review }).  Here every rank
-(one process per GPU) keeps its shard of the flattened object set resident in HBM and sweeps it with one kernel
-launch; the only exchange step is an RCCL all-gather of the per-shard violation bitmaps plus an all-reduce of the
-per-constraint counts, so that every rank ends with the full constraints x objects answer.  Objects never move.
+The reference's audit loop is serial (pkg/audit/manager.go:591-642: for obj { Client.Review }).  Here every rank (one
+process per GPU) keeps its shard of the flattened object set resident in HBM and sweeps it with one kernel launch; the only
+exchange step is issued by the ENGINE on the kernel's stream through its own RCCL communicator (gk_table_sweep_sharded):
+an in-place ncclAllGather of every shard's [violation bitmap | counts] slot plus an ncclAllReduce(sum) of the int64
+per-constraint totals, so that every rank ends with the full constraints x objects answer.  Objects never move.
+
+torch.distributed is plumbing only: it carries the RCCL unique id from rank 0 to the other ranks (and, in the CPU tests,
+stands in for the collectives through the test-only emulation library), and gathers the few top-k candidate records of
+the audit lists.
 """
 from __future__ import annotations
 
-import ctypes
+import ctypes as C
 
+import numpy as np
+
+from . import _lib as L
 from . import driver as D
 from . import synth
 
-_hip = None
 
+class ShardedResult:
+    """one sharded sweep: global totals + (optionally) the gathered bitmaps, as numpy views"""
 
-def _d2d(dst_ptr, src_ptr, nbytes):
-    """device-to-device copy between a raw HIP pointer handed out by the C ABI and a torch tensor (plumbing only)."""
-    global _hip
-    if _hip is None:
-        _hip = ctypes.CDLL("libamdhip64.so")
-        _hip.hipMemcpyAsync.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
-    rc = _hip.hipMemcpyAsync(dst_ptr, src_ptr, nbytes, 3, None)   # hipMemcpyDeviceToDevice on the default stream
-    if rc != 0:
-        raise RuntimeError("hipMemcpyAsync failed: %d" % rc)
+    def __init__(self, lib, ptr):
+        o = ptr.contents
+        self.world, self.rank, self.nc, self.stride_tiles, self.slot_bytes = o.world, o.rank, o.n_constraints, o.stride_tiles, o.slot_bytes
+        self.constraint_ids = np.ctypeslib.as_array(o.constraint_ids, (self.nc,)).copy() if self.nc else np.zeros(0, np.uint32)
+        self.shard_reviews = np.ctypeslib.as_array(o.shard_reviews, (self.world,)).copy()
+        self.totals = np.ctypeslib.as_array(o.totals, (self.nc,)).copy() if self.nc else np.zeros(0, np.int64)
+        self.kernel_ms, self.fast_kernel_ms, self.n_overflow = o.kernel_ms, o.fast_kernel_ms, o.n_overflow
+        self.d_gathered = o.d_gathered
+        self.gathered = None
+        if o.gathered:
+            raw = np.ctypeslib.as_array(o.gathered, (self.world * self.slot_bytes // 8,)).copy().view(np.uint8).reshape(self.world, self.slot_bytes)
+            self.gathered = raw
+        lib.gk_shard_free(ptr)
 
+    def bitmaps(self):
+        """-> list over ranks of [nc][ceil(shard reviews / 64)] uint64 violation bitmaps (the shard's own words)"""
+        out = []
+        for r in range(self.world):
+            bm = self.gathered[r, :self.nc * self.stride_tiles * 8].view(np.uint64).reshape(self.nc, self.stride_tiles)
+            out.append(bm[:, :(int(self.shard_reviews[r]) + 63) // 64].copy())
+        return out
 
-class _DeviceBytes:
-    """A byte range in device memory owned by the engine, exposed through the CUDA array interface so that torch can
-    alias it without a copy."""
-
-    def __init__(self, ptr, nbytes):
-        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+    def counts(self):
+        """[world][nc] violating objects per shard and constraint"""
+        off = self.nc * self.stride_tiles * 8
+        return np.stack([self.gathered[r, off:off + self.nc * 4].view(np.uint32) for r in range(self.world)])
 
 
 class ShardedSweep:
-    """One rank's shard of the audited objects, resident in HBM, plus the exchange buffers.
+    """One rank's shard of the audited objects, resident in HBM.  `dist`: an initialised torch.distributed (any backend);
+    None = single process (plain launches, no exchange)."""
 
-    Exchange step of a pass: ONE all-gather of `[violation bitmap | per-constraint counts]` (bytes) per rank, so every
-    rank ends with all shards' bitmaps and counts; the global totals are the sum of the gathered counts (`total_counts`).
-    On the device path nothing waits on the host between passes: the collective reads the engine's result buffer in
-    place (bitmap and counts are one contiguous allocation, aliased as a torch tensor) and is ordered after the kernels
-    by the stream; the host synchronises once, when the passes are collected."""
-
-    def __init__(self, client, objs=None, namespaces=None, dist=None, device=None, table=None, n=None):
+    def __init__(self, client, objs=None, namespaces=None, dist=None, device=None, table=None, n=None, keep_docs=False):
         """Either `objs` (+ their Namespace map) to flatten here, or an existing resident `table` of `n` reviews."""
         self.client = client
         self.dist = dist
+        self.objs = objs
         if table is None:
             rins = [D.to_review_in(D.AugmentedUnstructured(D.Unstructured(o), synth.namespace_for(o, namespaces), "Original"))
                     for o in objs]
-            table = client.driver.engine.create_table(rins, keep_docs=False, resident=True)   # the audit set stays on the GPU
+            table = client.driver.engine.create_table(rins, keep_docs=keep_docs, resident=True)   # the audit set stays on the GPU
             n = len(objs)
         self.table = table
         self.n = n
         self.nc = len(client.constraints)
-        self.n_tiles = (self.n + 63) // 64
-        self.bm_bytes = self.nc * self.n_tiles * 8
-        self.stage = self.gathered_raw = None
-        self.on_device = device is not None and str(device).startswith("cuda")
-        self._ptrs = None            # (d_viol, d_counts) of the table's result buffers, known after the first collect
-        self._alias = None           # torch view of the engine's [bitmap | counts] buffer (device path)
-        self._alias_ptr = None
+        self._cb = None
         if dist is not None:
+            self._join(dist)
+
+    def _join(self, dist):
+        """join the engine to the communicator of this job"""
+        eng = self.client.driver.engine
+        rank, world = dist.get_rank(), dist.get_world_size()
+        if eng.hostemu:
+            # TEST-ONLY: the CPU emulation has no RCCL; its collectives are callbacks into torch.distributed (gloo)
             import torch
-            self.world = dist.get_world_size()
-            self.stage = torch.zeros(self.bm_bytes + self.nc * 4, dtype=torch.uint8, device=device)
-            self.gathered_raw = torch.zeros(self.world * self.stage.numel(), dtype=torch.uint8, device=device)
 
-    # -- views of the gathered bytes ---------------------------------------------------------------------------------
-    @property
-    def gathered(self):
-        """[world * n_constraints * n_tiles] int64: every rank's violation bitmap, rank-major."""
-        import torch
-        g = self.gathered_raw.view(self.world, -1)[:, :self.bm_bytes].contiguous()
-        return g.view(torch.int64).reshape(-1)
+            def gather(_ctx, buf, slot_bytes):
+                raw = (C.c_uint8 * (world * slot_bytes)).from_address(buf)
+                mine = torch.from_numpy(np.frombuffer(raw, np.uint8, slot_bytes, rank * slot_bytes).copy())
+                parts = [torch.zeros(slot_bytes, dtype=torch.uint8) for _ in range(world)]
+                dist.all_gather(parts, mine)
+                np.frombuffer(raw, np.uint8)[:] = torch.cat(parts).numpy()
 
-    @property
-    def total_counts(self):
-        """[n_constraints] int32: violating objects per constraint over all shards."""
-        import torch
-        c = self.gathered_raw.view(self.world, -1)[:, self.bm_bytes:].contiguous().view(torch.int32)
-        return c.reshape(self.world, self.nc).sum(0, dtype=torch.int32)
+            def reduce(_ctx, buf, n):
+                arr = np.ctypeslib.as_array(buf, (n,))
+                t = torch.from_numpy(arr.copy())
+                dist.all_reduce(t)
+                arr[:] = t.numpy()
 
-    def _exchange(self):
-        self.dist.all_gather_into_tensor(self.gathered_raw, self.stage)
+            self._cb = (L.HE_ALLGATHER(gather), L.HE_ALLREDUCE(reduce))
+            eng._check(eng.lib.gk_comm_init_host(eng.handle, rank, world, self._cb[0], self._cb[1], None))
+            return
+        ident = [None]
+        if rank == 0:
+            buf = C.create_string_buffer(L.GK_COMM_ID_BYTES)
+            eng._check(eng.lib.gk_comm_unique_id(buf))
+            ident[0] = buf.raw
+        dist.broadcast_object_list(ident, src=0)
+        eng._check(eng.lib.gk_comm_init(eng.handle, ident[0], rank, world))
 
     def sweep(self, steps=1, download=False):
-        """`steps` passes of the hot path over the resident shard.  Single GPU: the launches are enqueued back to back
-        and collected once.  Sharded: every pass is followed by its exchange step.  Returns the EvalResult of the last
-        pass (kernel time = average over the passes)."""
+        """`steps` passes of the hot path over the resident shard.  Single process: the launches are enqueued back to back and
+        collected once -> EvalResult.  Sharded: every pass is local evaluation + the engine's exchange step -> ShardedResult
+        of the last pass."""
         if self.dist is None:
             for _ in range(steps):
                 self.table.launch()
             return self.table.eval(download=download, collect_only=True)
-        import torch
-        ev = None
-        if not self.on_device:
-            # CPU path of the exchange (gloo; used by tests/test_sweep_dist.py with the test-only emulated kernels):
-            # the same staging layout and collective on host tensors built from the downloaded results
-            import numpy as np
-            for _ in range(steps):
-                ev = self.table.eval(download=True)
-                raw = np.concatenate([ev.viol.reshape(-1).view(np.uint8), ev.counts.astype(np.int32).view(np.uint8)])
-                self.stage.copy_(torch.from_numpy(raw.copy()))
-                self._exchange()
-            return ev
-        done = 0
-        if self._ptrs is None and steps > 0:
-            # first pass ever: one collect to learn where the table's result buffers live (stable afterwards)
-            self.table.launch()
-            ev = self.table.eval(download=False, collect_only=True)
-            self._ptrs = (ev.d_viol, ev.d_counts)
-            self._stage_and_exchange()
-            done = 1
-        for _ in range(done, steps):
-            self.table.launch()
-            self._stage_and_exchange()
-        if steps > done:
-            ev = self.table.eval(download=False, collect_only=True)   # the one host synchronisation of the sweep
-            self._ptrs = (ev.d_viol, ev.d_counts)
-        if ev is not None and ev.n_overflow:
-            # reviews that overflow the LDS element capacities are re-run by the big variant only when a pass is
-            # collected, i.e. AFTER its exchange step: their bits would be missing from what the other ranks gathered
-            raise RuntimeError("%d review(s) of this shard need the large-capacity kernel variant; the stream-ordered exchange "
-                               "would gather their bits too early (create the table with resident=True so the plan variant fits "
-                               "the shard's arrays)" % ev.n_overflow)
-        torch.cuda.current_stream().synchronize()
-        if download:
-            self.table.launch()
-            ev = self.table.eval(download=True, collect_only=True)
-        return ev
+        eng = self.client.driver.engine
+        res = None
+        for k in range(steps):
+            out = C.POINTER(L.gk_shard_out)()
+            flags = L.GK_SHARD_DOWNLOAD if (download and k == steps - 1) else 0
+            eng._check(eng.lib.gk_table_sweep_sharded(eng.handle, self.table.handle, flags, C.byref(out)))
+            res = ShardedResult(eng.lib, out)
+        return res
 
-    def _stage_and_exchange(self):
-        d_viol, d_counts = self._ptrs
-        if d_counts == d_viol + self.bm_bytes:
-            # the engine keeps [bitmap | counts] contiguous: gather straight from its buffer, no staging copies
-            if self._alias is None or self._alias_ptr != d_viol:
-                import torch
-                try:
-                    self._alias = torch.as_tensor(_DeviceBytes(d_viol, self.stage.numel()), device=self.stage.device)
-                except Exception:
-                    self._alias = False
-                self._alias_ptr = d_viol
-            if self._alias is not False:
-                self.dist.all_gather_into_tensor(self.gathered_raw, self._alias)
-                return
-        base = self.stage.data_ptr()
-        _d2d(base, d_viol, self.bm_bytes)
-        _d2d(base + self.bm_bytes, d_counts, self.nc * 4)
-        self._exchange()
+    def audit_lists(self, limit=20, msg_size=256):
+        """Cross-shard audit lists (pkg/audit/manager.go:112-203, 885-941): every rank selects and renders the `limit`
+        smallest violations per constraint of ITS shard (device top-k, Client.AuditAggregate's machinery), the candidates
+        are gathered and merged in SVQueue.Less order -- the global `limit` smallest are among the per-shard ones.
+        Needs the shard's objects (constructed with objs=..., keep_docs=True).  -> {constraint key: [violation dict]}"""
+        c = self.client
+        ev = self.table.eval()
+        top = self.table.topk(limit)
+        row = {int(cid): i for i, cid in enumerate(ev.constraint_ids)}
+        mine = {}
+        for cid, (cons, ea, scoped) in c._active(D.AUDIT_EP).items():
+            if cid not in row:
+                continue
+            reviews, overflow = top.get(cid, ([], False))
+            if overflow:
+                reviews = [int(r) for r in D.EvalResult.bits(ev.viol[row[cid]], ev.n_reviews)]
+            cand = []
+            for r in reviews:
+                obj = self.objs[r]
+                g, ver, k = D.obj_gvk(obj)
+                for v in self.table.render(cid, r):
+                    cand.append({"group": g, "version": ver, "kind": k, "namespace": (obj.get("metadata") or {}).get("namespace", "") or "",
+                                 "name": (obj.get("metadata") or {}).get("name", "") or "", "message": D.truncate_string(v["msg"], msg_size),
+                                 "enforcementAction": ea, "enforcementActions": scoped})
+            cand.sort(key=_sv_key)
+            mine[(cons.get("kind", ""), cons.get("apiVersion", ""), (cons.get("metadata") or {}).get("name", ""))] = cand[:limit]
+        everyone = [mine]
+        if self.dist is not None:
+            everyone = [None] * self.dist.get_world_size()
+            self.dist.all_gather_object(everyone, mine)
+        merged = {}
+        for part in everyone:
+            for k, cand in part.items():
+                merged.setdefault(k, []).extend(cand)
+        return {k: sorted(v, key=_sv_key)[:limit] for k, v in merged.items()}
+
+
+def _sv_key(x):
+    """SVQueue.Less (pkg/audit/manager.go:118-138), byte-wise like Go string comparison"""
+    return tuple(s.encode("utf-8") for s in (x["group"], x["version"], x["kind"], x["namespace"], x["name"], x["message"], x["enforcementAction"]))

@@ -173,6 +173,34 @@ typedef struct {
 int gk_table_totals(gk_engine* e, gk_table* t, gk_totals_out** out);
 void gk_totals_free(gk_totals_out* o);
 
+/* ---- multi-GPU audit sweep (row e) ----------------------------------------------------------------------------------
+ * One process / engine per GPU; the audited objects are block-sharded over the ranks (each rank flattens its own shard
+ * into a resident table); policies are replicated.  gk_comm_init joins the engine to an RCCL communicator (rank 0 makes
+ * the id with gk_comm_unique_id and distributes it out of band, e.g. through the launcher's store).  One sweep step
+ * (gk_table_sweep_sharded) = local evaluation of the shard, then ONE exchange on the same stream: an in-place
+ * ncclAllGather of every shard's [violation bitmap | counts] slot and an ncclAllReduce(sum) of the int64 per-constraint
+ * totals, so that every rank ends with the full constraints x objects bitmap and the global totals.  Shards may differ in
+ * size: all slots use the bitmap stride of the largest shard (`stride_tiles`), a shard's own words come first.
+ * Collective: every rank must call it. */
+#define GK_COMM_ID_BYTES 128
+int gk_comm_unique_id(char id[GK_COMM_ID_BYTES]);
+int gk_comm_init(gk_engine* e, const char id[GK_COMM_ID_BYTES], int rank, int world);
+void gk_comm_destroy(gk_engine* e);
+typedef struct {
+  uint32_t world, rank, n_constraints, stride_tiles;
+  uint64_t slot_bytes;               /* bytes per rank in the gathered buffer: [n_constraints][stride_tiles] u64 | [n_constraints] u32 | pad */
+  const uint32_t* constraint_ids;    /* [n_constraints] bitmap-row order */
+  const uint32_t* shard_reviews;     /* [world] objects per shard */
+  const int64_t* totals;             /* [n_constraints] violating (constraint, object) pairs over ALL shards */
+  const uint64_t* gathered;          /* host copy of the gathered buffer (only with GK_SHARD_DOWNLOAD) */
+  const void* d_gathered;            /* the same on the device, valid until the table's next sweep */
+  float kernel_ms, fast_kernel_ms;
+  uint32_t n_overflow;
+} gk_shard_out;
+#define GK_SHARD_DOWNLOAD 1u
+int gk_table_sweep_sharded(gk_engine* e, gk_table* t, uint32_t flags, gk_shard_out** out);
+void gk_shard_free(gk_shard_out* o);
+
 /* ---- resident-set audit (row f2) -----------------------------------------------------------------------------------
  * pkg/audit's auditFromCache reviews, one by one, exactly the objects that were synced into the driver through
  * Driver.AddData (pkg/audit/manager.go:591-642; pkg/cachemanager/cachemanager.go:310-343).  gk_data_put / gk_data_remove

@@ -19,7 +19,7 @@
 
 namespace gk {
 
-struct DevTable { HostTable t; int pending = 0; std::vector<uint64_t> last_viol; };
+struct DevTable { HostTable t; int pending = 0; std::vector<uint64_t> last_viol; std::vector<uint8_t> shard_all; size_t shard_slot = 0; uint32_t shard_stride = 0, shard_nc = 0; };
 typedef void (*HeRowFn)(const Row*, uint32_t, uint32_t, const StrHdr*, const PlanView*, const uint8_t*, std::vector<uint32_t>*);
 typedef void (*HeFormFn)(const PlanView*, std::vector<uint32_t>*, uint32_t, const Row*, const uint8_t*, const uint32_t*, Results*);
 struct DevPlan {
@@ -147,6 +147,48 @@ void dev_topk(const DevTable* t, uint32_t nc, const std::vector<uint32_t>& order
     (*n)[c] = count < cap ? count : cap;
   }
 }
+// ---- sharded exchange on the CPU: the collectives are callbacks supplied by the test (torch.distributed / gloo), the slot
+// layout and the order of operations are those of kernels.hip
+typedef void (*HeAllGather)(void* ctx, void* buf, uint64_t slot_bytes);          // in place: buf = [world][slot_bytes]
+typedef void (*HeAllReduce)(void* ctx, long long* buf, uint64_t n);              // sum, in place
+struct DevComm { int rank = 0, world = 1; HeAllGather gather = nullptr; HeAllReduce reduce = nullptr; void* ctx = nullptr; };
+bool dev_comm_unique_id(char id[128], std::string*) { memset(id, 0, 128); return true; }
+DevComm* dev_comm_init(int, const char*, int, int, std::string* err) { *err = "the CPU emulation takes its collectives from gk_comm_init_host"; return nullptr; }
+DevComm* hostemu_comm(int rank, int world, HeAllGather g, HeAllReduce r, void* ctx) { DevComm* c = new DevComm(); c->rank = rank; c->world = world; c->gather = g; c->reduce = r; c->ctx = ctx; return c; }
+void dev_comm_free(DevComm* c) { delete c; }
+int dev_comm_rank(const DevComm* c) { return c->rank; }
+int dev_comm_world(const DevComm* c) { return c->world; }
+void dev_shard_setup(DevTable* t, DevComm* c, uint32_t nc, ShardInfo* info) {
+  std::vector<unsigned long long> sizes(c->world, 0);
+  sizes[c->rank] = t->t.n_reviews;
+  c->gather(c->ctx, sizes.data(), 8);
+  info->shard_reviews.clear();
+  uint32_t stride = 1;
+  for (int r = 0; r < c->world; r++) { info->shard_reviews.push_back((uint32_t)sizes[r]); stride = std::max<uint32_t>(stride, (uint32_t)((sizes[r] + GK_TILE - 1) / GK_TILE)); }
+  info->stride_tiles = stride;
+  info->slot_bytes = (((size_t)nc * stride * 8 + (size_t)nc * 4) + 15) & ~(size_t)15;
+  t->shard_stride = stride; t->shard_slot = info->slot_bytes; t->shard_nc = nc;
+  t->shard_all.assign((size_t)c->world * info->slot_bytes, 0);
+}
+void dev_shard_exchange(DevTable* t, DevComm* c, uint32_t nc, std::vector<int64_t>* totals, std::vector<uint64_t>* gathered, const void** d_gathered) {
+  if (t->shard_nc != nc || t->shard_all.empty()) throw std::runtime_error("dev_shard_exchange without dev_shard_setup");
+  const uint32_t nt = (t->t.n_reviews + GK_TILE - 1) / GK_TILE;
+  uint8_t* slot = t->shard_all.data() + (size_t)c->rank * t->shard_slot;
+  memset(slot, 0, t->shard_slot);
+  std::vector<long long> tot(nc, 0);
+  for (uint32_t k = 0; k < nc; k++) {
+    uint32_t cnt = 0;
+    for (uint32_t w = 0; w < nt; w++) { const uint64_t v = t->last_viol[(size_t)k * nt + w]; memcpy(slot + ((size_t)k * t->shard_stride + w) * 8, &v, 8); cnt += (uint32_t)__builtin_popcountll(v); }
+    memcpy(slot + (size_t)nc * t->shard_stride * 8 + (size_t)k * 4, &cnt, 4);
+    tot[k] = cnt;
+  }
+  c->gather(c->ctx, t->shard_all.data(), t->shard_slot);
+  c->reduce(c->ctx, tot.data(), nc);
+  totals->assign(tot.begin(), tot.end());
+  if (gathered) { gathered->resize(t->shard_all.size() / 8); memcpy(gathered->data(), t->shard_all.data(), t->shard_all.size()); }
+  if (d_gathered) *d_gathered = t->shard_all.data();
+}
+
 void dev_last_viol(const DevTable* t, uint32_t nc, std::vector<uint64_t>* viol) { (void)nc; *viol = t->last_viol; }
 void dev_eval_launch(const DevPlan*, const DevTable* dt, const EvalOptions&) { const_cast<DevTable*>(dt)->pending++; }
 void dev_eval(const DevPlan* p, const DevTable* dt, const EvalOptions& opt, EvalOut* o) { dev_eval_launch(p, dt, opt); dev_eval_finish(p, dt, opt, o); }
@@ -191,3 +233,11 @@ void dev_eval_finish(const DevPlan* p, const DevTable* dt, const EvalOptions& op
 }
 
 }  // namespace gk
+
+// TEST-ONLY entry point of libgkgpu_hostemu.so: join an engine to a "communicator" whose collectives are callbacks
+// (tests/test_sweep_dist.py wires them to torch.distributed / gloo)
+struct gk_engine;
+extern "C" int gk_comm_init_host_impl(gk_engine* e, gk::DevComm* c);
+extern "C" int gk_comm_init_host(gk_engine* e, int rank, int world, gk::HeAllGather g, gk::HeAllReduce r, void* ctx) {
+  return gk_comm_init_host_impl(e, gk::hostemu_comm(rank, world, g, r, ctx));
+}

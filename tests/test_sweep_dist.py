@@ -1,11 +1,13 @@
-"""Multi-GPU path on CPU: world_size 2, gloo.  Objects are block-sharded across ranks, each rank sweeps its shard and
-the per-shard violation bitmaps are all-gathered together with the per-constraint counts (gatekeeper_amd/sweep.py).
-The gathered result must equal the single-process sweep over all objects, bit for bit."""
+"""Multi-GPU path on CPU: world_size 2, gloo standing in for RCCL.  Each rank flattens and
+evaluates its shard of the audit set through the engine's sharded-sweep entry point (gk_table_sweep_sharded: local
+evaluation, then the in-place all-gather of [bitmap | counts] slots and the all-reduce of int64 totals -- the CPU emulation
+library takes the two collectives as callbacks, the slot layout and the sequence are the product's).  Shards are UNEVEN
+and not multiples of 64.  Every rank must end with the bitmaps, totals and merged top-k audit lists a single process gets."""
 import os
+import pickle
 import socket
 
 import numpy as np
-import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -14,7 +16,7 @@ from gatekeeper_amd import driver as D
 from gatekeeper_amd import synth
 from gatekeeper_amd.sweep import ShardedSweep
 
-N_PER_RANK = 256   # multiple of 64 so shard bitmaps concatenate word-aligned
+SHARDS = [451, 333]   # uneven, not multiples of 64
 
 
 def _client():
@@ -27,36 +29,49 @@ def _client():
     return c
 
 
-def _worker(rank, world, port, out_dir):
+def _objs():
+    objs = synth.gen_objects(sum(SHARDS), seed=21, mixed=True)
+    objs[500] = dict(objs[3])   # the same object key on both shards: ties across shards in the merged lists
+    return objs
 
+
+def _worker(rank, world, port, out_dir):
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
-    objs = synth.gen_objects(N_PER_RANK * world, seed=21, mixed=True)
-    shard = objs[rank * N_PER_RANK:(rank + 1) * N_PER_RANK]
-    sw = ShardedSweep(_client(), shard, synth.gen_namespaces(), dist=dist, device=torch.device("cpu"))
+    objs = _objs()
+    lo = sum(SHARDS[:rank])
+    shard = objs[lo:lo + SHARDS[rank]]
+    sw = ShardedSweep(_client(), shard, synth.gen_namespaces(), dist=dist, device=torch.device("cpu"), keep_docs=True)
     sw.sweep(2)
-    np.save(os.path.join(out_dir, "gathered_%d.npy" % rank), sw.gathered.numpy())
-    np.save(os.path.join(out_dir, "counts_%d.npy" % rank), sw.total_counts.numpy())
+    res = sw.sweep(1, download=True)
+    lists = sw.audit_lists(limit=5)
+    with open(os.path.join(out_dir, "rank_%d.pkl" % rank), "wb") as fh:
+        pickle.dump({"bitmaps": res.bitmaps(), "totals": res.totals, "counts": res.counts(), "shards": res.shard_reviews, "lists": lists,
+                     "ids": res.constraint_ids}, fh)
     dist.destroy_process_group()
 
 
 def test_sharded_sweep_matches_single_process(tmp_path):
-    world = 2
+    world = len(SHARDS)
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
-
-    objs = synth.gen_objects(N_PER_RANK * world, seed=21, mixed=True)
+    objs = _objs()
     nss = synth.gen_namespaces()
     c = _client()
-    rins = [D.to_review_in(D.AugmentedUnstructured(D.Unstructured(o), synth.namespace_for(o, nss), "Original")) for o in objs]
-    ref = c.driver.engine.create_table(rins, keep_docs=False).eval()
-    nc, nt = ref.n_constraints, N_PER_RANK // 64
+    single = ShardedSweep(c, objs, nss, keep_docs=True)
+    ref = single.table.eval()
+    ref_lists = single.audit_lists(limit=5)
+    n = len(objs)
+    ref_bits = np.stack([np.unpackbits(ref.viol[r].view(np.uint8), bitorder="little")[:n] for r in range(ref.n_constraints)])
     for rank in range(world):
-        g = np.load(os.path.join(str(tmp_path), "gathered_%d.npy" % rank)).view(np.uint64).reshape(world, nc, nt)
-        full = np.concatenate([g[r] for r in range(world)], axis=1)
-        assert (full == ref.viol).all(), "rank %d sees a different global bitmap" % rank
-        counts = np.load(os.path.join(str(tmp_path), "counts_%d.npy" % rank))
-        assert (counts == ref.counts.astype(np.int32)).all()
-    assert ref.counts.sum() > 0
+        got = pickle.load(open(os.path.join(str(tmp_path), "rank_%d.pkl" % rank), "rb"))
+        assert list(got["shards"]) == SHARDS and (got["ids"] == ref.constraint_ids).all()
+        bits = np.concatenate([np.stack([np.unpackbits(bm[r].view(np.uint8), bitorder="little")[:SHARDS[k]] for r in range(ref.n_constraints)])
+                               for k, bm in enumerate(got["bitmaps"])], axis=1)
+        assert (bits == ref_bits).all(), "rank %d sees a different global bitmap" % rank
+        assert (got["totals"] == ref.counts.astype(np.int64)).all()                 # all-reduced int64 totals
+        assert (got["counts"].sum(0) == ref.counts).all()                          # = sum of the gathered per-shard counts
+        assert got["lists"] == ref_lists                                           # merged top-k == single-process LimitQueue
+    assert ref.counts.sum() > 0 and sum(len(v) for v in ref_lists.values()) > 20
