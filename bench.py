@@ -90,6 +90,9 @@ def main():
     if world > 1 or os.environ.get("GK_FORCE_DIST"):   # GK_FORCE_DIST=1: exercise the sharded path on one GPU (world size 1)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     assert torch.cuda.is_available(), "bench.py needs an MI355X (there is no CPU fallback)"
