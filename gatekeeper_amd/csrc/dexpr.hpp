@@ -1,0 +1,105 @@
+// Leaf-local expressions ("dictionary predicates").
+//
+// Some template logic is a pure function of ONE review leaf: the quantity parsing of K8sContainerLimits
+// (demo/agilebank/templates/k8scontainterlimits_template.yaml: canonify_cpu / canonify_mem -- replace, substring, to_number,
+// re_match, arithmetic, a dozen function bodies) decides "is this cpu limit above 200m" from the limit string alone.  The
+// device has no string arithmetic -- and needs none: the partial evaluator records such a computation as an expression tree
+// over the leaf (DExpr), the lowering folds every boolean sub-formula that talks about a single leaf into ONE expression,
+// and the FLATTENER evaluates it with the concrete builtins once per distinct value of that column (memoised), shipping
+// the answers as a bit mask in a synthetic integer row next to the leaf (path + "$d").  On the device the predicate is a
+// bit test (P_BITS).  Exact by construction: the bits are computed by the same evaluator that renders the messages.
+#pragma once
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "builtins.hpp"
+#include "value.hpp"
+
+namespace gk {
+
+struct Atom;   // pe.hpp
+
+struct DExpr;
+typedef std::shared_ptr<const DExpr> DX;
+struct DExpr {
+  enum Kind { LEAF, CONST, CALL, ARITH, CMP, DEFINED, TRUTHY, AND, OR, NOT, TYPE_MASK } kind = LEAF;
+  Value c;                  // CONST
+  std::string name;         // CALL builtin name / ARITH operator
+  int cmp = 0;              // CMP: CmpOp
+  uint32_t mask = 0;        // TYPE_MASK: bit per RowType of the leaf-derived value
+  std::vector<DX> args;
+};
+
+inline DX dx_leaf() { static thread_local DX l = std::make_shared<const DExpr>(); return l; }
+inline DX dx_const(const Value& v) { DExpr e; e.kind = DExpr::CONST; e.c = v; return std::make_shared<const DExpr>(e); }
+inline DX dx_node(DExpr::Kind k, std::vector<DX> args, const std::string& name = "", int cmp = 0, uint32_t mask = 0) {
+  DExpr e; e.kind = k; e.args = std::move(args); e.name = name; e.cmp = cmp; e.mask = mask;
+  return std::make_shared<const DExpr>(e);
+}
+
+inline std::string dx_to_string(const DX& e) {
+  static const char* cmpn[] = {"==", "!=", "<", "<=", ">", ">="};
+  switch (e->kind) {
+    case DExpr::LEAF: return "$";
+    case DExpr::CONST: return to_term_string(e->c);
+    case DExpr::CALL: { std::string o = e->name + "("; for (size_t i = 0; i < e->args.size(); i++) { if (i) o += ","; o += dx_to_string(e->args[i]); } return o + ")"; }
+    case DExpr::ARITH: return "(" + dx_to_string(e->args[0]) + e->name + dx_to_string(e->args[1]) + ")";
+    case DExpr::CMP: return "(" + dx_to_string(e->args[0]) + cmpn[e->cmp] + dx_to_string(e->args[1]) + ")";
+    case DExpr::DEFINED: return "def(" + dx_to_string(e->args[0]) + ")";
+    case DExpr::TRUTHY: return "truthy(" + dx_to_string(e->args[0]) + ")";
+    case DExpr::NOT: return "!(" + dx_to_string(e->args[0]) + ")";
+    case DExpr::TYPE_MASK: return "type(" + dx_to_string(e->args[0]) + ")&" + std::to_string(e->mask);
+    case DExpr::AND: case DExpr::OR: {
+      std::string o = "(";
+      for (size_t i = 0; i < e->args.size(); i++) { if (i) o += e->kind == DExpr::AND ? " & " : " | "; o += dx_to_string(e->args[i]); }
+      return o + ")";
+    }
+  }
+  return "?";
+}
+
+inline bool dx_cmp_holds(int c, int op) {
+  switch (op) { case 0: return c == 0; case 1: return c != 0; case 2: return c < 0; case 3: return c <= 0; case 4: return c > 0; default: return c >= 0; }
+}
+
+// value of the expression for a concrete leaf; Undefined propagates (a builtin error / undefined operand)
+inline Value dx_eval(const DX& e, const Value& leaf) {
+  switch (e->kind) {
+    case DExpr::LEAF: return leaf;
+    case DExpr::CONST: return e->c;
+    case DExpr::CALL: {
+      ValueVec av;
+      for (auto& a : e->args) { Value v = dx_eval(a, leaf); if (!v.defined()) return Value(); av.push_back(v); }
+      return call_builtin(e->name, av);
+    }
+    case DExpr::ARITH: {
+      Value a = dx_eval(e->args[0], leaf), b = dx_eval(e->args[1], leaf);
+      if (!a.defined() || !b.defined()) return Value();
+      return rego_arith(e->name, a, b);
+    }
+    case DExpr::CMP: {
+      Value a = dx_eval(e->args[0], leaf), b = dx_eval(e->args[1], leaf);
+      if (!a.defined() || !b.defined()) return Value::boolean(false);
+      return Value::boolean(dx_cmp_holds(compare(a, b), e->cmp));
+    }
+    case DExpr::DEFINED: return Value::boolean(dx_eval(e->args[0], leaf).defined());
+    case DExpr::TRUTHY: { Value v = dx_eval(e->args[0], leaf); return Value::boolean(v.defined() && !(v.is_bool() && !v.b)); }
+    case DExpr::NOT: { Value v = dx_eval(e->args[0], leaf); return Value::boolean(!(v.is_bool() && v.b)); }
+    case DExpr::TYPE_MASK: {
+      Value v = dx_eval(e->args[0], leaf);
+      if (!v.defined()) return Value::boolean(false);
+      // RowType bits (plan.hpp): null 0, bool 1, int 2, float 3, string 4, object 5, array 6
+      uint32_t t = v.is_null() ? 0 : v.is_bool() ? 1 : v.is_number() ? ((v.is_int && v.i >= (i128)INT64_MIN && v.i <= (i128)INT64_MAX) ? 2 : 3) : v.is_string() ? 4 : v.is_object() ? 5 : 6;
+      uint32_t m = e->mask;
+      if (m & ((1u << 2) | (1u << 3))) m |= (1u << 2) | (1u << 3);   // "number" masks carry both numeric row types
+      return Value::boolean(((1u << t) & m) != 0);
+    }
+    case DExpr::AND: { for (auto& a : e->args) { Value v = dx_eval(a, leaf); if (!(v.is_bool() && v.b)) return Value::boolean(false); } return Value::boolean(true); }
+    case DExpr::OR: { for (auto& a : e->args) { Value v = dx_eval(a, leaf); if (v.is_bool() && v.b) return Value::boolean(true); } return Value::boolean(false); }
+  }
+  return Value();
+}
+inline bool dx_true(const DX& e, const Value& leaf) { Value v = dx_eval(e, leaf); return v.is_bool() && v.b; }
+
+}  // namespace gk

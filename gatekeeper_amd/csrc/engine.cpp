@@ -135,6 +135,7 @@ std::string autoreject_message(const Value& match, const ReviewDoc& doc) {
 struct gk_engine {
   gk_opts opts{};
   PathDict dict;
+  DictRegistry dict_reg;     // leaf-local expressions of the loaded constraints (dexpr.hpp): evaluated by the flattener
   NsCache ns_cache;
   std::shared_mutex mu;   // templates / constraints / inventory
   std::map<std::string, std::shared_ptr<Template>> templates;   // lower(kind)
@@ -229,6 +230,7 @@ struct gk_table {
   std::vector<uint32_t> last_ids;
   uint32_t n_reviews = 0;
   uint32_t rpt = GK_RPT_MIN;                // reviews per row group of this table
+  uint64_t dict_gen = 0;                    // generation of the dictionary-predicate registry the rows were flattened under
   ShardInfo shard;                          // sharded sweeps: slot layout agreed with the other ranks
   uint64_t shard_gen = 0;
   gk_table_stats stats{};
@@ -285,7 +287,7 @@ DevPlan* plan_for_table(gk_engine* e, gk_table* t, const HostPlan** host) {
   if (it == e->variants.end()) {
     std::unique_ptr<gk_engine::Variant> v(new gk_engine::Variant());
     try {
-      PlanBuilder pb(&e->dict);
+      PlanBuilder pb(&e->dict, &e->dict_reg);
       for (auto& c : e->constraints) if (c.alive) pb.add_constraint(c.viol, c.mf);
       PlanCaps pc = default_caps(e);
       pc.scope_cap = caps;
@@ -323,7 +325,7 @@ void ensure_plan(gk_engine* e) {
     // contributes one violation and one match formula), halved further while a chunk still does not lower
     std::vector<std::vector<const ConstraintRec*>> groups;
     auto builds = [&](const std::vector<const ConstraintRec*>& g, HostPlan* fast, HostPlan* big) {
-      PlanBuilder pb(&e->dict);
+      PlanBuilder pb(&e->dict, &e->dict_reg);
       for (auto* c : g) pb.add_constraint(c->viol, c->mf);
       *fast = pb.build(default_caps(e));
       *big = pb.build(bigcaps);
@@ -459,7 +461,7 @@ int gk_constraint_add(gk_engine* e, const char* json, size_t len, uint32_t* id_o
     rec.mf = compile_match(rec.match);
     // validate that it lowers (element scopes, register pressure) before accepting it
     {
-      PlanBuilder pb(&e->dict);
+      PlanBuilder pb(&e->dict, &e->dict_reg);
       pb.add_constraint(rec.viol, rec.mf);
       PlanCaps caps;
       pb.build(caps);
@@ -607,6 +609,7 @@ int gk_table_create(gk_engine* e, const gk_review_in* reviews, size_t n, uint32_
     uint32_t rpt = n >= 8192 ? 256 : GK_RPT_MIN;
     if (const char* rp = getenv("GK_RPT")) { int v = atoi(rp); if (v == 64 || v == 128 || v == 256 || v == 512) rpt = (uint32_t)v; }
     t->rpt = rpt;
+    t->dict_gen = e->dict_reg.gen();
     const size_t n_tiles = (n + rpt - 1) / rpt;
     size_t n_threads = std::max<size_t>(1, std::min<size_t>(std::thread::hardware_concurrency(), (n + 511) / 512));
     if (const char* ht = getenv("GK_HOST_THREADS")) n_threads = std::max(1, atoi(ht));
@@ -618,7 +621,7 @@ int gk_table_create(gk_engine* e, const gk_review_in* reviews, size_t n, uint32_
     std::vector<uint64_t> part_fast(n_threads, 0);
     auto work = [&](size_t w) {
       try {
-        Flattener fl(&e->dict);
+        Flattener fl(&e->dict, &e->dict_reg);
         parts[w].rpt = rpt;
         const size_t lo = std::min(n, w * tiles_per * rpt), hi = std::min(n, (w + 1) * tiles_per * rpt);
         for (size_t i = lo; i < hi; i++) {
@@ -798,6 +801,8 @@ int gk_table_eval(gk_engine* e, gk_table* t, uint32_t flags, gk_eval_out** out) 
   if (!e || !t || !out) return fail(GK_ERR_INVALID, "NULL argument");
   try {
     ensure_plan(e);
+    if (t->dict_gen != e->dict_reg.gen())
+      return fail(GK_ERR_INVALID, "the table was flattened before a constraint with dictionary predicates was added (its <leaf>.$d rows are missing): create it again");
     std::unique_ptr<EvalHolder> h(new EvalHolder());
     EvalOptions opt;
     opt.download = !(flags & GK_EVAL_NO_DOWNLOAD);
@@ -1185,6 +1190,7 @@ int gk_table_sweep_sharded(gk_engine* e, gk_table* t, uint32_t flags, gk_shard_o
   if (!e->comm) return fail(GK_ERR_INVALID, "gk_comm_init first");
   try {
     ensure_plan(e);
+    if (t->dict_gen != e->dict_reg.gen()) return fail(GK_ERR_INVALID, "the table was flattened before a constraint with dictionary predicates was added: create it again");
     std::unique_ptr<ShardHolder> h(new ShardHolder());
     std::lock_guard<std::mutex> l(e->plan_mu);
     if (!e->extra.empty()) return fail(GK_ERR_UNSUPPORTED, "sharded sweeps need the constraint set in one plan group (more than 64 distinct formulas loaded)");
@@ -1271,7 +1277,9 @@ int gk_resident_sweep(gk_engine* e, uint32_t flags, gk_sweep_out** out) {
     uint64_t flattened = 0;
     // compaction: when masked-out slots outnumber the live ones (or the chunks have piled up) everything is flattened
     // again into one chunk
-    if (R.n_dead_slots > R.n_live + 1024 || R.chunks.size() > 16) {
+    bool stale_rows = false;   // a constraint with dictionary predicates arrived: every chunk lacks its <leaf>.$d rows
+    for (auto& c : R.chunks) stale_rows = stale_rows || c.table->dict_gen != e->dict_reg.gen();
+    if (stale_rows || R.n_dead_slots > R.n_live + 1024 || R.chunks.size() > 16) {
       for (auto& c : R.chunks) resident_drop_chunk(c);
       R.chunks.clear();
       R.pending.clear();

@@ -66,6 +66,57 @@ uint32_t hash32(const uint8_t* p, size_t n) {
   return h;
 }
 
+// ------------------------------------------------------------------------------------------------ patterns / registry
+std::string pattern_to_string(const Pattern& p) {
+  std::string o = "review";
+  for (const PatStep& s : p) {
+    if (!s.any) { o += "." + s.key; continue; }
+    o += s.elems_only ? "[]" : "[*";
+    for (auto& k : s.only) o += "=" + k;
+    for (auto& k : s.except) o += "!" + k;
+    if (!s.elems_only) o += "]";
+  }
+  return o;
+}
+
+// does the concrete dictionary path `id` match the pattern (same rules as HostPlan::resolve_paths)?
+bool pattern_matches(const Pattern& pat, const PathDict& dict, uint32_t id) {
+  std::vector<PathDict::Info> chain;
+  while (id != 0 && id != PathDict::kNone) { chain.push_back(dict.info(id)); id = chain.back().parent; }
+  if (chain.size() != pat.size()) return false;
+  for (size_t i = 0; i < pat.size(); i++) {
+    const PathDict::Info& in = chain[chain.size() - 1 - i];
+    const PatStep& st = pat[i];
+    if (!st.any) { if (in.is_elem || in.key != st.key) return false; continue; }
+    if (in.is_elem) { if (!st.only.empty()) return false; continue; }
+    if (st.elems_only) return false;
+    if (!st.only.empty() && std::find(st.only.begin(), st.only.end(), in.key) == st.only.end()) return false;
+    if (std::find(st.except.begin(), st.except.end(), in.key) != st.except.end()) return false;
+  }
+  return true;
+}
+
+uint32_t DictRegistry::intern(const Pattern& leaf, const DX& dx) {
+  const std::string pk = pattern_to_string(leaf), dk = dx_to_string(dx);
+  std::unique_lock<std::shared_mutex> l(mu_);
+  Pat* p = nullptr;
+  for (auto& x : pats_) if (x.key == pk) p = &x;
+  if (!p) { pats_.push_back({leaf, pk, {}}); p = &pats_.back(); }
+  for (auto& e : p->entries) if (e.key == dk) return e.bit;
+  if (p->entries.size() >= 62) throw std::runtime_error("more than 62 dictionary predicates on " + pk);
+  p->entries.push_back({dx, dk, (uint32_t)p->entries.size()});
+  gen_++;
+  return p->entries.back().bit;
+}
+uint64_t DictRegistry::gen() const { std::shared_lock<std::shared_mutex> l(mu_); return gen_; }
+void DictRegistry::match(const PathDict& dict, uint32_t path_id, std::vector<DictEntry>* out) const {
+  std::shared_lock<std::shared_mutex> l(mu_);
+  out->clear();
+  // several patterns may cover one concrete path: their bit numbers are per PATTERN, so only one pattern may own a path's
+  // $d row -- the lowering registers element / key iterations in canonical form, which makes overlapping patterns equal
+  for (const auto& p : pats_) if (pattern_matches(p.pat, dict, path_id)) { if (!out->empty()) throw std::runtime_error("overlapping dictionary patterns on " + dict.to_string(path_id)); *out = p.entries; }
+}
+
 // ------------------------------------------------------------------------------------------------ NsCache
 void NsCache::put(const std::string& name, const Value& ns) { std::unique_lock<std::shared_mutex> l(mu_); m_[name] = ns; }
 void NsCache::remove(const std::string& name) { std::unique_lock<std::shared_mutex> l(mu_); m_.erase(name); }
@@ -182,7 +233,7 @@ ReviewDoc normalize_object(const Value& object, const Value& match_ns, const Val
 }
 
 // ------------------------------------------------------------------------------------------------ Flattener
-Flattener::Flattener(PathDict* dict) : dict_(dict) {
+Flattener::Flattener(PathDict* dict, const DictRegistry* reg) : dict_(dict), reg_(reg) {
   id_object_ = dict_->child(0, "object");
   id_old_ = dict_->child(0, "oldObject");
   id_m_ = dict_->child(0, "$m");
@@ -198,6 +249,35 @@ Flattener::Flattener(PathDict* dict) : dict_(dict) {
     c.gname = dict_->child(c.metadata, "generateName");
     c.labels = dict_->child(c.metadata, "labels");
   }
+}
+
+// is a dictionary predicate registered for this leaf path? (cached per path; the cache follows the registry's generation)
+bool Flattener::dict_wanted(uint32_t path) {
+  if (!reg_) return false;
+  if (path >= dict_paths_.size()) dict_paths_.resize((size_t)path * 2 + 64);
+  DictPath& d = dict_paths_[path];
+  if (d.state == 0) {
+    reg_->match(*dict_, path, &d.entries);
+    d.state = d.entries.empty() ? 1 : 2;
+    if (d.state == 2) d.dpath = child(path, "$d");
+  }
+  return dict_paths_[path].state == 2;
+}
+
+void Flattener::dict_row(uint32_t path, uint32_t meta, const Value& leaf) {
+  DictPath& d = dict_paths_[path];
+  // containers count by type and size only (the registered expressions cannot look inside them: pe.cpp scalar_fns)
+  std::string key = (leaf.is_array() || leaf.is_object() || leaf.is_set()) ? std::to_string(leaf.size()) : to_term_string(leaf);
+  key.push_back((char)('0' + (int)leaf.kind));
+  auto it = d.memo.find(key);
+  uint64_t mask;
+  if (it != d.memo.end()) mask = it->second;
+  else {
+    mask = 0;
+    for (const DictEntry& e : d.entries) if (dx_true(e.dx, leaf)) mask |= 1ull << e.bit;
+    if (d.memo.size() < 65536) d.memo.emplace(std::move(key), mask);
+  }
+  if (mask) emit(d.dpath, (meta & ~(uint32_t)ROW_TYPE_MASK & ~(uint32_t)ROW_STR_INLINE) | T_INT, (uint32_t)mask, (uint32_t)(mask >> 32));
 }
 
 void Flattener::emit(uint32_t path, uint32_t meta, uint32_t lo, uint32_t hi) {
@@ -245,9 +325,10 @@ uint32_t Flattener::elem(uint32_t parent) {
 void Flattener::walk(const Value& v, uint32_t path, uint32_t ords, int adepth, uint32_t extra) {
   uint32_t meta = ords | extra;
   switch (v.kind) {
-    case Value::Null: emit(path, meta | T_NULL, 0, 0); break;
-    case Value::Bool: emit(path, meta | T_BOOL, v.b ? 1 : 0, 0); break;
+    case Value::Null: emit(path, meta | T_NULL, 0, 0); if (dict_wanted(path)) dict_row(path, meta, v); break;
+    case Value::Bool: emit(path, meta | T_BOOL, v.b ? 1 : 0, 0); if (dict_wanted(path)) dict_row(path, meta, v); break;
     case Value::Number:
+      if (dict_wanted(path)) dict_row(path, meta, v);
       if (v.is_int && v.i >= (i128)INT64_MIN && v.i <= (i128)INT64_MAX) {
         uint64_t u = (uint64_t)(int64_t)v.i;
         emit(path, meta | T_INT, (uint32_t)u, (uint32_t)(u >> 32));
@@ -258,14 +339,16 @@ void Flattener::walk(const Value& v, uint32_t path, uint32_t ords, int adepth, u
         emit(path, meta | T_FLOAT | (v.is_int ? ROW_INEXACT : 0), (uint32_t)u, (uint32_t)(u >> 32));
       }
       break;
-    case Value::String: emit_string_row(path, meta, v.str()); break;
+    case Value::String: emit_string_row(path, meta, v.str()); if (dict_wanted(path)) dict_row(path, meta, v); break;
     case Value::Object: {
       emit(path, meta | T_OBJECT, (uint32_t)v.size(), 0);
+      if (dict_wanted(path)) dict_row(path, meta, v);
       for (const auto& kv : v.pairs()) walk(kv.second, child(path, kv.first.str()), ords, adepth, extra);
       break;
     }
     case Value::Array: case Value::Set: {
       emit(path, meta | T_ARRAY, (uint32_t)v.size(), 0);
+      if (dict_wanted(path)) dict_row(path, meta, v);
       uint32_t ep = elem(path);
       Ctr* c = nullptr;
       for (auto& x : ctrs_) if (x.path == ep) { c = &x; break; }
@@ -572,7 +655,7 @@ int Flattener::fast_value(uint32_t path, uint32_t ords, int adepth, uint32_t ext
     const uint32_t inst = ++obj_instance_;
     uint32_t count = 0;
     ws();
-    if (p_ < e_ && *p_ == '}') { p_++; return T_OBJECT; }
+    if (p_ < e_ && *p_ == '}') { p_++; if (dict_wanted(path)) dict_row(path, meta, Value::object({})); return T_OBJECT; }
     const CapIds* cap = nullptr;
     if (cur_facts_ && depth <= 1) cap = &cap_[cur_root_ == id_old_ ? 1 : 0];
     for (;;) {
@@ -601,6 +684,7 @@ int Flattener::fast_value(uint32_t path, uint32_t ords, int adepth, uint32_t ext
           const char* v; uint32_t vn;
           if (!fast_string(&v, &vn)) return -1;
           emit_str_n(ch, meta, v, vn);
+          if (dict_wanted(ch)) dict_row(ch, meta, Value::string(std::string(v, vn)));
           if (v == scratch_.data()) { scratch_keep_.emplace_back(new std::string(v, vn)); v = scratch_keep_.back()->data(); }
           want->p = v; want->n = vn; want->set = true;
           t = T_STRING;
@@ -616,6 +700,7 @@ int Flattener::fast_value(uint32_t path, uint32_t ords, int adepth, uint32_t ext
       return -1;
     }
     stage_[row].row.lo = count;
+    if (dict_wanted(path)) { ValuePairs ph; for (uint32_t k = 0; k < count; k++) ph.emplace_back(Value::integer((i128)k), Value::null()); dict_row(path, meta, Value::object(std::move(ph))); }
     return T_OBJECT;
   }
   if (c == '[') {
@@ -624,7 +709,7 @@ int Flattener::fast_value(uint32_t path, uint32_t ords, int adepth, uint32_t ext
     emit(path, meta | T_ARRAY, 0, 0);
     uint32_t count = 0;
     ws();
-    if (p_ < e_ && *p_ == ']') { p_++; return T_ARRAY; }
+    if (p_ < e_ && *p_ == ']') { p_++; if (dict_wanted(path)) dict_row(path, meta, Value::array({})); return T_ARRAY; }
     const uint32_t ep = elem(path);
     if (ep >= ctr_gen_.size()) { ctr_gen_.resize((size_t)ep * 2 + 64, 0); ctr_val_.resize(ctr_gen_.size(), 0); }
     if (ctr_gen_[ep] != review_gen_) { ctr_gen_[ep] = review_gen_; ctr_val_[ep] = 0; ctr_touched_.push_back(ep); }
@@ -643,17 +728,19 @@ int Flattener::fast_value(uint32_t path, uint32_t ords, int adepth, uint32_t ext
       return -1;
     }
     stage_[row].row.lo = count;
+    if (dict_wanted(path)) dict_row(path, meta, Value::array(ValueVec(count, Value::null())));
     return T_ARRAY;
   }
   if (c == '"') {
     const char* v; uint32_t vn;
     if (!fast_string(&v, &vn)) return -1;
     emit_str_n(path, meta, v, vn);
+    if (dict_wanted(path)) dict_row(path, meta, Value::string(std::string(v, vn)));
     return T_STRING;
   }
-  if (c == 't') { if (e_ - p_ < 4 || memcmp(p_, "true", 4) != 0) return -1; p_ += 4; emit(path, meta | T_BOOL, 1, 0); return T_BOOL; }
-  if (c == 'f') { if (e_ - p_ < 5 || memcmp(p_, "false", 5) != 0) return -1; p_ += 5; emit(path, meta | T_BOOL, 0, 0); return T_BOOL; }
-  if (c == 'n') { if (e_ - p_ < 4 || memcmp(p_, "null", 4) != 0) return -1; p_ += 4; emit(path, meta | T_NULL, 0, 0); return T_NULL; }
+  if (c == 't') { if (e_ - p_ < 4 || memcmp(p_, "true", 4) != 0) return -1; p_ += 4; emit(path, meta | T_BOOL, 1, 0); if (dict_wanted(path)) dict_row(path, meta, Value::boolean(true)); return T_BOOL; }
+  if (c == 'f') { if (e_ - p_ < 5 || memcmp(p_, "false", 5) != 0) return -1; p_ += 5; emit(path, meta | T_BOOL, 0, 0); if (dict_wanted(path)) dict_row(path, meta, Value::boolean(false)); return T_BOOL; }
+  if (c == 'n') { if (e_ - p_ < 4 || memcmp(p_, "null", 4) != 0) return -1; p_ += 4; emit(path, meta | T_NULL, 0, 0); if (dict_wanted(path)) dict_row(path, meta, Value::null()); return T_NULL; }
   // number: JsonParser::number + Flattener::walk
   const char* s = p_;
   bool is_int = true, neg = false;
@@ -673,10 +760,12 @@ int Flattener::fast_value(uint32_t path, uint32_t ords, int adepth, uint32_t ext
     for (size_t k = 0; k < nd; k++) x = x * 10 + (digits[k] - '0');
     if (neg) x = -x;
     emit(path, meta | T_INT, (uint32_t)(uint64_t)x, (uint32_t)((uint64_t)x >> 32));
+    if (dict_wanted(path)) dict_row(path, meta, Value::integer((i128)x));
     return T_INT;
   }
   {   // the general number rules, through the same Value code the tree walk uses
     Value v = parse_json(s, p_ - s);
+    if (dict_wanted(path)) dict_row(path, meta, v);
     if (v.is_int && v.i >= (i128)INT64_MIN && v.i <= (i128)INT64_MAX) {
       uint64_t u = (uint64_t)(int64_t)v.i;
       emit(path, meta | T_INT, (uint32_t)u, (uint32_t)(u >> 32));

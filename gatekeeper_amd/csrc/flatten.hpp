@@ -15,6 +15,7 @@
 #include <unordered_map>
 #include <vector>
 
+#include "dexpr.hpp"
 #include "plan.hpp"
 #include "value.hpp"
 
@@ -47,6 +48,34 @@ class PathDict {
   std::unordered_map<std::pair<uint32_t, std::string>, uint32_t, KeyHash> map_;
   std::vector<Info> infos_;
   uint32_t intern(uint32_t parent, const std::string& key, bool is_elem);
+};
+
+// ------------------------------------------------------------------------------------------------ path patterns
+struct PatStep {
+  bool any = false;                 // true: any single step
+  bool elems_only = false;          // any: only "[]" children (array-element scopes)
+  std::string key;                  // !any: exact member name
+  std::vector<std::string> only;    // any: member name must be one of (key iteration with ==)
+  std::vector<std::string> except;  // any: member name must not be one of
+};
+typedef std::vector<PatStep> Pattern;
+std::string pattern_to_string(const Pattern& p);
+bool pattern_matches(const Pattern& pat, const PathDict& dict, uint32_t path_id);
+
+// ------------------------------------------------------------------------------------------------ dictionary predicates
+// Leaf-local expressions (dexpr.hpp) registered by the loaded constraints: pattern of the leaf -> expressions, each with a
+// bit.  The flattener evaluates them per distinct leaf value and ships the answers as an integer row at <leaf>.$d.
+struct DictEntry { DX dx; std::string key; uint32_t bit; };
+class DictRegistry {
+ public:
+  uint32_t intern(const Pattern& leaf, const DX& dx);   // bit of the expression on leaves matching `leaf`; throws std::runtime_error beyond 62 bits
+  uint64_t gen() const;                                  // bumped by every new entry
+  void match(const PathDict& dict, uint32_t path_id, std::vector<DictEntry>* out) const;   // entries for a concrete leaf path
+ private:
+  struct Pat { Pattern pat; std::string key; std::vector<DictEntry> entries; };
+  mutable std::shared_mutex mu_;
+  std::vector<Pat> pats_;
+  uint64_t gen_ = 0;
 };
 
 uint32_t hash32(const uint8_t* p, size_t n);
@@ -159,7 +188,7 @@ struct RawReview {
 
 class Flattener {
  public:
-  explicit Flattener(PathDict* dict);
+  explicit Flattener(PathDict* dict, const DictRegistry* reg = nullptr);
   void add(const ReviewDoc& doc, HostTable* out);
   // Fast ingest: ONE pass over the JSON text of a review straight into rows -- no Value
   // tree -- including HandleReview's normalisation (target.go:81-179, 269-287) and the match-layer facts.  Produces
@@ -174,6 +203,12 @@ class Flattener {
 
  private:
   PathDict* dict_;
+  const DictRegistry* reg_ = nullptr;
+  uint64_t reg_gen_ = ~0ull;
+  struct DictPath { int state = 0; std::vector<DictEntry> entries; uint32_t dpath = 0; std::unordered_map<std::string, uint64_t> memo; };   // state 0 unknown, 1 none, 2 has entries
+  std::vector<DictPath> dict_paths_;
+  void dict_row(uint32_t path, uint32_t meta, const Value& leaf);   // emits <leaf>.$d when some registered expression is true
+  bool dict_wanted(uint32_t path);
   uint32_t id_object_, id_old_, id_m_, id_ns_;
   struct Ctr { uint32_t path, n; };
   std::vector<Ctr> ctrs_;

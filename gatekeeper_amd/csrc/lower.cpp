@@ -243,18 +243,6 @@ MatchFormulas compile_match(const Value& m) {
 }
 
 // ================================================================================================ lowering
-std::string pattern_to_string(const Pattern& p) {
-  std::string o = "review";
-  for (const PatStep& s : p) {
-    if (!s.any) { o += "." + s.key; continue; }
-    o += s.elems_only ? "[]" : "[*";
-    for (auto& k : s.only) o += "=" + k;
-    for (auto& k : s.except) o += "!" + k;
-    if (!s.elems_only) o += "]";
-  }
-  return o;
-}
-
 namespace {
 
 void conjuncts(const FP& f, std::vector<FP>& out) {
@@ -388,6 +376,178 @@ FP simplify(const FP& f) {
   }
 }
 
+FP rename_f(const FP& f, const std::map<int, int>& m);
+
+// ---- dictionary predicates (dexpr.hpp): every boolean sub-formula that talks about ONE leaf only and contains a DICT atom
+// becomes a single DICT atom, evaluated by the flattener per distinct value of that leaf.
+bool dict_foldable_atom(const Atom& a) {
+  switch (a.kind) {
+    case Atom::DICT: case Atom::TYPE: case Atom::TRUTHY: case Atom::DEFINED: case Atom::STR_PREFIX: case Atom::STR_SUFFIX: case Atom::STR_CONTAINS:
+    case Atom::STR_IN_SET: case Atom::STR_REGEX: case Atom::COUNT_CMP: return true;
+    case Atom::CMP: return !(a.k.is_array() || a.k.is_object() || a.k.is_set());
+    default: return false;
+  }
+}
+// leaf of a leaf-local formula ("" = not leaf-local); has_dict: it contains a DICT atom
+std::string leaf_of(const FP& f, bool* has_dict) {
+  switch (f->kind) {
+    case FNode::ATOM:
+      if (!dict_foldable_atom(f->atom)) return "";
+      if (f->atom.kind == Atom::DICT) *has_dict = true;
+      return spath_to_string(f->atom.path);
+    case FNode::NOT: return leaf_of(f->kids[0], has_dict);
+    case FNode::AND: case FNode::OR: {
+      std::string l;
+      for (auto& k : f->kids) { std::string x = leaf_of(k, has_dict); if (x.empty() || (!l.empty() && x != l)) return ""; l = x; }
+      return l;
+    }
+    default: return "";
+  }
+}
+// is the formula false whenever its leaf is absent? (device predicates only fire on rows that exist)
+bool needs_leaf(const FP& f) {
+  switch (f->kind) {
+    case FNode::ATOM: return true;
+    case FNode::AND: for (auto& k : f->kids) if (needs_leaf(k)) return true; return false;
+    case FNode::OR: for (auto& k : f->kids) if (!needs_leaf(k)) return false; return true;
+    default: return false;
+  }
+}
+const SPath* leaf_path_of(const FP& f) {
+  if (f->kind == FNode::ATOM) return &f->atom.path;
+  for (auto& k : f->kids) if (const SPath* p = leaf_path_of(k)) return p;
+  return nullptr;
+}
+DX to_dx(const FP& f) {
+  switch (f->kind) {
+    case FNode::T: return dx_const(Value::boolean(true));
+    case FNode::F: return dx_const(Value::boolean(false));
+    case FNode::NOT: return dx_node(DExpr::NOT, {to_dx(f->kids[0])});
+    case FNode::AND: case FNode::OR: { std::vector<DX> a; for (auto& k : f->kids) a.push_back(to_dx(k)); return dx_node(f->kind == FNode::AND ? DExpr::AND : DExpr::OR, a); }
+    case FNode::ATOM: {
+      const Atom& a = f->atom;
+      switch (a.kind) {
+        case Atom::DICT: return a.dx;
+        case Atom::DEFINED: return dx_const(Value::boolean(true));   // the expression is only evaluated for leaves that exist
+        case Atom::TRUTHY: return dx_node(DExpr::TRUTHY, {dx_leaf()});
+        case Atom::TYPE: return dx_node(DExpr::TYPE_MASK, {dx_leaf()}, "", 0, a.mask);
+        case Atom::CMP: return dx_node(DExpr::CMP, {dx_leaf(), dx_const(a.k)}, "", a.cmp);
+        case Atom::STR_PREFIX: return dx_node(DExpr::TRUTHY, {dx_node(DExpr::CALL, {dx_leaf(), dx_const(a.k)}, "startswith")});
+        case Atom::STR_SUFFIX: return dx_node(DExpr::TRUTHY, {dx_node(DExpr::CALL, {dx_leaf(), dx_const(a.k)}, "endswith")});
+        case Atom::STR_CONTAINS: return dx_node(DExpr::TRUTHY, {dx_node(DExpr::CALL, {dx_leaf(), dx_const(a.k)}, "contains")});
+        case Atom::STR_REGEX: return dx_node(DExpr::TRUTHY, {dx_node(DExpr::CALL, {dx_const(a.k), dx_leaf()}, "re_match")});
+        case Atom::COUNT_CMP:   // member count of a container leaf (the flattener hands containers over with their size)
+          return dx_node(DExpr::AND, {dx_node(DExpr::TYPE_MASK, {dx_leaf()}, "", 0, (1u << T_ARRAY) | (1u << T_OBJECT)), dx_node(DExpr::CMP, {dx_node(DExpr::CALL, {dx_leaf()}, "count"), dx_const(a.k)}, "", a.cmp)});
+        case Atom::STR_IN_SET: { std::vector<DX> alts; for (auto& v : a.k.items()) alts.push_back(dx_node(DExpr::CMP, {dx_leaf(), dx_const(v)}, "", C_EQ)); return dx_node(DExpr::OR, alts); }
+        default: break;
+      }
+    }
+    default: break;
+  }
+  throw Unsupported("unsupported on the device plan: formula is not leaf-local");
+}
+FP dict_atom(const SPath& leaf, DX dx) { Atom a; a.kind = Atom::DICT; a.path = leaf; a.dx = std::move(dx); return f_atom(a); }
+
+FP fold_dict(const FP& f) {
+  switch (f->kind) {
+    case FNode::NOT: return f_not(fold_dict(f->kids[0]));
+    case FNode::EXISTS: return f_exists(f->q, f->base, fold_dict(f->kids[0]));
+    case FNode::OR: {
+      // (E x in B. P(x)) | (E y in B. Q(y))  ==  E x in B. (P(x) | Q(x)): the alternatives of one template function over
+      // the same array then meet in ONE body, where they fold per leaf
+      std::vector<FP> kids;
+      std::map<std::string, size_t> by_base;
+      for (auto& k : f->kids) {
+        if (k->kind != FNode::EXISTS) { kids.push_back(k); continue; }
+        const std::string bk = spath_to_string(k->base);
+        auto it = by_base.find(bk);
+        if (it == by_base.end()) { by_base[bk] = kids.size(); kids.push_back(k); continue; }
+        const FP& first = kids[it->second];
+        std::map<int, int> m{{k->q, first->q}};
+        kids[it->second] = f_exists(first->q, first->base, f_or(first->kids[0], rename_f(k->kids[0], m)));
+      }
+      // (K & A) | (K & B)  ==  K & (A | B): conjuncts shared by every alternative of a merged body (the key test of
+      // `spec[field][_]`, for one) go back in front, where the lowering expects them
+      for (auto& k : kids) {
+        if (k->kind != FNode::EXISTS || k->kids[0]->kind != FNode::OR) continue;
+        std::vector<std::vector<FP>> alts;
+        for (auto& d : k->kids[0]->kids) { alts.emplace_back(); conjuncts(d, alts.back()); }
+        std::vector<FP> common;
+        for (auto& c0 : alts[0]) {
+          const std::string key = f_to_string(c0);
+          bool all = true;
+          for (size_t i = 1; i < alts.size() && all; i++) { bool has = false; for (auto& c : alts[i]) has = has || f_to_string(c) == key; all = has; }
+          if (all) common.push_back(c0);
+        }
+        if (common.empty()) continue;
+        FP body = f_false();
+        for (auto& a : alts) {
+          FP d = f_true();
+          for (auto& c : a) { bool shared = false; for (auto& c0 : common) shared = shared || f_to_string(c0) == f_to_string(c); if (!shared) d = f_and(d, c); }
+          body = f_or(body, d);
+        }
+        k = f_exists(k->q, k->base, f_and(f_all(common), body));
+      }
+      // group the leaf-local alternatives by leaf: a group with a DICT atom whose members all need the leaf folds
+      std::map<std::string, std::vector<FP>> groups;
+      std::vector<std::string> order;
+      std::vector<FP> rest;
+      for (auto& k : kids) {
+        bool hd = false;
+        std::string l = leaf_of(k, &hd);
+        if (l.empty() || !needs_leaf(k)) { rest.push_back(fold_dict(k)); continue; }
+        if (!groups.count(l)) order.push_back(l);
+        groups[l].push_back(k);
+      }
+      FP r = f_false();
+      for (auto& l : order) {
+        auto& g = groups[l];
+        bool hd = false;
+        for (auto& k : g) leaf_of(k, &hd);
+        if (hd) {
+          std::vector<DX> a;
+          for (auto& k : g) a.push_back(to_dx(k));
+          r = f_or(r, dict_atom(*leaf_path_of(g[0]), a.size() == 1 ? a[0] : dx_node(DExpr::OR, a)));
+        } else for (auto& k : g) r = f_or(r, fold_dict(k));
+      }
+      for (auto& k : rest) r = f_or(r, k);
+      return r;
+    }
+    case FNode::AND: {
+      // group the conjuncts by leaf; a group with a DICT atom and at least one conjunct that needs the leaf to exist folds
+      std::vector<FP> rest;
+      std::map<std::string, std::vector<FP>> groups;
+      std::vector<std::string> order;
+      for (auto& k : f->kids) {
+        bool hd = false;
+        std::string l = leaf_of(k, &hd);
+        if (l.empty()) { rest.push_back(fold_dict(k)); continue; }
+        if (!groups.count(l)) order.push_back(l);
+        groups[l].push_back(k);
+      }
+      FP r = f_true();
+      for (auto& l : order) {
+        auto& g = groups[l];
+        bool hd = false, needs = false;
+        for (auto& k : g) { leaf_of(k, &hd); needs = needs || needs_leaf(k); }
+        if (hd && needs) {
+          std::vector<DX> a;
+          for (auto& k : g) a.push_back(to_dx(k));
+          r = f_and(r, dict_atom(*leaf_path_of(g[0]), a.size() == 1 ? a[0] : dx_node(DExpr::AND, a)));
+        } else for (auto& k : g) r = f_and(r, fold_dict(k));
+      }
+      for (auto& k : rest) r = f_and(r, k);
+      return r;
+    }
+    case FNode::ATOM: {
+      // a lone DICT atom stays; a lone NOT(DICT) cannot be answered from a row that may not exist -- it reaches the
+      // lowering as NOT(bit test), which is right: no row <=> leaf absent or expression false
+      return f;
+    }
+    default: return f;
+  }
+}
+
 // ---- alpha-normalised canonical text: quantifier ids renumbered in order of first appearance, so structurally
 // identical (sub)formulas compiled for different constraints share predicates, derived bits and result slots.
 void collect_q(const FP& f, std::vector<int>& order) {
@@ -440,6 +600,7 @@ uint64_t string_key(const std::string& s) {
 
 struct Lowerer {
   PathDict* dict;
+  DictRegistry* reg = nullptr;
   HostPlan plan;
   PlanCaps caps;
   std::map<std::string, uint32_t> global_bits;            // canonical pred key -> global bit
@@ -633,6 +794,51 @@ struct Lowerer {
       emit(sc[0] | (slot[0] << 8) | (sc[1] << 16) | (slot[1] << 24));
       return r;
     }
+    if (a.kind == Atom::DICT) {
+      // bit test on the leaf's <leaf>.$d row; the bit belongs to (pattern of the leaf, expression) in the engine's registry
+      if (!reg) unsupported("dictionary predicate without a registry");
+      Pattern leaf_pat = pattern_of(a.path);
+      for (auto& st : leaf_pat) if (st.any && !st.elems_only && (!st.only.empty() || !st.except.empty())) unsupported("dictionary predicate under a filtered key iteration");
+      uint32_t bit;
+      try { bit = reg->intern(leaf_pat, a.dx); } catch (const std::runtime_error& ex) { unsupported(ex.what()); }
+      Atom b;
+      b.kind = Atom::DICT; b.path = a.path; b.dx = nullptr;
+      Step st; st.key = "$d";
+      b.path.push_back(st);
+      b.mask = bit;
+      Pattern pat = pattern_of(b.path);
+      std::string key = "dict|" + pattern_to_string(pat) + "|" + std::to_string(bit);
+      int li = last_looped(b.path);
+      Pred p{};
+      p.op = P_BITS; p.k = 1ull << bit;
+      if (li < 0) {
+        auto it = global_bits.find(key);
+        uint32_t gb;
+        if (it == global_bits.end()) {
+          gb = n_gbits++;
+          if (gb > 0xFFFF) unsupported("too many global predicates");
+          global_bits[key] = gb;
+          p.dst = D_GLOBAL; p.bit = (uint16_t)gb;
+          plan.preds.push_back(p);
+          plan.pred_patterns.push_back(pat);
+        } else gb = it->second;
+        emit(finst(F_LDG, r, gb & 0xFF, gb >> 8));
+        return r;
+      }
+      uint32_t sc = looped[b.path[li].q];
+      auto it = elem_bits[sc].find(key);
+      uint32_t eb;
+      if (it == elem_bits[sc].end()) {
+        eb = scope_nbits[sc]++;
+        if (eb >= ELEM_W0_BITS + 3 * 32) unsupported("too many predicates on one element scope");
+        elem_bits[sc][key] = eb;
+        p.dst = D_ELEM; p.scope = (uint8_t)sc; p.level = (uint8_t)scope_level[sc]; p.bit = (uint16_t)eb;
+        plan.preds.push_back(p);
+        plan.pred_patterns.push_back(pat);
+      } else eb = it->second;
+      emit(finst(F_LDE, r, sc, eb));
+      return r;
+    }
     Pattern pat = pattern_of(a.path);
     std::string key = atom_key(a, pat);
     int li = last_looped(a.path);
@@ -670,7 +876,7 @@ struct Lowerer {
   static bool path_has_q(const SPath& p, int q) { for (auto& s : p) if (s.iter && s.q == q) return true; return false; }
 
   // key constraints of quantifier q expressed by conjunct f; returns false if f is not such a constraint
-  bool key_constraint(const FP& f, int q, PatStep* ps) {
+  static bool key_constraint(const FP& f, int q, PatStep* ps) {
     if (f->kind == FNode::ATOM && f->atom.kind == Atom::KEYCMP && f->atom.q == q && f->atom.k.is_string()) {
       if (f->atom.cmp == C_EQ) ps->only.push_back(f->atom.k.str()); else ps->except.push_back(f->atom.k.str());
       return true;
@@ -919,6 +1125,37 @@ struct Lowerer {
   }
 };
 
+// Key iterations pinned to constants, as a formula rewrite (the lowering does the same for what is left):
+//   E k in B. (k == "a" | k == "b") & body(B[k])   ==   OR_c  defined(B.c) & body(B.c)
+// Run before fold_dict, so that `spec[field][_]` with field = "containers" becomes the concrete path spec.containers and
+// the alternatives over it can be merged.
+FP pin_pass(const FP& f) {
+  switch (f->kind) {
+    case FNode::NOT: return f_not(pin_pass(f->kids[0]));
+    case FNode::AND: { FP r = f_true(); for (auto& k : f->kids) r = f_and(r, pin_pass(k)); return r; }
+    case FNode::OR: { FP r = f_false(); for (auto& k : f->kids) r = f_or(r, pin_pass(k)); return r; }
+    case FNode::EXISTS: {
+      std::vector<FP> conj, rest;
+      conjuncts(f->kids[0], conj);
+      PatStep ps;
+      for (auto& c : conj) if (!Lowerer::key_constraint(c, f->q, &ps)) rest.push_back(c);
+      if (ps.only.empty() || !ps.except.empty()) return f_exists(f->q, f->base, pin_pass(f->kids[0]));
+      FP any = f_false();
+      for (const std::string& key : ps.only) {
+        SPath member = f->base;
+        Step st; st.key = key;
+        member.push_back(st);
+        Atom d; d.kind = Atom::DEFINED; d.path = member;
+        FP body = f_atom(d);
+        for (auto& c : rest) body = f_and(body, Lowerer::pin_key(c, f->q, key));
+        any = f_or(any, pin_pass(body));
+      }
+      return any;
+    }
+    default: return f;
+  }
+}
+
 }  // namespace
 
 uint32_t PlanBuilder::add_constraint(const FP& violation, const MatchFormulas& m) {
@@ -929,11 +1166,13 @@ uint32_t PlanBuilder::add_constraint(const FP& violation, const MatchFormulas& m
 HostPlan PlanBuilder::build(const PlanCaps& caps) {
   Lowerer L;
   L.dict = dict_;
+  L.reg = reg_;
   L.caps = caps;
   std::map<std::string, uint32_t> viol_ids, match_ids;
   std::vector<FP> viols, matches, errs;
   for (auto& c : cons_) {
-    FP v = simplify(c.viol), m = simplify(c.m.match), e = simplify(c.m.error);
+    FP v = simplify(fold_dict(simplify(pin_pass(simplify(c.viol))))), m = simplify(c.m.match), e = simplify(c.m.error);
+    if (getenv("GK_DEBUG_FORMULA")) { std::string t = f_to_string(v); fprintf(stderr, "[gkgpu formula] %zu chars: %s\n", t.size(), t.substr(0, (size_t)atoi(getenv("GK_DEBUG_FORMULA"))).c_str()); }
     std::string vk = canon(v), mk = canon(m) + "##" + canon(e);
     ConstraintSlot slot;
     auto it = viol_ids.find(vk);

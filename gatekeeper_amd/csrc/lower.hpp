@@ -29,15 +29,6 @@ struct PlanCaps {
   std::vector<uint16_t> scope_cap;       // optional: capacity per element scope (table-specialised variants), overrides level_cap
 };
 
-struct PatStep {
-  bool any = false;                 // true: any single step
-  bool elems_only = false;          // any: only "[]" children (array-element scopes)
-  std::string key;                  // !any: exact member name
-  std::vector<std::string> only;    // any: member name must be one of (key iteration with ==)
-  std::vector<std::string> except;  // any: member name must not be one of
-};
-typedef std::vector<PatStep> Pattern;
-
 struct HostPlan {
   std::vector<Pred> preds;
   std::vector<Pattern> pred_patterns;     // parallel to preds
@@ -57,17 +48,17 @@ struct HostPlan {
 
 class PlanBuilder {
  public:
-  explicit PlanBuilder(PathDict* dict) : dict_(dict) {}
+  explicit PlanBuilder(PathDict* dict, DictRegistry* reg = nullptr) : dict_(dict), reg_(reg) {}
   // returns the constraint index; formulas are deduplicated structurally
   uint32_t add_constraint(const FP& violation, const MatchFormulas& m);
   HostPlan build(const PlanCaps& caps);   // throws Unsupported
 
  private:
   PathDict* dict_;
+  DictRegistry* reg_;
   struct C { FP viol; MatchFormulas m; };
   std::vector<C> cons_;
 };
 
-std::string pattern_to_string(const Pattern& p);
 
 }  // namespace gk

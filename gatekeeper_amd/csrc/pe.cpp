@@ -90,6 +90,7 @@ std::string f_to_string(const FP& f) {
         case Atom::VEQ: return p + " === " + spath_to_string(a.path2);
         case Atom::SPLIT_PREFIX: return "splitprefix(" + p + "," + to_term_string(a.k) + ")";
         case Atom::KEYCMP: return "key(q" + std::to_string(a.q) + ") " + cmpn[a.cmp] + " " + to_term_string(a.k);
+        case Atom::DICT: return "dict(" + p + ": " + dx_to_string(a.dx) + ")";
       }
     }
   }
@@ -167,6 +168,30 @@ SVP rn_sv(const SVP& v, const QMap& m) {
 }
 
 Atom atom_path(Atom::Kind k, const SPath& p) { Atom a; a.kind = k; a.path = p; return a; }
+
+// ---- leaf-local values (dexpr.hpp): a review leaf, its count(), or anything already derived from one leaf
+bool leaf_local(const SVP& v, SPath* leaf, DX* dx) {
+  if (v->kind == SV::PATH && !v->path.empty()) { *leaf = v->path; *dx = dx_leaf(); return true; }
+  if (v->kind == SV::DERIVED) { *leaf = v->path; *dx = v->dx; return true; }
+  if (v->kind == SV::COUNTOF) { *leaf = v->path; *dx = dx_node(DExpr::CALL, {dx_leaf()}, "count"); return true; }
+  return false;
+}
+SVP sv_derived(const SPath& leaf, DX dx) { SV s; s.kind = SV::DERIVED; s.path = leaf; s.dx = std::move(dx); return mksv(s); }
+FP f_dict(const SPath& leaf, DX dx) { Atom a; a.kind = Atom::DICT; a.path = leaf; a.dx = std::move(dx); return f_atom(a); }
+// operands of one operation: constants and values derived from the SAME leaf -> their expressions
+bool same_leaf_args(const std::vector<SVP>& args, SPath* leaf, std::vector<DX>* dxs) {
+  bool have = false;
+  dxs->clear();
+  for (const SVP& a : args) {
+    if (a->kind == SV::CONST) { if (!a->c.defined()) return false; dxs->push_back(dx_const(a->c)); continue; }
+    SPath p; DX d;
+    if (!leaf_local(a, &p, &d)) return false;
+    if (have && spath_to_string(p) != spath_to_string(*leaf)) return false;
+    *leaf = p; have = true;
+    dxs->push_back(d);
+  }
+  return have;
+}
 constexpr uint32_t M_STRING = 1u << T_STRING, M_NUMBER = (1u << T_INT) | (1u << T_FLOAT), M_BOOL = 1u << T_BOOL,
                    M_NULL = 1u << T_NULL, M_ARRAY = 1u << T_ARRAY, M_OBJECT = 1u << T_OBJECT;
 FP f_type(const SPath& p, uint32_t mask) { Atom a = atom_path(Atom::TYPE, p); a.mask = mask; return f_atom(a); }
@@ -512,6 +537,11 @@ class PE {
     }
     if (a->kind == SV::CONST) return compare_f(b, flip_cmp(op), a);
     if (b->kind == SV::CONST && !b->c.defined()) return f_false();
+    if (a->kind == SV::DERIVED || b->kind == SV::DERIVED) {   // a computation on one leaf against a constant / the same leaf
+      SPath leaf; std::vector<DX> dx;
+      if (same_leaf_args({a, b}, &leaf, &dx)) return f_dict(leaf, dx_node(DExpr::CMP, {dx[0], dx[1]}, "", op));
+      unsupported("comparison between values derived from different review fields");
+    }
     switch (a->kind) {
       case SV::PATH:
         if (b->kind == SV::CONST) {
@@ -572,7 +602,9 @@ class PE {
         if (b->kind == SV::CONST && b->c.is_number() && b->c.is_int) {
           Atom c = atom_path(Atom::COUNT_CMP, a->path);
           c.cmp = op; c.k = b->c;
-          return f_atom(c);
+          // count() of a string is its length in code points: a dictionary predicate on the leaf
+          FP str = f_and(f_type(a->path, M_STRING), f_dict(a->path, dx_node(DExpr::CMP, {dx_node(DExpr::CALL, {dx_leaf()}, "count"), dx_const(b->c)}, "", op)));
+          return f_or(f_and(f_type(a->path, M_ARRAY | M_OBJECT), f_atom(c)), str);
         }
         break;
       case SV::CARD:
@@ -1119,6 +1151,10 @@ class PE {
       Value v = rego_arith(op, a->c, b->c);
       return v.defined() ? sv_const(v) : SVP();
     }
+    {   // arithmetic on one review leaf: recorded as an expression of that leaf (dexpr.hpp)
+      SPath leaf; std::vector<DX> dx;
+      if (!(a->kind == SV::STRX) && !(b->kind == SV::STRX) && same_leaf_args({a, b}, &leaf, &dx)) return sv_derived(leaf, dx_node(DExpr::ARITH, {dx[0], dx[1]}, op));
+    }
     if (a->kind == SV::STRX && a->xkind == SV::XCOUNT && b->kind == SV::CONST && b->c.is_number() && b->c.is_int && (op == "-" || op == "+")) {
       SV c = *a;
       c.idx += (int)(op == "-" ? -b->c.i : b->c.i);
@@ -1231,6 +1267,7 @@ class PE {
         out.push_back({mksv(c), s});
         return;
       }
+      if (x->kind == SV::DERIVED) { out.push_back({sv_derived(x->path, dx_node(DExpr::CALL, {x->dx}, "count")), s}); return; }
       unsupported("count() of this symbolic value", line);
     }
     if (name == "startswith" || name == "endswith" || name == "contains") {
@@ -1242,6 +1279,7 @@ class PE {
         push_bool(f_atom(at), f_type(a[0]->path, M_STRING));
         return;
       }
+      { SPath leaf; std::vector<DX> dx; if (same_leaf_args(a, &leaf, &dx)) { out.push_back({sv_derived(leaf, dx_node(DExpr::CALL, dx, name)), s}); return; } }
       unsupported(name + " with these symbolic operands", line);
     }
     if (name == "re_match" || name == "regex.match") {
@@ -1255,6 +1293,7 @@ class PE {
         push_bool(f_atom(at), f_type(a[1]->path, M_STRING));
         return;
       }
+      { SPath leaf; std::vector<DX> dx; if (same_leaf_args(a, &leaf, &dx)) { out.push_back({sv_derived(leaf, dx_node(DExpr::CALL, dx, name)), s}); return; } }
       unsupported(name + " with these symbolic operands", line);
     }
     if (name == "strings.any_prefix_match" || name == "strings.any_suffix_match") {
@@ -1276,6 +1315,7 @@ class PE {
       uint32_t m = name == "is_string" ? M_STRING : name == "is_number" ? M_NUMBER : name == "is_boolean" ? M_BOOL : name == "is_array" ? M_ARRAY : name == "is_object" ? M_OBJECT : name == "is_null" ? M_NULL : 0;
       if (a[0]->kind == SV::PATH) { push_bool(f_type(a[0]->path, m), f_atom(atom_path(Atom::DEFINED, a[0]->path))); return; }
       if (a[0]->kind == SV::OPAQUE || a[0]->kind == SV::STRX) { push_bool(name == "is_string" ? f_true() : f_false(), defined_f(a[0])); return; }
+      if (a[0]->kind == SV::DERIVED) { push_bool(f_dict(a[0]->path, dx_node(DExpr::TYPE_MASK, {a[0]->dx}, "", 0, m)), defined_f(a[0])); return; }
       if (a[0]->kind == SV::SET) { push_bool(name == "is_set" ? f_true() : f_false(), f_true()); return; }
       if (a[0]->kind == SV::ARR) { push_bool(name == "is_array" ? f_true() : f_false(), f_true()); return; }
       unsupported(name + " of this symbolic value", line);
@@ -1307,6 +1347,7 @@ class PE {
         out.push_back({mksv(x), s});
         return;
       }
+      { SPath leaf; std::vector<DX> dx; if (same_leaf_args(a, &leaf, &dx)) { out.push_back({sv_derived(leaf, dx_node(DExpr::CALL, dx, name)), s}); return; } }
       unsupported("trim() with these operands on review data", line);
     }
     if (name == "split") {
@@ -1336,6 +1377,14 @@ class PE {
         return;
       }
       unsupported("object.get with these operands on review data", line);
+    }
+    {   // a scalar builtin whose symbolic operands all derive from ONE leaf: an expression of that leaf.  Only builtins
+        // that look at nothing but a scalar's value or a container's size: the flattener evaluates the expression on the
+        // leaf's value, and hands a container leaf over as a placeholder of the same type and size
+      static const std::set<std::string> scalar_fns = {"to_number", "replace", "substring", "lower", "upper", "trim", "trim_space", "trim_left", "trim_right",
+          "trim_prefix", "trim_suffix", "startswith", "endswith", "contains", "re_match", "regex.match", "indexof", "abs", "round", "ceil", "floor", "format_int"};
+      SPath leaf; std::vector<DX> dx;
+      if (scalar_fns.count(name) && same_leaf_args(a, &leaf, &dx)) { out.push_back({sv_derived(leaf, dx_node(DExpr::CALL, dx, name)), s}); return; }
     }
     unsupported("builtin " + name + " applied to review data", line);
   }
@@ -1372,7 +1421,8 @@ FP PE::defined_f(const SVP& v) {
     case SV::SET: case SV::CARD: return f_true();
     case SV::OPAQUE: return v->f;
     case SV::BOOLF: return v->d;
-    case SV::COUNTOF: return f_type(v->path, M_ARRAY | M_OBJECT);
+    case SV::COUNTOF: return f_type(v->path, M_ARRAY | M_OBJECT | M_STRING);
+    case SV::DERIVED: return f_dict(v->path, dx_node(DExpr::DEFINED, {v->dx}));
     case SV::STRX: {
       if (v->xkind == SV::XCOMP) {
         Atom c = atom_path(Atom::SPLIT_COUNT, v->path);
@@ -1392,6 +1442,7 @@ FP PE::truthy_f(const SVP& v) {
     case SV::CONST: return (v->c.defined() && !(v->c.is_bool() && !v->c.b)) ? f_true() : f_false();
     case SV::PATH: return v->path.empty() ? f_true() : f_atom(atom_path(Atom::TRUTHY, v->path));
     case SV::BOOLF: return f_and(v->d, v->f);
+    case SV::DERIVED: return f_dict(v->path, dx_node(DExpr::TRUTHY, {v->dx}));
     default: return defined_f(v);
   }
 }
@@ -1402,6 +1453,7 @@ FP PE::is_string_f(const SVP& v) {
     case SV::PATH: return f_type(v->path, M_STRING);
     case SV::OPAQUE: return v->f;
     case SV::STRX: return v->xkind == SV::XCOUNT ? f_false() : defined_f(v);
+    case SV::DERIVED: return f_dict(v->path, dx_node(DExpr::TYPE_MASK, {v->dx}, "", 0, M_STRING));
     default: return f_false();
   }
 }

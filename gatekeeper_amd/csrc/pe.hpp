@@ -13,6 +13,7 @@
 #include <string>
 #include <vector>
 
+#include "dexpr.hpp"
 #include "rego_ast.hpp"
 #include "value.hpp"
 
@@ -30,7 +31,8 @@ typedef std::vector<Step> SPath;   // rooted at input.review
 
 struct Atom {
   enum Kind { DEFINED, TRUTHY, CMP, TYPE, STR_PREFIX, STR_SUFFIX, STR_CONTAINS, STR_IN_SET, STR_REGEX, SPLIT_CMP, SPLIT_COUNT,
-              COUNT_CMP, FLAG, VEQ, KEYCMP, SPLIT_PREFIX } kind = DEFINED;
+              COUNT_CMP, FLAG, VEQ, KEYCMP, SPLIT_PREFIX,
+              DICT /* leaf-local expression `dx` over the leaf at `path` is true (dexpr.hpp) */ } kind = DEFINED;
   SPath path;
   int cmp = 0;          // CmpOp
   Value k;              // constant operand (CMP / STR_* / SPLIT_* / COUNT_CMP / KEYCMP; STR_IN_SET: set/array of strings)
@@ -40,6 +42,7 @@ struct Atom {
   uint32_t flag = 0;    // FLAG: review flag bit index
   SPath path2;          // VEQ
   int q = -1;           // KEYCMP
+  DX dx;                // DICT
 };
 
 struct FNode;
@@ -71,7 +74,8 @@ struct CondElem { SVP v; FP cond; };
 struct Gen { SVP elem; std::vector<int> quants; std::vector<SPath> bases; FP cond; };
 
 struct SV {
-  enum Kind { CONST, PATH, KEYOF, OBJ, ARR, SET, OPAQUE, BOOLF, STRX, COUNTOF, CARD } kind = CONST;
+  enum Kind { CONST, PATH, KEYOF, OBJ, ARR, SET, OPAQUE, BOOLF, STRX, COUNTOF, CARD,
+              DERIVED /* value computed from ONE review leaf (`path`) by the expression `dx` */ } kind = CONST;
   Value c;                                        // CONST
   SPath path;                                     // PATH / STRX / COUNTOF
   int q = -1;                                     // KEYOF
@@ -83,6 +87,7 @@ struct SV {
   char cut = 0, sep = 0;                          // STRX
   enum XK { XTRIM, XARR, XCOMP, XCOUNT } xkind = XTRIM;
   int idx = 0;                                    // XCOMP index / XCOUNT offset
+  DX dx;                                          // DERIVED
 };
 
 struct Violation {   // render mode output

@@ -102,6 +102,7 @@ enum PredOp : uint32_t {
   P_PRESENT = 13,    // element marker: sets bit 0 and parent ordinal of the element word
   P_SPLIT_PREFIX = 14,  // split(trim(row, cut), sep) starts with the constant component list (fused path-prefix test)
   P_REGEX = 15,      // string row matches a constant regular expression (unanchored search): byte-class DFA in the const heap
+  P_BITS = 16,       // integer row (a <leaf>.$d dictionary row, dexpr.hpp) has one of the bits of the mask k set
 };
 enum CmpOp : uint32_t { C_EQ = 0, C_NE = 1, C_LT = 2, C_LE = 3, C_GT = 4, C_GE = 5 };
 enum PredDst : uint32_t { D_GLOBAL = 0, D_ELEM = 1 };

@@ -274,6 +274,7 @@ GK_HD bool eval_pred(const Row& r, const Pred& p, const StrHdr& h, const uint8_t
       for (uint32_t i = 0; i < s.n; i++) st = nxt[st * nc + cls[sbyte(s, i)]];
       return acc[st] != 0;
     }
+    case P_BITS: return t == T_INT && ((((uint64_t)r.hi << 32) | r.lo) & p.k) != 0;
     case P_COUNT_CMP: {
       int64_t a;
       if (t == T_OBJECT || t == T_ARRAY) a = r.lo;

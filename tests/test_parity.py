@@ -329,7 +329,7 @@ def test_template_families(backend, fixtures):
         supported += 1
         rv = [D.AugmentedUnstructured(D.Unstructured(o), None, "Original") for o in objs + pods]
         assert_parity(c, oc, rv)
-    assert supported >= 3   # requiredlabels (allowedRegex), allowedrepos, requiredprobes; containerlimits needs quantity arithmetic
+    assert supported >= 4   # requiredlabels (allowedRegex), allowedrepos, requiredprobes, containerlimits (dictionary predicates)
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
@@ -750,3 +750,34 @@ def test_row_group_geometries(backend, rpt, rpp, fixtures):
         assert_parity(c, oc, [D.AugmentedUnstructured(D.Unstructured(o), synth.namespace_for(o, nss), "Original") for o in objs[650:760]])
     finally:
         os.environ.pop("GK_RPT", None)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_container_limits_dictionary_predicates(backend, fixtures):
+    """K8sContainerLimits (demo/agilebank, test/bats, test/gator/policy copies): the quantity parsing -- replace / substring /
+    to_number / re_match / arithmetic over a dozen function bodies -- is a pure function of ONE leaf (the limit string), so it
+    runs as a DICTIONARY predicate: the flattener evaluates it per distinct value and ships a bit, the device tests the bit
+    (csrc/dexpr.hpp).  Parity with the oracle incl. unparseable, numeric, empty, missing and container-typed limits."""
+    paths = ["demo/agilebank/templates/k8scontainterlimits_template.yaml", "test/bats/tests/templates/k8scontainterlimits_template.yaml",
+             "test/gator/policy/testdata/templates/containerlimits/template.yaml"]
+    quantities = [("100m", "1Gi"), ("2", "2Gi"), (1, 1024), ("abc", "1Zi"), ("", ""), ("0.5", "500M"), ("300m", "1G"), ("200m", "1073741824"), ("1e3", "1Ei"),
+                  (None, None), ("250m", "128Mi"), ("m", "Gi"), (0.1, 1.5), ("201m", "1025Mi"), ("0200m", "1024Mi"), ([1, 2], {"a": 1}), ("1", "1Ti"), ("199m", "999M"),
+                  (True, False), ("2m", "1000000m"), ("\u00b5", "1Ki\u00e9")]
+    weird = [{"apiVersion": "v1", "kind": "Pod", "metadata": {"name": "w%d" % i, "namespace": "default"},
+              "spec": {"containers": [{"name": "c", "resources": {"limits": {"cpu": cpu, "memory": mem}}}, {"name": "nolimits"}, {"name": "half", "resources": {"limits": {"cpu": cpu}}}],
+                       "initContainers": [{"name": "i", "resources": {"limits": {"memory": mem, "cpu": "1"}}}]}} for i, (cpu, mem) in enumerate(quantities)]
+    pods = synth.gen_objects(300, seed=7)
+    seen = 0
+    for p in paths:
+        if p not in fixtures["yaml"]:
+            continue
+        t_ = json.loads(json.dumps(ydocs(fixtures, p)[0]))
+        kind = t_["spec"]["crd"]["spec"]["names"]["kind"]
+        t_["metadata"]["name"] = kind.lower()   # (the gator/policy test copy deliberately carries a non-matching name)
+        cons = [{"apiVersion": "constraints.gatekeeper.sh/v1beta1", "kind": kind, "metadata": {"name": "lim-%d" % i},
+                 "spec": {"match": {"kinds": [{"apiGroups": [""], "kinds": ["Pod"]}]}, "parameters": prm}}
+                for i, prm in enumerate([{"cpu": "200m", "memory": "1Gi"}, {"cpu": "1", "memory": "500M"}, {"cpu": "bogus", "memory": "1Xi"}])]
+        c, oc = load_both(backend, [t_], cons)
+        assert assert_parity(c, oc, [D.AugmentedUnstructured(D.Unstructured(o), None, "Original") for o in weird + pods]) > 100
+        seen += 1
+    assert seen >= 1
