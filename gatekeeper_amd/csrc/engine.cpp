@@ -42,6 +42,7 @@ struct ConstraintRec {
   Value object, params, match;
   FP viol;
   MatchFormulas mf;
+  std::shared_ptr<const PreparedConstraint> prep;   // simplified / folded once (lower.hpp), reused by every plan build
   bool alive = true;
 };
 
@@ -288,7 +289,7 @@ DevPlan* plan_for_table(gk_engine* e, gk_table* t, const HostPlan** host) {
     std::unique_ptr<gk_engine::Variant> v(new gk_engine::Variant());
     try {
       PlanBuilder pb(&e->dict, &e->dict_reg);
-      for (auto& c : e->constraints) if (c.alive) pb.add_constraint(c.viol, c.mf);
+      for (auto& c : e->constraints) if (c.alive) pb.add_constraint(c.prep);
       PlanCaps pc = default_caps(e);
       pc.scope_cap = caps;
       v->fast = pb.build(pc);
@@ -326,21 +327,24 @@ void ensure_plan(gk_engine* e) {
     std::vector<std::vector<const ConstraintRec*>> groups;
     auto builds = [&](const std::vector<const ConstraintRec*>& g, HostPlan* fast, HostPlan* big) {
       PlanBuilder pb(&e->dict, &e->dict_reg);
-      for (auto* c : g) pb.add_constraint(c->viol, c->mf);
+      for (auto* c : g) pb.add_constraint(c->prep);
       *fast = pb.build(default_caps(e));
       *big = pb.build(bigcaps);
     };
     std::vector<std::pair<HostPlan, HostPlan>> plans;
     std::function<void(const std::vector<const ConstraintRec*>&)> place = [&](const std::vector<const ConstraintRec*>& g) {
       HostPlan f, b;
+      auto t0 = std::chrono::steady_clock::now();
       try { builds(g, &f, &b); }
-      catch (const Unsupported&) {
+      catch (const Unsupported& u) {
+        if (getenv("GK_PLAN_TIMING")) fprintf(stderr, "[plan] %zu constraints: does not fit one plan (%s) after %.2f s\n", g.size(), u.what(), std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
         if (g.size() <= 1) throw;
         size_t half = g.size() > 64 ? 64 : g.size() / 2;
         for (size_t i = 0; i < g.size(); i += half)
           place(std::vector<const ConstraintRec*>(g.begin() + i, g.begin() + std::min(g.size(), i + half)));
         return;
       }
+      if (getenv("GK_PLAN_TIMING")) fprintf(stderr, "[plan] %zu constraints: built in %.2f s\n", g.size(), std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
       groups.push_back(g);
       plans.emplace_back(std::move(f), std::move(b));
     };
@@ -462,7 +466,8 @@ int gk_constraint_add(gk_engine* e, const char* json, size_t len, uint32_t* id_o
     // validate that it lowers (element scopes, register pressure) before accepting it
     {
       PlanBuilder pb(&e->dict, &e->dict_reg);
-      pb.add_constraint(rec.viol, rec.mf);
+      rec.prep = prepare_constraint(rec.viol, rec.mf);
+      pb.add_constraint(rec.prep);
       PlanCaps caps;
       pb.build(caps);
     }

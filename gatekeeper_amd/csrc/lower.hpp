@@ -46,18 +46,24 @@ struct HostPlan {
   void resolve_paths(const PathDict& dict);   // (re)builds ptab / pred_list for the current dictionary
 };
 
+// A constraint's formulas after the capacity-independent passes (simplify, pin_pass, fold_dict) and their structural keys:
+// computed once when the constraint is added, shared by every plan the constraint is lowered into (the default plan, the
+// big-capacity plan, per-table variants, constraint groups).
+struct PreparedConstraint { FP viol, match, error; std::string viol_key, match_key; };
+std::shared_ptr<const PreparedConstraint> prepare_constraint(const FP& violation, const MatchFormulas& m);
+
 class PlanBuilder {
  public:
   explicit PlanBuilder(PathDict* dict, DictRegistry* reg = nullptr) : dict_(dict), reg_(reg) {}
   // returns the constraint index; formulas are deduplicated structurally
-  uint32_t add_constraint(const FP& violation, const MatchFormulas& m);
+  uint32_t add_constraint(const FP& violation, const MatchFormulas& m) { return add_constraint(prepare_constraint(violation, m)); }
+  uint32_t add_constraint(std::shared_ptr<const PreparedConstraint> pc) { cons_.push_back(std::move(pc)); return (uint32_t)cons_.size() - 1; }
   HostPlan build(const PlanCaps& caps);   // throws Unsupported
 
  private:
   PathDict* dict_;
   DictRegistry* reg_;
-  struct C { FP viol; MatchFormulas m; };
-  std::vector<C> cons_;
+  std::vector<std::shared_ptr<const PreparedConstraint>> cons_;
 };
 
 

@@ -3,9 +3,9 @@
   config[1]  30 PSP constraints (5 in-tree PSP templates x 6 parameterisations) x N synthetic Pod reviews
   config[2]  50 constraints (the 30 + 20 with heavier match blocks) x N mixed cluster objects (audit sweep)
 
-The PSP templates themselves are the reference's own policy fixtures
-(pkg/webhook/testdata/psp-all-violations/psp-templates/*.yaml), shipped as data in tests/golden/reference_fixtures.json
-because /root/reference does not exist on the GPU box.  Constraint parameterisations and objects are generated here.
+The templates themselves are the reference's own policy fixtures (pkg/webhook/testdata/psp-all-violations/psp-templates/*.yaml,
+demo/agilebank/templates/*.yaml), shipped as data in gatekeeper_amd/data/policy_templates.json because /root/reference does
+not exist on the GPU box.  Constraint parameterisations and objects are generated here.
 Shared by bench.py, __graft_entry__.smoke() and tests/ so that every leg sees identical inputs.
 """
 from __future__ import annotations
@@ -52,7 +52,9 @@ class SplitMix64:
 
 
 def load_fixtures():
-    with open(os.path.join(_ROOT, "tests", "golden", "reference_fixtures.json"), encoding="utf-8") as fh:
+    """the reference's policy templates the synthetic workloads use (policy INPUTS shipped as data with the package:
+    gatekeeper_amd/data/policy_templates.json, written by tests/golden/make_golden.py from /root/reference)"""
+    with open(os.path.join(_ROOT, "gatekeeper_amd", "data", "policy_templates.json"), encoding="utf-8") as fh:
         return json.load(fh)
 
 
@@ -303,6 +305,70 @@ def audit_constraints():
         out.append({"apiVersion": "constraints.gatekeeper.sh/v1beta1", "kind": kind,
                     "metadata": {"name": "%s-x%d" % (kind.lower(), k)}, "spec": spec})
     return out
+
+
+# ------------------------------------------------------------------------------------------------ config[4]: 200 templates
+_FAMILIES = [   # (template file, [20 parameterisations])
+    ("demo/agilebank/templates/k8srequiredlabels_template.yaml",
+     [{"message": "label policy %d" % i, "labels": [{"key": k, "allowedRegex": rx}]} for i, (k, rx) in enumerate(
+         [("owner", "^[a-z]+$"), ("owner", "^(a|b|x)$"), ("team", "^team-[0-9]+$"), ("env", "^(prod|dev)$"), ("app", "^[a-z0-9-]{1,8}$"), ("tier", "web|db"),
+          ("owner", ".+\\.agilebank\\.demo$"), ("release", "^v[0-9]+$"), ("track", ""), ("zone", "^[a-c]$"), ("region", "^.{2,}$"), ("cost-center", "^[0-9]+$"),
+          ("project", "^p"), ("squad", "d$"), ("domain", "(?i)^CORE$"), ("criticality", "\\bprod\\b"), ("pci", "^(true|false)$"), ("tenant", "^[^0-9]*$"),
+          ("shard", "^x?$"), ("canary", "^.*$")])]),
+    ("demo/agilebank/templates/k8sallowedrepos_template.yaml",
+     [{"repos": r} for r in (["gcr.io/"], ["quay.io/", "gcr.io/"], ["openpolicyagent/"], ["nginx"], ["docker.io/library/"], ["gcr.io/proj/"], ["quay.io/org/"], ["busybox"],
+                             ["k8s.gcr.io/", "registry.k8s.io/"], [""], ["gcr.io/proj/app"], ["quay.io/org/tool:v3"], ["n", "b"], ["ghcr.io/"], ["openpolicyagent/opa"],
+                             ["gcr.io", "quay.io", "docker.io"], ["x"], ["nginx:1.2"], ["registry.internal:5000/"], ["quay.io/org/", "busybox", "nginx"])]),
+    ("demo/agilebank/remediation/k8sbannedimagetags_template.yaml",
+     [{"tags": t} for t in (["latest"], ["latest", "v3"], ["1.25"], ["0.9.2"], ["latest", "master", "main"], ["v3"], ["dev"], ["1.25", "latest"], ["stable"], ["edge", "canary"],
+                            ["0.9.2", "v3", "1.25"], ["nightly"], ["rc"], ["latest", "1.25", "0.9.2", "v3"], ["beta"], ["alpha", "latest"], ["v1"], ["v2"], ["test"], ["snapshot", "latest"])]),
+    ("demo/agilebank/templates/k8scontainterlimits_template.yaml",
+     [{"cpu": c, "memory": m} for c, m in (("200m", "1Gi"), ("100m", "128Mi"), ("1", "1Gi"), ("2", "2Gi"), ("500m", "512Mi"), ("150m", "1G"), ("1000m", "1000Mi"), ("50m", "64Mi"),
+                                           ("4", "8Gi"), ("250m", "256Mi"), ("300m", "1500M"), ("1", "1Ti"), ("199m", "1073741823"), ("2000m", "2048Mi"), ("3", "3Gi"),
+                                           ("120m", "100Mi"), ("1", "999Mi"), ("800m", "1Gi"), ("101m", "129Mi"), ("10", "1Ei"))]),
+    ("demo/agilebank/templates/k8srequiredprobes_template.yaml",
+     [{"probes": pr, "probeTypes": pt} for pr, pt in ((["readinessProbe", "livenessProbe"], ["tcpSocket", "httpGet", "exec"]), (["readinessProbe"], ["httpGet"]),
+                                                       (["livenessProbe"], ["tcpSocket", "httpGet", "exec"]), (["startupProbe"], ["exec"]))] * 5),
+]
+_CORPUS_MATCH = [
+    {"kinds": _POD_KINDS, "namespaces": ["prod-*", "*-system"]},
+    {"kinds": _POD_KINDS},
+    {"kinds": _POD_KINDS, "excludedNamespaces": ["kube-*"]},
+    {"kinds": [{"apiGroups": [""], "kinds": ["Pod"]}, {"apiGroups": ["apps"], "kinds": ["Deployment"]}], "namespaces": ["prod-*", "*-system"]},
+    {"kinds": _POD_KINDS, "namespaceSelector": {"matchLabels": {"env": "prod"}}},
+    {"kinds": _POD_KINDS, "labelSelector": {"matchExpressions": [{"key": "canary", "operator": "DoesNotExist"}]}, "namespaces": ["*-0*", "team-*"]},
+]
+
+
+def corpus(fixtures=None, n_templates=200):
+    """BASELINE.json configs[4]: `n_templates` ConstraintTemplates + one constraint each -- the in-tree families (required
+    labels with allowedRegex, allowed repos, banned image tags, container limits, required probes, the 5 PSP templates),
+    every copy under its own kind, x parameterisations incl. regex allow-lists and `namespaces: ["prod-*", "*-system"]` globs.
+    -> (templates, constraints)"""
+    fx = fixtures or load_fixtures()
+    fams = [(fx["yaml"][p]["docs"][0], params) for p, params in _FAMILIES]
+    for kind in sorted(_PARAMS):
+        t = next(t_ for t_ in psp_templates(fx) if t_["spec"]["crd"]["spec"]["names"]["kind"] == kind)
+        fams.append((t, [_PARAMS[kind][i % 6] for i in range(20)]))
+    templates, constraints = [], []
+    i = 0
+    while len(templates) < n_templates:
+        t, params = fams[i % len(fams)]
+        k = i // len(fams)
+        base_kind = t["spec"]["crd"]["spec"]["names"]["kind"]
+        kind = "%sV%02d" % (base_kind, k)
+        ct = json.loads(json.dumps(t))
+        ct["metadata"]["name"] = kind.lower()
+        ct["spec"]["crd"]["spec"]["names"]["kind"] = kind
+        templates.append(ct)
+        spec = {"match": _CORPUS_MATCH[(i + k) % len(_CORPUS_MATCH)]}
+        if params[k % len(params)] is not None:
+            spec["parameters"] = params[k % len(params)]
+        if i % 7 == 3:
+            spec["enforcementAction"] = "dryrun"
+        constraints.append({"apiVersion": "constraints.gatekeeper.sh/v1beta1", "kind": kind, "metadata": {"name": "%s-c" % kind.lower()}, "spec": spec})
+        i += 1
+    return templates, constraints
 
 
 def namespace_for(obj, namespaces):

@@ -91,6 +91,18 @@ def main():
     bundle["validate_constraint_cases"] = validate_constraint_cases(os.path.join(REF, "pkg/target/target_test.go"))
     with open(OUT, "w", encoding="utf-8") as fh:
         json.dump(bundle, fh, indent=1, sort_keys=True)
+    # the policy templates bench.py / smoke() load at run time (policy INPUTS, not oracle code) live with the package, so
+    # that the product bench does not read a test directory
+    keep = ("demo/agilebank/templates/k8srequiredlabels_template.yaml", "demo/agilebank/templates/k8sallowedrepos_template.yaml",
+            "demo/agilebank/templates/k8scontainterlimits_template.yaml", "demo/agilebank/templates/k8srequiredprobes_template.yaml",
+            "demo/agilebank/remediation/k8sbannedimagetags_template.yaml")
+    pol = {p: bundle["yaml"][p] for p in sorted(bundle["yaml"])
+           if p.startswith("pkg/webhook/testdata/psp-all-violations/psp-templates/") or p in keep}
+    pol_out = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "gatekeeper_amd", "data", "policy_templates.json")
+    os.makedirs(os.path.dirname(pol_out), exist_ok=True)
+    with open(pol_out, "w", encoding="utf-8") as fh:
+        json.dump({"yaml": pol}, fh, indent=1, sort_keys=True)
+    print("wrote %s: %d policy templates" % (pol_out, len(pol)))
     print("wrote %s: %d yaml files, %d go const files, %d ValidateConstraint rows" % (
         OUT, len(bundle["yaml"]), len(bundle["go_consts"]), len(bundle["validate_constraint_cases"])))
 

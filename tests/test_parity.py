@@ -781,3 +781,17 @@ def test_container_limits_dictionary_predicates(backend, fixtures):
         assert assert_parity(c, oc, [D.AugmentedUnstructured(D.Unstructured(o), None, "Original") for o in weird + pods]) > 100
         seen += 1
     assert seen >= 1
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_policy_corpus_200_templates(backend, fixtures):
+    """BASELINE.json configs[4] at oracle-sized N: 200 ConstraintTemplates (the in-tree families: required labels with
+    allowedRegex, allowed repos, banned image tags, container limits, required probes, 5 x PSP -- every copy its own kind)
+    + 200 constraints with regex allow-lists and `namespaces: ["prod-*", "*-system"]` globs, over the mixed object stream."""
+    templates, cons = synth.corpus()
+    assert len(templates) == 200 and len({t["spec"]["crd"]["spec"]["names"]["kind"] for t in templates}) == 200
+    c, oc = load_both(backend, templates, cons)
+    nss = synth.gen_namespaces()
+    objs = synth.gen_objects(250, seed=11, mixed=True)
+    rv = [D.AugmentedUnstructured(D.Unstructured(o), synth.namespace_for(o, nss), "Original") for o in objs]
+    assert assert_parity(c, oc, rv) > 2000
