@@ -74,13 +74,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--config", type=int, default=2, choices=[1, 2], help="1: 30 PSP x Pods (configs[1]); 2: 50 constraints x mixed objects (configs[2])")
+    ap.add_argument("--config", type=int, default=2, choices=[1, 2, 4],
+                    help="1: 30 PSP x Pods (configs[1]); 2: 50 constraints x mixed objects (configs[2]); 4: the 200-template policy corpus x mixed objects (configs[4]'s policy set)")
     ap.add_argument("--reviews", type=int, default=None, help="objects per GPU (weak) / in total (strong); default 1000000 (config 2), 100000 (config 1)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
     if args.reviews is None:
-        args.reviews = 1000000 if args.config == 2 else 100000
+        args.reviews = {1: 100000, 2: 1000000, 4: 200000}[args.config]
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -106,6 +107,8 @@ def main():
     fx = synth.load_fixtures()
     templates = synth.psp_templates(fx)
     constraints = synth.psp_constraints() if args.config == 1 else synth.audit_constraints()
+    if args.config == 4:
+        templates, constraints = synth.corpus(fx)
     nss = synth.gen_namespaces()
     if args.scaling == "strong":
         per_rank = (args.reviews + world - 1) // world
@@ -126,7 +129,7 @@ def main():
 
     # objects [start, start + n_local) of the global synthetic stream, as JSON text (native generator == synth.py)
     t_gen = time.perf_counter()
-    batch = synth.NativeBatch(drv.engine.lib, n_local, seed=synth.SEED, mixed=(args.config == 2), start=start, namespaces=nss)
+    batch = synth.NativeBatch(drv.engine.lib, n_local, seed=synth.SEED, mixed=(args.config != 1), start=start, namespaces=nss)
     t_gen = time.perf_counter() - t_gen
     # end-to-end leg: JSON -> parse -> HandleReview -> flatten -> HBM (this is what a non-resident review costs)
     table = drv.engine.create_table_native(batch.reviews, n_local, keep_docs=False, resident=True)
@@ -174,6 +177,8 @@ def main():
         full_table_bytes = int(res.n_rows) * 16 + n_local * 4   # what a kernel streaming every row would read
         cfg_name = ("configs[1]: 30 gatekeeper PSP constraints (5 in-tree PSP templates x 6 parameterisations) x %d synthetic Pod "
                     "AdmissionReviews" if args.config == 1 else
+                    "configs[4] policy set: 200 ConstraintTemplates + 200 constraints (required labels/allowedRegex, allowed repos, banned image tags, "
+                    "container limits, required probes, PSP x 5; namespace globs) x %d mixed synthetic cluster objects" if args.config == 4 else
                     "configs[2]: pkg/audit sweep, 50 constraints x %d mixed synthetic cluster objects (80%% Pod, 10%% Deployment, 5%% Namespace, "
                     "5%% Service/ConfigMap)") % total_reviews
         e2e_s = st["flatten_s"] + st["upload_s"]

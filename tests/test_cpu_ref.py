@@ -32,11 +32,14 @@ def _oracle_pairs(oc, cons, reviews):
     return viol, err, results
 
 
-@pytest.mark.parametrize("mixed", [False, True])
+@pytest.mark.parametrize("mixed", [False, True, "corpus"])
 def test_cpu_ref_matches_python_oracle_on_synthetic(mixed, fixtures):
     n = 400
     templates = synth.psp_templates(fixtures)
     cons = synth.audit_constraints() if mixed else synth.psp_constraints()
+    if mixed == "corpus":   # configs[4]'s 200 templates / constraints
+        n, mixed = 150, True
+        templates, cons = synth.corpus()
     oc = OC.Client()
     for t in templates:
         oc.add_template(t)
