@@ -23,12 +23,15 @@ GK_REVIEW_ADMISSION_REQUEST, GK_REVIEW_OBJECT = 0, 1
 GK_SRC_EMPTY, GK_SRC_ORIGINAL, GK_SRC_GENERATED, GK_SRC_ALL, GK_SRC_INVALID = 0, 1, 2, 3, 4
 GK_TABLE_KEEP_DOCS = 1
 GK_TABLE_RESIDENT = 2
+GK_TABLE_PROCESS_AUDIT = 4
+GK_TABLE_PROCESS_WEBHOOK = 8
+GK_REVIEW_EXCLUDED = 1
 GK_EVAL_WANT_MATCH, GK_EVAL_NO_DOWNLOAD, GK_EVAL_WANT_LIST, GK_EVAL_ASYNC, GK_EVAL_COLLECT = 1, 2, 4, 8, 16
 GK_SWEEP_RESULT_TOTALS = 1
 
 EXPORTS = [
     "gk_engine_create", "gk_engine_destroy", "gk_last_error", "gk_version", "gk_template_add", "gk_template_remove",
-    "gk_constraint_add", "gk_constraint_remove", "gk_data_put", "gk_data_remove", "gk_table_create", "gk_table_free",
+    "gk_constraint_add", "gk_constraint_remove", "gk_data_put", "gk_data_remove", "gk_excluder_replace", "gk_excluder_excluded", "gk_table_create", "gk_table_free",
     "gk_table_eval", "gk_eval_free", "gk_render", "gk_render_error", "gk_free", "gk_dump", "gk_table_topk", "gk_topk_free",
     "gk_table_totals", "gk_totals_free", "gk_table_get_stats", "gk_batcher_start", "gk_batcher_stop", "gk_query",
     "gk_resident_sweep", "gk_sweep_free", "gk_resident_review",
@@ -148,6 +151,8 @@ def load(hostemu: bool | None = None):
     lib.gk_constraint_remove.argtypes = [vp, cp, cp]
     lib.gk_data_put.argtypes = [vp, C.POINTER(cp), sz, cp, sz]
     lib.gk_data_remove.argtypes = [vp, C.POINTER(cp), sz]
+    lib.gk_excluder_replace.argtypes = [vp, C.c_char_p, sz]
+    lib.gk_excluder_excluded.argtypes = [vp, C.c_char_p, C.POINTER(gk_review_in), C.POINTER(C.c_int32)]
     lib.gk_table_create.argtypes = [vp, C.POINTER(gk_review_in), sz, u32, C.POINTER(C.c_int32), C.POINTER(vp)]
     lib.gk_table_free.argtypes = [vp]
     lib.gk_table_free.restype = None

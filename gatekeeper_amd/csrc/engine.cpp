@@ -58,6 +58,35 @@ bool wildcard_matches(const std::string& w, const std::string& c) {
 
 std::string selector_error(const Value& sel) { return selector_error_text(sel); }
 
+// IsNamespaceExcluded for one review (excluder.go:96-105).  Bare objects: the object itself (audit).  AdmissionRequests:
+// the webhook's view, common.go:149-189 -- oldObject on DELETE else object, its namespace overwritten by request.namespace;
+// an object that does not decode is an error there, which the handler logs and then reviews the request anyway.
+bool excluder_matches(const std::vector<std::string>& pats, const std::string& ns);
+bool review_excluded(const std::vector<std::string>& pats, int kind, const Value& body) {
+  if (!body.is_object()) return false;
+  const Value* obj = &body;
+  std::string ns;
+  if (kind == GK_REVIEW_ADMISSION_REQUEST) {
+    const Value* op = body.get("operation");
+    const bool del = op && op->is_string() && op->str() == "DELETE";
+    obj = body.get(del ? "oldObject" : "object");
+    const Value* k = obj && obj->is_object() ? obj->get("kind") : nullptr;
+    if (!k || !k->is_string() || k->str().empty()) return false;
+    const Value* rns = body.get("namespace");
+    if (rns && rns->is_string()) ns = rns->str();
+  } else {
+    ns = obj_string(*obj, "metadata", "namespace");
+  }
+  if (obj_is_namespace(*obj)) return excluder_matches(pats, obj_string(*obj, "metadata", "name"));
+  return excluder_matches(pats, ns);
+}
+
+// exactOrWildcardMatch (excluder.go:120-128)
+bool excluder_matches(const std::vector<std::string>& pats, const std::string& ns) {
+  for (auto& w : pats) if (wildcard_matches(w, ns)) return true;
+  return false;
+}
+
 // error text of match.Matches for one candidate object, "" if none (subset: the error sources of match.go)
 std::string candidate_error(const Value& m, const Value& obj, const Value& ns, int source, bool* matched) {
   *matched = false;
@@ -143,6 +172,10 @@ struct gk_engine {
   std::vector<ConstraintRec> constraints;
   Value inventory = Value::object({});   // data.inventory for host rendering: only referential templates read it, and those are refused (GK_ERR_UNSUPPORTED)
   int next_quant = 0;
+  // process excluder (pkg/controller/config/process/excluder.go): process -> namespace wildcards, replaced as a whole
+  // from the Config resource's spec.match; `excluder_gen` lets resident chunks notice a change (guarded by mu)
+  std::map<std::string, std::vector<std::string>> excluder;
+  uint64_t excluder_gen = 1;
   // plan cache
   std::mutex plan_mu;
   bool plan_dirty = true;
@@ -173,6 +206,8 @@ struct gk_engine {
     gk_table* table = nullptr;
     std::vector<uint32_t> obj_of_slot;
     std::vector<uint64_t> live;       // bit per slot: still the current version of a live object
+    std::vector<uint64_t> shown;      // live AND NOT excluded from the audit process by the excluder generation `excl_gen`
+    uint64_t excl_gen = 0;
     gk_eval_out* ev = nullptr;        // bitmaps of the chunk's most recent evaluation
     uint64_t plan_gen = 0;            // ... and the plan generation they belong to
     uint64_t n_live = 0;
@@ -595,6 +630,57 @@ int gk_data_remove(gk_engine* e, const char* const* path, size_t npath) {
   return GK_OK;
 }
 
+int gk_excluder_replace(gk_engine* e, const char* match_json, size_t len) {
+  if (!e) return fail(GK_ERR_INVALID, "NULL argument");
+  try {
+    static const char* all[] = {"audit", "webhook", "mutation-webhook", "sync"};   // allProcesses (excluder.go:31-36)
+    std::map<std::string, std::vector<std::string>> next;
+    auto put = [&](const std::string& proc, const std::string& ns) {
+      auto& v = next[proc];
+      if (std::find(v.begin(), v.end(), ns) == v.end()) v.push_back(ns);
+    };
+    if (match_json && len) {
+      Value m = parse_json(match_json, len);
+      if (!m.is_null() && !m.is_array()) return fail(GK_ERR_INVALID, "spec.match must be an array of {excludedNamespaces, processes}");
+      if (m.is_array()) for (const Value& ent : m.items()) {   // Excluder.Add (excluder.go:52-76)
+        if (!ent.is_object()) continue;
+        const Value* nss = ent.get("excludedNamespaces");
+        const Value* procs = ent.get("processes");
+        if (!nss || !nss->is_array() || !procs || !procs->is_array()) continue;
+        for (const Value& ns : nss->items()) {
+          if (!ns.is_string()) continue;
+          for (const Value& op : procs->items()) {
+            if (!op.is_string()) continue;
+            if (op.str() == "*") { for (const char* a : all) put(a, ns.str()); } else put(op.str(), ns.str());
+          }
+        }
+      }
+    }
+    std::unique_lock<std::shared_mutex> l(e->mu);
+    if (next != e->excluder) { e->excluder.swap(next); e->excluder_gen++; }   // Excluder.Replace
+    return GK_OK;
+  } catch (const JsonError& ex) { return fail(GK_ERR_INVALID, ex.what());
+  } catch (const std::exception& ex) { return fail(GK_ERR_INTERNAL, ex.what()); }
+}
+
+int gk_excluder_excluded(gk_engine* e, const char* process, const gk_review_in* review, int32_t* excluded) {
+  if (!e || !process || !review || !excluded) return fail(GK_ERR_INVALID, "NULL argument");
+  try {
+    *excluded = 0;
+    std::vector<std::string> pats;
+    {
+      std::shared_lock<std::shared_mutex> l(e->mu);
+      auto it = e->excluder.find(process);
+      if (it == e->excluder.end()) return GK_OK;
+      pats = it->second;
+    }
+    Value body;
+    try { body = parse_json(review->json, review->json_len); } catch (const std::exception&) { return GK_OK; }   // decode error: not excluded
+    *excluded = review_excluded(pats, review->kind, body) ? 1 : 0;
+    return GK_OK;
+  } catch (const std::exception& ex) { return fail(GK_ERR_INTERNAL, ex.what()); }
+}
+
 int gk_table_create(gk_engine* e, const gk_review_in* reviews, size_t n, uint32_t flags, int32_t* statuses, gk_table** out) {
   if (!e || !out || (n && !reviews)) return fail(GK_ERR_INVALID, "NULL argument");
   try {
@@ -624,6 +710,17 @@ int gk_table_create(gk_engine* e, const gk_review_in* reviews, size_t n, uint32_
     std::vector<HostTable> parts(n_threads);
     std::vector<std::string> part_err(n_threads);
     std::vector<uint64_t> part_fast(n_threads, 0);
+    // process excluder: reviews of a table built for a process (audit sweep / validating webhook) whose namespace the
+    // Config excludes for that process are skipped BEFORE evaluation -- pkg/audit/manager.go:530,599 (skipExcludedNamespace),
+    // pkg/webhook/policy.go:197, pkg/webhook/common.go:149-189.  They keep their slot, hold no rows and report
+    // GK_REVIEW_EXCLUDED.
+    std::vector<std::string> excl;
+    if (flags & (GK_TABLE_PROCESS_AUDIT | GK_TABLE_PROCESS_WEBHOOK)) {
+      std::shared_lock<std::shared_mutex> l(e->mu);
+      auto it = e->excluder.find((flags & GK_TABLE_PROCESS_AUDIT) ? "audit" : "webhook");
+      if (it != e->excluder.end()) excl = it->second;
+    }
+    const Flattener::ExcludeFn excl_fn = [&](bool is_ns, const std::string& ns, const std::string& name) { return excluder_matches(excl, is_ns ? name : ns); };
     auto work = [&](size_t w) {
       try {
         Flattener fl(&e->dict, &e->dict_reg);
@@ -636,7 +733,14 @@ int gk_table_create(gk_engine* e, const gk_review_in* reviews, size_t n, uint32_
             rr.kind = r.kind; rr.source = r.source; rr.json = r.json; rr.json_len = r.json_len;
             rr.ns_json = r.namespace_json; rr.ns_len = r.namespace_len; rr.nsobj_json = r.ns_object_json; rr.nsobj_len = r.ns_object_len;
             rr.operation = r.operation;
-            if (fl.add_json(rr, e->ns_cache, &parts[w], &t->obj_keys[i])) { if (statuses) statuses[i] = GK_OK; part_fast[w]++; continue; }
+            int rc = fl.add_json(rr, e->ns_cache, &parts[w], &t->obj_keys[i], excl.empty() ? nullptr : &excl_fn);
+            if (rc == Flattener::ADDED) { if (statuses) statuses[i] = GK_OK; part_fast[w]++; continue; }
+            if (rc == Flattener::EXCLUDED) {
+              if (statuses) statuses[i] = GK_REVIEW_EXCLUDED;
+              fl.add_skipped(&parts[w]);
+              part_fast[w]++;
+              continue;
+            }
           }
           ReviewDoc doc;
           int st = GK_OK;
@@ -644,6 +748,13 @@ int gk_table_create(gk_engine* e, const gk_review_in* reviews, size_t n, uint32_
             Value body = parse_json(r.json, r.json_len);
             Value mns = parse_opt(r.namespace_json, r.namespace_len);
             Value nso = parse_opt(r.ns_object_json, r.ns_object_len);
+            if (!excl.empty() && review_excluded(excl, r.kind, body)) {
+              if (statuses) statuses[i] = GK_REVIEW_EXCLUDED;
+              doc.request = Value::object({});
+              fl.add_skipped(&parts[w]);
+              if (keep) t->docs[i] = doc;
+              continue;
+            }
             if (r.kind == GK_REVIEW_OBJECT) doc = normalize_object(body, mns, nso, r.source, r.operation ? r.operation : "", e->ns_cache);
             else doc = normalize_admission_request(body, mns, nso, r.source, e->ns_cache);
           } catch (const std::exception& ex) {
@@ -664,7 +775,8 @@ int gk_table_create(gk_engine* e, const gk_review_in* reviews, size_t n, uint32_
             }
             t->obj_keys[i] = std::move(key);
           }
-          fl.add(doc, &parts[w]);
+          if (st == GK_ERR_REVIEW) fl.add_skipped(&parts[w]);   // HandleReview's error is the caller's answer: nothing is evaluated
+          else fl.add(doc, &parts[w]);
           if (keep) t->docs[i] = doc;
         }
         fl.flush(&parts[w]);
@@ -1327,7 +1439,24 @@ int gk_resident_sweep(gk_engine* e, uint32_t flags, gk_sweep_out** out) {
       if (rc != GK_OK) return rc;
       c.plan_gen = gen;
     }
-    // per-constraint totals over the live slots of all chunks
+    {   // audit-process excluder over the resident objects (manager.go:599): a mask beside `live`, refreshed when the Config changes
+      std::shared_lock<std::shared_mutex> l(e->mu);
+      auto ex = e->excluder.find("audit");
+      for (auto& c : R.chunks) {
+        if (c.excl_gen == e->excluder_gen && c.shown.size() == c.live.size()) {
+          for (size_t w = 0; w < c.live.size(); w++) c.shown[w] &= c.live[w];
+          continue;
+        }
+        c.shown = c.live;
+        if (ex != e->excluder.end() && !ex->second.empty())
+          for (size_t k = 0; k < c.obj_of_slot.size(); k++) {
+            const gk_engine::ResObj& o = R.objs[c.obj_of_slot[k]];
+            if (excluder_matches(ex->second, o.is_namespace ? o.path.back() : o.ns)) c.shown[k / 64] &= ~(1ull << (k % 64));
+          }
+        c.excl_gen = e->excluder_gen;
+      }
+    }
+    // per-constraint totals over the live, not excluded slots of all chunks
     if (!R.chunks.empty()) {
       const gk_eval_out* ev0 = R.chunks[0].ev;
       h->ids.assign(ev0->constraint_ids, ev0->constraint_ids + ev0->n_constraints);
@@ -1342,8 +1471,8 @@ int gk_resident_sweep(gk_engine* e, uint32_t flags, gk_sweep_out** out) {
     for (auto& c : R.chunks) {
       const gk_eval_out* ev = c.ev;
       for (uint32_t row = 0; row < ev->n_constraints && row < nc; row++)
-        for (uint32_t w = 0; w < ev->n_tiles; w++) h->pairs[row] += (uint64_t)__builtin_popcountll(ev->viol[(size_t)row * ev->n_tiles + w] & c.live[w]);
-      for (uint32_t w = 0; w < ev->n_tiles; w++) beyond += (uint64_t)__builtin_popcountll(ev->too_big[w] & c.live[w]);
+        for (uint32_t w = 0; w < ev->n_tiles; w++) h->pairs[row] += (uint64_t)__builtin_popcountll(ev->viol[(size_t)row * ev->n_tiles + w] & c.shown[w]);
+      for (uint32_t w = 0; w < ev->n_tiles; w++) beyond += (uint64_t)__builtin_popcountll(ev->too_big[w] & c.shown[w]);
     }
     if (flags & GK_SWEEP_RESULT_TOTALS) {   // results, not pairs (pkg/audit/manager.go:902): render the violating live pairs
       std::shared_lock<std::shared_mutex> l(e->mu);
@@ -1351,7 +1480,7 @@ int gk_resident_sweep(gk_engine* e, uint32_t flags, gk_sweep_out** out) {
         const gk_eval_out* ev = c.ev;
         for (uint32_t slot = 0; slot < c.obj_of_slot.size(); slot++) {
           const uint64_t bit = 1ull << (slot % 64);
-          if (!(c.live[slot / 64] & bit)) continue;
+          if (!(c.shown[slot / 64] & bit)) continue;
           bool any = false;
           for (uint32_t row = 0; row < ev->n_constraints && !any; row++) any = (ev->viol[(size_t)row * ev->n_tiles + slot / 64] & bit) != 0;
           if (!any) continue;
@@ -1384,12 +1513,17 @@ void gk_sweep_free(gk_sweep_out* o) { if (o) delete reinterpret_cast<SweepHolder
 
 namespace {
 // the cached answer for one resident object, as gk_query's JSON; false: not resident / not swept / its slot is stale
-bool resident_answer(gk_engine* e, uint32_t id, std::string* json, int* status, std::string* err) {
+// audit: the answer pkg/audit would get -- an object the Config excludes from the audit process is never reviewed ("[]")
+bool resident_answer(gk_engine* e, uint32_t id, std::string* json, int* status, std::string* err, bool audit = false) {
   gk_engine::Resident& R = e->resident;
   const gk_engine::ResObj& o = R.objs[id];
   if (!R.swept || !o.alive || o.chunk == UINT32_MAX) return false;
   const gk_engine::ResChunk& c = R.chunks[o.chunk];
   if (!c.ev || !(c.live[o.slot / 64] & (1ull << (o.slot % 64)))) return false;
+  if (audit) {
+    { std::shared_lock<std::shared_mutex> l(e->mu); if (c.excl_gen != e->excluder_gen) return false; }   // Config changed since the sweep
+    if (!(c.shown[o.slot / 64] & (1ull << (o.slot % 64)))) { *json = "[]"; *status = GK_OK; return true; }
+  }
   { std::lock_guard<std::mutex> l(e->plan_mu); if (e->plan_dirty || c.plan_gen != e->plan_gen) return false; }
   const gk_review_in in = resident_review_in(R, o);
   bool too_big = false;
@@ -1410,8 +1544,8 @@ int gk_resident_review(gk_engine* e, const char* const* path, size_t npath, char
     auto it = R.by_key.find(key);
     std::string js, err;
     int st = GK_OK;
-    if (it == R.by_key.end() || !resident_answer(e, it->second, &js, &st, &err))
-      return fail(GK_ERR_NOT_FOUND, "object is not in the swept resident set (unknown, changed since the last gk_resident_sweep, or policies changed)");
+    if (it == R.by_key.end() || !resident_answer(e, it->second, &js, &st, &err, true))
+      return fail(GK_ERR_NOT_FOUND, "object is not in the swept resident set (unknown, changed since the last gk_resident_sweep, or policies / the process excluder changed)");
     if (st != GK_OK) return fail(st, err);
     char* buf = (char*)malloc(js.size() + 1);
     memcpy(buf, js.c_str(), js.size() + 1);

@@ -426,6 +426,13 @@ void Flattener::add(const ReviewDoc& doc, HostTable* out) {
   finish_review(ns, doc.source, out);
 }
 
+void Flattener::add_skipped(HostTable* out) {
+  ReviewDoc none;
+  none.request = Value::object({});
+  add(none, out);
+  out->rflags.back() |= RF_SKIP;
+}
+
 // $ns rows (only what the match layer reads from Matchable.Namespace: name + labels), source flags, bookkeeping
 void Flattener::finish_review(const Value& ns, int source, HostTable* out) {
   if (ns.defined()) {
@@ -823,11 +830,11 @@ void Flattener::fast_match_facts(const ObjFacts& f, const Value& ns, bool is_old
   if (kind.empty()) review_flags_ |= is_old ? RF_OLD_BAD : RF_OBJ_BAD;
 }
 
-bool Flattener::add_json(const RawReview& r, const NsCache& cache, HostTable* out, std::string* obj_key) {
-  if (r.kind != 1 || !r.json) return false;   // AdmissionRequest documents take the general path
+int Flattener::add_json(const RawReview& r, const NsCache& cache, HostTable* out, std::string* obj_key, const ExcludeFn* excluded) {
+  if (r.kind != 1 || !r.json) return DECLINED;   // AdmissionRequest documents take the general path
   t_ = out;
   const size_t stage0 = stage_.size(), heap0 = out->heap.size();
-  auto bail = [&]() { stage_.resize(stage0); out->heap.resize(heap0); return false; };
+  auto bail = [&]() { stage_.resize(stage0); out->heap.resize(heap0); return (int)DECLINED; };
   ctrs_.clear();
   ctr_touched_.clear();
   scratch_keep_.clear();
@@ -852,6 +859,7 @@ bool Flattener::add_json(const RawReview& r, const NsCache& cache, HostTable* ou
   }
   const std::string name = fobj.name.set ? std::string(fobj.name.p, fobj.name.n) : std::string();
   const std::string nsfield = fobj.ns.set ? std::string(fobj.ns.p, fobj.ns.n) : std::string();
+  if (excluded && (*excluded)(kind == "Namespace" && group.empty(), nsfield, name)) { bail(); return EXCLUDED; }
   uint32_t members = 8;   // uid kind resource operation userInfo object oldObject options
   emit_str(0, "uid", "");
   uint32_t kp = child(0, "kind");
@@ -893,7 +901,7 @@ bool Flattener::add_json(const RawReview& r, const NsCache& cache, HostTable* ou
     k = group; k.push_back('\0'); k += version; k.push_back('\0'); k += kind; k.push_back('\0'); k += nsfield; k.push_back('\0'); k += name;
   }
   finish_review(ns, r.source, out);
-  return true;
+  return ADDED;
 }
 
 void Flattener::finish(HostTable* out) {

@@ -11,6 +11,7 @@
 #include <memory>
 #include <new>
 #include <shared_mutex>
+#include <functional>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -190,13 +191,18 @@ class Flattener {
  public:
   explicit Flattener(PathDict* dict, const DictRegistry* reg = nullptr);
   void add(const ReviewDoc& doc, HostTable* out);
+  void add_skipped(HostTable* out);   // a slot that holds no rows and is never evaluated (RF_SKIP)
   // Fast ingest: ONE pass over the JSON text of a review straight into rows -- no Value
   // tree -- including HandleReview's normalisation (target.go:81-179, 269-287) and the match-layer facts.  Produces
   // exactly the rows add(normalize_*(parse_json(..))) produces (tests/test_ingest.py compares table digests).
   // Returns false -- with nothing added -- when the text needs the general path (malformed JSON, duplicate object keys,
   // nesting beyond the fast parser's depth ...): the caller then runs parse_json + normalize_* + add, which also words
   // the errors.  obj_key: the audit sort key of the object (group \0 version \0 kind \0 namespace \0 name).
-  bool add_json(const RawReview& r, const NsCache& cache, HostTable* out, std::string* obj_key);
+  // `excluded` (may be NULL): called with (is a core Namespace, metadata.namespace, metadata.name) once the object's
+  // identity is known; true -> the review is dropped again and EXCLUDED is returned (process excluder, engine.cpp).
+  enum { DECLINED = 0, ADDED = 1, EXCLUDED = 2 };
+  typedef std::function<bool(bool, const std::string&, const std::string&)> ExcludeFn;
+  int add_json(const RawReview& r, const NsCache& cache, HostTable* out, std::string* obj_key, const ExcludeFn* excluded = nullptr);
   void finish(HostTable* out);   // flush + build_index
   void flush(HostTable* out);    // closes the tile being built (parallel table builds flush per part, then append)
   static void build_index(HostTable* out);   // slots + dense [tile][slot] index from the per-tile segment lists

@@ -81,7 +81,9 @@ enum ReviewFlag : uint32_t {
   RF_OLD_LABELS_BAD = 1u << 15,
   RF_NS_LABELS_BAD = 1u << 16,
   RF_OBJ_BAD = 1u << 17,         // request.object is a JSON object that Unstructured.UnmarshalJSON rejects (no `kind`):
-  RF_OLD_BAD = 1u << 18,         //   gkReviewToObject fails with ErrRequestObject (pkg/target/matcher.go:73-93)
+  RF_OLD_BAD = 1u << 18,
+  RF_SKIP = 1u << 19,            // the review is not evaluated: HandleReview rejected it, or the process excluder skips its
+                                 //   namespace (engine.cpp) -- no violation, match or autoreject bit for any constraint         //   gkReviewToObject fails with ErrRequestObject (pkg/target/matcher.go:73-93)
 };
 
 // ------------------------------------------------------------------------------------------------ predicates

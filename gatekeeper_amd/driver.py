@@ -402,7 +402,39 @@ class Engine:
         arr = (C.c_char_p * len(path))(*[p.encode() for p in path])
         self._check(self.lib.gk_data_remove(self.handle, arr, len(path)))
 
-    def create_table(self, reviews, keep_docs=True, resident=False):
+    @staticmethod
+    def _process_flag(process):
+        if process is None:
+            return 0
+        if process not in ("audit", "webhook"):
+            raise ValueError("tables are built for process 'audit' or 'webhook', not %r" % (process,))
+        return L.GK_TABLE_PROCESS_AUDIT if process == "audit" else L.GK_TABLE_PROCESS_WEBHOOK
+
+    def set_excluder(self, match_entries):
+        """process.Excluder.Replace(New().Add(entries)): entries = the Config resource's spec.match"""
+        js = json.dumps(match_entries or []).encode()
+        self._check(self.lib.gk_excluder_replace(self.handle, js, len(js)))
+
+    def is_excluded(self, process, review):
+        """process.Excluder.IsNamespaceExcluded for one review (a to_review_in value)"""
+        arr = (L.gk_review_in * 1)()
+        self._fill(arr[0], review)
+        out = C.c_int32(0)
+        self._check(self.lib.gk_excluder_excluded(self.handle, process.encode(), arr, C.byref(out)))
+        return bool(out.value)
+
+    @staticmethod
+    def _fill(a, r):
+        a.kind, a.source = r.kind, r.source
+        a.json, a.json_len = r.json, len(r.json)
+        if r.namespace is not None:
+            a.namespace_json, a.namespace_len = r.namespace, len(r.namespace)
+        if r.ns_object is not None:
+            a.ns_object_json, a.ns_object_len = r.ns_object, len(r.ns_object)
+        a.operation = r.operation
+
+    def create_table(self, reviews, keep_docs=True, resident=False, process=None):
+        """process: 'audit' / 'webhook' applies the process excluder -- excluded reviews get status GK_REVIEW_EXCLUDED"""
         n = len(reviews)
         arr = (L.gk_review_in * max(1, n))()
         keep = []
@@ -418,15 +450,15 @@ class Engine:
             a.operation = r.operation
         st = (C.c_int32 * max(1, n))()
         h = C.c_void_p()
-        flags = (L.GK_TABLE_KEEP_DOCS if keep_docs else 0) | (L.GK_TABLE_RESIDENT if resident else 0)
+        flags = (L.GK_TABLE_KEEP_DOCS if keep_docs else 0) | (L.GK_TABLE_RESIDENT if resident else 0) | self._process_flag(process)
         self._check(self.lib.gk_table_create(self.handle, arr, n, flags, st, C.byref(h)))
         return Table(self, h, list(st)[:n], n)
 
-    def create_table_native(self, reviews_ptr, n, keep_docs=False, resident=False):
+    def create_table_native(self, reviews_ptr, n, keep_docs=False, resident=False, process=None):
         """gk_table_create on an existing gk_review_in array (e.g. synth.NativeBatch.reviews)"""
         st = (C.c_int32 * max(1, n))()
         h = C.c_void_p()
-        flags = (L.GK_TABLE_KEEP_DOCS if keep_docs else 0) | (L.GK_TABLE_RESIDENT if resident else 0)
+        flags = (L.GK_TABLE_KEEP_DOCS if keep_docs else 0) | (L.GK_TABLE_RESIDENT if resident else 0) | self._process_flag(process)
         self._check(self.lib.gk_table_create(self.handle, reviews_ptr, n, flags, st, C.byref(h)))
         return Table(self, h, st, n)
 
@@ -839,10 +871,21 @@ class Client:
             info[self.driver.constraint_id(c)] = (c, ea, scoped)
         return info
 
-    def ReviewBatch(self, objs, enforcement_point=AUDIT_EP, namespaces=None):
+    def SetExcluder(self, match_entries):
+        """The Config resource's spec.match -> the process excluder (pkg/controller/config/process/excluder.go:52-82);
+        honoured by AuditAggregate / AuditFromCache (process "audit") and ReviewBatch(process=...)."""
+        self.driver.engine.set_excluder(match_entries)
+
+    def IsNamespaceExcluded(self, process, obj, namespace=None):
+        """process.Excluder.IsNamespaceExcluded (excluder.go:96-105); AdmissionRequests the way the webhook looks at them"""
+        r = to_review_in(obj, namespace)
+        return False if r is None else self.driver.engine.is_excluded(process, r)
+
+    def ReviewBatch(self, objs, enforcement_point=AUDIT_EP, namespaces=None, process=None):
         """Review many objects in ONE device launch (the shape the audit sweep takes).  -> one entry per object:
         list[Result], or a ReviewFailure for an object that HandleReview rejects or that is beyond the engine's limits
-        (never an empty list for those: the engine fails closed)."""
+        (never an empty list for those: the engine fails closed).  process ('audit' / 'webhook'): objects the Config
+        excludes for that process are skipped before evaluation ([]), as the audit manager / webhook handler do."""
         rins, idx = [], []
         for i, o in enumerate(objs):
             r = to_review_in(o, namespaces[i] if namespaces else None)
@@ -852,12 +895,12 @@ class Client:
         out = [[] for _ in objs]
         if not rins:
             return out
-        table = self.driver.engine.create_table(rins)
+        table = self.driver.engine.create_table(rins, process=process)
         try:
             ev = table.eval()
             failed = set()
             for k, st in enumerate(table.statuses):
-                if st != L.GK_OK:
+                if st not in (L.GK_OK, L.GK_REVIEW_EXCLUDED):
                     failed.add(k)
                     out[idx[k]] = ReviewFailure(idx[k], "review %d rejected by HandleReview" % idx[k])   # ErrReview
             for k in ev.too_big_reviews():
@@ -895,12 +938,12 @@ class Client:
         namespace, name, message, action; messages truncated to msg_size bytes, :1039-1048).  Only the top-k candidates
         selected on the device are rendered to messages for the lists.  -> AuditReport"""
         rins = [to_review_in(o, namespaces[i] if namespaces else None) for i, o in enumerate(objs)]
-        table = self.driver.engine.create_table(rins, resident=True)
+        table = self.driver.engine.create_table(rins, resident=True, process="audit")
         report = AuditReport()
         try:
             ev = table.eval()
             for k, st in enumerate(table.statuses):
-                if st != L.GK_OK:
+                if st not in (L.GK_OK, L.GK_REVIEW_EXCLUDED):
                     report.errors.append(ReviewFailure(k, "review %d rejected by HandleReview" % k))
             for k in ev.too_big_reviews():
                 report.errors.append(ReviewFailure(k, str(LimitError("review %d" % k)), LimitError("review %d" % k)))

@@ -80,6 +80,18 @@ typedef struct {
   const char* operation;        /* AugmentedUnstructured.Operation ("" / NULL = none) */
 } gk_review_in;
 
+/* ---- process excluder (row f3) ---------------------------------------------------------------------------- */
+/* Excluder.Replace(New().Add(config.spec.match)) -- pkg/controller/config/process/excluder.go:52-82, fed by the Config
+ * controller (pkg/controller/config/config_controller.go): match_json = the Config's spec.match, a JSON array of
+ * {"excludedNamespaces": [wildcard...], "processes": ["audit"|"webhook"|"mutation-webhook"|"sync"|"*"...]}; NULL / "[]"
+ * clears it.  Tables built with GK_TABLE_PROCESS_* and the resident sweep (process "audit") skip excluded objects before
+ * evaluation: pkg/audit/manager.go:530,599, pkg/webhook/policy.go:197. */
+int gk_excluder_replace(gk_engine* e, const char* match_json, size_t len);
+/* Excluder.IsNamespaceExcluded(process, obj) (excluder.go:96-105) for one review; AdmissionRequests are looked at the way
+ * the webhook does (pkg/webhook/common.go:149-189: oldObject on DELETE, namespace = request.namespace). */
+int gk_excluder_excluded(gk_engine* e, const char* process, const gk_review_in* review, int32_t* excluded);
+
+
 /* Flatten n reviews into key-path -> value SoA rows and upload them to HBM (they stay resident until freed).
  * A review that HandleReview rejects gets status GK_ERR_REVIEW in statuses[i] (may be NULL) and evaluates to nothing. */
 int gk_table_create(gk_engine* e, const gk_review_in* reviews, size_t n, uint32_t flags, int32_t* statuses, gk_table** out);
@@ -95,6 +107,9 @@ typedef struct {
 } gk_table_stats;
 int gk_table_get_stats(const gk_table* t, gk_table_stats* out);
 #define GK_TABLE_KEEP_DOCS 1u   /* keep parsed reviews on the host so violations can be rendered to messages */
+#define GK_TABLE_PROCESS_AUDIT 4u     /* apply the process excluder (gk_excluder_replace) for process "audit" / "webhook":     */
+#define GK_TABLE_PROCESS_WEBHOOK 8u   /* excluded reviews keep their slot, hold no rows and get status GK_REVIEW_EXCLUDED      */
+#define GK_REVIEW_EXCLUDED 1          /* statuses[i]: skipped before evaluation (not an error)                                 */
 #define GK_TABLE_RESIDENT 2u    /* the table is evaluated again and again (audit set): the engine may compile a plan variant
                                    whose LDS layout fits this table's array sizes (first evaluation pays the compile) */
 
