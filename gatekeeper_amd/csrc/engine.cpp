@@ -990,6 +990,7 @@ int gk_table_eval(gk_engine* e, gk_table* t, uint32_t flags, gk_eval_out** out) 
         bool str = false;
         for (uint32_t j = 0; j < (ent & 0xFF); j++) str = str || pred_needs_str(hp.path_preds[(ent >> 8) + j]);
         if (str) hdrs_read += n;
+        if (getenv("GK_PATH_STATS")) fprintf(stderr, "[path] %u rows %llu per-group %.1f str %d preds %u\n", pth, (unsigned long long)n, (double)n / std::max<uint32_t>(1, (p.n_reviews + t->rpt - 1) / t->rpt), (int)str, ent & 0xFF);
       }
       plan_bytes += (uint64_t)hp.path_preds.size() * sizeof(Pred) + hp.code.size() * 4 + hp.cheap.size();
     };
