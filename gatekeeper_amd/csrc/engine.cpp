@@ -1257,7 +1257,7 @@ void batcher_loop(gk_engine* e) {
         try {
           bool too_big = false;
           r->results = query_results_json(e, table, *ev, (uint32_t)i, ins[i], &too_big);
-          if (too_big) { r->status = GK_ERR_LIMIT; r->error = "review is beyond the engine's limits (more than 255 elements in an array that constraint predicates iterate)"; }
+          if (too_big) { r->status = GK_ERR_LIMIT; r->error = "review is beyond the engine's limits (more than 255 elements in an array that constraint predicates iterate, or an object where they iterate array elements)"; }
         } catch (const std::exception& ex) { r->status = GK_ERR_REGO; r->error = ex.what(); }
       }
     }
@@ -1530,7 +1530,7 @@ bool resident_answer(gk_engine* e, uint32_t id, std::string* json, int* status, 
   bool too_big = false;
   *json = query_results_json(e, c.table, *c.ev, o.slot, in, &too_big);
   *status = GK_OK;
-  if (too_big) { *status = GK_ERR_LIMIT; *err = "review is beyond the engine's limits (more than 255 elements in an array that constraint predicates iterate)"; }
+  if (too_big) { *status = GK_ERR_LIMIT; *err = "review is beyond the engine's limits (more than 255 elements in an array that constraint predicates iterate, or an object where they iterate array elements)"; }
   return true;
 }
 }  // namespace

@@ -15,7 +15,9 @@ size_t PathDict::KeyHash::operator()(const std::pair<uint32_t, std::string>& k) 
 PathDict::PathDict() { infos_.push_back({kNone, "", false, 0}); }
 
 uint32_t PathDict::intern(uint32_t parent, const std::string& key, bool is_elem) {
-  std::pair<uint32_t, std::string> k(parent, is_elem ? std::string("\x01[]") : key);
+  // the "[]" child is keyed by a flag beside the parent id (ids stay below 2^31), never by a reserved member name: an
+  // object member may be called anything
+  std::pair<uint32_t, std::string> k(is_elem ? (parent | 0x80000000u) : parent, is_elem ? std::string() : key);
   {
     std::shared_lock<std::shared_mutex> rl(mu_);
     auto it = map_.find(k);

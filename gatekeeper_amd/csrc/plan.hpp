@@ -92,7 +92,7 @@ enum PredOp : uint32_t {
   P_DEFINED = 1,     // row exists
   P_TRUTHY = 2,      // row exists and is not `false`
   P_CMP = 3,         // compare(row, const) <op> 0 under Rego's total order
-  P_TYPE = 4,        // (1<<type) & mask
+  P_TYPE = 4,        // (1<<type) & mask (b != 0: and the container row has members)
   P_STR_PREFIX = 5,  // string row startswith const
   P_STR_SUFFIX = 6,
   P_STR_CONTAINS = 7,

@@ -48,12 +48,14 @@ class UnsupportedError(EngineError):
 
 class LimitError(EngineError):
     """GK_ERR_LIMIT: the review is beyond the engine's limits (an array that element predicates iterate has more than
-    255 elements).  The engine reports such reviews in `too_big` and NEVER answers "no violations" for them: every caller
+    255 elements, or holds an OBJECT where the compiled predicates iterate array elements -- Rego's `x[_]` would walk the
+    object's values).  The engine reports such reviews in `too_big` and NEVER answers "no violations" for them: every caller
     below fails closed (raises / returns this error for that review) so the object can go to the reference CPU driver."""
 
     def __init__(self, what="review"):
         super().__init__(L.GK_ERR_LIMIT, "%s is beyond the engine's limits (more than 255 elements in an array that "
-                                         "constraint predicates iterate): not evaluated on the device" % what)
+                                         "constraint predicates iterate, or an object where they iterate array elements): "
+                                         "not evaluated on the device" % what)
 
 
 # ---------------------------------------------------------------------------------------------- review shapes

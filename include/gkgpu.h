@@ -28,8 +28,9 @@ typedef enum {
   GK_ERR_REVIEW = -6,       /* review rejected by HandleReview (target.go:81-138, e.g. ErrOldObjectIsNil) */
   GK_ERR_INTERNAL = -7,
   GK_ERR_LIMIT = -8         /* a review is beyond the engine's limits (an array that element predicates iterate has more
-                               than 255 elements): reported per review in gk_eval_out.too_big, NEVER evaluated to "no
-                               violations" -- the caller must fail closed or take that review to the reference CPU driver */
+                               than 255 elements, or an object sits where they iterate array elements): reported per
+                               review in gk_eval_out.too_big, NEVER evaluated to "no violations" -- the caller must fail
+                               closed or take that review to the reference CPU driver */
 } gk_status;
 
 typedef struct {

@@ -64,8 +64,26 @@ def load_both(backend, templates, constraints, data=(), validate=True, **kw):
     return c, oc
 
 
-def assert_parity(c, oc, reviews, ep=D.AUDIT_EP, namespaces=None):
-    """Product == oracle for every review: (1) the rendered result multisets (constraint, msg, details, actions), and
+def object_where_elements_are_iterated(review):
+    """True when some container-ish member of the reviewed object(s) is a non-empty OBJECT under a key where Kubernetes
+    holds arrays (the paths the PSP templates iterate with `[_]`): the engine refuses such reviews (fail closed) because
+    Rego would walk the object's values."""
+    arrays = ("containers", "initContainers", "ephemeralContainers", "volumes", "ports", "volumeMounts", "env")
+
+    def walk(v):
+        if isinstance(v, dict):
+            return any((k in arrays and isinstance(x, dict) and x) or walk(x) for k, x in v.items())
+        if isinstance(v, list):
+            return any(walk(x) for x in v)
+        return False
+    body = review.object if isinstance(review, D.AugmentedUnstructured) else review.admission_request if isinstance(review, D.AugmentedReview) else review
+    return walk(body)
+
+
+def assert_parity(c, oc, reviews, ep=D.AUDIT_EP, namespaces=None, refused=None):
+    """refused (a list, or None): reviews the engine REFUSES with a LimitError are collected there instead of failing the
+    comparison, provided they hold an object where array elements are iterated; everything else must match.
+    Product == oracle for every review: (1) the rendered result multisets (constraint, msg, details, actions), and
     (2) the RAW device bitmaps -- the violation bits and the match-error bits, before any host rendering -- against the
     pair sets the oracle's results imply, so that a spurious device bit cannot hide behind a renderer that returns []."""
     got = c.ReviewBatch(reviews, ep, namespaces)
@@ -73,6 +91,10 @@ def assert_parity(c, oc, reviews, ep=D.AUDIT_EP, namespaces=None):
     want_viol, want_err = set(), set()
     for i, (rv, g) in enumerate(zip(reviews, got)):
         exp = oc.review(to_oracle_review(rv), ep, namespaces[i] if namespaces else None)
+        if refused is not None and isinstance(g, D.ReviewFailure) and isinstance(g.cause, D.LimitError):
+            assert object_where_elements_are_iterated(rv), "review %d refused without cause: %r" % (i, g)
+            refused.append(i)
+            continue
         assert not isinstance(g, Exception), "review %d: %r" % (i, g)
         a, b = sorted(key(r) for r in g), sorted(key(r) for r in exp)
         assert a == b, "review %d: device %r != oracle %r" % (i, a, b)
@@ -85,9 +107,10 @@ def assert_parity(c, oc, reviews, ep=D.AUDIT_EP, namespaces=None):
     try:
         ev = table.eval()
         active = {cid: (cons.get("kind"), (cons.get("metadata") or {}).get("name")) for cid, (cons, _, _) in c._active(ep).items()}
-        assert not ev.too_big_reviews()
-        dev_viol = {(active[cid], r) for cid, r in ev.pairs("viol") if cid in active}
-        dev_err = {(active[cid], r) for cid, r in ev.pairs("err") if cid in active}
+        skip = set(refused or ())
+        assert set(int(r) for r in ev.too_big_reviews()) == skip
+        dev_viol = {(active[cid], r) for cid, r in ev.pairs("viol") if cid in active and r not in skip}
+        dev_err = {(active[cid], r) for cid, r in ev.pairs("err") if cid in active and r not in skip}
         assert dev_viol == want_viol, "raw violation bitmap != oracle pairs: only device %r, only oracle %r" % (
             sorted(dev_viol - want_viol)[:5], sorted(want_viol - dev_viol)[:5])
         assert dev_err == want_err, "raw match-error bitmap != oracle pairs: only device %r, only oracle %r" % (

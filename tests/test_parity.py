@@ -425,7 +425,9 @@ def test_structural_fuzz(backend, fixtures):
             else:
                 req["oldObject"] = m
             revs.append(D.AugmentedReview(D.AdmissionRequest(req), ns, "Original"))
-        assert assert_parity(c, oc, revs) > 50
+        refused = []
+        assert assert_parity(c, oc, revs, refused=refused) > 50
+        assert len(refused) < len(revs) // 10     # (objects mutated into the place of an iterated array: refused, fail closed)
 
 
 REGEX_TEMPLATE = {
@@ -795,3 +797,31 @@ def test_policy_corpus_200_templates(backend, fixtures):
     objs = synth.gen_objects(250, seed=11, mixed=True)
     rv = [D.AugmentedUnstructured(D.Unstructured(o), synth.namespace_for(o, nss), "Original") for o in objs]
     assert assert_parity(c, oc, rv) > 2000
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_member_names_and_objects_where_arrays_are_iterated(backend, fixtures):
+    """(1) A member literally named like an internal marker ("\\x01[]", "[]", "$d", "$m") is an ordinary key: it aliases
+    neither the array-element step of the key-path dictionary nor the synthetic subtrees.  (2) `containers[_]` over an
+    OBJECT walks its values in Rego; the device plan iterates array elements only, so such a review is REFUSED
+    (LimitError: fail closed) -- never answered "no violations"."""
+    tmpl = next(t for t in synth.psp_templates(fixtures) if t["spec"]["crd"]["spec"]["names"]["kind"] == "K8sPSPPrivilegedContainer")
+    cons = [{"apiVersion": "constraints.gatekeeper.sh/v1beta1", "kind": "K8sPSPPrivilegedContainer", "metadata": {"name": "p"},
+             "spec": {"match": {"kinds": [{"apiGroups": [""], "kinds": ["Pod"]}]}}}]
+    c, oc = load_both(backend, [tmpl], cons)
+    priv = {"name": "c", "image": "i", "securityContext": {"privileged": True}}
+    arrays, objects = [], []
+    for i, weird in enumerate(["\x01[]", "[]", "$d", "$m", "$ns", "plain"]):
+        objects.append({"apiVersion": "v1", "kind": "Pod", "metadata": {"name": "a%d" % i, "namespace": "d", "labels": {weird: "x"}},
+                        "spec": {"containers": {weird: priv}, weird: [priv]}})               # containers is an OBJECT with that member
+        arrays.append({"apiVersion": "v1", "kind": "Pod", "metadata": {"name": "b%d" % i, "namespace": "d", "labels": {weird: "x"}},
+                       "spec": {"containers": [priv, {"name": "ok", "image": "i", weird: {"securityContext": {"privileged": True}}}], weird: {"containers": [priv]}}})
+        arrays.append({"apiVersion": "v1", "kind": "Pod", "metadata": {"name": "c%d" % i, "namespace": "d"},
+                       "spec": {"containers": [{"name": "ok", "image": "i", weird: [priv]}], "initContainers": {}}})   # an EMPTY object iterates nothing
+    wrap = lambda p: D.AugmentedUnstructured(D.Unstructured(p), None, "Original")   # noqa: E731
+    assert assert_parity(c, oc, [wrap(p) for p in arrays]) == 6
+    got = c.ReviewBatch([wrap(p) for p in objects + arrays[:2]])
+    for g, p in zip(got, objects):
+        assert isinstance(g, D.ReviewFailure) and isinstance(g.cause, D.LimitError), p["metadata"]["name"]
+        assert len(oc.review(to_oracle_review(wrap(p)), D.AUDIT_EP, None)) == 1      # what Rego says: a violation
+    assert not isinstance(got[-1], Exception) and not isinstance(got[-2], Exception)
