@@ -145,7 +145,7 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts) {
       switch (p.op) {
         case P_DEFINED: cond = "true"; break;
         case P_TRUTHY: cond = "!(t == T_BOOL && r.lo == 0u)"; break;
-        case P_TYPE: cond = "((" + u(p.ctype) + " >> t) & 1u) != 0u" + std::string(p.b ? " && r.lo != 0u" : ""); break;
+        case P_TYPE: cond = "((" + u(p.ctype) + " >> t) & 1u) != 0u"; break;
         case P_BITS: cond = "t == T_INT && (r.lo & " + u((uint32_t)p.k) + ") | (r.hi & " + u((uint32_t)(p.k >> 32)) + ")"; cond = "(t == T_INT) && (((r.lo & " + u((uint32_t)p.k) + ") | (r.hi & " + u((uint32_t)(p.k >> 32)) + ")) != 0u)"; break;
         case P_COUNT_CMP: cond = std::string("(t == T_OBJECT || t == T_ARRAY) && ((int64_t)r.lo ") + kCmpOps[p.cmp] + " " + std::to_string((long long)(int64_t)p.k) + "ll)"; break;
         case P_CMP:

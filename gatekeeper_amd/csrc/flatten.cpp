@@ -119,6 +119,19 @@ void DictRegistry::match(const PathDict& dict, uint32_t path_id, std::vector<Dic
   for (const auto& p : pats_) if (pattern_matches(p.pat, dict, path_id)) { if (!out->empty()) throw std::runtime_error("overlapping dictionary patterns on " + dict.to_string(path_id)); *out = p.entries; }
 }
 
+void DictRegistry::add_guard(const Pattern& container) {
+  const std::string k = pattern_to_string(container);
+  std::unique_lock<std::shared_mutex> l(mu_);
+  for (auto& g : guards_) if (g.first == k) return;
+  guards_.emplace_back(k, container);
+  gen_++;
+}
+bool DictRegistry::guarded(const PathDict& dict, uint32_t path_id) const {
+  std::shared_lock<std::shared_mutex> l(mu_);
+  for (const auto& g : guards_) if (pattern_matches(g.second, dict, path_id)) return true;
+  return false;
+}
+
 // ------------------------------------------------------------------------------------------------ NsCache
 void NsCache::put(const std::string& name, const Value& ns) { std::unique_lock<std::shared_mutex> l(mu_); m_[name] = ns; }
 void NsCache::remove(const std::string& name) { std::unique_lock<std::shared_mutex> l(mu_); m_.erase(name); }
@@ -266,6 +279,14 @@ bool Flattener::dict_wanted(uint32_t path) {
   return dict_paths_[path].state == 2;
 }
 
+bool Flattener::guard_wanted(uint32_t path) {
+  if (!reg_) return false;
+  if (path >= dict_paths_.size()) dict_paths_.resize((size_t)path * 2 + 64);
+  DictPath& d = dict_paths_[path];
+  if (d.gstate == 0) d.gstate = reg_->guarded(*dict_, path) ? 2 : 1;
+  return d.gstate == 2;
+}
+
 void Flattener::dict_row(uint32_t path, uint32_t meta, const Value& leaf) {
   DictPath& d = dict_paths_[path];
   // containers count by type and size only (the registered expressions cannot look inside them: pe.cpp scalar_fns)
@@ -344,6 +365,7 @@ void Flattener::walk(const Value& v, uint32_t path, uint32_t ords, int adepth, u
     case Value::String: emit_string_row(path, meta, v.str()); if (dict_wanted(path)) dict_row(path, meta, v); break;
     case Value::Object: {
       emit(path, meta | T_OBJECT, (uint32_t)v.size(), 0);
+      if (v.size() && guard_wanted(path)) review_flags_ |= RF_REFUSE;
       if (dict_wanted(path)) dict_row(path, meta, v);
       for (const auto& kv : v.pairs()) walk(kv.second, child(path, kv.first.str()), ords, adepth, extra);
       break;
@@ -709,6 +731,7 @@ int Flattener::fast_value(uint32_t path, uint32_t ords, int adepth, uint32_t ext
       return -1;
     }
     stage_[row].row.lo = count;
+    if (count && guard_wanted(path)) review_flags_ |= RF_REFUSE;
     if (dict_wanted(path)) { ValuePairs ph; for (uint32_t k = 0; k < count; k++) ph.emplace_back(Value::integer((i128)k), Value::null()); dict_row(path, meta, Value::object(std::move(ph))); }
     return T_OBJECT;
   }

@@ -72,10 +72,15 @@ class DictRegistry {
   uint32_t intern(const Pattern& leaf, const DX& dx);   // bit of the expression on leaves matching `leaf`; throws std::runtime_error beyond 62 bits
   uint64_t gen() const;                                  // bumped by every new entry
   void match(const PathDict& dict, uint32_t path_id, std::vector<DictEntry>* out) const;   // entries for a concrete leaf path
+  // Guards: container paths under which the loaded constraints iterate ARRAY elements.  A review holding a non-empty
+  // OBJECT there is refused (RF_REFUSE): Rego's `x[_]` would walk the object's values, the compiled plan would not.
+  void add_guard(const Pattern& container);
+  bool guarded(const PathDict& dict, uint32_t path_id) const;
  private:
   struct Pat { Pattern pat; std::string key; std::vector<DictEntry> entries; };
   mutable std::shared_mutex mu_;
   std::vector<Pat> pats_;
+  std::vector<std::pair<std::string, Pattern>> guards_;
   uint64_t gen_ = 0;
 };
 
@@ -211,10 +216,11 @@ class Flattener {
   PathDict* dict_;
   const DictRegistry* reg_ = nullptr;
   uint64_t reg_gen_ = ~0ull;
-  struct DictPath { int state = 0; std::vector<DictEntry> entries; uint32_t dpath = 0; std::unordered_map<std::string, uint64_t> memo; };   // state 0 unknown, 1 none, 2 has entries
+  struct DictPath { int state = 0; int gstate = 0; std::vector<DictEntry> entries; uint32_t dpath = 0; std::unordered_map<std::string, uint64_t> memo; };   // state 0 unknown, 1 none, 2 has entries
   std::vector<DictPath> dict_paths_;
   void dict_row(uint32_t path, uint32_t meta, const Value& leaf);   // emits <leaf>.$d when some registered expression is true
   bool dict_wanted(uint32_t path);
+  bool guard_wanted(uint32_t path);   // is `path` a container under which element predicates iterate? (cached per path)
   uint32_t id_object_, id_old_, id_m_, id_ns_;
   struct Ctr { uint32_t path, n; };
   std::vector<Ctr> ctrs_;

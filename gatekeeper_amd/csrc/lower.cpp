@@ -1200,24 +1200,17 @@ HostPlan PlanBuilder::build(const PlanCaps& caps) {
   }
   L.emit(finst(F_END));
   // Guards: `x[_]` is lowered as iteration over ARRAY elements (rows carry dense element ordinals); Rego also iterates
-  // the values of an OBJECT.  A review that holds an object where the plan iterates elements is therefore refused, never
-  // guessed: the row of a non-empty container object sets the overflow bit (global bit 0), the review goes through the big variant, overflows
-  // again and is reported in too_big -- the caller fails closed.
-  {
+  // the values of an OBJECT.  A review that holds a non-empty object where the plan iterates elements is therefore
+  // refused, never guessed: the container patterns go to the registry, the flattener flags such reviews (RF_REFUSE) and
+  // the kernels report them in too_big -- the caller fails closed.  No rows, no device predicate.
+  if (reg_) {
     std::set<std::string> seen;
-    const size_t n0 = L.plan.pred_patterns.size();
-    for (size_t pi = 0; pi < n0; pi++) {
-      const Pattern pat = L.plan.pred_patterns[pi];
+    for (const Pattern& pat : L.plan.pred_patterns)
       for (size_t i = 0; i < pat.size(); i++) {
         if (!pat[i].any || !pat[i].elems_only) continue;
         Pattern prefix(pat.begin(), pat.begin() + i);
-        if (!seen.insert(pattern_to_string(prefix)).second) continue;
-        Pred g{};
-        g.op = P_TYPE; g.dst = D_GLOBAL; g.bit = 0; g.ctype = (uint8_t)(1u << T_OBJECT); g.b = 1;   // a NON-EMPTY object (an empty one iterates nothing either way)
-        L.plan.preds.push_back(g);
-        L.plan.pred_patterns.push_back(prefix);
+        if (seen.insert(pattern_to_string(prefix)).second) reg_->add_guard(prefix);
       }
-    }
   }
   HostPlan& p = L.plan;
   {   // derived-bit prologue blocks first (inner blocks were completed, hence appended, before outer ones)

@@ -82,6 +82,8 @@ enum ReviewFlag : uint32_t {
   RF_NS_LABELS_BAD = 1u << 16,
   RF_OBJ_BAD = 1u << 17,         // request.object is a JSON object that Unstructured.UnmarshalJSON rejects (no `kind`):
   RF_OLD_BAD = 1u << 18,
+  RF_REFUSE = 1u << 20,          // a non-empty OBJECT sits where the loaded constraints iterate array elements (flatten.hpp,
+                                 //   DictRegistry guards): reported in too_big, never evaluated
   RF_SKIP = 1u << 19,            // the review is not evaluated: HandleReview rejected it, or the process excluder skips its
                                  //   namespace (engine.cpp) -- no violation, match or autoreject bit for any constraint         //   gkReviewToObject fails with ErrRequestObject (pkg/target/matcher.go:73-93)
 };
@@ -92,7 +94,7 @@ enum PredOp : uint32_t {
   P_DEFINED = 1,     // row exists
   P_TRUTHY = 2,      // row exists and is not `false`
   P_CMP = 3,         // compare(row, const) <op> 0 under Rego's total order
-  P_TYPE = 4,        // (1<<type) & mask (b != 0: and the container row has members)
+  P_TYPE = 4,        // (1<<type) & mask
   P_STR_PREFIX = 5,  // string row startswith const
   P_STR_SUFFIX = 6,
   P_STR_CONTAINS = 7,

@@ -205,7 +205,7 @@ GK_HD bool eval_pred(const Row& r, const Pred& p, const StrHdr& h, const uint8_t
     case P_DEFINED: case P_PRESENT: case P_STORE: return true;
     case P_TRUTHY: return !(t == T_BOOL && r.lo == 0);
     case P_CMP: return cmp_test(cmp_row_const(r, p, h, heap, cheap), p.cmp);
-    case P_TYPE: return ((1u << t) & p.ctype) != 0 && (p.b == 0u || r.lo != 0u);   // b != 0: ... and the container has members
+    case P_TYPE: return ((1u << t) & p.ctype) != 0;
     case P_STR_PREFIX: case P_STR_SUFFIX: case P_STR_CONTAINS: {
       if (t != T_STRING) return false;
       uint32_t m = p.b;

@@ -208,6 +208,7 @@ void dev_eval_finish(const DevPlan* p, const DevTable* dt, const EvalOptions& op
     uint32_t tile = r / GK_TILE; uint64_t bit = 1ull << (r % GK_TILE);
     Results res{0, 0, 0};
     if (t.rflags[r] & RF_SKIP) continue;   // like the kernel's `usable` mask
+    if (t.rflags[r] & RF_REFUSE) { o->too_big[tile] |= bit; continue; }
     if (!eval_review(p->fast, t, r, &res, p->row ? p : nullptr)) {
       o->n_overflow++;
       if (!eval_review(p->big, t, r, &res)) { o->too_big[tile] |= bit; continue; }
