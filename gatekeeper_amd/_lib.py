@@ -37,7 +37,7 @@ EXPORTS = [
     "gk_resident_sweep", "gk_sweep_free", "gk_resident_review",
     "gk_comm_unique_id", "gk_comm_init", "gk_comm_destroy", "gk_table_sweep_sharded", "gk_shard_free",
     # include/gksynth.h (bench / test plumbing)
-    "gk_synth_batch_create", "gk_synth_batch_reviews", "gk_synth_batch_size", "gk_synth_batch_json_bytes", "gk_synth_batch_free",
+    "gk_synth_batch_create", "gk_synth_batch_reviews", "gk_synth_batch_size", "gk_synth_batch_json_bytes", "gk_synth_batch_free", "gk_synth_query_storm",
 ]
 
 
@@ -100,7 +100,13 @@ HE_ALLREDUCE = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_longlong), C.c_uint64
 
 
 class gk_batch_opts(C.Structure):
-    _fields_ = [("max_batch", C.c_uint32), ("window_us", C.c_uint32)]
+    _fields_ = [("max_batch", C.c_uint32), ("window_us", C.c_uint32), ("workers", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class gk_storm_out(C.Structure):
+    _fields_ = [("calls", C.c_uint64), ("errors", C.c_uint64), ("seconds", C.c_double), ("p50_us", C.c_double), ("p90_us", C.c_double),
+                ("p99_us", C.c_double), ("max_us", C.c_double), ("mean_batch", C.c_double), ("mean_queue_us", C.c_double),
+                ("mean_device_us", C.c_double), ("results", C.c_uint64)]
 
 
 class gk_query_stats(C.Structure):
@@ -197,5 +203,6 @@ def load(hostemu: bool | None = None):
     lib.gk_synth_batch_json_bytes.restype = C.c_uint64
     lib.gk_synth_batch_free.argtypes = [vp]
     lib.gk_synth_batch_free.restype = None
+    lib.gk_synth_query_storm.argtypes = [vp, vp, u32, u32, C.POINTER(gk_storm_out)]
     _cache[hostemu] = lib
     return lib

@@ -224,11 +224,14 @@ struct gk_engine {
     uint64_t n_live = 0, n_dead_slots = 0, flattened_total = 0;
   } resident;
   // ---- admission micro-batcher (gk_query): concurrent single-review calls coalesced into one table + one launch
+  struct BatchResult;   // one evaluated batch: table + bitmaps, shared by its requests until the last one has rendered
   struct Request {
     const gk_review_in* in = nullptr;
     std::chrono::steady_clock::time_point arrived;
     int status = GK_OK;
-    std::string results, error;
+    std::string error;
+    std::shared_ptr<BatchResult> batch;   // results are rendered by the CALLER's thread from its column of the bitmaps
+    uint32_t index = 0;
     uint32_t batch_size = 0;
     double queue_us = 0, device_us = 0;
     bool done = false;
@@ -238,9 +241,9 @@ struct gk_engine {
     std::mutex mu;
     std::condition_variable cv;
     std::deque<Request*> queue;
-    std::thread worker;
+    std::vector<std::thread> workers;   // each takes whole batches: one flattens while another's launch is on the device
     bool running = false, stop = false;
-    gk_batch_opts opts{64, 200};
+    gk_batch_opts opts{64, 200, 0, 0};
     uint64_t batches = 0, reviews = 0;
   } batcher;
 };
@@ -1223,6 +1226,14 @@ std::string query_results_json(gk_engine* e, gk_table* t, const gk_eval_out& ev,
   return out + "]";
 }
 
+}  // namespace
+struct gk_engine::BatchResult {
+  gk_table* table = nullptr;
+  gk_eval_out* ev = nullptr;
+  ~BatchResult() { if (ev) gk_eval_free(ev); if (table) gk_table_free(table); }
+};
+namespace {
+
 void batcher_loop(gk_engine* e) {
   gk_engine::Batcher& B = e->batcher;
   for (;;) {
@@ -1240,29 +1251,21 @@ void batcher_loop(gk_engine* e) {
     std::vector<gk_review_in> ins;
     for (auto* r : batch) ins.push_back(*r->in);
     std::vector<int32_t> st(batch.size(), GK_OK);
-    gk_table* table = nullptr;
-    gk_eval_out* ev = nullptr;
-    int rc = gk_table_create(e, ins.data(), ins.size(), 0, st.data(), &table);
+    auto br = std::make_shared<gk_engine::BatchResult>();
+    int rc = gk_table_create(e, ins.data(), ins.size(), 0, st.data(), &br->table);
     std::string err = rc == GK_OK ? "" : gk_last_error();
-    if (rc == GK_OK) { rc = gk_table_eval(e, table, 0, &ev); if (rc != GK_OK) err = gk_last_error(); }
-    const double dev_us = ev ? ev->kernel_ms * 1e3 : 0;
+    if (rc == GK_OK) { rc = gk_table_eval(e, br->table, 0, &br->ev); if (rc != GK_OK) err = gk_last_error(); }
+    const double dev_us = br->ev ? br->ev->kernel_ms * 1e3 : 0;
     for (size_t i = 0; i < batch.size(); i++) {
       gk_engine::Request* r = batch[i];
       r->batch_size = (uint32_t)batch.size();
       r->queue_us = std::chrono::duration<double, std::micro>(t_start - r->arrived).count();
       r->device_us = dev_us;
+      r->index = (uint32_t)i;
       if (rc != GK_OK) { r->status = rc; r->error = err; }
-      else if (st[i] != GK_OK) { r->status = GK_ERR_REVIEW; r->error = table->review_errors[i]; }
-      else {
-        try {
-          bool too_big = false;
-          r->results = query_results_json(e, table, *ev, (uint32_t)i, ins[i], &too_big);
-          if (too_big) { r->status = GK_ERR_LIMIT; r->error = "review is beyond the engine's limits (more than 255 elements in an array that constraint predicates iterate, or an object where they iterate array elements)"; }
-        } catch (const std::exception& ex) { r->status = GK_ERR_REGO; r->error = ex.what(); }
-      }
+      else if (st[i] != GK_OK) { r->status = GK_ERR_REVIEW; r->error = br->table->review_errors[i]; }
+      else r->batch = br;   // the caller renders its own results (gk_query): rendering runs in parallel across callers
     }
-    if (ev) gk_eval_free(ev);
-    if (table) gk_table_free(table);
     {
       std::lock_guard<std::mutex> l(B.mu);
       B.batches++; B.reviews += batch.size();
@@ -1558,12 +1561,16 @@ int gk_resident_review(gk_engine* e, const char* const* path, size_t npath, char
 int gk_batcher_start(gk_engine* e, const gk_batch_opts* opts) {
   if (!e) return fail(GK_ERR_INVALID, "NULL argument");
   gk_engine::Batcher& B = e->batcher;
-  std::lock_guard<std::mutex> l(B.mu);
-  if (opts) { B.opts = *opts; if (!B.opts.max_batch) B.opts.max_batch = 64; }
-  if (B.running) return GK_OK;
-  B.stop = false;
-  B.running = true;
-  B.worker = std::thread(batcher_loop, e);
+  {
+    std::unique_lock<std::mutex> l(B.mu);
+    if (opts) { B.opts = *opts; if (!B.opts.max_batch) B.opts.max_batch = 64; }
+    const uint32_t nw = std::max<uint32_t>(1, std::min<uint32_t>(16, B.opts.workers ? B.opts.workers : 2));
+    if (B.running && B.workers.size() == nw) return GK_OK;
+    if (B.running) { l.unlock(); gk_batcher_stop(e); l.lock(); }   // a different number of workers: restart them
+    B.stop = false;
+    B.running = true;
+    for (uint32_t w = 0; w < nw; w++) B.workers.emplace_back(batcher_loop, e);
+  }
   return GK_OK;
 }
 
@@ -1576,8 +1583,9 @@ void gk_batcher_stop(gk_engine* e) {
     B.stop = true;
   }
   B.cv.notify_all();
-  B.worker.join();
+  for (auto& w : B.workers) w.join();
   std::lock_guard<std::mutex> l(B.mu);
+  B.workers.clear();
   B.running = false;
 }
 
@@ -1624,6 +1632,16 @@ int gk_query(gk_engine* e, const gk_review_in* review, char** results_json, gk_q
     B.cv.notify_all();
     req.cv.wait(l, [&] { return req.done; });
   }
+  // render this review's results from its column of the batch's bitmaps -- in the caller's thread
+  std::string results;
+  if (req.status == GK_OK && req.batch) {
+    try {
+      bool too_big = false;
+      results = query_results_json(e, req.batch->table, *req.batch->ev, req.index, *review, &too_big);
+      if (too_big) { req.status = GK_ERR_LIMIT; req.error = "review is beyond the engine's limits (more than 255 elements in an array that constraint predicates iterate, or an object where they iterate array elements)"; }
+    } catch (const std::exception& ex) { req.status = GK_ERR_REGO; req.error = ex.what(); }
+    req.batch.reset();
+  }
   if (stats) {
     stats->batch_size = req.batch_size;
     stats->queue_us = req.queue_us;
@@ -1631,8 +1649,8 @@ int gk_query(gk_engine* e, const gk_review_in* review, char** results_json, gk_q
     stats->total_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - req.arrived).count();
   }
   if (req.status != GK_OK) return fail(req.status, req.error);
-  char* buf = (char*)malloc(req.results.size() + 1);
-  memcpy(buf, req.results.c_str(), req.results.size() + 1);
+  char* buf = (char*)malloc(results.size() + 1);
+  memcpy(buf, results.c_str(), results.size() + 1);
   *results_json = buf;
   return GK_OK;
 }

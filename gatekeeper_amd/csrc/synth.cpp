@@ -12,6 +12,8 @@
 #include <thread>
 #include <vector>
 
+#include <algorithm>
+#include <chrono>
 #include "../../include/gkgpu.h"
 #include "../../include/gksynth.h"
 
@@ -261,5 +263,44 @@ const gk_review_in* gk_synth_batch_reviews(const gk_synth_batch* b) { return b ?
 size_t gk_synth_batch_size(const gk_synth_batch* b) { return b ? b->reviews.size() : 0; }
 uint64_t gk_synth_batch_json_bytes(const gk_synth_batch* b) { return b ? b->json_bytes : 0; }
 void gk_synth_batch_free(gk_synth_batch* b) { delete b; }
+
+int gk_synth_query_storm(gk_engine* e, const gk_synth_batch* b, uint32_t threads, uint32_t per_thread, gk_storm_out* out) {
+  if (!e || !b || !out || !threads || !per_thread || b->reviews.empty()) return GK_ERR_INVALID;
+  struct PerThread { std::vector<double> lat; double batch = 0, queue = 0, device = 0; uint64_t errors = 0, results = 0; };
+  std::vector<PerThread> pt(threads);
+  const size_t n = b->reviews.size();
+  const auto t0 = std::chrono::steady_clock::now();
+  std::vector<std::thread> th;
+  for (uint32_t w = 0; w < threads; w++)
+    th.emplace_back([&, w]() {
+      PerThread& me = pt[w];
+      me.lat.reserve(per_thread);
+      for (uint32_t k = 0; k < per_thread; k++) {
+        const gk_review_in& rv = b->reviews[((size_t)w * per_thread + k) % n];
+        char* js = nullptr;
+        gk_query_stats st;
+        memset(&st, 0, sizeof st);
+        const int rc = gk_query(e, &rv, &js, &st);
+        if (rc != GK_OK) { me.errors++; continue; }
+        me.lat.push_back(st.total_us);
+        me.batch += st.batch_size; me.queue += st.queue_us; me.device += st.device_us;
+        if (js) { for (const char* p = js; (p = strstr(p, "\"constraint\"")) != nullptr; p += 12) me.results++; gk_free(js); }
+      }
+    });
+  for (auto& x : th) x.join();
+  memset(out, 0, sizeof *out);
+  out->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  std::vector<double> all;
+  double batch = 0, queue = 0, device = 0;
+  for (auto& p : pt) { all.insert(all.end(), p.lat.begin(), p.lat.end()); batch += p.batch; queue += p.queue; device += p.device; out->errors += p.errors; out->results += p.results; }
+  out->calls = all.size();
+  if (!all.empty()) {
+    std::sort(all.begin(), all.end());
+    auto q = [&](double f) { return all[std::min(all.size() - 1, (size_t)(f * all.size()))]; };
+    out->p50_us = q(0.50); out->p90_us = q(0.90); out->p99_us = q(0.99); out->max_us = all.back();
+    out->mean_batch = batch / all.size(); out->mean_queue_us = queue / all.size(); out->mean_device_us = device / all.size();
+  }
+  return GK_OK;
+}
 
 }  // extern "C"

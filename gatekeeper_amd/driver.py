@@ -639,9 +639,10 @@ class Driver:
         self.engine.lib.gk_free(out)
         return rows
 
-    def StartBatcher(self, max_batch=64, window_us=200):
-        """gk_batcher_start: how many concurrent Query calls share a launch, and how long the first one waits for company"""
-        opts = L.gk_batch_opts(max_batch, window_us)
+    def StartBatcher(self, max_batch=64, window_us=200, workers=0):
+        """gk_batcher_start: how many concurrent Query calls share a launch, how long the first one waits for company, and
+        how many batches may be in progress at once (0 = the engine's default, 2)"""
+        opts = L.gk_batch_opts(max_batch, window_us, workers, 0)
         self.engine._check(self.engine.lib.gk_batcher_start(self.engine.handle, C.byref(opts)))
 
     def Dump(self):

@@ -414,6 +414,18 @@ class NativeBatch:
         import ctypes as C
         return C.string_at(r.namespace_json, r.namespace_len) if r.namespace_json else None
 
+    def query_storm(self, engine, threads, per_thread):
+        """`threads` NATIVE threads x `per_thread` gk_query calls on this batch's reviews (include/gksynth.h) -> dict"""
+        from . import _lib as L
+        out = L.gk_storm_out()
+        rc = self.lib.gk_synth_query_storm(engine.handle, self.handle, threads, per_thread, out)
+        if rc != 0:
+            raise RuntimeError("gk_synth_query_storm failed: %d" % rc)
+        d = {k: getattr(out, k) for k, _ in L.gk_storm_out._fields_}
+        d["threads"] = threads
+        d["reviews_per_s"] = d["calls"] / d["seconds"] if d["seconds"] > 0 else 0.0
+        return d
+
     def free(self):
         if self.handle:
             self.lib.gk_synth_batch_free(self.handle)

@@ -248,7 +248,8 @@ int gk_resident_review(gk_engine* e, const char* const* path, size_t npath, char
  * Driver.Query evaluates ONE review (pkg/drivers/k8scel/driver.go:162-251) and the validating webhook calls it from up
  * to GOMAXPROCS request goroutines at once (pkg/webhook/policy.go:142-146, 748-757).  gk_query may be called from any
  * number of threads: the engine's batcher thread coalesces the calls that arrive within `window_us` (or `max_batch` of
- * them) into ONE flattened table and ONE launch, then answers each caller with its own results:
+ * them) into ONE flattened table and ONE launch; each caller then renders its own results from its column of the batch's
+ * bitmaps, in its own thread:
  *   [{"constraint": <id from gk_constraint_add>, "msg": "...", "details": {...}[, "autoreject": true]}, ...]
  * for every loaded constraint that matches the review and is violated (or whose Matcher.Match failed: autoreject).  The
  * caller keeps the results of the constraints it asked about (Driver.Query's `constraints` argument).
@@ -256,6 +257,8 @@ int gk_resident_review(gk_engine* e, const char* const* path, size_t npath, char
 typedef struct {
   uint32_t max_batch;    /* reviews per launch (0 = 64) */
   uint32_t window_us;    /* how long the first call of a batch waits for company */
+  uint32_t workers;      /* batches in progress at once: one is flattened while another's launch is on the device (0 = 2) */
+  uint32_t reserved;
 } gk_batch_opts;
 typedef struct {
   uint32_t batch_size;   /* reviews that shared the launch */

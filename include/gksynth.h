@@ -26,6 +26,19 @@ size_t gk_synth_batch_size(const gk_synth_batch* b);
 uint64_t gk_synth_batch_json_bytes(const gk_synth_batch* b);
 void gk_synth_batch_free(gk_synth_batch* b);
 
+/* Admission load generator (row f1 measurement): `threads` native threads each call gk_query `per_thread` times on the
+ * batch's reviews (round robin) -- the shape of the validating webhook's request goroutines, pkg/webhook/policy.go:142-146.
+ * Latency = arrival -> results ready as reported by gk_query_stats.total_us. */
+typedef struct {
+  uint64_t calls, errors;
+  double seconds;                      /* wall clock of the whole storm */
+  double p50_us, p90_us, p99_us, max_us;
+  double mean_batch;                   /* reviews per launch, averaged over calls */
+  double mean_queue_us, mean_device_us;
+  uint64_t results;                    /* violations + autoreject results returned */
+} gk_storm_out;
+int gk_synth_query_storm(gk_engine* e, const gk_synth_batch* b, uint32_t threads, uint32_t per_thread, gk_storm_out* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -54,3 +54,22 @@ def test_concurrent_queries_are_batched_and_exact(backend, fixtures):
     with pytest.raises(D.EngineError):
         c.driver.Query(D.TARGET_NAME, cons, D.AugmentedReview(D.AdmissionRequest({"operation": "DELETE", "object": objs[0]}), None, "Original"))
     assert c.driver.Query(D.TARGET_NAME, cons[:3], D.AugmentedUnstructured(D.Unstructured(objs[0]), None, "Original")).results is not None
+
+
+@pytest.mark.parametrize("backend", [b for b in BACKENDS if b.id in ("hostemu", "gpu")])
+def test_native_query_storm_counts_match_the_oracle(backend, fixtures):
+    """The load generator of the f1 measurement (gk_synth_query_storm: native threads calling gk_query): every call
+    succeeds, calls share launches, and the number of results returned equals what the oracle finds for the same reviews
+    at the same enforcement point set (gk_query answers for every loaded constraint)."""
+    c, oc = load_both(backend, synth.psp_templates(fixtures), synth.psp_constraints())
+    nss = synth.gen_namespaces()
+    n = 192
+    batch = synth.NativeBatch(c.driver.engine.lib, n, seed=67, namespaces=nss)
+    want = 0
+    for o in synth.gen_objects(n, seed=67):
+        want += len(oc.review(OT.AugmentedUnstructured(OT.Unstructured(o), synth.namespace_for(o, nss), "Original"), OC.AUDIT_EP))
+    c.driver.StartBatcher(max_batch=32, window_us=1000)
+    out = batch.query_storm(c.driver.engine, threads=8, per_thread=n // 8)
+    assert out["calls"] == n and out["errors"] == 0
+    assert out["results"] == want and want > 50
+    assert out["mean_batch"] > 1.5 and out["p50_us"] > 0 and out["p99_us"] >= out["p50_us"]
