@@ -107,16 +107,37 @@ uint32_t DictRegistry::intern(const Pattern& leaf, const DX& dx) {
   for (auto& e : p->entries) if (e.key == dk) return e.bit;
   if (p->entries.size() >= 62) throw std::runtime_error("more than 62 dictionary predicates on " + pk);
   p->entries.push_back({dx, dk, (uint32_t)p->entries.size()});
+  p->memo.clear();
   gen_++;
   return p->entries.back().bit;
 }
 uint64_t DictRegistry::gen() const { std::shared_lock<std::shared_mutex> l(mu_); return gen_; }
-void DictRegistry::match(const PathDict& dict, uint32_t path_id, std::vector<DictEntry>* out) const {
+bool DictRegistry::memo_get(int pi, size_t n_entries, const std::string& key, uint64_t* mask) const {
+  std::shared_lock<std::shared_mutex> l(mu_);
+  if (pi < 0 || (size_t)pi >= pats_.size() || pats_[pi].entries.size() != n_entries) return false;
+  auto it = pats_[pi].memo.find(key);
+  if (it == pats_[pi].memo.end()) return false;
+  *mask = it->second;
+  return true;
+}
+void DictRegistry::memo_put(int pi, size_t n_entries, const std::string& key, uint64_t mask) {
+  std::unique_lock<std::shared_mutex> l(mu_);
+  if (pi < 0 || (size_t)pi >= pats_.size() || pats_[pi].entries.size() != n_entries) return;   // the pattern gained an expression meanwhile
+  if (pats_[pi].memo.size() < 262144) pats_[pi].memo.emplace(key, mask);
+}
+void DictRegistry::match(const PathDict& dict, uint32_t path_id, std::vector<DictEntry>* out, int* pat_index) const {
   std::shared_lock<std::shared_mutex> l(mu_);
   out->clear();
+  if (pat_index) *pat_index = -1;
   // several patterns may cover one concrete path: their bit numbers are per PATTERN, so only one pattern may own a path's
   // $d row -- the lowering registers element / key iterations in canonical form, which makes overlapping patterns equal
-  for (const auto& p : pats_) if (pattern_matches(p.pat, dict, path_id)) { if (!out->empty()) throw std::runtime_error("overlapping dictionary patterns on " + dict.to_string(path_id)); *out = p.entries; }
+  for (size_t i = 0; i < pats_.size(); i++) {
+    const Pat& p = pats_[i];
+    if (!pattern_matches(p.pat, dict, path_id)) continue;
+    if (!out->empty()) throw std::runtime_error("overlapping dictionary patterns on " + dict.to_string(path_id));
+    *out = p.entries;
+    if (pat_index) *pat_index = (int)i;
+  }
 }
 
 void DictRegistry::add_guard(const Pattern& container) {
@@ -272,7 +293,7 @@ bool Flattener::dict_wanted(uint32_t path) {
   if (path >= dict_paths_.size()) dict_paths_.resize((size_t)path * 2 + 64);
   DictPath& d = dict_paths_[path];
   if (d.state == 0) {
-    reg_->match(*dict_, path, &d.entries);
+    reg_->match(*dict_, path, &d.entries, &d.pat);
     d.state = d.entries.empty() ? 1 : 2;
     if (d.state == 2) d.dpath = child(path, "$d");
   }
@@ -296,8 +317,11 @@ void Flattener::dict_row(uint32_t path, uint32_t meta, const Value& leaf) {
   uint64_t mask;
   if (it != d.memo.end()) mask = it->second;
   else {
-    mask = 0;
-    for (const DictEntry& e : d.entries) if (dx_true(e.dx, leaf)) mask |= 1ull << e.bit;
+    if (!reg_->memo_get(d.pat, d.entries.size(), key, &mask)) {   // first sight of this value in the whole engine
+      mask = 0;
+      for (const DictEntry& e : d.entries) if (dx_true(e.dx, leaf)) mask |= 1ull << e.bit;
+      const_cast<DictRegistry*>(reg_)->memo_put(d.pat, d.entries.size(), key, mask);
+    }
     if (d.memo.size() < 65536) d.memo.emplace(std::move(key), mask);
   }
   if (mask) emit(d.dpath, (meta & ~(uint32_t)ROW_TYPE_MASK & ~(uint32_t)ROW_STR_INLINE) | T_INT, (uint32_t)mask, (uint32_t)(mask >> 32));

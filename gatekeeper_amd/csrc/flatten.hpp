@@ -71,13 +71,17 @@ class DictRegistry {
  public:
   uint32_t intern(const Pattern& leaf, const DX& dx);   // bit of the expression on leaves matching `leaf`; throws std::runtime_error beyond 62 bits
   uint64_t gen() const;                                  // bumped by every new entry
-  void match(const PathDict& dict, uint32_t path_id, std::vector<DictEntry>* out) const;   // entries for a concrete leaf path
+  void match(const PathDict& dict, uint32_t path_id, std::vector<DictEntry>* out, int* pat_index = nullptr) const;   // entries for a concrete leaf path
+  // answers shared by every flattener of the engine, per pattern: distinct value -> bit mask.  A value is evaluated once
+  // per engine (not once per table part and thread); the memo of a pattern is dropped when it gains an expression.
+  bool memo_get(int pat_index, size_t n_entries, const std::string& key, uint64_t* mask) const;
+  void memo_put(int pat_index, size_t n_entries, const std::string& key, uint64_t mask);
   // Guards: container paths under which the loaded constraints iterate ARRAY elements.  A review holding a non-empty
   // OBJECT there is refused (RF_REFUSE): Rego's `x[_]` would walk the object's values, the compiled plan would not.
   void add_guard(const Pattern& container);
   bool guarded(const PathDict& dict, uint32_t path_id) const;
  private:
-  struct Pat { Pattern pat; std::string key; std::vector<DictEntry> entries; };
+  struct Pat { Pattern pat; std::string key; std::vector<DictEntry> entries; std::unordered_map<std::string, uint64_t> memo; };
   mutable std::shared_mutex mu_;
   std::vector<Pat> pats_;
   std::vector<std::pair<std::string, Pattern>> guards_;
@@ -216,7 +220,7 @@ class Flattener {
   PathDict* dict_;
   const DictRegistry* reg_ = nullptr;
   uint64_t reg_gen_ = ~0ull;
-  struct DictPath { int state = 0; int gstate = 0; std::vector<DictEntry> entries; uint32_t dpath = 0; std::unordered_map<std::string, uint64_t> memo; };   // state 0 unknown, 1 none, 2 has entries
+  struct DictPath { int state = 0; int gstate = 0; int pat = -1; std::vector<DictEntry> entries; uint32_t dpath = 0; std::unordered_map<std::string, uint64_t> memo; };   // state 0 unknown, 1 none, 2 has entries
   std::vector<DictPath> dict_paths_;
   void dict_row(uint32_t path, uint32_t meta, const Value& leaf);   // emits <leaf>.$d when some registered expression is true
   bool dict_wanted(uint32_t path);
