@@ -271,6 +271,7 @@ struct gk_table {
   uint32_t rpt = GK_RPT_MIN;                // reviews per row group of this table
   uint64_t dict_gen = 0;                    // generation of the dictionary-predicate registry the rows were flattened under
   ShardInfo shard;                          // sharded sweeps: slot layout agreed with the other ranks
+  std::vector<ShardInfo> group_shards;      // ... of the further plan groups (on their views)
   uint64_t shard_gen = 0;
   gk_table_stats stats{};
 };
@@ -1304,6 +1305,7 @@ struct ShardHolder {
   std::vector<uint32_t> ids, shard_reviews;
   std::vector<int64_t> totals;
   std::vector<uint64_t> gathered;
+  uint64_t merged_slot = 0;
 };
 
 int gk_table_sweep_sharded(gk_engine* e, gk_table* t, uint32_t flags, gk_shard_out** out) {
@@ -1314,12 +1316,15 @@ int gk_table_sweep_sharded(gk_engine* e, gk_table* t, uint32_t flags, gk_shard_o
     if (t->dict_gen != e->dict_reg.gen()) return fail(GK_ERR_INVALID, "the table was flattened before a constraint with dictionary predicates was added: create it again");
     std::unique_ptr<ShardHolder> h(new ShardHolder());
     std::lock_guard<std::mutex> l(e->plan_mu);
-    if (!e->extra.empty()) return fail(GK_ERR_UNSUPPORTED, "sharded sweeps need the constraint set in one plan group (more than 64 distinct formulas loaded)");
     const HostPlan* hp = nullptr;
     DevPlan* dp = plan_for_table(e, t, &hp);
-    const uint32_t nc = (uint32_t)e->plan_ids.size();
-    if (t->shard_gen != e->plan_gen || t->shard.shard_reviews.empty()) {   // (collective) once per table and plan
-      dev_shard_setup(t->dev, e->comm, nc, &t->shard);
+    const uint32_t nc0 = (uint32_t)e->plan_ids.size();
+    const size_t n_groups = 1 + e->extra.size();
+    while (t->views.size() < e->extra.size()) t->views.push_back(dev_table_view(t->dev));
+    if (t->shard_gen != e->plan_gen || t->shard.shard_reviews.empty() || t->group_shards.size() != e->extra.size()) {   // (collective) once per table and plan
+      dev_shard_setup(t->dev, e->comm, nc0, &t->shard);
+      t->group_shards.assign(e->extra.size(), ShardInfo());
+      for (size_t gi = 0; gi < e->extra.size(); gi++) dev_shard_setup(t->views[gi], e->comm, (uint32_t)e->extra[gi]->ids.size(), &t->group_shards[gi]);
       t->shard_gen = e->plan_gen;
     }
     EvalOptions opt;
@@ -1327,16 +1332,59 @@ int gk_table_sweep_sharded(gk_engine* e, gk_table* t, uint32_t flags, gk_shard_o
     opt.shard = true;
     EvalOut eo;
     // local evaluation, finished (incl. the large-capacity pass for overflowing reviews) BEFORE the exchange, so that the
-    // gathered bitmaps are complete; then the exchange step on the same stream
+    // gathered bitmaps are complete; then the exchange step on the same stream.  A constraint set that needs several
+    // plan groups runs one evaluation + exchange per group (each group has its own slot buffer on its view of the table).
     dev_eval(dp, t->dev, opt, &eo);
     const void* d_all = nullptr;
-    dev_shard_exchange(t->dev, e->comm, nc, &h->totals, (flags & GK_SHARD_DOWNLOAD) ? &h->gathered : nullptr, &d_all);
+    const bool want_host = (flags & GK_SHARD_DOWNLOAD) != 0;
+    std::vector<uint64_t> g0;
+    dev_shard_exchange(t->dev, e->comm, nc0, &h->totals, want_host ? &g0 : nullptr, &d_all);
+    uint32_t nc = nc0;
+    if (n_groups == 1) h->gathered.swap(g0);
+    else {
+      // merged view for the caller: per rank [all groups' bitmap rows | all groups' counts], same stride; host copy only
+      const int world = dev_comm_world(e->comm);
+      const uint32_t stride = t->shard.stride_tiles;
+      std::vector<std::vector<uint64_t>> parts(n_groups);
+      std::vector<uint32_t> ncs{nc0};
+      std::vector<uint64_t> slot_bytes{t->shard.slot_bytes};
+      parts[0].swap(g0);
+      for (size_t gi = 0; gi < e->extra.size(); gi++) {
+        EvalOut og;
+        dev_eval(e->extra[gi]->dev, t->views[gi], opt, &og);
+        eo.kernel_ms += og.kernel_ms; eo.fast_kernel_ms += og.fast_kernel_ms; eo.n_overflow += og.n_overflow;
+        std::vector<int64_t> tg;
+        const void* d_g = nullptr;
+        const uint32_t ncg = (uint32_t)e->extra[gi]->ids.size();
+        dev_shard_exchange(t->views[gi], e->comm, ncg, &tg, want_host ? &parts[gi + 1] : nullptr, &d_g);
+        h->totals.insert(h->totals.end(), tg.begin(), tg.end());
+        ncs.push_back(ncg); slot_bytes.push_back(t->group_shards[gi].slot_bytes);
+        nc += ncg;
+      }
+      d_all = nullptr;   // several device buffers: only the merged host copy is handed out
+      if (want_host) {
+        const uint64_t merged_slot = (((uint64_t)nc * stride * 8 + (uint64_t)nc * 4) + 15) & ~(uint64_t)15;
+        h->gathered.assign((size_t)world * merged_slot / 8, 0);
+        for (int r = 0; r < world; r++) {
+          uint8_t* dst = reinterpret_cast<uint8_t*>(h->gathered.data()) + (size_t)r * merged_slot;
+          size_t row0 = 0;
+          for (size_t g = 0; g < n_groups; g++) {
+            const uint8_t* src = reinterpret_cast<const uint8_t*>(parts[g].data()) + (size_t)r * slot_bytes[g];
+            memcpy(dst + row0 * stride * 8, src, (size_t)ncs[g] * stride * 8);
+            memcpy(dst + (size_t)nc * stride * 8 + row0 * 4, src + (size_t)ncs[g] * stride * 8, (size_t)ncs[g] * 4);
+            row0 += ncs[g];
+          }
+        }
+        h->merged_slot = merged_slot;
+      }
+    }
     h->ids = e->plan_ids;
+    for (auto& g : e->extra) h->ids.insert(h->ids.end(), g->ids.begin(), g->ids.end());
     h->shard_reviews = t->shard.shard_reviews;
     gk_shard_out& p = h->pub;
     memset(&p, 0, sizeof p);
     p.world = (uint32_t)dev_comm_world(e->comm); p.rank = (uint32_t)dev_comm_rank(e->comm);
-    p.n_constraints = nc; p.stride_tiles = t->shard.stride_tiles; p.slot_bytes = t->shard.slot_bytes;
+    p.n_constraints = nc; p.stride_tiles = t->shard.stride_tiles; p.slot_bytes = n_groups == 1 ? t->shard.slot_bytes : h->merged_slot;
     p.constraint_ids = h->ids.data(); p.shard_reviews = h->shard_reviews.data(); p.totals = h->totals.data();
     p.gathered = h->gathered.empty() ? nullptr : h->gathered.data();
     p.d_gathered = d_all;

@@ -197,6 +197,8 @@ void gk_totals_free(gk_totals_out* o);
  * ncclAllGather of every shard's [violation bitmap | counts] slot and an ncclAllReduce(sum) of the int64 per-constraint
  * totals, so that every rank ends with the full constraints x objects bitmap and the global totals.  Shards may differ in
  * size: all slots use the bitmap stride of the largest shard (`stride_tiles`), a shard's own words come first.
+ * A constraint set that needs several plan groups (more than 64 distinct formulas) runs one evaluation + exchange per
+ * group; `gathered` is then the merged host copy (all groups' rows in constraint_ids order) and `d_gathered` is NULL.
  * Collective: every rank must call it. */
 #define GK_COMM_ID_BYTES 128
 int gk_comm_unique_id(char id[GK_COMM_ID_BYTES]);

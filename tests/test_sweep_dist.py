@@ -19,12 +19,13 @@ from gatekeeper_amd.sweep import ShardedSweep
 SHARDS = [451, 333]   # uneven, not multiples of 64
 
 
-def _client():
+def _client(policies="audit"):
     fx = synth.load_fixtures()
     c = D.Client(D.Driver(hostemu=True))
-    for t in synth.psp_templates(fx):
+    templates, constraints = (synth.psp_templates(fx), synth.audit_constraints()) if policies == "audit" else synth.corpus(fx, 100)
+    for t in templates:
         c.AddTemplate(t)
-    for k in synth.audit_constraints():
+    for k in constraints:
         c.AddConstraint(k)
     return c
 
@@ -35,12 +36,12 @@ def _objs():
     return objs
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, policies="audit"):
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     objs = _objs()
     lo = sum(SHARDS[:rank])
     shard = objs[lo:lo + SHARDS[rank]]
-    sw = ShardedSweep(_client(), shard, synth.gen_namespaces(), dist=dist, device=torch.device("cpu"), keep_docs=True)
+    sw = ShardedSweep(_client(policies), shard, synth.gen_namespaces(), dist=dist, device=torch.device("cpu"), keep_docs=True)
     sw.sweep(2)
     res = sw.sweep(1, download=True)
     lists = sw.audit_lists(limit=5)
@@ -50,16 +51,22 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_sharded_sweep_matches_single_process(tmp_path):
+import pytest   # noqa: E402
+
+
+@pytest.mark.parametrize("policies", ["audit", "corpus100"])
+def test_sharded_sweep_matches_single_process(tmp_path, policies):
+    """corpus100: 100 templates / constraints = two plan groups (more than 64 distinct formulas): one evaluation + exchange
+    per group, merged into one [constraints x objects] answer"""
     world = len(SHARDS)
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), policies), nprocs=world, join=True)
     objs = _objs()
     nss = synth.gen_namespaces()
-    c = _client()
+    c = _client(policies)
     single = ShardedSweep(c, objs, nss, keep_docs=True)
     ref = single.table.eval()
     ref_lists = single.audit_lists(limit=5)
