@@ -879,8 +879,208 @@ void Flattener::fast_match_facts(const ObjFacts& f, const Value& ns, bool is_old
   if (kind.empty()) review_flags_ |= is_old ? RF_OLD_BAD : RF_OBJ_BAD;
 }
 
+namespace {
+struct Span { const char* p = nullptr; size_t n = 0; bool set() const { return p != nullptr; } };
+inline void skip_ws(const char*& p, const char* e) { while (p < e && (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r')) p++; }
+// advances p over one JSON value without interpreting it (the spans that matter are parsed properly afterwards)
+bool skip_value(const char*& p, const char* e) {
+  skip_ws(p, e);
+  if (p >= e) return false;
+  auto skip_string = [&]() { p++; while (p < e && *p != '"') { if (*p == '\\') p++; p++; } if (p >= e) return false; p++; return true; };
+  if (*p == '"') return skip_string();
+  if (*p == '{' || *p == '[') {
+    int depth = 0;
+    while (p < e) {
+      const char c = *p;
+      if (c == '"') { if (!skip_string()) return false; continue; }
+      if (c == '{' || c == '[') depth++;
+      else if (c == '}' || c == ']') { depth--; if (depth == 0) { p++; return true; } }
+      p++;
+    }
+    return false;
+  }
+  const char* s = p;
+  while (p < e && *p != ',' && *p != '}' && *p != ']' && *p != ' ' && *p != '\t' && *p != '\n' && *p != '\r') p++;
+  return p > s;
+}
+// members of a JSON object text: calls fn(key, key_len, value span); false on malformed text or an escaped / duplicate-prone key
+template <class F> bool scan_members(const char* p, const char* e, F fn) {
+  skip_ws(p, e);
+  if (p >= e || *p != '{') return false;
+  p++;
+  skip_ws(p, e);
+  if (p < e && *p == '}') { p++; skip_ws(p, e); return p == e; }
+  for (;;) {
+    skip_ws(p, e);
+    if (p >= e || *p != '"') return false;
+    const char* k = ++p;
+    while (p < e && *p != '"' && *p != '\\') p++;
+    if (p >= e || *p != '"') return false;   // escaped key: the general path words it
+    const size_t kn = (size_t)(p - k);
+    p++;
+    skip_ws(p, e);
+    if (p >= e || *p != ':') return false;
+    p++;
+    skip_ws(p, e);
+    const char* v = p;
+    if (!skip_value(p, e)) return false;
+    if (!fn(k, kn, Span{v, (size_t)(p - v)})) return false;
+    skip_ws(p, e);
+    if (p < e && *p == ',') { p++; continue; }
+    if (p < e && *p == '}') { p++; skip_ws(p, e); return p == e; }
+    return false;
+  }
+}
+inline bool span_is(const Span& s, char c) { return s.set() && s.n && *s.p == c; }
+inline bool span_null(const Span& s) { return !s.set() || (s.n == 4 && memcmp(s.p, "null", 4) == 0); }
+}  // namespace
+
+int Flattener::add_json_request(const RawReview& r, const NsCache& cache, HostTable* out, std::string* obj_key, const ExcludeFn* excluded) {
+  t_ = out;
+  const size_t stage0 = stage_.size(), heap0 = out->heap.size();
+  auto bail = [&]() { stage_.resize(stage0); out->heap.resize(heap0); return (int)DECLINED; };
+  ctrs_.clear();
+  ctr_touched_.clear();
+  scratch_keep_.clear();
+  review_flags_ = 0;
+  if (++review_gen_ == 0) { std::fill(ctr_gen_.begin(), ctr_gen_.end(), 0); review_gen_ = 1; }
+  // 1. the envelope: spans of the members normalize_admission_request reads; anything else is dropped (Go decodes into a
+  // struct) after a syntax check by the subtree parser
+  static const char* const kNames[] = {"uid", "kind", "resource", "operation", "userInfo", "object", "oldObject", "options", "subResource",
+                                       "requestSubResource", "name", "namespace", "requestKind", "requestResource", "dryRun"};
+  enum { M_UID, M_KIND, M_RESOURCE, M_OP, M_USER, M_OBJ, M_OLD, M_OPTS, M_SUBRES, M_REQSUBRES, M_NAME, M_NS, M_REQKIND, M_REQRES, M_DRYRUN, M_COUNT };
+  Span m[M_COUNT];
+  std::vector<Span> unknown;
+  bool ok = scan_members(r.json, r.json + r.json_len, [&](const char* k, size_t kn, Span v) {
+    for (int i = 0; i < M_COUNT; i++)
+      if (strlen(kNames[i]) == kn && memcmp(kNames[i], k, kn) == 0) { if (m[i].set()) return false; m[i] = v; return true; }   // duplicate member: general path
+    unknown.push_back(v);
+    return true;
+  });
+  if (!ok) return bail();
+  const uint32_t scratch_path = child(0, "$skip");
+  for (const Span& u : unknown) {   // syntax check only: parsed into a scratch subtree that is dropped again
+    const size_t sb = stage_.size(), hb = out->heap.size();
+    int tt = -1;
+    if (!fast_tree(u.p, u.n, scratch_path, nullptr, &tt)) return bail();
+    stage_.resize(sb); out->heap.resize(hb);
+  }
+  // a string member without escapes, viewed in place ("" for absent / non-string members: str_field)
+  bool declined = false;
+  auto str_of = [&](const Span& s, const char** p, uint32_t* n) {
+    *p = ""; *n = 0;
+    if (!span_is(s, '"')) {   // not a string: its syntax still has to be valid
+      if (s.set()) { const size_t sb = stage_.size(), hb = out->heap.size(); int tt = -1; if (!fast_tree(s.p, s.n, scratch_path, nullptr, &tt)) declined = true; stage_.resize(sb); out->heap.resize(hb); }
+      return;
+    }
+    if (s.n < 2 || memchr(s.p, '\\', s.n)) { declined = true; return; }   // escapes: general path
+    for (size_t i = 1; i + 1 < s.n; i++) if ((unsigned char)s.p[i] < 0x20) { declined = true; return; }
+    *p = s.p + 1; *n = (uint32_t)(s.n - 2);
+  };
+  auto triple = [&](const Span& s, const char* a, const char* b, const char* c, uint32_t path) {
+    Span f[3];
+    if (span_is(s, '{')) {
+      if (!scan_members(s.p, s.p + s.n, [&](const char* k, size_t kn, Span v) {
+            const char* names[3] = {a, b, c};
+            for (int i = 0; i < 3; i++) if (strlen(names[i]) == kn && memcmp(names[i], k, kn) == 0) { if (f[i].set()) return false; f[i] = v; return true; }
+            const size_t sb = stage_.size(), hb = out->heap.size(); int tt = -1;
+            const bool good = fast_tree(v.p, v.n, scratch_path, nullptr, &tt);
+            stage_.resize(sb); out->heap.resize(hb);
+            return good;
+          })) { declined = true; return; }
+    } else if (s.set()) { const char* dp; uint32_t dn; str_of(s, &dp, &dn); }   // (syntax check of a non-object member)
+    emit(path, T_OBJECT, 3, 0);
+    const char* names[3] = {a, b, c};
+    for (int i = 0; i < 3; i++) { const char* sp; uint32_t sn; str_of(f[i], &sp, &sn); emit_str_n(child(path, names[i]), 0, sp, sn); }
+  };
+  uint32_t members = 8;   // uid kind resource operation userInfo object oldObject options
+  const char* sp; uint32_t sn;
+  str_of(m[M_UID], &sp, &sn); emit_str_n(child(0, "uid"), 0, sp, sn);
+  triple(m[M_KIND], "group", "version", "kind", child(0, "kind"));
+  triple(m[M_RESOURCE], "group", "version", "resource", child(0, "resource"));
+  const char* op_p; uint32_t op_n;
+  str_of(m[M_OP], &op_p, &op_n); emit_str_n(child(0, "operation"), 0, op_p, op_n);
+  if (declined) return bail();
+  const bool del = op_n == 6 && memcmp(op_p, "DELETE", 6) == 0;
+  int type = -1;
+  if (span_is(m[M_USER], '{')) { if (!fast_tree(m[M_USER].p, m[M_USER].n, child(0, "userInfo"), nullptr, &type)) return bail(); }
+  else { if (m[M_USER].set()) { str_of(m[M_USER], &sp, &sn); if (declined) return bail(); } emit(child(0, "userInfo"), T_OBJECT, 0, 0); }
+  const bool has_obj = span_is(m[M_OBJ], '{'), has_old = span_is(m[M_OLD], '{');
+  for (const Span* s : {&m[M_OBJ], &m[M_OLD]}) if (s->set() && !span_is(*s, '{')) { str_of(*s, &sp, &sn); if (declined) return bail(); }   // non-object: null, after a syntax check
+  if (del && !has_old) return bail();   // ErrOldObjectIsNil: worded by the general path
+  ObjFacts fobj, fold;
+  const Span& osrc = del ? m[M_OLD] : m[M_OBJ];   // setObjectOnDelete (target.go:269-287)
+  const bool obj_present = del || has_obj;
+  if (obj_present) { if (!fast_tree(osrc.p, osrc.n, id_object_, &fobj, &type) || type != T_OBJECT) return bail(); }
+  else emit(id_object_, T_NULL, 0, 0);
+  if (has_old) { if (!fast_tree(m[M_OLD].p, m[M_OLD].n, id_old_, &fold, &type) || type != T_OBJECT) return bail(); }
+  else emit(id_old_, T_NULL, 0, 0);
+  if (m[M_OPTS].set()) { if (!fast_tree(m[M_OPTS].p, m[M_OPTS].n, child(0, "options"), nullptr, &type)) return bail(); }
+  else emit(child(0, "options"), T_NULL, 0, 0);
+  const char* rns_p = ""; uint32_t rns_n = 0;
+  for (int i : {M_SUBRES, M_REQSUBRES, M_NAME, M_NS}) {
+    str_of(m[i], &sp, &sn);
+    if (declined) return bail();
+    if (i == M_NS) { rns_p = sp; rns_n = sn; }
+    if (sn) { emit_str_n(child(0, kNames[i]), 0, sp, sn); members++; }
+  }
+  for (int i : {M_REQKIND, M_REQRES, M_DRYRUN}) {
+    if (span_null(m[i])) { if (m[i].set()) continue; else continue; }
+    if (!fast_tree(m[i].p, m[i].n, child(0, kNames[i]), nullptr, &type)) return bail();
+    members++;
+  }
+  // the webhook's process excluder looks at oldObject on DELETE else object, with the REQUEST's namespace (common.go:149-189)
+  const ObjFacts& fx = del ? fold : fobj;
+  if (excluded && (del ? has_old : has_obj) && fx.kind.set && fx.kind.n) {
+    std::string av = fx.api_version.set ? std::string(fx.api_version.p, fx.api_version.n) : std::string();
+    const bool core = std::count(av.begin(), av.end(), '/') != 1;   // group "" (schema.ParseGroupVersion)
+    const std::string kind(fx.kind.p, fx.kind.n);
+    if ((*excluded)(kind == "Namespace" && core, std::string(rns_p, rns_n), fx.name.set ? std::string(fx.name.p, fx.name.n) : std::string())) { bail(); return EXCLUDED; }
+  }
+  if (r.nsobj_json && r.nsobj_len) {
+    const size_t before = stage_.size(), hb = out->heap.size();
+    int t2 = -1;
+    if (!fast_tree(r.nsobj_json, r.nsobj_len, child(0, "namespaceObject"), nullptr, &t2)) return bail();
+    if (t2 == T_NULL) { stage_.resize(before); out->heap.resize(hb); } else members++;
+  }
+  emit(0, T_OBJECT, members, 0);
+  // Matchable.Namespace: the review's, else the nsCache entry of the REQUEST namespace (matcher.go:37-39)
+  Value ns;
+  if (r.ns_json && r.ns_len) {
+    auto it = ns_cache_.find(r.ns_json);
+    if (it == ns_cache_.end() || it->second.first != r.ns_len) {
+      Value v;
+      try { v = parse_json(r.ns_json, r.ns_len); } catch (const std::exception&) { return bail(); }
+      it = ns_cache_.insert_or_assign(r.ns_json, std::make_pair(r.ns_len, v)).first;
+    }
+    if (!it->second.second.is_null()) ns = it->second.second;
+  }
+  if (!ns.defined() && rns_n) ns = cache.get(std::string(rns_p, rns_n));
+  emit(id_m_, T_OBJECT, 2, 0);
+  if (obj_present) fast_match_facts(fobj, ns, false);
+  if (has_old) fast_match_facts(fold, ns, true);
+  if (obj_key) {   // the audit sort key: object (after setObjectOnDelete), else oldObject
+    const ObjFacts& k = obj_present ? fobj : fold;
+    std::string& key = *obj_key;
+    key.clear();
+    if (obj_present || has_old) {
+      std::string av = k.api_version.set ? std::string(k.api_version.p, k.api_version.n) : std::string(), group, version;
+      const size_t nsl = std::count(av.begin(), av.end(), '/');
+      if (!(av.empty() || av == "/")) { if (nsl == 0) version = av; else if (nsl == 1) { size_t i = av.find('/'); group = av.substr(0, i); version = av.substr(i + 1); } }
+      key = group; key.push_back('\0'); key += version; key.push_back('\0'); if (k.kind.set) key.append(k.kind.p, k.kind.n); key.push_back('\0');
+      if (k.ns.set) key.append(k.ns.p, k.ns.n);
+      key.push_back('\0');
+      if (k.name.set) key.append(k.name.p, k.name.n);
+    }
+  }
+  finish_review(ns, r.source, out);
+  return ADDED;
+}
+
 int Flattener::add_json(const RawReview& r, const NsCache& cache, HostTable* out, std::string* obj_key, const ExcludeFn* excluded) {
-  if (r.kind != 1 || !r.json) return DECLINED;   // AdmissionRequest documents take the general path
+  if (!r.json) return DECLINED;
+  if (r.kind == 0) return add_json_request(r, cache, out, obj_key, excluded);
+  if (r.kind != 1) return DECLINED;
   t_ = out;
   const size_t stage0 = stage_.size(), heap0 = out->heap.size();
   auto bail = [&]() { stage_.resize(stage0); out->heap.resize(heap0); return (int)DECLINED; };

@@ -212,6 +212,9 @@ class Flattener {
   enum { DECLINED = 0, ADDED = 1, EXCLUDED = 2 };
   typedef std::function<bool(bool, const std::string&, const std::string&)> ExcludeFn;
   int add_json(const RawReview& r, const NsCache& cache, HostTable* out, std::string* obj_key, const ExcludeFn* excluded = nullptr);
+  // ... of an admissionv1.AdmissionRequest document (the validating webhook's wire shape): the envelope members are
+  // located with a skipping scan, object / oldObject / userInfo / options go through the same one-pass subtree parser
+  int add_json_request(const RawReview& r, const NsCache& cache, HostTable* out, std::string* obj_key, const ExcludeFn* excluded);
   void finish(HostTable* out);   // flush + build_index
   void flush(HostTable* out);    // closes the tile being built (parallel table builds flush per part, then append)
   static void build_index(HostTable* out);   // slots + dense [tile][slot] index from the per-tile segment lists

@@ -236,8 +236,21 @@ int gk_synth_batch_create(uint64_t seed, uint64_t start, uint64_t n, int mixed, 
   b->reviews.resize(n);
   size_t n_threads = std::max<size_t>(1, std::min<size_t>(std::thread::hardware_concurrency(), n / 4096 + 1));
   std::vector<int> ns_idx(n, -1);
+  const bool as_request = (mixed & 2) != 0;   // Pods wrapped in the AdmissionRequest the webhook receives (CREATE)
+  if (as_request && (mixed & 1)) { delete b; return GK_ERR_INVALID; }
   auto work = [&](size_t w) {
-    for (uint64_t k = w; k < n; k += n_threads) b->json[k] = gen_object(seed, start + k, mixed != 0, nss, &ns_idx[k]);
+    for (uint64_t k = w; k < n; k += n_threads) {
+      std::string obj = gen_object(seed, start + k, (mixed & 1) != 0, nss, &ns_idx[k]);
+      if (as_request) {
+        const std::string name = fmt("pod-%07llu", (unsigned long long)(start + k));
+        obj = "{\"uid\": " + q(fmt("uid-%llu", (unsigned long long)(start + k))) + ", \"kind\": {\"group\": \"\", \"version\": \"v1\", \"kind\": \"Pod\"}, "
+              "\"resource\": {\"group\": \"\", \"version\": \"v1\", \"resource\": \"pods\"}, \"name\": " + q(name) + ", \"namespace\": " +
+              q(ns_idx[k] >= 0 ? nss[ns_idx[k]] : std::string()) + ", \"operation\": \"CREATE\", \"userInfo\": {\"username\": \"system:serviceaccount:ci:deployer\", "
+              "\"groups\": [\"system:serviceaccounts\", \"system:authenticated\"]}, \"object\": " + obj + ", \"oldObject\": null, \"dryRun\": false, "
+              "\"options\": {\"kind\": \"CreateOptions\", \"apiVersion\": \"meta.k8s.io/v1\"}}";
+      }
+      b->json[k] = std::move(obj);
+    }
   };
   if (n_threads <= 1) work(0);
   else {
@@ -248,7 +261,7 @@ int gk_synth_batch_create(uint64_t seed, uint64_t start, uint64_t n, int mixed, 
   for (uint64_t k = 0; k < n; k++) {
     gk_review_in& r = b->reviews[k];
     memset(&r, 0, sizeof r);
-    r.kind = GK_REVIEW_OBJECT;
+    r.kind = as_request ? GK_REVIEW_ADMISSION_REQUEST : GK_REVIEW_OBJECT;
     r.source = GK_SRC_ORIGINAL;
     r.json = b->json[k].data();
     r.json_len = b->json[k].size();

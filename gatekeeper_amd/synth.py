@@ -208,6 +208,16 @@ def gen_object(seed, i, mixed=False):
             "data": {"k%d" % k: rng.pick(LABEL_VALUES) for k in range(1 + rng.below(4))}}
 
 
+def admission_request_for(obj, i):
+    """the AdmissionRequest (CREATE) around Pod `i` of the stream, as the validating webhook receives it; the native
+    generator (mixed = 2) writes the same document"""
+    md = obj["metadata"]
+    return {"uid": "uid-%d" % i, "kind": {"group": "", "version": "v1", "kind": "Pod"}, "resource": {"group": "", "version": "v1", "resource": "pods"},
+            "name": md["name"], "namespace": md.get("namespace", ""), "operation": "CREATE",
+            "userInfo": {"username": "system:serviceaccount:ci:deployer", "groups": ["system:serviceaccounts", "system:authenticated"]},
+            "object": obj, "oldObject": None, "dryRun": False, "options": {"kind": "CreateOptions", "apiVersion": "meta.k8s.io/v1"}}
+
+
 def gen_objects(n, seed=SEED, mixed=False, start=0):
     """objects [start, start + n) of the synthetic stream `seed`.  mixed=False: all Pods (config[1]).  mixed=True: 80% Pod,
     10% Deployment, 5% Namespace, 5% Service/ConfigMap (config[2], the audit sweep).  The native generator
@@ -382,7 +392,8 @@ class NativeBatch:
     """objects [start, start + n) of stream `seed` generated by the native generator (csrc/synth.cpp): JSON text plus the
     gk_review_in array, handed to Engine.create_table_native without touching Python objects."""
 
-    def __init__(self, lib, n, seed=SEED, mixed=False, start=0, namespaces=None):
+    def __init__(self, lib, n, seed=SEED, mixed=False, start=0, namespaces=None, requests=False):
+        """requests=True: the Pods wrapped in AdmissionRequest documents (review kind GK_REVIEW_ADMISSION_REQUEST)"""
         import ctypes as C
         self.lib = lib
         arr, k = None, 0
@@ -390,7 +401,7 @@ class NativeBatch:
             self._ns = [json.dumps(namespaces[name]).encode() for name in NAMESPACES]
             arr, k = (C.c_char_p * len(self._ns))(*self._ns), len(self._ns)
         h = C.c_void_p()
-        rc = lib.gk_synth_batch_create(seed & 0xFFFFFFFFFFFFFFFF, start, n, 1 if mixed else 0, arr, k, C.byref(h))
+        rc = lib.gk_synth_batch_create(seed & 0xFFFFFFFFFFFFFFFF, start, n, (1 if mixed else 0) | (2 if requests else 0), arr, k, C.byref(h))
         if rc != 0:
             raise RuntimeError("gk_synth_batch_create failed: %d" % rc)
         self.handle = h

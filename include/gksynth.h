@@ -17,7 +17,8 @@ extern "C" {
 typedef struct gk_synth_batch gk_synth_batch;
 
 /* objects [start, start + n) of stream `seed`; mixed = 0: Pods only (configs[1]); 1: Pod / Deployment / Namespace /
- * Service / ConfigMap mix (configs[2]).  namespace_jsons: the 100 Namespace objects in synth.py NAMESPACES order (the
+ * Service / ConfigMap mix (configs[2]); 2: the Pods of 0, each wrapped in the admissionv1.AdmissionRequest (CREATE) the
+ * validating webhook receives (review kind GK_REVIEW_ADMISSION_REQUEST, synth.py admission_request_for).  namespace_jsons: the 100 Namespace objects in synth.py NAMESPACES order (the
  * review's Namespace is looked up by the object's metadata.namespace) or NULL for none. */
 int gk_synth_batch_create(uint64_t seed, uint64_t start, uint64_t n, int mixed, const char* const* namespace_jsons, size_t n_namespaces,
                           gk_synth_batch** out);

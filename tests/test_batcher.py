@@ -56,18 +56,23 @@ def test_concurrent_queries_are_batched_and_exact(backend, fixtures):
     assert c.driver.Query(D.TARGET_NAME, cons[:3], D.AugmentedUnstructured(D.Unstructured(objs[0]), None, "Original")).results is not None
 
 
+@pytest.mark.parametrize("requests", [False, True])
 @pytest.mark.parametrize("backend", [b for b in BACKENDS if b.id in ("hostemu", "gpu")])
-def test_native_query_storm_counts_match_the_oracle(backend, fixtures):
+def test_native_query_storm_counts_match_the_oracle(backend, fixtures, requests):
     """The load generator of the f1 measurement (gk_synth_query_storm: native threads calling gk_query): every call
     succeeds, calls share launches, and the number of results returned equals what the oracle finds for the same reviews
     at the same enforcement point set (gk_query answers for every loaded constraint)."""
     c, oc = load_both(backend, synth.psp_templates(fixtures), synth.psp_constraints())
     nss = synth.gen_namespaces()
     n = 192
-    batch = synth.NativeBatch(c.driver.engine.lib, n, seed=67, namespaces=nss)
+    batch = synth.NativeBatch(c.driver.engine.lib, n, seed=67, namespaces=nss, requests=requests)   # requests: the webhook's AdmissionRequest JSON
     want = 0
-    for o in synth.gen_objects(n, seed=67):
-        want += len(oc.review(OT.AugmentedUnstructured(OT.Unstructured(o), synth.namespace_for(o, nss), "Original"), OC.AUDIT_EP))
+    for i, o in enumerate(synth.gen_objects(n, seed=67)):
+        if requests:
+            rv = OT.AugmentedReview(OT.AdmissionRequest(synth.admission_request_for(o, i)), synth.namespace_for(o, nss), "Original")
+        else:
+            rv = OT.AugmentedUnstructured(OT.Unstructured(o), synth.namespace_for(o, nss), "Original")
+        want += len(oc.review(rv, OC.AUDIT_EP))
     c.driver.StartBatcher(max_batch=32, window_us=1000)
     out = batch.query_storm(c.driver.engine, threads=8, per_thread=n // 8)
     assert out["calls"] == n and out["errors"] == 0

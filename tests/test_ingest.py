@@ -85,3 +85,67 @@ def test_fast_ingest_adversarial_documents():
     assert list(tf.statuses) == list(ts.statuses) and tf.statuses[0] == L.GK_OK and tf.statuses[1] == L.GK_ERR_REVIEW
     sf, ss = tf.stats(), ts.stats()
     assert sf["digest"] == ss["digest"] and sf["fast_reviews"] == 1
+
+
+def _req(text, ns=None, nsobj=None, source="Original"):
+    return D.ReviewIn(L.GK_REVIEW_ADMISSION_REQUEST, text.encode() if isinstance(text, str) else text, ns, nsobj, source, "")
+
+
+def test_fast_ingest_of_admission_requests():
+    """AdmissionRequest documents (the webhook's wire shape, pkg/target/review.go:16-21) through the one-pass parser:
+    CREATE / UPDATE / DELETE, missing and wrong-typed envelope members, unknown members (dropped after a syntax check),
+    requestKind / dryRun / options / userInfo subtrees, namespaceObject, nsCache fallback on the REQUEST namespace --
+    digests equal the general path's; what it cannot take is declined and handled identically by the general path."""
+    eng = D.Engine(hostemu=True)
+    eng.put_data(["cluster", "v1", "Namespace", "cached"], {"apiVersion": "v1", "kind": "Namespace", "metadata": {"name": "cached", "labels": {"env": "x"}}})
+    nss = synth.gen_namespaces()
+    pods = synth.gen_objects(120, seed=91, mixed=True)
+    rins = []
+    for i, o in enumerate(pods):
+        api = o.get("apiVersion", "v1")
+        g, _, ver = api.rpartition("/")
+        req = {"uid": "u-%d" % i, "kind": {"group": g, "version": ver, "kind": o["kind"]}, "resource": {"group": g, "version": ver, "resource": o["kind"].lower() + "s"},
+               "name": o["metadata"]["name"], "operation": ["CREATE", "UPDATE", "DELETE", "CONNECT"][i % 4],
+               "userInfo": {"username": "alice", "groups": ["system:authenticated", "g%d" % (i % 3)], "extra": {"k": ["v"]}}}
+        if o["metadata"].get("namespace"):
+            req["namespace"] = o["metadata"]["namespace"] if i % 5 else "cached"
+        if i % 4 == 2:
+            req["oldObject"] = o
+            if i % 8 == 2:
+                req["object"] = None
+        elif i % 4 == 1:
+            old = json.loads(json.dumps(o)); old["metadata"]["labels"] = {"was": "old"}
+            req["object"], req["oldObject"] = o, old
+        else:
+            req["object"] = o
+        if i % 3 == 0:
+            req.update({"requestKind": {"group": g, "version": ver, "kind": o["kind"]}, "requestResource": None, "dryRun": bool(i % 2), "options": {"kind": "CreateOptions", "fieldManager": "kubectl"}})
+        if i % 7 == 0:
+            req.update({"subResource": "status", "requestSubResource": "", "somethingUnknown": {"deep": [1, {"x": "y"}]}, "another": "\\u00e9"})
+        text = json.dumps(req) if i % 2 else json.dumps(req, indent=1)
+        ns = synth.namespace_for(o, nss) if i % 3 else None
+        rins.append(_req(text, ns, {"metadata": {"name": "nsobj"}} if i % 4 == 0 else None, ["Original", "Generated", ""][i % 3]))
+    weird = [
+        '{}', '{"operation":"CREATE"}', '{"uid":5,"kind":"notanobject","resource":null,"operation":7,"userInfo":"x","object":[1],"oldObject":"s","options":3,"name":{},"namespace":["a"]}',
+        '{"kind":{"group":1,"version":null,"kind":"Pod","extra":[{}]},"object":{"metadata":{"name":"nokind"}},"operation":"UPDATE","oldObject":{"kind":"Pod","apiVersion":"v1","metadata":{"labels":{"a":1}}}}',
+        '{"object":{"apiVersion":"v1","kind":"Namespace","metadata":{"name":"itself"}},"namespace":"","name":""}',
+    ]
+    rins += [_req(w) for w in weird]
+    fast, slow = _digest(eng, rins, False), _digest(eng, rins, True)
+    assert fast["digest"] == slow["digest"] != 0 and fast["n_rows"] == slow["n_rows"] and fast["heap_bytes"] == slow["heap_bytes"]
+    assert fast["fast_reviews"] == len(rins) and slow["fast_reviews"] == 0
+    # declined (general path words the outcome): DELETE without oldObject, duplicate / escaped envelope members, malformed
+    # unknown members, escapes in envelope strings, non-object documents
+    odd = ['{"operation":"DELETE","object":{"kind":"Pod"}}', '{"uid":"a","uid":"b"}', '{"na\\u006de":"x","object":{"kind":"Pod"}}', '{"object":{"kind":"Pod"},"junk":tru}',
+           '{"uid":"a\\nb","object":{"kind":"Pod","apiVersion":"v1"}}', '[{"object":{}}]', '{"object":{"kind":"Pod"}} x', '{"object":{"kind":"Pod","kind":"Dup"}}']
+    rins2 = [_req(d) for d in odd] + [rins[0]]
+    os.environ["GK_TABLE_DIGEST"] = "1"
+    try:
+        tf = eng.create_table(rins2, keep_docs=False)
+        os.environ["GK_SLOW_INGEST"] = "1"
+        ts = eng.create_table(rins2, keep_docs=False)
+    finally:
+        os.environ.pop("GK_TABLE_DIGEST", None); os.environ.pop("GK_SLOW_INGEST", None)
+    assert list(tf.statuses) == list(ts.statuses) and tf.statuses[0] == L.GK_ERR_REVIEW and tf.statuses[-1] == L.GK_OK
+    sf, ss = tf.stats(), ts.stats()
+    assert sf["digest"] == ss["digest"] and sf["fast_reviews"] == 1

@@ -26,3 +26,14 @@ def test_native_generator_matches_python(mixed, seed, start, n):
     assert b.json_bytes == sum(len(b.json_text(i)) for i in range(n))
     assert kinds == ({"Pod", "Deployment", "Namespace", "Service", "ConfigMap"} if mixed and n >= 1000 else kinds)
     b.free()
+
+
+def test_native_admission_requests_match_python():
+    lib = L.load(hostemu=True)
+    nss = synth.gen_namespaces()
+    n, start = 200, 5000
+    b = synth.NativeBatch(lib, n, seed=9, start=start, namespaces=nss, requests=True)
+    for i, o in enumerate(synth.gen_objects(n, seed=9, start=start)):
+        assert json.loads(b.json_text(i)) == synth.admission_request_for(o, start + i), i
+        assert b.reviews[i].kind == L.GK_REVIEW_ADMISSION_REQUEST
+    b.free()

@@ -65,17 +65,23 @@ def main():
             out["runs"].append(r)
     # the same path driven by NATIVE threads (gk_synth_query_storm, include/gksynth.h): no Python, no GIL -- what a cgo
     # shim's request goroutines would see.  Reviews are AugmentedUnstructured{Pod, Namespace} documents as JSON text.
-    batch = synth.NativeBatch(drv.engine.lib, 8192, seed=78, namespaces=nss)
-    batch.query_storm(drv.engine, 8, 64)    # warm: dictionary growth + kernel specialisation for the batch geometries
-    out["native"] = {"what": "gk_query from native threads (30 PSP constraints, synthetic Pod reviews as JSON text); latency = arrival -> results "
-                             "ready (gk_query_stats.total_us): queueing + flatten + H2D + launch + D2H + rendering", "runs": []}
-    for max_batch, window, workers in ((64, 0, 1), (64, 0, 2), (64, 100, 2), (256, 200, 2), (256, 200, 4), (1024, 500, 4), (1024, 500, 8)):
-        drv.StartBatcher(max_batch=max_batch, window_us=window, workers=workers)
-        for threads in (1, 8, 64, 256):
-            per = max(64, min(2048, 16384 // threads))
-            r = batch.query_storm(drv.engine, threads, per)
-            r["window_us"], r["max_batch"], r["workers"] = window, max_batch, workers
-            out["native"]["runs"].append(r)
+    for shape in ("object", "admission_request"):
+        batch = synth.NativeBatch(drv.engine.lib, 8192, seed=78, namespaces=nss, requests=(shape == "admission_request"))
+        batch.query_storm(drv.engine, 8, 64)    # warm: dictionary growth + kernel specialisation for the batch geometries
+        key = "native" if shape == "object" else "native_admission_request"
+        out[key] = {"what": "gk_query from native threads (30 PSP constraints, synthetic Pod reviews as JSON text, shape: %s); latency = arrival -> "
+                            "results ready (gk_query_stats.total_us): queueing + flatten + H2D + launch + D2H + rendering" % (
+                                "AugmentedUnstructured{Pod, Namespace}" if shape == "object" else "admissionv1.AdmissionRequest (CREATE) + Namespace, the webhook's wire shape"),
+                    "runs": []}
+        combos = ((64, 0, 1), (64, 0, 2), (64, 100, 2), (256, 200, 2), (256, 200, 4), (1024, 500, 4), (1024, 500, 8)) if shape == "object" else ((64, 0, 2), (64, 100, 2), (256, 200, 4))
+        for max_batch, window, workers in combos:
+            drv.StartBatcher(max_batch=max_batch, window_us=window, workers=workers)
+            for threads in (1, 8, 64, 256):
+                per = max(64, min(2048, 16384 // threads))
+                r = batch.query_storm(drv.engine, threads, per)
+                r["window_us"], r["max_batch"], r["workers"] = window, max_batch, workers
+                out[key]["runs"].append(r)
+        batch.free()
     print(json.dumps(out))
 
 
