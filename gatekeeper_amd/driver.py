@@ -770,6 +770,29 @@ class AuditReport(dict):
         self.totals_per_action = {}
         self.errors = []
 
+    def constraint_status(self, key, timestamp, violations_limit=20):
+        """What updateConstraintStatus writes under the constraint's `status` (pkg/audit/manager.go:980-1034): auditTimestamp,
+        totalViolations and -- only when there are any -- violations: the kept entries popped from the max-heap, i.e. in
+        DESCENDING SVQueue order, each in StatusViolation's JSON shape (manager.go:100-109; namespace and
+        enforcementActions are omitempty)."""
+        ent = self.get(key) or {"total": 0, "violations": []}
+        out = []
+        for v in reversed(ent["violations"]):
+            if len(out) >= violations_limit:
+                break
+            e = {"group": v["group"], "version": v["version"], "kind": v["kind"], "name": v["name"]}
+            if v.get("namespace"):
+                e["namespace"] = v["namespace"]
+            e["message"] = v["message"]
+            e["enforcementAction"] = v["enforcementAction"]
+            if v.get("enforcementActions"):
+                e["enforcementActions"] = list(v["enforcementActions"])
+            out.append(e)
+        st = {"auditTimestamp": timestamp, "totalViolations": int(ent["total"])}
+        if out:
+            st["violations"] = out
+        return st
+
 
 class Client:
     """constraintclient.Client for the single K8sValidationTarget, evaluating on the device."""

@@ -63,3 +63,32 @@ def add_audit_responses(update_lists, totals_per_constraint, totals_per_action, 
         q.push({"group": g, "version": v, "kind": k, "namespace": obj_namespace(obj), "name": obj_name(obj),
                 "message": msg, "enforcementAction": r.enforcement_action,
                 "enforcementActions": r.scoped_enforcement_actions})
+
+
+def status_violations(queue: LimitQueue, violations_limit=DEFAULT_VIOLATIONS_LIMIT):
+    """updateConstraintStatus (manager.go:980-1003): the LimitQueue is POPPED into status.violations -- a max-heap, so the
+    list is in DESCENDING SVQueue order -- and each entry is StatusViolation's JSON (manager.go:100-109: namespace and
+    enforcementActions are omitempty)."""
+    out = []
+    for v in reversed(queue.sorted()):
+        if len(out) >= violations_limit:
+            break
+        e = {"group": v["group"], "version": v["version"], "kind": v["kind"], "name": v["name"]}
+        if v.get("namespace"):
+            e["namespace"] = v["namespace"]
+        e["message"] = v["message"]
+        e["enforcementAction"] = v["enforcementAction"]
+        if v.get("enforcementActions"):
+            e["enforcementActions"] = list(v["enforcementActions"])
+        out.append(e)
+    return out
+
+
+def constraint_status(queue: LimitQueue, total, timestamp, violations_limit=DEFAULT_VIOLATIONS_LIMIT):
+    """the fields updateConstraintStatus writes under the constraint's `status` (manager.go:1004-1034): violations is
+    REMOVED when there are none"""
+    st = {"auditTimestamp": timestamp, "totalViolations": int(total)}
+    v = status_violations(queue, violations_limit)
+    if v:
+        st["violations"] = v
+    return st

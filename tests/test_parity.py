@@ -361,6 +361,13 @@ def test_audit_aggregation(backend, fixtures):
         assert sum(totals.values()) > sum(pairs.values())   # the workload has multi-result pairs, so the two differ
         for k, q in lists.items():
             assert got[k]["violations"] == q.sorted(), k
+            # what updateConstraintStatus writes (manager.go:980-1034): popped from the max-heap = descending order
+            st = got.constraint_status(k, "2026-01-01T00:00:00Z", violations_limit=limit)
+            assert st == OA.constraint_status(q, totals[k], "2026-01-01T00:00:00Z", violations_limit=limit), k
+            assert [OA.sv_key(v) for v in st["violations"]] == sorted((OA.sv_key(v) for v in st["violations"]), reverse=True)
+            assert all("namespace" in v or not v.get("namespace") for v in st["violations"]) and st["totalViolations"] == totals[k]
+        clean = ("K8sNope", "constraints.gatekeeper.sh/v1beta1", "none")
+        assert got.constraint_status(clean, "t") == {"auditTimestamp": "t", "totalViolations": 0}     # status.violations removed
         assert sum(len(v["violations"]) for v in got.values()) == sum(len(q.items) for q in lists.values()) > 0
 
 
