@@ -51,6 +51,11 @@ std::vector<uint32_t> jit_path_classes(const HostPlan& plan, std::vector<std::ve
   return out;
 }
 
+uint32_t jit_res_k(const HostPlan& plan) {
+  const uint32_t need = std::max(plan.n_viol, plan.n_match);
+  return need <= 16 ? 16u : need <= 32 ? 32u : (uint32_t)GK_MAX_RES;
+}
+
 std::string generate_plan_source(const HostPlan& plan, uint32_t parts) {
   std::ostringstream o;
   std::vector<std::vector<Pred>> classes;
@@ -87,6 +92,12 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts) {
     for (size_t i = 0; i < zr.size(); i++) o << (i ? "," : "") << zr[i].second << "u";
     o << "};\n";
   }
+  // result slots kept per 64-review half and kind (kernel_body.inc GK_RES_K), and where each scope's element count lives
+  o << "#define GK_RES_K " << jit_res_k(plan) << "\n#define GK_N_SCOPES_K " << plan.scopes.size() << "\n"
+    << "GK_CONST_ARRAY uint32_t gk_count_off[" << std::max<size_t>(1, plan.scopes.size()) << "] = {";
+  for (size_t i = 0; i < plan.scopes.size(); i++) o << (i ? "," : "") << plan.scopes[i].count_off << "u";
+  if (plan.scopes.empty()) o << "0u";
+  o << "};\n";
   // ---------------------------------------------------------------------------------------------- phase 1
   // inlined into its single call site (the chunk loop): as a separate function every LDS atomic would first look the
   // dynamic-LDS base up in a table (s_getpc + s_load + full wait; seen in the gfx950 ISA) and the call frame costs scratch

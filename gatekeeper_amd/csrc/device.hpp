@@ -35,6 +35,7 @@ struct EvalOut {
   float fast_kernel_ms = 0;       // average duration of the dominant (LDS) kernel per launch since the last finish
   uint32_t n_launches = 0;        // launches averaged in fast_kernel_ms
   uint32_t lds_bytes = 0;         // accumulator LDS per workgroup of the dominant kernel's most recent launch
+  uint64_t list_bytes = 0;        // chunk lists the dominant kernel reads per launch (chunks.hpp)
   const void *d_viol = nullptr, *d_err = nullptr, *d_counts = nullptr;   // device-resident results (valid until the table's next launch)
 };
 

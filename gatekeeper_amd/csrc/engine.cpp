@@ -960,6 +960,7 @@ int gk_table_eval(gk_engine* e, gk_table* t, uint32_t flags, gk_eval_out** out) 
         o.list_total += og.list_total;
         o.n_overflow += og.n_overflow;
         o.kernel_ms += og.kernel_ms; o.fast_kernel_ms += og.fast_kernel_ms;
+        o.list_bytes += og.list_bytes;
         o.n_constraints += og.n_constraints;
         o.d_viol = o.d_err = o.d_counts = nullptr;   // not one contiguous device buffer any more
         h->ids.insert(h->ids.end(), e->extra[gi]->ids.begin(), e->extra[gi]->ids.end());
@@ -981,7 +982,7 @@ int gk_table_eval(gk_engine* e, gk_table* t, uint32_t flags, gk_eval_out** out) 
     t->last_nc = p.n_constraints; t->last_ids = h->ids;
     p.lds_bytes = h->lds_bytes;
     // algorithmic bytes: rows of the segments whose path carries predicates (+ their string headers
-    // where a predicate reads string bytes) + two index words per bound path and tile + review flags, all read once;
+    // where a predicate reads string bytes) + the groups' chunk lists (8 B per entry) + review flags, all read once;
     // plan tables read once; bitmaps written once; 8 B per list entry
     uint64_t rows_read = 0, hdrs_read = 0, bound = 0, plan_bytes = 0;
     auto account = [&](const HostPlan& hp) {   // every plan group streams its own bound segments
@@ -1001,8 +1002,8 @@ int gk_table_eval(gk_engine* e, gk_table* t, uint32_t flags, gk_eval_out** out) 
     account(e->fast);
     for (auto& g : e->extra) account(g->fast);
     p.n_rows_read = rows_read;
-    plan_bytes += bound * sizeof(Bind);
-    p.algo_bytes = rows_read * sizeof(Row) + hdrs_read * sizeof(StrHdr) + bound * 8 * ((p.n_reviews + t->rpt - 1) / t->rpt) +
+    (void)bound;
+    p.algo_bytes = rows_read * sizeof(Row) + hdrs_read * sizeof(StrHdr) + h->out.list_bytes +
                    t->dir_bytes * (1 + e->extra.size()) + plan_bytes + (uint64_t)p.n_constraints * p.n_tiles * 16 + (uint64_t)p.list_total * 8;
     *out = &h.release()->pub;
     return GK_OK;

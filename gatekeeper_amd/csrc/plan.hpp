@@ -43,6 +43,19 @@ struct Bind {
   uint32_t ent;
 };
 
+// Chunk lists (chunks.hpp): what a plan reads of a table, per row group, fixed when the plan is bound to the table.  A
+// group's list = the 64-row chunks of the segments of the plan's paths, in the order the group's waves take them;
+// entry 0 is the header.  Every group owns `capg` consecutive entries (header + chunks + unused tail).
+struct ChunkDesc {
+  uint32_t st;     // first row of the chunk                       | header: number of chunks of the group
+  uint32_t info;   // (rows - 1) | entry << GK_DESC_ENT_SHIFT       | header: GK_LIST_OVERFLOW
+};
+static_assert(sizeof(ChunkDesc) == 8, "ChunkDesc must be 8 bytes");
+constexpr uint32_t GK_DESC_ENT_SHIFT = 6;
+constexpr uint32_t GK_DESC_ENT_MASK = 0x01FFFFFFu;   // of info >> GK_DESC_ENT_SHIFT: path-table entry (first << 8 | count) or class id
+constexpr uint32_t GK_DESC_NEEDS_STR = 1u << 25;     // of info >> GK_DESC_ENT_SHIFT: some predicate of the class reads string bytes
+constexpr uint32_t GK_LIST_OVERFLOW = 1u;            // header: the group has more chunks than a list holds -> its reviews take the big path
+
 enum RowType : uint32_t { T_NULL = 0, T_BOOL = 1, T_INT = 2, T_FLOAT = 3, T_STRING = 4, T_OBJECT = 5, T_ARRAY = 6 };
 
 constexpr uint32_t ROW_TYPE_MASK = 0x7;

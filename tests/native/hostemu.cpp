@@ -12,6 +12,7 @@
 #include <unistd.h>
 
 #include <fstream>
+#include <map>
 
 #include "codegen.hpp"
 #include "device.hpp"
@@ -29,6 +30,7 @@ struct DevPlan {
   HeRowFn row = nullptr;
   HeFormFn form = nullptr;
   std::vector<uint32_t> cls;
+  std::map<std::string, std::pair<void*, void*>> emu_jit;   // GK_HOSTEMU_KERNEL=jit: geometry -> (dl handle, launcher) of the emulated plan-specialised kernel
 };
 
 struct VecAcc {
@@ -95,7 +97,11 @@ DevPlan* dev_plan_upload(int, const HostPlan& fast, const HostPlan& big) {
   }
   return p;
 }
-void dev_plan_free(DevPlan* p) { if (p && p->dl) dlclose(p->dl); delete p; }
+void dev_plan_free(DevPlan* p) {
+  if (p && p->dl) dlclose(p->dl);
+  // (the emulated plan-specialised kernels stay loaded: test-only, and the emulator's state is shared between objects)
+  delete p;
+}
 
 static PlanView view_of(const HostPlan& h) {
   return PlanView{h.ptab.data(), h.path_preds.data(), h.scopes.data(), h.code.data(), h.cheap.data(), h.dims};
@@ -189,6 +195,10 @@ void dev_shard_exchange(DevTable* t, DevComm* c, uint32_t nc, std::vector<int64_
   if (d_gathered) *d_gathered = t->shard_all.data();
 }
 
+// GK_HOSTEMU_KERNEL=1 | jit: additionally run the dominant kernel's HIP source (kernel_body.inc) through the kernel emulator
+// (kernel_emu.hpp; generic bytecode build | plan-specialised build compiled with g++) and require bit-identical outputs
+static void emu_kernel_check(const DevPlan* p, const DevTable* dt, const EvalOptions& opt, const EvalOut& want);
+
 void dev_last_viol(const DevTable* t, uint32_t nc, std::vector<uint64_t>* viol) { (void)nc; *viol = t->last_viol; }
 void dev_eval_launch(const DevPlan*, const DevTable* dt, const EvalOptions&) { const_cast<DevTable*>(dt)->pending++; }
 void dev_eval(const DevPlan* p, const DevTable* dt, const EvalOptions& opt, EvalOut* o) { dev_eval_launch(p, dt, opt); dev_eval_finish(p, dt, opt, o); }
@@ -231,9 +241,171 @@ void dev_eval_finish(const DevPlan* p, const DevTable* dt, const EvalOptions& op
   gk_op_counter = 0;
 #endif
   const_cast<DevTable*>(dt)->last_viol = o->viol;
+  if (getenv("GK_HOSTEMU_KERNEL")) emu_kernel_check(p, dt, opt, *o);
   o->kernel_ms = o->fast_kernel_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 
+}  // namespace gk
+
+// ------------------------------------------------------------------------------------------------ kernel emulation
+// (kept at the end of the file: kernel_emu.hpp defines HIP's names as macros)
+#include <map>
+#include <mutex>
+
+#include "chunks.hpp"
+#include "kernel_emu.hpp"
+
+namespace gk {
+#define GK_SKIP_BIG
+#define GK_KERNEL_BIG gk_emu_big
+#define GK_KERNEL_LINKAGE static
+#define GK_ROW_FN(r, i, ent, h, pv, heap, acc) eval_row_ent(r, i, ent, h, pv, heap, acc)
+#define GK_FORMULA_FN(pv, acc, flags, rows, heap, bounds) eval_formulas(pv, acc, flags, rows, heap, bounds)
+#define GK_RPT_K 64
+#define GK_KERNEL_TILES gk_emu_tiles_64
+#include "kernel_body.inc"
+#undef GK_RPT_K
+#undef GK_KERNEL_TILES
+#undef GK_TILES_BOUNDS
+#define GK_RPT_K 128
+#define GK_KERNEL_TILES gk_emu_tiles_128
+#include "kernel_body.inc"
+#undef GK_RPT_K
+#undef GK_KERNEL_TILES
+#undef GK_TILES_BOUNDS
+#define GK_RPT_K 256
+#define GK_KERNEL_TILES gk_emu_tiles_256
+#include "kernel_body.inc"
+#undef GK_RPT_K
+#undef GK_KERNEL_TILES
+#undef GK_TILES_BOUNDS
+#define GK_RPT_K 512
+#define GK_KERNEL_TILES gk_emu_tiles_512
+#include "kernel_body.inc"
+#undef GK_RPT_K
+#undef GK_KERNEL_TILES
+
+typedef void (*EmuJitLaunch)(unsigned, unsigned, size_t, const PlanView*, const Row*, const StrHdr*, const ChunkDesc*, uint32_t, const uint32_t*, const uint8_t*,
+                             uint32_t, uint32_t, const ConstraintSlot*, const OutPtrs*, uint32_t, uint32_t);
+static EmuJitLaunch emu_jit_for(const DevPlan* p, uint32_t rpt, uint32_t rpp, int block) {
+  char key[96];
+  snprintf(key, sizeof key, "%u/%u/%d", rpt, rpp, block);
+  DevPlan* mp = const_cast<DevPlan*>(p);
+  auto it = mp->emu_jit.find(key);
+  if (it != mp->emu_jit.end()) return (EmuJitLaunch)it->second.second;
+  static int counter = 0;
+  std::string base = "/tmp/gkemu_jit_" + std::to_string(getpid()) + "_" + std::to_string(counter++);
+  {
+    std::ofstream f(base + ".cpp");
+    const char* pf = getenv("GK_JIT_PREFETCH");
+    f << "#include \"" << GK_CSRC_DIR << "/../../tests/native/kernel_emu.hpp\"\n#include \"" << GK_CSRC_DIR << "/vm_core.hpp\"\n"
+      << "#define GK_RES_PROLOGUE const bool gk_l0 = (threadIdx.x & 63u) == 0u;\n"
+      << "#define GK_RES(kind, slot, b) do { const unsigned long long m_ = __ballot((b) != 0u); if (gk_l0) masks[(kind) * GK_RES_K + (slot)] = m_; } while (0)\n"
+      << generate_plan_source(p->fast, (uint32_t)(block / GK_TILE / ((int)rpt / GK_TILE)))
+      << "#define GK_RPT_K " << rpt << "\n#define GK_RPP_K " << rpp << "\n#define GK_BLOCK_K " << block << "\n#define GK_PREFETCH " << (pf ? pf : (rpt <= 128 ? "2" : "3")) << "\n#define GK_SKIP_BIG\n"
+      << "namespace gk {\n#define GK_KERNEL_TILES gk_jit_tiles\n#define GK_KERNEL_BIG gk_jit_big\n#define GK_KERNEL_LINKAGE static\n"
+         "#define GK_ROW_FN(r, i, ent, h, pv, heap, acc) jit_row(r, ent, h, heap, acc)\n#define GK_BIND_ALWAYS_STR 0\n"
+         "#define GK_FORMULA_FN(pv, acc, flags, rows, heap, bounds) jit_formulas(pv, acc, flags, rows, heap, bounds)\n"
+      << "#include \"" << GK_CSRC_DIR << "/kernel_body.inc\"\n}\n"
+      << "extern \"C\" void gk_emu_jit_launch(unsigned grid, unsigned block, size_t lds, const gk::PlanView* pv, const gk::Row* rows, const gk::StrHdr* shdr,\n"
+         "    const gk::ChunkDesc* lists, uint32_t capg, const uint32_t* rflags, const uint8_t* heap, uint32_t n, uint32_t nt, const gk::ConstraintSlot* slots,\n"
+         "    const gk::OutPtrs* out, uint32_t dbg, uint32_t rpp) {\n"
+         "  gkemu::launch(grid, block, lds, [&] { gk::gk_jit_tiles(*pv, rows, shdr, lists, capg, rflags, heap, n, nt, slots, *out, dbg, rpp); });\n}\n";
+  }
+  std::string cmd = "g++ -std=c++17 -O1 -shared -fPIC -w -o " + base + ".so " + base + ".cpp 2> " + base + ".log";
+  if (system(cmd.c_str()) != 0) throw std::runtime_error("kernel_emu: the plan-specialised kernel does not compile, see " + base + ".log");
+  void* dl = dlopen((base + ".so").c_str(), RTLD_NOW);
+  if (!dl) throw std::runtime_error(std::string("kernel_emu: dlopen failed: ") + dlerror());
+  EmuJitLaunch fn = (EmuJitLaunch)dlsym(dl, "gk_emu_jit_launch");
+  if (!getenv("GK_EMU_KEEP")) { unlink((base + ".cpp").c_str()); unlink((base + ".so").c_str()); unlink((base + ".log").c_str()); }
+  mp->emu_jit[key] = std::make_pair(dl, (void*)fn);
+  return fn;
+}
+
+static void emu_kernel_check(const DevPlan* p, const DevTable* dt, const EvalOptions& opt, const EvalOut& want) {
+  static std::mutex mu;   // the emulator keeps one workgroup's state in statics
+  std::lock_guard<std::mutex> lock(mu);
+  const bool jit = std::string(getenv("GK_HOSTEMU_KERNEL")) == "jit";
+  const HostTable& t = dt->t;
+  const HostPlan& hp = p->fast;
+  const uint32_t n = t.n_reviews, nc = (uint32_t)hp.slots.size(), nt = (n + GK_TILE - 1) / GK_TILE, rpt = t.rpt;
+  if (!n || !nc) return;
+  int block = gk_block_of((int)rpt);
+  if (jit && getenv("GK_JIT_BLOCK")) { const int f = atoi(getenv("GK_JIT_BLOCK")); if (f >= (int)rpt && f <= 1024 && f % (int)rpt == 0) block = f; }
+  // bound paths, costs and chunk lists exactly as kernels.hip builds them
+  std::vector<std::vector<Pred>> classes;
+  const std::vector<uint32_t> entries = jit ? jit_path_classes(hp, &classes) : hp.ptab;
+  std::vector<BoundPath> bound;
+  for (uint32_t s = 0; s < t.n_slots(); s++) {
+    const uint32_t path = t.slot_path[s];
+    if (path >= entries.size() || !entries[path]) continue;
+    const uint32_t ent = hp.ptab[path];
+    uint32_t c = 1;
+    for (uint32_t j = 0; j < (ent & 0xFF); j++) { const Pred& q = hp.path_preds[(ent >> 8) + j]; c += 1u + (pred_needs_str(q) ? 3u : 0u) + (q.dst == D_ELEM ? 1u : 0u); }
+    bound.push_back(BoundPath{s, entries[path], c});
+  }
+  const uint32_t n_groups = (n + rpt - 1) / rpt;
+  uint32_t list_cap = (uint32_t)std::min(block / GK_TILE, 8) * GK_WAVE_CHUNKS;
+  if (const char* lc = getenv("GK_EMU_LIST_CAP")) list_cap = std::min<uint32_t>(list_cap, (uint32_t)atoi(lc));   // test aid: list overflow
+  ChunkLists cl = build_chunk_lists(t.tile_idx.data(), n_groups, t.n_slots(), bound, list_cap, (uint32_t)(block / GK_TILE));
+  // reviews per pass
+  uint32_t rpp = rpt;
+  while (rpp > (uint32_t)GK_TILE && (size_t)hp.dims.acc_words * rpp * 4 > 140 * 1024) rpp /= 2;
+  if (const char* f = getenv("GK_FORCE_RPP")) rpp = std::min<uint32_t>(rpt, std::max<uint32_t>(GK_TILE, (uint32_t)atoi(f)));
+  const size_t lds = (size_t)hp.dims.acc_words * rpp * 4;
+  // outputs (garbage-filled: the kernel must write every word it owns)
+  std::vector<uint64_t> viol((size_t)nc * nt, 0xABABABABABABABABull), err((size_t)nc * nt, 0xABABABABABABABABull), match((size_t)nc * nt, 0xABABABABABABABABull);
+  std::vector<uint64_t> ovf(nt, 0xABABABABABABABABull), big(nt, 0xABABABABABABABABull);
+  std::vector<uint32_t> counts(nc, 0), list((size_t)std::max<uint32_t>(opt.list_capacity, 1) * 2, 0), lcnt(2, 0);
+  OutPtrs out{viol.data(), err.data(), opt.want_match ? match.data() : nullptr, ovf.data(), big.data(), counts.data(), list.data(), lcnt.data(), opt.list_capacity, nullptr};
+  PlanView pv = view_of(hp);
+  unsigned grid = (n_groups + 7u) / 8u * 8u;
+  if (const char* g = getenv("GK_EMU_GRID")) grid = std::min<unsigned>(grid, (unsigned)std::max(8, atoi(g) / 8 * 8));   // persistent workgroups: several groups each
+  else grid = std::min<unsigned>(grid, 16u);
+  const Row* rows = t.rows.data(); const StrHdr* shdr = t.shdr.data();
+  if (jit) {
+    EmuJitLaunch fn = emu_jit_for(p, rpt, rpp, block);
+    fn(grid, (unsigned)block, lds, &pv, rows, shdr, cl.d.data(), cl.capg, t.rflags.data(), t.heap.data(), n, nt, hp.slots.data(), &out, 0u, rpp);
+  } else {
+    auto fn = rpt == 64 ? gk_emu_tiles_64 : rpt == 128 ? gk_emu_tiles_128 : rpt == 256 ? gk_emu_tiles_256 : gk_emu_tiles_512;
+    gkemu::launch(grid, (unsigned)block, lds, [&] { fn(pv, rows, shdr, cl.d.data(), cl.capg, t.rflags.data(), t.heap.data(), n, nt, hp.slots.data(), out, 0u, rpp); });
+  }
+  // overflowed reviews: the big variant (per review, as above)
+  uint32_t n_ovf = 0;
+  for (uint32_t w = 0; w < nt; w++)
+    for (uint64_t m = ovf[w]; m; m &= m - 1) {
+      const uint32_t r = w * GK_TILE + (uint32_t)__builtin_ctzll(m);
+      const uint64_t bit = 1ull << (r % GK_TILE);
+      n_ovf++;
+      Results res{0, 0, 0};
+      if (!eval_review(p->big, t, r, &res)) { big[w] |= bit; continue; }
+      for (uint32_t c = 0; c < nc; c++) {
+        ConstraintSlot sl = hp.slots[c];
+        const bool m_ = (res.match >> sl.match) & 1, e = (res.err >> sl.match) & 1, v = m_ && ((res.viol >> sl.viol) & 1);
+        if (opt.want_match && m_) match[(size_t)c * nt + w] |= bit;
+        if (e) err[(size_t)c * nt + w] |= bit;
+        if (v) { viol[(size_t)c * nt + w] |= bit; lcnt[0]++; }   // (the big kernel appends its pairs to the same list)
+      }
+    }
+  if (lcnt[1] != n_ovf) throw std::runtime_error("kernel_emu: overflow counter and overflow bitmap disagree");
+  auto fail = [&](const char* what, uint32_t c, uint32_t w, uint64_t got, uint64_t exp) {
+    char buf[256];
+    snprintf(buf, sizeof buf, "kernel_emu (%s, rpt %u rpp %u grid %u): %s differs at constraint %u word %u: kernel %016llx, per-review %016llx", jit ? "jit" : "generic", rpt, rpp,
+             grid, what, c, w, (unsigned long long)got, (unsigned long long)exp);
+    throw std::runtime_error(buf);
+  };
+  for (uint32_t c = 0; c < nc; c++)
+    for (uint32_t w = 0; w < nt; w++) {
+      if (viol[(size_t)c * nt + w] != want.viol[(size_t)c * nt + w]) fail("violation bitmap", c, w, viol[(size_t)c * nt + w], want.viol[(size_t)c * nt + w]);
+      if (err[(size_t)c * nt + w] != want.err[(size_t)c * nt + w]) fail("autoreject bitmap", c, w, err[(size_t)c * nt + w], want.err[(size_t)c * nt + w]);
+      if (opt.want_match && match[(size_t)c * nt + w] != want.match[(size_t)c * nt + w]) fail("match bitmap", c, w, match[(size_t)c * nt + w], want.match[(size_t)c * nt + w]);
+    }
+  for (uint32_t w = 0; w < nt; w++) if (big[w] != want.too_big[w]) fail("too_big", 0, w, big[w], want.too_big[w]);
+  if (opt.list_capacity) {
+    if (lcnt[0] != want.list_total) throw std::runtime_error("kernel_emu: violation list length differs");
+  }
+  if (getenv("GK_EMU_VERBOSE")) fprintf(stderr, "[kernel_emu] %s rpt %u rpp %u grid %u groups %u capg %u chunks %llu overflowed %u: identical\n", jit ? "jit" : "generic", rpt, rpp, grid, n_groups, cl.capg, (unsigned long long)cl.n_chunks, n_ovf);
+}
 }  // namespace gk
 
 // TEST-ONLY entry point of libgkgpu_hostemu.so: join an engine to a "communicator" whose collectives are callbacks

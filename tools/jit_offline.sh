@@ -15,7 +15,7 @@ waves = os.environ.get("WAVES")
 rpt = int(os.environ.get("RPT", "64")); rpp = int(os.environ.get("RPP", str(rpt))); block = int(os.environ.get("BLOCK", "0")) or (256 if rpt <= 128 else rpt * 2)
 s = ("#include <hip/hip_runtime.h>\n" + ("#define GK_TILES_BOUNDS __launch_bounds__(%d, %s)\n" % (block, waves) if waves else "") + "#define GK_RPT_K %d\n#define GK_RPP_K %d\n#define GK_SKIP_BIG\n" % (rpt, rpp) + ("#define GK_BLOCK_K %s\n" % os.environ["BLOCK"] if os.environ.get("BLOCK") else "") + "".join("#define %s\n" % x.replace("=", " ") for x in os.environ.get("DEFINES", "").split(";") if x) + ("#define GK_PREFETCH %s\n" % os.environ["PREFETCH"] if os.environ.get("PREFETCH") else "") + text("plan.hpp") + text("vm_core.hpp") +
      "#define GK_RES_PROLOGUE const bool gk_l0 = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u;\n"
-     "#define GK_RES(kind, slot, b) do { const unsigned long long m_ = __ballot((b) != 0u); if (gk_l0) masks[(kind) * 64 + (slot)] = m_; } while (0)\n" + open(gen).read() +
+     "#define GK_RES(kind, slot, b) do { const unsigned long long m_ = __ballot((b) != 0u); if (gk_l0) masks[(kind) * GK_RES_K + (slot)] = m_; } while (0)\n" + open(gen).read() +
      "namespace gk {\n#define GK_KERNEL_TILES gk_jit_tiles\n#define GK_KERNEL_BIG gk_jit_big\n#define GK_KERNEL_LINKAGE extern \"C\"\n"
      "#define GK_ROW_FN(r, i, ent, h, pv, heap, acc) jit_row(r, ent, h, heap, acc)\n#define GK_BIND_ALWAYS_STR 0\n"
      "#define GK_FORMULA_FN(pv, acc, flags, rows, heap, bounds) jit_formulas(pv, acc, flags, rows, heap, bounds)\n" +
