@@ -102,14 +102,16 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts) {
   // inlined into its single call site (the chunk loop): as a separate function every LDS atomic would first look the
   // dynamic-LDS base up in a table (s_getpc + s_load + full wait; seen in the gfx950 ISA) and the call frame costs scratch
   const bool inline_row = !(getenv("GK_JIT_INLINE_ROW") && atoi(getenv("GK_JIT_INLINE_ROW")) == 0);   // tuning aid
-  o << "template <class Acc>\nGK_HD __attribute__((" << (inline_row ? "always_inline" : "noinline") << ")) void jit_row(Row r, uint32_t cls, StrHdr h, const uint8_t* heap, Acc acc) {\n"
+  o << "template <class Acc>\nGK_HD __attribute__((" << (inline_row ? "always_inline" : "noinline") << ")) void jit_row(Row r, uint32_t cls, StrHdr h, const uint8_t* heap, Acc acc, bool on) {\n"
     << "  const uint8_t* cheap = gk_plan_consts;\n  (void)cheap; (void)h;\n  cls = GK_UNI(cls) & ~GK_ENT_NEEDS_STR;   // one class per call: the dispatch is a scalar branch\n  switch (cls) {\n";
   // One class = the predicates of one key path.  Results are gathered in one mask per destination word (a single LDS
   // atomic per word, not per predicate); integer comparisons share one type test; short string equalities compare
   // the packed payload; everything else goes through eval_pred with a constexpr predicate.
   static const char* kCmpOps[] = {"==", "!=", "<", "<=", ">", ">="};
   for (size_t c = 1; c < classes.size(); c++) {
-    o << "    case " << c << ": {\n      const uint32_t t = r.meta & 7u; (void)t;\n";
+    // the class dispatch is wave-uniform and comes FIRST; the per-lane "this lane holds a row of this pass" test sits inside
+    // the case (around a divergent dispatch the structuriser threads every case exit through a chain of flow blocks)
+    o << "    case " << c << ": if (on) {\n      const uint32_t t = r.meta & 7u; (void)t;\n";
     const std::vector<Pred>& ps = classes[c];
     struct Group { int scope, level; bool always = false; std::vector<std::string> masks; std::vector<size_t> stores; bool present = false; };
     std::vector<Group> groups;          // element destinations by (scope, level)
@@ -276,7 +278,11 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts) {
           o << ind << "{ _Pragma(\"unroll\")\n";
           o << ind << "  for (uint32_t e" << d << " = 0; e" << d << " < " << sc.cap << "u; e" << d << "++) {\n";
         } else {
+          // run-time trip count (the wave's largest element count): partially unrolled, so that the LDS reads of several
+          // iterations are in flight together instead of one exposed LDS latency per element
+          static const int dyn_unroll = getenv("GK_LOOP_UNROLL") ? atoi(getenv("GK_LOOP_UNROLL")) : 1;   // tuning aid
           o << ind << "{ const uint32_t n" << d << " = GK_UNI(bounds[" << a << "]);\n";
+          if (dyn_unroll > 1) o << ind << "  _Pragma(\"unroll " << dyn_unroll << "\")\n";
           o << ind << "  for (uint32_t e" << d << " = 0; e" << d << " < n" << d << "; e" << d << "++) {\n";
         }
         o << ind << "    const uint32_t w" << d << " = acc.load(" << sc.word_off << "u + e" << d << " * " << (int)sc.wpe << "u);\n";

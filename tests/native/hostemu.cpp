@@ -76,7 +76,7 @@ DevPlan* dev_plan_upload(int, const HostPlan& fast, const HostPlan& big) {
       f << "#include <vector>\n#include \"" << GK_CSRC_DIR << "/vm_core.hpp\"\n" << generate_plan_source(fast)
         << "struct VecAcc { std::vector<uint32_t>* w; void or_word(uint32_t i, uint32_t m) { (*w)[i] |= m; } void max_word(uint32_t i, uint32_t v) { if ((*w)[i] < v) (*w)[i] = v; }\n"
            "  void store_word(uint32_t i, uint32_t v) { (*w)[i] = v; } uint32_t load(uint32_t i) const { return (*w)[i]; } };\n"
-           "extern \"C\" void gk_he_row(const gk::Row* r, uint32_t i, uint32_t cls, const gk::StrHdr* h, const gk::PlanView* pv, const uint8_t* heap, std::vector<uint32_t>* w) { VecAcc acc{w}; (void)i; (void)pv; gk::jit_row(*r, cls, *h, heap, acc); }\n"
+           "extern \"C\" void gk_he_row(const gk::Row* r, uint32_t i, uint32_t cls, const gk::StrHdr* h, const gk::PlanView* pv, const uint8_t* heap, std::vector<uint32_t>* w) { VecAcc acc{w}; (void)i; (void)pv; gk::jit_row(*r, cls, *h, heap, acc, true); }\n"
            "extern \"C\" void gk_he_form(const gk::PlanView* pv, std::vector<uint32_t>* w, uint32_t flags, const gk::Row* rows, const uint8_t* heap, const uint32_t* bounds, gk::Results* out) {\n"
            "  VecAcc acc{w}; std::vector<uint32_t> w2 = *w; VecAcc acc2{&w2};\n"
            "  gk::Results mono = gk::jit_formulas(*pv, acc2, flags, rows, heap, bounds);\n"
@@ -259,7 +259,7 @@ namespace gk {
 #define GK_SKIP_BIG
 #define GK_KERNEL_BIG gk_emu_big
 #define GK_KERNEL_LINKAGE static
-#define GK_ROW_FN(r, i, ent, h, pv, heap, acc) eval_row_ent(r, i, ent, h, pv, heap, acc)
+#define GK_ROW_FN(r, i, ent, h, pv, heap, acc, on) do { if (on) eval_row_ent(r, i, ent, h, pv, heap, acc); } while (0)
 #define GK_FORMULA_FN(pv, acc, flags, rows, heap, bounds) eval_formulas(pv, acc, flags, rows, heap, bounds)
 #define GK_RPT_K 64
 #define GK_KERNEL_TILES gk_emu_tiles_64
@@ -304,7 +304,7 @@ static EmuJitLaunch emu_jit_for(const DevPlan* p, uint32_t rpt, uint32_t rpp, in
       << generate_plan_source(p->fast, (uint32_t)(block / GK_TILE / ((int)rpt / GK_TILE)))
       << "#define GK_RPT_K " << rpt << "\n#define GK_RPP_K " << rpp << "\n#define GK_BLOCK_K " << block << "\n#define GK_PREFETCH " << (pf ? pf : (rpt <= 128 ? "2" : "3")) << "\n#define GK_SKIP_BIG\n"
       << "namespace gk {\n#define GK_KERNEL_TILES gk_jit_tiles\n#define GK_KERNEL_BIG gk_jit_big\n#define GK_KERNEL_LINKAGE static\n"
-         "#define GK_ROW_FN(r, i, ent, h, pv, heap, acc) jit_row(r, ent, h, heap, acc)\n#define GK_BIND_ALWAYS_STR 0\n"
+         "#define GK_ROW_FN(r, i, ent, h, pv, heap, acc, on) jit_row(r, ent, h, heap, acc, on)\n#define GK_BIND_ALWAYS_STR 0\n"
          "#define GK_FORMULA_FN(pv, acc, flags, rows, heap, bounds) jit_formulas(pv, acc, flags, rows, heap, bounds)\n"
       << "#include \"" << GK_CSRC_DIR << "/kernel_body.inc\"\n}\n"
       << "extern \"C\" void gk_emu_jit_launch(unsigned grid, unsigned block, size_t lds, const gk::PlanView* pv, const gk::Row* rows, const gk::StrHdr* shdr,\n"

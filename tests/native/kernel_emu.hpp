@@ -159,4 +159,6 @@ template <class T> static inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; 
 static inline uint32_t min(uint32_t a, uint32_t b) { return a < b ? a : b; }
 #define GK_DYN_LDS(name) uint32_t* name = gkemu::dyn_lds()
 #define GK_OPAQUE_V2(a, b) do { } while (0)
+#define GK_OPAQUE_V1(a) do { } while (0)
+#define GK_OPAQUE_S1(a) do { } while (0)
 #define GK_OPAQUE() do { } while (0)

@@ -17,7 +17,7 @@ s = ("#include <hip/hip_runtime.h>\n" + ("#define GK_TILES_BOUNDS __launch_bound
      "#define GK_RES_PROLOGUE const bool gk_l0 = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u;\n"
      "#define GK_RES(kind, slot, b) do { const unsigned long long m_ = __ballot((b) != 0u); if (gk_l0) masks[(kind) * GK_RES_K + (slot)] = m_; } while (0)\n" + open(gen).read() +
      "namespace gk {\n#define GK_KERNEL_TILES gk_jit_tiles\n#define GK_KERNEL_BIG gk_jit_big\n#define GK_KERNEL_LINKAGE extern \"C\"\n"
-     "#define GK_ROW_FN(r, i, ent, h, pv, heap, acc) jit_row(r, ent, h, heap, acc)\n#define GK_BIND_ALWAYS_STR 0\n"
+     "#define GK_ROW_FN(r, i, ent, h, pv, heap, acc, on) jit_row(r, ent, h, heap, acc, on)\n#define GK_BIND_ALWAYS_STR 0\n"
      "#define GK_FORMULA_FN(pv, acc, flags, rows, heap, bounds) jit_formulas(pv, acc, flags, rows, heap, bounds)\n" +
      (text("kernel_body.inc") if not os.environ.get("BODY") else "".join(l for l in open(os.environ["BODY"]) if not l.startswith("#include") and not l.startswith("#pragma once"))) + "}\n")
 open(dst, "w").write(s)
