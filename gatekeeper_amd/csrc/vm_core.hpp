@@ -112,11 +112,51 @@ GK_HD bool str_prefix_c(const StrRef& s, const uint8_t* c, uint32_t m, uint64_t 
   if (r) d |= (ld32(s.p + full) ^ ld32(c + full)) & ((1u << (8 * r)) - 1u);
   return d == 0;
 }
+// Word access.  A heap entry is 16-byte aligned and zero padded ([u32 len][bytes][pad]) and the table heap ends in 16 B of
+// slack, so whole aligned words -- also the one that straddles the end of the string -- can be read; bytes beyond the
+// string are masked by the callers.  Byte-wise access costs one dependent memory round trip PER BYTE on the device (the
+// compiler does not merge byte loads): with words, the loads of one comparison are independent and wait once.
+GK_HD uint32_t sword(const StrRef& s, uint32_t j) {   // bytes [j, j+4), j a multiple of 4
+  if (j < 8) return (uint32_t)(s.bits >> (8 * j));
+  if (j == 8) return s.w2;
+  return s.p ? ld32(s.p + j) : 0u;
+}
+GK_HD uint64_t swin(const StrRef& s, uint32_t at) {   // bytes [at, at+8), any alignment
+  const uint32_t a = at & ~3u, sh = (at & 3u) * 8u;
+  const uint32_t w0 = sword(s, a), w1 = sword(s, a + 4u), w2 = sword(s, a + 8u);
+  const uint64_t lo = ((uint64_t)w1 << 32) | w0;
+  return sh ? (lo >> sh) | ((uint64_t)w2 << (64u - sh)) : lo;
+}
+GK_HD uint64_t cwin(const uint8_t* c, uint32_t m) {   // up to 8 constant bytes as a little-endian word (folds for constexpr predicates)
+  uint64_t v = 0;
+  for (uint32_t i = 0; i < m && i < 8; i++) v |= (uint64_t)c[i] << (8 * i);
+  return v;
+}
 // m bytes of s starting at byte `at` equal the constant bytes c[0..m)
 GK_HD bool str_at_c(const StrRef& s, uint32_t at, const uint8_t* c, uint32_t m) {
-  uint32_t d = 0;
-  for (uint32_t i = 0; i < m; i++) d |= sbyte(s, at + i) ^ (uint32_t)c[i];
+  uint64_t d = 0;
+  for (uint32_t i = 0; i < m; i += 8) {
+    const uint32_t k = m - i < 8 ? m - i : 8;
+    d |= (swin(s, at + i) ^ cwin(c + i, k)) & mask_bytes(k);
+  }
   return d == 0;
+}
+// does the constant c[0..m), 1 <= m <= 8, occur anywhere in s?  One new aligned word per four positions.
+GK_HD bool str_contains_short(const StrRef& s, const uint8_t* c, uint32_t m) {
+  if (m > s.n) return false;
+  const uint64_t want = cwin(c, m), mk = mask_bytes(m);
+  const uint32_t last = s.n - m;   // last start position
+  uint32_t w0 = sword(s, 0), w1 = sword(s, 4), w2 = sword(s, 8);
+  bool any = false;
+  for (uint32_t a = 0; a <= last; a += 4) {
+    const uint64_t lo = ((uint64_t)w1 << 32) | w0;
+    any = any || ((lo ^ want) & mk) == 0;
+    if (a + 1 <= last) any = any || ((((lo >> 8) | ((uint64_t)w2 << 56)) ^ want) & mk) == 0;
+    if (a + 2 <= last) any = any || ((((lo >> 16) | ((uint64_t)w2 << 48)) ^ want) & mk) == 0;
+    if (a + 3 <= last) any = any || ((((lo >> 24) | ((uint64_t)w2 << 40)) ^ want) & mk) == 0;
+    w0 = w1; w1 = w2; w2 = sword(s, a + 12);
+  }
+  return any;
 }
 GK_HD int str_cmp_c(const StrRef& s, uint32_t at, uint32_t n, const uint8_t* c, uint32_t nc) {   // ordering (rare)
   uint32_t k = n < nc ? n : nc;
@@ -215,6 +255,7 @@ GK_HD bool eval_pred(const Row& r, const Pred& p, const StrHdr& h, const uint8_t
       const uint8_t* c = cheap + p.a;
       if (p.op == P_STR_PREFIX) return str_prefix_c(s, c, m, p.k);
       if (p.op == P_STR_SUFFIX) return str_at_c(s, s.n - m, c, m);
+      if (m <= 8) return str_contains_short(s, c, m);
       bool any = false;
       for (uint32_t i = 0; i + m <= s.n; i++) any = any || str_at_c(s, i, c, m);
       return any;
