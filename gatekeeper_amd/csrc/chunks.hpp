@@ -14,6 +14,15 @@
 
 namespace gk {
 
+// relative cost of a predicate list (only the ORDER matters): string predicates and element destinations (LDS atomics on
+// shared words) weigh more.  One definition for the host's list order and the code generator's class order.
+template <class PredT>
+inline uint32_t pred_list_cost(const PredT* preds, uint32_t n, bool (*needs_str)(const PredT&)) {
+  uint32_t c = 1;
+  for (uint32_t j = 0; j < n; j++) c += 1u + (needs_str(preds[j]) ? 3u : 0u) + (preds[j].dst == D_ELEM ? 1u : 0u);
+  return c;
+}
+
 struct BoundPath { uint32_t slot, ent, cost; };   // ent: what the kernel's row function takes (path-table entry or class id), flag in GK_ENT_NEEDS_STR
 
 struct ChunkLists {
@@ -28,7 +37,11 @@ struct ChunkLists {
 inline ChunkLists build_chunk_lists(const uint32_t* tile_idx, uint32_t n_groups, uint32_t n_slots, std::vector<BoundPath> bound, uint32_t list_cap,
                                     uint32_t n_waves) {
   ChunkLists out;
-  std::stable_sort(bound.begin(), bound.end(), [](const BoundPath& a, const BoundPath& b) { return a.cost > b.cost; });
+  // (ties by entry: the chunks of one predicate class are contiguous, and the classes come in the order gk::class_order
+  //  gives the code generator -- the plan-specialised kernel walks the list class by class)
+  std::stable_sort(bound.begin(), bound.end(), [](const BoundPath& a, const BoundPath& b) {
+    return a.cost != b.cost ? a.cost > b.cost : (a.ent & GK_DESC_ENT_MASK) < (b.ent & GK_DESC_ENT_MASK);
+  });
   std::vector<uint32_t> count(n_groups, 0);
   uint32_t longest = 0;
   for (uint32_t g = 0; g < n_groups; g++) {

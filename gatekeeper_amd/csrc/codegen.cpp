@@ -4,6 +4,7 @@
 // compiles the result for gfx950 with hiprtc when the plan is uploaded; tests/native/hostemu.cpp can compile the same
 // text with g++ to validate the generator in the GPU-less container.
 #include "codegen.hpp"
+#include "chunks.hpp"
 
 #include <algorithm>
 #include <cstdlib>
@@ -98,6 +99,15 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts) {
   for (size_t i = 0; i < plan.scopes.size(); i++) o << (i ? "," : "") << plan.scopes[i].count_off << "u";
   if (plan.scopes.empty()) o << "0u";
   o << "};\n";
+  {   // the classes in the order their chunks appear in every list (chunks.hpp: cost descending, class id ascending)
+    std::vector<uint32_t> order;
+    for (size_t c = 1; c < classes.size(); c++) order.push_back((uint32_t)c);
+    auto cost = [&](uint32_t c) { return pred_list_cost<Pred>(classes[c].data(), (uint32_t)classes[c].size(), [](const Pred& q) { return pred_needs_str(q); }); };
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { uint32_t ca = cost(a), cb = cost(b); return ca != cb ? ca > cb : a < b; });
+    o << "#define GK_CLASS_BLOCKS(X)";
+    for (uint32_t c : order) o << " X(" << c << "u)";
+    o << "\n";
+  }
   // ---------------------------------------------------------------------------------------------- phase 1
   // inlined into its single call site (the chunk loop): as a separate function every LDS atomic would first look the
   // dynamic-LDS base up in a table (s_getpc + s_load + full wait; seen in the gfx950 ISA) and the call frame costs scratch

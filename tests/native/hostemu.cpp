@@ -302,7 +302,7 @@ static EmuJitLaunch emu_jit_for(const DevPlan* p, uint32_t rpt, uint32_t rpp, in
       << "#define GK_RES_PROLOGUE const bool gk_l0 = (threadIdx.x & 63u) == 0u;\n"
       << "#define GK_RES(kind, slot, b) do { const unsigned long long m_ = __ballot((b) != 0u); if (gk_l0) masks[(kind) * GK_RES_K + (slot)] = m_; } while (0)\n"
       << generate_plan_source(p->fast, (uint32_t)(block / GK_TILE / ((int)rpt / GK_TILE)))
-      << "#define GK_RPT_K " << rpt << "\n#define GK_RPP_K " << rpp << "\n#define GK_BLOCK_K " << block << "\n#define GK_PREFETCH " << (pf ? pf : (rpt <= 128 ? "2" : "3")) << "\n#define GK_SKIP_BIG\n"
+      << "#define GK_RPT_K " << rpt << "\n#define GK_RPP_K " << rpp << "\n#define GK_BLOCK_K " << block << "\n#define GK_PREFETCH " << (pf ? pf : "1") << "\n#define GK_SKIP_BIG\n"
       << "namespace gk {\n#define GK_KERNEL_TILES gk_jit_tiles\n#define GK_KERNEL_BIG gk_jit_big\n#define GK_KERNEL_LINKAGE static\n"
          "#define GK_ROW_FN(r, i, ent, h, pv, heap, acc, on) jit_row(r, ent, h, heap, acc, on)\n#define GK_BIND_ALWAYS_STR 0\n"
          "#define GK_FORMULA_FN(pv, acc, flags, rows, heap, bounds) jit_formulas(pv, acc, flags, rows, heap, bounds)\n"
@@ -340,8 +340,7 @@ static void emu_kernel_check(const DevPlan* p, const DevTable* dt, const EvalOpt
     const uint32_t path = t.slot_path[s];
     if (path >= entries.size() || !entries[path]) continue;
     const uint32_t ent = hp.ptab[path];
-    uint32_t c = 1;
-    for (uint32_t j = 0; j < (ent & 0xFF); j++) { const Pred& q = hp.path_preds[(ent >> 8) + j]; c += 1u + (pred_needs_str(q) ? 3u : 0u) + (q.dst == D_ELEM ? 1u : 0u); }
+    const uint32_t c = pred_list_cost<Pred>(&hp.path_preds[ent >> 8], ent & 0xFF, [](const Pred& q) { return pred_needs_str(q); });
     bound.push_back(BoundPath{s, entries[path], c});
   }
   const uint32_t n_groups = (n + rpt - 1) / rpt;
