@@ -1,0 +1,44 @@
+"""The dominant kernel's HIP source (gatekeeper_amd/csrc/kernel_body.inc) executed on the CPU by the TEST-ONLY kernel
+emulator (tests/native/kernel_emu.hpp: one fiber per GPU thread, barriers and wave collectives with GPU semantics) and
+compared, bit for bit, with the per-review evaluation of the same plan -- so the kernel's STRUCTURE (persistent
+workgroups walking several row groups, host-built chunk lists, the double-buffered list staging, per-wave loop bounds,
+result words in LDS, multi-pass groups, list overflow -> big variant) is checked in the GPU-less container, for the
+generic bytecode build and for the plan-specialised build (the text hiprtc compiles on the device, here through g++).
+`GK_HOSTEMU_KERNEL=1|jit` switches the check on for ANY hostemu evaluation (a mismatch raises); these cases pin the
+geometries and limits the rest of the suite does not reach by itself."""
+import pytest
+
+from gatekeeper_amd import driver as D
+from gatekeeper_amd import synth
+
+
+def _sweep(monkeypatch, mode, n, env):
+    monkeypatch.setenv("GK_HOSTEMU_KERNEL", mode)
+    for k, v in env.items():
+        monkeypatch.setenv(k, str(v))
+    fx = synth.load_fixtures()
+    drv = D.Driver(device=0, hostemu=True)
+    client = D.Client(drv)
+    for t in synth.psp_templates(fx):
+        client.AddTemplate(t)
+    for k in synth.audit_constraints():
+        client.AddConstraint(k)
+    nss = synth.gen_namespaces()
+    batch = synth.NativeBatch(drv.engine.lib, n, seed=synth.SEED, mixed=True, start=0, namespaces=nss)
+    table = drv.engine.create_table_native(batch.reviews, n, keep_docs=False, resident=True)
+    table.launch()
+    ev = table.eval(download=True, collect_only=True)     # raises EngineError when the emulated kernel and the per-review path differ
+    assert int(ev.counts.sum()) > 0
+    return ev
+
+
+@pytest.mark.parametrize("mode", ["1", "jit"])
+@pytest.mark.parametrize("env", [
+    {"GK_RPT": 64, "GK_EMU_GRID": 8},                              # 4-wave groups, several groups per persistent workgroup
+    {"GK_RPT": 256, "GK_EMU_GRID": 8},                             # 8-wave groups, result words alias the list buffer (jit)
+    {"GK_RPT": 256, "GK_FORCE_RPP": 64, "GK_EMU_GRID": 8},         # multi-pass groups: four passes over the same chunk list
+    {"GK_RPT": 512, "GK_FORCE_RPP": 128, "GK_EMU_GRID": 8},        # 16 waves, two passes
+    {"GK_RPT": 128, "GK_EMU_LIST_CAP": 24, "GK_EMU_GRID": 8},      # lists overflow: the groups' reviews take the big variant
+], ids=["rpt64", "rpt256", "rpt256-4pass", "rpt512-2pass", "list-overflow"])
+def test_kernel_source_on_the_emulator(monkeypatch, mode, env):
+    _sweep(monkeypatch, mode, 1500, env)

@@ -1,0 +1,39 @@
+#!/bin/bash
+# GPU visit (final of a round): full gpu parity suite, smoke, default bench (configs[2]) with CPU baseline, rocprofv3 kernel
+# stats + PMC passes (SQ, FETCH_SIZE, WRITE_SIZE) of the same command, the sharded path through RCCL at world size 1,
+# configs[1], the 200-template corpus, admission latency.
+set -u
+tag=${1:-run}
+mkdir -p gpurun_out; export TMPDIR=/tmp
+timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 > gpurun_out/${tag}_pytest_gpu.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/${tag}_smoke.log 2>&1
+timeout 600 python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${tag}_stats -o stats -- python $GRAFT_REPO_ROOT/bench.py --steps 50 --warmup 5 --no-cpu-baseline > /dev/null 2> $GRAFT_REPO_ROOT/gpurun_out/${tag}_stats.err)
+run_pmc() { name=$1; shift; rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d gpurun_out/${tag}pmc_$name -o $name -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline > /dev/null 2> gpurun_out/${tag}pmc_$name.err; }
+run_pmc sq SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
+run_pmc fetch FETCH_SIZE
+run_pmc write WRITE_SIZE
+for d in sq fetch write; do
+  f=$(find gpurun_out/${tag}pmc_$d -name '*counter_collection.csv' | head -1)
+  [ -n "$f" ] && python - "$f" <<'PY' >> gpurun_out/${tag}_pmc.log
+import csv, sys, collections
+acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
+for r in csv.DictReader(open(sys.argv[1])):
+    k = r.get('Kernel_Name', '')
+    if 'tiles' not in k: continue
+    acc[k][r['Counter_Name']] += float(r['Counter_Value']); n[(k, r['Counter_Name'])] += 1
+for k in acc:
+    for c, v in sorted(acc[k].items()):
+        print('%s %s per_dispatch=%.1f dispatches=%d' % (k[:20], c, v / n[(k, c)], n[(k, c)]))
+PY
+done
+GK_FORCE_DIST=1 timeout 600 python bench.py --no-cpu-baseline --steps 50 > gpurun_out/${tag}_bench_rccl_w1.json 2> gpurun_out/${tag}_bench_rccl_w1.err
+timeout 600 python bench.py --config 1 --no-cpu-baseline > gpurun_out/${tag}_bench_config1.json 2> gpurun_out/${tag}_bench_config1.err
+timeout 900 python bench.py --config 4 --steps 50 --no-cpu-baseline > gpurun_out/${tag}_bench_config4.json 2> gpurun_out/${tag}_bench_config4.err
+timeout 600 python tools/latency_probe.py > gpurun_out/${tag}_latency.json 2> gpurun_out/${tag}_latency.err
+tail -3 gpurun_out/${tag}_pytest_gpu.log
+tail -2 gpurun_out/${tag}_smoke.log
+for f in bench bench_rccl_w1 bench_config1 bench_config4; do echo "== $f"; tail -c 1200 gpurun_out/${tag}_$f.json; tail -2 gpurun_out/${tag}_$f.err; done
+find gpurun_out/${tag}_stats -name '*kernel_stats.csv' | head -1 | xargs -r head -6
+cat gpurun_out/${tag}_pmc.log
+tail -c 800 gpurun_out/${tag}_latency.json
