@@ -121,9 +121,10 @@ GK_HD uint32_t sword(const StrRef& s, uint32_t j) {   // bytes [j, j+4), j a mul
   if (j == 8) return s.w2;
   return s.p ? ld32(s.p + j) : 0u;
 }
-GK_HD uint64_t swin(const StrRef& s, uint32_t at) {   // bytes [at, at+8), any alignment
-  const uint32_t a = at & ~3u, sh = (at & 3u) * 8u;
-  const uint32_t w0 = sword(s, a), w1 = sword(s, a + 4u), w2 = sword(s, a + 8u);
+GK_HD uint64_t swin(const StrRef& s, uint32_t at, uint32_t m) {   // bytes [at, at+m), m <= 8, any alignment; the bytes above m are unspecified
+  const uint32_t a = at & ~3u, sh = (at & 3u) * 8u, end = at + m;   // only the words that hold wanted bytes are read: nothing beyond
+  const uint32_t w0 = sword(s, a);                                  // the word of the string's last byte is ever touched
+  const uint32_t w1 = end > a + 4u ? sword(s, a + 4u) : 0u, w2 = end > a + 8u ? sword(s, a + 8u) : 0u;
   const uint64_t lo = ((uint64_t)w1 << 32) | w0;
   return sh ? (lo >> sh) | ((uint64_t)w2 << (64u - sh)) : lo;
 }
@@ -137,7 +138,7 @@ GK_HD bool str_at_c(const StrRef& s, uint32_t at, const uint8_t* c, uint32_t m) 
   uint64_t d = 0;
   for (uint32_t i = 0; i < m; i += 8) {
     const uint32_t k = m - i < 8 ? m - i : 8;
-    d |= (swin(s, at + i) ^ cwin(c + i, k)) & mask_bytes(k);
+    d |= (swin(s, at + i, k) ^ cwin(c + i, k)) & mask_bytes(k);
   }
   return d == 0;
 }
@@ -146,7 +147,7 @@ GK_HD bool str_contains_short(const StrRef& s, const uint8_t* c, uint32_t m) {
   if (m > s.n) return false;
   const uint64_t want = cwin(c, m), mk = mask_bytes(m);
   const uint32_t last = s.n - m;   // last start position
-  uint32_t w0 = sword(s, 0), w1 = sword(s, 4), w2 = sword(s, 8);
+  uint32_t w0 = sword(s, 0), w1 = sword(s, 4), w2 = sword(s, 8);   // (header words: no memory access)
   bool any = false;
   for (uint32_t a = 0; a <= last; a += 4) {
     const uint64_t lo = ((uint64_t)w1 << 32) | w0;
@@ -154,7 +155,7 @@ GK_HD bool str_contains_short(const StrRef& s, const uint8_t* c, uint32_t m) {
     if (a + 1 <= last) any = any || ((((lo >> 8) | ((uint64_t)w2 << 56)) ^ want) & mk) == 0;
     if (a + 2 <= last) any = any || ((((lo >> 16) | ((uint64_t)w2 << 48)) ^ want) & mk) == 0;
     if (a + 3 <= last) any = any || ((((lo >> 24) | ((uint64_t)w2 << 40)) ^ want) & mk) == 0;
-    w0 = w1; w1 = w2; w2 = sword(s, a + 12);
+    w0 = w1; w1 = w2; w2 = a + 12u < s.n ? sword(s, a + 12u) : 0u;   // (a start position in the next round needs bytes < n only)
   }
   return any;
 }
