@@ -15,7 +15,7 @@
 namespace gk {
 
 // relative cost of a predicate list (only the ORDER matters): string predicates and element destinations (LDS atomics on
-// shared words) weigh more.  One definition for the host's list order and the code generator's class order.
+// shared words) weigh more.
 template <class PredT>
 inline uint32_t pred_list_cost(const PredT* preds, uint32_t n, bool (*needs_str)(const PredT&)) {
   uint32_t c = 1;
@@ -37,8 +37,7 @@ struct ChunkLists {
 inline ChunkLists build_chunk_lists(const uint32_t* tile_idx, uint32_t n_groups, uint32_t n_slots, std::vector<BoundPath> bound, uint32_t list_cap,
                                     uint32_t n_waves) {
   ChunkLists out;
-  // (ties by entry: the chunks of one predicate class are contiguous, and the classes come in the order gk::class_order
-  //  gives the code generator -- the plan-specialised kernel walks the list class by class)
+  // (ties by entry: the chunks of one predicate class are contiguous)
   std::stable_sort(bound.begin(), bound.end(), [](const BoundPath& a, const BoundPath& b) {
     return a.cost != b.cost ? a.cost > b.cost : (a.ent & GK_DESC_ENT_MASK) < (b.ent & GK_DESC_ENT_MASK);
   });

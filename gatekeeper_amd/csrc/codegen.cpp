@@ -57,7 +57,7 @@ uint32_t jit_res_k(const HostPlan& plan) {
   return need <= 16 ? 16u : need <= 32 ? 32u : (uint32_t)GK_MAX_RES;
 }
 
-std::string generate_plan_source(const HostPlan& plan, uint32_t parts) {
+std::string generate_plan_source(const HostPlan& plan, uint32_t parts, const std::vector<uint64_t>* class_weight) {
   std::ostringstream o;
   std::vector<std::vector<Pred>> classes;
   jit_path_classes(plan, &classes);
@@ -99,21 +99,14 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts) {
   for (size_t i = 0; i < plan.scopes.size(); i++) o << (i ? "," : "") << plan.scopes[i].count_off << "u";
   if (plan.scopes.empty()) o << "0u";
   o << "};\n";
-  {   // the classes in the order their chunks appear in every list (chunks.hpp: cost descending, class id ascending)
-    std::vector<uint32_t> order;
-    for (size_t c = 1; c < classes.size(); c++) order.push_back((uint32_t)c);
-    auto cost = [&](uint32_t c) { return pred_list_cost<Pred>(classes[c].data(), (uint32_t)classes[c].size(), [](const Pred& q) { return pred_needs_str(q); }); };
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { uint32_t ca = cost(a), cb = cost(b); return ca != cb ? ca > cb : a < b; });
-    o << "#define GK_CLASS_BLOCKS(X)";
-    for (uint32_t c : order) o << " X(" << c << "u)";
-    o << "\n";
-  }
   // ---------------------------------------------------------------------------------------------- phase 1
   // inlined into its single call site (the chunk loop): as a separate function every LDS atomic would first look the
   // dynamic-LDS base up in a table (s_getpc + s_load + full wait; seen in the gfx950 ISA) and the call frame costs scratch
   const bool inline_row = !(getenv("GK_JIT_INLINE_ROW") && atoi(getenv("GK_JIT_INLINE_ROW")) == 0);   // tuning aid
   o << "template <class Acc>\nGK_HD __attribute__((" << (inline_row ? "always_inline" : "noinline") << ")) void jit_row(Row r, uint32_t cls, StrHdr h, const uint8_t* heap, Acc acc, bool on) {\n"
-    << "  const uint8_t* cheap = gk_plan_consts;\n  (void)cheap; (void)h;\n  cls = GK_UNI(cls) & ~GK_ENT_NEEDS_STR;   // one class per call: the dispatch is a scalar branch\n  switch (cls) {\n";
+    << "  const uint8_t* cheap = gk_plan_consts;\n  (void)cheap; (void)h;\n  cls = GK_UNI(cls) & ~GK_ENT_NEEDS_STR;   // one class per call: the dispatch is a scalar branch\n";
+  std::ostringstream& real_o = o;
+  std::vector<std::string> case_body(classes.size());
   // One class = the predicates of one key path.  Results are gathered in one mask per destination word (a single LDS
   // atomic per word, not per predicate); integer comparisons share one type test; short string equalities compare
   // the packed payload; everything else goes through eval_pred with a constexpr predicate.
@@ -121,7 +114,8 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts) {
   for (size_t c = 1; c < classes.size(); c++) {
     // the class dispatch is wave-uniform and comes FIRST; the per-lane "this lane holds a row of this pass" test sits inside
     // the case (around a divergent dispatch the structuriser threads every case exit through a chain of flow blocks)
-    o << "    case " << c << ": if (on) {\n      const uint32_t t = r.meta & 7u; (void)t;\n";
+    std::ostringstream o;   // (this class's body; assembled into the dispatch below)
+    o << "if (on) {\n      const uint32_t t = r.meta & 7u; (void)t;\n";
     const std::vector<Pred>& ps = classes[c];
     struct Group { int scope, level; bool always = false; std::vector<std::string> masks; std::vector<size_t> stores; bool present = false; };
     std::vector<Group> groups;          // element destinations by (scope, level)
@@ -235,9 +229,39 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts) {
       if (!w0_done && !extra.empty()) o << "          acc.or_word(" << sc.word_off << "u + ord * " << (int)sc.wpe << "u, 0u" << extra << ");\n";
       o << "        }\n      }\n";
     }
-    o << "    } break;\n";
+    o << "    }\n";
+    case_body[c] = o.str();
   }
-  o << "    default: break;\n  }\n}\n\n";
+  {
+    // The dispatch.  A `switch` becomes a compare tree on the way in and, because the cases hold divergent branches, a chain
+    // of structuriser flow blocks on the way out: ~14 taken branches per chunk for 38 classes (the AMDGPU backend has no
+    // jump tables).  The classes that own most chunks of the table the kernel is first compiled for are therefore tested
+    // FIRST, in an if / else-if chain ordered by chunk count (short way in, short way out); the rest stay in the switch.
+    // Any order is correct; another table only meets a less fitting one.
+    std::vector<uint32_t> hot;
+    if (class_weight) {
+      std::vector<uint32_t> ids;
+      for (size_t c = 1; c < classes.size(); c++) if (c < class_weight->size() && (*class_weight)[c] > 0) ids.push_back((uint32_t)c);
+      std::stable_sort(ids.begin(), ids.end(), [&](uint32_t a, uint32_t b) { return (*class_weight)[a] > (*class_weight)[b]; });
+      static const size_t n_hot = getenv("GK_JIT_HOT") ? (size_t)atoi(getenv("GK_JIT_HOT")) : 8;   // tuning aid
+      for (size_t i = 0; i < ids.size() && i < n_hot; i++) hot.push_back(ids[i]);
+    }
+    std::ostringstream& o = real_o;
+    // (every test of the chain compares its own opaque copy of the class: left alone, the optimiser folds the chain back
+    //  into the switch and lowers one balanced tree)
+    o << "#if defined(__HIP_DEVICE_COMPILE__)\n#define GK_DISPATCH_OPAQUE(x) asm volatile(\"\" : \"+s\"(x))\n#else\n#define GK_DISPATCH_OPAQUE(x) do { } while (0)\n#endif\n";
+    o << "  ";
+    for (size_t i = 0; i < hot.size(); i++)
+      o << "{ uint32_t cls" << i << " = cls; GK_DISPATCH_OPAQUE(cls" << i << "); if (cls" << i << " == " << hot[i] << "u) { " << case_body[hot[i]] << "  } else ";
+    o << "switch (cls) {\n";
+    for (size_t c = 1; c < classes.size(); c++) {
+      if (std::find(hot.begin(), hot.end(), (uint32_t)c) != hot.end()) continue;
+      o << "    case " << c << ": " << case_body[c] << "    break;\n";
+    }
+    o << "    default: break;\n  }\n";
+    for (size_t i = 0; i < hot.size(); i++) o << "}";
+    o << "\n}\n\n";
+  }
   // ---------------------------------------------------------------------------------------------- phase 2
   o << "template <class Acc>\nGK_HD Results jit_formulas(const PlanView& pv, Acc& acc, uint32_t flags, const Row* rows, const uint8_t* heap, const uint32_t* bounds) {\n"
     << "  (void)pv; (void)rows; (void)heap; (void)flags;\n  Results res = {0, 0, 0};\n  uint32_t";

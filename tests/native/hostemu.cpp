@@ -287,7 +287,7 @@ namespace gk {
 
 typedef void (*EmuJitLaunch)(unsigned, unsigned, size_t, const PlanView*, const Row*, const StrHdr*, const ChunkDesc*, uint32_t, const uint32_t*, const uint8_t*,
                              uint32_t, uint32_t, const ConstraintSlot*, const OutPtrs*, uint32_t, uint32_t);
-static EmuJitLaunch emu_jit_for(const DevPlan* p, uint32_t rpt, uint32_t rpp, int block) {
+static EmuJitLaunch emu_jit_for(const DevPlan* p, uint32_t rpt, uint32_t rpp, int block, const std::vector<uint64_t>& class_weight) {
   char key[96];
   snprintf(key, sizeof key, "%u/%u/%d", rpt, rpp, block);
   DevPlan* mp = const_cast<DevPlan*>(p);
@@ -301,7 +301,7 @@ static EmuJitLaunch emu_jit_for(const DevPlan* p, uint32_t rpt, uint32_t rpp, in
     f << "#include \"" << GK_CSRC_DIR << "/../../tests/native/kernel_emu.hpp\"\n#include \"" << GK_CSRC_DIR << "/vm_core.hpp\"\n"
       << "#define GK_RES_PROLOGUE const bool gk_l0 = (threadIdx.x & 63u) == 0u;\n"
       << "#define GK_RES(kind, slot, b) do { const unsigned long long m_ = __ballot((b) != 0u); if (gk_l0) masks[(kind) * GK_RES_K + (slot)] = m_; } while (0)\n"
-      << generate_plan_source(p->fast, (uint32_t)(block / GK_TILE / ((int)rpt / GK_TILE)))
+      << generate_plan_source(p->fast, (uint32_t)(block / GK_TILE / ((int)rpt / GK_TILE)), &class_weight)   // (as kernels.hip: dispatch ordered by the table's chunk counts)
       << "#define GK_RPT_K " << rpt << "\n#define GK_RPP_K " << rpp << "\n#define GK_BLOCK_K " << block << "\n#define GK_PREFETCH " << (pf ? pf : "1") << "\n#define GK_SKIP_BIG\n"
       << "namespace gk {\n#define GK_KERNEL_TILES gk_jit_tiles\n#define GK_KERNEL_BIG gk_jit_big\n#define GK_KERNEL_LINKAGE static\n"
          "#define GK_ROW_FN(r, i, ent, h, pv, heap, acc, on) jit_row(r, ent, h, heap, acc, on)\n#define GK_BIND_ALWAYS_STR 0\n"
@@ -363,7 +363,13 @@ static void emu_kernel_check(const DevPlan* p, const DevTable* dt, const EvalOpt
   else grid = std::min<unsigned>(grid, 16u);
   const Row* rows = t.rows.data(); const StrHdr* shdr = t.shdr.data();
   if (jit) {
-    EmuJitLaunch fn = emu_jit_for(p, rpt, rpp, block);
+    std::vector<uint64_t> weight;   // chunks per class in this table
+    for (const BoundPath& b : bound) {
+      const uint32_t c = b.ent & GK_DESC_ENT_MASK;
+      if (c >= weight.size()) weight.resize(c + 1, 0);
+      for (uint32_t g = 0; g < n_groups; g++) weight[c] += (t.tile_idx[(size_t)g * (t.n_slots() + 1) + b.slot + 1] - t.tile_idx[(size_t)g * (t.n_slots() + 1) + b.slot] + GK_TILE - 1) / GK_TILE;
+    }
+    EmuJitLaunch fn = emu_jit_for(p, rpt, rpp, block, weight);
     fn(grid, (unsigned)block, lds, &pv, rows, shdr, cl.d.data(), cl.capg, t.rflags.data(), t.heap.data(), n, nt, hp.slots.data(), &out, 0u, rpp);
   } else {
     auto fn = rpt == 64 ? gk_emu_tiles_64 : rpt == 128 ? gk_emu_tiles_128 : rpt == 256 ? gk_emu_tiles_256 : gk_emu_tiles_512;
