@@ -390,6 +390,7 @@ class Parser {
         if (t.text == "true") n.value = Value::boolean(true);
         else if (t.text == "false") n.value = Value::boolean(false);
         else if (t.text == "null") n.value = Value::null();
+        else if (t.text == "contains") { n.kind = Term::Var; n.name = t.text; }   // OPA: `contains` anywhere BUT in rule heads gets no special treatment (the builtin contains(s, sub))
         else fail(t.line, "unexpected keyword '" + t.text + "'");
         return mk(n);
       case Tok::Ident:

@@ -409,6 +409,8 @@ class Parser:
                 return ("scalar", False)
             if v == "null":
                 return ("scalar", None)
+            if v == "contains":     # OPA's parser: `contains` anywhere BUT in rule heads gets no special treatment (builtin contains(s, sub))
+                return ("var", v)
             raise RegoSyntaxError("line %d: unexpected keyword %r" % (t[2], v))
         if k == "ident":
             if v == "_":

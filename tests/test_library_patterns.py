@@ -1,0 +1,328 @@
+"""Policy patterns of the public gatekeeper-library, written out here as sixteen templates of the common shapes (allowed
+repos, disallowed tags, image digests, replica ranges, required annotations / resources, PSP capabilities / host
+namespaces / host ports / read-only root fs / volume types / users, NodePort, wildcard ingress, external IPs, https-only
+ingress): comprehension + any / all, set difference, helper rules with several bodies, function rules matched on
+constants, object.get, partial-set helper rules, regular expressions, the string builtins startswith / endswith /
+contains / concat / lower / sprintf.  The library itself is not part of /root/reference, so these are NOT reference-held
+vectors: the test widens the product-vs-oracle comparison (rendered results AND raw device bitmaps, parity_util) to the
+template shapes users actually load, all constraints at once in ONE plan.
+
+Also pins a parser rule both sides got wrong: `contains` is a keyword only in a rule head (`violation contains x if`);
+anywhere else it is the builtin contains(s, sub) (OPA's parser: "contains anywhere BUT in rule heads gets no special
+treatment") -- used as a statement, under `not`, in an assignment and inside a helper rule below."""
+import pytest
+
+from gatekeeper_amd import driver as D
+from parity_util import BACKENDS, assert_parity, load_both
+
+
+def tmpl(kind, rego):
+    return {"apiVersion": "templates.gatekeeper.sh/v1", "kind": "ConstraintTemplate", "metadata": {"name": kind.lower()},
+            "spec": {"crd": {"spec": {"names": {"kind": kind}}}, "targets": [{"target": "admission.k8s.gatekeeper.sh", "rego": rego}]}}
+
+
+T = {}
+T["K8sAllowedRepos"] = ('''package k8sallowedrepos
+violation[{"msg": msg}] {
+  container := input.review.object.spec.containers[_]
+  satisfied := [good | repo = input.parameters.repos[_] ; good = startswith(container.image, repo)]
+  not any(satisfied)
+  msg := sprintf("container <%v> has an invalid image repo <%v>, allowed repos are %v", [container.name, container.image, input.parameters.repos])
+}
+violation[{"msg": msg}] {
+  container := input.review.object.spec.initContainers[_]
+  satisfied := [good | repo = input.parameters.repos[_] ; good = startswith(container.image, repo)]
+  not any(satisfied)
+  msg := sprintf("initContainer <%v> has an invalid image repo <%v>, allowed repos are %v", [container.name, container.image, input.parameters.repos])
+}
+''', {"repos": ["gcr.io/good/", "docker.io/library/"]})
+T["K8sBlockNodePort"] = ('''package k8sblocknodeport
+violation[{"msg": msg}] {
+  input.review.kind.kind == "Service"
+  input.review.object.spec.type == "NodePort"
+  msg := "User is not allowed to create service of type NodePort"
+}
+''', {})
+T["K8sBlockWildcardIngress"] = ('''package K8sBlockWildcardIngress
+contains_wildcard(hostname) = true {
+  hostname == ""
+}
+contains_wildcard(hostname) = true {
+  contains(hostname, "*")
+}
+violation[{"msg": msg}] {
+  input.review.kind.kind == "Ingress"
+  hostnames := {object.get(rule, "host", "") | rule := input.review.object.spec.rules[_]}
+  contains_wildcard(hostnames[_])
+  msg := sprintf("Hostname '%v' is not allowed since it counts as a wildcard, which can be used to intercept traffic from other applications.", [hostnames[_]])
+}
+''', {})
+T["K8sDisallowedTags"] = ('''package k8sdisallowedtags
+violation[{"msg": msg}] {
+  container := input_containers[_]
+  tags := [forbid | tag = input.parameters.tags[_] ; forbid = endswith(container.image, concat(":", ["", tag]))]
+  any(tags)
+  msg := sprintf("container <%v> uses a disallowed tag <%v>; disallowed tags are %v", [container.name, container.image, input.parameters.tags])
+}
+violation[{"msg": msg}] {
+  container := input_containers[_]
+  tag := [contains(container.image, ":")]
+  not all(tag)
+  msg := sprintf("container <%v> didn't specify an image tag <%v>", [container.name, container.image])
+}
+input_containers[c] {
+  c := input.review.object.spec.containers[_]
+}
+input_containers[c] {
+  c := input.review.object.spec.initContainers[_]
+}
+''', {"tags": ["latest"]})
+T["K8sImageDigests"] = ('''package k8simagedigests
+violation[{"msg": msg}] {
+  container := input.review.object.spec.containers[_]
+  satisfied := [re_match("@[a-z0-9]+([+._-][a-z0-9]+)*:[a-zA-Z0-9=_-]+", container.image)]
+  not all(satisfied)
+  msg := sprintf("container <%v> uses an image without a digest <%v>", [container.name, container.image])
+}
+''', {})
+T["K8sReplicaLimits"] = ('''package k8sreplicalimits
+deployment_name = input.review.object.metadata.name
+violation[{"msg": msg}] {
+  spec := input.review.object.spec
+  not input_replica_limit(spec)
+  msg := sprintf("The provided number of replicas is not allowed for deployment: %v. Allowed ranges: %v", [deployment_name, input.parameters])
+}
+input_replica_limit(spec) {
+  provided := input.review.object.spec.replicas
+  count(input.parameters.ranges) > 0
+  range := input.parameters.ranges[_]
+  value_within_range(range, provided)
+}
+value_within_range(range, value) {
+  range.min_replicas <= value
+  range.max_replicas >= value
+}
+''', {"ranges": [{"min_replicas": 2, "max_replicas": 5}]})
+T["K8sRequiredAnnotations"] = ('''package k8srequiredannotations
+violation[{"msg": msg, "details": {"missing_annotations": missing}}] {
+  provided := {annotation | input.review.object.metadata.annotations[annotation]}
+  required := {annotation | annotation := input.parameters.annotations[_].key}
+  missing := required - provided
+  count(missing) > 0
+  msg := sprintf("you must provide annotation(s): %v", [missing])
+}
+violation[{"msg": msg}] {
+  value := input.review.object.metadata.annotations[key]
+  expected := input.parameters.annotations[_]
+  expected.key == key
+  expected.allowedRegex != ""
+  not re_match(expected.allowedRegex, value)
+  msg := sprintf("Annotation <%v: %v> does not satisfy allowed regex: %v", [key, value, expected.allowedRegex])
+}
+''', {"annotations": [{"key": "owner", "allowedRegex": "^[a-z]+$"}]})
+T["K8sPSPCapabilities"] = ('''package capabilities
+violation[{"msg": msg}] {
+  container := input.review.object.spec.containers[_]
+  has_disallowed_capabilities(container)
+  msg := sprintf("container <%v> has a disallowed capability. Allowed capabilities are %v", [container.name, get_default(input.parameters, "allowedCapabilities", "NONE")])
+}
+violation[{"msg": msg}] {
+  container := input.review.object.spec.containers[_]
+  missing_drop_capabilities(container)
+  msg := sprintf("container <%v> is not dropping all required capabilities. Container must drop all of %v or \\"ALL\\"", [container.name, input.parameters.requiredDropCapabilities])
+}
+has_disallowed_capabilities(container) {
+  allowed := {c | c := lower(input.parameters.allowedCapabilities[_])}
+  not allowed["*"]
+  capabilities := {c | c := lower(container.securityContext.capabilities.add[_])}
+  count(capabilities - allowed) > 0
+}
+missing_drop_capabilities(container) {
+  must_drop := {c | c := lower(input.parameters.requiredDropCapabilities[_])}
+  all := {"all"}
+  dropped := {c | c := lower(container.securityContext.capabilities.drop[_])}
+  count(must_drop - dropped) > 0
+  count(all - dropped) > 0
+}
+get_default(obj, param, _default) = out {
+  out = obj[param]
+}
+get_default(obj, param, _default) = out {
+  not obj[param]
+  not obj[param] == false
+  out = _default
+}
+''', {"allowedCapabilities": ["NET_BIND_SERVICE"], "requiredDropCapabilities": ["NET_RAW"]})
+T["K8sPSPHostNamespace"] = ('''package k8spsphostnamespace
+violation[{"msg": msg, "details": {}}] {
+  input_share_hostnamespace(input.review.object)
+  msg := sprintf("Sharing the host namespace is not allowed: %v", [input.review.object.metadata.name])
+}
+input_share_hostnamespace(o) {
+  o.spec.hostPID
+}
+input_share_hostnamespace(o) {
+  o.spec.hostIPC
+}
+''', {})
+T["K8sPSPHostNetworkingPorts"] = ('''package k8spsphostnetworkingports
+violation[{"msg": msg, "details": {}}] {
+  input_share_hostnetwork(input.review.object)
+  msg := sprintf("The specified hostNetwork and hostPort are not allowed, pod: %v. Allowed values: %v", [input.review.object.metadata.name, input.parameters])
+}
+input_share_hostnetwork(o) {
+  not input.parameters.hostNetwork
+  o.spec.hostNetwork
+}
+input_share_hostnetwork(o) {
+  hostPort := input_containers[_].ports[_].hostPort
+  hostPort < input.parameters.min
+}
+input_share_hostnetwork(o) {
+  hostPort := input_containers[_].ports[_].hostPort
+  hostPort > input.parameters.max
+}
+input_containers[c] {
+  c := input.review.object.spec.containers[_]
+}
+input_containers[c] {
+  c := input.review.object.spec.initContainers[_]
+}
+''', {"hostNetwork": False, "min": 80, "max": 9000})
+T["K8sPSPReadOnlyRootFilesystem"] = ('''package k8spspreadonlyrootfilesystem
+violation[{"msg": msg, "details": {}}] {
+  c := input_containers[_]
+  input_read_only_root_fs(c)
+  msg := sprintf("only read-only root filesystem container is allowed: %v", [c.name])
+}
+input_read_only_root_fs(c) {
+  not has_field(c, "securityContext")
+}
+input_read_only_root_fs(c) {
+  not c.securityContext.readOnlyRootFilesystem == true
+}
+input_containers[c] {
+  c := input.review.object.spec.containers[_]
+}
+has_field(object, field) = true {
+  object[field]
+}
+''', {})
+T["K8sPSPVolumeTypes"] = ('''package k8spspvolumetypes
+violation[{"msg": msg, "details": {}}] {
+  volume_fields := {x | input.review.object.spec.volumes[_][x]; x != "name"}
+  field := volume_fields[_]
+  not input_volume_type_allowed(field)
+  msg := sprintf("The volume type %v is not allowed, pod: %v. Allowed volume types: %v", [field, input.review.object.metadata.name, input.parameters.volumes])
+}
+input_volume_type_allowed(field) {
+  input.parameters.volumes[_] == "*"
+}
+input_volume_type_allowed(field) {
+  field == input.parameters.volumes[_]
+}
+''', {"volumes": ["configMap", "emptyDir", "secret"]})
+T["K8sExternalIPs"] = ('''package k8sexternalips
+violation[{"msg": msg}] {
+  input.review.kind.kind == "Service"
+  input.review.kind.group == ""
+  allowedIPs := {ip | ip := input.parameters.allowedIPs[_]}
+  externalIPs := {ip | ip := input.review.object.spec.externalIPs[_]}
+  forbiddenIPs := externalIPs - allowedIPs
+  count(forbiddenIPs) > 0
+  msg := sprintf("service has forbidden external IPs: %v", [forbiddenIPs])
+}
+''', {"allowedIPs": ["203.0.113.0"]})
+T["K8sHttpsOnly"] = ('''package k8shttpsonly
+violation[{"msg": msg}] {
+  input.review.object.kind == "Ingress"
+  re_match("^(extensions|networking.k8s.io)/", input.review.object.apiVersion)
+  ingress := input.review.object
+  not https_complete(ingress)
+  msg := sprintf("Ingress should be https. tls configuration and allow-http=false annotation are required for %v", [ingress.metadata.name])
+}
+https_complete(ingress) = true {
+  ingress.spec["tls"]
+  count(ingress.spec.tls) > 0
+  ingress.metadata.annotations["kubernetes.io/ingress.allow-http"] == "false"
+}
+''', {})
+T["K8sRequiredResources"] = ('''package k8srequiredresources
+violation[{"msg": msg}] {
+  container := input.review.object.spec.containers[_]
+  provided := {resource_type | container.resources.limits[resource_type]}
+  required := {resource_type | resource_type := input.parameters.limits[_]}
+  missing := required - provided
+  count(missing) > 0
+  msg := sprintf("container <%v> does not have <%v> limits defined", [container.name, missing])
+}
+''', {"limits": ["cpu", "memory"]})
+T["K8sPSPAllowedUsers"] = ('''package k8spspallowedusers
+violation[{"msg": msg}] {
+  rule := input.parameters.runAsUser.rule
+  container := input.review.object.spec.containers[_]
+  provided_user := get_user(container)
+  not accept_users(rule, provided_user)
+  msg := sprintf("Container %v is attempting to run as disallowed user %v", [container.name, provided_user])
+}
+get_user(c) = u { u := c.securityContext.runAsUser }
+accept_users("RunAsAny", provided_user) {true}
+accept_users("MustRunAsNonRoot", provided_user) = res {res := provided_user != 0}
+accept_users("MustRunAs", provided_user) = res  {
+  ranges := input.parameters.runAsUser.ranges
+  matching := {1 | provided_user >= ranges[j].min; provided_user <= ranges[j].max}
+  res := count(matching) > 0
+}
+''', {"runAsUser": {"rule": "MustRunAs", "ranges": [{"min": 100, "max": 200}]}})
+
+def pod(name, containers, **spec):
+    s = {"containers": containers}; s.update(spec)
+    return {"apiVersion": "v1", "kind": "Pod", "metadata": {"name": name, "namespace": "default", "annotations": {"owner": "Bob1"}}, "spec": s}
+OBJS = [
+ pod("p1", [{"name": "a", "image": "gcr.io/good/app:1.0", "securityContext": {"runAsUser": 150, "readOnlyRootFilesystem": True, "capabilities": {"add": ["NET_BIND_SERVICE"], "drop": ["ALL"]}}, "resources": {"limits": {"cpu": "1", "memory": "1Gi"}}}]),
+ pod("p2", [{"name": "a", "image": "evil.io/app:latest", "securityContext": {"runAsUser": 0, "capabilities": {"add": ["SYS_ADMIN"]}}, "ports": [{"hostPort": 22}]}, {"name": "b", "image": "docker.io/library/nginx", "resources": {"limits": {"cpu": "1"}}}], hostPID=True, hostNetwork=True,
+     volumes=[{"name": "v", "hostPath": {"path": "/"}}, {"name": "w", "emptyDir": {}}], initContainers=[{"name": "i", "image": "evil.io/init@sha256:abcdef0123"}]),
+ pod("p3", [{"name": "a", "image": "gcr.io/good/app@sha256:0123abcd", "securityContext": {"runAsUser": 500}}], hostIPC=False),
+ {"apiVersion": "v1", "kind": "Service", "metadata": {"name": "s1", "namespace": "default"}, "spec": {"type": "NodePort", "externalIPs": ["1.2.3.4", "203.0.113.0"]}},
+ {"apiVersion": "v1", "kind": "Service", "metadata": {"name": "s2", "namespace": "default"}, "spec": {"type": "ClusterIP"}},
+ {"apiVersion": "networking.k8s.io/v1", "kind": "Ingress", "metadata": {"name": "i1", "namespace": "default", "annotations": {"kubernetes.io/ingress.allow-http": "false"}}, "spec": {"tls": [{"hosts": ["a.com"]}], "rules": [{"host": "*.a.com"}, {"host": "b.com"}, {}]}},
+ {"apiVersion": "networking.k8s.io/v1", "kind": "Ingress", "metadata": {"name": "i2", "namespace": "default"}, "spec": {"rules": [{"host": "c.com"}]}},
+ {"apiVersion": "apps/v1", "kind": "Deployment", "metadata": {"name": "d1", "namespace": "default"}, "spec": {"replicas": 1, "template": {"spec": {"containers": [{"name": "x", "image": "gcr.io/good/x:1"}]}}}},
+ {"apiVersion": "apps/v1", "kind": "Deployment", "metadata": {"name": "d2", "namespace": "default", "annotations": {"owner": "alice"}}, "spec": {"replicas": 3}},
+]
+
+
+CONTAINS = {
+    "K8sContainsStmt": 'package k\nviolation[{"msg": msg}] {\n  contains(input.review.object.metadata.name, "bad")\n  msg := "bad name"\n}\n',
+    "K8sContainsAssign": 'package k\nviolation[{"msg": msg}] {\n  x := contains(input.review.object.metadata.name, "bad")\n  x == true\n  msg := "bad name"\n}\n',
+    "K8sContainsNot": 'package k\nviolation[{"msg": msg}] {\n  not contains(input.review.object.metadata.name, "good")\n  msg := "not good"\n}\n',
+    "K8sContainsHelper": 'package k\nviolation[{"msg": msg}] {\n  bad(input.review.object.metadata.name)\n  msg := "bad name"\n}\nbad(n) {\n  contains(n, "bad")\n}\n',
+}
+
+
+def _constraint(kind, params):
+    return {"apiVersion": "constraints.gatekeeper.sh/v1beta1", "kind": kind, "metadata": {"name": kind.lower() + "-1"}, "spec": {"parameters": params}}
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_library_patterns_one_plan(backend):
+    templates = [tmpl(k, rego) for k, (rego, _) in T.items()]
+    constraints = [_constraint(k, params) for k, (_, params) in T.items()]
+    c, oc = load_both(backend, templates, constraints)
+    reviews = [D.AugmentedUnstructured(D.Unstructured(o), None, "Original") for o in OBJS]
+    n = assert_parity(c, oc, reviews, D.GATOR_EP)
+    assert n == 44   # violations of the nine objects under the sixteen constraints (counted by the oracle; pinned so that both sides cannot drift together unnoticed)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_contains_is_a_builtin_outside_rule_heads(backend):
+    templates = [tmpl(k, rego) for k, rego in CONTAINS.items()]
+    constraints = [_constraint(k, {}) for k in CONTAINS]
+    c, oc = load_both(backend, templates, constraints)
+    objs = [{"apiVersion": "v1", "kind": "Pod", "metadata": {"name": n, "namespace": "d"}} for n in ("a-bad-pod", "good-pod", "verylongname-with-bad-inside-it")]
+    reviews = [D.AugmentedUnstructured(D.Unstructured(o), None, "Original") for o in objs]
+    assert assert_parity(c, oc, reviews, D.GATOR_EP) == 8
+    got = c.ReviewBatch(reviews, D.GATOR_EP)
+    assert [sorted(r.constraint["kind"] for r in g) for g in got] == [
+        ["K8sContainsAssign", "K8sContainsHelper", "K8sContainsNot", "K8sContainsStmt"], [],
+        ["K8sContainsAssign", "K8sContainsHelper", "K8sContainsNot", "K8sContainsStmt"]]
