@@ -1,0 +1,107 @@
+"""`gator test` on the engine (gatekeeper_amd/gator.py): the harness loop of pkg/gator/test/test.go:33-176 -- all objects in
+ONE device launch -- against the oracle's serial restatement, and the three output formats of cmd/gator/test/test.go:140-245
+as far as the reference pins them: test/gator/test/test.bats (exit status :70-97,125-135; valid JSON :158-166; the YAML's
+`.[i].result.msg` :27-50,168-175 with the message of :172; `deny` / non-deny enforcement actions :187-209)."""
+import json
+
+import pytest
+import yaml
+
+from gatekeeper_amd import driver as D
+from gatekeeper_amd import gator as G
+from oracle import gator as OG
+from parity_util import make_client
+
+GT = "test/gator/test/fixtures/"
+BACKENDS = [pytest.param("hostemu", id="hostemu"), pytest.param("gpu", marks=pytest.mark.gpu, id="gpu")]
+WANT_MSG = "Container <tomcat> in your <Pod> <test-pod1> has no <readinessProbe>"     # test.bats:172
+
+
+def docs(fixtures, *paths):
+    out = []
+    for p in paths:
+        out.extend(fixtures["yaml"][GT + p]["docs"])
+    return out
+
+
+def run(backend, objs):
+    c = make_client(backend)
+    c.enforcement_points = (D.GATOR_EP,)
+    return G.test(objs, client=c)
+
+
+def okey(pair):
+    r, o = pair
+    return (r.msg, json.dumps(r.metadata, sort_keys=True), r.enforcement_action, tuple(r.scoped_enforcement_actions or ()),
+            r.constraint["kind"], r.constraint["metadata"]["name"], o.get("kind"), (o.get("metadata") or {}).get("name"))
+
+
+def gkey(g):
+    r, o = g.result, g.violating_object
+    return (r.msg, json.dumps(r.metadata, sort_keys=True), r.enforcement_action, tuple(r.scoped_enforcement_actions or ()),
+            r.constraint["kind"], r.constraint["metadata"]["name"], o.get("kind"), (o.get("metadata") or {}).get("name"))
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("manifest,status", [
+    ("manifests/with-policies/no-violations.yaml", 0), ("manifests/with-policies/with-violations.yaml", 1),
+    ("manifests/with-policies/with-violations-rego-v1.yaml", 1), ("manifests/with-policies/with-violations-and-defaults.yaml", 1),
+    # (the *-2 manifests violate only through expanded resources, pkg/expansion: out of scope -- parity with the oracle only)
+    ("manifests/with-policies/with-violations-2.yaml", None), ("manifests/with-policies/no-violations-2.yaml", None)])
+def test_results_and_exit_status(backend, fixtures, manifest, status):
+    objs = docs(fixtures, manifest)
+    got = run(backend, objs)
+    assert sorted(gkey(g) for g in got) == sorted(okey(p) for p in OG.gator_test(objs))
+    want = OG.gator_test(objs)
+    if status is None:
+        status = 1 if any(r.enforcement_action == "deny" or "deny" in (r.scoped_enforcement_actions or ()) for r, _ in want) else 0
+    assert G.exit_code(got) == status                                    # test.bats:62-97
+    assert [(g.enforcement_action, g.msg) for g in got] == sorted((g.enforcement_action, g.msg) for g in got)   # types.go:68-74
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_output_formats(backend, fixtures):
+    got = run(backend, docs(fixtures, "manifests/with-policies/with-violations.yaml"))
+    assert got and G.exit_code(got) == 1
+    # json: valid, one document per result, the framework result's fields inlined (test.bats:158-166)
+    js = json.loads(G.format_output(got, "json"))
+    assert len(js) == len(got)
+    first = js[0]
+    assert first["msg"] == WANT_MSG and first["target"] == "admission.k8s.gatekeeper.sh" and first["enforcementAction"] == "deny"
+    assert first["violatingObject"]["metadata"]["name"] == "test-pod1" and first["trace"] is None
+    assert first["constraint"]["kind"] == "K8sRequiredProbes" and "details" in first["metadata"]
+    # yaml: `.[0].result.msg` (test.bats match_yaml_msg, :168-175)
+    ys = yaml.safe_load(G.format_output(got, "yaml"))
+    assert ys[0]["result"]["msg"] == WANT_MSG and ys[0]["violatingObject"]["kind"] == "Pod"
+    # human friendly: `<apiVersion>/<kind> <ns>/<name>: ["<constraint>"] Message: "<msg>"` (cmd/gator/test/test.go:213-241)
+    text = G.format_output(got)
+    assert text.splitlines()[0] == 'v1/Pod test-pod1: ["must-have-probes"] Message: "%s"' % WANT_MSG    # (the Pod carries no namespace)
+    assert len(text.splitlines()) == len(got)
+    # nothing to report
+    none = run(backend, docs(fixtures, "manifests/with-policies/no-violations.yaml"))
+    assert none == [] and G.format_output(none) == "" and G.format_output(none, "json") == "null" and G.exit_code(none) == 0
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_enforcement_action_decides_the_status(backend, fixtures):
+    """test.bats:187-209: a `deny` constraint fails the run; another action reports the violation but exits 0, and
+    --deny-only then prints nothing"""
+    objs = docs(fixtures, "manifests/no-policies/with-violations.yaml", "policies/default/template_k8srequiredprobes.yaml")
+    deny = run(backend, objs + docs(fixtures, "policies/enforcement_action/k8srequiredprobes/deny.yaml"))
+    assert G.exit_code(deny) == 1 and WANT_MSG in G.format_output(deny)
+    foo = run(backend, objs + docs(fixtures, "policies/enforcement_action/k8srequiredprobes/foo.yaml"))
+    assert foo and G.exit_code(foo) == 0 and WANT_MSG in G.format_output(foo)
+    assert G.format_output(foo, deny_only=True) == "" and G.format_output(foo, "json", deny_only=True) == "null"
+
+
+def test_bad_inputs_are_errors():
+    """test.Test returns an error before any review: a template the driver rejects ("adding template %q"), a constraint
+    whose template is missing ("adding constraint %q", test.go:66-79; pinned for the oracle by test_test.go:135-158).  (The
+    two invalid-resources manifests of test.bats:144-155 already fail in the YAML reader -- CLI, not this path.)"""
+    bad_rego = {"apiVersion": "templates.gatekeeper.sh/v1", "kind": "ConstraintTemplate", "metadata": {"name": "k8sbad"},
+                "spec": {"crd": {"spec": {"names": {"kind": "K8sBad"}}}, "targets": [{"target": "admission.k8s.gatekeeper.sh", "rego": "package x\nviolation[{"}]}}
+    with pytest.raises(G.GatorError, match="adding template 'k8sbad'"):
+        run("hostemu", [bad_rego])
+    orphan = {"apiVersion": "constraints.gatekeeper.sh/v1beta1", "kind": "K8sNoSuchTemplate", "metadata": {"name": "orphan"}, "spec": {}}
+    with pytest.raises(G.GatorError, match="adding constraint 'orphan'"):
+        run("hostemu", [orphan])

@@ -326,3 +326,19 @@ def test_contains_is_a_builtin_outside_rule_heads(backend):
     assert [sorted(r.constraint["kind"] for r in g) for g in got] == [
         ["K8sContainsAssign", "K8sContainsHelper", "K8sContainsNot", "K8sContainsStmt"], [],
         ["K8sContainsAssign", "K8sContainsHelper", "K8sContainsNot", "K8sContainsStmt"]]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_gator_bench_fixture_pairs(backend, fixtures):
+    """test/gator/bench/{basic,both}: the reference's own benchmark inputs -- K8sRequiredLabels and K8sAllowedRepos
+    (`strings.any_prefix_match`; `both` also carries a CEL source, the Rego one is the Rego driver's) with one valid and
+    one invalid Pod each: the valid one yields nothing, the invalid one exactly one violation."""
+    want_msgs = {"basic": [[], ['Missing required labels: {"team"}']],
+                 "both": [[], ['container <app> has an invalid image repo <quay.io/unauthorized/app:latest>, allowed repos are '
+                               '["gcr.io/myproject/", "docker.io/library/"]']]}
+    for d, want in want_msgs.items():
+        y = lambda f: fixtures["yaml"]["test/gator/bench/%s/%s.yaml" % (d, f)]["docs"]
+        c, oc = load_both(backend, y("template"), y("constraint"))
+        reviews = [D.AugmentedUnstructured(D.Unstructured(o), None, "Original") for o in y("resources")]
+        assert_parity(c, oc, reviews, D.GATOR_EP)
+        assert [sorted(r.msg for r in g) for g in c.ReviewBatch(reviews, D.GATOR_EP)] == want
