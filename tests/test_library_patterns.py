@@ -292,6 +292,308 @@ OBJS = [
 ]
 
 
+# ---- a second batch: PSP AppArmor / sysctls / fsGroup / SELinux / procMount, RBAC subjects, tty / stdin, service-account
+# token mounts, deprecated APIs, `some .. in` / `every`, and two shapes the device plan REFUSES (reported, never approximated)
+T2 = {}
+T2["K8sPSPAppArmor"] = ('''package k8spspapparmor
+violation[{"msg": msg, "details": {}}] {
+  metadata := input.review.object.metadata
+  container := input_containers[_]
+  not input_apparmor_allowed(container, metadata)
+  msg := sprintf("AppArmor profile is not allowed, pod: %v, container: %v. Allowed profiles: %v", [input.review.object.metadata.name, container.name, input.parameters.allowedProfiles])
+}
+input_apparmor_allowed(container, metadata) {
+  get_annotation_for(container, metadata) == input.parameters.allowedProfiles[_]
+}
+input_containers[c] {
+  c := input.review.object.spec.containers[_]
+}
+get_annotation_for(container, metadata) = out {
+  out = metadata.annotations[sprintf("container.apparmor.security.beta.kubernetes.io/%v", [container.name])]
+}
+get_annotation_for(container, metadata) = out {
+  not metadata.annotations[sprintf("container.apparmor.security.beta.kubernetes.io/%v", [container.name])]
+  out = "runtime/default"
+}
+''', {"allowedProfiles": ["runtime/default"]})
+T2["K8sPSPForbiddenSysctls"] = ('''package k8spspforbiddensysctls
+violation[{"msg": msg, "details": {}}] {
+  sysctl := input.review.object.spec.securityContext.sysctls[_].name
+  forbidden_sysctl(sysctl)
+  msg := sprintf("The sysctl %v is not allowed, pod: %v. Forbidden sysctls: %v", [sysctl, input.review.object.metadata.name, input.parameters.forbiddenSysctls])
+}
+forbidden_sysctl(sysctl) {
+  input.parameters.forbiddenSysctls[_] == "*"
+}
+forbidden_sysctl(sysctl) {
+  input.parameters.forbiddenSysctls[_] == sysctl
+}
+forbidden_sysctl(sysctl) {
+  forbidden := input.parameters.forbiddenSysctls[_]
+  endswith(forbidden, "*")
+  startswith(sysctl, trim_suffix(forbidden, "*"))
+}
+''', {"forbiddenSysctls": ["kernel.*", "net.core.somaxconn"]})
+T2["K8sPSPFSGroup"] = ('''package k8spspfsgroup
+violation[{"msg": msg, "details": {}}] {
+  spec := input.review.object.spec
+  not input_fsGroup_allowed(spec)
+  msg := sprintf("The provided pod spec fsGroup is not allowed, pod: %v. Allowed fsGroup: %v", [input.review.object.metadata.name, input.parameters])
+}
+input_fsGroup_allowed(spec) {
+  input.parameters.rule == "RunAsAny"
+}
+input_fsGroup_allowed(spec) {
+  input.parameters.rule == "MustRunAs"
+  fg := spec.securityContext.fsGroup
+  count(input.parameters.ranges) > 0
+  range := input.parameters.ranges[_]
+  value_within_range(range, fg)
+}
+input_fsGroup_allowed(spec) {
+  input.parameters.rule == "MayRunAs"
+  not has_field(spec, "securityContext")
+}
+input_fsGroup_allowed(spec) {
+  input.parameters.rule == "MayRunAs"
+  not spec.securityContext.fsGroup
+}
+input_fsGroup_allowed(spec) {
+  input.parameters.rule == "MayRunAs"
+  fg := spec.securityContext.fsGroup
+  count(input.parameters.ranges) > 0
+  range := input.parameters.ranges[_]
+  value_within_range(range, fg)
+}
+value_within_range(range, value) {
+  range.min <= value
+  range.max >= value
+}
+has_field(object, field) = true {
+  object[field]
+}
+''', {"rule": "MayRunAs", "ranges": [{"min": 1, "max": 1000}]})
+T2["K8sPSPSELinuxV2"] = ('''package k8spspselinux
+violation[{"msg": msg, "details": {}}] {
+  has_field(input.review.object.spec, "securityContext")
+  has_field(input.review.object.spec.securityContext, "seLinuxOptions")
+  not input_seLinuxOptions_allowed(input.review.object.spec.securityContext.seLinuxOptions)
+  msg := sprintf("SELinux options is not allowed, pod: %v. Allowed options: %v", [input.review.object.metadata.name, input.parameters.allowedSELinuxOptions])
+}
+violation[{"msg": msg, "details": {}}] {
+  c := input.review.object.spec.containers[_]
+  has_field(c.securityContext, "seLinuxOptions")
+  not input_seLinuxOptions_allowed(c.securityContext.seLinuxOptions)
+  msg := sprintf("SELinux options is not allowed, pod: %v, container %v. Allowed options: %v", [input.review.object.metadata.name, c.name, input.parameters.allowedSELinuxOptions])
+}
+input_seLinuxOptions_allowed(options) {
+  params := input.parameters.allowedSELinuxOptions[_]
+  field_allowed("level", options, params)
+  field_allowed("role", options, params)
+  field_allowed("type", options, params)
+  field_allowed("user", options, params)
+}
+field_allowed(field, options, params) {
+  params[field] == options[field]
+}
+field_allowed(field, options, params) {
+  not has_field(options, field)
+}
+has_field(object, field) = true {
+  object[field]
+}
+''', {"allowedSELinuxOptions": [{"level": "s0:c123,c456", "role": "object_r", "type": "svirt_sandbox_file_t", "user": "system_u"}]})
+T2["K8sPSPProcMount"] = ('''package k8spspprocmount
+violation[{"msg": msg, "details": {}}] {
+  c := input.review.object.spec.containers[_]
+  allowedProcMount := get_allowed_proc_mount(input)
+  not input_proc_mount_type_allowed(allowedProcMount, c)
+  msg := sprintf("ProcMount type is not allowed, container: %v. Allowed procMount types: %v", [c.name, allowedProcMount])
+}
+input_proc_mount_type_allowed(allowedProcMount, c) {
+  allowedProcMount == "default"
+  lower(c.securityContext.procMount) == "default"
+}
+input_proc_mount_type_allowed(allowedProcMount, c) {
+  allowedProcMount == "unmasked"
+}
+input_proc_mount_type_allowed(allowedProcMount, c) {
+  not c.securityContext.procMount
+}
+get_allowed_proc_mount(arg) = out {
+  not arg.parameters
+  out = "default"
+}
+get_allowed_proc_mount(arg) = out {
+  not arg.parameters.procMount
+  out = "default"
+}
+get_allowed_proc_mount(arg) = out {
+  arg.parameters.procMount
+  not valid_proc_mount(arg.parameters.procMount)
+  out = "default"
+}
+get_allowed_proc_mount(arg) = out {
+  valid_proc_mount(arg.parameters.procMount)
+  out = lower(arg.parameters.procMount)
+}
+valid_proc_mount(str) {
+  lower(str) == "default"
+}
+valid_proc_mount(str) {
+  lower(str) == "unmasked"
+}
+''', {"procMount": "Default"})
+T2["K8sDisallowAnonymous"] = ('''package k8sdisallowanonymous
+violation[{"msg": msg}] {
+  not is_allowed(input.review.object.roleRef, input.parameters.allowedRoles)
+  review(input.review.object.subjects[_])
+  msg := sprintf("Unauthenticated user reference is not allowed in %v %v ", [input.review.object.kind, input.review.object.metadata.name])
+}
+is_allowed(role, allowedRoles) {
+  role.name == allowedRoles[_]
+}
+review(subject) = true {
+  subject.name == "system:unauthenticated"
+}
+review(subject) = true {
+  subject.name == "system:anonymous"
+}
+''', {"allowedRoles": ["cluster-role-1"]})
+T2["K8sDisallowInteractiveTTY"] = ('''package k8sdisallowinteractivetty
+violation[{"msg": msg, "details": {}}] {
+  c := input_containers[_]
+  input_allow_interactive_fields(c)
+  msg := sprintf("Containers using tty or stdin (%v) are not allowed running image: %v", [c.name, c.image])
+}
+input_allow_interactive_fields(c) {
+  has_field(c, "stdin")
+  not c.stdin == false
+}
+input_allow_interactive_fields(c) {
+  has_field(c, "tty")
+  not c.tty == false
+}
+input_containers[c] {
+  c := input.review.object.spec.containers[_]
+}
+input_containers[c] {
+  c := input.review.object.spec.ephemeralContainers[_]
+}
+has_field(object, field) = true {
+  object[field]
+}
+has_field(object, field) = true {
+  object[field] == false
+}
+''', {})
+T2["K8sAutomountToken"] = ('''package k8sautomountserviceaccounttoken
+violation[{"msg": msg}] {
+  obj := input.review.object
+  mountServiceAccountToken(obj.spec)
+  msg := sprintf("Automounting service account token is disallowed, pod: %v", [obj.metadata.name])
+}
+mountServiceAccountToken(spec) {
+  spec.automountServiceAccountToken == true
+}
+mountServiceAccountToken(spec) {
+  not has_key(spec, "automountServiceAccountToken")
+  "/var/run/secrets/kubernetes.io/serviceaccount" == input_containers[_].volumeMounts[_].mountPath
+}
+input_containers[c] {
+  c := input.review.object.spec.containers[_]
+}
+has_key(x, k) {
+  _ = x[k]
+}
+''', {})
+T2["K8sNoUpdateServiceAccount"] = ('''package noupdateserviceaccount
+violation[{"msg": msg}] {
+  input.review.operation == "UPDATE"
+  new := input.review.object.spec.serviceAccountName
+  old := input.review.oldObject.spec.serviceAccountName
+  new != old
+  msg := sprintf("cannot update serviceAccountName from %v to %v", [old, new])
+}
+''', {})
+T2["K8sVerifyDeprecatedAPI"] = ('''package verifydeprecatedapi
+violation[{"msg": msg}] {
+  kvs := input.parameters.kvs[_]
+  kvs.deprecatedAPI == input.review.object.apiVersion
+  k := kvs.kinds[_]
+  k == input.review.object.kind
+  msg := get_message(input.review.object.kind, input.review.object.apiVersion, input.parameters.k8sVersion, kvs.targetAPI)
+}
+get_message(kind, apiVersion, k8sVersion, targetAPI) = msg {
+  not match(targetAPI)
+  msg := sprintf("API %v for %v is deprecated in Kubernetes version %v, please use %v instead", [kind, apiVersion, k8sVersion, targetAPI])
+}
+get_message(kind, apiVersion, k8sVersion, targetAPI) = msg {
+  match(targetAPI)
+  msg := sprintf("API %v for %v is deprecated in Kubernetes version %v, please see Kubernetes API deprecation guide", [kind, apiVersion, k8sVersion])
+}
+match(api) {
+  api == "None"
+}
+''', {"kvs": [{"deprecatedAPI": "apps/v1beta1", "kinds": ["Deployment"], "targetAPI": "apps/v1"}, {"deprecatedAPI": "networking.k8s.io/v1beta1", "kinds": ["Ingress"], "targetAPI": "None"}], "k8sVersion": 1.22})
+T2["K8sBlockLoadBalancer"] = ('''package k8sblockloadbalancer
+violation[{"msg": msg}] {
+  input.review.kind.kind == "Service"
+  input.review.object.spec.type == "LoadBalancer"
+  msg := "User is not allowed to create service of type LoadBalancer"
+}
+''', {})
+T2["K8sSomeInEvery"] = ('''package k8ssomeinevery
+import future.keywords.in
+import future.keywords.every
+violation[{"msg": msg}] {
+  some c in input.review.object.spec.containers
+  not c.image in input.parameters.images
+  msg := sprintf("image %v of %v not in list", [c.image, c.name])
+}
+violation[{"msg": msg}] {
+  count(input.review.object.spec.containers) > 0
+  every c in input.review.object.spec.containers {
+    startswith(c.image, "evil.io/")
+  }
+  msg := "all containers are evil"
+}
+''', {"images": ["gcr.io/good/app:1.0", "docker.io/library/nginx"]})
+T2["K8sStringOps"] = ('''package k8sstringops
+violation[{"msg": msg}] {
+  c := input.review.object.spec.containers[_]
+  parts := split(c.image, "/")
+  count(parts) > 2
+  host := parts[0]
+  not glob.match("*.io", [], host)
+  msg := sprintf("registry %v of %v", [host, upper(c.name)])
+}
+violation[{"msg": msg}] {
+  c := input.review.object.spec.containers[_]
+  img := replace(c.image, "evil", "good")
+  img != c.image
+  n := count(c.image)
+  msg := sprintf("%v -> %v (%d bytes, tag %v)", [c.image, img, n, substring(c.image, indexof(c.image, ":"), -1)])
+}
+''', {})
+
+OBJS2 = list(OBJS)
+OBJS2 = OBJS2 + [
+ {"apiVersion": "rbac.authorization.k8s.io/v1", "kind": "ClusterRoleBinding", "metadata": {"name": "crb1"}, "roleRef": {"name": "cluster-admin"}, "subjects": [{"name": "system:anonymous"}, {"name": "bob"}]},
+ {"apiVersion": "rbac.authorization.k8s.io/v1", "kind": "ClusterRoleBinding", "metadata": {"name": "crb2"}, "roleRef": {"name": "cluster-role-1"}, "subjects": [{"name": "system:unauthenticated"}]},
+ {"apiVersion": "apps/v1beta1", "kind": "Deployment", "metadata": {"name": "old", "namespace": "default"}, "spec": {"replicas": 2}},
+ {"apiVersion": "networking.k8s.io/v1beta1", "kind": "Ingress", "metadata": {"name": "oldi", "namespace": "default"}, "spec": {}},
+ {"apiVersion": "v1", "kind": "Service", "metadata": {"name": "lb", "namespace": "default"}, "spec": {"type": "LoadBalancer"}},
+ pod("p4", [{"name": "t", "image": "evil.io/x/y:1", "tty": True, "stdin": False, "securityContext": {"procMount": "Unmasked", "seLinuxOptions": {"level": "s0:c1", "role": "object_r"}}, "volumeMounts": [{"mountPath": "/var/run/secrets/kubernetes.io/serviceaccount"}]}],
+     securityContext={"fsGroup": 2000, "sysctls": [{"name": "kernel.shm_rmid_forced"}, {"name": "net.core.somaxconn"}, {"name": "vm.swappiness"}], "seLinuxOptions": {"level": "s0:c123,c456", "role": "object_r", "type": "svirt_sandbox_file_t", "user": "system_u"}}),
+ pod("p5", [{"name": "u", "image": "quay.io/a/b/c:2"}], automountServiceAccountToken=True, securityContext={"fsGroup": 500}),
+]
+OBJS2[-2]["metadata"]["annotations"] = {"container.apparmor.security.beta.kubernetes.io/t": "unconfined"}
+UNSUPPORTED2 = {"K8sPSPAppArmor": "review data indexed by a symbolic key",                      # annotations[sprintf(.., [container.name])]
+                "K8sNoUpdateServiceAccount": "equality between two review values outside an iteration",   # object vs oldObject field
+                "K8sStringOps": "undefined function glob.match"}
+
+
 CONTAINS = {
     "K8sContainsStmt": 'package k\nviolation[{"msg": msg}] {\n  contains(input.review.object.metadata.name, "bad")\n  msg := "bad name"\n}\n',
     "K8sContainsAssign": 'package k\nviolation[{"msg": msg}] {\n  x := contains(input.review.object.metadata.name, "bad")\n  x == true\n  msg := "bad name"\n}\n',
@@ -342,3 +644,17 @@ def test_gator_bench_fixture_pairs(backend, fixtures):
         reviews = [D.AugmentedUnstructured(D.Unstructured(o), None, "Original") for o in y("resources")]
         assert_parity(c, oc, reviews, D.GATOR_EP)
         assert [sorted(r.msg for r in g) for g in c.ReviewBatch(reviews, D.GATOR_EP)] == want
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_library_patterns_second_batch(backend):
+    good = {k: v for k, v in T2.items() if k not in UNSUPPORTED2}
+    c, oc = load_both(backend, [tmpl(k, rego) for k, (rego, _) in good.items()], [_constraint(k, params) for k, (_, params) in good.items()])
+    reviews = [D.AugmentedUnstructured(D.Unstructured(o), None, "Original") for o in OBJS2]
+    assert assert_parity(c, oc, reviews, D.GATOR_EP) == 17
+    # what the engine cannot compile exactly is an ERROR at AddTemplate / AddConstraint -- the cgo shim keeps such a
+    # template on the stock driver -- never a different answer
+    for kind, why in UNSUPPORTED2.items():
+        rego, params = T2[kind]
+        with pytest.raises((D.UnsupportedError, D.ClientError, D.EngineError), match=why):
+            c2, _ = load_both(backend, [tmpl(kind, rego)], [_constraint(kind, params)])
