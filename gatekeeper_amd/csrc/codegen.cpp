@@ -137,7 +137,7 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts, const std
         target[i] = m + " |= " + u(1u << (p.bit & 31)) + ";";
       } else {
         Group& g = group_of(p);
-        if (p.op == P_STORE) { g.stores.push_back(i); g.always = true; continue; }
+        if (p.op == P_STORE) { g.stores.push_back(i); g.always = true; if (p.level >= GK_LEVEL_ROOT) g.present = true; continue; }   // root scope: a store marks its element
         if (p.op == P_PRESENT) { g.present = true; g.always = true; continue; }
         std::string m = "me" + std::to_string(p.scope) + "_" + std::to_string(p.level) + "_" + std::to_string(elem_word_of_bit(p.bit));
         declare(m, g.masks);
@@ -216,7 +216,7 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts, const std
         o << "          }\n";
       }
       if (g.present) {
-        if (g.level > 0) extra += " | 1u | (row_ordinal(r, " + std::to_string(g.level - 1) + "u) << 24)";
+        if (g.level > 0 && g.level < (int)GK_LEVEL_ROOT) extra += " | 1u | (row_ordinal(r, " + std::to_string(g.level - 1) + "u) << 24)";
         else extra += " | 1u";
         o << "          acc.max_word(" << sc.count_off << "u, ord + 1u);\n";
       }

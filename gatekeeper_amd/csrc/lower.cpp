@@ -759,6 +759,22 @@ struct Lowerer {
     return id;
   }
 
+  // the one-element scope of review values that are compared with each other outside any iteration
+  uint32_t root_scope() {
+    auto it = scope_ids.find("$root");
+    if (it != scope_ids.end()) return it->second;
+    if (scope_patterns.size() >= GK_MAX_SCOPES) unsupported("too many element scopes");
+    uint32_t id = (uint32_t)scope_patterns.size();
+    scope_ids["$root"] = id;
+    scope_patterns.push_back(Pattern());
+    scope_level.push_back((int)GK_LEVEL_ROOT);
+    elem_bits.emplace_back();
+    val_slots.emplace_back();
+    derived_elem.emplace_back();
+    scope_nbits.push_back(1);
+    return id;   // (no P_PRESENT predicate: a stored value marks the element, vm_core.hpp / codegen.cpp)
+  }
+
   // innermost looped quantifier of a path: index of its ITER step, or -1
   int last_looped(const SPath& p) {
     for (int i = (int)p.size() - 1; i >= 0; i--) if (p[i].iter && looped.count(p[i].q)) return i;
@@ -772,11 +788,13 @@ struct Lowerer {
     if (a.kind == Atom::VEQ) {
       uint32_t sc[2], slot[2];
       const SPath* ps[2] = {&a.path, &a.path2};
+      bool root_side = false;
       for (int k = 0; k < 2; k++) {
         int li = last_looped(*ps[k]);
-        if (li < 0) unsupported("equality between two review values outside an iteration");
         for (size_t j = li + 1; j < ps[k]->size(); j++) if ((*ps[k])[j].iter) unsupported("join on a nested iteration");
-        sc[k] = looped[(*ps[k])[li].q];
+        // a value outside every iteration lives in the ROOT scope (one element per review)
+        if (li < 0) { sc[k] = root_scope(); root_side = true; }
+        else sc[k] = looped[(*ps[k])[li].q];
         Pattern pat = pattern_of(*ps[k]);
         std::string key = pattern_to_string(pat);
         auto it = val_slots[sc[k]].find(key);
@@ -789,6 +807,15 @@ struct Lowerer {
           plan.preds.push_back(p);
           plan.pred_patterns.push_back(pat);
         } else slot[k] = it->second;
+      }
+      if (root_side) {   // the comparison runs inside the (single-trip) loop over the root scope
+        int acc = alloc();
+        emit(finst(F_LOOP, root_scope(), 0, acc));
+        emit(finst(F_VEQ, r));
+        emit(sc[0] | (slot[0] << 8) | (sc[1] << 16) | (slot[1] << 24));
+        emit(finst(F_ENDLOOP, acc, r));
+        release(r);
+        return acc;
       }
       emit(finst(F_VEQ, r));
       emit(sc[0] | (slot[0] << 8) | (sc[1] << 16) | (slot[1] << 24));
@@ -1229,7 +1256,7 @@ HostPlan PlanBuilder::build(const PlanCaps& caps) {
     Scope sc{};
     uint32_t nb = L.scope_nbits[s];
     sc.wpe = (uint8_t)(nb <= ELEM_W0_BITS ? 1 : 1 + (nb - ELEM_W0_BITS + 31) / 32);
-    sc.cap = s < caps.scope_cap.size() && caps.scope_cap[s] ? caps.scope_cap[s] : caps.level_cap[L.scope_level[s]];
+    sc.cap = L.scope_level[s] >= (int)GK_LEVEL_ROOT ? 1 : s < caps.scope_cap.size() && caps.scope_cap[s] ? caps.scope_cap[s] : caps.level_cap[L.scope_level[s]];
     sc.nvals = (uint8_t)L.val_slots[s].size();
     sc.count_off = off++;
     sc.word_off = off;

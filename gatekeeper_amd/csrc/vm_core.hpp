@@ -42,7 +42,7 @@ struct PlanView {
 };
 
 GK_HD uint32_t row_type(const Row& r) { return r.meta & ROW_TYPE_MASK; }
-GK_HD uint32_t row_ordinal(const Row& r, uint32_t level) { return (r.meta >> (ROW_E_SHIFT0 + 8 * level)) & ROW_E_MASK; }
+GK_HD uint32_t row_ordinal(const Row& r, uint32_t level) { return level >= GK_LEVEL_ROOT ? 0u : (r.meta >> (ROW_E_SHIFT0 + 8 * level)) & ROW_E_MASK; }
 GK_HD uint32_t ld32(const uint8_t* p) { return *reinterpret_cast<const uint32_t*>(p); }
 GK_HD int64_t row_i64(const Row& r) { return (int64_t)(((uint64_t)r.hi << 32) | r.lo); }
 GK_HD double bits_f64(uint64_t b) { return __builtin_bit_cast(double, b); }
@@ -386,6 +386,7 @@ GK_HD void eval_row_ent(const Row& r, uint32_t row_index, uint32_t ent, const St
     if (p.op == P_STORE) {
       // value slot: the row's 64-bit payload; the element's type word gets a nibble (type + 1 | inline << 3)
       uint32_t vb = sc.val_off + ord * val_stride(sc.nvals);
+      if (p.level >= GK_LEVEL_ROOT) { acc.max_word(sc.count_off, 1u); acc.or_word(sc.word_off, 1u); }   // the root scope's element exists once a value is stored
       acc.store_word(vb + p.bit * 2u, r.lo);
       acc.store_word(vb + p.bit * 2u + 1u, r.hi);
       if (sc.nvals == 1) acc.or_word(sc.word_off + ord * wpe, val_nibble(r) << ELEM_NIBBLE_SHIFT);

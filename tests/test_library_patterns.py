@@ -293,7 +293,8 @@ OBJS = [
 
 
 # ---- a second batch: PSP AppArmor / sysctls / fsGroup / SELinux / procMount, RBAC subjects, tty / stdin, service-account
-# token mounts, deprecated APIs, `some .. in` / `every`, and two shapes the device plan REFUSES (reported, never approximated)
+# token mounts, service-account updates (object vs oldObject: tests/test_root_scope.py exercises it with UPDATE requests),
+# deprecated APIs, `some .. in` / `every`, and two shapes the device plan REFUSES (reported, never approximated)
 T2 = {}
 T2["K8sPSPAppArmor"] = ('''package k8spspapparmor
 violation[{"msg": msg, "details": {}}] {
@@ -590,7 +591,6 @@ OBJS2 = OBJS2 + [
 ]
 OBJS2[-2]["metadata"]["annotations"] = {"container.apparmor.security.beta.kubernetes.io/t": "unconfined"}
 UNSUPPORTED2 = {"K8sPSPAppArmor": "review data indexed by a symbolic key",                      # annotations[sprintf(.., [container.name])]
-                "K8sNoUpdateServiceAccount": "equality between two review values outside an iteration",   # object vs oldObject field
                 "K8sStringOps": "undefined function glob.match"}
 
 

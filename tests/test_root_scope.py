@@ -1,0 +1,87 @@
+"""Review values compared with EACH OTHER outside any iteration -- the shape of the "immutable field" policies
+(`input.review.object.spec.serviceAccountName != input.review.oldObject.spec.serviceAccountName`, the public library's
+noupdateserviceaccount), `name == namespace`, and an array element against a value outside its array.  The plan keeps such
+values in a one-element ROOT scope (plan.hpp GK_LEVEL_ROOT: a stored value marks the element; the comparison runs inside
+the scope's single-trip loop), so they use the same value slots and the same val_eq as joins between array elements:
+short and long strings, numbers (3 == 3.0, 3 != "3"), a side that is missing (undefined, not "different")."""
+import pytest
+
+from gatekeeper_amd import driver as D
+from parity_util import BACKENDS, assert_parity, load_both
+
+
+def tmpl(kind, rego):
+    return {"apiVersion": "templates.gatekeeper.sh/v1", "kind": "ConstraintTemplate", "metadata": {"name": kind.lower()},
+            "spec": {"crd": {"spec": {"names": {"kind": kind}}}, "targets": [{"target": "admission.k8s.gatekeeper.sh", "rego": rego}]}}
+T = {
+ "K8sNoUpdateSA": '''package noupdateserviceaccount
+violation[{"msg": msg}] {
+  input.review.operation == "UPDATE"
+  new := input.review.object.spec.serviceAccountName
+  old := input.review.oldObject.spec.serviceAccountName
+  new != old
+  msg := sprintf("cannot update serviceAccountName from %v to %v", [old, new])
+}
+''',
+ "K8sNameIsNamespace": '''package k
+violation[{"msg": msg}] {
+  input.review.object.metadata.name == input.review.object.metadata.namespace
+  msg := sprintf("name %v equals its namespace", [input.review.object.metadata.name])
+}
+''',
+ "K8sContainerNamedLikePod": '''package k
+violation[{"msg": msg}] {
+  c := input.review.object.spec.containers[_]
+  c.name == input.review.object.metadata.name
+  msg := sprintf("container %v is named like the pod", [c.name])
+}
+''',
+ "K8sImmutableReplicasAndImage": '''package k
+violation[{"msg": msg}] {
+  input.review.oldObject.spec.replicas != input.review.object.spec.replicas
+  msg := "replicas changed"
+}
+violation[{"msg": msg}] {
+  not input.review.oldObject.spec.paused == input.review.object.spec.paused
+  input.review.oldObject
+  msg := "paused differs or is missing"
+}
+''',
+}
+def pod(name, ns, sa=None, containers=("a",), **spec):
+    s = {"containers": [{"name": c, "image": "x"} for c in containers]}
+    if sa is not None: s["serviceAccountName"] = sa
+    s.update(spec)
+    return {"apiVersion": "v1", "kind": "Pod", "metadata": {"name": name, "namespace": ns}, "spec": s}
+def req(op, obj, old=None):
+    r = {"uid": "u", "kind": {"group": "", "version": "v1", "kind": "Pod"}, "operation": op, "name": obj["metadata"]["name"], "namespace": obj["metadata"]["namespace"],
+         "userInfo": {"username": "bob"}, "object": obj}
+    if old is not None: r["oldObject"] = old
+    return D.AugmentedReview(D.AdmissionRequest(r), None, "Original")
+reviews = [
+ req("UPDATE", pod("p", "d", "sa2"), pod("p", "d", "sa1")),
+ req("UPDATE", pod("p", "d", "sa1"), pod("p", "d", "sa1")),
+ req("UPDATE", pod("p", "d", "a-service-account-with-a-long-name-2"), pod("p", "d", "a-service-account-with-a-long-name-1")),
+ req("UPDATE", pod("p", "d", "a-service-account-with-a-long-name-1"), pod("p", "d", "a-service-account-with-a-long-name-1")),
+ req("UPDATE", pod("p", "d", "sa1"), pod("p", "d")),
+ req("UPDATE", pod("p", "d"), pod("p", "d", "sa1")),
+ req("CREATE", pod("p", "d", "sa2")),
+ req("UPDATE", pod("same", "same", "x", containers=("same", "b")), pod("same", "same", "x")),
+ req("UPDATE", pod("q", "d", "x", containers=("q",), replicas=3, paused=True), pod("q", "d", "x", replicas=2, paused=True)),
+ req("UPDATE", pod("q", "d", "x", replicas=3, paused=False), pod("q", "d", "x", replicas=3.0, paused=True)),
+ req("UPDATE", pod("q", "d", "x", replicas=3), pod("q", "d", "x", replicas="3")),
+ D.AugmentedUnstructured(D.Unstructured(pod("plain", "plain", "x", containers=("plain",))), None, "Original"),
+]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_values_compared_outside_iterations(backend):
+    c, oc = load_both(backend, [tmpl(k, r) for k, r in T.items()],
+                      [{"apiVersion": "constraints.gatekeeper.sh/v1beta1", "kind": k, "metadata": {"name": "x"}, "spec": {}} for k in T])
+    assert assert_parity(c, oc, reviews, D.GATOR_EP) == 20
+    got = c.ReviewBatch(reviews, D.GATOR_EP)
+    sa = [[r.msg for r in g if r.constraint["kind"] == "K8sNoUpdateSA"] for g in got]
+    assert sa[0] == ["cannot update serviceAccountName from sa1 to sa2"] and sa[1] == [] and len(sa[2]) == 1 and sa[3] == []
+    assert sa[4] == sa[5] == sa[6] == []          # a missing side is undefined, CREATE is not UPDATE
+    rep = [any(r.msg == "replicas changed" for r in g) for g in got]
+    assert rep[8] and not rep[9] and rep[10]      # 2 -> 3; 3.0 == 3; "3" != 3
