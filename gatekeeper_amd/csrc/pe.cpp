@@ -1376,7 +1376,38 @@ class PE {
         out.push_back({a[2], s});
         return;
       }
+      if (a[0]->kind == SV::PATH && a[1]->kind == SV::CONST && a[1]->c.is_array()) {   // object.get(obj, ["a", "b"], default): the value at the path, else the default
+        SPath p = a[0]->path;
+        bool keys_ok = true;
+        for (auto& k : a[1]->c.items()) { if (!k.is_string()) { keys_ok = false; break; } Step st; st.key = k.str(); p.push_back(st); }
+        if (keys_ok) {
+          if (a[1]->c.size() == 0) { out.push_back({a[0], s}); return; }
+          FP d = f_atom(atom_path(Atom::DEFINED, p));
+          State s1 = s; s1.conds.push_back(d);
+          out.push_back({sv_path(p), s1});
+          State s2 = s; s2.conds.push_back(f_and(f_type(a[0]->path, M_OBJECT), f_not(d)));
+          out.push_back({a[2], s2});
+          return;
+        }
+      }
       unsupported("object.get with these operands on review data", line);
+    }
+    if (name == "type_name") {   // total on defined operands; the result is only good for messages (comparing it is refused where it is compared)
+      need(1);
+      SV o; o.kind = SV::OPAQUE; o.f = defined_f(a[0]);
+      out.push_back({mksv(o), s});
+      return;
+    }
+    if (name == "concat" && a.size() == 2 && a[0]->kind == SV::CONST && a[0]->c.is_string() && a[1]->kind == SV::ARR && a[1]->gens.empty()) {
+      // concat(sep, [x, y, ..]) over an array literal: defined iff every element is a string; an opaque string otherwise
+      FP d = f_true();
+      bool plain = true;
+      for (auto& e : a[1]->elems) { if (e.cond && e.cond->kind != FNode::T) { plain = false; break; } d = f_and(d, is_string_f(e.v)); }
+      if (plain) {
+        SV o; o.kind = SV::OPAQUE; o.f = d;
+        out.push_back({mksv(o), s});
+        return;
+      }
     }
     {   // a scalar builtin whose symbolic operands all derive from ONE leaf: an expression of that leaf.  Only builtins
         // that look at nothing but a scalar's value or a container's size: the flattener evaluates the expression on the

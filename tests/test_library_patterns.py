@@ -658,3 +658,149 @@ def test_library_patterns_second_batch(backend):
         rego, params = T2[kind]
         with pytest.raises((D.UnsupportedError, D.ClientError, D.EngineError), match=why):
             c2, _ = load_both(backend, [tmpl(kind, rego)], [_constraint(kind, params)])
+
+
+# ---- a third batch: userInfo / namespaceObject, object.get with a key path, set algebra, type tests, arithmetic, default /
+# else rules, string builtins in messages, nested parameters -- bare objects AND AdmissionRequests; three shapes are refused
+T3 = {}
+T3["K8sUserInfo"] = ('''package k
+violation[{"msg": msg}] {
+  input.review.userInfo.groups[_] == "system:masters"
+  not startswith(input.review.userInfo.username, "system:")
+  msg := sprintf("user %v may not act as cluster admin on %v", [input.review.userInfo.username, input.review.object.metadata.name])
+}
+''', {})
+T3["K8sNamespaceObjectLabels"] = ('''package k
+violation[{"msg": msg}] {
+  input.review.namespaceObject.metadata.labels.env == "prod"
+  not input.review.object.metadata.labels.owner
+  msg := sprintf("objects in prod namespace %v need an owner label", [input.review.namespaceObject.metadata.name])
+}
+''', {})
+T3["K8sObjectGetPath"] = ('''package k
+violation[{"msg": msg}] {
+  policy := object.get(input.review.object, ["spec", "dnsPolicy"], "ClusterFirst")
+  not allowed(policy)
+  msg := sprintf("dnsPolicy %v is not allowed", [policy])
+}
+allowed(p) { p == input.parameters.allowed[_] }
+''', {"allowed": ["ClusterFirst", "Default"]})
+T3["K8sSetOps"] = ('''package k
+violation[{"msg": msg, "details": {"extra": extra, "common": common}}] {
+  have := {l | input.review.object.metadata.labels[l]}
+  allowed := {l | l := input.parameters.allowed[_]}
+  required := {l | l := input.parameters.required[_]}
+  extra := have - (allowed | required)
+  common := have & required
+  count(extra) > 0
+  msg := sprintf("labels %v are not allowed (%d required present)", [extra, count(common)])
+}
+''', {"allowed": ["app", "owner"], "required": ["team"]})
+T3["K8sTypeChecks"] = ('''package k
+violation[{"msg": msg}] {
+  v := input.review.object.spec.replicas
+  not is_number(v)
+  msg := sprintf("replicas must be a number, got %v", [type_name(v)])
+}
+violation[{"msg": msg}] {
+  is_string(input.review.object.spec.hostNetwork)
+  msg := "hostNetwork must be boolean"
+}
+''', {})
+T3["K8sArithmetic"] = ('''package k
+violation[{"msg": msg}] {
+  r := input.review.object.spec.replicas
+  r * 2 > input.parameters.max + 1
+  r % 2 == 1
+  msg := sprintf("%d replicas: too many and odd (limit %v)", [r, (input.parameters.max + 1) / 2])
+}
+''', {"max": 5})
+T3["K8sCountAndSum"] = ('''package k
+violation[{"msg": msg}] {
+  ports := [p | p := input.review.object.spec.containers[_].ports[_].containerPort]
+  count(ports) > input.parameters.maxPorts
+  msg := sprintf("%d ports exposed (sum %d, max %d), more than %d", [count(ports), sum(ports), max(ports), input.parameters.maxPorts])
+}
+''', {"maxPorts": 1})
+T3["K8sElseAndDefault"] = ('''package k
+default tier = "none"
+tier = "gold" { input.review.object.metadata.labels.tier == "gold" }
+tier = "silver" { input.review.object.metadata.labels.tier == "silver" }
+limit = 10 { tier == "gold" } else = 5 { tier == "silver" } else = 1
+violation[{"msg": msg}] {
+  count(input.review.object.spec.containers) > limit
+  msg := sprintf("tier %v allows %d containers", [tier, limit])
+}
+''', {})
+T3["K8sStringBuiltins"] = ('''package k
+violation[{"msg": msg}] {
+  n := input.review.object.metadata.name
+  trim_prefix(n, "tmp-") != n
+  msg := sprintf("%s (%q) is a temporary name; use %v", [upper(n), n, concat("-", ["perm", trim_prefix(n, "tmp-")])])
+}
+violation[{"msg": msg}] {
+  img := input.review.object.spec.containers[_].image
+  strings.any_suffix_match(img, input.parameters.badSuffixes)
+  msg := sprintf("image %v has a forbidden suffix", [img])
+}
+''', {"badSuffixes": [":latest", ":dev"]})
+T3["K8sObjectComprehension"] = ('''package k
+violation[{"msg": msg, "details": {"limits": limits}}] {
+  limits := {c.name: c.resources.limits.cpu | c := input.review.object.spec.containers[_]; c.resources.limits.cpu}
+  count(limits) < count(input.review.object.spec.containers)
+  msg := sprintf("only %d of %d containers have cpu limits", [count(limits), count(input.review.object.spec.containers)])
+}
+''', {})
+T3["K8sRegexAndSplit"] = ('''package k
+violation[{"msg": msg}] {
+  c := input.review.object.spec.containers[_]
+  parts := split(c.image, ":")
+  count(parts) == 2
+  not regex.match("^v?[0-9]+\\\\.[0-9]+(\\\\.[0-9]+)?$", parts[1])
+  msg := sprintf("tag %v of %v is not a version", [parts[1], parts[0]])
+}
+''', {})
+T3["K8sNestedParams"] = ('''package k
+violation[{"msg": msg}] {
+  rule := input.parameters.rules[_]
+  rule.kind == input.review.object.kind
+  lbl := rule.labels[_]
+  not input.review.object.metadata.labels[lbl.key]
+  msg := sprintf("%v needs label %v (%v)", [rule.kind, lbl.key, lbl.why])
+}
+''', {"rules": [{"kind": "Pod", "labels": [{"key": "app", "why": "routing"}, {"key": "team", "why": "billing"}]}, {"kind": "Service", "labels": [{"key": "app", "why": "routing"}]}]})
+def pod3(name, containers, labels=None, **spec):
+    s = {"containers": containers}; s.update(spec)
+    md = {"name": name, "namespace": "default"}
+    if labels is not None: md["labels"] = labels
+    return {"apiVersion": "v1", "kind": "Pod", "metadata": md, "spec": s}
+nsobj = {"apiVersion": "v1", "kind": "Namespace", "metadata": {"name": "default", "labels": {"env": "prod"}}}
+OBJ3 = [
+ pod3("tmp-job", [{"name": "a", "image": "r/a:latest", "ports": [{"containerPort": 80}, {"containerPort": 443}], "resources": {"limits": {"cpu": "1"}}}, {"name": "b", "image": "r/b:v1.2.3", "ports": [{"containerPort": 8080}]}], {"app": "x", "foo": "bar", "team": "t", "tier": "silver"}, dnsPolicy="None", replicas=7),
+ pod3("web", [{"name": "a", "image": "r/a:1.0"}], {"owner": "me", "tier": "gold"}, replicas="3", hostNetwork="true"),
+ pod3("solo", [{"name": "a", "image": "r/a:dev"}, {"name": "b", "image": "r/b"}], None, replicas=4),
+ {"apiVersion": "v1", "kind": "Service", "metadata": {"name": "svc", "namespace": "default", "labels": {"zzz": "1"}}, "spec": {}},
+]
+def reviews3(wrap):
+    out = []
+    for o in OBJ3:
+        out.append(wrap.AugmentedUnstructured(wrap.Unstructured(o), nsobj, "Original"))
+        req = {"uid": "u", "kind": {"group": "", "version": "v1", "kind": o["kind"]}, "operation": "CREATE", "name": o["metadata"]["name"], "namespace": "default",
+               "userInfo": {"username": "alice", "groups": ["dev", "system:masters"]}, "object": o}
+        out.append(wrap.AugmentedReview(wrap.AdmissionRequest(req), nsobj, "Original"))
+    return out
+UNSUPPORTED3 = {"K8sCountAndSum": "count\\(\\) of a set built from review data compared with a constant other than 0",
+                "K8sObjectComprehension": "object comprehension over review data",
+                "K8sRegexAndSplit": "regex.match with these symbolic operands"}
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_library_patterns_third_batch(backend):
+    good = {k: v for k, v in T3.items() if k not in UNSUPPORTED3}
+    c, oc = load_both(backend, [tmpl(k, rego) for k, (rego, _) in good.items()], [_constraint(k, params) for k, (_, params) in good.items()])
+    rv = reviews3(D)
+    assert assert_parity(c, oc, rv, D.GATOR_EP, namespaces=[nsobj] * len(rv)) == 42
+    for kind, why in UNSUPPORTED3.items():
+        rego, params = T3[kind]
+        with pytest.raises((D.UnsupportedError, D.ClientError, D.EngineError), match=why):
+            load_both(backend, [tmpl(kind, rego)], [_constraint(kind, params)])
