@@ -1,0 +1,183 @@
+"""Seeded differential test of the POLICY COMPILER (Rego parser -> partial evaluator -> lowering -> plan / generated
+source): random templates from a grammar of the constructs gatekeeper policies are made of -- helper rules with several
+bodies and negated calls, array and nested-array iteration, key iteration, comprehensions with set difference against
+parameters, comparisons with constants / parameters / parameter arrays, string and type builtins, arithmetic, object.get,
+messages built from review values -- over random objects whose members have random (also wrong) types.  The product,
+through the C ABI on the test-only CPU build (bytecode interpreter and generated plan source), must either agree with
+the oracle's tree-walking interpreter on every object or refuse the template (GK_ERR_UNSUPPORTED); a different answer
+is a bug.  Device execution of plans is covered by the gpu-marked parity tests; this one is about what the compiler
+makes of Rego, so it runs on the CPU builds only."""
+import json
+import random
+
+import pytest
+
+from gatekeeper_amd import driver as D
+from oracle import client as OC
+from oracle import target as OT
+from parity_util import make_client
+
+KEYS = ["a", "b", "c"]
+CONSTS = ['"x"', '"yy"', '"a-long-string-constant"', "1", "2", "true", "false", '""', "0"]
+STRS = ['"x"', '"y"', '"a-"', '"long-string-constant"']
+
+def scalar_path(rng, base="input.review.object"):
+    return base + "".join("." + rng.choice(KEYS) for _ in range(rng.randint(1, 2)))
+
+def elem_ctx(rng):
+    # an iteration: (statement binding e, element var)
+    arr = "input.review.object." + rng.choice(["items", "spec.items", "list"])
+    return "e := %s[_]" % arr, "e"
+
+def cond(rng, var=None):
+    p = (var + "." + rng.choice(KEYS)) if var and rng.random() < 0.7 else scalar_path(rng)
+    k = rng.randint(0, 11)
+    if k == 0: return "%s == %s" % (p, rng.choice(CONSTS))
+    if k == 1: return "%s != %s" % (p, rng.choice(CONSTS))
+    if k == 2: return "not %s" % p
+    if k == 3: return p
+    if k == 4: return "startswith(%s, %s)" % (p, rng.choice(STRS))
+    if k == 5: return "endswith(%s, %s)" % (p, rng.choice(STRS))
+    if k == 6: return "contains(%s, %s)" % (p, rng.choice(STRS))
+    if k == 7: return "%s %s %d" % (p, rng.choice(["<", "<=", ">", ">="]), rng.randint(0, 3))
+    if k == 8: return "%s(%s)" % (rng.choice(["is_string", "is_number", "is_boolean", "is_array", "is_object", "is_null"]), p)
+    if k == 9: return "count(%s) %s %d" % (p, rng.choice(["==", ">", "<"]), rng.randint(0, 2))
+    if k == 10: return "not %s == %s" % (p, rng.choice(CONSTS))
+    return "%s == input.parameters.%s" % (p, rng.choice(["p", "q"]))
+
+def cond2(rng, var=None):
+    p = (var + "." + rng.choice(KEYS)) if var and rng.random() < 0.7 else scalar_path(rng)
+    k = rng.randint(0, 11)
+    if k == 0: return "%s == input.parameters.allowed[_]" % p
+    if k == 1: return "lower(%s) == %s" % (p, rng.choice(STRS))
+    if k == 2: return "object.get(%s, \"%s\", %s) == %s" % (p.rsplit(".", 1)[0], p.rsplit(".", 1)[1], rng.choice(CONSTS), rng.choice(CONSTS))
+    if k == 3: return "%s + 1 > %d" % (p, rng.randint(0, 3))
+    if k == 4: return "trim_prefix(%s, \"a-\") != %s" % (p, p)
+    if k == 5: return "v%d := %s; v%d != %s" % (rng.randint(0, 9), p, 0, rng.choice(CONSTS))
+    if k == 6: return "%s[_] == %s" % (p, rng.choice(CONSTS))
+    if k == 7: return "%s[kk] == %s" % (p, rng.choice(CONSTS))
+    if k == 8: return "not %s[_] == %s" % (p, rng.choice(CONSTS))
+    if k == 9: return "count({z | z := %s[_]; z != %s}) > 0" % (p, rng.choice(CONSTS))
+    if k == 10: return "re_match(\"^[a-z]+-\", %s)" % p
+    return "%s.%s.%s" % (p, rng.choice(KEYS), rng.choice(KEYS))
+
+def body(rng, helpers):
+    stmts = []
+    var = None
+    if rng.random() < 0.6:
+        st, var = elem_ctx(rng); stmts.append(st)
+        if rng.random() < 0.3:
+            stmts.append("f := %s.%s[_]" % (var, rng.choice(["sub", "a"]))); 
+            if rng.random() < 0.5: var = "f"
+    for _ in range(rng.randint(1, 3)):
+        r = rng.random()
+        if helpers and r < 0.25:
+            h = rng.choice(helpers)
+            arg = var if var and rng.random() < 0.6 else "input.review.object"
+            stmts.append(("not " if rng.random() < 0.5 else "") + "%s(%s)" % (h, arg))
+        elif r < 0.35:
+            src = "input.review.object." + rng.choice(["items", "list"])
+            stmts.append("s%d := {x | x := %s[_].%s}" % (len(stmts), src, rng.choice(KEYS)))
+            stmts.append("count(s%d - {y | y := input.parameters.allowed[_]}) %s 0" % (len(stmts) - 1, rng.choice([">", "=="])))
+        elif r < 0.6:
+            c2 = cond2(rng, var)
+            if c2.startswith("v") and ":=" in c2:
+                nm = "w%d" % len(stmts); c2 = c2.replace(c2.split(" ")[0], nm, 1); c2 = c2.split(";")[0] + "; " + nm + " != " + rng.choice(CONSTS)
+            stmts.append(c2)
+        else:
+            stmts.append(cond(rng, var))
+    vals = [scalar_path(rng)] if rng.random() < 0.5 else []
+    if var: vals.append(var + "." + rng.choice(KEYS))
+    if vals and rng.random() < 0.8:
+        stmts.append('msg := sprintf("m%d %s", [%s])' % (rng.randint(0, 9), " ".join(["%v"] * len(vals)), ", ".join(vals)))
+    else:
+        stmts.append('msg := "m%d"' % rng.randint(0, 9))
+    return stmts
+
+def template(rng, i):
+    helpers = []
+    text = ["package k%d" % i]
+    for h in range(rng.randint(0, 2)):
+        name = "h%d" % h
+        for _ in range(rng.randint(1, 2)):
+            conds = []
+            for _ in range(rng.randint(1, 2)):
+                conds.append(cond(rng, "o"))
+            text.append("%s(o) {\n  %s\n}" % (name, "\n  ".join(conds)))
+        helpers.append(name)
+    for _ in range(rng.randint(1, 2)):
+        text.append('violation[{"msg": msg}] {\n  %s\n}' % "\n  ".join(body(rng, helpers)))
+    return "\n".join(text) + "\n"
+
+def rand_value(rng, depth=0):
+    r = rng.random()
+    if depth < 2 and r < 0.25:
+        return {k: rand_value(rng, depth + 1) for k in rng.sample(KEYS, rng.randint(0, 3))}
+    if depth < 2 and r < 0.35:
+        return [rand_value(rng, depth + 1) for _ in range(rng.randint(0, 3))]
+    return rng.choice(["x", "yy", "a-long-string-constant", "a-x", "", 0, 1, 2, 3, 1.5, True, False, None, "long-string-constant-a-"])
+
+def rand_obj(rng, n):
+    o = {"apiVersion": "v1", "kind": "Pod", "metadata": {"name": "o%d" % n, "namespace": "d"}}
+    for k in KEYS:
+        if rng.random() < 0.8: o[k] = rand_value(rng)
+    for arr in ("items", "list"):
+        if rng.random() < 0.8:
+            def el():
+                e = {k: rand_value(rng, 1) for k in rng.sample(KEYS, rng.randint(0, 3))}
+                if rng.random() < 0.5: e["sub"] = [{k: rand_value(rng, 2) for k in rng.sample(KEYS, rng.randint(0, 2))} for _ in range(rng.randint(0, 3))]
+                return e
+            o[arr] = [(el() if rng.random() < 0.85 else rand_value(rng, 1)) for _ in range(rng.randint(0, 4))] if rng.random() < 0.9 else rand_value(rng, 1)
+    if rng.random() < 0.6:
+        o["spec"] = {"items": [{k: rand_value(rng, 1) for k in rng.sample(KEYS, rng.randint(0, 3))} for _ in range(rng.randint(0, 3))]}
+    return o
+
+def tmpl(kind, rego):
+    return {"apiVersion": "templates.gatekeeper.sh/v1", "kind": "ConstraintTemplate", "metadata": {"name": kind.lower()},
+            "spec": {"crd": {"spec": {"names": {"kind": kind}}}, "targets": [{"target": "admission.k8s.gatekeeper.sh", "rego": rego}]}}
+
+def run(backend, seed, n_templates, n_objs, verbose=False):
+    rng = random.Random(seed)
+    objs = [rand_obj(rng, i) for i in range(n_objs)]
+    stats = {"ok": 0, "unsupported": 0, "diff": 0, "oracle_err": 0, "product_err": 0}
+    diffs = []
+    for i in range(n_templates):
+        rego = template(rng, i)
+        kind = "K8sFuzz%d" % i
+        params = {"p": rng.choice(["x", 1, True]), "q": rng.choice(["yy", 2]), "allowed": rng.sample(["x", "yy", 1, 2, True], 2)}
+        k = {"apiVersion": "constraints.gatekeeper.sh/v1beta1", "kind": kind, "metadata": {"name": "c"}, "spec": {"parameters": params}}
+        try:
+            oc = OC.Client(); oc.add_template(tmpl(kind, rego)); oc.add_constraint(k)
+            want = [sorted(r.msg for r in oc.review(OT.AugmentedUnstructured(OT.Unstructured(o), None, "Original"), OC.GATOR_EP)) for o in objs]
+        except Exception as e:
+            stats["oracle_err"] += 1
+            if verbose: print("ORACLE ERR", e, "\n", rego)
+            continue
+        try:
+            c = make_client(backend); c.AddTemplate(tmpl(kind, rego)); c.AddConstraint(k)
+        except D.UnsupportedError as e:
+            stats["unsupported"] += 1
+            if verbose: print("UNSUPPORTED", str(e)[:100])
+            continue
+        except Exception as e:
+            stats["product_err"] += 1; diffs.append(("ERR " + str(e)[:200], rego)); continue
+        got = []
+        res = c.ReviewBatch([D.AugmentedUnstructured(D.Unstructured(o), None, "Original") for o in objs], D.GATOR_EP)
+        refused = False
+        for g in res:
+            if isinstance(g, Exception):
+                refused = True; got.append("REFUSED")
+            else: got.append(sorted(r.msg for r in g))
+        bad = [(j, got[j], want[j]) for j in range(n_objs) if got[j] != "REFUSED" and got[j] != want[j]]
+        if bad:
+            stats["diff"] += 1; diffs.append((bad[:2], rego, [objs[b[0]] for b in bad[:2]]))
+        else: stats["ok"] += 1
+    return stats, diffs
+
+
+@pytest.mark.parametrize("backend", ["hostemu", "hostemu-gen"])
+@pytest.mark.parametrize("seed", [11, 12])
+def test_random_templates_agree_with_the_oracle(backend, seed):
+    stats, diffs = run(backend, seed, 70, 14)
+    assert not diffs, "product and oracle disagree:\n%s" % "\n-----\n".join("%s\n%s" % (d[0], d[1]) for d in diffs[:3])
+    assert stats["oracle_err"] == 0 and stats["ok"] >= 60, stats      # the grammar stays inside what both sides implement
