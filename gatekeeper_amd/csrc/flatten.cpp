@@ -98,12 +98,40 @@ bool pattern_matches(const Pattern& pat, const PathDict& dict, uint32_t id) {
   return true;
 }
 
-uint32_t DictRegistry::intern(const Pattern& leaf, const DX& dx) {
+// can two leaf patterns cover the same concrete path?
+static bool patterns_overlap(const Pattern& a, const Pattern& b) {
+  if (a.size() != b.size()) return false;
+  auto admits = [](const PatStep& any, const std::string& key) {
+    if (any.elems_only) return false;
+    if (!any.only.empty() && std::find(any.only.begin(), any.only.end(), key) == any.only.end()) return false;
+    return std::find(any.except.begin(), any.except.end(), key) == any.except.end();
+  };
+  for (size_t i = 0; i < a.size(); i++) {
+    const PatStep &x = a[i], &y = b[i];
+    if (!x.any && !y.any) { if (x.key != y.key) return false; }
+    else if (!x.any) { if (!admits(y, x.key)) return false; }
+    else if (!y.any) { if (!admits(x, y.key)) return false; }
+  }
+  return true;
+}
+
+uint32_t DictRegistry::intern(const Pattern& leaf_in, const DX& dx) {
+  // Canonical form: an unfiltered iteration step is registered as "any child", whether the lowering reached the leaf through
+  // an explicit element loop (elements only) or through a flat wildcard predicate (members and elements) -- the same leaf
+  // must own ONE pattern, because bit numbers are per pattern and a path has one $d row.  (The device predicates keep their
+  // own, exact patterns; a $d row on a path only the wider form covers is merely never read.)
+  Pattern leaf = leaf_in;
+  for (PatStep& st : leaf) if (st.any && st.only.empty() && st.except.empty()) st.elems_only = false;
   const std::string pk = pattern_to_string(leaf), dk = dx_to_string(dx);
   std::unique_lock<std::shared_mutex> l(mu_);
   Pat* p = nullptr;
   for (auto& x : pats_) if (x.key == pk) p = &x;
-  if (!p) { pats_.push_back({leaf, pk, {}}); p = &pats_.back(); }
+  if (!p) {
+    // a different pattern that covers some of the same paths (a constant member next to an iteration over the members of the
+    // same object) would need two $d rows on one path: refused here, at AddConstraint -- never at table creation
+    for (auto& x : pats_) if (patterns_overlap(x.pat, leaf)) throw std::runtime_error("dictionary predicates on overlapping leaf patterns (" + x.key + " and " + pk + ")");
+    pats_.push_back({leaf, pk, {}}); p = &pats_.back();
+  }
   for (auto& e : p->entries) if (e.key == dk) return e.bit;
   if (p->entries.size() >= 62) throw std::runtime_error("more than 62 dictionary predicates on " + pk);
   p->entries.push_back({dx, dk, (uint32_t)p->entries.size()});

@@ -1299,6 +1299,7 @@ void HostPlan::resolve_paths(const PathDict& dict) {
           // `except` list and equals none in an `only` list
           if (in.is_elem) { if (st.only.empty()) nxt.push_back(ch); continue; }
           if (st.elems_only) continue;
+          if (in.key == "$d") continue;   // the flattener's dictionary row under a leaf is not a member of the document
           if (!st.only.empty() && std::find(st.only.begin(), st.only.end(), in.key) == st.only.end()) continue;
           if (std::find(st.except.begin(), st.except.end(), in.key) != st.except.end()) continue;
           nxt.push_back(ch);

@@ -181,3 +181,76 @@ def test_random_templates_agree_with_the_oracle(backend, seed):
     stats, diffs = run(backend, seed, 70, 14)
     assert not diffs, "product and oracle disagree:\n%s" % "\n-----\n".join("%s\n%s" % (d[0], d[1]) for d in diffs[:3])
     assert stats["oracle_err"] == 0 and stats["ok"] >= 60, stats      # the grammar stays inside what both sides implement
+
+
+REGRESSIONS = {
+    # a wildcard step (`e.a[_]` with the element unused) matched the flattener's own `$d` dictionary row under the STRING e.a:
+    # the device saw "e.a has an element" and flagged a violation the renderer (rightly) could not produce
+    "iteration_over_a_string_that_owns_a_dictionary_row": '''package k
+violation[{"msg": msg}] {
+  e := input.review.object.list[_]
+  f := e.a[_]
+  trim_prefix(e.a, "a-") != e.a
+  msg := "m9"
+}
+''',
+    # the same leaf reached through an element loop and through a flat wildcard predicate registered two dictionary
+    # patterns that both covered list[].b: table creation failed with "overlapping dictionary patterns"
+    "one_leaf_two_iteration_forms": '''package k
+h0(o) {
+  count(o.b) < 0
+}
+violation[{"msg": msg}] {
+  e := input.review.object.list[_]
+  not h0(e)
+  endswith(e.a, "y")
+  count(e.a) > 1
+  msg := sprintf("m2 %v", [e.c])
+}
+violation[{"msg": msg}] {
+  e := input.review.object.list[_]
+  h0(input.review.object)
+  h0(e)
+  not h0(e)
+  msg := "m0"
+}
+''',
+}
+
+
+@pytest.mark.parametrize("backend", ["hostemu", "hostemu-gen"])
+@pytest.mark.parametrize("name", sorted(REGRESSIONS))
+def test_fuzz_regressions(backend, name):
+    rego = REGRESSIONS[name]
+    objs = [{"apiVersion": "v1", "kind": "Pod", "metadata": {"name": "o%d" % i, "namespace": "d"}, "list": l} for i, l in enumerate([
+        [True, {"b": "x", "a": "a-long-string-constant"}], [{"a": ["a-x"]}], [{"a": "a-x"}], [{"a": {"k": "a-x"}}], [{"a": "xy", "b": "", "c": 1}], [{"a": "y"}, {"b": [], "a": "yyy"}]])]
+    k = {"apiVersion": "constraints.gatekeeper.sh/v1beta1", "kind": "K8sX", "metadata": {"name": "c"}, "spec": {}}
+    c = make_client(backend)
+    c.AddTemplate(tmpl("K8sX", rego))
+    c.AddConstraint(k)
+    oc = OC.Client()
+    oc.add_template(tmpl("K8sX", rego))
+    oc.add_constraint(k)
+    got = [sorted(r.msg for r in g) for g in c.ReviewBatch([D.AugmentedUnstructured(D.Unstructured(o), None, "Original") for o in objs], D.GATOR_EP)]
+    want = [sorted(r.msg for r in oc.review(OT.AugmentedUnstructured(OT.Unstructured(o), None, "Original"), OC.GATOR_EP)) for o in objs]
+    assert got == want
+
+
+def test_overlapping_dictionary_patterns_are_refused_when_the_constraint_is_added():
+    """a constant member and an iteration over the members of the same object, both with dictionary predicates, would need
+    two `$d` rows on one path: GK_ERR_UNSUPPORTED at AddConstraint, not an error when a table is built"""
+    rego = '''package k
+violation[{"msg": msg}] {
+  to_number(input.review.object.metadata.labels.size) > 3
+  msg := "big"
+}
+violation[{"msg": msg}] {
+  v := input.review.object.metadata.labels[_]
+  to_number(v) > 100
+  msg := "huge"
+}
+'''
+    c = make_client("hostemu")
+    c.AddTemplate(tmpl("K8sX", rego))
+    with pytest.raises(D.UnsupportedError, match="overlapping leaf patterns"):
+        c.AddConstraint({"apiVersion": "constraints.gatekeeper.sh/v1beta1", "kind": "K8sX", "metadata": {"name": "c"}, "spec": {}})
