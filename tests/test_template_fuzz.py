@@ -19,7 +19,8 @@ from parity_util import make_client
 
 KEYS = ["a", "b", "c"]
 CONSTS = ['"x"', '"yy"', '"a-long-string-constant"', "1", "2", "true", "false", '""', "0"]
-STRS = ['"x"', '"y"', '"a-"', '"long-string-constant"']
+# (string lengths around the row layout's boundaries: <= 7 bytes inline, <= 12 in the string header, longer in the heap)
+STRS = ['"x"', '"y"', '"a-"', '"long-string-constant"', '"ab"', '"-suffix"', '"0123456"', '"01234567"', '"b0123456789c"', '"tail-of-a-longer-string"', '"é"']
 
 def scalar_path(rng, base="input.review.object"):
     return base + "".join("." + rng.choice(KEYS) for _ in range(rng.randint(1, 2)))
@@ -115,7 +116,9 @@ def rand_value(rng, depth=0):
         return {k: rand_value(rng, depth + 1) for k in rng.sample(KEYS, rng.randint(0, 3))}
     if depth < 2 and r < 0.35:
         return [rand_value(rng, depth + 1) for _ in range(rng.randint(0, 3))]
-    return rng.choice(["x", "yy", "a-long-string-constant", "a-x", "", 0, 1, 2, 3, 1.5, True, False, None, "long-string-constant-a-"])
+    return rng.choice(["x", "yy", "a-long-string-constant", "a-x", "", 0, 1, 2, 3, 1.5, True, False, None, "long-string-constant-a-",
+                       "0123456", "01234567", "x01234567", "ab0123456789cab", "b0123456789c", "b0123456789cx", "xb0123456789c", "a-b0123456789c-suffix",
+                       "head-tail-of-a-longer-string", "tail-of-a-longer-string", "abababab", "ababababababab", "é", "aé-suffix", "x-suffix", -1, 2.0, 10**12])
 
 def rand_obj(rng, n):
     o = {"apiVersion": "v1", "kind": "Pod", "metadata": {"name": "o%d" % n, "namespace": "d"}}
