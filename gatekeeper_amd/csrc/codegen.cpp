@@ -206,6 +206,8 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts, const std
       std::string w0 = "0u";
       for (const std::string& m : g.masks) if (m.back() == '0' && m[m.size() - 2] == '_') w0 = m;
       std::string extra;
+      // (a non-empty container cannot be compared by its payload: the review goes beyond the limits, vm_core.hpp P_STORE)
+      if (!g.stores.empty()) o << "          if ((t == T_OBJECT || t == T_ARRAY) && r.lo != 0u) acc.or_word(0u, 1u); else {\n";
       for (size_t i : g.stores) {
         const Pred& p = ps[i];
         uint32_t stride = val_stride(sc.nvals);
@@ -227,6 +229,7 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts, const std
         else o << "          if (" << m << ") acc.or_word(" << sc.word_off << "u + ord * " << (int)sc.wpe << "u + " << wi << "u, " << m << ");\n";
       }
       if (!w0_done && !extra.empty()) o << "          acc.or_word(" << sc.word_off << "u + ord * " << (int)sc.wpe << "u, 0u" << extra << ");\n";
+      if (!g.stores.empty()) o << "          }\n";
       o << "        }\n      }\n";
     }
     o << "    }\n";

@@ -384,6 +384,13 @@ GK_HD void eval_row_ent(const Row& r, uint32_t row_index, uint32_t ent, const St
     }
     uint32_t wpe = sc.wpe;
     if (p.op == P_STORE) {
+      // A stored value is compared with another one (Rego `==` between two review values).  Scalars decide by type and
+      // payload, empty containers by type; two NON-EMPTY containers would need a deep comparison the plan cannot do: the
+      // review is flagged beyond the engine's limits (reported in too_big, the caller fails closed) -- never guessed.
+      if (((r.meta & ROW_TYPE_MASK) == T_OBJECT || (r.meta & ROW_TYPE_MASK) == T_ARRAY) && r.lo != 0u) {
+        acc.or_word(GBIT_OVERFLOW >> 5, 1u << (GBIT_OVERFLOW & 31));
+        continue;
+      }
       // value slot: the row's 64-bit payload; the element's type word gets a nibble (type + 1 | inline << 3)
       uint32_t vb = sc.val_off + ord * val_stride(sc.nvals);
       if (p.level >= GK_LEVEL_ROOT) { acc.max_word(sc.count_off, 1u); acc.or_word(sc.word_off, 1u); }   // the root scope's element exists once a value is stored
@@ -429,7 +436,7 @@ GK_HD_COLD bool val_eq(uint32_t alo, uint32_t ahi, uint32_t an, uint32_t blo, ui
       for (uint32_t j = 0; j < na; j += 4) d |= ld32(heap + alo + j) ^ ld32(heap + blo + j);
       return d == 0;
     }
-    default: return false;   // composite joins are rejected by the compiler
+    default: return ta == tb && alo == 0u && blo == 0u;   // containers: two EMPTY ones of the same type are equal; a non-empty one is never stored (P_STORE refuses the review)
   }
 }
 
@@ -437,7 +444,7 @@ GK_HD_COLD bool val_eq(uint32_t alo, uint32_t ahi, uint32_t an, uint32_t blo, ui
 // inline strings / the same heap entry.  Only float operands and distinct heap strings with equal hashes call val_eq.
 GK_HD bool val_eq_quick(uint32_t alo, uint32_t ahi, uint32_t an, uint32_t blo, uint32_t bhi, uint32_t bn, const uint8_t* heap) {
   const uint32_t ta = an & 7u, tb = bn & 7u;   // type + 1
-  const bool same = (an == bn) & (alo == blo) & (ahi == bhi) & (ta != 0u);
+  const bool same = (an == bn) & (alo == blo) & (ahi == bhi) & (ta != 0u) & !((ta > T_STRING + 1u) & (alo != 0u));   // (containers: only empty ones compare)
   const bool fl = ((ta == T_FLOAT + 1u) & ((tb == T_FLOAT + 1u) | (tb == T_INT + 1u))) | ((tb == T_FLOAT + 1u) & (ta == T_INT + 1u));
   const bool hs = (an == T_STRING + 1u) & (bn == T_STRING + 1u) & (ahi == bhi) & (alo != blo);
   if (fl | hs) return val_eq(alo, ahi, an, blo, bhi, bn, heap);

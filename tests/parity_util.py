@@ -77,12 +77,26 @@ def object_where_elements_are_iterated(review):
             return any(walk(x) for x in v)
         return False
     body = review.object if isinstance(review, D.AugmentedUnstructured) else review.admission_request if isinstance(review, D.AugmentedReview) else review
+    return walk(body) or compared_value_is_a_container(body)
+
+
+def compared_value_is_a_container(body):
+    """True when a member the loaded templates compare with another review value (`volumeMounts[_].name == volumes[_].name`)
+    holds a NON-EMPTY container: equality of two such values is a deep comparison the plan cannot make, so the engine
+    refuses the review (fail closed) instead of comparing payloads."""
+    def walk(v):
+        if isinstance(v, dict):
+            return any((k == "name" and isinstance(x, (dict, list)) and len(x) > 0) or walk(x) for k, x in v.items())
+        if isinstance(v, list):
+            return any(walk(x) for x in v)
+        return False
     return walk(body)
 
 
 def assert_parity(c, oc, reviews, ep=D.AUDIT_EP, namespaces=None, refused=None):
     """refused (a list, or None): reviews the engine REFUSES with a LimitError are collected there instead of failing the
-    comparison, provided they hold an object where array elements are iterated; everything else must match.
+    comparison, provided they hold an object where array elements are iterated or a non-empty container where two review
+    values are compared; everything else must match.
     Product == oracle for every review: (1) the rendered result multisets (constraint, msg, details, actions), and
     (2) the RAW device bitmaps -- the violation bits and the match-error bits, before any host rendering -- against the
     pair sets the oracle's results imply, so that a spurious device bit cannot hide behind a renderer that returns []."""

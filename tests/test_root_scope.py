@@ -85,3 +85,32 @@ def test_values_compared_outside_iterations(backend):
     assert sa[4] == sa[5] == sa[6] == []          # a missing side is undefined, CREATE is not UPDATE
     rep = [any(r.msg == "replicas changed" for r in g) for g in got]
     assert rep[8] and not rep[9] and rep[10]      # 2 -> 3; 3.0 == 3; "3" != 3
+
+
+@pytest.mark.parametrize("backend", ["hostemu", "hostemu-gen"])
+def test_composite_operands_are_refused_not_guessed(backend):
+    """Rego's `==` between two review values is DEEP equality.  The plan compares type and payload: exact for scalars and for
+    empty containers; for a non-empty container it would have to guess -- the review is refused (LimitError, the caller fails
+    closed) whatever the other side holds.  (CPU builds: the refusal is decided by the row code shared with the device.)"""
+    rego = '''package k
+violation[{"msg": msg}] {
+  input.review.object.spec.selector == input.review.oldObject.spec.selector
+  msg := "selector unchanged"
+}
+'''
+    c, oc = load_both(backend, [tmpl("K8sSel", rego)], [{"apiVersion": "constraints.gatekeeper.sh/v1beta1", "kind": "K8sSel", "metadata": {"name": "x"}, "spec": {}}])
+
+    def upd(new, old):
+        def svc(sel):
+            return {"apiVersion": "v1", "kind": "Service", "metadata": {"name": "s", "namespace": "d"}, "spec": {"selector": sel}}
+        return D.AugmentedReview(D.AdmissionRequest({"uid": "u", "kind": {"group": "", "version": "v1", "kind": "Service"}, "operation": "UPDATE", "name": "s",
+                                                     "namespace": "d", "object": svc(new), "oldObject": svc(old)}), None, "Original")
+    cases = [({"app": "a"}, {"app": "a"}), ({"app": "a"}, {"app": "b"}), ({"app": "a"}, "a"), ({}, {}), ({}, []), ("x", "x"), ([], [])]
+    got = c.ReviewBatch([upd(n, o) for n, o in cases], D.GATOR_EP)
+    for k in (0, 1, 2):
+        assert isinstance(got[k], D.ReviewFailure) and isinstance(got[k].cause, D.LimitError), (k, got[k])
+    from parity_util import to_oracle_review
+    for k in (3, 4, 5, 6):
+        want = sorted(r.msg for r in oc.review(to_oracle_review(upd(*cases[k])), D.GATOR_EP))
+        assert sorted(r.msg for r in got[k]) == want
+    assert [len(got[k]) for k in (3, 4, 5, 6)] == [1, 0, 1, 1]
