@@ -18,6 +18,7 @@ from oracle import target as OT
 from parity_util import make_client
 
 KEYS = ["a", "b", "c"]
+ENVELOPE = False
 CONSTS = ['"x"', '"yy"', '"a-long-string-constant"', "1", "2", "true", "false", '""', "0"]
 # (string lengths around the row layout's boundaries: <= 7 bytes inline, <= 12 in the string header, longer in the heap)
 STRS = ['"x"', '"y"', '"a-"', '"long-string-constant"', '"ab"', '"-suffix"', '"0123456"', '"01234567"', '"b0123456789c"', '"tail-of-a-longer-string"', '"é"']
@@ -62,6 +63,20 @@ def cond2(rng, var=None):
     if k == 10: return "re_match(\"^[a-z]+-\", %s)" % p
     return "%s.%s.%s" % (p, rng.choice(KEYS), rng.choice(KEYS))
 
+def cond3(rng, var=None):
+    k = rng.randint(0, 9)
+    a = scalar_path(rng); b = scalar_path(rng, "input.review.oldObject")
+    if k == 0: return "%s == %s" % (a, b)
+    if k == 1: return "%s != %s" % (a, b)
+    if k == 2: return "not %s == %s" % (a, b)
+    if k == 3 and var: return "%s.%s == %s" % (var, rng.choice(KEYS), scalar_path(rng))
+    if k == 4 and var: return "%s.%s != %s" % (var, rng.choice(KEYS), scalar_path(rng))
+    if k == 5: return 'input.review.operation == "%s"' % rng.choice(["UPDATE", "CREATE", "DELETE"])
+    if k == 6: return 'input.review.userInfo.username == "%s"' % rng.choice(["bob", "alice"])
+    if k == 7: return 'input.review.userInfo.groups[_] == "%s"' % rng.choice(["dev", "ops"])
+    if k == 8: return "%s == %s" % (scalar_path(rng), scalar_path(rng))
+    return "%s" % b
+
 def body(rng, helpers):
     stmts = []
     var = None
@@ -80,6 +95,8 @@ def body(rng, helpers):
             src = "input.review.object." + rng.choice(["items", "list"])
             stmts.append("s%d := {x | x := %s[_].%s}" % (len(stmts), src, rng.choice(KEYS)))
             stmts.append("count(s%d - {y | y := input.parameters.allowed[_]}) %s 0" % (len(stmts) - 1, rng.choice([">", "=="])))
+        elif r < 0.75 and ENVELOPE:
+            stmts.append(cond3(rng, var))
         elif r < 0.6:
             c2 = cond2(rng, var)
             if c2.startswith("v") and ":=" in c2:
@@ -139,7 +156,25 @@ def tmpl(kind, rego):
     return {"apiVersion": "templates.gatekeeper.sh/v1", "kind": "ConstraintTemplate", "metadata": {"name": kind.lower()},
             "spec": {"crd": {"spec": {"names": {"kind": kind}}}, "targets": [{"target": "admission.k8s.gatekeeper.sh", "rego": rego}]}}
 
-def run(backend, seed, n_templates, n_objs, verbose=False):
+def mk_reviews(wrap, objs, rng_seed):
+    r = random.Random(rng_seed)
+    out = []
+    for i, o in enumerate(objs):
+        if not ENVELOPE or i % 3 == 0:
+            out.append(wrap.AugmentedUnstructured(wrap.Unstructured(o), None, "Original")); continue
+        op = r.choice(["UPDATE", "UPDATE", "CREATE", "DELETE"])
+        old = objs[r.randrange(len(objs))] if r.random() < 0.5 else json.loads(json.dumps(o))
+        if r.random() < 0.5 and isinstance(old.get("a"), (str, int)): old = dict(old, a="changed")
+        req = {"uid": "u%d" % i, "kind": {"group": "", "version": "v1", "kind": "Pod"}, "operation": op, "name": o["metadata"]["name"], "namespace": "d",
+               "userInfo": {"username": r.choice(["bob", "alice"]), "groups": r.sample(["dev", "ops", "qa"], r.randint(0, 2))}}
+        if op != "DELETE": req["object"] = o
+        if op != "CREATE": req["oldObject"] = old
+        out.append(wrap.AugmentedReview(wrap.AdmissionRequest(req), None, "Original"))
+    return out
+
+def run(backend, seed, n_templates, n_objs, envelope=False, verbose=False):
+    global ENVELOPE
+    ENVELOPE = envelope
     rng = random.Random(seed)
     objs = [rand_obj(rng, i) for i in range(n_objs)]
     stats = {"ok": 0, "unsupported": 0, "diff": 0, "oracle_err": 0, "product_err": 0}
@@ -151,7 +186,10 @@ def run(backend, seed, n_templates, n_objs, verbose=False):
         k = {"apiVersion": "constraints.gatekeeper.sh/v1beta1", "kind": kind, "metadata": {"name": "c"}, "spec": {"parameters": params}}
         try:
             oc = OC.Client(); oc.add_template(tmpl(kind, rego)); oc.add_constraint(k)
-            want = [sorted(r.msg for r in oc.review(OT.AugmentedUnstructured(OT.Unstructured(o), None, "Original"), OC.GATOR_EP)) for o in objs]
+            want = []
+            for rv in mk_reviews(OT, objs, seed):
+                try: want.append(sorted(r.msg for r in oc.review(rv, OC.GATOR_EP)))
+                except Exception as e: want.append("REJECTED")
         except Exception as e:
             stats["oracle_err"] += 1
             if verbose: print("ORACLE ERR", e, "\n", rego)
@@ -165,11 +203,14 @@ def run(backend, seed, n_templates, n_objs, verbose=False):
         except Exception as e:
             stats["product_err"] += 1; diffs.append(("ERR " + str(e)[:200], rego)); continue
         got = []
-        res = c.ReviewBatch([D.AugmentedUnstructured(D.Unstructured(o), None, "Original") for o in objs], D.GATOR_EP)
+        try:
+            res = c.ReviewBatch(mk_reviews(D, objs, seed), D.GATOR_EP)
+        except Exception as e:
+            stats["product_err"] += 1; diffs.append(("REVIEW ERR " + str(e)[:200], rego, [objs[6]] if "review 6" in str(e) else [], params)); continue
         refused = False
         for g in res:
             if isinstance(g, Exception):
-                refused = True; got.append("REFUSED")
+                refused = True; got.append("REFUSED" if isinstance(getattr(g, "cause", None), D.LimitError) else "REJECTED")
             else: got.append(sorted(r.msg for r in g))
         bad = [(j, got[j], want[j]) for j in range(n_objs) if got[j] != "REFUSED" and got[j] != want[j]]
         if bad:
@@ -179,9 +220,11 @@ def run(backend, seed, n_templates, n_objs, verbose=False):
 
 
 @pytest.mark.parametrize("backend", ["hostemu", "hostemu-gen"])
-@pytest.mark.parametrize("seed", [11, 12])
-def test_random_templates_agree_with_the_oracle(backend, seed):
-    stats, diffs = run(backend, seed, 70, 14)
+@pytest.mark.parametrize("seed,envelope", [(11, False), (12, False), (701, True)])
+def test_random_templates_agree_with_the_oracle(backend, seed, envelope):
+    """envelope: AdmissionRequests (CREATE / UPDATE / DELETE, oldObject, userInfo) mixed with bare objects, and conditions that
+    compare review values with each other (object vs oldObject, element vs outside value)"""
+    stats, diffs = run(backend, seed, 70, 14, envelope=envelope)
     assert not diffs, "product and oracle disagree:\n%s" % "\n-----\n".join("%s\n%s" % (d[0], d[1]) for d in diffs[:3])
     assert stats["oracle_err"] == 0 and stats["ok"] >= 60, stats      # the grammar stays inside what both sides implement
 
