@@ -300,3 +300,41 @@ violation[{"msg": msg}] {
     c.AddTemplate(tmpl("K8sX", rego))
     with pytest.raises(D.UnsupportedError, match="overlapping leaf patterns"):
         c.AddConstraint({"apiVersion": "constraints.gatekeeper.sh/v1beta1", "kind": "K8sX", "metadata": {"name": "c"}, "spec": {}})
+
+
+@pytest.mark.parametrize("backend", ["hostemu", "hostemu-gen"])
+def test_random_constraint_sets_in_one_plan(backend):
+    """a dozen random templates + constraints (random match blocks) loaded TOGETHER: common sub-formulas are shared across
+    constraints, dictionary predicates of different templates meet on the same leaves, one launch answers all of them"""
+    global ENVELOPE
+    ENVELOPE = True
+    seed = 31
+    rng = random.Random(seed)
+    objs = [rand_obj(rng, i) for i in range(14)]
+    n_loaded = 0
+    for g in range(3):
+        c, oc = make_client(backend), OC.Client()
+        for i in range(12):
+            rego, kind = template(rng, g * 100 + i), "K8sFuzz%dx%d" % (g, i)
+            params = {"p": rng.choice(["x", 1, True]), "q": rng.choice(["yy", 2]), "allowed": rng.sample(["x", "yy", 1, 2, True], 2)}
+            match = rng.choice([None, {"kinds": [{"apiGroups": [""], "kinds": ["Pod"]}]}, {"namespaces": ["d"]}, {"excludedNamespaces": ["d"]}, {"name": "o1*"}])
+            k = {"apiVersion": "constraints.gatekeeper.sh/v1beta1", "kind": kind, "metadata": {"name": "c"}, "spec": {"parameters": params}}
+            if match:
+                k["spec"]["match"] = match
+            try:
+                c.AddTemplate(tmpl(kind, rego))
+                c.AddConstraint(k)
+            except D.UnsupportedError:
+                c.RemoveTemplate(tmpl(kind, rego))
+                continue
+            oc.add_template(tmpl(kind, rego))
+            oc.add_constraint(k)
+            n_loaded += 1
+        got = c.ReviewBatch(mk_reviews(D, objs, seed), D.GATOR_EP)
+        for j, rv in enumerate(mk_reviews(OT, objs, seed)):
+            if isinstance(got[j], Exception):
+                assert isinstance(getattr(got[j], "cause", None), D.LimitError), got[j]      # refused (fail closed), never different
+                continue
+            want = sorted((r.constraint["kind"], r.msg) for r in oc.review(rv, OC.GATOR_EP))
+            assert sorted((r.constraint["kind"], r.msg) for r in got[j]) == want, (g, j)
+    assert n_loaded >= 30
