@@ -71,6 +71,14 @@ inline Value dx_eval(const DX& e, const Value& leaf) {
     case DExpr::CALL: {
       ValueVec av;
       for (auto& a : e->args) { Value v = dx_eval(a, leaf); if (!v.defined()) return Value(); av.push_back(v); }
+      if (e->name == "$index") {   // element of an array (a split component); negative index: from the end; out of range: undefined
+        if (av.size() != 2 || !av[0].is_array() || !av[1].is_number() || !av[1].is_int) return Value();
+        const long long n = (long long)av[0].size();
+        long long i = (long long)av[1].i;
+        if (i < 0) i += n;
+        if (i < 0 || i >= n) return Value();
+        return av[0].items()[(size_t)i];
+      }
       return call_builtin(e->name, av);
     }
     case DExpr::ARITH: {

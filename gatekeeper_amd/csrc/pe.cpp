@@ -174,6 +174,17 @@ bool leaf_local(const SVP& v, SPath* leaf, DX* dx) {
   if (v->kind == SV::PATH && !v->path.empty()) { *leaf = v->path; *dx = dx_leaf(); return true; }
   if (v->kind == SV::DERIVED) { *leaf = v->path; *dx = v->dx; return true; }
   if (v->kind == SV::COUNTOF) { *leaf = v->path; *dx = dx_node(DExpr::CALL, {dx_leaf()}, "count"); return true; }
+  if (v->kind == SV::STRX && !v->path.empty()) {
+    // trim(leaf, c) / split(.., sep) / a component / the component count: functions of the one string leaf
+    DX base = dx_leaf();
+    if (v->cut) base = dx_node(DExpr::CALL, {base, dx_const(Value::string(std::string(1, v->cut)))}, "trim");
+    *leaf = v->path;
+    if (v->xkind == SV::XTRIM) { *dx = base; return true; }
+    DX arr = dx_node(DExpr::CALL, {base, dx_const(Value::string(std::string(1, v->sep)))}, "split");
+    if (v->xkind == SV::XARR) { *dx = arr; return true; }
+    if (v->xkind == SV::XCOMP) { *dx = dx_node(DExpr::CALL, {arr, dx_const(Value::integer(v->idx))}, "$index"); return true; }
+    if (v->xkind == SV::XCOUNT) { *dx = dx_node(DExpr::ARITH, {dx_node(DExpr::CALL, {arr}, "count"), dx_const(Value::integer(v->idx))}, "+"); return true; }
+  }
   return false;
 }
 SVP sv_derived(const SPath& leaf, DX dx) { SV s; s.kind = SV::DERIVED; s.path = leaf; s.dx = std::move(dx); return mksv(s); }

@@ -661,7 +661,7 @@ def test_library_patterns_second_batch(backend):
 
 
 # ---- a third batch: userInfo / namespaceObject, object.get with a key path, set algebra, type tests, arithmetic, default /
-# else rules, string builtins in messages, nested parameters -- bare objects AND AdmissionRequests; three shapes are refused
+# else rules, string builtins in messages, nested parameters, a regular expression on a split() component -- bare objects AND AdmissionRequests; two shapes are refused
 T3 = {}
 T3["K8sUserInfo"] = ('''package k
 violation[{"msg": msg}] {
@@ -790,8 +790,7 @@ def reviews3(wrap):
         out.append(wrap.AugmentedReview(wrap.AdmissionRequest(req), nsobj, "Original"))
     return out
 UNSUPPORTED3 = {"K8sCountAndSum": "count\\(\\) of a set built from review data compared with a constant other than 0",
-                "K8sObjectComprehension": "object comprehension over review data",
-                "K8sRegexAndSplit": "regex.match with these symbolic operands"}
+                "K8sObjectComprehension": "object comprehension over review data"}
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
@@ -799,7 +798,7 @@ def test_library_patterns_third_batch(backend):
     good = {k: v for k, v in T3.items() if k not in UNSUPPORTED3}
     c, oc = load_both(backend, [tmpl(k, rego) for k, (rego, _) in good.items()], [_constraint(k, params) for k, (_, params) in good.items()])
     rv = reviews3(D)
-    assert assert_parity(c, oc, rv, D.GATOR_EP, namespaces=[nsobj] * len(rv)) == 42
+    assert assert_parity(c, oc, rv, D.GATOR_EP, namespaces=[nsobj] * len(rv)) == 46
     for kind, why in UNSUPPORTED3.items():
         rego, params = T3[kind]
         with pytest.raises((D.UnsupportedError, D.ClientError, D.EngineError), match=why):
