@@ -61,6 +61,15 @@ def cond2(rng, var=None):
     if k == 8: return "not %s[_] == %s" % (p, rng.choice(CONSTS))
     if k == 9: return "count({z | z := %s[_]; z != %s}) > 0" % (p, rng.choice(CONSTS))
     if k == 10: return "re_match(\"^[a-z]+-\", %s)" % p
+    if rng.random() < 0.5:
+        sep = rng.choice(["-", "0", "a"])
+        j = rng.randint(0, 5)
+        if j == 0: return "count(split(%s, \"%s\")) %s %d" % (p, sep, rng.choice(["==", ">", "<"]), rng.randint(1, 3))
+        if j == 1: return "split(%s, \"%s\")[%d] == %s" % (p, sep, rng.randint(0, 2), rng.choice(STRS))
+        if j == 2: return "startswith(split(%s, \"%s\")[%d], %s)" % (p, sep, rng.randint(0, 1), rng.choice(STRS))
+        if j == 3: return "re_match(\"^[0-9a-z]+$\", split(%s, \"%s\")[%d])" % (p, sep, rng.randint(0, 2))
+        if j == 4: return "not endswith(split(%s, \"%s\")[1], %s)" % (p, sep, rng.choice(STRS))
+        return "upper(split(trim(%s, \"a\"), \"%s\")[0]) != %s" % (p, sep, rng.choice(STRS))
     return "%s.%s.%s" % (p, rng.choice(KEYS), rng.choice(KEYS))
 
 def cond3(rng, var=None):
