@@ -76,6 +76,7 @@ std::string pattern_to_string(const Pattern& p) {
     o += s.elems_only ? "[]" : "[*";
     for (auto& k : s.only) o += "=" + k;
     for (auto& k : s.except) o += "!" + k;
+    for (auto& kp : s.kpreds) o += std::string(kp.neg ? "~!" : "~") + (char)('0' + kp.op) + kp.s;
     if (!s.elems_only) o += "]";
   }
   return o;
@@ -90,6 +91,9 @@ bool pattern_matches(const Pattern& pat, const PathDict& dict, uint32_t id) {
     const PathDict::Info& in = chain[chain.size() - 1 - i];
     const PatStep& st = pat[i];
     if (!st.any) { if (in.is_elem || in.key != st.key) return false; continue; }
+    bool kp_ok = true;
+    for (auto& kp : st.kpreds) if (!key_pred_holds(kp, in.key, in.is_elem)) kp_ok = false;
+    if (!kp_ok) return false;
     if (in.is_elem) { if (!st.only.empty()) return false; continue; }
     if (st.elems_only) return false;
     if (!st.only.empty() && std::find(st.only.begin(), st.only.end(), in.key) == st.only.end()) return false;
@@ -103,6 +107,7 @@ static bool patterns_overlap(const Pattern& a, const Pattern& b) {
   if (a.size() != b.size()) return false;
   auto admits = [](const PatStep& any, const std::string& key) {
     if (any.elems_only) return false;
+    for (auto& kp : any.kpreds) if (!key_pred_holds(kp, key, false)) return false;
     if (!any.only.empty() && std::find(any.only.begin(), any.only.end(), key) == any.only.end()) return false;
     return std::find(any.except.begin(), any.except.end(), key) == any.except.end();
   };
@@ -121,7 +126,7 @@ uint32_t DictRegistry::intern(const Pattern& leaf_in, const DX& dx) {
   // must own ONE pattern, because bit numbers are per pattern and a path has one $d row.  (The device predicates keep their
   // own, exact patterns; a $d row on a path only the wider form covers is merely never read.)
   Pattern leaf = leaf_in;
-  for (PatStep& st : leaf) if (st.any && st.only.empty() && st.except.empty()) st.elems_only = false;
+  for (PatStep& st : leaf) if (st.any && st.only.empty() && st.except.empty() && st.kpreds.empty()) st.elems_only = false;
   const std::string pk = pattern_to_string(leaf), dk = dx_to_string(dx);
   std::unique_lock<std::shared_mutex> l(mu_);
   Pat* p = nullptr;

@@ -52,12 +52,28 @@ class PathDict {
 };
 
 // ------------------------------------------------------------------------------------------------ path patterns
+// string test on the member NAME of a key iteration (`startswith(key, "x")` ..): decided when patterns are resolved against
+// the table's key paths, never on the device.  An array index is a number: it fails every positive test (the builtin is
+// undefined for it) and passes every negated one.
+struct KeyPred { uint8_t op = 0; bool neg = false; std::string s; };   // op: 6 prefix, 7 suffix, 8 contains, 9 "is a member name"
+inline bool key_pred_holds(const KeyPred& p, const std::string& key, bool is_elem) {
+  bool t = false;
+  if (!is_elem) {
+    if (p.op == KC_PREFIX) t = key.compare(0, p.s.size(), p.s) == 0 && key.size() >= p.s.size();
+    else if (p.op == KC_SUFFIX) t = key.size() >= p.s.size() && key.compare(key.size() - p.s.size(), p.s.size(), p.s) == 0;
+    else if (p.op == KC_CONTAINS) t = key.find(p.s) != std::string::npos;
+    else t = true;   // KC_ISNAME
+  }
+  return p.neg ? !t : t;
+}
+
 struct PatStep {
   bool any = false;                 // true: any single step
   bool elems_only = false;          // any: only "[]" children (array-element scopes)
   std::string key;                  // !any: exact member name
   std::vector<std::string> only;    // any: member name must be one of (key iteration with ==)
   std::vector<std::string> except;  // any: member name must not be one of
+  std::vector<KeyPred> kpreds;      // any: string tests the member name must pass
 };
 typedef std::vector<PatStep> Pattern;
 std::string pattern_to_string(const Pattern& p);

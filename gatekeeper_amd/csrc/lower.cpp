@@ -334,6 +334,17 @@ FP simplify(const FP& f) {
       std::vector<FP> uniq;
       std::set<std::string> seen;
       for (auto& k : flat) { if (k->kind == FNode::F) return f_false(); if (seen.insert(f_to_string(k)).second) uniq.push_back(k); }
+      // "the key is a member name" is implied by a positive string test on the same key (an index fails every such test)
+      {
+        std::vector<FP> u2;
+        for (auto& k : uniq) {
+          bool implied = false;
+          if (k->kind == FNode::ATOM && k->atom.kind == Atom::KEYCMP && k->atom.cmp == KC_ISNAME)
+            for (auto& o : uniq) if (o->kind == FNode::ATOM && o->atom.kind == Atom::KEYCMP && o->atom.q == k->atom.q && o->atom.cmp >= KC_PREFIX && o->atom.cmp < KC_ISNAME) implied = true;
+          if (!implied) u2.push_back(k);
+        }
+        uniq.swap(u2);
+      }
       // drop DEFINED(p) implied by another positive conjunct on p or below p
       std::vector<FP> keep;
       for (size_t i = 0; i < uniq.size(); i++) {
@@ -655,6 +666,7 @@ struct Lowerer {
         if (it == wild.end()) unsupported("free quantifier in a predicate path");
         ps.only = it->second.only;
         ps.except = it->second.except;
+        ps.kpreds = it->second.kpreds;
       }
       out.push_back(ps);
     }
@@ -825,7 +837,7 @@ struct Lowerer {
       // bit test on the leaf's <leaf>.$d row; the bit belongs to (pattern of the leaf, expression) in the engine's registry
       if (!reg) unsupported("dictionary predicate without a registry");
       Pattern leaf_pat = pattern_of(a.path);
-      for (auto& st : leaf_pat) if (st.any && !st.elems_only && (!st.only.empty() || !st.except.empty())) unsupported("dictionary predicate under a filtered key iteration");
+      for (auto& st : leaf_pat) if (st.any && !st.elems_only && (!st.only.empty() || !st.except.empty() || !st.kpreds.empty())) unsupported("dictionary predicate under a filtered key iteration");
       uint32_t bit;
       try { bit = reg->intern(leaf_pat, a.dx); } catch (const std::runtime_error& ex) { unsupported(ex.what()); }
       Atom b;
@@ -904,6 +916,15 @@ struct Lowerer {
 
   // key constraints of quantifier q expressed by conjunct f; returns false if f is not such a constraint
   static bool key_constraint(const FP& f, int q, PatStep* ps) {
+    if (f->kind == FNode::ATOM && f->atom.kind == Atom::KEYCMP && f->atom.q == q && f->atom.cmp >= KC_PREFIX) {   // string test on the member name
+      ps->kpreds.push_back(KeyPred{(uint8_t)f->atom.cmp, false, f->atom.k.is_string() ? f->atom.k.str() : std::string()});
+      return true;
+    }
+    if (f->kind == FNode::NOT && f->kids[0]->kind == FNode::ATOM && f->kids[0]->atom.kind == Atom::KEYCMP && f->kids[0]->atom.q == q && f->kids[0]->atom.cmp >= KC_PREFIX) {
+      const Atom& a = f->kids[0]->atom;
+      ps->kpreds.push_back(KeyPred{(uint8_t)a.cmp, true, a.k.is_string() ? a.k.str() : std::string()});
+      return true;
+    }
     if (f->kind == FNode::ATOM && f->atom.kind == Atom::KEYCMP && f->atom.q == q && f->atom.k.is_string()) {
       if (f->atom.cmp == C_EQ) ps->only.push_back(f->atom.k.str()); else ps->except.push_back(f->atom.k.str());
       return true;
@@ -933,6 +954,7 @@ struct Lowerer {
       case FNode::ATOM: {
         Atom a = f->atom;
         if (a.kind == Atom::KEYCMP && a.q == q) {
+          if (a.cmp >= KC_PREFIX) return key_pred_holds(KeyPred{(uint8_t)a.cmp, false, a.k.is_string() ? a.k.str() : std::string()}, key, false) ? f_true() : f_false();
           if (!a.k.is_string()) return a.cmp == C_NE ? f_true() : f_false();
           int c = key.compare(a.k.str());
           bool r = a.cmp == C_EQ ? c == 0 : a.cmp == C_NE ? c != 0 : a.cmp == C_LT ? c < 0 : a.cmp == C_LE ? c <= 0 : a.cmp == C_GT ? c > 0 : c >= 0;
@@ -1025,6 +1047,7 @@ struct Lowerer {
       if (!ps.only.empty() && ps.except.empty()) {
         FP any = f_false();
         for (const std::string& key : ps.only) {
+          { bool ok = true; for (auto& kp : ps.kpreds) if (!key_pred_holds(kp, key, false)) ok = false; if (!ok) continue; }   // string tests on the pinned name
           SPath member = f->base;
           Step st; st.key = key;
           member.push_back(st);
@@ -1169,6 +1192,7 @@ FP pin_pass(const FP& f) {
       if (ps.only.empty() || !ps.except.empty()) return f_exists(f->q, f->base, pin_pass(f->kids[0]));
       FP any = f_false();
       for (const std::string& key : ps.only) {
+        { bool ok = true; for (auto& kp : ps.kpreds) if (!key_pred_holds(kp, key, false)) ok = false; if (!ok) continue; }   // string tests on the pinned name
         SPath member = f->base;
         Step st; st.key = key;
         member.push_back(st);
@@ -1295,6 +1319,7 @@ void HostPlan::resolve_paths(const PathDict& dict) {
         for (uint32_t ch : children[id]) {
           const PathDict::Info& in = infos[ch];
           if (!st.any) { if (!in.is_elem && in.key == st.key) nxt.push_back(ch); continue; }
+          { bool kp_ok = true; for (auto& kp : st.kpreds) if (!key_pred_holds(kp, in.key, in.is_elem)) kp_ok = false; if (!kp_ok) continue; }
           // array elements under a key iteration: the key is a numeric index, which differs from every string in an
           // `except` list and equals none in an `only` list
           if (in.is_elem) { if (st.only.empty()) nxt.push_back(ch); continue; }

@@ -89,7 +89,11 @@ std::string f_to_string(const FP& f) {
         case Atom::FLAG: return "flag" + std::to_string(a.flag);
         case Atom::VEQ: return p + " === " + spath_to_string(a.path2);
         case Atom::SPLIT_PREFIX: return "splitprefix(" + p + "," + to_term_string(a.k) + ")";
-        case Atom::KEYCMP: return "key(q" + std::to_string(a.q) + ") " + cmpn[a.cmp] + " " + to_term_string(a.k);
+        case Atom::KEYCMP: {
+          static const char* kcn[] = {"startswith", "endswith", "contains", "isname"};
+          if (a.cmp >= KC_PREFIX) return std::string(kcn[a.cmp - KC_PREFIX]) + "(key(q" + std::to_string(a.q) + ")," + to_term_string(a.k) + ")";
+          return "key(q" + std::to_string(a.q) + ") " + cmpn[a.cmp] + " " + to_term_string(a.k);
+        }
         case Atom::DICT: return "dict(" + p + ": " + dx_to_string(a.dx) + ")";
       }
     }
@@ -1288,6 +1292,13 @@ class PE {
         Atom at = atom_path(name == "startswith" ? Atom::STR_PREFIX : name == "endswith" ? Atom::STR_SUFFIX : Atom::STR_CONTAINS, a[0]->path);
         at.k = a[1]->c;
         push_bool(f_atom(at), f_type(a[0]->path, M_STRING));
+        return;
+      }
+      if (a[0]->kind == SV::KEYOF && a[1]->kind == SV::CONST) {   // a string test on the member NAME of a key iteration
+        if (!a[1]->c.is_string()) return;
+        Atom t; t.kind = Atom::KEYCMP; t.q = a[0]->q; t.cmp = name == "startswith" ? KC_PREFIX : name == "endswith" ? KC_SUFFIX : KC_CONTAINS; t.k = a[1]->c;
+        Atom d; d.kind = Atom::KEYCMP; d.q = a[0]->q; d.cmp = KC_ISNAME; d.k = Value::string("");   // an array index is a number: the builtin is undefined for it
+        push_bool(f_atom(t), f_atom(d));
         return;
       }
       { SPath leaf; std::vector<DX> dx; if (same_leaf_args(a, &leaf, &dx)) { out.push_back({sv_derived(leaf, dx_node(DExpr::CALL, dx, name)), s}); return; } }

