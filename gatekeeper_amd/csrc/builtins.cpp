@@ -246,14 +246,74 @@ Value b_concat(ARGS) {
 Value b_contains(ARGS) { NEED(2); STR(0); STR(1); return Value::boolean(a[0].str().find(a[1].str()) != std::string::npos); }
 Value b_startswith(ARGS) { NEED(2); STR(0); STR(1); const std::string &s = a[0].str(), &p = a[1].str(); return Value::boolean(s.size() >= p.size() && s.compare(0, p.size(), p) == 0); }
 Value b_endswith(ARGS) { NEED(2); STR(0); STR(1); const std::string &s = a[0].str(), &p = a[1].str(); return Value::boolean(s.size() >= p.size() && s.compare(s.size() - p.size(), p.size(), p) == 0); }
-Value b_lower(ARGS) { NEED(1); STR(0); std::string s = a[0].str(); for (auto& c : s) if (c >= 'A' && c <= 'Z') c += 32; return Value::string(s); }
-Value b_upper(ARGS) { NEED(1); STR(0); std::string s = a[0].str(); for (auto& c : s) if (c >= 'a' && c <= 'z') c -= 32; return Value::string(s); }
+// lower / upper: Go's strings.ToLower / ToUpper -- rune by rune, Unicode SIMPLE case mappings (unicode_case.inc)
+#include "unicode_case.inc"
+static uint32_t map_case(uint32_t cp, const uint32_t (*tab)[2], size_t n) {
+  size_t lo = 0, hi = n;
+  while (lo < hi) { size_t mid = (lo + hi) / 2; if (tab[mid][0] < cp) lo = mid + 1; else hi = mid; }
+  return lo < n && tab[lo][0] == cp ? tab[lo][1] : cp;
+}
+static void put_utf8(std::string* o, uint32_t cp) {
+  if (cp < 0x80) o->push_back((char)cp);
+  else if (cp < 0x800) { o->push_back((char)(0xC0 | (cp >> 6))); o->push_back((char)(0x80 | (cp & 0x3F))); }
+  else if (cp < 0x10000) { o->push_back((char)(0xE0 | (cp >> 12))); o->push_back((char)(0x80 | ((cp >> 6) & 0x3F))); o->push_back((char)(0x80 | (cp & 0x3F))); }
+  else { o->push_back((char)(0xF0 | (cp >> 18))); o->push_back((char)(0x80 | ((cp >> 12) & 0x3F))); o->push_back((char)(0x80 | ((cp >> 6) & 0x3F))); o->push_back((char)(0x80 | (cp & 0x3F))); }
+}
+static std::string map_case_string(const std::string& s, bool upper) {
+  const uint32_t (*tab)[2] = upper ? kSimpleUpper : kSimpleLower;
+  const size_t n = upper ? sizeof(kSimpleUpper) / sizeof(kSimpleUpper[0]) : sizeof(kSimpleLower) / sizeof(kSimpleLower[0]);
+  std::string o;
+  o.reserve(s.size());
+  for (size_t i = 0; i < s.size();) {
+    const unsigned char c = (unsigned char)s[i];
+    size_t len = c < 0x80 ? 1 : (c >> 5) == 6 ? 2 : (c >> 4) == 14 ? 3 : (c >> 3) == 30 ? 4 : 0;
+    bool ok = len != 0 && i + len <= s.size();
+    for (size_t k = 1; ok && k < len; k++) if (((unsigned char)s[i + k] & 0xC0) != 0x80) ok = false;
+    if (!ok) { o.push_back((char)c); i++; continue; }   // (not UTF-8: the byte passes through; JSON strings are UTF-8)
+    uint32_t cp = len == 1 ? c : len == 2 ? (c & 0x1F) : len == 3 ? (c & 0x0F) : (c & 0x07);
+    for (size_t k = 1; k < len; k++) cp = (cp << 6) | ((unsigned char)s[i + k] & 0x3F);
+    put_utf8(&o, map_case(cp, tab, n));
+    i += len;
+  }
+  return o;
+}
+Value b_lower(ARGS) { NEED(1); STR(0); return Value::string(map_case_string(a[0].str(), false)); }
+Value b_upper(ARGS) { NEED(1); STR(0); return Value::string(map_case_string(a[0].str(), true)); }
 Value b_trim(ARGS) { NEED(2); STR(0); STR(1); return Value::string(trim_set(a[0].str(), a[1].str(), true, true)); }
 Value b_trim_left(ARGS) { NEED(2); STR(0); STR(1); return Value::string(trim_set(a[0].str(), a[1].str(), true, false)); }
 Value b_trim_right(ARGS) { NEED(2); STR(0); STR(1); return Value::string(trim_set(a[0].str(), a[1].str(), false, true)); }
 Value b_trim_prefix(ARGS) { NEED(2); STR(0); STR(1); const std::string &s = a[0].str(), &p = a[1].str(); return Value::string(s.compare(0, p.size(), p) == 0 && s.size() >= p.size() ? s.substr(p.size()) : s); }
 Value b_trim_suffix(ARGS) { NEED(2); STR(0); STR(1); const std::string &s = a[0].str(), &p = a[1].str(); return Value::string(s.size() >= p.size() && s.compare(s.size() - p.size(), p.size(), p) == 0 ? s.substr(0, s.size() - p.size()) : s); }
-Value b_trim_space(ARGS) { NEED(1); STR(0); return Value::string(trim_set(a[0].str(), " \t\n\r\v\f", true, true)); }
+// trim_space: Go's strings.TrimSpace = TrimFunc(s, unicode.IsSpace) -- White_Space code points, not only ASCII
+static bool go_is_space(uint32_t cp) {
+  return (cp >= 0x09 && cp <= 0x0D) || cp == 0x20 || cp == 0x85 || cp == 0xA0 || cp == 0x1680 || (cp >= 0x2000 && cp <= 0x200A) || cp == 0x2028 || cp == 0x2029 ||
+         cp == 0x202F || cp == 0x205F || cp == 0x3000;
+}
+static bool decode_rune_at(const std::string& s, size_t i, uint32_t* cp, size_t* len) {   // false: not UTF-8 at i (the byte counts as itself)
+  const unsigned char c = (unsigned char)s[i];
+  size_t n = c < 0x80 ? 1 : (c >> 5) == 6 ? 2 : (c >> 4) == 14 ? 3 : (c >> 3) == 30 ? 4 : 0;
+  if (n == 0 || i + n > s.size()) { *cp = c; *len = 1; return false; }
+  uint32_t v = n == 1 ? c : n == 2 ? (c & 0x1F) : n == 3 ? (c & 0x0F) : (c & 0x07);
+  for (size_t k = 1; k < n; k++) { if (((unsigned char)s[i + k] & 0xC0) != 0x80) { *cp = c; *len = 1; return false; } v = (v << 6) | ((unsigned char)s[i + k] & 0x3F); }
+  *cp = v; *len = n;
+  return true;
+}
+Value b_trim_space(ARGS) {
+  NEED(1); STR(0);
+  const std::string& s = a[0].str();
+  size_t lo = 0, hi = s.size();
+  while (lo < hi) { uint32_t cp; size_t n; decode_rune_at(s, lo, &cp, &n); if (!go_is_space(cp)) break; lo += n; }
+  while (hi > lo) {
+    size_t st = hi - 1;
+    while (st > lo && ((unsigned char)s[st] & 0xC0) == 0x80 && hi - st < 4) st--;   // back to the rune's lead byte
+    uint32_t cp; size_t n;
+    decode_rune_at(s, st, &cp, &n);
+    if (st + n != hi) { st = hi - 1; cp = (unsigned char)s[st]; }                    // (not UTF-8: the last byte by itself)
+    if (!go_is_space(cp)) break;
+    hi = st;
+  }
+  return Value::string(s.substr(lo, hi - lo));
+}
 Value b_split(ARGS) {
   NEED(2); STR(0); STR(1);
   const std::string &s = a[0].str(), &d = a[1].str();

@@ -1435,7 +1435,8 @@ class PE {
         // that look at nothing but a scalar's value or a container's size: the flattener evaluates the expression on the
         // leaf's value, and hands a container leaf over as a placeholder of the same type and size
       static const std::set<std::string> scalar_fns = {"to_number", "replace", "substring", "lower", "upper", "trim", "trim_space", "trim_left", "trim_right",
-          "trim_prefix", "trim_suffix", "startswith", "endswith", "contains", "re_match", "regex.match", "indexof", "abs", "round", "ceil", "floor", "format_int"};
+          "trim_prefix", "trim_suffix", "startswith", "endswith", "contains", "re_match", "regex.match", "indexof", "abs", "round", "ceil", "floor", "format_int",
+          "concat" /* of a constant separator and the split() of the leaf */};
       SPath leaf; std::vector<DX> dx;
       if (scalar_fns.count(name) && same_leaf_args(a, &leaf, &dx)) { out.push_back({sv_derived(leaf, dx_node(DExpr::CALL, dx, name)), s}); return; }
     }

@@ -18,6 +18,23 @@ class BuiltinError(Exception):
     pass
 
 
+# Go's unicode.IsSpace (strings.TrimSpace): the White_Space code points -- not Python's str.isspace set (which adds U+001C..U+001F)
+_GO_SPACES = "\t\n\v\f\r \x85\xa0\u1680" + "".join(chr(c) for c in range(0x2000, 0x200B)) + "\u2028\u2029\u202f\u205f\u3000"
+
+
+def _go_case(s, fn):
+    """Go's strings.ToLower / ToUpper (OPA's lower / upper): rune by rune with the SIMPLE Unicode case mappings -- a code point
+    whose full mapping has several code points keeps itself (U+00DF), U+0130 lowers to 'i'; no context rules (final sigma)."""
+    out = []
+    for c in s:
+        if c == "\u0130" and fn is str.lower:
+            out.append("i")
+            continue
+        m = fn(c)
+        out.append(m if len(m) == 1 else c)
+    return "".join(out)
+
+
 def _need(v, *types):
     for t in types:
         if t == "number":
@@ -688,14 +705,14 @@ BUILTINS = {
     "contains": lambda s, sub: _need(sub, "string") in _need(s, "string"),
     "startswith": lambda s, p: _need(s, "string").startswith(_need(p, "string")),
     "endswith": lambda s, p: _need(s, "string").endswith(_need(p, "string")),
-    "lower": lambda s: _need(s, "string").lower(),
-    "upper": lambda s: _need(s, "string").upper(),
+    "lower": lambda s: _go_case(_need(s, "string"), str.lower),
+    "upper": lambda s: _go_case(_need(s, "string"), str.upper),
     "trim": b_trim,
     "trim_left": lambda s, c: _need(s, "string").lstrip(_need(c, "string")) if c else s,
     "trim_right": lambda s, c: _need(s, "string").rstrip(_need(c, "string")) if c else s,
     "trim_prefix": lambda s, p: s[len(p):] if _need(s, "string").startswith(_need(p, "string")) else s,
     "trim_suffix": lambda s, p: s[:len(s) - len(p)] if p and _need(s, "string").endswith(_need(p, "string")) else s,
-    "trim_space": lambda s: _need(s, "string").strip(" \t\n\r\v\f\x85\xa0"),
+    "trim_space": lambda s: _need(s, "string").strip(_GO_SPACES),
     "split": b_split, "replace": b_replace, "substring": b_substring, "indexof": b_indexof,
     "format_int": b_format_int,
     "strings.reverse": lambda s: _need(s, "string")[::-1],

@@ -158,3 +158,44 @@ violation[{"msg": msg}] {
     reviews = [D.AugmentedUnstructured(D.Unstructured(kobj("a", {"team": "t1", "xteam": "t2"})), None, "Original")]
     assert assert_parity(c, oc, reviews, D.GATOR_EP) == 1
     assert [r.msg for r in c.ReviewBatch(reviews, D.GATOR_EP)[0]] == ["team is t1"]
+
+
+# ---- string builtins on non-ASCII strings: Go works rune by rune -- upper / lower with the SIMPLE Unicode case mappings
+# (U+00DF keeps itself, U+0130 lowers to 'i', no final-sigma context), trim_space with unicode.IsSpace (U+00A0, U+3000 ..),
+# count / substring / indexof in runes.  Product (generated unicode_case.inc) vs oracle (per-code-point mapping): one source
+# of tables, so this pins the MECHANISM (rune-wise, simple mappings), not the Unicode version -- found by the fuzzer: the
+# product mapped ASCII only.
+UNI_REGO = '''package k
+violation[{"msg": msg}] {
+  s := input.review.object.s
+  msg := sprintf("U=%v L=%v n=%v sub=%v idx=%v ts=[%v] rep=%v cat=%v", [upper(s), lower(s), count(s), substring(s, 1, 2), indexof(s, "x"), trim_space(s), replace(s, "é", "e"), concat("|", split(s, "x"))])
+}
+violation[{"msg": msg}] {
+  upper(input.review.object.s) == "É"
+  msg := "upper is É"
+}
+violation[{"msg": msg}] {
+  lower(input.review.object.s) == "привет"
+  msg := "lower is привет"
+}
+violation[{"msg": msg}] {
+  count(input.review.object.s) > 3
+  startswith(lower(input.review.object.s), "é")
+  msg := "long and starts with é"
+}
+'''
+UNI_STRS = ["é", "ß", "İstanbul", "ΣΊΣΥΦΟΣ", "ǅ", "ſtraße", "Привет", "ＡＢc", "éxàx", "  é ", "日本語x", "a\U0001F600x", "ǰŉ", "é" * 5]
+
+
+@pytest.mark.parametrize("backend", ["hostemu", "hostemu-gen"])
+def test_unicode_string_builtins(backend):
+    c, oc = load_both(backend, [tmpl("K8sU", UNI_REGO)], [{"apiVersion": "constraints.gatekeeper.sh/v1beta1", "kind": "K8sU", "metadata": {"name": "c"}, "spec": {}}])
+    objs = [{"apiVersion": "v1", "kind": "Pod", "metadata": {"name": "o%d" % i, "namespace": "d"}, "s": s} for i, s in enumerate(UNI_STRS)]
+    reviews = [D.AugmentedUnstructured(D.Unstructured(o), None, "Original") for o in objs]
+    assert assert_parity(c, oc, reviews, D.GATOR_EP) >= len(objs)
+    msgs = [sorted(r.msg for r in g) for g in c.ReviewBatch(reviews, D.GATOR_EP)]
+    assert any(m.startswith("U=É L=é n=1 ") for m in msgs[0]) and "upper is É" in msgs[0]
+    assert any(m.startswith("U=ß L=ß ") for m in msgs[1])                       # no single-rune uppercase: stays (Go), not "SS"
+    assert any(m.startswith("U=İSTANBUL L=istanbul ") for m in msgs[2])
+    assert "lower is привет" in msgs[6]
+    assert any("ts=[é]" in m for m in msgs[9])                                  # the trailing U+00A0 is trimmed
