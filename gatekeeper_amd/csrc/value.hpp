@@ -41,7 +41,7 @@ struct Value {
   static Value integer(i128 x) { Value v; v.kind = Number; v.is_int = true; v.i = x; v.d = (double)x; return v; }
   static Value real(double x) {
     Value v; v.kind = Number;
-    if (std::isfinite(x) && std::floor(x) == x && std::fabs(x) < 1e30) { v.is_int = true; v.i = (i128)x; v.d = x; }
+    if (std::isfinite(x) && std::floor(x) == x && std::fabs(x) < 1e21) { v.is_int = true; v.i = (i128)x; v.d = x; }
     else { v.is_int = false; v.d = x; }
     return v;
   }
@@ -143,29 +143,27 @@ inline std::string i128_to_string(i128 x) {
   return s;
 }
 
-// Go fmt %v of a float64: strconv 'g' with shortest repr and exponent threshold 21.
-inline std::string go_float_v(double f) {
-  if (f != f) return "NaN";
-  if (std::isinf(f)) return f > 0 ? "+Inf" : "-Inf";
-  if (f == 0) return "0";
+// shortest round-trip decimal digits of f (finite, != 0): sign, digits without trailing zeros, decimal exponent of the first digit
+inline void shortest_digits(double f, std::string* sign, std::string* digits, int* x) {
   char buf[64];
-  int prec = 1;
-  for (; prec <= 17; prec++) { snprintf(buf, sizeof buf, "%.*e", prec - 1, f); if (strtod(buf, nullptr) == f) break; }
+  for (int prec = 1; prec <= 17; prec++) { snprintf(buf, sizeof buf, "%.*e", prec - 1, f); if (strtod(buf, nullptr) == f) break; }
   std::string r(buf);
-  size_t epos = r.find('e');
+  const size_t epos = r.find('e');
   std::string mant = r.substr(0, epos);
-  int x = atoi(r.c_str() + epos + 1);
-  std::string sign;
-  if (mant[0] == '-') { sign = "-"; mant = mant.substr(1); }
-  std::string digits;
-  for (char c : mant) if (c != '.') digits.push_back(c);
-  while (digits.size() > 1 && digits.back() == '0') digits.pop_back();
-  if (x < -4 || x >= 21) {
-    std::string m = digits.substr(0, 1);
-    if (digits.size() > 1) m += "." + digits.substr(1);
-    char e[16]; snprintf(e, sizeof e, "e%c%02d", x >= 0 ? '+' : '-', std::abs(x));
-    return sign + m + e;
-  }
+  *x = atoi(r.c_str() + epos + 1);
+  sign->clear();
+  if (mant[0] == '-') { *sign = "-"; mant = mant.substr(1); }
+  digits->clear();
+  for (char c : mant) if (c != '.') digits->push_back(c);
+  while (digits->size() > 1 && digits->back() == '0') digits->pop_back();
+}
+inline std::string float_e_form(const std::string& sign, const std::string& digits, int x) {
+  std::string m = digits.substr(0, 1);
+  if (digits.size() > 1) m += "." + digits.substr(1);
+  char e[16]; snprintf(e, sizeof e, "e%c%02d", x >= 0 ? '+' : '-', std::abs(x));
+  return sign + m + e;
+}
+inline std::string float_f_form(const std::string& sign, const std::string& digits, int x) {
   if (x >= 0) {
     if ((int)digits.size() <= x + 1) return sign + digits + std::string(x + 1 - digits.size(), '0');
     return sign + digits.substr(0, x + 1) + "." + digits.substr(x + 1);
@@ -173,7 +171,35 @@ inline std::string go_float_v(double f) {
   return sign + "0." + std::string(-x - 1, '0') + digits;
 }
 
-inline std::string num_to_string(const Value& v) { return v.is_int ? i128_to_string(v.i) : go_float_v(v.d); }
+// Go fmt %v of a float64 = strconv.FormatFloat(f, 'g', -1, 64): shortest digits, the %e form when the decimal exponent is
+// < -4 or >= 6 (with the shortest precision strconv's %g decision uses precision 6): 6e+11, 1.2345675e+06, 123456.5
+inline std::string go_float_v(double f) {
+  if (f != f) return "NaN";
+  if (std::isinf(f)) return f > 0 ? "+Inf" : "-Inf";
+  if (f == 0) return std::signbit(f) ? "-0" : "0";
+  std::string sign, digits; int x;
+  shortest_digits(f, &sign, &digits, &x);
+  return (x < -4 || x >= 6) ? float_e_form(sign, digits, x) : float_f_form(sign, digits, x);
+}
+
+// encoding/json's floatEncoder (the text a float64 of a review object carries as an ast.Number: objects reach OPA through
+// a JSON round trip): 'f' with the shortest digits; 'e' when abs < 1e-6 or abs >= 1e21, a one-digit negative exponent
+// without its leading zero (e-09 -> e-9)
+inline std::string json_float_text(double f) {
+  if (f != f || std::isinf(f)) return go_float_v(f);
+  if (f == 0) return std::signbit(f) ? "-0" : "0";
+  std::string sign, digits; int x;
+  shortest_digits(f, &sign, &digits, &x);
+  if (std::fabs(f) < 1e-6 || std::fabs(f) >= 1e21) {
+    std::string s = float_e_form(sign, digits, x);
+    const size_t n = s.size();
+    if (n >= 4 && s[n - 4] == 'e' && s[n - 3] == '-' && s[n - 2] == '0') s = s.substr(0, n - 2) + s[n - 1];
+    return s;
+  }
+  return float_f_form(sign, digits, x);
+}
+
+inline std::string num_to_string(const Value& v) { return v.is_int ? i128_to_string(v.i) : json_float_text(v.d); }   // ast.Number.String()
 
 // Go strconv.Quote (ast.String.String()).
 inline std::string go_quote(const std::string& s) {

@@ -365,7 +365,7 @@ def _go_arg(v):
     if _isnum(v):
         if isinstance(v, int):
             return ("int", v)
-        if v.is_integer() and abs(v) < 2 ** 63:
+        if v.is_integer() and abs(v) < 1e21:      # number text without exponent: Number.Int(), else big.Int.SetString
             return ("int", int(v))
         return ("float64", v)
     if isinstance(v, str):
@@ -697,7 +697,7 @@ BUILTINS = {
     "count": b_count, "sum": b_sum, "product": b_product, "max": b_max, "min": b_min, "sort": b_sort,
     "any": b_any, "all": b_all,
     "abs": lambda x: abs(_need(x, "number")),
-    "round": lambda x: int(math.floor(_need(x, "number") + 0.5)) if x >= 0 else -int(math.floor(-x + 0.5)),
+    "round": lambda x: int(math.floor(x + 0.5)) if _need(x, "number") >= 0 else -int(math.floor(-x + 0.5)),
     "ceil": lambda x: int(math.ceil(_need(x, "number"))),
     "floor": lambda x: int(math.floor(_need(x, "number"))),
     "sprintf": lambda f, a: go_sprintf(_need(f, "string"), _need(a, "array")),

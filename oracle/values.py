@@ -233,46 +233,73 @@ def quote(s):
 
 
 def num_to_string(n):
+    """ast.Number.String(): the number's JSON text.  Review objects reach OPA through encoding/json (util.RoundTrip with
+    UseNumber), so a float64 carries the text encoding/json's floatEncoder wrote for it."""
     if isinstance(n, int):
         return str(n)
     if math.isfinite(n) and n.is_integer() and abs(n) < 1e21:
         return str(int(n))
-    return go_float_v(n)
+    return json_float_text(n)
 
 
-def go_float_v(f):
-    """Go fmt %v for float64: strconv.FormatFloat(f, 'g', -1, 64) with exponent threshold 21."""
-    if f != f:
-        return "NaN"
-    if f in (float("inf"), float("-inf")):
-        return "+Inf" if f > 0 else "-Inf"
-    if f == 0:
-        return "0"
-    r = repr(f)  # shortest round-trip digits
+def _shortest_digits(f):
+    """(sign, digits, x): shortest round-trip decimal digits of f != 0 and the decimal exponent of the first one"""
+    r = repr(abs(f))
     mant, _, exp = r.partition("e")
-    sign = ""
-    if mant.startswith("-"):
-        sign, mant = "-", mant[1:]
     ip, _, fp = mant.partition(".")
-    if fp == "0":
-        fp = ""
-    digits = (ip + fp).lstrip("0") or "0"
     e10 = int(exp) if exp else 0
-    # decimal exponent of the first significant digit
     if ip.strip("0"):
         x = len(ip.lstrip("0")) - 1 + e10
     else:
-        lead = len(fp) - len(fp.lstrip("0"))
-        x = -(lead + 1) + e10
-    digits = digits.rstrip("0") or "0"
-    if x < -4 or x >= 21:
-        m = digits[0] + ("." + digits[1:] if len(digits) > 1 else "")
-        return "%s%se%s%02d" % (sign, m, "+" if x >= 0 else "-", abs(x))
+        x = -(len(fp) - len(fp.lstrip("0")) + 1) + e10
+    digits = (ip + fp).strip("0") or "0"
+    return ("-" if f < 0 else ""), digits, x
+
+
+def _fmt_e(sign, digits, x, min_exp_digits):
+    m = digits[0] + ("." + digits[1:] if len(digits) > 1 else "")
+    return "%s%se%s%0*d" % (sign, m, "+" if x >= 0 else "-", min_exp_digits, abs(x))
+
+
+def _fmt_f(sign, digits, x):
     if x >= 0:
         if len(digits) <= x + 1:
             return sign + digits + "0" * (x + 1 - len(digits))
         return sign + digits[: x + 1] + "." + digits[x + 1:]
     return sign + "0." + "0" * (-x - 1) + digits
+
+
+def json_float_text(f):
+    """encoding/json floatEncoder (Go standard library, restated): strconv 'f' with the shortest digits, 'e' when
+    abs < 1e-6 or abs >= 1e21, and a one-digit negative exponent written without its leading zero (e-09 -> e-9)."""
+    if f != f or f in (float("inf"), float("-inf")):
+        return go_float_v(f)      # (not representable in JSON; never reaches here from a document)
+    if f == 0:
+        return "-0" if math.copysign(1.0, f) < 0 else "0"
+    sign, digits, x = _shortest_digits(f)
+    if abs(f) < 1e-6 or abs(f) >= 1e21:
+        s = _fmt_e(sign, digits, x, 2)
+        if len(s) >= 4 and s[-4] == "e" and s[-3] == "-" and s[-2] == "0":
+            s = s[:-2] + s[-1]
+        return s
+    return _fmt_f(sign, digits, x)
+
+
+def go_float_v(f):
+    """Go fmt %v of a float64 = strconv.FormatFloat(f, 'g', -1, 64) (Go standard library, restated): shortest round-trip
+    digits; the %e form when the decimal exponent is < -4 or >= 6 (strconv/ftoa.go: with the shortest precision the %g
+    decision uses precision 6), exponent of at least two digits -- fmt.Println(6e11) prints 6e+11, 1234567.5 prints
+    1.2345675e+06, 123456.5 prints 123456.5."""
+    if f != f:
+        return "NaN"
+    if f in (float("inf"), float("-inf")):
+        return "+Inf" if f > 0 else "-Inf"
+    if f == 0:
+        return "-0" if math.copysign(1.0, f) < 0 else "0"
+    sign, digits, x = _shortest_digits(f)
+    if x < -4 or x >= 6:
+        return _fmt_e(sign, digits, x, 2)
+    return _fmt_f(sign, digits, x)
 
 
 def to_string(v):

@@ -199,3 +199,37 @@ def test_unicode_string_builtins(backend):
     assert any(m.startswith("U=İSTANBUL L=istanbul ") for m in msgs[2])
     assert "lower is привет" in msgs[6]
     assert any("ts=[é]" in m for m in msgs[9])                                  # the trailing U+00A0 is trimmed
+
+
+# number text in messages.  Two Go formatters are restated (product: value.hpp, oracle: values.py), pinned here on outputs
+# the Go standard library is known for: fmt.Println(6e11) -> 6e+11 and 1e6 -> 1e+06 (fmt %v = strconv 'g' shortest, %e form
+# from exponent 6), encoding/json writing 1e21 as 1e+21, 1e20 as 100000000000000000000, 1e-7 as 1e-7, 0.00001 as 0.00001
+NUM_REGO = '''package k
+violation[{"msg": msg}] {
+  v := input.review.object.n
+  is_number(v)
+  msg := sprintf("v=%v arr=%v", [v, [v]])
+}
+'''
+NUM_CASES = [
+    (6e11, "v=600000000000 arr=[600000000000]"),       # integral: Number.Int() succeeds on the JSON text, printed as an int
+    (1e20, "v=100000000000000000000 arr=[100000000000000000000]"),     # beyond int64: big.Int of the exponent-free text
+    (1e21, "v=1e+21 arr=[1e+21]"),                     # text has an exponent: float64 through %v; the term prints its text
+    (1234567.5, "v=1.2345675e+06 arr=[1234567.5]"),    # %v of a float64 vs the JSON text of the same number
+    (123456.5, "v=123456.5 arr=[123456.5]"),
+    (0.00001, "v=1e-05 arr=[0.00001]"),
+    (2.5e-7, "v=2.5e-07 arr=[2.5e-7]"),
+    (0.5, "v=0.5 arr=[0.5]"),
+    (2.0, "v=2 arr=[2]"),
+    (2 ** 53 + 1, "v=9007199254740993 arr=[9007199254740993]"),
+]
+
+
+@pytest.mark.parametrize("backend", ["hostemu", "hostemu-gen"])
+def test_number_text_in_messages(backend):
+    c, oc = load_both(backend, [tmpl("K8sNum", NUM_REGO)], [{"apiVersion": "constraints.gatekeeper.sh/v1beta1", "kind": "K8sNum", "metadata": {"name": "c"}, "spec": {}}])
+    objs = [{"apiVersion": "v1", "kind": "Pod", "metadata": {"name": "o%d" % i, "namespace": "d"}, "n": n} for i, (n, _) in enumerate(NUM_CASES)]
+    reviews = [D.AugmentedUnstructured(D.Unstructured(o), None, "Original") for o in objs]
+    assert assert_parity(c, oc, reviews, D.GATOR_EP) == len(objs)
+    for (n, want), got in zip(NUM_CASES, c.ReviewBatch(reviews, D.GATOR_EP)):
+        assert [r.msg for r in got] == [want], n

@@ -20,6 +20,7 @@ from parity_util import make_client
 
 KEYS = ["a", "b", "c"]
 ENVELOPE = False
+NUMERIC = False
 CONSTS = ['"x"', '"yy"', '"a-long-string-constant"', "1", "2", "true", "false", '""', "0"]
 # (string lengths around the row layout's boundaries: <= 7 bytes inline, <= 12 in the string header, longer in the heap)
 STRS = ['"x"', '"y"', '"a-"', '"long-string-constant"', '"ab"', '"-suffix"', '"0123456"', '"01234567"', '"b0123456789c"', '"tail-of-a-longer-string"', '"é"']
@@ -96,6 +97,20 @@ default_tier = "none"
 tier(x) = "gold" { x == "x" } else = "silver" { x == "yy" } else = default_tier
 '''
 
+def cond5(rng, var=None):
+    """numbers: arithmetic, to_number, rounding, mixed int / float compares"""
+    p = (var + "." + rng.choice(KEYS)) if var and rng.random() < 0.6 else scalar_path(rng)
+    k = rng.randint(0, 8)
+    if k == 0: return "%s * 2 %s %s" % (p, rng.choice(["<", ">=", "==", "!="]), rng.choice(["3", "4", "2.0", "3.0", "-2"]))
+    if k == 1: return "%s - 1 == %s" % (p, rng.choice(["0", "1", "0.5", "-2"]))
+    if k == 2: return "to_number(%s) %s %s" % (p, rng.choice(["<", ">", "=="]), rng.choice(["1", "2", "1.5"]))
+    if k == 3: return "round(%s) == %s" % (p, rng.choice(["2", "1", "0"]))
+    if k == 4: return "abs(%s) > %s" % (p, rng.choice(["0", "1", "1.5"]))
+    if k == 5: return "%s / 2 == %s" % (p, rng.choice(["1", "0.5", "0.75", "1.5"]))
+    if k == 6: return "%s %% 2 == %s" % (p, rng.choice(["0", "1"]))
+    if k == 7: return "%s == %s" % (p, rng.choice(["2.0", "1.0", "1e0", "1000000000000", "0.0", "-1"]))
+    return "count(%s) + 1 > %d" % (p, rng.randint(1, 3))
+
 def cond3(rng, var=None):
     k = rng.randint(0, 9)
     a = scalar_path(rng); b = scalar_path(rng, "input.review.oldObject")
@@ -130,6 +145,8 @@ def body(rng, helpers):
             stmts.append("count(s%d - {y | y := input.parameters.allowed[_]}) %s 0" % (len(stmts) - 1, rng.choice([">", "=="])))
         elif r < 0.75 and ENVELOPE:
             stmts.append(cond3(rng, var))
+        elif r < 0.5 and NUMERIC:
+            stmts.append(cond5(rng, var))
         elif r < 0.68:
             stmts.extend(x.strip() for x in cond4(rng, var).split(";"))
         elif r < 0.8:
@@ -162,6 +179,10 @@ def template(rng, i):
         text.append('violation[{"msg": msg}] {\n  %s\n}' % "\n  ".join(body(rng, helpers)))
     return "\n".join(text) + "\n"
 
+# numbers at the edges (numeric strings and near-numbers for to_number, -0, beyond 2^53, the exponent forms of number text)
+# and strings whose case mapping / white space is not ASCII
+NUMERIC_VALUES = ["1", "2.5", "1e3", " 3", "0x10", 0.5, -0.0, 3.999999, 2**53 + 1, 1e21, 1234567.5, 0.00001, 2.5e-7, "İ", "ǅx", "ß-suffix", "\u00a0x\u3000"]
+
 def rand_value(rng, depth=0):
     r = rng.random()
     if depth < 2 and r < 0.25:
@@ -170,7 +191,7 @@ def rand_value(rng, depth=0):
         return [rand_value(rng, depth + 1) for _ in range(rng.randint(0, 3))]
     return rng.choice(["x", "yy", "a-long-string-constant", "a-x", "", 0, 1, 2, 3, 1.5, True, False, None, "long-string-constant-a-",
                        "0123456", "01234567", "x01234567", "ab0123456789cab", "b0123456789c", "b0123456789cx", "xb0123456789c", "a-b0123456789c-suffix",
-                       "head-tail-of-a-longer-string", "tail-of-a-longer-string", "abababab", "ababababababab", "é", "aé-suffix", "x-suffix", -1, 2.0, 10**12])
+                       "head-tail-of-a-longer-string", "tail-of-a-longer-string", "abababab", "ababababababab", "é", "aé-suffix", "x-suffix", -1, 2.0, 10**12] + (NUMERIC_VALUES if NUMERIC else []))
 
 def rand_obj(rng, n):
     o = {"apiVersion": "v1", "kind": "Pod", "metadata": {"name": "o%d" % n, "namespace": "d"}}
@@ -207,9 +228,10 @@ def mk_reviews(wrap, objs, rng_seed):
         out.append(wrap.AugmentedReview(wrap.AdmissionRequest(req), None, "Original"))
     return out
 
-def run(backend, seed, n_templates, n_objs, envelope=False, verbose=False):
-    global ENVELOPE
+def run(backend, seed, n_templates, n_objs, envelope=False, verbose=False, numeric=False):
+    global ENVELOPE, NUMERIC
     ENVELOPE = envelope
+    NUMERIC = numeric
     rng = random.Random(seed)
     objs = [rand_obj(rng, i) for i in range(n_objs)]
     stats = {"ok": 0, "unsupported": 0, "diff": 0, "oracle_err": 0, "product_err": 0}
@@ -255,11 +277,12 @@ def run(backend, seed, n_templates, n_objs, envelope=False, verbose=False):
 
 
 @pytest.mark.parametrize("backend", ["hostemu", "hostemu-gen"])
-@pytest.mark.parametrize("seed,envelope", [(11, False), (12, False), (701, True)])
-def test_random_templates_agree_with_the_oracle(backend, seed, envelope):
+@pytest.mark.parametrize("seed,envelope,numeric", [(11, False, False), (12, False, False), (701, True, False), (7001, False, True)])
+def test_random_templates_agree_with_the_oracle(backend, seed, envelope, numeric):
     """envelope: AdmissionRequests (CREATE / UPDATE / DELETE, oldObject, userInfo) mixed with bare objects, and conditions that
-    compare review values with each other (object vs oldObject, element vs outside value)"""
-    stats, diffs = run(backend, seed, 70, 14, envelope=envelope)
+    compare review values with each other (object vs oldObject, element vs outside value); numeric: arithmetic / to_number /
+    round / abs conditions over numbers at the edges, printed into the messages"""
+    stats, diffs = run(backend, seed, 70, 14, envelope=envelope, numeric=numeric)
     assert not diffs, "product and oracle disagree:\n%s" % "\n-----\n".join("%s\n%s" % (d[0], d[1]) for d in diffs[:3])
     assert stats["oracle_err"] == 0 and stats["ok"] >= 50, stats      # the grammar stays inside what both sides implement
 
