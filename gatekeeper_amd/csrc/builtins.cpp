@@ -500,7 +500,17 @@ Value rego_arith(const std::string& op, const Value& a, const Value& b) {
     if (ii && a.i % b.i == 0) return Value::integer(a.i / b.i);
     return norm_num(a.as_double() / b.as_double());
   }
-  if (op == "%") { if (!ii || b.i == 0) return U; return Value::integer(a.i % b.i); }
+  if (op == "%") {   // builtinRem: both through NumberToInt (an integral float such as 1e21 IS an integer there), big.Int.Rem (truncated)
+    auto as_int = [](const Value& v, i128* o) {
+      if (v.is_int) { *o = v.i; return true; }
+      const double d = v.as_double();
+      if (!std::isfinite(d) || std::floor(d) != d || std::fabs(d) >= 1e38) return false;
+      *o = (i128)d; return true;
+    };
+    i128 x, y;
+    if (!as_int(a, &x) || !as_int(b, &y) || y == 0) return U;
+    return Value::integer(x % y);
+  }
   return U;
 }
 

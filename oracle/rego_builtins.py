@@ -774,9 +774,14 @@ def arith(op, a, b):
             return a // b
         return _norm(a / b)
     if op == "%":
-        if not (isinstance(a, int) and isinstance(b, int)):
+        # topdown/arithmetic.go builtinRem (OPA, restated): both operands through builtins.NumberToInt -- a number whose
+        # big.Float value is integral (2.0, -0.0, 1e21) IS an integer there -- then big.Int.Rem: exact, truncated division
+        # (the sign of the dividend)
+        if not (float(a).is_integer() and float(b).is_integer()) if isinstance(a, float) or isinstance(b, float) else False:
             raise BuiltinError("modulo on floating-point number")
+        a, b = int(a), int(b)
         if b == 0:
             raise BuiltinError("modulo by zero")
-        return int(math.fmod(a, b))
+        r = abs(a) % abs(b)
+        return -r if a < 0 else r
     raise BuiltinError("bad operator " + op)

@@ -233,3 +233,24 @@ def test_number_text_in_messages(backend):
     assert assert_parity(c, oc, reviews, D.GATOR_EP) == len(objs)
     for (n, want), got in zip(NUM_CASES, c.ReviewBatch(reviews, D.GATOR_EP)):
         assert [r.msg for r in got] == [want], n
+
+
+# `%` is builtinRem: operands through builtins.NumberToInt (an integral float -- 2.0, -0.0, 1e21 -- is an integer there, any
+# other float makes the expression undefined), then big.Int.Rem: exact beyond 2^53, truncated (sign of the dividend)
+REM_REGO = '''package k
+violation[{"msg": msg}] {
+  r := input.review.object.n % 2
+  msg := sprintf("r=%v", [r])
+}
+'''
+REM_CASES = [(2 ** 53 + 1, ["r=1"]), (-0.0, ["r=0"]), (2.0, ["r=0"]), (1e21, ["r=0"]), (-3, ["r=-1"]), (7, ["r=1"]), (2.5, []), ("3", []), (None, [])]
+
+
+@pytest.mark.parametrize("backend", ["hostemu", "hostemu-gen"])
+def test_modulo_takes_integral_numbers(backend):
+    c, oc = load_both(backend, [tmpl("K8sRem", REM_REGO)], [{"apiVersion": "constraints.gatekeeper.sh/v1beta1", "kind": "K8sRem", "metadata": {"name": "c"}, "spec": {}}])
+    objs = [{"apiVersion": "v1", "kind": "Pod", "metadata": {"name": "o%d" % i, "namespace": "d"}, "n": n} for i, (n, _) in enumerate(REM_CASES)]
+    reviews = [D.AugmentedUnstructured(D.Unstructured(o), None, "Original") for o in objs]
+    assert_parity(c, oc, reviews, D.GATOR_EP)
+    for (n, want), got in zip(REM_CASES, c.ReviewBatch(reviews, D.GATOR_EP)):
+        assert [r.msg for r in got] == want, n
