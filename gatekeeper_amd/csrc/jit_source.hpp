@@ -1,0 +1,98 @@
+// The text handed to hiprtc for a plan-specialised build of the dominant kernel (kernels.hip jit_build), and the
+// row-group geometry it is built for.  Host-only and free of HIP calls, so the GPU-less test build can produce the very
+// same text and put it through hiprtc in the build container (tests/test_jit_source.py): a plan whose generated source
+// does not compile for gfx950 is caught before it reaches a GPU box.
+#pragma once
+#include <algorithm>
+#include <cstdlib>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "codegen.hpp"
+#include "lower.hpp"
+#include "plan.hpp"
+
+namespace gk {
+
+constexpr size_t GK_LDS_PER_CU = 160 * 1024;
+
+// threads per row group of the plan-specialised kernel: the geometry table of plan.hpp, or GK_JIT_BLOCK (tuning aid: more
+// waves per group, e.g. 512 threads for 128-review groups = three 8-wave groups per CU)
+inline int jit_block_of(uint32_t rpt) {
+  static const int forced = getenv("GK_JIT_BLOCK") ? atoi(getenv("GK_JIT_BLOCK")) : 0;
+  if (forced >= (int)rpt && forced <= 1024 && forced % (int)rpt == 0 && forced % GK_TILE == 0) return forced;
+  return gk_block_of((int)rpt);
+}
+// static LDS of the dominant kernel for a row-group geometry (kernel_body.inc: two chunk-list buffers; the result words of
+// phase 2 alias one of them when they fit; the generic build also keeps the waves' loop bounds there).  res_k = 0: the
+// generic bytecode build.
+inline uint32_t list_cap_of(int block) { return (uint32_t)std::min(block / GK_TILE, 8) * GK_WAVE_CHUNKS; }
+inline size_t static_lds_of(uint32_t rpt, int block, uint32_t res_k) {
+  const size_t list = (size_t)list_cap_of(block) * 8;
+  const size_t masks = (size_t)(rpt / GK_TILE) * 3 * (res_k ? res_k : GK_MAX_RES) * 8;
+  const size_t bounds = res_k ? 0 : (size_t)(block / GK_TILE) * GK_MAX_SCOPES * 4;
+  return 2 * list + (masks <= list ? 8 : masks) + bounds + GK_TILE * 4 + 64;
+}
+inline size_t max_dyn_lds_of(uint32_t rpt) { return GK_LDS_PER_CU - static_lds_of(rpt, gk_block_of((int)rpt), 0) - 256; }
+inline size_t max_dyn_lds_jit(uint32_t rpt, uint32_t res_k) { return GK_LDS_PER_CU - static_lds_of(rpt, jit_block_of(rpt), res_k) - 256; }
+
+// plan_hpp / vm_core_hpp / kernel_body: plan.hpp, vm_core.hpp and kernel_body.inc as text (build/jit_sources.inc)
+inline std::string assemble_jit_source(const HostPlan& plan, uint32_t rpt, uint32_t rpp, const std::vector<uint64_t>* class_weight, const char* plan_hpp,
+                                       const char* vm_core_hpp, const char* kernel_body) {
+  std::string src =
+      "typedef unsigned char uint8_t; typedef unsigned short uint16_t; typedef unsigned int uint32_t; typedef unsigned long long uint64_t;\n"
+      "typedef short int16_t; typedef int int32_t; typedef long long int64_t;\n";
+  src += plan_hpp;
+  src += vm_core_hpp;
+  // a finished formula of the staged parts: one ballot -> the slot's word of this half (kernel_body.inc, s_masks)
+  src += "#define GK_RES_PROLOGUE const bool gk_l0 = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u;\n"
+         "#define GK_RES(kind, slot, b) do { const unsigned long long m_ = __ballot((b) != 0u); if (gk_l0) masks[(kind) * GK_RES_K + (slot)] = m_; } while (0)\n";
+  const int block = jit_block_of(rpt);
+  src += generate_plan_source(plan, (uint32_t)(block / GK_TILE / ((int)rpt / GK_TILE)), class_weight);
+  if (block != gk_block_of((int)rpt)) src += "#define GK_BLOCK_K " + std::to_string(block) + "\n";
+  {
+    // register budget: as many waves per SIMD as the LDS footprint lets groups be resident per CU (waves per SIMD =
+    // groups per CU x waves per group / 4 SIMDs); measured on configs[1] with 64-review groups: 7 waves (72 VGPRs) edges
+    // out 8 (64 VGPRs, twice the spill traffic) and clearly beats 5-6
+    const size_t per_group = (size_t)plan.dims.acc_words * rpp * 4 + static_lds_of(rpt, block, jit_res_k(plan));
+    const size_t groups_per_cu = std::max<size_t>(1, GK_LDS_PER_CU / per_group);
+    int waves = (int)std::min<size_t>(8, std::max<size_t>(block / 256, groups_per_cu * (block / GK_TILE) / 4));   // waves per SIMD the LDS allows
+    if (const char* w = getenv("GK_JIT_WAVES")) waves = atoi(w);   // tuning aid
+    src += "#define GK_TILES_BOUNDS __launch_bounds__(" + std::to_string(block) + ", " + std::to_string(waves) + ")\n";
+  }
+  {
+    // chunks per batch (= loads in flight per wave) in phase 1.  Measured on configs[2] (profiles/r02_prefetch_ad.log): the
+    // time to stream the rows does not depend on the depth (1..5) -- 0.111 ms with the row evaluation switched off in every
+    // case -- and every extra chunk in flight costs registers and moves: 0.1755 / 0.186 / 0.190 / 0.196 / 0.210 ms for 1..5.
+    // Phase 1 is bound by instruction issue, not by load latency: ONE chunk ahead.
+    int depth = 1;
+    if (const char* d = getenv("GK_JIT_PREFETCH")) depth = std::max(1, std::min(8, atoi(d)));   // tuning aid
+    src += "#define GK_PREFETCH " + std::to_string(depth) + "\n";
+  }
+  src += "#define GK_RPT_K " + std::to_string(rpt) + "\n#define GK_RPP_K " + std::to_string(rpp) + "\n";
+  if (const char* defs = getenv("GK_JIT_DEFINES")) {   // tuning aid: "A=1;B" -> #define A 1, #define B (kernel_body.inc variants)
+    std::string d = defs, item;
+    for (size_t i = 0; i <= d.size(); i++) {
+      if (i < d.size() && d[i] != ';') { item.push_back(d[i]); continue; }
+      if (!item.empty()) { size_t eq = item.find('='); src += "#define " + (eq == std::string::npos ? item : item.substr(0, eq) + " " + item.substr(eq + 1)) + "\n"; }
+      item.clear();
+    }
+  }
+  src += "namespace gk {\n#define GK_KERNEL_TILES gk_jit_tiles\n#define GK_KERNEL_BIG gk_jit_big\n#define GK_KERNEL_LINKAGE extern \"C\"\n#define GK_SKIP_BIG\n"
+         "#define GK_ROW_FN(r, i, ent, h, pv, heap, acc, on) jit_row(r, ent, h, heap, acc, on)\n#define GK_BIND_ALWAYS_STR 0\n"
+         "#define GK_FORMULA_FN(pv, acc, flags, rows, heap, bounds) jit_formulas(pv, acc, flags, rows, heap, bounds)\n";
+  if (const char* bf = getenv("GK_JIT_BODY_FILE")) {   // tuning aid: A/B a variant of kernel_body.inc without rebuilding the library
+    FILE* f = fopen(bf, "r");
+    if (!f) throw std::runtime_error(std::string("GK_JIT_BODY_FILE: cannot open ") + bf);
+    std::string body, line;
+    char buf[4096];
+    while (fgets(buf, sizeof buf, f)) { line = buf; if (line.rfind("#include", 0) != 0 && line.rfind("#pragma once", 0) != 0) body += line; }
+    fclose(f);
+    src += body;
+  } else src += kernel_body;
+  src += "}\n";
+  return src;
+}
+
+}  // namespace gk

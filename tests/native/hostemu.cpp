@@ -16,6 +16,8 @@
 
 #include "codegen.hpp"
 #include "device.hpp"
+#include "jit_source.hpp"
+#include "jit_sources.inc"   // kPlanHpp, kVmCoreHpp, kKernelBody (the text the product embeds)
 #include "vm_core.hpp"
 
 namespace gk {
@@ -368,6 +370,12 @@ static void emu_kernel_check(const DevPlan* p, const DevTable* dt, const EvalOpt
       const uint32_t c = b.ent & GK_DESC_ENT_MASK;
       if (c >= weight.size()) weight.resize(c + 1, 0);
       for (uint32_t g = 0; g < n_groups; g++) weight[c] += (t.tile_idx[(size_t)g * (t.n_slots() + 1) + b.slot + 1] - t.tile_idx[(size_t)g * (t.n_slots() + 1) + b.slot] + GK_TILE - 1) / GK_TILE;
+    }
+    if (const char* dir = getenv("GK_EMU_HIP_SOURCE_DIR")) {
+      // test aid (tests/test_jit_source.py): the text kernels.hip would hand to hiprtc for this plan, geometry and table
+      static int n_dumped = 0;
+      std::ofstream f(std::string(dir) + "/gk_plan_" + std::to_string(getpid()) + "_" + std::to_string(n_dumped++) + "_" + std::to_string(rpt) + "_" + std::to_string(rpp) + ".hip");
+      f << assemble_jit_source(hp, rpt, rpp, &weight, kPlanHpp, kVmCoreHpp, kKernelBody);
     }
     EmuJitLaunch fn = emu_jit_for(p, rpt, rpp, block, weight);
     fn(grid, (unsigned)block, lds, &pv, rows, shdr, cl.d.data(), cl.capg, t.rflags.data(), t.heap.data(), n, nt, hp.slots.data(), &out, 0u, rpp);

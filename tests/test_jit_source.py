@@ -1,0 +1,134 @@
+"""The text the product hands to hiprtc for a plan-specialised build of the dominant kernel (csrc/jit_source.hpp
+assemble_jit_source: prelude + plan.hpp + vm_core.hpp + generated jit_row / jit_formulas + kernel_body.inc), produced by
+the GPU-less test build for real plans, geometries and tables, and compiled HERE with the same hiprtc call the product
+makes on the device (--offload-arch=gfx950 -O3 -std=c++17; hiprtc needs no GPU).  A plan whose generated source does not
+compile for gfx950 -- a construct g++ accepts and the device compiler does not, a register / LDS budget the launch bounds
+cannot meet -- fails in the build container instead of on the GPU box.  Scratch use of the compiled kernel is reported by
+the code object's metadata and must be zero for the bench plan."""
+import ctypes
+import glob
+import hashlib
+import os
+
+import pytest
+
+from gatekeeper_amd import driver as D
+from gatekeeper_amd import synth
+
+
+def _hiprtc():
+    for name in ("libhiprtc.so", "/opt/rocm/lib/libhiprtc.so"):
+        try:
+            return ctypes.CDLL(name)
+        except OSError:
+            continue
+    return None
+
+
+def compile_gfx950(rtc, src):
+    """(ok, log, code) of hiprtcCompileProgram with the product's options (kernels.hip jit_build)"""
+    prog = ctypes.c_void_p()
+    assert rtc.hiprtcCreateProgram(ctypes.byref(prog), src.encode(), b"gk_plan.hip", 0, None, None) == 0
+    opts = (ctypes.c_char_p * 3)(b"--offload-arch=gfx950", b"-O3", b"-std=c++17")
+    rc = rtc.hiprtcCompileProgram(prog, 3, opts)
+    n = ctypes.c_size_t()
+    rtc.hiprtcGetProgramLogSize(prog, ctypes.byref(n))
+    log = ctypes.create_string_buffer(max(n.value, 1))
+    rtc.hiprtcGetProgramLog(prog, log)
+    code = b""
+    if rc == 0:
+        rtc.hiprtcGetCodeSize(prog, ctypes.byref(n))
+        buf = ctypes.create_string_buffer(n.value)
+        rtc.hiprtcGetCode(prog, buf)
+        code = buf.raw
+    rtc.hiprtcDestroyProgram(ctypes.byref(prog))
+    return rc == 0, log.value.decode(errors="replace"), code
+
+
+def _dump_sources(monkeypatch, tmp_path, build_and_eval, env=()):
+    monkeypatch.setenv("GK_HOSTEMU_KERNEL", "jit")
+    monkeypatch.setenv("GK_EMU_HIP_SOURCE_DIR", str(tmp_path))
+    monkeypatch.setenv("GK_EMU_GRID", "8")
+    for k, v in env:
+        monkeypatch.setenv(k, str(v))
+    build_and_eval()
+    texts = {}
+    for f in sorted(glob.glob(os.path.join(str(tmp_path), "gk_plan_*.hip"))):
+        t = open(f).read()
+        texts.setdefault(hashlib.sha1(t.encode()).hexdigest(), (os.path.basename(f), t))
+    assert texts, "the emulated evaluation produced no plan-specialised source"
+    return list(texts.values())
+
+
+def _bench_plan(n):
+    def run():
+        fx = synth.load_fixtures()
+        drv = D.Driver(device=0, hostemu=True)
+        client = D.Client(drv)
+        for t in synth.psp_templates(fx):
+            client.AddTemplate(t)
+        for k in synth.audit_constraints():
+            client.AddConstraint(k)
+        batch = synth.NativeBatch(drv.engine.lib, n, seed=synth.SEED, mixed=True, start=0, namespaces=synth.gen_namespaces())
+        table = drv.engine.create_table_native(batch.reviews, n, keep_docs=False, resident=True)
+        table.launch()
+        table.eval(download=True, collect_only=True)
+    return run
+
+
+def _scratch_bytes(code):
+    """.private_segment_fixed_size of gk_jit_tiles from the code object's msgpack metadata (note record), -1 if not found"""
+    i = code.find(b".private_segment_fixed_size")
+    if i < 0:
+        return -1
+    v = code[i + len(b".private_segment_fixed_size")]
+    if v < 0x80:
+        return v                                   # msgpack positive fixint
+    if v == 0xCC:
+        return code[i + len(b".private_segment_fixed_size") + 1]
+    if v == 0xCD:
+        return int.from_bytes(code[i + len(b".private_segment_fixed_size") + 1:][:2], "big")
+    if v == 0xCE:
+        return int.from_bytes(code[i + len(b".private_segment_fixed_size") + 1:][:4], "big")
+    return -1
+
+
+@pytest.mark.parametrize("rpt", [64, 256])
+def test_bench_plan_source_compiles_for_gfx950_without_scratch(monkeypatch, tmp_path, rpt):
+    """configs[2]'s plan (50 constraints of the PSP family) in the geometries the bench tables use"""
+    rtc = _hiprtc()
+    if rtc is None:
+        pytest.skip("libhiprtc.so is not installed")
+    for name, text in _dump_sources(monkeypatch, tmp_path, _bench_plan(1200), env=[("GK_RPT", rpt)]):
+        ok, log, code = compile_gfx950(rtc, text)
+        assert ok, "%s does not compile for gfx950:\n%s" % (name, log[-3000:])
+        assert b"gk_jit_tiles" in code
+        if rpt == 256:      # the bench tables' geometry (4 waves per SIMD, 128 VGPRs); 64-review groups run at 7-8 waves and do spill a little
+            assert _scratch_bytes(code) == 0, "%s: the plan-specialised kernel spills (%d bytes of scratch per lane)" % (name, _scratch_bytes(code))
+
+
+def _pattern_plans():
+    """the parity cases of the policy-compiler tests, run once more on the emulated plan-specialised kernel"""
+    import test_library_patterns as L
+    import test_pe_builtins as P
+    import test_root_scope as R
+
+    def run():
+        L.test_library_patterns_one_plan("hostemu")
+        L.test_library_patterns_second_batch("hostemu")
+        L.test_library_patterns_third_batch("hostemu")
+        R.test_values_compared_outside_iterations("hostemu")
+        P.test_string_tests_on_iterated_keys("hostemu")
+        P.test_definedness_of_opaque_builtin_results("hostemu")
+    return run
+
+
+def test_library_pattern_sources_compile_for_gfx950(monkeypatch, tmp_path):
+    """every construct of the policy compiler that reaches generated code: dictionary predicates, element scopes with value
+    slots, the root scope, key string tests, staged formulas of multi-group plans"""
+    rtc = _hiprtc()
+    if rtc is None:
+        pytest.skip("libhiprtc.so is not installed")
+    for name, text in _dump_sources(monkeypatch, tmp_path, _pattern_plans()):
+        ok, log, _ = compile_gfx950(rtc, text)
+        assert ok, "%s does not compile for gfx950:\n%s" % (name, log[-3000:])
