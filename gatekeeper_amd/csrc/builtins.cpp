@@ -6,6 +6,7 @@
 #include <cmath>
 #include <map>
 #include <mutex>
+#include <set>
 #include <unordered_map>
 
 #include "regex.hpp"
@@ -478,6 +479,25 @@ const std::map<std::string, Fn>& table() {
 }  // namespace
 
 bool has_builtin(const std::string& name) { return table().count(name) != 0; }
+
+// Names OPA v1 defines as builtins (topdown + ast/builtins.go; third-party, restated from the published builtin reference)
+// plus gatekeeper's own external_data.  A template calling one of these that this engine does not implement is VALID Rego:
+// it must be refused as unsupported (the stock driver keeps it), not rejected as a type error.  http.send is left out on
+// purpose: the reference deployment disables it (--disable-opa-builtin={http.send}) and pins the resulting
+// "undefined function http.send" (test/bats/test.bats:492-498).
+bool is_opa_builtin(const std::string& name) {
+  static const char* const families[] = {"io.jwt.", "crypto.", "graphql.", "time.", "net.", "urlquery.", "base64url.", "base64.", "hex.", "yaml.", "json.",
+                                         "providers.", "rego.", "opa.", "bits.", "units.", "semver.", "uuid.", "glob.", "graph.", "regex.", "strings.", "numbers.",
+                                         "object.", "array.", "rand."};
+  for (const char* f : families) if (name.rfind(f, 0) == 0) return true;
+  static const std::set<std::string> names = {
+      "abs", "ceil", "floor", "round", "count", "sum", "product", "max", "min", "sort", "all", "any", "and", "or", "intersection", "union", "concat", "contains",
+      "endswith", "format_int", "indexof", "indexof_n", "lower", "replace", "split", "sprintf", "startswith", "substring", "trim", "trim_left", "trim_prefix",
+      "trim_right", "trim_suffix", "trim_space", "upper", "re_match", "to_number", "cast_array", "cast_boolean", "cast_null", "cast_object", "cast_set",
+      "cast_string", "is_array", "is_boolean", "is_null", "is_number", "is_object", "is_set", "is_string", "type_name", "walk", "trace", "print", "external_data",
+      "set_diff"};
+  return names.count(name) != 0;
+}
 
 Value call_builtin(const std::string& name, const ValueVec& args) {
   auto it = table().find(name);

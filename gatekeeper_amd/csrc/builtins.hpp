@@ -7,6 +7,7 @@
 
 namespace gk {
 bool has_builtin(const std::string& name);
+bool is_opa_builtin(const std::string& name);   // a builtin of OPA (or gatekeeper) whether or not this engine implements it
 Value call_builtin(const std::string& name, const ValueVec& args);        // Undefined on error / unknown
 Value rego_arith(const std::string& op, const Value& a, const Value& b);  // + - * / % & | (numbers and sets)
 std::string go_sprintf(const std::string& fmt, const ValueVec& args);

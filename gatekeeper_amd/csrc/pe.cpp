@@ -1222,7 +1222,10 @@ class PE {
         if (find_rules(pkg, full.back())) { user = true; fpkg = pkg; fname = full.back(); }
       }
     }
-    if (!user && !has_builtin(name)) throw RegoError("rego_type_error: undefined function " + name);
+    if (!user && !has_builtin(name)) {
+      if (is_opa_builtin(name)) unsupported("builtin " + name + " is not implemented by this engine", t->line);
+      throw RegoError("rego_type_error: undefined function " + name);
+    }
     eval_seq(t->args, 0, {}, s, r, [&](const std::vector<SVP>& args, const State& s2) {
       if (user) { call_function(fpkg, fname, args, s2, r, out); return; }
       bool all_const = true;
@@ -1557,6 +1560,48 @@ Template::Template(const std::string& rego, const std::vector<std::string>& libs
       scan(r.key, vars, uses_data_);
       scan(r.value, vars, uses_data_);
     }
+  // every called name resolves at AddTemplate time, as OPA's compiler has it: a rule of this template, a builtin this
+  // engine implements, a builtin OPA defines (valid Rego that this engine refuses: unsupported) -- anything else is
+  // `rego_type_error: undefined function` whether or not an evaluation would reach the call
+  for (const Module& m : modules_) {
+    std::string pkg;
+    for (size_t i = 0; i < m.package.size(); i++) { if (i) pkg += "."; pkg += m.package[i]; }
+    std::function<void(const TermP&)> calls;
+    std::function<void(const Body&)> calls_body = [&](const Body& b) {
+      for (const Literal& l : b) {
+        const Literal* cur = &l;
+        while (cur->kind == Literal::Not) cur = cur->inner.get();
+        calls(cur->a); calls(cur->b); calls(cur->c);
+        if (cur->body) calls_body(*cur->body);
+      }
+    };
+    calls = [&](const TermP& t) {
+      if (!t) return;
+      calls(t->head); calls(t->head2);
+      for (auto& a : t->args) calls(a);
+      if (t->body) calls_body(*t->body);
+      if (t->kind != Term::Call || t->path.empty()) return;
+      std::string name;
+      for (size_t i = 0; i < t->path.size(); i++) { if (i) name += "."; name += t->path[i]; }
+      if (t->path.size() == 1 && rules_.count({pkg, t->path[0]})) return;
+      std::vector<std::string> full = t->path;
+      for (auto& imp : m.imports) if (imp.second == t->path[0]) { full = imp.first; full.insert(full.end(), t->path.begin() + 1, t->path.end()); break; }
+      if (full[0] == "data" && full.size() >= 2) {
+        std::string fp;
+        for (size_t i = 1; i + 1 < full.size(); i++) { if (i > 1) fp += "."; fp += full[i]; }
+        if (rules_.count({fp, full.back()})) return;
+      }
+      if (has_builtin(name)) return;
+      if (is_opa_builtin(name)) throw Unsupported("unsupported on the device plan: builtin " + name + " is not implemented by this engine (line " + std::to_string(t->line) + ")");
+      throw RegoError("rego_type_error: undefined function " + name);
+    };
+    for (const Rule& r : m.rules) {
+      for (auto& a : r.args) calls(a);
+      calls(r.key); calls(r.value);
+      calls_body(r.body);
+      for (auto& e : r.elses) { calls(e.first); calls_body(e.second); }
+    }
+  }
   // the scan above does not descend into comprehension bodies; a textual check is a sound over-approximation
   if (!uses_data_) {
     for (const std::string* src : {&rego}) if (src->find("data.inventory") != std::string::npos) uses_data_ = true;

@@ -192,8 +192,13 @@ class _Query:
             raise RegoEvalError("recursion too deep in %s" % name)
         try:
             res = _NONE
+            default = _NONE
             for r in rules:
                 if r["kind"] != "func" or len(r["args"]) != len(args):
+                    continue
+                if r["default"]:      # `default f(_) := v` (OPA >= 0.51): the value when no other definition is defined
+                    for v, _ in self.eval_term(r["value"], {}, r):
+                        default = v
                     continue
                 envs = [{}]
                 for p, a in zip(r["args"], args):
@@ -204,7 +209,7 @@ class _Query:
                         if res is not _NONE and not equal(res, v):
                             raise RegoEvalError("function %s produced conflicting outputs" % name)
                         res = v
-            return res
+            return default if res is _NONE else res
         finally:
             self.depth -= 1
 

@@ -254,3 +254,31 @@ def test_modulo_takes_integral_numbers(backend):
     assert_parity(c, oc, reviews, D.GATOR_EP)
     for (n, want), got in zip(REM_CASES, c.ReviewBatch(reviews, D.GATOR_EP)):
         assert [r.msg for r in got] == want, n
+
+
+# A builtin OPA defines and this engine does not implement is VALID Rego: the template is refused as unsupported (the cgo
+# shim keeps it on the stock driver) -- not rejected as a type error.  http.send is the exception the reference pins: its
+# deployment disables it and test/bats/test.bats:492-498 expects "undefined function http.send".  A name nobody defines is a
+# type error on both sides.
+def _call_template(call):
+    return tmpl("K8sCall", 'package k\nviolation[{"msg": msg}] {\n  s := input.review.object.s\n  %s\n  msg := "hit"\n}\n' % call)
+
+
+@pytest.mark.parametrize("call", ['glob.match("*.example.com", [], s)', 'units.parse_bytes(s) > 1000', 'net.cidr_contains("10.0.0.0/8", s)',
+                                  'time.now_ns() > 0', 'x := base64.decode(s)', 'walk(input.review.object, [p, v])', 'external_data({"provider": "p", "keys": [s]})'])
+def test_known_builtins_without_an_implementation_are_unsupported(call):
+    from parity_util import make_client
+    with pytest.raises(D.UnsupportedError, match="not implemented by this engine"):
+        make_client("hostemu").AddTemplate(_call_template(call))
+
+
+@pytest.mark.parametrize("call", ['http.send({"method": "get", "url": s})', 'no.such.function(s)', 'frobnicate(s)'])
+def test_undefined_functions_are_type_errors(call):
+    from parity_util import make_client
+    with pytest.raises(D.ClientError, match="rego_type_error: undefined function"):      # at AddTemplate, like OPA's compiler
+        make_client("hostemu").AddTemplate(_call_template(call))
+    from oracle.rego_interp import Interp, RegoEvalError
+    from oracle.values import from_json
+    ip = Interp([_call_template(call)["spec"]["targets"][0]["rego"]], data=None)       # (the oracle resolves names when it evaluates)
+    with pytest.raises(RegoEvalError, match="undefined function"):
+        ip.violations(from_json({"review": {"object": {"s": "x"}}, "parameters": {}}))
