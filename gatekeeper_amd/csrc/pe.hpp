@@ -19,7 +19,7 @@
 
 namespace gk {
 
-struct Unsupported : std::runtime_error { using std::runtime_error::runtime_error; };   // construct not compilable
+// (Unsupported -- valid Rego this engine refuses -- is declared next to RegoError in rego_ast.hpp: the parser throws it too)
 
 // ------------------------------------------------------------------------------------------------ formulas
 struct Step {

@@ -16,6 +16,7 @@
 namespace gk {
 
 struct RegoError : std::runtime_error { using std::runtime_error::runtime_error; };
+struct Unsupported : std::runtime_error { using std::runtime_error::runtime_error; };   // valid Rego this engine does not compile: GK_ERR_UNSUPPORTED, the stock driver keeps the template
 
 struct Term;
 typedef std::shared_ptr<const Term> TermP;

@@ -186,6 +186,7 @@ class Parser {
     r.line = peek().line;
     r.is_default = accept_kw("default");
     r.name = expect(Tok::Ident).text;
+    if (at_op(".")) throw Unsupported("unsupported on the device plan: a reference as rule head (line " + std::to_string(r.line) + ")");   // `a.b.c { .. }` (OPA >= 0.46)
     if (at_op("(")) {
       next();
       skip_nl();
@@ -284,7 +285,7 @@ class Parser {
     if (at_op(":=")) { next(); skip_nl(); l.kind = Literal::Assign; l.b = term(); }
     else if (at_op("=")) { next(); skip_nl(); l.kind = Literal::Unify; l.b = term(); }
     else l.kind = Literal::Expr;
-    if (at_kw("with")) fail(l.line, "`with` is not supported");
+    if (at_kw("with")) throw Unsupported("unsupported on the device plan: the `with` modifier (line " + std::to_string(l.line) + ")");
     return l;
   }
 

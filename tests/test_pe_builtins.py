@@ -282,3 +282,13 @@ def test_undefined_functions_are_type_errors(call):
     ip = Interp([_call_template(call)["spec"]["targets"][0]["rego"]], data=None)       # (the oracle resolves names when it evaluates)
     with pytest.raises(RegoEvalError, match="undefined function"):
         ip.violations(from_json({"review": {"object": {"s": "x"}}, "parameters": {}}))
+
+
+@pytest.mark.parametrize("rego,why", [
+    ('package k\nallowed { input.x == 1 }\nviolation[{"msg": "m"}] {\n  not allowed with input as {"x": 2}\n}\n', "`with` modifier"),
+    ('package k\nviolation[{"msg": "m"}] { a.b.c }\na.b.c { input.review.object.kind == "Pod" }\n', "reference as rule head"),
+])
+def test_valid_rego_the_parser_does_not_take_is_unsupported_not_a_syntax_error(rego, why):
+    from parity_util import make_client
+    with pytest.raises(D.UnsupportedError, match=why):
+        make_client("hostemu").AddTemplate(tmpl("K8sSyn", rego))
