@@ -1,6 +1,10 @@
 #!/bin/bash
 # Offline view of the plan-specialised kernel: assembles the same source text kernels.hip hands to hiprtc (generated
 # part from GK_PLAN_SOURCE_DUMP) and compiles it with hipcc for gfx950, printing register / LDS / occupancy figures.
+# (The EXACT text of a product build -- prelude, launch bounds and tuning defines as csrc/jit_source.hpp assembles them -- is
+# written by the GPU-less test build with GK_HOSTEMU_KERNEL=jit GK_EMU_HIP_SOURCE_DIR=<dir>, or on a GPU box with
+# GK_JIT_DUMP=<file>; tests/test_jit_source.py puts that text through hiprtc.  This script is the quick variant for A/B-ing
+# geometry / prefetch / body variants by hand.)
 # usage: [RPT=512 RPP=512 WAVES=4] tools/jit_offline.sh /tmp/plan_src.hip [outdir]   (dump the source with GK_PLAN_SOURCE_DUMP=... GK_PLAN_SOURCE_PARTS=2 for RPT >= 128)
 set -e
 gen=${1:-/tmp/plan_src.hip}; out=${2:-/tmp/jit_offline}; mkdir -p $out
