@@ -4,6 +4,7 @@
 // does not compile for gfx950 is caught before it reaches a GPU box.
 #pragma once
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <stdexcept>
 #include <string>
