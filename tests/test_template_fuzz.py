@@ -10,6 +10,7 @@ is a bug.  Device execution of plans is covered by the gpu-marked parity tests; 
 makes of Rego, so it runs on the CPU builds only."""
 import json
 import random
+import re
 
 import pytest
 
@@ -212,6 +213,32 @@ def tmpl(kind, rego):
     return {"apiVersion": "templates.gatekeeper.sh/v1", "kind": "ConstraintTemplate", "metadata": {"name": kind.lower()},
             "spec": {"crd": {"spec": {"names": {"kind": kind}}}, "targets": [{"target": "admission.k8s.gatekeeper.sh", "rego": rego}]}}
 
+def to_v1(rego):
+    """the same template in Rego v1 syntax (`contains` / `if`, `:=` in heads and else chains); goes with source.version "v1" """
+    out = []
+    for line in rego.split("\n"):
+        if line and not line[0].isspace() and not line.startswith(("package", "import", "}")):      # a rule head
+            line = re.sub(r'^violation\[(\{.*?\})\] \{', r'violation contains \1 if {', line)
+            line = re.sub(r' else = (\S+) \{', r' else := \1 if {', line)
+            line = re.sub(r' else = (\S+)$', r' else := \1', line)
+            m = re.match(r'^(\w+\([^)]*\)) = (\S+) \{', line)
+            if m:
+                line = "%s := %s if {%s" % (m.group(1), m.group(2), line[m.end():])
+            else:
+                m = re.match(r'^(\w+\([^)]*\)) \{', line)
+                if m:
+                    line = "%s if {%s" % (m.group(1), line[m.end():])
+                else:
+                    m = re.match(r'^(\w+) = (.*)$', line)
+                    if m and "{" not in line:
+                        line = "%s := %s" % (m.group(1), m.group(2))
+        out.append(line)
+    return "\n".join(out)
+
+def tmpl_v1(kind, rego):
+    return {"apiVersion": "templates.gatekeeper.sh/v1", "kind": "ConstraintTemplate", "metadata": {"name": kind.lower()},
+            "spec": {"crd": {"spec": {"names": {"kind": kind}}}, "targets": [{"target": "admission.k8s.gatekeeper.sh", "code": [{"engine": "Rego", "source": {"version": "v1", "rego": rego}}]}]}}
+
 def mk_reviews(wrap, objs, rng_seed):
     r = random.Random(rng_seed)
     out = []
@@ -228,7 +255,7 @@ def mk_reviews(wrap, objs, rng_seed):
         out.append(wrap.AugmentedReview(wrap.AdmissionRequest(req), None, "Original"))
     return out
 
-def run(backend, seed, n_templates, n_objs, envelope=False, verbose=False, numeric=False):
+def run(backend, seed, n_templates, n_objs, envelope=False, verbose=False, numeric=False, v1=False):
     global ENVELOPE, NUMERIC
     ENVELOPE = envelope
     NUMERIC = numeric
@@ -238,11 +265,14 @@ def run(backend, seed, n_templates, n_objs, envelope=False, verbose=False, numer
     diffs = []
     for i in range(n_templates):
         rego = template(rng, i)
+        mk = tmpl
+        if v1:
+            rego, mk = to_v1(rego), tmpl_v1
         kind = "K8sFuzz%d" % i
         params = {"p": rng.choice(["x", 1, True]), "q": rng.choice(["yy", 2]), "allowed": rng.sample(["x", "yy", 1, 2, True], 2), "rules": [{"k": rng.choice(KEYS), "v": rng.choice(["x", 1, "yy"])} for _ in range(rng.randint(0, 2))]}
         k = {"apiVersion": "constraints.gatekeeper.sh/v1beta1", "kind": kind, "metadata": {"name": "c"}, "spec": {"parameters": params}}
         try:
-            oc = OC.Client(); oc.add_template(tmpl(kind, rego)); oc.add_constraint(k)
+            oc = OC.Client(); oc.add_template(mk(kind, rego)); oc.add_constraint(k)
             want = []
             for rv in mk_reviews(OT, objs, seed):
                 try: want.append(sorted(r.msg for r in oc.review(rv, OC.GATOR_EP)))
@@ -252,7 +282,7 @@ def run(backend, seed, n_templates, n_objs, envelope=False, verbose=False, numer
             if verbose: print("ORACLE ERR", e, "\n", rego)
             continue
         try:
-            c = make_client(backend); c.AddTemplate(tmpl(kind, rego)); c.AddConstraint(k)
+            c = make_client(backend); c.AddTemplate(mk(kind, rego)); c.AddConstraint(k)
         except D.UnsupportedError as e:
             stats["unsupported"] += 1
             if verbose: print("UNSUPPORTED", str(e)[:100])
@@ -277,12 +307,13 @@ def run(backend, seed, n_templates, n_objs, envelope=False, verbose=False, numer
 
 
 @pytest.mark.parametrize("backend", ["hostemu", "hostemu-gen"])
-@pytest.mark.parametrize("seed,envelope,numeric", [(11, False, False), (12, False, False), (701, True, False), (7001, False, True)])
-def test_random_templates_agree_with_the_oracle(backend, seed, envelope, numeric):
+@pytest.mark.parametrize("seed,envelope,numeric,v1", [(11, False, False, False), (12, False, False, False), (701, True, False, False), (7001, False, True, False),
+                                                     (8101, False, True, True)])
+def test_random_templates_agree_with_the_oracle(backend, seed, envelope, numeric, v1):
     """envelope: AdmissionRequests (CREATE / UPDATE / DELETE, oldObject, userInfo) mixed with bare objects, and conditions that
     compare review values with each other (object vs oldObject, element vs outside value); numeric: arithmetic / to_number /
-    round / abs conditions over numbers at the edges, printed into the messages"""
-    stats, diffs = run(backend, seed, 70, 14, envelope=envelope, numeric=numeric)
+    round / abs conditions over numbers at the edges, printed into the messages; v1: the templates in Rego v1 syntax (source.version "v1")"""
+    stats, diffs = run(backend, seed, 70, 14, envelope=envelope, numeric=numeric, v1=v1)
     assert not diffs, "product and oracle disagree:\n%s" % "\n-----\n".join("%s\n%s" % (d[0], d[1]) for d in diffs[:3])
     assert stats["oracle_err"] == 0 and stats["ok"] >= 50, stats      # the grammar stays inside what both sides implement
 
