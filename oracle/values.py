@@ -10,7 +10,11 @@ The reference evaluates ConstraintTemplate Rego with OPA v1.17.1 (go.mod:19), wh
   * value equality (true != 1, 1 == 1.0),
   * `String()` rendering of composite terms used by sprintf("%v") -- pinned by the reference at
     website/docs/constrainttemplates.md:118 (`you must provide labels: {"gatekeeper"}`) and
-    test/gator/test/test.bats:241.
+    test/gator/test/test.bats:241,
+  * number text: a float64 of a review object prints as encoding/json wrote it (json_float_text), a float64
+    `sprintf` argument as fmt's %v (go_float_v) -- the Go standard library's two formatters, restated from their
+    documented behaviour; the reference holds no vector with a non-integral number in a message: "parity unpinned"
+    beyond the well-known outputs tests/test_pe_builtins.py lists.
 
 Python representation
   null -> None, boolean -> bool, number -> int | float, string -> str,
