@@ -457,12 +457,27 @@ int gk_template_add(gk_engine* e, const char* kind, const char* rego, const char
     for (size_t i = 0; i < nlibs; i++) ls.emplace_back(libs[i]);
     auto t = std::make_shared<Template>(rego, ls);
     std::unique_lock<std::shared_mutex> l(e->mu);
-    e->templates[lower_str(kind)] = t;
-    // constraints of this kind must be recompiled against the new template
-    for (auto& c : e->constraints)
-      if (c.alive && lower_str(c.kind) == lower_str(kind)) {
-        try { c.viol = t->compile(c.params, &e->next_quant); } catch (const std::exception&) { c.alive = false; }
-      }
+    // Constraints of this kind are recompiled against the new template -- violation formula AND the prepared form every
+    // plan is built from -- and put through the checks gk_constraint_add runs (referential template, lowering).  All or
+    // nothing: when one of them does not compile the old template and its constraints stay as they are and the caller
+    // gets the error (the reference reports it on the ConstraintTemplate's status and keeps serving the old one).
+    const std::string k = lower_str(kind);
+    struct Redo { ConstraintRec* c; FP viol; std::shared_ptr<const PreparedConstraint> prep; };
+    std::vector<Redo> redo;
+    for (auto& c : e->constraints) {
+      if (!c.alive || lower_str(c.kind) != k) continue;
+      if (t->references_inventory())
+        return fail(GK_ERR_UNSUPPORTED, "unsupported on the device plan: template " + c.kind + " is referential (reads data.inventory)");
+      Redo r{&c, t->compile(c.params, &e->next_quant), nullptr};
+      r.prep = prepare_constraint(r.viol, c.mf);
+      PlanBuilder pb(&e->dict, &e->dict_reg);
+      pb.add_constraint(r.prep);
+      PlanCaps caps;
+      pb.build(caps);
+      redo.push_back(std::move(r));
+    }
+    e->templates[k] = t;
+    for (auto& r : redo) { r.c->viol = std::move(r.viol); r.c->prep = std::move(r.prep); }
     e->plan_dirty = true;
     return GK_OK;
   } catch (const RegoError& ex) { return fail(GK_ERR_REGO, ex.what());

@@ -752,7 +752,9 @@ class PE {
                 some_bad = f_or(some_bad, close_states({bad}, c.s));
               }
             });
-            all = f_not(some_bad);
+            // the domain is bound before the quantifier runs (OPA rewrites `every x in <ref>` into `d = <ref>; every x in d`):
+            // over an UNDEFINED domain the expression is undefined, not vacuously true
+            all = f_and(defined_f(c.v), f_not(some_bad));
           }
           push_cond(c.s, all, out);
         }
