@@ -79,9 +79,12 @@ struct ShardInfo {
 };
 void dev_shard_setup(DevTable* t, DevComm* c, uint32_t nc, ShardInfo* info);   // collective: exchanges the shard sizes
 // after a finished local evaluation of the shard (dev_eval): int64 totals <- counts, in-place all-gather of the slots,
-// all-reduce (sum) of the totals, on the evaluation stream; then synchronises and copies what was asked for to the host
-void dev_shard_exchange(DevTable* t, DevComm* c, uint32_t nc, std::vector<int64_t>* totals, std::vector<uint64_t>* gathered /* may be null */,
-                        const void** d_gathered);
+// all-reduce (sum) of the totals, on the evaluation stream; then synchronises and copies what was asked for to the host.
+// totals: [nc] violating pairs | [nc] autoreject pairs (match errors) | reviews beyond the engine's limits | reviews not
+// evaluated (`not_evaluated` of this rank: rejected by HandleReview when the table was built), each summed over ALL shards --
+// what the gathered violation bitmaps cannot say, so that a sharded audit fails closed like the single-GPU one
+void dev_shard_exchange(DevTable* t, DevComm* c, uint32_t nc, uint64_t not_evaluated, std::vector<int64_t>* totals,
+                        std::vector<uint64_t>* gathered /* may be null */, const void** d_gathered);
 void dev_eval_launch(const DevPlan* p, const DevTable* t, const EvalOptions& opt);          // asynchronous on the default stream
 void dev_eval_finish(const DevPlan* p, const DevTable* t, const EvalOptions& opt, EvalOut* out);   // sync, overflow re-run, download
 

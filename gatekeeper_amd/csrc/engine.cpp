@@ -1232,8 +1232,12 @@ std::string query_results_json(gk_engine* e, gk_table* t, const gk_eval_out& ev,
       continue;
     }
     auto it = e->templates.find(lower_str(c.kind));
-    if (it == e->templates.end()) continue;
-    for (auto& v : it->second->render(doc.request, c.params, e->inventory)) {
+    // the device flagged this pair: a template that has gone, or a renderer that finds nothing, is a disagreement between
+    // the plan and the evaluator -- an error for the caller (Client.ReviewBatch treats it the same way), never "no results"
+    if (it == e->templates.end()) throw std::runtime_error("device / renderer disagree: constraint " + c.kind + "/" + c.name + " has no template");
+    const auto vs = it->second->render(doc.request, c.params, e->inventory);
+    if (vs.empty()) throw std::runtime_error("device / renderer disagree: the plan reports a violation of " + c.kind + "/" + c.name + " that the evaluator does not render");
+    for (auto& v : vs) {
       ValuePairs o{{Value::string("constraint"), Value::integer(cid)}, {Value::string("msg"), Value::string(v.msg)},
                    {Value::string("details"), v.details.defined() ? v.details : Value::object({})}};
       if (out.size() > 1) out += ",";
@@ -1319,7 +1323,7 @@ void gk_comm_destroy(gk_engine* e) { if (e && e->comm) { dev_comm_free(e->comm);
 struct ShardHolder {
   gk_shard_out pub;   // first member
   std::vector<uint32_t> ids, shard_reviews;
-  std::vector<int64_t> totals;
+  std::vector<int64_t> totals, err_totals;
   std::vector<uint64_t> gathered;
   uint64_t merged_slot = 0;
 };
@@ -1354,7 +1358,19 @@ int gk_table_sweep_sharded(gk_engine* e, gk_table* t, uint32_t flags, gk_shard_o
     const void* d_all = nullptr;
     const bool want_host = (flags & GK_SHARD_DOWNLOAD) != 0;
     std::vector<uint64_t> g0;
-    dev_shard_exchange(t->dev, e->comm, nc0, &h->totals, want_host ? &g0 : nullptr, &d_all);
+    // what the bitmaps cannot say travels with the totals (fail closed, like Client.AuditAggregate): autoreject pairs, reviews
+    // beyond the engine's limits, reviews HandleReview rejected when this shard was built
+    uint64_t rejected = 0;
+    for (const std::string& er : t->review_errors) if (!er.empty()) rejected++;
+    int64_t beyond = 0, not_eval = 0;
+    auto split = [&](std::vector<int64_t>& raw, uint32_t ncg, bool first) {   // raw: [ncg] pairs | [ncg] autoreject | beyond | not evaluated
+      h->err_totals.insert(h->err_totals.end(), raw.begin() + ncg, raw.begin() + 2 * (size_t)ncg);
+      beyond += raw[2 * (size_t)ncg];
+      if (first) not_eval = raw[2 * (size_t)ncg + 1];
+      raw.resize(ncg);
+    };
+    dev_shard_exchange(t->dev, e->comm, nc0, rejected, &h->totals, want_host ? &g0 : nullptr, &d_all);
+    split(h->totals, nc0, true);
     uint32_t nc = nc0;
     if (n_groups == 1) h->gathered.swap(g0);
     else {
@@ -1372,7 +1388,8 @@ int gk_table_sweep_sharded(gk_engine* e, gk_table* t, uint32_t flags, gk_shard_o
         std::vector<int64_t> tg;
         const void* d_g = nullptr;
         const uint32_t ncg = (uint32_t)e->extra[gi]->ids.size();
-        dev_shard_exchange(t->views[gi], e->comm, ncg, &tg, want_host ? &parts[gi + 1] : nullptr, &d_g);
+        dev_shard_exchange(t->views[gi], e->comm, ncg, rejected, &tg, want_host ? &parts[gi + 1] : nullptr, &d_g);
+        split(tg, ncg, false);
         h->totals.insert(h->totals.end(), tg.begin(), tg.end());
         ncs.push_back(ncg); slot_bytes.push_back(t->group_shards[gi].slot_bytes);
         nc += ncg;
@@ -1405,6 +1422,7 @@ int gk_table_sweep_sharded(gk_engine* e, gk_table* t, uint32_t flags, gk_shard_o
     p.gathered = h->gathered.empty() ? nullptr : h->gathered.data();
     p.d_gathered = d_all;
     p.kernel_ms = eo.kernel_ms; p.fast_kernel_ms = eo.fast_kernel_ms; p.n_overflow = eo.n_overflow;
+    p.err_totals = h->err_totals.data(); p.beyond_limits = beyond; p.not_evaluated = not_eval;
     *out = &h.release()->pub;
     return GK_OK;
   } catch (const Unsupported& ex) { return fail(GK_ERR_UNSUPPORTED, ex.what());
@@ -1651,6 +1669,9 @@ void gk_batcher_stop(gk_engine* e) {
   std::lock_guard<std::mutex> l(B.mu);
   B.workers.clear();
   B.running = false;
+  B.stop = false;
+  for (auto* r : B.queue) { r->status = GK_ERR_INVALID; r->error = "the admission batcher was stopped"; r->done = true; r->cv.notify_one(); }
+  B.queue.clear();
 }
 
 int gk_query(gk_engine* e, const gk_review_in* review, char** results_json, gk_query_stats* stats) {
@@ -1685,16 +1706,24 @@ int gk_query(gk_engine* e, const gk_review_in* review, char** results_json, gk_q
       }
     }
   }
-  if (!e->batcher.running) { int rc = gk_batcher_start(e, nullptr); if (rc != GK_OK) return rc; }
   gk_engine::Request req;
   req.in = review;
   req.arrived = std::chrono::steady_clock::now();
   gk_engine::Batcher& B = e->batcher;
-  {
+  for (;;) {
+    // enqueue only while workers that will serve the queue exist -- decided under the batcher's lock: a request queued
+    // between gk_batcher_stop's `stop = true` and the moment the workers have gone would wait for ever
     std::unique_lock<std::mutex> l(B.mu);
-    B.queue.push_back(&req);
-    B.cv.notify_all();
-    req.cv.wait(l, [&] { return req.done; });
+    if (B.running && !B.stop) {
+      B.queue.push_back(&req);
+      B.cv.notify_all();
+      req.cv.wait(l, [&] { return req.done; });
+      break;
+    }
+    if (B.stop) return fail(GK_ERR_INVALID, "the admission batcher is shutting down");
+    l.unlock();
+    int rc = gk_batcher_start(e, nullptr);
+    if (rc != GK_OK) return rc;
   }
   // render this review's results from its column of the batch's bitmaps -- in the caller's thread
   std::string results;
@@ -1703,7 +1732,8 @@ int gk_query(gk_engine* e, const gk_review_in* review, char** results_json, gk_q
       bool too_big = false;
       results = query_results_json(e, req.batch->table, *req.batch->ev, req.index, *review, &too_big);
       if (too_big) { req.status = GK_ERR_LIMIT; req.error = "review is beyond the engine's limits (more than 255 elements in an array that constraint predicates iterate, or an object where they iterate array elements)"; }
-    } catch (const std::exception& ex) { req.status = GK_ERR_REGO; req.error = ex.what(); }
+    } catch (const RegoError& ex) { req.status = GK_ERR_REGO; req.error = ex.what();
+    } catch (const std::exception& ex) { req.status = GK_ERR_INTERNAL; req.error = ex.what(); }
     req.batch.reset();
   }
   if (stats) {

@@ -102,6 +102,17 @@ def test(objs, client=None):
     returns an error (a bad template / constraint, data that cannot be added, a review the target handler rejects or
     that is beyond the engine's limits)."""
     c = client or D.Client(enforcement_points=(D.GATOR_EP,))
+    # The reference expands every object through the ExpansionTemplates / mutators in the input and reviews the resultants
+    # as well (pkg/gator/test/test.go:88-96,139-176, pkg/expansion).  Expansion is outside this engine's path (SURVEY.md
+    # section 8: the mutation system is out of scope): input that asks for it is refused -- the caller falls back to the
+    # reference's gator -- instead of silently yielding fewer results than the reference would.
+    for o in objs:
+        api, kind = str(o.get("apiVersion", "")), o.get("kind", "")
+        if kind == "ExpansionTemplate" and api.startswith("expansion.gatekeeper.sh/"):
+            raise GatorError("expansion unsupported: the input holds ExpansionTemplate %r (resultant resources are not generated by this engine)"
+                             % ((o.get("metadata") or {}).get("name", "")))
+        if api.startswith("mutations.gatekeeper.sh/") and kind in ("Assign", "AssignMetadata", "ModifySet", "AssignImage"):
+            raise GatorError("expansion unsupported: the input holds the mutator %s %r" % (kind, (o.get("metadata") or {}).get("name", "")))
     for o in objs:
         if is_template(o):
             try:
@@ -137,7 +148,10 @@ def test(objs, client=None):
 
 
 def results(rs):
-    """GatorResponses.Results(): by enforcement action, then message (a stable sort here; the reference's is not)"""
+    """GatorResponses.Results(): by enforcement action, then message.  Unpinned against the reference: Go's sort.Slice is
+    not stable (results that tie on both keys may come out in another order there -- compare as multisets), and the
+    reference's YAML output round-trips through JSON first (numbers become float64 / int64, nil metadata is dropped) while
+    this module dumps the Python objects as they are."""
     return sorted(rs, key=lambda r: (r.enforcement_action or "", r.msg or ""))
 
 

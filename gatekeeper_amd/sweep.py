@@ -31,6 +31,9 @@ class ShardedResult:
         self.shard_reviews = np.ctypeslib.as_array(o.shard_reviews, (self.world,)).copy()
         self.totals = np.ctypeslib.as_array(o.totals, (self.nc,)).copy() if self.nc else np.zeros(0, np.int64)
         self.kernel_ms, self.fast_kernel_ms, self.n_overflow = o.kernel_ms, o.fast_kernel_ms, o.n_overflow
+        # fail closed: autoreject pairs per constraint, reviews beyond the engine's limits, reviews HandleReview rejected -- over ALL shards
+        self.err_totals = np.ctypeslib.as_array(o.err_totals, (self.nc,)).copy() if self.nc else np.zeros(0, np.int64)
+        self.beyond_limits, self.not_evaluated = int(o.beyond_limits), int(o.not_evaluated)
         self.d_gathered = o.d_gathered
         self.gathered = None
         if o.gathered:
@@ -105,10 +108,12 @@ class ShardedSweep:
         dist.broadcast_object_list(ident, src=0)
         eng._check(eng.lib.gk_comm_init(eng.handle, ident[0], rank, world))
 
-    def sweep(self, steps=1, download=False):
+    def sweep(self, steps=1, download=False, strict=False):
         """`steps` passes of the hot path over the resident shard.  Single process: the launches are enqueued back to back and
         collected once -> EvalResult.  Sharded: every pass is local evaluation + the engine's exchange step -> ShardedResult
-        of the last pass."""
+        of the last pass.  A sharded result carries `beyond_limits` / `not_evaluated` / `err_totals` (summed over all shards):
+        objects the totals and bitmaps say nothing about.  strict=True raises driver.LimitError / driver.ReviewFailure for
+        them, as Client.AuditAggregate reports them for a single table (every rank raises: the counts are global)."""
         if self.dist is None:
             for _ in range(steps):
                 self.table.launch()
@@ -120,6 +125,11 @@ class ShardedSweep:
             flags = L.GK_SHARD_DOWNLOAD if (download and k == steps - 1) else 0
             eng._check(eng.lib.gk_table_sweep_sharded(eng.handle, self.table.handle, flags, C.byref(out)))
             res = ShardedResult(eng.lib, out)
+        if strict and res is not None:
+            if res.beyond_limits:
+                raise D.LimitError("%d object(s) of the sharded set are beyond the engine's limits: review them on the CPU driver" % res.beyond_limits)
+            if res.not_evaluated:
+                raise D.ReviewFailure(-1, "%d object(s) of the sharded set were rejected by HandleReview" % res.not_evaluated)
         return res
 
     def audit_lists(self, limit=20, msg_size=256):

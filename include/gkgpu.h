@@ -214,6 +214,12 @@ typedef struct {
   const void* d_gathered;            /* the same on the device, valid until the table's next sweep */
   float kernel_ms, fast_kernel_ms;
   uint32_t n_overflow;
+  /* Fail closed (pkg/audit/manager.go:622-625 logs and skips a failed Review; it never counts it as clean): what the
+   * violation bitmaps cannot say, summed over ALL shards by the same all-reduce.  A caller that wants the reference's
+   * answer reviews these objects on the stock driver. */
+  const int64_t* err_totals;         /* [n_constraints] autoreject pairs: Matcher.Match returned an error (one Result each) */
+  int64_t beyond_limits;             /* reviews a plan group could not evaluate (beyond the engine's limits; counted per plan group) */
+  int64_t not_evaluated;             /* reviews HandleReview rejected when their shard's table was built (GK_ERR_REVIEW) */
 } gk_shard_out;
 #define GK_SHARD_DOWNLOAD 1u
 int gk_table_sweep_sharded(gk_engine* e, gk_table* t, uint32_t flags, gk_shard_out** out);

@@ -22,7 +22,7 @@
 
 namespace gk {
 
-struct DevTable { HostTable t; int pending = 0; std::vector<uint64_t> last_viol; std::vector<uint8_t> shard_all; size_t shard_slot = 0; uint32_t shard_stride = 0, shard_nc = 0; };
+struct DevTable { HostTable t; int pending = 0; std::vector<uint64_t> last_viol, last_err, last_big; std::vector<uint8_t> shard_all; size_t shard_slot = 0; uint32_t shard_stride = 0, shard_nc = 0; };
 typedef void (*HeRowFn)(const Row*, uint32_t, uint32_t, const StrHdr*, const PlanView*, const uint8_t*, std::vector<uint32_t>*);
 typedef void (*HeFormFn)(const PlanView*, std::vector<uint32_t>*, uint32_t, const Row*, const uint8_t*, const uint32_t*, Results*);
 struct DevPlan {
@@ -178,12 +178,16 @@ void dev_shard_setup(DevTable* t, DevComm* c, uint32_t nc, ShardInfo* info) {
   t->shard_stride = stride; t->shard_slot = info->slot_bytes; t->shard_nc = nc;
   t->shard_all.assign((size_t)c->world * info->slot_bytes, 0);
 }
-void dev_shard_exchange(DevTable* t, DevComm* c, uint32_t nc, std::vector<int64_t>* totals, std::vector<uint64_t>* gathered, const void** d_gathered) {
+void dev_shard_exchange(DevTable* t, DevComm* c, uint32_t nc, uint64_t not_evaluated, std::vector<int64_t>* totals, std::vector<uint64_t>* gathered,
+                        const void** d_gathered) {
   if (t->shard_nc != nc || t->shard_all.empty()) throw std::runtime_error("dev_shard_exchange without dev_shard_setup");
   const uint32_t nt = (t->t.n_reviews + GK_TILE - 1) / GK_TILE;
   uint8_t* slot = t->shard_all.data() + (size_t)c->rank * t->shard_slot;
   memset(slot, 0, t->shard_slot);
-  std::vector<long long> tot(nc, 0);
+  std::vector<long long> tot(2 * (size_t)nc + 2, 0);   // [nc] pairs | [nc] autoreject pairs | beyond limits | not evaluated
+  for (uint32_t k = 0; k < nc; k++) for (uint32_t w = 0; w < nt; w++) tot[nc + k] += __builtin_popcountll(t->last_err[(size_t)k * nt + w]);
+  for (uint32_t w = 0; w < nt && w < t->last_big.size(); w++) tot[2 * (size_t)nc] += __builtin_popcountll(t->last_big[w]);
+  tot[2 * (size_t)nc + 1] = (long long)not_evaluated;
   for (uint32_t k = 0; k < nc; k++) {
     uint32_t cnt = 0;
     for (uint32_t w = 0; w < nt; w++) { const uint64_t v = t->last_viol[(size_t)k * nt + w]; memcpy(slot + ((size_t)k * t->shard_stride + w) * 8, &v, 8); cnt += (uint32_t)__builtin_popcountll(v); }
@@ -191,7 +195,7 @@ void dev_shard_exchange(DevTable* t, DevComm* c, uint32_t nc, std::vector<int64_
     tot[k] = cnt;
   }
   c->gather(c->ctx, t->shard_all.data(), t->shard_slot);
-  c->reduce(c->ctx, tot.data(), nc);
+  c->reduce(c->ctx, tot.data(), (uint32_t)tot.size());
   totals->assign(tot.begin(), tot.end());
   if (gathered) { gathered->resize(t->shard_all.size() / 8); memcpy(gathered->data(), t->shard_all.data(), t->shard_all.size()); }
   if (d_gathered) *d_gathered = t->shard_all.data();
@@ -243,6 +247,8 @@ void dev_eval_finish(const DevPlan* p, const DevTable* dt, const EvalOptions& op
   gk_op_counter = 0;
 #endif
   const_cast<DevTable*>(dt)->last_viol = o->viol;
+  const_cast<DevTable*>(dt)->last_err = o->err;
+  const_cast<DevTable*>(dt)->last_big = o->too_big;
   if (getenv("GK_HOSTEMU_KERNEL")) emu_kernel_check(p, dt, opt, *o);
   o->kernel_ms = o->fast_kernel_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }

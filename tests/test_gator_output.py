@@ -105,3 +105,9 @@ def test_bad_inputs_are_errors():
     orphan = {"apiVersion": "constraints.gatekeeper.sh/v1beta1", "kind": "K8sNoSuchTemplate", "metadata": {"name": "orphan"}, "spec": {}}
     with pytest.raises(G.GatorError, match="adding constraint 'orphan'"):
         run("hostemu", [orphan])
+    # expansion is outside this engine's path: input that needs it is refused, never answered with fewer results (test.go:88-96)
+    et = {"apiVersion": "expansion.gatekeeper.sh/v1alpha1", "kind": "ExpansionTemplate", "metadata": {"name": "expand-deployments"},
+          "spec": {"applyTo": [{"groups": ["apps"], "kinds": ["Deployment"], "versions": ["v1"]}], "templateSource": "spec.template",
+                   "generatedGVK": {"kind": "Pod", "group": "", "version": "v1"}}}
+    with pytest.raises(G.GatorError, match="expansion unsupported"):
+        run("hostemu", [et])
