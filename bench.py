@@ -14,6 +14,7 @@ Prints ONE JSON line on rank 0 (contract in the task description) with
   end_to_end    the PCIe-inclusive leg: host parse + HandleReview + flatten + H2D of the same objects (never `value`)
   cpu_baseline  the compiled restated-reference CPU loop (oracle/cpu_ref.cpp) on 1 thread and on all host cores
   parity_sample the device bitmap of the timed table compared with that CPU loop on a sample of the same objects
+  parity_python_oracle   ... and with the pure-Python oracle (no code shared with the product) on 65 536 of them
 """
 import argparse
 import json
@@ -59,11 +60,43 @@ def cpu_leg(templates, constraints, batch, ev, budget_s=10.0):
     base = {"value": n1 * nc / one["seconds"], "unit": "evals/s", "cores": 1, "kind": "port",
             "sample": "first %d of the same synthetic objects x %d constraints, compiled restated-reference CPU loop (oracle/cpu_ref.cpp: "
                       "per-object marshal, per-constraint re-decode + match.Matches + tree-walking Rego evaluation; the Go/OPA "
-                      "reference itself cannot be built here), %.1f s on 1 thread" % (n1, nc, one["seconds"]),
+                      "reference itself cannot be built here), %.1f s on 1 thread.  NOTE: the loop shape and match.Matches are "
+                      "restated in cpu_ref.cpp, but its JSON reader, HandleReview normalisation and Rego tree-walker are the "
+                      "PRODUCT's host objects (flatten.o / pe.o) -- this times the product's concrete evaluator inside the "
+                      "reference's loop, not OPA; the independent checker is parity_python_oracle" % (n1, nc, one["seconds"]),
             "all_cores": {"value": nall * nc / allc["seconds"], "cores": cores, "sample_reviews": nall, "seconds": allc["seconds"]}}
     parity = {"n": nall, "constraints": nc, "pairs_equal": equal, "device_violating_pairs": dev_pairs, "cpu_violating_pairs": cpu_pairs,
-              "checker": "oracle/cpu_ref.cpp (violation + autoreject bitmaps, bit for bit)"}
+              "checker": "oracle/cpu_ref.cpp (violation + autoreject bitmaps, bit for bit; Match layer independent, Rego evaluator = the "
+                         "product's host interpreter -- see parity_python_oracle for the fully independent leg)"}
     return base, parity
+
+
+def python_oracle_leg(templates, constraints, batch, ev, n=16384):
+    """The INDEPENDENT full-size parity leg: the pure-Python oracle (oracle/client.py -- its own JSON reader, HandleReview,
+    Match layer and Rego interpreter, no code shared with the product) evaluates the first `n` of the timed objects, taken as
+    JSON text from the batch, and its (constraint, object) pair sets must equal the device's violation and autoreject bitmaps."""
+    import numpy as np
+    from oracle import bench_leg as BL
+    n = min(n, batch.n)
+    n = n // 64 * 64 or n
+    texts = [(batch.json_text(i), batch.namespace_text(i)) for i in range(n)]
+    viol, err, seconds, procs = BL.python_oracle_pairs(templates, constraints, texts)
+    row_of = {int(cid): i for i, cid in enumerate(ev.constraint_ids)}
+    words = (n + 63) // 64
+
+    def dev_pairs(bm):
+        out = set()
+        for row, cid in enumerate(batch_constraint_ids):
+            bits = np.unpackbits(bm[row_of[cid]][:words].view(np.uint8), bitorder="little")[:n]
+            out.update((row, int(i)) for i in np.nonzero(bits)[0])
+        return out
+    dv, de = dev_pairs(ev.viol), dev_pairs(ev.err)
+    return {"n": n, "constraints": len(constraints), "pairs_equal": dv == viol and de == err, "device_violating_pairs": len(dv),
+            "oracle_violating_pairs": len(viol), "device_autoreject_pairs": len(de), "oracle_autoreject_pairs": len(err),
+            "only_device": len(dv - viol) + len(de - err), "only_oracle": len(viol - dv) + len(err - de),
+            "seconds": seconds, "processes": procs, "oracle_evals_per_s": n * len(constraints) / seconds if seconds > 0 else None,
+            "checker": "oracle/client.py: pure-Python restatement (json.loads of the batch's JSON text -> HandleReview -> match.Matches -> "
+                       "tree-walking Rego interpreter); shares no code with the product"}
 
 
 batch_constraint_ids = []
@@ -79,6 +112,7 @@ def main():
     ap.add_argument("--reviews", type=int, default=None, help="objects per GPU (weak) / in total (strong); default 1000000 (config 2), 100000 (config 1)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--oracle-sample", type=int, default=65536, help="objects of the timed table the pure-Python oracle re-evaluates (parity_python_oracle)")
     args = ap.parse_args()
     if args.reviews is None:
         args.reviews = {1: 100000, 2: 1000000, 4: 200000}[args.config]
@@ -222,6 +256,10 @@ def main():
             pass
         if not args.no_cpu_baseline:
             out["cpu_baseline"], out["parity_sample"] = cpu_leg(templates, defaulted, batch, final)
+            try:
+                out["parity_python_oracle"] = python_oracle_leg(templates, constraints, batch, final, args.oracle_sample)
+            except Exception as ex:   # the checker must not cost the bench line; an absent leg is visible as such
+                out["parity_python_oracle"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

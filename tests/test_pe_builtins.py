@@ -126,7 +126,7 @@ KEY_OBJS = [kobj("a", {"example.com/x": "ok", "example.com/y": "no", "other": "n
         kobj("c", {}, None, "bad"), kobj("d", ["example.com/a"], {"a/allowed": "corp"}, {"a": "bad"})]
 
 
-@pytest.mark.parametrize("backend", ["hostemu", "hostemu-gen"])
+@pytest.mark.parametrize("backend", BACKENDS)
 def test_string_tests_on_iterated_keys(backend):
     c, oc = load_both(backend, [tmpl(k, r) for k, r in KEY_T.items()],
                       [{"apiVersion": "constraints.gatekeeper.sh/v1beta1", "kind": k, "metadata": {"name": "x"}, "spec": {}} for k in KEY_T])
@@ -138,7 +138,7 @@ def test_string_tests_on_iterated_keys(backend):
     assert got[2] == got[3] == []
 
 
-@pytest.mark.parametrize("backend", ["hostemu", "hostemu-gen"])
+@pytest.mark.parametrize("backend", BACKENDS)
 def test_key_pinned_to_a_constant_still_takes_its_string_tests(backend):
     rego = '''package k
 violation[{"msg": msg}] {
@@ -187,7 +187,7 @@ violation[{"msg": msg}] {
 UNI_STRS = ["é", "ß", "İstanbul", "ΣΊΣΥΦΟΣ", "ǅ", "ſtraße", "Привет", "ＡＢc", "éxàx", "  é ", "日本語x", "a\U0001F600x", "ǰŉ", "é" * 5]
 
 
-@pytest.mark.parametrize("backend", ["hostemu", "hostemu-gen"])
+@pytest.mark.parametrize("backend", BACKENDS)
 def test_unicode_string_builtins(backend):
     c, oc = load_both(backend, [tmpl("K8sU", UNI_REGO)], [{"apiVersion": "constraints.gatekeeper.sh/v1beta1", "kind": "K8sU", "metadata": {"name": "c"}, "spec": {}}])
     objs = [{"apiVersion": "v1", "kind": "Pod", "metadata": {"name": "o%d" % i, "namespace": "d"}, "s": s} for i, s in enumerate(UNI_STRS)]
@@ -225,7 +225,7 @@ NUM_CASES = [
 ]
 
 
-@pytest.mark.parametrize("backend", ["hostemu", "hostemu-gen"])
+@pytest.mark.parametrize("backend", BACKENDS)
 def test_number_text_in_messages(backend):
     c, oc = load_both(backend, [tmpl("K8sNum", NUM_REGO)], [{"apiVersion": "constraints.gatekeeper.sh/v1beta1", "kind": "K8sNum", "metadata": {"name": "c"}, "spec": {}}])
     objs = [{"apiVersion": "v1", "kind": "Pod", "metadata": {"name": "o%d" % i, "namespace": "d"}, "n": n} for i, (n, _) in enumerate(NUM_CASES)]
@@ -246,7 +246,7 @@ violation[{"msg": msg}] {
 REM_CASES = [(2 ** 53 + 1, ["r=1"]), (-0.0, ["r=0"]), (2.0, ["r=0"]), (1e21, ["r=0"]), (-3, ["r=-1"]), (7, ["r=1"]), (2.5, []), ("3", []), (None, [])]
 
 
-@pytest.mark.parametrize("backend", ["hostemu", "hostemu-gen"])
+@pytest.mark.parametrize("backend", BACKENDS)
 def test_modulo_takes_integral_numbers(backend):
     c, oc = load_both(backend, [tmpl("K8sRem", REM_REGO)], [{"apiVersion": "constraints.gatekeeper.sh/v1beta1", "kind": "K8sRem", "metadata": {"name": "c"}, "spec": {}}])
     objs = [{"apiVersion": "v1", "kind": "Pod", "metadata": {"name": "o%d" % i, "namespace": "d"}, "n": n} for i, (n, _) in enumerate(REM_CASES)]

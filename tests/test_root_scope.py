@@ -87,7 +87,7 @@ def test_values_compared_outside_iterations(backend):
     assert rep[8] and not rep[9] and rep[10]      # 2 -> 3; 3.0 == 3; "3" != 3
 
 
-@pytest.mark.parametrize("backend", ["hostemu", "hostemu-gen"])
+@pytest.mark.parametrize("backend", BACKENDS)
 def test_composite_operands_are_refused_not_guessed(backend):
     """Rego's `==` between two review values is DEEP equality.  The plan compares type and payload: exact for scalars and for
     empty containers; for a non-empty container it would have to guess -- the review is refused (LimitError, the caller fails

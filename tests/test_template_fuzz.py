@@ -17,7 +17,7 @@ import pytest
 from gatekeeper_amd import driver as D
 from oracle import client as OC
 from oracle import target as OT
-from parity_util import make_client
+from parity_util import BACKENDS, make_client
 
 KEYS = ["a", "b", "c"]
 ENVELOPE = False
@@ -306,7 +306,9 @@ def run(backend, seed, n_templates, n_objs, envelope=False, verbose=False, numer
     return stats, diffs
 
 
-@pytest.mark.parametrize("backend", ["hostemu", "hostemu-gen"])
+# one plan per random template: the CPU builds and the device's bytecode kernel (no compile per plan); the plan-specialised
+# device kernel costs a hiprtc build per plan (~2 s) and takes the same templates TEN to a plan below
+@pytest.mark.parametrize("backend", [b for b in BACKENDS if b.id != "gpu"])
 @pytest.mark.parametrize("seed,envelope,numeric,v1", [(11, False, False, False), (12, False, False, False), (701, True, False, False), (7001, False, True, False),
                                                      (8101, False, True, True)])
 def test_random_templates_agree_with_the_oracle(backend, seed, envelope, numeric, v1):
@@ -353,7 +355,7 @@ violation[{"msg": msg}] {
 }
 
 
-@pytest.mark.parametrize("backend", ["hostemu", "hostemu-gen"])
+@pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("name", sorted(REGRESSIONS))
 def test_fuzz_regressions(backend, name):
     rego = REGRESSIONS[name]
@@ -391,7 +393,7 @@ violation[{"msg": msg}] {
         c.AddConstraint({"apiVersion": "constraints.gatekeeper.sh/v1beta1", "kind": "K8sX", "metadata": {"name": "c"}, "spec": {}})
 
 
-@pytest.mark.parametrize("backend", ["hostemu", "hostemu-gen"])
+@pytest.mark.parametrize("backend", BACKENDS)
 def test_random_constraint_sets_in_one_plan(backend):
     """a dozen random templates + constraints (random match blocks) loaded TOGETHER: common sub-formulas are shared across
     constraints, dictionary predicates of different templates meet on the same leaves, one launch answers all of them"""
@@ -427,3 +429,62 @@ def test_random_constraint_sets_in_one_plan(backend):
             want = sorted((r.constraint["kind"], r.msg) for r in oc.review(rv, OC.GATOR_EP))
             assert sorted((r.constraint["kind"], r.msg) for r in got[j]) == want, (g, j)
     assert n_loaded >= 30
+
+
+def run_batched(backend, seed, n_templates, n_objs, per_plan=10, envelope=False, numeric=False, v1=False):
+    """the templates of run(..) with the same seed, `per_plan` of them loaded into ONE client (one plan, one launch, and on
+    the device ONE hiprtc build of the generated source); compared with the oracle per template"""
+    global ENVELOPE, NUMERIC
+    ENVELOPE, NUMERIC = envelope, numeric
+    rng = random.Random(seed)
+    objs = [rand_obj(rng, i) for i in range(n_objs)]
+    cases = []
+    for i in range(n_templates):
+        rego, mk = template(rng, i), tmpl
+        if v1:
+            rego, mk = to_v1(rego), tmpl_v1
+        kind = "K8sFuzz%d" % i
+        params = {"p": rng.choice(["x", 1, True]), "q": rng.choice(["yy", 2]), "allowed": rng.sample(["x", "yy", 1, 2, True], 2), "rules": [{"k": rng.choice(KEYS), "v": rng.choice(["x", 1, "yy"])} for _ in range(rng.randint(0, 2))]}
+        cases.append((kind, mk(kind, rego), {"apiVersion": "constraints.gatekeeper.sh/v1beta1", "kind": kind, "metadata": {"name": "c"}, "spec": {"parameters": params}}, rego))
+    compared = loaded = 0
+    for lo in range(0, n_templates, per_plan):
+        c, oc, kinds = make_client(backend), OC.Client(), {}
+        for kind, t, k, rego in cases[lo:lo + per_plan]:
+            try:
+                c.AddTemplate(t)
+                c.AddConstraint(k)
+            except D.UnsupportedError:
+                c.RemoveTemplate(t)
+                continue
+            oc.add_template(t)
+            oc.add_constraint(k)
+            kinds[kind] = rego
+        loaded += len(kinds)
+        if not kinds:
+            continue
+        got = c.ReviewBatch(mk_reviews(D, objs, seed), D.GATOR_EP)
+        for j, rv in enumerate(mk_reviews(OT, objs, seed)):
+            if isinstance(got[j], Exception):
+                if isinstance(getattr(got[j], "cause", None), D.LimitError):
+                    continue      # refused (fail closed), never different
+                try:
+                    oc.review(rv, OC.GATOR_EP)
+                except Exception:
+                    continue      # HandleReview rejects it on both sides
+                raise AssertionError("review %d fails only on the product: %r" % (j, got[j]))
+            want = sorted((r.constraint["kind"], r.msg) for r in oc.review(rv, OC.GATOR_EP))
+            have = sorted((r.constraint["kind"], r.msg) for r in got[j])
+            assert have == want, "seed %d plan %d review %d:\n%s" % (seed, lo // per_plan, j, "\n-----\n".join(kinds[k_] for k_ in sorted({x[0] for x in set(have) ^ set(want)})))
+            compared += 1
+    return loaded, compared
+
+
+@pytest.mark.parametrize("backend", [b for b in BACKENDS if b.id in ("hostemu-gen", "gpu")])
+@pytest.mark.parametrize("seed,envelope,numeric,v1", [(11, False, False, False), (12, False, False, False), (701, True, False, False), (7001, False, True, False),
+                                                     (8101, False, True, True)])
+def test_random_templates_ten_to_a_plan(backend, seed, envelope, numeric, v1):
+    """The random templates of test_random_templates_agree_with_the_oracle, ten to a plan, through the GENERATED source: on
+    the MI355X that is the hiprtc build of the plan-specialised kernel (shifts, signed / unsigned compares, lane reads, LDS
+    atomics as the device compiler lowers them), in the build container the same text compiled by g++."""
+    loaded, compared = run_batched(backend, seed, 70, 14, envelope=envelope, numeric=numeric, v1=v1)
+    assert loaded >= 50 and compared >= 40, (loaded, compared)
