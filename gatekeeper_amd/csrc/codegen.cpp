@@ -67,31 +67,9 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts, const std
   o << "GK_CONST_ARRAY unsigned char gk_plan_consts[" << plan.cheap.size() << "] = {";
   for (size_t i = 0; i < plan.cheap.size(); i++) o << (i ? "," : "") << (int)plan.cheap[i];
   o << "};\n";
-  {   // accumulator words that must start at zero: everything but value-slot payloads
-    std::vector<std::pair<uint32_t, uint32_t>> zr;
-    uint32_t lo = 0;
-    for (const Scope& sc : plan.scopes) {
-      if (sc.nvals == 0 || sc.cap == 0) continue;
-      uint32_t stride = val_stride(sc.nvals);
-      if (sc.nvals == 1) {   // payload only (the type nibble lives in the element word)
-        if (sc.val_off > lo) zr.emplace_back(lo, sc.val_off);
-        lo = sc.val_off + sc.cap * stride;
-      } else {
-        for (uint32_t e = 0; e < sc.cap; e++) {   // [payload x nvals][type word]
-          uint32_t tw = sc.val_off + e * stride + sc.nvals * 2u;
-          if (e == 0 && sc.val_off > lo) zr.emplace_back(lo, sc.val_off);
-          zr.emplace_back(tw, tw + 1);
-        }
-        lo = sc.val_off + sc.cap * stride;
-      }
-    }
-    if (plan.dims.acc_words > lo) zr.emplace_back(lo, plan.dims.acc_words);
-    o << "#define GK_HAS_ZERO_RANGES 1\nconstexpr uint32_t GK_N_ZERO_RANGES = " << zr.size() << "u;\n"
-      << "GK_CONST_ARRAY uint32_t gk_zero_lo[" << zr.size() << "] = {";
-    for (size_t i = 0; i < zr.size(); i++) o << (i ? "," : "") << zr[i].first << "u";
-    o << "};\nGK_CONST_ARRAY uint32_t gk_zero_hi[" << zr.size() << "] = {";
-    for (size_t i = 0; i < zr.size(); i++) o << (i ? "," : "") << zr[i].second << "u";
-    o << "};\n";
+  {   // accumulator words that must start at zero: all of them (an empty value slot is id 0)
+    o << "#define GK_HAS_ZERO_RANGES 1\nconstexpr uint32_t GK_N_ZERO_RANGES = 1u;\n"
+      << "GK_CONST_ARRAY uint32_t gk_zero_lo[1] = {0u};\nGK_CONST_ARRAY uint32_t gk_zero_hi[1] = {" << plan.dims.acc_words << "u};\n";
   }
   // result slots kept per 64-review half and kind (kernel_body.inc GK_RES_K), and where each scope's element count lives
   o << "#define GK_RES_K " << jit_res_k(plan) << "\n#define GK_N_SCOPES_K " << plan.scopes.size() << "\n"
@@ -203,19 +181,14 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts, const std
       if (!g.always) hit = "(" + hit + ") != 0u";
       o << "      if (" << hit << ") {\n        const uint32_t ord = row_ordinal(r, " << g.level << "u);\n"
         << "        if (ord >= " << sc.cap << "u || (r.meta & ROW_ORD_OVERFLOW)) acc.or_word(0u, 1u);\n        else {\n";
-      std::string w0 = "0u";
-      for (const std::string& m : g.masks) if (m.back() == '0' && m[m.size() - 2] == '_') w0 = m;
       std::string extra;
-      // (a non-empty container cannot be compared by its payload: the review goes beyond the limits, vm_core.hpp P_STORE)
-      if (!g.stores.empty()) o << "          if ((t == T_OBJECT || t == T_ARRAY) && r.lo != 0u) acc.or_word(0u, 1u); else {\n";
+      // a stored value = the row's VALUE ID (plan.hpp); a row without one (non-empty container, stale table) or with the
+      // overflow id cannot be compared: the review goes beyond the limits (vm_core.hpp P_STORE)
+      if (!g.stores.empty()) o << "          const uint32_t vid = row_vid(r);\n          if (vid == 0u || vid >= GK_VID_OVERFLOW) acc.or_word(0u, 1u); else {\n";
       for (size_t i : g.stores) {
         const Pred& p = ps[i];
-        uint32_t stride = val_stride(sc.nvals);
-        o << "          { const uint32_t vb = " << sc.val_off << "u + ord * " << stride << "u;\n"
-          << "            acc.store_word(vb + " << p.bit * 2u << "u, r.lo); acc.store_word(vb + " << p.bit * 2u + 1u << "u, r.hi);\n";
-        if (sc.nvals == 1) extra += " | (val_nibble(r) << " + std::to_string(ELEM_NIBBLE_SHIFT) + "u)";
-        else o << "            acc.or_word(vb + " << sc.nvals * 2u << "u, val_nibble(r) << " << 4u * p.bit << "u);\n";
-        o << "          }\n";
+        if (scope_packed(sc)) extra += " | (vid << " + std::to_string(ELEM_VID_SHIFT) + "u)";
+        else o << "          acc.store_word(" << sc.val_off << "u + ord * " << val_stride(sc.nvals) << "u + " << p.bit << "u, vid);\n";
       }
       if (g.present) {
         if (g.level > 0 && g.level < (int)GK_LEVEL_ROOT) extra += " | 1u | (row_ordinal(r, " + std::to_string(g.level - 1) + "u) << 24)";
@@ -348,16 +321,13 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts, const std
         const Scope& B = plan.scopes[sb];
         int da = var_of(sa), db = var_of(sb);
         if (da < 0 || db < 0) throw Unsupported("codegen: join outside its loops");
-        uint32_t sa_ = val_stride(A.nvals), sb_ = val_stride(B.nvals);
-        auto nib = [&](const Scope& S, int d, const char* w, uint32_t slot) {
+        auto vid = [&](const Scope& S, int d, uint32_t slot) {
           std::ostringstream x;
-          if (S.nvals == 1) x << "(w" << d << " >> " << ELEM_NIBBLE_SHIFT << "u) & 15u";   // word0 of the loop's current element is in a register
-          else x << "(acc.load(" << w << " + " << S.nvals * 2u << "u) >> " << 4u * slot << "u) & 15u";
+          if (scope_packed(S)) x << "((w" << d << " >> " << ELEM_VID_SHIFT << "u) & " << GK_VID_OVERFLOW << "u)";   // word0 of the loop's current element is in a register
+          else x << "acc.load(" << S.val_off << "u + e" << d << " * " << val_stride(S.nvals) << "u + " << slot << "u)";
           return x.str();
         };
-        o << ind << "{ const uint32_t wa = " << A.val_off << "u + e" << da << " * " << sa_ << "u, wb = " << B.val_off << "u + e" << db << " * " << sb_ << "u;\n"
-          << ind << "  b" << a << " = (uint32_t)val_eq_quick(acc.load(wa + " << la * 2u << "u), acc.load(wa + " << la * 2u + 1u << "u), " << nib(A, da, "wa", la)
-          << ", acc.load(wb + " << lb * 2u << "u), acc.load(wb + " << lb * 2u + 1u << "u), " << nib(B, db, "wb", lb) << ", heap); }\n";
+        o << ind << "b" << a << " = (uint32_t)vid_eq(" << vid(A, da, la) << ", " << vid(B, db, lb) << ");\n";
         break;
       }
       case F_STE: {

@@ -186,6 +186,19 @@ bool DictRegistry::guarded(const PathDict& dict, uint32_t path_id) const {
   return false;
 }
 
+void DictRegistry::add_value(const Pattern& leaf) {
+  const std::string k = pattern_to_string(leaf);
+  std::unique_lock<std::shared_mutex> l(mu_);
+  for (auto& g : values_) if (g.first == k) return;
+  values_.emplace_back(k, leaf);
+  gen_++;   // tables flattened before this do not carry the ids: they are stale (engine.cpp dict_gen)
+}
+bool DictRegistry::valued(const PathDict& dict, uint32_t path_id) const {
+  std::shared_lock<std::shared_mutex> l(mu_);
+  for (const auto& g : values_) if (pattern_matches(g.second, dict, path_id)) return true;
+  return false;
+}
+
 // ------------------------------------------------------------------------------------------------ NsCache
 void NsCache::put(const std::string& name, const Value& ns) { std::unique_lock<std::shared_mutex> l(mu_); m_[name] = ns; }
 void NsCache::remove(const std::string& name) { std::unique_lock<std::shared_mutex> l(mu_); m_.erase(name); }
@@ -360,8 +373,55 @@ void Flattener::dict_row(uint32_t path, uint32_t meta, const Value& leaf) {
   if (mask) emit(d.dpath, (meta & ~(uint32_t)ROW_TYPE_MASK & ~(uint32_t)ROW_STR_INLINE) | T_INT, (uint32_t)mask, (uint32_t)(mask >> 32));
 }
 
+bool Flattener::value_wanted(uint32_t path) {
+  if (!reg_) return false;
+  if (path >= dict_paths_.size()) dict_paths_.resize((size_t)path * 2 + 64);
+  DictPath& d = dict_paths_[path];
+  if (d.vstate == 0) d.vstate = reg_->valued(*dict_, path) ? 2 : 1;
+  return d.vstate == 2;
+}
+
+// VALUE ID of a row (plan.hpp): equal ids <=> equal Rego values, within one review.  Numbers are interned by numeric value
+// (an integral float is the integer: 1 == 1.0), strings by their bytes (an inline string's payload IS its bytes; heap strings
+// compare hash, length and bytes), the five valueless kinds have fixed ids.  A non-empty container gets none (0): its
+// equality would need a deep comparison, the predicate that wants the id then refuses the review.
+uint32_t Flattener::value_id(uint32_t meta, uint32_t lo, uint32_t hi) {
+  const uint32_t t = meta & ROW_TYPE_MASK;
+  VidEnt want{0, 0, 0, 0};
+  switch (t) {
+    case T_NULL: return GK_VID_NULL;
+    case T_BOOL: return lo ? GK_VID_TRUE : GK_VID_FALSE;
+    case T_ARRAY: return lo == 0 ? GK_VID_EMPTY_ARRAY : 0u;
+    case T_OBJECT: return lo == 0 ? GK_VID_EMPTY_OBJECT : 0u;
+    case T_INT: want.tag = 1; want.key = ((uint64_t)hi << 32) | lo; break;
+    case T_FLOAT: {
+      const uint64_t bits = ((uint64_t)hi << 32) | lo;
+      double d;
+      memcpy(&d, &bits, 8);
+      if (d >= -9223372036854775808.0 && d < 9223372036854775808.0 && d == (double)(int64_t)d && !(meta & ROW_INEXACT)) { want.tag = 1; want.key = (uint64_t)(int64_t)d; }
+      else { want.tag = 2; want.key = bits; }
+      break;
+    }
+    case T_STRING:
+      if (meta & ROW_STR_INLINE) { want.tag = 3; want.key = ((uint64_t)hi << 32) | lo; }
+      else { uint32_t n; memcpy(&n, &t_->heap[lo - 4], 4); want.tag = 4; want.key = ((uint64_t)n << 32) | hi; want.off = lo; }
+      break;
+    default: return 0u;
+  }
+  for (const VidEnt& e : vids_) {
+    if (e.tag != want.tag || e.key != want.key) continue;
+    if (want.tag != 4 || e.off == want.off || memcmp(&t_->heap[e.off], &t_->heap[want.off], (size_t)(want.key >> 32)) == 0) return e.id;
+  }
+  want.id = GK_VID_FIRST + (uint32_t)vids_.size();
+  if (want.id >= GK_VID_OVERFLOW) return GK_VID_OVERFLOW;   // more distinct compared values than ids: the review is refused where one is needed
+  vids_.push_back(want);
+  return want.id;
+}
+
 void Flattener::emit(uint32_t path, uint32_t meta, uint32_t lo, uint32_t hi) {
-  stage_.push_back({path, Row{t_->n_reviews % t_->rpt, meta, lo, hi}, StrHdr{{0, 0, 0, 0}}});
+  uint32_t rev = t_->n_reviews % t_->rpt;
+  if (value_wanted(path)) rev |= value_id(meta, lo, hi) << ROW_VID_SHIFT;
+  stage_.push_back({path, Row{rev, meta, lo, hi}, StrHdr{{0, 0, 0, 0}}});
 }
 
 uint32_t Flattener::put_string(const std::string& s, uint32_t* hash) {
@@ -490,6 +550,7 @@ void Flattener::add(const ReviewDoc& doc, HostTable* out) {
   ctrs_.clear();
   ctr_touched_.clear();
   review_flags_ = 0;
+  vids_.clear();
   const Value& req = doc.request;
   // root + request members (input.review.*)
   emit(0, T_OBJECT, (uint32_t)req.size(), 0);
@@ -788,6 +849,7 @@ int Flattener::fast_value(uint32_t path, uint32_t ords, int adepth, uint32_t ext
       return -1;
     }
     stage_[row].row.lo = count;
+    if (count) stage_[row].row.rev &= ROW_REV_MASK;   // a NON-EMPTY container has no value id (emit saw it empty)
     if (count && guard_wanted(path)) review_flags_ |= RF_REFUSE;
     if (dict_wanted(path)) { ValuePairs ph; for (uint32_t k = 0; k < count; k++) ph.emplace_back(Value::integer((i128)k), Value::null()); dict_row(path, meta, Value::object(std::move(ph))); }
     return T_OBJECT;
@@ -817,6 +879,7 @@ int Flattener::fast_value(uint32_t path, uint32_t ords, int adepth, uint32_t ext
       return -1;
     }
     stage_[row].row.lo = count;
+    if (count) stage_[row].row.rev &= ROW_REV_MASK;   // a NON-EMPTY container has no value id (emit saw it empty)
     if (dict_wanted(path)) dict_row(path, meta, Value::array(ValueVec(count, Value::null())));
     return T_ARRAY;
   }
@@ -976,6 +1039,7 @@ int Flattener::add_json_request(const RawReview& r, const NsCache& cache, HostTa
   ctr_touched_.clear();
   scratch_keep_.clear();
   review_flags_ = 0;
+  vids_.clear();
   if (++review_gen_ == 0) { std::fill(ctr_gen_.begin(), ctr_gen_.end(), 0); review_gen_ = 1; }
   // 1. the envelope: spans of the members normalize_admission_request reads; anything else is dropped (Go decodes into a
   // struct) after a syntax check by the subtree parser
@@ -1121,6 +1185,7 @@ int Flattener::add_json(const RawReview& r, const NsCache& cache, HostTable* out
   ctr_touched_.clear();
   scratch_keep_.clear();
   review_flags_ = 0;
+  vids_.clear();
   if (++review_gen_ == 0) { std::fill(ctr_gen_.begin(), ctr_gen_.end(), 0); review_gen_ = 1; }
   const std::string op = r.operation ? r.operation : "";
   const bool del = op == "DELETE";   // target.go:151-154 + setObjectOnDelete: the object is both oldObject and object

@@ -96,11 +96,15 @@ class DictRegistry {
   // OBJECT there is refused (RF_REFUSE): Rego's `x[_]` would walk the object's values, the compiled plan would not.
   void add_guard(const Pattern& container);
   bool guarded(const PathDict& dict, uint32_t path_id) const;
+  // Compared values: leaf patterns whose rows the loaded constraints compare with other review values (P_STORE).  The
+  // flattener gives the rows of matching paths a VALUE ID (plan.hpp ROW_VID_*), unique per distinct value within the review.
+  void add_value(const Pattern& leaf);
+  bool valued(const PathDict& dict, uint32_t path_id) const;
  private:
   struct Pat { Pattern pat; std::string key; std::vector<DictEntry> entries; std::unordered_map<std::string, uint64_t> memo; };
   mutable std::shared_mutex mu_;
   std::vector<Pat> pats_;
-  std::vector<std::pair<std::string, Pattern>> guards_;
+  std::vector<std::pair<std::string, Pattern>> guards_, values_;
   uint64_t gen_ = 0;
 };
 
@@ -239,11 +243,16 @@ class Flattener {
   PathDict* dict_;
   const DictRegistry* reg_ = nullptr;
   uint64_t reg_gen_ = ~0ull;
-  struct DictPath { int state = 0; int gstate = 0; int pat = -1; std::vector<DictEntry> entries; uint32_t dpath = 0; std::unordered_map<std::string, uint64_t> memo; };   // state 0 unknown, 1 none, 2 has entries
+  struct DictPath { int state = 0; int gstate = 0; int vstate = 0; int pat = -1; std::vector<DictEntry> entries; uint32_t dpath = 0; std::unordered_map<std::string, uint64_t> memo; };   // state 0 unknown, 1 none, 2 has entries
   std::vector<DictPath> dict_paths_;
   void dict_row(uint32_t path, uint32_t meta, const Value& leaf);   // emits <leaf>.$d when some registered expression is true
   bool dict_wanted(uint32_t path);
   bool guard_wanted(uint32_t path);   // is `path` a container under which element predicates iterate? (cached per path)
+  bool value_wanted(uint32_t path);   // are the rows of `path` compared with other review values? (cached per path)
+  // per-review interning of compared values -> value ids (plan.hpp ROW_VID_*)
+  struct VidEnt { uint64_t key; uint32_t tag, off, id; };   // tag 1 number-as-int64, 2 float bits, 3 inline string, 4 heap string (key = hash32 | len << 32, off = heap offset)
+  std::vector<VidEnt> vids_;
+  uint32_t value_id(uint32_t meta, uint32_t lo, uint32_t hi);
   uint32_t id_object_, id_old_, id_m_, id_ns_;
   struct Ctr { uint32_t path, n; };
   std::vector<Ctr> ctrs_;

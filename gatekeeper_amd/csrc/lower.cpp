@@ -1262,6 +1262,8 @@ HostPlan PlanBuilder::build(const PlanCaps& caps) {
         Pattern prefix(pat.begin(), pat.begin() + i);
         if (seen.insert(pattern_to_string(prefix)).second) reg_->add_guard(prefix);
       }
+    // rows that are compared with other review values need VALUE IDS: the flattener assigns them on the registered paths
+    for (size_t i = 0; i < L.plan.preds.size(); i++) if (L.plan.preds[i].op == P_STORE) reg_->add_value(L.plan.pred_patterns[i]);
   }
   HostPlan& p = L.plan;
   {   // derived-bit prologue blocks first (inner blocks were completed, hence appended, before outer ones)
@@ -1285,8 +1287,10 @@ HostPlan PlanBuilder::build(const PlanCaps& caps) {
     sc.count_off = off++;
     sc.word_off = off;
     off += (uint32_t)sc.cap * sc.wpe;
-    sc.val_off = off;
-    off += (uint32_t)sc.cap * val_stride(sc.nvals);
+    // value slots hold VALUE IDS (plan.hpp): one word per slot and element -- or, for the usual scope with one joined value
+    // and a handful of element bits, bits [23:8] of the element word itself (no accumulator words of their own)
+    if (sc.nvals == 1 && nb <= ELEM_PACK_BITS) sc.val_off = GK_VAL_PACKED;
+    else { sc.val_off = off; off += (uint32_t)sc.cap * val_stride(sc.nvals); }
     p.scopes.push_back(sc);
   }
   p.dims.n_preds = (uint32_t)p.preds.size();

@@ -27,7 +27,7 @@ namespace gk {
 //   rflags[n_reviews]            RF_*: match-layer facts computed once by the flattener
 //   heap                         string bytes, 16-byte aligned zero-padded entries [u32 len][bytes]
 struct Row {
-  uint32_t rev;    // review index within its row group (0 .. rpt-1)
+  uint32_t rev;    // [8:0] review index within its row group (0 .. rpt-1) | [31:9] VALUE ID of the row (see ROW_VID_* below), 0 = none
   uint32_t meta;   // see ROW_* below
   uint32_t lo;     // value payload
   uint32_t hi;
@@ -55,6 +55,19 @@ constexpr uint32_t GK_DESC_ENT_SHIFT = 6;
 constexpr uint32_t GK_DESC_ENT_MASK = 0x01FFFFFFu;   // of info >> GK_DESC_ENT_SHIFT: path-table entry (first << 8 | count) or class id
 constexpr uint32_t GK_DESC_NEEDS_STR = 1u << 25;     // of info >> GK_DESC_ENT_SHIFT: some predicate of the class reads string bytes
 constexpr uint32_t GK_LIST_OVERFLOW = 1u;            // header: the group has more chunks than a list holds -> its reviews take the big path
+
+// VALUE IDS.  Rows that the loaded constraints compare with OTHER review values (Rego `==` between two review values: joins
+// between array elements, object vs oldObject ...) carry an id that is unique per distinct Rego value WITHIN THEIR REVIEW:
+// the flattener interns the review's compared values (numbers by numeric value -- 1 == 1.0 --, strings by bytes, null / true
+// / false / empty array / empty object by kind), so that equality on the device is ONE integer compare, exact, with no
+// payload, type or heap access.  0 = the row carries no id (its path is not compared, or it is a non-empty container, whose
+// equality would need a deep comparison): a predicate that wants one flags the review beyond the engine's limits.
+// GK_VID_OVERFLOW = the review holds more distinct compared values than ids: same treatment.
+constexpr uint32_t ROW_REV_MASK = 0x1FFu;        // GK_RPT_MAX = 512 reviews per group
+constexpr uint32_t ROW_VID_SHIFT = 9;
+constexpr uint32_t GK_VID_BITS = 16;             // ids fit the element word (Scope::val_off == GK_VAL_PACKED)
+constexpr uint32_t GK_VID_OVERFLOW = (1u << GK_VID_BITS) - 1u;
+constexpr uint32_t GK_VID_NULL = 1, GK_VID_FALSE = 2, GK_VID_TRUE = 3, GK_VID_EMPTY_ARRAY = 4, GK_VID_EMPTY_OBJECT = 5, GK_VID_FIRST = 6;
 
 enum RowType : uint32_t { T_NULL = 0, T_BOOL = 1, T_INT = 2, T_FLOAT = 3, T_STRING = 4, T_OBJECT = 5, T_ARRAY = 6 };
 
@@ -148,12 +161,14 @@ static_assert(sizeof(Pred) == 32, "Pred must be 32 bytes");
 
 struct Scope {
   uint32_t word_off;   // first accumulator word (per review) of this scope's element words
-  uint32_t val_off;    // first accumulator word of value slots
+  uint32_t val_off;    // first accumulator word of value slots; GK_VAL_PACKED: the scope's single slot lives in the element word
   uint32_t count_off;  // accumulator word holding max ordinal + 1
   uint16_t cap;        // element capacity in this variant
-  uint8_t nvals;       // value slots per element: the element's value block is [lo, hi] x nvals + one type word
+  uint8_t nvals;       // value slots per element: one word each, holding the stored row's VALUE ID (0 = empty)
   uint8_t wpe;         // accumulator words per element
 };
+constexpr uint32_t GK_VAL_PACKED = 0xFFFFFFFFu;   // one value slot, <= 8 element bits: the id sits in bits [23:8] of element word 0
+constexpr uint32_t ELEM_VID_SHIFT = 8;
 
 // ------------------------------------------------------------------------------------------------ formulas
 // Phase 2: one lane per review runs this wave-uniform bytecode over the accumulators. 64 boolean registers.

@@ -338,20 +338,21 @@ GK_HD bool pred_needs_str(const Pred& p) {
   }
 }
 
-// type nibble of a stored join value: (type + 1) | inline-string flag << 3   (0 = slot empty)
-GK_HD uint32_t val_nibble(const Row& r) { return ((r.meta & ROW_TYPE_MASK) + 1u) | ((r.meta & ROW_STR_INLINE) ? 8u : 0u); }
+GK_HD uint32_t row_vid(const Row& r) { return r.rev >> ROW_VID_SHIFT; }   // the row's value id (plan.hpp), 0 = none
 
 // Accumulator word index helpers ----------------------------------------------------------------------------
 // global bit g lives in word g>>5. Global bit 0 is reserved: ELEMENT OVERFLOW (an ordinal >= scope capacity).
 constexpr uint32_t GBIT_OVERFLOW = 0;
-// element word layout: word0 = [0] present | [1..19] leaf bits | [23:20] type nibble of the scope's join value (when it
-// has exactly one) | [31:24] parent ordinal; leaf bits >= 20 spill to word 1+
+// element word layout: word0 = [0] present | [1..19] leaf bits | [31:24] parent ordinal; leaf bits >= 20 spill to word 1+.
+// A scope with ONE value slot and at most 8 element bits keeps the slot's value id in bits [23:8] of word0
+// (Scope::val_off == GK_VAL_PACKED): a join then reads nothing but the element words its loops hold in registers.
 constexpr uint32_t ELEM_W0_BITS = 20;
-constexpr uint32_t ELEM_NIBBLE_SHIFT = 20;
+constexpr uint32_t ELEM_PACK_BITS = 8;     // element bits (present included) a scope may use and still pack its value id
 GK_HD uint32_t elem_word_of_bit(uint32_t bit) { return bit < ELEM_W0_BITS ? 0 : 1 + ((bit - ELEM_W0_BITS) >> 5); }
 GK_HD uint32_t elem_mask_of_bit(uint32_t bit) { return bit < ELEM_W0_BITS ? (1u << bit) : (1u << ((bit - ELEM_W0_BITS) & 31)); }
-// value block of an element: [lo, hi] per slot; the type nibbles live in word0 (one slot) or in one extra word
-GK_HD uint32_t val_stride(uint32_t nvals) { return nvals <= 1 ? nvals * 2u : nvals * 2u + 1u; }
+// value slots of an element: one word each (the stored row's value id), unless packed into the element word
+GK_HD uint32_t val_stride(uint32_t nvals) { return nvals; }
+GK_HD bool scope_packed(const Scope& sc) { return sc.val_off == GK_VAL_PACKED; }
 
 // Phase 1 for one row. `Acc` provides or_word(w, mask), max_word(w, v), store_word(w, v) for THIS row's review.
 template <class Acc>
@@ -384,20 +385,18 @@ GK_HD void eval_row_ent(const Row& r, uint32_t row_index, uint32_t ent, const St
     }
     uint32_t wpe = sc.wpe;
     if (p.op == P_STORE) {
-      // A stored value is compared with another one (Rego `==` between two review values).  Scalars decide by type and
-      // payload, empty containers by type; two NON-EMPTY containers would need a deep comparison the plan cannot do: the
-      // review is flagged beyond the engine's limits (reported in too_big, the caller fails closed) -- never guessed.
-      if (((r.meta & ROW_TYPE_MASK) == T_OBJECT || (r.meta & ROW_TYPE_MASK) == T_ARRAY) && r.lo != 0u) {
+      // A stored value is compared with another one (Rego `==` between two review values): the slot takes the row's VALUE
+      // ID.  A row without one -- a non-empty container (its equality would need a deep comparison), a table flattened
+      // before the constraint registered the path -- or a review with more compared values than ids flags the review
+      // beyond the engine's limits (reported in too_big, the caller fails closed) -- never guessed.
+      const uint32_t vid = row_vid(r);
+      if (vid == 0u || vid >= GK_VID_OVERFLOW) {
         acc.or_word(GBIT_OVERFLOW >> 5, 1u << (GBIT_OVERFLOW & 31));
         continue;
       }
-      // value slot: the row's 64-bit payload; the element's type word gets a nibble (type + 1 | inline << 3)
-      uint32_t vb = sc.val_off + ord * val_stride(sc.nvals);
       if (p.level >= GK_LEVEL_ROOT) { acc.max_word(sc.count_off, 1u); acc.or_word(sc.word_off, 1u); }   // the root scope's element exists once a value is stored
-      acc.store_word(vb + p.bit * 2u, r.lo);
-      acc.store_word(vb + p.bit * 2u + 1u, r.hi);
-      if (sc.nvals == 1) acc.or_word(sc.word_off + ord * wpe, val_nibble(r) << ELEM_NIBBLE_SHIFT);
-      else acc.or_word(vb + sc.nvals * 2u, val_nibble(r) << (4u * p.bit));
+      if (scope_packed(sc)) acc.or_word(sc.word_off + ord * wpe, vid << ELEM_VID_SHIFT);
+      else acc.store_word(sc.val_off + ord * val_stride(sc.nvals) + p.bit, vid);
     } else if (p.op == P_PRESENT) {
       uint32_t parent = p.level > 0 ? row_ordinal(r, p.level - 1) : 0;
       acc.or_word(sc.word_off + ord * wpe, 1u | (parent << 24));
@@ -408,48 +407,9 @@ GK_HD void eval_row_ent(const Row& r, uint32_t row_index, uint32_t ent, const St
   }
 }
 
-// value-slot equality (joins).  A slot holds the stored row's 64-bit payload plus a type nibble; two values are equal
-// iff they have the same Rego type and content.  Memory is touched only to confirm two DIFFERENT heap strings whose
-// hashes agree.
-GK_HD_COLD bool val_eq(uint32_t alo, uint32_t ahi, uint32_t an, uint32_t blo, uint32_t bhi, uint32_t bn, const uint8_t* heap) {
-  if ((an & 7u) == 0u || (bn & 7u) == 0u) return false;
-  uint32_t ta = (an & 7u) - 1u, tb = (bn & 7u) - 1u;
-  if (type_rank(ta) != type_rank(tb)) return false;
-  switch (ta) {
-    case T_NULL: return true;
-    case T_BOOL: return alo == blo;
-    case T_INT: case T_FLOAT: {
-      if (ta == T_INT && tb == T_INT) return alo == blo && ahi == bhi;
-      uint64_t ua = ((uint64_t)ahi << 32) | alo, ub = ((uint64_t)bhi << 32) | blo;
-      double x = ta == T_INT ? (double)(int64_t)ua : bits_f64(ua);
-      double y = tb == T_INT ? (double)(int64_t)ub : bits_f64(ub);
-      return x == y;
-    }
-    case T_STRING: {
-      if ((an & 8u) != (bn & 8u)) return false;       // inline strings are <= 7 bytes, heap strings longer
-      if (an & 8u) return alo == blo && ahi == bhi;   // packed bytes + length
-      if (ahi != bhi) return false;                   // hash32 fast reject
-      if (alo == blo) return true;
-      uint32_t na = ld32(heap + alo - 4), nb = ld32(heap + blo - 4);
-      if (na != nb) return false;
-      uint32_t d = 0;
-      for (uint32_t j = 0; j < na; j += 4) d |= ld32(heap + alo + j) ^ ld32(heap + blo + j);
-      return d == 0;
-    }
-    default: return ta == tb && alo == 0u && blo == 0u;   // containers: two EMPTY ones of the same type are equal; a non-empty one is never stored (P_STORE refuses the review)
-  }
-}
-
-// The common cases of val_eq without control flow: identical type nibble and payload decide null / bool / int /
-// inline strings / the same heap entry.  Only float operands and distinct heap strings with equal hashes call val_eq.
-GK_HD bool val_eq_quick(uint32_t alo, uint32_t ahi, uint32_t an, uint32_t blo, uint32_t bhi, uint32_t bn, const uint8_t* heap) {
-  const uint32_t ta = an & 7u, tb = bn & 7u;   // type + 1
-  const bool same = (an == bn) & (alo == blo) & (ahi == bhi) & (ta != 0u) & !((ta > T_STRING + 1u) & (alo != 0u));   // (containers: only empty ones compare)
-  const bool fl = ((ta == T_FLOAT + 1u) & ((tb == T_FLOAT + 1u) | (tb == T_INT + 1u))) | ((tb == T_FLOAT + 1u) & (ta == T_INT + 1u));
-  const bool hs = (an == T_STRING + 1u) & (bn == T_STRING + 1u) & (ahi == bhi) & (alo != blo);
-  if (fl | hs) return val_eq(alo, ahi, an, blo, bhi, bn, heap);
-  return same;
-}
+// value-slot equality (joins): two stored values are equal iff their value ids are (ids are per distinct Rego value within
+// the review, plan.hpp); an empty slot (0) equals nothing
+GK_HD bool vid_eq(uint32_t a, uint32_t b) { return (a == b) & (a != 0u); }
 
 struct Results {
   uint64_t viol, match, err;
@@ -539,10 +499,11 @@ GK_HD Results eval_formulas(const PlanView& pv, Acc& acc, uint32_t flags, const 
         uint32_t sa = x & 0xFF, la = (x >> 8) & 0xFF, sb = (x >> 16) & 0xFF, lb = x >> 24;
         const Scope& A = pv.scopes[sa];
         const Scope& Bs = pv.scopes[sb];
-        uint32_t wa = A.val_off + cur[sa] * val_stride(A.nvals), wb = Bs.val_off + cur[sb] * val_stride(Bs.nvals);
-        uint32_t na = A.nvals == 1 ? (acc.load(A.word_off + cur[sa] * A.wpe) >> ELEM_NIBBLE_SHIFT) & 15u : (acc.load(wa + A.nvals * 2u) >> (4u * la)) & 15u;
-        uint32_t nb = Bs.nvals == 1 ? (acc.load(Bs.word_off + cur[sb] * Bs.wpe) >> ELEM_NIBBLE_SHIFT) & 15u : (acc.load(wb + Bs.nvals * 2u) >> (4u * lb)) & 15u;
-        uint64_t v = val_eq(acc.load(wa + la * 2u), acc.load(wa + la * 2u + 1u), na, acc.load(wb + lb * 2u), acc.load(wb + lb * 2u + 1u), nb, heap) ? 1 : 0;
+        const uint32_t ia = scope_packed(A) ? (acc.load(A.word_off + cur[sa] * A.wpe) >> ELEM_VID_SHIFT) & GK_VID_OVERFLOW
+                                            : acc.load(A.val_off + cur[sa] * val_stride(A.nvals) + la);
+        const uint32_t ib = scope_packed(Bs) ? (acc.load(Bs.word_off + cur[sb] * Bs.wpe) >> ELEM_VID_SHIFT) & GK_VID_OVERFLOW
+                                             : acc.load(Bs.val_off + cur[sb] * val_stride(Bs.nvals) + lb);
+        uint64_t v = vid_eq(ia, ib) ? 1 : 0;
         B = (B & ~(1ull << a)) | (v << a);
         break;
       }

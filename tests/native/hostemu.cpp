@@ -120,7 +120,7 @@ static bool eval_review(const HostPlan& hp, const HostTable& t, uint32_t r, Resu
     const uint32_t path = t.slot_path[s];
     if (path >= pv.dims.n_paths || pv.ptab[path] == 0) continue;
     for (uint32_t i = ix[s]; i < ix[s + 1]; i++) {
-      if (t.rows[i].rev != rl) continue;
+      if ((t.rows[i].rev & ROW_REV_MASK) != rl) continue;
       if (jit) {
         uint32_t c = path < jit->cls.size() ? jit->cls[path] : 0;
         // like the device: the string header is only fetched for classes flagged as reading string bytes
