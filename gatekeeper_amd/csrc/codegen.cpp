@@ -76,6 +76,9 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts, const std
     << "GK_CONST_ARRAY uint32_t gk_count_off[" << std::max<size_t>(1, plan.scopes.size()) << "] = {";
   for (size_t i = 0; i < plan.scopes.size(); i++) o << (i ? "," : "") << plan.scopes[i].count_off << "u";
   if (plan.scopes.empty()) o << "0u";
+  o << "};\nGK_CONST_ARRAY uint32_t gk_scope_cap[" << std::max<size_t>(1, plan.scopes.size()) << "] = {";
+  for (size_t i = 0; i < plan.scopes.size(); i++) o << (i ? "," : "") << plan.scopes[i].cap << "u";
+  if (plan.scopes.empty()) o << "0u";
   o << "};\n";
   // ---------------------------------------------------------------------------------------------- phase 1
   // inlined into its single call site (the chunk loop): as a separate function every LDS atomic would first look the
