@@ -36,6 +36,7 @@ EXPORTS = [
     "gk_table_totals", "gk_totals_free", "gk_table_get_stats", "gk_batcher_start", "gk_batcher_stop", "gk_query",
     "gk_resident_sweep", "gk_sweep_free", "gk_resident_review",
     "gk_comm_unique_id", "gk_comm_init", "gk_comm_destroy", "gk_table_sweep_sharded", "gk_shard_free",
+    "gk_jit_quiesce", "gk_jit_cache_stats",
     # include/gksynth.h (bench / test plumbing)
     "gk_synth_batch_create", "gk_synth_batch_reviews", "gk_synth_batch_size", "gk_synth_batch_json_bytes", "gk_synth_batch_free", "gk_synth_query_storm",
 ]
@@ -162,6 +163,10 @@ def load(hostemu: bool | None = None):
     lib.gk_table_create.argtypes = [vp, C.POINTER(gk_review_in), sz, u32, C.POINTER(C.c_int32), C.POINTER(vp)]
     lib.gk_table_free.argtypes = [vp]
     lib.gk_table_free.restype = None
+    lib.gk_jit_quiesce.argtypes = []
+    lib.gk_jit_quiesce.restype = None
+    lib.gk_jit_cache_stats.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.gk_jit_cache_stats.restype = None
     lib.gk_table_eval.argtypes = [vp, vp, u32, C.POINTER(C.POINTER(gk_eval_out))]
     lib.gk_eval_free.argtypes = [C.POINTER(gk_eval_out)]
     lib.gk_eval_free.restype = None

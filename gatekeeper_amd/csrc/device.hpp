@@ -85,6 +85,10 @@ void dev_shard_setup(DevTable* t, DevComm* c, uint32_t nc, ShardInfo* info);   /
 // what the gathered violation bitmaps cannot say, so that a sharded audit fails closed like the single-GPU one
 void dev_shard_exchange(DevTable* t, DevComm* c, uint32_t nc, uint64_t not_evaluated, std::vector<int64_t>* totals,
                         std::vector<uint64_t>* gathered /* may be null */, const void** d_gathered);
+// Plan-specialised builds of the dominant kernel run in the background for admission batches (kernels.hip jit_for): wait for
+// every build in flight / code-object cache counters (hits = builds served without hiprtc)
+void dev_jit_quiesce();
+void dev_jit_cache_stats(uint64_t* hits, uint64_t* compiles);
 void dev_eval_launch(const DevPlan* p, const DevTable* t, const EvalOptions& opt);          // asynchronous on the default stream
 void dev_eval_finish(const DevPlan* p, const DevTable* t, const EvalOptions& opt, EvalOut* out);   // sync, overflow re-run, download
 

@@ -1749,6 +1749,14 @@ int gk_query(gk_engine* e, const gk_review_in* review, char** results_json, gk_q
   return GK_OK;
 }
 
+void gk_jit_quiesce(void) { dev_jit_quiesce(); }
+void gk_jit_cache_stats(uint64_t* cache_hits, uint64_t* compiles) {
+  uint64_t h = 0, c = 0;
+  dev_jit_cache_stats(&h, &c);
+  if (cache_hits) *cache_hits = h;
+  if (compiles) *compiles = c;
+}
+
 int gk_dump(gk_engine* e, char** text_out) {
   if (!e || !text_out) return fail(GK_ERR_INVALID, "NULL argument");
   try {

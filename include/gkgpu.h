@@ -279,6 +279,18 @@ int gk_batcher_start(gk_engine* e, const gk_batch_opts* opts);   /* optional: gk
 void gk_batcher_stop(gk_engine* e);
 int gk_query(gk_engine* e, const gk_review_in* review, char** results_json, gk_query_stats* stats);
 
+/* ---- plan specialisation in the background -----------------------------------------------------------------------------
+ * After AddTemplate / AddConstraint (drivers.Driver, pkg/drivers/k8scel/driver.go:74-160) the next Query must not wait for a
+ * compiler: the reference's webhook gives a review 3 s by default and turns a Query error into an HTTP 500
+ * (pkg/webhook/policy.go:208-211).  The plan-specialised build of the dominant kernel (hiprtc, ~2 s) therefore runs on a
+ * background thread for admission batches; until its module is loaded the generic bytecode kernel -- same answers, parity
+ * tested -- serves them.  Resident (audit) tables wait for the build.  Code objects are cached by the hash of their source
+ * text (in memory; on disk under $GK_JIT_CACHE_DIR).
+ * gk_jit_quiesce waits for every build in flight (tests, orderly shutdown); gk_jit_cache_stats reports builds served from
+ * the cache / compiled by hiprtc since the process started. */
+void gk_jit_quiesce(void);
+void gk_jit_cache_stats(uint64_t* cache_hits, uint64_t* compiles);
+
 /* Debug: the compiled plan as text (Driver.Dump, pkg/drivers/k8scel/driver.go:253). */
 int gk_dump(gk_engine* e, char** text_out);
 

@@ -206,6 +206,8 @@ void dev_shard_exchange(DevTable* t, DevComm* c, uint32_t nc, uint64_t not_evalu
 static void emu_kernel_check(const DevPlan* p, const DevTable* dt, const EvalOptions& opt, const EvalOut& want);
 
 void dev_last_viol(const DevTable* t, uint32_t nc, std::vector<uint64_t>* viol) { (void)nc; *viol = t->last_viol; }
+void dev_jit_quiesce() {}
+void dev_jit_cache_stats(uint64_t* hits, uint64_t* compiles) { *hits = 0; *compiles = 0; }
 void dev_eval_launch(const DevPlan*, const DevTable* dt, const EvalOptions&) { const_cast<DevTable*>(dt)->pending++; }
 void dev_eval(const DevPlan* p, const DevTable* dt, const EvalOptions& opt, EvalOut* o) { dev_eval_launch(p, dt, opt); dev_eval_finish(p, dt, opt, o); }
 void dev_eval_finish(const DevPlan* p, const DevTable* dt, const EvalOptions& opt, EvalOut* o) {

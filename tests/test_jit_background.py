@@ -1,0 +1,86 @@
+"""Plan specialisation in the background (kernels.hip jit_for): the first Query after a policy change is answered by the
+bytecode kernel without waiting for hiprtc, the plan-specialised kernel takes over once its module is loaded, and identical
+source text is served from the code-object cache.
+
+The reference's webhook gives a review 3 s by default and turns a Driver.Query error into an HTTP 500
+(/root/reference/pkg/webhook/policy.go:208-211); a 2 s compile inside the first Query after every constraint change does
+not fit that budget."""
+import ctypes as C
+import os
+import time
+
+import pytest
+
+from gatekeeper_amd import driver as D
+from gatekeeper_amd import synth
+from oracle import client as OC
+from oracle import target as OT
+
+
+def _cache_stats(lib):
+    h, c = C.c_uint64(), C.c_uint64()
+    lib.gk_jit_cache_stats(C.byref(h), C.byref(c))
+    return h.value, c.value
+
+
+def _expect(oc, o, nss):
+    res = oc.review(OT.AugmentedUnstructured(OT.Unstructured(o), synth.namespace_for(o, nss), "Original"), OC.WEBHOOK_EP)
+    return sorted((r.constraint["metadata"]["name"], r.msg) for r in res)
+
+
+@pytest.mark.gpu
+def test_first_query_after_a_policy_change_does_not_wait_for_the_compiler(fixtures, tmp_path):
+    for k in ("GK_NO_JIT", "GK_JIT_STRICT", "GK_JIT_SYNC", "GK_HOSTEMU_JIT"):
+        os.environ.pop(k, None)
+    os.environ["GK_JIT_CACHE_DIR"] = str(tmp_path)
+    try:
+        drv = D.Driver(device=0, hostemu=False)
+        c, oc = D.Client(drv), OC.Client()
+        lib = drv.engine.lib
+        templates, constraints = synth.psp_templates(fixtures), synth.psp_constraints()
+        for t in templates:
+            c.AddTemplate(t)
+            oc.add_template(t)
+        for k in constraints[:-1]:
+            c.AddConstraint(k)
+            oc.add_constraint(k)
+        nss = synth.gen_namespaces()
+        objs = synth.gen_objects(48, seed=77)
+        rvs = [D.AugmentedUnstructured(D.Unstructured(o), synth.namespace_for(o, nss), "Original") for o in objs]
+
+        def query(i):
+            resp = drv.Query(D.TARGET_NAME, list(c.constraints.values()), rvs[i])
+            return sorted((r.constraint["metadata"]["name"], r.msg) for r in resp.results)
+        # warm the process (HIP context, allocator pool, the ahead-of-time kernels) on the first policy set
+        assert query(0) == _expect(oc, objs[0], nss)
+        lib.gk_jit_quiesce()
+        _, compiles0 = _cache_stats(lib)
+        # ---- the policy changes: the NEXT query must not pay for hiprtc
+        c.AddConstraint(constraints[-1])
+        oc.add_constraint(constraints[-1])
+        t0 = time.perf_counter()
+        first = query(1)
+        dt = time.perf_counter() - t0
+        assert first == _expect(oc, objs[1], nss)
+        assert dt < 0.05, "first query after AddConstraint took %.1f ms" % (dt * 1e3)
+        more = [query(i) for i in range(2, 10)]             # still (or already) correct while the build is running
+        assert more == [_expect(oc, objs[i], nss) for i in range(2, 10)]
+        lib.gk_jit_quiesce()                                  # the specialised module is loaded now
+        _, compiles1 = _cache_stats(lib)
+        assert compiles1 == compiles0 + 1                     # exactly one build happened, in the background
+        after = [query(i) for i in range(10, 48)]
+        assert after == [_expect(oc, objs[i], nss) for i in range(10, 48)]
+        assert sum(len(x) for x in after) > 0
+        # ---- the same policies again (constraint removed and re-added): identical source text -> code-object cache
+        c.RemoveConstraint(constraints[-1])
+        query(0)
+        lib.gk_jit_quiesce()
+        hits_a, compiles_a = _cache_stats(lib)
+        c.AddConstraint(constraints[-1])
+        assert query(1) == first
+        lib.gk_jit_quiesce()
+        hits_b, compiles_b = _cache_stats(lib)
+        assert compiles_b == compiles_a and hits_b == hits_a + 1
+        assert any(f.endswith(".co") for f in os.listdir(str(tmp_path)))     # ... and on disk for the next process
+    finally:
+        os.environ.pop("GK_JIT_CACHE_DIR", None)
