@@ -96,7 +96,14 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts, const std
     // the class dispatch is wave-uniform and comes FIRST; the per-lane "this lane holds a row of this pass" test sits inside
     // the case (around a divergent dispatch the structuriser threads every case exit through a chain of flow blocks)
     std::ostringstream o;   // (this class's body; assembled into the dispatch below)
-    o << "if (on) {\n      const uint32_t t = r.meta & 7u; (void)t;\n";
+    // FLAT bodies (default; GK_JIT_FLAT=0: the branchy form): no divergent branch in a case -- predicates become selects, every
+    // side effect an UNCONDITIONAL LDS atomic whose operand is neutral (OR 0 / MAX 0) for lanes without a row, for rows of
+    // another pass and for predicates that do not hold.  A case without divergent control flow needs no exec-mask
+    // bookkeeping (two scalar instructions per `if`) and leaves the wave-uniform class switch free of structuriser flow
+    // blocks: its exits are plain branches to the join instead of a chain of ~5 hops.  (Lanes without a row address their OWN
+    // review slot -- kernel_body.inc -- so the neutral operations do not pile up on one LDS bank.)
+    static const bool flat = !(getenv("GK_JIT_FLAT") && atoi(getenv("GK_JIT_FLAT")) == 0);
+    o << (flat ? "{\n      const uint32_t t = r.meta & 7u; (void)t;\n" : "if (on) {\n      const uint32_t t = r.meta & 7u; (void)t;\n");
     const std::vector<Pred>& ps = classes[c];
     struct Group { int scope, level; bool always = false; std::vector<std::string> masks; std::vector<size_t> stores; bool present = false; };
     std::vector<Group> groups;          // element destinations by (scope, level)
@@ -110,12 +117,14 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts, const std
       return groups.back();
     };
     std::vector<std::string> target(ps.size());   // "mask |= bit" statement per predicate
+    std::vector<std::string> tmask(ps.size()), tbit(ps.size());   // ... and its parts (flat form: mask |= cond ? bit : 0)
     for (size_t i = 0; i < ps.size(); i++) {
       const Pred& p = ps[i];
       if (p.dst == D_GLOBAL) {
         std::string m = "mg" + std::to_string(p.bit >> 5);
         declare(m, gmasks);
         target[i] = m + " |= " + u(1u << (p.bit & 31)) + ";";
+        tmask[i] = m; tbit[i] = u(1u << (p.bit & 31));
       } else {
         Group& g = group_of(p);
         if (p.op == P_STORE) { g.stores.push_back(i); g.always = true; if (p.level >= GK_LEVEL_ROOT) g.present = true; continue; }   // root scope: a store marks its element
@@ -123,13 +132,24 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts, const std
         std::string m = "me" + std::to_string(p.scope) + "_" + std::to_string(p.level) + "_" + std::to_string(elem_word_of_bit(p.bit));
         declare(m, g.masks);
         target[i] = m + " |= " + u(elem_mask_of_bit(p.bit)) + ";";
+        tmask[i] = m; tbit[i] = u(elem_mask_of_bit(p.bit));
         if (p.op == P_DEFINED) g.always = true;
       }
     }
     // integer comparisons: one type test for all of them
     std::vector<size_t> icmp;
     for (size_t i = 0; i < ps.size(); i++) if (ps[i].op == P_CMP && ps[i].ctype == T_INT && !target[i].empty()) icmp.push_back(i);
-    if (!icmp.empty()) {
+    if (!icmp.empty() && flat) {
+      // compare(row, integer constant) under Rego's total order, as selects: an integer row compares exactly, a float row as
+      // doubles (cmp_row_const), every other type by its rank against "number" (null / boolean below, string / composite above)
+      o << "      const bool isint = t == T_INT, isflt = t == T_FLOAT, below = t < T_INT;\n      const int64_t a = row_i64(r);\n      const double fa = row_f64(r);\n";
+      for (size_t i : icmp) {
+        const uint32_t op = ps[i].cmp;
+        const bool low = op == C_NE || op == C_LT || op == C_LE, high = op == C_NE || op == C_GT || op == C_GE;
+        o << "      " << tmask[i] << " |= (isint ? (a " << kCmpOps[op] << " " << (long long)(int64_t)ps[i].k << "ll) : isflt ? (fa " << kCmpOps[op] << " (double)"
+          << (long long)(int64_t)ps[i].k << "ll) : below ? " << (low ? "true" : "false") << " : " << (high ? "true" : "false") << ") ? " << tbit[i] << " : 0u;\n";
+      }
+    } else if (!icmp.empty()) {
       o << "      if (t == T_INT) {\n        const int64_t a = row_i64(r);\n";
       for (size_t i : icmp) o << "        if (a " << kCmpOps[ps[i].cmp] << " " << (long long)(int64_t)ps[i].k << "ll) " << target[i] << "\n";
       o << "      } else {\n";
@@ -172,9 +192,62 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts, const std
         }
         default: break;
       }
+      if (flat) {
+        if (cond.empty()) o << "      { constexpr Pred P = " << pred_literal(p) << "; " << tmask[i] << " |= eval_pred(r, P, h, heap, cheap) ? " << tbit[i] << " : 0u; }\n";
+        else if (cond == "true") o << "      " << target[i] << "\n";
+        else o << "      " << tmask[i] << " |= (" << cond << ") ? " << tbit[i] << " : 0u;\n";
+        continue;
+      }
       if (cond.empty()) o << "      { constexpr Pred P = " << pred_literal(p) << "; if (eval_pred(r, P, h, heap, cheap)) " << target[i] << " }\n";
       else if (cond == "true") o << "      " << target[i] << "\n";
       else o << "      if (" << cond << ") " << target[i] << "\n";
+    }
+    if (flat) {
+      bool any_group = !groups.empty();
+      if (any_group) o << "      bool ovf = false;\n";
+      for (size_t gi = 0; gi < groups.size(); gi++) {
+        const Group& g = groups[gi];
+        const Scope& sc = plan.scopes[g.scope];
+        const std::string n = std::to_string(gi);
+        std::string hit = "on";
+        if (!g.always) { std::string any; for (size_t k = 0; k < g.masks.size(); k++) any += (k ? " | " : "") + g.masks[k]; hit = "on && ((" + any + ") != 0u)"; }
+        o << "      const uint32_t ord" << n << " = row_ordinal(r, " << g.level << "u);\n";
+        std::string good = "ord" + n + " < " + std::to_string(sc.cap) + "u && !(r.meta & ROW_ORD_OVERFLOW)";
+        if (!g.stores.empty()) {   // a stored value = the row's VALUE ID; none / the overflow id: beyond the limits (vm_core.hpp P_STORE)
+          if (gi == 0 || true) o << "      const uint32_t vid" << n << " = row_vid(r);\n";
+          good += " && vid" + n + " != 0u && vid" + n + " < GK_VID_OVERFLOW";
+        }
+        o << "      const bool hit" << n << " = " << hit << ";\n      const bool ok" << n << " = hit" << n << " && " << good << ";\n"
+          << "      ovf = ovf || (hit" << n << " && !ok" << n << ");\n      const uint32_t o" << n << " = ok" << n << " ? ord" << n << " : 0u;\n";
+        std::string extra;
+        for (size_t i : g.stores) {
+          const Pred& p = ps[i];
+          if (scope_packed(sc)) extra += " | (vid" + n + " << " + std::to_string(ELEM_VID_SHIFT) + "u)";
+          else o << "      acc.or_word(" << sc.val_off << "u + o" << n << " * " << val_stride(sc.nvals) << "u + " << p.bit << "u, ok" << n << " ? vid" << n << " : 0u);\n";   // (the slot is zero and written once: OR = store)
+        }
+        if (g.present) {
+          if (g.level > 0 && g.level < (int)GK_LEVEL_ROOT) extra += " | 1u | (row_ordinal(r, " + std::to_string(g.level - 1) + "u) << 24)";
+          else extra += " | 1u";
+          o << "      acc.max_word(" << sc.count_off << "u, ok" << n << " ? o" << n << " + 1u : 0u);\n";
+        }
+        bool w0_done = false;
+        for (const std::string& m : g.masks) {
+          uint32_t wi = (uint32_t)atoi(m.substr(m.rfind('_') + 1).c_str());
+          if (wi == 0) { o << "      acc.or_word(" << sc.word_off << "u + o" << n << " * " << (int)sc.wpe << "u, ok" << n << " ? (" << m << extra << ") : 0u);\n"; w0_done = true; }
+          else o << "      acc.or_word(" << sc.word_off << "u + o" << n << " * " << (int)sc.wpe << "u + " << wi << "u, ok" << n << " ? " << m << " : 0u);\n";
+        }
+        if (!w0_done && !extra.empty()) o << "      acc.or_word(" << sc.word_off << "u + o" << n << " * " << (int)sc.wpe << "u, ok" << n << " ? (0u" << extra << ") : 0u);\n";
+      }
+      bool w0 = false;
+      for (const std::string& m : gmasks) {
+        const bool is0 = m == "mg0";
+        if (is0) w0 = true;
+        o << "      acc.or_word(" << m.substr(2) << "u, (on ? " << m << " : 0u)" << (is0 && any_group ? " | (ovf ? 1u : 0u)" : "") << ");\n";
+      }
+      if (any_group && !w0) o << "      acc.or_word(0u, ovf ? 1u : 0u);\n";
+      o << "    }\n";
+      case_body[c] = o.str();
+      continue;
     }
     for (const std::string& m : gmasks) o << "      if (" << m << ") acc.or_word(" << m.substr(2) << "u, " << m << ");\n";
     for (const Group& g : groups) {
