@@ -162,6 +162,70 @@ std::string autoreject_message(const Value& match, const ReviewDoc& doc) {
 
 }  // namespace
 
+// Persistent host workers for table builds.  A 64k-review batch gives each of 128 threads ~3 ms of flattening: spawning and
+// joining the threads per table cost more than the work (round 2: 4.6x on 256 threads).  The pool is process-wide and sized
+// to the hardware; run(n, fn) executes fn(0..n-1) on the workers and the caller, returns when all are done.  Concurrent
+// run() calls (the batcher's workers) are served one after the other.
+class HostWorkers {
+ public:
+  static HostWorkers& get() { static HostWorkers w; return w; }
+  void run(size_t n, const std::function<void(size_t)>& fn) {
+    if (n <= 1) { if (n) fn(0); return; }
+    std::lock_guard<std::mutex> serial(run_mu_);
+    {
+      std::lock_guard<std::mutex> l(mu_);
+      while (threads_.size() + 1 < n && threads_.size() < max_) threads_.emplace_back([this] { loop(); });
+      fn_ = &fn; n_ = n; next_ = 0; done_ = 0; gen_++;
+    }
+    cv_.notify_all();
+    work();
+    std::unique_lock<std::mutex> l(mu_);
+    done_cv_.wait(l, [&] { return done_ == n_; });
+    fn_ = nullptr;
+  }
+  ~HostWorkers() {
+    { std::lock_guard<std::mutex> l(mu_); stop_ = true; }
+    cv_.notify_all();
+    for (auto& t : threads_) t.join();
+  }
+ private:
+  HostWorkers() : max_(std::max<size_t>(1, std::thread::hardware_concurrency())) {}
+  void work() {
+    for (;;) {
+      size_t i;
+      const std::function<void(size_t)>* fn;
+      {
+        std::lock_guard<std::mutex> l(mu_);
+        if (!fn_ || next_ >= n_) return;
+        i = next_++;
+        fn = fn_;
+      }
+      (*fn)(i);
+      std::lock_guard<std::mutex> l(mu_);
+      if (++done_ == n_) done_cv_.notify_all();
+    }
+  }
+  void loop() {
+    uint64_t seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> l(mu_);
+        cv_.wait(l, [&] { return stop_ || (gen_ != seen && fn_ && next_ < n_); });
+        if (stop_) return;
+        seen = gen_;
+      }
+      work();
+    }
+  }
+  std::mutex mu_, run_mu_;
+  std::condition_variable cv_, done_cv_;
+  std::vector<std::thread> threads_;
+  const std::function<void(size_t)>* fn_ = nullptr;
+  size_t n_ = 0, next_ = 0, done_ = 0, max_;
+  uint64_t gen_ = 0;
+  bool stop_ = false;
+};
+
 struct gk_engine {
   gk_opts opts{};
   PathDict dict;
@@ -745,6 +809,18 @@ int gk_table_create(gk_engine* e, const gk_review_in* reviews, size_t n, uint32_
         Flattener fl(&e->dict, &e->dict_reg);
         parts[w].rpt = rpt;
         const size_t lo = std::min(n, w * tiles_per * rpt), hi = std::min(n, (w + 1) * tiles_per * rpt);
+        {
+          // the part's arrays, sized ONCE from the JSON text it will flatten (a row per ~9 bytes of Kubernetes JSON, a
+          // heap byte per ~5; a quarter on top): no growth by reallocation while 255 other threads do the same
+          size_t jb = 0;
+          for (size_t i = lo; i < hi; i++) jb += reviews[i].json_len + reviews[i].namespace_len / 4;
+          if (jb >= (256u << 10)) {
+            const size_t rows_est = jb / 7 + 4096;
+            parts[w].rows.presize(rows_est);
+            parts[w].shdr.presize(rows_est);
+            parts[w].heap.presize(jb / 4 + 65536);
+          }
+        }
         for (size_t i = lo; i < hi; i++) {
           const gk_review_in& r = reviews[i];
           if (!slow_only) {
@@ -803,9 +879,13 @@ int gk_table_create(gk_engine* e, const gk_review_in* reviews, size_t n, uint32_
     };
     auto run_threads = [&](const std::function<void(size_t)>& fn) {
       if (n_threads <= 1) { fn(0); return; }
-      std::vector<std::thread> th;
-      for (size_t w = 0; w < n_threads; w++) th.emplace_back(fn, w);
-      for (auto& x : th) x.join();
+      if (getenv("GK_HOST_SPAWN")) {   // tuning aid: a thread per part and table, as before round 3
+        std::vector<std::thread> th;
+        for (size_t w = 0; w < n_threads; w++) th.emplace_back(fn, w);
+        for (auto& x : th) x.join();
+        return;
+      }
+      HostWorkers::get().run(n_threads, fn);
     };
     // content digest (test aid, GK_TABLE_DIGEST=1): per part while its rows are still on the host; parts are combined in
     // order, strings by value (not by heap offset), so the digest does not depend on the number of host threads

@@ -144,18 +144,30 @@ std::string obj_string(const Value& obj, const char* a, const char* b = nullptr)
 void obj_gvk(const Value& obj, std::string* group, std::string* version, std::string* kind);
 bool obj_is_namespace(const Value& obj);
 
+// Host staging memory.  A table part is a few to a few hundred MB of rows, string headers and heap bytes that live until the
+// part has been copied to the device.  On a many-core host (256 threads building one table) the allocator traffic of such
+// blocks -- mmap, page-fault in, grow by mremap, munmap with a TLB shoot-down on every core -- serialises the threads on the
+// process's address-space lock: round 2 measured 4.6x on 256 threads.  Blocks of 1 MiB and more therefore come from a
+// process-wide pool: size classes of powers of two, handed back to the pool
+// (not to the kernel) when a part is released, up to GK_HOST_POOL_MB (default 8192) kept.  Smaller blocks use malloc / realloc.
+void* host_block_alloc(size_t bytes, size_t* cap_bytes);   // bytes >= kHostBlockMin; *cap_bytes = the size class
+void host_block_free(void* p, size_t cap_bytes);
+constexpr size_t kHostBlockMin = 1u << 20;
+
 // Growable array of PODs WITHOUT value-initialisation: the table arrays hold gigabytes, std::vector::resize would zero
-// every byte before it is overwritten and re-copy everything on growth (realloc grows large blocks in place / by mremap).
+// every byte before it is overwritten and re-copy everything on growth.
 template <class T>
 struct PodVec {
   T* p_ = nullptr;
   size_t n_ = 0, cap_ = 0;
+  size_t pooled_ = 0;   // size class in bytes when p_ is a pooled block, 0: malloc'ed
   PodVec() {}
   PodVec(const PodVec& o) { assign(o.p_, o.n_); }
-  PodVec(PodVec&& o) noexcept : p_(o.p_), n_(o.n_), cap_(o.cap_) { o.p_ = nullptr; o.n_ = o.cap_ = 0; }
+  PodVec(PodVec&& o) noexcept : p_(o.p_), n_(o.n_), cap_(o.cap_), pooled_(o.pooled_) { o.p_ = nullptr; o.n_ = o.cap_ = o.pooled_ = 0; }
   PodVec& operator=(const PodVec& o) { if (this != &o) assign(o.p_, o.n_); return *this; }
-  PodVec& operator=(PodVec&& o) noexcept { if (this != &o) { free(p_); p_ = o.p_; n_ = o.n_; cap_ = o.cap_; o.p_ = nullptr; o.n_ = o.cap_ = 0; } return *this; }
-  ~PodVec() { free(p_); }
+  PodVec& operator=(PodVec&& o) noexcept { if (this != &o) { release(); p_ = o.p_; n_ = o.n_; cap_ = o.cap_; pooled_ = o.pooled_; o.p_ = nullptr; o.n_ = o.cap_ = o.pooled_ = 0; } return *this; }
+  ~PodVec() { release(); }
+  void release() { if (pooled_) host_block_free(p_, pooled_); else free(p_); p_ = nullptr; n_ = cap_ = pooled_ = 0; }
   void assign(const T* src, size_t n) { resize(n); if (n) memcpy(p_, src, n * sizeof(T)); }
   size_t size() const { return n_; }
   bool empty() const { return n_ == 0; }
@@ -168,9 +180,20 @@ struct PodVec {
   T* end() { return p_ + n_; }
   const T* begin() const { return p_; }
   const T* end() const { return p_ + n_; }
+  // capacity for c elements from the host staging pool, for a vector that is sized up front (a part of a table build)
+  void presize(size_t c) {
+    if (c <= cap_ || c * sizeof(T) < kHostBlockMin) { reserve(c); return; }
+    size_t cap_bytes = 0;
+    T* q = static_cast<T*>(host_block_alloc(c * sizeof(T), &cap_bytes));
+    if (!q) throw std::bad_alloc();
+    if (n_) memcpy(static_cast<void*>(q), p_, n_ * sizeof(T));
+    if (pooled_) host_block_free(p_, pooled_); else free(p_);
+    p_ = q; cap_ = cap_bytes / sizeof(T); pooled_ = cap_bytes;
+  }
   void reserve(size_t c) {
     if (c <= cap_) return;
-    T* q = static_cast<T*>(realloc(p_, c * sizeof(T)));
+    if (pooled_) { presize(c); return; }   // (a pooled block is never realloc'ed)
+    T* q = static_cast<T*>(realloc(p_, c * sizeof(T)));   // organic growth: realloc moves pages instead of copying them
     if (!q) throw std::bad_alloc();
     p_ = q; cap_ = c;
   }
@@ -182,7 +205,7 @@ struct PodVec {
   void push_back(const T& v) { if (n_ == cap_) reserve(cap_ + cap_ / 2 + 1024); p_[n_++] = v; }
   void append(const T* src, size_t n) { size_t old = n_; resize(old + n); if (n) memcpy(static_cast<void*>(p_ + old), src, n * sizeof(T)); }
   void clear() { n_ = 0; }
-  void shrink_to_fit() { if (n_ == 0) { free(p_); p_ = nullptr; cap_ = 0; } }
+  void shrink_to_fit() { if (n_ == 0) release(); }
 };
 
 struct HostTable {
