@@ -36,7 +36,7 @@ EXPORTS = [
     "gk_table_totals", "gk_totals_free", "gk_table_get_stats", "gk_batcher_start", "gk_batcher_stop", "gk_query",
     "gk_resident_sweep", "gk_sweep_free", "gk_resident_review",
     "gk_comm_unique_id", "gk_comm_init", "gk_comm_destroy", "gk_table_sweep_sharded", "gk_shard_free",
-    "gk_jit_quiesce", "gk_jit_cache_stats",
+    "gk_jit_quiesce", "gk_jit_cache_stats", "gk_table_create_spool", "gk_spool_info_free",
     # include/gksynth.h (bench / test plumbing)
     "gk_synth_batch_create", "gk_synth_batch_reviews", "gk_synth_batch_size", "gk_synth_batch_json_bytes", "gk_synth_batch_free", "gk_synth_query_storm",
 ]
@@ -98,6 +98,11 @@ GK_SHARD_DOWNLOAD = 1
 GK_COMM_ID_BYTES = 128
 HE_ALLGATHER = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_uint64)     # test-only (libgkgpu_hostemu.so gk_comm_init_host)
 HE_ALLREDUCE = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_longlong), C.c_uint64)
+
+
+class gk_spool_info(C.Structure):
+    _fields_ = [("n_files", C.c_uint64), ("n_reviews", C.c_uint64), ("n_unreadable", C.c_uint64), ("n_namespace_missing", C.c_uint64), ("bytes", C.c_uint64),
+                ("names", C.POINTER(C.c_char_p))]
 
 
 class gk_batch_opts(C.Structure):
@@ -163,6 +168,9 @@ def load(hostemu: bool | None = None):
     lib.gk_table_create.argtypes = [vp, C.POINTER(gk_review_in), sz, u32, C.POINTER(C.c_int32), C.POINTER(vp)]
     lib.gk_table_free.argtypes = [vp]
     lib.gk_table_free.restype = None
+    lib.gk_table_create_spool.argtypes = [vp, cp, cp, u32, u32, C.POINTER(C.POINTER(gk_spool_info)), C.POINTER(vp)]
+    lib.gk_spool_info_free.argtypes = [C.POINTER(gk_spool_info)]
+    lib.gk_spool_info_free.restype = None
     lib.gk_jit_quiesce.argtypes = []
     lib.gk_jit_quiesce.restype = None
     lib.gk_jit_cache_stats.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]

@@ -96,13 +96,14 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts, const std
     // the class dispatch is wave-uniform and comes FIRST; the per-lane "this lane holds a row of this pass" test sits inside
     // the case (around a divergent dispatch the structuriser threads every case exit through a chain of flow blocks)
     std::ostringstream o;   // (this class's body; assembled into the dispatch below)
-    // FLAT bodies (default; GK_JIT_FLAT=0: the branchy form): no divergent branch in a case -- predicates become selects, every
+    // FLAT bodies (GK_JIT_FLAT=1; measured LEVEL with the branchy form on configs[2] in round 3, 0.1299 against 0.1287 ms,
+    // profiles/r03_variants_c_*.log -- kept as an alternative, parity-tested on the emulator): no divergent branch in a case -- predicates become selects, every
     // side effect an UNCONDITIONAL LDS atomic whose operand is neutral (OR 0 / MAX 0) for lanes without a row, for rows of
     // another pass and for predicates that do not hold.  A case without divergent control flow needs no exec-mask
     // bookkeeping (two scalar instructions per `if`) and leaves the wave-uniform class switch free of structuriser flow
     // blocks: its exits are plain branches to the join instead of a chain of ~5 hops.  (Lanes without a row address their OWN
     // review slot -- kernel_body.inc -- so the neutral operations do not pile up on one LDS bank.)
-    static const bool flat = !(getenv("GK_JIT_FLAT") && atoi(getenv("GK_JIT_FLAT")) == 0);
+    static const bool flat = getenv("GK_JIT_FLAT") && atoi(getenv("GK_JIT_FLAT")) != 0;
     o << (flat ? "{\n      const uint32_t t = r.meta & 7u; (void)t;\n" : "if (on) {\n      const uint32_t t = r.meta & 7u; (void)t;\n");
     const std::vector<Pred>& ps = classes[c];
     struct Group { int scope, level; bool always = false; std::vector<std::string> masks; std::vector<size_t> stores; bool present = false; };

@@ -6,6 +6,7 @@
 // pieces that sit on the hot path (pkg/target/target.go:81-179, matcher.go:21-93, ns_cache.go:15-87).
 #include <atomic>
 #include <cstring>
+#include <dirent.h>
 #include <algorithm>
 #include <chrono>
 #include <condition_variable>
@@ -226,7 +227,9 @@ class HostWorkers {
   bool stop_ = false;
 };
 
+static std::atomic<uint64_t> g_engine_uid{1};
 struct gk_engine {
+  const uint64_t uid = g_engine_uid++;   // (per-thread caches are keyed by it: an address may be reused by a later engine)
   gk_opts opts{};
   PathDict dict;
   DictRegistry dict_reg;     // leaf-local expressions of the loaded constraints (dexpr.hpp): evaluated by the flattener
@@ -806,7 +809,12 @@ int gk_table_create(gk_engine* e, const gk_review_in* reviews, size_t n, uint32_
     const Flattener::ExcludeFn excl_fn = [&](bool is_ns, const std::string& ns, const std::string& name) { return excluder_matches(excl, is_ns ? name : ns); };
     auto work = [&](size_t w) {
       try {
-        Flattener fl(&e->dict, &e->dict_reg);
+        // one Flattener per host thread and engine, kept across tables (Flattener::begin_table)
+        thread_local std::unordered_map<uint64_t, std::unique_ptr<Flattener>> tl_flatteners;
+        std::unique_ptr<Flattener>& slot = tl_flatteners[e->uid];
+        if (!slot) { if (tl_flatteners.size() > 8) { tl_flatteners.clear(); } tl_flatteners[e->uid].reset(new Flattener(&e->dict, &e->dict_reg)); }
+        Flattener& fl = *tl_flatteners[e->uid];
+        fl.begin_table();
         parts[w].rpt = rpt;
         const size_t lo = std::min(n, w * tiles_per * rpt), hi = std::min(n, (w + 1) * tiles_per * rpt);
         {
@@ -992,6 +1000,99 @@ int gk_table_create(gk_engine* e, const gk_review_in* reviews, size_t n, uint32_
     return GK_OK;
   } catch (const std::exception& ex) { return fail(GK_ERR_DEVICE, ex.what()); }
 }
+
+// ------------------------------------------------------------------------------------------------ audit spool (row f4)
+namespace {
+struct SpoolHolder {
+  gk_spool_info pub;   // first member
+  std::vector<std::string> names;
+  std::vector<const char*> ptrs;
+};
+bool read_file(const std::string& path, std::string* out) {
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) return false;
+  char buf[65536];
+  size_t n;
+  out->clear();
+  while ((n = fread(buf, 1, sizeof buf, f)) > 0) out->append(buf, n);
+  const bool ok = !ferror(f);
+  fclose(f);
+  return ok;
+}
+}  // namespace
+
+int gk_table_create_spool(gk_engine* e, const char* api_cache_dir, const char* kind, uint32_t folders, uint32_t flags,
+                          gk_spool_info** info, gk_table** out) {
+  if (!e || !api_cache_dir || !kind || !out) return fail(GK_ERR_INVALID, "NULL argument");
+  try {
+    std::unique_ptr<SpoolHolder> h(new SpoolHolder());
+    memset(&h->pub, 0, sizeof h->pub);
+    // 1. the files, folder by folder (reviewObjects, manager.go:676-686), numeric order within a folder
+    struct Item { std::string name, text, ns_text; };
+    std::vector<Item> items;
+    for (uint32_t fo = 0; fo < folders; fo++) {
+      const std::string sub = std::string(kind) + "_" + std::to_string(fo), dir = std::string(api_cache_dir) + "/" + sub;
+      std::vector<std::string> files;
+      if (DIR* d = opendir(dir.c_str())) {
+        while (dirent* de = readdir(d)) { if (de->d_name[0] != '.') files.emplace_back(de->d_name); }
+        closedir(d);
+      }   // (a folder that cannot be opened: "Unable to get files from directory", the loop goes on)
+      std::sort(files.begin(), files.end(), [](const std::string& a, const std::string& b) { return a.size() != b.size() ? a.size() < b.size() : a < b; });
+      for (const std::string& fn : files) {
+        h->pub.n_files++;
+        Item it;
+        it.name = sub + "/" + fn;
+        if (!read_file(dir + "/" + fn, &it.text)) { h->pub.n_unreadable++; continue; }
+        h->pub.bytes += it.text.size();
+        items.push_back(std::move(it));
+      }
+    }
+    // 2. the Namespace of every object, from the driver's cache (nsCache.Get, manager.go:694-704): looked up by metadata.namespace
+    std::unordered_map<std::string, std::string> ns_json;   // namespace name -> its JSON ("" = not cached)
+    std::vector<Item> kept;
+    for (Item& it : items) {
+      std::string nsname;
+      try {
+        Value v = parse_json(it.text.data(), it.text.size());
+        if (!v.is_object()) { h->pub.n_unreadable++; continue; }
+        nsname = obj_string(v, "metadata", "namespace");
+      } catch (const std::exception&) { h->pub.n_unreadable++; continue; }   // readUnstructured fails: logged, next file
+      if (!nsname.empty()) {
+        auto f = ns_json.find(nsname);
+        if (f == ns_json.end()) {
+          Value ns = e->ns_cache.get(nsname);
+          f = ns_json.emplace(nsname, ns.defined() ? to_json(ns) : std::string()).first;
+        }
+        if (f->second.empty()) { h->pub.n_namespace_missing++; continue; }   // "Unable to look up object namespace": skipped
+        it.ns_text = f->second;
+      }
+      kept.push_back(std::move(it));
+    }
+    // 3. one table of AugmentedUnstructured{Object, Namespace, Source: Original} + the namespaceObject option
+    std::vector<gk_review_in> rins(kept.size());
+    for (size_t i = 0; i < kept.size(); i++) {
+      gk_review_in& r = rins[i];
+      memset(&r, 0, sizeof r);
+      r.kind = GK_REVIEW_OBJECT;
+      r.source = GK_SRC_ORIGINAL;
+      r.json = kept[i].text.data(); r.json_len = kept[i].text.size();
+      if (!kept[i].ns_text.empty()) {
+        r.namespace_json = kept[i].ns_text.data(); r.namespace_len = kept[i].ns_text.size();
+        r.ns_object_json = kept[i].ns_text.data(); r.ns_object_len = kept[i].ns_text.size();
+      }
+      h->names.push_back(kept[i].name);
+    }
+    int rc = gk_table_create(e, rins.data(), rins.size(), flags, nullptr, out);
+    if (rc != GK_OK) return rc;
+    h->pub.n_reviews = kept.size();
+    for (auto& nm : h->names) h->ptrs.push_back(nm.c_str());
+    h->pub.names = h->ptrs.data();
+    if (info) *info = &h.release()->pub;
+    return GK_OK;
+  } catch (const std::exception& ex) { return fail(GK_ERR_INTERNAL, ex.what()); }
+}
+
+void gk_spool_info_free(gk_spool_info* info) { if (info) delete reinterpret_cast<SpoolHolder*>(info); }
 
 int gk_table_get_stats(const gk_table* t, gk_table_stats* out) {
   if (!t || !out) return fail(GK_ERR_INVALID, "NULL argument");

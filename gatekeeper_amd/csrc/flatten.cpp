@@ -146,7 +146,7 @@ uint32_t DictRegistry::intern(const Pattern& leaf_in, const DX& dx) {
   gen_++;
   return p->entries.back().bit;
 }
-uint64_t DictRegistry::gen() const { std::shared_lock<std::shared_mutex> l(mu_); return gen_; }
+uint64_t DictRegistry::gen() const { return gen_.load(std::memory_order_acquire); }
 bool DictRegistry::memo_get(int pi, size_t n_entries, const std::string& key, uint64_t* mask) const {
   std::shared_lock<std::shared_mutex> l(mu_);
   if (pi < 0 || (size_t)pi >= pats_.size() || pats_[pi].entries.size() != n_entries) return false;
@@ -374,6 +374,16 @@ Flattener::Flattener(PathDict* dict, const DictRegistry* reg) : dict_(dict), reg
     c.ns = dict_->child(c.metadata, "namespace");
     c.gname = dict_->child(c.metadata, "generateName");
     c.labels = dict_->child(c.metadata, "labels");
+  }
+}
+
+void Flattener::begin_table() {
+  ns_cache_.clear();
+  stage_.clear();
+  order_.clear();
+  if (reg_) {
+    const uint64_t g = reg_->gen();
+    if (g != reg_gen_) { dict_paths_.clear(); reg_gen_ = g; }
   }
 }
 

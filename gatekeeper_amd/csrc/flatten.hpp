@@ -6,6 +6,7 @@
 //  * Flattener: key-path -> value SoA rows (plan.hpp Row) + string heap + per-review header with the match-layer
 //    facts (RF_*) that pkg/mutation/match/match.go:73-258 derives from object/namespace/source.
 #pragma once
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -105,7 +106,7 @@ class DictRegistry {
   mutable std::shared_mutex mu_;
   std::vector<Pat> pats_;
   std::vector<std::pair<std::string, Pattern>> guards_, values_;
-  uint64_t gen_ = 0;
+  std::atomic<uint64_t> gen_{0};
 };
 
 uint32_t hash32(const uint8_t* p, size_t n);
@@ -242,6 +243,12 @@ struct RawReview {
 class Flattener {
  public:
   explicit Flattener(PathDict* dict, const DictRegistry* reg = nullptr);
+  // A Flattener may serve many tables one after the other (engine.cpp keeps one per host worker thread: its member-name
+  // table, its path caches and its memo of dictionary answers then survive from batch to batch instead of being rebuilt --
+  // through the engine's shared, locked structures -- by every thread for every table).  begin_table() starts a table:
+  // drops what is only valid within one (Namespace documents cached by text pointer) and, when the registry of dictionary
+  // predicates / guards / compared values has changed since the last table, the per-path answers derived from it.
+  void begin_table();
   void add(const ReviewDoc& doc, HostTable* out);
   void add_skipped(HostTable* out);   // a slot that holds no rows and is never evaluated (RF_SKIP)
   // Fast ingest: ONE pass over the JSON text of a review straight into rows -- no Value

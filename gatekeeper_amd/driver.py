@@ -456,6 +456,20 @@ class Engine:
         self._check(self.lib.gk_table_create(self.handle, arr, n, flags, st, C.byref(h)))
         return Table(self, h, list(st)[:n], n)
 
+    def create_table_spool(self, api_cache_dir, kind, folders, keep_docs=False, resident=True, process=None):
+        """gk_table_create_spool: ONE table of the objects pkg/audit spooled for `kind` under <api_cache_dir>/<kind>_<i>/
+        (manager.go:519-551), reviewed the way reviewObjects does (manager.go:667-776).  -> (Table, info dict); info["names"][i]
+        is the spool file of review i."""
+        info, h = C.POINTER(L.gk_spool_info)(), C.c_void_p()
+        flags = (L.GK_TABLE_KEEP_DOCS if keep_docs else 0) | (L.GK_TABLE_RESIDENT if resident else 0) | self._process_flag(process)
+        self._check(self.lib.gk_table_create_spool(self.handle, str(api_cache_dir).encode(), kind.encode(), int(folders), flags, C.byref(info), C.byref(h)))
+        o = info.contents
+        n = int(o.n_reviews)
+        d = {"n_files": int(o.n_files), "n_reviews": n, "n_unreadable": int(o.n_unreadable), "n_namespace_missing": int(o.n_namespace_missing),
+             "bytes": int(o.bytes), "names": [o.names[i].decode() for i in range(n)]}
+        self.lib.gk_spool_info_free(info)
+        return Table(self, h, [L.GK_OK] * n, n), d
+
     def create_table_native(self, reviews_ptr, n, keep_docs=False, resident=False, process=None):
         """gk_table_create on an existing gk_review_in array (e.g. synth.NativeBatch.reviews)"""
         st = (C.c_int32 * max(1, n))()

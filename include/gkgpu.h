@@ -114,6 +114,25 @@ int gk_table_get_stats(const gk_table* t, gk_table_stats* out);
 #define GK_TABLE_RESIDENT 2u    /* the table is evaluated again and again (audit set): the engine may compile a plan variant
                                    whose LDS layout fits this table's array sizes (first evaluation pays the compile) */
 
+/* ---- audit spool (row f4) ---------------------------------------------------------------------------------------------
+ * pkg/audit's auditResources lists every kind in chunks and writes each object, as JSON, to
+ *     <apiCacheDir>/<Kind>_<folder>/<index>                                   (manager.go:519-551)
+ * reviewObjects then re-reads the folders of one kind file by file, looks the object's Namespace up and reviews it as
+ * AugmentedUnstructured{Object, Namespace, Source: Original} with the Namespace also as the namespaceObject option
+ * (manager.go:667-776).  gk_table_create_spool is that loop's front end: it reads folders <kind>_0 .. <kind>_<folders-1>
+ * of `api_cache_dir` (files of a folder in numeric order of their names), attaches to every object the Namespace synced
+ * through gk_data_put (Driver.AddData) for its metadata.namespace, and builds ONE table of them (flags as gk_table_create).
+ * A file that cannot be read or is not a JSON object, and an object whose Namespace is not in the cache, is skipped and
+ * counted -- the reference logs the error and continues with the next file (manager.go:688-704).
+ * info->names[i] = "<Kind>_<folder>/<index>" of review i. */
+typedef struct {
+  uint64_t n_files, n_reviews, n_unreadable, n_namespace_missing, bytes;
+  const char* const* names;   /* [n_reviews] */
+} gk_spool_info;
+int gk_table_create_spool(gk_engine* e, const char* api_cache_dir, const char* kind, uint32_t folders, uint32_t flags,
+                          gk_spool_info** info, gk_table** out);
+void gk_spool_info_free(gk_spool_info* info);
+
 typedef struct {
   uint32_t n_reviews, n_constraints, n_tiles;   /* n_tiles = ceil(n_reviews / 64) */
   const uint32_t* constraint_ids;   /* [n_constraints] ids as returned by gk_constraint_add, in bitmap-row order */

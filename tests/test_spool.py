@@ -1,0 +1,68 @@
+"""Audit spool front end: pkg/audit's auditResources writes every listed object to
+<apiCacheDir>/<Kind>_<folder>/<index> (manager.go:519-551) and reviewObjects re-reads those folders file by file, attaches
+the object's Namespace and reviews it with Source Original + the namespaceObject option (manager.go:667-776).
+gk_table_create_spool takes that directory and evaluates it as one table; checked against the oracle's serial loop."""
+import json
+import os
+
+import pytest
+
+from gatekeeper_amd import driver as D
+from gatekeeper_amd import synth
+from oracle import client as OC
+from oracle import target as OT
+from parity_util import BACKENDS, key, load_both
+
+
+def _write_spool(root, kind, objs, chunk):
+    """what auditResources leaves behind for one kind listed in chunks of `chunk` objects"""
+    folders = 0
+    for lo in range(0, len(objs), chunk):
+        d = os.path.join(root, "%s_%d" % (kind, folders))
+        os.mkdir(d)
+        for i, o in enumerate(objs[lo:lo + chunk]):
+            with open(os.path.join(d, "%d" % i), "w") as fh:
+                json.dump(o, fh)
+        folders += 1
+    return folders
+
+
+@pytest.mark.parametrize("backend", [b for b in BACKENDS if b.id in ("hostemu", "gpu")])
+def test_spooled_objects_are_reviewed_like_review_objects(backend, fixtures, tmp_path):
+    nss = synth.gen_namespaces()
+    c, oc = load_both(backend, synth.psp_templates(fixtures), synth.audit_constraints())
+    pods = [o for o in synth.gen_objects(700, seed=13, mixed=True) if o["kind"] == "Pod"][:420]
+    cached = sorted({p["metadata"]["namespace"] for p in pods})[:-1]          # one namespace is NOT in the cache
+    for name in cached:
+        c.AddData(nss[name])
+        oc.add_data(nss[name])
+    folders = _write_spool(str(tmp_path), "Pod", pods, 100)
+    with open(os.path.join(str(tmp_path), "Pod_0", "100"), "w") as fh:       # a file that is not JSON: logged and skipped by the reference
+        fh.write("{not json")
+    table, info = c.driver.engine.create_table_spool(str(tmp_path), "Pod", folders, keep_docs=True)
+    try:
+        missing = [p for p in pods if p["metadata"]["namespace"] not in cached]
+        assert info["n_files"] == len(pods) + 1 and info["n_unreadable"] == 1 and info["n_namespace_missing"] == len(missing) > 0
+        assert info["n_reviews"] == len(pods) - len(missing)
+        # folder by folder, numeric file order: the order reviewObjects walks (modulo readdir order, which Go does not define)
+        want_names = ["Pod_%d/%d" % (i // 100, i % 100) for i, p in enumerate(pods) if p["metadata"]["namespace"] in cached]
+        assert info["names"] == want_names
+        ev = table.eval()
+        row = {int(cid): r for r, cid in enumerate(ev.constraint_ids)}
+        active = c._active(D.AUDIT_EP)
+        n_results = 0
+        for i, name in enumerate(info["names"]):
+            fo, fi = name.split("/")
+            obj = pods[int(fo.split("_")[1]) * 100 + int(fi)]
+            ns = nss[obj["metadata"]["namespace"]]
+            exp = oc.review(OT.AugmentedUnstructured(OT.Unstructured(obj), ns, "Original"), OC.AUDIT_EP, ns)
+            got = []
+            for cid, (cons, ea, scoped) in active.items():
+                if (int(ev.viol[row[cid]][i // 64]) >> (i % 64)) & 1:
+                    for v in table.render(cid, i):
+                        got.append(D.Result(v["msg"], cons, v.get("details"), ea, scoped))
+            assert sorted(key(r) for r in got) == sorted(key(r) for r in exp), name
+            n_results += len(exp)
+        assert n_results > 100
+    finally:
+        table.free()
