@@ -103,8 +103,12 @@ def test_bench_plan_source_compiles_for_gfx950_without_scratch(monkeypatch, tmp_
         ok, log, code = compile_gfx950(rtc, text)
         assert ok, "%s does not compile for gfx950:\n%s" % (name, log[-3000:])
         assert b"gk_jit_tiles" in code
-        if rpt == 256:      # the bench tables' geometry (4 waves per SIMD, 128 VGPRs); 64-review groups run at 7-8 waves and do spill a little
-            assert _scratch_bytes(code) == 0, "%s: the plan-specialised kernel spills (%d bytes of scratch per lane)" % (name, _scratch_bytes(code))
+        if rpt == 256:
+            # the bench tables' geometry.  Round 3 packs the accumulators into 34 words per review: three 8-wave groups per CU =
+            # 6 waves per SIMD = an 80-VGPR budget (it was 4 waves / 128 VGPRs and zero scratch).  At that budget the compiler
+            # parks up to 16 dwords of per-thread invariants (the next item's review flags, two LDS addresses) in scratch: written
+            # in the prologue / once per item, re-read in phase 2 -- never inside the chunk loop.  More than that is a regression.
+            assert 0 <= _scratch_bytes(code) <= 64, "%s: the plan-specialised kernel spills (%d bytes of scratch per lane)" % (name, _scratch_bytes(code))
 
 
 def _pattern_plans():
