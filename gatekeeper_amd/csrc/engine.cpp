@@ -244,7 +244,13 @@ struct gk_engine {
   std::map<std::string, std::vector<std::string>> excluder;
   uint64_t excluder_gen = 1;
   // plan cache
-  std::mutex plan_mu;
+  // Plans are read by every evaluation and replaced when the policy set (or the path dictionary) changes.  Evaluations of
+  // DIFFERENT tables run side by side -- each holds plan_rw shared for as long as its launches use the plan (the batcher's
+  // workers, a streamed batch being evaluated while the next one is uploaded) --; whoever replaces or walks the plans
+  // takes it exclusively.  plan_gate is a turnstile in front of the shared side, so that a waiting writer is not starved by
+  // a steady stream of readers; variants_mu guards the table-specialised variants, which evaluations create on demand.
+  std::shared_mutex plan_rw;
+  std::mutex plan_gate, variants_mu;
   bool plan_dirty = true;
   uint64_t plan_gen = 0;   // bumped whenever the device plan (and with it every variant) is rebuilt
   HostPlan fast, big;
@@ -373,7 +379,7 @@ PlanCaps default_caps(const gk_engine* e) {
 
 // Plan for one table.  Resident tables (audit sets evaluated again and again) get a variant whose element capacities
 // are what the table's largest arrays need: fewer accumulator words per review -> more tiles resident per CU, and
-// reviews that would overflow the default capacities stay on the LDS kernel.  Caller holds plan_mu; ensure_plan ran.
+// reviews that would overflow the default capacities stay on the LDS kernel.  Caller holds plan_rw (shared suffices) and variants_mu; ensure_plan ran.
 DevPlan* plan_for_table(gk_engine* e, gk_table* t, const HostPlan** host) {
   *host = &e->fast;
   if (!t->resident || e->fast.scopes.empty()) return e->dev_plan;
@@ -416,7 +422,13 @@ DevPlan* plan_for_table(gk_engine* e, gk_table* t, const HostPlan** host) {
 }
 
 void ensure_plan(gk_engine* e) {
-  std::lock_guard<std::mutex> l(e->plan_mu);
+  {   // the usual case: nothing changed -- decided without keeping other evaluations out
+    std::shared_lock<std::shared_mutex> pl(e->plan_rw);
+    std::shared_lock<std::shared_mutex> rl(e->mu);
+    if (!e->plan_dirty && e->dev_plan && e->fast.dict_size == e->dict.size()) return;
+  }
+  std::lock_guard<std::mutex> gate(e->plan_gate);
+  std::unique_lock<std::shared_mutex> l(e->plan_rw);
   std::shared_lock<std::shared_mutex> rl(e->mu);
   if (!e->plan_dirty && e->dev_plan && e->fast.dict_size == e->dict.size()) return;
   for (auto& v : e->variants) dev_plan_free(v.second->dev);
@@ -1125,26 +1137,30 @@ int gk_table_eval(gk_engine* e, gk_table* t, uint32_t flags, gk_eval_out** out) 
     opt.download = !(flags & GK_EVAL_NO_DOWNLOAD);
     opt.want_match = flags & GK_EVAL_WANT_MATCH;
     {
-      std::lock_guard<std::mutex> l(e->plan_mu);
+      { std::lock_guard<std::mutex> gate(e->plan_gate); }   // (a plan change that is waiting goes first)
+      std::shared_lock<std::shared_mutex> l(e->plan_rw);
       h->ids = e->plan_ids;
       if (flags & GK_EVAL_WANT_LIST) opt.list_capacity = std::max<uint32_t>(1024, t->n_reviews * 4u);
       const HostPlan* hp = nullptr;
-      DevPlan* dp = plan_for_table(e, t, &hp);
+      DevPlan* dp = nullptr;
+      { std::lock_guard<std::mutex> vl(e->variants_mu); dp = plan_for_table(e, t, &hp); }
       while (t->views.size() < e->extra.size()) t->views.push_back(dev_table_view(t->dev));
-      if (flags & GK_EVAL_ASYNC) {   // enqueue only; a later call without GK_EVAL_ASYNC collects
+      // every plan group is LAUNCHED before any is collected: the groups work on their own streams (views of the table) and
+      // overlap on the device as far as their footprints allow
+      if (!(flags & GK_EVAL_COLLECT)) {
         dev_eval_launch(dp, t->dev, opt);
         for (size_t gi = 0; gi < e->extra.size(); gi++) dev_eval_launch(e->extra[gi]->dev, t->views[gi], opt);
+      }
+      if (flags & GK_EVAL_ASYNC) {   // enqueue only; a later call without GK_EVAL_ASYNC collects
         *out = nullptr;
         return GK_OK;
       }
-      if (flags & GK_EVAL_COLLECT) dev_eval_finish(dp, t->dev, opt, &h->out);   // no new launch
-      else dev_eval(dp, t->dev, opt, &h->out);
+      dev_eval_finish(dp, t->dev, opt, &h->out);
       h->lds_bytes = h->out.lds_bytes;
       // further plan groups: same table, their rows are appended below the primary group's
       for (size_t gi = 0; gi < e->extra.size(); gi++) {
         EvalOut og;
-        if (flags & GK_EVAL_COLLECT) dev_eval_finish(e->extra[gi]->dev, t->views[gi], opt, &og);
-        else dev_eval(e->extra[gi]->dev, t->views[gi], opt, &og);
+        dev_eval_finish(e->extra[gi]->dev, t->views[gi], opt, &og);
         const uint32_t row_base = h->out.n_constraints;
         EvalOut& o = h->out;
         o.viol.insert(o.viol.end(), og.viol.begin(), og.viol.end());
@@ -1181,6 +1197,7 @@ int gk_table_eval(gk_engine* e, gk_table* t, uint32_t flags, gk_eval_out** out) 
     // where a predicate reads string bytes) + the groups' chunk lists (8 B per entry) + review flags, all read once;
     // plan tables read once; bitmaps written once; 8 B per list entry
     uint64_t rows_read = 0, hdrs_read = 0, bound = 0, plan_bytes = 0;
+    static const bool path_stats = getenv("GK_PATH_STATS") != nullptr;
     auto account = [&](const HostPlan& hp) {   // every plan group streams its own bound segments
       for (uint32_t pth : t->slot_path) {
         if (pth >= hp.ptab.size() || !hp.ptab[pth]) continue;
@@ -1191,12 +1208,15 @@ int gk_table_eval(gk_engine* e, gk_table* t, uint32_t flags, gk_eval_out** out) 
         bool str = false;
         for (uint32_t j = 0; j < (ent & 0xFF); j++) str = str || pred_needs_str(hp.path_preds[(ent >> 8) + j]);
         if (str) hdrs_read += n;
-        if (getenv("GK_PATH_STATS")) fprintf(stderr, "[path] %u rows %llu per-group %.1f str %d preds %u\n", pth, (unsigned long long)n, (double)n / std::max<uint32_t>(1, (p.n_reviews + t->rpt - 1) / t->rpt), (int)str, ent & 0xFF);
+        if (path_stats) fprintf(stderr, "[path] %u rows %llu per-group %.1f str %d preds %u\n", pth, (unsigned long long)n, (double)n / std::max<uint32_t>(1, (p.n_reviews + t->rpt - 1) / t->rpt), (int)str, ent & 0xFF);
       }
       plan_bytes += (uint64_t)hp.path_preds.size() * sizeof(Pred) + hp.code.size() * 4 + hp.cheap.size();
     };
-    account(e->fast);
-    for (auto& g : e->extra) account(g->fast);
+    {
+      std::shared_lock<std::shared_mutex> l(e->plan_rw);
+      account(e->fast);
+      for (auto& g : e->extra) account(g->fast);
+    }
     p.n_rows_read = rows_read;
     (void)bound;
     p.algo_bytes = rows_read * sizeof(Row) + hdrs_read * sizeof(StrHdr) + h->out.list_bytes +
@@ -1231,7 +1251,7 @@ int gk_table_topk(gk_engine* e, gk_table* t, uint32_t k, gk_topk_out** out) {
     const uint32_t cap = k + 64;
     h->ids = t->last_ids;
     {
-      std::lock_guard<std::mutex> l(e->plan_mu);
+      std::shared_lock<std::shared_mutex> l(e->plan_rw);
       const uint32_t nc0 = (uint32_t)e->plan_ids.size();
       dev_topk(t->dev, nc0, t->order, t->grp, k, cap, &h->reviews, &h->counts, &h->overflow);
       for (size_t gi = 0; gi < e->extra.size() && gi < t->views.size(); gi++) {   // further plan groups: rows appended
@@ -1269,7 +1289,7 @@ int gk_table_totals(gk_engine* e, gk_table* t, gk_totals_out** out) {
     const uint32_t nc = t->last_nc, nt = (t->n_reviews + GK_TILE - 1) / GK_TILE;
     std::vector<uint64_t> viol;
     {
-      std::lock_guard<std::mutex> l(e->plan_mu);
+      std::shared_lock<std::shared_mutex> l(e->plan_rw);
       dev_last_viol(t->dev, (uint32_t)e->plan_ids.size(), &viol);
       for (size_t gi = 0; gi < e->extra.size() && gi < t->views.size(); gi++) {
         std::vector<uint64_t> v;
@@ -1516,9 +1536,10 @@ int gk_table_sweep_sharded(gk_engine* e, gk_table* t, uint32_t flags, gk_shard_o
     ensure_plan(e);
     if (t->dict_gen != e->dict_reg.gen()) return fail(GK_ERR_INVALID, "the table was flattened before a constraint with dictionary predicates was added: create it again");
     std::unique_ptr<ShardHolder> h(new ShardHolder());
-    std::lock_guard<std::mutex> l(e->plan_mu);
+    std::shared_lock<std::shared_mutex> l(e->plan_rw);
     const HostPlan* hp = nullptr;
-    DevPlan* dp = plan_for_table(e, t, &hp);
+    DevPlan* dp = nullptr;
+    { std::lock_guard<std::mutex> vl(e->variants_mu); dp = plan_for_table(e, t, &hp); }
     const uint32_t nc0 = (uint32_t)e->plan_ids.size();
     const size_t n_groups = 1 + e->extra.size();
     while (t->views.size() < e->extra.size()) t->views.push_back(dev_table_view(t->dev));
@@ -1697,7 +1718,7 @@ int gk_resident_sweep(gk_engine* e, uint32_t flags, gk_sweep_out** out) {
     const auto t1 = std::chrono::steady_clock::now();
     ensure_plan(e);   // flattening may have interned new key paths: the plan is re-bound to the dictionary first
     uint64_t gen;
-    { std::lock_guard<std::mutex> l(e->plan_mu); gen = e->plan_gen; }
+    { std::shared_lock<std::shared_mutex> l(e->plan_rw); gen = e->plan_gen; }
     std::unique_ptr<SweepHolder> h(new SweepHolder());
     for (auto& c : R.chunks) {
       if (c.ev && c.plan_gen == gen) continue;   // bitmaps still valid: same rows, same policies
@@ -1728,7 +1749,8 @@ int gk_resident_sweep(gk_engine* e, uint32_t flags, gk_sweep_out** out) {
       const gk_eval_out* ev0 = R.chunks[0].ev;
       h->ids.assign(ev0->constraint_ids, ev0->constraint_ids + ev0->n_constraints);
     } else {
-      std::lock_guard<std::mutex> l(e->plan_mu);
+      { std::lock_guard<std::mutex> gate(e->plan_gate); }   // (a plan change that is waiting goes first)
+      std::shared_lock<std::shared_mutex> l(e->plan_rw);
       h->ids = e->plan_ids;
       for (auto& g : e->extra) h->ids.insert(h->ids.end(), g->ids.begin(), g->ids.end());
     }
@@ -1791,7 +1813,7 @@ bool resident_answer(gk_engine* e, uint32_t id, std::string* json, int* status, 
     { std::shared_lock<std::shared_mutex> l(e->mu); if (c.excl_gen != e->excluder_gen) return false; }   // Config changed since the sweep
     if (!(c.shown[o.slot / 64] & (1ull << (o.slot % 64)))) { *json = "[]"; *status = GK_OK; return true; }
   }
-  { std::lock_guard<std::mutex> l(e->plan_mu); if (e->plan_dirty || c.plan_gen != e->plan_gen) return false; }
+  { std::shared_lock<std::shared_mutex> l(e->plan_rw); if (e->plan_dirty || c.plan_gen != e->plan_gen) return false; }
   const gk_review_in in = resident_review_in(R, o);
   bool too_big = false;
   *json = query_results_json(e, c.table, *c.ev, o.slot, in, &too_big);
@@ -1943,7 +1965,7 @@ int gk_dump(gk_engine* e, char** text_out) {
   try {
     ensure_plan(e);
     std::ostringstream os;
-    std::lock_guard<std::mutex> l(e->plan_mu);
+    std::shared_lock<std::shared_mutex> l(e->plan_rw);
     const HostPlan& p = e->fast;
     os << "constraints=" << p.dims.n_constraints << " viol_formulas=" << p.n_viol << " match_formulas=" << p.n_match
        << " preds=" << p.dims.n_preds << " scopes=" << p.dims.n_scopes << " code_words=" << p.dims.n_code
