@@ -800,7 +800,10 @@ int gk_table_create(gk_engine* e, const gk_review_in* reviews, size_t n, uint32_
     t->rpt = rpt;
     t->dict_gen = e->dict_reg.gen();
     const size_t n_tiles = (n + rpt - 1) / rpt;
-    size_t n_threads = std::max<size_t>(1, std::min<size_t>(std::thread::hardware_concurrency(), (n + 511) / 512));
+    // host threads of a table build: at most 64 -- measured on the 256-thread GPU box (profiles/r03_phases_d_*.log): 1M objects
+    // flatten in 0.45 s on 64 threads, 0.61 s on 128, 0.68 s on 256 (first-touch page faults and the shared dictionaries
+    // contend; the GPU-side assembly does not care how many parts there are)
+    size_t n_threads = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(std::thread::hardware_concurrency(), 64), (n + 511) / 512));
     if (const char* ht = getenv("GK_HOST_THREADS")) n_threads = std::max(1, atoi(ht));
     n_threads = std::min(n_threads, std::max<size_t>(n_tiles, 1));
     const size_t tiles_per = (n_tiles + n_threads - 1) / std::max<size_t>(n_threads, 1);

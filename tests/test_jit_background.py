@@ -67,7 +67,8 @@ def test_first_query_after_a_policy_change_does_not_wait_for_the_compiler(fixtur
         assert more == [_expect(oc, objs[i], nss) for i in range(2, 10)]
         lib.gk_jit_quiesce()                                  # the specialised module is loaded now
         _, compiles1 = _cache_stats(lib)
-        assert compiles1 == compiles0 + 1                     # exactly one build happened, in the background
+        assert compiles1 == compiles0 + 1, (compiles0, compiles1)   # exactly one hiprtc run happened, in the background (plans re-uploaded
+        #                                                               while the path dictionary grows reuse its code object)
         after = [query(i) for i in range(10, 48)]
         assert after == [_expect(oc, objs[i], nss) for i in range(10, 48)]
         assert sum(len(x) for x in after) > 0
@@ -80,7 +81,7 @@ def test_first_query_after_a_policy_change_does_not_wait_for_the_compiler(fixtur
         assert query(1) == first
         lib.gk_jit_quiesce()
         hits_b, compiles_b = _cache_stats(lib)
-        assert compiles_b == compiles_a and hits_b == hits_a + 1
+        assert compiles_b == compiles_a and hits_b > hits_a            # served from the cache: no hiprtc run
         assert any(f.endswith(".co") for f in os.listdir(str(tmp_path)))     # ... and on disk for the next process
     finally:
         os.environ.pop("GK_JIT_CACHE_DIR", None)
