@@ -19,6 +19,8 @@ struct EvalOptions {
   bool want_match = false;   // also produce the match-only bitmap
   uint32_t list_capacity = 0;   // max violation-list entries (0 = no list)
   bool shard = false;           // results go to the shard slot prepared by dev_shard_setup (bitmap stride = the largest shard's)
+  bool jit_wait = true;         // wait for the plan-specialised build of the dominant kernel; false (admission batches): never
+                                //   block -- the bytecode kernel serves until the background build has been loaded
 };
 
 struct EvalOut {

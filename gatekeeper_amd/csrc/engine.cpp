@@ -1139,6 +1139,8 @@ int gk_table_eval(gk_engine* e, gk_table* t, uint32_t flags, gk_eval_out** out) 
     EvalOptions opt;
     opt.download = !(flags & GK_EVAL_NO_DOWNLOAD);
     opt.want_match = flags & GK_EVAL_WANT_MATCH;
+    // an admission batch (small, evaluated once) never waits for a compiler; an audit-sized or resident table does
+    opt.jit_wait = t->resident || t->n_reviews >= 8192;
     {
       { std::lock_guard<std::mutex> gate(e->plan_gate); }   // (a plan change that is waiting goes first)
       std::shared_lock<std::shared_mutex> l(e->plan_rw);

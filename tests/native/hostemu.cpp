@@ -366,7 +366,9 @@ static void emu_kernel_check(const DevPlan* p, const DevTable* dt, const EvalOpt
   std::vector<uint64_t> viol((size_t)nc * nt, 0xABABABABABABABABull), err((size_t)nc * nt, 0xABABABABABABABABull), match((size_t)nc * nt, 0xABABABABABABABABull);
   std::vector<uint64_t> ovf(nt, 0xABABABABABABABABull), big(nt, 0xABABABABABABABABull);
   std::vector<uint32_t> counts(nc, 0), list((size_t)std::max<uint32_t>(opt.list_capacity, 1) * 2, 0), lcnt(2, 0);
-  OutPtrs out{viol.data(), err.data(), opt.want_match ? match.data() : nullptr, ovf.data(), big.data(), counts.data(), list.data(), lcnt.data(), opt.list_capacity, nullptr};
+  std::vector<uint32_t> tickets(8, 0);   // group tickets per XCD (kernel_body.inc: dynamic group order), zero on entry; GK_EMU_DYN_GROUPS=1 exercises it
+  OutPtrs out{viol.data(), err.data(), opt.want_match ? match.data() : nullptr, ovf.data(), big.data(), counts.data(), list.data(), lcnt.data(), opt.list_capacity, nullptr,
+              getenv("GK_EMU_DYN_GROUPS") ? tickets.data() : nullptr};
   PlanView pv = view_of(hp);
   unsigned grid = (n_groups + 7u) / 8u * 8u;
   if (const char* g = getenv("GK_EMU_GRID")) grid = std::min<unsigned>(grid, (unsigned)std::max(8, atoi(g) / 8 * 8));   // persistent workgroups: several groups each
