@@ -84,7 +84,9 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts, const std
   // inlined into its single call site (the chunk loop): as a separate function every LDS atomic would first look the
   // dynamic-LDS base up in a table (s_getpc + s_load + full wait; seen in the gfx950 ISA) and the call frame costs scratch
   const bool inline_row = !(getenv("GK_JIT_INLINE_ROW") && atoi(getenv("GK_JIT_INLINE_ROW")) == 0);   // tuning aid
-  o << "template <class Acc>\nGK_HD __attribute__((" << (inline_row ? "always_inline" : "noinline") << ")) void jit_row(Row r, uint32_t cls, StrHdr h, const uint8_t* heap, Acc acc, bool on) {\n"
+  // `adv(class, r, h, acc, on)`: the caller's "does my next chunk have this class too?  then load it into r / h / acc / on" --
+  // a case body loops on it, so that a run of chunks of one class is dispatched once (kernel_body.inc GK_RUNS_K)
+  o << "template <class Acc, class Adv>\nGK_HD __attribute__((" << (inline_row ? "always_inline" : "noinline") << ")) void jit_row(Row r, uint32_t cls, StrHdr h, const uint8_t* heap, Acc acc, bool on, Adv adv) {\n"
     << "  const uint8_t* cheap = gk_plan_consts;\n  (void)cheap; (void)h;\n  cls = GK_UNI(cls) & ~GK_ENT_NEEDS_STR;   // one class per call: the dispatch is a scalar branch\n";
   std::ostringstream& real_o = o;
   std::vector<std::string> case_body(classes.size());
@@ -103,7 +105,7 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts, const std
     // bookkeeping (two scalar instructions per `if`) and leaves the wave-uniform class switch free of structuriser flow
     // blocks: its exits are plain branches to the join instead of a chain of ~5 hops.  (Lanes without a row address their OWN
     // review slot -- kernel_body.inc -- so the neutral operations do not pile up on one LDS bank.)
-    static const bool flat = getenv("GK_JIT_FLAT") && atoi(getenv("GK_JIT_FLAT")) != 0;
+    const bool flat = getenv("GK_JIT_FLAT") && atoi(getenv("GK_JIT_FLAT")) != 0;
     o << (flat ? "{\n      const uint32_t t = r.meta & 7u; (void)t;\n" : "if (on) {\n      const uint32_t t = r.meta & 7u; (void)t;\n");
     const std::vector<Pred>& ps = classes[c];
     struct Group { int scope, level; bool always = false; std::vector<std::string> masks; std::vector<size_t> stores; bool present = false; };
@@ -291,6 +293,12 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts, const std
     // jump tables).  The classes that own most chunks of the table the kernel is first compiled for are therefore tested
     // FIRST, in an if / else-if chain ordered by chunk count (short way in, short way out); the rest stay in the switch.
     // Any order is correct; another table only meets a less fitting one.
+    // RUN loops (kernel_body.inc GK_RUNS_K): the body of a class that owns two or more chunks per row group on average loops
+    // while the wave's next chunk has the same class.  (The loop inlines the caller's advance code: given to every class it
+    // doubled the kernel to 67 KB of code, beyond the instruction cache; the dense classes are where the runs are.)
+    std::vector<bool> loops(classes.size(), false);
+    if (class_weight && !class_weight->empty() && (*class_weight)[0] > 0)
+      for (size_t c = 1; c < classes.size() && c < class_weight->size(); c++) loops[c] = (*class_weight)[c] >= 2 * (*class_weight)[0];
     std::vector<uint32_t> hot;
     if (class_weight) {
       std::vector<uint32_t> ids;
@@ -305,15 +313,18 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts, const std
     o << "#if defined(__HIP_DEVICE_COMPILE__)\n#define GK_DISPATCH_OPAQUE(x) asm volatile(\"\" : \"+s\"(x))\n#else\n#define GK_DISPATCH_OPAQUE(x) do { } while (0)\n#endif\n";
     o << "  ";
     for (size_t i = 0; i < hot.size(); i++)
-      o << "{ uint32_t cls" << i << " = cls; GK_DISPATCH_OPAQUE(cls" << i << "); if (cls" << i << " == " << hot[i] << "u) { " << case_body[hot[i]] << "  } else ";
+      o << "{ uint32_t cls" << i << " = cls; GK_DISPATCH_OPAQUE(cls" << i << "); if (cls" << i << " == " << hot[i] << "u) { do { " << case_body[hot[i]] << "  } while ("
+        << (loops[hot[i]] ? "adv(" + std::to_string(hot[i]) + "u, r, h, acc, on)" : std::string("false")) << "); } else ";
     o << "switch (cls) {\n";
     for (size_t c = 1; c < classes.size(); c++) {
       if (std::find(hot.begin(), hot.end(), (uint32_t)c) != hot.end()) continue;
-      o << "    case " << c << ": " << case_body[c] << "    break;\n";
+      o << "    case " << c << ": do { " << case_body[c] << "    } while (" << (loops[c] ? "adv(" + std::to_string(c) + "u, r, h, acc, on)" : std::string("false")) << ");\n    break;\n";
     }
     o << "    default: break;\n  }\n";
     for (size_t i = 0; i < hot.size(); i++) o << "}";
-    o << "\n}\n\n";
+    o << "\n}\n"
+      << "struct GkNoAdv { template <class Acc> GK_HD bool operator()(uint32_t, Row&, StrHdr&, Acc&, bool&) const { return false; } };\n"
+      << "template <class Acc>\nGK_HD void jit_row(Row r, uint32_t cls, StrHdr h, const uint8_t* heap, Acc acc, bool on) { jit_row(r, cls, h, heap, acc, on, GkNoAdv{}); }\n\n";
   }
   // ---------------------------------------------------------------------------------------------- phase 2
   o << "template <class Acc>\nGK_HD Results jit_formulas(const PlanView& pv, Acc& acc, uint32_t flags, const Row* rows, const uint8_t* heap, const uint32_t* bounds) {\n"

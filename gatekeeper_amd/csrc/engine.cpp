@@ -796,6 +796,16 @@ int gk_table_create(gk_engine* e, const gk_review_in* reviews, size_t n, uint32_
     // reviews per row group: small batches (admission) keep 64-review groups; resident sets get large groups, whose
     // segments fill the lanes of the waves that stream them (plan.hpp / kernel_body.inc).  GK_RPT overrides (64|128|256|512).
     uint32_t rpt = n >= 8192 ? 256 : GK_RPT_MIN;
+    if (rpt == 256) {
+      // a large policy set (several plan groups, or accumulators too wide for three 256-review groups per CU) runs better on
+      // 128-review groups: 4-wave workgroups of half the LDS footprint keep more waves resident and let the plan groups'
+      // kernels share the CUs (configs[4]'s 200 templates: 0.81 against 1.11 ms per sweep, profiles/r03_variants_f_*.log)
+      try {
+        ensure_plan(e);
+        std::shared_lock<std::shared_mutex> pl(e->plan_rw);
+        if (!e->extra.empty() || (size_t)e->fast.dims.acc_words * 256 * 4 > 72 * 1024) rpt = 128;
+      } catch (const std::exception&) {}
+    }
     if (const char* rp = getenv("GK_RPT")) { int v = atoi(rp); if (v == 64 || v == 128 || v == 256 || v == 512) rpt = (uint32_t)v; }
     t->rpt = rpt;
     t->dict_gen = e->dict_reg.gen();

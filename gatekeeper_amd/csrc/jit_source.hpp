@@ -25,6 +25,8 @@ inline int jit_block_of(uint32_t rpt) {
   if (forced >= (int)rpt && forced <= 1024 && forced % (int)rpt == 0 && forced % GK_TILE == 0) return forced;
   return gk_block_of((int)rpt);
 }
+// runs of one predicate class per wave (chunks.hpp, kernel_body.inc GK_RUNS_K); GK_JIT_RUNS=0: one dispatch per chunk (tuning aid)
+inline bool jit_runs_enabled() { const char* v = getenv("GK_JIT_RUNS"); return !(v && atoi(v) == 0); }
 // static LDS of the dominant kernel for a row-group geometry (kernel_body.inc: two chunk-list buffers; the result words of
 // phase 2 alias one of them when they fit; the generic build also keeps the waves' loop bounds there).  res_k = 0: the
 // generic bytecode build.
@@ -72,6 +74,7 @@ inline std::string assemble_jit_source(const HostPlan& plan, uint32_t rpt, uint3
     src += "#define GK_PREFETCH " + std::to_string(depth) + "\n";
   }
   src += "#define GK_RPT_K " + std::to_string(rpt) + "\n#define GK_RPP_K " + std::to_string(rpp) + "\n";
+  if (jit_runs_enabled()) src += "#define GK_RUNS_K 1\n";
   if (const char* defs = getenv("GK_JIT_DEFINES")) {   // tuning aid: "A=1;B" -> #define A 1, #define B (kernel_body.inc variants)
     std::string d = defs, item;
     for (size_t i = 0; i <= d.size(); i++) {
@@ -82,6 +85,7 @@ inline std::string assemble_jit_source(const HostPlan& plan, uint32_t rpt, uint3
   }
   src += "namespace gk {\n#define GK_KERNEL_TILES gk_jit_tiles\n#define GK_KERNEL_BIG gk_jit_big\n#define GK_KERNEL_LINKAGE extern \"C\"\n#define GK_SKIP_BIG\n"
          "#define GK_ROW_FN(r, i, ent, h, pv, heap, acc, on) jit_row(r, ent, h, heap, acc, on)\n#define GK_BIND_ALWAYS_STR 0\n"
+         "#define GK_ROW_RUN_FN(r, ent, h, heap, acc, on, adv) jit_row(r, ent, h, heap, acc, on, adv)\n"
          "#define GK_FORMULA_FN(pv, acc, flags, rows, heap, bounds) jit_formulas(pv, acc, flags, rows, heap, bounds)\n";
   if (const char* bf = getenv("GK_JIT_BODY_FILE")) {   // tuning aid: A/B a variant of kernel_body.inc without rebuilding the library
     FILE* f = fopen(bf, "r");

@@ -54,6 +54,7 @@ static_assert(sizeof(ChunkDesc) == 8, "ChunkDesc must be 8 bytes");
 constexpr uint32_t GK_DESC_ENT_SHIFT = 6;
 constexpr uint32_t GK_DESC_ENT_MASK = 0x01FFFFFFu;   // of info >> GK_DESC_ENT_SHIFT: path-table entry (first << 8 | count) or class id
 constexpr uint32_t GK_DESC_NEEDS_STR = 1u << 25;     // of info >> GK_DESC_ENT_SHIFT: some predicate of the class reads string bytes
+constexpr uint32_t GK_DESC_NULL = 0xFFFFFFFFu;      // info of a padding entry (run-dealt lists, chunks.hpp): nothing to load, nothing to evaluate
 constexpr uint32_t GK_LIST_OVERFLOW = 1u;            // header: the group has more chunks than a list holds -> its reviews take the big path
 
 // VALUE IDS.  Rows that the loaded constraints compare with OTHER review values (Rego `==` between two review values: joins

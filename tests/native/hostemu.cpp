@@ -315,7 +315,9 @@ static EmuJitLaunch emu_jit_for(const DevPlan* p, uint32_t rpt, uint32_t rpp, in
       << "#define GK_RPT_K " << rpt << "\n#define GK_RPP_K " << rpp << "\n#define GK_BLOCK_K " << block << "\n#define GK_PREFETCH " << (pf ? pf : "1") << "\n#define GK_SKIP_BIG\n"
       << "namespace gk {\n#define GK_KERNEL_TILES gk_jit_tiles\n#define GK_KERNEL_BIG gk_jit_big\n#define GK_KERNEL_LINKAGE static\n"
          "#define GK_ROW_FN(r, i, ent, h, pv, heap, acc, on) jit_row(r, ent, h, heap, acc, on)\n#define GK_BIND_ALWAYS_STR 0\n"
+         "#define GK_ROW_RUN_FN(r, ent, h, heap, acc, on, adv) jit_row(r, ent, h, heap, acc, on, adv)\n"
          "#define GK_FORMULA_FN(pv, acc, flags, rows, heap, bounds) jit_formulas(pv, acc, flags, rows, heap, bounds)\n"
+      << (jit_runs_enabled() ? "#define GK_RUNS_K 1\n" : "")
       << "#include \"" << GK_CSRC_DIR << "/kernel_body.inc\"\n}\n"
       << "extern \"C\" void gk_emu_jit_launch(unsigned grid, unsigned block, size_t lds, const gk::PlanView* pv, const gk::Row* rows, const gk::StrHdr* shdr,\n"
          "    const gk::ChunkDesc* lists, uint32_t capg, const uint32_t* rflags, const uint8_t* heap, uint32_t n, uint32_t nt, const gk::ConstraintSlot* slots,\n"
@@ -356,7 +358,7 @@ static void emu_kernel_check(const DevPlan* p, const DevTable* dt, const EvalOpt
   const uint32_t n_groups = (n + rpt - 1) / rpt;
   uint32_t list_cap = (uint32_t)std::min(block / GK_TILE, 8) * GK_WAVE_CHUNKS;
   if (const char* lc = getenv("GK_EMU_LIST_CAP")) list_cap = std::min<uint32_t>(list_cap, (uint32_t)atoi(lc));   // test aid: list overflow
-  ChunkLists cl = build_chunk_lists(t.tile_idx.data(), n_groups, t.n_slots(), bound, list_cap, (uint32_t)(block / GK_TILE));
+  ChunkLists cl = build_chunk_lists(t.tile_idx.data(), n_groups, t.n_slots(), bound, list_cap, (uint32_t)(block / GK_TILE), jit && jit_runs_enabled());
   // reviews per pass
   uint32_t rpp = rpt;
   while (rpp > (uint32_t)GK_TILE && (size_t)hp.dims.acc_words * rpp * 4 > 140 * 1024) rpp /= 2;
@@ -366,9 +368,7 @@ static void emu_kernel_check(const DevPlan* p, const DevTable* dt, const EvalOpt
   std::vector<uint64_t> viol((size_t)nc * nt, 0xABABABABABABABABull), err((size_t)nc * nt, 0xABABABABABABABABull), match((size_t)nc * nt, 0xABABABABABABABABull);
   std::vector<uint64_t> ovf(nt, 0xABABABABABABABABull), big(nt, 0xABABABABABABABABull);
   std::vector<uint32_t> counts(nc, 0), list((size_t)std::max<uint32_t>(opt.list_capacity, 1) * 2, 0), lcnt(2, 0);
-  std::vector<uint32_t> tickets(8, 0);   // group tickets per XCD (kernel_body.inc: dynamic group order), zero on entry; GK_EMU_DYN_GROUPS=1 exercises it
-  OutPtrs out{viol.data(), err.data(), opt.want_match ? match.data() : nullptr, ovf.data(), big.data(), counts.data(), list.data(), lcnt.data(), opt.list_capacity, nullptr,
-              getenv("GK_EMU_DYN_GROUPS") ? tickets.data() : nullptr};
+  OutPtrs out{viol.data(), err.data(), opt.want_match ? match.data() : nullptr, ovf.data(), big.data(), counts.data(), list.data(), lcnt.data(), opt.list_capacity, nullptr};
   PlanView pv = view_of(hp);
   unsigned grid = (n_groups + 7u) / 8u * 8u;
   if (const char* g = getenv("GK_EMU_GRID")) grid = std::min<unsigned>(grid, (unsigned)std::max(8, atoi(g) / 8 * 8));   // persistent workgroups: several groups each
@@ -381,6 +381,7 @@ static void emu_kernel_check(const DevPlan* p, const DevTable* dt, const EvalOpt
       if (c >= weight.size()) weight.resize(c + 1, 0);
       for (uint32_t g = 0; g < n_groups; g++) weight[c] += (t.tile_idx[(size_t)g * (t.n_slots() + 1) + b.slot + 1] - t.tile_idx[(size_t)g * (t.n_slots() + 1) + b.slot] + GK_TILE - 1) / GK_TILE;
     }
+    if (!weight.empty()) weight[0] = n_groups;   // (slot 0 is no class: the number of row groups, codegen.cpp run loops)
     if (const char* dir = getenv("GK_EMU_HIP_SOURCE_DIR")) {
       // test aid (tests/test_jit_source.py): the text kernels.hip would hand to hiprtc for this plan, geometry and table
       static int n_dumped = 0;
