@@ -297,7 +297,7 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts, const std
     // while the wave's next chunk has the same class.  (The loop inlines the caller's advance code: given to every class it
     // doubled the kernel to 67 KB of code, beyond the instruction cache; the dense classes are where the runs are.)
     std::vector<bool> loops(classes.size(), false);
-    if (class_weight && !class_weight->empty() && (*class_weight)[0] > 0)
+    if (getenv("GK_JIT_RUNS") && atoi(getenv("GK_JIT_RUNS")) == 1 && class_weight && !class_weight->empty() && (*class_weight)[0] > 0)
       for (size_t c = 1; c < classes.size() && c < class_weight->size(); c++) loops[c] = (*class_weight)[c] >= 2 * (*class_weight)[0];
     std::vector<uint32_t> hot;
     if (class_weight) {

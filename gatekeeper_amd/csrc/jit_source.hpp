@@ -25,8 +25,12 @@ inline int jit_block_of(uint32_t rpt) {
   if (forced >= (int)rpt && forced <= 1024 && forced % (int)rpt == 0 && forced % GK_TILE == 0) return forced;
   return gk_block_of((int)rpt);
 }
-// runs of one predicate class per wave (chunks.hpp, kernel_body.inc GK_RUNS_K); GK_JIT_RUNS=0: one dispatch per chunk (tuning aid)
-inline bool jit_runs_enabled() { const char* v = getenv("GK_JIT_RUNS"); return !(v && atoi(v) == 0); }
+// RUNS of one predicate class per wave (chunks.hpp, kernel_body.inc GK_RUNS_K) -- measured SLOWER in round 3 and therefore off:
+// configs[2] 0.144 against 0.122 ms, the 200-template corpus 1.89 against 0.80 ms (profiles/r03_variants_g_class_runs.log; the
+// in-case loops inline the advance code into every dense class and the kernel grows from 40 to 52 KB of code).
+// GK_JIT_RUNS=1: run-dealt lists + in-case loops; 2: only the loop that reads list entries one chunk ahead (tuning aids).
+inline int jit_runs_mode() { const char* v = getenv("GK_JIT_RUNS"); return v ? atoi(v) : 0; }
+inline bool jit_runs_enabled() { return jit_runs_mode() == 1; }
 // static LDS of the dominant kernel for a row-group geometry (kernel_body.inc: two chunk-list buffers; the result words of
 // phase 2 alias one of them when they fit; the generic build also keeps the waves' loop bounds there).  res_k = 0: the
 // generic bytecode build.
@@ -74,7 +78,7 @@ inline std::string assemble_jit_source(const HostPlan& plan, uint32_t rpt, uint3
     src += "#define GK_PREFETCH " + std::to_string(depth) + "\n";
   }
   src += "#define GK_RPT_K " + std::to_string(rpt) + "\n#define GK_RPP_K " + std::to_string(rpp) + "\n";
-  if (jit_runs_enabled()) src += "#define GK_RUNS_K 1\n";
+  if (jit_runs_mode() != 0) src += "#define GK_RUNS_K 1\n";
   if (const char* defs = getenv("GK_JIT_DEFINES")) {   // tuning aid: "A=1;B" -> #define A 1, #define B (kernel_body.inc variants)
     std::string d = defs, item;
     for (size_t i = 0; i <= d.size(); i++) {

@@ -317,7 +317,7 @@ static EmuJitLaunch emu_jit_for(const DevPlan* p, uint32_t rpt, uint32_t rpp, in
          "#define GK_ROW_FN(r, i, ent, h, pv, heap, acc, on) jit_row(r, ent, h, heap, acc, on)\n#define GK_BIND_ALWAYS_STR 0\n"
          "#define GK_ROW_RUN_FN(r, ent, h, heap, acc, on, adv) jit_row(r, ent, h, heap, acc, on, adv)\n"
          "#define GK_FORMULA_FN(pv, acc, flags, rows, heap, bounds) jit_formulas(pv, acc, flags, rows, heap, bounds)\n"
-      << (jit_runs_enabled() ? "#define GK_RUNS_K 1\n" : "")
+      << (jit_runs_mode() != 0 ? "#define GK_RUNS_K 1\n" : "")
       << "#include \"" << GK_CSRC_DIR << "/kernel_body.inc\"\n}\n"
       << "extern \"C\" void gk_emu_jit_launch(unsigned grid, unsigned block, size_t lds, const gk::PlanView* pv, const gk::Row* rows, const gk::StrHdr* shdr,\n"
          "    const gk::ChunkDesc* lists, uint32_t capg, const uint32_t* rflags, const uint8_t* heap, uint32_t n, uint32_t nt, const gk::ConstraintSlot* slots,\n"
