@@ -326,6 +326,7 @@ struct gk_table {
   DevTable* dev = nullptr;
   HostTable host;               // rows/heap released after upload unless needed
   std::vector<ReviewDoc> docs;  // GK_TABLE_KEEP_DOCS
+  std::vector<gk_review_in> texts;   // GK_TABLE_KEEP_TEXT: where each review's JSON lives (caller-owned text)
   std::vector<std::string> review_errors;
   uint64_t dir_bytes = 0, n_rows = 0;      // review-flag bytes (read by every launch); rows in the table
   std::vector<uint32_t> path_rows;          // rows per path: which rows a plan reads
@@ -788,6 +789,7 @@ int gk_table_create(gk_engine* e, const gk_review_in* reviews, size_t n, uint32_
     t->review_errors.resize(n);
     t->obj_keys.resize(n);
     if (keep) t->docs.resize(n);
+    if ((flags & GK_TABLE_KEEP_TEXT) && !keep) t->texts.assign(reviews, reviews + n);
     const auto t_begin = std::chrono::steady_clock::now();
     // Reviews are flattened by host threads, each on a contiguous range of whole tiles (the path dictionary is shared and
     // thread-safe).  Fast path: JSON text -> rows in one pass (Flattener::add_json); reviews it declines -- and every
@@ -1293,11 +1295,25 @@ struct TotalsHolder {
 // Result-level totals.  The device answers "does (constraint, review) violate" (one bit); the reference counts RESULTS
 // (pkg/audit/manager.go:902: totalViolationsPerConstraint[key]++ per types.Result), and a violating pair yields as many
 // results as the template's violation set has distinct {msg, details} members for that review.  The violating pairs of
+// (the review document of table slot r: kept (GK_TABLE_KEEP_DOCS) or parsed now from the caller's text (GK_TABLE_KEEP_TEXT))
+static ReviewDoc make_doc(gk_engine* e, const gk_review_in& in) {
+  Value body = parse_json(in.json, in.json_len);
+  Value mns = parse_opt(in.namespace_json, in.namespace_len);
+  Value nso = parse_opt(in.ns_object_json, in.ns_object_len);
+  if (in.kind == GK_REVIEW_OBJECT) return normalize_object(body, mns, nso, in.source, in.operation ? in.operation : "", e->ns_cache);
+  return normalize_admission_request(body, mns, nso, in.source, e->ns_cache);
+}
+static const ReviewDoc* doc_for(gk_engine* e, const gk_table* t, uint32_t r, ReviewDoc* tmp) {
+  if (r < t->docs.size()) return &t->docs[r];
+  if (r < t->texts.size()) { *tmp = make_doc(e, t->texts[r]); return tmp; }
+  return nullptr;
+}
+
 // the table's most recent evaluation are rendered on host threads (the reference renders -- and logs -- every message
 // as well, manager.go:926-928); only the counts are kept.
 int gk_table_totals(gk_engine* e, gk_table* t, gk_totals_out** out) {
   if (!e || !t || !out) return fail(GK_ERR_INVALID, "NULL argument");
-  if (t->docs.size() != t->n_reviews) return fail(GK_ERR_INVALID, "table was created without GK_TABLE_KEEP_DOCS");
+  if (t->docs.size() != t->n_reviews && t->texts.size() != t->n_reviews) return fail(GK_ERR_INVALID, "table was created without GK_TABLE_KEEP_DOCS / GK_TABLE_KEEP_TEXT");
   try {
     std::unique_ptr<TotalsHolder> h(new TotalsHolder());
     h->ids = t->last_ids;
@@ -1333,22 +1349,24 @@ int gk_table_totals(gk_engine* e, gk_table* t, gk_totals_out** out) {
         for (;;) {
           const uint32_t tl = next_tile.fetch_add(1);
           if (tl >= nt) break;
-          for (uint32_t row = 0; row < nc; row++) {
-            for (uint64_t m = viol[(size_t)row * nt + tl]; m; m &= m - 1) {
-              const uint32_t r = tl * GK_TILE + (uint32_t)__builtin_ctzll(m);
+          // review-major: a violating review is parsed (GK_TABLE_KEEP_TEXT) at most once, then rendered for each of its constraints
+          uint64_t any = 0;
+          for (uint32_t row = 0; row < nc; row++) any |= viol[(size_t)row * nt + tl];
+          for (uint64_t m = any; m; m &= m - 1) {
+            const uint32_t b = (uint32_t)__builtin_ctzll(m), r = tl * GK_TILE + b;
+            ReviewDoc tmp;
+            const ReviewDoc* doc = doc_for(e, t, r, &tmp);
+            if (!doc) throw std::runtime_error("review document unavailable");
+            for (uint32_t row = 0; row < nc; row++) {
+              if (!((viol[(size_t)row * nt + tl] >> b) & 1ull)) continue;
               part_p[w][row]++;
-              part_r[w][row] += cref[row].tm->render(t->docs[r].request, cref[row].c->params, e->inventory).size();
+              part_r[w][row] += cref[row].tm->render(doc->request, cref[row].c->params, e->inventory).size();
             }
           }
         }
       } catch (const std::exception& ex) { errs[w] = ex.what(); }
     };
-    if (n_threads <= 1) work(0);
-    else {
-      std::vector<std::thread> th;
-      for (size_t w = 0; w < n_threads; w++) th.emplace_back(work, w);
-      for (auto& x : th) x.join();
-    }
+    HostWorkers::get().run(n_threads, work);
     for (auto& er : errs) if (!er.empty()) return fail(GK_ERR_REGO, er);
     for (size_t w = 0; w < n_threads; w++) for (uint32_t row = 0; row < nc; row++) { h->results[row] += part_r[w][row]; h->pairs[row] += part_p[w][row]; }
     h->pub.n_constraints = nc; h->pub.constraint_ids = h->ids.data(); h->pub.results = h->results.data(); h->pub.pairs = h->pairs.data();
@@ -1372,15 +1390,16 @@ void gk_eval_free(gk_eval_out* o) {
 
 int gk_render(gk_engine* e, gk_table* t, uint32_t constraint_id, uint32_t review, char** json_out) {
   if (!e || !t || !json_out) return fail(GK_ERR_INVALID, "NULL argument");
-  if (t->docs.empty()) return fail(GK_ERR_INVALID, "table was created without GK_TABLE_KEEP_DOCS");
-  if (review >= t->docs.size()) return fail(GK_ERR_INVALID, "review index out of range");
+  if (t->docs.empty() && t->texts.empty()) return fail(GK_ERR_INVALID, "table was created without GK_TABLE_KEEP_DOCS / GK_TABLE_KEEP_TEXT");
+  if (review >= std::max(t->docs.size(), t->texts.size())) return fail(GK_ERR_INVALID, "review index out of range");
   try {
     std::shared_lock<std::shared_mutex> l(e->mu);
     if (constraint_id >= e->constraints.size()) return fail(GK_ERR_NOT_FOUND, "unknown constraint id");
     const ConstraintRec& c = e->constraints[constraint_id];
     auto it = e->templates.find(lower_str(c.kind));
     if (it == e->templates.end()) return fail(GK_ERR_NOT_FOUND, "unknown constraint template validator: " + c.kind);
-    const ReviewDoc& doc = t->docs[review];
+    ReviewDoc tmp;
+    const ReviewDoc& doc = *doc_for(e, t, review, &tmp);
     ValueVec arr;
     auto vs = it->second->render(doc.request, c.params, e->inventory);
     for (auto& v : vs) {
@@ -1398,10 +1417,12 @@ int gk_render(gk_engine* e, gk_table* t, uint32_t constraint_id, uint32_t review
 
 int gk_render_error(gk_engine* e, gk_table* t, uint32_t constraint_id, uint32_t review, char** json_out) {
   if (!e || !t || !json_out) return fail(GK_ERR_INVALID, "NULL argument");
-  if (review >= t->docs.size()) return fail(GK_ERR_INVALID, "review index out of range (needs GK_TABLE_KEEP_DOCS)");
+  if (review >= std::max(t->docs.size(), t->texts.size())) return fail(GK_ERR_INVALID, "review index out of range (needs GK_TABLE_KEEP_DOCS / GK_TABLE_KEEP_TEXT)");
   std::shared_lock<std::shared_mutex> l(e->mu);
   if (constraint_id >= e->constraints.size()) return fail(GK_ERR_NOT_FOUND, "unknown constraint id");
-  std::string msg = autoreject_message(e->constraints[constraint_id].match, t->docs[review]);
+  ReviewDoc tmp;
+  std::string msg;
+  try { msg = autoreject_message(e->constraints[constraint_id].match, *doc_for(e, t, review, &tmp)); } catch (const std::exception& ex) { return fail(GK_ERR_REGO, ex.what()); }
   ValuePairs o{{Value::string("msg"), Value::string(msg)}, {Value::string("autoreject"), Value::boolean(true)}, {Value::string("details"), Value::object({})}};
   std::string s = to_json(Value::array({Value::object(o)}));
   char* buf = (char*)malloc(s.size() + 1);

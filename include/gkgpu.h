@@ -111,6 +111,9 @@ int gk_table_get_stats(const gk_table* t, gk_table_stats* out);
 #define GK_TABLE_PROCESS_AUDIT 4u     /* apply the process excluder (gk_excluder_replace) for process "audit" / "webhook":     */
 #define GK_TABLE_PROCESS_WEBHOOK 8u   /* excluded reviews keep their slot, hold no rows and get status GK_REVIEW_EXCLUDED      */
 #define GK_REVIEW_EXCLUDED 1          /* statuses[i]: skipped before evaluation (not an error)                                 */
+#define GK_TABLE_KEEP_TEXT 16u  /* remember WHERE the reviews' JSON text lives (the gk_review_in array is copied, the text is NOT: the
+                                   caller keeps it alive as long as the table) so that gk_table_totals / gk_render / gk_render_error
+                                   can parse the few reviews they need on demand -- no parsed copy of a million objects */
 #define GK_TABLE_RESIDENT 2u    /* the table is evaluated again and again (audit set): the engine may compile a plan variant
                                    whose LDS layout fits this table's array sizes (first evaluation pays the compile) */
 
@@ -171,7 +174,7 @@ void gk_eval_free(gk_eval_out* o);
 
 /* Driver.Query result rendering for one (constraint, review) pair flagged in `viol`: evaluates the template on the
  * host for that pair only and returns a JSON array [{"msg": "...", "details": ...}] (types.Result.Msg / Metadata).
- * Needs GK_TABLE_KEEP_DOCS. */
+ * Needs GK_TABLE_KEEP_DOCS or GK_TABLE_KEEP_TEXT. */
 int gk_render(gk_engine* e, gk_table* t, uint32_t constraint_id, uint32_t review, char** json_out);
 /* The autoreject result for a pair flagged in `err` (frameworks Client.Review turns a Matcher.Match error into a
  * result; message pinned by test/gator/test/test.bats:301): [{"msg": "unable to match constraints: ...", ...}] */
@@ -198,7 +201,8 @@ void gk_topk_free(gk_topk_out* o);
 /* Result-level totals of the table's most recent evaluation (row a11): pkg/audit/manager.go:902 increments
  * totalViolationsPerConstraint once per types.Result, and one violating (constraint, object) pair yields as many
  * results as the template's violation set has distinct {msg, details} members.  `pairs` = popcount of the bitmap row,
- * `results` = what the reference's counters hold.  Needs GK_TABLE_KEEP_DOCS. */
+ * `results` = what the reference's counters hold.  Needs GK_TABLE_KEEP_DOCS or GK_TABLE_KEEP_TEXT (then only the violating
+ * reviews are parsed, once each, on the host workers). */
 typedef struct {
   uint32_t n_constraints;
   const uint32_t* constraint_ids;

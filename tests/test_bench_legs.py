@@ -28,3 +28,45 @@ def test_python_oracle_leg_checks_the_bitmaps(fixtures):
     ev.viol[3][1] ^= np.uint64(1 << 17)          # one wrong bit must be found
     bad = bench.python_oracle_leg(templates, constraints, batch, ev, n)
     assert not bad["pairs_equal"] and bad["only_device"] + bad["only_oracle"] == 1
+
+
+def test_result_totals_from_kept_text_equal_kept_docs_and_the_oracle(fixtures):
+    """RESULT totals (pkg/audit/manager.go:902: one per types.Result) of a table built WITHOUT parsed documents
+    (GK_TABLE_KEEP_TEXT: only the violating reviews are parsed, once each) = the totals of a GK_TABLE_KEEP_DOCS table = the
+    oracle's result counts; gk_render works from the kept text as well."""
+    from oracle import client as OC
+    from oracle import target as OT
+    templates, constraints = synth.psp_templates(fixtures), synth.audit_constraints()
+    drv = D.Driver(device=0, hostemu=True)
+    client, oc = D.Client(drv), OC.Client()
+    for t in templates:
+        client.AddTemplate(t)
+        oc.add_template(t)
+    for k in constraints:
+        client.AddConstraint(k)
+        oc.add_constraint(k)
+    n = 400
+    nss = synth.gen_namespaces()
+    batch = synth.NativeBatch(drv.engine.lib, n, seed=synth.SEED, mixed=True, start=0, namespaces=nss)
+    lean = drv.engine.create_table_native(batch.reviews, n, keep_docs=False, resident=True, keep_text=True)
+    full = drv.engine.create_table_native(batch.reviews, n, keep_docs=True, resident=True)
+    ev = lean.eval()
+    full.eval()
+    a, b = lean.totals(), full.totals()
+    assert a == b and sum(r for r, _ in a.values()) > 100
+    want = {}
+    for o in synth.gen_objects(n, seed=synth.SEED, mixed=True):
+        for r in oc.review(OT.AugmentedUnstructured(OT.Unstructured(o), synth.namespace_for(o, nss), "Original"), OC.AUDIT_EP):
+            key = (r.constraint["kind"], r.constraint["metadata"]["name"])
+            want[key] = want.get(key, 0) + 1
+    got = {}
+    for cid, (cons, _, _) in client._active(D.AUDIT_EP).items():
+        if a.get(cid, (0, 0))[0]:
+            got[(cons["kind"], cons["metadata"]["name"])] = a[cid][0]
+    assert got == want
+    row = {int(cid): i for i, cid in enumerate(ev.constraint_ids)}
+    cid = next(c for c in a if a[c][1])
+    r = int(D.EvalResult.bits(ev.viol[row[cid]], ev.n_reviews)[0])
+    assert lean.render(cid, r) == full.render(cid, r) and lean.render(cid, r)
+    lean.free()
+    full.free()
