@@ -35,18 +35,28 @@ inline bool jit_runs_enabled() { return jit_runs_mode() == 1; }
 // phase 2 alias one of them when they fit; the generic build also keeps the waves' loop bounds there).  res_k = 0: the
 // generic bytecode build.
 inline uint32_t list_cap_of(int block) { return (uint32_t)std::min(block / GK_TILE, 8) * GK_WAVE_CHUNKS; }
-inline size_t static_lds_of(uint32_t rpt, int block, uint32_t res_k) {
-  const size_t list = (size_t)list_cap_of(block) * 8;
+// list capacity a plan-specialised build is compiled for: what the table's longest list needs (`need` entries incl. the
+// header), in steps of 128, at most the geometry's; the two list buffers are most of the kernel's static LDS, and at
+// configs[2] (90 entries of 512) the 6 KB saved are the difference between three and four resident groups per CU
+inline uint32_t jit_list_cap(int block, uint32_t need) {
+  const uint32_t full = list_cap_of(block);
+  if (getenv("GK_JIT_FULL_LISTS")) return full;   // tuning aid
+  uint32_t c = 128;
+  while (c < need && c < full) c += 128;
+  return std::min(c, full);
+}
+inline size_t static_lds_of(uint32_t rpt, int block, uint32_t res_k, uint32_t list_cap = 0) {
+  const size_t list = (size_t)(list_cap ? list_cap : list_cap_of(block)) * 8;
   const size_t masks = (size_t)(rpt / GK_TILE) * 3 * (res_k ? res_k : GK_MAX_RES) * 8;
   const size_t bounds = res_k ? 0 : (size_t)(block / GK_TILE) * GK_MAX_SCOPES * 4;
   return 2 * list + (masks <= list ? 8 : masks) + bounds + GK_TILE * 4 + 64;
 }
 inline size_t max_dyn_lds_of(uint32_t rpt) { return GK_LDS_PER_CU - static_lds_of(rpt, gk_block_of((int)rpt), 0) - 256; }
-inline size_t max_dyn_lds_jit(uint32_t rpt, uint32_t res_k) { return GK_LDS_PER_CU - static_lds_of(rpt, jit_block_of(rpt), res_k) - 256; }
+inline size_t max_dyn_lds_jit(uint32_t rpt, uint32_t res_k, uint32_t list_cap = 0) { return GK_LDS_PER_CU - static_lds_of(rpt, jit_block_of(rpt), res_k, list_cap) - 256; }
 
 // plan_hpp / vm_core_hpp / kernel_body: plan.hpp, vm_core.hpp and kernel_body.inc as text (build/jit_sources.inc)
 inline std::string assemble_jit_source(const HostPlan& plan, uint32_t rpt, uint32_t rpp, const std::vector<uint64_t>* class_weight, const char* plan_hpp,
-                                       const char* vm_core_hpp, const char* kernel_body) {
+                                       const char* vm_core_hpp, const char* kernel_body, uint32_t list_cap = 0) {
   std::string src =
       "typedef unsigned char uint8_t; typedef unsigned short uint16_t; typedef unsigned int uint32_t; typedef unsigned long long uint64_t;\n"
       "typedef short int16_t; typedef int int32_t; typedef long long int64_t;\n";
@@ -62,7 +72,7 @@ inline std::string assemble_jit_source(const HostPlan& plan, uint32_t rpt, uint3
     // register budget: as many waves per SIMD as the LDS footprint lets groups be resident per CU (waves per SIMD =
     // groups per CU x waves per group / 4 SIMDs); measured on configs[1] with 64-review groups: 7 waves (72 VGPRs) edges
     // out 8 (64 VGPRs, twice the spill traffic) and clearly beats 5-6
-    const size_t per_group = (size_t)plan.dims.acc_words * rpp * 4 + static_lds_of(rpt, block, jit_res_k(plan));
+    const size_t per_group = (size_t)plan.dims.acc_words * rpp * 4 + static_lds_of(rpt, block, jit_res_k(plan), list_cap);
     const size_t groups_per_cu = std::max<size_t>(1, GK_LDS_PER_CU / per_group);
     int waves = (int)std::min<size_t>(8, std::max<size_t>(block / 256, groups_per_cu * (block / GK_TILE) / 4));   // waves per SIMD the LDS allows
     if (const char* w = getenv("GK_JIT_WAVES")) waves = atoi(w);   // tuning aid
@@ -78,6 +88,7 @@ inline std::string assemble_jit_source(const HostPlan& plan, uint32_t rpt, uint3
     src += "#define GK_PREFETCH " + std::to_string(depth) + "\n";
   }
   src += "#define GK_RPT_K " + std::to_string(rpt) + "\n#define GK_RPP_K " + std::to_string(rpp) + "\n";
+  if (list_cap) src += "#define GK_LIST_CAP_K " + std::to_string(list_cap) + "\n";
   if (jit_runs_mode() != 0) src += "#define GK_RUNS_K 1\n";
   if (const char* defs = getenv("GK_JIT_DEFINES")) {   // tuning aid: "A=1;B" -> #define A 1, #define B (kernel_body.inc variants)
     std::string d = defs, item;
