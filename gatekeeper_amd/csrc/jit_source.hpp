@@ -35,12 +35,14 @@ inline bool jit_runs_enabled() { return jit_runs_mode() == 1; }
 // phase 2 alias one of them when they fit; the generic build also keeps the waves' loop bounds there).  res_k = 0: the
 // generic bytecode build.
 inline uint32_t list_cap_of(int block) { return (uint32_t)std::min(block / GK_TILE, 8) * GK_WAVE_CHUNKS; }
-// list capacity a plan-specialised build is compiled for: what the table's longest list needs (`need` entries incl. the
-// header), in steps of 128, at most the geometry's; the two list buffers are most of the kernel's static LDS, and at
-// configs[2] (90 entries of 512) the 6 KB saved are the difference between three and four resident groups per CU
+// list capacity a plan-specialised build is compiled for.  GK_JIT_TRIM_LISTS=1 (tuning aid): what the table's longest list
+// needs (`need` entries incl. the header), in steps of 128 -- the two list buffers are most of the kernel's static LDS, and
+// at configs[2] (90 entries of 512) the 3 KB saved are the difference between three and four resident groups per CU.  Measured
+// in round 3 and OFF: four groups mean a 64-VGPR budget, whose 12 spilled dwords are reloaded in phase 2 -- formulas 18.0 k
+// clocks per group against 10.0 k, 0.133 against 0.1235 ms (profiles/r03_variants_h_four_groups_per_cu_64_vgprs.log).
 inline uint32_t jit_list_cap(int block, uint32_t need) {
   const uint32_t full = list_cap_of(block);
-  if (getenv("GK_JIT_FULL_LISTS")) return full;   // tuning aid
+  if (!getenv("GK_JIT_TRIM_LISTS")) return full;
   uint32_t c = 128;
   while (c < need && c < full) c += 128;
   return std::min(c, full);
