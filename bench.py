@@ -367,7 +367,8 @@ def main():
                                        "one ncclAllReduce of int64 totals, issued by the engine on the kernel's stream" % world) if dist is not None else "1 GPU",
                        "global_violating_pairs": int(sharded.totals.sum()) if sharded is not None else int(counts.sum()),
                        "violating_pairs_rank0": int(counts.sum()), "reviews_beyond_limits_rank0": len(final.too_big_reviews())},
-            "roofline": {"bound": "hbm", "kernel": "gk_eval_tiles", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            # (the plan-specialised build -- what rocprofv3 shows for this workload; GK_NO_JIT=1 runs the generic bytecode build instead)
+            "roofline": {"bound": "hbm", "kernel": "gk_eval_tiles_256" if os.environ.get("GK_NO_JIT") else "gk_jit_tiles", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algo_bytes_per_launch": int(res.algo_bytes),
                          "avg_kernel_ms": iso.fast_kernel_ms, "launches_timed": int(iso.n_launches),
                          # (one event pair around all launches of a view; the plan groups of a >64-formula constraint set share
