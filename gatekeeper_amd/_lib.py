@@ -10,6 +10,7 @@ the flattener can be checked against the oracle in the GPU-less build container.
 """
 from __future__ import annotations
 
+import atexit
 import ctypes as C
 import os
 
@@ -96,6 +97,7 @@ class gk_shard_out(C.Structure):
 
 
 GK_SHARD_DOWNLOAD = 1
+GK_SHARD_ENQUEUE = 2
 GK_COMM_ID_BYTES = 128
 HE_ALLGATHER = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_uint64)     # test-only (libgkgpu_hostemu.so gk_comm_init_host)
 HE_ALLREDUCE = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_longlong), C.c_uint64)
@@ -218,5 +220,8 @@ def load(hostemu: bool | None = None):
     lib.gk_synth_batch_free.argtypes = [vp]
     lib.gk_synth_batch_free.restype = None
     lib.gk_synth_query_storm.argtypes = [vp, vp, u32, u32, C.POINTER(gk_storm_out)]
+    # a plan-specialised kernel may still be compiling in the background when the interpreter exits; exit() under a running
+    # hiprtc compile crashes in the compiler's teardown, so the builds are joined first (Python's atexit runs before exit())
+    atexit.register(lib.gk_jit_quiesce)
     _cache[hostemu] = lib
     return lib

@@ -84,7 +84,9 @@ void dev_shard_setup(DevTable* t, DevComm* c, uint32_t nc, ShardInfo* info);   /
 // all-reduce (sum) of the totals, on the evaluation stream; then synchronises and copies what was asked for to the host.
 // totals: [nc] violating pairs | [nc] autoreject pairs (match errors) | reviews beyond the engine's limits | reviews not
 // evaluated (`not_evaluated` of this rank: rejected by HandleReview when the table was built), each summed over ALL shards --
-// what the gathered violation bitmaps cannot say, so that a sharded audit fails closed like the single-GPU one
+// what the gathered violation bitmaps cannot say, so that a sharded audit fails closed like the single-GPU one.
+// totals == nullptr: ENQUEUE ONLY -- counts, all-gather and all-reduce go onto the stream behind the launches of
+// dev_eval_launch and the call returns without waiting (back-to-back sweeps; the collecting call comes last)
 void dev_shard_exchange(DevTable* t, DevComm* c, uint32_t nc, uint64_t not_evaluated, std::vector<int64_t>* totals,
                         std::vector<uint64_t>* gathered /* may be null */, const void** d_gathered);
 // Plan-specialised builds of the dominant kernel run in the background for admission batches (kernels.hip jit_for): wait for

@@ -522,6 +522,7 @@ int gk_engine_create(const gk_opts* opts, gk_engine** out) {
 void gk_engine_destroy(gk_engine* e) {
   if (!e) return;
   gk_batcher_stop(e);
+  dev_jit_quiesce();   // background builds of this engine's plans (a host that destroys its engines before exit() never exits under a running compile)
   if (e->comm) dev_comm_free(e->comm);
   for (auto& c : e->resident.chunks) { if (c.ev) gk_eval_free(c.ev); if (c.table) gk_table_free(c.table); }
   if (e->dev_plan) dev_plan_free(e->dev_plan);
@@ -1566,7 +1567,8 @@ struct ShardHolder {
 };
 
 int gk_table_sweep_sharded(gk_engine* e, gk_table* t, uint32_t flags, gk_shard_out** out) {
-  if (!e || !t || !out) return fail(GK_ERR_INVALID, "NULL argument");
+  const bool enqueue = (flags & GK_SHARD_ENQUEUE) != 0;
+  if (!e || !t || (!out && !enqueue)) return fail(GK_ERR_INVALID, "NULL argument");
   if (!e->comm) return fail(GK_ERR_INVALID, "gk_comm_init first");
   try {
     ensure_plan(e);
@@ -1588,6 +1590,19 @@ int gk_table_sweep_sharded(gk_engine* e, gk_table* t, uint32_t flags, gk_shard_o
     EvalOptions opt;
     opt.download = false;
     opt.shard = true;
+    opt.jit_wait = true;   // a shard of the audit set is a resident table: the plan-specialised kernel or nothing
+    uint64_t rejected = 0;
+    for (const std::string& er : t->review_errors) if (!er.empty()) rejected++;
+    if (enqueue) {   // sweep + exchange of every plan group onto the stream(s); whoever collects waits for them
+      dev_eval_launch(dp, t->dev, opt);
+      dev_shard_exchange(t->dev, e->comm, nc0, rejected, nullptr, nullptr, nullptr);
+      for (size_t gi = 0; gi < e->extra.size(); gi++) {
+        dev_eval_launch(e->extra[gi]->dev, t->views[gi], opt);
+        dev_shard_exchange(t->views[gi], e->comm, (uint32_t)e->extra[gi]->ids.size(), rejected, nullptr, nullptr, nullptr);
+      }
+      if (out) *out = nullptr;
+      return GK_OK;
+    }
     EvalOut eo;
     // local evaluation, finished (incl. the large-capacity pass for overflowing reviews) BEFORE the exchange, so that the
     // gathered bitmaps are complete; then the exchange step on the same stream.  A constraint set that needs several
@@ -1598,8 +1613,6 @@ int gk_table_sweep_sharded(gk_engine* e, gk_table* t, uint32_t flags, gk_shard_o
     std::vector<uint64_t> g0;
     // what the bitmaps cannot say travels with the totals (fail closed, like Client.AuditAggregate): autoreject pairs, reviews
     // beyond the engine's limits, reviews HandleReview rejected when this shard was built
-    uint64_t rejected = 0;
-    for (const std::string& er : t->review_errors) if (!er.empty()) rejected++;
     int64_t beyond = 0, not_eval = 0;
     auto split = [&](std::vector<int64_t>& raw, uint32_t ncg, bool first) {   // raw: [ncg] pairs | [ncg] autoreject | beyond | not evaluated
       h->err_totals.insert(h->err_totals.end(), raw.begin() + ncg, raw.begin() + 2 * (size_t)ncg);

@@ -110,8 +110,8 @@ class ShardedSweep:
 
     def sweep(self, steps=1, download=False, strict=False):
         """`steps` passes of the hot path over the resident shard.  Single process: the launches are enqueued back to back and
-        collected once -> EvalResult.  Sharded: every pass is local evaluation + the engine's exchange step -> ShardedResult
-        of the last pass.  A sharded result carries `beyond_limits` / `not_evaluated` / `err_totals` (summed over all shards):
+        collected once -> EvalResult.  Sharded: every pass is local evaluation + the engine's exchange step, enqueued back to
+        back on the shard's stream (GK_SHARD_ENQUEUE); the last pass collects -> ShardedResult of the last pass.  A sharded result carries `beyond_limits` / `not_evaluated` / `err_totals` (summed over all shards):
         objects the totals and bitmaps say nothing about.  strict=True raises driver.LimitError / driver.ReviewFailure for
         them, as Client.AuditAggregate reports them for a single table (every rank raises: the counts are global)."""
         if self.dist is None:
@@ -121,8 +121,11 @@ class ShardedSweep:
         eng = self.client.driver.engine
         res = None
         for k in range(steps):
+            if k < steps - 1:   # sweep + exchange enqueued back to back on the shard's stream; the last pass collects
+                eng._check(eng.lib.gk_table_sweep_sharded(eng.handle, self.table.handle, L.GK_SHARD_ENQUEUE, None))
+                continue
             out = C.POINTER(L.gk_shard_out)()
-            flags = L.GK_SHARD_DOWNLOAD if (download and k == steps - 1) else 0
+            flags = L.GK_SHARD_DOWNLOAD if download else 0
             eng._check(eng.lib.gk_table_sweep_sharded(eng.handle, self.table.handle, flags, C.byref(out)))
             res = ShardedResult(eng.lib, out)
         if strict and res is not None:

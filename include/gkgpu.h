@@ -245,6 +245,11 @@ typedef struct {
   int64_t not_evaluated;             /* reviews HandleReview rejected when their shard's table was built (GK_ERR_REVIEW) */
 } gk_shard_out;
 #define GK_SHARD_DOWNLOAD 1u
+/* GK_SHARD_ENQUEUE: put one sweep + its exchange step onto the table's stream and return at once (`out` is not written and may
+ * be NULL) -- back-to-back sweeps of a resident shard without a host round trip per sweep.  A call without the flag collects:
+ * it runs one more sweep, waits, and returns the answer.  Only that collecting sweep re-runs reviews that overflowed the
+ * dominant kernel's element capacity; the engine's limits apply as before.  Collective like every call of this function. */
+#define GK_SHARD_ENQUEUE 2u
 int gk_table_sweep_sharded(gk_engine* e, gk_table* t, uint32_t flags, gk_shard_out** out);
 void gk_shard_free(gk_shard_out* o);
 

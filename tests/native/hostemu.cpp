@@ -185,17 +185,19 @@ void dev_shard_exchange(DevTable* t, DevComm* c, uint32_t nc, uint64_t not_evalu
   uint8_t* slot = t->shard_all.data() + (size_t)c->rank * t->shard_slot;
   memset(slot, 0, t->shard_slot);
   std::vector<long long> tot(2 * (size_t)nc + 2, 0);   // [nc] pairs | [nc] autoreject pairs | beyond limits | not evaluated
-  for (uint32_t k = 0; k < nc; k++) for (uint32_t w = 0; w < nt; w++) tot[nc + k] += __builtin_popcountll(t->last_err[(size_t)k * nt + w]);
+  const bool have = t->last_viol.size() == (size_t)nc * nt && t->last_err.size() == (size_t)nc * nt;   // (an enqueue-only pass before the first finished evaluation exchanges zeros)
+  for (uint32_t k = 0; k < nc && have; k++) for (uint32_t w = 0; w < nt; w++) tot[nc + k] += __builtin_popcountll(t->last_err[(size_t)k * nt + w]);
   for (uint32_t w = 0; w < nt && w < t->last_big.size(); w++) tot[2 * (size_t)nc] += __builtin_popcountll(t->last_big[w]);
   tot[2 * (size_t)nc + 1] = (long long)not_evaluated;
   for (uint32_t k = 0; k < nc; k++) {
     uint32_t cnt = 0;
-    for (uint32_t w = 0; w < nt; w++) { const uint64_t v = t->last_viol[(size_t)k * nt + w]; memcpy(slot + ((size_t)k * t->shard_stride + w) * 8, &v, 8); cnt += (uint32_t)__builtin_popcountll(v); }
+    for (uint32_t w = 0; w < nt; w++) { const uint64_t v = have ? t->last_viol[(size_t)k * nt + w] : 0; memcpy(slot + ((size_t)k * t->shard_stride + w) * 8, &v, 8); cnt += (uint32_t)__builtin_popcountll(v); }
     memcpy(slot + (size_t)nc * t->shard_stride * 8 + (size_t)k * 4, &cnt, 4);
     tot[k] = cnt;
   }
   c->gather(c->ctx, t->shard_all.data(), t->shard_slot);
   c->reduce(c->ctx, tot.data(), (uint32_t)tot.size());
+  if (!totals) return;   // enqueue only
   totals->assign(tot.begin(), tot.end());
   if (gathered) { gathered->resize(t->shard_all.size() / 8); memcpy(gathered->data(), t->shard_all.data(), t->shard_all.size()); }
   if (d_gathered) *d_gathered = t->shard_all.data();

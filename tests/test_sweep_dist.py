@@ -43,7 +43,7 @@ def _worker(rank, world, port, out_dir, policies="audit"):
     shard = objs[lo:lo + SHARDS[rank]]
     sw = ShardedSweep(_client(policies), shard, synth.gen_namespaces(), dist=dist, device=torch.device("cpu"), keep_docs=True)
     sw.sweep(2)
-    res = sw.sweep(1, download=True)
+    res = sw.sweep(3, download=True)   # two enqueued sweep + exchange passes (GK_SHARD_ENQUEUE), the third collects
     lists = sw.audit_lists(limit=5)
     with open(os.path.join(out_dir, "rank_%d.pkl" % rank), "wb") as fh:
         pickle.dump({"bitmaps": res.bitmaps(), "totals": res.totals, "counts": res.counts(), "shards": res.shard_reviews, "lists": lists,
