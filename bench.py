@@ -37,7 +37,9 @@ def cpu_leg(templates, constraints, batch, ev, budget_s=10.0):
     from oracle import cpu_ref as CR
     ref = CR.CpuRef(templates, constraints)
     nc = len(constraints)
-    cores = os.cpu_count() or 1
+    # the CPUs this process may really use (gk_host_cpus: affinity mask and cgroup CPU quota applied -- the GPU boxes of this
+    # pool show 256 hardware threads behind a 16-CPU quota, and 256 threads under that quota are SLOWER than 16)
+    cores = int(batch.lib.gk_host_cpus()) or os.cpu_count() or 1
     probe_n = min(batch.n, 1024)
     probe = ref.review(batch.reviews, probe_n, 1)
     rate1 = probe_n / max(probe["seconds"], 1e-9)               # reviews/s on one thread
@@ -64,7 +66,8 @@ def cpu_leg(templates, constraints, batch, ev, budget_s=10.0):
                       "restated in cpu_ref.cpp, but its JSON reader, HandleReview normalisation and Rego tree-walker are the "
                       "PRODUCT's host objects (flatten.o / pe.o) -- this times the product's concrete evaluator inside the "
                       "reference's loop, not OPA; the independent checker is parity_python_oracle" % (n1, nc, one["seconds"]),
-            "all_cores": {"value": nall * nc / allc["seconds"], "cores": cores, "sample_reviews": nall, "seconds": allc["seconds"]}}
+            "all_cores": {"value": nall * nc / allc["seconds"], "cores": cores, "hardware_threads": os.cpu_count(), "sample_reviews": nall, "seconds": allc["seconds"],
+                          "note": "cores = CPUs usable under the affinity mask / cgroup CPU quota (gk_host_cpus), one thread each"}}
     parity = {"n": nall, "constraints": nc, "pairs_equal": equal, "device_violating_pairs": dev_pairs, "cpu_violating_pairs": cpu_pairs,
               "checker": "oracle/cpu_ref.cpp (violation + autoreject bitmaps, bit for bit; Match layer independent, Rego evaluator = the "
                          "product's host interpreter -- see parity_python_oracle for the fully independent leg)"}
@@ -380,6 +383,7 @@ def main():
             "end_to_end": {"what": "rank 0: JSON text -> parse -> HandleReview -> flatten -> row groups -> HBM for the %d objects of its shard "
                                    "(gk_table_create), then one sweep" % n_local,
                            "flatten_s": st["flatten_s"], "h2d_s": st["upload_s"], "sweep_s": dt / args.steps, "host_threads": st["host_threads"],
+                           "host_cpus_usable": int(drv.engine.lib.gk_host_cpus()), "host_hardware_threads": os.cpu_count(),
                            "json_bytes": st["json_bytes"], "reviews_per_s": n_local / e2e_s if e2e_s > 0 else None,
                            "evals_per_s": nc * n_local / (e2e_s + dt / args.steps) if e2e_s > 0 else None,
                            "json_MBps": st["json_bytes"] / st["flatten_s"] / 1e6 if st["flatten_s"] > 0 else None,

@@ -38,7 +38,7 @@ EXPORTS = [
     "gk_table_totals", "gk_totals_free", "gk_table_get_stats", "gk_batcher_start", "gk_batcher_stop", "gk_query",
     "gk_resident_sweep", "gk_sweep_free", "gk_resident_review",
     "gk_comm_unique_id", "gk_comm_init", "gk_comm_destroy", "gk_table_sweep_sharded", "gk_shard_free",
-    "gk_jit_quiesce", "gk_jit_cache_stats", "gk_table_create_spool", "gk_spool_info_free",
+    "gk_jit_quiesce", "gk_jit_cache_stats", "gk_host_cpus", "gk_table_create_spool", "gk_spool_info_free",
     # include/gksynth.h (bench / test plumbing)
     "gk_synth_batch_create", "gk_synth_batch_reviews", "gk_synth_batch_size", "gk_synth_batch_json_bytes", "gk_synth_batch_free", "gk_synth_query_storm",
 ]
@@ -160,6 +160,8 @@ def load(hostemu: bool | None = None):
     lib.gk_engine_destroy.restype = None
     lib.gk_last_error.restype = cp
     lib.gk_version.restype = cp
+    lib.gk_host_cpus.argtypes = []
+    lib.gk_host_cpus.restype = C.c_uint32
     lib.gk_template_add.argtypes = [vp, cp, cp, C.POINTER(cp), sz]
     lib.gk_template_remove.argtypes = [vp, cp]
     lib.gk_constraint_add.argtypes = [vp, cp, sz, C.POINTER(u32)]

@@ -190,7 +190,7 @@ class HostWorkers {
     for (auto& t : threads_) t.join();
   }
  private:
-  HostWorkers() : max_(std::max<size_t>(1, std::thread::hardware_concurrency())) {}
+  HostWorkers() : max_(std::max<size_t>(1, std::thread::hardware_concurrency())) {}   // (a ceiling: callers ask for host_cpus() workers unless GK_HOST_THREADS says otherwise)
   void work() {
     for (;;) {
       size_t i;
@@ -519,6 +519,8 @@ int gk_engine_create(const gk_opts* opts, gk_engine** out) {
   return GK_OK;
 }
 
+uint32_t gk_host_cpus(void) { return (uint32_t)host_cpus(); }
+
 void gk_engine_destroy(gk_engine* e) {
   if (!e) return;
   gk_batcher_stop(e);
@@ -816,7 +818,7 @@ int gk_table_create(gk_engine* e, const gk_review_in* reviews, size_t n, uint32_
     // host threads of a table build: at most 64 -- measured on the 256-thread GPU box (profiles/r03_phases_d_*.log): 1M objects
     // flatten in 0.45 s on 64 threads, 0.61 s on 128, 0.68 s on 256 (first-touch page faults and the shared dictionaries
     // contend; the GPU-side assembly does not care how many parts there are)
-    size_t n_threads = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(std::thread::hardware_concurrency(), 64), (n + 511) / 512));
+    size_t n_threads = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(host_cpus(), 64), (n + 511) / 512));
     if (const char* ht = getenv("GK_HOST_THREADS")) n_threads = std::max(1, atoi(ht));
     n_threads = std::min(n_threads, std::max<size_t>(n_tiles, 1));
     const size_t tiles_per = (n_tiles + n_threads - 1) / std::max<size_t>(n_threads, 1);
@@ -1340,7 +1342,7 @@ int gk_table_totals(gk_engine* e, gk_table* t, gk_totals_out** out) {
       if (it == e->templates.end()) return fail(GK_ERR_NOT_FOUND, "unknown constraint template validator: " + c.kind);
       cref[row] = {&c, it->second.get()};
     }
-    size_t n_threads = std::max<size_t>(1, std::min<size_t>(std::thread::hardware_concurrency(), nt / 4 + 1));
+    size_t n_threads = std::max<size_t>(1, std::min<size_t>(host_cpus(), nt / 4 + 1));
     if (const char* ht = getenv("GK_HOST_THREADS")) n_threads = std::max(1, atoi(ht));
     std::vector<std::vector<uint64_t>> part_r(n_threads, std::vector<uint64_t>(nc, 0)), part_p(n_threads, std::vector<uint64_t>(nc, 0));
     std::vector<std::string> errs(n_threads);

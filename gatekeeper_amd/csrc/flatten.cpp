@@ -1,5 +1,9 @@
 // See flatten.hpp.
 #include "flatten.hpp"
+
+#include <sched.h>
+#include <cstdio>
+#include <thread>
 #include <sys/mman.h>
 #include <mutex>
 
@@ -215,6 +219,27 @@ struct HostPool {
 };
 HostPool& host_pool() { static HostPool p; return p; }
 }  // namespace
+
+size_t host_cpus() {
+  static const size_t n = [] {
+    size_t hw = std::max<size_t>(1, std::thread::hardware_concurrency());
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof set, &set) == 0 && CPU_COUNT(&set) > 0) hw = std::min<size_t>(hw, (size_t)CPU_COUNT(&set));
+    long long quota = 0, period = 0;
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {   // cgroup v2: "<quota|max> <period>"
+      char q[32] = {0};
+      if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atoll(q);
+      fclose(f);
+    } else {
+      if (FILE* fq = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(fq, "%lld", &quota) != 1) quota = 0; fclose(fq); }
+      if (FILE* fp = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(fp, "%lld", &period) != 1) period = 0; fclose(fp); }
+    }
+    if (quota > 0 && period > 0) hw = std::min<size_t>(hw, (size_t)std::max<long long>(1, (quota + period - 1) / period));
+    return hw;
+  }();
+  return n;
+}
 
 void* host_block_alloc(size_t bytes, size_t* cap_bytes) {
   size_t cls = kHostBlockMin;

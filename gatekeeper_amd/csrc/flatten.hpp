@@ -151,6 +151,12 @@ bool obj_is_namespace(const Value& obj);
 // process's address-space lock: round 2 measured 4.6x on 256 threads.  Blocks of 1 MiB and more therefore come from a
 // process-wide pool: size classes of powers of two, handed back to the pool
 // (not to the kernel) when a part is released, up to GK_HOST_POOL_MB (default 8192) kept.  Smaller blocks use malloc / realloc.
+// CPUs this process may actually use: the hardware threads, cut down to the scheduler affinity mask and to the cgroup CPU
+// bandwidth quota (cpu.max, or cfs_quota_us / cfs_period_us under cgroup v1).  A container that sees 256 hardware threads
+// behind a 16-CPU quota is throttled for most of every period when 256 workers run (measured in round 3: RESULT totals of
+// 200 k objects 0.78 s on 16 threads, 2.6 s on 256; profiles/r03_host_threads_under_cpu_quota.json).  Every host pool sizes
+// itself by this number; GK_HOST_THREADS overrides it.
+size_t host_cpus();
 void* host_block_alloc(size_t bytes, size_t* cap_bytes);   // bytes >= kHostBlockMin; *cap_bytes = the size class
 void host_block_free(void* p, size_t cap_bytes);
 constexpr size_t kHostBlockMin = 1u << 20;

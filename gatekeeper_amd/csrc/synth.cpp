@@ -234,7 +234,7 @@ int gk_synth_batch_create(uint64_t seed, uint64_t start, uint64_t n, int mixed, 
   if (namespace_jsons) for (size_t k = 0; k < n_namespaces; k++) b->ns_json.emplace_back(namespace_jsons[k]);
   b->json.resize(n);
   b->reviews.resize(n);
-  size_t n_threads = std::max<size_t>(1, std::min<size_t>(std::thread::hardware_concurrency(), n / 4096 + 1));
+  size_t n_threads = std::max<size_t>(1, std::min<size_t>(gk_host_cpus(), n / 4096 + 1));
   std::vector<int> ns_idx(n, -1);
   const bool as_request = (mixed & 2) != 0;   // Pods wrapped in the AdmissionRequest the webhook receives (CREATE)
   if (as_request && (mixed & 1)) { delete b; return GK_ERR_INVALID; }

@@ -45,6 +45,9 @@ int gk_engine_create(const gk_opts* opts, gk_engine** out);
 void gk_engine_destroy(gk_engine* e);
 const char* gk_last_error(void);
 const char* gk_version(void);
+/* CPUs the engine's host pools size themselves by: hardware threads, cut down to the affinity mask and the cgroup CPU quota
+ * (a container that shows 256 hardware threads behind a 16-CPU quota gets 16); GK_HOST_THREADS overrides the pools. */
+uint32_t gk_host_cpus(void);
 
 /* ---- policy state (drivers.Driver Add/Remove*, boundary exemplar pkg/drivers/k8scel/driver.go:74-160) ----- */
 /* Driver.AddTemplate: kind as in spec.crd.spec.names.kind; rego + libs from Source.Value{"rego","libs"}
