@@ -818,7 +818,10 @@ int gk_table_create(gk_engine* e, const gk_review_in* reviews, size_t n, uint32_
     // host threads of a table build: at most 64 -- measured on the 256-thread GPU box (profiles/r03_phases_d_*.log): 1M objects
     // flatten in 0.45 s on 64 threads, 0.61 s on 128, 0.68 s on 256 (first-touch page faults and the shared dictionaries
     // contend; the GPU-side assembly does not care how many parts there are)
-    size_t n_threads = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(host_cpus(), 64), (n + 511) / 512));
+    // (ingest is a BURST: a 64 k-review batch is 20-25 ms of work on 64 threads, shorter than the 100 ms period of a cgroup CPU
+    //  quota, so it may run wider than the quota -- measured on a 16-CPU-quota box: streaming 2.3-2.5 M reviews/s on 64 threads,
+    //  1.8 M/s on 16; the 1 M-object build is the same either way.  Sustained host passes (gk_table_totals) size by host_cpus().)
+    size_t n_threads = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(std::thread::hardware_concurrency(), 64), (n + 511) / 512));
     if (const char* ht = getenv("GK_HOST_THREADS")) n_threads = std::max(1, atoi(ht));
     n_threads = std::min(n_threads, std::max<size_t>(n_tiles, 1));
     const size_t tiles_per = (n_tiles + n_threads - 1) / std::max<size_t>(n_threads, 1);

@@ -107,16 +107,46 @@ namespace {
 struct UnboundVar : std::runtime_error { using std::runtime_error::runtime_error; };
 
 SVP mksv(SV s) { return std::make_shared<const SV>(std::move(s)); }
-SVP sv_const(const Value& v) { SV s; s.kind = SV::CONST; s.c = v; return mksv(s); }
-SVP sv_path(const SPath& p) { SV s; s.kind = SV::PATH; s.path = p; return mksv(s); }
+SVP sv_const(const Value& v) { SV s; s.kind = SV::CONST; s.c = v; return mksv(std::move(s)); }
+SVP sv_path(const SPath& p) { SV s; s.kind = SV::PATH; s.path = p; return mksv(std::move(s)); }
 SVP sv_bool(FP t, FP d) {
   if ((t->kind == FNode::T || t->kind == FNode::F) && d->kind == FNode::T) return sv_const(Value::boolean(t->kind == FNode::T));
   if (d->kind == FNode::F) return sv_const(Value());
-  SV s; s.kind = SV::BOOLF; s.f = t; s.d = d; return mksv(s);
+  SV s; s.kind = SV::BOOLF; s.f = t; s.d = d; return mksv(std::move(s));
 }
 
+// Variable bindings of one evaluation state.  States are copied far more often than they are extended (every value an
+// expression yields carries its state), so the bindings are shared between copies and cloned by the first write: a sorted
+// vector behind a shared pointer (a std::map here was a node allocation per variable per copy -- a fifth of a host render).
+class Env {
+  typedef std::pair<std::string, SVP> E;
+  std::shared_ptr<std::vector<E>> v_;
+  std::vector<E>& own() {
+    if (!v_) v_ = std::make_shared<std::vector<E>>();
+    else if (v_.use_count() > 1) v_ = std::make_shared<std::vector<E>>(*v_);
+    return *v_;
+  }
+  static bool before(const E& e, const std::string& k) { return e.first < k; }
+ public:
+  const SVP* get(const std::string& k) const {
+    if (!v_) return nullptr;
+    auto it = std::lower_bound(v_->begin(), v_->end(), k, before);
+    return it != v_->end() && it->first == k ? &it->second : nullptr;
+  }
+  bool count(const std::string& k) const { return get(k) != nullptr; }
+  void set(const std::string& k, const SVP& v) {
+    std::vector<E>& o = own();
+    auto it = std::lower_bound(o.begin(), o.end(), k, before);
+    if (it != o.end() && it->first == k) it->second = v; else o.insert(it, E(k, v));
+  }
+  void erase(const std::string& k) {
+    if (!get(k)) return;
+    std::vector<E>& o = own();
+    o.erase(std::lower_bound(o.begin(), o.end(), k, before));
+  }
+};
 struct State {
-  std::map<std::string, SVP> env;
+  Env env;
   std::vector<FP> conds;
   std::vector<std::pair<int, SPath>> quants;
 };
@@ -168,7 +198,7 @@ SVP rn_sv(const SVP& v, const QMap& m) {
   }
   if (s.f) s.f = rn_f(s.f, m);
   if (s.d) s.d = rn_f(s.d, m);
-  return mksv(s);
+  return mksv(std::move(s));
 }
 
 Atom atom_path(Atom::Kind k, const SPath& p) { Atom a; a.kind = k; a.path = p; return a; }
@@ -191,7 +221,7 @@ bool leaf_local(const SVP& v, SPath* leaf, DX* dx) {
   }
   return false;
 }
-SVP sv_derived(const SPath& leaf, DX dx) { SV s; s.kind = SV::DERIVED; s.path = leaf; s.dx = std::move(dx); return mksv(s); }
+SVP sv_derived(const SPath& leaf, DX dx) { SV s; s.kind = SV::DERIVED; s.path = leaf; s.dx = std::move(dx); return mksv(std::move(s)); }
 FP f_dict(const SPath& leaf, DX dx) { Atom a; a.kind = Atom::DICT; a.path = leaf; a.dx = std::move(dx); return f_atom(a); }
 // operands of one operation: constants and values derived from the SAME leaf -> their expressions
 bool same_leaf_args(const std::vector<SVP>& args, SPath* leaf, std::vector<DX>* dxs) {
@@ -249,7 +279,7 @@ class PE {
     in.kind = SV::OBJ;
     in.fields.emplace_back(Value::string("parameters"), sv_const(params.defined() ? params : Value::object({})));
     in.fields.emplace_back(Value::string("review"), review);
-    input_ = mksv(in);
+    input_ = mksv(std::move(in));
   }
 
   // value of the main package's `violation` partial set
@@ -323,8 +353,8 @@ class PE {
       if (kind == Rule::PartialObject) {
         SV o; o.kind = SV::OBJ;
         for (auto& p : obj_pairs) o.fields.emplace_back(p.first->c, p.second);
-        v = fold(mksv(o));
-      } else v = fold(mksv(out));
+        v = fold(mksv(std::move(o)));
+      } else v = fold(mksv(std::move(out)));
       alts.push_back({v, {}, {}});
     } else {
       Alt def;
@@ -788,7 +818,7 @@ class PE {
     FP d = defined_f(v);
     if (d->kind == FNode::F) return;
     if (d->kind != FNode::T) s.conds.push_back(d);
-    if (name.compare(0, 2, "$w") != 0) s.env[name] = v;
+    if (name.compare(0, 2, "$w") != 0) s.env.set(name, v);
     out.push_back(std::move(s));
   }
 
@@ -876,7 +906,7 @@ class PE {
           SV v;
           v.kind = t->kind == Term::Array ? SV::ARR : SV::SET;
           for (auto& x : vals) v.elems.push_back({x, f_true()});
-          out.push_back({fold(mksv(v)), s2});
+          out.push_back({fold(mksv(std::move(v))), s2});
         });
         break;
       }
@@ -888,7 +918,7 @@ class PE {
             if (vals[i]->kind != SV::CONST) unsupported("symbolic object key", t->line);
             v.fields.emplace_back(vals[i]->c, vals[i + 1]);
           }
-          out.push_back({fold(mksv(v)), s2});
+          out.push_back({fold(mksv(std::move(v))), s2});
         });
         break;
       }
@@ -901,7 +931,7 @@ class PE {
           eval_term(t->head, b, r, hs);
           for (Val& h : hs) add_member(v, h.v, h.s, s.conds.size(), s.quants.size());
         }
-        out.push_back({fold(mksv(v)), s});
+        out.push_back({fold(mksv(std::move(v))), s});
         break;
       }
       case Term::ObjComp: {
@@ -950,8 +980,7 @@ class PE {
   }
 
   void eval_var(const TermP& t, const State& s, const Rule* r, Vals& out) {
-    auto it = s.env.find(t->name);
-    if (it != s.env.end()) { out.push_back({it->second, s}); return; }
+    if (const SVP* bound = s.env.get(t->name)) { out.push_back({*bound, s}); return; }
     if (t->name == "input") { out.push_back({input_, s}); return; }
     if (t->name == "data") { eval_data_ref({}, s, r, out, t->line); return; }
     if (find_rules(rule_pkg(r), t->name)) { use_alts(rule_alts(rule_pkg(r), t->name), s, out); return; }
@@ -1013,7 +1042,7 @@ class PE {
         SPath p = cur->path;
         Step st; st.iter = true; st.q = q;
         p.push_back(st);
-        fn(mksv(k), sv_path(p), n);
+        fn(mksv(std::move(k)), sv_path(p), n);
         break;
       }
       case SV::OBJ:
@@ -1108,7 +1137,7 @@ class PE {
                      k->cut == cur->cut && k->sep == cur->sep) {
             c.idx = k->idx;   // arr[count(arr) - m]
           } else unsupported("symbolic index into split()", line);
-          fn(mksv(c), s);
+          fn(mksv(std::move(c)), s);
           return;
         }
         unsupported("index into a derived string", line);
@@ -1123,7 +1152,7 @@ class PE {
       bool wild = op->name.compare(0, 2, "$w") == 0;
       iterate(cur, s, line, [&](const SVP& key, const SVP& val, const State& s2) {
         State n = s2;
-        if (!wild) { if (!key) unsupported("key of a conditional array", line); n.env[op->name] = key; }
+        if (!wild) { if (!key) unsupported("key of a conditional array", line); n.env.set(op->name, key); }
         walk(val, ops, i + 1, n, r, out, line);
       });
       return;
@@ -1175,7 +1204,7 @@ class PE {
     if (a->kind == SV::STRX && a->xkind == SV::XCOUNT && b->kind == SV::CONST && b->c.is_number() && b->c.is_int && (op == "-" || op == "+")) {
       SV c = *a;
       c.idx += (int)(op == "-" ? -b->c.i : b->c.i);
-      return mksv(c);
+      return mksv(std::move(c));
     }
     std::vector<CondElem> ae, be;
     std::vector<Gen> ag, bg;
@@ -1189,7 +1218,7 @@ class PE {
       if (op == "|") {
         o.elems = ae; o.elems.insert(o.elems.end(), be.begin(), be.end());
         o.gens = ag; o.gens.insert(o.gens.end(), bg.begin(), bg.end());
-        return fold(mksv(o));
+        return fold(mksv(std::move(o)));
       }
       bool diff = op == "-";
       for (auto& e : ae) {
@@ -1203,7 +1232,7 @@ class PE {
         n.cond = f_and(g.cond, diff ? f_not(m) : m);
         if (n.cond->kind != FNode::F) o.gens.push_back(n);
       }
-      return fold(mksv(o));
+      return fold(mksv(std::move(o)));
     }
     unsupported("arithmetic '" + op + "' on review data", line);
   }
@@ -1266,14 +1295,14 @@ class PE {
       if (a[0]->kind != SV::CONST || !a[0]->c.is_string()) unsupported("sprintf with a symbolic format", line);
       SV o; o.kind = SV::OPAQUE; o.f = defined_f(a[1]);
       if (a[1]->kind == SV::PATH) o.f = f_type(a[1]->path, M_ARRAY);
-      out.push_back({mksv(o), s});
+      out.push_back({mksv(std::move(o)), s});
       return;
     }
     if (name == "count") {
       need(1);
       const SVP& x = a[0];
-      if (x->kind == SV::PATH) { SV c; c.kind = SV::COUNTOF; c.path = x->path; out.push_back({mksv(c), s}); return; }
-      if (x->kind == SV::STRX && x->xkind == SV::XARR) { SV c = *x; c.xkind = SV::XCOUNT; c.idx = 0; out.push_back({mksv(c), s}); return; }
+      if (x->kind == SV::PATH) { SV c; c.kind = SV::COUNTOF; c.path = x->path; out.push_back({mksv(std::move(c)), s}); return; }
+      if (x->kind == SV::STRX && x->xkind == SV::XARR) { SV c = *x; c.xkind = SV::XCOUNT; c.idx = 0; out.push_back({mksv(std::move(c)), s}); return; }
       if (x->kind == SV::SET || x->kind == SV::ARR) {
         SV c; c.kind = SV::CARD; c.gens = x->gens; c.idx = x->kind == SV::ARR ? 1 : 0;
         if (x->kind == SV::ARR) c.elems = x->elems;
@@ -1284,7 +1313,7 @@ class PE {
             if (!merged) c.elems.push_back(e);
           }
         }
-        out.push_back({mksv(c), s});
+        out.push_back({mksv(std::move(c)), s});
         return;
       }
       if (x->kind == SV::DERIVED) { out.push_back({sv_derived(x->path, dx_node(DExpr::CALL, {x->dx}, "count")), s}); return; }
@@ -1371,7 +1400,7 @@ class PE {
       need(2);
       if (a[0]->kind == SV::PATH && a[1]->kind == SV::CONST && a[1]->c.is_string() && a[1]->c.str().size() == 1) {
         SV x; x.kind = SV::STRX; x.path = a[0]->path; x.cut = a[1]->c.str()[0]; x.xkind = SV::XTRIM;
-        out.push_back({mksv(x), s});
+        out.push_back({mksv(std::move(x)), s});
         return;
       }
       { SPath leaf; std::vector<DX> dx; if (same_leaf_args(a, &leaf, &dx)) { out.push_back({sv_derived(leaf, dx_node(DExpr::CALL, dx, name)), s}); return; } }
@@ -1381,8 +1410,8 @@ class PE {
       need(2);
       if (a[1]->kind == SV::CONST && a[1]->c.is_string() && a[1]->c.str().size() == 1) {
         SV x; x.kind = SV::STRX; x.sep = a[1]->c.str()[0]; x.xkind = SV::XARR;
-        if (a[0]->kind == SV::PATH) { x.path = a[0]->path; out.push_back({mksv(x), s}); return; }
-        if (a[0]->kind == SV::STRX && a[0]->xkind == SV::XTRIM) { x.path = a[0]->path; x.cut = a[0]->cut; out.push_back({mksv(x), s}); return; }
+        if (a[0]->kind == SV::PATH) { x.path = a[0]->path; out.push_back({mksv(std::move(x)), s}); return; }
+        if (a[0]->kind == SV::STRX && a[0]->xkind == SV::XTRIM) { x.path = a[0]->path; x.cut = a[0]->cut; out.push_back({mksv(std::move(x)), s}); return; }
       }
       unsupported("split() with these operands on review data", line);
     }
@@ -1422,7 +1451,7 @@ class PE {
     if (name == "type_name") {   // total on defined operands; the result is only good for messages (comparing it is refused where it is compared)
       need(1);
       SV o; o.kind = SV::OPAQUE; o.f = defined_f(a[0]);
-      out.push_back({mksv(o), s});
+      out.push_back({mksv(std::move(o)), s});
       return;
     }
     if (name == "concat" && a.size() == 2 && a[0]->kind == SV::CONST && a[0]->c.is_string() && a[1]->kind == SV::ARR && a[1]->gens.empty()) {
@@ -1432,7 +1461,7 @@ class PE {
       for (auto& e : a[1]->elems) { if (e.cond && e.cond->kind != FNode::T) { plain = false; break; } d = f_and(d, is_string_f(e.v)); }
       if (plain) {
         SV o; o.kind = SV::OPAQUE; o.f = d;
-        out.push_back({mksv(o), s});
+        out.push_back({mksv(std::move(o)), s});
         return;
       }
     }
