@@ -219,6 +219,7 @@ def main():
     ap.add_argument("--reviews", type=int, default=None, help="objects per GPU (weak) / in total (strong); default 1000000 (config 2), 100000 (config 1)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lean", action="store_true", help="tuning runs: the timed sweep and the roofline figures only (no RESULT totals, no CPU / oracle legs)")
     ap.add_argument("--streaming", action="store_true", help="configs[4] as a STREAM: batches of --batch reviews through ingest -> H2D -> launch -> D2H, "
                     "double-buffered, round robin over the ranks; reports the achieved rate and the batch latency percentiles (steps = --stream-batches)")
     ap.add_argument("--batch", type=int, default=65536, help="reviews per streamed batch")
@@ -402,6 +403,8 @@ def main():
         # violating pair) of the MEASURED table: the violating objects are parsed from the batch's JSON text (once each) and
         # rendered on the host workers -- a host pass over the violating pairs, outside the timed region
         try:
+            if args.lean:
+                raise RuntimeError("skipped (--lean)")
             t_tot = time.perf_counter()
             tot = table.totals()
             t_tot = time.perf_counter() - t_tot
@@ -409,7 +412,7 @@ def main():
                                           "what": "gk_table_totals on the timed table (GK_TABLE_KEEP_TEXT): host render of every violating pair, no parsed copy of the objects"}
         except Exception as ex:   # noqa: BLE001
             out["audit_result_totals"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and not args.lean:
             out["cpu_baseline"], out["parity_sample"] = cpu_leg(templates, defaulted, batch, final)
             try:
                 out["parity_python_oracle"] = python_oracle_leg(templates, constraints, batch, final, args.oracle_sample)

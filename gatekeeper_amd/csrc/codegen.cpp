@@ -7,6 +7,7 @@
 #include "chunks.hpp"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -475,7 +476,101 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts, const std
     }
     uint32_t n_stages = 0;
     for (auto& B : blks) n_stages = std::max(n_stages, B.stage + 1);
-    std::vector<std::vector<size_t>> parts((size_t)n_stages * NW);
+    std::vector<std::vector<size_t>> parts;
+    // CHAINS (round 3).  A block of a later stage only waits for the blocks that write the derived bits it reads.  When those
+    // run on the SAME wave, program order is all it needs (lane = review in every block: a wave reads back what its own lanes
+    // OR-ed into LDS): such a block is appended to its producers' share of stage 0.  Producers that sit in another share
+    // are DUPLICATED into this one when they are cheap (derived bits are ORs: writing one twice is harmless).  If every later
+    // block can be placed that way the formulas take ONE stage -- one barrier and one call per item instead of one per level
+    // of derived bits (configs[2]: three stages, the last two a dozen lines each, profiles/r03_*).  Otherwise: stages as before.
+    bool chained = false;
+    static const bool chain_on = !(getenv("GK_JIT_CHAIN") && atoi(getenv("GK_JIT_CHAIN")) == 0);   // tuning aid
+    if (chain_on && n_stages > 1) {
+      std::vector<std::vector<size_t>> deps(blks.size());   // direct producers
+      {
+        std::map<uint64_t, size_t> w2;
+        for (size_t bi = 0; bi < blks.size(); bi++) {
+          for (uint64_t r : blks[bi].reads) { auto it = w2.find(r); if (it != w2.end() && it->second != bi) deps[bi].push_back(it->second); }
+          for (uint64_t w : blks[bi].writes) w2[w] = bi;
+        }
+      }
+      std::vector<std::vector<size_t>> closure(blks.size());   // transitive producers, ascending
+      for (size_t bi = 0; bi < blks.size(); bi++) {
+        std::vector<size_t> c;
+        for (size_t d : deps[bi]) { c.push_back(d); c.insert(c.end(), closure[d].begin(), closure[d].end()); }
+        std::sort(c.begin(), c.end());
+        c.erase(std::unique(c.begin(), c.end()), c.end());
+        closure[bi] = c;
+      }
+      std::vector<std::vector<bool>> in_part(NW, std::vector<bool>(blks.size(), false));
+      std::vector<uint64_t> load(NW, 0);
+      uint64_t total = 0, dup_total = 0;
+      for (auto& B : blks) total += B.cost;
+      // (a) FAMILIES: blocks connected by derived bits go to one share as a whole (no duplicates), heaviest family to the
+      //     lightest share -- as long as no family outweighs a fair share by much
+      {
+        std::vector<size_t> root(blks.size());
+        for (size_t i = 0; i < blks.size(); i++) root[i] = i;
+        auto find = [&](size_t x) { while (root[x] != x) x = root[x] = root[root[x]]; return x; };
+        for (size_t bi = 0; bi < blks.size(); bi++) for (size_t d : deps[bi]) root[find(bi)] = find(d);
+        std::map<size_t, uint64_t> fam_cost;
+        for (size_t bi = 0; bi < blks.size(); bi++) fam_cost[find(bi)] += blks[bi].cost;
+        uint64_t biggest = 0;
+        for (auto& kv : fam_cost) biggest = std::max(biggest, kv.second);
+        if (biggest * NW <= total + total / 8) {
+          std::vector<size_t> fams;
+          for (auto& kv : fam_cost) fams.push_back(kv.first);
+          std::stable_sort(fams.begin(), fams.end(), [&](size_t x, size_t y) { return fam_cost[x] > fam_cost[y]; });
+          for (size_t f : fams) {
+            uint32_t w = 0;
+            for (uint32_t k = 1; k < NW; k++) if (load[k] < load[w]) w = k;
+            load[w] += fam_cost[f];
+            for (size_t bi = 0; bi < blks.size(); bi++) if (find(bi) == f) in_part[w][bi] = true;
+          }
+          chained = true;
+        }
+      }
+      // (b) a family too heavy for one share: stage-0 blocks dealt as the staged form deals them; a later block joins the share
+      //     that holds most of its producers, the missing ones are duplicated if that is cheap
+      if (!chained) {
+        std::vector<size_t> ids;
+        for (size_t bi = 0; bi < blks.size(); bi++) if (blks[bi].stage == 0) ids.push_back(bi);
+        std::stable_sort(ids.begin(), ids.end(), [&](size_t x, size_t y) { return blks[x].cost > blks[y].cost; });
+        for (size_t bi : ids) {
+          uint32_t w = 0;
+          for (uint32_t k = 1; k < NW; k++) if (load[k] < load[w]) w = k;
+          load[w] += blks[bi].cost;
+          in_part[w][bi] = true;
+        }
+        const uint64_t dup_max = std::max<uint64_t>(64, total / NW / 8);   // duplicated cost allowed per block
+        chained = true;
+        for (size_t bi = 0; bi < blks.size() && chained; bi++) {
+          if (blks[bi].stage == 0) continue;
+          uint32_t best = NW;
+          uint64_t best_extra = 0;
+          for (uint32_t k = 0; k < NW; k++) {
+            uint64_t extra = 0;
+            for (size_t d : closure[bi]) if (!in_part[k][d]) extra += blks[d].cost;
+            if (extra > dup_max) continue;
+            if (best == NW || extra + load[k] < best_extra + load[best]) { best = k; best_extra = extra; }
+          }
+          if (best == NW) { chained = false; break; }
+          for (size_t d : closure[bi]) in_part[best][d] = true;
+          in_part[best][bi] = true;
+          load[best] += best_extra + blks[bi].cost;
+          dup_total += best_extra;
+        }
+        if (chained && dup_total > total / 4) chained = false;   // (duplicates are work done twice)
+      }
+      if (chained) {
+        n_stages = 1;
+        parts.assign(NW, {});
+        for (uint32_t k = 0; k < NW; k++) for (size_t bi = 0; bi < blks.size(); bi++) if (in_part[k][bi]) parts[k].push_back(bi);
+      }
+      if (getenv("GK_DEBUG_STAGES")) fprintf(stderr, "[gkgpu stages] %zu blocks, cost %llu, chained %d, duplicated cost %llu\n", blks.size(), (unsigned long long)total, (int)chained, (unsigned long long)dup_total);
+    }
+    if (!chained) {
+    parts.assign((size_t)n_stages * NW, {});
     for (uint32_t st = 0; st < n_stages; st++) {   // greedy balance: heaviest block to the lightest wave
       std::vector<size_t> ids;
       for (size_t bi = 0; bi < blks.size(); bi++) if (blks[bi].stage == st) ids.push_back(bi);
@@ -487,6 +582,7 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts, const std
         load[w] += blks[bi].cost;
         parts[(size_t)st * NW + w].push_back(bi);
       }
+    }
     }
     o << "#define GK_HAS_STAGES 1\nconstexpr uint32_t GK_N_STAGES = " << n_stages << "u;\nconstexpr uint32_t GK_GEN_PARTS = " << NW << "u;\n"
       << "#ifndef GK_RES\n#define GK_RES(kind, slot, b) do { if ((kind) == 0) res.viol |= (uint64_t)(b) << (slot); else if ((kind) == 1) res.match |= (uint64_t)(b) << (slot); "

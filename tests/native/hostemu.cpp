@@ -2,6 +2,8 @@
 // AOT compiler, the flattener and the formula VM can be checked against the oracle in the GPU-less build container.
 // It executes exactly the same per-row / per-review code as kernels.hip, lane by lane.  The product library
 // (libgkgpu.so) never contains this file; gatekeeper_amd/_lib.py refuses to load it outside tests.
+#include <array>
+#include <map>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -361,6 +363,27 @@ static void emu_kernel_check(const DevPlan* p, const DevTable* dt, const EvalOpt
   uint32_t list_cap = (uint32_t)std::min(block / GK_TILE, 8) * GK_WAVE_CHUNKS;
   if (const char* lc = getenv("GK_EMU_LIST_CAP")) list_cap = std::min<uint32_t>(list_cap, (uint32_t)atoi(lc));   // test aid: list overflow
   ChunkLists cl = build_chunk_lists(t.tile_idx.data(), n_groups, t.n_slots(), bound, list_cap, (uint32_t)(block / GK_TILE), jit && jit_runs_enabled());
+  if (getenv("GK_EMU_CHUNK_STATS")) {   // diagnostic: chunks / rows per predicate class of this table's lists
+    std::map<uint32_t, std::array<uint64_t, 5>> st;   // class -> {chunks, rows, needs_str, chunks in segments of >= 128 rows, segments}
+    for (const BoundPath& b : bound) {
+      auto& e = st[b.ent & GK_DESC_ENT_MASK];
+      e[2] = (b.ent & GK_ENT_NEEDS_STR) ? 1 : 0;
+      for (uint32_t g = 0; g < n_groups; g++) {
+        const uint32_t lo = t.tile_idx[(size_t)g * (t.n_slots() + 1) + b.slot], hi = t.tile_idx[(size_t)g * (t.n_slots() + 1) + b.slot + 1];
+        if (hi == lo) continue;
+        const uint32_t ch = (hi - lo + GK_TILE - 1) / GK_TILE;
+        e[0] += ch; e[1] += hi - lo; e[4]++;
+        if (hi - lo >= 128) e[3] += (hi - lo) / 128 * 2;
+      }
+    }
+    uint64_t tc = 0, tr = 0, td = 0, ts = 0;
+    for (auto& kv : st) {
+      fprintf(stderr, "[chunk_stats] class %u str %llu chunks/group %.2f rows/chunk %.1f pairable %.2f segs/group %.2f cost %u\n", kv.first, (unsigned long long)kv.second[2], (double)kv.second[0] / n_groups,
+              kv.second[0] ? (double)kv.second[1] / kv.second[0] : 0.0, (double)kv.second[3] / n_groups, (double)kv.second[4] / n_groups, 0u);
+      tc += kv.second[0]; tr += kv.second[1]; if (!kv.second[2]) td += kv.second[3]; if (kv.second[2]) ts += kv.second[0];
+    }
+    fprintf(stderr, "[chunk_stats] groups %u chunks/group %.1f rows/group %.1f str chunks/group %.1f pairable non-str chunks/group %.1f\n", n_groups, (double)tc / n_groups, (double)tr / n_groups, (double)ts / n_groups, (double)td / n_groups);
+  }
   // reviews per pass
   uint32_t rpp = rpt;
   while (rpp > (uint32_t)GK_TILE && (size_t)hp.dims.acc_words * rpp * 4 > 140 * 1024) rpp /= 2;
