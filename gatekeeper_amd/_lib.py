@@ -74,7 +74,7 @@ class gk_topk_out(C.Structure):
 
 class gk_totals_out(C.Structure):
     _fields_ = [("n_constraints", C.c_uint32), ("constraint_ids", C.POINTER(C.c_uint32)), ("results", C.POINTER(C.c_uint64)),
-                ("pairs", C.POINTER(C.c_uint64))]
+                ("pairs", C.POINTER(C.c_uint64)), ("rendered_pairs", C.c_uint64)]
 
 
 class gk_table_stats(C.Structure):

@@ -403,6 +403,15 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts, const std
         o << ind << "  }\n" << ind << "}\n";
         break;
       }
+      case F_ENDLOOP2: {   // counting loop: a = once, b = body, c = twice
+        int d = stack.back().depth;
+        o << ind << "b" << c << " = b" << c << " | (b" << a << " & b" << b << " & v" << d << ");\n";
+        o << ind << "b" << a << " = b" << a << " | (b" << b << " & v" << d << ");\n";
+        stack.pop_back();
+        ind = ind.substr(0, ind.size() - 4);
+        o << ind << "  }\n" << ind << "}\n";
+        break;
+      }
       case F_VEQ: {
         uint32_t x = code[pc++];
         uint32_t sa = x & 0xFF, la = (x >> 8) & 0xFF, sb = (x >> 16) & 0xFF, lb = x >> 24;
@@ -464,7 +473,7 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts, const std
         uint32_t op = ins & 0xFF, b = (ins >> 16) & 0xFF, c = ins >> 24;
         if (op == F_VEQ) { pc++; B.cost += 12 * weight; }
         else if (op == F_LOOP) { B.cost += 4 * weight; weight *= 3; }
-        else if (op == F_ENDLOOP) { weight /= 3; B.cost += weight; }
+        else if (op == F_ENDLOOP || op == F_ENDLOOP2) { weight /= 3; B.cost += 2 * weight; }
         else B.cost += weight;
         if (op == F_STG) B.writes.push_back(1ull << 40 | b | (c << 8));
         if (op == F_STE) B.writes.push_back(2ull << 40 | (uint64_t)b << 16 | c);

@@ -44,6 +44,13 @@ struct ConstraintRec {
   FP viol;
   MatchFormulas mf;
   std::shared_ptr<const PreparedConstraint> prep;   // simplified / folded once (lower.hpp), reused by every plan build
+  // RESULT totals (gk_table_totals): "this review may yield MORE THAN ONE result" (Template::compile_multi) with the same match
+  // formulas, lowered into the totals plans; null = not lowerable: every violating pair of the constraint is rendered
+  std::shared_ptr<const PreparedConstraint> multi_prep;
+  // referential template (reads data.inventory): compiled against a snapshot of the synced objects, again whenever they change
+  // (refresh_referential); `broken`: why the current inventory does not compile -- every evaluation then fails (GK_ERR_UNSUPPORTED)
+  bool referential = false;
+  std::string broken;
   bool alive = true;
 };
 
@@ -237,7 +244,14 @@ struct gk_engine {
   std::shared_mutex mu;   // templates / constraints / inventory
   std::map<std::string, std::shared_ptr<Template>> templates;   // lower(kind)
   std::vector<ConstraintRec> constraints;
-  Value inventory = Value::object({});   // data.inventory for host rendering: only referential templates read it, and those are refused (GK_ERR_UNSUPPORTED)
+  // data.inventory (pkg/target/target.go:40-79 ProcessData: namespace/<ns>/<gv>/<Kind>/<name>, cluster/<gv>/<Kind>/<name>).  Kept only
+  // while a loaded constraint's template reads it (inv_tracking): inv_store mirrors gk_data_put / gk_data_remove, `inventory` is
+  // the document built from it (generation inv_built), and the referential constraints are compiled against it as a CONSTANT --
+  // again whenever it changes (inv_gen vs inv_compiled; refresh_referential, called by ensure_plan).
+  Value inventory = Value::object({});
+  bool inv_tracking = false;
+  std::map<std::string, std::pair<std::vector<std::string>, std::string>> inv_store;   // key -> (path, JSON text)
+  uint64_t inv_gen = 1, inv_built = 0, inv_compiled = 0;
   int next_quant = 0;
   // process excluder (pkg/controller/config/process/excluder.go): process -> namespace wildcards, replaced as a whole
   // from the Config resource's spec.match; `excluder_gen` lets resident chunks notice a change (guarded by mu)
@@ -266,6 +280,11 @@ struct gk_engine {
   std::vector<std::unique_ptr<Group>> extra;
   struct Variant { HostPlan fast; DevPlan* dev = nullptr; };
   std::map<std::vector<uint16_t>, std::unique_ptr<Variant>> variants;
+  // plans of the "more than one result" formulas (ConstraintRec::multi_prep), evaluated by gk_table_totals only; built on its
+  // first call after a policy change (totals_gen = the plan generation they belong to; guarded by totals_mu, plan_rw shared)
+  std::vector<std::unique_ptr<Group>> totals_groups;
+  uint64_t totals_gen = ~0ull;
+  std::mutex totals_mu;
   std::string last_dump;
   DevComm* comm = nullptr;   // multi-GPU exchange (gk_comm_init)
   // ---- resident set (row f2): every object synced through gk_data_put, flattened in HBM in chunks
@@ -332,6 +351,7 @@ struct gk_table {
   std::vector<uint32_t> path_rows;          // rows per path: which rows a plan reads
   std::vector<uint32_t> path_max;           // per element path: largest array of one review
   std::vector<DevTable*> views;             // one per extra plan group (shares the device arrays of `dev`)
+  std::vector<DevTable*> tviews;            // one per totals plan group (gk_table_totals)
   bool resident = false;
   uint64_t cached_gen = 0;                  // plan generation the cached variant choice belongs to
   DevPlan* cached_plan = nullptr;
@@ -422,7 +442,10 @@ DevPlan* plan_for_table(gk_engine* e, gk_table* t, const HostPlan** host) {
   return it->second->dev;
 }
 
+void refresh_referential(gk_engine* e);
+
 void ensure_plan(gk_engine* e) {
+  refresh_referential(e);   // referential constraints follow the synced inventory (no-op unless one is loaded and it changed)
   {   // the usual case: nothing changed -- decided without keeping other evaluations out
     std::shared_lock<std::shared_mutex> pl(e->plan_rw);
     std::shared_lock<std::shared_mutex> rl(e->mu);
@@ -441,6 +464,7 @@ void ensure_plan(gk_engine* e) {
     e->extra.clear();
     std::vector<const ConstraintRec*> alive;
     for (auto& c : e->constraints) if (c.alive) alive.push_back(&c);
+    for (auto* c : alive) if (!c->broken.empty()) throw Unsupported(c->broken);   // (a referential constraint the current inventory does not compile for)
     // groups of constraints that fit one plan: everything if possible, else chunks of <= 64 constraints (a constraint
     // contributes one violation and one match formula), halved further while a chunk still does not lower
     std::vector<std::vector<const ConstraintRec*>> groups;
@@ -501,6 +525,127 @@ void ensure_plan(gk_engine* e) {
 
 Value parse_opt(const char* p, size_t n) { return (p && n) ? parse_json(p, n) : Value(); }
 
+// "may yield more than one result" formula of a constraint (Template::compile_multi), prepared and checked to lower like the
+// violation formula is -- at AddConstraint time, so that the dictionary predicates / value-id paths it needs are registered
+// before tables are flattened.  Null when it does not lower: gk_table_totals then renders every violating pair of it.
+std::shared_ptr<const PreparedConstraint> prepare_multi(gk_engine* e, const Template& t, const Value& params, const MatchFormulas& mf, const Value& inventory = Value()) {
+  try {
+    FP multi = t.compile_multi(params, &e->next_quant, inventory);
+    auto prep = prepare_constraint(multi, mf);
+    // (frozen: the formula must be answerable from the rows, dictionary bits and value ids the violation formulas asked the
+    //  flattener for -- a guard of its own, say, would refuse reviews the violation formulas can evaluate)
+    PlanBuilder pb(&e->dict, &e->dict_reg, true);
+    pb.add_constraint(prep);
+    PlanCaps caps;
+    pb.build(caps);
+    return prep;
+  } catch (const std::exception& ex) {
+    if (getenv("GK_DEBUG_MULTI")) fprintf(stderr, "[gkgpu totals] no multi formula: %s\n", ex.what());
+    return nullptr;
+  }
+}
+
+// ---- referential templates (data.inventory) ----------------------------------------------------------------------------------
+// data.inventory as one document, from the mirror of the synced objects (caller holds mu exclusively)
+const Value& current_inventory(gk_engine* e) {
+  if (e->inv_built == e->inv_gen) return e->inventory;
+  struct Node { std::map<std::string, Node> kids; const std::string* json = nullptr; };
+  Node root;
+  for (auto& kv : e->inv_store) {
+    Node* n = &root;
+    for (auto& seg : kv.second.first) n = &n->kids[seg];
+    n->json = &kv.second.second;
+  }
+  std::function<Value(const Node&)> build = [&](const Node& n) -> Value {
+    if (n.json) return parse_json(n.json->data(), n.json->size());
+    ValuePairs ps;
+    for (auto& k : n.kids) ps.emplace_back(Value::string(k.first), build(k.second));
+    return Value::object(ps);
+  };
+  e->inventory = build(root);
+  e->inv_built = e->inv_gen;
+  return e->inventory;
+}
+
+// start mirroring the synced objects: everything gk_data_put holds so far (caller holds resident.mu AND mu exclusively, in that order)
+void start_inventory_tracking(gk_engine* e) {
+  if (e->inv_tracking) return;
+  for (auto& o : e->resident.objs) if (o.alive) e->inv_store[o.key] = {o.path, o.json};
+  e->inv_tracking = true;
+  e->inv_gen++;
+}
+
+// violation formula, prepared form and multi formula of a constraint against the current inventory (caller holds mu exclusively);
+// throws what compile / the lowering throw
+void compile_referential(gk_engine* e, const Template& t, ConstraintRec& c) {
+  const Value& inv = current_inventory(e);
+  FP viol = t.compile(c.params, &e->next_quant, inv);
+  auto prep = prepare_constraint(viol, c.mf);
+  {
+    PlanBuilder pb(&e->dict, &e->dict_reg);
+    pb.add_constraint(prep);
+    PlanCaps caps;
+    pb.build(caps);
+  }
+  c.viol = viol; c.prep = prep;
+  c.multi_prep = prepare_multi(e, t, c.params, c.mf, inv);
+}
+
+// The synced objects changed: the constraints of referential templates are compiled against the new inventory.  One that no
+// longer compiles (an inventory too large to unroll, say) is marked broken: evaluations fail with GK_ERR_UNSUPPORTED -- closed --
+// until the inventory or the constraint changes.
+void refresh_referential(gk_engine* e) {
+  {
+    std::shared_lock<std::shared_mutex> rl(e->mu);
+    if (!e->inv_tracking || e->inv_compiled == e->inv_gen) return;
+  }
+  std::lock_guard<std::mutex> gate(e->plan_gate);
+  std::unique_lock<std::shared_mutex> pl(e->plan_rw);
+  std::unique_lock<std::shared_mutex> l(e->mu);
+  if (!e->inv_tracking || e->inv_compiled == e->inv_gen) return;
+  for (auto& c : e->constraints) {
+    if (!c.alive || !c.referential) continue;
+    auto it = e->templates.find(lower_str(c.kind));
+    if (it == e->templates.end()) continue;
+    try { compile_referential(e, *it->second, c); c.broken.clear(); }
+    catch (const std::exception& ex) { c.broken = std::string("referential constraint ") + c.kind + "/" + c.name + " does not compile against the synced inventory: " + ex.what(); }
+  }
+  e->inv_compiled = e->inv_gen;
+  e->plan_dirty = true;
+}
+
+// The totals plans: the alive constraints' multi formulas in groups that fit one plan each (as ensure_plan groups the violation
+// formulas).  Caller holds plan_rw shared + mu shared + totals_mu; ensure_plan ran.
+void ensure_totals_plans(gk_engine* e) {
+  if (e->totals_gen == e->plan_gen) return;
+  for (auto& g : e->totals_groups) dev_plan_free(g->dev);
+  e->totals_groups.clear();
+  PlanCaps bigcaps;
+  bigcaps.level_cap[0] = bigcaps.level_cap[1] = bigcaps.level_cap[2] = 256;
+  std::vector<const ConstraintRec*> have;
+  for (auto& c : e->constraints) if (c.alive && c.multi_prep) have.push_back(&c);
+  std::function<void(const std::vector<const ConstraintRec*>&)> place = [&](const std::vector<const ConstraintRec*>& g) {
+    if (g.empty()) return;
+    std::unique_ptr<gk_engine::Group> grp(new gk_engine::Group());
+    try {
+      PlanBuilder pb(&e->dict, &e->dict_reg, true);
+      for (auto* c : g) pb.add_constraint(c->multi_prep);
+      grp->fast = pb.build(default_caps(e));
+      grp->big = pb.build(bigcaps);
+    } catch (const Unsupported&) {
+      if (g.size() <= 1) return;   // (checked alone at AddConstraint; should it fail now, its pairs are rendered)
+      const size_t half = g.size() > 64 ? 64 : g.size() / 2;
+      for (size_t i = 0; i < g.size(); i += half) place(std::vector<const ConstraintRec*>(g.begin() + i, g.begin() + std::min(g.size(), i + half)));
+      return;
+    }
+    for (auto* c : g) grp->ids.push_back(c->id);
+    grp->dev = dev_plan_upload(e->opts.device, grp->fast, grp->big);
+    e->totals_groups.push_back(std::move(grp));
+  };
+  place(have);
+  e->totals_gen = e->plan_gen;
+}
+
 }  // namespace
 
 extern "C" {
@@ -530,6 +675,7 @@ void gk_engine_destroy(gk_engine* e) {
   if (e->dev_plan) dev_plan_free(e->dev_plan);
   for (auto& v : e->variants) dev_plan_free(v.second->dev);
   for (auto& g : e->extra) dev_plan_free(g->dev);
+  for (auto& g : e->totals_groups) dev_plan_free(g->dev);
   delete e;
 }
 
@@ -539,28 +685,33 @@ int gk_template_add(gk_engine* e, const char* kind, const char* rego, const char
     std::vector<std::string> ls;
     for (size_t i = 0; i < nlibs; i++) ls.emplace_back(libs[i]);
     auto t = std::make_shared<Template>(rego, ls);
+    std::unique_lock<std::mutex> res_lock(e->resident.mu, std::defer_lock);
+    if (t->references_inventory()) res_lock.lock();   // (before mu: the order gk_resident_sweep uses)
     std::unique_lock<std::shared_mutex> l(e->mu);
     // Constraints of this kind are recompiled against the new template -- violation formula AND the prepared form every
     // plan is built from -- and put through the checks gk_constraint_add runs (referential template, lowering).  All or
     // nothing: when one of them does not compile the old template and its constraints stay as they are and the caller
     // gets the error (the reference reports it on the ConstraintTemplate's status and keeps serving the old one).
     const std::string k = lower_str(kind);
-    struct Redo { ConstraintRec* c; FP viol; std::shared_ptr<const PreparedConstraint> prep; };
+    struct Redo { ConstraintRec* c; FP viol; std::shared_ptr<const PreparedConstraint> prep, multi; bool referential; };
     std::vector<Redo> redo;
     for (auto& c : e->constraints) {
       if (!c.alive || lower_str(c.kind) != k) continue;
-      if (t->references_inventory())
-        return fail(GK_ERR_UNSUPPORTED, "unsupported on the device plan: template " + c.kind + " is referential (reads data.inventory)");
-      Redo r{&c, t->compile(c.params, &e->next_quant), nullptr};
+      const bool ref = t->references_inventory();
+      if (ref) start_inventory_tracking(e);
+      const Value inv = ref ? current_inventory(e) : Value();
+      Redo r{&c, t->compile(c.params, &e->next_quant, inv), nullptr, nullptr, ref};
       r.prep = prepare_constraint(r.viol, c.mf);
       PlanBuilder pb(&e->dict, &e->dict_reg);
       pb.add_constraint(r.prep);
       PlanCaps caps;
       pb.build(caps);
+      r.multi = prepare_multi(e, *t, c.params, c.mf, inv);
       redo.push_back(std::move(r));
     }
     e->templates[k] = t;
-    for (auto& r : redo) { r.c->viol = std::move(r.viol); r.c->prep = std::move(r.prep); }
+    for (auto& r : redo) { r.c->viol = std::move(r.viol); r.c->prep = std::move(r.prep); r.c->multi_prep = std::move(r.multi); r.c->referential = r.referential; r.c->broken.clear(); }
+    if (!redo.empty() && t->references_inventory()) e->inv_compiled = e->inv_gen;
     e->plan_dirty = true;
     return GK_OK;
   } catch (const RegoError& ex) { return fail(GK_ERR_REGO, ex.what());
@@ -593,20 +744,38 @@ int gk_constraint_add(gk_engine* e, const char* json, size_t len, uint32_t* id_o
     rec.params = (params && !params->is_null()) ? *params : Value::object({});
     const Value* match = spec ? spec->get("match") : nullptr;
     rec.match = (match && match->is_object()) ? *match : Value();
+    // (a referential template needs the synced objects: resident.mu is taken BEFORE mu, the order gk_resident_sweep uses)
+    bool referential = false;
+    {
+      std::shared_lock<std::shared_mutex> rl(e->mu);
+      auto it0 = e->templates.find(lower_str(rec.kind));
+      referential = it0 != e->templates.end() && it0->second->references_inventory();
+    }
+    std::unique_lock<std::mutex> res_lock(e->resident.mu, std::defer_lock);
+    if (referential) res_lock.lock();
     std::unique_lock<std::shared_mutex> l(e->mu);
     auto it = e->templates.find(lower_str(rec.kind));
     if (it == e->templates.end()) return fail(GK_ERR_NOT_FOUND, "unknown constraint template validator: " + rec.kind);
-    if (it->second->references_inventory())
-      return fail(GK_ERR_UNSUPPORTED, "unsupported on the device plan: template " + rec.kind + " is referential (reads data.inventory)");
-    rec.viol = it->second->compile(rec.params, &e->next_quant);
     rec.mf = compile_match(rec.match);
-    // validate that it lowers (element scopes, register pressure) before accepting it
-    {
-      PlanBuilder pb(&e->dict, &e->dict_reg);
-      rec.prep = prepare_constraint(rec.viol, rec.mf);
-      pb.add_constraint(rec.prep);
-      PlanCaps caps;
-      pb.build(caps);
+    if (it->second->references_inventory()) {
+      // Referential (data.inventory): the synced objects are a CONSTANT of the compiled formula -- iterating them unrolls into
+      // one alternative per object, so this serves inventories of the size the reference's fixtures have (an inventory that does
+      // not fit a plan is refused: GK_ERR_UNSUPPORTED, the stock driver keeps the template); recompiled whenever they change
+      if (!res_lock.owns_lock()) return fail(GK_ERR_INTERNAL, "the template of " + rec.kind + " changed while the constraint was added: try again");
+      start_inventory_tracking(e);
+      rec.referential = true;
+      compile_referential(e, *it->second, rec);
+    } else {
+      rec.viol = it->second->compile(rec.params, &e->next_quant);
+      // validate that it lowers (element scopes, register pressure) before accepting it
+      {
+        PlanBuilder pb(&e->dict, &e->dict_reg);
+        rec.prep = prepare_constraint(rec.viol, rec.mf);
+        pb.add_constraint(rec.prep);
+        PlanCaps caps;
+        pb.build(caps);
+      }
+      rec.multi_prep = prepare_multi(e, *it->second, rec.params, rec.mf);
     }
     for (auto& o : e->constraints) if (o.alive && o.kind == rec.kind && o.name == rec.name) o.alive = false;   // replace
     rec.id = (uint32_t)e->constraints.size();
@@ -669,6 +838,12 @@ int gk_data_put(gk_engine* e, const char* const* path, size_t npath, const char*
       std::unique_lock<std::shared_mutex> l(e->mu);
       // nsCache.Add: cluster-scoped core/v1 Namespace objects (ns_cache.go:22-43)
       if (is_ns) e->ns_cache.put(p[3], v);
+      if (e->inv_tracking) {   // data.inventory of the referential constraints
+        std::string k;
+        for (auto& x : p) { k += x; k.push_back('/'); }
+        auto& slot = e->inv_store[k];
+        if (slot.second.size() != len || memcmp(slot.second.data(), json, len) != 0) { slot = {p, std::string(json, len)}; e->inv_gen++; }
+      }
     }
     // the resident set: this version of the object is flattened by the next gk_resident_sweep
     gk_engine::Resident& R = e->resident;
@@ -713,6 +888,11 @@ int gk_data_remove(gk_engine* e, const char* const* path, size_t npath) {
   {
     std::unique_lock<std::shared_mutex> l(e->mu);
     if (is_ns) e->ns_cache.remove(p[3]);
+    if (e->inv_tracking) {
+      std::string k;
+      for (auto& x : p) { k += x; k.push_back('/'); }
+      if (e->inv_store.erase(k)) e->inv_gen++;
+    }
   }
   gk_engine::Resident& R = e->resident;
   std::lock_guard<std::mutex> rl(R.mu);
@@ -1136,6 +1316,7 @@ int gk_table_get_stats(const gk_table* t, gk_table_stats* out) {
 void gk_table_free(gk_table* t) {
   if (!t) return;
   for (DevTable* v : t->views) dev_table_free(v);
+  for (DevTable* v : t->tviews) dev_table_free(v);
   dev_table_free(t->dev);
   delete t;
 }
@@ -1315,6 +1496,47 @@ static const ReviewDoc* doc_for(gk_engine* e, const gk_table* t, uint32_t r, Rev
   return nullptr;
 }
 
+// Which violating pairs have to be RENDERED to know their result count: need[row][tile], a subset of viol.  The totals plans
+// (ensure_totals_plans) answer "this review may yield more than one result" per constraint on the device; a violating pair
+// they do not flag has exactly one result.  Everything they cannot answer stays in: constraints without a multi formula,
+// reviews beyond the totals plans' limits, GK_TOTALS_RENDER_ALL=1 (test aid: the host pass over every violating pair, as
+// before round 3).  Caller holds plan_rw shared and mu shared; ensure_plan ran; ids = constraint id per bitmap row.
+static std::vector<uint64_t> render_needed(gk_engine* e, gk_table* t, const std::vector<uint32_t>& ids, uint32_t nt, const std::vector<uint64_t>& viol) {
+  std::vector<uint64_t> need = viol;
+  if (getenv("GK_TOTALS_RENDER_ALL") || t->n_reviews == 0) return need;
+  if (t->dict_gen != e->dict_reg.gen()) return need;   // (a table flattened before the constraint set changed: no totals plan can read it)
+  std::lock_guard<std::mutex> tl(e->totals_mu);
+  ensure_totals_plans(e);
+  if (e->totals_groups.empty()) return need;
+  std::map<uint32_t, uint32_t> row_of;
+  for (uint32_t r = 0; r < ids.size(); r++) row_of[ids[r]] = r;
+  EvalOptions opt;
+  opt.download = true;
+  opt.jit_wait = false;   // one pass per audit: the bytecode kernel serves it unless the specialised build is there already
+  while (t->tviews.size() < e->totals_groups.size()) t->tviews.push_back(dev_table_view(t->dev));
+  for (size_t gi = 0; gi < e->totals_groups.size(); gi++) dev_eval_launch(e->totals_groups[gi]->dev, t->tviews[gi], opt);
+  std::vector<uint64_t> beyond(nt, 0);
+  std::vector<bool> answered(ids.size(), false);
+  std::vector<uint64_t> multi((size_t)ids.size() * nt, 0);
+  for (size_t gi = 0; gi < e->totals_groups.size(); gi++) {
+    EvalOut og;
+    dev_eval_finish(e->totals_groups[gi]->dev, t->tviews[gi], opt, &og);
+    for (uint32_t w = 0; w < nt && w < og.too_big.size(); w++) beyond[w] |= og.too_big[w];
+    for (uint32_t r = 0; r < e->totals_groups[gi]->ids.size() && r < og.n_constraints; r++) {
+      auto it = row_of.find(e->totals_groups[gi]->ids[r]);
+      if (it == row_of.end() || og.n_tiles != nt) continue;
+      answered[it->second] = true;
+      // (autoreject pairs of the totals plan are the main plan's: they carry no violation bit either way)
+      for (uint32_t w = 0; w < nt; w++) multi[(size_t)it->second * nt + w] = og.viol[(size_t)r * nt + w];
+    }
+  }
+  for (uint32_t r = 0; r < ids.size(); r++) {
+    if (!answered[r]) continue;
+    for (uint32_t w = 0; w < nt; w++) need[(size_t)r * nt + w] = viol[(size_t)r * nt + w] & (multi[(size_t)r * nt + w] | beyond[w]);
+  }
+  return need;
+}
+
 // the table's most recent evaluation are rendered on host threads (the reference renders -- and logs -- every message
 // as well, manager.go:926-928); only the counts are kept.
 int gk_table_totals(gk_engine* e, gk_table* t, gk_totals_out** out) {
@@ -1336,7 +1558,21 @@ int gk_table_totals(gk_engine* e, gk_table* t, gk_totals_out** out) {
     }
     if (viol.size() != (size_t)nc * nt) return fail(GK_ERR_INVALID, "gk_table_totals: evaluate the table first");
     h->results.assign(nc, 0); h->pairs.assign(nc, 0);
+    ensure_plan(e);
+    std::shared_lock<std::shared_mutex> pl(e->plan_rw);
     std::shared_lock<std::shared_mutex> rl(e->mu);
+    // Round 3: the device decides which violating pairs CAN have more than one result; every other violating pair counts one
+    // result without being rendered (configs[2]: 1.8 M violating pairs, ~1 % of them rendered)
+    const std::vector<uint64_t> need = render_needed(e, t, h->ids, nt, viol);
+    for (uint32_t row = 0; row < nc; row++)
+      for (uint32_t w = 0; w < nt; w++) {
+        const uint64_t v = viol[(size_t)row * nt + w];
+        h->pairs[row] += (uint64_t)__builtin_popcountll(v);
+        h->results[row] += (uint64_t)__builtin_popcountll(v & ~need[(size_t)row * nt + w]);   // exactly one result each
+      }
+    uint64_t n_rendered = 0;
+    for (uint64_t x : need) n_rendered += (uint64_t)__builtin_popcountll(x);
+    h->pub.rendered_pairs = n_rendered;
     struct CRef { const ConstraintRec* c; const Template* tm; };
     std::vector<CRef> cref(nc);
     for (uint32_t row = 0; row < nc; row++) {
@@ -1347,7 +1583,7 @@ int gk_table_totals(gk_engine* e, gk_table* t, gk_totals_out** out) {
     }
     size_t n_threads = std::max<size_t>(1, std::min<size_t>(host_cpus(), nt / 4 + 1));
     if (const char* ht = getenv("GK_HOST_THREADS")) n_threads = std::max(1, atoi(ht));
-    std::vector<std::vector<uint64_t>> part_r(n_threads, std::vector<uint64_t>(nc, 0)), part_p(n_threads, std::vector<uint64_t>(nc, 0));
+    std::vector<std::vector<uint64_t>> part_r(n_threads, std::vector<uint64_t>(nc, 0));
     std::vector<std::string> errs(n_threads);
     std::atomic<uint32_t> next_tile{0};
     auto work = [&](size_t w) {
@@ -1357,15 +1593,14 @@ int gk_table_totals(gk_engine* e, gk_table* t, gk_totals_out** out) {
           if (tl >= nt) break;
           // review-major: a violating review is parsed (GK_TABLE_KEEP_TEXT) at most once, then rendered for each of its constraints
           uint64_t any = 0;
-          for (uint32_t row = 0; row < nc; row++) any |= viol[(size_t)row * nt + tl];
+          for (uint32_t row = 0; row < nc; row++) any |= need[(size_t)row * nt + tl];
           for (uint64_t m = any; m; m &= m - 1) {
             const uint32_t b = (uint32_t)__builtin_ctzll(m), r = tl * GK_TILE + b;
             ReviewDoc tmp;
             const ReviewDoc* doc = doc_for(e, t, r, &tmp);
             if (!doc) throw std::runtime_error("review document unavailable");
             for (uint32_t row = 0; row < nc; row++) {
-              if (!((viol[(size_t)row * nt + tl] >> b) & 1ull)) continue;
-              part_p[w][row]++;
+              if (!((need[(size_t)row * nt + tl] >> b) & 1ull)) continue;
               part_r[w][row] += cref[row].tm->render(doc->request, cref[row].c->params, e->inventory).size();
             }
           }
@@ -1374,7 +1609,7 @@ int gk_table_totals(gk_engine* e, gk_table* t, gk_totals_out** out) {
     };
     HostWorkers::get().run(n_threads, work);
     for (auto& er : errs) if (!er.empty()) return fail(GK_ERR_REGO, er);
-    for (size_t w = 0; w < n_threads; w++) for (uint32_t row = 0; row < nc; row++) { h->results[row] += part_r[w][row]; h->pairs[row] += part_p[w][row]; }
+    for (size_t w = 0; w < n_threads; w++) for (uint32_t row = 0; row < nc; row++) h->results[row] += part_r[w][row];
     h->pub.n_constraints = nc; h->pub.constraint_ids = h->ids.data(); h->pub.results = h->results.data(); h->pub.pairs = h->pairs.data();
     *out = &h.release()->pub;
     return GK_OK;
@@ -1817,21 +2052,29 @@ int gk_resident_sweep(gk_engine* e, uint32_t flags, gk_sweep_out** out) {
         for (uint32_t w = 0; w < ev->n_tiles; w++) h->pairs[row] += (uint64_t)__builtin_popcountll(ev->viol[(size_t)row * ev->n_tiles + w] & c.shown[w]);
       for (uint32_t w = 0; w < ev->n_tiles; w++) beyond += (uint64_t)__builtin_popcountll(ev->too_big[w] & c.shown[w]);
     }
-    if (flags & GK_SWEEP_RESULT_TOTALS) {   // results, not pairs (pkg/audit/manager.go:902): render the violating live pairs
+    if (flags & GK_SWEEP_RESULT_TOTALS) {   // results, not pairs (pkg/audit/manager.go:902)
+      // as gk_table_totals: the device says which violating live pairs can have more than one result; the others count one
+      std::shared_lock<std::shared_mutex> pl(e->plan_rw);
       std::shared_lock<std::shared_mutex> l(e->mu);
       for (auto& c : R.chunks) {
         const gk_eval_out* ev = c.ev;
+        const uint32_t nt = ev->n_tiles, ncc = std::min<uint32_t>(ev->n_constraints, nc);
+        std::vector<uint64_t> shown_viol((size_t)nc * nt, 0);
+        for (uint32_t row = 0; row < ncc; row++)
+          for (uint32_t w = 0; w < nt; w++) shown_viol[(size_t)row * nt + w] = ev->viol[(size_t)row * nt + w] & c.shown[w];
+        const std::vector<uint64_t> need = render_needed(e, c.table, h->ids, nt, shown_viol);
+        for (uint32_t row = 0; row < ncc; row++)
+          for (uint32_t w = 0; w < nt; w++) h->results[row] += (uint64_t)__builtin_popcountll(shown_viol[(size_t)row * nt + w] & ~need[(size_t)row * nt + w]);
         for (uint32_t slot = 0; slot < c.obj_of_slot.size(); slot++) {
           const uint64_t bit = 1ull << (slot % 64);
-          if (!(c.shown[slot / 64] & bit)) continue;
           bool any = false;
-          for (uint32_t row = 0; row < ev->n_constraints && !any; row++) any = (ev->viol[(size_t)row * ev->n_tiles + slot / 64] & bit) != 0;
+          for (uint32_t row = 0; row < ncc && !any; row++) any = (need[(size_t)row * nt + slot / 64] & bit) != 0;
           if (!any) continue;
           const gk_review_in in = resident_review_in(R, R.objs[c.obj_of_slot[slot]]);
           ReviewDoc doc = normalize_object(parse_json(in.json, in.json_len), parse_opt(in.namespace_json, in.namespace_len),
                                            parse_opt(in.ns_object_json, in.ns_object_len), in.source, "", e->ns_cache);
-          for (uint32_t row = 0; row < ev->n_constraints && row < nc; row++) {
-            if (!(ev->viol[(size_t)row * ev->n_tiles + slot / 64] & bit)) continue;
+          for (uint32_t row = 0; row < ncc; row++) {
+            if (!(need[(size_t)row * nt + slot / 64] & bit)) continue;
             const ConstraintRec& k = e->constraints[h->ids[row]];
             auto it = e->templates.find(lower_str(k.kind));
             if (it != e->templates.end()) h->results[row] += it->second->render(doc.request, k.params, e->inventory).size();

@@ -126,7 +126,7 @@ static bool patterns_overlap(const Pattern& a, const Pattern& b) {
   return true;
 }
 
-uint32_t DictRegistry::intern(const Pattern& leaf_in, const DX& dx) {
+uint32_t DictRegistry::intern(const Pattern& leaf_in, const DX& dx, bool add) {
   // Canonical form: an unfiltered iteration step is registered as "any child", whether the lowering reached the leaf through
   // an explicit element loop (elements only) or through a flat wildcard predicate (members and elements) -- the same leaf
   // must own ONE pattern, because bit numbers are per pattern and a path has one $d row.  (The device predicates keep their
@@ -137,6 +137,7 @@ uint32_t DictRegistry::intern(const Pattern& leaf_in, const DX& dx) {
   std::unique_lock<std::shared_mutex> l(mu_);
   Pat* p = nullptr;
   for (auto& x : pats_) if (x.key == pk) p = &x;
+  if (!p && !add) throw std::runtime_error("needs a dictionary predicate no loaded constraint registered");
   if (!p) {
     // a different pattern that covers some of the same paths (a constant member next to an iteration over the members of the
     // same object) would need two $d rows on one path: refused here, at AddConstraint -- never at table creation
@@ -144,6 +145,7 @@ uint32_t DictRegistry::intern(const Pattern& leaf_in, const DX& dx) {
     pats_.push_back({leaf, pk, {}}); p = &pats_.back();
   }
   for (auto& e : p->entries) if (e.key == dk) return e.bit;
+  if (!add) throw std::runtime_error("needs a dictionary predicate no loaded constraint registered");
   if (p->entries.size() >= 62) throw std::runtime_error("more than 62 dictionary predicates on " + pk);
   p->entries.push_back({dx, dk, (uint32_t)p->entries.size()});
   p->memo.clear();
@@ -179,12 +181,14 @@ void DictRegistry::match(const PathDict& dict, uint32_t path_id, std::vector<Dic
   }
 }
 
-void DictRegistry::add_guard(const Pattern& container) {
+bool DictRegistry::add_guard(const Pattern& container, bool add) {
   const std::string k = pattern_to_string(container);
   std::unique_lock<std::shared_mutex> l(mu_);
-  for (auto& g : guards_) if (g.first == k) return;
+  for (auto& g : guards_) if (g.first == k) return true;
+  if (!add) return false;
   guards_.emplace_back(k, container);
   gen_++;
+  return true;
 }
 bool DictRegistry::guarded(const PathDict& dict, uint32_t path_id) const {
   std::shared_lock<std::shared_mutex> l(mu_);
@@ -192,12 +196,14 @@ bool DictRegistry::guarded(const PathDict& dict, uint32_t path_id) const {
   return false;
 }
 
-void DictRegistry::add_value(const Pattern& leaf) {
+bool DictRegistry::add_value(const Pattern& leaf, bool add) {
   const std::string k = pattern_to_string(leaf);
   std::unique_lock<std::shared_mutex> l(mu_);
-  for (auto& g : values_) if (g.first == k) return;
+  for (auto& g : values_) if (g.first == k) return true;
+  if (!add) return false;
   values_.emplace_back(k, leaf);
   gen_++;   // tables flattened before this do not carry the ids: they are stale (engine.cpp dict_gen)
+  return true;
 }
 bool DictRegistry::valued(const PathDict& dict, uint32_t path_id) const {
   std::shared_lock<std::shared_mutex> l(mu_);

@@ -86,7 +86,9 @@ bool pattern_matches(const Pattern& pat, const PathDict& dict, uint32_t path_id)
 struct DictEntry { DX dx; std::string key; uint32_t bit; };
 class DictRegistry {
  public:
-  uint32_t intern(const Pattern& leaf, const DX& dx);   // bit of the expression on leaves matching `leaf`; throws std::runtime_error beyond 62 bits
+  // bit of the expression on leaves matching `leaf`; throws std::runtime_error beyond 62 bits -- and, with add = false (a plan
+  // that must live with what the loaded constraints registered: the totals plans), when the entry does not exist yet
+  uint32_t intern(const Pattern& leaf, const DX& dx, bool add = true);
   uint64_t gen() const;                                  // bumped by every new entry
   void match(const PathDict& dict, uint32_t path_id, std::vector<DictEntry>* out, int* pat_index = nullptr) const;   // entries for a concrete leaf path
   // answers shared by every flattener of the engine, per pattern: distinct value -> bit mask.  A value is evaluated once
@@ -95,11 +97,11 @@ class DictRegistry {
   void memo_put(int pat_index, size_t n_entries, const std::string& key, uint64_t mask);
   // Guards: container paths under which the loaded constraints iterate ARRAY elements.  A review holding a non-empty
   // OBJECT there is refused (RF_REFUSE): Rego's `x[_]` would walk the object's values, the compiled plan would not.
-  void add_guard(const Pattern& container);
+  bool add_guard(const Pattern& container, bool add = true);   // false: not registered (and add = false)
   bool guarded(const PathDict& dict, uint32_t path_id) const;
   // Compared values: leaf patterns whose rows the loaded constraints compare with other review values (P_STORE).  The
   // flattener gives the rows of matching paths a VALUE ID (plan.hpp ROW_VID_*), unique per distinct value within the review.
-  void add_value(const Pattern& leaf);
+  bool add_value(const Pattern& leaf, bool add = true);        // false: not registered (and add = false)
   bool valued(const PathDict& dict, uint32_t path_id) const;
  private:
   struct Pat { Pattern pat; std::string key; std::vector<DictEntry> entries; std::unordered_map<std::string, uint64_t> memo; };

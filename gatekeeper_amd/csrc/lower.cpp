@@ -379,8 +379,8 @@ FP simplify(const FP& f) {
       std::vector<FP> conj, dep, indep;
       conjuncts(body, conj);
       for (auto& c : conj) (mentions_q(c, f->q) ? dep : indep).push_back(c);
-      if (indep.empty()) return f_exists(f->q, f->base, body);
-      FP inner = f_exists(f->q, f->base, f_all(dep));
+      if (indep.empty()) return f_exists_like(*f, body);   // (E2, "at least two children satisfy the body", hoists the same way)
+      FP inner = f_exists_like(*f, f_all(dep));
       return simplify(f_and(inner, f_all(indep)));
     }
     default: return f;
@@ -462,14 +462,14 @@ FP dict_atom(const SPath& leaf, DX dx) { Atom a; a.kind = Atom::DICT; a.path = l
 FP fold_dict(const FP& f) {
   switch (f->kind) {
     case FNode::NOT: return f_not(fold_dict(f->kids[0]));
-    case FNode::EXISTS: return f_exists(f->q, f->base, fold_dict(f->kids[0]));
+    case FNode::EXISTS: return f_exists_like(*f, fold_dict(f->kids[0]));
     case FNode::OR: {
       // (E x in B. P(x)) | (E y in B. Q(y))  ==  E x in B. (P(x) | Q(x)): the alternatives of one template function over
       // the same array then meet in ONE body, where they fold per leaf
       std::vector<FP> kids;
       std::map<std::string, size_t> by_base;
       for (auto& k : f->kids) {
-        if (k->kind != FNode::EXISTS) { kids.push_back(k); continue; }
+        if (k->kind != FNode::EXISTS || k->two) { kids.push_back(k); continue; }   // (E2 nodes count: they are not merged)
         const std::string bk = spath_to_string(k->base);
         auto it = by_base.find(bk);
         if (it == by_base.end()) { by_base[bk] = kids.size(); kids.push_back(k); continue; }
@@ -497,7 +497,7 @@ FP fold_dict(const FP& f) {
           for (auto& c : a) { bool shared = false; for (auto& c0 : common) shared = shared || f_to_string(c0) == f_to_string(c); if (!shared) d = f_and(d, c); }
           body = f_or(body, d);
         }
-        k = f_exists(k->q, k->base, f_and(f_all(common), body));
+        k = f_exists_like(*k, f_and(f_all(common), body));
       }
       // group the leaf-local alternatives by leaf: a group with a DICT atom whose members all need the leaf folds
       std::map<std::string, std::vector<FP>> groups;
@@ -612,6 +612,7 @@ uint64_t string_key(const std::string& s) {
 struct Lowerer {
   PathDict* dict;
   DictRegistry* reg = nullptr;
+  bool frozen = false;   // no new registry entries (PlanBuilder)
   HostPlan plan;
   PlanCaps caps;
   std::map<std::string, uint32_t> global_bits;            // canonical pred key -> global bit
@@ -839,7 +840,7 @@ struct Lowerer {
       Pattern leaf_pat = pattern_of(a.path);
       for (auto& st : leaf_pat) if (st.any && !st.elems_only && (!st.only.empty() || !st.except.empty() || !st.kpreds.empty())) unsupported("dictionary predicate under a filtered key iteration");
       uint32_t bit;
-      try { bit = reg->intern(leaf_pat, a.dx); } catch (const std::runtime_error& ex) { unsupported(ex.what()); }
+      try { bit = reg->intern(leaf_pat, a.dx, !frozen); } catch (const std::runtime_error& ex) { unsupported(ex.what()); }
       Atom b;
       b.kind = Atom::DICT; b.path = a.path; b.dx = nullptr;
       Step st; st.key = "$d";
@@ -967,13 +968,14 @@ struct Lowerer {
       case FNode::NOT: return f_not(pin_key(f->kids[0], q, key));
       case FNode::AND: { FP r = f_true(); for (auto& k : f->kids) r = f_and(r, pin_key(k, q, key)); return r; }
       case FNode::OR: { FP r = f_false(); for (auto& k : f->kids) r = f_or(r, pin_key(k, q, key)); return r; }
-      case FNode::EXISTS: return f_exists(f->q, pin_path(f->base), pin_key(f->kids[0], q, key));
+      case FNode::EXISTS: { FNode proto; proto.q = f->q; proto.base = pin_path(f->base); proto.two = f->two; return f_exists_like(proto, pin_key(f->kids[0], q, key)); }
     }
     return f;
   }
 
   // EXISTS chain that reduces to one wildcard predicate
   bool try_flat(const FP& f, std::vector<std::pair<int, PatStep>>& wilds, Atom* out) {
+    if (f->two) return false;   // a wildcard predicate cannot count
     int q = f->q;
     std::vector<FP> conj;
     conjuncts(f->kids[0], conj);
@@ -1023,6 +1025,19 @@ struct Lowerer {
 
   int lower_exists(const FP& f) {
     int q = f->q;
+    if (f->two) {
+      // "at least two children": a counting loop when the children form an element scope; anything else is answered with the
+      // plain EXISTS -- weaker, i.e. more pairs than necessary are rendered on the host, never fewer (Template::compile_multi)
+      const uint64_t regs0 = regs_used;
+      std::vector<uint32_t>* const code = cur_code ? cur_code : &plan.code;
+      const size_t code0 = code->size();
+      const std::map<int, uint32_t> looped0 = looped;
+      const std::set<int> pass0 = pass;
+      const std::map<int, PatStep> wild0 = wild;
+      try { return lower_count2(f); }
+      catch (const Unsupported&) { regs_used = regs0; code->resize(code0); looped = looped0; pass = pass0; wild = wild0; }
+      return lower_exists(f_exists(f->q, f->base, f->kids[0]));
+    }
     {
       std::vector<std::pair<int, PatStep>> wilds;
       Atom flat;
@@ -1154,6 +1169,35 @@ struct Lowerer {
     return acc;
   }
 
+  // E2 as a loop with two accumulators: `once` = some element satisfied the body, `twice` = a second one did
+  int lower_count2(const FP& f) {
+    int q = f->q;
+    {   // the children must be iterated as ELEMENTS: no key tests on q
+      std::vector<FP> conj;
+      conjuncts(f->kids[0], conj);
+      for (auto& c : conj) { PatStep tmp; if (key_constraint(c, q, &tmp)) unsupported("counting over object keys"); }
+    }
+    SPath elem = f->base;
+    Step st; st.iter = true; st.q = q;
+    elem.push_back(st);
+    looped[q] = 0;
+    uint32_t sc;
+    try { sc = scope_for(elem); } catch (...) { looped.erase(q); throw; }
+    looped[q] = sc;
+    uint32_t parent = 0;
+    for (int i = (int)f->base.size() - 1; i >= 0; i--)
+      if (f->base[i].iter) { if (looped.count(f->base[i].q)) parent = looped[f->base[i].q] + 1; break; }
+    int twice = alloc(), once = alloc();
+    emit(finst(F_CONST, twice, 0));
+    emit(finst(F_LOOP, sc, parent, once));
+    int r = lower(f->kids[0]);
+    emit(finst(F_ENDLOOP2, once, r, twice));
+    release(r);
+    release(once);
+    looped.erase(q);
+    return twice;
+  }
+
   int lower(const FP& f) {
     switch (f->kind) {
       case FNode::T: { int r = alloc(); emit(finst(F_CONST, r, 1)); return r; }
@@ -1189,7 +1233,8 @@ FP pin_pass(const FP& f) {
       conjuncts(f->kids[0], conj);
       PatStep ps;
       for (auto& c : conj) if (!Lowerer::key_constraint(c, f->q, &ps)) rest.push_back(c);
-      if (ps.only.empty() || !ps.except.empty()) return f_exists(f->q, f->base, pin_pass(f->kids[0]));
+      if (ps.only.empty() || !ps.except.empty()) return f_exists_like(*f, pin_pass(f->kids[0]));
+      // (an E2 over keys pinned to constants is answered as the plain EXISTS: weaker, see lower_exists)
       FP any = f_false();
       for (const std::string& key : ps.only) {
         { bool ok = true; for (auto& kp : ps.kpreds) if (!key_pred_holds(kp, key, false)) ok = false; if (!ok) continue; }   // string tests on the pinned name
@@ -1224,6 +1269,7 @@ HostPlan PlanBuilder::build(const PlanCaps& caps) {
   Lowerer L;
   L.dict = dict_;
   L.reg = reg_;
+  L.frozen = frozen_;
   L.caps = caps;
   std::map<std::string, uint32_t> viol_ids, match_ids;
   std::vector<FP> viols, matches, errs;
@@ -1256,14 +1302,27 @@ HostPlan PlanBuilder::build(const PlanCaps& caps) {
   // the kernels report them in too_big -- the caller fails closed.  No rows, no device predicate.
   if (reg_) {
     std::set<std::string> seen;
+    std::vector<Pattern> local_guards;
     for (const Pattern& pat : L.plan.pred_patterns)
       for (size_t i = 0; i < pat.size(); i++) {
         if (!pat[i].any || !pat[i].elems_only) continue;
         Pattern prefix(pat.begin(), pat.begin() + i);
-        if (seen.insert(pattern_to_string(prefix)).second) reg_->add_guard(prefix);
+        if (!seen.insert(pattern_to_string(prefix)).second || reg_->add_guard(prefix, !frozen_)) continue;
+        // frozen plan, guard not registered: a LOCAL guard -- a predicate of this plan that sets the review's overflow bit when
+        // the container is an object; the big variant sets it again, so the review ends in too_big FOR THIS PLAN ONLY (the totals
+        // plans: such a review is rendered; the violation formulas, which reach the members through wildcard predicates, are
+        // not disturbed)
+        local_guards.push_back(prefix);
       }
+    for (const Pattern& prefix : local_guards) {
+      Pred g{};
+      g.op = P_TYPE; g.dst = D_GLOBAL; g.bit = 0; g.ctype = (uint8_t)(1u << T_OBJECT);
+      L.plan.preds.push_back(g);
+      L.plan.pred_patterns.push_back(prefix);
+    }
     // rows that are compared with other review values need VALUE IDS: the flattener assigns them on the registered paths
-    for (size_t i = 0; i < L.plan.preds.size(); i++) if (L.plan.preds[i].op == P_STORE) reg_->add_value(L.plan.pred_patterns[i]);
+    for (size_t i = 0; i < L.plan.preds.size(); i++)
+      if (L.plan.preds[i].op == P_STORE && !reg_->add_value(L.plan.pred_patterns[i], !frozen_)) throw Unsupported("unsupported on the device plan: needs value ids no loaded constraint registered");
   }
   HostPlan& p = L.plan;
   {   // derived-bit prologue blocks first (inner blocks were completed, hence appended, before outer ones)

@@ -54,7 +54,9 @@ std::shared_ptr<const PreparedConstraint> prepare_constraint(const FP& violation
 
 class PlanBuilder {
  public:
-  explicit PlanBuilder(PathDict* dict, DictRegistry* reg = nullptr) : dict_(dict), reg_(reg) {}
+  // frozen: the plan must live with the registry entries (dictionary predicates, guards, value-id paths) the loaded constraints
+  // made -- build() throws Unsupported instead of adding one (the totals plans: they must not change what the flattener does)
+  explicit PlanBuilder(PathDict* dict, DictRegistry* reg = nullptr, bool frozen = false) : dict_(dict), reg_(reg), frozen_(frozen) {}
   // returns the constraint index; formulas are deduplicated structurally
   uint32_t add_constraint(const FP& violation, const MatchFormulas& m) { return add_constraint(prepare_constraint(violation, m)); }
   uint32_t add_constraint(std::shared_ptr<const PreparedConstraint> pc) { cons_.push_back(std::move(pc)); return (uint32_t)cons_.size() - 1; }
@@ -63,6 +65,7 @@ class PlanBuilder {
  private:
   PathDict* dict_;
   DictRegistry* reg_;
+  bool frozen_ = false;
   std::vector<std::shared_ptr<const PreparedConstraint>> cons_;
 };
 

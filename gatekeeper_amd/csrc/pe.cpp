@@ -50,6 +50,12 @@ FP f_exists(int q, const SPath& base, FP body) {
   FNode n; n.kind = FNode::EXISTS; n.q = q; n.base = base; n.kids = {body};
   return mkf(n);
 }
+FP f_exists2(int q, const SPath& base, FP body) {
+  if (body->kind == FNode::F) return f_false();
+  FNode n; n.kind = FNode::EXISTS; n.q = q; n.base = base; n.two = true; n.kids = {body};
+  return mkf(n);
+}
+FP f_exists_like(const FNode& proto, FP body) { return proto.two ? f_exists2(proto.q, proto.base, body) : f_exists(proto.q, proto.base, body); }
 FP f_all(const std::vector<FP>& v) { FP r = f_true(); for (auto& x : v) r = f_and(r, x); return r; }
 FP f_any(const std::vector<FP>& v) { FP r = f_false(); for (auto& x : v) r = f_or(r, x); return r; }
 
@@ -69,7 +75,7 @@ std::string f_to_string(const FP& f) {
       for (size_t i = 0; i < f->kids.size(); i++) { if (i) o += f->kind == FNode::AND ? " & " : " | "; o += f_to_string(f->kids[i]); }
       return o + ")";
     }
-    case FNode::EXISTS: return "E q" + std::to_string(f->q) + " in " + spath_to_string(f->base) + ". " + f_to_string(f->kids[0]);
+    case FNode::EXISTS: return std::string(f->two ? "E2 q" : "E q") + std::to_string(f->q) + " in " + spath_to_string(f->base) + ". " + f_to_string(f->kids[0]);
     case FNode::ATOM: {
       const Atom& a = f->atom;
       std::string p = spath_to_string(a.path);
@@ -1018,7 +1024,10 @@ class PE {
         return;
       }
     }
-    if (!concrete_) unsupported("reference to data.* (referential constraint; needs synced inventory)", line);
+    // symbolic mode: data.inventory is a CONSTANT when the caller hands a snapshot of the synced objects over (engine.cpp: the
+    // constraints of a referential template are recompiled when the inventory changes) -- iterating it unrolls into alternatives
+    // like an iteration over input.parameters does
+    if (!concrete_ && !inventory_.defined()) unsupported("reference to data.* (referential constraint; needs synced inventory)", line);
     ValuePairs root;
     if (inventory_.defined()) root.emplace_back(Value::string("inventory"), inventory_);
     walk(sv_const(Value::object(root)), ops, 0, s, r, out, line);
@@ -1640,8 +1649,8 @@ Template::Template(const std::string& rego, const std::vector<std::string>& libs
   }
 }
 
-FP Template::compile(const Value& parameters, int* next_quant) const {
-  PE pe(*this, parameters, sv_path({}), Value(), false, next_quant);
+FP Template::compile(const Value& parameters, int* next_quant, const Value& inventory) const {
+  PE pe(*this, parameters, sv_path({}), inventory, false, next_quant);
   pe.index_rules();
   SVP set;
   try {
@@ -1672,6 +1681,67 @@ FP Template::compile(const Value& parameters, int* next_quant) const {
     r = f_or(r, body);
   }
   return r;
+}
+
+FP Template::compile_multi(const Value& parameters, int* next_quant, const Value& inventory) const {
+  PE pe(*this, parameters, sv_path({}), inventory, false, next_quant);
+  pe.index_rules();
+  SVP set;
+  try {
+    set = pe.violation_set();
+  } catch (const UnboundVar& e) {
+    throw RegoError(e.what());
+  }
+  std::vector<CondElem> elems;
+  std::vector<Gen> gens;
+  if (set->kind == SV::CONST) { for (auto& x : set->c.items()) elems.push_back({sv_const(x), f_true()}); }
+  else { elems = set->elems; gens = set->gens; }
+  auto valid = [&](const SVP& e) -> FP {
+    if (e->kind == SV::CONST) {
+      const Value* m = e->c.get("msg");
+      return (e->c.is_object() && m && m->is_string()) ? f_true() : f_false();
+    }
+    if (e->kind != SV::OBJ) return f_false();
+    SVP msg;
+    for (auto& f : e->fields) if (f.first == Value::string("msg")) msg = f.second;
+    if (!msg) return f_false();
+    return f_and(pe.defined_f(e), pe.is_string_f(msg));
+  };
+  // one BRANCH per member expression of the set: `any` = it yields a result, `two` = it may yield two (two bindings of its
+  // review iterations; a branch without iterations yields at most one)
+  struct Branch { FP any, two; };
+  std::vector<Branch> br;
+  for (auto& e : elems) {
+    FP c = f_and(e.cond, valid(e.v));
+    if (c->kind != FNode::F) br.push_back({c, f_false()});
+  }
+  for (auto& g : gens) {
+    const FP body = f_and(g.cond, valid(g.elem));
+    if (body->kind == FNode::F) continue;
+    const size_t k = g.quants.size();
+    // inner[i] = E q_i .. E q_{k-1}. body   (inner[k] = body)
+    std::vector<FP> inner(k + 1);
+    inner[k] = body;
+    for (size_t i = k; i-- > 0;) inner[i] = f_exists(g.quants[i], g.bases[i], inner[i + 1]);
+    // two bindings differ first at some level i: two children of base_i with a satisfying rest, below a common prefix
+    FP two = f_false();
+    for (size_t i = k; i-- > 0;) {
+      FP t = f_exists2(g.quants[i], g.bases[i], inner[i + 1]);
+      for (size_t j = i; j-- > 0;) t = f_exists(g.quants[j], g.bases[j], t);
+      two = f_or(two, t);
+    }
+    br.push_back({inner[0], two});
+  }
+  if (br.size() > 12) {   // too many alternatives for the pairwise terms: every violating pair is rendered
+    FP r = f_false();
+    for (auto& b : br) r = f_or(r, b.any);
+    return r;
+  }
+  FP multi = f_false();
+  for (auto& b : br) multi = f_or(multi, b.two);
+  for (size_t i = 0; i < br.size(); i++)
+    for (size_t j = i + 1; j < br.size(); j++) multi = f_or(multi, f_and(br[i].any, br[j].any));
+  return multi;
 }
 
 std::vector<Violation> Template::render(const Value& review, const Value& parameters, const Value& inventory) const {

@@ -52,6 +52,7 @@ struct FNode {
   std::vector<FP> kids;
   int q = -1;           // EXISTS: quantifier id; quantifies over children of `base`
   SPath base;           // EXISTS
+  bool two = false;     // EXISTS: at least TWO children of `base` satisfy the body ("E2": instance counting for the RESULT totals)
   Atom atom;
 };
 
@@ -62,6 +63,8 @@ FP f_or(FP a, FP b);
 FP f_not(FP a);
 FP f_atom(const Atom& a);
 FP f_exists(int q, const SPath& base, FP body);
+FP f_exists2(int q, const SPath& base, FP body);              // at least two children of `base` satisfy the body
+FP f_exists_like(const FNode& proto, FP body);                // EXISTS / E2 with `proto`'s quantifier, base and flag
 FP f_all(const std::vector<FP>& v);
 FP f_any(const std::vector<FP>& v);
 std::string f_to_string(const FP& f);
@@ -103,7 +106,17 @@ class Template {
 
   // AOT: formula that is true iff the template yields >= 1 violation for a review, given constant parameters.
   // Throws Unsupported if the template uses constructs the device plan cannot express.
-  FP compile(const Value& parameters, int* next_quant) const;
+  // `inventory`: data.inventory as a CONSTANT (a snapshot of the synced objects) for referential templates; Undefined: a
+  // reference to data.* is refused (Unsupported)
+  FP compile(const Value& parameters, int* next_quant, const Value& inventory = Value()) const;
+
+  // AOT, for the audit's RESULT totals (pkg/audit/manager.go:893-904 counts types.Results, not violating pairs): a formula
+  // that is FALSE only if the template yields AT MOST ONE result for the review -- i.e. true whenever two different
+  // members of the violation set may exist: two rule bodies / unrolled parameter alternatives hold at once, or one body holds
+  // for two bindings of a review iteration.  Conservative by construction (it counts bindings, and equal messages of
+  // different bindings collapse in the set): a pair it flags is rendered on the host and counted exactly; a violating pair
+  // it does not flag has exactly one result.  Implies compile()'s formula.
+  FP compile_multi(const Value& parameters, int* next_quant, const Value& inventory = Value()) const;
 
   // Host rendering: the violation set for a concrete review document (input.review) and parameters.
   // `inventory` is data.inventory (may be Undefined).  Throws RegoError on evaluation errors.

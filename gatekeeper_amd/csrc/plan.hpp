@@ -190,6 +190,8 @@ enum FOp : uint32_t {
   F_END = 14,
   F_STE = 15,   // derived element bit: bit c of the current element of scope b |= reg a  (common-subformula cache)
   F_STG = 16,   // derived global bit (b | c<<8) |= reg a
+  F_ENDLOOP2 = 17,  // counting loop end: a = "once" reg (the loop's accumulator), b = body reg, c = "twice" reg:
+                    //   twice |= once & b & valid(elem);  once |= b & valid(elem);  next element
 };
 inline constexpr uint32_t finst(uint32_t op, uint32_t a = 0, uint32_t b = 0, uint32_t c = 0) {
   return op | (a << 8) | (b << 16) | (c << 24);

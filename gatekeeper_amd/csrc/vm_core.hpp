@@ -469,7 +469,7 @@ GK_HD Results eval_formulas(const PlanView& pv, Acc& acc, uint32_t flags, const 
             uint32_t w = GK_UNI(code[pc++]);
             uint32_t o = w & 0xFF;
             if (o == F_LOOP) nest++;
-            else if (o == F_ENDLOOP) nest--;
+            else if (o == F_ENDLOOP || o == F_ENDLOOP2) nest--;
             else if (o == F_VEQ) pc++;
           }
           break;
@@ -488,6 +488,20 @@ GK_HD Results eval_formulas(const PlanView& pv, Acc& acc, uint32_t flags, const 
         bool valid = (w0 & 1) != 0;
         if (par) valid = valid && ((w0 >> 24) == cur[par - 1]);
         uint64_t v = valid ? ((B >> b) & 1) : 0;
+        B |= v << a;
+        cur[s]++;
+        if (cur[s] < GK_UNI(bounds[s])) pc = loop_pc[depth - 1];
+        else depth--;
+        break;
+      }
+      case F_ENDLOOP2: {   // counting loop: a = once, b = body, c = twice
+        uint32_t s = loop_scope[depth - 1] & 0xFF, par = loop_scope[depth - 1] >> 8;
+        const Scope& sc = pv.scopes[s];
+        uint32_t w0 = acc.load(sc.word_off + cur[s] * sc.wpe);
+        bool valid = (w0 & 1) != 0;
+        if (par) valid = valid && ((w0 >> 24) == cur[par - 1]);
+        uint64_t v = valid ? ((B >> b) & 1) : 0;
+        B |= (v & (B >> a) & 1) << c;
         B |= v << a;
         cur[s]++;
         if (cur[s] < GK_UNI(bounds[s])) pc = loop_pc[depth - 1];

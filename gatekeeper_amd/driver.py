@@ -331,6 +331,7 @@ class Table:
         self.engine._check(self.engine.lib.gk_table_totals(self.engine.handle, self.handle, C.byref(out)))
         o = out.contents
         res = {int(o.constraint_ids[i]): (int(o.results[i]), int(o.pairs[i])) for i in range(o.n_constraints)}
+        self.rendered_pairs = int(o.rendered_pairs)   # violating pairs the host had to render (the device counted the others)
         self.engine.lib.gk_totals_free(out)
         return res
 

@@ -204,13 +204,17 @@ void gk_topk_free(gk_topk_out* o);
 /* Result-level totals of the table's most recent evaluation (row a11): pkg/audit/manager.go:902 increments
  * totalViolationsPerConstraint once per types.Result, and one violating (constraint, object) pair yields as many
  * results as the template's violation set has distinct {msg, details} members.  `pairs` = popcount of the bitmap row,
- * `results` = what the reference's counters hold.  Needs GK_TABLE_KEEP_DOCS or GK_TABLE_KEEP_TEXT (then only the violating
- * reviews are parsed, once each, on the host workers). */
+ * `results` = what the reference's counters hold.  The device answers, per violating pair, whether the template CAN yield more
+ * than one result for that review (two rule bodies / parameter alternatives hold, or one holds for two elements of an
+ * iterated collection); a pair it does not flag counts exactly one result, the flagged ones (`rendered_pairs`) are rendered on
+ * the host workers and counted.  Needs GK_TABLE_KEEP_DOCS or GK_TABLE_KEEP_TEXT (then only the rendered reviews are parsed,
+ * once each). */
 typedef struct {
   uint32_t n_constraints;
   const uint32_t* constraint_ids;
   const uint64_t* results;
   const uint64_t* pairs;
+  uint64_t rendered_pairs;   /* violating pairs whose result count needed the host renderer */
 } gk_totals_out;
 int gk_table_totals(gk_engine* e, gk_table* t, gk_totals_out** out);
 void gk_totals_free(gk_totals_out* o);

@@ -1,0 +1,176 @@
+"""RESULT totals (pkg/audit/manager.go:893-904: totalViolationsPerConstraint counts types.Results, not violating pairs) with
+the device deciding which violating pairs CAN have more than one result (Template::compile_multi -> the totals plans,
+gk_table_totals): a pair it does not flag counts one result unrendered, the flagged ones are rendered on the host.  Product vs
+oracle on the shapes where the two numbers differ -- several rule bodies, several elements of an iterated array, nested
+iterations, unrolled parameter alternatives whose conditions are identical, equal messages that collapse in the set -- and on
+the shape the counting loops cannot walk (an OBJECT where the template iterates elements: the totals plan refuses the review
+locally and it is rendered, while the violation bitmap is still answered on the device)."""
+import os
+
+import pytest
+
+from gatekeeper_amd import driver as D
+from oracle import client as OC
+from oracle import target as OT
+from parity_util import BACKENDS, make_client
+
+
+def tmpl(kind, rego):
+    return {"apiVersion": "templates.gatekeeper.sh/v1", "kind": "ConstraintTemplate", "metadata": {"name": kind.lower()},
+            "spec": {"crd": {"spec": {"names": {"kind": kind}}}, "targets": [{"target": "admission.k8s.gatekeeper.sh", "rego": rego}]}}
+
+
+T = {
+    # one body, one result per violating CONTAINER (the PSP shape)
+    "K8sPerElement": ('''package k
+violation[{"msg": msg}] {
+  c := input.review.object.spec.containers[_]
+  c.securityContext.privileged
+  msg := sprintf("privileged container %v", [c.name])
+}
+''', {}),
+    # two bodies over the same review: none, one or both hold
+    "K8sTwoBodies": ('''package k
+violation[{"msg": msg}] {
+  input.review.object.spec.hostNetwork
+  msg := "hostNetwork"
+}
+violation[{"msg": msg}] {
+  input.review.object.spec.hostPID
+  msg := "hostPID"
+}
+''', {}),
+    # nested iteration: a result per (container, port)
+    "K8sNested": ('''package k
+violation[{"msg": msg}] {
+  c := input.review.object.spec.containers[_]
+  p := c.ports[_]
+  p.hostPort > 0
+  msg := sprintf("%v uses host port %v", [c.name, p.hostPort])
+}
+''', {}),
+    # the message does not depend on the element: equal messages of different elements are ONE member of the set
+    "K8sSameMessage": ('''package k
+violation[{"msg": msg}] {
+  c := input.review.object.spec.containers[_]
+  c.securityContext.privileged
+  msg := "some container is privileged"
+}
+''', {}),
+    # parameter alternatives with IDENTICAL conditions and different messages: one result per alternative
+    "K8sParamAlternatives": ('''package k
+violation[{"msg": msg}] {
+  l := input.parameters.labels[_]
+  not input.review.object.metadata.labels.team
+  msg := sprintf("label team missing (reported for %v)", [l])
+}
+''', {"labels": ["a", "b", "c"]}),
+    # an element joined with a value outside its array + details in the head
+    "K8sDetails": ('''package k
+violation[{"msg": msg, "details": {"c": c.name}}] {
+  c := input.review.object.spec.containers[_]
+  not startswith(c.image, "good/")
+  msg := "image from a repository that is not allowed"
+}
+''', {}),
+}
+
+
+def pod(name, containers, **spec):
+    s = dict(spec)
+    s["containers"] = containers
+    return {"apiVersion": "v1", "kind": "Pod", "metadata": {"name": name, "namespace": "default", "labels": spec.pop("labels", {"app": name})}, "spec": s}
+
+
+def ctr(name, priv=False, image="good/x", ports=()):
+    c = {"name": name, "image": image}
+    if priv:
+        c["securityContext"] = {"privileged": True}
+    if ports:
+        c["ports"] = [{"hostPort": p, "containerPort": 80} for p in ports]
+    return c
+
+
+OBJS = [
+    pod("clean", [ctr("a")]),
+    pod("one", [ctr("a", priv=True), ctr("b")], hostNetwork=True),
+    pod("two", [ctr("a", priv=True, image="bad/x"), ctr("b", priv=True, image="bad/y", ports=(8080, 9090))], hostNetwork=True, hostPID=True),
+    pod("same-names", [ctr("a", priv=True, image="bad/x"), ctr("a", priv=True, image="bad/x", ports=(1,))]),      # equal messages collapse
+    pod("three", [ctr("a", ports=(1, 2)), ctr("b", ports=(3,)), ctr("c", priv=True, image="worse/z")], hostPID=True),
+    # an OBJECT where the templates iterate elements: Rego walks its values
+    {"apiVersion": "v1", "kind": "Pod", "metadata": {"name": "object-containers", "namespace": "default"},
+     "spec": {"containers": {"x": ctr("a", priv=True, image="bad/1"), "y": ctr("b", priv=True, image="bad/2")}}},
+]
+
+
+FLAT = {
+    # reaches the containers through ONE wildcard predicate: the violation formula needs no element loop, hence no guard on
+    # spec.containers -- counting its bindings does
+    "K8sFlat": ('''package k
+violation[{"msg": msg}] {
+  input.review.object.spec.containers[_].securityContext.privileged
+  msg := "privileged"
+}
+''', {}),
+    "K8sTwoBodies": T["K8sTwoBodies"],
+}
+
+
+def run_totals(backend, templates, objs):
+    c = make_client(backend)
+    oc = OC.Client()
+    for kind, (rego, params) in sorted(templates.items()):
+        k = {"apiVersion": "constraints.gatekeeper.sh/v1beta1", "kind": kind, "metadata": {"name": kind.lower()}, "spec": {"parameters": params}}
+        c.AddTemplate(tmpl(kind, rego)); c.AddConstraint(k)
+        oc.add_template(tmpl(kind, rego)); oc.add_constraint(k)
+    rins = [D.to_review_in(D.AugmentedUnstructured(D.Unstructured(o), None, "Original"), None) for o in objs]
+    table = c.driver.engine.create_table(rins, resident=True, process="audit")
+    try:
+        ev = table.eval()
+        refused = set(int(r) for r in ev.too_big_reviews())
+        got = table.totals()
+        rendered = table.rendered_pairs
+        os.environ["GK_TOTALS_RENDER_ALL"] = "1"
+        try:
+            every = table.totals()
+            rendered_all = table.rendered_pairs
+        finally:
+            del os.environ["GK_TOTALS_RENDER_ALL"]
+    finally:
+        table.free()
+    want, want_pairs = {}, {}
+    for i, o in enumerate(objs):
+        if i in refused:
+            continue   # beyond the engine's limits: reported, the caller fails closed (no bits, no results)
+        for r in oc.review(OT.AugmentedUnstructured(OT.Unstructured(o), None, "Original"), OC.AUDIT_EP):
+            key = r.constraint["kind"]
+            want[key] = want.get(key, 0) + 1
+            want_pairs.setdefault(key, set()).add(o["metadata"]["name"])
+    kind_of = {drv_id: rec[0].get("kind") for drv_id, rec in c._active(D.AUDIT_EP).items()}
+    results = {kind_of[cid]: v[0] for cid, v in got.items() if v[0]}
+    pairs = {kind_of[cid]: v[1] for cid, v in got.items() if v[1]}
+    assert results == want
+    assert pairs == {k: len(v) for k, v in want_pairs.items()}
+    assert got == every                                   # ... and the host pass over every violating pair says the same
+    assert rendered_all == sum(pairs.values())
+    return refused, want, want_pairs, rendered, rendered_all
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_result_totals_counted_on_the_device_equal_the_oracle(backend):
+    refused, want, want_pairs, rendered, rendered_all = run_totals(backend, T, OBJS)
+    # (the templates that join an element's fields loop over spec.containers in their VIOLATION formulas: the object in its place
+    #  is beyond the engine's limits for them, as before)
+    assert refused == {5}
+    # the workload separates results from pairs in every template but the one whose messages collapse
+    assert want["K8sPerElement"] > len(want_pairs["K8sPerElement"]) and want["K8sSameMessage"] == len(want_pairs["K8sSameMessage"])
+    assert want["K8sParamAlternatives"] == 3 * len(want_pairs["K8sParamAlternatives"])
+    assert rendered < rendered_all                        # the device answered part of them
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_an_object_where_bindings_are_counted_is_refused_by_the_totals_plan_only(backend):
+    refused, want, want_pairs, rendered, rendered_all = run_totals(backend, FLAT, OBJS)
+    assert not refused                      # the violation bitmap of every review comes from the device ...
+    assert "object-containers" in want_pairs["K8sFlat"]
+    assert 0 < rendered < rendered_all      # ... the object's result count from the renderer, the single-binding pairs from the device

@@ -281,7 +281,7 @@ def run(backend, seed, n_templates, n_objs, envelope=False, verbose=False, numer
     EVERY = every
     rng = random.Random(seed)
     objs = [rand_obj(rng, i) for i in range(n_objs)]
-    stats = {"ok": 0, "unsupported": 0, "diff": 0, "oracle_err": 0, "product_err": 0}
+    stats = {"ok": 0, "unsupported": 0, "diff": 0, "oracle_err": 0, "product_err": 0, "totals_ok": 0}
     diffs = []
     for i in range(n_templates):
         rego = template(rng, i)
@@ -322,7 +322,20 @@ def run(backend, seed, n_templates, n_objs, envelope=False, verbose=False, numer
         bad = [(j, got[j], want[j]) for j in range(n_objs) if got[j] != "REFUSED" and got[j] != want[j]]
         if bad:
             stats["diff"] += 1; diffs.append((bad[:2], rego, [objs[b[0]] for b in bad[:2]]))
-        else: stats["ok"] += 1
+            continue
+        stats["ok"] += 1
+        # RESULT totals (pkg/audit/manager.go:902): the device says which violating pairs can have more than one result, only
+        # those are rendered (gk_table_totals); the total must be the oracle's number of results over the same reviews
+        if not refused and "REJECTED" not in want:
+            try:
+                rep = c.AuditAggregate(mk_reviews(D, objs, seed), limit=1)
+            except Exception as e:
+                stats["product_err"] += 1; diffs.append(("TOTALS ERR " + str(e)[:200], rego)); continue
+            if not rep.errors:
+                total = sum(v["total"] for v in rep.values())
+                if total != sum(len(w) for w in want):
+                    stats["diff"] += 1; diffs.append(("RESULT totals %d, oracle %d" % (total, sum(len(w) for w in want)), rego, params))
+                else: stats["totals_ok"] += 1
     return stats, diffs
 
 
