@@ -464,6 +464,7 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts, const std
     std::vector<Blk> blks;
     size_t prev = 0;
     for (uint32_t e : plan.seg_ends) { blks.push_back({prev, e, 0, 0, {}, {}}); prev = e; }
+    static const uint64_t loop_weight = getenv("GK_JIT_LOOP_WEIGHT") ? (uint64_t)std::max(1, atoi(getenv("GK_JIT_LOOP_WEIGHT"))) : 3;   // tuning aid: cost of a loop body relative to straight-line code
     std::map<uint64_t, size_t> writer;   // derived bit -> block
     for (size_t bi = 0; bi < blks.size(); bi++) {
       Blk& B = blks[bi];
@@ -472,8 +473,8 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts, const std
         uint32_t ins = code[pc++];
         uint32_t op = ins & 0xFF, b = (ins >> 16) & 0xFF, c = ins >> 24;
         if (op == F_VEQ) { pc++; B.cost += 12 * weight; }
-        else if (op == F_LOOP) { B.cost += 4 * weight; weight *= 3; }
-        else if (op == F_ENDLOOP || op == F_ENDLOOP2) { weight /= 3; B.cost += 2 * weight; }
+        else if (op == F_LOOP) { B.cost += 4 * weight; weight *= loop_weight; }
+        else if (op == F_ENDLOOP || op == F_ENDLOOP2) { weight /= loop_weight; B.cost += (op == F_ENDLOOP2 ? 2 : 1) * weight; }
         else B.cost += weight;
         if (op == F_STG) B.writes.push_back(1ull << 40 | b | (c << 8));
         if (op == F_STE) B.writes.push_back(2ull << 40 | (uint64_t)b << 16 | c);

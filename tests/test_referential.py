@@ -1,0 +1,130 @@
+"""Referential templates (data.inventory) on the device plan.  The synced objects (Client.AddData -> gk_data_put) are a
+CONSTANT of the compiled formula: `other := data.inventory.namespace[ns][apiversion]["Ingress"][name]` unrolls into one
+alternative per synced Ingress, `other.spec.rules[_].host == host` becomes a comparison of the review's host with that
+object's hosts, `not identical(other, input.review)` a comparison of the review's name / namespace with its -- ordinary row
+predicates.  The constraints of a referential template are compiled again whenever the synced objects change
+(engine.cpp refresh_referential); an inventory that does not fit a plan makes every evaluation fail with GK_ERR_UNSUPPORTED
+(closed: the cgo shim keeps such a template on the stock driver), never a guess.
+
+Pinned by the reference: the message of test/gator/test/test.bats:222 for policies/default + manifests/referential-data
+through the `gator test` harness; everything else product vs oracle.  K8sUniqueServiceSelector (pkg/gator/fixtures/fixtures.go:414-471,
+test_test.go:135-158) and K8sUniqueLabel compare a value COMPUTED from a whole sub-object / several review fields with the
+inventory's: still refused when the constraint is added."""
+import pytest
+
+import reference_tables as T
+from conftest import gconst
+from gatekeeper_amd import driver as D
+from gatekeeper_amd import gator as G
+from oracle import client as OC
+from oracle import gator as OG
+from oracle import target as OT
+from parity_util import BACKENDS, make_client
+
+GT = "test/gator/test/fixtures/"
+
+
+def docs(fixtures, *paths):
+    out = []
+    for p in paths:
+        out.extend(fixtures["yaml"][p]["docs"])
+    return out
+
+
+def ingress(name, ns, *hosts, api="networking.k8s.io/v1"):
+    return {"apiVersion": api, "kind": "Ingress", "metadata": {"name": name, "namespace": ns}, "spec": {"rules": [{"host": h} for h in hosts]}}
+
+
+def both(backend, fixtures):
+    tmpl = docs(fixtures, GT + "policies/default/template_k8suniqueingresshost.yaml")[0]
+    con = docs(fixtures, GT + "policies/default/constraint_k8suniqueingresshost.yaml")[0]
+    c, oc = make_client(backend), OC.Client()
+    c.AddTemplate(tmpl); oc.add_template(tmpl)
+    c.AddConstraint(con); oc.add_constraint(con)
+    return c, oc
+
+
+def check(c, oc, objs, ep=D.GATOR_EP):
+    got = c.ReviewBatch([D.AugmentedUnstructured(D.Unstructured(o), None, "Original") for o in objs], ep)
+    n = 0
+    for o, g in zip(objs, got):
+        assert not isinstance(g, Exception), g
+        want = sorted(r.msg for r in oc.review(OT.AugmentedUnstructured(OT.Unstructured(o), None, "Original"), ep))
+        assert sorted(r.msg for r in g) == want, o["metadata"]["name"]
+        n += len(want)
+    return n
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_bats_referential_data_through_the_gator_harness(backend, fixtures):
+    """test.bats:211-223: `gator test -f policies/default -f manifests/referential-data` reports the ingress host conflict"""
+    pol = sorted(p for p in fixtures["yaml"] if p.startswith(GT + "policies/default/"))
+    ref = sorted(p for p in fixtures["yaml"] if p.startswith(GT + "manifests/referential-data/"))
+    objs = docs(fixtures, *(pol + ref))
+    c = make_client(backend)
+    c.enforcement_points = (D.GATOR_EP,)
+    got = G.test(objs, client=c)
+    assert T.MSG_INGRESS in [g.msg for g in got]
+    assert G.exit_code(got) == 1
+    assert sorted((g.msg, g.violating_object["metadata"]["name"]) for g in got) == sorted((r.msg, o["metadata"]["name"]) for r, o in OG.gator_test(objs))
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_the_compiled_constraint_follows_the_synced_objects(backend, fixtures):
+    c, oc = both(backend, fixtures)
+    a, b = ingress("a", "default", "x.example.com", api="extensions/v1beta1"), ingress("b", "default", "x.example.com", "y.example.com")
+    other_ns, same_name = ingress("c", "prod", "y.example.com"), ingress("a", "prod", "z.example.com")
+    not_ingress = {"apiVersion": "v1", "kind": "Service", "metadata": {"name": "svc", "namespace": "default"}, "spec": {"rules": [{"host": "x.example.com"}]}}
+    fresh = ingress("new", "default", "x.example.com", "unique.example.com")
+    everything = [a, b, other_ns, same_name, not_ingress, fresh]
+    assert check(c, oc, everything) == 0                       # nothing synced: nothing to conflict with
+    for o in (a, b):
+        c.AddData(o); oc.add_data(o)
+    assert check(c, oc, everything) == 4                       # a <-> b on x, c against b's y, the new one against both on x (ONE message: a set)
+    for o in (other_ns, same_name, not_ingress):
+        c.AddData(o); oc.add_data(o)
+    assert check(c, oc, everything) == 5                       # + b's second host against c (synced now); a Service's hosts are no Ingress hosts
+    c.RemoveData(a); oc.remove_data(a)
+    assert check(c, oc, everything) == 5 - 1                   # b no longer conflicts on x, a (unsynced now) still does, with b
+    b2 = ingress("b", "default", "q.example.com")
+    c.AddData(b2); oc.add_data(b2)                             # a synced object CHANGES
+    assert check(c, oc, [a, b2, other_ns, same_name, fresh]) == 0
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_result_totals_of_a_referential_constraint(backend, fixtures):
+    c, oc = both(backend, fixtures)
+    objs = [ingress("i%d" % i, "ns%d" % (i % 3), "h%d.example.com" % (i // 2), "shared.example.com" if i % 5 == 0 else "own%d.example.com" % i) for i in range(24)]
+    for o in objs:
+        c.AddData(o); oc.add_data(o)
+    want = sum(len(oc.review(OT.AugmentedUnstructured(OT.Unstructured(o), None, "Original"), OC.AUDIT_EP)) for o in objs)
+    rep = c.AuditAggregate([D.AugmentedUnstructured(D.Unstructured(o), None, "Original") for o in objs], limit=3)
+    assert not rep.errors and sum(v["total"] for v in rep.values()) == want
+    assert want > sum(v["total_pairs"] for v in rep.values())          # two conflicting hosts on one Ingress: two results, one pair
+
+
+def test_an_inventory_beyond_the_plan_fails_closed(fixtures):
+    c, oc = both("hostemu", fixtures)
+    objs = [ingress("i%d" % i, "default", "h%d.example.com" % i) for i in range(600)]
+    for o in objs:
+        c.AddData(o)
+    with pytest.raises(D.UnsupportedError, match="does not compile against the synced inventory"):
+        c.ReviewBatch([D.AugmentedUnstructured(D.Unstructured(objs[0]), None, "Original")], D.GATOR_EP)
+    for o in objs[40:]:
+        c.RemoveData(o)
+    for o in objs[:40]:
+        oc.add_data(o)
+    dup = ingress("dup", "default", "h7.example.com")
+    assert check(c, oc, [objs[0], dup]) == 1                   # the inventory fits again: the constraint serves again
+
+
+@pytest.mark.parametrize("name,reason", [("TemplateReferential", "symbolic operands")])
+def test_joins_on_computed_values_are_still_refused(fixtures, name, reason):
+    """K8sUniqueServiceSelector joins on flatten_selector(obj): a string computed from a whole map (fixtures.go:414-471)"""
+    tmpl, con = gconst(fixtures, name)[0], gconst(fixtures, "ConstraintReferential")[0]
+    c = make_client("hostemu")
+    c.AddTemplate(tmpl)
+    for o in gconst(fixtures, "ObjectReferentialInventory"):
+        c.AddData(o)
+    with pytest.raises(D.UnsupportedError, match=reason):
+        c.AddConstraint(con)
