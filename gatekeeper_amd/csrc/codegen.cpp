@@ -305,7 +305,10 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts, const std
       std::vector<uint32_t> ids;
       for (size_t c = 1; c < classes.size(); c++) if (c < class_weight->size() && (*class_weight)[c] > 0) ids.push_back((uint32_t)c);
       std::stable_sort(ids.begin(), ids.end(), [&](uint32_t a, uint32_t b) { return (*class_weight)[a] > (*class_weight)[b]; });
-      static const size_t n_hot = getenv("GK_JIT_HOT") ? (size_t)atoi(getenv("GK_JIT_HOT")) : 4;   // tuning aid; measured on configs[2] (profiles/r02_variants_f_hot_dispatch.log): 4 is level with 0, 8 and 16 are slower
+      // tuning aid.  Round 2 (profiles/r02_variants_f_hot_dispatch.log): a chain of 4 level with the plain switch, 8 and 16 slower.
+      // Round 3, on the kernel with one-stage formulas and the split output stage (profiles/r03_variants_l_*.log, one box):
+      // 0 -> 0.1148 ms, 2 -> 0.1164, 4 -> 0.1177, 6 -> 0.1205: the plain switch (one balanced compare tree) wins, default 0
+      static const size_t n_hot = getenv("GK_JIT_HOT") ? (size_t)atoi(getenv("GK_JIT_HOT")) : 0;
       for (size_t i = 0; i < ids.size() && i < n_hot; i++) hot.push_back(ids[i]);
     }
     std::ostringstream& o = real_o;

@@ -163,3 +163,4 @@ static inline uint32_t min(uint32_t a, uint32_t b) { return a < b ? a : b; }
 #define GK_OPAQUE_V1(a) do { } while (0)
 #define GK_OPAQUE_S1(a) do { } while (0)
 #define GK_OPAQUE() do { } while (0)
+#define GK_READLANE(v, k) ((uint32_t)gkemu::shfl((int)(v), (int)(k)))
