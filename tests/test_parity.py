@@ -595,6 +595,10 @@ def test_unsupported_is_an_error_not_a_fallback(backend, fixtures):
     k_ = gconst(fixtures, "ConstraintReferential")[0]
     c = make_client(backend)
     c.AddTemplate(t_)
+    # referential templates compile against the synced objects (tests/test_referential.py); this one joins on a value COMPUTED
+    # from a whole map, which no plan expresses: refused as soon as there is an inventory to join with
+    for o in gconst(fixtures, "ObjectReferentialInventory"):
+        c.AddData(o)
     with pytest.raises(D.UnsupportedError):
         c.AddConstraint(k_)
     with pytest.raises(D.ClientError):
