@@ -98,6 +98,7 @@ class gk_shard_out(C.Structure):
 
 GK_SHARD_DOWNLOAD = 1
 GK_SHARD_ENQUEUE = 2
+GK_SHARD_COLLECT = 4
 GK_COMM_ID_BYTES = 128
 HE_ALLGATHER = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_uint64)     # test-only (libgkgpu_hostemu.so gk_comm_init_host)
 HE_ALLREDUCE = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_longlong), C.c_uint64)

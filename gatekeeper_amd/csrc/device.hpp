@@ -19,6 +19,7 @@ struct EvalOptions {
   bool want_match = false;   // also produce the match-only bitmap
   uint32_t list_capacity = 0;   // max violation-list entries (0 = no list)
   bool shard = false;           // results go to the shard slot prepared by dev_shard_setup (bitmap stride = the largest shard's)
+  bool detached = false;        // (kernels.hip, internal) an enqueue-only pass that dev_eval_finish never collects: see dev_shard_enqueue
   bool jit_wait = true;         // wait for the plan-specialised build of the dominant kernel; false (admission batches): never
                                 //   block -- the bytecode kernel serves until the background build has been loaded
 };
@@ -73,22 +74,28 @@ void dev_comm_free(DevComm* c);
 int dev_comm_rank(const DevComm* c);
 int dev_comm_world(const DevComm* c);
 // A table evaluated as one SHARD: its violation bitmap and counts live in this rank's slot of an all-gather buffer
-// ([world] x ([nc][stride_tiles] u64 | [nc] u32 | pad)), stride_tiles = the largest shard's words per row.
+// ([world] x ([nc][stride_tiles] u64 | tail | pad), tail below), stride_tiles = the largest shard's words per row.
 struct ShardInfo {
   uint32_t stride_tiles = 0;            // bitmap words per row in every slot
   uint64_t slot_bytes = 0;
   std::vector<uint32_t> shard_reviews;  // [world]
 };
 void dev_shard_setup(DevTable* t, DevComm* c, uint32_t nc, ShardInfo* info);   // collective: exchanges the shard sizes
-// after a finished local evaluation of the shard (dev_eval): int64 totals <- counts, in-place all-gather of the slots,
-// all-reduce (sum) of the totals, on the evaluation stream; then synchronises and copies what was asked for to the host.
+// after a finished local evaluation of the shard (dev_eval): the slot's tail <- counts, ONE in-place all-gather of the slots,
+// int64 totals <- sums over the gathered tails, on the evaluation stream; then synchronises and copies what was asked for to
+// the host.  Slot: [nc][stride_tiles] u64 bitmap | [nc] u32 violating pairs | [nc] u32 autoreject pairs | u64 beyond | u64 not evaluated | pad.
 // totals: [nc] violating pairs | [nc] autoreject pairs (match errors) | reviews beyond the engine's limits | reviews not
 // evaluated (`not_evaluated` of this rank: rejected by HandleReview when the table was built), each summed over ALL shards --
 // what the gathered violation bitmaps cannot say, so that a sharded audit fails closed like the single-GPU one.
-// totals == nullptr: ENQUEUE ONLY -- counts, all-gather and all-reduce go onto the stream behind the launches of
+// totals == nullptr: ENQUEUE ONLY -- counts, all-gather and totals go onto the stream behind the launches of
 // dev_eval_launch and the call returns without waiting (back-to-back sweeps; the collecting call comes last)
 void dev_shard_exchange(DevTable* t, DevComm* c, uint32_t nc, uint64_t not_evaluated, std::vector<int64_t>* totals,
                         std::vector<uint64_t>* gathered /* may be null */, const void** d_gathered);
+// one enqueue-only sweep + exchange step of a resident shard (launch + exchange; captured into a graph from the second pass on)
+void dev_shard_enqueue(const DevPlan* p, DevTable* t, DevComm* c, const EvalOptions& opt, uint32_t nc, uint64_t not_evaluated, bool allow_graph);
+// the answer of the most recent enqueue-only pass, without sweeping again; false when there is none or when that pass left
+// reviews to the large-capacity re-run (which only a collecting sweep does)
+bool dev_shard_collect(DevTable* t, DevComm* c, uint32_t nc, std::vector<int64_t>* totals, std::vector<uint64_t>* gathered, const void** d_gathered);
 // Plan-specialised builds of the dominant kernel run in the background for admission batches (kernels.hip jit_for): wait for
 // every build in flight / code-object cache counters (hits = builds served without hiprtc)
 void dev_jit_quiesce();

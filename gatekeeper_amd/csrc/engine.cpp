@@ -347,6 +347,7 @@ struct gk_table {
   std::vector<ReviewDoc> docs;  // GK_TABLE_KEEP_DOCS
   std::vector<gk_review_in> texts;   // GK_TABLE_KEEP_TEXT: where each review's JSON lives (caller-owned text)
   std::vector<std::string> review_errors;
+  uint64_t n_rejected = ~0ull;              // non-empty review_errors (counted by the first sharded sweep)
   uint64_t dir_bytes = 0, n_rows = 0;      // review-flag bytes (read by every launch); rows in the table
   std::vector<uint32_t> path_rows;          // rows per path: which rows a plan reads
   std::vector<uint32_t> path_max;           // per element path: largest array of one review
@@ -1831,15 +1832,17 @@ int gk_table_sweep_sharded(gk_engine* e, gk_table* t, uint32_t flags, gk_shard_o
     opt.download = false;
     opt.shard = true;
     opt.jit_wait = true;   // a shard of the audit set is a resident table: the plan-specialised kernel or nothing
-    uint64_t rejected = 0;
-    for (const std::string& er : t->review_errors) if (!er.empty()) rejected++;
+    if (t->n_rejected == ~0ull) {   // (a table's reviews never change: counted once, not per sweep -- a million strings)
+      uint64_t nr = 0;
+      for (const std::string& er : t->review_errors) if (!er.empty()) nr++;
+      t->n_rejected = nr;
+    }
+    const uint64_t rejected = t->n_rejected;
     if (enqueue) {   // sweep + exchange of every plan group onto the stream(s); whoever collects waits for them
-      dev_eval_launch(dp, t->dev, opt);
-      dev_shard_exchange(t->dev, e->comm, nc0, rejected, nullptr, nullptr, nullptr);
-      for (size_t gi = 0; gi < e->extra.size(); gi++) {
-        dev_eval_launch(e->extra[gi]->dev, t->views[gi], opt);
-        dev_shard_exchange(t->views[gi], e->comm, (uint32_t)e->extra[gi]->ids.size(), rejected, nullptr, nullptr, nullptr);
-      }
+      // (five enqueues per plan group; GK_SHARD_GRAPH=1: a single plan group's step replays as one captured graph)
+      dev_shard_enqueue(dp, t->dev, e->comm, opt, nc0, rejected, e->extra.empty());
+      for (size_t gi = 0; gi < e->extra.size(); gi++)
+        dev_shard_enqueue(e->extra[gi]->dev, t->views[gi], e->comm, opt, (uint32_t)e->extra[gi]->ids.size(), rejected, false);
       if (out) *out = nullptr;
       return GK_OK;
     }
@@ -1847,20 +1850,24 @@ int gk_table_sweep_sharded(gk_engine* e, gk_table* t, uint32_t flags, gk_shard_o
     // local evaluation, finished (incl. the large-capacity pass for overflowing reviews) BEFORE the exchange, so that the
     // gathered bitmaps are complete; then the exchange step on the same stream.  A constraint set that needs several
     // plan groups runs one evaluation + exchange per group (each group has its own slot buffer on its view of the table).
-    dev_eval(dp, t->dev, opt, &eo);
     const void* d_all = nullptr;
     const bool want_host = (flags & GK_SHARD_DOWNLOAD) != 0;
     std::vector<uint64_t> g0;
+    // GK_SHARD_COLLECT: the answer of the last enqueue-only pass, without sweeping again -- unless some review of that pass,
+    // on any rank, was left to the large-capacity re-run (then this is an ordinary collecting sweep; every rank decides alike)
+    const bool collected = (flags & GK_SHARD_COLLECT) && e->extra.empty() &&
+                           dev_shard_collect(t->dev, e->comm, nc0, &h->totals, want_host ? &g0 : nullptr, &d_all);
+    if (!collected) dev_eval(dp, t->dev, opt, &eo);
     // what the bitmaps cannot say travels with the totals (fail closed, like Client.AuditAggregate): autoreject pairs, reviews
     // beyond the engine's limits, reviews HandleReview rejected when this shard was built
     int64_t beyond = 0, not_eval = 0;
-    auto split = [&](std::vector<int64_t>& raw, uint32_t ncg, bool first) {   // raw: [ncg] pairs | [ncg] autoreject | beyond | not evaluated
+    auto split = [&](std::vector<int64_t>& raw, uint32_t ncg, bool first) {   // raw: [ncg] pairs | [ncg] autoreject | beyond | not evaluated | left to the re-run
       h->err_totals.insert(h->err_totals.end(), raw.begin() + ncg, raw.begin() + 2 * (size_t)ncg);
       beyond += raw[2 * (size_t)ncg];
       if (first) not_eval = raw[2 * (size_t)ncg + 1];
       raw.resize(ncg);
     };
-    dev_shard_exchange(t->dev, e->comm, nc0, rejected, &h->totals, want_host ? &g0 : nullptr, &d_all);
+    if (!collected) dev_shard_exchange(t->dev, e->comm, nc0, rejected, &h->totals, want_host ? &g0 : nullptr, &d_all);
     split(h->totals, nc0, true);
     uint32_t nc = nc0;
     if (n_groups == 1) h->gathered.swap(g0);

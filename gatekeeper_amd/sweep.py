@@ -3,8 +3,9 @@
 The reference's audit loop is serial (pkg/audit/manager.go:591-642: for obj { Client.Review }).  Here every rank (one
 process per GPU) keeps its shard of the flattened object set resident in HBM and sweeps it with one kernel launch; the only
 exchange step is issued by the ENGINE on the kernel's stream through its own RCCL communicator (gk_table_sweep_sharded):
-an in-place ncclAllGather of every shard's [violation bitmap | counts] slot plus an ncclAllReduce(sum) of the int64
-per-constraint totals, so that every rank ends with the full constraints x objects answer.  Objects never move.
+ONE in-place ncclAllGather of every shard's [violation bitmap | counts | fail-closed counts] slot -- the int64 totals are
+the sums over the gathered slot tails --, so that every rank ends with the full constraints x objects answer.  Objects never
+move.  Back-to-back sweeps of a shard are enqueue-only: five enqueues per pass, no host round trip.
 
 torch.distributed is plumbing only: it carries the RCCL unique id from rank 0 to the other ranks (and, in the CPU tests,
 stands in for the collectives through the test-only emulation library), and gathers the few top-k candidate records of
@@ -108,24 +109,27 @@ class ShardedSweep:
         dist.broadcast_object_list(ident, src=0)
         eng._check(eng.lib.gk_comm_init(eng.handle, ident[0], rank, world))
 
-    def sweep(self, steps=1, download=False, strict=False):
+    def sweep(self, steps=1, download=False, strict=False, collect=False):
         """`steps` passes of the hot path over the resident shard.  Single process: the launches are enqueued back to back and
         collected once -> EvalResult.  Sharded: every pass is local evaluation + the engine's exchange step, enqueued back to
         back on the shard's stream (GK_SHARD_ENQUEUE); the last pass collects -> ShardedResult of the last pass.  A sharded result carries `beyond_limits` / `not_evaluated` / `err_totals` (summed over all shards):
         objects the totals and bitmaps say nothing about.  strict=True raises driver.LimitError / driver.ReviewFailure for
-        them, as Client.AuditAggregate reports them for a single table (every rank raises: the counts are global)."""
+        them, as Client.AuditAggregate reports them for a single table (every rank raises: the counts are global).
+        collect=True: ALL `steps` passes are enqueue-only and the answer of
+        the last one is collected without a further sweep (GK_SHARD_COLLECT; the engine sweeps once more only when that pass left
+        reviews to the large-capacity re-run)."""
         if self.dist is None:
             for _ in range(steps):
                 self.table.launch()
             return self.table.eval(download=download, collect_only=True)
         eng = self.client.driver.engine
         res = None
-        for k in range(steps):
-            if k < steps - 1:   # sweep + exchange enqueued back to back on the shard's stream; the last pass collects
+        for k in range(steps + (1 if collect else 0)):
+            if k < steps - 1 or (collect and k < steps):   # sweep + exchange enqueued back to back on the shard's stream; the last pass collects
                 eng._check(eng.lib.gk_table_sweep_sharded(eng.handle, self.table.handle, L.GK_SHARD_ENQUEUE, None))
                 continue
             out = C.POINTER(L.gk_shard_out)()
-            flags = L.GK_SHARD_DOWNLOAD if download else 0
+            flags = (L.GK_SHARD_DOWNLOAD if download else 0) | (L.GK_SHARD_COLLECT if collect else 0)
             eng._check(eng.lib.gk_table_sweep_sharded(eng.handle, self.table.handle, flags, C.byref(out)))
             res = ShardedResult(eng.lib, out)
         if strict and res is not None:

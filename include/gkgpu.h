@@ -223,10 +223,11 @@ void gk_totals_free(gk_totals_out* o);
  * One process / engine per GPU; the audited objects are block-sharded over the ranks (each rank flattens its own shard
  * into a resident table); policies are replicated.  gk_comm_init joins the engine to an RCCL communicator (rank 0 makes
  * the id with gk_comm_unique_id and distributes it out of band, e.g. through the launcher's store).  One sweep step
- * (gk_table_sweep_sharded) = local evaluation of the shard, then ONE exchange on the same stream: an in-place
- * ncclAllGather of every shard's [violation bitmap | counts] slot and an ncclAllReduce(sum) of the int64 per-constraint
- * totals, so that every rank ends with the full constraints x objects bitmap and the global totals.  Shards may differ in
- * size: all slots use the bitmap stride of the largest shard (`stride_tiles`), a shard's own words come first.
+ * (gk_table_sweep_sharded) = local evaluation of the shard, then ONE collective on the same stream: an in-place
+ * ncclAllGather of every shard's slot [violation bitmap | counts | what the bitmaps cannot say], so that every rank ends
+ * with the full constraints x objects bitmap; the global int64 totals are the sums over the gathered slot tails (a kernel on
+ * every rank, no second collective).  Shards may differ in size: all slots use the bitmap stride of the largest shard
+ * (`stride_tiles`), a shard's own words come first.
  * A constraint set that needs several plan groups (more than 64 distinct formulas) runs one evaluation + exchange per
  * group; `gathered` is then the merged host copy (all groups' rows in constraint_ids order) and `d_gathered` is NULL.
  * Collective: every rank must call it. */
@@ -236,7 +237,8 @@ int gk_comm_init(gk_engine* e, const char id[GK_COMM_ID_BYTES], int rank, int wo
 void gk_comm_destroy(gk_engine* e);
 typedef struct {
   uint32_t world, rank, n_constraints, stride_tiles;
-  uint64_t slot_bytes;               /* bytes per rank in the gathered buffer: [n_constraints][stride_tiles] u64 | [n_constraints] u32 | pad */
+  uint64_t slot_bytes;               /* bytes per rank in the gathered buffer: [n_constraints][stride_tiles] u64 | [n_constraints] u32 violating
+                                        objects | tail (autoreject counts, fail-closed counts; engine-internal) | pad */
   const uint32_t* constraint_ids;    /* [n_constraints] bitmap-row order */
   const uint32_t* shard_reviews;     /* [world] objects per shard */
   const int64_t* totals;             /* [n_constraints] violating (constraint, object) pairs over ALL shards */
@@ -245,7 +247,7 @@ typedef struct {
   float kernel_ms, fast_kernel_ms;
   uint32_t n_overflow;
   /* Fail closed (pkg/audit/manager.go:622-625 logs and skips a failed Review; it never counts it as clean): what the
-   * violation bitmaps cannot say, summed over ALL shards by the same all-reduce.  A caller that wants the reference's
+   * violation bitmaps cannot say, summed over ALL shards (it travels in the slot tails of the same all-gather).  A caller that wants the reference's
    * answer reviews these objects on the stock driver. */
   const int64_t* err_totals;         /* [n_constraints] autoreject pairs: Matcher.Match returned an error (one Result each) */
   int64_t beyond_limits;             /* reviews a plan group could not evaluate (beyond the engine's limits; counted per plan group) */
@@ -257,6 +259,12 @@ typedef struct {
  * it runs one more sweep, waits, and returns the answer.  Only that collecting sweep re-runs reviews that overflowed the
  * dominant kernel's element capacity; the engine's limits apply as before.  Collective like every call of this function. */
 #define GK_SHARD_ENQUEUE 2u
+/* GK_SHARD_COLLECT (without GK_SHARD_ENQUEUE): wait for the enqueue-only passes and return the answer of the LAST of them
+ * instead of sweeping once more.  Falls back to an ordinary collecting sweep when nothing was enqueued, when the constraint
+ * set needs several plan groups, or when that pass left reviews -- on any rank -- to the large-capacity re-run.  An enqueue-only
+ * pass is five enqueues (sweep, two slot-tail kernels, all-gather, totals); GK_SHARD_GRAPH=1 replays a single-plan-group pass as one
+ * captured graph instead. */
+#define GK_SHARD_COLLECT 4u
 int gk_table_sweep_sharded(gk_engine* e, gk_table* t, uint32_t flags, gk_shard_out** out);
 void gk_shard_free(gk_shard_out* o);
 

@@ -168,6 +168,7 @@ DevComm* hostemu_comm(int rank, int world, HeAllGather g, HeAllReduce r, void* c
 void dev_comm_free(DevComm* c) { delete c; }
 int dev_comm_rank(const DevComm* c) { return c->rank; }
 int dev_comm_world(const DevComm* c) { return c->world; }
+static size_t shard_tail_off(uint32_t nc, uint32_t stride) { return (size_t)nc * stride * 8; }
 void dev_shard_setup(DevTable* t, DevComm* c, uint32_t nc, ShardInfo* info) {
   std::vector<unsigned long long> sizes(c->world, 0);
   sizes[c->rank] = t->t.n_reviews;
@@ -176,7 +177,8 @@ void dev_shard_setup(DevTable* t, DevComm* c, uint32_t nc, ShardInfo* info) {
   uint32_t stride = 1;
   for (int r = 0; r < c->world; r++) { info->shard_reviews.push_back((uint32_t)sizes[r]); stride = std::max<uint32_t>(stride, (uint32_t)((sizes[r] + GK_TILE - 1) / GK_TILE)); }
   info->stride_tiles = stride;
-  info->slot_bytes = (((size_t)nc * stride * 8 + (size_t)nc * 4) + 15) & ~(size_t)15;
+  // slot (kernels.hip): [nc][stride] u64 bitmap | [nc] u32 violating pairs | [nc] u32 autoreject pairs | u64 beyond limits | u64 not evaluated | pad
+  info->slot_bytes = (shard_tail_off(nc, stride) + (size_t)nc * 8 + 16 + 15) & ~(size_t)15;
   t->shard_stride = stride; t->shard_slot = info->slot_bytes; t->shard_nc = nc;
   t->shard_all.assign((size_t)c->world * info->slot_bytes, 0);
 }
@@ -186,23 +188,34 @@ void dev_shard_exchange(DevTable* t, DevComm* c, uint32_t nc, uint64_t not_evalu
   const uint32_t nt = (t->t.n_reviews + GK_TILE - 1) / GK_TILE;
   uint8_t* slot = t->shard_all.data() + (size_t)c->rank * t->shard_slot;
   memset(slot, 0, t->shard_slot);
-  std::vector<long long> tot(2 * (size_t)nc + 2, 0);   // [nc] pairs | [nc] autoreject pairs | beyond limits | not evaluated
+  uint8_t* tail = slot + shard_tail_off(nc, t->shard_stride);
   const bool have = t->last_viol.size() == (size_t)nc * nt && t->last_err.size() == (size_t)nc * nt;   // (an enqueue-only pass before the first finished evaluation exchanges zeros)
-  for (uint32_t k = 0; k < nc && have; k++) for (uint32_t w = 0; w < nt; w++) tot[nc + k] += __builtin_popcountll(t->last_err[(size_t)k * nt + w]);
-  for (uint32_t w = 0; w < nt && w < t->last_big.size(); w++) tot[2 * (size_t)nc] += __builtin_popcountll(t->last_big[w]);
-  tot[2 * (size_t)nc + 1] = (long long)not_evaluated;
   for (uint32_t k = 0; k < nc; k++) {
-    uint32_t cnt = 0;
+    uint32_t cnt = 0, ecnt = 0;
     for (uint32_t w = 0; w < nt; w++) { const uint64_t v = have ? t->last_viol[(size_t)k * nt + w] : 0; memcpy(slot + ((size_t)k * t->shard_stride + w) * 8, &v, 8); cnt += (uint32_t)__builtin_popcountll(v); }
-    memcpy(slot + (size_t)nc * t->shard_stride * 8 + (size_t)k * 4, &cnt, 4);
-    tot[k] = cnt;
+    for (uint32_t w = 0; w < nt && have; w++) ecnt += (uint32_t)__builtin_popcountll(t->last_err[(size_t)k * nt + w]);
+    memcpy(tail + (size_t)k * 4, &cnt, 4);
+    memcpy(tail + ((size_t)nc + k) * 4, &ecnt, 4);
   }
-  c->gather(c->ctx, t->shard_all.data(), t->shard_slot);
-  c->reduce(c->ctx, tot.data(), (uint32_t)tot.size());
+  unsigned long long beyond = 0, ne = not_evaluated;
+  for (uint32_t w = 0; w < nt && w < t->last_big.size(); w++) beyond += (unsigned long long)__builtin_popcountll(t->last_big[w]);
+  memcpy(tail + (size_t)nc * 8, &beyond, 8);
+  memcpy(tail + (size_t)nc * 8 + 8, &ne, 8);
+  c->gather(c->ctx, t->shard_all.data(), t->shard_slot);   // the ONE collective of a sweep
   if (!totals) return;   // enqueue only
-  totals->assign(tot.begin(), tot.end());
+  totals->assign(2 * (size_t)nc + 2, 0);   // [nc] pairs | [nc] autoreject pairs | beyond limits | not evaluated: sums over the gathered tails
+  for (int r = 0; r < c->world; r++) {
+    const uint8_t* tl = t->shard_all.data() + (size_t)r * t->shard_slot + shard_tail_off(nc, t->shard_stride);
+    for (uint32_t i = 0; i < 2 * nc; i++) { uint32_t v; memcpy(&v, tl + (size_t)i * 4, 4); (*totals)[i] += v; }
+    for (uint32_t i = 0; i < 2; i++) { unsigned long long v; memcpy(&v, tl + (size_t)nc * 8 + (size_t)i * 8, 8); (*totals)[2 * (size_t)nc + i] += (long long)v; }
+  }
   if (gathered) { gathered->resize(t->shard_all.size() / 8); memcpy(gathered->data(), t->shard_all.data(), t->shard_all.size()); }
   if (d_gathered) *d_gathered = t->shard_all.data();
+}
+bool dev_shard_collect(DevTable*, DevComm*, uint32_t, std::vector<int64_t>*, std::vector<uint64_t>*, const void**) { return false; }   // (the emulation's enqueue-only passes exchange the LAST FINISHED evaluation: always sweep)
+void dev_shard_enqueue(const DevPlan* p, DevTable* t, DevComm* c, const EvalOptions& opt, uint32_t nc, uint64_t not_evaluated, bool) {
+  dev_eval_launch(p, t, opt);
+  dev_shard_exchange(t, c, nc, not_evaluated, nullptr, nullptr, nullptr);
 }
 
 // GK_HOSTEMU_KERNEL=1 | jit: additionally run the dominant kernel's HIP source (kernel_body.inc) through the kernel emulator

@@ -43,6 +43,7 @@ def _worker(rank, world, port, out_dir, policies="audit"):
     shard = objs[lo:lo + SHARDS[rank]]
     sw = ShardedSweep(_client(policies), shard, synth.gen_namespaces(), dist=dist, device=torch.device("cpu"), keep_docs=True)
     sw.sweep(2)
+    sw.sweep(2, collect=True)          # (the emulation has no enqueue-only answer: GK_SHARD_COLLECT falls back to a collecting sweep)
     res = sw.sweep(3, download=True)   # two enqueued sweep + exchange passes (GK_SHARD_ENQUEUE), the third collects
     lists = sw.audit_lists(limit=5)
     with open(os.path.join(out_dir, "rank_%d.pkl" % rank), "wb") as fh:
@@ -132,3 +133,67 @@ def test_sharded_sweep_fails_closed(tmp_path):
         assert (got["err_totals"] == ref_err).all()
         assert (got["totals"] == ref.counts.astype(np.int64)).all()
         assert got["raised"] and "beyond the engine's limits" in got["raised"]
+
+
+def _gpu_client():
+    fx = synth.load_fixtures()
+    c = D.Client(D.Driver(device=0, hostemu=False))
+    for t in synth.psp_templates(fx):
+        c.AddTemplate(t)
+    for k in synth.audit_constraints():
+        c.AddConstraint(k)
+    return c
+
+
+def _rccl_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    out = {}
+    for name, objs in (("limits", _limit_objs()), ("plain", _plain_objs())):
+        sw = ShardedSweep(_gpu_client(), objs, synth.gen_namespaces(), dist=dist, device=torch.device("cuda", 0), keep_docs=True)
+        first = sw.sweep(1, download=True)
+        # enqueue-only passes: the first runs directly, the second is captured into a graph, the others replay it.  collect=True hands
+        # out the answer of the LAST REPLAY ("plain"); with reviews left to the large-capacity re-run ("limits": 300 containers) it
+        # must fall back to one more, collecting sweep
+        res = sw.sweep(6, download=True, collect=True)
+        again = sw.sweep(3, download=True)
+        last = sw.sweep(2, download=True, collect=True)
+        out[name] = [{"bitmaps": r.bitmaps(), "totals": r.totals, "counts": r.counts(), "beyond": r.beyond_limits, "not_evaluated": r.not_evaluated,
+                      "err_totals": r.err_totals, "kernel_ms": r.kernel_ms} for r in (first, res, again, last)]
+    with open(os.path.join(out_dir, "rccl_%d.pkl" % rank), "wb") as fh:
+        pickle.dump(out, fh)
+    dist.destroy_process_group()
+
+
+def _plain_objs():
+    return synth.gen_objects(3000, seed=8, mixed=True)
+
+
+@pytest.mark.gpu
+def test_rccl_exchange_and_captured_sweeps_on_the_device(tmp_path):
+    """The engine's own RCCL path on the MI355X at world size 1 (librccl through dlopen, the in-place ncclAllGather of the slots,
+    the totals from the gathered tails) and the captured-graph replay of enqueue-only sweeps: bitmaps, totals and the
+    fail-closed counts equal the plain evaluation of the same table, before and after the graph takes over."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_rccl_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True)
+    got_all = pickle.load(open(os.path.join(str(tmp_path), "rccl_0.pkl"), "rb"))
+    for name, objs, beyond in (("limits", _limit_objs(), 2), ("plain", _plain_objs(), 0)):
+        single = ShardedSweep(_gpu_client(), objs, synth.gen_namespaces(), keep_docs=True)
+        ref = single.table.eval()
+        n = len(objs)
+        ref_err = np.array([int(np.unpackbits(ref.err[r].view(np.uint8)).sum()) for r in range(ref.n_constraints)], np.int64)
+        ref_bits = np.stack([np.unpackbits(ref.viol[r].view(np.uint8), bitorder="little")[:n] for r in range(ref.n_constraints)])
+        got = got_all[name]
+        assert len(got) == 4 and ref.counts.sum() > 0 and len(ref.too_big_reviews()) == beyond
+        for g in got:
+            bits = np.stack([np.unpackbits(g["bitmaps"][0][r].view(np.uint8), bitorder="little")[:n] for r in range(ref.n_constraints)])
+            assert (bits == ref_bits).all()
+            assert (g["totals"] == ref.counts.astype(np.int64)).all() and (g["counts"][0] == ref.counts).all()
+            assert g["beyond"] == beyond and g["not_evaluated"] == 0 and (g["err_totals"] == ref_err).all()
+        # "plain": the collected answers came from the enqueue-only passes themselves (no collecting sweep ran: no kernel time reported)
+        if name == "plain":
+            assert got[1]["kernel_ms"] == 0 and got[3]["kernel_ms"] == 0 and got[2]["kernel_ms"] > 0
