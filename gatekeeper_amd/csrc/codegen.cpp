@@ -160,9 +160,28 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts, const std
       for (size_t i : icmp) o << "        { constexpr Pred P = " << pred_literal(ps[i]) << "; if (eval_pred(r, P, h, heap, cheap)) " << target[i] << " }\n";
       o << "      }\n";
     }
+    // predicates on components of split(trim(row, cut), sep): the split itself -- where the separators are, vm_core.hpp
+    // SplitMask -- is computed ONCE per (cut, sep) of the class and shared by all of them (seven "banned tag" predicates on
+    // containers[].image used to scan the string seven times, a byte per memory round trip)
+    std::vector<uint32_t> split_pads;
+    for (size_t i = 0; i < ps.size(); i++)
+      if (!target[i].empty() && (ps[i].op == P_SPLIT_CMP || ps[i].op == P_SPLIT_COUNT || ps[i].op == P_SPLIT_PREFIX) &&
+          std::find(split_pads.begin(), split_pads.end(), ps[i].pad) == split_pads.end()) split_pads.push_back(ps[i].pad);
+    if (!split_pads.empty()) {
+      o << "      const bool isstr = t == T_STRING;\n      const StrRef s_ = make_str(r, h, heap);\n";
+      for (uint32_t pad : split_pads)
+        o << "      SplitMask sm_" << pad << "; sm_" << pad << ".seps = 0ull; sm_" << pad << ".lo = 0u; sm_" << pad << ".hi = 0u; sm_" << pad << ".fast = true;\n"
+          << "      if (isstr) sm_" << pad << " = split_mask(s_, (uint8_t)" << (pad >> 8) << "u, (uint8_t)" << (pad & 0xFFu) << "u);\n";
+    }
     for (size_t i = 0; i < ps.size(); i++) {
       const Pred& p = ps[i];
       if (target[i].empty() || (p.op == P_CMP && p.ctype == T_INT)) continue;
+      if (p.op == P_SPLIT_CMP || p.op == P_SPLIT_COUNT || p.op == P_SPLIT_PREFIX) {
+        const std::string call = std::string(p.op == P_SPLIT_PREFIX ? "eval_split_prefix" : "eval_split_pred") + "(s_, sm_" + std::to_string(p.pad) + ", P, cheap)";
+        if (flat) o << "      { constexpr Pred P = " << pred_literal(p) << "; " << tmask[i] << " |= (isstr && " << call << ") ? " << tbit[i] << " : 0u; }\n";
+        else o << "      { constexpr Pred P = " << pred_literal(p) << "; if (isstr && " << call << ") " << target[i] << " }\n";
+        continue;
+      }
       std::string cond;
       switch (p.op) {
         case P_DEFINED: cond = "true"; break;

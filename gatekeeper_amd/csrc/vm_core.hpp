@@ -216,8 +216,76 @@ GK_HD int cmp_row_const(const Row& r, const Pred& p, const StrHdr& h, const uint
   }
 }
 
-// component `idx` of split(trim(s, cut), sep): returns false when it does not exist.
-GK_HD bool split_component(const StrRef& s, uint8_t cut, uint8_t sep, int32_t idx, uint32_t* off, uint32_t* len, uint32_t* count) {
+// ---- byte-position masks.  Scanning a string byte by byte costs one DEPENDENT memory round trip per byte beyond the 12 header
+// bytes (split() on a 35-byte image reference: ~50 of them per predicate, measured as 88 % of the 200-template corpus sweep).
+// For strings of up to 64 bytes -- names, images, paths -- the positions of a byte value are ONE 64-bit mask instead: the header
+// bytes come from registers, the rest from at most three independent 16-byte loads and one word (a heap entry is 16-byte
+// aligned and zero padded: bytes 12.. of the string sit at entry offset 16..), compared four bytes at a time; splitting and
+// trimming are bit arithmetic on the masks.  Longer strings take the byte-wise path.
+GK_HD uint32_t eq4(uint32_t w, uint32_t pat) {   // bit k = byte k of w equals the pattern byte (exact per byte: no borrow between bytes)
+  const uint32_t x = w ^ pat;
+  uint32_t t = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
+  t >>= 7;
+  return (t | (t >> 7) | (t >> 14) | (t >> 21)) & 0xFu;
+}
+GK_HD uint64_t low_mask64(uint32_t n) { return n >= 64u ? ~0ull : ((1ull << n) - 1ull); }
+GK_HD uint32_t ctz64(uint64_t v) { return v ? (uint32_t)__builtin_ctzll(v) : 64u; }
+struct StrWords { uint32_t w[16]; };   // bytes 0..63 of a string, zero beyond its end
+GK_HD StrWords str_words64(const StrRef& s) {
+  StrWords o;
+  o.w[0] = (uint32_t)s.bits; o.w[1] = (uint32_t)(s.bits >> 32); o.w[2] = s.w2;
+  for (int j = 3; j < 16; j++) o.w[j] = 0u;
+  if (s.p) {
+    // (separate conditions, no use in between: the loads are issued back to back and waited for once)
+    if (s.n > 12u) { o.w[3] = ld32(s.p + 12); o.w[4] = ld32(s.p + 16); o.w[5] = ld32(s.p + 20); o.w[6] = ld32(s.p + 24); }
+    if (s.n > 28u) { o.w[7] = ld32(s.p + 28); o.w[8] = ld32(s.p + 32); o.w[9] = ld32(s.p + 36); o.w[10] = ld32(s.p + 40); }
+    if (s.n > 44u) { o.w[11] = ld32(s.p + 44); o.w[12] = ld32(s.p + 48); o.w[13] = ld32(s.p + 52); o.w[14] = ld32(s.p + 56); }
+    if (s.n > 60u) o.w[15] = ld32(s.p + 60);
+  }
+  return o;
+}
+GK_HD uint64_t eq_mask64(const StrWords& sw, uint32_t n, uint32_t ch) {   // bit i, i < min(n, 64): byte i equals ch
+  const uint32_t pat = (ch & 0xFFu) * 0x01010101u;
+  uint64_t m = 0;
+  for (int j = 0; j < 16; j++) m |= (uint64_t)eq4(sw.w[j], pat) << (4 * j);
+  return m & low_mask64(n);
+}
+GK_HD uint32_t select_bit64(uint64_t m, uint32_t k) {   // position of the k-th (0-based) set bit; 64 if there is none
+  for (uint32_t i = 0; i < k; i++) m &= m - 1ull;
+  return ctz64(m);
+}
+// [lo, hi) of trim(s, cut) from the mask of the positions that hold `cut` (n <= 64)
+GK_HD void trim_bounds64(uint64_t cut_mask, uint32_t n, uint32_t* lo, uint32_t* hi) {
+  const uint64_t keep = ~cut_mask & low_mask64(n);   // positions that are not the cut byte
+  if (!keep) { *lo = n; *hi = n; return; }
+  *lo = ctz64(keep);
+  *hi = 64u - (uint32_t)__builtin_clzll(keep);
+}
+// what split(trim(s, cut), sep) looks like: the separator positions inside [lo, hi).  One per (row, cut, sep): every
+// predicate on a component of the same split shares it (the plan-specialised build computes it once per class body).
+struct SplitMask { uint64_t seps; uint32_t lo, hi; bool fast; };
+GK_HD SplitMask split_mask(const StrRef& s, uint8_t cut, uint8_t sep) {
+  SplitMask o;
+  o.seps = 0; o.lo = 0; o.hi = s.n; o.fast = s.n <= 64u;
+  if (!o.fast) return o;
+  const StrWords sw = str_words64(s);
+  if (cut) trim_bounds64(eq_mask64(sw, s.n, cut), s.n, &o.lo, &o.hi);
+  o.seps = eq_mask64(sw, s.n, sep) & low_mask64(o.hi) & ~low_mask64(o.lo);
+  return o;
+}
+GK_HD bool split_component_fast(const SplitMask& sm, int32_t idx, uint32_t* off, uint32_t* len, uint32_t* count) {
+  const uint32_t cnt = (uint32_t)__builtin_popcountll(sm.seps) + 1u;
+  *count = cnt;
+  const int32_t want = idx >= 0 ? idx : (int32_t)cnt + idx;
+  if (want < 0 || want >= (int32_t)cnt) return false;
+  const uint32_t start = want == 0 ? sm.lo : select_bit64(sm.seps, (uint32_t)want - 1u) + 1u;
+  const uint32_t end = (uint32_t)want == cnt - 1u ? sm.hi : select_bit64(sm.seps, (uint32_t)want);
+  *off = start; *len = end - start;
+  return true;
+}
+
+// component `idx` of split(trim(s, cut), sep): returns false when it does not exist.  (byte-wise: strings beyond 64 bytes)
+GK_HD_COLD bool split_component_slow(const StrRef& s, uint8_t cut, uint8_t sep, int32_t idx, uint32_t* off, uint32_t* len, uint32_t* count) {
   uint32_t lo = 0, hi = s.n;
   if (cut) {
     while (lo < hi && sbyte(s, lo) == cut) lo++;
@@ -238,6 +306,35 @@ GK_HD bool split_component(const StrRef& s, uint8_t cut, uint8_t sep, int32_t id
     }
   }
   return false;
+}
+GK_HD bool split_component(const StrRef& s, const SplitMask& sm, uint8_t cut, uint8_t sep, int32_t idx, uint32_t* off, uint32_t* len, uint32_t* count) {
+  if (sm.fast) return split_component_fast(sm, idx, off, len, count);
+  return split_component_slow(s, cut, sep, idx, off, len, count);
+}
+// P_SPLIT_CMP / P_SPLIT_COUNT on a string row whose split is already known
+GK_HD bool eval_split_pred(const StrRef& s, const SplitMask& sm, const Pred& p, const uint8_t* cheap) {
+  uint32_t off = 0, len = 0, cnt = 0;
+  const uint8_t cut = (uint8_t)(p.pad >> 8), sep = (uint8_t)(p.pad & 0xFF);
+  const bool have = split_component(s, sm, cut, sep, p.idx, &off, &len, &cnt);
+  if (p.op == P_SPLIT_COUNT) { int64_t a = cnt, b = (int64_t)p.k; return cmp_test(a < b ? -1 : (a > b ? 1 : 0), p.cmp); }
+  if (!have) return false;
+  if (p.cmp == C_EQ || p.cmp == C_NE) { bool eq = len == p.b && str_at_c(s, off, cheap + p.a, len); return (p.cmp == C_EQ) == eq; }
+  return cmp_test(str_cmp_c(s, off, len, cheap + p.a, p.b), p.cmp);
+}
+// P_SPLIT_PREFIX: trim(s, cut) == P  or  trim(s, cut) starts with P + sep      (P = components joined by sep)
+GK_HD bool eval_split_prefix(const StrRef& s, const SplitMask& sm, const Pred& p, const uint8_t* cheap) {
+  const uint8_t cut = (uint8_t)(p.pad >> 8), sep = (uint8_t)(p.pad & 0xFF);
+  uint32_t lo = sm.lo, hi = sm.hi;
+  if (!sm.fast && cut) {
+    lo = 0; hi = s.n;
+    while (lo < hi && sbyte(s, lo) == cut) lo++;
+    while (hi > lo && sbyte(s, hi - 1) == cut) hi--;
+  }
+  const uint32_t len = hi - lo, m = p.b;
+  if (len < m) return false;
+  if (!str_at_c(s, lo, cheap + p.a, m)) return false;
+  if (len == m) return true;
+  return sm.fast ? ((sm.seps >> (lo + m)) & 1ull) != 0 : sbyte(s, lo + m) == sep;
 }
 
 GK_HD bool eval_pred(const Row& r, const Pred& p, const StrHdr& h, const uint8_t* heap, const uint8_t* cheap) {
@@ -278,30 +375,14 @@ GK_HD bool eval_pred(const Row& r, const Pred& p, const StrHdr& h, const uint8_t
       return hit;
     }
     case P_SPLIT_PREFIX: {
-      // trim(s, cut) == P  or  trim(s, cut) starts with P + sep      (P = components joined by sep)
       if (t != T_STRING) return false;
       StrRef s = make_str(r, h, heap);
-      uint8_t cut = (uint8_t)(p.pad >> 8), sep = (uint8_t)(p.pad & 0xFF);
-      uint32_t lo = 0, hi = s.n;
-      if (cut) {
-        while (lo < hi && sbyte(s, lo) == cut) lo++;
-        while (hi > lo && sbyte(s, hi - 1) == cut) hi--;
-      }
-      uint32_t len = hi - lo, m = p.b;
-      if (len < m) return false;
-      if (!str_at_c(s, lo, cheap + p.a, m)) return false;
-      return len == m || sbyte(s, lo + m) == sep;
+      return eval_split_prefix(s, split_mask(s, (uint8_t)(p.pad >> 8), (uint8_t)(p.pad & 0xFF)), p, cheap);
     }
     case P_SPLIT_CMP: case P_SPLIT_COUNT: {
       if (t != T_STRING) return false;
       StrRef s = make_str(r, h, heap);
-      uint32_t off = 0, len = 0, cnt = 0;
-      uint8_t cut = (uint8_t)(p.pad >> 8), sep = (uint8_t)(p.pad & 0xFF);
-      bool have = split_component(s, cut, sep, p.idx, &off, &len, &cnt);
-      if (p.op == P_SPLIT_COUNT) { int64_t a = cnt, b = (int64_t)p.k; return cmp_test(a < b ? -1 : (a > b ? 1 : 0), p.cmp); }
-      if (!have) return false;
-      if (p.cmp == C_EQ || p.cmp == C_NE) { bool eq = len == p.b && str_at_c(s, off, cheap + p.a, len); return (p.cmp == C_EQ) == eq; }
-      return cmp_test(str_cmp_c(s, off, len, cheap + p.a, p.b), p.cmp);
+      return eval_split_pred(s, split_mask(s, (uint8_t)(p.pad >> 8), (uint8_t)(p.pad & 0xFF)), p, cheap);
     }
     case P_REGEX: {
       // DFA table at cheap + p.a: [u32 n_states][u32 n_classes][u8 class_of_byte[256]][u8 accept[n_states]][u8 next[][]]
@@ -312,8 +393,17 @@ GK_HD bool eval_pred(const Row& r, const Pred& p, const StrHdr& h, const uint8_t
       const uint8_t* cls = d + 8;
       const uint8_t* acc = cls + 256;
       const uint8_t* nxt = acc + ns;
+      // four bytes per round: one word of the string (header words come from registers), four INDEPENDENT byte-class lookups
+      // (one wait), then the four dependent transitions -- a byte at a time every step waits for three chained loads
       uint32_t st = 0;
-      for (uint32_t i = 0; i < s.n; i++) st = nxt[st * nc + cls[sbyte(s, i)]];
+      for (uint32_t i = 0; i < s.n; i += 4) {
+        const uint32_t k = s.n - i, w = sword(s, i);
+        const uint32_t c0 = cls[w & 0xFFu], c1 = cls[(w >> 8) & 0xFFu], c2 = cls[(w >> 16) & 0xFFu], c3 = cls[w >> 24];
+        st = nxt[st * nc + c0];
+        if (k > 1) st = nxt[st * nc + c1];
+        if (k > 2) st = nxt[st * nc + c2];
+        if (k > 3) st = nxt[st * nc + c3];
+      }
       return acc[st] != 0;
     }
     case P_BITS: return t == T_INT && ((((uint64_t)r.hi << 32) | r.lo) & p.k) != 0;
