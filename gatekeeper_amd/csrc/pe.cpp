@@ -579,6 +579,72 @@ class PE {
     }
   }
 
+  // ---- formatted strings whose parts are known (sprintf over an array literal): [CONST text | PATH leaf] ...
+  // false (parts left empty: a plain opaque string) for anything but literal text, %% and %v / %s verbs matched by the arguments
+  static bool fmt_parts(const std::string& fmt, const std::vector<CondElem>& args, std::vector<CondElem>* parts) {
+    std::vector<CondElem> o;
+    std::string lit;
+    size_t next = 0;
+    auto flush = [&]() { if (!lit.empty()) { o.push_back({sv_const(Value::string(lit)), f_true()}); lit.clear(); } };
+    for (size_t i = 0; i < fmt.size(); i++) {
+      if (fmt[i] != '%') { lit += fmt[i]; continue; }
+      if (i + 1 >= fmt.size()) return false;
+      const char v = fmt[++i];
+      if (v == '%') { lit += '%'; continue; }
+      if ((v != 'v' && v != 's') || next >= args.size()) return false;
+      const CondElem& e = args[next++];
+      if (!e.cond || e.cond->kind != FNode::T) return false;
+      if (e.v->kind == SV::CONST) {
+        if (!e.v->c.is_string()) return false;   // (how a constant number prints is the concrete evaluator's business)
+        lit += *e.v->c.s;
+      } else if (e.v->kind == SV::PATH) { flush(); o.push_back({e.v, f_true()}); }
+      else return false;
+    }
+    if (next != args.size()) return false;   // (surplus arguments print as %!(EXTRA ...))
+    flush();
+    *parts = o;
+    return true;
+  }
+  // review leaves that are strings by construction: what gkReview / AdmissionRequest carry as Go strings
+  static bool string_by_construction(const SPath& p) {
+    for (auto& st : p) if (st.iter) return false;
+    if (p.size() == 1) return p[0].key == "name" || p[0].key == "namespace" || p[0].key == "operation";
+    if (p.size() == 2 && p[0].key == "kind") return p[1].key == "group" || p[1].key == "version" || p[1].key == "kind";
+    return false;
+  }
+  // could `%v` of a NON-string JSON value print this text?  (numbers, booleans, null, [..], {..}, set(): then the piece
+  // cannot be decided by a string comparison on the leaf alone)
+  static bool prints_like_non_string(const std::string& t) {
+    if (t.empty()) return false;
+    if (t == "true" || t == "false" || t == "null" || t == "<nil>" || t[0] == '[' || t[0] == '{' || t.compare(0, 4, "map[") == 0 || t.compare(0, 4, "set(") == 0) return true;
+    const char c = t[0];
+    return (c >= '0' && c <= '9') || c == '-' || c == '+' || c == '.' || t == "NaN" || t == "Inf";
+  }
+  // parts[i ..] spell exactly text[pos ..]: OR over the ways of cutting the text, AND of "leaf == piece" per cut
+  FP fmt_equals(const std::vector<CondElem>& parts, size_t i, const std::string& text, size_t pos, int* budget) {
+    if (i == parts.size()) return pos == text.size() ? f_true() : f_false();
+    const SVP& v = parts[i].v;
+    if (v->kind == SV::CONST) {
+      const std::string& lit = *v->c.s;
+      if (text.compare(pos, lit.size(), lit) != 0 || pos + lit.size() > text.size()) return f_false();
+      return fmt_equals(parts, i + 1, text, pos + lit.size(), budget);
+    }
+    FP r = f_false();
+    const bool last = i + 1 == parts.size();
+    for (size_t end = last ? text.size() : pos; end <= text.size(); end++) {
+      if (--*budget < 0) unsupported("comparison of a formatted string with a constant: too many ways to cut the constant");
+      FP rest = fmt_equals(parts, i + 1, text, end, budget);
+      if (rest->kind == FNode::F) continue;
+      const std::string piece = text.substr(pos, end - pos);
+      if (!string_by_construction(v->path) && prints_like_non_string(piece))
+        unsupported("comparison of a formatted review value with a constant that a number, boolean or container could print as");
+      Atom c = atom_path(Atom::CMP, v->path);
+      c.cmp = C_EQ; c.k = Value::string(piece);
+      r = f_or(r, f_and(f_atom(c), rest));
+    }
+    return r;
+  }
+
   // ---------------------------------------------------------------------------------------------- predicates
  public:
   FP compare_f(const SVP& a, int op, const SVP& b) {
@@ -594,7 +660,19 @@ class PE {
       unsupported("comparison between values derived from different review fields");
     }
     switch (a->kind) {
+      case SV::OPAQUE:
+        if (!a->elems.empty() && b->kind == SV::CONST && (op == C_EQ || op == C_NE)) {   // a formatted string with known parts
+          if (!b->c.is_string()) return op == C_EQ ? f_false() : a->f;   // a string never equals a non-string
+          int budget = 256;
+          FP eq = fmt_equals(a->elems, 0, *b->c.s, 0, &budget);
+          return op == C_EQ ? f_and(a->f, eq) : f_and(a->f, f_not(eq));
+        }
+        break;
       case SV::PATH:
+        if (b->kind == SV::PATH && spath_to_string(a->path) == spath_to_string(b->path) && (op == C_EQ || op == C_NE)) {   // a value and itself
+          FP d = f_atom(atom_path(Atom::DEFINED, a->path));
+          return op == C_EQ ? d : f_false();
+        }
         if (b->kind == SV::CONST) {
           const Value& k = b->c;
           if (k.is_array() || k.is_object() || k.is_set()) {
@@ -1304,8 +1382,27 @@ class PE {
       if (a[0]->kind != SV::CONST || !a[0]->c.is_string()) unsupported("sprintf with a symbolic format", line);
       SV o; o.kind = SV::OPAQUE; o.f = defined_f(a[1]);
       if (a[1]->kind == SV::PATH) o.f = f_type(a[1]->path, M_ARRAY);
+      // A format of literal text and %v / %s verbs over an array literal of constants and review leaves keeps its PARTS: such a
+      // string can still be compared with a constant (K8sUniqueLabel's make_apiversion: sprintf("%v/%v", [g, v]) == obj.apiVersion)
+      if (a[1]->kind == SV::ARR && a[1]->gens.empty()) fmt_parts(*a[0]->c.s, a[1]->elems, &o.elems);
       out.push_back({mksv(std::move(o)), s});
       return;
+    }
+    if (name == "array.concat") {   // of array values built from review data / conditional members: members of a, then of b
+      need(2);
+      std::vector<CondElem> ae, be;
+      std::vector<Gen> ag, bg;
+      const bool arr_a = a[0]->kind == SV::ARR || (a[0]->kind == SV::CONST && a[0]->c.is_array());
+      const bool arr_b = a[1]->kind == SV::ARR || (a[1]->kind == SV::CONST && a[1]->c.is_array());
+      if (arr_a && arr_b && as_setlike(a[0], &ae, &ag) && as_setlike(a[1], &be, &bg)) {
+        SV o; o.kind = SV::ARR;
+        o.elems = ae; o.elems.insert(o.elems.end(), be.begin(), be.end());
+        o.gens = ag; o.gens.insert(o.gens.end(), bg.begin(), bg.end());
+        out.push_back({fold(mksv(std::move(o))), s});
+        return;
+      }
+      if ((a[0]->kind == SV::CONST && !a[0]->c.is_array()) || (a[1]->kind == SV::CONST && !a[1]->c.is_array())) return;   // not an array: undefined
+      unsupported("array.concat with these operands on review data", line);
     }
     if (name == "count") {
       need(1);
@@ -1548,6 +1645,10 @@ FP PE::is_string_f(const SVP& v) {
   switch (v->kind) {
     case SV::CONST: return v->c.is_string() ? f_true() : f_false();
     case SV::PATH: return f_type(v->path, M_STRING);
+    case SV::KEYOF: {   // the key of an iteration: a member NAME is a string, an array index a number
+      Atom d; d.kind = Atom::KEYCMP; d.q = v->q; d.cmp = KC_ISNAME; d.k = Value::string("");
+      return f_atom(d);
+    }
     case SV::OPAQUE: return v->f;
     case SV::STRX: return v->xkind == SV::XCOUNT ? f_false() : defined_f(v);
     case SV::DERIVED: return f_dict(v->path, dx_node(DExpr::TYPE_MASK, {v->dx}, "", 0, M_STRING));

@@ -7,8 +7,10 @@ predicates.  The constraints of a referential template are compiled again whenev
 (closed: the cgo shim keeps such a template on the stock driver), never a guess.
 
 Pinned by the reference: the message of test/gator/test/test.bats:222 for policies/default + manifests/referential-data
-through the `gator test` harness; everything else product vs oracle.  K8sUniqueServiceSelector (pkg/gator/fixtures/fixtures.go:414-471,
-test_test.go:135-158) and K8sUniqueLabel compare a value COMPUTED from a whole sub-object / several review fields with the
+through the `gator test` harness; everything else product vs oracle.  K8sUniqueLabel (demo/basic, test/bats/test.bats:295-303
+"unique labels test") compares sprintf("%v/%v", [group, version]) of the review with the synced objects' apiVersion: a formatted
+string whose parts are known is compared with a constant piece by piece (pe.cpp fmt_equals).  K8sUniqueServiceSelector
+(pkg/gator/fixtures/fixtures.go:414-471, test_test.go:135-158) compares a value COMPUTED from a whole sub-object with the
 inventory's: still refused when the constraint is added."""
 import pytest
 
@@ -118,7 +120,7 @@ def test_an_inventory_beyond_the_plan_fails_closed(fixtures):
     assert check(c, oc, [objs[0], dup]) == 1                   # the inventory fits again: the constraint serves again
 
 
-@pytest.mark.parametrize("name,reason", [("TemplateReferential", "symbolic operands")])
+@pytest.mark.parametrize("name,reason", [("TemplateReferential", "sort applied to review data")])
 def test_joins_on_computed_values_are_still_refused(fixtures, name, reason):
     """K8sUniqueServiceSelector joins on flatten_selector(obj): a string computed from a whole map (fixtures.go:414-471)"""
     tmpl, con = gconst(fixtures, name)[0], gconst(fixtures, "ConstraintReferential")[0]
@@ -128,3 +130,93 @@ def test_joins_on_computed_values_are_still_refused(fixtures, name, reason):
         c.AddData(o)
     with pytest.raises(D.UnsupportedError, match=reason):
         c.AddConstraint(con)
+
+
+# ---- K8sUniqueLabel: demo/basic + the bats "unique labels test" (test/bats/test.bats:295-303: with no_dupe_cm synced, applying
+# bad/no_dupe_cm_2.yaml is denied)
+def unique_label(backend, fixtures, constraint_path):
+    tmpl = docs(fixtures, "test/bats/tests/templates/k8suniquelabel_template.yaml")[0]
+    con = docs(fixtures, constraint_path)[0]
+    c, oc = make_client(backend), OC.Client()
+    c.AddTemplate(tmpl); oc.add_template(tmpl)
+    c.AddConstraint(con); oc.add_constraint(con)
+    return c, oc
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_bats_unique_labels(backend, fixtures):
+    c, oc = unique_label(backend, fixtures, "test/bats/tests/constraints/all_cm_gatekeeper_label_unique.yaml")
+    good = docs(fixtures, "test/bats/tests/good/no_dupe_cm.yaml")[0]
+    bad = docs(fixtures, "test/bats/tests/bad/no_dupe_cm_2.yaml")[0]
+    assert check(c, oc, [good, bad]) == 0                       # nothing synced yet: no duplicate
+    c.AddData(good); oc.add_data(good)
+    got = c.ReviewBatch([D.AugmentedUnstructured(D.Unstructured(o), None, "Original") for o in (bad, good)], D.WEBHOOK_EP)
+    assert [r.msg for r in got[0]] == ["label gatekeeper has duplicate value not_duplicated"] and got[0][0].enforcement_action == "deny"
+    assert got[1] == []                                          # the synced object itself is not its own duplicate
+    assert check(c, oc, [good, bad], D.WEBHOOK_EP) == 1
+    c.RemoveData(good); oc.remove_data(good)
+    assert check(c, oc, [good, bad]) == 0
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_unique_label_over_cluster_and_namespaced_objects(backend, fixtures):
+    """identical_cluster / identical_namespace: same name in another namespace, same name and namespace under another kind or
+    group/version ("apps/v1" against make_apiversion's sprintf), label absent, label value shared by a cluster-scoped object"""
+    c, oc = unique_label(backend, fixtures, "demo/basic/constraints/all_ns_gatekeeper_label_unique.yaml")
+    con_all = {"apiVersion": "constraints.gatekeeper.sh/v1beta1", "kind": "K8sUniqueLabel", "metadata": {"name": "everything"}, "spec": {"parameters": {"label": "team"}}}
+    c.AddConstraint(con_all); oc.add_constraint(con_all)
+
+    def ns(name, labels): return {"apiVersion": "v1", "kind": "Namespace", "metadata": {"name": name, "labels": labels}}
+    def cm(name, nsn, labels, kind="ConfigMap", api="v1"): return {"apiVersion": api, "kind": kind, "metadata": {"name": name, "namespace": nsn, "labels": labels}}
+    inv = [ns("a", {"gatekeeper": "x", "team": "red"}), ns("b", {"gatekeeper": "y"}), ns("c", {}), cm("m1", "a", {"team": "blue"}), cm("m2", "b", {"other": "x"}),
+           cm("d1", "a", {"team": "green"}, "Deployment", "apps/v1"), cm("d1", "a", {"team": "teal"}, "Deployment", "extensions/v1beta1")]
+    for o in inv:
+        c.AddData(o); oc.add_data(o)
+    objs = [ns("d", {"gatekeeper": "x"}), ns("a", {"gatekeeper": "x", "team": "red"}), ns("e", {"gatekeeper": "z", "team": "blue"}), ns("f", {}),
+            cm("m1", "a", {"team": "blue"}), cm("m3", "a", {"team": "blue"}), cm("m1", "b", {"team": "blue"}), cm("zz", "b", {"team": "red"}),
+            cm("d1", "a", {"team": "green"}, "Deployment", "apps/v1"), cm("d1", "a", {"team": "green"}, "Deployment", "apps/v1beta2"), cm("d1", "a", {"team": "green"}, "StatefulSet", "apps/v1"),
+            cm("d1", "a", {"team": "teal"}, "Deployment", "extensions/v1beta1"), cm("d1", "a", {"team": "teal"}, "Deployment", "extensions/v1"),
+            cm("d1", "a", {"team": "teal"}, "Deployment", "v1beta1"), cm("q", "a", {"team": 7}), cm("q", "a", {"team": ""}), cm("q", "a", None)]
+    assert check(c, oc, objs) >= 9
+    assert check(c, oc, objs, D.AUDIT_EP) >= 9
+
+
+FMT = """package k
+violation[{"msg": msg}] {
+  want := sprintf("%v/%v:%v", [input.review.kind.group, input.review.kind.kind, input.review.name])
+  want == input.parameters.ids[_]
+  msg := sprintf("listed %v", [want])
+}
+violation[{"msg": msg}] {
+  sprintf("%s-%s", [input.review.namespace, input.review.name]) != input.parameters.not_this
+  input.review.kind.kind == "Secret"
+  msg := "another secret"
+}
+violation[{"msg": msg}] {
+  sprintf("%v%v", [input.review.name, input.review.namespace]) == "abab"
+  msg := "two adjacent verbs"
+}
+"""
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_formatted_review_strings_against_constants(backend):
+    """sprintf over review leaves that are strings by construction (review.kind.*, name, namespace) compared with constants: every way
+    of cutting the constant (separators inside the pieces, adjacent verbs, empty pieces), != and undefined operands"""
+    tmpl = {"apiVersion": "templates.gatekeeper.sh/v1", "kind": "ConstraintTemplate", "metadata": {"name": "k8sfmt"},
+            "spec": {"crd": {"spec": {"names": {"kind": "K8sFmt"}}}, "targets": [{"target": "admission.k8s.gatekeeper.sh", "rego": FMT}]}}
+    con = {"apiVersion": "constraints.gatekeeper.sh/v1beta1", "kind": "K8sFmt", "metadata": {"name": "x"},
+           "spec": {"parameters": {"ids": ["apps/Deployment:web", "/Pod:a/b:c", "/Pod:", "x/y/Z:n", 5, "/ConfigMap:7"], "not_this": "ns1-s1"}}}
+    c, oc = make_client(backend), OC.Client()
+    c.AddTemplate(tmpl); oc.add_template(tmpl)
+    c.AddConstraint(con); oc.add_constraint(con)
+
+    def o(api, kind, name, ns=None):
+        md = {"name": name}
+        if ns is not None:
+            md["namespace"] = ns
+        return {"apiVersion": api, "kind": kind, "metadata": md}
+    objs = [o("apps/v1", "Deployment", "web", "d"), o("apps/v1", "Deployment", "web2", "d"), o("v1", "Pod", "a/b:c", "d"), o("v1", "Pod", "", "d"), o("x/y/v1", "Z", "n", "d"),
+            o("v1", "ConfigMap", "7", "d"), o("v1", "Secret", "s1", "ns1"), o("v1", "Secret", "s2", "ns1"), o("v1", "Secret", "s1-x", "ns1"), o("v1", "Secret", "clusterwide"),
+            o("v1", "Pod", "ab", "ab"), o("v1", "Pod", "a", "bab"), o("v1", "Pod", "aba", "b"), o("v1", "Pod", "abab", ""), o("v1", "Pod", "ba", "ba")]
+    assert check(c, oc, objs) >= 8

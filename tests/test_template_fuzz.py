@@ -124,6 +124,11 @@ def cond3(rng, var=None):
     if k == 6: return 'input.review.userInfo.username == "%s"' % rng.choice(["bob", "alice"])
     if k == 7: return 'input.review.userInfo.groups[_] == "%s"' % rng.choice(["dev", "ops"])
     if k == 8: return "%s == %s" % (scalar_path(rng), scalar_path(rng))
+    if k == 9 and rng.random() < 0.6:   # a formatted string of review values against a constant (K8sUniqueLabel's make_apiversion): any leaf types
+        x, y = rng.choice([a, "input.review.name", "input.review.kind.kind"]), rng.choice([b, a, "input.review.namespace", "input.review.kind.group"])
+        fmt, want = rng.choice([("%v/%v", ["x/yy", "x/x", "/x", "yy/", "x/a-/yy", "1/x", "a-long-string-constant/x", "Pod/", "obj/default"]),
+                                ("%s%v", ["xyy", "xx", "x", "", "Podx"]), ("p-%v-%v", ["p-x-yy", "p--x", "p-x-y-yy", "p-true-x"])])
+        return 'sprintf("%s", [%s, %s]) %s "%s"' % (fmt, x, y, rng.choice(["==", "==", "!="]), rng.choice(want))
     return "%s" % b
 
 EVERY = False
