@@ -371,7 +371,7 @@ def main():
                        "rows_rank0": int(res.n_rows), "rows_read_rank0": int(res.n_rows_read), "table_bytes_rank0": int(st["device_bytes"]),
                        "timed_region_s": dt,
                        "parallelism": ("objects block-sharded across %d GPUs; per sweep ONE in-place ncclAllGather of [violation bitmaps | counts | fail-closed counts] "
-                                       "issued by the engine on the kernel's stream (global totals = sums over the gathered slot tails); five enqueues "
+                                       "issued by the engine on the kernel's stream (global totals = sums over the gathered slot tails); four enqueues "
                                        "per pass, no host round trip" % world) if dist is not None else "1 GPU",
                        "global_violating_pairs": int(sharded.totals.sum()) if sharded is not None else int(counts.sum()),
                        "violating_pairs_rank0": int(counts.sum()), "reviews_beyond_limits_rank0": len(final.too_big_reviews())},

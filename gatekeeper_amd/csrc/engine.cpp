@@ -1839,7 +1839,7 @@ int gk_table_sweep_sharded(gk_engine* e, gk_table* t, uint32_t flags, gk_shard_o
     }
     const uint64_t rejected = t->n_rejected;
     if (enqueue) {   // sweep + exchange of every plan group onto the stream(s); whoever collects waits for them
-      // (five enqueues per plan group; GK_SHARD_GRAPH=1: a single plan group's step replays as one captured graph)
+      // (four enqueues per plan group; GK_SHARD_GRAPH=1: a single plan group's step replays as one captured graph)
       dev_shard_enqueue(dp, t->dev, e->comm, opt, nc0, rejected, e->extra.empty());
       for (size_t gi = 0; gi < e->extra.size(); gi++)
         dev_shard_enqueue(e->extra[gi]->dev, t->views[gi], e->comm, opt, (uint32_t)e->extra[gi]->ids.size(), rejected, false);

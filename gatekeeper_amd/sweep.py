@@ -5,7 +5,7 @@ process per GPU) keeps its shard of the flattened object set resident in HBM and
 exchange step is issued by the ENGINE on the kernel's stream through its own RCCL communicator (gk_table_sweep_sharded):
 ONE in-place ncclAllGather of every shard's [violation bitmap | counts | fail-closed counts] slot -- the int64 totals are
 the sums over the gathered slot tails --, so that every rank ends with the full constraints x objects answer.  Objects never
-move.  Back-to-back sweeps of a shard are enqueue-only: five enqueues per pass, no host round trip.
+move.  Back-to-back sweeps of a shard are enqueue-only: four enqueues per pass, no host round trip.
 
 torch.distributed is plumbing only: it carries the RCCL unique id from rank 0 to the other ranks (and, in the CPU tests,
 stands in for the collectives through the test-only emulation library), and gathers the few top-k candidate records of

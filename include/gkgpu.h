@@ -262,7 +262,7 @@ typedef struct {
 /* GK_SHARD_COLLECT (without GK_SHARD_ENQUEUE): wait for the enqueue-only passes and return the answer of the LAST of them
  * instead of sweeping once more.  Falls back to an ordinary collecting sweep when nothing was enqueued, when the constraint
  * set needs several plan groups, or when that pass left reviews -- on any rank -- to the large-capacity re-run.  An enqueue-only
- * pass is five enqueues (sweep, two slot-tail kernels, all-gather, totals); GK_SHARD_GRAPH=1 replays a single-plan-group pass as one
+ * pass is four enqueues (sweep, slot-tail kernel, all-gather, totals); GK_SHARD_GRAPH=1 replays a single-plan-group pass as one
  * captured graph instead. */
 #define GK_SHARD_COLLECT 4u
 int gk_table_sweep_sharded(gk_engine* e, gk_table* t, uint32_t flags, gk_shard_out** out);

@@ -1,7 +1,7 @@
 """Multi-GPU path on CPU: world_size 2, gloo standing in for RCCL.  Each rank flattens and
 evaluates its shard of the audit set through the engine's sharded-sweep entry point (gk_table_sweep_sharded: local
-evaluation, then the in-place all-gather of [bitmap | counts] slots and the all-reduce of int64 totals -- the CPU emulation
-library takes the two collectives as callbacks, the slot layout and the sequence are the product's).  Shards are UNEVEN
+evaluation, then the ONE in-place all-gather of [bitmap | counts | tail] slots, the int64 totals being the sums over the gathered
+tails -- the CPU emulation library takes the collective as a callback, the slot layout and the sequence are the product's).  Shards are UNEVEN
 and not multiples of 64.  Every rank must end with the bitmaps, totals and merged top-k audit lists a single process gets."""
 import os
 import pickle
@@ -79,7 +79,7 @@ def test_sharded_sweep_matches_single_process(tmp_path, policies):
         bits = np.concatenate([np.stack([np.unpackbits(bm[r].view(np.uint8), bitorder="little")[:SHARDS[k]] for r in range(ref.n_constraints)])
                                for k, bm in enumerate(got["bitmaps"])], axis=1)
         assert (bits == ref_bits).all(), "rank %d sees a different global bitmap" % rank
-        assert (got["totals"] == ref.counts.astype(np.int64)).all()                 # all-reduced int64 totals
+        assert (got["totals"] == ref.counts.astype(np.int64)).all()                 # int64 totals over all shards (sums of the gathered slot tails)
         assert (got["counts"].sum(0) == ref.counts).all()                          # = sum of the gathered per-shard counts
         assert got["lists"] == ref_lists                                           # merged top-k == single-process LimitQueue
     assert ref.counts.sum() > 0 and sum(len(v) for v in ref_lists.values()) > 20
