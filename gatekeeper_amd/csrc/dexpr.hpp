@@ -9,7 +9,11 @@
 // the answers as a bit mask in a synthetic integer row next to the leaf (path + "$d").  On the device the predicate is a
 // bit test (P_BITS).  Exact by construction: the bits are computed by the same evaluator that renders the messages.
 #pragma once
+#include <functional>
+#include <map>
 #include <memory>
+#include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <vector>
 
@@ -30,6 +34,24 @@ struct DExpr {
   uint32_t mask = 0;        // TYPE_MASK: bit per RowType of the leaf-derived value
   std::vector<DX> args;
 };
+
+// DEEP expressions (round 3): a template's own helper function applied to ONE sub-document of the review -- closed (it reads
+// nothing but its arguments) but beyond what a formula over rows expresses (K8sUniqueServiceSelector's flatten_selector:
+// concat(",", sort([concat(":", [k, v]) | v = obj.spec.selector[k]]))).  The partial evaluator records the call as
+// CALL "$u:<id>" over the leaf; the flattener hands such an expression the leaf's REAL value (containers included: parsed
+// from the text span) and the registered closure runs the concrete evaluator on it -- the evaluator that renders the messages.
+// CALL "$wrap" rebuilds the argument from the narrowest sub-document the function looks at: $wrap(leaf, ["spec", "selector"])
+// = {"spec": {"selector": leaf}}.
+typedef std::function<Value(const ValueVec&)> DxUserFn;
+struct DxUserFns { std::shared_mutex mu; std::map<std::string, DxUserFn> fns; };
+inline DxUserFns& dx_user_fns() { static DxUserFns r; return r; }
+inline bool dx_is_user(const std::string& name) { return name.compare(0, 3, "$u:") == 0; }
+inline void dx_register_user(const std::string& name, DxUserFn fn) { DxUserFns& r = dx_user_fns(); std::unique_lock<std::shared_mutex> l(r.mu); r.fns[name] = std::move(fn); }
+inline Value dx_call_user(const std::string& name, const ValueVec& args) {
+  DxUserFn fn;
+  { DxUserFns& r = dx_user_fns(); std::shared_lock<std::shared_mutex> l(r.mu); auto it = r.fns.find(name); if (it == r.fns.end()) return Value(); fn = it->second; }
+  return fn(args);
+}
 
 inline DX dx_leaf() { static thread_local DX l = std::make_shared<const DExpr>(); return l; }
 inline DX dx_const(const Value& v) { DExpr e; e.kind = DExpr::CONST; e.c = v; return std::make_shared<const DExpr>(e); }
@@ -71,6 +93,13 @@ inline Value dx_eval(const DX& e, const Value& leaf) {
     case DExpr::CALL: {
       ValueVec av;
       for (auto& a : e->args) { Value v = dx_eval(a, leaf); if (!v.defined()) return Value(); av.push_back(v); }
+      if (dx_is_user(e->name)) return dx_call_user(e->name, av);
+      if (e->name == "$wrap") {   // the leaf under a constant key path: {"k0": {"k1": leaf}}
+        if (av.size() != 2 || !av[1].is_array()) return Value();
+        Value v = av[0];
+        for (size_t i = av[1].size(); i-- > 0;) { ValuePairs p; p.emplace_back(av[1].items()[i], v); v = Value::object(std::move(p)); }
+        return v;
+      }
       if (e->name == "$index") {   // element of an array (a split component); negative index: from the end; out of range: undefined
         if (av.size() != 2 || !av[0].is_array() || !av[1].is_number() || !av[1].is_int) return Value();
         const long long n = (long long)av[0].size();
@@ -107,6 +136,12 @@ inline Value dx_eval(const DX& e, const Value& leaf) {
     case DExpr::OR: { for (auto& a : e->args) { Value v = dx_eval(a, leaf); if (v.is_bool() && v.b) return Value::boolean(true); } return Value::boolean(false); }
   }
   return Value();
+}
+// does the expression look INSIDE a container leaf (a deep expression)?  Then the flattener must hand it the real value.
+inline bool dx_deep(const DX& e) {
+  if (e->kind == DExpr::CALL && dx_is_user(e->name)) return true;
+  for (auto& a : e->args) if (dx_deep(a)) return true;
+  return false;
 }
 inline bool dx_true(const DX& e, const Value& leaf) { Value v = dx_eval(e, leaf); return v.is_bool() && v.b; }
 

@@ -482,6 +482,8 @@ void ensure_plan(gk_engine* e) {
       try { builds(g, &f, &b); }
       catch (const Unsupported& u) {
         if (getenv("GK_PLAN_TIMING")) fprintf(stderr, "[plan] %zu constraints: does not fit one plan (%s) after %.2f s\n", g.size(), u.what(), std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+        if (g.size() == 1 && g[0]->referential)   // (its formula follows the synced objects: say so -- the same words refresh_referential uses)
+          throw Unsupported(std::string("referential constraint ") + g[0]->kind + "/" + g[0]->name + " does not compile against the synced inventory: " + u.what());
         if (g.size() <= 1) throw;
         size_t half = g.size() > 64 ? 64 : g.size() / 2;
         for (size_t i = 0; i < g.size(); i += half)
@@ -506,9 +508,17 @@ void ensure_plan(gk_engine* e) {
       e->extra.push_back(std::move(g));
     }
   } else {
-    e->fast.resolve_paths(e->dict);
-    e->big.resolve_paths(e->dict);
-    for (auto& g : e->extra) { g->fast.resolve_paths(e->dict); g->big.resolve_paths(e->dict); }
+    try {
+      e->fast.resolve_paths(e->dict);
+      e->big.resolve_paths(e->dict);
+      for (auto& g : e->extra) { g->fast.resolve_paths(e->dict); g->big.resolve_paths(e->dict); }
+    } catch (const Unsupported& u) {
+      // the plan was built before the table's key paths were known and does not fit them: with a referential constraint loaded
+      // that is its unrolled inventory (one predicate per synced value on the joined path) -- say so
+      for (auto& c : e->constraints) if (c.alive && c.referential)
+        throw Unsupported(std::string("referential constraint ") + c.kind + "/" + c.name + " does not compile against the synced inventory: " + u.what());
+      throw;
+    }
   }
   for (auto& g : e->extra) {
     if (g->dev) { dev_plan_free(g->dev); g->dev = nullptr; }
@@ -967,6 +977,10 @@ int gk_excluder_excluded(gk_engine* e, const char* process, const gk_review_in* 
 int gk_table_create(gk_engine* e, const gk_review_in* reviews, size_t n, uint32_t flags, int32_t* statuses, gk_table** out) {
   if (!e || !out || (n && !reviews)) return fail(GK_ERR_INVALID, "NULL argument");
   try {
+    // referential constraints follow the synced inventory: compiled again -- and their dictionary expressions registered -- BEFORE
+    // the rows are made, or the table would lack the <leaf>.$d rows the new plan reads (a plan that does not build is the
+    // evaluation's error to report, not this call's)
+    try { ensure_plan(e); } catch (const std::exception&) {}
     std::unique_ptr<gk_table> t(new gk_table());
     t->eng = e;
     bool keep = flags & GK_TABLE_KEEP_DOCS;

@@ -426,6 +426,8 @@ bool Flattener::dict_wanted(uint32_t path) {
   if (d.state == 0) {
     reg_->match(*dict_, path, &d.entries, &d.pat);
     d.state = d.entries.empty() ? 1 : 2;
+    d.deep = false;
+    for (const DictEntry& e : d.entries) if (dx_deep(e.dx)) d.deep = true;
     if (d.state == 2) d.dpath = child(path, "$d");
   }
   return dict_paths_[path].state == 2;
@@ -441,8 +443,9 @@ bool Flattener::guard_wanted(uint32_t path) {
 
 void Flattener::dict_row(uint32_t path, uint32_t meta, const Value& leaf) {
   DictPath& d = dict_paths_[path];
-  // containers count by type and size only (the registered expressions cannot look inside them: pe.cpp scalar_fns)
-  std::string key = (leaf.is_array() || leaf.is_object() || leaf.is_set()) ? std::to_string(leaf.size()) : to_term_string(leaf);
+  // containers count by type and size only (the registered expressions cannot look inside them: pe.cpp scalar_fns) -- unless
+  // an expression of this path is DEEP (dexpr.hpp): then the leaf is the real sub-document and the memo goes by its text
+  std::string key = ((leaf.is_array() || leaf.is_object() || leaf.is_set()) && !d.deep) ? std::to_string(leaf.size()) : to_term_string(leaf);
   key.push_back((char)('0' + (int)leaf.kind));
   auto it = d.memo.find(key);
   uint64_t mask;
@@ -883,6 +886,7 @@ int Flattener::fast_value(uint32_t path, uint32_t ords, int adepth, uint32_t ext
   const uint32_t meta = ords | extra;
   const char c = *p_;
   if (c == '{') {
+    const char* const span0 = p_;   // (a deep dictionary expression wants the container's text: dexpr.hpp)
     p_++;
     const size_t row = stage_.size();
     emit(path, meta | T_OBJECT, 0, 0);
@@ -936,10 +940,12 @@ int Flattener::fast_value(uint32_t path, uint32_t ords, int adepth, uint32_t ext
     stage_[row].row.lo = count;
     if (count) stage_[row].row.rev &= ROW_REV_MASK;   // a NON-EMPTY container has no value id (emit saw it empty)
     if (count && guard_wanted(path)) review_flags_ |= RF_REFUSE;
-    if (dict_wanted(path)) { ValuePairs ph; for (uint32_t k = 0; k < count; k++) ph.emplace_back(Value::integer((i128)k), Value::null()); dict_row(path, meta, Value::object(std::move(ph))); }
+    if (dict_deep(path)) dict_row(path, meta, parse_json(span0, (size_t)(p_ - span0)));
+    else if (dict_wanted(path)) { ValuePairs ph; for (uint32_t k = 0; k < count; k++) ph.emplace_back(Value::integer((i128)k), Value::null()); dict_row(path, meta, Value::object(std::move(ph))); }
     return T_OBJECT;
   }
   if (c == '[') {
+    const char* const span0 = p_;
     p_++;
     const size_t row = stage_.size();
     emit(path, meta | T_ARRAY, 0, 0);
@@ -965,7 +971,8 @@ int Flattener::fast_value(uint32_t path, uint32_t ords, int adepth, uint32_t ext
     }
     stage_[row].row.lo = count;
     if (count) stage_[row].row.rev &= ROW_REV_MASK;   // a NON-EMPTY container has no value id (emit saw it empty)
-    if (dict_wanted(path)) dict_row(path, meta, Value::array(ValueVec(count, Value::null())));
+    if (dict_deep(path)) dict_row(path, meta, parse_json(span0, (size_t)(p_ - span0)));
+    else if (dict_wanted(path)) dict_row(path, meta, Value::array(ValueVec(count, Value::null())));
     return T_ARRAY;
   }
   if (c == '"') {

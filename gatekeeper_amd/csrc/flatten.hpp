@@ -281,10 +281,11 @@ class Flattener {
   PathDict* dict_;
   const DictRegistry* reg_ = nullptr;
   uint64_t reg_gen_ = ~0ull;
-  struct DictPath { int state = 0; int gstate = 0; int vstate = 0; int pat = -1; std::vector<DictEntry> entries; uint32_t dpath = 0; std::unordered_map<std::string, uint64_t> memo; };   // state 0 unknown, 1 none, 2 has entries
+  struct DictPath { int state = 0; int gstate = 0; int vstate = 0; int pat = -1; bool deep = false /* some expression looks inside a container leaf */; std::vector<DictEntry> entries; uint32_t dpath = 0; std::unordered_map<std::string, uint64_t> memo; };   // state 0 unknown, 1 none, 2 has entries
   std::vector<DictPath> dict_paths_;
   void dict_row(uint32_t path, uint32_t meta, const Value& leaf);   // emits <leaf>.$d when some registered expression is true
   bool dict_wanted(uint32_t path);
+  bool dict_deep(uint32_t path) { return dict_wanted(path) && dict_paths_[path].deep; }
   bool guard_wanted(uint32_t path);   // is `path` a container under which element predicates iterate? (cached per path)
   bool value_wanted(uint32_t path);   // are the rows of `path` compared with other review values? (cached per path)
   // per-review interning of compared values -> value ids (plan.hpp ROW_VID_*)

@@ -212,7 +212,8 @@ Atom atom_path(Atom::Kind k, const SPath& p) { Atom a; a.kind = k; a.path = p; r
 // ---- leaf-local values (dexpr.hpp): a review leaf, its count(), or anything already derived from one leaf
 bool leaf_local(const SVP& v, SPath* leaf, DX* dx) {
   if (v->kind == SV::PATH && !v->path.empty()) { *leaf = v->path; *dx = dx_leaf(); return true; }
-  if (v->kind == SV::DERIVED) { *leaf = v->path; *dx = v->dx; return true; }
+  if (v->kind == SV::DERIVED) { if (v->idx == 1) return false;   // (a deep call narrowed to a sub-document: what it yields when the sub-document is ABSENT lives in v->c -- only comparisons / definedness / truth know about it)
+                                *leaf = v->path; *dx = v->dx; return true; }
   if (v->kind == SV::COUNTOF) { *leaf = v->path; *dx = dx_node(DExpr::CALL, {dx_leaf()}, "count"); return true; }
   if (v->kind == SV::STRX && !v->path.empty()) {
     // trim(leaf, c) / split(.., sep) / a component / the component count: functions of the one string leaf
@@ -654,6 +655,11 @@ class PE {
     }
     if (a->kind == SV::CONST) return compare_f(b, flip_cmp(op), a);
     if (b->kind == SV::CONST && !b->c.defined()) return f_false();
+    if (a->kind == SV::DERIVED && a->idx == 1 && b->kind == SV::CONST) {   // a deep call on a narrowed sub-document: present | absent
+      FP present = f_dict(a->path, dx_node(DExpr::CMP, {a->dx, dx_const(b->c)}, "", op));
+      FP absent = a->c.defined() && cmp_holds(compare(a->c, b->c), op) ? f_and(a->f, f_not(f_atom(atom_path(Atom::DEFINED, a->path)))) : f_false();
+      return f_or(present, absent);
+    }
     if (a->kind == SV::DERIVED || b->kind == SV::DERIVED) {   // a computation on one leaf against a constant / the same leaf
       SPath leaf; std::vector<DX> dx;
       if (same_leaf_args({a, b}, &leaf, &dx)) return f_dict(leaf, dx_node(DExpr::CMP, {dx[0], dx[1]}, "", op));
@@ -1345,7 +1351,16 @@ class PE {
       throw RegoError("rego_type_error: undefined function " + name);
     }
     eval_seq(t->args, 0, {}, s, r, [&](const std::vector<SVP>& args, const State& s2) {
-      if (user) { call_function(fpkg, fname, args, s2, r, out); return; }
+      if (user) {
+        if (concrete_) { call_function(fpkg, fname, args, s2, r, out); return; }
+        const size_t mark = out.size();
+        try { call_function(fpkg, fname, args, s2, r, out); return; }
+        catch (const Unsupported&) {
+          out.resize(mark);
+          if (!deep_call(fpkg, fname, args, s2, out)) throw;   // (a closed helper over ONE sub-document goes to the flattener: dexpr.hpp)
+          return;
+        }
+      }
       bool all_const = true;
       for (auto& a : args) if (a->kind != SV::CONST) all_const = false;
       if (all_const) {
@@ -1372,6 +1387,142 @@ class PE {
   }
 
   FP all_defined(const SVP& v) { return defined_f(v); }
+
+  // ---------------------------------------------------------------------------------------------- deep calls (dexpr.hpp)
+  // Is the function CLOSED: do its bodies (and everything they call or refer to in the package) read nothing but their
+  // arguments?  No `input`, no `data`, no rule that does.
+  bool closed_term(const TermP& t, const std::string& pkg, std::set<std::string>& visiting) {
+    if (!t) return true;
+    if (t->kind == Term::Var) {
+      if (t->name == "input" || t->name == "data") return false;
+      if (find_rules(pkg, t->name)) return closed_rules(pkg, t->name, visiting);
+      return true;
+    }
+    if (t->kind == Term::Call) {
+      std::string name;
+      for (size_t i = 0; i < t->path.size(); i++) { if (i) name += "."; name += t->path[i]; }
+      if (t->path.size() == 1 && find_rules(pkg, t->path[0])) { if (!closed_rules(pkg, t->path[0], visiting)) return false; }
+      else if (!has_builtin(name)) return false;   // (a function of another package, an unknown builtin: not our business here)
+    }
+    if (!closed_term(t->head, pkg, visiting) || !closed_term(t->head2, pkg, visiting)) return false;
+    for (auto& a : t->args) if (!closed_term(a, pkg, visiting)) return false;
+    if (t->body) for (const Literal& l : *t->body) if (!closed_literal(l, pkg, visiting)) return false;
+    return true;
+  }
+  bool closed_literal(const Literal& l, const std::string& pkg, std::set<std::string>& visiting) {
+    if (!closed_term(l.a, pkg, visiting) || !closed_term(l.b, pkg, visiting) || !closed_term(l.c, pkg, visiting)) return false;
+    if (l.inner && !closed_literal(*l.inner, pkg, visiting)) return false;
+    if (l.body) for (const Literal& x : *l.body) if (!closed_literal(x, pkg, visiting)) return false;
+    return true;
+  }
+  bool closed_rules(const std::string& pkg, const std::string& name, std::set<std::string>& visiting) {
+    if (!visiting.insert(name).second) return true;   // (already being checked further up: recursion decides nothing new)
+    const auto* rules = find_rules(pkg, name);
+    if (!rules) return false;
+    for (const Rule* r : *rules) {
+      for (auto& a : r->args) if (!closed_term(a, pkg, visiting)) return false;
+      if (!closed_term(r->key, pkg, visiting) || !closed_term(r->value, pkg, visiting)) return false;
+      for (const Literal& l : r->body) if (!closed_literal(l, pkg, visiting)) return false;
+      for (auto& e : r->elses) { if (!closed_term(e.first, pkg, visiting)) return false; for (const Literal& l : e.second) if (!closed_literal(l, pkg, visiting)) return false; }
+    }
+    return true;
+  }
+  // The constant key prefix under which EVERY use of variable `var` in the function reads (obj.spec.selector[key] -> ["spec",
+  // "selector"]); `whole` when the variable is also used as such (passed on, compared, iterated directly).
+  static void narrow_term(const TermP& t, const std::string& var, std::vector<std::string>* prefix, bool* have, bool* whole) {
+    if (!t || *whole) return;
+    if (t->kind == Term::Var) { if (t->name == var) *whole = true; return; }
+    if (t->kind == Term::Ref && t->head && t->head->kind == Term::Var && t->head->name == var) {
+      std::vector<std::string> keys;
+      for (auto& op : t->args) { if (op->kind == Term::Scalar && op->value.is_string()) keys.push_back(op->value.str()); else break; }
+      if (!*have) { *prefix = keys; *have = true; }
+      else { size_t n = 0; while (n < prefix->size() && n < keys.size() && (*prefix)[n] == keys[n]) n++; prefix->resize(n); }
+      for (auto& op : t->args) narrow_term(op, var, prefix, have, whole);
+      return;
+    }
+    narrow_term(t->head, var, prefix, have, whole);
+    narrow_term(t->head2, var, prefix, have, whole);
+    for (auto& a : t->args) narrow_term(a, var, prefix, have, whole);
+    if (t->body) for (const Literal& l : *t->body) narrow_literal(l, var, prefix, have, whole);
+  }
+  static void narrow_literal(const Literal& l, const std::string& var, std::vector<std::string>* prefix, bool* have, bool* whole) {
+    narrow_term(l.a, var, prefix, have, whole); narrow_term(l.b, var, prefix, have, whole); narrow_term(l.c, var, prefix, have, whole);
+    if (l.inner) narrow_literal(*l.inner, var, prefix, have, whole);
+    if (l.body) for (const Literal& x : *l.body) narrow_literal(x, var, prefix, have, whole);
+    for (auto& n : l.names) if (n == var) *whole = true;   // (`some obj`: the name is rebound -- give up narrowing)
+  }
+  // f(.., <one review sub-document>, ..) of a closed helper that the formula language cannot express: a value DERIVED from that
+  // sub-document by the flattener (the concrete evaluator runs the helper on the real value, once per distinct value).
+  bool deep_call(const std::string& pkg, const std::string& name, const std::vector<SVP>& args, const State& s, Vals& out) {
+    int sym = -1;
+    for (size_t i = 0; i < args.size(); i++) {
+      if (args[i]->kind == SV::CONST) { if (!args[i]->c.defined()) return false; continue; }
+      if (args[i]->kind != SV::PATH || args[i]->path.empty() || sym >= 0) return false;
+      sym = (int)i;
+    }
+    if (sym < 0) return false;
+    std::set<std::string> visiting;
+    if (!closed_rules(pkg, name, visiting)) return false;
+    std::shared_ptr<const Template> keep;
+    try { keep = T.shared_from_this(); } catch (const std::bad_weak_ptr&) { return false; }   // (a template on somebody's stack: no closure may outlive it)
+    // how far down the argument does the helper look?  Every body must name the argument by a variable
+    std::vector<std::string> prefix;
+    bool have = false, whole = false;
+    const auto* rules = find_rules(pkg, name);
+    for (const Rule* r : *rules) {
+      if (r->kind != Rule::Function || r->args.size() != args.size()) continue;
+      const TermP& a = r->args[(size_t)sym];
+      if (a->kind != Term::Var) { whole = true; break; }
+      narrow_term(r->value, a->name, &prefix, &have, &whole);
+      for (const Literal& l : r->body) narrow_literal(l, a->name, &prefix, &have, &whole);
+      for (auto& e : r->elses) { narrow_term(e.first, a->name, &prefix, &have, &whole); for (const Literal& l : e.second) narrow_literal(l, a->name, &prefix, &have, &whole); }
+    }
+    if (whole || !have) prefix.clear();
+    char idbuf[40];
+    snprintf(idbuf, sizeof idbuf, "%llx", (unsigned long long)(uintptr_t)keep.get());
+    const std::string fn_name = std::string("$u:") + idbuf + ":" + pkg + "." + name + "/" + std::to_string(args.size());
+    const std::string fpkg = pkg, fname = name;
+    dx_register_user(fn_name, [keep, fpkg, fname](const ValueVec& av) -> Value {
+      try {
+        int nq = 0;
+        PE pe(*keep, Value::object({}), sv_const(Value::object({})), Value(), true, &nq);
+        pe.index_rules();
+        std::vector<SVP> cargs;
+        for (const Value& v : av) cargs.push_back(sv_const(v));
+        Vals res;
+        pe.call_function(fpkg, fname, cargs, State(), nullptr, res);
+        Value got;
+        for (const Val& x : res) {
+          if (x.v->kind != SV::CONST || !x.v->c.defined()) continue;
+          if (got.defined() && !(got == x.v->c)) return Value();   // (conflicting outputs: an evaluation error in OPA -- no value here)
+          got = x.v->c;
+        }
+        return got;
+      } catch (const std::exception&) { return Value(); }
+    });
+    std::vector<DX> dxs;
+    ValueVec absent_args;
+    for (size_t i = 0; i < args.size(); i++) {
+      if ((int)i != sym) { dxs.push_back(dx_const(args[i]->c)); absent_args.push_back(args[i]->c); continue; }
+      if (prefix.empty()) { dxs.push_back(dx_leaf()); absent_args.push_back(Value()); continue; }
+      ValueVec keys;
+      for (auto& k : prefix) keys.push_back(Value::string(k));
+      dxs.push_back(dx_node(DExpr::CALL, {dx_leaf(), dx_const(Value::array(keys))}, "$wrap"));
+      absent_args.push_back(Value::object({}));   // the helper reads nothing else of its argument: without the sub-document it sees an empty object
+    }
+    SV d;
+    d.kind = SV::DERIVED;
+    d.path = args[(size_t)sym]->path;
+    for (auto& k : prefix) { Step st; st.key = k; d.path.push_back(st); }
+    d.dx = dx_node(DExpr::CALL, dxs, fn_name);
+    if (!prefix.empty()) {
+      d.idx = 1;
+      d.c = dx_call_user(fn_name, absent_args);
+      d.f = defined_f(args[(size_t)sym]);
+    }
+    out.push_back({mksv(std::move(d)), s});
+    return true;
+  }
 
   void symbolic_builtin(const std::string& name, const std::vector<SVP>& a, const State& s, int line, Vals& out) {
     auto need = [&](size_t n) { if (a.size() != n) throw RegoError("rego_type_error: " + name + ": arity mismatch"); };
@@ -1422,7 +1573,7 @@ class PE {
         out.push_back({mksv(std::move(c)), s});
         return;
       }
-      if (x->kind == SV::DERIVED) { out.push_back({sv_derived(x->path, dx_node(DExpr::CALL, {x->dx}, "count")), s}); return; }
+      if (x->kind == SV::DERIVED && x->idx != 1) { out.push_back({sv_derived(x->path, dx_node(DExpr::CALL, {x->dx}, "count")), s}); return; }
       unsupported("count() of this symbolic value", line);
     }
     if (name == "startswith" || name == "endswith" || name == "contains") {
@@ -1477,7 +1628,7 @@ class PE {
       uint32_t m = name == "is_string" ? M_STRING : name == "is_number" ? M_NUMBER : name == "is_boolean" ? M_BOOL : name == "is_array" ? M_ARRAY : name == "is_object" ? M_OBJECT : name == "is_null" ? M_NULL : 0;
       if (a[0]->kind == SV::PATH) { push_bool(f_type(a[0]->path, m), f_atom(atom_path(Atom::DEFINED, a[0]->path))); return; }
       if (a[0]->kind == SV::OPAQUE || a[0]->kind == SV::STRX) { push_bool(name == "is_string" ? f_true() : f_false(), defined_f(a[0])); return; }
-      if (a[0]->kind == SV::DERIVED) { push_bool(f_dict(a[0]->path, dx_node(DExpr::TYPE_MASK, {a[0]->dx}, "", 0, m)), defined_f(a[0])); return; }
+      if (a[0]->kind == SV::DERIVED && a[0]->idx != 1) { push_bool(f_dict(a[0]->path, dx_node(DExpr::TYPE_MASK, {a[0]->dx}, "", 0, m)), defined_f(a[0])); return; }
       if (a[0]->kind == SV::SET) { push_bool(name == "is_set" ? f_true() : f_false(), f_true()); return; }
       if (a[0]->kind == SV::ARR) { push_bool(name == "is_array" ? f_true() : f_false(), f_true()); return; }
       unsupported(name + " of this symbolic value", line);
@@ -1616,7 +1767,11 @@ FP PE::defined_f(const SVP& v) {
     case SV::OPAQUE: return v->f;
     case SV::BOOLF: return v->d;
     case SV::COUNTOF: return f_type(v->path, M_ARRAY | M_OBJECT | M_STRING);
-    case SV::DERIVED: return f_dict(v->path, dx_node(DExpr::DEFINED, {v->dx}));
+    case SV::DERIVED: {
+      FP present = f_dict(v->path, dx_node(DExpr::DEFINED, {v->dx}));
+      if (v->idx == 1 && v->c.defined()) return f_or(present, f_and(v->f, f_not(f_atom(atom_path(Atom::DEFINED, v->path)))));
+      return present;
+    }
     case SV::STRX: {
       if (v->xkind == SV::XCOMP) {
         Atom c = atom_path(Atom::SPLIT_COUNT, v->path);
@@ -1636,7 +1791,11 @@ FP PE::truthy_f(const SVP& v) {
     case SV::CONST: return (v->c.defined() && !(v->c.is_bool() && !v->c.b)) ? f_true() : f_false();
     case SV::PATH: return v->path.empty() ? f_true() : f_atom(atom_path(Atom::TRUTHY, v->path));
     case SV::BOOLF: return f_and(v->d, v->f);
-    case SV::DERIVED: return f_dict(v->path, dx_node(DExpr::TRUTHY, {v->dx}));
+    case SV::DERIVED: {
+      FP present = f_dict(v->path, dx_node(DExpr::TRUTHY, {v->dx}));
+      if (v->idx == 1 && v->c.defined() && !(v->c.is_bool() && !v->c.b)) return f_or(present, f_and(v->f, f_not(f_atom(atom_path(Atom::DEFINED, v->path)))));
+      return present;
+    }
     default: return defined_f(v);
   }
 }
@@ -1651,7 +1810,11 @@ FP PE::is_string_f(const SVP& v) {
     }
     case SV::OPAQUE: return v->f;
     case SV::STRX: return v->xkind == SV::XCOUNT ? f_false() : defined_f(v);
-    case SV::DERIVED: return f_dict(v->path, dx_node(DExpr::TYPE_MASK, {v->dx}, "", 0, M_STRING));
+    case SV::DERIVED: {
+      FP present = f_dict(v->path, dx_node(DExpr::TYPE_MASK, {v->dx}, "", 0, M_STRING));
+      if (v->idx == 1 && v->c.is_string()) return f_or(present, f_and(v->f, f_not(f_atom(atom_path(Atom::DEFINED, v->path)))));
+      return present;
+    }
     default: return f_false();
   }
 }

@@ -99,7 +99,7 @@ struct Violation {   // render mode output
 };
 
 // One compiled template: main module + libs.
-class Template {
+class Template : public std::enable_shared_from_this<Template> {
  public:
   Template(const std::string& rego, const std::vector<std::string>& libs);   // throws RegoError
   const std::string& package_name() const { return pkg_name_; }

@@ -591,14 +591,13 @@ def test_gator_verify_suite_template(backend, fixtures):
 
 @pytest.mark.parametrize("backend", BACKENDS)
 def test_unsupported_is_an_error_not_a_fallback(backend, fixtures):
-    t_ = gconst(fixtures, "TemplateReferential")[0]
-    k_ = gconst(fixtures, "ConstraintReferential")[0]
+    # valid Rego that no plan expresses (sorting review data in the rule body itself): refused, never approximated
+    t_ = {"apiVersion": "templates.gatekeeper.sh/v1", "kind": "ConstraintTemplate", "metadata": {"name": "k8ssorted"},
+          "spec": {"crd": {"spec": {"names": {"kind": "K8sSorted"}}}, "targets": [{"target": "admission.k8s.gatekeeper.sh", "rego":
+              'package k\nviolation[{"msg": "m"}] { sort(input.review.object.spec.names)[0] == input.parameters.first }\n'}]}}
+    k_ = {"apiVersion": "constraints.gatekeeper.sh/v1beta1", "kind": "K8sSorted", "metadata": {"name": "x"}, "spec": {"parameters": {"first": "a"}}}
     c = make_client(backend)
     c.AddTemplate(t_)
-    # referential templates compile against the synced objects (tests/test_referential.py); this one joins on a value COMPUTED
-    # from a whole map, which no plan expresses: refused as soon as there is an inventory to join with
-    for o in gconst(fixtures, "ObjectReferentialInventory"):
-        c.AddData(o)
     with pytest.raises(D.UnsupportedError):
         c.AddConstraint(k_)
     with pytest.raises(D.ClientError):

@@ -10,8 +10,8 @@ Pinned by the reference: the message of test/gator/test/test.bats:222 for polici
 through the `gator test` harness; everything else product vs oracle.  K8sUniqueLabel (demo/basic, test/bats/test.bats:295-303
 "unique labels test") compares sprintf("%v/%v", [group, version]) of the review with the synced objects' apiVersion: a formatted
 string whose parts are known is compared with a constant piece by piece (pe.cpp fmt_equals).  K8sUniqueServiceSelector
-(pkg/gator/fixtures/fixtures.go:414-471, test_test.go:135-158) compares a value COMPUTED from a whole sub-object with the
-inventory's: still refused when the constraint is added."""
+(pkg/gator/fixtures/fixtures.go:414-471, test_test.go:134-170) compares a value COMPUTED from a whole sub-object by a closed
+helper: a DEEP dictionary expression evaluated by the flattener (dexpr.hpp)."""
 import pytest
 
 import reference_tables as T
@@ -120,16 +120,67 @@ def test_an_inventory_beyond_the_plan_fails_closed(fixtures):
     assert check(c, oc, [objs[0], dup]) == 1                   # the inventory fits again: the constraint serves again
 
 
-@pytest.mark.parametrize("name,reason", [("TemplateReferential", "sort applied to review data")])
-def test_joins_on_computed_values_are_still_refused(fixtures, name, reason):
-    """K8sUniqueServiceSelector joins on flatten_selector(obj): a string computed from a whole map (fixtures.go:414-471)"""
-    tmpl, con = gconst(fixtures, name)[0], gconst(fixtures, "ConstraintReferential")[0]
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_gator_referential_constraint_pinned_by_test_test_go(backend, fixtures):
+    """pkg/gator/test/test_test.go:134-170 ("referential constraint with violation" / "without violation"): K8sUniqueServiceSelector
+    (fixtures.go:414-471) joins on flatten_selector(obj) = concat(",", sort([concat(":", [k, v]) | v = obj.spec.selector[k]])) -- no
+    formula over rows expresses that.  The helper is CLOSED (it reads nothing but its argument), so the partial evaluator hands
+    the call to the flattener as a DEEP dictionary expression over the narrowest sub-document it looks at (object.spec.selector):
+    the concrete evaluator runs the helper on every distinct selector once, the device tests a bit (dexpr.hpp)."""
+    tmpl, con = gconst(fixtures, "TemplateReferential")[0], gconst(fixtures, "ConstraintReferential")[0]
+    inv, deny, allow = (gconst(fixtures, k)[0] for k in ("ObjectReferentialInventory", "ObjectReferentialDeny", "ObjectReferentialAllow"))
+    for objs, want in (([tmpl, con, inv, deny], ["same selector as service <gatekeeper-test-service-disallowed> in namespace <default>",
+                                                 "same selector as service <gatekeeper-test-service-example> in namespace <default>"]),
+                       ([tmpl, con, inv, allow], [])):
+        c = make_client(backend)
+        c.enforcement_points = (D.GATOR_EP,)
+        got = G.test(objs, client=c)
+        assert sorted(g.msg for g in got) == want
+        assert sorted((g.msg, g.violating_object["metadata"]["name"]) for g in got) == sorted((r.msg, o["metadata"]["name"]) for r, o in OG.gator_test(objs))
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_unique_service_selector_over_odd_selectors(backend, fixtures):
+    """the deep expression against the oracle: key order, subsets and supersets, non-string values (skipped by the comprehension),
+    separators inside keys and values ("a:b" / "c" flattens like "a" / "b:c"), selector absent / empty / not an object, a synced
+    Service without a selector (flattens to "": equal to every review Service without string entries)"""
+    tmpl, con = gconst(fixtures, "TemplateReferential")[0], gconst(fixtures, "ConstraintReferential")[0]
+    c, oc = make_client(backend), OC.Client()
+    c.AddTemplate(tmpl); oc.add_template(tmpl)
+
+    def svc(name, ns, sel, kind="Service", api="v1"):
+        spec = {"ports": [{"port": 80}]}
+        if sel is not None:
+            spec["selector"] = sel
+        return {"apiVersion": api, "kind": kind, "metadata": {"name": name, "namespace": ns}, "spec": spec}
+    inv = [svc("s1", "default", {"app": "a", "tier": "web"}), svc("s2", "other", {"k": "v"}), svc("s3", "default", {"a:b": "c"}), svc("s4", "default", {"x": "1,y:2"}),
+           svc("none", "default", None), svc("dep", "default", {"k": "v"}, "Deployment", "apps/v1")]
+    for o in inv:
+        c.AddData(o); oc.add_data(o)
+    c.AddConstraint(con); oc.add_constraint(con)
+    objs = [svc("n1", "default", {"tier": "web", "app": "a"}), svc("s1", "default", {"app": "a", "tier": "web"}), svc("n2", "x", {"k": "v"}), svc("n3", "x", {"k": "w"}),
+            svc("n4", "x", {}), svc("n5", "x", {"k": "v", "z": "1"}), svc("n6", "x", {"k": 5}), svc("n7", "x", {"k": "v", "n": 5}), svc("n8", "x", {"a": "b:c"}),
+            svc("n9", "x", {"x": "1", "y": "2"}), svc("n10", "x", None), svc("n11", "x", ["k", "v"]), svc("n12", "x", "k:v"), svc("none", "default", None),
+            svc("n13", "x", {"app": "a"}), svc("d2", "x", {"k": "v"}, "Deployment", "apps/v1"), svc("s2", "other", {"k": "v"}), svc("s2", "default", {"k": "v"})]
+    assert check(c, oc, objs) >= 9
+    assert check(c, oc, objs, D.AUDIT_EP) >= 9
+    gone = inv[1]
+    c.RemoveData(gone); oc.remove_data(gone)
+    assert check(c, oc, objs) >= 6
+
+
+def test_what_is_still_refused(fixtures):
+    """an open helper (it reads input.parameters besides its argument) that sorts review data: no plan, no deep expression"""
+    rego = """package k
+norm(obj) = out { out := concat(",", sort([x | x = obj.spec.names[_]; x != input.parameters.skip])) }
+violation[{"msg": "m"}] { norm(input.review.object) == "a,b" }
+"""
+    tmpl = {"apiVersion": "templates.gatekeeper.sh/v1", "kind": "ConstraintTemplate", "metadata": {"name": "k8sopen"},
+            "spec": {"crd": {"spec": {"names": {"kind": "K8sOpen"}}}, "targets": [{"target": "admission.k8s.gatekeeper.sh", "rego": rego}]}}
     c = make_client("hostemu")
     c.AddTemplate(tmpl)
-    for o in gconst(fixtures, "ObjectReferentialInventory"):
-        c.AddData(o)
-    with pytest.raises(D.UnsupportedError, match=reason):
-        c.AddConstraint(con)
+    with pytest.raises(D.UnsupportedError, match="sort applied to review data"):
+        c.AddConstraint({"apiVersion": "constraints.gatekeeper.sh/v1beta1", "kind": "K8sOpen", "metadata": {"name": "x"}, "spec": {"parameters": {"skip": "z"}}})
 
 
 # ---- K8sUniqueLabel: demo/basic + the bats "unique labels test" (test/bats/test.bats:295-303: with no_dupe_cm synced, applying

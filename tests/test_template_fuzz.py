@@ -78,7 +78,11 @@ def cond2(rng, var=None):
 def cond4(rng, var=None):
     """key iteration, value-returning helpers, parameter rule arrays"""
     base = (var if var and rng.random() < 0.5 else "input.review.object") + "." + rng.choice(KEYS)
-    k = rng.randint(0, 7)
+    k = rng.randint(0, 9)
+    if k == 8:   # a closed helper the formula language cannot express (it sorts): a DEEP dictionary expression on the narrowest sub-document
+        return "joined(%s) %s %s" % (base if rng.random() < 0.5 else "input.review.object", rng.choice(["==", "==", "!="]), rng.choice(['"x,yy"', '"x"', '""', '"a-,x"', '"yy"']))
+    if k == 9:
+        return "count(keyset(%s)) %s %d" % (base, rng.choice(["==", ">"]), rng.randint(0, 2))
     if k == 0:
         kp = rng.choice(['startswith(key, "%s")', 'not startswith(key, "%s")', 'endswith(key, "%s")', 'not endswith(key, "%s")', 'contains(key, "%s")', 'not contains(key, "%s")',
                          'key == "%s"; startswith(key, "a")', 'key != "%s"; not startswith(key, "b")']) % rng.choice(["a", "b", "c", "ab"])
@@ -92,6 +96,8 @@ def cond4(rng, var=None):
     return "tier(%s) == \"%s\"" % (base, rng.choice(["gold", "none"]))
 
 LIB4 = '''
+joined(obj) = out { out := concat(",", sort([s | s := obj.list[_]; is_string(s)])) }
+keyset(obj) = ks { ks := {k | obj.sub[k]; not startswith(k, "a")} }
 norm(x) = y { y := lower(x) }
 pick(x) = y { is_number(x); y := x + 1 } else = 0 { is_string(x) }
 default_tier = "none"
