@@ -171,10 +171,13 @@ def _plain_objs():
 
 
 @pytest.mark.gpu
-def test_rccl_exchange_and_captured_sweeps_on_the_device(tmp_path):
+@pytest.mark.parametrize("graph", ["direct", "graph"])
+def test_rccl_exchange_and_captured_sweeps_on_the_device(tmp_path, graph, monkeypatch):
     """The engine's own RCCL path on the MI355X at world size 1 (librccl through dlopen, the in-place ncclAllGather of the slots,
-    the totals from the gathered tails) and the captured-graph replay of enqueue-only sweeps: bitmaps, totals and the
-    fail-closed counts equal the plain evaluation of the same table, before and after the graph takes over."""
+    the totals from the gathered tails), with the enqueue-only passes issued directly and replayed as a captured graph
+    (GK_SHARD_GRAPH=1): bitmaps, totals and the fail-closed counts equal the plain evaluation of the same table, for the answers
+    collected from the enqueue-only passes too."""
+    monkeypatch.setenv("GK_SHARD_GRAPH", "1" if graph == "graph" else "0")   # (read by the engine in the spawned worker: opt-in captured replay)
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
