@@ -171,13 +171,15 @@ def _plain_objs():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("graph", ["direct", "graph"])
+@pytest.mark.parametrize("graph", ["direct", "graph", "overlap"])
 def test_rccl_exchange_and_captured_sweeps_on_the_device(tmp_path, graph, monkeypatch):
     """The engine's own RCCL path on the MI355X at world size 1 (librccl through dlopen, the in-place ncclAllGather of the slots,
     the totals from the gathered tails), with the enqueue-only passes issued directly and replayed as a captured graph
-    (GK_SHARD_GRAPH=1): bitmaps, totals and the fail-closed counts equal the plain evaluation of the same table, for the answers
-    collected from the enqueue-only passes too."""
+    (GK_SHARD_GRAPH=1) or OVERLAPPED with the next pass's sweep (two slot buffers, exchange stream: what world size > 1 runs):
+    bitmaps, totals and the fail-closed counts equal the plain evaluation of the same table, for the answers collected from the
+    enqueue-only passes too."""
     monkeypatch.setenv("GK_SHARD_GRAPH", "1" if graph == "graph" else "0")   # (read by the engine in the spawned worker: opt-in captured replay)
+    monkeypatch.setenv("GK_SHARD_OVERLAP", "1" if graph == "overlap" else "0")   # two slot buffers + exchange stream, the default at world size > 1
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
