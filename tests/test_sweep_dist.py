@@ -22,7 +22,7 @@ SHARDS = [451, 333]   # uneven, not multiples of 64
 def _client(policies="audit"):
     fx = synth.load_fixtures()
     c = D.Client(D.Driver(hostemu=True))
-    templates, constraints = (synth.psp_templates(fx), synth.audit_constraints()) if policies == "audit" else synth.corpus(fx, 100)
+    templates, constraints = (synth.psp_templates(fx), synth.audit_constraints()) if policies == "audit" else synth.corpus(fx, 72)
     for t in templates:
         c.AddTemplate(t)
     for k in constraints:
@@ -55,9 +55,9 @@ def _worker(rank, world, port, out_dir, policies="audit"):
 import pytest   # noqa: E402
 
 
-@pytest.mark.parametrize("policies", ["audit", "corpus100"])
+@pytest.mark.parametrize("policies", ["audit", "corpus72"])
 def test_sharded_sweep_matches_single_process(tmp_path, policies):
-    """corpus100: 100 templates / constraints = two plan groups (more than 64 distinct formulas): one evaluation + exchange
+    """corpus72: 72 templates / constraints = two plan groups (more than 64 distinct formulas): one evaluation + exchange
     per group, merged into one [constraints x objects] answer"""
     world = len(SHARDS)
     s = socket.socket()

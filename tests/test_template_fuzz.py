@@ -359,9 +359,12 @@ def test_random_templates_agree_with_the_oracle(backend, seed, envelope, numeric
     """envelope: AdmissionRequests (CREATE / UPDATE / DELETE, oldObject, userInfo) mixed with bare objects, and conditions that
     compare review values with each other (object vs oldObject, element vs outside value); numeric: arithmetic / to_number /
     round / abs conditions over numbers at the edges, printed into the messages; v1: the templates in Rego v1 syntax (source.version "v1")"""
-    stats, diffs = run(backend, seed, 70, 14, envelope=envelope, numeric=numeric, v1=v1)
+    # (the generated-source build pays a g++ run per plan: 40 templates keep the GPU-less suite within minutes; the interpreter
+    #  build and the device take all 70; tools/fuzz_campaign.py runs seed ranges of any length)
+    n_templates = 40 if getattr(backend, "id", backend) == "hostemu-gen" or backend == "hostemu-gen" else 70
+    stats, diffs = run(backend, seed, n_templates, 14, envelope=envelope, numeric=numeric, v1=v1)
     assert not diffs, "product and oracle disagree:\n%s" % "\n-----\n".join("%s\n%s" % (d[0], d[1]) for d in diffs[:3])
-    assert stats["oracle_err"] == 0 and stats["ok"] >= 50, stats      # the grammar stays inside what both sides implement
+    assert stats["oracle_err"] == 0 and stats["ok"] >= n_templates * 5 // 7, stats      # the grammar stays inside what both sides implement
 
 
 REGRESSIONS = {
@@ -540,7 +543,7 @@ def test_random_templates_with_every_and_some_in(backend, seed):
     """`every x in <review ref> { .. }`, `every k, v in ..`, `some x in ..` over absent / empty / scalar / mixed-type domains
     (round-2 advisor finding: `every` over an UNDEFINED domain compiled to "vacuously true"; the grammar did not cover it)"""
     try:
-        stats, diffs = run(backend, seed, 60, 14, every=True)
+        stats, diffs = run(backend, seed, 36 if backend == "hostemu-gen" else 60, 14, every=True)
     finally:
         global EVERY
         EVERY = False
