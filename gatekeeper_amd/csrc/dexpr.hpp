@@ -33,6 +33,8 @@ struct DExpr {
   int cmp = 0;              // CMP: CmpOp
   uint32_t mask = 0;        // TYPE_MASK: bit per RowType of the leaf-derived value
   std::vector<DX> args;
+  std::string text;         // canonical text (dx_to_string), composed ONCE when the node is made from its children's: lowering keys
+                            // formulas by it, and re-deriving it per lookup made a K8sContainerLimits constraint take 3 s to add
 };
 
 // DEEP expressions (round 3): a template's own helper function applied to ONE sub-document of the review -- closed (it reads
@@ -53,33 +55,36 @@ inline Value dx_call_user(const std::string& name, const ValueVec& args) {
   return fn(args);
 }
 
-inline DX dx_leaf() { static thread_local DX l = std::make_shared<const DExpr>(); return l; }
-inline DX dx_const(const Value& v) { DExpr e; e.kind = DExpr::CONST; e.c = v; return std::make_shared<const DExpr>(e); }
-inline DX dx_node(DExpr::Kind k, std::vector<DX> args, const std::string& name = "", int cmp = 0, uint32_t mask = 0) {
-  DExpr e; e.kind = k; e.args = std::move(args); e.name = name; e.cmp = cmp; e.mask = mask;
-  return std::make_shared<const DExpr>(e);
-}
-
-inline std::string dx_to_string(const DX& e) {
+inline std::string dx_compose_text(const DExpr* e) {
   static const char* cmpn[] = {"==", "!=", "<", "<=", ">", ">="};
   switch (e->kind) {
     case DExpr::LEAF: return "$";
     case DExpr::CONST: return to_term_string(e->c);
-    case DExpr::CALL: { std::string o = e->name + "("; for (size_t i = 0; i < e->args.size(); i++) { if (i) o += ","; o += dx_to_string(e->args[i]); } return o + ")"; }
-    case DExpr::ARITH: return "(" + dx_to_string(e->args[0]) + e->name + dx_to_string(e->args[1]) + ")";
-    case DExpr::CMP: return "(" + dx_to_string(e->args[0]) + cmpn[e->cmp] + dx_to_string(e->args[1]) + ")";
-    case DExpr::DEFINED: return "def(" + dx_to_string(e->args[0]) + ")";
-    case DExpr::TRUTHY: return "truthy(" + dx_to_string(e->args[0]) + ")";
-    case DExpr::NOT: return "!(" + dx_to_string(e->args[0]) + ")";
-    case DExpr::TYPE_MASK: return "type(" + dx_to_string(e->args[0]) + ")&" + std::to_string(e->mask);
+    case DExpr::CALL: { std::string o = e->name + "("; for (size_t i = 0; i < e->args.size(); i++) { if (i) o += ","; o += e->args[i]->text; } return o + ")"; }
+    case DExpr::ARITH: return "(" + e->args[0]->text + e->name + e->args[1]->text + ")";
+    case DExpr::CMP: return "(" + e->args[0]->text + cmpn[e->cmp] + e->args[1]->text + ")";
+    case DExpr::DEFINED: return "def(" + e->args[0]->text + ")";
+    case DExpr::TRUTHY: return "truthy(" + e->args[0]->text + ")";
+    case DExpr::NOT: return "!(" + e->args[0]->text + ")";
+    case DExpr::TYPE_MASK: return "type(" + e->args[0]->text + ")&" + std::to_string(e->mask);
     case DExpr::AND: case DExpr::OR: {
       std::string o = "(";
-      for (size_t i = 0; i < e->args.size(); i++) { if (i) o += e->kind == DExpr::AND ? " & " : " | "; o += dx_to_string(e->args[i]); }
+      for (size_t i = 0; i < e->args.size(); i++) { if (i) o += e->kind == DExpr::AND ? " & " : " | "; o += e->args[i]->text; }
       return o + ")";
     }
   }
   return "?";
 }
+
+inline DX dx_leaf() { static thread_local DX l = [] { DExpr e; e.text = dx_compose_text(&e); return std::make_shared<const DExpr>(e); }(); return l; }
+inline DX dx_const(const Value& v) { DExpr e; e.kind = DExpr::CONST; e.c = v; e.text = dx_compose_text(&e); return std::make_shared<const DExpr>(std::move(e)); }
+inline DX dx_node(DExpr::Kind k, std::vector<DX> args, const std::string& name = "", int cmp = 0, uint32_t mask = 0) {
+  DExpr e; e.kind = k; e.args = std::move(args); e.name = name; e.cmp = cmp; e.mask = mask;
+  e.text = dx_compose_text(&e);
+  return std::make_shared<const DExpr>(std::move(e));
+}
+
+inline const std::string& dx_to_string(const DX& e) { return e->text; }
 
 inline bool dx_cmp_holds(int c, int op) {
   switch (op) { case 0: return c == 0; case 1: return c != 0; case 2: return c < 0; case 3: return c <= 0; case 4: return c > 0; default: return c >= 0; }

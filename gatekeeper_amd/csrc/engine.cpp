@@ -47,6 +47,8 @@ struct ConstraintRec {
   // RESULT totals (gk_table_totals): "this review may yield MORE THAN ONE result" (Template::compile_multi) with the same match
   // formulas, lowered into the totals plans; null = not lowerable: every violating pair of the constraint is rendered
   std::shared_ptr<const PreparedConstraint> multi_prep;
+  bool multi_ready = false;   // multi_prep is what it will be (possibly null); false: derived by the first gk_table_totals that needs it
+                              //   (half of a K8sContainerLimits AddConstraint went into a formula only the audit's RESULT totals read)
   // referential template (reads data.inventory): compiled against a snapshot of the synced objects, again whenever they change
   // (refresh_referential); `broken`: why the current inventory does not compile -- every evaluation then fails (GK_ERR_UNSUPPORTED)
   bool referential = false;
@@ -600,6 +602,7 @@ void compile_referential(gk_engine* e, const Template& t, ConstraintRec& c) {
   }
   c.viol = viol; c.prep = prep;
   c.multi_prep = prepare_multi(e, t, c.params, c.mf, inv);
+  c.multi_ready = true;
 }
 
 // The synced objects changed: the constraints of referential templates are compiled against the new inventory.  One that no
@@ -633,6 +636,14 @@ void ensure_totals_plans(gk_engine* e) {
   e->totals_groups.clear();
   PlanCaps bigcaps;
   bigcaps.level_cap[0] = bigcaps.level_cap[1] = bigcaps.level_cap[2] = 256;
+  // the "more than one result" formulas still owed (AddConstraint leaves them to the first totals that need them; only this
+  // function -- under totals_mu -- and the exclusive holders of mu touch multi_prep / multi_ready)
+  for (auto& c : e->constraints) {
+    if (!c.alive || c.multi_ready) continue;
+    auto it = e->templates.find(lower_str(c.kind));
+    c.multi_prep = it == e->templates.end() ? nullptr : prepare_multi(e, *it->second, c.params, c.mf);
+    c.multi_ready = true;
+  }
   std::vector<const ConstraintRec*> have;
   for (auto& c : e->constraints) if (c.alive && c.multi_prep) have.push_back(&c);
   std::function<void(const std::vector<const ConstraintRec*>&)> place = [&](const std::vector<const ConstraintRec*>& g) {
@@ -721,7 +732,7 @@ int gk_template_add(gk_engine* e, const char* kind, const char* rego, const char
       redo.push_back(std::move(r));
     }
     e->templates[k] = t;
-    for (auto& r : redo) { r.c->viol = std::move(r.viol); r.c->prep = std::move(r.prep); r.c->multi_prep = std::move(r.multi); r.c->referential = r.referential; r.c->broken.clear(); }
+    for (auto& r : redo) { r.c->viol = std::move(r.viol); r.c->prep = std::move(r.prep); r.c->multi_prep = std::move(r.multi); r.c->multi_ready = true; r.c->referential = r.referential; r.c->broken.clear(); }
     if (!redo.empty() && t->references_inventory()) e->inv_compiled = e->inv_gen;
     e->plan_dirty = true;
     return GK_OK;
@@ -786,7 +797,7 @@ int gk_constraint_add(gk_engine* e, const char* json, size_t len, uint32_t* id_o
         PlanCaps caps;
         pb.build(caps);
       }
-      rec.multi_prep = prepare_multi(e, *it->second, rec.params, rec.mf);
+      rec.multi_ready = false;   // (prepare_multi: on demand, ensure_totals_plans)
     }
     for (auto& o : e->constraints) if (o.alive && o.kind == rec.kind && o.name == rec.name) o.alive = false;   // replace
     rec.id = (uint32_t)e->constraints.size();

@@ -400,7 +400,17 @@ bool dict_foldable_atom(const Atom& a) {
   }
 }
 // leaf of a leaf-local formula ("" = not leaf-local); has_dict: it contains a DICT atom
+static std::string leaf_of_uncached(const FP& f, bool* has_dict);
 std::string leaf_of(const FP& f, bool* has_dict) {
+  if (f->leaf_state == 0) {   // (asked again and again for the same sub-formulas while conjunctions are folded per leaf)
+    bool d = false;
+    f->leaf_text = leaf_of_uncached(f, &d);
+    f->leaf_state = d ? 2 : 1;
+  }
+  if (f->leaf_state == 2 && !f->leaf_text.empty()) *has_dict = true;
+  return f->leaf_text;
+}
+static std::string leaf_of_uncached(const FP& f, bool* has_dict) {
   switch (f->kind) {
     case FNode::ATOM:
       if (!dict_foldable_atom(f->atom)) return "";
@@ -576,20 +586,29 @@ SPath rename_path(const SPath& p, const std::map<int, int>& m) {
   for (auto& s : o) if (s.iter) { auto it = m.find(s.q); if (it != m.end()) s.q = it->second; }
   return o;
 }
+static bool path_renamed(const SPath& p, const std::map<int, int>& m) { for (auto& s : p) if (s.iter) { auto it = m.find(s.q); if (it != m.end() && it->second != s.q) return true; } return false; }
+static bool q_renamed(int q, const std::map<int, int>& m) { if (q < 0) return false; auto it = m.find(q); return it != m.end() && it->second != q; }
 FP rename_f(const FP& f, const std::map<int, int>& m) {
   switch (f->kind) {
     case FNode::T: case FNode::F: return f;
     case FNode::ATOM: {
+      if (!path_renamed(f->atom.path, m) && !path_renamed(f->atom.path2, m) && !q_renamed(f->atom.q, m)) return f;   // (nothing to rename: shared, not copied)
       Atom a = f->atom;
       a.path = rename_path(a.path, m); a.path2 = rename_path(a.path2, m);
       if (a.q >= 0) { auto it = m.find(a.q); if (it != m.end()) a.q = it->second; }
       return f_atom(a);
     }
     default: {
+      bool same = !path_renamed(f->base, m) && !q_renamed(f->q, m);
+      std::vector<FP> kids;
+      kids.reserve(f->kids.size());
+      for (auto& k : f->kids) { kids.push_back(rename_f(k, m)); if (kids.back().get() != k.get()) same = false; }
+      if (same) return f;
       FNode n = *f;
-      for (auto& k : n.kids) k = rename_f(k, m);
+      n.kids = std::move(kids);
       n.base = rename_path(n.base, m);
       if (n.q >= 0) { auto it = m.find(n.q); if (it != m.end()) n.q = it->second; }
+      n.canon_set = false; n.canon.clear(); n.leaf_state = 0; n.leaf_text.clear();   // (an edited copy: its text is derived afresh)
       return std::make_shared<const FNode>(n);
     }
   }

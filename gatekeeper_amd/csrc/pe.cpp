@@ -13,7 +13,7 @@ namespace gk {
 
 // ================================================================================================ formulas
 namespace {
-FP mkf(FNode n) { return std::make_shared<const FNode>(std::move(n)); }
+FP mkf(FNode n) { n.canon_set = false; n.canon.clear(); n.leaf_state = 0; n.leaf_text.clear(); return std::make_shared<const FNode>(std::move(n)); }   // (a copy that was edited carries no text)
 }
 // per-thread singletons: the reference count of a process-wide one would be the hottest cache line of every host thread
 // that renders messages (gk_table_totals, the CPU baseline loop)
@@ -64,7 +64,12 @@ std::string spath_to_string(const SPath& p) {
   for (const Step& s : p) { if (s.iter) o += "[q" + std::to_string(s.q) + "]"; else o += "." + s.key; }
   return o;
 }
+static std::string f_compose_text(const FP& f);
 std::string f_to_string(const FP& f) {
+  if (!f->canon_set) { f->canon = f_compose_text(f); f->canon_set = true; }
+  return f->canon;
+}
+static std::string f_compose_text(const FP& f) {
   static const char* cmpn[] = {"==", "!=", "<", "<=", ">", ">="};
   switch (f->kind) {
     case FNode::T: return "true";
@@ -169,11 +174,14 @@ SPath rn_path(const SPath& p, const QMap& m) {
   for (Step& s : o) if (s.iter) { auto it = m.find(s.q); if (it != m.end()) s.q = it->second; }
   return o;
 }
+static bool path_mentions(const SPath& p, const QMap& m) { for (const Step& s : p) if (s.iter && m.count(s.q)) return true; return false; }
 FP rn_f(const FP& f, const QMap& m) {
   if (m.empty()) return f;
   switch (f->kind) {
     case FNode::T: case FNode::F: return f;
     case FNode::ATOM: {
+      // (most sub-formulas of a renaming mention none of the renamed quantifiers: they are shared, not copied)
+      if (!path_mentions(f->atom.path, m) && !path_mentions(f->atom.path2, m) && !(f->atom.q >= 0 && m.count(f->atom.q))) return f;
       Atom a = f->atom;
       a.path = rn_path(a.path, m);
       a.path2 = rn_path(a.path2, m);
@@ -181,8 +189,13 @@ FP rn_f(const FP& f, const QMap& m) {
       return f_atom(a);
     }
     default: {
+      bool same = !path_mentions(f->base, m) && !(f->q >= 0 && m.count(f->q));
+      std::vector<FP> kids;
+      kids.reserve(f->kids.size());
+      for (auto& k : f->kids) { kids.push_back(rn_f(k, m)); if (kids.back().get() != k.get()) same = false; }
+      if (same) return f;
       FNode n = *f;
-      for (auto& k : n.kids) k = rn_f(k, m);
+      n.kids = std::move(kids);
       n.base = rn_path(n.base, m);
       if (n.q >= 0) { auto it = m.find(n.q); if (it != m.end()) n.q = it->second; }
       return mkf(n);

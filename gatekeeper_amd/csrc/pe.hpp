@@ -54,6 +54,13 @@ struct FNode {
   SPath base;           // EXISTS
   bool two = false;     // EXISTS: at least TWO children of `base` satisfy the body ("E2": instance counting for the RESULT totals)
   Atom atom;
+  // canonical text (f_to_string), derived once per node: lowering keys sub-formulas by it over and over.  Nodes are immutable
+  // once made (mkf / f_* reset the cache of a copy they are handed); formulas are built and lowered under the engine's locks
+  mutable std::string canon;
+  mutable bool canon_set = false;
+  // (lower.cpp leaf_of, cached the same way: the leaf of a leaf-local formula, "" = not leaf-local; whether it holds a DICT atom)
+  mutable std::string leaf_text;
+  mutable int leaf_state = 0;   // 0 unknown, 1 known without a DICT atom, 2 known with one
 };
 
 FP f_true();

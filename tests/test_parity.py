@@ -804,9 +804,9 @@ def test_policy_corpus_200_templates(backend, fixtures):
     assert len(templates) == 200 and len({t["spec"]["crd"]["spec"]["names"]["kind"] for t in templates}) == 200
     c, oc = load_both(backend, templates, cons)
     nss = synth.gen_namespaces()
-    objs = synth.gen_objects(150, seed=11, mixed=True)
-    rv = [D.AugmentedUnstructured(D.Unstructured(o), synth.namespace_for(o, nss), "Original") for o in objs]
-    assert assert_parity(c, oc, rv) > 1200
+    objs = synth.gen_objects(64, seed=11, mixed=True)     # (the oracle's tree-walker pays ~1 ms per pair: 12 800 of them here; tests/test_cpu_ref.py
+    rv = [D.AugmentedUnstructured(D.Unstructured(o), synth.namespace_for(o, nss), "Original") for o in objs]   #  takes the corpus to thousands of objects against the compiled loop)
+    assert assert_parity(c, oc, rv) > 450
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
