@@ -14,6 +14,7 @@
 #include <unistd.h>
 
 #include <fstream>
+#include <sstream>
 #include <map>
 
 #include "codegen.hpp"
@@ -75,8 +76,9 @@ DevPlan* dev_plan_upload(int, const HostPlan& fast, const HostPlan& big) {
   if (getenv("GK_HOSTEMU_JIT")) {
     static int counter = 0;
     std::string base = "/tmp/gkjit_hostemu_" + std::to_string(getpid()) + "_" + std::to_string(counter++);
+    std::ostringstream text;
     {
-      std::ofstream f(base + ".cpp");
+      std::ostringstream& f = text;
       f << "#include <vector>\n#include \"" << GK_CSRC_DIR << "/vm_core.hpp\"\n" << generate_plan_source(fast)
         << "struct VecAcc { std::vector<uint32_t>* w; void or_word(uint32_t i, uint32_t m) { (*w)[i] |= m; } void max_word(uint32_t i, uint32_t v) { if ((*w)[i] < v) (*w)[i] = v; }\n"
            "  void store_word(uint32_t i, uint32_t v) { (*w)[i] = v; } uint32_t load(uint32_t i) const { return (*w)[i]; } };\n"
@@ -89,10 +91,26 @@ DevPlan* dev_plan_upload(int, const HostPlan& fast, const HostPlan& big) {
            "  if (r.viol != mono.viol || r.match != mono.match || r.err != mono.err) { r.viol = ~0ull; r.match = ~0ull; r.err = ~0ull; }   // staged and monolithic code must agree\n"
            "  *out = r; }\n";
     }
-    std::string cmd = "g++ -std=c++17 -O1 -shared -fPIC -o " + base + ".so " + base + ".cpp 2> " + base + ".log";
-    if (system(cmd.c_str()) != 0) throw std::runtime_error("hostemu: generated plan source does not compile, see " + base + ".log");
-    p->dl = dlopen((base + ".so").c_str(), RTLD_NOW);
-    if (!p->dl) throw std::runtime_error(std::string("hostemu: dlopen failed: ") + dlerror());
+    // The same policy sets are loaded by many tests: the g++ run (about a second) is skipped when this exact text -- and the
+    // header it includes -- was built before (a cache under /tmp keyed by their hash; written under a private name, then renamed)
+    const std::string src = text.str();
+    uint64_t hsh = 1469598103934665603ull;
+    auto mix = [&](const std::string& t) { for (unsigned char ch : t) { hsh ^= ch; hsh *= 1099511628211ull; } };
+    mix(src);
+    { std::ifstream hdr(std::string(GK_CSRC_DIR) + "/vm_core.hpp"); std::stringstream hs; hs << hdr.rdbuf(); mix(hs.str()); }
+    { std::ifstream hdr(std::string(GK_CSRC_DIR) + "/plan.hpp"); std::stringstream hs; hs << hdr.rdbuf(); mix(hs.str()); }
+    char hx[32];
+    snprintf(hx, sizeof hx, "%016llx", (unsigned long long)hsh);
+    const std::string cached = std::string("/tmp/gk_hostemu_cache/plan_") + hx + ".so";
+    if (!getenv("GK_HOSTEMU_NO_CACHE")) p->dl = dlopen(cached.c_str(), RTLD_NOW);
+    if (!p->dl) {
+      { std::ofstream f(base + ".cpp"); f << src; }
+      std::string cmd = "g++ -std=c++17 -O1 -shared -fPIC -o " + base + ".so " + base + ".cpp 2> " + base + ".log";
+      if (system(cmd.c_str()) != 0) throw std::runtime_error("hostemu: generated plan source does not compile, see " + base + ".log");
+      p->dl = dlopen((base + ".so").c_str(), RTLD_NOW);
+      if (!p->dl) throw std::runtime_error(std::string("hostemu: dlopen failed: ") + dlerror());
+      if (!getenv("GK_HOSTEMU_NO_CACHE")) { if (system("mkdir -p /tmp/gk_hostemu_cache") == 0) (void)rename((base + ".so").c_str(), cached.c_str()); }
+    }
     p->row = (HeRowFn)dlsym(p->dl, "gk_he_row");
     p->form = (HeFormFn)dlsym(p->dl, "gk_he_form");
     std::vector<std::vector<Pred>> classes;
