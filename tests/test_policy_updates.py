@@ -81,3 +81,50 @@ def test_every_over_absent_empty_and_non_collection_domains(backend):
     assert by_name["all-a"] == ["all named a"]
     assert by_name["one-b"] == ["not all a"]
     assert by_name["unnamed"] == ["not all a"]
+
+
+DEEP1 = ('package k\n'
+         'joined(obj) = out { out := concat(",", sort([s | s := obj.spec.names[_]; is_string(s)])) }\n'
+         'violation[{"msg": msg}] { j := joined(input.review.object); j == input.parameters.want; msg := sprintf("v1 %v", [j]) }\n')
+DEEP2 = ('package k\n'
+         'joined(obj) = out { out := concat("+", sort([upper(s) | s := obj.spec.names[_]; is_string(s)])) }\n'
+         'violation[{"msg": msg}] { j := joined(input.review.object); j == input.parameters.want; msg := sprintf("v2 %v", [j]) }\n')
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_template_with_a_deep_helper_replaced(backend):
+    """A closed helper the formula language cannot express (it sorts) is evaluated by the FLATTENER on the sub-document it reads
+    (spec.names) -- a deep dictionary expression, dexpr.hpp.  Replacing the template must replace the closure: the same constraints
+    answer with the new helper, on the device and in the renderer; two constraints with different parameters share the expression."""
+    c, oc = load_both(backend, [_tmpl("KDeep", DEEP1)], [_cons("KDeep", "ab", {"want": "a,b"}), _cons("KDeep", "empty", {"want": ""}), _cons("KDeep", "up", {"want": "A+B"})])
+    objs = [_cm("ba", names=["b", "a"]), _cm("ab7", names=["a", 7, "b"]), _cm("none"), _cm("empty", names=[]), _cm("scalar", names="a,b"), _cm("abc", names=["c", "b", "a"]),
+            _cm("obj", names={"x": "b", "y": "a"})]
+    rv = [D.AugmentedUnstructured(D.Unstructured(o), None, "Original") for o in objs]
+    assert assert_parity(c, oc, rv) == 6
+    got = c.ReviewBatch(rv, D.AUDIT_EP)
+    assert [sorted(r.msg for r in g) for g in got] == [["v1 a,b"], ["v1 a,b"], ["v1 "], ["v1 "], ["v1 "], [], ["v1 a,b"]]
+    c.AddTemplate(_tmpl("KDeep", DEEP2))
+    oc.add_template(_tmpl("KDeep", DEEP2))
+    assert assert_parity(c, oc, rv) == 6
+    got = c.ReviewBatch(rv, D.AUDIT_EP)
+    assert [sorted(r.msg for r in g) for g in got] == [["v2 A+B"], ["v2 A+B"], ["v2 "], ["v2 "], ["v2 "], [], ["v2 A+B"]]
+
+
+FMT_MANY = 'package k\nviolation[{"msg": "m"}] { sprintf("%v%v%v%v", [input.review.name, input.review.namespace, input.review.kind.kind, input.review.kind.group]) == input.parameters.s }\n'
+
+
+def test_formatted_comparison_limits_and_array_concat_of_non_arrays():
+    """(1) a constant that can be cut in too many ways for adjacent verbs is refused, not approximated; (2) array.concat with a
+    non-array constant operand is undefined (the rule body fails), as in OPA"""
+    c, oc = load_both("hostemu", [_tmpl("KFmtMany", FMT_MANY)], [])
+    with pytest.raises(D.UnsupportedError, match="too many ways to cut"):
+        c.AddConstraint(_cons("KFmtMany", "x", {"s": "a" * 40}))
+    c.AddConstraint(_cons("KFmtMany", "short", {"s": "abPod"}))
+    oc.add_constraint(_cons("KFmtMany", "short", {"s": "abPod"}))
+    pods = [{"apiVersion": "v1", "kind": "Pod", "metadata": {"name": n, "namespace": ns}} for n, ns in (("a", "b"), ("ab", ""), ("", "ab"), ("x", "y"))]
+    assert assert_parity(c, oc, [D.AugmentedUnstructured(D.Unstructured(o), None, "Original") for o in pods]) >= 1
+    rego = ('package k\nviolation[{"msg": "never"}] { x := array.concat(input.parameters.notarray, [o | o := input.review.object.spec.names[_]]); count(x) >= 0 }\n'
+            'violation[{"msg": msg}] { x := array.concat(["p"], [o | o := input.review.object.spec.names[_]; o != "skip"]); count(x) > 1; msg := sprintf("%v", [count(x)]) }\n')
+    c2, oc2 = load_both("hostemu", [_tmpl("KConcat", rego)], [_cons("KConcat", "x", {"notarray": "str"})])
+    objs = [_cm("two", names=["a", "b"]), _cm("skip", names=["skip"]), _cm("none"), _cm("one", names=["z"])]
+    assert assert_parity(c2, oc2, [D.AugmentedUnstructured(D.Unstructured(o), None, "Original") for o in objs]) == 2
