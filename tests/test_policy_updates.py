@@ -124,7 +124,8 @@ def test_formatted_comparison_limits_and_array_concat_of_non_arrays():
     pods = [{"apiVersion": "v1", "kind": "Pod", "metadata": {"name": n, "namespace": ns}} for n, ns in (("a", "b"), ("ab", ""), ("", "ab"), ("x", "y"))]
     assert assert_parity(c, oc, [D.AugmentedUnstructured(D.Unstructured(o), None, "Original") for o in pods]) >= 1
     rego = ('package k\nviolation[{"msg": "never"}] { x := array.concat(input.parameters.notarray, [o | o := input.review.object.spec.names[_]]); count(x) >= 0 }\n'
-            'violation[{"msg": msg}] { x := array.concat(["p"], [o | o := input.review.object.spec.names[_]; o != "skip"]); count(x) > 1; msg := sprintf("%v", [count(x)]) }\n')
-    c2, oc2 = load_both("hostemu", [_tmpl("KConcat", rego)], [_cons("KConcat", "x", {"notarray": "str"})])
-    objs = [_cm("two", names=["a", "b"]), _cm("skip", names=["skip"]), _cm("none"), _cm("one", names=["z"])]
-    assert assert_parity(c2, oc2, [D.AugmentedUnstructured(D.Unstructured(o), None, "Original") for o in objs]) == 2
+            'violation[{"msg": "found"}] { x := array.concat(["p"], [o | o := input.review.object.spec.names[_]; o != "skip"]); x[_] == input.parameters.find }\n')
+    c2, oc2 = load_both("hostemu", [_tmpl("KConcat", rego)], [_cons("KConcat", "b", {"notarray": "str", "find": "b"}), _cons("KConcat", "p", {"notarray": 3, "find": "p"}),
+                                                              _cons("KConcat", "skip", {"notarray": {}, "find": "skip"})])
+    objs = [_cm("two", names=["a", "b"]), _cm("skip", names=["skip", "b"]), _cm("none"), _cm("one", names=["z"])]
+    assert assert_parity(c2, oc2, [D.AugmentedUnstructured(D.Unstructured(o), None, "Original") for o in objs]) == 2 + 4
