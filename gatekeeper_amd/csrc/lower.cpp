@@ -426,7 +426,12 @@ static std::string leaf_of_uncached(const FP& f, bool* has_dict) {
   }
 }
 // is the formula false whenever its leaf is absent? (device predicates only fire on rows that exist)
+static bool needs_leaf_uncached(const FP& f);
 bool needs_leaf(const FP& f) {
+  if (f->needs_leaf_state == 0) f->needs_leaf_state = needs_leaf_uncached(f) ? 2 : 1;
+  return f->needs_leaf_state == 2;
+}
+static bool needs_leaf_uncached(const FP& f) {
   switch (f->kind) {
     case FNode::ATOM: return true;
     case FNode::AND: for (auto& k : f->kids) if (needs_leaf(k)) return true; return false;
@@ -608,7 +613,7 @@ FP rename_f(const FP& f, const std::map<int, int>& m) {
       n.kids = std::move(kids);
       n.base = rename_path(n.base, m);
       if (n.q >= 0) { auto it = m.find(n.q); if (it != m.end()) n.q = it->second; }
-      n.canon_set = false; n.canon.clear(); n.leaf_state = 0; n.leaf_text.clear();   // (an edited copy: its text is derived afresh)
+      n.canon_set = false; n.canon.clear(); n.leaf_state = 0; n.needs_leaf_state = 0; n.leaf_text.clear();   // (an edited copy: its text is derived afresh)
       return std::make_shared<const FNode>(n);
     }
   }

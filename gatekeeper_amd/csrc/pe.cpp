@@ -13,7 +13,7 @@ namespace gk {
 
 // ================================================================================================ formulas
 namespace {
-FP mkf(FNode n) { n.canon_set = false; n.canon.clear(); n.leaf_state = 0; n.leaf_text.clear(); return std::make_shared<const FNode>(std::move(n)); }   // (a copy that was edited carries no text)
+FP mkf(FNode n) { n.canon_set = false; n.canon.clear(); n.leaf_state = 0; n.needs_leaf_state = 0; n.leaf_text.clear(); return std::make_shared<const FNode>(std::move(n)); }   // (a copy that was edited carries no text)
 }
 // per-thread singletons: the reference count of a process-wide one would be the hottest cache line of every host thread
 // that renders messages (gk_table_totals, the CPU baseline loop)

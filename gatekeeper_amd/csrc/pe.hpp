@@ -61,6 +61,7 @@ struct FNode {
   // (lower.cpp leaf_of, cached the same way: the leaf of a leaf-local formula, "" = not leaf-local; whether it holds a DICT atom)
   mutable std::string leaf_text;
   mutable int leaf_state = 0;   // 0 unknown, 1 known without a DICT atom, 2 known with one
+  mutable int needs_leaf_state = 0;   // (lower.cpp needs_leaf) 0 unknown, 1 no, 2 yes
 };
 
 FP f_true();
