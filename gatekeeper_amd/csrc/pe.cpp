@@ -17,8 +17,8 @@ FP mkf(FNode n) { n.canon_set = false; n.canon.clear(); n.leaf_state = 0; n.need
 }
 // per-thread singletons: the reference count of a process-wide one would be the hottest cache line of every host thread
 // that renders messages (gk_table_totals, the CPU baseline loop)
-FP f_true() { static thread_local FP t = [] { FNode n; n.kind = FNode::T; return mkf(n); }(); return t; }
-FP f_false() { static thread_local FP f = [] { FNode n; n.kind = FNode::F; return mkf(n); }(); return f; }
+FP f_true() { static thread_local FP t = [] { FNode n; n.kind = FNode::T; return mkf(std::move(n)); }(); return t; }
+FP f_false() { static thread_local FP f = [] { FNode n; n.kind = FNode::F; return mkf(std::move(n)); }(); return f; }
 FP f_and(FP a, FP b) {
   if (a->kind == FNode::F || b->kind == FNode::F) return f_false();
   if (a->kind == FNode::T) return b;
@@ -26,7 +26,7 @@ FP f_and(FP a, FP b) {
   FNode n; n.kind = FNode::AND;
   if (a->kind == FNode::AND) n.kids = a->kids; else n.kids.push_back(a);
   if (b->kind == FNode::AND) n.kids.insert(n.kids.end(), b->kids.begin(), b->kids.end()); else n.kids.push_back(b);
-  return mkf(n);
+  return mkf(std::move(n));
 }
 FP f_or(FP a, FP b) {
   if (a->kind == FNode::T || b->kind == FNode::T) return f_true();
@@ -35,25 +35,25 @@ FP f_or(FP a, FP b) {
   FNode n; n.kind = FNode::OR;
   if (a->kind == FNode::OR) n.kids = a->kids; else n.kids.push_back(a);
   if (b->kind == FNode::OR) n.kids.insert(n.kids.end(), b->kids.begin(), b->kids.end()); else n.kids.push_back(b);
-  return mkf(n);
+  return mkf(std::move(n));
 }
 FP f_not(FP a) {
   if (a->kind == FNode::T) return f_false();
   if (a->kind == FNode::F) return f_true();
   if (a->kind == FNode::NOT) return a->kids[0];
   FNode n; n.kind = FNode::NOT; n.kids = {a};
-  return mkf(n);
+  return mkf(std::move(n));
 }
-FP f_atom(const Atom& a) { FNode n; n.kind = FNode::ATOM; n.atom = a; return mkf(n); }
+FP f_atom(const Atom& a) { FNode n; n.kind = FNode::ATOM; n.atom = a; return mkf(std::move(n)); }
 FP f_exists(int q, const SPath& base, FP body) {
   if (body->kind == FNode::F) return f_false();
   FNode n; n.kind = FNode::EXISTS; n.q = q; n.base = base; n.kids = {body};
-  return mkf(n);
+  return mkf(std::move(n));
 }
 FP f_exists2(int q, const SPath& base, FP body) {
   if (body->kind == FNode::F) return f_false();
   FNode n; n.kind = FNode::EXISTS; n.q = q; n.base = base; n.two = true; n.kids = {body};
-  return mkf(n);
+  return mkf(std::move(n));
 }
 FP f_exists_like(const FNode& proto, FP body) { return proto.two ? f_exists2(proto.q, proto.base, body) : f_exists(proto.q, proto.base, body); }
 FP f_all(const std::vector<FP>& v) { FP r = f_true(); for (auto& x : v) r = f_and(r, x); return r; }
@@ -198,7 +198,7 @@ FP rn_f(const FP& f, const QMap& m) {
       n.kids = std::move(kids);
       n.base = rn_path(n.base, m);
       if (n.q >= 0) { auto it = m.find(n.q); if (it != m.end()) n.q = it->second; }
-      return mkf(n);
+      return mkf(std::move(n));
     }
   }
 }
