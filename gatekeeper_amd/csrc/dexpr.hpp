@@ -49,6 +49,7 @@ struct DxUserFns { std::shared_mutex mu; std::map<std::string, DxUserFn> fns; };
 inline DxUserFns& dx_user_fns() { static DxUserFns r; return r; }
 inline bool dx_is_user(const std::string& name) { return name.compare(0, 3, "$u:") == 0; }
 inline void dx_register_user(const std::string& name, DxUserFn fn) { DxUserFns& r = dx_user_fns(); std::unique_lock<std::shared_mutex> l(r.mu); r.fns[name] = std::move(fn); }
+inline void dx_unregister_user(const std::string& name) { DxUserFns& r = dx_user_fns(); std::unique_lock<std::shared_mutex> l(r.mu); r.fns.erase(name); }
 inline Value dx_call_user(const std::string& name, const ValueVec& args) {
   DxUserFn fn;
   { DxUserFns& r = dx_user_fns(); std::shared_lock<std::shared_mutex> l(r.mu); auto it = r.fns.find(name); if (it == r.fns.end()) return Value(); fn = it->second; }

@@ -1495,8 +1495,14 @@ class PE {
     snprintf(idbuf, sizeof idbuf, "%llx", (unsigned long long)(uintptr_t)keep.get());
     const std::string fn_name = std::string("$u:") + idbuf + ":" + pkg + "." + name + "/" + std::to_string(args.size());
     const std::string fpkg = pkg, fname = name;
-    dx_register_user(fn_name, [keep, fpkg, fname](const ValueVec& av) -> Value {
+    // (the closure must not keep the template alive -- the registry outlives every engine --: a weak reference; the template's
+    //  destructor takes the entry out again, and an expression of a template that is gone answers "undefined")
+    const std::weak_ptr<const Template> weak = keep;
+    if (std::find(T.deep_fns_.begin(), T.deep_fns_.end(), fn_name) == T.deep_fns_.end()) T.deep_fns_.push_back(fn_name);
+    dx_register_user(fn_name, [weak, fpkg, fname](const ValueVec& av) -> Value {
       try {
+        std::shared_ptr<const Template> keep = weak.lock();
+        if (!keep) return Value();
         int nq = 0;
         PE pe(*keep, Value::object({}), sv_const(Value::object({})), Value(), true, &nq);
         pe.index_rules();
@@ -1833,6 +1839,7 @@ FP PE::is_string_f(const SVP& v) {
 }
 
 // ================================================================================================ Template
+Template::~Template() { for (const std::string& n : deep_fns_) dx_unregister_user(n); }
 Template::Template(const std::string& rego, const std::vector<std::string>& libs) {
   modules_.push_back(parse_rego(rego));
   for (auto& l : libs) {

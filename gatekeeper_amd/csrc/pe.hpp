@@ -131,6 +131,7 @@ class Template : public std::enable_shared_from_this<Template> {
   std::vector<Violation> render(const Value& review, const Value& parameters, const Value& inventory) const;
 
   bool references_inventory() const { return uses_data_; }
+  ~Template();   // drops the deep-expression closures registered for this template (dexpr.hpp)
 
  private:
   friend class PE;
@@ -138,6 +139,7 @@ class Template : public std::enable_shared_from_this<Template> {
   std::map<std::pair<std::string, std::string>, std::vector<const Rule*>> rules_;   // (pkg, name)
   std::string pkg_name_;
   bool uses_data_ = false;
+  mutable std::vector<std::string> deep_fns_;   // names under which closures over this template sit in the deep-expression registry
 };
 
 }  // namespace gk
