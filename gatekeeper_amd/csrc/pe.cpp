@@ -905,9 +905,9 @@ class PE {
     if (find_rules(rule_pkg(r), name)) return true;
     return import_of(r, name) != nullptr;
   }
-  std::string rule_pkg(const Rule* r) { return rule_pkgs_.at(r); }
+  const std::string& rule_pkg(const Rule* r) { return T.rule_pkgs_.at(r); }
   const std::vector<std::string>* import_of(const Rule* r, const std::string& alias) {
-    const Module* m = rule_mods_.at(r);
+    const Module* m = T.rule_mods_.at(r);
     for (auto& im : m->imports) if (im.second == alias && im.first.size() > 1) return &im.first;
     return nullptr;
   }
@@ -1753,17 +1753,8 @@ class PE {
     unsupported("builtin " + name + " applied to review data", line);
   }
 
-  std::map<const Rule*, std::string> rule_pkgs_;
-  std::map<const Rule*, const Module*> rule_mods_;
-
  public:
-  void index_rules() {
-    for (const Module& m : T.modules_) {
-      std::string pkg;
-      for (size_t i = 0; i < m.package.size(); i++) { if (i) pkg += "."; pkg += m.package[i]; }
-      for (const Rule& r : m.rules) { rule_pkgs_[&r] = pkg; rule_mods_[&r] = &m; }
-    }
-  }
+  void index_rules() {}   // (the rule -> package / module index lives in the Template: built once, not per evaluation)
 };
 
 FP PE::defined_f(const SVP& v) {
@@ -1851,7 +1842,7 @@ Template::Template(const std::string& rego, const std::vector<std::string>& libs
     std::string pkg;
     for (size_t i = 0; i < m.package.size(); i++) { if (i) pkg += "."; pkg += m.package[i]; }
     if (&m == &modules_[0]) pkg_name_ = pkg;
-    for (const Rule& r : m.rules) rules_[{pkg, r.name}].push_back(&r);
+    for (const Rule& r : m.rules) { rules_[{pkg, r.name}].push_back(&r); rule_pkgs_[&r] = pkg; rule_mods_[&r] = &m; }
   }
   if (!rules_.count({pkg_name_, "violation"})) throw RegoError("invalid rego: missing required rule violation");
   // static safety check + data usage scan

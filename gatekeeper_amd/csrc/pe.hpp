@@ -138,6 +138,8 @@ class Template : public std::enable_shared_from_this<Template> {
   std::vector<Module> modules_;
   std::map<std::pair<std::string, std::string>, std::vector<const Rule*>> rules_;   // (pkg, name)
   std::string pkg_name_;
+  std::map<const Rule*, std::string> rule_pkgs_;        // rule -> its package / module (what every evaluation used to rebuild)
+  std::map<const Rule*, const Module*> rule_mods_;
   bool uses_data_ = false;
   mutable std::vector<std::string> deep_fns_;   // names under which closures over this template sit in the deep-expression registry
 };
