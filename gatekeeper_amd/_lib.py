@@ -106,7 +106,7 @@ HE_ALLREDUCE = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_longlong), C.c_uint64
 
 class gk_spool_info(C.Structure):
     _fields_ = [("n_files", C.c_uint64), ("n_reviews", C.c_uint64), ("n_unreadable", C.c_uint64), ("n_namespace_missing", C.c_uint64), ("bytes", C.c_uint64),
-                ("names", C.POINTER(C.c_char_p))]
+                ("names", C.POINTER(C.c_char_p)), ("n_folders_missing", C.c_uint64)]
 
 
 class gk_batch_opts(C.Structure):

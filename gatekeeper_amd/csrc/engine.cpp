@@ -1275,7 +1275,7 @@ int gk_table_create_spool(gk_engine* e, const char* api_cache_dir, const char* k
       if (DIR* d = opendir(dir.c_str())) {
         while (dirent* de = readdir(d)) { if (de->d_name[0] != '.') files.emplace_back(de->d_name); }
         closedir(d);
-      }   // (a folder that cannot be opened: "Unable to get files from directory", the loop goes on)
+      } else h->pub.n_folders_missing++;   // (a folder that cannot be opened: "Unable to get files from directory", the loop goes on)
       std::sort(files.begin(), files.end(), [](const std::string& a, const std::string& b) { return a.size() != b.size() ? a.size() < b.size() : a < b; });
       for (const std::string& fn : files) {
         h->pub.n_files++;

@@ -467,6 +467,7 @@ class Engine:
         o = info.contents
         n = int(o.n_reviews)
         d = {"n_files": int(o.n_files), "n_reviews": n, "n_unreadable": int(o.n_unreadable), "n_namespace_missing": int(o.n_namespace_missing),
+             "n_folders_missing": int(o.n_folders_missing),
              "bytes": int(o.bytes), "names": [o.names[i].decode() for i in range(n)]}
         self.lib.gk_spool_info_free(info)
         return Table(self, h, [L.GK_OK] * n, n), d

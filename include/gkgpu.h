@@ -129,11 +129,13 @@ int gk_table_get_stats(const gk_table* t, gk_table_stats* out);
  * of `api_cache_dir` (files of a folder in numeric order of their names), attaches to every object the Namespace synced
  * through gk_data_put (Driver.AddData) for its metadata.namespace, and builds ONE table of them (flags as gk_table_create).
  * A file that cannot be read or is not a JSON object, and an object whose Namespace is not in the cache, is skipped and
- * counted -- the reference logs the error and continues with the next file (manager.go:688-704).
+ * counted -- the reference logs the error and continues with the next file (manager.go:688-704); so is a folder that cannot
+ * be opened ("Unable to get files from directory", manager.go:680-684: getFilesFromDir's error is logged, the loop goes on).
  * info->names[i] = "<Kind>_<folder>/<index>" of review i. */
 typedef struct {
   uint64_t n_files, n_reviews, n_unreadable, n_namespace_missing, bytes;
   const char* const* names;   /* [n_reviews] */
+  uint64_t n_folders_missing;  /* folders <kind>_<i>, i < folders, that do not exist / cannot be opened */
 } gk_spool_info;
 int gk_table_create_spool(gk_engine* e, const char* api_cache_dir, const char* kind, uint32_t folders, uint32_t flags,
                           gk_spool_info** info, gk_table** out);

@@ -66,3 +66,36 @@ def test_spooled_objects_are_reviewed_like_review_objects(backend, fixtures, tmp
         assert n_results > 100
     finally:
         table.free()
+
+
+def test_spool_directory_cases_of_the_reference(fixtures, tmp_path):
+    """pkg/audit/manager_test.go:511-557 (Test_getFilesFromDir): a directory that does not exist is an error of getFilesFromDir --
+    which reviewObjects LOGS before going on with the next folder (manager.go:680-684): counted, not fatal --, an empty one yields
+    no files, one with 15 files yields all 15 (whatever the batch size)"""
+    c, _ = load_both("hostemu", synth.psp_templates(fixtures), synth.audit_constraints())
+    eng = c.driver.engine
+    for root, folders in ((str(tmp_path / "does" / "not" / "exist"), 1), (str(tmp_path), 3)):
+        table, info = eng.create_table_spool(root, "Pod", folders)
+        try:
+            assert info["n_folders_missing"] == folders and info["n_files"] == 0 and info["n_reviews"] == 0 and info["names"] == []
+        finally:
+            table.free()
+    os.mkdir(str(tmp_path / "Pod_0"))
+    table, info = eng.create_table_spool(str(tmp_path), "Pod", 1)
+    try:
+        assert info["n_folders_missing"] == 0 and info["n_files"] == 0 and info["n_reviews"] == 0 and info["names"] == []
+    finally:
+        table.free()
+    pods = [o for o in synth.gen_objects(80, seed=2, mixed=True) if o["kind"] == "Pod"][:15]
+    nss = synth.gen_namespaces()
+    for p in pods:
+        c.AddData(nss[p["metadata"]["namespace"]])
+    for i, p in enumerate(pods):
+        with open(str(tmp_path / "Pod_0" / ("%d" % i)), "w") as fh:
+            json.dump(p, fh)
+    table, info = eng.create_table_spool(str(tmp_path), "Pod", 2)          # (Pod_1 was never written: one folder missing)
+    try:
+        assert info["n_files"] == 15 and info["n_reviews"] == 15 and info["n_unreadable"] == 0 and info["n_folders_missing"] == 1
+        assert info["names"] == ["Pod_0/%d" % i for i in range(15)]
+    finally:
+        table.free()
