@@ -835,3 +835,31 @@ def test_member_names_and_objects_where_arrays_are_iterated(backend, fixtures):
         assert isinstance(g, D.ReviewFailure) and isinstance(g.cause, D.LimitError), p["metadata"]["name"]
         assert len(oc.review(to_oracle_review(wrap(p)), D.AUDIT_EP, None)) == 1      # what Rego says: a violation
     assert not isinstance(got[-1], Exception) and not isinstance(got[-2], Exception)
+
+
+OPERATION_REGO = '''package k
+violation[{"msg": msg}] {
+  op := object.get(input.review, "operation", "<none>")
+  has_obj := object.get(input.review, "object", null) != null
+  has_old := object.get(input.review, "oldObject", null) != null
+  msg := sprintf("op=%v object=%v oldObject=%v", [op, has_obj, has_old])
+}
+'''
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_augmented_unstructured_operation_and_delete(backend):
+    """pkg/target/target_test.go:1218-1286 (TestAugmentedUnstructuredDeleteUsesOldObject / ...NonDeletePreservesObject): CREATE,
+    UPDATE and a missing operation are preserved with the object in `object` and no oldObject; DELETE carries the object as
+    oldObject, and HandleReview's setObjectOnDelete (target.go:269-287) then shows it as `object` too"""
+    tmpl = {"apiVersion": "templates.gatekeeper.sh/v1", "kind": "ConstraintTemplate", "metadata": {"name": "k8sop"},
+            "spec": {"crd": {"spec": {"names": {"kind": "K8sOp"}}}, "targets": [{"target": "admission.k8s.gatekeeper.sh", "rego": OPERATION_REGO}]}}
+    con = {"apiVersion": "constraints.gatekeeper.sh/v1beta1", "kind": "K8sOp", "metadata": {"name": "x"}, "spec": {}}
+    c, oc = load_both(backend, [tmpl], [con])
+    thing = {"apiVersion": "some/v1", "kind": "Thing", "metadata": {"name": "foo"}}
+    want = {"CREATE": "op=CREATE object=true oldObject=false", "UPDATE": "op=UPDATE object=true oldObject=false", "": "op= object=true oldObject=false",   # (AdmissionRequest.Operation has no omitempty: an empty string, not absent)
+            "DELETE": "op=DELETE object=true oldObject=true"}
+    rv = [D.AugmentedUnstructured(D.Unstructured(thing), None, "Original", op) for op in want]
+    assert assert_parity(c, oc, rv) == 4
+    got = c.ReviewBatch(rv, D.AUDIT_EP)
+    assert [[r.msg for r in g] for g in got] == [[m] for m in want.values()]
