@@ -181,6 +181,65 @@ def _valid_label_key(k):
     return name != "" and len(name) <= 63 and bool(_QNAME_RE.match(name))
 
 
+def check_matcher(constraint):
+    """K8sValidationTarget.ToMatcher (pkg/target/target.go:246-261; target_test.go:562-655): spec.match must be a map whose fields
+    convert into the typed match.Match (pkg/mutation/match/match.go:32-78) -- strings where it has strings, lists of strings,
+    label selectors of the metav1 shape; unknown fields are ignored, null is the zero value.  Run by Client.AddConstraint
+    whether or not the constraint is validated (ToMatcher is not part of ValidateConstraint).  Raises ClientError."""
+    spec = constraint.get("spec")
+    mt = spec.get("match") if isinstance(spec, dict) else None
+    if mt is None:
+        return
+    if not isinstance(mt, dict):
+        raise ClientError("unable to create matcher: spec.match is %s, not a map" % type(mt).__name__)
+    strings, string_lists, selectors = ("source", "scope", "name"), ("namespaces", "excludedNamespaces"), ("labelSelector", "namespaceSelector")
+
+    def bad(what, want):
+        raise ClientError("unable to create matcher: spec.match.%s must be %s" % (what, want))
+
+    def str_list(v, what):
+        if v is not None and not (isinstance(v, list) and all(x is None or isinstance(x, str) for x in v)):
+            bad(what, "a list of strings")
+    for f in strings:
+        if mt.get(f) is not None and not isinstance(mt[f], str):
+            bad(f, "a string")
+    for f in string_lists:
+        str_list(mt.get(f), f)
+    kinds = mt.get("kinds")
+    if kinds is not None:
+        if not isinstance(kinds, list):
+            bad("kinds", "a list")
+        for i, k in enumerate(kinds):
+            if k is None:
+                continue
+            if not isinstance(k, dict):
+                bad("kinds[%d]" % i, "a map")
+            str_list(k.get("apiGroups"), "kinds[%d].apiGroups" % i)
+            str_list(k.get("kinds"), "kinds[%d].kinds" % i)
+    for f in selectors:
+        sel = mt.get(f)
+        if sel is None:
+            continue
+        if not isinstance(sel, dict):
+            bad(f, "a map")
+        ml = sel.get("matchLabels")
+        if ml is not None and not (isinstance(ml, dict) and all(v is None or isinstance(v, str) for v in ml.values())):
+            bad(f + ".matchLabels", "a map of strings")
+        me = sel.get("matchExpressions")
+        if me is not None:
+            if not isinstance(me, list):
+                bad(f + ".matchExpressions", "a list")
+            for i, e in enumerate(me):
+                if e is None:
+                    continue
+                if not isinstance(e, dict):
+                    bad("%s.matchExpressions[%d]" % (f, i), "a map")
+                for key in ("key", "operator"):
+                    if e.get(key) is not None and not isinstance(e[key], str):
+                        bad("%s.matchExpressions[%d].%s" % (f, i, key), "a string")
+                str_list(e.get("values"), "%s.matchExpressions[%d].values" % (f, i))
+
+
 def validate_constraint(constraint):
     """K8sValidationTarget.ValidateConstraint (pkg/target/target.go:185-219), run by Client.AddConstraint as the
     frameworks client does: spec.match.labelSelector / namespaceSelector must be maps that decode into a
@@ -849,6 +908,7 @@ class Client:
             raise ClientError("missing ConstraintTemplate: %s" % kind)   # ErrMissingConstraintTemplate
         if validate:
             validate_constraint(c)   # the target handler's check (target.go:185-219); validate=False: Match-layer error-path tests
+        check_matcher(c)             # ToMatcher (target.go:246-261): always
         c = apply_schema_defaults(self.templates[kind.lower()], c)
         self.driver.AddConstraint(c)
         self.constraints[(kind, (c.get("metadata") or {}).get("name", ""))] = c

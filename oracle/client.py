@@ -269,7 +269,11 @@ class Client:
                 raise ClientError(str(e))
         name = (c.get("metadata") or {}).get("name", "")
         c = apply_schema_defaults(self.templates[kind.lower()], c)
-        self.constraints[(kind, name)] = (c, t.to_matcher(c, self.cache))
+        try:
+            matcher = t.to_matcher(c, self.cache)      # (always: ToMatcher is not part of ValidateConstraint)
+        except t.ReviewError as e:
+            raise ClientError(str(e))
+        self.constraints[(kind, name)] = (c, matcher)
 
     def remove_constraint(self, c):
         self.constraints.pop((c.get("kind", ""), (c.get("metadata") or {}).get("name", "")), None)

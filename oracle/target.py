@@ -252,13 +252,60 @@ def validate_constraint(constraint: dict):
             raise ReviewError("spec.labelSelector: %s" % e)
 
 
+ERR_CREATING_MATCHER = "unable to create matcher"   # target.go ErrCreatingMatcher
+
+# The typed shape of spec.match (pkg/mutation/match/match.go:32-65 Match, :67-78 Kinds; metav1.LabelSelector / LabelSelectorRequirement)
+# as runtime.DefaultUnstructuredConverter.FromUnstructured sees it (target.go:253 convertToMatch): a field of the wrong JSON type is
+# an error, an unknown field is ignored, null is the zero value.
+_SELECTOR = ("struct", {"matchLabels": ("map", "str"), "matchExpressions": ("list", ("struct", {"key": "str", "operator": "str", "values": ("list", "str")}))})
+_MATCH_SHAPE = ("struct", {"source": "str", "scope": "str", "name": "str", "namespaces": ("list", "str"), "excludedNamespaces": ("list", "str"),
+                           "kinds": ("list", ("struct", {"apiGroups": ("list", "str"), "kinds": ("list", "str")})),
+                           "labelSelector": _SELECTOR, "namespaceSelector": _SELECTOR})
+
+
+def _shape_error(v, shape, where):
+    """None, or why `v` does not convert into the typed field"""
+    if v is None:
+        return None
+    if shape == "str":
+        return None if isinstance(v, str) else "%s: expected string, got %s" % (where, type(v).__name__)
+    kind, inner = shape
+    if kind == "list":
+        if not isinstance(v, list):
+            return "%s: expected list, got %s" % (where, type(v).__name__)
+        for i, x in enumerate(v):
+            e = _shape_error(x, inner, "%s[%d]" % (where, i))
+            if e:
+                return e
+        return None
+    if not isinstance(v, dict):
+        return "%s: expected map, got %s" % (where, type(v).__name__)
+    if kind == "map":
+        for k, x in v.items():
+            e = _shape_error(x, inner, "%s.%s" % (where, k))
+            if e:
+                return e
+        return None
+    for k, sub in inner.items():
+        e = _shape_error(v.get(k), sub, "%s.%s" % (where, k))
+        if e:
+            return e
+    return None
+
+
 def to_matcher(constraint: dict, cache: NsCache) -> Matcher:
-    """target.go:246-261: spec.match absent/null => match-everything Matcher."""
+    """target.go:246-261 (pinned by target_test.go:562-655 TestToMatcher): spec.match absent => match-everything Matcher; a
+    spec.match that is not a map, or whose fields do not convert into match.Match, is ErrCreatingMatcher."""
     spec = constraint.get("spec")
     mt = spec.get("match") if isinstance(spec, dict) else None
-    if isinstance(mt, dict):
-        return Matcher(mt, cache)
-    return Matcher(None, cache)
+    if mt is None:
+        return Matcher(None, cache)
+    if not isinstance(mt, dict):
+        raise ReviewError("%s: .spec.match accessor error: %r is of the type %s, expected map[string]interface{}" % (ERR_CREATING_MATCHER, mt, type(mt).__name__))
+    err = _shape_error(mt, _MATCH_SHAPE, "spec.match")
+    if err:
+        raise ReviewError("%s: %s" % (ERR_CREATING_MATCHER, err))
+    return Matcher(mt, cache)
 
 
 def review_input_json(review: GkReview, namespace_obj=None) -> dict:

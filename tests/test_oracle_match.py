@@ -222,3 +222,34 @@ def test_enforcement_action_tables():
         assert f(AUDIT, {"spec": {}}) == []
         with pytest.raises(mod.ClientError):
             f(AUDIT, {"spec": {"scopedEnforcementActions": "invalid"}})
+
+
+def test_to_matcher_rows():
+    """pkg/target/target_test.go:562-655 (TestToMatcher): no match fields -> a matcher of everything; fooConstraint's match fields ->
+    a matcher; spec.match of the wrong type (3.0) and a match FIELD of the wrong type (kinds: 3.0) -> ErrCreatingMatcher.  Oracle and
+    product mirror (driver.check_matcher) refuse the same constraints, validated or not (ToMatcher is not ValidateConstraint)."""
+    from gatekeeper_amd import driver as D
+    from oracle import client as OC
+    foo = {"kinds": [{"apiGroups": ["some"], "kinds": ["Thing"]}], "scope": "Namespaced", "namespaces": ["my-ns"],
+           "labelSelector": {"matchLabels": {"obj": "label"}}, "namespaceSelector": {"matchLabels": {"ns": "label"}}, "source": "All"}
+    rows = [("no match fields", None, True), ("match fields", foo, True), ("invalid Match type", 3.0, False), ("invalid Match field type", {"kinds": 3.0}, False),
+            # the same converter refuses every other wrongly typed field; unknown fields are ignored, null is the zero value
+            ("namespaces not a list", {"namespaces": "my-ns"}, False), ("kind entry not a map", {"kinds": ["Thing"]}, False), ("apiGroups of numbers", {"kinds": [{"apiGroups": [1]}]}, False),
+            ("matchLabels value not a string", {"labelSelector": {"matchLabels": {"a": 1}}}, False), ("expression values not a list", {"namespaceSelector": {"matchExpressions": [{"key": "a", "operator": "In", "values": "x"}]}}, False),
+            ("scope a number", {"scope": 1}, False), ("unknown field", {"nonesuch": 3.0}, True), ("null fields", {"kinds": None, "labelSelector": None, "name": None}, True)]
+    tmpl = {"apiVersion": "templates.gatekeeper.sh/v1", "kind": "ConstraintTemplate", "metadata": {"name": "k8sx"},
+            "spec": {"crd": {"spec": {"names": {"kind": "K8sX"}}}, "targets": [{"target": "admission.k8s.gatekeeper.sh", "rego": 'package k\nviolation[{"msg": "m"}] { true }\n'}]}}
+    for name, match, ok in rows:
+        con = {"apiVersion": "constraints.gatekeeper.sh/v1beta1", "kind": "K8sX", "metadata": {"name": "x"}, "spec": ({"match": match} if match is not None else {})}
+        if ok:
+            tg.to_matcher(con, tg.NsCache())
+            D.check_matcher(con)
+        else:
+            with pytest.raises(tg.ReviewError, match=tg.ERR_CREATING_MATCHER):
+                tg.to_matcher(con, tg.NsCache())
+            with pytest.raises(D.ClientError, match="unable to create matcher"):
+                D.check_matcher(con)
+            oc = OC.Client()
+            oc.add_template(tmpl)
+            with pytest.raises(OC.ClientError):
+                oc.add_constraint(con, validate=False)
