@@ -253,3 +253,40 @@ def test_to_matcher_rows():
             oc.add_template(tmpl)
             with pytest.raises(OC.ClientError):
                 oc.add_constraint(con, validate=False)
+
+
+def test_constraint_validation_rows():
+    """pkg/webhook/policy_test.go:686-802 (TestConstraintValidation) with the constraints of :49-139: a label / namespace selector
+    whose `In` expression has no values is refused, the same with values is accepted, by the oracle's and the product mirror's
+    AddConstraint alike.  (The sixth pair, enforcementAction "test", is refused by the webhook's validation of Constraint RESOURCES --
+    policy.go validateGatekeeperResources, control plane -- not by the client's AddConstraint: out of this path.)"""
+    from gatekeeper_amd import driver as D
+    from oracle import client as OC
+    tmpl = {"apiVersion": "templates.gatekeeper.sh/v1", "kind": "ConstraintTemplate", "metadata": {"name": "k8sgoodrego"},
+            "spec": {"crd": {"spec": {"names": {"kind": "K8sGoodRego"}}}, "targets": [{"target": "admission.k8s.gatekeeper.sh", "rego": 'package k\nviolation[{"msg": "m"}] { true }\n'}]}}
+
+    def con(name, match, ea=None):
+        spec = {"match": match}
+        if ea:
+            spec["enforcementAction"] = ea
+        return {"apiVersion": "constraints.gatekeeper.sh/v1beta1", "kind": "K8sGoodRego", "metadata": {"name": name}, "spec": spec}
+    ns_k, pod_k = [{"apiGroups": [""], "kinds": ["Namespace"]}], [{"apiGroups": [""], "kinds": ["Pod"]}]
+    good, bad = [{"operator": "In", "key": "something", "values": ["anything"]}], [{"operator": "In", "key": "something"}]
+    rows = [(con("good-labelselector", {"kinds": ns_k, "labelSelector": {"matchExpressions": good}}), False),
+            (con("bad-labelselector", {"kinds": ns_k, "labelSelector": {"matchExpressions": bad}}), True),
+            (con("good-namespaceselector", {"kinds": pod_k, "namespaceSelector": {"matchExpressions": good}}), False),
+            (con("bad-namespaceselector", {"kinds": pod_k, "namespaceSelector": {"matchExpressions": bad}}), True),
+            (con("good-enforcementaction", {"kinds": pod_k}, "dryrun"), False)]
+    for k, want_err in rows:
+        oc = OC.Client()
+        oc.add_template(tmpl)
+        pc = D.Client(D.Driver(hostemu=True))
+        pc.AddTemplate(tmpl)
+        if want_err:
+            with pytest.raises(OC.ClientError):
+                oc.add_constraint(k)
+            with pytest.raises(D.ClientError):
+                pc.AddConstraint(k)
+        else:
+            oc.add_constraint(k)
+            pc.AddConstraint(k)
