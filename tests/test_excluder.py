@@ -174,3 +174,19 @@ def test_resident_audit_honours_config_changes(backend, fixtures):
     assert s_all == 0 and s_ex > 40 and n_ex < n_all and sw["flattened"] == 0    # a Config change re-flattens nothing
     n_back, _, sw2 = compare(None)
     assert n_back == n_all and sw2["flattened"] == 0
+
+
+def test_review_default_ns_row():
+    """pkg/webhook/policy_test.go:512-583 (TestReviewDefaultNS): Config match {excludedNamespaces: ["default"], processes: ["*"]};
+    a Pod whose own metadata.namespace is "" arrives with request.namespace "default" -> the webhook allows it without a review
+    (the request's namespace decides, `*` covers the webhook process)"""
+    entries = [{"excludedNamespaces": ["default"], "processes": ["*"]}]
+    ox = OX.Excluder(entries)
+    c = make_client("hostemu")
+    c.SetExcluder(entries)
+    req = {"uid": "u", "kind": {"group": "", "version": "v1", "kind": "Pod"}, "userInfo": {}, "operation": "CREATE", "namespace": "default",
+           "object": {"apiVersion": "v1", "kind": "Pod", "metadata": {"name": "acbd", "namespace": ""}}}
+    assert ox.webhook_skips("webhook", req) is True
+    assert c.IsNamespaceExcluded("webhook", D.AdmissionRequest(req)) is True
+    other = dict(req, namespace="kube-public")
+    assert ox.webhook_skips("webhook", other) is False and c.IsNamespaceExcluded("webhook", D.AdmissionRequest(other)) is False
