@@ -74,22 +74,27 @@ def cpu_leg(templates, constraints, batch, ev, budget_s=10.0):
     return base, parity
 
 
-def python_oracle_leg(templates, constraints, batch, ev, n=16384):
+def oracle_pairs_of(templates, constraints, batch, n):
+    """(viol pairs, err pairs, seconds, processes) of the pure-Python oracle over the first n objects of `batch` (JSON text)"""
+    from oracle import bench_leg as BL
+    texts = [(batch.json_text(i), batch.namespace_text(i)) for i in range(n)]
+    return BL.python_oracle_pairs(templates, constraints, texts)
+
+
+def python_oracle_leg(templates, constraints, batch, ev, n=16384, ids=None, oracle=None):
     """The INDEPENDENT full-size parity leg: the pure-Python oracle (oracle/client.py -- its own JSON reader, HandleReview,
     Match layer and Rego interpreter, no code shared with the product) evaluates the first `n` of the timed objects, taken as
     JSON text from the batch, and its (constraint, object) pair sets must equal the device's violation and autoreject bitmaps."""
     import numpy as np
-    from oracle import bench_leg as BL
     n = min(n, batch.n)
     n = n // 64 * 64 or n
-    texts = [(batch.json_text(i), batch.namespace_text(i)) for i in range(n)]
-    viol, err, seconds, procs = BL.python_oracle_pairs(templates, constraints, texts)
+    viol, err, seconds, procs = oracle if oracle is not None else oracle_pairs_of(templates, constraints, batch, n)
     row_of = {int(cid): i for i, cid in enumerate(ev.constraint_ids)}
     words = (n + 63) // 64
 
     def dev_pairs(bm):
         out = set()
-        for row, cid in enumerate(batch_constraint_ids):
+        for row, cid in enumerate(ids if ids is not None else batch_constraint_ids):
             bits = np.unpackbits(bm[row_of[cid]][:words].view(np.uint8), bitorder="little")[:n]
             out.update((row, int(i)) for i in np.nonzero(bits)[0])
         return out
@@ -102,7 +107,7 @@ def python_oracle_leg(templates, constraints, batch, ev, n=16384):
                        "tree-walking Rego interpreter); shares no code with the product"}
 
 
-def stream_leg(args, drv, client, templates, constraints, nss, rank, world, dev, dist):
+def stream_leg(args, drv, client, templates, constraints, nss, rank, world, dev, dist, keep_first=None):
     """configs[4]: STREAMING admission -- the offered load arrives in batches of `--batch` reviews (JSON text); a rank takes the
     batches  k = rank (mod world)  (round robin over the GPUs, no collective) and runs each through
         ingest (JSON -> rows on the host threads) -> H2D + device assembly -> launch(es) -> D2H of the bitmaps
@@ -138,6 +143,8 @@ def stream_leg(args, drv, client, templates, constraints, nss, rank, world, dev,
                 ev = table.eval(download=True)
                 t_dev1 = time.perf_counter()
                 st = table.stats()
+                if k == 0 and keep_first is not None:      # (objects [0, batch) of the global stream: the parity leg's objects)
+                    keep_first.append(ev)
                 done.append({"k": k, "arrival": arrival, "ingest_s": t_ingest1 - t_ingest0, "flatten_s": st["flatten_s"], "h2d_s": st["upload_s"],
                              "device_s": t_dev1 - t_dev0, "kernel_ms": float(ev.kernel_ms), "fast_kernel_ms": float(ev.fast_kernel_ms),
                              "complete": t_dev1, "pairs": int(ev.counts.sum()), "too_big": len(ev.too_big_reviews()),
@@ -209,12 +216,168 @@ def stream_leg(args, drv, client, templates, constraints, nss, rank, world, dev,
 batch_constraint_ids = []
 
 
+def _sig(x, digits=4):
+    return float("%.*g" % (digits, x)) if x is not None else None
+
+
+def side_point(config, reviews, steps, warmup, oracle_n, dev_index, fx, nss, with_stream=False, stream_args=None, dev=None):
+    """One more BASELINE config measured the way the headline one is -- its own engine, policy set and resident table --
+    for the `other_configs` of the default bench line: `steps` sweeps of the table in HBM between two synchronisations,
+    the dominant kernel's duration from per-launch HIP events, and (oracle_n > 0) the INDEPENDENT parity leg: the device
+    bitmaps of THAT table (the bench's row-group geometry, plan groups and streams) against the pure-Python oracle on the
+    first `oracle_n` objects, taken as JSON text.  with_stream: the same engine then runs configs[4]'s STREAM (stream_leg)
+    and the bitmaps of its first batch -- the same objects -- are checked against the same oracle pairs.
+    Reference shape being replaced: the serial audit loop, /root/reference/pkg/audit/manager.go:591-642."""
+    import torch
+    from gatekeeper_amd import driver as D
+    from gatekeeper_amd import synth
+    templates = synth.psp_templates(fx)
+    constraints = synth.psp_constraints() if config == 1 else synth.audit_constraints()
+    if config == 4:
+        templates, constraints = synth.corpus(fx)
+    t_pol = time.perf_counter()
+    drv = D.Driver(device=dev_index, hostemu=False)
+    client = D.Client(drv)
+    for t in templates:
+        client.AddTemplate(t)
+    for k in constraints:
+        client.AddConstraint(k)
+    t_pol = time.perf_counter() - t_pol
+    defaulted = [client.constraints[(k["kind"], k["metadata"]["name"])] for k in constraints]
+    ids = [drv.constraint_id(c) for c in defaulted]
+    nc = len(constraints)
+    t_gen = time.perf_counter()
+    batch = synth.NativeBatch(drv.engine.lib, reviews, seed=synth.SEED, mixed=(config != 1), start=0, namespaces=nss)
+    t_gen = time.perf_counter() - t_gen
+    table = drv.engine.create_table_native(batch.reviews, reviews, keep_docs=False, resident=True)
+    st = table.stats()
+
+    def local(k, download=False):
+        for _ in range(k):
+            table.launch()
+        return table.eval(download=download, collect_only=True)
+    t_first = time.perf_counter()
+    local(1)                                   # (plan upload, hiprtc builds of every plan group, binding)
+    t_first = time.perf_counter() - t_first
+    if warmup:
+        local(warmup)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = local(steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    os.environ["GK_EVENT_PER_LAUNCH"] = "1"
+    iso = local(min(steps, 20))
+    del os.environ["GK_EVENT_PER_LAUNCH"]
+    final = local(1, download=True)
+    groups = int(final.n_plan_groups)
+    # several plan groups run on their own streams and overlap: the sum of their kernels' durations is not the sweep's duration --
+    # the sweep is what the timed region measures; one group: the kernel's own events
+    kernel_s = iso.fast_kernel_ms / 1e3 if groups == 1 else dt / steps
+    once = int(final.algo_bytes_once)
+    out = {"workload": "configs[%d]: %d constraints x %d synthetic %s, resident in HBM" % (config if config != 2 else 3 if reviews > 2000000 else 2, nc, reviews,
+                                                                                               "Pod reviews" if config == 1 else "mixed cluster objects"),
+           "constraints": nc, "reviews": reviews, "steps": steps, "ms_per_step": dt / steps * 1e3, "evals_per_s": nc * reviews * steps / dt,
+           "plan_groups": groups, "rows": int(final.n_rows), "rows_read": int(final.n_rows_read), "table_bytes": int(st["device_bytes"]),
+           "roofline": {"bound": "hbm", "kernel": "gk_jit_tiles", "algo_bytes_per_sweep_table_once": once, "algo_bytes_per_sweep_every_group": int(final.algo_bytes),
+                        "seconds": kernel_s, "clock": "per-launch HIP events" if groups == 1 else "wall clock of the timed sweeps (the plan groups overlap on their streams)",
+                        "sum_of_group_kernels_ms": iso.fast_kernel_ms, "achieved": once / kernel_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": once / kernel_s / 1e9 / HBM_PEAK_GBS, "lds_bytes_per_tile": int(final.lds_bytes)},
+           "ingest": {"flatten_s": st["flatten_s"], "h2d_s": st["upload_s"], "json_bytes": st["json_bytes"], "generate_s": t_gen,
+                      "reviews_per_s": reviews / (st["flatten_s"] + st["upload_s"])},
+           "policy_load_s": t_pol, "first_sweep_s": t_first, "violating_pairs": int(final.counts.sum()), "reviews_beyond_limits": len(final.too_big_reviews())}
+    oracle = None
+    if oracle_n > 0:
+        try:
+            n = min(oracle_n, reviews) // 64 * 64
+            oracle = oracle_pairs_of(templates, constraints, batch, n)
+            out["parity_python_oracle"] = python_oracle_leg(templates, constraints, batch, final, n, ids=ids, oracle=oracle)
+            out["parity_python_oracle"]["geometry"] = "the timed table itself: %d reviews, %d plan group(s), LDS %d B per row group" % (reviews, groups, int(final.lds_bytes))
+        except Exception as ex:   # noqa: BLE001
+            out["parity_python_oracle"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+    table.free()
+    stream = None
+    if with_stream:
+        try:
+            first = []
+            r = stream_leg(stream_args, drv, client, templates, constraints, nss, 0, 1, dev, None, keep_first=first)
+            stream = {"offered_reviews_per_s": stream_args.offered, "batch": stream_args.batch, "batches": r["batches_all"], "achieved_reviews_per_s": r["reviews_all"] / r["dt"],
+                      "evals_per_s": nc * r["reviews_all"] / r["dt"], "batch_latency_ms": r["lat_ms"], "stage_mean_ms": r["stage_mean_ms"],
+                      "device_kernels_ms_per_batch": r["kernel_s"] * 1e3, "reviews_beyond_limits": r["too_big"]}
+            if oracle is not None and first:
+                n = min(oracle_n, stream_args.batch) // 64 * 64
+                stream["parity_python_oracle"] = python_oracle_leg(templates, constraints, batch, first[0], n, ids=ids, oracle=oracle)
+                stream["parity_python_oracle"]["geometry"] = "the first streamed batch (objects [0, %d) of the same stream): a %d-review table built, evaluated and downloaded by the streaming pipeline" % (stream_args.batch, stream_args.batch)
+        except Exception as ex:   # noqa: BLE001
+            stream = {"error": "%s: %s" % (type(ex).__name__, ex)}
+    batch.free()
+    drv.engine.close()
+    return out, stream
+
+
+def other_configs(args, dev_index, dev, fx, nss, budget_s=170.0):
+    """configs[1], configs[4] (resident + streaming) and the N = 1 point of configs[3], each in its own engine; a leg is skipped
+    (and says so) once the budget is spent so that the default run stays within a few minutes."""
+    t_start = time.perf_counter()
+    detail, brief = {}, {}
+
+    def left():
+        return budget_s - (time.perf_counter() - t_start)
+
+    def parity_brief(pp):
+        if not pp:
+            return None
+        if "error" in pp:
+            return {"error": pp["error"][:80]}
+        return {"n": pp["n"], "equal": pp["pairs_equal"], "pairs": pp["oracle_violating_pairs"], "s": _sig(pp["seconds"], 3)}
+
+    def run(name, fn):
+        if left() <= 0:
+            detail[name] = brief[name] = {"skipped": "time budget of the default run spent"}
+            return None
+        try:
+            t = time.perf_counter()
+            r = fn()
+            r[0]["leg_seconds"] = time.perf_counter() - t
+            return r
+        except Exception as ex:   # noqa: BLE001
+            detail[name] = brief[name] = {"error": ("%s: %s" % (type(ex).__name__, ex))[:200]}
+            return None
+
+    def resident_brief(d):
+        rf = d["roofline"]
+        return {"w": "%dx%d" % (d["constraints"], d["reviews"]), "ms": _sig(d["ms_per_step"]), "evals_s": _sig(d["evals_per_s"]), "frac": _sig(rf["frac"], 3),
+                "GBs": _sig(rf["achieved"]), "groups": d["plan_groups"], "parity": parity_brief(d.get("parity_python_oracle")), "leg_s": _sig(d["leg_seconds"], 3)}
+    r = run("configs1", lambda: side_point(1, 100000, max(args.steps, 50), args.warmup, args.side_oracle_sample, dev_index, fx, nss))
+    if r:
+        detail["configs1"], brief["configs1"] = r[0], resident_brief(r[0])
+    import copy
+    sa = copy.copy(args)
+    sa.stream_batches, sa.warmup, sa.stream_unique, sa.batch, sa.offered = 16, 2, 8, 65536, 1e6
+    r = run("configs4", lambda: side_point(4, 200000, max(args.steps, 20), args.warmup, args.side_oracle_sample, dev_index, fx, nss, with_stream=True, stream_args=sa, dev=dev))
+    if r:
+        detail["configs4"], brief["configs4"] = r[0], resident_brief(r[0])
+        detail["configs4_stream"] = r[1]
+        if r[1] and "error" not in r[1]:
+            brief["configs4_stream"] = {"offered": r[1]["offered_reviews_per_s"], "achieved": _sig(r[1]["achieved_reviews_per_s"]), "p50_ms": _sig(r[1]["batch_latency_ms"]["p50"], 3),
+                                        "p99_ms": _sig(r[1]["batch_latency_ms"]["p99"], 3), "parity": parity_brief(r[1].get("parity_python_oracle"))}
+        else:
+            brief["configs4_stream"] = r[1]
+    r = run("configs3_n1", lambda: side_point(2, 10000000, max(args.steps, 20), 3, 0, dev_index, fx, nss))
+    if r:
+        d = r[0]
+        d["note"] = "the origin of configs[3]'s strong-scaling curve: all 10 M objects on ONE MI355X (N > 1: bench.py --gpus N --scaling strong --reviews 10000000); the table is far beyond the 256 MiB Infinity Cache"
+        detail["configs3_n1"] = d
+        brief["configs3_n1"] = dict(resident_brief(d), ingest_s=_sig(d["ingest"]["flatten_s"] + d["ingest"]["h2d_s"], 3), table_GB=_sig(d["table_bytes"] / 1e9, 3))
+    return detail, brief
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--config", type=int, default=2, choices=[1, 2, 4],
+    ap.add_argument("--config", type=int, default=None, choices=[1, 2, 4],
                     help="1: 30 PSP x Pods (configs[1]); 2: 50 constraints x mixed objects (configs[2]); 4: the 200-template policy corpus x mixed objects (configs[4]'s policy set)")
     ap.add_argument("--reviews", type=int, default=None, help="objects per GPU (weak) / in total (strong); default 1000000 (config 2), 100000 (config 1)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
@@ -226,8 +389,14 @@ def main():
     ap.add_argument("--stream-batches", type=int, default=16, help="timed batches over all ranks")
     ap.add_argument("--stream-unique", type=int, default=8, help="distinct pre-generated batches per rank (cycled)")
     ap.add_argument("--offered", type=float, default=1e6, help="offered load in reviews/s over all ranks (0: closed loop, as fast as the pipeline goes)")
-    ap.add_argument("--oracle-sample", type=int, default=65536, help="objects of the timed table the pure-Python oracle re-evaluates (parity_python_oracle)")
+    ap.add_argument("--oracle-sample", type=int, default=262144, help="objects of the timed table the pure-Python oracle re-evaluates (parity_python_oracle)")
+    ap.add_argument("--side-oracle-sample", type=int, default=16384, help="... of every other_configs table")
+    ap.add_argument("--no-other-configs", action="store_true", help="only the headline workload (the default run adds configs[1], configs[4] resident + streaming "
+                    "and the N = 1 point of configs[3] as `other_configs`, each with its own parity leg)")
     args = ap.parse_args()
+    want_others = args.config is None and not args.no_other_configs and not args.lean and not args.streaming and args.scaling == "weak" and args.reviews is None
+    if args.config is None:
+        args.config = 2
     if args.reviews is None:
         args.reviews = {1: 100000, 2: 1000000, 4: 200000}[args.config]
 
@@ -438,6 +607,19 @@ def main():
                 out["parity_python_oracle"] = python_oracle_leg(templates, constraints, batch, final, args.oracle_sample)
             except Exception as ex:   # the checker must not cost the bench line; an absent leg is visible as such
                 out["parity_python_oracle"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+        # every other BASELINE config, each with its own independent parity leg at the bench's geometry.  LAST in the line and
+        # compact: the driver's record keeps the tail of the line; the full records sit in other_configs_detail before it.
+        if want_others and world == 1:
+            sweep = table = batch = None   # (the headline table and its text leave HBM / host memory before the 10 M-object point)
+            import gc
+            gc.collect()
+            detail, brief = other_configs(args, local_rank, dev, fx, nss)
+            out["other_configs_detail"] = detail
+            pp, ps = out.get("parity_python_oracle") or {}, out.get("parity_sample") or {}
+            brief["configs2"] = {"w": "%dx%d" % (nc, total_reviews), "ms": _sig(out["ms_per_step"]), "frac": _sig(out["roofline"]["frac"], 3),
+                                 "parity": {"n": pp.get("n"), "equal": pp.get("pairs_equal"), "pairs": pp.get("oracle_violating_pairs"), "s": _sig(pp.get("seconds"), 3)},
+                                 "cpu_loop_parity": {"n": ps.get("n"), "equal": ps.get("pairs_equal")}}
+            out["other_configs"] = brief
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

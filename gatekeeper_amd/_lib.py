@@ -64,7 +64,8 @@ class gk_eval_out(C.Structure):
                 ("list_len", C.c_uint32), ("list_total", C.c_uint32), ("n_overflow", C.c_uint32),
                 ("kernel_ms", C.c_float), ("fast_kernel_ms", C.c_float),
                 ("algo_bytes", C.c_uint64), ("n_rows", C.c_uint64), ("n_launches", C.c_uint32), ("lds_bytes", C.c_uint32),
-                ("d_viol", C.c_void_p), ("d_err", C.c_void_p), ("d_counts", C.c_void_p), ("n_rows_read", C.c_uint64)]
+                ("d_viol", C.c_void_p), ("d_err", C.c_void_p), ("d_counts", C.c_void_p), ("n_rows_read", C.c_uint64),
+                ("algo_bytes_once", C.c_uint64), ("n_plan_groups", C.c_uint32), ("reserved0", C.c_uint32)]
 
 
 class gk_topk_out(C.Structure):
@@ -106,7 +107,8 @@ HE_ALLREDUCE = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_longlong), C.c_uint64
 
 class gk_spool_info(C.Structure):
     _fields_ = [("n_files", C.c_uint64), ("n_reviews", C.c_uint64), ("n_unreadable", C.c_uint64), ("n_namespace_missing", C.c_uint64), ("bytes", C.c_uint64),
-                ("names", C.POINTER(C.c_char_p)), ("n_folders_missing", C.c_uint64)]
+                ("names", C.POINTER(C.c_char_p)), ("n_folders_missing", C.c_uint64), ("statuses", C.POINTER(C.c_int32)), ("n_rejected", C.c_uint64),
+                ("n_excluded", C.c_uint64)]
 
 
 class gk_batch_opts(C.Structure):

@@ -348,6 +348,7 @@ struct gk_table {
   HostTable host;               // rows/heap released after upload unless needed
   std::vector<ReviewDoc> docs;  // GK_TABLE_KEEP_DOCS
   std::vector<gk_review_in> texts;   // GK_TABLE_KEEP_TEXT: where each review's JSON lives (caller-owned text)
+  std::shared_ptr<void> owned_text;  // gk_table_create_spool: the table owns the spooled text its `texts` point into
   std::vector<std::string> review_errors;
   uint64_t n_rejected = ~0ull;              // non-empty review_errors (counted by the first sharded sweep)
   uint64_t dir_bytes = 0, n_rows = 0;      // review-flag bytes (read by every launch); rows in the table
@@ -733,7 +734,8 @@ int gk_template_add(gk_engine* e, const char* kind, const char* rego, const char
     }
     e->templates[k] = t;
     for (auto& r : redo) { r.c->viol = std::move(r.viol); r.c->prep = std::move(r.prep); r.c->multi_prep = std::move(r.multi); r.c->multi_ready = true; r.c->referential = r.referential; r.c->broken.clear(); }
-    if (!redo.empty() && t->references_inventory()) e->inv_compiled = e->inv_gen;
+    // (inv_compiled stays as it is: referential constraints of OTHER kinds may still hold an older inventory -- refresh_referential
+    // recompiles every one of them at the next evaluation; marking the inventory compiled here left them stale, i.e. missed violations)
     e->plan_dirty = true;
     return GK_OK;
   } catch (const RegoError& ex) { return fail(GK_ERR_REGO, ex.what());
@@ -1246,6 +1248,7 @@ struct SpoolHolder {
   gk_spool_info pub;   // first member
   std::vector<std::string> names;
   std::vector<const char*> ptrs;
+  std::vector<int32_t> statuses;
 };
 bool read_file(const std::string& path, std::string* out) {
   FILE* f = fopen(path.c_str(), "rb");
@@ -1321,9 +1324,18 @@ int gk_table_create_spool(gk_engine* e, const char* api_cache_dir, const char* k
       }
       h->names.push_back(kept[i].name);
     }
-    int rc = gk_table_create(e, rins.data(), rins.size(), flags, nullptr, out);
+    h->statuses.assign(std::max<size_t>(1, kept.size()), GK_OK);
+    int rc = gk_table_create(e, rins.data(), rins.size(), flags, h->statuses.data(), out);
     if (rc != GK_OK) return rc;
+    h->statuses.resize(kept.size());
     h->pub.n_reviews = kept.size();
+    h->pub.statuses = h->statuses.data();
+    // (HandleReview's verdict per spooled object, as gk_table_create reports it: the reference logs "Unable to review object from
+    //  file" for a rejected one and goes on; GK_REVIEW_EXCLUDED = the process excluder skipped it)
+    for (int32_t st : h->statuses) { if (st == GK_REVIEW_EXCLUDED) h->pub.n_excluded++; else if (st != GK_OK) h->pub.n_rejected++; }
+    // GK_TABLE_KEEP_TEXT remembers WHERE the text lives: here it lives in `kept`, so the table takes it over (round-3 advisor
+    // finding: gk_table_totals / gk_render read freed memory).  Moving the vector keeps every string where it is.
+    if ((*out)->texts.size() == kept.size() && !kept.empty()) (*out)->owned_text = std::make_shared<std::vector<Item>>(std::move(kept));
     for (auto& nm : h->names) h->ptrs.push_back(nm.c_str());
     h->pub.names = h->ptrs.data();
     if (info) *info = &h.release()->pub;
@@ -1427,9 +1439,12 @@ int gk_table_eval(gk_engine* e, gk_table* t, uint32_t flags, gk_eval_out** out) 
     // where a predicate reads string bytes) + the groups' chunk lists (8 B per entry) + review flags, all read once;
     // plan tables read once; bitmaps written once; 8 B per list entry
     uint64_t rows_read = 0, hdrs_read = 0, bound = 0, plan_bytes = 0;
+    std::vector<uint8_t> seen(t->slot_path.size(), 0);   // per slot: 1 = rows counted, 2 = string headers counted (table-once figure)
+    uint64_t rows_once = 0, hdrs_once = 0;
     static const bool path_stats = getenv("GK_PATH_STATS") != nullptr;
     auto account = [&](const HostPlan& hp) {   // every plan group streams its own bound segments
-      for (uint32_t pth : t->slot_path) {
+      for (size_t si = 0; si < t->slot_path.size(); si++) {
+        const uint32_t pth = t->slot_path[si];
         if (pth >= hp.ptab.size() || !hp.ptab[pth]) continue;
         bound++;
         uint64_t n = pth < t->path_rows.size() ? t->path_rows[pth] : 0;
@@ -1438,6 +1453,8 @@ int gk_table_eval(gk_engine* e, gk_table* t, uint32_t flags, gk_eval_out** out) 
         bool str = false;
         for (uint32_t j = 0; j < (ent & 0xFF); j++) str = str || pred_needs_str(hp.path_preds[(ent >> 8) + j]);
         if (str) hdrs_read += n;
+        if (!(seen[si] & 1)) { seen[si] |= 1; rows_once += n; }
+        if (str && !(seen[si] & 2)) { seen[si] |= 2; hdrs_once += n; }
         if (path_stats) fprintf(stderr, "[path] %u rows %llu per-group %.1f str %d preds %u\n", pth, (unsigned long long)n, (double)n / std::max<uint32_t>(1, (p.n_reviews + t->rpt - 1) / t->rpt), (int)str, ent & 0xFF);
       }
       plan_bytes += (uint64_t)hp.path_preds.size() * sizeof(Pred) + hp.code.size() * 4 + hp.cheap.size();
@@ -1451,6 +1468,8 @@ int gk_table_eval(gk_engine* e, gk_table* t, uint32_t flags, gk_eval_out** out) 
     (void)bound;
     p.algo_bytes = rows_read * sizeof(Row) + hdrs_read * sizeof(StrHdr) + h->out.list_bytes +
                    t->dir_bytes * (1 + e->extra.size()) + plan_bytes + (uint64_t)p.n_constraints * p.n_tiles * 16 + (uint64_t)p.list_total * 8;
+    p.algo_bytes_once = p.algo_bytes - (rows_read - rows_once) * sizeof(Row) - (hdrs_read - hdrs_once) * sizeof(StrHdr) - t->dir_bytes * e->extra.size();
+    p.n_plan_groups = 1 + (uint32_t)e->extra.size();
     *out = &h.release()->pub;
     return GK_OK;
   } catch (const Unsupported& ex) { return fail(GK_ERR_UNSUPPORTED, ex.what());

@@ -138,6 +138,7 @@ class EvalResult:
         self.kernel_ms, self.fast_kernel_ms = o.kernel_ms, o.fast_kernel_ms
         self.algo_bytes, self.n_rows, self.n_launches = o.algo_bytes, o.n_rows, o.n_launches
         self.n_rows_read = o.n_rows_read
+        self.algo_bytes_once, self.n_plan_groups = o.algo_bytes_once, o.n_plan_groups
         self.lds_bytes = o.lds_bytes
         self.d_viol, self.d_err, self.d_counts = o.d_viol, o.d_err, o.d_counts
         lib.gk_eval_free(ptr)
@@ -516,20 +517,21 @@ class Engine:
         self._check(self.lib.gk_table_create(self.handle, arr, n, flags, st, C.byref(h)))
         return Table(self, h, list(st)[:n], n)
 
-    def create_table_spool(self, api_cache_dir, kind, folders, keep_docs=False, resident=True, process=None):
+    def create_table_spool(self, api_cache_dir, kind, folders, keep_docs=False, resident=True, process=None, keep_text=False):
         """gk_table_create_spool: ONE table of the objects pkg/audit spooled for `kind` under <api_cache_dir>/<kind>_<i>/
         (manager.go:519-551), reviewed the way reviewObjects does (manager.go:667-776).  -> (Table, info dict); info["names"][i]
         is the spool file of review i."""
         info, h = C.POINTER(L.gk_spool_info)(), C.c_void_p()
-        flags = (L.GK_TABLE_KEEP_DOCS if keep_docs else 0) | (L.GK_TABLE_RESIDENT if resident else 0) | self._process_flag(process)
+        flags = (L.GK_TABLE_KEEP_DOCS if keep_docs else 0) | (L.GK_TABLE_RESIDENT if resident else 0) | self._process_flag(process) | (L.GK_TABLE_KEEP_TEXT if keep_text else 0)
         self._check(self.lib.gk_table_create_spool(self.handle, str(api_cache_dir).encode(), kind.encode(), int(folders), flags, C.byref(info), C.byref(h)))
         o = info.contents
         n = int(o.n_reviews)
         d = {"n_files": int(o.n_files), "n_reviews": n, "n_unreadable": int(o.n_unreadable), "n_namespace_missing": int(o.n_namespace_missing),
              "n_folders_missing": int(o.n_folders_missing),
-             "bytes": int(o.bytes), "names": [o.names[i].decode() for i in range(n)]}
+             "bytes": int(o.bytes), "names": [o.names[i].decode() for i in range(n)], "n_rejected": int(o.n_rejected), "n_excluded": int(o.n_excluded)}
+        statuses = [int(o.statuses[i]) for i in range(n)]   # HandleReview's verdict per spooled object: the fail-closed loops read them
         self.lib.gk_spool_info_free(info)
-        return Table(self, h, [L.GK_OK] * n, n), d
+        return Table(self, h, statuses, n), d
 
     def create_table_native(self, reviews_ptr, n, keep_docs=False, resident=False, process=None, keep_text=False):
         """gk_table_create on an existing gk_review_in array (e.g. synth.NativeBatch.reviews).  keep_text: the table remembers

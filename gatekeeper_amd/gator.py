@@ -111,8 +111,8 @@ def test(objs, client=None):
         if kind == "ExpansionTemplate" and api.startswith("expansion.gatekeeper.sh/"):
             raise GatorError("expansion unsupported: the input holds ExpansionTemplate %r (resultant resources are not generated by this engine)"
                              % ((o.get("metadata") or {}).get("name", "")))
-        if api.startswith("mutations.gatekeeper.sh/") and kind in ("Assign", "AssignMetadata", "ModifySet", "AssignImage"):
-            raise GatorError("expansion unsupported: the input holds the mutator %s %r" % (kind, (o.get("metadata") or {}).get("name", "")))
+        # (mutators alone change nothing: pkg/gator/expand applies them to the RESULTANTS of an ExpansionTemplate only
+        #  (expand.go:69-107) -- without one the reference's results are those of the same input without the mutators)
     for o in objs:
         if is_template(o):
             try:

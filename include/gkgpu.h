@@ -127,7 +127,8 @@ int gk_table_get_stats(const gk_table* t, gk_table_stats* out);
  * AugmentedUnstructured{Object, Namespace, Source: Original} with the Namespace also as the namespaceObject option
  * (manager.go:667-776).  gk_table_create_spool is that loop's front end: it reads folders <kind>_0 .. <kind>_<folders-1>
  * of `api_cache_dir` (files of a folder in numeric order of their names), attaches to every object the Namespace synced
- * through gk_data_put (Driver.AddData) for its metadata.namespace, and builds ONE table of them (flags as gk_table_create).
+ * through gk_data_put (Driver.AddData) for its metadata.namespace, and builds ONE table of them (flags as gk_table_create;
+ * with GK_TABLE_KEEP_TEXT the TABLE owns the spooled text until gk_table_free).
  * A file that cannot be read or is not a JSON object, and an object whose Namespace is not in the cache, is skipped and
  * counted -- the reference logs the error and continues with the next file (manager.go:688-704); so is a folder that cannot
  * be opened ("Unable to get files from directory", manager.go:680-684: getFilesFromDir's error is logged, the loop goes on).
@@ -136,6 +137,8 @@ typedef struct {
   uint64_t n_files, n_reviews, n_unreadable, n_namespace_missing, bytes;
   const char* const* names;   /* [n_reviews] */
   uint64_t n_folders_missing;  /* folders <kind>_<i>, i < folders, that do not exist / cannot be opened */
+  const int32_t* statuses;     /* [n_reviews] as gk_table_create's: GK_OK, GK_REVIEW_EXCLUDED (process excluder) or HandleReview's error */
+  uint64_t n_rejected, n_excluded;   /* how many of them are errors ("Unable to review object from file") / GK_REVIEW_EXCLUDED */
 } gk_spool_info;
 int gk_table_create_spool(gk_engine* e, const char* api_cache_dir, const char* kind, uint32_t folders, uint32_t flags,
                           gk_spool_info** info, gk_table** out);
@@ -163,6 +166,10 @@ typedef struct {
   const void* d_err;         /* lets the caller hand them to RCCL (all-gather of per-shard violation bitmaps)      */
   const void* d_counts;
   uint64_t n_rows_read;      /* rows in the segments whose key path carries predicates of the current plan */
+  uint64_t algo_bytes_once;  /* algo_bytes with the TABLE counted once: a constraint set that needs several plan groups walks the
+                                table once per group today; rows / string headers / review flags bound by ANY group count once
+                                here (chunk lists, plan tables and bitmaps are per group).  == algo_bytes for a single group */
+  uint32_t n_plan_groups, reserved0;
 } gk_eval_out;
 
 #define GK_EVAL_WANT_MATCH 1u

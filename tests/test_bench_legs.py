@@ -70,3 +70,27 @@ def test_result_totals_from_kept_text_equal_kept_docs_and_the_oracle(fixtures):
     assert lean.render(cid, r) == full.render(cid, r) and lean.render(cid, r)
     lean.free()
     full.free()
+
+
+def test_other_configs_legs_run_on_the_cpu_build(fixtures, monkeypatch):
+    """The default bench line's `other_configs` (configs[1], configs[4] resident + streaming, each with its own parity leg against
+    the pure-Python oracle at the leg's own table geometry): the Python plumbing of bench.side_point on the TEST-ONLY CPU build of
+    the engine, small sizes -- so that a GPU visit is not spent on a typo.  The product bench never takes this route: bench.main
+    asserts a device and side_point asks for hostemu=False; here Driver is patched."""
+    import argparse
+    import torch
+
+    class EmuDriver(D.Driver):
+        def __init__(self, device=0, hostemu=None, **kw):
+            super().__init__(device=device, hostemu=True, **kw)
+    monkeypatch.setattr(D, "Driver", EmuDriver)
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+    nss = synth.gen_namespaces()
+    out, stream = bench.side_point(1, 384, 2, 1, 128, 0, fixtures, nss)
+    assert stream is None and out["parity_python_oracle"]["pairs_equal"] and out["parity_python_oracle"]["n"] == 128
+    assert out["plan_groups"] == 1 and out["roofline"]["algo_bytes_per_sweep_table_once"] == out["roofline"]["algo_bytes_per_sweep_every_group"] > 0
+    sa = argparse.Namespace(stream_batches=2, warmup=1, stream_unique=2, batch=128, offered=0.0)
+    out, stream = bench.side_point(4, 256, 1, 0, 64, 0, fixtures, nss, with_stream=True, stream_args=sa, dev=None)
+    assert out["plan_groups"] == 4 and out["parity_python_oracle"]["pairs_equal"], out.get("parity_python_oracle")
+    assert out["roofline"]["algo_bytes_per_sweep_table_once"] < out["roofline"]["algo_bytes_per_sweep_every_group"]
+    assert "error" not in stream and stream["parity_python_oracle"]["pairs_equal"] and stream["batches"] == 2

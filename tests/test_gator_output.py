@@ -94,7 +94,7 @@ def test_enforcement_action_decides_the_status(backend, fixtures):
     assert G.format_output(foo, deny_only=True) == "" and G.format_output(foo, "json", deny_only=True) == "null"
 
 
-def test_bad_inputs_are_errors():
+def test_bad_inputs_are_errors(fixtures):
     """test.Test returns an error before any review: a template the driver rejects ("adding template %q"), a constraint
     whose template is missing ("adding constraint %q", test.go:66-79; pinned for the oracle by test_test.go:135-158).  (The
     two invalid-resources manifests of test.bats:144-155 already fail in the YAML reader -- CLI, not this path.)"""
@@ -111,3 +111,11 @@ def test_bad_inputs_are_errors():
                    "generatedGVK": {"kind": "Pod", "group": "", "version": "v1"}}}
     with pytest.raises(G.GatorError, match="expansion unsupported"):
         run("hostemu", [et])
+    # a mutator WITHOUT an ExpansionTemplate changes nothing in the reference (pkg/gator/expand/expand.go:69-107 mutates the
+    # resultants of an expansion only): same results as the input without it (round-3 advisor finding: it was refused)
+    objs = docs(fixtures, "manifests/with-policies/with-violations.yaml")
+    mut = {"apiVersion": "mutations.gatekeeper.sh/v1", "kind": "Assign", "metadata": {"name": "always-pull"},
+           "spec": {"applyTo": [{"groups": [""], "kinds": ["Pod"], "versions": ["v1"]}], "location": "spec.containers[name:*].imagePullPolicy",
+                    "parameters": {"assign": {"value": "Always"}}}}
+    got = run("hostemu", objs + [mut])           # (the mutator is reviewed as an object like everything else, test.go:109)
+    assert sorted(gkey(g) for g in got) == sorted(okey(p) for p in OG.gator_test(objs + [mut])) and len(got) >= len(run("hostemu", objs)) > 0

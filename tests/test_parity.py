@@ -847,7 +847,7 @@ violation[{"msg": msg}] {
 '''
 
 
-@pytest.mark.parametrize("backend", [b for b in BACKENDS if b.id.startswith("hostemu")])   # (written after the round's last GPU visit: the device backends join next round)
+@pytest.mark.parametrize("backend", BACKENDS)
 def test_augmented_unstructured_operation_and_delete(backend):
     """pkg/target/target_test.go:1218-1286 (TestAugmentedUnstructuredDeleteUsesOldObject / ...NonDeletePreservesObject): CREATE,
     UPDATE and a missing operation are preserved with the object in `object` and no oldObject; DELETE carries the object as

@@ -91,8 +91,8 @@ DEEP2 = ('package k\n'
          'violation[{"msg": msg}] { j := joined(input.review.object); j == input.parameters.want; msg := sprintf("v2 %v", [j]) }\n')
 
 
-@pytest.mark.parametrize("backend", [b for b in BACKENDS if b.id.startswith("hostemu")])   # (written after the round's last GPU visit: the device backends join next round;
-def test_template_with_a_deep_helper_replaced(backend):                                       #  deep expressions on the device: tests/test_referential.py, run there)
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_template_with_a_deep_helper_replaced(backend):
     """A closed helper the formula language cannot express (it sorts) is evaluated by the FLATTENER on the sub-document it reads
     (spec.names) -- a deep dictionary expression, dexpr.hpp.  Replacing the template must replace the closure: the same constraints
     answer with the new helper, on the device and in the renderer; two constraints with different parameters share the expression."""

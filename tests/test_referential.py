@@ -271,3 +271,37 @@ def test_formatted_review_strings_against_constants(backend):
             o("v1", "ConfigMap", "7", "d"), o("v1", "Secret", "s1", "ns1"), o("v1", "Secret", "s2", "ns1"), o("v1", "Secret", "s1-x", "ns1"), o("v1", "Secret", "clusterwide"),
             o("v1", "Pod", "ab", "ab"), o("v1", "Pod", "a", "bab"), o("v1", "Pod", "aba", "b"), o("v1", "Pod", "abab", ""), o("v1", "Pod", "ba", "ba")]
     assert check(c, oc, objs) >= 8
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_replacing_one_referential_template_leaves_no_other_kind_on_a_stale_inventory(backend, fixtures):
+    """round-3 advisor finding (fail-open): two referential kinds; a data change with no review in between, then AddTemplate of ONE
+    kind.  gk_template_add recompiled that kind against the new inventory and marked the inventory compiled -- the other kind's
+    constraint kept the older snapshot and missed the violation until the next data change."""
+    tmpl_a = docs(fixtures, GT + "policies/default/template_k8suniqueingresshost.yaml")[0]
+    con_a = docs(fixtures, GT + "policies/default/constraint_k8suniqueingresshost.yaml")[0]
+    import copy
+    tmpl_b = copy.deepcopy(tmpl_a)
+    tmpl_b["metadata"]["name"] = "k8suniqueingresshostb"
+    tmpl_b["spec"]["crd"]["spec"]["names"]["kind"] = "K8sUniqueIngressHostB"
+    for t in tmpl_b["spec"]["targets"]:
+        t["rego"] = t["rego"].replace("package k8suniqueingresshost", "package k8suniqueingresshostb")
+    con_b = copy.deepcopy(con_a)
+    con_b["kind"] = "K8sUniqueIngressHostB"
+    con_b["metadata"]["name"] = "unique-ingress-host-b"
+    c, oc = make_client(backend), OC.Client()
+    for t in (tmpl_a, tmpl_b):
+        c.AddTemplate(t); oc.add_template(t)
+    for k in (con_a, con_b):
+        c.AddConstraint(k); oc.add_constraint(k)
+    a, b = ingress("a", "default", "a.example.com"), ingress("b", "default", "b.example.com")
+    probe = ingress("new", "default", "b.example.com")
+    c.AddData(a); oc.add_data(a)
+    assert check(c, oc, [probe]) == 0
+    c.AddData(b); oc.add_data(b)                               # no review in between
+    edited = copy.deepcopy(tmpl_b)
+    for t in edited["spec"]["targets"]:
+        t["rego"] = t["rego"].replace("ingress host conflicts", "INGRESS host conflicts")
+    assert edited != tmpl_b
+    c.AddTemplate(edited); oc.add_template(edited)
+    assert check(c, oc, [probe]) == 2                          # BOTH kinds see b

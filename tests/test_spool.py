@@ -99,3 +99,48 @@ def test_spool_directory_cases_of_the_reference(fixtures, tmp_path):
         assert info["names"] == ["Pod_0/%d" % i for i in range(15)]
     finally:
         table.free()
+
+
+def test_spool_reports_skipped_objects_and_owns_kept_text(fixtures, tmp_path):
+    """round-3 advisor findings: (1) the spool front end fabricated [GK_OK]*n: the statuses gk_table_create reports (here the
+    process excluder's GK_REVIEW_EXCLUDED for "audit"; HandleReview's errors travel the same way) reach the Table, the info
+    carries n_rejected / n_excluded; (2) GK_TABLE_KEEP_TEXT on a spool table pointed into strings gk_table_create_spool had freed:
+    the table owns the spooled text now, so totals / render work after the call returned."""
+    c, oc = load_both("hostemu", synth.psp_templates(fixtures), synth.audit_constraints())
+    nss = synth.gen_namespaces()
+    pods = [o for o in synth.gen_objects(300, seed=21, mixed=True) if o["kind"] == "Pod"][:60]
+    for p in pods:
+        c.AddData(nss[p["metadata"]["namespace"]])
+        oc.add_data(nss[p["metadata"]["namespace"]])
+    skip_ns = pods[7]["metadata"]["namespace"]
+    c.SetExcluder([{"excludedNamespaces": [skip_ns], "processes": ["audit"]}])
+    skipped = [i for i, p in enumerate(pods) if p["metadata"]["namespace"] == skip_ns]
+    os.mkdir(str(tmp_path / "Pod_0"))
+    for i, p in enumerate(pods):
+        with open(str(tmp_path / "Pod_0" / ("%d" % i)), "w") as fh:
+            json.dump(p, fh)
+    table, info = c.driver.engine.create_table_spool(str(tmp_path), "Pod", 1, keep_text=True, process="audit")
+    try:
+        assert info["n_reviews"] == 60 and info["n_rejected"] == 0 and info["n_excluded"] == len(skipped) > 0
+        assert [i for i, st in enumerate(table.statuses) if st != 0] == skipped
+        import gc
+        junk = [bytes(200) * (i % 7 + 1) for i in range(20000)]          # churn the heap: freed text would be overwritten
+        del junk
+        gc.collect()
+        ev = table.eval()
+        row = {int(cid): r for r, cid in enumerate(ev.constraint_ids)}
+        active = c._active(D.AUDIT_EP)
+        n = 0
+        for i, p in enumerate(pods):
+            ns = nss[p["metadata"]["namespace"]]
+            exp = [] if i in skipped else oc.review(OT.AugmentedUnstructured(OT.Unstructured(p), ns, "Original"), OC.AUDIT_EP, ns)
+            got = []
+            for cid, (cons, ea, scoped) in active.items():
+                if (int(ev.viol[row[cid]][i // 64]) >> (i % 64)) & 1:
+                    for v in table.render(cid, i):                       # parses the review from the text the TABLE keeps
+                        got.append(D.Result(v["msg"], cons, v.get("details"), ea, scoped))
+            assert sorted(key(r) for r in got) == sorted(key(r) for r in exp), i
+            n += len(exp)
+        assert n > 10
+    finally:
+        table.free()

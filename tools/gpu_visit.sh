@@ -1,0 +1,60 @@
+#!/bin/bash
+# One gpurun visit on an MI355X box.  usage: tools/gpu_visit.sh TAG STAGE...   stages (run in the order given):
+#   tests      the whole gpu-marked suite (GK_JIT_STRICT=1: a hiprtc failure fails the test)
+#   smoke      __graft_entry__.smoke()
+#   bench      the default bench line (configs[2] + other_configs) as the driver runs it (--steps 20 --warmup 5)
+#   lean       bench.py --lean --steps 50 (the headline kernel only: tuning runs)
+#   stats      rocprofv3 --kernel-trace --stats of the lean command
+#   pmc        rocprofv3 --pmc passes of the lean command (SQ, FETCH_SIZE, WRITE_SIZE: separate passes, --kernel-trace only)
+#   c1 | c4    bench.py --config 1 | 4 --lean
+#   stream     bench.py --config 4 --streaming (offered 1 M/s) and closed loop
+#   env:X=Y    export X=Y for the following stages;  unset:X
+# Everything lands under gpurun_out/TAG_*; copy what is to be judged into profiles/.
+set -u
+tag=$1; shift
+mkdir -p gpurun_out; export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-$PWD}
+pmc_summary() {
+  for d in "$@"; do
+    f=$(find gpurun_out/${tag}_pmc_$d -name '*counter_collection.csv' | head -1)
+    [ -n "$f" ] && python - "$f" <<'PY'
+import csv, sys, collections
+acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
+for r in csv.DictReader(open(sys.argv[1])):
+    k = r.get('Kernel_Name', '')
+    if 'tiles' not in k: continue
+    acc[k][r['Counter_Name']] += float(r['Counter_Value']); n[(k, r['Counter_Name'])] += 1
+for k in acc:
+    for c, v in sorted(acc[k].items()):
+        print('%s %s per_dispatch=%.1f dispatches=%d' % (k[:20], c, v / n[(k, c)], n[(k, c)]))
+PY
+  done
+}
+for stage in "$@"; do
+  case $stage in
+    env:*) export "${stage#env:}";;
+    unset:*) unset "${stage#unset:}";;
+    tests) GK_JIT_STRICT=1 timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -8 > gpurun_out/${tag}_pytest_gpu.log; tail -3 gpurun_out/${tag}_pytest_gpu.log;;
+    smoke) timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${tag}_smoke.log 2>&1; tail -2 gpurun_out/${tag}_smoke.log;;
+    bench) s=$(date +%s); timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err; echo "bench rc=$? wall=$(( $(date +%s) - s ))s"; tail -c 2400 gpurun_out/${tag}_bench.json; tail -3 gpurun_out/${tag}_bench.err;;
+    lean) timeout 600 python bench.py --lean --steps 50 --warmup 5 > gpurun_out/${tag}_lean${GK_VARIANT:-}.json 2> gpurun_out/${tag}_lean${GK_VARIANT:-}.err; python - gpurun_out/${tag}_lean${GK_VARIANT:-}.json <<'PY'
+import json, sys
+try:
+    j = json.loads(open(sys.argv[1]).read().strip().split('\n')[-1]); r = j['roofline']
+    print('lean: step %.4f ms kernel %.4f ms frac %.4f algo %d' % (j['ms_per_step'], r['avg_kernel_ms'], r['frac'], r['algo_bytes_per_launch']))
+except Exception as e: print('lean: no line', e)
+PY
+      tail -2 gpurun_out/${tag}_lean${GK_VARIANT:-}.err;;
+    c1|c4) timeout 600 python bench.py --config ${stage#c} --lean --steps 50 --warmup 5 > gpurun_out/${tag}_${stage}.json 2> gpurun_out/${tag}_${stage}.err; tail -c 1500 gpurun_out/${tag}_${stage}.json; tail -2 gpurun_out/${tag}_${stage}.err;;
+    stream) timeout 600 python bench.py --config 4 --streaming > gpurun_out/${tag}_stream_offered_1M.json 2> gpurun_out/${tag}_stream.err; tail -c 1200 gpurun_out/${tag}_stream_offered_1M.json
+            timeout 600 python bench.py --config 4 --streaming --offered 0 > gpurun_out/${tag}_stream_closed_loop.json 2>> gpurun_out/${tag}_stream.err; tail -c 1200 gpurun_out/${tag}_stream_closed_loop.json;;
+    stats) (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}_stats -o stats -- python $R/bench.py --steps 50 --warmup 5 --lean > /dev/null 2> $R/gpurun_out/${tag}_stats.err)
+           find gpurun_out/${tag}_stats -name '*kernel_stats.csv' | head -1 | xargs -r head -6;;
+    pmc) run_pmc() { name=$1; shift; timeout 400 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d gpurun_out/${tag}_pmc_$name -o $name -- python bench.py --steps 5 --warmup 1 --lean > /dev/null 2> gpurun_out/${tag}_pmc_$name.err; }
+         run_pmc sq SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
+         run_pmc fetch FETCH_SIZE
+         run_pmc write WRITE_SIZE
+         pmc_summary sq fetch write | tee gpurun_out/${tag}_pmc_summary.txt;;
+    *) echo "unknown stage $stage";;
+  esac
+done
