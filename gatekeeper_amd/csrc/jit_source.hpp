@@ -53,6 +53,17 @@ inline size_t static_lds_of(uint32_t rpt, int block, uint32_t res_k, uint32_t li
   const size_t bounds = res_k ? 0 : (size_t)(block / GK_TILE) * GK_MAX_SCOPES * 4;
   return 2 * list + (masks <= list ? 8 : masks) + bounds + GK_TILE * 4 + 64;
 }
+// ROW RING of the plan-specialised kernel (kernel_body.inc GK_RING_K): slots of 1 KiB per wave, behind the accumulators in dynamic
+// LDS, filled by LDS-DMA.  Audit-sized row groups (>= 256 reviews) only; GK_JIT_RING=0 | 4 | 8 (tuning aid; 0 = rows through
+// registers, one chunk in flight per wave, as in rounds 1-3).
+#ifndef GK_RING_DEFAULT
+#define GK_RING_DEFAULT 0
+#endif
+inline uint32_t jit_ring_slots(uint32_t rpt) {
+  static const int v = getenv("GK_JIT_RING") ? atoi(getenv("GK_JIT_RING")) : GK_RING_DEFAULT;
+  return rpt >= 256 && (v == 4 || v == 8) ? (uint32_t)v : 0u;
+}
+inline size_t jit_ring_bytes(uint32_t rpt) { return (size_t)jit_ring_slots(rpt) * 1024 * (size_t)(jit_block_of(rpt) / GK_TILE); }
 inline size_t max_dyn_lds_of(uint32_t rpt) { return GK_LDS_PER_CU - static_lds_of(rpt, gk_block_of((int)rpt), 0) - 256; }
 inline size_t max_dyn_lds_jit(uint32_t rpt, uint32_t res_k, uint32_t list_cap = 0) { return GK_LDS_PER_CU - static_lds_of(rpt, jit_block_of(rpt), res_k, list_cap) - 256; }
 
@@ -74,7 +85,7 @@ inline std::string assemble_jit_source(const HostPlan& plan, uint32_t rpt, uint3
     // register budget: as many waves per SIMD as the LDS footprint lets groups be resident per CU (waves per SIMD =
     // groups per CU x waves per group / 4 SIMDs); measured on configs[1] with 64-review groups: 7 waves (72 VGPRs) edges
     // out 8 (64 VGPRs, twice the spill traffic) and clearly beats 5-6
-    const size_t per_group = (size_t)plan.dims.acc_words * rpp * 4 + static_lds_of(rpt, block, jit_res_k(plan), list_cap);
+    const size_t per_group = (size_t)plan.dims.acc_words * rpp * 4 + jit_ring_bytes(rpt) + static_lds_of(rpt, block, jit_res_k(plan), list_cap);
     const size_t groups_per_cu = std::max<size_t>(1, GK_LDS_PER_CU / per_group);
     int waves = (int)std::min<size_t>(8, std::max<size_t>(block / 256, groups_per_cu * (block / GK_TILE) / 4));   // waves per SIMD the LDS allows
     if (const char* w = getenv("GK_JIT_WAVES")) waves = atoi(w);   // tuning aid
@@ -92,6 +103,7 @@ inline std::string assemble_jit_source(const HostPlan& plan, uint32_t rpt, uint3
   src += "#define GK_RPT_K " + std::to_string(rpt) + "\n#define GK_RPP_K " + std::to_string(rpp) + "\n";
   if (list_cap) src += "#define GK_LIST_CAP_K " + std::to_string(list_cap) + "\n";
   if (jit_runs_mode() != 0) src += "#define GK_RUNS_K 1\n";
+  if (jit_ring_slots(rpt)) src += "#define GK_RING_K " + std::to_string(jit_ring_slots(rpt)) + "\n";
   if (const char* defs = getenv("GK_JIT_DEFINES")) {   // tuning aid: "A=1;B" -> #define A 1, #define B (kernel_body.inc variants)
     std::string d = defs, item;
     for (size_t i = 0; i <= d.size(); i++) {

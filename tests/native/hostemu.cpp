@@ -334,7 +334,7 @@ typedef void (*EmuJitLaunch)(unsigned, unsigned, size_t, const PlanView*, const 
                              uint32_t, uint32_t, const ConstraintSlot*, const OutPtrs*, uint32_t, uint32_t);
 static EmuJitLaunch emu_jit_for(const DevPlan* p, uint32_t rpt, uint32_t rpp, int block, const std::vector<uint64_t>& class_weight) {
   char key[96];
-  snprintf(key, sizeof key, "%u/%u/%d", rpt, rpp, block);
+  snprintf(key, sizeof key, "%u/%u/%d/%u", rpt, rpp, block, jit_ring_slots(rpt));
   DevPlan* mp = const_cast<DevPlan*>(p);
   auto it = mp->emu_jit.find(key);
   if (it != mp->emu_jit.end()) return (EmuJitLaunch)it->second.second;
@@ -353,6 +353,7 @@ static EmuJitLaunch emu_jit_for(const DevPlan* p, uint32_t rpt, uint32_t rpp, in
          "#define GK_ROW_RUN_FN(r, ent, h, heap, acc, on, adv) jit_row(r, ent, h, heap, acc, on, adv)\n"
          "#define GK_FORMULA_FN(pv, acc, flags, rows, heap, bounds) jit_formulas(pv, acc, flags, rows, heap, bounds)\n"
       << (jit_runs_mode() != 0 ? "#define GK_RUNS_K 1\n" : "")
+      << (jit_ring_slots(rpt) ? "#define GK_RING_K " + std::to_string(jit_ring_slots(rpt)) + "\n" : std::string())
       << "#include \"" << GK_CSRC_DIR << "/kernel_body.inc\"\n}\n"
       << "extern \"C\" void gk_emu_jit_launch(unsigned grid, unsigned block, size_t lds, const gk::PlanView* pv, const gk::Row* rows, const gk::StrHdr* shdr,\n"
          "    const gk::ChunkDesc* lists, uint32_t capg, const uint32_t* rflags, const uint8_t* heap, uint32_t n, uint32_t nt, const gk::ConstraintSlot* slots,\n"
@@ -445,7 +446,7 @@ static void emu_kernel_check(const DevPlan* p, const DevTable* dt, const EvalOpt
       f << assemble_jit_source(hp, rpt, rpp, &weight, kPlanHpp, kVmCoreHpp, kKernelBody);
     }
     EmuJitLaunch fn = emu_jit_for(p, rpt, rpp, block, weight);
-    fn(grid, (unsigned)block, lds, &pv, rows, shdr, cl.d.data(), cl.capg, t.rflags.data(), t.heap.data(), n, nt, hp.slots.data(), &out, 0u, rpp);
+    fn(grid, (unsigned)block, lds + jit_ring_bytes(rpt), &pv, rows, shdr, cl.d.data(), cl.capg, t.rflags.data(), t.heap.data(), n, nt, hp.slots.data(), &out, 0u, rpp);
   } else {
     auto fn = rpt == 64 ? gk_emu_tiles_64 : rpt == 128 ? gk_emu_tiles_128 : rpt == 256 ? gk_emu_tiles_256 : gk_emu_tiles_512;
     gkemu::launch(grid, (unsigned)block, lds, [&] { fn(pv, rows, shdr, cl.d.data(), cl.capg, t.rflags.data(), t.heap.data(), n, nt, hp.slots.data(), out, 0u, rpp); });

@@ -164,3 +164,9 @@ static inline uint32_t min(uint32_t a, uint32_t b) { return a < b ? a : b; }
 #define GK_OPAQUE_S1(a) do { } while (0)
 #define GK_OPAQUE() do { } while (0)
 #define GK_READLANE(v, k) ((uint32_t)gkemu::shfl((int)(v), (int)(k)))
+// LDS-DMA of the device build (kernel_body.inc GK_LDS_DMA16): here every lane copies its 16 bytes at once -- a lane only ever
+// reads back what it requested itself, behind GK_WAIT_VM
+typedef uintptr_t gk_ldsaddr_t;
+#define GK_LDS_ADDR(p) ((gk_ldsaddr_t)(uintptr_t)(p))
+#define GK_LDS_DMA16(gptr, ldsaddr) memcpy(reinterpret_cast<unsigned char*>(ldsaddr) + (gkemu::st().cur->tid & 63u) * 16u, (gptr), 16)
+#define GK_WAIT_VM(n) do { } while (0)

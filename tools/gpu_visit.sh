@@ -3,6 +3,7 @@
 #   tests      the whole gpu-marked suite (GK_JIT_STRICT=1: a hiprtc failure fails the test)
 #   smoke      __graft_entry__.smoke()
 #   bench      the default bench line (configs[2] + other_configs) as the driver runs it (--steps 20 --warmup 5)
+#   benchq     the headline workload alone with its parity legs (cpu loop, python oracle on 16 384, RESULT totals)
 #   lean       bench.py --lean --steps 50 (the headline kernel only: tuning runs)
 #   stats      rocprofv3 --kernel-trace --stats of the lean command
 #   pmc        rocprofv3 --pmc passes of the lean command (SQ, FETCH_SIZE, WRITE_SIZE: separate passes, --kernel-trace only)
@@ -44,7 +45,17 @@ try:
     print('lean: step %.4f ms kernel %.4f ms frac %.4f algo %d' % (j['ms_per_step'], r['avg_kernel_ms'], r['frac'], r['algo_bytes_per_launch']))
 except Exception as e: print('lean: no line', e)
 PY
-      tail -2 gpurun_out/${tag}_lean${GK_VARIANT:-}.err;;
+      grep "gkgpu prof" gpurun_out/${tag}_lean${GK_VARIANT:-}.err | tail -1; grep -v "gkgpu prof\|amdgpu.ids" gpurun_out/${tag}_lean${GK_VARIANT:-}.err | tail -2;;
+    benchq) timeout 600 python bench.py --no-other-configs --oracle-sample 16384 --steps 50 --warmup 5 > gpurun_out/${tag}_benchq${GK_VARIANT:-}.json 2> gpurun_out/${tag}_benchq${GK_VARIANT:-}.err; python - gpurun_out/${tag}_benchq${GK_VARIANT:-}.json <<'PY'
+import json, sys
+try:
+    j = json.loads(open(sys.argv[1]).read().strip().split('\n')[-1]); r = j['roofline']
+    print('benchq: step %.4f ms kernel %.4f ms frac %.4f | cpu-loop parity %s (n=%s) python-oracle parity %s (n=%s) totals equal %s' % (j['ms_per_step'], r['avg_kernel_ms'], r['frac'],
+          j.get('parity_sample', {}).get('pairs_equal'), j.get('parity_sample', {}).get('n'), j.get('parity_python_oracle', {}).get('pairs_equal'), j.get('parity_python_oracle', {}).get('n'),
+          j.get('audit_result_totals', {}).get('host_pass_over_every_pair', {}).get('equal')))
+except Exception as e: print('benchq: no line', e)
+PY
+      tail -2 gpurun_out/${tag}_benchq${GK_VARIANT:-}.err;;
     c1|c4) timeout 600 python bench.py --config ${stage#c} --lean --steps 50 --warmup 5 > gpurun_out/${tag}_${stage}.json 2> gpurun_out/${tag}_${stage}.err; tail -c 1500 gpurun_out/${tag}_${stage}.json; tail -2 gpurun_out/${tag}_${stage}.err;;
     stream) timeout 600 python bench.py --config 4 --streaming > gpurun_out/${tag}_stream_offered_1M.json 2> gpurun_out/${tag}_stream.err; tail -c 1200 gpurun_out/${tag}_stream_offered_1M.json
             timeout 600 python bench.py --config 4 --streaming --offered 0 > gpurun_out/${tag}_stream_closed_loop.json 2>> gpurun_out/${tag}_stream.err; tail -c 1200 gpurun_out/${tag}_stream_closed_loop.json;;
