@@ -59,6 +59,7 @@ DevTable* dev_table_view(DevTable* base);
 uint64_t dev_table_bytes(const DevTable* t);
 DevPlan* dev_plan_upload(int device, const HostPlan& fast, const HostPlan& big);
 void dev_plan_free(DevPlan* p);
+void dev_plan_no_jit(DevPlan* p);   // this plan is served by the bytecode kernel only (the small one-sweep-per-audit plans of the RESULT totals)
 void dev_eval(const DevPlan* p, const DevTable* t, const EvalOptions& opt, EvalOut* out);   // launch + finish; throws std::runtime_error
 // first-k violating reviews per bitmap row in `order` (reviews sorted by object key; grp = dense key rank, ties equal);
 // uses the bitmaps of the table's most recent evaluation.  idx: [nc][cap], n: [nc], ovf: [nc]

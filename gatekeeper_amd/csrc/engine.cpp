@@ -49,6 +49,14 @@ struct ConstraintRec {
   std::shared_ptr<const PreparedConstraint> multi_prep;
   bool multi_ready = false;   // multi_prep is what it will be (possibly null); false: derived by the first gk_table_totals that needs it
                               //   (half of a K8sContainerLimits AddConstraint went into a formula only the audit's RESULT totals read)
+  // RESULT COUNTS on the device (round 4; Template::count_forms): rows whose true values sum to the review's number of results
+  // + a flag "cannot tell" (rendered).  `cforms` is derived with the violation formula (one evaluation of the template) so that
+  // the message-key paths are registered with the flattener at AddConstraint; `count_rows` / `count_flag` are the prepared,
+  // trial-lowered forms (first gk_table_totals; empty = this constraint is served by multi_prep as in round 3)
+  std::shared_ptr<const Template::CountForms> cforms;
+  std::vector<std::shared_ptr<const PreparedConstraint>> count_rows;
+  std::shared_ptr<const PreparedConstraint> count_flag;
+  bool count_ready = false;
   // referential template (reads data.inventory): compiled against a snapshot of the synced objects, again whenever they change
   // (refresh_referential); `broken`: why the current inventory does not compile -- every evaluation then fails (GK_ERR_UNSUPPORTED)
   bool referential = false;
@@ -278,7 +286,7 @@ struct gk_engine {
   // constraint sets are split: the first group is the primary plan above, the others are evaluated one after the
   // other over the same resident table (each on its own view: result buffers + path binding) and their bitmap rows
   // are appended, so callers see one [n_constraints][n_tiles] answer.
-  struct Group { HostPlan fast, big; DevPlan* dev = nullptr; std::vector<uint32_t> ids; };
+  struct Group { HostPlan fast, big; DevPlan* dev = nullptr; std::vector<uint32_t> ids; std::vector<uint8_t> roles; };   // roles: totals groups only (TR_*)
   std::vector<std::unique_ptr<Group>> extra;
   struct Variant { HostPlan fast; DevPlan* dev = nullptr; };
   std::map<std::vector<uint16_t>, std::unique_ptr<Variant>> variants;
@@ -539,6 +547,82 @@ void ensure_plan(gk_engine* e) {
 
 Value parse_opt(const char* p, size_t n) { return (p && n) ? parse_json(p, n) : Value(); }
 
+// thresholds per counted iteration: "at least k elements fire", k = 2 .. GK_COUNT_KMAX (one more flags the review); GK_COUNT_KMAX=0
+// switches the device-side result counting off (round 3's "more than one result?" decision serves alone)
+enum : uint8_t { TR_MULTI = 0, TR_FLAG = 1, TR_COUNT = 2 };   // what a row of a totals plan answers (gk_engine::Group::roles)
+int count_kmax() { return getenv("GK_COUNT_KMAX") ? atoi(getenv("GK_COUNT_KMAX")) : 4; }   // (read per call: a test switches it within one process)
+
+// The counting forms of a constraint from the evaluation that gave its violation formula; registers the message-key paths with
+// the flattener (caller holds mu exclusively: a new key path makes the tables flattened so far stale, like a new value path)
+std::shared_ptr<const Template::CountForms> derive_count_forms(gk_engine* e, const Template::CountInfo& ci, const MatchFormulas& mf, FP* merged_viol = nullptr) {
+  if (count_kmax() < 2) return nullptr;
+  try {
+    const auto tf0 = std::chrono::steady_clock::now();
+    auto cf = std::make_shared<Template::CountForms>(Template::count_forms(ci, count_kmax()));
+    if (getenv("GK_DEBUG_LOAD")) fprintf(stderr, "[gkgpu load]   count_forms %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - tf0).count());
+    if (merged_viol && cf->viol && ci.br.size() > 8 && !getenv("GK_NO_MERGED_VIOL")) *merged_viol = cf->viol;   // (a constraint with many unrolled alternatives: the merged form is the smaller formula)
+    if (!cf->ok) return nullptr;
+    // What the counting plans will read must be registered NOW, before tables are flattened: the merged bodies of the counted
+    // branches fold their leaf-local parts into dictionary expressions of their own (the violation formula folds the union of
+    // all alternatives).  One trial lowering of every branch's plain row and of the flag, against the live registry; the
+    // threshold rows repeat those bodies.  A form that does not lower: no counting for this constraint (round 3's answer serves).
+    // What the counting plans will read must be registered NOW, before tables are flattened: the merged bodies of the counted
+    // branches fold their leaf-local parts into dictionary expressions of their own (the violation formula folds the union of all
+    // alternatives).  The forms are prepared (simplified, folded) and their dictionary atoms interned in the registry's COUNTING
+    // space -- no lowering: that happens once, at the first gk_table_totals, against the then frozen registry.
+    {
+      PrepMemoScope memo;
+      std::vector<FP> probe;
+      for (uint32_t i : cf->firsts) probe.push_back(cf->rows[i]);
+      probe.push_back(cf->flag);
+      std::function<void(const FP&)> walk = [&](const FP& f) {
+        if (f->kind == FNode::ATOM) {
+          if (f->atom.kind != Atom::DICT) return;
+          Pattern pat;
+          for (const Step& st : f->atom.path) { PatStep ps; if (st.iter) ps.any = true; else ps.key = st.key; pat.push_back(ps); }
+          e->dict_reg.counting().intern(pat, f->atom.dx, true);
+          return;
+        }
+        for (auto& k : f->kids) walk(k);
+      };
+      for (auto& f : probe) walk(prepare_constraint(f, mf)->viol);
+    }
+    for (const SPath& key : cf->keys) {
+      Pattern pat;
+      for (const Step& st : key) { PatStep ps; if (st.iter) { ps.any = true; ps.elems_only = true; } else ps.key = st.key; pat.push_back(ps); }
+      e->dict_reg.add_key(pat);
+    }
+    return cf;
+  } catch (const std::exception& ex) {
+    if (getenv("GK_DEBUG_MULTI")) fprintf(stderr, "[gkgpu totals] no counting forms: %s\n", ex.what());
+    return nullptr;
+  }
+}
+
+// the counting forms prepared and trial-lowered against the FROZEN registry (as prepare_multi): all or nothing
+void prepare_counts(gk_engine* e, ConstraintRec& c) {
+  c.count_rows.clear(); c.count_flag = nullptr; c.count_ready = true;
+  if (!c.cforms || !c.cforms->ok) return;
+  try {
+    PrepMemoScope memo;   // (the rows and the flag share their bodies, node for node)
+    std::vector<std::shared_ptr<const PreparedConstraint>> rows;
+    for (const FP& r : c.cforms->rows) rows.push_back(prepare_constraint(r, c.mf));
+    auto flag = prepare_constraint(c.cforms->flag, c.mf);
+    std::vector<std::shared_ptr<const PreparedConstraint>> all = rows;
+    all.push_back(flag);
+    for (size_t i = 0; i < all.size(); i += 24) {   // (trial builds in batches that fit a plan's result slots)
+      PlanBuilder pb(&e->dict, &e->dict_reg, true);
+      pb.use_counting_space();
+      for (size_t j = i; j < std::min(all.size(), i + 24); j++) pb.add_constraint(all[j]);
+      PlanCaps caps;
+      pb.build(caps);
+    }
+    c.count_rows = std::move(rows); c.count_flag = std::move(flag);
+  } catch (const std::exception& ex) {
+    if (getenv("GK_DEBUG_MULTI")) fprintf(stderr, "[gkgpu totals] %s/%s: counting forms do not lower (%s): the multi formula serves\n", c.kind.c_str(), c.name.c_str(), ex.what());
+  }
+}
+
 // "may yield more than one result" formula of a constraint (Template::compile_multi), prepared and checked to lower like the
 // violation formula is -- at AddConstraint time, so that the dictionary predicates / value-id paths it needs are registered
 // before tables are flattened.  Null when it does not lower: gk_table_totals then renders every violating pair of it.
@@ -593,7 +677,8 @@ void start_inventory_tracking(gk_engine* e) {
 // throws what compile / the lowering throw
 void compile_referential(gk_engine* e, const Template& t, ConstraintRec& c) {
   const Value& inv = current_inventory(e);
-  FP viol = t.compile(c.params, &e->next_quant, inv);
+  const Template::CountInfo ci = t.compile_all(c.params, &e->next_quant, inv);
+  FP viol = ci.viol;
   auto prep = prepare_constraint(viol, c.mf);
   {
     PlanBuilder pb(&e->dict, &e->dict_reg);
@@ -604,6 +689,8 @@ void compile_referential(gk_engine* e, const Template& t, ConstraintRec& c) {
   c.viol = viol; c.prep = prep;
   c.multi_prep = prepare_multi(e, t, c.params, c.mf, inv);
   c.multi_ready = true;
+  c.cforms = derive_count_forms(e, ci, c.mf);
+  c.count_ready = false;
 }
 
 // The synced objects changed: the constraints of referential templates are compiled against the new inventory.  One that no
@@ -645,27 +732,51 @@ void ensure_totals_plans(gk_engine* e) {
     c.multi_prep = it == e->templates.end() ? nullptr : prepare_multi(e, *it->second, c.params, c.mf);
     c.multi_ready = true;
   }
-  std::vector<const ConstraintRec*> have;
-  for (auto& c : e->constraints) if (c.alive && c.multi_prep) have.push_back(&c);
-  std::function<void(const std::vector<const ConstraintRec*>&)> place = [&](const std::vector<const ConstraintRec*>& g) {
+  // ... and the counting forms (round 4): a constraint whose forms lower is served by its count rows + flag row, any other by
+  // its multi formula (round 3), one without either has every violating pair rendered
+  const auto tc0 = std::chrono::steady_clock::now();
+  for (auto& c : e->constraints) if (c.alive && !c.count_ready) prepare_counts(e, c);
+  const auto tc1 = std::chrono::steady_clock::now();
+  struct Item { std::shared_ptr<const PreparedConstraint> prep; uint32_t cid; uint8_t role; };
+  std::vector<Item> have;
+  for (auto& c : e->constraints) {
+    if (!c.alive) continue;
+    if (c.count_flag) {
+      have.push_back({c.count_flag, c.id, TR_FLAG});
+      for (auto& r : c.count_rows) have.push_back({r, c.id, TR_COUNT});
+    } else if (c.multi_prep) have.push_back({c.multi_prep, c.id, TR_MULTI});
+  }
+  std::function<void(const std::vector<Item>&)> place = [&](const std::vector<Item>& g) {
     if (g.empty()) return;
     std::unique_ptr<gk_engine::Group> grp(new gk_engine::Group());
     try {
       PlanBuilder pb(&e->dict, &e->dict_reg, true);
-      for (auto* c : g) pb.add_constraint(c->multi_prep);
+      pb.use_counting_space(g[0].role != TR_MULTI);   // (a group holds rows of one kind: place() is called per kind)
+      for (auto& it : g) pb.add_constraint(it.prep);
       grp->fast = pb.build(default_caps(e));
       grp->big = pb.build(bigcaps);
     } catch (const Unsupported&) {
-      if (g.size() <= 1) return;   // (checked alone at AddConstraint; should it fail now, its pairs are rendered)
-      const size_t half = g.size() > 64 ? 64 : g.size() / 2;
-      for (size_t i = 0; i < g.size(); i += half) place(std::vector<const ConstraintRec*>(g.begin() + i, g.begin() + std::min(g.size(), i + half)));
+      if (g.size() <= 1) {   // (checked at preparation; should it fail now: a flag / multi row that is missing means "render", a
+        if (!g.empty() && g[0].role == TR_COUNT) throw;   //  missing count row would be an undercount -- never silently)
+        return;
+      }
+      const size_t half = g.size() > 48 ? 48 : g.size() / 2;
+      for (size_t i = 0; i < g.size(); i += half) place(std::vector<Item>(g.begin() + i, g.begin() + std::min(g.size(), i + half)));
       return;
     }
-    for (auto* c : g) grp->ids.push_back(c->id);
+    for (auto& it : g) { grp->ids.push_back(it.cid); grp->roles.push_back(it.role); }
     grp->dev = dev_plan_upload(e->opts.device, grp->fast, grp->big);
+    dev_plan_no_jit(grp->dev);   // (dozens of small plans, one sweep per audit each: the bytecode kernel serves them)
     e->totals_groups.push_back(std::move(grp));
   };
-  place(have);
+  {
+    std::vector<Item> multis, counts;
+    for (auto& it : have) (it.role == TR_MULTI ? multis : counts).push_back(it);
+    place(multis);
+    place(counts);
+    if (getenv("GK_DEBUG_MULTI")) fprintf(stderr, "[gkgpu totals] %zu multi rows, %zu count / flag rows -> %zu plans; counting forms prepared in %.2f s, plans built in %.2f s\n", multis.size(), counts.size(),
+                                          e->totals_groups.size(), std::chrono::duration<double>(tc1 - tc0).count(), std::chrono::duration<double>(std::chrono::steady_clock::now() - tc1).count());
+  }
   e->totals_gen = e->plan_gen;
 }
 
@@ -716,24 +827,26 @@ int gk_template_add(gk_engine* e, const char* kind, const char* rego, const char
     // nothing: when one of them does not compile the old template and its constraints stay as they are and the caller
     // gets the error (the reference reports it on the ConstraintTemplate's status and keeps serving the old one).
     const std::string k = lower_str(kind);
-    struct Redo { ConstraintRec* c; FP viol; std::shared_ptr<const PreparedConstraint> prep, multi; bool referential; };
+    struct Redo { ConstraintRec* c; FP viol; std::shared_ptr<const PreparedConstraint> prep, multi; bool referential; std::shared_ptr<const Template::CountForms> cforms; };
     std::vector<Redo> redo;
     for (auto& c : e->constraints) {
       if (!c.alive || lower_str(c.kind) != k) continue;
       const bool ref = t->references_inventory();
       if (ref) start_inventory_tracking(e);
       const Value inv = ref ? current_inventory(e) : Value();
-      Redo r{&c, t->compile(c.params, &e->next_quant, inv), nullptr, nullptr, ref};
+      const Template::CountInfo ci = t->compile_all(c.params, &e->next_quant, inv);
+      Redo r{&c, ci.viol, nullptr, nullptr, ref, nullptr};
       r.prep = prepare_constraint(r.viol, c.mf);
       PlanBuilder pb(&e->dict, &e->dict_reg);
       pb.add_constraint(r.prep);
       PlanCaps caps;
       pb.build(caps);
       r.multi = prepare_multi(e, *t, c.params, c.mf, inv);
+      r.cforms = derive_count_forms(e, ci, c.mf);
       redo.push_back(std::move(r));
     }
     e->templates[k] = t;
-    for (auto& r : redo) { r.c->viol = std::move(r.viol); r.c->prep = std::move(r.prep); r.c->multi_prep = std::move(r.multi); r.c->multi_ready = true; r.c->referential = r.referential; r.c->broken.clear(); }
+    for (auto& r : redo) { r.c->viol = std::move(r.viol); r.c->prep = std::move(r.prep); r.c->multi_prep = std::move(r.multi); r.c->multi_ready = true; r.c->referential = r.referential; r.c->broken.clear(); r.c->cforms = std::move(r.cforms); r.c->count_ready = false; r.c->count_rows.clear(); r.c->count_flag = nullptr; }
     // (inv_compiled stays as it is: referential constraints of OTHER kinds may still hold an older inventory -- refresh_referential
     // recompiles every one of them at the next evaluation; marking the inventory compiled here left them stale, i.e. missed violations)
     e->plan_dirty = true;
@@ -790,7 +903,19 @@ int gk_constraint_add(gk_engine* e, const char* json, size_t len, uint32_t* id_o
       rec.referential = true;
       compile_referential(e, *it->second, rec);
     } else {
-      rec.viol = it->second->compile(rec.params, &e->next_quant);
+      const auto ta0 = std::chrono::steady_clock::now();
+      PrepMemoScope memo;   // (the violation formula and the counting forms share their bodies node for node: simplified and folded once)
+      const Template::CountInfo ci = it->second->compile_all(rec.params, &e->next_quant);
+      rec.viol = ci.viol;
+      const auto ta1 = std::chrono::steady_clock::now();
+      rec.cforms = derive_count_forms(e, ci, rec.mf, &rec.viol);
+      const auto ta2 = std::chrono::steady_clock::now();
+      if (getenv("GK_DEBUG_COUNTS")) {
+        fprintf(stderr, "[gkgpu counts] %s/%s: %zu branches, forms %s\n", rec.kind.c_str(), rec.name.c_str(), ci.br.size(), rec.cforms ? "ok" : "none");
+        for (auto& b : ci.br) fprintf(stderr, "   nq=%d keyed=%d const=%d head=%d pre=[%s] sep=[%s] tail=%d key=%s sig0=%s\n", b.nq, (int)b.keyed, (int)b.is_const, (int)b.head, b.pre.c_str(), b.sep.c_str(), (int)b.sep_tail,
+                                    spath_to_string(b.key).c_str(), b.sig.empty() ? "" : b.sig[0].c_str());
+        if (rec.cforms) fprintf(stderr, "   flag: %s\n", f_to_string(rec.cforms->flag).substr(0, 600).c_str());
+      }
       // validate that it lowers (element scopes, register pressure) before accepting it
       {
         PlanBuilder pb(&e->dict, &e->dict_reg);
@@ -800,6 +925,9 @@ int gk_constraint_add(gk_engine* e, const char* json, size_t len, uint32_t* id_o
         pb.build(caps);
       }
       rec.multi_ready = false;   // (prepare_multi: on demand, ensure_totals_plans)
+      if (getenv("GK_DEBUG_LOAD")) fprintf(stderr, "[gkgpu load] %s/%s: evaluate %.3f s, counting forms %.3f s, prepare + trial plan %.3f s\n", rec.kind.c_str(), rec.name.c_str(),
+                                           std::chrono::duration<double>(ta1 - ta0).count(), std::chrono::duration<double>(ta2 - ta1).count(),
+                                           std::chrono::duration<double>(std::chrono::steady_clock::now() - ta2).count());
     }
     for (auto& o : e->constraints) if (o.alive && o.kind == rec.kind && o.name == rec.name) o.alive = false;   // replace
     rec.id = (uint32_t)e->constraints.size();
@@ -1546,8 +1674,12 @@ static const ReviewDoc* doc_for(gk_engine* e, const gk_table* t, uint32_t r, Rev
 // they do not flag has exactly one result.  Everything they cannot answer stays in: constraints without a multi formula,
 // reviews beyond the totals plans' limits, GK_TOTALS_RENDER_ALL=1 (test aid: the host pass over every violating pair, as
 // before round 3).  Caller holds plan_rw shared and mu shared; ensure_plan ran; ids = constraint id per bitmap row.
-static std::vector<uint64_t> render_needed(gk_engine* e, gk_table* t, const std::vector<uint32_t>& ids, uint32_t nt, const std::vector<uint64_t>& viol) {
+// `counted[row]` (round 4): the device COUNTED the results of the row's unflagged pairs -- `sum[row]` of them -- instead of deciding
+// "exactly one".
+static std::vector<uint64_t> render_needed(gk_engine* e, gk_table* t, const std::vector<uint32_t>& ids, uint32_t nt, const std::vector<uint64_t>& viol,
+                                           std::vector<uint8_t>* counted, std::vector<uint64_t>* sum) {
   std::vector<uint64_t> need = viol;
+  counted->assign(ids.size(), 0); sum->assign(ids.size(), 0);
   if (getenv("GK_TOTALS_RENDER_ALL") || t->n_reviews == 0) return need;
   if (t->dict_gen != e->dict_reg.gen()) return need;   // (a table flattened before the constraint set changed: no totals plan can read it)
   std::lock_guard<std::mutex> tl(e->totals_mu);
@@ -1559,25 +1691,62 @@ static std::vector<uint64_t> render_needed(gk_engine* e, gk_table* t, const std:
   opt.download = true;
   opt.jit_wait = false;   // one pass per audit: the bytecode kernel serves it unless the specialised build is there already
   while (t->tviews.size() < e->totals_groups.size()) t->tviews.push_back(dev_table_view(t->dev));
-  for (size_t gi = 0; gi < e->totals_groups.size(); gi++) dev_eval_launch(e->totals_groups[gi]->dev, t->tviews[gi], opt);
   std::vector<uint64_t> beyond(nt, 0);
-  std::vector<bool> answered(ids.size(), false);
+  std::vector<uint8_t> answered(ids.size(), 0);   // 1: a multi row, 2: a flag row (count rows follow)
   std::vector<uint64_t> multi((size_t)ids.size() * nt, 0);
-  for (size_t gi = 0; gi < e->totals_groups.size(); gi++) {
-    EvalOut og;
-    dev_eval_finish(e->totals_groups[gi]->dev, t->tviews[gi], opt, &og);
-    for (uint32_t w = 0; w < nt && w < og.too_big.size(); w++) beyond[w] |= og.too_big[w];
-    for (uint32_t r = 0; r < e->totals_groups[gi]->ids.size() && r < og.n_constraints; r++) {
-      auto it = row_of.find(e->totals_groups[gi]->ids[r]);
-      if (it == row_of.end() || og.n_tiles != nt) continue;
-      answered[it->second] = true;
-      // (autoreject pairs of the totals plan are the main plan's: they carry no violation bit either way)
-      for (uint32_t w = 0; w < nt; w++) multi[(size_t)it->second * nt + w] = og.viol[(size_t)r * nt + w];
+  std::vector<std::vector<uint64_t>> count_rows;   // count rows of all groups, with the main row they belong to
+  std::vector<uint32_t> count_main;
+  // (the groups are launched in waves: each holds a view of the table -- a stream and result buffers of its own)
+  const size_t wave = 8;
+  for (size_t g0 = 0; g0 < e->totals_groups.size(); g0 += wave) {
+    const size_t g1 = std::min(e->totals_groups.size(), g0 + wave);
+    for (size_t gi = g0; gi < g1; gi++) dev_eval_launch(e->totals_groups[gi]->dev, t->tviews[gi], opt);
+    for (size_t gi = g0; gi < g1; gi++) {
+      EvalOut og;
+      dev_eval_finish(e->totals_groups[gi]->dev, t->tviews[gi], opt, &og);
+      const gk_engine::Group& G = *e->totals_groups[gi];
+      for (uint32_t w = 0; w < nt && w < og.too_big.size(); w++) beyond[w] |= og.too_big[w];
+      for (uint32_t r = 0; r < G.ids.size() && r < og.n_constraints; r++) {
+        auto it = row_of.find(G.ids[r]);
+        if (it == row_of.end() || og.n_tiles != nt) continue;
+        const uint8_t role = r < G.roles.size() ? G.roles[r] : (uint8_t)TR_MULTI;
+        const uint64_t* bits = &og.viol[(size_t)r * nt];
+        // (autoreject pairs of the totals plan are the main plan's: they carry no violation bit either way)
+        if (role == TR_COUNT) { count_rows.emplace_back(bits, bits + nt); count_main.push_back(it->second); continue; }
+        answered[it->second] = role == TR_FLAG ? 2 : 1;
+        for (uint32_t w = 0; w < nt; w++) multi[(size_t)it->second * nt + w] = bits[w];
+      }
     }
   }
   for (uint32_t r = 0; r < ids.size(); r++) {
     if (!answered[r]) continue;
     for (uint32_t w = 0; w < nt; w++) need[(size_t)r * nt + w] = viol[(size_t)r * nt + w] & (multi[(size_t)r * nt + w] | beyond[w]);
+    if (answered[r] == 2) (*counted)[r] = 1;
+  }
+  for (size_t k = 0; k < count_rows.size(); k++) {
+    const uint32_t r = count_main[k];
+    if (!(*counted)[r]) continue;   // (its flag row is missing: the pairs are rendered)
+    uint64_t n = 0;
+    for (uint32_t w = 0; w < nt; w++) n += (uint64_t)__builtin_popcountll(count_rows[k][w] & viol[(size_t)r * nt + w] & ~need[(size_t)r * nt + w]);
+    (*sum)[r] += n;
+  }
+  if (getenv("GK_DEBUG_COUNT_CHECK")) {   // debugging aid: every counted pair is rendered as well and compared, review by review
+    int shown = 0;
+    for (uint32_t r = 0; r < ids.size() && shown < 12; r++) {
+      if (!(*counted)[r]) continue;
+      const ConstraintRec& c = e->constraints[ids[r]];
+      auto itt = e->templates.find(lower_str(c.kind));
+      for (uint32_t i = 0; i < t->n_reviews && shown < 12; i++) {
+        const uint32_t w = i / 64; const uint64_t b = 1ull << (i % 64);
+        if (!(viol[(size_t)r * nt + w] & b) || (need[(size_t)r * nt + w] & b)) continue;
+        uint32_t dev = 0;
+        for (size_t k = 0; k < count_rows.size(); k++) if (count_main[k] == r && (count_rows[k][w] & b)) dev++;
+        ReviewDoc tmp;
+        const ReviewDoc* doc = doc_for(e, t, i, &tmp);
+        const size_t host = doc ? itt->second->render(doc->request, c.params, e->inventory).size() : 0;
+        if (host != dev) { shown++; fprintf(stderr, "[gkgpu count check] %s/%s review %u: device %u, renderer %zu\n", c.kind.c_str(), c.name.c_str(), i, dev, host); }
+      }
+    }
   }
   return need;
 }
@@ -1608,13 +1777,17 @@ int gk_table_totals(gk_engine* e, gk_table* t, gk_totals_out** out) {
     std::shared_lock<std::shared_mutex> rl(e->mu);
     // Round 3: the device decides which violating pairs CAN have more than one result; every other violating pair counts one
     // result without being rendered (configs[2]: 1.8 M violating pairs, ~1 % of them rendered)
-    const std::vector<uint64_t> need = render_needed(e, t, h->ids, nt, viol);
-    for (uint32_t row = 0; row < nc; row++)
+    std::vector<uint8_t> counted;
+    std::vector<uint64_t> counted_sum;
+    const std::vector<uint64_t> need = render_needed(e, t, h->ids, nt, viol, &counted, &counted_sum);
+    for (uint32_t row = 0; row < nc; row++) {
       for (uint32_t w = 0; w < nt; w++) {
         const uint64_t v = viol[(size_t)row * nt + w];
         h->pairs[row] += (uint64_t)__builtin_popcountll(v);
-        h->results[row] += (uint64_t)__builtin_popcountll(v & ~need[(size_t)row * nt + w]);   // exactly one result each
+        if (!counted[row]) h->results[row] += (uint64_t)__builtin_popcountll(v & ~need[(size_t)row * nt + w]);   // exactly one result each
       }
+      if (counted[row]) h->results[row] += counted_sum[row];   // (round 4) counted on the device: as many as their count rows say
+    }
     uint64_t n_rendered = 0;
     for (uint64_t x : need) n_rendered += (uint64_t)__builtin_popcountll(x);
     h->pub.rendered_pairs = n_rendered;
@@ -2113,9 +2286,13 @@ int gk_resident_sweep(gk_engine* e, uint32_t flags, gk_sweep_out** out) {
         std::vector<uint64_t> shown_viol((size_t)nc * nt, 0);
         for (uint32_t row = 0; row < ncc; row++)
           for (uint32_t w = 0; w < nt; w++) shown_viol[(size_t)row * nt + w] = ev->viol[(size_t)row * nt + w] & c.shown[w];
-        const std::vector<uint64_t> need = render_needed(e, c.table, h->ids, nt, shown_viol);
-        for (uint32_t row = 0; row < ncc; row++)
+        std::vector<uint8_t> counted;
+        std::vector<uint64_t> counted_sum;
+        const std::vector<uint64_t> need = render_needed(e, c.table, h->ids, nt, shown_viol, &counted, &counted_sum);
+        for (uint32_t row = 0; row < ncc; row++) {
+          if (counted[row]) { h->results[row] += counted_sum[row]; continue; }   // (round 4: counted on the device)
           for (uint32_t w = 0; w < nt; w++) h->results[row] += (uint64_t)__builtin_popcountll(shown_viol[(size_t)row * nt + w] & ~need[(size_t)row * nt + w]);
+        }
         for (uint32_t slot = 0; slot < c.obj_of_slot.size(); slot++) {
           const uint64_t bit = 1ull << (slot % 64);
           bool any = false;

@@ -152,7 +152,11 @@ uint32_t DictRegistry::intern(const Pattern& leaf_in, const DX& dx, bool add) {
   gen_++;
   return p->entries.back().bit;
 }
-uint64_t DictRegistry::gen() const { return gen_.load(std::memory_order_acquire); }
+uint64_t DictRegistry::gen() const {
+  uint64_t g = gen_.load(std::memory_order_acquire);
+  if (const DictRegistry* c = counting_if_any()) g += c->gen() << 32;   // (a new counting expression makes earlier tables stale as well)
+  return g;
+}
 bool DictRegistry::memo_get(int pi, size_t n_entries, const std::string& key, uint64_t* mask) const {
   std::shared_lock<std::shared_mutex> l(mu_);
   if (pi < 0 || (size_t)pi >= pats_.size() || pats_[pi].entries.size() != n_entries) return false;
@@ -204,6 +208,20 @@ bool DictRegistry::add_value(const Pattern& leaf, bool add) {
   values_.emplace_back(k, leaf);
   gen_++;   // tables flattened before this do not carry the ids: they are stale (engine.cpp dict_gen)
   return true;
+}
+bool DictRegistry::add_key(const Pattern& leaf, bool add) {
+  const std::string k = pattern_to_string(leaf);
+  std::unique_lock<std::shared_mutex> l(mu_);
+  for (auto& g : keys_) if (g.first == k) return true;
+  if (!add) return false;
+  keys_.emplace_back(k, leaf);
+  gen_++;   // tables flattened before this do not carry review.$dup for these paths: they are stale (engine.cpp dict_gen)
+  return true;
+}
+bool DictRegistry::keyed(const PathDict& dict, uint32_t path_id) const {
+  std::shared_lock<std::shared_mutex> l(mu_);
+  for (const auto& g : keys_) if (pattern_matches(g.second, dict, path_id)) return true;
+  return false;
 }
 bool DictRegistry::valued(const PathDict& dict, uint32_t path_id) const {
   std::shared_lock<std::shared_mutex> l(mu_);
@@ -425,10 +443,14 @@ bool Flattener::dict_wanted(uint32_t path) {
   DictPath& d = dict_paths_[path];
   if (d.state == 0) {
     reg_->match(*dict_, path, &d.entries, &d.pat);
-    d.state = d.entries.empty() ? 1 : 2;
+    d.centries.clear(); d.cpat = -1;
+    if (const DictRegistry* c = reg_->counting_if_any()) c->match(*dict_, path, &d.centries, &d.cpat);
+    d.state = d.entries.empty() && d.centries.empty() ? 1 : 2;
     d.deep = false;
     for (const DictEntry& e : d.entries) if (dx_deep(e.dx)) d.deep = true;
-    if (d.state == 2) d.dpath = child(path, "$d");
+    for (const DictEntry& e : d.centries) if (dx_deep(e.dx)) d.deep = true;
+    if (!d.entries.empty()) d.dpath = child(path, "$d");
+    if (!d.centries.empty()) d.cpath = child(path, "$c");
   }
   return dict_paths_[path].state == 2;
 }
@@ -447,18 +469,29 @@ void Flattener::dict_row(uint32_t path, uint32_t meta, const Value& leaf) {
   // an expression of this path is DEEP (dexpr.hpp): then the leaf is the real sub-document and the memo goes by its text
   std::string key = ((leaf.is_array() || leaf.is_object() || leaf.is_set()) && !d.deep) ? std::to_string(leaf.size()) : to_term_string(leaf);
   key.push_back((char)('0' + (int)leaf.kind));
-  auto it = d.memo.find(key);
-  uint64_t mask;
-  if (it != d.memo.end()) mask = it->second;
-  else {
-    if (!reg_->memo_get(d.pat, d.entries.size(), key, &mask)) {   // first sight of this value in the whole engine
-      mask = 0;
-      for (const DictEntry& e : d.entries) if (dx_true(e.dx, leaf)) mask |= 1ull << e.bit;
-      const_cast<DictRegistry*>(reg_)->memo_put(d.pat, d.entries.size(), key, mask);
+  // (both masks are worked out BEFORE a row is emitted: emit() may grow dict_paths_ -- the new row's path id asks value_wanted /
+  //  key_wanted -- and `d` would dangle)
+  uint64_t masks[2] = {0, 0};
+  const uint32_t dpaths[2] = {d.dpath, d.cpath};
+  auto one = [&](const DictRegistry* reg, int pat, const std::vector<DictEntry>& entries, std::unordered_map<std::string, uint64_t>& memo, uint64_t* out) {
+    if (entries.empty()) return;
+    auto it = memo.find(key);
+    uint64_t mask;
+    if (it != memo.end()) mask = it->second;
+    else {
+      if (!reg->memo_get(pat, entries.size(), key, &mask)) {   // first sight of this value in the whole engine
+        mask = 0;
+        for (const DictEntry& e : entries) if (dx_true(e.dx, leaf)) mask |= 1ull << e.bit;
+        const_cast<DictRegistry*>(reg)->memo_put(pat, entries.size(), key, mask);
+      }
+      if (memo.size() < 65536) memo.emplace(key, mask);
     }
-    if (d.memo.size() < 65536) d.memo.emplace(std::move(key), mask);
-  }
-  if (mask) emit(d.dpath, (meta & ~(uint32_t)ROW_TYPE_MASK & ~(uint32_t)ROW_STR_INLINE) | T_INT, (uint32_t)mask, (uint32_t)(mask >> 32));
+    *out = mask;
+  };
+  one(reg_, d.pat, d.entries, d.memo, &masks[0]);
+  if (!d.centries.empty()) one(reg_->counting_if_any(), d.cpat, d.centries, d.cmemo, &masks[1]);   // (<leaf>.$c: the counting plans' expressions)
+  for (int k = 0; k < 2; k++)
+    if (masks[k]) emit(dpaths[k], (meta & ~(uint32_t)ROW_TYPE_MASK & ~(uint32_t)ROW_STR_INLINE) | T_INT, (uint32_t)masks[k], (uint32_t)(masks[k] >> 32));
 }
 
 bool Flattener::value_wanted(uint32_t path) {
@@ -506,9 +539,22 @@ uint32_t Flattener::value_id(uint32_t meta, uint32_t lo, uint32_t hi) {
   return want.id;
 }
 
+bool Flattener::key_wanted(uint32_t path) {
+  if (!reg_) return false;
+  if (path >= dict_paths_.size()) dict_paths_.resize((size_t)path * 2 + 64);
+  DictPath& d = dict_paths_[path];
+  if (d.kstate == 0) d.kstate = reg_->keyed(*dict_, path) ? 2 : 1;
+  return d.kstate == 2;
+}
+
 void Flattener::emit(uint32_t path, uint32_t meta, uint32_t lo, uint32_t hi) {
   uint32_t rev = t_->n_reviews % t_->rpt;
   if (value_wanted(path)) rev |= value_id(meta, lo, hi) << ROW_VID_SHIFT;
+  if (key_wanted(path)) {   // a message key: equal values within the review (or one without an id) -> review.$dup (finish_review)
+    const uint32_t id = value_id(meta, lo, hi);
+    if (id == 0u || id == GK_VID_OVERFLOW || std::find(key_ids_.begin(), key_ids_.end(), id) != key_ids_.end()) dup_seen_ = true;
+    else key_ids_.push_back(id);
+  }
   stage_.push_back({path, Row{rev, meta, lo, hi}, StrHdr{{0, 0, 0, 0}}});
 }
 
@@ -639,6 +685,7 @@ void Flattener::add(const ReviewDoc& doc, HostTable* out) {
   ctr_touched_.clear();
   review_flags_ = 0;
   vids_.clear();
+  begin_review_keys();
   const Value& req = doc.request;
   // root + request members (input.review.*)
   emit(0, T_OBJECT, (uint32_t)req.size(), 0);
@@ -686,6 +733,10 @@ void Flattener::finish_review(const Value& ns, int source, HostTable* out) {
     case SRC_ALL: review_flags_ |= RF_SRC_ALL; break;
     case SRC_INVALID: review_flags_ |= RF_SRC_INVALID; break;
     default: break;
+  }
+  if (dup_seen_) {   // (round 4) two message keys of this review are equal: the counting plans leave it to the renderer
+    if (!id_dup_) id_dup_ = child(0, "$dup");
+    emit(id_dup_, T_BOOL, 1, 0);
   }
   out->rflags.push_back(review_flags_);
   for (const Ctr& c : ctrs_) {
@@ -1132,6 +1183,7 @@ int Flattener::add_json_request(const RawReview& r, const NsCache& cache, HostTa
   scratch_keep_.clear();
   review_flags_ = 0;
   vids_.clear();
+  begin_review_keys();
   if (++review_gen_ == 0) { std::fill(ctr_gen_.begin(), ctr_gen_.end(), 0); review_gen_ = 1; }
   // 1. the envelope: spans of the members normalize_admission_request reads; anything else is dropped (Go decodes into a
   // struct) after a syntax check by the subtree parser
@@ -1278,6 +1330,7 @@ int Flattener::add_json(const RawReview& r, const NsCache& cache, HostTable* out
   scratch_keep_.clear();
   review_flags_ = 0;
   vids_.clear();
+  begin_review_keys();
   if (++review_gen_ == 0) { std::fill(ctr_gen_.begin(), ctr_gen_.end(), 0); review_gen_ = 1; }
   const std::string op = r.operation ? r.operation : "";
   const bool del = op == "DELETE";   // target.go:151-154 + setObjectOnDelete: the object is both oldObject and object

@@ -103,12 +103,23 @@ class DictRegistry {
   // flattener gives the rows of matching paths a VALUE ID (plan.hpp ROW_VID_*), unique per distinct value within the review.
   bool add_value(const Pattern& leaf, bool add = true);        // false: not registered (and add = false)
   bool valued(const PathDict& dict, uint32_t path_id) const;
+  // Message keys (round 4, result counting: pe.hpp Template::count_forms): leaf patterns whose values lead the messages of a
+  // per-element violation.  A review in which two rows of such paths hold the SAME value -- or one that is no scalar -- gets the
+  // synthetic row  review.$dup : true ; the counting plans then leave the review's pairs to the host renderer.
+  bool add_key(const Pattern& leaf, bool add = true);
+  bool keyed(const PathDict& dict, uint32_t path_id) const;
+  // The COUNTING space (round 4): the dictionary expressions the result-counting plans read live in a registry of their own and
+  // travel in a row of their own, <leaf>.$c -- the 62 bits per leaf of <leaf>.$d belong to the violation formulas alone (a
+  // constraint must never become unloadable because the totals of another one took its bits).
+  DictRegistry& counting() { std::unique_lock<std::shared_mutex> l(mu_); if (!counting_) counting_.reset(new DictRegistry()); return *counting_; }
+  const DictRegistry* counting_if_any() const { std::shared_lock<std::shared_mutex> l(mu_); return counting_.get(); }
  private:
   struct Pat { Pattern pat; std::string key; std::vector<DictEntry> entries; std::unordered_map<std::string, uint64_t> memo; };
   mutable std::shared_mutex mu_;
   std::vector<Pat> pats_;
-  std::vector<std::pair<std::string, Pattern>> guards_, values_;
+  std::vector<std::pair<std::string, Pattern>> guards_, values_, keys_;
   std::atomic<uint64_t> gen_{0};
+  std::unique_ptr<DictRegistry> counting_;
 };
 
 uint32_t hash32(const uint8_t* p, size_t n);
@@ -281,13 +292,19 @@ class Flattener {
   PathDict* dict_;
   const DictRegistry* reg_ = nullptr;
   uint64_t reg_gen_ = ~0ull;
-  struct DictPath { int state = 0; int gstate = 0; int vstate = 0; int pat = -1; bool deep = false /* some expression looks inside a container leaf */; std::vector<DictEntry> entries; uint32_t dpath = 0; std::unordered_map<std::string, uint64_t> memo; };   // state 0 unknown, 1 none, 2 has entries
+  struct DictPath { int state = 0; int gstate = 0; int vstate = 0; int kstate = 0; int pat = -1; bool deep = false /* some expression looks inside a container leaf */; std::vector<DictEntry> entries; uint32_t dpath = 0; std::unordered_map<std::string, uint64_t> memo;   // state 0 unknown, 1 none, 2 has entries
+                    int cpat = -1; std::vector<DictEntry> centries; uint32_t cpath = 0; std::unordered_map<std::string, uint64_t> cmemo; /* the counting space: <leaf>.$c */ };
   std::vector<DictPath> dict_paths_;
   void dict_row(uint32_t path, uint32_t meta, const Value& leaf);   // emits <leaf>.$d when some registered expression is true
   bool dict_wanted(uint32_t path);
   bool dict_deep(uint32_t path) { return dict_wanted(path) && dict_paths_[path].deep; }
   bool guard_wanted(uint32_t path);   // is `path` a container under which element predicates iterate? (cached per path)
   bool value_wanted(uint32_t path);   // are the rows of `path` compared with other review values? (cached per path)
+  bool key_wanted(uint32_t path);     // do the rows of `path` lead per-element messages? (DictRegistry::add_key)
+  std::vector<uint32_t> key_ids_;     // value ids of the key rows of the current review
+  bool dup_seen_ = false;             // ... two of them were equal (or not a scalar): review.$dup
+  uint32_t id_dup_ = 0;
+  void begin_review_keys() { key_ids_.clear(); dup_seen_ = false; }
   // per-review interning of compared values -> value ids (plan.hpp ROW_VID_*)
   struct VidEnt { uint64_t key; uint32_t tag, off, id; };   // tag 1 number-as-int64, 2 float bits, 3 inline string, 4 heap string (key = hash32 | len << 32, off = heap offset)
   std::vector<VidEnt> vids_;

@@ -60,7 +60,7 @@ inline size_t static_lds_of(uint32_t rpt, int block, uint32_t res_k, uint32_t li
 #define GK_RING_DEFAULT 0
 #endif
 inline uint32_t jit_ring_slots(uint32_t rpt) {
-  static const int v = getenv("GK_JIT_RING") ? atoi(getenv("GK_JIT_RING")) : GK_RING_DEFAULT;
+  const int v = getenv("GK_JIT_RING") ? atoi(getenv("GK_JIT_RING")) : GK_RING_DEFAULT;   // (read per call: the tests switch it within one process)
   return rpt >= 256 && (v == 4 || v == 8) ? (uint32_t)v : 0u;
 }
 inline size_t jit_ring_bytes(uint32_t rpt) { return (size_t)jit_ring_slots(rpt) * 1024 * (size_t)(jit_block_of(rpt) / GK_TILE); }

@@ -321,7 +321,30 @@ void fuse_split_prefix(std::vector<FP>& conj) {
   }
 }
 
-FP simplify(const FP& f) {
+// ---- memo of the three pure passes (simplify, pin_pass, fold_dict), keyed by NODE: the formulas prepared for one constraint's result
+// counting -- a row per threshold, the flag with its pairwise terms -- share their (large, merged) bodies as nodes, and every
+// prepare_constraint walked them afresh: 6 s per K8sContainerLimits constraint.  Scoped (PrepMemoScope): the nodes outlive it.
+struct PrepMemo { std::unordered_map<const FNode*, FP> simp, pin, fold; std::vector<FP> keep; };
+static thread_local PrepMemo* g_prep_memo = nullptr;
+static FP simplify_impl(const FP& f);
+static FP fold_dict_impl(const FP& f);
+static FP pin_pass_impl(const FP& f);
+#define GK_MEMO_PASS(name, field)                                                                       \
+  FP name(const FP& f) {                                                                                \
+    if (!g_prep_memo || f->kind == FNode::T || f->kind == FNode::F || f->kind == FNode::ATOM) return name##_impl(f); \
+    auto it = g_prep_memo->field.find(f.get());                                                         \
+    if (it != g_prep_memo->field.end()) return it->second;                                              \
+    FP r = name##_impl(f);                                                                              \
+    g_prep_memo->keep.push_back(f);   /* (the key stays a live node) */                                 \
+    g_prep_memo->field.emplace(f.get(), r);                                                             \
+    return r;                                                                                           \
+  }
+GK_MEMO_PASS(simplify, simp)
+GK_MEMO_PASS(fold_dict, fold)
+GK_MEMO_PASS(pin_pass, pin)
+#undef GK_MEMO_PASS
+
+static FP simplify_impl(const FP& f) {
   switch (f->kind) {
     case FNode::AND: {
       std::vector<FP> flat0, flat;
@@ -474,7 +497,7 @@ DX to_dx(const FP& f) {
 }
 FP dict_atom(const SPath& leaf, DX dx) { Atom a; a.kind = Atom::DICT; a.path = leaf; a.dx = std::move(dx); return f_atom(a); }
 
-FP fold_dict(const FP& f) {
+static FP fold_dict_impl(const FP& f) {
   switch (f->kind) {
     case FNode::NOT: return f_not(fold_dict(f->kids[0]));
     case FNode::EXISTS: return f_exists_like(*f, fold_dict(f->kids[0]));
@@ -637,6 +660,7 @@ struct Lowerer {
   PathDict* dict;
   DictRegistry* reg = nullptr;
   bool frozen = false;   // no new registry entries (PlanBuilder)
+  bool counting = false; // dictionary predicates of the registry's counting space: <leaf>.$c (PlanBuilder::use_counting_space)
   HostPlan plan;
   PlanCaps caps;
   std::map<std::string, uint32_t> global_bits;            // canonical pred key -> global bit
@@ -864,10 +888,10 @@ struct Lowerer {
       Pattern leaf_pat = pattern_of(a.path);
       for (auto& st : leaf_pat) if (st.any && !st.elems_only && (!st.only.empty() || !st.except.empty() || !st.kpreds.empty())) unsupported("dictionary predicate under a filtered key iteration");
       uint32_t bit;
-      try { bit = reg->intern(leaf_pat, a.dx, !frozen); } catch (const std::runtime_error& ex) { unsupported(ex.what()); }
+      try { bit = (counting ? &reg->counting() : reg)->intern(leaf_pat, a.dx, !frozen); } catch (const std::runtime_error& ex) { unsupported(ex.what()); }
       Atom b;
       b.kind = Atom::DICT; b.path = a.path; b.dx = nullptr;
-      Step st; st.key = "$d";
+      Step st; st.key = counting ? "$c" : "$d";
       b.path.push_back(st);
       b.mask = bit;
       Pattern pat = pattern_of(b.path);
@@ -992,7 +1016,7 @@ struct Lowerer {
       case FNode::NOT: return f_not(pin_key(f->kids[0], q, key));
       case FNode::AND: { FP r = f_true(); for (auto& k : f->kids) r = f_and(r, pin_key(k, q, key)); return r; }
       case FNode::OR: { FP r = f_false(); for (auto& k : f->kids) r = f_or(r, pin_key(k, q, key)); return r; }
-      case FNode::EXISTS: { FNode proto; proto.q = f->q; proto.base = pin_path(f->base); proto.two = f->two; return f_exists_like(proto, pin_key(f->kids[0], q, key)); }
+      case FNode::EXISTS: { FNode proto; proto.q = f->q; proto.base = pin_path(f->base); proto.two = f->two; proto.atleast = f->atleast; return f_exists_like(proto, pin_key(f->kids[0], q, key)); }
     }
     return f;
   }
@@ -1060,6 +1084,7 @@ struct Lowerer {
       const std::map<int, PatStep> wild0 = wild;
       try { return lower_count2(f); }
       catch (const Unsupported&) { regs_used = regs0; code->resize(code0); looped = looped0; pass = pass0; wild = wild0; }
+      if (f->atleast > 2) unsupported("counting loop (at least " + std::to_string(f->atleast) + " elements) where elements cannot be counted");   // (a threshold must be exact: no weaker answer)
       return lower_exists(f_exists(f->q, f->base, f->kids[0]));
     }
     {
@@ -1211,6 +1236,31 @@ struct Lowerer {
     uint32_t parent = 0;
     for (int i = (int)f->base.size() - 1; i >= 0; i--)
       if (f->base[i].iter) { if (looped.count(f->base[i].q)) parent = looped[f->base[i].q] + 1; break; }
+    if (f->atleast > 2) {
+      // E_k, k > 2: k accumulators c[1..k], c[j] = "at least j elements satisfied the body so far"; per element, from the top:
+      // c[j] |= c[j-1] & hit, with hit = body & "the element exists" (its PRESENT bit -- top-level scopes only: a nested
+      // element also has to belong to the enclosing one, which F_ENDLOOP checks and a plain register operation cannot)
+      if (parent != 0) { looped.erase(q); unsupported("counting elements of a nested array"); }
+      const int k = f->atleast;
+      std::vector<int> c((size_t)k + 1, -1);
+      for (int j = k; j >= 2; j--) { c[j] = alloc(); emit(finst(F_CONST, c[j], 0)); }
+      c[1] = alloc();
+      emit(finst(F_LOOP, sc, parent, c[1]));
+      int r = lower(f->kids[0]);
+      int pres = alloc();
+      emit(finst(F_LDE, pres, sc, 0));       // bit 0 of the element word: P_PRESENT
+      emit(finst(F_AND, r, r, pres));
+      for (int j = k; j >= 2; j--) {
+        emit(finst(F_AND, pres, c[j - 1], r));
+        emit(finst(F_OR, c[j], c[j], pres));
+      }
+      release(pres);
+      emit(finst(F_ENDLOOP, c[1], r));
+      release(r);
+      for (int j = 1; j < k; j++) release(c[j]);
+      looped.erase(q);
+      return c[k];
+    }
     int twice = alloc(), once = alloc();
     emit(finst(F_CONST, twice, 0));
     emit(finst(F_LOOP, sc, parent, once));
@@ -1247,7 +1297,7 @@ struct Lowerer {
 //   E k in B. (k == "a" | k == "b") & body(B[k])   ==   OR_c  defined(B.c) & body(B.c)
 // Run before fold_dict, so that `spec[field][_]` with field = "containers" becomes the concrete path spec.containers and
 // the alternatives over it can be merged.
-FP pin_pass(const FP& f) {
+static FP pin_pass_impl(const FP& f) {
   switch (f->kind) {
     case FNode::NOT: return f_not(pin_pass(f->kids[0]));
     case FNode::AND: { FP r = f_true(); for (auto& k : f->kids) r = f_and(r, pin_pass(k)); return r; }
@@ -1278,6 +1328,193 @@ FP pin_pass(const FP& f) {
 
 }  // namespace
 
+
+// ---- result counting (pe.hpp Template::count_forms) ---------------------------------------------------------------------------
+namespace {
+bool is_prefix_of(const std::string& a, const std::string& b) { return a.size() <= b.size() && b.compare(0, a.size(), a) == 0; }
+// can branches x and y be told apart by their messages alone, whatever they are bound to?  (pe.hpp, count_forms)
+bool messages_differ(const Template::CountBranch& x, const Template::CountBranch& y) {
+  if (x.is_const && y.is_const) return x.text != y.text;
+  if (x.is_const != y.is_const) {
+    const Template::CountBranch &c = x.is_const ? x : y, &h = x.is_const ? y : x;
+    return h.head && !is_prefix_of(h.pre, c.text);
+  }
+  if (!x.head || !y.head) return false;
+  if (!is_prefix_of(x.pre, y.pre) && !is_prefix_of(y.pre, x.pre)) return true;
+  if (!(x.keyed && y.keyed) || x.pre != y.pre) return false;
+  // same literal head, both keyed on string leaves that are pairwise different across the whole review unless they are the SAME
+  // element of the same array (count_forms flags everything else): different leaves
+  if (x.sig.size() < 2 || y.sig.size() < 2 || x.sig[1] != y.sig[1]) return true;
+  // the same leaf pattern: possibly the same element -- then the text behind the key has to differ
+  if (x.sep_tail && y.sep_tail) return x.sep != y.sep;
+  if (!is_prefix_of(x.sep, y.sep) && !is_prefix_of(y.sep, x.sep)) return true;
+  if (x.sig.size() != y.sig.size() || x.sig[0] != y.sig[0]) return false;
+  int diff = 0;
+  for (size_t i = 1; i < x.sig.size(); i++) {
+    if (x.sig[i] == y.sig[i]) { if (x.sig[i] == "?") return false; continue; }   // (an operand nobody can compare)
+    if (x.sig[i][0] != 'C' || y.sig[i][0] != 'C') return false;
+    diff++;
+  }
+  return diff == 1;   // the same format and operands but for ONE constant: the same element prints two different texts
+}
+
+typedef Template::CountBranch CB;
+
+std::string path_sig_q(const SPath& p) { std::string o; for (auto& st : p) { if (st.iter) o += "[]"; else { o += "."; o += st.key; } } return o; }
+
+// A branch with TWO open iterations whose OUTER one walks the keys of an object and is pinned to constants by its body
+// (K8sContainerLimits: spec[field][_] with field == "containers" | "initContainers") becomes one branch per constant with the
+// inner iteration alone -- what pin_pass does to the violation formula.
+void expand_pinned(const CB& b, std::vector<CB>* out) {
+  if (b.nq != 2 || !b.body) { out->push_back(b); return; }
+  // the generator's quantifiers: the outer one is b.q over b.base; the inner base is read off the key path / body: the first
+  // EXISTS-free body talks about  base[q_outer][q_inner]...  -- find q_inner as the iter step behind q_outer in the key path
+  int q_in = -1;
+  SPath inner_base;
+  const SPath* probe = b.head ? &b.key : nullptr;
+  if (probe) {
+    for (size_t i = 0; i + 1 < probe->size(); i++)
+      if ((*probe)[i].iter && (*probe)[i].q == b.q && (*probe)[i + 1].iter) { q_in = (*probe)[i + 1].q; inner_base.assign(probe->begin(), probe->begin() + i + 1); break; }
+  }
+  if (getenv("GK_DEBUG_COUNTS") && (q_in < 0 || inner_base.size() != b.base.size() + 1)) {
+    static int shown = 0;
+    if (shown++ < 3) fprintf(stderr, "[gkgpu counts] no inner iteration: q=%d base=%s key=%s q_in=%d any=%s\n", b.q, spath_to_string(b.base).c_str(), spath_to_string(b.key).c_str(), q_in, f_to_string(b.any).substr(0, 1500).c_str());
+  }
+  if (q_in < 0 || inner_base.size() != b.base.size() + 1) { out->push_back(b); return; }
+  for (size_t i = 0; i < b.base.size(); i++) if (b.base[i].iter) { out->push_back(b); return; }
+  std::vector<FP> conj, rest;
+  conjuncts(b.body, conj);
+  PatStep ps;
+  for (auto& c : conj) if (!Lowerer::key_constraint(c, b.q, &ps)) rest.push_back(c);
+  if (getenv("GK_DEBUG_COUNTS") && (ps.only.empty() || !ps.except.empty())) {
+    static int shown = 0;
+    if (shown++ < 3) { fprintf(stderr, "[gkgpu counts] not pinned: q=%d only=%zu except=%zu kpreds=%zu body=%s\n", b.q, ps.only.size(), ps.except.size(), ps.kpreds.size(), f_to_string(b.body).substr(0, 700).c_str()); }
+  }
+  if (ps.only.empty() || !ps.except.empty()) { out->push_back(b); return; }
+  auto pin_path = [&](SPath p, const std::string& key) { for (auto& s : p) if (s.iter && s.q == b.q) { s.iter = false; s.q = -1; s.key = key; } return p; };
+  for (const std::string& key : ps.only) {
+    { bool ok = true; for (auto& kp : ps.kpreds) if (!key_pred_holds(kp, key, false)) ok = false; if (!ok) continue; }
+    CB n = b;
+    n.nq = 1; n.q = q_in;
+    n.base = pin_path(inner_base, key);
+    FP body = f_true();
+    for (auto& c : rest) body = f_and(body, Lowerer::pin_key(c, b.q, key));
+    n.body = body;   // (f_and folds the constants pin_key makes of the key tests)
+    if (n.body->kind == FNode::F) continue;
+    n.any = f_exists(q_in, n.base, n.body);
+    n.two = f_exists2(q_in, n.base, n.body);
+    n.key = pin_path(b.key, key);
+    for (auto& e : n.sig) if (e.size() > 1 && e[0] == 'P') { /* leaf signatures name the pinned member */ size_t at = e.find("[][]"); if (at != std::string::npos) e = e.substr(0, at) + "." + key + e.substr(at + 2); }
+    // keyed as Template::compile_all decides it, now that one iteration over a top-level array is left
+    n.keyed = n.head && n.key.size() > n.base.size() + 1 && n.key[n.base.size()].iter && n.key[n.base.size()].q == q_in && (!n.sep.empty() || n.sep_tail);
+    for (size_t i = n.base.size() + 1; n.keyed && i < n.key.size(); i++) if (n.key[i].iter) n.keyed = false;
+    out->push_back(std::move(n));
+  }
+}
+
+// Branches that print the SAME message for the same binding (same format, every operand comparable and equal, same iteration)
+// are one branch: the set keeps one member however many rule bodies / unrolled alternatives produce it.
+// OR of conjunctions with what they have in common factored out:  (c & a1) | (c & a2) ..  ==  c & (a1 | a2 ..)  -- the unrolled
+// alternatives of one message (K8sContainerLimits: hundreds of unit-suffix cases) then differ in sub-formulas about ONE leaf,
+// which fold into one dictionary expression instead of one per alternative
+FP or_factored(const std::vector<FP>& alts) {
+  if (alts.size() == 1) return alts[0];
+  std::vector<std::vector<FP>> cs(alts.size());
+  std::map<std::string, size_t> seen;
+  for (size_t i = 0; i < alts.size(); i++) {
+    conjuncts(alts[i], cs[i]);
+    std::set<std::string> mine;
+    for (auto& c : cs[i]) if (mine.insert(f_to_string(c)).second) seen[f_to_string(c)]++;
+  }
+  FP common = f_true();
+  std::set<std::string> is_common;
+  for (auto& c : cs[0]) { const std::string t = f_to_string(c); if (seen[t] == alts.size() && is_common.insert(t).second) common = f_and(common, c); }
+  FP any = f_false();
+  for (auto& v : cs) {
+    FP rest = f_true();
+    for (auto& c : v) if (!is_common.count(f_to_string(c))) rest = f_and(rest, c);
+    any = f_or(any, rest);
+  }
+  return f_and(common, any);
+}
+
+void merge_equal(std::vector<CB>* br) {
+  std::vector<CB> out;
+  std::vector<std::vector<FP>> alts;
+  std::map<std::string, size_t> at;
+  for (CB& b : *br) {
+    std::string key;
+    bool mergeable = b.nq <= 1 && (b.is_const || (b.head && !b.sig.empty()));
+    if (b.is_const) key = "C|" + b.text;
+    else if (mergeable) { for (auto& e : b.sig) { if (e == "?") mergeable = false; key += e; key.push_back('\x1f'); } }
+    if (mergeable) key += "|" + std::to_string(b.nq) + "|" + path_sig_q(b.base);
+    auto it = mergeable ? at.find(key) : at.end();
+    if (!mergeable || it == at.end()) { if (mergeable) at[key] = out.size(); alts.push_back({b.nq == 0 ? b.any : b.body}); out.push_back(std::move(b)); continue; }
+    CB& a = out[it->second];
+    if (a.nq == 0) { alts[it->second].push_back(b.any); continue; }
+    std::map<int, int> m; m[b.q] = a.q;
+    alts[it->second].push_back(rename_f(b.body, m));
+    a.keyed = a.keyed && b.keyed;
+  }
+  for (size_t i = 0; i < out.size(); i++) {
+    if (alts[i].size() < 2) continue;
+    CB& a = out[i];
+    if (a.nq == 0) { a.any = or_factored(alts[i]); continue; }
+    a.body = or_factored(alts[i]);
+    a.any = f_exists(a.q, a.base, a.body);
+    a.two = f_exists2(a.q, a.base, a.body);
+  }
+  br->swap(out);
+}
+}  // namespace
+
+Template::CountForms Template::count_forms(const CountInfo& ci, int kmax) {
+  CountForms cf;
+  cf.flag = f_false();
+  std::vector<CB> br;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (const CB& b : ci.br) expand_pinned(b, &br);
+  const auto t1 = std::chrono::steady_clock::now();
+  merge_equal(&br);
+  if (getenv("GK_DEBUG_LOAD")) fprintf(stderr, "[gkgpu load]   count_forms: pinning %.3f s, merging %.3f s (%zu -> %zu branches)\n", std::chrono::duration<double>(t1 - t0).count(),
+                                       std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count(), ci.br.size(), br.size());
+  if (getenv("GK_DEBUG_COUNTS")) {
+    fprintf(stderr, "[gkgpu counts] %zu branches -> %zu after pinning and merging\n", ci.br.size(), br.size());
+    for (auto& b : br) fprintf(stderr, "   + nq=%d keyed=%d const=%d pre=[%s] sep=[%s] tail=%d key=%s sig=%s\n", b.nq, (int)b.keyed, (int)b.is_const, b.pre.c_str(), b.sep.c_str(), (int)b.sep_tail,
+                               spath_to_string(b.key).c_str(), [&] { std::string o; for (auto& e : b.sig) o += e + " | "; return o; }().c_str());
+  }
+  Atom dup; dup.kind = Atom::DEFINED;
+  { Step st; st.key = "$dup"; dup.path.push_back(st); }
+  bool any_keyed = false;
+  cf.viol = f_false();
+  for (const CB& b : br) cf.viol = f_or(cf.viol, b.any);
+  for (const CB& b : br) {
+    if (b.nq == 0) cf.firsts.push_back((uint32_t)cf.rows.size());   // (the flag holds the body of every branch with an iteration)
+    cf.rows.push_back(b.any);
+    if (b.nq == 0) continue;
+    if (!b.keyed) { cf.flag = f_or(cf.flag, b.two); continue; }
+    any_keyed = true;
+    cf.keys.push_back(b.key);
+    // the key of every firing element is a string without the first character of the literal behind it
+    Atom ty; ty.kind = Atom::TYPE; ty.path = b.key; ty.mask = 1u << T_STRING;
+    FP good = f_atom(ty);
+    if (!b.sep.empty()) { Atom c; c.kind = Atom::STR_CONTAINS; c.path = b.key; c.k = Value::string(b.sep.substr(0, 1)); good = f_and(good, f_not(f_atom(c))); }
+    cf.flag = f_or(cf.flag, f_exists(b.q, b.base, f_and(b.body, f_not(good))));
+    for (int k = 2; k <= kmax; k++) cf.rows.push_back(f_exists_k(b.q, b.base, b.body, k));
+    cf.flag = f_or(cf.flag, f_exists_k(b.q, b.base, b.body, kmax + 1));   // more firing elements than thresholds
+  }
+  if (any_keyed) cf.flag = f_or(cf.flag, f_atom(dup));
+  if (br.size() > 24) return cf;   // (too many alternatives for the pairwise terms: ok stays false, compile_multi's answer serves)
+  for (size_t i = 0; i < br.size(); i++)
+    for (size_t j = i + 1; j < br.size(); j++)
+      if (!messages_differ(br[i], br[j])) cf.flag = f_or(cf.flag, f_and(br[i].any, br[j].any));
+  cf.ok = true;
+  return cf;
+}
+
+PrepMemoScope::PrepMemoScope() { prev_ = g_prep_memo; mine_ = new PrepMemo(); g_prep_memo = (PrepMemo*)mine_; }
+PrepMemoScope::~PrepMemoScope() { g_prep_memo = (PrepMemo*)prev_; delete (PrepMemo*)mine_; }
+
 std::shared_ptr<const PreparedConstraint> prepare_constraint(const FP& violation, const MatchFormulas& mf) {
   auto pc = std::make_shared<PreparedConstraint>();
   pc->viol = simplify(fold_dict(simplify(pin_pass(simplify(violation)))));
@@ -1294,6 +1531,7 @@ HostPlan PlanBuilder::build(const PlanCaps& caps) {
   L.dict = dict_;
   L.reg = reg_;
   L.frozen = frozen_;
+  L.counting = counting_;
   L.caps = caps;
   std::map<std::string, uint32_t> viol_ids, match_ids;
   std::vector<FP> viols, matches, errs;
@@ -1411,7 +1649,7 @@ void HostPlan::resolve_paths(const PathDict& dict) {
           // `except` list and equals none in an `only` list
           if (in.is_elem) { if (st.only.empty()) nxt.push_back(ch); continue; }
           if (st.elems_only) continue;
-          if (in.key == "$d") continue;   // the flattener's dictionary row under a leaf is not a member of the document
+          if (in.key == "$d" || in.key == "$c") continue;   // the flattener's dictionary rows under a leaf are not members of the document
           if (!st.only.empty() && std::find(st.only.begin(), st.only.end(), in.key) == st.only.end()) continue;
           if (std::find(st.except.begin(), st.except.end(), in.key) != st.except.end()) continue;
           nxt.push_back(ch);

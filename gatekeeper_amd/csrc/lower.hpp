@@ -49,6 +49,8 @@ struct HostPlan {
 // A constraint's formulas after the capacity-independent passes (simplify, pin_pass, fold_dict) and their structural keys:
 // computed once when the constraint is added, shared by every plan the constraint is lowered into (the default plan, the
 // big-capacity plan, per-table variants, constraint groups).
+// while one is alive on this thread, prepare_constraint's passes remember what they made of every formula NODE (lower.cpp PrepMemo)
+struct PrepMemoScope { PrepMemoScope(); ~PrepMemoScope(); PrepMemoScope(const PrepMemoScope&) = delete; private: void* prev_; void* mine_; };
 struct PreparedConstraint { FP viol, match, error; std::string viol_key, match_key; };
 std::shared_ptr<const PreparedConstraint> prepare_constraint(const FP& violation, const MatchFormulas& m);
 
@@ -61,11 +63,13 @@ class PlanBuilder {
   uint32_t add_constraint(const FP& violation, const MatchFormulas& m) { return add_constraint(prepare_constraint(violation, m)); }
   uint32_t add_constraint(std::shared_ptr<const PreparedConstraint> pc) { cons_.push_back(std::move(pc)); return (uint32_t)cons_.size() - 1; }
   HostPlan build(const PlanCaps& caps);   // throws Unsupported
+  // the plan's dictionary predicates live in the registry's COUNTING space (<leaf>.$c rows; flatten.hpp): the result-counting plans
+  void use_counting_space(bool on = true) { counting_ = on; }
 
  private:
   PathDict* dict_;
   DictRegistry* reg_;
-  bool frozen_ = false;
+  bool frozen_ = false, counting_ = false;
   std::vector<std::shared_ptr<const PreparedConstraint>> cons_;
 };
 

@@ -55,7 +55,13 @@ FP f_exists2(int q, const SPath& base, FP body) {
   FNode n; n.kind = FNode::EXISTS; n.q = q; n.base = base; n.two = true; n.kids = {body};
   return mkf(std::move(n));
 }
-FP f_exists_like(const FNode& proto, FP body) { return proto.two ? f_exists2(proto.q, proto.base, body) : f_exists(proto.q, proto.base, body); }
+FP f_exists_k(int q, const SPath& base, FP body, int k) {
+  if (k <= 1) return f_exists(q, base, body);
+  if (body->kind == FNode::F) return f_false();
+  FNode n; n.kind = FNode::EXISTS; n.q = q; n.base = base; n.two = true; n.atleast = k; n.kids = {body};
+  return mkf(std::move(n));
+}
+FP f_exists_like(const FNode& proto, FP body) { return proto.two ? f_exists_k(proto.q, proto.base, body, proto.atleast) : f_exists(proto.q, proto.base, body); }
 FP f_all(const std::vector<FP>& v) { FP r = f_true(); for (auto& x : v) r = f_and(r, x); return r; }
 FP f_any(const std::vector<FP>& v) { FP r = f_false(); for (auto& x : v) r = f_or(r, x); return r; }
 
@@ -80,7 +86,7 @@ static std::string f_compose_text(const FP& f) {
       for (size_t i = 0; i < f->kids.size(); i++) { if (i) o += f->kind == FNode::AND ? " & " : " | "; o += f_to_string(f->kids[i]); }
       return o + ")";
     }
-    case FNode::EXISTS: return std::string(f->two ? "E2 q" : "E q") + std::to_string(f->q) + " in " + spath_to_string(f->base) + ". " + f_to_string(f->kids[0]);
+    case FNode::EXISTS: return std::string(f->two ? "E" + std::to_string(f->atleast) + " q" : "E q") + std::to_string(f->q) + " in " + spath_to_string(f->base) + ". " + f_to_string(f->kids[0]);
     case FNode::ATOM: {
       const Atom& a = f->atom;
       std::string p = spath_to_string(a.path);
@@ -206,6 +212,7 @@ SVP rn_sv(const SVP& v, const QMap& m) {
   if (m.empty() || !v || v->kind == SV::CONST) return v;
   SV s = *v;
   s.path = rn_path(s.path, m);
+  s.hkeypath = rn_path(s.hkeypath, m);   // (the head of a formatted message names the same iterations as its operands)
   if (s.q >= 0) { auto it = m.find(s.q); if (it != m.end()) s.q = it->second; }
   for (auto& f : s.fields) f.second = rn_sv(f.second, m);
   for (auto& e : s.elems) { e.v = rn_sv(e.v, m); e.cond = rn_f(e.cond, m); }
@@ -618,6 +625,42 @@ class PE {
     flush();
     *parts = o;
     return true;
+  }
+  // ---- the HEAD of a formatted string, for the result counting (pe.hpp SV::hhead): literal text, the first verb's operand when it
+  // is a review leaf printed with %v / %s, the literal text behind it; plus a signature of the format and every operand
+  static std::string path_sig(const SPath& p) { std::string o; for (auto& st : p) { if (st.iter) o += "[]"; else { o += "."; o += st.key; } } return o; }
+  static void fmt_head(const std::string& fmt, const std::vector<CondElem>& args, SV* o) {
+    o->hsig.clear();
+    o->hsig.push_back(fmt);
+    for (auto& e : args) {
+      if (!e.cond || e.cond->kind != FNode::T) o->hsig.push_back("?");
+      else if (e.v->kind == SV::CONST) o->hsig.push_back("C" + to_term_string(e.v->c));
+      else if (e.v->kind == SV::PATH) o->hsig.push_back("P" + path_sig(e.v->path));
+      else o->hsig.push_back("?");
+    }
+    std::string pre, sep;
+    size_t i = 0;
+    auto literal = [&](std::string* out) -> bool {   // literal text up to the next verb (%% is a literal %); false: malformed
+      for (; i < fmt.size(); i++) {
+        if (fmt[i] != '%') { out->push_back(fmt[i]); continue; }
+        if (i + 1 >= fmt.size()) return false;
+        if (fmt[i + 1] == '%') { out->push_back('%'); i++; continue; }
+        return true;
+      }
+      return true;
+    };
+    if (!literal(&pre)) return;
+    o->hhead = true;
+    o->hpre = pre;
+    o->hkeypath.clear();
+    if (i >= fmt.size()) { o->hsep_tail = true; return; }   // (no verb at all: the text is a constant -- handled as literal head only)
+    const char v = fmt[i + 1];
+    if ((v != 'v' && v != 's') || args.empty() || !args[0].cond || args[0].cond->kind != FNode::T || args[0].v->kind != SV::PATH) return;   // head = literal text only
+    i += 2;
+    if (!literal(&sep)) { o->hhead = false; return; }
+    o->hkeypath = args[0].v->path;
+    o->hsep = sep;
+    o->hsep_tail = i >= fmt.size();
   }
   // review leaves that are strings by construction: what gkReview / AdmissionRequest carry as Go strings
   static bool string_by_construction(const SPath& p) {
@@ -1555,6 +1598,7 @@ class PE {
       // A format of literal text and %v / %s verbs over an array literal of constants and review leaves keeps its PARTS: such a
       // string can still be compared with a constant (K8sUniqueLabel's make_apiversion: sprintf("%v/%v", [g, v]) == obj.apiVersion)
       if (a[1]->kind == SV::ARR && a[1]->gens.empty()) fmt_parts(*a[0]->c.s, a[1]->elems, &o.elems);
+      if (a[1]->kind == SV::ARR && a[1]->gens.empty()) fmt_head(*a[0]->c.s, a[1]->elems, &o);
       out.push_back({mksv(std::move(o)), s});
       return;
     }
@@ -2017,6 +2061,85 @@ FP Template::compile_multi(const Value& parameters, int* next_quant, const Value
   for (size_t i = 0; i < br.size(); i++)
     for (size_t j = i + 1; j < br.size(); j++) multi = f_or(multi, f_and(br[i].any, br[j].any));
   return multi;
+}
+
+Template::CountInfo Template::compile_all(const Value& parameters, int* next_quant, const Value& inventory) const {
+  PE pe(*this, parameters, sv_path({}), inventory, false, next_quant);
+  pe.index_rules();
+  SVP set;
+  try {
+    set = pe.violation_set();
+  } catch (const UnboundVar& e) {
+    throw RegoError(e.what());
+  }
+  std::vector<CondElem> elems;
+  std::vector<Gen> gens;
+  if (set->kind == SV::CONST) { for (auto& x : set->c.items()) elems.push_back({sv_const(x), f_true()}); }
+  else { elems = set->elems; gens = set->gens; }
+  auto msg_of = [&](const SVP& e) -> SVP {
+    if (e->kind == SV::CONST) { const Value* m = e->c.get("msg"); return (e->c.is_object() && m) ? sv_const(*m) : SVP(); }
+    if (e->kind != SV::OBJ) return SVP();
+    for (auto& f : e->fields) if (f.first == Value::string("msg")) return f.second;
+    return SVP();
+  };
+  auto valid = [&](const SVP& e) -> FP {
+    if (e->kind == SV::CONST) {
+      const Value* m = e->c.get("msg");
+      return (e->c.is_object() && m && m->is_string()) ? f_true() : f_false();
+    }
+    if (e->kind != SV::OBJ) return f_false();
+    SVP msg = msg_of(e);
+    if (!msg) return f_false();
+    return f_and(pe.defined_f(e), pe.is_string_f(msg));
+  };
+  auto head_of = [&](const SVP& e, CountBranch* b) {
+    SVP m = msg_of(e);
+    if (!m) return;
+    if (m->kind == SV::CONST && m->c.is_string()) { b->is_const = true; b->text = m->c.str(); return; }
+    if (m->kind != SV::OPAQUE || !m->hhead) return;
+    b->head = true; b->pre = m->hpre; b->sep = m->hsep; b->sep_tail = m->hsep_tail; b->key = m->hkeypath; b->sig = m->hsig;
+  };
+  CountInfo ci;
+  ci.viol = f_false();
+  for (auto& e : elems) {
+    FP c = f_and(e.cond, valid(e.v));
+    ci.viol = f_or(ci.viol, c);
+    if (c->kind == FNode::F) continue;
+    CountBranch b;
+    b.any = c; b.two = f_false();
+    head_of(e.v, &b);
+    ci.br.push_back(std::move(b));
+  }
+  for (auto& g : gens) {
+    const FP body = f_and(g.cond, valid(g.elem));
+    const size_t k = g.quants.size();
+    std::vector<FP> inner(k + 1);
+    inner[k] = body;
+    for (size_t i = k; i-- > 0;) inner[i] = f_exists(g.quants[i], g.bases[i], inner[i + 1]);
+    ci.viol = f_or(ci.viol, inner[0]);
+    if (body->kind == FNode::F) continue;
+    FP two = f_false();
+    for (size_t i = k; i-- > 0;) {
+      FP t = f_exists2(g.quants[i], g.bases[i], inner[i + 1]);
+      for (size_t j = i; j-- > 0;) t = f_exists(g.quants[j], g.bases[j], t);
+      two = f_or(two, t);
+    }
+    CountBranch b;
+    b.any = inner[0]; b.two = two; b.body = body; b.nq = (int)k;
+    if (k >= 1) { b.q = g.quants[0]; b.base = g.bases[0]; }
+    head_of(g.elem, &b);
+    // keyed: ONE iteration, and the key operand is a leaf of its element (base[q].x.y, no further iteration)
+    if (k == 1 && b.head && b.key.size() > b.base.size() + 1) {
+      bool ok = true;
+      for (size_t i = 0; i < b.base.size(); i++) { const Step &x = b.key[i], &y = b.base[i]; if (x.iter != y.iter || x.key != y.key || x.q != y.q) ok = false; }
+      if (ok && !(b.key[b.base.size()].iter && b.key[b.base.size()].q == b.q)) ok = false;
+      for (size_t i = b.base.size() + 1; ok && i < b.key.size(); i++) if (b.key[i].iter) ok = false;
+      for (size_t i = 0; ok && i < b.base.size(); i++) if (b.base[i].iter) ok = false;   // (top-level arrays only: the thresholds count elements of ONE array)
+      b.keyed = ok && (!b.sep.empty() || b.sep_tail);
+    }
+    ci.br.push_back(std::move(b));
+  }
+  return ci;
 }
 
 std::vector<Violation> Template::render(const Value& review, const Value& parameters, const Value& inventory) const {

@@ -53,6 +53,7 @@ struct FNode {
   int q = -1;           // EXISTS: quantifier id; quantifies over children of `base`
   SPath base;           // EXISTS
   bool two = false;     // EXISTS: at least TWO children of `base` satisfy the body ("E2": instance counting for the RESULT totals)
+  int atleast = 2;      // ... with `two`: at least THIS MANY children do ("E3", "E4", ..: the result COUNTS of round 4)
   Atom atom;
   // canonical text (f_to_string), derived once per node: lowering keys sub-formulas by it over and over.  Nodes are immutable
   // once made (mkf / f_* reset the cache of a copy they are handed); formulas are built and lowered under the engine's locks
@@ -72,6 +73,7 @@ FP f_not(FP a);
 FP f_atom(const Atom& a);
 FP f_exists(int q, const SPath& base, FP body);
 FP f_exists2(int q, const SPath& base, FP body);              // at least two children of `base` satisfy the body
+FP f_exists_k(int q, const SPath& base, FP body, int k);      // at least k (>= 1; 1 is the plain EXISTS)
 FP f_exists_like(const FNode& proto, FP body);                // EXISTS / E2 with `proto`'s quantifier, base and flag
 FP f_all(const std::vector<FP>& v);
 FP f_any(const std::vector<FP>& v);
@@ -99,6 +101,14 @@ struct SV {
   enum XK { XTRIM, XARR, XCOMP, XCOUNT } xkind = XTRIM;
   int idx = 0;                                    // XCOMP index / XCOUNT offset
   DX dx;                                          // DERIVED
+  // OPAQUE from sprintf: the HEAD of the formatted text -- literal text `hpre`, then the first verb's operand `hkey` (a review
+  // leaf), then literal text `hsep` up to the next verb (`hsep_tail`: up to the END of the format) -- and a signature of format
+  // and operands (`hsig`: one entry per operand, "C<json>" for constants, "P<path>" for review leaves with quantifiers erased,
+  // "?" otherwise; entry 0 is the format).  What the result counting needs to tell messages apart (Template::count_forms).
+  bool hhead = false, hsep_tail = false;
+  std::string hpre, hsep;
+  SPath hkeypath;
+  std::vector<std::string> hsig;
 };
 
 struct Violation {   // render mode output
@@ -125,6 +135,34 @@ class Template : public std::enable_shared_from_this<Template> {
   // different bindings collapse in the set): a pair it flags is rendered on the host and counted exactly; a violating pair
   // it does not flag has exactly one result.  Implies compile()'s formula.
   FP compile_multi(const Value& parameters, int* next_quant, const Value& inventory = Value()) const;
+
+  // AOT, round 4: the result COUNT on the device.  compile() and compile_multi() in one evaluation, plus what is needed to count
+  // the members of the violation set without rendering them: per branch of the set (rule body x unrolled parameter alternative)
+  // its condition, its open review iteration and the head of its message.  count_forms() turns that into
+  //     rows[]   boolean formulas whose TRUE values, summed over the rows, are the number of results of a review, and
+  //     flag     "cannot tell": the pair is rendered on the host (as every flagged pair of compile_multi was)
+  // -- exact whenever `flag` is false.  The argument: a branch with ONE open iteration over array elements whose message starts
+  // "<literal><%v of a leaf of the element><literal>.." yields one result per firing element PROVIDED those leaves are strings
+  // that do not hold the first character of the literal behind them (the message then parses back into the leaf: different
+  // leaves, different messages) and no two of them are equal (the flattener marks a review in which a key-registered leaf value
+  // repeats: review.$dup); thresholds "at least k elements fire" (E_k) count them.  Two branches never yield the same message
+  // when their literal heads are not prefixes of one another, when they are constants that differ, when they differ in exactly
+  // one constant operand of the same format, or when both are keyed on such leaves (all distinct, see above).  Anything else
+  // that can hold together is flagged.
+  struct CountBranch {
+    FP any, two, body;            // yields a result | may yield two (compile_multi) | the iteration's body (nq == 1)
+    int nq = 0, q = -1;           // open review iterations; the quantifier of the only one
+    SPath base;                   // ... and what it iterates
+    bool is_const = false, head = false, sep_tail = false, keyed = false;
+    std::string text, pre, sep;   // constant message | literal head | literal behind the key operand
+    SPath key;                    // the key operand's leaf (keyed: a leaf of the iteration's element)
+    std::vector<std::string> sig;
+  };
+  struct CountInfo { FP viol; std::vector<CountBranch> br; };
+  struct CountForms { bool ok = false; FP flag; FP viol /* the violation formula again, as the OR over the pinned + merged branches: the same truth table in a
+                                                          fraction of the nodes when hundreds of unrolled alternatives print one message */; std::vector<FP> rows; std::vector<SPath> keys; std::vector<uint32_t> firsts /* rows[i] of the branches WITHOUT an iteration (the flag holds the bodies of the others) */; };
+  CountInfo compile_all(const Value& parameters, int* next_quant, const Value& inventory = Value()) const;
+  static CountForms count_forms(const CountInfo& ci, int kmax);
 
   // Host rendering: the violation set for a concrete review document (input.review) and parameters.
   // `inventory` is data.inventory (may be Undefined).  Throws RegoError on evaluation errors.

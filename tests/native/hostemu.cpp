@@ -119,6 +119,7 @@ DevPlan* dev_plan_upload(int, const HostPlan& fast, const HostPlan& big) {
   }
   return p;
 }
+void dev_plan_no_jit(DevPlan*) {}
 void dev_plan_free(DevPlan* p) {
   if (p && p->dl) dlclose(p->dl);
   // (the emulated plan-specialised kernels stay loaded: test-only, and the emulator's state is shared between objects)

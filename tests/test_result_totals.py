@@ -174,3 +174,106 @@ def test_an_object_where_bindings_are_counted_is_refused_by_the_totals_plan_only
     assert not refused                      # the violation bitmap of every review comes from the device ...
     assert "object-containers" in want_pairs["K8sFlat"]
     assert 0 < rendered < rendered_all      # ... the object's result count from the renderer, the single-binding pairs from the device
+
+
+# ---- round 4: the result COUNT on the device (Template::count_forms).  A branch with one iteration over array elements whose
+# message starts "<text><%v of a leaf of the element><text>.." counts one result per firing element -- thresholds "at least k
+# elements fire" -- provided the leaves are strings, free of the first character of the text behind them and pairwise different
+# (review.$dup); everything that argument does not cover is flagged and rendered.  Each case below sits on one edge of it.
+COUNTED = {
+    # the PSP / library shape: "<name>" leads the message.  Two rule bodies print the SAME message (merged: one result per element)
+    "K8sKeyed": ('''package k
+violation[{"msg": msg}] {
+  c := input.review.object.spec.containers[_]
+  c.securityContext.privileged
+  msg := sprintf("container <%v> is privileged (image %v)", [c.name, c.image])
+}
+violation[{"msg": msg}] {
+  c := input.review.object.spec.containers[_]
+  c.securityContext.allowPrivilegeEscalation
+  msg := sprintf("container <%v> is privileged (image %v)", [c.name, c.image])
+}
+''', {}),
+    # unrolled parameter alternatives that differ in ONE constant operand + a second format whose text behind the key differs
+    "K8sProbes": ('''package k
+violation[{"msg": msg}] {
+  c := input.review.object.spec.containers[_]
+  p := input.parameters.probes[_]
+  not c[p]
+  msg := sprintf("Container <%v> in your <%v> has no <%v>", [c.name, input.review.kind.kind, p])
+}
+violation[{"msg": msg}] {
+  c := input.review.object.spec.containers[_]
+  not c.resources
+  msg := sprintf("Container <%v> has no resources", [c.name])
+}
+''', {"probes": ["readinessProbe", "livenessProbe"]}),
+    # the array is named by an iterated, pinned key (K8sContainerLimits' spec[field][_]): one branch per pinned member
+    "K8sFields": ('''package k
+violation[{"msg": msg}] {
+  field := {"containers", "initContainers"}[_]
+  c := input.review.object.spec[field][_]
+  not startswith(c.image, "good/")
+  msg := sprintf("container <%v> has a bad image", [c.name])
+}
+''', {}),
+}
+
+
+def cpod(name, containers, init=()):
+    s = {"containers": containers}
+    if init:
+        s["initContainers"] = list(init)
+    return {"apiVersion": "v1", "kind": "Pod", "metadata": {"name": name, "namespace": "default"}, "spec": s}
+
+
+def cc(name, priv=False, esc=False, image="good/x", probes=(), resources=True):
+    c = {"name": name, "image": image}
+    sc = {}
+    if priv:
+        sc["privileged"] = True
+    if esc:
+        sc["allowPrivilegeEscalation"] = True
+    if sc:
+        c["securityContext"] = sc
+    for p in probes:
+        c[p] = {"httpGet": {"path": "/"}}
+    if resources:
+        c["resources"] = {"limits": {"cpu": "1"}}
+    return c
+
+
+COUNT_OBJS = [
+    cpod("clean", [cc("a", probes=("readinessProbe", "livenessProbe"))]),
+    cpod("three", [cc("a", priv=True, image="bad/1"), cc("b", priv=True, esc=True, image="bad/2", resources=False), cc("c", esc=True, probes=("livenessProbe",))]),
+    cpod("both-arrays", [cc("a", image="bad/1"), cc("b")], init=[cc("i0", image="bad/2"), cc("i1", image="bad/3")]),
+    cpod("five", [cc("c%d" % i, priv=True, image="bad/%d" % i, resources=False) for i in range(5)]),
+    cpod("seven", [cc("c%d" % i, priv=True) for i in range(7)]),                                    # more firing elements than thresholds
+    cpod("dup-names", [cc("a", priv=True, image="bad/1"), cc("a", priv=True, image="bad/2")]),                     # equal keys: review.$dup
+    cpod("dup-across", [cc("a", image="bad/1")], init=[cc("a", image="bad/1")]),                                     # ... across the two arrays
+    cpod("separator", [cc("x> is privileged (image y", priv=True, image="bad/1"), cc("b", priv=True)]),            # the key holds the text's first character
+    cpod("number-name", [cc(7, priv=True), cc("7", priv=True)]),                                                     # 7 and "7" print alike
+    cpod("no-name", [{"image": "bad/1", "securityContext": {"privileged": True}}, cc("b", priv=True)]),              # undefined key: no message at all
+] + [cpod("plain-%d" % i, [cc("m%d-%d" % (i, j), priv=j % 2 == 0, esc=j % 3 == 0, image=("bad/%d" % j) if (i + j) % 2 else "good/x", resources=j != 1) for j in range(2 + i % 3)],
+          init=[cc("init%d" % i, image="bad/i")] if i % 2 else ()) for i in range(6)]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_result_counts_on_the_device_at_the_edges_of_the_argument(backend):
+    refused, want, want_pairs, rendered, rendered_all = run_totals(backend, COUNTED, COUNT_OBJS)
+    assert not refused
+    for kind in COUNTED:
+        assert want[kind] > len(want_pairs[kind])          # several results per pair everywhere
+    # rendered: only what the argument does not cover -- too many elements, equal keys, the separator inside a key, a key that
+    # is no string; the rest (most pairs, all of them with several results) was COUNTED
+    # (seven and five -- the default is four thresholds, GK_COUNT_KMAX --: 2 pairs each; dup-names: 3; dup-across: 2; separator: 3;
+    #  number-name: 2)
+    assert 0 < rendered <= 14 and rendered_all >= rendered + 10
+
+
+def test_counting_is_switched_off_by_its_knob(monkeypatch):
+    """GK_COUNT_KMAX=0: round 3's decision ("can this pair have more than one result?") serves alone -- same totals, more rendering"""
+    _, _, _, rendered_counted, _ = run_totals("hostemu", COUNTED, COUNT_OBJS)
+    monkeypatch.setenv("GK_COUNT_KMAX", "0")
+    _, _, _, rendered_multi, _ = run_totals("hostemu", COUNTED, COUNT_OBJS)
+    assert rendered_counted < rendered_multi
