@@ -220,7 +220,32 @@ def _sig(x, digits=4):
     return float("%.*g" % (digits, x)) if x is not None else None
 
 
-def side_point(config, reviews, steps, warmup, oracle_n, dev_index, fx, nss, with_stream=False, stream_args=None, dev=None):
+def totals_leg(table):
+    """audit RESULT totals of an evaluated table (gk_table_totals: pkg/audit/manager.go:893-904 counts types.Results): the device
+    COUNTS the results of the violating pairs it can (round 4: thresholds per counted iteration) and flags the rest for the host
+    renderer; checked against the host pass that renders EVERY violating pair (GK_TOTALS_RENDER_ALL=1)."""
+    t_cold = time.perf_counter()
+    tot = table.totals()                       # first call: prepares the counting forms, builds + uploads the totals plans
+    t_cold = time.perf_counter() - t_cold
+    t_tot = time.perf_counter()
+    tot = table.totals()
+    t_tot = time.perf_counter() - t_tot
+    rendered = table.rendered_pairs
+    os.environ["GK_TOTALS_RENDER_ALL"] = "1"
+    try:
+        t_all = time.perf_counter()
+        tot_all = table.totals()
+        t_all = time.perf_counter() - t_all
+    finally:
+        del os.environ["GK_TOTALS_RENDER_ALL"]
+    pairs = int(sum(p for _, p in tot.values()))
+    return {"seconds": t_tot, "seconds_first_call": t_cold, "results": int(sum(r for r, _ in tot.values())), "violating_pairs": pairs, "rendered_pairs": int(rendered),
+            "rendered_share": rendered / pairs if pairs else 0.0, "host_pass_over_every_pair": {"seconds": t_all, "equal": tot == tot_all},
+            "what": "gk_table_totals on the timed table (GK_TABLE_KEEP_TEXT): the device counts the results of the violating pairs it can tell apart by their "
+                    "messages' heads and flags the others, the host renders those only; checked against rendering every violating pair"}
+
+
+def side_point(config, reviews, steps, warmup, oracle_n, dev_index, fx, nss, with_stream=False, stream_args=None, dev=None, totals=False):
     """One more BASELINE config measured the way the headline one is -- its own engine, policy set and resident table --
     for the `other_configs` of the default bench line: `steps` sweeps of the table in HBM between two synchronisations,
     the dominant kernel's duration from per-launch HIP events, and (oracle_n > 0) the INDEPENDENT parity leg: the device
@@ -249,7 +274,7 @@ def side_point(config, reviews, steps, warmup, oracle_n, dev_index, fx, nss, wit
     t_gen = time.perf_counter()
     batch = synth.NativeBatch(drv.engine.lib, reviews, seed=synth.SEED, mixed=(config != 1), start=0, namespaces=nss)
     t_gen = time.perf_counter() - t_gen
-    table = drv.engine.create_table_native(batch.reviews, reviews, keep_docs=False, resident=True)
+    table = drv.engine.create_table_native(batch.reviews, reviews, keep_docs=False, resident=True, keep_text=totals)
     st = table.stats()
 
     def local(k, download=False):
@@ -295,6 +320,11 @@ def side_point(config, reviews, steps, warmup, oracle_n, dev_index, fx, nss, wit
             out["parity_python_oracle"]["geometry"] = "the timed table itself: %d reviews, %d plan group(s), LDS %d B per row group" % (reviews, groups, int(final.lds_bytes))
         except Exception as ex:   # noqa: BLE001
             out["parity_python_oracle"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+    if totals:
+        try:
+            out["audit_result_totals"] = totals_leg(table)
+        except Exception as ex:   # noqa: BLE001
+            out["audit_result_totals"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
     table.free()
     stream = None
     if with_stream:
@@ -315,7 +345,7 @@ def side_point(config, reviews, steps, warmup, oracle_n, dev_index, fx, nss, wit
     return out, stream
 
 
-def other_configs(args, dev_index, dev, fx, nss, budget_s=170.0):
+def other_configs(args, dev_index, dev, fx, nss, budget_s=200.0):
     """configs[1], configs[4] (resident + streaming) and the N = 1 point of configs[3], each in its own engine; a leg is skipped
     (and says so) once the budget is spent so that the default run stays within a few minutes."""
     t_start = time.perf_counter()
@@ -354,9 +384,13 @@ def other_configs(args, dev_index, dev, fx, nss, budget_s=170.0):
     import copy
     sa = copy.copy(args)
     sa.stream_batches, sa.warmup, sa.stream_unique, sa.batch, sa.offered = 16, 2, 8, 65536, 1e6
-    r = run("configs4", lambda: side_point(4, 200000, max(args.steps, 20), args.warmup, args.side_oracle_sample, dev_index, fx, nss, with_stream=True, stream_args=sa, dev=dev))
+    r = run("configs4", lambda: side_point(4, 200000, max(args.steps, 20), args.warmup, args.side_oracle_sample, dev_index, fx, nss, with_stream=True, stream_args=sa, dev=dev, totals=True))
     if r:
         detail["configs4"], brief["configs4"] = r[0], resident_brief(r[0])
+        tl = r[0].get("audit_result_totals") or {}
+        brief["configs4"]["totals"] = ({"error": tl["error"][:80]} if "error" in tl else
+                                       {"s": _sig(tl.get("seconds"), 3), "first_s": _sig(tl.get("seconds_first_call"), 3), "rendered_share": _sig(tl.get("rendered_share"), 3),
+                                        "equal": (tl.get("host_pass_over_every_pair") or {}).get("equal"), "host_pass_s": _sig((tl.get("host_pass_over_every_pair") or {}).get("seconds"), 3)})
         detail["configs4_stream"] = r[1]
         if r[1] and "error" not in r[1]:
             brief["configs4_stream"] = {"offered": r[1]["offered_reviews_per_s"], "achieved": _sig(r[1]["achieved_reviews_per_s"]), "p50_ms": _sig(r[1]["batch_latency_ms"]["p50"], 3),
@@ -580,25 +614,7 @@ def main():
         try:
             if args.lean:
                 raise RuntimeError("skipped (--lean)")
-            t_cold = time.perf_counter()
-            tot = table.totals()                       # first call: builds + uploads the totals plans
-            t_cold = time.perf_counter() - t_cold
-            t_tot = time.perf_counter()
-            tot = table.totals()
-            t_tot = time.perf_counter() - t_tot
-            rendered = table.rendered_pairs
-            os.environ["GK_TOTALS_RENDER_ALL"] = "1"
-            try:
-                t_all = time.perf_counter()
-                tot_all = table.totals()
-                t_all = time.perf_counter() - t_all
-            finally:
-                del os.environ["GK_TOTALS_RENDER_ALL"]
-            out["audit_result_totals"] = {"seconds": t_tot, "seconds_first_call": t_cold, "results": int(sum(r for r, _ in tot.values())),
-                                          "violating_pairs": int(sum(p for _, p in tot.values())), "rendered_pairs": int(rendered),
-                                          "host_pass_over_every_pair": {"seconds": t_all, "equal": tot == tot_all},
-                                          "what": "gk_table_totals on the timed table (GK_TABLE_KEEP_TEXT): the device flags the violating pairs that can have "
-                                                  "more than one result, the host renders those only; checked against rendering every violating pair"}
+            out["audit_result_totals"] = totals_leg(table)
         except Exception as ex:   # noqa: BLE001
             out["audit_result_totals"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
         if not args.no_cpu_baseline and not args.lean:
@@ -618,7 +634,9 @@ def main():
             pp, ps = out.get("parity_python_oracle") or {}, out.get("parity_sample") or {}
             brief["configs2"] = {"w": "%dx%d" % (nc, total_reviews), "ms": _sig(out["ms_per_step"]), "frac": _sig(out["roofline"]["frac"], 3),
                                  "parity": {"n": pp.get("n"), "equal": pp.get("pairs_equal"), "pairs": pp.get("oracle_violating_pairs"), "s": _sig(pp.get("seconds"), 3)},
-                                 "cpu_loop_parity": {"n": ps.get("n"), "equal": ps.get("pairs_equal")}}
+                                 "cpu_loop_parity": {"n": ps.get("n"), "equal": ps.get("pairs_equal")},
+                                 "totals": {"s": _sig((out.get("audit_result_totals") or {}).get("seconds"), 3), "rendered_share": _sig((out.get("audit_result_totals") or {}).get("rendered_share"), 3),
+                                            "equal": ((out.get("audit_result_totals") or {}).get("host_pass_over_every_pair") or {}).get("equal")}}
             out["other_configs"] = brief
         print(json.dumps(out))
     if dist is not None:
