@@ -3,7 +3,11 @@
 // It executes exactly the same per-row / per-review code as kernels.hip, lane by lane.  The product library
 // (libgkgpu.so) never contains this file; gatekeeper_amd/_lib.py refuses to load it outside tests.
 #include <array>
+#include <condition_variable>
+#include <deque>
+#include <functional>
 #include <map>
+#include <thread>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -20,6 +24,9 @@
 #include "codegen.hpp"
 #include "device.hpp"
 #include "jit_source.hpp"
+#include "shard_pipe.hpp"
+#include <memory>
+#include <mutex>
 #include "jit_sources.inc"   // kPlanHpp, kVmCoreHpp, kKernelBody (the text the product embeds)
 #include "vm_core.hpp"
 
@@ -67,7 +74,8 @@ DevTable* dev_table_assemble(int, std::vector<DevPart*>& parts, const HostTable&
   d->t.heap.resize_zero(d->t.heap.size() + 16);
   return d;
 }
-void dev_table_free(DevTable* t) { delete t; }
+void hostemu_table_gone(const DevTable* t);
+void dev_table_free(DevTable* t) { hostemu_table_gone(t); delete t; }
 DevTable* dev_table_view(DevTable* base) { DevTable* v = new DevTable(*base); v->pending = 0; v->last_viol.clear(); return v; }
 uint64_t dev_table_bytes(const DevTable* t) { return t->t.rows.size() * 32 + t->t.tile_idx.size() * 4 + t->t.heap.size(); }
 DevPlan* dev_plan_upload(int, const HostPlan& fast, const HostPlan& big) {
@@ -177,10 +185,24 @@ void dev_topk(const DevTable* t, uint32_t nc, const std::vector<uint32_t>& order
   }
 }
 // ---- sharded exchange on the CPU: the collectives are callbacks supplied by the test (torch.distributed / gloo), the slot
-// layout and the order of operations are those of kernels.hip
+// layout is kernels.hip's and the ORDER OF OPERATIONS of the passes is the product's own: csrc/shard_pipe.hpp, instantiated here
+// with a worker THREAD for the exchange stream and condition variables for the events (the table's stream is the calling thread).
+// GK_SHARD_OVERLAP=1 therefore runs the two-buffer overlapped exchange for real -- pass k's all-gather on the exchange thread
+// while pass k + 1 is evaluated -- at any world size gloo offers.
 typedef void (*HeAllGather)(void* ctx, void* buf, uint64_t slot_bytes);          // in place: buf = [world][slot_bytes]
 typedef void (*HeAllReduce)(void* ctx, long long* buf, uint64_t n);              // sum, in place
-struct DevComm { int rank = 0, world = 1; HeAllGather gather = nullptr; HeAllReduce reduce = nullptr; void* ctx = nullptr; };
+struct DevComm {
+  int rank = 0, world = 1; HeAllGather gather = nullptr; HeAllReduce reduce = nullptr; void* ctx = nullptr;
+  // collectives of one communicator run in ISSUE order on every rank, whichever stream (thread) carries them -- as RCCL's do
+  std::mutex mu; std::condition_variable cv; uint64_t issued = 0, serving = 0;
+  uint64_t ticket() { std::lock_guard<std::mutex> l(mu); return issued++; }
+  void gather_in_order(uint64_t tk, void* buf, uint64_t slot_bytes) {
+    { std::unique_lock<std::mutex> l(mu); cv.wait(l, [&] { return serving == tk; }); }
+    gather(ctx, buf, slot_bytes);
+    { std::lock_guard<std::mutex> l(mu); serving++; }
+    cv.notify_all();
+  }
+};
 bool dev_comm_unique_id(char id[128], std::string*) { memset(id, 0, 128); return true; }
 DevComm* dev_comm_init(int, const char*, int, int, std::string* err) { *err = "the CPU emulation takes its collectives from gk_comm_init_host"; return nullptr; }
 DevComm* hostemu_comm(int rank, int world, HeAllGather g, HeAllReduce r, void* ctx) { DevComm* c = new DevComm(); c->rank = rank; c->world = world; c->gather = g; c->reduce = r; c->ctx = ctx; return c; }
@@ -188,10 +210,48 @@ void dev_comm_free(DevComm* c) { delete c; }
 int dev_comm_rank(const DevComm* c) { return c->rank; }
 int dev_comm_world(const DevComm* c) { return c->world; }
 static size_t shard_tail_off(uint32_t nc, uint32_t stride) { return (size_t)nc * stride * 8; }
+
+// a stream: closures run in order on a thread of their own; an event: "everything recorded up to generation g has run"
+struct EmuStream {
+  std::thread th; std::mutex mu; std::condition_variable cv; std::deque<std::function<void()>> q; bool stop = false, busy = false; std::string error;
+  EmuStream() { th = std::thread([this] {
+    for (;;) {
+      std::function<void()> fn;
+      { std::unique_lock<std::mutex> l(mu); cv.wait(l, [&] { return stop || !q.empty(); }); if (q.empty()) return; fn = std::move(q.front()); q.pop_front(); busy = true; }
+      try { fn(); } catch (const std::exception& ex) { std::lock_guard<std::mutex> l(mu); if (error.empty()) error = ex.what(); }
+      { std::lock_guard<std::mutex> l(mu); busy = false; }
+      cv.notify_all();
+    } }); }
+  ~EmuStream() { { std::lock_guard<std::mutex> l(mu); stop = true; } cv.notify_all(); if (th.joinable()) th.join(); }
+  void push(std::function<void()> fn) { { std::lock_guard<std::mutex> l(mu); q.push_back(std::move(fn)); } cv.notify_all(); }
+  void sync() { std::unique_lock<std::mutex> l(mu); cv.wait(l, [&] { return q.empty() && !busy; }); if (!error.empty()) { std::string e = error; error.clear(); throw std::runtime_error("exchange stream: " + e); } }
+};
+struct EmuEvent { std::mutex mu; std::condition_variable cv; uint64_t issued = 0, done = 0; };
+struct ShardState {   // what Work holds for a shard in kernels.hip
+  std::vector<uint8_t> buf[2];
+  std::vector<long long> totals[2];   // totals over the gathered tails, per buffer (the product keeps ONE d_totals: written in pass order)
+  std::unique_ptr<EmuStream> comm;
+  EmuEvent ev[2][2];   // [event kind][buffer]
+  struct Backend;
+  ShardPipe<Backend> pipe;
+  bool enqueued = false;   // an enqueue-only pass ran since the setup: its answer can be collected
+};
+struct DevTableShard { std::shared_ptr<ShardState> st; };
+static std::map<const DevTable*, std::shared_ptr<ShardState>>& shard_states() { static std::map<const DevTable*, std::shared_ptr<ShardState>> m; return m; }
+static std::mutex& shard_states_mu() { static std::mutex m; return m; }
+static std::shared_ptr<ShardState> shard_state_of(const DevTable* t, bool make = false) {
+  std::lock_guard<std::mutex> l(shard_states_mu());
+  auto it = shard_states().find(t);
+  if (it != shard_states().end()) return it->second;
+  if (!make) return nullptr;
+  return shard_states()[t] = std::make_shared<ShardState>();
+}
+void hostemu_table_gone(const DevTable* t) { std::shared_ptr<ShardState> st; { std::lock_guard<std::mutex> l(shard_states_mu()); auto it = shard_states().find(t); if (it != shard_states().end()) { st = it->second; shard_states().erase(it); } } }
+
 void dev_shard_setup(DevTable* t, DevComm* c, uint32_t nc, ShardInfo* info) {
   std::vector<unsigned long long> sizes(c->world, 0);
   sizes[c->rank] = t->t.n_reviews;
-  c->gather(c->ctx, sizes.data(), 8);
+  c->gather_in_order(c->ticket(), sizes.data(), 8);
   info->shard_reviews.clear();
   uint32_t stride = 1;
   for (int r = 0; r < c->world; r++) { info->shard_reviews.push_back((uint32_t)sizes[r]); stride = std::max<uint32_t>(stride, (uint32_t)((sizes[r] + GK_TILE - 1) / GK_TILE)); }
@@ -199,42 +259,102 @@ void dev_shard_setup(DevTable* t, DevComm* c, uint32_t nc, ShardInfo* info) {
   // slot (kernels.hip): [nc][stride] u64 bitmap | [nc] u32 violating pairs | [nc] u32 autoreject pairs | u64 beyond limits | u64 not evaluated | pad
   info->slot_bytes = (shard_tail_off(nc, stride) + (size_t)nc * 8 + 16 + 15) & ~(size_t)15;
   t->shard_stride = stride; t->shard_slot = info->slot_bytes; t->shard_nc = nc;
-  t->shard_all.assign((size_t)c->world * info->slot_bytes, 0);
+  hostemu_table_gone(t);
+  auto st = shard_state_of(t, true);
+  st->pipe.overlap = getenv("GK_SHARD_OVERLAP") && atoi(getenv("GK_SHARD_OVERLAP")) != 0;   // (opt-in, as in kernels.hip)
+  for (int b = 0; b < (st->pipe.overlap ? 2 : 1); b++) st->buf[b].assign((size_t)c->world * info->slot_bytes, 0);
+  if (st->pipe.overlap) st->comm.reset(new EmuStream());
+  t->shard_all.clear();
 }
+
+struct ShardState::Backend {
+  const DevPlan* p; DevTable* t; DevComm* c; EvalOptions opt; uint32_t nc; uint64_t not_evaluated; ShardState* st;
+  int sel = 0;
+  void on(ShardStream s, std::function<void()> fn) { if (s == SS_TABLE) fn(); else st->comm->push(std::move(fn)); }   // (the table's stream is the calling thread)
+  void select(int b) { sel = b; }
+  void sweep() { EvalOut tmp; EvalOptions o = opt; o.download = true; dev_eval_launch(p, t, o); dev_eval_finish(p, t, o, &tmp); }   // -> t->last_viol / last_err / last_big
+  void tail() {
+    const uint32_t nt = (t->t.n_reviews + GK_TILE - 1) / GK_TILE;
+    uint8_t* slot = st->buf[sel].data() + (size_t)c->rank * t->shard_slot;
+    memset(slot, 0, t->shard_slot);
+    uint8_t* tl = slot + shard_tail_off(nc, t->shard_stride);
+    const bool have = t->last_viol.size() == (size_t)nc * nt && t->last_err.size() == (size_t)nc * nt;
+    for (uint32_t k = 0; k < nc; k++) {
+      uint32_t cnt = 0, ecnt = 0;
+      for (uint32_t w = 0; w < nt; w++) { const uint64_t v = have ? t->last_viol[(size_t)k * nt + w] : 0; memcpy(slot + ((size_t)k * t->shard_stride + w) * 8, &v, 8); cnt += (uint32_t)__builtin_popcountll(v); }
+      for (uint32_t w = 0; w < nt && have; w++) ecnt += (uint32_t)__builtin_popcountll(t->last_err[(size_t)k * nt + w]);
+      memcpy(tl + (size_t)k * 4, &cnt, 4);
+      memcpy(tl + ((size_t)nc + k) * 4, &ecnt, 4);
+    }
+    unsigned long long beyond = 0, ne = not_evaluated;
+    for (uint32_t w = 0; w < nt && w < t->last_big.size(); w++) beyond += (unsigned long long)__builtin_popcountll(t->last_big[w]);
+    memcpy(tl + (size_t)nc * 8, &beyond, 8);
+    memcpy(tl + (size_t)nc * 8 + 8, &ne, 8);
+  }
+  void gather(ShardStream s) {
+    const uint64_t tk = c->ticket();   // (issue order = the calling thread's order, the same on every rank)
+    uint8_t* buf = st->buf[sel].data(); const uint64_t sb = t->shard_slot; DevComm* cc = c;
+    on(s, [cc, tk, buf, sb] { cc->gather_in_order(tk, buf, sb); });
+  }
+  void totals(ShardStream s) {
+    ShardState* S = st; const int b = sel; const uint32_t n = nc, stride = t->shard_stride; const size_t sb = t->shard_slot; const int world = c->world;
+    on(s, [S, b, n, stride, sb, world] {
+      std::vector<long long>& T = S->totals[b];
+      T.assign(2 * (size_t)n + 2, 0);   // [nc] pairs | [nc] autoreject pairs | beyond limits | not evaluated: sums over the gathered tails
+      for (int r = 0; r < world; r++) {
+        const uint8_t* tl = S->buf[b].data() + (size_t)r * sb + shard_tail_off(n, stride);
+        for (uint32_t i = 0; i < 2 * n; i++) { uint32_t v; memcpy(&v, tl + (size_t)i * 4, 4); T[i] += v; }
+        for (uint32_t i = 0; i < 2; i++) { unsigned long long v; memcpy(&v, tl + (size_t)n * 8 + (size_t)i * 8, 8); T[2 * (size_t)n + i] += (long long)v; }
+      }
+    });
+  }
+  void record(ShardEvent e, int b, ShardStream s) {
+    EmuEvent* ev = &st->ev[e][b];
+    uint64_t g; { std::lock_guard<std::mutex> l(ev->mu); g = ++ev->issued; }
+    on(s, [ev, g] { { std::lock_guard<std::mutex> l(ev->mu); if (ev->done < g) ev->done = g; } ev->cv.notify_all(); });
+  }
+  void wait(ShardStream s, ShardEvent e, int b) {
+    EmuEvent* ev = &st->ev[e][b];
+    uint64_t g; { std::lock_guard<std::mutex> l(ev->mu); g = ev->issued; }   // (the most recent record at the time of the call, as hipStreamWaitEvent)
+    on(s, [ev, g] { std::unique_lock<std::mutex> l(ev->mu); ev->cv.wait(l, [&] { return ev->done >= g; }); });
+  }
+  void sync(ShardStream s) { if (s == SS_COMM && st->comm) st->comm->sync(); }
+};
+
+static void shard_read(DevTable* t, ShardState* st, uint32_t nc, std::vector<int64_t>* totals, std::vector<uint64_t>* gathered, const void** d_gathered) {
+  const int b = st->pipe.cur;
+  totals->assign(st->totals[b].begin(), st->totals[b].end());
+  totals->resize(2 * (size_t)nc + 2, 0);
+  if (gathered) { gathered->resize(st->buf[b].size() / 8); memcpy(gathered->data(), st->buf[b].data(), st->buf[b].size()); }
+  if (d_gathered) *d_gathered = st->buf[b].data();
+}
+// the exchange of a collecting sweep: on the table's stream, into the CURRENT buffer, after whatever the exchange stream still runs
 void dev_shard_exchange(DevTable* t, DevComm* c, uint32_t nc, uint64_t not_evaluated, std::vector<int64_t>* totals, std::vector<uint64_t>* gathered,
                         const void** d_gathered) {
-  if (t->shard_nc != nc || t->shard_all.empty()) throw std::runtime_error("dev_shard_exchange without dev_shard_setup");
-  const uint32_t nt = (t->t.n_reviews + GK_TILE - 1) / GK_TILE;
-  uint8_t* slot = t->shard_all.data() + (size_t)c->rank * t->shard_slot;
-  memset(slot, 0, t->shard_slot);
-  uint8_t* tail = slot + shard_tail_off(nc, t->shard_stride);
-  const bool have = t->last_viol.size() == (size_t)nc * nt && t->last_err.size() == (size_t)nc * nt;   // (an enqueue-only pass before the first finished evaluation exchanges zeros)
-  for (uint32_t k = 0; k < nc; k++) {
-    uint32_t cnt = 0, ecnt = 0;
-    for (uint32_t w = 0; w < nt; w++) { const uint64_t v = have ? t->last_viol[(size_t)k * nt + w] : 0; memcpy(slot + ((size_t)k * t->shard_stride + w) * 8, &v, 8); cnt += (uint32_t)__builtin_popcountll(v); }
-    for (uint32_t w = 0; w < nt && have; w++) ecnt += (uint32_t)__builtin_popcountll(t->last_err[(size_t)k * nt + w]);
-    memcpy(tail + (size_t)k * 4, &cnt, 4);
-    memcpy(tail + ((size_t)nc + k) * 4, &ecnt, 4);
-  }
-  unsigned long long beyond = 0, ne = not_evaluated;
-  for (uint32_t w = 0; w < nt && w < t->last_big.size(); w++) beyond += (unsigned long long)__builtin_popcountll(t->last_big[w]);
-  memcpy(tail + (size_t)nc * 8, &beyond, 8);
-  memcpy(tail + (size_t)nc * 8 + 8, &ne, 8);
-  c->gather(c->ctx, t->shard_all.data(), t->shard_slot);   // the ONE collective of a sweep
-  if (!totals) return;   // enqueue only
-  totals->assign(2 * (size_t)nc + 2, 0);   // [nc] pairs | [nc] autoreject pairs | beyond limits | not evaluated: sums over the gathered tails
-  for (int r = 0; r < c->world; r++) {
-    const uint8_t* tl = t->shard_all.data() + (size_t)r * t->shard_slot + shard_tail_off(nc, t->shard_stride);
-    for (uint32_t i = 0; i < 2 * nc; i++) { uint32_t v; memcpy(&v, tl + (size_t)i * 4, 4); (*totals)[i] += v; }
-    for (uint32_t i = 0; i < 2; i++) { unsigned long long v; memcpy(&v, tl + (size_t)nc * 8 + (size_t)i * 8, 8); (*totals)[2 * (size_t)nc + i] += (long long)v; }
-  }
-  if (gathered) { gathered->resize(t->shard_all.size() / 8); memcpy(gathered->data(), t->shard_all.data(), t->shard_all.size()); }
-  if (d_gathered) *d_gathered = t->shard_all.data();
+  auto st = shard_state_of(t);
+  if (t->shard_nc != nc || !st) throw std::runtime_error("dev_shard_exchange without dev_shard_setup");
+  ShardState::Backend be{nullptr, t, c, EvalOptions(), nc, not_evaluated, st.get()};
+  st->pipe.drain(be);
+  be.select(st->pipe.cur);
+  be.tail(); be.gather(SS_TABLE); be.totals(SS_TABLE);
+  if (!totals) return;
+  shard_read(t, st.get(), nc, totals, gathered, d_gathered);
 }
-bool dev_shard_collect(DevTable*, DevComm*, uint32_t, std::vector<int64_t>*, std::vector<uint64_t>*, const void**) { return false; }   // (the emulation's enqueue-only passes exchange the LAST FINISHED evaluation: always sweep)
+// the answer of the LAST enqueue-only pass without sweeping again (kernels.hip dev_shard_collect)
+bool dev_shard_collect(DevTable* t, DevComm* c, uint32_t nc, std::vector<int64_t>* totals, std::vector<uint64_t>* gathered, const void** d_gathered) {
+  auto st = shard_state_of(t);
+  if (!st || t->shard_nc != nc || !st->enqueued) return false;
+  ShardState::Backend be{nullptr, t, c, EvalOptions(), nc, 0, st.get()};
+  st->pipe.drain(be);
+  shard_read(t, st.get(), nc, totals, gathered, d_gathered);
+  return true;
+}
 void dev_shard_enqueue(const DevPlan* p, DevTable* t, DevComm* c, const EvalOptions& opt, uint32_t nc, uint64_t not_evaluated, bool) {
-  dev_eval_launch(p, t, opt);
-  dev_shard_exchange(t, c, nc, not_evaluated, nullptr, nullptr, nullptr);
+  auto st = shard_state_of(t);
+  if (!st || t->shard_nc != nc) throw std::runtime_error("dev_shard_enqueue without dev_shard_setup");
+  ShardState::Backend be{p, t, c, opt, nc, not_evaluated, st.get()};
+  st->pipe.enqueue(be);
+  st->enqueued = true;
 }
 
 // GK_HOSTEMU_KERNEL=1 | jit: additionally run the dominant kernel's HIP source (kernel_body.inc) through the kernel emulator

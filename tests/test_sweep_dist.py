@@ -43,7 +43,7 @@ def _worker(rank, world, port, out_dir, policies="audit"):
     shard = objs[lo:lo + SHARDS[rank]]
     sw = ShardedSweep(_client(policies), shard, synth.gen_namespaces(), dist=dist, device=torch.device("cpu"), keep_docs=True)
     sw.sweep(2)
-    sw.sweep(2, collect=True)          # (the emulation has no enqueue-only answer: GK_SHARD_COLLECT falls back to a collecting sweep)
+    sw.sweep(2, collect=True)          # (GK_SHARD_COLLECT: the answer of the last enqueue-only pass; a set with several plan groups sweeps once more)
     res = sw.sweep(3, download=True)   # two enqueued sweep + exchange passes (GK_SHARD_ENQUEUE), the third collects
     lists = sw.audit_lists(limit=5)
     with open(os.path.join(out_dir, "rank_%d.pkl" % rank), "wb") as fh:
@@ -202,3 +202,73 @@ def test_rccl_exchange_and_captured_sweeps_on_the_device(tmp_path, graph, monkey
         # "plain": the collected answers came from the enqueue-only passes themselves (no collecting sweep ran: no kernel time reported)
         if name == "plain":
             assert got[1]["kernel_ms"] == 0 and got[3]["kernel_ms"] == 0 and got[2]["kernel_ms"] > 0
+
+
+# ---- round 4: the OVERLAPPED exchange at world size 4.  The order of operations of the enqueue-only passes -- two slot buffers, the
+# exchange stream, the "slot complete" / "exchange over" events -- is ONE definition (csrc/shard_pipe.hpp) with two backends: HIP
+# streams + RCCL in the product, a worker thread + condition variables + the gloo callback in the CPU build.  Here it runs for real:
+# pass k's all-gather travels on the exchange thread while pass k + 1 is evaluated, with three plan groups (three pipelines sharing
+# one communicator: collectives in issue order) and uneven shards; every answer handed out equals the single-process one.
+SHARDS4 = [173, 64, 201, 97]
+
+
+def _client3():
+    """> 128 distinct formulas = three plan groups; K8sContainerLimits left out (0.9 s of policy load per copy, four processes)"""
+    fx = synth.load_fixtures()
+    c = D.Client(D.Driver(hostemu=True))
+    templates, constraints = synth.corpus(fx, 160)
+    keep = [i for i, k in enumerate(constraints) if "ContainerLimits" not in k["kind"]]
+    for i in keep:
+        c.AddTemplate(templates[i])
+        c.AddConstraint(constraints[i])
+    return c
+
+
+def _objs4():
+    return synth.gen_objects(sum(SHARDS4), seed=33, mixed=True)
+
+
+def _overlap_worker(rank, world, port, out_dir, policies):
+    os.environ["GK_SHARD_OVERLAP"] = "1"
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    objs = _objs4()
+    lo = sum(SHARDS4[:rank])
+    shard = objs[lo:lo + SHARDS4[rank]]
+    sw = ShardedSweep(_client3() if policies == "three-groups" else _client("audit"), shard, synth.gen_namespaces(), dist=dist, device=torch.device("cpu"))
+    answers = [sw.sweep(1, download=True),                       # a collecting sweep
+               sw.sweep(3, download=True),                       # two overlapped enqueue-only passes, the third collects
+               sw.sweep(4, download=True, collect=True),         # four overlapped passes, the answer of the LAST one is handed out
+               sw.sweep(2, download=True)]                       # ... and the buffers are sound afterwards
+    with open(os.path.join(out_dir, "ovl_%d.pkl" % rank), "wb") as fh:
+        pickle.dump([{"bitmaps": r.bitmaps(), "totals": r.totals, "counts": r.counts(), "shards": r.shard_reviews, "ids": r.constraint_ids,
+                      "beyond": r.beyond_limits, "not_evaluated": r.not_evaluated} for r in answers], fh)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("policies", ["one-group", "three-groups"])
+def test_overlapped_exchange_at_world_size_four(tmp_path, policies):
+    world = len(SHARDS4)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_overlap_worker, args=(world, port, str(tmp_path), policies), nprocs=world, join=True)
+    objs = _objs4()
+    c = _client3() if policies == "three-groups" else _client("audit")
+    single = ShardedSweep(c, objs, synth.gen_namespaces())
+    ref = single.table.eval()
+    n = len(objs)
+    if policies == "three-groups":
+        assert ref.n_plan_groups == 3
+    ref_bits = np.stack([np.unpackbits(ref.viol[r].view(np.uint8), bitorder="little")[:n] for r in range(ref.n_constraints)])
+    for rank in range(world):
+        answers = pickle.load(open(os.path.join(str(tmp_path), "ovl_%d.pkl" % rank), "rb"))
+        assert len(answers) == 4
+        for k, got in enumerate(answers):
+            assert list(got["shards"]) == SHARDS4 and (got["ids"] == ref.constraint_ids).all()
+            bits = np.concatenate([np.stack([np.unpackbits(bm[r].view(np.uint8), bitorder="little")[:SHARDS4[j]] for r in range(ref.n_constraints)])
+                                   for j, bm in enumerate(got["bitmaps"])], axis=1)
+            assert (bits == ref_bits).all(), "rank %d, answer %d: a different global bitmap" % (rank, k)
+            assert (got["totals"] == ref.counts.astype(np.int64)).all() and (got["counts"].sum(0) == ref.counts).all()
+            assert got["beyond"] == 0 and got["not_evaluated"] == 0
+    assert ref.counts.sum() > 100
