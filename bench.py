@@ -177,7 +177,7 @@ def stream_leg(args, drv, client, templates, constraints, nss, rank, world, dev,
             arrival = arrival if period > 0 and t0 is not None else now
         b = batches[j % uniq]
         t_i0 = time.perf_counter()
-        table = drv.engine.create_table_native(b.reviews, bsz, keep_docs=False, resident=True)
+        table = drv.engine.create_table_native(b.reviews, bsz, keep_docs=False, resident=True, pruned=not getattr(args, "no_prune", False))
         t_i1 = time.perf_counter()
         q.put((k, table, arrival, t_i0, t_i1))
         if errors:
@@ -245,7 +245,7 @@ def totals_leg(table):
                     "messages' heads and flags the others, the host renders those only; checked against rendering every violating pair"}
 
 
-def side_point(config, reviews, steps, warmup, oracle_n, dev_index, fx, nss, with_stream=False, stream_args=None, dev=None, totals=False):
+def side_point(config, reviews, steps, warmup, oracle_n, dev_index, fx, nss, with_stream=False, stream_args=None, dev=None, totals=False, n_templates=200):
     """One more BASELINE config measured the way the headline one is -- its own engine, policy set and resident table --
     for the `other_configs` of the default bench line: `steps` sweeps of the table in HBM between two synchronisations,
     the dominant kernel's duration from per-launch HIP events, and (oracle_n > 0) the INDEPENDENT parity leg: the device
@@ -259,7 +259,7 @@ def side_point(config, reviews, steps, warmup, oracle_n, dev_index, fx, nss, wit
     templates = synth.psp_templates(fx)
     constraints = synth.psp_constraints() if config == 1 else synth.audit_constraints()
     if config == 4:
-        templates, constraints = synth.corpus(fx)
+        templates, constraints = synth.corpus(fx, n_templates)   # (200: configs[4]; the CPU test of this function loads fewer)
     t_pol = time.perf_counter()
     drv = D.Driver(device=dev_index, hostemu=False)
     client = D.Client(drv)
@@ -274,7 +274,7 @@ def side_point(config, reviews, steps, warmup, oracle_n, dev_index, fx, nss, wit
     t_gen = time.perf_counter()
     batch = synth.NativeBatch(drv.engine.lib, reviews, seed=synth.SEED, mixed=(config != 1), start=0, namespaces=nss)
     t_gen = time.perf_counter() - t_gen
-    table = drv.engine.create_table_native(batch.reviews, reviews, keep_docs=False, resident=True, keep_text=totals)
+    table = drv.engine.create_table_native(batch.reviews, reviews, keep_docs=False, resident=True, keep_text=totals, pruned=True)
     st = table.stats()
 
     def local(k, download=False):
@@ -425,6 +425,8 @@ def main():
     ap.add_argument("--offered", type=float, default=1e6, help="offered load in reviews/s over all ranks (0: closed loop, as fast as the pipeline goes)")
     ap.add_argument("--oracle-sample", type=int, default=262144, help="objects of the timed table the pure-Python oracle re-evaluates (parity_python_oracle)")
     ap.add_argument("--side-oracle-sample", type=int, default=16384, help="... of every other_configs table")
+    ap.add_argument("--no-prune", action="store_true", help="tables with a row for every key path of every object (rounds 1-3) instead of GK_TABLE_PRUNED: rows of the key "
+                    "paths the loaded constraints read; the kernel's algorithmic bytes are the same, the ingest and the table are not")
     ap.add_argument("--no-other-configs", action="store_true", help="only the headline workload (the default run adds configs[1], configs[4] resident + streaming "
                     "and the N = 1 point of configs[3] as `other_configs`, each with its own parity leg)")
     args = ap.parse_args()
@@ -512,7 +514,7 @@ def main():
     batch = synth.NativeBatch(drv.engine.lib, n_local, seed=synth.SEED, mixed=(args.config != 1), start=start, namespaces=nss)
     t_gen = time.perf_counter() - t_gen
     # end-to-end leg: JSON -> parse -> HandleReview -> flatten -> HBM (this is what a non-resident review costs)
-    table = drv.engine.create_table_native(batch.reviews, n_local, keep_docs=False, resident=True, keep_text=True)   # (text kept by `batch`: RESULT totals below)
+    table = drv.engine.create_table_native(batch.reviews, n_local, keep_docs=False, resident=True, keep_text=True, pruned=not getattr(args, "no_prune", False))   # (text kept by `batch`: RESULT totals below)
     st = table.stats()
     sweep = ShardedSweep(client, table=table, n=n_local, dist=dist, device=dev)
 

@@ -25,6 +25,7 @@ GK_SRC_EMPTY, GK_SRC_ORIGINAL, GK_SRC_GENERATED, GK_SRC_ALL, GK_SRC_INVALID = 0,
 GK_TABLE_KEEP_DOCS = 1
 GK_TABLE_RESIDENT = 2
 GK_TABLE_KEEP_TEXT = 16
+GK_TABLE_PRUNED = 32
 GK_TABLE_PROCESS_AUDIT = 4
 GK_TABLE_PROCESS_WEBHOOK = 8
 GK_REVIEW_EXCLUDED = 1

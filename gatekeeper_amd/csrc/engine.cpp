@@ -54,6 +54,7 @@ struct ConstraintRec {
   // the message-key paths are registered with the flattener at AddConstraint; `count_rows` / `count_flag` are the prepared,
   // trial-lowered forms (first gk_table_totals; empty = this constraint is served by multi_prep as in round 3)
   std::shared_ptr<const Template::CountForms> cforms;
+  std::vector<Pattern> count_reads;   // the paths the counting forms' atoms name (publish_read_set: pruned tables must hold their rows)
   std::vector<std::shared_ptr<const PreparedConstraint>> count_rows;
   std::shared_ptr<const PreparedConstraint> count_flag;
   bool count_ready = false;
@@ -376,6 +377,8 @@ struct gk_table {
   uint32_t n_reviews = 0;
   uint32_t rpt = GK_RPT_MIN;                // reviews per row group of this table
   uint64_t dict_gen = 0;                    // generation of the dictionary-predicate registry the rows were flattened under
+  bool pruned = false;                      // GK_TABLE_PRUNED: rows of the registry's read set only ...
+  uint64_t reads_gen = 0;                   // ... as it was when the table was built (DictRegistry::reads_gen)
   ShardInfo shard;                          // sharded sweeps: slot layout agreed with the other ranks
   std::vector<ShardInfo> group_shards;      // ... of the further plan groups (on their views)
   uint64_t shard_gen = 0;
@@ -455,6 +458,17 @@ DevPlan* plan_for_table(gk_engine* e, gk_table* t, const HostPlan** host) {
 }
 
 void refresh_referential(gk_engine* e);
+// The READ SET of pruned tables (GK_TABLE_PRUNED; flatten.hpp DictRegistry::set_reads): every path pattern some plan has a predicate
+// on -- all plan groups, both capacities -- plus the paths the constraints' counting forms name (their plans are built at the
+// first gk_table_totals, after the tables).  Caller holds plan_rw exclusively and mu shared (ensure_plan).
+void publish_read_set(gk_engine* e) {
+  std::vector<Pattern> pats;
+  auto take = [&](const HostPlan& hp) { pats.insert(pats.end(), hp.pred_patterns.begin(), hp.pred_patterns.end()); };
+  take(e->fast); take(e->big);
+  for (auto& g : e->extra) { take(g->fast); take(g->big); }
+  for (auto& c : e->constraints) if (c.alive) pats.insert(pats.end(), c.count_reads.begin(), c.count_reads.end());
+  e->dict_reg.set_reads(pats);
+}
 
 void ensure_plan(gk_engine* e) {
   refresh_referential(e);   // referential constraints follow the synced inventory (no-op unless one is loaded and it changed)
@@ -543,6 +557,7 @@ void ensure_plan(gk_engine* e) {
   e->dev_plan = dev_plan_upload(e->opts.device, e->fast, e->big);
   e->plan_gen++;
   e->plan_dirty = false;
+  publish_read_set(e);
 }
 
 Value parse_opt(const char* p, size_t n) { return (p && n) ? parse_json(p, n) : Value(); }
@@ -554,7 +569,9 @@ int count_kmax() { return getenv("GK_COUNT_KMAX") ? atoi(getenv("GK_COUNT_KMAX")
 
 // The counting forms of a constraint from the evaluation that gave its violation formula; registers the message-key paths with
 // the flattener (caller holds mu exclusively: a new key path makes the tables flattened so far stale, like a new value path)
-std::shared_ptr<const Template::CountForms> derive_count_forms(gk_engine* e, const Template::CountInfo& ci, const MatchFormulas& mf, FP* merged_viol = nullptr) {
+std::shared_ptr<const Template::CountForms> derive_count_forms(gk_engine* e, const Template::CountInfo& ci, const MatchFormulas& mf, FP* merged_viol = nullptr,
+                                                                 std::vector<Pattern>* reads = nullptr) {
+  if (reads) reads->clear();
   if (count_kmax() < 2) return nullptr;
   try {
     const auto tf0 = std::chrono::steady_clock::now();
@@ -575,14 +592,16 @@ std::shared_ptr<const Template::CountForms> derive_count_forms(gk_engine* e, con
       std::vector<FP> probe;
       for (uint32_t i : cf->firsts) probe.push_back(cf->rows[i]);
       probe.push_back(cf->flag);
+      auto pattern_of = [](const SPath& p) { Pattern pat; for (const Step& st : p) { PatStep ps; if (st.iter) ps.any = true; else ps.key = st.key; pat.push_back(ps); } return pat; };
       std::function<void(const FP&)> walk = [&](const FP& f) {
         if (f->kind == FNode::ATOM) {
-          if (f->atom.kind != Atom::DICT) return;
-          Pattern pat;
-          for (const Step& st : f->atom.path) { PatStep ps; if (st.iter) ps.any = true; else ps.key = st.key; pat.push_back(ps); }
-          e->dict_reg.counting().intern(pat, f->atom.dx, true);
+          if (f->atom.kind == Atom::DICT) { e->dict_reg.counting().intern(pattern_of(f->atom.path), f->atom.dx, true); return; }
+          // (every other atom reads rows of its path: a pruned table must hold them -- publish_read_set)
+          if (reads && !f->atom.path.empty()) reads->push_back(pattern_of(f->atom.path));
+          if (reads && !f->atom.path2.empty()) reads->push_back(pattern_of(f->atom.path2));
           return;
         }
+        if (reads && f->kind == FNode::EXISTS) { SPath el = f->base; Step st; st.iter = true; st.q = f->q; el.push_back(st); reads->push_back(pattern_of(el)); }   // (the element marker rows of a counted array)
         for (auto& k : f->kids) walk(k);
       };
       for (auto& f : probe) walk(prepare_constraint(f, mf)->viol);
@@ -689,7 +708,7 @@ void compile_referential(gk_engine* e, const Template& t, ConstraintRec& c) {
   c.viol = viol; c.prep = prep;
   c.multi_prep = prepare_multi(e, t, c.params, c.mf, inv);
   c.multi_ready = true;
-  c.cforms = derive_count_forms(e, ci, c.mf);
+  c.cforms = derive_count_forms(e, ci, c.mf, nullptr, &c.count_reads);
   c.count_ready = false;
 }
 
@@ -827,7 +846,7 @@ int gk_template_add(gk_engine* e, const char* kind, const char* rego, const char
     // nothing: when one of them does not compile the old template and its constraints stay as they are and the caller
     // gets the error (the reference reports it on the ConstraintTemplate's status and keeps serving the old one).
     const std::string k = lower_str(kind);
-    struct Redo { ConstraintRec* c; FP viol; std::shared_ptr<const PreparedConstraint> prep, multi; bool referential; std::shared_ptr<const Template::CountForms> cforms; };
+    struct Redo { ConstraintRec* c; FP viol; std::shared_ptr<const PreparedConstraint> prep, multi; bool referential; std::shared_ptr<const Template::CountForms> cforms; std::vector<Pattern> reads; };
     std::vector<Redo> redo;
     for (auto& c : e->constraints) {
       if (!c.alive || lower_str(c.kind) != k) continue;
@@ -842,11 +861,11 @@ int gk_template_add(gk_engine* e, const char* kind, const char* rego, const char
       PlanCaps caps;
       pb.build(caps);
       r.multi = prepare_multi(e, *t, c.params, c.mf, inv);
-      r.cforms = derive_count_forms(e, ci, c.mf);
+      r.cforms = derive_count_forms(e, ci, c.mf, nullptr, &r.reads);
       redo.push_back(std::move(r));
     }
     e->templates[k] = t;
-    for (auto& r : redo) { r.c->viol = std::move(r.viol); r.c->prep = std::move(r.prep); r.c->multi_prep = std::move(r.multi); r.c->multi_ready = true; r.c->referential = r.referential; r.c->broken.clear(); r.c->cforms = std::move(r.cforms); r.c->count_ready = false; r.c->count_rows.clear(); r.c->count_flag = nullptr; }
+    for (auto& r : redo) { r.c->viol = std::move(r.viol); r.c->prep = std::move(r.prep); r.c->multi_prep = std::move(r.multi); r.c->multi_ready = true; r.c->referential = r.referential; r.c->broken.clear(); r.c->cforms = std::move(r.cforms); r.c->count_reads = std::move(r.reads); r.c->count_ready = false; r.c->count_rows.clear(); r.c->count_flag = nullptr; }
     // (inv_compiled stays as it is: referential constraints of OTHER kinds may still hold an older inventory -- refresh_referential
     // recompiles every one of them at the next evaluation; marking the inventory compiled here left them stale, i.e. missed violations)
     e->plan_dirty = true;
@@ -908,7 +927,7 @@ int gk_constraint_add(gk_engine* e, const char* json, size_t len, uint32_t* id_o
       const Template::CountInfo ci = it->second->compile_all(rec.params, &e->next_quant);
       rec.viol = ci.viol;
       const auto ta1 = std::chrono::steady_clock::now();
-      rec.cforms = derive_count_forms(e, ci, rec.mf, &rec.viol);
+      rec.cforms = derive_count_forms(e, ci, rec.mf, &rec.viol, &rec.count_reads);
       const auto ta2 = std::chrono::steady_clock::now();
       if (getenv("GK_DEBUG_COUNTS")) {
         fprintf(stderr, "[gkgpu counts] %s/%s: %zu branches, forms %s\n", rec.kind.c_str(), rec.name.c_str(), ci.br.size(), rec.cforms ? "ok" : "none");
@@ -1150,6 +1169,8 @@ int gk_table_create(gk_engine* e, const gk_review_in* reviews, size_t n, uint32_
     if (const char* rp = getenv("GK_RPT")) { int v = atoi(rp); if (v == 64 || v == 128 || v == 256 || v == 512) rpt = (uint32_t)v; }
     t->rpt = rpt;
     t->dict_gen = e->dict_reg.gen();
+    t->pruned = ((flags & GK_TABLE_PRUNED) != 0 || getenv("GK_FORCE_PRUNE") != nullptr) && !getenv("GK_NO_PRUNE");   // (GK_FORCE_PRUNE: the test suites run every table pruned)
+    t->reads_gen = e->dict_reg.reads_gen();
     const size_t n_tiles = (n + rpt - 1) / rpt;
     // host threads of a table build: at most 64 -- measured on the 256-thread GPU box (profiles/r03_phases_d_*.log): 1M objects
     // flatten in 0.45 s on 64 threads, 0.61 s on 128, 0.68 s on 256 (first-touch page faults and the shared dictionaries
@@ -1183,6 +1204,7 @@ int gk_table_create(gk_engine* e, const gk_review_in* reviews, size_t n, uint32_
         std::unique_ptr<Flattener>& slot = tl_flatteners[e->uid];
         if (!slot) { if (tl_flatteners.size() > 8) { tl_flatteners.clear(); } tl_flatteners[e->uid].reset(new Flattener(&e->dict, &e->dict_reg)); }
         Flattener& fl = *tl_flatteners[e->uid];
+        fl.set_pruning(t->pruned);
         fl.begin_table();
         parts[w].rpt = rpt;
         const size_t lo = std::min(n, w * tiles_per * rpt), hi = std::min(n, (w + 1) * tiles_per * rpt);
@@ -1500,6 +1522,8 @@ int gk_table_eval(gk_engine* e, gk_table* t, uint32_t flags, gk_eval_out** out) 
     ensure_plan(e);
     if (t->dict_gen != e->dict_reg.gen())
       return fail(GK_ERR_INVALID, "the table was flattened before a constraint with dictionary predicates was added (its <leaf>.$d rows are missing): create it again");
+    if (t->pruned && t->reads_gen != e->dict_reg.reads_gen())
+      return fail(GK_ERR_INVALID, "the pruned table was flattened before a constraint that reads other key paths was added (GK_TABLE_PRUNED): create it again");
     std::unique_ptr<EvalHolder> h(new EvalHolder());
     EvalOptions opt;
     opt.download = !(flags & GK_EVAL_NO_DOWNLOAD);
@@ -1682,6 +1706,7 @@ static std::vector<uint64_t> render_needed(gk_engine* e, gk_table* t, const std:
   counted->assign(ids.size(), 0); sum->assign(ids.size(), 0);
   if (getenv("GK_TOTALS_RENDER_ALL") || t->n_reviews == 0) return need;
   if (t->dict_gen != e->dict_reg.gen()) return need;   // (a table flattened before the constraint set changed: no totals plan can read it)
+  if (t->pruned && t->reads_gen != e->dict_reg.reads_gen()) return need;
   std::lock_guard<std::mutex> tl(e->totals_mu);
   ensure_totals_plans(e);
   if (e->totals_groups.empty()) return need;
@@ -1969,9 +1994,20 @@ void batcher_loop(gk_engine* e) {
     for (auto* r : batch) ins.push_back(*r->in);
     std::vector<int32_t> st(batch.size(), GK_OK);
     auto br = std::make_shared<gk_engine::BatchResult>();
-    int rc = gk_table_create(e, ins.data(), ins.size(), 0, st.data(), &br->table);
-    std::string err = rc == GK_OK ? "" : gk_last_error();
-    if (rc == GK_OK) { rc = gk_table_eval(e, br->table, 0, &br->ev); if (rc != GK_OK) err = gk_last_error(); }
+    // an admission batch serves the policy set loaded now and is evaluated once: a PRUNED table (rows of the key paths that set reads,
+    // the ingest walks past the rest).  A constraint that arrives between the two calls makes it stale: built again, once
+    int rc = GK_OK;
+    std::string err;
+    for (int attempt = 0; attempt < 2; attempt++) {
+      if (br->table) { gk_table_free(br->table); br->table = nullptr; }
+      rc = gk_table_create(e, ins.data(), ins.size(), GK_TABLE_PRUNED, st.data(), &br->table);
+      err = rc == GK_OK ? "" : gk_last_error();
+      if (rc != GK_OK) break;
+      rc = gk_table_eval(e, br->table, 0, &br->ev);
+      if (rc == GK_OK) break;
+      err = gk_last_error();
+      if (rc != GK_ERR_INVALID) break;
+    }
     const double dev_us = br->ev ? br->ev->kernel_ms * 1e3 : 0;
     for (size_t i = 0; i < batch.size(); i++) {
       gk_engine::Request* r = batch[i];
@@ -2031,6 +2067,8 @@ int gk_table_sweep_sharded(gk_engine* e, gk_table* t, uint32_t flags, gk_shard_o
   try {
     ensure_plan(e);
     if (t->dict_gen != e->dict_reg.gen()) return fail(GK_ERR_INVALID, "the table was flattened before a constraint with dictionary predicates was added: create it again");
+    if (t->pruned && t->reads_gen != e->dict_reg.reads_gen())
+      return fail(GK_ERR_INVALID, "the pruned table was flattened before a constraint that reads other key paths was added (GK_TABLE_PRUNED): create it again");
     std::unique_ptr<ShardHolder> h(new ShardHolder());
     std::shared_lock<std::shared_mutex> l(e->plan_rw);
     const HostPlan* hp = nullptr;
@@ -2196,7 +2234,7 @@ int gk_resident_sweep(gk_engine* e, uint32_t flags, gk_sweep_out** out) {
     // compaction: when masked-out slots outnumber the live ones (or the chunks have piled up) everything is flattened
     // again into one chunk
     bool stale_rows = false;   // a constraint with dictionary predicates arrived: every chunk lacks its <leaf>.$d rows
-    for (auto& c : R.chunks) stale_rows = stale_rows || c.table->dict_gen != e->dict_reg.gen();
+    for (auto& c : R.chunks) stale_rows = stale_rows || c.table->dict_gen != e->dict_reg.gen() || (c.table->pruned && c.table->reads_gen != e->dict_reg.reads_gen());
     if (stale_rows || R.n_dead_slots > R.n_live + 1024 || R.chunks.size() > 16) {
       for (auto& c : R.chunks) resident_drop_chunk(c);
       R.chunks.clear();
@@ -2215,7 +2253,7 @@ int gk_resident_sweep(gk_engine* e, uint32_t flags, gk_sweep_out** out) {
       R.pending.clear();
       if (!ins.empty()) {
         std::vector<int32_t> st(ins.size(), GK_OK);
-        int rc = gk_table_create(e, ins.data(), ins.size(), GK_TABLE_RESIDENT, st.data(), &c.table);
+        int rc = gk_table_create(e, ins.data(), ins.size(), GK_TABLE_RESIDENT | GK_TABLE_PRUNED, st.data(), &c.table);   // (stale chunks are flattened again: stale_rows above)
         if (rc != GK_OK) return rc;
         c.live.assign((ins.size() + 63) / 64, 0);
         for (size_t k = 0; k < ins.size(); k++) {

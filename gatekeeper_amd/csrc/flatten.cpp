@@ -108,6 +108,26 @@ bool pattern_matches(const Pattern& pat, const PathDict& dict, uint32_t id) {
   return true;
 }
 
+bool pattern_reaches(const Pattern& pat, const PathDict& dict, uint32_t id, bool* full) {
+  std::vector<PathDict::Info> chain;
+  while (id != 0 && id != PathDict::kNone) { chain.push_back(dict.info(id)); id = chain.back().parent; }
+  *full = chain.size() == pat.size();
+  if (chain.size() > pat.size()) return false;
+  for (size_t i = 0; i < chain.size(); i++) {
+    const PathDict::Info& in = chain[chain.size() - 1 - i];
+    const PatStep& st = pat[i];
+    if (!st.any) { if (in.is_elem || in.key != st.key) return false; continue; }
+    bool kp_ok = true;
+    for (auto& kp : st.kpreds) if (!key_pred_holds(kp, in.key, in.is_elem)) kp_ok = false;
+    if (!kp_ok) return false;
+    if (in.is_elem) { if (!st.only.empty()) return false; continue; }
+    if (st.elems_only) return false;
+    if (!st.only.empty() && std::find(st.only.begin(), st.only.end(), in.key) == st.only.end()) return false;
+    if (std::find(st.except.begin(), st.except.end(), in.key) != st.except.end()) return false;
+  }
+  return true;
+}
+
 // can two leaf patterns cover the same concrete path?
 static bool patterns_overlap(const Pattern& a, const Pattern& b) {
   if (a.size() != b.size()) return false;
@@ -208,6 +228,37 @@ bool DictRegistry::add_value(const Pattern& leaf, bool add) {
   values_.emplace_back(k, leaf);
   gen_++;   // tables flattened before this do not carry the ids: they are stale (engine.cpp dict_gen)
   return true;
+}
+bool DictRegistry::set_reads(const std::vector<Pattern>& pats) {
+  std::vector<std::pair<std::string, Pattern>> v;
+  for (const Pattern& p : pats) v.emplace_back(pattern_to_string(p), p);
+  std::sort(v.begin(), v.end(), [](const std::pair<std::string, Pattern>& a, const std::pair<std::string, Pattern>& b) { return a.first < b.first; });
+  v.erase(std::unique(v.begin(), v.end(), [](const std::pair<std::string, Pattern>& a, const std::pair<std::string, Pattern>& b) { return a.first == b.first; }), v.end());
+  std::unique_lock<std::shared_mutex> l(mu_);
+  bool same = v.size() == reads_.size();
+  for (size_t i = 0; same && i < v.size(); i++) same = v[i].first == reads_[i].first;
+  if (same) return false;
+  reads_.swap(v);
+  reads_gen_++;
+  return true;
+}
+void DictRegistry::interest(std::vector<const Pattern*>* out) const {
+  for (auto& p : pats_) out->push_back(&p.pat);
+  for (auto& g : guards_) out->push_back(&g.second);
+  for (auto& g : values_) out->push_back(&g.second);
+  for (auto& g : keys_) out->push_back(&g.second);
+}
+uint32_t DictRegistry::read_state(const PathDict& dict, uint32_t path_id) const {
+  uint32_t st = 0;
+  bool full = false;
+  std::shared_lock<std::shared_mutex> l(mu_);
+  for (const auto& r : reads_) if (pattern_reaches(r.second, dict, path_id, &full)) { st |= 2u; if (full) st |= 1u; }
+  if (st == 3u) return st;
+  std::vector<const Pattern*> more;
+  interest(&more);
+  if (counting_) { std::shared_lock<std::shared_mutex> l2(counting_->mu_); counting_->interest(&more); for (const Pattern* p : more) if (pattern_reaches(*p, dict, path_id, &full)) st |= 2u; return st; }
+  for (const Pattern* p : more) if (pattern_reaches(*p, dict, path_id, &full)) st |= 2u;
+  return st;
 }
 bool DictRegistry::add_key(const Pattern& leaf, bool add) {
   const std::string k = pattern_to_string(leaf);
@@ -432,7 +483,8 @@ void Flattener::begin_table() {
   order_.clear();
   if (reg_) {
     const uint64_t g = reg_->gen();
-    if (g != reg_gen_) { dict_paths_.clear(); reg_gen_ = g; }
+    const uint64_t rg = reg_->reads_gen();
+    if (g != reg_gen_ || rg != reads_gen_seen_) { dict_paths_.clear(); reg_gen_ = g; reads_gen_seen_ = rg; }
   }
 }
 
@@ -491,7 +543,7 @@ void Flattener::dict_row(uint32_t path, uint32_t meta, const Value& leaf) {
   one(reg_, d.pat, d.entries, d.memo, &masks[0]);
   if (!d.centries.empty()) one(reg_->counting_if_any(), d.cpat, d.centries, d.cmemo, &masks[1]);   // (<leaf>.$c: the counting plans' expressions)
   for (int k = 0; k < 2; k++)
-    if (masks[k]) emit(dpaths[k], (meta & ~(uint32_t)ROW_TYPE_MASK & ~(uint32_t)ROW_STR_INLINE) | T_INT, (uint32_t)masks[k], (uint32_t)(masks[k] >> 32));
+    if (masks[k]) emit(dpaths[k], (meta & ~(uint32_t)ROW_TYPE_MASK & ~(uint32_t)ROW_STR_INLINE) | T_INT, (uint32_t)masks[k], (uint32_t)(masks[k] >> 32), true);
 }
 
 bool Flattener::value_wanted(uint32_t path) {
@@ -547,7 +599,24 @@ bool Flattener::key_wanted(uint32_t path) {
   return d.kstate == 2;
 }
 
-void Flattener::emit(uint32_t path, uint32_t meta, uint32_t lo, uint32_t hi) {
+uint32_t Flattener::read_state(uint32_t path) {
+  if (path >= dict_paths_.size()) dict_paths_.resize((size_t)path * 2 + 64);
+  DictPath& d = dict_paths_[path];
+  if (d.rstate == 0) d.rstate = 4u | reg_->read_state(*dict_, path);
+  return d.rstate & 3u;
+}
+
+bool Flattener::emit(uint32_t path, uint32_t meta, uint32_t lo, uint32_t hi, bool always) {
+  if (pruning_ && !always && !(read_state(path) & 1u)) {
+    // a pruned table holds no row of this path -- what the flattener itself derives from the value still happens: a message key
+    // is still compared with the review's other keys (review.$dup)
+    if (key_wanted(path)) {
+      const uint32_t id = value_id(meta, lo, hi);
+      if (id == 0u || id == GK_VID_OVERFLOW || std::find(key_ids_.begin(), key_ids_.end(), id) != key_ids_.end()) dup_seen_ = true;
+      else key_ids_.push_back(id);
+    }
+    return false;
+  }
   uint32_t rev = t_->n_reviews % t_->rpt;
   if (value_wanted(path)) rev |= value_id(meta, lo, hi) << ROW_VID_SHIFT;
   if (key_wanted(path)) {   // a message key: equal values within the review (or one without an id) -> review.$dup (finish_review)
@@ -556,6 +625,7 @@ void Flattener::emit(uint32_t path, uint32_t meta, uint32_t lo, uint32_t hi) {
     else key_ids_.push_back(id);
   }
   stage_.push_back({path, Row{rev, meta, lo, hi}, StrHdr{{0, 0, 0, 0}}});
+  return true;
 }
 
 uint32_t Flattener::put_string(const std::string& s, uint32_t* hash) {
@@ -574,6 +644,7 @@ uint32_t Flattener::put_string(const std::string& s, uint32_t* hash) {
 }
 
 void Flattener::emit_string_row(uint32_t path, uint32_t meta, const std::string& s) {
+  if (pruning_ && !(read_state(path) & 1u) && !key_wanted(path)) return;   // (no row of this path in a pruned table: no heap entry either)
   if (s.size() <= 7) {   // inline: no heap entry, no memory access on the device
     uint64_t bits = 0;
     memcpy(&bits, s.data(), s.size());
@@ -581,8 +652,7 @@ void Flattener::emit_string_row(uint32_t path, uint32_t meta, const std::string&
     return;
   }
   uint32_t hsh, off = put_string(s, &hsh);
-  emit(path, meta | T_STRING, off, hsh);
-  memcpy(&stage_.back().hdr, &t_->heap[off - 4], 16);   // entry header: length + first 12 bytes
+  if (emit(path, meta | T_STRING, off, hsh)) memcpy(&stage_.back().hdr, &t_->heap[off - 4], 16);   // entry header: length + first 12 bytes
 }
 
 void Flattener::emit_str(uint32_t parent, const char* key, const std::string& s) { emit_string_row(child(parent, key), 0, s); }
@@ -618,7 +688,12 @@ void Flattener::walk(const Value& v, uint32_t path, uint32_t ords, int adepth, u
       emit(path, meta | T_OBJECT, (uint32_t)v.size(), 0);
       if (v.size() && guard_wanted(path)) review_flags_ |= RF_REFUSE;
       if (dict_wanted(path)) dict_row(path, meta, v);
-      for (const auto& kv : v.pairs()) walk(kv.second, child(path, kv.first.str()), ords, adepth, extra);
+      for (const auto& kv : v.pairs()) {
+        const uint32_t ch = child(path, kv.first.str());
+        // GK_TABLE_PRUNED, as the one-pass parser: a member nothing reaches is not walked (metadata and its members always are)
+        if (pruning_ && !(read_state(ch) & 2u) && !walk_always(path, ch)) continue;
+        walk(kv.second, ch, ords, adepth, extra);
+      }
       break;
     }
     case Value::Array: case Value::Set: {
@@ -636,12 +711,23 @@ void Flattener::walk(const Value& v, uint32_t path, uint32_t ords, int adepth, u
           if (ord >= 255) { ord = 255; ex |= ROW_ORD_OVERFLOW; review_flags_ |= RF_TOO_BIG; }
           o2 |= ord << (ROW_E_SHIFT0 + 8 * adepth);
         } else ex |= ROW_DEEP;
+        if (pruning_ && !(read_state(ep) & 2u)) continue;   // (the ordinal is taken: the elements that ARE walked count as in the parser)
         walk(e, ep, o2, adepth + 1, ex);
       }
       break;
     }
     default: break;
   }
+}
+
+// members the pruned walk never skips: metadata of the candidate objects and what is directly in it (the one-pass parser captures the
+// match layer's facts there)
+bool Flattener::walk_always(uint32_t parent, uint32_t ch) {
+  for (int k = 0; k < 2; k++) {
+    const CapIds& c = cap_[k];
+    if ((parent == (k ? id_old_ : id_object_) && ch == c.metadata) || parent == c.metadata) return true;
+  }
+  return false;
 }
 
 void Flattener::match_facts(const Value& obj, const Value& ns, bool is_old, uint32_t m_parent) {
@@ -736,7 +822,7 @@ void Flattener::finish_review(const Value& ns, int source, HostTable* out) {
   }
   if (dup_seen_) {   // (round 4) two message keys of this review are equal: the counting plans leave it to the renderer
     if (!id_dup_) id_dup_ = child(0, "$dup");
-    emit(id_dup_, T_BOOL, 1, 0);
+    emit(id_dup_, T_BOOL, 1, 0, true);
   }
   out->rflags.push_back(review_flags_);
   for (const Ctr& c : ctrs_) {
@@ -813,15 +899,40 @@ void HostTable::append(const HostTable& part) {
 // ------------------------------------------------------------------------------------------------ fast ingest
 // JSON text -> rows in one pass (see flatten.hpp).  Grammar and value semantics are those of value.hpp's JsonParser;
 // anything unusual bails out (returns false / -1) so that the general path decides.
+uint32_t Flattener::fast_child_at(uint32_t parent, uint32_t pos, const char* key, uint32_t len) {
+  static const bool nopred = getenv("GK_NO_PRED") != nullptr;   // tuning aid
+  if (nopred) return fast_child(parent, key, len);
+  if (parent < pred_.size() && pos < pred_[parent].size()) {
+    const PredEnt& pe = pred_[parent][pos];
+    if (pe.id != 0xFFFFFFFFu && pe.len == len && memcmp(key_arena_.data() + pe.off, key, len) == 0) return pe.id;
+  }
+  const uint32_t id = fast_child(parent, key, len);
+  if (pos < 64) {   // (positions beyond 64 -- label maps, annotation maps -- are not worth remembering: their names vary)
+    if (parent >= pred_.size()) pred_.resize((size_t)parent * 2 + 64);
+    std::vector<PredEnt>& v = pred_[parent];
+    if (pos >= v.size()) v.resize(pos + 1);
+    // the name's bytes live in key_arena_ (fast_child interned them): find them through the table once more is not needed --
+    // fast_child left the slot it used in last_slot_
+    v[pos].id = id; v[pos].off = key_tab_[last_slot_].off; v[pos].len = len;
+  }
+  return id;
+}
+
 uint32_t Flattener::fast_child(uint32_t parent, const char* key, uint32_t len) {
   uint64_t h = 1469598103934665603ull ^ ((uint64_t)parent * 0x9E3779B97F4A7C15ull);
-  for (uint32_t i = 0; i < len; i++) { h ^= (uint8_t)key[i]; h *= 1099511628211ull; }
+  {   // eight bytes of the name per round (member names are short: one or two rounds), the tail byte by byte
+    uint32_t i = 0;
+    for (; i + 8 <= len; i += 8) { uint64_t w; memcpy(&w, key + i, 8); h = (h ^ w) * 0x9E3779B97F4A7C15ull; h ^= h >> 32; }
+    uint64_t w = 0;
+    memcpy(&w, key + i, len - i);
+    h = (h ^ w ^ ((uint64_t)len << 56)) * 1099511628211ull;
+  }
   h ^= h >> 29;
   if (key_tab_.empty()) key_tab_.resize(2048);
   size_t mask = key_tab_.size() - 1, i = (size_t)h & mask;
   while (key_tab_[i].used) {
     const KeySlot& k = key_tab_[i];
-    if (k.hash == h && k.parent == parent && k.len == len && memcmp(key_arena_.data() + k.off, key, len) == 0) return k.id;
+    if (k.hash == h && k.parent == parent && k.len == len && memcmp(key_arena_.data() + k.off, key, len) == 0) { last_slot_ = i; return k.id; }
     i = (i + 1) & mask;
   }
   const uint32_t id = dict_->child(parent, std::string(key, len));
@@ -838,6 +949,7 @@ uint32_t Flattener::fast_child(uint32_t parent, const char* key, uint32_t len) {
   k.used = true; k.hash = h; k.parent = parent; k.id = id; k.off = (uint32_t)key_arena_.size(); k.len = len;
   key_arena_.append(key, len);
   key_count_++;
+  last_slot_ = i;
   return id;
 }
 
@@ -911,6 +1023,7 @@ bool Flattener::fast_string(const char** s, uint32_t* n) {
 }
 
 void Flattener::emit_str_n(uint32_t path, uint32_t meta, const char* s, uint32_t n) {
+  if (pruning_ && !(read_state(path) & 1u) && !key_wanted(path)) return;
   if (n <= 7) {   // inline: no heap entry, no memory access on the device
     uint64_t bits = 0;
     memcpy(&bits, s, n);
@@ -925,8 +1038,7 @@ void Flattener::emit_str_n(uint32_t path, uint32_t meta, const char* s, uint32_t
   memset(&h[end - 16], 0, 16);     // zero padding: the device compares whole words
   memcpy(&h[at], &n, 4);
   memcpy(&h[at + 4], s, n);
-  emit(path, meta | T_STRING, (uint32_t)(at + 4), hash32((const uint8_t*)s, n));
-  memcpy(&stage_.back().hdr, &h[at], 16);   // entry header: length + first 12 bytes
+  if (emit(path, meta | T_STRING, (uint32_t)(at + 4), hash32((const uint8_t*)s, n))) memcpy(&stage_.back().hdr, &h[at], 16);   // entry header: length + first 12 bytes
 }
 
 // one JSON value at p_ -> rows under `path`; returns its RowType, -1 to bail out
@@ -940,7 +1052,7 @@ int Flattener::fast_value(uint32_t path, uint32_t ords, int adepth, uint32_t ext
     const char* const span0 = p_;   // (a deep dictionary expression wants the container's text: dexpr.hpp)
     p_++;
     const size_t row = stage_.size();
-    emit(path, meta | T_OBJECT, 0, 0);
+    const bool has_row = emit(path, meta | T_OBJECT, 0, 0);
     const uint32_t inst = ++obj_instance_;
     uint32_t count = 0;
     ws();
@@ -952,7 +1064,7 @@ int Flattener::fast_value(uint32_t path, uint32_t ords, int adepth, uint32_t ext
       if (p_ >= e_ || *p_ != '"') return -1;
       const char* k; uint32_t kn;
       if (!fast_string(&k, &kn)) return -1;
-      const uint32_t ch = fast_child(path, k, kn);
+      const uint32_t ch = fast_child_at(path, count, k, kn);
       if (ch >= dup_gen_.size()) dup_gen_.resize((size_t)ch * 2 + 64, 0);
       if (dup_gen_[ch] == inst) return -1;   // duplicate member name: the general path applies "last one wins"
       dup_gen_[ch] = inst;
@@ -967,7 +1079,12 @@ int Flattener::fast_value(uint32_t path, uint32_t ords, int adepth, uint32_t ext
         else if (path == cap->metadata) { if (ch == cap->name) want = &cur_facts_->name; else if (ch == cap->ns) want = &cur_facts_->ns; else if (ch == cap->gname) want = &cur_facts_->gname; }
       }
       int t;
-      if (want) {
+      // GK_TABLE_PRUNED: no pattern of any kind reaches this member or anything below it -- validated and walked past.  (metadata and
+      // its members are always visited: the match layer's facts are captured there; metadata.labels needs the TYPE of
+      // every value, which the skipper reports.)
+      if (pruning_ && !want && !(cap && ((depth == 0 && ch == cap->metadata) || (depth == 1 && path == cap->metadata))) && !(read_state(ch) & 2u)) {
+        t = skip_value(depth + 1);
+      } else if (want) {
         ws();
         if (p_ < e_ && *p_ == '"') {
           const char* v; uint32_t vn;
@@ -988,8 +1105,10 @@ int Flattener::fast_value(uint32_t path, uint32_t ords, int adepth, uint32_t ext
       if (p_ < e_ && *p_ == '}') { p_++; break; }
       return -1;
     }
-    stage_[row].row.lo = count;
-    if (count) stage_[row].row.rev &= ROW_REV_MASK;   // a NON-EMPTY container has no value id (emit saw it empty)
+    if (has_row) {
+      stage_[row].row.lo = count;
+      if (count) stage_[row].row.rev &= ROW_REV_MASK;   // a NON-EMPTY container has no value id (emit saw it empty)
+    }
     if (count && guard_wanted(path)) review_flags_ |= RF_REFUSE;
     if (dict_deep(path)) dict_row(path, meta, parse_json(span0, (size_t)(p_ - span0)));
     else if (dict_wanted(path)) { ValuePairs ph; for (uint32_t k = 0; k < count; k++) ph.emplace_back(Value::integer((i128)k), Value::null()); dict_row(path, meta, Value::object(std::move(ph))); }
@@ -999,7 +1118,7 @@ int Flattener::fast_value(uint32_t path, uint32_t ords, int adepth, uint32_t ext
     const char* const span0 = p_;
     p_++;
     const size_t row = stage_.size();
-    emit(path, meta | T_ARRAY, 0, 0);
+    const bool has_row = emit(path, meta | T_ARRAY, 0, 0);
     uint32_t count = 0;
     ws();
     if (p_ < e_ && *p_ == ']') { p_++; if (dict_wanted(path)) dict_row(path, meta, Value::array({})); return T_ARRAY; }
@@ -1013,15 +1132,18 @@ int Flattener::fast_value(uint32_t path, uint32_t ords, int adepth, uint32_t ext
         if (ord >= 255) { ord = 255; ex |= ROW_ORD_OVERFLOW; review_flags_ |= RF_TOO_BIG; }
         o2 |= ord << (ROW_E_SHIFT0 + 8 * adepth);
       } else ex |= ROW_DEEP;
-      if (fast_value(ep, o2, adepth + 1, ex, depth + 1) < 0) return -1;
+      if (pruning_ && !(read_state(ep) & 2u)) { if (skip_value(depth + 1) < 0) return -1; }
+      else if (fast_value(ep, o2, adepth + 1, ex, depth + 1) < 0) return -1;
       count++;
       ws();
       if (p_ < e_ && *p_ == ',') { p_++; continue; }
       if (p_ < e_ && *p_ == ']') { p_++; break; }
       return -1;
     }
-    stage_[row].row.lo = count;
-    if (count) stage_[row].row.rev &= ROW_REV_MASK;   // a NON-EMPTY container has no value id (emit saw it empty)
+    if (has_row) {
+      stage_[row].row.lo = count;
+      if (count) stage_[row].row.rev &= ROW_REV_MASK;   // a NON-EMPTY container has no value id (emit saw it empty)
+    }
     if (dict_deep(path)) dict_row(path, meta, parse_json(span0, (size_t)(p_ - span0)));
     else if (dict_wanted(path)) dict_row(path, meta, Value::array(ValueVec(count, Value::null())));
     return T_ARRAY;
@@ -1072,6 +1194,66 @@ int Flattener::fast_value(uint32_t path, uint32_t ords, int adepth, uint32_t ext
     emit(path, meta | T_FLOAT | (v.is_int ? ROW_INEXACT : 0), (uint32_t)u, (uint32_t)(u >> 32));
     return T_FLOAT;
   }
+}
+
+// p_ at a value nothing reads: the same syntax checks as fast_value (a malformed value must still send the review down the general
+// path, which rejects it the way the reference's decoder does), no path lookups, no rows
+int Flattener::skip_value(int depth) {
+  if (depth > 96) return -1;
+  ws();
+  if (p_ >= e_) return -1;
+  const char c = *p_;
+  if (c == '{') {
+    p_++;
+    ws();
+    if (p_ < e_ && *p_ == '}') { p_++; return T_OBJECT; }
+    for (;;) {
+      ws();
+      if (p_ >= e_ || *p_ != '"') return -1;
+      const char* k; uint32_t kn;
+      if (!fast_string(&k, &kn)) return -1;
+      ws();
+      if (p_ >= e_ || *p_ != ':') return -1;
+      p_++;
+      if (skip_value(depth + 1) < 0) return -1;
+      ws();
+      if (p_ < e_ && *p_ == ',') { p_++; continue; }
+      if (p_ < e_ && *p_ == '}') { p_++; return T_OBJECT; }
+      return -1;
+    }
+  }
+  if (c == '[') {
+    p_++;
+    ws();
+    if (p_ < e_ && *p_ == ']') { p_++; return T_ARRAY; }
+    for (;;) {
+      if (skip_value(depth + 1) < 0) return -1;
+      ws();
+      if (p_ < e_ && *p_ == ',') { p_++; continue; }
+      if (p_ < e_ && *p_ == ']') { p_++; return T_ARRAY; }
+      return -1;
+    }
+  }
+  if (c == '"') { const char* v; uint32_t vn; return fast_string(&v, &vn) ? (int)T_STRING : -1; }
+  if (c == 't') { if (e_ - p_ < 4 || memcmp(p_, "true", 4) != 0) return -1; p_ += 4; return T_BOOL; }
+  if (c == 'f') { if (e_ - p_ < 5 || memcmp(p_, "false", 5) != 0) return -1; p_ += 5; return T_BOOL; }
+  if (c == 'n') { if (e_ - p_ < 4 || memcmp(p_, "null", 4) != 0) return -1; p_ += 4; return T_NULL; }
+  const char* s0 = p_;
+  bool is_int = true;
+  if (p_ < e_ && *p_ == '-') p_++;
+  if (p_ >= e_ || !(*p_ >= '0' && *p_ <= '9')) return -1;
+  const char* digits = p_;
+  while (p_ < e_ && *p_ >= '0' && *p_ <= '9') p_++;
+  const size_t nd = p_ - digits;
+  if (p_ < e_ && *p_ == '.') { is_int = false; p_++; while (p_ < e_ && *p_ >= '0' && *p_ <= '9') p_++; }
+  if (p_ < e_ && (*p_ == 'e' || *p_ == 'E')) {
+    is_int = false; p_++;
+    if (p_ < e_ && (*p_ == '+' || *p_ == '-')) p_++;
+    while (p_ < e_ && *p_ >= '0' && *p_ <= '9') p_++;
+  }
+  if (is_int && nd <= 18) return T_INT;
+  Value v = parse_json(s0, p_ - s0);   // (the general number rules decide, as in fast_value)
+  return v.is_int && v.i >= (i128)INT64_MIN && v.i <= (i128)INT64_MAX ? (int)T_INT : (int)T_FLOAT;
 }
 
 bool Flattener::fast_tree(const char* json, size_t len, uint32_t root, ObjFacts* facts, int* type) {

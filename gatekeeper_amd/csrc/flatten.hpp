@@ -79,6 +79,8 @@ struct PatStep {
 typedef std::vector<PatStep> Pattern;
 std::string pattern_to_string(const Pattern& p);
 bool pattern_matches(const Pattern& pat, const PathDict& dict, uint32_t path_id);
+// the first steps of `pat` match the whole path (the pattern reaches this path or something below it); *full: it matches exactly
+bool pattern_reaches(const Pattern& pat, const PathDict& dict, uint32_t path_id, bool* full);
 
 // ------------------------------------------------------------------------------------------------ dictionary predicates
 // Leaf-local expressions (dexpr.hpp) registered by the loaded constraints: pattern of the leaf -> expressions, each with a
@@ -111,6 +113,14 @@ class DictRegistry {
   // The COUNTING space (round 4): the dictionary expressions the result-counting plans read live in a registry of their own and
   // travel in a row of their own, <leaf>.$c -- the 62 bits per leaf of <leaf>.$d belong to the violation formulas alone (a
   // constraint must never become unloadable because the totals of another one took its bits).
+  // The READ SET (round 4, GK_TABLE_PRUNED): the patterns of every path some loaded plan has a predicate on (engine.cpp ensure_plan)
+  // plus the paths the counting forms name.  A pruned table holds rows for these paths only and its parser walks past subtrees no
+  // pattern of any kind (reads, dictionary leaves, guards, value and key paths) reaches into.  A change of the set makes pruned
+  // tables stale (reads_gen), as a new dictionary predicate makes every table stale (gen).
+  bool set_reads(const std::vector<Pattern>& pats);   // true: the set changed
+  uint64_t reads_gen() const { return reads_gen_.load(std::memory_order_acquire); }
+  // bit 0: rows of `path_id` are read; bit 1: some pattern reaches `path_id` or below it (the parser must visit it)
+  uint32_t read_state(const PathDict& dict, uint32_t path_id) const;
   DictRegistry& counting() { std::unique_lock<std::shared_mutex> l(mu_); if (!counting_) counting_.reset(new DictRegistry()); return *counting_; }
   const DictRegistry* counting_if_any() const { std::shared_lock<std::shared_mutex> l(mu_); return counting_.get(); }
  private:
@@ -120,6 +130,9 @@ class DictRegistry {
   std::vector<std::pair<std::string, Pattern>> guards_, values_, keys_;
   std::atomic<uint64_t> gen_{0};
   std::unique_ptr<DictRegistry> counting_;
+  std::vector<std::pair<std::string, Pattern>> reads_;
+  std::atomic<uint64_t> reads_gen_{0};
+  void interest(std::vector<const Pattern*>* out) const;   // every pattern that makes the flattener do something below a path (caller holds mu_)
 };
 
 uint32_t hash32(const uint8_t* p, size_t n);
@@ -262,6 +275,7 @@ struct RawReview {
 class Flattener {
  public:
   explicit Flattener(PathDict* dict, const DictRegistry* reg = nullptr);
+  void set_pruning(bool on) { pruning_ = on && reg_ != nullptr; }
   // A Flattener may serve many tables one after the other (engine.cpp keeps one per host worker thread: its member-name
   // table, its path caches and its memo of dictionary answers then survive from batch to batch instead of being rebuilt --
   // through the engine's shared, locked structures -- by every thread for every table).  begin_table() starts a table:
@@ -291,8 +305,8 @@ class Flattener {
  private:
   PathDict* dict_;
   const DictRegistry* reg_ = nullptr;
-  uint64_t reg_gen_ = ~0ull;
-  struct DictPath { int state = 0; int gstate = 0; int vstate = 0; int kstate = 0; int pat = -1; bool deep = false /* some expression looks inside a container leaf */; std::vector<DictEntry> entries; uint32_t dpath = 0; std::unordered_map<std::string, uint64_t> memo;   // state 0 unknown, 1 none, 2 has entries
+  uint64_t reg_gen_ = ~0ull, reads_gen_seen_ = ~0ull;
+  struct DictPath { int state = 0; int gstate = 0; int vstate = 0; int kstate = 0; uint32_t rstate = 0 /* 4 | read_state once known */; int pat = -1; bool deep = false /* some expression looks inside a container leaf */; std::vector<DictEntry> entries; uint32_t dpath = 0; std::unordered_map<std::string, uint64_t> memo;   // state 0 unknown, 1 none, 2 has entries
                     int cpat = -1; std::vector<DictEntry> centries; uint32_t cpath = 0; std::unordered_map<std::string, uint64_t> cmemo; /* the counting space: <leaf>.$c */ };
   std::vector<DictPath> dict_paths_;
   void dict_row(uint32_t path, uint32_t meta, const Value& leaf);   // emits <leaf>.$d when some registered expression is true
@@ -301,6 +315,12 @@ class Flattener {
   bool guard_wanted(uint32_t path);   // is `path` a container under which element predicates iterate? (cached per path)
   bool value_wanted(uint32_t path);   // are the rows of `path` compared with other review values? (cached per path)
   bool key_wanted(uint32_t path);     // do the rows of `path` lead per-element messages? (DictRegistry::add_key)
+  // GK_TABLE_PRUNED: rows only for the registry's read set, subtrees nothing reaches into are validated and walked past
+  bool pruning_ = false;
+  uint32_t read_state(uint32_t path);   // DictRegistry::read_state, cached per path
+  bool emit_row_wanted(uint32_t path) { return !pruning_ || (read_state(path) & 1u); }
+  bool walk_always(uint32_t parent, uint32_t ch);
+  int skip_value(int depth);            // p_ at a value: validates it as fast_value would, emits nothing; its RowType or -1
   std::vector<uint32_t> key_ids_;     // value ids of the key rows of the current review
   bool dup_seen_ = false;             // ... two of them were equal (or not a scalar): review.$dup
   uint32_t id_dup_ = 0;
@@ -323,7 +343,7 @@ class Flattener {
   uint32_t child(uint32_t parent, const std::string& key);
   uint32_t elem(uint32_t parent);
   void walk(const Value& v, uint32_t path, uint32_t meta_ords, int adepth, uint32_t extra);
-  void emit(uint32_t path, uint32_t meta, uint32_t lo, uint32_t hi);
+  bool emit(uint32_t path, uint32_t meta, uint32_t lo, uint32_t hi, bool always = false);   // false: a pruned table does not hold rows of this path
   uint32_t put_string(const std::string& s, uint32_t* hash);
   void emit_str(uint32_t parent, const char* key, const std::string& s);
   void emit_string_row(uint32_t path, uint32_t meta, const std::string& s);
@@ -336,7 +356,13 @@ class Flattener {
   struct KeySlot { uint64_t hash = 0; uint32_t parent = 0, id = 0, off = 0, len = 0; bool used = false; };
   std::vector<KeySlot> key_tab_;      // open addressing: (parent path, member name) -> child path
   std::string key_arena_;
-  size_t key_count_ = 0;
+  size_t key_count_ = 0, last_slot_ = 0;
+  // PREDICTED children (round 4): objects of one kind list their members in one order, so the i-th member of the object at path P
+  // is, nearly always, the member that was i-th there last time -- one length compare + memcmp instead of hashing the name.
+  // pred_[P] = what the members of the most recent object at P were, by position (id kNone: nothing predicted yet)
+  struct PredEnt { uint32_t id = 0xFFFFFFFFu, off = 0, len = 0; };
+  std::vector<std::vector<PredEnt>> pred_;
+  uint32_t fast_child_at(uint32_t parent, uint32_t pos, const char* key, uint32_t len);
   std::vector<uint32_t> ctr_gen_, ctr_val_;   // per element path: review generation / running ordinal
   std::vector<uint32_t> ctr_touched_;
   std::vector<uint32_t> dup_gen_;             // per path: id of the object instance that last produced it (duplicate keys)
@@ -354,7 +380,7 @@ class Flattener {
   bool fast_tree(const char* json, size_t len, uint32_t root, ObjFacts* facts, int* type);
   void emit_str_n(uint32_t path, uint32_t meta, const char* s, uint32_t n);
   void fast_match_facts(const ObjFacts& f, const Value& ns, bool is_old);
-  void ws() { while (p_ < e_ && (*p_ == ' ' || *p_ == '\n' || *p_ == '\t' || *p_ == '\r')) p_++; }
+  void ws() { if (p_ < e_ && (unsigned char)*p_ > ' ') return; while (p_ < e_ && (*p_ == ' ' || *p_ == '\n' || *p_ == '\t' || *p_ == '\r')) p_++; }
 };
 
 }  // namespace gk

@@ -533,12 +533,13 @@ class Engine:
         self.lib.gk_spool_info_free(info)
         return Table(self, h, statuses, n), d
 
-    def create_table_native(self, reviews_ptr, n, keep_docs=False, resident=False, process=None, keep_text=False):
+    def create_table_native(self, reviews_ptr, n, keep_docs=False, resident=False, process=None, keep_text=False, pruned=False):
         """gk_table_create on an existing gk_review_in array (e.g. synth.NativeBatch.reviews).  keep_text: the table remembers
         where the JSON text lives (the batch must outlive it) and parses only the reviews it has to render (totals, messages)"""
         st = (C.c_int32 * max(1, n))()
         h = C.c_void_p()
-        flags = (L.GK_TABLE_KEEP_DOCS if keep_docs else 0) | (L.GK_TABLE_RESIDENT if resident else 0) | self._process_flag(process) | (L.GK_TABLE_KEEP_TEXT if keep_text else 0)
+        flags = ((L.GK_TABLE_KEEP_DOCS if keep_docs else 0) | (L.GK_TABLE_RESIDENT if resident else 0) | self._process_flag(process) | (L.GK_TABLE_KEEP_TEXT if keep_text else 0)
+                 | (L.GK_TABLE_PRUNED if pruned else 0))   # pruned: rows of the key paths the loaded constraints read, nothing else (include/gkgpu.h)
         self._check(self.lib.gk_table_create(self.handle, reviews_ptr, n, flags, st, C.byref(h)))
         return Table(self, h, st, n)
 

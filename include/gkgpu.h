@@ -117,6 +117,11 @@ int gk_table_get_stats(const gk_table* t, gk_table_stats* out);
 #define GK_TABLE_KEEP_TEXT 16u  /* remember WHERE the reviews' JSON text lives (the gk_review_in array is copied, the text is NOT: the
                                    caller keeps it alive as long as the table) so that gk_table_totals / gk_render / gk_render_error
                                    can parse the few reviews they need on demand -- no parsed copy of a million objects */
+#define GK_TABLE_PRUNED 32u     /* the table serves the policy set loaded NOW: it holds rows only for the key paths some loaded constraint
+                                   reads, and the ingest walks past sub-documents nothing reads (syntax still checked).  A constraint that
+                                   arrives later and reads another path makes it stale: gk_table_eval / gk_table_sweep_sharded / gk_table_totals
+                                   then fail with GK_ERR_INVALID ("create it again"), as after a new dictionary predicate.  What pkg/audit's
+                                   per-sweep list and the webhook's per-request decode amount to: the objects are read again anyway */
 #define GK_TABLE_RESIDENT 2u    /* the table is evaluated again and again (audit set): the engine may compile a plan variant
                                    whose LDS layout fits this table's array sizes (first evaluation pays the compile) */
 
