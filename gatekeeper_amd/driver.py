@@ -608,6 +608,8 @@ class Driver:
     """drivers.Driver backed by the MI355X engine."""
 
     RUN_TIME_NS = "templateRunTimeNS"
+    BATCH_SIZE = "batchSize"
+    QUEUE_NS = "queueNS"
 
     def __init__(self, device=0, gather_stats=False, hostemu=None, elem_cap=None):
         self.engine = Engine(device, elem_cap=elem_cap, hostemu=hostemu)
@@ -685,9 +687,11 @@ class Driver:
         self.last_query_stats = {"batch_size": st.batch_size, "queue_us": st.queue_us, "device_us": st.device_us, "total_us": st.total_us}
         stats = []
         if self.gather_stats or stats_enabled:
-            stats.append({"scope": "template", "statsFor": "batch", "stats": [
-                {"name": self.RUN_TIME_NS, "value": int(st.device_us * 1e3),
-                 "source": {"type": "engine", "value": self.Name()}}], "labels": [{"name": "target", "value": target}]})
+            src = {"type": "engine", "value": self.Name()}
+            stats.append({"scope": "template", "statsFor": "gkgpu", "stats": [
+                {"name": self.RUN_TIME_NS, "value": int(st.device_us * 1e3), "source": src},
+                {"name": self.BATCH_SIZE, "value": int(st.batch_size), "source": src},
+                {"name": self.QUEUE_NS, "value": int(st.queue_us * 1e3), "source": src}], "labels": [{"name": "target", "value": target}]})
         return QueryResponse(results, stats)
 
     def ResidentSweep(self, result_totals=False):
@@ -728,8 +732,12 @@ class Driver:
         return self.engine.dump()
 
     def GetDescriptionForStat(self, stat_name):
-        if stat_name == self.RUN_TIME_NS:
-            return "the number of nanoseconds the device kernels took to evaluate all constraints for a batch of reviews"
+        """drivers.Driver.GetDescriptionForStat (pkg/drivers/k8scel/driver.go:257-264): the stats of QueryResponse.stats_entries"""
+        desc = {self.RUN_TIME_NS: "the number of nanoseconds the device kernels took to evaluate all constraints for the review's batch",
+                self.BATCH_SIZE: "the number of reviews that shared the device launch",
+                self.QUEUE_NS: "the number of nanoseconds the review waited for its batch to close"}
+        if stat_name in desc:
+            return desc[stat_name]
         raise ClientError("unknown stat name for Rego: %s" % stat_name)
 
 

@@ -78,3 +78,44 @@ def test_native_query_storm_counts_match_the_oracle(backend, fixtures, requests)
     assert out["calls"] == n and out["errors"] == 0
     assert out["results"] == want and want > 50
     assert out["mean_batch"] > 1.5 and out["p50_us"] > 0 and out["p99_us"] >= out["p50_us"]
+
+
+def test_query_stats_entries_and_their_descriptions(fixtures):
+    """drivers.QueryResponse.StatsEntries + Driver.GetDescriptionForStat (pkg/drivers/k8scel/driver.go:231-247,257-264): one device
+    launch answers every constraint of the review's batch, so the engine reports per-review figures (gk_query_stats) at template scope;
+    every stat it names has a description, an unknown name is an error -- and the removal half of drivers.Driver (RemoveConstraint,
+    RemoveTemplate, RemoveData) leaves an engine that answers like a fresh one"""
+    c, oc = load_both("hostemu", synth.psp_templates(fixtures), synth.psp_constraints())
+    nss = synth.gen_namespaces()
+    pod = next(o for o in synth.gen_objects(50, seed=9) if o["spec"].get("hostNetwork") or any((x.get("securityContext") or {}).get("privileged") for x in o["spec"]["containers"]))
+    rv = D.AugmentedUnstructured(D.Unstructured(pod), synth.namespace_for(pod, nss), "Original")
+    cons = list(c.constraints.values())
+    resp = c.driver.Query(D.TARGET_NAME, cons, rv, stats_enabled=True)
+    assert len(resp.results) > 0 and len(resp.stats_entries) == 1 and not c.driver.Query(D.TARGET_NAME, cons, rv).stats_entries
+    entry = resp.stats_entries[0]
+    names = [s["name"] for s in entry["stats"]]
+    assert entry["scope"] == "template" and names == [D.Driver.RUN_TIME_NS, D.Driver.BATCH_SIZE, D.Driver.QUEUE_NS]
+    assert all(isinstance(s["value"], int) and s["value"] >= 0 and s["source"] == {"type": "engine", "value": "Rego"} for s in entry["stats"])
+    assert entry["stats"][1]["value"] >= 1
+    for n in names:
+        assert c.driver.GetDescriptionForStat(n)
+    with pytest.raises(D.ClientError, match="unknown stat name"):
+        c.driver.GetDescriptionForStat("nope")
+    # removal: one constraint, then a whole template (its constraints go with it), then a synced Namespace
+    before = sorted(key(r) for r in c.Review(rv, D.WEBHOOK_EP))
+    gone = cons[0]
+    c.RemoveConstraint(gone)
+    oc.remove_constraint(gone)
+    want = sorted(key(r) for r in oc.review(OT.AugmentedUnstructured(OT.Unstructured(pod), synth.namespace_for(pod, nss), "Original"), OC.WEBHOOK_EP))
+    assert sorted(key(r) for r in c.Review(rv, D.WEBHOOK_EP)) == want
+    tmpl = next(t for t in synth.psp_templates(fixtures) if t["spec"]["crd"]["spec"]["names"]["kind"] == "K8sPSPPrivilegedContainer")
+    c.RemoveTemplate(tmpl)
+    oc.remove_template(tmpl)
+    want = sorted(key(r) for r in oc.review(OT.AugmentedUnstructured(OT.Unstructured(pod), synth.namespace_for(pod, nss), "Original"), OC.WEBHOOK_EP))
+    got = sorted(key(r) for r in c.Review(rv, D.WEBHOOK_EP))
+    assert got == want and len(got) <= len(before)
+    ns = nss[pod["metadata"]["namespace"]]
+    c.AddData(ns)
+    c.RemoveData(ns)
+    assert sorted(key(r) for r in c.Review(rv, D.WEBHOOK_EP)) == want
+    assert "constraints=" in c.driver.Dump()
