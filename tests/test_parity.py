@@ -802,11 +802,13 @@ def test_policy_corpus_200_templates(backend, fixtures):
     + 200 constraints with regex allow-lists and `namespaces: ["prod-*", "*-system"]` globs, over the mixed object stream."""
     templates, cons = synth.corpus()
     assert len(templates) == 200 and len({t["spec"]["crd"]["spec"]["names"]["kind"] for t in templates}) == 200
+    if backend == "hostemu-gen":   # (the second CPU backend -- the generated plan source through g++ -- takes every other copy: the CPU suite's budget;
+        templates, cons = templates[::2], cons[::2]   #  hostemu and both device backends load all 200)
     c, oc = load_both(backend, templates, cons)
     nss = synth.gen_namespaces()
     objs = synth.gen_objects(64, seed=11, mixed=True)     # (the oracle's tree-walker pays ~1 ms per pair: 12 800 of them here; tests/test_cpu_ref.py
     rv = [D.AugmentedUnstructured(D.Unstructured(o), synth.namespace_for(o, nss), "Original") for o in objs]   #  takes the corpus to thousands of objects against the compiled loop)
-    assert assert_parity(c, oc, rv) > 450
+    assert assert_parity(c, oc, rv) > (200 if backend == "hostemu-gen" else 450)
 
 
 @pytest.mark.parametrize("backend", BACKENDS)

@@ -15,7 +15,7 @@ from parity_util import BACKENDS, make_client
 
 
 def _load(c, fixtures, corpus=False):
-    templates, constraints = synth.corpus(fixtures, 40) if corpus else (synth.psp_templates(fixtures), synth.audit_constraints())
+    templates, constraints = synth.corpus(fixtures, 24) if corpus else (synth.psp_templates(fixtures), synth.audit_constraints())
     for t in templates:
         c.AddTemplate(t)
     for k in constraints:
@@ -23,7 +23,7 @@ def _load(c, fixtures, corpus=False):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
-@pytest.mark.parametrize("corpus", [False, True], ids=["audit-50", "corpus-40"])
+@pytest.mark.parametrize("corpus", [False, True], ids=["audit-50", "corpus-24"])
 def test_pruned_table_answers_like_the_full_one(backend, fixtures, corpus):
     c = make_client(backend)
     _load(c, fixtures, corpus)
