@@ -62,8 +62,21 @@ FP f_exists_k(int q, const SPath& base, FP body, int k) {
   return mkf(std::move(n));
 }
 FP f_exists_like(const FNode& proto, FP body) { return proto.two ? f_exists_k(proto.q, proto.base, body, proto.atleast) : f_exists(proto.q, proto.base, body); }
-FP f_all(const std::vector<FP>& v) { FP r = f_true(); for (auto& x : v) r = f_and(r, x); return r; }
-FP f_any(const std::vector<FP>& v) { FP r = f_false(); for (auto& x : v) r = f_or(r, x); return r; }
+// (one node for the whole list: folding with f_and / f_or copies the growing child vector once per element)
+static FP f_fold(const std::vector<FP>& v, FNode::Kind kind) {
+  const FNode::Kind zero = kind == FNode::AND ? FNode::F : FNode::T, unit = kind == FNode::AND ? FNode::T : FNode::F;
+  FNode n; n.kind = kind;
+  for (auto& x : v) {
+    if (x->kind == zero) return kind == FNode::AND ? f_false() : f_true();
+    if (x->kind == unit) continue;
+    if (x->kind == kind) n.kids.insert(n.kids.end(), x->kids.begin(), x->kids.end()); else n.kids.push_back(x);
+  }
+  if (n.kids.empty()) return kind == FNode::AND ? f_true() : f_false();
+  if (n.kids.size() == 1) return n.kids[0];
+  return mkf(std::move(n));
+}
+FP f_all(const std::vector<FP>& v) { return f_fold(v, FNode::AND); }
+FP f_any(const std::vector<FP>& v) { return f_fold(v, FNode::OR); }
 
 std::string spath_to_string(const SPath& p) {
   std::string o = "review";
@@ -71,7 +84,7 @@ std::string spath_to_string(const SPath& p) {
   return o;
 }
 static std::string f_compose_text(const FP& f);
-std::string f_to_string(const FP& f) {
+const std::string& f_to_string(const FP& f) {
   if (!f->canon_set) { f->canon = f_compose_text(f); f->canon_set = true; }
   return f->canon;
 }
@@ -856,9 +869,36 @@ class PE {
     return r;
   }
 
+  // `dict(leaf: X == k)` with a constant k: the pieces (X by its canonical text)
+  static bool dict_eq_const(const FP& c, const Atom** at, const DExpr** lhs, const Value** k) {
+    if (c->kind != FNode::ATOM || c->atom.kind != Atom::DICT || !c->atom.dx) return false;
+    const DExpr& d = *c->atom.dx;
+    if (d.kind != DExpr::CMP || d.cmp != C_EQ || d.args.size() != 2) return false;
+    const int ci = d.args[1]->kind == DExpr::CONST ? 1 : d.args[0]->kind == DExpr::CONST ? 0 : -1;
+    if (ci < 0 || d.args[1 - ci]->kind == DExpr::CONST) return false;
+    *at = &c->atom; *lhs = d.args[1 - ci].get(); *k = &d.args[ci]->c;
+    return true;
+  }
   void push_cond(State s, FP c, States& out) {
     if (c->kind == FNode::F) return;
-    if (c->kind != FNode::T) s.conds.push_back(c);
+    if (c->kind != FNode::T) {
+      // A state that already holds X == k1 cannot also hold X == k2: the alternatives of a helper with constant heads applied
+      // twice to the same value (K8sContainerLimits' mem_multiple(suffix): 14 x 14 states, 14 of them feasible) stop here
+      // instead of travelling through every later stage as formulas that are false by construction.
+      const Atom* at; const DExpr* lhs; const Value* k;
+      if (dict_eq_const(c, &at, &lhs, &k)) {
+        std::string leaf;
+        for (const FP& o : s.conds) {
+          const Atom* at2; const DExpr* lhs2; const Value* k2;
+          if (!dict_eq_const(o, &at2, &lhs2, &k2) || lhs2->text != lhs->text) continue;
+          if (leaf.empty()) leaf = spath_to_string(at->path);
+          if (spath_to_string(at2->path) != leaf) continue;
+          if (compare(*k, *k2) != 0) return;                     // contradiction
+          out.push_back(std::move(s)); return;                    // the same condition again
+        }
+      }
+      s.conds.push_back(c);
+    }
     out.push_back(std::move(s));
   }
 

@@ -77,7 +77,7 @@ FP f_exists_k(int q, const SPath& base, FP body, int k);      // at least k (>= 
 FP f_exists_like(const FNode& proto, FP body);                // EXISTS / E2 with `proto`'s quantifier, base and flag
 FP f_all(const std::vector<FP>& v);
 FP f_any(const std::vector<FP>& v);
-std::string f_to_string(const FP& f);
+const std::string& f_to_string(const FP& f);   // (the node's cached canonical text)
 std::string spath_to_string(const SPath& p);
 
 // ------------------------------------------------------------------------------------------------ symbolic values
