@@ -1,5 +1,6 @@
 // See flatten.hpp.
 #include "flatten.hpp"
+#include <immintrin.h>
 
 #include <sched.h>
 #include <cstdio>
@@ -478,7 +479,10 @@ Flattener::Flattener(PathDict* dict, const DictRegistry* reg) : dict_(dict), reg
 }
 
 void Flattener::begin_table() {
+  use_index_ = ix_supported() && !getenv("GK_NO_INDEX");
   ns_cache_.clear();
+  ns_memo_.clear();
+  ns_memo_name_.clear();
   stage_.clear();
   order_.clear();
   if (reg_) {
@@ -611,6 +615,7 @@ bool Flattener::emit(uint32_t path, uint32_t meta, uint32_t lo, uint32_t hi, boo
     // a pruned table holds no row of this path -- what the flattener itself derives from the value still happens: a message key
     // is still compared with the review's other keys (review.$dup)
     if (key_wanted(path)) {
+      emit_side_effects_ = true;
       const uint32_t id = value_id(meta, lo, hi);
       if (id == 0u || id == GK_VID_OVERFLOW || std::find(key_ids_.begin(), key_ids_.end(), id) != key_ids_.end()) dup_seen_ = true;
       else key_ids_.push_back(id);
@@ -618,8 +623,9 @@ bool Flattener::emit(uint32_t path, uint32_t meta, uint32_t lo, uint32_t hi, boo
     return false;
   }
   uint32_t rev = t_->n_reviews % t_->rpt;
-  if (value_wanted(path)) rev |= value_id(meta, lo, hi) << ROW_VID_SHIFT;
+  if (value_wanted(path)) { rev |= value_id(meta, lo, hi) << ROW_VID_SHIFT; emit_side_effects_ = true; }
   if (key_wanted(path)) {   // a message key: equal values within the review (or one without an id) -> review.$dup (finish_review)
+    emit_side_effects_ = true;
     const uint32_t id = value_id(meta, lo, hi);
     if (id == 0u || id == GK_VID_OVERFLOW || std::find(key_ids_.begin(), key_ids_.end(), id) != key_ids_.end()) dup_seen_ = true;
     else key_ids_.push_back(id);
@@ -798,6 +804,30 @@ void Flattener::add_skipped(HostTable* out) {
 
 // $ns rows (only what the match layer reads from Matchable.Namespace: name + labels), source flags, bookkeeping
 void Flattener::finish_review(const Value& ns, int source, HostTable* out) {
+  ns_rows(ns);
+  finish_tail(source, out);
+}
+void Flattener::finish_review_memo(NsMemo* m, int source, HostTable* out) {
+  if (m->rows_state == 1 && m->owner == out) {
+    const uint32_t cur = out->n_reviews % out->rpt;
+    for (const Staged& s : m->rows) { stage_.push_back(s); stage_.back().row.rev = cur; }
+    review_flags_ |= m->flags;
+  } else if (m->rows_state == 2) ns_rows(m->ns);
+  else {   // record: the rows depend on the Namespace alone unless an emit interned a value id / compared a key or an array was counted
+    const size_t s0 = stage_.size(), c0 = ctrs_.size(), t0 = ctr_touched_.size();
+    const uint32_t f0 = review_flags_;
+    review_flags_ = 0;
+    emit_side_effects_ = false;
+    ns_rows(m->ns);
+    bool ok = !emit_side_effects_ && ctrs_.size() == c0 && ctr_touched_.size() == t0;
+    for (size_t i = s0; i < stage_.size() && ok; i++) if (stage_[i].row.rev & ~ROW_REV_MASK) ok = false;
+    if (ok) { m->rows.assign(stage_.begin() + s0, stage_.end()); m->flags = review_flags_; m->owner = out; m->rows_state = 1; }
+    else m->rows_state = 2;
+    review_flags_ |= f0;
+  }
+  finish_tail(source, out);
+}
+void Flattener::ns_rows(const Value& ns) {
   if (ns.defined()) {
     review_flags_ |= RF_NS_PRESENT;
     emit(id_ns_, T_OBJECT, 1, 0);
@@ -813,6 +843,8 @@ void Flattener::finish_review(const Value& ns, int source, HostTable* out) {
       walk(*lb, child(md, "labels"), 0, 0, 0);
     } else if (lb) review_flags_ |= RF_NS_LABELS_BAD;
   }
+}
+void Flattener::finish_tail(int source, HostTable* out) {
   switch (source) {
     case SRC_ORIGINAL: review_flags_ |= RF_SRC_ORIGINAL; break;
     case SRC_GENERATED: review_flags_ |= RF_SRC_GENERATED; break;
@@ -1256,10 +1288,300 @@ int Flattener::skip_value(int depth) {
   return v.is_int && v.i >= (i128)INT64_MIN && v.i <= (i128)INT64_MAX ? (int)T_INT : (int)T_FLOAT;
 }
 
+// ------------------------------------------------------------------------------------------------ structural index
+// Stage 1.  Per 64-byte block: B = backslashes, Q = quotes not escaped by an odd run of backslashes (the carry of a run crossing the
+// block edge travels in `prev_escaped`), S = prefix-xor of Q (carry-less multiply by all-ones) = opening quote .. the byte before
+// the closing quote, OP = { } [ ] : , outside strings, SC = any other byte that is neither white space nor a quote outside strings;
+// tokens = OP | Q | first byte of every run of SC.
+bool Flattener::ix_supported() {
+  static const bool ok = __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("pclmul") && __builtin_cpu_supports("bmi2");
+  return ok;
+}
+__attribute__((target("avx512f,avx512bw,pclmul,bmi,bmi2,lzcnt,popcnt")))
+static uint32_t ix_stage1(const char* s, uint32_t len, uint32_t* out, uint64_t* bs_out, bool* any_bs) {
+  uint64_t prev_in_string = 0, prev_escaped = 0, prev_scalar = 0, bs_or = 0;
+  uint32_t n = 0;
+  const __m512i c_bs = _mm512_set1_epi8('\\'), c_q = _mm512_set1_epi8('"'), c_20 = _mm512_set1_epi8(0x20), c_ob = _mm512_set1_epi8('{'), c_cb = _mm512_set1_epi8('}'),
+                c_col = _mm512_set1_epi8(':'), c_com = _mm512_set1_epi8(','), c_nl = _mm512_set1_epi8('\n'), c_tab = _mm512_set1_epi8('\t'), c_cr = _mm512_set1_epi8('\r');
+  for (uint32_t base = 0; base < len; base += 64) {
+    const uint32_t rem = len - base;
+    const uint64_t valid = rem >= 64 ? ~0ull : (~0ull >> (64 - rem));
+    const __m512i v = rem >= 64 ? _mm512_loadu_si512((const void*)(s + base)) : _mm512_maskz_loadu_epi8((__mmask64)valid, (const void*)(s + base));
+    uint64_t bs = _mm512_cmpeq_epi8_mask(v, c_bs);
+    uint64_t quote = _mm512_cmpeq_epi8_mask(v, c_q);
+    bs_out[base >> 6] = bs;
+    bs_or |= bs;
+    if (bs | prev_escaped) {   // bytes escaped by a backslash: the byte after every ODD-length run's last backslash
+      bs &= ~prev_escaped;
+      const uint64_t follows = (bs << 1) | prev_escaped;
+      const uint64_t even = 0x5555555555555555ull;
+      const uint64_t odd_starts = bs & ~even & ~follows;
+      uint64_t on_even;
+      prev_escaped = __builtin_add_overflow(odd_starts, bs, &on_even) ? 1 : 0;
+      const uint64_t escaped = (even ^ (on_even << 1)) & follows;
+      quote &= ~escaped;
+    }
+    const uint64_t in_string = (uint64_t)_mm_cvtsi128_si64(_mm_clmulepi64_si128(_mm_set_epi64x(0, (long long)quote), _mm_set1_epi8((char)0xFF), 0)) ^ prev_in_string;
+    prev_in_string = (uint64_t)((int64_t)in_string >> 63);
+    const __m512i lower = _mm512_or_si512(v, c_20);   // '[' | 0x20 = '{', ']' | 0x20 = '}'
+    const uint64_t op = _mm512_cmpeq_epi8_mask(lower, c_ob) | _mm512_cmpeq_epi8_mask(lower, c_cb) | _mm512_cmpeq_epi8_mask(v, c_col) | _mm512_cmpeq_epi8_mask(v, c_com);
+    const uint64_t wsm = _mm512_cmpeq_epi8_mask(v, c_20) | _mm512_cmpeq_epi8_mask(v, c_nl) | _mm512_cmpeq_epi8_mask(v, c_tab) | _mm512_cmpeq_epi8_mask(v, c_cr);
+    const uint64_t scalar = ~(op | wsm | quote) & ~in_string & valid;
+    const uint64_t scalar_start = scalar & ~((scalar << 1) | prev_scalar);
+    prev_scalar = scalar >> 63;
+    uint64_t bits = ((op & ~in_string) | quote | scalar_start) & valid;
+    while (bits) { out[n++] = base + (uint32_t)_tzcnt_u64(bits); bits = _blsr_u64(bits); }
+  }
+  *any_bs = bs_or != 0;
+  return n;
+}
+void Flattener::ix_build(const char* json, size_t len) {
+  if (ix_.size() < len + 2) ix_.resize(len + 2 + len / 2);
+  if (ix_bs_.size() < len / 64 + 2) ix_bs_.resize(len / 64 + 2 + len / 128);
+  ix_json_ = json; ix_len_ = (uint32_t)len;
+  ix_n_ = ix_stage1(json, (uint32_t)len, ix_.data(), ix_bs_.data(), &ix_any_bs_);
+  ix_[ix_n_] = (uint32_t)len;   // sentinel: where the last token's text ends at the latest
+  ixp_ = 0;
+  p_ = json; e_ = json + len;   // (strings with escapes are decoded by fast_string)
+}
+bool Flattener::ix_has_bs(uint32_t a, uint32_t b) const {
+  if (!ix_any_bs_ || a >= b) return false;
+  const uint32_t wa = a >> 6, wb = (b - 1) >> 6;
+  const uint64_t ma = ~0ull << (a & 63), mb = ~0ull >> (63 - ((b - 1) & 63));
+  if (wa == wb) return (ix_bs_[wa] & ma & mb) != 0;
+  if (ix_bs_[wa] & ma) return true;
+  for (uint32_t w = wa + 1; w < wb; w++) if (ix_bs_[w]) return true;
+  return (ix_bs_[wb] & mb) != 0;
+}
+// token ixp_ is a quote that opens a string (the caller looked): the next token is the quote that closes it, or the text ends inside
+bool Flattener::ix_string(const char** s, uint32_t* n) {
+  if (ixp_ + 1 >= ix_n_) return false;
+  const uint32_t a = ix_[ixp_] + 1, b = ix_[ixp_ + 1];
+  if (ix_has_bs(a, b)) {
+    p_ = ix_json_ + a - 1;
+    if (!fast_string(s, n) || p_ != ix_json_ + b + 1) return false;
+  } else { *s = ix_json_ + a; *n = b - a; }
+  ixp_ += 2;
+  return true;
+}
+bool Flattener::ix_skip_string() {
+  if (ixp_ + 1 >= ix_n_) return false;
+  const uint32_t a = ix_[ixp_] + 1, b = ix_[ixp_ + 1];
+  if (ix_has_bs(a, b)) { const char* s; uint32_t n; p_ = ix_json_ + a - 1; if (!fast_string(&s, &n) || p_ != ix_json_ + b + 1) return false; }   // (the escapes must be valid ones)
+  ixp_ += 2;
+  return true;
+}
+// token ixp_ starts a scalar that is not a string.  Its text runs to the next token at most, and what follows it up to there is
+// white space by construction (any other byte would have started a token) -- so "the grammar consumed the whole run" is one look
+// at the byte after.
+int Flattener::ix_scalar(bool rows, uint32_t path, uint32_t meta) {
+  const char* s = ix_json_ + ix_[ixp_];
+  const char* lim = ix_json_ + ix_[ixp_ + 1];
+  auto ends = [&](const char* q) { return q == lim || *q == ' ' || *q == '\n' || *q == '\t' || *q == '\r'; };
+  const char c = *s;
+  if (c == 't') { if (lim - s < 4 || memcmp(s, "true", 4) != 0 || !ends(s + 4)) return -1; ixp_++; if (rows) { emit(path, meta | T_BOOL, 1, 0); if (dict_wanted(path)) dict_row(path, meta, Value::boolean(true)); } return T_BOOL; }
+  if (c == 'f') { if (lim - s < 5 || memcmp(s, "false", 5) != 0 || !ends(s + 5)) return -1; ixp_++; if (rows) { emit(path, meta | T_BOOL, 0, 0); if (dict_wanted(path)) dict_row(path, meta, Value::boolean(false)); } return T_BOOL; }
+  if (c == 'n') { if (lim - s < 4 || memcmp(s, "null", 4) != 0 || !ends(s + 4)) return -1; ixp_++; if (rows) { emit(path, meta | T_NULL, 0, 0); if (dict_wanted(path)) dict_row(path, meta, Value::null()); } return T_NULL; }
+  const char* q = s;
+  bool is_int = true, neg = false;
+  if (q < lim && *q == '-') { neg = true; q++; }
+  if (q >= lim || !(*q >= '0' && *q <= '9')) return -1;
+  const char* digits = q;
+  while (q < lim && *q >= '0' && *q <= '9') q++;
+  const size_t nd = q - digits;
+  if (q < lim && *q == '.') { is_int = false; q++; while (q < lim && *q >= '0' && *q <= '9') q++; }
+  if (q < lim && (*q == 'e' || *q == 'E')) {
+    is_int = false; q++;
+    if (q < lim && (*q == '+' || *q == '-')) q++;
+    while (q < lim && *q >= '0' && *q <= '9') q++;
+  }
+  if (!ends(q)) return -1;
+  ixp_++;
+  if (is_int && nd <= 18) {
+    if (rows) {
+      int64_t x = 0;
+      for (size_t k = 0; k < nd; k++) x = x * 10 + (digits[k] - '0');
+      if (neg) x = -x;
+      emit(path, meta | T_INT, (uint32_t)(uint64_t)x, (uint32_t)((uint64_t)x >> 32));
+      if (dict_wanted(path)) dict_row(path, meta, Value::integer((i128)x));
+    }
+    return T_INT;
+  }
+  Value v = parse_json(s, q - s);   // the general number rules, through the same Value code the tree walk uses
+  const bool as_int = v.is_int && v.i >= (i128)INT64_MIN && v.i <= (i128)INT64_MAX;
+  if (rows) {
+    if (dict_wanted(path)) dict_row(path, meta, v);
+    if (as_int) { const uint64_t u = (uint64_t)(int64_t)v.i; emit(path, meta | T_INT, (uint32_t)u, (uint32_t)(u >> 32)); }
+    else { const double d = v.as_double(); uint64_t u; memcpy(&u, &d, 8); emit(path, meta | T_FLOAT | (v.is_int ? ROW_INEXACT : 0), (uint32_t)u, (uint32_t)(u >> 32)); }
+  }
+  return as_int ? (int)T_INT : (int)T_FLOAT;
+}
+
+// fast_value over tokens: the same rows, facts, flags and bail-outs, member for member
+int Flattener::ix_value(uint32_t path, uint32_t ords, int adepth, uint32_t extra, int depth) {
+  if (depth > 96 || ixp_ >= ix_n_) return -1;
+  const uint32_t meta = ords | extra;
+  const uint32_t at = ix_[ixp_];
+  const char* const js = ix_json_;
+  const char c = js[at];
+  if (c == '{') {
+    ixp_++;
+    const size_t row = stage_.size();
+    const bool has_row = emit(path, meta | T_OBJECT, 0, 0);
+    const uint32_t inst = ++obj_instance_;
+    uint32_t count = 0;
+    if (ixp_ < ix_n_ && js[ix_[ixp_]] == '}') { ixp_++; if (dict_wanted(path)) dict_row(path, meta, Value::object({})); return T_OBJECT; }
+    const CapIds* cap = nullptr;
+    if (cur_facts_ && depth <= 1) cap = &cap_[cur_root_ == id_old_ ? 1 : 0];
+    for (;;) {
+      if (ixp_ >= ix_n_ || js[ix_[ixp_]] != '"') return -1;
+      const char* k; uint32_t kn;
+      if (!ix_string(&k, &kn)) return -1;
+      const uint32_t ch = fast_child_at(path, count, k, kn);
+      if (ch >= dup_gen_.size()) dup_gen_.resize((size_t)ch * 2 + 64, 0);
+      if (dup_gen_[ch] == inst) return -1;   // duplicate member name: the general path applies "last one wins"
+      dup_gen_[ch] = inst;
+      if (ixp_ >= ix_n_ || js[ix_[ixp_]] != ':') return -1;
+      ixp_++;
+      if (ixp_ >= ix_n_) return -1;
+      Captured* want = nullptr;
+      if (cap) {
+        if (depth == 0) { if (ch == cap->api_version) want = &cur_facts_->api_version; else if (ch == cap->kind) want = &cur_facts_->kind; }
+        else if (path == cap->metadata) { if (ch == cap->name) want = &cur_facts_->name; else if (ch == cap->ns) want = &cur_facts_->ns; else if (ch == cap->gname) want = &cur_facts_->gname; }
+      }
+      int t;
+      if (pruning_ && !want && !(cap && ((depth == 0 && ch == cap->metadata) || (depth == 1 && path == cap->metadata))) && !(read_state(ch) & 2u)) {
+        t = ix_skip(depth + 1);
+      } else if (want && js[ix_[ixp_]] == '"') {
+        const char* v; uint32_t vn;
+        if (!ix_string(&v, &vn)) return -1;
+        emit_str_n(ch, meta, v, vn);
+        if (dict_wanted(ch)) dict_row(ch, meta, Value::string(std::string(v, vn)));
+        if (v == scratch_.data()) { scratch_keep_.emplace_back(new std::string(v, vn)); v = scratch_keep_.back()->data(); }
+        want->p = v; want->n = vn; want->set = true;
+        t = T_STRING;
+      } else t = ix_value(ch, ords, adepth, extra, depth + 1);
+      if (t < 0) return -1;
+      if (cap && depth == 1 && path == cap->metadata && ch == cap->labels && t != T_OBJECT) cur_facts_->labels_bad = true;
+      if (cur_facts_ && depth == 2 && path == cap_[cur_root_ == id_old_ ? 1 : 0].labels && t != T_STRING) cur_facts_->labels_bad = true;
+      count++;
+      if (ixp_ >= ix_n_) return -1;
+      const char d = js[ix_[ixp_]];
+      if (d == ',') { ixp_++; continue; }
+      if (d == '}') { ixp_++; break; }
+      return -1;
+    }
+    if (has_row) {
+      stage_[row].row.lo = count;
+      if (count) stage_[row].row.rev &= ROW_REV_MASK;   // a NON-EMPTY container has no value id (emit saw it empty)
+    }
+    if (count && guard_wanted(path)) review_flags_ |= RF_REFUSE;
+    if (dict_deep(path)) dict_row(path, meta, parse_json(js + at, (size_t)(ix_[ixp_ - 1] + 1 - at)));
+    else if (dict_wanted(path)) { ValuePairs ph; for (uint32_t k = 0; k < count; k++) ph.emplace_back(Value::integer((i128)k), Value::null()); dict_row(path, meta, Value::object(std::move(ph))); }
+    return T_OBJECT;
+  }
+  if (c == '[') {
+    ixp_++;
+    const size_t row = stage_.size();
+    const bool has_row = emit(path, meta | T_ARRAY, 0, 0);
+    uint32_t count = 0;
+    if (ixp_ < ix_n_ && js[ix_[ixp_]] == ']') { ixp_++; if (dict_wanted(path)) dict_row(path, meta, Value::array({})); return T_ARRAY; }
+    const uint32_t ep = elem(path);
+    if (ep >= ctr_gen_.size()) { ctr_gen_.resize((size_t)ep * 2 + 64, 0); ctr_val_.resize(ctr_gen_.size(), 0); }
+    if (ctr_gen_[ep] != review_gen_) { ctr_gen_[ep] = review_gen_; ctr_val_[ep] = 0; ctr_touched_.push_back(ep); }
+    const bool skip_elems = pruning_ && !(read_state(ep) & 2u);
+    for (;;) {
+      uint32_t ord = ctr_val_[ep]++;
+      uint32_t ex = extra, o2 = ords;
+      if (adepth < 3) {
+        if (ord >= 255) { ord = 255; ex |= ROW_ORD_OVERFLOW; review_flags_ |= RF_TOO_BIG; }
+        o2 |= ord << (ROW_E_SHIFT0 + 8 * adepth);
+      } else ex |= ROW_DEEP;
+      if (skip_elems) { if (ix_skip(depth + 1) < 0) return -1; }
+      else if (ix_value(ep, o2, adepth + 1, ex, depth + 1) < 0) return -1;
+      count++;
+      if (ixp_ >= ix_n_) return -1;
+      const char d = js[ix_[ixp_]];
+      if (d == ',') { ixp_++; continue; }
+      if (d == ']') { ixp_++; break; }
+      return -1;
+    }
+    if (has_row) {
+      stage_[row].row.lo = count;
+      if (count) stage_[row].row.rev &= ROW_REV_MASK;
+    }
+    if (dict_deep(path)) dict_row(path, meta, parse_json(js + at, (size_t)(ix_[ixp_ - 1] + 1 - at)));
+    else if (dict_wanted(path)) dict_row(path, meta, Value::array(ValueVec(count, Value::null())));
+    return T_ARRAY;
+  }
+  if (c == '"') {
+    const char* v; uint32_t vn;
+    if (!ix_string(&v, &vn)) return -1;
+    emit_str_n(path, meta, v, vn);
+    if (dict_wanted(path)) dict_row(path, meta, Value::string(std::string(v, vn)));
+    return T_STRING;
+  }
+  if (c == '}' || c == ']' || c == ':' || c == ',') return -1;
+  return ix_scalar(true, path, meta);
+}
+
+// skip_value over tokens: a value nothing reads is a run of tokens; the same grammar, checked by a state machine with an explicit
+// stack (bit per open container), no path lookups, no rows
+int Flattener::ix_skip(int depth) {
+  if (ixp_ >= ix_n_) return -1;
+  const char* const js = ix_json_;
+  uint8_t stack[100];
+  int sp = 0, top = -1;
+  char c;
+value:
+  if (depth + sp > 96 || ixp_ >= ix_n_) return -1;
+  c = js[ix_[ixp_]];
+  if (c == '{') {
+    if (sp == 0) top = T_OBJECT;
+    ixp_++;
+    if (ixp_ < ix_n_ && js[ix_[ixp_]] == '}') { ixp_++; goto after; }
+    stack[sp++] = 1;
+    goto key;
+  }
+  if (c == '[') {
+    if (sp == 0) top = T_ARRAY;
+    ixp_++;
+    if (ixp_ < ix_n_ && js[ix_[ixp_]] == ']') { ixp_++; goto after; }
+    stack[sp++] = 0;
+    goto value;
+  }
+  if (c == '"') { if (!ix_skip_string()) return -1; if (sp == 0) top = T_STRING; goto after; }
+  if (c == '}' || c == ']' || c == ':' || c == ',') return -1;
+  { const int t = ix_scalar(false, 0, 0); if (t < 0) return -1; if (sp == 0) top = t; }
+after:
+  if (sp == 0) return top;
+  if (ixp_ >= ix_n_) return -1;
+  c = js[ix_[ixp_]];
+  if (c == ',') { ixp_++; if (stack[sp - 1]) goto key; goto value; }
+  if (c == (stack[sp - 1] ? '}' : ']')) { ixp_++; sp--; goto after; }
+  return -1;
+key:
+  if (depth + sp > 96) return -1;
+  if (ixp_ >= ix_n_ || js[ix_[ixp_]] != '"' || !ix_skip_string()) return -1;
+  if (ixp_ >= ix_n_ || js[ix_[ixp_]] != ':') return -1;
+  ixp_++;
+  goto value;
+}
+
 bool Flattener::fast_tree(const char* json, size_t len, uint32_t root, ObjFacts* facts, int* type) {
-  p_ = json; e_ = json + len;
   cur_facts_ = facts; cur_root_ = root;
-  int t = fast_value(root, 0, 0, 0, 0);
+  int t;
+  if (use_index_ && len < 0x7FFFFF00u) {
+    ix_build(json, len);
+    t = ix_value(root, 0, 0, 0, 0);
+    cur_facts_ = nullptr;
+    if (t < 0 || ixp_ != ix_n_) return false;
+    *type = t;
+    if (facts) facts->present = true;
+    return true;
+  }
+  p_ = json; e_ = json + len;
+  t = fast_value(root, 0, 0, 0, 0);
   cur_facts_ = nullptr;
   if (t < 0) return false;
   ws();
@@ -1520,62 +1842,124 @@ int Flattener::add_json(const RawReview& r, const NsCache& cache, HostTable* out
   int type = -1;
   if (!fast_tree(r.json, r.json_len, id_object_, &fobj, &type) || type != T_OBJECT) return bail();
   if (del && (!fast_tree(r.json, r.json_len, id_old_, &fold, &type) || type != T_OBJECT)) return bail();
-  // the request around it (normalize_object + normalize_admission_request)
-  std::string av = fobj.api_version.set ? std::string(fobj.api_version.p, fobj.api_version.n) : std::string();
-  std::string kind = fobj.kind.set ? std::string(fobj.kind.p, fobj.kind.n) : std::string();
-  std::string group, version;
+  // the request around it (normalize_object + normalize_admission_request); schema.ParseGroupVersion on the captured text
+  if (!env_.ready) env_init();
+  const char* const avp = fobj.api_version.set ? fobj.api_version.p : ""; const uint32_t avn = fobj.api_version.set ? fobj.api_version.n : 0;
+  const char* const kindp = fobj.kind.set ? fobj.kind.p : ""; const uint32_t kindn = fobj.kind.set ? fobj.kind.n : 0;
+  const char* groupp = ""; uint32_t groupn = 0; const char* verp = ""; uint32_t vern = 0;
   {
-    size_t nsl = std::count(av.begin(), av.end(), '/');
-    if (!(av.empty() || av == "/")) {
-      if (nsl == 0) version = av;
-      else if (nsl == 1) { size_t i = av.find('/'); group = av.substr(0, i); version = av.substr(i + 1); }
+    uint32_t nsl = 0, first = 0;
+    for (uint32_t i = 0; i < avn; i++) if (avp[i] == '/') { if (!nsl) first = i; nsl++; }
+    if (!(avn == 0 || (avn == 1 && avp[0] == '/'))) {
+      if (nsl == 0) { verp = avp; vern = avn; }
+      else if (nsl == 1) { groupp = avp; groupn = first; verp = avp + first + 1; vern = avn - first - 1; }
     }
   }
-  const std::string name = fobj.name.set ? std::string(fobj.name.p, fobj.name.n) : std::string();
-  const std::string nsfield = fobj.ns.set ? std::string(fobj.ns.p, fobj.ns.n) : std::string();
-  if (excluded && (*excluded)(kind == "Namespace" && group.empty(), nsfield, name)) { bail(); return EXCLUDED; }
+  const char* const namep = fobj.name.set ? fobj.name.p : ""; const uint32_t namen = fobj.name.set ? fobj.name.n : 0;
+  const char* const nsp = fobj.ns.set ? fobj.ns.p : ""; const uint32_t nsn = fobj.ns.set ? fobj.ns.n : 0;
+  if (excluded && (*excluded)(kindn == 9 && memcmp(kindp, "Namespace", 9) == 0 && groupn == 0, std::string(nsp, nsn), std::string(namep, namen))) { bail(); return EXCLUDED; }
   uint32_t members = 8;   // uid kind resource operation userInfo object oldObject options
-  emit_str(0, "uid", "");
-  uint32_t kp = child(0, "kind");
-  emit(kp, T_OBJECT, 3, 0);
-  emit_str(kp, "group", group); emit_str(kp, "version", version); emit_str(kp, "kind", kind);
-  uint32_t rp = child(0, "resource");
-  emit(rp, T_OBJECT, 3, 0);
-  emit_str(rp, "group", ""); emit_str(rp, "version", ""); emit_str(rp, "resource", "");
-  emit_str(0, "operation", op);
-  emit(child(0, "userInfo"), T_OBJECT, 0, 0);
+  emit_str_n(env_.uid, 0, "", 0);
+  emit(env_.kind, T_OBJECT, 3, 0);
+  emit_str_n(env_.k_group, 0, groupp, groupn); emit_str_n(env_.k_version, 0, verp, vern); emit_str_n(env_.k_kind, 0, kindp, kindn);
+  emit(env_.resource, T_OBJECT, 3, 0);
+  emit_str_n(env_.r_group, 0, "", 0); emit_str_n(env_.r_version, 0, "", 0); emit_str_n(env_.r_resource, 0, "", 0);
+  emit_str_n(env_.operation, 0, op.data(), (uint32_t)op.size());
+  emit(env_.user_info, T_OBJECT, 0, 0);
   if (!del) emit(id_old_, T_NULL, 0, 0);
-  emit(child(0, "options"), T_NULL, 0, 0);
-  if (!name.empty()) { emit_str(0, "name", name); members++; }
-  if (!nsfield.empty()) { emit_str(0, "namespace", nsfield); members++; }
+  emit(env_.options, T_NULL, 0, 0);
+  if (namen) { emit_str_n(env_.name, 0, namep, namen); members++; }
+  if (nsn) { emit_str_n(env_.ns, 0, nsp, nsn); members++; }
   if (r.nsobj_json && r.nsobj_len) {
     const size_t before = stage_.size(), hb = out->heap.size();
     int t2 = -1;
-    if (!fast_tree(r.nsobj_json, r.nsobj_len, child(0, "namespaceObject"), nullptr, &t2)) return bail();
+    if (!fast_tree(r.nsobj_json, r.nsobj_len, env_.nsobj, nullptr, &t2)) return bail();
     if (t2 == T_NULL) { stage_.resize(before); out->heap.resize(hb); } else members++;
   }
   emit(0, T_OBJECT, members, 0);
   // Matchable.Namespace: the review's, else the nsCache entry of the request namespace (matcher.go:37-39)
-  Value ns;
+  NsMemo* memo = nullptr;
   if (r.ns_json && r.ns_len) {
-    auto it = ns_cache_.find(r.ns_json);
-    if (it == ns_cache_.end() || it->second.first != r.ns_len) {
-      Value v;
-      try { v = parse_json(r.ns_json, r.ns_len); } catch (const std::exception&) { return bail(); }
-      it = ns_cache_.insert_or_assign(r.ns_json, std::make_pair(r.ns_len, v)).first;
+    auto it = ns_memo_.find(r.ns_json);
+    if (it == ns_memo_.end() || it->second.len != r.ns_len) {
+      NsMemo m;
+      m.len = r.ns_len;
+      try { Value v = parse_json(r.ns_json, r.ns_len); if (!v.is_null()) m.ns = v; } catch (const std::exception&) { return bail(); }
+      if (m.ns.defined()) m.nsname = obj_string(m.ns, "metadata", "name");
+      it = ns_memo_.insert_or_assign(r.ns_json, std::move(m)).first;
     }
-    if (!it->second.second.is_null()) ns = it->second.second;
+    if (it->second.ns.defined()) memo = &it->second;
   }
-  if (!ns.defined() && !nsfield.empty()) ns = cache.get(nsfield);
+  if (!memo && nsn) {
+    const std::string nsfield(nsp, nsn);
+    auto it = ns_memo_name_.find(nsfield);
+    if (it == ns_memo_name_.end()) {
+      NsMemo m;
+      m.ns = cache.get(nsfield);
+      if (m.ns.defined()) m.nsname = obj_string(m.ns, "metadata", "name");
+      it = ns_memo_name_.emplace(nsfield, std::move(m)).first;
+    }
+    memo = &it->second;
+  }
+  static const Value no_ns;
+  static const std::string no_name;
+  const bool ns_defined = memo && memo->ns.defined();
   emit(id_m_, T_OBJECT, 2, 0);
-  fast_match_facts(fobj, ns, false);
-  if (del) fast_match_facts(fold, ns, true);
+  fast_match_facts_n(fobj, ns_defined, ns_defined ? memo->nsname : no_name, false);
+  if (del) fast_match_facts_n(fold, ns_defined, ns_defined ? memo->nsname : no_name, true);
   if (obj_key) {
     std::string& k = *obj_key;
-    k = group; k.push_back('\0'); k += version; k.push_back('\0'); k += kind; k.push_back('\0'); k += nsfield; k.push_back('\0'); k += name;
+    k.clear();
+    k.reserve(groupn + vern + kindn + nsn + namen + 4);
+    k.append(groupp, groupn); k.push_back('\0'); k.append(verp, vern); k.push_back('\0'); k.append(kindp, kindn); k.push_back('\0'); k.append(nsp, nsn); k.push_back('\0'); k.append(namep, namen);
   }
-  finish_review(ns, r.source, out);
+  if (memo) finish_review_memo(memo, r.source, out);
+  else finish_review(no_ns, r.source, out);
   return ADDED;
+}
+
+void Flattener::env_init() {
+  EnvIds& v = env_;
+  v.uid = child(0, "uid");
+  v.kind = child(0, "kind"); v.k_group = child(v.kind, "group"); v.k_version = child(v.kind, "version"); v.k_kind = child(v.kind, "kind");
+  v.resource = child(0, "resource"); v.r_group = child(v.resource, "group"); v.r_version = child(v.resource, "version"); v.r_resource = child(v.resource, "resource");
+  v.operation = child(0, "operation"); v.user_info = child(0, "userInfo"); v.options = child(0, "options");
+  v.name = child(0, "name"); v.ns = child(0, "namespace"); v.nsobj = child(0, "namespaceObject");
+  for (int w = 0; w < 2; w++) {
+    v.m_sub[w] = child(id_m_, w ? "old" : "o");
+    v.m_group[w] = child(v.m_sub[w], "group"); v.m_kind[w] = child(v.m_sub[w], "kind"); v.m_name[w] = child(v.m_sub[w], "name");
+    v.m_gname[w] = child(v.m_sub[w], "gname"); v.m_nsname[w] = child(v.m_sub[w], "nsname");
+  }
+  v.ready = true;
+}
+// match_facts() on the captured strings, Matchable.Namespace reduced to its name
+void Flattener::fast_match_facts_n(const ObjFacts& f, bool ns_defined, const std::string& ns_name, bool is_old) {
+  if (!env_.ready) env_init();
+  const int w = is_old ? 1 : 0;
+  const char* const avp = f.api_version.set ? f.api_version.p : ""; const uint32_t avn = f.api_version.set ? f.api_version.n : 0;
+  const char* const kindp = f.kind.set ? f.kind.p : ""; const uint32_t kindn = f.kind.set ? f.kind.n : 0;
+  uint32_t nsl = 0, first = 0;
+  for (uint32_t i = 0; i < avn; i++) if (avp[i] == '/') { if (!nsl) first = i; nsl++; }
+  const uint32_t groupn = (!(avn == 0 || (avn == 1 && avp[0] == '/')) && nsl == 1) ? first : 0;
+  const bool is_ns = kindn == 9 && memcmp(kindp, "Namespace", 9) == 0 && groupn == 0;
+  emit(env_.m_sub[w], T_OBJECT, 0, 0);
+  emit_str_n(env_.m_group[w], 0, avp, groupn);
+  emit_str_n(env_.m_kind[w], 0, kindp, kindn);
+  const char* const namep = f.name.set ? f.name.p : ""; const uint32_t namen = f.name.set ? f.name.n : 0;
+  const uint32_t nsn = f.ns.set ? f.ns.n : 0;
+  emit_str_n(env_.m_name[w], 0, namep, namen);
+  emit_str_n(env_.m_gname[w], 0, f.gname.set ? f.gname.p : "", f.gname.set ? f.gname.n : 0);
+  bool has_nsname = true;
+  if (is_ns) emit_str_n(env_.m_nsname[w], 0, namep, namen);
+  else if (ns_defined) emit_str_n(env_.m_nsname[w], 0, ns_name.data(), (uint32_t)ns_name.size());
+  else if (nsn) emit_str_n(env_.m_nsname[w], 0, f.ns.p, nsn);
+  else has_nsname = false;
+  review_flags_ |= is_old ? RF_HAS_OLD : RF_HAS_OBJ;
+  if (is_ns) review_flags_ |= is_old ? RF_OLD_IS_NS : RF_OBJ_IS_NS;
+  if (nsn) review_flags_ |= is_old ? RF_OLD_HAS_NSFIELD : RF_OBJ_HAS_NSFIELD;
+  if (has_nsname) review_flags_ |= is_old ? RF_OLD_HAS_NSNAME : RF_OBJ_HAS_NSNAME;
+  if (f.labels_bad) review_flags_ |= is_old ? RF_OLD_LABELS_BAD : RF_OBJ_LABELS_BAD;
+  if (kindn == 0) review_flags_ |= is_old ? RF_OLD_BAD : RF_OBJ_BAD;
 }
 
 void Flattener::finish(HostTable* out) {

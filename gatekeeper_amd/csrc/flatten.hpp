@@ -374,12 +374,49 @@ class Flattener {
   uint32_t cur_root_ = 0;                     // its root path (object / oldObject)
   struct CapIds { uint32_t api_version, kind, metadata, name, ns, gname, labels; } cap_[2];   // [0] object, [1] oldObject
   std::unordered_map<const char*, std::pair<size_t, Value>> ns_cache_;   // parsed Namespace documents by text pointer
+  // (round 4) what a review takes from its Namespace is the same for every review of that namespace: the name the match layer
+  // compares and the $ns rows.  Kept per table part (begin_table drops it): the rows hold offsets into the part's heap.
+  struct NsMemo {
+    size_t len = 0; Value ns; std::string nsname;
+    int rows_state = 0;               // 0 not recorded yet, 1 `rows` / `flags` replay, 2 not replayable (value ids, message keys, element counters)
+    std::vector<Staged> rows; uint32_t flags = 0; const HostTable* owner = nullptr;
+  };
+  std::unordered_map<const char*, NsMemo> ns_memo_;
+  std::unordered_map<std::string, NsMemo> ns_memo_name_;
+  bool emit_side_effects_ = false;    // an emit() interned a value id or compared a message key since this was cleared
+  void ns_rows(const Value& ns);                                        // the $ns rows of finish_review
+  void finish_review_memo(NsMemo* m, int source, HostTable* out);       // finish_review with the $ns rows replayed
+  void finish_tail(int source, HostTable* out);
+  // paths of the request envelope add_json writes around an object, resolved once
+  struct EnvIds { bool ready = false; uint32_t uid, kind, k_group, k_version, k_kind, resource, r_group, r_version, r_resource, operation, user_info, options, name, ns, nsobj,
+                  m_sub[2], m_group[2], m_kind[2], m_name[2], m_gname[2], m_nsname[2]; } env_;
+  void env_init();
+  void fast_match_facts_n(const ObjFacts& f, bool ns_defined, const std::string& ns_name, bool is_old);
   uint32_t fast_child(uint32_t parent, const char* key, uint32_t len);
   int fast_value(uint32_t path, uint32_t ords, int adepth, uint32_t extra, int depth);   // -> RowType of the value, -1 = bail
   bool fast_string(const char** s, uint32_t* n);   // decodes the string at p_ (views the text when it has no escapes)
   bool fast_tree(const char* json, size_t len, uint32_t root, ObjFacts* facts, int* type);
   void emit_str_n(uint32_t path, uint32_t meta, const char* s, uint32_t n);
   void fast_match_facts(const ObjFacts& f, const Value& ns, bool is_old);
+  // ---- structural index (round 4): stage 1 classifies the document 64 bytes at a time (AVX-512: unescaped quotes, the in-string
+  // mask by carry-less multiply, the six structural characters, the first character of every other scalar) into an array of token
+  // positions; stage 2 (ix_value / ix_skip: the grammar and the row semantics of fast_value / skip_value) walks TOKENS, not bytes: no
+  // white-space loops, a string's length is the distance of two tokens, an unread subtree is a run of tokens checked by a small
+  // state machine.  Hosts without AVX-512BW + PCLMUL keep the byte-at-a-time path (GK_NO_INDEX=1 forces it: the tests compare both).
+  std::vector<uint32_t> ix_;          // token positions (+ one sentinel: the document's length)
+  std::vector<uint64_t> ix_bs_;       // backslash bits per 64-byte block
+  const char* ix_json_ = nullptr;
+  uint32_t ix_n_ = 0, ixp_ = 0, ix_len_ = 0;
+  bool ix_any_bs_ = false;
+  bool use_index_ = false;            // decided per table (begin_table): the CPU has the instructions and GK_NO_INDEX is not set
+  static bool ix_supported();
+  void ix_build(const char* json, size_t len);
+  bool ix_has_bs(uint32_t a, uint32_t b) const;            // a backslash in [a, b)?
+  bool ix_string(const char** s, uint32_t* n);             // the string whose opening quote is token ixp_; advances past its closing quote
+  bool ix_skip_string();
+  int ix_scalar(bool emit_rows, uint32_t path, uint32_t meta);   // literal / number at token ixp_: its RowType (rows + dictionary row when asked), -1 = bail
+  int ix_value(uint32_t path, uint32_t ords, int adepth, uint32_t extra, int depth);
+  int ix_skip(int depth);
   void ws() { if (p_ < e_ && (unsigned char)*p_ > ' ') return; while (p_ < e_ && (*p_ == ' ' || *p_ == '\n' || *p_ == '\t' || *p_ == '\r')) p_++; }
 };
 

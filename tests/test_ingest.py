@@ -32,8 +32,16 @@ def _raw(text, ns=None, nsobj=None, op="", source="Original"):
     return r
 
 
+@pytest.fixture(params=["index", "bytes"])
+def tokens(request, monkeypatch):
+    """both scanners of the fast path: the structural index (AVX-512 hosts) and the byte-at-a-time one every other host runs"""
+    if request.param == "bytes":
+        monkeypatch.setenv("GK_NO_INDEX", "1")
+    return request.param
+
+
 @pytest.mark.parametrize("mixed", [False, True])
-def test_fast_ingest_equals_general_path_on_synthetic(mixed):
+def test_fast_ingest_equals_general_path_on_synthetic(mixed, tokens):
     eng = D.Engine(hostemu=True)
     nss = synth.gen_namespaces()
     objs = synth.gen_objects(700, seed=77, mixed=mixed)
@@ -44,7 +52,7 @@ def test_fast_ingest_equals_general_path_on_synthetic(mixed):
     assert _digest(eng, rins, False, threads=3)["digest"] == fast["digest"] == _digest(eng, rins, False, threads=1)["digest"]
 
 
-def test_fast_ingest_adversarial_documents():
+def test_fast_ingest_adversarial_documents(tokens):
     """escapes, surrogate pairs, numbers at the int64 / float boundaries, empty containers, deep nesting, arrays of arrays,
     > 255 elements, DELETE, namespaceObject (incl. null), wrong-typed metadata, missing kind, whitespace, nsCache fallback"""
     eng = D.Engine(hostemu=True)
@@ -91,7 +99,7 @@ def _req(text, ns=None, nsobj=None, source="Original"):
     return D.ReviewIn(L.GK_REVIEW_ADMISSION_REQUEST, text.encode() if isinstance(text, str) else text, ns, nsobj, source, "")
 
 
-def test_fast_ingest_of_admission_requests():
+def test_fast_ingest_of_admission_requests(tokens):
     """AdmissionRequest documents (the webhook's wire shape, pkg/target/review.go:16-21) through the one-pass parser:
     CREATE / UPDATE / DELETE, missing and wrong-typed envelope members, unknown members (dropped after a syntax check),
     requestKind / dryRun / options / userInfo subtrees, namespaceObject, nsCache fallback on the REQUEST namespace --
