@@ -261,6 +261,24 @@ uint32_t DictRegistry::read_state(const PathDict& dict, uint32_t path_id) const 
   for (const Pattern* p : more) if (pattern_reaches(*p, dict, path_id, &full)) st |= 2u;
   return st;
 }
+bool DictRegistry::child_names(const PathDict& dict, uint32_t path_id, std::vector<std::string>* names) const {
+  size_t depth = 0;
+  for (uint32_t id = path_id; id != 0 && id != PathDict::kNone; id = dict.info(id).parent) depth++;
+  std::shared_lock<std::shared_mutex> l(mu_);
+  std::vector<const Pattern*> all;
+  for (const auto& r : reads_) all.push_back(&r.second);
+  interest(&all);
+  std::unique_ptr<std::shared_lock<std::shared_mutex>> l2;
+  if (counting_) { l2.reset(new std::shared_lock<std::shared_mutex>(counting_->mu_)); counting_->interest(&all); }
+  bool full = false;
+  for (const Pattern* p : all) {
+    if (p->size() <= depth || !pattern_reaches(*p, dict, path_id, &full) || full) continue;
+    const PatStep& st = (*p)[depth];
+    if (st.any) return false;
+    if (std::find(names->begin(), names->end(), st.key) == names->end()) names->push_back(st.key);
+  }
+  return true;
+}
 bool DictRegistry::add_key(const Pattern& leaf, bool add) {
   const std::string k = pattern_to_string(leaf);
   std::unique_lock<std::shared_mutex> l(mu_);
@@ -488,7 +506,7 @@ void Flattener::begin_table() {
   if (reg_) {
     const uint64_t g = reg_->gen();
     const uint64_t rg = reg_->reads_gen();
-    if (g != reg_gen_ || rg != reads_gen_seen_) { dict_paths_.clear(); reg_gen_ = g; reads_gen_seen_ = rg; }
+    if (g != reg_gen_ || rg != reads_gen_seen_) { dict_paths_.clear(); pbits_.clear(); kid_filter_.clear(); kid_arena_.clear(); reg_gen_ = g; reads_gen_seen_ = rg; }
   }
 }
 
@@ -610,11 +628,39 @@ uint32_t Flattener::read_state(uint32_t path) {
   return d.rstate & 3u;
 }
 
+const Flattener::KidFilter* Flattener::kid_filter(uint32_t path) {
+  if (path >= kid_filter_.size()) kid_filter_.resize((size_t)path * 2 + 64);
+  if (kid_filter_[path].state == 0) {
+    std::vector<std::string> names;
+    const bool listed = reg_->child_names(*dict_, path, &names) && names.size() <= 24;
+    std::vector<KidEnt> kids;
+    if (listed) for (const std::string& n : names) { kids.push_back({child(path, n), (uint32_t)kid_arena_.size(), (uint32_t)n.size()}); kid_arena_ += n; }
+    if (path >= kid_filter_.size()) kid_filter_.resize((size_t)path * 2 + 64);   // (child() does not touch it; belt and braces)
+    kid_filter_[path].kids = std::move(kids);
+    kid_filter_[path].state = listed ? 2 : 1;
+  }
+  return kid_filter_[path].state == 2 ? &kid_filter_[path] : nullptr;
+}
+
+uint8_t Flattener::pbits_slow(uint32_t path) {
+  uint8_t b = PB_KNOWN;
+  if (!pruning_) b |= PB_ROW | PB_BELOW;
+  else { const uint32_t r = read_state(path); if (r & 1u) b |= PB_ROW; if (r & 2u) b |= PB_BELOW; }
+  if (value_wanted(path)) b |= PB_VALUE;
+  if (key_wanted(path)) b |= PB_KEY;
+  if (dict_wanted(path)) { b |= PB_DICT; if (dict_paths_[path].deep) b |= PB_DEEP; }
+  if (guard_wanted(path)) b |= PB_GUARD;
+  if (path >= pbits_.size()) pbits_.resize((size_t)path * 2 + 64, 0);
+  pbits_[path] = b;
+  return b;
+}
+
 bool Flattener::emit(uint32_t path, uint32_t meta, uint32_t lo, uint32_t hi, bool always) {
-  if (pruning_ && !always && !(read_state(path) & 1u)) {
+  const uint8_t pb = pbits(path);
+  if (!always && !(pb & PB_ROW)) {
     // a pruned table holds no row of this path -- what the flattener itself derives from the value still happens: a message key
     // is still compared with the review's other keys (review.$dup)
-    if (key_wanted(path)) {
+    if (pb & PB_KEY) {
       emit_side_effects_ = true;
       const uint32_t id = value_id(meta, lo, hi);
       if (id == 0u || id == GK_VID_OVERFLOW || std::find(key_ids_.begin(), key_ids_.end(), id) != key_ids_.end()) dup_seen_ = true;
@@ -622,9 +668,9 @@ bool Flattener::emit(uint32_t path, uint32_t meta, uint32_t lo, uint32_t hi, boo
     }
     return false;
   }
-  uint32_t rev = t_->n_reviews % t_->rpt;
-  if (value_wanted(path)) { rev |= value_id(meta, lo, hi) << ROW_VID_SHIFT; emit_side_effects_ = true; }
-  if (key_wanted(path)) {   // a message key: equal values within the review (or one without an id) -> review.$dup (finish_review)
+  uint32_t rev = rev_cur_;
+  if (pb & PB_VALUE) { rev |= value_id(meta, lo, hi) << ROW_VID_SHIFT; emit_side_effects_ = true; }
+  if (pb & PB_KEY) {   // a message key: equal values within the review (or one without an id) -> review.$dup (finish_review)
     emit_side_effects_ = true;
     const uint32_t id = value_id(meta, lo, hi);
     if (id == 0u || id == GK_VID_OVERFLOW || std::find(key_ids_.begin(), key_ids_.end(), id) != key_ids_.end()) dup_seen_ = true;
@@ -773,6 +819,7 @@ void Flattener::match_facts(const Value& obj, const Value& ns, bool is_old, uint
 
 void Flattener::add(const ReviewDoc& doc, HostTable* out) {
   t_ = out;
+  rev_cur_ = out->n_reviews % out->rpt;
   ctrs_.clear();
   ctr_touched_.clear();
   review_flags_ = 0;
@@ -931,40 +978,56 @@ void HostTable::append(const HostTable& part) {
 // ------------------------------------------------------------------------------------------------ fast ingest
 // JSON text -> rows in one pass (see flatten.hpp).  Grammar and value semantics are those of value.hpp's JsonParser;
 // anything unusual bails out (returns false / -1) so that the general path decides.
+// the first eight bytes of a member name (zero-padded): one load when eight bytes can be read at the name (it lies inside the
+// document text, which goes on after the closing quote), else a copy
+inline uint64_t Flattener::name8(const char* key, uint32_t len) const {
+  uint64_t w = 0;
+  if (len >= 8) { memcpy(&w, key, 8); return w; }
+  if (key >= ix_json_ && key + 8 <= ix_json_ + ix_len_) { memcpy(&w, key, 8); return len ? (w & (~0ull >> (64 - 8 * len))) : 0; }
+  memcpy(&w, key, len);
+  return w;
+}
 uint32_t Flattener::fast_child_at(uint32_t parent, uint32_t pos, const char* key, uint32_t len) {
   static const bool nopred = getenv("GK_NO_PRED") != nullptr;   // tuning aid
-  if (nopred) return fast_child(parent, key, len);
+  const uint64_t w8 = name8(key, len);
+  if (nopred) return fast_child_w(parent, key, len, w8);
   if (parent < pred_.size() && pos < pred_[parent].size()) {
     const PredEnt& pe = pred_[parent][pos];
-    if (pe.id != 0xFFFFFFFFu && pe.len == len && memcmp(key_arena_.data() + pe.off, key, len) == 0) return pe.id;
+    if (pe.len == len && pe.first8 == w8 && pe.id != 0xFFFFFFFFu && (len <= 8 || memcmp(key_arena_.data() + pe.off + 8, key + 8, len - 8) == 0)) return pe.id;
   }
-  const uint32_t id = fast_child(parent, key, len);
+  const uint32_t id = fast_child_w(parent, key, len, w8);
   if (pos < 64) {   // (positions beyond 64 -- label maps, annotation maps -- are not worth remembering: their names vary)
     if (parent >= pred_.size()) pred_.resize((size_t)parent * 2 + 64);
     std::vector<PredEnt>& v = pred_[parent];
     if (pos >= v.size()) v.resize(pos + 1);
-    // the name's bytes live in key_arena_ (fast_child interned them): find them through the table once more is not needed --
-    // fast_child left the slot it used in last_slot_
-    v[pos].id = id; v[pos].off = key_tab_[last_slot_].off; v[pos].len = len;
+    // the name's bytes live in key_arena_ (fast_child interned them): fast_child left the slot it used in last_slot_
+    v[pos].id = id; v[pos].off = key_tab_[last_slot_].off; v[pos].len = len; v[pos].first8 = w8;
   }
   return id;
 }
 
 uint32_t Flattener::fast_child(uint32_t parent, const char* key, uint32_t len) {
+  uint64_t w = 0;
+  memcpy(&w, key, len < 8 ? len : 8);
+  return fast_child_w(parent, key, len, w);
+}
+uint32_t Flattener::fast_child_w(uint32_t parent, const char* key, uint32_t len, uint64_t w8) {
   uint64_t h = 1469598103934665603ull ^ ((uint64_t)parent * 0x9E3779B97F4A7C15ull);
-  {   // eight bytes of the name per round (member names are short: one or two rounds), the tail byte by byte
-    uint32_t i = 0;
+  h = (h ^ w8) * 0x9E3779B97F4A7C15ull; h ^= h >> 32;
+  if (len > 8) {   // eight bytes of the name per round, the tail byte by byte
+    uint32_t i = 8;
     for (; i + 8 <= len; i += 8) { uint64_t w; memcpy(&w, key + i, 8); h = (h ^ w) * 0x9E3779B97F4A7C15ull; h ^= h >> 32; }
     uint64_t w = 0;
     memcpy(&w, key + i, len - i);
-    h = (h ^ w ^ ((uint64_t)len << 56)) * 1099511628211ull;
+    h = (h ^ w) * 0x9E3779B97F4A7C15ull;
   }
+  h = (h ^ ((uint64_t)len << 56)) * 1099511628211ull;
   h ^= h >> 29;
   if (key_tab_.empty()) key_tab_.resize(2048);
   size_t mask = key_tab_.size() - 1, i = (size_t)h & mask;
   while (key_tab_[i].used) {
     const KeySlot& k = key_tab_[i];
-    if (k.hash == h && k.parent == parent && k.len == len && memcmp(key_arena_.data() + k.off, key, len) == 0) { last_slot_ = i; return k.id; }
+    if (k.hash == h && k.first8 == w8 && k.parent == parent && k.len == len && (len <= 8 || memcmp(key_arena_.data() + k.off + 8, key + 8, len - 8) == 0)) { last_slot_ = i; return k.id; }
     i = (i + 1) & mask;
   }
   const uint32_t id = dict_->child(parent, std::string(key, len));
@@ -978,7 +1041,7 @@ uint32_t Flattener::fast_child(uint32_t parent, const char* key, uint32_t len) {
     while (key_tab_[i].used) i = (i + 1) & mask;
   }
   KeySlot& k = key_tab_[i];
-  k.used = true; k.hash = h; k.parent = parent; k.id = id; k.off = (uint32_t)key_arena_.size(); k.len = len;
+  k.used = true; k.hash = h; k.first8 = w8; k.parent = parent; k.id = id; k.off = (uint32_t)key_arena_.size(); k.len = len;
   key_arena_.append(key, len);
   key_count_++;
   last_slot_ = i;
@@ -1055,7 +1118,7 @@ bool Flattener::fast_string(const char** s, uint32_t* n) {
 }
 
 void Flattener::emit_str_n(uint32_t path, uint32_t meta, const char* s, uint32_t n) {
-  if (pruning_ && !(read_state(path) & 1u) && !key_wanted(path)) return;
+  if (!(pbits(path) & (PB_ROW | PB_KEY))) return;
   if (n <= 7) {   // inline: no heap entry, no memory access on the device
     uint64_t bits = 0;
     memcpy(&bits, s, n);
@@ -1335,11 +1398,67 @@ static uint32_t ix_stage1(const char* s, uint32_t len, uint32_t* out, uint64_t* 
   *any_bs = bs_or != 0;
   return n;
 }
+__attribute__((target("avx512f,avx512bw,avx512vbmi,avx512vbmi2,pclmul,bmi,bmi2,lzcnt,popcnt")))
+static uint32_t ix_stage1_compress(const char* s, uint32_t len, uint32_t* out, uint64_t* bs_out, bool* any_bs) {
+  uint64_t prev_in_string = 0, prev_escaped = 0, prev_scalar = 0, bs_or = 0;
+  uint32_t n = 0;
+  const __m512i c_bs = _mm512_set1_epi8('\\'), c_q = _mm512_set1_epi8('"'), c_20 = _mm512_set1_epi8(0x20), c_ob = _mm512_set1_epi8('{'), c_cb = _mm512_set1_epi8('}'),
+                c_col = _mm512_set1_epi8(':'), c_com = _mm512_set1_epi8(','), c_nl = _mm512_set1_epi8('\n'), c_tab = _mm512_set1_epi8('\t'), c_cr = _mm512_set1_epi8('\r');
+  alignas(64) static const uint8_t iota_b[64] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31,
+                                                 32, 33, 34, 35, 36, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51, 52, 53, 54, 55, 56, 57, 58, 59, 60, 61, 62, 63};
+  const __m512i iota = _mm512_load_si512((const void*)iota_b);
+  for (uint32_t base = 0; base < len; base += 64) {
+    const uint32_t rem = len - base;
+    const uint64_t valid = rem >= 64 ? ~0ull : (~0ull >> (64 - rem));
+    const __m512i v = rem >= 64 ? _mm512_loadu_si512((const void*)(s + base)) : _mm512_maskz_loadu_epi8((__mmask64)valid, (const void*)(s + base));
+    uint64_t bs = _mm512_cmpeq_epi8_mask(v, c_bs);
+    uint64_t quote = _mm512_cmpeq_epi8_mask(v, c_q);
+    bs_out[base >> 6] = bs;
+    bs_or |= bs;
+    if (bs | prev_escaped) {   // bytes escaped by a backslash: the byte after every ODD-length run's last backslash
+      bs &= ~prev_escaped;
+      const uint64_t follows = (bs << 1) | prev_escaped;
+      const uint64_t even = 0x5555555555555555ull;
+      const uint64_t odd_starts = bs & ~even & ~follows;
+      uint64_t on_even;
+      prev_escaped = __builtin_add_overflow(odd_starts, bs, &on_even) ? 1 : 0;
+      const uint64_t escaped = (even ^ (on_even << 1)) & follows;
+      quote &= ~escaped;
+    }
+    const uint64_t in_string = (uint64_t)_mm_cvtsi128_si64(_mm_clmulepi64_si128(_mm_set_epi64x(0, (long long)quote), _mm_set1_epi8((char)0xFF), 0)) ^ prev_in_string;
+    prev_in_string = (uint64_t)((int64_t)in_string >> 63);
+    const __m512i lower = _mm512_or_si512(v, c_20);   // '[' | 0x20 = '{', ']' | 0x20 = '}'
+    const uint64_t op = _mm512_cmpeq_epi8_mask(lower, c_ob) | _mm512_cmpeq_epi8_mask(lower, c_cb) | _mm512_cmpeq_epi8_mask(v, c_col) | _mm512_cmpeq_epi8_mask(v, c_com);
+    const uint64_t wsm = _mm512_cmpeq_epi8_mask(v, c_20) | _mm512_cmpeq_epi8_mask(v, c_nl) | _mm512_cmpeq_epi8_mask(v, c_tab) | _mm512_cmpeq_epi8_mask(v, c_cr);
+    const uint64_t scalar = ~(op | wsm | quote) & ~in_string & valid;
+    const uint64_t scalar_start = scalar & ~((scalar << 1) | prev_scalar);
+    prev_scalar = scalar >> 63;
+    const uint64_t bits = ((op & ~in_string) | quote | scalar_start) & valid;
+    // positions of the set bits: VPCOMPRESSB packs the byte numbers 0..63 under the mask, widened 16 at a time (no loop over
+    // bits, no data-dependent branch per token; the stores run up to 64 entries past n: ix_build leaves that room)
+    const uint32_t cnt = (uint32_t)_mm_popcnt_u64(bits);
+    const __m512i packed = _mm512_maskz_compress_epi8((__mmask64)bits, iota);
+    const __m512i vb = _mm512_set1_epi32((int)base);
+    uint32_t* o = out + n;
+    _mm512_storeu_si512((void*)o, _mm512_add_epi32(vb, _mm512_cvtepu8_epi32(_mm512_castsi512_si128(packed))));
+    if (cnt > 16) {
+      _mm512_storeu_si512((void*)(o + 16), _mm512_add_epi32(vb, _mm512_cvtepu8_epi32(_mm512_extracti32x4_epi32(packed, 1))));
+      if (cnt > 32) {
+        _mm512_storeu_si512((void*)(o + 32), _mm512_add_epi32(vb, _mm512_cvtepu8_epi32(_mm512_extracti32x4_epi32(packed, 2))));
+        if (cnt > 48) _mm512_storeu_si512((void*)(o + 48), _mm512_add_epi32(vb, _mm512_cvtepu8_epi32(_mm512_extracti32x4_epi32(packed, 3))));
+      }
+    }
+    n += cnt;
+  }
+  *any_bs = bs_or != 0;
+  return n;
+}
 void Flattener::ix_build(const char* json, size_t len) {
-  if (ix_.size() < len + 2) ix_.resize(len + 2 + len / 2);
+  if (ix_.size() < len + 80) ix_.resize(len + 80 + len / 2);
   if (ix_bs_.size() < len / 64 + 2) ix_bs_.resize(len / 64 + 2 + len / 128);
   ix_json_ = json; ix_len_ = (uint32_t)len;
-  ix_n_ = ix_stage1(json, (uint32_t)len, ix_.data(), ix_bs_.data(), &ix_any_bs_);
+  static const bool compress = __builtin_cpu_supports("avx512vbmi2") && __builtin_cpu_supports("avx512vbmi") && !getenv("GK_NO_VBMI2");
+  ix_n_ = compress ? ix_stage1_compress(json, (uint32_t)len, ix_.data(), ix_bs_.data(), &ix_any_bs_) : ix_stage1(json, (uint32_t)len, ix_.data(), ix_bs_.data(), &ix_any_bs_);
   ix_[ix_n_] = (uint32_t)len;   // sentinel: where the last token's text ends at the latest
   ixp_ = 0;
   p_ = json; e_ = json + len;   // (strings with escapes are decoded by fast_string)
@@ -1379,9 +1498,9 @@ int Flattener::ix_scalar(bool rows, uint32_t path, uint32_t meta) {
   const char* lim = ix_json_ + ix_[ixp_ + 1];
   auto ends = [&](const char* q) { return q == lim || *q == ' ' || *q == '\n' || *q == '\t' || *q == '\r'; };
   const char c = *s;
-  if (c == 't') { if (lim - s < 4 || memcmp(s, "true", 4) != 0 || !ends(s + 4)) return -1; ixp_++; if (rows) { emit(path, meta | T_BOOL, 1, 0); if (dict_wanted(path)) dict_row(path, meta, Value::boolean(true)); } return T_BOOL; }
-  if (c == 'f') { if (lim - s < 5 || memcmp(s, "false", 5) != 0 || !ends(s + 5)) return -1; ixp_++; if (rows) { emit(path, meta | T_BOOL, 0, 0); if (dict_wanted(path)) dict_row(path, meta, Value::boolean(false)); } return T_BOOL; }
-  if (c == 'n') { if (lim - s < 4 || memcmp(s, "null", 4) != 0 || !ends(s + 4)) return -1; ixp_++; if (rows) { emit(path, meta | T_NULL, 0, 0); if (dict_wanted(path)) dict_row(path, meta, Value::null()); } return T_NULL; }
+  if (c == 't') { if (lim - s < 4 || memcmp(s, "true", 4) != 0 || !ends(s + 4)) return -1; ixp_++; if (rows) { emit(path, meta | T_BOOL, 1, 0); if (pbits(path) & PB_DICT) dict_row(path, meta, Value::boolean(true)); } return T_BOOL; }
+  if (c == 'f') { if (lim - s < 5 || memcmp(s, "false", 5) != 0 || !ends(s + 5)) return -1; ixp_++; if (rows) { emit(path, meta | T_BOOL, 0, 0); if (pbits(path) & PB_DICT) dict_row(path, meta, Value::boolean(false)); } return T_BOOL; }
+  if (c == 'n') { if (lim - s < 4 || memcmp(s, "null", 4) != 0 || !ends(s + 4)) return -1; ixp_++; if (rows) { emit(path, meta | T_NULL, 0, 0); if (pbits(path) & PB_DICT) dict_row(path, meta, Value::null()); } return T_NULL; }
   const char* q = s;
   bool is_int = true, neg = false;
   if (q < lim && *q == '-') { neg = true; q++; }
@@ -1403,14 +1522,14 @@ int Flattener::ix_scalar(bool rows, uint32_t path, uint32_t meta) {
       for (size_t k = 0; k < nd; k++) x = x * 10 + (digits[k] - '0');
       if (neg) x = -x;
       emit(path, meta | T_INT, (uint32_t)(uint64_t)x, (uint32_t)((uint64_t)x >> 32));
-      if (dict_wanted(path)) dict_row(path, meta, Value::integer((i128)x));
+      if (pbits(path) & PB_DICT) dict_row(path, meta, Value::integer((i128)x));
     }
     return T_INT;
   }
   Value v = parse_json(s, q - s);   // the general number rules, through the same Value code the tree walk uses
   const bool as_int = v.is_int && v.i >= (i128)INT64_MIN && v.i <= (i128)INT64_MAX;
   if (rows) {
-    if (dict_wanted(path)) dict_row(path, meta, v);
+    if (pbits(path) & PB_DICT) dict_row(path, meta, v);
     if (as_int) { const uint64_t u = (uint64_t)(int64_t)v.i; emit(path, meta | T_INT, (uint32_t)u, (uint32_t)(u >> 32)); }
     else { const double d = v.as_double(); uint64_t u; memcpy(&u, &d, 8); emit(path, meta | T_FLOAT | (v.is_int ? ROW_INEXACT : 0), (uint32_t)u, (uint32_t)(u >> 32)); }
   }
@@ -1430,14 +1549,32 @@ int Flattener::ix_value(uint32_t path, uint32_t ords, int adepth, uint32_t extra
     const bool has_row = emit(path, meta | T_OBJECT, 0, 0);
     const uint32_t inst = ++obj_instance_;
     uint32_t count = 0;
-    if (ixp_ < ix_n_ && js[ix_[ixp_]] == '}') { ixp_++; if (dict_wanted(path)) dict_row(path, meta, Value::object({})); return T_OBJECT; }
+    if (ixp_ < ix_n_ && js[ix_[ixp_]] == '}') { ixp_++; if (pbits(path) & PB_DICT) dict_row(path, meta, Value::object({})); return T_OBJECT; }
     const CapIds* cap = nullptr;
     if (cur_facts_ && depth <= 1) cap = &cap_[cur_root_ == id_old_ ? 1 : 0];
+    // (the object's own row and its dictionary row carry the member COUNT, which the general path takes after "last one wins" on
+    //  duplicate names: with either kept, every name gets its id and duplicates are seen)
+    const KidFilter* const kf = (pruning_ && !(cap && (depth == 0 || path == cap->metadata)) && !has_row && !(pbits(path) & PB_DICT)) ? kid_filter(path) : nullptr;
     for (;;) {
       if (ixp_ >= ix_n_ || js[ix_[ixp_]] != '"') return -1;
       const char* k; uint32_t kn;
       if (!ix_string(&k, &kn)) return -1;
-      const uint32_t ch = fast_child_at(path, count, k, kn);
+      uint32_t ch;
+      if (kf) {
+        ch = PathDict::kNone;
+        for (const KidEnt& ke : kf->kids) if (ke.len == kn && memcmp(kid_arena_.data() + ke.off, k, kn) == 0) { ch = ke.id; break; }
+        if (ch == PathDict::kNone) {   // a member no pattern names: its value is checked and walked past
+          if (ixp_ >= ix_n_ || js[ix_[ixp_]] != ':') return -1;
+          ixp_++;
+          if (ix_skip(depth + 1) < 0) return -1;
+          count++;
+          if (ixp_ >= ix_n_) return -1;
+          const char d = js[ix_[ixp_]];
+          if (d == ',') { ixp_++; continue; }
+          if (d == '}') { ixp_++; break; }
+          return -1;
+        }
+      } else ch = fast_child_at(path, count, k, kn);
       if (ch >= dup_gen_.size()) dup_gen_.resize((size_t)ch * 2 + 64, 0);
       if (dup_gen_[ch] == inst) return -1;   // duplicate member name: the general path applies "last one wins"
       dup_gen_[ch] = inst;
@@ -1450,13 +1587,13 @@ int Flattener::ix_value(uint32_t path, uint32_t ords, int adepth, uint32_t extra
         else if (path == cap->metadata) { if (ch == cap->name) want = &cur_facts_->name; else if (ch == cap->ns) want = &cur_facts_->ns; else if (ch == cap->gname) want = &cur_facts_->gname; }
       }
       int t;
-      if (pruning_ && !want && !(cap && ((depth == 0 && ch == cap->metadata) || (depth == 1 && path == cap->metadata))) && !(read_state(ch) & 2u)) {
+      if (!want && !(pbits(ch) & PB_BELOW) && !(cap && ((depth == 0 && ch == cap->metadata) || (depth == 1 && path == cap->metadata)))) {
         t = ix_skip(depth + 1);
       } else if (want && js[ix_[ixp_]] == '"') {
         const char* v; uint32_t vn;
         if (!ix_string(&v, &vn)) return -1;
         emit_str_n(ch, meta, v, vn);
-        if (dict_wanted(ch)) dict_row(ch, meta, Value::string(std::string(v, vn)));
+        if (pbits(ch) & PB_DICT) dict_row(ch, meta, Value::string(std::string(v, vn)));
         if (v == scratch_.data()) { scratch_keep_.emplace_back(new std::string(v, vn)); v = scratch_keep_.back()->data(); }
         want->p = v; want->n = vn; want->set = true;
         t = T_STRING;
@@ -1475,9 +1612,9 @@ int Flattener::ix_value(uint32_t path, uint32_t ords, int adepth, uint32_t extra
       stage_[row].row.lo = count;
       if (count) stage_[row].row.rev &= ROW_REV_MASK;   // a NON-EMPTY container has no value id (emit saw it empty)
     }
-    if (count && guard_wanted(path)) review_flags_ |= RF_REFUSE;
-    if (dict_deep(path)) dict_row(path, meta, parse_json(js + at, (size_t)(ix_[ixp_ - 1] + 1 - at)));
-    else if (dict_wanted(path)) { ValuePairs ph; for (uint32_t k = 0; k < count; k++) ph.emplace_back(Value::integer((i128)k), Value::null()); dict_row(path, meta, Value::object(std::move(ph))); }
+    if (count && (pbits(path) & PB_GUARD)) review_flags_ |= RF_REFUSE;
+    if (pbits(path) & PB_DEEP) dict_row(path, meta, parse_json(js + at, (size_t)(ix_[ixp_ - 1] + 1 - at)));
+    else if (pbits(path) & PB_DICT) { ValuePairs ph; for (uint32_t k = 0; k < count; k++) ph.emplace_back(Value::integer((i128)k), Value::null()); dict_row(path, meta, Value::object(std::move(ph))); }
     return T_OBJECT;
   }
   if (c == '[') {
@@ -1485,11 +1622,11 @@ int Flattener::ix_value(uint32_t path, uint32_t ords, int adepth, uint32_t extra
     const size_t row = stage_.size();
     const bool has_row = emit(path, meta | T_ARRAY, 0, 0);
     uint32_t count = 0;
-    if (ixp_ < ix_n_ && js[ix_[ixp_]] == ']') { ixp_++; if (dict_wanted(path)) dict_row(path, meta, Value::array({})); return T_ARRAY; }
+    if (ixp_ < ix_n_ && js[ix_[ixp_]] == ']') { ixp_++; if (pbits(path) & PB_DICT) dict_row(path, meta, Value::array({})); return T_ARRAY; }
     const uint32_t ep = elem(path);
     if (ep >= ctr_gen_.size()) { ctr_gen_.resize((size_t)ep * 2 + 64, 0); ctr_val_.resize(ctr_gen_.size(), 0); }
     if (ctr_gen_[ep] != review_gen_) { ctr_gen_[ep] = review_gen_; ctr_val_[ep] = 0; ctr_touched_.push_back(ep); }
-    const bool skip_elems = pruning_ && !(read_state(ep) & 2u);
+    const bool skip_elems = !(pbits(ep) & PB_BELOW);
     for (;;) {
       uint32_t ord = ctr_val_[ep]++;
       uint32_t ex = extra, o2 = ords;
@@ -1510,15 +1647,15 @@ int Flattener::ix_value(uint32_t path, uint32_t ords, int adepth, uint32_t extra
       stage_[row].row.lo = count;
       if (count) stage_[row].row.rev &= ROW_REV_MASK;
     }
-    if (dict_deep(path)) dict_row(path, meta, parse_json(js + at, (size_t)(ix_[ixp_ - 1] + 1 - at)));
-    else if (dict_wanted(path)) dict_row(path, meta, Value::array(ValueVec(count, Value::null())));
+    if (pbits(path) & PB_DEEP) dict_row(path, meta, parse_json(js + at, (size_t)(ix_[ixp_ - 1] + 1 - at)));
+    else if (pbits(path) & PB_DICT) dict_row(path, meta, Value::array(ValueVec(count, Value::null())));
     return T_ARRAY;
   }
   if (c == '"') {
     const char* v; uint32_t vn;
     if (!ix_string(&v, &vn)) return -1;
     emit_str_n(path, meta, v, vn);
-    if (dict_wanted(path)) dict_row(path, meta, Value::string(std::string(v, vn)));
+    if (pbits(path) & PB_DICT) dict_row(path, meta, Value::string(std::string(v, vn)));
     return T_STRING;
   }
   if (c == '}' || c == ']' || c == ':' || c == ',') return -1;
@@ -1581,6 +1718,7 @@ bool Flattener::fast_tree(const char* json, size_t len, uint32_t root, ObjFacts*
     return true;
   }
   p_ = json; e_ = json + len;
+  ix_json_ = json; ix_len_ = (uint32_t)len;   // (name8 reads eight bytes at a member name when they lie inside the document)
   t = fast_value(root, 0, 0, 0, 0);
   cur_facts_ = nullptr;
   if (t < 0) return false;
@@ -1680,6 +1818,7 @@ inline bool span_null(const Span& s) { return !s.set() || (s.n == 4 && memcmp(s.
 
 int Flattener::add_json_request(const RawReview& r, const NsCache& cache, HostTable* out, std::string* obj_key, const ExcludeFn* excluded) {
   t_ = out;
+  rev_cur_ = out->n_reviews % out->rpt;
   const size_t stage0 = stage_.size(), heap0 = out->heap.size();
   auto bail = [&]() { stage_.resize(stage0); out->heap.resize(heap0); return (int)DECLINED; };
   ctrs_.clear();
@@ -1827,6 +1966,7 @@ int Flattener::add_json(const RawReview& r, const NsCache& cache, HostTable* out
   if (r.kind == 0) return add_json_request(r, cache, out, obj_key, excluded);
   if (r.kind != 1) return DECLINED;
   t_ = out;
+  rev_cur_ = out->n_reviews % out->rpt;
   const size_t stage0 = stage_.size(), heap0 = out->heap.size();
   auto bail = [&]() { stage_.resize(stage0); out->heap.resize(heap0); return (int)DECLINED; };
   ctrs_.clear();

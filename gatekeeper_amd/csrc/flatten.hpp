@@ -121,6 +121,9 @@ class DictRegistry {
   uint64_t reads_gen() const { return reads_gen_.load(std::memory_order_acquire); }
   // bit 0: rows of `path_id` are read; bit 1: some pattern reaches `path_id` or below it (the parser must visit it)
   uint32_t read_state(const PathDict& dict, uint32_t path_id) const;
+  // the member names through which some pattern (of the read set or of anything else the flattener acts on) goes on below
+  // `path_id`; false: some pattern continues with a step that takes any name -- every member must be looked at
+  bool child_names(const PathDict& dict, uint32_t path_id, std::vector<std::string>* names) const;
   DictRegistry& counting() { std::unique_lock<std::shared_mutex> l(mu_); if (!counting_) counting_.reset(new DictRegistry()); return *counting_; }
   const DictRegistry* counting_if_any() const { std::shared_lock<std::shared_mutex> l(mu_); return counting_.get(); }
  private:
@@ -275,7 +278,7 @@ struct RawReview {
 class Flattener {
  public:
   explicit Flattener(PathDict* dict, const DictRegistry* reg = nullptr);
-  void set_pruning(bool on) { pruning_ = on && reg_ != nullptr; }
+  void set_pruning(bool on) { const bool p = on && reg_ != nullptr; if (p != pruning_) { pbits_.clear(); kid_filter_.clear(); kid_arena_.clear(); } pruning_ = p; }
   // A Flattener may serve many tables one after the other (engine.cpp keeps one per host worker thread: its member-name
   // table, its path caches and its memo of dictionary answers then survive from batch to batch instead of being rebuilt --
   // through the engine's shared, locked structures -- by every thread for every table).  begin_table() starts a table:
@@ -317,6 +320,19 @@ class Flattener {
   bool key_wanted(uint32_t path);     // do the rows of `path` lead per-element messages? (DictRegistry::add_key)
   // GK_TABLE_PRUNED: rows only for the registry's read set, subtrees nothing reaches into are validated and walked past
   bool pruning_ = false;
+  // everything the hot path asks about a path, in one byte (lazily derived from the caches above; dropped with them)
+  enum : uint8_t { PB_KNOWN = 1, PB_ROW = 2 /* rows of the path are kept */, PB_BELOW = 4 /* the parser must visit it */, PB_VALUE = 8, PB_KEY = 16, PB_DICT = 32, PB_GUARD = 64, PB_DEEP = 128 };
+  std::vector<uint8_t> pbits_;
+  // WANTED MEMBERS of an object path in a pruned table (round 4): when no row of the object itself is kept, only the members some
+  // pattern names can matter -- the others are walked past without a path id (no hashing of label keys, env names, port fields)
+  struct KidEnt { uint32_t id, off, len; };
+  struct KidFilter { uint8_t state = 0 /* 0 unknown, 1 every member, 2 the list */; std::vector<KidEnt> kids; };
+  std::vector<KidFilter> kid_filter_;
+  std::string kid_arena_;
+  const KidFilter* kid_filter(uint32_t path);   // nullptr: every member is looked up
+  uint32_t rev_cur_ = 0;              // the current review's number inside its row group (every row carries it)
+  uint8_t pbits_slow(uint32_t path);
+  uint8_t pbits(uint32_t path) { if (path < pbits_.size()) { const uint8_t b = pbits_[path]; if (b) return b; } return pbits_slow(path); }
   uint32_t read_state(uint32_t path);   // DictRegistry::read_state, cached per path
   bool emit_row_wanted(uint32_t path) { return !pruning_ || (read_state(path) & 1u); }
   bool walk_always(uint32_t parent, uint32_t ch);
@@ -353,14 +369,14 @@ class Flattener {
   // ---- fast ingest state
   struct Captured { const char* p = nullptr; uint32_t n = 0; bool set = false; };   // a string value seen at a known path
   struct ObjFacts { Captured api_version, kind, name, ns, gname; bool labels_bad = false; bool present = false; };
-  struct KeySlot { uint64_t hash = 0; uint32_t parent = 0, id = 0, off = 0, len = 0; bool used = false; };
+  struct KeySlot { uint64_t hash = 0, first8 = 0 /* the name's first eight bytes, zero-padded */; uint32_t parent = 0, id = 0, off = 0, len = 0; bool used = false; };
   std::vector<KeySlot> key_tab_;      // open addressing: (parent path, member name) -> child path
   std::string key_arena_;
   size_t key_count_ = 0, last_slot_ = 0;
   // PREDICTED children (round 4): objects of one kind list their members in one order, so the i-th member of the object at path P
   // is, nearly always, the member that was i-th there last time -- one length compare + memcmp instead of hashing the name.
   // pred_[P] = what the members of the most recent object at P were, by position (id kNone: nothing predicted yet)
-  struct PredEnt { uint32_t id = 0xFFFFFFFFu, off = 0, len = 0; };
+  struct PredEnt { uint64_t first8 = 0; uint32_t id = 0xFFFFFFFFu, off = 0, len = 0; };
   std::vector<std::vector<PredEnt>> pred_;
   uint32_t fast_child_at(uint32_t parent, uint32_t pos, const char* key, uint32_t len);
   std::vector<uint32_t> ctr_gen_, ctr_val_;   // per element path: review generation / running ordinal
@@ -393,6 +409,8 @@ class Flattener {
   void env_init();
   void fast_match_facts_n(const ObjFacts& f, bool ns_defined, const std::string& ns_name, bool is_old);
   uint32_t fast_child(uint32_t parent, const char* key, uint32_t len);
+  uint32_t fast_child_w(uint32_t parent, const char* key, uint32_t len, uint64_t w8);
+  uint64_t name8(const char* key, uint32_t len) const;
   int fast_value(uint32_t path, uint32_t ords, int adepth, uint32_t extra, int depth);   // -> RowType of the value, -1 = bail
   bool fast_string(const char** s, uint32_t* n);   // decodes the string at p_ (views the text when it has no escapes)
   bool fast_tree(const char* json, size_t len, uint32_t root, ObjFacts* facts, int* type);
