@@ -370,7 +370,12 @@ struct gk_table {
   DevPlan* cached_plan = nullptr;
   const HostPlan* cached_host = nullptr;
   std::vector<uint32_t> slot_path;          // path of each slot of the table's row-group index
-  std::vector<std::string> obj_keys;        // per review: group \0 version \0 kind \0 namespace \0 name (audit order, manager.go:118-138)
+  // per review: group \0 version \0 kind \0 namespace \0 name (audit order, manager.go:118-138) -- the bytes in one arena per host
+  // thread's part, (offset, length) per review: a std::string per review was a malloc and a free per review
+  std::vector<std::string> key_arena;
+  std::vector<std::pair<uint32_t, uint32_t>> key_span;
+  size_t key_per_part = 1;
+  std::string_view obj_key(size_t i) const { const auto& sp = key_span[i]; return std::string_view(key_arena[i / key_per_part].data() + sp.first, sp.second); }
   std::vector<uint32_t> order, grp;         // reviews sorted by obj_keys / dense rank with ties equal (built by the first gk_table_topk)
   uint32_t last_nc = 0;
   std::vector<uint32_t> last_ids;
@@ -1145,7 +1150,7 @@ int gk_table_create(gk_engine* e, const gk_review_in* reviews, size_t n, uint32_
     t->eng = e;
     bool keep = flags & GK_TABLE_KEEP_DOCS;
     t->review_errors.resize(n);
-    t->obj_keys.resize(n);
+    t->key_span.assign(n, {0u, 0u});
     if (keep) t->docs.resize(n);
     if ((flags & GK_TABLE_KEEP_TEXT) && !keep) t->texts.assign(reviews, reviews + n);
     const auto t_begin = std::chrono::steady_clock::now();
@@ -1182,6 +1187,8 @@ int gk_table_create(gk_engine* e, const gk_review_in* reviews, size_t n, uint32_
     if (const char* ht = getenv("GK_HOST_THREADS")) n_threads = std::max(1, atoi(ht));
     n_threads = std::min(n_threads, std::max<size_t>(n_tiles, 1));
     const size_t tiles_per = (n_tiles + n_threads - 1) / std::max<size_t>(n_threads, 1);
+    t->key_per_part = std::max<size_t>(1, tiles_per * rpt);
+    t->key_arena.assign(std::max<size_t>(n_threads, 1), std::string());
     const bool slow_only = keep || getenv("GK_SLOW_INGEST") != nullptr;
     std::vector<HostTable> parts(n_threads);
     std::vector<std::string> part_err(n_threads);
@@ -1220,6 +1227,10 @@ int gk_table_create(gk_engine* e, const gk_review_in* reviews, size_t n, uint32_
             parts[w].heap.presize(jb / 4 + 65536);
           }
         }
+        std::string key_scratch;
+        std::string& arena = t->key_arena[w];
+        arena.reserve((hi - lo) * 40);
+        auto put_key = [&](size_t i, const std::string& k) { t->key_span[i] = {(uint32_t)arena.size(), (uint32_t)k.size()}; arena += k; };
         for (size_t i = lo; i < hi; i++) {
           const gk_review_in& r = reviews[i];
           if (i + 2 < hi && reviews[i + 2].json) {   // the text of the review after next: first touched by the scanner otherwise, a DRAM round trip per line
@@ -1232,8 +1243,8 @@ int gk_table_create(gk_engine* e, const gk_review_in* reviews, size_t n, uint32_
             rr.kind = r.kind; rr.source = r.source; rr.json = r.json; rr.json_len = r.json_len;
             rr.ns_json = r.namespace_json; rr.ns_len = r.namespace_len; rr.nsobj_json = r.ns_object_json; rr.nsobj_len = r.ns_object_len;
             rr.operation = r.operation;
-            int rc = fl.add_json(rr, e->ns_cache, &parts[w], &t->obj_keys[i], excl.empty() ? nullptr : &excl_fn);
-            if (rc == Flattener::ADDED) { if (statuses) statuses[i] = GK_OK; part_fast[w]++; continue; }
+            int rc = fl.add_json(rr, e->ns_cache, &parts[w], &key_scratch, excl.empty() ? nullptr : &excl_fn);
+            if (rc == Flattener::ADDED) { put_key(i, key_scratch); if (statuses) statuses[i] = GK_OK; part_fast[w]++; continue; }
             if (rc == Flattener::EXCLUDED) {
               if (statuses) statuses[i] = GK_REVIEW_EXCLUDED;
               fl.add_skipped(&parts[w]);
@@ -1272,7 +1283,7 @@ int gk_table_create(gk_engine* e, const gk_review_in* reviews, size_t n, uint32_
               key = g_; key.push_back('\0'); key += v_; key.push_back('\0'); key += k_; key.push_back('\0');
               key += obj_string(*o, "metadata", "namespace"); key.push_back('\0'); key += obj_string(*o, "metadata", "name");
             }
-            t->obj_keys[i] = std::move(key);
+            put_key(i, key);
           }
           if (st == GK_ERR_REVIEW) fl.add_skipped(&parts[w]);   // HandleReview's error is the caller's answer: nothing is evaluated
           else fl.add(doc, &parts[w]);
@@ -1365,7 +1376,7 @@ int gk_table_create(gk_engine* e, const gk_review_in* reviews, size_t n, uint32_
       for (auto& pd : part_digest) for (uint64_t x : pd) mix(x);
       for (uint32_t f : H.rflags) mix(f);
       for (uint32_t sp : H.slot_path) mix(sp);
-      for (auto& k : t->obj_keys) for (unsigned char c : k) mix(c);
+      for (size_t i = 0; i < n; i++) for (unsigned char c : t->obj_key(i)) mix(c);
       t->stats.digest = d;
     }
     const auto t_indexed = std::chrono::steady_clock::now();
@@ -1645,11 +1656,11 @@ int gk_table_topk(gk_engine* e, gk_table* t, uint32_t k, gk_topk_out** out) {
       t->order.resize(t->n_reviews);
       for (uint32_t i = 0; i < t->n_reviews; i++) t->order[i] = i;
       // field-wise order == order of the \0-joined keys (\0 sorts below every byte a name can contain)
-      std::stable_sort(t->order.begin(), t->order.end(), [&](uint32_t a, uint32_t b) { return t->obj_keys[a] < t->obj_keys[b]; });
+      std::stable_sort(t->order.begin(), t->order.end(), [&](uint32_t a, uint32_t b) { return t->obj_key(a) < t->obj_key(b); });
       t->grp.resize(t->n_reviews);
       uint32_t gid = 0;
       for (uint32_t p = 0; p < t->n_reviews; p++) {
-        if (p && t->obj_keys[t->order[p]] != t->obj_keys[t->order[p - 1]]) gid++;
+        if (p && t->obj_key(t->order[p]) != t->obj_key(t->order[p - 1])) gid++;
         t->grp[p] = gid;
       }
     }

@@ -630,16 +630,15 @@ uint32_t Flattener::read_state(uint32_t path) {
 
 const Flattener::KidFilter* Flattener::kid_filter(uint32_t path) {
   if (path >= kid_filter_.size()) kid_filter_.resize((size_t)path * 2 + 64);
-  if (kid_filter_[path].state == 0) {
+  if (!kid_filter_[path]) {
     std::vector<std::string> names;
     const bool listed = reg_->child_names(*dict_, path, &names) && names.size() <= 24;
-    std::vector<KidEnt> kids;
-    if (listed) for (const std::string& n : names) { kids.push_back({child(path, n), (uint32_t)kid_arena_.size(), (uint32_t)n.size()}); kid_arena_ += n; }
-    if (path >= kid_filter_.size()) kid_filter_.resize((size_t)path * 2 + 64);   // (child() does not touch it; belt and braces)
-    kid_filter_[path].kids = std::move(kids);
-    kid_filter_[path].state = listed ? 2 : 1;
+    std::unique_ptr<KidFilter> f(new KidFilter());
+    if (listed) for (const std::string& n : names) { f->kids.push_back({child(path, n), (uint32_t)kid_arena_.size(), (uint32_t)n.size()}); kid_arena_ += n; }
+    f->state = listed ? 2 : 1;
+    kid_filter_[path] = std::move(f);
   }
-  return kid_filter_[path].state == 2 ? &kid_filter_[path] : nullptr;
+  return kid_filter_[path]->state == 2 ? kid_filter_[path].get() : nullptr;
 }
 
 uint8_t Flattener::pbits_slow(uint32_t path) {

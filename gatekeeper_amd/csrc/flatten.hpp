@@ -327,7 +327,7 @@ class Flattener {
   // pattern names can matter -- the others are walked past without a path id (no hashing of label keys, env names, port fields)
   struct KidEnt { uint32_t id, off, len; };
   struct KidFilter { uint8_t state = 0 /* 0 unknown, 1 every member, 2 the list */; std::vector<KidEnt> kids; };
-  std::vector<KidFilter> kid_filter_;
+  std::vector<std::unique_ptr<KidFilter>> kid_filter_;   // (by path; the entries stay where they are when the vector grows: a parse holds one per open object)
   std::string kid_arena_;
   const KidFilter* kid_filter(uint32_t path);   // nullptr: every member is looked up
   uint32_t rev_cur_ = 0;              // the current review's number inside its row group (every row carries it)
