@@ -516,6 +516,11 @@ def main():
     # end-to-end leg: JSON -> parse -> HandleReview -> flatten -> HBM (this is what a non-resident review costs)
     table = drv.engine.create_table_native(batch.reviews, n_local, keep_docs=False, resident=True, keep_text=True, pruned=not getattr(args, "no_prune", False))   # (text kept by `batch`: RESULT totals below)
     st = table.stats()
+    st_again = None
+    if not args.lean and n_local <= 2_000_000:   # the same batch once more: what ingest costs once the host threads' caches, the staging pool and the path tables are warm
+        again = drv.engine.create_table_native(batch.reviews, n_local, keep_docs=False, resident=True, pruned=not getattr(args, "no_prune", False))
+        st_again = again.stats()
+        again.free()
     sweep = ShardedSweep(client, table=table, n=n_local, dist=dist, device=dev)
 
     def barrier():
@@ -597,6 +602,8 @@ def main():
                            "json_bytes": st["json_bytes"], "reviews_per_s": n_local / e2e_s if e2e_s > 0 else None,
                            "evals_per_s": nc * n_local / (e2e_s + dt / args.steps) if e2e_s > 0 else None,
                            "json_MBps": st["json_bytes"] / st["flatten_s"] / 1e6 if st["flatten_s"] > 0 else None,
+                           "second_table_of_the_same_batch": None if not st_again else {"flatten_s": st_again["flatten_s"], "h2d_s": st_again["upload_s"],
+                                                                                        "json_MBps": st_again["json_bytes"] / st_again["flatten_s"] / 1e6 if st_again["flatten_s"] > 0 else None},
                            "generate_s": t_gen},
         }
         # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes of this same command (bench.py

@@ -136,6 +136,27 @@ class DictRegistry {
   std::vector<std::pair<std::string, Pattern>> reads_;
   std::atomic<uint64_t> reads_gen_{0};
   void interest(std::vector<const Pattern*>* out) const;   // every pattern that makes the flattener do something below a path (caller holds mu_)
+  // What the patterns say about a concrete path is the same for every flattener of the engine: worked out once per path and state
+  // of the registry (a table part per host thread, 64 threads: each of them matching every path against every pattern was half
+  // the wall clock of a 200-template table's first ingest).  Dropped when gen() / reads_gen() move.
+  struct Facts { uint8_t known = 0, read = 0; bool guarded = false, valued = false, keyed = false; int pat = -1; };
+  enum : uint8_t { F_READ = 1, F_GUARD = 2, F_VALUE = 4, F_KEY = 8, F_PAT = 16 };
+  mutable std::shared_mutex fmu_;
+  mutable std::vector<Facts> facts_;
+  mutable std::unordered_map<uint32_t, std::pair<bool, std::vector<std::string>>> names_;
+  mutable uint64_t facts_stamp_ = ~0ull;
+  uint32_t read_state_now(const PathDict& dict, uint32_t path_id) const;
+  bool child_names_now(const PathDict& dict, uint32_t path_id, std::vector<std::string>* names) const;
+  uint64_t stamp() const { return gen() * 0x9E3779B97F4A7C15ull + reads_gen(); }
+  bool facts_get(uint64_t st, uint32_t path, uint8_t bit, Facts* out) const;
+  template <class F> void facts_put(uint64_t st, uint32_t path, uint8_t bit, F set) const {
+    if (st != stamp()) return;   // the registry moved while the fact was being worked out
+    std::unique_lock<std::shared_mutex> l(fmu_);
+    if (facts_stamp_ != st) { facts_.clear(); names_.clear(); facts_stamp_ = st; }
+    if (path >= facts_.size()) facts_.resize((size_t)path * 2 + 64);
+    set(facts_[path]);
+    facts_[path].known |= bit;
+  }
 };
 
 uint32_t hash32(const uint8_t* p, size_t n);
