@@ -646,6 +646,11 @@ def main():
                                  "cpu_loop_parity": {"n": ps.get("n"), "equal": ps.get("pairs_equal")},
                                  "totals": {"s": _sig((out.get("audit_result_totals") or {}).get("seconds"), 3), "rendered_share": _sig((out.get("audit_result_totals") or {}).get("rendered_share"), 3),
                                             "equal": ((out.get("audit_result_totals") or {}).get("host_pass_over_every_pair") or {}).get("equal")}}
+            e2e = out.get("end_to_end") or {}
+            again = e2e.get("second_table_of_the_same_batch") or {}
+            brief["configs2"]["ingest"] = {"first_table_json_MBps": _sig(e2e.get("json_MBps"), 4), "first_table_flatten_s": _sig(e2e.get("flatten_s"), 3),
+                                           "second_table_json_MBps": _sig(again.get("json_MBps"), 4), "second_table_flatten_s": _sig(again.get("flatten_s"), 3),
+                                           "host_threads": e2e.get("host_threads"), "host_cpus_usable": e2e.get("host_cpus_usable")}
             out["other_configs"] = brief
         print(json.dumps(out))
     if dist is not None:
