@@ -601,7 +601,7 @@ bool Flattener::guard_wanted(uint32_t path) {
   return d.gstate == 2;
 }
 
-void Flattener::dict_row(uint32_t path, uint32_t meta, const Value& leaf) {
+void Flattener::dict_row(uint32_t path, uint32_t meta, const Value& leaf, uint64_t* masks_out) {
   DictPath& d = dict_paths_[path];
   // containers count by type and size only (the registered expressions cannot look inside them: pe.cpp scalar_fns) -- unless
   // an expression of this path is DEEP (dexpr.hpp): then the leaf is the real sub-document and the memo goes by its text
@@ -628,6 +628,54 @@ void Flattener::dict_row(uint32_t path, uint32_t meta, const Value& leaf) {
   };
   one(reg_, d.pat, d.entries, d.memo, &masks[0]);
   if (!d.centries.empty()) one(reg_->counting_if_any(), d.cpat, d.centries, d.cmemo, &masks[1]);   // (<leaf>.$c: the counting plans' expressions)
+  if (masks_out) { masks_out[0] = masks[0]; masks_out[1] = masks[1]; return; }
+  for (int k = 0; k < 2; k++)
+    if (masks[k]) emit(dpaths[k], (meta & ~(uint32_t)ROW_TYPE_MASK & ~(uint32_t)ROW_STR_INLINE) | T_INT, (uint32_t)masks[k], (uint32_t)(masks[k] >> 32), true);
+}
+
+// dict_row for a STRING leaf given as bytes: the answers are remembered per path under the bytes themselves (no Value, no quoted
+// term text, no std::string key per row -- the dictionary leaves of a policy set are mostly strings: images, quantities, names)
+void Flattener::dict_row_str(uint32_t path, uint32_t meta, const char* s, uint32_t n) {
+  uint64_t h = 0x9E3779B97F4A7C15ull ^ ((uint64_t)n * 0xD6E8FEB86659FD93ull);
+  {
+    uint32_t i = 0;
+    for (; i + 8 <= n; i += 8) { uint64_t w; memcpy(&w, s + i, 8); h = (h ^ w) * 0x9FB21C651E98DF25ull; h ^= h >> 32; }
+    if (i < n) { uint64_t w = 0; memcpy(&w, s + i, n - i); h = (h ^ w) * 0x9FB21C651E98DF25ull; h ^= h >> 32; }
+    h |= 1;   // (0 marks an empty slot)
+  }
+  uint64_t masks[2] = {0, 0};
+  bool found = false;
+  {
+    DictPath& d = dict_paths_[path];
+    if (!d.smemo) { d.smemo.reset(new StrMemo()); d.smemo->tab.resize(256); }
+    StrMemo& M = *d.smemo;
+    size_t mask = M.tab.size() - 1, i = (size_t)(h >> 7) & mask;
+    for (; M.tab[i].hash; i = (i + 1) & mask) {
+      const StrMemo::Ent& e = M.tab[i];
+      if (e.hash == h && e.len == n && memcmp(M.arena.data() + e.off, s, n) == 0) { masks[0] = e.m[0]; masks[1] = e.m[1]; found = true; break; }
+    }
+  }
+  if (!found) {
+    dict_row(path, meta, Value::string(std::string(s, n)), masks);
+    DictPath& d = dict_paths_[path];
+    StrMemo& M = *d.smemo;
+    if (M.count < 65536) {
+      if ((M.count + 1) * 2 > M.tab.size()) {
+        std::vector<StrMemo::Ent> old;
+        old.swap(M.tab);
+        M.tab.resize(old.size() * 2);
+        const size_t mk = M.tab.size() - 1;
+        for (const StrMemo::Ent& e : old) if (e.hash) { size_t j = (size_t)(e.hash >> 7) & mk; while (M.tab[j].hash) j = (j + 1) & mk; M.tab[j] = e; }
+      }
+      const size_t mk = M.tab.size() - 1;
+      size_t j = (size_t)(h >> 7) & mk;
+      while (M.tab[j].hash) j = (j + 1) & mk;
+      M.tab[j] = StrMemo::Ent{h, (uint32_t)M.arena.size(), n, {masks[0], masks[1]}};
+      M.arena.append(s, n);
+      M.count++;
+    }
+  }
+  const uint32_t dpaths[2] = {dict_paths_[path].dpath, dict_paths_[path].cpath};
   for (int k = 0; k < 2; k++)
     if (masks[k]) emit(dpaths[k], (meta & ~(uint32_t)ROW_TYPE_MASK & ~(uint32_t)ROW_STR_INLINE) | T_INT, (uint32_t)masks[k], (uint32_t)(masks[k] >> 32), true);
 }
@@ -1656,7 +1704,7 @@ int Flattener::ix_value(uint32_t path, uint32_t ords, int adepth, uint32_t extra
         const char* v; uint32_t vn;
         if (!ix_string(&v, &vn)) return -1;
         emit_str_n(ch, meta, v, vn);
-        if (pbits(ch) & PB_DICT) dict_row(ch, meta, Value::string(std::string(v, vn)));
+        if (pbits(ch) & PB_DICT) dict_row_str(ch, meta, v, vn);
         if (v == scratch_.data()) { scratch_keep_.emplace_back(new std::string(v, vn)); v = scratch_keep_.back()->data(); }
         want->p = v; want->n = vn; want->set = true;
         t = T_STRING;
@@ -1718,7 +1766,7 @@ int Flattener::ix_value(uint32_t path, uint32_t ords, int adepth, uint32_t extra
     const char* v; uint32_t vn;
     if (!ix_string(&v, &vn)) return -1;
     emit_str_n(path, meta, v, vn);
-    if (pbits(path) & PB_DICT) dict_row(path, meta, Value::string(std::string(v, vn)));
+    if (pbits(path) & PB_DICT) dict_row_str(path, meta, v, vn);
     return T_STRING;
   }
   if (c == '}' || c == ']' || c == ':' || c == ',') return -1;

@@ -1,6 +1,6 @@
 set -u
 mkdir -p gpurun_out
-for th in 64 32 16; do
+for th in 64 32; do
   GK_PROFILE_HOST=1 GK_HOST_THREADS=$th timeout 300 python bench.py --no-other-configs --no-cpu-baseline --oracle-sample 0 --steps 20 --warmup 5 > gpurun_out/r4o_th$th.json 2> gpurun_out/r4o_th$th.err
   grep "gkgpu host" gpurun_out/r4o_th$th.err | head -3
   python - gpurun_out/r4o_th$th.json <<'PY'
