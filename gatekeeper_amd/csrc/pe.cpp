@@ -8,6 +8,8 @@
 #include "builtins.hpp"
 #include "regex.hpp"
 #include "plan.hpp"
+#include <atomic>
+#include <chrono>
 
 namespace gk {
 
@@ -1914,7 +1916,7 @@ FP PE::is_string_f(const SVP& v) {
 }
 
 // ================================================================================================ Template
-Template::~Template() { for (const std::string& n : deep_fns_) dx_unregister_user(n); }
+Template::~Template() { for (const std::string& n : deep_fns_) dx_unregister_user(n); drop_cindex(); }
 Template::Template(const std::string& rego, const std::vector<std::string>& libs) {
   modules_.push_back(parse_rego(rego));
   for (auto& l : libs) {
@@ -2183,13 +2185,31 @@ Template::CountInfo Template::compile_all(const Value& parameters, int* next_qua
 }
 
 std::vector<Violation> Template::render(const Value& review, const Value& parameters, const Value& inventory) const {
-  int nq = 0;
-  PE pe(*this, parameters, sv_const(review), inventory, true, &nq);
-  pe.index_rules();
-  SVP set = pe.violation_set();
+  // GK_RENDER=pe: the partial evaluator only (as before round 4); GK_RENDER_CHECK=1: both evaluators, a difference is an error
+  static const bool pe_only = getenv("GK_RENDER") && std::string(getenv("GK_RENDER")) == "pe";
+  static const bool check = getenv("GK_RENDER_CHECK") != nullptr;
+  Value setv;
+  const bool fast = !pe_only && render_fast(review, parameters, inventory, &setv);
+  static const bool stats = getenv("GK_RENDER_STATS") != nullptr;   // debugging aid: how many calls each evaluator served
+  if (stats) {
+    static std::atomic<long> n_fast{0}, n_pe{0};
+    static const int reg = atexit([] {});
+    (void)reg;
+    const long a = fast ? ++n_fast : n_fast.load(), b = fast ? n_pe.load() : ++n_pe;
+    if (((a + b) & 1023) == 0 || !fast) fprintf(stderr, "[gkgpu render] concrete evaluator %ld calls, partial evaluator %ld (last: %s)\n", a, b, pkg_name_.c_str());
+  }
+  if (!fast || check) {
+    int nq = 0;
+    PE pe(*this, parameters, sv_const(review), inventory, true, &nq);
+    pe.index_rules();
+    SVP set = pe.violation_set();
+    if (set->kind != SV::CONST) throw RegoError("internal: concrete evaluation left a symbolic residue");
+    if (fast && check && !(set->c == setv)) throw RegoError("internal: the concrete evaluators disagree: " + to_term_string(setv) + " against " + to_term_string(set->c));
+    setv = set->c;
+  }
   std::vector<Violation> out;
-  if (set->kind != SV::CONST) throw RegoError("internal: concrete evaluation left a symbolic residue");
-  for (const Value& v : set->c.items()) {
+  if (!setv.is_set() && !setv.is_array()) return out;
+  for (const Value& v : setv.items()) {
     if (!v.is_object()) continue;
     const Value* m = v.get("msg");
     if (!m || !m->is_string()) continue;

@@ -10,6 +10,7 @@
 #pragma once
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -171,8 +172,16 @@ class Template : public std::enable_shared_from_this<Template> {
   bool references_inventory() const { return uses_data_; }
   ~Template();   // drops the deep-expression closures registered for this template (dexpr.hpp)
 
+  // (ceval.cpp) the concrete evaluator render() tries first: the violation set as a Value; false = not evaluated there
+  struct CIndex;
+  bool render_fast(const Value& review, const Value& parameters, const Value& inventory, Value* set) const;
+
  private:
   friend class PE;
+  const CIndex& cindex() const;   // what is known about the terms before any review is seen, built on first use
+  void drop_cindex();
+  mutable std::once_flag cindex_once_;
+  mutable CIndex* cindex_ = nullptr;
   std::vector<Module> modules_;
   std::map<std::pair<std::string, std::string>, std::vector<const Rule*>> rules_;   // (pkg, name)
   std::string pkg_name_;
