@@ -2186,8 +2186,10 @@ Template::CountInfo Template::compile_all(const Value& parameters, int* next_qua
 
 std::vector<Violation> Template::render(const Value& review, const Value& parameters, const Value& inventory) const {
   // GK_RENDER=pe: the partial evaluator only (as before round 4); GK_RENDER_CHECK=1: both evaluators, a difference is an error
-  static const bool pe_only = getenv("GK_RENDER") && std::string(getenv("GK_RENDER")) == "pe";
-  static const bool check = getenv("GK_RENDER_CHECK") != nullptr;
+  // (read per call: the test suite switches the cross-check on for everything it renders, tests/conftest.py)
+  const char* const mode = getenv("GK_RENDER");
+  const bool pe_only = mode && strcmp(mode, "pe") == 0;
+  const bool check = getenv("GK_RENDER_CHECK") != nullptr;
   Value setv;
   const bool fast = !pe_only && render_fast(review, parameters, inventory, &setv);
   static const bool stats = getenv("GK_RENDER_STATS") != nullptr;   // debugging aid: how many calls each evaluator served
