@@ -68,13 +68,18 @@ class CEval {
  public:
   typedef Template::CIndex CIndex;
   typedef CIndex::RuleSet RuleSet;
-  CEval(const CIndex& ix, const std::string& main_pkg, const Value& params, const Value& review, const Value& inventory) : ix_(ix), main_pkg_(main_pkg), inventory_(inventory) {
+  CEval(const CIndex& ix, const std::string& main_pkg, const Value& params, const Value& review, const Value& inventory)
+      : ix_(ix), main_pkg_(main_pkg), inventory_(inventory), env_(scratch().env), sols_pool_(scratch().sols) {
+    static const Value k_parameters = Value::string("parameters"), k_review = Value::string("review"), empty_object = Value::object({});
     ValuePairs in;
-    in.emplace_back(Value::string("parameters"), params.defined() ? params : Value::object({}));
-    in.emplace_back(Value::string("review"), review);
+    in.reserve(2);
+    in.emplace_back(k_parameters, params.defined() ? params : empty_object);
+    in.emplace_back(k_review, review);
     input_ = Value::object(std::move(in));
-    env_.reserve(64);
+    env_.clear();
+    if (env_.capacity() < 64) env_.reserve(64);
   }
+  ~CEval() { env_.clear(); for (auto& s : sols_pool_) { s->binds.clear(); s->ends.clear(); } }   // (the values go; the capacity stays for the thread's next call)
   Value violation_set() {
     const RuleSet* rs = ix_.find(main_pkg_, "violation");
     if (!rs) return Value::set({});
@@ -88,13 +93,31 @@ class CEval {
   const std::string& main_pkg_;
   Value input_, inventory_;
   struct Bind { const std::string* name; Value v; bool shadow; };
-  std::vector<Bind> env_;
+  struct Sols { std::vector<Bind> binds; std::vector<uint32_t> ends; };
+  // the binding stack and the solution lists keep their capacity from one call of a thread to its next (an evaluation allocates
+  // for the values it makes, not for its own bookkeeping)
+  struct Scratch { std::vector<Bind> env; std::vector<std::unique_ptr<Sols>> sols; std::vector<std::unique_ptr<ValueVec>> vecs; };
+  // a value list for the duration of a scope (call arguments, the members a comprehension collects), from the thread's pool
+  struct Lease {
+    CEval& e; ValueVec& v;
+    explicit Lease(CEval& ev) : e(ev), v(ev.lease()) {}
+    ~Lease() { v.clear(); e.vec_depth_--; }
+  };
+  ValueVec& lease() {
+    std::vector<std::unique_ptr<ValueVec>>& p = scratch().vecs;
+    if (vec_depth_ >= p.size()) p.emplace_back(new ValueVec());
+    ValueVec& v = *p[vec_depth_++];
+    v.clear();
+    return v;
+  }
+  size_t vec_depth_ = 0;
+  static Scratch& scratch() { static thread_local Scratch s; return s; }
+  std::vector<Bind>& env_;
   size_t frame_ = 0;   // bindings below belong to callers: a rule body does not see them
   int depth_ = 0;
   struct RuleVal { bool done = false, in_progress = false; std::vector<Value> alts; };
   std::map<const RuleSet*, RuleVal> cache_;
-  struct Sols { std::vector<Bind> binds; std::vector<uint32_t> ends; };
-  std::vector<std::unique_ptr<Sols>> sols_pool_;
+  std::vector<std::unique_ptr<Sols>>& sols_pool_;
   size_t sols_depth_ = 0;
 
   // ---- bindings
@@ -305,14 +328,17 @@ class CEval {
         break;
       }
       case Term::Array: case Term::SetLit: {
-        ValueVec acc;
+        Lease L(*this);
+        ValueVec& acc = L.v;
         seq(t.args, 0, acc, r, [&]() { const Value v = t.kind == Term::Array ? Value::array(acc) : Value::set(acc); kv(v); });
         break;
       }
       case Term::Object: {
-        ValueVec acc;
+        Lease L(*this);
+        ValueVec& acc = L.v;
         seq(t.args, 0, acc, r, [&]() {
           ValuePairs p;
+          p.reserve(acc.size() / 2);
           for (size_t i = 0; i + 1 < acc.size(); i += 2) p.emplace_back(acc[i], acc[i + 1]);
           const Value v = Value::object(std::move(p));
           kv(v);
@@ -320,9 +346,13 @@ class CEval {
         break;
       }
       case Term::ArrComp: case Term::SetComp: {
-        ValueVec items;
-        body(*t.body, r, [&]() { term(*t.head, r, [&](const Value& h) { items.push_back(h); }); });
-        const Value v = t.kind == Term::ArrComp ? Value::array(std::move(items)) : Value::set(std::move(items));
+        Value v;
+        {
+          Lease L(*this);
+          ValueVec& items = L.v;
+          body(*t.body, r, [&]() { term(*t.head, r, [&](const Value& h) { items.push_back(h); }); });
+          v = t.kind == Term::ArrComp ? Value::array(items) : Value::set(items);
+        }
         kv(v);
         break;
       }
@@ -392,7 +422,8 @@ class CEval {
     auto it = ix_.calls.find(&t);
     if (it == ix_.calls.end() || !it->second.known) throw CFallback();
     const CIndex::CallInfo& ci = it->second;
-    ValueVec args;
+    Lease L(*this);
+    ValueVec& args = L.v;
     seq(t.args, 0, args, r, [&]() {
       if (ci.user) { call_function(ci.user, args, kv); return; }
       const Value v = call_builtin(ci.builtin, args);
@@ -407,6 +438,7 @@ class CEval {
     if (++depth_ > 64) throw CFallback();   // (the general evaluator words the recursion error)
     const ValueVec args = args_in;   // (the caller's accumulator moves on)
     std::vector<Value> results;
+    results.reserve(2);
     const size_t saved_frame = frame_, mark = env_.size();
     for (const Rule* fr : *rules) {
       if (fr->kind != Rule::Function || fr->args.size() != args.size()) continue;
@@ -443,12 +475,13 @@ class CEval {
       const Rule::Kind kind = (*rs)[0]->kind;
       if (kind == Rule::Function) throw CFallback();
       if (kind == Rule::PartialSet) {
-        ValueVec items;
+        Lease L(*this);
+        ValueVec& items = L.v;
         for (const Rule* r : *rs) {
           frame_ = env_.size();
           body(r->body, r, [&]() { term(*r->key, r, [&](const Value& k) { items.push_back(k); }); });
         }
-        alts.push_back(Value::set(std::move(items)));
+        alts.push_back(Value::set(items));
       } else if (kind == Rule::PartialObject) {
         ValuePairs pairs;
         for (const Rule* r : *rs) {
