@@ -114,11 +114,26 @@ inline Value Value::set(ValueVec x) {
   Value v; v.kind = Set; v.arr = std::make_shared<const ValueVec>(std::move(x)); return v;
 }
 inline Value Value::object(ValuePairs x) {
-  std::stable_sort(x.begin(), x.end(), [](const std::pair<Value, Value>& p, const std::pair<Value, Value>& q) { return p.first < q.first; });
-  // last write wins for duplicate keys
-  ValuePairs out;
-  for (auto& p : x) { if (!out.empty() && out.back().first == p.first) out.back().second = p.second; else out.push_back(p); }
-  Value v; v.kind = Object; v.obj = std::make_shared<const ValuePairs>(std::move(out)); return v;
+  // sorted by key, stable (the later of two equal keys stays behind the earlier one), then last write wins -- all in place: small
+  // objects (nearly all of them) by insertion, which needs no scratch buffer; no second vector for the result
+  bool sorted = true;
+  for (size_t i = 1; i < x.size() && sorted; i++) if (!(x[i - 1].first < x[i].first)) sorted = false;   // (strictly ascending: nothing to do at all)
+  if (!sorted) {
+    if (x.size() <= 24) {
+      for (size_t i = 1; i < x.size(); i++) {
+        size_t j = i;
+        while (j > 0 && x[i].first < x[j - 1].first) j--;
+        if (j != i) std::rotate(x.begin() + j, x.begin() + i, x.begin() + i + 1);
+      }
+    } else std::stable_sort(x.begin(), x.end(), [](const std::pair<Value, Value>& p, const std::pair<Value, Value>& q) { return p.first < q.first; });
+    size_t w = 0;
+    for (size_t i = 0; i < x.size(); i++) {
+      if (w > 0 && x[w - 1].first == x[i].first) x[w - 1].second = std::move(x[i].second);
+      else { if (w != i) x[w] = std::move(x[i]); w++; }
+    }
+    x.resize(w);
+  }
+  Value v; v.kind = Object; v.obj = std::make_shared<const ValuePairs>(std::move(x)); return v;
 }
 inline const Value* Value::get(const Value& key) const {
   if (kind != Object) return nullptr;
@@ -327,15 +342,16 @@ class JsonParser {
       p_++; ws();
       ValuePairs pairs;
       if (p_ < e_ && *p_ == '}') { p_++; return Value::object(std::move(pairs)); }
+      pairs.reserve(8);
       for (;;) {
         ws();
         if (p_ >= e_ || *p_ != '"') fail("expected object key");
-        std::string k = str();
+        Value kv = key();
         ws();
         if (p_ >= e_ || *p_ != ':') fail("expected ':'");
         p_++; ws();
         Value v = value(depth + 1);
-        pairs.emplace_back(Value::string(std::move(k)), std::move(v));
+        pairs.emplace_back(std::move(kv), std::move(v));
         ws();
         if (p_ < e_ && *p_ == ',') { p_++; continue; }
         if (p_ < e_ && *p_ == '}') { p_++; break; }
@@ -362,6 +378,24 @@ class JsonParser {
     if (c == 'f') { lit("false"); return Value::boolean(false); }
     if (c == 'n') { lit("null"); return Value::null(); }
     return number();
+  }
+  // An object key as a Value.  Member names repeat from document to document: short names without escapes come from a small
+  // per-thread table of shared string values (no allocation, no copy of the bytes); anything else is decoded as any string is.
+  Value key() {
+    const char* q = p_ + 1;
+    while (q < e_ && *q != '"' && *q != '\\' && q - p_ <= 40) q++;
+    if (q >= e_ || *q != '"') return Value::string(str());
+    const char* s = p_ + 1;
+    const size_t n = (size_t)(q - s);
+    struct Ent { uint64_t h = 0; Value v; };
+    static thread_local std::vector<Ent> tab(1024);
+    uint64_t h = 1469598103934665603ull ^ (n * 0x9E3779B97F4A7C15ull);
+    for (size_t i = 0; i < n; i++) { h ^= (unsigned char)s[i]; h *= 1099511628211ull; }
+    h |= 1;
+    Ent& e = tab[(size_t)(h >> 20) & 1023];
+    if (e.h != h || e.v.s->size() != n || memcmp(e.v.s->data(), s, n) != 0) { e.h = h; e.v = Value::string(std::string(s, n)); }
+    p_ = q + 1;
+    return e.v;
   }
   void lit(const char* w) {
     size_t n = strlen(w);
