@@ -423,7 +423,7 @@ def main():
     ap.add_argument("--stream-batches", type=int, default=16, help="timed batches over all ranks")
     ap.add_argument("--stream-unique", type=int, default=8, help="distinct pre-generated batches per rank (cycled)")
     ap.add_argument("--offered", type=float, default=1e6, help="offered load in reviews/s over all ranks (0: closed loop, as fast as the pipeline goes)")
-    ap.add_argument("--oracle-sample", type=int, default=262144, help="objects of the timed table the pure-Python oracle re-evaluates (parity_python_oracle)")
+    ap.add_argument("--oracle-sample", type=int, default=1048576, help="objects of the timed table the pure-Python oracle re-evaluates (parity_python_oracle)")
     ap.add_argument("--side-oracle-sample", type=int, default=16384, help="... of every other_configs table")
     ap.add_argument("--no-prune", action="store_true", help="tables with a row for every key path of every object (rounds 1-3) instead of GK_TABLE_PRUNED: rows of the key "
                     "paths the loaded constraints read; the kernel's algorithmic bytes are the same, the ingest and the table are not")
