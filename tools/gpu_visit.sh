@@ -7,6 +7,7 @@
 #   lean       bench.py --lean --steps 50 (the headline kernel only: tuning runs)
 #   stats      rocprofv3 --kernel-trace --stats of the lean command
 #   pmc        rocprofv3 --pmc passes of the lean command (SQ, FETCH_SIZE, WRITE_SIZE: separate passes, --kernel-trace only)
+#   pmc4       the SQ and FETCH_SIZE passes on bench.py --config 4 --lean (the 200-template corpus kernel)
 #   c1 | c4    bench.py --config 1 | 4 --lean
 #   stream     bench.py --config 4 --streaming (offered 1 M/s) and closed loop
 #   env:X=Y    export X=Y for the following stages;  unset:X
@@ -66,6 +67,10 @@ PY
          run_pmc fetch FETCH_SIZE
          run_pmc write WRITE_SIZE
          pmc_summary sq fetch write | tee gpurun_out/${tag}_pmc_summary.txt;;
+    pmc4) run_pmc4() { name=$1; shift; timeout 400 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d gpurun_out/${tag}_pmc_$name -o $name -- python bench.py --config 4 --steps 5 --warmup 1 --lean > /dev/null 2> gpurun_out/${tag}_pmc_$name.err; }
+         run_pmc4 sq4 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
+         run_pmc4 fetch4 FETCH_SIZE
+         pmc_summary sq4 fetch4 | tee gpurun_out/${tag}_pmc4_summary.txt;;
     *) echo "unknown stage $stage";;
   esac
 done
