@@ -1677,7 +1677,9 @@ int Flattener::ix_value(uint32_t path, uint32_t ords, int adepth, uint32_t extra
         if (ch == PathDict::kNone) {   // a member no pattern names: its value is checked and walked past
           if (ixp_ >= ix_n_ || js[ix_[ixp_]] != ':') return -1;
           ixp_++;
-          if (ix_skip(depth + 1) < 0) return -1;
+          const int ts = ix_skip(depth + 1);
+          if (ts < 0) return -1;
+          if (cur_facts_ && depth == 2 && path == cap_[cur_root_ == id_old_ ? 1 : 0].labels && ts != T_STRING) cur_facts_->labels_bad = true;   // (GetLabels() needs every value to be a string, read or not)
           count++;
           if (ixp_ >= ix_n_) return -1;
           const char d = js[ix_[ixp_]];

@@ -32,11 +32,15 @@ def _raw(text, ns=None, nsobj=None, op="", source="Original"):
     return r
 
 
-@pytest.fixture(params=["index", "bytes"])
+@pytest.fixture(params=["index", "bytes", "index-pruned", "bytes-pruned"])
 def tokens(request, monkeypatch):
-    """both scanners of the fast path: the structural index (AVX-512 hosts) and the byte-at-a-time one every other host runs"""
-    if request.param == "bytes":
+    """both scanners of the fast path -- the structural index (AVX-512 hosts) and the byte-at-a-time one every other host runs --
+    each on full tables and on PRUNED ones (GK_FORCE_PRUNE: every table of the test; the general path prunes the same way, so the
+    digests must still agree -- a non-string label value under a key nothing reads is still a bad label map)"""
+    if request.param.startswith("bytes"):
         monkeypatch.setenv("GK_NO_INDEX", "1")
+    if request.param.endswith("pruned"):
+        monkeypatch.setenv("GK_FORCE_PRUNE", "1")
     return request.param
 
 
@@ -157,3 +161,41 @@ def test_fast_ingest_of_admission_requests(tokens):
     assert list(tf.statuses) == list(ts.statuses) and tf.statuses[0] == L.GK_ERR_REVIEW and tf.statuses[-1] == L.GK_OK
     sf, ss = tf.stats(), ts.stats()
     assert sf["digest"] == ss["digest"] and sf["fast_reviews"] == 1
+
+
+@pytest.mark.parametrize("policy", ["psp", "corpus"])
+def test_pruned_ingest_with_a_policy_loaded_equals_the_general_path(policy, fixtures, monkeypatch):
+    """With a policy set loaded the read set is not empty: a pruned table keeps some rows, walks past the rest, and objects whose
+    own rows are not kept look only for the members some pattern names.  Synthetic objects plus broken ones (non-string label values
+    under keys nothing reads, wrong-typed metadata, duplicate names inside a walked-past subtree): the structural-index scanner, the
+    byte scanner and the general path build the same table."""
+    drv = D.Driver(device=0, hostemu=True)
+    client = D.Client(drv)
+    if policy == "psp":
+        ts, cs = synth.psp_templates(fixtures), synth.audit_constraints()
+    else:
+        ts, cs = synth.corpus(fixtures)
+        ts = ts[::5]
+        kinds = {t["spec"]["crd"]["spec"]["names"]["kind"] for t in ts}
+        cs = [c for c in cs if c["kind"] in kinds]
+    for t in ts:
+        client.AddTemplate(t)
+    for c in cs:
+        client.AddConstraint(c)
+    nss = synth.gen_namespaces()
+    objs = synth.gen_objects(300, seed=91, mixed=True)
+    rins = [D.to_review_in(D.AugmentedUnstructured(D.Unstructured(o), synth.namespace_for(o, nss), "Original")) for o in objs]
+    odd = [
+        '{"apiVersion":"v1","kind":"Pod","metadata":{"name":"l1","namespace":"dev-00","labels":{"zz-unread":5,"app":"x"}},"spec":{"containers":[{"name":"c","image":"nginx"}]}}',
+        '{"apiVersion":"v1","kind":"Pod","metadata":{"name":"l2","labels":{"zz-unread":{"a":1}}},"spec":{"containers":[{"name":"c","image":"nginx","env":[{"name":"A","name":"B","value":1}]}]}}',
+        '{"apiVersion":"v1","kind":"Pod","metadata":{"name":"l3","annotations":{"k":"v\\"q\\\\"}},"spec":{"containers":[{"name":"c\\u00e9","image":"gcr.io/a/b:latest","securityContext":{"privileged":true,"zz":[1,[2,{"y":null}]]},"ports":[{"hostPort":80,"zz":"q"}]}],"volumes":[{"name":"v","hostPath":{"path":"/etc"}}],"hostNetwork":true}}',
+        '{"apiVersion":"apps/v1","kind":"Deployment","metadata":{"name":"d","labels":{"a":"b"}},"spec":{"template":{"spec":{"containers":[{"name":"x","image":"busybox","resources":{"limits":{"cpu":"2","memory":"1Gi","zz":1e3}}}]}}}}',
+    ]
+    rins += [_raw(d, None, None) for d in odd]
+    monkeypatch.setenv("GK_FORCE_PRUNE", "1")
+    slow = _digest(drv.engine, rins, True)
+    fast = _digest(drv.engine, rins, False)
+    monkeypatch.setenv("GK_NO_INDEX", "1")
+    fast_bytes = _digest(drv.engine, rins, False)
+    assert fast["digest"] == slow["digest"] == fast_bytes["digest"] != 0 and fast["n_rows"] == slow["n_rows"] == fast_bytes["n_rows"] > 1000
+    assert fast["fast_reviews"] == len(rins) == fast_bytes["fast_reviews"]
