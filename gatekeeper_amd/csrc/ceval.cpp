@@ -283,19 +283,19 @@ class CEval {
       case Term::Var: {
         if (const Value* b = bound(t.name)) { const Value v = *b; kv(v); return; }   // (a copy: the continuation may grow the binding stack)
         if (t.name == "input") { kv(input_); return; }
-        if (t.name == "data") { data_ref(t, nullptr, 0, r, kv); return; }
+        if (t.name == "data") { data_ref(t, nullptr, r, kv); return; }
         if (const RuleSet* rs = ix_.find(*info(r).pkg, t.name)) { for (const Value& v : rule_values(rs)) kv(v); return; }   // (a finished entry of the cache never changes)
         throw CUnbound();
       }
       case Term::Ref: {
         const Term& head = *t.head;
         if (head.kind == Term::Var && !bound(head.name)) {
-          if (head.name == "data") { data_ref(t, &t.args, 0, r, kv); return; }
+          if (head.name == "data") { data_ref(t, &t.args, r, kv); return; }
           auto io = ix_.import_ops.find(&t);
           if (io != ix_.import_ops.end()) {
             const std::vector<std::string>* imp = import_of(r, head.name);
             if (!imp) throw CFallback();
-            if ((*imp)[0] == "data") { data_ref(t, &t.args, 0, r, kv); return; }
+            if ((*imp)[0] == "data") { data_ref(t, &t.args, r, kv); return; }
             walk_keys(input_, io->second, 0, [&](const Value& v) { walk(v, t.args, 0, r, kv); });
             return;
           }
@@ -402,7 +402,7 @@ class CEval {
     index(cur, keys[i], [&](const Value& nxt) { walk_keys(nxt, keys, i + 1, kv); });
   }
   // data.<...>: a rule of a loaded package (the longest package prefix that names one), else the base document {inventory: ..}
-  void data_ref(const Term& t, const std::vector<TermP>* ops, size_t, const Rule* r, KV kv) {
+  void data_ref(const Term& t, const std::vector<TermP>* ops, const Rule* r, KV kv) {
     static const std::vector<TermP> none;
     const std::vector<TermP>& o = ops ? *ops : none;
     auto it = ix_.data_refs.find(&t);
