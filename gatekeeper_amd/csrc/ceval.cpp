@@ -434,9 +434,8 @@ class CEval {
     if (i == args.size()) { k(); return; }
     unify_value(*fr->args[i], args[i], fr, [&]() { unify_args(fr, args, i + 1, k); });
   }
-  void call_function(const RuleSet* rules, const ValueVec& args_in, KV kv) {
+  void call_function(const RuleSet* rules, const ValueVec& args, KV kv) {   // (`args`: the caller's leased list; nothing below touches it -- nested calls lease their own)
     if (++depth_ > 64) throw CFallback();   // (the general evaluator words the recursion error)
-    const ValueVec args = args_in;   // (the caller's accumulator moves on)
     std::vector<Value> results;
     results.reserve(2);
     const size_t saved_frame = frame_, mark = env_.size();
