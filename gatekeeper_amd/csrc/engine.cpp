@@ -515,7 +515,9 @@ void ensure_plan(gk_engine* e) {
         if (g.size() == 1 && g[0]->referential)   // (its formula follows the synced objects: say so -- the same words refresh_referential uses)
           throw Unsupported(std::string("referential constraint ") + g[0]->kind + "/" + g[0]->name + " does not compile against the synced inventory: " + u.what());
         if (g.size() <= 1) throw;
-        size_t half = g.size() > 64 ? 64 : g.size() / 2;
+        size_t cap = 64;
+        if (const char* gm = getenv("GK_GROUP_MAX")) cap = (size_t)std::max(1, std::min(64, atoi(gm)));   // tuning aid: smaller plan groups (smaller code objects, fewer accumulator words, more walks of the table)
+        size_t half = g.size() > cap ? cap : g.size() / 2;
         for (size_t i = 0; i < g.size(); i += half)
           place(std::vector<const ConstraintRec*>(g.begin() + i, g.begin() + std::min(g.size(), i + half)));
         return;
