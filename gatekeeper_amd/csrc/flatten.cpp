@@ -462,10 +462,12 @@ bool obj_is_namespace(const Value& obj) {
 // ------------------------------------------------------------------------------------------------ normalisation
 namespace {
 Value S(const std::string& s) { return Value::string(s); }
+// a string LITERAL as a Value: made once (member names of the normalised request: a dozen per review otherwise)
+#define SK(lit) ([]() -> const Value& { static const Value v_ = Value::string(lit); return v_; }())
 
 Value str_field(const Value& o, const char* k) {
   const Value* v = o.get(k);
-  return (v && v->is_string()) ? *v : S("");
+  return (v && v->is_string()) ? *v : SK("");
 }
 
 Value triple(const Value* o, const char* a, const char* b, const char* c) {
@@ -486,13 +488,13 @@ ReviewDoc normalize_admission_request(const Value& request, const Value& match_n
                                       const NsCache& cache) {
   if (!request.is_object()) throw ReviewError("invalid request object: AdmissionRequest must be a JSON object");
   ValuePairs p;
-  p.emplace_back(S("uid"), str_field(request, "uid"));
-  p.emplace_back(S("kind"), triple(request.get("kind"), "group", "version", "kind"));
-  p.emplace_back(S("resource"), triple(request.get("resource"), "group", "version", "resource"));
+  p.emplace_back(SK("uid"), str_field(request, "uid"));
+  p.emplace_back(SK("kind"), triple(request.get("kind"), "group", "version", "kind"));
+  p.emplace_back(SK("resource"), triple(request.get("resource"), "group", "version", "resource"));
   Value op = str_field(request, "operation");
-  p.emplace_back(S("operation"), op);
+  p.emplace_back(SK("operation"), op);
   const Value* ui = request.get("userInfo");
-  p.emplace_back(S("userInfo"), (ui && ui->is_object()) ? *ui : Value::object({}));
+  p.emplace_back(SK("userInfo"), (ui && ui->is_object()) ? *ui : Value::object({}));
   const Value* obj = request.get("object");
   const Value* old = request.get("oldObject");
   Value vobj = (obj && obj->is_object()) ? *obj : Value::null();
@@ -501,10 +503,10 @@ ReviewDoc normalize_admission_request(const Value& request, const Value& match_n
     if (!vold.is_object()) throw ReviewError("oldObject cannot be nil for DELETE operations");
     vobj = vold;
   }
-  p.emplace_back(S("object"), vobj);
-  p.emplace_back(S("oldObject"), vold);
+  p.emplace_back(SK("object"), vobj);
+  p.emplace_back(SK("oldObject"), vold);
   const Value* opts = request.get("options");
-  p.emplace_back(S("options"), opts ? *opts : Value::null());
+  p.emplace_back(SK("options"), opts ? *opts : Value::null());
   for (const char* k : {"subResource", "requestSubResource", "name", "namespace"}) {
     const Value* v = request.get(k);
     if (v && v->is_string() && !v->str().empty()) p.emplace_back(S(k), *v);
@@ -513,7 +515,7 @@ ReviewDoc normalize_admission_request(const Value& request, const Value& match_n
     const Value* v = request.get(k);
     if (v && !v->is_null()) p.emplace_back(S(k), *v);
   }
-  if (ns_object.defined() && !ns_object.is_null()) p.emplace_back(S("namespaceObject"), ns_object);
+  if (ns_object.defined() && !ns_object.is_null()) p.emplace_back(SK("namespaceObject"), ns_object);
   ReviewDoc d;
   d.request = Value::object(std::move(p));
   d.source = source;
@@ -530,14 +532,14 @@ ReviewDoc normalize_object(const Value& object, const Value& match_ns, const Val
   if (!object.is_object()) throw ReviewError("invalid request object: object must be a JSON object");
   std::string g, v, k;
   obj_gvk(object, &g, &v, &k);
-  ValuePairs kind{{S("group"), S(g)}, {S("version"), S(v)}, {S("kind"), S(k)}};
+  ValuePairs kind{{SK("group"), S(g)}, {SK("version"), S(v)}, {SK("kind"), S(k)}};
   ValuePairs req;
-  req.emplace_back(S("kind"), Value::object(std::move(kind)));
-  req.emplace_back(S("name"), S(obj_string(object, "metadata", "name")));
-  req.emplace_back(S("namespace"), S(obj_string(object, "metadata", "namespace")));
-  if (!operation.empty()) req.emplace_back(S("operation"), S(operation));
-  if (operation == "DELETE") req.emplace_back(S("oldObject"), object);   // target.go:151-154
-  else req.emplace_back(S("object"), object);
+  req.emplace_back(SK("kind"), Value::object(std::move(kind)));
+  req.emplace_back(SK("name"), S(obj_string(object, "metadata", "name")));
+  req.emplace_back(SK("namespace"), S(obj_string(object, "metadata", "namespace")));
+  if (!operation.empty()) req.emplace_back(SK("operation"), S(operation));
+  if (operation == "DELETE") req.emplace_back(SK("oldObject"), object);   // target.go:151-154
+  else req.emplace_back(SK("object"), object);
   return normalize_admission_request(Value::object(std::move(req)), match_ns, ns_object, source, cache);
 }
 

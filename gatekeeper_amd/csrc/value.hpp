@@ -69,7 +69,7 @@ struct Value {
     return 0;
   }
   const Value* get(const Value& key) const;       // object lookup
-  const Value* get(const char* key) const { return get(Value::string(key)); }
+  const Value* get(const char* key) const;        // object lookup by a string key (no Value is made for the key)
   bool set_has(const Value& v) const;
 };
 
@@ -139,6 +139,18 @@ inline const Value* Value::get(const Value& key) const {
   if (kind != Object) return nullptr;
   auto it = std::lower_bound(obj->begin(), obj->end(), key, [](const std::pair<Value, Value>& p, const Value& k) { return p.first < k; });
   if (it != obj->end() && it->first == key) return &it->second;
+  return nullptr;
+}
+inline const Value* Value::get(const char* key) const {
+  if (kind != Object) return nullptr;
+  const size_t kn = strlen(key);
+  // keys sort by kind first (null < boolean < number < string < ..), strings by their bytes
+  auto less = [&](const std::pair<Value, Value>& p, int) {
+    if (p.first.kind != String) return p.first.kind < String;
+    return p.first.s->compare(0, std::string::npos, key, kn) < 0;
+  };
+  auto it = std::lower_bound(obj->begin(), obj->end(), 0, less);
+  if (it != obj->end() && it->first.kind == String && it->first.s->size() == kn && memcmp(it->first.s->data(), key, kn) == 0) return &it->second;
   return nullptr;
 }
 inline bool Value::set_has(const Value& v) const {
