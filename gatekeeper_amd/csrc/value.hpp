@@ -385,14 +385,14 @@ class JsonParser {
       }
       return Value::array(std::move(items));
     }
-    if (c == '"') return Value::string(str());
+    if (c == '"') return key();   // (string values repeat as well -- images, protocols, label values: the same table serves them)
     if (c == 't') { lit("true"); return Value::boolean(true); }
     if (c == 'f') { lit("false"); return Value::boolean(false); }
     if (c == 'n') { lit("null"); return Value::null(); }
     return number();
   }
-  // An object key as a Value.  Member names repeat from document to document: short names without escapes come from a small
-  // per-thread table of shared string values (no allocation, no copy of the bytes); anything else is decoded as any string is.
+  // A string as a Value.  Member names (and many values) repeat from document to document: short strings without escapes come
+  // from a small per-thread table of shared string values (no allocation, no copy of the bytes); anything else is decoded.
   Value key() {
     const char* q = p_ + 1;
     while (q < e_ && *q != '"' && *q != '\\' && q - p_ <= 40) q++;
