@@ -1905,8 +1905,8 @@ int gk_render(gk_engine* e, gk_table* t, uint32_t constraint_id, uint32_t review
     ValueVec arr;
     auto vs = it->second->render(doc.request, c.params, e->inventory);
     for (auto& v : vs) {
-      ValuePairs o{{Value::string("msg"), Value::string(v.msg)}};
-      o.emplace_back(Value::string("details"), v.details.defined() ? v.details : Value::object({}));
+      static const Value k_msg = Value::string("msg"), k_details = Value::string("details"), no_details = Value::object({});
+      ValuePairs o{{k_details, v.details.defined() ? v.details : no_details}, {k_msg, Value::string(v.msg)}};
       arr.push_back(Value::object(o));
     }
     std::string s = to_json(Value::array(arr));
@@ -1977,8 +1977,8 @@ std::string query_results_json(gk_engine* e, gk_table* t, const gk_eval_out& ev,
     const auto vs = it->second->render(doc.request, c.params, e->inventory);
     if (vs.empty()) throw std::runtime_error("device / renderer disagree: the plan reports a violation of " + c.kind + "/" + c.name + " that the evaluator does not render");
     for (auto& v : vs) {
-      ValuePairs o{{Value::string("constraint"), Value::integer(cid)}, {Value::string("msg"), Value::string(v.msg)},
-                   {Value::string("details"), v.details.defined() ? v.details : Value::object({})}};
+      static const Value k_constraint = Value::string("constraint"), k_msg = Value::string("msg"), k_details = Value::string("details"), no_details = Value::object({});
+      ValuePairs o{{k_constraint, Value::integer(cid)}, {k_details, v.details.defined() ? v.details : no_details}, {k_msg, Value::string(v.msg)}};   // (in key order: Value::object has nothing to sort)
       if (out.size() > 1) out += ",";
       out += to_json(Value::object(o));
     }
