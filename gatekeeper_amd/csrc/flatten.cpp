@@ -564,7 +564,6 @@ Flattener::Flattener(PathDict* dict, const DictRegistry* reg) : dict_(dict), reg
 
 void Flattener::begin_table() {
   use_index_ = ix_supported() && !getenv("GK_NO_INDEX");
-  ns_cache_.clear();
   ns_memo_.clear();
   ns_memo_name_.clear();
   stage_.clear();
@@ -1844,37 +1843,6 @@ bool Flattener::fast_tree(const char* json, size_t len, uint32_t root, ObjFacts*
   return true;
 }
 
-void Flattener::fast_match_facts(const ObjFacts& f, const Value& ns, bool is_old) {
-  // = match_facts() on the captured strings
-  std::string av = f.api_version.set ? std::string(f.api_version.p, f.api_version.n) : std::string();
-  std::string kind = f.kind.set ? std::string(f.kind.p, f.kind.n) : std::string();
-  std::string group;
-  size_t nsl = std::count(av.begin(), av.end(), '/');
-  if (!(av.empty() || av == "/") && nsl == 1) group = av.substr(0, av.find('/'));
-  const bool is_ns = kind == "Namespace" && group.empty();
-  uint32_t sub = child(id_m_, is_old ? "old" : "o");
-  emit(sub, T_OBJECT, 0, 0);
-  emit_str(sub, "group", group);
-  emit_str(sub, "kind", kind);
-  const std::string name = f.name.set ? std::string(f.name.p, f.name.n) : std::string();
-  const std::string nsfield = f.ns.set ? std::string(f.ns.p, f.ns.n) : std::string();
-  emit_str(sub, "name", name);
-  emit_str(sub, "gname", f.gname.set ? std::string(f.gname.p, f.gname.n) : std::string());
-  bool has_nsname = true;
-  std::string nsname;
-  if (is_ns) nsname = name;
-  else if (ns.defined()) nsname = obj_string(ns, "metadata", "name");
-  else if (!nsfield.empty()) nsname = nsfield;
-  else has_nsname = false;
-  if (has_nsname) emit_str(sub, "nsname", nsname);
-  review_flags_ |= is_old ? RF_HAS_OLD : RF_HAS_OBJ;
-  if (is_ns) review_flags_ |= is_old ? RF_OLD_IS_NS : RF_OBJ_IS_NS;
-  if (!nsfield.empty()) review_flags_ |= is_old ? RF_OLD_HAS_NSFIELD : RF_OBJ_HAS_NSFIELD;
-  if (has_nsname) review_flags_ |= is_old ? RF_OLD_HAS_NSNAME : RF_OBJ_HAS_NSNAME;
-  if (f.labels_bad) review_flags_ |= is_old ? RF_OLD_LABELS_BAD : RF_OBJ_LABELS_BAD;
-  if (kind.empty()) review_flags_ |= is_old ? RF_OLD_BAD : RF_OBJ_BAD;
-}
-
 namespace {
 struct Span { const char* p = nullptr; size_t n = 0; bool set() const { return p != nullptr; } };
 inline void skip_ws(const char*& p, const char* e) { while (p < e && (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r')) p++; }
@@ -1930,6 +1898,35 @@ template <class F> bool scan_members(const char* p, const char* e, F fn) {
 inline bool span_is(const Span& s, char c) { return s.set() && s.n && *s.p == c; }
 inline bool span_null(const Span& s) { return !s.set() || (s.n == 4 && memcmp(s.p, "null", 4) == 0); }
 }  // namespace
+
+// Matchable.Namespace of a review: the one handed along with it, else the nsCache entry of `nsfield` (matcher.go:37-39); nullptr:
+// neither.  What a review takes from it is remembered per table part (NsMemo).  *bad: the Namespace text does not parse.
+Flattener::NsMemo* Flattener::ns_memo_for(const RawReview& r, const char* nsp, uint32_t nsn, const NsCache& cache, bool* bad) {
+  NsMemo* memo = nullptr;
+  if (r.ns_json && r.ns_len) {
+    auto it = ns_memo_.find(r.ns_json);
+    if (it == ns_memo_.end() || it->second.len != r.ns_len) {
+      NsMemo m;
+      m.len = r.ns_len;
+      try { Value v = parse_json(r.ns_json, r.ns_len); if (!v.is_null()) m.ns = v; } catch (const std::exception&) { *bad = true; return nullptr; }
+      if (m.ns.defined()) m.nsname = obj_string(m.ns, "metadata", "name");
+      it = ns_memo_.insert_or_assign(r.ns_json, std::move(m)).first;
+    }
+    if (it->second.ns.defined()) memo = &it->second;
+  }
+  if (!memo && nsn) {
+    const std::string nsfield(nsp, nsn);
+    auto it = ns_memo_name_.find(nsfield);
+    if (it == ns_memo_name_.end()) {
+      NsMemo m;
+      m.ns = cache.get(nsfield);
+      if (m.ns.defined()) m.nsname = obj_string(m.ns, "metadata", "name");
+      it = ns_memo_name_.emplace(nsfield, std::move(m)).first;
+    }
+    memo = &it->second;
+  }
+  return memo;
+}
 
 int Flattener::add_json_request(const RawReview& r, const NsCache& cache, HostTable* out, std::string* obj_key, const ExcludeFn* excluded) {
   t_ = out;
@@ -1994,16 +1991,17 @@ int Flattener::add_json_request(const RawReview& r, const NsCache& cache, HostTa
   };
   uint32_t members = 8;   // uid kind resource operation userInfo object oldObject options
   const char* sp; uint32_t sn;
-  str_of(m[M_UID], &sp, &sn); emit_str_n(child(0, "uid"), 0, sp, sn);
-  triple(m[M_KIND], "group", "version", "kind", child(0, "kind"));
-  triple(m[M_RESOURCE], "group", "version", "resource", child(0, "resource"));
+  if (!env_.ready) env_init();
+  str_of(m[M_UID], &sp, &sn); emit_str_n(env_.uid, 0, sp, sn);
+  triple(m[M_KIND], "group", "version", "kind", env_.kind);
+  triple(m[M_RESOURCE], "group", "version", "resource", env_.resource);
   const char* op_p; uint32_t op_n;
-  str_of(m[M_OP], &op_p, &op_n); emit_str_n(child(0, "operation"), 0, op_p, op_n);
+  str_of(m[M_OP], &op_p, &op_n); emit_str_n(env_.operation, 0, op_p, op_n);
   if (declined) return bail();
   const bool del = op_n == 6 && memcmp(op_p, "DELETE", 6) == 0;
   int type = -1;
-  if (span_is(m[M_USER], '{')) { if (!fast_tree(m[M_USER].p, m[M_USER].n, child(0, "userInfo"), nullptr, &type)) return bail(); }
-  else { if (m[M_USER].set()) { str_of(m[M_USER], &sp, &sn); if (declined) return bail(); } emit(child(0, "userInfo"), T_OBJECT, 0, 0); }
+  if (span_is(m[M_USER], '{')) { if (!fast_tree(m[M_USER].p, m[M_USER].n, env_.user_info, nullptr, &type)) return bail(); }
+  else { if (m[M_USER].set()) { str_of(m[M_USER], &sp, &sn); if (declined) return bail(); } emit(env_.user_info, T_OBJECT, 0, 0); }
   const bool has_obj = span_is(m[M_OBJ], '{'), has_old = span_is(m[M_OLD], '{');
   for (const Span* s : {&m[M_OBJ], &m[M_OLD]}) if (s->set() && !span_is(*s, '{')) { str_of(*s, &sp, &sn); if (declined) return bail(); }   // non-object: null, after a syntax check
   if (del && !has_old) return bail();   // ErrOldObjectIsNil: worded by the general path
@@ -2014,8 +2012,8 @@ int Flattener::add_json_request(const RawReview& r, const NsCache& cache, HostTa
   else emit(id_object_, T_NULL, 0, 0);
   if (has_old) { if (!fast_tree(m[M_OLD].p, m[M_OLD].n, id_old_, &fold, &type) || type != T_OBJECT) return bail(); }
   else emit(id_old_, T_NULL, 0, 0);
-  if (m[M_OPTS].set()) { if (!fast_tree(m[M_OPTS].p, m[M_OPTS].n, child(0, "options"), nullptr, &type)) return bail(); }
-  else emit(child(0, "options"), T_NULL, 0, 0);
+  if (m[M_OPTS].set()) { if (!fast_tree(m[M_OPTS].p, m[M_OPTS].n, env_.options, nullptr, &type)) return bail(); }
+  else emit(env_.options, T_NULL, 0, 0);
   const char* rns_p = ""; uint32_t rns_n = 0;
   for (int i : {M_SUBRES, M_REQSUBRES, M_NAME, M_NS}) {
     str_of(m[i], &sp, &sn);
@@ -2039,25 +2037,20 @@ int Flattener::add_json_request(const RawReview& r, const NsCache& cache, HostTa
   if (r.nsobj_json && r.nsobj_len) {
     const size_t before = stage_.size(), hb = out->heap.size();
     int t2 = -1;
-    if (!fast_tree(r.nsobj_json, r.nsobj_len, child(0, "namespaceObject"), nullptr, &t2)) return bail();
+    if (!fast_tree(r.nsobj_json, r.nsobj_len, env_.nsobj, nullptr, &t2)) return bail();
     if (t2 == T_NULL) { stage_.resize(before); out->heap.resize(hb); } else members++;
   }
   emit(0, T_OBJECT, members, 0);
   // Matchable.Namespace: the review's, else the nsCache entry of the REQUEST namespace (matcher.go:37-39)
-  Value ns;
-  if (r.ns_json && r.ns_len) {
-    auto it = ns_cache_.find(r.ns_json);
-    if (it == ns_cache_.end() || it->second.first != r.ns_len) {
-      Value v;
-      try { v = parse_json(r.ns_json, r.ns_len); } catch (const std::exception&) { return bail(); }
-      it = ns_cache_.insert_or_assign(r.ns_json, std::make_pair(r.ns_len, v)).first;
-    }
-    if (!it->second.second.is_null()) ns = it->second.second;
-  }
-  if (!ns.defined() && rns_n) ns = cache.get(std::string(rns_p, rns_n));
+  bool ns_bad = false;
+  NsMemo* memo = ns_memo_for(r, rns_p, rns_n, cache, &ns_bad);
+  if (ns_bad) return bail();
+  static const Value no_ns;
+  static const std::string no_name;
+  const bool ns_defined = memo && memo->ns.defined();
   emit(id_m_, T_OBJECT, 2, 0);
-  if (obj_present) fast_match_facts(fobj, ns, false);
-  if (has_old) fast_match_facts(fold, ns, true);
+  if (obj_present) fast_match_facts_n(fobj, ns_defined, ns_defined ? memo->nsname : no_name, false);
+  if (has_old) fast_match_facts_n(fold, ns_defined, ns_defined ? memo->nsname : no_name, true);
   if (obj_key) {   // the audit sort key: object (after setObjectOnDelete), else oldObject
     const ObjFacts& k = obj_present ? fobj : fold;
     std::string& key = *obj_key;
@@ -2072,7 +2065,8 @@ int Flattener::add_json_request(const RawReview& r, const NsCache& cache, HostTa
       if (k.name.set) key.append(k.name.p, k.name.n);
     }
   }
-  finish_review(ns, r.source, out);
+  if (memo) finish_review_memo(memo, r.source, out);
+  else finish_review(no_ns, r.source, out);
   return ADDED;
 }
 
@@ -2133,29 +2127,9 @@ int Flattener::add_json(const RawReview& r, const NsCache& cache, HostTable* out
   }
   emit(0, T_OBJECT, members, 0);
   // Matchable.Namespace: the review's, else the nsCache entry of the request namespace (matcher.go:37-39)
-  NsMemo* memo = nullptr;
-  if (r.ns_json && r.ns_len) {
-    auto it = ns_memo_.find(r.ns_json);
-    if (it == ns_memo_.end() || it->second.len != r.ns_len) {
-      NsMemo m;
-      m.len = r.ns_len;
-      try { Value v = parse_json(r.ns_json, r.ns_len); if (!v.is_null()) m.ns = v; } catch (const std::exception&) { return bail(); }
-      if (m.ns.defined()) m.nsname = obj_string(m.ns, "metadata", "name");
-      it = ns_memo_.insert_or_assign(r.ns_json, std::move(m)).first;
-    }
-    if (it->second.ns.defined()) memo = &it->second;
-  }
-  if (!memo && nsn) {
-    const std::string nsfield(nsp, nsn);
-    auto it = ns_memo_name_.find(nsfield);
-    if (it == ns_memo_name_.end()) {
-      NsMemo m;
-      m.ns = cache.get(nsfield);
-      if (m.ns.defined()) m.nsname = obj_string(m.ns, "metadata", "name");
-      it = ns_memo_name_.emplace(nsfield, std::move(m)).first;
-    }
-    memo = &it->second;
-  }
+  bool ns_bad = false;
+  NsMemo* memo = ns_memo_for(r, nsp, nsn, cache, &ns_bad);
+  if (ns_bad) return bail();
   static const Value no_ns;
   static const std::string no_name;
   const bool ns_defined = memo && memo->ns.defined();

@@ -412,7 +412,6 @@ class Flattener {
   ObjFacts* cur_facts_ = nullptr;             // facts of the object / oldObject tree being parsed
   uint32_t cur_root_ = 0;                     // its root path (object / oldObject)
   struct CapIds { uint32_t api_version, kind, metadata, name, ns, gname, labels; } cap_[2];   // [0] object, [1] oldObject
-  std::unordered_map<const char*, std::pair<size_t, Value>> ns_cache_;   // parsed Namespace documents by text pointer
   // (round 4) what a review takes from its Namespace is the same for every review of that namespace: the name the match layer
   // compares and the $ns rows.  Kept per table part (begin_table drops it): the rows hold offsets into the part's heap.
   struct NsMemo {
@@ -423,6 +422,7 @@ class Flattener {
   std::unordered_map<const char*, NsMemo> ns_memo_;
   std::unordered_map<std::string, NsMemo> ns_memo_name_;
   bool emit_side_effects_ = false;    // an emit() interned a value id or compared a message key since this was cleared
+  NsMemo* ns_memo_for(const RawReview& r, const char* nsp, uint32_t nsn, const NsCache& cache, bool* bad);
   void ns_rows(const Value& ns);                                        // the $ns rows of finish_review
   void finish_review_memo(NsMemo* m, int source, HostTable* out);       // finish_review with the $ns rows replayed
   void finish_tail(int source, HostTable* out);
@@ -438,7 +438,6 @@ class Flattener {
   bool fast_string(const char** s, uint32_t* n);   // decodes the string at p_ (views the text when it has no escapes)
   bool fast_tree(const char* json, size_t len, uint32_t root, ObjFacts* facts, int* type);
   void emit_str_n(uint32_t path, uint32_t meta, const char* s, uint32_t n);
-  void fast_match_facts(const ObjFacts& f, const Value& ns, bool is_old);
   // ---- structural index (round 4): stage 1 classifies the document 64 bytes at a time (AVX-512: unescaped quotes, the in-string
   // mask by carry-less multiply, the six structural characters, the first character of every other scalar) into an array of token
   // positions; stage 2 (ix_value / ix_skip: the grammar and the row semantics of fast_value / skip_value) walks TOKENS, not bytes: no
