@@ -626,7 +626,7 @@ def main():
             out["audit_result_totals"] = totals_leg(table)
         except Exception as ex:   # noqa: BLE001
             out["audit_result_totals"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
-        if not args.no_cpu_baseline and not args.lean:
+        if not args.no_cpu_baseline and not args.lean and world == 1:   # (the checkers and the CPU baseline: N = 1 only -- at N > 1 the other ranks would wait ~2 min for rank 0)
             out["cpu_baseline"], out["parity_sample"] = cpu_leg(templates, defaulted, batch, final)
             try:
                 out["parity_python_oracle"] = python_oracle_leg(templates, constraints, batch, final, args.oracle_sample)
