@@ -199,3 +199,39 @@ def test_pruned_ingest_with_a_policy_loaded_equals_the_general_path(policy, fixt
     fast_bytes = _digest(drv.engine, rins, False)
     assert fast["digest"] == slow["digest"] == fast_bytes["digest"] != 0 and fast["n_rows"] == slow["n_rows"] == fast_bytes["n_rows"] > 1000
     assert fast["fast_reviews"] == len(rins) == fast_bytes["fast_reviews"]
+
+
+def test_structural_index_at_every_block_alignment():
+    """Stage 1 of the structural index works on 64-byte blocks with carries between them (is the first byte escaped? inside a
+    string? the continuation of a scalar?).  Documents full of the carried states -- runs of backslashes of every parity before
+    quotes, escaped quotes, strings and numbers longer than a block, unicode escapes, scalars glued to brackets, tabs and CRs --
+    shifted through every alignment by leading white space: the index scanner, the byte scanner and the general path agree."""
+    eng = D.Engine(hostemu=True)
+    runs = "".join('"b%d":"x%s\\"y","c%d":"%s",' % (k, "\\\\" * k, k, "\\\\" * k) for k in range(0, 9))
+    body = ('{"apiVersion":"v1","kind":"Pod","metadata":{"name":"n","labels":{"a":"' + "L" * 70 + '","e":"\\u00e9\\ud83d\\ude00\\n\\t"}},'
+            '"spec":{' + runs + '"big":123456789012345678,"neg":-0.5e-3,"t":true,"f":false,"z":null,\t"arr":[1,[2,[3,[]]],{"k":{}}],\r\n'
+            '"s":"' + 'q\\"' * 40 + '","containers":[{"name":"c","image":"' + "i" * 130 + '","args":["--x=\\\\","\\\\\\"","end"]}]}}')
+    json.loads(body)   # (the test's own document must be JSON)
+    rins = [_raw(" " * k + body + ("\n" * (k % 3)), None, None) for k in range(0, 140)]
+    slow = _digest(eng, rins, True)
+    fast = _digest(eng, rins, False)
+    os.environ["GK_NO_INDEX"] = "1"
+    try:
+        fast_bytes = _digest(eng, rins, False)
+    finally:
+        os.environ.pop("GK_NO_INDEX", None)
+    assert fast["fast_reviews"] == len(rins) == fast_bytes["fast_reviews"]
+    assert fast["digest"] == slow["digest"] == fast_bytes["digest"] != 0 and fast["n_rows"] == slow["n_rows"] == fast_bytes["n_rows"]
+    # ... and text that is NOT JSON at the places the carries decide: an unterminated escape at the end, a quote escaped by an odd run
+    # that closes nothing, a scalar glued to a string -- declined by both scanners, rejected by the general path, at every alignment
+    bad = ['{"a":"x\\\\\\"}', '{"a":"x\\', '{"a":"x"y}', '{"a":tru e}', '{"a":1 2}', '{"a":"b"}}', '{"a" "b"}']
+    for doc in bad:
+        rb = [_raw(" " * k + doc, None, None) for k in (0, 1, 57, 58, 59, 60, 61, 62, 63, 64, 65)]
+        t1 = eng.create_table(rb, keep_docs=False)
+        os.environ["GK_NO_INDEX"] = "1"
+        try:
+            t2 = eng.create_table(rb, keep_docs=False)
+        finally:
+            os.environ.pop("GK_NO_INDEX", None)
+        assert list(t1.statuses) == list(t2.statuses) == [L.GK_ERR_REVIEW] * len(rb), doc
+        t1.free(); t2.free()
