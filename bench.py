@@ -64,7 +64,7 @@ def cpu_leg(templates, constraints, batch, ev, budget_s=10.0):
                       "per-object marshal, per-constraint re-decode + match.Matches + tree-walking Rego evaluation; the Go/OPA "
                       "reference itself cannot be built here), %.1f s on 1 thread.  NOTE: the loop shape and match.Matches are "
                       "restated in cpu_ref.cpp, but its JSON reader, HandleReview normalisation and Rego tree-walker are the "
-                      "PRODUCT's host objects (flatten.o / pe.o) -- this times the product's concrete evaluator inside the "
+                      "PRODUCT's host objects (flatten.o / pe.o / ceval.o) -- this times the product's concrete evaluator inside the "
                       "reference's loop, not OPA; the independent checker is parity_python_oracle" % (n1, nc, one["seconds"]),
             "all_cores": {"value": nall * nc / allc["seconds"], "cores": cores, "hardware_threads": os.cpu_count(), "sample_reviews": nall, "seconds": allc["seconds"],
                           "note": "cores = CPUs usable under the affinity mask / cgroup CPU quota (gk_host_cpus), one thread each"}}
