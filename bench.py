@@ -74,6 +74,52 @@ def cpu_leg(templates, constraints, batch, ev, budget_s=10.0):
     return base, parity
 
 
+def indep_leg(templates, constraints, batch, ev, ids=None, budget_s=8.0):
+    """The INDEPENDENT COMPILED checker (oracle/indep_check.cpp -> oracle/libgkindep.so: a C++ restatement of the Python oracle -- own
+    JSON reader, value model, Rego parser + tree-walking interpreter, Match layer; no object of the product linked) over ALL objects
+    of the timed table, taken as JSON text from the batch: its violation / autoreject bitmaps against the device's, bit for bit.
+    -> (cpu_baseline of the restated reference: one thread on a bounded sample + all usable cores on the whole table, parity record)"""
+    import numpy as np
+    from oracle.indep_check import IndepChecker
+    ck = IndepChecker(templates, constraints)
+    nc, n = len(constraints), batch.n
+    cores = int(batch.lib.gk_host_cpus()) or os.cpu_count() or 1
+    t0 = time.perf_counter()
+    ck.check(batch.reviews, min(n, 512), 1)
+    rate1 = min(n, 512) / max(time.perf_counter() - t0, 1e-9)
+    n1 = int(max(64, min(n, rate1 * budget_s)) // 64 * 64) or n
+    t0 = time.perf_counter()
+    ck.check(batch.reviews, n1, 1)
+    s1 = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    viol, err = ck.check(batch.reviews, n, cores)
+    s_all = time.perf_counter() - t0
+    ck.close()
+    row_of = {int(cid): i for i, cid in enumerate(ev.constraint_ids)}
+    words = (n + 63) // 64
+    tail = np.uint64((1 << (n % 64)) - 1) if n % 64 else None
+    equal, dev_pairs, ck_pairs, dev_err, ck_err = True, 0, 0, 0, 0
+    for row, cid in enumerate(ids if ids is not None else batch_constraint_ids):
+        d_v, d_e = np.array(ev.viol[row_of[cid]][:words], copy=True), np.array(ev.err[row_of[cid]][:words], copy=True)
+        if tail is not None:
+            d_v[-1] &= tail
+            d_e[-1] &= tail
+        equal = equal and bool((d_v == viol[row][:words]).all()) and bool((d_e == err[row][:words]).all())
+        dev_pairs += int(np.unpackbits(d_v.view(np.uint8)).sum()); ck_pairs += int(np.unpackbits(viol[row][:words].view(np.uint8)).sum())
+        dev_err += int(np.unpackbits(d_e.view(np.uint8)).sum()); ck_err += int(np.unpackbits(err[row][:words].view(np.uint8)).sum())
+    base = {"value": n1 * nc / s1, "unit": "evals/s", "cores": 1, "kind": "port",
+            "sample": "first %d of the same synthetic objects x %d constraints, %.1f s on 1 thread of the independent compiled restatement of the reference's "
+                      "path (oracle/indep_check.cpp: per object JSON decode -> HandleReview -> per constraint match.Matches -> tree-walking Rego evaluation of the "
+                      "template; own reader / parser / interpreter / Match layer, nothing of the product linked; the Go/OPA reference itself cannot be built here)" % (n1, nc, s1),
+            "all_cores": {"value": n * nc / s_all, "cores": cores, "hardware_threads": os.cpu_count(), "sample_reviews": n, "seconds": s_all,
+                          "note": "cores = CPUs usable under the affinity mask / cgroup CPU quota (gk_host_cpus), one thread each; the whole timed table"}}
+    parity = {"n": n, "constraints": nc, "pairs_equal": equal, "device_violating_pairs": dev_pairs, "checker_violating_pairs": ck_pairs,
+              "device_autoreject_pairs": dev_err, "checker_autoreject_pairs": ck_err, "seconds": s_all, "threads": cores,
+              "checker": "oracle/indep_check.cpp -> oracle/libgkindep.so: compiled, independent of the product (one source file + the C++ standard library on its link line), "
+                         "pinned against the Python oracle by tests/test_indep_check.py; every object of the timed table, bit for bit"}
+    return base, parity
+
+
 def oracle_pairs_of(templates, constraints, batch, n):
     """(viol pairs, err pairs, seconds, processes) of the pure-Python oracle over the first n objects of `batch` (JSON text)"""
     from oracle import bench_leg as BL
@@ -627,7 +673,13 @@ def main():
         except Exception as ex:   # noqa: BLE001
             out["audit_result_totals"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
         if not args.no_cpu_baseline and not args.lean and world == 1:   # (the checkers and the CPU baseline: N = 1 only -- at N > 1 the other ranks would wait ~2 min for rank 0)
-            out["cpu_baseline"], out["parity_sample"] = cpu_leg(templates, defaulted, batch, final)
+            product_loop, out["parity_sample"] = cpu_leg(templates, defaulted, batch, final)
+            try:   # cpu_baseline = the independent compiled restatement; the loop around the product's own evaluator stays beside it
+                out["cpu_baseline"], out["parity_compiled_independent"] = indep_leg(templates, constraints, batch, final)
+                out["cpu_baseline"]["product_evaluator_in_the_reference_loop"] = product_loop
+            except Exception as ex:   # noqa: BLE001
+                out["cpu_baseline"] = product_loop
+                out["parity_compiled_independent"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
             try:
                 out["parity_python_oracle"] = python_oracle_leg(templates, constraints, batch, final, args.oracle_sample)
             except Exception as ex:   # the checker must not cost the bench line; an absent leg is visible as such
@@ -644,6 +696,7 @@ def main():
             brief["configs2"] = {"w": "%dx%d" % (nc, total_reviews), "ms": _sig(out["ms_per_step"]), "frac": _sig(out["roofline"]["frac"], 3),
                                  "parity": {"n": pp.get("n"), "equal": pp.get("pairs_equal"), "pairs": pp.get("oracle_violating_pairs"), "s": _sig(pp.get("seconds"), 3)},
                                  "cpu_loop_parity": {"n": ps.get("n"), "equal": ps.get("pairs_equal")},
+                                 "compiled_independent_parity": {k: (out.get("parity_compiled_independent") or {}).get(k) for k in ("n", "pairs_equal", "checker_violating_pairs", "seconds", "error") if k in (out.get("parity_compiled_independent") or {})},
                                  "totals": {"s": _sig((out.get("audit_result_totals") or {}).get("seconds"), 3), "rendered_share": _sig((out.get("audit_result_totals") or {}).get("rendered_share"), 3),
                                             "equal": ((out.get("audit_result_totals") or {}).get("host_pass_over_every_pair") or {}).get("equal")}}
             e2e = out.get("end_to_end") or {}

@@ -1,0 +1,1504 @@
+// ORACLE (test infrastructure only -- never linked into, loaded by or called from the product path).
+//
+// The INDEPENDENT COMPILED CHECKER of bench.py's full-size parity leg: a C++ restatement of the Python oracle
+//   oracle/values.py  oracle/rego_parser.py  oracle/rego_interp.py  oracle/rego_builtins.py (the builtins the bench's policy
+//   sets call)  oracle/match.py  oracle/target.py (object reviews)  oracle/client.py Client.review
+// with its own JSON reader, its own value model, its own Rego parser and tree-walking interpreter and its own Match layer.
+// NOTHING of gatekeeper_amd/csrc is compiled into it or linked with it (oracle/Makefile: this one file, the C++ standard
+// library, pthreads); of the product it sees only the public C header's `gk_review_in` (a struct of pointers and lengths),
+// so that the JSON TEXT of the batch the timed table was built from is read where it lies.
+//
+// What it restates (through the Python oracle, which cites them line by line): pkg/target/target.go:81-179 (HandleReview for
+// unstructured objects), pkg/target/matcher.go:21-93, pkg/mutation/match/match.go:32-268, pkg/wildcard/wildcard.go:17-41,
+// apimachinery's label selectors, and OPA's topdown evaluation of the template's `violation` set (frameworks Driver.Query,
+// called from pkg/audit/manager.go:621,719).  It answers, per (constraint, object): does the constraint match and the template
+// yield a result (violation bit), or does matching fail (autoreject bit) -- the two bitmaps the device produces.
+// Scope: AugmentedUnstructured{object, namespace, source "Original"} reviews at the audit enforcement point, the Rego subset of
+// oracle/rego_parser.py, the builtins listed in BUILTINS below; anything else is reported as an error, never guessed.
+// Pinned by tests/test_indep_check.py against the Python oracle (fixtures, synthetic configs, the corpus).
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <regex>
+#include <set>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <type_traits>
+#include <vector>
+
+#include "../include/gkgpu.h"   // gk_review_in only (plain C struct: pointers and lengths)
+
+namespace ic {
+
+typedef __int128 i128;
+
+// ================================================================================================ values (oracle/values.py)
+struct V;
+typedef std::shared_ptr<const V> VP;
+struct V {
+  enum K { Null = 0, Bool = 1, Num = 2, Str = 3, Arr = 4, Obj = 5, Set = 6 } k = Null;
+  bool b = false;
+  bool is_int = true;
+  i128 i = 0;
+  double d = 0;
+  std::string s;
+  std::vector<VP> a;                      // Arr: in order; Set: sorted, unique
+  std::vector<std::pair<VP, VP>> o;       // Obj: sorted by key, unique keys
+};
+int compare(const VP& a, const VP& b);
+static VP mk_null() { static const VP v = std::make_shared<const V>(); return v; }
+static VP mk_bool(bool x) { static const VP t = [] { V v; v.k = V::Bool; v.b = true; return std::make_shared<const V>(v); }(), f = [] { V v; v.k = V::Bool; v.b = false; return std::make_shared<const V>(v); }(); return x ? t : f; }
+static VP mk_int(i128 x) { V v; v.k = V::Num; v.is_int = true; v.i = x; v.d = (double)x; return std::make_shared<const V>(std::move(v)); }
+static VP mk_float(double x) {   // (_norm: an integral float below 2^63 is the integer)
+  V v; v.k = V::Num;
+  if (std::isfinite(x) && std::floor(x) == x && std::fabs(x) < 9223372036854775808.0) { v.is_int = true; v.i = (i128)x; v.d = x; }
+  else { v.is_int = false; v.d = x; }
+  return std::make_shared<const V>(std::move(v));
+}
+static VP mk_str(std::string s) { V v; v.k = V::Str; v.s = std::move(s); return std::make_shared<const V>(std::move(v)); }
+static VP mk_arr(std::vector<VP> a) { V v; v.k = V::Arr; v.a = std::move(a); return std::make_shared<const V>(std::move(v)); }
+static VP mk_set(std::vector<VP> a) {
+  std::sort(a.begin(), a.end(), [](const VP& x, const VP& y) { return compare(x, y) < 0; });
+  a.erase(std::unique(a.begin(), a.end(), [](const VP& x, const VP& y) { return compare(x, y) == 0; }), a.end());
+  V v; v.k = V::Set; v.a = std::move(a); return std::make_shared<const V>(std::move(v));
+}
+static VP mk_obj(std::vector<std::pair<VP, VP>> o) {   // RObj(pairs): a later pair with an equal key replaces the earlier one
+  std::stable_sort(o.begin(), o.end(), [](const std::pair<VP, VP>& x, const std::pair<VP, VP>& y) { return compare(x.first, y.first) < 0; });
+  std::vector<std::pair<VP, VP>> out;
+  for (auto& p : o) { if (!out.empty() && compare(out.back().first, p.first) == 0) out.back().second = p.second; else out.push_back(p); }
+  V v; v.k = V::Obj; v.o = std::move(out); return std::make_shared<const V>(std::move(v));
+}
+static int cmp_num(const V& a, const V& b) {
+  if (a.is_int && b.is_int) return a.i < b.i ? -1 : (a.i > b.i ? 1 : 0);
+  const double x = a.is_int ? (double)a.i : a.d, y = b.is_int ? (double)b.i : b.d;
+  return x < y ? -1 : (x > y ? 1 : 0);
+}
+int compare(const VP& a, const VP& b) {   // values.py compare: null < boolean < number < string < array < object < set
+  if (a->k != b->k) return a->k < b->k ? -1 : 1;
+  switch (a->k) {
+    case V::Null: return 0;
+    case V::Bool: return (int)a->b - (int)b->b;
+    case V::Num: return cmp_num(*a, *b);
+    case V::Str: { const int c = a->s.compare(b->s); return c < 0 ? -1 : (c > 0 ? 1 : 0); }
+    case V::Arr: case V::Set: {
+      const size_t n = std::min(a->a.size(), b->a.size());
+      for (size_t i = 0; i < n; i++) { const int c = compare(a->a[i], b->a[i]); if (c) return c; }
+      return a->a.size() < b->a.size() ? -1 : (a->a.size() > b->a.size() ? 1 : 0);
+    }
+    case V::Obj: {
+      const size_t n = std::min(a->o.size(), b->o.size());
+      for (size_t i = 0; i < n; i++) {
+        int c = compare(a->o[i].first, b->o[i].first); if (c) return c;
+        c = compare(a->o[i].second, b->o[i].second); if (c) return c;
+      }
+      return a->o.size() < b->o.size() ? -1 : (a->o.size() > b->o.size() ? 1 : 0);
+    }
+  }
+  return 0;
+}
+static bool equal(const VP& a, const VP& b) { return compare(a, b) == 0; }
+static const VP* obj_get(const V& o, const VP& key) {
+  if (o.k != V::Obj) return nullptr;
+  auto it = std::lower_bound(o.o.begin(), o.o.end(), key, [](const std::pair<VP, VP>& p, const VP& k) { return compare(p.first, k) < 0; });
+  return it != o.o.end() && compare(it->first, key) == 0 ? &it->second : nullptr;
+}
+static const VP* obj_get(const V& o, const char* key) {
+  if (o.k != V::Obj) return nullptr;
+  for (auto& p : o.o) if (p.first->k == V::Str && p.first->s == key) return &p.second;
+  return nullptr;
+}
+static bool set_has(const V& s, const VP& x) { return std::binary_search(s.a.begin(), s.a.end(), x, [](const VP& p, const VP& q) { return compare(p, q) < 0; }); }
+static size_t utf8_len(const std::string& s) { size_t n = 0; for (unsigned char c : s) if ((c & 0xC0) != 0x80) n++; return n; }
+
+// ast term String() (values.py to_string) -- what sprintf("%v") prints
+static std::string quote(const std::string& s) {
+  std::string o = "\"";
+  char buf[8];
+  for (unsigned char c : s) {
+    switch (c) {
+      case '"': o += "\\\""; break; case '\\': o += "\\\\"; break; case '\n': o += "\\n"; break; case '\t': o += "\\t"; break; case '\r': o += "\\r"; break;
+      case '\a': o += "\\a"; break; case '\b': o += "\\b"; break; case '\f': o += "\\f"; break; case '\v': o += "\\v"; break;
+      default: if (c < 0x20 || c == 0x7F) { snprintf(buf, sizeof buf, "\\x%02x", c); o += buf; } else o.push_back((char)c);
+    }
+  }
+  return o + "\"";
+}
+static std::string i128_str(i128 x) {
+  if (x == 0) return "0";
+  const bool neg = x < 0;
+  unsigned __int128 u = neg ? (unsigned __int128)(-(x + 1)) + 1 : (unsigned __int128)x;
+  std::string s;
+  while (u) { s.push_back((char)('0' + (int)(u % 10))); u /= 10; }
+  if (neg) s.push_back('-');
+  std::reverse(s.begin(), s.end());
+  return s;
+}
+static std::string num_str(const V& v) {
+  if (v.is_int) return i128_str(v.i);
+  char buf[64];
+  snprintf(buf, sizeof buf, "%.17g", v.d);   // (the digits of a message are not what this checker compares: pair existence is)
+  return buf;
+}
+static std::string to_string(const VP& v) {
+  switch (v->k) {
+    case V::Null: return "null";
+    case V::Bool: return v->b ? "true" : "false";
+    case V::Num: return num_str(*v);
+    case V::Str: return quote(v->s);
+    case V::Arr: { std::string o = "["; for (size_t i = 0; i < v->a.size(); i++) { if (i) o += ", "; o += to_string(v->a[i]); } return o + "]"; }
+    case V::Obj: { std::string o = "{"; for (size_t i = 0; i < v->o.size(); i++) { if (i) o += ", "; o += to_string(v->o[i].first) + ": " + to_string(v->o[i].second); } return o + "}"; }
+    case V::Set: { if (v->a.empty()) return "set()"; std::string o = "{"; for (size_t i = 0; i < v->a.size(); i++) { if (i) o += ", "; o += to_string(v->a[i]); } return o + "}"; }
+  }
+  return "";
+}
+
+// ================================================================================================ JSON reader
+struct JsonErr : std::runtime_error { using std::runtime_error::runtime_error; };
+class Json {
+ public:
+  Json(const char* p, size_t n) : p_(p), e_(p + n) {}
+  VP parse() { ws(); VP v = value(0); ws(); if (p_ != e_) throw JsonErr("trailing characters"); return v; }
+
+ private:
+  const char *p_, *e_;
+  void ws() { while (p_ < e_ && (*p_ == ' ' || *p_ == '\n' || *p_ == '\t' || *p_ == '\r')) p_++; }
+  VP value(int depth) {
+    if (depth > 512) throw JsonErr("too deep");
+    if (p_ >= e_) throw JsonErr("unexpected end");
+    const char c = *p_;
+    if (c == '{') {
+      p_++; ws();
+      std::vector<std::pair<VP, VP>> pairs;
+      if (p_ < e_ && *p_ == '}') { p_++; return mk_obj(std::move(pairs)); }
+      for (;;) {
+        ws();
+        if (p_ >= e_ || *p_ != '"') throw JsonErr("expected key");
+        VP k = mk_str(str());
+        ws();
+        if (p_ >= e_ || *p_ != ':') throw JsonErr("expected ':'");
+        p_++; ws();
+        VP v = value(depth + 1);
+        pairs.emplace_back(std::move(k), std::move(v));
+        ws();
+        if (p_ < e_ && *p_ == ',') { p_++; continue; }
+        if (p_ < e_ && *p_ == '}') { p_++; break; }
+        throw JsonErr("expected ',' or '}'");
+      }
+      return mk_obj(std::move(pairs));   // (json.loads: the last of two equal keys wins)
+    }
+    if (c == '[') {
+      p_++; ws();
+      std::vector<VP> items;
+      if (p_ < e_ && *p_ == ']') { p_++; return mk_arr(std::move(items)); }
+      for (;;) {
+        ws();
+        items.push_back(value(depth + 1));
+        ws();
+        if (p_ < e_ && *p_ == ',') { p_++; continue; }
+        if (p_ < e_ && *p_ == ']') { p_++; break; }
+        throw JsonErr("expected ',' or ']'");
+      }
+      return mk_arr(std::move(items));
+    }
+    if (c == '"') return mk_str(str());
+    if (c == 't') { lit("true"); return mk_bool(true); }
+    if (c == 'f') { lit("false"); return mk_bool(false); }
+    if (c == 'n') { lit("null"); return mk_null(); }
+    return number();
+  }
+  void lit(const char* w) { const size_t n = strlen(w); if ((size_t)(e_ - p_) < n || memcmp(p_, w, n) != 0) throw JsonErr("bad literal"); p_ += n; }
+  VP number() {   // (json.loads: int without fraction / exponent, else float)
+    const char* s = p_;
+    bool is_int = true;
+    if (p_ < e_ && *p_ == '-') p_++;
+    if (p_ >= e_ || !(*p_ >= '0' && *p_ <= '9')) throw JsonErr("bad number");
+    while (p_ < e_ && *p_ >= '0' && *p_ <= '9') p_++;
+    if (p_ < e_ && *p_ == '.') { is_int = false; p_++; while (p_ < e_ && *p_ >= '0' && *p_ <= '9') p_++; }
+    if (p_ < e_ && (*p_ == 'e' || *p_ == 'E')) { is_int = false; p_++; if (p_ < e_ && (*p_ == '+' || *p_ == '-')) p_++; while (p_ < e_ && *p_ >= '0' && *p_ <= '9') p_++; }
+    const std::string t(s, p_ - s);
+    if (is_int && t.size() <= 37) {
+      i128 x = 0; size_t k = t[0] == '-' ? 1 : 0;
+      for (; k < t.size(); k++) x = x * 10 + (t[k] - '0');
+      return mk_int(t[0] == '-' ? -x : x);
+    }
+    V v; v.k = V::Num; v.is_int = false; v.d = strtod(t.c_str(), nullptr);   // (a Python float: no normalisation to int at read time; compare / equal are numeric)
+    return std::make_shared<const V>(std::move(v));
+  }
+  static void utf8(std::string& o, uint32_t cp) {
+    if (cp < 0x80) o.push_back((char)cp);
+    else if (cp < 0x800) { o.push_back((char)(0xC0 | (cp >> 6))); o.push_back((char)(0x80 | (cp & 0x3F))); }
+    else if (cp < 0x10000) { o.push_back((char)(0xE0 | (cp >> 12))); o.push_back((char)(0x80 | ((cp >> 6) & 0x3F))); o.push_back((char)(0x80 | (cp & 0x3F))); }
+    else { o.push_back((char)(0xF0 | (cp >> 18))); o.push_back((char)(0x80 | ((cp >> 12) & 0x3F))); o.push_back((char)(0x80 | ((cp >> 6) & 0x3F))); o.push_back((char)(0x80 | (cp & 0x3F))); }
+  }
+  uint32_t hex4() {
+    if (e_ - p_ < 4) throw JsonErr("bad escape");
+    uint32_t v = 0;
+    for (int k = 0; k < 4; k++) { const char c = *p_++; v <<= 4; if (c >= '0' && c <= '9') v |= c - '0'; else if (c >= 'a' && c <= 'f') v |= c - 'a' + 10; else if (c >= 'A' && c <= 'F') v |= c - 'A' + 10; else throw JsonErr("bad escape"); }
+    return v;
+  }
+  std::string str() {
+    p_++;
+    std::string o;
+    for (;;) {
+      if (p_ >= e_) throw JsonErr("unterminated string");
+      const char c = *p_++;
+      if (c == '"') return o;
+      if (c != '\\') { o.push_back(c); continue; }
+      if (p_ >= e_) throw JsonErr("bad escape");
+      const char x = *p_++;
+      switch (x) {
+        case '"': o.push_back('"'); break; case '\\': o.push_back('\\'); break; case '/': o.push_back('/'); break; case 'b': o.push_back('\b'); break;
+        case 'f': o.push_back('\f'); break; case 'n': o.push_back('\n'); break; case 'r': o.push_back('\r'); break; case 't': o.push_back('\t'); break;
+        case 'u': {
+          uint32_t cp = hex4();
+          if (cp >= 0xD800 && cp < 0xDC00 && e_ - p_ >= 6 && p_[0] == '\\' && p_[1] == 'u') {
+            const char* save = p_;
+            p_ += 2;
+            const uint32_t lo = hex4();
+            if (lo >= 0xDC00 && lo < 0xE000) cp = 0x10000 + ((cp - 0xD800) << 10) + (lo - 0xDC00); else p_ = save;
+          }
+          utf8(o, cp);
+          break;
+        }
+        default: throw JsonErr("bad escape");
+      }
+    }
+  }
+};
+static VP parse_json(const char* p, size_t n) { return Json(p, n).parse(); }
+
+// ================================================================================================ Rego AST + parser (oracle/rego_parser.py)
+struct RegoErr : std::runtime_error { using std::runtime_error::runtime_error; };
+struct Term;
+typedef std::shared_ptr<const Term> TP;
+struct Literal;
+typedef std::vector<Literal> Body;
+struct Term {
+  enum K { Scalar, Var, Ref, Call, Array, Object, SetT, ArrComp, SetComp, ObjComp, BinOp } k = Scalar;
+  VP val;                          // Scalar
+  std::string name;                // Var name; BinOp operator
+  TP head, head2;                  // Ref head; comprehension head (key for ObjComp) / value
+  std::vector<TP> args;            // Ref operands; Call args; Array / Set elements; Object k, v, k, v..; BinOp l, r
+  std::vector<std::string> path;   // Call: dotted name
+  std::shared_ptr<const Body> body;
+};
+struct Literal {
+  enum K { Expr, Assign, Unify, Not, Some, SomeIn, Every } k = Expr;
+  TP a, b, c;                      // Expr: a; Assign / Unify: a, b; SomeIn / Every: key a (may be null), value b, collection c
+  std::vector<std::string> names;  // Some
+  std::shared_ptr<const Literal> inner;
+  std::shared_ptr<const Body> body;
+};
+struct Rule {
+  enum K { Complete, SetR, ObjectR, Func } k = Complete;
+  std::string name;
+  std::vector<TP> args;
+  TP key, value;
+  Body body;
+  bool is_default = false;
+  std::vector<std::pair<TP, Body>> elses;
+  std::vector<std::string> pkg;
+  std::map<std::string, std::vector<std::string>> imports;   // alias -> path
+};
+struct Module { std::vector<std::string> package; std::vector<std::pair<std::vector<std::string>, std::string>> imports; std::vector<Rule> rules; };
+
+struct Tok { enum K { NL, Num, Ident, Kw, Str, Op, Eof } k; std::string s; VP num; int line; };
+static const std::set<std::string> KEYWORDS = {"package", "import", "default", "not", "some", "every", "in", "if", "contains", "else", "with", "as", "true", "false", "null"};
+static std::vector<Tok> tokenize(const std::string& src) {
+  std::vector<Tok> toks;
+  size_t pos = 0;
+  int line = 1;
+  auto isid0 = [](char c) { return (c >= 'A' && c <= 'Z') || (c >= 'a' && c <= 'z') || c == '_'; };
+  auto isdig = [](char c) { return c >= '0' && c <= '9'; };
+  while (pos < src.size()) {
+    const char c = src[pos];
+    if (c == ' ' || c == '\t' || c == '\r') { pos++; continue; }
+    if (c == '#') { while (pos < src.size() && src[pos] != '\n') pos++; continue; }
+    if (c == '\n') { toks.push_back({Tok::NL, "\n", nullptr, line}); line++; pos++; continue; }
+    if (isdig(c) || (c == '.' && pos + 1 < src.size() && isdig(src[pos + 1]))) {
+      size_t q = pos;
+      bool flt = false;
+      while (q < src.size() && isdig(src[q])) q++;
+      if (q < src.size() && src[q] == '.' && q + 1 < src.size() && isdig(src[q + 1])) { flt = true; q++; while (q < src.size() && isdig(src[q])) q++; }
+      if (q < src.size() && (src[q] == 'e' || src[q] == 'E')) {
+        size_t r = q + 1;
+        if (r < src.size() && (src[r] == '+' || src[r] == '-')) r++;
+        if (r < src.size() && isdig(src[r])) { flt = true; q = r; while (q < src.size() && isdig(src[q])) q++; }
+      }
+      const std::string t = src.substr(pos, q - pos);
+      VP v;
+      if (flt) { V x; x.k = V::Num; x.is_int = false; x.d = strtod(t.c_str(), nullptr); v = std::make_shared<const V>(std::move(x)); }
+      else { i128 x = 0; for (char d : t) x = x * 10 + (d - '0'); v = mk_int(x); }
+      toks.push_back({Tok::Num, t, v, line});
+      pos = q;
+      continue;
+    }
+    if (isid0(c)) {
+      size_t q = pos;
+      while (q < src.size() && (isid0(src[q]) || isdig(src[q]))) q++;
+      const std::string t = src.substr(pos, q - pos);
+      toks.push_back({KEYWORDS.count(t) ? Tok::Kw : Tok::Ident, t, nullptr, line});
+      pos = q;
+      continue;
+    }
+    if (c == '"') {
+      size_t q = pos + 1;
+      std::string o;
+      for (;;) {
+        if (q >= src.size() || src[q] == '\n') throw RegoErr("line " + std::to_string(line) + ": unterminated string");
+        const char d = src[q++];
+        if (d == '"') break;
+        if (d != '\\') { o.push_back(d); continue; }
+        if (q >= src.size()) throw RegoErr("bad escape");
+        const char e = src[q++];
+        switch (e) {
+          case '"': o.push_back('"'); break; case '\\': o.push_back('\\'); break; case '/': o.push_back('/'); break; case 'b': o.push_back('\b'); break;
+          case 'f': o.push_back('\f'); break; case 'n': o.push_back('\n'); break; case 'r': o.push_back('\r'); break; case 't': o.push_back('\t'); break;
+          case 'u': {
+            if (q + 4 > src.size()) throw RegoErr("bad escape");
+            const uint32_t cp = (uint32_t)strtoul(src.substr(q, 4).c_str(), nullptr, 16);
+            q += 4;
+            if (cp < 0x80) o.push_back((char)cp);
+            else if (cp < 0x800) { o.push_back((char)(0xC0 | (cp >> 6))); o.push_back((char)(0x80 | (cp & 0x3F))); }
+            else { o.push_back((char)(0xE0 | (cp >> 12))); o.push_back((char)(0x80 | ((cp >> 6) & 0x3F))); o.push_back((char)(0x80 | (cp & 0x3F))); }
+            break;
+          }
+          default: throw RegoErr(std::string("bad escape \\") + e);
+        }
+      }
+      toks.push_back({Tok::Str, o, nullptr, line});
+      pos = q;
+      continue;
+    }
+    if (c == '`') {
+      const size_t q = src.find('`', pos + 1);
+      if (q == std::string::npos) throw RegoErr("unterminated raw string");
+      const std::string t = src.substr(pos + 1, q - pos - 1);
+      toks.push_back({Tok::Str, t, nullptr, line});
+      line += (int)std::count(t.begin(), t.end(), '\n');
+      pos = q + 1;
+      continue;
+    }
+    static const char* two[] = {":=", "==", "!=", "<=", ">="};
+    bool done = false;
+    for (const char* t : two) if (src.compare(pos, 2, t) == 0) { toks.push_back({Tok::Op, t, nullptr, line}); pos += 2; done = true; break; }
+    if (done) continue;
+    if (strchr("{}[]().,;:|=<>+-*/%&", c)) { toks.push_back({Tok::Op, std::string(1, c), nullptr, line}); pos++; continue; }
+    throw RegoErr("line " + std::to_string(line) + ": unexpected character");
+  }
+  toks.push_back({Tok::Eof, "", nullptr, line});
+  return toks;
+}
+
+class Parser {
+ public:
+  explicit Parser(const std::string& src) : toks_(tokenize(src)) {}
+  Module parse_module() {
+    Module m;
+    skip_nl();
+    expect(Tok::Kw, "package");
+    m.package = parse_dotted();
+    for (;;) {
+      skip_nl();
+      if (at(Tok::Eof)) break;
+      if (accept(Tok::Kw, "import")) {
+        std::vector<std::string> path = parse_dotted();
+        std::string alias;
+        if (accept(Tok::Kw, "as")) alias = expect(Tok::Ident).s;
+        m.imports.emplace_back(path, alias);
+        continue;
+      }
+      m.rules.push_back(parse_rule());
+    }
+    return m;
+  }
+
+ private:
+  std::vector<Tok> toks_;
+  size_t i_ = 0;
+  int wild_ = 0;
+  const Tok& peek(bool skip = false) const { size_t i = i_; if (skip) while (toks_[i].k == Tok::NL) i++; return toks_[i]; }
+  const Tok& next(bool skip = false) { if (skip) skip_nl(); return toks_[i_++]; }
+  void skip_nl() { while (toks_[i_].k == Tok::NL) i_++; }
+  bool at(Tok::K k, const char* v = nullptr, bool skip = false) const { const Tok& t = peek(skip); return t.k == k && (!v || t.s == v); }
+  bool at_op(const char* v, bool skip = false) const { return at(Tok::Op, v, skip); }
+  bool accept(Tok::K k, const char* v = nullptr, bool skip = false) { if (at(k, v, skip)) { next(skip); return true; } return false; }
+  const Tok& expect(Tok::K k, const char* v = nullptr, bool skip = false) {
+    const Tok& t = next(skip);
+    if (t.k != k || (v && t.s != v)) throw RegoErr("line " + std::to_string(t.line) + ": expected " + (v ? v : "token") + ", got " + t.s);
+    return t;
+  }
+  [[noreturn]] void err(const std::string& m) const { throw RegoErr("line " + std::to_string(peek().line) + ": " + m + " (at " + peek().s + ")"); }
+  std::vector<std::string> parse_dotted() {
+    const Tok& t = next();
+    if (t.k != Tok::Ident && t.k != Tok::Kw) throw RegoErr("expected identifier");
+    std::vector<std::string> parts{t.s};
+    for (;;) {
+      if (accept(Tok::Op, ".")) parts.push_back(next().s);
+      else if (at_op("[")) { next(); parts.push_back(expect(Tok::Str).s); expect(Tok::Op, "]"); }
+      else break;
+    }
+    return parts;
+  }
+  Rule parse_rule() {
+    Rule r;
+    r.is_default = accept(Tok::Kw, "default");
+    r.name = expect(Tok::Ident).s;
+    if (at_op("(")) {
+      next(); skip_nl();
+      while (!at_op(")", true)) { r.args.push_back(parse_term()); if (!accept(Tok::Op, ",", true)) break; }
+      expect(Tok::Op, ")", true);
+      r.k = Rule::Func;
+    } else if (at_op("[")) {
+      next();
+      r.key = parse_term();
+      expect(Tok::Op, "]", true);
+      r.k = Rule::SetR;
+    } else if (accept(Tok::Kw, "contains")) {
+      skip_nl();
+      r.key = parse_term();
+      r.k = Rule::SetR;
+    }
+    if (at_op("=") || at_op(":=")) { next(); r.value = parse_term(); if (r.k == Rule::SetR) r.k = Rule::ObjectR; }
+    const bool has_if = accept(Tok::Kw, "if", at(Tok::Kw, "if", true));
+    if (has_if) skip_nl();
+    if (at_op("{")) r.body = parse_braced_body();
+    else if (has_if) r.body.push_back(parse_literal());
+    while (at(Tok::Kw, "else", true)) {
+      next(true);
+      TP val;
+      if (at_op("=") || at_op(":=")) { next(); val = parse_term(); }
+      accept(Tok::Kw, "if");
+      Body b;
+      if (at_op("{")) b = parse_braced_body();
+      else if (at(Tok::NL) || at(Tok::Eof)) {}
+      else b.push_back(parse_literal());
+      r.elses.emplace_back(val, b);
+    }
+    if (r.is_default && !r.value) err("default rule needs a value");
+    return r;
+  }
+  Body parse_braced_body() { expect(Tok::Op, "{"); Body b = parse_body_until("}"); expect(Tok::Op, "}", true); return b; }
+  Body parse_body_until(const char* closer) {
+    Body lits;
+    for (;;) {
+      skip_nl();
+      while (accept(Tok::Op, ";")) skip_nl();
+      if (at_op(closer)) break;
+      lits.push_back(parse_literal());
+      if (!(at(Tok::NL) || at_op(";") || at_op(closer))) err("expected end of literal");
+    }
+    return lits;
+  }
+  Literal parse_literal() {
+    Literal l;
+    if (accept(Tok::Kw, "not")) { l.k = Literal::Not; l.inner = std::make_shared<const Literal>(parse_literal()); return l; }
+    if (at(Tok::Kw, "some")) {
+      next();
+      TP first = parse_term(false, true);
+      if (at_op(",")) {
+        next();
+        TP second = parse_term(false, true);
+        if (accept(Tok::Kw, "in")) { l.k = Literal::SomeIn; l.a = first; l.b = second; l.c = parse_term(); return l; }
+        l.k = Literal::Some;
+        l.names = {first->name, second->name};
+        while (accept(Tok::Op, ",")) l.names.push_back(parse_term(false, true)->name);
+        return l;
+      }
+      if (accept(Tok::Kw, "in")) { l.k = Literal::SomeIn; l.b = first; l.c = parse_term(); return l; }
+      l.k = Literal::Some;
+      l.names = {first->name};
+      return l;
+    }
+    if (at(Tok::Kw, "every")) {
+      next();
+      TP first = parse_term(false, true), key;
+      if (accept(Tok::Op, ",")) { key = first; first = parse_term(false, true); }
+      expect(Tok::Kw, "in");
+      l.k = Literal::Every; l.a = key; l.b = first; l.c = parse_term();
+      l.body = std::make_shared<const Body>(parse_braced_body());
+      return l;
+    }
+    TP lhs = parse_term();
+    if (at_op(":=")) { next(); l.k = Literal::Assign; l.a = lhs; l.b = parse_term(false, false, true); }
+    else if (at_op("=")) { next(); l.k = Literal::Unify; l.a = lhs; l.b = parse_term(false, false, true); }
+    else { l.k = Literal::Expr; l.a = lhs; }
+    if (at(Tok::Kw, "with")) err("`with` is not supported");
+    return l;
+  }
+  static TP binop(const std::string& op, TP l, TP r) { Term t; t.k = Term::BinOp; t.name = op; t.args = {l, r}; return std::make_shared<const Term>(std::move(t)); }
+  TP parse_term(bool no_bitor = false, bool no_in = false, bool after_op = false) { if (after_op) skip_nl(); return parse_relation(no_bitor, no_in); }
+  TP parse_relation(bool no_bitor, bool no_in) {
+    TP l = parse_bitor(no_bitor);
+    for (;;) {
+      const Tok& t = peek();
+      if (t.k == Tok::Op && (t.s == "==" || t.s == "!=" || t.s == "<" || t.s == "<=" || t.s == ">" || t.s == ">=")) {
+        const std::string op = t.s;
+        next(); skip_nl();
+        l = binop(op, l, parse_bitor(no_bitor));
+      } else if (t.k == Tok::Kw && t.s == "in" && !no_in) { next(); l = binop("in", l, parse_bitor(no_bitor)); }
+      else return l;
+    }
+  }
+  TP parse_bitor(bool no_bitor) { TP l = parse_bitand(); while (!no_bitor && at_op("|")) { next(); skip_nl(); l = binop("|", l, parse_bitand()); } return l; }
+  TP parse_bitand() { TP l = parse_arith(); while (at_op("&")) { next(); skip_nl(); l = binop("&", l, parse_arith()); } return l; }
+  TP parse_arith() { TP l = parse_factor(); while (at_op("+") || at_op("-")) { const std::string op = next().s; skip_nl(); l = binop(op, l, parse_factor()); } return l; }
+  TP parse_factor() { TP l = parse_unary(); while (at_op("*") || at_op("/") || at_op("%")) { const std::string op = next().s; skip_nl(); l = binop(op, l, parse_unary()); } return l; }
+  static TP scalar(VP v) { Term t; t.k = Term::Scalar; t.val = std::move(v); return std::make_shared<const Term>(std::move(t)); }
+  static TP var(const std::string& n) { Term t; t.k = Term::Var; t.name = n; return std::make_shared<const Term>(std::move(t)); }
+  TP parse_unary() {
+    if (at_op("-")) {
+      next();
+      TP t = parse_unary();
+      if (t->k == Term::Scalar && t->val->k == V::Num) {
+        if (t->val->is_int) return scalar(mk_int(-t->val->i));
+        V x; x.k = V::Num; x.is_int = false; x.d = -t->val->d;
+        return scalar(std::make_shared<const V>(std::move(x)));
+      }
+      return binop("-", scalar(mk_int(0)), t);
+    }
+    return parse_postfix(parse_primary());
+  }
+  TP parse_postfix(TP head) {
+    std::vector<TP> ops;
+    for (;;) {
+      if (at_op(".")) { next(); const Tok& t = next(); if (t.k != Tok::Ident && t.k != Tok::Kw) throw RegoErr("expected field name"); ops.push_back(scalar(mk_str(t.s))); }
+      else if (at_op("[")) { next(); skip_nl(); ops.push_back(parse_term()); expect(Tok::Op, "]", true); }
+      else if (at_op("(")) {
+        if (head->k != Term::Var) err("call on non-name");
+        std::vector<std::string> path{head->name};
+        for (auto& o : ops) { if (o->k != Term::Scalar || o->val->k != V::Str) err("call on non-name"); path.push_back(o->val->s); }
+        next(); skip_nl();
+        Term c; c.k = Term::Call; c.path = path;
+        while (!at_op(")", true)) { c.args.push_back(parse_term()); if (!accept(Tok::Op, ",", true)) break; }
+        expect(Tok::Op, ")", true);
+        head = std::make_shared<const Term>(std::move(c));
+        ops.clear();
+      } else break;
+    }
+    if (!ops.empty()) { Term r; r.k = Term::Ref; r.head = head; r.args = ops; return std::make_shared<const Term>(std::move(r)); }
+    return head;
+  }
+  TP parse_primary() {
+    const Tok t = next();
+    if (t.k == Tok::Num) return scalar(t.num);
+    if (t.k == Tok::Str) return scalar(mk_str(t.s));
+    if (t.k == Tok::Kw) {
+      if (t.s == "true") return scalar(mk_bool(true));
+      if (t.s == "false") return scalar(mk_bool(false));
+      if (t.s == "null") return scalar(mk_null());
+      if (t.s == "contains") return var(t.s);
+      throw RegoErr("line " + std::to_string(t.line) + ": unexpected keyword " + t.s);
+    }
+    if (t.k == Tok::Ident) {
+      if (t.s == "_") return var("$w" + std::to_string(++wild_));
+      if (t.s == "set" && at_op("(")) {
+        const size_t save = i_;
+        next();
+        if (accept(Tok::Op, ")")) { Term s; s.k = Term::SetT; return std::make_shared<const Term>(std::move(s)); }
+        i_ = save;
+      }
+      return var(t.s);
+    }
+    if (t.k == Tok::Op) {
+      if (t.s == "(") { skip_nl(); TP e = parse_term(); expect(Tok::Op, ")", true); return e; }
+      if (t.s == "[") return parse_array_or_comp();
+      if (t.s == "{") return parse_brace_term();
+    }
+    throw RegoErr("line " + std::to_string(t.line) + ": unexpected token " + t.s);
+  }
+  TP parse_array_or_comp() {
+    skip_nl();
+    Term a; a.k = Term::Array;
+    if (accept(Tok::Op, "]")) return std::make_shared<const Term>(std::move(a));
+    TP first = parse_term(true);
+    if (at_op("|", true)) {
+      next(true);
+      Term c; c.k = Term::ArrComp; c.head = first; c.body = std::make_shared<const Body>(parse_body_until("]"));
+      expect(Tok::Op, "]", true);
+      return std::make_shared<const Term>(std::move(c));
+    }
+    a.args.push_back(first);
+    while (accept(Tok::Op, ",", true)) { skip_nl(); if (at_op("]")) break; a.args.push_back(parse_term()); }
+    expect(Tok::Op, "]", true);
+    return std::make_shared<const Term>(std::move(a));
+  }
+  TP parse_brace_term() {
+    skip_nl();
+    if (accept(Tok::Op, "}")) { Term o; o.k = Term::Object; return std::make_shared<const Term>(std::move(o)); }
+    TP first = parse_term(true);
+    if (at_op(":", true)) {
+      next(true); skip_nl();
+      TP val = parse_term(true);
+      if (at_op("|", true)) {
+        next(true);
+        Term c; c.k = Term::ObjComp; c.head = first; c.head2 = val; c.body = std::make_shared<const Body>(parse_body_until("}"));
+        expect(Tok::Op, "}", true);
+        return std::make_shared<const Term>(std::move(c));
+      }
+      Term o; o.k = Term::Object; o.args = {first, val};
+      while (accept(Tok::Op, ",", true)) {
+        skip_nl();
+        if (at_op("}")) break;
+        TP k = parse_term();
+        expect(Tok::Op, ":", true); skip_nl();
+        o.args.push_back(k); o.args.push_back(parse_term());
+      }
+      expect(Tok::Op, "}", true);
+      return std::make_shared<const Term>(std::move(o));
+    }
+    if (at_op("|", true)) {
+      next(true);
+      Term c; c.k = Term::SetComp; c.head = first; c.body = std::make_shared<const Body>(parse_body_until("}"));
+      expect(Tok::Op, "}", true);
+      return std::make_shared<const Term>(std::move(c));
+    }
+    Term s; s.k = Term::SetT; s.args.push_back(first);
+    while (accept(Tok::Op, ",", true)) { skip_nl(); if (at_op("}")) break; s.args.push_back(parse_term()); }
+    expect(Tok::Op, "}", true);
+    return std::make_shared<const Term>(std::move(s));
+  }
+};
+
+// ================================================================================================ builtins (oracle/rego_builtins.py, the ones the bench's policies call)
+struct BuiltinErr {};   // the call is undefined
+static const V& need(const VP& v, V::K k) { if (v->k != k) throw BuiltinErr(); return *v; }
+static VP arith(const std::string& op, const VP& a, const VP& b) {
+  if (op == "-" && a->k == V::Set && b->k == V::Set) { std::vector<VP> o; for (auto& x : a->a) if (!set_has(*b, x)) o.push_back(x); return mk_set(std::move(o)); }
+  if (op == "&") { need(a, V::Set); need(b, V::Set); std::vector<VP> o; for (auto& x : a->a) if (set_has(*b, x)) o.push_back(x); return mk_set(std::move(o)); }
+  if (op == "|") { need(a, V::Set); need(b, V::Set); std::vector<VP> o = a->a; o.insert(o.end(), b->a.begin(), b->a.end()); return mk_set(std::move(o)); }
+  const V& x = need(a, V::Num); const V& y = need(b, V::Num);
+  const bool ii = x.is_int && y.is_int;
+  const double dx = x.is_int ? (double)x.i : x.d, dy = y.is_int ? (double)y.i : y.d;
+  if (op == "+") return ii ? mk_int(x.i + y.i) : mk_float(dx + dy);
+  if (op == "-") return ii ? mk_int(x.i - y.i) : mk_float(dx - dy);
+  if (op == "*") return ii ? mk_int(x.i * y.i) : mk_float(dx * dy);
+  if (op == "/") {
+    if (dy == 0) throw BuiltinErr();
+    if (ii && x.i % y.i == 0) return mk_int(x.i / y.i);
+    return mk_float(dx / dy);
+  }
+  if (op == "%") {
+    if ((!x.is_int && std::floor(x.d) != x.d) || (!y.is_int && std::floor(y.d) != y.d)) throw BuiltinErr();
+    const i128 p = x.is_int ? x.i : (i128)x.d, q = y.is_int ? y.i : (i128)y.d;
+    if (q == 0) throw BuiltinErr();
+    const i128 r = (p < 0 ? -p : p) % (q < 0 ? -q : q);
+    return mk_int(p < 0 ? -r : r);
+  }
+  throw BuiltinErr();
+}
+static std::string go_sprintf(const std::string& fmt, const std::vector<VP>& args) {   // (%v / %s / %d of what the policies print; the digits are not compared)
+  std::string o;
+  size_t ai = 0;
+  for (size_t i = 0; i < fmt.size(); i++) {
+    if (fmt[i] != '%') { o.push_back(fmt[i]); continue; }
+    if (++i >= fmt.size()) { o += "%!(NOVERB)"; break; }
+    while (i < fmt.size() && strchr("+-# 0123456789.", fmt[i])) i++;
+    if (i >= fmt.size()) { o += "%!(NOVERB)"; break; }
+    const char verb = fmt[i];
+    if (verb == '%') { o.push_back('%'); continue; }
+    if (ai >= args.size()) { o += std::string("%!") + verb + "(MISSING)"; continue; }
+    const VP& a = args[ai++];
+    if (a->k == V::Str && (verb == 'v' || verb == 's')) o += a->s;
+    else if (a->k == V::Num && (verb == 'v' || verb == 'd')) o += num_str(*a);
+    else o += to_string(a);
+  }
+  if (ai < args.size()) o += "%!(EXTRA)";
+  return o;
+}
+static std::shared_ptr<const std::regex> go_regex(const std::string& pat) {   // (the policies' patterns -- ^[0-9]+$, anchors, classes -- mean the same in ECMAScript)
+  static std::mutex mu;
+  static std::map<std::string, std::shared_ptr<const std::regex>> cache;
+  std::lock_guard<std::mutex> l(mu);
+  auto it = cache.find(pat);
+  if (it != cache.end()) return it->second;
+  std::shared_ptr<const std::regex> r;
+  try { r = std::make_shared<const std::regex>(pat, std::regex::ECMAScript); } catch (const std::regex_error&) { r = nullptr; }
+  cache[pat] = r;
+  return r;
+}
+typedef VP (*BuiltinFn)(const std::vector<VP>&);
+static const std::map<std::string, std::pair<int, BuiltinFn>>& BUILTINS() {
+  static const std::map<std::string, std::pair<int, BuiltinFn>> m = {
+      {"count", {1, [](const std::vector<VP>& a) -> VP { const V& x = *a[0]; if (x.k == V::Str) return mk_int((i128)utf8_len(x.s)); if (x.k == V::Arr || x.k == V::Set) return mk_int((i128)x.a.size()); if (x.k == V::Obj) return mk_int((i128)x.o.size()); throw BuiltinErr(); }}},
+      {"any", {1, [](const std::vector<VP>& a) -> VP { if (a[0]->k != V::Arr && a[0]->k != V::Set) throw BuiltinErr(); for (auto& x : a[0]->a) if (x->k == V::Bool && x->b) return mk_bool(true); return mk_bool(false); }}},
+      {"all", {1, [](const std::vector<VP>& a) -> VP { if (a[0]->k != V::Arr && a[0]->k != V::Set) throw BuiltinErr(); for (auto& x : a[0]->a) if (!(x->k == V::Bool && x->b)) return mk_bool(false); return mk_bool(true); }}},
+      {"startswith", {2, [](const std::vector<VP>& a) -> VP { const std::string& s = need(a[0], V::Str).s; const std::string& p = need(a[1], V::Str).s; return mk_bool(s.size() >= p.size() && s.compare(0, p.size(), p) == 0); }}},
+      {"endswith", {2, [](const std::vector<VP>& a) -> VP { const std::string& s = need(a[0], V::Str).s; const std::string& p = need(a[1], V::Str).s; return mk_bool(s.size() >= p.size() && s.compare(s.size() - p.size(), p.size(), p) == 0); }}},
+      {"contains", {2, [](const std::vector<VP>& a) -> VP { return mk_bool(need(a[0], V::Str).s.find(need(a[1], V::Str).s) != std::string::npos); }}},
+      {"is_string", {1, [](const std::vector<VP>& a) -> VP { return mk_bool(a[0]->k == V::Str); }}},
+      {"is_number", {1, [](const std::vector<VP>& a) -> VP { return mk_bool(a[0]->k == V::Num); }}},
+      {"is_boolean", {1, [](const std::vector<VP>& a) -> VP { return mk_bool(a[0]->k == V::Bool); }}},
+      {"is_array", {1, [](const std::vector<VP>& a) -> VP { return mk_bool(a[0]->k == V::Arr); }}},
+      {"is_object", {1, [](const std::vector<VP>& a) -> VP { return mk_bool(a[0]->k == V::Obj); }}},
+      {"is_set", {1, [](const std::vector<VP>& a) -> VP { return mk_bool(a[0]->k == V::Set); }}},
+      {"is_null", {1, [](const std::vector<VP>& a) -> VP { return mk_bool(a[0]->k == V::Null); }}},
+      {"sprintf", {2, [](const std::vector<VP>& a) -> VP { return mk_str(go_sprintf(need(a[0], V::Str).s, need(a[1], V::Arr).a)); }}},
+      {"re_match", {2, [](const std::vector<VP>& a) -> VP { auto r = go_regex(need(a[0], V::Str).s); const std::string& s = need(a[1], V::Str).s; if (!r) throw BuiltinErr(); return mk_bool(std::regex_search(s, *r)); }}},
+      {"regex.match", {2, [](const std::vector<VP>& a) -> VP { auto r = go_regex(need(a[0], V::Str).s); const std::string& s = need(a[1], V::Str).s; if (!r) throw BuiltinErr(); return mk_bool(std::regex_search(s, *r)); }}},
+      {"replace", {3, [](const std::vector<VP>& a) -> VP {
+         const std::string& s = need(a[0], V::Str).s; const std::string& old = need(a[1], V::Str).s; const std::string& nw = need(a[2], V::Str).s;
+         std::string o;
+         if (old.empty()) {   // str.replace("", new): between every two code points and at both ends
+           o = nw;
+           for (size_t i = 0; i < s.size();) { size_t j = i + 1; while (j < s.size() && ((unsigned char)s[j] & 0xC0) == 0x80) j++; o.append(s, i, j - i); o += nw; i = j; }
+           return mk_str(o);
+         }
+         for (size_t i = 0; i < s.size();) { if (s.compare(i, old.size(), old) == 0) { o += nw; i += old.size(); } else o.push_back(s[i++]); }
+         return mk_str(o);
+       }}},
+      {"split", {2, [](const std::vector<VP>& a) -> VP {
+         const std::string& s = need(a[0], V::Str).s; const std::string& d = need(a[1], V::Str).s;
+         std::vector<VP> o;
+         if (d.empty()) { for (size_t i = 0; i < s.size();) { size_t j = i + 1; while (j < s.size() && ((unsigned char)s[j] & 0xC0) == 0x80) j++; o.push_back(mk_str(s.substr(i, j - i))); i = j; } return mk_arr(std::move(o)); }
+         size_t pos = 0;
+         for (;;) { const size_t q = s.find(d, pos); if (q == std::string::npos) { o.push_back(mk_str(s.substr(pos))); break; } o.push_back(mk_str(s.substr(pos, q - pos))); pos = q + d.size(); }
+         return mk_arr(std::move(o));
+       }}},
+      {"substring", {3, [](const std::vector<VP>& a) -> VP {   // by code point
+         const std::string& s = need(a[0], V::Str).s; const V& off = need(a[1], V::Num); const V& ln = need(a[2], V::Num);
+         const long long o = off.is_int ? (long long)off.i : (long long)off.d, l = ln.is_int ? (long long)ln.i : (long long)ln.d;
+         if (o < 0) throw BuiltinErr();
+         std::vector<size_t> starts;
+         for (size_t i = 0; i < s.size(); i++) if (((unsigned char)s[i] & 0xC0) != 0x80) starts.push_back(i);
+         if ((size_t)o >= starts.size()) return mk_str("");
+         const size_t b = starts[(size_t)o];
+         if (l < 0 || (size_t)(o + l) >= starts.size()) return mk_str(s.substr(b));
+         return mk_str(s.substr(b, starts[(size_t)(o + l)] - b));
+       }}},
+      {"trim", {2, [](const std::vector<VP>& a) -> VP {   // (ASCII cut sets, as the policies use)
+         const std::string& s = need(a[0], V::Str).s; const std::string& cut = need(a[1], V::Str).s;
+         if (cut.empty()) return a[0];
+         size_t lo = 0, hi = s.size();
+         while (lo < hi && cut.find(s[lo]) != std::string::npos) lo++;
+         while (hi > lo && cut.find(s[hi - 1]) != std::string::npos) hi--;
+         return mk_str(s.substr(lo, hi - lo));
+       }}},
+      {"trim_prefix", {2, [](const std::vector<VP>& a) -> VP { const std::string& s = need(a[0], V::Str).s; const std::string& p = need(a[1], V::Str).s; return s.size() >= p.size() && s.compare(0, p.size(), p) == 0 ? mk_str(s.substr(p.size())) : a[0]; }}},
+      {"trim_suffix", {2, [](const std::vector<VP>& a) -> VP { const std::string& s = need(a[0], V::Str).s; const std::string& p = need(a[1], V::Str).s; return !p.empty() && s.size() >= p.size() && s.compare(s.size() - p.size(), p.size(), p) == 0 ? mk_str(s.substr(0, s.size() - p.size())) : a[0]; }}},
+      {"lower", {1, [](const std::vector<VP>& a) -> VP { std::string s = need(a[0], V::Str).s; for (char& c : s) if (c >= 'A' && c <= 'Z') c = (char)(c + 32); for (unsigned char c : s) if (c >= 0x80) throw std::runtime_error("lower: non-ASCII text is outside this checker's scope"); return mk_str(s); }}},
+      {"upper", {1, [](const std::vector<VP>& a) -> VP { std::string s = need(a[0], V::Str).s; for (char& c : s) if (c >= 'a' && c <= 'z') c = (char)(c - 32); for (unsigned char c : s) if (c >= 0x80) throw std::runtime_error("upper: non-ASCII text is outside this checker's scope"); return mk_str(s); }}},
+      {"concat", {2, [](const std::vector<VP>& a) -> VP {
+         const std::string& d = need(a[0], V::Str).s;
+         if (a[1]->k != V::Arr && a[1]->k != V::Set) throw BuiltinErr();
+         std::string o;
+         for (size_t i = 0; i < a[1]->a.size(); i++) { if (i) o += d; o += need(a[1]->a[i], V::Str).s; }
+         return mk_str(o);
+       }}},
+      {"to_number", {1, [](const std::vector<VP>& a) -> VP {
+         const V& x = *a[0];
+         if (x.k == V::Null) return mk_int(0);
+         if (x.k == V::Bool) return mk_int(x.b ? 1 : 0);
+         if (x.k == V::Num) return a[0];
+         if (x.k != V::Str) throw BuiltinErr();
+         const std::string& s = x.s;   // [+-]?(\d+\.?\d*([eE][+-]?\d+)?|\.\d+([eE][+-]?\d+)?|0[xX][0-9a-fA-F]+|[iI]nf|NaN)
+         size_t i = 0;
+         if (i < s.size() && (s[i] == '+' || s[i] == '-')) i++;
+         const std::string body = s.substr(i);
+         auto dig = [](char c) { return c >= '0' && c <= '9'; };
+         bool ok = false, is_int = false;
+         if (body == "inf" || body == "Inf" || body == "NaN") ok = true;
+         else if (body.size() > 2 && body[0] == '0' && (body[1] == 'x' || body[1] == 'X')) { ok = true; for (size_t k = 2; k < body.size(); k++) if (!isxdigit((unsigned char)body[k])) ok = false; }
+         else {
+           size_t k = 0, nd = 0;
+           while (k < body.size() && dig(body[k])) { k++; nd++; }
+           bool frac = false;
+           if (k < body.size() && body[k] == '.') { frac = true; k++; size_t fd = 0; while (k < body.size() && dig(body[k])) { k++; fd++; } if (nd == 0 && fd == 0) nd = 0; else if (nd == 0) nd = fd ? 1 : 0; }
+           bool ex = false;
+           if (nd && k < body.size() && (body[k] == 'e' || body[k] == 'E')) { size_t r = k + 1; if (r < body.size() && (body[r] == '+' || body[r] == '-')) r++; size_t ed = 0; while (r < body.size() && dig(body[r])) { r++; ed++; } if (ed) { ex = true; k = r; } }
+           ok = nd > 0 && k == body.size();
+           is_int = ok && !frac && !ex;
+         }
+         if (!ok) throw BuiltinErr();
+         if (is_int && s.size() <= 37) { i128 v = 0; for (char c : body) v = v * 10 + (c - '0'); return mk_int(s[0] == '-' ? -v : v); }
+         if (body.size() > 2 && (body[1] == 'x' || body[1] == 'X')) throw BuiltinErr();   // (int("0x..") and float("0x..") both fail in the Python oracle)
+         const double d = strtod(s.c_str(), nullptr);
+         return mk_float(d);
+       }}},
+  };
+  return m;
+}
+
+// ================================================================================================ interpreter (oracle/rego_interp.py)
+struct Unbound {};   // a variable used where it cannot be bound yet
+struct EvalErr : std::runtime_error { using std::runtime_error::runtime_error; };
+template <class Sig> class fref;
+template <class R, class... A>
+class fref<R(A...)> {
+  void* obj_;
+  R (*call_)(void*, A...);
+
+ public:
+  template <class F, class = typename std::enable_if<!std::is_same<typename std::decay<F>::type, fref>::value>::type>
+  fref(F&& f) : obj_((void*)std::addressof(f)), call_([](void* o, A... a) -> R { return (*(typename std::remove_reference<F>::type*)o)(static_cast<A>(a)...); }) {}
+  R operator()(A... a) const { return call_(obj_, static_cast<A>(a)...); }
+};
+// environments: an immutable chain, a binding is a new link (what dict(env) + assignment is in the Python oracle)
+struct Env;
+typedef std::shared_ptr<const Env> EP;
+struct Env { const std::string* name; VP v; bool gone; EP up; };
+static EP bind(const EP& e, const std::string& name, const VP& v) { return std::make_shared<const Env>(Env{&name, v, false, e}); }
+static EP unbind(const EP& e, const std::string& name) { return std::make_shared<const Env>(Env{&name, nullptr, true, e}); }
+static const VP* lookup(const EP& e, const std::string& name) {
+  for (const Env* p = e.get(); p; p = p->up.get()) if (p->name == &name || *p->name == name) return p->gone ? nullptr : &p->v;
+  return nullptr;
+}
+typedef fref<void(const EP&)> KE;
+typedef fref<void(const VP&, const EP&)> KV;
+
+struct Program {   // one compiled template: main module + libs (Interp.__init__)
+  std::vector<std::shared_ptr<Module>> modules;
+  std::map<std::pair<std::vector<std::string>, std::string>, std::vector<const Rule*>> rules;
+  std::vector<std::string> main_pkg;
+  VP data;
+  void load(const std::vector<std::string>& sources) {
+    for (auto& s : sources) modules.push_back(std::make_shared<Module>(Parser(s).parse_module()));
+    for (auto& m : modules)
+      for (Rule& r : m->rules) {
+        r.pkg = m->package;
+        for (auto& im : m->imports) r.imports[im.second.empty() ? im.first.back() : im.second] = im.first;
+      }
+    for (auto& m : modules) for (const Rule& r : m->rules) rules[{r.pkg, r.name}].push_back(&r);
+    main_pkg = modules[0]->package;
+    data = mk_obj({});
+  }
+  const std::vector<const Rule*>* find(const std::vector<std::string>& pkg, const std::string& name) const { auto it = rules.find({pkg, name}); return it == rules.end() ? nullptr : &it->second; }
+};
+
+class Query {
+ public:
+  Query(const Program& p, VP input) : P(p), input_(std::move(input)) {}
+  // the `violation` partial set of the main package (Interp.violations)
+  VP violations() {
+    if (!P.find(P.main_pkg, "violation")) return mk_set({});
+    VP s = rule_value(P.main_pkg, "violation");
+    return s ? s : mk_set({});
+  }
+
+ private:
+  const Program& P;
+  VP input_;
+  struct Cached { bool in_progress = false, done = false; VP v; };
+  std::map<std::pair<std::vector<std::string>, std::string>, Cached> cache_;
+  int depth_ = 0;
+
+  VP rule_value(const std::vector<std::string>& pkg, const std::string& name) {   // nullptr: undefined
+    Cached& c = cache_[{pkg, name}];
+    if (c.done) return c.v;
+    if (c.in_progress) throw EvalErr("recursive rule " + name);
+    c.in_progress = true;
+    const std::vector<const Rule*>& rules = *P.find(pkg, name);
+    const Rule::K kind = rules[0]->k;
+    VP res;
+    if (kind == Rule::Func) throw EvalErr("function " + name + " referenced without call");
+    if (kind == Rule::SetR) {
+      std::vector<VP> out;
+      for (const Rule* r : rules) eval_body(r->body, nullptr, *r, [&](const EP& env) { eval_term(*r->key, env, *r, [&](const VP& v, const EP&) { out.push_back(v); }); });
+      res = mk_set(std::move(out));
+    } else if (kind == Rule::ObjectR) {
+      std::vector<std::pair<VP, VP>> pairs;
+      for (const Rule* r : rules)
+        eval_body(r->body, nullptr, *r, [&](const EP& env) { eval_term(*r->key, env, *r, [&](const VP& k, const EP& e2) { eval_term(*r->value, e2, *r, [&](const VP& v, const EP&) { pairs.emplace_back(k, v); }); }); });
+      res = mk_obj(std::move(pairs));
+    } else {
+      VP def;
+      for (const Rule* r : rules) {
+        if (r->is_default) { eval_term(*r->value, nullptr, *r, [&](const VP& v, const EP&) { def = v; }); continue; }
+        VP v = complete_def(*r, nullptr);
+        if (v) { if (res && !equal(res, v)) throw EvalErr("complete rule " + name + " produced conflicting values"); res = v; }
+      }
+      if (!res) res = def;
+    }
+    Cached& c2 = cache_[{pkg, name}];
+    c2.v = res; c2.done = true; c2.in_progress = false;
+    return res;
+  }
+  VP complete_def(const Rule& r, const EP& env) {   // one definition with its else chain; nullptr: undefined
+    for (size_t li = 0; li <= r.elses.size(); li++) {
+      const TP& val_t = li == 0 ? r.value : r.elses[li - 1].first;
+      const Body& body = li == 0 ? r.body : r.elses[li - 1].second;
+      VP res;
+      eval_body(body, env, r, [&](const EP& e) {
+        VP v;
+        if (!val_t) v = mk_bool(true);
+        else { bool first = true; eval_term(*val_t, e, r, [&](const VP& x, const EP&) { if (first) { v = x; first = false; } }); if (!v) return; }
+        if (res && !equal(res, v)) throw EvalErr("rule " + r.name + " produced conflicting values");
+        res = v;
+      });
+      if (res) return res;
+    }
+    return nullptr;
+  }
+  VP call_function(const std::vector<std::string>& pkg, const std::string& name, const std::vector<VP>& args) {
+    const std::vector<const Rule*>& rules = *P.find(pkg, name);
+    if (++depth_ > 200) { depth_--; throw EvalErr("recursion too deep in " + name); }
+    struct Dec { int& d; ~Dec() { d--; } } dec{depth_};
+    VP res, def;
+    for (const Rule* r : rules) {
+      if (r->k != Rule::Func || r->args.size() != args.size()) continue;
+      if (r->is_default) { eval_term(*r->value, nullptr, *r, [&](const VP& v, const EP&) { def = v; }); continue; }
+      unify_args(*r, args, 0, nullptr, [&](const EP& e) {
+        VP v = complete_def(*r, e);
+        if (v) { if (res && !equal(res, v)) throw EvalErr("function " + name + " produced conflicting outputs"); res = v; }
+      });
+    }
+    return res ? res : def;
+  }
+  void unify_args(const Rule& r, const std::vector<VP>& args, size_t i, const EP& env, KE k) {
+    if (i == args.size()) { k(env); return; }
+    unify_value(*r.args[i], args[i], env, r, [&](const EP& e) { unify_args(r, args, i + 1, e, k); });
+  }
+
+  // ---- bodies: the first literal that can be evaluated goes first (eval_body)
+  void eval_body(const Body& lits, const EP& env, const Rule& rule, KE k) {
+    std::vector<const Literal*> ptrs;
+    for (auto& l : lits) ptrs.push_back(&l);
+    eval_lits(ptrs, env, rule, k);
+  }
+  void eval_lits(const std::vector<const Literal*>& lits, const EP& env, const Rule& rule, KE k) {
+    if (lits.empty()) { k(env); return; }
+    for (size_t i = 0; i < lits.size(); i++) {
+      std::vector<EP> sols;
+      try { eval_literal(*lits[i], env, rule, [&](const EP& e) { sols.push_back(e); }); }
+      catch (const Unbound&) { continue; }
+      std::vector<const Literal*> rest;
+      for (size_t j = 0; j < lits.size(); j++) if (j != i) rest.push_back(lits[j]);
+      for (const EP& e : sols) eval_lits(rest, e, rule, k);
+      return;
+    }
+    throw Unbound();
+  }
+  void eval_literal(const Literal& l, const EP& env, const Rule& rule, KE k) {
+    switch (l.k) {
+      case Literal::Expr: eval_term(*l.a, env, rule, [&](const VP& v, const EP& e) { if (!(v->k == V::Bool && !v->b)) k(e); }); break;
+      case Literal::Assign: case Literal::Unify: unify_terms(*l.a, *l.b, env, rule, k); break;
+      case Literal::Not: { bool any = false; eval_literal(*l.inner, env, rule, [&](const EP&) { any = true; }); if (!any) k(env); break; }
+      case Literal::Some: { EP e = env; for (auto& n : l.names) e = unbind(e, n); k(e); break; }
+      case Literal::SomeIn:
+        eval_term(*l.c, env, rule, [&](const VP& coll, const EP& e) {
+          iter_kv(coll, [&](const VP& key, const VP& val) {
+            unify_value(*l.b, val, e, rule, [&](const EP& e2) { if (!l.a) k(e2); else unify_value(*l.a, key, e2, rule, k); });
+          });
+        });
+        break;
+      case Literal::Every:
+        eval_term(*l.c, env, rule, [&](const VP& coll, const EP& e) {
+          bool ok = true;
+          iter_kv(coll, [&](const VP& key, const VP& val) {
+            if (!ok) return;
+            bool sat = false;
+            unify_value(*l.b, val, e, rule, [&](const EP& e2) {
+              auto run = [&](const EP& e3) { if (!sat) eval_body(*l.body, e3, rule, [&](const EP&) { sat = true; }); };
+              if (!l.a) run(e2); else unify_value(*l.a, key, e2, rule, run);
+            });
+            if (!sat) ok = false;
+          });
+          if (ok) k(e);
+        });
+        break;
+    }
+  }
+
+  // ---- unification
+  bool is_global(const std::string& name, const Rule& rule) const { return name == "input" || name == "data" || P.find(rule.pkg, name) || rule.imports.count(name); }
+  bool is_unbound_var(const Term& t, const EP& env, const Rule& rule) const { return t.k == Term::Var && !lookup(env, t.name) && !is_global(t.name, rule); }
+  bool has_unbound(const Term& t, const EP& env, const Rule& rule) const {
+    if (t.k == Term::Var) return is_unbound_var(t, env, rule);
+    if (t.k == Term::Array) { for (auto& x : t.args) if (has_unbound(*x, env, rule)) return true; return false; }
+    if (t.k == Term::Object) { for (size_t i = 1; i < t.args.size(); i += 2) if (has_unbound(*t.args[i], env, rule)) return true; return false; }   // (values only, as the Python oracle)
+    return false;
+  }
+  void unify_terms(const Term& a, const Term& b, const EP& env, const Rule& rule, KE k) {
+    if (is_unbound_var(a, env, rule)) eval_term(b, env, rule, [&](const VP& v, const EP& e) { k(bind(e, a.name, v)); });
+    else if (is_unbound_var(b, env, rule)) eval_term(a, env, rule, [&](const VP& v, const EP& e) { k(bind(e, b.name, v)); });
+    else if ((a.k == Term::Array || a.k == Term::Object) && has_unbound(a, env, rule)) eval_term(b, env, rule, [&](const VP& v, const EP& e) { unify_value(a, v, e, rule, k); });
+    else if ((b.k == Term::Array || b.k == Term::Object) && has_unbound(b, env, rule)) eval_term(a, env, rule, [&](const VP& v, const EP& e) { unify_value(b, v, e, rule, k); });
+    else eval_term(a, env, rule, [&](const VP& va, const EP& e) { eval_term(b, e, rule, [&](const VP& vb, const EP& e2) { if (equal(va, vb)) k(e2); }); });
+  }
+  void unify_array(const Term& pat, const V& val, size_t i, const EP& env, const Rule& rule, KE k) {
+    if (i == pat.args.size()) { k(env); return; }
+    unify_value(*pat.args[i], val.a[i], env, rule, [&](const EP& e) { unify_array(pat, val, i + 1, e, rule, k); });
+  }
+  void unify_object(const Term& pat, const V& val, size_t i, const EP& env, const Rule& rule, KE k) {
+    if (2 * i >= pat.args.size()) { k(env); return; }
+    eval_term(*pat.args[2 * i], env, rule, [&](const VP& kv, const EP& e1) {
+      const VP* f = obj_get(val, kv);
+      if (f) unify_value(*pat.args[2 * i + 1], *f, e1, rule, [&](const EP& e2) { unify_object(pat, val, i + 1, e2, rule, k); });
+    });
+  }
+  void unify_value(const Term& pat, const VP& val, const EP& env, const Rule& rule, KE k) {
+    if (pat.k == Term::Var && is_unbound_var(pat, env, rule)) { k(bind(env, pat.name, val)); return; }
+    if (pat.k == Term::Array && has_unbound(pat, env, rule)) { if (val->k == V::Arr && val->a.size() == pat.args.size()) unify_array(pat, *val, 0, env, rule, k); return; }
+    if (pat.k == Term::Object && has_unbound(pat, env, rule)) { if (val->k == V::Obj && val->o.size() == pat.args.size() / 2) unify_object(pat, *val, 0, env, rule, k); return; }
+    eval_term(pat, env, rule, [&](const VP& v, const EP& e) { if (equal(v, val)) k(e); });
+  }
+
+  // ---- terms
+  void eval_seq(const std::vector<TP>& ts, size_t i, std::vector<VP>& acc, const EP& env, const Rule& rule, fref<void(const std::vector<VP>&, const EP&)> k) {
+    if (i == ts.size()) { k(acc, env); return; }
+    eval_term(*ts[i], env, rule, [&](const VP& v, const EP& e) { acc.push_back(v); eval_seq(ts, i + 1, acc, e, rule, k); acc.pop_back(); });
+  }
+  static void iter_kv(const VP& c, fref<void(const VP&, const VP&)> fn) {
+    if (c->k == V::Arr) { for (size_t i = 0; i < c->a.size(); i++) fn(mk_int((i128)i), c->a[i]); }
+    else if (c->k == V::Obj) { for (auto& p : c->o) fn(p.first, p.second); }
+    else if (c->k == V::Set) { for (auto& x : c->a) fn(x, x); }
+  }
+  static VP index(const VP& cur, const VP& key) {   // nullptr: nothing there (_index)
+    if (cur->k == V::Obj) { const VP* v = obj_get(*cur, key); return v ? *v : nullptr; }
+    if (cur->k == V::Arr) {
+      if (key->k != V::Num) return nullptr;
+      i128 i;
+      if (key->is_int) i = key->i; else { if (std::floor(key->d) != key->d) return nullptr; i = (i128)key->d; }
+      return i >= 0 && (size_t)i < cur->a.size() ? cur->a[(size_t)i] : nullptr;
+    }
+    if (cur->k == V::Set) return set_has(*cur, key) ? key : nullptr;
+    return nullptr;
+  }
+  void walk(const VP& cur, const std::vector<TP>& ops, size_t i, const EP& env, const Rule& rule, KV k) {
+    if (i == ops.size()) { k(cur, env); return; }
+    const Term& op = *ops[i];
+    if (op.k == Term::Var && is_unbound_var(op, env, rule)) { iter_kv(cur, [&](const VP& key, const VP& val) { walk(val, ops, i + 1, bind(env, op.name, key), rule, k); }); return; }
+    if (op.k == Term::Scalar) { VP nxt = index(cur, op.val); if (nxt) walk(nxt, ops, i + 1, env, rule, k); return; }
+    if ((op.k == Term::Array || op.k == Term::Object) && has_unbound(op, env, rule)) { iter_kv(cur, [&](const VP& key, const VP& val) { unify_value(op, key, env, rule, [&](const EP& e) { walk(val, ops, i + 1, e, rule, k); }); }); return; }
+    eval_term(op, env, rule, [&](const VP& kv, const EP& e) { VP nxt = index(cur, kv); if (nxt) walk(nxt, ops, i + 1, e, rule, k); });
+  }
+  void eval_data_ref(const std::vector<TP>& ops, const EP& env, const Rule& rule, KV k) {
+    std::vector<std::string> consts;
+    for (auto& o : ops) { if (o->k == Term::Scalar && o->val->k == V::Str) consts.push_back(o->val->s); else break; }
+    for (size_t n = consts.size(); n-- > 0;) {
+      const std::vector<std::string> pkg(consts.begin(), consts.begin() + n);
+      if (P.find(pkg, consts[n])) { VP v = rule_value(pkg, consts[n]); if (v) walk(v, ops, n + 1, env, rule, k); return; }
+    }
+    walk(P.data, ops, 0, env, rule, k);
+  }
+  void eval_call(const Term& t, const EP& env, const Rule& rule, KV k) {
+    std::string name;
+    for (size_t i = 0; i < t.path.size(); i++) { if (i) name += "."; name += t.path[i]; }
+    const std::vector<std::string>* tpkg = nullptr;
+    std::vector<std::string> pkgbuf;
+    std::string tname;
+    if (t.path.size() == 1 && P.find(rule.pkg, t.path[0])) { tpkg = &rule.pkg; tname = t.path[0]; }
+    else if (t.path[0] == "data" && t.path.size() >= 2) { pkgbuf.assign(t.path.begin() + 1, t.path.end() - 1); if (P.find(pkgbuf, t.path.back())) { tpkg = &pkgbuf; tname = t.path.back(); } }
+    else if (rule.imports.count(t.path[0])) {
+      std::vector<std::string> full = rule.imports.at(t.path[0]);
+      full.insert(full.end(), t.path.begin() + 1, t.path.end());
+      if (full[0] == "data" && full.size() >= 2) { pkgbuf.assign(full.begin() + 1, full.end() - 1); if (P.find(pkgbuf, full.back())) { tpkg = &pkgbuf; tname = full.back(); } }
+    }
+    const std::pair<int, BuiltinFn>* bf = nullptr;
+    if (!tpkg) { auto it = BUILTINS().find(name); if (it == BUILTINS().end()) throw EvalErr("undefined function " + name + " (outside this checker's builtins)"); bf = &it->second; }
+    std::vector<VP> acc;
+    eval_seq(t.args, 0, acc, env, rule, [&](const std::vector<VP>& args, const EP& e) {
+      if (tpkg) { const std::vector<VP> copy = args; VP v = call_function(*tpkg, tname, copy); if (v) k(v, e); return; }
+      if ((int)args.size() != bf->first) throw EvalErr(name + ": wrong number of arguments");
+      VP v;
+      try { v = bf->second(args); } catch (const BuiltinErr&) { return; }
+      k(v, e);
+    });
+  }
+  void eval_term(const Term& t, const EP& env, const Rule& rule, KV k) {
+    switch (t.k) {
+      case Term::Scalar: k(t.val, env); break;
+      case Term::Var: {
+        if (const VP* b = lookup(env, t.name)) { k(*b, env); return; }
+        if (t.name == "input") { k(input_, env); return; }
+        if (t.name == "data") { eval_data_ref({}, env, rule, k); return; }
+        if (P.find(rule.pkg, t.name)) { VP v = rule_value(rule.pkg, t.name); if (v) k(v, env); return; }
+        throw Unbound();
+      }
+      case Term::Ref: {
+        const Term& head = *t.head;
+        if (head.k == Term::Var && head.name == "data" && !lookup(env, "data")) { eval_data_ref(t.args, env, rule, k); return; }
+        if (head.k == Term::Var && rule.imports.count(head.name) && !lookup(env, head.name)) {
+          const std::vector<std::string>& path = rule.imports.at(head.name);
+          std::vector<TP> full;
+          for (size_t i = 1; i < path.size(); i++) { Term s; s.k = Term::Scalar; s.val = mk_str(path[i]); full.push_back(std::make_shared<const Term>(std::move(s))); }
+          full.insert(full.end(), t.args.begin(), t.args.end());
+          if (path[0] == "data") eval_data_ref(full, env, rule, k); else walk(input_, full, 0, env, rule, k);
+          return;
+        }
+        eval_term(head, env, rule, [&](const VP& hv, const EP& e) { walk(hv, t.args, 0, e, rule, k); });
+        break;
+      }
+      case Term::Call: eval_call(t, env, rule, k); break;
+      case Term::BinOp: {
+        const std::string& op = t.name;
+        eval_term(*t.args[0], env, rule, [&](const VP& a, const EP& e) {
+          eval_term(*t.args[1], e, rule, [&](const VP& b, const EP& e2) {
+            if (op == "==" || op == "!=" || op == "<" || op == "<=" || op == ">" || op == ">=") {
+              const int c = compare(a, b);
+              const bool r = op == "==" ? c == 0 : op == "!=" ? c != 0 : op == "<" ? c < 0 : op == "<=" ? c <= 0 : op == ">" ? c > 0 : c >= 0;
+              k(mk_bool(r), e2);
+            } else if (op == "in") {
+              bool any = false;
+              iter_kv(b, [&](const VP&, const VP& v) { if (equal(a, v)) any = true; });
+              k(mk_bool(any), e2);
+            } else {
+              VP v;
+              try { v = arith(op, a, b); } catch (const BuiltinErr&) { return; }
+              k(v, e2);
+            }
+          });
+        });
+        break;
+      }
+      case Term::Array: case Term::SetT: {
+        std::vector<VP> acc;
+        eval_seq(t.args, 0, acc, env, rule, [&](const std::vector<VP>& vals, const EP& e) { k(t.k == Term::Array ? mk_arr(vals) : mk_set(vals), e); });
+        break;
+      }
+      case Term::Object: {
+        std::vector<VP> acc;
+        eval_seq(t.args, 0, acc, env, rule, [&](const std::vector<VP>& vals, const EP& e) {
+          std::vector<std::pair<VP, VP>> p;
+          for (size_t i = 0; i + 1 < vals.size(); i += 2) p.emplace_back(vals[i], vals[i + 1]);
+          k(mk_obj(std::move(p)), e);
+        });
+        break;
+      }
+      case Term::ArrComp: case Term::SetComp: {
+        std::vector<VP> out;
+        eval_body(*t.body, env, rule, [&](const EP& e) { eval_term(*t.head, e, rule, [&](const VP& v, const EP&) { out.push_back(v); }); });
+        k(t.k == Term::ArrComp ? mk_arr(std::move(out)) : mk_set(std::move(out)), env);
+        break;
+      }
+      case Term::ObjComp: {
+        std::vector<std::pair<VP, VP>> out;
+        eval_body(*t.body, env, rule, [&](const EP& e) { eval_term(*t.head, e, rule, [&](const VP& kv, const EP& e2) { eval_term(*t.head2, e2, rule, [&](const VP& vv, const EP&) { out.emplace_back(kv, vv); }); }); });
+        k(mk_obj(std::move(out)), env);
+        break;
+      }
+    }
+  }
+};
+
+// ================================================================================================ Match layer (oracle/match.py, oracle/target.py Matcher)
+struct MatchErr : std::runtime_error { using std::runtime_error::runtime_error; };
+static std::string s_of(const VP* v) { return v && (*v)->k == V::Str ? (*v)->s : std::string(); }
+static const V* meta_of(const V& obj) { const VP* m = obj_get(obj, "metadata"); return m && (*m)->k == V::Obj ? m->get() : nullptr; }
+static std::string obj_name(const V& o) { const V* m = meta_of(o); return m ? s_of(obj_get(*m, "name")) : ""; }
+static std::string obj_generate_name(const V& o) { const V* m = meta_of(o); return m ? s_of(obj_get(*m, "generateName")) : ""; }
+static std::string obj_namespace(const V& o) { const V* m = meta_of(o); return m ? s_of(obj_get(*m, "namespace")) : ""; }
+static std::map<std::string, std::string> obj_labels(const V& o) {   // GetLabels -> NestedStringMap: one non-string value empties the map
+  std::map<std::string, std::string> out;
+  const V* m = meta_of(o);
+  const VP* l = m ? obj_get(*m, "labels") : nullptr;
+  if (!l || (*l)->k != V::Obj) return out;
+  for (auto& p : (*l)->o) if (p.second->k != V::Str) return {};
+  for (auto& p : (*l)->o) if (p.first->k == V::Str) out[p.first->s] = p.second->s;
+  return out;
+}
+static void parse_gv(const std::string& av, std::string* g, std::string* v) {
+  g->clear(); v->clear();
+  if (av.empty() || av == "/") return;
+  const size_t n = (size_t)std::count(av.begin(), av.end(), '/');
+  if (n == 0) *v = av;
+  else if (n == 1) { const size_t i = av.find('/'); *g = av.substr(0, i); *v = av.substr(i + 1); }
+}
+static void obj_gvk(const V& o, std::string* g, std::string* v, std::string* k) { parse_gv(s_of(obj_get(o, "apiVersion")), g, v); *k = s_of(obj_get(o, "kind")); }
+static bool is_namespace(const V& o) { std::string g, v, k; obj_gvk(o, &g, &v, &k); return k == "Namespace" && g.empty(); }
+static bool starts(const std::string& s, const std::string& p) { return s.size() >= p.size() && s.compare(0, p.size(), p) == 0; }
+static bool ends(const std::string& s, const std::string& p) { return s.size() >= p.size() && s.compare(s.size() - p.size(), p.size(), p) == 0; }
+static bool wildcard_matches(const std::string& w, const std::string& c) {   // wildcard.go:17-30
+  const bool pre = !w.empty() && w[0] == '*', suf = !w.empty() && w.back() == '*';
+  if (pre && suf) { std::string inner = w.substr(1); if (!inner.empty() && inner.back() == '*') inner.pop_back(); return c.find(inner) != std::string::npos; }
+  if (pre) return ends(c, w.substr(1));
+  if (suf) return starts(c, w.substr(0, w.size() - 1));
+  return w == c;
+}
+static bool wildcard_matches_generate_name(const std::string& w, const std::string& c) {   // wildcard.go:32-41
+  const bool pre = !w.empty() && w[0] == '*', suf = !w.empty() && w.back() == '*';
+  if (pre && suf) { std::string inner = w.substr(1); if (!inner.empty() && inner.back() == '*') inner.pop_back(); return c.find(inner) != std::string::npos; }
+  if (suf) return starts(c, w.substr(0, w.size() - 1));
+  return false;
+}
+static bool alnum(char c) { return (c >= 'A' && c <= 'Z') || (c >= 'a' && c <= 'z') || (c >= '0' && c <= '9'); }
+static bool qname(const std::string& s) {   // ^([A-Za-z0-9][-A-Za-z0-9_.]*)?[A-Za-z0-9]$
+  if (s.empty() || !alnum(s.back()) || !alnum(s[0])) return false;
+  for (char c : s) if (!(alnum(c) || c == '-' || c == '_' || c == '.')) return false;
+  return true;
+}
+static bool dns1123_sub(const std::string& s) {
+  size_t pos = 0;
+  while (pos <= s.size()) {
+    size_t q = s.find('.', pos);
+    if (q == std::string::npos) q = s.size();
+    const std::string lab = s.substr(pos, q - pos);
+    auto lc = [](char c) { return (c >= 'a' && c <= 'z') || (c >= '0' && c <= '9'); };
+    if (lab.empty() || !lc(lab[0]) || !lc(lab.back())) return false;
+    for (char c : lab) if (!(lc(c) || c == '-')) return false;
+    pos = q + 1;
+  }
+  return true;
+}
+static bool valid_label_key(const std::string& k) {
+  const size_t n = (size_t)std::count(k.begin(), k.end(), '/');
+  std::string name = k;
+  if (n == 1) { const size_t i = k.find('/'); const std::string prefix = k.substr(0, i); name = k.substr(i + 1); if (prefix.empty() || prefix.size() > 253 || !dns1123_sub(prefix)) return false; }
+  else if (n > 1) return false;
+  return !name.empty() && name.size() <= 63 && qname(name);
+}
+static bool valid_label_value(const std::string& v) { return v.size() <= 63 && (v.empty() || qname(v)); }
+struct Req { std::string key, op; std::vector<std::string> vals; };
+static Req new_requirement(const VP& key, const std::string& op, const std::vector<VP>& vals) {
+  if (key->k != V::Str || !valid_label_key(key->s)) throw MatchErr("key: Invalid value");
+  if (op == "In" || op == "NotIn") { if (vals.empty()) throw MatchErr("values: Invalid value: []"); }
+  else if (op == "Equals") { if (vals.size() != 1) throw MatchErr("values: Invalid value: exact-match"); }
+  else if (!vals.empty()) throw MatchErr("values: Invalid value: values set must be empty");
+  Req r; r.key = key->s; r.op = op;
+  for (auto& v : vals) { if (v->k != V::Str || !valid_label_value(v->s)) throw MatchErr("values: Invalid value"); r.vals.push_back(v->s); }
+  return r;
+}
+static bool truthy_py(const VP* v) {   // Python `x or default`
+  if (!v) return false;
+  const V& x = **v;
+  switch (x.k) { case V::Null: return false; case V::Bool: return x.b; case V::Num: return x.is_int ? x.i != 0 : x.d != 0; case V::Str: return !x.s.empty(); case V::Arr: case V::Set: return !x.a.empty(); case V::Obj: return !x.o.empty(); }
+  return false;
+}
+// selector_requirements: false = the empty selector (everything)
+static bool selector_requirements(const V& sel, std::vector<Req>* reqs) {
+  const VP* ml = obj_get(sel, "matchLabels");
+  const VP* me = obj_get(sel, "matchExpressions");
+  const size_t nml = truthy_py(ml) && (*ml)->k == V::Obj ? (*ml)->o.size() : 0, nme = truthy_py(me) && (*me)->k == V::Arr ? (*me)->a.size() : 0;
+  if (nml + nme == 0) return false;
+  if (nml) for (auto& p : (*ml)->o) reqs->push_back(new_requirement(p.first, "Equals", {p.second}));   // (sorted keys: the object's own order)
+  if (nme) for (auto& e : (*me)->a) {
+    if (e->k != V::Obj) throw MatchErr("malformed requirement");
+    const std::string op = s_of(obj_get(*e, "operator"));
+    if (op != "In" && op != "NotIn" && op != "Exists" && op != "DoesNotExist") throw MatchErr("\"" + op + "\" is not a valid label selector operator");
+    const VP* key = obj_get(*e, "key");
+    const VP* vals = obj_get(*e, "values");
+    reqs->push_back(new_requirement(key ? *key : mk_str(""), op, truthy_py(vals) && (*vals)->k == V::Arr ? (*vals)->a : std::vector<VP>()));
+  }
+  return true;
+}
+static bool selector_matches(const std::vector<Req>& reqs, const std::map<std::string, std::string>& labels) {
+  for (const Req& r : reqs) {
+    auto it = labels.find(r.key);
+    const bool has = it != labels.end();
+    const bool in = has && std::find(r.vals.begin(), r.vals.end(), it->second) != r.vals.end();
+    bool ok;
+    if (r.op == "In" || r.op == "Equals") ok = in;
+    else if (r.op == "NotIn") ok = !has || !in;
+    else if (r.op == "Exists") ok = has;
+    else ok = !has;
+    if (!ok) return false;
+  }
+  return true;
+}
+static std::vector<std::string> str_list(const VP* v) { std::vector<std::string> o; if (truthy_py(v) && (*v)->k == V::Arr) for (auto& x : (*v)->a) o.push_back(x->k == V::Str ? x->s : std::string("\x01not-a-string")); return o; }
+static bool contains(const std::vector<std::string>& v, const std::string& s) { return std::find(v.begin(), v.end(), s) != v.end(); }
+// match.Matches (match.go:32-65) for one object; throws MatchErr
+static bool matches(const V& match, const V& obj, const V* ns, const std::string& source) {
+  {   // kinds_match
+    const VP* kinds = obj_get(match, "kinds");
+    if (truthy_py(kinds) && (*kinds)->k == V::Arr && !(*kinds)->a.empty()) {
+      std::string g, v, k; obj_gvk(obj, &g, &v, &k);
+      bool any = false;
+      for (auto& kk : (*kinds)->a) {
+        if (kk->k != V::Obj) continue;
+        const std::vector<std::string> ks = str_list(obj_get(*kk, "kinds")), gs = str_list(obj_get(*kk, "apiGroups"));
+        if (!(ks.empty() || contains(ks, "*") || contains(ks, k))) continue;
+        if (gs.empty() || contains(gs, "*") || contains(gs, g)) { any = true; break; }
+      }
+      if (!any) return false;
+    }
+  }
+  const bool is_ns = is_namespace(obj);
+  {   // scope_match
+    const bool has_ns = !obj_namespace(obj).empty() || ns != nullptr;
+    const std::string scope = s_of(obj_get(match, "scope"));
+    if (scope == "Cluster" && !(is_ns || !has_ns)) return false;
+    if (scope == "Namespaced" && !(!is_ns && has_ns)) return false;
+  }
+  bool have_name = true;
+  std::string eff;
+  if (is_ns) eff = obj_name(obj);
+  else if (ns) { const V* m = meta_of(*ns); eff = m ? s_of(obj_get(*m, "name")) : ""; }
+  else if (!obj_namespace(obj).empty()) eff = obj_namespace(obj);
+  else have_name = false;
+  {   // namespaces_match / excluded_namespaces_match
+    const std::vector<std::string> nss = str_list(obj_get(match, "namespaces"));
+    if (!nss.empty() && have_name) { bool any = false; for (auto& n : nss) if (wildcard_matches(n, eff)) any = true; if (!any) return false; }
+    const std::vector<std::string> ex = str_list(obj_get(match, "excludedNamespaces"));
+    if (!ex.empty() && have_name) { for (auto& n : ex) if (wildcard_matches(n, eff)) return false; }
+  }
+  {   // label_selector_match
+    const VP* sel = obj_get(match, "labelSelector");
+    if (sel && (*sel)->k != V::Null) {
+      if ((*sel)->k != V::Obj) throw MatchErr("labelSelector is not a map");
+      std::vector<Req> reqs;
+      if (selector_requirements(**sel, &reqs) && !selector_matches(reqs, obj_labels(obj))) return false;
+    }
+  }
+  {   // namespace_selector_match
+    const VP* sel = obj_get(match, "namespaceSelector");
+    if (sel && (*sel)->k != V::Null && !(!is_ns && !ns && obj_namespace(obj).empty())) {
+      if ((*sel)->k != V::Obj) throw MatchErr("namespaceSelector is not a map");
+      std::vector<Req> reqs;
+      const bool some = selector_requirements(**sel, &reqs);
+      if (is_ns) { if (some && !selector_matches(reqs, obj_labels(obj))) return false; }
+      else {
+        if (!ns) throw MatchErr("namespace selector for namespace-scoped object but missing Namespace");
+        if (some && !selector_matches(reqs, obj_labels(*ns))) return false;
+      }
+    }
+  }
+  {   // names_match
+    const std::string name = s_of(obj_get(match, "name"));
+    if (!name.empty() && !(wildcard_matches(name, obj_name(obj)) || wildcard_matches_generate_name(name, obj_generate_name(obj)))) return false;
+  }
+  {   // source_match
+    std::string m_src = s_of(obj_get(match, "source"));
+    if (m_src.empty()) m_src = "All";
+    else if (m_src != "All" && m_src != "Generated" && m_src != "Original") throw MatchErr("invalid source field");
+    if (source.empty() && m_src != "All") throw MatchErr("source field not specified");
+    if (m_src != "All") {
+      if (source != "All" && source != "Generated" && source != "Original") throw MatchErr("invalid source field");
+      if (m_src != source) return false;
+    }
+  }
+  return true;
+}
+
+// ================================================================================================ the client (oracle/client.py Client.review for object reviews at the audit enforcement point)
+struct Constraint { VP doc, match, params; std::string kind; const Program* prog = nullptr; };
+struct Checker {
+  std::map<std::string, std::unique_ptr<Program>> templates;   // lower(kind)
+  std::vector<Constraint> constraints;                        // rows
+};
+static std::string lower_ascii(std::string s) { for (char& c : s) if (c >= 'A' && c <= 'Z') c = (char)(c + 32); return s; }
+static const VP* path_get(const VP& v, std::initializer_list<const char*> keys) {
+  const VP* cur = &v;
+  for (const char* k : keys) { if ((*cur)->k != V::Obj) return nullptr; cur = obj_get(**cur, k); if (!cur) return nullptr; }
+  return cur;
+}
+static Checker* build(const char* templates_json, const char* constraints_json) {
+  std::unique_ptr<Checker> c(new Checker());
+  VP ts = parse_json(templates_json, strlen(templates_json));
+  if (ts->k != V::Arr) throw std::runtime_error("templates: expected a JSON array");
+  for (auto& t : ts->a) {
+    const VP* kind = path_get(t, {"spec", "crd", "spec", "names", "kind"});
+    const VP* targets = path_get(t, {"spec", "targets"});
+    if (!kind || (*kind)->k != V::Str || !targets || (*targets)->k != V::Arr || (*targets)->a.size() != 1) throw std::runtime_error("invalid ConstraintTemplate");
+    const VP& tg = (*targets)->a[0];
+    const VP* rego = path_get(tg, {"rego"});
+    if (!rego || (*rego)->k != V::Str) throw std::runtime_error("template " + (*kind)->s + " has no Rego source");
+    std::vector<std::string> sources{(*rego)->s};
+    if (const VP* libs = path_get(tg, {"libs"})) if ((*libs)->k == V::Arr) for (auto& l : (*libs)->a) if (l->k == V::Str) sources.push_back(l->s);
+    std::unique_ptr<Program> p(new Program());
+    p->load(sources);
+    c->templates[lower_ascii((*kind)->s)] = std::move(p);
+  }
+  VP cs = parse_json(constraints_json, strlen(constraints_json));
+  if (cs->k != V::Arr) throw std::runtime_error("constraints: expected a JSON array");
+  for (auto& k : cs->a) {
+    Constraint x;
+    x.doc = k;
+    x.kind = s_of(path_get(k, {"kind"}));
+    auto it = c->templates.find(lower_ascii(x.kind));
+    if (it == c->templates.end()) throw std::runtime_error("missing ConstraintTemplate: " + x.kind);
+    x.prog = it->second.get();
+    const VP* m = path_get(k, {"spec", "match"});
+    if (m && (*m)->k != V::Null) { if ((*m)->k != V::Obj) throw std::runtime_error("unable to create matcher: spec.match is not a map"); x.match = *m; }
+    const VP* p = path_get(k, {"spec", "parameters"});
+    x.params = p && (*p)->k != V::Null ? *p : mk_obj({});
+    c->constraints.push_back(std::move(x));
+  }
+  return c.release();
+}
+// one object: which rows violate, which are autorejected (matching failed)
+static void review_one(const Checker& c, const char* json, size_t json_len, const char* ns_json, size_t ns_len, std::vector<uint32_t>* viol, std::vector<uint32_t>* err) {
+  const VP obj = parse_json(json, json_len);
+  if (obj->k != V::Obj) throw std::runtime_error("review object is not a JSON object");
+  VP ns;
+  if (ns_json && ns_len) { ns = parse_json(ns_json, ns_len); if (ns->k == V::Null) ns = nullptr; }
+  // unstructuredToAdmissionRequest (target.go:159-179) + review_input_json: what input.review holds
+  std::string g, v, k;
+  obj_gvk(*obj, &g, &v, &k);
+  std::vector<std::pair<VP, VP>> rv;
+  rv.emplace_back(mk_str("uid"), mk_str(""));
+  rv.emplace_back(mk_str("kind"), mk_obj({{mk_str("group"), mk_str(g)}, {mk_str("version"), mk_str(v)}, {mk_str("kind"), mk_str(k)}}));
+  rv.emplace_back(mk_str("resource"), mk_obj({{mk_str("group"), mk_str("")}, {mk_str("version"), mk_str("")}, {mk_str("resource"), mk_str("")}}));
+  rv.emplace_back(mk_str("operation"), mk_str(""));
+  rv.emplace_back(mk_str("userInfo"), mk_obj({}));
+  rv.emplace_back(mk_str("object"), obj);
+  rv.emplace_back(mk_str("oldObject"), mk_null());
+  rv.emplace_back(mk_str("options"), mk_null());
+  const std::string name = obj_name(*obj), nsf = obj_namespace(*obj);
+  if (!name.empty()) rv.emplace_back(mk_str("name"), mk_str(name));
+  if (!nsf.empty()) rv.emplace_back(mk_str("namespace"), mk_str(nsf));
+  const VP review = mk_obj(std::move(rv));
+  const bool kind_ok = !k.empty();   // gkReviewToObject: a document without a `kind` does not unmarshal (matcher.go:73-93)
+  std::map<std::pair<const Program*, const V*>, bool> memo;   // (program, parameters) -> yields a result
+  for (size_t row = 0; row < c.constraints.size(); row++) {
+    const Constraint& x = c.constraints[row];
+    bool ok = true;
+    if (x.match) {
+      if (!kind_ok) { err->push_back((uint32_t)row); continue; }
+      try { ok = matches(*x.match, *obj, ns.get(), "Original"); } catch (const MatchErr&) { err->push_back((uint32_t)row); continue; }
+    }
+    if (!ok) continue;
+    auto key = std::make_pair(x.prog, x.params.get());
+    auto it = memo.find(key);
+    bool any;
+    if (it != memo.end()) any = it->second;
+    else {
+      Query q(*x.prog, mk_obj({{mk_str("review"), review}, {mk_str("parameters"), x.params}}));
+      const VP set = q.violations();
+      any = false;
+      for (auto& r : set->a) { if (r->k != V::Obj) continue; const VP* m = obj_get(*r, "msg"); if (m && (*m)->k == V::Str) { any = true; break; } }
+      memo[key] = any;
+    }
+    if (any) viol->push_back((uint32_t)row);
+  }
+}
+
+}  // namespace ic
+
+// ================================================================================================ C entry points (ctypes: oracle/indep_check.py)
+static thread_local std::string g_ic_err;
+extern "C" {
+const char* ic_last_error() { return g_ic_err.c_str(); }
+void* ic_create(const char* templates_json, const char* constraints_json) {
+  try { return ic::build(templates_json, constraints_json); }
+  catch (const std::exception& e) { g_ic_err = e.what(); return nullptr; }
+}
+void ic_destroy(void* h) { delete static_cast<ic::Checker*>(h); }
+// bitmaps [n_constraints][words] (bit r of word r / 64 of row c: pair (c, review r)), zeroed by the caller; returns 0, or -1 with ic_last_error()
+int ic_check(void* h, const gk_review_in* reviews, size_t n, uint64_t* viol, uint64_t* err, size_t words, int threads) {
+  const ic::Checker& c = *static_cast<ic::Checker*>(h);
+  if (threads < 1) threads = 1;
+  std::atomic<size_t> next{0};
+  std::mutex mu;
+  std::string first_err;
+  auto work = [&]() {
+    std::vector<uint32_t> v, e;
+    for (;;) {
+      const size_t lo = next.fetch_add(64);   // (64 reviews = one word per row: no two threads share a word)
+      if (lo >= n) return;
+      for (size_t i = lo; i < std::min(n, lo + 64); i++) {
+        v.clear(); e.clear();
+        try { ic::review_one(c, reviews[i].json, reviews[i].json_len, reviews[i].namespace_json, reviews[i].namespace_len, &v, &e); }
+        catch (const std::exception& ex) { std::lock_guard<std::mutex> l(mu); if (first_err.empty()) first_err = "review " + std::to_string(i) + ": " + ex.what(); return; }
+        catch (const ic::Unbound&) { std::lock_guard<std::mutex> l(mu); if (first_err.empty()) first_err = "review " + std::to_string(i) + ": unsafe variable"; return; }
+        for (uint32_t row : v) viol[(size_t)row * words + i / 64] |= 1ull << (i % 64);
+        for (uint32_t row : e) err[(size_t)row * words + i / 64] |= 1ull << (i % 64);
+      }
+    }
+  };
+  std::vector<std::thread> th;
+  for (int t = 1; t < threads; t++) th.emplace_back(work);
+  work();
+  for (auto& t : th) t.join();
+  if (!first_err.empty()) { g_ic_err = first_err; return -1; }
+  return 0;
+}
+}

@@ -96,3 +96,29 @@ def test_other_configs_legs_run_on_the_cpu_build(fixtures, monkeypatch):
     assert out["plan_groups"] == 3 and out["parity_python_oracle"]["pairs_equal"], out.get("parity_python_oracle")
     assert out["roofline"]["algo_bytes_per_sweep_table_once"] < out["roofline"]["algo_bytes_per_sweep_every_group"]
     assert "error" not in stream and stream["parity_python_oracle"]["pairs_equal"] and stream["batches"] == 2
+
+
+def test_compiled_independent_leg_checks_the_bitmaps(fixtures):
+    """bench.indep_leg: the independent compiled checker (oracle/libgkindep.so) over every object of the table it is pointed at, from
+    the batch's JSON text alone; equal to the product's bitmaps, and a flipped bit is found (the table ends inside a bitmap word)."""
+    templates, constraints = synth.psp_templates(fixtures), synth.audit_constraints()
+    drv = D.Driver(device=0, hostemu=True)
+    client = D.Client(drv)
+    for t in templates:
+        client.AddTemplate(t)
+    for k in constraints:
+        client.AddConstraint(k)
+    defaulted = [client.constraints[(k["kind"], k["metadata"]["name"])] for k in constraints]
+    bench.batch_constraint_ids[:] = [drv.constraint_id(c) for c in defaulted]
+    n = 1000
+    batch = synth.NativeBatch(drv.engine.lib, n, seed=synth.SEED, mixed=True, start=0, namespaces=synth.gen_namespaces())
+    table = drv.engine.create_table_native(batch.reviews, n, keep_docs=False, resident=True, pruned=True)
+    table.launch()
+    ev = table.eval(download=True, collect_only=True)
+    base, par = bench.indep_leg(templates, constraints, batch, ev, budget_s=0.2)
+    assert par["pairs_equal"] and par["n"] == n and par["device_violating_pairs"] == par["checker_violating_pairs"] > 500
+    assert base["kind"] == "port" and base["cores"] == 1 and base["value"] > 0 and base["all_cores"]["sample_reviews"] == n
+    ev.viol = np.array(ev.viol, copy=True)
+    ev.viol[5][2] ^= np.uint64(1 << 9)
+    _, bad = bench.indep_leg(templates, constraints, batch, ev, budget_s=0.1)
+    assert not bad["pairs_equal"]

@@ -1,0 +1,103 @@
+"""The independent compiled checker (oracle/indep_check.cpp -> oracle/libgkindep.so: no product object linked) against the
+Python oracle it restates: the same violation and autoreject pairs on the bench's policy sets x synthetic objects, structurally
+mutated objects and objects without namespaces / with broken labels."""
+import json
+import subprocess
+import os
+
+import numpy as np
+import pytest
+
+from gatekeeper_amd import synth
+from oracle import client as OC
+from oracle import target as OT
+from oracle.indep_check import IndepChecker
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_the_checker_links_nothing_of_the_product():
+    subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "libgkindep.so"], check=True, capture_output=True, timeout=600)
+    mk = open(os.path.join(ROOT, "oracle", "Makefile")).read()
+    rule = [l for l in mk.splitlines() if "indep_check.cpp" in l and "$(CXX)" in l]
+    assert rule and "$(OBJS)" not in rule[0] and "build/" not in rule[0] and "gkgpu" not in rule[0].replace("libgkindep", "")
+    out = subprocess.run(["ldd", os.path.join(ROOT, "oracle", "libgkindep.so")], capture_output=True, text=True).stdout
+    assert "gkgpu" not in out and "hip" not in out.lower() and "torch" not in out
+    src = open(os.path.join(ROOT, "oracle", "indep_check.cpp")).read()
+    assert [l for l in src.splitlines() if l.startswith("#include \"")] == ['#include "../include/gkgpu.h"   // gk_review_in only (plain C struct: pointers and lengths)']
+
+
+def _python_pairs(templates, constraints, objs_ns):
+    oc = OC.Client()
+    for t in templates:
+        oc.add_template(t)
+    for c in constraints:
+        oc.add_constraint(c)
+    keys = {(c["kind"], c["metadata"]["name"]): i for i, c in enumerate(constraints)}
+    viol, err = set(), set()
+    for i, (o, ns) in enumerate(objs_ns):
+        for r in oc.review(OT.AugmentedUnstructured(OT.Unstructured(o), ns, "Original"), OC.AUDIT_EP):
+            row = keys[(r.constraint["kind"], r.constraint["metadata"]["name"])]
+            (err if r.msg.startswith("unable to match constraints: ") and not r.metadata.get("details") else viol).add((row, i))
+    return viol, err
+
+
+def _pairs_of(bm, n):
+    out = set()
+    for row in range(bm.shape[0]):
+        bits = np.unpackbits(bm[row].view(np.uint8), bitorder="little")[:n]
+        out.update((row, int(i)) for i in np.nonzero(bits)[0])
+    return out
+
+
+@pytest.mark.parametrize("policy", ["audit-50", "psp-30", "corpus"])
+def test_compiled_checker_equals_the_python_oracle(policy, fixtures):
+    if policy == "audit-50":
+        ts, cs = synth.psp_templates(fixtures), synth.audit_constraints()
+    elif policy == "psp-30":
+        ts, cs = synth.psp_templates(fixtures), synth.psp_constraints()
+    else:
+        ts, cs = synth.corpus(fixtures)
+        ts = ts[::3]
+        kinds = {t["spec"]["crd"]["spec"]["names"]["kind"] for t in ts}
+        cs = [c for c in cs if c["kind"] in kinds]
+    nss = synth.gen_namespaces()
+    objs = synth.gen_objects(260, seed=41, mixed=True)
+    objs_ns = [(o, synth.namespace_for(o, nss)) for o in objs]
+    # objects the reference's decoder / matcher trips over: no kind, labels that are no string map, no namespace, a Namespace
+    objs_ns += [({"apiVersion": "v1", "metadata": {"name": "nokind"}}, None),
+                ({"apiVersion": "v1", "kind": "Pod", "metadata": {"name": "badlabels", "namespace": "dev-00", "labels": {"a": 1}}, "spec": {"containers": [{"name": "c", "image": "nginx"}]}}, None),
+                ({"apiVersion": "v1", "kind": "Pod", "metadata": {"name": "nons"}, "spec": {"containers": [{"name": "c", "image": "nginx", "securityContext": {"privileged": True}}]}}, None),
+                ({"apiVersion": "v1", "kind": "Namespace", "metadata": {"name": "prod-00", "labels": {"env": "prod"}}}, None),
+                ({"apiVersion": "apps/v1", "kind": "Deployment", "metadata": {"name": "d", "namespace": "dev-01"}, "spec": {"template": {"spec": {"containers": "notalist"}}}}, synth.gen_namespaces().get("dev-01"))]
+    want_v, want_e = _python_pairs(ts, cs, objs_ns)
+    ck = IndepChecker(ts, cs)
+    viol, err = ck.check_texts([(json.dumps(o), json.dumps(ns) if ns is not None else None) for o, ns in objs_ns], threads=3)
+    got_v, got_e = _pairs_of(viol, len(objs_ns)), _pairs_of(err, len(objs_ns))
+    assert len(want_v) > 100
+    assert got_v == want_v, (sorted(got_v - want_v)[:5], sorted(want_v - got_v)[:5])
+    assert got_e == want_e, (sorted(got_e - want_e)[:5], sorted(want_e - got_e)[:5])
+
+
+def test_compiled_checker_on_structurally_mutated_objects(fixtures):
+    """wrong types, missing members, arrays where objects are expected (tests/test_parity.py _mutate): both restatements answer alike"""
+    from test_parity import _mutate
+    ts, cs = synth.psp_templates(fixtures), synth.audit_constraints()
+    nss = synth.gen_namespaces()
+    objs_ns = []
+    for seed in (5, 6, 7):
+        rng = synth.SplitMix64(seed)
+        for o in synth.gen_objects(120, seed=seed, mixed=True):
+            m = _mutate(rng, _mutate(rng, o))
+            if not isinstance(m, dict):
+                m = {"apiVersion": "v1", "kind": "Pod", "metadata": {"name": "m"}}
+            md = m.get("metadata")
+            ns = synth.namespace_for(m, nss) if isinstance(md, dict) and isinstance(md.get("namespace"), str) else None
+            objs_ns.append((m, ns))
+    want_v, want_e = _python_pairs(ts, cs, objs_ns)
+    ck = IndepChecker(ts, cs)
+    viol, err = ck.check_texts([(json.dumps(o), json.dumps(ns) if ns is not None else None) for o, ns in objs_ns], threads=2)
+    got_v, got_e = _pairs_of(viol, len(objs_ns)), _pairs_of(err, len(objs_ns))
+    assert len(want_v) > 100 and len(want_e) > 0
+    assert got_v == want_v, (sorted(got_v - want_v)[:5], sorted(want_v - got_v)[:5])
+    assert got_e == want_e, (sorted(got_e - want_e)[:5], sorted(want_e - got_e)[:5])
