@@ -366,6 +366,10 @@ def side_point(config, reviews, steps, warmup, oracle_n, dev_index, fx, nss, wit
             out["parity_python_oracle"]["geometry"] = "the timed table itself: %d reviews, %d plan group(s), LDS %d B per row group" % (reviews, groups, int(final.lds_bytes))
         except Exception as ex:   # noqa: BLE001
             out["parity_python_oracle"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+        try:   # ... and the independent COMPILED checker over EVERY object of this table (the 10 M-object point passes oracle_n = 0: no checker there)
+            _, out["parity_compiled_independent"] = indep_leg(templates, constraints, batch, final, ids=ids, budget_s=0.5)
+        except Exception as ex:   # noqa: BLE001
+            out["parity_compiled_independent"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
     if totals:
         try:
             out["audit_result_totals"] = totals_leg(table)
@@ -423,7 +427,9 @@ def other_configs(args, dev_index, dev, fx, nss, budget_s=200.0):
     def resident_brief(d):
         rf = d["roofline"]
         return {"w": "%dx%d" % (d["constraints"], d["reviews"]), "ms": _sig(d["ms_per_step"]), "evals_s": _sig(d["evals_per_s"]), "frac": _sig(rf["frac"], 3),
-                "GBs": _sig(rf["achieved"]), "groups": d["plan_groups"], "parity": parity_brief(d.get("parity_python_oracle")), "leg_s": _sig(d["leg_seconds"], 3)}
+                "GBs": _sig(rf["achieved"]), "groups": d["plan_groups"], "parity": parity_brief(d.get("parity_python_oracle")),
+                "compiled": {k: (_sig(v, 3) if isinstance(v, float) else v) for k, v in (d.get("parity_compiled_independent") or {}).items() if k in ("n", "pairs_equal", "seconds", "error")},
+                "leg_s": _sig(d["leg_seconds"], 3)}
     r = run("configs1", lambda: side_point(1, 100000, max(args.steps, 50), args.warmup, args.side_oracle_sample, dev_index, fx, nss))
     if r:
         detail["configs1"], brief["configs1"] = r[0], resident_brief(r[0])
