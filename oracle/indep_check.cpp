@@ -714,14 +714,31 @@ static std::string go_sprintf(const std::string& fmt, const std::vector<VP>& arg
   if (ai < args.size()) o += "%!(EXTRA)";
   return o;
 }
-static std::shared_ptr<const std::regex> go_regex(const std::string& pat) {   // (the policies' patterns -- ^[0-9]+$, anchors, classes -- mean the same in ECMAScript)
+// Go regexp (RE2 syntax) through std::regex (ECMAScript): the policies' patterns -- anchors, classes, alternation, counted
+// repetition, a leading (?i) -- mean the same in both.  What this translation does not cover is an ERROR of the checker (never
+// "undefined", which is what an invalid pattern is in OPA): other inline flags, \pL classes, \z, named groups, a pattern std::regex
+// rejects.
+static std::shared_ptr<const std::regex> go_regex(const std::string& pat) {
   static std::mutex mu;
   static std::map<std::string, std::shared_ptr<const std::regex>> cache;
   std::lock_guard<std::mutex> l(mu);
   auto it = cache.find(pat);
   if (it != cache.end()) return it->second;
+  std::string body = pat;
+  auto flags = std::regex::ECMAScript;
+  if (body.compare(0, 2, "(?") == 0) {
+    const size_t close = body.find(')');
+    if (close != std::string::npos && body.find_first_not_of("imsU-", 2) == close) {   // a flags-only group at the very start
+      if (body.substr(2, close - 2) != "i") throw std::runtime_error("regex flags " + body.substr(0, close + 1) + " are outside this checker's scope");
+      flags |= std::regex::icase;
+      body = body.substr(close + 1);
+    }
+  }
+  if (body.find("(?") != std::string::npos || body.find("\\p") != std::string::npos || body.find("\\z") != std::string::npos || body.find("\\A") != std::string::npos || body.find("\\Q") != std::string::npos || body.find("[[:") != std::string::npos)
+    throw std::runtime_error("regex " + pat + " is outside this checker's scope");
   std::shared_ptr<const std::regex> r;
-  try { r = std::make_shared<const std::regex>(pat, std::regex::ECMAScript); } catch (const std::regex_error&) { r = nullptr; }
+  try { r = std::make_shared<const std::regex>(body, flags); }
+  catch (const std::regex_error&) { throw std::runtime_error("regex " + pat + " is outside this checker's scope (std::regex rejects it)"); }
   cache[pat] = r;
   return r;
 }
@@ -742,8 +759,8 @@ static const std::map<std::string, std::pair<int, BuiltinFn>>& BUILTINS() {
       {"is_set", {1, [](const std::vector<VP>& a) -> VP { return mk_bool(a[0]->k == V::Set); }}},
       {"is_null", {1, [](const std::vector<VP>& a) -> VP { return mk_bool(a[0]->k == V::Null); }}},
       {"sprintf", {2, [](const std::vector<VP>& a) -> VP { return mk_str(go_sprintf(need(a[0], V::Str).s, need(a[1], V::Arr).a)); }}},
-      {"re_match", {2, [](const std::vector<VP>& a) -> VP { auto r = go_regex(need(a[0], V::Str).s); const std::string& s = need(a[1], V::Str).s; if (!r) throw BuiltinErr(); return mk_bool(std::regex_search(s, *r)); }}},
-      {"regex.match", {2, [](const std::vector<VP>& a) -> VP { auto r = go_regex(need(a[0], V::Str).s); const std::string& s = need(a[1], V::Str).s; if (!r) throw BuiltinErr(); return mk_bool(std::regex_search(s, *r)); }}},
+      {"re_match", {2, [](const std::vector<VP>& a) -> VP { const std::string& p = need(a[0], V::Str).s; const std::string& s = need(a[1], V::Str).s; return mk_bool(std::regex_search(s, *go_regex(p))); }}},
+      {"regex.match", {2, [](const std::vector<VP>& a) -> VP { const std::string& p = need(a[0], V::Str).s; const std::string& s = need(a[1], V::Str).s; return mk_bool(std::regex_search(s, *go_regex(p))); }}},
       {"replace", {3, [](const std::vector<VP>& a) -> VP {
          const std::string& s = need(a[0], V::Str).s; const std::string& old = need(a[1], V::Str).s; const std::string& nw = need(a[2], V::Str).s;
          std::string o;

@@ -101,3 +101,36 @@ def test_compiled_checker_on_structurally_mutated_objects(fixtures):
     assert len(want_v) > 100 and len(want_e) > 0
     assert got_v == want_v, (sorted(got_v - want_v)[:5], sorted(want_v - got_v)[:5])
     assert got_e == want_e, (sorted(got_e - want_e)[:5], sorted(want_e - got_e)[:5])
+
+
+@pytest.mark.parametrize("policy,n", [("audit-50", 20000), ("corpus-200", 3000)])
+def test_product_equals_the_compiled_checker_at_sizes_the_python_oracle_does_not_reach(policy, n, fixtures):
+    """the product's bitmaps (CPU build of the engine here; the gpu suite and bench.py do the same on the device) against the independent
+    compiled checker on every object -- tens of thousands of objects x the whole policy set in seconds"""
+    from gatekeeper_amd import driver as D
+    ts, cs = (synth.psp_templates(fixtures), synth.audit_constraints()) if policy == "audit-50" else synth.corpus(fixtures)
+    drv = D.Driver(device=0, hostemu=True)
+    client = D.Client(drv)
+    for t in ts:
+        client.AddTemplate(t)
+    for c in cs:
+        client.AddConstraint(c)
+    batch = synth.NativeBatch(drv.engine.lib, n, seed=synth.SEED + 3, mixed=True, start=0, namespaces=synth.gen_namespaces())
+    table = drv.engine.create_table_native(batch.reviews, n, keep_docs=False, resident=True, pruned=True)
+    ev = table.eval(download=True, collect_only=True)
+    ids = [drv.constraint_id(client.constraints[(k["kind"], k["metadata"]["name"])]) for k in cs]
+    ck = IndepChecker(ts, cs)
+    viol, err = ck.check(batch.reviews, n, threads=4)
+    row_of = {int(cid): i for i, cid in enumerate(ev.constraint_ids)}
+    words = (n + 63) // 64
+    tail = np.uint64((1 << (n % 64)) - 1) if n % 64 else None
+    pairs = 0
+    for row, cid in enumerate(ids):
+        d_v, d_e = np.array(ev.viol[row_of[cid]][:words], copy=True), np.array(ev.err[row_of[cid]][:words], copy=True)
+        if tail is not None:
+            d_v[-1] &= tail
+            d_e[-1] &= tail
+        assert (d_v == viol[row]).all() and (d_e == err[row]).all(), (policy, cs[row]["kind"], cs[row]["metadata"]["name"])
+        pairs += int(np.unpackbits(d_v.view(np.uint8)).sum())
+    assert pairs > n // 2
+    assert len(ev.too_big_reviews()) == 0
