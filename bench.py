@@ -74,7 +74,7 @@ def cpu_leg(templates, constraints, batch, ev, budget_s=10.0):
     return base, parity
 
 
-def indep_leg(templates, constraints, batch, ev, ids=None, budget_s=8.0):
+def indep_leg(templates, constraints, batch, ev, ids=None, budget_s=8.0, n=None):
     """The INDEPENDENT COMPILED checker (oracle/indep_check.cpp -> oracle/libgkindep.so: a C++ restatement of the Python oracle -- own
     JSON reader, value model, Rego parser + tree-walking interpreter, Match layer; no object of the product linked) over ALL objects
     of the timed table, taken as JSON text from the batch: its violation / autoreject bitmaps against the device's, bit for bit.
@@ -82,7 +82,7 @@ def indep_leg(templates, constraints, batch, ev, ids=None, budget_s=8.0):
     import numpy as np
     from oracle.indep_check import IndepChecker
     ck = IndepChecker(templates, constraints)
-    nc, n = len(constraints), batch.n
+    nc, n = len(constraints), min(n or batch.n, batch.n)   # (n: the first n objects only -- a streamed batch of the same objects)
     cores = int(batch.lib.gk_host_cpus()) or os.cpu_count() or 1
     t0 = time.perf_counter()
     ck.check(batch.reviews, min(n, 512), 1)
@@ -388,6 +388,11 @@ def side_point(config, reviews, steps, warmup, oracle_n, dev_index, fx, nss, wit
                 n = min(oracle_n, stream_args.batch) // 64 * 64
                 stream["parity_python_oracle"] = python_oracle_leg(templates, constraints, batch, first[0], n, ids=ids, oracle=oracle)
                 stream["parity_python_oracle"]["geometry"] = "the first streamed batch (objects [0, %d) of the same stream): a %d-review table built, evaluated and downloaded by the streaming pipeline" % (stream_args.batch, stream_args.batch)
+            if oracle_n > 0 and first and stream_args.batch <= reviews:
+                try:   # every object of that streamed batch against the independent compiled checker
+                    _, stream["parity_compiled_independent"] = indep_leg(templates, constraints, batch, first[0], ids=ids, budget_s=0.2, n=stream_args.batch)
+                except Exception as ex:   # noqa: BLE001
+                    stream["parity_compiled_independent"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
         except Exception as ex:   # noqa: BLE001
             stream = {"error": "%s: %s" % (type(ex).__name__, ex)}
     batch.free()
@@ -446,7 +451,8 @@ def other_configs(args, dev_index, dev, fx, nss, budget_s=200.0):
         detail["configs4_stream"] = r[1]
         if r[1] and "error" not in r[1]:
             brief["configs4_stream"] = {"offered": r[1]["offered_reviews_per_s"], "achieved": _sig(r[1]["achieved_reviews_per_s"]), "p50_ms": _sig(r[1]["batch_latency_ms"]["p50"], 3),
-                                        "p99_ms": _sig(r[1]["batch_latency_ms"]["p99"], 3), "parity": parity_brief(r[1].get("parity_python_oracle"))}
+                                        "p99_ms": _sig(r[1]["batch_latency_ms"]["p99"], 3), "parity": parity_brief(r[1].get("parity_python_oracle")),
+                                        "compiled": {k: (_sig(v, 3) if isinstance(v, float) else v) for k, v in (r[1].get("parity_compiled_independent") or {}).items() if k in ("n", "pairs_equal", "seconds", "error")}}
         else:
             brief["configs4_stream"] = r[1]
     r = run("configs3_n1", lambda: side_point(2, 10000000, max(args.steps, 20), 3, 0, dev_index, fx, nss))

@@ -98,6 +98,7 @@ def test_other_configs_legs_run_on_the_cpu_build(fixtures, monkeypatch):
     assert out["parity_compiled_independent"].get("pairs_equal") and out["parity_compiled_independent"]["n"] == 256, out["parity_compiled_independent"]
     assert out["roofline"]["algo_bytes_per_sweep_table_once"] < out["roofline"]["algo_bytes_per_sweep_every_group"]
     assert "error" not in stream and stream["parity_python_oracle"]["pairs_equal"] and stream["batches"] == 2
+    assert stream["parity_compiled_independent"].get("pairs_equal") and stream["parity_compiled_independent"]["n"] == 128, stream["parity_compiled_independent"]
 
 
 def test_compiled_independent_leg_checks_the_bitmaps(fixtures):
