@@ -39,15 +39,39 @@ std::string bad_verb(char verb, const GoArg& a) {
   return o + "(float64=" + go_float_v(a.f) + ")";
 }
 
+// fmt counts width and precision in runes (fmt/print.go padString: utf8.RuneCountInString; fmtS truncates at rune boundaries)
+size_t fmt_rune_count(const std::string& s) {
+  size_t n = 0;
+  for (unsigned char c : s) n += (c & 0xC0) != 0x80;
+  return n;
+}
+std::string rune_prefix(const std::string& s, size_t runes) {
+  size_t b = 0;
+  for (; b < s.size() && runes; runes--) { b++; while (b < s.size() && ((unsigned char)s[b] & 0xC0) == 0x80) b++; }
+  return s.substr(0, b);
+}
+
+// fmt %c (fmt/format.go fmtC): the rune's UTF-8; anything that is no valid code point prints as U+FFFD
+void append_rune(std::string& o, i128 r) {
+  if (r < 0 || r > 0x10FFFF || (r >= 0xD800 && r <= 0xDFFF)) r = 0xFFFD;
+  const uint32_t c = (uint32_t)r;
+  if (c < 0x80) o.push_back((char)c);
+  else if (c < 0x800) { o.push_back((char)(0xC0 | (c >> 6))); o.push_back((char)(0x80 | (c & 0x3F))); }
+  else if (c < 0x10000) { o.push_back((char)(0xE0 | (c >> 12))); o.push_back((char)(0x80 | ((c >> 6) & 0x3F))); o.push_back((char)(0x80 | (c & 0x3F))); }
+  else { o.push_back((char)(0xF0 | (c >> 18))); o.push_back((char)(0x80 | ((c >> 12) & 0x3F))); o.push_back((char)(0x80 | ((c >> 6) & 0x3F))); o.push_back((char)(0x80 | (c & 0x3F))); }
+}
+
 std::string pad(std::string s, const std::string& flags, int width) {
-  if (width < 0 || (int)s.size() >= width) return s;
-  if (flags.find('-') != std::string::npos) return s + std::string(width - s.size(), ' ');
+  const size_t len = fmt_rune_count(s);
+  if (width < 0 || len >= (size_t)width) return s;
+  const size_t fill = (size_t)width - len;
+  if (flags.find('-') != std::string::npos) return s + std::string(fill, ' ');
   if (flags.find('0') != std::string::npos && !s.empty() && (isdigit((unsigned char)s[0]) || s[0] == '+' || s[0] == '-')) {
     std::string sign;
     if (s[0] == '+' || s[0] == '-') { sign = s.substr(0, 1); s = s.substr(1); }
-    return sign + std::string(width - s.size() - sign.size(), '0') + s;
+    return sign + std::string(fill, '0') + s;
   }
-  return std::string(width - s.size(), ' ') + s;
+  return std::string(fill, ' ') + s;
 }
 
 std::string to_base(i128 v, int base, bool upper) {
@@ -79,42 +103,104 @@ std::string go_sprintf(const std::string& fmt, const ValueVec& argv) {
     if (j < n && fmt[j] == '.') { j++; prec = 0; while (j < n && isdigit((unsigned char)fmt[j])) prec = prec * 10 + (fmt[j++] - '0'); }
     if (j >= n) { out += "%!(NOVERB)"; break; }
     char verb = fmt[j++];
+    std::string wide;   // a verb beyond ASCII is one whole rune (doPrintf decodes it); never a valid verb
+    if ((unsigned char)verb >= 0x80) { wide.push_back(verb); while (j < n && ((unsigned char)fmt[j] & 0xC0) == 0x80) wide.push_back(fmt[j++]); }
     i = j;
     if (verb == '%') { out.push_back('%'); continue; }
-    if (ai >= args.size()) { out += "%!"; out.push_back(verb); out += "(MISSING)"; continue; }
+    if (ai >= args.size()) { out += "%!"; if (wide.empty()) out.push_back(verb); else out += wide; out += "(MISSING)"; continue; }
     const GoArg& a = args[ai++];
+    if (!wide.empty()) { out += "%!" + wide + bad_verb('?', a).substr(3); continue; }
     std::string s;
-    bool plus = flags.find('+') != std::string::npos;
+    const bool plus = flags.find('+') != std::string::npos, space = flags.find(' ') != std::string::npos;
+    const bool sharp = flags.find('#') != std::string::npos, minus = flags.find('-') != std::string::npos;
+    const bool zero = flags.find('0') != std::string::npos && !minus;
+    bool bad = false;
+    // fmt/format.go fmtInteger: precision = minimum digits (%.0d of 0 prints nothing), the 0 flag = precision from the width, '#' the
+    // base prefix, then the sign; whatever is left of the width is spaces
+    auto integer = [&](int base, bool upper, bool o_prefix) {
+      const bool neg = a.i < 0;
+      std::string d = to_base(neg ? -a.i : a.i, base, upper);
+      int p = 0;
+      if (prec >= 0) { p = prec; if (prec == 0 && a.i == 0) d.clear(); }
+      else if (zero && width >= 0) { p = width; if (neg || plus || space) p--; }
+      if ((int)d.size() < p) d.insert(0, (size_t)p - d.size(), '0');
+      if (sharp) {
+        if (base == 2) d.insert(0, "0b");
+        else if (base == 8) { if (d.empty() || d[0] != '0') d.insert(0, "0"); }
+        else if (base == 16) d.insert(0, upper ? "0X" : "0x");
+      }
+      if (o_prefix) d.insert(0, "0o");
+      if (neg) d.insert(0, "-"); else if (plus) d.insert(0, "+"); else if (space) d.insert(0, " ");
+      const size_t len = d.size();
+      if (width >= 0 && len < (size_t)width) d = minus ? d + std::string((size_t)width - len, ' ') : std::string((size_t)width - len, ' ') + d;
+      return d;
+    };
+    // fmtFloat: the sign is '-', '+' with the plus flag, ' ' with the space flag; the 0 flag pads between sign and digits
+    auto floating = [&](std::string num) {
+      if (num[0] != '-') { if (plus) num.insert(0, "+"); else if (space) num.insert(0, " "); }
+      if (width < 0 || num.size() >= (size_t)width) return num;
+      const size_t fill = (size_t)width - num.size();
+      if (minus) return num + std::string(fill, ' ');
+      if (!zero) return std::string(fill, ' ') + num;
+      const bool sign = num[0] == '-' || num[0] == '+' || num[0] == ' ';
+      return (sign ? num.substr(0, 1) : std::string()) + std::string(fill, '0') + num.substr(sign ? 1 : 0);
+    };
     switch (verb) {
       case 'v':
-        if (a.kind == 2) s = a.s;
-        else if (a.kind == 0) s = ((plus && a.i >= 0) ? "+" : "") + i128_to_string(a.i);
-        else s = go_float_v(a.f);
+        if (a.kind == 2) s = pad(a.s, flags, width);
+        else if (a.kind == 0) s = integer(10, false, false);
+        else s = floating(go_float_v(a.f));
         break;
-      case 's': s = a.kind == 2 ? (prec >= 0 ? a.s.substr(0, prec) : a.s) : bad_verb(verb, a); break;
-      case 'q': s = a.kind == 2 ? go_quote(a.s) : bad_verb(verb, a); break;
-      case 'd': s = a.kind == 0 ? ((plus && a.i >= 0) ? "+" : "") + i128_to_string(a.i) : bad_verb(verb, a); break;
+      case 's': if (a.kind == 2) s = pad(prec >= 0 ? rune_prefix(a.s, (size_t)prec) : a.s, flags, width); else bad = true; break;
+      case 'q': if (a.kind == 2) s = pad(go_quote(a.s), flags, width); else bad = true; break;
+      case 'd': if (a.kind == 0) s = integer(10, false, false); else bad = true; break;
       case 'x': case 'X':
-        if (a.kind == 0) s = to_base(a.i, 16, verb == 'X');
-        else if (a.kind == 2) { const char* d = verb == 'X' ? "0123456789ABCDEF" : "0123456789abcdef"; for (unsigned char c : a.s) { s.push_back(d[c >> 4]); s.push_back(d[c & 15]); } }
-        else s = bad_verb(verb, a);
-        break;
-      case 'o': s = a.kind == 0 ? to_base(a.i, 8, false) : bad_verb(verb, a); break;
-      case 'b': s = a.kind == 0 ? to_base(a.i, 2, false) : bad_verb(verb, a); break;
-      case 'c': if (a.kind == 0) { s.push_back((char)a.i); } else s = bad_verb(verb, a); break;
-      case 'f': case 'e': case 'E': case 'g': case 'G':
-        if (a.kind == 1) {
-          char buf[128], f[16];
-          snprintf(f, sizeof f, "%%.%d%c", prec < 0 ? 6 : prec, verb);
-          snprintf(buf, sizeof buf, f, a.f);
-          s = buf;
-          if (verb == 'e' || verb == 'E') {   // Go prints at least two exponent digits, C too; nothing to fix
+        if (a.kind == 0) s = integer(16, verb == 'X', false);
+        else if (a.kind == 2) {   // fmtSbx: the precision counts bytes, ' ' separates them, '#' prefixes (each byte when separated)
+          const char* d = verb == 'X' ? "0123456789ABCDEF" : "0123456789abcdef";
+          const size_t nb = prec >= 0 && (size_t)prec < a.s.size() ? (size_t)prec : a.s.size();
+          for (size_t k = 0; k < nb; k++) {
+            const unsigned char c = (unsigned char)a.s[k];
+            if (space && k) s.push_back(' ');
+            if (sharp && (space || k == 0)) s += verb == 'X' ? "0X" : "0x";
+            s.push_back(d[c >> 4]); s.push_back(d[c & 15]);
           }
-        } else s = bad_verb(verb, a);
+          s = pad(s, flags, width);
+        }
+        else bad = true;
         break;
-      default: s = bad_verb(verb, a);
+      case 'o': if (a.kind == 0) s = integer(8, false, false); else bad = true; break;
+      case 'O': if (a.kind == 0) s = integer(8, false, true); else bad = true; break;
+      case 'b': if (a.kind == 0) s = integer(2, false, false); else bad = true; break;
+      case 'c': if (a.kind == 0) { append_rune(s, a.i); s = pad(s, flags, width); } else bad = true; break;
+      case 'U':
+        if (a.kind == 0 && a.i >= 0) { s = to_base(a.i, 16, true); if (s.size() < 4) s.insert(0, 4 - s.size(), '0'); s = pad("U+" + s, flags, width); }
+        else bad = true;
+        break;
+      case 'T': {   // the operand's Go type (printArg: fmtS(reflect.TypeOf(arg).String()))
+        const std::string t = a.kind == 0 ? "int" : a.kind == 1 ? "float64" : "string";
+        s = pad(prec >= 0 ? rune_prefix(t, (size_t)prec) : t, flags, width);
+        break;
+      }
+      case 'f': case 'F': case 'e': case 'E': case 'g': case 'G':
+        if (a.kind == 1) {
+          if ((verb == 'g' || verb == 'G') && prec < 0) {   // %g without a precision is the shortest text that round-trips, as %v
+            s = go_float_v(a.f);
+            if (verb == 'G') for (char& c : s) if (c == 'e') c = 'E';
+          } else {
+            char f[24];
+            snprintf(f, sizeof f, "%%.%d%c", prec < 0 ? 6 : prec, verb == 'F' ? 'f' : verb);
+            const int need = snprintf(nullptr, 0, f, a.f);   // %f of 1.8e308 is 300+ digits
+            s.resize((size_t)need + 1);
+            snprintf(&s[0], s.size(), f, a.f);
+            s.resize((size_t)need);
+          }
+          s = floating(s);
+        } else bad = true;
+        break;
+      default: bad = true;
     }
-    out += pad(s, flags, width);
+    out += bad ? bad_verb(verb, a) : s;   // (badVerb writes past the width: no padding)
   }
   if (ai < args.size()) {
     out += "%!(EXTRA ";

@@ -141,11 +141,59 @@ static std::string i128_str(i128 x) {
   std::reverse(s.begin(), s.end());
   return s;
 }
-static std::string num_str(const V& v) {
-  if (v.is_int) return i128_str(v.i);
+// shortest digits that round-trip (what Go's strconv and Python's repr print): (digits, decimal exponent of the first digit)
+static void shortest_digits(double f, std::string* digits, int* x) {
   char buf[64];
-  snprintf(buf, sizeof buf, "%.17g", v.d);   // (the digits of a message are not what this checker compares: pair existence is)
-  return buf;
+  for (int p = 1; p <= 17; p++) {
+    snprintf(buf, sizeof buf, "%.*e", p - 1, std::fabs(f));
+    if (strtod(buf, nullptr) == std::fabs(f) || p == 17) break;
+  }
+  std::string m(buf);
+  const size_t e = m.find('e');
+  *x = atoi(m.c_str() + e + 1);
+  std::string d;
+  for (size_t i = 0; i < e; i++) if (m[i] != '.') d.push_back(m[i]);
+  while (d.size() > 1 && d.back() == '0') d.pop_back();
+  *digits = d;
+}
+static std::string fmt_e(const std::string& sign, const std::string& digits, int x, int min_exp_digits) {
+  std::string m = digits.substr(0, 1) + (digits.size() > 1 ? "." + digits.substr(1) : "");
+  char eb[16];
+  snprintf(eb, sizeof eb, "e%c%0*d", x >= 0 ? '+' : '-', min_exp_digits, x >= 0 ? x : -x);
+  return sign + m + eb;
+}
+static std::string fmt_f(const std::string& sign, const std::string& digits, int x) {
+  if (x >= 0) {
+    if ((int)digits.size() <= x + 1) return sign + digits + std::string((size_t)(x + 1 - (int)digits.size()), '0');
+    return sign + digits.substr(0, (size_t)x + 1) + "." + digits.substr((size_t)x + 1);
+  }
+  return sign + "0." + std::string((size_t)(-x - 1), '0') + digits;
+}
+static std::string json_float_text(double f) {   // encoding/json floatEncoder (values.py json_float_text)
+  if (f == 0) return std::signbit(f) ? "-0" : "0";
+  std::string digits; int x;
+  shortest_digits(f, &digits, &x);
+  const std::string sign = f < 0 ? "-" : "";
+  if (std::fabs(f) < 1e-6 || std::fabs(f) >= 1e21) {
+    std::string s = fmt_e(sign, digits, x, 2);
+    if (s.size() >= 4 && s[s.size() - 4] == 'e' && s[s.size() - 3] == '-' && s[s.size() - 2] == '0') s = s.substr(0, s.size() - 2) + s.back();
+    return s;
+  }
+  return fmt_f(sign, digits, x);
+}
+static std::string go_float_v(double f) {   // fmt %v of a float64 (values.py go_float_v)
+  if (f != f) return "NaN";
+  if (std::isinf(f)) return f > 0 ? "+Inf" : "-Inf";
+  if (f == 0) return std::signbit(f) ? "-0" : "0";
+  std::string digits; int x;
+  shortest_digits(f, &digits, &x);
+  const std::string sign = f < 0 ? "-" : "";
+  return (x < -4 || x >= 6) ? fmt_e(sign, digits, x, 2) : fmt_f(sign, digits, x);
+}
+static std::string num_str(const V& v) {   // ast.Number.String() (values.py num_to_string)
+  if (v.is_int) return i128_str(v.i);
+  if (std::isfinite(v.d) && std::floor(v.d) == v.d && std::fabs(v.d) < 1e21) return i128_str((i128)v.d);
+  return json_float_text(v.d);
 }
 static std::string to_string(const VP& v) {
   switch (v->k) {
@@ -695,23 +743,89 @@ static VP arith(const std::string& op, const VP& a, const VP& b) {
   }
   throw BuiltinErr();
 }
-static std::string go_sprintf(const std::string& fmt, const std::vector<VP>& args) {   // (%v / %s / %d of what the policies print; the digits are not compared)
+// builtinSprintf (rego_builtins.py go_sprintf) for the verbs messages are made of -- %v %s %d, flags and widths; any other verb is
+// outside this checker's scope (an error, not a guess)
+static std::string go_sprintf(const std::string& fmt, const std::vector<VP>& args) {
+  struct Arg { int kind; std::string s; i128 i; double d; };   // 0 string, 1 int, 2 float64
+  std::vector<Arg> as;
+  for (const VP& a : args) {
+    Arg x{0, "", 0, 0};
+    if (a->k == V::Num) {
+      if (a->is_int) { x.kind = 1; x.i = a->i; }
+      else if (std::floor(a->d) == a->d && std::fabs(a->d) < 1e21) { x.kind = 1; x.i = (i128)a->d; }
+      else { x.kind = 2; x.d = a->d; }
+    } else if (a->k == V::Str) x.s = a->s;
+    else x.s = to_string(a);
+    as.push_back(x);
+  }
+  auto pad = [](std::string s, const std::string& flags, int width) {
+    const size_t n = utf8_len(s);
+    if (width < 0 || n >= (size_t)width) return s;
+    if (flags.find('-') != std::string::npos) return s + std::string((size_t)width - n, ' ');
+    if (flags.find('0') != std::string::npos && !s.empty() && ((s[0] >= '0' && s[0] <= '9') || s[0] == '+' || s[0] == '-')) {
+      std::string sign;
+      if (s[0] == '+' || s[0] == '-') { sign = s.substr(0, 1); s = s.substr(1); }
+      return sign + std::string((size_t)width - n, '0') + s;
+    }
+    return std::string((size_t)width - n, ' ') + s;
+  };
   std::string o;
   size_t ai = 0;
   for (size_t i = 0; i < fmt.size(); i++) {
     if (fmt[i] != '%') { o.push_back(fmt[i]); continue; }
-    if (++i >= fmt.size()) { o += "%!(NOVERB)"; break; }
-    while (i < fmt.size() && strchr("+-# 0123456789.", fmt[i])) i++;
-    if (i >= fmt.size()) { o += "%!(NOVERB)"; break; }
-    const char verb = fmt[i];
+    size_t j = i + 1;
+    std::string flags;
+    while (j < fmt.size() && strchr("+-# 0", fmt[j])) flags.push_back(fmt[j++]);
+    int width = -1, prec = -1;
+    if (j < fmt.size() && fmt[j] >= '0' && fmt[j] <= '9') { width = 0; while (j < fmt.size() && fmt[j] >= '0' && fmt[j] <= '9') width = width * 10 + (fmt[j++] - '0'); }
+    if (j < fmt.size() && fmt[j] == '.') { j++; prec = 0; while (j < fmt.size() && fmt[j] >= '0' && fmt[j] <= '9') prec = prec * 10 + (fmt[j++] - '0'); }
+    if (j >= fmt.size()) { o += "%!(NOVERB)"; break; }
+    std::string verb_rune(1, fmt[j]);   // the verb is the next rune, whatever it is
+    while (j + 1 < fmt.size() && (unsigned char)verb_rune[0] >= 0x80 && ((unsigned char)fmt[j + 1] & 0xC0) == 0x80) verb_rune.push_back(fmt[++j]);
+    const char verb = verb_rune.size() == 1 ? verb_rune[0] : '\0';
+    i = j;
     if (verb == '%') { o.push_back('%'); continue; }
-    if (ai >= args.size()) { o += std::string("%!") + verb + "(MISSING)"; continue; }
-    const VP& a = args[ai++];
-    if (a->k == V::Str && (verb == 'v' || verb == 's')) o += a->s;
-    else if (a->k == V::Num && (verb == 'v' || verb == 'd')) o += num_str(*a);
-    else o += to_string(a);
+    if (ai >= as.size()) { o += "%!" + verb_rune + "(MISSING)"; continue; }
+    const Arg& a = as[ai++];
+    std::string s;
+    auto bad = [&]() { return "%!" + verb_rune + (a.kind == 0 ? "(string=" + a.s + ")" : a.kind == 1 ? "(int=" + i128_str(a.i) + ")" : "(float64=" + go_float_v(a.d) + ")"); };
+    const bool plus = flags.find('+') != std::string::npos, space = flags.find(' ') != std::string::npos, left = flags.find('-') != std::string::npos;
+    const bool zero = flags.find('0') != std::string::npos && !left;
+    // an integer operand (fmtInteger): precision or, with the 0 flag, the width = minimum digits; then the sign; spaces fill the width
+    auto integer = [&]() {
+      const bool neg = a.i < 0;
+      std::string d = i128_str(neg ? -a.i : a.i);
+      size_t min_digits = 0;
+      if (prec >= 0) { min_digits = (size_t)prec; if (prec == 0 && a.i == 0) d.clear(); }
+      else if (zero && width > 0) min_digits = (size_t)width - ((neg || plus || space) && width > 0 ? 1 : 0);
+      while (d.size() < min_digits) d.insert(d.begin(), '0');
+      d = (neg ? "-" : plus ? "+" : space ? " " : "") + d;
+      if (width > 0 && d.size() < (size_t)width) { const std::string fill((size_t)width - d.size(), ' '); d = left ? d + fill : fill + d; }
+      return d;
+    };
+    // a float64 operand (fmtFloat): sign by flag, zeros go between the sign and the digits
+    auto floating = [&](std::string t) {
+      if (t[0] != '-') t = (plus ? "+" : space ? " " : "") + t;
+      if (width <= 0 || t.size() >= (size_t)width) return t;
+      const std::string fill((size_t)width - t.size(), zero ? '0' : ' ');
+      if (left) return t + fill;
+      if (zero && (t[0] == '-' || t[0] == '+' || t[0] == ' ')) return t.substr(0, 1) + fill + t.substr(1);
+      return fill + t;
+    };
+    if (verb == 'v') s = a.kind == 0 ? pad(a.s, flags, width) : a.kind == 1 ? integer() : floating(go_float_v(a.d));
+    else if (verb == 's') { if (a.kind != 0) s = bad(); else if (prec < 0) s = pad(a.s, flags, width); else { size_t b = 0, n = 0; while (b < a.s.size() && n < (size_t)prec) { b++; while (b < a.s.size() && ((unsigned char)a.s[b] & 0xC0) == 0x80) b++; n++; } s = pad(a.s.substr(0, b), flags, width); } }
+    else if (verb == 'd') s = a.kind == 1 ? integer() : bad();
+    else if (verb == 'q') s = a.kind == 0 ? pad(quote(a.s), flags, width) : bad();
+    else if (verb == 'T') { std::string t = a.kind == 0 ? "string" : a.kind == 1 ? "int" : "float64"; if (prec >= 0 && (size_t)prec < t.size()) t.resize((size_t)prec); s = pad(t, flags, width); }
+    else if (verb == '\0' || verb == 't' || verb == 'p' || !strchr("bcdeEfFgGoOqsUvxX", verb)) s = bad();   // no verb of fmt at all, or none for these operands
+    else throw std::runtime_error(std::string("sprintf verb %") + verb + " is outside this checker's scope");
+    o += s;   // (a bad verb is written outside the width)
   }
-  if (ai < args.size()) o += "%!(EXTRA)";
+  if (ai < as.size()) {
+    o += "%!(EXTRA ";
+    for (size_t k = ai; k < as.size(); k++) { if (k > ai) o += ", "; o += as[k].kind == 0 ? "string=" + as[k].s : as[k].kind == 1 ? "int=" + i128_str(as[k].i) : "float64=" + go_float_v(as[k].d); }
+    o += ")";
+  }
   return o;
 }
 // Go regexp (RE2 syntax) through std::regex (ECMAScript): the policies' patterns -- anchors, classes, alternation, counted
@@ -1478,6 +1592,54 @@ static void review_one(const Checker& c, const char* json, size_t json_len, cons
   }
 }
 
+// the messages of one object: row -> the msg of every result (one per distinct (msg, details), as Client.review's driver dedupes)
+static void review_messages(const Checker& c, const char* json, size_t json_len, const char* ns_json, size_t ns_len, std::map<uint32_t, std::vector<std::string>>* out) {
+  const VP obj = parse_json(json, json_len);
+  if (obj->k != V::Obj) throw std::runtime_error("review object is not a JSON object");
+  VP ns;
+  if (ns_json && ns_len) { ns = parse_json(ns_json, ns_len); if (ns->k == V::Null) ns = nullptr; }
+  std::string g, v, k;
+  obj_gvk(*obj, &g, &v, &k);
+  std::vector<std::pair<VP, VP>> rv;
+  rv.emplace_back(mk_str("uid"), mk_str(""));
+  rv.emplace_back(mk_str("kind"), mk_obj({{mk_str("group"), mk_str(g)}, {mk_str("version"), mk_str(v)}, {mk_str("kind"), mk_str(k)}}));
+  rv.emplace_back(mk_str("resource"), mk_obj({{mk_str("group"), mk_str("")}, {mk_str("version"), mk_str("")}, {mk_str("resource"), mk_str("")}}));
+  rv.emplace_back(mk_str("operation"), mk_str(""));
+  rv.emplace_back(mk_str("userInfo"), mk_obj({}));
+  rv.emplace_back(mk_str("object"), obj);
+  rv.emplace_back(mk_str("oldObject"), mk_null());
+  rv.emplace_back(mk_str("options"), mk_null());
+  const std::string name = obj_name(*obj), nsf = obj_namespace(*obj);
+  if (!name.empty()) rv.emplace_back(mk_str("name"), mk_str(name));
+  if (!nsf.empty()) rv.emplace_back(mk_str("namespace"), mk_str(nsf));
+  const VP review = mk_obj(std::move(rv));
+  for (size_t row = 0; row < c.constraints.size(); row++) {
+    const Constraint& x = c.constraints[row];
+    if (x.match) {
+      if (k.empty()) continue;
+      try { if (!matches(*x.match, *obj, ns.get(), "Original")) continue; } catch (const MatchErr&) { continue; }
+    }
+    Query q(*x.prog, mk_obj({{mk_str("review"), review}, {mk_str("parameters"), x.params}}));
+    const VP set = q.violations();
+    std::set<std::pair<std::string, std::string>> seen;
+    for (auto& r : set->a) {
+      if (r->k != V::Obj) continue;
+      const VP* m = obj_get(*r, "msg");
+      if (!m || (*m)->k != V::Str) continue;
+      const VP* d = obj_get(*r, "details");
+      if (seen.insert({(*m)->s, d ? to_string(*d) : std::string("{}")}).second) (*out)[(uint32_t)row].push_back((*m)->s);
+    }
+  }
+}
+static std::string json_quote(const std::string& s) {
+  std::string o = "\"";
+  char buf[8];
+  for (unsigned char ch : s) {
+    if (ch == '"') o += "\\\""; else if (ch == '\\') o += "\\\\"; else if (ch < 0x20) { snprintf(buf, sizeof buf, "\\u%04x", ch); o += buf; } else o.push_back((char)ch);
+  }
+  return o + "\"";
+}
+
 }  // namespace ic
 
 // ================================================================================================ C entry points (ctypes: oracle/indep_check.py)
@@ -1489,6 +1651,26 @@ void* ic_create(const char* templates_json, const char* constraints_json) {
   catch (const std::exception& e) { g_ic_err = e.what(); return nullptr; }
 }
 void ic_destroy(void* h) { delete static_cast<ic::Checker*>(h); }
+// the messages of ONE review as JSON {"<row>": ["msg", ..]} (rows with results only); free with ic_free; NULL with ic_last_error()
+char* ic_messages(void* h, const gk_review_in* r) {
+  try {
+    std::map<uint32_t, std::vector<std::string>> out;
+    ic::review_messages(*static_cast<ic::Checker*>(h), r->json, r->json_len, r->namespace_json, r->namespace_len, &out);
+    std::string js = "{";
+    for (auto& kv : out) {
+      if (js.size() > 1) js += ",";
+      js += "\"" + std::to_string(kv.first) + "\":[";
+      for (size_t i = 0; i < kv.second.size(); i++) { if (i) js += ","; js += ic::json_quote(kv.second[i]); }
+      js += "]";
+    }
+    js += "}";
+    char* buf = (char*)malloc(js.size() + 1);
+    memcpy(buf, js.c_str(), js.size() + 1);
+    return buf;
+  } catch (const std::exception& e) { g_ic_err = e.what(); return nullptr; }
+  catch (const ic::Unbound&) { g_ic_err = "unsafe variable"; return nullptr; }
+}
+void ic_free(void* p) { free(p); }
 // bitmaps [n_constraints][words] (bit r of word r / 64 of row c: pair (c, review r)), zeroed by the caller; returns 0, or -1 with ic_last_error()
 int ic_check(void* h, const gk_review_in* reviews, size_t n, uint64_t* viol, uint64_t* err, size_t words, int threads) {
   const ic::Checker& c = *static_cast<ic::Checker*>(h);

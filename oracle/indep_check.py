@@ -37,6 +37,9 @@ def _load():
     lib.ic_last_error.restype = C.c_char_p
     lib.ic_check.restype = C.c_int
     lib.ic_check.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    lib.ic_messages.restype = C.c_void_p
+    lib.ic_messages.argtypes = [C.c_void_p, C.c_void_p]
+    lib.ic_free.argtypes = [C.c_void_p]
     return lib
 
 
@@ -77,6 +80,20 @@ class IndepChecker:
             arr[i].kind, arr[i].json, arr[i].json_len = 1, t, len(t)
             arr[i].namespace_json, arr[i].namespace_len = ns, len(ns) if ns else 0
         return self.check(arr, len(texts), threads)
+
+    def messages(self, text, ns=None):
+        """the messages of ONE object: {row: [msg, ..]} -- one msg per distinct (msg, details), in the checker's set order"""
+        r = ReviewIn()
+        t = text.encode() if isinstance(text, str) else text
+        nsb = (ns.encode() if isinstance(ns, str) else ns) if ns else None
+        r.kind, r.json, r.json_len, r.namespace_json, r.namespace_len = 1, t, len(t), nsb, len(nsb) if nsb else 0
+        p = self.lib.ic_messages(self.h, C.byref(r))
+        if not p:
+            raise RuntimeError("compiled checker: " + self.lib.ic_last_error().decode())
+        try:
+            return {int(k): v for k, v in json.loads(C.string_at(p).decode()).items()}
+        finally:
+            self.lib.ic_free(p)
 
     def close(self):
         if self.h:

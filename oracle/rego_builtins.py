@@ -357,7 +357,10 @@ def go_regex(pat):
 
 
 # ---------------------------------------------------------------- sprintf (Go fmt)
-_VERB_RE = re.compile(r"%([-+# 0]*)(\d+|\*)?(?:\.(\d+|\*))?([a-zA-Z%])")
+# fmt's doPrintf: flags, width, .precision, then the verb = the next rune WHATEVER it is ("%!" is the bad verb '!'); a format that ends
+# before the verb prints %!(NOVERB).  Not modelled (by the product either; no template of the corpus uses them): explicit argument
+# indexes %[n]d and the '*' width / precision -- '[' and '*' are read as (bad) verbs.
+_VERB_RE = re.compile(r"%([-+# 0]*)(\d+)?(?:\.(\d*))?(.)?", re.S)
 
 
 def _go_arg(v):
@@ -394,6 +397,99 @@ def _pad(s, flags, width):
     return " " * (width - len(s)) + s
 
 
+_DIGITS = "0123456789abcdef"
+
+
+def _fmt_integer(val, base, flags, width, prec, upper=False, o_prefix=False):
+    """fmt/format.go fmtInteger: precision = minimum number of digits (%.0d of 0 prints nothing); without one the 0 flag turns the
+    width into that minimum; '#' adds the base prefix; then the sign ('-', '+' flag, ' ' flag); the rest of the width is spaces"""
+    neg, u = val < 0, abs(val)
+    digits = ""
+    while u:
+        digits = _DIGITS[u % base] + digits
+        u //= base
+    digits = digits or "0"
+    if upper:
+        digits = digits.upper()
+    zero = "0" in flags and "-" not in flags
+    if prec is not None:
+        if prec == 0 and val == 0:
+            digits = ""
+        digits = digits.rjust(prec, "0")
+    elif zero and width is not None:
+        digits = digits.rjust(width - (1 if neg or "+" in flags or " " in flags else 0), "0")
+    if "#" in flags:
+        if base == 2:
+            digits = "0b" + digits
+        elif base == 8 and not digits.startswith("0"):
+            digits = "0" + digits
+        elif base == 16:
+            digits = ("0X" if upper else "0x") + digits
+    if o_prefix:
+        digits = "0o" + digits
+    digits = ("-" if neg else "+" if "+" in flags else " " if " " in flags else "") + digits
+    if width is not None and len(digits) < width:
+        digits = digits.ljust(width) if "-" in flags else digits.rjust(width)
+    return digits
+
+
+def _fmt_float(num, flags, width):
+    """fmt/format.go fmtFloat: sign '-', or '+' / ' ' by flag; the 0 flag pads between the sign and the digits"""
+    if not num.startswith("-"):
+        num = ("+" if "+" in flags else " " if " " in flags else "") + num
+    if width is None or len(num) >= width:
+        return num
+    if "-" in flags:
+        return num.ljust(width)
+    if "0" not in flags:
+        return num.rjust(width)
+    sign = num[0] if num[0] in "+- " else ""
+    return sign + num[len(sign):].rjust(width - len(sign), "0")
+
+
+def _format_operand(verb, flags, width, prec, kind, val):
+    """one verb applied to one operand (fmt/print.go printArg -> fmtInteger / fmtFloat / fmtString / badVerb: a bad verb is written
+    as it is, outside the width).  Not modelled (no template of the corpus uses them): %q of an integer (quoted rune), %x / %b of a
+    float64, '#' on v / q / floats, '+' on q, %t (operands are never Go bools here: builtinSprintf stringifies them)"""
+    if verb == "T":   # printArg: the operand's Go type through fmtS
+        return _pad(kind if prec is None else kind[:prec], flags, width)
+    if kind == "int":
+        if verb in "vd":
+            return _fmt_integer(val, 10, flags, width, prec)
+        if verb in "xX":
+            return _fmt_integer(val, 16, flags, width, prec, upper=verb == "X")
+        if verb in "oO":
+            return _fmt_integer(val, 8, flags, width, prec, o_prefix=verb == "O")
+        if verb == "b":
+            return _fmt_integer(val, 2, flags, width, prec)
+        if verb == "c":   # fmtC: no valid code point -> U+FFFD
+            return _pad(chr(val) if 0 <= val <= 0x10FFFF and not 0xD800 <= val <= 0xDFFF else "\ufffd", flags, width)
+        if verb == "U" and val >= 0:
+            return _pad("U+%04X" % val, flags, width)
+    elif kind == "float64":
+        if verb == "v" or (verb in "gG" and prec is None):   # %g without a precision: the shortest text that round-trips
+            num = go_float_v(val)
+            return _fmt_float(num.replace("e", "E") if verb == "G" else num, flags, width)
+        if verb in "feEgGF":
+            num = ("%." + str(6 if prec is None else prec) + ("f" if verb == "F" else verb)) % val
+            return _fmt_float(num, flags, width)
+    else:
+        if verb == "v":
+            return _pad(val, flags, width)
+        if verb == "s":
+            return _pad(val if prec is None else val[:prec], flags, width)
+        if verb == "q":
+            return _pad(quote(val), flags, width)
+        if verb in "xX":   # fmtSbx: precision in bytes, ' ' between bytes, '#' prefix (on every byte when separated)
+            raw = val.encode()
+            raw = raw if prec is None else raw[:prec]
+            pre = ("0X" if verb == "X" else "0x") if "#" in flags else ""
+            hx = [("%02X" if verb == "X" else "%02x") % c for c in raw]
+            text = " ".join(pre + h for h in hx) if " " in flags else (pre if hx else "") + "".join(hx)
+            return _pad(text, flags, width)
+    return _bad(verb, kind, val)
+
+
 def go_sprintf(fmt, args):
     args = [_go_arg(a) for a in args]
     out = []
@@ -403,6 +499,9 @@ def go_sprintf(fmt, args):
         out.append(fmt[pos:m.start()])
         pos = m.end()
         flags, width, prec, verb = m.group(1), m.group(2), m.group(3), m.group(4)
+        if verb is None:
+            out.append("%!(NOVERB)")
+            continue
         if verb == "%":
             out.append("%")
             continue
@@ -411,47 +510,10 @@ def go_sprintf(fmt, args):
             continue
         kind, val = args[ai]
         ai += 1
-        width = int(width) if width and width != "*" else None
-        prec = int(prec) if prec and prec != "*" else None
-        if verb == "v":
-            if kind == "string":
-                s = val
-            elif kind == "int":
-                s = ("+" if "+" in flags and val >= 0 else "") + str(val)
-            else:
-                s = go_float_v(val)
-        elif verb == "s":
-            s = (val if prec is None else val[:prec]) if kind == "string" else _bad(verb, kind, val)
-        elif verb == "q":
-            s = quote(val) if kind == "string" else _bad(verb, kind, val)
-        elif verb == "d":
-            s = (("+" if "+" in flags and val >= 0 else "") + str(val)) if kind == "int" else _bad(verb, kind, val)
-        elif verb in "xXob":
-            if kind == "int":
-                s = {"x": "%x", "X": "%X", "o": "%o"}.get(verb, "%s") % val if verb != "b" else bin(val)[2:]
-            elif kind == "string" and verb in "xX":
-                s = val.encode().hex()
-                s = s.upper() if verb == "X" else s
-            else:
-                s = _bad(verb, kind, val)
-        elif verb in "feEgG":
-            if kind == "float64" or kind == "int":
-                if kind == "int":
-                    s = _bad(verb, kind, val)
-                else:
-                    p = 6 if prec is None else prec
-                    s = ("%." + str(p) + verb) % val
-                    if verb in "eE":
-                        s = re.sub(r"e([+-])(\d)$", r"e\g<1>0\2", s)
-            else:
-                s = _bad(verb, kind, val)
-        elif verb == "t":
-            s = _bad(verb, kind, val)
-        elif verb == "c":
-            s = chr(val) if kind == "int" else _bad(verb, kind, val)
-        else:
-            s = "%%!%s(%s=%s)" % (verb, kind, val if kind != "float64" else go_float_v(val))
-        out.append(_pad(s, flags, width))
+        width = int(width) if width else None
+        prec = (int(prec) if prec else 0) if prec is not None else None
+        s = _format_operand(verb, flags, width, prec, kind, val)
+        out.append(s)
     out.append(fmt[pos:])
     if ai < len(args):
         extra = ", ".join("%s=%s" % (k, v if k != "float64" else go_float_v(v)) for k, v in args[ai:])

@@ -134,3 +134,131 @@ def test_product_equals_the_compiled_checker_at_sizes_the_python_oracle_does_not
         pairs += int(np.unpackbits(d_v.view(np.uint8)).sum())
     assert pairs > n // 2
     assert len(ev.too_big_reviews()) == 0
+
+
+def _python_messages(templates, constraints, objs_ns):
+    oc = OC.Client()
+    for t in templates:
+        oc.add_template(t)
+    for c in constraints:
+        oc.add_constraint(c)
+    keys = {(c["kind"], c["metadata"]["name"]): i for i, c in enumerate(constraints)}
+    out = {}
+    for i, (o, ns) in enumerate(objs_ns):
+        for r in oc.review(OT.AugmentedUnstructured(OT.Unstructured(o), ns, "Original"), OC.AUDIT_EP):
+            if r.msg.startswith("unable to match constraints: ") and not r.metadata.get("details"):
+                continue
+            out.setdefault((keys[(r.constraint["kind"], r.constraint["metadata"]["name"])], i), []).append(r.msg)
+    return {k: sorted(v) for k, v in out.items()}
+
+
+@pytest.mark.parametrize("policy", ["audit-50", "corpus"])
+def test_compiled_checker_messages_equal_the_python_oracle(policy, fixtures):
+    """the TEXT of every violation (sprintf verbs, number and composite formatting, concat/format_int), not only which pairs violate"""
+    if policy == "audit-50":
+        ts, cs = synth.psp_templates(fixtures), synth.audit_constraints()
+    else:
+        ts, cs = synth.corpus(fixtures)
+        ts = ts[1::3]
+        kinds = {t["spec"]["crd"]["spec"]["names"]["kind"] for t in ts}
+        cs = [c for c in cs if c["kind"] in kinds]
+    nss = synth.gen_namespaces()
+    objs = synth.gen_objects(200, seed=43, mixed=True)
+    # numbers the formatting rules differ on: integral floats, exponents, fractions, big integers
+    objs += [{"apiVersion": "v1", "kind": "Pod", "metadata": {"name": "nums", "namespace": "dev-00"},
+              "spec": {"containers": [{"name": "c", "image": "nginx", "securityContext": {"runAsUser": v, "privileged": True},
+                                       "ports": [{"hostPort": v, "containerPort": 80}]}],
+                       "securityContext": {"fsGroup": v, "supplementalGroups": [v, 1]}}}
+             for v in (1.5, 2.0, 1e21, 1e-7, 123456789012, 0.000123, -3.25, 1e6, 999999.5, 1234567.25)]
+    objs_ns = [(o, synth.namespace_for(o, nss)) for o in objs]
+    want = _python_messages(ts, cs, objs_ns)
+    ck = IndepChecker(ts, cs)
+    got = {}
+    for i, (o, ns) in enumerate(objs_ns):
+        for row, msgs in ck.messages(json.dumps(o), json.dumps(ns) if ns is not None else None).items():
+            got[(row, i)] = sorted(msgs)
+    assert len(want) > 100
+    assert got.keys() == want.keys()
+    bad = [(k, got[k], want[k]) for k in want if got[k] != want[k]]
+    assert not bad, bad[:3]
+
+
+@pytest.mark.parametrize("policy,n", [("audit-50", 4000), ("corpus-200", 1200)])
+def test_product_messages_equal_the_compiled_checker(policy, n, fixtures):
+    """every message the product renders (gk_render over the flagged pairs: the concrete evaluator, cross-checked against the partial
+    evaluator by GK_RENDER_CHECK) against the independent compiled checker's text for the same pair"""
+    from gatekeeper_amd import driver as D
+    ts, cs = (synth.psp_templates(fixtures), synth.audit_constraints()) if policy == "audit-50" else synth.corpus(fixtures)
+    drv = D.Driver(device=0, hostemu=True)
+    client = D.Client(drv)
+    for t in ts:
+        client.AddTemplate(t)
+    for c in cs:
+        client.AddConstraint(c)
+    batch = synth.NativeBatch(drv.engine.lib, n, seed=synth.SEED + 9, mixed=True, start=0, namespaces=synth.gen_namespaces())
+    table = drv.engine.create_table_native(batch.reviews, n, keep_docs=True, resident=False, pruned=False)
+    ev = table.eval()
+    ids = [drv.constraint_id(client.constraints[(k["kind"], k["metadata"]["name"])]) for k in cs]
+    row_of_cid = {cid: row for row, cid in enumerate(ids)}
+    product = {}
+    for cid, r in ev.pairs("viol"):
+        product[(row_of_cid[int(cid)], int(r))] = sorted(v["msg"] for v in table.render(cid, r))
+    ck = IndepChecker(ts, cs)
+    checker = {}
+    for i in range(n):
+        rin = batch.reviews[i]
+        for row, msgs in ck.messages(rin.json, rin.namespace_json).items():
+            checker[(row, i)] = sorted(msgs)
+    assert len(product) > n
+    assert product.keys() == checker.keys()
+    bad = [(k, product[k], checker[k]) for k in checker if product[k] != checker[k]]
+    assert not bad, bad[:3]
+    table.free()
+
+
+FORMAT_TEMPLATE = {
+    "apiVersion": "templates.gatekeeper.sh/v1", "kind": "ConstraintTemplate", "metadata": {"name": "k8sformats"},
+    "spec": {"crd": {"spec": {"names": {"kind": "K8sFormats"}}},
+             "targets": [{"target": "admission.k8s.gatekeeper.sh", "rego": """
+package k8sformats
+violation[{"msg": msg}] {
+  x := input.review.object.spec.x
+  msg := sprintf("v=%v|w=%8v|l=%-8v|z=%08v|plus=%+v|s=%s|d=%d|q=%q|all=%v|obj=%v|pct=%%|%v", [x, x, x, x, x, x, x, x, input.review.object.spec, {"k": x, "n": [x, 1.5]}])
+}
+violation[{"msg": msg}] {
+  x := input.review.object.spec.x
+  msg := sprintf("extra %v", [x, x, "tail"])
+}
+violation[{"msg": msg}] {
+  x := input.review.object.spec.x
+  msg := concat("/", [sprintf("%v", [x]), sprintf("%d", [input.review.object.spec.n]), sprintf("%5.2s|%v", ["héllo", [x]])])
+}
+"""}]}}
+
+
+def test_message_formatting_three_ways():
+    """sprintf verbs / flags / widths, MISSING and EXTRA operands, numbers in every notation and composite operands: the Python oracle,
+    the compiled checker and the product's renderer print the same text"""
+    from gatekeeper_amd import driver as D
+    ts = [FORMAT_TEMPLATE]
+    cs = [{"apiVersion": "constraints.gatekeeper.sh/v1beta1", "kind": "K8sFormats", "metadata": {"name": "f"}, "spec": {}}]
+    xs = [1, -7, 2.0, 1.5, -3.25, 1e21, 1e20, 1e-7, 0.000123, 123456789012, 1e6, 999999.5, 1234567.25, 100000.0, 1e-5, 0.0001,
+          "str", "", "with \"quote\" and \\ and é", True, None, [1, 2.5, "a"], {"a": 1e7, "b": [True, None]}, 9007199254740993, 0.1, 5e-324, 1.7976931348623157e308]
+    objs_ns = [({"apiVersion": "v1", "kind": "Pod", "metadata": {"name": "p%d" % i}, "spec": {"x": x, "n": 255 + i}}, None) for i, x in enumerate(xs)]
+    want = _python_messages(ts, cs, objs_ns)
+    ck = IndepChecker(ts, cs)
+    got = {}
+    for i, (o, _ns) in enumerate(objs_ns):
+        for row, msgs in ck.messages(json.dumps(o)).items():
+            got[(row, i)] = sorted(msgs)
+    assert len(want) == len(xs) and all(len(v) == 3 for v in want.values())
+    bad = [(k, got.get(k), want[k]) for k in want if got.get(k) != want[k]]
+    assert not bad, bad[:2]
+    drv = D.Driver(device=0, hostemu=True)
+    client = D.Client(drv)
+    client.AddTemplate(ts[0])
+    client.AddConstraint(cs[0])
+    res = client.ReviewBatch([D.AugmentedUnstructured(D.Unstructured(o), None, "Original") for o, _ in objs_ns])
+    product = {(0, i): sorted(r.msg for r in rs) for i, rs in enumerate(res)}
+    bad = [(k, product.get(k), want[k]) for k in want if product.get(k) != want[k]]
+    assert not bad, bad[:2]
