@@ -188,7 +188,9 @@ def check_matcher(constraint):
     label selectors of the metav1 shape; unknown fields are ignored, null is the zero value.  Run by Client.AddConstraint
     whether or not the constraint is validated (ToMatcher is not part of ValidateConstraint).  Raises ClientError."""
     spec = constraint.get("spec")
-    mt = spec.get("match") if isinstance(spec, dict) else None
+    if spec is not None and not isinstance(spec, dict):   # NestedMap's accessor error on the way to spec.match
+        raise ClientError("unable to create matcher: spec is %s, not a map" % type(spec).__name__)
+    mt = spec.get("match") if spec else None
     if mt is None:
         return
     if not isinstance(mt, dict):
@@ -246,7 +248,9 @@ def validate_constraint(constraint):
     frameworks client does: spec.match.labelSelector / namespaceSelector must be maps that decode into a
     metav1.LabelSelector and pass apimachinery's ValidateLabelSelector.  Raises ClientError."""
     spec = constraint.get("spec")
-    mt = spec.get("match") if isinstance(spec, dict) else None
+    if spec is not None and not isinstance(spec, dict):   # unstructured.NestedMap(spec, match, labelSelector): accessor error
+        raise ClientError("spec must be an object")
+    mt = spec.get("match") if spec else None
     if mt is None:
         return
     if not isinstance(mt, dict):

@@ -25,53 +25,65 @@ ALL_EP = "*"
 
 
 class ClientError(Exception):
-    pass
+    """any error the frameworks client or its Rego driver hands back to the caller"""
 
 
 class Result:
-    """frameworks types.Result"""
+    """frameworks types.Result: Target, Msg, Metadata{"details"}, Constraint, EnforcementAction, ScopedEnforcementActions"""
+
+    __slots__ = ("target", "msg", "constraint", "metadata", "enforcement_action", "scoped_enforcement_actions")
 
     def __init__(self, msg, constraint, details=None, enforcement_action="deny", scoped_actions=None,
                  target=t.TARGET_NAME):
-        self.target = target
-        self.msg = msg
-        self.constraint = constraint
-        self.metadata = {"details": details if details is not None else {}}
-        self.enforcement_action = enforcement_action
-        self.scoped_enforcement_actions = scoped_actions
+        self.target, self.msg, self.constraint = target, msg, constraint
+        self.metadata = {"details": {} if details is None else details}
+        self.enforcement_action, self.scoped_enforcement_actions = enforcement_action, scoped_actions
 
     def key(self):
-        c = self.constraint
-        return (c.get("kind"), c.get("metadata", {}).get("name"), self.msg, repr(hk(from_json(self.metadata))),
-                self.enforcement_action, tuple(self.scoped_enforcement_actions or ()))
+        """what two Results must share to be the same Result (order-free comparison of result lists)"""
+        meta = self.constraint.get("metadata", {})
+        scoped = tuple(self.scoped_enforcement_actions) if self.scoped_enforcement_actions else ()
+        return (self.constraint.get("kind"), meta.get("name"), self.msg, repr(hk(from_json(self.metadata))), self.enforcement_action, scoped)
 
     def __repr__(self):
-        return "Result(%r, %s/%s, %s)" % (self.msg, self.constraint.get("kind"),
-                                          self.constraint.get("metadata", {}).get("name"), self.enforcement_action)
+        return "Result(%r, %s/%s, %s)" % (self.msg, self.constraint.get("kind"), self.constraint.get("metadata", {}).get("name"), self.enforcement_action)
+
+
+def _field(node, *path):
+    """unstructured.NestedFieldNoCopy: (value, found); nil on the way is "not found", anything else that is no map an error"""
+    for name in path:
+        if node is None:
+            return None, False
+        if not isinstance(node, dict):
+            raise TypeError("%r accessor error: %r is not a map" % (".".join(path), node))
+        if name not in node:
+            return None, False
+        node = node[name]
+    return node, True
 
 
 def template_source(ct: dict):
-    """(kind, target, rego, libs) of a ConstraintTemplate. `code[engine=Rego]` wins over legacy `rego`
-    (website/docs/constrainttemplates.md:216-232, pkg/fakes/fixtures.go:33-42)."""
-    spec = ct.get("spec")
-    if not isinstance(spec, dict):
+    """(kind, target, rego, libs) of a ConstraintTemplate: the one target's `code[engine=Rego].source`, or, without one, the legacy
+    `rego` / `libs` fields (website/docs/constrainttemplates.md:216-232, pkg/fakes/fixtures.go:33-42)."""
+    if not isinstance(ct.get("spec"), dict):
         raise ClientError("invalid ConstraintTemplate: spec must be an object")
     try:
-        kind = spec["crd"]["spec"]["names"]["kind"]
-    except (KeyError, TypeError):
+        kind, found = _field(ct, "spec", "crd", "spec", "names", "kind")
+    except TypeError:
+        kind, found = None, False
+    if not found:
         raise ClientError("invalid ConstraintTemplate: missing spec.crd.spec.names.kind")
-    targets = spec.get("targets") or []
-    if len(targets) != 1:
-        raise ClientError("invalid ConstraintTemplate: expected exactly 1 target, got %d" % len(targets))
-    tg = targets[0]
-    rego, libs = None, []
-    for code in tg.get("code") or []:
-        if code.get("engine") == "Rego":
-            src = code.get("source") or {}
-            rego, libs = src.get("rego"), list(src.get("libs") or [])
-    if rego is None:
-        rego, libs = tg.get("rego"), list(tg.get("libs") or [])
-    return kind, tg.get("target"), rego, libs
+    target_list = ct["spec"].get("targets")
+    if not target_list or len(target_list) != 1:
+        raise ClientError("invalid ConstraintTemplate: expected exactly 1 target, got %d" % len(target_list or ()))
+    (tgt,) = target_list
+    chosen = None
+    for entry in tgt.get("code") or ():      # (the last Rego entry wins, as the driver's loop leaves it)
+        if entry.get("engine") == "Rego":
+            chosen = entry.get("source") or {}
+    if chosen is None or chosen.get("rego") is None:
+        chosen = tgt
+    return kind, tgt.get("target"), chosen.get("rego"), list(chosen.get("libs") or ())
 
 
 class RegoDriver:
@@ -148,176 +160,203 @@ class RegoDriver:
         return out
 
 
+_ACTIONS = frozenset(("deny", "dryrun", "warn", "scoped"))
+
+
 def get_enforcement_action(c):
-    """pkg/util/enforcement_action.go:132-151 (pinned by enforcement_action_test.go:113-165): default deny; anything
-    outside {deny, dryrun, warn, scoped} is "unrecognized"; a spec / enforcementAction of the wrong type is an error."""
-    spec = c.get("spec")
-    if spec is None:
-        return "deny"
-    if not isinstance(spec, dict) or not isinstance(spec.get("enforcementAction", ""), str):
-        raise ClientError("unable to parse spec.enforcementAction")   # ErrInvalidSpecEnforcementAction
-    ea = spec.get("enforcementAction", "")
-    if ea == "":
-        return "deny"
-    return ea if ea in ("deny", "dryrun", "warn", "scoped") else "unrecognized"
+    """util.GetEnforcementAction (pkg/util/enforcement_action.go:132-151; rows: enforcement_action_test.go:113-165):
+    NestedString(spec.enforcementAction) -- absent is "", which defaults to deny; present but no string (or a spec that is no map)
+    is ErrInvalidSpecEnforcementAction; a string outside the four actions is classified "unrecognized"."""
+    try:
+        value, found = _field(c, "spec", "enforcementAction")
+    except TypeError:
+        found, value = True, None
+    if found and not isinstance(value, str):
+        raise ClientError("unable to parse spec.enforcementAction")
+    action = value if found and value else "deny"
+    return action if action in _ACTIONS else "unrecognized"
+
+
+def _enforcement_point_enabled(scoped_action, ep):
+    """enforcementPointEnabled (enforcement_action.go:167-174)"""
+    for point in scoped_action.get("enforcementPoints") or ():
+        if isinstance(point, dict) and (point.get("name") == ep or point.get("name") == ALL_EP):
+            return True
+    return False
 
 
 def scoped_actions_for_ep(ep, c):
-    """pkg/util/enforcement_action.go:153-174 (pinned by enforcement_action_test.go:235-385): the actions whose
-    enforcementPoints name `ep` or "*"; a scopedEnforcementActions value that is not a list of objects is an error."""
-    spec = c.get("spec") if isinstance(c.get("spec"), dict) else {}
-    seas = spec.get("scopedEnforcementActions")
-    if seas is None:
+    """util.ScopedActionForEP (enforcement_action.go:153-165; rows: enforcement_action_test.go:235-385): the Action of every
+    scopedEnforcementActions entry enabled for `ep`; the JSON round trip into []ScopedEnforcementAction fails for anything that
+    is no list of objects (convertToScopedEnforcementActions :119-130)"""
+    try:
+        listed, found = _field(c, "spec", "scopedEnforcementActions")
+    except TypeError:
+        listed, found = None, False
+    if not found or listed is None:
         return []
-    if not isinstance(seas, list) or not all(isinstance(x, dict) for x in seas):
+    if not isinstance(listed, list) or any(not isinstance(entry, dict) for entry in listed):
         raise ClientError("could not convert JSON to scopedEnforcementActions")
-    out = []
-    for sea in seas:
-        for p in sea.get("enforcementPoints") or []:
-            if isinstance(p, dict) and p.get("name") in (ep, ALL_EP):
-                out.append(sea.get("action"))
-                break
-    return out
+    return [entry.get("action") for entry in listed if _enforcement_point_enabled(entry, ep)]
 
 
-def _default(schema, value):
-    """Structural-schema defaulting (k8s apiextensions `default`), as Client.AddConstraint applies through the
-    template's generated CRD (pinned by test/gator/test/test.bats:277-291)."""
+def _walk_defaults(schema, value):
+    """Structural-schema defaulting (k8s apiextensions-apiserver pkg/apiserver/schema/defaulting Default): a property that is absent
+    and has a `default` gets a copy of it; then properties / additionalProperties / items are visited below the value.  What
+    Client.AddConstraint does through the template's generated CRD (test/gator/test/test.bats:277-291)."""
     if not isinstance(schema, dict):
         return value
-    if isinstance(value, dict):
-        props = schema.get("properties") or {}
-        for k, sub in props.items():
-            if k not in value and isinstance(sub, dict) and "default" in sub:
-                value[k] = copy.deepcopy(sub["default"])
-            if k in value:
-                value[k] = _default(sub, value[k])
-        addl = schema.get("additionalProperties")
-        if isinstance(addl, dict):
-            for k in value:
-                if k not in props:
-                    value[k] = _default(addl, value[k])
-    elif isinstance(value, list):
-        items = schema.get("items")
-        if isinstance(items, dict):
-            value = [_default(items, v) for v in value]
+    if isinstance(value, list):
+        item = schema.get("items")
+        return [_walk_defaults(item, member) for member in value] if isinstance(item, dict) else value
+    if not isinstance(value, dict):
+        return value
+    properties = schema.get("properties") or {}
+    for prop, prop_schema in properties.items():
+        if isinstance(prop_schema, dict) and "default" in prop_schema and prop not in value:
+            value[prop] = copy.deepcopy(prop_schema["default"])
+    additional = schema.get("additionalProperties")
+    for member in value:
+        below = properties.get(member, additional if member not in properties else None)
+        if isinstance(below, dict):
+            value[member] = _walk_defaults(below, value[member])
     return value
 
 
+def _mentions_default(schema):
+    if isinstance(schema, dict):
+        return any("default" in k for k in schema) or any(_mentions_default(v) for v in schema.values())
+    if isinstance(schema, list):
+        return any(_mentions_default(v) for v in schema)
+    return isinstance(schema, str) and "default" in schema
+
+
 def apply_schema_defaults(ct, c):
+    """the constraint as the driver sees it: spec.parameters defaulted by the template's openAPIV3Schema (the schema OF parameters)"""
     try:
-        schema = ct["spec"]["crd"]["spec"]["validation"]["openAPIV3Schema"]
-    except (KeyError, TypeError):
+        schema, found = _field(ct, "spec", "crd", "spec", "validation", "openAPIV3Schema")
+    except TypeError:
         return c
-    if not isinstance(schema, dict):
+    if not found or not isinstance(schema, dict):
         return c
     c = copy.deepcopy(c)
-    spec = c.get("spec")
-    if not isinstance(spec, dict):
-        if "default" not in str(schema):
+    if not isinstance(c.get("spec"), dict):
+        if not _mentions_default(schema):
             return c
-        spec = c["spec"] = {}
-    if "parameters" not in spec:
-        if "default" in schema:
-            spec["parameters"] = copy.deepcopy(schema["default"])
-        else:
+        c["spec"] = {}
+    if "parameters" not in c["spec"]:
+        if "default" not in schema:
             return c
-    spec["parameters"] = _default(schema, spec["parameters"])
+        c["spec"]["parameters"] = copy.deepcopy(schema["default"])
+    c["spec"]["parameters"] = _walk_defaults(schema, c["spec"]["parameters"])
     return c
 
 
+def _kind_and_name(resource):
+    return resource.get("kind", ""), (resource.get("metadata") or {}).get("name", "")
+
+
 class Client:
-    """Restated constraintclient.Client for the single K8sValidationTarget."""
+    """Restated constraintclient.Client for the single K8sValidationTarget: a template registry keyed by the lower-cased kind, a
+    constraint registry keyed by (kind, name) holding the defaulted constraint with its Matcher, and the target's Namespace cache."""
 
     def __init__(self, driver=None, enforcement_points=(WEBHOOK_EP, AUDIT_EP, GATOR_EP)):
-        self.driver = driver or RegoDriver()
+        self.driver = RegoDriver() if driver is None else driver
         self.cache = t.NsCache()
-        self.templates = {}       # lower(kind) -> ct
-        self.constraints = {}     # (kind, name) -> (constraint, matcher)
+        self.templates = {}
+        self.constraints = {}
         self.enforcement_points = tuple(enforcement_points)
 
-    # ---- state
+    # ---- templates
     def add_template(self, ct):
-        kind, target, _, _ = template_source(ct)
-        name = (ct.get("metadata") or {}).get("name", "")
-        if name != kind.lower():
-            raise ClientError("the ConstraintTemplate's name must be the lowercase of kind: got %r for kind %r"
-                              % (name, kind))
-        if target != t.TARGET_NAME:
-            raise ClientError("unknown target %r" % target)
+        """Client.AddTemplate: the name is the lower-cased kind (ErrInvalidConstraintTemplate otherwise), the one target must be this
+        client's, then the driver compiles it"""
+        kind, target_name, _rego, _libs = template_source(ct)
+        registry_key = kind.lower()
+        given = (ct.get("metadata") or {}).get("name", "")
+        if given != registry_key:
+            raise ClientError("the ConstraintTemplate's name must be the lowercase of kind: got %r for kind %r" % (given, kind))
+        if target_name != t.TARGET_NAME:
+            raise ClientError("unknown target %r" % target_name)
         self.driver.add_template(ct)
-        self.templates[kind.lower()] = ct
+        self.templates[registry_key] = ct
 
     def remove_template(self, ct):
-        kind, _, _, _ = template_source(ct)
+        """Client.RemoveTemplate: the template and every constraint of its kind go"""
+        registry_key = template_source(ct)[0].lower()
         self.driver.remove_template(ct)
-        self.templates.pop(kind.lower(), None)
-        for k in [k for k in self.constraints if k[0].lower() == kind.lower()]:
-            del self.constraints[k]
+        self.templates.pop(registry_key, None)
+        self.constraints = {key: entry for key, entry in self.constraints.items() if key[0].lower() != registry_key}
 
+    # ---- constraints
     def add_constraint(self, c, validate=True):
-        """validate: the target handler's ValidateConstraint (target.go:185-219), as frameworks' client does on
-        AddConstraint; tests of the Match layer's own error paths (match_test.go) install invalid selectors with
-        validate=False."""
-        kind = c.get("kind", "")
-        if kind.lower() not in self.templates:
-            raise ClientError("missing ConstraintTemplate: %s" % kind)   # ErrMissingConstraintTemplate
-        if validate:
-            try:
-                t.validate_constraint(c)
-            except t.ReviewError as e:
-                raise ClientError(str(e))
-        name = (c.get("metadata") or {}).get("name", "")
-        c = apply_schema_defaults(self.templates[kind.lower()], c)
+        """Client.AddConstraint: ErrMissingConstraintTemplate without the template; the target handler's ValidateConstraint
+        (target.go:185-219; validate=False lets tests of the Match layer's own error paths, match_test.go, install selectors the
+        handler would refuse); CRD defaulting; then ToMatcher (target.go:246-261 -- not part of ValidateConstraint, always run)"""
+        kind, name = _kind_and_name(c)
+        template = self.templates.get(kind.lower())
+        if template is None:
+            raise ClientError("missing ConstraintTemplate: %s" % kind)
         try:
-            matcher = t.to_matcher(c, self.cache)      # (always: ToMatcher is not part of ValidateConstraint)
-        except t.ReviewError as e:
-            raise ClientError(str(e))
-        self.constraints[(kind, name)] = (c, matcher)
+            if validate:
+                t.validate_constraint(c)
+            defaulted = apply_schema_defaults(template, c)
+            self.constraints[(kind, name)] = (defaulted, t.to_matcher(defaulted, self.cache))
+        except t.ReviewError as err:
+            raise ClientError(str(err))
 
     def remove_constraint(self, c):
-        self.constraints.pop((c.get("kind", ""), (c.get("metadata") or {}).get("name", "")), None)
+        self.constraints.pop(_kind_and_name(c), None)
+
+    # ---- data
+    def _processed(self, obj):
+        return t.process_data(obj if isinstance(obj, t.Unstructured) else t.Unstructured(obj))
 
     def add_data(self, obj):
-        handled, path, data = t.process_data(t.Unstructured(obj) if not isinstance(obj, t.Unstructured) else obj)
-        if not handled:
-            return
-        self.cache.add(path, data)
-        self.driver.add_data(t.TARGET_NAME, path, data)
+        """Client.AddData: ProcessData names the storage path; the target's cache and the driver's data.inventory both take it"""
+        handled, path, data = self._processed(obj)
+        if handled:
+            self.cache.add(path, data)
+            self.driver.add_data(t.TARGET_NAME, path, data)
 
     def remove_data(self, obj):
-        handled, path, _ = t.process_data(t.Unstructured(obj) if not isinstance(obj, t.Unstructured) else obj)
+        handled, path, _data = self._processed(obj)
         if handled:
             self.cache.remove(path)
             self.driver.remove_data(t.TARGET_NAME, path)
 
     # ---- review
+    def _enforced(self, c, enforcement_point):
+        """(enforcement action, scoped actions | None) or None when a scoped constraint names no action for this point"""
+        action = get_enforcement_action(c)
+        if action != "scoped":
+            return action, None
+        at_this_point = scoped_actions_for_ep(enforcement_point, c)
+        return (action, at_this_point) if at_this_point else None
+
     def review(self, obj, enforcement_point=AUDIT_EP, namespace=None):
-        """-> list[Result]. `namespace` is the reviews.Namespace(nsMap) option (namespaceObject)."""
+        """Client.Review -> list[Result].  HandleReview decides whether the target takes the object at all; every constraint (in key
+        order) enforced at the point is matched -- a Matcher error becomes that constraint's autoreject Result; the matching ones go
+        to the driver in ONE Query, and its Results are stamped with their constraint's actions.  `namespace` is the
+        reviews.Namespace(nsMap) option (namespaceObject)."""
         handled, review = t.handle_review(obj)
         if not handled:
             return []
-        matched = []
-        results = []
+        rejected, to_query, actions = [], [], {}
         for key in sorted(self.constraints):
             c, matcher = self.constraints[key]
-            ea = get_enforcement_action(c)
-            scoped = None
-            if ea == "scoped":
-                scoped = scoped_actions_for_ep(enforcement_point, c)
-                if not scoped:
-                    continue
-            try:
-                ok = matcher.match_review(review)
-            except t.ReviewError as e:
-                results.append(Result("unable to match constraints: %s" % e, c, {}, ea, scoped))
+            enforced = self._enforced(c, enforcement_point)
+            if enforced is None:
                 continue
-            if ok:
-                matched.append((c, ea, scoped))
-        if matched:
-            rs = self.driver.query(t.TARGET_NAME, [c for c, _, _ in matched], review, namespace)
-            info = {id(c): (ea, scoped) for c, ea, scoped in matched}
-            for r in rs:
-                r.enforcement_action, r.scoped_enforcement_actions = info[id(r.constraint)]
-                results.append(r)
-        return results
+            try:
+                if matcher.match_review(review):
+                    to_query.append(c)
+                    actions[id(c)] = enforced
+            except t.ReviewError as err:
+                rejected.append(Result("unable to match constraints: %s" % err, c, {}, *enforced))
+        if not to_query:
+            return rejected
+        answered = self.driver.query(t.TARGET_NAME, to_query, review, namespace)
+        for result in answered:
+            result.enforcement_action, result.scoped_enforcement_actions = actions[id(result.constraint)]
+        return rejected + answered

@@ -40,33 +40,27 @@ class Unstructured(dict):
 
 
 class AugmentedReview:
-    """pkg/target/review.go:9-14"""
+    """pkg/target/review.go:9-14: AdmissionRequest, Namespace, Source, IsAdmission"""
+    __slots__ = ("admission_request", "namespace", "source", "is_admission")
 
     def __init__(self, admission_request, namespace=None, source="", is_admission=False):
-        self.admission_request = admission_request
-        self.namespace = namespace
-        self.source = source
-        self.is_admission = is_admission
+        self.admission_request, self.namespace, self.source, self.is_admission = admission_request, namespace, source, is_admission
 
 
 class AugmentedUnstructured:
-    """pkg/target/data.go:26-31"""
+    """pkg/target/data.go:26-31: Object, Namespace, Source, Operation"""
+    __slots__ = ("object", "namespace", "source", "operation")
 
     def __init__(self, obj, namespace=None, source="", operation=""):
-        self.object = obj
-        self.namespace = namespace
-        self.source = source
-        self.operation = operation
+        self.object, self.namespace, self.source, self.operation = obj, namespace, source, operation
 
 
 class GkReview:
-    """pkg/target/review.go:16-21: the embedded AdmissionRequest plus unexported namespace/source/isAdmission."""
+    """pkg/target/review.go:16-21: the embedded AdmissionRequest plus unexported namespace / source / isAdmission"""
+    __slots__ = ("request", "namespace", "source", "is_admission")
 
     def __init__(self, request, namespace=None, source="", is_admission=False):
-        self.request = request
-        self.namespace = namespace
-        self.source = source
-        self.is_admission = is_admission
+        self.request, self.namespace, self.source, self.is_admission = request, namespace, source, is_admission
 
 
 def _raw(req, key):
@@ -109,9 +103,8 @@ def set_object_on_delete(review: GkReview):
 
 def handle_review(obj):
     """target.go:81-138 -> (handled, GkReview|None). Raises ReviewError on error."""
-    if isinstance(obj, AugmentedReview):
-        review = GkReview(AdmissionRequest(copy.copy(obj.admission_request)), obj.namespace, obj.source,
-                          obj.is_admission)
+    if isinstance(obj, AugmentedReview):     # (value or pointer: one case each in the Go switch)
+        review = GkReview(AdmissionRequest(copy.copy(obj.admission_request)), namespace=obj.namespace, source=obj.source, is_admission=obj.is_admission)
     elif isinstance(obj, AugmentedUnstructured):
         review = augmented_unstructured_to_admission_request(obj)
     elif isinstance(obj, AdmissionRequest):
@@ -141,6 +134,25 @@ def process_data(obj):
     return True, path, dict(obj)
 
 
+def _to_namespace(obj):
+    """toNamespace (ns_cache.go:79-87): runtime.DefaultUnstructuredConverter.FromUnstructured into the typed corev1.Namespace -- a
+    field of the wrong JSON type fails (third-party converter: restated for the struct-typed top-level fields and ObjectMeta's two
+    map[string]string fields)"""
+    def refuse(what):
+        raise ReviewError("cannot cache type: cannot cache Namespace: " + what)
+    for struct_field in ("metadata", "spec", "status"):
+        value = obj.get(struct_field)
+        if not (value is None or isinstance(value, dict)):
+            refuse("%s must be an object" % struct_field)
+    object_meta = obj.get("metadata") or {}
+    for string_map in ("labels", "annotations"):
+        value = object_meta.get(string_map)
+        if value is None:
+            continue
+        if not isinstance(value, dict) or any(not isinstance(member, str) for member in value.values()):
+            refuse("metadata.%s must be a map of strings" % string_map)
+
+
 class NsCache:
     """ns_cache.go:15-87"""
 
@@ -153,16 +165,7 @@ class NsCache:
         g, _, k = m.obj_gvk(obj)
         if not (g == "" and k == "Namespace"):
             return
-        # toNamespace (ns_cache.go:79-87): conversion into the typed corev1.Namespace fails on fields of the wrong JSON
-        # type (third-party converter; restated for the typed top-level fields and string maps of ObjectMeta)
-        for f in ("metadata", "spec", "status"):
-            if f in obj and obj[f] is not None and not isinstance(obj[f], dict):
-                raise ReviewError("cannot cache type: cannot cache Namespace: %s must be an object" % f)
-        md = obj.get("metadata") or {}
-        for f in ("labels", "annotations"):
-            v = md.get(f)
-            if v is not None and not (isinstance(v, dict) and all(isinstance(x, str) for x in v.values())):
-                raise ReviewError("cannot cache type: cannot cache Namespace: metadata.%s must be a map of strings" % f)
+        _to_namespace(obj)
         self.cache["/".join(key)] = obj
 
     def remove(self, key):
@@ -216,40 +219,64 @@ class Matcher:
         return False
 
 
+def _go_type(v):
+    return {dict: "map[string]interface {}", list: "[]interface {}", str: "string", bool: "bool", int: "int64", float: "float64"}.get(type(v), type(v).__name__)
+
+
+def nested_map(obj, *fields):
+    """unstructured.NestedMap -> (map | None, found): nil on the way or an absent key is "not found"; a non-map on the way, or a
+    non-map VALUE, is the accessor error (apimachinery unstructured/helpers.go NestedFieldNoCopy / jsonPath)"""
+    value = obj
+    for depth, name in enumerate(fields):
+        if value is None:
+            return None, False
+        if not isinstance(value, dict):
+            raise ReviewError(".%s accessor error: %r is of the type %s, expected map[string]interface{}" % (".".join(fields[:depth + 1]), value, _go_type(value)))
+        if name not in value:
+            return None, False
+        value = value[name]
+    if value is not None and not isinstance(value, dict):
+        raise ReviewError(".%s accessor error: %r is of the type %s, expected map[string]interface{}" % (".".join(fields), value, _go_type(value)))
+    return value, True
+
+
+def convert_to_label_selector(selector):
+    """convertToLabelSelector (target.go:221-231): the JSON round trip into metav1.LabelSelector {matchLabels map[string]string,
+    matchExpressions []{key string, operator string, values []string}} -- a member of another JSON type fails json.Unmarshal"""
+    def refuse(why):
+        raise ReviewError("Could not convert JSON to LabelSelector: " + why)
+    labels = selector.get("matchLabels")
+    if labels is not None:
+        if not isinstance(labels, dict) or any(not isinstance(k, str) or not isinstance(v, str) for k, v in labels.items()):
+            refuse("matchLabels must be a map of strings")
+    requirements = selector.get("matchExpressions")
+    if requirements is None:
+        return selector
+    if not isinstance(requirements, list) or any(not isinstance(r, dict) for r in requirements):
+        refuse("matchExpressions must be a list of requirements")
+    for r in requirements:
+        values = r.get("values")
+        strings_ok = isinstance(r.get("key", ""), str) and isinstance(r.get("operator", ""), str)
+        values_ok = values is None or (isinstance(values, list) and all(isinstance(v, str) for v in values))
+        if not (strings_ok and values_ok):
+            refuse("malformed requirement")
+    return selector
+
+
 def validate_constraint(constraint: dict):
-    """K8sValidationTarget.ValidateConstraint (target.go:185-219): spec.match.labelSelector / namespaceSelector must be
-    maps (unstructured.NestedMap), decode into metav1.LabelSelector (matchLabels: map[string]string, matchExpressions:
-    [{key, operator, values: []string}]) and pass apimachinery's ValidateLabelSelector (third-party; same rules as
-    labels.NewRequirement, restated in match.selector_requirements).  Raises ReviewError.
-    Pinned by target_test.go:42-399 (11 cases)."""
-    spec = constraint.get("spec")
-    mt = spec.get("match") if isinstance(spec, dict) else None
-    if mt is None:
-        return
-    if not isinstance(mt, dict):
-        raise ReviewError("spec.match accessor error: %r is of the type %s, expected map[string]interface{}" % (mt, type(mt).__name__))
-    for field in ("labelSelector", "namespaceSelector"):
-        if field not in mt or mt[field] is None:
+    """K8sValidationTarget.ValidateConstraint (target.go:185-219; rows: target_test.go:42-399): for spec.match.labelSelector, then
+    spec.match.namespaceSelector -- NestedMap, convertToLabelSelector, apimachinery's ValidateLabelSelector (third-party; the rules
+    of labels.NewRequirement, restated in match.selector_requirements) under the field path spec.labelSelector for BOTH (as the
+    reference passes it).  Raises ReviewError."""
+    for which in ("labelSelector", "namespaceSelector"):
+        selector, found = nested_map(constraint, "spec", "match", which)
+        if not found or selector is None:
             continue
-        sel = mt[field]
-        if not isinstance(sel, dict):
-            raise ReviewError(".spec.match.%s accessor error: %r is of the type %s, expected map[string]interface{}" % (field, sel, type(sel).__name__))
-        ml = sel.get("matchLabels")
-        if ml is not None and not (isinstance(ml, dict) and all(isinstance(k, str) and isinstance(v, str) for k, v in ml.items())):
-            raise ReviewError("Could not convert JSON to LabelSelector: matchLabels must be a map of strings")
-        me = sel.get("matchExpressions")
-        if me is not None:
-            if not isinstance(me, list) or not all(isinstance(e, dict) for e in me):
-                raise ReviewError("Could not convert JSON to LabelSelector: matchExpressions must be a list of requirements")
-            for e in me:
-                vals = e.get("values")
-                if not isinstance(e.get("key", ""), str) or not isinstance(e.get("operator", ""), str) or not (
-                        vals is None or (isinstance(vals, list) and all(isinstance(v, str) for v in vals))):
-                    raise ReviewError("Could not convert JSON to LabelSelector: malformed requirement")
+        typed = convert_to_label_selector(selector)
         try:
-            m.selector_requirements(sel)
-        except m.MatchError as e:
-            raise ReviewError("spec.labelSelector: %s" % e)
+            m.selector_requirements(typed)
+        except m.MatchError as err:
+            raise ReviewError("spec.labelSelector: %s" % err)
 
 
 ERR_CREATING_MATCHER = "unable to create matcher"   # target.go ErrCreatingMatcher
@@ -294,18 +321,19 @@ def _shape_error(v, shape, where):
 
 
 def to_matcher(constraint: dict, cache: NsCache) -> Matcher:
-    """target.go:246-261 (pinned by target_test.go:562-655 TestToMatcher): spec.match absent => match-everything Matcher; a
-    spec.match that is not a map, or whose fields do not convert into match.Match, is ErrCreatingMatcher."""
-    spec = constraint.get("spec")
-    mt = spec.get("match") if isinstance(spec, dict) else None
-    if mt is None:
-        return Matcher(None, cache)
-    if not isinstance(mt, dict):
-        raise ReviewError("%s: .spec.match accessor error: %r is of the type %s, expected map[string]interface{}" % (ERR_CREATING_MATCHER, mt, type(mt).__name__))
-    err = _shape_error(mt, _MATCH_SHAPE, "spec.match")
-    if err:
+    """K8sValidationTarget.ToMatcher (target.go:246-261; rows: target_test.go:562-655 TestToMatcher): NestedMap(spec.match) -- absent
+    or null is the match-everything Matcher; an accessor error or a spec.match whose members do not convert into match.Match
+    (convertToMatch) is ErrCreatingMatcher."""
+    try:
+        match_map, found = nested_map(constraint, "spec", "match")
+    except ReviewError as err:
         raise ReviewError("%s: %s" % (ERR_CREATING_MATCHER, err))
-    return Matcher(mt, cache)
+    if not found or match_map is None:
+        return Matcher(None, cache)
+    why_not = _shape_error(match_map, _MATCH_SHAPE, "spec.match")
+    if why_not:
+        raise ReviewError("%s: %s" % (ERR_CREATING_MATCHER, why_not))
+    return Matcher(match_map, cache)
 
 
 def review_input_json(review: GkReview, namespace_obj=None) -> dict:

@@ -253,6 +253,24 @@ def test_to_matcher_rows():
             oc.add_template(tmpl)
             with pytest.raises(OC.ClientError):
                 oc.add_constraint(con, validate=False)
+    # unstructured.NestedMap's accessor error on the way down: a spec that is no map is refused by ToMatcher and by ValidateConstraint;
+    # a null spec is "not found"
+    for spec, ok in (("text", False), ([1], False), (3.0, False), (None, True)):
+        con = {"apiVersion": "constraints.gatekeeper.sh/v1beta1", "kind": "K8sX", "metadata": {"name": "x"}, "spec": spec}
+        if ok:
+            tg.to_matcher(con, tg.NsCache())
+            tg.validate_constraint(con)
+            D.check_matcher(con)
+            D.validate_constraint(con)
+            continue
+        with pytest.raises(tg.ReviewError, match=tg.ERR_CREATING_MATCHER):
+            tg.to_matcher(con, tg.NsCache())
+        with pytest.raises(tg.ReviewError, match="accessor error"):
+            tg.validate_constraint(con)
+        with pytest.raises(D.ClientError, match="unable to create matcher"):
+            D.check_matcher(con)
+        with pytest.raises(D.ClientError):
+            D.validate_constraint(con)
 
 
 def test_constraint_validation_rows():
