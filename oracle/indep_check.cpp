@@ -1545,88 +1545,126 @@ static Checker* build(const char* templates_json, const char* constraints_json) 
   }
   return c.release();
 }
-// one object: which rows violate, which are autorejected (matching failed)
-static void review_one(const Checker& c, const char* json, size_t json_len, const char* ns_json, size_t ns_len, std::vector<uint32_t>* viol, std::vector<uint32_t>* err) {
-  const VP obj = parse_json(json, json_len);
-  if (obj->k != V::Obj) throw std::runtime_error("review object is not a JSON object");
-  VP ns;
-  if (ns_json && ns_len) { ns = parse_json(ns_json, ns_len); if (ns->k == V::Null) ns = nullptr; }
-  // unstructuredToAdmissionRequest (target.go:159-179) + review_input_json: what input.review holds
-  std::string g, v, k;
-  obj_gvk(*obj, &g, &v, &k);
-  std::vector<std::pair<VP, VP>> rv;
-  rv.emplace_back(mk_str("uid"), mk_str(""));
-  rv.emplace_back(mk_str("kind"), mk_obj({{mk_str("group"), mk_str(g)}, {mk_str("version"), mk_str(v)}, {mk_str("kind"), mk_str(k)}}));
-  rv.emplace_back(mk_str("resource"), mk_obj({{mk_str("group"), mk_str("")}, {mk_str("version"), mk_str("")}, {mk_str("resource"), mk_str("")}}));
-  rv.emplace_back(mk_str("operation"), mk_str(""));
-  rv.emplace_back(mk_str("userInfo"), mk_obj({}));
-  rv.emplace_back(mk_str("object"), obj);
-  rv.emplace_back(mk_str("oldObject"), mk_null());
-  rv.emplace_back(mk_str("options"), mk_null());
-  const std::string name = obj_name(*obj), nsf = obj_namespace(*obj);
-  if (!name.empty()) rv.emplace_back(mk_str("name"), mk_str(name));
-  if (!nsf.empty()) rv.emplace_back(mk_str("namespace"), mk_str(nsf));
-  const VP review = mk_obj(std::move(rv));
-  const bool kind_ok = !k.empty();   // gkReviewToObject: a document without a `kind` does not unmarshal (matcher.go:73-93)
+// ---- K8sValidationTarget.HandleReview (oracle/target.py handle_review; target.go:81-179, 269-287) for both shapes of gk_review_in
+struct ReviewErr : std::runtime_error { using std::runtime_error::runtime_error; };   // HandleReview refuses the input (no results at all)
+struct Rv {
+  VP input;         // input.review: the AdmissionRequest as the Rego driver sees it (review_input_json)
+  VP obj, old;      // request.object / request.oldObject when they hold a JSON object (RawExtension with bytes), else null pointers
+  VP ns;            // gkReview.namespace
+  std::string source;
+};
+static VP raw_of(const std::map<std::string, VP>& req, const char* key) {
+  auto it = req.find(key);
+  return it != req.end() && it->second->k == V::Obj ? it->second : nullptr;
+}
+static VP member(const std::map<std::string, VP>& req, const char* key) { auto it = req.find(key); return it == req.end() ? nullptr : it->second; }
+static Rv handle_review(const gk_review_in& r) {
+  static const char* const kSources[] = {"", "Original", "Generated", "All"};
+  Rv rv;
+  rv.source = r.source >= 0 && r.source <= 3 ? kSources[r.source] : "invalid";
+  if (r.namespace_json && r.namespace_len) { rv.ns = parse_json(r.namespace_json, r.namespace_len); if (rv.ns->k == V::Null) rv.ns = nullptr; }
+  const VP doc = parse_json(r.json, r.json_len);
+  if (doc->k != V::Obj) throw ReviewErr("the review is not a JSON object");
+  std::map<std::string, VP> req;   // the AdmissionRequest's members by name
+  if (r.kind == 1) {   // unstructuredToAdmissionRequest / augmentedUnstructuredToAdmissionRequest (target.go:140-179)
+    std::string g, v, k;
+    obj_gvk(*doc, &g, &v, &k);
+    req["kind"] = mk_obj({{mk_str("group"), mk_str(g)}, {mk_str("version"), mk_str(v)}, {mk_str("kind"), mk_str(k)}});
+    req["object"] = doc;
+    req["name"] = mk_str(obj_name(*doc));
+    req["namespace"] = mk_str(obj_namespace(*doc));
+    const std::string op = r.operation ? r.operation : "";
+    if (!op.empty()) req["operation"] = mk_str(op);
+    if (op == "DELETE") { req["oldObject"] = doc; req["object"] = mk_null(); }
+  } else if (r.kind == 0) {
+    for (auto& kv : doc->o) if (kv.first->k == V::Str) req[kv.first->s] = kv.second;
+  } else throw ReviewErr("unknown review kind");
+  // setObjectOnDelete (target.go:269-287)
+  if (s_of(req.count("operation") ? &req["operation"] : nullptr) == "DELETE") {
+    if (!raw_of(req, "oldObject")) throw ReviewErr("oldObject cannot be nil for DELETE operations");
+    req["object"] = req["oldObject"];
+  }
+  rv.obj = raw_of(req, "object");
+  rv.old = raw_of(req, "oldObject");
+  // review_input_json: admissionv1.AdmissionRequest's struct tags -- uid / kind / resource / operation / userInfo always there, the
+  // RawExtensions null when empty, omitempty on subResource, requestSubResource, name, namespace, requestKind, requestResource, dryRun
+  auto text_of = [](const VP& o, const char* key) { if (!o || o->k != V::Obj) return mk_str(""); const VP* p = obj_get(*o, key); return p ? *p : mk_str(""); };
+  const VP kind = member(req, "kind"), res = member(req, "resource");
+  const VP kind_or_empty = kind && truthy_py(&kind) ? kind : nullptr, res_or_empty = res && truthy_py(&res) ? res : nullptr;
+  std::vector<std::pair<VP, VP>> in;
+  const VP uid = member(req, "uid"), oper = member(req, "operation"), user = member(req, "userInfo"), options = member(req, "options");
+  in.emplace_back(mk_str("uid"), uid ? uid : mk_str(""));
+  in.emplace_back(mk_str("kind"), mk_obj({{mk_str("group"), text_of(kind_or_empty, "group")}, {mk_str("version"), text_of(kind_or_empty, "version")}, {mk_str("kind"), text_of(kind_or_empty, "kind")}}));
+  in.emplace_back(mk_str("resource"), mk_obj({{mk_str("group"), text_of(res_or_empty, "group")}, {mk_str("version"), text_of(res_or_empty, "version")}, {mk_str("resource"), text_of(res_or_empty, "resource")}}));
+  in.emplace_back(mk_str("operation"), oper ? oper : mk_str(""));
+  in.emplace_back(mk_str("userInfo"), user && truthy_py(&user) ? user : mk_obj({}));
+  in.emplace_back(mk_str("object"), rv.obj ? rv.obj : mk_null());
+  in.emplace_back(mk_str("oldObject"), rv.old ? rv.old : mk_null());
+  in.emplace_back(mk_str("options"), options ? options : mk_null());
+  for (const char* k : {"subResource", "requestSubResource", "name", "namespace"}) { const VP v = member(req, k); if (v && truthy_py(&v)) in.emplace_back(mk_str(k), v); }
+  for (const char* k : {"requestKind", "requestResource", "dryRun"}) { const VP v = member(req, k); if (v && v->k != V::Null) in.emplace_back(mk_str(k), v); }
+  if (r.ns_object_json && r.ns_object_len) in.emplace_back(mk_str("namespaceObject"), parse_json(r.ns_object_json, r.ns_object_len));
+  rv.input = mk_obj(std::move(in));
+  return rv;
+}
+// Matcher.Match (matcher.go:21-71; target.py Matcher.match_review): gkReviewToObject refuses a document without a `kind`, then matchAny
+// over object and oldObject.  Throws MatchErr (the constraint's autoreject).  The Namespace is the one handed in with the review (this
+// checker keeps no cache: callers pass what the cache would answer).
+static bool match_review(const V& match, const Rv& rv) {
+  for (const VP* o : {&rv.obj, &rv.old}) {
+    if (!*o) continue;
+    const VP* kind = obj_get(**o, "kind");
+    if (!kind || (*kind)->k != V::Str || (*kind)->s.empty()) throw MatchErr("invalid request object: failed to unmarshal gkReview object");
+  }
+  int nil = 0;
+  for (const VP* o : {&rv.obj, &rv.old}) {
+    if (!*o) { nil++; continue; }
+    if (matches(match, **o, rv.ns.get(), rv.source)) return true;
+  }
+  if (nil == 2) throw MatchErr("invalid request object: neither object nor old object are defined");
+  return false;
+}
+
+// one review: which rows violate, which are autorejected (matching failed)
+static void review_one(const Checker& c, const gk_review_in& r, std::vector<uint32_t>* viol, std::vector<uint32_t>* err) {
+  const Rv rv = handle_review(r);
   std::map<std::pair<const Program*, const V*>, bool> memo;   // (program, parameters) -> yields a result
   for (size_t row = 0; row < c.constraints.size(); row++) {
     const Constraint& x = c.constraints[row];
-    bool ok = true;
     if (x.match) {
-      if (!kind_ok) { err->push_back((uint32_t)row); continue; }
-      try { ok = matches(*x.match, *obj, ns.get(), "Original"); } catch (const MatchErr&) { err->push_back((uint32_t)row); continue; }
+      try { if (!match_review(*x.match, rv)) continue; } catch (const MatchErr&) { err->push_back((uint32_t)row); continue; }
     }
-    if (!ok) continue;
     auto key = std::make_pair(x.prog, x.params.get());
     auto it = memo.find(key);
     bool any;
     if (it != memo.end()) any = it->second;
     else {
-      Query q(*x.prog, mk_obj({{mk_str("review"), review}, {mk_str("parameters"), x.params}}));
+      Query q(*x.prog, mk_obj({{mk_str("review"), rv.input}, {mk_str("parameters"), x.params}}));
       const VP set = q.violations();
       any = false;
-      for (auto& r : set->a) { if (r->k != V::Obj) continue; const VP* m = obj_get(*r, "msg"); if (m && (*m)->k == V::Str) { any = true; break; } }
+      for (auto& res : set->a) { if (res->k != V::Obj) continue; const VP* m = obj_get(*res, "msg"); if (m && (*m)->k == V::Str) { any = true; break; } }
       memo[key] = any;
     }
     if (any) viol->push_back((uint32_t)row);
   }
 }
 
-// the messages of one object: row -> the msg of every result (one per distinct (msg, details), as Client.review's driver dedupes)
-static void review_messages(const Checker& c, const char* json, size_t json_len, const char* ns_json, size_t ns_len, std::map<uint32_t, std::vector<std::string>>* out) {
-  const VP obj = parse_json(json, json_len);
-  if (obj->k != V::Obj) throw std::runtime_error("review object is not a JSON object");
-  VP ns;
-  if (ns_json && ns_len) { ns = parse_json(ns_json, ns_len); if (ns->k == V::Null) ns = nullptr; }
-  std::string g, v, k;
-  obj_gvk(*obj, &g, &v, &k);
-  std::vector<std::pair<VP, VP>> rv;
-  rv.emplace_back(mk_str("uid"), mk_str(""));
-  rv.emplace_back(mk_str("kind"), mk_obj({{mk_str("group"), mk_str(g)}, {mk_str("version"), mk_str(v)}, {mk_str("kind"), mk_str(k)}}));
-  rv.emplace_back(mk_str("resource"), mk_obj({{mk_str("group"), mk_str("")}, {mk_str("version"), mk_str("")}, {mk_str("resource"), mk_str("")}}));
-  rv.emplace_back(mk_str("operation"), mk_str(""));
-  rv.emplace_back(mk_str("userInfo"), mk_obj({}));
-  rv.emplace_back(mk_str("object"), obj);
-  rv.emplace_back(mk_str("oldObject"), mk_null());
-  rv.emplace_back(mk_str("options"), mk_null());
-  const std::string name = obj_name(*obj), nsf = obj_namespace(*obj);
-  if (!name.empty()) rv.emplace_back(mk_str("name"), mk_str(name));
-  if (!nsf.empty()) rv.emplace_back(mk_str("namespace"), mk_str(nsf));
-  const VP review = mk_obj(std::move(rv));
+// the messages of one review: row -> the msg of every result (one per distinct (msg, details), as Client.review's driver dedupes)
+static void review_messages(const Checker& c, const gk_review_in& r, std::map<uint32_t, std::vector<std::string>>* out) {
+  const Rv rv = handle_review(r);
   for (size_t row = 0; row < c.constraints.size(); row++) {
     const Constraint& x = c.constraints[row];
     if (x.match) {
-      if (k.empty()) continue;
-      try { if (!matches(*x.match, *obj, ns.get(), "Original")) continue; } catch (const MatchErr&) { continue; }
+      try { if (!match_review(*x.match, rv)) continue; } catch (const MatchErr&) { continue; }
     }
-    Query q(*x.prog, mk_obj({{mk_str("review"), review}, {mk_str("parameters"), x.params}}));
+    Query q(*x.prog, mk_obj({{mk_str("review"), rv.input}, {mk_str("parameters"), x.params}}));
     const VP set = q.violations();
     std::set<std::pair<std::string, std::string>> seen;
-    for (auto& r : set->a) {
-      if (r->k != V::Obj) continue;
-      const VP* m = obj_get(*r, "msg");
+    for (auto& res : set->a) {
+      if (res->k != V::Obj) continue;
+      const VP* m = obj_get(*res, "msg");
       if (!m || (*m)->k != V::Str) continue;
-      const VP* d = obj_get(*r, "details");
+      const VP* d = obj_get(*res, "details");
       if (seen.insert({(*m)->s, d ? to_string(*d) : std::string("{}")}).second) (*out)[(uint32_t)row].push_back((*m)->s);
     }
   }
@@ -1655,7 +1693,7 @@ void ic_destroy(void* h) { delete static_cast<ic::Checker*>(h); }
 char* ic_messages(void* h, const gk_review_in* r) {
   try {
     std::map<uint32_t, std::vector<std::string>> out;
-    ic::review_messages(*static_cast<ic::Checker*>(h), r->json, r->json_len, r->namespace_json, r->namespace_len, &out);
+    ic::review_messages(*static_cast<ic::Checker*>(h), *r, &out);
     std::string js = "{";
     for (auto& kv : out) {
       if (js.size() > 1) js += ",";
@@ -1672,12 +1710,15 @@ char* ic_messages(void* h, const gk_review_in* r) {
 }
 void ic_free(void* p) { free(p); }
 // bitmaps [n_constraints][words] (bit r of word r / 64 of row c: pair (c, review r)), zeroed by the caller; returns 0, or -1 with ic_last_error()
-int ic_check(void* h, const gk_review_in* reviews, size_t n, uint64_t* viol, uint64_t* err, size_t words, int threads) {
+// `rejected` ([n] bytes, may be NULL): 1 where HandleReview refuses the review (no results, as the product's statuses[i]); with NULL
+// such a review is an error of the call.
+int ic_check_reviews(void* h, const gk_review_in* reviews, size_t n, uint64_t* viol, uint64_t* err, uint8_t* rejected, size_t words, int threads) {
   const ic::Checker& c = *static_cast<ic::Checker*>(h);
   if (threads < 1) threads = 1;
   std::atomic<size_t> next{0};
   std::mutex mu;
   std::string first_err;
+  auto fail = [&](size_t i, const std::string& what) { std::lock_guard<std::mutex> l(mu); if (first_err.empty()) first_err = "review " + std::to_string(i) + ": " + what; };
   auto work = [&]() {
     std::vector<uint32_t> v, e;
     for (;;) {
@@ -1685,9 +1726,10 @@ int ic_check(void* h, const gk_review_in* reviews, size_t n, uint64_t* viol, uin
       if (lo >= n) return;
       for (size_t i = lo; i < std::min(n, lo + 64); i++) {
         v.clear(); e.clear();
-        try { ic::review_one(c, reviews[i].json, reviews[i].json_len, reviews[i].namespace_json, reviews[i].namespace_len, &v, &e); }
-        catch (const std::exception& ex) { std::lock_guard<std::mutex> l(mu); if (first_err.empty()) first_err = "review " + std::to_string(i) + ": " + ex.what(); return; }
-        catch (const ic::Unbound&) { std::lock_guard<std::mutex> l(mu); if (first_err.empty()) first_err = "review " + std::to_string(i) + ": unsafe variable"; return; }
+        try { ic::review_one(c, reviews[i], &v, &e); }
+        catch (const ic::ReviewErr& ex) { if (rejected) { rejected[i] = 1; continue; } fail(i, ex.what()); return; }
+        catch (const std::exception& ex) { fail(i, ex.what()); return; }
+        catch (const ic::Unbound&) { fail(i, "unsafe variable"); return; }
         for (uint32_t row : v) viol[(size_t)row * words + i / 64] |= 1ull << (i % 64);
         for (uint32_t row : e) err[(size_t)row * words + i / 64] |= 1ull << (i % 64);
       }
@@ -1699,5 +1741,8 @@ int ic_check(void* h, const gk_review_in* reviews, size_t n, uint64_t* viol, uin
   for (auto& t : th) t.join();
   if (!first_err.empty()) { g_ic_err = first_err; return -1; }
   return 0;
+}
+int ic_check(void* h, const gk_review_in* reviews, size_t n, uint64_t* viol, uint64_t* err, size_t words, int threads) {
+  return ic_check_reviews(h, reviews, n, viol, err, nullptr, words, threads);
 }
 }

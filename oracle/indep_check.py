@@ -37,6 +37,8 @@ def _load():
     lib.ic_last_error.restype = C.c_char_p
     lib.ic_check.restype = C.c_int
     lib.ic_check.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    lib.ic_check_reviews.restype = C.c_int
+    lib.ic_check_reviews.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
     lib.ic_messages.restype = C.c_void_p
     lib.ic_messages.argtypes = [C.c_void_p, C.c_void_p]
     lib.ic_free.argtypes = [C.c_void_p]
@@ -69,6 +71,19 @@ class IndepChecker:
             raise RuntimeError("compiled checker: " + self.lib.ic_last_error().decode())
         return viol, err
 
+    def check_reviews(self, reviews, n, threads=None):
+        """every shape of gk_review_in (bare objects with Operation / Source, AdmissionRequests, DELETE).  -> (viol, err, rejected):
+        rejected[i] = 1 where HandleReview refuses review i (it has no results at all)"""
+        words = (n + 63) // 64
+        viol = np.zeros((self.n_constraints, max(words, 1)), dtype=np.uint64)
+        err = np.zeros_like(viol)
+        rejected = np.zeros(max(n, 1), dtype=np.uint8)
+        threads = threads or max(1, min(os.cpu_count() or 1, 64))
+        rc = self.lib.ic_check_reviews(self.h, C.cast(reviews, C.c_void_p), n, viol.ctypes.data, err.ctypes.data, rejected.ctypes.data, max(words, 1), threads)
+        if rc != 0:
+            raise RuntimeError("compiled checker: " + self.lib.ic_last_error().decode())
+        return viol, err, rejected[:n]
+
     def check_texts(self, texts, threads=None):
         """texts: [(object JSON text, namespace JSON text | None)]"""
         arr = (ReviewIn * max(len(texts), 1))()
@@ -77,7 +92,7 @@ class IndepChecker:
             t = t.encode() if isinstance(t, str) else t
             ns = (ns.encode() if isinstance(ns, str) else ns) if ns else None
             keep.append((t, ns))
-            arr[i].kind, arr[i].json, arr[i].json_len = 1, t, len(t)
+            arr[i].kind, arr[i].source, arr[i].json, arr[i].json_len = 1, 1, t, len(t)   # (bare object, Source "Original")
             arr[i].namespace_json, arr[i].namespace_len = ns, len(ns) if ns else 0
         return self.check(arr, len(texts), threads)
 
@@ -86,7 +101,7 @@ class IndepChecker:
         r = ReviewIn()
         t = text.encode() if isinstance(text, str) else text
         nsb = (ns.encode() if isinstance(ns, str) else ns) if ns else None
-        r.kind, r.json, r.json_len, r.namespace_json, r.namespace_len = 1, t, len(t), nsb, len(nsb) if nsb else 0
+        r.kind, r.source, r.json, r.json_len, r.namespace_json, r.namespace_len = 1, 1, t, len(t), nsb, len(nsb) if nsb else 0
         p = self.lib.ic_messages(self.h, C.byref(r))
         if not p:
             raise RuntimeError("compiled checker: " + self.lib.ic_last_error().decode())

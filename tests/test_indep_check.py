@@ -262,3 +262,172 @@ def test_message_formatting_three_ways():
     product = {(0, i): sorted(r.msg for r in rs) for i, rs in enumerate(res)}
     bad = [(k, product.get(k), want[k]) for k in want if product.get(k) != want[k]]
     assert not bad, bad[:2]
+
+
+ENVELOPE_TEMPLATE = {
+    "apiVersion": "templates.gatekeeper.sh/v1", "kind": "ConstraintTemplate", "metadata": {"name": "k8senvelope"},
+    "spec": {"crd": {"spec": {"names": {"kind": "K8sEnvelope"}}},
+             "targets": [{"target": "admission.k8s.gatekeeper.sh", "rego": """
+package k8senvelope
+violation[{"msg": msg}] {
+  input.review.operation == "DELETE"
+  msg := sprintf("delete of %v by %v", [input.review.name, input.review.userInfo.username])
+}
+violation[{"msg": msg}] {
+  input.review.dryRun == true
+  msg := "dry run"
+}
+violation[{"msg": msg}] {
+  input.review.oldObject.metadata.labels.was == "old"
+  msg := "was old"
+}
+violation[{"msg": msg}] {
+  input.review.namespaceObject.metadata.labels[k]
+  msg := sprintf("namespace label %v", [k])
+}
+violation[{"msg": msg}] {
+  not input.review.namespace
+  msg := sprintf("no namespace in the request for %v", [input.review.kind.kind])
+}
+"""}]}}
+
+
+def _review_shapes(n, seed):
+    """every input shape of HandleReview (target.go:81-138) over synthetic objects: bare objects with Operation / Source, AdmissionRequests
+    (CREATE / UPDATE / DELETE / CONNECT; object, oldObject, both, neither; envelope members present, null, missing), objects without a
+    kind, DELETE without oldObject (HandleReview's error), the reviews.Namespace option"""
+    from gatekeeper_amd import driver as D
+    nss = synth.gen_namespaces()
+    rng = synth.SplitMix64(seed)
+    out = []
+    for i, o in enumerate(synth.gen_objects(n, seed=seed, mixed=True)):
+        ns = synth.namespace_for(o, nss)
+        shape = rng.below(10)
+        source = ["Original", "Generated", "All", ""][rng.below(8) % 4] if rng.below(4) == 0 else "Original"
+        nsobj = ns if rng.below(5) == 0 else None
+        if shape == 0:
+            out.append(D.to_review_in(D.AugmentedUnstructured(D.Unstructured(o), ns, source, ["", "CREATE", "DELETE", "UPDATE"][rng.below(4)]), nsobj))
+            continue
+        if shape == 1:
+            out.append(D.to_review_in(D.Unstructured(o), nsobj))
+            continue
+        api = o.get("apiVersion", "v1")
+        g, _, ver = api.rpartition("/")
+        req = {"uid": "u-%d" % i, "kind": {"group": g, "version": ver, "kind": o["kind"]}, "name": o["metadata"]["name"],
+               "operation": ["CREATE", "UPDATE", "DELETE", "CONNECT"][rng.below(4)]}
+        if rng.below(3):
+            req["userInfo"] = {"username": "user-%d" % rng.below(5), "groups": ["system:authenticated"]}
+        if o["metadata"].get("namespace") and rng.below(6):
+            req["namespace"] = o["metadata"]["namespace"]
+        kind_of = rng.below(8)
+        if kind_of == 0:
+            req["oldObject"] = o
+        elif kind_of == 1:
+            old = json.loads(json.dumps(o))
+            old["metadata"]["labels"] = {"was": "old"}
+            req["object"], req["oldObject"] = o, old
+        elif kind_of == 2:
+            req["object"], req["oldObject"] = None, None
+        elif kind_of == 3:
+            nokind = {k: v for k, v in o.items() if k != "kind"}
+            req["object"] = nokind
+        else:
+            req["object"] = o
+        if rng.below(3) == 0:
+            req.update({"dryRun": bool(rng.below(2)), "requestKind": {"group": g, "version": ver, "kind": o["kind"]}, "options": {"kind": "CreateOptions"}})
+        if shape == 2:
+            out.append(D.to_review_in(D.AdmissionRequest(req), nsobj))
+        else:
+            out.append(D.to_review_in(D.AugmentedReview(D.AdmissionRequest(req), ns if rng.below(8) else None, source), nsobj))
+    return out
+
+
+def _c_reviews(rins):
+    from gatekeeper_amd import _lib as L
+    from gatekeeper_amd import driver as D
+    arr = (L.gk_review_in * max(1, len(rins)))()
+    for a, r in zip(arr, rins):
+        D.Engine._fill(a, r)
+    return arr
+
+
+def test_review_shapes_checker_equals_the_python_oracle(fixtures):
+    """HandleReview + Matcher.Match + input.review of the checker, pinned against the Python oracle on every input shape"""
+    from gatekeeper_amd import driver as D
+    from gatekeeper_amd import _lib as L
+    ts = synth.psp_templates(fixtures) + [ENVELOPE_TEMPLATE]
+    cs = synth.audit_constraints() + [{"apiVersion": "constraints.gatekeeper.sh/v1beta1", "kind": "K8sEnvelope", "metadata": {"name": "envelope"}, "spec": {}},
+                                      {"apiVersion": "constraints.gatekeeper.sh/v1beta1", "kind": "K8sEnvelope", "metadata": {"name": "envelope-generated"},
+                                       "spec": {"match": {"source": "Generated", "kinds": [{"apiGroups": [""], "kinds": ["Pod"]}]}}}]
+    rins = _review_shapes(500, 71)
+    oc = OC.Client()
+    for t in ts:
+        oc.add_template(t)
+    for c in cs:
+        oc.add_constraint(c)
+    keys = {(c["kind"], c["metadata"]["name"]): i for i, c in enumerate(cs)}
+    src_name = {v: k for k, v in D._SOURCES.items()}
+    want_v, want_e, want_rej = set(), set(), set()
+    for i, r in enumerate(rins):
+        body, ns = json.loads(r.json), json.loads(r.namespace) if r.namespace else None
+        nsobj = json.loads(r.ns_object) if r.ns_object else None
+        source = src_name.get(r.source, "invalid")
+        op = r.operation.decode() if r.operation else ""
+        shape = OT.AugmentedUnstructured(OT.Unstructured(body), ns, source, op) if r.kind == L.GK_REVIEW_OBJECT else OT.AugmentedReview(OT.AdmissionRequest(body), ns, source)
+        try:
+            results = oc.review(shape, OC.AUDIT_EP, namespace=nsobj)
+        except OT.ReviewError:
+            want_rej.add(i)
+            continue
+        for res in results:
+            row = keys[(res.constraint["kind"], res.constraint["metadata"]["name"])]
+            (want_e if res.msg.startswith("unable to match constraints: ") and not res.metadata.get("details") else want_v).add((row, i))
+    ck = IndepChecker(ts, cs)
+    viol, err, rejected = ck.check_reviews(_c_reviews(rins), len(rins), threads=3)
+    assert {int(i) for i in np.nonzero(rejected)[0]} == want_rej and len(want_rej) > 5
+    got_v, got_e = _pairs_of(viol, len(rins)), _pairs_of(err, len(rins))
+    assert len(want_v) > 500 and len(want_e) > 20
+    assert got_v == want_v, (sorted(got_v - want_v)[:5], sorted(want_v - got_v)[:5])
+    assert got_e == want_e, (sorted(got_e - want_e)[:5], sorted(want_e - got_e)[:5])
+
+
+def test_review_shapes_product_equals_the_compiled_checker(fixtures):
+    """20 000 reviews of every HandleReview shape x 52 constraints: the product's bitmaps and review statuses (CPU build of the engine)
+    against the independent compiled checker"""
+    from gatekeeper_amd import driver as D
+    from gatekeeper_amd import _lib as L
+    ts = synth.psp_templates(fixtures) + [ENVELOPE_TEMPLATE]
+    cs = synth.audit_constraints() + [{"apiVersion": "constraints.gatekeeper.sh/v1beta1", "kind": "K8sEnvelope", "metadata": {"name": "envelope"}, "spec": {}},
+                                      {"apiVersion": "constraints.gatekeeper.sh/v1beta1", "kind": "K8sEnvelope", "metadata": {"name": "envelope-generated"},
+                                       "spec": {"match": {"source": "Generated", "kinds": [{"apiGroups": [""], "kinds": ["Pod"]}]}}}]
+    n = 20000
+    rins = _review_shapes(n, 72)
+    drv = D.Driver(device=0, hostemu=True)
+    client = D.Client(drv)
+    for t in ts:
+        client.AddTemplate(t)
+    for c in cs:
+        client.AddConstraint(c)
+    table = drv.engine.create_table(rins, keep_docs=False)
+    ev = table.eval()
+    ids = [drv.constraint_id(client.constraints[(k["kind"], k["metadata"]["name"])]) for k in cs]
+    ck = IndepChecker(ts, cs)
+    viol, err, rejected = ck.check_reviews(_c_reviews(rins), n, threads=4)
+    product_rejected = {i for i, st in enumerate(table.statuses) if st != L.GK_OK}
+    assert product_rejected == {int(i) for i in np.nonzero(rejected)[0]} and len(product_rejected) > 100
+    assert len(ev.too_big_reviews()) == 0
+    row_of = {int(cid): i for i, cid in enumerate(ev.constraint_ids)}
+    words = (n + 63) // 64
+    tail = np.uint64((1 << (n % 64)) - 1) if n % 64 else None
+    pairs = errs = 0
+    for row, cid in enumerate(ids):
+        d_v, d_e = np.array(ev.viol[row_of[cid]][:words], copy=True), np.array(ev.err[row_of[cid]][:words], copy=True)
+        if tail is not None:
+            d_v[-1] &= tail
+            d_e[-1] &= tail
+        assert (d_v == viol[row]).all(), ("viol", cs[row]["kind"], cs[row]["metadata"]["name"], [int(i) for i in np.nonzero(np.unpackbits((d_v ^ viol[row]).view(np.uint8), bitorder="little"))[0][:5]])
+        assert (d_e == err[row]).all(), ("err", cs[row]["kind"], cs[row]["metadata"]["name"], [int(i) for i in np.nonzero(np.unpackbits((d_e ^ err[row]).view(np.uint8), bitorder="little"))[0][:5]])
+        pairs += int(np.unpackbits(d_v.view(np.uint8)).sum())
+        errs += int(np.unpackbits(d_e.view(np.uint8)).sum())
+    assert pairs > n and errs > 1000
+    table.free()
