@@ -120,6 +120,37 @@ def indep_leg(templates, constraints, batch, ev, ids=None, budget_s=8.0, n=None)
     return base, parity
 
 
+def messages_leg(templates, constraints, batch, ev, table, ids=None, n_objects=2048):
+    """Message TEXT against the independent compiled checker: for the first n_objects of the timed table every violating pair the device
+    flagged is rendered by the product (gk_render over the kept JSON text) and compared, message for message, with the checker's own
+    evaluation and formatting of the same object (oracle/indep_check.cpp ic_messages: its own number printing and sprintf)."""
+    import numpy as np
+    from oracle.indep_check import IndepChecker
+    n = min(n_objects, batch.n)
+    ck = IndepChecker(templates, constraints)
+    cids = list(ids if ids is not None else batch_constraint_ids)
+    row_of = {int(cid): i for i, cid in enumerate(ev.constraint_ids)}
+    words = (n + 63) // 64
+    flagged = [np.unpackbits(np.array(ev.viol[row_of[cid]][:words], copy=True).view(np.uint8), bitorder="little")[:n] for cid in cids]
+    t0 = time.perf_counter()
+    pairs = messages = 0
+    first_difference = None
+    for i in range(n):
+        want = {row: sorted(m) for row, m in ck.messages(batch.json_text(i), batch.namespace_text(i)).items()}
+        got = {row: sorted(v["msg"] for v in table.render(cid, i)) for row, cid in enumerate(cids) if flagged[row][i]}
+        pairs += len(got)
+        messages += sum(len(m) for m in got.values())
+        if got != want and first_difference is None:
+            row = next(r for r in sorted(set(got) | set(want)) if got.get(r) != want.get(r))
+            first_difference = {"object": i, "constraint": "%s/%s" % (constraints[row]["kind"], constraints[row]["metadata"]["name"]),
+                                "product": got.get(row), "checker": want.get(row)}
+    ck.close()
+    return {"objects": n, "violating_pairs": pairs, "messages": messages, "messages_equal": first_difference is None, "first_difference": first_difference,
+            "seconds": time.perf_counter() - t0,
+            "what": "every message the product renders for the first %d objects of the timed table (pairs flagged on the device) against the text the "
+                    "independent compiled checker produces for the same objects" % n}
+
+
 def oracle_pairs_of(templates, constraints, batch, n):
     """(viol pairs, err pairs, seconds, processes) of the pure-Python oracle over the first n objects of `batch` (JSON text)"""
     from oracle import bench_leg as BL
@@ -370,6 +401,11 @@ def side_point(config, reviews, steps, warmup, oracle_n, dev_index, fx, nss, wit
             _, out["parity_compiled_independent"] = indep_leg(templates, constraints, batch, final, ids=ids, budget_s=0.5)
         except Exception as ex:   # noqa: BLE001
             out["parity_compiled_independent"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+        if totals:   # (the table keeps the JSON text: its pairs can be rendered)
+            try:
+                out["parity_messages_compiled_independent"] = messages_leg(templates, constraints, batch, final, table, ids=ids, n_objects=1024)
+            except Exception as ex:   # noqa: BLE001
+                out["parity_messages_compiled_independent"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
     if totals:
         try:
             out["audit_result_totals"] = totals_leg(table)
@@ -434,6 +470,7 @@ def other_configs(args, dev_index, dev, fx, nss, budget_s=200.0):
         return {"w": "%dx%d" % (d["constraints"], d["reviews"]), "ms": _sig(d["ms_per_step"]), "evals_s": _sig(d["evals_per_s"]), "frac": _sig(rf["frac"], 3),
                 "GBs": _sig(rf["achieved"]), "groups": d["plan_groups"], "parity": parity_brief(d.get("parity_python_oracle")),
                 "compiled": {k: (_sig(v, 3) if isinstance(v, float) else v) for k, v in (d.get("parity_compiled_independent") or {}).items() if k in ("n", "pairs_equal", "seconds", "error")},
+                "messages": {k: v for k, v in (d.get("parity_messages_compiled_independent") or {}).items() if k in ("objects", "messages", "messages_equal", "error")},
                 "leg_s": _sig(d["leg_seconds"], 3)}
     r = run("configs1", lambda: side_point(1, 100000, max(args.steps, 50), args.warmup, args.side_oracle_sample, dev_index, fx, nss))
     if r:
@@ -692,6 +729,10 @@ def main():
             except Exception as ex:   # noqa: BLE001
                 out["cpu_baseline"] = product_loop
                 out["parity_compiled_independent"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+            try:   # ... and the TEXT of the messages, on a prefix of the table
+                out["parity_messages_compiled_independent"] = messages_leg(templates, constraints, batch, final, table)
+            except Exception as ex:   # noqa: BLE001
+                out["parity_messages_compiled_independent"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
             try:
                 out["parity_python_oracle"] = python_oracle_leg(templates, constraints, batch, final, args.oracle_sample)
             except Exception as ex:   # the checker must not cost the bench line; an absent leg is visible as such
@@ -709,6 +750,7 @@ def main():
                                  "parity": {"n": pp.get("n"), "equal": pp.get("pairs_equal"), "pairs": pp.get("oracle_violating_pairs"), "s": _sig(pp.get("seconds"), 3)},
                                  "cpu_loop_parity": {"n": ps.get("n"), "equal": ps.get("pairs_equal")},
                                  "compiled_independent_parity": {k: (out.get("parity_compiled_independent") or {}).get(k) for k in ("n", "pairs_equal", "checker_violating_pairs", "seconds", "error") if k in (out.get("parity_compiled_independent") or {})},
+                                 "messages": {k: v for k, v in (out.get("parity_messages_compiled_independent") or {}).items() if k in ("objects", "messages", "messages_equal", "error")},
                                  "totals": {"s": _sig((out.get("audit_result_totals") or {}).get("seconds"), 3), "rendered_share": _sig((out.get("audit_result_totals") or {}).get("rendered_share"), 3),
                                             "equal": ((out.get("audit_result_totals") or {}).get("host_pass_over_every_pair") or {}).get("equal")}}
             e2e = out.get("end_to_end") or {}

@@ -96,6 +96,8 @@ def test_other_configs_legs_run_on_the_cpu_build(fixtures, monkeypatch):
     assert "error" not in tl and tl["host_pass_over_every_pair"]["equal"] and tl["results"] > tl["violating_pairs"] and tl["rendered_share"] < 0.1, tl
     assert out["plan_groups"] == 3 and out["parity_python_oracle"]["pairs_equal"], out.get("parity_python_oracle")
     assert out["parity_compiled_independent"].get("pairs_equal") and out["parity_compiled_independent"]["n"] == 256, out["parity_compiled_independent"]
+    pm = out["parity_messages_compiled_independent"]
+    assert pm.get("messages_equal") and pm["objects"] == 256 and pm["messages"] >= pm["violating_pairs"] > 256, pm
     assert out["roofline"]["algo_bytes_per_sweep_table_once"] < out["roofline"]["algo_bytes_per_sweep_every_group"]
     assert "error" not in stream and stream["parity_python_oracle"]["pairs_equal"] and stream["batches"] == 2
     assert stream["parity_compiled_independent"].get("pairs_equal") and stream["parity_compiled_independent"]["n"] == 128, stream["parity_compiled_independent"]
@@ -125,3 +127,29 @@ def test_compiled_independent_leg_checks_the_bitmaps(fixtures):
     ev.viol[5][2] ^= np.uint64(1 << 9)
     _, bad = bench.indep_leg(templates, constraints, batch, ev, budget_s=0.1)
     assert not bad["pairs_equal"]
+
+
+def test_messages_leg_compares_rendered_text_with_the_compiled_checker(fixtures):
+    """bench.messages_leg: every message rendered for a prefix of the table against the compiled checker's text; a table whose bitmaps
+    claim a pair the checker has no message for is reported with the first difference"""
+    templates, constraints = synth.psp_templates(fixtures), synth.audit_constraints()
+    drv = D.Driver(device=0, hostemu=True)
+    client = D.Client(drv)
+    for t in templates:
+        client.AddTemplate(t)
+    for k in constraints:
+        client.AddConstraint(k)
+    defaulted = [client.constraints[(k["kind"], k["metadata"]["name"])] for k in constraints]
+    bench.batch_constraint_ids[:] = [drv.constraint_id(c) for c in defaulted]
+    n = 600
+    batch = synth.NativeBatch(drv.engine.lib, n, seed=synth.SEED, mixed=True, start=0, namespaces=synth.gen_namespaces())
+    table = drv.engine.create_table_native(batch.reviews, n, keep_docs=False, resident=True, keep_text=True, pruned=True)
+    table.launch()
+    ev = table.eval(download=True, collect_only=True)
+    leg = bench.messages_leg(templates, constraints, batch, ev, table, n_objects=400)
+    assert leg["messages_equal"] and leg["objects"] == 400 and leg["messages"] >= leg["violating_pairs"] > 300, leg
+    ev.viol = np.array(ev.viol, copy=True)
+    row = next(r for r in range(len(constraints)) if not (int(ev.viol[r][0]) >> 7) & 1)
+    ev.viol[row][0] |= np.uint64(1 << 7)      # a pair the policy does not produce: the product renders nothing for it, the checker has no entry
+    bad = bench.messages_leg(templates, constraints, batch, ev, table, n_objects=64)
+    assert not bad["messages_equal"] and bad["first_difference"]["object"] == 7
