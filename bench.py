@@ -92,7 +92,7 @@ def indep_leg(templates, constraints, batch, ev, ids=None, budget_s=8.0, n=None)
     ck.check(batch.reviews, n1, 1)
     s1 = time.perf_counter() - t0
     t0 = time.perf_counter()
-    viol, err = ck.check(batch.reviews, n, cores)
+    viol, err, results = ck.check_totals(batch.reviews, n, cores)   # (the RESULT totals come out of the same pass)
     s_all = time.perf_counter() - t0
     ck.close()
     row_of = {int(cid): i for i, cid in enumerate(ev.constraint_ids)}
@@ -116,8 +116,23 @@ def indep_leg(templates, constraints, batch, ev, ids=None, budget_s=8.0, n=None)
     parity = {"n": n, "constraints": nc, "pairs_equal": equal, "device_violating_pairs": dev_pairs, "checker_violating_pairs": ck_pairs,
               "device_autoreject_pairs": dev_err, "checker_autoreject_pairs": ck_err, "seconds": s_all, "threads": cores,
               "checker": "oracle/indep_check.cpp -> oracle/libgkindep.so: compiled, independent of the product (one source file + the C++ standard library on its link line), "
-                         "pinned against the Python oracle by tests/test_indep_check.py; every object of the timed table, bit for bit"}
+                         "pinned against the Python oracle by tests/test_indep_check.py; every object of the timed table, bit for bit",
+              "checker_results": int(results.sum()), "_results_by_row": [int(x) for x in results]}
     return base, parity
+
+
+def totals_against_checker(table, parity, ids=None):
+    """gk_table_totals of the timed table (RESULTS per constraint: device counts + host rendering of the flagged pairs) against the
+    RESULT totals the independent compiled checker counted in its pass over the same objects (indep_leg).  parity: indep_leg's record;
+    its private per-row list is consumed here."""
+    by_row = parity.pop("_results_by_row", None)
+    if by_row is None or parity.get("n") != table.n:
+        return None
+    tot = table.totals()
+    cids = list(ids if ids is not None else batch_constraint_ids)
+    equal = all(int(tot[cid][0]) == by_row[row] for row, cid in enumerate(cids))
+    return {"equal": equal, "checker_results": int(sum(by_row)), "product_results": int(sum(r for r, _ in tot.values())),
+            "what": "RESULT totals per constraint: gk_table_totals against the independent compiled checker's count of distinct (msg, details) per violating pair, every object of the table"}
 
 
 def messages_leg(templates, constraints, batch, ev, table, ids=None, n_objects=2048):
@@ -411,6 +426,13 @@ def side_point(config, reviews, steps, warmup, oracle_n, dev_index, fx, nss, wit
             out["audit_result_totals"] = totals_leg(table)
         except Exception as ex:   # noqa: BLE001
             out["audit_result_totals"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+        try:   # ... against the RESULT totals the compiled checker counted over the same objects
+            vs = totals_against_checker(table, out.get("parity_compiled_independent") or {}, ids=ids)
+            if vs is not None:
+                out["audit_result_totals"]["independent_compiled_checker"] = vs
+        except Exception as ex:   # noqa: BLE001
+            out["audit_result_totals"]["independent_compiled_checker"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+    (out.get("parity_compiled_independent") or {}).pop("_results_by_row", None)
     table.free()
     stream = None
     if with_stream:
@@ -427,6 +449,7 @@ def side_point(config, reviews, steps, warmup, oracle_n, dev_index, fx, nss, wit
             if oracle_n > 0 and first and stream_args.batch <= reviews:
                 try:   # every object of that streamed batch against the independent compiled checker
                     _, stream["parity_compiled_independent"] = indep_leg(templates, constraints, batch, first[0], ids=ids, budget_s=0.2, n=stream_args.batch)
+                    stream["parity_compiled_independent"].pop("_results_by_row", None)
                 except Exception as ex:   # noqa: BLE001
                     stream["parity_compiled_independent"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
         except Exception as ex:   # noqa: BLE001
@@ -484,7 +507,8 @@ def other_configs(args, dev_index, dev, fx, nss, budget_s=200.0):
         tl = r[0].get("audit_result_totals") or {}
         brief["configs4"]["totals"] = ({"error": tl["error"][:80]} if "error" in tl else
                                        {"s": _sig(tl.get("seconds"), 3), "first_s": _sig(tl.get("seconds_first_call"), 3), "rendered_share": _sig(tl.get("rendered_share"), 3),
-                                        "equal": (tl.get("host_pass_over_every_pair") or {}).get("equal"), "host_pass_s": _sig((tl.get("host_pass_over_every_pair") or {}).get("seconds"), 3)})
+                                        "equal": (tl.get("host_pass_over_every_pair") or {}).get("equal"), "host_pass_s": _sig((tl.get("host_pass_over_every_pair") or {}).get("seconds"), 3),
+                                        "equal_compiled_checker": (tl.get("independent_compiled_checker") or {}).get("equal")})
         detail["configs4_stream"] = r[1]
         if r[1] and "error" not in r[1]:
             brief["configs4_stream"] = {"offered": r[1]["offered_reviews_per_s"], "achieved": _sig(r[1]["achieved_reviews_per_s"]), "p50_ms": _sig(r[1]["batch_latency_ms"]["p50"], 3),
@@ -729,6 +753,13 @@ def main():
             except Exception as ex:   # noqa: BLE001
                 out["cpu_baseline"] = product_loop
                 out["parity_compiled_independent"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+            try:   # ... the RESULT totals the checker counted in that pass against gk_table_totals
+                vs = totals_against_checker(table, out["parity_compiled_independent"])
+                if vs is not None and isinstance(out.get("audit_result_totals"), dict):
+                    out["audit_result_totals"]["independent_compiled_checker"] = vs
+            except Exception as ex:   # noqa: BLE001
+                out["audit_result_totals"] = dict(out.get("audit_result_totals") or {}, independent_compiled_checker={"error": "%s: %s" % (type(ex).__name__, ex)})
+            out["parity_compiled_independent"].pop("_results_by_row", None)
             try:   # ... and the TEXT of the messages, on a prefix of the table
                 out["parity_messages_compiled_independent"] = messages_leg(templates, constraints, batch, final, table)
             except Exception as ex:   # noqa: BLE001
@@ -752,7 +783,8 @@ def main():
                                  "compiled_independent_parity": {k: (out.get("parity_compiled_independent") or {}).get(k) for k in ("n", "pairs_equal", "checker_violating_pairs", "seconds", "error") if k in (out.get("parity_compiled_independent") or {})},
                                  "messages": {k: v for k, v in (out.get("parity_messages_compiled_independent") or {}).items() if k in ("objects", "messages", "messages_equal", "error")},
                                  "totals": {"s": _sig((out.get("audit_result_totals") or {}).get("seconds"), 3), "rendered_share": _sig((out.get("audit_result_totals") or {}).get("rendered_share"), 3),
-                                            "equal": ((out.get("audit_result_totals") or {}).get("host_pass_over_every_pair") or {}).get("equal")}}
+                                            "equal": ((out.get("audit_result_totals") or {}).get("host_pass_over_every_pair") or {}).get("equal"),
+                                            "equal_compiled_checker": ((out.get("audit_result_totals") or {}).get("independent_compiled_checker") or {}).get("equal")}}
             e2e = out.get("end_to_end") or {}
             again = e2e.get("second_table_of_the_same_batch") or {}
             brief["configs2"]["ingest"] = {"first_table_json_MBps": _sig(e2e.get("json_MBps"), 4), "first_table_flatten_s": _sig(e2e.get("flatten_s"), 3),

@@ -1626,9 +1626,11 @@ static bool match_review(const V& match, const Rv& rv) {
 }
 
 // one review: which rows violate, which are autorejected (matching failed)
-static void review_one(const Checker& c, const gk_review_in& r, std::vector<uint32_t>* viol, std::vector<uint32_t>* err) {
+// results (may be null): per row, += the number of types.Results of this review -- one per distinct (msg, details), as the Rego driver
+// dedupes them (what pkg/audit/manager.go:893-904 totals per constraint)
+static void review_one(const Checker& c, const gk_review_in& r, std::vector<uint32_t>* viol, std::vector<uint32_t>* err, uint64_t* results = nullptr) {
   const Rv rv = handle_review(r);
-  std::map<std::pair<const Program*, const V*>, bool> memo;   // (program, parameters) -> yields a result
+  std::map<std::pair<const Program*, const V*>, uint32_t> memo;   // (program, parameters) -> how many results
   for (size_t row = 0; row < c.constraints.size(); row++) {
     const Constraint& x = c.constraints[row];
     if (x.match) {
@@ -1636,16 +1638,25 @@ static void review_one(const Checker& c, const gk_review_in& r, std::vector<uint
     }
     auto key = std::make_pair(x.prog, x.params.get());
     auto it = memo.find(key);
-    bool any;
-    if (it != memo.end()) any = it->second;
+    uint32_t count;
+    if (it != memo.end()) count = it->second;
     else {
       Query q(*x.prog, mk_obj({{mk_str("review"), rv.input}, {mk_str("parameters"), x.params}}));
       const VP set = q.violations();
-      any = false;
-      for (auto& res : set->a) { if (res->k != V::Obj) continue; const VP* m = obj_get(*res, "msg"); if (m && (*m)->k == V::Str) { any = true; break; } }
-      memo[key] = any;
+      count = 0;
+      std::set<std::pair<std::string, std::string>> seen;
+      for (auto& res : set->a) {
+        if (res->k != V::Obj) continue;
+        const VP* m = obj_get(*res, "msg");
+        if (!m || (*m)->k != V::Str) continue;
+        if (!results) { count = 1; break; }
+        const VP* d = obj_get(*res, "details");
+        if (seen.insert({(*m)->s, d ? to_string(*d) : std::string("{}")}).second) count++;
+      }
+      memo[key] = count;
     }
-    if (any) viol->push_back((uint32_t)row);
+    if (count) viol->push_back((uint32_t)row);
+    if (results) results[row] += count;
   }
 }
 
@@ -1712,7 +1723,12 @@ void ic_free(void* p) { free(p); }
 // bitmaps [n_constraints][words] (bit r of word r / 64 of row c: pair (c, review r)), zeroed by the caller; returns 0, or -1 with ic_last_error()
 // `rejected` ([n] bytes, may be NULL): 1 where HandleReview refuses the review (no results, as the product's statuses[i]); with NULL
 // such a review is an error of the call.
+// results ([n_constraints], may be NULL, zeroed by the caller): RESULT totals per constraint over all n reviews
+int ic_check_totals(void* h, const gk_review_in* reviews, size_t n, uint64_t* viol, uint64_t* err, uint8_t* rejected, uint64_t* results, size_t words, int threads);
 int ic_check_reviews(void* h, const gk_review_in* reviews, size_t n, uint64_t* viol, uint64_t* err, uint8_t* rejected, size_t words, int threads) {
+  return ic_check_totals(h, reviews, n, viol, err, rejected, nullptr, words, threads);
+}
+int ic_check_totals(void* h, const gk_review_in* reviews, size_t n, uint64_t* viol, uint64_t* err, uint8_t* rejected, uint64_t* results, size_t words, int threads) {
   const ic::Checker& c = *static_cast<ic::Checker*>(h);
   if (threads < 1) threads = 1;
   std::atomic<size_t> next{0};
@@ -1721,12 +1737,14 @@ int ic_check_reviews(void* h, const gk_review_in* reviews, size_t n, uint64_t* v
   auto fail = [&](size_t i, const std::string& what) { std::lock_guard<std::mutex> l(mu); if (first_err.empty()) first_err = "review " + std::to_string(i) + ": " + what; };
   auto work = [&]() {
     std::vector<uint32_t> v, e;
+    std::vector<uint64_t> mine(results ? c.constraints.size() : 0, 0);
+    struct Flush { std::vector<uint64_t>& m; uint64_t* out; std::mutex& mu; ~Flush() { if (!out) return; std::lock_guard<std::mutex> l(mu); for (size_t k = 0; k < m.size(); k++) out[k] += m[k]; } } flush{mine, results, mu};
     for (;;) {
       const size_t lo = next.fetch_add(64);   // (64 reviews = one word per row: no two threads share a word)
       if (lo >= n) return;
       for (size_t i = lo; i < std::min(n, lo + 64); i++) {
         v.clear(); e.clear();
-        try { ic::review_one(c, reviews[i], &v, &e); }
+        try { ic::review_one(c, reviews[i], &v, &e, results ? mine.data() : nullptr); }
         catch (const ic::ReviewErr& ex) { if (rejected) { rejected[i] = 1; continue; } fail(i, ex.what()); return; }
         catch (const std::exception& ex) { fail(i, ex.what()); return; }
         catch (const ic::Unbound&) { fail(i, "unsafe variable"); return; }

@@ -39,6 +39,8 @@ def _load():
     lib.ic_check.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
     lib.ic_check_reviews.restype = C.c_int
     lib.ic_check_reviews.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    lib.ic_check_totals.restype = C.c_int
+    lib.ic_check_totals.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
     lib.ic_messages.restype = C.c_void_p
     lib.ic_messages.argtypes = [C.c_void_p, C.c_void_p]
     lib.ic_free.argtypes = [C.c_void_p]
@@ -83,6 +85,19 @@ class IndepChecker:
         if rc != 0:
             raise RuntimeError("compiled checker: " + self.lib.ic_last_error().decode())
         return viol, err, rejected[:n]
+
+    def check_totals(self, reviews, n, threads=None):
+        """as check(), plus the RESULT totals per constraint (pkg/audit/manager.go:893-904: one per types.Result = per distinct
+        (msg, details) of a violating pair).  -> (viol, err, results[n_constraints])"""
+        words = (n + 63) // 64
+        viol = np.zeros((self.n_constraints, max(words, 1)), dtype=np.uint64)
+        err = np.zeros_like(viol)
+        results = np.zeros(max(self.n_constraints, 1), dtype=np.uint64)
+        threads = threads or max(1, min(os.cpu_count() or 1, 64))
+        rc = self.lib.ic_check_totals(self.h, C.cast(reviews, C.c_void_p), n, viol.ctypes.data, err.ctypes.data, None, results.ctypes.data, max(words, 1), threads)
+        if rc != 0:
+            raise RuntimeError("compiled checker: " + self.lib.ic_last_error().decode())
+        return viol, err, results[:self.n_constraints]
 
     def check_texts(self, texts, threads=None):
         """texts: [(object JSON text, namespace JSON text | None)]"""

@@ -96,6 +96,8 @@ def test_other_configs_legs_run_on_the_cpu_build(fixtures, monkeypatch):
     assert "error" not in tl and tl["host_pass_over_every_pair"]["equal"] and tl["results"] > tl["violating_pairs"] and tl["rendered_share"] < 0.1, tl
     assert out["plan_groups"] == 3 and out["parity_python_oracle"]["pairs_equal"], out.get("parity_python_oracle")
     assert out["parity_compiled_independent"].get("pairs_equal") and out["parity_compiled_independent"]["n"] == 256, out["parity_compiled_independent"]
+    assert tl["independent_compiled_checker"]["equal"] and tl["independent_compiled_checker"]["checker_results"] == tl["results"], tl["independent_compiled_checker"]
+    assert "_results_by_row" not in out["parity_compiled_independent"]
     pm = out["parity_messages_compiled_independent"]
     assert pm.get("messages_equal") and pm["objects"] == 256 and pm["messages"] >= pm["violating_pairs"] > 256, pm
     assert out["roofline"]["algo_bytes_per_sweep_table_once"] < out["roofline"]["algo_bytes_per_sweep_every_group"]
@@ -117,10 +119,13 @@ def test_compiled_independent_leg_checks_the_bitmaps(fixtures):
     bench.batch_constraint_ids[:] = [drv.constraint_id(c) for c in defaulted]
     n = 1000
     batch = synth.NativeBatch(drv.engine.lib, n, seed=synth.SEED, mixed=True, start=0, namespaces=synth.gen_namespaces())
-    table = drv.engine.create_table_native(batch.reviews, n, keep_docs=False, resident=True, pruned=True)
+    table = drv.engine.create_table_native(batch.reviews, n, keep_docs=False, resident=True, keep_text=True, pruned=True)
     table.launch()
     ev = table.eval(download=True, collect_only=True)
     base, par = bench.indep_leg(templates, constraints, batch, ev, budget_s=0.2)
+    vs = bench.totals_against_checker(table, dict(par))      # (the main line's call: gk_table_totals against the checker's RESULT totals)
+    assert vs["equal"] and vs["checker_results"] == vs["product_results"] == par["checker_results"]
+    assert par["checker_results"] == sum(par["_results_by_row"]) >= par["checker_violating_pairs"]
     assert par["pairs_equal"] and par["n"] == n and par["device_violating_pairs"] == par["checker_violating_pairs"] > 500
     assert base["kind"] == "port" and base["cores"] == 1 and base["value"] > 0 and base["all_cores"]["sample_reviews"] == n
     ev.viol = np.array(ev.viol, copy=True)

@@ -431,3 +431,30 @@ def test_review_shapes_product_equals_the_compiled_checker(fixtures):
         errs += int(np.unpackbits(d_e.view(np.uint8)).sum())
     assert pairs > n and errs > 1000
     table.free()
+
+
+@pytest.mark.parametrize("policy,n", [("audit-50", 6000), ("corpus-200", 2500)])
+def test_result_totals_product_equals_the_compiled_checker(policy, n, fixtures):
+    """gk_table_totals (the audit's totalViolationsPerConstraint: RESULTS, several per violating pair -- counted on the device where the
+    plan can, rendered on the host where it cannot) against the independent compiled checker's count of distinct (msg, details) per pair"""
+    from gatekeeper_amd import driver as D
+    ts, cs = (synth.psp_templates(fixtures), synth.audit_constraints()) if policy == "audit-50" else synth.corpus(fixtures)
+    drv = D.Driver(device=0, hostemu=True)
+    client = D.Client(drv)
+    for t in ts:
+        client.AddTemplate(t)
+    for c in cs:
+        client.AddConstraint(c)
+    batch = synth.NativeBatch(drv.engine.lib, n, seed=synth.SEED + 21, mixed=True, start=0, namespaces=synth.gen_namespaces())
+    table = drv.engine.create_table_native(batch.reviews, n, keep_docs=False, resident=True, keep_text=True, pruned=True)
+    table.eval()
+    product = table.totals()
+    ids = [drv.constraint_id(client.constraints[(k["kind"], k["metadata"]["name"])]) for k in cs]
+    ck = IndepChecker(ts, cs)
+    viol, _err, results = ck.check_totals(batch.reviews, n, threads=4)
+    for row, cid in enumerate(ids):
+        pairs = int(np.unpackbits(viol[row].view(np.uint8)).sum())
+        assert product[cid] == (int(results[row]), pairs), (cs[row]["kind"], cs[row]["metadata"]["name"], product[cid], int(results[row]), pairs)
+    assert int(results.sum()) > sum(p for _, p in product.values()) > n     # several results per pair do occur
+    assert table.rendered_pairs < sum(p for _, p in product.values()) // 5  # ... and most pairs were counted, not rendered
+    table.free()
