@@ -109,7 +109,6 @@ std::string go_sprintf(const std::string& fmt, const ValueVec& argv) {
     if (verb == '%') { out.push_back('%'); continue; }
     if (ai >= args.size()) { out += "%!"; if (wide.empty()) out.push_back(verb); else out += wide; out += "(MISSING)"; continue; }
     const GoArg& a = args[ai++];
-    if (!wide.empty()) { out += "%!" + wide + bad_verb('?', a).substr(3); continue; }
     std::string s;
     const bool plus = flags.find('+') != std::string::npos, space = flags.find(' ') != std::string::npos;
     const bool sharp = flags.find('#') != std::string::npos, minus = flags.find('-') != std::string::npos;
@@ -145,14 +144,26 @@ std::string go_sprintf(const std::string& fmt, const ValueVec& argv) {
       const bool sign = num[0] == '-' || num[0] == '+' || num[0] == ' ';
       return (sign ? num.substr(0, 1) : std::string()) + std::string(fill, '0') + num.substr(sign ? 1 : 0);
     };
-    switch (verb) {
-      case 'v':
-        if (a.kind == 2) s = pad(a.s, flags, width);
-        else if (a.kind == 0) s = integer(10, false, false);
-        else s = floating(go_float_v(a.f));
-        break;
-      case 's': if (a.kind == 2) s = pad(prec >= 0 ? rune_prefix(a.s, (size_t)prec) : a.s, flags, width); else bad = true; break;
-      case 'q': if (a.kind == 2) s = pad(go_quote(a.s), flags, width); else bad = true; break;
+    auto c_float = [&](char conv, int p) {
+      char f[24];
+      snprintf(f, sizeof f, "%%.%d%c", p, conv);
+      const int need = snprintf(nullptr, 0, f, a.f);   // %f of 1.8e308 is 300+ digits
+      std::string t((size_t)need + 1, '\0');
+      snprintf(&t[0], t.size(), f, a.f);
+      t.resize((size_t)need);
+      return t;
+    };
+    // the operand under %v with this directive's flags, width and precision (printArg(arg, 'v')): a string is cut to the precision
+    // (fmtS), an integer takes it as minimum digits, a float64 prints %g -- the shortest text, or that many significant digits
+    auto as_v = [&]() {
+      if (a.kind == 2) return pad(prec >= 0 ? rune_prefix(a.s, (size_t)prec) : a.s, flags, width);
+      if (a.kind == 0) return integer(10, false, false);
+      return floating(prec >= 0 ? c_float('g', prec) : go_float_v(a.f));
+    };
+    switch (wide.empty() ? verb : '\0') {
+      case 'v': s = as_v(); break;
+      case 's': if (a.kind == 2) s = as_v(); else bad = true; break;
+      case 'q': if (a.kind == 2) s = pad(go_quote(prec >= 0 ? rune_prefix(a.s, (size_t)prec) : a.s), flags, width); else bad = true; break;
       case 'd': if (a.kind == 0) s = integer(10, false, false); else bad = true; break;
       case 'x': case 'X':
         if (a.kind == 0) s = integer(16, verb == 'X', false);
@@ -187,20 +198,18 @@ std::string go_sprintf(const std::string& fmt, const ValueVec& argv) {
           if ((verb == 'g' || verb == 'G') && prec < 0) {   // %g without a precision is the shortest text that round-trips, as %v
             s = go_float_v(a.f);
             if (verb == 'G') for (char& c : s) if (c == 'e') c = 'E';
-          } else {
-            char f[24];
-            snprintf(f, sizeof f, "%%.%d%c", prec < 0 ? 6 : prec, verb == 'F' ? 'f' : verb);
-            const int need = snprintf(nullptr, 0, f, a.f);   // %f of 1.8e308 is 300+ digits
-            s.resize((size_t)need + 1);
-            snprintf(&s[0], s.size(), f, a.f);
-            s.resize((size_t)need);
-          }
+          } else s = c_float(verb == 'F' ? 'f' : verb, prec < 0 ? 6 : prec);
           s = floating(s);
         } else bad = true;
         break;
       default: bad = true;
     }
-    out += bad ? bad_verb(verb, a) : s;   // (badVerb writes past the width: no padding)
+    if (bad) {   // badVerb (fmt/print.go): %!verb(type=value) with the value printed as %v UNDER THIS DIRECTIVE'S flags, width and precision
+      out += "%!";
+      if (wide.empty()) out.push_back(verb); else out += wide;
+      out += a.kind == 0 ? "(int=" : a.kind == 1 ? "(float64=" : "(string=";
+      out += as_v() + ")";
+    } else out += s;
   }
   if (ai < args.size()) {
     out += "%!(EXTRA ";

@@ -788,7 +788,6 @@ static std::string go_sprintf(const std::string& fmt, const std::vector<VP>& arg
     if (ai >= as.size()) { o += "%!" + verb_rune + "(MISSING)"; continue; }
     const Arg& a = as[ai++];
     std::string s;
-    auto bad = [&]() { return "%!" + verb_rune + (a.kind == 0 ? "(string=" + a.s + ")" : a.kind == 1 ? "(int=" + i128_str(a.i) + ")" : "(float64=" + go_float_v(a.d) + ")"); };
     const bool plus = flags.find('+') != std::string::npos, space = flags.find(' ') != std::string::npos, left = flags.find('-') != std::string::npos;
     const bool zero = flags.find('0') != std::string::npos && !left;
     // an integer operand (fmtInteger): precision or, with the 0 flag, the width = minimum digits; then the sign; spaces fill the width
@@ -812,10 +811,27 @@ static std::string go_sprintf(const std::string& fmt, const std::vector<VP>& arg
       if (zero && (t[0] == '-' || t[0] == '+' || t[0] == ' ')) return t.substr(0, 1) + fill + t.substr(1);
       return fill + t;
     };
-    if (verb == 'v') s = a.kind == 0 ? pad(a.s, flags, width) : a.kind == 1 ? integer() : floating(go_float_v(a.d));
-    else if (verb == 's') { if (a.kind != 0) s = bad(); else if (prec < 0) s = pad(a.s, flags, width); else { size_t b = 0, n = 0; while (b < a.s.size() && n < (size_t)prec) { b++; while (b < a.s.size() && ((unsigned char)a.s[b] & 0xC0) == 0x80) b++; n++; } s = pad(a.s.substr(0, b), flags, width); } }
+    auto cut = [&](const std::string& t) {   // fmtS / fmtQ: the precision counts runes
+      if (prec < 0) return t;
+      size_t b = 0, n = 0;
+      while (b < t.size() && n < (size_t)prec) { b++; while (b < t.size() && ((unsigned char)t[b] & 0xC0) == 0x80) b++; n++; }
+      return t.substr(0, b);
+    };
+    // the operand under %v with this directive's flags, width and precision; a float64 with a precision prints that many significant digits (%g)
+    auto as_v = [&]() {
+      if (a.kind == 0) return pad(cut(a.s), flags, width);
+      if (a.kind == 1) return integer();
+      if (prec < 0) return floating(go_float_v(a.d));
+      char buf[64];
+      snprintf(buf, sizeof buf, "%.*g", prec, a.d);
+      return floating(buf);
+    };
+    // badVerb: %!verb(type=value), the value printed as %v under the same flags
+    auto bad = [&]() { return "%!" + verb_rune + (a.kind == 0 ? "(string=" : a.kind == 1 ? "(int=" : "(float64=") + as_v() + ")"; };
+    if (verb == 'v') s = as_v();
+    else if (verb == 's') s = a.kind == 0 ? as_v() : bad();
     else if (verb == 'd') s = a.kind == 1 ? integer() : bad();
-    else if (verb == 'q') s = a.kind == 0 ? pad(quote(a.s), flags, width) : bad();
+    else if (verb == 'q') s = a.kind == 0 ? pad(quote(cut(a.s)), flags, width) : bad();
     else if (verb == 'T') { std::string t = a.kind == 0 ? "string" : a.kind == 1 ? "int" : "float64"; if (prec >= 0 && (size_t)prec < t.size()) t.resize((size_t)prec); s = pad(t, flags, width); }
     else if (verb == '\0' || verb == 't' || verb == 'p' || !strchr("bcdeEfFgGoOqsUvxX", verb)) s = bad();   // no verb of fmt at all, or none for these operands
     else throw std::runtime_error(std::string("sprintf verb %") + verb + " is outside this checker's scope");

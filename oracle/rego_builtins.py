@@ -447,14 +447,27 @@ def _fmt_float(num, flags, width):
     return sign + num[len(sign):].rjust(width - len(sign), "0")
 
 
+def _as_v(flags, width, prec, kind, val):
+    """the operand under %v with the directive's flags, width and precision (printArg(arg, 'v')): fmtS cuts a string to the precision,
+    fmtInteger takes it as the minimum number of digits, fmtFloat prints %g -- the shortest text, or `prec` significant digits"""
+    if kind == "string":
+        return _pad(val if prec is None else val[:prec], flags, width)
+    if kind == "int":
+        return _fmt_integer(val, 10, flags, width, prec)
+    return _fmt_float(go_float_v(val) if prec is None else ("%." + str(prec) + "g") % val, flags, width)
+
+
 def _format_operand(verb, flags, width, prec, kind, val):
-    """one verb applied to one operand (fmt/print.go printArg -> fmtInteger / fmtFloat / fmtString / badVerb: a bad verb is written
-    as it is, outside the width).  Not modelled (no template of the corpus uses them): %q of an integer (quoted rune), %x / %b of a
-    float64, '#' on v / q / floats, '+' on q, %t (operands are never Go bools here: builtinSprintf stringifies them)"""
+    """one verb applied to one operand (fmt/print.go printArg -> fmtInteger / fmtFloat / fmtString / badVerb).  badVerb writes
+    %!verb(type=value) with the value printed as %v UNDER THE SAME flags, width and precision.  Not modelled (no template of the
+    corpus uses them): %q of an integer (quoted rune), %x / %b of a float64, '#' on v / q / floats, '+' on q, %t (operands are never
+    Go bools here: builtinSprintf stringifies them)"""
     if verb == "T":   # printArg: the operand's Go type through fmtS
         return _pad(kind if prec is None else kind[:prec], flags, width)
+    if verb == "v":
+        return _as_v(flags, width, prec, kind, val)
     if kind == "int":
-        if verb in "vd":
+        if verb == "d":
             return _fmt_integer(val, 10, flags, width, prec)
         if verb in "xX":
             return _fmt_integer(val, 16, flags, width, prec, upper=verb == "X")
@@ -467,19 +480,17 @@ def _format_operand(verb, flags, width, prec, kind, val):
         if verb == "U" and val >= 0:
             return _pad("U+%04X" % val, flags, width)
     elif kind == "float64":
-        if verb == "v" or (verb in "gG" and prec is None):   # %g without a precision: the shortest text that round-trips
+        if verb in "gG" and prec is None:   # %g without a precision: the shortest text that round-trips
             num = go_float_v(val)
             return _fmt_float(num.replace("e", "E") if verb == "G" else num, flags, width)
         if verb in "feEgGF":
             num = ("%." + str(6 if prec is None else prec) + ("f" if verb == "F" else verb)) % val
             return _fmt_float(num, flags, width)
     else:
-        if verb == "v":
-            return _pad(val, flags, width)
         if verb == "s":
-            return _pad(val if prec is None else val[:prec], flags, width)
-        if verb == "q":
-            return _pad(quote(val), flags, width)
+            return _as_v(flags, width, prec, kind, val)
+        if verb == "q":   # fmtQ: cut to the precision first, then quote
+            return _pad(quote(val if prec is None else val[:prec]), flags, width)
         if verb in "xX":   # fmtSbx: precision in bytes, ' ' between bytes, '#' prefix (on every byte when separated)
             raw = val.encode()
             raw = raw if prec is None else raw[:prec]
@@ -487,7 +498,7 @@ def _format_operand(verb, flags, width, prec, kind, val):
             hx = [("%02X" if verb == "X" else "%02x") % c for c in raw]
             text = " ".join(pre + h for h in hx) if " " in flags else (pre if hx else "") + "".join(hx)
             return _pad(text, flags, width)
-    return _bad(verb, kind, val)
+    return "%%!%s(%s=%s)" % (verb, kind, _as_v(flags, width, prec, kind, val))
 
 
 def go_sprintf(fmt, args):

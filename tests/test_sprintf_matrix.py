@@ -1,5 +1,5 @@
 """sprintf (topdown/strings.go builtinSprintf -> Go's fmt.Sprintf) three ways: the Python oracle against known answers of fmt's
-documented behaviour (fmt/format.go fmtInteger, fmtFloat, fmtS, fmtSbx, fmtC; print.go badVerb / NOVERB / MISSING / EXTRA), then the
+documented behaviour (fmt/format.go fmtInteger, fmtFloat, fmtS, fmtSbx, fmtC; print.go badVerb -- the operand as %v under the directive's own flags -- / NOVERB / MISSING / EXTRA), then the
 product's renderer and the independent compiled checker against the oracle on a verb x flag x operand matrix.
 
 The known answers are written from fmt's documented rules, not from a Go run (no Go toolchain here).  Not modelled by any of the
@@ -20,7 +20,8 @@ KNOWN = [("%g", [1234567.25], "1.23456725e+06"), ("%.3d", [7], "007"), ("%8.3d",
          ("%#b", [5], "0b101"), ("%+.1f", [1.5], "+1.5"), ("%08.2f", [-1.5], "-0001.50"), ("% x", ["hi"], "68 69"), ("%# x", ["hi"], "0x68 0x69"),
          ("%.0d", [0], ""), ("%5.0d", [0], "     "), ("%c", [128512], "\U0001F600"), ("%c", [-1], "�"), ("%6.2f", [3.14159], "  3.14"),
          ("%e", [1500.5], "1.500500e+03"), ("%G", [1e-7], "1E-07"), ("%-5d|", [42], "42   |"), ("%05d", [42], "00042"), ("%+v", [1.5], "+1.5"),
-         ("%8v|", ["é"], "       é|"), ("%.2s", ["héllo"], "hé"), ("%20d", ["s"], "%!d(string=s)"), ("%", [1], "%!(NOVERB)%!(EXTRA int=1)"),
+         ("%8v|", ["é"], "       é|"), ("%.2s", ["héllo"], "hé"), ("%20d", ["s"], "%!d(string=                   s)"), ("%5s", [5], "%!s(int=    5)"), ("%08d", [1.5], "%!d(float64=000001.5)"), ("%.2v", ["héllo"], "hé"),
+         ("%.3v", [1234567.25], "1.23e+06"), ("%.2q", ["héllo"], '"hé"'), ("%8.3d", ["hello"], "%!d(string=     hel)"), ("%.3v", [7], "007"), ("%-6x|", [1.5], "%!x(float64=1.5   )|"), ("%", [1], "%!(NOVERB)%!(EXTRA int=1)"),
          ("%!", [1], "%!!(int=1)"), ("%d %d", [1], "1 %!d(MISSING)"), ("%x", ["hi"], "6869"), ("%X", [255], "FF"), ("%q", ["a\"b"], '"a\\"b"'),
          ("%5%", [], "%"), ("%-08d|", [42], "42      |"), ("%+08d", [42], "+0000042"), ("%08v", [1.5], "000001.5"), ("%b", [-5], "-101"),
          ("%o", [64], "100"), ("%#X", [255], "0XFF"), ("%.2x", ["hello"], "6865"), ("%v", [1e21], "1e+21"), ("%v", [1e6], "1000000"),
