@@ -229,23 +229,53 @@ inline std::string json_float_text(double f) {
 inline std::string num_to_string(const Value& v) { return v.is_int ? i128_to_string(v.i) : json_float_text(v.d); }   // ast.Number.String()
 
 // Go strconv.Quote (ast.String.String()).
+// strconv.IsPrint for runes >= 0x80 (categories L, M, N, P, S): tools/gen_unicode_print.py
+#include "unicode_print.inc"
+inline bool go_is_print(uint32_t r) {
+  const size_t n = sizeof kPrintRanges / sizeof kPrintRanges[0];
+  size_t lo = 0, hi = n;
+  while (lo < hi) { const size_t mid = (lo + hi) >> 1; if (kPrintRanges[mid][1] < r) lo = mid + 1; else hi = mid; }
+  return lo < n && kPrintRanges[lo][0] <= r;
+}
+
+// strconv.Quote (ast.String.String(), fmt %q): a printable rune is written as it is; \a \b \f \n \r \t \v; \xNN for the other ASCII
+// controls and for a byte that is no UTF-8; \uNNNN / \UNNNNNNNN for any other rune IsPrint refuses (NBSP, zero-width and other format
+// characters, line separators, unassigned and private-use code points)
 inline std::string go_quote(const std::string& s) {
   std::string o = "\"";
-  for (unsigned char c : s) {
-    switch (c) {
-      case '"': o += "\\\""; break;
-      case '\\': o += "\\\\"; break;
-      case '\n': o += "\\n"; break;
-      case '\t': o += "\\t"; break;
-      case '\r': o += "\\r"; break;
-      case '\a': o += "\\a"; break;
-      case '\b': o += "\\b"; break;
-      case '\f': o += "\\f"; break;
-      case '\v': o += "\\v"; break;
-      default:
-        if (c < 0x20 || c == 0x7f) { char b[8]; snprintf(b, sizeof b, "\\x%02x", c); o += b; }
-        else o.push_back((char)c);
+  char b[16];
+  for (size_t i = 0; i < s.size();) {
+    const unsigned char c = (unsigned char)s[i];
+    if (c < 0x80) {
+      switch (c) {
+        case '"': o += "\\\""; break;
+        case '\\': o += "\\\\"; break;
+        case '\n': o += "\\n"; break;
+        case '\t': o += "\\t"; break;
+        case '\r': o += "\\r"; break;
+        case '\a': o += "\\a"; break;
+        case '\b': o += "\\b"; break;
+        case '\f': o += "\\f"; break;
+        case '\v': o += "\\v"; break;
+        default:
+          if (c < 0x20 || c == 0x7f) { snprintf(b, sizeof b, "\\x%02x", c); o += b; }
+          else o.push_back((char)c);
+      }
+      i++;
+      continue;
     }
+    const int len = c >= 0xF0 ? 4 : c >= 0xE0 ? 3 : c >= 0xC0 ? 2 : 0;
+    uint32_t r = len == 4 ? c & 7u : len == 3 ? c & 15u : c & 31u;
+    bool ok = len != 0 && i + (size_t)len <= s.size();
+    for (int k = 1; ok && k < len; k++) {
+      const unsigned char d = (unsigned char)s[i + (size_t)k];
+      if ((d & 0xC0) != 0x80) ok = false; else r = (r << 6) | (d & 63u);
+    }
+    if (ok && (r < (len == 2 ? 0x80u : len == 3 ? 0x800u : 0x10000u) || r > 0x10FFFF || (r >= 0xD800 && r <= 0xDFFF))) ok = false;
+    if (!ok) { snprintf(b, sizeof b, "\\x%02x", c); o += b; i++; continue; }   // (DecodeRune's RuneError of width 1)
+    if (go_is_print(r)) o.append(s, i, (size_t)len);
+    else { snprintf(b, sizeof b, r < 0x10000 ? "\\u%04x" : "\\U%08x", r); o += b; }
+    i += (size_t)len;
   }
   o.push_back('"');
   return o;

@@ -119,15 +119,127 @@ static bool set_has(const V& s, const VP& x) { return std::binary_search(s.a.beg
 static size_t utf8_len(const std::string& s) { size_t n = 0; for (unsigned char c : s) if ((c & 0xC0) != 0x80) n++; return n; }
 
 // ast term String() (values.py to_string) -- what sprintf("%v") prints
+// BEGIN GENERATED PRINT RANGES
+// GENERATED by tools/gen_unicode_print.py from Python's unicodedata 13.0.0: the code points >= U+0080 that Go's strconv.IsPrint calls
+// printable (categories L, M, N, P, S), as inclusive ranges in ascending order.
+static const uint32_t kIcPrintRanges[][2] = {
+  {0xA1,0xAC}, {0xAE,0x377}, {0x37A,0x37F}, {0x384,0x38A}, {0x38C,0x38C}, {0x38E,0x3A1}, {0x3A3,0x52F}, {0x531,0x556},
+  {0x559,0x58A}, {0x58D,0x58F}, {0x591,0x5C7}, {0x5D0,0x5EA}, {0x5EF,0x5F4}, {0x606,0x61B}, {0x61E,0x6DC}, {0x6DE,0x70D},
+  {0x710,0x74A}, {0x74D,0x7B1}, {0x7C0,0x7FA}, {0x7FD,0x82D}, {0x830,0x83E}, {0x840,0x85B}, {0x85E,0x85E}, {0x860,0x86A},
+  {0x8A0,0x8B4}, {0x8B6,0x8C7}, {0x8D3,0x8E1}, {0x8E3,0x983}, {0x985,0x98C}, {0x98F,0x990}, {0x993,0x9A8}, {0x9AA,0x9B0},
+  {0x9B2,0x9B2}, {0x9B6,0x9B9}, {0x9BC,0x9C4}, {0x9C7,0x9C8}, {0x9CB,0x9CE}, {0x9D7,0x9D7}, {0x9DC,0x9DD}, {0x9DF,0x9E3},
+  {0x9E6,0x9FE}, {0xA01,0xA03}, {0xA05,0xA0A}, {0xA0F,0xA10}, {0xA13,0xA28}, {0xA2A,0xA30}, {0xA32,0xA33}, {0xA35,0xA36},
+  {0xA38,0xA39}, {0xA3C,0xA3C}, {0xA3E,0xA42}, {0xA47,0xA48}, {0xA4B,0xA4D}, {0xA51,0xA51}, {0xA59,0xA5C}, {0xA5E,0xA5E},
+  {0xA66,0xA76}, {0xA81,0xA83}, {0xA85,0xA8D}, {0xA8F,0xA91}, {0xA93,0xAA8}, {0xAAA,0xAB0}, {0xAB2,0xAB3}, {0xAB5,0xAB9},
+  {0xABC,0xAC5}, {0xAC7,0xAC9}, {0xACB,0xACD}, {0xAD0,0xAD0}, {0xAE0,0xAE3}, {0xAE6,0xAF1}, {0xAF9,0xAFF}, {0xB01,0xB03},
+  {0xB05,0xB0C}, {0xB0F,0xB10}, {0xB13,0xB28}, {0xB2A,0xB30}, {0xB32,0xB33}, {0xB35,0xB39}, {0xB3C,0xB44}, {0xB47,0xB48},
+  {0xB4B,0xB4D}, {0xB55,0xB57}, {0xB5C,0xB5D}, {0xB5F,0xB63}, {0xB66,0xB77}, {0xB82,0xB83}, {0xB85,0xB8A}, {0xB8E,0xB90},
+  {0xB92,0xB95}, {0xB99,0xB9A}, {0xB9C,0xB9C}, {0xB9E,0xB9F}, {0xBA3,0xBA4}, {0xBA8,0xBAA}, {0xBAE,0xBB9}, {0xBBE,0xBC2},
+  {0xBC6,0xBC8}, {0xBCA,0xBCD}, {0xBD0,0xBD0}, {0xBD7,0xBD7}, {0xBE6,0xBFA}, {0xC00,0xC0C}, {0xC0E,0xC10}, {0xC12,0xC28},
+  {0xC2A,0xC39}, {0xC3D,0xC44}, {0xC46,0xC48}, {0xC4A,0xC4D}, {0xC55,0xC56}, {0xC58,0xC5A}, {0xC60,0xC63}, {0xC66,0xC6F},
+  {0xC77,0xC8C}, {0xC8E,0xC90}, {0xC92,0xCA8}, {0xCAA,0xCB3}, {0xCB5,0xCB9}, {0xCBC,0xCC4}, {0xCC6,0xCC8}, {0xCCA,0xCCD},
+  {0xCD5,0xCD6}, {0xCDE,0xCDE}, {0xCE0,0xCE3}, {0xCE6,0xCEF}, {0xCF1,0xCF2}, {0xD00,0xD0C}, {0xD0E,0xD10}, {0xD12,0xD44},
+  {0xD46,0xD48}, {0xD4A,0xD4F}, {0xD54,0xD63}, {0xD66,0xD7F}, {0xD81,0xD83}, {0xD85,0xD96}, {0xD9A,0xDB1}, {0xDB3,0xDBB},
+  {0xDBD,0xDBD}, {0xDC0,0xDC6}, {0xDCA,0xDCA}, {0xDCF,0xDD4}, {0xDD6,0xDD6}, {0xDD8,0xDDF}, {0xDE6,0xDEF}, {0xDF2,0xDF4},
+  {0xE01,0xE3A}, {0xE3F,0xE5B}, {0xE81,0xE82}, {0xE84,0xE84}, {0xE86,0xE8A}, {0xE8C,0xEA3}, {0xEA5,0xEA5}, {0xEA7,0xEBD},
+  {0xEC0,0xEC4}, {0xEC6,0xEC6}, {0xEC8,0xECD}, {0xED0,0xED9}, {0xEDC,0xEDF}, {0xF00,0xF47}, {0xF49,0xF6C}, {0xF71,0xF97},
+  {0xF99,0xFBC}, {0xFBE,0xFCC}, {0xFCE,0xFDA}, {0x1000,0x10C5}, {0x10C7,0x10C7}, {0x10CD,0x10CD}, {0x10D0,0x1248}, {0x124A,0x124D},
+  {0x1250,0x1256}, {0x1258,0x1258}, {0x125A,0x125D}, {0x1260,0x1288}, {0x128A,0x128D}, {0x1290,0x12B0}, {0x12B2,0x12B5}, {0x12B8,0x12BE},
+  {0x12C0,0x12C0}, {0x12C2,0x12C5}, {0x12C8,0x12D6}, {0x12D8,0x1310}, {0x1312,0x1315}, {0x1318,0x135A}, {0x135D,0x137C}, {0x1380,0x1399},
+  {0x13A0,0x13F5}, {0x13F8,0x13FD}, {0x1400,0x167F}, {0x1681,0x169C}, {0x16A0,0x16F8}, {0x1700,0x170C}, {0x170E,0x1714}, {0x1720,0x1736},
+  {0x1740,0x1753}, {0x1760,0x176C}, {0x176E,0x1770}, {0x1772,0x1773}, {0x1780,0x17DD}, {0x17E0,0x17E9}, {0x17F0,0x17F9}, {0x1800,0x180D},
+  {0x1810,0x1819}, {0x1820,0x1878}, {0x1880,0x18AA}, {0x18B0,0x18F5}, {0x1900,0x191E}, {0x1920,0x192B}, {0x1930,0x193B}, {0x1940,0x1940},
+  {0x1944,0x196D}, {0x1970,0x1974}, {0x1980,0x19AB}, {0x19B0,0x19C9}, {0x19D0,0x19DA}, {0x19DE,0x1A1B}, {0x1A1E,0x1A5E}, {0x1A60,0x1A7C},
+  {0x1A7F,0x1A89}, {0x1A90,0x1A99}, {0x1AA0,0x1AAD}, {0x1AB0,0x1AC0}, {0x1B00,0x1B4B}, {0x1B50,0x1B7C}, {0x1B80,0x1BF3}, {0x1BFC,0x1C37},
+  {0x1C3B,0x1C49}, {0x1C4D,0x1C88}, {0x1C90,0x1CBA}, {0x1CBD,0x1CC7}, {0x1CD0,0x1CFA}, {0x1D00,0x1DF9}, {0x1DFB,0x1F15}, {0x1F18,0x1F1D},
+  {0x1F20,0x1F45}, {0x1F48,0x1F4D}, {0x1F50,0x1F57}, {0x1F59,0x1F59}, {0x1F5B,0x1F5B}, {0x1F5D,0x1F5D}, {0x1F5F,0x1F7D}, {0x1F80,0x1FB4},
+  {0x1FB6,0x1FC4}, {0x1FC6,0x1FD3}, {0x1FD6,0x1FDB}, {0x1FDD,0x1FEF}, {0x1FF2,0x1FF4}, {0x1FF6,0x1FFE}, {0x2010,0x2027}, {0x2030,0x205E},
+  {0x2070,0x2071}, {0x2074,0x208E}, {0x2090,0x209C}, {0x20A0,0x20BF}, {0x20D0,0x20F0}, {0x2100,0x218B}, {0x2190,0x2426}, {0x2440,0x244A},
+  {0x2460,0x2B73}, {0x2B76,0x2B95}, {0x2B97,0x2C2E}, {0x2C30,0x2C5E}, {0x2C60,0x2CF3}, {0x2CF9,0x2D25}, {0x2D27,0x2D27}, {0x2D2D,0x2D2D},
+  {0x2D30,0x2D67}, {0x2D6F,0x2D70}, {0x2D7F,0x2D96}, {0x2DA0,0x2DA6}, {0x2DA8,0x2DAE}, {0x2DB0,0x2DB6}, {0x2DB8,0x2DBE}, {0x2DC0,0x2DC6},
+  {0x2DC8,0x2DCE}, {0x2DD0,0x2DD6}, {0x2DD8,0x2DDE}, {0x2DE0,0x2E52}, {0x2E80,0x2E99}, {0x2E9B,0x2EF3}, {0x2F00,0x2FD5}, {0x2FF0,0x2FFB},
+  {0x3001,0x303F}, {0x3041,0x3096}, {0x3099,0x30FF}, {0x3105,0x312F}, {0x3131,0x318E}, {0x3190,0x31E3}, {0x31F0,0x321E}, {0x3220,0x9FFC},
+  {0xA000,0xA48C}, {0xA490,0xA4C6}, {0xA4D0,0xA62B}, {0xA640,0xA6F7}, {0xA700,0xA7BF}, {0xA7C2,0xA7CA}, {0xA7F5,0xA82C}, {0xA830,0xA839},
+  {0xA840,0xA877}, {0xA880,0xA8C5}, {0xA8CE,0xA8D9}, {0xA8E0,0xA953}, {0xA95F,0xA97C}, {0xA980,0xA9CD}, {0xA9CF,0xA9D9}, {0xA9DE,0xA9FE},
+  {0xAA00,0xAA36}, {0xAA40,0xAA4D}, {0xAA50,0xAA59}, {0xAA5C,0xAAC2}, {0xAADB,0xAAF6}, {0xAB01,0xAB06}, {0xAB09,0xAB0E}, {0xAB11,0xAB16},
+  {0xAB20,0xAB26}, {0xAB28,0xAB2E}, {0xAB30,0xAB6B}, {0xAB70,0xABED}, {0xABF0,0xABF9}, {0xAC00,0xD7A3}, {0xD7B0,0xD7C6}, {0xD7CB,0xD7FB},
+  {0xF900,0xFA6D}, {0xFA70,0xFAD9}, {0xFB00,0xFB06}, {0xFB13,0xFB17}, {0xFB1D,0xFB36}, {0xFB38,0xFB3C}, {0xFB3E,0xFB3E}, {0xFB40,0xFB41},
+  {0xFB43,0xFB44}, {0xFB46,0xFBC1}, {0xFBD3,0xFD3F}, {0xFD50,0xFD8F}, {0xFD92,0xFDC7}, {0xFDF0,0xFDFD}, {0xFE00,0xFE19}, {0xFE20,0xFE52},
+  {0xFE54,0xFE66}, {0xFE68,0xFE6B}, {0xFE70,0xFE74}, {0xFE76,0xFEFC}, {0xFF01,0xFFBE}, {0xFFC2,0xFFC7}, {0xFFCA,0xFFCF}, {0xFFD2,0xFFD7},
+  {0xFFDA,0xFFDC}, {0xFFE0,0xFFE6}, {0xFFE8,0xFFEE}, {0xFFFC,0xFFFD}, {0x10000,0x1000B}, {0x1000D,0x10026}, {0x10028,0x1003A}, {0x1003C,0x1003D},
+  {0x1003F,0x1004D}, {0x10050,0x1005D}, {0x10080,0x100FA}, {0x10100,0x10102}, {0x10107,0x10133}, {0x10137,0x1018E}, {0x10190,0x1019C}, {0x101A0,0x101A0},
+  {0x101D0,0x101FD}, {0x10280,0x1029C}, {0x102A0,0x102D0}, {0x102E0,0x102FB}, {0x10300,0x10323}, {0x1032D,0x1034A}, {0x10350,0x1037A}, {0x10380,0x1039D},
+  {0x1039F,0x103C3}, {0x103C8,0x103D5}, {0x10400,0x1049D}, {0x104A0,0x104A9}, {0x104B0,0x104D3}, {0x104D8,0x104FB}, {0x10500,0x10527}, {0x10530,0x10563},
+  {0x1056F,0x1056F}, {0x10600,0x10736}, {0x10740,0x10755}, {0x10760,0x10767}, {0x10800,0x10805}, {0x10808,0x10808}, {0x1080A,0x10835}, {0x10837,0x10838},
+  {0x1083C,0x1083C}, {0x1083F,0x10855}, {0x10857,0x1089E}, {0x108A7,0x108AF}, {0x108E0,0x108F2}, {0x108F4,0x108F5}, {0x108FB,0x1091B}, {0x1091F,0x10939},
+  {0x1093F,0x1093F}, {0x10980,0x109B7}, {0x109BC,0x109CF}, {0x109D2,0x10A03}, {0x10A05,0x10A06}, {0x10A0C,0x10A13}, {0x10A15,0x10A17}, {0x10A19,0x10A35},
+  {0x10A38,0x10A3A}, {0x10A3F,0x10A48}, {0x10A50,0x10A58}, {0x10A60,0x10A9F}, {0x10AC0,0x10AE6}, {0x10AEB,0x10AF6}, {0x10B00,0x10B35}, {0x10B39,0x10B55},
+  {0x10B58,0x10B72}, {0x10B78,0x10B91}, {0x10B99,0x10B9C}, {0x10BA9,0x10BAF}, {0x10C00,0x10C48}, {0x10C80,0x10CB2}, {0x10CC0,0x10CF2}, {0x10CFA,0x10D27},
+  {0x10D30,0x10D39}, {0x10E60,0x10E7E}, {0x10E80,0x10EA9}, {0x10EAB,0x10EAD}, {0x10EB0,0x10EB1}, {0x10F00,0x10F27}, {0x10F30,0x10F59}, {0x10FB0,0x10FCB},
+  {0x10FE0,0x10FF6}, {0x11000,0x1104D}, {0x11052,0x1106F}, {0x1107F,0x110BC}, {0x110BE,0x110C1}, {0x110D0,0x110E8}, {0x110F0,0x110F9}, {0x11100,0x11134},
+  {0x11136,0x11147}, {0x11150,0x11176}, {0x11180,0x111DF}, {0x111E1,0x111F4}, {0x11200,0x11211}, {0x11213,0x1123E}, {0x11280,0x11286}, {0x11288,0x11288},
+  {0x1128A,0x1128D}, {0x1128F,0x1129D}, {0x1129F,0x112A9}, {0x112B0,0x112EA}, {0x112F0,0x112F9}, {0x11300,0x11303}, {0x11305,0x1130C}, {0x1130F,0x11310},
+  {0x11313,0x11328}, {0x1132A,0x11330}, {0x11332,0x11333}, {0x11335,0x11339}, {0x1133B,0x11344}, {0x11347,0x11348}, {0x1134B,0x1134D}, {0x11350,0x11350},
+  {0x11357,0x11357}, {0x1135D,0x11363}, {0x11366,0x1136C}, {0x11370,0x11374}, {0x11400,0x1145B}, {0x1145D,0x11461}, {0x11480,0x114C7}, {0x114D0,0x114D9},
+  {0x11580,0x115B5}, {0x115B8,0x115DD}, {0x11600,0x11644}, {0x11650,0x11659}, {0x11660,0x1166C}, {0x11680,0x116B8}, {0x116C0,0x116C9}, {0x11700,0x1171A},
+  {0x1171D,0x1172B}, {0x11730,0x1173F}, {0x11800,0x1183B}, {0x118A0,0x118F2}, {0x118FF,0x11906}, {0x11909,0x11909}, {0x1190C,0x11913}, {0x11915,0x11916},
+  {0x11918,0x11935}, {0x11937,0x11938}, {0x1193B,0x11946}, {0x11950,0x11959}, {0x119A0,0x119A7}, {0x119AA,0x119D7}, {0x119DA,0x119E4}, {0x11A00,0x11A47},
+  {0x11A50,0x11AA2}, {0x11AC0,0x11AF8}, {0x11C00,0x11C08}, {0x11C0A,0x11C36}, {0x11C38,0x11C45}, {0x11C50,0x11C6C}, {0x11C70,0x11C8F}, {0x11C92,0x11CA7},
+  {0x11CA9,0x11CB6}, {0x11D00,0x11D06}, {0x11D08,0x11D09}, {0x11D0B,0x11D36}, {0x11D3A,0x11D3A}, {0x11D3C,0x11D3D}, {0x11D3F,0x11D47}, {0x11D50,0x11D59},
+  {0x11D60,0x11D65}, {0x11D67,0x11D68}, {0x11D6A,0x11D8E}, {0x11D90,0x11D91}, {0x11D93,0x11D98}, {0x11DA0,0x11DA9}, {0x11EE0,0x11EF8}, {0x11FB0,0x11FB0},
+  {0x11FC0,0x11FF1}, {0x11FFF,0x12399}, {0x12400,0x1246E}, {0x12470,0x12474}, {0x12480,0x12543}, {0x13000,0x1342E}, {0x14400,0x14646}, {0x16800,0x16A38},
+  {0x16A40,0x16A5E}, {0x16A60,0x16A69}, {0x16A6E,0x16A6F}, {0x16AD0,0x16AED}, {0x16AF0,0x16AF5}, {0x16B00,0x16B45}, {0x16B50,0x16B59}, {0x16B5B,0x16B61},
+  {0x16B63,0x16B77}, {0x16B7D,0x16B8F}, {0x16E40,0x16E9A}, {0x16F00,0x16F4A}, {0x16F4F,0x16F87}, {0x16F8F,0x16F9F}, {0x16FE0,0x16FE4}, {0x16FF0,0x16FF1},
+  {0x17000,0x187F7}, {0x18800,0x18CD5}, {0x18D00,0x18D08}, {0x1B000,0x1B11E}, {0x1B150,0x1B152}, {0x1B164,0x1B167}, {0x1B170,0x1B2FB}, {0x1BC00,0x1BC6A},
+  {0x1BC70,0x1BC7C}, {0x1BC80,0x1BC88}, {0x1BC90,0x1BC99}, {0x1BC9C,0x1BC9F}, {0x1D000,0x1D0F5}, {0x1D100,0x1D126}, {0x1D129,0x1D172}, {0x1D17B,0x1D1E8},
+  {0x1D200,0x1D245}, {0x1D2E0,0x1D2F3}, {0x1D300,0x1D356}, {0x1D360,0x1D378}, {0x1D400,0x1D454}, {0x1D456,0x1D49C}, {0x1D49E,0x1D49F}, {0x1D4A2,0x1D4A2},
+  {0x1D4A5,0x1D4A6}, {0x1D4A9,0x1D4AC}, {0x1D4AE,0x1D4B9}, {0x1D4BB,0x1D4BB}, {0x1D4BD,0x1D4C3}, {0x1D4C5,0x1D505}, {0x1D507,0x1D50A}, {0x1D50D,0x1D514},
+  {0x1D516,0x1D51C}, {0x1D51E,0x1D539}, {0x1D53B,0x1D53E}, {0x1D540,0x1D544}, {0x1D546,0x1D546}, {0x1D54A,0x1D550}, {0x1D552,0x1D6A5}, {0x1D6A8,0x1D7CB},
+  {0x1D7CE,0x1DA8B}, {0x1DA9B,0x1DA9F}, {0x1DAA1,0x1DAAF}, {0x1E000,0x1E006}, {0x1E008,0x1E018}, {0x1E01B,0x1E021}, {0x1E023,0x1E024}, {0x1E026,0x1E02A},
+  {0x1E100,0x1E12C}, {0x1E130,0x1E13D}, {0x1E140,0x1E149}, {0x1E14E,0x1E14F}, {0x1E2C0,0x1E2F9}, {0x1E2FF,0x1E2FF}, {0x1E800,0x1E8C4}, {0x1E8C7,0x1E8D6},
+  {0x1E900,0x1E94B}, {0x1E950,0x1E959}, {0x1E95E,0x1E95F}, {0x1EC71,0x1ECB4}, {0x1ED01,0x1ED3D}, {0x1EE00,0x1EE03}, {0x1EE05,0x1EE1F}, {0x1EE21,0x1EE22},
+  {0x1EE24,0x1EE24}, {0x1EE27,0x1EE27}, {0x1EE29,0x1EE32}, {0x1EE34,0x1EE37}, {0x1EE39,0x1EE39}, {0x1EE3B,0x1EE3B}, {0x1EE42,0x1EE42}, {0x1EE47,0x1EE47},
+  {0x1EE49,0x1EE49}, {0x1EE4B,0x1EE4B}, {0x1EE4D,0x1EE4F}, {0x1EE51,0x1EE52}, {0x1EE54,0x1EE54}, {0x1EE57,0x1EE57}, {0x1EE59,0x1EE59}, {0x1EE5B,0x1EE5B},
+  {0x1EE5D,0x1EE5D}, {0x1EE5F,0x1EE5F}, {0x1EE61,0x1EE62}, {0x1EE64,0x1EE64}, {0x1EE67,0x1EE6A}, {0x1EE6C,0x1EE72}, {0x1EE74,0x1EE77}, {0x1EE79,0x1EE7C},
+  {0x1EE7E,0x1EE7E}, {0x1EE80,0x1EE89}, {0x1EE8B,0x1EE9B}, {0x1EEA1,0x1EEA3}, {0x1EEA5,0x1EEA9}, {0x1EEAB,0x1EEBB}, {0x1EEF0,0x1EEF1}, {0x1F000,0x1F02B},
+  {0x1F030,0x1F093}, {0x1F0A0,0x1F0AE}, {0x1F0B1,0x1F0BF}, {0x1F0C1,0x1F0CF}, {0x1F0D1,0x1F0F5}, {0x1F100,0x1F1AD}, {0x1F1E6,0x1F202}, {0x1F210,0x1F23B},
+  {0x1F240,0x1F248}, {0x1F250,0x1F251}, {0x1F260,0x1F265}, {0x1F300,0x1F6D7}, {0x1F6E0,0x1F6EC}, {0x1F6F0,0x1F6FC}, {0x1F700,0x1F773}, {0x1F780,0x1F7D8},
+  {0x1F7E0,0x1F7EB}, {0x1F800,0x1F80B}, {0x1F810,0x1F847}, {0x1F850,0x1F859}, {0x1F860,0x1F887}, {0x1F890,0x1F8AD}, {0x1F8B0,0x1F8B1}, {0x1F900,0x1F978},
+  {0x1F97A,0x1F9CB}, {0x1F9CD,0x1FA53}, {0x1FA60,0x1FA6D}, {0x1FA70,0x1FA74}, {0x1FA78,0x1FA7A}, {0x1FA80,0x1FA86}, {0x1FA90,0x1FAA8}, {0x1FAB0,0x1FAB6},
+  {0x1FAC0,0x1FAC2}, {0x1FAD0,0x1FAD6}, {0x1FB00,0x1FB92}, {0x1FB94,0x1FBCA}, {0x1FBF0,0x1FBF9}, {0x20000,0x2A6DD}, {0x2A700,0x2B734}, {0x2B740,0x2B81D},
+  {0x2B820,0x2CEA1}, {0x2CEB0,0x2EBE0}, {0x2F800,0x2FA1D}, {0x30000,0x3134A}, {0xE0100,0xE01EF},
+};
+// END GENERATED PRINT RANGES
+static bool rune_is_print(uint32_t r) {   // strconv.IsPrint for r >= 0x80
+  size_t lo = 0, hi = sizeof kIcPrintRanges / sizeof kIcPrintRanges[0];
+  while (lo < hi) { const size_t mid = (lo + hi) / 2; if (kIcPrintRanges[mid][1] < r) lo = mid + 1; else hi = mid; }
+  return lo < sizeof kIcPrintRanges / sizeof kIcPrintRanges[0] && kIcPrintRanges[lo][0] <= r;
+}
+// strconv.Quote: printable runes as they are, the C escapes, \xNN for other ASCII controls and for bytes that are no UTF-8, \uNNNN /
+// \UNNNNNNNN for every other rune that is not printable (NBSP, format characters, unassigned and private-use code points ...)
 static std::string quote(const std::string& s) {
   std::string o = "\"";
-  char buf[8];
-  for (unsigned char c : s) {
-    switch (c) {
-      case '"': o += "\\\""; break; case '\\': o += "\\\\"; break; case '\n': o += "\\n"; break; case '\t': o += "\\t"; break; case '\r': o += "\\r"; break;
-      case '\a': o += "\\a"; break; case '\b': o += "\\b"; break; case '\f': o += "\\f"; break; case '\v': o += "\\v"; break;
-      default: if (c < 0x20 || c == 0x7F) { snprintf(buf, sizeof buf, "\\x%02x", c); o += buf; } else o.push_back((char)c);
+  char buf[16];
+  for (size_t i = 0; i < s.size();) {
+    const unsigned char c = (unsigned char)s[i];
+    if (c < 0x80) {
+      switch (c) {
+        case '"': o += "\\\""; break; case '\\': o += "\\\\"; break; case '\n': o += "\\n"; break; case '\t': o += "\\t"; break; case '\r': o += "\\r"; break;
+        case '\a': o += "\\a"; break; case '\b': o += "\\b"; break; case '\f': o += "\\f"; break; case '\v': o += "\\v"; break;
+        default: if (c < 0x20 || c == 0x7F) { snprintf(buf, sizeof buf, "\\x%02x", c); o += buf; } else o.push_back((char)c);
+      }
+      i++;
+      continue;
     }
+    int len = c >= 0xF0 ? 4 : c >= 0xE0 ? 3 : c >= 0xC0 ? 2 : 0;
+    uint32_t r = len == 4 ? c & 7u : len == 3 ? c & 15u : c & 31u;
+    bool ok = len && i + (size_t)len <= s.size();
+    for (int k = 1; ok && k < len; k++) { const unsigned char d = (unsigned char)s[i + (size_t)k]; if ((d & 0xC0) != 0x80) ok = false; else r = (r << 6) | (d & 63u); }
+    if (ok && (r < (len == 2 ? 0x80u : len == 3 ? 0x800u : 0x10000u) || r > 0x10FFFF || (r >= 0xD800 && r <= 0xDFFF))) ok = false;   // overlong, out of range, surrogate
+    if (!ok) { snprintf(buf, sizeof buf, "\\x%02x", c); o += buf; i++; continue; }
+    if (rune_is_print(r)) o.append(s, i, (size_t)len);
+    else { snprintf(buf, sizeof buf, r < 0x10000 ? "\\u%04x" : "\\U%08x", r); o += buf; }
+    i += (size_t)len;
   }
   return o + "\"";
 }

@@ -23,6 +23,7 @@ Python representation
 from __future__ import annotations
 
 import math
+import unicodedata
 
 
 class RObj:
@@ -222,16 +223,27 @@ _ESC = {'"': '\\"', "\\": "\\\\", "\n": "\\n", "\t": "\\t", "\r": "\\r", "\a": "
         "\v": "\\v"}
 
 
+def _go_is_print(ch):
+    """strconv.IsPrint / unicode.IsPrint: letters, marks, numbers, punctuation, symbols and the ASCII space"""
+    return ch == " " or unicodedata.category(ch)[0] in "LMNPS"
+
+
 def quote(s):
-    """Go strconv.Quote (what ast.String.String() uses)."""
+    """Go strconv.Quote (what ast.String.String() and fmt's %q use): printable runes as they are, the C escapes, \\xNN for the other
+    ASCII controls, \\uNNNN / \\UNNNNNNNN for every other rune IsPrint refuses (NBSP, format characters, unassigned code points ...)"""
     out = ['"']
     for ch in s:
+        cp = ord(ch)
         if ch in _ESC:
             out.append(_ESC[ch])
-        elif ord(ch) < 0x20 or ord(ch) == 0x7F:
-            out.append("\\x%02x" % ord(ch))
-        else:
+        elif cp < 0x20 or cp == 0x7F:
+            out.append("\\x%02x" % cp)
+        elif cp < 0x80 or _go_is_print(ch):
             out.append(ch)
+        elif 0xD800 <= cp <= 0xDFFF:
+            out.append("\\ufffd")      # (a lone surrogate is no valid rune)
+        else:
+            out.append("\\u%04x" % cp if cp < 0x10000 else "\\U%08x" % cp)
     out.append('"')
     return "".join(out)
 

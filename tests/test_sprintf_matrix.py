@@ -91,3 +91,36 @@ def test_checker_sprintf_equals_the_oracle_on_its_verbs():
         g = sorted(ck.messages(json.dumps(o)).get(0, []))
         bad = [(a, b) for a, b in zip(g, w) if a != b]
         assert len(g) == len(w) == n and not bad, (x, bad[:3])
+
+
+QUOTE_TEMPLATE = {"apiVersion": "templates.gatekeeper.sh/v1", "kind": "ConstraintTemplate", "metadata": {"name": "k8squote"},
+                  "spec": {"crd": {"spec": {"names": {"kind": "K8sQuote"}}},
+                           "targets": [{"target": "admission.k8s.gatekeeper.sh", "rego": """
+package k8squote
+violation[{"msg": msg}] {
+  x := input.review.object.spec.x
+  msg := sprintf("q=%q v=%v arr=%v obj=%v set=%v", [x, x, [x], {"k": x}, {x}])
+}
+"""}]}}
+# control characters, DEL, NBSP and other non-ASCII spaces, format characters (ZWSP, BOM, soft hyphen, word joiner), the replacement
+# character, unassigned and private-use code points, combining marks, supplementary planes: strconv.Quote / IsPrint decide per code point
+CODE_POINTS = [0x9, 0xA, 0xD, 0x7, 0x7F, 0x0, 0x1B, 0xA0, 0x200B, 0xFFFD, 0x1F600, 0x378, 0x22, 0x5C, 0xE9, 0x2028, 0xFEFF, 0xAD, 0xE000, 0x4E2D, 0x301, 0x85,
+               0xE0041, 0x10000, 0x1, 0x1F, 0x27, 0xB, 0xC, 0x8, 0x3000, 0x2003, 0x600, 0x61C, 0xFFF9, 0x10FFFF, 0xD7FF, 0x2060, 0x180E, 0x1D173]
+
+
+def test_string_quoting_three_ways():
+    """%q and the term text of strings inside arrays / objects / sets (ast.String.String() = strconv.Quote): product, oracle, checker"""
+    con = {"apiVersion": "constraints.gatekeeper.sh/v1beta1", "kind": "K8sQuote", "metadata": {"name": "q"}, "spec": {}}
+    objs = [{"apiVersion": "v1", "kind": "Pod", "metadata": {"name": "p%d" % i}, "spec": {"x": "a" + chr(c) + "z"}} for i, c in enumerate(CODE_POINTS)]
+    oc = OC.Client()
+    oc.add_template(QUOTE_TEMPLATE)
+    oc.add_constraint(con)
+    cl = D.Client(D.Driver(device=0, hostemu=True))
+    cl.AddTemplate(QUOTE_TEMPLATE)
+    cl.AddConstraint(con)
+    got = cl.ReviewBatch([D.AugmentedUnstructured(D.Unstructured(o), None, "Original") for o in objs])
+    ck = IndepChecker([QUOTE_TEMPLATE], [con])
+    for c, o, g in zip(CODE_POINTS, objs, got):
+        want = [r.msg for r in oc.review(OT.AugmentedUnstructured(OT.Unstructured(o), None, "Original"), OC.AUDIT_EP)]
+        assert len(want) == 1 and [r.msg for r in g] == want == ck.messages(json.dumps(o)).get(0), hex(c)
+    assert oc.review(OT.AugmentedUnstructured(OT.Unstructured(objs[7]), None, "Original"), OC.AUDIT_EP)[0].msg.startswith('q="a\\u00a0z" v=a z arr=["a\\u00a0z"]')
