@@ -545,7 +545,7 @@ Value b_intersection(ARGS) {
   for (size_t k = 1; k < a[0].size(); k++) { const Value& s = a[0].items()[k]; if (!s.is_set()) return U; ValueVec nx; for (auto& v : cur) if (s.set_has(v)) nx.push_back(v); cur = nx; }
   return Value::set(cur);
 }
-Value b_json_marshal(ARGS) { NEED(1); return Value::string(to_json(a[0])); }
+Value b_json_marshal(ARGS) { NEED(1); std::string o; to_json(a[0], o, /*go_marshal=*/true); return Value::string(o); }   // encoding/json.Marshal(ast.JSON(x))
 Value b_json_unmarshal(ARGS) { NEED(1); STR(0); try { return parse_json(a[0].str()); } catch (const JsonError&) { return U; } }
 Value b_true(ARGS) { (void)a; return Value::boolean(true); }
 

@@ -315,9 +315,20 @@ inline std::string to_term_string(const Value& v) {
 // ---------------------------------------------------------------------------------------------- JSON
 struct JsonError : std::runtime_error { using std::runtime_error::runtime_error; };
 
-inline void json_escape(const std::string& s, std::string& o) {
+// go_marshal: as encoding/json's Marshal writes strings (the json.marshal builtin) -- additionally < > & as \u003c \u003e \u0026
+// (EscapeHTML is on by default) and U+2028 / U+2029 as \u2028 / \u2029
+inline void json_escape(const std::string& s, std::string& o, bool go_marshal = false) {
   o.push_back('"');
-  for (unsigned char c : s) {
+  for (size_t i = 0; i < s.size(); i++) {
+    const unsigned char c = (unsigned char)s[i];
+    if (go_marshal) {
+      if (c == '<' || c == '>' || c == '&') { char b[8]; snprintf(b, sizeof b, "\\u%04x", c); o += b; continue; }
+      if (c == 0xE2 && i + 2 < s.size() && (unsigned char)s[i + 1] == 0x80 && ((unsigned char)s[i + 2] == 0xA8 || (unsigned char)s[i + 2] == 0xA9)) {
+        o += (unsigned char)s[i + 2] == 0xA8 ? "\\u2028" : "\\u2029";
+        i += 2;
+        continue;
+      }
+    }
     switch (c) {
       case '"': o += "\\\""; break;
       case '\\': o += "\\\\"; break;
@@ -335,15 +346,15 @@ inline void json_escape(const std::string& s, std::string& o) {
 }
 
 // JSON text of a value; sets become sorted arrays (OPA ast.JSON), non-string object keys use their term string.
-inline void to_json(const Value& v, std::string& o) {
+inline void to_json(const Value& v, std::string& o, bool go_marshal = false) {
   switch (v.kind) {
     case Value::Null: case Value::Undefined: o += "null"; break;
     case Value::Bool: o += v.b ? "true" : "false"; break;
     case Value::Number: o += num_to_string(v); break;
-    case Value::String: json_escape(*v.s, o); break;
+    case Value::String: json_escape(*v.s, o, go_marshal); break;
     case Value::Array: case Value::Set:
       o.push_back('[');
-      for (size_t k = 0; k < v.arr->size(); k++) { if (k) o.push_back(','); to_json((*v.arr)[k], o); }
+      for (size_t k = 0; k < v.arr->size(); k++) { if (k) o.push_back(','); to_json((*v.arr)[k], o, go_marshal); }
       o.push_back(']');
       break;
     case Value::Object:
@@ -351,9 +362,9 @@ inline void to_json(const Value& v, std::string& o) {
       for (size_t k = 0; k < v.obj->size(); k++) {
         if (k) o.push_back(',');
         const Value& key = (*v.obj)[k].first;
-        json_escape(key.is_string() ? *key.s : to_term_string(key), o);
+        json_escape(key.is_string() ? *key.s : to_term_string(key), o, go_marshal);
         o.push_back(':');
-        to_json((*v.obj)[k].second, o);
+        to_json((*v.obj)[k].second, o, go_marshal);
       }
       o.push_back('}');
       break;

@@ -532,6 +532,40 @@ def go_sprintf(fmt, args):
     return "".join(out)
 
 
+# ---------------------------------------------------------------- json.marshal
+_JSON_SHORT = {'"': '\\"', "\\": "\\\\", "\n": "\\n", "\r": "\\r", "\t": "\\t", "\b": "\\b", "\f": "\\f"}
+
+
+def _go_json_string(s):
+    """encoding/json's string encoder with EscapeHTML on (json.Marshal's default): the short escapes, \\u00NN for the other controls,
+    < > & as \\u003c \\u003e \\u0026, U+2028 / U+2029 escaped; everything else as it is"""
+    out = ['"']
+    for ch in s:
+        if ch in _JSON_SHORT:
+            out.append(_JSON_SHORT[ch])
+        elif ord(ch) < 0x20 or ch in "<>&\u2028\u2029":
+            out.append("\\u%04x" % ord(ch))
+        else:
+            out.append(ch)
+    out.append('"')
+    return "".join(out)
+
+
+def _go_json_marshal(x):
+    """builtinJSONMarshal (topdown/encoding.go): json.Marshal(ast.JSON(x)) -- compact, object keys sorted, numbers as their own text"""
+    if x is None:
+        return "null"
+    if x is True or x is False:
+        return "true" if x else "false"
+    if isinstance(x, (int, float)):
+        return num_to_string(x)
+    if isinstance(x, str):
+        return _go_json_string(x)
+    if isinstance(x, (list, tuple)):
+        return "[" + ",".join(_go_json_marshal(v) for v in x) + "]"
+    return "{" + ",".join(_go_json_string(k) + ":" + _go_json_marshal(x[k]) for k in sorted(x)) + "}"
+
+
 # ---------------------------------------------------------------- builtins
 def b_count(x):
     if isinstance(x, str):
@@ -802,7 +836,7 @@ BUILTINS = {
     "array.concat": lambda a, b: _need(a, "array") + _need(b, "array"),
     "array.slice": b_array_slice, "array.reverse": lambda a: _need(a, "array")[::-1],
     "union": b_union, "intersection": b_intersection,
-    "json.marshal": lambda x: json.dumps(to_json(x), separators=(",", ":"), sort_keys=True, ensure_ascii=False),
+    "json.marshal": lambda x: _go_json_marshal(to_json(x)),
     "json.unmarshal": lambda s: _json_unmarshal(s),
     "print": lambda *a: True, "trace": lambda s: True,
 }

@@ -124,3 +124,33 @@ def test_string_quoting_three_ways():
         want = [r.msg for r in oc.review(OT.AugmentedUnstructured(OT.Unstructured(o), None, "Original"), OC.AUDIT_EP)]
         assert len(want) == 1 and [r.msg for r in g] == want == ck.messages(json.dumps(o)).get(0), hex(c)
     assert oc.review(OT.AugmentedUnstructured(OT.Unstructured(objs[7]), None, "Original"), OC.AUDIT_EP)[0].msg.startswith('q="a\\u00a0z" v=a z arr=["a\\u00a0z"]')
+
+
+MARSHAL_TEMPLATE = {"apiVersion": "templates.gatekeeper.sh/v1", "kind": "ConstraintTemplate", "metadata": {"name": "k8smarshal"},
+                    "spec": {"crd": {"spec": {"names": {"kind": "K8sMarshal"}}},
+                             "targets": [{"target": "admission.k8s.gatekeeper.sh", "rego": """
+package k8smarshal
+violation[{"msg": msg}] {
+  msg := json.marshal({"k": input.parameters.xs, "n": input.parameters.ns, "s": {"b", "a"}})
+}
+"""}]}}
+
+
+def test_json_marshal_writes_strings_as_encoding_json():
+    """json.marshal = encoding/json.Marshal(ast.JSON(x)) (topdown/encoding.go): EscapeHTML is on (< > & escaped), U+2028 / U+2029 escaped,
+    the short escapes, \\u00NN for other controls, DEL and non-ASCII raw; keys sorted, sets as arrays, numbers as their JSON text"""
+    cps = [0x3C, 0x3E, 0x26, 0x2028, 0x2029, 0x7F, 0x1, 0x1F, 0x9, 0xA, 0xD, 0x8, 0xC, 0x22, 0x5C, 0x2F, 0xA0, 0xE9, 0x1F600]
+    con = {"apiVersion": "constraints.gatekeeper.sh/v1beta1", "kind": "K8sMarshal", "metadata": {"name": "m"},
+           "spec": {"parameters": {"xs": ["a" + chr(c) + "z" for c in cps], "ns": [1.5, 1e21, 2.0, 100000000000000000000, 0.000001, 1e-7, -0.5]}}}
+    obj = {"apiVersion": "v1", "kind": "Pod", "metadata": {"name": "p"}}
+    oc = OC.Client()
+    oc.add_template(MARSHAL_TEMPLATE)
+    oc.add_constraint(con)
+    cl = D.Client(D.Driver(device=0, hostemu=True))
+    cl.AddTemplate(MARSHAL_TEMPLATE)
+    cl.AddConstraint(con)
+    want = [r.msg for r in oc.review(OT.AugmentedUnstructured(OT.Unstructured(obj), None, "Original"), OC.AUDIT_EP)]
+    got = [r.msg for r in cl.ReviewBatch([D.AugmentedUnstructured(D.Unstructured(obj), None, "Original")])[0]]
+    text = ('{"k":["a\\\\u003cz","a\\\\u003ez","a\\\\u0026z","a\\\\u2028z","a\\\\u2029z","a\\x7fz","a\\\\u0001z","a\\\\u001fz","a\\\\tz","a\\\\nz","a\\\\rz","a\\\\bz","a\\\\fz",'
+            '"a\\\\"z","a\\\\\\\\z","a/z","a\\xa0z","a\\xe9z","a\\U0001f600z"],"n":[1.5,1e+21,2,100000000000000000000,0.000001,1e-7,-0.5],"s":["a","b"]}')
+    assert got == want == [text.encode().decode("unicode_escape")], (got, want)
