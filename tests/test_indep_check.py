@@ -117,7 +117,8 @@ def test_product_equals_the_compiled_checker_at_sizes_the_python_oracle_does_not
         client.AddConstraint(c)
     batch = synth.NativeBatch(drv.engine.lib, n, seed=synth.SEED + 3, mixed=True, start=0, namespaces=synth.gen_namespaces())
     table = drv.engine.create_table_native(batch.reviews, n, keep_docs=False, resident=True, pruned=True)
-    ev = table.eval(download=True, collect_only=True)
+    table.launch()
+    ev = table.eval(download=True, collect_only=True)      # (the bench's shape: enqueue, then collect)
     ids = [drv.constraint_id(client.constraints[(k["kind"], k["metadata"]["name"])]) for k in cs]
     ck = IndepChecker(ts, cs)
     viol, err = ck.check(batch.reviews, n, threads=4)

@@ -35,6 +35,8 @@ steps = [("review_shapes_20000x52", lambda: T.test_review_shapes_product_equals_
          ("result_totals_corpus_2500", lambda: T.test_result_totals_product_equals_the_compiled_checker("corpus-200", 2500, fx)),
          ("bitmaps_corpus_3000", lambda: T.test_product_equals_the_compiled_checker_at_sizes_the_python_oracle_does_not_reach("corpus-200", 3000, fx)),
          ("messages_corpus_600", lambda: T.test_product_messages_equal_the_compiled_checker("corpus-200", 600, fx))]
+only = [x for x in os.environ.get("GK_CHECK_STEPS", "").split(",") if x]
+steps = [st for st in steps if not only or st[0] in only]
 out = {"backend": "cpu build (dry run)" if ON_CPU else "device", "steps": {}}
 for name, fn in steps:
     if time.time() - t0 > BUDGET_S:
