@@ -367,6 +367,8 @@ void dev_jit_cache_stats(uint64_t* hits, uint64_t* compiles) { *hits = 0; *compi
 void dev_eval_launch(const DevPlan*, const DevTable* dt, const EvalOptions&) { const_cast<DevTable*>(dt)->pending++; }
 void dev_eval(const DevPlan* p, const DevTable* dt, const EvalOptions& opt, EvalOut* o) { dev_eval_launch(p, dt, opt); dev_eval_finish(p, dt, opt, o); }
 void dev_eval_finish(const DevPlan* p, const DevTable* dt, const EvalOptions& opt, EvalOut* o) {
+  // as strict as the device (kernels.hip dev_eval_finish): collecting needs a launch -- a test that forgets it must fail here too
+  if (dt->pending == 0 && dt->t.n_reviews != 0 && !p->fast.slots.empty()) throw std::runtime_error("dev_eval_finish without a pending launch");
   o->n_launches = (uint32_t)dt->pending; const_cast<DevTable*>(dt)->pending = 0;
   o->lds_bytes = p->fast.dims.acc_words * dt->t.rpt * 4;
   const HostTable& t = dt->t;
