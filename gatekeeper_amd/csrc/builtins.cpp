@@ -281,15 +281,15 @@ Value parse_number_str(const std::string& x) {
   if (x.empty()) return U;
   size_t i = 0;
   if (x[i] == '+' || x[i] == '-') i++;
-  size_t digits = 0, dot = 0, exp = 0;
+  size_t digits = 0, dot = 0, exp = 0, exp_digits = 0;
   for (; i < x.size(); i++) {
     char c = x[i];
-    if (isdigit((unsigned char)c)) digits++;
+    if (isdigit((unsigned char)c)) { digits++; exp_digits += exp; }
     else if (c == '.' && !dot && !exp) dot = 1;
     else if ((c == 'e' || c == 'E') && digits && !exp) { exp = 1; if (i + 1 < x.size() && (x[i + 1] == '+' || x[i + 1] == '-')) i++; }
     else return U;
   }
-  if (!digits) return U;
+  if (!digits || (exp && !exp_digits)) return U;   // ("1e", "1e+": strconv.ParseFloat's syntax error)
   if (!dot && !exp && x.size() <= 37) {
     i128 v = 0; size_t k = 0; bool neg = false;
     if (x[0] == '-') { neg = true; k = 1; } else if (x[0] == '+') k = 1;
@@ -459,7 +459,19 @@ Value b_format_int(ARGS) {
   i128 v = a[0].is_int ? a[0].i : (i128)std::floor(a[0].d);
   return Value::string(to_base(v, base, false));
 }
-Value b_reverse(ARGS) { NEED(1); STR(0); std::string s = a[0].str(); std::reverse(s.begin(), s.end()); return Value::string(s); }
+Value b_reverse(ARGS) {   // strings.reverse: rune by rune (builtinReverse converts to []rune)
+  NEED(1); STR(0);
+  const std::string& s = a[0].str();
+  std::string o;
+  o.reserve(s.size());
+  for (size_t end = s.size(); end > 0;) {
+    size_t b = end - 1;
+    while (b > 0 && ((unsigned char)s[b] & 0xC0) == 0x80) b--;
+    o.append(s, b, end - b);
+    end = b;
+  }
+  return Value::string(o);
+}
 Value b_any_prefix(ARGS) {
   NEED(2); std::vector<std::string> ss, bs; if (!to_strs(a[0], &ss) || !to_strs(a[1], &bs)) return U;
   for (auto& s : ss) for (auto& b : bs) if (s.size() >= b.size() && s.compare(0, b.size(), b) == 0) return Value::boolean(true);

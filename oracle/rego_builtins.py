@@ -680,7 +680,9 @@ def b_to_number(x):
     if _isnum(x):
         return x
     if isinstance(x, str):
-        if not re.fullmatch(r"[+-]?(\d+\.?\d*([eE][+-]?\d+)?|\.\d+([eE][+-]?\d+)?|0[xX][0-9a-fA-F]+|[iI]nf|NaN)", x):
+        # builtinToNumber: strconv.ParseFloat's decimal syntax (ASCII digits only); Inf / Infinity / NaN, which ParseFloat would
+        # take, are refused by the builtin itself
+        if not re.fullmatch(r"[+-]?([0-9]+\.?[0-9]*([eE][+-]?[0-9]+)?|\.[0-9]+([eE][+-]?[0-9]+)?)", x):
             raise BuiltinError("to_number: invalid syntax")
         try:
             return int(x)
