@@ -456,8 +456,26 @@ Value b_format_int(ARGS) {
   NEED(2); NUM(0); NUM(1);
   int base = (int)a[1].as_double();
   if (base != 2 && base != 8 && base != 10 && base != 16) return U;
-  i128 v = a[0].is_int ? a[0].i : (i128)std::floor(a[0].d);
-  return Value::string(to_base(v, base, false));
+  if (a[0].is_int) return Value::string(to_base(a[0].i, base, false));
+  // builtinFormatInt (OPA topdown/strings.go, restated): big.Float.Int -- TRUNCATED towards zero (-2.5 -> -2, -0.5 -> 0),
+  // then %b / %o / %d / %x of the big.Int: a float64 beyond 128 bits still prints its exact integer value
+  const double t = std::trunc(a[0].d);
+  if (!std::isfinite(t)) return U;
+  if (std::fabs(t) < 0x1p126) return Value::string(to_base((i128)t, base, false));
+  int e2 = 0;
+  const double m = std::frexp(std::fabs(t), &e2);                  // |t| = m * 2^e2, m in [0.5, 1): 53 bits of m are an integer
+  unsigned long long mant = (unsigned long long)std::ldexp(m, 53);
+  e2 -= 53;
+  std::vector<uint32_t> dig;                                       // little-endian digits in `base`
+  for (; mant; mant /= (unsigned)base) dig.push_back((uint32_t)(mant % (unsigned)base));
+  for (int k = 0; k < e2; k++) {
+    uint32_t carry = 0;
+    for (auto& d : dig) { const uint32_t x = d * 2 + carry; d = x % (uint32_t)base; carry = x / (uint32_t)base; }
+    if (carry) dig.push_back(carry);
+  }
+  std::string o = t < 0 ? "-" : "";
+  for (size_t k = dig.size(); k-- > 0;) o += "0123456789abcdef"[dig[k]];
+  return Value::string(o);
 }
 Value b_reverse(ARGS) {   // strings.reverse: rune by rune (builtinReverse converts to []rune)
   NEED(1); STR(0);
@@ -619,9 +637,11 @@ Value rego_arith(const std::string& op, const Value& a, const Value& b) {
   if (op == "|") { if (!a.is_set() || !b.is_set()) return U; ValueVec o = a.items(); o.insert(o.end(), b.items().begin(), b.items().end()); return Value::set(o); }
   if (!a.is_number() || !b.is_number()) return U;
   bool ii = a.is_int && b.is_int;
-  if (op == "+") return ii ? Value::integer(a.i + b.i) : norm_num(a.as_double() + b.as_double());
-  if (op == "-") return ii ? Value::integer(a.i - b.i) : norm_num(a.as_double() - b.as_double());
-  if (op == "*") return ii ? Value::integer(a.i * b.i) : norm_num(a.as_double() * b.as_double());
+  // (integers are 128-bit here; a result beyond that continues as a float instead of wrapping)
+  i128 r;
+  if (op == "+") return ii && !__builtin_add_overflow(a.i, b.i, &r) ? Value::integer(r) : norm_num(a.as_double() + b.as_double());
+  if (op == "-") return ii && !__builtin_sub_overflow(a.i, b.i, &r) ? Value::integer(r) : norm_num(a.as_double() - b.as_double());
+  if (op == "*") return ii && !__builtin_mul_overflow(a.i, b.i, &r) ? Value::integer(r) : norm_num(a.as_double() * b.as_double());
   if (op == "/") {
     if (b.as_double() == 0) return U;
     if (ii && a.i % b.i == 0) return Value::integer(a.i / b.i);

@@ -50,3 +50,41 @@ violation[{"msg": msg}] {
         assert accepted == {INPUTS.index(x) for x in ("123", "1e3", "+1", "-0", "1.50", ".5", "5.", "1E+2")}
     if name == "reverse":
         assert "%d: %s" % (INPUTS.index("aaz z"), '"z zaa"'.strip('"')) in want
+
+
+NUM_CALLS = [("fi10", "format_int(x, 10)"), ("fi16", "format_int(x, 16)"), ("fi2", "format_int(x, 2)"), ("fi8", "format_int(x, 8)"), ("abs", "abs(x)"), ("round", "round(x)"),
+             ("mod", "x % 3"), ("div", "x / 2"), ("mulf", "x * 0.1"), ("spf", 'sprintf("%f|%.2f|%8.3f|%e|%g|%.0f", [x, x, x, x, x, x])'), ("json", "json.marshal([x, {\"k\": x}])"),
+             ("slice", "array.slice([1, 2, 3, 4], x, 3)"), ("substr", 'substring("abcdef", 1, x)'), ("oget", 'object.get({"1": "a", "k": 2}, x, "dflt")'), ("set", "count({x, 1, 1.0})")]
+NUM_INPUTS = [0, 1, -1, 2, 3, 7, -7, 2.5, -2.5, 0.5, -0.5, 1.5, 3.5, 1000.0, 1e-7, 0.1, 2147483648, 1.0, 100.0, -0.0, 1e6, 12345.678, 4294967296, -3, 255, 0.30000000000000004]
+
+
+@pytest.mark.parametrize("name,expr", NUM_CALLS)
+def test_numeric_builtin_on_awkward_inputs(name, expr):
+    """Numbers either side of zero, halves, integral floats, 2^31 / 2^32: product against the Python oracle.  Found with it:
+    format_int FLOORED a negative fraction (OPA's builtinFormatInt truncates: big.Float.Int), printed 0 for a float beyond
+    128 bits, and integer + - * wrapped beyond 128 bits (now continues as a float)."""
+    kind = "K8sN" + name.title()
+    template = {"apiVersion": "templates.gatekeeper.sh/v1", "kind": "ConstraintTemplate", "metadata": {"name": kind.lower()},
+                "spec": {"crd": {"spec": {"names": {"kind": kind}}}, "targets": [{"target": "admission.k8s.gatekeeper.sh", "rego": """
+package k
+violation[{"msg": msg}] {
+  x := input.parameters.xs[i]
+  r := %s
+  msg := sprintf("%%d: %%v", [i, r])
+}
+""" % expr}]}}
+    xs = NUM_INPUTS + ([1.7976931348623157e308] if name.startswith("fi") else [])
+    con = {"apiVersion": "constraints.gatekeeper.sh/v1beta1", "kind": kind, "metadata": {"name": "c"}, "spec": {"parameters": {"xs": xs}}}
+    obj = {"apiVersion": "v1", "kind": "Pod", "metadata": {"name": "p"}}
+    oc = OC.Client()
+    oc.add_template(template)
+    oc.add_constraint(con)
+    want = sorted(r.msg for r in oc.review(OT.AugmentedUnstructured(OT.Unstructured(obj), None, "Original"), OC.AUDIT_EP))
+    cl = D.Client(D.Driver(device=0, hostemu=True))
+    cl.AddTemplate(template)
+    cl.AddConstraint(con)
+    got = sorted(r.msg for r in cl.ReviewBatch([D.AugmentedUnstructured(D.Unstructured(obj), None, "Original")])[0])
+    assert got == want, [(g, w) for g, w in zip(got, want) if g != w][:3]
+    if name == "fi10":
+        assert "%d: -2" % xs.index(-2.5) in want and "%d: 0" % xs.index(-0.5) in want and "%d: 12345" % xs.index(12345.678) in want
+        assert any(m.startswith("%d: 17976931348623157081452742373170435679807056752584499659891747680315726078" % (len(xs) - 1)) for m in want)
