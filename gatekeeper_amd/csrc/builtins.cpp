@@ -99,9 +99,13 @@ std::string go_sprintf(const std::string& fmt, const ValueVec& argv) {
     std::string flags;
     while (j < n && strchr("-+# 0", fmt[j])) flags.push_back(fmt[j++]);
     int width = -1, prec = -1;
-    if (j < n && isdigit((unsigned char)fmt[j])) { width = 0; while (j < n && isdigit((unsigned char)fmt[j])) width = width * 10 + (fmt[j++] - '0'); }
-    if (j < n && fmt[j] == '.') { j++; prec = 0; while (j < n && isdigit((unsigned char)fmt[j])) prec = prec * 10 + (fmt[j++] - '0'); }
-    if (j >= n) { out += "%!(NOVERB)"; break; }
+    // fmt/print.go parsenum: a number that is already beyond 1e6 when a further digit arrives is "crazy long": the directive -- and with
+    // it the rest of the format -- is given up as %!(NOVERB) (no width or precision of billions ever reaches an allocation)
+    bool too_large = false;
+    auto number = [&](int* v) { *v = 0; while (j < n && isdigit((unsigned char)fmt[j])) { if (*v > 1000000) { too_large = true; return; } *v = *v * 10 + (fmt[j++] - '0'); } };
+    if (j < n && isdigit((unsigned char)fmt[j])) number(&width);
+    if (!too_large && j < n && fmt[j] == '.') { j++; number(&prec); }
+    if (too_large || j >= n) { out += "%!(NOVERB)"; break; }
     char verb = fmt[j++];
     std::string wide;   // a verb beyond ASCII is one whole rune (doPrintf decodes it); never a valid verb
     if ((unsigned char)verb >= 0x80) { wide.push_back(verb); while (j < n && ((unsigned char)fmt[j] & 0xC0) == 0x80) wide.push_back(fmt[j++]); }

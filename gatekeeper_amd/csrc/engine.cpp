@@ -608,7 +608,10 @@ std::shared_ptr<const Template::CountForms> derive_count_forms(gk_engine* e, con
           if (reads && !f->atom.path2.empty()) reads->push_back(pattern_of(f->atom.path2));
           return;
         }
-        if (reads && f->kind == FNode::EXISTS) { SPath el = f->base; Step st; st.iter = true; st.q = f->q; el.push_back(st); reads->push_back(pattern_of(el)); }   // (the element marker rows of a counted array)
+        if (reads && f->kind == FNode::EXISTS) {   // (the element marker rows of a counted array -- and the container's own row: the plan-local guard of a counting loop looks at its type)
+          SPath el = f->base; Step st; st.iter = true; st.q = f->q; el.push_back(st); reads->push_back(pattern_of(el));
+          if (!f->base.empty()) reads->push_back(pattern_of(f->base));
+        }
         for (auto& k : f->kids) walk(k);
       };
       for (auto& f : probe) walk(prepare_constraint(f, mf)->viol);
@@ -853,7 +856,7 @@ int gk_template_add(gk_engine* e, const char* kind, const char* rego, const char
     // nothing: when one of them does not compile the old template and its constraints stay as they are and the caller
     // gets the error (the reference reports it on the ConstraintTemplate's status and keeps serving the old one).
     const std::string k = lower_str(kind);
-    struct Redo { ConstraintRec* c; FP viol; std::shared_ptr<const PreparedConstraint> prep, multi; bool referential; std::shared_ptr<const Template::CountForms> cforms; std::vector<Pattern> reads; };
+    struct Redo { ConstraintRec* c; FP viol; std::shared_ptr<const PreparedConstraint> prep, multi; bool referential; std::shared_ptr<const Template::CountForms> cforms; std::vector<Pattern> reads; Template::CountInfo ci; };
     std::vector<Redo> redo;
     for (auto& c : e->constraints) {
       if (!c.alive || lower_str(c.kind) != k) continue;
@@ -868,10 +871,13 @@ int gk_template_add(gk_engine* e, const char* kind, const char* rego, const char
       PlanCaps caps;
       pb.build(caps);
       r.multi = prepare_multi(e, *t, c.params, c.mf, inv);
-      r.cforms = derive_count_forms(e, ci, c.mf, nullptr, &r.reads);
+      r.ci = ci;
       redo.push_back(std::move(r));
     }
     e->templates[k] = t;
+    // the counting forms register message keys and dictionary atoms with the flattener (every table becomes stale): only now that
+    // every constraint of the kind compiled -- a replacement that is refused leaves the registry as it was (round-4 advisor finding)
+    for (auto& r : redo) r.cforms = derive_count_forms(e, r.ci, r.c->mf, nullptr, &r.reads);
     for (auto& r : redo) { r.c->viol = std::move(r.viol); r.c->prep = std::move(r.prep); r.c->multi_prep = std::move(r.multi); r.c->multi_ready = true; r.c->referential = r.referential; r.c->broken.clear(); r.c->cforms = std::move(r.cforms); r.c->count_reads = std::move(r.reads); r.c->count_ready = false; r.c->count_rows.clear(); r.c->count_flag = nullptr; }
     // (inv_compiled stays as it is: referential constraints of OTHER kinds may still hold an older inventory -- refresh_referential
     // recompiles every one of them at the next evaluation; marking the inventory compiled here left them stale, i.e. missed violations)
@@ -1741,10 +1747,20 @@ static std::vector<uint64_t> render_needed(gk_engine* e, gk_table* t, const std:
   std::vector<uint32_t> count_main;
   // (the groups are launched in waves: each holds a view of the table -- a stream and result buffers of its own)
   const size_t wave = 8;
+  // A PRUNED table holds rows of the published read set only (publish_read_set: the main plans and the counting forms' paths).  A
+  // totals plan that has a predicate on any other path -- the lazily prepared "more than one result?" formulas are not published --
+  // would read "absent" where the object has a value: its rows stay unanswered for this table and their pairs are rendered
+  // (round-4 advisor finding: nothing enforced that compile_multi reads the violation formula's paths only)
+  std::vector<uint8_t> usable(e->totals_groups.size(), 1);
+  if (t->pruned)
+    for (size_t gi = 0; gi < e->totals_groups.size(); gi++)
+      for (const HostPlan* hp : {&e->totals_groups[gi]->fast, &e->totals_groups[gi]->big})
+        for (const Pattern& pat : hp->pred_patterns) if (!e->dict_reg.reads_has(pat)) { usable[gi] = 0; if (getenv("GK_DEBUG_MULTI")) fprintf(stderr, "[gkgpu totals] plan %zu reads %s: not in the pruned table's read set\n", gi, pattern_to_string(pat).c_str()); }
   for (size_t g0 = 0; g0 < e->totals_groups.size(); g0 += wave) {
     const size_t g1 = std::min(e->totals_groups.size(), g0 + wave);
-    for (size_t gi = g0; gi < g1; gi++) dev_eval_launch(e->totals_groups[gi]->dev, t->tviews[gi], opt);
+    for (size_t gi = g0; gi < g1; gi++) if (usable[gi]) dev_eval_launch(e->totals_groups[gi]->dev, t->tviews[gi], opt);
     for (size_t gi = g0; gi < g1; gi++) {
+      if (!usable[gi]) continue;
       EvalOut og;
       dev_eval_finish(e->totals_groups[gi]->dev, t->tviews[gi], opt, &og);
       const gk_engine::Group& G = *e->totals_groups[gi];

@@ -271,6 +271,27 @@ bool DictRegistry::set_reads(const std::vector<Pattern>& pats) {
   reads_gen_++;
   return true;
 }
+// every concrete path `p` matches is matched by `r` as well (sufficient, step by step; not necessary)
+static bool pattern_covers(const Pattern& r, const Pattern& p) {
+  if (r.size() != p.size()) return false;
+  for (size_t i = 0; i < r.size(); i++) {
+    const PatStep &x = r[i], &y = p[i];
+    if (!x.any) { if (y.any || x.key != y.key) return false; continue; }
+    const bool plain = x.only.empty() && x.except.empty() && x.kpreds.empty();
+    if (plain && !x.elems_only) continue;                       // any child at all
+    if (plain && x.elems_only && y.any && y.elems_only) continue;   // any element: whatever the other one asks of elements
+    Pattern a{x}, b{y};
+    if (pattern_to_string(a) != pattern_to_string(b)) return false;   // (the same filters)
+  }
+  return true;
+}
+bool DictRegistry::reads_has(const Pattern& pat) const {
+  // (dictionary rows <leaf>.$d / <leaf>.$c and review.$dup are made by the flattener for every registered entry, pruned table or not)
+  if (!pat.empty() && !pat.back().any && (pat.back().key == "$d" || pat.back().key == "$c" || pat.back().key == "$dup")) return true;
+  std::shared_lock<std::shared_mutex> l(mu_);
+  for (const auto& r : reads_) if (pattern_covers(r.second, pat)) return true;
+  return false;
+}
 void DictRegistry::interest(std::vector<const Pattern*>* out) const {
   for (auto& p : pats_) out->push_back(&p.pat);
   for (auto& g : guards_) out->push_back(&g.second);

@@ -118,6 +118,7 @@ class DictRegistry {
   // pattern of any kind (reads, dictionary leaves, guards, value and key paths) reaches into.  A change of the set makes pruned
   // tables stale (reads_gen), as a new dictionary predicate makes every table stale (gen).
   bool set_reads(const std::vector<Pattern>& pats);   // true: the set changed
+  bool reads_has(const Pattern& pat) const;            // some pattern of the published read set matches every path this one matches
   uint64_t reads_gen() const { return reads_gen_.load(std::memory_order_acquire); }
   // bit 0: rows of `path_id` are read; bit 1: some pattern reaches `path_id` or below it (the parser must visit it)
   uint32_t read_state(const PathDict& dict, uint32_t path_id) const;

@@ -1358,6 +1358,12 @@ bool messages_differ(const Template::CountBranch& x, const Template::CountBranch
   return diff == 1;   // the same format and operands but for ONE constant: the same element prints two different texts
 }
 
+// ... or by their details: two constants that differ make two members whatever the messages say
+bool results_differ(const Template::CountBranch& x, const Template::CountBranch& y) {
+  if (x.dsig != "?" && y.dsig != "?" && x.dsig != y.dsig) return true;
+  return messages_differ(x, y);
+}
+
 typedef Template::CountBranch CB;
 
 std::string path_sig_q(const SPath& p) { std::string o; for (auto& st : p) { if (st.iter) o += "[]"; else { o += "."; o += st.key; } } return o; }
@@ -1447,7 +1453,10 @@ void merge_equal(std::vector<CB>* br) {
     bool mergeable = b.nq <= 1 && (b.is_const || (b.head && !b.sig.empty()));
     if (b.is_const) key = "C|" + b.text;
     else if (mergeable) { for (auto& e : b.sig) { if (e == "?") mergeable = false; key += e; key.push_back('\x1f'); } }
-    if (mergeable) key += "|" + std::to_string(b.nq) + "|" + path_sig_q(b.base);
+    // ... and the same `details`: members that differ in details only stay apart in the set (one result each), so only branches
+    // whose details are the same CONSTANT (or absent) are one branch; details that depend on the review are never merged
+    if (b.dsig == "?") mergeable = false;
+    if (mergeable) key += "|" + std::to_string(b.nq) + "|" + path_sig_q(b.base) + "|D" + b.dsig;
     auto it = mergeable ? at.find(key) : at.end();
     if (!mergeable || it == at.end()) { if (mergeable) at[key] = out.size(); alts.push_back({b.nq == 0 ? b.any : b.body}); out.push_back(std::move(b)); continue; }
     CB& a = out[it->second];
@@ -1507,7 +1516,7 @@ Template::CountForms Template::count_forms(const CountInfo& ci, int kmax) {
   if (br.size() > 24) return cf;   // (too many alternatives for the pairwise terms: ok stays false, compile_multi's answer serves)
   for (size_t i = 0; i < br.size(); i++)
     for (size_t j = i + 1; j < br.size(); j++)
-      if (!messages_differ(br[i], br[j])) cf.flag = f_or(cf.flag, f_and(br[i].any, br[j].any));
+      if (!results_differ(br[i], br[j])) cf.flag = f_or(cf.flag, f_and(br[i].any, br[j].any));
   cf.ok = true;
   return cf;
 }

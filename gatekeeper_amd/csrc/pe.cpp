@@ -2134,7 +2134,31 @@ Template::CountInfo Template::compile_all(const Value& parameters, int* next_qua
     if (!msg) return f_false();
     return f_and(pe.defined_f(e), pe.is_string_f(msg));
   };
+  // a symbolic value that is a constant whatever the review holds (constants nested in object / array constructors)
+  std::function<bool(const SVP&, Value*)> const_of = [&](const SVP& v, Value* out) -> bool {
+    if (!v) return false;
+    if (v->kind == SV::CONST) { *out = v->c; return true; }
+    if (v->kind == SV::OBJ) {
+      std::vector<std::pair<Value, Value>> kv;
+      for (auto& f : v->fields) { Value x; if (!const_of(f.second, &x)) return false; kv.emplace_back(f.first, x); }
+      *out = Value::object(std::move(kv));
+      return true;
+    }
+    if (v->kind == SV::ARR && v->gens.empty()) {
+      std::vector<Value> xs;
+      for (auto& el : v->elems) { Value x; if (el.cond->kind != FNode::T || !const_of(el.v, &x)) return false; xs.push_back(x); }
+      *out = Value::array(std::move(xs));
+      return true;
+    }
+    return false;
+  };
+  auto details_of = [&](const SVP& e, CountBranch* b) {
+    if (e->kind == SV::CONST) { const Value* d = e->c.is_object() ? e->c.get("details") : nullptr; if (d) b->dsig = "C" + to_term_string(*d); return; }
+    if (e->kind != SV::OBJ) return;
+    for (auto& f : e->fields) if (f.first == Value::string("details")) { Value d; b->dsig = const_of(f.second, &d) ? "C" + to_term_string(d) : "?"; }
+  };
   auto head_of = [&](const SVP& e, CountBranch* b) {
+    details_of(e, b);
     SVP m = msg_of(e);
     if (!m) return;
     if (m->kind == SV::CONST && m->c.is_string()) { b->is_const = true; b->text = m->c.str(); return; }
@@ -2220,7 +2244,9 @@ std::vector<Violation> Template::render(const Value& review, const Value& parame
     const Value* d = v.get("details");
     if (d) x.details = *d;
     bool dup = false;
-    for (auto& o : out) if (o.msg == x.msg && ((!o.details.defined() && !x.details.defined()) || (o.details.defined() && x.details.defined() && o.details == x.details))) dup = true;
+    // (a member without details and one with {} are the same result: the driver's hook reports object.get(r, "details", {}))
+    auto empty_obj = [](const Value& d) { return !d.defined() || (d.is_object() && d.size() == 0); };
+    for (auto& o : out) if (o.msg == x.msg && ((empty_obj(o.details) && empty_obj(x.details)) || (o.details.defined() && x.details.defined() && o.details == x.details))) dup = true;
     if (!dup) out.push_back(x);
   }
   return out;

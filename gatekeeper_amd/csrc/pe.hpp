@@ -158,6 +158,9 @@ class Template : public std::enable_shared_from_this<Template> {
     std::string text, pre, sep;   // constant message | literal head | literal behind the key operand
     SPath key;                    // the key operand's leaf (keyed: a leaf of the iteration's element)
     std::vector<std::string> sig;
+    // the member's `details` (the set keeps {msg, details} members apart that differ in details only, pkg/audit/manager.go:902 counts
+    // one result each): "C<term>" a constant ("C{}" when the member has none: the driver reports {}), "?" anything that depends on the review
+    std::string dsig = "C{}";
   };
   struct CountInfo { FP viol; std::vector<CountBranch> br; };
   struct CountForms { bool ok = false; FP flag; FP viol /* the violation formula again, as the OR over the pinned + merged branches: the same truth table in a

@@ -889,9 +889,10 @@ static std::string go_sprintf(const std::string& fmt, const std::vector<VP>& arg
     std::string flags;
     while (j < fmt.size() && strchr("+-# 0", fmt[j])) flags.push_back(fmt[j++]);
     int width = -1, prec = -1;
-    if (j < fmt.size() && fmt[j] >= '0' && fmt[j] <= '9') { width = 0; while (j < fmt.size() && fmt[j] >= '0' && fmt[j] <= '9') width = width * 10 + (fmt[j++] - '0'); }
-    if (j < fmt.size() && fmt[j] == '.') { j++; prec = 0; while (j < fmt.size() && fmt[j] >= '0' && fmt[j] <= '9') prec = prec * 10 + (fmt[j++] - '0'); }
-    if (j >= fmt.size()) { o += "%!(NOVERB)"; break; }
+    bool too_large = false;   // (fmt parsenum: beyond 1e6 with a further digit to come, the directive and the rest of the format are %!(NOVERB))
+    if (j < fmt.size() && fmt[j] >= '0' && fmt[j] <= '9') { width = 0; while (j < fmt.size() && fmt[j] >= '0' && fmt[j] <= '9') { if (width > 1000000) { too_large = true; break; } width = width * 10 + (fmt[j++] - '0'); } }
+    if (!too_large && j < fmt.size() && fmt[j] == '.') { j++; prec = 0; while (j < fmt.size() && fmt[j] >= '0' && fmt[j] <= '9') { if (prec > 1000000) { too_large = true; break; } prec = prec * 10 + (fmt[j++] - '0'); } }
+    if (too_large || j >= fmt.size()) { o += "%!(NOVERB)"; break; }
     std::string verb_rune(1, fmt[j]);   // the verb is the next rune, whatever it is
     while (j + 1 < fmt.size() && (unsigned char)verb_rune[0] >= 0x80 && ((unsigned char)fmt[j + 1] & 0xC0) == 0x80) verb_rune.push_back(fmt[++j]);
     const char verb = verb_rune.size() == 1 ? verb_rune[0] : '\0';

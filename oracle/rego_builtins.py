@@ -501,6 +501,16 @@ def _format_operand(verb, flags, width, prec, kind, val):
     return "%%!%s(%s=%s)" % (verb, kind, _as_v(flags, width, prec, kind, val))
 
 
+def _too_large(digits):
+    """parsenum's overflow rule: tooLarge(num) is asked before every further digit"""
+    num = 0
+    for ch in digits or "":
+        if num > 1000000:
+            return True
+        num = num * 10 + ord(ch) - 48
+    return False
+
+
 def go_sprintf(fmt, args):
     args = [_go_arg(a) for a in args]
     out = []
@@ -510,6 +520,12 @@ def go_sprintf(fmt, args):
         out.append(fmt[pos:m.start()])
         pos = m.end()
         flags, width, prec, verb = m.group(1), m.group(2), m.group(3), m.group(4)
+        if _too_large(width) or _too_large(prec):
+            # fmt/print.go parsenum: a number already beyond 1e6 with a further digit to come gives up the directive AND the rest
+            # of the format (it returns the format's end as the next position): %!(NOVERB), then the operands are all EXTRA
+            out.append("%!(NOVERB)")
+            pos = len(fmt)
+            break
         if verb is None:
             out.append("%!(NOVERB)")
             continue

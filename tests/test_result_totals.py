@@ -277,3 +277,61 @@ def test_counting_is_switched_off_by_its_knob(monkeypatch):
     monkeypatch.setenv("GK_COUNT_KMAX", "0")
     _, _, _, rendered_multi, _ = run_totals("hostemu", COUNTED, COUNT_OBJS)
     assert rendered_counted < rendered_multi
+
+
+# members of the violation set that differ in `details` ONLY are different results (the set holds {msg, details} objects; the
+# driver reports one types.Result per member, pkg/audit/manager.go:902 counts each): round-4 advisor finding -- branches were
+# merged by the message's signature alone and three unrolled parameter alternatives with one constant message counted once
+DETAILS = {
+    # one constant message, details from an unrolled parameter: a result per label
+    "K8sDetailsPerParam": ('''package k
+violation[{"msg": "label team missing", "details": {"label": l}}] {
+  l := input.parameters.labels[_]
+  not input.review.object.metadata.labels.team
+}
+''', {"labels": ["a", "b", "c"]}),
+    # two bodies that print the same formatted message with different constant details
+    "K8sDetailsTwoBodies": ('''package k
+violation[{"msg": msg, "details": {"why": "network"}}] {
+  input.review.object.spec.hostNetwork
+  msg := sprintf("pod %v shares a host namespace", [input.review.object.metadata.name])
+}
+violation[{"msg": msg, "details": {"why": "pid"}}] {
+  input.review.object.spec.hostPID
+  msg := sprintf("pod %v shares a host namespace", [input.review.object.metadata.name])
+}
+''', {}),
+    # ... the SAME constant details: one member however many bodies produce it
+    "K8sDetailsEqual": ('''package k
+violation[{"msg": "shares a host namespace", "details": {"n": 1}}] { input.review.object.spec.hostNetwork }
+violation[{"msg": "shares a host namespace", "details": {"n": 1}}] { input.review.object.spec.hostPID }
+''', {}),
+    # details that depend on the review, one constant message, two bodies: members differ iff the details do
+    "K8sDetailsFromReview": ('''package k
+violation[{"msg": "host namespace", "details": {"v": input.review.object.spec.hostNetwork}}] { input.review.object.spec.hostNetwork }
+violation[{"msg": "host namespace", "details": {"v": input.review.object.spec.hostPID}}] { input.review.object.spec.hostPID }
+''', {}),
+    # absent details and an explicit {} are the same member (the driver reports {} for both)
+    "K8sDetailsAbsentOrEmpty": ('''package k
+violation[{"msg": "host namespace"}] { input.review.object.spec.hostNetwork }
+violation[{"msg": "host namespace", "details": {}}] { input.review.object.spec.hostPID }
+''', {}),
+}
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_members_that_differ_in_details_only_are_counted_apart(backend):
+    objs = [
+        pod("clean", [ctr("a")], labels={"team": "x"}),
+        pod("no-team", [ctr("a")]),
+        pod("net", [ctr("a")], hostNetwork=True),
+        pod("pid", [ctr("a")], hostPID=True, labels={"team": "x"}),
+        pod("both", [ctr("a")], hostNetwork=True, hostPID=True),
+        pod("both-with-team", [ctr("a")], hostNetwork=True, hostPID=True, labels={"team": "x"}),
+    ]
+    refused, want, want_pairs, rendered, rendered_all = run_totals(backend, DETAILS, objs)
+    assert not refused
+    assert want["K8sDetailsPerParam"] == 3 * len(want_pairs["K8sDetailsPerParam"])       # three labels, three results
+    assert want["K8sDetailsTwoBodies"] == len(want_pairs["K8sDetailsTwoBodies"]) + 2     # "both" and "both-with-team" yield two
+    assert want["K8sDetailsEqual"] == len(want_pairs["K8sDetailsEqual"])                 # equal members collapse
+    assert want["K8sDetailsFromReview"] == len(want_pairs["K8sDetailsFromReview"])       # {"v": true} twice is one member

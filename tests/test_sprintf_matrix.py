@@ -26,7 +26,10 @@ KNOWN = [("%g", [1234567.25], "1.23456725e+06"), ("%.3d", [7], "007"), ("%8.3d",
          ("%5%", [], "%"), ("%-08d|", [42], "42      |"), ("%+08d", [42], "+0000042"), ("%08v", [1.5], "000001.5"), ("%b", [-5], "-101"),
          ("%o", [64], "100"), ("%#X", [255], "0XFF"), ("%.2x", ["hello"], "6865"), ("%v", [1e21], "1e+21"), ("%v", [1e6], "1000000"),
          ("%v", [1234567.25], "1.23456725e+06"), ("%s", [1], "%!s(int=1)"), ("%d", [1.5], "%!d(float64=1.5)"), ("%v", [2.0], "2"),
-         ("%v %v", [1, 2, "x"], "1 2%!(EXTRA string=x)"), ("%é", [1], "%!é(int=1)"), ("100%%", [], "100%"), ("%v", [[1, "a"]], '[1, "a"]'), ("%T %T %T", [1, 1.5, "s"], "int float64 string"), ("%p", [1], "%!p(int=1)")]
+         ("%v %v", [1, 2, "x"], "1 2%!(EXTRA string=x)"), ("%é", [1], "%!é(int=1)"), ("100%%", [], "100%"), ("%v", [[1, "a"]], '[1, "a"]'), ("%T %T %T", [1, 1.5, "s"], "int float64 string"), ("%p", [1], "%!p(int=1)"),
+         # fmt/print.go parsenum gives a width / precision up once it is beyond 1e6 with a further digit to come -- the directive AND the rest of the
+         # format (no allocation of gigabytes): round-4 advisor finding
+         ("a%99999999dz", [1], "a%!(NOVERB)%!(EXTRA int=1)"), ("%.20000000000f|", [1.5], "%!(NOVERB)%!(EXTRA float64=1.5)"), ("%7d|", [1], "      1|")]
 
 
 @pytest.mark.parametrize("fmt,args,want", KNOWN)
@@ -47,7 +50,7 @@ violation[{"msg": msg}] {
 }
 """}]}}
 MODS = ("", "8", "-8", "08", "+", ".2", "8.3", "#", " ", "+.1", "-12.4", "+08", ".0", "# ")
-MALFORMED = ["%", "%%", "100%", "%!", "% d", "%5%", "%z", "%v %v %v", "é%3vé", "%é", "%-", "%8", "%.", "%.3"]
+MALFORMED = ["%", "%%", "100%", "%!", "% d", "%5%", "%z", "%v %v %v", "é%3vé", "%é", "%-", "%8", "%.", "%.3", "x%123456789dy", "%.99999999999s tail %v"]
 OPERANDS = [0, 1, -7, 255, 65, 1.5, -3.25, 1e21, 1e-7, 0.000123, 123456789012, 1234567.25, 100000.5, 2.5, 0.5, "str", "", "héllo wörld", "a\"b\\c\n",
             True, False, None, [1, 2.5, "a"], {"a": 1}, 9007199254740993, 5e-324, 1.7976931348623157e308, 0x1F600, 128, -1]
 
