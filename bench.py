@@ -121,6 +121,93 @@ def indep_leg(templates, constraints, batch, ev, ids=None, budget_s=8.0, n=None)
     return base, parity
 
 
+def strided_words(n, want_objects, edge_words=2048):
+    """bitmap words (64 objects each) of an n-object table to re-evaluate: the first, the middle and the last `edge_words` words --
+    the table's first, middle and LAST row groups, where 32-bit row / heap offsets and tile indices are largest -- plus evenly
+    spread words in between until about `want_objects` objects are covered.  Sorted, distinct."""
+    import numpy as np
+    words = (n + 63) // 64
+    if words * 64 <= want_objects or words <= 3 * edge_words:
+        return np.arange(words, dtype=np.int64)
+    mid = words // 2 - edge_words // 2
+    fixed = np.concatenate([np.arange(edge_words), np.arange(mid, mid + edge_words), np.arange(words - edge_words, words)])
+    rest = max(0, want_objects // 64 - len(fixed))
+    spread = np.linspace(edge_words, words - edge_words - 1, num=rest, dtype=np.int64) if rest else np.zeros(0, np.int64)
+    return np.unique(np.concatenate([fixed, spread]).astype(np.int64))
+
+
+def strided_indep_leg(templates, constraints, batch, ev, ids=None, want_objects=1 << 20, known_prefix=None, edge_words=2048):
+    """The independent compiled checker (oracle/libgkindep.so) over a STRIDED sample of a table too large to re-evaluate whole in
+    the default run (configs[3]'s N = 1 point: 10 M objects): whole 64-object bitmap words -- the first, middle and last 2048 words
+    and an even spread between them -- are re-evaluated from the batch's JSON text and compared, word for word, with the device's
+    violation and autoreject bitmaps; per constraint the pair totals over the sample must agree as well.  known_prefix: (n, [pairs
+    per constraint]) of a table of the first n objects of the same stream checked in full elsewhere (configs[2]): the device's
+    popcounts over the first n objects of THIS table must reproduce them.
+    Reference loop being restated: /root/reference/pkg/audit/manager.go:591-642."""
+    import ctypes as C
+    import numpy as np
+    from gatekeeper_amd import _lib as L
+    from oracle.indep_check import IndepChecker
+    n = batch.n
+    sel = strided_words(n, want_objects, edge_words)
+    m = 0
+    src = batch.reviews
+    arr = (L.gk_review_in * (len(sel) * 64))()
+    sz = C.sizeof(L.gk_review_in)
+    base = C.addressof(src.contents)
+    spans = []            # (first sample object, first table word, words) of every run of consecutive words
+    run0 = 0
+    for i in range(1, len(sel) + 1):
+        if i == len(sel) or sel[i] != sel[i - 1] + 1:
+            w0, nw = int(sel[run0]), i - run0
+            cnt = min(nw * 64, n - w0 * 64)
+            C.memmove(C.addressof(arr) + m * sz, base + w0 * 64 * sz, cnt * sz)
+            spans.append((m, w0, nw))
+            m += nw * 64 if cnt == nw * 64 else cnt
+            run0 = i
+    cores = int(batch.lib.gk_host_cpus()) or os.cpu_count() or 1
+    ck = IndepChecker(templates, constraints)
+    t0 = time.perf_counter()
+    viol, err, results = ck.check_totals(arr, m, cores)
+    seconds = time.perf_counter() - t0
+    ck.close()
+    row_of = {int(cid): i for i, cid in enumerate(ev.constraint_ids)}
+    cids = list(ids if ids is not None else batch_constraint_ids)
+    equal, dev_pairs, ck_pairs, dev_err, ck_err, totals_equal = True, 0, 0, 0, 0, True
+    first_bad = None
+    tail_word = (n // 64) if n % 64 else -1
+    tail = np.uint64((1 << (n % 64)) - 1)
+    for row, cid in enumerate(cids):
+        dv_all, de_all = ev.viol[row_of[cid]], ev.err[row_of[cid]]
+        d_v, d_e = np.array(dv_all[sel], copy=True), np.array(de_all[sel], copy=True)
+        if tail_word >= 0 and sel[-1] == tail_word:
+            d_v[-1] &= tail
+            d_e[-1] &= tail
+        c_v, c_e = viol[row][:len(sel)], err[row][:len(sel)]
+        same = bool((d_v == c_v).all()) and bool((d_e == c_e).all())
+        if not same and first_bad is None:
+            k = int(np.nonzero((d_v != c_v) | (d_e != c_e))[0][0])
+            first_bad = {"constraint": "%s/%s" % (constraints[row]["kind"], constraints[row]["metadata"]["name"]), "table_word": int(sel[k]),
+                         "device": "%016x" % int(d_v[k]), "checker": "%016x" % int(c_v[k])}
+        equal = equal and same
+        a, b = int(np.unpackbits(d_v.view(np.uint8)).sum()), int(np.unpackbits(c_v.view(np.uint8)).sum())
+        totals_equal = totals_equal and a == b
+        dev_pairs += a; ck_pairs += b
+        dev_err += int(np.unpackbits(d_e.view(np.uint8)).sum()); ck_err += int(np.unpackbits(c_e.view(np.uint8)).sum())
+    out = {"n": int(m), "of": int(n), "words": int(len(sel)), "runs": len(spans), "first_word": int(sel[0]), "last_word": int(sel[-1]), "table_words": (n + 63) // 64,
+           "constraints": len(cids), "pairs_equal": equal, "per_constraint_totals_equal": totals_equal,
+           "device_violating_pairs": dev_pairs, "checker_violating_pairs": ck_pairs, "device_autoreject_pairs": dev_err, "checker_autoreject_pairs": ck_err,
+           "checker_results": int(results.sum()), "seconds": seconds, "threads": cores, "first_difference": first_bad,
+           "checker": "oracle/indep_check.cpp -> oracle/libgkindep.so (independent of the product) over a strided sample: the first, middle and last 2048 bitmap "
+                      "words of the table and an even spread between them, every object of those words, bit for bit, plus the per-constraint pair totals of the sample"}
+    if known_prefix is not None and known_prefix[0] <= n and known_prefix[0] % 64 == 0:
+        pw = known_prefix[0] // 64
+        mine = [int(np.unpackbits(np.ascontiguousarray(ev.viol[row_of[cid]][:pw]).view(np.uint8)).sum()) for cid in cids]
+        out["prefix_totals"] = {"objects": int(known_prefix[0]), "equal": mine == [int(x) for x in known_prefix[1]], "pairs": int(sum(mine)),
+                                "what": "device popcounts per constraint over the first %d objects of this table against the fully checked table of the same objects" % known_prefix[0]}
+    return out
+
+
 def totals_against_checker(table, parity, ids=None):
     """gk_table_totals of the timed table (RESULTS per constraint: device counts + host rendering of the flagged pairs) against the
     RESULT totals the independent compiled checker counted in its pass over the same objects (indep_leg).  parity: indep_leg's record;
@@ -337,7 +424,8 @@ def totals_leg(table):
                     "messages' heads and flags the others, the host renders those only; checked against rendering every violating pair"}
 
 
-def side_point(config, reviews, steps, warmup, oracle_n, dev_index, fx, nss, with_stream=False, stream_args=None, dev=None, totals=False, n_templates=200):
+def side_point(config, reviews, steps, warmup, oracle_n, dev_index, fx, nss, with_stream=False, stream_args=None, dev=None, totals=False, n_templates=200,
+               strided_n=0, known_prefix=None):
     """One more BASELINE config measured the way the headline one is -- its own engine, policy set and resident table --
     for the `other_configs` of the default bench line: `steps` sweeps of the table in HBM between two synchronisations,
     the dominant kernel's duration from per-launch HIP events, and (oracle_n > 0) the INDEPENDENT parity leg: the device
@@ -404,6 +492,11 @@ def side_point(config, reviews, steps, warmup, oracle_n, dev_index, fx, nss, wit
                       "reviews_per_s": reviews / (st["flatten_s"] + st["upload_s"])},
            "policy_load_s": t_pol, "first_sweep_s": t_first, "violating_pairs": int(final.counts.sum()), "reviews_beyond_limits": len(final.too_big_reviews())}
     oracle = None
+    if strided_n > 0:   # a table too large for the whole-table legs: the compiled checker over a strided sample (first / middle / last row groups included)
+        try:
+            out["parity_compiled_independent"] = strided_indep_leg(templates, constraints, batch, final, ids=ids, want_objects=strided_n, known_prefix=known_prefix)
+        except Exception as ex:   # noqa: BLE001
+            out["parity_compiled_independent"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
     if oracle_n > 0:
         try:
             n = min(oracle_n, reviews) // 64 * 64
@@ -459,7 +552,7 @@ def side_point(config, reviews, steps, warmup, oracle_n, dev_index, fx, nss, wit
     return out, stream
 
 
-def other_configs(args, dev_index, dev, fx, nss, budget_s=200.0):
+def other_configs(args, dev_index, dev, fx, nss, budget_s=200.0, known_prefix=None):
     """configs[1], configs[4] (resident + streaming) and the N = 1 point of configs[3], each in its own engine; a leg is skipped
     (and says so) once the budget is spent so that the default run stays within a few minutes."""
     t_start = time.perf_counter()
@@ -494,7 +587,7 @@ def other_configs(args, dev_index, dev, fx, nss, budget_s=200.0):
                 "GBs": _sig(rf["achieved"]), "groups": d["plan_groups"], "parity": parity_brief(d.get("parity_python_oracle")),
                 "compiled": {k: (_sig(v, 3) if isinstance(v, float) else v) for k, v in (d.get("parity_compiled_independent") or {}).items() if k in ("n", "pairs_equal", "seconds", "error")},
                 "messages": {k: v for k, v in (d.get("parity_messages_compiled_independent") or {}).items() if k in ("objects", "messages", "messages_equal", "error")},
-                "leg_s": _sig(d["leg_seconds"], 3)}
+                "leg_s": _sig(d["leg_seconds"], 3), "first_sweep_s": _sig(d.get("first_sweep_s"), 3)}
     r = run("configs1", lambda: side_point(1, 100000, max(args.steps, 50), args.warmup, args.side_oracle_sample, dev_index, fx, nss))
     if r:
         detail["configs1"], brief["configs1"] = r[0], resident_brief(r[0])
@@ -516,12 +609,17 @@ def other_configs(args, dev_index, dev, fx, nss, budget_s=200.0):
                                         "compiled": {k: (_sig(v, 3) if isinstance(v, float) else v) for k, v in (r[1].get("parity_compiled_independent") or {}).items() if k in ("n", "pairs_equal", "seconds", "error")}}
         else:
             brief["configs4_stream"] = r[1]
-    r = run("configs3_n1", lambda: side_point(2, 10000000, max(args.steps, 20), 3, 0, dev_index, fx, nss))
+    r = run("configs3_n1", lambda: side_point(2, 10000000, max(args.steps, 20), 3, 0, dev_index, fx, nss, strided_n=args.strided_sample, known_prefix=known_prefix))
     if r:
         d = r[0]
         d["note"] = "the origin of configs[3]'s strong-scaling curve: all 10 M objects on ONE MI355X (N > 1: bench.py --gpus N --scaling strong --reviews 10000000); the table is far beyond the 256 MiB Infinity Cache"
         detail["configs3_n1"] = d
         brief["configs3_n1"] = dict(resident_brief(d), ingest_s=_sig(d["ingest"]["flatten_s"] + d["ingest"]["h2d_s"], 3), table_GB=_sig(d["table_bytes"] / 1e9, 3))
+        pc = d.get("parity_compiled_independent") or {}
+        # (`parity`: the leg this table has -- the compiled checker over the strided sample, incl. the first, middle and last row groups)
+        brief["configs3_n1"]["parity"] = ({"error": pc["error"][:80]} if "error" in pc else
+                                          {"n": pc.get("n"), "equal": pc.get("pairs_equal"), "totals_equal": pc.get("per_constraint_totals_equal"), "pairs": pc.get("checker_violating_pairs"),
+                                           "last_word": pc.get("last_word"), "table_words": pc.get("table_words"), "prefix_1M_equal": (pc.get("prefix_totals") or {}).get("equal"), "s": _sig(pc.get("seconds"), 3)}) if pc else None
     return detail, brief
 
 
@@ -548,7 +646,33 @@ def main():
                     "paths the loaded constraints read; the kernel's algorithmic bytes are the same, the ingest and the table are not")
     ap.add_argument("--no-other-configs", action="store_true", help="only the headline workload (the default run adds configs[1], configs[4] resident + streaming "
                     "and the N = 1 point of configs[3] as `other_configs`, each with its own parity leg)")
+    ap.add_argument("--strided-sample", type=int, default=1 << 20, help="objects of the 10 M-object configs[3] table the independent compiled checker re-evaluates "
+                    "(whole bitmap words: the first, middle and last 2048 words + an even spread)")
+    ap.add_argument("--test-hostemu", action="store_true", help="TEST ONLY (tests/test_bench_dist.py): the CPU emulation build of the engine and gloo instead of an MI355X "
+                    "and RCCL, to exercise this file's sharded path in the GPU-less build container; the line says so (`emulated`) and is not a measurement")
     args = ap.parse_args()
+    # ---- ranks.  The driver starts N > 1 as `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` (WORLD_SIZE set);
+    # a bare `python bench.py --gpus N` starts its own N ranks the same way.  Either way the line is printed only if the job really
+    # has N ranks: a world size that differs from --gpus is an error (exit 2), never a silent N = 1 line.
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        import subprocess
+        if not args.test_hostemu:
+            import torch
+            have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+            if have < args.gpus:
+                sys.stderr.write("bench.py --gpus %d: only %d GPU(s) visible on this box -- refusing to print a line for fewer ranks than asked for\n" % (args.gpus, have))
+                sys.exit(2)
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1", "--master-port", str(port),
+               os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    if env_world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE): refusing to print a line for another job size\n" % (args.gpus, env_world))
+        sys.exit(2)
     want_others = args.config is None and not args.no_other_configs and not args.lean and not args.streaming and args.scaling == "weak" and args.reviews is None
     if args.config is None:
         args.config = 2
@@ -560,17 +684,28 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    emu = bool(args.test_hostemu)
     if world > 1 or os.environ.get("GK_FORCE_DIST"):   # GK_FORCE_DIST=1: exercise the sharded path on one GPU (world size 1)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    assert torch.cuda.is_available(), "bench.py needs an MI355X (there is no CPU fallback)"
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
+        if emu:
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if dist.get_world_size() != args.gpus:
+            sys.stderr.write("bench.py: --gpus %d but the process group has %d rank(s)\n" % (args.gpus, dist.get_world_size()))
+            sys.exit(2)
+    if emu:
+        dev = torch.device("cpu")
+        torch.cuda.synchronize = lambda *a, **k: None   # (this process only: the emulation has no device to wait for)
+    else:
+        assert torch.cuda.is_available(), "bench.py needs an MI355X (there is no CPU fallback)"
+        dev = torch.device("cuda", local_rank)
+        torch.cuda.set_device(dev)
 
     from gatekeeper_amd import driver as D
     from gatekeeper_amd import synth
@@ -590,7 +725,7 @@ def main():
         start, n_local = rank * args.reviews, args.reviews
         total_reviews = args.reviews * world
 
-    drv = D.Driver(device=local_rank, hostemu=False)
+    drv = D.Driver(device=local_rank, hostemu=emu)
     client = D.Client(drv)
     for t in templates:
         client.AddTemplate(t)
@@ -641,6 +776,11 @@ def main():
         st_again = again.stats()
         again.free()
     sweep = ShardedSweep(client, table=table, n=n_local, dist=dist, device=dev)
+    # the job size as the engine's communicator itself reports it (ncclCommCount): must be the --gpus asked for on EVERY rank
+    rccl_rank, rccl_ranks = sweep.comm_info() if dist is not None else (0, None)
+    if dist is not None and (rccl_ranks != args.gpus or rccl_rank != rank):
+        sys.stderr.write("bench.py rank %d: the engine's communicator reports rank %d of %d, --gpus is %d\n" % (rank, rccl_rank, rccl_ranks, args.gpus))
+        sys.exit(2)
 
     def barrier():
         if dist is not None:
@@ -695,7 +835,9 @@ def main():
             "metric": "AdmissionReview x constraint evals/sec",
             "value": evals / dt, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-            "dtype": "u32", "data": "synthetic",
+            "dtype": "u32", "data": "synthetic" if not emu else "synthetic -- CPU EMULATION of the kernels (--test-hostemu): plumbing test, not a measurement",
+            # ranks of the engine's own communicator, read back from RCCL (ncclCommCount) after gk_comm_init; null: one process, no exchange step
+            "rccl_ranks": rccl_ranks,
             "config": {"workload": cfg_name, "constraints": nc, "reviews_total": total_reviews, "reviews_rank0": n_local,
                        "rows_rank0": int(res.n_rows), "rows_read_rank0": int(res.n_rows_read), "table_bytes_rank0": int(st["device_bytes"]),
                        "timed_region_s": dt,
@@ -725,6 +867,8 @@ def main():
                                                                                         "json_MBps": st_again["json_bytes"] / st_again["flatten_s"] / 1e6 if st_again["flatten_s"] > 0 else None},
                            "generate_s": t_gen},
         }
+        if emu:
+            out["emulated"] = True
         # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes of this same command (bench.py
         # cannot run a profiler around itself); only reported when the profiled workload is the one just timed
         try:
@@ -774,7 +918,9 @@ def main():
             sweep = table = batch = None   # (the headline table and its text leave HBM / host memory before the 10 M-object point)
             import gc
             gc.collect()
-            detail, brief = other_configs(args, local_rank, dev, fx, nss)
+            row_of0 = {int(cid): i for i, cid in enumerate(final.constraint_ids)}
+            known = (n_local, [int(counts[row_of0[cid]]) for cid in batch_constraint_ids]) if n_local % 64 == 0 else None
+            detail, brief = other_configs(args, local_rank, dev, fx, nss, known_prefix=known)
             out["other_configs_detail"] = detail
             pp, ps = out.get("parity_python_oracle") or {}, out.get("parity_sample") or {}
             brief["configs2"] = {"w": "%dx%d" % (nc, total_reviews), "ms": _sig(out["ms_per_step"]), "frac": _sig(out["roofline"]["frac"], 3),

@@ -38,8 +38,8 @@ EXPORTS = [
     "gk_table_eval", "gk_eval_free", "gk_render", "gk_render_error", "gk_free", "gk_dump", "gk_table_topk", "gk_topk_free",
     "gk_table_totals", "gk_totals_free", "gk_table_get_stats", "gk_batcher_start", "gk_batcher_stop", "gk_query",
     "gk_resident_sweep", "gk_sweep_free", "gk_resident_review",
-    "gk_comm_unique_id", "gk_comm_init", "gk_comm_destroy", "gk_table_sweep_sharded", "gk_shard_free",
-    "gk_jit_quiesce", "gk_jit_cache_stats", "gk_host_cpus", "gk_table_create_spool", "gk_spool_info_free",
+    "gk_comm_unique_id", "gk_comm_init", "gk_comm_destroy", "gk_comm_info", "gk_table_sweep_sharded", "gk_shard_free",
+    "gk_jit_quiesce", "gk_jit_cache_stats", "gk_jit_cache_dir", "gk_jit_cache_drop_memory", "gk_host_cpus", "gk_table_create_spool", "gk_spool_info_free",
     # include/gksynth.h (bench / test plumbing)
     "gk_synth_batch_create", "gk_synth_batch_reviews", "gk_synth_batch_size", "gk_synth_batch_json_bytes", "gk_synth_batch_free", "gk_synth_query_storm",
 ]
@@ -184,6 +184,10 @@ def load(hostemu: bool | None = None):
     lib.gk_jit_quiesce.restype = None
     lib.gk_jit_cache_stats.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.gk_jit_cache_stats.restype = None
+    lib.gk_jit_cache_dir.argtypes = []
+    lib.gk_jit_cache_dir.restype = C.c_char_p
+    lib.gk_jit_cache_drop_memory.argtypes = []
+    lib.gk_jit_cache_drop_memory.restype = None
     lib.gk_table_eval.argtypes = [vp, vp, u32, C.POINTER(C.POINTER(gk_eval_out))]
     lib.gk_eval_free.argtypes = [C.POINTER(gk_eval_out)]
     lib.gk_eval_free.restype = None
@@ -199,6 +203,7 @@ def load(hostemu: bool | None = None):
     lib.gk_comm_init.argtypes = [vp, C.c_char_p, C.c_int, C.c_int]
     lib.gk_comm_destroy.argtypes = [vp]
     lib.gk_comm_destroy.restype = None
+    lib.gk_comm_info.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.gk_table_sweep_sharded.argtypes = [vp, vp, u32, C.POINTER(C.POINTER(gk_shard_out))]
     lib.gk_shard_free.argtypes = [C.POINTER(gk_shard_out)]
     lib.gk_shard_free.restype = None

@@ -74,6 +74,7 @@ DevComm* dev_comm_init(int device, const char id[128], int rank, int world, std:
 void dev_comm_free(DevComm* c);
 int dev_comm_rank(const DevComm* c);
 int dev_comm_world(const DevComm* c);
+bool dev_comm_query(const DevComm* c, int* rank, int* world, std::string* err);   // ncclCommUserRank / ncclCommCount of the live communicator
 // A table evaluated as one SHARD: its violation bitmap and counts live in this rank's slot of an all-gather buffer
 // ([world] x ([nc][stride_tiles] u64 | tail | pad), tail below), stride_tiles = the largest shard's words per row.
 struct ShardInfo {
@@ -101,6 +102,9 @@ bool dev_shard_collect(DevTable* t, DevComm* c, uint32_t nc, std::vector<int64_t
 // every build in flight / code-object cache counters (hits = builds served without hiprtc)
 void dev_jit_quiesce();
 void dev_jit_cache_stats(uint64_t* hits, uint64_t* compiles);
+void dev_jit_cache_drop_memory();        // forget the code objects held in memory; the disk cache stays (what a restarted process sees)
+const char* dev_jit_cache_dir();         // "" = no disk cache
+void dev_jit_prefetch(const DevPlan* p, const DevTable* t);   // start the build this (plan, table) will ask for; never waits
 void dev_eval_launch(const DevPlan* p, const DevTable* t, const EvalOptions& opt);          // asynchronous on the default stream
 void dev_eval_finish(const DevPlan* p, const DevTable* t, const EvalOptions& opt, EvalOut* out);   // sync, overflow re-run, download
 

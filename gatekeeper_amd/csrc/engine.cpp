@@ -1566,6 +1566,8 @@ int gk_table_eval(gk_engine* e, gk_table* t, uint32_t flags, gk_eval_out** out) 
       // every plan group is LAUNCHED before any is collected: the groups work on their own streams (views of the table) and
       // overlap on the device as far as their footprints allow
       if (!(flags & GK_EVAL_COLLECT)) {
+        // (several plan groups: their plan-specialised builds are all started first and compile side by side)
+        if (!e->extra.empty() && opt.jit_wait) { dev_jit_prefetch(dp, t->dev); for (size_t gi = 0; gi < e->extra.size(); gi++) dev_jit_prefetch(e->extra[gi]->dev, t->views[gi]); }
         dev_eval_launch(dp, t->dev, opt);
         for (size_t gi = 0; gi < e->extra.size(); gi++) dev_eval_launch(e->extra[gi]->dev, t->views[gi], opt);
       }
@@ -2086,6 +2088,16 @@ int gk_comm_init_host_impl(gk_engine* e, DevComm* c) { if (!e || !c) return GK_E
 
 void gk_comm_destroy(gk_engine* e) { if (e && e->comm) { dev_comm_free(e->comm); e->comm = nullptr; } }
 
+int gk_comm_info(gk_engine* e, int32_t* rank, int32_t* world) {
+  if (!e || !rank || !world) return fail(GK_ERR_INVALID, "NULL argument");
+  if (!e->comm) return fail(GK_ERR_INVALID, "gk_comm_init first");
+  std::string err;
+  int r = 0, w = 0;
+  if (!dev_comm_query(e->comm, &r, &w, &err)) return fail(GK_ERR_DEVICE, err);
+  *rank = r; *world = w;
+  return GK_OK;
+}
+
 struct ShardHolder {
   gk_shard_out pub;   // first member
   std::vector<uint32_t> ids, shard_reviews;
@@ -2550,6 +2562,8 @@ int gk_query(gk_engine* e, const gk_review_in* review, char** results_json, gk_q
 }
 
 void gk_jit_quiesce(void) { dev_jit_quiesce(); }
+void gk_jit_cache_drop_memory(void) { dev_jit_cache_drop_memory(); }
+const char* gk_jit_cache_dir(void) { return dev_jit_cache_dir(); }
 void gk_jit_cache_stats(uint64_t* cache_hits, uint64_t* compiles) {
   uint64_t h = 0, c = 0;
   dev_jit_cache_stats(&h, &c);

@@ -109,6 +109,13 @@ class ShardedSweep:
         dist.broadcast_object_list(ident, src=0)
         eng._check(eng.lib.gk_comm_init(eng.handle, ident[0], rank, world))
 
+    def comm_info(self):
+        """(rank, ranks) as the engine's communicator itself reports them (ncclCommUserRank / ncclCommCount)"""
+        eng = self.client.driver.engine
+        r, w = C.c_int32(-1), C.c_int32(-1)
+        eng._check(eng.lib.gk_comm_info(eng.handle, C.byref(r), C.byref(w)))
+        return int(r.value), int(w.value)
+
     def sweep(self, steps=1, download=False, strict=False, collect=False):
         """`steps` passes of the hot path over the resident shard.  Single process: the launches are enqueued back to back and
         collected once -> EvalResult.  Sharded: every pass is local evaluation + the engine's exchange step, enqueued back to

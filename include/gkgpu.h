@@ -249,6 +249,9 @@ void gk_totals_free(gk_totals_out* o);
 int gk_comm_unique_id(char id[GK_COMM_ID_BYTES]);
 int gk_comm_init(gk_engine* e, const char id[GK_COMM_ID_BYTES], int rank, int world);
 void gk_comm_destroy(gk_engine* e);
+/* rank and size of the engine's communicator as RCCL itself reports them (ncclCommUserRank / ncclCommCount): a launcher that believes
+ * it started N ranks can check that the exchange really spans N GPUs.  GK_ERR_INVALID before gk_comm_init. */
+int gk_comm_info(gk_engine* e, int32_t* rank, int32_t* world);
 typedef struct {
   uint32_t world, rank, n_constraints, stride_tiles;
   uint64_t slot_bytes;               /* bytes per rank in the gathered buffer: [n_constraints][stride_tiles] u64 | [n_constraints] u32 violating
@@ -349,6 +352,12 @@ int gk_query(gk_engine* e, const gk_review_in* review, char** results_json, gk_q
  * the cache / compiled by hiprtc since the process started. */
 void gk_jit_quiesce(void);
 void gk_jit_cache_stats(uint64_t* cache_hits, uint64_t* compiles);
+/* The disk cache is on by default: $GK_JIT_CACHE_DIR, else $XDG_CACHE_HOME/gkgpu-jit, else $HOME/.cache/gkgpu-jit, else
+ * /tmp/gkgpu-jit-<uid>; GK_JIT_CACHE_DIR="" (or "off") disables it.  Files are named by the hash of the kernel's source text, the
+ * target (gfx950) and the hiprtc version.  gk_jit_cache_dir: the directory in use ("" = none).  gk_jit_cache_drop_memory forgets the
+ * code objects held in memory, so that the next build of a known text is served from the file, as after a restart of the process. */
+const char* gk_jit_cache_dir(void);
+void gk_jit_cache_drop_memory(void);
 
 /* Debug: the compiled plan as text (Driver.Dump, pkg/drivers/k8scel/driver.go:253). */
 int gk_dump(gk_engine* e, char** text_out);

@@ -209,6 +209,7 @@ DevComm* hostemu_comm(int rank, int world, HeAllGather g, HeAllReduce r, void* c
 void dev_comm_free(DevComm* c) { delete c; }
 int dev_comm_rank(const DevComm* c) { return c->rank; }
 int dev_comm_world(const DevComm* c) { return c->world; }
+bool dev_comm_query(const DevComm* c, int* rank, int* world, std::string*) { *rank = c->rank; *world = c->world; return true; }   // (what the test's gloo group said)
 static size_t shard_tail_off(uint32_t nc, uint32_t stride) { return (size_t)nc * stride * 8; }
 
 // a stream: closures run in order on a thread of their own; an event: "everything recorded up to generation g has run"
@@ -364,6 +365,9 @@ static void emu_kernel_check(const DevPlan* p, const DevTable* dt, const EvalOpt
 void dev_last_viol(const DevTable* t, uint32_t nc, std::vector<uint64_t>* viol) { (void)nc; *viol = t->last_viol; }
 void dev_jit_quiesce() {}
 void dev_jit_cache_stats(uint64_t* hits, uint64_t* compiles) { *hits = 0; *compiles = 0; }
+void dev_jit_cache_drop_memory() {}
+const char* dev_jit_cache_dir() { return ""; }
+void dev_jit_prefetch(const DevPlan*, const DevTable*) {}
 void dev_eval_launch(const DevPlan*, const DevTable* dt, const EvalOptions&) { const_cast<DevTable*>(dt)->pending++; }
 void dev_eval(const DevPlan* p, const DevTable* dt, const EvalOptions& opt, EvalOut* o) { dev_eval_launch(p, dt, opt); dev_eval_finish(p, dt, opt, o); }
 void dev_eval_finish(const DevPlan* p, const DevTable* dt, const EvalOptions& opt, EvalOut* o) {

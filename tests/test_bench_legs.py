@@ -158,3 +158,44 @@ def test_messages_leg_compares_rendered_text_with_the_compiled_checker(fixtures)
     ev.viol[row][0] |= np.uint64(1 << 7)      # a pair the policy does not produce: the product renders nothing for it, the checker has no entry
     bad = bench.messages_leg(templates, constraints, batch, ev, table, n_objects=64)
     assert not bad["messages_equal"] and bad["first_difference"]["object"] == 7
+
+
+def test_strided_compiled_leg_covers_the_edges_and_finds_a_flipped_bit(fixtures):
+    """bench.strided_indep_leg (the parity leg of the 10 M-object configs[3] table): whole bitmap words -- first, middle, last and an
+    even spread -- re-evaluated by the independent compiled checker; equal to the product's bitmaps on a table that ends inside a word,
+    the per-constraint totals of the sample agree, the prefix totals reproduce a fully evaluated smaller table, and one flipped bit in
+    the LAST word is found."""
+    templates, constraints = synth.psp_templates(fixtures), synth.audit_constraints()
+    drv = D.Driver(device=0, hostemu=True)
+    client = D.Client(drv)
+    for t in templates:
+        client.AddTemplate(t)
+    for k in constraints:
+        client.AddConstraint(k)
+    defaulted = [client.constraints[(k["kind"], k["metadata"]["name"])] for k in constraints]
+    ids = [drv.constraint_id(c) for c in defaulted]
+    n = 2021
+    nss = synth.gen_namespaces()
+    batch = synth.NativeBatch(drv.engine.lib, n, seed=synth.SEED, mixed=True, start=0, namespaces=nss)
+    table = drv.engine.create_table_native(batch.reviews, n, keep_docs=False, resident=True)
+    table.launch()
+    ev = table.eval(download=True, collect_only=True)
+    words = bench.strided_words(n, 640, 2)
+    assert list(words[:2]) == [0, 1] and list(words[-2:]) == [30, 31] and 15 in words and 10 <= len(words) <= 12
+    # the fully evaluated table of the first 640 objects of the same stream: its per-constraint pairs are this table's prefix totals
+    small = synth.NativeBatch(drv.engine.lib, 640, seed=synth.SEED, mixed=True, start=0, namespaces=nss)
+    st = drv.engine.create_table_native(small.reviews, 640, keep_docs=False, resident=True)
+    st.launch()
+    sev = st.eval(download=True, collect_only=True)
+    row = {int(c): i for i, c in enumerate(sev.constraint_ids)}
+    known = (640, [int(sev.counts[row[c]]) for c in ids])
+    leg = bench.strided_indep_leg(templates, constraints, batch, ev, ids=ids, want_objects=640, known_prefix=known, edge_words=2)
+    assert leg["pairs_equal"] and leg["per_constraint_totals_equal"] and leg["first_difference"] is None, leg
+    assert leg["last_word"] == leg["table_words"] - 1 == 31 and leg["first_word"] == 0 and leg["n"] == (len(words) - 1) * 64 + n % 64
+    assert leg["device_violating_pairs"] == leg["checker_violating_pairs"] > 100 and leg["prefix_totals"]["equal"]
+    ev.viol = np.array(ev.viol, copy=True)
+    ev.viol[7][31] ^= np.uint64(1 << 3)           # review 1987, in the table's last (partial) word
+    bad = bench.strided_indep_leg(templates, constraints, batch, ev, ids=ids, want_objects=640, edge_words=2)
+    assert not bad["pairs_equal"] and bad["first_difference"]["table_word"] == 31
+    # the whole table when it is small enough
+    assert len(bench.strided_words(n, 1 << 20)) == 32
