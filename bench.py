@@ -395,6 +395,11 @@ def stream_leg(args, drv, client, templates, constraints, nss, rank, world, dev,
 batch_constraint_ids = []
 
 
+def C_u64():
+    import ctypes
+    return ctypes.c_uint64()
+
+
 def _sig(x, digits=4):
     return float("%.*g" % (digits, x)) if x is not None else None
 
@@ -425,7 +430,7 @@ def totals_leg(table):
 
 
 def side_point(config, reviews, steps, warmup, oracle_n, dev_index, fx, nss, with_stream=False, stream_args=None, dev=None, totals=False, n_templates=200,
-               strided_n=0, known_prefix=None):
+               strided_n=0, known_prefix=None, warm_probe=False):
     """One more BASELINE config measured the way the headline one is -- its own engine, policy set and resident table --
     for the `other_configs` of the default bench line: `steps` sweeps of the table in HBM between two synchronisations,
     the dominant kernel's duration from per-launch HIP events, and (oracle_n > 0) the INDEPENDENT parity leg: the device
@@ -527,6 +532,36 @@ def side_point(config, reviews, steps, warmup, oracle_n, dev_index, fx, nss, wit
             out["audit_result_totals"]["independent_compiled_checker"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
     (out.get("parity_compiled_independent") or {}).pop("_results_by_row", None)
     table.free()
+    if warm_probe:
+        # what a RESTARTED process pays for its first sweep: the code objects held in memory are dropped, a second engine loads the same
+        # policies and builds the same table -- its plan-specialised kernels come from the disk cache (on by default), not from hiprtc
+        try:
+            lib = drv.engine.lib
+            h0, c0 = C_u64(), C_u64()
+            lib.gk_jit_cache_stats(h0, c0)
+            lib.gk_jit_cache_drop_memory()
+            drv2 = D.Driver(device=dev_index, hostemu=False)
+            client2 = D.Client(drv2)
+            for t in templates:
+                client2.AddTemplate(t)
+            for k in constraints:
+                client2.AddConstraint(k)
+            table2 = drv2.engine.create_table_native(batch.reviews, reviews, keep_docs=False, resident=True, pruned=True)
+            t_warm = time.perf_counter()
+            table2.launch()
+            again = table2.eval(download=True, collect_only=True)
+            t_warm = time.perf_counter() - t_warm
+            h1, c1 = C_u64(), C_u64()
+            lib.gk_jit_cache_stats(h1, c1)
+            out["first_sweep_warm_s"] = t_warm
+            out["jit_cache"] = {"dir": (lib.gk_jit_cache_dir() or b"").decode(), "compiles_cold": int(c0.value), "compiles_during_warm_sweep": int(c1.value - c0.value),
+                                "served_from_cache_during_warm_sweep": int(h1.value - h0.value), "same_pairs": int(again.counts.sum()) == out["violating_pairs"],
+                                "what": "first_sweep_s: a fresh process, empty cache (hiprtc of every plan group, side by side); first_sweep_warm_s: a second engine after "
+                                        "gk_jit_cache_drop_memory -- the code objects come from the disk cache"}
+            table2.free()
+            drv2.engine.close()
+        except Exception as ex:   # noqa: BLE001
+            out["jit_cache"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
     stream = None
     if with_stream:
         try:
@@ -587,14 +622,14 @@ def other_configs(args, dev_index, dev, fx, nss, budget_s=200.0, known_prefix=No
                 "GBs": _sig(rf["achieved"]), "groups": d["plan_groups"], "parity": parity_brief(d.get("parity_python_oracle")),
                 "compiled": {k: (_sig(v, 3) if isinstance(v, float) else v) for k, v in (d.get("parity_compiled_independent") or {}).items() if k in ("n", "pairs_equal", "seconds", "error")},
                 "messages": {k: v for k, v in (d.get("parity_messages_compiled_independent") or {}).items() if k in ("objects", "messages", "messages_equal", "error")},
-                "leg_s": _sig(d["leg_seconds"], 3), "first_sweep_s": _sig(d.get("first_sweep_s"), 3)}
+                "leg_s": _sig(d["leg_seconds"], 3), "first_sweep_s": _sig(d.get("first_sweep_s"), 3), "first_sweep_warm_s": _sig(d.get("first_sweep_warm_s"), 3)}
     r = run("configs1", lambda: side_point(1, 100000, max(args.steps, 50), args.warmup, args.side_oracle_sample, dev_index, fx, nss))
     if r:
         detail["configs1"], brief["configs1"] = r[0], resident_brief(r[0])
     import copy
     sa = copy.copy(args)
     sa.stream_batches, sa.warmup, sa.stream_unique, sa.batch, sa.offered = 16, 2, 8, 65536, 1e6
-    r = run("configs4", lambda: side_point(4, 200000, max(args.steps, 20), args.warmup, args.side_oracle_sample, dev_index, fx, nss, with_stream=True, stream_args=sa, dev=dev, totals=True))
+    r = run("configs4", lambda: side_point(4, 200000, max(args.steps, 20), args.warmup, args.side_oracle_sample, dev_index, fx, nss, with_stream=True, stream_args=sa, dev=dev, totals=True, warm_probe=True))
     if r:
         detail["configs4"], brief["configs4"] = r[0], resident_brief(r[0])
         tl = r[0].get("audit_result_totals") or {}

@@ -50,6 +50,18 @@ std::vector<uint32_t> jit_path_classes(const HostPlan& plan, std::vector<std::ve
     } else id = it->second;
     out[i] = id | (str ? GK_ENT_NEEDS_STR : 0u);
   }
+  // CANONICAL numbering: by the predicate lists themselves, not by the order in which key paths got their ids -- the host threads
+  // of the first table's ingest intern paths in whatever order they meet them, and the generated text (hence the code-object
+  // cache key, on disk too) must not depend on that: the same policy set over the same objects is the same kernel in every process
+  std::vector<uint32_t> renum(classes->size(), 0);
+  {
+    uint32_t next = 1;
+    for (auto& kv : ids) renum[kv.second] = next++;   // (std::map: ascending by the lists' bytes)
+    std::vector<std::vector<Pred>> sorted(classes->size());
+    for (size_t c = 1; c < classes->size(); c++) sorted[renum[c]] = std::move((*classes)[c]);
+    classes->swap(sorted);
+  }
+  for (auto& e : out) if (e) e = renum[e & ~GK_ENT_NEEDS_STR] | (e & GK_ENT_NEEDS_STR);
   return out;
 }
 

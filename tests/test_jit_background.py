@@ -86,3 +86,52 @@ def test_first_query_after_a_policy_change_does_not_wait_for_the_compiler(fixtur
         assert any(f.endswith(".co") for f in os.listdir(str(tmp_path)))     # ... and on disk for the next process
     finally:
         os.environ.pop("GK_JIT_CACHE_DIR", None)
+
+
+@pytest.mark.gpu
+def test_disk_cache_is_on_by_default_and_serves_a_restarted_engine(fixtures, tmp_path, monkeypatch):
+    """No GK_JIT_CACHE_DIR: the code objects go to $XDG_CACHE_HOME/gkgpu-jit (here a directory of the test), named by source hash, gfx950
+    and the hiprtc version.  After gk_jit_cache_drop_memory -- what a restarted process sees -- a second engine with the same policies
+    and the same table loads every plan group's kernel from the files: no hiprtc run, the same answers.  A policy set of several plan
+    groups starts all its builds before it waits for the first (they compile side by side)."""
+    for k in ("GK_NO_JIT", "GK_JIT_CACHE_DIR", "GK_JIT_ASYNC"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("XDG_CACHE_HOME", str(tmp_path))
+    monkeypatch.setenv("GK_JIT_STRICT", "1")
+    templates, constraints = synth.corpus(fixtures, 140)        # three plan groups
+    nss = synth.gen_namespaces()
+
+    def sweep():
+        drv = D.Driver(device=0, hostemu=False)
+        c = D.Client(drv)
+        for t in templates:
+            c.AddTemplate(t)
+        for k in constraints:
+            c.AddConstraint(k)
+        batch = synth.NativeBatch(drv.engine.lib, 9000, seed=synth.SEED, mixed=True, start=0, namespaces=nss)
+        table = drv.engine.create_table_native(batch.reviews, 9000, keep_docs=False, resident=True, pruned=True)
+        t0 = time.perf_counter()
+        table.launch()
+        ev = table.eval(download=True, collect_only=True)
+        dt = time.perf_counter() - t0
+        counts = [int(x) for x in ev.counts]
+        groups = int(ev.n_plan_groups)
+        table.free(); batch.free(); drv.engine.close()
+        return drv.engine.lib, counts, groups, dt
+    lib, counts_cold, groups, dt_cold = sweep()
+    assert groups == 3
+    cache = os.path.join(str(tmp_path), "gkgpu-jit")
+    assert lib.gk_jit_cache_dir().decode() == cache
+    files = [f for f in os.listdir(cache) if f.endswith(".co")]
+    assert len(files) >= 3 and all(f.startswith("gk_gfx950_rtc") for f in files), files
+    hits0, compiles0 = _cache_stats(lib)
+    assert compiles0 >= 3
+    lib.gk_jit_cache_drop_memory()
+    _, counts_warm, _, dt_warm = sweep()
+    hits1, compiles1 = _cache_stats(lib)
+    assert counts_warm == counts_cold and sum(counts_cold) > 0
+    assert compiles1 == compiles0 and hits1 >= hits0 + 3, (hits0, hits1, compiles0, compiles1)     # every group from its file
+    assert dt_warm < dt_cold
+    # switched off: no directory, no files
+    monkeypatch.setenv("GK_JIT_CACHE_DIR", "off")
+    assert lib.gk_jit_cache_dir() == b""
