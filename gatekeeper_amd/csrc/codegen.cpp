@@ -11,6 +11,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <set>
+#include <functional>
 #include <sstream>
 
 namespace gk {
@@ -368,17 +370,43 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts, const std
   o << ";\n";
   // the global predicate words are read once; derived global bits (F_STG) update the register copy as well
   for (uint32_t w = 0; w < plan.dims.n_gwords; w++) o << "  uint32_t g" << w << " = acc.load(" << w << "u);\n";
-  struct Loop { uint32_t scope; int depth; };
+  struct Loop { uint32_t scope; int depth; int lit; };   // lit: the element index as a literal (preloaded form), -1: a run-time loop variable
   std::vector<Loop> stack;
+  // PRELOADED form of the staged parts (round 5).  The formulas are LDS-latency bound: every loop of every formula re-reads its
+  // scope's element words (an LDS round trip in front of a handful of bit operations; ~450 instructions took 10 k clocks per
+  // row group).  Here a part reads each element word it needs ONCE, up front -- all reads in flight together -- into registers
+  // W<scope>_<element>; loops are unrolled by the generator (every iteration a copy of the body with the element index as a
+  // literal; iterations beyond the wave's largest element count are skipped by a scalar branch), derived element bits update the
+  // register copy as well as LDS.  Used when the unrolled text stays small (`pre_budget` operations per plan); GK_JIT_PRELOAD=0
+  // keeps the loops.
+  std::ostringstream* out_ = &o;
+  bool pre = false;                                    // generating the preloaded form
+  std::set<std::pair<uint32_t, uint32_t>> pre_words;   // (scope, element) words the part being generated reads
+  std::set<uint32_t> pre_bounds;                       // scopes whose run-time bound the part needs
+  std::map<std::string, std::string> pre_vals;         // unpacked value slots: register name -> its load
+  size_t pre_ops = 0;
   auto var_of = [&](uint32_t scope) -> int {
     for (size_t i = stack.size(); i-- > 0;) if (stack[i].scope == scope) return stack[i].depth;
     return -1;
   };
   const std::vector<uint32_t>& code = plan.code;
-  auto gen = [&](size_t pc0, size_t pc1, bool staged, std::string ind) {
+  auto loop_end = [&](size_t pc) -> size_t {   // pc: first instruction of a loop body -> the index of its F_ENDLOOP / F_ENDLOOP2
+    int depth = 0;
+    for (;;) {
+      const uint32_t op = code[pc] & 0xFF;
+      if (op == F_VEQ) { pc += 2; continue; }
+      if (op == F_LOOP) depth++;
+      if (op == F_ENDLOOP || op == F_ENDLOOP2) { if (depth == 0) return pc; depth--; }
+      if (op == F_END) throw Unsupported("codegen: loop without an end");
+      pc++;
+    }
+  };
+  std::function<void(size_t, size_t, bool, std::string)> gen = [&](size_t pc0, size_t pc1, bool staged, std::string ind) {
+  std::ostringstream& o = *out_;
   for (size_t pc = pc0; pc < pc1;) {
     uint32_t ins = code[pc++];
     uint32_t op = ins & 0xFF, a = (ins >> 8) & 0xFF, b = (ins >> 16) & 0xFF, c = ins >> 24;
+    pre_ops++;
     switch (op) {
       case F_LDG: { uint32_t bit = b | (c << 8); o << ind << "b" << a << " = (g" << (bit >> 5) << " >> " << (bit & 31) << ") & 1u;\n"; break; }
       case F_LDF: o << ind << "b" << a << " = (flags >> " << b << ") & 1u;\n"; break;
@@ -402,6 +430,33 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts, const std
         const Scope& sc = plan.scopes[a];
         int d = (int)stack.size();
         o << ind << "b" << c << " = 0u;\n";
+        if (pre) {
+          // every element a copy of the body; the loop's own F_ENDLOOP closes each copy (below)
+          const size_t end = loop_end(pc);
+          uint64_t nest0 = sc.cap;
+          for (const Loop& l : stack) nest0 *= plan.scopes[l.scope].cap;
+          const bool guarded = !(sc.cap <= 4 && nest0 <= 4);   // small nests: every copy runs (absent elements hold zero words)
+          if (guarded) pre_bounds.insert(a);
+          int pd = -1;
+          if (b) { pd = var_of(b - 1); if (pd < 0) throw Unsupported("codegen: parent loop not open"); }
+          // (a large scope under another loop is read where it is used -- one LDS read with a constant address per copy -- instead of
+          //  being kept in registers across the whole run: 12 words of a volumes array pushed the kernel past its 80-VGPR budget)
+          static const uint32_t pre_cap = getenv("GK_JIT_PRELOAD_CAP") ? (uint32_t)atoi(getenv("GK_JIT_PRELOAD_CAP")) : 8u;
+          const bool in_regs = sc.cap <= pre_cap || stack.empty();
+          for (uint32_t e = 0; e < sc.cap; e++) {
+            if (in_regs) pre_words.insert({a, e});
+            o << ind << (guarded ? "if (" + std::to_string(e) + "u < ns" + std::to_string(a) + ") " : std::string()) << "{\n";
+            o << ind << "  constexpr uint32_t e" << d << " = " << e << "u; (void)e" << d << ";\n";
+            if (in_regs) o << ind << "  const uint32_t w" << d << " = W" << a << "_" << e << ";\n";
+            else o << ind << "  const uint32_t w" << d << " = acc.load(" << (sc.word_off + e * sc.wpe) << "u);\n";
+            o << ind << "  uint32_t v" << d << " = w" << d << " & 1u;\n";
+            if (b) o << ind << "  v" << d << " = v" << d << " & (uint32_t)((w" << d << " >> 24) == e" << pd << ");\n";
+            stack.push_back({a, d, (int)e});
+            gen(pc, end + 1, staged, ind + "  ");   // (its F_ENDLOOP pops the stack and closes the copy)
+          }
+          pc = end + 1;
+          break;
+        }
         // small capacities: constant trip count, fully unrolled -- the element words of absent elements are zero, so
         // they contribute nothing, and the compiler can issue all LDS reads of the nest at once
         uint64_t nest = sc.cap;
@@ -425,13 +480,14 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts, const std
           if (pd < 0) throw Unsupported("codegen: parent loop not open");
           o << ind << "    v" << d << " = v" << d << " & (uint32_t)((w" << d << " >> 24) == e" << pd << ");\n";
         }
-        stack.push_back({a, d});
+        stack.push_back({a, d, -1});
         ind += "    ";
         break;
       }
       case F_ENDLOOP: {
         int d = stack.back().depth;
         o << ind << "b" << a << " = b" << a << " | (b" << b << " & v" << d << ");\n";
+        if (pre) { stack.pop_back(); o << ind.substr(0, ind.size() - 2) << "}\n"; return; }
         stack.pop_back();
         ind = ind.substr(0, ind.size() - 4);
         o << ind << "  }\n" << ind << "}\n";
@@ -441,6 +497,7 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts, const std
         int d = stack.back().depth;
         o << ind << "b" << c << " = b" << c << " | (b" << a << " & b" << b << " & v" << d << ");\n";
         o << ind << "b" << a << " = b" << a << " | (b" << b << " & v" << d << ");\n";
+        if (pre) { stack.pop_back(); o << ind.substr(0, ind.size() - 2) << "}\n"; return; }
         stack.pop_back();
         ind = ind.substr(0, ind.size() - 4);
         o << ind << "  }\n" << ind << "}\n";
@@ -456,6 +513,13 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts, const std
         auto vid = [&](const Scope& S, int d, uint32_t slot) {
           std::ostringstream x;
           if (scope_packed(S)) x << "((w" << d << " >> " << ELEM_VID_SHIFT << "u) & " << GK_VID_OVERFLOW << "u)";   // word0 of the loop's current element is in a register
+          else if (pre) {
+            int lit = -1;
+            for (const Loop& l : stack) if (l.depth == d) lit = l.lit;
+            const std::string name = "X" + std::to_string(&S - &plan.scopes[0]) + "_" + std::to_string(lit) + "_" + std::to_string(slot);
+            pre_vals[name] = "acc.load(" + std::to_string(S.val_off + (uint32_t)lit * val_stride(S.nvals) + slot) + "u)";
+            x << name;
+          }
           else x << "acc.load(" << S.val_off << "u + e" << d << " * " << val_stride(S.nvals) << "u + " << slot << "u)";
           return x.str();
         };
@@ -466,6 +530,12 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts, const std
         const Scope& sc = plan.scopes[b];
         int d = var_of(b);
         if (d < 0) throw Unsupported("codegen: element store outside its loop");
+        if (pre && elem_word_of_bit(c) == 0 && pre_words.count({b, (uint32_t)[&] { int lit = -1; for (const Loop& l : stack) if (l.depth == d) lit = l.lit; return lit; }()})) {
+          int lit = -1;
+          for (const Loop& l : stack) if (l.depth == d) lit = l.lit;
+          o << ind << "if (b" << a << ") { acc.or_word(" << sc.word_off << "u + e" << d << " * " << (int)sc.wpe << "u, " << u(elem_mask_of_bit(c)) << "); W" << b << "_" << lit << " |= " << u(elem_mask_of_bit(c)) << "; }\n";
+          break;
+        }
         o << ind << "if (b" << a << ") acc.or_word(" << sc.word_off << "u + e" << d << " * " << (int)sc.wpe << "u + " << elem_word_of_bit(c) << "u, " << u(elem_mask_of_bit(c)) << ");\n";
         break;
       }
@@ -628,6 +698,26 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts, const std
       }
     }
     }
+    // the preloaded form when its unrolled text stays small: operations after unrolling, summed over the parts
+    bool use_pre = !(getenv("GK_JIT_PRELOAD") && atoi(getenv("GK_JIT_PRELOAD")) == 0);
+    if (use_pre) {
+      static const size_t pre_budget = getenv("GK_JIT_PRELOAD_BUDGET") ? (size_t)atoll(getenv("GK_JIT_PRELOAD_BUDGET")) : 12000;
+      std::function<uint64_t(size_t, size_t)> unrolled = [&](size_t pc, size_t pc1) -> uint64_t {
+        uint64_t n = 0;
+        while (pc < pc1) {
+          const uint32_t ins = code[pc], op = ins & 0xFF;
+          if (op == F_VEQ) { pc += 2; n += 2; continue; }
+          if (op == F_LOOP) { const size_t end = loop_end(pc + 1); n += (uint64_t)plan.scopes[(ins >> 8) & 0xFF].cap * (4 + unrolled(pc + 1, end)); pc = end + 1; continue; }
+          n++; pc++;
+        }
+        return n;
+      };
+      uint64_t total = 0;
+      for (auto& part : parts) for (size_t bi : part) total += unrolled(blks[bi].pc0, blks[bi].pc1);
+      for (const Scope& sc : plan.scopes) if (sc.cap > 16) total = ~0ull;   // (large capacities keep their loops)
+      if (total > pre_budget) use_pre = false;
+      if (getenv("GK_DEBUG_STAGES")) fprintf(stderr, "[gkgpu stages] preloaded form: %llu operations after unrolling -> %s\n", (unsigned long long)total, use_pre ? "used" : "loops kept");
+    }
     o << "#define GK_HAS_STAGES 1\nconstexpr uint32_t GK_N_STAGES = " << n_stages << "u;\nconstexpr uint32_t GK_GEN_PARTS = " << NW << "u;\n"
       << "#ifndef GK_RES\n#define GK_RES(kind, slot, b) do { if ((kind) == 0) res.viol |= (uint64_t)(b) << (slot); else if ((kind) == 1) res.match |= (uint64_t)(b) << (slot); "
          "else res.err |= (uint64_t)(b) << (slot); } while (0)\n#define GK_RES_PROLOGUE\n#endif\n"
@@ -641,6 +731,44 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts, const std
       o << "    case " << p << ": {\n";
       std::vector<size_t> order = parts[p];
       std::sort(order.begin(), order.end());
+      if (use_pre) {
+        // RUNS of consecutive blocks share one set of preloaded registers; a run ends where the words it keeps live would exceed
+        // `pre_live` (the kernel runs at an 80-VGPR budget: everything preloaded at the top of the part spilled 19 dwords).  A later
+        // run re-reads what an earlier one derived: the same wave's LDS operations complete in order.
+        static const size_t pre_live = getenv("GK_JIT_PRELOAD_LIVE") ? (size_t)atoi(getenv("GK_JIT_PRELOAD_LIVE")) : 16;
+        std::set<uint32_t> bounds_done;
+        std::ostringstream run_body;
+        std::set<std::pair<uint32_t, uint32_t>> run_words;
+        std::map<std::string, std::string> run_vals;
+        auto flush = [&]() {
+          if (run_body.str().empty()) return;
+          o << "      {\n";
+          for (auto& we : run_words) {
+            const Scope& sc = plan.scopes[we.first];
+            o << "      uint32_t W" << we.first << "_" << we.second << " = acc.load(" << (sc.word_off + we.second * sc.wpe) << "u);\n";
+          }
+          for (auto& kv : run_vals) o << "      const uint32_t " << kv.first << " = " << kv.second << ";\n";
+          o << run_body.str() << "      }\n";
+          run_body.str(""); run_body.clear(); run_words.clear(); run_vals.clear();
+        };
+        for (size_t bi : order) {
+          std::ostringstream body;
+          out_ = &body; pre = true;
+          pre_words.clear(); pre_bounds.clear(); pre_vals.clear();
+          stack.clear();
+          gen(blks[bi].pc0, blks[bi].pc1, true, "      ");
+          out_ = &o; pre = false;
+          for (uint32_t sidx : pre_bounds) if (bounds_done.insert(sidx).second) { flush(); o << "      const uint32_t ns" << sidx << " = GK_UNI(bounds[" << sidx << "]);\n"; }
+          std::set<std::pair<uint32_t, uint32_t>> uw = run_words;
+          uw.insert(pre_words.begin(), pre_words.end());
+          std::map<std::string, std::string> uv = run_vals;
+          uv.insert(pre_vals.begin(), pre_vals.end());
+          if (uw.size() + uv.size() > pre_live && !run_body.str().empty()) { flush(); uw = pre_words; uv = pre_vals; }
+          run_words.swap(uw); run_vals.swap(uv);
+          run_body << body.str();
+        }
+        flush();
+      } else
       for (size_t bi : order) { stack.clear(); gen(blks[bi].pc0, blks[bi].pc1, true, "      "); }
       o << "    } break;\n";
     }

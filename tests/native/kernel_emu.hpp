@@ -169,4 +169,5 @@ static inline uint32_t min(uint32_t a, uint32_t b) { return a < b ? a : b; }
 typedef uintptr_t gk_ldsaddr_t;
 #define GK_LDS_ADDR(p) ((gk_ldsaddr_t)(uintptr_t)(p))
 #define GK_LDS_DMA16(gptr, ldsaddr) memcpy(reinterpret_cast<unsigned char*>(ldsaddr) + (gkemu::st().cur->tid & 63u) * 16u, (gptr), 16)
+#define GK_LDS_DMA4(gptr, ldsaddr) memcpy(reinterpret_cast<unsigned char*>(ldsaddr) + (gkemu::st().cur->tid & 63u) * 4u, (gptr), 4)
 #define GK_WAIT_VM(n) do { } while (0)
