@@ -602,7 +602,13 @@ std::shared_ptr<const Template::CountForms> derive_count_forms(gk_engine* e, con
       auto pattern_of = [](const SPath& p) { Pattern pat; for (const Step& st : p) { PatStep ps; if (st.iter) ps.any = true; else ps.key = st.key; pat.push_back(ps); } return pat; };
       std::function<void(const FP&)> walk = [&](const FP& f) {
         if (f->kind == FNode::ATOM) {
-          if (f->atom.kind == Atom::DICT) { e->dict_reg.counting().intern(pattern_of(f->atom.path), f->atom.dx, true); return; }
+          if (f->atom.kind == Atom::DICT) {
+            if (!f->atom.alt) { e->dict_reg.counting().intern(pattern_of(f->atom.path), f->atom.dx, true); return; }
+            // (a promoted group of row predicates: when the counting dictionary cannot take it the totals plan reads the rows)
+            try { e->dict_reg.counting().intern(pattern_of(f->atom.path), f->atom.dx, true); } catch (const std::runtime_error&) {}
+            walk(f->atom.alt);
+            return;
+          }
           // (every other atom reads rows of its path: a pruned table must hold them -- publish_read_set)
           if (reads && !f->atom.path.empty()) reads->push_back(pattern_of(f->atom.path));
           if (reads && !f->atom.path2.empty()) reads->push_back(pattern_of(f->atom.path2));

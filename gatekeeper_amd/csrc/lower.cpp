@@ -417,7 +417,7 @@ FP rename_f(const FP& f, const std::map<int, int>& m);
 bool dict_foldable_atom(const Atom& a) {
   switch (a.kind) {
     case Atom::DICT: case Atom::TYPE: case Atom::TRUTHY: case Atom::DEFINED: case Atom::STR_PREFIX: case Atom::STR_SUFFIX: case Atom::STR_CONTAINS:
-    case Atom::STR_IN_SET: case Atom::STR_REGEX: case Atom::COUNT_CMP: return true;
+    case Atom::STR_IN_SET: case Atom::STR_REGEX: case Atom::COUNT_CMP: case Atom::SPLIT_CMP: case Atom::SPLIT_COUNT: case Atom::SPLIT_PREFIX: return true;
     case Atom::CMP: return !(a.k.is_array() || a.k.is_object() || a.k.is_set());
     default: return false;
   }
@@ -488,6 +488,21 @@ DX to_dx(const FP& f) {
         case Atom::COUNT_CMP:   // member count of a container leaf (the flattener hands containers over with their size)
           return dx_node(DExpr::AND, {dx_node(DExpr::TYPE_MASK, {dx_leaf()}, "", 0, (1u << T_ARRAY) | (1u << T_OBJECT)), dx_node(DExpr::CMP, {dx_node(DExpr::CALL, {dx_leaf()}, "count"), dx_const(a.k)}, "", a.cmp)});
         case Atom::STR_IN_SET: { std::vector<DX> alts; for (auto& v : a.k.items()) alts.push_back(dx_node(DExpr::CMP, {dx_leaf(), dx_const(v)}, "", C_EQ)); return dx_node(DExpr::OR, alts); }
+        case Atom::SPLIT_CMP: case Atom::SPLIT_COUNT: case Atom::SPLIT_PREFIX: {
+          // split(trim(leaf, cut), sep) as the partial evaluator spells it (pe.cpp leaf_local); a leaf that is no string, a component
+          // that does not exist: the builtin / $index is undefined and the comparison false -- what the row predicates answer
+          DX base = dx_leaf();
+          if (a.cut) base = dx_node(DExpr::CALL, {base, dx_const(Value::string(std::string(1, a.cut)))}, "trim");
+          if (a.kind == Atom::SPLIT_PREFIX) {   // trim(s) == P  |  startswith(trim(s), P + sep)      (P = the components joined by sep)
+            std::string joined;
+            for (size_t i = 0; i < a.k.items().size(); i++) { if (i) joined.push_back(a.sep); joined += a.k.items()[i].str(); }
+            return dx_node(DExpr::OR, {dx_node(DExpr::CMP, {base, dx_const(Value::string(joined))}, "", C_EQ),
+                                       dx_node(DExpr::TRUTHY, {dx_node(DExpr::CALL, {base, dx_const(Value::string(joined + std::string(1, a.sep)))}, "startswith")})});
+          }
+          DX arr = dx_node(DExpr::CALL, {base, dx_const(Value::string(std::string(1, a.sep)))}, "split");
+          if (a.kind == Atom::SPLIT_COUNT) return dx_node(DExpr::CMP, {dx_node(DExpr::CALL, {arr}, "count"), dx_const(a.k)}, "", a.cmp);
+          return dx_node(DExpr::CMP, {dx_node(DExpr::CALL, {arr, dx_const(Value::integer(a.idx))}, "$index"), dx_const(a.k)}, "", a.cmp);
+        }
         default: break;
       }
     }
@@ -495,7 +510,41 @@ DX to_dx(const FP& f) {
   }
   throw Unsupported("unsupported on the device plan: formula is not leaf-local");
 }
-FP dict_atom(const SPath& leaf, DX dx) { Atom a; a.kind = Atom::DICT; a.path = leaf; a.dx = std::move(dx); return f_atom(a); }
+FP dict_atom(const SPath& leaf, DX dx, FP alt = nullptr) { Atom a; a.kind = Atom::DICT; a.path = leaf; a.dx = std::move(dx); a.alt = std::move(alt); return f_atom(a); }
+
+// PROMOTION (round 5).  Tests that read a string leaf's BYTES -- prefix / suffix / contains / regex / split components -- cost the
+// kernel tens of vector instructions per row and constraint (an image row of the 200-template corpus is tested against the
+// constants of up to 22 constraints, one predicate after the other: 1 460 clocks per 64-row chunk against 230 in configs[2]'s
+// kernel).  They are pure functions of ONE leaf: a leaf-local group that holds such a test becomes a dictionary expression like the
+// quantity arithmetic of K8sContainerLimits always was -- evaluated by the flattener once per DISTINCT value of the leaf with the
+// concrete builtins (memoised per engine), shipped as a bit of the <leaf>.$d row, tested on the device with one AND.  The atom
+// keeps the group as `alt`: where the dictionary cannot take the expression the lowering evaluates the rows as before.
+// GK_DICT_STRINGS=0 switches the promotion off (tuning / A-B aid).
+static bool promote_strings() { static const bool on = !(getenv("GK_DICT_STRINGS") && atoi(getenv("GK_DICT_STRINGS")) == 0); return on; }
+static bool reads_string_bytes(const FP& f) {
+  switch (f->kind) {
+    case FNode::ATOM:
+      switch (f->atom.kind) {
+        case Atom::STR_PREFIX: case Atom::STR_SUFFIX: case Atom::STR_CONTAINS: case Atom::STR_REGEX: case Atom::SPLIT_CMP: case Atom::SPLIT_COUNT: case Atom::SPLIT_PREFIX: return true;
+        case Atom::STR_IN_SET: return true;
+        default: return false;
+      }
+    case FNode::NOT: case FNode::AND: case FNode::OR: for (auto& k : f->kids) if (reads_string_bytes(k)) return true; return false;
+    default: return false;
+  }
+}
+static bool promotable_leaf(const SPath& p) {   // (the match layer's synthetic subtrees are compiled by compile_match, never folded)
+  if (p.empty()) return false;
+  for (auto& st : p) if (!st.iter && !st.key.empty() && st.key[0] == '$') return false;
+  return true;
+}
+static bool promotable(const std::vector<FP>& g) {
+  if (!promote_strings() || g.empty()) return false;
+  const SPath* lp = leaf_path_of(g[0]);
+  if (!lp || !promotable_leaf(*lp)) return false;
+  for (auto& k : g) if (reads_string_bytes(k)) return true;
+  return false;
+}
 
 static FP fold_dict_impl(const FP& f) {
   switch (f->kind) {
@@ -557,6 +606,10 @@ static FP fold_dict_impl(const FP& f) {
           std::vector<DX> a;
           for (auto& k : g) a.push_back(to_dx(k));
           r = f_or(r, dict_atom(*leaf_path_of(g[0]), a.size() == 1 ? a[0] : dx_node(DExpr::OR, a)));
+        } else if (promotable(g)) {
+          std::vector<DX> a;
+          for (auto& k : g) a.push_back(to_dx(k));
+          r = f_or(r, dict_atom(*leaf_path_of(g[0]), a.size() == 1 ? a[0] : dx_node(DExpr::OR, a), f_any(g)));
         } else for (auto& k : g) r = f_or(r, fold_dict(k));
       }
       for (auto& k : rest) r = f_or(r, k);
@@ -583,6 +636,10 @@ static FP fold_dict_impl(const FP& f) {
           std::vector<DX> a;
           for (auto& k : g) a.push_back(to_dx(k));
           r = f_and(r, dict_atom(*leaf_path_of(g[0]), a.size() == 1 ? a[0] : dx_node(DExpr::AND, a)));
+        } else if (needs && promotable(g)) {
+          std::vector<DX> a;
+          for (auto& k : g) a.push_back(to_dx(k));
+          r = f_and(r, dict_atom(*leaf_path_of(g[0]), a.size() == 1 ? a[0] : dx_node(DExpr::AND, a), f_all(g)));
         } else for (auto& k : g) r = f_and(r, fold_dict(k));
       }
       for (auto& k : rest) r = f_and(r, k);
@@ -591,6 +648,7 @@ static FP fold_dict_impl(const FP& f) {
     case FNode::ATOM: {
       // a lone DICT atom stays; a lone NOT(DICT) cannot be answered from a row that may not exist -- it reaches the
       // lowering as NOT(bit test), which is right: no row <=> leaf absent or expression false
+      if (f->atom.kind != Atom::DICT && dict_foldable_atom(f->atom) && promotable({f})) return dict_atom(f->atom.path, to_dx(f), f);
       return f;
     }
     default: return f;
@@ -886,9 +944,16 @@ struct Lowerer {
       // bit test on the leaf's <leaf>.$d row; the bit belongs to (pattern of the leaf, expression) in the engine's registry
       if (!reg) unsupported("dictionary predicate without a registry");
       Pattern leaf_pat = pattern_of(a.path);
-      for (auto& st : leaf_pat) if (st.any && !st.elems_only && (!st.only.empty() || !st.except.empty() || !st.kpreds.empty())) unsupported("dictionary predicate under a filtered key iteration");
       uint32_t bit;
+      if (a.alt) {   // a promoted group of row predicates: what the dictionary cannot take is evaluated from the rows, as before
+        bool ok = true;
+        for (auto& st : leaf_pat) if (st.any && !st.elems_only && (!st.only.empty() || !st.except.empty() || !st.kpreds.empty())) ok = false;
+        if (ok) { try { bit = (counting ? &reg->counting() : reg)->intern(leaf_pat, a.dx, !frozen); } catch (const std::runtime_error&) { ok = false; } }
+        if (!ok) { release(r); return lower(a.alt); }
+      } else {
+      for (auto& st : leaf_pat) if (st.any && !st.elems_only && (!st.only.empty() || !st.except.empty() || !st.kpreds.empty())) unsupported("dictionary predicate under a filtered key iteration");
       try { bit = (counting ? &reg->counting() : reg)->intern(leaf_pat, a.dx, !frozen); } catch (const std::runtime_error& ex) { unsupported(ex.what()); }
+      }
       Atom b;
       b.kind = Atom::DICT; b.path = a.path; b.dx = nullptr;
       Step st; st.key = counting ? "$c" : "$d";

@@ -30,6 +30,7 @@ struct Step {
 };
 typedef std::vector<Step> SPath;   // rooted at input.review
 
+struct FNode;
 struct Atom {
   enum Kind { DEFINED, TRUTHY, CMP, TYPE, STR_PREFIX, STR_SUFFIX, STR_CONTAINS, STR_IN_SET, STR_REGEX, SPLIT_CMP, SPLIT_COUNT,
               COUNT_CMP, FLAG, VEQ, KEYCMP, SPLIT_PREFIX,
@@ -44,9 +45,12 @@ struct Atom {
   SPath path2;          // VEQ
   int q = -1;           // KEYCMP
   DX dx;                // DICT
+  // DICT made by PROMOTING plain row predicates (string tests on one leaf, lower.cpp fold_dict): the formula it stands for, as the
+  // device would evaluate it from the leaf's own rows.  The lowering falls back to it when the dictionary cannot take the expression
+  // (62 bits per leaf pattern, overlapping patterns, a frozen registry); not part of the atom's identity (the text is path + dx)
+  std::shared_ptr<const FNode> alt;
 };
 
-struct FNode;
 typedef std::shared_ptr<const FNode> FP;
 struct FNode {
   enum Kind { T, F, AND, OR, NOT, EXISTS, ATOM } kind = T;
