@@ -495,7 +495,8 @@ def side_point(config, reviews, steps, warmup, oracle_n, dev_index, fx, nss, wit
                         "frac": once / kernel_s / 1e9 / HBM_PEAK_GBS, "lds_bytes_per_tile": int(final.lds_bytes)},
            "ingest": {"flatten_s": st["flatten_s"], "h2d_s": st["upload_s"], "json_bytes": st["json_bytes"], "generate_s": t_gen,
                       "reviews_per_s": reviews / (st["flatten_s"] + st["upload_s"])},
-           "policy_load_s": t_pol, "first_sweep_s": t_first, "violating_pairs": int(final.counts.sum()), "reviews_beyond_limits": len(final.too_big_reviews())}
+           "policy_load_s": t_pol, "first_sweep_s": t_first, "violating_pairs": int(final.counts.sum()), "reviews_beyond_limits": len(final.too_big_reviews()),
+           "reviews_evaluated_on_host": len(getattr(final, "host_evaluated", []))}
     oracle = None
     if strided_n > 0:   # a table too large for the whole-table legs: the compiled checker over a strided sample (first / middle / last row groups included)
         try:
@@ -880,7 +881,9 @@ def main():
                                        "issued by the engine on the kernel's stream (global totals = sums over the gathered slot tails); four enqueues "
                                        "per pass, no host round trip" % world) if dist is not None else "1 GPU",
                        "global_violating_pairs": int(sharded.totals.sum()) if sharded is not None else int(counts.sum()),
-                       "violating_pairs_rank0": int(counts.sum()), "reviews_beyond_limits_rank0": len(final.too_big_reviews())},
+                       "violating_pairs_rank0": int(counts.sum()), "reviews_beyond_limits_rank0": len(final.too_big_reviews()),
+                       # reviews beyond the DEVICE's limits that the engine's exact host evaluator answered instead of refusing them
+                       "reviews_evaluated_on_host_rank0": len(getattr(final, "host_evaluated", []))},
             # (the plan-specialised build -- what rocprofv3 shows for this workload; GK_NO_JIT=1 runs the generic bytecode build instead)
             "roofline": {"bound": "hbm", "kernel": "gk_eval_tiles_256" if os.environ.get("GK_NO_JIT") else "gk_jit_tiles", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algo_bytes_per_launch": int(res.algo_bytes),

@@ -379,6 +379,26 @@ struct gk_table {
   std::vector<uint32_t> order, grp;         // reviews sorted by obj_keys / dense rank with ties equal (built by the first gk_table_topk)
   uint32_t last_nc = 0;
   std::vector<uint32_t> last_ids;
+  // Reviews that may end up beyond the device's limits (RF_TOO_BIG / RF_REFUSE / RF_HOST_CAND at flatten time): their text is kept
+  // whatever the table's flags, so that gk_table_eval can evaluate them on the host (complete_on_host) instead of refusing them
+  struct OwnedReview {
+    int32_t kind = 0, source = 0;
+    std::string json, ns, nsobj, op;
+    bool has_ns = false, has_nsobj = false, has_op = false;
+    gk_review_in in() const {
+      gk_review_in r{};
+      r.kind = kind; r.source = source; r.json = json.data(); r.json_len = json.size();
+      r.namespace_json = has_ns ? ns.data() : nullptr; r.namespace_len = has_ns ? ns.size() : 0;
+      r.ns_object_json = has_nsobj ? nsobj.data() : nullptr; r.ns_object_len = has_nsobj ? nsobj.size() : 0;
+      r.operation = has_op ? op.c_str() : nullptr;
+      return r;
+    }
+  };
+  std::map<uint32_t, OwnedReview> big_texts;
+  std::mutex big_mu;
+  // (row, review) pairs the host evaluation of the most recent gk_table_eval added: violations / autoreject errors the device
+  // bitmaps do not hold (gk_table_totals and gk_table_topk read those)
+  std::vector<std::pair<uint32_t, uint32_t>> host_viol, host_err;
   uint32_t n_reviews = 0;
   uint32_t rpt = GK_RPT_MIN;                // reviews per row group of this table
   uint64_t dict_gen = 0;                    // generation of the dictionary-predicate registry the rows were flattened under
@@ -1245,6 +1265,19 @@ int gk_table_create(gk_engine* e, const gk_review_in* reviews, size_t n, uint32_
         std::string& arena = t->key_arena[w];
         arena.reserve((hi - lo) * 40);
         auto put_key = [&](size_t i, const std::string& k) { t->key_span[i] = {(uint32_t)arena.size(), (uint32_t)k.size()}; arena += k; };
+        // a review that may turn out to be beyond the device's limits keeps its text with the table (rare: a copy per such review)
+        auto keep_if_big = [&](size_t i, const HostTable& part) {
+          if (part.rflags.empty() || !(part.rflags.back() & (RF_TOO_BIG | RF_REFUSE | RF_HOST_CAND))) return;
+          const gk_review_in& r = reviews[i];
+          gk_table::OwnedReview o;
+          o.kind = r.kind; o.source = r.source;
+          o.json.assign(r.json ? r.json : "", r.json ? r.json_len : 0);
+          if (r.namespace_json) { o.has_ns = true; o.ns.assign(r.namespace_json, r.namespace_len); }
+          if (r.ns_object_json) { o.has_nsobj = true; o.nsobj.assign(r.ns_object_json, r.ns_object_len); }
+          if (r.operation) { o.has_op = true; o.op = r.operation; }
+          std::lock_guard<std::mutex> bl(t->big_mu);
+          t->big_texts[(uint32_t)i] = std::move(o);
+        };
         for (size_t i = lo; i < hi; i++) {
           const gk_review_in& r = reviews[i];
           if (i + 2 < hi && reviews[i + 2].json) {   // the text of the review after next: first touched by the scanner otherwise, a DRAM round trip per line
@@ -1258,7 +1291,7 @@ int gk_table_create(gk_engine* e, const gk_review_in* reviews, size_t n, uint32_
             rr.ns_json = r.namespace_json; rr.ns_len = r.namespace_len; rr.nsobj_json = r.ns_object_json; rr.nsobj_len = r.ns_object_len;
             rr.operation = r.operation;
             int rc = fl.add_json(rr, e->ns_cache, &parts[w], &key_scratch, excl.empty() ? nullptr : &excl_fn);
-            if (rc == Flattener::ADDED) { put_key(i, key_scratch); if (statuses) statuses[i] = GK_OK; part_fast[w]++; continue; }
+            if (rc == Flattener::ADDED) { put_key(i, key_scratch); if (statuses) statuses[i] = GK_OK; part_fast[w]++; keep_if_big(i, parts[w]); continue; }
             if (rc == Flattener::EXCLUDED) {
               if (statuses) statuses[i] = GK_REVIEW_EXCLUDED;
               fl.add_skipped(&parts[w]);
@@ -1300,7 +1333,7 @@ int gk_table_create(gk_engine* e, const gk_review_in* reviews, size_t n, uint32_
             put_key(i, key);
           }
           if (st == GK_ERR_REVIEW) fl.add_skipped(&parts[w]);   // HandleReview's error is the caller's answer: nothing is evaluated
-          else fl.add(doc, &parts[w]);
+          else { fl.add(doc, &parts[w]); keep_if_big(i, parts[w]); }
           if (keep) t->docs[i] = doc;
         }
         fl.flush(&parts[w]);
@@ -1544,7 +1577,9 @@ struct EvalHolder {
   uint32_t lds_bytes = 0;
   EvalOut out;
   std::vector<uint32_t> ids;
+  std::vector<uint32_t> host_evaluated;   // reviews beyond the device's limits that the host evaluator answered (complete_on_host)
 };
+static void complete_on_host(gk_engine* e, gk_table* t, EvalHolder* h, bool want_match, bool want_list);
 
 int gk_table_eval(gk_engine* e, gk_table* t, uint32_t flags, gk_eval_out** out) {
   if (!e || !t || !out) return fail(GK_ERR_INVALID, "NULL argument");
@@ -1604,8 +1639,12 @@ int gk_table_eval(gk_engine* e, gk_table* t, uint32_t flags, gk_eval_out** out) 
         h->ids.insert(h->ids.end(), e->extra[gi]->ids.begin(), e->extra[gi]->ids.end());
       }
     }
+    // reviews the device could not evaluate (too_big) are answered by the engine's own exact evaluator where their text is at hand
+    if (opt.download) complete_on_host(e, t, h.get(), opt.want_match, (flags & GK_EVAL_WANT_LIST) != 0);
     gk_eval_out& p = h->pub;
     memset(&p, 0, sizeof p);
+    p.n_host_evaluated = (uint32_t)h->host_evaluated.size();
+    p.host_evaluated = h->host_evaluated.empty() ? nullptr : h->host_evaluated.data();
     p.n_reviews = h->out.n_reviews; p.n_constraints = h->out.n_constraints; p.n_tiles = h->out.n_tiles;
     p.constraint_ids = h->ids.data();
     p.viol = h->out.viol.data(); p.err = h->out.err.data();
@@ -1695,6 +1734,15 @@ int gk_table_topk(gk_engine* e, gk_table* t, uint32_t k, gk_topk_out** out) {
         h->overflow.insert(h->overflow.end(), o.begin(), o.end());
       }
     }
+    // (violating pairs the host evaluation of the last gk_table_eval added are no part of the device bitmaps: they join the candidates
+    //  -- a candidate too many costs a rendering, the host sorts and cuts the lists anyway; a full row says "walk the bitmap row")
+    for (auto& hp : t->host_viol) {
+      const uint32_t row = hp.first;
+      if (row >= h->counts.size()) continue;
+      uint32_t* lst = &h->reviews[(size_t)row * cap];
+      if (std::find(lst, lst + h->counts[row], hp.second) != lst + h->counts[row]) continue;
+      if (h->counts[row] < cap) lst[h->counts[row]++] = hp.second; else h->overflow[row] = 1;
+    }
     h->pub.n_constraints = t->last_nc; h->pub.stride = cap;
     h->pub.constraint_ids = h->ids.data(); h->pub.counts = h->counts.data(); h->pub.reviews = h->reviews.data(); h->pub.overflow = h->overflow.data();
     *out = &h.release()->pub;
@@ -1722,7 +1770,109 @@ static ReviewDoc make_doc(gk_engine* e, const gk_review_in& in) {
 static const ReviewDoc* doc_for(gk_engine* e, const gk_table* t, uint32_t r, ReviewDoc* tmp) {
   if (r < t->docs.size()) return &t->docs[r];
   if (r < t->texts.size()) { *tmp = make_doc(e, t->texts[r]); return tmp; }
+  auto it = t->big_texts.find(r);   // (written while the table was built, read-only afterwards)
+  if (it != t->big_texts.end()) { const gk_review_in in = it->second.in(); *tmp = make_doc(e, in); return tmp; }
   return nullptr;
+}
+
+// ---- exact host evaluation of the reviews the device refuses (round 5).  A review with more than 255 elements in an iterated
+// array, an object where predicates iterate array elements, or a non-empty container in a value join sets its bit in too_big:
+// the kernels never guess.  The reference has no such limit (its audit loop reviews every object, pkg/audit/manager.go:591-642),
+// and the engine owns an exact evaluator (ceval.cpp: the one that renders the messages).  So, for every too_big review whose
+// text the table holds (kept at flatten time for exactly these reviews):
+//   * the MATCH layer is answered by the device from a STRIPPED copy of the review -- object / oldObject cut down to apiVersion,
+//     kind and metadata, which is all match.Matches reads (pkg/mutation/match/match.go:32-258) -- flattened into a one-review table
+//     and evaluated with GK_EVAL_WANT_MATCH: the same compiled formulas, the same error conditions;
+//   * for every constraint that matches, the template's violation set is evaluated on the whole document: a bit per non-empty set.
+// The review's too_big bit is cleared and its index reported in gk_eval_out.host_evaluated.  Anything that goes wrong on the way
+// (no text, the stripped review refused as well, an evaluation error, a policy change in between) leaves the review in too_big:
+// fail closed, as before.
+static Value strip_object(const Value& o) {
+  if (!o.is_object()) return o;
+  ValuePairs keep;
+  for (auto& kv : o.pairs()) if (kv.first.is_string() && (kv.first.str() == "apiVersion" || kv.first.str() == "kind" || kv.first.str() == "metadata")) keep.push_back(kv);
+  return Value::object(std::move(keep));
+}
+static void complete_on_host(gk_engine* e, gk_table* t, EvalHolder* h, bool want_match, bool want_list) {
+  EvalOut& o = h->out;
+  if (const char* off = getenv("GK_HOST_EVAL")) if (atoi(off) == 0) return;   // (GK_HOST_EVAL=0: the device's answer alone -- refusals stay in too_big; read per call: a test switches it)
+  static const bool dbg = getenv("GK_DEBUG_HOST") != nullptr;
+  auto why = [&](uint32_t r, const char* what) { if (dbg) fprintf(stderr, "[gkgpu host] review %u stays refused: %s\n", r, what); };
+  t->host_viol.clear(); t->host_err.clear();
+  const uint32_t nt = o.n_tiles, nc = o.n_constraints;
+  bool any = false;
+  for (uint32_t w = 0; w < nt && w < o.too_big.size(); w++) any = any || o.too_big[w] != 0;
+  if (!any || nc == 0 || h->ids.size() != nc) return;
+  for (uint32_t w = 0; w < nt && w < o.too_big.size(); w++) {
+    for (uint64_t m = o.too_big[w]; m; m &= m - 1) {
+      const uint32_t b = (uint32_t)__builtin_ctzll(m), r = w * GK_TILE + b;
+      if (r >= t->n_reviews) continue;
+      try {
+        // the review's raw text
+        gk_review_in in{};
+        if (r < t->texts.size()) in = t->texts[r];
+        else { auto it = t->big_texts.find(r); if (it == t->big_texts.end()) { why(r, "no text kept"); continue; } in = it->second.in(); }
+        // 1. match layer: the stripped review on the device
+        Value body = parse_json(in.json, in.json_len);
+        if (!body.is_object()) { why(r, "not an object"); continue; }
+        Value stripped;
+        if (in.kind == GK_REVIEW_OBJECT) stripped = strip_object(body);
+        else {
+          ValuePairs kv = body.pairs();
+          for (auto& pr : kv) if (pr.first.is_string() && (pr.first.str() == "object" || pr.first.str() == "oldObject")) pr.second = strip_object(pr.second);
+          stripped = Value::object(std::move(kv));
+        }
+        const std::string stext = to_json(stripped);
+        gk_review_in sin = in;
+        sin.json = stext.data(); sin.json_len = stext.size();
+        gk_table* mt = nullptr;
+        int32_t st = GK_OK;
+        if (gk_table_create(e, &sin, 1, 0, &st, &mt) != GK_OK || !mt) { why(r, "stripped table"); continue; }
+        std::unique_ptr<gk_table, void (*)(gk_table*)> mt_guard(mt, gk_table_free);
+        if (st != GK_OK) { why(r, "stripped review rejected"); continue; }
+        gk_eval_out* mo = nullptr;
+        if (gk_table_eval(e, mt, GK_EVAL_WANT_MATCH, &mo) != GK_OK || !mo) { why(r, gk_last_error()); continue; }
+        std::unique_ptr<gk_eval_out, void (*)(gk_eval_out*)> mo_guard(mo, gk_eval_free);
+        if (mo->n_constraints != nc || (mo->too_big[0] & 1ull) || !mo->match) { why(r, "stripped review refused as well"); continue; }
+        bool same = true;
+        for (uint32_t row = 0; row < nc; row++) same = same && mo->constraint_ids[row] == h->ids[row];
+        if (!same) { why(r, "policy changed"); continue; }   // (the policy set changed between the two evaluations)
+        // 2. violations: the template's violation set on the whole document, for the constraints that match
+        ReviewDoc tmp;
+        const ReviewDoc* doc = doc_for(e, t, r, &tmp);
+        if (!doc) { why(r, "no document"); continue; }
+        std::vector<uint8_t> v(nc, 0), er(nc, 0), ma(nc, 0);
+        {
+          std::shared_lock<std::shared_mutex> l(e->mu);
+          for (uint32_t row = 0; row < nc; row++) {
+            er[row] = (uint8_t)(mo->err[row] & 1ull);
+            ma[row] = (uint8_t)(mo->match[row] & 1ull);
+            if (!ma[row]) continue;
+            const ConstraintRec& c = e->constraints[h->ids[row]];
+            auto it = e->templates.find(lower_str(c.kind));
+            if (it == e->templates.end()) throw std::runtime_error("no template");
+            v[row] = it->second->render(doc->request, c.params, e->inventory).empty() ? 0 : 1;
+          }
+        }
+        // 3. the answer replaces the refusal
+        const uint64_t bit = 1ull << b;
+        for (uint32_t row = 0; row < nc; row++) {
+          uint64_t& vw = o.viol[(size_t)row * nt + w];
+          uint64_t& ew = o.err[(size_t)row * nt + w];
+          if ((vw & bit) && row < o.counts.size() && o.counts[row]) o.counts[row]--;   // (never set for a refused review; kept consistent anyway)
+          vw &= ~bit; ew &= ~bit;
+          if (v[row]) { vw |= bit; if (row < o.counts.size()) o.counts[row]++; t->host_viol.emplace_back(row, r); if (want_list) { o.list.push_back(row); o.list.push_back(r); o.list_total++; } }
+          if (er[row]) { ew |= bit; t->host_err.emplace_back(row, r); }
+          if (want_match && !o.match.empty()) { uint64_t& mw = o.match[(size_t)row * nt + w]; mw = ma[row] ? (mw | bit) : (mw & ~bit); }
+        }
+        o.too_big[w] &= ~bit;
+        h->host_evaluated.push_back(r);
+      } catch (const std::exception& ex) {
+        why(r, ex.what());
+        // (an evaluation error, a document that does not parse: the review stays refused -- fail closed)
+      }
+    }
+  }
 }
 
 // Which violating pairs have to be RENDERED to know their result count: need[row][tile], a subset of viol.  The totals plans
@@ -1846,7 +1996,10 @@ int gk_table_totals(gk_engine* e, gk_table* t, gk_totals_out** out) {
     // result without being rendered (configs[2]: 1.8 M violating pairs, ~1 % of them rendered)
     std::vector<uint8_t> counted;
     std::vector<uint64_t> counted_sum;
-    const std::vector<uint64_t> need = render_needed(e, t, h->ids, nt, viol, &counted, &counted_sum);
+    // (pairs the host evaluation of the last gk_table_eval added are no part of the device bitmaps: they join here and are rendered)
+    for (auto& hp : t->host_viol) if (hp.first < nc && hp.second / GK_TILE < nt) viol[(size_t)hp.first * nt + hp.second / GK_TILE] |= 1ull << (hp.second % GK_TILE);
+    std::vector<uint64_t> need = render_needed(e, t, h->ids, nt, viol, &counted, &counted_sum);
+    for (auto& hp : t->host_viol) if (hp.first < nc && hp.second / GK_TILE < nt) need[(size_t)hp.first * nt + hp.second / GK_TILE] |= 1ull << (hp.second % GK_TILE);
     for (uint32_t row = 0; row < nc; row++) {
       for (uint32_t w = 0; w < nt; w++) {
         const uint64_t v = viol[(size_t)row * nt + w];

@@ -802,7 +802,11 @@ bool Flattener::emit(uint32_t path, uint32_t meta, uint32_t lo, uint32_t hi, boo
     return false;
   }
   uint32_t rev = rev_cur_;
-  if (pb & PB_VALUE) { rev |= value_id(meta, lo, hi) << ROW_VID_SHIFT; emit_side_effects_ = true; }
+  if (pb & PB_VALUE) {
+    const uint32_t vid = value_id(meta, lo, hi);
+    if (vid == 0u || vid >= GK_VID_OVERFLOW) review_flags_ |= RF_HOST_CAND;
+    rev |= vid << ROW_VID_SHIFT; emit_side_effects_ = true;
+  }
   if (pb & PB_KEY) {   // a message key: equal values within the review (or one without an id) -> review.$dup (finish_review)
     emit_side_effects_ = true;
     const uint32_t id = value_id(meta, lo, hi);
@@ -1335,7 +1339,7 @@ int Flattener::fast_value(uint32_t path, uint32_t ords, int adepth, uint32_t ext
     }
     if (has_row) {
       stage_[row].row.lo = count;
-      if (count) stage_[row].row.rev &= ROW_REV_MASK;   // a NON-EMPTY container has no value id (emit saw it empty)
+      if (count) { if (stage_[row].row.rev & ~ROW_REV_MASK) review_flags_ |= RF_HOST_CAND; stage_[row].row.rev &= ROW_REV_MASK; }   // a NON-EMPTY container has no value id (emit saw it empty)
     }
     if (count && guard_wanted(path)) review_flags_ |= RF_REFUSE;
     if (dict_deep(path)) dict_row(path, meta, parse_json(span0, (size_t)(p_ - span0)));
@@ -1370,7 +1374,7 @@ int Flattener::fast_value(uint32_t path, uint32_t ords, int adepth, uint32_t ext
     }
     if (has_row) {
       stage_[row].row.lo = count;
-      if (count) stage_[row].row.rev &= ROW_REV_MASK;   // a NON-EMPTY container has no value id (emit saw it empty)
+      if (count) { if (stage_[row].row.rev & ~ROW_REV_MASK) review_flags_ |= RF_HOST_CAND; stage_[row].row.rev &= ROW_REV_MASK; }   // a NON-EMPTY container has no value id (emit saw it empty)
     }
     if (dict_deep(path)) dict_row(path, meta, parse_json(span0, (size_t)(p_ - span0)));
     else if (dict_wanted(path)) dict_row(path, meta, Value::array(ValueVec(count, Value::null())));
@@ -1745,7 +1749,7 @@ int Flattener::ix_value(uint32_t path, uint32_t ords, int adepth, uint32_t extra
     }
     if (has_row) {
       stage_[row].row.lo = count;
-      if (count) stage_[row].row.rev &= ROW_REV_MASK;   // a NON-EMPTY container has no value id (emit saw it empty)
+      if (count) { if (stage_[row].row.rev & ~ROW_REV_MASK) review_flags_ |= RF_HOST_CAND; stage_[row].row.rev &= ROW_REV_MASK; }   // a NON-EMPTY container has no value id (emit saw it empty)
     }
     if (count && (pbits(path) & PB_GUARD)) review_flags_ |= RF_REFUSE;
     if (pbits(path) & PB_DEEP) dict_row(path, meta, parse_json(js + at, (size_t)(ix_[ixp_ - 1] + 1 - at)));
@@ -1780,7 +1784,7 @@ int Flattener::ix_value(uint32_t path, uint32_t ords, int adepth, uint32_t extra
     }
     if (has_row) {
       stage_[row].row.lo = count;
-      if (count) stage_[row].row.rev &= ROW_REV_MASK;
+      if (count) { if (stage_[row].row.rev & ~ROW_REV_MASK) review_flags_ |= RF_HOST_CAND; stage_[row].row.rev &= ROW_REV_MASK; }
     }
     if (pbits(path) & PB_DEEP) dict_row(path, meta, parse_json(js + at, (size_t)(ix_[ixp_ - 1] + 1 - at)));
     else if (pbits(path) & PB_DICT) dict_row(path, meta, Value::array(ValueVec(count, Value::null())));

@@ -111,6 +111,9 @@ enum ReviewFlag : uint32_t {
   RF_OLD_BAD = 1u << 18,
   RF_REFUSE = 1u << 20,          // a non-empty OBJECT sits where the loaded constraints iterate array elements (flatten.hpp,
                                  //   DictRegistry guards): reported in too_big, never evaluated
+  RF_HOST_CAND = 1u << 21,       // a compared value of the review has no value id (a non-empty container, or more distinct values than ids):
+                                 //   if a predicate wants it the review ends up in too_big -- the engine keeps such a review's text and
+                                 //   evaluates it on the host then (engine.cpp complete_on_host); no kernel reads the bit
   RF_SKIP = 1u << 19,            // the review is not evaluated: HandleReview rejected it, or the process excluder skips its
                                  //   namespace (engine.cpp) -- no violation, match or autoreject bit for any constraint         //   gkReviewToObject fails with ErrRequestObject (pkg/target/matcher.go:73-93)
 };

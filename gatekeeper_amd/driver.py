@@ -139,6 +139,8 @@ class EvalResult:
         self.algo_bytes, self.n_rows, self.n_launches = o.algo_bytes, o.n_rows, o.n_launches
         self.n_rows_read = o.n_rows_read
         self.algo_bytes_once, self.n_plan_groups = o.algo_bytes_once, o.n_plan_groups
+        # reviews beyond the device's limits that the engine's host evaluator answered (their bits are in the bitmaps, not in too_big)
+        self.host_evaluated = [int(o.host_evaluated[i]) for i in range(o.n_host_evaluated)] if o.n_host_evaluated else []
         self.lds_bytes = o.lds_bytes
         self.d_viol, self.d_err, self.d_counts = o.d_viol, o.d_err, o.d_counts
         lib.gk_eval_free(ptr)

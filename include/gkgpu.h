@@ -174,7 +174,14 @@ typedef struct {
   uint64_t algo_bytes_once;  /* algo_bytes with the TABLE counted once: a constraint set that needs several plan groups walks the
                                 table once per group today; rows / string headers / review flags bound by ANY group count once
                                 here (chunk lists, plan tables and bitmaps are per group).  == algo_bytes for a single group */
-  uint32_t n_plan_groups, reserved0;
+  uint32_t n_plan_groups;
+  /* Reviews beyond the device's limits that the engine answered with its own exact host evaluator instead of refusing them (their bits
+   * in viol / err / match are set from that evaluation, their too_big bit is clear): the match layer from a stripped copy of the review
+   * on the device, the template's violation set by the evaluator that renders the messages.  The reference has no such limit
+   * (pkg/audit/manager.go:591-642 reviews every object).  What is still set in too_big could not be completed (no text at hand, an
+   * evaluation error): the caller fails closed for those. */
+  uint32_t n_host_evaluated;
+  const uint32_t* host_evaluated;   /* [n_host_evaluated] review indices */
 } gk_eval_out;
 
 #define GK_EVAL_WANT_MATCH 1u

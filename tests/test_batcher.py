@@ -21,8 +21,9 @@ def test_concurrent_queries_are_batched_and_exact(backend, fixtures):
     objs.append({"apiVersion": "v1", "kind": "Pod", "metadata": {"name": "huge"}, "spec": {"containers": [{"name": "c%d" % i, "image": "x"} for i in range(300)]}})
     cons = list(c.constraints.values())
     c.driver.StartBatcher(max_batch=32, window_us=2000)
+    objs[-1]["spec"]["containers"][41]["securityContext"] = {"privileged": True}   # (a violation hidden among 300 containers)
     expected = []
-    for o in objs[:-1]:
+    for o in objs:
         res = oc.review(OT.AugmentedUnstructured(OT.Unstructured(o), synth.namespace_for(o, nss), "Original"), OC.WEBHOOK_EP)
         expected.append(sorted((r.constraint["metadata"]["name"], r.msg) for r in res))
     got, sizes, errors = [None] * len(objs), [0] * len(objs), []
@@ -46,8 +47,9 @@ def test_concurrent_queries_are_batched_and_exact(backend, fixtures):
     for t in threads:
         t.join()
     assert not errors, errors
-    assert isinstance(got[-1], D.LimitError)          # the review beyond the limits fails closed, its batch mates are answered
-    assert got[:-1] == expected
+    # the review beyond the DEVICE's limits (300 containers) is answered by the engine's host evaluator (round 5; refused until then),
+    # its batch mates by the device as ever
+    assert got == expected and expected[-1]
     assert sum(len(e) for e in expected) > 0
     assert max(sizes) > 1                              # calls really shared launches
     # a review HandleReview rejects is an error for that caller only
