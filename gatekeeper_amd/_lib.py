@@ -36,7 +36,7 @@ EXPORTS = [
     "gk_engine_create", "gk_engine_destroy", "gk_last_error", "gk_version", "gk_template_add", "gk_template_remove",
     "gk_constraint_add", "gk_constraint_remove", "gk_data_put", "gk_data_remove", "gk_excluder_replace", "gk_excluder_excluded", "gk_table_create", "gk_table_free",
     "gk_table_eval", "gk_eval_free", "gk_render", "gk_render_error", "gk_free", "gk_dump", "gk_table_topk", "gk_topk_free",
-    "gk_table_totals", "gk_totals_free", "gk_table_get_stats", "gk_batcher_start", "gk_batcher_stop", "gk_query",
+    "gk_table_totals", "gk_totals_free", "gk_table_get_stats", "gk_batcher_start", "gk_batcher_stop", "gk_query", "gk_query_ex",
     "gk_resident_sweep", "gk_sweep_free", "gk_resident_review",
     "gk_comm_unique_id", "gk_comm_init", "gk_comm_destroy", "gk_comm_info", "gk_table_sweep_sharded", "gk_shard_free",
     "gk_jit_quiesce", "gk_jit_cache_stats", "gk_jit_cache_dir", "gk_jit_cache_drop_memory", "gk_host_cpus", "gk_table_create_spool", "gk_spool_info_free",
@@ -45,8 +45,13 @@ EXPORTS = [
 ]
 
 
+GK_OPT_NO_REFERENTIAL, GK_OPT_GATHER_STATS, GK_OPT_TRACE = 1, 2, 4
+GK_QUERY_TRACE = 1
+
+
 class gk_opts(C.Structure):
-    _fields_ = [("device", C.c_int32), ("elem_cap", C.c_uint16 * 3), ("reserved", C.c_uint16)]
+    _fields_ = [("device", C.c_int32), ("elem_cap", C.c_uint16 * 3), ("reserved", C.c_uint16), ("flags", C.c_uint32), ("reserved2", C.c_uint32),
+                ("disabled_builtins", C.POINTER(C.c_char_p)), ("n_disabled_builtins", C.c_size_t)]
 
 
 class gk_review_in(C.Structure):
@@ -218,6 +223,7 @@ def load(hostemu: bool | None = None):
     lib.gk_batcher_stop.argtypes = [vp]
     lib.gk_batcher_stop.restype = None
     lib.gk_query.argtypes = [vp, C.POINTER(gk_review_in), C.POINTER(vp), C.POINTER(gk_query_stats)]
+    lib.gk_query_ex.argtypes = [vp, C.POINTER(gk_review_in), u32, C.POINTER(vp), C.POINTER(vp), C.POINTER(gk_query_stats)]
     lib.gk_table_get_stats.argtypes = [vp, C.POINTER(gk_table_stats)]
     lib.gk_table_totals.argtypes = [vp, vp, C.POINTER(C.POINTER(gk_totals_out))]
     lib.gk_totals_free.argtypes = [C.POINTER(gk_totals_out)]

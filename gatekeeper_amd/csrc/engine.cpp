@@ -249,6 +249,7 @@ static std::atomic<uint64_t> g_engine_uid{1};
 struct gk_engine {
   const uint64_t uid = g_engine_uid++;   // (per-thread caches are keyed by it: an address may be reused by a later engine)
   gk_opts opts{};
+  std::set<std::string> disabled_builtins{"http.send"};   // rego.DisableBuiltins (gk_opts.disabled_builtins; the deployment's default)
   PathDict dict;
   DictRegistry dict_reg;     // leaf-local expressions of the loaded constraints (dexpr.hpp): evaluated by the flattener
   NsCache ns_cache;
@@ -848,7 +849,11 @@ int gk_engine_create(const gk_opts* opts, gk_engine** out) {
   std::string err = dev_init(dev);
   if (!err.empty()) return fail(GK_ERR_DEVICE, err);
   gk_engine* e = new gk_engine();
-  if (opts) e->opts = *opts;
+  if (opts) {
+    e->opts = *opts;
+    if (opts->disabled_builtins) { e->disabled_builtins.clear(); for (size_t i = 0; i < opts->n_disabled_builtins; i++) if (opts->disabled_builtins[i]) e->disabled_builtins.insert(opts->disabled_builtins[i]); }
+    e->opts.disabled_builtins = nullptr; e->opts.n_disabled_builtins = 0;   // (the caller's array is not kept)
+  }
   *out = e;
   return GK_OK;
 }
@@ -873,7 +878,11 @@ int gk_template_add(gk_engine* e, const char* kind, const char* rego, const char
   try {
     std::vector<std::string> ls;
     for (size_t i = 0; i < nlibs; i++) ls.emplace_back(libs[i]);
-    auto t = std::make_shared<Template>(rego, ls);
+    auto t = std::make_shared<Template>(rego, ls, &e->disabled_builtins);
+    // rego.Externs() without "inventory" (GK_OPT_NO_REFERENTIAL, --enable-referential-rules=false): the frameworks' reference check
+    // refuses a template that reads data.inventory when it is added (the wording of its error is the third-party driver's: unpinned)
+    if ((e->opts.flags & GK_OPT_NO_REFERENTIAL) && t->references_inventory())
+      return fail(GK_ERR_REGO, std::string("check refs failed on module {templates[\"admission.k8s.gatekeeper.sh\"][\"") + kind + "\"]}: disallowed ref data.inventory (referential rules are disabled)");
     std::unique_lock<std::mutex> res_lock(e->resident.mu, std::defer_lock);
     if (t->references_inventory()) res_lock.lock();   // (before mu: the order gk_resident_sweep uses)
     std::unique_lock<std::shared_mutex> l(e->mu);
@@ -2645,8 +2654,45 @@ void gk_batcher_stop(gk_engine* e) {
   B.queue.clear();
 }
 
-int gk_query(gk_engine* e, const gk_review_in* review, char** results_json, gk_query_stats* stats) {
+int gk_query(gk_engine* e, const gk_review_in* review, char** results_json, gk_query_stats* stats) { return gk_query_ex(e, review, 0, results_json, nullptr, stats); }
+
+// the trace of one answered review (QueryResponse.Trace): where and how it was evaluated, what every constraint yielded
+static std::string query_trace(gk_engine* e, const char* where, const std::string& results, const gk_query_stats* st) {
+  std::ostringstream os;
+  os << "gkgpu trace: evaluated " << where;
+  if (st) os << "; batch of " << st->batch_size << " review(s), queued " << (long long)(st->queue_us * 1e3) << " ns, device " << (long long)(st->device_us * 1e3) << " ns";
+  os << "\n";
+  std::map<uint32_t, std::vector<std::string>> by;
+  try {
+    Value rows = parse_json(results.data(), results.size());
+    if (rows.is_array()) for (const Value& r : rows.items()) {
+      const Value* c = r.get("constraint"); const Value* m = r.get("msg"); const Value* ar = r.get("autoreject");
+      if (c && c->is_number() && m && m->is_string()) by[(uint32_t)c->i].push_back(std::string(ar ? "autoreject: " : "violation: ") + m->str());
+    }
+  } catch (const std::exception&) {}
+  std::shared_lock<std::shared_mutex> l(e->mu);
+  for (const ConstraintRec& c : e->constraints) {
+    if (!c.alive) continue;
+    os << "  constraint " << c.kind << "/" << c.name << " (id " << c.id << "): ";
+    auto it = by.find(c.id);
+    if (it == by.end()) { os << "no result (does not match, or matches and is satisfied)\n"; continue; }
+    os << it->second.size() << " result(s)\n";
+    for (auto& m : it->second) os << "    " << m << "\n";
+  }
+  return os.str();
+}
+
+int gk_query_ex(gk_engine* e, const gk_review_in* review, uint32_t qflags, char** results_json, char** trace_out, gk_query_stats* stats) {
   if (!e || !review || !results_json) return fail(GK_ERR_INVALID, "NULL argument");
+  if (trace_out) *trace_out = nullptr;
+  const bool want_trace = trace_out && ((qflags & GK_QUERY_TRACE) || (e->opts.flags & GK_OPT_TRACE));
+  auto put_trace = [&](const char* where, const std::string& js, const gk_query_stats* st) {
+    if (!want_trace) return;
+    const std::string t = query_trace(e, where, js, st);
+    char* b = (char*)malloc(t.size() + 1);
+    memcpy(b, t.c_str(), t.size() + 1);
+    *trace_out = b;
+  };
   // a review that is byte for byte a swept resident object (same object text, the Namespace the sweep used, no Source --
   // what pkg/audit's auditFromCache sends, manager.go:611-614) is answered from the sweep's bitmap column: no flatten, no launch
   if (review->kind == GK_REVIEW_OBJECT && review->source == GK_SRC_EMPTY && review->json && !(review->operation && *review->operation)) {
@@ -2670,6 +2716,7 @@ int gk_query(gk_engine* e, const gk_review_in* review, char** results_json, gk_q
               char* buf = (char*)malloc(js.size() + 1);
               memcpy(buf, js.c_str(), js.size() + 1);
               *results_json = buf;
+              put_trace("from the resident sweep's bitmaps (the review is a swept object: no flatten, no launch)", js, nullptr);
               return GK_OK;
             }
           } catch (const std::exception&) { /* fall through to the regular path */ }
@@ -2698,9 +2745,11 @@ int gk_query(gk_engine* e, const gk_review_in* review, char** results_json, gk_q
   }
   // render this review's results from its column of the batch's bitmaps -- in the caller's thread
   std::string results;
+  bool on_host = false;
   if (req.status == GK_OK && req.batch) {
     try {
       bool too_big = false;
+      for (uint32_t k = 0; k < req.batch->ev->n_host_evaluated; k++) on_host = on_host || req.batch->ev->host_evaluated[k] == req.index;
       results = query_results_json(e, req.batch->table, *req.batch->ev, req.index, *review, &too_big);
       if (too_big) { req.status = GK_ERR_LIMIT; req.error = "review is beyond the engine's limits (more than 255 elements in an array that constraint predicates iterate, or an object where they iterate array elements)"; }
     } catch (const RegoError& ex) { req.status = GK_ERR_REGO; req.error = ex.what();
@@ -2717,6 +2766,10 @@ int gk_query(gk_engine* e, const gk_review_in* review, char** results_json, gk_q
   char* buf = (char*)malloc(results.size() + 1);
   memcpy(buf, results.c_str(), results.size() + 1);
   *results_json = buf;
+  gk_query_stats mine{};
+  mine.batch_size = req.batch_size; mine.queue_us = req.queue_us; mine.device_us = req.device_us;
+  put_trace(on_host ? "by the host evaluator (the review is beyond the device's limits: match layer from the stripped review on the device, violation sets by the concrete evaluator)"
+                    : "on the device (match + violation bitmaps of the batch's one launch; messages rendered by the host evaluator for the flagged pairs)", results, &mine);
   return GK_OK;
 }
 

@@ -1445,7 +1445,8 @@ class PE {
       }
     }
     if (!user && !has_builtin(name)) {
-      if (is_opa_builtin(name)) unsupported("builtin " + name + " is not implemented by this engine", t->line);
+      // (a DISABLED builtin never gets here: the template's static check refuses it when it is added, pe.cpp Template::Template)
+      if (is_opa_builtin(name) || name == "http.send") unsupported("builtin " + name + " is not implemented by this engine", t->line);
       throw RegoError("rego_type_error: undefined function " + name);
     }
     eval_seq(t->args, 0, {}, s, r, [&](const std::vector<SVP>& args, const State& s2) {
@@ -1917,7 +1918,9 @@ FP PE::is_string_f(const SVP& v) {
 
 // ================================================================================================ Template
 Template::~Template() { for (const std::string& n : deep_fns_) dx_unregister_user(n); drop_cindex(); }
-Template::Template(const std::string& rego, const std::vector<std::string>& libs) {
+Template::Template(const std::string& rego, const std::vector<std::string>& libs, const std::set<std::string>* disabled_in) {
+  static const std::set<std::string> k_default_disabled = {"http.send"};
+  const std::set<std::string>& disabled = disabled_in ? *disabled_in : k_default_disabled;
   modules_.push_back(parse_rego(rego));
   for (auto& l : libs) {
     modules_.push_back(parse_rego(l));
@@ -1939,12 +1942,6 @@ Template::Template(const std::string& rego, const std::vector<std::string>& libs
     if (t->head2) scan(t->head2, vars, data);
     for (auto& a : t->args) scan(a, vars, data);
   };
-  // a full smoke evaluation with empty inputs surfaces unsafe variables / undefined functions at AddTemplate time
-  try {
-    render(Value::object({}), Value::object({}), Value());
-  } catch (const UnboundVar& e) {
-    throw RegoError(e.what());
-  }
   for (const Module& m : modules_)
     for (const Rule& r : m.rules) {
       std::function<void(const Body&)> sb = [&](const Body& b) {
@@ -1992,8 +1989,9 @@ Template::Template(const std::string& rego, const std::vector<std::string>& libs
         for (size_t i = 1; i + 1 < full.size(); i++) { if (i > 1) fp += "."; fp += full[i]; }
         if (rules_.count({fp, full.back()})) return;
       }
+      if (disabled.count(name)) throw RegoError("rego_type_error: undefined function " + name);   // (rego.DisableBuiltins: the capability is gone from the compiler)
       if (has_builtin(name)) return;
-      if (is_opa_builtin(name)) throw Unsupported("unsupported on the device plan: builtin " + name + " is not implemented by this engine (line " + std::to_string(t->line) + ")");
+      if (is_opa_builtin(name) || name == "http.send") throw Unsupported("unsupported on the device plan: builtin " + name + " is not implemented by this engine (line " + std::to_string(t->line) + ")");
       throw RegoError("rego_type_error: undefined function " + name);
     };
     for (const Rule& r : m.rules) {
@@ -2002,6 +2000,13 @@ Template::Template(const std::string& rego, const std::vector<std::string>& libs
       calls_body(r.body);
       for (auto& e : r.elses) { calls(e.first); calls_body(e.second); }
     }
+  }
+  // a full smoke evaluation with empty inputs surfaces unsafe variables at AddTemplate time (after the static check of the called names: a disabled builtin is
+  // `undefined function` whether or not an evaluation would reach it)
+  try {
+    render(Value::object({}), Value::object({}), Value());
+  } catch (const UnboundVar& e) {
+    throw RegoError(e.what());
   }
   // the scan above does not descend into comprehension bodies; a textual check is a sound over-approximation
   if (!uses_data_) {

@@ -11,6 +11,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -124,7 +125,10 @@ struct Violation {   // render mode output
 // One compiled template: main module + libs.
 class Template : public std::enable_shared_from_this<Template> {
  public:
-  Template(const std::string& rego, const std::vector<std::string>& libs);   // throws RegoError
+  // disabled: builtins the driver was constructed without (rego.DisableBuiltins, main.go:424): a call of one is `rego_type_error:
+  // undefined function`, as for a name nobody defines.  nullptr = the reference deployment's default, {"http.send"}
+  // (--disable-opa-builtin, test/bats/test.bats:492-498)
+  Template(const std::string& rego, const std::vector<std::string>& libs, const std::set<std::string>* disabled = nullptr);   // throws RegoError
   const std::string& package_name() const { return pkg_name_; }
 
   // AOT: formula that is true iff the template yields >= 1 violation for a review, given constant parameters.

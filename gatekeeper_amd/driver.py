@@ -416,7 +416,9 @@ class Table:
 class Engine:
     """OO view of gk_engine."""
 
-    def __init__(self, device=0, elem_cap=None, hostemu=None):
+    def __init__(self, device=0, elem_cap=None, hostemu=None, referential=True, gather_stats=False, tracing=False, disabled_builtins=None):
+        """referential / gather_stats / tracing / disabled_builtins: the rego.Arg surface (gk_opts.flags, .disabled_builtins);
+        disabled_builtins=None keeps the deployment's default {"http.send"}"""
         self.lib = L.load(hostemu)
         self.hostemu = bool(hostemu)
         opts = L.gk_opts()
@@ -424,6 +426,11 @@ class Engine:
         if elem_cap:
             for i, v in enumerate(elem_cap):
                 opts.elem_cap[i] = v
+        opts.flags = (0 if referential else L.GK_OPT_NO_REFERENTIAL) | (L.GK_OPT_GATHER_STATS if gather_stats else 0) | (L.GK_OPT_TRACE if tracing else 0)
+        if disabled_builtins is not None:
+            names = [n.encode() for n in disabled_builtins]
+            self._disabled = (C.c_char_p * max(len(names), 1))(*names)
+            opts.disabled_builtins, opts.n_disabled_builtins = self._disabled, len(names)
         h = C.c_void_p()
         self._check(self.lib.gk_engine_create(C.byref(opts), C.byref(h)))
         self.handle = h
@@ -580,9 +587,12 @@ class Result:
 
 
 class QueryResponse:
-    def __init__(self, results, stats_entries=None):
+    """drivers.QueryResponse{Results, Trace *string, StatsEntries} (pkg/drivers/k8scel/driver.go:162-251)"""
+
+    def __init__(self, results, stats_entries=None, trace=None):
         self.results = results
         self.stats_entries = stats_entries or []
+        self.trace = trace
 
 
 class ClientError(Exception):
@@ -614,12 +624,17 @@ class Driver:
     """drivers.Driver backed by the MI355X engine."""
 
     RUN_TIME_NS = "templateRunTimeNS"
-    BATCH_SIZE = "batchSize"
-    QUEUE_NS = "queueNS"
+    CONSTRAINT_COUNT = "constraintCount"
 
-    def __init__(self, device=0, gather_stats=False, hostemu=None, elem_cap=None):
-        self.engine = Engine(device, elem_cap=elem_cap, hostemu=hostemu)
+    def __init__(self, device=0, gather_stats=False, hostemu=None, elem_cap=None, tracing=False, referential=True, disabled_builtins=None, print_enabled=False):
+        """the rego.Arg surface of the reference's construction sites: rego.Tracing(b), rego.GatherStats(), rego.Externs("inventory")
+        (referential=True: --enable-referential-rules, main.go:479-484), rego.DisableBuiltins(names...) (main.go:424;
+        None = the deployment's default {"http.send"}), rego.PrintEnabled (a label of the stats entries only)"""
+        self.engine = Engine(device, elem_cap=elem_cap, hostemu=hostemu, referential=referential, gather_stats=gather_stats, tracing=tracing,
+                             disabled_builtins=disabled_builtins)
         self.gather_stats = gather_stats
+        self.tracing = tracing
+        self.print_enabled = print_enabled
         self._ids = {}   # (kind, name) -> engine constraint id
 
     def Name(self):
@@ -664,7 +679,7 @@ class Driver:
             raise EngineError(L.GK_ERR_NOT_FOUND, "unknown constraint template validator: %s" % constraint.get("kind"))
         return self._ids[key]
 
-    def Query(self, target, constraints, review, namespace=None, stats_enabled=False):
+    def Query(self, target, constraints, review, namespace=None, stats_enabled=False, tracing=False):
         """One review against the (already matched) constraints -> QueryResponse, through the engine's micro-batcher
         (gk_query): safe to call from many threads at once -- the webhook's concurrency, pkg/webhook/policy.go:142-146 --
         and concurrent calls share one flattened table and one launch.  The device evaluates match AND violation for
@@ -679,8 +694,8 @@ class Driver:
             a.namespace_json, a.namespace_len = rin.namespace, len(rin.namespace)
         if rin.ns_object is not None:
             a.ns_object_json, a.ns_object_len = rin.ns_object, len(rin.ns_object)
-        out, st = C.c_void_p(), L.gk_query_stats()
-        rc = self.engine.lib.gk_query(self.engine.handle, arr, C.byref(out), C.byref(st))
+        out, trace_p, st = C.c_void_p(), C.c_void_p(), L.gk_query_stats()
+        rc = self.engine.lib.gk_query_ex(self.engine.handle, arr, L.GK_QUERY_TRACE if tracing else 0, C.byref(out), C.byref(trace_p), C.byref(st))
         if rc == L.GK_ERR_LIMIT:
             raise LimitError()
         if rc == L.GK_ERR_REVIEW:
@@ -691,14 +706,28 @@ class Driver:
         wanted = {self.constraint_id(c): c for c in constraints}
         results = [Result(v["msg"], wanted[v["constraint"]], v.get("details", {})) for v in rows if v["constraint"] in wanted]
         self.last_query_stats = {"batch_size": st.batch_size, "queue_us": st.queue_us, "device_us": st.device_us, "total_us": st.total_us}
+        trace = None
+        if trace_p.value:
+            trace = C.string_at(trace_p).decode()
+            self.engine.lib.gk_free(trace_p)
+        # instrumentation.StatsEntry per template kind, in the Rego driver's shape (pkg/gator/test/test_test.go:357-391): scope "template",
+        # statsFor the kind, stats templateRunTimeNS + constraintCount with source {engine, Rego}, labels TracingEnabled / PrintEnabled /
+        # target.  One launch answers every kind of the batch: its device time is what each entry reports (never 0: the reference's
+        # test requires a run time).
         stats = []
         if self.gather_stats or stats_enabled:
             src = {"type": "engine", "value": self.Name()}
-            stats.append({"scope": "template", "statsFor": "gkgpu", "stats": [
-                {"name": self.RUN_TIME_NS, "value": int(st.device_us * 1e3), "source": src},
-                {"name": self.BATCH_SIZE, "value": int(st.batch_size), "source": src},
-                {"name": self.QUEUE_NS, "value": int(st.queue_us * 1e3), "source": src}], "labels": [{"name": "target", "value": target}]})
-        return QueryResponse(results, stats)
+            run_ns = max(1, int(st.device_us * 1e3) or int(st.total_us * 1e3))
+            by_kind = {}
+            for c in constraints:
+                by_kind[c.get("kind", "")] = by_kind.get(c.get("kind", ""), 0) + 1
+            for kind in sorted(by_kind):
+                stats.append({"scope": "template", "statsFor": kind,
+                              "stats": [{"name": self.RUN_TIME_NS, "value": run_ns, "source": src},
+                                        {"name": self.CONSTRAINT_COUNT, "value": by_kind[kind], "source": src}],
+                              "labels": [{"name": "TracingEnabled", "value": bool(self.tracing or tracing)}, {"name": "PrintEnabled", "value": bool(self.print_enabled)},
+                                         {"name": "target", "value": target}]})
+        return QueryResponse(results, stats, trace)
 
     def ResidentSweep(self, result_totals=False):
         """gk_resident_sweep: bring the HBM-resident set (everything AddData'd) up to date and evaluate all constraints over
@@ -739,9 +768,8 @@ class Driver:
 
     def GetDescriptionForStat(self, stat_name):
         """drivers.Driver.GetDescriptionForStat (pkg/drivers/k8scel/driver.go:257-264): the stats of QueryResponse.stats_entries"""
-        desc = {self.RUN_TIME_NS: "the number of nanoseconds the device kernels took to evaluate all constraints for the review's batch",
-                self.BATCH_SIZE: "the number of reviews that shared the device launch",
-                self.QUEUE_NS: "the number of nanoseconds the review waited for its batch to close"}
+        desc = {self.RUN_TIME_NS: "the number of nanoseconds it took to evaluate all constraints for a template (here: the device time of the launch the review's batch shared)",
+                self.CONSTRAINT_COUNT: "the number of constraints that were evaluated for the given constraint kind"}
         if stat_name in desc:
             return desc[stat_name]
         raise ClientError("unknown stat name for Rego: %s" % stat_name)

@@ -33,10 +33,24 @@ typedef enum {
                                closed or take that review to the reference CPU driver */
 } gk_status;
 
+/* gk_opts.flags -- the rego.Arg surface the reference constructs its driver with (main.go:424,479-484; pkg/gator/test/test.go:175-190);
+ * all zero = the reference deployment's defaults (referential rules on, no stats, no trace) */
+#define GK_OPT_NO_REFERENTIAL 1u   /* rego.Externs() instead of rego.Externs("inventory") (--enable-referential-rules=false): a template that
+                                      refers to data.inventory is refused by gk_template_add (GK_ERR_REGO), never compiled */
+#define GK_OPT_GATHER_STATS 2u     /* rego.GatherStats(): gk_query_ex fills its stats for every call (the caller turns them into
+                                      instrumentation.StatsEntry) */
+#define GK_OPT_TRACE 4u            /* rego.Tracing(true): gk_query_ex returns a trace text for every call (QueryResponse.Trace) */
 typedef struct {
   int32_t device;          /* HIP device ordinal (one engine per GPU; one process per GPU under torch.distributed) */
   uint16_t elem_cap[3];    /* LDS element capacity per array-nesting level; 0 = default (8, 12, 12); larger reviews take the HBM-accumulator kernel variant */
   uint16_t reserved;
+  uint32_t flags;          /* GK_OPT_* */
+  uint32_t reserved2;
+  /* rego.DisableBuiltins(names...): a template that calls one of them is `rego_type_error: undefined function <name>` at
+   * gk_template_add.  NULL = the deployment's default {"http.send"} (--disable-opa-builtin, test/bats/test.bats:492-498); an array
+   * (n_disabled_builtins may be 0) replaces it.  Copied by gk_engine_create. */
+  const char* const* disabled_builtins;
+  size_t n_disabled_builtins;
 } gk_opts;
 
 /* ---- lifecycle ------------------------------------------------------------------------------------------- */
@@ -347,6 +361,12 @@ typedef struct {
 int gk_batcher_start(gk_engine* e, const gk_batch_opts* opts);   /* optional: gk_query starts it with the defaults (64, 200 us) */
 void gk_batcher_stop(gk_engine* e);
 int gk_query(gk_engine* e, const gk_review_in* review, char** results_json, gk_query_stats* stats);
+/* gk_query plus QueryResponse.Trace (pkg/drivers/k8scel/driver.go:162-251: `Trace *string` when the review asks for tracing or the
+ * driver was built with it): flags & GK_QUERY_TRACE, or an engine created with GK_OPT_TRACE, makes *trace_out a text (gk_free) that
+ * says how the review was answered -- the batch it shared, where it was evaluated (device / host evaluator / resident sweep) and,
+ * per loaded constraint, whether it applied and what it yielded; NULL otherwise.  trace_out may be NULL. */
+#define GK_QUERY_TRACE 1u
+int gk_query_ex(gk_engine* e, const gk_review_in* review, uint32_t flags, char** results_json, char** trace_out, gk_query_stats* stats);
 
 /* ---- plan specialisation in the background -----------------------------------------------------------------------------
  * After AddTemplate / AddConstraint (drivers.Driver, pkg/drivers/k8scel/driver.go:74-160) the next Query must not wait for a

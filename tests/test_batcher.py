@@ -93,12 +93,15 @@ def test_query_stats_entries_and_their_descriptions(fixtures):
     rv = D.AugmentedUnstructured(D.Unstructured(pod), synth.namespace_for(pod, nss), "Original")
     cons = list(c.constraints.values())
     resp = c.driver.Query(D.TARGET_NAME, cons, rv, stats_enabled=True)
-    assert len(resp.results) > 0 and len(resp.stats_entries) == 1 and not c.driver.Query(D.TARGET_NAME, cons, rv).stats_entries
+    # one entry per template kind of the queried constraints, in the Rego driver's shape (pkg/gator/test/test_test.go:357-391)
+    kinds = sorted({k["kind"] for k in cons})
+    assert len(resp.results) > 0 and [e["statsFor"] for e in resp.stats_entries] == kinds and not c.driver.Query(D.TARGET_NAME, cons, rv).stats_entries
     entry = resp.stats_entries[0]
     names = [s["name"] for s in entry["stats"]]
-    assert entry["scope"] == "template" and names == [D.Driver.RUN_TIME_NS, D.Driver.BATCH_SIZE, D.Driver.QUEUE_NS]
-    assert all(isinstance(s["value"], int) and s["value"] >= 0 and s["source"] == {"type": "engine", "value": "Rego"} for s in entry["stats"])
-    assert entry["stats"][1]["value"] >= 1
+    assert entry["scope"] == "template" and names == [D.Driver.RUN_TIME_NS, D.Driver.CONSTRAINT_COUNT]
+    assert all(isinstance(s["value"], int) and s["value"] >= 1 and s["source"] == {"type": "engine", "value": "Rego"} for s in entry["stats"])
+    assert sum(e["stats"][1]["value"] for e in resp.stats_entries) == len(cons)
+    assert entry["labels"] == [{"name": "TracingEnabled", "value": False}, {"name": "PrintEnabled", "value": False}, {"name": "target", "value": D.TARGET_NAME}]
     for n in names:
         assert c.driver.GetDescriptionForStat(n)
     with pytest.raises(D.ClientError, match="unknown stat name"):
