@@ -277,6 +277,13 @@ struct gk_engine {
   // a steady stream of readers; variants_mu guards the table-specialised variants, which evaluations create on demand.
   std::shared_mutex plan_rw;
   std::mutex plan_gate, variants_mu;
+  // POLICY EPOCH: Driver.Query holds the driver's read lock for the whole call and AddTemplate / AddConstraint / Remove* its write
+  // lock (pkg/drivers/k8scel/driver.go:61,131,140,168-169) -- a query never sees a policy set change between its two halves.  Here
+  // an admission batch is flattened for the policy set loaded now (a pruned table) and evaluated a moment later: the batcher holds
+  // this lock shared around the two steps, the four policy mutators take it exclusively (policy_gate: the turnstile that keeps a
+  // waiting writer from being starved by back-to-back batches).  Nothing else takes it, so it nests with no other lock order.
+  std::shared_mutex policy_rw;
+  std::mutex policy_gate;
   bool plan_dirty = true;
   uint64_t plan_gen = 0;   // bumped whenever the device plan (and with it every variant) is rebuilt
   HostPlan fast, big;
@@ -875,6 +882,8 @@ void gk_engine_destroy(gk_engine* e) {
 
 int gk_template_add(gk_engine* e, const char* kind, const char* rego, const char* const* libs, size_t nlibs) {
   if (!e || !kind || !rego) return fail(GK_ERR_INVALID, "NULL argument");
+  std::lock_guard<std::mutex> policy_turn(e->policy_gate);
+  std::unique_lock<std::shared_mutex> policy_change(e->policy_rw);   // (no admission batch is between its flatten and its launch)
   try {
     std::vector<std::string> ls;
     for (size_t i = 0; i < nlibs; i++) ls.emplace_back(libs[i]);
@@ -926,6 +935,8 @@ int gk_template_add(gk_engine* e, const char* kind, const char* rego, const char
 
 int gk_template_remove(gk_engine* e, const char* kind) {
   if (!e || !kind) return fail(GK_ERR_INVALID, "NULL argument");
+  std::lock_guard<std::mutex> policy_turn(e->policy_gate);
+  std::unique_lock<std::shared_mutex> policy_change(e->policy_rw);   // (no admission batch is between its flatten and its launch)
   std::unique_lock<std::shared_mutex> l(e->mu);
   std::string k = lower_str(kind);
   if (!e->templates.erase(k)) return fail(GK_ERR_NOT_FOUND, "unknown template " + k);
@@ -936,6 +947,8 @@ int gk_template_remove(gk_engine* e, const char* kind) {
 
 int gk_constraint_add(gk_engine* e, const char* json, size_t len, uint32_t* id_out) {
   if (!e || !json) return fail(GK_ERR_INVALID, "NULL argument");
+  std::lock_guard<std::mutex> policy_turn(e->policy_gate);
+  std::unique_lock<std::shared_mutex> policy_change(e->policy_rw);   // (no admission batch is between its flatten and its launch)
   try {
     Value c = parse_json(json, len);
     if (!c.is_object()) return fail(GK_ERR_INVALID, "constraint must be a JSON object");
@@ -1011,6 +1024,8 @@ int gk_constraint_add(gk_engine* e, const char* json, size_t len, uint32_t* id_o
 
 int gk_constraint_remove(gk_engine* e, const char* kind, const char* name) {
   if (!e || !kind || !name) return fail(GK_ERR_INVALID, "NULL argument");
+  std::lock_guard<std::mutex> policy_turn(e->policy_gate);
+  std::unique_lock<std::shared_mutex> policy_change(e->policy_rw);   // (no admission batch is between its flatten and its launch)
   std::unique_lock<std::shared_mutex> l(e->mu);
   bool found = false;
   for (auto& c : e->constraints) if (c.alive && c.kind == kind && c.name == name) { c.alive = false; found = true; }
@@ -2202,9 +2217,11 @@ void batcher_loop(gk_engine* e) {
     // the ingest walks past the rest).  A constraint that arrives between the two calls makes it stale: built again, once
     int rc = GK_OK;
     std::string err;
-    for (int attempt = 0; attempt < 2; attempt++) {
+    { std::lock_guard<std::mutex> turn(e->policy_gate); }   // (a policy change that is waiting goes first)
+    std::shared_lock<std::shared_mutex> policy_epoch(e->policy_rw);   // the policy set does not change between the flatten and the launch
+    for (int attempt = 0; attempt < 3; attempt++) {   // (what can still make the table stale: a referential constraint recompiled against a changed inventory)
       if (br->table) { gk_table_free(br->table); br->table = nullptr; }
-      rc = gk_table_create(e, ins.data(), ins.size(), GK_TABLE_PRUNED, st.data(), &br->table);
+      rc = gk_table_create(e, ins.data(), ins.size(), attempt < 2 ? GK_TABLE_PRUNED : 0u, st.data(), &br->table);
       err = rc == GK_OK ? "" : gk_last_error();
       if (rc != GK_OK) break;
       rc = gk_table_eval(e, br->table, 0, &br->ev);
@@ -2212,6 +2229,7 @@ void batcher_loop(gk_engine* e) {
       err = gk_last_error();
       if (rc != GK_ERR_INVALID) break;
     }
+    policy_epoch.unlock();
     const double dev_us = br->ev ? br->ev->kernel_ms * 1e3 : 0;
     for (size_t i = 0; i < batch.size(); i++) {
       gk_engine::Request* r = batch[i];

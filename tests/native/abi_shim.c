@@ -90,16 +90,18 @@ static void* query_worker(void* p) {
     in.kind = GK_REVIEW_OBJECT; in.source = GK_SRC_ORIGINAL; in.json = text; in.json_len = strlen(text);
     rc = gk_query_ex(E, &in, (q % 8 == 0) ? GK_QUERY_TRACE : 0u, &js, &trace, &st);
     take_back(text);                                   /* borrowed for the call only */
-    if (rc != GK_OK || !js) { a->failures++; continue; }
+    if (rc != GK_OK || !js) { a->failures++; fprintf(stderr, "abi_shim: thread %d query %d: rc %d: %s\n", a->id, q, rc, gk_last_error()); continue; }
     /* whatever the replacing thread is doing, the answer is one of the two templates' -- never a mixture, never nothing */
     {
       const int has_v1 = strstr(js, "v1: label team is missing") != NULL, has_v2 = strstr(js, "v2: label team is missing") != NULL;
       const int has_priv = strstr(js, "privileged container c0") != NULL;
-      if (labelled ? (has_v1 || has_v2) : (has_v1 == has_v2)) a->failures++;
-      if (has_priv != priv) a->failures++;
-      if ((q % 8 == 0) && (!trace || !strstr(trace, "gkgpu trace"))) a->failures++;
-      if ((q % 8 != 0) && trace) a->failures++;
-      if (st.batch_size < 1) a->failures++;
+      int bad = 0;
+      if (labelled ? (has_v1 || has_v2) : (has_v1 == has_v2)) bad |= 1;
+      if (has_priv != priv) bad |= 2;
+      if ((q % 8 == 0) && (!trace || !strstr(trace, "gkgpu trace"))) bad |= 4;
+      if ((q % 8 != 0) && trace) bad |= 8;
+      if (st.batch_size < 1) bad |= 16;
+      if (bad) { a->failures++; fprintf(stderr, "abi_shim: thread %d query %d: check %d failed (labelled %d, privileged %d): %s\n", a->id, q, bad, labelled, priv, js); }
       a->results += has_v1 + has_v2 + has_priv;
     }
     gk_free(js);
