@@ -72,7 +72,7 @@ uint32_t jit_res_k(const HostPlan& plan) {
   return need <= 16 ? 16u : need <= 32 ? 32u : (uint32_t)GK_MAX_RES;
 }
 
-std::string generate_plan_source(const HostPlan& plan, uint32_t parts, const std::vector<uint64_t>* class_weight) {
+std::string generate_plan_source(const HostPlan& plan, uint32_t parts) {
   std::ostringstream o;
   std::vector<std::vector<Pred>> classes;
   jit_path_classes(plan, &classes);
@@ -99,9 +99,7 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts, const std
   // inlined into its single call site (the chunk loop): as a separate function every LDS atomic would first look the
   // dynamic-LDS base up in a table (s_getpc + s_load + full wait; seen in the gfx950 ISA) and the call frame costs scratch
   const bool inline_row = !(getenv("GK_JIT_INLINE_ROW") && atoi(getenv("GK_JIT_INLINE_ROW")) == 0);   // tuning aid
-  // `adv(class, r, h, acc, on)`: the caller's "does my next chunk have this class too?  then load it into r / h / acc / on" --
-  // a case body loops on it, so that a run of chunks of one class is dispatched once (kernel_body.inc GK_RUNS_K)
-  o << "template <class Acc, class Adv>\nGK_HD __attribute__((" << (inline_row ? "always_inline" : "noinline") << ")) void jit_row(Row r, uint32_t cls, StrHdr h, const uint8_t* heap, Acc acc, bool on, Adv adv) {\n"
+  o << "template <class Acc>\nGK_HD __attribute__((" << (inline_row ? "always_inline" : "noinline") << ")) void jit_row(Row r, uint32_t cls, StrHdr h, const uint8_t* heap, Acc acc, bool on) {\n"
     << "  const uint8_t* cheap = gk_plan_consts;\n  (void)cheap; (void)h;\n  cls = GK_UNI(cls) & ~GK_ENT_NEEDS_STR;   // one class per call: the dispatch is a scalar branch\n";
   std::ostringstream& real_o = o;
   std::vector<std::string> case_body(classes.size());
@@ -113,15 +111,9 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts, const std
     // the class dispatch is wave-uniform and comes FIRST; the per-lane "this lane holds a row of this pass" test sits inside
     // the case (around a divergent dispatch the structuriser threads every case exit through a chain of flow blocks)
     std::ostringstream o;   // (this class's body; assembled into the dispatch below)
-    // FLAT bodies (GK_JIT_FLAT=1; measured LEVEL with the branchy form on configs[2] in round 3, 0.1299 against 0.1287 ms,
-    // profiles/r03_variants_c_*.log -- kept as an alternative, parity-tested on the emulator): no divergent branch in a case -- predicates become selects, every
-    // side effect an UNCONDITIONAL LDS atomic whose operand is neutral (OR 0 / MAX 0) for lanes without a row, for rows of
-    // another pass and for predicates that do not hold.  A case without divergent control flow needs no exec-mask
-    // bookkeeping (two scalar instructions per `if`) and leaves the wave-uniform class switch free of structuriser flow
-    // blocks: its exits are plain branches to the join instead of a chain of ~5 hops.  (Lanes without a row address their OWN
-    // review slot -- kernel_body.inc -- so the neutral operations do not pile up on one LDS bank.)
-    const bool flat = getenv("GK_JIT_FLAT") && atoi(getenv("GK_JIT_FLAT")) != 0;
-    o << (flat ? "{\n      const uint32_t t = r.meta & 7u; (void)t;\n" : "if (on) {\n      const uint32_t t = r.meta & 7u; (void)t;\n");
+    // (a branch-free form of these bodies -- predicates as selects, every LDS atomic unconditional with a neutral operand -- measured
+    //  level with this one in round 3, 0.1299 against 0.1287 ms on configs[2], profiles/r03_variants_c_*.log, and was removed in round 5)
+    o << "if (on) {\n      const uint32_t t = r.meta & 7u; (void)t;\n";
     const std::vector<Pred>& ps = classes[c];
     struct Group { int scope, level; bool always = false; std::vector<std::string> masks; std::vector<size_t> stores; bool present = false; };
     std::vector<Group> groups;          // element destinations by (scope, level)
@@ -135,14 +127,12 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts, const std
       return groups.back();
     };
     std::vector<std::string> target(ps.size());   // "mask |= bit" statement per predicate
-    std::vector<std::string> tmask(ps.size()), tbit(ps.size());   // ... and its parts (flat form: mask |= cond ? bit : 0)
     for (size_t i = 0; i < ps.size(); i++) {
       const Pred& p = ps[i];
       if (p.dst == D_GLOBAL) {
         std::string m = "mg" + std::to_string(p.bit >> 5);
         declare(m, gmasks);
         target[i] = m + " |= " + u(1u << (p.bit & 31)) + ";";
-        tmask[i] = m; tbit[i] = u(1u << (p.bit & 31));
       } else {
         Group& g = group_of(p);
         if (p.op == P_STORE) { g.stores.push_back(i); g.always = true; if (p.level >= GK_LEVEL_ROOT) g.present = true; continue; }   // root scope: a store marks its element
@@ -150,24 +140,13 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts, const std
         std::string m = "me" + std::to_string(p.scope) + "_" + std::to_string(p.level) + "_" + std::to_string(elem_word_of_bit(p.bit));
         declare(m, g.masks);
         target[i] = m + " |= " + u(elem_mask_of_bit(p.bit)) + ";";
-        tmask[i] = m; tbit[i] = u(elem_mask_of_bit(p.bit));
         if (p.op == P_DEFINED) g.always = true;
       }
     }
     // integer comparisons: one type test for all of them
     std::vector<size_t> icmp;
     for (size_t i = 0; i < ps.size(); i++) if (ps[i].op == P_CMP && ps[i].ctype == T_INT && !target[i].empty()) icmp.push_back(i);
-    if (!icmp.empty() && flat) {
-      // compare(row, integer constant) under Rego's total order, as selects: an integer row compares exactly, a float row as
-      // doubles (cmp_row_const), every other type by its rank against "number" (null / boolean below, string / composite above)
-      o << "      const bool isint = t == T_INT, isflt = t == T_FLOAT, below = t < T_INT;\n      const int64_t a = row_i64(r);\n      const double fa = row_f64(r);\n";
-      for (size_t i : icmp) {
-        const uint32_t op = ps[i].cmp;
-        const bool low = op == C_NE || op == C_LT || op == C_LE, high = op == C_NE || op == C_GT || op == C_GE;
-        o << "      " << tmask[i] << " |= (isint ? (a " << kCmpOps[op] << " " << (long long)(int64_t)ps[i].k << "ll) : isflt ? (fa " << kCmpOps[op] << " (double)"
-          << (long long)(int64_t)ps[i].k << "ll) : below ? " << (low ? "true" : "false") << " : " << (high ? "true" : "false") << ") ? " << tbit[i] << " : 0u;\n";
-      }
-    } else if (!icmp.empty()) {
+    if (!icmp.empty()) {
       o << "      if (t == T_INT) {\n        const int64_t a = row_i64(r);\n";
       for (size_t i : icmp) o << "        if (a " << kCmpOps[ps[i].cmp] << " " << (long long)(int64_t)ps[i].k << "ll) " << target[i] << "\n";
       o << "      } else {\n";
@@ -192,8 +171,7 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts, const std
       if (target[i].empty() || (p.op == P_CMP && p.ctype == T_INT)) continue;
       if (p.op == P_SPLIT_CMP || p.op == P_SPLIT_COUNT || p.op == P_SPLIT_PREFIX) {
         const std::string call = std::string(p.op == P_SPLIT_PREFIX ? "eval_split_prefix" : "eval_split_pred") + "(s_, sm_" + std::to_string(p.pad) + ", P, cheap)";
-        if (flat) o << "      { constexpr Pred P = " << pred_literal(p) << "; " << tmask[i] << " |= (isstr && " << call << ") ? " << tbit[i] << " : 0u; }\n";
-        else o << "      { constexpr Pred P = " << pred_literal(p) << "; if (isstr && " << call << ") " << target[i] << " }\n";
+        o << "      { constexpr Pred P = " << pred_literal(p) << "; if (isstr && " << call << ") " << target[i] << " }\n";
         continue;
       }
       std::string cond;
@@ -229,62 +207,9 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts, const std
         }
         default: break;
       }
-      if (flat) {
-        if (cond.empty()) o << "      { constexpr Pred P = " << pred_literal(p) << "; " << tmask[i] << " |= eval_pred(r, P, h, heap, cheap) ? " << tbit[i] << " : 0u; }\n";
-        else if (cond == "true") o << "      " << target[i] << "\n";
-        else o << "      " << tmask[i] << " |= (" << cond << ") ? " << tbit[i] << " : 0u;\n";
-        continue;
-      }
       if (cond.empty()) o << "      { constexpr Pred P = " << pred_literal(p) << "; if (eval_pred(r, P, h, heap, cheap)) " << target[i] << " }\n";
       else if (cond == "true") o << "      " << target[i] << "\n";
       else o << "      if (" << cond << ") " << target[i] << "\n";
-    }
-    if (flat) {
-      bool any_group = !groups.empty();
-      if (any_group) o << "      bool ovf = false;\n";
-      for (size_t gi = 0; gi < groups.size(); gi++) {
-        const Group& g = groups[gi];
-        const Scope& sc = plan.scopes[g.scope];
-        const std::string n = std::to_string(gi);
-        std::string hit = "on";
-        if (!g.always) { std::string any; for (size_t k = 0; k < g.masks.size(); k++) any += (k ? " | " : "") + g.masks[k]; hit = "on && ((" + any + ") != 0u)"; }
-        o << "      const uint32_t ord" << n << " = row_ordinal(r, " << g.level << "u);\n";
-        std::string good = "ord" + n + " < " + std::to_string(sc.cap) + "u && !(r.meta & ROW_ORD_OVERFLOW)";
-        if (!g.stores.empty()) {   // a stored value = the row's VALUE ID; none / the overflow id: beyond the limits (vm_core.hpp P_STORE)
-          if (gi == 0 || true) o << "      const uint32_t vid" << n << " = row_vid(r);\n";
-          good += " && vid" + n + " != 0u && vid" + n + " < GK_VID_OVERFLOW";
-        }
-        o << "      const bool hit" << n << " = " << hit << ";\n      const bool ok" << n << " = hit" << n << " && " << good << ";\n"
-          << "      ovf = ovf || (hit" << n << " && !ok" << n << ");\n      const uint32_t o" << n << " = ok" << n << " ? ord" << n << " : 0u;\n";
-        std::string extra;
-        for (size_t i : g.stores) {
-          const Pred& p = ps[i];
-          if (scope_packed(sc)) extra += " | (vid" + n + " << " + std::to_string(ELEM_VID_SHIFT) + "u)";
-          else o << "      acc.or_word(" << sc.val_off << "u + o" << n << " * " << val_stride(sc.nvals) << "u + " << p.bit << "u, ok" << n << " ? vid" << n << " : 0u);\n";   // (the slot is zero and written once: OR = store)
-        }
-        if (g.present) {
-          if (g.level > 0 && g.level < (int)GK_LEVEL_ROOT) extra += " | 1u | (row_ordinal(r, " + std::to_string(g.level - 1) + "u) << 24)";
-          else extra += " | 1u";
-          o << "      acc.max_word(" << sc.count_off << "u, ok" << n << " ? o" << n << " + 1u : 0u);\n";
-        }
-        bool w0_done = false;
-        for (const std::string& m : g.masks) {
-          uint32_t wi = (uint32_t)atoi(m.substr(m.rfind('_') + 1).c_str());
-          if (wi == 0) { o << "      acc.or_word(" << sc.word_off << "u + o" << n << " * " << (int)sc.wpe << "u, ok" << n << " ? (" << m << extra << ") : 0u);\n"; w0_done = true; }
-          else o << "      acc.or_word(" << sc.word_off << "u + o" << n << " * " << (int)sc.wpe << "u + " << wi << "u, ok" << n << " ? " << m << " : 0u);\n";
-        }
-        if (!w0_done && !extra.empty()) o << "      acc.or_word(" << sc.word_off << "u + o" << n << " * " << (int)sc.wpe << "u, ok" << n << " ? (0u" << extra << ") : 0u);\n";
-      }
-      bool w0 = false;
-      for (const std::string& m : gmasks) {
-        const bool is0 = m == "mg0";
-        if (is0) w0 = true;
-        o << "      acc.or_word(" << m.substr(2) << "u, (on ? " << m << " : 0u)" << (is0 && any_group ? " | (ovf ? 1u : 0u)" : "") << ");\n";
-      }
-      if (any_group && !w0) o << "      acc.or_word(0u, ovf ? 1u : 0u);\n";
-      o << "    }\n";
-      case_body[c] = o.str();
-      continue;
     }
     for (const std::string& m : gmasks) o << "      if (" << m << ") acc.or_word(" << m.substr(2) << "u, " << m << ");\n";
     for (const Group& g : groups) {
@@ -322,46 +247,18 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts, const std
     case_body[c] = o.str();
   }
   {
-    // The dispatch.  A `switch` becomes a compare tree on the way in and, because the cases hold divergent branches, a chain
-    // of structuriser flow blocks on the way out: ~14 taken branches per chunk for 38 classes (the AMDGPU backend has no
-    // jump tables).  The classes that own most chunks of the table the kernel is first compiled for are therefore tested
-    // FIRST, in an if / else-if chain ordered by chunk count (short way in, short way out); the rest stay in the switch.
-    // Any order is correct; another table only meets a less fitting one.
-    // RUN loops (kernel_body.inc GK_RUNS_K): the body of a class that owns two or more chunks per row group on average loops
-    // while the wave's next chunk has the same class.  (The loop inlines the caller's advance code: given to every class it
-    // doubled the kernel to 67 KB of code, beyond the instruction cache; the dense classes are where the runs are.)
-    std::vector<bool> loops(classes.size(), false);
-    if (getenv("GK_JIT_RUNS") && atoi(getenv("GK_JIT_RUNS")) == 1 && class_weight && !class_weight->empty() && (*class_weight)[0] > 0)
-      for (size_t c = 1; c < classes.size() && c < class_weight->size(); c++) loops[c] = (*class_weight)[c] >= 2 * (*class_weight)[0];
-    std::vector<uint32_t> hot;
-    if (class_weight) {
-      std::vector<uint32_t> ids;
-      for (size_t c = 1; c < classes.size(); c++) if (c < class_weight->size() && (*class_weight)[c] > 0) ids.push_back((uint32_t)c);
-      std::stable_sort(ids.begin(), ids.end(), [&](uint32_t a, uint32_t b) { return (*class_weight)[a] > (*class_weight)[b]; });
-      // tuning aid.  Round 2 (profiles/r02_variants_f_hot_dispatch.log): a chain of 4 level with the plain switch, 8 and 16 slower.
-      // Round 3, on the kernel with one-stage formulas and the split output stage (profiles/r03_variants_l_*.log, one box):
-      // 0 -> 0.1148 ms, 2 -> 0.1164, 4 -> 0.1177, 6 -> 0.1205: the plain switch (one balanced compare tree) wins, default 0
-      static const size_t n_hot = getenv("GK_JIT_HOT") ? (size_t)atoi(getenv("GK_JIT_HOT")) : 0;
-      for (size_t i = 0; i < ids.size() && i < n_hot; i++) hot.push_back(ids[i]);
-    }
+    // The dispatch: one `switch` over the class (a balanced compare tree: the AMDGPU backend has no jump tables).  Testing the classes
+    // that own most chunks first, in an if / else-if chain, measured slower (profiles/r02_variants_f_hot_dispatch.log,
+    // r03_variants_l_*.log: 0.1148 ms with the plain switch, 0.1164 / 0.1177 / 0.1205 with chains of 2 / 4 / 6) and went in round 5 --
+    // with it the generated text stopped depending on the table's chunk statistics: one policy set, one kernel, one cache entry.
     std::ostringstream& o = real_o;
-    // (every test of the chain compares its own opaque copy of the class: left alone, the optimiser folds the chain back
-    //  into the switch and lowers one balanced tree)
-    o << "#if defined(__HIP_DEVICE_COMPILE__)\n#define GK_DISPATCH_OPAQUE(x) asm volatile(\"\" : \"+s\"(x))\n#else\n#define GK_DISPATCH_OPAQUE(x) do { } while (0)\n#endif\n";
     o << "  ";
-    for (size_t i = 0; i < hot.size(); i++)
-      o << "{ uint32_t cls" << i << " = cls; GK_DISPATCH_OPAQUE(cls" << i << "); if (cls" << i << " == " << hot[i] << "u) { do { " << case_body[hot[i]] << "  } while ("
-        << (loops[hot[i]] ? "adv(" + std::to_string(hot[i]) + "u, r, h, acc, on)" : std::string("false")) << "); } else ";
     o << "switch (cls) {\n";
     for (size_t c = 1; c < classes.size(); c++) {
-      if (std::find(hot.begin(), hot.end(), (uint32_t)c) != hot.end()) continue;
-      o << "    case " << c << ": do { " << case_body[c] << "    } while (" << (loops[c] ? "adv(" + std::to_string(c) + "u, r, h, acc, on)" : std::string("false")) << ");\n    break;\n";
+      o << "    case " << c << ": do { " << case_body[c] << "    } while (false);\n    break;\n";
     }
     o << "    default: break;\n  }\n";
-    for (size_t i = 0; i < hot.size(); i++) o << "}";
-    o << "\n}\n"
-      << "struct GkNoAdv { template <class Acc> GK_HD bool operator()(uint32_t, Row&, StrHdr&, Acc&, bool&) const { return false; } };\n"
-      << "template <class Acc>\nGK_HD void jit_row(Row r, uint32_t cls, StrHdr h, const uint8_t* heap, Acc acc, bool on) { jit_row(r, cls, h, heap, acc, on, GkNoAdv{}); }\n\n";
+    o << "\n}\n\n";
   }
   // ---------------------------------------------------------------------------------------------- phase 2
   o << "template <class Acc>\nGK_HD Results jit_formulas(const PlanView& pv, Acc& acc, uint32_t flags, const Row* rows, const uint8_t* heap, const uint32_t* bounds) {\n"

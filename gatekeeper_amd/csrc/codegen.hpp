@@ -9,9 +9,7 @@
 namespace gk {
 // HIP/C++ text defining gk::jit_row and gk::jit_formulas for this plan (to be compiled after plan.hpp + vm_core.hpp).
 // `parts`: formula shares per 64-review half of the kernel geometry the source is compiled for (gk_parts_of(rpt))
-// `class_weight` (optional): chunks per predicate class (index = class id) in the table the source is first compiled for --
-// orders the class dispatch, nothing else
-std::string generate_plan_source(const HostPlan& plan, uint32_t parts = GK_PARTS_MIN_RPT, const std::vector<uint64_t>* class_weight = nullptr);
+std::string generate_plan_source(const HostPlan& plan, uint32_t parts = GK_PARTS_MIN_RPT);
 // result slots per kind the plan-specialised kernel keeps per 64-review half (16, 32 or GK_MAX_RES)
 uint32_t jit_res_k(const HostPlan& plan);
 // path table for the generated dispatch: ptab_class[path] = predicate-list class id (0 = none)

@@ -25,12 +25,6 @@ inline int jit_block_of(uint32_t rpt) {
   if (forced >= (int)rpt && forced <= 1024 && forced % (int)rpt == 0 && forced % GK_TILE == 0) return forced;
   return gk_block_of((int)rpt);
 }
-// RUNS of one predicate class per wave (chunks.hpp, kernel_body.inc GK_RUNS_K) -- measured SLOWER in round 3 and therefore off:
-// configs[2] 0.144 against 0.122 ms, the 200-template corpus 1.89 against 0.80 ms (profiles/r03_variants_g_class_runs.log; the
-// in-case loops inline the advance code into every dense class and the kernel grows from 40 to 52 KB of code).
-// GK_JIT_RUNS=1: run-dealt lists + in-case loops; 2: only the loop that reads list entries one chunk ahead (tuning aids).
-inline int jit_runs_mode() { const char* v = getenv("GK_JIT_RUNS"); return v ? atoi(v) : 0; }
-inline bool jit_runs_enabled() { return jit_runs_mode() == 1; }
 // static LDS of the dominant kernel for a row-group geometry (kernel_body.inc: two chunk-list buffers; the result words of
 // phase 2 alias one of them when they fit; the generic build also keeps the waves' loop bounds there).  res_k = 0: the
 // generic bytecode build.
@@ -53,22 +47,11 @@ inline size_t static_lds_of(uint32_t rpt, int block, uint32_t res_k, uint32_t li
   const size_t bounds = res_k ? 0 : (size_t)(block / GK_TILE) * GK_MAX_SCOPES * 4;
   return 2 * list + (masks <= list ? 8 : masks) + bounds + GK_TILE * 4 + 64;
 }
-// ROW RING of the plan-specialised kernel (kernel_body.inc GK_RING_K): slots of 1 KiB per wave, behind the accumulators in dynamic
-// LDS, filled by LDS-DMA.  Audit-sized row groups (>= 256 reviews) only; GK_JIT_RING=0 | 4 | 8 (tuning aid; 0 = rows through
-// registers, one chunk in flight per wave, as in rounds 1-3).
-#ifndef GK_RING_DEFAULT
-#define GK_RING_DEFAULT 0
-#endif
-inline uint32_t jit_ring_slots(uint32_t rpt) {
-  const int v = getenv("GK_JIT_RING") ? atoi(getenv("GK_JIT_RING")) : GK_RING_DEFAULT;   // (read per call: the tests switch it within one process)
-  return rpt >= 256 && (v == 4 || v == 8) ? (uint32_t)v : 0u;
-}
-inline size_t jit_ring_bytes(uint32_t rpt) { return (size_t)jit_ring_slots(rpt) * 1024 * (size_t)(jit_block_of(rpt) / GK_TILE); }
 inline size_t max_dyn_lds_of(uint32_t rpt) { return GK_LDS_PER_CU - static_lds_of(rpt, gk_block_of((int)rpt), 0) - 256; }
 inline size_t max_dyn_lds_jit(uint32_t rpt, uint32_t res_k, uint32_t list_cap = 0) { return GK_LDS_PER_CU - static_lds_of(rpt, jit_block_of(rpt), res_k, list_cap) - 256; }
 
 // plan_hpp / vm_core_hpp / kernel_body: plan.hpp, vm_core.hpp and kernel_body.inc as text (build/jit_sources.inc)
-inline std::string assemble_jit_source(const HostPlan& plan, uint32_t rpt, uint32_t rpp, const std::vector<uint64_t>* class_weight, const char* plan_hpp,
+inline std::string assemble_jit_source(const HostPlan& plan, uint32_t rpt, uint32_t rpp, const char* plan_hpp,
                                        const char* vm_core_hpp, const char* kernel_body, uint32_t list_cap = 0) {
   std::string src =
       "typedef unsigned char uint8_t; typedef unsigned short uint16_t; typedef unsigned int uint32_t; typedef unsigned long long uint64_t;\n"
@@ -79,13 +62,13 @@ inline std::string assemble_jit_source(const HostPlan& plan, uint32_t rpt, uint3
   src += "#define GK_RES_PROLOGUE const bool gk_l0 = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u;\n"
          "#define GK_RES(kind, slot, b) do { const unsigned long long m_ = __ballot((b) != 0u); if (gk_l0) masks[(kind) * GK_RES_K + (slot)] = m_; } while (0)\n";
   const int block = jit_block_of(rpt);
-  src += generate_plan_source(plan, (uint32_t)(block / GK_TILE / ((int)rpt / GK_TILE)), class_weight);
+  src += generate_plan_source(plan, (uint32_t)(block / GK_TILE / ((int)rpt / GK_TILE)));
   if (block != gk_block_of((int)rpt)) src += "#define GK_BLOCK_K " + std::to_string(block) + "\n";
   {
     // register budget: as many waves per SIMD as the LDS footprint lets groups be resident per CU (waves per SIMD =
     // groups per CU x waves per group / 4 SIMDs); measured on configs[1] with 64-review groups: 7 waves (72 VGPRs) edges
     // out 8 (64 VGPRs, twice the spill traffic) and clearly beats 5-6
-    const size_t per_group = (size_t)plan.dims.acc_words * rpp * 4 + jit_ring_bytes(rpt) + static_lds_of(rpt, block, jit_res_k(plan), list_cap);
+    const size_t per_group = (size_t)plan.dims.acc_words * rpp * 4 + static_lds_of(rpt, block, jit_res_k(plan), list_cap);
     const size_t groups_per_cu = std::max<size_t>(1, GK_LDS_PER_CU / per_group);
     int waves = (int)std::min<size_t>(8, std::max<size_t>(block / 256, groups_per_cu * (block / GK_TILE) / 4));   // waves per SIMD the LDS allows
     if (const char* w = getenv("GK_JIT_WAVES")) waves = atoi(w);   // tuning aid
@@ -102,8 +85,6 @@ inline std::string assemble_jit_source(const HostPlan& plan, uint32_t rpt, uint3
   }
   src += "#define GK_RPT_K " + std::to_string(rpt) + "\n#define GK_RPP_K " + std::to_string(rpp) + "\n";
   if (list_cap) src += "#define GK_LIST_CAP_K " + std::to_string(list_cap) + "\n";
-  if (jit_runs_mode() != 0) src += "#define GK_RUNS_K 1\n";
-  if (jit_ring_slots(rpt)) src += "#define GK_RING_K " + std::to_string(jit_ring_slots(rpt)) + "\n";
   if (const char* defs = getenv("GK_JIT_DEFINES")) {   // tuning aid: "A=1;B" -> #define A 1, #define B (kernel_body.inc variants)
     std::string d = defs, item;
     for (size_t i = 0; i <= d.size(); i++) {
@@ -114,7 +95,6 @@ inline std::string assemble_jit_source(const HostPlan& plan, uint32_t rpt, uint3
   }
   src += "namespace gk {\n#define GK_KERNEL_TILES gk_jit_tiles\n#define GK_KERNEL_BIG gk_jit_big\n#define GK_KERNEL_LINKAGE extern \"C\"\n#define GK_SKIP_BIG\n"
          "#define GK_ROW_FN(r, i, ent, h, pv, heap, acc, on) jit_row(r, ent, h, heap, acc, on)\n#define GK_BIND_ALWAYS_STR 0\n"
-         "#define GK_ROW_RUN_FN(r, ent, h, heap, acc, on, adv) jit_row(r, ent, h, heap, acc, on, adv)\n"
          "#define GK_FORMULA_FN(pv, acc, flags, rows, heap, bounds) jit_formulas(pv, acc, flags, rows, heap, bounds)\n";
   if (const char* bf = getenv("GK_JIT_BODY_FILE")) {   // tuning aid: A/B a variant of kernel_body.inc without rebuilding the library
     FILE* f = fopen(bf, "r");

@@ -459,9 +459,9 @@ namespace gk {
 
 typedef void (*EmuJitLaunch)(unsigned, unsigned, size_t, const PlanView*, const Row*, const StrHdr*, const ChunkDesc*, uint32_t, const uint32_t*, const uint8_t*,
                              uint32_t, uint32_t, const ConstraintSlot*, const OutPtrs*, uint32_t, uint32_t);
-static EmuJitLaunch emu_jit_for(const DevPlan* p, uint32_t rpt, uint32_t rpp, int block, const std::vector<uint64_t>& class_weight) {
+static EmuJitLaunch emu_jit_for(const DevPlan* p, uint32_t rpt, uint32_t rpp, int block) {
   char key[96];
-  snprintf(key, sizeof key, "%u/%u/%d/%u", rpt, rpp, block, jit_ring_slots(rpt));
+  snprintf(key, sizeof key, "%u/%u/%d", rpt, rpp, block);
   DevPlan* mp = const_cast<DevPlan*>(p);
   auto it = mp->emu_jit.find(key);
   if (it != mp->emu_jit.end()) return (EmuJitLaunch)it->second.second;
@@ -473,14 +473,11 @@ static EmuJitLaunch emu_jit_for(const DevPlan* p, uint32_t rpt, uint32_t rpp, in
     f << "#include \"" << GK_CSRC_DIR << "/../../tests/native/kernel_emu.hpp\"\n#include \"" << GK_CSRC_DIR << "/vm_core.hpp\"\n"
       << "#define GK_RES_PROLOGUE const bool gk_l0 = (threadIdx.x & 63u) == 0u;\n"
       << "#define GK_RES(kind, slot, b) do { const unsigned long long m_ = __ballot((b) != 0u); if (gk_l0) masks[(kind) * GK_RES_K + (slot)] = m_; } while (0)\n"
-      << generate_plan_source(p->fast, (uint32_t)(block / GK_TILE / ((int)rpt / GK_TILE)), &class_weight)   // (as kernels.hip: dispatch ordered by the table's chunk counts)
+      << generate_plan_source(p->fast, (uint32_t)(block / GK_TILE / ((int)rpt / GK_TILE)))
       << "#define GK_RPT_K " << rpt << "\n#define GK_RPP_K " << rpp << "\n#define GK_BLOCK_K " << block << "\n#define GK_PREFETCH " << (pf ? pf : "1") << "\n#define GK_SKIP_BIG\n"
       << "namespace gk {\n#define GK_KERNEL_TILES gk_jit_tiles\n#define GK_KERNEL_BIG gk_jit_big\n#define GK_KERNEL_LINKAGE static\n"
          "#define GK_ROW_FN(r, i, ent, h, pv, heap, acc, on) jit_row(r, ent, h, heap, acc, on)\n#define GK_BIND_ALWAYS_STR 0\n"
-         "#define GK_ROW_RUN_FN(r, ent, h, heap, acc, on, adv) jit_row(r, ent, h, heap, acc, on, adv)\n"
          "#define GK_FORMULA_FN(pv, acc, flags, rows, heap, bounds) jit_formulas(pv, acc, flags, rows, heap, bounds)\n"
-      << (jit_runs_mode() != 0 ? "#define GK_RUNS_K 1\n" : "")
-      << (jit_ring_slots(rpt) ? "#define GK_RING_K " + std::to_string(jit_ring_slots(rpt)) + "\n" : std::string())
       << "#include \"" << GK_CSRC_DIR << "/kernel_body.inc\"\n}\n"
       << "extern \"C\" void gk_emu_jit_launch(unsigned grid, unsigned block, size_t lds, const gk::PlanView* pv, const gk::Row* rows, const gk::StrHdr* shdr,\n"
          "    const gk::ChunkDesc* lists, uint32_t capg, const uint32_t* rflags, const uint8_t* heap, uint32_t n, uint32_t nt, const gk::ConstraintSlot* slots,\n"
@@ -521,7 +518,7 @@ static void emu_kernel_check(const DevPlan* p, const DevTable* dt, const EvalOpt
   const uint32_t n_groups = (n + rpt - 1) / rpt;
   uint32_t list_cap = (uint32_t)std::min(block / GK_TILE, 8) * GK_WAVE_CHUNKS;
   if (const char* lc = getenv("GK_EMU_LIST_CAP")) list_cap = std::min<uint32_t>(list_cap, (uint32_t)atoi(lc));   // test aid: list overflow
-  ChunkLists cl = build_chunk_lists(t.tile_idx.data(), n_groups, t.n_slots(), bound, list_cap, (uint32_t)(block / GK_TILE), jit && jit_runs_enabled());
+  ChunkLists cl = build_chunk_lists(t.tile_idx.data(), n_groups, t.n_slots(), bound, list_cap, (uint32_t)(block / GK_TILE));
   if (getenv("GK_EMU_CHUNK_STATS")) {   // diagnostic: chunks / rows per predicate class of this table's lists
     std::map<uint32_t, std::array<uint64_t, 5>> st;   // class -> {chunks, rows, needs_str, chunks in segments of >= 128 rows, segments}
     for (const BoundPath& b : bound) {
@@ -559,21 +556,14 @@ static void emu_kernel_check(const DevPlan* p, const DevTable* dt, const EvalOpt
   else grid = std::min<unsigned>(grid, 16u);
   const Row* rows = t.rows.data(); const StrHdr* shdr = t.shdr.data();
   if (jit) {
-    std::vector<uint64_t> weight;   // chunks per class in this table
-    for (const BoundPath& b : bound) {
-      const uint32_t c = b.ent & GK_DESC_ENT_MASK;
-      if (c >= weight.size()) weight.resize(c + 1, 0);
-      for (uint32_t g = 0; g < n_groups; g++) weight[c] += (t.tile_idx[(size_t)g * (t.n_slots() + 1) + b.slot + 1] - t.tile_idx[(size_t)g * (t.n_slots() + 1) + b.slot] + GK_TILE - 1) / GK_TILE;
-    }
-    if (!weight.empty()) weight[0] = n_groups;   // (slot 0 is no class: the number of row groups, codegen.cpp run loops)
     if (const char* dir = getenv("GK_EMU_HIP_SOURCE_DIR")) {
       // test aid (tests/test_jit_source.py): the text kernels.hip would hand to hiprtc for this plan, geometry and table
       static int n_dumped = 0;
       std::ofstream f(std::string(dir) + "/gk_plan_" + std::to_string(getpid()) + "_" + std::to_string(n_dumped++) + "_" + std::to_string(rpt) + "_" + std::to_string(rpp) + ".hip");
-      f << assemble_jit_source(hp, rpt, rpp, &weight, kPlanHpp, kVmCoreHpp, kKernelBody);
+      f << assemble_jit_source(hp, rpt, rpp, kPlanHpp, kVmCoreHpp, kKernelBody);
     }
-    EmuJitLaunch fn = emu_jit_for(p, rpt, rpp, block, weight);
-    fn(grid, (unsigned)block, lds + jit_ring_bytes(rpt), &pv, rows, shdr, cl.d.data(), cl.capg, t.rflags.data(), t.heap.data(), n, nt, hp.slots.data(), &out, 0u, rpp);
+    EmuJitLaunch fn = emu_jit_for(p, rpt, rpp, block);
+    fn(grid, (unsigned)block, lds, &pv, rows, shdr, cl.d.data(), cl.capg, t.rflags.data(), t.heap.data(), n, nt, hp.slots.data(), &out, 0u, rpp);
   } else {
     auto fn = rpt == 64 ? gk_emu_tiles_64 : rpt == 128 ? gk_emu_tiles_128 : rpt == 256 ? gk_emu_tiles_256 : gk_emu_tiles_512;
     gkemu::launch(grid, (unsigned)block, lds, [&] { fn(pv, rows, shdr, cl.d.data(), cl.capg, t.rflags.data(), t.heap.data(), n, nt, hp.slots.data(), out, 0u, rpp); });

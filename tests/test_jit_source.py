@@ -136,16 +136,3 @@ def test_library_pattern_sources_compile_for_gfx950(monkeypatch, tmp_path):
     for name, text in _dump_sources(monkeypatch, tmp_path, _pattern_plans()):
         ok, log, _ = compile_gfx950(rtc, text)
         assert ok, "%s does not compile for gfx950:\n%s" % (name, log[-3000:])
-
-
-def test_row_ring_variant_compiles_for_gfx950(monkeypatch, tmp_path):
-    """GK_JIT_RING=4 (opt-in, round 4): rows and string headers travel by LDS-DMA (global_load_lds_dwordx4) into a per-wave ring
-    behind the accumulators; the text must carry the ring, compile for gfx950 without scratch and hold the DMA instruction"""
-    rtc = _hiprtc()
-    if rtc is None:
-        pytest.skip("libhiprtc.so is not installed")
-    for name, text in _dump_sources(monkeypatch, tmp_path, _bench_plan(1200), env=[("GK_RPT", 256), ("GK_JIT_RING", 4)]):
-        assert "#define GK_RING_K 4" in text and "__launch_bounds__(512, 4)" in text      # 75 KB per group: two groups per CU
-        ok, log, code = compile_gfx950(rtc, text)
-        assert ok, "%s does not compile for gfx950:\n%s" % (name, log[-3000:])
-        assert _scratch_bytes(code) == 0

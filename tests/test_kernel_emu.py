@@ -39,11 +39,6 @@ def _sweep(monkeypatch, mode, n, env):
     {"GK_RPT": 256, "GK_FORCE_RPP": 64, "GK_EMU_GRID": 8},         # multi-pass groups: four passes over the same chunk list
     {"GK_RPT": 512, "GK_FORCE_RPP": 128, "GK_EMU_GRID": 8},        # 16 waves, two passes
     {"GK_RPT": 128, "GK_EMU_LIST_CAP": 24, "GK_EMU_GRID": 8},      # lists overflow: the groups' reviews take the big variant
-    {"GK_RPT": 256, "GK_EMU_GRID": 16, "GK_JIT_FLAT": 1},          # the branch-free row bodies (opt-in variant)
-    {"GK_RPT": 256, "GK_EMU_GRID": 8, "GK_JIT_RUNS": 1},           # runs of one class per wave + in-case loops (opt-in variant)
-    {"GK_RPT": 64, "GK_EMU_GRID": 8, "GK_JIT_RUNS": 2},            # list entries read one chunk ahead (opt-in variant)
-    {"GK_RPT": 256, "GK_EMU_GRID": 8, "GK_JIT_RING": 4},           # rows through the LDS-DMA ring, next item requested before the formulas (opt-in variant, round 4)
-    {"GK_RPT": 256, "GK_FORCE_RPP": 128, "GK_EMU_GRID": 8, "GK_JIT_RING": 8},   # ... 8 slots, two passes per group
-], ids=["rpt64", "rpt256", "rpt256-4pass", "rpt512-2pass", "list-overflow", "flat-bodies", "class-runs", "entry-lookahead", "row-ring", "row-ring-2pass"])
+], ids=["rpt64", "rpt256", "rpt256-4pass", "rpt512-2pass", "list-overflow"])
 def test_kernel_source_on_the_emulator(monkeypatch, mode, env):
     _sweep(monkeypatch, mode, 1500, env)
