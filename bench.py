@@ -462,9 +462,9 @@ def side_point(config, reviews, steps, warmup, oracle_n, dev_index, fx, nss, wit
     table = drv.engine.create_table_native(batch.reviews, reviews, keep_docs=False, resident=True, keep_text=totals, pruned=True)
     st = table.stats()
 
-    def local(k, download=False):
+    def local(k, download=False, time_each=False):
         for _ in range(k):
-            table.launch()
+            table.launch(time_each=time_each)
         return table.eval(download=download, collect_only=True)
     t_first = time.perf_counter()
     local(1)                                   # (plan upload, hiprtc builds of every plan group, binding)
@@ -476,9 +476,7 @@ def side_point(config, reviews, steps, warmup, oracle_n, dev_index, fx, nss, wit
     res = local(steps)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    os.environ["GK_EVENT_PER_LAUNCH"] = "1"
-    iso = local(min(steps, 20))
-    del os.environ["GK_EVENT_PER_LAUNCH"]
+    iso = local(min(steps, 20), time_each=True)   # an event pair per launch: the kernel's own duration
     final = local(1, download=True)
     groups = int(final.n_plan_groups)
     # several plan groups run on their own streams and overlap: the sum of their kernels' durations is not the sweep's duration --
@@ -823,10 +821,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def local(steps, download=False):
+    def local(steps, download=False, time_each=False):
         """plain launches of the hot path over this rank's shard, no exchange"""
         for _ in range(steps):
-            table.launch()
+            table.launch(time_each=time_each)
         return table.eval(download=download, collect_only=True)
 
     def sharded_step(steps):
@@ -846,9 +844,7 @@ def main():
     counts = final.counts
     # isolated kernel duration: a second, untimed pass with one HIP event pair per launch (the timed region above
     # brackets all launches with one pair, i.e. its average includes the gaps between consecutive launches)
-    os.environ["GK_EVENT_PER_LAUNCH"] = "1"
-    iso = local(min(args.steps, 20))
-    del os.environ["GK_EVENT_PER_LAUNCH"]
+    iso = local(min(args.steps, 20), time_each=True)
     if dist is not None:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

@@ -98,7 +98,7 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts) {
   // ---------------------------------------------------------------------------------------------- phase 1
   // inlined into its single call site (the chunk loop): as a separate function every LDS atomic would first look the
   // dynamic-LDS base up in a table (s_getpc + s_load + full wait; seen in the gfx950 ISA) and the call frame costs scratch
-  const bool inline_row = !(getenv("GK_JIT_INLINE_ROW") && atoi(getenv("GK_JIT_INLINE_ROW")) == 0);   // tuning aid
+  const bool inline_row = true;
   o << "template <class Acc>\nGK_HD __attribute__((" << (inline_row ? "always_inline" : "noinline") << ")) void jit_row(Row r, uint32_t cls, StrHdr h, const uint8_t* heap, Acc acc, bool on) {\n"
     << "  const uint8_t* cheap = gk_plan_consts;\n  (void)cheap; (void)h;\n  cls = GK_UNI(cls) & ~GK_ENT_NEEDS_STR;   // one class per call: the dispatch is a scalar branch\n";
   std::ostringstream& real_o = o;
@@ -338,7 +338,7 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts) {
           if (b) { pd = var_of(b - 1); if (pd < 0) throw Unsupported("codegen: parent loop not open"); }
           // (a large scope under another loop is read where it is used -- one LDS read with a constant address per copy -- instead of
           //  being kept in registers across the whole run: 12 words of a volumes array pushed the kernel past its 80-VGPR budget)
-          static const uint32_t pre_cap = getenv("GK_JIT_PRELOAD_CAP") ? (uint32_t)atoi(getenv("GK_JIT_PRELOAD_CAP")) : 8u;
+          constexpr uint32_t pre_cap = 8u;   // (16: 10 spilled dwords and 0.1167 against 0.1080 ms; 4: 0.1090 -- profiles/r05_variants_g_preload.log)
           const bool in_regs = sc.cap <= pre_cap || stack.empty();
           for (uint32_t e = 0; e < sc.cap; e++) {
             if (in_regs) pre_words.insert({a, e});
@@ -358,14 +358,14 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts) {
         // they contribute nothing, and the compiler can issue all LDS reads of the nest at once
         uint64_t nest = sc.cap;
         for (const Loop& l : stack) nest *= plan.scopes[l.scope].cap;
-        static const uint64_t unroll_max = getenv("GK_UNROLL_MAX") ? (uint64_t)atoi(getenv("GK_UNROLL_MAX")) : 4;   // tuning aid
+        constexpr uint64_t unroll_max = 4;
         if (sc.cap <= 16 && nest <= unroll_max) {
           o << ind << "{ _Pragma(\"unroll\")\n";
           o << ind << "  for (uint32_t e" << d << " = 0; e" << d << " < " << sc.cap << "u; e" << d << "++) {\n";
         } else {
           // run-time trip count (the wave's largest element count): partially unrolled, so that the LDS reads of several
           // iterations are in flight together instead of one exposed LDS latency per element
-          static const int dyn_unroll = getenv("GK_LOOP_UNROLL") ? atoi(getenv("GK_LOOP_UNROLL")) : 1;   // tuning aid
+          constexpr int dyn_unroll = 1;   // (partial unrolling of the run-time-bounded loops measured slower in round 3: 0.127 / 0.140 against 0.122 ms)
           o << ind << "{ const uint32_t n" << d << " = GK_UNI(bounds[" << a << "]);\n";
           if (dyn_unroll > 1) o << ind << "  _Pragma(\"unroll " << dyn_unroll << "\")\n";
           o << ind << "  for (uint32_t e" << d << " = 0; e" << d << " < n" << d << "; e" << d << "++) {\n";
@@ -465,7 +465,7 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts) {
     std::vector<Blk> blks;
     size_t prev = 0;
     for (uint32_t e : plan.seg_ends) { blks.push_back({prev, e, 0, 0, {}, {}}); prev = e; }
-    static const uint64_t loop_weight = getenv("GK_JIT_LOOP_WEIGHT") ? (uint64_t)std::max(1, atoi(getenv("GK_JIT_LOOP_WEIGHT"))) : 3;   // tuning aid: cost of a loop body relative to straight-line code
+    constexpr uint64_t loop_weight = 3;   // cost of a loop body relative to straight-line code
     std::map<uint64_t, size_t> writer;   // derived bit -> block
     for (size_t bi = 0; bi < blks.size(); bi++) {
       Blk& B = blks[bi];
@@ -495,7 +495,7 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts) {
     // block can be placed that way the formulas take ONE stage -- one barrier and one call per item instead of one per level
     // of derived bits (configs[2]: three stages, the last two a dozen lines each, profiles/r03_*).  Otherwise: stages as before.
     bool chained = false;
-    static const bool chain_on = !(getenv("GK_JIT_CHAIN") && atoi(getenv("GK_JIT_CHAIN")) == 0);   // tuning aid
+    constexpr bool chain_on = true;
     if (chain_on && n_stages > 1) {
       std::vector<std::vector<size_t>> deps(blks.size());   // direct producers
       {
@@ -578,7 +578,6 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts) {
         parts.assign(NW, {});
         for (uint32_t k = 0; k < NW; k++) for (size_t bi = 0; bi < blks.size(); bi++) if (in_part[k][bi]) parts[k].push_back(bi);
       }
-      if (getenv("GK_DEBUG_STAGES")) fprintf(stderr, "[gkgpu stages] %zu blocks, cost %llu, chained %d, duplicated cost %llu\n", blks.size(), (unsigned long long)total, (int)chained, (unsigned long long)dup_total);
     }
     if (!chained) {
     parts.assign((size_t)n_stages * NW, {});
@@ -598,7 +597,7 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts) {
     // the preloaded form when its unrolled text stays small: operations after unrolling, summed over the parts
     bool use_pre = !(getenv("GK_JIT_PRELOAD") && atoi(getenv("GK_JIT_PRELOAD")) == 0);
     if (use_pre) {
-      static const size_t pre_budget = getenv("GK_JIT_PRELOAD_BUDGET") ? (size_t)atoll(getenv("GK_JIT_PRELOAD_BUDGET")) : 12000;
+      constexpr size_t pre_budget = 12000;   // (100 000 -- every part of the corpus plans unrolled -- measured slower: 0.6045 against 0.5141 ms summed over the groups)
       std::function<uint64_t(size_t, size_t)> unrolled = [&](size_t pc, size_t pc1) -> uint64_t {
         uint64_t n = 0;
         while (pc < pc1) {
@@ -613,7 +612,6 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts) {
       for (auto& part : parts) for (size_t bi : part) total += unrolled(blks[bi].pc0, blks[bi].pc1);
       for (const Scope& sc : plan.scopes) if (sc.cap > 16) total = ~0ull;   // (large capacities keep their loops)
       if (total > pre_budget) use_pre = false;
-      if (getenv("GK_DEBUG_STAGES")) fprintf(stderr, "[gkgpu stages] preloaded form: %llu operations after unrolling -> %s\n", (unsigned long long)total, use_pre ? "used" : "loops kept");
     }
     o << "#define GK_HAS_STAGES 1\nconstexpr uint32_t GK_N_STAGES = " << n_stages << "u;\nconstexpr uint32_t GK_GEN_PARTS = " << NW << "u;\n"
       << "#ifndef GK_RES\n#define GK_RES(kind, slot, b) do { if ((kind) == 0) res.viol |= (uint64_t)(b) << (slot); else if ((kind) == 1) res.match |= (uint64_t)(b) << (slot); "
@@ -632,7 +630,7 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts) {
         // RUNS of consecutive blocks share one set of preloaded registers; a run ends where the words it keeps live would exceed
         // `pre_live` (the kernel runs at an 80-VGPR budget: everything preloaded at the top of the part spilled 19 dwords).  A later
         // run re-reads what an earlier one derived: the same wave's LDS operations complete in order.
-        static const size_t pre_live = getenv("GK_JIT_PRELOAD_LIVE") ? (size_t)atoi(getenv("GK_JIT_PRELOAD_LIVE")) : 16;
+        constexpr size_t pre_live = 16;
         std::set<uint32_t> bounds_done;
         std::ostringstream run_body;
         std::set<std::pair<uint32_t, uint32_t>> run_words;

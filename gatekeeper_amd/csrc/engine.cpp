@@ -475,10 +475,6 @@ DevPlan* plan_for_table(gk_engine* e, gk_table* t, const HostPlan** host) {
       pc.scope_cap = caps;
       v->fast = pb.build(pc);
       if (v->fast.scopes.size() != e->fast.scopes.size()) throw std::runtime_error("scope layout changed");
-      if (const char* dump = getenv("GK_PLAN_SOURCE_DUMP")) {
-        FILE* f = fopen((std::string(dump) + ".variant").c_str(), "w");
-        if (f) { std::string src = generate_plan_source(v->fast, getenv("GK_PLAN_SOURCE_PARTS") ? (uint32_t)atoi(getenv("GK_PLAN_SOURCE_PARTS")) : (uint32_t)GK_PARTS_MIN_RPT); fwrite(src.data(), 1, src.size(), f); fclose(f); }
-      }
       v->dev = dev_plan_upload(e->opts.device, v->fast, e->big);
     } catch (const std::exception&) { v->dev = nullptr; }   // e.g. LDS limit: the default plan serves the table
     it = e->variants.emplace(caps, std::move(v)).first;
@@ -536,10 +532,8 @@ void ensure_plan(gk_engine* e) {
     std::vector<std::pair<HostPlan, HostPlan>> plans;
     std::function<void(const std::vector<const ConstraintRec*>&)> place = [&](const std::vector<const ConstraintRec*>& g) {
       HostPlan f, b;
-      auto t0 = std::chrono::steady_clock::now();
       try { builds(g, &f, &b); }
       catch (const Unsupported& u) {
-        if (getenv("GK_PLAN_TIMING")) fprintf(stderr, "[plan] %zu constraints: does not fit one plan (%s) after %.2f s\n", g.size(), u.what(), std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
         if (g.size() == 1 && g[0]->referential)   // (its formula follows the synced objects: say so -- the same words refresh_referential uses)
           throw Unsupported(std::string("referential constraint ") + g[0]->kind + "/" + g[0]->name + " does not compile against the synced inventory: " + u.what());
         if (g.size() <= 1) throw;
@@ -550,7 +544,6 @@ void ensure_plan(gk_engine* e) {
           place(std::vector<const ConstraintRec*>(g.begin() + i, g.begin() + std::min(g.size(), i + half)));
         return;
       }
-      if (getenv("GK_PLAN_TIMING")) fprintf(stderr, "[plan] %zu constraints: built in %.2f s\n", g.size(), std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
       groups.push_back(g);
       plans.emplace_back(std::move(f), std::move(b));
     };
@@ -584,10 +577,6 @@ void ensure_plan(gk_engine* e) {
     if (g->dev) { dev_plan_free(g->dev); g->dev = nullptr; }
     g->dev = dev_plan_upload(e->opts.device, g->fast, g->big);
   }
-  if (const char* dump = getenv("GK_PLAN_SOURCE_DUMP")) {   // debugging aid: the plan-specialised source text
-    FILE* f = fopen(dump, "w");
-    if (f) { std::string src = generate_plan_source(e->fast, getenv("GK_PLAN_SOURCE_PARTS") ? (uint32_t)atoi(getenv("GK_PLAN_SOURCE_PARTS")) : (uint32_t)GK_PARTS_MIN_RPT); fwrite(src.data(), 1, src.size(), f); fclose(f); }
-  }
   if (e->dev_plan) { dev_plan_free(e->dev_plan); e->dev_plan = nullptr; }
   e->dev_plan = dev_plan_upload(e->opts.device, e->fast, e->big);
   e->plan_gen++;
@@ -612,7 +601,7 @@ std::shared_ptr<const Template::CountForms> derive_count_forms(gk_engine* e, con
     const auto tf0 = std::chrono::steady_clock::now();
     auto cf = std::make_shared<Template::CountForms>(Template::count_forms(ci, count_kmax()));
     if (getenv("GK_DEBUG_LOAD")) fprintf(stderr, "[gkgpu load]   count_forms %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - tf0).count());
-    if (merged_viol && cf->viol && ci.br.size() > 8 && !getenv("GK_NO_MERGED_VIOL")) *merged_viol = cf->viol;   // (a constraint with many unrolled alternatives: the merged form is the smaller formula)
+    if (merged_viol && cf->viol && ci.br.size() > 8) *merged_viol = cf->viol;   // (a constraint with many unrolled alternatives: the merged form is the smaller formula)
     if (!cf->ok) return nullptr;
     // What the counting plans will read must be registered NOW, before tables are flattened: the merged bodies of the counted
     // branches fold their leaf-local parts into dictionary expressions of their own (the violation formula folds the union of
@@ -1365,12 +1354,6 @@ int gk_table_create(gk_engine* e, const gk_review_in* reviews, size_t n, uint32_
     };
     auto run_threads = [&](const std::function<void(size_t)>& fn) {
       if (n_threads <= 1) { fn(0); return; }
-      if (getenv("GK_HOST_SPAWN")) {   // tuning aid: a thread per part and table, as before round 3
-        std::vector<std::thread> th;
-        for (size_t w = 0; w < n_threads; w++) th.emplace_back(fn, w);
-        for (auto& x : th) x.join();
-        return;
-      }
       HostWorkers::get().run(n_threads, fn);
     };
     // content digest (test aid, GK_TABLE_DIGEST=1): per part while its rows are still on the host; parts are combined in
@@ -1411,7 +1394,6 @@ int gk_table_create(gk_engine* e, const gk_review_in* reviews, size_t n, uint32_
         part_upload_s[w] = std::chrono::duration<double>(std::chrono::steady_clock::now() - u0).count();
       } catch (const std::exception& ex) { part_err[w] = ex.what(); }
     });
-    const auto t_parsed = std::chrono::steady_clock::now();
     for (auto& pe_ : part_err) if (!pe_.empty()) { for (DevPart* dp : dev_parts) dev_part_free(dp); return fail(GK_ERR_INTERNAL, pe_); }
     // ---- what is global: row / heap bases by prefix sum -> segment starts, the slot index, review flags
     HostTable& H = t->host;
@@ -1453,19 +1435,12 @@ int gk_table_create(gk_engine* e, const gk_review_in* reviews, size_t n, uint32_
     const auto t_indexed = std::chrono::steady_clock::now();
     t->dev = dev_table_assemble(e->opts.device, dev_parts, t->host);
     const auto t_up = std::chrono::steady_clock::now();
-    if (getenv("GK_PROFILE_HOST")) {
-      double umax = 0;
-      for (double u : part_upload_s) umax = std::max(umax, u);
-      fprintf(stderr, "[gkgpu host] %zu reviews on %zu threads: flatten+upload (overlapped) %.3f s (slowest part upload %.3f s), index %.3f s, assemble %.3f s\n",
-              n, n_threads, std::chrono::duration<double>(t_parsed - t_begin).count(), umax,
-              std::chrono::duration<double>(t_indexed - t_parsed).count(), std::chrono::duration<double>(t_up - t_indexed).count());
-    }
     t->n_reviews = (uint32_t)n;
     t->dir_bytes = t->host.rflags.size() * 4;
     t->slot_path = t->host.slot_path;
     t->path_rows = t->host.path_rows;
     t->path_max = t->host.path_max;
-    t->resident = (flags & GK_TABLE_RESIDENT) || getenv("GK_SPECIALIZE_ALL");
+    t->resident = (flags & GK_TABLE_RESIDENT) != 0;
     t->stats.n_reviews = n; t->stats.n_rows = t->n_rows; t->stats.host_threads = (uint32_t)n_threads;
     t->stats.device_bytes = dev_table_bytes(t->dev);
     // the parts' transfers overlap the flattening of the other host threads: upload_s is what is NOT hidden (slot index,
@@ -1617,6 +1592,7 @@ int gk_table_eval(gk_engine* e, gk_table* t, uint32_t flags, gk_eval_out** out) 
     EvalOptions opt;
     opt.download = !(flags & GK_EVAL_NO_DOWNLOAD);
     opt.want_match = flags & GK_EVAL_WANT_MATCH;
+    opt.time_each = (flags & GK_EVAL_TIME_EACH) != 0;
     // an admission batch (small, evaluated once) never waits for a compiler; an audit-sized or resident table does
     opt.jit_wait = t->resident || t->n_reviews >= 8192;
     {
@@ -1688,7 +1664,6 @@ int gk_table_eval(gk_engine* e, gk_table* t, uint32_t flags, gk_eval_out** out) 
     uint64_t rows_read = 0, hdrs_read = 0, bound = 0, plan_bytes = 0;
     std::vector<uint8_t> seen(t->slot_path.size(), 0);   // per slot: 1 = rows counted, 2 = string headers counted (table-once figure)
     uint64_t rows_once = 0, hdrs_once = 0;
-    static const bool path_stats = getenv("GK_PATH_STATS") != nullptr;
     auto account = [&](const HostPlan& hp) {   // every plan group streams its own bound segments
       for (size_t si = 0; si < t->slot_path.size(); si++) {
         const uint32_t pth = t->slot_path[si];
@@ -1702,7 +1677,6 @@ int gk_table_eval(gk_engine* e, gk_table* t, uint32_t flags, gk_eval_out** out) 
         if (str) hdrs_read += n;
         if (!(seen[si] & 1)) { seen[si] |= 1; rows_once += n; }
         if (str && !(seen[si] & 2)) { seen[si] |= 2; hdrs_once += n; }
-        if (path_stats) fprintf(stderr, "[path] %u rows %llu per-group %.1f str %d preds %u\n", pth, (unsigned long long)n, (double)n / std::max<uint32_t>(1, (p.n_reviews + t->rpt - 1) / t->rpt), (int)str, ent & 0xFF);
       }
       plan_bytes += (uint64_t)hp.path_preds.size() * sizeof(Pred) + hp.code.size() * 4 + hp.cheap.size();
     };

@@ -1125,9 +1125,7 @@ inline uint64_t Flattener::name8(const char* key, uint32_t len) const {
   return w;
 }
 uint32_t Flattener::fast_child_at(uint32_t parent, uint32_t pos, const char* key, uint32_t len) {
-  static const bool nopred = getenv("GK_NO_PRED") != nullptr;   // tuning aid
   const uint64_t w8 = name8(key, len);
-  if (nopred) return fast_child_w(parent, key, len, w8);
   if (parent < pred_.size() && pos < pred_[parent].size()) {
     const PredEnt& pe = pred_[parent][pos];
     if (pe.len == len && pe.first8 == w8 && pe.id != 0xFFFFFFFFu && (len <= 8 || memcmp(key_arena_.data() + pe.off + 8, key + 8, len - 8) == 0)) return pe.id;

@@ -29,18 +29,10 @@ inline int jit_block_of(uint32_t rpt) {
 // phase 2 alias one of them when they fit; the generic build also keeps the waves' loop bounds there).  res_k = 0: the
 // generic bytecode build.
 inline uint32_t list_cap_of(int block) { return (uint32_t)std::min(block / GK_TILE, 8) * GK_WAVE_CHUNKS; }
-// list capacity a plan-specialised build is compiled for.  GK_JIT_TRIM_LISTS=1 (tuning aid): what the table's longest list
-// needs (`need` entries incl. the header), in steps of 128 -- the two list buffers are most of the kernel's static LDS, and
-// at configs[2] (90 entries of 512) the 3 KB saved are the difference between three and four resident groups per CU.  Measured
-// in round 3 and OFF: four groups mean a 64-VGPR budget, whose 12 spilled dwords are reloaded in phase 2 -- formulas 18.0 k
-// clocks per group against 10.0 k, 0.133 against 0.1235 ms (profiles/r03_variants_h_four_groups_per_cu_64_vgprs.log).
-inline uint32_t jit_list_cap(int block, uint32_t need) {
-  const uint32_t full = list_cap_of(block);
-  if (!getenv("GK_JIT_TRIM_LISTS")) return full;
-  uint32_t c = 128;
-  while (c < need && c < full) c += 128;
-  return std::min(c, full);
-}
+// list capacity a plan-specialised build is compiled for: the geometry's full capacity.  (Trimming it to what the table's longest list
+// needs buys a fourth resident group per CU at configs[2] -- and a 64-VGPR budget whose spills cost more: 0.133 against 0.1235 ms,
+// profiles/r03_variants_h_four_groups_per_cu_64_vgprs.log; removed in round 5.)
+inline uint32_t jit_list_cap(int block, uint32_t) { return list_cap_of(block); }
 inline size_t static_lds_of(uint32_t rpt, int block, uint32_t res_k, uint32_t list_cap = 0) {
   const size_t list = (size_t)(list_cap ? list_cap : list_cap_of(block)) * 8;
   const size_t masks = (size_t)(rpt / GK_TILE) * 3 * (res_k ? res_k : GK_MAX_RES) * 8;

@@ -1594,7 +1594,6 @@ std::shared_ptr<const PreparedConstraint> prepare_constraint(const FP& violation
   pc->viol = simplify(fold_dict(simplify(pin_pass(simplify(violation)))));
   pc->match = simplify(mf.match);
   pc->error = simplify(mf.error);
-  if (getenv("GK_DEBUG_FORMULA")) { std::string t = f_to_string(pc->viol); fprintf(stderr, "[gkgpu formula] %zu chars: %s\n", t.size(), t.substr(0, (size_t)atoi(getenv("GK_DEBUG_FORMULA"))).c_str()); }
   pc->viol_key = canon(pc->viol);
   pc->match_key = canon(pc->match) + "##" + canon(pc->error);
   return pc;
@@ -1609,7 +1608,6 @@ HostPlan PlanBuilder::build(const PlanCaps& caps) {
   L.caps = caps;
   std::map<std::string, uint32_t> viol_ids, match_ids;
   std::vector<FP> viols, matches, errs;
-  auto T0 = std::chrono::steady_clock::now();
   for (auto& c : cons_) {
     const FP &v = c->viol, &m = c->match, &e = c->error;
     const std::string &vk = c->viol_key, &mk = c->match_key;
@@ -1622,7 +1620,6 @@ HostPlan PlanBuilder::build(const PlanCaps& caps) {
   }
   if (viols.size() > GK_MAX_RES || matches.size() > GK_MAX_RES)
     throw Unsupported("more than 64 distinct violation or match formulas in one plan (split the constraint set)");
-  auto T1 = std::chrono::steady_clock::now();
   std::vector<uint32_t> main_ends;
   for (size_t i = 0; i < viols.size(); i++) { int r = L.lower(viols[i]); L.emit(finst(F_RES, r, 0, (uint32_t)i)); L.release(r); main_ends.push_back((uint32_t)L.plan.code.size()); }
   for (size_t i = 0; i < matches.size(); i++) {
@@ -1697,9 +1694,7 @@ HostPlan PlanBuilder::build(const PlanCaps& caps) {
   while (p.cheap.size() & 3) p.cheap.push_back(0);
   if (p.cheap.empty()) p.cheap.resize(4, 0);
   p.dims.const_bytes = (uint32_t)p.cheap.size();
-  auto T2 = std::chrono::steady_clock::now();
   p.resolve_paths(*dict_);
-  if (getenv("GK_PLAN_TIMING") && cons_.size() > 1) fprintf(stderr, "[plan]   dedupe %.2f s, lower %.2f s, resolve %.2f s\n", std::chrono::duration<double>(T1 - T0).count(), std::chrono::duration<double>(T2 - T1).count(), std::chrono::duration<double>(std::chrono::steady_clock::now() - T2).count());
   return p;
 }
 

@@ -204,6 +204,8 @@ typedef struct {
 #define GK_EVAL_ASYNC 8u         /* enqueue one launch on the default stream and return (out = NULL); the next call
                                     without this flag synchronises, and reports the average kernel time per launch */
 #define GK_EVAL_COLLECT 16u      /* do not launch: synchronise and collect the results of the pending GK_EVAL_ASYNC launches */
+#define GK_EVAL_TIME_EACH 32u    /* with GK_EVAL_ASYNC: an event pair around THIS launch (fast_kernel_ms of the collecting call = the sum of the
+                                    isolated kernel durations / launches) instead of one pair around all pending launches, gaps included */
 
 /* The hot path: every loaded constraint x every review of the table -- Match (a3-a7) + violation predicate (a8/a9).
  * Replaces the per-object Client.Review loops at pkg/audit/manager.go:591-642,706-719 and pkg/webhook/policy.go:826. */

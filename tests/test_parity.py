@@ -628,7 +628,7 @@ def test_edge_cases(backend, fixtures):
     rv = [D.AugmentedUnstructured(D.Unstructured(o), None, "Original") for o in [small[0], big, small[1]]]
     table = c.driver.engine.create_table([D.to_review_in(r) for r in rv])
     ev = table.eval()
-    assert ev.n_overflow == (0 if os.environ.get("GK_SPECIALIZE_ALL") else 1)
+    assert ev.n_overflow == 1
     table.free()
     # a resident table gets a plan variant sized for its largest arrays: the same review stays on the LDS kernel
     table = c.driver.engine.create_table([D.to_review_in(r) for r in rv], resident=True)
@@ -645,7 +645,7 @@ def test_edge_cases(backend, fixtures):
     wrv = [D.AugmentedUnstructured(D.Unstructured(o), None, "Original") for o in wide + objs[:3]]
     table = c.driver.engine.create_table([D.to_review_in(r) for r in wrv])
     ev = table.eval()
-    assert (ev.n_overflow >= 64 or os.environ.get("GK_SPECIALIZE_ALL")) and int(ev.too_big.sum()) == 0
+    assert ev.n_overflow >= 64 and int(ev.too_big.sum()) == 0
     table.free()
     assert_parity(c, oc, wrv)
     # DELETE: object := oldObject (target.go:269-287); missing oldObject is a review error
