@@ -12,9 +12,9 @@ per-shard violation bitmaps / counts are exchanged with one RCCL all-gather insi
 Prints ONE JSON line on rank 0 (contract in the task description) with
   roofline      dominant kernel: algorithmic bytes per launch / average launch duration (HIP events) vs 8 TB/s HBM
   end_to_end    the PCIe-inclusive leg: host parse + HandleReview + flatten + H2D of the same objects (never `value`)
-  cpu_baseline  the compiled restated-reference CPU loop (oracle/cpu_ref.cpp) on 1 thread and on all host cores
-  parity_sample the device bitmap of the timed table compared with that CPU loop on a sample of the same objects
-  parity_python_oracle   ... and with the pure-Python oracle (no code shared with the product) on 65 536 of them
+  cpu_baseline  the independent compiled restatement of the reference's loop (oracle/indep_check.cpp) on 1 thread and on all host cores
+  parity_sample / parity_compiled_independent   the device bitmaps of the timed table against that checker, every object, bit for bit
+  parity_python_oracle   ... and against the pure-Python oracle (no code shared with the product either)
 """
 import argparse
 import json
@@ -26,52 +26,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-
-
-def cpu_leg(templates, constraints, batch, ev, budget_s=10.0):
-    """cpu_baseline + parity_sample.  The compiled restatement of the reference's serial audit loop (oracle/cpu_ref.cpp:
-    per object marshal, per constraint re-decode + match.Matches + template evaluation; pkg/audit/manager.go:591-642) is
-    timed on ONE thread (the reference's shape) and on all host cores, each on a bounded sample of the SAME objects the
-    device table holds; its violation / autoreject bitmaps are compared with the device's over the larger sample."""
-    import numpy as np
-    from oracle import cpu_ref as CR
-    ref = CR.CpuRef(templates, constraints)
-    nc = len(constraints)
-    # the CPUs this process may really use (gk_host_cpus: affinity mask and cgroup CPU quota applied -- the GPU boxes of this
-    # pool show 256 hardware threads behind a 16-CPU quota, and 256 threads under that quota are SLOWER than 16)
-    cores = int(batch.lib.gk_host_cpus()) or os.cpu_count() or 1
-    probe_n = min(batch.n, 1024)
-    probe = ref.review(batch.reviews, probe_n, 1)
-    rate1 = probe_n / max(probe["seconds"], 1e-9)               # reviews/s on one thread
-    n1 = int(max(64, min(batch.n, rate1 * budget_s)) // 64 * 64) or batch.n
-    one = ref.review(batch.reviews, n1, 1)
-    probe_all_n = int(min(batch.n, max(1024, cores * 128)) // 64 * 64) or batch.n
-    probe_all = ref.review(batch.reviews, probe_all_n, cores)                 # measured, not assumed, all-core rate
-    rate_all = probe_all_n / max(probe_all["seconds"], 1e-9)
-    nall = int(max(n1, min(batch.n, rate_all * budget_s)) // 64 * 64) or batch.n
-    allc = ref.review(batch.reviews, nall, cores)
-    # parity: device bitmap rows (by constraint key) vs the CPU loop, over the all-core sample
-    row_of = {int(cid): i for i, cid in enumerate(ev.constraint_ids)}
-    words = nall // 64
-    equal, dev_pairs, cpu_pairs = True, 0, 0
-    for row, cid in enumerate(batch_constraint_ids):
-        d_v, d_e = ev.viol[row_of[cid]][:words], ev.err[row_of[cid]][:words]
-        equal = equal and bool((d_v == allc["viol"][row][:words]).all()) and bool((d_e == allc["err"][row][:words]).all())
-        dev_pairs += int(np.unpackbits(d_v.view(np.uint8)).sum())
-        cpu_pairs += int(np.unpackbits(allc["viol"][row][:words].view(np.uint8)).sum())
-    base = {"value": n1 * nc / one["seconds"], "unit": "evals/s", "cores": 1, "kind": "port",
-            "sample": "first %d of the same synthetic objects x %d constraints, compiled restated-reference CPU loop (oracle/cpu_ref.cpp: "
-                      "per-object marshal, per-constraint re-decode + match.Matches + tree-walking Rego evaluation; the Go/OPA "
-                      "reference itself cannot be built here), %.1f s on 1 thread.  NOTE: the loop shape and match.Matches are "
-                      "restated in cpu_ref.cpp, but its JSON reader, HandleReview normalisation and Rego tree-walker are the "
-                      "PRODUCT's host objects (flatten.o / pe.o / ceval.o) -- this times the product's concrete evaluator inside the "
-                      "reference's loop, not OPA; the independent checker is parity_python_oracle" % (n1, nc, one["seconds"]),
-            "all_cores": {"value": nall * nc / allc["seconds"], "cores": cores, "hardware_threads": os.cpu_count(), "sample_reviews": nall, "seconds": allc["seconds"],
-                          "note": "cores = CPUs usable under the affinity mask / cgroup CPU quota (gk_host_cpus), one thread each"}}
-    parity = {"n": nall, "constraints": nc, "pairs_equal": equal, "device_violating_pairs": dev_pairs, "cpu_violating_pairs": cpu_pairs,
-              "checker": "oracle/cpu_ref.cpp (violation + autoreject bitmaps, bit for bit; Match layer independent, Rego evaluator = the "
-                         "product's host interpreter -- see parity_python_oracle for the fully independent leg)"}
-    return base, parity
 
 
 def indep_leg(templates, constraints, batch, ev, ids=None, budget_s=8.0, n=None):
@@ -924,13 +878,15 @@ def main():
         except Exception as ex:   # noqa: BLE001
             out["audit_result_totals"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
         if not args.no_cpu_baseline and not args.lean and world == 1:   # (the checkers and the CPU baseline: N = 1 only -- at N > 1 the other ranks would wait ~2 min for rank 0)
-            product_loop, out["parity_sample"] = cpu_leg(templates, defaulted, batch, final)
-            try:   # cpu_baseline = the independent compiled restatement; the loop around the product's own evaluator stays beside it
+            # cpu_baseline AND the parity checker are the INDEPENDENT compiled restatement (oracle/libgkindep.so: nothing of the product
+            # linked).  Until round 4 `parity_sample` came from oracle/cpu_ref.cpp, whose JSON reader and Rego evaluator are the product's
+            # own host objects -- product against product for the Rego half; that loop is no part of the bench line any more.
+            try:
                 out["cpu_baseline"], out["parity_compiled_independent"] = indep_leg(templates, constraints, batch, final)
-                out["cpu_baseline"]["product_evaluator_in_the_reference_loop"] = product_loop
             except Exception as ex:   # noqa: BLE001
-                out["cpu_baseline"] = product_loop
+                out["cpu_baseline"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
                 out["parity_compiled_independent"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+            out["parity_sample"] = {k: v for k, v in out["parity_compiled_independent"].items() if k in ("n", "constraints", "pairs_equal", "device_violating_pairs", "checker_violating_pairs", "checker", "error")}
             try:   # ... the RESULT totals the checker counted in that pass against gk_table_totals
                 vs = totals_against_checker(table, out["parity_compiled_independent"])
                 if vs is not None and isinstance(out.get("audit_result_totals"), dict):
@@ -956,10 +912,9 @@ def main():
             known = (n_local, [int(counts[row_of0[cid]]) for cid in batch_constraint_ids]) if n_local % 64 == 0 else None
             detail, brief = other_configs(args, local_rank, dev, fx, nss, known_prefix=known)
             out["other_configs_detail"] = detail
-            pp, ps = out.get("parity_python_oracle") or {}, out.get("parity_sample") or {}
+            pp = out.get("parity_python_oracle") or {}
             brief["configs2"] = {"w": "%dx%d" % (nc, total_reviews), "ms": _sig(out["ms_per_step"]), "frac": _sig(out["roofline"]["frac"], 3),
                                  "parity": {"n": pp.get("n"), "equal": pp.get("pairs_equal"), "pairs": pp.get("oracle_violating_pairs"), "s": _sig(pp.get("seconds"), 3)},
-                                 "cpu_loop_parity": {"n": ps.get("n"), "equal": ps.get("pairs_equal")},
                                  "compiled_independent_parity": {k: (out.get("parity_compiled_independent") or {}).get(k) for k in ("n", "pairs_equal", "checker_violating_pairs", "seconds", "error") if k in (out.get("parity_compiled_independent") or {})},
                                  "messages": {k: v for k, v in (out.get("parity_messages_compiled_independent") or {}).items() if k in ("objects", "messages", "messages_equal", "error")},
                                  "totals": {"s": _sig((out.get("audit_result_totals") or {}).get("seconds"), 3), "rendered_share": _sig((out.get("audit_result_totals") or {}).get("rendered_share"), 3),

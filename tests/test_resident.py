@@ -90,8 +90,8 @@ def test_audit_from_cache_incremental(backend, fixtures):
 
 @pytest.mark.parametrize("backend", [b for b in BACKENDS if b.id in ("hostemu", "gpu")])
 def test_resident_set_10k_against_compiled_reference(backend, fixtures):
-    """10 000 synced objects, 1 % mutated: per-constraint violating-pair totals of the sweep == the compiled restatement of
-    the reference's serial loop (oracle/cpu_ref.cpp) over the same objects."""
+    """10 000 synced objects, 1 % mutated: per-constraint violating-pair and RESULT totals of the sweep == the independent compiled
+    checker (oracle/libgkindep.so) and the compiled loop around the product's evaluator (oracle/cpu_ref.cpp) over the same objects."""
     c, oc = load_both(backend, synth.psp_templates(fixtures), synth.audit_constraints())
     nss = synth.gen_namespaces()
     objs = synth.gen_objects(10000, seed=77, mixed=True)
@@ -128,3 +128,12 @@ def test_resident_set_10k_against_compiled_reference(backend, fixtures):
     pairs = {c.driver.constraint_id(k): int(np.unpackbits(out["viol"][row].view(np.uint8)).sum()) for row, k in enumerate(cons)}
     results = {c.driver.constraint_id(k): int(out["results"][row]) for row, k in enumerate(cons)}
     assert s1["pairs"] == pairs and s1["results"] == results and sum(pairs.values()) > 1000
+    # ... and through the INDEPENDENT compiled checker (oracle/indep_check.cpp: nothing of the product linked; the loop above shares the
+    # product's JSON reader and Rego evaluator): the same pair and RESULT totals per constraint
+    from oracle.indep_check import IndepChecker
+    ck = IndepChecker(synth.psp_templates(fixtures), synth.audit_constraints())
+    viol, err, res = ck.check_totals(arr, len(all_objs), 4)
+    ck.close()
+    ipairs = {c.driver.constraint_id(k): int(np.unpackbits(viol[row].view(np.uint8)).sum()) for row, k in enumerate(cons)}
+    iresults = {c.driver.constraint_id(k): int(res[row]) for row, k in enumerate(cons)}
+    assert s1["pairs"] == ipairs and s1["results"] == iresults
