@@ -298,6 +298,66 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts) {
       pc++;
     }
   };
+  // CONJUNCTION bodies (round 5).  Most loops of a compiled policy set ask "does SOME element hold bits b1 & b2 & !b3 .." -- a
+  // conjunction of literals of the element's own words (after the string tests became dictionary bits nearly every container loop
+  // of the 200-template corpus has that shape).  Evaluated bit by bit that is an extract per literal, a combine per literal and two
+  // operations to accumulate, per element; as ONE masked compare per element word -- (w & care) == want, the element's presence bit
+  // among the literals, so that the zero word of an absent element fails by itself -- it is two vector operations and a scalar OR.
+  // -> care / want per word of the element (index = word), false when the body is anything but such a conjunction.
+  struct Conj { std::vector<uint32_t> care, want; bool never = false; };
+  auto conj_body = [&](uint32_t scope, size_t pc, size_t end, uint32_t result_reg, Conj* out) -> bool {
+    struct Lit { uint32_t bit; bool pos; };
+    struct Val { int kind = 0; std::vector<Lit> lits; };   // kind 0: unknown, 1: conjunction of lits, 2: constant false, 3: constant true
+    std::map<uint32_t, Val> regs;
+    auto conj_and = [&](const Val& x, const Val& y) -> Val {
+      Val r;
+      if (x.kind == 0 || y.kind == 0) return r;
+      if (x.kind == 2 || y.kind == 2) { r.kind = 2; return r; }
+      if (x.kind == 3) return y;
+      if (y.kind == 3) return x;
+      r.kind = 1; r.lits = x.lits;
+      for (const Lit& l : y.lits) {
+        bool dup = false;
+        for (const Lit& m : r.lits) if (m.bit == l.bit) { if (m.pos != l.pos) { r.kind = 2; r.lits.clear(); return r; } dup = true; }
+        if (!dup) r.lits.push_back(l);
+      }
+      return r;
+    };
+    auto neg = [&](const Val& x) -> Val {
+      Val r;
+      if (x.kind == 2) r.kind = 3; else if (x.kind == 3) r.kind = 2;
+      else if (x.kind == 1 && x.lits.size() == 1) { r.kind = 1; r.lits = {Lit{x.lits[0].bit, !x.lits[0].pos}}; }
+      return r;
+    };
+    while (pc < end) {
+      const uint32_t ins = code[pc++];
+      const uint32_t op = ins & 0xFF, a = (ins >> 8) & 0xFF, b = (ins >> 16) & 0xFF, c = ins >> 24;
+      switch (op) {
+        case F_LDE: { if (b != scope) return false; Val v; v.kind = 1; v.lits = {Lit{c, true}}; regs[a] = v; break; }
+        case F_AND: regs[a] = conj_and(regs[b], regs[c]); break;
+        case F_ANDN: regs[a] = conj_and(regs[b], neg(regs[c])); break;
+        case F_NOT: regs[a] = neg(regs[b]); break;
+        case F_MOV: regs[a] = regs[b]; break;
+        case F_CONST: { Val v; v.kind = (b & 1) ? 3 : 2; regs[a] = v; break; }
+        default: return false;   // a nested loop, a join, a derived bit, a global / flag bit, a disjunction: the general form
+      }
+      if (regs[a].kind == 0) return false;
+    }
+    const Val& body = regs[result_reg];
+    if (body.kind == 0) return false;
+    const Scope& sc = plan.scopes[scope];
+    out->care.assign(sc.wpe, 0u); out->want.assign(sc.wpe, 0u);
+    out->care[0] = 1u; out->want[0] = 1u;   // the element is present
+    if (body.kind == 2) { out->never = true; return true; }
+    if (body.kind == 1) for (const Lit& l : body.lits) {
+      const uint32_t w = elem_word_of_bit(l.bit), m = elem_mask_of_bit(l.bit);
+      if (w >= sc.wpe) return false;
+      if ((out->care[w] & m) && (((out->want[w] & m) != 0) != l.pos)) { out->never = true; return true; }
+      out->care[w] |= m;
+      if (l.pos) out->want[w] |= m;
+    }
+    return true;
+  };
   std::function<void(size_t, size_t, bool, std::string)> gen = [&](size_t pc0, size_t pc1, bool staged, std::string ind) {
   std::ostringstream& o = *out_;
   for (size_t pc = pc0; pc < pc1;) {
@@ -327,6 +387,51 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts) {
         const Scope& sc = plan.scopes[a];
         int d = (int)stack.size();
         o << ind << "b" << c << " = 0u;\n";
+        {
+          // the conjunction form: one masked compare per element (word), accumulated as a wave mask
+          const size_t end = loop_end(pc);
+          const uint32_t endins = code[end];
+          Conj cj;
+          static const bool conj_on = !(getenv("GK_JIT_CONJ") && atoi(getenv("GK_JIT_CONJ")) == 0);   // (A/B aid)
+          if (conj_on && (endins & 0xFF) == F_ENDLOOP && ((endins >> 8) & 0xFF) == c && sc.cap <= 16 && conj_body(a, pc, end, (endins >> 16) & 0xFF, &cj)) {
+            int pd = -1;
+            if (b) { pd = var_of(b - 1); if (pd < 0) throw Unsupported("codegen: parent loop not open"); }
+            if (!cj.never) {
+              const bool dyn = !(pre || (sc.cap <= 16 && [&] { uint64_t n = sc.cap; for (const Loop& l : stack) n *= plan.scopes[l.scope].cap; return n <= 4; }()));
+              o << ind << "{ uint32_t t_ = 0u;\n";
+              auto term = [&](const std::string& w0name, uint32_t e_lit, bool have_lit, const std::string& evar) {
+                std::string t;
+                for (uint32_t k = 0; k < sc.wpe; k++) {
+                  if (!cj.care[k]) continue;
+                  std::string wk;
+                  if (k == 0) wk = w0name;
+                  else if (have_lit) wk = "acc.load(" + std::to_string(sc.word_off + e_lit * sc.wpe + k) + "u)";
+                  else wk = "acc.load(" + std::to_string(sc.word_off + k) + "u + " + evar + " * " + std::to_string((int)sc.wpe) + "u)";
+                  if (!t.empty()) t += " & ";   // (bitwise on purpose: `&&` is control flow -- a divergent branch per element)
+                  t += "(uint32_t)((" + wk + " & " + u(cj.care[k]) + ") == " + u(cj.want[k]) + ")";
+                }
+                if (b) t += " & (uint32_t)((" + w0name + " >> 24) == e" + std::to_string(pd) + ")";
+                return t;
+              };
+              if (!dyn) {
+                for (uint32_t e = 0; e < sc.cap; e++) {
+                  std::string w0name;
+                  const bool in_regs = pre && (sc.cap <= 8u || stack.empty());
+                  if (in_regs) { pre_words.insert({a, e}); w0name = "W" + std::to_string(a) + "_" + std::to_string(e); }
+                  else w0name = "acc.load(" + std::to_string(sc.word_off + e * sc.wpe) + "u)";
+                  o << ind << "  t_ |= " << term(w0name, e, true, "") << ";\n";
+                }
+              } else {
+                o << ind << "  const uint32_t nq_ = GK_UNI(bounds[" << a << "]);\n"
+                  << ind << "  for (uint32_t eq_ = 0; eq_ < nq_; eq_++) { const uint32_t wq_ = acc.load(" << sc.word_off << "u + eq_ * " << (int)sc.wpe << "u); t_ |= " << term("wq_", 0, false, "eq_") << "; }\n";
+              }
+              o << ind << "  b" << c << " = t_; }\n";
+            }
+            pre_ops += (size_t)sc.cap * 3;
+            pc = end + 1;
+            break;
+          }
+        }
         if (pre) {
           // every element a copy of the body; the loop's own F_ENDLOOP closes each copy (below)
           const size_t end = loop_end(pc);

@@ -298,7 +298,7 @@ struct gk_engine {
   struct Group { HostPlan fast, big; DevPlan* dev = nullptr; std::vector<uint32_t> ids; std::vector<uint8_t> roles; };   // roles: totals groups only (TR_*)
   std::vector<std::unique_ptr<Group>> extra;
   struct Variant { HostPlan fast; DevPlan* dev = nullptr; };
-  std::map<std::vector<uint16_t>, std::unique_ptr<Variant>> variants;
+  std::map<std::pair<size_t, std::vector<uint16_t>>, std::unique_ptr<Variant>> variants;   // key: (plan group, capacities)
   // plans of the "more than one result" formulas (ConstraintRec::multi_prep), evaluated by gk_table_totals only; built on its
   // first call after a policy change (totals_gen = the plan generation they belong to; guarded by totals_mu, plan_rw shared)
   std::vector<std::unique_ptr<Group>> totals_groups;
@@ -374,9 +374,9 @@ struct gk_table {
   std::vector<DevTable*> views;             // one per extra plan group (shares the device arrays of `dev`)
   std::vector<DevTable*> tviews;            // one per totals plan group (gk_table_totals)
   bool resident = false;
-  uint64_t cached_gen = 0;                  // plan generation the cached variant choice belongs to
-  DevPlan* cached_plan = nullptr;
-  const HostPlan* cached_host = nullptr;
+  uint64_t cached_gen = 0;                  // plan generation the cached variant choices belong to
+  std::vector<DevPlan*> cached_plan;        // per plan group (0 = the primary plan)
+  std::vector<const HostPlan*> cached_host;
   std::vector<uint32_t> slot_path;          // path of each slot of the table's row-group index
   // per review: group \0 version \0 kind \0 namespace \0 name (audit order, manager.go:118-138) -- the bytes in one arena per host
   // thread's part, (offset, length) per review: a std::string per review was a malloc and a free per review
@@ -449,15 +449,22 @@ PlanCaps default_caps(const gk_engine* e) {
 // Plan for one table.  Resident tables (audit sets evaluated again and again) get a variant whose element capacities
 // are what the table's largest arrays need: fewer accumulator words per review -> more tiles resident per CU, and
 // reviews that would overflow the default capacities stay on the LDS kernel.  Caller holds plan_rw (shared suffices) and variants_mu; ensure_plan ran.
-DevPlan* plan_for_table(gk_engine* e, gk_table* t, const HostPlan** host) {
-  *host = &e->fast;
-  if (!t->resident || e->fast.scopes.empty()) return e->dev_plan;
-  if (t->cached_gen == e->plan_gen && t->cached_plan) { *host = t->cached_host; return t->cached_plan; }   // per launch: no rescan
-  std::vector<uint16_t> caps(e->fast.scopes.size(), 1);
-  for (size_t p = 0; p < e->fast.ptab.size(); p++) {
-    uint32_t ent = e->fast.ptab[p];
+// `group`: 0 = the primary plan, g >= 1 = e->extra[g - 1] (a policy set of more than 64 formulas: round 5 -- the further groups ran
+// with the default capacities (8, 8, 8, 12, 12 -> 81 accumulator words for the 200-template corpus, whose pods hold at most 4
+// containers) until then).
+DevPlan* plan_for_group(gk_engine* e, gk_table* t, size_t group, const HostPlan** host) {
+  const HostPlan& base = group == 0 ? e->fast : e->extra[group - 1]->fast;
+  DevPlan* base_dev = group == 0 ? e->dev_plan : e->extra[group - 1]->dev;
+  *host = &base;
+  if (!t->resident || base.scopes.empty()) return base_dev;
+  if (t->cached_gen != e->plan_gen) { t->cached_plan.clear(); t->cached_host.clear(); t->cached_gen = e->plan_gen; }
+  if (t->cached_plan.size() <= group) { t->cached_plan.resize(group + 1, nullptr); t->cached_host.resize(group + 1, nullptr); }
+  if (t->cached_plan[group]) { *host = t->cached_host[group]; return t->cached_plan[group]; }   // per launch: no rescan
+  std::vector<uint16_t> caps(base.scopes.size(), 1);
+  for (size_t p = 0; p < base.ptab.size(); p++) {
+    uint32_t ent = base.ptab[p];
     for (uint32_t j = 0; j < (ent & 0xFF); j++) {
-      const Pred& pr = e->fast.path_preds[(ent >> 8) + j];
+      const Pred& pr = base.path_preds[(ent >> 8) + j];
       if (pr.op != P_PRESENT || pr.dst != D_ELEM) continue;
       uint32_t need = p < t->path_max.size() ? t->path_max[p] : 0;
       if (need > caps[pr.scope]) caps[pr.scope] = (uint16_t)std::min<uint32_t>(need, 255);
@@ -465,26 +472,28 @@ DevPlan* plan_for_table(gk_engine* e, gk_table* t, const HostPlan** host) {
   }
   static const uint16_t steps[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192, 255};
   for (auto& c : caps) for (uint16_t s : steps) if (s >= c) { c = s; break; }
-  auto it = e->variants.find(caps);
+  const std::pair<size_t, std::vector<uint16_t>> key(group, caps);
+  auto it = e->variants.find(key);
   if (it == e->variants.end()) {
     std::unique_ptr<gk_engine::Variant> v(new gk_engine::Variant());
     try {
       PlanBuilder pb(&e->dict, &e->dict_reg);
-      for (auto& c : e->constraints) if (c.alive) pb.add_constraint(c.prep);
+      const std::vector<uint32_t>& ids = group == 0 ? e->plan_ids : e->extra[group - 1]->ids;
+      for (uint32_t id : ids) pb.add_constraint(e->constraints[id].prep);
       PlanCaps pc = default_caps(e);
       pc.scope_cap = caps;
       v->fast = pb.build(pc);
-      if (v->fast.scopes.size() != e->fast.scopes.size()) throw std::runtime_error("scope layout changed");
-      v->dev = dev_plan_upload(e->opts.device, v->fast, e->big);
+      if (v->fast.scopes.size() != base.scopes.size()) throw std::runtime_error("scope layout changed");
+      v->dev = dev_plan_upload(e->opts.device, v->fast, group == 0 ? e->big : e->extra[group - 1]->big);
     } catch (const std::exception&) { v->dev = nullptr; }   // e.g. LDS limit: the default plan serves the table
-    it = e->variants.emplace(caps, std::move(v)).first;
+    it = e->variants.emplace(key, std::move(v)).first;
   }
-  t->cached_gen = e->plan_gen;
-  if (!it->second->dev) { t->cached_plan = e->dev_plan; t->cached_host = &e->fast; return e->dev_plan; }
+  if (!it->second->dev) { t->cached_plan[group] = base_dev; t->cached_host[group] = &base; return base_dev; }
   *host = &it->second->fast;
-  t->cached_plan = it->second->dev; t->cached_host = &it->second->fast;
+  t->cached_plan[group] = it->second->dev; t->cached_host[group] = &it->second->fast;
   return it->second->dev;
 }
+DevPlan* plan_for_table(gk_engine* e, gk_table* t, const HostPlan** host) { return plan_for_group(e, t, 0, host); }
 
 void refresh_referential(gk_engine* e);
 // The READ SET of pruned tables (GK_TABLE_PRUNED; flatten.hpp DictRegistry::set_reads): every path pattern some plan has a predicate
@@ -1604,13 +1613,15 @@ int gk_table_eval(gk_engine* e, gk_table* t, uint32_t flags, gk_eval_out** out) 
       DevPlan* dp = nullptr;
       { std::lock_guard<std::mutex> vl(e->variants_mu); dp = plan_for_table(e, t, &hp); }
       while (t->views.size() < e->extra.size()) t->views.push_back(dev_table_view(t->dev));
+      std::vector<DevPlan*> gdev(e->extra.size(), nullptr);   // the further plan groups: table-sized variants as well
+      { std::lock_guard<std::mutex> vl(e->variants_mu); for (size_t gi = 0; gi < e->extra.size(); gi++) { const HostPlan* gh = nullptr; gdev[gi] = plan_for_group(e, t, gi + 1, &gh); } }
       // every plan group is LAUNCHED before any is collected: the groups work on their own streams (views of the table) and
       // overlap on the device as far as their footprints allow
       if (!(flags & GK_EVAL_COLLECT)) {
         // (several plan groups: their plan-specialised builds are all started first and compile side by side)
-        if (!e->extra.empty() && opt.jit_wait) { dev_jit_prefetch(dp, t->dev); for (size_t gi = 0; gi < e->extra.size(); gi++) dev_jit_prefetch(e->extra[gi]->dev, t->views[gi]); }
+        if (!e->extra.empty() && opt.jit_wait) { dev_jit_prefetch(dp, t->dev); for (size_t gi = 0; gi < e->extra.size(); gi++) dev_jit_prefetch(gdev[gi], t->views[gi]); }
         dev_eval_launch(dp, t->dev, opt);
-        for (size_t gi = 0; gi < e->extra.size(); gi++) dev_eval_launch(e->extra[gi]->dev, t->views[gi], opt);
+        for (size_t gi = 0; gi < e->extra.size(); gi++) dev_eval_launch(gdev[gi], t->views[gi], opt);
       }
       if (flags & GK_EVAL_ASYNC) {   // enqueue only; a later call without GK_EVAL_ASYNC collects
         *out = nullptr;
@@ -1621,7 +1632,7 @@ int gk_table_eval(gk_engine* e, gk_table* t, uint32_t flags, gk_eval_out** out) 
       // further plan groups: same table, their rows are appended below the primary group's
       for (size_t gi = 0; gi < e->extra.size(); gi++) {
         EvalOut og;
-        dev_eval_finish(e->extra[gi]->dev, t->views[gi], opt, &og);
+        dev_eval_finish(gdev[gi], t->views[gi], opt, &og);
         const uint32_t row_base = h->out.n_constraints;
         EvalOut& o = h->out;
         o.viol.insert(o.viol.end(), og.viol.begin(), og.viol.end());
