@@ -1686,6 +1686,7 @@ int gk_table_eval(gk_engine* e, gk_table* t, uint32_t flags, gk_eval_out** out) 
         bool str = false;
         for (uint32_t j = 0; j < (ent & 0xFF); j++) str = str || pred_needs_str(hp.path_preds[(ent >> 8) + j]);
         if (str) hdrs_read += n;
+        if (getenv("GK_DEBUG_PATH_ROWS")) fprintf(stderr, "[gkgpu paths] %-70s rows %9llu preds %3u%s\n", e->dict.to_string(pth).c_str(), (unsigned long long)n, ent & 0xFF, str ? " +hdr" : "");
         if (!(seen[si] & 1)) { seen[si] |= 1; rows_once += n; }
         if (str && !(seen[si] & 2)) { seen[si] |= 2; hdrs_once += n; }
       }

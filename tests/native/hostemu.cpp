@@ -555,6 +555,7 @@ static void emu_kernel_check(const DevPlan* p, const DevTable* dt, const EvalOpt
   if (const char* g = getenv("GK_EMU_GRID")) grid = std::min<unsigned>(grid, (unsigned)std::max(8, atoi(g) / 8 * 8));   // persistent workgroups: several groups each
   else grid = std::min<unsigned>(grid, 16u);
   const Row* rows = t.rows.data(); const StrHdr* shdr = t.shdr.data();
+  const uint32_t emu_dbg = getenv("GK_EMU_STAGGER") ? ((uint32_t)atoi(getenv("GK_EMU_STAGGER")) & 0xFFFu) << 8 : 0u;   // the launch word's stagger field, as dev_eval_launch sets it for >= 1024 groups
   if (jit) {
     if (const char* dir = getenv("GK_EMU_HIP_SOURCE_DIR")) {
       // test aid (tests/test_jit_source.py): the text kernels.hip would hand to hiprtc for this plan, geometry and table
@@ -563,10 +564,10 @@ static void emu_kernel_check(const DevPlan* p, const DevTable* dt, const EvalOpt
       f << assemble_jit_source(hp, rpt, rpp, kPlanHpp, kVmCoreHpp, kKernelBody);
     }
     EmuJitLaunch fn = emu_jit_for(p, rpt, rpp, block);
-    fn(grid, (unsigned)block, lds, &pv, rows, shdr, cl.d.data(), cl.capg, t.rflags.data(), t.heap.data(), n, nt, hp.slots.data(), &out, 0u, rpp);
+    fn(grid, (unsigned)block, lds, &pv, rows, shdr, cl.d.data(), cl.capg, t.rflags.data(), t.heap.data(), n, nt, hp.slots.data(), &out, emu_dbg, rpp);
   } else {
     auto fn = rpt == 64 ? gk_emu_tiles_64 : rpt == 128 ? gk_emu_tiles_128 : rpt == 256 ? gk_emu_tiles_256 : gk_emu_tiles_512;
-    gkemu::launch(grid, (unsigned)block, lds, [&] { fn(pv, rows, shdr, cl.d.data(), cl.capg, t.rflags.data(), t.heap.data(), n, nt, hp.slots.data(), out, 0u, rpp); });
+    gkemu::launch(grid, (unsigned)block, lds, [&] { fn(pv, rows, shdr, cl.d.data(), cl.capg, t.rflags.data(), t.heap.data(), n, nt, hp.slots.data(), out, emu_dbg, rpp); });
   }
   // overflowed reviews: the big variant (per review, as above)
   uint32_t n_ovf = 0;

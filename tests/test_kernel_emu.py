@@ -39,6 +39,9 @@ def _sweep(monkeypatch, mode, n, env):
     {"GK_RPT": 256, "GK_FORCE_RPP": 64, "GK_EMU_GRID": 8},         # multi-pass groups: four passes over the same chunk list
     {"GK_RPT": 512, "GK_FORCE_RPP": 128, "GK_EMU_GRID": 8},        # 16 waves, two passes
     {"GK_RPT": 128, "GK_EMU_LIST_CAP": 24, "GK_EMU_GRID": 8},      # lists overflow: the groups' reviews take the big variant
-], ids=["rpt64", "rpt256", "rpt256-4pass", "rpt512-2pass", "list-overflow"])
+    {"GK_RPT": 64, "GK_EMU_GRID": 32, "GK_EMU_STAGGER": 1},        # staggered grid, 4 workgroups per XCD over 24 groups: 3 per XCD = a partial FIRST round only
+    {"GK_RPT": 64, "GK_EMU_GRID": 16, "GK_EMU_STAGGER": 1},        # 2 per XCD: one full round + a partial one
+    {"GK_RPT": 64, "GK_EMU_GRID": 32, "GK_EMU_STAGGER": 1, "N": 2900},   # 46 groups, 6 per XCD over 4 workgroups: one full round + a partial one of 2
+], ids=["rpt64", "rpt256", "rpt256-4pass", "rpt512-2pass", "list-overflow", "stagger-partial-first", "stagger-partial-last", "stagger-partial-last-4"])
 def test_kernel_source_on_the_emulator(monkeypatch, mode, env):
-    _sweep(monkeypatch, mode, 1500, env)
+    _sweep(monkeypatch, mode, env.get("N", 1500), {k: v for k, v in env.items() if k != "N"})

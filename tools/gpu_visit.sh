@@ -3,7 +3,7 @@
 #   tests      the whole gpu-marked suite (GK_JIT_STRICT=1: a hiprtc failure fails the test)
 #   smoke      __graft_entry__.smoke()
 #   bench      the default bench line (configs[2] + other_configs) as the driver runs it (--steps 20 --warmup 5)
-#   benchq     the headline workload alone with its parity legs (cpu loop, python oracle on 16 384, RESULT totals)
+#   benchq     the headline workload alone with its parity legs (independent compiled checker, python oracle on 16 384, RESULT totals)
 #   lean       bench.py --lean --steps 50 (the headline kernel only: tuning runs)
 #   stats      rocprofv3 --kernel-trace --stats of the lean command
 #   pmc        rocprofv3 --pmc passes of the lean command (SQ, FETCH_SIZE, WRITE_SIZE: separate passes, --kernel-trace only)
@@ -66,7 +66,18 @@ PY
          run_pmc sq SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
          run_pmc fetch FETCH_SIZE
          run_pmc write WRITE_SIZE
-         pmc_summary sq fetch write | tee gpurun_out/${tag}_pmc_summary.txt;;
+         pmc_summary sq fetch write | tee gpurun_out/${tag}_pmc_summary.txt
+         python - gpurun_out/${tag}_pmc_summary.txt $tag > gpurun_out/${tag}_pmc_latest.json <<'PY'
+import json, re, sys
+v = {}
+for line in open(sys.argv[1]):
+    m = re.match(r"\S+ (\S+) per_dispatch=([0-9.]+)", line)
+    if m and "jit_tiles" in line: v[m.group(1)] = float(m.group(2))
+if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+    print(json.dumps({"config": 2, "reviews": 1000000, "hbm_bytes_per_launch": int((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024), "fetch_kb": v["FETCH_SIZE"], "write_kb": v["WRITE_SIZE"],
+                      "source": "profiles/%s_summary.txt (rocprofv3 --pmc, separate passes of `bench.py --steps 5 --warmup 1 --lean` with --kernel-trace only; HBM bytes = 2 x FETCH_SIZE KB (gfx950 correction, MI355X_MICROARCH.md) + WRITE_SIZE KB, KB = 1024 B)" % "r05_pmc_" + sys.argv[2][3:] + "_config2_1M"}, indent=1))
+PY
+         ;;
     pmc4) run_pmc4() { name=$1; shift; timeout 400 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d gpurun_out/${tag}_pmc_$name -o $name -- python bench.py --config 4 --steps 5 --warmup 1 --lean > /dev/null 2> gpurun_out/${tag}_pmc_$name.err; }
          run_pmc4 sq4 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
          run_pmc4 fetch4 FETCH_SIZE
