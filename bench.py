@@ -855,13 +855,21 @@ def main():
                                                                                         "json_MBps": st_again["json_bytes"] / st_again["flatten_s"] / 1e6 if st_again["flatten_s"] > 0 else None},
                            "generate_s": t_gen},
         }
+        if args.config == 2 and n_local == 1000000 and world == 1 and kernel_s > 0 and not os.environ.get("GK_DICT_MATCH"):
+            # Round 5 moved the match layer's five string facts per review (5 rows + 5 string headers = 160 of ~380 bytes) into ONE
+            # dictionary row: the sweep streams 234 MB where rounds 1-4 streamed 379 MB -- `frac` is priced on what
+            # is streamed NOW, so a launch that got a third faster shows a LOWER fraction.  For the comparison with earlier rounds:
+            out["roofline"]["round4_layout"] = {"algo_bytes_per_launch": 378794260, "frac_of_this_launch_time_at_those_bytes": 378794260 / kernel_s / 1e9 / HBM_PEAK_GBS,
+                                                "what": "the same launch time priced at the bytes the round-4 table layout streamed for this workload (GK_DICT_MATCH=0 builds that layout: 0.1136 ms = 0.417 on the box that ran this layout in 0.0763 ms, profiles/r05_variants_r_match_dictionary.log)"}
         if emu:
             out["emulated"] = True
         # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes of this same command (bench.py
         # cannot run a profiler around itself); only reported when the profiled workload is the one just timed
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
-            if pmc.get("config") == args.config and pmc.get("reviews") == n_local and world == 1:
+            # (... and the profiled build streamed the bytes this one does: a PMC figure of an earlier table layout says nothing)
+            same_bytes = pmc.get("algo_bytes_per_launch") is None or abs(pmc["algo_bytes_per_launch"] - int(res.algo_bytes)) <= 0.02 * int(res.algo_bytes)
+            if pmc.get("config") == args.config and pmc.get("reviews") == n_local and world == 1 and same_bytes:
                 out["roofline"]["traffic"] = pmc["hbm_bytes_per_launch"]
                 out["roofline"]["traffic_source"] = pmc["source"]
         except (OSError, ValueError):

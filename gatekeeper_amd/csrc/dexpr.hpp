@@ -9,6 +9,7 @@
 // the answers as a bit mask in a synthetic integer row next to the leaf (path + "$d").  On the device the predicate is a
 // bit test (P_BITS).  Exact by construction: the bits are computed by the same evaluator that renders the messages.
 #pragma once
+#include <cstring>
 #include <functional>
 #include <map>
 #include <memory>
@@ -150,5 +151,45 @@ inline bool dx_deep(const DX& e) {
   return false;
 }
 inline bool dx_true(const DX& e, const Value& leaf) { Value v = dx_eval(e, leaf); return v.is_bool() && v.b; }
+
+// dx_true for a STRING leaf given as bytes, for the shapes the lowering makes of string tests (comparisons with string constants,
+// startswith / endswith / contains, type tests, and / or / not over them): no Value, no allocation.  *ok = false: the expression holds
+// something else -- the caller asks dx_true.  (The match facts of a review -- names are as good as unique -- cannot go through a memo.)
+inline bool dx_true_str(const DX& e, const char* s, size_t n, bool* ok) {
+  switch (e->kind) {
+    case DExpr::CONST: if (e->c.is_bool()) return e->c.b; *ok = false; return false;
+    case DExpr::AND: { for (auto& a : e->args) { if (!dx_true_str(a, s, n, ok)) return false; if (!*ok) return false; } return true; }
+    case DExpr::OR: { for (auto& a : e->args) { if (dx_true_str(a, s, n, ok)) return true; if (!*ok) return false; } return false; }
+    case DExpr::NOT: { const bool v = dx_true_str(e->args[0], s, n, ok); return !v; }
+    case DExpr::DEFINED: if (e->args.size() == 1 && e->args[0]->kind == DExpr::LEAF) return true; *ok = false; return false;
+    case DExpr::TYPE_MASK: if (e->args.size() == 1 && e->args[0]->kind == DExpr::LEAF) return ((e->mask >> 4) & 1u) != 0; *ok = false; return false;
+    case DExpr::CMP: {
+      if (e->args.size() != 2 || e->args[0]->kind != DExpr::LEAF || e->args[1]->kind != DExpr::CONST || !e->args[1]->c.is_string()) { *ok = false; return false; }
+      const std::string& k = e->args[1]->c.str();
+      if (e->cmp == 0 || e->cmp == 1) { const bool eq = k.size() == n && memcmp(k.data(), s, n) == 0; return e->cmp == 0 ? eq : !eq; }
+      const size_t m = n < k.size() ? n : k.size();
+      int c = m ? memcmp(s, k.data(), m) : 0;
+      if (c == 0) c = n < k.size() ? -1 : n > k.size() ? 1 : 0;
+      return dx_cmp_holds(c, e->cmp);
+    }
+    case DExpr::TRUTHY: {
+      if (e->args.size() != 1) { *ok = false; return false; }
+      const DExpr& c = *e->args[0];
+      if (c.kind == DExpr::LEAF) return true;   // a string is not `false`
+      if (c.kind != DExpr::CALL || c.args.size() != 2 || c.args[0]->kind != DExpr::LEAF || c.args[1]->kind != DExpr::CONST || !c.args[1]->c.is_string()) { *ok = false; return false; }
+      const std::string& k = c.args[1]->c.str();
+      if (c.name == "startswith") return k.size() <= n && memcmp(s, k.data(), k.size()) == 0;
+      if (c.name == "endswith") return k.size() <= n && memcmp(s + n - k.size(), k.data(), k.size()) == 0;
+      if (c.name == "contains") {
+        if (k.empty()) return true;
+        if (k.size() > n) return false;
+        for (size_t i = 0; i + k.size() <= n; i++) if (s[i] == k[0] && memcmp(s + i, k.data(), k.size()) == 0) return true;
+        return false;
+      }
+      *ok = false; return false;
+    }
+    default: *ok = false; return false;
+  }
+}
 
 }  // namespace gk

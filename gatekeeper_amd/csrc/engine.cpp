@@ -1924,6 +1924,11 @@ static std::vector<uint64_t> render_needed(gk_engine* e, gk_table* t, const std:
     for (size_t gi = 0; gi < e->totals_groups.size(); gi++)
       for (const HostPlan* hp : {&e->totals_groups[gi]->fast, &e->totals_groups[gi]->big})
         for (const Pattern& pat : hp->pred_patterns) if (!e->dict_reg.reads_has(pat)) { usable[gi] = 0; if (getenv("GK_DEBUG_MULTI")) fprintf(stderr, "[gkgpu totals] plan %zu reads %s: not in the pruned table's read set\n", gi, pattern_to_string(pat).c_str()); }
+  // (a constraint's flag row and its count rows may sit in different plans: with ANY of them unanswered its pairs are rendered -- a flag
+  //  row that says "counted" with a count row missing would undercount)
+  std::vector<uint8_t> blocked(ids.size(), 0);
+  for (size_t gi = 0; gi < e->totals_groups.size(); gi++)
+    if (!usable[gi]) for (uint32_t id : e->totals_groups[gi]->ids) { auto it = row_of.find(id); if (it != row_of.end()) blocked[it->second] = 1; }
   for (size_t g0 = 0; g0 < e->totals_groups.size(); g0 += wave) {
     const size_t g1 = std::min(e->totals_groups.size(), g0 + wave);
     for (size_t gi = g0; gi < g1; gi++) if (usable[gi]) dev_eval_launch(e->totals_groups[gi]->dev, t->tviews[gi], opt);
@@ -1935,7 +1940,7 @@ static std::vector<uint64_t> render_needed(gk_engine* e, gk_table* t, const std:
       for (uint32_t w = 0; w < nt && w < og.too_big.size(); w++) beyond[w] |= og.too_big[w];
       for (uint32_t r = 0; r < G.ids.size() && r < og.n_constraints; r++) {
         auto it = row_of.find(G.ids[r]);
-        if (it == row_of.end() || og.n_tiles != nt) continue;
+        if (it == row_of.end() || og.n_tiles != nt || blocked[it->second]) continue;
         const uint8_t role = r < G.roles.size() ? G.roles[r] : (uint8_t)TR_MULTI;
         const uint64_t* bits = &og.viol[(size_t)r * nt];
         // (autoreject pairs of the totals plan are the main plan's: they carry no violation bit either way)

@@ -150,6 +150,10 @@ static bool patterns_overlap(const Pattern& a, const Pattern& b) {
   return true;
 }
 
+bool match_group_pattern(const Pattern& p) {
+  return p.size() == 3 && !p[0].any && p[0].key == "$m" && !p[1].any && !p[2].any && !p[2].key.empty() && p[2].key[0] != '$';
+}
+
 uint32_t DictRegistry::intern(const Pattern& leaf_in, const DX& dx, bool add) {
   // Canonical form: an unfiltered iteration step is registered as "any child", whether the lowering reached the leaf through
   // an explicit element loop (elements only) or through a flat wildcard predicate (members and elements) -- the same leaf
@@ -170,8 +174,12 @@ uint32_t DictRegistry::intern(const Pattern& leaf_in, const DX& dx, bool add) {
   }
   for (auto& e : p->entries) if (e.key == dk) return e.bit;
   if (!add) throw std::runtime_error("needs a dictionary predicate no loaded constraint registered");
-  if (p->entries.size() >= 62) throw std::runtime_error("more than 62 dictionary predicates on " + pk);
-  p->entries.push_back({dx, dk, (uint32_t)p->entries.size()});
+  // MATCH GROUP: the facts of one candidate (review.$m.<o|old>.<fact>) travel in ONE row, review.$m.<o|old>.$d -- their
+  // expressions take their bits from one space (the flattener ORs the facts' masks, match_group_row)
+  size_t used = p->entries.size();
+  if (match_group_pattern(leaf)) { used = 0; for (auto& x : pats_) if (match_group_pattern(x.pat) && x.pat[1].key == leaf[1].key) used += x.entries.size(); }
+  if (used >= 62) throw std::runtime_error("more than 62 dictionary predicates on " + pk);
+  p->entries.push_back({dx, dk, (uint32_t)used});
   p->memo.clear();
   gen_++;
   return p->entries.back().bit;
@@ -657,7 +665,15 @@ void Flattener::dict_row(uint32_t path, uint32_t meta, const Value& leaf, uint64
 
 // dict_row for a STRING leaf given as bytes: the answers are remembered per path under the bytes themselves (no Value, no quoted
 // term text, no std::string key per row -- the dictionary leaves of a policy set are mostly strings: images, quantities, names)
-void Flattener::dict_row_str(uint32_t path, uint32_t meta, const char* s, uint32_t n) {
+void Flattener::dict_row_str(uint32_t path, uint32_t meta, const char* s, uint32_t n, uint64_t* masks_out, bool use_memo) {
+  if (!use_memo) {   // a leaf whose values are as good as unique (a match candidate's name): straight evaluation where the expressions allow
+    DictPath& d = dict_paths_[path];
+    bool ok = true;
+    uint64_t m[2] = {0, 0};
+    for (const DictEntry& e : d.entries) { if (dx_true_str(e.dx, s, n, &ok)) m[0] |= 1ull << e.bit; if (!ok) break; }
+    if (ok) for (const DictEntry& e : d.centries) { if (dx_true_str(e.dx, s, n, &ok)) m[1] |= 1ull << e.bit; if (!ok) break; }
+    if (ok && masks_out) { masks_out[0] = m[0]; masks_out[1] = m[1]; return; }
+  }
   uint64_t h = 0x9E3779B97F4A7C15ull ^ ((uint64_t)n * 0xD6E8FEB86659FD93ull);
   {
     uint32_t i = 0;
@@ -678,7 +694,15 @@ void Flattener::dict_row_str(uint32_t path, uint32_t meta, const char* s, uint32
     }
   }
   if (!found) {
-    dict_row(path, meta, Value::string(std::string(s, n)), masks);
+    {
+      // string tests against constants are evaluated here, on the bytes (dx_true_str); anything else -- quantity arithmetic, regular
+      // expressions, split components -- goes through the engine-wide memo of the pattern (dict_row), evaluated once per engine
+      DictPath& d0 = dict_paths_[path];
+      bool ok = true;
+      for (const DictEntry& e : d0.entries) { if (dx_true_str(e.dx, s, n, &ok)) masks[0] |= 1ull << e.bit; if (!ok) break; }
+      if (ok) for (const DictEntry& e : d0.centries) { if (dx_true_str(e.dx, s, n, &ok)) masks[1] |= 1ull << e.bit; if (!ok) break; }
+      if (!ok) { masks[0] = masks[1] = 0; dict_row(path, meta, Value::string(std::string(s, n)), masks); }
+    }
     DictPath& d = dict_paths_[path];
     StrMemo& M = *d.smemo;
     if (M.count < 65536) {
@@ -697,9 +721,25 @@ void Flattener::dict_row_str(uint32_t path, uint32_t meta, const char* s, uint32
       M.count++;
     }
   }
+  if (masks_out) { masks_out[0] = masks[0]; masks_out[1] = masks[1]; return; }
   const uint32_t dpaths[2] = {dict_paths_[path].dpath, dict_paths_[path].cpath};
   for (int k = 0; k < 2; k++)
     if (masks[k]) emit(dpaths[k], (meta & ~(uint32_t)ROW_TYPE_MASK & ~(uint32_t)ROW_STR_INLINE) | T_INT, (uint32_t)masks[k], (uint32_t)(masks[k] >> 32), true);
+}
+
+// One match fact of a candidate (review.$m.<o|old>.<fact>): its string row (where some plan still reads it) and, OR-ed into `acc`,
+// the answers of the dictionary expressions registered on it -- the candidate's facts share one dictionary row (match_group_row)
+void Flattener::match_fact(uint32_t path, const char* s, uint32_t n, uint64_t* acc, bool use_memo) {
+  emit_str_n(path, 0, s, n);
+  if (dict_wanted(path)) {
+    uint64_t m[2] = {0, 0};
+    dict_row_str(path, 0, s, n, m, use_memo);
+    acc[0] |= m[0]; acc[1] |= m[1];
+  }
+}
+void Flattener::match_group_row(int w, const uint64_t* acc) {
+  if (acc[0]) emit(env_.m_d[w], T_INT, (uint32_t)acc[0], (uint32_t)(acc[0] >> 32), true);
+  if (acc[1]) emit(env_.m_c[w], T_INT, (uint32_t)acc[1], (uint32_t)(acc[1] >> 32), true);
 }
 
 bool Flattener::value_wanted(uint32_t path) {
@@ -926,19 +966,25 @@ void Flattener::match_facts(const Value& obj, const Value& ns, bool is_old, uint
   bool is_ns = (k == "Namespace" && g.empty());
   std::string name = obj_string(obj, "metadata", "name");
   std::string nsfield = obj_string(obj, "metadata", "namespace");
-  uint32_t sub = dict_->child(m_parent, is_old ? "old" : "o");
+  if (!env_.ready) env_init();
+  const int w = is_old ? 1 : 0;
+  uint32_t sub = env_.m_sub[w];
+  (void)m_parent;
   emit(sub, T_OBJECT, 0, 0);
-  emit_str(sub, "group", g);
-  emit_str(sub, "kind", k);
-  emit_str(sub, "name", name);
-  emit_str(sub, "gname", obj_string(obj, "metadata", "generateName"));
+  uint64_t acc[2] = {0, 0};
+  const std::string gname = obj_string(obj, "metadata", "generateName");
+  match_fact(env_.m_group[w], g.data(), (uint32_t)g.size(), acc);
+  match_fact(env_.m_kind[w], k.data(), (uint32_t)k.size(), acc);
+  match_fact(env_.m_name[w], name.data(), (uint32_t)name.size(), acc, false);
+  match_fact(env_.m_gname[w], gname.data(), (uint32_t)gname.size(), acc, false);
   bool has_nsname = true;
   std::string nsname;
   if (is_ns) nsname = name;
   else if (ns.defined()) nsname = obj_string(ns, "metadata", "name");
   else if (!nsfield.empty()) nsname = nsfield;
   else has_nsname = false;
-  if (has_nsname) emit_str(sub, "nsname", nsname);
+  if (has_nsname) match_fact(env_.m_nsname[w], nsname.data(), (uint32_t)nsname.size(), acc);
+  match_group_row(w, acc);
   review_flags_ |= is_old ? RF_HAS_OLD : RF_HAS_OBJ;
   if (is_ns) review_flags_ |= is_old ? RF_OLD_IS_NS : RF_OBJ_IS_NS;
   if (!nsfield.empty()) review_flags_ |= is_old ? RF_OLD_HAS_NSFIELD : RF_OBJ_HAS_NSFIELD;
@@ -2181,6 +2227,7 @@ void Flattener::env_init() {
     v.m_sub[w] = child(id_m_, w ? "old" : "o");
     v.m_group[w] = child(v.m_sub[w], "group"); v.m_kind[w] = child(v.m_sub[w], "kind"); v.m_name[w] = child(v.m_sub[w], "name");
     v.m_gname[w] = child(v.m_sub[w], "gname"); v.m_nsname[w] = child(v.m_sub[w], "nsname");
+    v.m_d[w] = child(v.m_sub[w], "$d"); v.m_c[w] = child(v.m_sub[w], "$c");
   }
   v.ready = true;
 }
@@ -2195,17 +2242,19 @@ void Flattener::fast_match_facts_n(const ObjFacts& f, bool ns_defined, const std
   const uint32_t groupn = (!(avn == 0 || (avn == 1 && avp[0] == '/')) && nsl == 1) ? first : 0;
   const bool is_ns = kindn == 9 && memcmp(kindp, "Namespace", 9) == 0 && groupn == 0;
   emit(env_.m_sub[w], T_OBJECT, 0, 0);
-  emit_str_n(env_.m_group[w], 0, avp, groupn);
-  emit_str_n(env_.m_kind[w], 0, kindp, kindn);
+  uint64_t acc[2] = {0, 0};
+  match_fact(env_.m_group[w], avp, groupn, acc);
+  match_fact(env_.m_kind[w], kindp, kindn, acc);
   const char* const namep = f.name.set ? f.name.p : ""; const uint32_t namen = f.name.set ? f.name.n : 0;
   const uint32_t nsn = f.ns.set ? f.ns.n : 0;
-  emit_str_n(env_.m_name[w], 0, namep, namen);
-  emit_str_n(env_.m_gname[w], 0, f.gname.set ? f.gname.p : "", f.gname.set ? f.gname.n : 0);
+  match_fact(env_.m_name[w], namep, namen, acc, false);
+  match_fact(env_.m_gname[w], f.gname.set ? f.gname.p : "", f.gname.set ? f.gname.n : 0, acc, false);
   bool has_nsname = true;
-  if (is_ns) emit_str_n(env_.m_nsname[w], 0, namep, namen);
-  else if (ns_defined) emit_str_n(env_.m_nsname[w], 0, ns_name.data(), (uint32_t)ns_name.size());
-  else if (nsn) emit_str_n(env_.m_nsname[w], 0, f.ns.p, nsn);
+  if (is_ns) match_fact(env_.m_nsname[w], namep, namen, acc);
+  else if (ns_defined) match_fact(env_.m_nsname[w], ns_name.data(), (uint32_t)ns_name.size(), acc);
+  else if (nsn) match_fact(env_.m_nsname[w], f.ns.p, nsn, acc);
   else has_nsname = false;
+  match_group_row(w, acc);
   review_flags_ |= is_old ? RF_HAS_OLD : RF_HAS_OBJ;
   if (is_ns) review_flags_ |= is_old ? RF_OLD_IS_NS : RF_OBJ_IS_NS;
   if (nsn) review_flags_ |= is_old ? RF_OLD_HAS_NSFIELD : RF_OBJ_HAS_NSFIELD;

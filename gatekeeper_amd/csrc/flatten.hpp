@@ -81,6 +81,8 @@ std::string pattern_to_string(const Pattern& p);
 bool pattern_matches(const Pattern& pat, const PathDict& dict, uint32_t path_id);
 // the first steps of `pat` match the whole path (the pattern reaches this path or something below it); *full: it matches exactly
 bool pattern_reaches(const Pattern& pat, const PathDict& dict, uint32_t path_id, bool* full);
+// review.$m.<o|old>.<fact>: a leaf of a candidate's MATCH GROUP (the group's dictionary expressions share one row, see DictRegistry::intern)
+bool match_group_pattern(const Pattern& pat);
 
 // ------------------------------------------------------------------------------------------------ dictionary predicates
 // Leaf-local expressions (dexpr.hpp) registered by the loaded constraints: pattern of the leaf -> expressions, each with a
@@ -336,7 +338,9 @@ class Flattener {
                     int cpat = -1; std::vector<DictEntry> centries; uint32_t cpath = 0; std::unordered_map<std::string, uint64_t> cmemo; /* the counting space: <leaf>.$c */ };
   std::vector<DictPath> dict_paths_;
   void dict_row(uint32_t path, uint32_t meta, const Value& leaf, uint64_t* masks_out = nullptr);   // emits <leaf>.$d / .$c when some registered expression is true (masks_out: hands the two masks back instead)
-  void dict_row_str(uint32_t path, uint32_t meta, const char* s, uint32_t n);
+  void dict_row_str(uint32_t path, uint32_t meta, const char* s, uint32_t n, uint64_t* masks_out = nullptr, bool use_memo = true);
+  void match_fact(uint32_t path, const char* s, uint32_t n, uint64_t* acc, bool use_memo = true);   // one fact of a match candidate: string row + dictionary answers
+  void match_group_row(int w, const uint64_t* acc);                            // review.$m.<o|old>.$d / .$c
   bool dict_wanted(uint32_t path);
   bool dict_deep(uint32_t path) { return dict_wanted(path) && dict_paths_[path].deep; }
   bool guard_wanted(uint32_t path);   // is `path` a container under which element predicates iterate? (cached per path)
@@ -429,7 +433,7 @@ class Flattener {
   void finish_tail(int source, HostTable* out);
   // paths of the request envelope add_json writes around an object, resolved once
   struct EnvIds { bool ready = false; uint32_t uid, kind, k_group, k_version, k_kind, resource, r_group, r_version, r_resource, operation, user_info, options, name, ns, nsobj,
-                  m_sub[2], m_group[2], m_kind[2], m_name[2], m_gname[2], m_nsname[2]; } env_;
+                  m_sub[2], m_group[2], m_kind[2], m_name[2], m_gname[2], m_nsname[2], m_d[2], m_c[2]; } env_;
   void env_init();
   void fast_match_facts_n(const ObjFacts& f, bool ns_defined, const std::string& ns_name, bool is_old);
   uint32_t fast_child(uint32_t parent, const char* key, uint32_t len);

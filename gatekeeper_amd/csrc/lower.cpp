@@ -533,8 +533,23 @@ static bool reads_string_bytes(const FP& f) {
     default: return false;
   }
 }
-static bool promotable_leaf(const SPath& p) {   // (the match layer's synthetic subtrees are compiled by compile_match, never folded)
+// MATCH FACTS (round 5).  The five strings the match layer compares -- review.$m.<o|old>.{kind, group, name, gname, nsname}, a row with a
+// string header each: 160 of configs[2]'s ~380 bytes per review -- are tested against constants only.  Every leaf-local group on one of
+// them becomes a dictionary expression whatever it reads, and the five leaves of a candidate share ONE dictionary row,
+// review.$m.<o|old>.$d (flatten.hpp DictRegistry "match group": their bits come from one 62-bit space): a sweep reads one 16-byte row
+// per review where it read five rows and five headers.  GK_DICT_MATCH=0 keeps the rows (A/B aid).
+bool match_fact_leaf(const SPath& p) {
+  static const bool on = !(getenv("GK_DICT_MATCH") && atoi(getenv("GK_DICT_MATCH")) == 0);
+  return on && p.size() == 3 && !p[0].iter && p[0].key == "$m" && !p[1].iter && !p[2].iter && !p[2].key.empty() && p[2].key[0] != '$';
+}
+// (folding a MATCH formula promotes the match facts only: the labels a selector names keep their rows, which the counting plans --
+//  frozen, in the counting space -- lower the same way.  GK_TEST_FOLD_MATCH_LABELS=1, test aid: promote them as well -- the counting
+//  plans then read label rows a pruned table does not hold, which is how tests/test_pruned.py reaches render_needed's unanswered plans)
+static thread_local bool g_fold_match_only = false;
+static bool promotable_leaf(const SPath& p) {   // (the other synthetic subtrees -- $ns -- keep their rows)
   if (p.empty()) return false;
+  if (match_fact_leaf(p)) return true;
+  if (g_fold_match_only && !getenv("GK_TEST_FOLD_MATCH_LABELS")) return false;
   for (auto& st : p) if (!st.iter && !st.key.empty() && st.key[0] == '$') return false;
   return true;
 }
@@ -542,6 +557,7 @@ static bool promotable(const std::vector<FP>& g) {
   if (!promote_strings() || g.empty()) return false;
   const SPath* lp = leaf_path_of(g[0]);
   if (!lp || !promotable_leaf(*lp)) return false;
+  if (match_fact_leaf(*lp)) return true;
   for (auto& k : g) if (reads_string_bytes(k)) return true;
   return false;
 }
@@ -945,18 +961,22 @@ struct Lowerer {
       if (!reg) unsupported("dictionary predicate without a registry");
       Pattern leaf_pat = pattern_of(a.path);
       uint32_t bit;
+      // (a match fact's expressions live in the main space, whoever asks: the constraint's own violation plan registered them -- the
+      //  counting space is for what only the result counts read)
+      const bool cnt = counting && !match_fact_leaf(a.path);
       if (a.alt) {   // a promoted group of row predicates: what the dictionary cannot take is evaluated from the rows, as before
         bool ok = true;
         for (auto& st : leaf_pat) if (st.any && !st.elems_only && (!st.only.empty() || !st.except.empty() || !st.kpreds.empty())) ok = false;
-        if (ok) { try { bit = (counting ? &reg->counting() : reg)->intern(leaf_pat, a.dx, !frozen); } catch (const std::runtime_error&) { ok = false; } }
+        if (ok) { try { bit = (cnt ? &reg->counting() : reg)->intern(leaf_pat, a.dx, !frozen); } catch (const std::runtime_error&) { ok = false; } }
         if (!ok) { release(r); return lower(a.alt); }
       } else {
       for (auto& st : leaf_pat) if (st.any && !st.elems_only && (!st.only.empty() || !st.except.empty() || !st.kpreds.empty())) unsupported("dictionary predicate under a filtered key iteration");
-      try { bit = (counting ? &reg->counting() : reg)->intern(leaf_pat, a.dx, !frozen); } catch (const std::runtime_error& ex) { unsupported(ex.what()); }
+      try { bit = (cnt ? &reg->counting() : reg)->intern(leaf_pat, a.dx, !frozen); } catch (const std::runtime_error& ex) { unsupported(ex.what()); }
       }
       Atom b;
       b.kind = Atom::DICT; b.path = a.path; b.dx = nullptr;
-      Step st; st.key = counting ? "$c" : "$d";
+      Step st; st.key = cnt ? "$c" : "$d";
+      if (match_fact_leaf(a.path)) b.path.pop_back();   // the candidate's five facts share review.$m.<o|old>.$d
       b.path.push_back(st);
       b.mask = bit;
       Pattern pat = pattern_of(b.path);
@@ -1592,8 +1612,12 @@ PrepMemoScope::~PrepMemoScope() { g_prep_memo = (PrepMemo*)prev_; delete (PrepMe
 std::shared_ptr<const PreparedConstraint> prepare_constraint(const FP& violation, const MatchFormulas& mf) {
   auto pc = std::make_shared<PreparedConstraint>();
   pc->viol = simplify(fold_dict(simplify(pin_pass(simplify(violation)))));
-  pc->match = simplify(mf.match);
-  pc->error = simplify(mf.error);
+  g_fold_match_only = true;
+  try {
+    pc->match = simplify(fold_dict(simplify(mf.match)));
+    pc->error = simplify(fold_dict(simplify(mf.error)));
+  } catch (...) { g_fold_match_only = false; throw; }
+  g_fold_match_only = false;
   pc->viol_key = canon(pc->viol);
   pc->match_key = canon(pc->match) + "##" + canon(pc->error);
   return pc;

@@ -53,6 +53,29 @@ def test_pruned_table_answers_like_the_full_one(backend, fixtures, corpus):
 
 
 @forced
+def test_a_totals_plan_the_pruned_table_cannot_answer_leaves_the_whole_constraint_to_the_renderer(fixtures, monkeypatch):
+    """A constraint's flag row and its count rows can sit in different totals plans.  When a pruned table lacks a path one of them
+    reads, the constraint's pairs must ALL be rendered: a flag row answering "counted" next to a missing count row undercounted
+    (K8sContainerLimits of the corpus: 645 results against 706).  The test aid makes the match formulas' label tests dictionary bits,
+    which the frozen counting plans lower from label rows the pruned table does not hold."""
+    monkeypatch.setenv("GK_TEST_FOLD_MATCH_LABELS", "1")
+    c = make_client("hostemu")
+    _load(c, fixtures, True)
+    eng = c.driver.engine
+    n = 1500
+    batch = synth.NativeBatch(eng.lib, n, seed=synth.SEED, mixed=True, start=0, namespaces=synth.gen_namespaces())
+    full = eng.create_table_native(batch.reviews, n, resident=True, keep_text=True)
+    lean = eng.create_table_native(batch.reviews, n, resident=True, keep_text=True, pruned=True)
+    try:
+        full.eval(), lean.eval()
+        assert full.totals() == lean.totals()
+        assert lean.rendered_pairs > 4 * full.rendered_pairs       # ... because the pruned table's unanswered constraints were rendered
+    finally:
+        full.free()
+        lean.free()
+
+
+@forced
 def test_a_constraint_that_reads_another_path_makes_pruned_tables_stale(fixtures):
     c = make_client("hostemu")
     fx = fixtures

@@ -62,7 +62,7 @@ PY
             timeout 600 python bench.py --config 4 --streaming --offered 0 > gpurun_out/${tag}_stream_closed_loop.json 2>> gpurun_out/${tag}_stream.err; tail -c 1200 gpurun_out/${tag}_stream_closed_loop.json;;
     stats) (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}_stats -o stats -- python $R/bench.py --steps 50 --warmup 5 --lean > /dev/null 2> $R/gpurun_out/${tag}_stats.err)
            find gpurun_out/${tag}_stats -name '*kernel_stats.csv' | head -1 | xargs -r head -6;;
-    pmc) run_pmc() { name=$1; shift; timeout 400 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d gpurun_out/${tag}_pmc_$name -o $name -- python bench.py --steps 5 --warmup 1 --lean > /dev/null 2> gpurun_out/${tag}_pmc_$name.err; }
+    pmc) run_pmc() { name=$1; shift; timeout 400 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d gpurun_out/${tag}_pmc_$name -o $name -- python bench.py --steps 5 --warmup 1 --lean > gpurun_out/${tag}_pmc_$name.json 2> gpurun_out/${tag}_pmc_$name.err; }
          run_pmc sq SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
          run_pmc fetch FETCH_SIZE
          run_pmc write WRITE_SIZE
@@ -73,8 +73,10 @@ v = {}
 for line in open(sys.argv[1]):
     m = re.match(r"\S+ (\S+) per_dispatch=([0-9.]+)", line)
     if m and "jit_tiles" in line: v[m.group(1)] = float(m.group(2))
+try: ALGO = json.loads(open("gpurun_out/%s_pmc_fetch.json" % sys.argv[2]).read().strip().split("\n")[-1])["roofline"]["algo_bytes_per_launch"]
+except Exception: ALGO = None
 if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
-    print(json.dumps({"config": 2, "reviews": 1000000, "hbm_bytes_per_launch": int((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024), "fetch_kb": v["FETCH_SIZE"], "write_kb": v["WRITE_SIZE"],
+    print(json.dumps({"config": 2, "reviews": 1000000, "algo_bytes_per_launch": ALGO, "hbm_bytes_per_launch": int((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024), "fetch_kb": v["FETCH_SIZE"], "write_kb": v["WRITE_SIZE"],
                       "source": "profiles/%s_summary.txt (rocprofv3 --pmc, separate passes of `bench.py --steps 5 --warmup 1 --lean` with --kernel-trace only; HBM bytes = 2 x FETCH_SIZE KB (gfx950 correction, MI355X_MICROARCH.md) + WRITE_SIZE KB, KB = 1024 B)" % "r05_pmc_" + sys.argv[2][3:] + "_config2_1M"}, indent=1))
 PY
          ;;
