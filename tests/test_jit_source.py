@@ -93,13 +93,36 @@ def _scratch_bytes(code):
     return -1
 
 
+def _row_load_wait_gaps(code, tmp_path):
+    """per `global_load_dwordx4` of gk_jit_tiles: instructions (text order) up to the next `s_waitcnt vmcnt`; None without llvm-objdump"""
+    import re
+    import subprocess
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        return None
+    co = os.path.join(str(tmp_path), "gk_plan.co")
+    with open(co, "wb") as f:
+        f.write(code)
+    dis = subprocess.run([objdump, "-d", co], capture_output=True, text=True).stdout
+    ops = [m.group(1) + " " + m.group(2) for m in (re.match(r"\s+([a-z_0-9]+)\s+(.*?)\s*//", line) for line in dis.splitlines()) if m]
+    gaps = []
+    for i, op in enumerate(ops):
+        if op.startswith("global_load_dwordx4"):
+            j = next((k for k in range(i + 1, len(ops)) if ops[k].startswith("s_waitcnt") and "vmcnt" in ops[k]), len(ops))
+            gaps.append(j - i)
+    return gaps
+
+
 @pytest.mark.parametrize("rpt", [64, 256])
 def test_bench_plan_source_compiles_for_gfx950_without_scratch(monkeypatch, tmp_path, rpt):
     """configs[2]'s plan (50 constraints of the PSP family) in the geometries the bench tables use"""
     rtc = _hiprtc()
     if rtc is None:
         pytest.skip("libhiprtc.so is not installed")
-    for name, text in _dump_sources(monkeypatch, tmp_path, _bench_plan(1200), env=[("GK_RPT", rpt)]):
+    # (a 1 200-object table's plan variant has fewer accumulator words than the bench tables': more groups fit per CU and the budget
+    #  would be 8 waves per SIMD = 64 VGPRs; the bench tables' budget is 6 waves = 80 VGPRs, which is what is checked here)
+    env = [("GK_RPT", rpt)] + ([("GK_JIT_WAVES", 6)] if rpt == 256 else [])
+    for name, text in _dump_sources(monkeypatch, tmp_path, _bench_plan(1200), env=env):
         ok, log, code = compile_gfx950(rtc, text)
         assert ok, "%s does not compile for gfx950:\n%s" % (name, log[-3000:])
         assert b"gk_jit_tiles" in code
@@ -109,6 +132,12 @@ def test_bench_plan_source_compiles_for_gfx950_without_scratch(monkeypatch, tmp_
             # parks up to 16 dwords of per-thread invariants (the next item's review flags, two LDS addresses) in scratch: written
             # in the prologue / once per item, re-read in phase 2 -- never inside the chunk loop.  More than that is a regression.
             assert 0 <= _scratch_bytes(code) <= 96, "%s: the plan-specialised kernel spills (%d bytes of scratch per lane)" % (name, _scratch_bytes(code))
+            # the prefetch distances the source intends are only real when the ISA shows them: no row load (16-byte loads) may be
+            # waited for right behind its request.  (Round 5 found the next item's first rows waited for two instructions after the
+            # request -- the compiler's copy into the chunk loop's entry registers -- with the whole output stage behind that wait.)
+            gaps = _row_load_wait_gaps(code, tmp_path)
+            if gaps is not None:
+                assert gaps and min(gaps) >= 16, "%s: a row load is waited for %d instructions after its request (gaps %s)" % (name, min(gaps), gaps)
 
 
 def _pattern_plans():

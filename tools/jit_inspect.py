@@ -3,7 +3,10 @@
 GK_EMU_HIP_SOURCE_DIR=<dir>, or GK_JIT_DUMP=<file> on a GPU box) through hiprtc with the product's options -- hiprtc needs
 no GPU -- and prints what bounds occupancy and issue: VGPR / SGPR / spills / LDS / scratch, instruction mix of the whole
 kernel, and optionally the disassembly.
-usage: tools/jit_inspect.py <gk_plan_*.hip> [--asm out.s] [--define NAME=VAL ...] [--sub OLD NEW]"""
+usage: tools/jit_inspect.py <gk_plan_*.hip> [--asm out.s] [--define NAME=VAL ...] [--sub OLD NEW] [--body kernel_body.inc] [--waits]
+--body replaces the kernel body inside the dumped text by another file (what GK_JIT_BODY_FILE does on a GPU box);
+--waits prints the kernel's vector-memory instructions, barriers and s_waitcnt vmcnt in program order: where a load is issued and
+where the wave first waits for it -- the prefetch distances the source intends are only real when this listing shows them."""
 import argparse
 import collections
 import os
@@ -27,8 +30,15 @@ def main():
     ap.add_argument("--asm")
     ap.add_argument("--define", action="append", default=[])
     ap.add_argument("--sub", nargs=2, action="append", default=[])
+    ap.add_argument("--body")
+    ap.add_argument("--waits", action="store_true")
     a = ap.parse_args()
     text = open(a.src).read()
+    if a.body:
+        mark = "// Kernel bodies shared by the ahead-of-time build"
+        at = text.index(mark)
+        body = "".join(l for l in open(a.body) if not l.startswith("#include") and not l.startswith("#pragma once"))
+        text = text[:at] + body + "}\n"
     for d in a.define:
         k, _, v = d.partition("=")
         text, n = re.subn(r"#define %s\b.*" % re.escape(k), "#define %s %s" % (k, v), text, count=1)
@@ -84,6 +94,16 @@ def main():
         else:
             mix["other"] += 1
     print("static mix: " + " ".join("%s=%d" % kv for kv in mix.most_common()) + " total=%d" % sum(mix.values()))
+    if a.waits:
+        n = 0
+        for line in dis.splitlines():
+            m = re.match(r"\s+([a-z_0-9]+)\s+(.*?)\s*//", line)
+            if not m:
+                continue
+            n += 1
+            op = m.group(1)
+            if op.startswith(("global_", "scratch_", "buffer_", "flat_")) or op == "s_barrier" or (op == "s_waitcnt" and "vmcnt" in m.group(2)):
+                print("%6d  %s %s" % (n, op, m.group(2)))
     if a.asm:
         open(a.asm, "w").write(dis)
         print("disassembly -> %s" % a.asm)
