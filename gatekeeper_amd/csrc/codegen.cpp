@@ -445,17 +445,37 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts) {
           //  being kept in registers across the whole run: 12 words of a volumes array pushed the kernel past its 80-VGPR budget)
           constexpr uint32_t pre_cap = 8u;   // (16: 10 spilled dwords and 0.1167 against 0.1080 ms; 4: 0.1090 -- profiles/r05_variants_g_preload.log)
           const bool in_regs = sc.cap <= pre_cap || stack.empty();
+          // ROLLING reads of a scope that is read where it is used: every copy is a basic block of its own (the scalar guard), so a
+          // read at the top of the copy is an exposed LDS round trip in front of half a dozen bit operations -- 36 of them in the
+          // volumeMounts x volumes join of configs[2].  Two registers carry the words of the next two elements instead: copy e takes
+          // its word from one of them and requests element e + 2 into it (copy e + 2 runs only when copy e did: the guards are
+          // thresholds of one count).  Not when the body stores derived bits into this scope's words (a later copy must see them).
+          static const bool roll_on = !(getenv("GK_JIT_ROLL") && atoi(getenv("GK_JIT_ROLL")) == 0);   // (A/B aid)
+          bool roll = roll_on && !in_regs && sc.cap >= 3;
+          if (roll) for (size_t q = pc; q < end; q++) {
+            const uint32_t qi = code[q], qop = qi & 0xFF;
+            if (qop == F_VEQ) { q++; continue; }
+            if (qop == F_STE && ((qi >> 16) & 0xFF) == a) { roll = false; break; }
+          }
+          const auto word_at = [&](uint32_t e) { return std::to_string(sc.word_off + e * sc.wpe) + "u"; };
+          if (roll) o << ind << "{ uint32_t P" << d << "a = acc.load(" << word_at(0) << "), P" << d << "b = acc.load(" << word_at(1) << ");\n";
           for (uint32_t e = 0; e < sc.cap; e++) {
             if (in_regs) pre_words.insert({a, e});
             o << ind << (guarded ? "if (" + std::to_string(e) + "u < ns" + std::to_string(a) + ") " : std::string()) << "{\n";
             o << ind << "  constexpr uint32_t e" << d << " = " << e << "u; (void)e" << d << ";\n";
             if (in_regs) o << ind << "  const uint32_t w" << d << " = W" << a << "_" << e << ";\n";
+            else if (roll) {
+              const char* pn = (e & 1u) ? "b" : "a";
+              o << ind << "  const uint32_t w" << d << " = P" << d << pn << ";\n";
+              if (e + 2 < sc.cap) o << ind << "  P" << d << pn << " = acc.load(" << word_at(e + 2) << ");\n";
+            }
             else o << ind << "  const uint32_t w" << d << " = acc.load(" << (sc.word_off + e * sc.wpe) << "u);\n";
             o << ind << "  uint32_t v" << d << " = w" << d << " & 1u;\n";
             if (b) o << ind << "  v" << d << " = v" << d << " & (uint32_t)((w" << d << " >> 24) == e" << pd << ");\n";
             stack.push_back({a, d, (int)e});
             gen(pc, end + 1, staged, ind + "  ");   // (its F_ENDLOOP pops the stack and closes the copy)
           }
+          if (roll) o << ind << "}\n";
           pc = end + 1;
           break;
         }
