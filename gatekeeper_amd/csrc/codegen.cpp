@@ -277,6 +277,7 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts) {
   // register copy as well as LDS.  Used when the unrolled text stays small (`pre_budget` operations per plan); GK_JIT_PRELOAD=0
   // keeps the loops.
   std::ostringstream* out_ = &o;
+  uint64_t res_slots[3] = {0, 0, 0};                   // result slots (per kind) the staged part being generated hands to GK_RES
   bool pre = false;                                    // generating the preloaded form
   std::set<std::pair<uint32_t, uint32_t>> pre_words;   // (scope, element) words the part being generated reads
   std::set<uint32_t> pre_bounds;                       // scopes whose run-time bound the part needs
@@ -571,7 +572,7 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts) {
         const char* f = b == 0 ? "viol" : b == 1 ? "match" : "err";
         // staged parts hand the result of slot c to GK_RES: on the device one ballot turns the 64 lanes' answers into the
         // slot's bitmap word (kernel_body.inc), elsewhere it accumulates into `res` like the monolithic function
-        if (staged) o << ind << "GK_RES(" << b << ", " << c << ", b" << a << ");\n";
+        if (staged) { o << ind << "GK_RES(" << b << ", " << c << ", b" << a << ");\n"; if (b < 3 && c < 64) res_slots[b] |= 1ull << c; }
         else o << ind << "res." << f << " |= (uint64_t)b" << a << " << " << c << ";\n";
         break;
       }
@@ -741,6 +742,7 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts) {
     o << "#define GK_HAS_STAGES 1\nconstexpr uint32_t GK_N_STAGES = " << n_stages << "u;\nconstexpr uint32_t GK_GEN_PARTS = " << NW << "u;\n"
       << "#ifndef GK_RES\n#define GK_RES(kind, slot, b) do { if ((kind) == 0) res.viol |= (uint64_t)(b) << (slot); else if ((kind) == 1) res.match |= (uint64_t)(b) << (slot); "
          "else res.err |= (uint64_t)(b) << (slot); } while (0)\n#define GK_RES_PROLOGUE\n#endif\n"
+         "#ifndef GK_RES_FLUSH\n#define GK_RES_FLUSH(m0, m1, m2)\n#endif\n"
       << "template <class Acc>\nGK_HD void jit_formula_part(uint32_t part, Acc& acc, uint32_t flags, const uint8_t* heap, const uint32_t* bounds, Results& res, unsigned long long* masks) {\n"
       << "  (void)heap; (void)flags; (void)bounds; (void)res; (void)masks;\n  GK_RES_PROLOGUE\n  uint32_t";
     for (int i = 0; i < 64; i++) o << (i ? ", " : " ") << "b" << i << " = 0u";
@@ -749,6 +751,7 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts) {
     o << "  switch (part) {\n";
     for (size_t p = 0; p < parts.size(); p++) {
       o << "    case " << p << ": {\n";
+      res_slots[0] = res_slots[1] = res_slots[2] = 0;
       std::vector<size_t> order = parts[p];
       std::sort(order.begin(), order.end());
       if (use_pre) {
@@ -790,6 +793,8 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts) {
         flush();
       } else
       for (size_t bi : order) { stack.clear(); gen(blks[bi].pc0, blks[bi].pc1, true, "      "); }
+      // the part's finished slots leave the wave together (jit_source.hpp jit_res_macros: lane s holds slot s's word)
+      { char fb[128]; snprintf(fb, sizeof fb, "      GK_RES_FLUSH(0x%llxull, 0x%llxull, 0x%llxull);\n", (unsigned long long)res_slots[0], (unsigned long long)res_slots[1], (unsigned long long)res_slots[2]); o << fb; }
       o << "    } break;\n";
     }
     o << "    default: break;\n  }\n";

@@ -42,6 +42,29 @@ inline size_t static_lds_of(uint32_t rpt, int block, uint32_t res_k, uint32_t li
 inline size_t max_dyn_lds_of(uint32_t rpt) { return GK_LDS_PER_CU - static_lds_of(rpt, gk_block_of((int)rpt), 0) - 256; }
 inline size_t max_dyn_lds_jit(uint32_t rpt, uint32_t res_k, uint32_t list_cap = 0) { return GK_LDS_PER_CU - static_lds_of(rpt, jit_block_of(rpt), res_k, list_cap) - 256; }
 
+// A finished formula of the staged parts (generated GK_RES(kind, slot, b)): one ballot turns the 64 reviews' answers into the slot's
+// bitmap word of this half.  The words stay in the WAVE until the part is through -- lane s of a register pair per kind holds slot s's
+// word (v_writelane, two vector operations per result) -- and leave it with one predicated 8-byte LDS store per kind (GK_RES_FLUSH,
+// the part's slots as constants from the generator): lane s = slot s is the layout the output stage reads (kernel_body.inc, s_masks).
+// Before: every result was an exec-mask round trip around a one-lane LDS store (s_and_saveexec, two moves, ds_write_b64, s_or),
+// ~25 times per wave and row group.  The text is shared with the test-only kernel emulator, which supplies its own GK_LANE_ID /
+// GK_WRITELANE (tests/native/hostemu.cpp).  GK_JIT_RES_LANES=0 (A/B aid) keeps the one-lane stores.
+inline std::string jit_res_macros() {
+  static const bool lanes = !(getenv("GK_JIT_RES_LANES") && atoi(getenv("GK_JIT_RES_LANES")) == 0);
+  if (!lanes)
+    return "#define GK_RES_PROLOGUE const bool gk_l0 = GK_LANE_ID() == 0u;\n"
+           "#define GK_RES(kind, slot, b) do { const unsigned long long m_ = __ballot((b) != 0u); if (gk_l0) masks[(kind) * GK_RES_K + (slot)] = m_; } while (0)\n"
+           "#define GK_RES_FLUSH(m0, m1, m2)\n";
+  return "#define GK_RES_PROLOGUE uint32_t gk_rl0 = 0u, gk_rh0 = 0u, gk_rl1 = 0u, gk_rh1 = 0u, gk_rl2 = 0u, gk_rh2 = 0u;\n"
+         "#define GK_RES(kind, slot, b) do { const unsigned long long m_ = __ballot((b) != 0u); gk_rl##kind = GK_WRITELANE((uint32_t)m_, slot, gk_rl##kind); "
+         "gk_rh##kind = GK_WRITELANE((uint32_t)(m_ >> 32), slot, gk_rh##kind); } while (0)\n"
+         "#define GK_RES_FLUSH(m0, m1, m2) do { const uint32_t l_ = GK_LANE_ID() & 63u; "
+         "if (((unsigned long long)(m0) >> l_) & 1ull) masks[0u * GK_RES_K + l_] = ((unsigned long long)gk_rh0 << 32) | gk_rl0; "
+         "if (((unsigned long long)(m1) >> l_) & 1ull) masks[1u * GK_RES_K + l_] = ((unsigned long long)gk_rh1 << 32) | gk_rl1; "
+         "if (((unsigned long long)(m2) >> l_) & 1ull) masks[2u * GK_RES_K + l_] = ((unsigned long long)gk_rh2 << 32) | gk_rl2; "
+         "(void)gk_rl0; (void)gk_rh0; (void)gk_rl1; (void)gk_rh1; (void)gk_rl2; (void)gk_rh2; } while (0)\n";
+}
+
 // plan_hpp / vm_core_hpp / kernel_body: plan.hpp, vm_core.hpp and kernel_body.inc as text (build/jit_sources.inc)
 inline std::string assemble_jit_source(const HostPlan& plan, uint32_t rpt, uint32_t rpp, const char* plan_hpp,
                                        const char* vm_core_hpp, const char* kernel_body, uint32_t list_cap = 0) {
@@ -50,9 +73,11 @@ inline std::string assemble_jit_source(const HostPlan& plan, uint32_t rpt, uint3
       "typedef short int16_t; typedef int int32_t; typedef long long int64_t;\n";
   src += plan_hpp;
   src += vm_core_hpp;
-  // a finished formula of the staged parts: one ballot -> the slot's word of this half (kernel_body.inc, s_masks)
-  src += "#define GK_RES_PROLOGUE const bool gk_l0 = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u;\n"
-         "#define GK_RES(kind, slot, b) do { const unsigned long long m_ = __ballot((b) != 0u); if (gk_l0) masks[(kind) * GK_RES_K + (slot)] = m_; } while (0)\n";
+  src += "#define GK_LANE_ID() __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u))\n"
+         // (v_writelane_b32: lane `l` -- an immediate -- of the register takes the wave-uniform value; hiprtc's clang has no builtin for it)
+         "static __device__ inline uint32_t gk_writelane(uint32_t v, const uint32_t l, uint32_t o) { asm(\"v_writelane_b32 %0, %1, %2\" : \"+v\"(o) : \"s\"(v), \"n\"(l)); return o; }\n"
+         "#define GK_WRITELANE(v, l, o) gk_writelane((uint32_t)(v), (l), (o))\n";
+  src += jit_res_macros();
   const int block = jit_block_of(rpt);
   src += generate_plan_source(plan, (uint32_t)(block / GK_TILE / ((int)rpt / GK_TILE)));
   if (block != gk_block_of((int)rpt)) src += "#define GK_BLOCK_K " + std::to_string(block) + "\n";

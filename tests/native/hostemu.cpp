@@ -471,8 +471,9 @@ static EmuJitLaunch emu_jit_for(const DevPlan* p, uint32_t rpt, uint32_t rpp, in
     std::ofstream f(base + ".cpp");
     const char* pf = getenv("GK_JIT_PREFETCH");
     f << "#include \"" << GK_CSRC_DIR << "/../../tests/native/kernel_emu.hpp\"\n#include \"" << GK_CSRC_DIR << "/vm_core.hpp\"\n"
-      << "#define GK_RES_PROLOGUE const bool gk_l0 = (threadIdx.x & 63u) == 0u;\n"
-      << "#define GK_RES(kind, slot, b) do { const unsigned long long m_ = __ballot((b) != 0u); if (gk_l0) masks[(kind) * GK_RES_K + (slot)] = m_; } while (0)\n"
+      << "#define GK_LANE_ID() (threadIdx.x & 63u)\n"
+      << "#define GK_WRITELANE(v, l, o) ((threadIdx.x & 63u) == (uint32_t)(l) ? (uint32_t)(v) : (uint32_t)(o))\n"
+      << jit_res_macros()
       << generate_plan_source(p->fast, (uint32_t)(block / GK_TILE / ((int)rpt / GK_TILE)))
       << "#define GK_RPT_K " << rpt << "\n#define GK_RPP_K " << rpp << "\n#define GK_BLOCK_K " << block << "\n#define GK_PREFETCH " << (pf ? pf : "1") << "\n#define GK_SKIP_BIG\n"
       << "namespace gk {\n#define GK_KERNEL_TILES gk_jit_tiles\n#define GK_KERNEL_BIG gk_jit_big\n#define GK_KERNEL_LINKAGE static\n"
