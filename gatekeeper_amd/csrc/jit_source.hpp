@@ -48,7 +48,7 @@ inline size_t max_dyn_lds_jit(uint32_t rpt, uint32_t res_k, uint32_t list_cap = 
 // the part's slots as constants from the generator): lane s = slot s is the layout the output stage reads (kernel_body.inc, s_masks).
 // Before: every result was an exec-mask round trip around a one-lane LDS store (s_and_saveexec, two moves, ds_write_b64, s_or),
 // ~25 times per wave and row group.  The text is shared with the test-only kernel emulator, which supplies its own GK_LANE_ID /
-// GK_WRITELANE (tests/native/hostemu.cpp).  GK_JIT_RES_LANES=0 (A/B aid) keeps the one-lane stores.
+// GK_WRITELANE2 (tests/native/hostemu.cpp).  GK_JIT_RES_LANES=0 (A/B aid) keeps the one-lane stores.
 inline std::string jit_res_macros() {
   static const bool lanes = !(getenv("GK_JIT_RES_LANES") && atoi(getenv("GK_JIT_RES_LANES")) == 0);
   if (!lanes)
@@ -56,8 +56,7 @@ inline std::string jit_res_macros() {
            "#define GK_RES(kind, slot, b) do { const unsigned long long m_ = __ballot((b) != 0u); if (gk_l0) masks[(kind) * GK_RES_K + (slot)] = m_; } while (0)\n"
            "#define GK_RES_FLUSH(m0, m1, m2)\n";
   return "#define GK_RES_PROLOGUE uint32_t gk_rl0 = 0u, gk_rh0 = 0u, gk_rl1 = 0u, gk_rh1 = 0u, gk_rl2 = 0u, gk_rh2 = 0u;\n"
-         "#define GK_RES(kind, slot, b) do { const unsigned long long m_ = __ballot((b) != 0u); gk_rl##kind = GK_WRITELANE((uint32_t)m_, slot, gk_rl##kind); "
-         "gk_rh##kind = GK_WRITELANE((uint32_t)(m_ >> 32), slot, gk_rh##kind); } while (0)\n"
+         "#define GK_RES(kind, slot, b) do { const unsigned long long m_ = __ballot((b) != 0u); GK_WRITELANE2(m_, slot, gk_rl##kind, gk_rh##kind); } while (0)\n"
          "#define GK_RES_FLUSH(m0, m1, m2) do { const uint32_t l_ = GK_LANE_ID() & 63u; "
          "if (((unsigned long long)(m0) >> l_) & 1ull) masks[0u * GK_RES_K + l_] = ((unsigned long long)gk_rh0 << 32) | gk_rl0; "
          "if (((unsigned long long)(m1) >> l_) & 1ull) masks[1u * GK_RES_K + l_] = ((unsigned long long)gk_rh1 << 32) | gk_rl1; "
@@ -74,9 +73,14 @@ inline std::string assemble_jit_source(const HostPlan& plan, uint32_t rpt, uint3
   src += plan_hpp;
   src += vm_core_hpp;
   src += "#define GK_LANE_ID() __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u))\n"
-         // (v_writelane_b32: lane `l` -- an immediate -- of the register takes the wave-uniform value; hiprtc's clang has no builtin for it)
-         "static __device__ inline uint32_t gk_writelane(uint32_t v, const uint32_t l, uint32_t o) { asm(\"v_writelane_b32 %0, %1, %2\" : \"+v\"(o) : \"s\"(v), \"n\"(l)); return o; }\n"
-         "#define GK_WRITELANE(v, l, o) gk_writelane((uint32_t)(v), (l), (o))\n";
+         // (v_writelane_b32: lane `l` -- an immediate -- of a register takes a wave-uniform value; hiprtc's clang has no builtin for it.
+         //  gfx950 wants TWO wait states between a vector instruction that writes an SGPR -- the compare whose mask is the ballot --
+         //  and a vector instruction that reads it; the compiler's hazard recogniser does not look into inline assembly, so the s_nop
+         //  is part of the text.  Without it the device read stale masks now and then: 1 805 2xx instead of 1 809 882 violating pairs
+         //  of configs[2], a different count every run -- profiles/r05_variants_t_result_lanes.log.)
+         "static __device__ inline void gk_writelane2(unsigned long long m, const uint32_t l, uint32_t& lo, uint32_t& hi) {\n"
+         "  asm(\"s_nop 1\\n\\tv_writelane_b32 %0, %2, %4\\n\\tv_writelane_b32 %1, %3, %4\" : \"+v\"(lo), \"+v\"(hi) : \"s\"((uint32_t)m), \"s\"((uint32_t)(m >> 32)), \"n\"(l)); }\n"
+         "#define GK_WRITELANE2(m, l, lo, hi) gk_writelane2((m), (l), (lo), (hi))\n";
   src += jit_res_macros();
   const int block = jit_block_of(rpt);
   src += generate_plan_source(plan, (uint32_t)(block / GK_TILE / ((int)rpt / GK_TILE)));
