@@ -69,7 +69,8 @@ std::vector<uint32_t> jit_path_classes(const HostPlan& plan, std::vector<std::ve
 
 uint32_t jit_res_k(const HostPlan& plan) {
   const uint32_t need = std::max(plan.n_viol, plan.n_match);
-  return need <= 16 ? 16u : need <= 32 ? 32u : (uint32_t)GK_MAX_RES;
+  // (in steps of four above 16: 4 halves x 3 kinds x 20 slots of configs[2] fit the 256-entry chunk-list buffer they alias, 32 did not)
+  return need <= 16 ? 16u : std::min<uint32_t>((uint32_t)GK_MAX_RES, (need + 3u) / 4u * 4u);
 }
 
 std::string generate_plan_source(const HostPlan& plan, uint32_t parts) {

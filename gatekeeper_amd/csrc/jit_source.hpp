@@ -32,7 +32,14 @@ inline uint32_t list_cap_of(int block) { return (uint32_t)std::min(block / GK_TI
 // list capacity a plan-specialised build is compiled for: the geometry's full capacity.  (Trimming it to what the table's longest list
 // needs buys a fourth resident group per CU at configs[2] -- and a 64-VGPR budget whose spills cost more: 0.133 against 0.1235 ms,
 // profiles/r03_variants_h_four_groups_per_cu_64_vgprs.log; removed in round 5.)
-inline uint32_t jit_list_cap(int block, uint32_t) { return list_cap_of(block); }
+// GK_JIT_LIST_TRIM=1 (tuning aid, with GK_JIT_WAVES=8): the trimmed capacity again -- round 5 re-measures four groups per CU on the
+// leaner kernel (the sixth round of configs[2]'s 3 907 groups on 768 workgroups is a tenth of the launch).
+inline uint32_t jit_list_cap(int block, uint32_t need) {
+  static const bool trim = getenv("GK_JIT_LIST_TRIM") && atoi(getenv("GK_JIT_LIST_TRIM")) != 0;
+  const uint32_t full = list_cap_of(block);
+  if (!trim || need == 0) return full;
+  return std::min(full, std::max<uint32_t>(128u, (need + 127u) / 128u * 128u));
+}
 inline size_t static_lds_of(uint32_t rpt, int block, uint32_t res_k, uint32_t list_cap = 0) {
   const size_t list = (size_t)(list_cap ? list_cap : list_cap_of(block)) * 8;
   const size_t masks = (size_t)(rpt / GK_TILE) * 3 * (res_k ? res_k : GK_MAX_RES) * 8;

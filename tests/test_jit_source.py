@@ -94,7 +94,7 @@ def _scratch_bytes(code):
 
 
 def _row_load_wait_gaps(code, tmp_path):
-    """per `global_load_dwordx4` of gk_jit_tiles: instructions (text order) up to the next `s_waitcnt vmcnt`; None without llvm-objdump"""
+    """per `global_load_dwordx4` of gk_jit_tiles: instructions on the fall-through path up to the next `s_waitcnt vmcnt`; None without llvm-objdump"""
     import re
     import subprocess
     objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
@@ -108,8 +108,14 @@ def _row_load_wait_gaps(code, tmp_path):
     gaps = []
     for i, op in enumerate(ops):
         if op.startswith("global_load_dwordx4"):
-            j = next((k for k in range(i + 1, len(ops)) if ops[k].startswith("s_waitcnt") and "vmcnt" in ops[k]), len(ops))
-            gaps.append(j - i)
+            gap = 10 ** 6   # (an unconditional branch ends the fall-through path: what follows in the text is another block)
+            for k in range(i + 1, len(ops)):
+                if ops[k].startswith("s_waitcnt") and "vmcnt" in ops[k]:
+                    gap = k - i
+                    break
+                if ops[k].startswith(("s_branch", "s_endpgm", "s_setpc")):
+                    break
+            gaps.append(gap)
     return gaps
 
 
