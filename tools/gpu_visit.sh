@@ -77,7 +77,7 @@ try: ALGO = json.loads(open("gpurun_out/%s_pmc_fetch.json" % sys.argv[2]).read()
 except Exception: ALGO = None
 if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
     print(json.dumps({"config": 2, "reviews": 1000000, "algo_bytes_per_launch": ALGO, "hbm_bytes_per_launch": int((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024), "fetch_kb": v["FETCH_SIZE"], "write_kb": v["WRITE_SIZE"],
-                      "source": "profiles/%s_summary.txt (rocprofv3 --pmc, separate passes of `bench.py --steps 5 --warmup 1 --lean` with --kernel-trace only; HBM bytes = 2 x FETCH_SIZE KB (gfx950 correction, MI355X_MICROARCH.md) + WRITE_SIZE KB, KB = 1024 B)" % "r05_pmc_" + sys.argv[2][3:] + "_config2_1M"}, indent=1))
+                      "source": "profiles/%s_summary.txt (rocprofv3 --pmc, separate passes of `bench.py --steps 5 --warmup 1 --lean` with --kernel-trace only; HBM bytes = 2 x FETCH_SIZE KB (gfx950 correction, MI355X_MICROARCH.md) + WRITE_SIZE KB, KB = 1024 B)" % ("r05_pmc_" + sys.argv[2][3:] + "_config2_1M")}, indent=1))
 PY
          ;;
     pmc4) run_pmc4() { name=$1; shift; timeout 400 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d gpurun_out/${tag}_pmc_$name -o $name -- python bench.py --config 4 --steps 5 --warmup 1 --lean > /dev/null 2> gpurun_out/${tag}_pmc_$name.err; }
