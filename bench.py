@@ -581,7 +581,9 @@ def other_configs(args, dev_index, dev, fx, nss, budget_s=200.0, known_prefix=No
         detail["configs1"], brief["configs1"] = r[0], resident_brief(r[0])
     import copy
     sa = copy.copy(args)
-    sa.stream_batches, sa.warmup, sa.stream_unique, sa.batch, sa.offered = 16, 2, 8, 65536, 1e6
+    # (batches of 16 384 reviews: at the offered 10^6/s a batch of 65 536 answered in 8.3 ms mean / 9.8-12 ms p99, one of 16 384 in 3.8 / 5.6 ms,
+    #  and the closed loop moves 5.7 M reviews/s instead of 4.1 M -- profiles/r05_stream_y_batch_sizes.log)
+    sa.stream_batches, sa.warmup, sa.stream_unique, sa.batch, sa.offered = 64, 2, 8, 16384, 1e6
     r = run("configs4", lambda: side_point(4, 200000, max(args.steps, 20), args.warmup, args.side_oracle_sample, dev_index, fx, nss, with_stream=True, stream_args=sa, dev=dev, totals=True, warm_probe=True))
     if r:
         detail["configs4"], brief["configs4"] = r[0], resident_brief(r[0])
@@ -624,8 +626,8 @@ def main():
     ap.add_argument("--lean", action="store_true", help="tuning runs: the timed sweep and the roofline figures only (no RESULT totals, no CPU / oracle legs)")
     ap.add_argument("--streaming", action="store_true", help="configs[4] as a STREAM: batches of --batch reviews through ingest -> H2D -> launch -> D2H, "
                     "double-buffered, round robin over the ranks; reports the achieved rate and the batch latency percentiles (steps = --stream-batches)")
-    ap.add_argument("--batch", type=int, default=65536, help="reviews per streamed batch")
-    ap.add_argument("--stream-batches", type=int, default=16, help="timed batches over all ranks")
+    ap.add_argument("--batch", type=int, default=16384, help="reviews per streamed batch")
+    ap.add_argument("--stream-batches", type=int, default=64, help="timed batches over all ranks")
     ap.add_argument("--stream-unique", type=int, default=8, help="distinct pre-generated batches per rank (cycled)")
     ap.add_argument("--offered", type=float, default=1e6, help="offered load in reviews/s over all ranks (0: closed loop, as fast as the pipeline goes)")
     ap.add_argument("--oracle-sample", type=int, default=1048576, help="objects of the timed table the pure-Python oracle re-evaluates (parity_python_oracle)")
@@ -724,7 +726,7 @@ def main():
 
     if args.streaming:
         if args.warmup > 8:
-            args.warmup = 2 * world      # (the non-streaming default of 10 sweeps would be 10 x 64k reviews of warm-up)
+            args.warmup = 2 * world      # (the non-streaming default of 10 sweeps would be 10 batches of warm-up)
         r = stream_leg(args, drv, client, templates, constraints, nss, rank, world, dev, dist)
         if rank == 0:
             nc = len(constraints)
@@ -745,7 +747,7 @@ def main():
                                       "value counts host ingest + PCIe: this is the end-to-end streaming rate, host-bound"},
                    "roofline": {"bound": "hbm", "kernel": "gk_jit_tiles", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                                 "traffic": None, "algo_bytes_per_launch": r["algo_bytes"], "avg_kernel_ms": r["kernel_s"] * 1e3, "lds_bytes_per_tile": r["lds"],
-                                "note": "dominant kernel per plan group launch over one 64k-review batch (launch-bound at this size); the resident-sweep record is the roofline line"}}
+                                "note": "dominant kernel per plan group launch over one %d-review batch (launch-bound at this size); the resident-sweep record is the roofline line" % args.batch}}
             print(json.dumps(out))
         if dist is not None:
             dist.destroy_process_group()
