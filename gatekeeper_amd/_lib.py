@@ -29,7 +29,7 @@ GK_TABLE_PRUNED = 32
 GK_TABLE_PROCESS_AUDIT = 4
 GK_TABLE_PROCESS_WEBHOOK = 8
 GK_REVIEW_EXCLUDED = 1
-GK_EVAL_WANT_MATCH, GK_EVAL_NO_DOWNLOAD, GK_EVAL_WANT_LIST, GK_EVAL_ASYNC, GK_EVAL_COLLECT, GK_EVAL_TIME_EACH = 1, 2, 4, 8, 16, 32
+GK_EVAL_WANT_MATCH, GK_EVAL_NO_DOWNLOAD, GK_EVAL_WANT_LIST, GK_EVAL_ASYNC, GK_EVAL_COLLECT, GK_EVAL_TIME_EACH, GK_EVAL_KERNEL_ONLY = 1, 2, 4, 8, 16, 32, 64
 GK_SWEEP_RESULT_TOTALS = 1
 
 EXPORTS = [

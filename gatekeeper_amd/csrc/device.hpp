@@ -20,6 +20,7 @@ struct EvalOptions {
   uint32_t list_capacity = 0;   // max violation-list entries (0 = no list)
   bool shard = false;           // results go to the shard slot prepared by dev_shard_setup (bitmap stride = the largest shard's)
   bool detached = false;        // (kernels.hip, internal) an enqueue-only pass that dev_eval_finish never collects: see dev_shard_enqueue
+  bool kernel_only = false;     // GK_EVAL_KERNEL_ONLY: no totals kernel behind the dominant one (back-to-back timing of that kernel)
   bool time_each = false;       // GK_EVAL_TIME_EACH: an event pair around EVERY launch (isolated kernel durations) instead of one around all pending ones
   bool jit_wait = true;         // wait for the plan-specialised build of the dominant kernel; false (admission batches): never
                                 //   block -- the bytecode kernel serves until the background build has been loaded

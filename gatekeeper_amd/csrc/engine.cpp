@@ -1602,6 +1602,7 @@ int gk_table_eval(gk_engine* e, gk_table* t, uint32_t flags, gk_eval_out** out) 
     opt.download = !(flags & GK_EVAL_NO_DOWNLOAD);
     opt.want_match = flags & GK_EVAL_WANT_MATCH;
     opt.time_each = (flags & GK_EVAL_TIME_EACH) != 0;
+    opt.kernel_only = (flags & GK_EVAL_KERNEL_ONLY) != 0 && (flags & GK_EVAL_ASYNC) != 0;
     // an admission batch (small, evaluated once) never waits for a compiler; an audit-sized or resident table does
     opt.jit_wait = t->resident || t->n_reviews >= 8192;
     {

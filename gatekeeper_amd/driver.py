@@ -353,11 +353,13 @@ class Table:
         self.engine._check(lib.gk_table_eval(self.engine.handle, self.handle, flags, C.byref(out)))
         return EvalResult(lib, out)
 
-    def launch(self, want_match=False, time_each=False):
+    def launch(self, want_match=False, time_each=False, kernel_only=False):
         """Enqueue one evaluation launch without waiting (GK_EVAL_ASYNC); a later eval() collects.  time_each: an event pair around
-        this launch alone (GK_EVAL_TIME_EACH: isolated kernel durations)"""
+        this launch alone (GK_EVAL_TIME_EACH: isolated kernel durations); kernel_only: the dominant kernel without the totals kernel
+        behind it (GK_EVAL_KERNEL_ONLY: consecutive launches of that kernel under the collecting call's one event pair)"""
         out = C.POINTER(L.gk_eval_out)()
-        flags = L.GK_EVAL_ASYNC | (L.GK_EVAL_WANT_MATCH if want_match else 0) | (L.GK_EVAL_TIME_EACH if time_each else 0)
+        flags = L.GK_EVAL_ASYNC | (L.GK_EVAL_WANT_MATCH if want_match else 0) | (L.GK_EVAL_TIME_EACH if time_each else 0) | (
+            L.GK_EVAL_KERNEL_ONLY if kernel_only else 0)
         self.engine._check(self.engine.lib.gk_table_eval(self.engine.handle, self.handle, flags, C.byref(out)))
 
     def _render(self, fn, cid, review):

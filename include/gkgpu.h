@@ -204,6 +204,10 @@ typedef struct {
 #define GK_EVAL_ASYNC 8u         /* enqueue one launch on the default stream and return (out = NULL); the next call
                                     without this flag synchronises, and reports the average kernel time per launch */
 #define GK_EVAL_COLLECT 16u      /* do not launch: synchronise and collect the results of the pending GK_EVAL_ASYNC launches */
+#define GK_EVAL_KERNEL_ONLY 64u  /* with GK_EVAL_ASYNC: enqueue the dominant kernel alone, without the per-constraint totals kernel behind it (timing runs:
+                                    consecutive launches of that kernel under ONE event pair -- fast_kernel_ms of the collecting call is then the kernel's
+                                    back-to-back average, free of the event records a pair per launch puts between the launches); the totals the
+                                    collecting call reports are not those of these launches */
 #define GK_EVAL_TIME_EACH 32u    /* with GK_EVAL_ASYNC: an event pair around THIS launch (fast_kernel_ms of the collecting call = the sum of the
                                     isolated kernel durations / launches) instead of one pair around all pending launches, gaps included */
 

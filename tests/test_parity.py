@@ -870,3 +870,30 @@ def test_augmented_unstructured_operation_and_delete(backend):
     assert assert_parity(c, oc, rv) == 4
     got = c.ReviewBatch(rv, D.AUDIT_EP)
     assert [[r.msg for r in g] for g in got] == [[m] for m in want.values()]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_kernel_only_launches_leave_the_bitmaps_of_a_full_launch(backend, fixtures):
+    """GK_EVAL_KERNEL_ONLY (the bench's back-to-back timing of the dominant kernel): launches without the totals kernel behind them write the same
+    bitmaps as a full launch; the totals of a later full launch are untouched by them."""
+    import numpy as np
+    client = make_client(backend)
+    for t in synth.psp_templates(fixtures):
+        client.AddTemplate(t)
+    for k in synth.audit_constraints():
+        client.AddConstraint(k)
+    drv = client.driver
+    n = 700
+    batch = synth.NativeBatch(drv.engine.lib, n, seed=synth.SEED, mixed=True, start=0, namespaces=synth.gen_namespaces())
+    table = drv.engine.create_table_native(batch.reviews, n, keep_docs=False, resident=True)
+    table.launch()
+    full = table.eval(download=True, collect_only=True)
+    viol, counts = np.array(full.viol, copy=True), np.array(full.counts, copy=True)
+    assert counts.sum() > 100
+    for _ in range(3):
+        table.launch(kernel_only=True)
+    only = table.eval(download=True, collect_only=True)
+    assert np.array_equal(np.array(only.viol), viol)
+    table.launch()
+    again = table.eval(download=True, collect_only=True)
+    assert np.array_equal(np.array(again.viol), viol) and np.array_equal(np.array(again.counts), counts)
