@@ -583,8 +583,9 @@ def other_configs(args, dev_index, dev, fx, nss, budget_s=200.0, known_prefix=No
     import copy
     sa = copy.copy(args)
     # (batches of 16 384 reviews: at the offered 10^6/s a batch of 65 536 answered in 8.3 ms mean / 9.8-12 ms p99, one of 16 384 in 3.8 / 5.6 ms,
-    #  and the closed loop moves 5.7 M reviews/s instead of 4.1 M -- profiles/r05_stream_y_batch_sizes.log)
-    sa.stream_batches, sa.warmup, sa.stream_unique, sa.batch, sa.offered = 64, 2, 8, 16384, 1e6
+    #  and the closed loop moves 5.7 M reviews/s instead of 4.1 M -- profiles/r05_stream_y_batch_sizes.log;
+    #  eight warm-up batches: pool growth and the first uploads of a new batch geometry showed as one 15 ms batch among the first timed ones)
+    sa.stream_batches, sa.warmup, sa.stream_unique, sa.batch, sa.offered = 64, 8, 8, 16384, 1e6
     r = run("configs4", lambda: side_point(4, 200000, max(args.steps, 20), args.warmup, args.side_oracle_sample, dev_index, fx, nss, with_stream=True, stream_args=sa, dev=dev, totals=True, warm_probe=True))
     if r:
         detail["configs4"], brief["configs4"] = r[0], resident_brief(r[0])
