@@ -2,7 +2,7 @@
 # the body of commit 2e1cb22 (tools/scratch/kernel_body_r05r.inc, through GK_JIT_BODY_FILE), one and two chunks in flight per wave,
 # on configs[2], [1] and the corpus; per-phase clocks; then the parity legs of the headline workload on the new body.
 set -u; mkdir -p gpurun_out; export TMPDIR=/tmp
-OLD=$PWD/tools/scratch/kernel_body_r05r.inc
+OLD=$PWD/tools/scratch/kernel_body_r05r.inc   # (not kept in the tree: git show 2e1cb22:gatekeeper_amd/csrc/kernel_body.inc > tools/scratch/kernel_body_r05r.inc)
 run() { tag=$1; shift; timeout 300 python bench.py "$@" --lean --steps 50 --warmup 5 > gpurun_out/r05s_$tag.json 2> gpurun_out/r05s_$tag.err; rc=$?
   python - gpurun_out/r05s_$tag.json $tag $rc <<'PY'
 import json, sys

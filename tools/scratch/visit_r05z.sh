@@ -1,7 +1,7 @@
 # visit r05z (one box): the chunk loop with two slots that swap roles (tools/scratch/kernel_body_pingpong.inc through GK_JIT_BODY_FILE,
 # GK_JIT_DEFINES=GK_PINGPONG=1: no slot copies at the back edge, an explicit wait in front of the next request) against the product body
 set -u; mkdir -p gpurun_out; export TMPDIR=/tmp
-PP=$PWD/tools/scratch/kernel_body_pingpong.inc
+PP=$PWD/tools/scratch/kernel_body_pingpong.inc   # (kept as a patch: patch -o tools/scratch/kernel_body_pingpong.inc gatekeeper_amd/csrc/kernel_body.inc tools/scratch/kernel_body_pingpong.patch)
 run() { tag=$1; shift; timeout 300 python bench.py "$@" --lean --steps 50 --warmup 5 > gpurun_out/r05z_$tag.json 2> gpurun_out/r05z_$tag.err; rc=$?
   python - gpurun_out/r05z_$tag.json $tag $rc <<'PY'
 import json, sys
