@@ -45,3 +45,25 @@ def _sweep(monkeypatch, mode, n, env):
 ], ids=["rpt64", "rpt256", "rpt256-4pass", "rpt512-2pass", "list-overflow", "stagger-partial-first", "stagger-partial-last", "stagger-partial-last-4"])
 def test_kernel_source_on_the_emulator(monkeypatch, mode, env):
     _sweep(monkeypatch, mode, env.get("N", 1500), {k: v for k, v in env.items() if k != "N"})
+
+
+def test_corpus_plan_groups_on_the_emulator(monkeypatch):
+    """The 200-template corpus: four plan groups, up to 64 result slots per kind -- lanes 32..63 of the result registers (jit_source.hpp
+    jit_res_macros: GK_RES keeps a slot's word in lane `slot`, GK_RES_FLUSH stores the part's slots), element scopes read at use with
+    rolling registers, 128-review groups; the plan-specialised text on the emulator against the per-review evaluation."""
+    monkeypatch.setenv("GK_HOSTEMU_KERNEL", "jit")
+    monkeypatch.setenv("GK_EMU_GRID", "8")
+    fx = synth.load_fixtures()
+    templates, constraints = synth.corpus(fx, 200)
+    drv = D.Driver(device=0, hostemu=True)
+    client = D.Client(drv)
+    for t in templates:
+        client.AddTemplate(t)
+    for k in constraints:
+        client.AddConstraint(k)
+    n = 512
+    batch = synth.NativeBatch(drv.engine.lib, n, seed=synth.SEED, mixed=True, start=0, namespaces=synth.gen_namespaces())
+    table = drv.engine.create_table_native(batch.reviews, n, keep_docs=False, resident=True)
+    table.launch()
+    ev = table.eval(download=True, collect_only=True)     # raises EngineError when the emulated kernel and the per-review path differ
+    assert int(ev.n_plan_groups) >= 3 and int(ev.counts.sum()) > 1000
