@@ -171,3 +171,34 @@ def test_library_pattern_sources_compile_for_gfx950(monkeypatch, tmp_path):
     for name, text in _dump_sources(monkeypatch, tmp_path, _pattern_plans()):
         ok, log, _ = compile_gfx950(rtc, text)
         assert ok, "%s does not compile for gfx950:\n%s" % (name, log[-3000:])
+
+def test_corpus_plan_sources_compile_for_gfx950_and_keep_their_prefetch_distance(monkeypatch, tmp_path):
+    """the 200-template corpus: every plan group's text (128-review groups) through hiprtc; the next item's row loads are not waited for
+    behind their request in any of them"""
+    rtc = _hiprtc()
+    if rtc is None:
+        pytest.skip("libhiprtc.so is not installed")
+
+    def run():
+        fx = synth.load_fixtures()
+        templates, constraints = synth.corpus(fx, 200)
+        drv = D.Driver(device=0, hostemu=True)
+        client = D.Client(drv)
+        for t in templates:
+            client.AddTemplate(t)
+        for k in constraints:
+            client.AddConstraint(k)
+        n = 512
+        batch = synth.NativeBatch(drv.engine.lib, n, seed=synth.SEED, mixed=True, start=0, namespaces=synth.gen_namespaces())
+        table = drv.engine.create_table_native(batch.reviews, n, keep_docs=False, resident=True)
+        table.launch()
+        table.eval(download=True, collect_only=True)
+    texts = _dump_sources(monkeypatch, tmp_path, run)
+    assert len(texts) >= 3
+    for name, text in texts:
+        ok, log, code = compile_gfx950(rtc, text)
+        assert ok, "%s does not compile for gfx950:\n%s" % (name, log[-3000:])
+        assert 0 <= _scratch_bytes(code) <= 64, "%s: %d bytes of scratch per lane" % (name, _scratch_bytes(code))
+        gaps = _row_load_wait_gaps(code, tmp_path)
+        if gaps is not None:
+            assert gaps and min(gaps) >= 16, "%s: a row load is waited for %d instructions after its request (gaps %s)" % (name, min(gaps), gaps)
