@@ -26,18 +26,20 @@ GK_TABLE_KEEP_DOCS = 1
 GK_TABLE_RESIDENT = 2
 GK_TABLE_KEEP_TEXT = 16
 GK_TABLE_PRUNED = 32
+GK_TABLE_PRE_MATCHED = 64
 GK_TABLE_PROCESS_AUDIT = 4
 GK_TABLE_PROCESS_WEBHOOK = 8
 GK_REVIEW_EXCLUDED = 1
 GK_EVAL_WANT_MATCH, GK_EVAL_NO_DOWNLOAD, GK_EVAL_WANT_LIST, GK_EVAL_ASYNC, GK_EVAL_COLLECT, GK_EVAL_TIME_EACH, GK_EVAL_KERNEL_ONLY = 1, 2, 4, 8, 16, 32, 64
+GK_EVAL_DEVICE_ONLY = 128
 GK_SWEEP_RESULT_TOTALS = 1
 
 EXPORTS = [
     "gk_engine_create", "gk_engine_destroy", "gk_last_error", "gk_version", "gk_template_add", "gk_template_remove",
     "gk_constraint_add", "gk_constraint_remove", "gk_data_put", "gk_data_remove", "gk_excluder_replace", "gk_excluder_excluded", "gk_table_create", "gk_table_free",
     "gk_table_eval", "gk_eval_free", "gk_render", "gk_render_error", "gk_free", "gk_dump", "gk_table_topk", "gk_topk_free",
-    "gk_table_totals", "gk_totals_free", "gk_table_get_stats", "gk_batcher_start", "gk_batcher_stop", "gk_query", "gk_query_ex",
-    "gk_resident_sweep", "gk_sweep_free", "gk_resident_review",
+    "gk_table_totals", "gk_totals_free", "gk_table_get_stats", "gk_batcher_start", "gk_batcher_stop", "gk_query", "gk_query_ex", "gk_query_ex2",
+    "gk_resident_sweep", "gk_sweep_free", "gk_resident_review", "gk_resident_review_ex",
     "gk_comm_unique_id", "gk_comm_init", "gk_comm_destroy", "gk_comm_info", "gk_table_sweep_sharded", "gk_shard_free",
     "gk_jit_quiesce", "gk_jit_cache_stats", "gk_jit_cache_dir", "gk_jit_cache_drop_memory", "gk_host_cpus", "gk_table_create_spool", "gk_spool_info_free",
     # include/gksynth.h (bench / test plumbing)
@@ -47,6 +49,7 @@ EXPORTS = [
 
 GK_OPT_NO_REFERENTIAL, GK_OPT_GATHER_STATS, GK_OPT_TRACE = 1, 2, 4
 GK_QUERY_TRACE = 1
+GK_QUERY_PRE_MATCHED = 2
 
 
 class gk_opts(C.Structure):
@@ -224,6 +227,8 @@ def load(hostemu: bool | None = None):
     lib.gk_batcher_stop.restype = None
     lib.gk_query.argtypes = [vp, C.POINTER(gk_review_in), C.POINTER(vp), C.POINTER(gk_query_stats)]
     lib.gk_query_ex.argtypes = [vp, C.POINTER(gk_review_in), u32, C.POINTER(vp), C.POINTER(vp), C.POINTER(gk_query_stats)]
+    lib.gk_query_ex2.argtypes = [vp, C.POINTER(gk_review_in), C.POINTER(u32), sz, u32, C.POINTER(vp), C.POINTER(vp), C.POINTER(gk_query_stats)]
+    lib.gk_resident_review_ex.argtypes = [vp, C.POINTER(cp), sz, C.POINTER(u32), sz, u32, C.POINTER(vp)]
     lib.gk_table_get_stats.argtypes = [vp, C.POINTER(gk_table_stats)]
     lib.gk_table_totals.argtypes = [vp, vp, C.POINTER(C.POINTER(gk_totals_out))]
     lib.gk_totals_free.argtypes = [C.POINTER(gk_totals_out)]

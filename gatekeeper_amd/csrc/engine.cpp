@@ -15,6 +15,7 @@
 #include <thread>
 #include <map>
 #include <unordered_map>
+#include <unordered_set>
 #include <memory>
 #include <mutex>
 #include <shared_mutex>
@@ -338,6 +339,7 @@ struct gk_engine {
   struct BatchResult;   // one evaluated batch: table + bitmaps, shared by its requests until the last one has rendered
   struct Request {
     const gk_review_in* in = nullptr;
+    bool pre_matched = false;               // GK_QUERY_PRE_MATCHED: the review's RF_PREMATCHED bit in the batch's table
     std::chrono::steady_clock::time_point arrived;
     int status = GK_OK;
     std::string error;
@@ -374,6 +376,7 @@ struct gk_table {
   std::vector<DevTable*> views;             // one per extra plan group (shares the device arrays of `dev`)
   std::vector<DevTable*> tviews;            // one per totals plan group (gk_table_totals)
   bool resident = false;
+  bool any_prematched = false;              // some review carries RF_PREMATCHED (host.rflags says which)
   uint64_t cached_gen = 0;                  // plan generation the cached variant choices belong to
   std::vector<DevPlan*> cached_plan;        // per plan group (0 = the primary plan)
   std::vector<const HostPlan*> cached_host;
@@ -406,7 +409,11 @@ struct gk_table {
   std::mutex big_mu;
   // (row, review) pairs the host evaluation of the most recent gk_table_eval added: violations / autoreject errors the device
   // bitmaps do not hold (gk_table_totals and gk_table_topk read those)
+  // (stamped with the constraint-id list of that evaluation: a reader whose own list differs -- a policy change renumbered the rows --
+  //  drops them; host_mu orders the evaluation that writes them and the totals / top-k calls that read them)
   std::vector<std::pair<uint32_t, uint32_t>> host_viol, host_err;
+  std::vector<uint32_t> host_ids;
+  std::mutex host_mu;
   uint32_t n_reviews = 0;
   uint32_t rpt = GK_RPT_MIN;                // reviews per row group of this table
   uint64_t dict_gen = 0;                    // generation of the dictionary-predicate registry the rows were flattened under
@@ -1195,7 +1202,12 @@ int gk_excluder_excluded(gk_engine* e, const char* process, const gk_review_in* 
   } catch (const std::exception& ex) { return fail(GK_ERR_INTERNAL, ex.what()); }
 }
 
+// `prem` (may be NULL): per review, non-zero = the caller ran Matcher.Match itself (RF_PREMATCHED, plan.hpp); GK_TABLE_PRE_MATCHED = all of them
+static int table_create_impl(gk_engine* e, const gk_review_in* reviews, size_t n, uint32_t flags, int32_t* statuses, const uint8_t* prem, gk_table** out);
 int gk_table_create(gk_engine* e, const gk_review_in* reviews, size_t n, uint32_t flags, int32_t* statuses, gk_table** out) {
+  return table_create_impl(e, reviews, n, flags, statuses, nullptr, out);
+}
+static int table_create_impl(gk_engine* e, const gk_review_in* reviews, size_t n, uint32_t flags, int32_t* statuses, const uint8_t* prem, gk_table** out) {
   if (!e || !out || (n && !reviews)) return fail(GK_ERR_INVALID, "NULL argument");
   try {
     // referential constraints follow the synced inventory: compiled again -- and their dictionary expressions registered -- BEFORE
@@ -1431,6 +1443,8 @@ int gk_table_create(gk_engine* e, const gk_review_in* reviews, size_t n, uint32_
       t->stats.heap_bytes = hb;
       H.n_rows_total = rb;
     }
+    if (prem || (flags & GK_TABLE_PRE_MATCHED))
+      for (size_t i = 0; i < n && i < H.rflags.size(); i++) if ((flags & GK_TABLE_PRE_MATCHED) || prem[i]) { H.rflags[i] |= RF_PREMATCHED; t->any_prematched = true; }
     Flattener::build_index(&t->host);
     if (want_digest) {
       uint64_t d = 1469598103934665603ull;
@@ -1652,7 +1666,8 @@ int gk_table_eval(gk_engine* e, gk_table* t, uint32_t flags, gk_eval_out** out) 
       }
     }
     // reviews the device could not evaluate (too_big) are answered by the engine's own exact evaluator where their text is at hand
-    if (opt.download) complete_on_host(e, t, h.get(), opt.want_match, (flags & GK_EVAL_WANT_LIST) != 0);
+    if (opt.download && !(flags & GK_EVAL_DEVICE_ONLY)) complete_on_host(e, t, h.get(), opt.want_match, (flags & GK_EVAL_WANT_LIST) != 0);
+    else if (opt.download) { std::lock_guard<std::mutex> hl(t->host_mu); t->host_viol.clear(); t->host_err.clear(); t->host_ids.clear(); }
     gk_eval_out& p = h->pub;
     memset(&p, 0, sizeof p);
     p.n_host_evaluated = (uint32_t)h->host_evaluated.size();
@@ -1747,12 +1762,18 @@ int gk_table_topk(gk_engine* e, gk_table* t, uint32_t k, gk_topk_out** out) {
     }
     // (violating pairs the host evaluation of the last gk_table_eval added are no part of the device bitmaps: they join the candidates
     //  -- a candidate too many costs a rendering, the host sorts and cuts the lists anyway; a full row says "walk the bitmap row")
-    for (auto& hp : t->host_viol) {
-      const uint32_t row = hp.first;
-      if (row >= h->counts.size()) continue;
-      uint32_t* lst = &h->reviews[(size_t)row * cap];
-      if (std::find(lst, lst + h->counts[row], hp.second) != lst + h->counts[row]) continue;
-      if (h->counts[row] < cap) lst[h->counts[row]++] = hp.second; else h->overflow[row] = 1;
+    std::vector<std::pair<uint32_t, uint32_t>> hv;
+    { std::lock_guard<std::mutex> hl(t->host_mu); if (t->host_ids == h->ids) hv = t->host_viol; }   // (another policy set's pairs: dropped)
+    if (!hv.empty()) {
+      std::vector<std::unordered_set<uint32_t>> have(h->counts.size());   // (a set per touched row, not a linear search per pair)
+      for (auto& hp : hv) {
+        const uint32_t row = hp.first;
+        if (row >= h->counts.size()) continue;
+        uint32_t* lst = &h->reviews[(size_t)row * cap];
+        if (have[row].empty()) have[row].insert(lst, lst + h->counts[row]);
+        if (!have[row].insert(hp.second).second) continue;
+        if (h->counts[row] < cap) lst[h->counts[row]++] = hp.second; else h->overflow[row] = 1;
+      }
     }
     h->pub.n_constraints = t->last_nc; h->pub.stride = cap;
     h->pub.constraint_ids = h->ids.data(); h->pub.counts = h->counts.data(); h->pub.reviews = h->reviews.data(); h->pub.overflow = h->overflow.data();
@@ -1804,84 +1825,127 @@ static Value strip_object(const Value& o) {
   for (auto& kv : o.pairs()) if (kv.first.is_string() && (kv.first.str() == "apiVersion" || kv.first.str() == "kind" || kv.first.str() == "metadata")) keep.push_back(kv);
   return Value::object(std::move(keep));
 }
+// (the nested evaluation of a stripped review must never complete on the host again: a stripped review that is still beyond the
+//  device's limits -- 300 metadata.ownerReferences iterated by an element-scoped rule -- strips to itself and would recurse without
+//  bound; with the guard it takes the "refused as well" branch below and the review stays in too_big: fail closed)
+static thread_local int tl_host_completion_depth = 0;
+// at most this many refused reviews are completed per evaluation; the rest stay in too_big (fail closed) -- the host evaluator is
+// the exception path, not a second engine: a table of a million 300-container pods belongs on the reference driver
+static constexpr size_t GK_HOST_COMPLETIONS_MAX = 4096;
 static void complete_on_host(gk_engine* e, gk_table* t, EvalHolder* h, bool want_match, bool want_list) {
   EvalOut& o = h->out;
-  if (const char* off = getenv("GK_HOST_EVAL")) if (atoi(off) == 0) return;   // (GK_HOST_EVAL=0: the device's answer alone -- refusals stay in too_big; read per call: a test switches it)
+  static const bool env_off = [] { const char* off = getenv("GK_HOST_EVAL"); return off && atoi(off) == 0; }();   // (GK_HOST_EVAL=0, read once: the device's answer alone; per call: GK_EVAL_DEVICE_ONLY)
   static const bool dbg = getenv("GK_DEBUG_HOST") != nullptr;
   auto why = [&](uint32_t r, const char* what) { if (dbg) fprintf(stderr, "[gkgpu host] review %u stays refused: %s\n", r, what); };
-  t->host_viol.clear(); t->host_err.clear();
+  // the pairs this pass adds belong to THIS evaluation: collected locally, published under the table's lock with the constraint-id
+  // list they index (gk_table_totals / gk_table_topk drop them when their own list differs)
+  std::vector<std::pair<uint32_t, uint32_t>> add_viol, add_err;
+  struct Publish {
+    gk_table* t; EvalHolder* h; std::vector<std::pair<uint32_t, uint32_t>>*v, *er;
+    ~Publish() { std::lock_guard<std::mutex> hl(t->host_mu); t->host_viol.swap(*v); t->host_err.swap(*er); t->host_ids = h->ids; }
+  } publish{t, h, &add_viol, &add_err};
+  if (env_off || tl_host_completion_depth > 0) return;
+  struct Depth { Depth() { tl_host_completion_depth++; } ~Depth() { tl_host_completion_depth--; } } depth_guard;
   const uint32_t nt = o.n_tiles, nc = o.n_constraints;
-  bool any = false;
-  for (uint32_t w = 0; w < nt && w < o.too_big.size(); w++) any = any || o.too_big[w] != 0;
-  if (!any || nc == 0 || h->ids.size() != nc) return;
-  for (uint32_t w = 0; w < nt && w < o.too_big.size(); w++) {
+  if (nc == 0 || h->ids.size() != nc) return;
+  // ---- the candidates: refused reviews whose text is at hand
+  struct Cand { uint32_t r; gk_review_in in; bool prem; std::string stext; int mrow = -1; };
+  std::vector<Cand> cands;
+  for (uint32_t w = 0; w < nt && w < o.too_big.size(); w++)
     for (uint64_t m = o.too_big[w]; m; m &= m - 1) {
-      const uint32_t b = (uint32_t)__builtin_ctzll(m), r = w * GK_TILE + b;
+      const uint32_t r = w * GK_TILE + (uint32_t)__builtin_ctzll(m);
       if (r >= t->n_reviews) continue;
-      try {
-        // the review's raw text
-        gk_review_in in{};
-        if (r < t->texts.size()) in = t->texts[r];
-        else { auto it = t->big_texts.find(r); if (it == t->big_texts.end()) { why(r, "no text kept"); continue; } in = it->second.in(); }
-        // 1. match layer: the stripped review on the device
-        Value body = parse_json(in.json, in.json_len);
-        if (!body.is_object()) { why(r, "not an object"); continue; }
-        Value stripped;
-        if (in.kind == GK_REVIEW_OBJECT) stripped = strip_object(body);
-        else {
-          ValuePairs kv = body.pairs();
-          for (auto& pr : kv) if (pr.first.is_string() && (pr.first.str() == "object" || pr.first.str() == "oldObject")) pr.second = strip_object(pr.second);
-          stripped = Value::object(std::move(kv));
-        }
-        const std::string stext = to_json(stripped);
-        gk_review_in sin = in;
-        sin.json = stext.data(); sin.json_len = stext.size();
-        gk_table* mt = nullptr;
-        int32_t st = GK_OK;
-        if (gk_table_create(e, &sin, 1, 0, &st, &mt) != GK_OK || !mt) { why(r, "stripped table"); continue; }
-        std::unique_ptr<gk_table, void (*)(gk_table*)> mt_guard(mt, gk_table_free);
-        if (st != GK_OK) { why(r, "stripped review rejected"); continue; }
-        gk_eval_out* mo = nullptr;
-        if (gk_table_eval(e, mt, GK_EVAL_WANT_MATCH, &mo) != GK_OK || !mo) { why(r, gk_last_error()); continue; }
-        std::unique_ptr<gk_eval_out, void (*)(gk_eval_out*)> mo_guard(mo, gk_eval_free);
-        if (mo->n_constraints != nc || (mo->too_big[0] & 1ull) || !mo->match) { why(r, "stripped review refused as well"); continue; }
-        bool same = true;
-        for (uint32_t row = 0; row < nc; row++) same = same && mo->constraint_ids[row] == h->ids[row];
-        if (!same) { why(r, "policy changed"); continue; }   // (the policy set changed between the two evaluations)
-        // 2. violations: the template's violation set on the whole document, for the constraints that match
-        ReviewDoc tmp;
-        const ReviewDoc* doc = doc_for(e, t, r, &tmp);
-        if (!doc) { why(r, "no document"); continue; }
-        std::vector<uint8_t> v(nc, 0), er(nc, 0), ma(nc, 0);
-        {
-          std::shared_lock<std::shared_mutex> l(e->mu);
-          for (uint32_t row = 0; row < nc; row++) {
-            er[row] = (uint8_t)(mo->err[row] & 1ull);
-            ma[row] = (uint8_t)(mo->match[row] & 1ull);
-            if (!ma[row]) continue;
-            const ConstraintRec& c = e->constraints[h->ids[row]];
-            auto it = e->templates.find(lower_str(c.kind));
-            if (it == e->templates.end()) throw std::runtime_error("no template");
-            v[row] = it->second->render(doc->request, c.params, e->inventory).empty() ? 0 : 1;
-          }
-        }
-        // 3. the answer replaces the refusal
-        const uint64_t bit = 1ull << b;
-        for (uint32_t row = 0; row < nc; row++) {
-          uint64_t& vw = o.viol[(size_t)row * nt + w];
-          uint64_t& ew = o.err[(size_t)row * nt + w];
-          if ((vw & bit) && row < o.counts.size() && o.counts[row]) o.counts[row]--;   // (never set for a refused review; kept consistent anyway)
-          vw &= ~bit; ew &= ~bit;
-          if (v[row]) { vw |= bit; if (row < o.counts.size()) o.counts[row]++; t->host_viol.emplace_back(row, r); if (want_list) { o.list.push_back(row); o.list.push_back(r); o.list_total++; } }
-          if (er[row]) { ew |= bit; t->host_err.emplace_back(row, r); }
-          if (want_match && !o.match.empty()) { uint64_t& mw = o.match[(size_t)row * nt + w]; mw = ma[row] ? (mw | bit) : (mw & ~bit); }
-        }
-        o.too_big[w] &= ~bit;
-        h->host_evaluated.push_back(r);
-      } catch (const std::exception& ex) {
-        why(r, ex.what());
-        // (an evaluation error, a document that does not parse: the review stays refused -- fail closed)
+      if (cands.size() >= GK_HOST_COMPLETIONS_MAX) { why(r, "more refused reviews than one evaluation completes"); continue; }
+      Cand c;
+      c.r = r;
+      if (r < t->texts.size()) c.in = t->texts[r];
+      else { auto it = t->big_texts.find(r); if (it == t->big_texts.end()) { why(r, "no text kept"); continue; } c.in = it->second.in(); }
+      c.prem = r < t->host.rflags.size() && (t->host.rflags[r] & RF_PREMATCHED) != 0;
+      cands.push_back(std::move(c));
+    }
+  if (cands.empty()) return;
+  // ---- 1. match layer: the stripped reviews on the device, ONE table and ONE launch for all of them -- unless the caller ran
+  //         Matcher.Match itself (RF_PREMATCHED: every constraint counts as matching, nothing is autorejected)
+  std::vector<gk_review_in> sins;
+  for (Cand& c : cands) {
+    if (c.prem) continue;
+    try {
+      Value body = parse_json(c.in.json, c.in.json_len);
+      if (!body.is_object()) { why(c.r, "not an object"); continue; }
+      Value stripped;
+      if (c.in.kind == GK_REVIEW_OBJECT) stripped = strip_object(body);
+      else {
+        ValuePairs kv = body.pairs();
+        for (auto& pr : kv) if (pr.first.is_string() && (pr.first.str() == "object" || pr.first.str() == "oldObject")) pr.second = strip_object(pr.second);
+        stripped = Value::object(std::move(kv));
       }
+      c.stext = to_json(stripped);
+      c.mrow = (int)sins.size();
+      sins.push_back(c.in);
+    } catch (const std::exception& ex) { why(c.r, ex.what()); }
+  }
+  for (Cand& c : cands) if (c.mrow >= 0) { sins[c.mrow].json = c.stext.data(); sins[c.mrow].json_len = c.stext.size(); }   // (after the loop: the strings no longer move)
+  gk_table* mt = nullptr;
+  gk_eval_out* mo = nullptr;
+  std::vector<int32_t> mst(sins.size(), GK_OK);
+  std::unique_ptr<gk_table, void (*)(gk_table*)> mt_guard(nullptr, gk_table_free);
+  std::unique_ptr<gk_eval_out, void (*)(gk_eval_out*)> mo_guard(nullptr, gk_eval_free);
+  bool match_ok = sins.empty();
+  if (!sins.empty()) {
+    if (gk_table_create(e, sins.data(), sins.size(), 0, mst.data(), &mt) == GK_OK && mt) {
+      mt_guard.reset(mt);
+      if (gk_table_eval(e, mt, GK_EVAL_WANT_MATCH | GK_EVAL_DEVICE_ONLY, &mo) == GK_OK && mo) {
+        mo_guard.reset(mo);
+        match_ok = mo->n_constraints == nc && mo->match != nullptr;
+        for (uint32_t row = 0; row < nc && match_ok; row++) match_ok = mo->constraint_ids[row] == h->ids[row];   // (else: the policy set changed between the two evaluations)
+      }
+    }
+    if (!match_ok && dbg) fprintf(stderr, "[gkgpu host] the stripped reviews' match table failed: %s\n", gk_last_error());
+  }
+  // ---- 2. violations: the template's violation set on the whole document, for the constraints that match; 3. the answer replaces the refusal
+  for (Cand& c : cands) {
+    const uint32_t r = c.r, w = r / GK_TILE;
+    const uint64_t bit = 1ull << (r % GK_TILE);
+    try {
+      std::vector<uint8_t> v(nc, 0), er(nc, 0), ma(nc, c.prem ? 1 : 0);
+      if (!c.prem) {
+        if (c.mrow < 0 || !match_ok) { why(r, "no match answer"); continue; }
+        if (mst[c.mrow] != GK_OK) { why(r, "stripped review rejected"); continue; }
+        const uint32_t mw = (uint32_t)c.mrow / GK_TILE;
+        const uint64_t mbit = 1ull << ((uint32_t)c.mrow % GK_TILE);
+        if (mo->too_big[mw] & mbit) { why(r, "stripped review refused as well"); continue; }
+        for (uint32_t row = 0; row < nc; row++) {
+          er[row] = (mo->err[(size_t)row * mo->n_tiles + mw] & mbit) ? 1 : 0;
+          ma[row] = (mo->match[(size_t)row * mo->n_tiles + mw] & mbit) ? 1 : 0;
+        }
+      }
+      ReviewDoc tmp;
+      const ReviewDoc* doc = doc_for(e, t, r, &tmp);
+      if (!doc) { why(r, "no document"); continue; }
+      {
+        std::shared_lock<std::shared_mutex> l(e->mu);
+        for (uint32_t row = 0; row < nc; row++) {
+          if (!ma[row]) continue;
+          const ConstraintRec& cr = e->constraints[h->ids[row]];
+          auto it = e->templates.find(lower_str(cr.kind));
+          if (it == e->templates.end()) throw std::runtime_error("no template");
+          v[row] = it->second->render(doc->request, cr.params, e->inventory).empty() ? 0 : 1;
+        }
+      }
+      for (uint32_t row = 0; row < nc; row++) {
+        uint64_t& vw = o.viol[(size_t)row * nt + w];
+        uint64_t& ew = o.err[(size_t)row * nt + w];
+        if ((vw & bit) && row < o.counts.size() && o.counts[row]) o.counts[row]--;   // (never set for a refused review; kept consistent anyway)
+        vw &= ~bit; ew &= ~bit;
+        if (v[row]) { vw |= bit; if (row < o.counts.size()) o.counts[row]++; add_viol.emplace_back(row, r); if (want_list) { o.list.push_back(row); o.list.push_back(r); o.list_total++; } }
+        if (er[row]) { ew |= bit; add_err.emplace_back(row, r); }
+        if (want_match && !o.match.empty()) { uint64_t& mw = o.match[(size_t)row * nt + w]; mw = ma[row] ? (mw | bit) : (mw & ~bit); }
+      }
+      o.too_big[w] &= ~bit;
+      h->host_evaluated.push_back(r);
+    } catch (const std::exception& ex) {
+      why(r, ex.what());
+      // (an evaluation error, a document that does not parse: the review stays refused -- fail closed)
     }
   }
 }
@@ -2013,9 +2077,11 @@ int gk_table_totals(gk_engine* e, gk_table* t, gk_totals_out** out) {
     std::vector<uint8_t> counted;
     std::vector<uint64_t> counted_sum;
     // (pairs the host evaluation of the last gk_table_eval added are no part of the device bitmaps: they join here and are rendered)
-    for (auto& hp : t->host_viol) if (hp.first < nc && hp.second / GK_TILE < nt) viol[(size_t)hp.first * nt + hp.second / GK_TILE] |= 1ull << (hp.second % GK_TILE);
+    std::vector<std::pair<uint32_t, uint32_t>> hv;
+    { std::lock_guard<std::mutex> hl(t->host_mu); if (t->host_ids == h->ids) hv = t->host_viol; }   // (another policy set's pairs: dropped)
+    for (auto& hp : hv) if (hp.first < nc && hp.second / GK_TILE < nt) viol[(size_t)hp.first * nt + hp.second / GK_TILE] |= 1ull << (hp.second % GK_TILE);
     std::vector<uint64_t> need = render_needed(e, t, h->ids, nt, viol, &counted, &counted_sum);
-    for (auto& hp : t->host_viol) if (hp.first < nc && hp.second / GK_TILE < nt) need[(size_t)hp.first * nt + hp.second / GK_TILE] |= 1ull << (hp.second % GK_TILE);
+    for (auto& hp : hv) if (hp.first < nc && hp.second / GK_TILE < nt) need[(size_t)hp.first * nt + hp.second / GK_TILE] |= 1ull << (hp.second % GK_TILE);
     for (uint32_t row = 0; row < nc; row++) {
       for (uint32_t w = 0; w < nt; w++) {
         const uint64_t v = viol[(size_t)row * nt + w];
@@ -2133,7 +2199,9 @@ namespace {
 
 // results of ONE review of an evaluated table as the JSON gk_query returns; renders from `doc` (parsed lazily: most
 // admission reviews violate nothing and never become a Value tree)
-std::string query_results_json(gk_engine* e, gk_table* t, const gk_eval_out& ev, uint32_t r, const gk_review_in& in, bool* too_big) {
+// `wanted` (may be NULL): sorted constraint ids the caller asked about (Driver.Query's `constraints`); others are not rendered
+std::string query_results_json(gk_engine* e, gk_table* t, const gk_eval_out& ev, uint32_t r, const gk_review_in& in, bool* too_big,
+                               const std::vector<uint32_t>* wanted = nullptr) {
   const uint32_t nt = ev.n_tiles, w = r / GK_TILE;
   const uint64_t bit = 1ull << (r % GK_TILE);
   *too_big = (ev.too_big[w] & bit) != 0;
@@ -2154,6 +2222,7 @@ std::string query_results_json(gk_engine* e, gk_table* t, const gk_eval_out& ev,
     const bool is_err = (ev.err[(size_t)row * nt + w] & bit) != 0, is_viol = (ev.viol[(size_t)row * nt + w] & bit) != 0;
     if (!is_err && !is_viol) continue;
     const uint32_t cid = ev.constraint_ids[row];
+    if (wanted && !std::binary_search(wanted->begin(), wanted->end(), cid)) continue;
     const ConstraintRec& c = e->constraints[cid];
     need_doc();
     if (is_err) {
@@ -2202,7 +2271,9 @@ void batcher_loop(gk_engine* e) {
     }
     const auto t_start = std::chrono::steady_clock::now();
     std::vector<gk_review_in> ins;
-    for (auto* r : batch) ins.push_back(*r->in);
+    std::vector<uint8_t> prem;
+    bool any_prem = false;
+    for (auto* r : batch) { ins.push_back(*r->in); prem.push_back(r->pre_matched ? 1 : 0); any_prem = any_prem || r->pre_matched; }
     std::vector<int32_t> st(batch.size(), GK_OK);
     auto br = std::make_shared<gk_engine::BatchResult>();
     // an admission batch serves the policy set loaded now and is evaluated once: a PRUNED table (rows of the key paths that set reads,
@@ -2213,7 +2284,7 @@ void batcher_loop(gk_engine* e) {
     std::shared_lock<std::shared_mutex> policy_epoch(e->policy_rw);   // the policy set does not change between the flatten and the launch
     for (int attempt = 0; attempt < 3; attempt++) {   // (what can still make the table stale: a referential constraint recompiled against a changed inventory)
       if (br->table) { gk_table_free(br->table); br->table = nullptr; }
-      rc = gk_table_create(e, ins.data(), ins.size(), attempt < 2 ? GK_TABLE_PRUNED : 0u, st.data(), &br->table);
+      rc = table_create_impl(e, ins.data(), ins.size(), attempt < 2 ? GK_TABLE_PRUNED : 0u, st.data(), any_prem ? prem.data() : nullptr, &br->table);
       err = rc == GK_OK ? "" : gk_last_error();
       if (rc != GK_OK) break;
       rc = gk_table_eval(e, br->table, 0, &br->ev);
@@ -2590,7 +2661,7 @@ void gk_sweep_free(gk_sweep_out* o) { if (o) delete reinterpret_cast<SweepHolder
 namespace {
 // the cached answer for one resident object, as gk_query's JSON; false: not resident / not swept / its slot is stale
 // audit: the answer pkg/audit would get -- an object the Config excludes from the audit process is never reviewed ("[]")
-bool resident_answer(gk_engine* e, uint32_t id, std::string* json, int* status, std::string* err, bool audit = false) {
+bool resident_answer(gk_engine* e, uint32_t id, std::string* json, int* status, std::string* err, bool audit = false, const std::vector<uint32_t>* wanted = nullptr) {
   gk_engine::Resident& R = e->resident;
   const gk_engine::ResObj& o = R.objs[id];
   if (!R.swept || !o.alive || o.chunk == UINT32_MAX) return false;
@@ -2603,24 +2674,66 @@ bool resident_answer(gk_engine* e, uint32_t id, std::string* json, int* status, 
   { std::shared_lock<std::shared_mutex> l(e->plan_rw); if (e->plan_dirty || c.plan_gen != e->plan_gen) return false; }
   const gk_review_in in = resident_review_in(R, o);
   bool too_big = false;
-  *json = query_results_json(e, c.table, *c.ev, o.slot, in, &too_big);
+  *json = query_results_json(e, c.table, *c.ev, o.slot, in, &too_big, wanted);
   *status = GK_OK;
   if (too_big) { *status = GK_ERR_LIMIT; *err = "review is beyond the engine's limits (more than 255 elements in an array that constraint predicates iterate, or an object where they iterate array elements)"; }
   return true;
 }
 }  // namespace
 
-int gk_resident_review(gk_engine* e, const char* const* path, size_t npath, char** results_json) {
+// Driver.Query's `constraints` as a sorted id list; GK_ERR_NOT_FOUND for an id that is not loaded
+static int wanted_ids(gk_engine* e, const uint32_t* ids, size_t n, std::vector<uint32_t>* out) {
+  out->assign(ids, ids + n);
+  std::sort(out->begin(), out->end());
+  out->erase(std::unique(out->begin(), out->end()), out->end());
+  std::shared_lock<std::shared_mutex> l(e->mu);
+  for (uint32_t id : *out)
+    if (id >= e->constraints.size() || !e->constraints[id].alive) return fail(GK_ERR_NOT_FOUND, "unknown constraint template validator: constraint id " + std::to_string(id) + " is not loaded");
+  return GK_OK;
+}
+static int put_string(const std::string& js, char** out) {
+  char* buf = (char*)malloc(js.size() + 1);
+  if (!buf) return fail(GK_ERR_INTERNAL, "out of memory");
+  memcpy(buf, js.c_str(), js.size() + 1);
+  *out = buf;
+  return GK_OK;
+}
+
+int gk_resident_review(gk_engine* e, const char* const* path, size_t npath, char** results_json) { return gk_resident_review_ex(e, path, npath, nullptr, 0, 0, results_json); }
+
+int gk_resident_review_ex(gk_engine* e, const char* const* path, size_t npath, const uint32_t* constraint_ids, size_t n_constraints, uint32_t flags, char** results_json) {
   if (!e || !path || !npath || !results_json) return fail(GK_ERR_INVALID, "NULL argument");
   try {
+    std::vector<uint32_t> wanted;
+    if (constraint_ids) { int rc = wanted_ids(e, constraint_ids, n_constraints, &wanted); if (rc != GK_OK) return rc; }
     gk_engine::Resident& R = e->resident;
-    std::lock_guard<std::mutex> rl(R.mu);
     std::string key;
     for (size_t i = 0; i < npath; i++) { key += path[i]; key.push_back('/'); }
+    if (flags & GK_QUERY_PRE_MATCHED) {
+      // the sweep kept match AND violation: the caller's own match is answered by evaluating the resident text again, pre-matched
+      // (copies: the resident set may change while the batcher works)
+      std::string obj, ns;
+      bool has_ns = false;
+      {
+        std::lock_guard<std::mutex> rl(R.mu);
+        auto it = R.by_key.find(key);
+        if (it == R.by_key.end() || !R.objs[it->second].alive) return fail(GK_ERR_NOT_FOUND, "object is not in the resident set");
+        const gk_engine::ResObj& o = R.objs[it->second];
+        obj = o.json;
+        if (const gk_engine::ResObj* n = resident_namespace_of(R, o)) { has_ns = true; ns = n->json; }
+      }
+      gk_review_in in;
+      memset(&in, 0, sizeof in);
+      in.kind = GK_REVIEW_OBJECT; in.source = GK_SRC_EMPTY;
+      in.json = obj.data(); in.json_len = obj.size();
+      if (has_ns) { in.namespace_json = ns.data(); in.namespace_len = ns.size(); in.ns_object_json = ns.data(); in.ns_object_len = ns.size(); }
+      return gk_query_ex2(e, &in, constraint_ids, n_constraints, GK_QUERY_PRE_MATCHED, results_json, nullptr, nullptr);
+    }
+    std::lock_guard<std::mutex> rl(R.mu);
     auto it = R.by_key.find(key);
     std::string js, err;
     int st = GK_OK;
-    if (it == R.by_key.end() || !resident_answer(e, it->second, &js, &st, &err, true))
+    if (it == R.by_key.end() || !resident_answer(e, it->second, &js, &st, &err, true, constraint_ids ? &wanted : nullptr))
       return fail(GK_ERR_NOT_FOUND, "object is not in the swept resident set (unknown, changed since the last gk_resident_sweep, or policies / the process excluder changed)");
     if (st != GK_OK) return fail(st, err);
     char* buf = (char*)malloc(js.size() + 1);
@@ -2667,7 +2780,7 @@ void gk_batcher_stop(gk_engine* e) {
 int gk_query(gk_engine* e, const gk_review_in* review, char** results_json, gk_query_stats* stats) { return gk_query_ex(e, review, 0, results_json, nullptr, stats); }
 
 // the trace of one answered review (QueryResponse.Trace): where and how it was evaluated, what every constraint yielded
-static std::string query_trace(gk_engine* e, const char* where, const std::string& results, const gk_query_stats* st) {
+static std::string query_trace(gk_engine* e, const char* where, const std::string& results, const gk_query_stats* st, const std::vector<uint32_t>* wanted = nullptr) {
   std::ostringstream os;
   os << "gkgpu trace: evaluated " << where;
   if (st) os << "; batch of " << st->batch_size << " review(s), queued " << (long long)(st->queue_us * 1e3) << " ns, device " << (long long)(st->device_us * 1e3) << " ns";
@@ -2682,10 +2795,10 @@ static std::string query_trace(gk_engine* e, const char* where, const std::strin
   } catch (const std::exception&) {}
   std::shared_lock<std::shared_mutex> l(e->mu);
   for (const ConstraintRec& c : e->constraints) {
-    if (!c.alive) continue;
+    if (!c.alive || (wanted && !std::binary_search(wanted->begin(), wanted->end(), c.id))) continue;
     os << "  constraint " << c.kind << "/" << c.name << " (id " << c.id << "): ";
     auto it = by.find(c.id);
-    if (it == by.end()) { os << "no result (does not match, or matches and is satisfied)\n"; continue; }
+    if (it == by.end()) { os << (wanted ? "no result\n" : "no result (does not match, or matches and is satisfied)\n"); continue; }
     os << it->second.size() << " result(s)\n";
     for (auto& m : it->second) os << "    " << m << "\n";
   }
@@ -2693,19 +2806,36 @@ static std::string query_trace(gk_engine* e, const char* where, const std::strin
 }
 
 int gk_query_ex(gk_engine* e, const gk_review_in* review, uint32_t qflags, char** results_json, char** trace_out, gk_query_stats* stats) {
+  return gk_query_ex2(e, review, nullptr, 0, qflags, results_json, trace_out, stats);
+}
+
+int gk_query_ex2(gk_engine* e, const gk_review_in* review, const uint32_t* constraint_ids, size_t n_constraints, uint32_t qflags,
+                 char** results_json, char** trace_out, gk_query_stats* stats) {
   if (!e || !review || !results_json) return fail(GK_ERR_INVALID, "NULL argument");
   if (trace_out) *trace_out = nullptr;
+  const bool pre_matched = (qflags & GK_QUERY_PRE_MATCHED) != 0;
+  std::vector<uint32_t> wanted_v;
+  const std::vector<uint32_t>* wanted = nullptr;
+  if (constraint_ids) {
+    int rc = wanted_ids(e, constraint_ids, n_constraints, &wanted_v);
+    if (rc != GK_OK) return rc;
+    wanted = &wanted_v;
+    if (wanted_v.empty()) {   // Driver.Query with no constraints: nothing to evaluate
+      if (stats) memset(stats, 0, sizeof *stats);
+      return put_string("[]", results_json);
+    }
+  }
   const bool want_trace = trace_out && ((qflags & GK_QUERY_TRACE) || (e->opts.flags & GK_OPT_TRACE));
   auto put_trace = [&](const char* where, const std::string& js, const gk_query_stats* st) {
     if (!want_trace) return;
-    const std::string t = query_trace(e, where, js, st);
+    const std::string t = query_trace(e, where, js, st, wanted);
     char* b = (char*)malloc(t.size() + 1);
     memcpy(b, t.c_str(), t.size() + 1);
     *trace_out = b;
   };
   // a review that is byte for byte a swept resident object (same object text, the Namespace the sweep used, no Source --
   // what pkg/audit's auditFromCache sends, manager.go:611-614) is answered from the sweep's bitmap column: no flatten, no launch
-  if (review->kind == GK_REVIEW_OBJECT && review->source == GK_SRC_EMPTY && review->json && !(review->operation && *review->operation)) {
+  if (!pre_matched && review->kind == GK_REVIEW_OBJECT && review->source == GK_SRC_EMPTY && review->json && !(review->operation && *review->operation)) {
     gk_engine::Resident& R = e->resident;
     std::unique_lock<std::mutex> rl(R.mu, std::try_to_lock);
     if (rl.owns_lock() && R.swept) {
@@ -2720,7 +2850,7 @@ int gk_query_ex(gk_engine* e, const gk_review_in* review, uint32_t qflags, char*
           std::string js, err;
           int st = GK_OK;
           try {
-            if (resident_answer(e, it->second, &js, &st, &err)) {
+            if (resident_answer(e, it->second, &js, &st, &err, false, wanted)) {
               if (stats) { stats->batch_size = 0; stats->queue_us = 0; stats->device_us = 0; stats->total_us = 0; }
               if (st != GK_OK) return fail(st, err);
               char* buf = (char*)malloc(js.size() + 1);
@@ -2736,6 +2866,7 @@ int gk_query_ex(gk_engine* e, const gk_review_in* review, uint32_t qflags, char*
   }
   gk_engine::Request req;
   req.in = review;
+  req.pre_matched = pre_matched;
   req.arrived = std::chrono::steady_clock::now();
   gk_engine::Batcher& B = e->batcher;
   for (;;) {
@@ -2760,7 +2891,7 @@ int gk_query_ex(gk_engine* e, const gk_review_in* review, uint32_t qflags, char*
     try {
       bool too_big = false;
       for (uint32_t k = 0; k < req.batch->ev->n_host_evaluated; k++) on_host = on_host || req.batch->ev->host_evaluated[k] == req.index;
-      results = query_results_json(e, req.batch->table, *req.batch->ev, req.index, *review, &too_big);
+      results = query_results_json(e, req.batch->table, *req.batch->ev, req.index, *review, &too_big, wanted);
       if (too_big) { req.status = GK_ERR_LIMIT; req.error = "review is beyond the engine's limits (more than 255 elements in an array that constraint predicates iterate, or an object where they iterate array elements)"; }
     } catch (const RegoError& ex) { req.status = GK_ERR_REGO; req.error = ex.what();
     } catch (const std::exception& ex) { req.status = GK_ERR_INTERNAL; req.error = ex.what(); }
@@ -2778,8 +2909,10 @@ int gk_query_ex(gk_engine* e, const gk_review_in* review, uint32_t qflags, char*
   *results_json = buf;
   gk_query_stats mine{};
   mine.batch_size = req.batch_size; mine.queue_us = req.queue_us; mine.device_us = req.device_us;
-  put_trace(on_host ? "by the host evaluator (the review is beyond the device's limits: match layer from the stripped review on the device, violation sets by the concrete evaluator)"
-                    : "on the device (match + violation bitmaps of the batch's one launch; messages rendered by the host evaluator for the flagged pairs)", results, &mine);
+  put_trace(on_host ? (pre_matched ? "by the host evaluator (the review is beyond the device's limits; pre-matched by the caller: violation sets by the concrete evaluator)"
+                                   : "by the host evaluator (the review is beyond the device's limits: match layer from the stripped review on the device, violation sets by the concrete evaluator)")
+                    : (pre_matched ? "on the device (pre-matched by the caller: violation bitmaps of the batch's one launch; messages rendered by the host evaluator for the flagged pairs)"
+                                   : "on the device (match + violation bitmaps of the batch's one launch; messages rendered by the host evaluator for the flagged pairs)"), results, &mine);
   return GK_OK;
 }
 

@@ -114,6 +114,9 @@ enum ReviewFlag : uint32_t {
   RF_HOST_CAND = 1u << 21,       // a compared value of the review has no value id (a non-empty container, or more distinct values than ids):
                                  //   if a predicate wants it the review ends up in too_big -- the engine keeps such a review's text and
                                  //   evaluates it on the host then (engine.cpp complete_on_host); no kernel reads the bit
+  RF_PREMATCHED = 1u << 22,      // the CALLER ran Matcher.Match (Client.Review, pkg/target/matcher.go:21-42) and asks for the violation sets of
+                                 //   the constraints it hands over (Driver.Query's contract, pkg/drivers/k8scel/driver.go:162-251): every match
+                                 //   formula counts as true for this review and no autoreject bit is written (kernel_body.inc output stage)
   RF_SKIP = 1u << 19,            // the review is not evaluated: HandleReview rejected it, or the process excluder skips its
                                  //   namespace (engine.cpp) -- no violation, match or autoreject bit for any constraint         //   gkReviewToObject fails with ErrRequestObject (pkg/target/matcher.go:73-93)
 };

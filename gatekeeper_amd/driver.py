@@ -344,11 +344,12 @@ class Table:
     def __init__(self, engine, handle, statuses, n):
         self.engine, self.handle, self.statuses, self.n = engine, handle, statuses, n
 
-    def eval(self, want_match=False, download=True, want_list=False, collect_only=False):
-        """Launch + collect (or, with collect_only, just collect the pending launch()es)."""
+    def eval(self, want_match=False, download=True, want_list=False, collect_only=False, host_eval=True):
+        """Launch + collect (or, with collect_only, just collect the pending launch()es).  host_eval=False: the device's answer alone
+        (GK_EVAL_DEVICE_ONLY: reviews beyond the device's limits stay in too_big)."""
         lib = self.engine.lib
         flags = (L.GK_EVAL_WANT_MATCH if want_match else 0) | (0 if download else L.GK_EVAL_NO_DOWNLOAD) | (
-            L.GK_EVAL_WANT_LIST if want_list else 0) | (L.GK_EVAL_COLLECT if collect_only else 0)
+            L.GK_EVAL_WANT_LIST if want_list else 0) | (L.GK_EVAL_COLLECT if collect_only else 0) | (0 if host_eval else L.GK_EVAL_DEVICE_ONLY)
         out = C.POINTER(L.gk_eval_out)()
         self.engine._check(lib.gk_table_eval(self.engine.handle, self.handle, flags, C.byref(out)))
         return EvalResult(lib, out)
@@ -512,8 +513,9 @@ class Engine:
             a.ns_object_json, a.ns_object_len = r.ns_object, len(r.ns_object)
         a.operation = r.operation
 
-    def create_table(self, reviews, keep_docs=True, resident=False, process=None):
-        """process: 'audit' / 'webhook' applies the process excluder -- excluded reviews get status GK_REVIEW_EXCLUDED"""
+    def create_table(self, reviews, keep_docs=True, resident=False, process=None, pre_matched=False):
+        """process: 'audit' / 'webhook' applies the process excluder -- excluded reviews get status GK_REVIEW_EXCLUDED;
+        pre_matched: GK_TABLE_PRE_MATCHED (the caller ran Matcher.Match: violation sets alone, no autoreject)"""
         n = len(reviews)
         arr = (L.gk_review_in * max(1, n))()
         keep = []
@@ -529,7 +531,8 @@ class Engine:
             a.operation = r.operation
         st = (C.c_int32 * max(1, n))()
         h = C.c_void_p()
-        flags = (L.GK_TABLE_KEEP_DOCS if keep_docs else 0) | (L.GK_TABLE_RESIDENT if resident else 0) | self._process_flag(process)
+        flags = (L.GK_TABLE_KEEP_DOCS if keep_docs else 0) | (L.GK_TABLE_RESIDENT if resident else 0) | self._process_flag(process) | (
+            L.GK_TABLE_PRE_MATCHED if pre_matched else 0)
         self._check(self.lib.gk_table_create(self.handle, arr, n, flags, st, C.byref(h)))
         return Table(self, h, list(st)[:n], n)
 
@@ -683,22 +686,38 @@ class Driver:
         return self._ids[key]
 
     def Query(self, target, constraints, review, namespace=None, stats_enabled=False, tracing=False):
-        """One review against the (already matched) constraints -> QueryResponse, through the engine's micro-batcher
-        (gk_query): safe to call from many threads at once -- the webhook's concurrency, pkg/webhook/policy.go:142-146 --
-        and concurrent calls share one flattened table and one launch.  The device evaluates match AND violation for
-        every loaded constraint; results of constraints not asked about are dropped here."""
+        """drivers.Driver.Query as the reference defines it (pkg/drivers/k8scel/driver.go:162-251; frameworks drivers/rego): the
+        caller -- Client.Review -- has ALREADY run Matcher.Match (pkg/target/matcher.go:21-42); `constraints` are evaluated and never
+        matched again, no autoreject comes out of here.  What goes down is what a Go driver can reach: the AdmissionRequest of the
+        review (ARGetter) and the reviews.Namespace option -- NOT gkReview.namespace / .source (unexported, pkg/target/review.go:16-21).
+        gk_query_ex2(constraint ids, GK_QUERY_PRE_MATCHED), through the engine's micro-batcher: safe to call from many threads at
+        once -- the webhook's concurrency, pkg/webhook/policy.go:142-146 -- and concurrent calls share one table and one launch."""
+        return self._query(target, constraints, review, namespace, stats_enabled, tracing, True)
+
+    def QueryMatching(self, target, constraints, review, namespace=None, stats_enabled=False, tracing=False):
+        """The engine's own admission entry for callers that own namespace + source (this Python mirror, batch / audit code): Match AND
+        violation are evaluated on the device for the listed constraints, a failed Matcher.Match comes back as an autoreject row
+        (Result.msg "unable to match constraints: ...") -- Client.Review's three steps in one launch."""
+        return self._query(target, constraints, review, namespace, stats_enabled, tracing, False)
+
+    def _query(self, target, constraints, review, namespace, stats_enabled, tracing, pre_matched):
         rin = to_review_in(review, namespace)
         if rin is None:
             raise EngineError(L.GK_ERR_INVALID, "cannot convert review to ARGetter")
         arr = (L.gk_review_in * 1)()
         a = arr[0]
-        a.kind, a.source, a.json, a.json_len, a.operation = rin.kind, rin.source, rin.json, len(rin.json), rin.operation
-        if rin.namespace is not None:
-            a.namespace_json, a.namespace_len = rin.namespace, len(rin.namespace)
+        a.kind, a.json, a.json_len, a.operation = rin.kind, rin.json, len(rin.json), rin.operation
+        if not pre_matched:   # (a pre-matched Query hands over neither: a Go driver cannot read them)
+            a.source = rin.source
+            if rin.namespace is not None:
+                a.namespace_json, a.namespace_len = rin.namespace, len(rin.namespace)
         if rin.ns_object is not None:
             a.ns_object_json, a.ns_object_len = rin.ns_object, len(rin.ns_object)
+        wanted = {self.constraint_id(c): c for c in constraints}
+        ids = (C.c_uint32 * max(1, len(wanted)))(*sorted(wanted))
         out, trace_p, st = C.c_void_p(), C.c_void_p(), L.gk_query_stats()
-        rc = self.engine.lib.gk_query_ex(self.engine.handle, arr, L.GK_QUERY_TRACE if tracing else 0, C.byref(out), C.byref(trace_p), C.byref(st))
+        rc = self.engine.lib.gk_query_ex2(self.engine.handle, arr, ids, len(wanted), (L.GK_QUERY_TRACE if tracing else 0) | (L.GK_QUERY_PRE_MATCHED if pre_matched else 0),
+                                          C.byref(out), C.byref(trace_p), C.byref(st))
         if rc == L.GK_ERR_LIMIT:
             raise LimitError()
         if rc == L.GK_ERR_REVIEW:
@@ -706,7 +725,6 @@ class Driver:
         self.engine._check(rc)
         rows = json.loads(C.string_at(out).decode())
         self.engine.lib.gk_free(out)
-        wanted = {self.constraint_id(c): c for c in constraints}
         results = [Result(v["msg"], wanted[v["constraint"]], v.get("details", {})) for v in rows if v["constraint"] in wanted]
         self.last_query_stats = {"batch_size": st.batch_size, "queue_us": st.queue_us, "device_us": st.device_us, "total_us": st.total_us}
         trace = None
@@ -744,6 +762,23 @@ class Driver:
                "results": ({int(o.constraint_ids[i]): int(o.results[i]) for i in range(o.n_constraints)} if o.results else None)}
         self.engine.lib.gk_sweep_free(out)
         return res
+
+    def ResidentReviewPreMatched(self, path, constraints):
+        """gk_resident_review_ex(GK_QUERY_PRE_MATCHED): the violation sets of `constraints` (the caller matched them) for one resident
+        object -- its resident text evaluated again through the admission batcher.  None when the object is not resident."""
+        arr = (C.c_char_p * len(path))(*[p.encode() for p in path])
+        wanted = sorted(self.constraint_id(c) for c in constraints)
+        ids = (C.c_uint32 * max(1, len(wanted)))(*wanted)
+        out = C.c_void_p()
+        rc = self.engine.lib.gk_resident_review_ex(self.engine.handle, arr, len(path), ids, len(wanted), L.GK_QUERY_PRE_MATCHED, C.byref(out))
+        if rc == L.GK_ERR_NOT_FOUND:
+            return None
+        if rc == L.GK_ERR_LIMIT:
+            raise LimitError("/".join(path))
+        self.engine._check(rc)
+        rows = json.loads(C.string_at(out).decode())
+        self.engine.lib.gk_free(out)
+        return rows
 
     def ResidentReview(self, path):
         """gk_resident_review: the swept answer of one resident object (rows of gk_query's JSON), or None when the object is

@@ -136,6 +136,11 @@ int gk_table_get_stats(const gk_table* t, gk_table_stats* out);
                                    arrives later and reads another path makes it stale: gk_table_eval / gk_table_sweep_sharded / gk_table_totals
                                    then fail with GK_ERR_INVALID ("create it again"), as after a new dictionary predicate.  What pkg/audit's
                                    per-sweep list and the webhook's per-request decode amount to: the objects are read again anyway */
+#define GK_TABLE_PRE_MATCHED 64u /* the CALLER ran Matcher.Match (pkg/target/matcher.go:21-42) for every review of the table and wants the
+                                   violation sets alone -- Driver.Query's contract (pkg/drivers/k8scel/driver.go:162-251: the constraints handed
+                                   over are evaluated, never matched again): every constraint counts as matching every usable review, no
+                                   autoreject bit is written, namespace_json / source of the reviews are not looked at.  The caller keeps the
+                                   (constraint, review) pairs it matched.  Per call of the admission path: GK_QUERY_PRE_MATCHED */
 #define GK_TABLE_RESIDENT 2u    /* the table is evaluated again and again (audit set): the engine may compile a plan variant
                                    whose LDS layout fits this table's array sizes (first evaluation pays the compile) */
 
@@ -208,6 +213,9 @@ typedef struct {
                                     consecutive launches of that kernel under ONE event pair -- fast_kernel_ms of the collecting call is then the kernel's
                                     back-to-back average, free of the event records a pair per launch puts between the launches); the totals the
                                     collecting call reports are not those of these launches */
+#define GK_EVAL_DEVICE_ONLY 128u /* the device's answer alone: reviews beyond the device's limits stay in too_big instead of being answered by the
+                                    engine's host evaluator (gk_eval_out.host_evaluated stays empty); GK_HOST_EVAL=0 in the environment of the
+                                    process does the same for every call */
 #define GK_EVAL_TIME_EACH 32u    /* with GK_EVAL_ASYNC: an event pair around THIS launch (fast_kernel_ms of the collecting call = the sum of the
                                     isolated kernel durations / launches) instead of one pair around all pending launches, gaps included */
 
@@ -340,6 +348,12 @@ int gk_resident_sweep(gk_engine* e, uint32_t flags, gk_sweep_out** out);
 void gk_sweep_free(gk_sweep_out* o);
 /* results of one swept object, in gk_query's JSON; GK_ERR_NOT_FOUND when the object is unknown or its answer is stale */
 int gk_resident_review(gk_engine* e, const char* const* path, size_t npath, char** results_json);
+/* the same for a caller that matched itself (gk_query_ex2's arguments).  With GK_QUERY_PRE_MATCHED the sweep's bitmaps -- match AND
+ * violation -- cannot answer: the object's resident text is evaluated again through the admission batcher (one flatten + its share of
+ * a launch), pre-matched, with the review auditFromCache builds (the synced Namespace as namespaceObject); GK_ERR_NOT_FOUND when the
+ * object is not resident.  Without the flag: gk_resident_review restricted to the listed constraints. */
+int gk_resident_review_ex(gk_engine* e, const char* const* path, size_t npath, const uint32_t* constraint_ids, size_t n_constraints,
+                          uint32_t flags, char** results_json);
 
 /* ---- admission path: micro-batched Driver.Query (row f1) ----------------------------------------------------------
  * Driver.Query evaluates ONE review (pkg/drivers/k8scel/driver.go:162-251) and the validating webhook calls it from up
@@ -373,6 +387,22 @@ int gk_query(gk_engine* e, const gk_review_in* review, char** results_json, gk_q
  * per loaded constraint, whether it applied and what it yielded; NULL otherwise.  trace_out may be NULL. */
 #define GK_QUERY_TRACE 1u
 int gk_query_ex(gk_engine* e, const gk_review_in* review, uint32_t flags, char** results_json, char** trace_out, gk_query_stats* stats);
+/* Driver.Query as the reference defines it (pkg/drivers/k8scel/driver.go:162-251; frameworks drivers/rego Query): the caller --
+ * Client.Review -- has ALREADY run Matcher.Match (pkg/target/matcher.go:21-42) and hands over exactly the constraints that matched;
+ * the driver evaluates those and never matches again.  A Go driver cannot do anything else: gkReview.namespace and gkReview.source,
+ * which Match reads, are unexported and have no accessor (pkg/target/review.go:16-21), so it cannot pass them down.
+ *   constraint_ids / n_constraints: the ids (gk_constraint_add) of Driver.Query's `constraints`; results of other constraints are
+ *     not returned.  NULL = every loaded constraint.  n_constraints == 0 with a non-NULL pointer: "[]" at once (the Rego driver
+ *     returns early on an empty list).  An id that is not loaded: GK_ERR_NOT_FOUND ("unknown constraint template validator").
+ *   GK_QUERY_PRE_MATCHED: for the listed constraints the VIOLATION sets are returned whatever this engine's own match layer says
+ *     about the review (a `match.source: Generated` constraint, a namespaceSelector on a Namespace the engine has never been
+ *     synced: the caller matched them, the caller knows); no autoreject rows; review->namespace_json and review->source are not
+ *     looked at; the review is never answered from the resident sweep's match-and-violation bitmaps.  Without the flag the call is
+ *     gk_query_ex restricted to the listed constraints (the engine matches: the batch / audit callers that own namespace + source).
+ * Calls with and without the flag share batches: the mode is a per-review bit of the batch's table (GK_TABLE_PRE_MATCHED). */
+#define GK_QUERY_PRE_MATCHED 2u
+int gk_query_ex2(gk_engine* e, const gk_review_in* review, const uint32_t* constraint_ids, size_t n_constraints, uint32_t flags,
+                 char** results_json, char** trace_out, gk_query_stats* stats);
 
 /* ---- plan specialisation in the background -----------------------------------------------------------------------------
  * After AddTemplate / AddConstraint (drivers.Driver, pkg/drivers/k8scel/driver.go:74-160) the next Query must not wait for a

@@ -5,7 +5,9 @@
  *
  *     gk_engine_create(gk_opts: flags + disabled builtins)        rego.New(args...)            main.go:424-486
  *     gk_template_add / gk_constraint_add / gk_data_put           Driver.AddTemplate / AddConstraint / AddData
- *     N threads x gk_query_ex (blocking, micro-batched)           Driver.Query from the webhook's goroutines, pkg/webhook/policy.go:142-146,826
+ *     N threads x gk_query_ex2 (blocking, micro-batched)          Driver.Query from the webhook's goroutines, pkg/webhook/policy.go:142-146,826:
+ *       odd threads the way the Go shim calls it -- the constraint ids Client.Review matched, GK_QUERY_PRE_MATCHED, no namespace, no
+ *       source (a Go driver cannot read either: pkg/target/review.go:16-21) --, even threads let the engine match (gk_query_ex)
  *       ... while another thread REPLACES the template and adds / removes a constraint      (Query must be re-entrant and never see
  *           a half-replaced policy set: pkg/drivers/k8scel/driver.go:61,131,140,168-169 guards the same with a RWMutex)
  *     gk_table_create / gk_table_eval / gk_render                 the audit's batch path, pkg/audit/manager.go:706-719
@@ -51,6 +53,7 @@ static const char* REGO_PRIV =
 
 static gk_engine* E;
 static volatile int g_stop;
+static uint32_t g_ids[3];   /* need-team, no-priv, gen-only (match.source: Generated) */
 
 /* a heap copy of a string that is POISONED and freed after the call it was lent to: the engine must have copied what it keeps */
 static char* lend(const char* s) { char* p = (char*)malloc(strlen(s) + 1); strcpy(p, s); return p; }
@@ -87,17 +90,29 @@ static void* query_worker(void* p) {
              a->id, q, labelled ? ", \"labels\": {\"team\": \"a\"}" : "", priv ? ", \"securityContext\": {\"privileged\": true}" : "");
     text = lend(obj);
     memset(&in, 0, sizeof in);
-    in.kind = GK_REVIEW_OBJECT; in.source = GK_SRC_ORIGINAL; in.json = text; in.json_len = strlen(text);
-    rc = gk_query_ex(E, &in, (q % 8 == 0) ? GK_QUERY_TRACE : 0u, &js, &trace, &st);
+    in.kind = GK_REVIEW_OBJECT; in.json = text; in.json_len = strlen(text);
+    if (a->id % 2) {
+      /* Driver.Query: the caller matched (say: an expansion resultant, Source Generated -- all three constraints apply); the driver
+       * is handed their ids and nothing the match layer reads */
+      rc = gk_query_ex2(E, &in, g_ids, 3, GK_QUERY_PRE_MATCHED | ((q % 8 == 0) ? GK_QUERY_TRACE : 0u), &js, &trace, &st);
+    } else {
+      in.source = GK_SRC_ORIGINAL;
+      rc = gk_query_ex(E, &in, (q % 8 == 0) ? GK_QUERY_TRACE : 0u, &js, &trace, &st);
+    }
     take_back(text);                                   /* borrowed for the call only */
     if (rc != GK_OK || !js) { a->failures++; fprintf(stderr, "abi_shim: thread %d query %d: rc %d: %s\n", a->id, q, rc, gk_last_error()); continue; }
     /* whatever the replacing thread is doing, the answer is one of the two templates' -- never a mixture, never nothing */
     {
       const int has_v1 = strstr(js, "v1: label team is missing") != NULL, has_v2 = strstr(js, "v2: label team is missing") != NULL;
-      const int has_priv = strstr(js, "privileged container c0") != NULL;
+      const char* first_priv = strstr(js, "privileged container c0");
+      const int has_priv = first_priv != NULL;
+      /* pre-matched callers handed over `gen-only` as well: the privileged pod violates it too, whatever its match block says;
+       * callers that let the engine match sent Source Original: `gen-only` does not apply */
+      const int n_priv = has_priv + (first_priv && strstr(first_priv + 1, "privileged container c0") != NULL);
       int bad = 0;
       if (labelled ? (has_v1 || has_v2) : (has_v1 == has_v2)) bad |= 1;
-      if (has_priv != priv) bad |= 2;
+      if (n_priv != (priv ? (a->id % 2 ? 2 : 1) : 0)) bad |= 2;
+      if (strstr(js, "autoreject") != NULL) bad |= 32;
       if ((q % 8 == 0) && (!trace || !strstr(trace, "gkgpu trace"))) bad |= 4;
       if ((q % 8 != 0) && trace) bad |= 8;
       if (st.batch_size < 1) bad |= 16;
@@ -149,9 +164,22 @@ int main(int argc, char** argv) {
   add_template("K8sPriv", REGO_PRIV);
   CHECK(gk_template_add(E, "K8sHttp", "package h\nviolation[{\"msg\": \"x\"}] { http.send({\"method\": \"get\", \"url\": \"u\"}) }\n", NULL, 0) == GK_ERR_REGO, "disabled builtin");
   CHECK(strstr(gk_last_error(), "undefined function http.send") != NULL, "disabled builtin: message");
-  add_constraint("{\"apiVersion\": \"constraints.gatekeeper.sh/v1beta1\", \"kind\": \"K8sRequiredLabels\", \"metadata\": {\"name\": \"need-team\"}, "
-                 "\"spec\": {\"match\": {\"kinds\": [{\"apiGroups\": [\"\"], \"kinds\": [\"Pod\"]}]}, \"parameters\": {\"labels\": [\"team\"]}}}");
-  add_constraint("{\"apiVersion\": \"constraints.gatekeeper.sh/v1beta1\", \"kind\": \"K8sPriv\", \"metadata\": {\"name\": \"no-priv\"}, \"spec\": {}}");
+  g_ids[0] = add_constraint("{\"apiVersion\": \"constraints.gatekeeper.sh/v1beta1\", \"kind\": \"K8sRequiredLabels\", \"metadata\": {\"name\": \"need-team\"}, "
+                            "\"spec\": {\"match\": {\"kinds\": [{\"apiGroups\": [\"\"], \"kinds\": [\"Pod\"]}]}, \"parameters\": {\"labels\": [\"team\"]}}}");
+  g_ids[1] = add_constraint("{\"apiVersion\": \"constraints.gatekeeper.sh/v1beta1\", \"kind\": \"K8sPriv\", \"metadata\": {\"name\": \"no-priv\"}, \"spec\": {}}");
+  g_ids[2] = add_constraint("{\"apiVersion\": \"constraints.gatekeeper.sh/v1beta1\", \"kind\": \"K8sPriv\", \"metadata\": {\"name\": \"gen-only\"}, "
+                            "\"spec\": {\"match\": {\"source\": \"Generated\"}}}");
+  {   /* Driver.Query with an empty constraint list answers at once; an id that is not loaded is "unknown constraint template validator" */
+    gk_review_in in;
+    char* js = NULL;
+    const uint32_t nobody = 4242;
+    const char* pod = "{\"apiVersion\": \"v1\", \"kind\": \"Pod\", \"metadata\": {\"name\": \"p\"}}";
+    memset(&in, 0, sizeof in);
+    in.kind = GK_REVIEW_OBJECT; in.json = pod; in.json_len = strlen(pod);
+    CHECK(gk_query_ex2(E, &in, g_ids, 0, GK_QUERY_PRE_MATCHED, &js, NULL, NULL) == GK_OK && js && strcmp(js, "[]") == 0, "gk_query_ex2 with no constraints");
+    gk_free(js);
+    CHECK(gk_query_ex2(E, &in, &nobody, 1, GK_QUERY_PRE_MATCHED, &js, NULL, NULL) == GK_ERR_NOT_FOUND, "gk_query_ex2 with an unknown id");
+  }
   {
     uint32_t id = 0;
     const char* orphan = "{\"apiVersion\": \"constraints.gatekeeper.sh/v1beta1\", \"kind\": \"K8sNoSuchKind\", \"metadata\": {\"name\": \"o\"}, \"spec\": {}}";
@@ -200,7 +228,7 @@ int main(int argc, char** argv) {
     for (i = 0; i < N; i++) { take_back(texts[i]); CHECK(statuses[i] == GK_OK, "review status"); }
     memset(in, 0, sizeof in);
     CHECK(gk_table_eval(E, t, GK_EVAL_WANT_MATCH, &ev) == GK_OK, "gk_table_eval");
-    CHECK(ev->n_reviews == N && ev->n_constraints == 2 && ev->n_tiles == 2, "gk_eval_out shape");
+    CHECK(ev->n_reviews == N && ev->n_constraints == 3 && ev->n_tiles == 2, "gk_eval_out shape");
     for (row = 0; row < ev->n_constraints; row++) viol_pairs += ev->counts[row];
     CHECK(viol_pairs == 35 + 14, "violating pairs");          /* 35 pods without the label, 14 privileged */
     for (row = 0; row < ev->n_constraints; row++) {
@@ -214,7 +242,7 @@ int main(int argc, char** argv) {
         }
       }
     }
-    CHECK(gk_table_topk(E, t, 20, &top) == GK_OK && top->n_constraints == 2, "gk_table_topk");
+    CHECK(gk_table_topk(E, t, 20, &top) == GK_OK && top->n_constraints == 3, "gk_table_topk");
     gk_topk_free(top);
     gk_eval_free(ev);
     gk_table_free(t);

@@ -395,7 +395,8 @@ void dev_eval_finish(const DevPlan* p, const DevTable* dt, const EvalOptions& op
     }
     for (uint32_t c = 0; c < nc; c++) {
       ConstraintSlot sl = p->fast.slots[c];
-      bool m = (res.match >> sl.match) & 1, e = (res.err >> sl.match) & 1, v = m && ((res.viol >> sl.viol) & 1);
+      const bool prem = (t.rflags[r] & RF_PREMATCHED) != 0;   // (kernel_body.inc: the caller matched, nothing is autorejected)
+      bool m = prem || ((res.match >> sl.match) & 1), e = !prem && ((res.err >> sl.match) & 1), v = m && ((res.viol >> sl.viol) & 1);
       if (opt.want_match && m) o->match[(size_t)c * nt + tile] |= bit;
       if (e) o->err[(size_t)c * nt + tile] |= bit;
       if (v) {

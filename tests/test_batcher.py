@@ -33,7 +33,7 @@ def test_concurrent_queries_are_batched_and_exact(backend, fixtures):
             for i in range(w, len(objs), 16):
                 rv = D.AugmentedUnstructured(D.Unstructured(objs[i]), synth.namespace_for(objs[i], nss), "Original")
                 try:
-                    resp = c.driver.Query(D.TARGET_NAME, cons, rv)
+                    resp = c.driver.QueryMatching(D.TARGET_NAME, cons, rv)
                     got[i] = sorted((r.constraint["metadata"]["name"], r.msg) for r in resp.results)
                 except D.LimitError as e:
                     got[i] = e
@@ -54,8 +54,8 @@ def test_concurrent_queries_are_batched_and_exact(backend, fixtures):
     assert max(sizes) > 1                              # calls really shared launches
     # a review HandleReview rejects is an error for that caller only
     with pytest.raises(D.EngineError):
-        c.driver.Query(D.TARGET_NAME, cons, D.AugmentedReview(D.AdmissionRequest({"operation": "DELETE", "object": objs[0]}), None, "Original"))
-    assert c.driver.Query(D.TARGET_NAME, cons[:3], D.AugmentedUnstructured(D.Unstructured(objs[0]), None, "Original")).results is not None
+        c.driver.QueryMatching(D.TARGET_NAME, cons, D.AugmentedReview(D.AdmissionRequest({"operation": "DELETE", "object": objs[0]}), None, "Original"))
+    assert c.driver.QueryMatching(D.TARGET_NAME, cons[:3], D.AugmentedUnstructured(D.Unstructured(objs[0]), None, "Original")).results is not None
 
 
 @pytest.mark.parametrize("requests", [False, True])
@@ -92,10 +92,10 @@ def test_query_stats_entries_and_their_descriptions(fixtures):
     pod = next(o for o in synth.gen_objects(50, seed=9) if o["spec"].get("hostNetwork") or any((x.get("securityContext") or {}).get("privileged") for x in o["spec"]["containers"]))
     rv = D.AugmentedUnstructured(D.Unstructured(pod), synth.namespace_for(pod, nss), "Original")
     cons = list(c.constraints.values())
-    resp = c.driver.Query(D.TARGET_NAME, cons, rv, stats_enabled=True)
+    resp = c.driver.QueryMatching(D.TARGET_NAME, cons, rv, stats_enabled=True)
     # one entry per template kind of the queried constraints, in the Rego driver's shape (pkg/gator/test/test_test.go:357-391)
     kinds = sorted({k["kind"] for k in cons})
-    assert len(resp.results) > 0 and [e["statsFor"] for e in resp.stats_entries] == kinds and not c.driver.Query(D.TARGET_NAME, cons, rv).stats_entries
+    assert len(resp.results) > 0 and [e["statsFor"] for e in resp.stats_entries] == kinds and not c.driver.QueryMatching(D.TARGET_NAME, cons, rv).stats_entries
     entry = resp.stats_entries[0]
     names = [s["name"] for s in entry["stats"]]
     assert entry["scope"] == "template" and names == [D.Driver.RUN_TIME_NS, D.Driver.CONSTRAINT_COUNT]

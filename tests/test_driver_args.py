@@ -78,7 +78,7 @@ def test_gather_stats_has_the_rego_drivers_shape():
     """Test_Test_withStats (pkg/gator/test/test_test.go:332-418): one entry per review and template -- scope "template", statsFor the kind,
     templateRunTimeNS (non-zero) and constraintCount (1) from source {engine, Rego}, labels TracingEnabled / PrintEnabled / target"""
     drv, c, rv = _never_validate(gather_stats=True)
-    resp = drv.Query(D.TARGET_NAME, list(c.constraints.values()), rv)
+    resp = drv.QueryMatching(D.TARGET_NAME, list(c.constraints.values()), rv)
     assert [r.msg for r in resp.results] == ["never validate"]
     src = {"type": "engine", "value": "Rego"}
     assert len(resp.stats_entries) == 1
@@ -91,16 +91,16 @@ def test_gather_stats_has_the_rego_drivers_shape():
     for s in e["stats"]:
         assert drv.GetDescriptionForStat(s["name"])
     plain, c2, rv2 = _never_validate()
-    assert not plain.Query(D.TARGET_NAME, list(c2.constraints.values()), rv2).stats_entries       # no GatherStats, no stats
+    assert not plain.QueryMatching(D.TARGET_NAME, list(c2.constraints.values()), rv2).stats_entries       # no GatherStats, no stats
 
 
 def test_tracing_returns_a_trace():
     drv, c, rv = _never_validate(tracing=True)                       # rego.Tracing(true): every Query carries one
-    resp = drv.Query(D.TARGET_NAME, list(c.constraints.values()), rv)
+    resp = drv.QueryMatching(D.TARGET_NAME, list(c.constraints.values()), rv)
     assert resp.trace and "NeverValidate/always-fail" in resp.trace and "never validate" in resp.trace and "on the device" in resp.trace
     plain, c2, rv2 = _never_validate()
-    assert plain.Query(D.TARGET_NAME, list(c2.constraints.values()), rv2).trace is None
-    asked = plain.Query(D.TARGET_NAME, list(c2.constraints.values()), rv2, tracing=True)            # ... or the review asks for it
+    assert plain.QueryMatching(D.TARGET_NAME, list(c2.constraints.values()), rv2).trace is None
+    asked = plain.QueryMatching(D.TARGET_NAME, list(c2.constraints.values()), rv2, tracing=True)            # ... or the review asks for it
     assert asked.trace and "1 result(s)" in asked.trace
     # a review the host evaluator answers says so
     huge = {"apiVersion": "v1", "kind": "Pod", "metadata": {"name": "huge"}, "spec": {"containers": [{"name": "c%d" % i, "image": "x"} for i in range(300)]}}
@@ -111,5 +111,5 @@ def test_tracing_returns_a_trace():
         c4.AddTemplate(t)
     for k in synth.psp_constraints():
         c4.AddConstraint(k)
-    r4 = d4.Query(D.TARGET_NAME, list(c4.constraints.values()), D.AugmentedUnstructured(D.Unstructured(huge), None, "Original"), tracing=True)
+    r4 = d4.QueryMatching(D.TARGET_NAME, list(c4.constraints.values()), D.AugmentedUnstructured(D.Unstructured(huge), None, "Original"), tracing=True)
     assert "host evaluator" in r4.trace

@@ -49,7 +49,7 @@ def test_first_query_after_a_policy_change_does_not_wait_for_the_compiler(fixtur
         rvs = [D.AugmentedUnstructured(D.Unstructured(o), synth.namespace_for(o, nss), "Original") for o in objs]
 
         def query(i):
-            resp = drv.Query(D.TARGET_NAME, list(c.constraints.values()), rvs[i])
+            resp = drv.QueryMatching(D.TARGET_NAME, list(c.constraints.values()), rvs[i])
             return sorted((r.constraint["metadata"]["name"], r.msg) for r in resp.results)
         # warm the process (HIP context, allocator pool, the ahead-of-time kernels) on the first policy set
         assert query(0) == _expect(oc, objs[0], nss)

@@ -669,7 +669,7 @@ def test_edge_cases(backend, fixtures):
     hr = D.AugmentedUnstructured(D.Unstructured(huge_priv), None, "Original")
     want = sorted(key(r) for r in oc.review(to_oracle_review(hr), D.AUDIT_EP, None))
     assert want and sorted(key(r) for r in c.Review(hr)) == want
-    assert sorted((r.constraint["metadata"]["name"], r.msg) for r in c.driver.Query(D.TARGET_NAME, list(c.constraints.values()), hr).results) == \
+    assert sorted((r.constraint["metadata"]["name"], r.msg) for r in c.driver.QueryMatching(D.TARGET_NAME, list(c.constraints.values()), hr).results) == \
         sorted((r.constraint["metadata"]["name"], r.msg) for r in oc.review(to_oracle_review(hr), D.AUDIT_EP, None))
     batch = c.ReviewBatch([rv[0], hr, rv[1]])
     assert sorted(key(r) for r in batch[1]) == want

@@ -82,7 +82,7 @@ def test_audit_from_cache_incremental(backend, fixtures):
     path = next(p for p, o in c.cached.items() if o.get("kind") == "Pod" and (o["metadata"].get("namespace") in nss))
     o = c.cached[path]
     ns = relabel if o["metadata"]["namespace"] == "prod-03" else nss[o["metadata"]["namespace"]]
-    resp = c.driver.Query(D.TARGET_NAME, list(c.constraints.values()), D.AugmentedUnstructured(D.Unstructured(o), ns, ""), ns)
+    resp = c.driver.QueryMatching(D.TARGET_NAME, list(c.constraints.values()), D.AugmentedUnstructured(D.Unstructured(o), ns, ""), ns)
     assert c.driver.last_query_stats["batch_size"] == 0          # served from the resident set
     want = oc.review(OT.AugmentedUnstructured(OT.Unstructured(o), ns, ""), OC.AUDIT_EP, ns)
     assert sorted((r.constraint["metadata"]["name"], r.msg) for r in resp.results) == sorted((r.constraint["metadata"]["name"], r.msg) for r in want if not r.msg.startswith("unable to match"))

@@ -132,11 +132,7 @@ def test_sharded_sweep_fails_closed(tmp_path):
     single = ShardedSweep(_client("audit"), objs, synth.gen_namespaces(), keep_docs=True)
     # (the sharded exchange carries what the DEVICE answers: the reference here is the device's answer alone -- gk_table_eval's host
     #  evaluation of refused reviews, round 5, is switched off for it; with it on the same table has no refusal left)
-    os.environ["GK_HOST_EVAL"] = "0"
-    try:
-        ref = single.table.eval()
-    finally:
-        del os.environ["GK_HOST_EVAL"]
+    ref = single.table.eval(host_eval=False)
     assert sorted(int(r) for r in ref.too_big_reviews()) == [7, 150]
     full = single.table.eval()
     assert not full.too_big_reviews() and sorted(full.host_evaluated) == [7, 150]
@@ -202,11 +198,7 @@ def test_rccl_exchange_and_captured_sweeps_on_the_device(tmp_path, graph, monkey
     got_all = pickle.load(open(os.path.join(str(tmp_path), "rccl_0.pkl"), "rb"))
     for name, objs, beyond in (("limits", _limit_objs(), 2), ("plain", _plain_objs(), 0)):
         single = ShardedSweep(_gpu_client(), objs, synth.gen_namespaces(), keep_docs=True)
-        os.environ["GK_HOST_EVAL"] = "0"   # (the exchange carries the DEVICE's answer: the reference is the plain evaluation without the host evaluator's completions)
-        try:
-            ref = single.table.eval()
-        finally:
-            del os.environ["GK_HOST_EVAL"]
+        ref = single.table.eval(host_eval=False)   # (the exchange carries the DEVICE's answer: the reference is the plain evaluation without the host evaluator's completions)
         n = len(objs)
         ref_err = np.array([int(np.unpackbits(ref.err[r].view(np.uint8)).sum()) for r in range(ref.n_constraints)], np.int64)
         ref_bits = np.stack([np.unpackbits(ref.viol[r].view(np.uint8), bitorder="little")[:n] for r in range(ref.n_constraints)])
