@@ -41,7 +41,7 @@ EXPORTS = [
     "gk_table_totals", "gk_totals_free", "gk_table_get_stats", "gk_batcher_start", "gk_batcher_stop", "gk_query", "gk_query_ex", "gk_query_ex2",
     "gk_resident_sweep", "gk_sweep_free", "gk_resident_review", "gk_resident_review_ex",
     "gk_comm_unique_id", "gk_comm_init", "gk_comm_destroy", "gk_comm_info", "gk_table_sweep_sharded", "gk_shard_free",
-    "gk_jit_quiesce", "gk_jit_cache_stats", "gk_jit_cache_dir", "gk_jit_cache_drop_memory", "gk_host_cpus", "gk_table_create_spool", "gk_spool_info_free",
+    "gk_jit_quiesce", "gk_jit_cache_stats", "gk_jit_cache_dir", "gk_jit_cache_drop_memory", "gk_host_cpus", "gk_table_create_spool", "gk_spool_info_free", "gk_debug_set",
     # include/gksynth.h (bench / test plumbing)
     "gk_synth_batch_create", "gk_synth_batch_reviews", "gk_synth_batch_size", "gk_synth_batch_json_bytes", "gk_synth_batch_free", "gk_synth_query_storm",
 ]
@@ -229,6 +229,7 @@ def load(hostemu: bool | None = None):
     lib.gk_query_ex.argtypes = [vp, C.POINTER(gk_review_in), u32, C.POINTER(vp), C.POINTER(vp), C.POINTER(gk_query_stats)]
     lib.gk_query_ex2.argtypes = [vp, C.POINTER(gk_review_in), C.POINTER(u32), sz, u32, C.POINTER(vp), C.POINTER(vp), C.POINTER(gk_query_stats)]
     lib.gk_resident_review_ex.argtypes = [vp, C.POINTER(cp), sz, C.POINTER(u32), sz, u32, C.POINTER(vp)]
+    lib.gk_debug_set.argtypes = [cp, C.c_int64]
     lib.gk_table_get_stats.argtypes = [vp, C.POINTER(gk_table_stats)]
     lib.gk_table_totals.argtypes = [vp, vp, C.POINTER(C.POINTER(gk_totals_out))]
     lib.gk_totals_free.argtypes = [C.POINTER(gk_totals_out)]

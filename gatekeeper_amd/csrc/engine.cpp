@@ -1702,7 +1702,8 @@ int gk_table_eval(gk_engine* e, gk_table* t, uint32_t flags, gk_eval_out** out) 
         bool str = false;
         for (uint32_t j = 0; j < (ent & 0xFF); j++) str = str || pred_needs_str(hp.path_preds[(ent >> 8) + j]);
         if (str) hdrs_read += n;
-        if (getenv("GK_DEBUG_PATH_ROWS")) fprintf(stderr, "[gkgpu paths] %-70s rows %9llu preds %3u%s\n", e->dict.to_string(pth).c_str(), (unsigned long long)n, ent & 0xFF, str ? " +hdr" : "");
+        static const bool dbg_path_rows = getenv("GK_DEBUG_PATH_ROWS") != nullptr;   // (read once)
+        if (dbg_path_rows) fprintf(stderr, "[gkgpu paths] %-70s rows %9llu preds %3u%s\n", e->dict.to_string(pth).c_str(), (unsigned long long)n, ent & 0xFF, str ? " +hdr" : "");
         if (!(seen[si] & 1)) { seen[si] |= 1; rows_once += n; }
         if (str && !(seen[si] & 2)) { seen[si] |= 2; hdrs_once += n; }
       }
@@ -2914,6 +2915,12 @@ int gk_query_ex2(gk_engine* e, const gk_review_in* review, const uint32_t* const
                     : (pre_matched ? "on the device (pre-matched by the caller: violation bitmaps of the batch's one launch; messages rendered by the host evaluator for the flagged pairs)"
                                    : "on the device (match + violation bitmaps of the batch's one launch; messages rendered by the host evaluator for the flagged pairs)"), results, &mine);
   return GK_OK;
+}
+
+int gk_debug_set(const char* key, int64_t value) {
+  if (!key) return fail(GK_ERR_INVALID, "NULL argument");
+  if (strcmp(key, "fold_match_labels") == 0) { g_test_fold_match_labels.store(value != 0); return GK_OK; }
+  return fail(GK_ERR_NOT_FOUND, std::string("gk_debug_set: unknown key ") + key);
 }
 
 void gk_jit_quiesce(void) { dev_jit_quiesce(); }

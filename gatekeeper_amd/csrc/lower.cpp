@@ -5,11 +5,13 @@
 #include "regex.hpp"
 #include "vm_core.hpp"
 
+#include <atomic>
 #include <functional>
 #include <regex>
 #include <set>
 
 namespace gk {
+std::atomic<int> g_test_fold_match_labels{0};   // test aid, set through gk_debug_set("fold_match_labels", 1): nothing reads the environment while lowering
 
 // ================================================================================================ match blocks
 namespace {
@@ -543,13 +545,13 @@ bool match_fact_leaf(const SPath& p) {
   return on && p.size() == 3 && !p[0].iter && p[0].key == "$m" && !p[1].iter && !p[2].iter && !p[2].key.empty() && p[2].key[0] != '$';
 }
 // (folding a MATCH formula promotes the match facts only: the labels a selector names keep their rows, which the counting plans --
-//  frozen, in the counting space -- lower the same way.  GK_TEST_FOLD_MATCH_LABELS=1, test aid: promote them as well -- the counting
+//  frozen, in the counting space -- lower the same way.  gk_debug_set("fold_match_labels", 1), test aid: promote them as well -- the counting
 //  plans then read label rows a pruned table does not hold, which is how tests/test_pruned.py reaches render_needed's unanswered plans)
 static thread_local bool g_fold_match_only = false;
 static bool promotable_leaf(const SPath& p) {   // (the other synthetic subtrees -- $ns -- keep their rows)
   if (p.empty()) return false;
   if (match_fact_leaf(p)) return true;
-  if (g_fold_match_only && !getenv("GK_TEST_FOLD_MATCH_LABELS")) return false;
+  if (g_fold_match_only && !g_test_fold_match_labels.load(std::memory_order_relaxed)) return false;
   for (auto& st : p) if (!st.iter && !st.key.empty() && st.key[0] == '$') return false;
   return true;
 }

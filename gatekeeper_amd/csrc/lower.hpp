@@ -13,6 +13,7 @@
 #include "pe.hpp"
 #include "plan.hpp"
 
+#include <atomic>
 namespace gk {
 
 struct MatchFormulas {
@@ -73,5 +74,8 @@ class PlanBuilder {
   std::vector<std::shared_ptr<const PreparedConstraint>> cons_;
 };
 
+
+// test aid (gk_debug_set "fold_match_labels"): match formulas' label tests become dictionary bits as well
+extern std::atomic<int> g_test_fold_match_labels;
 
 }  // namespace gk

@@ -422,6 +422,11 @@ void gk_jit_cache_stats(uint64_t* cache_hits, uint64_t* compiles);
 const char* gk_jit_cache_dir(void);
 void gk_jit_cache_drop_memory(void);
 
+/* Test and tuning hooks that used to be environment switches read on the compile path (nothing there reads the environment any more).
+ * Not for deployments.  Keys: "fold_match_labels" (0 | 1: the match formulas' label tests become dictionary bits as well -- how
+ * tests/test_pruned.py reaches the totals plans a pruned table cannot answer).  GK_ERR_NOT_FOUND for an unknown key. */
+int gk_debug_set(const char* key, int64_t value);
+
 /* Debug: the compiled plan as text (Driver.Dump, pkg/drivers/k8scel/driver.go:253). */
 int gk_dump(gk_engine* e, char** text_out);
 

@@ -58,9 +58,12 @@ def test_a_totals_plan_the_pruned_table_cannot_answer_leaves_the_whole_constrain
     reads, the constraint's pairs must ALL be rendered: a flag row answering "counted" next to a missing count row undercounted
     (K8sContainerLimits of the corpus: 645 results against 706).  The test aid makes the match formulas' label tests dictionary bits,
     which the frozen counting plans lower from label rows the pruned table does not hold."""
-    monkeypatch.setenv("GK_TEST_FOLD_MATCH_LABELS", "1")
     c = make_client("hostemu")
-    _load(c, fixtures, True)
+    assert c.driver.engine.lib.gk_debug_set(b"fold_match_labels", 1) == 0
+    try:
+        _load(c, fixtures, True)
+    finally:
+        c.driver.engine.lib.gk_debug_set(b"fold_match_labels", 0)
     eng = c.driver.engine
     n = 1500
     batch = synth.NativeBatch(eng.lib, n, seed=synth.SEED, mixed=True, start=0, namespaces=synth.gen_namespaces())
