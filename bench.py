@@ -854,7 +854,7 @@ def main():
                          "avg_kernel_ms_event_pair_per_launch": iso.fast_kernel_ms,
                          # (one event pair around all launches of a view; the plan groups of a >64-formula constraint set share
                          #  the stream, so the figure is only meaningful for a single group)
-                         "avg_launch_ms_back_to_back": res.fast_kernel_ms if nc <= 64 else None, "lds_bytes_per_tile": int(res.lds_bytes),
+                         "avg_launch_ms_back_to_back": res.fast_kernel_ms if nc <= 64 else None, "lds_bytes_per_tile": int(res.lds_bytes), "kernel_text_hash": "%016x" % int(res.kernel_text_hash),
                          "full_table_bytes": full_table_bytes,
                          "full_table_GBps": full_table_bytes / kernel_s / 1e9 if kernel_s > 0 else None,
                          "kernel_only_evals_per_s": nc * n_local / kernel_s if kernel_s > 0 else None},
@@ -883,9 +883,17 @@ def main():
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
             # (... and the profiled build streamed the bytes this one does: a PMC figure of an earlier table layout says nothing)
             same_bytes = pmc.get("algo_bytes_per_launch") is None or abs(pmc["algo_bytes_per_launch"] - int(res.algo_bytes)) <= 0.02 * int(res.algo_bytes)
-            if pmc.get("config") == args.config and pmc.get("reviews") == n_local and world == 1 and same_bytes:
-                out["roofline"]["traffic"] = pmc["hbm_bytes_per_launch"]
-                out["roofline"]["traffic_source"] = pmc["source"]
+            # (... and ran the kernel text this run timed: the passes are stamped with the hash bench.py printed under them -- a PMC
+            #  figure measured on another kernel or table layout can never ride this line)
+            same_kernel = pmc.get("kernel_text_hash") == "%016x" % int(res.kernel_text_hash)
+            if pmc.get("config") == args.config and pmc.get("reviews") == n_local and world == 1:
+                if same_bytes and same_kernel:
+                    out["roofline"]["traffic"] = pmc["hbm_bytes_per_launch"]
+                    out["roofline"]["traffic_source"] = pmc["source"]
+                else:
+                    out["roofline"]["traffic_dropped"] = ("profiles/pmc_latest.json was measured on kernel text %s streaming %s bytes per launch; this run timed kernel text %016x "
+                                                          "streaming %d: the stale figure is not reported" % (pmc.get("kernel_text_hash"), pmc.get("algo_bytes_per_launch"),
+                                                                                                             int(res.kernel_text_hash), int(res.algo_bytes)))
         except (OSError, ValueError):
             pass
         # the audit's RESULT totals (pkg/audit/manager.go:893-904: totalViolationsPerConstraint counts types.Results, several per

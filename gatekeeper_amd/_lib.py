@@ -75,7 +75,7 @@ class gk_eval_out(C.Structure):
                 ("algo_bytes", C.c_uint64), ("n_rows", C.c_uint64), ("n_launches", C.c_uint32), ("lds_bytes", C.c_uint32),
                 ("d_viol", C.c_void_p), ("d_err", C.c_void_p), ("d_counts", C.c_void_p), ("n_rows_read", C.c_uint64),
                 ("algo_bytes_once", C.c_uint64), ("n_plan_groups", C.c_uint32), ("n_host_evaluated", C.c_uint32),
-                ("host_evaluated", C.POINTER(C.c_uint32))]
+                ("host_evaluated", C.POINTER(C.c_uint32)), ("kernel_text_hash", C.c_uint64)]
 
 
 class gk_topk_out(C.Structure):

@@ -41,6 +41,7 @@ struct EvalOut {
   uint32_t n_launches = 0;        // launches averaged in fast_kernel_ms
   uint32_t lds_bytes = 0;         // accumulator LDS per workgroup of the dominant kernel's most recent launch
   uint64_t list_bytes = 0;        // chunk lists the dominant kernel reads per launch (chunks.hpp)
+  uint64_t kernel_hash = 0;       // FNV-64 of the plan-specialised kernel's source text (0: the bytecode kernel ran)
   const void *d_viol = nullptr, *d_err = nullptr, *d_counts = nullptr;   // device-resident results (valid until the table's next launch)
 };
 

@@ -1660,6 +1660,7 @@ int gk_table_eval(gk_engine* e, gk_table* t, uint32_t flags, gk_eval_out** out) 
         o.n_overflow += og.n_overflow;
         o.kernel_ms += og.kernel_ms; o.fast_kernel_ms += og.fast_kernel_ms;
         o.list_bytes += og.list_bytes;
+        o.kernel_hash = o.kernel_hash * 1099511628211ull ^ og.kernel_hash;   // (several plan groups: one figure that names all their texts)
         o.n_constraints += og.n_constraints;
         o.d_viol = o.d_err = o.d_counts = nullptr;   // not one contiguous device buffer any more
         h->ids.insert(h->ids.end(), e->extra[gi]->ids.begin(), e->extra[gi]->ids.end());
@@ -1685,6 +1686,7 @@ int gk_table_eval(gk_engine* e, gk_table* t, uint32_t flags, gk_eval_out** out) 
     p.n_rows = t->n_rows;
     t->last_nc = p.n_constraints; t->last_ids = h->ids;
     p.lds_bytes = h->lds_bytes;
+    p.kernel_text_hash = h->out.kernel_hash;
     // algorithmic bytes: rows of the segments whose path carries predicates (+ their string headers
     // where a predicate reads string bytes) + the groups' chunk lists (8 B per entry) + review flags, all read once;
     // plan tables read once; bitmaps written once; 8 B per list entry

@@ -142,6 +142,7 @@ class EvalResult:
         # reviews beyond the device's limits that the engine's host evaluator answered (their bits are in the bitmaps, not in too_big)
         self.host_evaluated = [int(o.host_evaluated[i]) for i in range(o.n_host_evaluated)] if o.n_host_evaluated else []
         self.lds_bytes = o.lds_bytes
+        self.kernel_text_hash = int(o.kernel_text_hash)
         self.d_viol, self.d_err, self.d_counts = o.d_viol, o.d_err, o.d_counts
         lib.gk_eval_free(ptr)
 

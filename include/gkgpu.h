@@ -201,6 +201,9 @@ typedef struct {
    * evaluation error): the caller fails closed for those. */
   uint32_t n_host_evaluated;
   const uint32_t* host_evaluated;   /* [n_host_evaluated] review indices */
+  uint64_t kernel_text_hash;        /* FNV-64 of the source text of the plan-specialised dominant kernel that ran (several plan groups: their
+                                       hashes combined; 0: the bytecode kernel ran).  Names the kernel a measurement was taken on: bench.py
+                                       reports PMC traffic only from passes stamped with the hash of the kernel it timed */
 } gk_eval_out;
 
 #define GK_EVAL_WANT_MATCH 1u

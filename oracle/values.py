@@ -216,6 +216,12 @@ def to_json(v):
         return [to_json(x) for x in v]
     if isinstance(v, RSet):
         return [to_json(x) for x in sorted_values(v.elems())]
+    if isinstance(v, float) and math.isfinite(v) and v.is_integer() and abs(v) < 1e21:
+        # ast.JSON hands a Number over as json.Number = its TEXT, and the text of a review object's number is what encoding/json
+        # wrote for the float64 / int64 the object was decoded into (pkg/target/target.go:140-179 marshals obj.Object; apimachinery's
+        # decoder turns `3.0` and `1e2` into float64 3 and 100, the encoder writes `3` and `100`): an integral float is an integer
+        # in `details`, exactly as num_to_string prints it in `msg`.  (Negative zero: Go writes `-0`, a JSON reader makes 0 of it.)
+        return int(v)
     return v
 
 

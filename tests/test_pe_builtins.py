@@ -6,7 +6,10 @@ an intermediate member that is not an object, a root that is not an object."""
 import pytest
 
 from gatekeeper_amd import driver as D
-from parity_util import BACKENDS, assert_parity, load_both
+import ctypes as C
+
+from oracle import client as OC
+from parity_util import BACKENDS, assert_parity, load_both, to_oracle_review
 
 
 def tmpl(kind, rego):
@@ -223,6 +226,54 @@ NUM_CASES = [
     (2.0, "v=2 arr=[2]"),
     (2 ** 53 + 1, "v=9007199254740993 arr=[9007199254740993]"),
 ]
+
+
+# ... and in `details`.  Decided from the reference's decode path: an audited / gator object is an unstructured.Unstructured (apimachinery's
+# JSON decoder: `3.0` and `1e2` become float64 3 and 100, `-0` int64 0), HandleReview marshals obj.Object again (pkg/target/target.go:140-179:
+# encoding/json writes 3, 100, 0) and OPA carries that TEXT as the ast.Number -- sprintf prints it through Number.Int() / float64 %v,
+# ast.JSON returns it as json.Number in `details`.  Product (value.hpp), oracle (values.py) and the compiled checker agree on the text.
+NUM_DETAIL_REGO = '''package k
+violation[{"msg": msg, "details": {"r": n, "twice": n * 2}}] {
+  n := input.review.object.n
+  msg := sprintf("n=%v", [n])
+}
+'''
+NUM_DETAIL_CASES = [   # (JSON text of the object's number, msg, text of details.r, text of details.twice)
+    ("3.0", "n=3", "3", "6"), ("1e2", "n=100", "100", "200"), ("-0", "n=0", "0", "0"), ("-0.0", "n=0", "0", "0"), ("1e21", "n=1e+21", "1e+21", "2e+21"),
+    ("0.000001", "n=1e-06", "0.000001", "0.000002"), ("1e-7", "n=1e-07", "1e-7", "2e-7"), ("100000000000000000000", "n=100000000000000000000", "100000000000000000000", "200000000000000000000"),
+    ("2.50", "n=2.5", "2.5", "5"), ("7", "n=7", "7", "14"), ("1.5e3", "n=1500", "1500", "3000"),
+]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_number_text_in_details(backend):
+    import json
+    from oracle.values import num_to_string
+    c, oc = load_both(backend, [tmpl("K8sNumD", NUM_DETAIL_REGO)], [{"apiVersion": "constraints.gatekeeper.sh/v1beta1", "kind": "K8sNumD", "metadata": {"name": "c"}, "spec": {}}])
+    cid = c.driver.constraint_id(list(c.constraints.values())[0])
+    objs = [json.loads('{"apiVersion": "v1", "kind": "Pod", "metadata": {"name": "o%d", "namespace": "d"}, "n": %s}' % (i, text)) for i, (text, _, _, _) in enumerate(NUM_DETAIL_CASES)]
+    reviews = [D.AugmentedUnstructured(D.Unstructured(o), None, "Original") for o in objs]
+    assert assert_parity(c, oc, reviews, D.GATOR_EP) == len(objs)     # (msg AND details, as values)
+    table = c.driver.engine.create_table([D.to_review_in(r) for r in reviews])
+    try:
+        table.eval()
+        for i, (text, msg, r_text, twice_text) in enumerate(NUM_DETAIL_CASES):
+            # the product's raw JSON text (gk_render), not what a JSON reader makes of it
+            p = C.c_void_p()
+            assert c.driver.engine.lib.gk_render(c.driver.engine.handle, table.handle, cid, i, C.byref(p)) == 0
+            raw = C.string_at(p).decode()
+            c.driver.engine.lib.gk_free(p)
+            assert '"msg":"%s"' % msg in raw.replace('": ', '":').replace(', ', ','), (text, raw)
+            assert '"r":%s' % r_text in raw.replace('": ', '":'), (text, raw)
+            assert '"twice":%s' % twice_text in raw.replace('": ', '":'), (text, raw)
+            # the oracle's values in the same text
+            exp = oc.review(to_oracle_review(reviews[i]), OC.GATOR_EP)
+            assert [r.msg for r in exp] == [msg]
+            det = exp[0].metadata["details"]
+            assert num_to_string(det["r"]) == r_text and num_to_string(det["twice"]) == twice_text, (text, det)
+            assert not isinstance(det["r"], float) or not det["r"].is_integer() or abs(det["r"]) >= 1e21, (text, det)
+    finally:
+        table.free()
 
 
 @pytest.mark.parametrize("backend", BACKENDS)

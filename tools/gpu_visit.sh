@@ -73,11 +73,13 @@ v = {}
 for line in open(sys.argv[1]):
     m = re.match(r"\S+ (\S+) per_dispatch=([0-9.]+)", line)
     if m and "jit_tiles" in line: v[m.group(1)] = float(m.group(2))
-try: ALGO = json.loads(open("gpurun_out/%s_pmc_fetch.json" % sys.argv[2]).read().strip().split("\n")[-1])["roofline"]["algo_bytes_per_launch"]
-except Exception: ALGO = None
+try:
+    RL = json.loads(open("gpurun_out/%s_pmc_fetch.json" % sys.argv[2]).read().strip().split("\n")[-1])["roofline"]
+    ALGO, KHASH = RL["algo_bytes_per_launch"], RL.get("kernel_text_hash")
+except Exception: ALGO = KHASH = None
 if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
-    print(json.dumps({"config": 2, "reviews": 1000000, "algo_bytes_per_launch": ALGO, "hbm_bytes_per_launch": int((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024), "fetch_kb": v["FETCH_SIZE"], "write_kb": v["WRITE_SIZE"],
-                      "source": "profiles/%s_summary.txt (rocprofv3 --pmc, separate passes of `bench.py --steps 5 --warmup 1 --lean` with --kernel-trace only; HBM bytes = 2 x FETCH_SIZE KB (gfx950 correction, MI355X_MICROARCH.md) + WRITE_SIZE KB, KB = 1024 B)" % ("r05_pmc_" + sys.argv[2][3:] + "_config2_1M")}, indent=1))
+    print(json.dumps({"config": 2, "reviews": 1000000, "algo_bytes_per_launch": ALGO, "kernel_text_hash": KHASH, "hbm_bytes_per_launch": int((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024), "fetch_kb": v["FETCH_SIZE"], "write_kb": v["WRITE_SIZE"],
+                      "source": "profiles/%s_summary.txt (rocprofv3 --pmc, separate passes of `bench.py --steps 5 --warmup 1 --lean` with --kernel-trace only; HBM bytes = 2 x FETCH_SIZE KB (gfx950 correction, MI355X_MICROARCH.md) + WRITE_SIZE KB, KB = 1024 B)" % (sys.argv[2][:3] + "_pmc_" + sys.argv[2][3:] + "_config2_1M")}, indent=1))
 PY
          ;;
     pmc4) run_pmc4() { name=$1; shift; timeout 400 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d gpurun_out/${tag}_pmc_$name -o $name -- python bench.py --config 4 --steps 5 --warmup 1 --lean > /dev/null 2> gpurun_out/${tag}_pmc_$name.err; }
