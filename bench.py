@@ -845,6 +845,15 @@ def main():
                        "violating_pairs_rank0": int(counts.sum()), "reviews_beyond_limits_rank0": len(final.too_big_reviews()),
                        # reviews beyond the DEVICE's limits that the engine's exact host evaluator answered instead of refusing them
                        "reviews_evaluated_on_host_rank0": len(getattr(final, "host_evaluated", []))},
+            # N > 1: what the exchange step costs next to the local sweep (rank 0's figures of one collecting sweep behind the timed region:
+            # HIP events around the all-gather alone; the timed passes are enqueue-only and carry no events).  `ms_per_step` against
+            # sweep_ms_local + exchange_ms says whether the overlapped exchange (GK_SHARD_OVERLAP, default at world size > 1) hid it.
+            "exchange": None if sharded is None else {
+                "exchange_bytes_per_rank": sharded.exchange_bytes_inbound, "exchange_ms": sharded.exchange_ms, "sweep_ms_local": float(sharded.fast_kernel_ms),
+                "overlap_enabled": sharded.exchange_overlapped, "slot_bytes": int(sharded.slot_bytes),
+                "exchange_GBps_inbound": sharded.exchange_bytes_inbound / (sharded.exchange_ms * 1e6) if sharded.exchange_ms > 0 else None,
+                "hidden_by_overlap": (dt / args.steps * 1e3) < 0.75 * (float(sharded.fast_kernel_ms) + sharded.exchange_ms) if sharded.exchange_ms > 0 else None,
+                "bound": ("exchange" if sharded.exchange_ms > float(sharded.fast_kernel_ms) else "sweep") if sharded.exchange_ms > 0 else None},
             # (the plan-specialised build -- what rocprofv3 shows for this workload; GK_NO_JIT=1 runs the generic bytecode build instead)
             "roofline": {"bound": "hbm", "kernel": "gk_eval_tiles_256" if os.environ.get("GK_NO_JIT") else "gk_jit_tiles", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algo_bytes_per_launch": int(res.algo_bytes),

@@ -104,7 +104,8 @@ class gk_shard_out(C.Structure):
     _fields_ = [("world", C.c_uint32), ("rank", C.c_uint32), ("n_constraints", C.c_uint32), ("stride_tiles", C.c_uint32), ("slot_bytes", C.c_uint64),
                 ("constraint_ids", C.POINTER(C.c_uint32)), ("shard_reviews", C.POINTER(C.c_uint32)), ("totals", C.POINTER(C.c_int64)),
                 ("gathered", C.POINTER(C.c_uint64)), ("d_gathered", C.c_void_p), ("kernel_ms", C.c_float), ("fast_kernel_ms", C.c_float),
-                ("n_overflow", C.c_uint32), ("err_totals", C.POINTER(C.c_int64)), ("beyond_limits", C.c_int64), ("not_evaluated", C.c_int64)]
+                ("n_overflow", C.c_uint32), ("err_totals", C.POINTER(C.c_int64)), ("beyond_limits", C.c_int64), ("not_evaluated", C.c_int64),
+                ("exchange_ms", C.c_float), ("exchange_overlapped", C.c_uint32), ("exchange_bytes_inbound", C.c_uint64)]
 
 
 GK_SHARD_DOWNLOAD = 1

@@ -96,6 +96,11 @@ void dev_shard_setup(DevTable* t, DevComm* c, uint32_t nc, ShardInfo* info);   /
 // dev_eval_launch and the call returns without waiting (back-to-back sweeps; the collecting call comes last)
 void dev_shard_exchange(DevTable* t, DevComm* c, uint32_t nc, uint64_t not_evaluated, std::vector<int64_t>* totals,
                         std::vector<uint64_t>* gathered /* may be null */, const void** d_gathered);
+// the exchange step of the most recent COLLECTING dev_shard_exchange of this table (enqueue-only passes are not timed): duration of the
+// all-gather alone (events around it on its stream; 0 when no collecting exchange ran), the bytes this rank RECEIVES in it
+// ((world - 1) x slot), and whether consecutive enqueue-only passes overlap their exchange with the next sweep
+struct ShardExchangeStats { float exchange_ms = 0; uint64_t inbound_bytes = 0; bool overlap = false; };
+ShardExchangeStats dev_shard_exchange_stats(const DevTable* t, const DevComm* c);
 // one enqueue-only sweep + exchange step of a resident shard (launch + exchange; captured into a graph from the second pass on)
 void dev_shard_enqueue(const DevPlan* p, DevTable* t, DevComm* c, const EvalOptions& opt, uint32_t nc, uint64_t not_evaluated, bool allow_graph);
 // the answer of the most recent enqueue-only pass, without sweeping again; false when there is none or when that pass left

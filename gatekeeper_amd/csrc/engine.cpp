@@ -2474,6 +2474,17 @@ int gk_table_sweep_sharded(gk_engine* e, gk_table* t, uint32_t flags, gk_shard_o
     p.d_gathered = d_all;
     p.kernel_ms = eo.kernel_ms; p.fast_kernel_ms = eo.fast_kernel_ms; p.n_overflow = eo.n_overflow;
     p.err_totals = h->err_totals.data(); p.beyond_limits = beyond; p.not_evaluated = not_eval;
+    {   // the exchange step's own figures (the primary plan group's; further groups exchange the same number of bytes per row)
+      const ShardExchangeStats xs = dev_shard_exchange_stats(t->dev, e->comm);
+      p.exchange_ms = collected ? 0.f : xs.exchange_ms;   // (a collected enqueue-only pass was not timed)
+      p.exchange_bytes_inbound = xs.inbound_bytes;
+      for (size_t gi = 0; gi < e->extra.size() && gi < t->views.size(); gi++) {
+        const ShardExchangeStats xg = dev_shard_exchange_stats(t->views[gi], e->comm);
+        if (!collected) p.exchange_ms += xg.exchange_ms;
+        p.exchange_bytes_inbound += xg.inbound_bytes;
+      }
+      p.exchange_overlapped = xs.overlap ? 1u : 0u;
+    }
     *out = &h.release()->pub;
     return GK_OK;
   } catch (const Unsupported& ex) { return fail(GK_ERR_UNSUPPORTED, ex.what());

@@ -35,6 +35,8 @@ class ShardedResult:
         # fail closed: autoreject pairs per constraint, reviews beyond the engine's limits, reviews HandleReview rejected -- over ALL shards
         self.err_totals = np.ctypeslib.as_array(o.err_totals, (self.nc,)).copy() if self.nc else np.zeros(0, np.int64)
         self.beyond_limits, self.not_evaluated = int(o.beyond_limits), int(o.not_evaluated)
+        # the exchange step of this call: the all-gather's own duration (0: an enqueue-only pass was handed out), bytes received, overlap mode
+        self.exchange_ms, self.exchange_overlapped, self.exchange_bytes_inbound = float(o.exchange_ms), bool(o.exchange_overlapped), int(o.exchange_bytes_inbound)
         self.d_gathered = o.d_gathered
         self.gathered = None
         if o.gathered:

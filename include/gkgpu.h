@@ -307,6 +307,11 @@ typedef struct {
   const int64_t* err_totals;         /* [n_constraints] autoreject pairs: Matcher.Match returned an error (one Result each) */
   int64_t beyond_limits;             /* reviews a plan group could not evaluate (beyond the engine's limits; counted per plan group) */
   int64_t not_evaluated;             /* reviews HandleReview rejected when their shard's table was built (GK_ERR_REVIEW) */
+  /* the exchange step, so that a scaling run can be read: */
+  float exchange_ms;                 /* duration of the all-gather alone (HIP events around it on its stream) in THIS call's collecting exchange;
+                                        0 when the call handed out an enqueue-only pass (GK_SHARD_COLLECT: those passes carry no events) */
+  uint32_t exchange_overlapped;      /* 1: consecutive enqueue-only passes run their all-gather on the exchange stream, under the next sweep */
+  uint64_t exchange_bytes_inbound;   /* bytes this rank receives per sweep: (world - 1) x slot_bytes (summed over plan groups) */
 } gk_shard_out;
 #define GK_SHARD_DOWNLOAD 1u
 /* GK_SHARD_ENQUEUE: put one sweep + its exchange step onto the table's stream and return at once (`out` is not written and may

@@ -32,7 +32,7 @@
 
 namespace gk {
 
-struct DevTable { HostTable t; int pending = 0; std::vector<uint64_t> last_viol, last_err, last_big; std::vector<uint8_t> shard_all; size_t shard_slot = 0; uint32_t shard_stride = 0, shard_nc = 0; };
+struct DevTable { HostTable t; int pending = 0; std::vector<uint64_t> last_viol, last_err, last_big; std::vector<uint8_t> shard_all; size_t shard_slot = 0; uint32_t shard_stride = 0, shard_nc = 0; float exchange_ms = 0; int exchange_world = 0; };
 typedef void (*HeRowFn)(const Row*, uint32_t, uint32_t, const StrHdr*, const PlanView*, const uint8_t*, std::vector<uint32_t>*);
 typedef void (*HeFormFn)(const PlanView*, std::vector<uint32_t>*, uint32_t, const Row*, const uint8_t*, const uint32_t*, Results*);
 struct DevPlan {
@@ -337,9 +337,21 @@ void dev_shard_exchange(DevTable* t, DevComm* c, uint32_t nc, uint64_t not_evalu
   ShardState::Backend be{nullptr, t, c, EvalOptions(), nc, not_evaluated, st.get()};
   st->pipe.drain(be);
   be.select(st->pipe.cur);
-  be.tail(); be.gather(SS_TABLE); be.totals(SS_TABLE);
+  be.tail();
+  const auto x0 = std::chrono::steady_clock::now();
+  be.gather(SS_TABLE);
+  if (totals) { t->exchange_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - x0).count(); t->exchange_world = c->world; }
+  be.totals(SS_TABLE);
   if (!totals) return;
   shard_read(t, st.get(), nc, totals, gathered, d_gathered);
+}
+ShardExchangeStats dev_shard_exchange_stats(const DevTable* t, const DevComm* c) {
+  ShardExchangeStats s;
+  if (!t || !c) return s;
+  s.exchange_ms = t->exchange_ms;
+  s.inbound_bytes = (uint64_t)(c->world > 0 ? c->world - 1 : 0) * t->shard_slot;
+  s.overlap = false;
+  return s;
 }
 // the answer of the LAST enqueue-only pass without sweeping again (kernels.hip dev_shard_collect)
 bool dev_shard_collect(DevTable* t, DevComm* c, uint32_t nc, std::vector<int64_t>* totals, std::vector<uint64_t>* gathered, const void** d_gathered) {

@@ -54,6 +54,13 @@ def test_sharded_bench_at_world_size_two_equals_one_process():
     assert two["config"]["global_violating_pairs"] == one["config"]["global_violating_pairs"] > 1000
     assert two["config"]["violating_pairs_rank0"] < two["config"]["global_violating_pairs"]
     assert "CPU EMULATION" in two["data"]
+    # the exchange step is readable from the line: bytes received per rank = one other rank's slot, the all-gather's own duration, the local
+    # sweep beside it, whether the overlapped pipeline is on (never in the emulation), and what bounds a step; absent at N = 1
+    x = two["exchange"]
+    assert one["exchange"] is None
+    assert set(x) >= {"exchange_bytes_per_rank", "exchange_ms", "sweep_ms_local", "overlap_enabled", "hidden_by_overlap", "bound", "slot_bytes"}
+    assert x["exchange_bytes_per_rank"] == x["slot_bytes"] * (two["n_gpus"] - 1) > 50 * (1344 // 64) * 8
+    assert x["exchange_ms"] > 0 and x["sweep_ms_local"] > 0 and x["overlap_enabled"] is False and x["bound"] in ("exchange", "sweep")
     # strong scaling: 2 688 objects split over two ranks
     rc, strong, err = _run(["--gpus", "2", "--reviews", "2688", "--scaling", "strong"] + common)
     assert rc == 0 and strong is not None, err[-2000:]

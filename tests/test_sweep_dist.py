@@ -282,3 +282,50 @@ def test_overlapped_exchange_at_world_size_four(tmp_path, policies):
             assert (got["totals"] == ref.counts.astype(np.int64)).all() and (got["counts"].sum(0) == ref.counts).all()
             assert got["beyond"] == 0 and got["not_evaluated"] == 0
     assert ref.counts.sum() > 100
+
+
+# ---- world size 8 (the node SURVEY.md section 8e asks for), uneven shards -- one of them EMPTY, one a single object, one not a multiple
+# of 64: the slot stride is the largest shard's, every rank ends with the same gathered bitmaps and totals, and the exchange figures
+# the bench line prints (bytes received = 7 slots) are those of the slot layout
+SHARDS8 = [130, 64, 1, 200, 0, 77, 128, 40]
+
+
+def _world8_worker(rank, world, port, out_dir):
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    objs = synth.gen_objects(sum(SHARDS8), seed=37, mixed=True)
+    lo = sum(SHARDS8[:rank])
+    sw = ShardedSweep(_client("audit"), objs[lo:lo + SHARDS8[rank]], synth.gen_namespaces(), dist=dist, device=torch.device("cpu"))
+    answers = [sw.sweep(1, download=True), sw.sweep(3, download=True, collect=True)]
+    with open(os.path.join(out_dir, "w8_%d.pkl" % rank), "wb") as fh:
+        pickle.dump([{"bitmaps": r.bitmaps(), "totals": r.totals, "counts": r.counts(), "shards": r.shard_reviews, "ids": r.constraint_ids, "slot": r.slot_bytes,
+                      "stride": r.stride_tiles, "inbound": r.exchange_bytes_inbound, "exchange_ms": r.exchange_ms, "beyond": r.beyond_limits} for r in answers], fh)
+    dist.destroy_process_group()
+
+
+def test_uneven_shards_at_world_size_eight(tmp_path):
+    world = len(SHARDS8)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ["GK_HOST_THREADS"] = "1"
+    try:
+        mp.spawn(_world8_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    finally:
+        del os.environ["GK_HOST_THREADS"]
+    objs = synth.gen_objects(sum(SHARDS8), seed=37, mixed=True)
+    single = ShardedSweep(_client("audit"), objs, synth.gen_namespaces())
+    ref = single.table.eval()
+    n = len(objs)
+    ref_bits = np.stack([np.unpackbits(ref.viol[r].view(np.uint8), bitorder="little")[:n] for r in range(ref.n_constraints)])
+    for rank in range(world):
+        answers = pickle.load(open(os.path.join(str(tmp_path), "w8_%d.pkl" % rank), "rb"))
+        for k, got in enumerate(answers):
+            assert list(got["shards"]) == SHARDS8 and (got["ids"] == ref.constraint_ids).all()
+            assert got["stride"] == (max(SHARDS8) + 63) // 64 and got["inbound"] == 7 * got["slot"]
+            bits = np.concatenate([np.stack([np.unpackbits(bm[r].view(np.uint8), bitorder="little")[:SHARDS8[j]] for r in range(ref.n_constraints)]).reshape(ref.n_constraints, SHARDS8[j])
+                                   for j, bm in enumerate(got["bitmaps"])], axis=1)
+            assert (bits == ref_bits).all(), "rank %d, answer %d: a different global bitmap" % (rank, k)
+            assert (got["totals"] == ref.counts.astype(np.int64)).all() and (got["counts"].sum(0) == ref.counts).all() and got["beyond"] == 0
+        assert answers[0]["exchange_ms"] > 0 and answers[1]["exchange_ms"] == 0     # a collecting exchange is timed, a handed-out enqueue-only pass is not
+    assert ref.counts.sum() > 100
