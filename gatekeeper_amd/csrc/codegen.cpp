@@ -67,11 +67,12 @@ std::vector<uint32_t> jit_path_classes(const HostPlan& plan, std::vector<std::ve
   return out;
 }
 
-uint32_t jit_res_k(const HostPlan& plan) {
-  const uint32_t need = std::max(plan.n_viol, plan.n_match);
-  // (in steps of four above 16: 4 halves x 3 kinds x 20 slots of configs[2] fit the 256-entry chunk-list buffer they alias, 32 did not)
-  return need <= 16 ? 16u : std::min<uint32_t>((uint32_t)GK_MAX_RES, (need + 3u) / 4u * 4u);
-}
+// result slots the plan-specialised kernel keeps per 64-review half: KV violation slots, KM match slots and KM error slots, in that
+// order (kernel_body.inc s_masks).  In steps of four: 4 halves x (20 + 2 x 8) slots of configs[2] fit the 256-entry chunk-list buffer
+// they alias.
+uint32_t jit_res_kv(const HostPlan& plan) { return std::min<uint32_t>((uint32_t)GK_MAX_VIOL, std::max<uint32_t>(4u, (plan.n_viol + 3u) / 4u * 4u)); }
+uint32_t jit_res_km(const HostPlan& plan) { return std::min<uint32_t>((uint32_t)GK_MAX_RES, std::max<uint32_t>(4u, (plan.n_match + 3u) / 4u * 4u)); }
+uint32_t jit_res_k(const HostPlan& plan) { return jit_res_kv(plan) + 2u * jit_res_km(plan); }   // result words per half
 
 std::string generate_plan_source(const HostPlan& plan, uint32_t parts) {
   std::ostringstream o;
@@ -88,7 +89,7 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts) {
       << "GK_CONST_ARRAY uint32_t gk_zero_lo[1] = {0u};\nGK_CONST_ARRAY uint32_t gk_zero_hi[1] = {" << plan.dims.acc_words << "u};\n";
   }
   // result slots kept per 64-review half and kind (kernel_body.inc GK_RES_K), and where each scope's element count lives
-  o << "#define GK_RES_K " << jit_res_k(plan) << "\n#define GK_N_SCOPES_K " << plan.scopes.size() << "\n"
+  o << "#define GK_RES_KV " << jit_res_kv(plan) << "\n#define GK_RES_KM " << jit_res_km(plan) << "\n#define GK_N_SCOPES_K " << plan.scopes.size() << "\n"
     << "GK_CONST_ARRAY uint32_t gk_count_off[" << std::max<size_t>(1, plan.scopes.size()) << "] = {";
   for (size_t i = 0; i < plan.scopes.size(); i++) o << (i ? "," : "") << plan.scopes[i].count_off << "u";
   if (plan.scopes.empty()) o << "0u";
@@ -263,7 +264,7 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts) {
   }
   // ---------------------------------------------------------------------------------------------- phase 2
   o << "template <class Acc>\nGK_HD Results jit_formulas(const PlanView& pv, Acc& acc, uint32_t flags, const Row* rows, const uint8_t* heap, const uint32_t* bounds) {\n"
-    << "  (void)pv; (void)rows; (void)heap; (void)flags;\n  Results res = {0, 0, 0};\n  uint32_t";
+    << "  (void)pv; (void)rows; (void)heap; (void)flags;\n  Results res = {};\n  uint32_t";
   for (int i = 0; i < 64; i++) o << (i ? ", " : " ") << "b" << i << " = 0u";
   o << ";\n";
   // the global predicate words are read once; derived global bits (F_STG) update the register copy as well
@@ -278,7 +279,9 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts) {
   // register copy as well as LDS.  Used when the unrolled text stays small (`pre_budget` operations per plan); GK_JIT_PRELOAD=0
   // keeps the loops.
   std::ostringstream* out_ = &o;
-  uint64_t res_slots[3] = {0, 0, 0};                   // result slots (per kind) the staged part being generated hands to GK_RES
+  // result slots (per KIND) the staged part being generated hands to GK_RES.  Kinds: 0 = violation slots 0..63, 1 = match, 2 = error,
+  // 3.. = violation slots 64.., 128.., 192.. (one kind per bank of 64: a kind's words ride in one register pair, lane = slot & 63)
+  uint64_t res_slots[2 + GK_VIOL_WORDS] = {};
   bool pre = false;                                    // generating the preloaded form
   std::set<std::pair<uint32_t, uint32_t>> pre_words;   // (scope, element) words the part being generated reads
   std::set<uint32_t> pre_bounds;                       // scopes whose run-time bound the part needs
@@ -573,7 +576,12 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts) {
         const char* f = b == 0 ? "viol" : b == 1 ? "match" : "err";
         // staged parts hand the result of slot c to GK_RES: on the device one ballot turns the 64 lanes' answers into the
         // slot's bitmap word (kernel_body.inc), elsewhere it accumulates into `res` like the monolithic function
-        if (staged) { o << ind << "GK_RES(" << b << ", " << c << ", b" << a << ");\n"; if (b < 3 && c < 64) res_slots[b] |= 1ull << c; }
+        if (staged) {
+          const uint32_t kind = (b == 0 && c >= 64) ? 2u + (c >> 6) : b, lane_ = (b == 0) ? (c & 63u) : c;
+          if (kind >= 2u + GK_VIOL_WORDS || lane_ >= 64u) throw Unsupported("codegen: result slot out of range");
+          o << ind << "GK_RES(" << kind << ", " << lane_ << ", b" << a << ");\n";
+          res_slots[kind] |= 1ull << lane_;
+        } else if (b == 0) o << ind << "res.viol[" << (c >> 6) << "] |= (uint64_t)b" << a << " << " << (c & 63u) << ";\n";
         else o << ind << "res." << f << " |= (uint64_t)b" << a << " << " << c << ";\n";
         break;
       }
@@ -741,9 +749,9 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts) {
       if (total > pre_budget) use_pre = false;
     }
     o << "#define GK_HAS_STAGES 1\nconstexpr uint32_t GK_N_STAGES = " << n_stages << "u;\nconstexpr uint32_t GK_GEN_PARTS = " << NW << "u;\n"
-      << "#ifndef GK_RES\n#define GK_RES(kind, slot, b) do { if ((kind) == 0) res.viol |= (uint64_t)(b) << (slot); else if ((kind) == 1) res.match |= (uint64_t)(b) << (slot); "
-         "else res.err |= (uint64_t)(b) << (slot); } while (0)\n#define GK_RES_PROLOGUE\n#endif\n"
-         "#ifndef GK_RES_FLUSH\n#define GK_RES_FLUSH(m0, m1, m2)\n#endif\n"
+      << "#ifndef GK_RES\n#define GK_RES(kind, slot, b) do { if ((kind) == 0) res.viol[0] |= (uint64_t)(b) << (slot); else if ((kind) == 1) res.match |= (uint64_t)(b) << (slot); "
+         "else if ((kind) == 2) res.err |= (uint64_t)(b) << (slot); else res.viol[(kind) - 2] |= (uint64_t)(b) << (slot); } while (0)\n#define GK_RES_PROLOGUE\n#endif\n"
+         "#ifndef GK_RES_FLUSH\n#define GK_RES_FLUSH(m0, m1, m2, m3, m4, m5)\n#endif\n"
       << "template <class Acc>\nGK_HD void jit_formula_part(uint32_t part, Acc& acc, uint32_t flags, const uint8_t* heap, const uint32_t* bounds, Results& res, unsigned long long* masks) {\n"
       << "  (void)heap; (void)flags; (void)bounds; (void)res; (void)masks;\n  GK_RES_PROLOGUE\n  uint32_t";
     for (int i = 0; i < 64; i++) o << (i ? ", " : " ") << "b" << i << " = 0u";
@@ -752,7 +760,7 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts) {
     o << "  switch (part) {\n";
     for (size_t p = 0; p < parts.size(); p++) {
       o << "    case " << p << ": {\n";
-      res_slots[0] = res_slots[1] = res_slots[2] = 0;
+      for (auto& rs : res_slots) rs = 0;
       std::vector<size_t> order = parts[p];
       std::sort(order.begin(), order.end());
       if (use_pre) {
@@ -795,7 +803,13 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts) {
       } else
       for (size_t bi : order) { stack.clear(); gen(blks[bi].pc0, blks[bi].pc1, true, "      "); }
       // the part's finished slots leave the wave together (jit_source.hpp jit_res_macros: lane s holds slot s's word)
-      { char fb[128]; snprintf(fb, sizeof fb, "      GK_RES_FLUSH(0x%llxull, 0x%llxull, 0x%llxull);\n", (unsigned long long)res_slots[0], (unsigned long long)res_slots[1], (unsigned long long)res_slots[2]); o << fb; }
+      {
+        static_assert(GK_VIOL_WORDS == 4, "GK_RES_FLUSH takes the masks of six kinds");
+        char fb[256];
+        snprintf(fb, sizeof fb, "      GK_RES_FLUSH(0x%llxull, 0x%llxull, 0x%llxull, 0x%llxull, 0x%llxull, 0x%llxull);\n", (unsigned long long)res_slots[0], (unsigned long long)res_slots[1],
+                 (unsigned long long)res_slots[2], (unsigned long long)res_slots[3], (unsigned long long)res_slots[4], (unsigned long long)res_slots[5]);
+        o << fb;
+      }
       o << "    } break;\n";
     }
     o << "    default: break;\n  }\n";

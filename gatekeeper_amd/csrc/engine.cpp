@@ -31,6 +31,7 @@
 
 using namespace gk;
 
+static std::atomic<int> g_debug_group_max{0};   // gk_debug_set("group_max", n): plan groups of at most n constraints (0 = as many as fit)
 namespace {
 
 thread_local std::string g_err;
@@ -536,7 +537,7 @@ void ensure_plan(gk_engine* e) {
     std::vector<const ConstraintRec*> alive;
     for (auto& c : e->constraints) if (c.alive) alive.push_back(&c);
     for (auto* c : alive) if (!c->broken.empty()) throw Unsupported(c->broken);   // (a referential constraint the current inventory does not compile for)
-    // groups of constraints that fit one plan: everything if possible, else chunks of <= 64 constraints (a constraint
+    // groups of constraints that fit one plan: everything if possible, else chunks of <= GK_MAX_VIOL constraints (a constraint
     // contributes one violation and one match formula), halved further while a chunk still does not lower
     std::vector<std::vector<const ConstraintRec*>> groups;
     auto builds = [&](const std::vector<const ConstraintRec*>& g, HostPlan* fast, HostPlan* big) {
@@ -548,13 +549,20 @@ void ensure_plan(gk_engine* e) {
     std::vector<std::pair<HostPlan, HostPlan>> plans;
     std::function<void(const std::vector<const ConstraintRec*>&)> place = [&](const std::vector<const ConstraintRec*>& g) {
       HostPlan f, b;
+      // (test / tuning aid, gk_debug_set("group_max", n): no plan group of more than n constraints -- the several-group machinery,
+      //  which a set of more than 256 distinct violation formulas still takes, stays testable with a small corpus)
+      if (const int forced = g_debug_group_max.load(); forced > 0 && g.size() > (size_t)forced) {
+        for (size_t i = 0; i < g.size(); i += (size_t)forced)
+          place(std::vector<const ConstraintRec*>(g.begin() + i, g.begin() + std::min(g.size(), i + (size_t)forced)));
+        return;
+      }
       try { builds(g, &f, &b); }
       catch (const Unsupported& u) {
         if (g.size() == 1 && g[0]->referential)   // (its formula follows the synced objects: say so -- the same words refresh_referential uses)
           throw Unsupported(std::string("referential constraint ") + g[0]->kind + "/" + g[0]->name + " does not compile against the synced inventory: " + u.what());
         if (g.size() <= 1) throw;
-        size_t cap = 64;
-        if (const char* gm = getenv("GK_GROUP_MAX")) cap = (size_t)std::max(1, std::min(64, atoi(gm)));   // tuning aid: smaller plan groups (smaller code objects, fewer accumulator words, more walks of the table)
+        size_t cap = GK_MAX_VIOL;   // (a constraint contributes at most one violation formula; round 6: 256 slots per plan, 64 before)
+        if (const char* gm = getenv("GK_GROUP_MAX")) cap = (size_t)std::max(1, std::min((int)GK_MAX_VIOL, atoi(gm)));   // tuning aid: smaller plan groups (smaller code objects, fewer accumulator words, more walks of the table)
         size_t half = g.size() > cap ? cap : g.size() / 2;
         for (size_t i = 0; i < g.size(); i += half)
           place(std::vector<const ConstraintRec*>(g.begin() + i, g.begin() + std::min(g.size(), i + half)));
@@ -2932,6 +2940,7 @@ int gk_query_ex2(gk_engine* e, const gk_review_in* review, const uint32_t* const
 
 int gk_debug_set(const char* key, int64_t value) {
   if (!key) return fail(GK_ERR_INVALID, "NULL argument");
+  if (strcmp(key, "group_max") == 0) { g_debug_group_max.store((int)std::max<int64_t>(0, std::min<int64_t>(value, 1 << 20))); return GK_OK; }
   if (strcmp(key, "fold_match_labels") == 0) { g_test_fold_match_labels.store(value != 0); return GK_OK; }
   return fail(GK_ERR_NOT_FOUND, std::string("gk_debug_set: unknown key ") + key);
 }

@@ -42,7 +42,7 @@ inline uint32_t jit_list_cap(int block, uint32_t need) {
 }
 inline size_t static_lds_of(uint32_t rpt, int block, uint32_t res_k, uint32_t list_cap = 0) {
   const size_t list = (size_t)(list_cap ? list_cap : list_cap_of(block)) * 8;
-  const size_t masks = (size_t)(rpt / GK_TILE) * 3 * (res_k ? res_k : GK_MAX_RES) * 8;
+  const size_t masks = (size_t)(rpt / GK_TILE) * (res_k ? res_k : (uint32_t)(GK_MAX_VIOL + 2 * GK_MAX_RES)) * 8;   // res_k: result words per half (jit_res_k)
   const size_t bounds = res_k ? 0 : (size_t)(block / GK_TILE) * GK_MAX_SCOPES * 4;
   return 2 * list + (masks <= list ? 8 : masks) + bounds + GK_TILE * 4 + 64;
 }
@@ -58,17 +58,25 @@ inline size_t max_dyn_lds_jit(uint32_t rpt, uint32_t res_k, uint32_t list_cap = 
 // GK_WRITELANE2 (tests/native/hostemu.cpp).  GK_JIT_RES_LANES=0 (A/B aid) keeps the one-lane stores.
 inline std::string jit_res_macros() {
   static const bool lanes = !(getenv("GK_JIT_RES_LANES") && atoi(getenv("GK_JIT_RES_LANES")) == 0);
+  // where a kind's slots start in the half's result words: kind 0 = violation slots 0..63, 1 = match, 2 = error, 3 / 4 / 5 = violation
+  // slots 64.. / 128.. / 192.. (round 6: up to GK_MAX_VIOL violation formulas per plan, one register pair per bank of 64)
+  const std::string base =
+      "#define GK_RES_BASE(kind) ((kind) == 0 ? 0u : (kind) == 1 ? (uint32_t)GK_RES_KV : (kind) == 2 ? (uint32_t)(GK_RES_KV + GK_RES_KM) : ((uint32_t)(kind) - 2u) * 64u)\n";
   if (!lanes)
-    return "#define GK_RES_PROLOGUE const bool gk_l0 = GK_LANE_ID() == 0u;\n"
-           "#define GK_RES(kind, slot, b) do { const unsigned long long m_ = __ballot((b) != 0u); if (gk_l0) masks[(kind) * GK_RES_K + (slot)] = m_; } while (0)\n"
-           "#define GK_RES_FLUSH(m0, m1, m2)\n";
-  return "#define GK_RES_PROLOGUE uint32_t gk_rl0 = 0u, gk_rh0 = 0u, gk_rl1 = 0u, gk_rh1 = 0u, gk_rl2 = 0u, gk_rh2 = 0u;\n"
-         "#define GK_RES(kind, slot, b) do { const unsigned long long m_ = __ballot((b) != 0u); GK_WRITELANE2(m_, slot, gk_rl##kind, gk_rh##kind); } while (0)\n"
-         "#define GK_RES_FLUSH(m0, m1, m2) do { const uint32_t l_ = GK_LANE_ID() & 63u; "
-         "if (((unsigned long long)(m0) >> l_) & 1ull) masks[0u * GK_RES_K + l_] = ((unsigned long long)gk_rh0 << 32) | gk_rl0; "
-         "if (((unsigned long long)(m1) >> l_) & 1ull) masks[1u * GK_RES_K + l_] = ((unsigned long long)gk_rh1 << 32) | gk_rl1; "
-         "if (((unsigned long long)(m2) >> l_) & 1ull) masks[2u * GK_RES_K + l_] = ((unsigned long long)gk_rh2 << 32) | gk_rl2; "
-         "(void)gk_rl0; (void)gk_rh0; (void)gk_rl1; (void)gk_rh1; (void)gk_rl2; (void)gk_rh2; } while (0)\n";
+    return base +
+           "#define GK_RES_PROLOGUE const bool gk_l0 = GK_LANE_ID() == 0u;\n"
+           "#define GK_RES(kind, slot, b) do { const unsigned long long m_ = __ballot((b) != 0u); if (gk_l0) masks[GK_RES_BASE(kind) + (slot)] = m_; } while (0)\n"
+           "#define GK_RES_FLUSH(m0, m1, m2, m3, m4, m5)\n";
+  std::string pro = "#define GK_RES_PROLOGUE uint32_t", flush = "#define GK_RES_FLUSH(m0, m1, m2, m3, m4, m5) do { const uint32_t l_ = GK_LANE_ID() & 63u; ", voids;
+  for (int k = 0; k < 2 + GK_VIOL_WORDS; k++) {
+    const std::string ks = std::to_string(k);
+    pro += std::string(k ? "," : "") + " gk_rl" + ks + " = 0u, gk_rh" + ks + " = 0u";
+    flush += "if (((unsigned long long)(m" + ks + ") >> l_) & 1ull) masks[GK_RES_BASE(" + ks + ") + l_] = ((unsigned long long)gk_rh" + ks + " << 32) | gk_rl" + ks + "; ";
+    voids += "(void)gk_rl" + ks + "; (void)gk_rh" + ks + "; ";
+  }
+  return base + pro + ";\n"
+         "#define GK_RES(kind, slot, b) do { const unsigned long long m_ = __ballot((b) != 0u); GK_WRITELANE2(m_, slot, gk_rl##kind, gk_rh##kind); } while (0)\n" +
+         flush + voids + "} while (0)\n";
 }
 
 // plan_hpp / vm_core_hpp / kernel_body: plan.hpp, vm_core.hpp and kernel_body.inc as text (build/jit_sources.inc)

@@ -1644,8 +1644,8 @@ HostPlan PlanBuilder::build(const PlanCaps& caps) {
     if (jt == match_ids.end()) { slot.match = (uint16_t)matches.size(); match_ids[mk] = slot.match; matches.push_back(m); errs.push_back(e); } else slot.match = (uint16_t)jt->second;
     L.plan.slots.push_back(slot);
   }
-  if (viols.size() > GK_MAX_RES || matches.size() > GK_MAX_RES)
-    throw Unsupported("more than 64 distinct violation or match formulas in one plan (split the constraint set)");
+  if (viols.size() > GK_MAX_VIOL || matches.size() > GK_MAX_RES)
+    throw Unsupported("more than 256 distinct violation or 64 distinct match formulas in one plan (split the constraint set)");
   std::vector<uint32_t> main_ends;
   for (size_t i = 0; i < viols.size(); i++) { int r = L.lower(viols[i]); L.emit(finst(F_RES, r, 0, (uint32_t)i)); L.release(r); main_ends.push_back((uint32_t)L.plan.code.size()); }
   for (size_t i = 0; i < matches.size(); i++) {
@@ -1720,6 +1720,7 @@ HostPlan PlanBuilder::build(const PlanCaps& caps) {
   while (p.cheap.size() & 3) p.cheap.push_back(0);
   if (p.cheap.empty()) p.cheap.resize(4, 0);
   p.dims.const_bytes = (uint32_t)p.cheap.size();
+  p.dims.n_viol = p.n_viol; p.dims.n_match = p.n_match;
   p.resolve_paths(*dict_);
   return p;
 }

@@ -216,7 +216,12 @@ constexpr int GK_RPT_MAX = 512;
 constexpr int GK_PARTS_MIN_RPT = 4;    // formula shares per 64-review half in the 64-review geometry (256 threads)
 inline constexpr int gk_block_of(int rpt) { return rpt <= 128 ? 256 : rpt * 2; }          // threads per row group
 inline constexpr int gk_parts_of(int rpt) { return gk_block_of(rpt) / GK_TILE / (rpt / GK_TILE); }   // formula shares per half
-constexpr int GK_MAX_RES = 64;         // unique formulas per result class per pass
+constexpr int GK_MAX_RES = 64;         // distinct MATCH formulas (and their error formulas) per plan: one 64-bit result word per review
+// distinct VIOLATION formulas per plan (round 6): GK_VIOL_WORDS banks of 64 result slots -- a policy set of a few hundred templates is ONE
+// plan and one walk of the table (the 200-template corpus: 102 violation formulas, 6 match formulas), where rounds 1-5 cut it into
+// groups of <= 64 constraints that each walked the table
+constexpr int GK_VIOL_WORDS = 4;
+constexpr int GK_MAX_VIOL = 64 * GK_VIOL_WORDS;
 constexpr int GK_MAX_SCOPES = 32;
 constexpr int GK_WAVE_CHUNKS = 64;      // 64-row chunks one wave queues per tile (LDS); beyond: the tile's reviews take the big path
 constexpr uint32_t GK_ENT_NEEDS_STR = 0x80000000u;   // class entry flag (plan-specialised build): some predicate reads string bytes
@@ -230,6 +235,7 @@ struct PlanDims {
   uint32_t n_gwords;      // global bitset words
   uint32_t acc_words;     // accumulator words per review (globals + scopes)
   uint32_t const_bytes;
+  uint32_t n_viol, n_match;   // result slots in use (distinct violation / match formulas)
 };
 
 }  // namespace gk

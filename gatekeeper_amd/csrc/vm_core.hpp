@@ -505,7 +505,9 @@ GK_HD void eval_row_ent(const Row& r, uint32_t row_index, uint32_t ent, const St
 GK_HD bool vid_eq(uint32_t a, uint32_t b) { return (a == b) & (a != 0u); }
 
 struct Results {
-  uint64_t viol, match, err;
+  uint64_t viol[GK_VIOL_WORDS];   // bit (s & 63) of word (s >> 6): violation formula s
+  uint64_t match, err;
+  GK_HD bool viol_bit(uint32_t s) const { return (viol[s >> 6] >> (s & 63u)) & 1ull; }
 };
 
 // Phase 2 for one review. `bounds[s]` = loop trip count for scope s (any value >= this review's element count;
@@ -513,7 +515,7 @@ struct Results {
 template <class Acc>
 GK_HD Results eval_formulas(const PlanView& pv, Acc& acc, uint32_t flags, const Row* rows, const uint8_t* heap, const uint32_t* bounds) {
   uint64_t B = 0;
-  Results res = {0, 0, 0};
+  Results res = {};
   uint32_t cur[GK_MAX_SCOPES];
   uint32_t loop_pc[8];
   uint32_t loop_scope[8];
@@ -626,7 +628,7 @@ GK_HD Results eval_formulas(const PlanView& pv, Acc& acc, uint32_t flags, const 
       }
       case F_RES: {
         uint64_t v = (B >> a) & 1;
-        if (b == 0) res.viol |= v << c;
+        if (b == 0) res.viol[c >> 6] |= v << (c & 63u);
         else if (b == 1) res.match |= v << c;
         else res.err |= v << c;
         break;

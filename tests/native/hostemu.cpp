@@ -94,9 +94,10 @@ DevPlan* dev_plan_upload(int, const HostPlan& fast, const HostPlan& big) {
            "extern \"C\" void gk_he_form(const gk::PlanView* pv, std::vector<uint32_t>* w, uint32_t flags, const gk::Row* rows, const uint8_t* heap, const uint32_t* bounds, gk::Results* out) {\n"
            "  VecAcc acc{w}; std::vector<uint32_t> w2 = *w; VecAcc acc2{&w2};\n"
            "  gk::Results mono = gk::jit_formulas(*pv, acc2, flags, rows, heap, bounds);\n"
-           "  gk::Results r = {0, 0, 0};\n"
+           "  gk::Results r = {};\n"
            "  for (uint32_t st = 0; st < gk::GK_N_STAGES; st++) for (uint32_t wv = 0; wv < gk::GK_GEN_PARTS; wv++) gk::jit_formula_part(st * gk::GK_GEN_PARTS + (gk::GK_GEN_PARTS - 1 - wv), acc, flags, heap, bounds, r, nullptr);\n"
-           "  if (r.viol != mono.viol || r.match != mono.match || r.err != mono.err) { r.viol = ~0ull; r.match = ~0ull; r.err = ~0ull; }   // staged and monolithic code must agree\n"
+           "  bool same = r.match == mono.match && r.err == mono.err; for (int k = 0; k < gk::GK_VIOL_WORDS; k++) same = same && r.viol[k] == mono.viol[k];\n"
+           "  if (!same) { for (int k = 0; k < gk::GK_VIOL_WORDS; k++) r.viol[k] = ~0ull; r.match = ~0ull; r.err = ~0ull; }   // staged and monolithic code must agree\n"
            "  *out = r; }\n";
     }
     // The same policy sets are loaded by many tests: the g++ run (about a second) is skipped when this exact text -- and the
@@ -398,7 +399,7 @@ void dev_eval_finish(const DevPlan* p, const DevTable* dt, const EvalOptions& op
   auto t0 = std::chrono::steady_clock::now();
   for (uint32_t r = 0; r < n; r++) {
     uint32_t tile = r / GK_TILE; uint64_t bit = 1ull << (r % GK_TILE);
-    Results res{0, 0, 0};
+    Results res{};
     if (t.rflags[r] & RF_SKIP) continue;   // like the kernel's `usable` mask
     if (t.rflags[r] & RF_REFUSE) { o->too_big[tile] |= bit; continue; }
     if (!eval_review(p->fast, t, r, &res, p->row ? p : nullptr)) {
@@ -408,7 +409,7 @@ void dev_eval_finish(const DevPlan* p, const DevTable* dt, const EvalOptions& op
     for (uint32_t c = 0; c < nc; c++) {
       ConstraintSlot sl = p->fast.slots[c];
       const bool prem = (t.rflags[r] & RF_PREMATCHED) != 0;   // (kernel_body.inc: the caller matched, nothing is autorejected)
-      bool m = prem || ((res.match >> sl.match) & 1), e = !prem && ((res.err >> sl.match) & 1), v = m && ((res.viol >> sl.viol) & 1);
+      bool m = prem || ((res.match >> sl.match) & 1), e = !prem && ((res.err >> sl.match) & 1), v = m && res.viol_bit(sl.viol);
       if (opt.want_match && m) o->match[(size_t)c * nt + tile] |= bit;
       if (e) o->err[(size_t)c * nt + tile] |= bit;
       if (v) {
@@ -590,11 +591,11 @@ static void emu_kernel_check(const DevPlan* p, const DevTable* dt, const EvalOpt
       const uint32_t r = w * GK_TILE + (uint32_t)__builtin_ctzll(m);
       const uint64_t bit = 1ull << (r % GK_TILE);
       n_ovf++;
-      Results res{0, 0, 0};
+      Results res{};
       if (!eval_review(p->big, t, r, &res)) { big[w] |= bit; continue; }
       for (uint32_t c = 0; c < nc; c++) {
         ConstraintSlot sl = hp.slots[c];
-        const bool m_ = (res.match >> sl.match) & 1, e = (res.err >> sl.match) & 1, v = m_ && ((res.viol >> sl.viol) & 1);
+        const bool m_ = (res.match >> sl.match) & 1, e = (res.err >> sl.match) & 1, v = m_ && res.viol_bit(sl.viol);
         if (opt.want_match && m_) match[(size_t)c * nt + w] |= bit;
         if (e) err[(size_t)c * nt + w] |= bit;
         if (v) { viol[(size_t)c * nt + w] |= bit; lcnt[0]++; }   // (the big kernel appends its pairs to the same list)

@@ -132,3 +132,18 @@ def assert_parity(c, oc, reviews, ep=D.AUDIT_EP, namespaces=None, refused=None):
     finally:
         table.free()
     return total
+
+
+import contextlib   # noqa: E402
+
+
+@contextlib.contextmanager
+def plan_group_max(lib, n):
+    """gk_debug_set("group_max", n) for the policy changes inside the block: plan groups of at most n constraints -- what rounds 1-5 did
+    at 64; since round 6 a plan holds up to 256 distinct violation formulas and the in-tree corpora are ONE plan.  The several-group path
+    (still taken beyond 256 violation / 64 match formulas) stays tested through this knob."""
+    assert lib.gk_debug_set(b"group_max", int(n)) == 0
+    try:
+        yield
+    finally:
+        lib.gk_debug_set(b"group_max", 0)

@@ -91,7 +91,13 @@ def test_other_configs_legs_run_on_the_cpu_build(fixtures, monkeypatch):
     assert out["parity_compiled_independent"]["pairs_equal"] and out["parity_compiled_independent"]["n"] == 384
     assert out["plan_groups"] == 1 and out["roofline"]["algo_bytes_per_sweep_table_once"] == out["roofline"]["algo_bytes_per_sweep_every_group"] > 0
     sa = argparse.Namespace(stream_batches=2, warmup=1, stream_unique=2, batch=128, offered=0.0)
-    out, stream = bench.side_point(4, 256, 1, 0, 64, 0, fixtures, nss, with_stream=True, stream_args=sa, dev=None, totals=True, n_templates=140)
+    from gatekeeper_amd import _lib
+    lib = _lib.load(hostemu=True)
+    lib.gk_debug_set(b"group_max", 64)     # (the several-group legs of the bench: the corpus is one plan since round 6)
+    try:
+        out, stream = bench.side_point(4, 256, 1, 0, 64, 0, fixtures, nss, with_stream=True, stream_args=sa, dev=None, totals=True, n_templates=140)
+    finally:
+        lib.gk_debug_set(b"group_max", 0)
     tl = out["audit_result_totals"]
     assert "error" not in tl and tl["host_pass_over_every_pair"]["equal"] and tl["results"] > tl["violating_pairs"] and tl["rendered_share"] < 0.1, tl
     assert out["plan_groups"] == 3 and out["parity_python_oracle"]["pairs_equal"], out.get("parity_python_oracle")

@@ -118,6 +118,8 @@ def test_disk_cache_is_on_by_default_and_serves_a_restarted_engine(fixtures, tmp
         groups = int(ev.n_plan_groups)
         table.free(); batch.free(); drv.engine.close()
         return drv.engine.lib, counts, groups, dt
+    from gatekeeper_amd import _lib
+    _lib.load(hostemu=False).gk_debug_set(b"group_max", 64)    # (several plan groups: the corpus is one plan since round 6)
     lib, counts_cold, groups, dt_cold = sweep()
     assert groups == 3
     cache = os.path.join(str(tmp_path), "gkgpu-jit")
@@ -134,4 +136,5 @@ def test_disk_cache_is_on_by_default_and_serves_a_restarted_engine(fixtures, tmp
     assert dt_warm < dt_cold
     # switched off: no directory, no files
     monkeypatch.setenv("GK_JIT_CACHE_DIR", "off")
+    lib.gk_debug_set(b"group_max", 0)
     assert lib.gk_jit_cache_dir() == b""

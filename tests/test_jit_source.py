@@ -172,9 +172,13 @@ def test_library_pattern_sources_compile_for_gfx950(monkeypatch, tmp_path):
         ok, log, _ = compile_gfx950(rtc, text)
         assert ok, "%s does not compile for gfx950:\n%s" % (name, log[-3000:])
 
-def test_corpus_plan_sources_compile_for_gfx950_and_keep_their_prefetch_distance(monkeypatch, tmp_path):
-    """the 200-template corpus: every plan group's text (128-review groups) through hiprtc; the next item's row loads are not waited for
-    behind their request in any of them"""
+@pytest.mark.parametrize("group_max", [0, 64], ids=["one-plan", "groups-of-64"])
+def test_corpus_plan_sources_compile_for_gfx950_and_keep_their_prefetch_distance(monkeypatch, tmp_path, group_max):
+    """the 200-template corpus -- as the ONE plan it is since round 6 (two banks of violation result slots) and as the plan groups of at most
+    64 constraints of rounds 1-5: every text (128-review groups) through hiprtc; the next item's row loads are not waited for behind their
+    request in any of them"""
+    from gatekeeper_amd import _lib
+    lib = _lib.load(hostemu=True)
     rtc = _hiprtc()
     if rtc is None:
         pytest.skip("libhiprtc.so is not installed")
@@ -193,8 +197,12 @@ def test_corpus_plan_sources_compile_for_gfx950_and_keep_their_prefetch_distance
         table = drv.engine.create_table_native(batch.reviews, n, keep_docs=False, resident=True)
         table.launch()
         table.eval(download=True, collect_only=True)
-    texts = _dump_sources(monkeypatch, tmp_path, run)
-    assert len(texts) >= 3
+    assert lib.gk_debug_set(b"group_max", group_max) == 0
+    try:
+        texts = _dump_sources(monkeypatch, tmp_path, run)
+    finally:
+        lib.gk_debug_set(b"group_max", 0)
+    assert len(texts) >= 3 if group_max else len(texts) == 1
     for name, text in texts:
         ok, log, code = compile_gfx950(rtc, text)
         assert ok, "%s does not compile for gfx950:\n%s" % (name, log[-3000:])

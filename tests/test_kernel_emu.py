@@ -47,10 +47,17 @@ def test_kernel_source_on_the_emulator(monkeypatch, mode, env):
     _sweep(monkeypatch, mode, env.get("N", 1500), {k: v for k, v in env.items() if k != "N"})
 
 
-def test_corpus_plan_groups_on_the_emulator(monkeypatch):
-    """The 200-template corpus: four plan groups, up to 64 result slots per kind -- lanes 32..63 of the result registers (jit_source.hpp
-    jit_res_macros: GK_RES keeps a slot's word in lane `slot`, GK_RES_FLUSH stores the part's slots), element scopes read at use with
-    rolling registers, 128-review groups; the plan-specialised text on the emulator against the per-review evaluation."""
+@pytest.mark.parametrize("group_max", [0, 64], ids=["one-plan", "groups-of-64"])
+def test_corpus_plan_groups_on_the_emulator(monkeypatch, group_max):
+    """The 200-template corpus.  one-plan (round 6): ONE plan of 102 distinct violation formulas -- two banks of 64 violation result slots
+    (jit_source.hpp jit_res_macros: kinds 0 and 3, a register pair each; the output stage gathers a constraint's word from the bank its
+    slot lives in), constraints beyond the first 64 read their slots from the plan's slot table.  groups-of-64: the four plan groups of
+    rounds 1-5 (the path a set beyond 256 formulas still takes), up to 64 result slots per kind -- lanes 32..63 of the result registers,
+    element scopes read at use with rolling registers.  128-review groups; the plan-specialised text on the emulator against the
+    per-review evaluation."""
+    from gatekeeper_amd import _lib
+    lib = _lib.load(hostemu=True)
+    assert lib.gk_debug_set(b"group_max", group_max) == 0
     monkeypatch.setenv("GK_HOSTEMU_KERNEL", "jit")
     monkeypatch.setenv("GK_EMU_GRID", "8")
     fx = synth.load_fixtures()
@@ -65,5 +72,8 @@ def test_corpus_plan_groups_on_the_emulator(monkeypatch):
     batch = synth.NativeBatch(drv.engine.lib, n, seed=synth.SEED, mixed=True, start=0, namespaces=synth.gen_namespaces())
     table = drv.engine.create_table_native(batch.reviews, n, keep_docs=False, resident=True)
     table.launch()
-    ev = table.eval(download=True, collect_only=True)     # raises EngineError when the emulated kernel and the per-review path differ
-    assert int(ev.n_plan_groups) >= 3 and int(ev.counts.sum()) > 1000
+    try:
+        ev = table.eval(download=True, collect_only=True)     # raises EngineError when the emulated kernel and the per-review path differ
+    finally:
+        lib.gk_debug_set(b"group_max", 0)
+    assert (int(ev.n_plan_groups) >= 3 if group_max else int(ev.n_plan_groups) == 1) and int(ev.counts.sum()) > 1000 and ev.n_constraints == 200

@@ -22,6 +22,9 @@ SHARDS = [451, 333]   # uneven, not multiples of 64
 def _client(policies="audit"):
     fx = synth.load_fixtures()
     c = D.Client(D.Driver(hostemu=True))
+    # (the corpus tests are about SEVERAL plan groups -- one evaluation + exchange per group: groups of at most 64 constraints, as in
+    #  rounds 1-5; since round 6 these corpora would be one plan.  Set in every process that builds a client, never reset: test processes)
+    c.driver.engine.lib.gk_debug_set(b"group_max", 0 if policies == "audit" else 64)
     templates, constraints = (synth.psp_templates(fx), synth.audit_constraints()) if policies == "audit" else synth.corpus(fx, 82)
     for t, k in zip(templates, constraints) if policies != "audit" else ():
         if "ContainerLimits" in k["kind"]:   # (0.9 s of policy load per copy, three processes: the CPU suite's budget; 74 constraints are left)
@@ -226,6 +229,7 @@ def _client3():
     """> 128 distinct formulas = three plan groups; K8sContainerLimits left out (0.9 s of policy load per copy, four processes)"""
     fx = synth.load_fixtures()
     c = D.Client(D.Driver(hostemu=True))
+    c.driver.engine.lib.gk_debug_set(b"group_max", 64)
     templates, constraints = synth.corpus(fx, 160)
     keep = [i for i, k in enumerate(constraints) if "ContainerLimits" not in k["kind"]]
     for i in keep:
