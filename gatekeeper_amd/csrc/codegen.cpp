@@ -117,6 +117,12 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts) {
     //  level with this one in round 3, 0.1299 against 0.1287 ms on configs[2], profiles/r03_variants_c_*.log, and was removed in round 5)
     o << "if (on) {\n      const uint32_t t = r.meta & 7u; (void)t;\n";
     const std::vector<Pred>& ps = classes[c];
+    // a CARRIER class (plan.hpp T_ABSENT): the path's rows carry an element marker besides the member's own predicates, and an element
+    // without the member has a row of type T_ABSENT there -- it exists for the marker alone: every other predicate of the class sees
+    // "no row" (`real`), as eval_pred does
+    bool mixed = false;
+    for (const Pred& p : ps) if (p.op == P_PRESENT && ps.size() > 1) mixed = true;
+    if (mixed) o << "      const bool real = t != 7u;\n";
     struct Group { int scope, level; bool always = false; std::vector<std::string> masks; std::vector<size_t> stores; bool present = false; };
     std::vector<Group> groups;          // element destinations by (scope, level)
     std::vector<std::string> gmasks;    // global destination words
@@ -209,6 +215,7 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts) {
         }
         default: break;
       }
+      if (mixed && !cond.empty()) cond = cond == "true" ? "real" : "real && (" + cond + ")";
       if (cond.empty()) o << "      { constexpr Pred P = " << pred_literal(p) << "; if (eval_pred(r, P, h, heap, cheap)) " << target[i] << " }\n";
       else if (cond == "true") o << "      " << target[i] << "\n";
       else o << "      if (" << cond << ") " << target[i] << "\n";
@@ -216,7 +223,7 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts) {
     for (const std::string& m : gmasks) o << "      if (" << m << ") acc.or_word(" << m.substr(2) << "u, " << m << ");\n";
     for (const Group& g : groups) {
       const Scope& sc = plan.scopes[g.scope];
-      std::string hit = g.always ? "true" : "";
+      std::string hit = g.always ? ((mixed && !(g.present && g.level < (int)GK_LEVEL_ROOT)) ? "real" : "true") : "";   // (only the marker's own group is written for a T_ABSENT row)
       if (!g.always) for (size_t k = 0; k < g.masks.size(); k++) hit += (k ? " | " : "") + g.masks[k];
       if (!g.always) hit = "(" + hit + ") != 0u";
       o << "      if (" << hit << ") {\n        const uint32_t ord = row_ordinal(r, " << g.level << "u);\n"
@@ -224,11 +231,14 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts) {
       std::string extra;
       // a stored value = the row's VALUE ID (plan.hpp); a row without one (non-empty container, stale table) or with the
       // overflow id cannot be compared: the review goes beyond the limits (vm_core.hpp P_STORE)
-      if (!g.stores.empty()) o << "          const uint32_t vid = row_vid(r);\n          if (vid == 0u || vid >= GK_VID_OVERFLOW) acc.or_word(0u, 1u); else {\n";
+      if (!g.stores.empty()) {
+        if (mixed) o << "          const uint32_t vid = real ? row_vid(r) : 0u;\n          if (real && (vid == 0u || vid >= GK_VID_OVERFLOW)) acc.or_word(0u, 1u); else {\n";
+        else o << "          const uint32_t vid = row_vid(r);\n          if (vid == 0u || vid >= GK_VID_OVERFLOW) acc.or_word(0u, 1u); else {\n";
+      }
       for (size_t i : g.stores) {
         const Pred& p = ps[i];
         if (scope_packed(sc)) extra += " | (vid << " + std::to_string(ELEM_VID_SHIFT) + "u)";
-        else o << "          acc.store_word(" << sc.val_off << "u + ord * " << val_stride(sc.nvals) << "u + " << p.bit << "u, vid);\n";
+        else o << "          " << (mixed ? "if (real) " : "") << "acc.store_word(" << sc.val_off << "u + ord * " << val_stride(sc.nvals) << "u + " << p.bit << "u, vid);\n";
       }
       if (g.present) {
         if (g.level > 0 && g.level < (int)GK_LEVEL_ROOT) extra += " | 1u | (row_ordinal(r, " + std::to_string(g.level - 1) + "u) << 24)";

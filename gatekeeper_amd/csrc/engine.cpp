@@ -475,6 +475,8 @@ DevPlan* plan_for_group(gk_engine* e, gk_table* t, size_t group, const HostPlan*
       const Pred& pr = base.path_preds[(ent >> 8) + j];
       if (pr.op != P_PRESENT || pr.dst != D_ELEM) continue;
       uint32_t need = p < t->path_max.size() ? t->path_max[p] : 0;
+      // (the marker rides on a member of the element -- plan.hpp T_ABSENT: the element count is the element path's, its parent)
+      if (const PathDict::Info in = e->dict.info((uint32_t)p); !in.is_elem && in.parent < t->path_max.size()) need = std::max(need, t->path_max[in.parent]);
       if (need > caps[pr.scope]) caps[pr.scope] = (uint16_t)std::min<uint32_t>(need, 255);
     }
   }

@@ -257,6 +257,22 @@ bool DictRegistry::guarded(const PathDict& dict, uint32_t path_id) const {
   return r;
 }
 
+bool DictRegistry::add_carrier(const Pattern& elem, const std::string& member, bool add, std::string* chosen) {
+  const std::string k = pattern_to_string(elem);
+  std::unique_lock<std::shared_mutex> l(mu_);
+  for (auto& c : carriers_) if (c.key == k) { if (chosen) *chosen = c.member; return true; }
+  if (!add || member.empty()) return false;
+  carriers_.push_back(Carrier{k, elem, member});
+  gen_++;   // tables flattened before this lack the T_ABSENT rows: they are stale (engine.cpp dict_gen)
+  if (chosen) *chosen = member;
+  return true;
+}
+bool DictRegistry::carrier_of(const PathDict& dict, uint32_t elem_path_id, std::string* member) const {
+  std::shared_lock<std::shared_mutex> l(mu_);
+  for (const auto& c : carriers_) if (pattern_matches(c.elem, dict, elem_path_id)) { if (member) *member = c.member; return true; }
+  return false;
+}
+
 bool DictRegistry::add_value(const Pattern& leaf, bool add) {
   const std::string k = pattern_to_string(leaf);
   std::unique_lock<std::shared_mutex> l(mu_);
@@ -600,8 +616,19 @@ void Flattener::begin_table() {
   if (reg_) {
     const uint64_t g = reg_->gen();
     const uint64_t rg = reg_->reads_gen();
-    if (g != reg_gen_ || rg != reads_gen_seen_) { dict_paths_.clear(); pbits_.clear(); kid_filter_.clear(); kid_arena_.clear(); reg_gen_ = g; reads_gen_seen_ = rg; }
+    if (g != reg_gen_ || rg != reads_gen_seen_) { dict_paths_.clear(); pbits_.clear(); kid_filter_.clear(); kid_arena_.clear(); carrier_cache_.clear(); reg_gen_ = g; reads_gen_seen_ = rg; }
   }
+}
+
+// the carrier member's path of an element path (plan.hpp T_ABSENT), 0 = none
+uint32_t Flattener::carrier_slow(uint32_t elem_path) {
+  if (elem_path >= carrier_cache_.size()) carrier_cache_.resize((size_t)elem_path * 2 + 64, 0);
+  std::string member;
+  uint32_t v = 1u;
+  if (reg_ && reg_->carrier_of(*dict_, elem_path, &member)) v = 2u + child(elem_path, member);
+  if (elem_path >= carrier_cache_.size()) carrier_cache_.resize((size_t)elem_path * 2 + 64, 0);   // (child() may have grown the dictionary, not this vector: kept for symmetry)
+  carrier_cache_[elem_path] = v;
+  return v == 1u ? 0u : v - 2u;
 }
 
 // is a dictionary predicate registered for this leaf path? (cached per path; the cache follows the registry's generation)
@@ -857,6 +884,12 @@ bool Flattener::emit(uint32_t path, uint32_t meta, uint32_t lo, uint32_t hi, boo
   return true;
 }
 
+// the row that exists for the element marker alone (plan.hpp T_ABSENT): no value, hence no value id, no message key, no dictionary row
+void Flattener::emit_absent(uint32_t path, uint32_t meta) {
+  if (!(pbits(path) & PB_ROW)) return;
+  stage_.push_back({path, Row{rev_cur_, (meta & ~ROW_TYPE_MASK) | T_ABSENT, 0u, 0u}, StrHdr{{0, 0, 0, 0}}});
+}
+
 uint32_t Flattener::put_string(const std::string& s, uint32_t* hash) {
   // 16-byte aligned, zero-padded entry [u32 len][bytes][pad]: one aligned 16 B load fetches len + the first 12 bytes
   PodVec<uint8_t>& h = t_->heap;
@@ -942,6 +975,12 @@ void Flattener::walk(const Value& v, uint32_t path, uint32_t ords, int adepth, u
         } else ex |= ROW_DEEP;
         if (pruning_ && !(read_state(ep) & 2u)) continue;   // (the ordinal is taken: the elements that ARE walked count as in the parser)
         walk(e, ep, o2, adepth + 1, ex);
+        // element carrier (plan.hpp T_ABSENT): exactly one row at the carrier member's path per element
+        if (const uint32_t cp = carrier_child(ep)) {
+          bool has = false;
+          if (e.is_object()) { const std::string& mk = dict_->info(cp).key; for (const auto& kv : e.pairs()) if (kv.first.is_string() && kv.first.str() == mk) { has = true; break; } }
+          if (!has) emit_absent(cp, o2 | ex);
+        }
       }
       break;
     }
@@ -1409,7 +1448,13 @@ int Flattener::fast_value(uint32_t path, uint32_t ords, int adepth, uint32_t ext
         o2 |= ord << (ROW_E_SHIFT0 + 8 * adepth);
       } else ex |= ROW_DEEP;
       if (pruning_ && !(read_state(ep) & 2u)) { if (skip_value(depth + 1) < 0) return -1; }
-      else if (fast_value(ep, o2, adepth + 1, ex, depth + 1) < 0) return -1;
+      else {
+        // element carrier (plan.hpp T_ABSENT): an object that held the carrier member marked its path with an instance number drawn
+        // while this element was parsed (dup_gen_); anything else gets the row that exists for the element marker alone
+        const uint32_t cp = carrier_child(ep), inst0 = obj_instance_;
+        if (fast_value(ep, o2, adepth + 1, ex, depth + 1) < 0) return -1;
+        if (cp && !(cp < dup_gen_.size() && dup_gen_[cp] > inst0)) emit_absent(cp, o2 | ex);
+      }
       count++;
       ws();
       if (p_ < e_ && *p_ == ',') { p_++; continue; }
@@ -1818,7 +1863,11 @@ int Flattener::ix_value(uint32_t path, uint32_t ords, int adepth, uint32_t extra
         o2 |= ord << (ROW_E_SHIFT0 + 8 * adepth);
       } else ex |= ROW_DEEP;
       if (skip_elems) { if (ix_skip(depth + 1) < 0) return -1; }
-      else if (ix_value(ep, o2, adepth + 1, ex, depth + 1) < 0) return -1;
+      else {
+        const uint32_t cp = carrier_child(ep), inst0 = obj_instance_;   // (element carrier: see fast_value)
+        if (ix_value(ep, o2, adepth + 1, ex, depth + 1) < 0) return -1;
+        if (cp && !(cp < dup_gen_.size() && dup_gen_[cp] > inst0)) emit_absent(cp, o2 | ex);
+      }
       count++;
       if (ixp_ >= ix_n_) return -1;
       const char d = js[ix_[ixp_]];

@@ -112,6 +112,12 @@ class DictRegistry {
   // synthetic row  review.$dup : true ; the counting plans then leave the review's pairs to the host renderer.
   bool add_key(const Pattern& leaf, bool add = true);
   bool keyed(const PathDict& dict, uint32_t path_id) const;
+  // Element carriers (plan.hpp T_ABSENT): `elem` = an array-element pattern X[] the plans iterate, `member` = the member of the element
+  // whose rows carry the element marker.  ONE carrier per element pattern, first come first served: *chosen = the registered member
+  // (the caller's or an earlier one).  false: none registered (and add = false, or no member offered).  A new carrier makes the
+  // tables flattened so far stale (gen): they lack the T_ABSENT rows of elements without the member.
+  bool add_carrier(const Pattern& elem, const std::string& member, bool add, std::string* chosen);
+  bool carrier_of(const PathDict& dict, uint32_t elem_path_id, std::string* member) const;
   // The COUNTING space (round 4): the dictionary expressions the result-counting plans read live in a registry of their own and
   // travel in a row of their own, <leaf>.$c -- the 62 bits per leaf of <leaf>.$d belong to the violation formulas alone (a
   // constraint must never become unloadable because the totals of another one took its bits).
@@ -134,6 +140,8 @@ class DictRegistry {
   mutable std::shared_mutex mu_;
   std::vector<Pat> pats_;
   std::vector<std::pair<std::string, Pattern>> guards_, values_, keys_;
+  struct Carrier { std::string key; Pattern elem; std::string member; };
+  std::vector<Carrier> carriers_;
   std::atomic<uint64_t> gen_{0};
   std::unique_ptr<DictRegistry> counting_;
   std::vector<std::pair<std::string, Pattern>> reads_;
@@ -351,6 +359,13 @@ class Flattener {
   // everything the hot path asks about a path, in one byte (lazily derived from the caches above; dropped with them)
   enum : uint8_t { PB_KNOWN = 1, PB_ROW = 2 /* rows of the path are kept */, PB_BELOW = 4 /* the parser must visit it */, PB_VALUE = 8, PB_KEY = 16, PB_DICT = 32, PB_GUARD = 64, PB_DEEP = 128 };
   std::vector<uint8_t> pbits_;
+  // per element path: 0 = not looked up yet, 1 = no carrier, else 2 + the path id of the carrier member (follows the registry's generation)
+  std::vector<uint32_t> carrier_cache_;
+  uint32_t carrier_slow(uint32_t elem_path);
+  uint32_t carrier_child(uint32_t elem_path) {   // 0: the element pattern has no carrier
+    if (elem_path < carrier_cache_.size()) { const uint32_t c = carrier_cache_[elem_path]; if (c) return c == 1u ? 0u : c - 2u; }
+    return carrier_slow(elem_path);
+  }
   // WANTED MEMBERS of an object path in a pruned table (round 4): when no row of the object itself is kept, only the members some
   // pattern names can matter -- the others are walked past without a path id (no hashing of label keys, env names, port fields)
   struct KidEnt { uint32_t id, off, len; };
@@ -387,6 +402,7 @@ class Flattener {
   uint32_t child(uint32_t parent, const std::string& key);
   uint32_t elem(uint32_t parent);
   void walk(const Value& v, uint32_t path, uint32_t meta_ords, int adepth, uint32_t extra);
+  void emit_absent(uint32_t path, uint32_t meta);   // the carrier row of an element without the carrier member (plan.hpp T_ABSENT)
   bool emit(uint32_t path, uint32_t meta, uint32_t lo, uint32_t hi, bool always = false);   // false: a pruned table does not hold rows of this path
   uint32_t put_string(const std::string& s, uint32_t* hash);
   void emit_str(uint32_t parent, const char* key, const std::string& s);

@@ -742,6 +742,7 @@ struct Lowerer {
   std::map<std::string, uint32_t> global_bits;            // canonical pred key -> global bit
   std::map<std::string, uint32_t> scope_ids;              // element pattern -> scope
   std::vector<Pattern> scope_patterns;
+  std::vector<size_t> present_pred;   // per scope: index of its P_PRESENT predicate in plan.preds (SIZE_MAX: the root scope has none)
   std::vector<int> scope_level;
   std::vector<std::map<std::string, uint32_t>> elem_bits;  // per scope
   std::vector<std::map<std::string, uint32_t>> val_slots;  // per scope
@@ -891,6 +892,7 @@ struct Lowerer {
     scope_nbits.push_back(1);
     Pred p{};
     p.op = P_PRESENT; p.dst = D_ELEM; p.scope = (uint8_t)id; p.level = (uint8_t)level;
+    present_pred.push_back(plan.preds.size());
     plan.preds.push_back(p);
     plan.pred_patterns.push_back(pat);
     return id;
@@ -909,6 +911,7 @@ struct Lowerer {
     val_slots.emplace_back();
     derived_elem.emplace_back();
     scope_nbits.push_back(1);
+    present_pred.push_back(SIZE_MAX);
     return id;   // (no P_PRESENT predicate: a stored value marks the element, vm_core.hpp / codegen.cpp)
   }
 
@@ -1682,6 +1685,33 @@ HostPlan PlanBuilder::build(const PlanCaps& caps) {
     // rows that are compared with other review values need VALUE IDS: the flattener assigns them on the registered paths
     for (size_t i = 0; i < L.plan.preds.size(); i++)
       if (L.plan.preds[i].op == P_STORE && !reg_->add_value(L.plan.pred_patterns[i], !frozen_)) throw Unsupported("unsupported on the device plan: needs value ids no loaded constraint registered");
+  }
+  // ELEMENT CARRIERS (plan.hpp T_ABSENT, round 6).  A scope's element marker is read from the rows of ONE member of the element instead of
+  // the element's own rows, when the registry names a carrier for the element pattern -- or this plan can offer one: a member of the
+  // element it has a predicate on anyway (`name`, in every in-tree template that iterates containers / volumes / volumeMounts: half
+  // of configs[2]'s rows were such pairs).  The flattener guarantees one row at the carrier's path per element.  GK_CARRIERS=0: off.
+  static const bool carriers_on = !(getenv("GK_CARRIERS") && atoi(getenv("GK_CARRIERS")) == 0);
+  if (reg_ && carriers_on) {
+    for (size_t s = 0; s < L.scope_patterns.size(); s++) {
+      const size_t pi = s < L.present_pred.size() ? L.present_pred[s] : SIZE_MAX;
+      if (pi == SIZE_MAX) continue;
+      const Pattern elem = L.scope_patterns[s];
+      const std::string prefix = pattern_to_string(elem);
+      std::string offer;
+      for (size_t q = 0; q < L.plan.pred_patterns.size(); q++) {
+        const Pattern& pat = L.plan.pred_patterns[q];
+        if (q == pi || pat.size() != elem.size() + 1) continue;
+        const PatStep& last = pat.back();
+        if (last.any || last.key.empty() || last.key[0] == '$') continue;
+        if (pattern_to_string(Pattern(pat.begin(), pat.end() - 1)) != prefix) continue;
+        if (last.key == "name") { offer = "name"; break; }
+        if (offer.empty() || last.key < offer) offer = last.key;
+      }
+      std::string chosen;
+      if (!reg_->add_carrier(elem, offer, !frozen_, &chosen)) continue;
+      PatStep step; step.key = chosen;
+      L.plan.pred_patterns[pi].push_back(step);
+    }
   }
   HostPlan& p = L.plan;
   {   // derived-bit prologue blocks first (inner blocks were completed, hence appended, before outer ones)

@@ -70,7 +70,14 @@ constexpr uint32_t GK_VID_BITS = 16;             // ids fit the element word (Sc
 constexpr uint32_t GK_VID_OVERFLOW = (1u << GK_VID_BITS) - 1u;
 constexpr uint32_t GK_VID_NULL = 1, GK_VID_FALSE = 2, GK_VID_TRUE = 3, GK_VID_EMPTY_ARRAY = 4, GK_VID_EMPTY_OBJECT = 5, GK_VID_FIRST = 6;
 
-enum RowType : uint32_t { T_NULL = 0, T_BOOL = 1, T_INT = 2, T_FLOAT = 3, T_STRING = 4, T_OBJECT = 5, T_ARRAY = 6 };
+enum RowType : uint32_t { T_NULL = 0, T_BOOL = 1, T_INT = 2, T_FLOAT = 3, T_STRING = 4, T_OBJECT = 5, T_ARRAY = 6,
+                          // ELEMENT CARRIERS (round 6).  Half of the rows a sweep read were pairs: an array element's own row (the element
+                          // marker: presence, parent ordinal, count) and the row of its `name` member (a value id, a test).  The plans now
+                          // hang the marker on the rows of ONE member of the element -- the carrier, registered per element pattern
+                          // (flatten.hpp DictRegistry::add_carrier) -- and the flattener guarantees exactly one row at the carrier's path per
+                          // element: the member's own row, or, for an element without the member (or one that is no object), a row of THIS
+                          // type, which exists for the marker alone: every other predicate treats it as "no row" (vm_core.hpp eval_pred).
+                          T_ABSENT = 7 };
 
 constexpr uint32_t ROW_TYPE_MASK = 0x7;
 constexpr uint32_t ROW_RESERVED3 = 1u << 3;    // unused

@@ -342,6 +342,7 @@ GK_HD bool eval_split_prefix(const StrRef& s, const SplitMask& sm, const Pred& p
 
 GK_HD bool eval_pred(const Row& r, const Pred& p, const StrHdr& h, const uint8_t* heap, const uint8_t* cheap) {
   uint32_t t = row_type(r);
+  if (t == T_ABSENT) return p.op == P_PRESENT;   // a carrier row of an element without the member: it exists for the element marker alone (plan.hpp)
   switch (p.op) {
     case P_DEFINED: case P_PRESENT: case P_STORE: return true;
     case P_TRUTHY: return !(t == T_BOOL && r.lo == 0);
