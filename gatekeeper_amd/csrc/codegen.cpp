@@ -121,8 +121,11 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts) {
     // without the member has a row of type T_ABSENT there -- it exists for the marker alone: every other predicate of the class sees
     // "no row" (`real`), as eval_pred does
     bool mixed = false;
-    for (const Pred& p : ps) if (p.op == P_PRESENT && ps.size() > 1) mixed = true;
-    if (mixed) o << "      const bool real = t != 7u;\n";
+    for (const Pred& p : ps) if (p.op == P_PRESENT) mixed = true;
+    if (mixed) o << "      const bool real = t != 7u; (void)real;\n";
+    // (any other class: a T_ABSENT row may sit on its path all the same -- ANOTHER plan of the engine, or one loaded earlier, made the
+    //  path a carrier -- and is no row to this class at all)
+    else o << "      if (t != 7u) {\n";
     struct Group { int scope, level; bool always = false; std::vector<std::string> masks; std::vector<size_t> stores; bool present = false; };
     std::vector<Group> groups;          // element destinations by (scope, level)
     std::vector<std::string> gmasks;    // global destination words
@@ -255,6 +258,7 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts) {
       if (!g.stores.empty()) o << "          }\n";
       o << "        }\n      }\n";
     }
+    if (!mixed) o << "      }\n";
     o << "    }\n";
     case_body[c] = o.str();
   }

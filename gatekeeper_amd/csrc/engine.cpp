@@ -646,9 +646,11 @@ std::shared_ptr<const Template::CountForms> derive_count_forms(gk_engine* e, con
       std::function<void(const FP&)> walk = [&](const FP& f) {
         if (f->kind == FNode::ATOM) {
           if (f->atom.kind == Atom::DICT) {
-            if (!f->atom.alt) { e->dict_reg.counting().intern(pattern_of(f->atom.path), f->atom.dx, true); return; }
+            // (the review facts live in the main space, whoever asks: lower.cpp REVIEW FACTS)
+            const bool facts = review_fact_leaf(f->atom.path);
+            if (!f->atom.alt) { if (facts) e->dict_reg.intern(pattern_of(f->atom.path), f->atom.dx, true, nullptr, false); else e->dict_reg.counting().intern(pattern_of(f->atom.path), f->atom.dx, true); return; }
             // (a promoted group of row predicates: when the counting dictionary cannot take it the totals plan reads the rows)
-            try { e->dict_reg.counting().intern(pattern_of(f->atom.path), f->atom.dx, true); } catch (const std::runtime_error&) {}
+            try { if (facts) e->dict_reg.intern(pattern_of(f->atom.path), f->atom.dx, true, nullptr, true); else e->dict_reg.counting().intern(pattern_of(f->atom.path), f->atom.dx, true); } catch (const std::runtime_error&) {}
             walk(f->atom.alt);
             return;
           }
@@ -2942,6 +2944,7 @@ int gk_query_ex2(gk_engine* e, const gk_review_in* review, const uint32_t* const
 
 int gk_debug_set(const char* key, int64_t value) {
   if (!key) return fail(GK_ERR_INVALID, "NULL argument");
+  if (strcmp(key, "dict_facts") == 0) { g_debug_dict_facts.store(value != 0); return GK_OK; }
   if (strcmp(key, "group_max") == 0) { g_debug_group_max.store((int)std::max<int64_t>(0, std::min<int64_t>(value, 1 << 20))); return GK_OK; }
   if (strcmp(key, "fold_match_labels") == 0) { g_test_fold_match_labels.store(value != 0); return GK_OK; }
   return fail(GK_ERR_NOT_FOUND, std::string("gk_debug_set: unknown key ") + key);

@@ -154,7 +154,19 @@ bool match_group_pattern(const Pattern& p) {
   return p.size() == 3 && !p[0].any && p[0].key == "$m" && !p[1].any && !p[2].any && !p[2].key.empty() && p[2].key[0] != '$';
 }
 
-uint32_t DictRegistry::intern(const Pattern& leaf_in, const DX& dx, bool add) {
+std::atomic<int> g_debug_dict_facts{1};   // gk_debug_set("dict_facts", 0): a row per leaf, as before round 6 (test aid)
+bool review_fact_pattern(const Pattern& p) {
+  static const bool on = !(getenv("GK_DICT_FACTS") && atoi(getenv("GK_DICT_FACTS")) == 0);   // (A/B aid, read once: 0 keeps a row per leaf)
+  if (!on || !g_debug_dict_facts.load(std::memory_order_relaxed) || p.empty() || match_group_pattern(p)) return false;
+  for (const PatStep& st : p) if (st.any || st.key.empty()) return false;
+  // what lies INSIDE the candidate objects and the labels of the review's Namespace: every such leaf goes through the subtree parsers,
+  // which evaluate the dictionary expressions of whatever they meet.  (The members of the request envelope -- kind, operation, name,
+  // userInfo ... -- and the roots `object` / `oldObject` themselves are written by the envelope code: their tests stay row predicates.)
+  if (p.size() >= 2 && (p[0].key == "object" || p[0].key == "oldObject")) { for (size_t i = 1; i < p.size(); i++) if (p[i].key[0] == '$') return false; return true; }
+  return p.size() == 4 && p[0].key == "$ns" && p[1].key == "metadata" && p[2].key == "labels" && p[3].key[0] != '$';
+}
+
+uint32_t DictRegistry::intern(const Pattern& leaf_in, const DX& dx, bool add, bool* is_facts, bool has_fallback) {
   // Canonical form: an unfiltered iteration step is registered as "any child", whether the lowering reached the leaf through
   // an explicit element loop (elements only) or through a flat wildcard predicate (members and elements) -- the same leaf
   // must own ONE pattern, because bit numbers are per pattern and a path has one $d row.  (The device predicates keep their
@@ -171,14 +183,24 @@ uint32_t DictRegistry::intern(const Pattern& leaf_in, const DX& dx, bool add) {
     // same object) would need two $d rows on one path: refused here, at AddConstraint -- never at table creation
     for (auto& x : pats_) if (patterns_overlap(x.pat, leaf)) throw std::runtime_error("dictionary predicates on overlapping leaf patterns (" + x.key + " and " + pk + ")");
     pats_.push_back({leaf, pk, {}}); p = &pats_.back();
+    // REVIEW FACTS: a leaf without an iteration on the way joins the shared row -- when its first expression comes with a
+    // row-predicate fallback (a promoted test: if the 62 shared bits run out the lowering reads the leaf's rows instead).  A leaf whose
+    // first expression has none (quantity arithmetic, a deep expression) keeps its own row and its own 62 bits: it must never
+    // become unloadable because other leaves took the shared ones.
+    p->facts = has_fallback && review_fact_pattern(leaf);
   }
+  if (is_facts) *is_facts = p->facts;
   for (auto& e : p->entries) if (e.key == dk) return e.bit;
   if (!add) throw std::runtime_error("needs a dictionary predicate no loaded constraint registered");
   // MATCH GROUP: the facts of one candidate (review.$m.<o|old>.<fact>) travel in ONE row, review.$m.<o|old>.$d -- their
   // expressions take their bits from one space (the flattener ORs the facts' masks, match_group_row)
   size_t used = p->entries.size();
   if (match_group_pattern(leaf)) { used = 0; for (auto& x : pats_) if (match_group_pattern(x.pat) && x.pat[1].key == leaf[1].key) used += x.entries.size(); }
-  if (used >= 62) throw std::runtime_error("more than 62 dictionary predicates on " + pk);
+  if (p->facts) { used = 0; for (auto& x : pats_) if (x.facts) used += x.entries.size(); }   // (one bit space for every leaf of the review facts row)
+  if (used >= 62) {
+    if (p->entries.empty()) { pats_.pop_back(); }   // (a pattern created for this expression alone does not stay behind empty)
+    throw std::runtime_error("more than 62 dictionary predicates on " + pk);
+  }
   p->entries.push_back({dx, dk, (uint32_t)used});
   p->memo.clear();
   gen_++;
@@ -208,14 +230,15 @@ bool DictRegistry::facts_get(uint64_t st, uint32_t path, uint8_t bit, Facts* out
   *out = facts_[path];
   return true;
 }
-void DictRegistry::match(const PathDict& dict, uint32_t path_id, std::vector<DictEntry>* out, int* pat_index) const {
+void DictRegistry::match(const PathDict& dict, uint32_t path_id, std::vector<DictEntry>* out, int* pat_index, bool* is_facts) const {
   const uint64_t st = stamp();
   Facts f;
+  if (is_facts) *is_facts = false;
   if (facts_get(st, path_id, F_PAT, &f)) {
     std::shared_lock<std::shared_mutex> l(mu_);
     out->clear();
     if (pat_index) *pat_index = -1;
-    if (f.pat >= 0 && (size_t)f.pat < pats_.size()) { *out = pats_[f.pat].entries; if (pat_index) *pat_index = f.pat; }
+    if (f.pat >= 0 && (size_t)f.pat < pats_.size()) { *out = pats_[f.pat].entries; if (pat_index) *pat_index = f.pat; if (is_facts) *is_facts = pats_[f.pat].facts; }
     return;
   }
   int found = -1;
@@ -231,6 +254,7 @@ void DictRegistry::match(const PathDict& dict, uint32_t path_id, std::vector<Dic
     if (!out->empty()) throw std::runtime_error("overlapping dictionary patterns on " + dict.to_string(path_id));
     *out = p.entries;
     if (pat_index) *pat_index = (int)i;
+    if (is_facts) *is_facts = p.facts;
     found = (int)i;
   }
 }
@@ -637,14 +661,14 @@ bool Flattener::dict_wanted(uint32_t path) {
   if (path >= dict_paths_.size()) dict_paths_.resize((size_t)path * 2 + 64);
   DictPath& d = dict_paths_[path];
   if (d.state == 0) {
-    reg_->match(*dict_, path, &d.entries, &d.pat);
+    reg_->match(*dict_, path, &d.entries, &d.pat, &d.facts);
     d.centries.clear(); d.cpat = -1;
     if (const DictRegistry* c = reg_->counting_if_any()) c->match(*dict_, path, &d.centries, &d.cpat);
     d.state = d.entries.empty() && d.centries.empty() ? 1 : 2;
     d.deep = false;
     for (const DictEntry& e : d.entries) if (dx_deep(e.dx)) d.deep = true;
     for (const DictEntry& e : d.centries) if (dx_deep(e.dx)) d.deep = true;
-    if (!d.entries.empty()) d.dpath = child(path, "$d");
+    if (!d.entries.empty() && !d.facts) d.dpath = child(path, "$d");
     if (!d.centries.empty()) d.cpath = child(path, "$c");
   }
   return dict_paths_[path].state == 2;
@@ -686,6 +710,7 @@ void Flattener::dict_row(uint32_t path, uint32_t meta, const Value& leaf, uint64
   one(reg_, d.pat, d.entries, d.memo, &masks[0]);
   if (!d.centries.empty()) one(reg_->counting_if_any(), d.cpat, d.centries, d.cmemo, &masks[1]);   // (<leaf>.$c: the counting plans' expressions)
   if (masks_out) { masks_out[0] = masks[0]; masks_out[1] = masks[1]; return; }
+  if (dict_paths_[path].facts) { facts_acc_ |= masks[0]; masks[0] = 0; }   // (a leaf of the review facts row: review.$r.$d, finish_tail)
   for (int k = 0; k < 2; k++)
     if (masks[k]) emit(dpaths[k], (meta & ~(uint32_t)ROW_TYPE_MASK & ~(uint32_t)ROW_STR_INLINE) | T_INT, (uint32_t)masks[k], (uint32_t)(masks[k] >> 32), true);
 }
@@ -749,6 +774,7 @@ void Flattener::dict_row_str(uint32_t path, uint32_t meta, const char* s, uint32
     }
   }
   if (masks_out) { masks_out[0] = masks[0]; masks_out[1] = masks[1]; return; }
+  if (dict_paths_[path].facts) { facts_acc_ |= masks[0]; masks[0] = 0; }   // (a leaf of the review facts row)
   const uint32_t dpaths[2] = {dict_paths_[path].dpath, dict_paths_[path].cpath};
   for (int k = 0; k < 2; k++)
     if (masks[k]) emit(dpaths[k], (meta & ~(uint32_t)ROW_TYPE_MASK & ~(uint32_t)ROW_STR_INLINE) | T_INT, (uint32_t)masks[k], (uint32_t)(masks[k] >> 32), true);
@@ -1081,18 +1107,22 @@ void Flattener::finish_review_memo(NsMemo* m, int source, HostTable* out) {
     const uint32_t cur = out->n_reviews % out->rpt;
     for (const Staged& s : m->rows) { stage_.push_back(s); stage_.back().row.rev = cur; }
     review_flags_ |= m->flags;
+    facts_acc_ |= m->facts;
   } else if (m->rows_state == 2) ns_rows(m->ns);
   else {   // record: the rows depend on the Namespace alone unless an emit interned a value id / compared a key or an array was counted
     const size_t s0 = stage_.size(), c0 = ctrs_.size(), t0 = ctr_touched_.size();
     const uint32_t f0 = review_flags_;
+    const uint64_t a0 = facts_acc_;
     review_flags_ = 0;
+    facts_acc_ = 0;
     emit_side_effects_ = false;
     ns_rows(m->ns);
     bool ok = !emit_side_effects_ && ctrs_.size() == c0 && ctr_touched_.size() == t0;
     for (size_t i = s0; i < stage_.size() && ok; i++) if (stage_[i].row.rev & ~ROW_REV_MASK) ok = false;
-    if (ok) { m->rows.assign(stage_.begin() + s0, stage_.end()); m->flags = review_flags_; m->owner = out; m->rows_state = 1; }
+    if (ok) { m->rows.assign(stage_.begin() + s0, stage_.end()); m->flags = review_flags_; m->facts = facts_acc_; m->owner = out; m->rows_state = 1; }
     else m->rows_state = 2;
     review_flags_ |= f0;
+    facts_acc_ |= a0;
   }
   finish_tail(source, out);
 }
@@ -1124,6 +1154,10 @@ void Flattener::finish_tail(int source, HostTable* out) {
   if (dup_seen_) {   // (round 4) two message keys of this review are equal: the counting plans leave it to the renderer
     if (!id_dup_) id_dup_ = child(0, "$dup");
     emit(id_dup_, T_BOOL, 1, 0, true);
+  }
+  if (facts_acc_) {   // (round 6) the review facts row: the answers of the dictionary expressions on the review's non-iterated leaves
+    if (!id_facts_d_) id_facts_d_ = child(child(0, "$r"), "$d");
+    emit(id_facts_d_, T_INT, (uint32_t)facts_acc_, (uint32_t)(facts_acc_ >> 32), true);
   }
   out->rflags.push_back(review_flags_);
   for (const Ctr& c : ctrs_) {

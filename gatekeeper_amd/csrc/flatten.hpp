@@ -83,6 +83,12 @@ bool pattern_matches(const Pattern& pat, const PathDict& dict, uint32_t path_id)
 bool pattern_reaches(const Pattern& pat, const PathDict& dict, uint32_t path_id, bool* full);
 // review.$m.<o|old>.<fact>: a leaf of a candidate's MATCH GROUP (the group's dictionary expressions share one row, see DictRegistry::intern)
 bool match_group_pattern(const Pattern& pat);
+// a leaf of the REVIEW FACTS group (round 6): no iteration step on the way (review.object.metadata.name, review.object.metadata.labels.env,
+// review.$ns.metadata.labels.pci, review.object.spec.hostNetwork ...), outside the match group.  Such a leaf occurs at most once per
+// review, so the dictionary expressions on ALL of them share one bit space and travel in ONE row per review, review.$r.$d (the
+// flattener ORs the leaves' masks) -- where every such leaf used to cost a row (and most a string header) and a chunk per row group.
+bool review_fact_pattern(const Pattern& pat);
+extern std::atomic<int> g_debug_dict_facts;
 
 // ------------------------------------------------------------------------------------------------ dictionary predicates
 // Leaf-local expressions (dexpr.hpp) registered by the loaded constraints: pattern of the leaf -> expressions, each with a
@@ -92,9 +98,11 @@ class DictRegistry {
  public:
   // bit of the expression on leaves matching `leaf`; throws std::runtime_error beyond 62 bits -- and, with add = false (a plan
   // that must live with what the loaded constraints registered: the totals plans), when the entry does not exist yet
-  uint32_t intern(const Pattern& leaf, const DX& dx, bool add = true);
+  // is_facts (may be NULL): the bit lives in the review facts row review.$r.$d, not in <leaf>.$d (review_fact_pattern; a leaf whose
+  // first expression arrived without a row-predicate fallback keeps a row of its own -- see intern)
+  uint32_t intern(const Pattern& leaf, const DX& dx, bool add = true, bool* is_facts = nullptr, bool has_fallback = false);
   uint64_t gen() const;                                  // bumped by every new entry
-  void match(const PathDict& dict, uint32_t path_id, std::vector<DictEntry>* out, int* pat_index = nullptr) const;   // entries for a concrete leaf path
+  void match(const PathDict& dict, uint32_t path_id, std::vector<DictEntry>* out, int* pat_index = nullptr, bool* is_facts = nullptr) const;   // entries for a concrete leaf path
   // answers shared by every flattener of the engine, per pattern: distinct value -> bit mask.  A value is evaluated once
   // per engine (not once per table part and thread); the memo of a pattern is dropped when it gains an expression.
   bool memo_get(int pat_index, size_t n_entries, const std::string& key, uint64_t* mask) const;
@@ -136,7 +144,7 @@ class DictRegistry {
   DictRegistry& counting() { std::unique_lock<std::shared_mutex> l(mu_); if (!counting_) counting_.reset(new DictRegistry()); return *counting_; }
   const DictRegistry* counting_if_any() const { std::shared_lock<std::shared_mutex> l(mu_); return counting_.get(); }
  private:
-  struct Pat { Pattern pat; std::string key; std::vector<DictEntry> entries; std::unordered_map<std::string, uint64_t> memo; };
+  struct Pat { Pattern pat; std::string key; std::vector<DictEntry> entries; std::unordered_map<std::string, uint64_t> memo; bool facts = false; /* bits of review.$r.$d */ };
   mutable std::shared_mutex mu_;
   std::vector<Pat> pats_;
   std::vector<std::pair<std::string, Pattern>> guards_, values_, keys_;
@@ -342,7 +350,7 @@ class Flattener {
   const DictRegistry* reg_ = nullptr;
   uint64_t reg_gen_ = ~0ull, reads_gen_seen_ = ~0ull;
   struct StrMemo { struct Ent { uint64_t hash = 0; uint32_t off = 0, len = 0; uint64_t m[2] = {0, 0}; }; std::vector<Ent> tab; size_t count = 0; std::string arena; };
-  struct DictPath { std::unique_ptr<StrMemo> smemo; int state = 0; int gstate = 0; int vstate = 0; int kstate = 0; uint32_t rstate = 0 /* 4 | read_state once known */; int pat = -1; bool deep = false /* some expression looks inside a container leaf */; std::vector<DictEntry> entries; uint32_t dpath = 0; std::unordered_map<std::string, uint64_t> memo;   // state 0 unknown, 1 none, 2 has entries
+  struct DictPath { std::unique_ptr<StrMemo> smemo; int state = 0; int gstate = 0; int vstate = 0; int kstate = 0; uint32_t rstate = 0 /* 4 | read_state once known */; int pat = -1; bool facts = false /* the main-space answers go to the review facts row, review.$r.$d */; bool deep = false /* some expression looks inside a container leaf */; std::vector<DictEntry> entries; uint32_t dpath = 0; std::unordered_map<std::string, uint64_t> memo;   // state 0 unknown, 1 none, 2 has entries
                     int cpat = -1; std::vector<DictEntry> centries; uint32_t cpath = 0; std::unordered_map<std::string, uint64_t> cmemo; /* the counting space: <leaf>.$c */ };
   std::vector<DictPath> dict_paths_;
   void dict_row(uint32_t path, uint32_t meta, const Value& leaf, uint64_t* masks_out = nullptr);   // emits <leaf>.$d / .$c when some registered expression is true (masks_out: hands the two masks back instead)
@@ -383,7 +391,9 @@ class Flattener {
   std::vector<uint32_t> key_ids_;     // value ids of the key rows of the current review
   bool dup_seen_ = false;             // ... two of them were equal (or not a scalar): review.$dup
   uint32_t id_dup_ = 0;
-  void begin_review_keys() { key_ids_.clear(); dup_seen_ = false; }
+  void begin_review_keys() { key_ids_.clear(); dup_seen_ = false; facts_acc_ = 0; }
+  uint64_t facts_acc_ = 0;   // the review facts row of the review being flattened (review.$r.$d), emitted by finish_tail
+  uint32_t id_facts_d_ = 0;
   // per-review interning of compared values -> value ids (plan.hpp ROW_VID_*)
   struct VidEnt { uint64_t key; uint32_t tag, off, id; };   // tag 1 number-as-int64, 2 float bits, 3 inline string, 4 heap string (key = hash32 | len << 32, off = heap offset)
   std::vector<VidEnt> vids_;
@@ -438,7 +448,7 @@ class Flattener {
   struct NsMemo {
     size_t len = 0; Value ns; std::string nsname;
     int rows_state = 0;               // 0 not recorded yet, 1 `rows` / `flags` replay, 2 not replayable (value ids, message keys, element counters)
-    std::vector<Staged> rows; uint32_t flags = 0; const HostTable* owner = nullptr;
+    std::vector<Staged> rows; uint32_t flags = 0; uint64_t facts = 0; const HostTable* owner = nullptr;
   };
   std::unordered_map<const char*, NsMemo> ns_memo_;
   std::unordered_map<std::string, NsMemo> ns_memo_name_;

@@ -12,6 +12,11 @@
 
 namespace gk {
 std::atomic<int> g_test_fold_match_labels{0};   // test aid, set through gk_debug_set("fold_match_labels", 1): nothing reads the environment while lowering
+bool review_fact_leaf(const SPath& p) {
+  Pattern pat;
+  for (const Step& st : p) { PatStep ps; if (st.iter) ps.any = true; else ps.key = st.key; pat.push_back(ps); }
+  return review_fact_pattern(pat);
+}
 
 // ================================================================================================ match blocks
 namespace {
@@ -544,6 +549,12 @@ bool match_fact_leaf(const SPath& p) {
   static const bool on = !(getenv("GK_DICT_MATCH") && atoi(getenv("GK_DICT_MATCH")) == 0);
   return on && p.size() == 3 && !p[0].iter && p[0].key == "$m" && !p[1].iter && !p[2].iter && !p[2].key.empty() && p[2].key[0] != '$';
 }
+// REVIEW FACTS (round 6).  A leaf that no iteration leads to -- review.object.metadata.name (every library template's message names the
+// object: `def(review.object.metadata.name)`, a row per review and a chunk per row group for ONE bit), the labels a selector or a
+// template names, review.$ns.metadata.labels.<k>, spec.hostNetwork ... -- occurs at most once per review.  Every leaf-local group on
+// such a leaf becomes a dictionary expression whatever it reads, and all of them share ONE row per review, review.$r.$d
+// (flatten.hpp review_fact_pattern; 62 bits for the loaded policy set: what does not fit keeps the rows).  configs[2]: a third of the
+// rows a sweep still read after the element carriers.  GK_DICT_FACTS=0 keeps a row per leaf (A/B aid).
 // (folding a MATCH formula promotes the match facts only: the labels a selector names keep their rows, which the counting plans --
 //  frozen, in the counting space -- lower the same way.  gk_debug_set("fold_match_labels", 1), test aid: promote them as well -- the counting
 //  plans then read label rows a pruned table does not hold, which is how tests/test_pruned.py reaches render_needed's unanswered plans)
@@ -551,6 +562,7 @@ static thread_local bool g_fold_match_only = false;
 static bool promotable_leaf(const SPath& p) {   // (the other synthetic subtrees -- $ns -- keep their rows)
   if (p.empty()) return false;
   if (match_fact_leaf(p)) return true;
+  if (review_fact_leaf(p)) return true;   // (in a match formula as well: the review facts live in the main space, whoever asks -- see the DICT lowering)
   if (g_fold_match_only && !g_test_fold_match_labels.load(std::memory_order_relaxed)) return false;
   for (auto& st : p) if (!st.iter && !st.key.empty() && st.key[0] == '$') return false;
   return true;
@@ -559,7 +571,7 @@ static bool promotable(const std::vector<FP>& g) {
   if (!promote_strings() || g.empty()) return false;
   const SPath* lp = leaf_path_of(g[0]);
   if (!lp || !promotable_leaf(*lp)) return false;
-  if (match_fact_leaf(*lp)) return true;
+  if (match_fact_leaf(*lp) || review_fact_leaf(*lp)) return true;
   for (auto& k : g) if (reads_string_bytes(k)) return true;
   return false;
 }
@@ -968,20 +980,24 @@ struct Lowerer {
       uint32_t bit;
       // (a match fact's expressions live in the main space, whoever asks: the constraint's own violation plan registered them -- the
       //  counting space is for what only the result counts read)
-      const bool cnt = counting && !match_fact_leaf(a.path);
+      // (... and so do the review facts: a leaf no iteration leads to keeps its expressions in the main space and its bits in review.$r.$d)
+      const bool cnt = counting && !match_fact_leaf(a.path) && !review_fact_leaf(a.path);
+      bool in_facts = false;
       if (a.alt) {   // a promoted group of row predicates: what the dictionary cannot take is evaluated from the rows, as before
         bool ok = true;
         for (auto& st : leaf_pat) if (st.any && !st.elems_only && (!st.only.empty() || !st.except.empty() || !st.kpreds.empty())) ok = false;
-        if (ok) { try { bit = (cnt ? &reg->counting() : reg)->intern(leaf_pat, a.dx, !frozen); } catch (const std::runtime_error&) { ok = false; } }
+        if (ok) { try { bit = (cnt ? &reg->counting() : reg)->intern(leaf_pat, a.dx, !frozen, &in_facts, true); } catch (const std::runtime_error&) { ok = false; } }
         if (!ok) { release(r); return lower(a.alt); }
       } else {
       for (auto& st : leaf_pat) if (st.any && !st.elems_only && (!st.only.empty() || !st.except.empty() || !st.kpreds.empty())) unsupported("dictionary predicate under a filtered key iteration");
-      try { bit = (cnt ? &reg->counting() : reg)->intern(leaf_pat, a.dx, !frozen); } catch (const std::runtime_error& ex) { unsupported(ex.what()); }
+      try { bit = (cnt ? &reg->counting() : reg)->intern(leaf_pat, a.dx, !frozen, &in_facts, false); } catch (const std::runtime_error& ex) { unsupported(ex.what()); }
       }
+      if (cnt) in_facts = false;
       Atom b;
       b.kind = Atom::DICT; b.path = a.path; b.dx = nullptr;
       Step st; st.key = cnt ? "$c" : "$d";
       if (match_fact_leaf(a.path)) b.path.pop_back();   // the candidate's five facts share review.$m.<o|old>.$d
+      if (in_facts) { b.path.clear(); Step rs; rs.key = "$r"; b.path.push_back(rs); }   // the review facts share review.$r.$d
       b.path.push_back(st);
       b.mask = bit;
       Pattern pat = pattern_of(b.path);

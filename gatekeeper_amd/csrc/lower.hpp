@@ -75,6 +75,7 @@ class PlanBuilder {
 };
 
 
+bool review_fact_leaf(const SPath& p);   // a leaf of the review facts row (lower.cpp REVIEW FACTS)
 // test aid (gk_debug_set "fold_match_labels"): match formulas' label tests become dictionary bits as well
 extern std::atomic<int> g_test_fold_match_labels;
 

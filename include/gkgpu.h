@@ -434,7 +434,8 @@ void gk_jit_cache_drop_memory(void);
  * Not for deployments.  Keys: "fold_match_labels" (0 | 1: the match formulas' label tests become dictionary bits as well -- how
  * tests/test_pruned.py reaches the totals plans a pruned table cannot answer); "group_max" (n > 0: no plan group of more than n
  * constraints, takes effect at the next policy change -- the several-group path, which a set of more than 256 distinct violation
- * formulas takes by itself, tested with small corpora; 0 = as many as fit).  GK_ERR_NOT_FOUND for an unknown key. */
+ * formulas takes by itself, tested with small corpora; 0 = as many as fit); "dict_facts" (0: the tests on a review's non-iterated leaves
+ * keep a row per leaf instead of sharing the review facts row, for the policies loaded while it is 0).  GK_ERR_NOT_FOUND for an unknown key. */
 int gk_debug_set(const char* key, int64_t value);
 
 /* Debug: the compiled plan as text (Driver.Dump, pkg/drivers/k8scel/driver.go:253). */

@@ -124,6 +124,7 @@ DevPlan* dev_plan_upload(int, const HostPlan& fast, const HostPlan& big) {
     p->form = (HeFormFn)dlsym(p->dl, "gk_he_form");
     std::vector<std::vector<Pred>> classes;
     p->cls = jit_path_classes(fast, &classes);
+    if (const char* keep = getenv("GK_HOSTEMU_KEEP_SRC")) { static int n_kept = 0; std::ofstream f(std::string(keep) + "/plan_" + std::to_string(getpid()) + "_" + std::to_string(n_kept++) + ".cpp"); f << src; }   // (debug aid)
     unlink((base + ".cpp").c_str()); unlink((base + ".so").c_str()); unlink((base + ".log").c_str());
   }
   return p;

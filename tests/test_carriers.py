@@ -89,3 +89,31 @@ def test_the_plans_read_member_rows_not_element_rows():
         assert n_containers <= ev.n_rows_read < 2 * n_containers
     finally:
         table.free()
+
+
+# ---- a T_ABSENT row sits on its path for EVERY plan of the engine, not only for the one that made the path a carrier (found by
+# tests/test_template_fuzz.py on the generated code, round 6)
+T_GT = tmpl("IGt", 'package k\nviolation[{"msg": "a > 2"}] {\n  e := input.review.object.spec.items[_]\n  e.a > 2\n}\n')                     # makes `a` the carrier of spec.items[]
+T_ANY = tmpl("IAnyA", 'package k\nviolation[{"msg": "some item has a"}] {\n  input.review.object.spec.items[_].a\n}\n')                       # a flat wildcard test on the carrier's path
+T_B = tmpl("IB", 'package k\nviolation[{"msg": msg}] {\n  e := input.review.object.spec.items[_]\n  e.b == 1\n  msg := "b is 1"\n}\n')       # iterates the same elements, never looks at `a`
+T_NOT = tmpl("INotA", 'package k\nviolation[{"msg": "an item without a"}] {\n  e := input.review.object.spec.items[_]\n  not e.a\n}\n')
+
+
+def _items(name, items):
+    return {"apiVersion": "v1", "kind": "Pod", "metadata": {"name": name, "namespace": "d"}, "spec": {"items": items}}
+
+
+ITEM_OBJS = [_items("none", [{"b": 1}]), _items("one", [{"a": 3, "b": 1}]), _items("mixed", [{"b": 2}, {"a": 1}, {"b": 1}, 7, []]), _items("empty", []),
+             _items("falsy", [{"a": False}, {"a": None}]), _items("nested", [{"a": {"a": 5}}, {"b": {"a": 3}}])]
+
+
+@pytest.mark.parametrize("group_max", [0, 1], ids=["one-plan", "a-plan-per-constraint"])
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_absent_rows_are_no_rows_to_other_predicates_and_other_plans(backend, group_max):
+    templates = [T_GT, T_ANY, T_B, T_NOT]
+    from parity_util import plan_group_max
+    from gatekeeper_amd import _lib
+    with plan_group_max(_lib.load(hostemu=backend.startswith("hostemu")), group_max):
+        c, oc = load_both(backend, templates, [con(t["spec"]["crd"]["spec"]["names"]["kind"]) for t in templates])
+        reviews = [D.AugmentedUnstructured(D.Unstructured(o), None, "Original") for o in ITEM_OBJS]
+        assert assert_parity(c, oc, reviews, D.GATOR_EP) >= 8
