@@ -245,6 +245,16 @@ std::shared_ptr<Regex> get_regex(const std::string& pat) {
   return r;
 }
 
+bool builtin_regex_search(const std::string& pat, const char* s, size_t n, bool* valid) {
+  // (a per-thread front of the locked cache: the ingest asks for the same handful of patterns millions of times)
+  static thread_local std::unordered_map<std::string, std::shared_ptr<Regex>> tl;
+  auto it = tl.find(pat);
+  if (it == tl.end()) it = tl.emplace(pat, get_regex(pat)).first;
+  if (!it->second) { *valid = false; return false; }
+  *valid = true;
+  return it->second->search(std::string(s, n));
+}
+
 namespace {
 
 // utf-8 helpers: strings are byte strings; Rego's count/substring work on code points

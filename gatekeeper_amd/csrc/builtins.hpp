@@ -13,4 +13,6 @@ Value rego_arith(const std::string& op, const Value& a, const Value& b);  // + -
 std::string go_sprintf(const std::string& fmt, const ValueVec& args);
 class Regex;
 std::shared_ptr<Regex> get_regex(const std::string& pat);   // compiled-pattern cache; nullptr for an invalid pattern
+// re_match(pat, <the n bytes at s>) without a Value: *valid = false for a pattern Go refuses (the builtin is then undefined)
+bool builtin_regex_search(const std::string& pat, const char* s, size_t n, bool* valid);
 }  // namespace gk

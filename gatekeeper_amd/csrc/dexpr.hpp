@@ -155,6 +155,38 @@ inline bool dx_true(const DX& e, const Value& leaf) { Value v = dx_eval(e, leaf)
 // dx_true for a STRING leaf given as bytes, for the shapes the lowering makes of string tests (comparisons with string constants,
 // startswith / endswith / contains, type tests, and / or / not over them): no Value, no allocation.  *ok = false: the expression holds
 // something else -- the caller asks dx_true.  (The match facts of a review -- names are as good as unique -- cannot go through a memo.)
+// split($, "<sep>") with a non-empty constant separator over the leaf itself (Go strings.Split: the components between the occurrences)
+inline bool dx_is_leaf_split(const DExpr& c, const std::string** sep) {
+  if (c.kind != DExpr::CALL || c.name != "split" || c.args.size() != 2 || c.args[0]->kind != DExpr::LEAF || c.args[1]->kind != DExpr::CONST || !c.args[1]->c.is_string()) return false;
+  *sep = &c.args[1]->c.str();
+  return !(*sep)->empty();
+}
+// The components of split(<leaf bytes>, sep), worked out ONCE per leaf value and separator: the dictionary expressions of a policy set ask
+// for them dozens of times per value (every banned-tag constraint its own `$index(split($, ":"), -1) == "..."`).  One slot per thread:
+// the entries of a leaf are evaluated one after the other on the same bytes.
+struct DxSplitCache { const char* s = nullptr; size_t n = 0; std::string sep; std::vector<uint32_t> cut; /* component k = [cut[2k], cut[2k+1]) */ };
+inline const DxSplitCache& dx_split_of(const char* s, size_t n, const std::string& sep) {
+  static thread_local DxSplitCache c;
+  if (c.s == s && c.n == n && c.sep == sep && !c.cut.empty()) return c;
+  c.s = s; c.n = n; c.sep = sep; c.cut.clear();
+  uint32_t start = 0;
+  for (size_t i = 0; i + sep.size() <= n;) {
+    if (memcmp(s + i, sep.data(), sep.size()) == 0) { c.cut.push_back(start); c.cut.push_back((uint32_t)i); i += sep.size(); start = (uint32_t)i; } else i++;
+  }
+  c.cut.push_back(start); c.cut.push_back((uint32_t)n);
+  return c;
+}
+inline void dx_split_forget() { const_cast<DxSplitCache&>(dx_split_of(nullptr, 0, std::string(1, '\0'))); }   // (the bytes behind a cached pointer may change: called per leaf value)
+inline size_t dx_split_count(const char* s, size_t n, const std::string& sep) { return dx_split_of(s, n, sep).cut.size() / 2; }
+// component `idx` (negative: from the end) of the split; false: out of range
+inline bool dx_split_component(const char* s, size_t n, const std::string& sep, long long idx, const char** cp, size_t* cn) {
+  const DxSplitCache& c = dx_split_of(s, n, sep);
+  const long long cnt = (long long)(c.cut.size() / 2);
+  if (idx < 0) idx += cnt;
+  if (idx < 0 || idx >= cnt) return false;
+  *cp = s + c.cut[2 * (size_t)idx]; *cn = c.cut[2 * (size_t)idx + 1] - c.cut[2 * (size_t)idx];
+  return true;
+}
 inline bool dx_true_str(const DX& e, const char* s, size_t n, bool* ok) {
   switch (e->kind) {
     case DExpr::CONST: if (e->c.is_bool()) return e->c.b; *ok = false; return false;
@@ -164,6 +196,28 @@ inline bool dx_true_str(const DX& e, const char* s, size_t n, bool* ok) {
     case DExpr::DEFINED: if (e->args.size() == 1 && e->args[0]->kind == DExpr::LEAF) return true; *ok = false; return false;
     case DExpr::TYPE_MASK: if (e->args.size() == 1 && e->args[0]->kind == DExpr::LEAF) return ((e->mask >> 4) & 1u) != 0; *ok = false; return false;
     case DExpr::CMP: {
+      if (e->args.size() == 2 && e->args[0]->kind == DExpr::CALL && e->args[1]->kind == DExpr::CONST) {
+        // the shapes `split(image, ":")` makes (the banned-tag templates of the library): count(split($, sep)) <op> int and
+        // $index(split($, sep), i) <op> "string" -- on the bytes (round 6: with unique image tags the per-value memo never hits and the
+        // generic evaluator, a Value tree per call, was 60 % of the ingest of the 200-template corpus)
+        const DExpr& L = *e->args[0];
+        const Value& K = e->args[1]->c;
+        const std::string* sep = nullptr;
+        if (L.name == "count" && L.args.size() == 1 && dx_is_leaf_split(*L.args[0], &sep) && K.is_number() && K.is_int) {
+          const i128 c = (i128)dx_split_count(s, n, *sep);
+          return dx_cmp_holds(c < K.i ? -1 : c > K.i ? 1 : 0, e->cmp);
+        }
+        if (L.name == "$index" && L.args.size() == 2 && dx_is_leaf_split(*L.args[0], &sep) && L.args[1]->kind == DExpr::CONST && L.args[1]->c.is_number() && L.args[1]->c.is_int && K.is_string()) {
+          const char* cp = nullptr; size_t cn = 0;
+          if (!dx_split_component(s, n, *sep, (long long)L.args[1]->c.i, &cp, &cn)) return false;   // (an undefined operand: the comparison is false)
+          const std::string& k = K.str();
+          const size_t m = cn < k.size() ? cn : k.size();
+          int c = m ? memcmp(cp, k.data(), m) : 0;
+          if (c == 0) c = cn < k.size() ? -1 : cn > k.size() ? 1 : 0;
+          return dx_cmp_holds(c, e->cmp);
+        }
+        *ok = false; return false;
+      }
       if (e->args.size() != 2 || e->args[0]->kind != DExpr::LEAF || e->args[1]->kind != DExpr::CONST || !e->args[1]->c.is_string()) { *ok = false; return false; }
       const std::string& k = e->args[1]->c.str();
       if (e->cmp == 0 || e->cmp == 1) { const bool eq = k.size() == n && memcmp(k.data(), s, n) == 0; return e->cmp == 0 ? eq : !eq; }
@@ -176,6 +230,11 @@ inline bool dx_true_str(const DX& e, const char* s, size_t n, bool* ok) {
       if (e->args.size() != 1) { *ok = false; return false; }
       const DExpr& c = *e->args[0];
       if (c.kind == DExpr::LEAF) return true;   // a string is not `false`
+      if (c.kind == DExpr::CALL && (c.name == "re_match" || c.name == "regex.match") && c.args.size() == 2 && c.args[0]->kind == DExpr::CONST && c.args[0]->c.is_string() && c.args[1]->kind == DExpr::LEAF) {
+        bool valid = true;
+        const bool hit = builtin_regex_search(c.args[0]->c.str(), s, n, &valid);
+        return valid && hit;   // (an invalid pattern: the builtin is undefined, hence not truthy)
+      }
       if (c.kind != DExpr::CALL || c.args.size() != 2 || c.args[0]->kind != DExpr::LEAF || c.args[1]->kind != DExpr::CONST || !c.args[1]->c.is_string()) { *ok = false; return false; }
       const std::string& k = c.args[1]->c.str();
       if (c.name == "startswith") return k.size() <= n && memcmp(s, k.data(), k.size()) == 0;
@@ -191,5 +250,131 @@ inline bool dx_true_str(const DX& e, const char* s, size_t n, bool* ok) {
     default: *ok = false; return false;
   }
 }
+
+// ---- the dictionary expressions of ONE leaf compiled for string values (round 6).  dx_true_str walks every entry's tree on its own: a
+// leaf with 80 expressions (containers[].image of the 200-template corpus) re-tests the same prefixes and re-reads the same split
+// component dozens of times per value, comparing builtin NAMES on the way -- 25 us per value once the values are unique and no memo
+// hits.  DxStrProg flattens the entries into (a) the DISTINCT primitive tests -- each evaluated at most once per value, the split
+// components shared -- and (b) a postfix boolean program per entry over their answers.  An entry with a node the compiler does not
+// know stays generic (`generic[i]`: the caller asks dx_true_str / dx_true for it).
+struct DxStrProg {
+  enum PKind : uint8_t { P_TRUE, P_FALSE, P_ISSTR, P_EQ, P_CMP, P_PREFIX, P_SUFFIX, P_CONTAINS, P_SPLIT_COUNT, P_SPLIT_IDX, P_REGEX };
+  struct Prim { PKind kind; int cmp = 0; std::string k, sep; long long idx = 0; i128 num = 0; bool yes = false; };
+  enum : uint8_t { O_PRIM, O_AND, O_OR, O_NOT };
+  struct Op { uint8_t op; uint32_t a; };   // O_PRIM: primitive id; O_AND / O_OR: operand count
+  std::vector<Prim> prims;
+  std::map<std::string, uint32_t> prim_ids;
+  std::vector<std::vector<Op>> progs;      // per entry
+  std::vector<uint8_t> generic;            // per entry: 1 = not compiled
+  mutable std::vector<int8_t> val;         // per primitive: -1 unknown, 0 / 1 (scratch of one evaluation)
+  mutable std::vector<uint8_t> stack;
+
+  uint32_t prim(const Prim& p, const std::string& key) {
+    auto it = prim_ids.find(key);
+    if (it != prim_ids.end()) return it->second;
+    prims.push_back(p);
+    return prim_ids[key] = (uint32_t)prims.size() - 1;
+  }
+  bool compile(const DX& e, std::vector<Op>* out) {
+    switch (e->kind) {
+      case DExpr::CONST: { if (!e->c.is_bool()) return false; Prim p; p.kind = e->c.b ? P_TRUE : P_FALSE; out->push_back({O_PRIM, prim(p, e->c.b ? "T" : "F")}); return true; }
+      case DExpr::AND: case DExpr::OR: {
+        for (auto& a : e->args) if (!compile(a, out)) return false;
+        out->push_back({(uint8_t)(e->kind == DExpr::AND ? O_AND : O_OR), (uint32_t)e->args.size()});
+        return true;
+      }
+      case DExpr::NOT: { if (e->args.size() != 1 || !compile(e->args[0], out)) return false; out->push_back({O_NOT, 0}); return true; }
+      case DExpr::DEFINED: { if (e->args.size() != 1 || e->args[0]->kind != DExpr::LEAF) return false; Prim p; p.kind = P_TRUE; out->push_back({O_PRIM, prim(p, "T")}); return true; }
+      case DExpr::TYPE_MASK: { if (e->args.size() != 1 || e->args[0]->kind != DExpr::LEAF) return false; Prim p; p.kind = ((e->mask >> 4) & 1u) ? P_TRUE : P_FALSE; out->push_back({O_PRIM, prim(p, p.kind == P_TRUE ? "T" : "F")}); return true; }
+      case DExpr::CMP: {
+        if (e->args.size() != 2 || e->args[1]->kind != DExpr::CONST) return false;
+        const DExpr& L = *e->args[0];
+        const Value& K = e->args[1]->c;
+        const std::string* sep = nullptr;
+        Prim p; p.cmp = e->cmp;
+        if (L.kind == DExpr::LEAF && K.is_string()) { p.kind = (e->cmp == 0 || e->cmp == 1) ? P_EQ : P_CMP; p.k = K.str(); out->push_back({O_PRIM, prim(p, e->text)}); return true; }
+        if (L.kind != DExpr::CALL) return false;
+        if (L.name == "count" && L.args.size() == 1 && dx_is_leaf_split(*L.args[0], &sep) && K.is_number() && K.is_int) { p.kind = P_SPLIT_COUNT; p.sep = *sep; p.num = K.i; out->push_back({O_PRIM, prim(p, e->text)}); return true; }
+        if (L.name == "$index" && L.args.size() == 2 && dx_is_leaf_split(*L.args[0], &sep) && L.args[1]->kind == DExpr::CONST && L.args[1]->c.is_number() && L.args[1]->c.is_int && K.is_string()) {
+          p.kind = P_SPLIT_IDX; p.sep = *sep; p.idx = (long long)L.args[1]->c.i; p.k = K.str(); out->push_back({O_PRIM, prim(p, e->text)}); return true;
+        }
+        return false;
+      }
+      case DExpr::TRUTHY: {
+        if (e->args.size() != 1) return false;
+        const DExpr& c = *e->args[0];
+        Prim p;
+        if (c.kind == DExpr::LEAF) { p.kind = P_TRUE; out->push_back({O_PRIM, prim(p, "T")}); return true; }
+        if (c.kind != DExpr::CALL || c.args.size() != 2) return false;
+        if ((c.name == "re_match" || c.name == "regex.match") && c.args[0]->kind == DExpr::CONST && c.args[0]->c.is_string() && c.args[1]->kind == DExpr::LEAF) { p.kind = P_REGEX; p.k = c.args[0]->c.str(); out->push_back({O_PRIM, prim(p, e->text)}); return true; }
+        if (c.args[0]->kind != DExpr::LEAF || c.args[1]->kind != DExpr::CONST || !c.args[1]->c.is_string()) return false;
+        p.k = c.args[1]->c.str();
+        if (c.name == "startswith") p.kind = P_PREFIX; else if (c.name == "endswith") p.kind = P_SUFFIX; else if (c.name == "contains") p.kind = P_CONTAINS; else return false;
+        out->push_back({O_PRIM, prim(p, e->text)});
+        return true;
+      }
+      default: return false;
+    }
+  }
+  template <class Entries> void build(const Entries& entries) {
+    prims.clear(); prim_ids.clear(); progs.clear(); generic.clear();
+    for (const auto& en : entries) {
+      std::vector<Op> pr;
+      const bool ok = compile(en.dx, &pr);
+      if (!ok) pr.clear();
+      progs.push_back(std::move(pr));
+      generic.push_back(ok ? 0 : 1);
+    }
+    val.assign(prims.size(), -1);
+  }
+  bool eval_prim(uint32_t id, const char* s, size_t n) const {
+    int8_t& v = val[id];
+    if (v >= 0) return v != 0;
+    const Prim& p = prims[id];
+    bool r = false;
+    switch (p.kind) {
+      case P_TRUE: r = true; break;
+      case P_FALSE: r = false; break;
+      case P_ISSTR: r = true; break;
+      case P_EQ: { const bool eq = p.k.size() == n && memcmp(p.k.data(), s, n) == 0; r = p.cmp == 0 ? eq : !eq; break; }
+      case P_CMP: { const size_t m = n < p.k.size() ? n : p.k.size(); int c = m ? memcmp(s, p.k.data(), m) : 0; if (c == 0) c = n < p.k.size() ? -1 : n > p.k.size() ? 1 : 0; r = dx_cmp_holds(c, p.cmp); break; }
+      case P_PREFIX: r = p.k.size() <= n && memcmp(s, p.k.data(), p.k.size()) == 0; break;
+      case P_SUFFIX: r = p.k.size() <= n && memcmp(s + n - p.k.size(), p.k.data(), p.k.size()) == 0; break;
+      case P_CONTAINS: {
+        if (p.k.empty()) { r = true; break; }
+        if (p.k.size() > n) break;
+        for (size_t i = 0; i + p.k.size() <= n && !r; i++) r = s[i] == p.k[0] && memcmp(s + i, p.k.data(), p.k.size()) == 0;
+        break;
+      }
+      case P_SPLIT_COUNT: { const i128 c = (i128)dx_split_count(s, n, p.sep); r = dx_cmp_holds(c < p.num ? -1 : c > p.num ? 1 : 0, p.cmp); break; }
+      case P_SPLIT_IDX: {
+        const char* cp = nullptr; size_t cn = 0;
+        if (!dx_split_component(s, n, p.sep, p.idx, &cp, &cn)) break;
+        const size_t m = cn < p.k.size() ? cn : p.k.size();
+        int c = m ? memcmp(cp, p.k.data(), m) : 0;
+        if (c == 0) c = cn < p.k.size() ? -1 : cn > p.k.size() ? 1 : 0;
+        r = dx_cmp_holds(c, p.cmp);
+        break;
+      }
+      case P_REGEX: { bool valid = true; const bool hit = builtin_regex_search(p.k, s, n, &valid); r = valid && hit; break; }
+    }
+    v = r ? 1 : 0;
+    return r;
+  }
+  void begin_value() const { std::fill(val.begin(), val.end(), (int8_t)-1); dx_split_forget(); }
+  bool eval(size_t entry, const char* s, size_t n) const {   // (every operand is evaluated: the primitives are memoised, the trees are small)
+    stack.clear();
+    for (const Op& o : progs[entry]) {
+      if (o.op == O_PRIM) stack.push_back(eval_prim(o.a, s, n) ? 1 : 0);
+      else if (o.op == O_NOT) stack.back() = !stack.back();
+      else {
+        bool r = o.op == O_AND;
+        for (uint32_t k = 0; k < o.a; k++) { const bool x = stack.back() != 0; stack.pop_back(); r = o.op == O_AND ? (r && x) : (r || x); }
+        stack.push_back(r ? 1 : 0);
+      }
+    }
+    return !stack.empty() && stack.back() != 0;
+  }
+};
 
 }  // namespace gk

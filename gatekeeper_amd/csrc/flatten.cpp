@@ -201,6 +201,7 @@ uint32_t DictRegistry::intern(const Pattern& leaf_in, const DX& dx, bool add, bo
     if (p->entries.empty()) { pats_.pop_back(); }   // (a pattern created for this expression alone does not stay behind empty)
     throw std::runtime_error("more than 62 dictionary predicates on " + pk);
   }
+  { static const bool dbg = getenv("GK_DEBUG_DICT") != nullptr; if (dbg) fprintf(stderr, "[gkgpu dict] %s%s bit %zu: %s\n", pk.c_str(), p->facts ? " (review facts)" : "", used, dk.substr(0, 300).c_str()); }
   p->entries.push_back({dx, dk, (uint32_t)used});
   p->memo.clear();
   gen_++;
@@ -722,6 +723,7 @@ void Flattener::dict_row_str(uint32_t path, uint32_t meta, const char* s, uint32
     DictPath& d = dict_paths_[path];
     bool ok = true;
     uint64_t m[2] = {0, 0};
+    dx_split_forget();
     for (const DictEntry& e : d.entries) { if (dx_true_str(e.dx, s, n, &ok)) m[0] |= 1ull << e.bit; if (!ok) break; }
     if (ok) for (const DictEntry& e : d.centries) { if (dx_true_str(e.dx, s, n, &ok)) m[1] |= 1ull << e.bit; if (!ok) break; }
     if (ok && masks_out) { masks_out[0] = m[0]; masks_out[1] = m[1]; return; }
@@ -734,30 +736,47 @@ void Flattener::dict_row_str(uint32_t path, uint32_t meta, const char* s, uint32
     h |= 1;   // (0 marks an empty slot)
   }
   uint64_t masks[2] = {0, 0};
-  bool found = false;
+  bool found = false, bypass = false;
   {
     DictPath& d = dict_paths_[path];
     if (!d.smemo) { d.smemo.reset(new StrMemo()); d.smemo->tab.resize(256); }
     StrMemo& M = *d.smemo;
-    size_t mask = M.tab.size() - 1, i = (size_t)(h >> 7) & mask;
-    for (; M.tab[i].hash; i = (i + 1) & mask) {
-      const StrMemo::Ent& e = M.tab[i];
-      if (e.hash == h && e.len == n && memcmp(M.arena.data() + e.off, s, n) == 0) { masks[0] = e.m[0]; masks[1] = e.m[1]; found = true; break; }
+    if (M.bypass_left) { M.bypass_left--; bypass = true; }
+    else {
+      size_t mask = M.tab.size() - 1, i = (size_t)(h >> 7) & mask;
+      for (; M.tab[i].hash; i = (i + 1) & mask) {
+        const StrMemo::Ent& e = M.tab[i];
+        if (e.hash == h && e.len == n && memcmp(M.arena.data() + e.off, s, n) == 0) { masks[0] = e.m[0]; masks[1] = e.m[1]; found = true; break; }
+      }
+      M.hits += found ? 1u : 0u;
+      if (++M.seen == 8192u) { if (M.hits * 8u < M.seen) M.bypass_left = 7u * 8192u; M.seen = M.hits = 0; }
     }
   }
   if (!found) {
     {
       // string tests against constants are evaluated here, on the bytes (dx_true_str); anything else -- quantity arithmetic, regular
       // expressions, split components -- goes through the engine-wide memo of the pattern (dict_row), evaluated once per engine
+      // (PER ENTRY since round 6: one expression the byte evaluator does not know no longer sends the leaf's whole list through the
+      //  generic evaluator -- and through the engine-wide memo, which a column of unique values only fills)
       DictPath& d0 = dict_paths_[path];
-      bool ok = true;
-      for (const DictEntry& e : d0.entries) { if (dx_true_str(e.dx, s, n, &ok)) masks[0] |= 1ull << e.bit; if (!ok) break; }
-      if (ok) for (const DictEntry& e : d0.centries) { if (dx_true_str(e.dx, s, n, &ok)) masks[1] |= 1ull << e.bit; if (!ok) break; }
-      if (!ok) { masks[0] = masks[1] = 0; dict_row(path, meta, Value::string(std::string(s, n)), masks); }
+      Value leaf;
+      for (int k = 0; k < 2; k++) {
+        const std::vector<DictEntry>& es = k ? d0.centries : d0.entries;
+        if (es.empty()) continue;
+        if (!d0.sprog[k]) { d0.sprog[k].reset(new DxStrProg()); d0.sprog[k]->build(es); }   // (dict_paths_ is dropped with the registry's generation: the program follows the entries)
+        const DxStrProg& P = *d0.sprog[k];
+        P.begin_value();
+        for (size_t i = 0; i < es.size(); i++) {
+          bool hit;
+          if (!P.generic[i]) hit = P.eval(i, s, n);
+          else { if (!leaf.defined()) leaf = Value::string(std::string(s, n)); hit = dx_true(es[i].dx, leaf); }
+          if (hit) masks[k] |= 1ull << es[i].bit;
+        }
+      }
     }
     DictPath& d = dict_paths_[path];
     StrMemo& M = *d.smemo;
-    if (M.count < 65536) {
+    if (M.count < 65536 && !bypass) {
       if ((M.count + 1) * 2 > M.tab.size()) {
         std::vector<StrMemo::Ent> old;
         old.swap(M.tab);

@@ -349,8 +349,11 @@ class Flattener {
   PathDict* dict_;
   const DictRegistry* reg_ = nullptr;
   uint64_t reg_gen_ = ~0ull, reads_gen_seen_ = ~0ull;
-  struct StrMemo { struct Ent { uint64_t hash = 0; uint32_t off = 0, len = 0; uint64_t m[2] = {0, 0}; }; std::vector<Ent> tab; size_t count = 0; std::string arena; };
-  struct DictPath { std::unique_ptr<StrMemo> smemo; int state = 0; int gstate = 0; int vstate = 0; int kstate = 0; uint32_t rstate = 0 /* 4 | read_state once known */; int pat = -1; bool facts = false /* the main-space answers go to the review facts row, review.$r.$d */; bool deep = false /* some expression looks inside a container leaf */; std::vector<DictEntry> entries; uint32_t dpath = 0; std::unordered_map<std::string, uint64_t> memo;   // state 0 unknown, 1 none, 2 has entries
+  struct StrMemo { struct Ent { uint64_t hash = 0; uint32_t off = 0, len = 0; uint64_t m[2] = {0, 0}; }; std::vector<Ent> tab; size_t count = 0; std::string arena;
+                   // a column of (nearly) unique values -- image tags pinned by digest, generated names -- only fills the memo: after a window of
+                   // 8192 look-ups with fewer than one hit in eight the next seven windows evaluate straight (round 6)
+                   uint32_t seen = 0, hits = 0, bypass_left = 0; };
+  struct DictPath { std::unique_ptr<StrMemo> smemo; int state = 0; int gstate = 0; int vstate = 0; int kstate = 0; uint32_t rstate = 0 /* 4 | read_state once known */; int pat = -1; std::unique_ptr<DxStrProg> sprog[2] /* the entries / centries compiled for string values (dexpr.hpp) */; bool facts = false /* the main-space answers go to the review facts row, review.$r.$d */; bool deep = false /* some expression looks inside a container leaf */; std::vector<DictEntry> entries; uint32_t dpath = 0; std::unordered_map<std::string, uint64_t> memo;   // state 0 unknown, 1 none, 2 has entries
                     int cpat = -1; std::vector<DictEntry> centries; uint32_t cpath = 0; std::unordered_map<std::string, uint64_t> cmemo; /* the counting space: <leaf>.$c */ };
   std::vector<DictPath> dict_paths_;
   void dict_row(uint32_t path, uint32_t meta, const Value& leaf, uint64_t* masks_out = nullptr);   // emits <leaf>.$d / .$c when some registered expression is true (masks_out: hands the two masks back instead)

@@ -84,8 +84,21 @@ std::string labels_json(const Labels& l) {
   return o + "}";
 }
 
+// HIGH CARDINALITY (gk_synth_batch_create, mixed | 16): every container carries an image tag and a name no other container of the stream
+// has (a digest-like tag, as a registry that pins by digest produces; a generated name), so that the flattener's per-value memos of the
+// dictionary expressions on `image` / `name` never hit -- the low-cardinality default (a dozen images) always does.  The random stream
+// that decides everything else is untouched: the objects are the default ones with longer strings in those two places.
+static thread_local uint64_t g_high_card = 0;   // 0: off; else a per-object salt
 std::string gen_container(Rng& r, int idx, const std::vector<std::string>& vols, bool init) {
-  std::string o = "{\"name\": " + q(fmt(init ? "init-%llu" : "c%llu", (uint64_t)idx)) + ", \"image\": " + q(r.pick(IMAGES));
+  std::string image = r.pick(IMAGES), cname = fmt(init ? "init-%llu" : "c%llu", (uint64_t)idx);
+  if (g_high_card) {
+    uint64_t h = (g_high_card + (uint64_t)idx * 0x9E3779B97F4A7C15ull + (init ? 0x5851F42D4C957F2Dull : 0)) * 0xD6E8FEB86659FD93ull;
+    h ^= h >> 29;
+    const size_t colon = image.rfind(':');
+    image = (colon == std::string::npos || image.find('/', colon) != std::string::npos ? image : image.substr(0, colon)) + fmt(":sha-%016llx", (unsigned long long)h);
+    cname += fmt("-%08llx", (unsigned long long)(h >> 32));
+  }
+  std::string o = "{\"name\": " + q(cname) + ", \"image\": " + q(image);
   if (r.chance(0.6)) {
     std::string sc;
     auto add = [&](const std::string& kv) { if (!sc.empty()) sc += ", "; sc += kv; };
@@ -240,7 +253,9 @@ int gk_synth_batch_create(uint64_t seed, uint64_t start, uint64_t n, int mixed, 
   if (as_request && (mixed & 1)) { delete b; return GK_ERR_INVALID; }
   auto work = [&](size_t w) {
     for (uint64_t k = w; k < n; k += n_threads) {
+      g_high_card = (mixed & 16) ? ((seed * 0x2545F4914F6CDD1Dull) ^ ((start + k + 1) * 0x9E3779B97F4A7C15ull)) | 1ull : 0ull;
       std::string obj = gen_object(seed, start + k, (mixed & 1) != 0, nss, &ns_idx[k]);
+      g_high_card = 0;
       if (as_request) {
         const std::string name = fmt("pod-%07llu", (unsigned long long)(start + k));
         obj = "{\"uid\": " + q(fmt("uid-%llu", (unsigned long long)(start + k))) + ", \"kind\": {\"group\": \"\", \"version\": \"v1\", \"kind\": \"Pod\"}, "

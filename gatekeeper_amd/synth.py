@@ -392,8 +392,9 @@ class NativeBatch:
     """objects [start, start + n) of stream `seed` generated by the native generator (csrc/synth.cpp): JSON text plus the
     gk_review_in array, handed to Engine.create_table_native without touching Python objects."""
 
-    def __init__(self, lib, n, seed=SEED, mixed=False, start=0, namespaces=None, requests=False):
-        """requests=True: the Pods wrapped in AdmissionRequest documents (review kind GK_REVIEW_ADMISSION_REQUEST)"""
+    def __init__(self, lib, n, seed=SEED, mixed=False, start=0, namespaces=None, requests=False, high_cardinality=False):
+        """requests=True: the Pods wrapped in AdmissionRequest documents (review kind GK_REVIEW_ADMISSION_REQUEST);
+        high_cardinality=True: every container's image tag and name unique in the stream (include/gksynth.h: ingest measurements)"""
         import ctypes as C
         self.lib = lib
         arr, k = None, 0
@@ -401,7 +402,7 @@ class NativeBatch:
             self._ns = [json.dumps(namespaces[name]).encode() for name in NAMESPACES]
             arr, k = (C.c_char_p * len(self._ns))(*self._ns), len(self._ns)
         h = C.c_void_p()
-        rc = lib.gk_synth_batch_create(seed & 0xFFFFFFFFFFFFFFFF, start, n, (1 if mixed else 0) | (2 if requests else 0), arr, k, C.byref(h))
+        rc = lib.gk_synth_batch_create(seed & 0xFFFFFFFFFFFFFFFF, start, n, (1 if mixed else 0) | (2 if requests else 0) | (16 if high_cardinality else 0), arr, k, C.byref(h))
         if rc != 0:
             raise RuntimeError("gk_synth_batch_create failed: %d" % rc)
         self.handle = h

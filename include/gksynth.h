@@ -19,7 +19,10 @@ typedef struct gk_synth_batch gk_synth_batch;
 /* objects [start, start + n) of stream `seed`; mixed = 0: Pods only (configs[1]); 1: Pod / Deployment / Namespace /
  * Service / ConfigMap mix (configs[2]); 2: the Pods of 0, each wrapped in the admissionv1.AdmissionRequest (CREATE) the
  * validating webhook receives (review kind GK_REVIEW_ADMISSION_REQUEST, synth.py admission_request_for).  namespace_jsons: the 100 Namespace objects in synth.py NAMESPACES order (the
- * review's Namespace is looked up by the object's metadata.namespace) or NULL for none. */
+ * review's Namespace is looked up by the object's metadata.namespace) or NULL for none.
+ * mixed | 16: HIGH CARDINALITY -- every container gets an image tag and a name unique in the stream (the per-value memos of the ingest's
+ * dictionary expressions then never hit; the default vocabulary of a dozen images always does).  Ingest measurements only: the Python
+ * generator (synth.py) does not mirror it. */
 int gk_synth_batch_create(uint64_t seed, uint64_t start, uint64_t n, int mixed, const char* const* namespace_jsons, size_t n_namespaces,
                           gk_synth_batch** out);
 const gk_review_in* gk_synth_batch_reviews(const gk_synth_batch* b);

@@ -235,3 +235,58 @@ def test_structural_index_at_every_block_alignment():
             os.environ.pop("GK_NO_INDEX", None)
         assert list(t1.statuses) == list(t2.statuses) == [L.GK_ERR_REVIEW] * len(rb), doc
         t1.free(); t2.free()
+
+
+def test_high_cardinality_batch_takes_the_same_rows_on_every_ingest_path(fixtures, monkeypatch):
+    """include/gksynth.h `mixed | 16`: every container's image tag and name unique in the stream -- the dictionary expressions of the
+    200-template corpus (80 on containers[].image: repos, banned tags through split components) are then evaluated per VALUE by the
+    compiled string program (csrc/dexpr.hpp DxStrProg), never out of a memo.  One-pass ingest == general path (which walks the parsed
+    document and evaluates the same expressions) row for row, and the bitmaps equal those of the default batch wherever the policies do
+    not look at tags or names (the objects are the default ones with longer strings in those two places)."""
+    import ctypes as C
+    import json
+    from parity_util import make_client
+    monkeypatch.setenv("GK_TABLE_DIGEST", "1")
+    c = make_client("hostemu")
+    templates, constraints = synth.corpus(fixtures, 200)
+    for t in templates:
+        c.AddTemplate(t)
+    for k in constraints:
+        c.AddConstraint(k)
+    eng = c.driver.engine
+    n = 1200
+    nss = synth.gen_namespaces()
+    hc = synth.NativeBatch(eng.lib, n, seed=synth.SEED, mixed=True, namespaces=nss, high_cardinality=True)
+    base = synth.NativeBatch(eng.lib, n, seed=synth.SEED, mixed=True, namespaces=nss)
+    images, names = set(), set()
+    n_containers = 0
+    for i in range(n):
+        o = json.loads(hc.json_text(i))
+        for cont in ((o.get("spec") or {}).get("containers") or []) if o.get("kind") == "Pod" else []:
+            images.add(cont["image"]); names.add(cont["name"]); n_containers += 1
+    assert n_containers > 1000 and len(images) == n_containers and len(names) == n_containers
+    digests = {}
+    for mode in ("index", "text", "general"):
+        for k in ("GK_NO_INDEX", "GK_SLOW_INGEST"):
+            monkeypatch.delenv(k, raising=False)
+        if mode == "text":
+            monkeypatch.setenv("GK_NO_INDEX", "1")
+        if mode == "general":
+            monkeypatch.setenv("GK_SLOW_INGEST", "1")
+        t = eng.create_table_native(hc.reviews, n, resident=True)
+        st = t.stats()
+        digests[mode] = (st["digest"], st["n_rows"])
+        if mode == "index":
+            ev_hc = t.eval()
+        t.free()
+    for k in ("GK_NO_INDEX", "GK_SLOW_INGEST"):
+        monkeypatch.delenv(k, raising=False)
+    assert digests["index"] == digests["text"] == digests["general"] and digests["index"][0] != 0
+    tb = eng.create_table_native(base.reviews, n, resident=True)
+    ev_b = tb.eval()
+    tb.free()
+    kinds = [k["kind"] for k in constraints]
+    same = [i for i, cid in enumerate(ev_b.constraint_ids) if not any(w in c.constraints[next(key for key in c.constraints if c.driver.constraint_id(c.constraints[key]) == int(cid))]["kind"]
+                                                                          for w in ("Image", "Repo", "Tag", "Digest"))]
+    assert len(same) > 100 and all((ev_b.viol[i] == ev_hc.viol[i]).all() for i in same)
+    assert int(ev_hc.counts.sum()) > 1000 and kinds

@@ -19,6 +19,8 @@ def main():
     ap.add_argument("--repeat", type=int, default=4)
     ap.add_argument("--config", type=int, default=2, choices=[2, 4])
     ap.add_argument("--no-prune", action="store_true")
+    ap.add_argument("--high-cardinality", action="store_true", help="every container's image tag and name unique in the stream: the per-value memos of the "
+                                                                     "dictionary expressions never hit (the default vocabulary of a dozen images always does)")
     a = ap.parse_args()
     os.environ["GK_HOST_THREADS"] = str(a.threads)
     from gatekeeper_amd import driver as D
@@ -34,7 +36,7 @@ def main():
         client.AddTemplate(t)
     for k in constraints:
         client.AddConstraint(k)
-    batch = synth.NativeBatch(drv.engine.lib, a.reviews, seed=synth.SEED, mixed=True, start=0, namespaces=synth.gen_namespaces())
+    batch = synth.NativeBatch(drv.engine.lib, a.reviews, seed=synth.SEED, mixed=True, start=0, namespaces=synth.gen_namespaces(), high_cardinality=a.high_cardinality)
     for i in range(a.repeat):
         t0 = time.perf_counter()
         table = drv.engine.create_table_native(batch.reviews, a.reviews, keep_docs=False, resident=True, pruned=not a.no_prune)
