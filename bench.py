@@ -899,6 +899,21 @@ def main():
                 if same_bytes and same_kernel:
                     out["roofline"]["traffic"] = pmc["hbm_bytes_per_launch"]
                     out["roofline"]["traffic_source"] = pmc["source"]
+                    # The SECOND roof.  Round 6 cut the bytes a sweep streams by 45 % (element carriers, the review facts row) and the
+                    # kernel's time by 17 %: `frac` -- bytes over time against the HBM peak -- FELL, although nothing about the memory
+                    # system got worse.  What binds the kernel is instruction issue at the occupancy its LDS footprint allows; the
+                    # SQ counters of the same PMC passes say how close to THAT roof it runs: wave64 VALU instructions per launch
+                    # against what the device's SIMDs can issue in the kernel's duration (a wave64 VALU instruction occupies a
+                    # SIMD-32 for two cycles: 256 CUs x 4 SIMDs x 2.4 GHz / 2), and the share of wave cycles with an instruction in flight.
+                    sq = pmc.get("sq") or {}
+                    if sq.get("SQ_INSTS_VALU") and kernel_s > 0:
+                        peak_valu = 256 * 4 * 2.4e9 / 2.0
+                        out["roofline"]["issue"] = {
+                            "valu_wave_insts_per_launch": sq.get("SQ_INSTS_VALU"), "salu_wave_insts_per_launch": sq.get("SQ_INSTS_SALU"), "lds_wave_insts_per_launch": sq.get("SQ_INSTS_LDS"),
+                            "valu_issue_frac": sq["SQ_INSTS_VALU"] / kernel_s / peak_valu, "peak_valu_wave_insts_per_s": peak_valu,
+                            "waves_waiting_share": (sq.get("SQ_WAIT_ANY") / sq["SQ_WAVE_CYCLES"]) if sq.get("SQ_WAVE_CYCLES") else None,
+                            "waves_issuing_share": (sq.get("SQ_ACTIVE_INST_ANY") / sq["SQ_WAVE_CYCLES"]) if sq.get("SQ_WAVE_CYCLES") else None,
+                            "what": "rocprofv3 --pmc SQ_* of the same command and kernel text (profiles/pmc_latest.json); valu_issue_frac = VALU wave instructions / (kernel time x 256 CUs x 4 SIMD-32 x 2.4 GHz / 2 cycles per wave64 instruction)"}
                 else:
                     out["roofline"]["traffic_dropped"] = ("profiles/pmc_latest.json was measured on kernel text %s streaming %s bytes per launch; this run timed kernel text %016x "
                                                           "streaming %d: the stale figure is not reported" % (pmc.get("kernel_text_hash"), pmc.get("algo_bytes_per_launch"),
@@ -964,6 +979,13 @@ def main():
             brief["configs2"]["ingest"] = {"first_table_json_MBps": _sig(e2e.get("json_MBps"), 4), "first_table_flatten_s": _sig(e2e.get("flatten_s"), 3),
                                            "second_table_json_MBps": _sig(again.get("json_MBps"), 4), "second_table_flatten_s": _sig(again.get("flatten_s"), 3),
                                            "host_threads": e2e.get("host_threads"), "host_cpus_usable": e2e.get("host_cpus_usable")}
+            # `roofline` beside the table no cache can hold: configs[3]'s N = 1 point (10 M objects, > 1 GB streamed per sweep, far beyond
+            # the 256 MiB Infinity Cache -- configs[2]'s 130 MB fit in it, and FETCH_SIZE counts cache hits)
+            d3 = detail.get("configs3_n1") or {}
+            if "roofline" in d3:
+                r3 = d3["roofline"]
+                out["roofline"]["uncached_table"] = {"workload": d3.get("workload"), "algo_bytes_per_launch": r3.get("algo_bytes_per_sweep_table_once"), "avg_kernel_ms": r3.get("seconds", 0) * 1e3,
+                                                     "achieved": r3.get("achieved"), "frac": r3.get("frac"), "ms_per_step": d3.get("ms_per_step"), "table_bytes": d3.get("table_bytes")}
             out["other_configs"] = brief
         print(json.dumps(out))
     if dist is not None:

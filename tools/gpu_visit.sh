@@ -78,7 +78,7 @@ try:
     ALGO, KHASH = RL["algo_bytes_per_launch"], RL.get("kernel_text_hash")
 except Exception: ALGO = KHASH = None
 if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
-    print(json.dumps({"config": 2, "reviews": 1000000, "algo_bytes_per_launch": ALGO, "kernel_text_hash": KHASH, "hbm_bytes_per_launch": int((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024), "fetch_kb": v["FETCH_SIZE"], "write_kb": v["WRITE_SIZE"],
+    print(json.dumps({"config": 2, "reviews": 1000000, "algo_bytes_per_launch": ALGO, "kernel_text_hash": KHASH, "sq": {k: x for k, x in v.items() if k.startswith("SQ_")}, "hbm_bytes_per_launch": int((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024), "fetch_kb": v["FETCH_SIZE"], "write_kb": v["WRITE_SIZE"],
                       "source": "profiles/%s_summary.txt (rocprofv3 --pmc, separate passes of `bench.py --steps 5 --warmup 1 --lean` with --kernel-trace only; HBM bytes = 2 x FETCH_SIZE KB (gfx950 correction, MI355X_MICROARCH.md) + WRITE_SIZE KB, KB = 1024 B)" % (sys.argv[2][:3] + "_pmc_" + sys.argv[2][3:] + "_config2_1M")}, indent=1))
 PY
          ;;
