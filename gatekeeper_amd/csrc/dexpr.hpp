@@ -326,7 +326,16 @@ struct DxStrProg {
       generic.push_back(ok ? 0 : 1);
     }
     val.assign(prims.size(), -1);
+    // a leaf whose expressions do not look at the string's bytes (def($), type tests: `def(review.object.metadata.name)` of every library
+    // template's message) answers the same for EVERY string: worked out once, no hashing, no memo -- names are as good as unique
+    constant = true;
+    for (uint8_t g : generic) if (g) constant = false;
+    for (const Prim& p : prims) if (p.kind != P_TRUE && p.kind != P_FALSE && p.kind != P_ISSTR) constant = false;
+    constant_true.assign(progs.size(), 0);
+    if (constant) { begin_value(); for (size_t i = 0; i < progs.size(); i++) constant_true[i] = eval(i, "", 0) ? 1 : 0; }
   }
+  bool constant = false;                   // every entry's answer is the same for every string value
+  std::vector<uint8_t> constant_true;
   bool eval_prim(uint32_t id, const char* s, size_t n) const {
     int8_t& v = val[id];
     if (v >= 0) return v != 0;

@@ -728,6 +728,27 @@ void Flattener::dict_row_str(uint32_t path, uint32_t meta, const char* s, uint32
     if (ok) for (const DictEntry& e : d.centries) { if (dx_true_str(e.dx, s, n, &ok)) m[1] |= 1ull << e.bit; if (!ok) break; }
     if (ok && masks_out) { masks_out[0] = m[0]; masks_out[1] = m[1]; return; }
   }
+  {
+    // (the entries compiled for string values: built once per path and registry generation)
+    DictPath& d = dict_paths_[path];
+    bool all_const = true;
+    for (int k = 0; k < 2; k++) {
+      const std::vector<DictEntry>& es = k ? d.centries : d.entries;
+      if (es.empty()) continue;
+      if (!d.sprog[k]) { d.sprog[k].reset(new DxStrProg()); d.sprog[k]->build(es); }
+      all_const = all_const && d.sprog[k]->constant;
+    }
+    if (all_const) {   // no expression of this leaf looks at the bytes: one answer for every string
+      uint64_t m[2] = {0, 0};
+      for (int k = 0; k < 2; k++) { const std::vector<DictEntry>& es = k ? d.centries : d.entries; for (size_t i = 0; i < es.size(); i++) if (d.sprog[k]->constant_true[i]) m[k] |= 1ull << es[i].bit; }
+      if (masks_out) { masks_out[0] = m[0]; masks_out[1] = m[1]; return; }
+      if (d.facts) { facts_acc_ |= m[0]; m[0] = 0; }
+      const uint32_t dp[2] = {d.dpath, d.cpath};
+      for (int k = 0; k < 2; k++)
+        if (m[k]) emit(dp[k], (meta & ~(uint32_t)ROW_TYPE_MASK & ~(uint32_t)ROW_STR_INLINE) | T_INT, (uint32_t)m[k], (uint32_t)(m[k] >> 32), true);
+      return;
+    }
+  }
   uint64_t h = 0x9E3779B97F4A7C15ull ^ ((uint64_t)n * 0xD6E8FEB86659FD93ull);
   {
     uint32_t i = 0;
