@@ -29,13 +29,14 @@ inline int jit_block_of(uint32_t rpt) {
 // phase 2 alias one of them when they fit; the generic build also keeps the waves' loop bounds there).  res_k = 0: the
 // generic bytecode build.
 inline uint32_t list_cap_of(int block) { return (uint32_t)std::min(block / GK_TILE, 8) * GK_WAVE_CHUNKS; }
-// list capacity a plan-specialised build is compiled for: the geometry's full capacity.  (Trimming it to what the table's longest list
-// needs buys a fourth resident group per CU at configs[2] -- and a 64-VGPR budget whose spills cost more: 0.133 against 0.1235 ms,
-// profiles/r03_variants_h_four_groups_per_cu_64_vgprs.log; removed in round 5.)
-// GK_JIT_LIST_TRIM=1 (tuning aid, with GK_JIT_WAVES=8): the trimmed capacity again -- round 5 re-measures four groups per CU on the
-// leaner kernel (the sixth round of configs[2]'s 3 907 groups on 768 workgroups is a tenth of the launch).
+// list capacity a plan-specialised build is compiled for: what the table's longest list needs, in steps of 128 (round 6).  With the
+// trimmed lists a FOURTH row group is resident per CU at configs[2] / [3] (34 KB of accumulators per 256-review group) and the kernel is
+// built for 8 waves per SIMD (64 VGPRs).  History: round 3 measured that slower (0.133 against 0.1235 ms, spills), round 5 again
+// (0.0695 against 0.0680); on round 6's kernel -- a third fewer rows per group, the list shorter -- it is faster: 1 M objects 0.0596 /
+// 0.0588 / 0.0603 against 0.0605 / 0.0606 / 0.0602 ms per step, the 10 M-object table 0.530 against 0.568 ms
+// (profiles/r06_variants_k_four_groups_per_cu.log).  GK_JIT_LIST_TRIM=0: the geometry's full capacity (A/B aid).
 inline uint32_t jit_list_cap(int block, uint32_t need) {
-  static const bool trim = getenv("GK_JIT_LIST_TRIM") && atoi(getenv("GK_JIT_LIST_TRIM")) != 0;
+  static const bool trim = !(getenv("GK_JIT_LIST_TRIM") && atoi(getenv("GK_JIT_LIST_TRIM")) == 0);
   const uint32_t full = list_cap_of(block);
   if (!trim || need == 0) return full;
   return std::min(full, std::max<uint32_t>(128u, (need + 127u) / 128u * 128u));
