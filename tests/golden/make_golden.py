@@ -44,6 +44,7 @@ YAML_GLOBS = [
 GO_CONST_FILES = [
     "pkg/gator/fixtures/fixtures.go",
     "pkg/target/target_integration_test.go",
+    "pkg/gator/verify/runner_integer_test.go",   # round 6: TestRunner_Run_Integer (K8sReplicaLimits, three template flavours, 0 / 1 violations)
 ]
 
 
@@ -60,7 +61,7 @@ def load_docs(path):
 def go_consts(path):
     src = open(path, encoding="utf-8").read()
     out = {}
-    for m in re.finditer(r"^\s*(\w+)\s*=\s*`([^`]*)`", src, re.M):
+    for m in re.finditer(r"^\s*(?:const\s+)?(\w+)\s*=\s*`([^`]*)`", src, re.M):
         name, text = m.group(1), m.group(2)
         try:
             docs = [d for d in yaml.safe_load_all(text) if d is not None]

@@ -273,3 +273,21 @@ def test_sprintf_formatting():
     assert go_float_v(0.5) == "0.5" and go_float_v(1e21) == "1e+21" and go_float_v(1.5e-7) == "1.5e-07"
     assert go_float_v(123456789.25) == "1.2345678925e+08" or go_float_v(123456789.25) == "123456789.25"
     assert to_string(from_json({"x": "a\"b"})) == '{"x": "a\\"b"}'
+
+
+# ------------------------------------------------------------------ pkg/gator/verify/runner_integer_test.go (pinned in round 6)
+INTEGER_FLAVOURS = [("templateV1Beta1Integer", "constraintV1Beta1Integer"), ("templateV1Beta1IntegerNonStructural", "constraintV1Beta1Integer"),
+                    ("templateV1Integer", "constraintV1Integer")]
+
+
+def test_runner_run_integer(fixtures):
+    """TestRunner_Run_Integer (runner_integer_test.go:231-308): K8sReplicaLimits in three template flavours (structural v1beta1,
+    non-structural v1beta1, v1); the Deployment with 3 replicas yields 0 violations, the one with 100 yields exactly 1 -- integers of
+    the parameters (min_replicas / max_replicas) compared with an integer of the object, whatever the CRD schema says about them."""
+    consts = fixtures["go_consts"]["pkg/gator/verify/runner_integer_test.go"]
+    allow, deny = consts["objectIntegerAllowed"]["docs"][0], consts["objectIntegerDisallowed"]["docs"][0]
+    for tname, cname in INTEGER_FLAVOURS:
+        tmpl, cons = consts[tname]["docs"][0], consts[cname]["docs"][0]
+        assert verify_case(tmpl, cons, allow) == []
+        res = verify_case(tmpl, cons, deny)
+        assert len(res) == 1 and res[0].msg.startswith("The provided number of replicas is not allowed for deployment: disallowed-deployment. Allowed ranges: ")

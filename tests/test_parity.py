@@ -897,3 +897,30 @@ def test_kernel_only_launches_leave_the_bitmaps_of_a_full_launch(backend, fixtur
     table.launch()
     again = table.eval(download=True, collect_only=True)
     assert np.array_equal(np.array(again.viol), viol) and np.array_equal(np.array(again.counts), counts)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_gator_verify_integer_vectors(backend, fixtures):
+    """pkg/gator/verify/runner_integer_test.go TestRunner_Run_Integer (a reference-held vector pinned in round 6): K8sReplicaLimits in
+    its three template flavours; 3 replicas: 0 violations, 100 replicas: exactly 1 -- on the device, and the message with the parameters
+    object printed by %v equal to the oracle's; further replica counts around the range's ends (and a float, a string, none) by parity."""
+    consts = fixtures["go_consts"]["pkg/gator/verify/runner_integer_test.go"]
+    allow, deny = consts["objectIntegerAllowed"]["docs"][0], consts["objectIntegerDisallowed"]["docs"][0]
+    import copy
+    extra = []
+    for i, rep in enumerate([2, 3, 50, 51, 3.0, 2.5, "3", None]):
+        o = copy.deepcopy(allow)
+        o["metadata"]["name"] = "d%d" % i
+        if rep is None:
+            del o["spec"]["replicas"]
+        else:
+            o["spec"]["replicas"] = rep
+        extra.append(o)
+    for tname, cname in (("templateV1Beta1Integer", "constraintV1Beta1Integer"), ("templateV1Beta1IntegerNonStructural", "constraintV1Beta1Integer"),
+                         ("templateV1Integer", "constraintV1Integer")):
+        c, oc = load_both(backend, [consts[tname]["docs"][0]], [consts[cname]["docs"][0]])
+        rv = [D.AugmentedUnstructured(D.Unstructured(o), None, "Original") for o in [allow, deny] + extra]
+        got = c.ReviewBatch(rv, D.GATOR_EP)
+        assert len(got[0]) == 0 and len(got[1]) == 1
+        assert got[1][0].msg == 'The provided number of replicas is not allowed for deployment: disallowed-deployment. Allowed ranges: {"ranges": [{"max_replicas": 50, "min_replicas": 3}]}'
+        assert assert_parity(c, oc, rv, D.GATOR_EP) >= 5
