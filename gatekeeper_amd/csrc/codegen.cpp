@@ -781,7 +781,7 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts) {
         // RUNS of consecutive blocks share one set of preloaded registers; a run ends where the words it keeps live would exceed
         // `pre_live` (the kernel runs at an 80-VGPR budget: everything preloaded at the top of the part spilled 19 dwords).  A later
         // run re-reads what an earlier one derived: the same wave's LDS operations complete in order.
-        constexpr size_t pre_live = 16;
+        static const size_t pre_live = getenv("GK_JIT_PRE_LIVE") ? (size_t)std::max(1, atoi(getenv("GK_JIT_PRE_LIVE"))) : 16;   // (tuning aid, read once)
         std::set<uint32_t> bounds_done;
         std::ostringstream run_body;
         std::set<std::pair<uint32_t, uint32_t>> run_words;
