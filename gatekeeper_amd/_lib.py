@@ -43,7 +43,7 @@ EXPORTS = [
     "gk_comm_unique_id", "gk_comm_init", "gk_comm_destroy", "gk_comm_info", "gk_table_sweep_sharded", "gk_shard_free",
     "gk_jit_quiesce", "gk_jit_cache_stats", "gk_jit_cache_dir", "gk_jit_cache_drop_memory", "gk_host_cpus", "gk_table_create_spool", "gk_spool_info_free", "gk_debug_set",
     # include/gksynth.h (bench / test plumbing)
-    "gk_synth_batch_create", "gk_synth_batch_reviews", "gk_synth_batch_size", "gk_synth_batch_json_bytes", "gk_synth_batch_free", "gk_synth_query_storm",
+    "gk_synth_batch_create", "gk_synth_batch_reviews", "gk_synth_batch_size", "gk_synth_batch_json_bytes", "gk_synth_batch_free", "gk_synth_query_storm", "gk_synth_query_storm_ex",
 ]
 
 
@@ -245,6 +245,7 @@ def load(hostemu: bool | None = None):
     lib.gk_synth_batch_free.argtypes = [vp]
     lib.gk_synth_batch_free.restype = None
     lib.gk_synth_query_storm.argtypes = [vp, vp, u32, u32, C.POINTER(gk_storm_out)]
+    lib.gk_synth_query_storm_ex.argtypes = [vp, vp, u32, u32, C.POINTER(u32), sz, u32, C.POINTER(gk_storm_out)]
     # a plan-specialised kernel may still be compiling in the background when the interpreter exits; exit() under a running
     # hiprtc compile crashes in the compiler's teardown, so the builds are joined first (Python's atexit runs before exit())
     atexit.register(lib.gk_jit_quiesce)

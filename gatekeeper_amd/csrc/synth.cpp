@@ -293,6 +293,10 @@ uint64_t gk_synth_batch_json_bytes(const gk_synth_batch* b) { return b ? b->json
 void gk_synth_batch_free(gk_synth_batch* b) { delete b; }
 
 int gk_synth_query_storm(gk_engine* e, const gk_synth_batch* b, uint32_t threads, uint32_t per_thread, gk_storm_out* out) {
+  return gk_synth_query_storm_ex(e, b, threads, per_thread, nullptr, 0, 0, out);
+}
+int gk_synth_query_storm_ex(gk_engine* e, const gk_synth_batch* b, uint32_t threads, uint32_t per_thread, const uint32_t* constraint_ids, size_t n_constraints,
+                            uint32_t query_flags, gk_storm_out* out) {
   if (!e || !b || !out || !threads || !per_thread || b->reviews.empty()) return GK_ERR_INVALID;
   struct PerThread { std::vector<double> lat; double batch = 0, queue = 0, device = 0; uint64_t errors = 0, results = 0; };
   std::vector<PerThread> pt(threads);
@@ -308,7 +312,8 @@ int gk_synth_query_storm(gk_engine* e, const gk_synth_batch* b, uint32_t threads
         char* js = nullptr;
         gk_query_stats st;
         memset(&st, 0, sizeof st);
-        const int rc = gk_query(e, &rv, &js, &st);
+        // (constraint ids: Driver.Query as the Go shim calls it -- gk_query_ex2, pre-matched when the flag says so; none: gk_query)
+        const int rc = constraint_ids ? gk_query_ex2(e, &rv, constraint_ids, n_constraints, query_flags, &js, nullptr, &st) : gk_query(e, &rv, &js, &st);
         if (rc != GK_OK) { me.errors++; continue; }
         me.lat.push_back(st.total_us);
         me.batch += st.batch_size; me.queue += st.queue_us; me.device += st.device_us;

@@ -426,11 +426,17 @@ class NativeBatch:
         import ctypes as C
         return C.string_at(r.namespace_json, r.namespace_len) if r.namespace_json else None
 
-    def query_storm(self, engine, threads, per_thread):
-        """`threads` NATIVE threads x `per_thread` gk_query calls on this batch's reviews (include/gksynth.h) -> dict"""
+    def query_storm(self, engine, threads, per_thread, constraint_ids=None, pre_matched=False):
+        """`threads` NATIVE threads x `per_thread` gk_query calls on this batch's reviews (include/gksynth.h) -> dict.
+        constraint_ids: through gk_query_ex2 with that list (Driver.Query as the Go shim calls it), pre_matched: GK_QUERY_PRE_MATCHED"""
+        import ctypes as C
         from . import _lib as L
         out = L.gk_storm_out()
-        rc = self.lib.gk_synth_query_storm(engine.handle, self.handle, threads, per_thread, out)
+        if constraint_ids is not None:
+            ids = (C.c_uint32 * max(1, len(constraint_ids)))(*constraint_ids)
+            rc = self.lib.gk_synth_query_storm_ex(engine.handle, self.handle, threads, per_thread, ids, len(constraint_ids), L.GK_QUERY_PRE_MATCHED if pre_matched else 0, out)
+        else:
+            rc = self.lib.gk_synth_query_storm(engine.handle, self.handle, threads, per_thread, out)
         if rc != 0:
             raise RuntimeError("gk_synth_query_storm failed: %d" % rc)
         d = {k: getattr(out, k) for k, _ in L.gk_storm_out._fields_}

@@ -42,6 +42,9 @@ typedef struct {
   uint64_t results;                    /* violations + autoreject results returned */
 } gk_storm_out;
 int gk_synth_query_storm(gk_engine* e, const gk_synth_batch* b, uint32_t threads, uint32_t per_thread, gk_storm_out* out);
+/* the same through gk_query_ex2: Driver.Query the way the Go shim calls it -- the listed constraints, `query_flags` (GK_QUERY_PRE_MATCHED) */
+int gk_synth_query_storm_ex(gk_engine* e, const gk_synth_batch* b, uint32_t threads, uint32_t per_thread, const uint32_t* constraint_ids, size_t n_constraints,
+                            uint32_t query_flags, gk_storm_out* out);
 
 #ifdef __cplusplus
 }

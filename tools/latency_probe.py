@@ -81,6 +81,19 @@ def main():
                 r = batch.query_storm(drv.engine, threads, per)
                 r["window_us"], r["max_batch"], r["workers"] = window, max_batch, workers
                 out[key]["runs"].append(r)
+        if shape == "admission_request":
+            # Driver.Query as the Go shim calls it (round 6): gk_query_ex2 with every loaded constraint's id, GK_QUERY_PRE_MATCHED --
+            # beside the same storm through gk_query (the engine matches as well), same batcher settings
+            ids = sorted(drv.constraint_id(c) for c in cons)
+            out["native_pre_matched"] = {"what": "gk_query_ex2(constraint ids, GK_QUERY_PRE_MATCHED) from native threads, AdmissionRequest reviews: the reference's Driver.Query contract", "runs": []}
+            for max_batch, window, workers in ((64, 0, 2), (256, 200, 4)):
+                drv.StartBatcher(max_batch=max_batch, window_us=window, workers=workers)
+                for threads in (1, 8, 64, 256):
+                    per = max(64, min(2048, 16384 // threads))
+                    for name, kw in (("engine_matches", {}), ("pre_matched", {"constraint_ids": ids, "pre_matched": True})):
+                        r = batch.query_storm(drv.engine, threads, per, **kw)
+                        r["window_us"], r["max_batch"], r["workers"], r["mode"] = window, max_batch, workers, name
+                        out["native_pre_matched"]["runs"].append(r)
         batch.free()
     print(json.dumps(out))
 
