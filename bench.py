@@ -847,7 +847,7 @@ def main():
                        "reviews_evaluated_on_host_rank0": len(getattr(final, "host_evaluated", []))},
             # N > 1: what the exchange step costs next to the local sweep (rank 0's figures of one collecting sweep behind the timed region:
             # HIP events around the all-gather alone; the timed passes are enqueue-only and carry no events).  `ms_per_step` against
-            # sweep_ms_local + exchange_ms says whether the overlapped exchange (GK_SHARD_OVERLAP, default at world size > 1) hid it.
+            # sweep_ms_local + exchange_ms says whether the overlapped exchange (GK_SHARD_OVERLAP=1, opt-in) hid it.
             "exchange": None if sharded is None else {
                 "exchange_bytes_per_rank": sharded.exchange_bytes_inbound, "exchange_ms": sharded.exchange_ms, "sweep_ms_local": float(sharded.fast_kernel_ms),
                 "overlap_enabled": sharded.exchange_overlapped, "slot_bytes": int(sharded.slot_bytes),

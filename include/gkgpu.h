@@ -323,9 +323,9 @@ typedef struct {
  * instead of sweeping once more.  Falls back to an ordinary collecting sweep when nothing was enqueued, when the constraint
  * set needs several plan groups, or when that pass left reviews -- on any rank -- to the large-capacity re-run.  An enqueue-only
  * pass is four enqueues (sweep, slot-tail kernel, all-gather, totals); GK_SHARD_GRAPH=1 replays a single-plan-group pass as one
- * captured graph instead.  At world size > 1 (GK_SHARD_OVERLAP=0 | 1 overrides) consecutive enqueue-only passes alternate
- * between two slot buffers and their all-gathers run on an exchange stream: the exchange of one pass overlaps the sweep of
- * the next; `d_gathered` / `gathered` of the collecting call are those of the last pass. */
+ * captured graph instead.  With GK_SHARD_OVERLAP=1 (opt-in: tested on the host-side emulation only, it has never met a second GPU)
+ * consecutive enqueue-only passes alternate between two slot buffers and their all-gathers run on an exchange stream: the exchange
+ * of one pass overlaps the sweep of the next; `d_gathered` / `gathered` of the collecting call are those of the last pass. */
 #define GK_SHARD_COLLECT 4u
 int gk_table_sweep_sharded(gk_engine* e, gk_table* t, uint32_t flags, gk_shard_out** out);
 void gk_shard_free(gk_shard_out* o);
