@@ -120,6 +120,14 @@ inline std::string assemble_jit_source(const HostPlan& plan, uint32_t rpt, uint3
     if (const char* d = getenv("GK_JIT_PREFETCH")) depth = std::max(1, std::min(8, atoi(d)));   // tuning aid
     src += "#define GK_PREFETCH " + std::to_string(depth) + "\n";
   }
+  {
+    // wave priorities per phase (kernel_body.inc GK_PRIO_LEVELS, round 6): phase 1 and the output / request / clearing stage at
+    // priority 3, bounds and formulas at 0 -- configs[2] 0.0526 -> 0.0499 ms per sweep, the 10 M-object table 0.499 -> 0.468
+    // (profiles/r06_variants_x_*.log).  GK_JIT_PRIO: tuning aid (four digits; 0 = off).
+    int prio = 3003;
+    if (const char* pm = getenv("GK_JIT_PRIO")) prio = std::max(0, std::min(3333, atoi(pm)));
+    if (prio) src += "#define GK_PRIO_LEVELS " + std::to_string(prio) + "\n";
+  }
   src += "#define GK_RPT_K " + std::to_string(rpt) + "\n#define GK_RPP_K " + std::to_string(rpp) + "\n";
   if (list_cap) src += "#define GK_LIST_CAP_K " + std::to_string(list_cap) + "\n";
   if (const char* defs = getenv("GK_JIT_DEFINES")) {   // tuning aid: "A=1;B" -> #define A 1, #define B (kernel_body.inc variants)

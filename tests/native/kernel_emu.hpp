@@ -152,6 +152,7 @@ struct gk_u32x4 { uint32_t x, y, z, w; };
 #define __popcll(x) __builtin_popcountll(x)
 #define __builtin_readcyclecounter() gkemu::clock_()
 #define __builtin_amdgcn_s_sleep(n) do { } while (0)
+#define __builtin_amdgcn_s_setprio(n) do { } while (0)
 #define __builtin_amdgcn_mbcnt_lo(m, v) ((v) + ((gkemu::st().cur->tid & 63u) < 32u ? (gkemu::st().cur->tid & 63u) : 32u))
 #define __builtin_amdgcn_mbcnt_hi(m, v) ((v) + ((gkemu::st().cur->tid & 63u) < 32u ? 0u : (gkemu::st().cur->tid & 63u) - 32u))
 template <class T> static inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
