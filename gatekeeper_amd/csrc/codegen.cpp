@@ -781,7 +781,10 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts) {
         // RUNS of consecutive blocks share one set of preloaded registers; a run ends where the words it keeps live would exceed
         // `pre_live` (the kernel runs at an 80-VGPR budget: everything preloaded at the top of the part spilled 19 dwords).  A later
         // run re-reads what an earlier one derived: the same wave's LDS operations complete in order.
-        static const size_t pre_live = getenv("GK_JIT_PRE_LIVE") ? (size_t)std::max(1, atoi(getenv("GK_JIT_PRE_LIVE"))) : 16;   // (tuning aid, read once)
+        // (4 since round 6: at the 64-VGPR budget of four row groups per CU, and with the formulas running below the other phases'
+        //  priority, short runs win -- 10 M objects 0.432 -> 0.417 ms, configs[2] 0.0470 -> 0.0462, the corpus level; 16 before:
+        //  profiles/r06_variants_ae_*.log)
+        static const size_t pre_live = getenv("GK_JIT_PRE_LIVE") ? (size_t)std::max(1, atoi(getenv("GK_JIT_PRE_LIVE"))) : 4;   // (tuning aid, read once)
         std::set<uint32_t> bounds_done;
         std::ostringstream run_body;
         std::set<std::pair<uint32_t, uint32_t>> run_words;

@@ -127,6 +127,11 @@ inline std::string assemble_jit_source(const HostPlan& plan, uint32_t rpt, uint3
     int prio = 3003;
     if (const char* pm = getenv("GK_JIT_PRIO")) prio = std::max(0, std::min(3333, atoi(pm)));
     if (prio) src += "#define GK_PRIO_LEVELS " + std::to_string(prio) + "\n";
+    // ... and inside the formulas the share of wave 0 of every half -- the one that goes on to write the violation words -- one level
+    // above the other share(s): 10 M objects 0.457 -> 0.440 ms, 3 M 0.140 -> 0.135, configs[2] 0.0482 -> 0.0465 (profiles/r06_variants_a{b,c,d}_*.log)
+    int part0 = 1;
+    if (const char* pp = getenv("GK_JIT_PRIO_PART0")) part0 = std::max(0, std::min(3, atoi(pp)));
+    if (prio && part0) src += "#define GK_PRIO_PART0 " + std::to_string(part0) + "\n";
   }
   src += "#define GK_RPT_K " + std::to_string(rpt) + "\n#define GK_RPP_K " + std::to_string(rpp) + "\n";
   if (list_cap) src += "#define GK_LIST_CAP_K " + std::to_string(list_cap) + "\n";
