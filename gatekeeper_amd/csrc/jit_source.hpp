@@ -133,6 +133,7 @@ inline std::string assemble_jit_source(const HostPlan& plan, uint32_t rpt, uint3
     if (const char* pp = getenv("GK_JIT_PRIO_PART0")) part0 = std::max(0, std::min(3, atoi(pp)));
     if (prio && part0) src += "#define GK_PRIO_PART0 " + std::to_string(part0) + "\n";
   }
+  if (getenv("GK_KERNEL_PROF") || getenv("GK_DBG_PHASE")) src += "#define GK_WITH_PROF 1\n";   // (kernel_body.inc: the phase marks and switches, only when asked for)
   src += "#define GK_RPT_K " + std::to_string(rpt) + "\n#define GK_RPP_K " + std::to_string(rpp) + "\n";
   if (list_cap) src += "#define GK_LIST_CAP_K " + std::to_string(list_cap) + "\n";
   if (const char* defs = getenv("GK_JIT_DEFINES")) {   // tuning aid: "A=1;B" -> #define A 1, #define B (kernel_body.inc variants)
