@@ -146,6 +146,41 @@ def test_bench_plan_source_compiles_for_gfx950_without_scratch(monkeypatch, tmp_
                 assert gaps and min(gaps) >= 16, "%s: a row load is waited for %d instructions after its request (gaps %s)" % (name, min(gaps), gaps)
 
 
+def test_bench_plan_text_sets_wave_priorities_and_carries_no_profiling_aids(monkeypatch, tmp_path):
+    """round 6: the plan-specialised text defines a wave priority per phase (GK_PRIO_LEVELS 3003, wave 0's formula share one level up) and
+    carries the phase marks / phase switches only when GK_KERNEL_PROF or GK_DBG_PHASE is set -- both measured on the device
+    (profiles/r06_variants_{y,ad,ai}_*.log: -9 %, -4 %, -6 % on configs[2]); the ISA shows the s_setprio instructions and no clock reads"""
+    import re
+    import subprocess
+    monkeypatch.delenv("GK_KERNEL_PROF", raising=False)
+    monkeypatch.delenv("GK_DBG_PHASE", raising=False)
+    monkeypatch.delenv("GK_JIT_PRIO", raising=False)
+    texts = _dump_sources(monkeypatch, tmp_path, _bench_plan(1200), env=[("GK_RPT", 256)])
+    rtc = _hiprtc()
+    for name, text in texts:
+        assert "#define GK_PRIO_LEVELS 3003" in text and "#define GK_PRIO_PART0 1" in text, name
+        assert "#define GK_WITH_PROF" not in text, name
+        if rtc is None:
+            continue
+        ok, log, code = compile_gfx950(rtc, text)
+        assert ok, log[-3000:]
+        objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+        if os.path.exists(objdump):
+            co = os.path.join(str(tmp_path), "prio.co")
+            with open(co, "wb") as f:
+                f.write(code)
+            dis = subprocess.run([objdump, "-d", co], capture_output=True, text=True).stdout
+            assert len(re.findall(r"\bs_setprio\b", dis)) >= 4, "no wave priorities in the ISA"
+            # (the stagger of the launch word reads the clock twice, in front of the group loop; the seven phase marks would add seven reads)
+            assert len(re.findall(r"s_memtime|s_memrealtime", dis)) <= 2, "clock reads (profiling marks) in the default text"
+    # ... and with the marks asked for, they are in the text
+    sub = tmp_path / "with_prof"
+    sub.mkdir()
+    monkeypatch.setenv("GK_KERNEL_PROF", "1")
+    for name, text in _dump_sources(monkeypatch, sub, _bench_plan(1200), env=[("GK_RPT", 256)]):
+        assert "#define GK_WITH_PROF" in text, name
+
+
 def _pattern_plans():
     """the parity cases of the policy-compiler tests, run once more on the emulated plan-specialised kernel"""
     import test_library_patterns as L
