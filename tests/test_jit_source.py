@@ -171,8 +171,8 @@ def test_bench_plan_text_sets_wave_priorities_and_carries_no_profiling_aids(monk
                 f.write(code)
             dis = subprocess.run([objdump, "-d", co], capture_output=True, text=True).stdout
             assert len(re.findall(r"\bs_setprio\b", dis)) >= 4, "no wave priorities in the ISA"
-            # (the stagger of the launch word reads the clock twice, in front of the group loop; the seven phase marks would add seven reads)
-            assert len(re.findall(r"s_memtime|s_memrealtime", dis)) <= 2, "clock reads (profiling marks) in the default text"
+            # (the stagger of the launch word reads the clock in front of the group loop (three reads in the ISA); the seven phase marks would add seven reads)
+            assert len(re.findall(r"s_memtime|s_memrealtime", dis)) <= 3, "clock reads (profiling marks) in the default text"
     # ... and with the marks asked for, they are in the text
     sub = tmp_path / "with_prof"
     sub.mkdir()
