@@ -41,14 +41,20 @@ inline uint32_t jit_list_cap(int block, uint32_t need) {
   if (!trim || need == 0) return full;
   return std::min(full, std::max<uint32_t>(128u, (need + 127u) / 128u * 128u));
 }
-inline size_t static_lds_of(uint32_t rpt, int block, uint32_t res_k, uint32_t list_cap = 0) {
+// words of the plan-specialised kernel's per-constraint totals in LDS (kernel_body.inc GK_TOT_K): the plan's constraints rounded up to
+// 64; 0 = the build carries none (more than 256 constraints, or GK_FUSED_TOTALS=0 -- A/B aid: the popcount kernel behind every sweep)
+inline uint32_t jit_tot_k(uint32_t n_constraints) {
+  static const bool on = !(getenv("GK_FUSED_TOTALS") && atoi(getenv("GK_FUSED_TOTALS")) == 0);
+  return on && n_constraints && n_constraints <= 256u ? (n_constraints + 63u) / 64u * 64u : 0u;
+}
+inline size_t static_lds_of(uint32_t rpt, int block, uint32_t res_k, uint32_t list_cap = 0, uint32_t tot_k = 0) {
   const size_t list = (size_t)(list_cap ? list_cap : list_cap_of(block)) * 8;
   const size_t masks = (size_t)(rpt / GK_TILE) * (res_k ? res_k : (uint32_t)(GK_MAX_VIOL + 2 * GK_MAX_RES)) * 8;   // res_k: result words per half (jit_res_k)
   const size_t bounds = res_k ? 0 : (size_t)(block / GK_TILE) * GK_MAX_SCOPES * 4;
-  return 2 * list + (masks <= list ? 8 : masks) + bounds + GK_TILE * 4 + 64;
+  return 2 * list + (masks <= list ? 8 : masks) + bounds + GK_TILE * 4 + 64 + (size_t)tot_k * 4;
 }
 inline size_t max_dyn_lds_of(uint32_t rpt) { return GK_LDS_PER_CU - static_lds_of(rpt, gk_block_of((int)rpt), 0) - 256; }
-inline size_t max_dyn_lds_jit(uint32_t rpt, uint32_t res_k, uint32_t list_cap = 0) { return GK_LDS_PER_CU - static_lds_of(rpt, jit_block_of(rpt), res_k, list_cap) - 256; }
+inline size_t max_dyn_lds_jit(uint32_t rpt, uint32_t res_k, uint32_t list_cap = 0, uint32_t tot_k = 0) { return GK_LDS_PER_CU - static_lds_of(rpt, jit_block_of(rpt), res_k, list_cap, tot_k) - 256; }
 
 // A finished formula of the staged parts (generated GK_RES(kind, slot, b)): one ballot turns the 64 reviews' answers into the slot's
 // bitmap word of this half.  The words stay in the WAVE until the part is through -- lane s of a register pair per kind holds slot s's
@@ -105,7 +111,7 @@ inline std::string assemble_jit_source(const HostPlan& plan, uint32_t rpt, uint3
     // register budget: as many waves per SIMD as the LDS footprint lets groups be resident per CU (waves per SIMD =
     // groups per CU x waves per group / 4 SIMDs); measured on configs[1] with 64-review groups: 7 waves (72 VGPRs) edges
     // out 8 (64 VGPRs, twice the spill traffic) and clearly beats 5-6
-    const size_t per_group = (size_t)plan.dims.acc_words * rpp * 4 + static_lds_of(rpt, block, jit_res_k(plan), list_cap);
+    const size_t per_group = (size_t)plan.dims.acc_words * rpp * 4 + static_lds_of(rpt, block, jit_res_k(plan), list_cap, jit_tot_k(plan.dims.n_constraints));
     const size_t groups_per_cu = std::max<size_t>(1, GK_LDS_PER_CU / per_group);
     int waves = (int)std::min<size_t>(8, std::max<size_t>(block / 256, groups_per_cu * (block / GK_TILE) / 4));   // waves per SIMD the LDS allows
     if (const char* w = getenv("GK_JIT_WAVES")) waves = atoi(w);   // tuning aid
@@ -136,6 +142,7 @@ inline std::string assemble_jit_source(const HostPlan& plan, uint32_t rpt, uint3
   if (getenv("GK_KERNEL_PROF") || getenv("GK_DBG_PHASE")) src += "#define GK_WITH_PROF 1\n";   // (kernel_body.inc: the phase marks and switches, only when asked for)
   src += "#define GK_RPT_K " + std::to_string(rpt) + "\n#define GK_RPP_K " + std::to_string(rpp) + "\n";
   if (list_cap) src += "#define GK_LIST_CAP_K " + std::to_string(list_cap) + "\n";
+  if (const uint32_t tk = jit_tot_k(plan.dims.n_constraints)) src += "#define GK_TOT_K " + std::to_string(tk) + "\n";   // (kernel_body.inc: per-constraint totals left as one row per workgroup)
   if (const char* defs = getenv("GK_JIT_DEFINES")) {   // tuning aid: "A=1;B" -> #define A 1, #define B (kernel_body.inc variants)
     std::string d = defs, item;
     for (size_t i = 0; i <= d.size(); i++) {

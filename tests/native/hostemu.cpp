@@ -491,6 +491,7 @@ static EmuJitLaunch emu_jit_for(const DevPlan* p, uint32_t rpt, uint32_t rpp, in
       << jit_res_macros()
       << generate_plan_source(p->fast, (uint32_t)(block / GK_TILE / ((int)rpt / GK_TILE)))
       << "#define GK_RPT_K " << rpt << "\n#define GK_RPP_K " << rpp << "\n#define GK_BLOCK_K " << block << "\n#define GK_PREFETCH " << (pf ? pf : "1") << "\n#define GK_SKIP_BIG\n"
+      << (jit_tot_k(p->fast.dims.n_constraints) ? "#define GK_TOT_K " + std::to_string(jit_tot_k(p->fast.dims.n_constraints)) + "\n" : std::string())
       << "namespace gk {\n#define GK_KERNEL_TILES gk_jit_tiles\n#define GK_KERNEL_BIG gk_jit_big\n#define GK_KERNEL_LINKAGE static\n"
          "#define GK_ROW_FN(r, i, ent, h, pv, heap, acc, on) jit_row(r, ent, h, heap, acc, on)\n#define GK_BIND_ALWAYS_STR 0\n"
          "#define GK_FORMULA_FN(pv, acc, flags, rows, heap, bounds) jit_formulas(pv, acc, flags, rows, heap, bounds)\n"
@@ -570,6 +571,11 @@ static void emu_kernel_check(const DevPlan* p, const DevTable* dt, const EvalOpt
   unsigned grid = (n_groups + 7u) / 8u * 8u;
   if (const char* g = getenv("GK_EMU_GRID")) grid = std::min<unsigned>(grid, (unsigned)std::max(8, atoi(g) / 8 * 8));   // persistent workgroups: several groups each
   else grid = std::min<unsigned>(grid, 16u);
+  // per-workgroup violation counts (kernel_body.inc GK_TOT_K, the plan-specialised text): every workgroup of the grid writes its row
+  const uint32_t tot_k = jit ? jit_tot_k(hp.dims.n_constraints) : 0u;
+  const bool emu_partial = tot_k != 0;
+  std::vector<uint32_t> partial((size_t)grid * tot_k, 0xABABABABu);
+  if (emu_partial) out.partial = partial.data();
   const Row* rows = t.rows.data(); const StrHdr* shdr = t.shdr.data();
   const uint32_t emu_dbg = getenv("GK_EMU_STAGGER") ? ((uint32_t)atoi(getenv("GK_EMU_STAGGER")) & 0xFFFu) << 8 : 0u;   // the launch word's stagger field, as dev_eval_launch sets it for >= 1024 groups
   if (jit) {
@@ -585,6 +591,14 @@ static void emu_kernel_check(const DevPlan* p, const DevTable* dt, const EvalOpt
     auto fn = rpt == 64 ? gk_emu_tiles_64 : rpt == 128 ? gk_emu_tiles_128 : rpt == 256 ? gk_emu_tiles_256 : gk_emu_tiles_512;
     gkemu::launch(grid, (unsigned)block, lds, [&] { fn(pv, rows, shdr, cl.d.data(), cl.capg, t.rflags.data(), t.heap.data(), n, nt, hp.slots.data(), out, emu_dbg, rpp); });
   }
+  // the workgroups' own counts add up to the popcount of the rows they wrote (what gk_sum_partials hands out as the totals)
+  if (emu_partial)
+    for (uint32_t c = 0; c < nc; c++) {
+      uint64_t by_rows = 0, by_wgs = 0;
+      for (uint32_t w = 0; w < nt; w++) by_rows += (uint64_t)__builtin_popcountll(viol[(size_t)c * nt + w]);
+      for (unsigned g = 0; g < grid; g++) by_wgs += partial[(size_t)g * tot_k + c];
+      if (by_rows != by_wgs) throw std::runtime_error("kernel_emu: per-workgroup violation counts of constraint " + std::to_string(c) + " sum to " + std::to_string(by_wgs) + ", its bitmap row holds " + std::to_string(by_rows));
+    }
   // overflowed reviews: the big variant (per review, as above)
   uint32_t n_ovf = 0;
   for (uint32_t w = 0; w < nt; w++)

@@ -164,6 +164,7 @@ static inline uint32_t min(uint32_t a, uint32_t b) { return a < b ? a : b; }
 #define GK_OPAQUE_V1(a) do { } while (0)
 #define GK_OPAQUE_S1(a) do { } while (0)
 #define GK_OPAQUE() do { } while (0)
+#define GK_LDS_ADD(p, v) ((void)(*(p) += (v)))
 #define GK_READLANE(v, k) ((uint32_t)gkemu::shfl((int)(v), (int)(k)))
 // LDS-DMA of the device build (kernel_body.inc GK_LDS_DMA16): here every lane copies its 16 bytes at once -- a lane only ever
 // reads back what it requested itself, behind GK_WAIT_VM
