@@ -47,6 +47,25 @@ inline uint32_t jit_tot_k(uint32_t n_constraints) {
   static const bool on = !(getenv("GK_FUSED_TOTALS") && atoi(getenv("GK_FUSED_TOTALS")) == 0);
   return on && n_constraints && n_constraints <= 256u ? (n_constraints + 63u) / 64u * 64u : 0u;
 }
+// ... unless the array costs the kernel a resident row group per CU.  MEASURED on the MI355X (profiles/r06_variants_a{q,r,u}_*.log):
+// configs[2] -- 34 816 B of accumulators + 4 608 B of static LDS per 256-review group = 39 424 B -- keeps four groups per CU resident;
+// EIGHT bytes more (39 432 B) and the fourth group of every CU runs behind the other three: the persistent grid of 1 024 workgroups
+// takes 25 % longer (0.0442 -> 0.0540 ms; 10 M objects 0.410 -> 0.492), whatever the eight bytes are used for.  4 x 39 424 = 157 696 B
+// is therefore what this file takes as a CU's LDS when it decides whether the totals array fits (the runtime's own limit, 160 KiB,
+// sizes everything else as before): a plan whose exact footprint would lose a group to the array keeps the popcount kernel.
+constexpr size_t GK_LDS_PER_CU_MEASURED = 157696;
+inline size_t jit_static_lds_exact(uint32_t rpt, uint32_t res_k, uint32_t list_cap, uint32_t tot_k) {   // kernel_body.inc: s_work, s_masks_own (only when the result words do not alias a list buffer), s_slw, s_tot
+  const size_t list = (size_t)list_cap * 8, masks = (size_t)(rpt / GK_TILE) * res_k * 8;
+  return 2 * list + (masks <= list ? 0 : masks) + GK_TILE * 4 + (size_t)tot_k * 4;
+}
+inline uint32_t jit_tot_k(uint32_t n_constraints, size_t dyn_lds, uint32_t rpt, int block, uint32_t res_k, uint32_t list_cap) {
+  const uint32_t tk = jit_tot_k(n_constraints);
+  if (!tk || !list_cap) return tk;
+  const size_t by_waves = std::max<size_t>(1, 32 / (size_t)std::max(1, block / GK_TILE));   // (8 waves per SIMD: more groups than that are never resident)
+  const size_t with = std::min(by_waves, GK_LDS_PER_CU_MEASURED / (dyn_lds + jit_static_lds_exact(rpt, res_k, list_cap, tk)));
+  const size_t without = std::min(by_waves, GK_LDS_PER_CU_MEASURED / (dyn_lds + jit_static_lds_exact(rpt, res_k, list_cap, 0)));
+  return with < without ? 0u : tk;
+}
 inline size_t static_lds_of(uint32_t rpt, int block, uint32_t res_k, uint32_t list_cap = 0, uint32_t tot_k = 0) {
   const size_t list = (size_t)(list_cap ? list_cap : list_cap_of(block)) * 8;
   const size_t masks = (size_t)(rpt / GK_TILE) * (res_k ? res_k : (uint32_t)(GK_MAX_VIOL + 2 * GK_MAX_RES)) * 8;   // res_k: result words per half (jit_res_k)
@@ -111,7 +130,7 @@ inline std::string assemble_jit_source(const HostPlan& plan, uint32_t rpt, uint3
     // register budget: as many waves per SIMD as the LDS footprint lets groups be resident per CU (waves per SIMD =
     // groups per CU x waves per group / 4 SIMDs); measured on configs[1] with 64-review groups: 7 waves (72 VGPRs) edges
     // out 8 (64 VGPRs, twice the spill traffic) and clearly beats 5-6
-    const size_t per_group = (size_t)plan.dims.acc_words * rpp * 4 + static_lds_of(rpt, block, jit_res_k(plan), list_cap, jit_tot_k(plan.dims.n_constraints));
+    const size_t per_group = (size_t)plan.dims.acc_words * rpp * 4 + static_lds_of(rpt, block, jit_res_k(plan), list_cap, jit_tot_k(plan.dims.n_constraints, (size_t)plan.dims.acc_words * rpp * 4, rpt, block, jit_res_k(plan), list_cap ? list_cap : list_cap_of(block)));
     const size_t groups_per_cu = std::max<size_t>(1, GK_LDS_PER_CU / per_group);
     int waves = (int)std::min<size_t>(8, std::max<size_t>(block / 256, groups_per_cu * (block / GK_TILE) / 4));   // waves per SIMD the LDS allows
     if (const char* w = getenv("GK_JIT_WAVES")) waves = atoi(w);   // tuning aid
@@ -142,7 +161,7 @@ inline std::string assemble_jit_source(const HostPlan& plan, uint32_t rpt, uint3
   if (getenv("GK_KERNEL_PROF") || getenv("GK_DBG_PHASE")) src += "#define GK_WITH_PROF 1\n";   // (kernel_body.inc: the phase marks and switches, only when asked for)
   src += "#define GK_RPT_K " + std::to_string(rpt) + "\n#define GK_RPP_K " + std::to_string(rpp) + "\n";
   if (list_cap) src += "#define GK_LIST_CAP_K " + std::to_string(list_cap) + "\n";
-  if (const uint32_t tk = jit_tot_k(plan.dims.n_constraints)) src += "#define GK_TOT_K " + std::to_string(tk) + "\n";   // (kernel_body.inc: per-constraint totals left as one row per workgroup)
+  if (const uint32_t tk = jit_tot_k(plan.dims.n_constraints, (size_t)plan.dims.acc_words * rpp * 4, rpt, block, jit_res_k(plan), list_cap ? list_cap : list_cap_of(block))) src += "#define GK_TOT_K " + std::to_string(tk) + "\n";   // (kernel_body.inc: per-constraint totals left as one row per workgroup)
   if (const char* defs = getenv("GK_JIT_DEFINES")) {   // tuning aid: "A=1;B" -> #define A 1, #define B (kernel_body.inc variants)
     std::string d = defs, item;
     for (size_t i = 0; i <= d.size(); i++) {

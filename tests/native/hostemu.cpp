@@ -491,7 +491,7 @@ static EmuJitLaunch emu_jit_for(const DevPlan* p, uint32_t rpt, uint32_t rpp, in
       << jit_res_macros()
       << generate_plan_source(p->fast, (uint32_t)(block / GK_TILE / ((int)rpt / GK_TILE)))
       << "#define GK_RPT_K " << rpt << "\n#define GK_RPP_K " << rpp << "\n#define GK_BLOCK_K " << block << "\n#define GK_PREFETCH " << (pf ? pf : "1") << "\n#define GK_SKIP_BIG\n"
-      << (jit_tot_k(p->fast.dims.n_constraints) ? "#define GK_TOT_K " + std::to_string(jit_tot_k(p->fast.dims.n_constraints)) + "\n" : std::string())
+      << (jit_tot_k(p->fast.dims.n_constraints) ? "#define GK_TOT_K " + std::to_string(jit_tot_k(p->fast.dims.n_constraints)) + "\n" : std::string())   // (the emulator has no CU to fill: the array whenever the plan allows it)
       << "namespace gk {\n#define GK_KERNEL_TILES gk_jit_tiles\n#define GK_KERNEL_BIG gk_jit_big\n#define GK_KERNEL_LINKAGE static\n"
          "#define GK_ROW_FN(r, i, ent, h, pv, heap, acc, on) jit_row(r, ent, h, heap, acc, on)\n#define GK_BIND_ALWAYS_STR 0\n"
          "#define GK_FORMULA_FN(pv, acc, flags, rows, heap, bounds) jit_formulas(pv, acc, flags, rows, heap, bounds)\n"

@@ -247,3 +247,28 @@ def test_corpus_plan_sources_compile_for_gfx950_and_keep_their_prefetch_distance
         gaps = _row_load_wait_gaps(code, tmp_path)
         if gaps is not None:
             assert gaps and min(gaps) >= 16, "%s: a row load is waited for %d instructions after its request (gaps %s)" % (name, min(gaps), gaps)
+
+
+def test_totals_rows_in_the_text_and_the_occupancy_guard(monkeypatch, tmp_path):
+    """round 6, last step: the plan-specialised text of the benchmark plan keeps the per-constraint totals as one row per workgroup
+    (`GK_TOT_K` = the constraints rounded up to 64: no popcount kernel behind a sweep) -- unless the LDS array would cost a resident
+    row group per CU.  The cliff is measured (profiles/r06_variants_a{q,r,u}_*.log: 39 424 B per 256-review group keep four groups
+    per CU, 39 432 B do not and the persistent grid takes 25 % longer): jit_source.hpp jit_tot_k decides with the exact footprint."""
+    import subprocess
+    monkeypatch.delenv("GK_FUSED_TOTALS", raising=False)
+    for name, text in _dump_sources(monkeypatch, tmp_path, _bench_plan(1200), env=[("GK_RPT", 256)]):
+        assert "#define GK_TOT_K 64\n" in text, name
+        assert "GK_LDS_ADD(&s_tot[" in text and "out.partial[(size_t)blockIdx.x * GK_TOT_K + q] = s_tot[q]" in text, name
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gatekeeper_amd", "csrc")
+    src = tmp_path / "tot_k.cpp"
+    src.write_text('#include <cstdio>\n#include "plan.hpp"\n#include "codegen.hpp"\n#include "jit_source.hpp"\n'
+                   'int main() { using namespace gk;\n'
+                   '  // (constraints, accumulator bytes per group, reviews per group, threads, result words per half, list capacity)\n'
+                   '  printf("%u %u %u %u %u\\n", jit_tot_k(50, 34816, 256, 512, 10, 256), jit_tot_k(100, 34816, 256, 512, 10, 256),\n'
+                   '         jit_tot_k(100, 20000, 256, 512, 10, 256), jit_tot_k(300, 20000, 256, 512, 10, 256), jit_tot_k(200, 8192, 64, 256, 10, 128)); }\n')
+    exe = tmp_path / "tot_k"
+    subprocess.run(["g++", "-std=c++17", "-I", csrc, "-o", str(exe), str(src)], check=True)
+    got = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()
+    # configs[2]: 34 816 + 2 x 2 048 + 256 + 256 = 39 424 -> four groups, the array stays; 100 constraints would need 512 B -> three groups: popcount kernel;
+    # smaller accumulators: room for it; beyond 256 constraints: never; 64-review groups are bound by waves, not LDS: stays
+    assert got == ["64", "0", "128", "0", "256"], got
