@@ -501,7 +501,8 @@ static EmuJitLaunch emu_jit_for(const DevPlan* p, uint32_t rpt, uint32_t rpp, in
          "    const gk::OutPtrs* out, uint32_t dbg, uint32_t rpp) {\n"
          "  gkemu::launch(grid, block, lds, [&] { gk::gk_jit_tiles(*pv, rows, shdr, lists, capg, rflags, heap, n, nt, slots, *out, dbg, rpp); });\n}\n";
   }
-  std::string cmd = "g++ -std=c++17 -O1 -shared -fPIC -w -o " + base + ".so " + base + ".cpp 2> " + base + ".log";
+  // (GK_EMU_CXXFLAGS, e.g. -fsanitize=undefined: the generated text under a sanitizer -- what g++ and the device compiler may disagree on)
+  std::string cmd = std::string(getenv("GK_EMU_CXX") ? getenv("GK_EMU_CXX") : "g++") + std::string(" -std=c++17 -O1 -shared -fPIC -w ") + (getenv("GK_EMU_CXXFLAGS") ? getenv("GK_EMU_CXXFLAGS") : "") + " -o " + base + ".so " + base + ".cpp 2> " + base + ".log";
   if (system(cmd.c_str()) != 0) throw std::runtime_error("kernel_emu: the plan-specialised kernel does not compile, see " + base + ".log");
   void* dl = dlopen((base + ".so").c_str(), RTLD_NOW);
   if (!dl) throw std::runtime_error(std::string("kernel_emu: dlopen failed: ") + dlerror());

@@ -6,6 +6,7 @@
 // has arrived -- a lane waiting at a barrier while its wave is in a collective is reported as a deadlock, as are
 // mismatched collectives.  Never part of the product library.
 #pragma once
+#include <cstdlib>
 #include <ucontext.h>
 
 #include <cstdint>
@@ -72,7 +73,11 @@ inline void run_block(unsigned block) {
   }
   for (;;) {
     bool progressed = false, any_live = false;
-    for (unsigned t = 0; t < block; t++) {
+    // (GK_EMU_REVERSE: the threads take their turns from the last to the first -- rows of one review that the device's waves process
+    //  concurrently reach the accumulators in the opposite order: an order-dependent pair of phase-1 operations shows up as a difference)
+    static const bool reverse = getenv("GK_EMU_REVERSE") != nullptr;
+    for (unsigned t0 = 0; t0 < block; t0++) {
+      const unsigned t = reverse ? block - 1u - t0 : t0;
       Fiber& f = s.fibers[t];
       if (f.state != F_RUN) continue;
       s.cur = &f;
