@@ -25,7 +25,8 @@ int main(int argc, char** argv) {
   }
   hiprtcProgram prog;
   if (hiprtcCreateProgram(&prog, src.c_str(), "gk_plan.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) { fprintf(stderr, "gkjitc: hiprtcCreateProgram failed\n"); return 1; }
-  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};   // (the options of the in-process build, kernels.hip)
+  const char* opt_level = getenv("GK_JIT_OPT") ? getenv("GK_JIT_OPT") : "-O3";   // (diagnostic aid, e.g. -O1: is a device-only difference the optimiser's? use with GK_JIT_CACHE_DIR=off -- the cache is keyed by the text)
+      const char* opts[] = {"--offload-arch=gfx950", opt_level, "-std=c++17"};   // (the options of the in-process build, kernels.hip)
   if (hiprtcCompileProgram(prog, 3, opts) != HIPRTC_SUCCESS) {
     size_t ls = 0;
     hiprtcGetProgramLogSize(prog, &ls);
