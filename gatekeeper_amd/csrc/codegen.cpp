@@ -78,6 +78,9 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts) {
   std::ostringstream o;
   std::vector<std::vector<Pred>> classes;
   jit_path_classes(plan, &classes);
+  // (GK_BIT: bit 0 of a formula value; the device text defines it as an opaque copy + mask BEFORE this source -- jit_source.hpp jit_res_macros,
+  //  where the reason is written down; anything else that compiles the plan source gets the plain mask)
+  o << "#ifndef GK_BIT\n#define GK_BIT(b) ((b) & 1u)\n#endif\n";
   o << "namespace gk {\n";
   // the plan's constant heap as a constant-initialised array: with constexpr predicates every constant-string load has
   // a compile-time address, so the optimiser folds the bytes into immediates (no memory traffic for constants)
@@ -574,16 +577,16 @@ std::string generate_plan_source(const HostPlan& plan, uint32_t parts) {
         if (pre && elem_word_of_bit(c) == 0 && pre_words.count({b, (uint32_t)[&] { int lit = -1; for (const Loop& l : stack) if (l.depth == d) lit = l.lit; return lit; }()})) {
           int lit = -1;
           for (const Loop& l : stack) if (l.depth == d) lit = l.lit;
-          o << ind << "if (b" << a << ") { acc.or_word(" << sc.word_off << "u + e" << d << " * " << (int)sc.wpe << "u, " << u(elem_mask_of_bit(c)) << "); W" << b << "_" << lit << " |= " << u(elem_mask_of_bit(c)) << "; }\n";
+          o << ind << "if (GK_BIT(b" << a << ")) { acc.or_word(" << sc.word_off << "u + e" << d << " * " << (int)sc.wpe << "u, " << u(elem_mask_of_bit(c)) << "); W" << b << "_" << lit << " |= " << u(elem_mask_of_bit(c)) << "; }\n";
           break;
         }
-        o << ind << "if (b" << a << ") acc.or_word(" << sc.word_off << "u + e" << d << " * " << (int)sc.wpe << "u + " << elem_word_of_bit(c) << "u, " << u(elem_mask_of_bit(c)) << ");\n";
+        o << ind << "if (GK_BIT(b" << a << ")) acc.or_word(" << sc.word_off << "u + e" << d << " * " << (int)sc.wpe << "u + " << elem_word_of_bit(c) << "u, " << u(elem_mask_of_bit(c)) << ");\n";
         break;
       }
       case F_STG: {
         uint32_t bit = b | (c << 8);
-        if (staged) o << ind << "if (b" << a << ") { g" << (bit >> 5) << " |= " << u(1u << (bit & 31)) << "; acc.or_word(" << (bit >> 5) << "u, " << u(1u << (bit & 31)) << "); }\n";
-        else o << ind << "if (b" << a << ") g" << (bit >> 5) << " |= " << u(1u << (bit & 31)) << ";\n";
+        if (staged) o << ind << "if (GK_BIT(b" << a << ")) { g" << (bit >> 5) << " |= " << u(1u << (bit & 31)) << "; acc.or_word(" << (bit >> 5) << "u, " << u(1u << (bit & 31)) << "); }\n";
+        else o << ind << "if (GK_BIT(b" << a << ")) g" << (bit >> 5) << " |= " << u(1u << (bit & 31)) << ";\n";
         break;
       }
       case F_RES: {

@@ -86,12 +86,20 @@ inline std::string jit_res_macros() {
   static const bool lanes = !(getenv("GK_JIT_RES_LANES") && atoi(getenv("GK_JIT_RES_LANES")) == 0);
   // where a kind's slots start in the half's result words: kind 0 = violation slots 0..63, 1 = match, 2 = error, 3 / 4 / 5 = violation
   // slots 64.. / 128.. / 192.. (round 6: up to GK_MAX_VIOL violation formulas per plan, one register pair per bank of 64)
-  const std::string base =
+  // GK_BIT(b): bit 0 of a formula value, read through an opaque copy.  hiprtc for gfx950 (ROCm 7.2) folds the generated `& 1u` masks of a
+  // chain like  b = !bit1 | (bit2 & bit1 & !bit3)  over (g >> k) terms into ONE v_bitop3_b32 over the UNMASKED shifts and then tests the
+  // whole register (v_cmp_ne_u32 0, v): the higher bits of the accumulator word leak into the answer -- device fuzz seeds 9820 / 9833,
+  // a template flagged for every review, right on the bytecode kernel, the CPU build and the emulator (DESIGN.md section 11,
+  // profiles/r06_device_fuzz_ba_bk_*.log, tools/scratch/seed_9820_pair_plan_text.hip).  Behind the empty asm the compiler knows nothing
+  // about the value: the mask and the test are real instructions.  The kernel emulator defines GK_BIT itself (tests/native/hostemu.cpp).
+  const std::string bit =
+      "#ifndef GK_BIT\nstatic __device__ inline uint32_t gk_bit(uint32_t b) { asm volatile(\"\" : \"+v\"(b)); return b & 1u; }\n#define GK_BIT(b) gk_bit(b)\n#endif\n";
+  const std::string base = bit +
       "#define GK_RES_BASE(kind) ((kind) == 0 ? 0u : (kind) == 1 ? (uint32_t)GK_RES_KV : (kind) == 2 ? (uint32_t)(GK_RES_KV + GK_RES_KM) : ((uint32_t)(kind) - 2u) * 64u)\n";
   if (!lanes)
     return base +
            "#define GK_RES_PROLOGUE const bool gk_l0 = GK_LANE_ID() == 0u;\n"
-           "#define GK_RES(kind, slot, b) do { const unsigned long long m_ = __ballot((b) != 0u); if (gk_l0) masks[GK_RES_BASE(kind) + (slot)] = m_; } while (0)\n"
+           "#define GK_RES(kind, slot, b) do { const unsigned long long m_ = __ballot(GK_BIT(b) != 0u); if (gk_l0) masks[GK_RES_BASE(kind) + (slot)] = m_; } while (0)\n"
            "#define GK_RES_FLUSH(m0, m1, m2, m3, m4, m5)\n";
   std::string pro = "#define GK_RES_PROLOGUE uint32_t", flush = "#define GK_RES_FLUSH(m0, m1, m2, m3, m4, m5) do { const uint32_t l_ = GK_LANE_ID() & 63u; ", voids;
   for (int k = 0; k < 2 + GK_VIOL_WORDS; k++) {
@@ -101,7 +109,7 @@ inline std::string jit_res_macros() {
     voids += "(void)gk_rl" + ks + "; (void)gk_rh" + ks + "; ";
   }
   return base + pro + ";\n"
-         "#define GK_RES(kind, slot, b) do { const unsigned long long m_ = __ballot((b) != 0u); GK_WRITELANE2(m_, slot, gk_rl##kind, gk_rh##kind); } while (0)\n" +
+         "#define GK_RES(kind, slot, b) do { const unsigned long long m_ = __ballot(GK_BIT(b) != 0u); GK_WRITELANE2(m_, slot, gk_rl##kind, gk_rh##kind); } while (0)\n" +
          flush + voids + "} while (0)\n";
 }
 

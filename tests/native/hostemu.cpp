@@ -487,6 +487,7 @@ static EmuJitLaunch emu_jit_for(const DevPlan* p, uint32_t rpt, uint32_t rpp, in
     const char* pf = getenv("GK_JIT_PREFETCH");
     f << "#include \"" << GK_CSRC_DIR << "/../../tests/native/kernel_emu.hpp\"\n#include \"" << GK_CSRC_DIR << "/vm_core.hpp\"\n"
       << "#define GK_LANE_ID() (threadIdx.x & 63u)\n"
+      << "#define GK_BIT(b) ((b) & 1u)\n"   // (jit_source.hpp: on the device an opaque copy in front of the mask)
       << "#define GK_WRITELANE2(m, l, lo, hi) do { if ((threadIdx.x & 63u) == (uint32_t)(l)) { (lo) = (uint32_t)(m); (hi) = (uint32_t)((m) >> 32); } } while (0)\n"
       << jit_res_macros()
       << generate_plan_source(p->fast, (uint32_t)(block / GK_TILE / ((int)rpt / GK_TILE)))

@@ -552,15 +552,13 @@ def test_random_templates_with_every_and_some_in(backend, seed):
 
 
 @pytest.mark.gpu
-@pytest.mark.xfail(strict=False, reason="OPEN at the end of round 6 (profiles/INDEX_r06.md, DESIGN.md section 11): two seeds of the device fuzz campaign over NEW seeds "
-                                        "(9500..10099, after the round's last kernel change; it fails with GK_FUSED_TOTALS=0 as well) -- two templates with "
-                                        "`count(set - allowed) == 0` over the same array, loaded in one order, flag reviews on the MI355X that the CPU build, the "
-                                        "kernel emulator and the oracle do not; the driver raises (device / renderer disagree) instead of reporting them")
 @pytest.mark.parametrize("seed", [9820, 9833])
-def test_open_device_only_disagreement_of_two_count_templates(seed):
-    """tools/scratch/device_fuzz_campaign.py 9500 10099 on the MI355X: 598 seeds agree, these two do not (profiles/r06_device_fuzz_a{x,z}_*.log;
-    reduced to a pair of templates each by tools/scratch/device_fuzz_diag.py, raw bitmaps by tools/scratch/device_fuzz_probe.py).  Kept as an
-    expected failure so that the fix turns it green (XPASS) and nobody reads the campaign's earlier `0 failing seeds` as covering these."""
+def test_device_only_disagreement_of_two_count_templates_is_gone(seed):
+    """Found by tools/scratch/device_fuzz_campaign.py 9500 10099 on the MI355X in the last hours of round 6 (598 seeds agreed, these two did
+    not: a template flagged for every review by the plan-specialised kernel only) and traced to the device compiler: hiprtc for gfx950
+    folds the generated `& 1u` masks of a chain over (g >> k) terms into one v_bitop3_b32 over the UNMASKED shifts and then tests the whole
+    register, so higher bits of the accumulator word leak into the formula's value.  Every test of a formula value now goes through GK_BIT
+    (an opaque copy, then the mask: jit_source.hpp jit_res_macros); profiles/r06_device_fuzz_ba_bk_*.log, r06_visit_bo_gk_bit_fix.log."""
     mode = seed % 4
     loaded, compared = run_batched("gpu", seed, 60, 14, envelope=mode == 1, numeric=mode >= 2, v1=mode == 3)
     assert loaded >= 40 and compared >= 40
